@@ -1,0 +1,160 @@
+// TEST INFRASTRUCTURE - NOT PART OF THE PRODUCT PATH.
+//
+// oracle/_ref/libmmref.so: a thin extern "C" shim over the *real* reference classes,
+// compiled by oracle/Makefile from the sources where they lie under /root/reference
+// (no reference source is copied into this repository).  Only tests/,
+// __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it; it is used to
+//   (1) pin the plain-C restatement in oracle/*.c,
+//   (2) generate the committed fixtures under tests/golden/ (tests/golden/make_golden.py),
+//   (3) serve as the "reference" CPU baseline (AVX2 striped Smith-Waterman, uint8->int16).
+//
+// Reference entry points driven here:
+//   SubstitutionMatrix(blosum62.out, 2.0, 0.0)              src/alignment/Alignment.cpp:152
+//   Sequence::mapSequence                                    src/alignment/Alignment.cpp:339,367
+//   SmithWaterman::ssw_init / ssw_align                      src/alignment/Matcher.cpp:58,82
+//   EvalueComputation(dbResidues, m, gapOpen, gapExtend)     src/alignment/Alignment.cpp:263
+//   UngappedAlignment::createProfile / scoreSingelSequence…  src/prefiltering/QueryMatcher.cpp:119
+//   SubstitutionMatrix::calcLocalAaBiasCorrection            src/commons/SubstitutionMatrix.cpp:79-112
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "Debug.h"
+#include "EvalueComputation.h"
+#include "Parameters.h"
+#include "Sequence.h"
+#include "StripedSmithWaterman.h"
+#include "SubstitutionMatrix.h"
+
+extern "C" {
+
+struct mmref_sw_result {
+    uint32_t score;
+    int32_t q_start, q_end, t_start, t_end;
+    int32_t word;            // 0: uint8 pass sufficed, 1: int16 re-run (StripedSmithWaterman.cpp:916-920)
+    float q_cov, t_cov;
+    double evalue;
+    uint32_t ident;          // identicalAACnt (only with backtrace)
+    int32_t bt_len;          // length of backtrace string written to bt (0 if none)
+};
+
+struct mmref_ctx {
+    SubstitutionMatrix *m;
+    EvalueComputation *evaluer;
+    SmithWaterman *sw;
+    Sequence *q;
+    Sequence *t;
+    int gapOpen, gapExtend;
+    size_t maxLen;
+    bool compBias;
+};
+
+// matrix_file: path to <reference>/data/blosum62.out (read at run time by the reference's own
+// SubstitutionMatrix; tests that need it are skipped when /root/reference is absent).
+mmref_ctx *mmref_new(const char *matrix_file, float bit_factor, float score_bias, int max_len, int gap_open,
+                     int gap_extend, int comp_bias, uint64_t db_residues) {
+    Debug::setDebugLevel(Debug::ERROR);
+    mmref_ctx *c = new mmref_ctx();
+    c->m = new SubstitutionMatrix(matrix_file, bit_factor, score_bias);
+    c->evaluer = new EvalueComputation(db_residues, c->m, gap_open, gap_extend);
+    c->maxLen = max_len;
+    c->compBias = comp_bias != 0;
+    c->sw = new SmithWaterman(max_len, c->m->alphabetSize, c->compBias, 1.0f, c->m);
+    c->q = new Sequence(max_len, Parameters::DBTYPE_AMINO_ACIDS, c->m, 0, false, c->compBias);
+    c->t = new Sequence(max_len, Parameters::DBTYPE_AMINO_ACIDS, c->m, 0, false, c->compBias);
+    c->gapOpen = gap_open;
+    c->gapExtend = gap_extend;
+    return c;
+}
+
+void mmref_free(mmref_ctx *c) {
+    delete c->q;
+    delete c->t;
+    delete c->sw;
+    delete c->evaluer;
+    delete c->m;
+    delete c;
+}
+
+int mmref_alphabet_size(mmref_ctx *c) { return c->m->alphabetSize; }
+
+// int matrix as the aligner sees it (Matcher::setSubstitutionMatrix, Matcher.cpp:29-36)
+void mmref_get_matrix(mmref_ctx *c, int8_t *out /*alphabet^2*/) {
+    int a = c->m->alphabetSize;
+    for (int i = 0; i < a; i++)
+        for (int j = 0; j < a; j++) out[i * a + j] = (int8_t)c->m->subMatrix[i][j];
+}
+
+// ASCII -> numeric with the reference's aa2num table
+void mmref_aa2num(mmref_ctx *c, const char *seq, int len, uint8_t *out) {
+    for (int i = 0; i < len; i++) out[i] = c->m->aa2num[(unsigned char)seq[i]];
+}
+
+void mmref_num2aa(mmref_ctx *c, char *out /*alphabet*/) {
+    for (int i = 0; i < c->m->alphabetSize; i++) out[i] = c->m->num2aa[i];
+}
+
+// float composition bias as the reference computes it (SubstitutionMatrix.cpp:79-112)
+void mmref_comp_bias(mmref_ctx *c, const uint8_t *num, int len, float scale, float *out) {
+    SubstitutionMatrix::calcLocalAaBiasCorrection(c->m, num, len, out, scale);
+}
+
+// query given as numeric codes (SequenceLookup-style mapSequence overload, Sequence.h:88)
+void mmref_sw_set_query(mmref_ctx *c, const uint8_t *qnum, int qlen) {
+    c->q->mapSequence(0, 0, std::make_pair((const unsigned char *)qnum, (const unsigned int)qlen));
+    int a = c->m->alphabetSize;
+    std::vector<int8_t> tiny(a * a);
+    mmref_get_matrix(c, tiny.data());
+    c->sw->ssw_init(c->q, tiny.data(), c->m);
+}
+
+// mode: Matcher::SCORE_ONLY=0, SCORE_COV=1, SCORE_COV_SEQID=2 (Matcher.h:24-26)
+void mmref_sw_align(mmref_ctx *c, const uint8_t *tnum, int tlen, int mode, double evalue_thr, int cov_mode,
+                    float cov_thr, mmref_sw_result *res, char *bt, int bt_cap) {
+    std::string backtrace;
+    int32_t maskLen = c->q->L / 2;
+    s_align a = c->sw->ssw_align(tnum, tlen, backtrace, c->gapOpen, c->gapExtend, mode, evalue_thr, c->evaluer,
+                                 cov_mode, cov_thr, 0.0f, maskLen);
+    res->score = a.score1;
+    res->q_start = a.qStartPos1;
+    res->q_end = a.qEndPos1;
+    res->t_start = a.dbStartPos1;
+    res->t_end = a.dbEndPos1;
+    res->word = a.word;
+    res->q_cov = a.qCov;
+    res->t_cov = a.tCov;
+    res->evalue = a.evalue;
+    res->ident = a.identicalAACnt;
+    res->bt_len = 0;
+    if (bt != NULL && (int)backtrace.size() < bt_cap) {
+        memcpy(bt, backtrace.data(), backtrace.size());
+        bt[backtrace.size()] = 0;
+        res->bt_len = (int)backtrace.size();
+    }
+    delete[] a.cigar;
+}
+
+// batch: one query against n targets, score/end only; returns wall-clock-free results.
+// Used by bench.py's cpu_baseline ("reference" kind) from several threads, one ctx per thread.
+void mmref_sw_batch_score(mmref_ctx *c, const uint8_t *tdata, const uint64_t *toff, const uint32_t *ids, int n,
+                          uint32_t *score, int32_t *qend, int32_t *tend) {
+    std::string backtrace;
+    int32_t maskLen = c->q->L / 2;
+    for (int i = 0; i < n; i++) {
+        uint32_t id = ids[i];
+        const uint8_t *t = tdata + toff[id];
+        int tlen = (int)(toff[id + 1] - toff[id]);
+        s_align a = c->sw->ssw_align(t, tlen, backtrace, c->gapOpen, c->gapExtend, 0, 1e300, c->evaluer, 0, 0.0f,
+                                     0.0f, maskLen);
+        score[i] = a.score1;
+        qend[i] = a.qEndPos1;
+        tend[i] = a.dbEndPos1;
+    }
+}
+
+double mmref_evalue(mmref_ctx *c, double score, double qlen) { return c->evaluer->computeEvalue(score, qlen); }
+double mmref_bitscore(mmref_ctx *c, double score) { return c->evaluer->computeBitScore(score); }
+
+}  // extern "C"
