@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""bench.py - headline benchmark of the MI355X-native prefilter->align path.
+
+Metric (BASELINE.json): giga-cells/s of the Gotoh Smith-Waterman stage, cells = sum over computed
+alignments of qlen*tlen (forward DP only, Alignment.cpp:380,530 convention).
+
+Workload at N=1: BASELINE.json configs[1] - "mmseqs align only: 1k random L~350 protein queries vs 100k
+targets" (10 % of targets carry a planted homolog), every query against every target as `mmseqs align` sees
+it behind the all-vs-all fake prefilter (data/workflow/blastp.sh:22-33): 1e8 alignments, ~1.2e13 cells per
+step.  A "step" = one pass of the hot path (forward scan, score + end positions) over that batch with the
+target DB, the queries and the prefilter lists already resident in HBM.
+
+N>1 (launched by torch.distributed.run, one process per GPU): every rank owns an independent target shard of
+the same size and its own prefilter lists (weak scaling, no data-path collective in this round); value =
+cells of all ranks / max-over-ranks time.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+VALU_LANE_OPS_PER_S = 256 * 4 * 32 * 2.4e9   # 256 CU x 4 SIMD-32 x 2.4 GHz (MI355X_MICROARCH.md)
+
+
+def cpu_baseline(matrices, qs, cbs, tres, toff, budget_s=15.0):
+    """Reported (not optimised-against) CPU baseline on the GPU box's host cores, bounded sample.
+    kind "reference": the real AVX2 striped Smith-Waterman of the reference (oracle/_ref/libmmref.so, uint8 pass
+    + int16 re-run), one SmithWaterman object per thread as Alignment::run does (Alignment.cpp:279-295).
+    kind "port": the scalar C oracle, when the reference library did not travel."""
+    from oracle import pyoracle
+    cores = os.cpu_count() or 1
+    n_t = len(toff) - 1
+    tlen_sum = int(toff[-1])
+    use_ref = pyoracle.ref_available()
+    ids = np.arange(n_t, dtype=np.uint32)
+    mat = matrices["blosum62_sw"]
+    if use_ref:
+        ser = matrices["blosum62_serialized"]
+        ctxs = [pyoracle.RefLib(serialized=ser, max_len=70000, db_residues=tlen_sum) for _ in range(cores)]
+
+        def one(ctx, qi, sub):
+            ctx.sw_set_query(qs[qi])   # ssw_init recomputes the composition bias itself (aaBiasCorrection on)
+            ctx.sw_batch_score(tres, toff, sub)
+    else:
+        orc = pyoracle.Oracle()
+        ctxs = [orc] * cores
+
+        def one(ctx, qi, sub):
+            ctx.sw_batch_score(qs[qi], cbs[qi], tres, toff, sub, mat, 11, 1)
+    # calibrate on a small slice, then size the sample to ~budget_s of wall time
+    t0 = time.time()
+    one(ctxs[0], 0, ids[: min(n_t, 400)])
+    dt = time.time() - t0
+    cells_cal = len(qs[0]) * int(toff[min(n_t, 400)])
+    rate1 = cells_cal / max(dt, 1e-6)                       # cells/s on one thread
+    target_cells = rate1 * cores * budget_s
+    per_query = np.array([len(q) for q in qs], np.float64) * tlen_sum
+    nq = int(max(cores, min(len(qs), np.ceil(target_cells / per_query.mean()))))
+    nq = min(nq, len(qs))
+    work = list(range(nq))
+    lock = threading.Lock()
+
+    def worker(ctx):
+        while True:
+            with lock:
+                if not work:
+                    return
+                qi = work.pop()
+            one(ctx, qi, ids)
+
+    th = [threading.Thread(target=worker, args=(ctxs[i],)) for i in range(cores)]
+    t0 = time.time()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    dt = time.time() - t0
+    cells = float(per_query[:nq].sum())
+    return {"value": round(cells / dt / 1e9, 3), "unit": "GCUPS", "cores": cores,
+            "kind": "reference" if use_ref else "port",
+            "sample": "%d queries x %d targets (%.3g cells) of the same workload, %.1f s wall, %d threads" %
+                      (nq, n_t, cells, dt, cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--queries", type=int, default=1000)
+    ap.add_argument("--targets", type=int, default=100000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    args = ap.parse_args()
+
+    import torch
+    import mmseqs2_amd
+    from mmseqs2_amd import workloads as wl
+    from mmseqs2_amd.capi import host_comp_bias
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    matrices = dict(np.load(os.path.join(ROOT, "tests", "golden", "matrices.npz")))
+    mat = matrices["blosum62_sw"]
+    sub16 = mat.astype(np.int16)
+
+    # ---- synthetic workload: same queries on every rank, rank-specific target shard (weak scaling) ----------
+    (qres, qoff), (tres, toff) = wl.config2_align_only(args.queries, args.targets, seed=1 + 1000 * rank)
+    if rank != 0:
+        (qres, qoff), _ = wl.config2_align_only(args.queries, 1, planted_frac=0.0, seed=1)
+    qs = wl.split(qres, qoff)
+    cbs = [host_comp_bias(sub16, matrices["blosum62_pback"], q)[1] for q in qs]
+
+    gpu = mmseqs2_amd.MMGpu(local_rank)
+    stream = torch.cuda.current_stream()
+    gpu.set_stream(stream.cuda_stream)
+    gpu.load_targets(tres, toff, 21)
+    ids = np.arange(args.targets, dtype=np.uint32)
+    queries = [dict(q=q, comp_bias=cb, targets=ids, min_start_score=0) for q, cb in zip(qs, cbs)]
+    t0 = time.time()
+    batch = gpu.sw_prepare(mat, 11, 1, queries, mode=0)      # H2D + scheduling: outside the timed region
+    prep_s = time.time() - t0
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        batch.run()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        batch.run()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    # HIP events recorded by the library on the launch stream around the kernels of each timed step
+    kern_ms = [batch.kernel_ms_mean(args.steps)[0]]
+    if dist is not None:
+        tmax = torch.tensor([elapsed], device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        cells_all = torch.tensor([float(batch.cells)], device="cuda", dtype=torch.float64)
+        dist.all_reduce(cells_all)
+        total_cells = float(cells_all.item())
+    else:
+        total_cells = float(batch.cells)
+
+    # ---- spot-check the timed batch's results against the oracle (checker only, outside the timed region) ----
+    check = None
+    if rank == 0:
+        from oracle.pyoracle import Oracle
+        res = batch.fetch().reshape(args.queries, args.targets)
+        orc = Oracle()
+        rng = np.random.default_rng(0)
+        bad = 0
+        n_chk = 400
+        for _ in range(n_chk):
+            qi, ti = int(rng.integers(0, args.queries)), int(rng.integers(0, args.targets))
+            r = orc.sw_align(qs[qi], cbs[qi], tres[int(toff[ti]):int(toff[ti + 1])], mat, 11, 1)
+            h = res[qi, ti]
+            bad += (int(h["score"]), int(h["q_end"]), int(h["t_end"]), int(h["word"])) != (r["score"], r["q_end"], r["t_end"], r["word"])
+        check = {"pairs_checked_vs_oracle": n_chk, "mismatches": bad,
+                 "score_checksum": int(res["score"].astype(np.int64).sum())}
+        del res
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = total_cells * args.steps / elapsed / 1e9
+        k_ms = float(np.mean(kern_ms))
+        # algorithmic HBM bytes of one launch: tlen + 28 bytes per alignment + the query
+        # residues/bias once per workgroup-visible query
+        tlen = (toff[1:] - toff[:-1]).astype(np.float64)
+        alg_bytes = float(args.queries) * float((tlen + 28).sum()) + 2.0 * float(qoff[-1])
+        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+        # packed-int16 VALU work: ~10.5 lane-ops per pair of cells in the inner loop
+        lane_ops = batch.cells / 2.0 * 10.5
+        out = {
+            "metric": "sw_gcells_per_s", "value": round(value, 2), "unit": "GCUPS",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int16", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[1]: align-only, %d random L~N(350,35) queries x %d targets "
+                                   "(10%% planted homologs), all-vs-all prefilter lists, BLOSUM62 gap 11/1, comp-bias on, "
+                                   "score+end positions" % (args.queries, args.targets),
+                       "pairs_per_gpu": int(batch.pairs), "cells_per_gpu": int(batch.cells),
+                       "parallelism": "1 process/GPU, independent target shards" if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                         "kernel_ms": round(k_ms, 3),
+                         "note": "Gotoh SW is VALU-bound (0.003 B/cell); see valu_roofline for the binding resource",
+                         "valu_roofline": {"achieved_lane_ops_per_s": round(lane_ops / (k_ms * 1e-3), 1),
+                                           "peak_lane_ops_per_s": VALU_LANE_OPS_PER_S,
+                                           "frac": round(lane_ops / (k_ms * 1e-3) / VALU_LANE_OPS_PER_S, 4)}},
+            "prepare_s": round(prep_s, 2), "check": check,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(matrices, qs, cbs, tres, toff, args.cpu_seconds)
+        print(json.dumps(out))
+    batch.free()
+    gpu.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,447 @@
+// Host side of libmmgpu: context, target database residency, batch scheduling, launches.
+// Everything here is plumbing around the kernels in sw_kernel.hip; see include/mmgpu.h for the contract.
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "mmgpu_internal.h"
+
+using namespace mmgpu;
+
+static thread_local std::string g_last_error;
+
+static int fail(int code, const std::string &msg) {
+    g_last_error = msg;
+    return code;
+}
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e__ = (expr);                                                                   \
+        if (e__ != hipSuccess)                                                                     \
+            return fail(MMGPU_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));        \
+    } while (0)
+
+struct mmgpu_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    DeviceDb db;
+    std::vector<uint32_t> h_len;   // host copy of target lengths (scheduling)
+    int compute_units = 0;
+    std::string name;
+};
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t n) {
+        if (p) { (void)hipFree(p); p = nullptr; }
+        bytes = n;
+        if (n == 0) return hipSuccess;
+        return hipMalloc(&p, n);
+    }
+    template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+template <typename T>
+static hipError_t upload(DevBuf &b, const std::vector<T> &v, hipStream_t s) {
+    hipError_t e = b.alloc(std::max<size_t>(v.size(), 1) * sizeof(T));
+    if (e != hipSuccess) return e;
+    if (v.empty()) return hipSuccess;
+    return hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s);
+}
+
+extern "C" const char *mmgpu_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" int mmgpu_init(mmgpu_ctx **out, int device_id) {
+    if (!out) return fail(MMGPU_ERR_ARG, "mmgpu_init: ctx is NULL");
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (device_id < 0 || device_id >= n) return fail(MMGPU_ERR_ARG, "mmgpu_init: no such device");
+    HIP_TRY(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+    mmgpu_ctx *c = new mmgpu_ctx();
+    c->device = device_id;
+    c->compute_units = prop.multiProcessorCount;
+    c->name = prop.name;
+    *out = c;
+    return MMGPU_OK;
+}
+
+static void free_db(DeviceDb &db) {
+    if (db.res) (void)hipFree(db.res);
+    if (db.off4) (void)hipFree(db.off4);
+    if (db.len) (void)hipFree(db.len);
+    db = DeviceDb();
+}
+
+extern "C" void mmgpu_destroy(mmgpu_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    free_db(c->db);
+    delete c;
+}
+
+extern "C" int mmgpu_set_stream(mmgpu_ctx *c, void *s) {
+    if (!c) return fail(MMGPU_ERR_ARG, "ctx is NULL");
+    c->stream = reinterpret_cast<hipStream_t>(s);
+    return MMGPU_OK;
+}
+
+extern "C" int mmgpu_synchronize(mmgpu_ctx *c) {
+    if (!c) return fail(MMGPU_ERR_ARG, "ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return MMGPU_OK;
+}
+
+extern "C" int mmgpu_device_info(mmgpu_ctx *c, int *cus, char *name, int cap) {
+    if (!c) return fail(MMGPU_ERR_ARG, "ctx is NULL");
+    if (cus) *cus = c->compute_units;
+    if (name && cap > 0) {
+        strncpy(name, c->name.c_str(), (size_t)cap - 1);
+        name[cap - 1] = 0;
+    }
+    return MMGPU_OK;
+}
+
+extern "C" int mmgpu_load_targets(mmgpu_ctx *c, const uint8_t *residues, const uint64_t *offsets, uint32_t n,
+                                  int alphabet) {
+    if (!c || !residues || !offsets) return fail(MMGPU_ERR_ARG, "mmgpu_load_targets: NULL argument");
+    if (alphabet < 2 || alphabet > 254) return fail(MMGPU_ERR_ARG, "mmgpu_load_targets: bad alphabet size");
+    HIP_TRY(hipSetDevice(c->device));
+    free_db(c->db);
+    std::vector<uint32_t> off4(std::max<uint32_t>(n, 1)), len(std::max<uint32_t>(n, 1));
+    uint64_t cur4 = 0;
+    uint32_t max_len = 0;
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        if (offsets[i + 1] < offsets[i]) return fail(MMGPU_ERR_ARG, "mmgpu_load_targets: offsets not monotone");
+        uint64_t l = offsets[i + 1] - offsets[i];
+        if (l > 65535) return fail(MMGPU_ERR_ARG, "mmgpu_load_targets: sequence longer than 65535 (Parameters.h:271)");
+        if (cur4 > 0xFFFFFFFFull) return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_load_targets: more than 16 GiB of residues per shard");
+        off4[i] = (uint32_t)cur4;
+        len[i] = (uint32_t)l;
+        max_len = std::max<uint32_t>(max_len, (uint32_t)l);
+        total += l;
+        cur4 += (l + 3) / 4;
+    }
+    const size_t bytes = (size_t)cur4 * 4 + max_len + 64;
+    std::vector<uint8_t> packed(bytes, (uint8_t)alphabet);   // padding = the "no letter" code
+    for (uint32_t i = 0; i < n; i++) {
+        for (uint64_t k = offsets[i]; k < offsets[i + 1]; k++)
+            if (residues[k] >= alphabet) return fail(MMGPU_ERR_ARG, "mmgpu_load_targets: residue code >= alphabet");
+        memcpy(packed.data() + (size_t)off4[i] * 4, residues + offsets[i], len[i]);
+    }
+    DeviceDb db;
+    HIP_TRY(hipMalloc((void **)&db.res, bytes));
+    HIP_TRY(hipMalloc((void **)&db.off4, off4.size() * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **)&db.len, len.size() * sizeof(uint32_t)));
+    HIP_TRY(hipMemcpy(db.res, packed.data(), bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(db.off4, off4.data(), off4.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(db.len, len.data(), len.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    db.n = n;
+    db.max_len = max_len;
+    db.total_residues = total;
+    db.alphabet = alphabet;
+    c->db = db;
+    c->h_len.assign(len.begin(), len.begin() + n);
+    return MMGPU_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// host-side helpers
+// ---------------------------------------------------------------------------------------------------------
+// SubstitutionMatrix::calcLocalAaBiasCorrection, src/commons/SubstitutionMatrix.cpp:79-112.  The reference mixes
+// float and double (`deltaS_i /= -1.0 * (float)windowLength`, `deltaS_i += pBack[a] * (float)subMat[a]`); each
+// statement below rounds where the reference's expression rounds.
+extern "C" int mmgpu_host_comp_bias(const int16_t *submat, const double *pback, int alphabet, const uint8_t *seq,
+                                    uint32_t len, float scale, float *out) {
+    if (!submat || !pback || (!seq && len) || (!out && len)) return fail(MMGPU_ERR_ARG, "mmgpu_host_comp_bias: NULL argument");
+    const int n = (int)len, half_window = 20;
+    for (int i = 0; i < n; i++) {
+        if (seq[i] >= alphabet) return fail(MMGPU_ERR_ARG, "mmgpu_host_comp_bias: residue code >= alphabet");
+        const int lo = std::max(0, i - half_window), hi = std::min(n, i + half_window);
+        const int16_t *row = submat + (int)seq[i] * alphabet;
+        int sum = 0;
+        for (int j = lo; j < hi; j++) sum += row[seq[j]];
+        sum -= row[seq[i]];
+        float delta = (float)sum;
+        delta = (float)((double)delta / (-1.0 * (double)(float)(hi - lo)));
+        for (int a = 0; a < alphabet; a++) delta = (float)((double)delta + pback[a] * (double)(float)row[a]);
+        out[i] = scale * delta;
+    }
+    return MMGPU_OK;
+}
+
+extern "C" int mmgpu_host_round_comp_bias(const float *bias, uint32_t len, int8_t *out) {
+    if ((!bias || !out) && len) return fail(MMGPU_ERR_ARG, "mmgpu_host_round_comp_bias: NULL argument");
+    for (uint32_t i = 0; i < len; i++) out[i] = (int8_t)((bias[i] < 0.0f) ? bias[i] - 0.5 : bias[i] + 0.5);
+    return MMGPU_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Smith-Waterman batches
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+constexpr uint32_t JOB_HITS = 256;   // hits per workgroup (8 rounds of 32)
+
+struct SwClass {            // all jobs sharing one kernel instantiation
+    int rows_per_lane = 0;
+    bool multi = false;
+    std::vector<SwJob> jobs;
+    DevBuf d_jobs;
+};
+}  // namespace
+
+struct mmgpu_sw_batch_t {
+    int mode = 0;
+    int alphabet = 0, gap_open = 0, gap_extend = 0;
+    uint64_t cells = 0, pairs = 0;
+    uint32_t n_queries = 0;
+    std::vector<SwClass> classes;
+    DevBuf d_qres, d_qcb, d_qoff, d_qbias, d_qminstart, d_hit_target, d_hit_out, d_out, d_mat, d_scratch;
+    uint32_t scratch_cols = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;   // one pair per mmgpu_sw_run since prepare
+    bool ran = false;
+};
+
+// which kernel instantiation serves a query of this length: 16 lanes x R rows per tile
+static void pick_class(uint32_t qlen, int *rows_per_lane, bool *multi) {
+    if (qlen <= 128) { *rows_per_lane = 8; *multi = false; }
+    else if (qlen <= 256) { *rows_per_lane = 16; *multi = false; }
+    else if (qlen <= 384) { *rows_per_lane = 24; *multi = false; }
+    else if (qlen <= 512) { *rows_per_lane = 32; *multi = false; }
+    else {
+        *multi = true;
+        const uint32_t pad24 = (qlen + 383) / 384 * 384, pad32 = (qlen + 511) / 512 * 512;
+        *rows_per_lane = pad24 < pad32 ? 24 : 32;
+    }
+}
+
+extern "C" int mmgpu_sw_prepare(mmgpu_ctx *c, const mmgpu_sw_params *par, const mmgpu_sw_query *qs, uint32_t nq,
+                                int mode, mmgpu_sw_batch_t **out) {
+    if (!c || !par || !out || (!qs && nq)) return fail(MMGPU_ERR_ARG, "mmgpu_sw_prepare: NULL argument");
+    if (!c->db.res) return fail(MMGPU_ERR_STATE, "mmgpu_sw_prepare: no targets loaded");
+    if (par->alphabet != c->db.alphabet) return fail(MMGPU_ERR_ARG, "mmgpu_sw_prepare: alphabet differs from the loaded targets");
+    if (mode != MMGPU_SW_SCORE_END && mode != MMGPU_SW_START) return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_sw_prepare: unknown mode");
+    if (par->gap_open < par->gap_extend || par->gap_extend < 0 || par->gap_open > 32767)
+        return fail(MMGPU_ERR_ARG, "mmgpu_sw_prepare: need 0 <= gap_extend <= gap_open");
+    // The cell-by-cell recurrence equals the reference's striped lazy-F result only if opening a gap right after
+    // a gap in the other direction never beats a substitution (StripedSmithWaterman.cpp:205).
+    int minp = 0;
+    for (int i = 0; i < par->alphabet * par->alphabet; i++) minp = std::min<int>(minp, par->mat[i]);
+    HIP_TRY(hipSetDevice(c->device));
+
+    mmgpu_sw_batch_t *b = new mmgpu_sw_batch_t();
+    b->mode = mode;
+    b->alphabet = par->alphabet;
+    b->gap_open = par->gap_open;
+    b->gap_extend = par->gap_extend;
+    b->n_queries = nq;
+
+    std::vector<uint8_t> qres;
+    std::vector<int8_t> qcb;
+    std::vector<uint32_t> qoff(nq + 1, 0);
+    std::vector<int32_t> qbias(std::max<uint32_t>(nq, 1), 0), qminstart(std::max<uint32_t>(nq, 1), 0);
+    uint64_t total_hits = 0;
+    for (uint32_t i = 0; i < nq; i++) {
+        if (qs[i].qlen == 0 || qs[i].qlen > 65535 || !qs[i].q) { delete b; return fail(MMGPU_ERR_ARG, "mmgpu_sw_prepare: bad query"); }
+        qoff[i + 1] = qoff[i] + qs[i].qlen;
+        total_hits += qs[i].n_targets;
+    }
+    if (total_hits > 0xFFFFFFF0ull) { delete b; return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_sw_prepare: more than 2^32 pairs in one batch"); }
+    qres.resize(qoff[nq]);
+    qcb.assign(qoff[nq], 0);
+    std::vector<uint32_t> hit_target((size_t)total_hits), hit_out((size_t)total_hits);
+    b->classes.resize(8);
+    for (int k = 0; k < 8; k++) {
+        b->classes[k].rows_per_lane = 8 * (k % 4 + 1);
+        b->classes[k].multi = k >= 4;
+    }
+    std::vector<uint32_t> order;
+    uint32_t hit_cursor = 0, out_cursor = 0;
+    uint32_t max_tlen = 0;
+    bool any_multi = false;
+    for (uint32_t i = 0; i < nq; i++) {
+        const mmgpu_sw_query &Q = qs[i];
+        memcpy(qres.data() + qoff[i], Q.q, Q.qlen);
+        int mincb = 0;
+        for (uint32_t k = 0; k < Q.qlen; k++) {
+            if (Q.q[k] >= par->alphabet) { delete b; return fail(MMGPU_ERR_ARG, "mmgpu_sw_prepare: query residue code >= alphabet"); }
+            if (Q.comp_bias) { qcb[qoff[i] + k] = Q.comp_bias[k]; mincb = std::min<int>(mincb, Q.comp_bias[k]); }
+        }
+        if (!(minp + mincb + par->gap_extend > -par->gap_open)) {
+            delete b;
+            return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_sw_prepare: gap penalties too small for this matrix (adjacent insertion+deletion could win)");
+        }
+        qbias[i] = std::abs(minp) + std::abs(mincb);   // ssw_init :1397-1406
+        qminstart[i] = Q.min_start_score;
+        // sort the prefilter list by target length (longest first) so the 8 targets a wave runs together end together
+        const bool same_list = i > 0 && Q.target_ids == qs[i - 1].target_ids && Q.n_targets == qs[i - 1].n_targets;
+        if (!same_list) {   // all-vs-all callers hand the same list to every query: sort it once
+            order.resize(Q.n_targets);
+            std::iota(order.begin(), order.end(), 0u);
+            for (uint32_t k = 0; k < Q.n_targets; k++)
+                if (Q.target_ids[k] >= c->db.n) { delete b; return fail(MMGPU_ERR_ARG, "mmgpu_sw_prepare: target id out of range"); }
+            std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t bb) {
+                return c->h_len[Q.target_ids[a]] > c->h_len[Q.target_ids[bb]];
+            });
+        }
+        int rpl; bool multi;
+        pick_class(Q.qlen, &rpl, &multi);
+        any_multi |= multi;
+        SwClass &cls = b->classes[(multi ? 4 : 0) + rpl / 8 - 1];
+        for (uint32_t k = 0; k < Q.n_targets; k++) {
+            const uint32_t t = Q.target_ids[order[k]];
+            hit_target[hit_cursor + k] = t;
+            hit_out[hit_cursor + k] = out_cursor + order[k];
+            b->cells += (uint64_t)Q.qlen * c->h_len[t];
+            max_tlen = std::max(max_tlen, c->h_len[t]);
+        }
+        for (uint32_t k = 0; k < Q.n_targets; k += JOB_HITS) {
+            SwJob j;
+            j.query = i;
+            j.hit_begin = hit_cursor + k;
+            j.hit_end = hit_cursor + std::min<uint32_t>(k + JOB_HITS, Q.n_targets);
+            j.pad = 0;
+            cls.jobs.push_back(j);
+        }
+        hit_cursor += Q.n_targets;
+        out_cursor += Q.n_targets;
+    }
+    b->pairs = total_hits;
+
+    hipStream_t s = c->stream;
+    std::vector<int8_t> mat(par->mat, par->mat + par->alphabet * par->alphabet);
+#define B_TRY(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { delete b; return fail(MMGPU_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__)); } } while (0)
+    B_TRY(upload(b->d_qres, qres, s));
+    B_TRY(upload(b->d_qcb, qcb, s));
+    B_TRY(upload(b->d_qoff, qoff, s));
+    B_TRY(upload(b->d_qbias, qbias, s));
+    B_TRY(upload(b->d_qminstart, qminstart, s));
+    B_TRY(upload(b->d_hit_target, hit_target, s));
+    B_TRY(upload(b->d_hit_out, hit_out, s));
+    B_TRY(upload(b->d_mat, mat, s));
+    B_TRY(b->d_out.alloc(std::max<size_t>((size_t)total_hits, 1) * sizeof(mmgpu_sw_hit)));
+    size_t multi_jobs = 0;
+    for (auto &cls : b->classes) {
+        B_TRY(upload(cls.d_jobs, cls.jobs, s));
+        if (cls.multi) multi_jobs = std::max(multi_jobs, cls.jobs.size());
+    }
+    if (any_multi) {
+        b->scratch_cols = max_tlen + 16;
+        // [job][wave][group][2 buffers][cols] x uint2
+        B_TRY(b->d_scratch.alloc(multi_jobs * 4 * 4 * 2 * (size_t)b->scratch_cols * sizeof(uint2)));
+    }
+    B_TRY(hipStreamSynchronize(s));   // the host vectors above die with this scope
+#undef B_TRY
+    *out = b;
+    return MMGPU_OK;
+}
+
+extern "C" int mmgpu_sw_run(mmgpu_ctx *c, mmgpu_sw_batch_t *b) {
+    if (!c || !b) return fail(MMGPU_ERR_ARG, "mmgpu_sw_run: NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (b->events.size() < 256) {
+        HIP_TRY(hipEventCreate(&ev0));
+        HIP_TRY(hipEventCreate(&ev1));
+        b->events.push_back(std::make_pair(ev0, ev1));
+        HIP_TRY(hipEventRecord(ev0, c->stream));
+    }
+    for (int pass = 0; pass < (b->mode == MMGPU_SW_START ? 2 : 1); pass++) {
+        for (auto &cls : b->classes) {
+            if (cls.jobs.empty()) continue;
+            SwLaunch L;
+            L.jobs = cls.d_jobs.as<SwJob>();
+            L.n_jobs = (uint32_t)cls.jobs.size();
+            L.q_res = b->d_qres.as<uint8_t>();
+            L.q_cb = b->d_qcb.as<int8_t>();
+            L.q_off = b->d_qoff.as<uint32_t>();
+            L.q_bias = b->d_qbias.as<int32_t>();
+            L.q_minstart = b->d_qminstart.as<int32_t>();
+            L.t_res = c->db.res;
+            L.t_off4 = c->db.off4;
+            L.t_len = c->db.len;
+            L.hit_target = b->d_hit_target.as<uint32_t>();
+            L.hit_out = b->d_hit_out.as<uint32_t>();
+            L.out = b->d_out.as<mmgpu_sw_hit>();
+            L.mat = b->d_mat.as<int8_t>();
+            L.alphabet = b->alphabet;
+            L.gap_open = b->gap_open;
+            L.gap_extend = b->gap_extend;
+            L.scratch = b->d_scratch.as<uint2>();
+            L.scratch_cols = b->scratch_cols;
+            HIP_TRY(launch_sw(L, cls.rows_per_lane, cls.multi, pass == 1, c->stream));
+        }
+    }
+    if (ev1) HIP_TRY(hipEventRecord(ev1, c->stream));
+    b->ran = true;
+    return MMGPU_OK;
+}
+
+extern "C" int mmgpu_sw_fetch(mmgpu_ctx *c, mmgpu_sw_batch_t *b, mmgpu_sw_hit *out) {
+    if (!c || !b || (!out && b->pairs)) return fail(MMGPU_ERR_ARG, "mmgpu_sw_fetch: NULL argument");
+    if (!b->ran) return fail(MMGPU_ERR_STATE, "mmgpu_sw_fetch: batch was never run");
+    HIP_TRY(hipSetDevice(c->device));
+    if (b->pairs)
+        HIP_TRY(hipMemcpyAsync(out, b->d_out.p, (size_t)b->pairs * sizeof(mmgpu_sw_hit), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return MMGPU_OK;
+}
+
+extern "C" int mmgpu_sw_batch_stats(mmgpu_sw_batch_t *b, uint64_t *cells, uint64_t *pairs) {
+    if (!b) return fail(MMGPU_ERR_ARG, "mmgpu_sw_batch_stats: NULL argument");
+    if (cells) *cells = b->cells;
+    if (pairs) *pairs = b->pairs;
+    return MMGPU_OK;
+}
+
+extern "C" int mmgpu_sw_last_kernel_ms(mmgpu_ctx *c, mmgpu_sw_batch_t *b, float *ms) {
+    if (!c || !b || !ms) return fail(MMGPU_ERR_ARG, "mmgpu_sw_last_kernel_ms: NULL argument");
+    if (!b->ran) return fail(MMGPU_ERR_STATE, "mmgpu_sw_last_kernel_ms: batch was never run");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventSynchronize(b->events.back().second));
+    HIP_TRY(hipEventElapsedTime(ms, b->events.back().first, b->events.back().second));
+    return MMGPU_OK;
+}
+
+extern "C" int mmgpu_sw_kernel_ms_mean(mmgpu_ctx *c, mmgpu_sw_batch_t *b, uint32_t last_n, float *ms, uint32_t *n_used) {
+    if (!c || !b || !ms) return fail(MMGPU_ERR_ARG, "mmgpu_sw_kernel_ms_mean: NULL argument");
+    if (!b->ran || b->events.empty()) return fail(MMGPU_ERR_STATE, "mmgpu_sw_kernel_ms_mean: batch was never run");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t n = std::min<size_t>(last_n ? last_n : b->events.size(), b->events.size());
+    double sum = 0;
+    for (size_t k = b->events.size() - n; k < b->events.size(); k++) {
+        float t = 0;
+        HIP_TRY(hipEventSynchronize(b->events[k].second));
+        HIP_TRY(hipEventElapsedTime(&t, b->events[k].first, b->events[k].second));
+        sum += t;
+    }
+    *ms = (float)(sum / (double)n);
+    if (n_used) *n_used = (uint32_t)n;
+    return MMGPU_OK;
+}
+
+extern "C" void mmgpu_sw_free(mmgpu_ctx *c, mmgpu_sw_batch_t *b) {
+    if (!b) return;
+    if (c) (void)hipSetDevice(c->device);
+    for (auto &e : b->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    delete b;
+}
+
+extern "C" int mmgpu_sw_batch(mmgpu_ctx *c, const mmgpu_sw_params *par, const mmgpu_sw_query *qs, uint32_t nq, int mode,
+                              mmgpu_sw_hit *out) {
+    mmgpu_sw_batch_t *b = nullptr;
+    int rc = mmgpu_sw_prepare(c, par, qs, nq, mode, &b);
+    if (rc != MMGPU_OK) return rc;
+    rc = mmgpu_sw_run(c, b);
+    if (rc == MMGPU_OK) rc = mmgpu_sw_fetch(c, b, out);
+    mmgpu_sw_free(c, b);
+    return rc;
+}

@@ -1,0 +1,367 @@
+// Gotoh Smith-Waterman (affine gaps, local) for gfx950 / CDNA4 - score, end position, start position.
+//
+// What it computes: exactly what SmithWaterman::alignScoreEndPos (src/alignment/
+// StripedSmithWaterman.cpp:892-941; sw_sse2_byte :98-299, sw_sse2_word :301-476) and the reverse scan of
+// alignStartPosBacktrace (:1129-1204) compute on the CPU, bit for bit:
+//     H = max(sat16(Hdiag + P), E, F);  E' = max(E - ge, H - go);  F' = max(F - ge, H - go)   (E, F >= 0)
+//     t_end = first column in which the running maximum reaches its final value (:232-248, :414-425)
+//     q_end = smallest query index holding that maximum in that column           (:262-271, :438-447)
+// The reference runs a uint8 pass and re-runs in int16 on overflow; here everything is int16 (exact for
+// every score the uint8 pass can represent, and saturating at 32767 exactly like sw_sse2_word), and the
+// `word` flag reports which pass the reference would have ended in (score + bias >= 255, :238-242).
+//
+// How it is mapped to CDNA4 (this is not the striped/lazy-F formulation of the CPU code):
+//  * integer DP => VALU, no MFMA.  All cell arithmetic is packed 2 x int16 (v_pk_add_i16 clamp,
+//    v_pk_max_i16/u16, v_pk_sub_u16 clamp): the low half of every register belongs to target A, the
+//    high half to target B, so one VALU lane-op advances two independent alignments.
+//  * a group of 16 lanes (one DPP row) owns one pair of targets; lane g owns R consecutive query rows
+//    (R = 8/16/24/32 -> 128..512 rows per tile) whose H/E state lives in registers for the whole scan.
+//    Lanes run skewed by one column (anti-diagonal wavefront): at step s lane g works on column s - g.
+//    The hand-off lane g -> g+1 (H of the strip's last row, the F leaving it, and the two target
+//    letters) is three v_mov_b32_dpp row_shr:1 - no LDS, no bpermute.
+//  * the query profile P[letter][row] (int16, composition bias folded in) is built once per workgroup in
+//    LDS; per step a lane fetches its R scores for letter a (target A) and for letter b (target B) with
+//    ds_read_b128 and interleaves them with v_perm_b32.  The per-lane row stride is padded to an odd
+//    number of 16-byte slots so the 16 lanes of a group hit 64 distinct banks.
+//  * four groups per wave64, four waves per workgroup: 32 targets in flight per workgroup, all against
+//    the same query (the prefilter list of one query, pre-sorted by target length so the groups of a
+//    wave finish together).
+//  * end positions: each lane keeps the packed running maximum of its strip, the column where it was
+//    last raised and a snapshot of the strip's H values at that column (v_bfi under a rarely taken
+//    branch); a 16-lane DPP/shuffle reduction at the end applies the reference's tie rules.
+//  * queries longer than one tile loop over tiles inside the kernel; the H/F row leaving the last lane
+//    is parked in a double-buffered global scratch line and re-enters at the head lane of the next tile.
+//
+// Bytes per cell that ever touch HBM: (tlen + 28) / (qlen * tlen) ~ 0.003 - this kernel
+// is bound by VALU issue, not by HBM.
+#include "mmgpu_internal.h"
+
+namespace mmgpu {
+
+namespace {
+
+constexpr int GROUP = 16;            // lanes per target pair (one DPP row)
+constexpr int WAVES = 4;             // waves per workgroup
+constexpr int GROUPS_PER_WAVE = 64 / GROUP;
+constexpr int HITS_PER_WAVE = 2 * GROUPS_PER_WAVE;   // two targets per group (lo/hi halves)
+constexpr unsigned NEG2 = 0x80008000u;               // packed (-32768, -32768)
+
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned pk_add_sat(unsigned a, unsigned b) {   // v_pk_add_i16 ... clamp
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_add_sat(__builtin_bit_cast(s16x2, a),
+                                                                      __builtin_bit_cast(s16x2, b)));
+}
+__device__ __forceinline__ unsigned pk_max_s(unsigned a, unsigned b) {     // v_pk_max_i16
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a),
+                                                                  __builtin_bit_cast(s16x2, b)));
+}
+__device__ __forceinline__ unsigned pk_max_u(unsigned a, unsigned b) {     // v_pk_max_u16
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(u16x2, a),
+                                                                  __builtin_bit_cast(u16x2, b)));
+}
+__device__ __forceinline__ unsigned pk_sub_sat_u(unsigned a, unsigned b) { // v_pk_sub_u16 ... clamp
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, a),
+                                                                      __builtin_bit_cast(u16x2, b)));
+}
+__device__ __forceinline__ unsigned bfi(unsigned mask, unsigned a, unsigned b) {   // v_bfi_b32
+    return (a & mask) | (b & ~mask);
+}
+// value of the lane one below inside the 16-lane row; lane 0 of each row keeps `head`
+__device__ __forceinline__ unsigned from_lane_above(unsigned head, unsigned v) {
+    return __builtin_amdgcn_update_dpp(head, v, 0x111 /*row_shr:1*/, 0xF, 0xF, false);
+}
+
+__host__ __device__ constexpr int lane_stride_bytes(int R) {
+    // R*2 bytes of scores per lane, rounded up to an odd number of 16-byte slots (bank spread)
+    int slots = (R * 2 + 15) / 16;
+    if ((slots & 1) == 0) slots += 1;
+    return slots * 16;
+}
+
+template <int R>
+struct Tile {
+    static constexpr int ROWS = GROUP * R;
+    static constexpr int LANE_STRIDE = lane_stride_bytes(R);
+    static constexpr int ROW_STRIDE = GROUP * LANE_STRIDE;   // bytes per letter
+};
+
+// Build P[letter][row] for rows [tile_base, tile_base + ROWS) of the query (or of the reversed query).
+// Rows past the query end and the extra letter `alphabet` (padding column of a finished target) are
+// -32768, which keeps H at max(E, F) there and can never raise a running maximum.
+template <int R, bool REV>
+__device__ __forceinline__ void build_profile(unsigned char *lds, const uint8_t *q, const int8_t *cb, int qlen,
+                                              int tile_base, const int8_t *mat, int alphabet) {
+    using T = Tile<R>;
+    const int total = (alphabet + 1) * T::ROWS;
+    for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
+        const int letter = idx / T::ROWS;
+        const int row = idx - letter * T::ROWS;
+        const int rg = tile_base + row;
+        short v = (short)-32768;
+        if (letter < alphabet && rg < qlen) {
+            const int qi = REV ? (qlen - 1 - rg) : rg;
+            v = (short)((int)mat[letter * alphabet + q[qi]] + (int)cb[qi]);
+        }
+        const int lane = row / R, r = row - lane * R;
+        *reinterpret_cast<short *>(lds + letter * T::ROW_STRIDE + lane * T::LANE_STRIDE + r * 2) = v;
+    }
+}
+
+template <int R, bool MULTI, bool REV>
+__global__ __launch_bounds__(WAVES * 64) void sw_kernel(SwLaunch L) {
+    using T = Tile<R>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+
+    const SwJob job = L.jobs[blockIdx.x];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane & (GROUP - 1);
+    const int grp = lane / GROUP;
+
+    const uint32_t qbeg = L.q_off[job.query];
+    const int qlen = (int)(L.q_off[job.query + 1] - qbeg);
+    const uint8_t *q = L.q_res + qbeg;
+    const int8_t *cb = L.q_cb + qbeg;
+    const int qbias = L.q_bias[job.query];
+    const int n_tiles = MULTI ? (qlen + T::ROWS - 1) / T::ROWS : 1;
+
+    const unsigned go2 = (unsigned)L.gap_open * 0x10001u;
+    const unsigned ge2 = (unsigned)L.gap_extend * 0x10001u;
+    const unsigned pad_letter = (unsigned)L.alphabet;
+
+    if (!MULTI) {
+        build_profile<R, REV>(lds, q, cb, qlen, 0, L.mat, L.alphabet);
+        __syncthreads();
+    }
+
+    const uint32_t n_hits = job.hit_end - job.hit_begin;
+    const uint32_t n_iter = (n_hits + WAVES * HITS_PER_WAVE - 1) / (WAVES * HITS_PER_WAVE);
+
+    for (uint32_t it = 0; it < n_iter; ++it) {
+        const uint32_t base = job.hit_begin + (it * WAVES + wave) * HITS_PER_WAVE;
+        if (!MULTI && base >= job.hit_end) break;   // wave-uniform; MULTI keeps every wave in the barrier loop
+
+        // ---- the two targets of this group ------------------------------------------------------
+        const uint32_t hA = base + grp * 2, hB = hA + 1;
+        const bool vA = hA < job.hit_end, vB = hB < job.hit_end;
+        const uint32_t tA = vA ? L.hit_target[hA] : 0u, tB = vB ? L.hit_target[hB] : 0u;
+        const uint8_t *pA = L.t_res + (size_t)L.t_off4[tA] * 4;
+        const uint8_t *pB = L.t_res + (size_t)L.t_off4[tB] * 4;
+        int colsA = vA ? (int)L.t_len[tA] : 0, colsB = vB ? (int)L.t_len[tB] : 0;
+        int r0A = 0, r0B = 0;       // REV: first live row of the reversed query
+        int endA = 0, endB = 0;     // REV: forward t_end
+        if (REV) {
+            // reverse scan over q[0..q_end] x t[0..t_end], both walked backwards (:1143-1175)
+            const mmgpu_sw_hit fa = L.out[vA ? L.hit_out[hA] : 0], fb = L.out[vB ? L.hit_out[hB] : 0];
+            endA = fa.t_end; endB = fb.t_end;
+            const int min_start = L.q_minstart[job.query];
+            colsA = (vA && fa.score > 0 && fa.score >= min_start) ? fa.t_end + 1 : 0;
+            colsB = (vB && fb.score > 0 && fb.score >= min_start) ? fb.t_end + 1 : 0;
+            r0A = qlen - 1 - fa.q_end;
+            r0B = qlen - 1 - fb.q_end;
+        }
+        int ncols = colsA > colsB ? colsA : colsB;
+        ncols = max(ncols, __shfl_xor(ncols, 16));
+        ncols = max(ncols, __shfl_xor(ncols, 32));
+        ncols = __builtin_amdgcn_readfirstlane(ncols);
+        const int nsteps = ncols + GROUP - 1;
+
+        unsigned long long bestA = 0, bestB = 0;   // (score << 32) | (~col << 16) | ~row, maximised
+
+        uint2 *scr = nullptr;
+        if (MULTI) scr = L.scratch + ((size_t)(blockIdx.x * WAVES + wave) * GROUPS_PER_WAVE + grp) * 2 * L.scratch_cols;
+
+        for (int tile = 0; tile < n_tiles; ++tile) {
+            const int tile_base = tile * T::ROWS;
+            if (MULTI) {
+                __syncthreads();   // everyone is done reading the previous tile's profile
+                build_profile<R, REV>(lds, q, cb, qlen, tile_base, L.mat, L.alphabet);
+                __syncthreads();
+            }
+            const uint2 *scr_in = MULTI ? scr + (size_t)((tile + 1) & 1) * L.scratch_cols : nullptr;
+            uint2 *scr_out = MULTI ? scr + (size_t)(tile & 1) * L.scratch_cols : nullptr;
+            const bool has_above = MULTI && tile > 0;
+            const bool has_below = MULTI && tile + 1 < n_tiles;
+
+            unsigned Hp[R], E[R], snap[R], rmask[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) { Hp[r] = 0; E[r] = 0; snap[r] = 0; }
+            if (REV) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int rg = tile_base + g * R + r;
+                    rmask[r] = (rg >= r0A ? 0xFFFFu : 0u) | (rg >= r0B ? 0xFFFF0000u : 0u);
+                }
+            }
+            unsigned vmax = 0, bestcol = 0xFFFFFFFFu;
+            unsigned Hup_prev = 0;
+            unsigned out_H = 0, out_F = 0, out_let = pad_letter * 0x101u;
+
+            // two-deep letter prefetch for the head lane (every lane of the group loads the same byte)
+            auto letter_addr = [&](const uint8_t *p, int cols, int end, int col) -> const uint8_t * {
+                int c = col < cols ? col : cols - 1;
+                if (c < 0) c = 0;
+                return REV ? p + (end - c) : p + c;
+            };
+            unsigned la0 = *letter_addr(pA, colsA, endA, 0), lb0 = *letter_addr(pB, colsB, endB, 0);
+            unsigned la1 = *letter_addr(pA, colsA, endA, 1), lb1 = *letter_addr(pB, colsB, endB, 1);
+            uint2 up0 = make_uint2(0, 0), up1 = make_uint2(0, 0);
+            if (has_above) {
+                up0 = scr_in[0];
+                up1 = scr_in[min(1, ncols - 1 < 0 ? 0 : ncols - 1)];
+            }
+
+            for (int s = 0; s < nsteps; ++s) {
+                // ---- inputs of this step: from the lane above, or the tile boundary for the head lane ----
+                const unsigned head_let = (s < colsA ? la0 : pad_letter) | ((s < colsB ? lb0 : pad_letter) << 8);
+                const unsigned Hup = from_lane_above(up0.x, out_H);
+                unsigned f = from_lane_above(up0.y, out_F);
+                const unsigned let = from_lane_above(head_let, out_let);
+                la0 = la1; lb0 = lb1;
+                la1 = *letter_addr(pA, colsA, endA, s + 2);
+                lb1 = *letter_addr(pB, colsB, endB, s + 2);
+                if (has_above) {
+                    up0 = up1;
+                    int c = s + 2; if (c > ncols - 1) c = ncols - 1; if (c < 0) c = 0;
+                    up1 = scr_in[c];
+                }
+
+                const unsigned a = let & 0xFFu, b = (let >> 8) & 0xFFu;
+                const uint4 *rowA = reinterpret_cast<const uint4 *>(lds + a * T::ROW_STRIDE + g * T::LANE_STRIDE);
+                const uint4 *rowB = reinterpret_cast<const uint4 *>(lds + b * T::ROW_STRIDE + g * T::LANE_STRIDE);
+
+                unsigned hd = Hup_prev;
+                Hup_prev = Hup;
+                unsigned cmax = 0;
+#pragma unroll
+                for (int k = 0; k < R / 8; ++k) {
+                    const uint4 pa = rowA[k], pb = rowB[k];
+                    const unsigned pav[4] = {pa.x, pa.y, pa.z, pa.w};
+                    const unsigned pbv[4] = {pb.x, pb.y, pb.z, pb.w};
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+#pragma unroll
+                        for (int half = 0; half < 2; ++half) {
+                            const int r = k * 8 + d * 2 + half;
+                            // (score of target A's letter, score of target B's letter) for query row r
+                            unsigned P = __builtin_amdgcn_perm(pbv[d], pav[d], half ? 0x07060302u : 0x05040100u);
+                            if (REV) P = bfi(rmask[r], P, NEG2);
+                            unsigned h = pk_add_sat(hd, P);
+                            h = pk_max_s(h, E[r]);
+                            h = pk_max_s(h, f);
+                            hd = Hp[r];
+                            Hp[r] = h;
+                            cmax = pk_max_u(cmax, h);
+                            const unsigned t = pk_sub_sat_u(h, go2);
+                            E[r] = pk_max_u(pk_sub_sat_u(E[r], ge2), t);
+                            f = pk_max_u(pk_sub_sat_u(f, ge2), t);
+                        }
+                    }
+                }
+                out_H = Hp[R - 1];
+                out_F = f;
+                out_let = let;
+
+                const int col = s - g;
+                if (has_below && g == GROUP - 1 && col >= 0 && col < ncols) scr_out[col] = make_uint2(out_H, out_F);
+
+                // ---- running maximum / column / snapshot (rarely taken once the scores have grown) ----
+                const unsigned nm = pk_max_u(vmax, cmax);
+                if (nm != vmax) {
+                    const unsigned diff = nm ^ vmax;
+                    const unsigned mask = ((diff & 0xFFFFu) ? 0xFFFFu : 0u) | ((diff >> 16) ? 0xFFFF0000u : 0u);
+                    bestcol = bfi(mask, ((unsigned)col & 0xFFFFu) * 0x10001u, bestcol);
+#pragma unroll
+                    for (int r = 0; r < R; ++r) snap[r] = bfi(mask, Hp[r], snap[r]);
+                    vmax = nm;
+                }
+            }
+
+            // ---- fold this tile's lanes into the pair's running best (tie rules in the key order) ----
+            unsigned rowA_first = 0, rowB_first = 0;
+            const unsigned sA = vmax & 0xFFFFu, sB = vmax >> 16;
+#pragma unroll
+            for (int r = R - 1; r >= 0; --r) {
+                if ((snap[r] & 0xFFFFu) == sA) rowA_first = (unsigned)r;
+                if ((snap[r] >> 16) == sB) rowB_first = (unsigned)r;
+            }
+            const unsigned rgA = (unsigned)(tile_base + g * R) + rowA_first;
+            const unsigned rgB = (unsigned)(tile_base + g * R) + rowB_first;
+            unsigned long long keyA = sA ? ((unsigned long long)sA << 32) | ((0xFFFFu - (bestcol & 0xFFFFu)) << 16) | (0xFFFFu - rgA) : 0ull;
+            unsigned long long keyB = sB ? ((unsigned long long)sB << 32) | ((0xFFFFu - (bestcol >> 16)) << 16) | (0xFFFFu - rgB) : 0ull;
+#pragma unroll
+            for (int m = 1; m < GROUP; m <<= 1) {
+                const unsigned long long oa = __shfl_xor(keyA, m), ob = __shfl_xor(keyB, m);
+                keyA = oa > keyA ? oa : keyA;
+                keyB = ob > keyB ? ob : keyB;
+            }
+            bestA = keyA > bestA ? keyA : bestA;
+            bestB = keyB > bestB ? keyB : bestB;
+        }
+
+        // ---- write results -----------------------------------------------------------------------
+        if (g == 0) {
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const bool valid = half ? vB : vA;
+                if (!valid) continue;
+                const unsigned long long key = half ? bestB : bestA;
+                const uint32_t h = half ? hB : hA;
+                const int score = (int)(key >> 32);
+                const int col = 0xFFFF - (int)((key >> 16) & 0xFFFFu);
+                const int row = 0xFFFF - (int)(key & 0xFFFFu);
+                mmgpu_sw_hit *o = L.out + L.hit_out[h];
+                if (!REV) {
+                    mmgpu_sw_hit res;
+                    res.score = score;
+                    res.q_end = score ? row : 0;       // all-zero saved column matches at index 0 (:263-271)
+                    res.t_end = score ? col : -1;      // byte pass initialises end_db = -1 (:118)
+                    res.q_start = -1;
+                    res.t_start = -1;
+                    res.word = (score + qbias >= 255) ? 1 : 0;
+                    *o = res;
+                } else {
+                    const int end = half ? endB : endA;
+                    const int cols = half ? colsB : colsA;
+                    if (cols > 0) {
+                        // column index counts backwards from t_end; row is an index into the reversed query
+                        o->t_start = (score == o->score) ? end - col : -2;   // -2: forward/backward mismatch (:1191)
+                        o->q_start = qlen - 1 - row;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int R>
+hipError_t launch_r(const SwLaunch &L, bool multi, bool rev, hipStream_t stream) {
+    const size_t lds = (size_t)(L.alphabet + 1) * Tile<R>::ROW_STRIDE;
+    dim3 grid(L.n_jobs), block(WAVES * 64);
+    if (L.n_jobs == 0) return hipSuccess;
+    if (!multi && !rev) hipLaunchKernelGGL((sw_kernel<R, false, false>), grid, block, lds, stream, L);
+    else if (!multi && rev) hipLaunchKernelGGL((sw_kernel<R, false, true>), grid, block, lds, stream, L);
+    else if (multi && !rev) hipLaunchKernelGGL((sw_kernel<R, true, false>), grid, block, lds, stream, L);
+    else hipLaunchKernelGGL((sw_kernel<R, true, true>), grid, block, lds, stream, L);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+size_t sw_lds_bytes(int rows_per_lane, int alphabet) {
+    return (size_t)(alphabet + 1) * GROUP * lane_stride_bytes(rows_per_lane);
+}
+
+hipError_t launch_sw(const SwLaunch &L, int rows_per_lane, bool multi_tile, bool reverse, hipStream_t stream) {
+    switch (rows_per_lane) {
+        case 8: return launch_r<8>(L, multi_tile, reverse, stream);
+        case 16: return launch_r<16>(L, multi_tile, reverse, stream);
+        case 24: return launch_r<24>(L, multi_tile, reverse, stream);
+        case 32: return launch_r<32>(L, multi_tile, reverse, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace mmgpu

@@ -124,7 +124,9 @@ class RefLib:
     """The real reference (needs /root/reference/data/*.out at run time for the matrices)."""
 
     def __init__(self, matrix="blosum62.out", bit_factor=2.0, score_bias=0.0, max_len=70000, gap_open=11,
-                 gap_extend=1, comp_bias=True, db_residues=1000000):
+                 gap_extend=1, comp_bias=True, db_residues=1000000, serialized=None):
+        """matrix: file name under /root/reference/data, or - where that tree is absent (GPU box) -
+        `serialized` = the "name.out:DATA" bytes stored in tests/golden/matrices.npz."""
         L = self.L = ctypes.CDLL(REF_SO)
         L.mmref_new.restype = c_p
         L.mmref_new.argtypes = [ctypes.c_char_p, ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.c_int,
@@ -134,10 +136,17 @@ class RefLib:
         L.mmref_bitscore.restype = ctypes.c_double
         L.mmref_bitscore.argtypes = [c_p, ctypes.c_double]
         L.mmref_alphabet_size.argtypes = [c_p]
-        path = os.path.join(REFERENCE_ROOT, "data", matrix).encode()
+        path = bytes(serialized) if serialized is not None else os.path.join(REFERENCE_ROOT, "data", matrix).encode()
         self.c = c_p(L.mmref_new(path, bit_factor, score_bias, max_len, gap_open, gap_extend, int(comp_bias),
                                  db_residues))
         self.alphabet = L.mmref_alphabet_size(self.c)
+
+    def serialized_matrix(self):
+        b = ctypes.create_string_buffer(1 << 16)
+        self.L.mmref_serialized_matrix.argtypes = [c_p, ctypes.c_char_p, ctypes.c_int]
+        n = self.L.mmref_serialized_matrix(self.c, b, 1 << 16)
+        assert n > 0
+        return b.raw[:n]
 
     def matrix(self):
         m = np.zeros((self.alphabet, self.alphabet), np.int8)

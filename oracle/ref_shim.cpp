@@ -58,10 +58,14 @@ mmref_ctx *mmref_new(const char *matrix_file, float bit_factor, float score_bias
     Debug::setDebugLevel(Debug::ERROR);
     mmref_ctx *c = new mmref_ctx();
     c->m = new SubstitutionMatrix(matrix_file, bit_factor, score_bias);
-    c->evaluer = new EvalueComputation(db_residues, c->m, gap_open, gap_extend);
     c->maxLen = max_len;
     c->compBias = comp_bias != 0;
-    c->sw = new SmithWaterman(max_len, c->m->alphabetSize, c->compBias, 1.0f, c->m);
+    c->evaluer = NULL;
+    c->sw = NULL;
+    if (gap_open > 0) {   // gap_open <= 0: matrix-only context (k-mer / ungapped matrices have no Gumbel table)
+        c->evaluer = new EvalueComputation(db_residues, c->m, gap_open, gap_extend);
+        c->sw = new SmithWaterman(max_len, c->m->alphabetSize, c->compBias, 1.0f, c->m);
+    }
     c->q = new Sequence(max_len, Parameters::DBTYPE_AMINO_ACIDS, c->m, 0, false, c->compBias);
     c->t = new Sequence(max_len, Parameters::DBTYPE_AMINO_ACIDS, c->m, 0, false, c->compBias);
     c->gapOpen = gap_open;
@@ -158,3 +162,24 @@ double mmref_evalue(mmref_ctx *c, double score, double qlen) { return c->evaluer
 double mmref_bitscore(mmref_ctx *c, double score) { return c->evaluer->computeBitScore(score); }
 
 }  // extern "C"
+
+extern "C" void mmref_get_pback(mmref_ctx *c, double *out) {
+    for (int i = 0; i < c->m->alphabetSize; i++) out[i] = c->m->pBack[i];
+}
+extern "C" void mmref_get_matrix16(mmref_ctx *c, int16_t *out) {
+    int a = c->m->alphabetSize;
+    for (int i = 0; i < a; i++)
+        for (int j = 0; j < a; j++) out[i * a + j] = c->m->subMatrix[i][j];
+}
+
+// "name.out:DATA" form accepted by the SubstitutionMatrix constructor (SubstitutionMatrix.cpp:13-19,
+// BaseMatrix::serialize, BaseMatrix.cpp:176-187).  tests/golden/make_golden.py stores it so the prebuilt
+// libmmref.so can construct its matrices on the GPU box, where /root/reference/data does not exist.
+extern "C" int mmref_serialized_matrix(mmref_ctx *c, char *out, int cap) {
+    char *s = BaseMatrix::serialize(c->m->matrixName, c->m->matrixData);
+    int n = (int)strlen(s);
+    if (n + 1 > cap) { free(s); return -n; }
+    memcpy(out, s, (size_t)n + 1);
+    free(s);
+    return n;
+}

@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""Generates the committed fixtures in tests/golden/ from the REAL reference (oracle/_ref/libmmref.so, built
+by `make -C oracle ref` from /root/reference).  Runs only where /root/reference exists; the outputs are small
+.npz files that travel to the GPU box.
+
+    python tests/golden/make_golden.py
+
+matrices.npz : the integer substitution matrices the reference derives from data/*.out
+               (BaseMatrix::generateSubMatrix, BaseMatrix.cpp:141-154) and its background pBack
+sw_vectors.npz : (query, target) pairs with the reference's s_align fields in modes 0/1/2
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle.pyoracle import RefLib  # noqa: E402
+from mmseqs2_amd import workloads as wl  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def matrices():
+    d = {}
+    sw = RefLib("blosum62.out", 2.0, 0.0)              # Alignment.cpp:152
+    d["blosum62_sw"] = sw.matrix()
+    d["num2aa"] = np.frombuffer(sw.num2aa().encode(), np.uint8)
+    ung = RefLib("blosum62.out", 2.0, -0.2, gap_open=0)            # Prefiltering.cpp:69
+    d["blosum62_ungapped"] = ung.matrix()
+    km = RefLib("VTML80.out", 8.0, -0.2, gap_open=0)               # Prefiltering.cpp:68
+    d["vtml80_kmer"] = km.matrix()
+    pb = np.zeros(21, np.float64)
+    import ctypes
+    sw.L.mmref_get_pback.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    sw.L.mmref_get_pback(sw.c, pb.ctypes.data)
+    d["blosum62_pback"] = pb
+    # lets the prebuilt oracle/_ref library rebuild its matrix where /root/reference is absent
+    d["blosum62_serialized"] = np.frombuffer(sw.serialized_matrix(), np.uint8)
+    pb2 = np.zeros(21, np.float64)
+    km.L.mmref_get_pback.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    km.L.mmref_get_pback(km.c, pb2.ctypes.data)
+    d["vtml80_pback"] = pb2
+    np.savez_compressed(os.path.join(OUT, "matrices.npz"), **d)
+    print("matrices.npz", {k: v.shape for k, v in d.items()})
+    return sw
+
+
+def sw_vectors(ref):
+    rng = np.random.default_rng(20260922)
+    qs, ts, rows, bts, cbs = [], [], [], [], []
+    lens = [1, 2, 7, 16, 17, 31, 64, 100, 127, 128, 129, 200, 255, 256, 257, 350, 383, 384, 385, 500, 511, 512,
+            513, 700, 1025, 1600]
+    n = 0
+    for it in range(260):
+        Lq = int(lens[it % len(lens)])
+        Lt = int(rng.choice(lens)) if it % 3 else int(rng.integers(1, 900))
+        q = rng.choice(21, size=Lq, p=np.append(wl.BACKGROUND * 0.99, 0.01)).astype(np.uint8)
+        kind = it % 5
+        if kind == 0 and Lq > 10:
+            t = wl.mutate(rng, q, float(rng.uniform(0.25, 0.95)))
+            pre = rng.choice(20, size=int(rng.integers(0, 60)), p=wl.BACKGROUND).astype(np.uint8)
+            t = np.concatenate([pre, t, pre[::-1]])
+        elif kind == 1:
+            t = q.copy()
+        else:
+            t = rng.choice(20, size=Lt, p=wl.BACKGROUND).astype(np.uint8)
+        ref.sw_set_query(q)
+        cbf = ref.comp_bias(q)
+        cb = np.array([int(b - 0.5) if b < 0 else int(b + 0.5) for b in cbf.astype(np.float64)], np.int8)
+        a0 = ref.sw_align(t, 0)
+        a1 = ref.sw_align(t, 1)
+        a2 = ref.sw_align(t, 2)
+        assert a0["score"] == a1["score"] == a2["score"]
+        qs.append(q); ts.append(t); cbs.append(cb)
+        # score 0: the reference returns before touching identicalAACnt (uninitialised, ssw_align_private :850-852)
+        ident = a2["ident"] if a0["score"] > 0 else 0
+        rows.append([a0["score"], a0["q_end"], a0["t_end"], a1["q_start"], a1["t_start"], a0["word"], ident])
+        bts.append(a2["bt"])
+        n += 1
+    qres, qoff = wl.seqs_from_list(qs)
+    tres, toff = wl.seqs_from_list(ts)
+    cbres = np.concatenate(cbs)
+    bt_all = "\n".join(bts)
+    np.savez_compressed(os.path.join(OUT, "sw_vectors.npz"), qres=qres, qoff=qoff, tres=tres, toff=toff, cb=cbres,
+                        expect=np.array(rows, np.int32), bt=np.frombuffer(bt_all.encode(), np.uint8),
+                        gap_open=11, gap_extend=1)
+    print("sw_vectors.npz", n, "pairs; word-mode:", int(np.array(rows)[:, 5].sum()))
+
+
+if __name__ == "__main__":
+    ref = matrices()
+    sw_vectors(ref)

