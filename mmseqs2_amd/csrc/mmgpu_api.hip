@@ -210,17 +210,13 @@ struct mmgpu_sw_batch_t {
     bool ran = false;
 };
 
-// which kernel instantiation serves a query of this length: 16 lanes x R rows per tile
+// which kernel instantiation serves a query of this length: 16 lanes x R rows per tile, R even, at most 512 rows
+// per tile; longer queries are cut into equal tiles (multi-tile kernel).
 static void pick_class(uint32_t qlen, int *rows_per_lane, bool *multi) {
-    if (qlen <= 128) { *rows_per_lane = 8; *multi = false; }
-    else if (qlen <= 256) { *rows_per_lane = 16; *multi = false; }
-    else if (qlen <= 384) { *rows_per_lane = 24; *multi = false; }
-    else if (qlen <= 512) { *rows_per_lane = 32; *multi = false; }
-    else {
-        *multi = true;
-        const uint32_t pad24 = (qlen + 383) / 384 * 384, pad32 = (qlen + 511) / 512 * 512;
-        *rows_per_lane = pad24 < pad32 ? 24 : 32;
-    }
+    const uint32_t n_tiles = (qlen + 511) / 512;
+    const uint32_t rows = (qlen + n_tiles - 1) / n_tiles;       // rows per tile before rounding
+    *rows_per_lane = (int)(2 * ((rows + 31) / 32));
+    *multi = n_tiles > 1;
 }
 
 extern "C" int mmgpu_sw_prepare(mmgpu_ctx *c, const mmgpu_sw_params *par, const mmgpu_sw_query *qs, uint32_t nq,
@@ -258,10 +254,10 @@ extern "C" int mmgpu_sw_prepare(mmgpu_ctx *c, const mmgpu_sw_params *par, const 
     qres.resize(qoff[nq]);
     qcb.assign(qoff[nq], 0);
     std::vector<uint32_t> hit_target((size_t)total_hits), hit_out((size_t)total_hits);
-    b->classes.resize(8);
-    for (int k = 0; k < 8; k++) {
-        b->classes[k].rows_per_lane = 8 * (k % 4 + 1);
-        b->classes[k].multi = k >= 4;
+    b->classes.resize(32);   // [0,16): single tile R = 2..32, [16,32): multi-tile
+    for (int k = 0; k < 32; k++) {
+        b->classes[k].rows_per_lane = 2 * (k % 16 + 1);
+        b->classes[k].multi = k >= 16;
     }
     std::vector<uint32_t> order;
     uint32_t hit_cursor = 0, out_cursor = 0;
@@ -295,7 +291,7 @@ extern "C" int mmgpu_sw_prepare(mmgpu_ctx *c, const mmgpu_sw_params *par, const 
         int rpl; bool multi;
         pick_class(Q.qlen, &rpl, &multi);
         any_multi |= multi;
-        SwClass &cls = b->classes[(multi ? 4 : 0) + rpl / 8 - 1];
+        SwClass &cls = b->classes[(multi ? 16 : 0) + rpl / 2 - 1];
         for (uint32_t k = 0; k < Q.n_targets; k++) {
             const uint32_t t = Q.target_ids[order[k]];
             hit_target[hit_cursor + k] = t;

@@ -15,7 +15,7 @@
 //    v_pk_max_i16/u16, v_pk_sub_u16 clamp): the low half of every register belongs to target A, the
 //    high half to target B, so one VALU lane-op advances two independent alignments.
 //  * a group of 16 lanes (one DPP row) owns one pair of targets; lane g owns R consecutive query rows
-//    (R = 8/16/24/32 -> 128..512 rows per tile) whose H/E state lives in registers for the whole scan.
+//    (R = 2,4,..,32 -> 32..512 rows per tile) whose H/E state lives in registers for the whole scan.
 //    Lanes run skewed by one column (anti-diagonal wavefront): at step s lane g works on column s - g.
 //    The hand-off lane g -> g+1 (H of the strip's last row, the F leaving it, and the two target
 //    letters) is three v_mov_b32_dpp row_shr:1 - no LDS, no bpermute.
@@ -235,30 +235,38 @@ __global__ __launch_bounds__(WAVES * 64) void sw_kernel(SwLaunch L) {
                 unsigned hd = Hup_prev;
                 Hup_prev = Hup;
                 unsigned cmax = 0;
+                // R scores per target as R/2 packed dwords: ds_read_b128 for whole 16-byte slots, b64/b32 for the tail
+                unsigned pav[R / 2], pbv[R / 2];
 #pragma unroll
                 for (int k = 0; k < R / 8; ++k) {
                     const uint4 pa = rowA[k], pb = rowB[k];
-                    const unsigned pav[4] = {pa.x, pa.y, pa.z, pa.w};
-                    const unsigned pbv[4] = {pb.x, pb.y, pb.z, pb.w};
+                    pav[4 * k] = pa.x; pav[4 * k + 1] = pa.y; pav[4 * k + 2] = pa.z; pav[4 * k + 3] = pa.w;
+                    pbv[4 * k] = pb.x; pbv[4 * k + 1] = pb.y; pbv[4 * k + 2] = pb.z; pbv[4 * k + 3] = pb.w;
+                }
+                if constexpr ((R / 2) % 4 >= 2) {
+                    const uint2 pa = *reinterpret_cast<const uint2 *>(rowA + R / 8);
+                    const uint2 pb = *reinterpret_cast<const uint2 *>(rowB + R / 8);
+                    pav[(R / 8) * 4] = pa.x; pav[(R / 8) * 4 + 1] = pa.y;
+                    pbv[(R / 8) * 4] = pb.x; pbv[(R / 8) * 4 + 1] = pb.y;
+                }
+                if constexpr ((R / 2) % 2 == 1) {
+                    pav[R / 2 - 1] = reinterpret_cast<const unsigned *>(rowA)[R / 2 - 1];
+                    pbv[R / 2 - 1] = reinterpret_cast<const unsigned *>(rowB)[R / 2 - 1];
+                }
 #pragma unroll
-                    for (int d = 0; d < 4; ++d) {
-#pragma unroll
-                        for (int half = 0; half < 2; ++half) {
-                            const int r = k * 8 + d * 2 + half;
-                            // (score of target A's letter, score of target B's letter) for query row r
-                            unsigned P = __builtin_amdgcn_perm(pbv[d], pav[d], half ? 0x07060302u : 0x05040100u);
-                            if (REV) P = bfi(rmask[r], P, NEG2);
-                            unsigned h = pk_add_sat(hd, P);
-                            h = pk_max_s(h, E[r]);
-                            h = pk_max_s(h, f);
-                            hd = Hp[r];
-                            Hp[r] = h;
-                            cmax = pk_max_u(cmax, h);
-                            const unsigned t = pk_sub_sat_u(h, go2);
-                            E[r] = pk_max_u(pk_sub_sat_u(E[r], ge2), t);
-                            f = pk_max_u(pk_sub_sat_u(f, ge2), t);
-                        }
-                    }
+                for (int r = 0; r < R; ++r) {
+                    // (score of target A's letter, score of target B's letter) for query row r
+                    unsigned P = __builtin_amdgcn_perm(pbv[r / 2], pav[r / 2], (r & 1) ? 0x07060302u : 0x05040100u);
+                    if (REV) P = bfi(rmask[r], P, NEG2);
+                    unsigned h = pk_add_sat(hd, P);
+                    h = pk_max_s(h, E[r]);
+                    h = pk_max_s(h, f);
+                    hd = Hp[r];
+                    Hp[r] = h;
+                    cmax = pk_max_u(cmax, h);
+                    const unsigned t = pk_sub_sat_u(h, go2);
+                    E[r] = pk_max_u(pk_sub_sat_u(E[r], ge2), t);
+                    f = pk_max_u(pk_sub_sat_u(f, ge2), t);
                 }
                 out_H = Hp[R - 1];
                 out_F = f;
@@ -343,8 +351,12 @@ hipError_t launch_r(const SwLaunch &L, bool multi, bool rev, hipStream_t stream)
     if (L.n_jobs == 0) return hipSuccess;
     if (!multi && !rev) hipLaunchKernelGGL((sw_kernel<R, false, false>), grid, block, lds, stream, L);
     else if (!multi && rev) hipLaunchKernelGGL((sw_kernel<R, false, true>), grid, block, lds, stream, L);
-    else if (multi && !rev) hipLaunchKernelGGL((sw_kernel<R, true, false>), grid, block, lds, stream, L);
-    else hipLaunchKernelGGL((sw_kernel<R, true, true>), grid, block, lds, stream, L);
+    else if constexpr (R >= 18) {
+        if (!rev) hipLaunchKernelGGL((sw_kernel<R, true, false>), grid, block, lds, stream, L);
+        else hipLaunchKernelGGL((sw_kernel<R, true, true>), grid, block, lds, stream, L);
+    } else {
+        return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 
@@ -355,11 +367,13 @@ size_t sw_lds_bytes(int rows_per_lane, int alphabet) {
 }
 
 hipError_t launch_sw(const SwLaunch &L, int rows_per_lane, bool multi_tile, bool reverse, hipStream_t stream) {
+    static_assert(GROUP == 16, "dispatch table assumes 16-lane groups");
     switch (rows_per_lane) {
-        case 8: return launch_r<8>(L, multi_tile, reverse, stream);
-        case 16: return launch_r<16>(L, multi_tile, reverse, stream);
-        case 24: return launch_r<24>(L, multi_tile, reverse, stream);
-        case 32: return launch_r<32>(L, multi_tile, reverse, stream);
+#define MMGPU_SW_CASE(R) case R: return launch_r<R>(L, multi_tile, reverse, stream);
+        MMGPU_SW_CASE(2) MMGPU_SW_CASE(4) MMGPU_SW_CASE(6) MMGPU_SW_CASE(8) MMGPU_SW_CASE(10) MMGPU_SW_CASE(12)
+        MMGPU_SW_CASE(14) MMGPU_SW_CASE(16) MMGPU_SW_CASE(18) MMGPU_SW_CASE(20) MMGPU_SW_CASE(22) MMGPU_SW_CASE(24)
+        MMGPU_SW_CASE(26) MMGPU_SW_CASE(28) MMGPU_SW_CASE(30) MMGPU_SW_CASE(32)
+#undef MMGPU_SW_CASE
         default: return hipErrorInvalidValue;
     }
 }

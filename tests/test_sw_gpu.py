@@ -47,7 +47,7 @@ def test_golden_vectors(gpu, oracle, matrices, sw_vectors):
         assert got == list(exp[i][:6]), (i, got, list(exp[i][:6]))
 
 
-@pytest.mark.parametrize("qlen", [1, 5, 64, 128, 129, 256, 300, 384, 385, 512])
+@pytest.mark.parametrize("qlen", [1, 5, 33, 64, 97, 128, 129, 161, 200, 256, 275, 300, 340, 384, 385, 420, 470, 512])
 def test_single_tile_classes_vs_oracle(gpu, oracle, matrices, qlen):
     """One query per kernel instantiation boundary (R = 8/16/24/32) against 300 ragged targets incl. homologs."""
     rng = np.random.default_rng(100 + qlen)
@@ -67,7 +67,7 @@ def test_single_tile_classes_vs_oracle(gpu, oracle, matrices, qlen):
     _check(out, oracle, mat, q, cb, tres, toff, ids, True, "qlen%d" % qlen)
 
 
-@pytest.mark.parametrize("qlen", [513, 700, 1025, 2500])
+@pytest.mark.parametrize("qlen", [513, 600, 700, 830, 1025, 1400, 2500])
 def test_multi_tile_vs_oracle(gpu, oracle, matrices, qlen):
     rng = np.random.default_rng(200 + qlen)
     mat = matrices["blosum62_sw"]
