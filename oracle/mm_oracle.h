@@ -3,6 +3,7 @@
  * file:line every function restates. */
 #ifndef MM_ORACLE_H
 #define MM_ORACLE_H
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -43,6 +44,75 @@ void mmo_sw_batch_score(const uint8_t *q, int qlen, const int8_t *comp_bias, con
                         const uint64_t *toff, const uint32_t *ids, int n, const int8_t *mat, int alphabet,
                         int gap_open, int gap_extend, int32_t *score, int32_t *q_end, int32_t *t_end,
                         int32_t *word);
+
+/* prefilter_oracle.c */
+typedef struct {
+    uint32_t id;       /* hit_t::seqId   (QueryMatcher.h:33-49) */
+    int32_t score;     /* hit_t::prefScore */
+    uint16_t diagonal; /* hit_t::diagonal */
+} mmo_pf_hit;
+
+/* similar-k-mer generator inputs: mmo_pf_score_matrix outputs for span 3 and 2 (row stride = element count) */
+typedef struct {
+    int k, kalph;
+    const int16_t *s3;
+    const uint32_t *i3;
+    const int16_t *s2;
+    const uint32_t *i2;
+} mmo_pf_gen;
+
+typedef struct {
+    /* inputs */
+    const mmo_pf_gen *gen;
+    int alphabet;
+    int spaced;
+    int kmer_thr;
+    const uint64_t *offsets;
+    const uint32_t *ids;
+    const uint16_t *pos;
+    const uint8_t *tdata; /* SequenceLookup */
+    const uint64_t *toff;
+    uint32_t n_targets;
+    const int8_t *ungapped_mat; /* alphabet x alphabet */
+    uint32_t bins;              /* CacheFriendlyOperations<BINS>, QueryMatcher.cpp:460-488 */
+    uint64_t max_hits;          /* maxHitsPerQuery before min(., dbSize) */
+    uint32_t min_diag_score;
+} mmo_pf_params;
+
+typedef struct {
+    uint64_t db_matches;   /* statistics_t::dbMatches */
+    uint64_t kmer_list_len; /* sum of similar k-mers over positions */
+    uint64_t double_hits;   /* foundDiagonals after findDuplicates */
+    uint64_t after_keepmax;
+    uint32_t diag_thr;
+    int truncated;
+    int overflow; /* 1 = the databaseHits overflow path would trigger (not restated) */
+} mmo_pf_stats;
+
+typedef struct {
+    int32_t *thr_out;
+    uint32_t *nsim_out;
+    uint32_t *arr_id;
+    uint16_t *arr_diag;
+    uint64_t arr_cap;
+    uint32_t *dd_id;
+    uint16_t *dd_diag;
+    uint8_t *dd_count;
+    uint64_t dd_cap;
+} mmo_pf_dump;
+
+void mmo_pf_score_matrix(const int16_t *submat, int alphabet, int kalph, int span, int16_t *score, uint32_t *index);
+size_t mmo_pf_kmer_list(const mmo_pf_gen *g, const uint8_t *kmer, int threshold, uint64_t *out, size_t cap);
+int mmo_pf_pattern(int k, int spaced, uint8_t *pos_in_pattern);
+uint64_t mmo_pf_index_build(const uint8_t *tdata, const uint64_t *toff, uint32_t n, const int16_t *kmer_submat,
+                            int alphabet, int k, int spaced, int kmer_thr, uint64_t *offsets, uint32_t *ids,
+                            uint16_t *pos);
+void mmo_pf_ungapped_corr(const float *bias, int qlen, int8_t *corr);
+int mmo_pf_ungapped_score(const uint8_t *q, const int8_t *corr, int qlen, const int8_t *mat, int alphabet,
+                          const uint8_t *t, int tlen, uint16_t diagonal);
+int mmo_pf_match_query(const mmo_pf_params *P, const uint8_t *q, int qlen, const float *comp_bias,
+                       uint32_t identity_id, mmo_pf_hit *hits, uint64_t hit_cap, uint64_t *n_hits, mmo_pf_stats *st,
+                       mmo_pf_dump *dump);
 
 /* compbias_oracle.c */
 void mmo_comp_bias(const int16_t *submat /*alphabet^2, row-major short matrix*/, const double *pback, int alphabet,

@@ -200,3 +200,224 @@ class RefLib:
 
     def bitscore(self, score):
         return self.L.mmref_bitscore(self.c, float(score))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# prefilter (prefilter_oracle.c / ref_shim_pref.cpp)
+class PfGen(ctypes.Structure):
+    _fields_ = [("k", ctypes.c_int), ("kalph", ctypes.c_int), ("s3", c_p), ("i3", c_p), ("s2", c_p), ("i2", c_p)]
+
+
+class PfParams(ctypes.Structure):
+    _fields_ = [("gen", ctypes.POINTER(PfGen)), ("alphabet", ctypes.c_int), ("spaced", ctypes.c_int),
+                ("kmer_thr", ctypes.c_int), ("offsets", c_p), ("ids", c_p), ("pos", c_p), ("tdata", c_p),
+                ("toff", c_p), ("n_targets", ctypes.c_uint32), ("ungapped_mat", c_p), ("bins", ctypes.c_uint32),
+                ("max_hits", ctypes.c_uint64), ("min_diag_score", ctypes.c_uint32)]
+
+
+class PfStats(ctypes.Structure):
+    _fields_ = [("db_matches", ctypes.c_uint64), ("kmer_list_len", ctypes.c_uint64),
+                ("double_hits", ctypes.c_uint64), ("after_keepmax", ctypes.c_uint64),
+                ("diag_thr", ctypes.c_uint32), ("truncated", ctypes.c_int), ("overflow", ctypes.c_int)]
+
+
+class PfDump(ctypes.Structure):
+    _fields_ = [("thr_out", c_p), ("nsim_out", c_p), ("arr_id", c_p), ("arr_diag", c_p), ("arr_cap", ctypes.c_uint64),
+                ("dd_id", c_p), ("dd_diag", c_p), ("dd_count", c_p), ("dd_cap", ctypes.c_uint64)]
+
+
+class PfHit(ctypes.Structure):
+    _fields_ = [("id", ctypes.c_uint32), ("score", ctypes.c_int32), ("diagonal", ctypes.c_uint16)]
+
+
+PF_HIT_DTYPE = np.dtype([("id", np.uint32), ("score", np.int32), ("diagonal", np.uint16), ("_pad", np.uint16)])
+
+
+def kmer_threshold(sens, k):
+    """Prefiltering::getKmerThreshold (Prefiltering.cpp:1080-1095), sequence queries."""
+    if k == 6:
+        return int(163.2 - 8.917 * sens)
+    if k == 7:
+        return int(186.15 - 11.22 * sens)
+    raise ValueError(k)
+
+
+class PfOracle:
+    """Plain-C restatement of the prefilter: score matrices, similar k-mers, index, matchQuery."""
+
+    def __init__(self, kmer_mat16, ungapped_mat8, k=6, spaced=True):
+        if not os.path.exists(ORACLE_SO):
+            build_oracle()
+        L = self.L = ctypes.CDLL(ORACLE_SO)
+        L.mmo_pf_kmer_list.restype = ctypes.c_size_t
+        L.mmo_pf_index_build.restype = ctypes.c_uint64
+        self.kmer_mat16 = np.ascontiguousarray(kmer_mat16, np.int16)
+        self.ungapped_mat = np.ascontiguousarray(ungapped_mat8, np.int8)
+        self.alphabet = self.kmer_mat16.shape[0]
+        self.kalph = self.alphabet - 1
+        self.k = k
+        self.spaced = int(spaced)
+        n3, n2 = self.kalph ** 3, self.kalph ** 2
+        self.s3 = np.zeros((n3, n3), np.int16)
+        self.i3 = np.zeros((n3, n3), np.uint32)
+        self.s2 = np.zeros((n2, n2), np.int16)
+        self.i2 = np.zeros((n2, n2), np.uint32)
+        L.mmo_pf_score_matrix(_ptr(self.kmer_mat16), self.alphabet, self.kalph, 3, _ptr(self.s3), _ptr(self.i3))
+        L.mmo_pf_score_matrix(_ptr(self.kmer_mat16), self.alphabet, self.kalph, 2, _ptr(self.s2), _ptr(self.i2))
+        self.gen = PfGen(k, self.kalph, self.s3.ctypes.data, self.i3.ctypes.data, self.s2.ctypes.data,
+                         self.i2.ctypes.data)
+
+    def kmer_list(self, kmer, thr, cap=1 << 20):
+        kmer = np.ascontiguousarray(kmer, np.uint8)
+        out = np.zeros(cap, np.uint64)
+        n = self.L.mmo_pf_kmer_list(ctypes.byref(self.gen), _ptr(kmer), int(thr), _ptr(out), ctypes.c_size_t(cap))
+        return out[:min(n, cap)].copy(), n
+
+    def build_index(self, tdata, toff, kmer_thr):
+        self.tdata = np.ascontiguousarray(tdata, np.uint8)
+        self.toff = np.ascontiguousarray(toff, np.uint64)
+        n = len(self.toff) - 1
+        table = self.kalph ** self.k
+        self.offsets = np.zeros(table + 1, np.uint64)
+        args = (_ptr(self.tdata), _ptr(self.toff), n, _ptr(self.kmer_mat16), self.alphabet, self.k, self.spaced,
+                int(kmer_thr), _ptr(self.offsets))
+        total = self.L.mmo_pf_index_build(*args, None, None)
+        self.ids = np.zeros(max(total, 1), np.uint32)
+        self.pos = np.zeros(max(total, 1), np.uint16)
+        self.L.mmo_pf_index_build(*args, _ptr(self.ids), _ptr(self.pos))
+        self.n_entries = int(total)
+        self.n_targets = n
+        self.kmer_thr = int(kmer_thr)
+        return self.offsets, self.ids[:total], self.pos[:total]
+
+    def ungapped_corr(self, bias, qlen):
+        out = np.zeros(qlen, np.int8)
+        b = None if bias is None else np.ascontiguousarray(bias, np.float32)
+        self.L.mmo_pf_ungapped_corr(_ptr(b), qlen, _ptr(out))
+        return out
+
+    def ungapped_score(self, q, corr, t, diagonal):
+        q = np.ascontiguousarray(q, np.uint8)
+        t = np.ascontiguousarray(t, np.uint8)
+        corr = np.ascontiguousarray(corr, np.int8)
+        return self.L.mmo_pf_ungapped_score(_ptr(q), _ptr(corr), len(q), _ptr(self.ungapped_mat), self.alphabet,
+                                            _ptr(t), len(t), ctypes.c_uint16(int(diagonal) & 0xFFFF))
+
+    def match(self, q, comp_bias, bins, max_hits=300, min_diag_score=15, identity_id=None, dump=False):
+        q = np.ascontiguousarray(q, np.uint8)
+        cb = None if comp_bias is None else np.ascontiguousarray(comp_bias, np.float32)
+        P = PfParams(ctypes.pointer(self.gen), self.alphabet, self.spaced, self.kmer_thr, self.offsets.ctypes.data,
+                     self.ids.ctypes.data, self.pos.ctypes.data, self.tdata.ctypes.data, self.toff.ctypes.data,
+                     self.n_targets, self.ungapped_mat.ctypes.data, bins, max_hits, min_diag_score)
+        cap = int(min(max_hits, self.n_targets)) + 2
+        hits = np.zeros(cap, PF_HIT_DTYPE)
+        nh = ctypes.c_uint64(0)
+        st = PfStats()
+        D = None
+        keep = {}
+        if dump:
+            arr_cap = 2 * max(1000000, self.n_targets)
+            keep = dict(thr=np.zeros(len(q), np.int32), nsim=np.zeros(len(q), np.uint32),
+                        arr_id=np.zeros(arr_cap, np.uint32), arr_diag=np.zeros(arr_cap, np.uint16),
+                        dd_id=np.zeros(arr_cap // 2, np.uint32), dd_diag=np.zeros(arr_cap // 2, np.uint16),
+                        dd_count=np.zeros(arr_cap // 2, np.uint8))
+            D = PfDump(keep["thr"].ctypes.data, keep["nsim"].ctypes.data, keep["arr_id"].ctypes.data,
+                       keep["arr_diag"].ctypes.data, arr_cap, keep["dd_id"].ctypes.data, keep["dd_diag"].ctypes.data,
+                       keep["dd_count"].ctypes.data, arr_cap // 2)
+        ident = 0xFFFFFFFF if identity_id is None else int(identity_id)
+        rc = self.L.mmo_pf_match_query(ctypes.byref(P), _ptr(q), len(q), _ptr(cb), ctypes.c_uint32(ident), _ptr(hits),
+                                       ctypes.c_uint64(cap), ctypes.byref(nh), ctypes.byref(st),
+                                       ctypes.byref(D) if D is not None else None)
+        stats = {f: getattr(st, f) for f, _ in PfStats._fields_}
+        stats["rc"] = rc
+        res = hits[: nh.value]
+        out = dict(id=res["id"].copy(), score=res["score"].copy(), diagonal=res["diagonal"].copy(), stats=stats)
+        if dump:
+            out["thr"] = keep["thr"]
+            out["nsim"] = keep["nsim"]
+            n = stats["db_matches"]
+            out["arr_id"] = keep["arr_id"][:n].copy()
+            out["arr_diag"] = keep["arr_diag"][:n].copy()
+            d = stats["double_hits"]
+            out["dd_id"] = keep["dd_id"][:d].copy()
+            out["dd_diag"] = keep["dd_diag"][:d].copy()
+            out["dd_count"] = keep["dd_count"][:d].copy()
+        return out
+
+
+class RefPrefilter:
+    """The real reference prefilter classes (needs /root/reference/data at run time)."""
+
+    def __init__(self, k=6, kmer_matrix="VTML80.out", ungapped_matrix="blosum62.out"):
+        L = self.L = ctypes.CDLL(REF_SO)
+        L.mmref_pref_new.restype = c_p
+        L.mmref_pref_new.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int]
+        for f in ("mmref_pref_index_entries", "mmref_pref_index_table_size", "mmref_pref_kmer_list",
+                  "mmref_pref_match", "mmref_pref_score_matrix"):
+            getattr(L, f).restype = ctypes.c_uint64
+        L.mmref_pref_make_matcher.restype = ctypes.c_uint
+        d = os.path.join(REFERENCE_ROOT, "data")
+        self.c = c_p(L.mmref_pref_new(os.path.join(d, kmer_matrix).encode(), os.path.join(d, ungapped_matrix).encode(), k))
+        self.k = k
+        self.alphabet = L.mmref_pref_alphabet(self.c)
+
+    def matrices(self):
+        a = self.alphabet
+        km = np.zeros((a, a), np.int8)
+        um = np.zeros((a, a), np.int8)
+        km16 = np.zeros((a, a), np.int16)
+        pb = np.zeros(a, np.float64)
+        self.L.mmref_pref_get_matrices(self.c, _ptr(km), _ptr(um), _ptr(km16), _ptr(pb))
+        return km, um, km16, pb
+
+    def score_matrix(self, which):
+        rs = ctypes.c_uint64(0)
+        n = self.L.mmref_pref_score_matrix(self.c, which, ctypes.byref(rs), None, None)
+        s = np.zeros((n, n), np.int16)
+        i = np.zeros((n, n), np.uint32)
+        self.L.mmref_pref_score_matrix(self.c, which, ctypes.byref(rs), _ptr(s), _ptr(i))
+        return s, i
+
+    def build_index(self, tdata, toff, kmer_thr, spaced=True):
+        self._tdata = np.ascontiguousarray(tdata, np.uint8)
+        self._toff = np.ascontiguousarray(toff, np.uint64)
+        self.L.mmref_pref_build_index(self.c, _ptr(self._tdata), _ptr(self._toff), len(self._toff) - 1, int(kmer_thr),
+                                      int(spaced))
+        self.kmer_thr = int(kmer_thr)
+        self.spaced = spaced
+
+    def index_dump(self):
+        ne = self.L.mmref_pref_index_entries(self.c)
+        ts = self.L.mmref_pref_index_table_size(self.c)
+        off = np.zeros(ts + 1, np.uint64)
+        ids = np.zeros(max(ne, 1), np.uint32)
+        pos = np.zeros(max(ne, 1), np.uint16)
+        self.L.mmref_pref_index_dump(self.c, _ptr(off), _ptr(ids), _ptr(pos))
+        return off, ids[:ne], pos[:ne]
+
+    def kmer_list(self, kmer, thr, cap=1 << 20):
+        kmer = np.ascontiguousarray(kmer, np.uint8)
+        out = np.zeros(cap, np.uint64)
+        n = self.L.mmref_pref_kmer_list(self.c, _ptr(kmer), int(thr), _ptr(out), ctypes.c_uint64(cap))
+        return out[:min(n, cap)].copy(), n
+
+    def make_matcher(self, max_seq_len=32000, max_hits=300, comp_bias=True, comp_bias_scale=1.0, min_diag_score=15,
+                     force_bins=0):
+        self.max_hits = max_hits
+        return self.L.mmref_pref_make_matcher(self.c, self.kmer_thr, max_seq_len, ctypes.c_uint64(max_hits),
+                                              int(comp_bias), ctypes.c_float(comp_bias_scale), 1, min_diag_score,
+                                              int(self.spaced), int(force_bins))
+
+    def match(self, q, identity_id=None):
+        q = np.ascontiguousarray(q, np.uint8)
+        cap = self.max_hits + 2
+        ids = np.zeros(cap, np.uint32)
+        sc = np.zeros(cap, np.int32)
+        dg = np.zeros(cap, np.uint16)
+        dbm = ctypes.c_uint64(0)
+        kpp = ctypes.c_double(0)
+        ident = 0xFFFFFFFF if identity_id is None else int(identity_id)
+        n = self.L.mmref_pref_match(self.c, _ptr(q), len(q), ctypes.c_uint32(ident), _ptr(ids), _ptr(sc), _ptr(dg),
+                                    ctypes.c_uint64(cap), ctypes.byref(dbm), ctypes.byref(kpp))
+        return dict(id=ids[:n].copy(), score=sc[:n].copy(), diagonal=dg[:n].copy(), db_matches=dbm.value,
+                    kmers_per_pos=kpp.value)

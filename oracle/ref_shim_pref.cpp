@@ -1,0 +1,216 @@
+// TEST INFRASTRUCTURE - NOT PART OF THE PRODUCT PATH.
+//
+// Prefilter half of oracle/_ref/libmmref.so: drives the REAL reference classes
+//   ExtendedSubstitutionMatrix::calcScoreMatrix   src/prefiltering/ExtendedSubstitutionMatrix.cpp:20-71
+//   IndexTable::addKmerCount/addSequence/...      src/prefiltering/IndexTable.h:135-191,350-403
+//   SequenceLookup::addSequence                   src/prefiltering/SequenceLookup.cpp
+//   KmerGenerator::generateKmerList               src/prefiltering/KmerGenerator.cpp:108-184
+//   QueryMatcher::matchQuery                      src/prefiltering/QueryMatcher.cpp:103-241
+// in the order Prefiltering's constructor / getIndexTable / runSplit use them
+// (Prefiltering.cpp:68-69, 220-225, 544-583, 826-842, 873), from numeric sequences, without DBReader and
+// without tantan masking (IndexBuilder.cpp:146-156; `--mask 0`), so that the plain-C restatement in
+// oracle/prefilter_oracle.c can be fuzzed against it.
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "Debug.h"
+#include "ExtendedSubstitutionMatrix.h"
+#include "IndexTable.h"
+#include "Indexer.h"
+#include "KmerGenerator.h"
+#include "Parameters.h"
+#include "QueryMatcher.h"
+#include "Sequence.h"
+#include "SequenceLookup.h"
+#include "SubstitutionMatrix.h"
+
+namespace {
+
+// QueryMatcher keeps its bin count (chosen from the host's L2 size, QueryMatcher.cpp:460-488) protected.
+struct MatcherProbe : public QueryMatcher {
+    using QueryMatcher::QueryMatcher;
+    unsigned int bins() const { return activeCounter; }
+    // Emulate a host with a different L2 size: replace the CacheFriendlyOperations<BINS> instance that
+    // initDiagonalMatcher (QueryMatcher.cpp:460-488) picked by the one another host would have picked.
+    void forceBins(unsigned int b) {
+        deleteDiagonalMatcher(activeCounter);
+#define MMREF_FORCE(x) case x: cachedOperation##x = new CacheFriendlyOperations<x>(dbSize, maxDbMatches / x); activeCounter = x; break;
+        switch (b) {
+            MMREF_FORCE(2) MMREF_FORCE(4) MMREF_FORCE(8) MMREF_FORCE(16) MMREF_FORCE(32) MMREF_FORCE(64)
+            MMREF_FORCE(128) MMREF_FORCE(256) MMREF_FORCE(512) MMREF_FORCE(1024) MMREF_FORCE(2048)
+            default: cachedOperation2 = new CacheFriendlyOperations<2>(dbSize, maxDbMatches / 2); activeCounter = 2;
+        }
+#undef MMREF_FORCE
+    }
+};
+
+struct PrefCtx {
+    SubstitutionMatrix *kmerMat;      // VTML80, bit factor 8, bias -0.2   (Prefiltering.cpp:68)
+    SubstitutionMatrix *ungappedMat;  // blosum62, bit factor 2, bias -0.2 (Prefiltering.cpp:69)
+    ScoreMatrix two, three;
+    IndexTable *index;
+    SequenceLookup *lookup;
+    MatcherProbe *matcher;
+    KmerGenerator *gen;
+    Sequence *qseq;
+    int kmerSize;
+    size_t dbSize;
+    unsigned maxLen;
+};
+
+}  // namespace
+
+extern "C" {
+
+void *mmref_pref_new(const char *kmer_matrix, const char *ungapped_matrix, int kmer_size) {
+    Debug::setDebugLevel(Debug::ERROR);
+    PrefCtx *c = new PrefCtx();
+    c->kmerMat = new SubstitutionMatrix(kmer_matrix, 8.0f, -0.2f);
+    c->ungappedMat = new SubstitutionMatrix(ungapped_matrix, 2.0f, -0.2f);
+    c->kmerSize = kmer_size;
+    const int alph = c->kmerMat->alphabetSize;
+    c->kmerMat->alphabetSize = alph - 1;   // Prefiltering.cpp:221-224: X is not part of the k-mer alphabet
+    c->two = ExtendedSubstitutionMatrix::calcScoreMatrix(*c->kmerMat, 2);
+    c->three = ExtendedSubstitutionMatrix::calcScoreMatrix(*c->kmerMat, 3);
+    c->kmerMat->alphabetSize = alph;
+    c->index = NULL;
+    c->lookup = NULL;
+    c->matcher = NULL;
+    c->gen = NULL;
+    c->qseq = NULL;
+    return c;
+}
+
+int mmref_pref_alphabet(void *h) { return ((PrefCtx *)h)->kmerMat->alphabetSize; }
+
+void mmref_pref_get_matrices(void *h, int8_t *kmer_mat, int8_t *ungapped_mat, int16_t *kmer_mat16, double *kmer_pback) {
+    PrefCtx *c = (PrefCtx *)h;
+    int a = c->kmerMat->alphabetSize;
+    for (int i = 0; i < a; i++)
+        for (int j = 0; j < a; j++) {
+            kmer_mat[i * a + j] = (int8_t)c->kmerMat->subMatrix[i][j];
+            kmer_mat16[i * a + j] = c->kmerMat->subMatrix[i][j];
+            ungapped_mat[i * a + j] = (int8_t)c->ungappedMat->subMatrix[i][j];
+        }
+    for (int i = 0; i < a; i++) kmer_pback[i] = c->kmerMat->pBack[i];
+}
+
+// which: 2 or 3; returns elementSize, *row_size; copies when out pointers are non-NULL (elementSize*elementSize each,
+// i.e. without the SIMD padding columns)
+uint64_t mmref_pref_score_matrix(void *h, int which, uint64_t *row_size, int16_t *score, uint32_t *index) {
+    PrefCtx *c = (PrefCtx *)h;
+    const ScoreMatrix &m = which == 2 ? c->two : c->three;
+    if (row_size) *row_size = m.rowSize;
+    if (score && index)
+        for (size_t r = 0; r < m.elementSize; r++)
+            for (size_t z = 0; z < m.elementSize; z++) {
+                score[r * m.elementSize + z] = m.score[r * m.rowSize + z];
+                index[r * m.elementSize + z] = m.index[r * m.rowSize + z];
+            }
+    return m.elementSize;
+}
+
+// Build index + sequence lookup over numeric targets exactly as IndexBuilder::fillDatabase does for amino-acid
+// targets with masking off (IndexBuilder.cpp:118-166, 226-270).
+void mmref_pref_build_index(void *h, const uint8_t *tdata, const uint64_t *toff, uint32_t n, int kmer_thr, int spaced) {
+    PrefCtx *c = (PrefCtx *)h;
+    const int alph = c->kmerMat->alphabetSize;
+    unsigned maxLen = 1;
+    for (uint32_t i = 0; i < n; i++) maxLen = std::max<unsigned>(maxLen, (unsigned)(toff[i + 1] - toff[i]));
+    c->maxLen = maxLen + 1;
+    c->dbSize = n;
+    delete c->index;
+    delete c->lookup;
+    c->index = new IndexTable(alph - 1, c->kmerSize, false);          // Prefiltering.cpp:560-563
+    c->lookup = new SequenceLookup(n, toff[n]);
+    char *idScore = new char[alph];
+    for (int a = 0; a < alph; a++) idScore[a] = (char)c->kmerMat->subMatrix[a][a];   // IndexBuilder.cpp:11-22
+    Sequence s(c->maxLen, Parameters::DBTYPE_AMINO_ACIDS, c->kmerMat, c->kmerSize, spaced != 0, false, true);
+    Indexer idxer(alph - 1, c->kmerSize);
+    std::vector<unsigned int> buffer(c->maxLen + 8);
+    size_t tableSize = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        unsigned len = (unsigned)(toff[i + 1] - toff[i]);
+        s.mapSequence(i, i, std::make_pair((const unsigned char *)(tdata + toff[i]), (const unsigned int)len));
+        c->index->addKmerCount(&s, &idxer, buffer.data(), kmer_thr, idScore);
+        c->lookup->addSequence(s.numSequence, s.L, i, toff[i]);
+        tableSize += len;
+    }
+    c->index->initMemory(tableSize);
+    c->index->init();
+    IndexEntryLocalTmp *tmp = (IndexEntryLocalTmp *)malloc((c->maxLen + 8) * sizeof(IndexEntryLocalTmp));
+    for (uint32_t i = 0; i < n; i++) {
+        s.mapSequence(i, i, c->lookup->getSequence(i));
+        c->index->addSequence(&s, &idxer, &tmp, c->maxLen + 8, kmer_thr, idScore);
+    }
+    free(tmp);
+    delete[] idScore;
+    c->index->revertPointer();
+    c->index->sortDBSeqLists();
+}
+
+uint64_t mmref_pref_index_entries(void *h) { return ((PrefCtx *)h)->index->getTableEntriesNum(); }
+uint64_t mmref_pref_index_table_size(void *h) { return ((PrefCtx *)h)->index->getTableSize(); }
+
+void mmref_pref_index_dump(void *h, uint64_t *offsets /*tableSize+1*/, uint32_t *seq_id, uint16_t *pos_j) {
+    PrefCtx *c = (PrefCtx *)h;
+    size_t ts = c->index->getTableSize();
+    for (size_t k = 0; k <= ts; k++) offsets[k] = c->index->getOffsets()[k];
+    IndexEntryLocal *e = c->index->getEntries();
+    for (uint64_t k = 0; k < c->index->getTableEntriesNum(); k++) {
+        seq_id[k] = e[k].seqId;
+        pos_j[k] = e[k].position_j;
+    }
+}
+
+// similar k-mer list for one k-mer (already extracted residues) at threshold thr; returns count
+uint64_t mmref_pref_kmer_list(void *h, const uint8_t *kmer, int thr, uint64_t *out, uint64_t cap) {
+    PrefCtx *c = (PrefCtx *)h;
+    if (!c->gen) {
+        c->gen = new KmerGenerator(c->kmerSize, c->kmerMat->alphabetSize - 1, (short)thr);
+        c->gen->setDivideStrategy(&c->three, &c->two);
+    }
+    c->gen->setThreshold((short)thr);
+    std::pair<size_t *, size_t> r = c->gen->generateKmerList(kmer);
+    for (size_t i = 0; i < r.second && i < cap; i++) out[i] = r.first[i];
+    return r.second;
+}
+
+// create the matcher as Prefiltering::runSplit does (Prefiltering.cpp:826-842)
+unsigned mmref_pref_make_matcher(void *h, int kmer_thr, unsigned max_seq_len, uint64_t max_hits, int comp_bias,
+                                 float comp_bias_scale, int diag_scoring, unsigned min_diag_score, int spaced,
+                                 unsigned force_bins) {
+    PrefCtx *c = (PrefCtx *)h;
+    delete c->matcher;
+    delete c->qseq;
+    unsigned ml = std::max(max_seq_len, c->maxLen);
+    c->matcher = new MatcherProbe(c->index, c->lookup, c->kmerMat, c->ungappedMat, (short)kmer_thr, c->kmerSize,
+                                  c->dbSize, ml, max_hits, comp_bias != 0, comp_bias_scale, diag_scoring != 0,
+                                  min_diag_score, false, false);
+    if (force_bins) c->matcher->forceBins(force_bins);
+    c->matcher->setSubstitutionMatrix(&c->three, &c->two);
+    c->qseq = new Sequence(ml, Parameters::DBTYPE_AMINO_ACIDS, c->kmerMat, c->kmerSize, spaced != 0, comp_bias != 0, true);
+    return c->matcher->bins();
+}
+
+// matchQuery: returns number of hits; identity_id = UINT32_MAX for none
+uint64_t mmref_pref_match(void *h, const uint8_t *q, uint32_t qlen, uint32_t identity_id, uint32_t *ids, int32_t *scores,
+                          uint16_t *diags, uint64_t cap, uint64_t *db_matches, double *kmers_per_pos) {
+    PrefCtx *c = (PrefCtx *)h;
+    c->qseq->mapSequence(0, 0, std::make_pair((const unsigned char *)q, (const unsigned int)qlen));
+    DBLocalId ident = identity_id == UINT32_MAX ? DB_LOCAL_ID_INVALID : (DBLocalId)identity_id;
+    std::pair<hit_t *, size_t> r = c->matcher->matchQuery(c->qseq, ident, false);
+    for (size_t i = 0; i < r.second && i < cap; i++) {
+        ids[i] = (uint32_t)r.first[i].seqId;
+        scores[i] = r.first[i].prefScore;
+        diags[i] = r.first[i].diagonal;
+    }
+    if (db_matches) *db_matches = c->matcher->getStatistics()->dbMatches;
+    if (kmers_per_pos) *kmers_per_pos = c->matcher->getStatistics()->kmersPerPos;
+    return r.second;
+}
+
+}  // extern "C"
