@@ -130,6 +130,107 @@ int mmgpu_sw_last_kernel_ms(mmgpu_ctx *ctx, mmgpu_sw_batch_t *batch, float *ms);
 int mmgpu_sw_kernel_ms_mean(mmgpu_ctx *ctx, mmgpu_sw_batch_t *batch, uint32_t last_n, float *ms, uint32_t *n_used);
 void mmgpu_sw_free(mmgpu_ctx *ctx, mmgpu_sw_batch_t *batch);
 
+/* ---- k-mer prefilter (behind Prefiltering::runSplit) ---------------------------------------------------------
+ * Host-side table builders.  In a drop-in build the reference's own objects supply these tables
+ * (ExtendedSubstitutionMatrix::calcScoreMatrix, Prefiltering.cpp:220-225; IndexBuilder::fillDatabase,
+ * Prefiltering.cpp:544-583) and the two functions below are not needed; they exist so that callers without the
+ * reference (bench.py, tests) can build bit-identical tables. */
+/* ScoreMatrix of all span-mers over the first kalph = alphabet-1 letters (ExtendedSubstitutionMatrix.cpp:20-71):
+ * score/index are [n][n], n = kalph^span, rows sorted by descending score, ties in enumeration order. */
+int mmgpu_host_score_matrix(const int16_t *submat, int alphabet, int span, int16_t *score, uint32_t *index);
+/* IndexTable over numeric targets, masking off (IndexTable.h:135-191,350-403; IndexBuilder.cpp:118-166,226-270):
+ * one entry (seqId, first position) per distinct k-mer of a target whose window has no X and whose self score
+ * is >= kmer_thr.  offsets has (alphabet-1)^k + 1 elements.  Call with ids == pos == NULL to get the entry
+ * count in *n_entries (offsets is filled), then again with arrays of that size. */
+int mmgpu_host_index_build(const uint8_t *residues, const uint64_t *seq_offsets, uint32_t n_targets,
+                           const int16_t *kmer_submat, int alphabet, int kmer_size, int spaced, int kmer_thr,
+                           uint64_t *offsets, uint32_t *ids, uint16_t *pos, uint64_t *n_entries);
+
+/* Everything QueryMatcher's constructor receives that lives in memory (Prefiltering.cpp:826-842). */
+typedef struct {
+    int kmer_size;              /* 6 (7 is not implemented on the device yet -> MMGPU_ERR_UNSUPPORTED) */
+    int alphabet;               /* subMat->alphabetSize, 21 */
+    int spaced;                 /* spaced k-mer pattern of Sequence.h:24-27 */
+    const int16_t *score3;      /* ScoreMatrix::score of _3merSubMatrix */
+    const uint32_t *index3;     /* ScoreMatrix::index */
+    size_t row3;                /* ScoreMatrix::rowSize (elements per row incl. SIMD padding) */
+    const uint64_t *offsets;    /* IndexTable::getOffsets(), (alphabet-1)^k + 1 */
+    const uint32_t *entry_ids;  /* IndexEntryLocal::seqId    } either these two arrays ...               */
+    const uint16_t *entry_pos;  /* IndexEntryLocal::position_j }                                          */
+    const void *entries6;       /* ... or IndexTable::getEntries(): packed 6-byte IndexEntryLocal records */
+    uint64_t n_entries;
+    const int8_t *ungapped_mat; /* ungappedSubMat as int8, alphabet x alphabet (blosum62, bit factor 2) */
+} mmgpu_pf_index;
+/* Copies the tables into HBM.  The SequenceLookup the ungapped scorer reads is the database given to
+ * mmgpu_load_targets (call that first, with the - possibly masked - SequenceLookup residues). */
+int mmgpu_pf_load_index(mmgpu_ctx *ctx, const mmgpu_pf_index *index);
+
+typedef struct {
+    int kmer_thr;            /* Prefiltering::getKmerThreshold */
+    uint32_t max_hits;       /* maxResListLen (--max-seqs); min(., dbSize) is applied like QueryMatcher.cpp:47 */
+    uint32_t min_diag_score; /* --min-ungapped-score (15); must be >= 1 */
+    uint32_t ref_bins;       /* the CacheFriendlyOperations<N> the CPU run would use (QueryMatcher.cpp:460-488);
+                                only decides which of several equal-score hits survive the max_hits cut.
+                                0 = derive from dbSize and this host's L2 size like the reference */
+} mmgpu_pf_params;
+
+typedef struct {
+    const uint8_t *q;        /* Sequence::numSequence */
+    uint32_t qlen;
+    const float *comp_bias;  /* QueryMatcher::compositionBias (mmgpu_host_comp_bias over the k-mer matrix), NULL = 0 */
+    uint32_t identity_id;    /* targetSeqId of Prefiltering.cpp:855-868, UINT32_MAX = none */
+} mmgpu_pf_query;
+
+/* == hit_t (QueryMatcher.h:33-49) */
+typedef struct {
+    uint32_t id;
+    int32_t score;
+    uint16_t diagonal;
+    uint16_t reserved;
+} mmgpu_pf_hit;
+
+#define MMGPU_PF_OK 0
+#define MMGPU_PF_OVERFLOW 1 /* the query gathers >= 2*max(1e6,dbSize) index entries: the reference takes its
+                               buffer-overflow path (QueryMatcher.cpp:310-346); not computed here, the host must
+                               run QueryMatcher::matchQuery for this query */
+
+typedef struct {
+    uint64_t db_matches;     /* statistics_t::dbMatches */
+    uint64_t kmer_list_len;  /* sum over positions of similar k-mers (kmersPerPos * L) */
+    uint32_t double_hits;    /* elements after keepMaxScoreElementOnly with count >= min_diag_score */
+    uint32_t diag_thr;       /* diagonalThr; bit 31 = scoreIsTruncated */
+} mmgpu_pf_qstat;
+
+/* One call = the query loop of Prefiltering::runSplit (:848-917) up to the hit_t list, for nq queries.
+ * hits has nq * hit_stride entries (hit_stride >= min(max_hits, dbSize)); counts/status have nq entries. */
+typedef struct mmgpu_pf_batch_t mmgpu_pf_batch_t;
+int mmgpu_pf_batch(mmgpu_ctx *ctx, const mmgpu_pf_params *params, const mmgpu_pf_query *queries, uint32_t n_queries,
+                   mmgpu_pf_hit *hits, uint32_t hit_stride, uint32_t *counts, int32_t *status);
+/* split form: prepare = host prep + H2D; run = all kernels (contains two small D2H size read-backs);
+ * fetch = D2H of the results */
+int mmgpu_pf_prepare(mmgpu_ctx *ctx, const mmgpu_pf_params *params, const mmgpu_pf_query *queries,
+                     uint32_t n_queries, mmgpu_pf_batch_t **batch);
+int mmgpu_pf_run(mmgpu_ctx *ctx, mmgpu_pf_batch_t *batch);
+int mmgpu_pf_fetch(mmgpu_ctx *ctx, mmgpu_pf_batch_t *batch, mmgpu_pf_hit *hits, uint32_t hit_stride,
+                   uint32_t *counts, int32_t *status, mmgpu_pf_qstat *stats /* may be NULL */);
+/* milliseconds per stage of the last run (HIP events on the context's stream; synchronises):
+ * ms[0] similar k-mers + lists, ms[1] gather/split, ms[2] replay/score, ms[3] select, ms[4] whole run */
+int mmgpu_pf_stage_ms(mmgpu_ctx *ctx, mmgpu_pf_batch_t *batch, float ms[5]);
+/* Stage dumps for the parity tests: copies one intermediate buffer of the last run to the host.
+ * *bytes = size of the buffer; copies min(cap, *bytes).  Layouts are those of mmseqs2_amd/csrc/mmgpu_internal.h. */
+#define MMGPU_PF_DBG_NSIM 0       /* uint32[n_pos]   similar k-mers per window                              */
+#define MMGPU_PF_DBG_LIST_BASE 1  /* uint32[n_pos+1]                                                         */
+#define MMGPU_PF_DBG_LISTS 2      /* {start,len,lprefix,pos} uint32 x 4 per similar k-mer                     */
+#define MMGPU_PF_DBG_PEB 3        /* uint32[n_pos+1] arrival index of each window's first entry (per query)   */
+#define MMGPU_PF_DBG_SPLIT 4      /* uint64[n_tiles][4096] entries grouped by bin                             */
+#define MMGPU_PF_DBG_BIN_OFF 5    /* uint16[n_tiles][bins+1]                                                  */
+#define MMGPU_PF_DBG_CAND_BASE 6  /* uint32[nq*bins+1]                                                        */
+#define MMGPU_PF_DBG_SURV 7       /* {id,arr,score,diag|pad} 16 B records, query q at cand_base[q*bins]       */
+#define MMGPU_PF_DBG_SURV_COUNT 8 /* uint32[nq]                                                               */
+#define MMGPU_PF_DBG_BINS 9       /* uint32[2]: device bins, reference bins                                   */
+int mmgpu_pf_debug_fetch(mmgpu_ctx *ctx, mmgpu_pf_batch_t *batch, int what, void *dst, size_t cap, size_t *bytes);
+void mmgpu_pf_free(mmgpu_ctx *ctx, mmgpu_pf_batch_t *batch);
+
 #ifdef __cplusplus
 }
 #endif

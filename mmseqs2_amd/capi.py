@@ -49,7 +49,35 @@ EXPORTED_SYMBOLS = [
     "mmgpu_init", "mmgpu_destroy", "mmgpu_last_error", "mmgpu_set_stream", "mmgpu_synchronize",
     "mmgpu_device_info", "mmgpu_host_comp_bias", "mmgpu_host_round_comp_bias", "mmgpu_load_targets", "mmgpu_sw_batch", "mmgpu_sw_prepare", "mmgpu_sw_run",
     "mmgpu_sw_fetch", "mmgpu_sw_batch_stats", "mmgpu_sw_last_kernel_ms", "mmgpu_sw_kernel_ms_mean", "mmgpu_sw_free",
+    "mmgpu_host_score_matrix", "mmgpu_host_index_build", "mmgpu_pf_load_index", "mmgpu_pf_batch", "mmgpu_pf_prepare",
+    "mmgpu_pf_run", "mmgpu_pf_fetch", "mmgpu_pf_stage_ms", "mmgpu_pf_debug_fetch", "mmgpu_pf_free",
 ]
+
+
+class PfIndexDesc(ctypes.Structure):
+    _fields_ = [("kmer_size", ctypes.c_int), ("alphabet", ctypes.c_int), ("spaced", ctypes.c_int), ("score3", c_p),
+                ("index3", c_p), ("row3", ctypes.c_size_t), ("offsets", c_p), ("entry_ids", c_p), ("entry_pos", c_p),
+                ("entries6", c_p), ("n_entries", ctypes.c_uint64), ("ungapped_mat", c_p)]
+
+
+class PfParams(ctypes.Structure):
+    _fields_ = [("kmer_thr", ctypes.c_int), ("max_hits", ctypes.c_uint32), ("min_diag_score", ctypes.c_uint32),
+                ("ref_bins", ctypes.c_uint32)]
+
+
+class PfQuery(ctypes.Structure):
+    _fields_ = [("q", c_p), ("qlen", ctypes.c_uint32), ("comp_bias", c_p), ("identity_id", ctypes.c_uint32)]
+
+
+PF_HIT_DTYPE = np.dtype([("id", np.uint32), ("score", np.int32), ("diagonal", np.uint16), ("reserved", np.uint16)])
+PF_QSTAT_DTYPE = np.dtype([("db_matches", np.uint64), ("kmer_list_len", np.uint64), ("double_hits", np.uint32),
+                           ("diag_thr", np.uint32)])
+PF_LIST_DTYPE = np.dtype([("start", np.uint32), ("len", np.uint32), ("lprefix", np.uint32), ("pos", np.uint32)])
+PF_CAND_DTYPE = np.dtype([("id", np.uint32), ("arr", np.uint32), ("score", np.uint32), ("diag", np.uint16),
+                          ("pad", np.uint16)])
+PF_DBG = dict(nsim=(0, np.uint32), list_base=(1, np.uint32), lists=(2, PF_LIST_DTYPE), peb=(3, np.uint32),
+              split=(4, np.uint64), bin_off=(5, np.uint16), cand_base=(6, np.uint32), surv=(7, PF_CAND_DTYPE),
+              surv_count=(8, np.uint32), bins=(9, np.uint32))
 
 
 def load_library():
@@ -75,6 +103,18 @@ def load_library():
     L.mmgpu_sw_kernel_ms_mean.argtypes = [c_p, c_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_uint32)]
     L.mmgpu_sw_free.argtypes = [c_p, c_p]
     L.mmgpu_sw_free.restype = None
+    L.mmgpu_host_score_matrix.argtypes = [c_p, ctypes.c_int, ctypes.c_int, c_p, c_p]
+    L.mmgpu_host_index_build.argtypes = [c_p, c_p, ctypes.c_uint32, c_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                         ctypes.c_int, c_p, c_p, c_p, ctypes.POINTER(ctypes.c_uint64)]
+    L.mmgpu_pf_load_index.argtypes = [c_p, ctypes.POINTER(PfIndexDesc)]
+    L.mmgpu_pf_batch.argtypes = [c_p, ctypes.POINTER(PfParams), c_p, ctypes.c_uint32, c_p, ctypes.c_uint32, c_p, c_p]
+    L.mmgpu_pf_prepare.argtypes = [c_p, ctypes.POINTER(PfParams), c_p, ctypes.c_uint32, ctypes.POINTER(c_p)]
+    L.mmgpu_pf_run.argtypes = [c_p, c_p]
+    L.mmgpu_pf_fetch.argtypes = [c_p, c_p, c_p, ctypes.c_uint32, c_p, c_p, c_p]
+    L.mmgpu_pf_stage_ms.argtypes = [c_p, c_p, ctypes.POINTER(ctypes.c_float)]
+    L.mmgpu_pf_debug_fetch.argtypes = [c_p, c_p, ctypes.c_int, c_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
+    L.mmgpu_pf_free.argtypes = [c_p, c_p]
+    L.mmgpu_pf_free.restype = None
     return L
 
 
@@ -95,6 +135,83 @@ def host_comp_bias(submat16, pback, seq, scale=1.0, lib=None):
     if L.mmgpu_host_round_comp_bias(_ptr(f), len(f), _ptr(r)) != 0:
         raise MMGpuError(L.mmgpu_last_error().decode())
     return f, r
+
+
+def host_score_matrix(submat16, span, lib=None):
+    """ScoreMatrix of all span-mers (ExtendedSubstitutionMatrix::calcScoreMatrix); returns (score int16[n][n], index)."""
+    L = lib or load_library()
+    submat16 = np.ascontiguousarray(submat16, np.int16)
+    n = (submat16.shape[0] - 1) ** span
+    score = np.zeros((n, n), np.int16)
+    index = np.zeros((n, n), np.uint32)
+    if L.mmgpu_host_score_matrix(_ptr(submat16), submat16.shape[0], span, _ptr(score), _ptr(index)) != 0:
+        raise MMGpuError(L.mmgpu_last_error().decode())
+    return score, index
+
+
+def host_index_build(residues, offsets, kmer_submat16, k, spaced, kmer_thr, lib=None):
+    """IndexTable over numeric targets (masking off); returns (offsets uint64[kalph^k+1], ids uint32[], pos uint16[])."""
+    L = lib or load_library()
+    residues = np.ascontiguousarray(residues, np.uint8)
+    offsets = np.ascontiguousarray(offsets, np.uint64)
+    kmer_submat16 = np.ascontiguousarray(kmer_submat16, np.int16)
+    a = kmer_submat16.shape[0]
+    table = (a - 1) ** k
+    koff = np.zeros(table + 1, np.uint64)
+    ne = ctypes.c_uint64()
+    args = (_ptr(residues), _ptr(offsets), len(offsets) - 1, _ptr(kmer_submat16), a, k, int(spaced), int(kmer_thr), _ptr(koff))
+    if L.mmgpu_host_index_build(*args, None, None, ctypes.byref(ne)) != 0:
+        raise MMGpuError(L.mmgpu_last_error().decode())
+    ids = np.zeros(max(ne.value, 1), np.uint32)
+    pos = np.zeros(max(ne.value, 1), np.uint16)
+    if L.mmgpu_host_index_build(*args, _ptr(ids), _ptr(pos), ctypes.byref(ne)) != 0:
+        raise MMGpuError(L.mmgpu_last_error().decode())
+    return koff, ids[:ne.value], pos[:ne.value]
+
+
+class PfBatch:
+    """A prepared prefilter batch (queries resident in HBM)."""
+
+    def __init__(self, gpu, handle, keep, nq, max_hits):
+        self.gpu, self.handle, self._keep, self.nq, self.max_hits = gpu, handle, keep, nq, max_hits
+
+    def run(self):
+        self.gpu._check(self.gpu.L.mmgpu_pf_run(self.gpu.ctx, self.handle))
+
+    def fetch(self):
+        """-> (hits[nq][stride], counts[nq], status[nq], stats[nq])"""
+        stride = max(self.max_hits, 1)
+        hits = np.zeros((max(self.nq, 1), stride), PF_HIT_DTYPE)
+        counts = np.zeros(max(self.nq, 1), np.uint32)
+        status = np.zeros(max(self.nq, 1), np.int32)
+        stats = np.zeros(max(self.nq, 1), PF_QSTAT_DTYPE)
+        self.gpu._check(self.gpu.L.mmgpu_pf_fetch(self.gpu.ctx, self.handle, _ptr(hits), stride, _ptr(counts), _ptr(status),
+                                                  _ptr(stats)))
+        return hits[:self.nq], counts[:self.nq], status[:self.nq], stats[:self.nq]
+
+    def stage_ms(self):
+        ms = (ctypes.c_float * 5)()
+        self.gpu._check(self.gpu.L.mmgpu_pf_stage_ms(self.gpu.ctx, self.handle, ms))
+        return [float(x) for x in ms]
+
+    def debug(self, what):
+        code, dt = PF_DBG[what]
+        n = ctypes.c_size_t()
+        self.gpu._check(self.gpu.L.mmgpu_pf_debug_fetch(self.gpu.ctx, self.handle, code, None, 0, ctypes.byref(n)))
+        out = np.zeros(max(n.value // np.dtype(dt).itemsize, 1), dt)
+        self.gpu._check(self.gpu.L.mmgpu_pf_debug_fetch(self.gpu.ctx, self.handle, code, _ptr(out), n.value, ctypes.byref(n)))
+        return out[: n.value // np.dtype(dt).itemsize]
+
+    def free(self):
+        if self.handle is not None:
+            self.gpu.L.mmgpu_pf_free(self.gpu.ctx, self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 class SwBatch:
@@ -202,3 +319,41 @@ class MMGpu:
         h = c_p()
         self._check(self.L.mmgpu_sw_prepare(self.ctx, ctypes.byref(par), ctypes.cast(arr, c_p), len(queries), mode, ctypes.byref(h)))
         return SwBatch(self, h, keep)
+
+    # ---- prefilter ----
+    def pf_load_index(self, k, alphabet, spaced, score3, index3, offsets, entry_ids, entry_pos, ungapped_mat):
+        score3 = np.ascontiguousarray(score3, np.int16)
+        index3 = np.ascontiguousarray(index3, np.uint32)
+        offsets = np.ascontiguousarray(offsets, np.uint64)
+        entry_ids = np.ascontiguousarray(entry_ids, np.uint32)
+        entry_pos = np.ascontiguousarray(entry_pos, np.uint16)
+        ungapped_mat = np.ascontiguousarray(ungapped_mat, np.int8)
+        d = PfIndexDesc(k, alphabet, int(spaced), _ptr(score3), _ptr(index3), score3.shape[1], _ptr(offsets),
+                        _ptr(entry_ids), _ptr(entry_pos), None, len(entry_ids), _ptr(ungapped_mat))
+        self._check(self.L.mmgpu_pf_load_index(self.ctx, ctypes.byref(d)))
+
+    def _pf_marshal(self, queries):
+        """queries: list of dicts {q: uint8[], comp_bias: float32[]|None, identity_id: int|None}"""
+        arr = (PfQuery * max(len(queries), 1))()
+        keep = []
+        for i, qd in enumerate(queries):
+            q = np.ascontiguousarray(qd["q"], np.uint8)
+            cb = None if qd.get("comp_bias") is None else np.ascontiguousarray(qd["comp_bias"], np.float32)
+            keep += [q, cb]
+            ident = qd.get("identity_id")
+            arr[i] = PfQuery(_ptr(q), len(q), _ptr(cb), 0xFFFFFFFF if ident is None else int(ident))
+        return arr, keep
+
+    def pf_prepare(self, queries, kmer_thr, max_hits=300, min_diag_score=15, ref_bins=0):
+        arr, keep = self._pf_marshal(queries)
+        par = PfParams(int(kmer_thr), int(max_hits), int(min_diag_score), int(ref_bins))
+        h = c_p()
+        self._check(self.L.mmgpu_pf_prepare(self.ctx, ctypes.byref(par), ctypes.cast(arr, c_p), len(queries), ctypes.byref(h)))
+        return PfBatch(self, h, keep, len(queries), min(int(max_hits), self.n_targets))
+
+    def pf_batch(self, queries, kmer_thr, max_hits=300, min_diag_score=15, ref_bins=0):
+        b = self.pf_prepare(queries, kmer_thr, max_hits, min_diag_score, ref_bins)
+        b.run()
+        out = b.fetch()
+        b.free()
+        return out

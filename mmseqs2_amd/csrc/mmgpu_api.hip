@@ -11,48 +11,10 @@
 
 using namespace mmgpu;
 
-static thread_local std::string g_last_error;
-
-static int fail(int code, const std::string &msg) {
-    g_last_error = msg;
-    return code;
+namespace mmgpu {
+thread_local std::string g_last_error;
 }
-#define HIP_TRY(expr)                                                                              \
-    do {                                                                                           \
-        hipError_t e__ = (expr);                                                                   \
-        if (e__ != hipSuccess)                                                                     \
-            return fail(MMGPU_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));        \
-    } while (0)
-
-struct mmgpu_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    DeviceDb db;
-    std::vector<uint32_t> h_len;   // host copy of target lengths (scheduling)
-    int compute_units = 0;
-    std::string name;
-};
-
-struct DevBuf {
-    void *p = nullptr;
-    size_t bytes = 0;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t n) {
-        if (p) { (void)hipFree(p); p = nullptr; }
-        bytes = n;
-        if (n == 0) return hipSuccess;
-        return hipMalloc(&p, n);
-    }
-    template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
-};
-
-template <typename T>
-static hipError_t upload(DevBuf &b, const std::vector<T> &v, hipStream_t s) {
-    hipError_t e = b.alloc(std::max<size_t>(v.size(), 1) * sizeof(T));
-    if (e != hipSuccess) return e;
-    if (v.empty()) return hipSuccess;
-    return hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s);
-}
+using mmgpu::g_last_error;
 
 extern "C" const char *mmgpu_last_error(void) { return g_last_error.c_str(); }
 
@@ -83,6 +45,7 @@ extern "C" void mmgpu_destroy(mmgpu_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     free_db(c->db);
+    mmgpu::pf_index_free(c);
     delete c;
 }
 

@@ -5,6 +5,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+#include <string>
+#include <vector>
+
 #include "../../include/mmgpu.h"
 
 namespace mmgpu {
@@ -62,5 +66,153 @@ struct SwLaunch {
 hipError_t launch_sw(const SwLaunch &L, int rows_per_lane, bool multi_tile, bool reverse, hipStream_t stream);
 size_t sw_lds_bytes(int rows_per_lane, int alphabet);
 
+// ---------------------------------------------------------------------------------------------------------
+// prefilter (pf_kernels.hip)
+constexpr int PF_T = 4096;             // arrival-ordered index entries per tile
+constexpr int PF_IDS_PER_BIN = 4096;   // targets per replay bin (one 16 KB LDS state table per wavefront)
+constexpr int PF_MAX_HITS = 4096;      // largest --max-seqs the select kernel sorts in LDS
+
+struct PfList {        // index list of one similar k-mer of one query position
+    uint32_t start;    // first entry in the index arrays
+    uint32_t len;
+    uint32_t lprefix;  // entries of earlier lists of the same position
+    uint32_t pos;      // batch-global query position
+};
+
+struct PfCand {        // double-diagonal candidate / surviving element
+    uint32_t id;
+    uint32_t arr;      // arrival index of the emitting index entry within its query
+    uint32_t score;    // exact ungapped score
+    uint16_t diag;
+    uint16_t pad;
+};
+
+struct PfKmerArgs {
+    const uint8_t *q_res;      // batch residues, concatenated
+    const int16_t *q_thr;      // per position: adjusted k-mer threshold, -1 = no window / X in window
+    uint32_t n_pos;
+    uint8_t pat[8];            // Sequence::aaPosInSpacedPattern
+    uint32_t kalph, n3;
+    const int16_t *s3;         // [n3][n3] ScoreMatrix::score of the 3-mer matrix (no padding columns)
+    const uint32_t *i3;        // [n3][n3] ScoreMatrix::index
+    const uint32_t *offsets;   // IndexTable::offsets, [kalph^k + 1]
+    // count pass
+    uint32_t *nsim;
+    // emit pass
+    const uint32_t *list_base; // [n_pos + 1]
+    PfList *lists;
+    uint32_t *pos_entries;
+};
+
+struct PfSplitArgs {
+    const uint32_t *tile_q, *tile_idx;
+    const uint32_t *q_off;            // [nq + 1]
+    const uint32_t *q_entries;        // [nq]
+    const uint32_t *pos_entry_base;   // [n_pos + 1], relative to the query
+    const uint32_t *list_base;        // [n_pos + 1]
+    const PfList *lists;
+    const uint32_t *idx_ids;          // IndexEntryLocal::seqId
+    const uint16_t *idx_pos;          // IndexEntryLocal::position_j
+    uint32_t bins;
+    uint64_t *split;                  // [n_tiles][PF_T]
+    uint16_t *bin_off;                // [n_tiles][bins + 1]
+    uint32_t *bucket_count;           // [nq][bins]
+};
+
+struct PfDedupArgs {
+    uint32_t n_queries, bins;
+    const uint32_t *q_tile_base, *q_ntiles;
+    const uint64_t *split;
+    const uint16_t *bin_off;
+    const uint32_t *cand_base;        // [nq * bins + 1]
+    PfCand *cand, *surv;
+    uint32_t *surv_count;             // [nq]
+    const uint32_t *q_off;
+    const uint8_t *q_res;
+    const int8_t *q_corr;             // UngappedAlignment::aaCorrectionScore per position
+    const int8_t *mat;                // ungapped matrix, alphabet x alphabet
+    int alphabet;
+    const uint8_t *t_res;
+    const uint32_t *t_off4, *t_len;
+    uint32_t min_diag_score;
+};
+
+struct PfSelectArgs {
+    const PfCand *surv;
+    const uint32_t *cand_base;        // survivors of query q start at cand_base[q * bins]
+    uint32_t bins;
+    const uint32_t *surv_count;
+    const uint32_t *q_identity;
+    const int32_t *q_self_score;
+    uint32_t max_hits, min_diag_score, ref_bins;
+    mmgpu_pf_hit *hits;
+    uint32_t hit_stride;
+    uint32_t *hit_count, *q_diag_thr;
+};
+
+hipError_t launch_pf_kmers(const PfKmerArgs &A, bool emit, hipStream_t s);
+hipError_t launch_pf_scan(const uint32_t *in, const uint32_t *q_off, uint32_t nq, const uint64_t *base, uint32_t *out,
+                          uint64_t *totals, hipStream_t s);
+hipError_t launch_pf_split(const PfSplitArgs &A, uint32_t n_tiles, hipStream_t s);
+hipError_t launch_pf_dedup(const PfDedupArgs &A, hipStream_t s);
+hipError_t launch_pf_select(const PfSelectArgs &A, uint32_t nq, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------------------
+// host-side plumbing shared by mmgpu_api.hip and pf_api.hip
+extern thread_local std::string g_last_error;
+inline int fail(int code, const std::string &msg) {
+    g_last_error = msg;
+    return code;
+}
+#define HIP_TRY(expr)                                                                                      \
+    do {                                                                                                   \
+        hipError_t e__ = (expr);                                                                           \
+        if (e__ != hipSuccess)                                                                             \
+            return mmgpu::fail(MMGPU_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));         \
+    } while (0)
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    DevBuf(DevBuf &&o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t n) {
+        if (p) { (void)hipFree(p); p = nullptr; }
+        bytes = n;
+        if (n == 0) return hipSuccess;
+        return hipMalloc(&p, n);
+    }
+    // grow-only (contents are not preserved)
+    hipError_t reserve(size_t n) { return n <= bytes ? hipSuccess : alloc(n + n / 8); }
+    template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+template <typename T>
+inline hipError_t upload(DevBuf &b, const std::vector<T> &v, hipStream_t s) {
+    hipError_t e = b.alloc(std::max<size_t>(v.size(), 1) * sizeof(T));
+    if (e != hipSuccess) return e;
+    if (v.empty()) return hipSuccess;
+    return hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s);
+}
+
+struct PfIndex;   // pf_api.hip
+
 }  // namespace mmgpu
+
+struct mmgpu_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    mmgpu::DeviceDb db;
+    std::vector<uint32_t> h_len;   // host copy of target lengths (scheduling)
+    int compute_units = 0;
+    std::string name;
+    mmgpu::PfIndex *pf = nullptr;  // prefilter index resident in HBM (pf_api.hip)
+};
+
+namespace mmgpu {
+void pf_index_free(mmgpu_ctx *c);
+}
 #endif

@@ -1,0 +1,694 @@
+// Host side of the prefilter half of libmmgpu: table builders, index residency, batch preparation and the
+// launch sequence around pf_kernels.hip.  See include/mmgpu.h for the contract.
+#include <unistd.h>
+
+#include <atomic>
+#include <cmath>
+#include <cstring>
+#include <thread>
+
+#include "mmgpu_internal.h"
+
+using namespace mmgpu;
+
+namespace mmgpu {
+
+struct PfIndex {
+    int k = 0, alphabet = 0, kalph = 0, spaced = 0;
+    uint8_t pat[8] = {0};
+    int pattern_len = 0;
+    uint32_t n3 = 0;
+    uint64_t table = 0, n_entries = 0;
+    DevBuf d_s3, d_i3, d_offsets, d_ids, d_pos, d_mat;
+    std::vector<int8_t> h_mat;   // ungapped matrix (host copy for the self score)
+};
+
+void pf_index_free(mmgpu_ctx *c) {
+    if (c && c->pf) {
+        delete c->pf;
+        c->pf = nullptr;
+    }
+}
+
+}  // namespace mmgpu
+
+static const uint8_t SPACED6[] = {1, 1, 0, 1, 0, 1, 0, 0, 1, 1};      // Sequence.h:25
+static const uint8_t SPACED7[] = {1, 1, 0, 1, 0, 1, 1, 0, 0, 1, 1};   // Sequence.h:27
+
+static int window_pattern(int k, int spaced, uint8_t *pat) {
+    if (!spaced) {
+        for (int i = 0; i < k; i++) pat[i] = (uint8_t)i;
+        return k;
+    }
+    const uint8_t *p = k == 6 ? SPACED6 : SPACED7;
+    const int n = k == 6 ? 10 : 11;
+    int c = 0;
+    for (int i = 0; i < n; i++)
+        if (p[i]) pat[c++] = (uint8_t)i;
+    return n;
+}
+
+static unsigned host_threads() {
+    unsigned n = std::thread::hardware_concurrency();
+    return n == 0 ? 1 : std::min(n, 64u);
+}
+
+template <typename F>
+static void parallel_for(size_t n, F f) {
+    const unsigned nt = (unsigned)std::min<size_t>(host_threads(), std::max<size_t>(n, 1));
+    if (nt <= 1) {
+        f(0, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    const size_t chunk = (n + nt - 1) / nt;
+    for (unsigned t = 0; t < nt; t++) {
+        const size_t a = std::min(n, (size_t)t * chunk), b = std::min(n, a + chunk);
+        if (a < b) th.emplace_back([=] { f(a, b); });
+    }
+    for (auto &x : th) x.join();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// ExtendedSubstitutionMatrix::calcScoreMatrix (src/prefiltering/ExtendedSubstitutionMatrix.cpp:20-71).  Row r lists
+// every span-mer by descending score; the reference uses std::stable_sort over the cartesian-product enumeration
+// (first residue slowest, :103-128).  Scores are small integers, so a stable counting sort per row does the same.
+extern "C" int mmgpu_host_score_matrix(const int16_t *submat, int alphabet, int span, int16_t *score, uint32_t *index) {
+    if (!submat || !score || !index) return fail(MMGPU_ERR_ARG, "mmgpu_host_score_matrix: NULL argument");
+    if (alphabet < 3 || alphabet > 32 || span < 1 || span > 3) return fail(MMGPU_ERR_ARG, "mmgpu_host_score_matrix: bad alphabet/span");
+    const int ka = alphabet - 1;
+    size_t n = 1;
+    for (int i = 0; i < span; i++) n *= (size_t)ka;
+    // enumeration e -> (index in int2index order, residues)
+    std::vector<uint32_t> e2idx(n);
+    std::vector<uint8_t> e2res(n * (size_t)span);
+    for (size_t e = 0; e < n; e++) {
+        size_t t = e;
+        for (int p = span - 1; p >= 0; p--) {
+            e2res[e * span + p] = (uint8_t)(t % (size_t)ka);
+            t /= (size_t)ka;
+        }
+        size_t idx = 0, pw = 1;
+        for (int p = 0; p < span; p++) {
+            idx += e2res[e * span + p] * pw;
+            pw *= (size_t)ka;
+        }
+        e2idx[e] = (uint32_t)idx;
+    }
+    int lo = 0, hi = 0;
+    for (int a = 0; a < ka; a++)
+        for (int b = 0; b < ka; b++) {
+            lo = std::min<int>(lo, submat[a * alphabet + b]);
+            hi = std::max<int>(hi, submat[a * alphabet + b]);
+        }
+    const int smin = lo * span, smax = hi * span, range = smax - smin + 1;
+    parallel_for(n, [&](size_t r0, size_t r1) {
+        std::vector<int16_t> sc(n);
+        std::vector<uint32_t> cursor((size_t)range + 1);
+        for (size_t e = r0; e < r1; e++) {
+            const uint8_t *a = &e2res[e * span];
+            std::fill(cursor.begin(), cursor.end(), 0u);
+            for (size_t f = 0; f < n; f++) {
+                const uint8_t *b = &e2res[f * span];
+                int s = 0;
+                for (int p = 0; p < span; p++) s += submat[a[p] * alphabet + b[p]];
+                sc[f] = (int16_t)s;
+                cursor[(size_t)(smax - s) + 1]++;   // bucket 0 = highest score
+            }
+            for (int z = 0; z < range; z++) cursor[(size_t)z + 1] += cursor[z];
+            int16_t *srow = score + (size_t)e2idx[e] * n;
+            uint32_t *irow = index + (size_t)e2idx[e] * n;
+            for (size_t f = 0; f < n; f++) {
+                const uint32_t o = cursor[(size_t)(smax - sc[f])]++;
+                srow[o] = sc[f];
+                irow[o] = e2idx[f];
+            }
+        }
+    });
+    return MMGPU_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// IndexTable::addKmerCount / addSequence / sortDBSeqLists (src/prefiltering/IndexTable.h:135-191,350-403) as
+// IndexBuilder::fillDatabase drives them with masking off (IndexBuilder.cpp:118-166,226-270).
+namespace {
+struct KmerWindows {
+    int k, ka, alphabet, plen, thr;
+    uint8_t pat[8];
+    int8_t self[32];   // (char) subMatrix[a][a], IndexBuilder.cpp:11-22
+    // unique k-mers of one target with their first position, sorted by k-mer; key = kmer << 16 | pos
+    void extract(const uint8_t *s, uint64_t len, std::vector<uint64_t> &buf) const {
+        buf.clear();
+        for (uint64_t i = 0; i + (uint64_t)plen <= len; i++) {
+            uint64_t idx = 0, pw = 1;
+            int sc = 0;
+            bool x = false;
+            for (int p = 0; p < k; p++) {
+                const uint8_t r = s[i + pat[p]];
+                if (r >= ka) { x = true; break; }
+                idx += r * pw;
+                pw *= (uint64_t)ka;
+                sc += self[r];
+            }
+            if (x || (thr > 0 && sc < thr)) continue;
+            buf.push_back((idx << 16) | (i & 0xFFFFu));
+        }
+        std::sort(buf.begin(), buf.end());
+        size_t w = 0;
+        uint64_t prev = ~0ull;
+        for (size_t z = 0; z < buf.size(); z++) {
+            if ((buf[z] >> 16) != prev) buf[w++] = buf[z];
+            prev = buf[z] >> 16;
+        }
+        buf.resize(w);
+    }
+};
+}  // namespace
+
+extern "C" int mmgpu_host_index_build(const uint8_t *residues, const uint64_t *seq_off, uint32_t n, const int16_t *kmer_submat,
+                                      int alphabet, int k, int spaced, int kmer_thr, uint64_t *offsets, uint32_t *ids,
+                                      uint16_t *pos, uint64_t *n_entries) {
+    if (!residues || !seq_off || !kmer_submat || !offsets || !n_entries)
+        return fail(MMGPU_ERR_ARG, "mmgpu_host_index_build: NULL argument");
+    if ((k != 6 && k != 7) || alphabet < 3 || alphabet > 32) return fail(MMGPU_ERR_ARG, "mmgpu_host_index_build: bad k/alphabet");
+    if ((ids == nullptr) != (pos == nullptr)) return fail(MMGPU_ERR_ARG, "mmgpu_host_index_build: ids and pos go together");
+    KmerWindows W;
+    W.k = k;
+    W.ka = alphabet - 1;
+    W.alphabet = alphabet;
+    W.thr = kmer_thr;
+    W.plen = window_pattern(k, spaced, W.pat);
+    for (int a = 0; a < alphabet; a++) W.self[a] = (int8_t)(char)kmer_submat[a * alphabet + a];
+    uint64_t table = 1;
+    for (int i = 0; i < k; i++) table *= (uint64_t)W.ka;
+    std::vector<std::atomic<uint32_t>> cnt(table);
+    for (auto &c : cnt) c.store(0, std::memory_order_relaxed);
+    parallel_for(n, [&](size_t a, size_t b) {
+        std::vector<uint64_t> buf;
+        for (size_t t = a; t < b; t++) {
+            W.extract(residues + seq_off[t], seq_off[t + 1] - seq_off[t], buf);
+            for (uint64_t v : buf) cnt[v >> 16].fetch_add(1, std::memory_order_relaxed);
+        }
+    });
+    uint64_t run = 0;
+    for (uint64_t z = 0; z < table; z++) {
+        offsets[z] = run;
+        run += cnt[z].load(std::memory_order_relaxed);
+    }
+    offsets[table] = run;
+    *n_entries = run;
+    if (!ids) return MMGPU_OK;
+    for (auto &c : cnt) c.store(0, std::memory_order_relaxed);
+    parallel_for(n, [&](size_t a, size_t b) {
+        std::vector<uint64_t> buf;
+        for (size_t t = a; t < b; t++) {
+            W.extract(residues + seq_off[t], seq_off[t + 1] - seq_off[t], buf);
+            for (uint64_t v : buf) {
+                const uint64_t o = offsets[v >> 16] + cnt[v >> 16].fetch_add(1, std::memory_order_relaxed);
+                ids[o] = (uint32_t)t;
+                pos[o] = (uint16_t)(v & 0xFFFFu);
+            }
+        }
+    });
+    // sortDBSeqLists: every list by (seqId, position); one entry per (k-mer, target), so seqId alone decides
+    parallel_for(table, [&](size_t a, size_t b) {
+        std::vector<uint64_t> tmp;
+        for (size_t z = a; z < b; z++) {
+            const uint64_t o0 = offsets[z], o1 = offsets[z + 1];
+            if (o1 - o0 < 2) continue;
+            tmp.resize(o1 - o0);
+            for (uint64_t e = o0; e < o1; e++) tmp[e - o0] = ((uint64_t)ids[e] << 16) | pos[e];
+            std::sort(tmp.begin(), tmp.end());
+            for (uint64_t e = o0; e < o1; e++) {
+                ids[e] = (uint32_t)(tmp[e - o0] >> 16);
+                pos[e] = (uint16_t)(tmp[e - o0] & 0xFFFFu);
+            }
+        }
+    });
+    return MMGPU_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+extern "C" int mmgpu_pf_load_index(mmgpu_ctx *c, const mmgpu_pf_index *ix) {
+    if (!c || !ix) return fail(MMGPU_ERR_ARG, "mmgpu_pf_load_index: NULL argument");
+    if (!c->db.res) return fail(MMGPU_ERR_STATE, "mmgpu_pf_load_index: load the targets (SequenceLookup) first");
+    if (ix->kmer_size != 6) return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_pf_load_index: only k = 6 is implemented on the device");
+    if (ix->alphabet != c->db.alphabet) return fail(MMGPU_ERR_ARG, "mmgpu_pf_load_index: alphabet differs from the loaded targets");
+    if (!ix->score3 || !ix->index3 || !ix->offsets || !ix->ungapped_mat) return fail(MMGPU_ERR_ARG, "mmgpu_pf_load_index: NULL table");
+    if (!ix->entries6 && !(ix->entry_ids && ix->entry_pos) && ix->n_entries) return fail(MMGPU_ERR_ARG, "mmgpu_pf_load_index: no index entries");
+    if (ix->n_entries >= 0xFFFFFFFFull) return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_pf_load_index: >= 2^32 index entries per shard");
+    if (c->db.max_len >= 32768) return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_pf_load_index: targets of length >= 32768 (computeLongScore) are not implemented");
+    HIP_TRY(hipSetDevice(c->device));
+    pf_index_free(c);
+    PfIndex *P = new PfIndex();
+    P->k = ix->kmer_size;
+    P->alphabet = ix->alphabet;
+    P->kalph = ix->alphabet - 1;
+    P->spaced = ix->spaced;
+    P->pattern_len = window_pattern(P->k, P->spaced, P->pat);
+    P->n3 = (uint32_t)(P->kalph * P->kalph * P->kalph);
+    P->table = 1;
+    for (int i = 0; i < P->k; i++) P->table *= (uint64_t)P->kalph;
+    P->n_entries = ix->n_entries;
+    const size_t n3 = P->n3;
+    if (ix->row3 < n3) { delete P; return fail(MMGPU_ERR_ARG, "mmgpu_pf_load_index: row3 smaller than kalph^3"); }
+#define P_TRY(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { delete P; return fail(MMGPU_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__)); } } while (0)
+    P_TRY(P->d_s3.alloc(n3 * n3 * sizeof(int16_t)));
+    P_TRY(P->d_i3.alloc(n3 * n3 * sizeof(uint32_t)));
+    P_TRY(hipMemcpy2D(P->d_s3.p, n3 * sizeof(int16_t), ix->score3, ix->row3 * sizeof(int16_t), n3 * sizeof(int16_t), n3, hipMemcpyHostToDevice));
+    P_TRY(hipMemcpy2D(P->d_i3.p, n3 * sizeof(uint32_t), ix->index3, ix->row3 * sizeof(uint32_t), n3 * sizeof(uint32_t), n3, hipMemcpyHostToDevice));
+    {
+        std::vector<uint32_t> off32(P->table + 1);
+        for (uint64_t z = 0; z <= P->table; z++) {
+            if (ix->offsets[z] > ix->n_entries || (z && ix->offsets[z] < ix->offsets[z - 1])) { delete P; return fail(MMGPU_ERR_ARG, "mmgpu_pf_load_index: offsets not monotone / out of range"); }
+            off32[z] = (uint32_t)ix->offsets[z];
+        }
+        P_TRY(upload(P->d_offsets, off32, nullptr));
+        P_TRY(hipDeviceSynchronize());
+    }
+    {
+        const size_t ne = (size_t)ix->n_entries;
+        std::vector<uint32_t> ids(std::max<size_t>(ne, 1));
+        std::vector<uint16_t> pos(std::max<size_t>(ne, 1));
+        if (ix->entry_ids) {
+            memcpy(ids.data(), ix->entry_ids, ne * sizeof(uint32_t));
+            memcpy(pos.data(), ix->entry_pos, ne * sizeof(uint16_t));
+        } else {
+            const uint8_t *e6 = (const uint8_t *)ix->entries6;
+            for (size_t e = 0; e < ne; e++) {
+                memcpy(&ids[e], e6 + e * 6, 4);
+                memcpy(&pos[e], e6 + e * 6 + 4, 2);
+            }
+        }
+        for (size_t e = 0; e < ne; e++)
+            if (ids[e] >= c->db.n) { delete P; return fail(MMGPU_ERR_ARG, "mmgpu_pf_load_index: index entry names a target that is not loaded"); }
+        P_TRY(upload(P->d_ids, ids, nullptr));
+        P_TRY(upload(P->d_pos, pos, nullptr));
+        P_TRY(hipDeviceSynchronize());
+    }
+    P->h_mat.assign(ix->ungapped_mat, ix->ungapped_mat + ix->alphabet * ix->alphabet);
+    P_TRY(upload(P->d_mat, P->h_mat, nullptr));
+    P_TRY(hipDeviceSynchronize());
+#undef P_TRY
+    c->pf = P;
+    return MMGPU_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+struct mmgpu_pf_batch_t {
+    mmgpu_pf_params par;
+    uint32_t nq = 0, n_pos = 0;
+    uint32_t max_hits = 0;     // min(par.max_hits, dbSize)
+    uint32_t bins = 0, ref_bins = 0;
+    uint64_t max_db_matches = 0;
+    std::vector<uint32_t> q_off;
+    // device: inputs
+    DevBuf d_qres, d_qthr, d_qcorr, d_qoff, d_qident, d_qself;
+    // device: working set (grow-only, reused across runs)
+    DevBuf d_nsim, d_qtot, d_qbase, d_list_base, d_lists, d_pos_entries, d_peb, d_qentries;
+    DevBuf d_tile_q, d_tile_idx, d_qtile_base, d_qntiles, d_split, d_bin_off, d_bucket_count, d_bucket_off;
+    DevBuf d_cand_base, d_cand, d_surv, d_surv_count, d_hits, d_hit_count, d_diag_thr;
+    // host mirrors of the last run
+    std::vector<uint64_t> q_lists, q_entries;
+    std::vector<int32_t> status;
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    uint64_t last_lists = 0, last_entries = 0;
+    uint32_t last_tiles = 0;
+    bool ran = false;
+};
+
+static uint32_t reference_bins(uint64_t dbsize) {
+    // QueryMatcher::initDiagonalMatcher (QueryMatcher.cpp:460-488), Util::getL2CacheSize (Util.cpp:346-361)
+    uint64_t l2 = 262144;
+#if defined(_SC_LEVEL2_CACHE_SIZE)
+    const long v = sysconf(_SC_LEVEL2_CACHE_SIZE);
+    if (v > 0) l2 = (uint64_t)v;
+#endif
+    for (uint32_t b = 2; b <= 1024; b <<= 1)
+        if (dbsize / b < l2) return b;
+    return 2048;
+}
+
+extern "C" int mmgpu_pf_prepare(mmgpu_ctx *c, const mmgpu_pf_params *par, const mmgpu_pf_query *qs, uint32_t nq,
+                                mmgpu_pf_batch_t **out) {
+    if (!c || !par || !out || (!qs && nq)) return fail(MMGPU_ERR_ARG, "mmgpu_pf_prepare: NULL argument");
+    if (!c->pf || !c->db.res) return fail(MMGPU_ERR_STATE, "mmgpu_pf_prepare: no index loaded");
+    if (par->min_diag_score < 1) return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_pf_prepare: min_diag_score must be >= 1");
+    if (par->max_hits < 1) return fail(MMGPU_ERR_ARG, "mmgpu_pf_prepare: max_hits must be >= 1");
+    const PfIndex &P = *c->pf;
+    const uint32_t max_hits = (uint32_t)std::min<uint64_t>(par->max_hits, c->db.n);
+    if (max_hits > PF_MAX_HITS) return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_pf_prepare: max_hits above 4096 is not implemented");
+    if (par->ref_bins && (par->ref_bins < 2 || par->ref_bins > 2048 || (par->ref_bins & (par->ref_bins - 1))))
+        return fail(MMGPU_ERR_ARG, "mmgpu_pf_prepare: ref_bins must be a power of two in [2, 2048]");
+    uint32_t bins = 1;
+    while ((uint64_t)bins * PF_IDS_PER_BIN < c->db.n) bins <<= 1;
+    if (bins > 2048) return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_pf_prepare: more than 8M targets per shard");
+    HIP_TRY(hipSetDevice(c->device));
+
+    mmgpu_pf_batch_t *b = new mmgpu_pf_batch_t();
+    b->par = *par;
+    b->nq = nq;
+    b->max_hits = max_hits;
+    b->bins = bins;
+    b->ref_bins = par->ref_bins ? par->ref_bins : reference_bins(c->db.n);
+    b->max_db_matches = std::max<uint64_t>(1000000, c->db.n) * 2;   // QueryMatcher.cpp:44-45
+    b->q_off.assign(nq + 1, 0);
+    uint64_t tot = 0;
+    for (uint32_t i = 0; i < nq; i++) {
+        if (!qs[i].q || qs[i].qlen == 0) { delete b; return fail(MMGPU_ERR_ARG, "mmgpu_pf_prepare: bad query"); }
+        if (qs[i].qlen >= 32768) { delete b; return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_pf_prepare: queries of length >= 32768 (computeLongScore) are not implemented"); }
+        tot += qs[i].qlen;
+        if (tot > 0x7FFFFFFFull) { delete b; return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_pf_prepare: more than 2^31 query residues per batch"); }
+        b->q_off[i + 1] = (uint32_t)tot;
+    }
+    b->n_pos = (uint32_t)tot;
+    std::vector<uint8_t> qres(tot);
+    std::vector<int16_t> qthr(tot, -1);
+    std::vector<int8_t> qcorr(tot, 0);
+    std::vector<uint32_t> qident(std::max<uint32_t>(nq, 1), 0xFFFFFFFFu);
+    std::vector<int32_t> qself(std::max<uint32_t>(nq, 1), 0);
+    std::atomic<bool> bad(false);
+    parallel_for(nq, [&](size_t a, size_t e) {
+        for (size_t i = a; i < e; i++) {
+            const mmgpu_pf_query &Q = qs[i];
+            const uint32_t o = b->q_off[i];
+            const int L = (int)Q.qlen;
+            for (int p = 0; p < L; p++) {
+                if (Q.q[p] >= P.alphabet) bad = true;
+                qres[o + p] = Q.q[p];
+            }
+            qident[i] = Q.identity_id;
+            // QueryMatcher::match, QueryMatcher.cpp:255-274: per-window threshold
+            for (int p = 0; p + P.pattern_len <= L; p++) {
+                float bc = 0;
+                bool x = false;
+                for (int z = 0; z < P.k; z++) {
+                    bc += Q.comp_bias ? Q.comp_bias[p + (short)P.pat[z]] : 0.0f;
+                    if (Q.q[p + P.pat[z]] >= P.kalph) x = true;
+                }
+                if (x) continue;
+                const short bias = (short)((bc < 0.0) ? bc - 0.5 : bc + 0.5);
+                const int t0 = par->kmer_thr - bias;
+                qthr[o + p] = (int16_t)(short)(t0 > 0 ? t0 : 0);
+            }
+            // UngappedAlignment::createProfile, UngappedAlignment.cpp:396-400
+            for (int p = 0; p < L; p++) {
+                float v = Q.comp_bias ? Q.comp_bias[p] : 0.0f;
+                v = (v < 0.0) ? v / 4 - 0.5 : v / 4 + 0.5;
+                qcorr[o + p] = (int8_t)(char)v;
+            }
+            // rescoreHits' self score (QueryMatcher.cpp:566): best ungapped segment of the query against itself
+            int sc = 0, mx = 0;
+            for (int p = 0; p < L && !bad; p++) {
+                const int cur = (int)(int8_t)(P.h_mat[(size_t)Q.q[p] * P.alphabet + Q.q[p]] + qcorr[o + p]);
+                sc += cur;
+                sc = sc < 0 ? 0 : sc;
+                mx = sc > mx ? sc : mx;
+            }
+            qself[i] = mx;
+        }
+    });
+    if (bad) { delete b; return fail(MMGPU_ERR_ARG, "mmgpu_pf_prepare: query residue code >= alphabet"); }
+    hipStream_t s = c->stream;
+#define B_TRY(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { delete b; return fail(MMGPU_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__)); } } while (0)
+    B_TRY(upload(b->d_qres, qres, s));
+    B_TRY(upload(b->d_qthr, qthr, s));
+    B_TRY(upload(b->d_qcorr, qcorr, s));
+    B_TRY(upload(b->d_qoff, b->q_off, s));
+    B_TRY(upload(b->d_qident, qident, s));
+    B_TRY(upload(b->d_qself, qself, s));
+    const size_t np = std::max<size_t>(tot, 1), nqq = std::max<uint32_t>(nq, 1);
+    B_TRY(b->d_nsim.alloc(np * 4));
+    B_TRY(b->d_list_base.alloc((np + 1) * 4));
+    B_TRY(b->d_pos_entries.alloc(np * 4));
+    B_TRY(b->d_peb.alloc((np + 1) * 4));
+    B_TRY(b->d_qtot.alloc(nqq * 8));
+    B_TRY(b->d_qbase.alloc(nqq * 8));
+    B_TRY(b->d_qentries.alloc(nqq * 4));
+    B_TRY(b->d_qtile_base.alloc(nqq * 4));
+    B_TRY(b->d_qntiles.alloc(nqq * 4));
+    B_TRY(b->d_bucket_count.alloc((size_t)nqq * bins * 4));
+    B_TRY(b->d_bucket_off.alloc(((size_t)nqq + 1) * 4));
+    B_TRY(b->d_cand_base.alloc(((size_t)nqq * bins + 1) * 4));
+    B_TRY(b->d_surv_count.alloc(nqq * 4));
+    B_TRY(b->d_hits.alloc((size_t)nqq * max_hits * sizeof(mmgpu_pf_hit)));
+    B_TRY(b->d_hit_count.alloc(nqq * 4));
+    B_TRY(b->d_diag_thr.alloc(nqq * 4));
+    for (auto &e : b->ev) B_TRY(hipEventCreate(&e));
+    B_TRY(hipStreamSynchronize(s));
+#undef B_TRY
+    *out = b;
+    return MMGPU_OK;
+}
+
+extern "C" int mmgpu_pf_run(mmgpu_ctx *c, mmgpu_pf_batch_t *b) {
+    if (!c || !b) return fail(MMGPU_ERR_ARG, "mmgpu_pf_run: NULL argument");
+    if (!c->pf) return fail(MMGPU_ERR_STATE, "mmgpu_pf_run: no index loaded");
+    HIP_TRY(hipSetDevice(c->device));
+    const PfIndex &P = *c->pf;
+    hipStream_t s = c->stream;
+    const uint32_t nq = b->nq;
+    b->status.assign(nq, MMGPU_PF_OK);
+    b->q_lists.assign(nq, 0);
+    b->q_entries.assign(nq, 0);
+    if (nq == 0) { b->ran = true; return MMGPU_OK; }
+    HIP_TRY(hipEventRecord(b->ev[0], s));
+
+    // ---- stage 0: similar k-mers and their index lists, in the reference's order ----
+    PfKmerArgs K;
+    memset(&K, 0, sizeof(K));
+    K.q_res = b->d_qres.as<uint8_t>();
+    K.q_thr = b->d_qthr.as<int16_t>();
+    K.n_pos = b->n_pos;
+    memcpy(K.pat, P.pat, sizeof(K.pat));
+    K.kalph = (uint32_t)P.kalph;
+    K.n3 = P.n3;
+    K.s3 = P.d_s3.as<int16_t>();
+    K.i3 = P.d_i3.as<uint32_t>();
+    K.offsets = P.d_offsets.as<uint32_t>();
+    K.nsim = b->d_nsim.as<uint32_t>();
+    HIP_TRY(launch_pf_kmers(K, false, s));
+    HIP_TRY(launch_pf_scan(b->d_nsim.as<uint32_t>(), b->d_qoff.as<uint32_t>(), nq, nullptr, nullptr, b->d_qtot.as<uint64_t>(), s));
+    HIP_TRY(hipMemcpyAsync(b->q_lists.data(), b->d_qtot.p, nq * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    std::vector<uint64_t> qbase(nq);
+    uint64_t total_lists = 0;
+    for (uint32_t i = 0; i < nq; i++) {
+        qbase[i] = total_lists;
+        total_lists += b->q_lists[i];
+    }
+    if (total_lists >= 0xFFFFFFFFull) return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_pf_run: >= 2^32 similar k-mers in one batch; use smaller batches");
+    HIP_TRY(hipMemcpyAsync(b->d_qbase.p, qbase.data(), nq * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(launch_pf_scan(b->d_nsim.as<uint32_t>(), b->d_qoff.as<uint32_t>(), nq, b->d_qbase.as<uint64_t>(), b->d_list_base.as<uint32_t>(), nullptr, s));
+    b->last_lists = total_lists;
+    HIP_TRY(b->d_lists.reserve(std::max<uint64_t>(total_lists, 1) * sizeof(PfList)));
+    K.list_base = b->d_list_base.as<uint32_t>();
+    K.lists = b->d_lists.as<PfList>();
+    K.pos_entries = b->d_pos_entries.as<uint32_t>();
+    HIP_TRY(launch_pf_kmers(K, true, s));
+    HIP_TRY(launch_pf_scan(b->d_pos_entries.as<uint32_t>(), b->d_qoff.as<uint32_t>(), nq, nullptr, b->d_peb.as<uint32_t>(), b->d_qtot.as<uint64_t>(), s));
+    HIP_TRY(hipMemcpyAsync(b->q_entries.data(), b->d_qtot.p, nq * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));   // qbase (pageable) has been consumed, q_entries is valid
+    HIP_TRY(hipEventRecord(b->ev[1], s));
+
+    // ---- tiles ----
+    std::vector<uint32_t> qent(nq), qtb(nq), qnt(nq), tile_q, tile_idx;
+    std::vector<uint64_t> qebase(nq);
+    uint64_t total_entries = 0;
+    for (uint32_t i = 0; i < nq; i++) {
+        uint64_t e = b->q_entries[i];
+        if (e >= b->max_db_matches) {   // QueryMatcher.cpp:310: the reference would take its overflow path
+            b->status[i] = MMGPU_PF_OVERFLOW;
+            e = 0;
+        }
+        qent[i] = (uint32_t)e;
+        qebase[i] = total_entries;
+        total_entries += e;
+        qtb[i] = (uint32_t)tile_q.size();
+        qnt[i] = (uint32_t)((e + PF_T - 1) / PF_T);
+        for (uint32_t t = 0; t < qnt[i]; t++) {
+            tile_q.push_back(i);
+            tile_idx.push_back(t);
+        }
+    }
+    if (total_entries >= 0xFFFFFFFFull) return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_pf_run: >= 2^32 index entries in one batch; use smaller batches");
+    const uint32_t n_tiles = (uint32_t)tile_q.size();
+    b->last_tiles = n_tiles;
+    b->last_entries = total_entries;
+    const uint32_t B = b->bins;
+    HIP_TRY(hipMemcpyAsync(b->d_qentries.p, qent.data(), nq * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(b->d_qtile_base.p, qtb.data(), nq * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(b->d_qntiles.p, qnt.data(), nq * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(b->d_qbase.p, qebase.data(), nq * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(b->d_tile_q.reserve(std::max<size_t>(n_tiles, 1) * 4));
+    HIP_TRY(b->d_tile_idx.reserve(std::max<size_t>(n_tiles, 1) * 4));
+    if (n_tiles) {
+        HIP_TRY(hipMemcpyAsync(b->d_tile_q.p, tile_q.data(), (size_t)n_tiles * 4, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(b->d_tile_idx.p, tile_idx.data(), (size_t)n_tiles * 4, hipMemcpyHostToDevice, s));
+    }
+    HIP_TRY(b->d_split.reserve(std::max<size_t>(n_tiles, 1) * PF_T * sizeof(uint64_t)));
+    HIP_TRY(b->d_bin_off.reserve(std::max<size_t>(n_tiles, 1) * (B + 1) * sizeof(uint16_t)));
+    HIP_TRY(b->d_cand.reserve(std::max<uint64_t>(total_entries, 1) * sizeof(PfCand)));
+    HIP_TRY(b->d_surv.reserve(std::max<uint64_t>(total_entries, 1) * sizeof(PfCand)));
+    HIP_TRY(hipMemsetAsync(b->d_bucket_count.p, 0, (size_t)nq * B * 4, s));
+    HIP_TRY(hipMemsetAsync(b->d_surv_count.p, 0, (size_t)nq * 4, s));
+
+    // ---- stage 1: gather + stable split ----
+    PfSplitArgs SA;
+    SA.tile_q = b->d_tile_q.as<uint32_t>();
+    SA.tile_idx = b->d_tile_idx.as<uint32_t>();
+    SA.q_off = b->d_qoff.as<uint32_t>();
+    SA.q_entries = b->d_qentries.as<uint32_t>();
+    SA.pos_entry_base = b->d_peb.as<uint32_t>();
+    SA.list_base = b->d_list_base.as<uint32_t>();
+    SA.lists = b->d_lists.as<PfList>();
+    SA.idx_ids = P.d_ids.as<uint32_t>();
+    SA.idx_pos = P.d_pos.as<uint16_t>();
+    SA.bins = B;
+    SA.split = b->d_split.as<uint64_t>();
+    SA.bin_off = b->d_bin_off.as<uint16_t>();
+    SA.bucket_count = b->d_bucket_count.as<uint32_t>();
+    HIP_TRY(launch_pf_split(SA, n_tiles, s));
+    // cand_base[q * B + bin] = entries of earlier queries + entries of earlier bins of this query
+    {
+        std::vector<uint32_t> boff(nq + 1);
+        for (uint32_t i = 0; i <= nq; i++) boff[i] = i * B;
+        HIP_TRY(hipMemcpyAsync(b->d_bucket_off.p, boff.data(), (size_t)(nq + 1) * 4, hipMemcpyHostToDevice, s));
+        HIP_TRY(launch_pf_scan(b->d_bucket_count.as<uint32_t>(), b->d_bucket_off.as<uint32_t>(), nq, b->d_qbase.as<uint64_t>(),
+                               b->d_cand_base.as<uint32_t>(), nullptr, s));
+        HIP_TRY(hipStreamSynchronize(s));   // host vectors above are pageable
+    }
+    HIP_TRY(hipEventRecord(b->ev[2], s));
+
+    // ---- stage 2: replay, ungapped score, best element per target ----
+    PfDedupArgs D;
+    D.n_queries = nq;
+    D.bins = B;
+    D.q_tile_base = b->d_qtile_base.as<uint32_t>();
+    D.q_ntiles = b->d_qntiles.as<uint32_t>();
+    D.split = b->d_split.as<uint64_t>();
+    D.bin_off = b->d_bin_off.as<uint16_t>();
+    D.cand_base = b->d_cand_base.as<uint32_t>();
+    D.cand = b->d_cand.as<PfCand>();
+    D.surv = b->d_surv.as<PfCand>();
+    D.surv_count = b->d_surv_count.as<uint32_t>();
+    D.q_off = b->d_qoff.as<uint32_t>();
+    D.q_res = b->d_qres.as<uint8_t>();
+    D.q_corr = b->d_qcorr.as<int8_t>();
+    D.mat = P.d_mat.as<int8_t>();
+    D.alphabet = P.alphabet;
+    D.t_res = c->db.res;
+    D.t_off4 = c->db.off4;
+    D.t_len = c->db.len;
+    D.min_diag_score = b->par.min_diag_score;
+    HIP_TRY(launch_pf_dedup(D, s));
+    HIP_TRY(hipEventRecord(b->ev[3], s));
+
+    // ---- stage 3: top max_hits per query ----
+    PfSelectArgs S;
+    S.surv = b->d_surv.as<PfCand>();
+    S.surv_count = b->d_surv_count.as<uint32_t>();
+    S.q_identity = b->d_qident.as<uint32_t>();
+    S.q_self_score = b->d_qself.as<int32_t>();
+    S.max_hits = b->max_hits;
+    S.min_diag_score = b->par.min_diag_score;
+    S.ref_bins = b->ref_bins;
+    S.hits = b->d_hits.as<mmgpu_pf_hit>();
+    S.hit_stride = b->max_hits;
+    S.hit_count = b->d_hit_count.as<uint32_t>();
+    S.q_diag_thr = b->d_diag_thr.as<uint32_t>();
+    S.cand_base = b->d_cand_base.as<uint32_t>();
+    S.bins = B;
+    HIP_TRY(launch_pf_select(S, nq, s));
+    HIP_TRY(hipEventRecord(b->ev[4], s));
+    b->ran = true;
+    return MMGPU_OK;
+}
+
+extern "C" int mmgpu_pf_fetch(mmgpu_ctx *c, mmgpu_pf_batch_t *b, mmgpu_pf_hit *hits, uint32_t hit_stride, uint32_t *counts,
+                              int32_t *status, mmgpu_pf_qstat *stats) {
+    if (!c || !b || ((!hits || !counts) && b->nq)) return fail(MMGPU_ERR_ARG, "mmgpu_pf_fetch: NULL argument");
+    if (!b->ran) return fail(MMGPU_ERR_STATE, "mmgpu_pf_fetch: batch was never run");
+    if (hit_stride < b->max_hits) return fail(MMGPU_ERR_ARG, "mmgpu_pf_fetch: hit_stride smaller than min(max_hits, dbSize)");
+    const uint32_t nq = b->nq;
+    if (nq == 0) return MMGPU_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    std::vector<uint32_t> thr(nq), surv(nq);
+    HIP_TRY(hipMemcpy2DAsync(hits, (size_t)hit_stride * sizeof(mmgpu_pf_hit), b->d_hits.p, (size_t)b->max_hits * sizeof(mmgpu_pf_hit),
+                             (size_t)b->max_hits * sizeof(mmgpu_pf_hit), nq, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(counts, b->d_hit_count.p, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(thr.data(), b->d_diag_thr.p, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(surv.data(), b->d_surv_count.p, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    for (uint32_t i = 0; i < nq; i++) {
+        if (b->status[i] != MMGPU_PF_OK) counts[i] = 0;
+        if (status) status[i] = b->status[i];
+        if (stats) {
+            stats[i].db_matches = b->q_entries[i];
+            stats[i].kmer_list_len = b->q_lists[i];
+            stats[i].double_hits = surv[i];
+            stats[i].diag_thr = thr[i];
+        }
+    }
+    return MMGPU_OK;
+}
+
+extern "C" int mmgpu_pf_stage_ms(mmgpu_ctx *c, mmgpu_pf_batch_t *b, float ms[5]) {
+    if (!c || !b || !ms) return fail(MMGPU_ERR_ARG, "mmgpu_pf_stage_ms: NULL argument");
+    if (!b->ran || b->nq == 0) return fail(MMGPU_ERR_STATE, "mmgpu_pf_stage_ms: batch was never run");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventSynchronize(b->ev[4]));
+    for (int k = 0; k < 4; k++) HIP_TRY(hipEventElapsedTime(&ms[k], b->ev[k], b->ev[k + 1]));
+    HIP_TRY(hipEventElapsedTime(&ms[4], b->ev[0], b->ev[4]));
+    return MMGPU_OK;
+}
+
+extern "C" int mmgpu_pf_debug_fetch(mmgpu_ctx *c, mmgpu_pf_batch_t *b, int what, void *dst, size_t cap, size_t *bytes) {
+    if (!c || !b || !bytes) return fail(MMGPU_ERR_ARG, "mmgpu_pf_debug_fetch: NULL argument");
+    if (!b->ran) return fail(MMGPU_ERR_STATE, "mmgpu_pf_debug_fetch: batch was never run");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const void *src = nullptr;
+    size_t n = 0;
+    uint32_t binsv[2] = {b->bins, b->ref_bins};
+    switch (what) {
+        case MMGPU_PF_DBG_NSIM: src = b->d_nsim.p; n = (size_t)b->n_pos * 4; break;
+        case MMGPU_PF_DBG_LIST_BASE: src = b->d_list_base.p; n = ((size_t)b->n_pos + 1) * 4; break;
+        case MMGPU_PF_DBG_LISTS: src = b->d_lists.p; n = (size_t)b->last_lists * sizeof(PfList); break;
+        case MMGPU_PF_DBG_PEB: src = b->d_peb.p; n = ((size_t)b->n_pos + 1) * 4; break;
+        case MMGPU_PF_DBG_SPLIT: src = b->d_split.p; n = (size_t)b->last_tiles * PF_T * 8; break;
+        case MMGPU_PF_DBG_BIN_OFF: src = b->d_bin_off.p; n = (size_t)b->last_tiles * (b->bins + 1) * 2; break;
+        case MMGPU_PF_DBG_CAND_BASE: src = b->d_cand_base.p; n = ((size_t)b->nq * b->bins + 1) * 4; break;
+        case MMGPU_PF_DBG_SURV: src = b->d_surv.p; n = (size_t)b->last_entries * sizeof(PfCand); break;
+        case MMGPU_PF_DBG_SURV_COUNT: src = b->d_surv_count.p; n = (size_t)b->nq * 4; break;
+        case MMGPU_PF_DBG_BINS:
+            *bytes = sizeof(binsv);
+            if (dst && cap >= sizeof(binsv)) memcpy(dst, binsv, sizeof(binsv));
+            return MMGPU_OK;
+        default: return fail(MMGPU_ERR_ARG, "mmgpu_pf_debug_fetch: unknown buffer");
+    }
+    *bytes = n;
+    const size_t m = std::min(n, cap);
+    if (dst && m) HIP_TRY(hipMemcpy(dst, src, m, hipMemcpyDeviceToHost));
+    return MMGPU_OK;
+}
+
+extern "C" void mmgpu_pf_free(mmgpu_ctx *c, mmgpu_pf_batch_t *b) {
+    if (!b) return;
+    if (c) (void)hipSetDevice(c->device);
+    for (auto &e : b->ev)
+        if (e) (void)hipEventDestroy(e);
+    delete b;
+}
+
+extern "C" int mmgpu_pf_batch(mmgpu_ctx *c, const mmgpu_pf_params *par, const mmgpu_pf_query *qs, uint32_t nq,
+                              mmgpu_pf_hit *hits, uint32_t hit_stride, uint32_t *counts, int32_t *status) {
+    mmgpu_pf_batch_t *b = nullptr;
+    int rc = mmgpu_pf_prepare(c, par, qs, nq, &b);
+    if (rc != MMGPU_OK) return rc;
+    rc = mmgpu_pf_run(c, b);
+    if (rc == MMGPU_OK) rc = mmgpu_pf_fetch(c, b, hits, hit_stride, counts, status, nullptr);
+    mmgpu_pf_free(c, b);
+    return rc;
+}

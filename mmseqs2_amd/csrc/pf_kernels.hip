@@ -1,0 +1,722 @@
+// k-mer / double-diagonal / ungapped prefilter for gfx950 (CDNA4): device side.
+//
+// What it computes: QueryMatcher::matchQuery (src/prefiltering/QueryMatcher.cpp:103-241) for amino-acid
+// queries with diagonal scoring, bit for bit (hit set, scores, diagonals, order):
+//   a5  KmerGenerator::generateKmerList (KmerGenerator.cpp:108-184)            -> pf_kmers_kernel
+//   a6  QueryMatcher::match gather of index lists (QueryMatcher.cpp:243-376)    -> pf_kmers_kernel<true> + pf_split_kernel
+//   a7  CacheFriendlyOperations::findDuplicates (.cpp:38-49,185-278)            -> pf_dedup_kernel phase 1
+//   a8  UngappedAlignment::align (UngappedAlignment.cpp:36-57,423-437)          -> pf_dedup_kernel phase 2
+//   a9  keepMaxElement (.cpp:354-384), computeScoreThreshold (QueryMatcher.h:211-221),
+//       radixSortByScoreSize/rescoreHits/getResult (QueryMatcher.cpp:401-458,536-586), final sort -> pf_dedup_kernel
+//       phase 3 + pf_select_kernel
+//
+// The CPU algorithm is order dependent: the "double hit" test compares the low 8 bits
+// of the diagonal of CONSECUTIVE index entries of one target in arrival order (query position, then similar
+// k-mer rank, then index order), and ties at the --max-seqs cut are broken by the CPU's bin order.  The mapping
+// below keeps that order without ever sorting the ~4e5 entries a query touches:
+//   * similar k-mers and their index lists are enumerated by one wavefront per query position, in the reference's
+//     order, and laid out by prefix sums, so every index entry has a well defined ARRIVAL INDEX;
+//   * the arrival stream of a query is cut into tiles of PF_T entries; one workgroup gathers a tile (random 6-byte
+//     index reads, the HBM-bound part), splits it STABLY into B bins by target id (id & (B-1), like the CPU's
+//     cache bins but sized for LDS: <= 4096 targets per bin) in LDS and writes it out grouped by bin;
+//   * one wavefront per (query, bin) then replays its bin in arrival order with the CPU's own state machine held
+//     in a 16 KB LDS table (previous diagonal / last emitted diagonal per target); equal targets inside one
+//     64-entry round are resolved with ballot matching, so the sequential semantics are exact;
+//   * the same wavefront scores its candidates (ungapped Kadane on the diagonal) and keeps one best element per
+//     target; a workgroup per query selects the top max_hits by (score, CPU bin order, arrival index) with a
+//     radix select and sorts them.
+// Integer/byte work throughout: no MFMA; the rooflines are HBM (gather, split) and LDS/VALU issue (replay).
+#include "mmgpu_internal.h"
+
+namespace mmgpu {
+
+namespace {
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
+__device__ __forceinline__ uint64_t lanes_below(int lane) { return (1ull << lane) - 1ull; }
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+    const int lane = lane_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(v, d);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+// Largest lane m with start[m] <= x, for per-lane non-decreasing `start` with start[0] <= x.  Every lane of
+// the wave must call this (it shuffles).
+__device__ __forceinline__ int seg_find(uint32_t start_mine, uint32_t x) {
+    int lo = 0;
+#pragma unroll
+    for (int step = 32; step >= 1; step >>= 1) {
+        const uint32_t s = __shfl(start_mine, lo + step);
+        if (s <= x) lo += step;
+    }
+    return lo;
+}
+
+// Lanes of the wave whose `key` (low nbits) equals mine, among lanes with active == true.
+__device__ __forceinline__ uint64_t match_lanes(uint32_t key, int nbits, bool active) {
+    uint64_t m = __ballot(active);
+    for (int b = 0; b < nbits; b++) {
+        const bool bit = (key >> b) & 1u;
+        const uint64_t bal = __ballot(bit && active);
+        m &= bit ? bal : ~bal;
+    }
+    return m;
+}
+
+__device__ __forceinline__ int highest_lane(uint64_t m) { return 63 - __clzll((long long)m); }
+
+// ---------------------------------------------------------------------------------------------------------
+// a5 + first half of a6: one wavefront per query position.
+//   EMIT = false: nsim[gp] = number of similar k-mers of the window starting at gp
+//   EMIT = true : lists[list_base[gp] + r] = index list of the r-th similar k-mer, pos_entries[gp] = sum of lengths
+// k = 6: the k-mer splits into two 3-mers (KmerGenerator::setDivideStrategy, KmerGenerator.cpp:42-87); row A / row B
+// are the score-sorted 3-mer rows of the first / last three window residues.  Order of the output list:
+// i over row A while sA[i] >= thr - sB[0], j over row B while sB[j] >= thr - sA[i]  (calculateArrayProduct :187-216).
+template <bool EMIT>
+__global__ __launch_bounds__(256) void pf_kmers_kernel(PfKmerArgs A) {
+    const int lane = lane_id();
+    const uint32_t gp = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (gp >= A.n_pos) return;
+    const int thr = A.q_thr[gp];
+    if (thr < 0) {   // no window here, or the window contains X (QueryMatcher.cpp:264-268)
+        if (lane == 0) {
+            if (EMIT) A.pos_entries[gp] = 0; else A.nsim[gp] = 0;
+        }
+        return;
+    }
+    const uint8_t *q = A.q_res + gp;
+    const uint32_t ka = A.kalph;
+    const uint32_t rowA = q[A.pat[0]] + ka * (q[A.pat[1]] + ka * q[A.pat[2]]);
+    const uint32_t rowB = q[A.pat[3]] + ka * (q[A.pat[4]] + ka * q[A.pat[5]]);
+    const uint32_t n3 = A.n3;
+    const int16_t *sA = A.s3 + (size_t)rowA * n3;
+    const uint32_t *iA = A.i3 + (size_t)rowA * n3;
+    const int16_t *sB = A.s3 + (size_t)rowB * n3;
+    const uint32_t *iB = A.i3 + (size_t)rowB * n3;
+    const int cutoff1 = (int)(short)(thr - (int)sB[0]);
+    uint32_t nlists = 0, running = 0;
+    uint32_t lbase = 0;
+    if (EMIT) lbase = A.list_base[gp];
+    for (uint32_t c0 = 0; c0 < n3; c0 += 64) {
+        const uint32_t ia = c0 + (uint32_t)lane;
+        const int sc = ia < n3 ? (int)sA[ia] : -32768;
+        const bool inA = ia < n3 && sc >= cutoff1;
+        const uint64_t bal = __ballot(inA);
+        if (bal == 0) break;
+        uint32_t ni = 0;
+        if (inA) {
+            const int cutoff2 = (int)(short)(thr - sc);
+            uint32_t lo = 0, hi = n3;   // first j with sB[j] < cutoff2 (row sorted descending)
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if ((int)sB[mid] >= cutoff2) lo = mid + 1; else hi = mid;
+            }
+            ni = lo;
+        }
+        const uint32_t incl = wave_incl_scan(ni);
+        const uint32_t total = __shfl(incl, 63);
+        if (EMIT) {
+            const uint32_t excl = incl - ni;
+            const uint32_t my_idx = inA ? iA[ia] : 0u;
+            for (uint32_t r0 = 0; r0 < total; r0 += 64) {
+                const uint32_t x = r0 + (uint32_t)lane;
+                const bool act = x < total;
+                const int m = seg_find(excl, x);
+                const uint32_t ex_m = __shfl(excl, m);
+                const uint32_t k_a = __shfl(my_idx, m);
+                uint32_t start = 0, len = 0;
+                if (act) {
+                    const uint32_t kmer = k_a + iB[x - ex_m] * n3;
+                    start = A.offsets[kmer];
+                    len = A.offsets[kmer + 1] - start;
+                }
+                const uint32_t li = wave_incl_scan(len);
+                if (act) {
+                    PfList rec;
+                    rec.start = start;
+                    rec.len = len;
+                    rec.lprefix = running + li - len;
+                    rec.pos = gp;
+                    A.lists[(size_t)lbase + nlists + x] = rec;
+                }
+                running += __shfl(li, 63);
+            }
+        }
+        nlists += total;
+        if (bal != ~0ull) break;
+    }
+    if (lane == 0) {
+        if (EMIT) A.pos_entries[gp] = running; else A.nsim[gp] = nlists;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Exclusive scan of in[q_off[q] .. q_off[q+1]) per query (one workgroup per query), written relative to the query
+// (+ base[q] when base != nullptr); totals[q] = the query's sum (64-bit).  out has one extra element per batch:
+// the last workgroup also writes out[n_pos] = base[nq-1] + total so that out[gp+1] is valid for every gp.
+__global__ __launch_bounds__(256) void pf_scan_kernel(const uint32_t *in, const uint32_t *q_off, uint32_t nq,
+                                                      const uint64_t *base, uint32_t *out, uint64_t *totals) {
+    __shared__ uint32_t wsum[4];
+    __shared__ uint64_t carry_s;
+    const uint32_t q = blockIdx.x;
+    const uint32_t p0 = q_off[q], p1 = q_off[q + 1];
+    const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    const uint64_t b = base ? base[q] : 0ull;
+    for (uint32_t c = p0; c < p1; c += 256) {
+        const uint32_t i = c + threadIdx.x;
+        const uint32_t v = i < p1 ? in[i] : 0u;
+        const uint32_t incl = wave_incl_scan(v);
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int w = 0; w < wave; w++) woff += wsum[w];
+        const uint64_t carry = carry_s;
+        if (i < p1 && out) out[i] = (uint32_t)(b + carry + woff + incl - v);
+        __syncthreads();
+        if (threadIdx.x == 255) carry_s = carry + woff + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (totals) totals[q] = carry_s;
+        if (out && q == nq - 1) out[p1] = (uint32_t)(b + carry_s);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// second half of a6 + hashIndexEntry (CacheFriendlyOperations.cpp:341-351): one workgroup per tile of PF_T
+// arrival-ordered index entries of one query.  Gathers (seqId, position_j) -> (id, diagonal = i - j), splits the
+// tile stably by bin = id & (B-1), writes it grouped by bin plus the B+1 bin offsets of the tile.
+// Entry word: id | diagonal << 32 | slot-in-tile << 48  (slot = arrival index - tile start).
+__global__ __launch_bounds__(256) void pf_split_kernel(PfSplitArgs A) {
+    __shared__ uint64_t stage[PF_T];
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+    uint32_t *cnt = reinterpret_cast<uint32_t *>(dyn_lds);   // [4][B]
+    __shared__ uint32_t wsum[4];
+    const uint32_t B = A.bins;
+    const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
+    const uint32_t t = blockIdx.x;
+    const uint32_t q = A.tile_q[t];
+    const uint32_t a0 = A.tile_idx[t] * (uint32_t)PF_T;
+    const uint32_t q_entries = A.q_entries[q];
+    const uint32_t tile_n = min((uint32_t)PF_T, q_entries - a0);
+    const uint32_t qp0 = A.q_off[q], qlen = A.q_off[q + 1] - qp0;
+
+    for (uint32_t k = threadIdx.x; k < 4 * B; k += 256) cnt[k] = 0;
+
+    // ---- phase A: gather this wave's quarter of the tile into `stage`, arrival order ----
+    const uint32_t wa = a0 + (uint32_t)wave * (PF_T / 4);
+    const uint32_t wb = min(a0 + tile_n, wa + PF_T / 4);
+    if (wa < wb) {
+        // position holding arrival index wa: largest p with peb[p] <= wa
+        uint32_t lo = 0, hi = qlen - 1;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi + 1) >> 1;
+            if (A.pos_entry_base[qp0 + mid] <= wa) lo = mid; else hi = mid - 1;
+        }
+        const uint32_t gp = qp0 + lo;
+        const uint32_t rel = wa - A.pos_entry_base[gp];
+        uint32_t l0 = A.list_base[gp], l1 = A.list_base[gp + 1] - 1;
+        while (l0 < l1) {   // largest list of this position with lprefix <= rel
+            const uint32_t mid = (l0 + l1 + 1) >> 1;
+            if (A.lists[mid].lprefix <= rel) l0 = mid; else l1 = mid - 1;
+        }
+        uint32_t L = l0;
+        const uint32_t Lend = A.list_base[qp0 + qlen];
+        uint32_t cur = wa;
+        while (cur < wb) {
+            const uint32_t ri = L + (uint32_t)lane;
+            const bool valid = ri < Lend;
+            PfList r;
+            r.start = 0; r.len = 0; r.lprefix = 0; r.pos = qp0;
+            if (valid) r = A.lists[ri];
+            const uint32_t es = valid ? A.pos_entry_base[r.pos] + r.lprefix : 0xFFFFFFFFu;
+            const uint32_t ee = es + r.len;
+            const uint32_t nvalid = min(64u, Lend - L);
+            const uint32_t chunk_end = min(wb, (uint32_t)__shfl(ee, (int)nvalid - 1));
+            for (uint32_t x0 = cur; x0 < chunk_end; x0 += 64) {
+                const uint32_t x = x0 + (uint32_t)lane;
+                const bool act = x < chunk_end;
+                const int m = seg_find(es, x);
+                const uint32_t es_m = __shfl(es, m);
+                const uint32_t st_m = __shfl(r.start, m);
+                const uint32_t gp_m = __shfl(r.pos, m);
+                if (act) {
+                    const uint32_t e = st_m + (x - es_m);
+                    const uint32_t id = A.idx_ids[e];
+                    const uint32_t j = A.idx_pos[e];
+                    const uint32_t diag = ((gp_m - qp0) - j) & 0xFFFFu;
+                    const uint32_t slot = x - a0;
+                    stage[slot] = (uint64_t)id | ((uint64_t)diag << 32) | ((uint64_t)slot << 48);
+                }
+            }
+            if (chunk_end > cur) cur = chunk_end;
+            L += 64;
+            if (L >= Lend) break;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase B: per-(wave, bin) counts and each entry's rank inside its (wave, bin) ----
+    int nbits = 0;
+    while ((1u << nbits) < B) nbits++;
+    uint64_t ent[16];
+    uint32_t rk[16];
+    uint32_t *mycnt = cnt + (uint32_t)wave * B;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const uint32_t slot = (uint32_t)wave * (PF_T / 4) + (uint32_t)r * 64u + (uint32_t)lane;
+        const bool valid = slot < tile_n;
+        ent[r] = valid ? stage[slot] : 0ull;
+        const uint32_t bin = (uint32_t)ent[r] & (B - 1);
+        const uint64_t m = match_lanes(bin, nbits, valid);
+        const uint32_t rank = (uint32_t)__popcll(m & lanes_below(lane));
+        uint32_t c = 0;
+        if (valid) c = mycnt[bin];
+        rk[r] = c + rank;
+        if (valid && rank == 0) mycnt[bin] = c + (uint32_t)__popcll(m);
+    }
+    __syncthreads();
+
+    // ---- scan: bin totals -> tile bin offsets; cnt[w][b] becomes the absolute start of (bin b, wave w) ----
+    {
+        const uint32_t bpt = B >= 256 ? B / 256 : 1;   // bins per thread, contiguous
+        const uint32_t b0 = threadIdx.x * bpt;
+        uint32_t s = 0;
+        if (b0 < B)
+            for (uint32_t b = b0; b < b0 + bpt; b++)
+                for (int w = 0; w < 4; w++) s += cnt[(uint32_t)w * B + b];
+        const uint32_t incl = wave_incl_scan(s);
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        uint32_t run = incl - s;
+        for (int w = 0; w < wave; w++) run += wsum[w];
+        if (b0 < B) {
+            uint16_t *bo = A.bin_off + (size_t)t * (B + 1);
+            for (uint32_t b = b0; b < b0 + bpt; b++) {
+                bo[b] = (uint16_t)run;
+                uint32_t tot = 0;
+                for (int w = 0; w < 4; w++) {
+                    const uint32_t c = cnt[(uint32_t)w * B + b];
+                    cnt[(uint32_t)w * B + b] = run + tot;
+                    tot += c;
+                }
+                if (tot) atomicAdd(&A.bucket_count[(size_t)q * B + b], tot);
+                run += tot;
+            }
+            if (b0 + bpt == B) bo[B] = (uint16_t)run;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase C: stable scatter inside LDS (every entry is in a register now), then coalesced write-out ----
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const uint32_t slot = (uint32_t)wave * (PF_T / 4) + (uint32_t)r * 64u + (uint32_t)lane;
+        if (slot < tile_n) {
+            const uint32_t bin = (uint32_t)ent[r] & (B - 1);
+            stage[mycnt[bin] + rk[r]] = ent[r];
+        }
+    }
+    __syncthreads();
+    uint64_t *dst = A.split + (size_t)t * PF_T;
+    for (uint32_t s = threadIdx.x; s < tile_n; s += 256) dst[s] = stage[s];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// a7 + a8 + keepMaxElement: one wavefront per (query, bin), four per workgroup.
+//
+// Phase 1 replays the bin's entries in arrival order.  Per target the CPU keeps `prev` = low byte of the previous
+// entry's diagonal (zero-initialised, CacheFriendlyOperations.cpp:186-208) and emits an entry whose byte equals it;
+// the emitted list is then run-length de-duplicated per target on that byte (:240-265).  State word per target:
+// bits 0-7 prev, 8-15 last emitted byte, bit 16 "has emitted".
+// Phase 2: ungapped score of every candidate (scalarDiagonalScoring, UngappedAlignment.cpp:45-57; overlap as in
+// computeSingelSequenceScores :423-437).
+// Phase 3: per target keep the first candidate (bin order = arrival order) whose count = min(255, score) is the
+// target's maximum (keepMaxElement, .cpp:354-384); survivors with count >= min_diag_score go to the query's list.
+__global__ __launch_bounds__(256) void pf_dedup_kernel(PfDedupArgs A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+    __shared__ int8_t smat[32 * 32];
+    const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
+    for (int k = (int)threadIdx.x; k < A.alphabet * A.alphabet; k += 256) smat[k] = A.mat[k];
+    __syncthreads();
+    const uint32_t B = A.bins;
+    const uint64_t bucket = (uint64_t)blockIdx.x * 4u + (uint32_t)wave;
+    if (bucket >= (uint64_t)A.n_queries * B) return;
+    const uint32_t q = (uint32_t)(bucket / B), bin = (uint32_t)(bucket % B);
+    const uint32_t ntiles = A.q_ntiles[q];
+    if (ntiles == 0) return;
+    const uint32_t tb = A.q_tile_base[q];
+    uint32_t *S = reinterpret_cast<uint32_t *>(dyn_lds) + (size_t)wave * PF_IDS_PER_BIN;
+    int bshift = 0;
+    while ((1u << bshift) < B) bshift++;
+    for (int k = lane; k < PF_IDS_PER_BIN; k += 64) S[k] = 0;
+
+    PfCand *cand = A.cand + A.cand_base[bucket];
+    uint32_t ncand = 0;
+    // ---- phase 1 ----
+    for (uint32_t t0 = 0; t0 < ntiles; t0 += 64) {
+        const uint32_t tl = t0 + (uint32_t)lane;
+        uint32_t o0 = 0, n = 0;
+        if (tl < ntiles) {
+            const uint16_t *bo = A.bin_off + (size_t)(tb + tl) * (B + 1) + bin;
+            o0 = bo[0];
+            n = (uint32_t)bo[1] - o0;
+        }
+        const uint32_t incl = wave_incl_scan(n);
+        const uint32_t total = __shfl(incl, 63);
+        const uint32_t excl = incl - n;
+        for (uint32_t x0 = 0; x0 < total; x0 += 64) {
+            const uint32_t x = x0 + (uint32_t)lane;
+            const bool act = x < total;
+            const int m = seg_find(excl, x);
+            const uint32_t ex_m = __shfl(excl, m);
+            const uint32_t o_m = __shfl(o0, m);
+            uint64_t e = 0;
+            if (act) e = A.split[(size_t)(tb + t0 + (uint32_t)m) * PF_T + o_m + (x - ex_m)];
+            const uint32_t id = (uint32_t)e;
+            const uint32_t diag = (uint32_t)(e >> 32) & 0xFFFFu;
+            const uint32_t d8 = diag & 0xFFu;
+            const uint32_t key = id >> bshift;   // < PF_IDS_PER_BIN
+            const uint64_t same = match_lanes(key, 12, act);
+            const uint64_t below = lanes_below(lane);
+            uint32_t st = 0;
+            if (act) st = S[key];
+            // stage 1: does my diagonal byte equal the previous entry's of this target?
+            const uint64_t pm = same & below;
+            const int pl = pm ? highest_lane(pm) : lane;
+            const uint32_t d_pl = __shfl(d8, pl);
+            const uint32_t prevd = pm ? d_pl : (st & 0xFFu);
+            const bool flag = act && d8 == prevd;
+            // stage 2: run-length de-duplication over the flagged entries of this target
+            const uint64_t fl = __ballot(flag);
+            const uint64_t fm = same & fl;
+            const uint64_t fbelow = fm & below;
+            const int fpl = fbelow ? highest_lane(fbelow) : lane;
+            const uint32_t d_fpl = __shfl(d8, fpl);
+            bool keep;
+            if (fbelow) keep = flag && d_fpl != d8;
+            else keep = flag && (((st >> 16) & 1u) == 0u || ((st >> 8) & 0xFFu) != d8);
+            // state update by the last lane of every target group
+            const int fhi = fm ? highest_lane(fm) : lane;
+            const uint32_t d_fhi = __shfl(d8, fhi);
+            if (act && (same & ~below & ~(1ull << lane)) == 0) {
+                uint32_t ns = d8;
+                if (fm) ns |= (d_fhi << 8) | (1u << 16);
+                else ns |= st & 0x1FF00u;
+                S[key] = ns;
+            }
+            const uint64_t kb = __ballot(keep);
+            if (keep) {
+                PfCand c;
+                c.id = id;
+                c.arr = (t0 + (uint32_t)m) * (uint32_t)PF_T + (uint32_t)(e >> 48);
+                c.score = 0;
+                c.diag = (uint16_t)diag;
+                c.pad = 0;
+                cand[ncand + (uint32_t)__popcll(kb & below)] = c;
+            }
+            ncand += (uint32_t)__popcll(kb);
+        }
+    }
+    if (ncand == 0) return;
+    __threadfence();   // phase 2 reads candidates written by other lanes of this wave
+
+    // ---- phase 2: ungapped diagonal score, one candidate per lane ----
+    const uint32_t qp0 = A.q_off[q];
+    const int qlen = (int)(A.q_off[q + 1] - qp0);
+    const uint8_t *qr = A.q_res + qp0;
+    const int8_t *qc = A.q_corr + qp0;
+    const int alph = A.alphabet;
+    for (uint32_t c0 = 0; c0 < ncand; c0 += 64) {
+        const uint32_t ci = c0 + (uint32_t)lane;
+        if (ci < ncand) {
+            const uint32_t id = cand[ci].id;
+            const int d = (int)(short)cand[ci].diag;
+            const int tlen = (int)A.t_len[id];
+            const uint8_t *t = A.t_res + (size_t)A.t_off4[id] * 4;
+            int len = 0, qs = 0, ts = 0;
+            const int mind = d < 0 ? -d : d;
+            if (d >= 0 && mind < qlen) {
+                len = min(tlen, qlen - mind);
+                qs = mind;
+            } else if (d < 0 && mind < tlen) {
+                len = min(tlen - mind, qlen);
+                ts = mind;
+            }
+            int score = 0, mx = 0;
+            for (int p = 0; p < len; p++) {
+                const int sc = (int)(int8_t)(smat[(int)qr[qs + p] * alph + (int)t[ts + p]] + qc[qs + p]);
+                score += sc;
+                score = score < 0 ? 0 : score;
+                mx = score > mx ? score : mx;
+            }
+            cand[ci].score = (uint32_t)mx;
+        }
+    }
+    __threadfence();
+
+    // ---- phase 3: best element per target ----
+    for (int k = lane; k < PF_IDS_PER_BIN; k += 64) S[k] = 0;
+    for (uint32_t c0 = 0; c0 < ncand; c0 += 64) {
+        const uint32_t ci = c0 + (uint32_t)lane;
+        if (ci < ncand) {
+            const uint32_t cnt = min(255u, cand[ci].score);
+            const uint32_t k2 = (cnt << 24) | (0xFFFFFFu - min(ci, 0xFFFFFEu));
+            atomicMax(&S[cand[ci].id >> bshift], k2);
+        }
+    }
+    PfCand *surv = A.surv + A.cand_base[(uint64_t)q * B];
+    for (uint32_t c0 = 0; c0 < ncand; c0 += 64) {
+        const uint32_t ci = c0 + (uint32_t)lane;
+        bool win = false;
+        PfCand c;
+        c.id = 0; c.arr = 0; c.score = 0; c.diag = 0; c.pad = 0;
+        if (ci < ncand) {
+            c = cand[ci];
+            const uint32_t cnt = min(255u, c.score);
+            const uint32_t k2 = (cnt << 24) | (0xFFFFFFu - min(ci, 0xFFFFFEu));
+            win = S[c.id >> bshift] == k2 && cnt >= A.min_diag_score;
+        }
+        const uint64_t wb = __ballot(win);
+        if (wb) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&A.surv_count[q], (uint32_t)__popcll(wb));
+            base = __shfl(base, 0);
+            if (win) surv[base + (uint32_t)__popcll(wb & lanes_below(lane))] = c;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// a9: one workgroup per query over the query's surviving elements (one per target).
+__device__ __forceinline__ uint32_t rescaled_count(uint32_t score, float fms) {
+    // rescoreHits, QueryMatcher.cpp:576-581
+    const uint32_t ns = score - 255u;
+    const float sc = (float)min(ns, 65535u);
+    const float r = __fmul_rn(__fdiv_rn(sc, fms), 255.0f);
+    const double dd = (double)r + 0.5;
+    return (uint32_t)(int)dd & 0xFFu;
+}
+
+__global__ __launch_bounds__(256) void pf_select_kernel(PfSelectArgs A) {
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t sh_thr, sh_trunc, sh_nelig, sh_nsel;
+    __shared__ uint64_t sh_prefix, sh_mask;
+    __shared__ uint32_t sh_remaining;
+    __shared__ uint64_t skey[PF_MAX_HITS];
+    __shared__ uint16_t sdiag[PF_MAX_HITS];
+    const uint32_t q = blockIdx.x;
+    const uint32_t n = A.surv_count[q];
+    const PfCand *S = A.surv + A.cand_base[(uint64_t)q * A.bins];
+    const uint32_t ident = A.q_identity[q];
+    const uint32_t max_hits = A.max_hits;   // already min(maxHitsPerQuery, dbSize)
+    mmgpu_pf_hit *out = A.hits + (size_t)q * A.hit_stride;
+
+    for (int k = (int)threadIdx.x; k < 256; k += 256) hist[k] = 0;
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < n; k += 256) atomicAdd(&hist[min(255u, S[k].score)], 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // computeScoreThreshold, QueryMatcher.h:211-221
+        uint32_t found = 0, thr = 0;
+        for (thr = 255; thr > 0; thr--) {
+            found += hist[thr];
+            if (found >= max_hits) break;
+        }
+        const uint32_t dthr = max(A.min_diag_score, thr);
+        sh_thr = dthr;
+        sh_trunc = dthr >= 255u ? 1u : 0u;
+        sh_nelig = 0;
+        sh_nsel = 0;
+    }
+    __syncthreads();
+    const uint32_t dthr = sh_thr;
+    const bool trunc = sh_trunc != 0;
+    int ms = A.q_self_score[q] - 255;
+    ms = ms > 1 ? ms : 1;
+    ms = ms < 65535 ? ms : 65535;
+    const float fms = (float)ms;
+    const uint32_t refmask = A.ref_bins - 1;
+
+    // sort key of an element: (255 - count) : bin of the reference's CacheFriendlyOperations : arrival index
+    auto key_of = [&](const PfCand &c, bool *elig) -> uint64_t {
+        const uint32_t cnt = min(255u, c.score);
+        uint32_t kc;
+        if (trunc) {
+            *elig = cnt >= 255u && c.id != ident;
+            kc = rescaled_count(c.score, fms);
+        } else {
+            *elig = cnt >= dthr && c.id != ident;
+            kc = cnt;
+        }
+        return ((uint64_t)(255u - kc) << 43) | ((uint64_t)(c.id & refmask) << 32) | (uint64_t)c.arr;
+    };
+
+    uint32_t mine = 0;
+    for (uint32_t k = threadIdx.x; k < n; k += 256) {
+        bool el;
+        (void)key_of(S[k], &el);
+        mine += el ? 1u : 0u;
+    }
+    if (mine) atomicAdd(&sh_nelig, mine);
+    __syncthreads();
+    const uint32_t nelig = sh_nelig;
+    const uint32_t has_ident = ident != 0xFFFFFFFFu ? 1u : 0u;
+    const uint32_t want = max_hits > has_ident ? max_hits - has_ident : 0u;
+
+    // radix select of the `want` smallest keys (keys are unique: the arrival index is)
+    uint64_t kstar = ~0ull;
+    if (nelig > want && want > 0) {
+        if (threadIdx.x == 0) {
+            sh_prefix = 0;
+            sh_mask = 0;
+            sh_remaining = want;
+        }
+        __syncthreads();
+        for (int shift = 48; shift >= 0; shift -= 8) {
+            for (int k = (int)threadIdx.x; k < 256; k += 256) hist[k] = 0;
+            __syncthreads();
+            const uint64_t prefix = sh_prefix, mask = sh_mask;
+            for (uint32_t k = threadIdx.x; k < n; k += 256) {
+                bool el;
+                const uint64_t key = key_of(S[k], &el);
+                if (el && (key & mask) == prefix) atomicAdd(&hist[(uint32_t)(key >> shift) & 0xFFu], 1u);
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                uint32_t rem = sh_remaining, cum = 0, d = 0;
+                for (d = 0; d < 256; d++) {
+                    if (cum + hist[d] >= rem) break;
+                    cum += hist[d];
+                }
+                sh_remaining = rem - cum;
+                sh_prefix = prefix | ((uint64_t)d << shift);
+                sh_mask = mask | (0xFFull << shift);
+            }
+            __syncthreads();
+        }
+        kstar = sh_prefix;
+    }
+    __syncthreads();
+
+    // gather the selected elements, compute prefScore (getResult, QueryMatcher.cpp:430-452)
+    if (want > 0) {
+        for (uint32_t k = threadIdx.x; k < n; k += 256) {
+            bool el;
+            const PfCand c = S[k];
+            const uint64_t key = key_of(c, &el);
+            if (el && key <= kstar) {
+                const uint32_t slot = atomicAdd(&sh_nsel, 1u);
+                if (slot < PF_MAX_HITS) {
+                    uint32_t pref;
+                    const uint32_t cnt = min(255u, c.score);
+                    if (trunc) pref = 255u + (rescaled_count(c.score, fms) * (uint32_t)ms / 255u);
+                    else pref = cnt >= 255u ? c.score : cnt;
+                    skey[slot] = ((uint64_t)(0xFFFFFFFFu - pref) << 32) | (uint64_t)c.id;
+                    sdiag[slot] = c.diag;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t nsel = min(sh_nsel, (uint32_t)PF_MAX_HITS);
+    // bitonic sort by (prefScore desc, id asc)   (hit_t::compareHitsByScoreAndId, QueryMatcher.h:38-49)
+    uint32_t np2 = 1;
+    while (np2 < nsel) np2 <<= 1;
+    for (uint32_t k = nsel + threadIdx.x; k < np2; k += 256) {
+        skey[k] = ~0ull;
+        sdiag[k] = 0;
+    }
+    __syncthreads();
+    for (uint32_t size = 2; size <= np2; size <<= 1) {
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            for (uint32_t k = threadIdx.x; k < np2 / 2; k += 256) {
+                const uint32_t i = 2 * k - (k & (stride - 1));
+                const uint32_t j = i + stride;
+                const bool up = (i & size) == 0;
+                const uint64_t a = skey[i], b = skey[j];
+                if ((a > b) == up) {
+                    skey[i] = b;
+                    skey[j] = a;
+                    const uint16_t t = sdiag[i];
+                    sdiag[i] = sdiag[j];
+                    sdiag[j] = t;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (uint32_t k = threadIdx.x; k < nsel; k += 256) {
+        mmgpu_pf_hit h;
+        h.id = (uint32_t)skey[k];
+        h.score = (int32_t)(0xFFFFFFFFu - (uint32_t)(skey[k] >> 32));
+        h.diagonal = sdiag[k];
+        h.reserved = 0;
+        out[has_ident + k] = h;
+    }
+    if (threadIdx.x == 0) {
+        if (has_ident && max_hits > 0) {   // self hit first, score USHRT_MAX (getResult :408-424)
+            mmgpu_pf_hit h;
+            h.id = ident;
+            h.score = 65535;
+            h.diagonal = 0;
+            h.reserved = 0;
+            out[0] = h;
+        }
+        A.hit_count[q] = (max_hits > 0 ? has_ident : 0u) + nsel;
+        A.q_diag_thr[q] = dthr | (trunc ? 0x80000000u : 0u);
+    }
+}
+
+}  // namespace
+
+hipError_t launch_pf_kmers(const PfKmerArgs &A, bool emit, hipStream_t s) {
+    if (A.n_pos == 0) return hipSuccess;
+    const dim3 grid((A.n_pos + 3) / 4), block(256);
+    if (emit) hipLaunchKernelGGL(pf_kmers_kernel<true>, grid, block, 0, s, A);
+    else hipLaunchKernelGGL(pf_kmers_kernel<false>, grid, block, 0, s, A);
+    return hipGetLastError();
+}
+
+hipError_t launch_pf_scan(const uint32_t *in, const uint32_t *q_off, uint32_t nq, const uint64_t *base, uint32_t *out,
+                          uint64_t *totals, hipStream_t s) {
+    if (nq == 0) return hipSuccess;
+    hipLaunchKernelGGL(pf_scan_kernel, dim3(nq), dim3(256), 0, s, in, q_off, nq, base, out, totals);
+    return hipGetLastError();
+}
+
+hipError_t launch_pf_split(const PfSplitArgs &A, uint32_t n_tiles, hipStream_t s) {
+    if (n_tiles == 0) return hipSuccess;
+    hipLaunchKernelGGL(pf_split_kernel, dim3(n_tiles), dim3(256), 4 * A.bins * sizeof(uint32_t), s, A);
+    return hipGetLastError();
+}
+
+hipError_t launch_pf_dedup(const PfDedupArgs &A, hipStream_t s) {
+    const uint64_t buckets = (uint64_t)A.n_queries * A.bins;
+    if (buckets == 0) return hipSuccess;
+    const size_t lds = 4 * PF_IDS_PER_BIN * sizeof(uint32_t);   // 64 KB of state tables + 1 KB static
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(pf_dedup_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(pf_dedup_kernel, dim3((unsigned)((buckets + 3) / 4)), dim3(256), lds, s, A);
+    return hipGetLastError();
+}
+
+hipError_t launch_pf_select(const PfSelectArgs &A, uint32_t nq, hipStream_t s) {
+    if (nq == 0) return hipSuccess;
+    hipLaunchKernelGGL(pf_select_kernel, dim3(nq), dim3(256), 0, s, A);
+    return hipGetLastError();
+}
+
+}  // namespace mmgpu

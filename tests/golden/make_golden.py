@@ -8,6 +8,8 @@ by `make -C oracle ref` from /root/reference).  Runs only where /root/reference 
 matrices.npz : the integer substitution matrices the reference derives from data/*.out
                (BaseMatrix::generateSubMatrix, BaseMatrix.cpp:141-154) and its background pBack
 sw_vectors.npz : (query, target) pairs with the reference's s_align fields in modes 0/1/2
+prefilter_vectors.npz : queries + targets with the hit_t lists QueryMatcher::matchQuery returns (real reference
+               classes through oracle/ref_shim_pref.cpp) for several (max_hits, bin count) settings
 """
 import os
 import sys
@@ -89,6 +91,49 @@ def sw_vectors(ref):
     print("sw_vectors.npz", n, "pairs; word-mode:", int(np.array(rows)[:, 5].sum()))
 
 
+def prefilter_vectors():
+    from oracle.pyoracle import RefPrefilter, Oracle, kmer_threshold
+    rng = np.random.default_rng(20260923)
+    k, sens = 6, 5.7
+    ref = RefPrefilter(k)
+    km8, um8, km16, pback = ref.matrices()
+    (qres, qoff), (tres, toff) = wl.config2_align_only(24, 1500, planted_frac=0.4, seed=31)
+    tres, qres = tres.copy(), qres.copy()
+    tres[rng.choice(len(tres), len(tres) // 400, replace=False)] = 20     # some X
+    qres[rng.choice(len(qres), len(qres) // 250, replace=False)] = 20
+    qs = wl.split(qres, qoff)
+    qs[3] = qs[3][:9]            # shorter than the spaced pattern: no k-mer window at all
+    qs[4] = qs[4][:10]           # exactly one window
+    qs[5] = np.tile(np.array([9, 9, 9, 0, 9, 9, 15, 9], np.uint8), 40)   # low complexity: strong composition bias
+    qres, qoff = wl.seqs_from_list(qs)
+    thr = kmer_threshold(sens, k)
+    ref.build_index(tres, toff, thr)
+    swo = Oracle()
+    settings = [(300, 2), (300, 64), (20, 2), (7, 16), (3, 2048), (28, 2), (28, 8), (33, 4)]   # (max_hits, CacheFriendlyOperations bins)
+    d = dict(qres=qres, qoff=qoff, tres=tres, toff=toff, kmer_thr=thr, k=k, spaced=1, min_diag_score=15,
+             settings=np.array(settings, np.int32), vtml80_kmer16=km16, vtml80_pback=pback, blosum62_ungapped=um8)
+    ident = np.array([0xFFFFFFFF if i % 3 else int(rng.integers(0, 1500)) for i in range(len(qs))], np.uint32)
+    d["identity"] = ident
+    cbs = [swo.comp_bias(km16, pback, q) for q in qs]
+    d["comp_bias"] = np.concatenate(cbs).astype(np.float32)
+    for si, (mh, bins) in enumerate(settings):
+        got = ref.make_matcher(max_hits=mh, force_bins=bins)
+        assert got == bins
+        ids, scs, dgs, cnt, dbm = [], [], [], [], []
+        for qi, q in enumerate(qs):
+            r = ref.match(q, None if ident[qi] == 0xFFFFFFFF else int(ident[qi]))
+            ids.append(r["id"]); scs.append(r["score"]); dgs.append(r["diagonal"]); cnt.append(len(r["id"]))
+            dbm.append(r["db_matches"])
+        d["hit_id_%d" % si] = np.concatenate(ids).astype(np.uint32)
+        d["hit_score_%d" % si] = np.concatenate(scs).astype(np.int32)
+        d["hit_diag_%d" % si] = np.concatenate(dgs).astype(np.uint16)
+        d["hit_count_%d" % si] = np.array(cnt, np.uint32)
+        d["db_matches"] = np.array(dbm, np.uint64)
+        print("prefilter setting", (mh, bins), "hits", int(np.sum(cnt)), "saturated", int((np.concatenate(scs) > 255).sum()))
+    np.savez_compressed(os.path.join(OUT, "prefilter_vectors.npz"), **d)
+
+
 if __name__ == "__main__":
     ref = matrices()
     sw_vectors(ref)
+    prefilter_vectors()

@@ -1,0 +1,89 @@
+"""CPU tests of the prefilter: the plain-C restatement (oracle/prefilter_oracle.c) against the golden hit lists
+recorded from the real reference classes, the product's host-side table builders against the restatement, and -
+where /root/reference and oracle/_ref are present - the restatement against the reference itself."""
+import numpy as np
+import pytest
+
+from mmseqs2_amd import capi
+from tests import pf_common as pc
+
+
+def test_oracle_matches_golden_prefilter_hits():
+    g = pc.golden()
+    o = pc.pf_oracle()
+    o.build_index(g["tres"], g["toff"], int(g["kmer_thr"]))
+    qs = pc.golden_queries(g)
+    n_sat = n_cut = 0
+    for si, (mh, bins) in enumerate(g["settings"].tolist()):
+        exp = pc.expected_hits(g, si)
+        for qi, qd in enumerate(qs):
+            r = o.match(qd["q"], qd["comp_bias"], bins, max_hits=mh, min_diag_score=int(g["min_diag_score"]),
+                        identity_id=qd["identity_id"])
+            assert r["stats"]["rc"] == 0
+            assert r["stats"]["db_matches"] == int(g["db_matches"][qi])
+            assert np.array_equal(r["id"], exp[qi][0]), (si, qi)
+            assert np.array_equal(r["score"], exp[qi][1]), (si, qi)
+            assert np.array_equal(r["diagonal"], exp[qi][2]), (si, qi)
+            n_sat += int((r["score"] > 255).sum())
+            n_cut += r["stats"]["truncated"]
+    assert n_sat > 500 and n_cut > 20   # the fixture exercises exact rescoring and the truncated-threshold path
+
+
+def test_host_score_matrix_matches_oracle():
+    g = pc.golden()
+    o = pc.pf_oracle()
+    s3, i3 = capi.host_score_matrix(g["vtml80_kmer16"], 3)
+    s2, i2 = capi.host_score_matrix(g["vtml80_kmer16"], 2)
+    assert np.array_equal(s3, o.s3) and np.array_equal(i3, o.i3)
+    assert np.array_equal(s2, o.s2) and np.array_equal(i2, o.i2)
+
+
+@pytest.mark.parametrize("spaced", [True, False])
+def test_host_index_build_matches_oracle(spaced):
+    from oracle.pyoracle import PfOracle
+    g = pc.golden()
+    base = pc.pf_oracle()
+    o = PfOracle.__new__(PfOracle)          # share the score matrices, change the pattern
+    o.__dict__.update(base.__dict__)
+    o.spaced = int(spaced)
+    thr = int(g["kmer_thr"])
+    off, ids, pos = o.build_index(g["tres"], g["toff"], thr)
+    hoff, hids, hpos = capi.host_index_build(g["tres"], g["toff"], g["vtml80_kmer16"], int(g["k"]), spaced, thr)
+    assert np.array_equal(off, hoff) and np.array_equal(ids, hids) and np.array_equal(pos, hpos)
+    assert len(ids) > 100000
+
+
+def test_oracle_fuzz_vs_reference():
+    """Where the real reference is available: index, similar k-mers and matchQuery for forced bin counts."""
+    from oracle import pyoracle
+    if not (pyoracle.ref_available() and pyoracle.ref_matrix_available()):
+        pytest.skip("real reference (oracle/_ref + /root/reference/data) not available here")
+    ref = pyoracle.RefPrefilter(6)
+    km8, um8, km16, pback = ref.matrices()
+    g = pc.golden()
+    assert np.array_equal(km16, g["vtml80_kmer16"]) and np.array_equal(um8, g["blosum62_ungapped"])
+    o = pc.pf_oracle()
+    rng = np.random.default_rng(3)
+    for _ in range(100):
+        kmer = rng.integers(0, 20, 6).astype(np.uint8)
+        thr = int(rng.integers(70, 140))
+        a, na = o.kmer_list(kmer, thr)
+        b, nb = ref.kmer_list(kmer, thr)
+        assert na == nb and np.array_equal(a, b)
+    (qres, qoff), (tres, toff) = pc.synthetic_case(10, 1200, seed=77, planted=0.5)
+    thr = pyoracle.kmer_threshold(5.7, 6)
+    ref.build_index(tres, toff, thr)
+    o.build_index(tres, toff, thr)
+    ro, ri, rp = ref.index_dump()
+    assert np.array_equal(ro, o.offsets) and np.array_equal(ri, o.ids[:o.n_entries])
+    swo = pyoracle.Oracle()
+    from mmseqs2_amd import workloads as wl
+    for mh, fb in ((300, 0), (12, 32), (5, 2)):
+        bins = ref.make_matcher(max_hits=mh, force_bins=fb)
+        for qi, q in enumerate(wl.split(qres, qoff)):
+            cb = swo.comp_bias(km16, pback, q)
+            ident = None if qi % 2 else qi
+            r = ref.match(q, ident)
+            x = o.match(q, cb, bins, max_hits=mh, identity_id=ident)
+            assert np.array_equal(r["id"], x["id"]) and np.array_equal(r["score"], x["score"])
+            assert np.array_equal(r["diagonal"], x["diagonal"]) and r["db_matches"] == x["stats"]["db_matches"]
