@@ -21,6 +21,10 @@ struct PfIndex {
     uint64_t table = 0, n_entries = 0;
     DevBuf d_s3, d_i3, d_offsets, d_ids, d_pos, d_mat;
     std::vector<int8_t> h_mat;   // ungapped matrix (host copy for the self score)
+    // Large working buffers, shared by all batches of this context (grow-only; batches run one at a time on the
+    // context's stream): index lists, split tiles, candidates, survivors.
+    DevBuf w_lists, w_split, w_bin_off, w_cand, w_surv, w_tile_q, w_tile_idx;
+    const void *w_owner = nullptr;   // batch whose last run the working buffers hold (debug fetch)
 };
 
 void pf_index_free(mmgpu_ctx *c) {
@@ -305,9 +309,9 @@ struct mmgpu_pf_batch_t {
     // device: inputs
     DevBuf d_qres, d_qthr, d_qcorr, d_qoff, d_qident, d_qself;
     // device: working set (grow-only, reused across runs)
-    DevBuf d_nsim, d_qtot, d_qbase, d_list_base, d_lists, d_pos_entries, d_peb, d_qentries;
-    DevBuf d_tile_q, d_tile_idx, d_qtile_base, d_qntiles, d_split, d_bin_off, d_bucket_count, d_bucket_off;
-    DevBuf d_cand_base, d_cand, d_surv, d_surv_count, d_hits, d_hit_count, d_diag_thr;
+    DevBuf d_nsim, d_qtot, d_qbase, d_list_base, d_pos_entries, d_peb, d_qentries;
+    DevBuf d_qtile_base, d_qntiles, d_bucket_count, d_bucket_off;
+    DevBuf d_cand_base, d_surv_count, d_hits, d_hit_count, d_diag_thr;
     // host mirrors of the last run
     std::vector<uint64_t> q_lists, q_entries;
     std::vector<int32_t> status;
@@ -445,7 +449,8 @@ extern "C" int mmgpu_pf_run(mmgpu_ctx *c, mmgpu_pf_batch_t *b) {
     if (!c || !b) return fail(MMGPU_ERR_ARG, "mmgpu_pf_run: NULL argument");
     if (!c->pf) return fail(MMGPU_ERR_STATE, "mmgpu_pf_run: no index loaded");
     HIP_TRY(hipSetDevice(c->device));
-    const PfIndex &P = *c->pf;
+    PfIndex &P = *c->pf;
+    P.w_owner = b;
     hipStream_t s = c->stream;
     const uint32_t nq = b->nq;
     b->status.assign(nq, MMGPU_PF_OK);
@@ -481,9 +486,9 @@ extern "C" int mmgpu_pf_run(mmgpu_ctx *c, mmgpu_pf_batch_t *b) {
     HIP_TRY(hipMemcpyAsync(b->d_qbase.p, qbase.data(), nq * 8, hipMemcpyHostToDevice, s));
     HIP_TRY(launch_pf_scan(b->d_nsim.as<uint32_t>(), b->d_qoff.as<uint32_t>(), nq, b->d_qbase.as<uint64_t>(), b->d_list_base.as<uint32_t>(), nullptr, s));
     b->last_lists = total_lists;
-    HIP_TRY(b->d_lists.reserve(std::max<uint64_t>(total_lists, 1) * sizeof(PfList)));
+    HIP_TRY(P.w_lists.reserve(std::max<uint64_t>(total_lists, 1) * sizeof(PfList)));
     K.list_base = b->d_list_base.as<uint32_t>();
-    K.lists = b->d_lists.as<PfList>();
+    K.lists = P.w_lists.as<PfList>();
     K.pos_entries = b->d_pos_entries.as<uint32_t>();
     HIP_TRY(launch_pf_kmers(K, true, s));
     HIP_TRY(launch_pf_scan(b->d_pos_entries.as<uint32_t>(), b->d_qoff.as<uint32_t>(), nq, nullptr, b->d_peb.as<uint32_t>(), b->d_qtot.as<uint64_t>(), s));
@@ -520,33 +525,33 @@ extern "C" int mmgpu_pf_run(mmgpu_ctx *c, mmgpu_pf_batch_t *b) {
     HIP_TRY(hipMemcpyAsync(b->d_qtile_base.p, qtb.data(), nq * 4, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(b->d_qntiles.p, qnt.data(), nq * 4, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(b->d_qbase.p, qebase.data(), nq * 8, hipMemcpyHostToDevice, s));
-    HIP_TRY(b->d_tile_q.reserve(std::max<size_t>(n_tiles, 1) * 4));
-    HIP_TRY(b->d_tile_idx.reserve(std::max<size_t>(n_tiles, 1) * 4));
+    HIP_TRY(P.w_tile_q.reserve(std::max<size_t>(n_tiles, 1) * 4));
+    HIP_TRY(P.w_tile_idx.reserve(std::max<size_t>(n_tiles, 1) * 4));
     if (n_tiles) {
-        HIP_TRY(hipMemcpyAsync(b->d_tile_q.p, tile_q.data(), (size_t)n_tiles * 4, hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemcpyAsync(b->d_tile_idx.p, tile_idx.data(), (size_t)n_tiles * 4, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(P.w_tile_q.p, tile_q.data(), (size_t)n_tiles * 4, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(P.w_tile_idx.p, tile_idx.data(), (size_t)n_tiles * 4, hipMemcpyHostToDevice, s));
     }
-    HIP_TRY(b->d_split.reserve(std::max<size_t>(n_tiles, 1) * PF_T * sizeof(uint64_t)));
-    HIP_TRY(b->d_bin_off.reserve(std::max<size_t>(n_tiles, 1) * (B + 1) * sizeof(uint16_t)));
-    HIP_TRY(b->d_cand.reserve(std::max<uint64_t>(total_entries, 1) * sizeof(PfCand)));
-    HIP_TRY(b->d_surv.reserve(std::max<uint64_t>(total_entries, 1) * sizeof(PfCand)));
+    HIP_TRY(P.w_split.reserve(std::max<size_t>(n_tiles, 1) * PF_T * sizeof(uint64_t)));
+    HIP_TRY(P.w_bin_off.reserve(std::max<size_t>(n_tiles, 1) * (B + 1) * sizeof(uint16_t)));
+    HIP_TRY(P.w_cand.reserve(std::max<uint64_t>(total_entries, 1) * sizeof(PfCand)));
+    HIP_TRY(P.w_surv.reserve(std::max<uint64_t>(total_entries, 1) * sizeof(PfCand)));
     HIP_TRY(hipMemsetAsync(b->d_bucket_count.p, 0, (size_t)nq * B * 4, s));
     HIP_TRY(hipMemsetAsync(b->d_surv_count.p, 0, (size_t)nq * 4, s));
 
     // ---- stage 1: gather + stable split ----
     PfSplitArgs SA;
-    SA.tile_q = b->d_tile_q.as<uint32_t>();
-    SA.tile_idx = b->d_tile_idx.as<uint32_t>();
+    SA.tile_q = P.w_tile_q.as<uint32_t>();
+    SA.tile_idx = P.w_tile_idx.as<uint32_t>();
     SA.q_off = b->d_qoff.as<uint32_t>();
     SA.q_entries = b->d_qentries.as<uint32_t>();
     SA.pos_entry_base = b->d_peb.as<uint32_t>();
     SA.list_base = b->d_list_base.as<uint32_t>();
-    SA.lists = b->d_lists.as<PfList>();
+    SA.lists = P.w_lists.as<PfList>();
     SA.idx_ids = P.d_ids.as<uint32_t>();
     SA.idx_pos = P.d_pos.as<uint16_t>();
     SA.bins = B;
-    SA.split = b->d_split.as<uint64_t>();
-    SA.bin_off = b->d_bin_off.as<uint16_t>();
+    SA.split = P.w_split.as<uint64_t>();
+    SA.bin_off = P.w_bin_off.as<uint16_t>();
     SA.bucket_count = b->d_bucket_count.as<uint32_t>();
     HIP_TRY(launch_pf_split(SA, n_tiles, s));
     // cand_base[q * B + bin] = entries of earlier queries + entries of earlier bins of this query
@@ -566,11 +571,11 @@ extern "C" int mmgpu_pf_run(mmgpu_ctx *c, mmgpu_pf_batch_t *b) {
     D.bins = B;
     D.q_tile_base = b->d_qtile_base.as<uint32_t>();
     D.q_ntiles = b->d_qntiles.as<uint32_t>();
-    D.split = b->d_split.as<uint64_t>();
-    D.bin_off = b->d_bin_off.as<uint16_t>();
+    D.split = P.w_split.as<uint64_t>();
+    D.bin_off = P.w_bin_off.as<uint16_t>();
     D.cand_base = b->d_cand_base.as<uint32_t>();
-    D.cand = b->d_cand.as<PfCand>();
-    D.surv = b->d_surv.as<PfCand>();
+    D.cand = P.w_cand.as<PfCand>();
+    D.surv = P.w_surv.as<PfCand>();
     D.surv_count = b->d_surv_count.as<uint32_t>();
     D.q_off = b->d_qoff.as<uint32_t>();
     D.q_res = b->d_qres.as<uint8_t>();
@@ -586,7 +591,7 @@ extern "C" int mmgpu_pf_run(mmgpu_ctx *c, mmgpu_pf_batch_t *b) {
 
     // ---- stage 3: top max_hits per query ----
     PfSelectArgs S;
-    S.surv = b->d_surv.as<PfCand>();
+    S.surv = P.w_surv.as<PfCand>();
     S.surv_count = b->d_surv_count.as<uint32_t>();
     S.q_identity = b->d_qident.as<uint32_t>();
     S.q_self_score = b->d_qself.as<int32_t>();
@@ -649,18 +654,20 @@ extern "C" int mmgpu_pf_debug_fetch(mmgpu_ctx *c, mmgpu_pf_batch_t *b, int what,
     if (!b->ran) return fail(MMGPU_ERR_STATE, "mmgpu_pf_debug_fetch: batch was never run");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (!c->pf || c->pf->w_owner != b) return fail(MMGPU_ERR_STATE, "mmgpu_pf_debug_fetch: another batch ran after this one");
+    PfIndex &P = *c->pf;
     const void *src = nullptr;
     size_t n = 0;
     uint32_t binsv[2] = {b->bins, b->ref_bins};
     switch (what) {
         case MMGPU_PF_DBG_NSIM: src = b->d_nsim.p; n = (size_t)b->n_pos * 4; break;
         case MMGPU_PF_DBG_LIST_BASE: src = b->d_list_base.p; n = ((size_t)b->n_pos + 1) * 4; break;
-        case MMGPU_PF_DBG_LISTS: src = b->d_lists.p; n = (size_t)b->last_lists * sizeof(PfList); break;
+        case MMGPU_PF_DBG_LISTS: src = P.w_lists.p; n = (size_t)b->last_lists * sizeof(PfList); break;
         case MMGPU_PF_DBG_PEB: src = b->d_peb.p; n = ((size_t)b->n_pos + 1) * 4; break;
-        case MMGPU_PF_DBG_SPLIT: src = b->d_split.p; n = (size_t)b->last_tiles * PF_T * 8; break;
-        case MMGPU_PF_DBG_BIN_OFF: src = b->d_bin_off.p; n = (size_t)b->last_tiles * (b->bins + 1) * 2; break;
+        case MMGPU_PF_DBG_SPLIT: src = P.w_split.p; n = (size_t)b->last_tiles * PF_T * 8; break;
+        case MMGPU_PF_DBG_BIN_OFF: src = P.w_bin_off.p; n = (size_t)b->last_tiles * (b->bins + 1) * 2; break;
         case MMGPU_PF_DBG_CAND_BASE: src = b->d_cand_base.p; n = ((size_t)b->nq * b->bins + 1) * 4; break;
-        case MMGPU_PF_DBG_SURV: src = b->d_surv.p; n = (size_t)b->last_entries * sizeof(PfCand); break;
+        case MMGPU_PF_DBG_SURV: src = P.w_surv.p; n = (size_t)b->last_entries * sizeof(PfCand); break;
         case MMGPU_PF_DBG_SURV_COUNT: src = b->d_surv_count.p; n = (size_t)b->nq * 4; break;
         case MMGPU_PF_DBG_BINS:
             *bytes = sizeof(binsv);

@@ -79,3 +79,70 @@ def config2_align_only(n_queries=1000, n_targets=100000, planted_frac=0.10, seed
 
 def split(res, off):
     return [res[int(off[i]):int(off[i + 1])] for i in range(len(off) - 1)]
+
+
+def mutate_many(rng, seeds_res, seeds_off, parents, id_lo=0.3, id_hi=0.95, max_indels=3, max_indel_len=10):
+    """Vectorised family generator: child c is a copy of seed parents[c] with substitutions down to an identity
+    drawn from U(id_lo, id_hi) and up to max_indels deletions and insertions of 1..max_indel_len residues.
+    Returns (residues, offsets)."""
+    seeds_off = seeds_off.astype(np.int64)
+    parents = np.asarray(parents, np.int64)
+    lens = (seeds_off[parents + 1] - seeds_off[parents])
+    off = np.zeros(len(parents) + 1, np.int64)
+    off[1:] = np.cumsum(lens)
+    total = int(off[-1])
+    child_of = np.repeat(np.arange(len(parents)), lens)
+    within = np.arange(total, dtype=np.int64) - off[child_of]
+    res = seeds_res[seeds_off[parents][child_of] + within].astype(np.uint8)
+    ident = rng.uniform(id_lo, id_hi, len(parents))
+    mut = rng.random(total) > ident[child_of]
+    res[mut] = rng.choice(20, size=int(mut.sum()), p=BACKGROUND).astype(np.uint8)
+    # deletions
+    ok = lens >= 2 * max_indel_len + 4
+    nev = np.where(ok, rng.integers(0, max_indels + 1, len(parents)), 0)
+    ev_child = np.repeat(np.arange(len(parents)), nev)
+    ev_len = rng.integers(1, max_indel_len + 1, len(ev_child))
+    ev_pos = (rng.random(len(ev_child)) * (lens[ev_child] - max_indel_len - 2)).astype(np.int64) + 1
+    is_del = rng.random(len(ev_child)) < 0.5
+    ds = off[ev_child[is_del]] + ev_pos[is_del]
+    d = (np.bincount(ds, minlength=total + 1) - np.bincount(ds + ev_len[is_del], minlength=total + 1))[:total + 1]
+    keep = np.cumsum(d[:-1]) == 0
+    kept_per_child = np.add.reduceat(keep.astype(np.int64), off[:-1]) if total else np.zeros(0, np.int64)
+    kept_per_child[lens == 0] = 0
+    res = res[keep]
+    lens2 = kept_per_child
+    off2 = np.zeros(len(parents) + 1, np.int64)
+    off2[1:] = np.cumsum(lens2)
+    # insertions (positions relative to the sequence after deletions)
+    ic, il = ev_child[~is_del], ev_len[~is_del]
+    ipos = off2[ic] + np.minimum(ev_pos[~is_del], np.maximum(lens2[ic] - 1, 0))
+    where = np.repeat(ipos, il)
+    res = np.insert(res, where, rng.choice(20, size=len(where), p=BACKGROUND).astype(np.uint8))
+    lens3 = lens2 + np.bincount(ic, weights=il, minlength=len(parents)).astype(np.int64)
+    off3 = np.zeros(len(parents) + 1, np.uint64)
+    off3[1:] = np.cumsum(lens3)
+    return res, off3
+
+
+def config3_prefilter(n_families=20000, members=50, n_queries=10000, seed=10, chunk=100000):
+    """BASELINE.json configs[2] (SURVEY.md section 8d): family seeds with L = clamp(LogNormal(5.45, 0.6), 30, 5000);
+    targets = `members` mutated members per family, shuffled; queries = one new mutated member of n_queries distinct
+    families.  Returns ((qres, qoff), (tres, toff), family_of_target, family_of_query)."""
+    rs = np.random.default_rng(seed)
+    rt = np.random.default_rng(seed + 1)
+    rq = np.random.default_rng(seed + 2)
+    sres, soff = lognormal_seqs(rs, n_families)
+    fam = np.repeat(np.arange(n_families), members)
+    rt.shuffle(fam)
+    parts, lens = [], []
+    for c in range(0, len(fam), chunk):
+        r, o = mutate_many(rt, sres, soff, fam[c:c + chunk])
+        parts.append(r)
+        lens.append(np.diff(o.astype(np.int64)))
+    tres = np.concatenate(parts) if parts else np.zeros(0, np.uint8)
+    lens = np.concatenate(lens) if lens else np.zeros(0, np.int64)
+    toff = np.zeros(len(fam) + 1, np.uint64)
+    toff[1:] = np.cumsum(lens)
+    qfam = rq.choice(n_families, n_queries, replace=False)
+    qres, qoff = mutate_many(rq, sres, soff, qfam)
+    return (qres, qoff), (tres, toff), fam, qfam

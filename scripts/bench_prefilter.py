@@ -1,0 +1,82 @@
+"""Prefilter throughput on one GPU (development harness; bench.py carries the judged line).
+    python scripts/bench_prefilter.py --families 20000 --members 50 --queries 10000 --batch 1024 --steps 2
+Workload: BASELINE.json configs[2] scaled by --families/--members/--queries."""
+import argparse, json, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import mmseqs2_amd
+from mmseqs2_amd import capi, workloads as wl
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--families", type=int, default=2000)
+ap.add_argument("--members", type=int, default=50)
+ap.add_argument("--queries", type=int, default=1000)
+ap.add_argument("--batch", type=int, default=512)
+ap.add_argument("--steps", type=int, default=2)
+ap.add_argument("--sens", type=float, default=5.7)
+ap.add_argument("--max-hits", type=int, default=300)
+ap.add_argument("--check", type=int, default=0, help="queries to verify against the oracle")
+args = ap.parse_args()
+
+m = dict(np.load(os.path.join(ROOT, "tests", "golden", "matrices.npz")))
+km16 = m["vtml80_kmer"].astype(np.int16)
+t0 = time.time()
+(qres, qoff), (tres, toff), fam, qfam = wl.config3_prefilter(args.families, args.members, args.queries)
+t_gen = time.time() - t0
+qs = wl.split(qres, qoff)
+gpu = mmseqs2_amd.MMGpu(0)
+thr = int(163.2 - 8.917 * args.sens)
+t0 = time.time(); s3, i3 = capi.host_score_matrix(km16, 3); t_sm = time.time() - t0
+t0 = time.time(); off, ids, pos = capi.host_index_build(tres, toff, km16, 6, True, thr); t_ix = time.time() - t0
+t0 = time.time()
+gpu.load_targets(tres, toff, 21)
+gpu.pf_load_index(6, 21, True, s3, i3, off, ids, pos, m["blosum62_ungapped"])
+t_load = time.time() - t0
+t0 = time.time()
+cbs = [capi.host_comp_bias(km16, m["vtml80_pback"], q)[0] for q in qs]
+queries = [dict(q=q, comp_bias=cb, identity_id=None) for q, cb in zip(qs, cbs)]
+batches = [gpu.pf_prepare(queries[i:i + args.batch], thr, max_hits=args.max_hits, ref_bins=2) for i in range(0, len(queries), args.batch)]
+t_prep = time.time() - t0
+for b in batches:      # warm-up (also sizes the working buffers)
+    b.run()
+gpu.synchronize()
+t0 = time.perf_counter()
+for _ in range(args.steps):
+    for b in batches:
+        b.run()
+gpu.synchronize()
+dt = (time.perf_counter() - t0) / args.steps
+stage = np.zeros(5)
+ent = lists = hits_n = ovf = 0
+allhits = []
+for b in batches:
+    stage += np.array(b.stage_ms())
+    h, c, st, stats = b.fetch()
+    ent += int(stats["db_matches"].sum()); lists += int(stats["kmer_list_len"].sum()); hits_n += int(c.sum()); ovf += int((st != 0).sum())
+    allhits.append((h, c, st))
+out = dict(queries=len(qs), targets=len(toff) - 1, residues=int(toff[-1]), index_entries=len(ids),
+           queries_per_s=round(len(qs) / dt, 1), s_per_pass=round(dt, 4), stage_ms=[round(x, 2) for x in stage],
+           db_matches=ent, similar_kmers=lists, hits=hits_n, overflow_queries=ovf,
+           gather_GBps=round(ent * 20 / (stage[1] * 1e-3) / 1e9, 2) if stage[1] else None,
+           entries_per_query=round(ent / max(len(qs), 1)), t_gen=round(t_gen, 1), t_score_matrix=round(t_sm, 1),
+           t_index_build=round(t_ix, 1), t_load=round(t_load, 1), t_prepare=round(t_prep, 1))
+# family recall: fraction of (query, same-family target) pairs the hit lists contain
+if args.check:
+    from oracle.pyoracle import PfOracle
+    orc = PfOracle(km16, m["blosum62_ungapped"], 6, True)
+    orc.build_index(tres, toff, thr)
+    bad = 0
+    rng = np.random.default_rng(0)
+    for qi in rng.choice(len(qs), args.check, replace=False):
+        bi, wi = divmod(int(qi), args.batch)
+        h, c, st = allhits[bi]
+        o = orc.match(qs[qi], cbs[qi], 2, max_hits=args.max_hits)   # ref_bins default resolves to 2 on this host class
+        n = int(c[wi])
+        same = n == len(o["id"]) and np.array_equal(h[wi]["id"][:n], o["id"]) and np.array_equal(h[wi]["score"][:n], o["score"]) and np.array_equal(h[wi]["diagonal"][:n], o["diagonal"])
+        if o["stats"]["overflow"]:
+            same = st[wi] == 1
+        bad += not same
+    out["checked_vs_oracle"] = args.check
+    out["mismatches"] = bad
+print(json.dumps(out))
