@@ -213,9 +213,22 @@ int mmgpu_pf_prepare(mmgpu_ctx *ctx, const mmgpu_pf_params *params, const mmgpu_
 int mmgpu_pf_run(mmgpu_ctx *ctx, mmgpu_pf_batch_t *batch);
 int mmgpu_pf_fetch(mmgpu_ctx *ctx, mmgpu_pf_batch_t *batch, mmgpu_pf_hit *hits, uint32_t hit_stride,
                    uint32_t *counts, int32_t *status, mmgpu_pf_qstat *stats /* may be NULL */);
+/* Device-resident hand-over for multi-GPU runs: copies the batch's hit lists into caller-owned DEVICE memory
+ * (e.g. a torch tensor that is then all-gathered over RCCL): d_hits [nq][hit_stride] mmgpu_pf_hit, d_counts [nq]. */
+int mmgpu_pf_fetch_device(mmgpu_ctx *ctx, mmgpu_pf_batch_t *batch, void *d_hits, uint32_t hit_stride, void *d_counts);
+/* Device analogue of Prefiltering::mergeTargetSplits (Prefiltering.cpp:412-526) on gathered lists:
+ * d_hits [n_splits][nq][stride], d_counts [n_splits][nq] (device pointers); ids of split s get id_offsets[s] added
+ * (dbFrom, Prefiltering.cpp:879-881); every query's lists are concatenated and sorted by (|score| desc, id asc).
+ * d_out_hits [nq][n_splits*stride], d_out_counts [nq].  No truncation, like the reference (which instead lowers
+ * maxResListLen per split, Prefiltering.cpp:391-394 - pass that value as max_hits of each split's batch). */
+int mmgpu_pf_merge_splits(mmgpu_ctx *ctx, const void *d_hits, const void *d_counts, uint32_t n_splits, uint32_t n_queries,
+                          uint32_t stride, const uint32_t *id_offsets, void *d_out_hits, void *d_out_counts);
 /* milliseconds per stage of the last run (HIP events on the context's stream; synchronises):
- * ms[0] similar k-mers + lists, ms[1] gather/split, ms[2] replay/score, ms[3] select, ms[4] whole run */
-int mmgpu_pf_stage_ms(mmgpu_ctx *ctx, mmgpu_pf_batch_t *batch, float ms[5]);
+ * ms[0] similar k-mers + index lists, ms[1] gather + bin split, ms[2] double-diagonal replay, ms[3] ungapped scoring,
+ * ms[4] best element per target, ms[5] top-N select, ms[6] whole run (including the two host read-backs) */
+int mmgpu_pf_stage_ms(mmgpu_ctx *ctx, mmgpu_pf_batch_t *batch, float ms[7]);
+/* ungapped diagonal cells scored by the last run (sum of overlap lengths of the double-diagonal candidates) */
+int mmgpu_pf_last_cells(mmgpu_ctx *ctx, mmgpu_pf_batch_t *batch, uint64_t *cells, uint64_t *candidates);
 /* Stage dumps for the parity tests: copies one intermediate buffer of the last run to the host.
  * *bytes = size of the buffer; copies min(cap, *bytes).  Layouts are those of mmseqs2_amd/csrc/mmgpu_internal.h. */
 #define MMGPU_PF_DBG_NSIM 0       /* uint32[n_pos]   similar k-mers per window                              */

@@ -50,7 +50,7 @@ EXPORTED_SYMBOLS = [
     "mmgpu_device_info", "mmgpu_host_comp_bias", "mmgpu_host_round_comp_bias", "mmgpu_load_targets", "mmgpu_sw_batch", "mmgpu_sw_prepare", "mmgpu_sw_run",
     "mmgpu_sw_fetch", "mmgpu_sw_batch_stats", "mmgpu_sw_last_kernel_ms", "mmgpu_sw_kernel_ms_mean", "mmgpu_sw_free",
     "mmgpu_host_score_matrix", "mmgpu_host_index_build", "mmgpu_pf_load_index", "mmgpu_pf_batch", "mmgpu_pf_prepare",
-    "mmgpu_pf_run", "mmgpu_pf_fetch", "mmgpu_pf_stage_ms", "mmgpu_pf_debug_fetch", "mmgpu_pf_free",
+    "mmgpu_pf_run", "mmgpu_pf_fetch", "mmgpu_pf_stage_ms", "mmgpu_pf_last_cells", "mmgpu_pf_fetch_device", "mmgpu_pf_merge_splits", "mmgpu_pf_debug_fetch", "mmgpu_pf_free",
 ]
 
 
@@ -112,6 +112,9 @@ def load_library():
     L.mmgpu_pf_run.argtypes = [c_p, c_p]
     L.mmgpu_pf_fetch.argtypes = [c_p, c_p, c_p, ctypes.c_uint32, c_p, c_p, c_p]
     L.mmgpu_pf_stage_ms.argtypes = [c_p, c_p, ctypes.POINTER(ctypes.c_float)]
+    L.mmgpu_pf_fetch_device.argtypes = [c_p, c_p, c_p, ctypes.c_uint32, c_p]
+    L.mmgpu_pf_merge_splits.argtypes = [c_p, c_p, c_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, c_p, c_p, c_p]
+    L.mmgpu_pf_last_cells.argtypes = [c_p, c_p, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
     L.mmgpu_pf_debug_fetch.argtypes = [c_p, c_p, ctypes.c_int, c_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
     L.mmgpu_pf_free.argtypes = [c_p, c_p]
     L.mmgpu_pf_free.restype = None
@@ -189,10 +192,20 @@ class PfBatch:
                                                   _ptr(stats)))
         return hits[:self.nq], counts[:self.nq], status[:self.nq], stats[:self.nq]
 
+    def fetch_device(self, d_hits_ptr, stride, d_counts_ptr):
+        """D2D copy of the hit lists into caller-owned device memory (raw pointers, e.g. torch tensor.data_ptr())."""
+        self.gpu._check(self.gpu.L.mmgpu_pf_fetch_device(self.gpu.ctx, self.handle, c_p(d_hits_ptr), stride, c_p(d_counts_ptr)))
+
     def stage_ms(self):
-        ms = (ctypes.c_float * 5)()
+        ms = (ctypes.c_float * 7)()
         self.gpu._check(self.gpu.L.mmgpu_pf_stage_ms(self.gpu.ctx, self.handle, ms))
         return [float(x) for x in ms]
+
+    def last_cells(self):
+        """(ungapped cells scored, double-diagonal candidates) of the last run"""
+        a, b = ctypes.c_uint64(), ctypes.c_uint64()
+        self.gpu._check(self.gpu.L.mmgpu_pf_last_cells(self.gpu.ctx, self.handle, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
 
     def debug(self, what):
         code, dt = PF_DBG[what]
@@ -357,3 +370,29 @@ class MMGpu:
         out = b.fetch()
         b.free()
         return out
+
+    def pf_merge_splits(self, d_hits_ptr, d_counts_ptr, n_splits, nq, stride, id_offsets, d_out_hits_ptr, d_out_counts_ptr):
+        off = np.ascontiguousarray(id_offsets, np.uint32)
+        self._check(self.L.mmgpu_pf_merge_splits(self.ctx, c_p(d_hits_ptr), c_p(d_counts_ptr), n_splits, nq, stride, _ptr(off),
+                                                 c_p(d_out_hits_ptr), c_p(d_out_counts_ptr)))
+
+
+def split_max_hits(max_hits, n_splits):
+    """maxResListLen of one target split (Prefiltering.cpp:391-394)."""
+    if n_splits <= 1:
+        return int(max_hits)
+    import math
+    return max(1, int(max_hits) // n_splits + int(4 * math.sqrt(float(max_hits) / float(n_splits))))
+
+
+def merge_hit_lists_host(lists, id_offsets):
+    """Host mirror of mmgpu_pf_merge_splits for one query (used by the CPU tests of the multi-GPU path):
+    lists = [structured PF_HIT_DTYPE arrays per split] -> concatenated, global ids, sorted (|score| desc, id asc)."""
+    parts = []
+    for h, off in zip(lists, id_offsets):
+        h = h.copy()
+        h["id"] = h["id"] + np.uint32(off)
+        parts.append(h)
+    allh = np.concatenate(parts) if parts else np.zeros(0, PF_HIT_DTYPE)
+    order = np.lexsort((allh["id"], -np.abs(allh["score"].astype(np.int64))))
+    return allh[order]

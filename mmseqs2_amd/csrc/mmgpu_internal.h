@@ -127,6 +127,8 @@ struct PfDedupArgs {
     const uint32_t *cand_base;        // [nq * bins + 1]
     PfCand *cand, *surv;
     uint32_t *surv_count;             // [nq]
+    uint32_t *cand_count;             // [nq * bins]
+    uint64_t *cell_counter;           // ungapped cells scored (statistics), may be null
     const uint32_t *q_off;
     const uint8_t *q_res;
     const int8_t *q_corr;             // UngappedAlignment::aaCorrectionScore per position
@@ -150,11 +152,23 @@ struct PfSelectArgs {
     uint32_t *hit_count, *q_diag_thr;
 };
 
+constexpr int PF_MERGE_CAP = 8192;     // hits per query the split-merge kernel sorts in LDS
+
+struct PfMergeArgs {
+    const mmgpu_pf_hit *hits;    // [n_splits][nq][stride]
+    const uint32_t *counts;      // [n_splits][nq]
+    uint32_t n_splits, nq, stride;
+    uint32_t id_offset[64];
+    mmgpu_pf_hit *out_hits;      // [nq][n_splits * stride]
+    uint32_t *out_counts;        // [nq]
+};
+
+hipError_t launch_pf_merge(const PfMergeArgs &A, hipStream_t s);
 hipError_t launch_pf_kmers(const PfKmerArgs &A, bool emit, hipStream_t s);
 hipError_t launch_pf_scan(const uint32_t *in, const uint32_t *q_off, uint32_t nq, const uint64_t *base, uint32_t *out,
                           uint64_t *totals, hipStream_t s);
 hipError_t launch_pf_split(const PfSplitArgs &A, uint32_t n_tiles, hipStream_t s);
-hipError_t launch_pf_dedup(const PfDedupArgs &A, hipStream_t s);
+hipError_t launch_pf_dedup(const PfDedupArgs &A, hipEvent_t after_replay, hipEvent_t after_ungapped, hipStream_t s);
 hipError_t launch_pf_select(const PfSelectArgs &A, uint32_t nq, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------------------------

@@ -311,11 +311,12 @@ struct mmgpu_pf_batch_t {
     // device: working set (grow-only, reused across runs)
     DevBuf d_nsim, d_qtot, d_qbase, d_list_base, d_pos_entries, d_peb, d_qentries;
     DevBuf d_qtile_base, d_qntiles, d_bucket_count, d_bucket_off;
-    DevBuf d_cand_base, d_surv_count, d_hits, d_hit_count, d_diag_thr;
+    DevBuf d_cand_base, d_cand_count, d_cells, d_surv_count, d_hits, d_hit_count, d_diag_thr;
     // host mirrors of the last run
     std::vector<uint64_t> q_lists, q_entries;
     std::vector<int32_t> status;
-    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // 5, 6: inside stage 2
+    uint64_t last_cells = 0;
     uint64_t last_lists = 0, last_entries = 0;
     uint32_t last_tiles = 0;
     bool ran = false;
@@ -366,9 +367,9 @@ extern "C" int mmgpu_pf_prepare(mmgpu_ctx *c, const mmgpu_pf_params *par, const 
         b->q_off[i + 1] = (uint32_t)tot;
     }
     b->n_pos = (uint32_t)tot;
-    std::vector<uint8_t> qres(tot);
+    std::vector<uint8_t> qres(tot + 64, 0);    // + slack: the ungapped kernel reads whole dwords
     std::vector<int16_t> qthr(tot, -1);
-    std::vector<int8_t> qcorr(tot, 0);
+    std::vector<int8_t> qcorr(tot + 64, 0);
     std::vector<uint32_t> qident(std::max<uint32_t>(nq, 1), 0xFFFFFFFFu);
     std::vector<int32_t> qself(std::max<uint32_t>(nq, 1), 0);
     std::atomic<bool> bad(false);
@@ -434,6 +435,8 @@ extern "C" int mmgpu_pf_prepare(mmgpu_ctx *c, const mmgpu_pf_params *par, const 
     B_TRY(b->d_bucket_count.alloc((size_t)nqq * bins * 4));
     B_TRY(b->d_bucket_off.alloc(((size_t)nqq + 1) * 4));
     B_TRY(b->d_cand_base.alloc(((size_t)nqq * bins + 1) * 4));
+    B_TRY(b->d_cand_count.alloc((size_t)nqq * bins * 4));
+    B_TRY(b->d_cells.alloc(8));
     B_TRY(b->d_surv_count.alloc(nqq * 4));
     B_TRY(b->d_hits.alloc((size_t)nqq * max_hits * sizeof(mmgpu_pf_hit)));
     B_TRY(b->d_hit_count.alloc(nqq * 4));
@@ -537,6 +540,7 @@ extern "C" int mmgpu_pf_run(mmgpu_ctx *c, mmgpu_pf_batch_t *b) {
     HIP_TRY(P.w_surv.reserve(std::max<uint64_t>(total_entries, 1) * sizeof(PfCand)));
     HIP_TRY(hipMemsetAsync(b->d_bucket_count.p, 0, (size_t)nq * B * 4, s));
     HIP_TRY(hipMemsetAsync(b->d_surv_count.p, 0, (size_t)nq * 4, s));
+    HIP_TRY(hipMemsetAsync(b->d_cells.p, 0, 8, s));
 
     // ---- stage 1: gather + stable split ----
     PfSplitArgs SA;
@@ -586,7 +590,9 @@ extern "C" int mmgpu_pf_run(mmgpu_ctx *c, mmgpu_pf_batch_t *b) {
     D.t_off4 = c->db.off4;
     D.t_len = c->db.len;
     D.min_diag_score = b->par.min_diag_score;
-    HIP_TRY(launch_pf_dedup(D, s));
+    D.cand_count = b->d_cand_count.as<uint32_t>();
+    D.cell_counter = b->d_cells.as<uint64_t>();
+    HIP_TRY(launch_pf_dedup(D, b->ev[5], b->ev[6], s));
     HIP_TRY(hipEventRecord(b->ev[3], s));
 
     // ---- stage 3: top max_hits per query ----
@@ -625,6 +631,7 @@ extern "C" int mmgpu_pf_fetch(mmgpu_ctx *c, mmgpu_pf_batch_t *b, mmgpu_pf_hit *h
     HIP_TRY(hipMemcpyAsync(counts, b->d_hit_count.p, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(thr.data(), b->d_diag_thr.p, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(surv.data(), b->d_surv_count.p, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&b->last_cells, b->d_cells.p, 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     for (uint32_t i = 0; i < nq; i++) {
         if (b->status[i] != MMGPU_PF_OK) counts[i] = 0;
@@ -639,13 +646,67 @@ extern "C" int mmgpu_pf_fetch(mmgpu_ctx *c, mmgpu_pf_batch_t *b, mmgpu_pf_hit *h
     return MMGPU_OK;
 }
 
-extern "C" int mmgpu_pf_stage_ms(mmgpu_ctx *c, mmgpu_pf_batch_t *b, float ms[5]) {
+extern "C" int mmgpu_pf_fetch_device(mmgpu_ctx *c, mmgpu_pf_batch_t *b, void *d_hits, uint32_t hit_stride, void *d_counts) {
+    if (!c || !b || ((!d_hits || !d_counts) && b->nq)) return fail(MMGPU_ERR_ARG, "mmgpu_pf_fetch_device: NULL argument");
+    if (!b->ran) return fail(MMGPU_ERR_STATE, "mmgpu_pf_fetch_device: batch was never run");
+    if (hit_stride < b->max_hits) return fail(MMGPU_ERR_ARG, "mmgpu_pf_fetch_device: hit_stride smaller than min(max_hits, dbSize)");
+    if (b->nq == 0) return MMGPU_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpy2DAsync(d_hits, (size_t)hit_stride * sizeof(mmgpu_pf_hit), b->d_hits.p, (size_t)b->max_hits * sizeof(mmgpu_pf_hit),
+                             (size_t)b->max_hits * sizeof(mmgpu_pf_hit), b->nq, hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(d_counts, b->d_hit_count.p, (size_t)b->nq * 4, hipMemcpyDeviceToDevice, c->stream));
+    return MMGPU_OK;
+}
+
+extern "C" int mmgpu_pf_merge_splits(mmgpu_ctx *c, const void *d_hits, const void *d_counts, uint32_t n_splits, uint32_t nq,
+                                     uint32_t stride, const uint32_t *id_offsets, void *d_out_hits, void *d_out_counts) {
+    if (!c || ((!d_hits || !d_counts || !d_out_hits || !d_out_counts) && nq) || !id_offsets)
+        return fail(MMGPU_ERR_ARG, "mmgpu_pf_merge_splits: NULL argument");
+    if (n_splits < 1 || n_splits > 64) return fail(MMGPU_ERR_ARG, "mmgpu_pf_merge_splits: n_splits must be in [1, 64]");
+    if ((uint64_t)n_splits * stride > PF_MERGE_CAP) return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_pf_merge_splits: more than 8192 hits per query");
+    HIP_TRY(hipSetDevice(c->device));
+    PfMergeArgs A;
+    A.hits = (const mmgpu_pf_hit *)d_hits;
+    A.counts = (const uint32_t *)d_counts;
+    A.n_splits = n_splits;
+    A.nq = nq;
+    A.stride = stride;
+    memset(A.id_offset, 0, sizeof(A.id_offset));
+    for (uint32_t i = 0; i < n_splits; i++) A.id_offset[i] = id_offsets[i];
+    A.out_hits = (mmgpu_pf_hit *)d_out_hits;
+    A.out_counts = (uint32_t *)d_out_counts;
+    HIP_TRY(launch_pf_merge(A, c->stream));
+    return MMGPU_OK;
+}
+
+extern "C" int mmgpu_pf_stage_ms(mmgpu_ctx *c, mmgpu_pf_batch_t *b, float ms[7]) {
     if (!c || !b || !ms) return fail(MMGPU_ERR_ARG, "mmgpu_pf_stage_ms: NULL argument");
     if (!b->ran || b->nq == 0) return fail(MMGPU_ERR_STATE, "mmgpu_pf_stage_ms: batch was never run");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipEventSynchronize(b->ev[4]));
-    for (int k = 0; k < 4; k++) HIP_TRY(hipEventElapsedTime(&ms[k], b->ev[k], b->ev[k + 1]));
-    HIP_TRY(hipEventElapsedTime(&ms[4], b->ev[0], b->ev[4]));
+    HIP_TRY(hipEventElapsedTime(&ms[0], b->ev[0], b->ev[1]));
+    HIP_TRY(hipEventElapsedTime(&ms[1], b->ev[1], b->ev[2]));
+    HIP_TRY(hipEventElapsedTime(&ms[2], b->ev[2], b->ev[5]));
+    HIP_TRY(hipEventElapsedTime(&ms[3], b->ev[5], b->ev[6]));
+    HIP_TRY(hipEventElapsedTime(&ms[4], b->ev[6], b->ev[3]));
+    HIP_TRY(hipEventElapsedTime(&ms[5], b->ev[3], b->ev[4]));
+    HIP_TRY(hipEventElapsedTime(&ms[6], b->ev[0], b->ev[4]));
+    return MMGPU_OK;
+}
+
+extern "C" int mmgpu_pf_last_cells(mmgpu_ctx *c, mmgpu_pf_batch_t *b, uint64_t *cells, uint64_t *candidates) {
+    if (!c || !b) return fail(MMGPU_ERR_ARG, "mmgpu_pf_last_cells: NULL argument");
+    if (!b->ran) return fail(MMGPU_ERR_STATE, "mmgpu_pf_last_cells: batch was never run");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (cells) HIP_TRY(hipMemcpy(cells, b->d_cells.p, 8, hipMemcpyDeviceToHost));
+    if (candidates) {
+        std::vector<uint32_t> cc((size_t)b->nq * b->bins);
+        if (!cc.empty()) HIP_TRY(hipMemcpy(cc.data(), b->d_cand_count.p, cc.size() * 4, hipMemcpyDeviceToHost));
+        uint64_t t = 0;
+        for (uint32_t v : cc) t += v;
+        *candidates = t;
+    }
     return MMGPU_OK;
 }
 

@@ -4,11 +4,11 @@
 // queries with diagonal scoring, bit for bit (hit set, scores, diagonals, order):
 //   a5  KmerGenerator::generateKmerList (KmerGenerator.cpp:108-184)            -> pf_kmers_kernel
 //   a6  QueryMatcher::match gather of index lists (QueryMatcher.cpp:243-376)    -> pf_kmers_kernel<true> + pf_split_kernel
-//   a7  CacheFriendlyOperations::findDuplicates (.cpp:38-49,185-278)            -> pf_dedup_kernel phase 1
-//   a8  UngappedAlignment::align (UngappedAlignment.cpp:36-57,423-437)          -> pf_dedup_kernel phase 2
+//   a7  CacheFriendlyOperations::findDuplicates (.cpp:38-49,185-278)            -> pf_replay_kernel
+//   a8  UngappedAlignment::align (UngappedAlignment.cpp:36-57,423-437)          -> pf_ungapped_kernel
 //   a9  keepMaxElement (.cpp:354-384), computeScoreThreshold (QueryMatcher.h:211-221),
-//       radixSortByScoreSize/rescoreHits/getResult (QueryMatcher.cpp:401-458,536-586), final sort -> pf_dedup_kernel
-//       phase 3 + pf_select_kernel
+//       radixSortByScoreSize/rescoreHits/getResult (QueryMatcher.cpp:401-458,536-586), final sort -> pf_keepmax_kernel
+//       + pf_select_kernel
 //
 // The CPU algorithm is order dependent: the "double hit" test compares the low 8 bits
 // of the diagonal of CONSECUTIVE index entries of one target in arrival order (query position, then similar
@@ -330,37 +330,36 @@ __global__ __launch_bounds__(256) void pf_split_kernel(PfSplitArgs A) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// a7 + a8 + keepMaxElement: one wavefront per (query, bin), four per workgroup.
-//
-// Phase 1 replays the bin's entries in arrival order.  Per target the CPU keeps `prev` = low byte of the previous
-// entry's diagonal (zero-initialised, CacheFriendlyOperations.cpp:186-208) and emits an entry whose byte equals it;
-// the emitted list is then run-length de-duplicated per target on that byte (:240-265).  State word per target:
-// bits 0-7 prev, 8-15 last emitted byte, bit 16 "has emitted".
-// Phase 2: ungapped score of every candidate (scalarDiagonalScoring, UngappedAlignment.cpp:45-57; overlap as in
-// computeSingelSequenceScores :423-437).
-// Phase 3: per target keep the first candidate (bin order = arrival order) whose count = min(255, score) is the
-// target's maximum (keepMaxElement, .cpp:354-384); survivors with count >= min_diag_score go to the query's list.
-__global__ __launch_bounds__(256) void pf_dedup_kernel(PfDedupArgs A) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
-    __shared__ int8_t smat[32 * 32];
+// a7: one wavefront per (query, bin), four per workgroup: replay of the bin's entries in arrival order.
+// Per target the CPU keeps `prev` = low byte of the previous entry's diagonal (zero-initialised,
+// CacheFriendlyOperations.cpp:186-208) and emits an entry whose byte equals it; the emitted list is then run-length
+// de-duplicated per target on that byte (:240-265).  State per target in LDS: uint16 = prev | last emitted byte << 8,
+// plus one "has emitted" bit (8.5 KB per wavefront).  Output: candidates (id, diagonal, arrival index) in arrival
+// order at cand[cand_base[bucket] ..), their number in cand_count[bucket].
+__global__ __launch_bounds__(256) void pf_replay_kernel(PfDedupArgs A) {
+    __shared__ uint16_t s_state[4][PF_IDS_PER_BIN];
+    __shared__ uint32_t s_emit[4][PF_IDS_PER_BIN / 32];
     const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
-    for (int k = (int)threadIdx.x; k < A.alphabet * A.alphabet; k += 256) smat[k] = A.mat[k];
-    __syncthreads();
     const uint32_t B = A.bins;
     const uint64_t bucket = (uint64_t)blockIdx.x * 4u + (uint32_t)wave;
     if (bucket >= (uint64_t)A.n_queries * B) return;
     const uint32_t q = (uint32_t)(bucket / B), bin = (uint32_t)(bucket % B);
     const uint32_t ntiles = A.q_ntiles[q];
-    if (ntiles == 0) return;
+    if (ntiles == 0) {
+        if (lane == 0) A.cand_count[bucket] = 0;
+        return;
+    }
     const uint32_t tb = A.q_tile_base[q];
-    uint32_t *S = reinterpret_cast<uint32_t *>(dyn_lds) + (size_t)wave * PF_IDS_PER_BIN;
+    uint16_t *S = s_state[wave];
+    uint32_t *E = s_emit[wave];
     int bshift = 0;
     while ((1u << bshift) < B) bshift++;
     for (int k = lane; k < PF_IDS_PER_BIN; k += 64) S[k] = 0;
+    for (int k = lane; k < PF_IDS_PER_BIN / 32; k += 64) E[k] = 0;
 
     PfCand *cand = A.cand + A.cand_base[bucket];
     uint32_t ncand = 0;
-    // ---- phase 1 ----
+    const uint64_t below = lanes_below(lane);
     for (uint32_t t0 = 0; t0 < ntiles; t0 += 64) {
         const uint32_t tl = t0 + (uint32_t)lane;
         uint32_t o0 = 0, n = 0;
@@ -372,22 +371,38 @@ __global__ __launch_bounds__(256) void pf_dedup_kernel(PfDedupArgs A) {
         const uint32_t incl = wave_incl_scan(n);
         const uint32_t total = __shfl(incl, 63);
         const uint32_t excl = incl - n;
-        for (uint32_t x0 = 0; x0 < total; x0 += 64) {
-            const uint32_t x = x0 + (uint32_t)lane;
-            const bool act = x < total;
+        // software pipeline: the entry of round r+1 is requested before round r is processed
+        uint64_t e_next = 0;
+        uint32_t tile_next = 0;
+        {
+            const uint32_t x = (uint32_t)lane;
             const int m = seg_find(excl, x);
-            const uint32_t ex_m = __shfl(excl, m);
-            const uint32_t o_m = __shfl(o0, m);
-            uint64_t e = 0;
-            if (act) e = A.split[(size_t)(tb + t0 + (uint32_t)m) * PF_T + o_m + (x - ex_m)];
+            const uint32_t ex_m = __shfl(excl, m), o_m = __shfl(o0, m);
+            tile_next = t0 + (uint32_t)m;
+            if (x < total) e_next = A.split[(size_t)(tb + tile_next) * PF_T + o_m + (x - ex_m)];
+        }
+        for (uint32_t x0 = 0; x0 < total; x0 += 64) {
+            const uint64_t e = e_next;
+            const uint32_t tile_cur = tile_next;
+            const bool act = x0 + (uint32_t)lane < total;
+            if (x0 + 64 < total) {
+                const uint32_t x = x0 + 64 + (uint32_t)lane;
+                const int m = seg_find(excl, x);
+                const uint32_t ex_m = __shfl(excl, m), o_m = __shfl(o0, m);
+                tile_next = t0 + (uint32_t)m;
+                e_next = 0;
+                if (x < total) e_next = A.split[(size_t)(tb + tile_next) * PF_T + o_m + (x - ex_m)];
+            }
             const uint32_t id = (uint32_t)e;
             const uint32_t diag = (uint32_t)(e >> 32) & 0xFFFFu;
             const uint32_t d8 = diag & 0xFFu;
             const uint32_t key = id >> bshift;   // < PF_IDS_PER_BIN
             const uint64_t same = match_lanes(key, 12, act);
-            const uint64_t below = lanes_below(lane);
-            uint32_t st = 0;
-            if (act) st = S[key];
+            uint32_t st = 0, em = 0;
+            if (act) {
+                st = S[key];
+                em = (E[key >> 5] >> (key & 31u)) & 1u;
+            }
             // stage 1: does my diagonal byte equal the previous entry's of this target?
             const uint64_t pm = same & below;
             const int pl = pm ? highest_lane(pm) : lane;
@@ -402,21 +417,25 @@ __global__ __launch_bounds__(256) void pf_dedup_kernel(PfDedupArgs A) {
             const uint32_t d_fpl = __shfl(d8, fpl);
             bool keep;
             if (fbelow) keep = flag && d_fpl != d8;
-            else keep = flag && (((st >> 16) & 1u) == 0u || ((st >> 8) & 0xFFu) != d8);
+            else keep = flag && (em == 0u || ((st >> 8) & 0xFFu) != d8);
             // state update by the last lane of every target group
             const int fhi = fm ? highest_lane(fm) : lane;
             const uint32_t d_fhi = __shfl(d8, fhi);
             if (act && (same & ~below & ~(1ull << lane)) == 0) {
                 uint32_t ns = d8;
-                if (fm) ns |= (d_fhi << 8) | (1u << 16);
-                else ns |= st & 0x1FF00u;
-                S[key] = ns;
+                if (fm) {
+                    ns |= d_fhi << 8;
+                    if (em == 0u) atomicOr(&E[key >> 5], 1u << (key & 31u));
+                } else {
+                    ns |= st & 0xFF00u;
+                }
+                S[key] = (uint16_t)ns;
             }
             const uint64_t kb = __ballot(keep);
             if (keep) {
                 PfCand c;
                 c.id = id;
-                c.arr = (t0 + (uint32_t)m) * (uint32_t)PF_T + (uint32_t)(e >> 48);
+                c.arr = tile_cur * (uint32_t)PF_T + (uint32_t)(e >> 48);
                 c.score = 0;
                 c.diag = (uint16_t)diag;
                 c.pad = 0;
@@ -425,23 +444,71 @@ __global__ __launch_bounds__(256) void pf_dedup_kernel(PfDedupArgs A) {
             ncand += (uint32_t)__popcll(kb);
         }
     }
-    if (ncand == 0) return;
-    __threadfence();   // phase 2 reads candidates written by other lanes of this wave
+    if (lane == 0) A.cand_count[bucket] = ncand;
+}
 
-    // ---- phase 2: ungapped diagonal score, one candidate per lane ----
+// ---------------------------------------------------------------------------------------------------------
+// a8: ungapped score of every candidate: s = max(0, s + P[q_pos][t_res]), best = max s along the diagonal
+// (scalarDiagonalScoring, UngappedAlignment.cpp:45-57; overlap as in computeSingelSequenceScores :423-437;
+// P = matrix + per-position composition term, createProfile :388-421).
+// One wavefront per (query, bin); a 16-lane group per candidate (4 candidates in flight per wavefront); per pass a
+// lane owns 16 consecutive diagonal cells (so a group reads 256 contiguous target bytes) and summarises them as the
+// function s -> (max(a, s + b), running best max(M, s + P)); a 4-step ordered tree over the group composes the 16
+// summaries, lane 0 of the group applies them to the carried score.  Bytes per cell: 1 (target) from HBM, the query
+// side stays in L1/L2.
+struct Seg {
+    int a, b, P, M;
+};
+__device__ __forceinline__ Seg seg_combine(const Seg &l, const Seg &r) {   // l then r
+    Seg o;
+    o.b = l.b + r.b;
+    o.a = max(r.a, l.a + r.b);
+    o.P = max(l.P, l.b + r.P);
+    o.M = max(max(l.M, r.M), l.a + r.P);
+    return o;
+}
+__device__ __forceinline__ void load16(const uint8_t *p, uint32_t w[4]) {
+    // 16 bytes from an arbitrarily aligned address via five aligned dwords
+    const uintptr_t u = reinterpret_cast<uintptr_t>(p);
+    const uint32_t *a = reinterpret_cast<const uint32_t *>(u & ~(uintptr_t)3);
+    const uint32_t sh = (uint32_t)(u & 3u);
+    const uint32_t d0 = a[0], d1 = a[1], d2 = a[2], d3 = a[3], d4 = a[4];
+    w[0] = __builtin_amdgcn_alignbyte(d1, d0, sh);
+    w[1] = __builtin_amdgcn_alignbyte(d2, d1, sh);
+    w[2] = __builtin_amdgcn_alignbyte(d3, d2, sh);
+    w[3] = __builtin_amdgcn_alignbyte(d4, d3, sh);
+}
+
+__global__ __launch_bounds__(256) void pf_ungapped_kernel(PfDedupArgs A) {
+    __shared__ int8_t smat[32 * 32];
+    const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
+    for (int k = (int)threadIdx.x; k < A.alphabet * A.alphabet; k += 256) smat[k] = A.mat[k];
+    for (int k = A.alphabet * A.alphabet + (int)threadIdx.x; k < 32 * 32; k += 256) smat[k] = 0;
+    __syncthreads();
+    const uint32_t B = A.bins;
+    const uint64_t bucket = (uint64_t)blockIdx.x * 4u + (uint32_t)wave;
+    if (bucket >= (uint64_t)A.n_queries * B) return;
+    const uint32_t ncand = A.cand_count[bucket];
+    if (ncand == 0) return;
+    const uint32_t q = (uint32_t)(bucket / B);
+    PfCand *cand = A.cand + A.cand_base[bucket];
     const uint32_t qp0 = A.q_off[q];
     const int qlen = (int)(A.q_off[q + 1] - qp0);
     const uint8_t *qr = A.q_res + qp0;
-    const int8_t *qc = A.q_corr + qp0;
+    const uint8_t *qc = reinterpret_cast<const uint8_t *>(A.q_corr) + qp0;
     const int alph = A.alphabet;
-    for (uint32_t c0 = 0; c0 < ncand; c0 += 64) {
-        const uint32_t ci = c0 + (uint32_t)lane;
-        if (ci < ncand) {
+    const int grp = lane >> 4, gl = lane & 15;
+    uint64_t cells = 0;
+    for (uint32_t c0 = 0; c0 < ncand; c0 += 4) {
+        const uint32_t ci = c0 + (uint32_t)grp;
+        const bool valid = ci < ncand;
+        int len = 0, qs = 0, ts = 0;
+        const uint8_t *t = A.t_res;
+        if (valid) {
             const uint32_t id = cand[ci].id;
             const int d = (int)(short)cand[ci].diag;
             const int tlen = (int)A.t_len[id];
-            const uint8_t *t = A.t_res + (size_t)A.t_off4[id] * 4;
-            int len = 0, qs = 0, ts = 0;
+            t = A.t_res + (size_t)A.t_off4[id] * 4;
             const int mind = d < 0 ? -d : d;
             if (d >= 0 && mind < qlen) {
                 len = min(tlen, qlen - mind);
@@ -450,19 +517,108 @@ __global__ __launch_bounds__(256) void pf_dedup_kernel(PfDedupArgs A) {
                 len = min(tlen - mind, qlen);
                 ts = mind;
             }
-            int score = 0, mx = 0;
-            for (int p = 0; p < len; p++) {
-                const int sc = (int)(int8_t)(smat[(int)qr[qs + p] * alph + (int)t[ts + p]] + qc[qs + p]);
-                score += sc;
-                score = score < 0 ? 0 : score;
-                mx = score > mx ? score : mx;
+        }
+        int maxlen = len;
+        maxlen = max(maxlen, __shfl_xor(maxlen, 16));
+        maxlen = max(maxlen, __shfl_xor(maxlen, 32));
+        int s = 0, best = 0;
+        for (int p0 = 0; p0 < maxlen; p0 += 256) {
+            const int o = p0 + gl * 16;
+            Seg g;
+            g.a = 0; g.b = 0; g.P = -(1 << 28); g.M = 0;
+            if (o < len) {
+                uint32_t tw[4], qw[4], cw[4];
+                load16(t + ts + o, tw);
+                load16(qr + qs + o, qw);
+                load16(qc + qs + o, cw);
+                const int nn = min(16, len - o);
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    const int tb_ = (int)((tw[k >> 2] >> ((k & 3) * 8)) & 0xFFu);
+                    const int qb = (int)((qw[k >> 2] >> ((k & 3) * 8)) & 0xFFu);
+                    const int cb = (int)(int8_t)((cw[k >> 2] >> ((k & 3) * 8)) & 0xFFu);
+                    const int x = (int)(int8_t)(smat[(qb * alph + tb_) & 1023] + cb);
+                    if (k < nn) {
+                        g.b += x;
+                        g.a = max(0, g.a + x);
+                        g.P = max(g.P, g.b);
+                        g.M = max(g.M, g.a);
+                    }
+                }
             }
-            cand[ci].score = (uint32_t)mx;
+            // ordered tree over the 16 lanes of the group
+#pragma unroll
+            for (int d = 1; d < 16; d <<= 1) {
+                Seg r;
+                r.a = __shfl_down(g.a, d);
+                r.b = __shfl_down(g.b, d);
+                r.P = __shfl_down(g.P, d);
+                r.M = __shfl_down(g.M, d);
+                if ((gl & (2 * d - 1)) == 0) g = seg_combine(g, r);
+            }
+            if (gl == 0 && p0 < len) {
+                best = max(best, max(g.M, s + g.P));
+                s = max(g.a, s + g.b);
+            }
+        }
+        if (valid && gl == 0) {
+            cand[ci].score = (uint32_t)best;
+            cells += (uint64_t)len;
         }
     }
-    __threadfence();
+    if (A.cell_counter) {
+        for (int d = 1; d < 64; d <<= 1) cells += __shfl_xor((unsigned long long)cells, d);
+        if (lane == 0 && cells) atomicAdd((unsigned long long *)A.cell_counter, (unsigned long long)cells);
+    }
+}
 
-    // ---- phase 3: best element per target ----
+// ---------------------------------------------------------------------------------------------------------
+// keepMaxElement (CacheFriendlyOperations.cpp:354-384): per target keep the first candidate (bin order = arrival
+// order) whose count = min(255, score) is the target's maximum; survivors with count >= min_diag_score are appended
+// to the query's list.  One wavefront per (query, bin); LDS table of (count << 24 | ~candidate index) per target.
+__global__ __launch_bounds__(256) void pf_keepmax_kernel(PfDedupArgs A) {
+    __shared__ uint32_t s_tab[4][PF_IDS_PER_BIN];
+    const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
+    const uint32_t B = A.bins;
+    const uint64_t bucket = (uint64_t)blockIdx.x * 4u + (uint32_t)wave;
+    if (bucket >= (uint64_t)A.n_queries * B) return;
+    const uint32_t ncand = A.cand_count[bucket];
+    if (ncand == 0) return;
+    const uint32_t q = (uint32_t)(bucket / B);
+    const PfCand *cand = A.cand + A.cand_base[bucket];
+    uint32_t *S = s_tab[wave];
+    int bshift = 0;
+    while ((1u << bshift) < B) bshift++;
+    if (ncand <= 64) {
+        // common case: the whole bucket fits one round, resolve with ballot matching instead of the table
+        PfCand c;
+        c.id = 0; c.arr = 0; c.score = 0; c.diag = 0; c.pad = 0;
+        const bool act = (uint32_t)lane < ncand;
+        if (act) c = cand[lane];
+        const uint32_t cnt = min(255u, c.score);
+        const uint64_t same = match_lanes(c.id >> bshift, 12, act);
+        // best (count, lowest lane) inside my target group
+        bool win = act;
+        uint64_t m = same & ~(1ull << lane);
+        while (__ballot(m != 0)) {
+            const int o = m ? __ffsll((long long)m) - 1 : lane;
+            const uint32_t oc = __shfl(cnt, o);
+            if (m) {
+                if (oc > cnt || (oc == cnt && o < lane)) win = false;
+                m &= m - 1;
+            }
+        }
+        win = win && cnt >= A.min_diag_score;
+        const uint64_t wb = __ballot(win);
+        if (wb) {
+            PfCand *surv = A.surv + A.cand_base[(uint64_t)q * B];
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&A.surv_count[q], (uint32_t)__popcll(wb));
+            base = __shfl(base, 0);
+            if (win) surv[base + (uint32_t)__popcll(wb & lanes_below(lane))] = c;
+        }
+        return;
+    }
     for (int k = lane; k < PF_IDS_PER_BIN; k += 64) S[k] = 0;
     for (uint32_t c0 = 0; c0 < ncand; c0 += 64) {
         const uint32_t ci = c0 + (uint32_t)lane;
@@ -675,6 +831,74 @@ __global__ __launch_bounds__(256) void pf_select_kernel(PfSelectArgs A) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Device analogue of Prefiltering::mergeTargetSplits (Prefiltering.cpp:412-526): the hit lists of one query from
+// n_splits target shards (gathered with one all-gather over RCCL) are concatenated, shard-local ids become global
+// ids (+ id_offset[split], the dbFrom convention of Prefiltering.cpp:879-881) and the result is sorted with
+// hit_t::compareHitsByScoreAndId.  One workgroup per query, bitonic sort in LDS.
+__global__ __launch_bounds__(256) void pf_merge_kernel(PfMergeArgs A) {
+    __shared__ uint64_t skey[PF_MERGE_CAP];
+    __shared__ uint16_t sdiag[PF_MERGE_CAP];
+    __shared__ uint32_t sbase[65];
+    const uint32_t q = blockIdx.x;
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (uint32_t sp = 0; sp < A.n_splits; sp++) {
+            sbase[sp] = run;
+            run += min(A.counts[(size_t)sp * A.nq + q], A.stride);
+        }
+        sbase[A.n_splits] = run;
+    }
+    __syncthreads();
+    const uint32_t total = sbase[A.n_splits];
+    for (uint32_t sp = 0; sp < A.n_splits; sp++) {
+        const uint32_t n = sbase[sp + 1] - sbase[sp];
+        const mmgpu_pf_hit *src = A.hits + ((size_t)sp * A.nq + q) * A.stride;
+        for (uint32_t k = threadIdx.x; k < n; k += 256) {
+            const mmgpu_pf_hit h = src[k];
+            const uint32_t a = (uint32_t)(h.score < 0 ? -h.score : h.score);
+            skey[sbase[sp] + k] = ((uint64_t)(0xFFFFFFFFu - a) << 32) | (uint64_t)(h.id + A.id_offset[sp]);
+            sdiag[sbase[sp] + k] = h.diagonal;
+        }
+    }
+    uint32_t np2 = 1;
+    while (np2 < total) np2 <<= 1;
+    __syncthreads();
+    for (uint32_t k = total + threadIdx.x; k < np2; k += 256) {
+        skey[k] = ~0ull;
+        sdiag[k] = 0;
+    }
+    __syncthreads();
+    for (uint32_t size = 2; size <= np2; size <<= 1) {
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            for (uint32_t k = threadIdx.x; k < np2 / 2; k += 256) {
+                const uint32_t i = 2 * k - (k & (stride - 1));
+                const uint32_t j = i + stride;
+                const bool up = (i & size) == 0;
+                const uint64_t a = skey[i], b = skey[j];
+                if ((a > b) == up) {
+                    skey[i] = b;
+                    skey[j] = a;
+                    const uint16_t t = sdiag[i];
+                    sdiag[i] = sdiag[j];
+                    sdiag[j] = t;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    mmgpu_pf_hit *dst = A.out_hits + (size_t)q * A.n_splits * A.stride;
+    for (uint32_t k = threadIdx.x; k < total; k += 256) {
+        mmgpu_pf_hit h;
+        h.id = (uint32_t)skey[k];
+        h.score = (int32_t)(0xFFFFFFFFu - (uint32_t)(skey[k] >> 32));
+        h.diagonal = sdiag[k];
+        h.reserved = 0;
+        dst[k] = h;
+    }
+    if (threadIdx.x == 0) A.out_counts[q] = total;
+}
+
 }  // namespace
 
 hipError_t launch_pf_kmers(const PfKmerArgs &A, bool emit, hipStream_t s) {
@@ -698,18 +922,24 @@ hipError_t launch_pf_split(const PfSplitArgs &A, uint32_t n_tiles, hipStream_t s
     return hipGetLastError();
 }
 
-hipError_t launch_pf_dedup(const PfDedupArgs &A, hipStream_t s) {
+hipError_t launch_pf_dedup(const PfDedupArgs &A, hipEvent_t after_replay, hipEvent_t after_ungapped, hipStream_t s) {
     const uint64_t buckets = (uint64_t)A.n_queries * A.bins;
     if (buckets == 0) return hipSuccess;
-    const size_t lds = 4 * PF_IDS_PER_BIN * sizeof(uint32_t);   // 64 KB of state tables + 1 KB static
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(pf_dedup_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(pf_dedup_kernel, dim3((unsigned)((buckets + 3) / 4)), dim3(256), lds, s, A);
+    const dim3 grid((unsigned)((buckets + 3) / 4)), block(256);
+    hipLaunchKernelGGL(pf_replay_kernel, grid, block, 0, s, A);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    if (after_replay && (e = hipEventRecord(after_replay, s)) != hipSuccess) return e;
+    hipLaunchKernelGGL(pf_ungapped_kernel, grid, block, 0, s, A);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    if (after_ungapped && (e = hipEventRecord(after_ungapped, s)) != hipSuccess) return e;
+    hipLaunchKernelGGL(pf_keepmax_kernel, grid, block, 0, s, A);
+    return hipGetLastError();
+}
+
+hipError_t launch_pf_merge(const PfMergeArgs &A, hipStream_t s) {
+    if (A.nq == 0) return hipSuccess;
+    hipLaunchKernelGGL(pf_merge_kernel, dim3(A.nq), dim3(256), 0, s, A);
     return hipGetLastError();
 }
 

@@ -348,7 +348,9 @@ class PfOracle:
 class RefPrefilter:
     """The real reference prefilter classes (needs /root/reference/data at run time)."""
 
-    def __init__(self, k=6, kmer_matrix="VTML80.out", ungapped_matrix="blosum62.out"):
+    def __init__(self, k=6, kmer_matrix="VTML80.out", ungapped_matrix="blosum62.out", serialized=None):
+        """serialized = (kmer "name.out:DATA" bytes, ungapped bytes) from tests/golden/matrices.npz where
+        /root/reference/data is absent (GPU box)."""
         L = self.L = ctypes.CDLL(REF_SO)
         L.mmref_pref_new.restype = c_p
         L.mmref_pref_new.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int]
@@ -356,8 +358,13 @@ class RefPrefilter:
                   "mmref_pref_match", "mmref_pref_score_matrix"):
             getattr(L, f).restype = ctypes.c_uint64
         L.mmref_pref_make_matcher.restype = ctypes.c_uint
+        L.mmref_pref_match_batch.restype = ctypes.c_double
         d = os.path.join(REFERENCE_ROOT, "data")
-        self.c = c_p(L.mmref_pref_new(os.path.join(d, kmer_matrix).encode(), os.path.join(d, ungapped_matrix).encode(), k))
+        if serialized is not None:
+            a, b = bytes(serialized[0]), bytes(serialized[1])
+        else:
+            a, b = os.path.join(d, kmer_matrix).encode(), os.path.join(d, ungapped_matrix).encode()
+        self.c = c_p(L.mmref_pref_new(a, b, k))
         self.k = k
         self.alphabet = L.mmref_pref_alphabet(self.c)
 
@@ -421,3 +428,17 @@ class RefPrefilter:
                                     ctypes.c_uint64(cap), ctypes.byref(dbm), ctypes.byref(kpp))
         return dict(id=ids[:n].copy(), score=sc[:n].copy(), diagonal=dg[:n].copy(), db_matches=dbm.value,
                     kmers_per_pos=kpp.value)
+
+    def match_batch(self, qres, qoff, n_threads, max_hits=300, comp_bias=True, min_diag_score=15, max_seq_len=32000):
+        """Multi-threaded query loop (CPU baseline). Returns (seconds, total hits, total db matches, hit counts)."""
+        qres = np.ascontiguousarray(qres, np.uint8)
+        qoff = np.ascontiguousarray(qoff, np.uint64)
+        nq = len(qoff) - 1
+        th = ctypes.c_uint64(0)
+        dbm = ctypes.c_uint64(0)
+        counts = np.zeros(max(nq, 1), np.uint32)
+        sec = self.L.mmref_pref_match_batch(self.c, _ptr(qres), _ptr(qoff), nq, int(n_threads), self.kmer_thr,
+                                            int(max_seq_len), ctypes.c_uint64(max_hits), int(comp_bias),
+                                            int(min_diag_score), int(self.spaced), ctypes.byref(th), ctypes.byref(dbm),
+                                            _ptr(counts))
+        return sec, th.value, dbm.value, counts[:nq]

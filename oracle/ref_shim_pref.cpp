@@ -10,6 +10,8 @@
 // (Prefiltering.cpp:68-69, 220-225, 544-583, 826-842, 873), from numeric sequences, without DBReader and
 // without tantan masking (IndexBuilder.cpp:146-156; `--mask 0`), so that the plain-C restatement in
 // oracle/prefilter_oracle.c can be fuzzed against it.
+#include <omp.h>
+
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
@@ -128,25 +130,37 @@ void mmref_pref_build_index(void *h, const uint8_t *tdata, const uint64_t *toff,
     c->lookup = new SequenceLookup(n, toff[n]);
     char *idScore = new char[alph];
     for (int a = 0; a < alph; a++) idScore[a] = (char)c->kmerMat->subMatrix[a][a];   // IndexBuilder.cpp:11-22
-    Sequence s(c->maxLen, Parameters::DBTYPE_AMINO_ACIDS, c->kmerMat, c->kmerSize, spaced != 0, false, true);
-    Indexer idxer(alph - 1, c->kmerSize);
-    std::vector<unsigned int> buffer(c->maxLen + 8);
     size_t tableSize = 0;
-    for (uint32_t i = 0; i < n; i++) {
-        unsigned len = (unsigned)(toff[i + 1] - toff[i]);
-        s.mapSequence(i, i, std::make_pair((const unsigned char *)(tdata + toff[i]), (const unsigned int)len));
-        c->index->addKmerCount(&s, &idxer, buffer.data(), kmer_thr, idScore);
-        c->lookup->addSequence(s.numSequence, s.L, i, toff[i]);
-        tableSize += len;
+    // same structure as IndexBuilder::fillDatabase: thread-private Sequence/Indexer/buffers, atomic adds inside
+    // IndexTable (IndexBuilder.cpp:118-166)
+#pragma omp parallel reduction(+ : tableSize)
+    {
+        Sequence s(c->maxLen, Parameters::DBTYPE_AMINO_ACIDS, c->kmerMat, c->kmerSize, spaced != 0, false, true);
+        Indexer idxer(alph - 1, c->kmerSize);
+        std::vector<unsigned int> buffer(c->maxLen + 8);
+#pragma omp for schedule(dynamic, 100)
+        for (uint32_t i = 0; i < n; i++) {
+            unsigned len = (unsigned)(toff[i + 1] - toff[i]);
+            s.mapSequence(i, i, std::make_pair((const unsigned char *)(tdata + toff[i]), (const unsigned int)len));
+            c->index->addKmerCount(&s, &idxer, buffer.data(), kmer_thr, idScore);
+            c->lookup->addSequence(s.numSequence, s.L, i, toff[i]);
+            tableSize += len;
+        }
     }
     c->index->initMemory(tableSize);
     c->index->init();
-    IndexEntryLocalTmp *tmp = (IndexEntryLocalTmp *)malloc((c->maxLen + 8) * sizeof(IndexEntryLocalTmp));
-    for (uint32_t i = 0; i < n; i++) {
-        s.mapSequence(i, i, c->lookup->getSequence(i));
-        c->index->addSequence(&s, &idxer, &tmp, c->maxLen + 8, kmer_thr, idScore);
+#pragma omp parallel
+    {
+        Sequence s(c->maxLen, Parameters::DBTYPE_AMINO_ACIDS, c->kmerMat, c->kmerSize, spaced != 0, false, true);
+        Indexer idxer(alph - 1, c->kmerSize);
+        IndexEntryLocalTmp *tmp = (IndexEntryLocalTmp *)malloc((c->maxLen + 8) * sizeof(IndexEntryLocalTmp));
+#pragma omp for schedule(dynamic, 100)
+        for (uint32_t i = 0; i < n; i++) {
+            s.mapSequence(i, i, c->lookup->getSequence(i));
+            c->index->addSequence(&s, &idxer, &tmp, c->maxLen + 8, kmer_thr, idScore);
+        }
+        free(tmp);
     }
-    free(tmp);
     delete[] idScore;
     c->index->revertPointer();
     c->index->sortDBSeqLists();
@@ -211,6 +225,41 @@ uint64_t mmref_pref_match(void *h, const uint8_t *q, uint32_t qlen, uint32_t ide
     if (db_matches) *db_matches = c->matcher->getStatistics()->dbMatches;
     if (kmers_per_pos) *kmers_per_pos = c->matcher->getStatistics()->kmersPerPos;
     return r.second;
+}
+
+// CPU baseline: the query loop of Prefiltering::runSplit (Prefiltering.cpp:820-917) - one QueryMatcher + Sequence per
+// OpenMP thread, dynamic schedule - over nq queries; returns the wall time of the loop (matcher construction excluded,
+// as the reference's own "Time for processing" excludes setup) and the total number of hits / index matches.
+double mmref_pref_match_batch(void *h, const uint8_t *qdata, const uint64_t *qoff, uint32_t nq, int n_threads, int kmer_thr,
+                              unsigned max_seq_len, uint64_t max_hits, int comp_bias, unsigned min_diag_score, int spaced,
+                              uint64_t *total_hits, uint64_t *total_db_matches, uint32_t *hit_counts) {
+    PrefCtx *c = (PrefCtx *)h;
+    unsigned ml = std::max(max_seq_len, c->maxLen);
+    uint64_t hits = 0, dbm = 0;
+    double t_loop = 0;
+#pragma omp parallel num_threads(n_threads) reduction(+ : hits, dbm)
+    {
+        QueryMatcher matcher(c->index, c->lookup, c->kmerMat, c->ungappedMat, (short)kmer_thr, c->kmerSize, c->dbSize, ml,
+                             max_hits, comp_bias != 0, 1.0f, true, min_diag_score, false, false);
+        matcher.setSubstitutionMatrix(&c->three, &c->two);
+        Sequence seq(ml, Parameters::DBTYPE_AMINO_ACIDS, c->kmerMat, c->kmerSize, spaced != 0, comp_bias != 0, true);
+#pragma omp barrier
+        double t0 = omp_get_wtime();
+#pragma omp for schedule(dynamic, 1)
+        for (uint32_t i = 0; i < nq; i++) {
+            seq.mapSequence(i, i, std::make_pair((const unsigned char *)(qdata + qoff[i]), (const unsigned int)(qoff[i + 1] - qoff[i])));
+            std::pair<hit_t *, size_t> r = matcher.matchQuery(&seq, DB_LOCAL_ID_INVALID, false);
+            hits += r.second;
+            dbm += matcher.getStatistics()->dbMatches;
+            if (hit_counts) hit_counts[i] = (uint32_t)r.second;
+        }
+        double t1 = omp_get_wtime();   // after the implicit barrier of the omp for
+#pragma omp master
+        t_loop = t1 - t0;
+    }
+    if (total_hits) *total_hits = hits;
+    if (total_db_matches) *total_db_matches = dbm;
+    return t_loop;
 }
 
 }  // extern "C"

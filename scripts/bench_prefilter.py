@@ -47,17 +47,20 @@ for _ in range(args.steps):
         b.run()
 gpu.synchronize()
 dt = (time.perf_counter() - t0) / args.steps
-stage = np.zeros(5)
+stage = np.zeros(7)
+cells = cands = 0
 ent = lists = hits_n = ovf = 0
 allhits = []
 for b in batches:
     stage += np.array(b.stage_ms())
     h, c, st, stats = b.fetch()
+    cc = b.last_cells(); cells += cc[0]; cands += cc[1]
     ent += int(stats["db_matches"].sum()); lists += int(stats["kmer_list_len"].sum()); hits_n += int(c.sum()); ovf += int((st != 0).sum())
     allhits.append((h, c, st))
 out = dict(queries=len(qs), targets=len(toff) - 1, residues=int(toff[-1]), index_entries=len(ids),
            queries_per_s=round(len(qs) / dt, 1), s_per_pass=round(dt, 4), stage_ms=[round(x, 2) for x in stage],
-           db_matches=ent, similar_kmers=lists, hits=hits_n, overflow_queries=ovf,
+           db_matches=ent, similar_kmers=lists, ungapped_cells=cells, candidates=cands,
+           ungapped_GBps=round(cells / (stage[3] * 1e-3) / 1e9, 1) if stage[3] else None, hits=hits_n, overflow_queries=ovf,
            gather_GBps=round(ent * 20 / (stage[1] * 1e-3) / 1e9, 2) if stage[1] else None,
            entries_per_query=round(ent / max(len(qs), 1)), t_gen=round(t_gen, 1), t_score_matrix=round(t_sm, 1),
            t_index_build=round(t_ix, 1), t_load=round(t_load, 1), t_prepare=round(t_prep, 1))

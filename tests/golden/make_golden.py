@@ -44,6 +44,7 @@ def matrices():
     km.L.mmref_get_pback.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     km.L.mmref_get_pback(km.c, pb2.ctypes.data)
     d["vtml80_pback"] = pb2
+    d["vtml80_serialized"] = np.frombuffer(km.serialized_matrix(), np.uint8)
     np.savez_compressed(os.path.join(OUT, "matrices.npz"), **d)
     print("matrices.npz", {k: v.shape for k, v in d.items()})
     return sw

@@ -57,3 +57,14 @@ def synthetic_case(n_queries, n_targets, seed, planted=0.2, x_every=400):
     tres[rng.choice(len(tres), max(1, len(tres) // x_every), replace=False)] = 20
     qres[rng.choice(len(qres), max(1, len(qres) // x_every), replace=False)] = 20
     return (qres, qoff), (tres, toff)
+
+
+def shards(g, world):
+    """Contiguous target shards (residues, offsets) and their sizes."""
+    n = len(g["toff"]) - 1
+    cut = [n * r // world for r in range(world + 1)]
+    out = []
+    for r in range(world):
+        o = g["toff"][cut[r]:cut[r + 1] + 1].astype(np.int64)
+        out.append((g["tres"][o[0]:o[-1]], (o - o[0]).astype(np.uint64)))
+    return out, [cut[r + 1] - cut[r] for r in range(world)]

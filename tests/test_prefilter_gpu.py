@@ -72,3 +72,51 @@ def test_prefilter_empty_and_tiny(gpu, golden_case):
     q = np.array([0, 1, 2], np.uint8)
     hits, counts, status, stats = gpu.pf_batch([dict(q=q, comp_bias=None, identity_id=7)], int(g["kmer_thr"]))
     assert counts[0] == 1 and hits[0]["id"][0] == 7 and hits[0]["score"][0] == 65535
+
+
+def test_split_merge_on_device(gpu):
+    """Two target shards processed one after the other on this GPU, lists handed over in device memory
+    (mmgpu_pf_fetch_device), merged by mmgpu_pf_merge_splits: equals the host mirror and the oracle per shard."""
+    import torch
+    from mmseqs2_amd import capi, distributed as D
+    g = pc.golden()
+    orc = pc.pf_oracle()
+    thr = int(g["kmer_thr"])
+    world = 2
+    sh, sizes = pc.shards(g, world)
+    mh = capi.split_max_hits(300, world)
+    qs = pc.golden_queries(g)
+    for qd in qs:
+        qd["identity_id"] = None
+    nq = len(qs)
+    dev = torch.device("cuda", 0)
+    gh = torch.zeros((world, nq, mh, 3), dtype=torch.int32, device=dev)
+    gc = torch.zeros((world, nq), dtype=torch.int32, device=dev)
+    host = []
+    for r in range(world):
+        chk.load_case(gpu, g, sh[r][0], sh[r][1], thr)
+        b = gpu.pf_prepare(qs, thr, max_hits=mh, ref_bins=2)
+        b.run()
+        b.fetch_device(gh[r].data_ptr(), mh, gc[r].data_ptr())
+        hits, counts, status, stats = b.fetch()
+        host.append((hits.copy(), counts.copy()))
+        orc.build_index(sh[r][0], sh[r][1], thr)
+        for qi, qd in enumerate(qs):          # each shard against the oracle
+            o = orc.match(qd["q"], qd["comp_bias"], 2, max_hits=mh)
+            n = int(counts[qi])
+            assert np.array_equal(hits[qi]["id"][:n], o["id"]) and np.array_equal(hits[qi]["score"][:n], o["score"])
+        b.free()
+    out_h = torch.zeros((nq, world * mh, 3), dtype=torch.int32, device=dev)
+    out_c = torch.zeros((nq,), dtype=torch.int32, device=dev)
+    gpu.pf_merge_splits(gh.data_ptr(), gc.data_ptr(), world, nq, mh, D.shard_id_offsets(sizes), out_h.data_ptr(), out_c.data_ptr())
+    gpu.synchronize()
+    oh = out_h.cpu().numpy().reshape(nq, world * mh * 3).view(capi.PF_HIT_DTYPE).reshape(nq, world * mh)
+    oc = out_c.cpu().numpy()
+    off = D.shard_id_offsets(sizes)
+    for qi in range(nq):
+        exp = capi.merge_hit_lists_host([host[r][0][qi, :host[r][1][qi]] for r in range(world)], off)
+        n = int(oc[qi])
+        assert n == len(exp)
+        assert np.array_equal(oh[qi]["id"][:n], exp["id"]) and np.array_equal(oh[qi]["score"][:n], exp["score"])
+        assert np.array_equal(oh[qi]["diagonal"][:n], exp["diagonal"])
+    chk.load_case(gpu, g, g["tres"], g["toff"], thr)
