@@ -14,6 +14,12 @@ N>1 (launched by torch.distributed.run, one process per GPU): every rank owns an
 the same size and its own prefilter lists (weak scaling, no data-path collective in this round); value =
 cells of all ranks / max-over-ranks time.
 
+The same line carries a second object, "search": BASELINE.json configs[2] (10k queries x 1M targets, -s 5.7,
+UniRef50-like lengths, 50-member families) through the k-mer prefilter and the gapped alignment of its hit lists -
+queries/s, per-stage milliseconds, the roofline of the HBM-bound gather kernel and the reference's own prefilter
+loop timed on the host cores.  With N>1 every rank holds its own 1M-target shard (weak scaling), the per-query hit
+lists are all-gathered over RCCL and merged on the device (mergeTargetSplits semantics).
+
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -101,6 +107,169 @@ def cpu_baseline(matrices, qs, cbs, tres, toff, budget_s=15.0):
                       "%.1f s wall, %d threads" % (len(sample), chunk, nq, cells, dt, cores)}
 
 
+def search_cpu_baseline(matrices, qres, qoff, tres, toff, kmer_thr, budget_s):
+    """The reference's own prefilter query loop (QueryMatcher::matchQuery per OpenMP thread, Prefiltering.cpp:820-917)
+    from oracle/_ref/libmmref.so on the host cores, bounded sample of the same queries against the same targets."""
+    from oracle import pyoracle
+    if not pyoracle.ref_available():
+        return None
+    cores = os.cpu_count() or 1
+    ref = pyoracle.RefPrefilter(6, serialized=(matrices["vtml80_serialized"].tobytes(), matrices["blosum62_serialized"].tobytes()))
+    t0 = time.time()
+    ref.build_index(tres, toff, kmer_thr)
+    t_index = time.time() - t0
+    nq = len(qoff) - 1
+    n_cal = min(nq, max(cores, 64))
+    sec, hits, dbm, _ = ref.match_batch(qres[:int(qoff[n_cal])], qoff[:n_cal + 1], cores)
+    rate = n_cal / max(sec, 1e-3)
+    n = int(min(nq, max(n_cal, rate * budget_s)))
+    sec, hits, dbm, _ = ref.match_batch(qres[:int(qoff[n])], qoff[:n + 1], cores)
+    return {"value": round(n / sec, 1), "unit": "queries/s (prefilter only)", "cores": cores, "kind": "reference",
+            "sample": "first %d of the %d queries against the same %d targets, %.1f s wall, %d threads; reference index build "
+                      "%.1f s (not counted)" % (n, nq, len(toff) - 1, sec, cores, t_index),
+            "db_matches_per_query": round(dbm / n), "hits_per_query": round(hits / n, 1)}
+
+
+def search_section(args, gpu, torch, dist, rank, world, matrices, barrier):
+    """BASELINE.json configs[2]/[3]: k-mer prefilter + gapped alignment of the hit lists, one target shard per rank."""
+    from mmseqs2_amd import capi, workloads as wl
+    from mmseqs2_amd import distributed as D
+    km16 = matrices["vtml80_kmer"].astype(np.int16)
+    sens, k, max_res = 5.7, 6, 300
+    kmer_thr = int(163.2 - 8.917 * sens)          # Prefiltering::getKmerThreshold, Prefiltering.cpp:1080-1095
+    t0 = time.time()
+    (qres, qoff), (tres, toff), _, _ = wl.config3_prefilter(args.pf_families, args.pf_members, args.pf_queries, seed=10,
+                                                             target_seed=11 + 1000 * rank)
+    t_gen = time.time() - t0
+    qs = wl.split(qres, qoff)
+    nq, nt = len(qs), len(toff) - 1
+    t0 = time.time()
+    s3, i3 = capi.host_score_matrix(km16, 3)
+    koff, kids, kpos = capi.host_index_build(tres, toff, km16, k, True, kmer_thr)
+    t_index = time.time() - t0
+    gpu.load_targets(tres, toff, 21)
+    gpu.pf_load_index(k, 21, True, s3, i3, koff, kids, kpos, matrices["blosum62_ungapped"])
+    cbs = [capi.host_comp_bias(km16, matrices["vtml80_pback"], q)[0] for q in qs]
+    queries = [dict(q=q, comp_bias=cb, identity_id=None) for q, cb in zip(qs, cbs)]
+    mh = capi.split_max_hits(max_res, world)      # Prefiltering.cpp:391-394
+    bsz = args.pf_batch
+    batches = [gpu.pf_prepare(queries[i:i + bsz], kmer_thr, max_hits=mh, min_diag_score=15, ref_bins=2)
+               for i in range(0, nq, bsz)]
+    shard_sizes = [nt] * world
+
+    def one_pass(keep):
+        merged = []
+        for b in batches:
+            b.run()
+            if world > 1:
+                mh_t, mc_t = D.gather_and_merge_device(gpu, b, b.nq, mh, shard_sizes)
+                if keep:
+                    merged.append((mh_t, mc_t))
+        return merged
+
+    one_pass(False)                                # warm-up, sizes the working buffers
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.pf_steps):
+        merged = one_pass(True)
+    barrier()
+    t_pf = (time.perf_counter() - t0) / args.pf_steps
+    if dist is not None:
+        tm = torch.tensor([t_pf], device="cuda")
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        t_pf = float(tm.item())
+    stage = np.zeros(7)
+    ent = sim = cells = cands = nhits = ovf = 0
+    lists = []
+    for bi, b in enumerate(batches):
+        stage += np.array(b.stage_ms())
+        h, c, st, stats = b.fetch()
+        cc = b.last_cells()
+        cells += cc[0]
+        cands += cc[1]
+        ent += int(stats["db_matches"].sum())
+        sim += int(stats["kmer_list_len"].sum())
+        ovf += int((st != 0).sum())
+        if world > 1:
+            mh_t, mc_t = merged[bi]
+            hh = mh_t.cpu().numpy().reshape(b.nq, -1).view(capi.PF_HIT_DTYPE).reshape(b.nq, -1)
+            cc2 = mc_t.cpu().numpy()
+            for qi in range(b.nq):
+                ids = hh[qi]["id"][:cc2[qi]]
+                own = (ids >= rank * nt) & (ids < (rank + 1) * nt)     # pairs run on the GPU owning the target
+                lists.append((ids[own] - rank * nt).astype(np.uint32))
+            nhits += int(cc2.sum())
+        else:
+            for qi in range(b.nq):
+                lists.append(h[qi]["id"][:c[qi]].copy())
+            nhits += int(c.sum())
+
+    # ---- spot check of the prefilter lists against the oracle on a reduced copy of the problem is done by the
+    # tests; here: the alignment of the lists (Alignment::run behind the prefilter DB) ----
+    mat = matrices["blosum62_sw"]
+    sub16 = mat.astype(np.int16)
+    t0 = time.time()
+    swq = []
+    for q, ids in zip(qs, lists):
+        swq.append(dict(q=q, comp_bias=capi.host_comp_bias(sub16, matrices["blosum62_pback"], q)[1], targets=ids,
+                        min_start_score=1))
+    swb = gpu.sw_prepare(mat, 11, 1, swq, mode=1)
+    t_handoff = time.time() - t0
+    swb.run()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.pf_steps):
+        swb.run()
+    barrier()
+    t_sw = (time.perf_counter() - t0) / args.pf_steps
+    sw_cells, sw_pairs = swb.cells, swb.pairs
+    if dist is not None:
+        tm = torch.tensor([t_sw], device="cuda")
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        t_sw = float(tm.item())
+        tot = torch.tensor([float(sw_cells), float(sw_pairs), float(ent)], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tot)
+        sw_cells, sw_pairs, ent_all = float(tot[0]), float(tot[1]), float(tot[2])
+    else:
+        ent_all = float(ent)
+    swb.free()
+    res = None
+    if rank == 0:
+        # algorithmic HBM bytes of the gather/split kernel (SURVEY.md section 8d): ~20 B per index entry touched
+        # (6 B entry gathered, 8 B written + 8 B re-read for the replay, amortised list descriptors)
+        alg = 20.0 * ent
+        achieved = alg / (stage[1] * 1e-3) / 1e9 if stage[1] > 0 else 0.0
+        res = {
+            "workload": "BASELINE.json configs[2]: %d queries x %d targets per GPU (%d families x %d members, L~LogNormal(5.45,0.6)), "
+                        "-s 5.7 (k=6, k-mer thr %d), --max-seqs %d%s, then alignment of the hit lists (score, ends, starts)"
+                        % (nq, nt, args.pf_families, args.pf_members, kmer_thr, max_res,
+                           " (per-split %d, Prefiltering.cpp:391-394)" % mh if world > 1 else ""),
+            "queries_per_s": round(nq / (t_pf + t_sw), 1), "prefilter_queries_per_s": round(nq / t_pf, 1),
+            "prefilter_s": round(t_pf, 4), "align_s": round(t_sw, 4), "handoff_s": round(t_handoff, 2),
+            "targets_total": nt * world, "n_gpus": world,
+            "stage_ms": {"kmers_lists": round(stage[0], 2), "gather_split": round(stage[1], 2), "replay": round(stage[2], 2),
+                         "ungapped": round(stage[3], 2), "keepmax": round(stage[4], 2), "select": round(stage[5], 2),
+                         "total_rank0": round(stage[6], 2)},
+            "db_matches": int(ent), "similar_kmers": int(sim), "double_diagonal_candidates": int(cands),
+            "ungapped_cells": int(cells), "prefilter_hits": int(nhits), "overflow_queries": int(ovf),
+            "align_pairs": int(sw_pairs), "align_cells": int(sw_cells),
+            "align_gcups": round(sw_cells / t_sw / 1e9, 1),
+            "roofline": {"kernel": "pf_split_kernel (index gather + stable bin split)", "bound": "hbm",
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel_ms": round(stage[1], 3), "algorithmic_bytes_per_entry": 20,
+                         "ungapped": {"kernel": "pf_ungapped_kernel", "bound": "hbm", "unit": "GB/s",
+                                      "achieved": round(cells / (stage[3] * 1e-3) / 1e9, 1) if stage[3] > 0 else None,
+                                      "peak": HBM_PEAK_GBS, "bytes_per_cell": 1}},
+            "setup_s": {"generate": round(t_gen, 1), "tables_index_host": round(t_index, 1)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = search_cpu_baseline(matrices, qres, qoff, tres, toff, kmer_thr, args.cpu_seconds)
+    for b in batches:
+        b.free()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -109,6 +278,12 @@ def main():
     ap.add_argument("--queries", type=int, default=1000)
     ap.add_argument("--targets", type=int, default=100000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-search", action="store_true", help="skip the configs[2] prefilter+align section")
+    ap.add_argument("--pf-families", type=int, default=20000)
+    ap.add_argument("--pf-members", type=int, default=50)
+    ap.add_argument("--pf-queries", type=int, default=10000)
+    ap.add_argument("--pf-batch", type=int, default=1024)
+    ap.add_argument("--pf-steps", type=int, default=2)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
 
@@ -195,6 +370,12 @@ def main():
                  "score_checksum": int(res["score"].astype(np.int64).sum())}
         del res
 
+    batch_cells, batch_pairs = batch.cells, batch.pairs
+    batch.free()
+    search = None
+    if not args.no_search:
+        search = search_section(args, gpu, torch, dist, rank, world, matrices, barrier)
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = total_cells * args.steps / elapsed / 1e9
@@ -205,7 +386,7 @@ def main():
         alg_bytes = float(args.queries) * float((tlen + 28).sum()) + 2.0 * float(qoff[-1])
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
         # packed-int16 VALU work the algorithm needs: 10 VOP3P lane-ops per pair of cells
-        lane_ops = batch.cells / 2.0 * 10.0
+        lane_ops = batch_cells / 2.0 * 10.0
         out = {
             "metric": "sw_gcells_per_s", "value": round(value, 2), "unit": "GCUPS",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
@@ -213,7 +394,7 @@ def main():
             "config": {"workload": "BASELINE.json configs[1]: align-only, %d random L~N(350,35) queries x %d targets "
                                    "(10%% planted homologs), all-vs-all prefilter lists, BLOSUM62 gap 11/1, comp-bias on, "
                                    "score+end positions" % (args.queries, args.targets),
-                       "pairs_per_gpu": int(batch.pairs), "cells_per_gpu": int(batch.cells),
+                       "pairs_per_gpu": int(batch_pairs), "cells_per_gpu": int(batch_cells),
                        "parallelism": "1 process/GPU, independent target shards" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
@@ -226,8 +407,9 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(matrices, qs, cbs, tres, toff, args.cpu_seconds)
+        if search is not None:
+            out["search"] = search
         print(json.dumps(out))
-    batch.free()
     gpu.close()
     if dist is not None:
         dist.destroy_process_group()

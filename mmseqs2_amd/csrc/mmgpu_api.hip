@@ -151,13 +151,18 @@ extern "C" int mmgpu_host_round_comp_bias(const float *bias, uint32_t len, int8_
 // Smith-Waterman batches
 // ---------------------------------------------------------------------------------------------------------
 namespace {
-constexpr uint32_t JOB_HITS = 256;   // hits per workgroup (8 rounds of 32)
+constexpr uint32_t JOB_HITS = 256;   // most hits per workgroup (8 rounds of 32)
+constexpr uint32_t JOB_ROUND = 32;   // targets a workgroup has in flight
+constexpr uint64_t JOB_CELLS = 60000000ull;   // cut a job once it holds this many forward cells
+constexpr int SW_STREAMS = 8;        // kernel instantiations (classes) run concurrently on side streams
 
 struct SwClass {            // all jobs sharing one kernel instantiation
     int rows_per_lane = 0;
     bool multi = false;
     std::vector<SwJob> jobs;
+    std::vector<uint64_t> job_cells;
     DevBuf d_jobs;
+    DevBuf d_scratch;   // multi-tile classes: [job][4 waves][4 groups][2 buffers][scratch_cols] x uint2
 };
 }  // namespace
 
@@ -167,7 +172,10 @@ struct mmgpu_sw_batch_t {
     uint64_t cells = 0, pairs = 0;
     uint32_t n_queries = 0;
     std::vector<SwClass> classes;
-    DevBuf d_qres, d_qcb, d_qoff, d_qbias, d_qminstart, d_hit_target, d_hit_out, d_out, d_mat, d_scratch;
+    DevBuf d_qres, d_qcb, d_qoff, d_qbias, d_qminstart, d_hit_target, d_hit_out, d_out, d_mat;
+    std::vector<hipStream_t> side;   // side streams the classes run on
+    hipEvent_t fork = nullptr;
+    std::vector<hipEvent_t> join;
     uint32_t scratch_cols = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;   // one pair per mmgpu_sw_run since prepare
     bool ran = false;
@@ -262,13 +270,25 @@ extern "C" int mmgpu_sw_prepare(mmgpu_ctx *c, const mmgpu_sw_params *par, const 
             b->cells += (uint64_t)Q.qlen * c->h_len[t];
             max_tlen = std::max(max_tlen, c->h_len[t]);
         }
-        for (uint32_t k = 0; k < Q.n_targets; k += JOB_HITS) {
+        // Jobs: consecutive hits of the (length-sorted) list, cut at multiples of one workgroup round (32 targets)
+        // once a job holds JOB_CELLS forward cells, at the latest after JOB_HITS hits - a 5000-residue query against
+        // 300 long targets must not become one 7e9-cell workgroup.
+        for (uint32_t k = 0; k < Q.n_targets;) {
+            uint64_t jc = 0;
+            uint32_t e = k;
+            while (e < Q.n_targets && e - k < JOB_HITS) {
+                const uint32_t stop = std::min<uint32_t>(e + JOB_ROUND, Q.n_targets);
+                for (; e < stop; e++) jc += (uint64_t)Q.qlen * c->h_len[hit_target[hit_cursor + e]];
+                if (jc >= JOB_CELLS) break;
+            }
             SwJob j;
             j.query = i;
             j.hit_begin = hit_cursor + k;
-            j.hit_end = hit_cursor + std::min<uint32_t>(k + JOB_HITS, Q.n_targets);
+            j.hit_end = hit_cursor + e;
             j.pad = 0;
             cls.jobs.push_back(j);
+            cls.job_cells.push_back(jc);
+            k = e;
         }
         hit_cursor += Q.n_targets;
         out_cursor += Q.n_targets;
@@ -287,15 +307,21 @@ extern "C" int mmgpu_sw_prepare(mmgpu_ctx *c, const mmgpu_sw_params *par, const 
     B_TRY(upload(b->d_hit_out, hit_out, s));
     B_TRY(upload(b->d_mat, mat, s));
     B_TRY(b->d_out.alloc(std::max<size_t>((size_t)total_hits, 1) * sizeof(mmgpu_sw_hit)));
-    size_t multi_jobs = 0;
     for (auto &cls : b->classes) {
+        // longest job first: the dispatcher hands out workgroups in blockIdx order, so the tail is the shortest jobs
+        std::vector<uint32_t> ord(cls.jobs.size());
+        std::iota(ord.begin(), ord.end(), 0u);
+        std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t bb) { return cls.job_cells[a] > cls.job_cells[bb]; });
+        std::vector<SwJob> sorted(cls.jobs.size());
+        for (size_t z = 0; z < ord.size(); z++) sorted[z] = cls.jobs[ord[z]];
+        cls.jobs.swap(sorted);
         B_TRY(upload(cls.d_jobs, cls.jobs, s));
-        if (cls.multi) multi_jobs = std::max(multi_jobs, cls.jobs.size());
     }
     if (any_multi) {
         b->scratch_cols = max_tlen + 16;
-        // [job][wave][group][2 buffers][cols] x uint2
-        B_TRY(b->d_scratch.alloc(multi_jobs * 4 * 4 * 2 * (size_t)b->scratch_cols * sizeof(uint2)));
+        for (auto &cls : b->classes)
+            if (cls.multi && !cls.jobs.empty())
+                B_TRY(cls.d_scratch.alloc(cls.jobs.size() * 4 * 4 * 2 * (size_t)b->scratch_cols * sizeof(uint2)));
     }
     B_TRY(hipStreamSynchronize(s));   // the host vectors above die with this scope
 #undef B_TRY
@@ -313,9 +339,22 @@ extern "C" int mmgpu_sw_run(mmgpu_ctx *c, mmgpu_sw_batch_t *b) {
         b->events.push_back(std::make_pair(ev0, ev1));
         HIP_TRY(hipEventRecord(ev0, c->stream));
     }
-    for (int pass = 0; pass < (b->mode == MMGPU_SW_START ? 2 : 1); pass++) {
-        for (auto &cls : b->classes) {
-            if (cls.jobs.empty()) continue;
+    // Every class is its own kernel instantiation with its own (often small) grid: run them concurrently on side
+    // streams forked from the context's stream; the reverse scan of a class follows its forward scan in-stream.
+    if (b->side.empty()) {
+        b->side.resize(SW_STREAMS);
+        for (auto &st : b->side) HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&b->fork, hipEventDisableTiming));
+        b->join.resize(SW_STREAMS);
+        for (auto &e : b->join) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    HIP_TRY(hipEventRecord(b->fork, c->stream));
+    for (auto &st : b->side) HIP_TRY(hipStreamWaitEvent(st, b->fork, 0));
+    int slot = 0;
+    for (auto &cls : b->classes) {
+        if (cls.jobs.empty()) continue;
+        hipStream_t st = b->side[slot++ % SW_STREAMS];
+        for (int pass = 0; pass < (b->mode == MMGPU_SW_START ? 2 : 1); pass++) {
             SwLaunch L;
             L.jobs = cls.d_jobs.as<SwJob>();
             L.n_jobs = (uint32_t)cls.jobs.size();
@@ -334,10 +373,14 @@ extern "C" int mmgpu_sw_run(mmgpu_ctx *c, mmgpu_sw_batch_t *b) {
             L.alphabet = b->alphabet;
             L.gap_open = b->gap_open;
             L.gap_extend = b->gap_extend;
-            L.scratch = b->d_scratch.as<uint2>();
+            L.scratch = cls.d_scratch.as<uint2>();
             L.scratch_cols = b->scratch_cols;
-            HIP_TRY(launch_sw(L, cls.rows_per_lane, cls.multi, pass == 1, c->stream));
+            HIP_TRY(launch_sw(L, cls.rows_per_lane, cls.multi, pass == 1, st));
         }
+    }
+    for (int k = 0; k < SW_STREAMS; k++) {
+        HIP_TRY(hipEventRecord(b->join[k], b->side[k]));
+        HIP_TRY(hipStreamWaitEvent(c->stream, b->join[k], 0));
     }
     if (ev1) HIP_TRY(hipEventRecord(ev1, c->stream));
     b->ran = true;
@@ -391,6 +434,9 @@ extern "C" void mmgpu_sw_free(mmgpu_ctx *c, mmgpu_sw_batch_t *b) {
     if (!b) return;
     if (c) (void)hipSetDevice(c->device);
     for (auto &e : b->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    for (auto &st : b->side) (void)hipStreamDestroy(st);
+    if (b->fork) (void)hipEventDestroy(b->fork);
+    for (auto &e : b->join) (void)hipEventDestroy(e);
     delete b;
 }
 

@@ -124,12 +124,13 @@ def mutate_many(rng, seeds_res, seeds_off, parents, id_lo=0.3, id_hi=0.95, max_i
     return res, off3
 
 
-def config3_prefilter(n_families=20000, members=50, n_queries=10000, seed=10, chunk=100000):
+def config3_prefilter(n_families=20000, members=50, n_queries=10000, seed=10, chunk=100000, target_seed=None):
     """BASELINE.json configs[2] (SURVEY.md section 8d): family seeds with L = clamp(LogNormal(5.45, 0.6), 30, 5000);
     targets = `members` mutated members per family, shuffled; queries = one new mutated member of n_queries distinct
     families.  Returns ((qres, qoff), (tres, toff), family_of_target, family_of_query)."""
     rs = np.random.default_rng(seed)
-    rt = np.random.default_rng(seed + 1)
+    # target_seed: a different set of family members over the SAME families and queries (one shard per GPU)
+    rt = np.random.default_rng(seed + 1 if target_seed is None else target_seed)
     rq = np.random.default_rng(seed + 2)
     sres, soff = lognormal_seqs(rs, n_families)
     fam = np.repeat(np.arange(n_families), members)

@@ -44,6 +44,11 @@ def reflib():
 
 @pytest.fixture(scope="session")
 def gpu():
+    # torch first: it ships its own HIP runtime, and the process must end up with ONE libamdhip64 (the first one loaded
+    # wins the soname); loading libmmgpu.so first makes torch.cuda fail later ("No HIP GPUs are available")
+    import torch
+    if torch.cuda.is_available():
+        torch.cuda.init()
     import mmseqs2_amd
     g = mmseqs2_amd.MMGpu(0)   # raises if libmmgpu.so is missing or no GPU: no fallback
     yield g
