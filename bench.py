@@ -107,6 +107,26 @@ def cpu_baseline(matrices, qs, cbs, tres, toff, budget_s=15.0):
                       "%.1f s wall, %d threads" % (len(sample), chunk, nq, cells, dt, cores)}
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same workload
+    (profiles/r01_prefilter_config3_pmc_{fetch,write}_size.txt: separate --pmc FETCH_SIZE / WRITE_SIZE runs of
+    scripts/bench_prefilter.py at configs[2] scale, unit KB, mean per dispatch).  FETCH_SIZE is reported as measured;
+    MI355X_MICROARCH.md notes it under-counts wide coalesced reads by 2x on gfx950, so this is a lower bound."""
+    tot = 0.0
+    for kind in ("fetch", "write"):
+        path = os.path.join(ROOT, "profiles", "r01_prefilter_config3_pmc_%s_size.txt" % kind)
+        if not os.path.exists(path):
+            return None
+        found = False
+        for line in open(path):
+            if kernel in line and "_SIZE" in line and "mean=" in line:
+                tot += float(line.split("mean=")[1]) * 1024.0
+                found = True
+        if not found:
+            return None
+    return {"bytes_per_launch": round(tot), "source": "profiles/r01_prefilter_config3_pmc_*_size.txt (FETCH_SIZE + WRITE_SIZE, KB)"}
+
+
 def search_cpu_baseline(matrices, qres, qoff, tres, toff, kmer_thr, budget_s):
     """The reference's own prefilter query loop (QueryMatcher::matchQuery per OpenMP thread, Prefiltering.cpp:820-917)
     from oracle/_ref/libmmref.so on the host cores, bounded sample of the same queries against the same targets."""
@@ -235,6 +255,7 @@ def search_section(args, gpu, torch, dist, rank, world, matrices, barrier):
     swb.free()
     res = None
     if rank == 0:
+        traffic = pmc_traffic("pf_split_kernel")
         # algorithmic HBM bytes of the gather/split kernel: ~20 B per index entry touched
         # (6 B entry gathered, 8 B written + 8 B re-read for the replay, amortised list descriptors)
         alg = 20.0 * ent
@@ -256,8 +277,9 @@ def search_section(args, gpu, torch, dist, rank, world, matrices, barrier):
             "align_gcups": round(sw_cells / t_sw / 1e9, 1),
             "roofline": {"kernel": "pf_split_kernel (index gather + stable bin split)", "bound": "hbm",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "kernel_ms": round(stage[1], 3), "algorithmic_bytes_per_entry": 20,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "kernel_ms": round(stage[1], 3), "launches": len(batches),
+                         "algorithmic_bytes_per_launch": round(alg / len(batches)), "algorithmic_bytes_per_entry": 20,
                          "ungapped": {"kernel": "pf_ungapped_kernel", "bound": "hbm", "unit": "GB/s",
                                       "achieved": round(cells / (stage[3] * 1e-3) / 1e9, 1) if stage[3] > 0 else None,
                                       "peak": HBM_PEAK_GBS, "bytes_per_cell": 1}},

@@ -111,8 +111,7 @@ struct PfSplitArgs {
     const uint32_t *pos_entry_base;   // [n_pos + 1], relative to the query
     const uint32_t *list_base;        // [n_pos + 1]
     const PfList *lists;
-    const uint32_t *idx_ids;          // IndexEntryLocal::seqId
-    const uint16_t *idx_pos;          // IndexEntryLocal::position_j
+    const uint64_t *idx_entries;      // IndexEntryLocal re-packed to 8 bytes: seqId | position_j << 32 (one line per list)
     uint32_t bins;
     uint64_t *split;                  // [n_tiles][PF_T]
     uint16_t *bin_off;                // [n_tiles][bins + 1]

@@ -19,7 +19,7 @@ struct PfIndex {
     int pattern_len = 0;
     uint32_t n3 = 0;
     uint64_t table = 0, n_entries = 0;
-    DevBuf d_s3, d_i3, d_offsets, d_ids, d_pos, d_mat;
+    DevBuf d_s3, d_i3, d_offsets, d_entries, d_mat;
     std::vector<int8_t> h_mat;   // ungapped matrix (host copy for the self score)
     // Large working buffers, shared by all batches of this context (grow-only; batches run one at a time on the
     // context's stream): index lists, split tiles, candidates, survivors.
@@ -272,22 +272,22 @@ extern "C" int mmgpu_pf_load_index(mmgpu_ctx *c, const mmgpu_pf_index *ix) {
     }
     {
         const size_t ne = (size_t)ix->n_entries;
-        std::vector<uint32_t> ids(std::max<size_t>(ne, 1));
-        std::vector<uint16_t> pos(std::max<size_t>(ne, 1));
-        if (ix->entry_ids) {
-            memcpy(ids.data(), ix->entry_ids, ne * sizeof(uint32_t));
-            memcpy(pos.data(), ix->entry_pos, ne * sizeof(uint16_t));
-        } else {
-            const uint8_t *e6 = (const uint8_t *)ix->entries6;
-            for (size_t e = 0; e < ne; e++) {
-                memcpy(&ids[e], e6 + e * 6, 4);
-                memcpy(&pos[e], e6 + e * 6 + 4, 2);
+        std::vector<uint64_t> ent(std::max<size_t>(ne, 1));
+        const uint8_t *e6 = (const uint8_t *)ix->entries6;
+        for (size_t e = 0; e < ne; e++) {
+            uint32_t id;
+            uint16_t pj;
+            if (ix->entry_ids) {
+                id = ix->entry_ids[e];
+                pj = ix->entry_pos[e];
+            } else {
+                memcpy(&id, e6 + e * 6, 4);
+                memcpy(&pj, e6 + e * 6 + 4, 2);
             }
+            if (id >= c->db.n) { delete P; return fail(MMGPU_ERR_ARG, "mmgpu_pf_load_index: index entry names a target that is not loaded"); }
+            ent[e] = (uint64_t)id | ((uint64_t)pj << 32);
         }
-        for (size_t e = 0; e < ne; e++)
-            if (ids[e] >= c->db.n) { delete P; return fail(MMGPU_ERR_ARG, "mmgpu_pf_load_index: index entry names a target that is not loaded"); }
-        P_TRY(upload(P->d_ids, ids, nullptr));
-        P_TRY(upload(P->d_pos, pos, nullptr));
+        P_TRY(upload(P->d_entries, ent, nullptr));
         P_TRY(hipDeviceSynchronize());
     }
     P->h_mat.assign(ix->ungapped_mat, ix->ungapped_mat + ix->alphabet * ix->alphabet);
@@ -551,8 +551,7 @@ extern "C" int mmgpu_pf_run(mmgpu_ctx *c, mmgpu_pf_batch_t *b) {
     SA.pos_entry_base = b->d_peb.as<uint32_t>();
     SA.list_base = b->d_list_base.as<uint32_t>();
     SA.lists = P.w_lists.as<PfList>();
-    SA.idx_ids = P.d_ids.as<uint32_t>();
-    SA.idx_pos = P.d_pos.as<uint16_t>();
+    SA.idx_entries = P.d_entries.as<uint64_t>();
     SA.bins = B;
     SA.split = P.w_split.as<uint64_t>();
     SA.bin_off = P.w_bin_off.as<uint16_t>();

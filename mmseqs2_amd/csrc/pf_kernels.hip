@@ -249,8 +249,9 @@ __global__ __launch_bounds__(256) void pf_split_kernel(PfSplitArgs A) {
                 const uint32_t gp_m = __shfl(r.pos, m);
                 if (act) {
                     const uint32_t e = st_m + (x - es_m);
-                    const uint32_t id = A.idx_ids[e];
-                    const uint32_t j = A.idx_pos[e];
+                    const uint64_t ent = A.idx_entries[e];   // one 8-byte load: seqId | position_j << 32
+                    const uint32_t id = (uint32_t)ent;
+                    const uint32_t j = (uint32_t)(ent >> 32);
                     const uint32_t diag = ((gp_m - qp0) - j) & 0xFFFFu;
                     const uint32_t slot = x - a0;
                     stage[slot] = (uint64_t)id | ((uint64_t)diag << 32) | ((uint64_t)slot << 48);
