@@ -130,6 +130,30 @@ int mmgpu_sw_last_kernel_ms(mmgpu_ctx *ctx, mmgpu_sw_batch_t *batch, float *ms);
 int mmgpu_sw_kernel_ms_mean(mmgpu_ctx *ctx, mmgpu_sw_batch_t *batch, uint32_t last_n, float *ms, uint32_t *n_used);
 void mmgpu_sw_free(mmgpu_ctx *ctx, mmgpu_sw_batch_t *batch);
 
+/* ---- backtrace / CIGAR (behind alignStartPosBacktrace's banded_sw, StripedSmithWaterman.cpp:1220-1247,1478-1693) ----
+ * For the pairs the host selects after its E-value / coverage checks (Matcher::SCORE_COV_SEQID or -a): the
+ * reference's banded scalar Gotoh over [q_start..q_end] x [t_start..t_end] (band |dlen|+1, doubled until the score
+ * is reached) with its tie rules, and the walk back from the bottom-right corner.  Output per pair: the backtrace
+ * string of computerBacktrace (:1280-1308) - 'M', 'I' (consumes query), 'D' (consumes target) - and
+ * identicalAACnt. */
+typedef struct {
+    uint64_t bt_off;  /* offset of this pair's string in the caller's bt buffer */
+    uint32_t bt_len;  /* its length (no terminating NUL); 0 unless status == MMGPU_BT_OK */
+    uint32_t ident;   /* identicalAACnt */
+    int32_t status;
+    int32_t reserved;
+} mmgpu_sw_bt;
+#define MMGPU_BT_OK 0
+#define MMGPU_BT_TOO_LARGE 1 /* band/direction storage above the device scratch budget: host runs banded_sw itself */
+#define MMGPU_BT_FAILED 2    /* the walk left the band (the reference reads unrelated memory there) */
+#define MMGPU_BT_NO_START 3  /* the pair has no start position (mode 0, score below min_start_score, score 0) */
+/* pair_index: indices into the batch's result array (the order of mmgpu_sw_fetch); the batch must have been run with
+ * MMGPU_SW_START.  Strings are written back to back in pair_index order (each pair reserves
+ * (q_end-q_start+1)+(t_end-t_start+1)+1 bytes); *bt_used receives the bytes reserved.  If bt_cap is too small the
+ * call fails with MMGPU_ERR_ARG and *bt_used holds the size needed. */
+int mmgpu_sw_traceback(mmgpu_ctx *ctx, mmgpu_sw_batch_t *batch, const uint32_t *pair_index, uint32_t n_pairs,
+                       mmgpu_sw_bt *info, char *bt, size_t bt_cap, size_t *bt_used);
+
 /* ---- k-mer prefilter (behind Prefiltering::runSplit) ---------------------------------------------------------
  * Host-side table builders.  In a drop-in build the reference's own objects supply these tables
  * (ExtendedSubstitutionMatrix::calcScoreMatrix, Prefiltering.cpp:220-225; IndexBuilder::fillDatabase,

@@ -41,6 +41,8 @@ class SwQuery(ctypes.Structure):
                 ("n_targets", ctypes.c_uint32), ("min_start_score", ctypes.c_int32)]
 
 
+SW_BT_DTYPE = np.dtype([("bt_off", np.uint64), ("bt_len", np.uint32), ("ident", np.uint32), ("status", np.int32),
+                        ("reserved", np.int32)])
 SW_HIT_DTYPE = np.dtype([("score", np.int32), ("q_end", np.int32), ("t_end", np.int32), ("q_start", np.int32),
                          ("t_start", np.int32), ("word", np.int32)])
 
@@ -49,6 +51,7 @@ EXPORTED_SYMBOLS = [
     "mmgpu_init", "mmgpu_destroy", "mmgpu_last_error", "mmgpu_set_stream", "mmgpu_synchronize",
     "mmgpu_device_info", "mmgpu_host_comp_bias", "mmgpu_host_round_comp_bias", "mmgpu_load_targets", "mmgpu_sw_batch", "mmgpu_sw_prepare", "mmgpu_sw_run",
     "mmgpu_sw_fetch", "mmgpu_sw_batch_stats", "mmgpu_sw_last_kernel_ms", "mmgpu_sw_kernel_ms_mean", "mmgpu_sw_free",
+    "mmgpu_sw_traceback",
     "mmgpu_host_score_matrix", "mmgpu_host_index_build", "mmgpu_pf_load_index", "mmgpu_pf_batch", "mmgpu_pf_prepare",
     "mmgpu_pf_run", "mmgpu_pf_fetch", "mmgpu_pf_stage_ms", "mmgpu_pf_last_cells", "mmgpu_pf_fetch_device", "mmgpu_pf_merge_splits", "mmgpu_pf_debug_fetch", "mmgpu_pf_free",
 ]
@@ -103,6 +106,7 @@ def load_library():
     L.mmgpu_sw_kernel_ms_mean.argtypes = [c_p, c_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_uint32)]
     L.mmgpu_sw_free.argtypes = [c_p, c_p]
     L.mmgpu_sw_free.restype = None
+    L.mmgpu_sw_traceback.argtypes = [c_p, c_p, c_p, ctypes.c_uint32, c_p, c_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
     L.mmgpu_host_score_matrix.argtypes = [c_p, ctypes.c_int, ctypes.c_int, c_p, c_p]
     L.mmgpu_host_index_build.argtypes = [c_p, c_p, ctypes.c_uint32, c_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                          ctypes.c_int, c_p, c_p, c_p, ctypes.POINTER(ctypes.c_uint64)]
@@ -243,6 +247,22 @@ class SwBatch:
         out = np.zeros(self.pairs, SW_HIT_DTYPE)
         self.gpu._check(self.gpu.L.mmgpu_sw_fetch(self.gpu.ctx, self.handle, _ptr(out)))
         return out
+
+    def traceback(self, pair_index):
+        """Backtrace strings ('M','I','D') and identity counts of the selected result slots (batch mode >= 1).
+        Returns (info SW_BT_DTYPE[n], list of str)."""
+        idx = np.ascontiguousarray(pair_index, np.uint32)
+        info = np.zeros(max(len(idx), 1), SW_BT_DTYPE)
+        used = ctypes.c_size_t(0)
+        rc = self.gpu.L.mmgpu_sw_traceback(self.gpu.ctx, self.handle, _ptr(idx), len(idx), _ptr(info), None, 0, ctypes.byref(used))
+        if rc != 0 and used.value == 0:
+            self.gpu._check(rc)
+        buf = np.zeros(max(used.value, 1), np.uint8)
+        self.gpu._check(self.gpu.L.mmgpu_sw_traceback(self.gpu.ctx, self.handle, _ptr(idx), len(idx), _ptr(info), _ptr(buf),
+                                                      buf.size, ctypes.byref(used)))
+        info = info[:len(idx)]
+        strs = [bytes(buf[int(r["bt_off"]):int(r["bt_off"]) + int(r["bt_len"])]).decode() for r in info]
+        return info, strs
 
     def kernel_ms(self):
         ms = ctypes.c_float()

@@ -173,6 +173,10 @@ struct mmgpu_sw_batch_t {
     uint32_t n_queries = 0;
     std::vector<SwClass> classes;
     DevBuf d_qres, d_qcb, d_qoff, d_qbias, d_qminstart, d_hit_target, d_hit_out, d_out, d_mat;
+    std::vector<uint32_t> h_out_target;   // target id of every result slot (kept for mmgpu_sw_traceback, mode >= START)
+    std::vector<uint32_t> h_qout_off;     // [nq + 1] first result slot of every query
+    std::vector<uint32_t> h_qoff;         // [nq + 1] residue offsets
+    DevBuf d_bt_scratch, d_bt_jobs, d_bt_info, d_bt_str;
     std::vector<hipStream_t> side;   // side streams the classes run on
     hipEvent_t fork = nullptr;
     std::vector<hipEvent_t> join;
@@ -232,6 +236,8 @@ extern "C" int mmgpu_sw_prepare(mmgpu_ctx *c, const mmgpu_sw_params *par, const 
     }
     std::vector<uint32_t> order;
     uint32_t hit_cursor = 0, out_cursor = 0;
+    b->h_qout_off.assign(nq + 1, 0);
+    if (mode >= MMGPU_SW_START) b->h_out_target.resize((size_t)total_hits);
     uint32_t max_tlen = 0;
     bool any_multi = false;
     for (uint32_t i = 0; i < nq; i++) {
@@ -290,10 +296,14 @@ extern "C" int mmgpu_sw_prepare(mmgpu_ctx *c, const mmgpu_sw_params *par, const 
             cls.job_cells.push_back(jc);
             k = e;
         }
+        if (mode >= MMGPU_SW_START)
+            for (uint32_t k = 0; k < Q.n_targets; k++) b->h_out_target[out_cursor + k] = Q.target_ids[k];
         hit_cursor += Q.n_targets;
         out_cursor += Q.n_targets;
+        b->h_qout_off[i + 1] = out_cursor;
     }
     b->pairs = total_hits;
+    b->h_qoff = qoff;
 
     hipStream_t s = c->stream;
     std::vector<int8_t> mat(par->mat, par->mat + par->alphabet * par->alphabet);
@@ -449,4 +459,102 @@ extern "C" int mmgpu_sw_batch(mmgpu_ctx *c, const mmgpu_sw_params *par, const mm
     if (rc == MMGPU_OK) rc = mmgpu_sw_fetch(c, b, out);
     mmgpu_sw_free(c, b);
     return rc;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// backtrace
+// ---------------------------------------------------------------------------------------------------------
+extern "C" int mmgpu_sw_traceback(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const uint32_t *pair_index, uint32_t n, mmgpu_sw_bt *info,
+                                  char *bt, size_t bt_cap, size_t *bt_used) {
+    if (!c || !b || (!pair_index && n) || (!info && n)) return fail(MMGPU_ERR_ARG, "mmgpu_sw_traceback: NULL argument");
+    if (b->mode < MMGPU_SW_START) return fail(MMGPU_ERR_STATE, "mmgpu_sw_traceback: the batch was prepared without MMGPU_SW_START");
+    if (!b->ran) return fail(MMGPU_ERR_STATE, "mmgpu_sw_traceback: batch was never run");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    std::vector<mmgpu_sw_hit> res((size_t)b->pairs);
+    if (b->pairs) HIP_TRY(hipMemcpyAsync(res.data(), b->d_out.p, (size_t)b->pairs * sizeof(mmgpu_sw_hit), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    std::vector<BtJob> jobs;
+    jobs.reserve(n);
+    uint64_t off = 0;
+    for (uint32_t k = 0; k < n; k++) {
+        const uint32_t p = pair_index[k];
+        if (p >= b->pairs) return fail(MMGPU_ERR_ARG, "mmgpu_sw_traceback: pair index out of range");
+        const mmgpu_sw_hit &h = res[p];
+        info[k].bt_off = off;
+        info[k].bt_len = 0;
+        info[k].ident = 0;
+        info[k].reserved = 0;
+        if (h.score <= 0 || h.q_start < 0 || h.t_start < 0 || h.q_end < h.q_start || h.t_end < h.t_start) {
+            info[k].status = MMGPU_BT_NO_START;
+            continue;
+        }
+        info[k].status = MMGPU_BT_TOO_LARGE;   // overwritten by the kernel
+        BtJob j;
+        j.slot = k;
+        j.query = (uint32_t)(std::upper_bound(b->h_qout_off.begin(), b->h_qout_off.end(), p) - b->h_qout_off.begin() - 1);
+        j.target = b->h_out_target[p];
+        j.q_start = h.q_start; j.q_end = h.q_end; j.t_start = h.t_start; j.t_end = h.t_end; j.score = h.score;
+        j.bt_off = off;
+        off += (uint64_t)(h.q_end - h.q_start + 1) + (uint64_t)(h.t_end - h.t_start + 1) + 1;
+        jobs.push_back(j);
+    }
+    if (bt_used) *bt_used = (size_t)off;
+    if (off > bt_cap || (!bt && off)) return fail(MMGPU_ERR_ARG, "mmgpu_sw_traceback: bt buffer too small (see *bt_used)");
+    if (jobs.empty()) return MMGPU_OK;
+    auto cost = [](const BtJob &j) {
+        const int64_t ql = j.q_end - j.q_start + 1, tl = j.t_end - j.t_start + 1;
+        return ql * (2 * (std::llabs(tl - ql) + 1) + 1);
+    };
+    std::stable_sort(jobs.begin(), jobs.end(), [&](const BtJob &x, const BtJob &y) { return cost(x) > cost(y); });
+    HIP_TRY(b->d_bt_jobs.reserve(jobs.size() * sizeof(BtJob)));
+    HIP_TRY(b->d_bt_info.reserve((size_t)n * sizeof(mmgpu_sw_bt)));
+    HIP_TRY(b->d_bt_str.reserve((size_t)off + 16));
+    HIP_TRY(hipMemcpyAsync(b->d_bt_jobs.p, jobs.data(), jobs.size() * sizeof(BtJob), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(b->d_bt_info.p, info, (size_t)n * sizeof(mmgpu_sw_bt), hipMemcpyHostToDevice, s));
+    BtLaunch L;
+    L.q_res = b->d_qres.as<uint8_t>();
+    L.q_cb = b->d_qcb.as<int8_t>();
+    L.q_off = b->d_qoff.as<uint32_t>();
+    L.t_res = c->db.res;
+    L.t_off4 = c->db.off4;
+    L.mat = b->d_mat.as<int8_t>();
+    L.alphabet = b->alphabet;
+    L.gap_open = b->gap_open;
+    L.gap_extend = b->gap_extend;
+    L.info = b->d_bt_info.as<mmgpu_sw_bt>();
+    L.bt = b->d_bt_str.as<char>();
+    // tier 1: every job, 39 KB of scratch per lane (band <= 256, 64 K cells); tier 2: the jobs tier 1 refused,
+    // 4 MB per lane (band <= 4096, 8 M cells), few at a time
+    const uint32_t tier_band[2] = {515u, 8195u}, tier_dir[2] = {8192u, 1048576u}, tier_blocks[2] = {8192u, 48u};
+    std::vector<mmgpu_sw_bt> back((size_t)n);
+    for (int tier = 0; tier < 2; tier++) {
+        const uint32_t wpl = 3u * tier_band[tier] + tier_dir[tier];
+        const size_t blocks_max = tier_blocks[tier];
+        const size_t njobs = jobs.size();
+        const size_t blocks_needed = std::min<size_t>((njobs + 63) / 64, blocks_max);
+        HIP_TRY(b->d_bt_scratch.reserve(blocks_needed * (size_t)wpl * 64 * sizeof(uint32_t)));
+        L.scratch = b->d_bt_scratch.as<uint32_t>();
+        L.words_per_lane = wpl;
+        L.band_cap = tier_band[tier];
+        for (size_t j0 = 0; j0 < njobs; j0 += blocks_max * 64) {
+            L.jobs = b->d_bt_jobs.as<BtJob>() + j0;
+            L.n_jobs = (uint32_t)std::min<size_t>(njobs - j0, blocks_max * 64);
+            HIP_TRY(launch_sw_traceback(L, s));
+        }
+        HIP_TRY(hipMemcpyAsync(back.data(), b->d_bt_info.p, (size_t)n * sizeof(mmgpu_sw_bt), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (tier == 1) break;
+        std::vector<BtJob> again;
+        for (const BtJob &j : jobs)
+            if (back[j.slot].status == MMGPU_BT_TOO_LARGE) again.push_back(j);
+        if (again.empty()) break;
+        jobs.swap(again);
+        HIP_TRY(hipMemcpyAsync(b->d_bt_jobs.p, jobs.data(), jobs.size() * sizeof(BtJob), hipMemcpyHostToDevice, s));
+    }
+    for (uint32_t k = 0; k < n; k++)
+        if (info[k].status != MMGPU_BT_NO_START) info[k] = back[k];
+    if (off) HIP_TRY(hipMemcpyAsync(bt, b->d_bt_str.p, (size_t)off, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return MMGPU_OK;
 }

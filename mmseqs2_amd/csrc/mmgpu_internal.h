@@ -171,6 +171,34 @@ hipError_t launch_pf_dedup(const PfDedupArgs &A, hipEvent_t after_replay, hipEve
 hipError_t launch_pf_select(const PfSelectArgs &A, uint32_t nq, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------------------------
+// banded traceback (bt_kernel.hip)
+struct BtJob {
+    uint32_t slot;      // where the caller wants the result (index into info[])
+    uint32_t query, target;
+    int32_t q_start, q_end, t_start, t_end, score;
+    uint64_t bt_off;
+};
+
+struct BtLaunch {
+    const BtJob *jobs;
+    uint32_t n_jobs;
+    const uint8_t *q_res;
+    const int8_t *q_cb;
+    const uint32_t *q_off;
+    const uint8_t *t_res;
+    const uint32_t *t_off4;
+    const int8_t *mat;
+    int alphabet, gap_open, gap_extend;
+    uint32_t *scratch;          // [blocks][words_per_lane][64 lanes]
+    uint32_t words_per_lane;
+    uint32_t band_cap;          // words per band row (3 rows), the rest of words_per_lane holds direction bits
+    mmgpu_sw_bt *info;          // indexed by BtJob::slot
+    char *bt;
+};
+
+hipError_t launch_sw_traceback(const BtLaunch &L, hipStream_t stream);
+
+// ---------------------------------------------------------------------------------------------------------
 // host-side plumbing shared by mmgpu_api.hip and pf_api.hip
 extern thread_local std::string g_last_error;
 inline int fail(int code, const std::string &msg) {

@@ -167,3 +167,69 @@ def test_size_independent_properties_at_scale(gpu, matrices):
     assert np.all(a["q_end"] < qlen[:, None]) and np.all(a["q_end"] >= 0)
     # checksum of checksums, recorded for the log
     print("checksum", int(a["score"].astype(np.int64).sum()), int(a["t_end"].astype(np.int64).sum()))
+
+
+def test_traceback_golden_vectors(gpu, matrices, sw_vectors):
+    """Backtrace strings and identity counts of every golden pair against the REAL reference's (banded_sw +
+    computerBacktrace, recorded in tests/golden/sw_vectors.npz)."""
+    v = sw_vectors
+    mat = matrices["blosum62_sw"]
+    gpu.load_targets(v["tres"], v["toff"], 21)
+    qoff = v["qoff"].astype(np.int64)
+    queries = [dict(q=v["qres"][qoff[i]:qoff[i + 1]], comp_bias=v["cb"][qoff[i]:qoff[i + 1]],
+                    targets=np.array([i], np.uint32), min_start_score=0) for i in range(len(qoff) - 1)]
+    b = gpu.sw_prepare(mat, GO, GE, queries, mode=1)
+    b.run()
+    res = b.fetch()
+    info, strs = b.traceback(np.arange(len(queries), dtype=np.uint32))
+    n_bt = 0
+    for i in range(len(queries)):
+        if res[i]["score"] <= 0:
+            assert info[i]["status"] == 3 and strs[i] == ""
+            continue
+        assert info[i]["status"] == 0, (i, int(info[i]["status"]))
+        assert strs[i] == v["bt"][i], (i, strs[i][:60], v["bt"][i][:60])
+        assert int(info[i]["ident"]) == int(v["expect"][i][6]), i
+        n_bt += 1
+    assert n_bt > 150
+    b.free()
+
+
+def test_traceback_vs_oracle_lists(gpu, oracle, matrices):
+    """A prefilter-like list (homologs of several identities and indel loads, plus unrelated targets), arbitrary
+    subset and order of pairs, against the oracle's banded backtrace."""
+    rng = np.random.default_rng(77)
+    mat = matrices["blosum62_sw"]
+    qs, tl = [], []
+    for k in range(6):
+        qs.append(rng.choice(20, size=int(rng.integers(40, 900)), p=wl.BACKGROUND).astype(np.uint8))
+    for k in range(240):
+        src = qs[k % 6]
+        if k % 5 == 4:
+            tl.append(rng.choice(20, size=int(rng.integers(30, 600)), p=wl.BACKGROUND).astype(np.uint8))
+        else:
+            h = wl.mutate(rng, src, float(rng.uniform(0.25, 0.98)), max_indels=6, max_indel_len=25)
+            pre = rng.choice(20, size=int(rng.integers(0, 80)), p=wl.BACKGROUND).astype(np.uint8)
+            tl.append(np.concatenate([pre, h, pre[::-1]]))
+    tres, toff = wl.seqs_from_list(tl)
+    gpu.load_targets(tres, toff, 21)
+    ids = np.arange(240, dtype=np.uint32)
+    queries = [dict(q=q, comp_bias=_round_cb(oracle, matrices, q), targets=ids, min_start_score=0) for q in qs]
+    b = gpu.sw_prepare(mat, GO, GE, queries, mode=1)
+    b.run()
+    res = b.fetch()
+    pick = rng.permutation(6 * 240)[:700].astype(np.uint32)
+    info, strs = b.traceback(pick)
+    n_ok = 0
+    for k, p in enumerate(pick.tolist()):
+        qi, ti = divmod(p, 240)
+        r = oracle.sw_align(qs[qi], queries[qi]["comp_bias"], tl[ti], mat, GO, GE, need_start=True, need_bt=True)
+        if r["score"] <= 0:
+            assert info[k]["status"] == 3
+            continue
+        assert info[k]["status"] == 0, (k, p, int(info[k]["status"]))
+        assert strs[k] == r["bt"], (k, p, strs[k][:50], r["bt"][:50])
+        assert int(info[k]["ident"]) == r["ident"]
+        n_ok += 1
+    assert n_ok > 500
+    b.free()
