@@ -107,6 +107,16 @@ def cpu_baseline(matrices, qs, cbs, tres, toff, budget_s=15.0):
                       "%.1f s wall, %d threads" % (len(sample), chunk, nq, cells, dt, cores)}
 
 
+def allreduce(torch, dist, values, op="sum"):
+    """All-reduce of a few python floats (device tensor with nccl, host tensor with gloo)."""
+    if dist is None:
+        return [float(v) for v in values]
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor([float(v) for v in values], device=dev, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM)
+    return [float(v) for v in t.cpu()]
+
+
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same workload
     (profiles/r01_prefilter_config3_pmc_{fetch,write}_size.txt: separate --pmc FETCH_SIZE / WRITE_SIZE runs of
@@ -194,10 +204,7 @@ def search_section(args, gpu, torch, dist, rank, world, matrices, barrier):
         merged = one_pass(True)
     barrier()
     t_pf = (time.perf_counter() - t0) / args.pf_steps
-    if dist is not None:
-        tm = torch.tensor([t_pf], device="cuda")
-        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-        t_pf = float(tm.item())
+    t_pf = allreduce(torch, dist, [t_pf], "max")[0]
     stage = np.zeros(7)
     ent = sim = cells = cands = nhits = ovf = 0
     lists = []
@@ -243,15 +250,14 @@ def search_section(args, gpu, torch, dist, rank, world, matrices, barrier):
     barrier()
     t_sw = (time.perf_counter() - t0) / args.pf_steps
     sw_cells, sw_pairs = swb.cells, swb.pairs
-    if dist is not None:
-        tm = torch.tensor([t_sw], device="cuda")
-        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-        t_sw = float(tm.item())
-        tot = torch.tensor([float(sw_cells), float(sw_pairs), float(ent)], device="cuda", dtype=torch.float64)
-        dist.all_reduce(tot)
-        sw_cells, sw_pairs, ent_all = float(tot[0]), float(tot[1]), float(tot[2])
-    else:
-        ent_all = float(ent)
+    # backtraces (Matcher::SCORE_COV_SEQID / -a) for the hit lists of the first 1000 queries
+    bt_n = int(sum(len(x) for x in lists[:1000]))
+    t0 = time.perf_counter()
+    bt_info, _ = swb.traceback(np.arange(bt_n, dtype=np.uint32)) if bt_n else (np.zeros(0, capi.SW_BT_DTYPE), [])
+    t_bt = time.perf_counter() - t0
+    bt_ok = int((bt_info["status"] == 0).sum()) if bt_n else 0
+    t_sw = allreduce(torch, dist, [t_sw], "max")[0]
+    sw_cells, sw_pairs = allreduce(torch, dist, [sw_cells, sw_pairs])
     swb.free()
     res = None
     if rank == 0:
@@ -275,6 +281,8 @@ def search_section(args, gpu, torch, dist, rank, world, matrices, barrier):
             "ungapped_cells": int(cells), "prefilter_hits": int(nhits), "overflow_queries": int(ovf),
             "align_pairs": int(sw_pairs), "align_cells": int(sw_cells),
             "align_gcups": round(sw_cells / t_sw / 1e9, 1),
+            "backtrace": {"pairs": bt_n, "with_cigar": bt_ok, "s_incl_download": round(t_bt, 4),
+                          "pairs_per_s": round(bt_n / t_bt, 1) if t_bt > 0 else None},
             "roofline": {"kernel": "pf_split_kernel (index gather + stable bin split)", "bound": "hbm",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
@@ -320,12 +328,18 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d" % (args.gpus, args.gpus))
-    torch.cuda.set_device(local_rank)
+    # MMGPU_BENCH_BACKEND=gloo lets several ranks share one GPU to exercise the N>1 code path on a 1-GPU box
+    backend = os.environ.get("MMGPU_BENCH_BACKEND", "nccl")
+    device_index = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(device_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     matrices = dict(np.load(os.path.join(ROOT, "tests", "golden", "matrices.npz")))
     mat = matrices["blosum62_sw"]
@@ -338,7 +352,7 @@ def main():
     qs = wl.split(qres, qoff)
     cbs = [host_comp_bias(sub16, matrices["blosum62_pback"], q)[1] for q in qs]
 
-    gpu = mmseqs2_amd.MMGpu(local_rank)
+    gpu = mmseqs2_amd.MMGpu(device_index)
     stream = torch.cuda.current_stream()
     gpu.set_stream(stream.cuda_stream)
     gpu.load_targets(tres, toff, 21)
@@ -364,15 +378,8 @@ def main():
     elapsed = time.perf_counter() - t0
     # HIP events recorded by the library on the launch stream around the kernels of each timed step
     kern_ms = [batch.kernel_ms_mean(args.steps)[0]]
-    if dist is not None:
-        tmax = torch.tensor([elapsed], device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-        cells_all = torch.tensor([float(batch.cells)], device="cuda", dtype=torch.float64)
-        dist.all_reduce(cells_all)
-        total_cells = float(cells_all.item())
-    else:
-        total_cells = float(batch.cells)
+    elapsed = allreduce(torch, dist, [elapsed], "max")[0]
+    total_cells = allreduce(torch, dist, [batch.cells])[0]
 
     # ---- spot-check the timed batch's results against the oracle (checker only, outside the timed region) ----
     check = None

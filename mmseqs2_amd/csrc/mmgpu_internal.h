@@ -70,6 +70,7 @@ size_t sw_lds_bytes(int rows_per_lane, int alphabet);
 // prefilter (pf_kernels.hip)
 constexpr int PF_T = 4096;             // arrival-ordered index entries per tile
 constexpr int PF_IDS_PER_BIN = 4096;   // targets per replay bin (one 16 KB LDS state table per wavefront)
+constexpr int PF_QSTAGE = 2048;         // longest query whose residues the ungapped kernel stages in LDS
 constexpr int PF_MAX_HITS = 4096;      // largest --max-seqs the select kernel sorts in LDS
 
 struct PfList {        // index list of one similar k-mer of one query position
@@ -96,6 +97,9 @@ struct PfKmerArgs {
     const int16_t *s3;         // [n3][n3] ScoreMatrix::score of the 3-mer matrix (no padding columns)
     const uint32_t *i3;        // [n3][n3] ScoreMatrix::index
     const uint32_t *offsets;   // IndexTable::offsets, [kalph^k + 1]
+    const uint16_t *cum3;      // [n3][cum_w]: cum3[row][k] = number of entries of the row with score >= score_min + k
+    uint32_t cum_w;
+    int32_t score_min;
     // count pass
     uint32_t *nsim;
     // emit pass

@@ -19,7 +19,9 @@ struct PfIndex {
     int pattern_len = 0;
     uint32_t n3 = 0;
     uint64_t table = 0, n_entries = 0;
-    DevBuf d_s3, d_i3, d_offsets, d_entries, d_mat;
+    DevBuf d_s3, d_i3, d_cum3, d_offsets, d_entries, d_mat;
+    uint32_t cum_w = 0;
+    int32_t score_min = 0;
     std::vector<int8_t> h_mat;   // ungapped matrix (host copy for the self score)
     // Large working buffers, shared by all batches of this context (grow-only; batches run one at a time on the
     // context's stream): index lists, split tiles, candidates, survivors.
@@ -262,6 +264,30 @@ extern "C" int mmgpu_pf_load_index(mmgpu_ctx *c, const mmgpu_pf_index *ix) {
     P_TRY(hipMemcpy2D(P->d_s3.p, n3 * sizeof(int16_t), ix->score3, ix->row3 * sizeof(int16_t), n3 * sizeof(int16_t), n3, hipMemcpyHostToDevice));
     P_TRY(hipMemcpy2D(P->d_i3.p, n3 * sizeof(uint32_t), ix->index3, ix->row3 * sizeof(uint32_t), n3 * sizeof(uint32_t), n3, hipMemcpyHostToDevice));
     {
+        // cumulative counts per row: #entries with score >= c is one lookup instead of a binary search in the row
+        int lo = 32767, hi = -32768;
+        for (size_t r = 0; r < n3; r++) {
+            lo = std::min<int>(lo, ix->score3[r * ix->row3 + n3 - 1]);
+            hi = std::max<int>(hi, ix->score3[r * ix->row3]);
+        }
+        P->score_min = lo;
+        P->cum_w = (uint32_t)(hi - lo + 2);
+        std::vector<uint16_t> cum(n3 * (size_t)P->cum_w);
+        for (size_t r = 0; r < n3; r++) {
+            const int16_t *row = ix->score3 + r * ix->row3;
+            size_t j = 0;   // rows are sorted descending: walk thresholds from high to low
+            for (int k = (int)P->cum_w - 1; k >= 0; k--) {
+                const int c = lo + k;
+                while (j < n3 && row[j] >= c) j++;
+                cum[r * P->cum_w + (size_t)k] = (uint16_t)j;
+            }
+            for (size_t z = 1; z < n3; z++)
+                if (row[z] > row[z - 1]) { delete P; return fail(MMGPU_ERR_ARG, "mmgpu_pf_load_index: score3 rows are not sorted by descending score"); }
+        }
+        P_TRY(upload(P->d_cum3, cum, nullptr));
+        P_TRY(hipDeviceSynchronize());
+    }
+    {
         std::vector<uint32_t> off32(P->table + 1);
         for (uint64_t z = 0; z <= P->table; z++) {
             if (ix->offsets[z] > ix->n_entries || (z && ix->offsets[z] < ix->offsets[z - 1])) { delete P; return fail(MMGPU_ERR_ARG, "mmgpu_pf_load_index: offsets not monotone / out of range"); }
@@ -474,6 +500,9 @@ extern "C" int mmgpu_pf_run(mmgpu_ctx *c, mmgpu_pf_batch_t *b) {
     K.s3 = P.d_s3.as<int16_t>();
     K.i3 = P.d_i3.as<uint32_t>();
     K.offsets = P.d_offsets.as<uint32_t>();
+    K.cum3 = P.d_cum3.as<uint16_t>();
+    K.cum_w = P.cum_w;
+    K.score_min = P.score_min;
     K.nsim = b->d_nsim.as<uint32_t>();
     HIP_TRY(launch_pf_kmers(K, false, s));
     HIP_TRY(launch_pf_scan(b->d_nsim.as<uint32_t>(), b->d_qoff.as<uint32_t>(), nq, nullptr, nullptr, b->d_qtot.as<uint64_t>(), s));

@@ -26,6 +26,8 @@
 //     target; a workgroup per query selects the top max_hits by (score, CPU bin order, arrival index) with a
 //     radix select and sorts them.
 // Integer/byte work throughout: no MFMA; the rooflines are HBM (gather, split) and LDS/VALU issue (replay).
+#include <cstdlib>
+
 #include "mmgpu_internal.h"
 
 namespace mmgpu {
@@ -70,6 +72,13 @@ __device__ __forceinline__ uint64_t match_lanes(uint32_t key, int nbits, bool ac
 
 __device__ __forceinline__ int highest_lane(uint64_t m) { return 63 - __clzll((long long)m); }
 
+struct __attribute__((packed, aligned(4))) U32Pair {   // two adjacent uint32 at 4-byte alignment: global_load_dwordx2
+    uint32_t a, b;
+};
+struct __attribute__((packed, aligned(4))) U32Quad {
+    uint32_t a, b, c, d;
+};
+
 // ---------------------------------------------------------------------------------------------------------
 // a5 + first half of a6: one wavefront per query position.
 //   EMIT = false: nsim[gp] = number of similar k-mers of the window starting at gp
@@ -99,24 +108,21 @@ __global__ __launch_bounds__(256) void pf_kmers_kernel(PfKmerArgs A) {
     const int16_t *sB = A.s3 + (size_t)rowB * n3;
     const uint32_t *iB = A.i3 + (size_t)rowB * n3;
     const int cutoff1 = (int)(short)(thr - (int)sB[0]);
+    // number of entries of a score-sorted row with score >= c: one lookup in the per-row cumulative table
+    const uint16_t *cumA = A.cum3 + (size_t)rowA * A.cum_w;
+    const uint16_t *cumB = A.cum3 + (size_t)rowB * A.cum_w;
+    const int smin = A.score_min, smax = A.score_min + (int)A.cum_w - 2;
+    const uint32_t nA = cutoff1 <= smin ? n3 : (cutoff1 > smax ? 0u : (uint32_t)cumA[cutoff1 - smin]);
     uint32_t nlists = 0, running = 0;
     uint32_t lbase = 0;
     if (EMIT) lbase = A.list_base[gp];
-    for (uint32_t c0 = 0; c0 < n3; c0 += 64) {
+    for (uint32_t c0 = 0; c0 < nA; c0 += 64) {
         const uint32_t ia = c0 + (uint32_t)lane;
-        const int sc = ia < n3 ? (int)sA[ia] : -32768;
-        const bool inA = ia < n3 && sc >= cutoff1;
-        const uint64_t bal = __ballot(inA);
-        if (bal == 0) break;
+        const bool inA = ia < nA;
         uint32_t ni = 0;
         if (inA) {
-            const int cutoff2 = (int)(short)(thr - sc);
-            uint32_t lo = 0, hi = n3;   // first j with sB[j] < cutoff2 (row sorted descending)
-            while (lo < hi) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if ((int)sB[mid] >= cutoff2) lo = mid + 1; else hi = mid;
-            }
-            ni = lo;
+            const int cutoff2 = (int)(short)(thr - (int)sA[ia]);
+            ni = cutoff2 <= smin ? n3 : (cutoff2 > smax ? 0u : (uint32_t)cumB[cutoff2 - smin]);
         }
         const uint32_t incl = wave_incl_scan(ni);
         const uint32_t total = __shfl(incl, 63);
@@ -132,8 +138,9 @@ __global__ __launch_bounds__(256) void pf_kmers_kernel(PfKmerArgs A) {
                 uint32_t start = 0, len = 0;
                 if (act) {
                     const uint32_t kmer = k_a + iB[x - ex_m] * n3;
-                    start = A.offsets[kmer];
-                    len = A.offsets[kmer + 1] - start;
+                    const U32Pair o = *reinterpret_cast<const U32Pair *>(A.offsets + kmer);   // one 8-byte request
+                    start = o.a;
+                    len = o.b - o.a;
                 }
                 const uint32_t li = wave_incl_scan(len);
                 if (act) {
@@ -148,7 +155,6 @@ __global__ __launch_bounds__(256) void pf_kmers_kernel(PfKmerArgs A) {
             }
         }
         nlists += total;
-        if (bal != ~0ull) break;
     }
     if (lane == 0) {
         if (EMIT) A.pos_entries[gp] = running; else A.nsim[gp] = nlists;
@@ -230,35 +236,50 @@ __global__ __launch_bounds__(256) void pf_split_kernel(PfSplitArgs A) {
         uint32_t L = l0;
         const uint32_t Lend = A.list_base[qp0 + qlen];
         uint32_t cur = wa;
+        PfList r;
+        r.start = 0; r.len = 0; r.lprefix = 0; r.pos = qp0;
+        if (L + (uint32_t)lane < Lend) r = A.lists[L + (uint32_t)lane];
         while (cur < wb) {
-            const uint32_t ri = L + (uint32_t)lane;
-            const bool valid = ri < Lend;
-            PfList r;
-            r.start = 0; r.len = 0; r.lprefix = 0; r.pos = qp0;
-            if (valid) r = A.lists[ri];
+            const bool valid = L + (uint32_t)lane < Lend;
+            // the next 64 list records are requested before this chunk's entries are gathered
+            PfList rn;
+            rn.start = 0; rn.len = 0; rn.lprefix = 0; rn.pos = qp0;
+            if (L + 64u + (uint32_t)lane < Lend) rn = A.lists[L + 64u + (uint32_t)lane];
             const uint32_t es = valid ? A.pos_entry_base[r.pos] + r.lprefix : 0xFFFFFFFFu;
             const uint32_t ee = es + r.len;
             const uint32_t nvalid = min(64u, Lend - L);
             const uint32_t chunk_end = min(wb, (uint32_t)__shfl(ee, (int)nvalid - 1));
-            for (uint32_t x0 = cur; x0 < chunk_end; x0 += 64) {
-                const uint32_t x = x0 + (uint32_t)lane;
-                const bool act = x < chunk_end;
-                const int m = seg_find(es, x);
-                const uint32_t es_m = __shfl(es, m);
-                const uint32_t st_m = __shfl(r.start, m);
-                const uint32_t gp_m = __shfl(r.pos, m);
-                if (act) {
-                    const uint32_t e = st_m + (x - es_m);
-                    const uint64_t ent = A.idx_entries[e];   // one 8-byte load: seqId | position_j << 32
-                    const uint32_t id = (uint32_t)ent;
-                    const uint32_t j = (uint32_t)(ent >> 32);
-                    const uint32_t diag = ((gp_m - qp0) - j) & 0xFFFFu;
-                    const uint32_t slot = x - a0;
-                    stage[slot] = (uint64_t)id | ((uint64_t)diag << 32) | ((uint64_t)slot << 48);
+            for (uint32_t x0 = cur; x0 < chunk_end; x0 += 256) {
+                // four rounds at a time: all index-entry loads are in flight before the first LDS store
+                uint32_t eidx[4], ipos[4], slot[4];
+                bool act[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t x = x0 + 64u * (uint32_t)k + (uint32_t)lane;
+                    act[k] = x < chunk_end;
+                    const int m = seg_find(es, x);
+                    const uint32_t es_m = __shfl(es, m);
+                    const uint32_t st_m = __shfl(r.start, m);
+                    const uint32_t gp_m = __shfl(r.pos, m);
+                    eidx[k] = st_m + (x - es_m);
+                    ipos[k] = gp_m - qp0;
+                    slot[k] = x - a0;
+                }
+                uint64_t ent[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) ent[k] = act[k] ? A.idx_entries[eidx[k]] : 0ull;   // seqId | position_j << 32
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    if (act[k]) {
+                        const uint32_t id = (uint32_t)ent[k];
+                        const uint32_t diag = (ipos[k] - (uint32_t)(ent[k] >> 32)) & 0xFFFFu;
+                        stage[slot[k]] = (uint64_t)id | ((uint64_t)diag << 32) | ((uint64_t)slot[k] << 48);
+                    }
                 }
             }
             if (chunk_end > cur) cur = chunk_end;
             L += 64;
+            r = rn;
             if (L >= Lend) break;
         }
     }
@@ -469,10 +490,20 @@ __device__ __forceinline__ Seg seg_combine(const Seg &l, const Seg &r) {   // l 
     return o;
 }
 __device__ __forceinline__ void load16(const uint8_t *p, uint32_t w[4]) {
-    // 16 bytes from an arbitrarily aligned address via five aligned dwords
+    // 16 bytes from an arbitrarily aligned address: one 16-byte + one 4-byte request on the enclosing aligned dwords
     const uintptr_t u = reinterpret_cast<uintptr_t>(p);
     const uint32_t *a = reinterpret_cast<const uint32_t *>(u & ~(uintptr_t)3);
     const uint32_t sh = (uint32_t)(u & 3u);
+    const U32Quad d = *reinterpret_cast<const U32Quad *>(a);
+    const uint32_t d4 = a[4];
+    w[0] = __builtin_amdgcn_alignbyte(d.b, d.a, sh);
+    w[1] = __builtin_amdgcn_alignbyte(d.c, d.b, sh);
+    w[2] = __builtin_amdgcn_alignbyte(d.d, d.c, sh);
+    w[3] = __builtin_amdgcn_alignbyte(d4, d.d, sh);
+}
+__device__ __forceinline__ void load16_lds(const uint32_t *base, uint32_t byte_off, uint32_t w[4]) {
+    const uint32_t *a = base + (byte_off >> 2);
+    const uint32_t sh = byte_off & 3u;
     const uint32_t d0 = a[0], d1 = a[1], d2 = a[2], d3 = a[3], d4 = a[4];
     w[0] = __builtin_amdgcn_alignbyte(d1, d0, sh);
     w[1] = __builtin_amdgcn_alignbyte(d2, d1, sh);
@@ -480,8 +511,132 @@ __device__ __forceinline__ void load16(const uint8_t *p, uint32_t w[4]) {
     w[3] = __builtin_amdgcn_alignbyte(d4, d3, sh);
 }
 
+__global__ __launch_bounds__(256) void pf_ungapped_group_kernel(PfDedupArgs A) {
+    __shared__ int8_t smat[32 * 32];
+    const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
+    for (int k = (int)threadIdx.x; k < A.alphabet * A.alphabet; k += 256) smat[k] = A.mat[k];
+    for (int k = A.alphabet * A.alphabet + (int)threadIdx.x; k < 32 * 32; k += 256) smat[k] = 0;
+    __syncthreads();
+    // one wavefront per (query, group of 64 consecutive bins): enough candidates per wavefront to keep the
+    // load -> score pipeline busy (a single bin holds ~12 at configs[2])
+    const uint32_t B = A.bins;
+    const uint32_t gpq = (B + 63) / 64;                       // bin groups per query
+    const uint64_t wg = (uint64_t)blockIdx.x * 4u + (uint32_t)wave;
+    if (wg >= (uint64_t)A.n_queries * gpq) return;
+    const uint32_t q = (uint32_t)(wg / gpq);
+    const uint32_t bin0 = (uint32_t)(wg % gpq) * 64u;
+    const uint64_t bucket0 = (uint64_t)q * B + bin0;
+    uint32_t cnt = 0, cbase = 0;
+    if (bin0 + (uint32_t)lane < B) {
+        cnt = A.cand_count[bucket0 + (uint32_t)lane];
+        cbase = A.cand_base[bucket0 + (uint32_t)lane];
+    }
+    const uint32_t incl = wave_incl_scan(cnt);
+    const uint32_t total = __shfl(incl, 63);
+    if (total == 0) return;
+    const uint32_t excl = incl - cnt;
+    const uint32_t qp0 = A.q_off[q];
+    const int qlen = (int)(A.q_off[q + 1] - qp0);
+    const uint8_t *qr = A.q_res + qp0;
+    const uint8_t *qc = reinterpret_cast<const uint8_t *>(A.q_corr) + qp0;
+    const int alph = A.alphabet;
+    const int grp = lane >> 4, gl = lane & 15;
+    uint64_t cells = 0;
+    // candidate of the NEXT iteration (record + target meta) is fetched while the current one is scored
+    uint32_t n_ci = 0, n_id = 0, n_tlen = 0, n_off4 = 0;
+    int n_d = 0;
+    bool n_valid = false;
+    auto fetch = [&](uint32_t c0) {
+        const uint32_t x = c0 + (uint32_t)grp;
+        n_valid = x < total;
+        const int m = seg_find(excl, x);
+        const uint32_t ex_m = __shfl(excl, m), cb_m = __shfl(cbase, m);
+        n_ci = cb_m + (x - ex_m);
+        n_id = 0; n_d = 0; n_tlen = 0; n_off4 = 0;
+        if (n_valid) {
+            n_id = A.cand[n_ci].id;
+            n_d = (int)(short)A.cand[n_ci].diag;
+            n_tlen = A.t_len[n_id];
+            n_off4 = A.t_off4[n_id];
+        }
+    };
+    fetch(0);
+    for (uint32_t c0 = 0; c0 < total; c0 += 4) {
+        const bool valid = n_valid;
+        const uint32_t ci = n_ci;
+        const int d = n_d, tlen = (int)n_tlen;
+        const uint8_t *t = A.t_res + (size_t)n_off4 * 4;
+        if (c0 + 4 < total) fetch(c0 + 4);
+        int len = 0, qs = 0, ts = 0;
+        if (valid) {
+            const int mind = d < 0 ? -d : d;
+            if (d >= 0 && mind < qlen) {
+                len = min(tlen, qlen - mind);
+                qs = mind;
+            } else if (d < 0 && mind < tlen) {
+                len = min(tlen - mind, qlen);
+                ts = mind;
+            }
+        }
+        int maxlen = len;
+        maxlen = max(maxlen, __shfl_xor(maxlen, 16));
+        maxlen = max(maxlen, __shfl_xor(maxlen, 32));
+        int s = 0, best = 0;
+        for (int p0 = 0; p0 < maxlen; p0 += 256) {
+            const int o = p0 + gl * 16;
+            Seg g;
+            g.a = 0; g.b = 0; g.P = -(1 << 28); g.M = 0;
+            if (o < len) {
+                uint32_t tw[4], qw[4], cw[4];
+                load16(t + ts + o, tw);
+                load16(qr + qs + o, qw);
+                load16(qc + qs + o, cw);
+                const int nn = min(16, len - o);
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    const int tb_ = (int)((tw[k >> 2] >> ((k & 3) * 8)) & 0xFFu);
+                    const int qb = (int)((qw[k >> 2] >> ((k & 3) * 8)) & 0xFFu);
+                    const int cb = (int)(int8_t)((cw[k >> 2] >> ((k & 3) * 8)) & 0xFFu);
+                    const int x = (int)(int8_t)(smat[(qb * alph + tb_) & 1023] + cb);
+                    if (k < nn) {
+                        g.b += x;
+                        g.a = max(0, g.a + x);
+                        g.P = max(g.P, g.b);
+                        g.M = max(g.M, g.a);
+                    }
+                }
+            }
+            // ordered tree over the 16 lanes of the group
+#pragma unroll
+            for (int dd = 1; dd < 16; dd <<= 1) {
+                Seg r;
+                r.a = __shfl_down(g.a, dd);
+                r.b = __shfl_down(g.b, dd);
+                r.P = __shfl_down(g.P, dd);
+                r.M = __shfl_down(g.M, dd);
+                if ((gl & (2 * dd - 1)) == 0) g = seg_combine(g, r);
+            }
+            if (gl == 0 && p0 < len) {
+                best = max(best, max(g.M, s + g.P));
+                s = max(g.a, s + g.b);
+            }
+        }
+        if (valid && gl == 0) {
+            A.cand[ci].score = (uint32_t)best;
+            cells += (uint64_t)len;
+        }
+    }
+    if (A.cell_counter) {
+        for (int dd = 1; dd < 64; dd <<= 1) cells += __shfl_xor((unsigned long long)cells, dd);
+        if (lane == 0 && cells) atomicAdd((unsigned long long *)A.cell_counter, (unsigned long long)cells);
+    }
+}
+
+// Variant: one wavefront per (query, bin) - many more, shorter wavefronts; latency is hidden by occupancy instead of
+// by the in-wave prefetch.  Selected at run time (MMGPU_PF_UNGAPPED=1), kept for A/B measurements.
 __global__ __launch_bounds__(256) void pf_ungapped_kernel(PfDedupArgs A) {
     __shared__ int8_t smat[32 * 32];
+    __shared__ uint32_t s_q[4][2][PF_QSTAGE / 4 + 8];   // per wavefront: query residues / correction bytes
     const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
     for (int k = (int)threadIdx.x; k < A.alphabet * A.alphabet; k += 256) smat[k] = A.mat[k];
     for (int k = A.alphabet * A.alphabet + (int)threadIdx.x; k < 32 * 32; k += 256) smat[k] = 0;
@@ -500,6 +655,19 @@ __global__ __launch_bounds__(256) void pf_ungapped_kernel(PfDedupArgs A) {
     const int alph = A.alphabet;
     const int grp = lane >> 4, gl = lane & 15;
     uint64_t cells = 0;
+    // all candidates of a bin belong to one query: its residues and correction bytes are staged in LDS once
+    // (queries up to PF_QSTAGE residues; longer ones read the query side from L1/L2)
+    const bool staged = qlen <= PF_QSTAGE;
+    if (staged) {
+        const uint32_t *gq = reinterpret_cast<const uint32_t *>(qr - (qp0 & 3u));   // batch arrays are 4-byte aligned
+        const uint32_t *gc = reinterpret_cast<const uint32_t *>(qc - (qp0 & 3u));
+        const int nw = (int)(((qp0 & 3u) + (uint32_t)qlen + 3u) / 4u) + 5;
+        for (int k = lane; k < nw; k += 64) {
+            s_q[wave][0][k] = gq[k];
+            s_q[wave][1][k] = gc[k];
+        }
+    }
+    const uint32_t qsh = qp0 & 3u;
     for (uint32_t c0 = 0; c0 < ncand; c0 += 4) {
         const uint32_t ci = c0 + (uint32_t)grp;
         const bool valid = ci < ncand;
@@ -530,8 +698,13 @@ __global__ __launch_bounds__(256) void pf_ungapped_kernel(PfDedupArgs A) {
             if (o < len) {
                 uint32_t tw[4], qw[4], cw[4];
                 load16(t + ts + o, tw);
-                load16(qr + qs + o, qw);
-                load16(qc + qs + o, cw);
+                if (staged) {
+                    load16_lds(s_q[wave][0], qsh + (uint32_t)(qs + o), qw);
+                    load16_lds(s_q[wave][1], qsh + (uint32_t)(qs + o), cw);
+                } else {
+                    load16(qr + qs + o, qw);
+                    load16(qc + qs + o, cw);
+                }
                 const int nn = min(16, len - o);
 #pragma unroll
                 for (int k = 0; k < 16; k++) {
@@ -931,7 +1104,13 @@ hipError_t launch_pf_dedup(const PfDedupArgs &A, hipEvent_t after_replay, hipEve
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (after_replay && (e = hipEventRecord(after_replay, s)) != hipSuccess) return e;
-    hipLaunchKernelGGL(pf_ungapped_kernel, grid, block, 0, s, A);
+    static const int variant = [] { const char *v = getenv("MMGPU_PF_UNGAPPED"); return v ? atoi(v) : 1; }();
+    if (variant == 2) {
+        const uint64_t ugroups = (uint64_t)A.n_queries * ((A.bins + 63) / 64);
+        hipLaunchKernelGGL(pf_ungapped_group_kernel, dim3((unsigned)((ugroups + 3) / 4)), block, 0, s, A);
+    } else {
+        hipLaunchKernelGGL(pf_ungapped_kernel, grid, block, 0, s, A);
+    }
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (after_ungapped && (e = hipEventRecord(after_ungapped, s)) != hipSuccess) return e;
     hipLaunchKernelGGL(pf_keepmax_kernel, grid, block, 0, s, A);

@@ -18,9 +18,13 @@ def allgather_hit_lists(hits_t, counts_t, group=None):
     world = dist.get_world_size(group)
     out_h = torch.empty((world,) + tuple(hits_t.shape), dtype=hits_t.dtype, device=hits_t.device)
     out_c = torch.empty((world,) + tuple(counts_t.shape), dtype=counts_t.dtype, device=counts_t.device)
-    if hits_t.is_cuda:
+    if hits_t.is_cuda and dist.get_backend(group) != "gloo":
         dist.all_gather_into_tensor(out_h, hits_t.contiguous(), group=group)
         dist.all_gather_into_tensor(out_c, counts_t.contiguous(), group=group)
+    elif hits_t.is_cuda:
+        # debugging aid only (several ranks on one GPU, MMGPU_BENCH_BACKEND=gloo): stage through the host
+        gh, gc = allgather_hit_lists(hits_t.cpu(), counts_t.cpu(), group)
+        return gh.to(hits_t.device), gc.to(hits_t.device)
     else:
         hl = [torch.empty_like(hits_t) for _ in range(world)]
         cl = [torch.empty_like(counts_t) for _ in range(world)]

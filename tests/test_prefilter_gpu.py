@@ -120,3 +120,51 @@ def test_split_merge_on_device(gpu):
         assert np.array_equal(oh[qi]["id"][:n], exp["id"]) and np.array_equal(oh[qi]["score"][:n], exp["score"])
         assert np.array_equal(oh[qi]["diagonal"][:n], exp["diagonal"])
     chk.load_case(gpu, g, g["tres"], g["toff"], thr)
+
+
+def test_prefilter_100k_targets_properties_and_oracle_sample(gpu):
+    """BASELINE configs[2] at 1/10 scale (1000 queries x 100 000 targets, 25 device bins): size-independent properties
+    over all queries - the result does not depend on the batch size, lists are sorted by (score desc, id asc), ids are
+    unique and in range, counts <= max_hits, db_matches identical across batchings - and a seeded sample of queries
+    against the oracle over the full database."""
+    g = pc.golden()
+    m = g
+    (qres, qoff), (tres, toff), _, _ = wl.config3_prefilter(2000, 50, 1000, seed=10)
+    thr = int(g["kmer_thr"])
+    chk.load_case(gpu, g, tres, toff, thr)
+    from mmseqs2_amd import capi
+    qs = wl.split(qres, qoff)
+    queries = [dict(q=q, comp_bias=capi.host_comp_bias(g["vtml80_kmer16"], g["vtml80_pback"], q, lib=gpu.L)[0],
+                    identity_id=None) for q in qs]
+    runs = []
+    for bsz in (1000, 173):
+        hs, cs, dm = [], [], []
+        for i in range(0, len(queries), bsz):
+            h, c, st, stats = gpu.pf_batch(queries[i:i + bsz], thr, max_hits=300, ref_bins=2)
+            assert np.all(st == 0)
+            hs.append(h); cs.append(c); dm.append(stats["db_matches"])
+        runs.append((np.concatenate(hs), np.concatenate(cs), np.concatenate(dm)))
+    (h0, c0, d0), (h1, c1, d1) = runs
+    assert np.array_equal(c0, c1) and np.array_equal(d0, d1)
+    nt = len(toff) - 1
+    for qi in range(len(qs)):
+        n = int(c0[qi])
+        assert n <= 300
+        a, b = h0[qi][:n], h1[qi][:n]
+        assert np.array_equal(a["id"], b["id"]) and np.array_equal(a["score"], b["score"]) and np.array_equal(a["diagonal"], b["diagonal"])
+        sc = a["score"].astype(np.int64)
+        assert np.all(sc[:-1] >= sc[1:])
+        same = sc[:-1] == sc[1:]
+        assert np.all(a["id"][:-1][same] < a["id"][1:][same])
+        assert len(np.unique(a["id"])) == n and (n == 0 or int(a["id"].max()) < nt)
+        assert np.all(sc >= 15)
+    orc = pc.pf_oracle()
+    orc.build_index(tres, toff, thr)
+    rng = np.random.default_rng(4)
+    for qi in rng.choice(len(qs), 12, replace=False):
+        o = orc.match(qs[qi], queries[qi]["comp_bias"], 2, max_hits=300)
+        n = int(c0[qi])
+        assert int(d0[qi]) == o["stats"]["db_matches"]
+        assert np.array_equal(h0[qi]["id"][:n], o["id"]) and np.array_equal(h0[qi]["score"][:n], o["score"])
+        assert np.array_equal(h0[qi]["diagonal"][:n], o["diagonal"])
+    chk.load_case(gpu, g, g["tres"], g["toff"], thr)
