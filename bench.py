@@ -261,7 +261,9 @@ def search_section(args, gpu, torch, dist, rank, world, matrices, barrier):
     swb.free()
     res = None
     if rank == 0:
-        traffic = pmc_traffic("pf_split_kernel")
+        # the committed PMC passes were taken on exactly the default workload (10k x 1M, batches of 1024)
+        default_wl = (args.pf_families, args.pf_members, args.pf_queries, args.pf_batch) == (20000, 50, 10000, 1024)
+        traffic = pmc_traffic("pf_split_kernel") if default_wl else None
         # algorithmic HBM bytes of the gather/split kernel: ~20 B per index entry touched
         # (6 B entry gathered, 8 B written + 8 B re-read for the replay, amortised list descriptors)
         alg = 20.0 * ent
