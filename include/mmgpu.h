@@ -259,12 +259,12 @@ int mmgpu_pf_last_cells(mmgpu_ctx *ctx, mmgpu_pf_batch_t *batch, uint64_t *cells
 #define MMGPU_PF_DBG_LIST_BASE 1  /* uint32[n_pos+1]                                                         */
 #define MMGPU_PF_DBG_LISTS 2      /* {start,len,lprefix,pos} uint32 x 4 per similar k-mer                     */
 #define MMGPU_PF_DBG_PEB 3        /* uint32[n_pos+1] arrival index of each window's first entry (per query)   */
-#define MMGPU_PF_DBG_SPLIT 4      /* uint64[n_tiles][4096] entries grouped by bin                             */
+#define MMGPU_PF_DBG_SPLIT 4      /* uint64[n_tiles][tile] entries grouped by bin                             */
 #define MMGPU_PF_DBG_BIN_OFF 5    /* uint16[n_tiles][bins+1]                                                  */
 #define MMGPU_PF_DBG_CAND_BASE 6  /* uint32[nq*bins+1]                                                        */
 #define MMGPU_PF_DBG_SURV 7       /* {id,arr,score,diag|pad} 16 B records, query q at cand_base[q*bins]       */
 #define MMGPU_PF_DBG_SURV_COUNT 8 /* uint32[nq]                                                               */
-#define MMGPU_PF_DBG_BINS 9       /* uint32[2]: device bins, reference bins                                   */
+#define MMGPU_PF_DBG_BINS 9       /* uint32[3]: device bins, reference bins, entries per tile                 */
 int mmgpu_pf_debug_fetch(mmgpu_ctx *ctx, mmgpu_pf_batch_t *batch, int what, void *dst, size_t cap, size_t *bytes);
 void mmgpu_pf_free(mmgpu_ctx *ctx, mmgpu_pf_batch_t *batch);
 

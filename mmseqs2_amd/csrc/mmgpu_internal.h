@@ -68,8 +68,9 @@ size_t sw_lds_bytes(int rows_per_lane, int alphabet);
 
 // ---------------------------------------------------------------------------------------------------------
 // prefilter (pf_kernels.hip)
-constexpr int PF_T = 4096;             // arrival-ordered index entries per tile
+constexpr int PF_T = 4096;             // arrival-ordered index entries per tile (2048: 22 % slower, more tiles)
 constexpr int PF_IDS_PER_BIN = 4096;   // targets per replay bin (one 16 KB LDS state table per wavefront)
+constexpr int PF_CAND0 = 32;            // candidates per (query, bin) kept in the dense array
 constexpr int PF_QSTAGE = 2048;         // longest query whose residues the ungapped kernel stages in LDS
 constexpr int PF_MAX_HITS = 4096;      // largest --max-seqs the select kernel sorts in LDS
 
@@ -129,6 +130,7 @@ struct PfDedupArgs {
     const uint16_t *bin_off;
     const uint32_t *cand_base;        // [nq * bins + 1]
     PfCand *cand, *surv;
+    PfCand *cand_small;               // [nq * bins][PF_CAND0]
     uint32_t *surv_count;             // [nq]
     uint32_t *cand_count;             // [nq * bins]
     uint64_t *cell_counter;           // ungapped cells scored (statistics), may be null

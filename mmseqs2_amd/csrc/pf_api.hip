@@ -337,7 +337,7 @@ struct mmgpu_pf_batch_t {
     // device: working set (grow-only, reused across runs)
     DevBuf d_nsim, d_qtot, d_qbase, d_list_base, d_pos_entries, d_peb, d_qentries;
     DevBuf d_qtile_base, d_qntiles, d_bucket_count, d_bucket_off;
-    DevBuf d_cand_base, d_cand_count, d_cells, d_surv_count, d_hits, d_hit_count, d_diag_thr;
+    DevBuf d_cand_small, d_cand_base, d_cand_count, d_cells, d_surv_count, d_hits, d_hit_count, d_diag_thr;
     // host mirrors of the last run
     std::vector<uint64_t> q_lists, q_entries;
     std::vector<int32_t> status;
@@ -462,6 +462,7 @@ extern "C" int mmgpu_pf_prepare(mmgpu_ctx *c, const mmgpu_pf_params *par, const 
     B_TRY(b->d_bucket_off.alloc(((size_t)nqq + 1) * 4));
     B_TRY(b->d_cand_base.alloc(((size_t)nqq * bins + 1) * 4));
     B_TRY(b->d_cand_count.alloc((size_t)nqq * bins * 4));
+    B_TRY(b->d_cand_small.alloc((size_t)nqq * bins * PF_CAND0 * sizeof(PfCand)));
     B_TRY(b->d_cells.alloc(8));
     B_TRY(b->d_surv_count.alloc(nqq * 4));
     B_TRY(b->d_hits.alloc((size_t)nqq * max_hits * sizeof(mmgpu_pf_hit)));
@@ -619,6 +620,7 @@ extern "C" int mmgpu_pf_run(mmgpu_ctx *c, mmgpu_pf_batch_t *b) {
     D.t_len = c->db.len;
     D.min_diag_score = b->par.min_diag_score;
     D.cand_count = b->d_cand_count.as<uint32_t>();
+    D.cand_small = b->d_cand_small.as<PfCand>();
     D.cell_counter = b->d_cells.as<uint64_t>();
     HIP_TRY(launch_pf_dedup(D, b->ev[5], b->ev[6], s));
     HIP_TRY(hipEventRecord(b->ev[3], s));
@@ -747,7 +749,7 @@ extern "C" int mmgpu_pf_debug_fetch(mmgpu_ctx *c, mmgpu_pf_batch_t *b, int what,
     PfIndex &P = *c->pf;
     const void *src = nullptr;
     size_t n = 0;
-    uint32_t binsv[2] = {b->bins, b->ref_bins};
+    uint32_t binsv[3] = {b->bins, b->ref_bins, (uint32_t)PF_T};
     switch (what) {
         case MMGPU_PF_DBG_NSIM: src = b->d_nsim.p; n = (size_t)b->n_pos * 4; break;
         case MMGPU_PF_DBG_LIST_BASE: src = b->d_list_base.p; n = ((size_t)b->n_pos + 1) * 4; break;

@@ -26,8 +26,6 @@
 //     target; a workgroup per query selects the top max_hits by (score, CPU bin order, arrival index) with a
 //     radix select and sorts them.
 // Integer/byte work throughout: no MFMA; the rooflines are HBM (gather, split) and LDS/VALU issue (replay).
-#include <cstdlib>
-
 #include "mmgpu_internal.h"
 
 namespace mmgpu {
@@ -71,6 +69,13 @@ __device__ __forceinline__ uint64_t match_lanes(uint32_t key, int nbits, bool ac
 }
 
 __device__ __forceinline__ int highest_lane(uint64_t m) { return 63 - __clzll((long long)m); }
+
+// Candidate k of a (query, bin) bucket: the first PF_CAND0 live in a dense [bucket][PF_CAND0] array (a bucket holds ~12
+// candidates at configs[2]; the dense array keeps the replay/score/keepmax kernels inside a few hundred MB instead of
+// a region as large as all index entries), later ones in the bucket's slice of the entry-sized overflow array.
+__device__ __forceinline__ PfCand *cand_slot(const PfDedupArgs &A, uint64_t bucket, uint32_t k) {
+    return k < (uint32_t)PF_CAND0 ? A.cand_small + bucket * PF_CAND0 + k : A.cand + A.cand_base[bucket] + k;
+}
 
 struct __attribute__((packed, aligned(4))) U32Pair {   // two adjacent uint32 at 4-byte alignment: global_load_dwordx2
     uint32_t a, b;
@@ -288,11 +293,12 @@ __global__ __launch_bounds__(256) void pf_split_kernel(PfSplitArgs A) {
     // ---- phase B: per-(wave, bin) counts and each entry's rank inside its (wave, bin) ----
     int nbits = 0;
     while ((1u << nbits) < B) nbits++;
-    uint64_t ent[16];
-    uint32_t rk[16];
+    constexpr int ROUNDS = PF_T / 256;   // entries per thread
+    uint64_t ent[ROUNDS];
+    uint32_t rk[ROUNDS];
     uint32_t *mycnt = cnt + (uint32_t)wave * B;
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
+    for (int r = 0; r < ROUNDS; r++) {
         const uint32_t slot = (uint32_t)wave * (PF_T / 4) + (uint32_t)r * 64u + (uint32_t)lane;
         const bool valid = slot < tile_n;
         ent[r] = valid ? stage[slot] : 0ull;
@@ -339,7 +345,7 @@ __global__ __launch_bounds__(256) void pf_split_kernel(PfSplitArgs A) {
 
     // ---- phase C: stable scatter inside LDS (every entry is in a register now), then coalesced write-out ----
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
+    for (int r = 0; r < ROUNDS; r++) {
         const uint32_t slot = (uint32_t)wave * (PF_T / 4) + (uint32_t)r * 64u + (uint32_t)lane;
         if (slot < tile_n) {
             const uint32_t bin = (uint32_t)ent[r] & (B - 1);
@@ -379,7 +385,6 @@ __global__ __launch_bounds__(256) void pf_replay_kernel(PfDedupArgs A) {
     for (int k = lane; k < PF_IDS_PER_BIN; k += 64) S[k] = 0;
     for (int k = lane; k < PF_IDS_PER_BIN / 32; k += 64) E[k] = 0;
 
-    PfCand *cand = A.cand + A.cand_base[bucket];
     uint32_t ncand = 0;
     const uint64_t below = lanes_below(lane);
     for (uint32_t t0 = 0; t0 < ntiles; t0 += 64) {
@@ -461,7 +466,7 @@ __global__ __launch_bounds__(256) void pf_replay_kernel(PfDedupArgs A) {
                 c.score = 0;
                 c.diag = (uint16_t)diag;
                 c.pad = 0;
-                cand[ncand + (uint32_t)__popcll(kb & below)] = c;
+                *cand_slot(A, bucket, ncand + (uint32_t)__popcll(kb & below)) = c;
             }
             ncand += (uint32_t)__popcll(kb);
         }
@@ -511,129 +516,6 @@ __device__ __forceinline__ void load16_lds(const uint32_t *base, uint32_t byte_o
     w[3] = __builtin_amdgcn_alignbyte(d4, d3, sh);
 }
 
-__global__ __launch_bounds__(256) void pf_ungapped_group_kernel(PfDedupArgs A) {
-    __shared__ int8_t smat[32 * 32];
-    const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
-    for (int k = (int)threadIdx.x; k < A.alphabet * A.alphabet; k += 256) smat[k] = A.mat[k];
-    for (int k = A.alphabet * A.alphabet + (int)threadIdx.x; k < 32 * 32; k += 256) smat[k] = 0;
-    __syncthreads();
-    // one wavefront per (query, group of 64 consecutive bins): enough candidates per wavefront to keep the
-    // load -> score pipeline busy (a single bin holds ~12 at configs[2])
-    const uint32_t B = A.bins;
-    const uint32_t gpq = (B + 63) / 64;                       // bin groups per query
-    const uint64_t wg = (uint64_t)blockIdx.x * 4u + (uint32_t)wave;
-    if (wg >= (uint64_t)A.n_queries * gpq) return;
-    const uint32_t q = (uint32_t)(wg / gpq);
-    const uint32_t bin0 = (uint32_t)(wg % gpq) * 64u;
-    const uint64_t bucket0 = (uint64_t)q * B + bin0;
-    uint32_t cnt = 0, cbase = 0;
-    if (bin0 + (uint32_t)lane < B) {
-        cnt = A.cand_count[bucket0 + (uint32_t)lane];
-        cbase = A.cand_base[bucket0 + (uint32_t)lane];
-    }
-    const uint32_t incl = wave_incl_scan(cnt);
-    const uint32_t total = __shfl(incl, 63);
-    if (total == 0) return;
-    const uint32_t excl = incl - cnt;
-    const uint32_t qp0 = A.q_off[q];
-    const int qlen = (int)(A.q_off[q + 1] - qp0);
-    const uint8_t *qr = A.q_res + qp0;
-    const uint8_t *qc = reinterpret_cast<const uint8_t *>(A.q_corr) + qp0;
-    const int alph = A.alphabet;
-    const int grp = lane >> 4, gl = lane & 15;
-    uint64_t cells = 0;
-    // candidate of the NEXT iteration (record + target meta) is fetched while the current one is scored
-    uint32_t n_ci = 0, n_id = 0, n_tlen = 0, n_off4 = 0;
-    int n_d = 0;
-    bool n_valid = false;
-    auto fetch = [&](uint32_t c0) {
-        const uint32_t x = c0 + (uint32_t)grp;
-        n_valid = x < total;
-        const int m = seg_find(excl, x);
-        const uint32_t ex_m = __shfl(excl, m), cb_m = __shfl(cbase, m);
-        n_ci = cb_m + (x - ex_m);
-        n_id = 0; n_d = 0; n_tlen = 0; n_off4 = 0;
-        if (n_valid) {
-            n_id = A.cand[n_ci].id;
-            n_d = (int)(short)A.cand[n_ci].diag;
-            n_tlen = A.t_len[n_id];
-            n_off4 = A.t_off4[n_id];
-        }
-    };
-    fetch(0);
-    for (uint32_t c0 = 0; c0 < total; c0 += 4) {
-        const bool valid = n_valid;
-        const uint32_t ci = n_ci;
-        const int d = n_d, tlen = (int)n_tlen;
-        const uint8_t *t = A.t_res + (size_t)n_off4 * 4;
-        if (c0 + 4 < total) fetch(c0 + 4);
-        int len = 0, qs = 0, ts = 0;
-        if (valid) {
-            const int mind = d < 0 ? -d : d;
-            if (d >= 0 && mind < qlen) {
-                len = min(tlen, qlen - mind);
-                qs = mind;
-            } else if (d < 0 && mind < tlen) {
-                len = min(tlen - mind, qlen);
-                ts = mind;
-            }
-        }
-        int maxlen = len;
-        maxlen = max(maxlen, __shfl_xor(maxlen, 16));
-        maxlen = max(maxlen, __shfl_xor(maxlen, 32));
-        int s = 0, best = 0;
-        for (int p0 = 0; p0 < maxlen; p0 += 256) {
-            const int o = p0 + gl * 16;
-            Seg g;
-            g.a = 0; g.b = 0; g.P = -(1 << 28); g.M = 0;
-            if (o < len) {
-                uint32_t tw[4], qw[4], cw[4];
-                load16(t + ts + o, tw);
-                load16(qr + qs + o, qw);
-                load16(qc + qs + o, cw);
-                const int nn = min(16, len - o);
-#pragma unroll
-                for (int k = 0; k < 16; k++) {
-                    const int tb_ = (int)((tw[k >> 2] >> ((k & 3) * 8)) & 0xFFu);
-                    const int qb = (int)((qw[k >> 2] >> ((k & 3) * 8)) & 0xFFu);
-                    const int cb = (int)(int8_t)((cw[k >> 2] >> ((k & 3) * 8)) & 0xFFu);
-                    const int x = (int)(int8_t)(smat[(qb * alph + tb_) & 1023] + cb);
-                    if (k < nn) {
-                        g.b += x;
-                        g.a = max(0, g.a + x);
-                        g.P = max(g.P, g.b);
-                        g.M = max(g.M, g.a);
-                    }
-                }
-            }
-            // ordered tree over the 16 lanes of the group
-#pragma unroll
-            for (int dd = 1; dd < 16; dd <<= 1) {
-                Seg r;
-                r.a = __shfl_down(g.a, dd);
-                r.b = __shfl_down(g.b, dd);
-                r.P = __shfl_down(g.P, dd);
-                r.M = __shfl_down(g.M, dd);
-                if ((gl & (2 * dd - 1)) == 0) g = seg_combine(g, r);
-            }
-            if (gl == 0 && p0 < len) {
-                best = max(best, max(g.M, s + g.P));
-                s = max(g.a, s + g.b);
-            }
-        }
-        if (valid && gl == 0) {
-            A.cand[ci].score = (uint32_t)best;
-            cells += (uint64_t)len;
-        }
-    }
-    if (A.cell_counter) {
-        for (int dd = 1; dd < 64; dd <<= 1) cells += __shfl_xor((unsigned long long)cells, dd);
-        if (lane == 0 && cells) atomicAdd((unsigned long long *)A.cell_counter, (unsigned long long)cells);
-    }
-}
-
-// Variant: one wavefront per (query, bin) - many more, shorter wavefronts; latency is hidden by occupancy instead of
-// by the in-wave prefetch.  Selected at run time (MMGPU_PF_UNGAPPED=1), kept for A/B measurements.
 __global__ __launch_bounds__(256) void pf_ungapped_kernel(PfDedupArgs A) {
     __shared__ int8_t smat[32 * 32];
     __shared__ uint32_t s_q[4][2][PF_QSTAGE / 4 + 8];   // per wavefront: query residues / correction bytes
@@ -647,7 +529,6 @@ __global__ __launch_bounds__(256) void pf_ungapped_kernel(PfDedupArgs A) {
     const uint32_t ncand = A.cand_count[bucket];
     if (ncand == 0) return;
     const uint32_t q = (uint32_t)(bucket / B);
-    PfCand *cand = A.cand + A.cand_base[bucket];
     const uint32_t qp0 = A.q_off[q];
     const int qlen = (int)(A.q_off[q + 1] - qp0);
     const uint8_t *qr = A.q_res + qp0;
@@ -674,8 +555,9 @@ __global__ __launch_bounds__(256) void pf_ungapped_kernel(PfDedupArgs A) {
         int len = 0, qs = 0, ts = 0;
         const uint8_t *t = A.t_res;
         if (valid) {
-            const uint32_t id = cand[ci].id;
-            const int d = (int)(short)cand[ci].diag;
+            const PfCand *cp = cand_slot(A, bucket, ci);
+            const uint32_t id = cp->id;
+            const int d = (int)(short)cp->diag;
             const int tlen = (int)A.t_len[id];
             t = A.t_res + (size_t)A.t_off4[id] * 4;
             const int mind = d < 0 ? -d : d;
@@ -736,7 +618,7 @@ __global__ __launch_bounds__(256) void pf_ungapped_kernel(PfDedupArgs A) {
             }
         }
         if (valid && gl == 0) {
-            cand[ci].score = (uint32_t)best;
+            cand_slot(A, bucket, ci)->score = (uint32_t)best;
             cells += (uint64_t)len;
         }
     }
@@ -759,7 +641,6 @@ __global__ __launch_bounds__(256) void pf_keepmax_kernel(PfDedupArgs A) {
     const uint32_t ncand = A.cand_count[bucket];
     if (ncand == 0) return;
     const uint32_t q = (uint32_t)(bucket / B);
-    const PfCand *cand = A.cand + A.cand_base[bucket];
     uint32_t *S = s_tab[wave];
     int bshift = 0;
     while ((1u << bshift) < B) bshift++;
@@ -768,7 +649,7 @@ __global__ __launch_bounds__(256) void pf_keepmax_kernel(PfDedupArgs A) {
         PfCand c;
         c.id = 0; c.arr = 0; c.score = 0; c.diag = 0; c.pad = 0;
         const bool act = (uint32_t)lane < ncand;
-        if (act) c = cand[lane];
+        if (act) c = *cand_slot(A, bucket, (uint32_t)lane);
         const uint32_t cnt = min(255u, c.score);
         const uint64_t same = match_lanes(c.id >> bshift, 12, act);
         // best (count, lowest lane) inside my target group
@@ -797,9 +678,10 @@ __global__ __launch_bounds__(256) void pf_keepmax_kernel(PfDedupArgs A) {
     for (uint32_t c0 = 0; c0 < ncand; c0 += 64) {
         const uint32_t ci = c0 + (uint32_t)lane;
         if (ci < ncand) {
-            const uint32_t cnt = min(255u, cand[ci].score);
+            const PfCand *cp = cand_slot(A, bucket, ci);
+            const uint32_t cnt = min(255u, cp->score);
             const uint32_t k2 = (cnt << 24) | (0xFFFFFFu - min(ci, 0xFFFFFEu));
-            atomicMax(&S[cand[ci].id >> bshift], k2);
+            atomicMax(&S[cp->id >> bshift], k2);
         }
     }
     PfCand *surv = A.surv + A.cand_base[(uint64_t)q * B];
@@ -809,7 +691,7 @@ __global__ __launch_bounds__(256) void pf_keepmax_kernel(PfDedupArgs A) {
         PfCand c;
         c.id = 0; c.arr = 0; c.score = 0; c.diag = 0; c.pad = 0;
         if (ci < ncand) {
-            c = cand[ci];
+            c = *cand_slot(A, bucket, ci);
             const uint32_t cnt = min(255u, c.score);
             const uint32_t k2 = (cnt << 24) | (0xFFFFFFu - min(ci, 0xFFFFFEu));
             win = S[c.id >> bshift] == k2 && cnt >= A.min_diag_score;
@@ -1104,13 +986,7 @@ hipError_t launch_pf_dedup(const PfDedupArgs &A, hipEvent_t after_replay, hipEve
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (after_replay && (e = hipEventRecord(after_replay, s)) != hipSuccess) return e;
-    static const int variant = [] { const char *v = getenv("MMGPU_PF_UNGAPPED"); return v ? atoi(v) : 1; }();
-    if (variant == 2) {
-        const uint64_t ugroups = (uint64_t)A.n_queries * ((A.bins + 63) / 64);
-        hipLaunchKernelGGL(pf_ungapped_group_kernel, dim3((unsigned)((ugroups + 3) / 4)), block, 0, s, A);
-    } else {
-        hipLaunchKernelGGL(pf_ungapped_kernel, grid, block, 0, s, A);
-    }
+    hipLaunchKernelGGL(pf_ungapped_kernel, grid, block, 0, s, A);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (after_ungapped && (e = hipEventRecord(after_ungapped, s)) != hipSuccess) return e;
     hipLaunchKernelGGL(pf_keepmax_kernel, grid, block, 0, s, A);

@@ -5,7 +5,6 @@ import numpy as np
 from mmseqs2_amd import capi
 from tests import pf_common as pc
 
-PF_T = 4096
 
 
 def load_case(gpu, g_or_mats, tres, toff, kmer_thr, k=6, spaced=True):
@@ -34,6 +33,7 @@ def check(gpu, orc, queries, max_hits, ref_bins, min_diag_score=15, stages=True,
         for w in ("nsim", "peb", "split", "bin_off", "cand_base", "surv", "surv_count", "bins"):
             dbg[w] = b.debug(w)
         bins = int(dbg["bins"][0])
+        PF_T = int(dbg["bins"][2])
         rep.append("device bins %d, reference bins %d" % (bins, int(dbg["bins"][1])))
     qoff = np.concatenate([[0], np.cumsum([len(q["q"]) for q in queries])]).astype(np.int64)
     tile_base = 0
