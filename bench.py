@@ -207,7 +207,7 @@ def search_section(args, gpu, torch, dist, rank, world, matrices, barrier):
     t_pf = allreduce(torch, dist, [t_pf], "max")[0]
     stage = np.zeros(7)
     ent = sim = cells = cands = nhits = ovf = 0
-    lists = []
+    lists, slot_index = [], []
     for bi, b in enumerate(batches):
         stage += np.array(b.stage_ms())
         h, c, st, stats = b.fetch()
@@ -225,6 +225,7 @@ def search_section(args, gpu, torch, dist, rank, world, matrices, barrier):
                 ids = hh[qi]["id"][:cc2[qi]]
                 own = (ids >= rank * nt) & (ids < (rank + 1) * nt)     # pairs run on the GPU owning the target
                 lists.append((ids[own] - rank * nt).astype(np.uint32))
+                slot_index.append((len(lists) - 1) * world * mh + np.nonzero(own)[0])
             nhits += int(cc2.sum())
         else:
             for qi in range(b.nq):
@@ -244,9 +245,17 @@ def search_section(args, gpu, torch, dist, rank, world, matrices, barrier):
     t_handoff = time.time() - t0
     swb.run()
     barrier()
+    def align_pass():
+        swb.run()
+        if world > 1:
+            # second exchange of the path: the alignment results of the merged lists, one all-reduce over RCCL
+            return D.exchange_sw_results(swb.fetch(), np.concatenate(slot_index) if slot_index else np.zeros(0, np.int64),
+                                         nq * world * mh, device=torch.device("cuda", torch.cuda.current_device()))
+        return None
+
     t0 = time.perf_counter()
     for _ in range(args.pf_steps):
-        swb.run()
+        sw_all = align_pass()
     barrier()
     t_sw = (time.perf_counter() - t0) / args.pf_steps
     sw_cells, sw_pairs = swb.cells, swb.pairs

@@ -253,20 +253,31 @@ __global__ __launch_bounds__(WAVES * 64) void sw_kernel(SwLaunch L) {
                     pav[R / 2 - 1] = reinterpret_cast<const unsigned *>(rowA)[R / 2 - 1];
                     pbv[R / 2 - 1] = reinterpret_cast<const unsigned *>(rowB)[R / 2 - 1];
                 }
+                // Phase 1 (no dependencies between rows): everything that only needs the previous column -
+                // diagonal + score, max with E, and E - ge.  Phase 2 is the serial F chain down the strip
+                // (max -> sub -> max per row) with the off-chain ops of the row (f - ge, column maximum, E
+                // update) available to sit behind each dependent VOP3P op.  Compared with the single-loop form
+                // the compiler needs 23 fewer register moves and 10 fewer wait states per column at R = 24
+                // (346 -> 313 instructions); pinning the order with sched_barrier / asm anchors was tried and
+                // costs more wait states than it saves.
+                unsigned pre[R], es[R];
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     // (score of target A's letter, score of target B's letter) for query row r
                     unsigned P = __builtin_amdgcn_perm(pbv[r / 2], pav[r / 2], (r & 1) ? 0x07060302u : 0x05040100u);
                     if (REV) P = bfi(rmask[r], P, NEG2);
-                    unsigned h = pk_add_sat(hd, P);
-                    h = pk_max_s(h, E[r]);
-                    h = pk_max_s(h, f);
-                    hd = Hp[r];
-                    Hp[r] = h;
-                    cmax = pk_max_u(cmax, h);
+                    pre[r] = pk_max_s(pk_add_sat(r == 0 ? hd : Hp[r - 1], P), E[r]);
+                    es[r] = pk_sub_sat_u(E[r], ge2);
+                }
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const unsigned h = pk_max_s(pre[r], f);
+                    const unsigned fs = pk_sub_sat_u(f, ge2);
                     const unsigned t = pk_sub_sat_u(h, go2);
-                    E[r] = pk_max_u(pk_sub_sat_u(E[r], ge2), t);
-                    f = pk_max_u(pk_sub_sat_u(f, ge2), t);
+                    cmax = pk_max_u(cmax, h);
+                    f = pk_max_u(fs, t);
+                    E[r] = pk_max_u(es[r], t);
+                    Hp[r] = h;
                 }
                 out_H = Hp[R - 1];
                 out_F = f;

@@ -69,3 +69,18 @@ def gather_and_merge_host(hits, counts, shard_sizes, group=None):
     gc = gc.numpy()
     off = shard_id_offsets(shard_sizes)
     return [capi.merge_hit_lists_host([gh[s, q, :gc[s, q]] for s in range(gh.shape[0])], off) for q in range(nq)]
+
+
+def exchange_sw_results(local_res, slot_index, n_slots, device=None, group=None):
+    """Alignment results of the merged lists: every rank aligned the pairs whose target it owns (local_res, structured
+    capi.SW_HIT_DTYPE, one per owned pair) and knows the slot of each pair in the flattened [nq * n_splits * stride]
+    merged-list array (slot_index).  Slots are owned by exactly one rank, so ONE all-reduce (sum) of the int32 view
+    gives every rank the complete result array.  Returns a numpy array of n_slots SW_HIT_DTYPE records (zeros in
+    slots no rank owns, i.e. padding of the merged lists)."""
+    full = np.zeros(n_slots, capi.SW_HIT_DTYPE)
+    full[np.asarray(slot_index, np.int64)] = local_res
+    t = torch.from_numpy(full.view(np.int32).reshape(n_slots, 6))
+    if device is not None and dist.get_backend(group) != "gloo":
+        t = t.to(device)
+    dist.all_reduce(t, group=group)
+    return t.cpu().numpy().reshape(-1).view(capi.SW_HIT_DTYPE)

@@ -49,8 +49,23 @@ def _worker(rank, world, port, nq, q):
     mh = capi.split_max_hits(300, world)
     hits, counts = _local_hits(g, shards[rank], mh, nq)
     merged = D.gather_and_merge_host(hits, counts, sizes)
+    # alignment results of the merged lists: each rank fills the slots of the targets it owns, one all-reduce
+    off = D.shard_id_offsets(sizes)
+    lo, hi = int(off[rank]), int(off[rank]) + sizes[rank]
+    stride = world * mh
+    slots, vals = [], []
+    for qi, m in enumerate(merged):
+        for k, gid in enumerate(m["id"].tolist()):
+            if lo <= gid < hi:
+                slots.append(qi * stride + k)
+                vals.append(gid * 7 + qi)                 # stands for the alignment score of (query, target)
+    loc = np.zeros(len(slots), capi.SW_HIT_DTYPE)
+    loc["score"] = vals
+    loc["q_end"] = rank + 1
+    full = D.exchange_sw_results(loc, slots, nq * stride)
     if rank == 0:
-        q.put([(m["id"].tolist(), m["score"].tolist(), m["diagonal"].tolist()) for m in merged])
+        q.put(([(m["id"].tolist(), m["score"].tolist(), m["diagonal"].tolist()) for m in merged],
+               full["score"].tolist(), full["q_end"].tolist()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -65,7 +80,7 @@ def test_two_rank_allgather_merge_matches_split_semantics():
     procs = [ctx.Process(target=_worker, args=(r, world, port, nq, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = q.get(timeout=600)
+    got, sw_score, sw_owner = q.get(timeout=600)
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
@@ -83,6 +98,13 @@ def test_two_rank_allgather_merge_matches_split_semantics():
         sc = np.abs(np.array(got[qi][1]))
         assert np.all(np.diff(sc) <= 0)
         assert all(0 <= i < sum(sizes) for i in got[qi][0])
+    # exchanged alignment results: every merged-list slot carries the value its owner computed
+    stride = world * mh
+    for qi in range(nq):
+        for k, gid in enumerate(got[qi][0]):
+            assert sw_score[qi * stride + k] == gid * 7 + qi
+            assert sw_owner[qi * stride + k] == (1 if gid < sizes[0] else 2)
+        assert all(v == 0 for v in sw_score[qi * stride + len(got[qi][0]):(qi + 1) * stride])
     # with one split the merged list is the plain list
     one = capi.merge_hit_lists_host([per[0][0][0, :per[0][1][0]]], [0])
     assert one["id"].tolist() == per[0][0][0]["id"][:per[0][1][0]].tolist()
