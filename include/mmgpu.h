@@ -248,8 +248,9 @@ int mmgpu_pf_fetch_device(mmgpu_ctx *ctx, mmgpu_pf_batch_t *batch, void *d_hits,
 int mmgpu_pf_merge_splits(mmgpu_ctx *ctx, const void *d_hits, const void *d_counts, uint32_t n_splits, uint32_t n_queries,
                           uint32_t stride, const uint32_t *id_offsets, void *d_out_hits, void *d_out_counts);
 /* milliseconds per stage of the last run (HIP events on the context's stream; synchronises):
- * ms[0] similar k-mers + index lists, ms[1] gather + bin split, ms[2] double-diagonal replay, ms[3] ungapped scoring,
- * ms[4] best element per target, ms[5] top-N select, ms[6] whole run (including the two host read-backs) */
+ * ms[0] similar k-mers + index lists, ms[1] gather + bin split, ms[2] double-diagonal replay + ungapped scoring + best
+ * element per target (bins with <= 64 candidates, i.e. nearly all), ms[3] ungapped scoring of larger bins, ms[4] best
+ * element per target of larger bins, ms[5] top-N select, ms[6] whole run (including the two host read-backs) */
 int mmgpu_pf_stage_ms(mmgpu_ctx *ctx, mmgpu_pf_batch_t *batch, float ms[7]);
 /* ungapped diagonal cells scored by the last run (sum of overlap lengths of the double-diagonal candidates) */
 int mmgpu_pf_last_cells(mmgpu_ctx *ctx, mmgpu_pf_batch_t *batch, uint64_t *cells, uint64_t *candidates);

@@ -133,7 +133,7 @@ struct PfDedupArgs {
     PfCand *cand_small;               // [nq * bins][PF_CAND0]
     uint32_t *surv_count;             // [nq]
     uint32_t *cand_count;             // [nq * bins]
-    uint64_t *cell_counter;           // ungapped cells scored (statistics), may be null
+    uint64_t *cell_counter;           // [nq] ungapped cells scored per query (statistics), may be null
     const uint32_t *q_off;
     const uint8_t *q_res;
     const int8_t *q_corr;             // UngappedAlignment::aaCorrectionScore per position

@@ -463,7 +463,7 @@ extern "C" int mmgpu_pf_prepare(mmgpu_ctx *c, const mmgpu_pf_params *par, const 
     B_TRY(b->d_cand_base.alloc(((size_t)nqq * bins + 1) * 4));
     B_TRY(b->d_cand_count.alloc((size_t)nqq * bins * 4));
     B_TRY(b->d_cand_small.alloc((size_t)nqq * bins * PF_CAND0 * sizeof(PfCand)));
-    B_TRY(b->d_cells.alloc(8));
+    B_TRY(b->d_cells.alloc((size_t)nqq * 8));
     B_TRY(b->d_surv_count.alloc(nqq * 4));
     B_TRY(b->d_hits.alloc((size_t)nqq * max_hits * sizeof(mmgpu_pf_hit)));
     B_TRY(b->d_hit_count.alloc(nqq * 4));
@@ -570,7 +570,7 @@ extern "C" int mmgpu_pf_run(mmgpu_ctx *c, mmgpu_pf_batch_t *b) {
     HIP_TRY(P.w_surv.reserve(std::max<uint64_t>(total_entries, 1) * sizeof(PfCand)));
     HIP_TRY(hipMemsetAsync(b->d_bucket_count.p, 0, (size_t)nq * B * 4, s));
     HIP_TRY(hipMemsetAsync(b->d_surv_count.p, 0, (size_t)nq * 4, s));
-    HIP_TRY(hipMemsetAsync(b->d_cells.p, 0, 8, s));
+    HIP_TRY(hipMemsetAsync(b->d_cells.p, 0, (size_t)nq * 8, s));
 
     // ---- stage 1: gather + stable split ----
     PfSplitArgs SA;
@@ -661,7 +661,6 @@ extern "C" int mmgpu_pf_fetch(mmgpu_ctx *c, mmgpu_pf_batch_t *b, mmgpu_pf_hit *h
     HIP_TRY(hipMemcpyAsync(counts, b->d_hit_count.p, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(thr.data(), b->d_diag_thr.p, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(surv.data(), b->d_surv_count.p, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(&b->last_cells, b->d_cells.p, 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     for (uint32_t i = 0; i < nq; i++) {
         if (b->status[i] != MMGPU_PF_OK) counts[i] = 0;
@@ -729,7 +728,13 @@ extern "C" int mmgpu_pf_last_cells(mmgpu_ctx *c, mmgpu_pf_batch_t *b, uint64_t *
     if (!b->ran) return fail(MMGPU_ERR_STATE, "mmgpu_pf_last_cells: batch was never run");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (cells) HIP_TRY(hipMemcpy(cells, b->d_cells.p, 8, hipMemcpyDeviceToHost));
+    if (cells) {
+        std::vector<uint64_t> qc(b->nq);
+        if (b->nq) HIP_TRY(hipMemcpy(qc.data(), b->d_cells.p, (size_t)b->nq * 8, hipMemcpyDeviceToHost));
+        uint64_t t = 0;
+        for (uint64_t v : qc) t += v;
+        *cells = t;
+    }
     if (candidates) {
         std::vector<uint32_t> cc((size_t)b->nq * b->bins);
         if (!cc.empty()) HIP_TRY(hipMemcpy(cc.data(), b->d_cand_count.p, cc.size() * 4, hipMemcpyDeviceToHost));

@@ -70,6 +70,24 @@ __device__ __forceinline__ uint64_t match_lanes(uint32_t key, int nbits, bool ac
 
 __device__ __forceinline__ int highest_lane(uint64_t m) { return 63 - __clzll((long long)m); }
 
+// Largest index in [lo, hi] whose value (base[idx * stride], non-decreasing, base[lo * stride] <= key) is <= key.
+// The whole wavefront probes 64 evenly spaced elements per round: log64 instead of log2 dependent memory round trips.
+__device__ __forceinline__ uint32_t wave_search_le(const uint32_t *base, uint32_t stride, uint32_t lo, uint32_t hi, uint32_t key) {
+    const uint32_t lane = (uint32_t)lane_id();
+    while (hi > lo) {
+        const uint32_t span = hi - lo + 1;
+        const uint32_t step = (span + 63u) / 64u;
+        const uint32_t idx = lo + lane * step;
+        const bool in = idx <= hi;
+        const uint32_t v = in ? base[(size_t)idx * stride] : 0xFFFFFFFFu;
+        const uint64_t le = __ballot(in && v <= key);   // a prefix of the lanes
+        const uint32_t k = (uint32_t)__popcll(le) - 1u;
+        lo += k * step;
+        hi = min(hi, lo + step - 1u);
+    }
+    return lo;
+}
+
 // Candidate k of a (query, bin) bucket: the first PF_CAND0 live in a dense [bucket][PF_CAND0] array (a bucket holds ~12
 // candidates at configs[2]; the dense array keeps the replay/score/keepmax kernels inside a few hundred MB instead of
 // a region as large as all index entries), later ones in the bucket's slice of the entry-sized overflow array.
@@ -225,19 +243,11 @@ __global__ __launch_bounds__(256) void pf_split_kernel(PfSplitArgs A) {
     const uint32_t wa = a0 + (uint32_t)wave * (PF_T / 4);
     const uint32_t wb = min(a0 + tile_n, wa + PF_T / 4);
     if (wa < wb) {
-        // position holding arrival index wa: largest p with peb[p] <= wa
-        uint32_t lo = 0, hi = qlen - 1;
-        while (lo < hi) {
-            const uint32_t mid = (lo + hi + 1) >> 1;
-            if (A.pos_entry_base[qp0 + mid] <= wa) lo = mid; else hi = mid - 1;
-        }
-        const uint32_t gp = qp0 + lo;
+        // position holding arrival index wa (largest p with peb[p] <= wa), then the list inside it
+        const uint32_t pidx = wave_search_le(A.pos_entry_base + qp0, 1, 0, qlen - 1, wa);
+        const uint32_t gp = qp0 + pidx;
         const uint32_t rel = wa - A.pos_entry_base[gp];
-        uint32_t l0 = A.list_base[gp], l1 = A.list_base[gp + 1] - 1;
-        while (l0 < l1) {   // largest list of this position with lprefix <= rel
-            const uint32_t mid = (l0 + l1 + 1) >> 1;
-            if (A.lists[mid].lprefix <= rel) l0 = mid; else l1 = mid - 1;
-        }
+        const uint32_t l0 = wave_search_le(&A.lists[0].lprefix, sizeof(PfList) / 4, A.list_base[gp], A.list_base[gp + 1] - 1, rel);
         uint32_t L = l0;
         const uint32_t Lend = A.list_base[qp0 + qlen];
         uint32_t cur = wa;
@@ -358,6 +368,211 @@ __global__ __launch_bounds__(256) void pf_split_kernel(PfSplitArgs A) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// a8: ungapped score of every candidate: s = max(0, s + P[q_pos][t_res]), best = max s along the diagonal
+// (scalarDiagonalScoring, UngappedAlignment.cpp:45-57; overlap as in computeSingelSequenceScores :423-437;
+// P = matrix + per-position composition term, createProfile :388-421).
+// One wavefront per (query, bin); a 16-lane group per candidate (4 candidates in flight per wavefront); per pass a
+// lane owns 16 consecutive diagonal cells (so a group reads 256 contiguous target bytes) and summarises them as the
+// function s -> (max(a, s + b), running best max(M, s + P)); a 4-step ordered tree over the group composes the 16
+// summaries, lane 0 of the group applies them to the carried score.  Bytes per cell: 1 (target) from HBM, the query
+// side stays in L1/L2.
+struct Seg {
+    int a, b, P, M;
+};
+__device__ __forceinline__ Seg seg_combine(const Seg &l, const Seg &r) {   // l then r
+    Seg o;
+    o.b = l.b + r.b;
+    o.a = max(r.a, l.a + r.b);
+    o.P = max(l.P, l.b + r.P);
+    o.M = max(max(l.M, r.M), l.a + r.P);
+    return o;
+}
+__device__ __forceinline__ void load16(const uint8_t *p, uint32_t w[4]) {
+    // 16 bytes from an arbitrarily aligned address: one 16-byte + one 4-byte request on the enclosing aligned dwords
+    const uintptr_t u = reinterpret_cast<uintptr_t>(p);
+    const uint32_t *a = reinterpret_cast<const uint32_t *>(u & ~(uintptr_t)3);
+    const uint32_t sh = (uint32_t)(u & 3u);
+    const U32Quad d = *reinterpret_cast<const U32Quad *>(a);
+    const uint32_t d4 = a[4];
+    w[0] = __builtin_amdgcn_alignbyte(d.b, d.a, sh);
+    w[1] = __builtin_amdgcn_alignbyte(d.c, d.b, sh);
+    w[2] = __builtin_amdgcn_alignbyte(d.d, d.c, sh);
+    w[3] = __builtin_amdgcn_alignbyte(d4, d.d, sh);
+}
+__device__ __forceinline__ void load16_lds(const uint32_t *base, uint32_t byte_off, uint32_t w[4]) {
+    const uint32_t *a = base + (byte_off >> 2);
+    const uint32_t sh = byte_off & 3u;
+    const uint32_t d0 = a[0], d1 = a[1], d2 = a[2], d3 = a[3], d4 = a[4];
+    w[0] = __builtin_amdgcn_alignbyte(d1, d0, sh);
+    w[1] = __builtin_amdgcn_alignbyte(d2, d1, sh);
+    w[2] = __builtin_amdgcn_alignbyte(d3, d2, sh);
+    w[3] = __builtin_amdgcn_alignbyte(d4, d3, sh);
+}
+
+__device__ __forceinline__ Seg seg_cells(const uint32_t tw[4], const uint32_t qw[4], const uint32_t cw[4], int nn,
+                                         const int8_t *smat, int alph) {
+    Seg g;
+    g.a = 0; g.b = 0; g.P = -(1 << 28); g.M = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int tb_ = (int)((tw[k >> 2] >> ((k & 3) * 8)) & 0xFFu);
+        const int qb = (int)((qw[k >> 2] >> ((k & 3) * 8)) & 0xFFu);
+        const int cb = (int)(int8_t)((cw[k >> 2] >> ((k & 3) * 8)) & 0xFFu);
+        const int x = (int)(int8_t)(smat[(qb * alph + tb_) & 1023] + cb);
+        if (k < nn) {
+            g.b += x;
+            g.a = max(0, g.a + x);
+            g.P = max(g.P, g.b);
+            g.M = max(g.M, g.a);
+        }
+    }
+    return g;
+}
+__device__ __forceinline__ Seg seg_tree16(Seg g, int gl) {   // ordered tree over the 16 lanes of a group; result in lane 0
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) {
+        Seg r;
+        r.a = __shfl_down(g.a, d);
+        r.b = __shfl_down(g.b, d);
+        r.P = __shfl_down(g.P, d);
+        r.M = __shfl_down(g.M, d);
+        if ((gl & (2 * d - 1)) == 0) g = seg_combine(g, r);
+    }
+    return g;
+}
+
+// Scores up to 64 candidates of one (query, bin) bucket - lane l holds candidate cb0 + l - and, when the bucket has no
+// more than 64 candidates, finishes keepMaxElement for it.  Latency plan: target metadata of the whole chunk in one
+// round trip, then the first 256 diagonal cells of 8 candidates at a time are requested together before any is scored.
+// s_q == nullptr: the query side is read from global memory (L1/L2) instead of the LDS copy.
+__device__ __forceinline__ uint64_t score_chunk(const PfDedupArgs &A, const int8_t *smat, const uint32_t *s_qres,
+                                                const uint32_t *s_qcorr, uint64_t bucket, uint32_t q, uint32_t cb0,
+                                                uint32_t nin, uint32_t ncand, PfCand c, int bshift) {
+    const int lane = lane_id();
+    const int grp = lane >> 4, gl = lane & 15;
+    const uint32_t qp0 = A.q_off[q];
+    const int qlen = (int)(A.q_off[q + 1] - qp0);
+    const uint8_t *qr = A.q_res + qp0;
+    const uint8_t *qc = reinterpret_cast<const uint8_t *>(A.q_corr) + qp0;
+    const uint32_t qsh = qp0 & 3u;
+    const int alph = A.alphabet;
+    const bool has = (uint32_t)lane < nin;
+    auto query16 = [&](int off, uint32_t qw[4], uint32_t cw[4]) {
+        if (s_qres) {
+            load16_lds(s_qres, qsh + (uint32_t)off, qw);
+            load16_lds(s_qcorr, qsh + (uint32_t)off, cw);
+        } else {
+            load16(qr + off, qw);
+            load16(qc + off, cw);
+        }
+    };
+    int my_len = 0, my_qs = 0;
+    unsigned long long my_addr = 0;
+    uint64_t cells = 0;
+    if (has) {
+        const int d = (int)(short)c.diag;
+        const int tlen = (int)A.t_len[c.id];
+        const uint8_t *t = A.t_res + (size_t)A.t_off4[c.id] * 4;
+        const int mind = d < 0 ? -d : d;
+        int ts = 0;
+        if (d >= 0 && mind < qlen) {
+            my_len = min(tlen, qlen - mind);
+            my_qs = mind;
+        } else if (d < 0 && mind < tlen) {
+            my_len = min(tlen - mind, qlen);
+            ts = mind;
+        }
+        my_addr = (unsigned long long)reinterpret_cast<uintptr_t>(t + ts);
+        cells = (uint64_t)my_len;
+    }
+    int my_score = 0;
+    constexpr int UN = 2;   // candidates per group in flight: 4 groups x UN = 8 per round trip
+    for (uint32_t k0 = 0; k0 < nin; k0 += 4 * UN) {
+        uint32_t tw[UN][4], qw[UN][4], cw[UN][4];
+        int len_u[UN], qs_u[UN];
+        unsigned long long addr_u[UN];
+#pragma unroll
+        for (int u = 0; u < UN; u++) {
+            const int src = (int)k0 + u * 4 + grp;          // < 64
+            len_u[u] = __shfl(my_len, src);
+            qs_u[u] = __shfl(my_qs, src);
+            addr_u[u] = __shfl(my_addr, src);
+            if ((uint32_t)src >= nin) len_u[u] = 0;
+#pragma unroll
+            for (int z = 0; z < 4; z++) { tw[u][z] = 0; qw[u][z] = 0; cw[u][z] = 0; }
+            if (gl * 16 < len_u[u]) {
+                load16(reinterpret_cast<const uint8_t *>((uintptr_t)addr_u[u]) + gl * 16, tw[u]);
+                query16(qs_u[u] + gl * 16, qw[u], cw[u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UN; u++) {
+            const int len = len_u[u];
+            Seg g;
+            g.a = 0; g.b = 0; g.P = -(1 << 28); g.M = 0;
+            if (gl * 16 < len) g = seg_cells(tw[u], qw[u], cw[u], min(16, len - gl * 16), smat, alph);
+            g = seg_tree16(g, gl);
+            int sc = 0, best = 0;
+            if (gl == 0 && len > 0) {
+                best = max(g.M, g.P);
+                sc = max(g.a, g.b);
+            }
+            int maxlen = len;
+            maxlen = max(maxlen, __shfl_xor(maxlen, 16));
+            maxlen = max(maxlen, __shfl_xor(maxlen, 32));
+            for (int p0 = 256; p0 < maxlen; p0 += 256) {      // diagonals longer than one pass
+                const int o = p0 + gl * 16;
+                Seg h;
+                h.a = 0; h.b = 0; h.P = -(1 << 28); h.M = 0;
+                if (o < len) {
+                    uint32_t t2[4], q2[4], c2[4];
+                    load16(reinterpret_cast<const uint8_t *>((uintptr_t)addr_u[u]) + o, t2);
+                    query16(qs_u[u] + o, q2, c2);
+                    h = seg_cells(t2, q2, c2, min(16, len - o), smat, alph);
+                }
+                h = seg_tree16(h, gl);
+                if (gl == 0 && p0 < len) {
+                    best = max(best, max(h.M, sc + h.P));
+                    sc = max(h.a, sc + h.b);
+                }
+            }
+            // hand the four group results to the candidates' own lanes
+            const int r0 = __shfl(best, 0), r1 = __shfl(best, 16), r2 = __shfl(best, 32), r3 = __shfl(best, 48);
+            const int rel = lane - ((int)k0 + u * 4);
+            if (rel >= 0 && rel < 4) my_score = rel == 0 ? r0 : (rel == 1 ? r1 : (rel == 2 ? r2 : r3));
+        }
+    }
+    c.score = (uint32_t)my_score;
+    if (has) cand_slot(A, bucket, cb0 + (uint32_t)lane)->score = c.score;
+    if (ncand <= 64) {
+        // keepMaxElement for the whole bucket right here (the common case; larger buckets go to pf_keepmax_kernel):
+        // per target the first candidate holding the target's maximum count
+        const uint32_t cnt = min(255u, c.score);
+        const uint64_t same = match_lanes(c.id >> bshift, 12, has);
+        bool win = has;
+        uint64_t m = same & ~(1ull << lane);
+        while (__ballot(m != 0)) {
+            const int o = m ? __ffsll((long long)m) - 1 : lane;
+            const uint32_t oc = __shfl(cnt, o);
+            if (m) {
+                if (oc > cnt || (oc == cnt && o < lane)) win = false;
+                m &= m - 1;
+            }
+        }
+        win = win && cnt >= A.min_diag_score;
+        const uint64_t wb = __ballot(win);
+        if (wb) {
+            PfCand *surv = A.surv + A.cand_base[(uint64_t)q * A.bins];
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&A.surv_count[q], (uint32_t)__popcll(wb));
+            base = __shfl(base, 0);
+            if (win) surv[base + (uint32_t)__popcll(wb & lanes_below(lane))] = c;
+        }
+    }
+    return cells;
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // a7: one wavefront per (query, bin), four per workgroup: replay of the bin's entries in arrival order.
 // Per target the CPU keeps `prev` = low byte of the previous entry's diagonal (zero-initialised,
 // CacheFriendlyOperations.cpp:186-208) and emits an entry whose byte equals it; the emitted list is then run-length
@@ -367,7 +582,11 @@ __global__ __launch_bounds__(256) void pf_split_kernel(PfSplitArgs A) {
 __global__ __launch_bounds__(256) void pf_replay_kernel(PfDedupArgs A) {
     __shared__ uint16_t s_state[4][PF_IDS_PER_BIN];
     __shared__ uint32_t s_emit[4][PF_IDS_PER_BIN / 32];
+    __shared__ uint32_t s_cand[4][3][64];   // first 64 candidates of the bucket: id, arrival index, diagonal
+    __shared__ int8_t smat[32 * 32];
     const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
+    for (int k = (int)threadIdx.x; k < 32 * 32; k += 256) smat[k] = k < A.alphabet * A.alphabet ? A.mat[k] : (int8_t)0;
+    __syncthreads();
     const uint32_t B = A.bins;
     const uint64_t bucket = (uint64_t)blockIdx.x * 4u + (uint32_t)wave;
     if (bucket >= (uint64_t)A.n_queries * B) return;
@@ -466,59 +685,39 @@ __global__ __launch_bounds__(256) void pf_replay_kernel(PfDedupArgs A) {
                 c.score = 0;
                 c.diag = (uint16_t)diag;
                 c.pad = 0;
-                *cand_slot(A, bucket, ncand + (uint32_t)__popcll(kb & below)) = c;
+                const uint32_t ck = ncand + (uint32_t)__popcll(kb & below);
+                *cand_slot(A, bucket, ck) = c;
+                if (ck < 64) {
+                    s_cand[wave][0][ck] = c.id;
+                    s_cand[wave][1][ck] = c.arr;
+                    s_cand[wave][2][ck] = diag;
+                }
             }
             ncand += (uint32_t)__popcll(kb);
         }
     }
     if (lane == 0) A.cand_count[bucket] = ncand;
+    // a8 + keepMaxElement for the common case of at most 64 candidates, straight from LDS (no second kernel's
+    // count -> record -> metadata round trips); larger buckets are left to pf_ungapped_kernel / pf_keepmax_kernel
+    if (ncand > 0 && ncand <= 64) {
+        PfCand c;
+        c.id = 0; c.arr = 0; c.score = 0; c.diag = 0; c.pad = 0;
+        if ((uint32_t)lane < ncand) {
+            c.id = s_cand[wave][0][lane];
+            c.arr = s_cand[wave][1][lane];
+            c.diag = (uint16_t)s_cand[wave][2][lane];
+        }
+        uint64_t cells = score_chunk(A, smat, nullptr, nullptr, bucket, q, 0, ncand, ncand, c, bshift);
+        if (A.cell_counter) {
+            for (int dd = 1; dd < 64; dd <<= 1) cells += __shfl_xor((unsigned long long)cells, dd);
+            if (lane == 0 && cells) atomicAdd((unsigned long long *)&A.cell_counter[q], (unsigned long long)cells);
+        }
+    }
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// a8: ungapped score of every candidate: s = max(0, s + P[q_pos][t_res]), best = max s along the diagonal
-// (scalarDiagonalScoring, UngappedAlignment.cpp:45-57; overlap as in computeSingelSequenceScores :423-437;
-// P = matrix + per-position composition term, createProfile :388-421).
-// One wavefront per (query, bin); a 16-lane group per candidate (4 candidates in flight per wavefront); per pass a
-// lane owns 16 consecutive diagonal cells (so a group reads 256 contiguous target bytes) and summarises them as the
-// function s -> (max(a, s + b), running best max(M, s + P)); a 4-step ordered tree over the group composes the 16
-// summaries, lane 0 of the group applies them to the carried score.  Bytes per cell: 1 (target) from HBM, the query
-// side stays in L1/L2.
-struct Seg {
-    int a, b, P, M;
-};
-__device__ __forceinline__ Seg seg_combine(const Seg &l, const Seg &r) {   // l then r
-    Seg o;
-    o.b = l.b + r.b;
-    o.a = max(r.a, l.a + r.b);
-    o.P = max(l.P, l.b + r.P);
-    o.M = max(max(l.M, r.M), l.a + r.P);
-    return o;
-}
-__device__ __forceinline__ void load16(const uint8_t *p, uint32_t w[4]) {
-    // 16 bytes from an arbitrarily aligned address: one 16-byte + one 4-byte request on the enclosing aligned dwords
-    const uintptr_t u = reinterpret_cast<uintptr_t>(p);
-    const uint32_t *a = reinterpret_cast<const uint32_t *>(u & ~(uintptr_t)3);
-    const uint32_t sh = (uint32_t)(u & 3u);
-    const U32Quad d = *reinterpret_cast<const U32Quad *>(a);
-    const uint32_t d4 = a[4];
-    w[0] = __builtin_amdgcn_alignbyte(d.b, d.a, sh);
-    w[1] = __builtin_amdgcn_alignbyte(d.c, d.b, sh);
-    w[2] = __builtin_amdgcn_alignbyte(d.d, d.c, sh);
-    w[3] = __builtin_amdgcn_alignbyte(d4, d.d, sh);
-}
-__device__ __forceinline__ void load16_lds(const uint32_t *base, uint32_t byte_off, uint32_t w[4]) {
-    const uint32_t *a = base + (byte_off >> 2);
-    const uint32_t sh = byte_off & 3u;
-    const uint32_t d0 = a[0], d1 = a[1], d2 = a[2], d3 = a[3], d4 = a[4];
-    w[0] = __builtin_amdgcn_alignbyte(d1, d0, sh);
-    w[1] = __builtin_amdgcn_alignbyte(d2, d1, sh);
-    w[2] = __builtin_amdgcn_alignbyte(d3, d2, sh);
-    w[3] = __builtin_amdgcn_alignbyte(d4, d3, sh);
-}
-
+// Buckets with more than 64 candidates (the replay kernel scores the others itself): one wavefront per (query, bin).
 __global__ __launch_bounds__(256) void pf_ungapped_kernel(PfDedupArgs A) {
     __shared__ int8_t smat[32 * 32];
-    __shared__ uint32_t s_q[4][2][PF_QSTAGE / 4 + 8];   // per wavefront: query residues / correction bytes
     const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
     for (int k = (int)threadIdx.x; k < A.alphabet * A.alphabet; k += 256) smat[k] = A.mat[k];
     for (int k = A.alphabet * A.alphabet + (int)threadIdx.x; k < 32 * 32; k += 256) smat[k] = 0;
@@ -527,104 +726,21 @@ __global__ __launch_bounds__(256) void pf_ungapped_kernel(PfDedupArgs A) {
     const uint64_t bucket = (uint64_t)blockIdx.x * 4u + (uint32_t)wave;
     if (bucket >= (uint64_t)A.n_queries * B) return;
     const uint32_t ncand = A.cand_count[bucket];
-    if (ncand == 0) return;
+    if (ncand <= 64) return;
     const uint32_t q = (uint32_t)(bucket / B);
-    const uint32_t qp0 = A.q_off[q];
-    const int qlen = (int)(A.q_off[q + 1] - qp0);
-    const uint8_t *qr = A.q_res + qp0;
-    const uint8_t *qc = reinterpret_cast<const uint8_t *>(A.q_corr) + qp0;
-    const int alph = A.alphabet;
-    const int grp = lane >> 4, gl = lane & 15;
+    int bshift = 0;
+    while ((1u << bshift) < B) bshift++;
     uint64_t cells = 0;
-    // all candidates of a bin belong to one query: its residues and correction bytes are staged in LDS once
-    // (queries up to PF_QSTAGE residues; longer ones read the query side from L1/L2)
-    const bool staged = qlen <= PF_QSTAGE;
-    if (staged) {
-        const uint32_t *gq = reinterpret_cast<const uint32_t *>(qr - (qp0 & 3u));   // batch arrays are 4-byte aligned
-        const uint32_t *gc = reinterpret_cast<const uint32_t *>(qc - (qp0 & 3u));
-        const int nw = (int)(((qp0 & 3u) + (uint32_t)qlen + 3u) / 4u) + 5;
-        for (int k = lane; k < nw; k += 64) {
-            s_q[wave][0][k] = gq[k];
-            s_q[wave][1][k] = gc[k];
-        }
+    for (uint32_t cb0 = 0; cb0 < ncand; cb0 += 64) {
+        const uint32_t nin = min(64u, ncand - cb0);
+        PfCand c;
+        c.id = 0; c.arr = 0; c.score = 0; c.diag = 0; c.pad = 0;
+        if ((uint32_t)lane < nin) c = *cand_slot(A, bucket, cb0 + (uint32_t)lane);
+        cells += score_chunk(A, smat, nullptr, nullptr, bucket, q, cb0, nin, ncand, c, bshift);
     }
-    const uint32_t qsh = qp0 & 3u;
-    for (uint32_t c0 = 0; c0 < ncand; c0 += 4) {
-        const uint32_t ci = c0 + (uint32_t)grp;
-        const bool valid = ci < ncand;
-        int len = 0, qs = 0, ts = 0;
-        const uint8_t *t = A.t_res;
-        if (valid) {
-            const PfCand *cp = cand_slot(A, bucket, ci);
-            const uint32_t id = cp->id;
-            const int d = (int)(short)cp->diag;
-            const int tlen = (int)A.t_len[id];
-            t = A.t_res + (size_t)A.t_off4[id] * 4;
-            const int mind = d < 0 ? -d : d;
-            if (d >= 0 && mind < qlen) {
-                len = min(tlen, qlen - mind);
-                qs = mind;
-            } else if (d < 0 && mind < tlen) {
-                len = min(tlen - mind, qlen);
-                ts = mind;
-            }
-        }
-        int maxlen = len;
-        maxlen = max(maxlen, __shfl_xor(maxlen, 16));
-        maxlen = max(maxlen, __shfl_xor(maxlen, 32));
-        int s = 0, best = 0;
-        for (int p0 = 0; p0 < maxlen; p0 += 256) {
-            const int o = p0 + gl * 16;
-            Seg g;
-            g.a = 0; g.b = 0; g.P = -(1 << 28); g.M = 0;
-            if (o < len) {
-                uint32_t tw[4], qw[4], cw[4];
-                load16(t + ts + o, tw);
-                if (staged) {
-                    load16_lds(s_q[wave][0], qsh + (uint32_t)(qs + o), qw);
-                    load16_lds(s_q[wave][1], qsh + (uint32_t)(qs + o), cw);
-                } else {
-                    load16(qr + qs + o, qw);
-                    load16(qc + qs + o, cw);
-                }
-                const int nn = min(16, len - o);
-#pragma unroll
-                for (int k = 0; k < 16; k++) {
-                    const int tb_ = (int)((tw[k >> 2] >> ((k & 3) * 8)) & 0xFFu);
-                    const int qb = (int)((qw[k >> 2] >> ((k & 3) * 8)) & 0xFFu);
-                    const int cb = (int)(int8_t)((cw[k >> 2] >> ((k & 3) * 8)) & 0xFFu);
-                    const int x = (int)(int8_t)(smat[(qb * alph + tb_) & 1023] + cb);
-                    if (k < nn) {
-                        g.b += x;
-                        g.a = max(0, g.a + x);
-                        g.P = max(g.P, g.b);
-                        g.M = max(g.M, g.a);
-                    }
-                }
-            }
-            // ordered tree over the 16 lanes of the group
-#pragma unroll
-            for (int d = 1; d < 16; d <<= 1) {
-                Seg r;
-                r.a = __shfl_down(g.a, d);
-                r.b = __shfl_down(g.b, d);
-                r.P = __shfl_down(g.P, d);
-                r.M = __shfl_down(g.M, d);
-                if ((gl & (2 * d - 1)) == 0) g = seg_combine(g, r);
-            }
-            if (gl == 0 && p0 < len) {
-                best = max(best, max(g.M, s + g.P));
-                s = max(g.a, s + g.b);
-            }
-        }
-        if (valid && gl == 0) {
-            cand_slot(A, bucket, ci)->score = (uint32_t)best;
-            cells += (uint64_t)len;
-        }
-    }
-    if (A.cell_counter) {
-        for (int d = 1; d < 64; d <<= 1) cells += __shfl_xor((unsigned long long)cells, d);
-        if (lane == 0 && cells) atomicAdd((unsigned long long *)A.cell_counter, (unsigned long long)cells);
+    if (A.cell_counter) {   // statistics: one counter per query (a single global counter serialises 2.6 M atomics)
+        for (int dd = 1; dd < 64; dd <<= 1) cells += __shfl_xor((unsigned long long)cells, dd);
+        if (lane == 0 && cells) atomicAdd((unsigned long long *)&A.cell_counter[q], (unsigned long long)cells);
     }
 }
 
@@ -639,41 +755,11 @@ __global__ __launch_bounds__(256) void pf_keepmax_kernel(PfDedupArgs A) {
     const uint64_t bucket = (uint64_t)blockIdx.x * 4u + (uint32_t)wave;
     if (bucket >= (uint64_t)A.n_queries * B) return;
     const uint32_t ncand = A.cand_count[bucket];
-    if (ncand == 0) return;
+    if (ncand <= 64) return;   // scored and reduced by pf_ungapped_kernel already
     const uint32_t q = (uint32_t)(bucket / B);
     uint32_t *S = s_tab[wave];
     int bshift = 0;
     while ((1u << bshift) < B) bshift++;
-    if (ncand <= 64) {
-        // common case: the whole bucket fits one round, resolve with ballot matching instead of the table
-        PfCand c;
-        c.id = 0; c.arr = 0; c.score = 0; c.diag = 0; c.pad = 0;
-        const bool act = (uint32_t)lane < ncand;
-        if (act) c = *cand_slot(A, bucket, (uint32_t)lane);
-        const uint32_t cnt = min(255u, c.score);
-        const uint64_t same = match_lanes(c.id >> bshift, 12, act);
-        // best (count, lowest lane) inside my target group
-        bool win = act;
-        uint64_t m = same & ~(1ull << lane);
-        while (__ballot(m != 0)) {
-            const int o = m ? __ffsll((long long)m) - 1 : lane;
-            const uint32_t oc = __shfl(cnt, o);
-            if (m) {
-                if (oc > cnt || (oc == cnt && o < lane)) win = false;
-                m &= m - 1;
-            }
-        }
-        win = win && cnt >= A.min_diag_score;
-        const uint64_t wb = __ballot(win);
-        if (wb) {
-            PfCand *surv = A.surv + A.cand_base[(uint64_t)q * B];
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(&A.surv_count[q], (uint32_t)__popcll(wb));
-            base = __shfl(base, 0);
-            if (win) surv[base + (uint32_t)__popcll(wb & lanes_below(lane))] = c;
-        }
-        return;
-    }
     for (int k = lane; k < PF_IDS_PER_BIN; k += 64) S[k] = 0;
     for (uint32_t c0 = 0; c0 < ncand; c0 += 64) {
         const uint32_t ci = c0 + (uint32_t)lane;

@@ -17,6 +17,7 @@ ap.add_argument("--steps", type=int, default=2)
 ap.add_argument("--sens", type=float, default=5.7)
 ap.add_argument("--max-hits", type=int, default=300)
 ap.add_argument("--check", type=int, default=0, help="queries to verify against the oracle")
+ap.add_argument("--sort", type=int, default=1, help="form batches of similar-length queries (residue-bounded)")
 args = ap.parse_args()
 
 m = dict(np.load(os.path.join(ROOT, "tests", "golden", "matrices.npz")))
@@ -36,7 +37,18 @@ t_load = time.time() - t0
 t0 = time.time()
 cbs = [capi.host_comp_bias(km16, m["vtml80_pback"], q)[0] for q in qs]
 queries = [dict(q=q, comp_bias=cb, identity_id=None) for q, cb in zip(qs, cbs)]
-batches = [gpu.pf_prepare(queries[i:i + args.batch], thr, max_hits=args.max_hits, ref_bins=2) for i in range(0, len(queries), args.batch)]
+if args.sort:
+    order = np.argsort([-len(q) for q in qs], kind="stable")
+    groups, cur, res = [], [], 0
+    for qi in order:
+        if cur and (res + len(qs[qi]) > args.batch * 280 or len(cur) >= 4 * args.batch):
+            groups.append(cur); cur, res = [], 0
+        cur.append(int(qi)); res += len(qs[qi])
+    if cur:
+        groups.append(cur)
+else:
+    groups = [list(range(i, min(i + args.batch, len(queries)))) for i in range(0, len(queries), args.batch)]
+batches = [gpu.pf_prepare([queries[i] for i in g], thr, max_hits=args.max_hits, ref_bins=2) for g in groups]
 t_prep = time.time() - t0
 for b in batches:      # warm-up (also sizes the working buffers)
     b.run()
@@ -57,7 +69,7 @@ for b in batches:
     cc = b.last_cells(); cells += cc[0]; cands += cc[1]
     ent += int(stats["db_matches"].sum()); lists += int(stats["kmer_list_len"].sum()); hits_n += int(c.sum()); ovf += int((st != 0).sum())
     allhits.append((h, c, st))
-out = dict(queries=len(qs), targets=len(toff) - 1, residues=int(toff[-1]), index_entries=len(ids),
+out = dict(batches=len(batches), queries=len(qs), targets=len(toff) - 1, residues=int(toff[-1]), index_entries=len(ids),
            queries_per_s=round(len(qs) / dt, 1), s_per_pass=round(dt, 4), stage_ms=[round(x, 2) for x in stage],
            db_matches=ent, similar_kmers=lists, ungapped_cells=cells, candidates=cands,
            ungapped_GBps=round(cells / (stage[3] * 1e-3) / 1e9, 1) if stage[3] else None, hits=hits_n, overflow_queries=ovf,
@@ -65,6 +77,7 @@ out = dict(queries=len(qs), targets=len(toff) - 1, residues=int(toff[-1]), index
            entries_per_query=round(ent / max(len(qs), 1)), t_gen=round(t_gen, 1), t_score_matrix=round(t_sm, 1),
            t_index_build=round(t_ix, 1), t_load=round(t_load, 1), t_prepare=round(t_prep, 1))
 # family recall: fraction of (query, same-family target) pairs the hit lists contain
+where = {qi: (bi, wi) for bi, g in enumerate(groups) for wi, qi in enumerate(g)}
 if args.check:
     from oracle.pyoracle import PfOracle
     orc = PfOracle(km16, m["blosum62_ungapped"], 6, True)
@@ -72,7 +85,7 @@ if args.check:
     bad = 0
     rng = np.random.default_rng(0)
     for qi in rng.choice(len(qs), args.check, replace=False):
-        bi, wi = divmod(int(qi), args.batch)
+        bi, wi = where[int(qi)]
         h, c, st = allhits[bi]
         o = orc.match(qs[qi], cbs[qi], 2, max_hits=args.max_hits)   # ref_bins default resolves to 2 on this host class
         n = int(c[wi])
