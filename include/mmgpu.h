@@ -172,12 +172,15 @@ int mmgpu_host_index_build(const uint8_t *residues, const uint64_t *seq_offsets,
 
 /* Everything QueryMatcher's constructor receives that lives in memory (Prefiltering.cpp:826-842). */
 typedef struct {
-    int kmer_size;              /* 6 (7 is not implemented on the device yet -> MMGPU_ERR_UNSUPPORTED) */
+    int kmer_size;              /* 6 or 7 */
     int alphabet;               /* subMat->alphabetSize, 21 */
     int spaced;                 /* spaced k-mer pattern of Sequence.h:24-27 */
     const int16_t *score3;      /* ScoreMatrix::score of _3merSubMatrix */
     const uint32_t *index3;     /* ScoreMatrix::index */
     size_t row3;                /* ScoreMatrix::rowSize (elements per row incl. SIMD padding) */
+    const int16_t *score2;      /* _2merSubMatrix (needed for kmer_size 7 only, may be NULL otherwise) */
+    const uint32_t *index2;
+    size_t row2;
     const uint64_t *offsets;    /* IndexTable::getOffsets(), (alphabet-1)^k + 1 */
     const uint32_t *entry_ids;  /* IndexEntryLocal::seqId    } either these two arrays ...               */
     const uint16_t *entry_pos;  /* IndexEntryLocal::position_j }                                          */

@@ -59,7 +59,8 @@ EXPORTED_SYMBOLS = [
 
 class PfIndexDesc(ctypes.Structure):
     _fields_ = [("kmer_size", ctypes.c_int), ("alphabet", ctypes.c_int), ("spaced", ctypes.c_int), ("score3", c_p),
-                ("index3", c_p), ("row3", ctypes.c_size_t), ("offsets", c_p), ("entry_ids", c_p), ("entry_pos", c_p),
+                ("index3", c_p), ("row3", ctypes.c_size_t), ("score2", c_p), ("index2", c_p), ("row2", ctypes.c_size_t),
+                ("offsets", c_p), ("entry_ids", c_p), ("entry_pos", c_p),
                 ("entries6", c_p), ("n_entries", ctypes.c_uint64), ("ungapped_mat", c_p)]
 
 
@@ -354,14 +355,19 @@ class MMGpu:
         return SwBatch(self, h, keep)
 
     # ---- prefilter ----
-    def pf_load_index(self, k, alphabet, spaced, score3, index3, offsets, entry_ids, entry_pos, ungapped_mat):
+    def pf_load_index(self, k, alphabet, spaced, score3, index3, offsets, entry_ids, entry_pos, ungapped_mat,
+                      score2=None, index2=None):
         score3 = np.ascontiguousarray(score3, np.int16)
         index3 = np.ascontiguousarray(index3, np.uint32)
         offsets = np.ascontiguousarray(offsets, np.uint64)
         entry_ids = np.ascontiguousarray(entry_ids, np.uint32)
         entry_pos = np.ascontiguousarray(entry_pos, np.uint16)
         ungapped_mat = np.ascontiguousarray(ungapped_mat, np.int8)
-        d = PfIndexDesc(k, alphabet, int(spaced), _ptr(score3), _ptr(index3), score3.shape[1], _ptr(offsets),
+        if score2 is not None:
+            score2 = np.ascontiguousarray(score2, np.int16)
+            index2 = np.ascontiguousarray(index2, np.uint32)
+        d = PfIndexDesc(k, alphabet, int(spaced), _ptr(score3), _ptr(index3), score3.shape[1], _ptr(score2), _ptr(index2),
+                        0 if score2 is None else score2.shape[1], _ptr(offsets),
                         _ptr(entry_ids), _ptr(entry_pos), None, len(entry_ids), _ptr(ungapped_mat))
         self._check(self.L.mmgpu_pf_load_index(self.ctx, ctypes.byref(d)))
 

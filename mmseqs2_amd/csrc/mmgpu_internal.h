@@ -101,6 +101,13 @@ struct PfKmerArgs {
     const uint16_t *cum3;      // [n3][cum_w]: cum3[row][k] = number of entries of the row with score >= score_min + k
     uint32_t cum_w;
     int32_t score_min;
+    // k = 7 only: the 2-mer tables
+    int k;
+    const int16_t *s2;         // [n2][n2]
+    const uint32_t *i2;
+    const uint16_t *cum2;      // [n2][cum2_w]
+    uint32_t cum2_w;
+    int32_t score2_min;
     // count pass
     uint32_t *nsim;
     // emit pass

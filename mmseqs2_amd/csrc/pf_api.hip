@@ -19,9 +19,9 @@ struct PfIndex {
     int pattern_len = 0;
     uint32_t n3 = 0;
     uint64_t table = 0, n_entries = 0;
-    DevBuf d_s3, d_i3, d_cum3, d_offsets, d_entries, d_mat;
-    uint32_t cum_w = 0;
-    int32_t score_min = 0;
+    DevBuf d_s3, d_i3, d_cum3, d_s2, d_i2, d_cum2, d_offsets, d_entries, d_mat;
+    uint32_t cum_w = 0, cum2_w = 0;
+    int32_t score_min = 0, score2_min = 0;
     std::vector<int8_t> h_mat;   // ungapped matrix (host copy for the self score)
     // Large working buffers, shared by all batches of this context (grow-only; batches run one at a time on the
     // context's stream): index lists, split tiles, candidates, survivors.
@@ -238,7 +238,8 @@ extern "C" int mmgpu_host_index_build(const uint8_t *residues, const uint64_t *s
 extern "C" int mmgpu_pf_load_index(mmgpu_ctx *c, const mmgpu_pf_index *ix) {
     if (!c || !ix) return fail(MMGPU_ERR_ARG, "mmgpu_pf_load_index: NULL argument");
     if (!c->db.res) return fail(MMGPU_ERR_STATE, "mmgpu_pf_load_index: load the targets (SequenceLookup) first");
-    if (ix->kmer_size != 6) return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_pf_load_index: only k = 6 is implemented on the device");
+    if (ix->kmer_size != 6 && ix->kmer_size != 7) return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_pf_load_index: k must be 6 or 7");
+    if (ix->kmer_size == 7 && (!ix->score2 || !ix->index2)) return fail(MMGPU_ERR_ARG, "mmgpu_pf_load_index: k = 7 needs the 2-mer ScoreMatrix");
     if (ix->alphabet != c->db.alphabet) return fail(MMGPU_ERR_ARG, "mmgpu_pf_load_index: alphabet differs from the loaded targets");
     if (!ix->score3 || !ix->index3 || !ix->offsets || !ix->ungapped_mat) return fail(MMGPU_ERR_ARG, "mmgpu_pf_load_index: NULL table");
     if (!ix->entries6 && !(ix->entry_ids && ix->entry_pos) && ix->n_entries) return fail(MMGPU_ERR_ARG, "mmgpu_pf_load_index: no index entries");
@@ -263,29 +264,44 @@ extern "C" int mmgpu_pf_load_index(mmgpu_ctx *c, const mmgpu_pf_index *ix) {
     P_TRY(P->d_i3.alloc(n3 * n3 * sizeof(uint32_t)));
     P_TRY(hipMemcpy2D(P->d_s3.p, n3 * sizeof(int16_t), ix->score3, ix->row3 * sizeof(int16_t), n3 * sizeof(int16_t), n3, hipMemcpyHostToDevice));
     P_TRY(hipMemcpy2D(P->d_i3.p, n3 * sizeof(uint32_t), ix->index3, ix->row3 * sizeof(uint32_t), n3 * sizeof(uint32_t), n3, hipMemcpyHostToDevice));
-    {
-        // cumulative counts per row: #entries with score >= c is one lookup instead of a binary search in the row
+    // cumulative counts per row: #entries with score >= c is one lookup instead of a binary search in the row
+    auto build_cum = [&](const int16_t *score, size_t row_stride, size_t n, DevBuf &dst, uint32_t *w_out, int32_t *min_out) -> int {
         int lo = 32767, hi = -32768;
-        for (size_t r = 0; r < n3; r++) {
-            lo = std::min<int>(lo, ix->score3[r * ix->row3 + n3 - 1]);
-            hi = std::max<int>(hi, ix->score3[r * ix->row3]);
+        for (size_t r = 0; r < n; r++) {
+            lo = std::min<int>(lo, score[r * row_stride + n - 1]);
+            hi = std::max<int>(hi, score[r * row_stride]);
         }
-        P->score_min = lo;
-        P->cum_w = (uint32_t)(hi - lo + 2);
-        std::vector<uint16_t> cum(n3 * (size_t)P->cum_w);
-        for (size_t r = 0; r < n3; r++) {
-            const int16_t *row = ix->score3 + r * ix->row3;
+        const uint32_t w = (uint32_t)(hi - lo + 2);
+        std::vector<uint16_t> cum(n * (size_t)w);
+        for (size_t r = 0; r < n; r++) {
+            const int16_t *row = score + r * row_stride;
+            for (size_t z = 1; z < n; z++)
+                if (row[z] > row[z - 1]) return 1;
             size_t j = 0;   // rows are sorted descending: walk thresholds from high to low
-            for (int k = (int)P->cum_w - 1; k >= 0; k--) {
+            for (int k = (int)w - 1; k >= 0; k--) {
                 const int c = lo + k;
-                while (j < n3 && row[j] >= c) j++;
-                cum[r * P->cum_w + (size_t)k] = (uint16_t)j;
+                while (j < n && row[j] >= c) j++;
+                cum[r * w + (size_t)k] = (uint16_t)j;
             }
-            for (size_t z = 1; z < n3; z++)
-                if (row[z] > row[z - 1]) { delete P; return fail(MMGPU_ERR_ARG, "mmgpu_pf_load_index: score3 rows are not sorted by descending score"); }
         }
-        P_TRY(upload(P->d_cum3, cum, nullptr));
-        P_TRY(hipDeviceSynchronize());
+        if (upload(dst, cum, nullptr) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return 2;
+        *w_out = w;
+        *min_out = lo;
+        return 0;
+    };
+    {
+        const int rc = build_cum(ix->score3, ix->row3, n3, P->d_cum3, &P->cum_w, &P->score_min);
+        if (rc) { delete P; return fail(rc == 1 ? MMGPU_ERR_ARG : MMGPU_ERR_HIP, rc == 1 ? "mmgpu_pf_load_index: score3 rows are not sorted by descending score" : "mmgpu_pf_load_index: upload failed"); }
+    }
+    if (P->k == 7) {
+        const size_t n2 = (size_t)P->kalph * P->kalph;
+        if (ix->row2 < n2) { delete P; return fail(MMGPU_ERR_ARG, "mmgpu_pf_load_index: row2 smaller than kalph^2"); }
+        P_TRY(P->d_s2.alloc(n2 * n2 * sizeof(int16_t)));
+        P_TRY(P->d_i2.alloc(n2 * n2 * sizeof(uint32_t)));
+        P_TRY(hipMemcpy2D(P->d_s2.p, n2 * sizeof(int16_t), ix->score2, ix->row2 * sizeof(int16_t), n2 * sizeof(int16_t), n2, hipMemcpyHostToDevice));
+        P_TRY(hipMemcpy2D(P->d_i2.p, n2 * sizeof(uint32_t), ix->index2, ix->row2 * sizeof(uint32_t), n2 * sizeof(uint32_t), n2, hipMemcpyHostToDevice));
+        const int rc = build_cum(ix->score2, ix->row2, n2, P->d_cum2, &P->cum2_w, &P->score2_min);
+        if (rc) { delete P; return fail(rc == 1 ? MMGPU_ERR_ARG : MMGPU_ERR_HIP, rc == 1 ? "mmgpu_pf_load_index: score2 rows are not sorted by descending score" : "mmgpu_pf_load_index: upload failed"); }
     }
     {
         std::vector<uint32_t> off32(P->table + 1);
@@ -504,6 +520,12 @@ extern "C" int mmgpu_pf_run(mmgpu_ctx *c, mmgpu_pf_batch_t *b) {
     K.cum3 = P.d_cum3.as<uint16_t>();
     K.cum_w = P.cum_w;
     K.score_min = P.score_min;
+    K.k = P.k;
+    K.s2 = P.d_s2.as<int16_t>();
+    K.i2 = P.d_i2.as<uint32_t>();
+    K.cum2 = P.d_cum2.as<uint16_t>();
+    K.cum2_w = P.cum2_w;
+    K.score2_min = P.score2_min;
     K.nsim = b->d_nsim.as<uint32_t>();
     HIP_TRY(launch_pf_kmers(K, false, s));
     HIP_TRY(launch_pf_scan(b->d_nsim.as<uint32_t>(), b->d_qoff.as<uint32_t>(), nq, nullptr, nullptr, b->d_qtot.as<uint64_t>(), s));

@@ -185,6 +185,112 @@ __global__ __launch_bounds__(256) void pf_kmers_kernel(PfKmerArgs A) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// k = 7: the k-mer splits into (2, 2, 3) residues (setDivideStrategy case kmerSize % 3 == 1, reversed,
+// KmerGenerator.cpp:57-86).  generateKmerList runs two products: row A (2-mer of residues 0,1) x row B (2-mer of 2,3)
+// with the branch-and-bound cutoffs, then every element of that intermediate list, in order, x row C (3-mer of 4..6)
+// with cutoff thr - score (the second product has cutoff1 = -1000, i.e. no early exit, :165).  Same output contract as
+// pf_kmers_kernel.
+template <bool EMIT>
+__global__ __launch_bounds__(256) void pf_kmers7_kernel(PfKmerArgs A) {
+    const int lane = lane_id();
+    const uint32_t gp = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (gp >= A.n_pos) return;
+    const int thr = A.q_thr[gp];
+    if (thr < 0) {
+        if (lane == 0) {
+            if (EMIT) A.pos_entries[gp] = 0; else A.nsim[gp] = 0;
+        }
+        return;
+    }
+    const uint8_t *q = A.q_res + gp;
+    const uint32_t ka = A.kalph;
+    const uint32_t n2 = ka * ka, n3 = A.n3;
+    const uint32_t rowA = q[A.pat[0]] + ka * q[A.pat[1]];
+    const uint32_t rowB = q[A.pat[2]] + ka * q[A.pat[3]];
+    const uint32_t rowC = q[A.pat[4]] + ka * (q[A.pat[5]] + ka * q[A.pat[6]]);
+    const int16_t *sA = A.s2 + (size_t)rowA * n2;
+    const uint32_t *iA = A.i2 + (size_t)rowA * n2;
+    const int16_t *sB = A.s2 + (size_t)rowB * n2;
+    const uint32_t *iB = A.i2 + (size_t)rowB * n2;
+    const uint32_t *iC = A.i3 + (size_t)rowC * n3;
+    const uint16_t *cumA = A.cum2 + (size_t)rowA * A.cum2_w;
+    const uint16_t *cumB = A.cum2 + (size_t)rowB * A.cum2_w;
+    const uint16_t *cumC = A.cum3 + (size_t)rowC * A.cum_w;
+    const int min2 = A.score2_min, max2 = A.score2_min + (int)A.cum2_w - 2;
+    const int min3 = A.score_min, max3 = A.score_min + (int)A.cum_w - 2;
+    auto count2 = [&](const uint16_t *cum, int c) -> uint32_t { return c <= min2 ? n2 : (c > max2 ? 0u : (uint32_t)cum[c - min2]); };
+    auto count3 = [&](const uint16_t *cum, int c) -> uint32_t { return c <= min3 ? n3 : (c > max3 ? 0u : (uint32_t)cum[c - min3]); };
+    const int hB = (int)sB[0], hC = (int)A.s3[(size_t)rowC * n3];
+    const int rest0 = (int)(short)(hB + (int)(short)hC), rest1 = (int)(short)hC;
+    const int cutoff1 = (int)(short)(thr - rest0);
+    const uint32_t nA = count2(cumA, cutoff1);
+    const uint32_t mult2 = n2, mult3 = n2 * n2;   // Indexer::powers[2], powers[4]
+    uint32_t nlists = 0, running = 0;
+    uint32_t lbase = 0;
+    if (EMIT) lbase = A.list_base[gp];
+    for (uint32_t c0 = 0; c0 < nA; c0 += 64) {
+        const uint32_t ia = c0 + (uint32_t)lane;
+        const bool inA = ia < nA;
+        const int scA = inA ? (int)sA[ia] : 0;
+        const uint32_t idxA = inA ? iA[ia] : 0u;
+        uint32_t n1 = 0;
+        if (inA) n1 = count2(cumB, (int)(short)(thr - scA - rest1));
+        const uint32_t incl1 = wave_incl_scan(n1);
+        const uint32_t total1 = __shfl(incl1, 63);
+        const uint32_t excl1 = incl1 - n1;
+        for (uint32_t e0 = 0; e0 < total1; e0 += 64) {          // intermediate elements (i, j), 64 at a time
+            const uint32_t x = e0 + (uint32_t)lane;
+            const bool actE = x < total1;
+            const int m = seg_find(excl1, x);
+            const uint32_t ex_m = __shfl(excl1, m);
+            const int sc_i = __shfl(scA, m);
+            const uint32_t idx_i = __shfl(idxA, m);
+            int sc_e = 0;
+            uint32_t idx_e = 0, n2e = 0;
+            if (actE) {
+                const uint32_t j = x - ex_m;
+                sc_e = (int)(short)(sc_i + (int)sB[j]);
+                idx_e = idx_i + iB[j] * mult2;
+                n2e = count3(cumC, (int)(short)(thr - sc_e));
+            }
+            const uint32_t incl2 = wave_incl_scan(n2e);
+            const uint32_t total2 = __shfl(incl2, 63);
+            if (EMIT) {
+                const uint32_t excl2 = incl2 - n2e;
+                for (uint32_t r0 = 0; r0 < total2; r0 += 64) {
+                    const uint32_t y = r0 + (uint32_t)lane;
+                    const bool act = y < total2;
+                    const int me = seg_find(excl2, y);
+                    const uint32_t ex_e = __shfl(excl2, me);
+                    const uint32_t k_e = __shfl(idx_e, me);
+                    uint32_t start = 0, len = 0;
+                    if (act) {
+                        const uint32_t kmer = k_e + iC[y - ex_e] * mult3;
+                        const U32Pair o = *reinterpret_cast<const U32Pair *>(A.offsets + kmer);
+                        start = o.a;
+                        len = o.b - o.a;
+                    }
+                    const uint32_t li = wave_incl_scan(len);
+                    if (act) {
+                        PfList rec;
+                        rec.start = start;
+                        rec.len = len;
+                        rec.lprefix = running + li - len;
+                        rec.pos = gp;
+                        A.lists[(size_t)lbase + nlists + y] = rec;
+                    }
+                    running += __shfl(li, 63);
+                }
+            }
+            nlists += total2;
+        }
+    }
+    if (lane == 0) {
+        if (EMIT) A.pos_entries[gp] = running; else A.nsim[gp] = nlists;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Exclusive scan of in[q_off[q] .. q_off[q+1]) per query (one workgroup per query), written relative to the query
 // (+ base[q] when base != nullptr); totals[q] = the query's sum (64-bit).  out has one extra element per batch:
 // the last workgroup also writes out[n_pos] = base[nq-1] + total so that out[gp+1] is valid for every gp.
@@ -1046,8 +1152,13 @@ __global__ __launch_bounds__(256) void pf_merge_kernel(PfMergeArgs A) {
 hipError_t launch_pf_kmers(const PfKmerArgs &A, bool emit, hipStream_t s) {
     if (A.n_pos == 0) return hipSuccess;
     const dim3 grid((A.n_pos + 3) / 4), block(256);
-    if (emit) hipLaunchKernelGGL(pf_kmers_kernel<true>, grid, block, 0, s, A);
-    else hipLaunchKernelGGL(pf_kmers_kernel<false>, grid, block, 0, s, A);
+    if (A.k == 7) {
+        if (emit) hipLaunchKernelGGL(pf_kmers7_kernel<true>, grid, block, 0, s, A);
+        else hipLaunchKernelGGL(pf_kmers7_kernel<false>, grid, block, 0, s, A);
+    } else {
+        if (emit) hipLaunchKernelGGL(pf_kmers_kernel<true>, grid, block, 0, s, A);
+        else hipLaunchKernelGGL(pf_kmers_kernel<false>, grid, block, 0, s, A);
+    }
     return hipGetLastError();
 }
 

@@ -168,3 +168,30 @@ def test_prefilter_100k_targets_properties_and_oracle_sample(gpu):
         assert np.array_equal(h0[qi]["id"][:n], o["id"]) and np.array_equal(h0[qi]["score"][:n], o["score"])
         assert np.array_equal(h0[qi]["diagonal"][:n], o["diagonal"])
     chk.load_case(gpu, g, g["tres"], g["toff"], thr)
+
+
+def test_prefilter_k7(gpu):
+    """k = 7 (the reference's choice for target sets of 3.35e9 residues and more, IndexTable.h:441-449): the (2,2,3)
+    similar-k-mer generator, a 20^7-entry offset table, hit lists against the oracle (itself pinned against the real
+    reference for k = 7, scripts/fuzz and tests/test_prefilter_oracle.py)."""
+    from oracle.pyoracle import PfOracle, kmer_threshold
+    g = pc.golden()
+    thr7 = kmer_threshold(5.7, 7)
+    base = pc.pf_oracle()
+    orc = PfOracle.__new__(PfOracle)
+    orc.__dict__.update(base.__dict__)
+    orc.k = 7
+    import ctypes
+    from oracle.pyoracle import PfGen
+    orc.gen = PfGen(7, orc.kalph, orc.s3.ctypes.data, orc.i3.ctypes.data, orc.s2.ctypes.data, orc.i2.ctypes.data)
+    n = 400
+    tres, toff = g["tres"][:int(g["toff"][n])], g["toff"][:n + 1]
+    orc.build_index(tres, toff, thr7)
+    chk.load_case(gpu, g, tres, toff, thr7, k=7)
+    qs = pc.golden_queries(g)[:10]
+    for qd in qs:
+        qd["identity_id"] = None
+    ok, rep = chk.check(gpu, orc, qs, 300, 2, stages=True, label="k7")
+    assert ok, "\n".join(rep)
+    thr = int(g["kmer_thr"])
+    chk.load_case(gpu, g, g["tres"], g["toff"], thr)

@@ -70,6 +70,19 @@ def test_oracle_fuzz_vs_reference():
         a, na = o.kmer_list(kmer, thr)
         b, nb = ref.kmer_list(kmer, thr)
         assert na == nb and np.array_equal(a, b)
+    # k = 7: (2,2,3) divide strategy
+    from oracle.pyoracle import PfOracle, PfGen
+    ref7 = pyoracle.RefPrefilter(7)
+    o7 = PfOracle.__new__(PfOracle)
+    o7.__dict__.update(o.__dict__)
+    o7.k = 7
+    o7.gen = PfGen(7, o.kalph, o.s3.ctypes.data, o.i3.ctypes.data, o.s2.ctypes.data, o.i2.ctypes.data)
+    for _ in range(100):
+        kmer = rng.integers(0, 20, 7).astype(np.uint8)
+        thr = int(rng.integers(80, 160))
+        a, na = o7.kmer_list(kmer, thr)
+        b, nb = ref7.kmer_list(kmer, thr)
+        assert na == nb and np.array_equal(a, b)
     (qres, qoff), (tres, toff) = pc.synthetic_case(10, 1200, seed=77, planted=0.5)
     thr = pyoracle.kmer_threshold(5.7, 6)
     ref.build_index(tres, toff, thr)
