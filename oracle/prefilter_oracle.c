@@ -436,6 +436,82 @@ static size_t mmo_keep_max(mmo_cr *io, size_t n, uint32_t bins, uint32_t n_targe
     return outn;
 }
 
+
+/* hashElements (CacheFriendlyOperations.cpp:325-338): stable scatter of CounterResults into bins by id & (bins-1);
+ * returns the bin boundaries (bins + 1 entries, caller frees) and fills tmp in bin order. */
+static size_t *mmo_hash_elements(const mmo_cr *in, size_t n, uint32_t bins, mmo_cr *tmp) {
+    size_t *bcnt = (size_t *)calloc(bins + 1, sizeof(size_t));
+    for (size_t e = 0; e < n; e++) bcnt[(in[e].id & (bins - 1)) + 1]++;
+    for (uint32_t b = 0; b < bins; b++) bcnt[b + 1] += bcnt[b];
+    size_t *cur = (size_t *)malloc(bins * sizeof(size_t));
+    for (uint32_t b = 0; b < bins; b++) cur[b] = bcnt[b];
+    for (size_t e = 0; e < n; e++) tmp[cur[in[e].id & (bins - 1)]++] = in[e];
+    free(cur);
+    return bcnt;
+}
+
+/* mergeElementsByDiagonal(keepScoredHits = true) -> mergeDiagonalKeepScoredHitsDuplicates
+ * (CacheFriendlyOperations.cpp:60-71,119-148): per bin the diagonal bytes + 1 are written in forward order, then
+ * the bin is walked BACKWARDS; an element is kept when it already carries a score or its diagonal byte differs
+ * from the element of the same target seen just before in that walk.  Output order: bins ascending, each reversed. */
+static size_t mmo_merge_keep_scored(mmo_cr *io, size_t n, uint32_t bins, uint32_t n_targets) {
+    uint32_t bits = 0;
+    while ((1u << bits) < bins) bits++;
+    uint8_t *dup = (uint8_t *)calloc(((size_t)n_targets >> bits) + 2, 1);
+    mmo_cr *tmp = (mmo_cr *)malloc((n + 1) * sizeof(mmo_cr));
+    size_t *bcnt = mmo_hash_elements(io, n, bins, tmp);
+    size_t outn = 0;
+    for (uint32_t b = 0; b < bins; b++) {
+        for (size_t z = bcnt[b]; z < bcnt[b + 1]; z++) dup[tmp[z].id >> bits] = (uint8_t)((uint8_t)tmp[z].diagonal + 1);
+        for (size_t z = bcnt[b + 1]; z-- > bcnt[b];) {
+            size_t h = tmp[z].id >> bits;
+            io[outn] = tmp[z];
+            outn += (io[outn].count != 0 || dup[h] != (uint8_t)tmp[z].diagonal) ? 1 : 0;
+            dup[h] = (uint8_t)tmp[z].diagonal;
+        }
+    }
+    free(dup);
+    free(tmp);
+    free(bcnt);
+    return outn;
+}
+
+/* mergeElementsByDiagonal(keepScoredHits = false) -> mergeDiagonalDuplicates (:60-71,83-115): the diagonal bytes + 1
+ * are written in REVERSE order (so a target's slot ends with its first element's), then the bin is walked forwards
+ * and an element is kept when its diagonal byte differs from the previous element of the same target. */
+static size_t mmo_merge_diag_dup(mmo_cr *io, size_t n, uint32_t bins, uint32_t n_targets) {
+    uint32_t bits = 0;
+    while ((1u << bits) < bins) bits++;
+    uint8_t *dup = (uint8_t *)calloc(((size_t)n_targets >> bits) + 2, 1);
+    mmo_cr *tmp = (mmo_cr *)malloc((n + 1) * sizeof(mmo_cr));
+    size_t *bcnt = mmo_hash_elements(io, n, bins, tmp);
+    size_t outn = 0;
+    for (uint32_t b = 0; b < bins; b++) {
+        for (size_t z = bcnt[b + 1]; z-- > bcnt[b];) dup[tmp[z].id >> bits] = (uint8_t)((uint8_t)tmp[z].diagonal + 1);
+        for (size_t z = bcnt[b]; z < bcnt[b + 1]; z++) {
+            size_t h = tmp[z].id >> bits;
+            io[outn] = tmp[z];
+            outn += (dup[h] != (uint8_t)tmp[z].diagonal) ? 1 : 0;
+            dup[h] = (uint8_t)tmp[z].diagonal;
+        }
+    }
+    free(dup);
+    free(tmp);
+    free(bcnt);
+    return outn;
+}
+
+/* UngappedAlignment::computeScores (UngappedAlignment.cpp:315-346): only elements without a score are scored */
+static void mmo_score_unscored(mmo_cr *fd, size_t n, const mmo_pf_params *P, const uint8_t *q, const int8_t *corr, int qlen) {
+    for (size_t z = 0; z < n; z++) {
+        if (fd[z].count != 0) continue;
+        const uint8_t *t = P->tdata + P->toff[fd[z].id];
+        int tlen = (int)(P->toff[fd[z].id + 1] - P->toff[fd[z].id]);
+        int sc = mmo_diag_score(q, corr, qlen, P->ungapped_mat, P->alphabet, t, tlen, (int)(short)fd[z].diagonal);
+        fd[z].count = (uint8_t)(sc > 255 ? 255 : sc);
+    }
+}
+
 /* radixSortByScoreSize (QueryMatcher.cpp:536-561) */
 static size_t mmo_radix_by_score(const unsigned *sizes, mmo_cr *w, unsigned thr, const mmo_cr *r, size_t n) {
     mmo_cr *ptr[256];
@@ -482,17 +558,22 @@ int mmo_pf_match_query(const mmo_pf_params *P, const uint8_t *q, int qlen, const
     const size_t max_db_matches = found_cap * 2;               /* :45 */
     size_t max_hits = P->max_hits < db ? (size_t)P->max_hits : db; /* :47 */
 
-    /* ---- match() (:243-376) ---- */
+    /* ---- match() (:243-376), including the databaseHits overflow path (:310-346) ---- */
     size_t acap = 1 << 16, an = 0;
     uint32_t *aid = (uint32_t *)malloc(acap * sizeof(uint32_t));
     uint16_t *adg = (uint16_t *)malloc(acap * sizeof(uint16_t));
     size_t simcap = 1 << 20;
     uint64_t *sim = (uint64_t *)malloc(simcap * sizeof(uint64_t));
+    mmo_cr *fd = (mmo_cr *)malloc((2 * found_cap + 16) * sizeof(mmo_cr)); /* foundDiagonals (+ radix ping-pong half) */
+    size_t overflow_hits = 0, overflow_matches = 0;
+    int8_t *corr = (int8_t *)malloc((size_t)qlen + 1);
+    mmo_pf_ungapped_corr(comp_bias, qlen, corr);
     if (dump && dump->thr_out)
         for (int i = 0; i < qlen; i++) dump->thr_out[i] = -1;
     if (dump && dump->nsim_out)
         for (int i = 0; i < qlen; i++) dump->nsim_out[i] = 0;
-    for (int i = 0; i + plen <= qlen; i++) {
+    int aborted = 0;
+    for (int i = 0; i + plen <= qlen && !aborted; i++) {
         uint8_t w[8];
         float bc = 0;
         int hasx = 0;
@@ -517,9 +598,24 @@ int mmo_pf_match_query(const mmo_pf_params *P, const uint8_t *q, int qlen, const
         for (size_t z = 0; z < ns; z++) { /* :296-350 */
             uint64_t o0 = P->offsets[sim[z]], o1 = P->offsets[sim[z] + 1];
             size_t len = (size_t)(o1 - o0);
-            if (an + len >= max_db_matches) { /* :310: overflow path, not restated */
-                S.overflow = 1;
-                goto done_fail;
+            if (an + len >= max_db_matches) { /* :310 (sequenceHits + seqListSize) >= lastSequenceHit */
+                S.overflow++;
+                /* everything gathered so far (incl. the lists of this position) is matched on its own */
+                size_t hc = mmo_find_duplicates(aid, adg, an, P->bins, P->n_targets, fd + overflow_hits,
+                                                found_cap - overflow_hits);
+                if (overflow_hits != 0) { /* second overflow onwards (:320-328) */
+                    overflow_hits = mmo_merge_keep_scored(fd, hc + overflow_hits, P->bins, P->n_targets);
+                    mmo_score_unscored(fd, overflow_hits, P, q, corr, qlen);
+                    overflow_hits = mmo_keep_max(fd, overflow_hits, P->bins, P->n_targets);
+                } else {
+                    overflow_hits = hc;
+                }
+                overflow_matches += an;
+                an = 0;
+                if (len >= max_db_matches) { /* :343 goto outer */
+                    aborted = 1;
+                    break;
+                }
             }
             if (an + len > acap) {
                 while (an + len > acap) acap *= 2;
@@ -533,7 +629,7 @@ int mmo_pf_match_query(const mmo_pf_params *P, const uint8_t *q, int qlen, const
             }
         }
     }
-    S.db_matches = an;
+    S.db_matches = overflow_matches + an;
     if (dump && dump->arr_id)
         for (size_t e = 0; e < an && e < dump->arr_cap; e++) {
             dump->arr_id[e] = aid[e];
@@ -541,19 +637,15 @@ int mmo_pf_match_query(const mmo_pf_params *P, const uint8_t *q, int qlen, const
         }
 
     {
-        /* ---- findDuplicates ---- */
-        mmo_cr *fd = (mmo_cr *)malloc((2 * (an + 1) + 16) * sizeof(mmo_cr));
-        size_t rs = an ? mmo_find_duplicates(aid, adg, an, P->bins, P->n_targets, fd, found_cap) : 0;
-        S.double_hits = rs;
-        /* ---- ungappedAlignment->align (:131): count = min(255, best ungapped score on the diagonal) ---- */
-        int8_t *corr = (int8_t *)malloc((size_t)qlen + 1);
-        mmo_pf_ungapped_corr(comp_bias, qlen, corr);
-        for (size_t z = 0; z < rs; z++) {
-            const uint8_t *t = P->tdata + P->toff[fd[z].id];
-            int tlen = (int)(P->toff[fd[z].id + 1] - P->toff[fd[z].id]);
-            int sc = mmo_diag_score(q, corr, qlen, P->ungapped_mat, alphabet, t, tlen, (int)(short)fd[z].diagonal);
-            fd[z].count = (uint8_t)(sc > 255 ? 255 : sc);
+        /* ---- last segment (:353-362): findDuplicates, and after an overflow the merge with the earlier hits ---- */
+        size_t rs = 0;
+        if (an > 0) {
+            rs = mmo_find_duplicates(aid, adg, an, P->bins, P->n_targets, fd + overflow_hits, found_cap - overflow_hits);
+            if (overflow_hits != 0) rs = mmo_merge_diag_dup(fd, overflow_hits + rs, P->bins, P->n_targets);
         }
+        S.double_hits = rs;
+        /* ---- ungappedAlignment->align (:131): count = min(255, best ungapped score), unscored elements only ---- */
+        mmo_score_unscored(fd, rs, P, q, corr, qlen);
         if (dump && dump->dd_id)
             for (size_t z = 0; z < rs && z < dump->dd_cap; z++) {
                 dump->dd_id[z] = fd[z].id;
@@ -659,11 +751,4 @@ int mmo_pf_match_query(const mmo_pf_params *P, const uint8_t *q, int qlen, const
     free(sim);
     if (st) *st = S;
     return 0;
-done_fail:
-    free(aid);
-    free(adg);
-    free(sim);
-    *n_hits = 0;
-    if (st) *st = S;
-    return 1;
 }
