@@ -149,6 +149,9 @@ struct PfDedupArgs {
     const uint8_t *t_res;
     const uint32_t *t_off4, *t_len;
     uint32_t min_diag_score;
+    // overflow emulation (null when the batch has no query on the overflow path)
+    const uint32_t *q_nseg;           // [nq] databaseHits flushes of the query (0 = ordinary query)
+    const uint32_t *seg_start;        // [nq][PF_MAX_SEG + 2] arrival index at which segment k starts
 };
 
 struct PfSelectArgs {
@@ -163,6 +166,44 @@ struct PfSelectArgs {
     uint32_t hit_stride;
     uint32_t *hit_count, *q_diag_thr;
 };
+
+constexpr int PF_MAX_SEG = 62;         // databaseHits flushes per query the device emulates (QueryMatcher.cpp:310-346)
+
+struct PfSegArgs {
+    const uint32_t *ovf_queries;      // queries that gather >= maxDbMatches entries
+    uint32_t n_ovf;
+    const uint32_t *q_off, *list_base, *pos_entry_base;
+    const PfList *lists;
+    uint64_t cap;                     // maxDbMatches
+    uint32_t *seg_start;              // [nq][PF_MAX_SEG + 2]
+    uint32_t *q_nseg;                 // [nq]; PF_MAX_SEG + 1 = more flushes than emulated
+    uint32_t *q_final;                // [nq] entries of the last segment
+    const uint32_t *q_entries;
+};
+
+struct PfOvfElem {                    // element of foundDiagonals on the overflow path
+    uint32_t id;
+    uint32_t score;                   // exact ungapped score, 0 = not scored yet (CounterResult::count == 0)
+    long long ord;                    // position key: order inside a CPU bin through the merges (reversal = negation)
+    uint16_t diag;
+    uint16_t pad0;
+    uint32_t pad1;
+};
+
+struct PfOvfArgs {
+    PfDedupArgs D;
+    const uint32_t *ovf_queries;
+    uint32_t n_ovf;
+    uint32_t step;                    // flush number 1..nseg, nseg + 1 = the final merge
+    const uint32_t *q_final;
+    const uint64_t *ovf_base;         // [n_ovf] first element of the query's region in buf_a / buf_b
+    PfOvfElem *buf_a, *buf_b;
+    uint32_t *o_count;                // [n_ovf * bins]
+    uint32_t *totals;                 // [n_ovf][PF_MAX_SEG + 2] overflowHitCount after flush k
+};
+
+hipError_t launch_pf_segments(const PfSegArgs &A, hipStream_t s);
+hipError_t launch_pf_overflow(const PfOvfArgs &A, hipStream_t s);
 
 constexpr int PF_MERGE_CAP = 8192;     // hits per query the split-merge kernel sorts in LDS
 

@@ -353,6 +353,7 @@ struct mmgpu_pf_batch_t {
     // device: working set (grow-only, reused across runs)
     DevBuf d_nsim, d_qtot, d_qbase, d_list_base, d_pos_entries, d_peb, d_qentries;
     DevBuf d_qtile_base, d_qntiles, d_bucket_count, d_bucket_off;
+    DevBuf d_ovf_queries, d_qnseg, d_seg_start, d_qfinal, d_ovf_base, d_ovf_a, d_ovf_b, d_ovf_ocount, d_ovf_totals;
     DevBuf d_cand_small, d_cand_base, d_cand_count, d_cells, d_surv_count, d_hits, d_hit_count, d_diag_thr;
     // host mirrors of the last run
     std::vector<uint64_t> q_lists, q_entries;
@@ -551,16 +552,65 @@ extern "C" int mmgpu_pf_run(mmgpu_ctx *c, mmgpu_pf_batch_t *b) {
     HIP_TRY(hipStreamSynchronize(s));   // qbase (pageable) has been consumed, q_entries is valid
     HIP_TRY(hipEventRecord(b->ev[1], s));
 
+    // ---- queries on the reference's overflow path (QueryMatcher.cpp:310-346): segment boundaries ----
+    std::vector<uint32_t> ovf_q;
+    for (uint32_t i = 0; i < nq; i++)
+        if (b->q_entries[i] >= b->max_db_matches) ovf_q.push_back(i);
+    std::vector<uint32_t> h_nseg(nq, 0);
+    uint32_t max_seg = 0;
+    if (!ovf_q.empty()) {
+        HIP_TRY(b->d_ovf_queries.reserve(ovf_q.size() * 4));
+        HIP_TRY(b->d_qnseg.reserve((size_t)nq * 4));
+        HIP_TRY(b->d_qfinal.reserve((size_t)nq * 4));
+        HIP_TRY(b->d_seg_start.reserve((size_t)nq * (PF_MAX_SEG + 2) * 4));
+        HIP_TRY(hipMemcpyAsync(b->d_ovf_queries.p, ovf_q.data(), ovf_q.size() * 4, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemsetAsync(b->d_qnseg.p, 0, (size_t)nq * 4, s));
+        HIP_TRY(hipMemsetAsync(b->d_qfinal.p, 0, (size_t)nq * 4, s));
+        std::vector<uint32_t> e32(nq);
+        for (uint32_t i = 0; i < nq; i++) e32[i] = (uint32_t)std::min<uint64_t>(b->q_entries[i], 0xFFFFFFFFull);
+        HIP_TRY(hipMemcpyAsync(b->d_qentries.p, e32.data(), (size_t)nq * 4, hipMemcpyHostToDevice, s));
+        PfSegArgs G;
+        G.ovf_queries = b->d_ovf_queries.as<uint32_t>();
+        G.n_ovf = (uint32_t)ovf_q.size();
+        G.q_off = b->d_qoff.as<uint32_t>();
+        G.list_base = b->d_list_base.as<uint32_t>();
+        G.pos_entry_base = b->d_peb.as<uint32_t>();
+        G.lists = P.w_lists.as<PfList>();
+        G.cap = b->max_db_matches;
+        G.seg_start = b->d_seg_start.as<uint32_t>();
+        G.q_nseg = b->d_qnseg.as<uint32_t>();
+        G.q_final = b->d_qfinal.as<uint32_t>();
+        G.q_entries = b->d_qentries.as<uint32_t>();
+        HIP_TRY(launch_pf_segments(G, s));
+        HIP_TRY(hipMemcpyAsync(h_nseg.data(), b->d_qnseg.p, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        bool rewrite = false;
+        std::vector<uint32_t> keep;
+        for (uint32_t i : ovf_q) {
+            if (h_nseg[i] == 0 || h_nseg[i] > (uint32_t)PF_MAX_SEG || b->q_entries[i] > 0xFFFFFFFFull) {
+                h_nseg[i] = 0;      // more flushes than the device emulates: the host runs the reference for this query
+                b->status[i] = MMGPU_PF_OVERFLOW;
+                rewrite = true;
+            } else {
+                keep.push_back(i);
+                max_seg = std::max(max_seg, h_nseg[i]);
+            }
+        }
+        ovf_q.swap(keep);
+        if (rewrite) {
+            HIP_TRY(hipMemcpyAsync(b->d_qnseg.p, h_nseg.data(), (size_t)nq * 4, hipMemcpyHostToDevice, s));
+            if (!ovf_q.empty()) HIP_TRY(hipMemcpyAsync(b->d_ovf_queries.p, ovf_q.data(), ovf_q.size() * 4, hipMemcpyHostToDevice, s));
+            HIP_TRY(hipStreamSynchronize(s));
+        }
+    }
+
     // ---- tiles ----
     std::vector<uint32_t> qent(nq), qtb(nq), qnt(nq), tile_q, tile_idx;
     std::vector<uint64_t> qebase(nq);
     uint64_t total_entries = 0;
     for (uint32_t i = 0; i < nq; i++) {
         uint64_t e = b->q_entries[i];
-        if (e >= b->max_db_matches) {   // QueryMatcher.cpp:310: the reference would take its overflow path
-            b->status[i] = MMGPU_PF_OVERFLOW;
-            e = 0;
-        }
+        if (b->status[i] == MMGPU_PF_OVERFLOW) e = 0;   // not processed on the device
         qent[i] = (uint32_t)e;
         qebase[i] = total_entries;
         total_entries += e;
@@ -643,8 +693,39 @@ extern "C" int mmgpu_pf_run(mmgpu_ctx *c, mmgpu_pf_batch_t *b) {
     D.min_diag_score = b->par.min_diag_score;
     D.cand_count = b->d_cand_count.as<uint32_t>();
     D.cand_small = b->d_cand_small.as<PfCand>();
+    D.q_nseg = ovf_q.empty() ? nullptr : b->d_qnseg.as<uint32_t>();
+    D.seg_start = ovf_q.empty() ? nullptr : b->d_seg_start.as<uint32_t>();
     D.cell_counter = b->d_cells.as<uint64_t>();
     HIP_TRY(launch_pf_dedup(D, b->ev[5], b->ev[6], s));
+    if (!ovf_q.empty()) {
+        // the flushes of the overflow path, one launch per flush (the total kept after flush k decides what flush k+1 does)
+        std::vector<uint64_t> obase(ovf_q.size());
+        uint64_t oe = 0;
+        for (size_t z = 0; z < ovf_q.size(); z++) { obase[z] = oe; oe += qent[ovf_q[z]]; }
+        HIP_TRY(b->d_ovf_base.reserve(obase.size() * 8));
+        HIP_TRY(b->d_ovf_a.reserve(std::max<uint64_t>(oe, 1) * sizeof(PfOvfElem)));
+        HIP_TRY(b->d_ovf_b.reserve(std::max<uint64_t>(oe, 1) * sizeof(PfOvfElem)));
+        HIP_TRY(b->d_ovf_ocount.reserve(ovf_q.size() * (size_t)B * 4));
+        HIP_TRY(b->d_ovf_totals.reserve(ovf_q.size() * (size_t)(PF_MAX_SEG + 2) * 4));
+        HIP_TRY(hipMemcpyAsync(b->d_ovf_base.p, obase.data(), obase.size() * 8, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemsetAsync(b->d_ovf_ocount.p, 0, ovf_q.size() * (size_t)B * 4, s));
+        HIP_TRY(hipMemsetAsync(b->d_ovf_totals.p, 0, ovf_q.size() * (size_t)(PF_MAX_SEG + 2) * 4, s));
+        PfOvfArgs O;
+        O.D = D;
+        O.ovf_queries = b->d_ovf_queries.as<uint32_t>();
+        O.n_ovf = (uint32_t)ovf_q.size();
+        O.q_final = b->d_qfinal.as<uint32_t>();
+        O.ovf_base = b->d_ovf_base.as<uint64_t>();
+        O.buf_a = b->d_ovf_a.as<PfOvfElem>();
+        O.buf_b = b->d_ovf_b.as<PfOvfElem>();
+        O.o_count = b->d_ovf_ocount.as<uint32_t>();
+        O.totals = b->d_ovf_totals.as<uint32_t>();
+        for (uint32_t step = 1; step <= max_seg + 1; step++) {
+            O.step = step;
+            HIP_TRY(launch_pf_overflow(O, s));
+        }
+        HIP_TRY(hipStreamSynchronize(s));   // obase is pageable
+    }
     HIP_TRY(hipEventRecord(b->ev[3], s));
 
     // ---- stage 3: top max_hits per query ----

@@ -712,6 +712,9 @@ __global__ __launch_bounds__(256) void pf_replay_kernel(PfDedupArgs A) {
 
     uint32_t ncand = 0;
     const uint64_t below = lanes_below(lane);
+    const uint32_t nseg = A.q_nseg ? A.q_nseg[q] : 0u;
+    const uint32_t *segs = A.seg_start ? A.seg_start + (size_t)q * (PF_MAX_SEG + 2) : nullptr;
+    uint32_t cur_seg = 0, next_boundary = nseg ? segs[1] : 0xFFFFFFFFu;
     for (uint32_t t0 = 0; t0 < ntiles; t0 += 64) {
         const uint32_t tl = t0 + (uint32_t)lane;
         uint32_t o0 = 0, n = 0;
@@ -749,63 +752,80 @@ __global__ __launch_bounds__(256) void pf_replay_kernel(PfDedupArgs A) {
             const uint32_t diag = (uint32_t)(e >> 32) & 0xFFFFu;
             const uint32_t d8 = diag & 0xFFu;
             const uint32_t key = id >> bshift;   // < PF_IDS_PER_BIN
-            const uint64_t same = match_lanes(key, 12, act);
-            uint32_t st = 0, em = 0;
-            if (act) {
-                st = S[key];
-                em = (E[key >> 5] >> (key & 31u)) & 1u;
-            }
-            // stage 1: does my diagonal byte equal the previous entry's of this target?
-            const uint64_t pm = same & below;
-            const int pl = pm ? highest_lane(pm) : lane;
-            const uint32_t d_pl = __shfl(d8, pl);
-            const uint32_t prevd = pm ? d_pl : (st & 0xFFu);
-            const bool flag = act && d8 == prevd;
-            // stage 2: run-length de-duplication over the flagged entries of this target
-            const uint64_t fl = __ballot(flag);
-            const uint64_t fm = same & fl;
-            const uint64_t fbelow = fm & below;
-            const int fpl = fbelow ? highest_lane(fbelow) : lane;
-            const uint32_t d_fpl = __shfl(d8, fpl);
-            bool keep;
-            if (fbelow) keep = flag && d_fpl != d8;
-            else keep = flag && (em == 0u || ((st >> 8) & 0xFFu) != d8);
-            // state update by the last lane of every target group
-            const int fhi = fm ? highest_lane(fm) : lane;
-            const uint32_t d_fhi = __shfl(d8, fhi);
-            if (act && (same & ~below & ~(1ull << lane)) == 0) {
-                uint32_t ns = d8;
-                if (fm) {
-                    ns |= d_fhi << 8;
-                    if (em == 0u) atomicOr(&E[key >> 5], 1u << (key & 31u));
-                } else {
-                    ns |= st & 0xFF00u;
+            const uint32_t arr = tile_cur * (uint32_t)PF_T + (uint32_t)(e >> 48);
+            // Overflow path (nseg > 0): the reference flushes databaseHits at segment boundaries and starts the
+            // double-diagonal state from scratch (QueryMatcher.cpp:310-346), so a round that straddles a boundary is
+            // processed in pieces with the tables cleared in between.
+            uint64_t todo = __ballot(act);
+            while (todo) {
+                const bool now = act && ((todo >> lane) & 1ull) && arr < next_boundary;
+                if (__ballot(now)) {
+                    const uint64_t same = match_lanes(key, 12, now);
+                    uint32_t st = 0, em = 0;
+                    if (now) {
+                        st = S[key];
+                        em = (E[key >> 5] >> (key & 31u)) & 1u;
+                    }
+                    // stage 1: does my diagonal byte equal the previous entry's of this target?
+                    const uint64_t pm = same & below;
+                    const int pl = pm ? highest_lane(pm) : lane;
+                    const uint32_t d_pl = __shfl(d8, pl);
+                    const uint32_t prevd = pm ? d_pl : (st & 0xFFu);
+                    const bool flag = now && d8 == prevd;
+                    // stage 2: run-length de-duplication over the flagged entries of this target
+                    const uint64_t fl = __ballot(flag);
+                    const uint64_t fm = same & fl;
+                    const uint64_t fbelow = fm & below;
+                    const int fpl = fbelow ? highest_lane(fbelow) : lane;
+                    const uint32_t d_fpl = __shfl(d8, fpl);
+                    bool keep;
+                    if (fbelow) keep = flag && d_fpl != d8;
+                    else keep = flag && (em == 0u || ((st >> 8) & 0xFFu) != d8);
+                    // state update by the last lane of every target group
+                    const int fhi = fm ? highest_lane(fm) : lane;
+                    const uint32_t d_fhi = __shfl(d8, fhi);
+                    if (now && (same & ~below & ~(1ull << lane)) == 0) {
+                        uint32_t ns = d8;
+                        if (fm) {
+                            ns |= d_fhi << 8;
+                            if (em == 0u) atomicOr(&E[key >> 5], 1u << (key & 31u));
+                        } else {
+                            ns |= st & 0xFF00u;
+                        }
+                        S[key] = (uint16_t)ns;
+                    }
+                    const uint64_t kb = __ballot(keep);
+                    if (keep) {
+                        PfCand c;
+                        c.id = id;
+                        c.arr = arr;
+                        c.score = 0;
+                        c.diag = (uint16_t)diag;
+                        c.pad = (uint16_t)cur_seg;
+                        const uint32_t ck = ncand + (uint32_t)__popcll(kb & below);
+                        *cand_slot(A, bucket, ck) = c;
+                        if (ck < 64) {
+                            s_cand[wave][0][ck] = c.id;
+                            s_cand[wave][1][ck] = c.arr;
+                            s_cand[wave][2][ck] = diag;
+                        }
+                    }
+                    ncand += (uint32_t)__popcll(kb);
                 }
-                S[key] = (uint16_t)ns;
-            }
-            const uint64_t kb = __ballot(keep);
-            if (keep) {
-                PfCand c;
-                c.id = id;
-                c.arr = tile_cur * (uint32_t)PF_T + (uint32_t)(e >> 48);
-                c.score = 0;
-                c.diag = (uint16_t)diag;
-                c.pad = 0;
-                const uint32_t ck = ncand + (uint32_t)__popcll(kb & below);
-                *cand_slot(A, bucket, ck) = c;
-                if (ck < 64) {
-                    s_cand[wave][0][ck] = c.id;
-                    s_cand[wave][1][ck] = c.arr;
-                    s_cand[wave][2][ck] = diag;
+                todo &= ~__ballot(now);
+                if (todo) {   // the remaining entries belong to the next segment: fresh state
+                    for (int k = lane; k < PF_IDS_PER_BIN; k += 64) S[k] = 0;
+                    for (int k = lane; k < PF_IDS_PER_BIN / 32; k += 64) E[k] = 0;
+                    cur_seg++;
+                    next_boundary = cur_seg + 1 <= nseg ? segs[cur_seg + 1] : 0xFFFFFFFFu;
                 }
             }
-            ncand += (uint32_t)__popcll(kb);
         }
     }
     if (lane == 0) A.cand_count[bucket] = ncand;
     // a8 + keepMaxElement for the common case of at most 64 candidates, straight from LDS (no second kernel's
     // count -> record -> metadata round trips); larger buckets are left to pf_ungapped_kernel / pf_keepmax_kernel
-    if (ncand > 0 && ncand <= 64) {
+    if (ncand > 0 && ncand <= 64 && nseg == 0) {
         PfCand c;
         c.id = 0; c.arr = 0; c.score = 0; c.diag = 0; c.pad = 0;
         if ((uint32_t)lane < ncand) {
@@ -832,8 +852,8 @@ __global__ __launch_bounds__(256) void pf_ungapped_kernel(PfDedupArgs A) {
     const uint64_t bucket = (uint64_t)blockIdx.x * 4u + (uint32_t)wave;
     if (bucket >= (uint64_t)A.n_queries * B) return;
     const uint32_t ncand = A.cand_count[bucket];
-    if (ncand <= 64) return;
     const uint32_t q = (uint32_t)(bucket / B);
+    if (ncand <= 64 || (A.q_nseg && A.q_nseg[q])) return;   // small bins are done; overflow queries have their own path
     int bshift = 0;
     while ((1u << bshift) < B) bshift++;
     uint64_t cells = 0;
@@ -861,8 +881,8 @@ __global__ __launch_bounds__(256) void pf_keepmax_kernel(PfDedupArgs A) {
     const uint64_t bucket = (uint64_t)blockIdx.x * 4u + (uint32_t)wave;
     if (bucket >= (uint64_t)A.n_queries * B) return;
     const uint32_t ncand = A.cand_count[bucket];
-    if (ncand <= 64) return;   // scored and reduced by pf_ungapped_kernel already
     const uint32_t q = (uint32_t)(bucket / B);
+    if (ncand <= 64 || (A.q_nseg && A.q_nseg[q])) return;   // scored and reduced already / overflow path
     uint32_t *S = s_tab[wave];
     int bshift = 0;
     while ((1u << bshift) < B) bshift++;
@@ -894,6 +914,292 @@ __global__ __launch_bounds__(256) void pf_keepmax_kernel(PfDedupArgs A) {
             if (lane == 0) base = atomicAdd(&A.surv_count[q], (uint32_t)__popcll(wb));
             base = __shfl(base, 0);
             if (win) surv[base + (uint32_t)__popcll(wb & lanes_below(lane))] = c;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Overflow path of QueryMatcher::match (QueryMatcher.cpp:310-346): a query whose index lists hold >= maxDbMatches
+// entries is processed by the reference in SEGMENTS - whenever the next list would not fit, everything gathered so
+// far goes through findDuplicates on its own, the buffer is emptied and gathering continues.
+// pf_segments_kernel finds the segment boundaries (arrival indices) of such a query: one wavefront per query,
+// 64-ary search over its list records for the first list with start + len >= segment start + cap.
+__global__ __launch_bounds__(64) void pf_segments_kernel(PfSegArgs A) {
+    const uint32_t q = A.ovf_queries[blockIdx.x];
+    const int lane = lane_id();
+    const uint32_t qp0 = A.q_off[q], qp1 = A.q_off[q + 1];
+    const uint32_t l0 = A.list_base[qp0], l1 = A.list_base[qp1];   // this query's list records
+    const uint32_t total = A.q_entries[q];
+    uint32_t *seg = A.seg_start + (size_t)q * (PF_MAX_SEG + 2);
+    uint32_t nseg = 0, seg_begin = 0, lcur = l0;
+    if (lane == 0) seg[0] = 0;
+    while (true) {
+        const uint64_t limit = (uint64_t)seg_begin + A.cap;   // first list with start + len >= limit opens a new segment
+        if ((uint64_t)total < limit) break;                   // (start + len <= total for every list)
+        // lists [lcur, l1): value(l) = start(l) + len(l) is non-decreasing; find the first l with value >= limit
+        uint32_t lo = lcur, hi = l1;                          // answer in [lo, hi]; hi == l1 means none
+        while (lo < hi) {
+            const uint32_t span = hi - lo;
+            const uint32_t step = (span + 63u) / 64u;
+            const uint32_t idx = lo + (uint32_t)lane * step;
+            bool ge = true;                                   // beyond the range counts as "satisfies"
+            if (idx < hi) {
+                const PfList r = A.lists[idx];
+                ge = (uint64_t)A.pos_entry_base[r.pos] + r.lprefix + r.len >= limit;
+            }
+            const uint64_t m = __ballot(ge);                  // a suffix of the lanes
+            const uint32_t first = m ? (uint32_t)(__ffsll((long long)m) - 1) : 64u;
+            // the answer lies in (lo + (first-1)*step, lo + first*step]
+            const uint32_t nhi = min(hi, lo + first * step);
+            const uint32_t nlo = first == 0 ? lo : min(hi, lo + (first - 1u) * step + 1u);
+            lo = nlo;
+            hi = nhi;
+            if (step == 1) { lo = hi = nhi; }
+        }
+        if (lo >= l1) break;
+        const PfList r = A.lists[lo];
+        const uint32_t start = A.pos_entry_base[r.pos] + r.lprefix;
+        if (nseg >= (uint32_t)PF_MAX_SEG) { nseg = PF_MAX_SEG + 1; break; }
+        nseg++;
+        if (lane == 0) seg[nseg] = start;
+        seg_begin = start;
+        lcur = lo;
+    }
+    if (lane == 0) {
+        A.q_nseg[q] = nseg;
+        A.q_final[q] = total - seg_begin;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// One flush / the final merge of the overflow path for every (overflow query, bin): a single wavefront keeps the
+// reference's foundDiagonals semantics for its bin.  All operations of the reference (mergeDiagonalKeepScoredHits-
+// Duplicates, mergeDiagonalDuplicates, keepMaxElement, CacheFriendlyOperations.cpp:83-148,354-384) act per target on
+// the elements in array order, and a target lives in exactly one bin, so a bin can be processed on its own; the
+// position of an element inside the CPU's array (needed only to break score ties at the --max-seqs cut) is carried as
+// a key `ord` for which appending = larger key and the reversal done by the keep-scored merge = negation.
+__device__ __forceinline__ PfOvfElem ovf_from_cand(const PfCand &c, uint32_t step) {
+    PfOvfElem e;
+    e.id = c.id;
+    e.score = 0;
+    e.ord = ((long long)step << 33) + (long long)c.arr;   // |ord| < 2^39 for PF_MAX_SEG + 1 <= 63 steps
+    e.diag = c.diag;
+    e.pad0 = 0;
+    e.pad1 = 0;
+    return e;
+}
+
+__global__ __launch_bounds__(256) void pf_overflow_kernel(PfOvfArgs A) {
+    __shared__ uint32_t s_tab[4][PF_IDS_PER_BIN];
+    __shared__ int8_t smat[32 * 32];
+    const PfDedupArgs &D = A.D;
+    const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
+    for (int k = (int)threadIdx.x; k < 32 * 32; k += 256) smat[k] = k < D.alphabet * D.alphabet ? D.mat[k] : (int8_t)0;
+    __syncthreads();
+    const uint32_t B = D.bins;
+    const uint64_t w = (uint64_t)blockIdx.x * 4u + (uint32_t)wave;
+    if (w >= (uint64_t)A.n_ovf * B) return;
+    const uint32_t qi = (uint32_t)(w / B), bin = (uint32_t)(w % B);
+    const uint32_t q = A.ovf_queries[qi];
+    const uint32_t ns = D.q_nseg[q];
+    const uint32_t step = A.step;
+    if (ns > (uint32_t)PF_MAX_SEG || step > ns + 1) return;
+    const bool final_step = step == ns + 1;
+    if (final_step && A.q_final[q] == 0) return;      // numMatches == 0 after the last flush: hitCount stays 0 (:353-362)
+    const uint64_t bucket = (uint64_t)q * B + bin;
+    const uint32_t ncand = D.cand_count[bucket];
+    uint32_t *tab = s_tab[wave];
+    int bshift = 0;
+    while ((1u << bshift) < B) bshift++;
+    const uint64_t below = lanes_below(lane);
+    const uint64_t base = A.ovf_base[qi] + (uint64_t)(D.cand_base[bucket] - D.cand_base[(uint64_t)q * B]);
+    PfOvfElem *O = A.buf_a + base, *S = A.buf_b + base;
+    uint32_t nO = A.o_count[(size_t)qi * B + bin];
+    uint32_t *totals = A.totals + (size_t)qi * (PF_MAX_SEG + 2);
+
+    // candidates of segment step-1 of this bin: a contiguous run of the bin's candidate list (tags are sorted)
+    uint32_t c_lo = 0, c_hi = 0;
+    for (uint32_t c0 = 0; c0 < ncand; c0 += 64) {
+        const uint32_t ci = c0 + (uint32_t)lane;
+        uint32_t tag = 0xFFFFu;
+        if (ci < ncand) tag = cand_slot(D, bucket, ci)->pad;
+        c_lo += (uint32_t)__popcll(__ballot(ci < ncand && tag < step - 1));
+        c_hi += (uint32_t)__popcll(__ballot(ci < ncand && tag <= step - 1));
+    }
+    const uint32_t nC = c_hi - c_lo;
+    const uint32_t prev_total = step > 1 ? totals[step - 1] : 0u;
+    // append the segment's candidates behind O (unscored)
+    for (uint32_t c0 = 0; c0 < nC; c0 += 64) {
+        const uint32_t k = c0 + (uint32_t)lane;
+        if (k < nC) O[nO + k] = ovf_from_cand(*cand_slot(D, bucket, c_lo + k), step);
+    }
+    uint32_t n = nO + nC;
+    __threadfence();
+    const bool do_merge = final_step ? prev_total != 0 : (step > 1 && prev_total != 0);
+    PfOvfElem *cur = O;
+    if (do_merge && !final_step) {
+        // mergeDiagonalKeepScoredHitsDuplicates: diag + 1 written forwards, then walked backwards
+        for (uint32_t r0 = 0; r0 < n; r0 += 64) {
+            const uint32_t idx = r0 + (uint32_t)lane;
+            const bool act = idx < n;
+            uint32_t id = 0, d8 = 0;
+            if (act) { id = O[idx].id; d8 = O[idx].diag & 0xFFu; }
+            const uint32_t key = id >> bshift;
+            const uint64_t same = match_lanes(key, 12, act);
+            if (act && (same & ~below & ~(1ull << lane)) == 0) tab[key] = (d8 + 1u) & 0xFFu;
+        }
+        uint32_t m = 0;
+        for (uint32_t r0 = 0; r0 < n; r0 += 64) {
+            const bool act = r0 + (uint32_t)lane < n;
+            const uint32_t idx = act ? n - 1u - (r0 + (uint32_t)lane) : 0u;
+            PfOvfElem e;
+            e.id = 0; e.score = 0; e.ord = 0; e.diag = 0; e.pad0 = 0; e.pad1 = 0;
+            if (act) e = O[idx];
+            const uint32_t d8 = e.diag & 0xFFu, key = e.id >> bshift;
+            const uint64_t same = match_lanes(key, 12, act);
+            const uint64_t pm = same & below;
+            const int pl = pm ? highest_lane(pm) : lane;
+            const uint32_t d_pl = __shfl(d8, pl);
+            uint32_t prev = 0;
+            if (act) prev = pm ? d_pl : tab[key];
+            const bool keep = act && (e.score != 0 || prev != d8);
+            if (act && (same & ~below & ~(1ull << lane)) == 0) tab[key] = d8;
+            const uint64_t kb = __ballot(keep);
+            if (keep) {
+                e.ord = -e.ord;
+                S[m + (uint32_t)__popcll(kb & below)] = e;
+            }
+            m += (uint32_t)__popcll(kb);
+        }
+        n = m;
+        cur = S;
+    } else if (do_merge && final_step) {
+        // mergeDiagonalDuplicates: diag + 1 written backwards (the first element of a target wins), walked forwards
+        for (uint32_t r0 = 0; r0 < n; r0 += 64) {
+            const bool act = r0 + (uint32_t)lane < n;
+            const uint32_t idx = act ? n - 1u - (r0 + (uint32_t)lane) : 0u;
+            uint32_t id = 0, d8 = 0;
+            if (act) { id = O[idx].id; d8 = O[idx].diag & 0xFFu; }
+            const uint32_t key = id >> bshift;
+            const uint64_t same = match_lanes(key, 12, act);
+            if (act && (same & ~below & ~(1ull << lane)) == 0) tab[key] = (d8 + 1u) & 0xFFu;
+        }
+        uint32_t m = 0;
+        for (uint32_t r0 = 0; r0 < n; r0 += 64) {
+            const uint32_t idx = r0 + (uint32_t)lane;
+            const bool act = idx < n;
+            PfOvfElem e;
+            e.id = 0; e.score = 0; e.ord = 0; e.diag = 0; e.pad0 = 0; e.pad1 = 0;
+            if (act) e = O[idx];
+            const uint32_t d8 = e.diag & 0xFFu, key = e.id >> bshift;
+            const uint64_t same = match_lanes(key, 12, act);
+            const uint64_t pm = same & below;
+            const int pl = pm ? highest_lane(pm) : lane;
+            const uint32_t d_pl = __shfl(d8, pl);
+            uint32_t prev = 0;
+            if (act) prev = pm ? d_pl : tab[key];
+            const bool keep = act && prev != d8;
+            if (act && (same & ~below & ~(1ull << lane)) == 0) tab[key] = d8;
+            const uint64_t kb = __ballot(keep);
+            if (keep) S[m + (uint32_t)__popcll(kb & below)] = e;
+            m += (uint32_t)__popcll(kb);
+        }
+        n = m;
+        cur = S;
+    }
+    __threadfence();
+    const bool do_score = final_step || (step > 1 && prev_total != 0);
+    if (!do_score) {   // first flush (or nothing kept so far): the candidates simply become foundDiagonals (:329-331)
+        if (lane == 0) {
+            A.o_count[(size_t)qi * B + bin] = n;
+            if (n) atomicAdd(&totals[step], n);
+        }
+        return;
+    }
+    // UngappedAlignment::align: elements without a score only (computeScores, UngappedAlignment.cpp:322-324)
+    const uint32_t qp0 = D.q_off[q];
+    const int qlen = (int)(D.q_off[q + 1] - qp0);
+    const uint8_t *qr = D.q_res + qp0;
+    const int8_t *qc = D.q_corr + qp0;
+    for (uint32_t r0 = 0; r0 < n; r0 += 64) {
+        const uint32_t idx = r0 + (uint32_t)lane;
+        if (idx < n && cur[idx].score == 0) {
+            const uint32_t id = cur[idx].id;
+            const int d = (int)(short)cur[idx].diag;
+            const int tlen = (int)D.t_len[id];
+            const uint8_t *t = D.t_res + (size_t)D.t_off4[id] * 4;
+            const int mind = d < 0 ? -d : d;
+            int len = 0, qs = 0, ts = 0;
+            if (d >= 0 && mind < qlen) { len = min(tlen, qlen - mind); qs = mind; }
+            else if (d < 0 && mind < tlen) { len = min(tlen - mind, qlen); ts = mind; }
+            int sc = 0, mx = 0;
+            for (int p = 0; p < len; p++) {
+                const int x = (int)(int8_t)(smat[((int)qr[qs + p] * D.alphabet + (int)t[ts + p]) & 1023] + qc[qs + p]);
+                sc += x;
+                sc = sc < 0 ? 0 : sc;
+                mx = sc > mx ? sc : mx;
+            }
+            cur[idx].score = (uint32_t)mx;
+        }
+    }
+    __threadfence();
+    // keepMaxElement: per target the first element holding the maximum count, plus every zero-count element after it
+    for (int k = lane; k < PF_IDS_PER_BIN; k += 64) tab[k] = 0;
+    for (uint32_t r0 = 0; r0 < n; r0 += 64) {
+        const uint32_t idx = r0 + (uint32_t)lane;
+        if (idx < n) {
+            const uint32_t cnt = min(255u, cur[idx].score);
+            atomicMax(&tab[cur[idx].id >> bshift], (cnt << 24) | (0xFFFFFFu - min(idx, 0xFFFFFEu)));
+        }
+    }
+    PfOvfElem *dst = cur == O ? S : O;
+    uint32_t m = 0;
+    PfCand *surv = D.surv + D.cand_base[(uint64_t)q * B];
+    for (uint32_t r0 = 0; r0 < n; r0 += 64) {
+        const uint32_t idx = r0 + (uint32_t)lane;
+        bool keep = false;
+        PfOvfElem e;
+        e.id = 0; e.score = 0; e.ord = 0; e.diag = 0; e.pad0 = 0; e.pad1 = 0;
+        if (idx < n) {
+            e = cur[idx];
+            const uint32_t cnt = min(255u, e.score);
+            const uint32_t first = 0xFFFFFFu - (tab[e.id >> bshift] & 0xFFFFFFu);
+            keep = idx == first || (cnt == 0 && idx > first);
+            if (final_step) keep = keep && cnt >= D.min_diag_score;
+        }
+        const uint64_t kb = __ballot(keep);
+        if (final_step) {
+            if (kb) {
+                uint32_t sb = 0;
+                if (lane == 0) sb = atomicAdd(&D.surv_count[q], (uint32_t)__popcll(kb));
+                sb = __shfl(sb, 0);
+                if (keep) {
+                    const unsigned long long o45 = (unsigned long long)(e.ord + (1ll << 40));   // in (0, 2^41)
+                    PfCand c;
+                    c.id = e.id;
+                    c.arr = (uint32_t)o45;
+                    c.score = e.score;
+                    c.diag = e.diag;
+                    c.pad = (uint16_t)(o45 >> 32);
+                    surv[sb + (uint32_t)__popcll(kb & below)] = c;
+                }
+            }
+        } else if (keep) {
+            dst[m + (uint32_t)__popcll(kb & below)] = e;
+        }
+        m += (uint32_t)__popcll(kb);
+    }
+    if (!final_step) {
+        __threadfence();
+        if (dst != O) {   // foundDiagonals lives in buf_a between launches
+            for (uint32_t r0 = 0; r0 < m; r0 += 64) {
+                const uint32_t idx = r0 + (uint32_t)lane;
+                if (idx < m) O[idx] = dst[idx];
+            }
+        }
+        if (lane == 0) {
+            A.o_count[(size_t)qi * B + bin] = m;
+            if (m) atomicAdd(&totals[step], m);
         }
     }
 }
@@ -949,7 +1255,7 @@ __global__ __launch_bounds__(256) void pf_select_kernel(PfSelectArgs A) {
     const float fms = (float)ms;
     const uint32_t refmask = A.ref_bins - 1;
 
-    // sort key of an element: (255 - count) : bin of the reference's CacheFriendlyOperations : arrival index
+    // sort key of an element: (255 - count) : bin of the reference's CacheFriendlyOperations (11 bits) : order key (45 bits)
     auto key_of = [&](const PfCand &c, bool *elig) -> uint64_t {
         const uint32_t cnt = min(255u, c.score);
         uint32_t kc;
@@ -960,7 +1266,9 @@ __global__ __launch_bounds__(256) void pf_select_kernel(PfSelectArgs A) {
             *elig = cnt >= dthr && c.id != ident;
             kc = cnt;
         }
-        return ((uint64_t)(255u - kc) << 43) | ((uint64_t)(c.id & refmask) << 32) | (uint64_t)c.arr;
+        // order inside the CPU's array: arrival index (ordinary queries) or the 48-bit merge key of the overflow path
+        const uint64_t ord = ((uint64_t)c.pad << 32) | (uint64_t)c.arr;
+        return ((uint64_t)(255u - kc) << 56) | ((uint64_t)(c.id & refmask) << 45) | (ord & ((1ull << 45) - 1));
     };
 
     uint32_t mine = 0;
@@ -984,7 +1292,7 @@ __global__ __launch_bounds__(256) void pf_select_kernel(PfSelectArgs A) {
             sh_remaining = want;
         }
         __syncthreads();
-        for (int shift = 48; shift >= 0; shift -= 8) {
+        for (int shift = 56; shift >= 0; shift -= 8) {
             for (int k = (int)threadIdx.x; k < 256; k += 256) hist[k] = 0;
             __syncthreads();
             const uint64_t prefix = sh_prefix, mask = sh_mask;
@@ -1187,6 +1495,19 @@ hipError_t launch_pf_dedup(const PfDedupArgs &A, hipEvent_t after_replay, hipEve
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (after_ungapped && (e = hipEventRecord(after_ungapped, s)) != hipSuccess) return e;
     hipLaunchKernelGGL(pf_keepmax_kernel, grid, block, 0, s, A);
+    return hipGetLastError();
+}
+
+hipError_t launch_pf_segments(const PfSegArgs &A, hipStream_t s) {
+    if (A.n_ovf == 0) return hipSuccess;
+    hipLaunchKernelGGL(pf_segments_kernel, dim3(A.n_ovf), dim3(64), 0, s, A);
+    return hipGetLastError();
+}
+
+hipError_t launch_pf_overflow(const PfOvfArgs &A, hipStream_t s) {
+    const uint64_t waves = (uint64_t)A.n_ovf * A.D.bins;
+    if (waves == 0) return hipSuccess;
+    hipLaunchKernelGGL(pf_overflow_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, A);
     return hipGetLastError();
 }
 

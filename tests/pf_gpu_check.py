@@ -41,11 +41,8 @@ def check(gpu, orc, queries, max_hits, ref_bins, min_diag_score=15, stages=True,
     for qi, qd in enumerate(queries):
         o = orc.match(qd["q"], qd.get("comp_bias"), ref_bins, max_hits=max_hits, min_diag_score=min_diag_score,
                       identity_id=qd.get("identity_id"), dump=stages)
-        if o["stats"]["overflow"]:
-            if status[qi] != 1:
-                ok = False
-                rep.append("q%d: oracle overflow but device status %d" % (qi, status[qi]))
-            continue
+        if status[qi] == 1 and o["stats"]["overflow"] > 62:
+            continue          # more flushes than the device emulates: handed back to the host, by contract
         if status[qi] != 0:
             ok = False
             rep.append("q%d: device status %d" % (qi, status[qi]))

@@ -195,3 +195,42 @@ def test_prefilter_k7(gpu):
     assert ok, "\n".join(rep)
     thr = int(g["kmer_thr"])
     chk.load_case(gpu, g, g["tres"], g["toff"], thr)
+
+
+def _long_query(rng, tl, ql, homolog_frac):
+    parts = []
+    while sum(len(p) for p in parts) < ql:
+        r = rng.random()
+        if r < homolog_frac:
+            parts.append(wl.mutate(rng, tl[int(rng.integers(0, len(tl)))], 0.7))
+        elif r < 0.8:
+            parts.append(rng.choice(20, size=200, p=wl.BACKGROUND).astype(np.uint8))
+        else:
+            parts.append(np.tile(rng.integers(0, 20, 3).astype(np.uint8), 30))
+    return np.concatenate(parts)[:ql]
+
+
+@pytest.mark.parametrize("nt,ql,frac", [(60000, 30000, 0.5), (100000, 31000, 0.02), (200000, 31000, 0.5)])
+def test_prefilter_overflow_path(gpu, nt, ql, frac):
+    """Queries that gather >= 2*max(1e6, dbSize) index entries: the reference flushes its databaseHits buffer and merges
+    the segments (QueryMatcher.cpp:310-346; 1, 2 and 5 flushes here, saturated and low-score cuts, several CPU bin
+    counts).  Device emulation against the oracle (pinned against the real reference for exactly these shapes)."""
+    from oracle.pyoracle import Oracle
+    g = pc.golden()
+    rng = np.random.default_rng(5)
+    (qres, qoff), (tres, toff) = wl.config2_align_only(4, nt, 0.2, seed=9)
+    thr = int(g["kmer_thr"])
+    orc = pc.pf_oracle()
+    orc.build_index(tres, toff, thr)
+    chk.load_case(gpu, g, tres, toff, thr)
+    swo = Oracle()
+    tl = wl.split(tres, toff)
+    qs = []
+    for q in (_long_query(rng, tl, ql, frac), wl.split(qres, qoff)[0], _long_query(rng, tl, ql - 777, frac)):
+        qs.append(dict(q=q, comp_bias=swo.comp_bias(g["vtml80_kmer16"], g["vtml80_pback"], q), identity_id=None))
+    for mh, rb, st in ((300, 2, True), (50, 16, False), (300, 128, False)):
+        ok, rep = chk.check(gpu, orc, qs, mh, rb, stages=st, label="overflow/%d/%d/%d" % (nt, mh, rb))
+        assert ok, "\n".join(rep)
+        assert any("status" not in r for r in rep)
+    orc.build_index(g["tres"], g["toff"], thr)
+    chk.load_case(gpu, g, g["tres"], g["toff"], thr)
