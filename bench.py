@@ -293,7 +293,7 @@ def search_section(args, gpu, torch, dist, rank, world, matrices, barrier):
             "prefilter_s": round(t_pf, 4), "align_s": round(t_sw, 4), "handoff_s": round(t_handoff, 2),
             "targets_total": nt * world, "n_gpus": world,
             "stage_ms": {"kmers_lists": round(stage[0], 2), "gather_split": round(stage[1], 2), "replay_score_keepmax": round(stage[2], 2),
-                         "large_bins_score": round(stage[3], 2), "large_bins_keepmax": round(stage[4], 2),
+                         "large_bins_score": round(stage[3], 2), "large_bins_keepmax_and_overflow_path": round(stage[4], 2),
                          "select": round(stage[5], 2),
                          "total_rank0": round(stage[6], 2)},
             "db_matches": int(ent), "similar_kmers": int(sim), "double_diagonal_candidates": int(cands),

@@ -217,9 +217,9 @@ typedef struct {
 } mmgpu_pf_hit;
 
 #define MMGPU_PF_OK 0
-#define MMGPU_PF_OVERFLOW 1 /* the query gathers >= 2*max(1e6,dbSize) index entries: the reference takes its
-                               buffer-overflow path (QueryMatcher.cpp:310-346); not computed here, the host must
-                               run QueryMatcher::matchQuery for this query */
+#define MMGPU_PF_OVERFLOW 1 /* the query needs more than 62 flushes of the reference's databaseHits buffer
+                               (QueryMatcher.cpp:310-346; up to 62 are emulated on the device): not computed here,
+                               the host must run QueryMatcher::matchQuery for this query */
 
 typedef struct {
     uint64_t db_matches;     /* statistics_t::dbMatches */
