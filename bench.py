@@ -41,7 +41,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 VALU_LANE_OPS_PER_S = 256 * 4 * 16 * 2.4e9
 
 
-def cpu_baseline(matrices, qs, cbs, tres, toff, budget_s=15.0):
+def cpu_baseline(matrices, qs, cbs, tres, toff, budget_s=15.0, gpu_res=None):
     """Reported (not optimised-against) CPU baseline on the GPU box's host cores, bounded sample.
     kind "reference": the real AVX2 striped Smith-Waterman of the reference (oracle/_ref/libmmref.so, uint8 pass
     + int16 re-run), one SmithWaterman object per thread as Alignment::run does (Alignment.cpp:279-295).
@@ -66,6 +66,8 @@ def cpu_baseline(matrices, qs, cbs, tres, toff, budget_s=15.0):
     qlens = np.array([len(q) for q in qs], np.float64)
     items = [(qi, ci) for qi in range(len(qs)) for ci in range(len(chunks))]
 
+    mism = [0, 0]   # pairs compared with the device results, pairs that differ (score, q_end, t_end)
+
     def run_items(sub):
         work = list(sub)
         lock = threading.Lock()
@@ -81,9 +83,18 @@ def cpu_baseline(matrices, qs, cbs, tres, toff, budget_s=15.0):
                     ctx.sw_set_query(qs[qi])   # ssw_init recomputes the composition bias itself
                     last_q = qi
                 if use_ref:
-                    ctx.sw_batch_score(tres, toff, chunks[ci])
+                    sc, qe, te = ctx.sw_batch_score(tres, toff, chunks[ci])
                 else:
-                    ctx.sw_batch_score(qs[qi], cbs[qi], tres, toff, chunks[ci], mat, 11, 1)
+                    sc, qe, te, _ = ctx.sw_batch_score(qs[qi], cbs[qi], tres, toff, chunks[ci], mat, 11, 1)
+                if gpu_res is not None:
+                    g = gpu_res[qi, chunks[ci]]
+                    # the reference's uint8 pass leaves q_end undefined (0) when the score is 0
+                    pos = sc > 0
+                    bad = int(np.count_nonzero(g["score"] != sc)) + int(np.count_nonzero((g["t_end"] != te) & pos)) \
+                        + int(np.count_nonzero((g["q_end"] != qe) & pos))
+                    with lock:
+                        mism[0] += len(sc)
+                        mism[1] += bad
 
         th = [threading.Thread(target=worker, args=(ctxs[i],)) for i in range(cores)]
         t0 = time.time()
@@ -101,7 +112,10 @@ def cpu_baseline(matrices, qs, cbs, tres, toff, budget_s=15.0):
     sample = items[len(cal):len(cal) + n_items]
     dt, cells = run_items(sample)
     nq = len(set(qi for qi, _ in sample))
-    return {"value": round(cells / dt / 1e9, 3), "unit": "GCUPS", "cores": cores,
+    parity = None
+    if gpu_res is not None:
+        parity = {"pairs_compared": mism[0], "field_mismatches": mism[1], "fields": "score, q_end, t_end"}
+    return {"value": round(cells / dt / 1e9, 3), "unit": "GCUPS", "cores": cores, "parity_vs_baseline": parity,
             "kind": "reference" if use_ref else "port",
             "sample": "%d (query, %d-target chunk) items over %d queries of the same workload (%.3g cells), "
                       "%.1f s wall, %d threads" % (len(sample), chunk, nq, cells, dt, cores)}
@@ -137,9 +151,11 @@ def pmc_traffic(kernel):
     return {"bytes_per_launch": round(tot), "source": "profiles/r01_prefilter_config3_pmc_*_size.txt (FETCH_SIZE + WRITE_SIZE, KB)"}
 
 
-def search_cpu_baseline(matrices, qres, qoff, tres, toff, kmer_thr, budget_s):
+def search_cpu_baseline(matrices, qres, qoff, tres, toff, kmer_thr, budget_s, gpu_lists=None):
     """The reference's own prefilter query loop (QueryMatcher::matchQuery per OpenMP thread, Prefiltering.cpp:820-917)
-    from oracle/_ref/libmmref.so on the host cores, bounded sample of the same queries against the same targets."""
+    from oracle/_ref/libmmref.so on the host cores, bounded sample of the same queries against the same targets.
+    The lists it produces are also the checker of the device lists at full size (gpu_lists = per-query
+    (ids, scores, diagonals) of the timed run): bit-identical or counted as a mismatch."""
     from oracle import pyoracle
     if not pyoracle.ref_available():
         return None
@@ -153,11 +169,23 @@ def search_cpu_baseline(matrices, qres, qoff, tres, toff, kmer_thr, budget_s):
     sec, hits, dbm, _ = ref.match_batch(qres[:int(qoff[n_cal])], qoff[:n_cal + 1], cores)
     rate = n_cal / max(sec, 1e-3)
     n = int(min(nq, max(n_cal, rate * budget_s)))
-    sec, hits, dbm, _ = ref.match_batch(qres[:int(qoff[n])], qoff[:n + 1], cores)
-    return {"value": round(n / sec, 1), "unit": "queries/s (prefilter only)", "cores": cores, "kind": "reference",
-            "sample": "first %d of the %d queries against the same %d targets, %.1f s wall, %d threads; reference index build "
-                      "%.1f s (not counted)" % (n, nq, len(toff) - 1, sec, cores, t_index),
-            "db_matches_per_query": round(dbm / n), "hits_per_query": round(hits / n, 1)}
+    sec, hits, dbm, counts, lists = ref.match_batch(qres[:int(qoff[n])], qoff[:n + 1], cores, want_lists=True)
+    out = {"value": round(n / sec, 1), "unit": "queries/s (prefilter only)", "cores": cores, "kind": "reference",
+           "sample": "first %d of the %d queries against the same %d targets, %.1f s wall, %d threads; reference index build "
+                     "%.1f s (not counted)" % (n, nq, len(toff) - 1, sec, cores, t_index),
+           "db_matches_per_query": round(dbm / n), "hits_per_query": round(hits / n, 1)}
+    if gpu_lists is not None:
+        bad = 0
+        for qi in range(n):
+            gi, gs, gd = gpu_lists[qi]
+            c = int(counts[qi])
+            same = (len(gi) == c and np.array_equal(gi, lists["ids"][qi, :c]) and np.array_equal(gs, lists["scores"][qi, :c])
+                    and np.array_equal(gd, lists["diags"][qi, :c]))
+            bad += not same
+        out["parity_vs_reference"] = {"queries_compared": n, "queries_with_different_hit_lists": int(bad),
+                                      "reference_cache_bins": int(lists["bins"]),
+                                      "fields": "hit ids, prefilter scores, diagonals, order"}
+    return out
 
 
 def search_section(args, gpu, torch, dist, rank, world, matrices, barrier):
@@ -207,7 +235,7 @@ def search_section(args, gpu, torch, dist, rank, world, matrices, barrier):
     t_pf = allreduce(torch, dist, [t_pf], "max")[0]
     stage = np.zeros(7)
     ent = sim = cells = cands = nhits = ovf = 0
-    lists, slot_index = [], []
+    lists, slot_index, full_lists = [], [], []
     for bi, b in enumerate(batches):
         stage += np.array(b.stage_ms())
         h, c, st, stats = b.fetch()
@@ -230,6 +258,7 @@ def search_section(args, gpu, torch, dist, rank, world, matrices, barrier):
         else:
             for qi in range(b.nq):
                 lists.append(h[qi]["id"][:c[qi]].copy())
+                full_lists.append((h[qi]["id"][:c[qi]].copy(), h[qi]["score"][:c[qi]].copy(), h[qi]["diagonal"][:c[qi]].copy()))
             nhits += int(c.sum())
 
     # ---- spot check of the prefilter lists against the oracle on a reduced copy of the problem is done by the
@@ -315,7 +344,7 @@ def search_section(args, gpu, torch, dist, rank, world, matrices, barrier):
             "setup_s": {"generate": round(t_gen, 1), "tables_index_host": round(t_index, 1)},
         }
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = search_cpu_baseline(matrices, qres, qoff, tres, toff, kmer_thr, args.cpu_seconds)
+            res["cpu_baseline"] = search_cpu_baseline(matrices, qres, qoff, tres, toff, kmer_thr, args.cpu_seconds, full_lists)
     for b in batches:
         b.free()
     return res
@@ -404,6 +433,7 @@ def main():
 
     # ---- spot-check the timed batch's results against the oracle (checker only, outside the timed region) ----
     check = None
+    res = None
     if rank == 0:
         from oracle.pyoracle import Oracle
         res = batch.fetch().reshape(args.queries, args.targets)
@@ -418,7 +448,6 @@ def main():
             bad += (int(h["score"]), int(h["q_end"]), int(h["t_end"]), int(h["word"])) != (r["score"], r["q_end"], r["t_end"], r["word"])
         check = {"pairs_checked_vs_oracle": n_chk, "mismatches": bad,
                  "score_checksum": int(res["score"].astype(np.int64).sum())}
-        del res
 
     batch_cells, batch_pairs = batch.cells, batch.pairs
     batch.free()
@@ -456,7 +485,7 @@ def main():
             "prepare_s": round(prep_s, 2), "check": check,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(matrices, qs, cbs, tres, toff, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(matrices, qs, cbs, tres, toff, args.cpu_seconds, res)
         if search is not None:
             out["search"] = search
         print(json.dumps(out))

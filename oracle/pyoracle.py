@@ -429,16 +429,26 @@ class RefPrefilter:
         return dict(id=ids[:n].copy(), score=sc[:n].copy(), diagonal=dg[:n].copy(), db_matches=dbm.value,
                     kmers_per_pos=kpp.value)
 
-    def match_batch(self, qres, qoff, n_threads, max_hits=300, comp_bias=True, min_diag_score=15, max_seq_len=32000):
-        """Multi-threaded query loop (CPU baseline). Returns (seconds, total hits, total db matches, hit counts)."""
+    def match_batch(self, qres, qoff, n_threads, max_hits=300, comp_bias=True, min_diag_score=15, max_seq_len=32000,
+                    want_lists=False):
+        """Multi-threaded query loop (CPU baseline). Returns (seconds, total hits, total db matches, hit counts[,
+        lists dict with ids/scores/diags [nq][max_hits] and the CacheFriendlyOperations bin count used])."""
         qres = np.ascontiguousarray(qres, np.uint8)
         qoff = np.ascontiguousarray(qoff, np.uint64)
         nq = len(qoff) - 1
         th = ctypes.c_uint64(0)
         dbm = ctypes.c_uint64(0)
         counts = np.zeros(max(nq, 1), np.uint32)
+        ids = sc = dg = None
+        if want_lists:
+            ids = np.zeros((max(nq, 1), max_hits), np.uint32)
+            sc = np.zeros((max(nq, 1), max_hits), np.int32)
+            dg = np.zeros((max(nq, 1), max_hits), np.uint16)
+        bins = ctypes.c_uint(0)
         sec = self.L.mmref_pref_match_batch(self.c, _ptr(qres), _ptr(qoff), nq, int(n_threads), self.kmer_thr,
                                             int(max_seq_len), ctypes.c_uint64(max_hits), int(comp_bias),
                                             int(min_diag_score), int(self.spaced), ctypes.byref(th), ctypes.byref(dbm),
-                                            _ptr(counts))
+                                            _ptr(counts), _ptr(ids), _ptr(sc), _ptr(dg), ctypes.byref(bins))
+        if want_lists:
+            return sec, th.value, dbm.value, counts[:nq], dict(ids=ids[:nq], scores=sc[:nq], diags=dg[:nq], bins=bins.value)
         return sec, th.value, dbm.value, counts[:nq]

@@ -232,15 +232,18 @@ uint64_t mmref_pref_match(void *h, const uint8_t *q, uint32_t qlen, uint32_t ide
 // as the reference's own "Time for processing" excludes setup) and the total number of hits / index matches.
 double mmref_pref_match_batch(void *h, const uint8_t *qdata, const uint64_t *qoff, uint32_t nq, int n_threads, int kmer_thr,
                               unsigned max_seq_len, uint64_t max_hits, int comp_bias, unsigned min_diag_score, int spaced,
-                              uint64_t *total_hits, uint64_t *total_db_matches, uint32_t *hit_counts) {
+                              uint64_t *total_hits, uint64_t *total_db_matches, uint32_t *hit_counts,
+                              uint32_t *hit_ids, int32_t *hit_scores, uint16_t *hit_diags, unsigned *bins_used) {
     PrefCtx *c = (PrefCtx *)h;
     unsigned ml = std::max(max_seq_len, c->maxLen);
     uint64_t hits = 0, dbm = 0;
     double t_loop = 0;
 #pragma omp parallel num_threads(n_threads) reduction(+ : hits, dbm)
     {
-        QueryMatcher matcher(c->index, c->lookup, c->kmerMat, c->ungappedMat, (short)kmer_thr, c->kmerSize, c->dbSize, ml,
+        MatcherProbe matcher(c->index, c->lookup, c->kmerMat, c->ungappedMat, (short)kmer_thr, c->kmerSize, c->dbSize, ml,
                              max_hits, comp_bias != 0, 1.0f, true, min_diag_score, false, false);
+#pragma omp master
+        if (bins_used) *bins_used = matcher.bins();
         matcher.setSubstitutionMatrix(&c->three, &c->two);
         Sequence seq(ml, Parameters::DBTYPE_AMINO_ACIDS, c->kmerMat, c->kmerSize, spaced != 0, comp_bias != 0, true);
 #pragma omp barrier
@@ -252,6 +255,12 @@ double mmref_pref_match_batch(void *h, const uint8_t *qdata, const uint64_t *qof
             hits += r.second;
             dbm += matcher.getStatistics()->dbMatches;
             if (hit_counts) hit_counts[i] = (uint32_t)r.second;
+            if (hit_ids)   // full lists, for the full-size parity check of bench.py
+                for (size_t z = 0; z < r.second && z < max_hits; z++) {
+                    hit_ids[(size_t)i * max_hits + z] = (uint32_t)r.first[z].seqId;
+                    hit_scores[(size_t)i * max_hits + z] = r.first[z].prefScore;
+                    hit_diags[(size_t)i * max_hits + z] = r.first[z].diagonal;
+                }
         }
         double t1 = omp_get_wtime();   // after the implicit barrier of the omp for
 #pragma omp master
