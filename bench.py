@@ -131,14 +131,14 @@ def allreduce(torch, dist, values, op="sum"):
     return [float(v) for v in t.cpu()]
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same workload
-    (profiles/r01_prefilter_config3_pmc_{fetch,write}_size.txt: separate --pmc FETCH_SIZE / WRITE_SIZE runs of
-    scripts/bench_prefilter.py at configs[2] scale, unit KB, mean per dispatch).  FETCH_SIZE is reported as measured;
-    MI355X_MICROARCH.md notes it under-counts wide coalesced reads by 2x on gfx950, so this is a lower bound."""
+def pmc_traffic(kernel, stem="r01_prefilter_config3"):
+    """HBM bytes per launch of `kernel` (summed over its template instantiations) from the committed rocprofv3 PMC
+    passes of this same workload (profiles/<stem>_pmc_{fetch,write}_size.txt: separate --pmc FETCH_SIZE / WRITE_SIZE
+    runs, unit KB, mean per dispatch).  FETCH_SIZE is reported as measured; MI355X_MICROARCH.md notes it under-counts
+    wide coalesced reads by 2x on gfx950, so this is a lower bound."""
     tot = 0.0
     for kind in ("fetch", "write"):
-        path = os.path.join(ROOT, "profiles", "r01_prefilter_config3_pmc_%s_size.txt" % kind)
+        path = os.path.join(ROOT, "profiles", "%s_pmc_%s_size.txt" % (stem, kind))
         if not os.path.exists(path):
             return None
         found = False
@@ -148,7 +148,7 @@ def pmc_traffic(kernel):
                 found = True
         if not found:
             return None
-    return {"bytes_per_launch": round(tot), "source": "profiles/r01_prefilter_config3_pmc_*_size.txt (FETCH_SIZE + WRITE_SIZE, KB)"}
+    return {"bytes_per_launch": round(tot), "source": "profiles/%s_pmc_*_size.txt (FETCH_SIZE + WRITE_SIZE, KB)" % stem}
 
 
 def search_cpu_baseline(matrices, qres, qoff, tres, toff, kmer_thr, budget_s, gpu_lists=None):
@@ -476,7 +476,10 @@ def main():
                        "pairs_per_gpu": int(batch_pairs), "cells_per_gpu": int(batch_cells),
                        "parallelism": "1 process/GPU, independent target shards" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 6),
+                         # per step = one launch of every sw_kernel<R> instantiation; PMC passes of this exact workload
+                         "traffic": pmc_traffic("sw_kernel<", "r01_sw_config2") if (args.queries, args.targets) == (1000, 100000) else None,
+                         "algorithmic_bytes_per_launch": round(alg_bytes),
                          "kernel_ms": round(k_ms, 3),
                          "note": "Gotoh SW is VALU-bound (0.003 B/cell); see valu_roofline for the binding resource",
                          "valu_roofline": {"achieved_lane_ops_per_s": round(lane_ops / (k_ms * 1e-3), 1),
