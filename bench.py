@@ -203,10 +203,11 @@ def search_section(args, gpu, torch, dist, rank, world, matrices, barrier):
     nq, nt = len(qs), len(toff) - 1
     t0 = time.time()
     s3, i3 = capi.host_score_matrix(km16, 3)
-    koff, kids, kpos = capi.host_index_build(tres, toff, km16, k, True, kmer_thr)
-    t_index = time.time() - t0
     gpu.load_targets(tres, toff, 21)
-    gpu.pf_load_index(k, 21, True, s3, i3, koff, kids, kpos, matrices["blosum62_ungapped"])
+    # the k-mer index is built in HBM from the resident targets (IndexBuilder::fillDatabase, masking off)
+    gpu.pf_build_index(k, 21, True, s3, i3, km16, kmer_thr, matrices["blosum62_ungapped"])
+    gpu.synchronize()
+    t_index = time.time() - t0
     cbs = [capi.host_comp_bias(km16, matrices["vtml80_pback"], q)[0] for q in qs]
     queries = [dict(q=q, comp_bias=cb, identity_id=None) for q, cb in zip(qs, cbs)]
     mh = capi.split_max_hits(max_res, world)      # Prefiltering.cpp:391-394
@@ -341,7 +342,7 @@ def search_section(args, gpu, torch, dist, rank, world, matrices, barrier):
                                           "entries_per_s": round(ent / (stage[2] * 1e-3), 1) if stage[2] > 0 else None,
                                           "ungapped_cells_per_s": round(cells / (stage[2] * 1e-3), 1) if stage[2] > 0 else None,
                                           "algorithmic_GBps": round((8.0 * ent + 1.0 * cells) / (stage[2] * 1e-3) / 1e9, 1) if stage[2] > 0 else None}},
-            "setup_s": {"generate": round(t_gen, 1), "tables_index_host": round(t_index, 1)},
+            "setup_s": {"generate": round(t_gen, 1), "score_tables_upload_and_device_index_build": round(t_index, 2)},
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = search_cpu_baseline(matrices, qres, qoff, tres, toff, kmer_thr, args.cpu_seconds, full_lists)

@@ -192,6 +192,16 @@ typedef struct {
  * mmgpu_load_targets (call that first, with the - possibly masked - SequenceLookup residues). */
 int mmgpu_pf_load_index(mmgpu_ctx *ctx, const mmgpu_pf_index *index);
 
+/* Device-side index construction (GPU-resident DB): IndexBuilder::fillDatabase with masking
+ * off (IndexBuilder.cpp:118-166,226-270) over the targets made resident by mmgpu_load_targets - the same index
+ * mmgpu_host_index_build returns, built in HBM.  `tables` supplies the score matrices and the ungapped matrix as for
+ * mmgpu_pf_load_index (its offsets / entries fields are ignored); kmer_submat is BaseMatrix::subMatrix of the k-mer
+ * matrix (short, alphabet x alphabet), kmer_thr the k-mer threshold that also gates which target k-mers are indexed
+ * (IndexTable.h:146-154). */
+int mmgpu_pf_build_index(mmgpu_ctx *ctx, const mmgpu_pf_index *tables, const int16_t *kmer_submat, int kmer_thr);
+/* test hook: copies the resident index back in the host builder's layout (any pointer may be NULL) */
+int mmgpu_pf_debug_index(mmgpu_ctx *ctx, uint64_t *offsets, uint32_t *ids, uint16_t *pos, uint64_t *n_entries);
+
 typedef struct {
     int kmer_thr;            /* Prefiltering::getKmerThreshold */
     uint32_t max_hits;       /* maxResListLen (--max-seqs); min(., dbSize) is applied like QueryMatcher.cpp:47 */

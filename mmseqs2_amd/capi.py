@@ -53,7 +53,7 @@ EXPORTED_SYMBOLS = [
     "mmgpu_sw_fetch", "mmgpu_sw_batch_stats", "mmgpu_sw_last_kernel_ms", "mmgpu_sw_kernel_ms_mean", "mmgpu_sw_free",
     "mmgpu_sw_traceback",
     "mmgpu_host_score_matrix", "mmgpu_host_index_build", "mmgpu_pf_load_index", "mmgpu_pf_batch", "mmgpu_pf_prepare",
-    "mmgpu_pf_run", "mmgpu_pf_fetch", "mmgpu_pf_stage_ms", "mmgpu_pf_last_cells", "mmgpu_pf_fetch_device", "mmgpu_pf_merge_splits", "mmgpu_pf_debug_fetch", "mmgpu_pf_free",
+    "mmgpu_pf_run", "mmgpu_pf_fetch", "mmgpu_pf_stage_ms", "mmgpu_pf_last_cells", "mmgpu_pf_fetch_device", "mmgpu_pf_merge_splits", "mmgpu_pf_build_index", "mmgpu_pf_debug_index", "mmgpu_pf_debug_fetch", "mmgpu_pf_free",
 ]
 
 
@@ -112,6 +112,8 @@ def load_library():
     L.mmgpu_host_index_build.argtypes = [c_p, c_p, ctypes.c_uint32, c_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                          ctypes.c_int, c_p, c_p, c_p, ctypes.POINTER(ctypes.c_uint64)]
     L.mmgpu_pf_load_index.argtypes = [c_p, ctypes.POINTER(PfIndexDesc)]
+    L.mmgpu_pf_build_index.argtypes = [c_p, ctypes.POINTER(PfIndexDesc), c_p, ctypes.c_int]
+    L.mmgpu_pf_debug_index.argtypes = [c_p, c_p, c_p, c_p, ctypes.POINTER(ctypes.c_uint64)]
     L.mmgpu_pf_batch.argtypes = [c_p, ctypes.POINTER(PfParams), c_p, ctypes.c_uint32, c_p, ctypes.c_uint32, c_p, c_p]
     L.mmgpu_pf_prepare.argtypes = [c_p, ctypes.POINTER(PfParams), c_p, ctypes.c_uint32, ctypes.POINTER(c_p)]
     L.mmgpu_pf_run.argtypes = [c_p, c_p]
@@ -370,6 +372,29 @@ class MMGpu:
                         0 if score2 is None else score2.shape[1], _ptr(offsets),
                         _ptr(entry_ids), _ptr(entry_pos), None, len(entry_ids), _ptr(ungapped_mat))
         self._check(self.L.mmgpu_pf_load_index(self.ctx, ctypes.byref(d)))
+
+    def pf_build_index(self, k, alphabet, spaced, score3, index3, kmer_submat16, kmer_thr, ungapped_mat, score2=None,
+                       index2=None):
+        """Index construction on the device over the loaded targets (masking off)."""
+        score3 = np.ascontiguousarray(score3, np.int16)
+        index3 = np.ascontiguousarray(index3, np.uint32)
+        ungapped_mat = np.ascontiguousarray(ungapped_mat, np.int8)
+        km = np.ascontiguousarray(kmer_submat16, np.int16)
+        if score2 is not None:
+            score2 = np.ascontiguousarray(score2, np.int16)
+            index2 = np.ascontiguousarray(index2, np.uint32)
+        d = PfIndexDesc(k, alphabet, int(spaced), _ptr(score3), _ptr(index3), score3.shape[1], _ptr(score2), _ptr(index2),
+                        0 if score2 is None else score2.shape[1], None, None, None, None, 0, _ptr(ungapped_mat))
+        self._check(self.L.mmgpu_pf_build_index(self.ctx, ctypes.byref(d), _ptr(km), int(kmer_thr)))
+
+    def pf_debug_index(self, k, alphabet):
+        ne = ctypes.c_uint64()
+        self._check(self.L.mmgpu_pf_debug_index(self.ctx, None, None, None, ctypes.byref(ne)))
+        off = np.zeros((alphabet - 1) ** k + 1, np.uint64)
+        ids = np.zeros(max(ne.value, 1), np.uint32)
+        pos = np.zeros(max(ne.value, 1), np.uint16)
+        self._check(self.L.mmgpu_pf_debug_index(self.ctx, _ptr(off), _ptr(ids), _ptr(pos), ctypes.byref(ne)))
+        return off, ids[:ne.value], pos[:ne.value]
 
     def _pf_marshal(self, queries):
         """queries: list of dicts {q: uint8[], comp_bias: float32[]|None, identity_id: int|None}"""

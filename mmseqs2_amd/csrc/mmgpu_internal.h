@@ -225,6 +225,36 @@ hipError_t launch_pf_dedup(const PfDedupArgs &A, hipEvent_t after_replay, hipEve
 hipError_t launch_pf_select(const PfSelectArgs &A, uint32_t nq, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------------------------
+// index construction (ix_kernels.hip)
+struct IxArgs {
+    const uint8_t *t_res;
+    const uint32_t *t_off4, *t_len;
+    uint32_t n_targets;
+    int k, pattern_len, kmer_thr;
+    uint32_t kalph;
+    uint8_t pat[8];
+    int8_t self_score[32];      // (char) subMatrix[a][a], IndexBuilder.cpp:11-22
+    uint32_t *counts;           // [table]: count pass = list lengths, fill pass = write cursors
+    const uint32_t *offsets;    // [table + 1] (fill pass)
+    uint64_t *entries;          // fill pass: seqId | position << 32, unordered inside a list
+    uint32_t *scratch;          // one uint32 per residue slot, used by targets with more than 4096 windows
+};
+
+struct IxSortArgs {
+    uint64_t table;
+    const uint32_t *offsets;
+    const uint64_t *src;
+    uint64_t *dst;
+    uint32_t *long_lists;       // k-mers whose list has more than 16 entries
+    uint32_t *n_long;
+    uint32_t long_cap;
+};
+
+hipError_t launch_ix_target(const IxArgs &A, bool fill, hipStream_t s);
+hipError_t launch_ix_sort_short(const IxSortArgs &A, hipStream_t s);
+hipError_t launch_ix_sort_long(const IxSortArgs &A, uint32_t n_long, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------------------
 // banded traceback (bt_kernel.hip)
 struct BtJob {
     uint32_t slot;      // where the caller wants the result (index into info[])

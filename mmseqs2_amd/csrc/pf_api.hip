@@ -235,15 +235,20 @@ extern "C" int mmgpu_host_index_build(const uint8_t *residues, const uint64_t *s
 }
 
 // ---------------------------------------------------------------------------------------------------------
-extern "C" int mmgpu_pf_load_index(mmgpu_ctx *c, const mmgpu_pf_index *ix) {
+// tables every QueryMatcher gets (score matrices, cumulative counts, ungapped matrix): shared by the two ways of
+// obtaining the index (host arrays / built in HBM).  `from_host` = validate and copy the host index as well.
+static int pf_setup(mmgpu_ctx *c, const mmgpu_pf_index *ix, bool from_host, PfIndex **out) {
     if (!c || !ix) return fail(MMGPU_ERR_ARG, "mmgpu_pf_load_index: NULL argument");
     if (!c->db.res) return fail(MMGPU_ERR_STATE, "mmgpu_pf_load_index: load the targets (SequenceLookup) first");
     if (ix->kmer_size != 6 && ix->kmer_size != 7) return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_pf_load_index: k must be 6 or 7");
     if (ix->kmer_size == 7 && (!ix->score2 || !ix->index2)) return fail(MMGPU_ERR_ARG, "mmgpu_pf_load_index: k = 7 needs the 2-mer ScoreMatrix");
     if (ix->alphabet != c->db.alphabet) return fail(MMGPU_ERR_ARG, "mmgpu_pf_load_index: alphabet differs from the loaded targets");
-    if (!ix->score3 || !ix->index3 || !ix->offsets || !ix->ungapped_mat) return fail(MMGPU_ERR_ARG, "mmgpu_pf_load_index: NULL table");
-    if (!ix->entries6 && !(ix->entry_ids && ix->entry_pos) && ix->n_entries) return fail(MMGPU_ERR_ARG, "mmgpu_pf_load_index: no index entries");
-    if (ix->n_entries >= 0xFFFFFFFFull) return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_pf_load_index: >= 2^32 index entries per shard");
+    if (!ix->score3 || !ix->index3 || !ix->ungapped_mat) return fail(MMGPU_ERR_ARG, "mmgpu_pf_load_index: NULL table");
+    if (from_host) {
+        if (!ix->offsets) return fail(MMGPU_ERR_ARG, "mmgpu_pf_load_index: NULL table");
+        if (!ix->entries6 && !(ix->entry_ids && ix->entry_pos) && ix->n_entries) return fail(MMGPU_ERR_ARG, "mmgpu_pf_load_index: no index entries");
+        if (ix->n_entries >= 0xFFFFFFFFull) return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_pf_load_index: >= 2^32 index entries per shard");
+    }
     if (c->db.max_len >= 32768) return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_pf_load_index: targets of length >= 32768 (computeLongScore) are not implemented");
     HIP_TRY(hipSetDevice(c->device));
     pf_index_free(c);
@@ -256,7 +261,7 @@ extern "C" int mmgpu_pf_load_index(mmgpu_ctx *c, const mmgpu_pf_index *ix) {
     P->n3 = (uint32_t)(P->kalph * P->kalph * P->kalph);
     P->table = 1;
     for (int i = 0; i < P->k; i++) P->table *= (uint64_t)P->kalph;
-    P->n_entries = ix->n_entries;
+    P->n_entries = from_host ? ix->n_entries : 0;
     const size_t n3 = P->n3;
     if (ix->row3 < n3) { delete P; return fail(MMGPU_ERR_ARG, "mmgpu_pf_load_index: row3 smaller than kalph^3"); }
 #define P_TRY(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { delete P; return fail(MMGPU_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__)); } } while (0)
@@ -303,40 +308,152 @@ extern "C" int mmgpu_pf_load_index(mmgpu_ctx *c, const mmgpu_pf_index *ix) {
         const int rc = build_cum(ix->score2, ix->row2, n2, P->d_cum2, &P->cum2_w, &P->score2_min);
         if (rc) { delete P; return fail(rc == 1 ? MMGPU_ERR_ARG : MMGPU_ERR_HIP, rc == 1 ? "mmgpu_pf_load_index: score2 rows are not sorted by descending score" : "mmgpu_pf_load_index: upload failed"); }
     }
-    {
-        std::vector<uint32_t> off32(P->table + 1);
-        for (uint64_t z = 0; z <= P->table; z++) {
-            if (ix->offsets[z] > ix->n_entries || (z && ix->offsets[z] < ix->offsets[z - 1])) { delete P; return fail(MMGPU_ERR_ARG, "mmgpu_pf_load_index: offsets not monotone / out of range"); }
-            off32[z] = (uint32_t)ix->offsets[z];
-        }
-        P_TRY(upload(P->d_offsets, off32, nullptr));
-        P_TRY(hipDeviceSynchronize());
-    }
-    {
-        const size_t ne = (size_t)ix->n_entries;
-        std::vector<uint64_t> ent(std::max<size_t>(ne, 1));
-        const uint8_t *e6 = (const uint8_t *)ix->entries6;
-        for (size_t e = 0; e < ne; e++) {
-            uint32_t id;
-            uint16_t pj;
-            if (ix->entry_ids) {
-                id = ix->entry_ids[e];
-                pj = ix->entry_pos[e];
-            } else {
-                memcpy(&id, e6 + e * 6, 4);
-                memcpy(&pj, e6 + e * 6 + 4, 2);
+    if (from_host) {
+        {
+            std::vector<uint32_t> off32(P->table + 1);
+            for (uint64_t z = 0; z <= P->table; z++) {
+                if (ix->offsets[z] > ix->n_entries || (z && ix->offsets[z] < ix->offsets[z - 1])) { delete P; return fail(MMGPU_ERR_ARG, "mmgpu_pf_load_index: offsets not monotone / out of range"); }
+                off32[z] = (uint32_t)ix->offsets[z];
             }
-            if (id >= c->db.n) { delete P; return fail(MMGPU_ERR_ARG, "mmgpu_pf_load_index: index entry names a target that is not loaded"); }
-            ent[e] = (uint64_t)id | ((uint64_t)pj << 32);
+            P_TRY(upload(P->d_offsets, off32, nullptr));
+            P_TRY(hipDeviceSynchronize());
         }
-        P_TRY(upload(P->d_entries, ent, nullptr));
-        P_TRY(hipDeviceSynchronize());
+        {
+            const size_t ne = (size_t)ix->n_entries;
+            std::vector<uint64_t> ent(std::max<size_t>(ne, 1));
+            const uint8_t *e6 = (const uint8_t *)ix->entries6;
+            for (size_t e = 0; e < ne; e++) {
+                uint32_t id;
+                uint16_t pj;
+                if (ix->entry_ids) {
+                    id = ix->entry_ids[e];
+                    pj = ix->entry_pos[e];
+                } else {
+                    memcpy(&id, e6 + e * 6, 4);
+                    memcpy(&pj, e6 + e * 6 + 4, 2);
+                }
+                if (id >= c->db.n) { delete P; return fail(MMGPU_ERR_ARG, "mmgpu_pf_load_index: index entry names a target that is not loaded"); }
+                ent[e] = (uint64_t)id | ((uint64_t)pj << 32);
+            }
+            P_TRY(upload(P->d_entries, ent, nullptr));
+            P_TRY(hipDeviceSynchronize());
+        }
     }
     P->h_mat.assign(ix->ungapped_mat, ix->ungapped_mat + ix->alphabet * ix->alphabet);
     P_TRY(upload(P->d_mat, P->h_mat, nullptr));
     P_TRY(hipDeviceSynchronize());
 #undef P_TRY
+    *out = P;
+    return MMGPU_OK;
+}
+
+
+extern "C" int mmgpu_pf_load_index(mmgpu_ctx *c, const mmgpu_pf_index *ix) {
+    PfIndex *P = nullptr;
+    const int rc = pf_setup(c, ix, true, &P);
+    if (rc != MMGPU_OK) return rc;
     c->pf = P;
+    return MMGPU_OK;
+}
+
+// IndexBuilder::fillDatabase on the device (ix_kernels.hip): count, scan, scatter, sort every list by seqId.
+extern "C" int mmgpu_pf_build_index(mmgpu_ctx *c, const mmgpu_pf_index *ix, const int16_t *kmer_submat, int kmer_thr) {
+    if (!kmer_submat) return fail(MMGPU_ERR_ARG, "mmgpu_pf_build_index: NULL argument");
+    PfIndex *P = nullptr;
+    int rc = pf_setup(c, ix, false, &P);
+    if (rc != MMGPU_OK) return rc;
+    hipStream_t s = c->stream;
+#define X_TRY(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { delete P; return fail(MMGPU_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__)); } } while (0)
+    const uint64_t table = P->table;
+    if (table >= 0xFFFFFFF0ull) { delete P; return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_pf_build_index: k-mer table too large"); }
+    DevBuf d_counts, d_scratch, d_chunk_off, d_chunk_tot, d_chunk_base, d_tmp, d_long, d_nlong;
+    X_TRY(d_counts.alloc(table * 4));
+    X_TRY(P->d_offsets.alloc((table + 1) * 4));
+    X_TRY(hipMemsetAsync(d_counts.p, 0, table * 4, s));
+    IxArgs A;
+    memset(&A, 0, sizeof(A));
+    A.t_res = c->db.res;
+    A.t_off4 = c->db.off4;
+    A.t_len = c->db.len;
+    A.n_targets = c->db.n;
+    A.k = P->k;
+    A.pattern_len = P->pattern_len;
+    A.kmer_thr = kmer_thr;
+    A.kalph = (uint32_t)P->kalph;
+    memcpy(A.pat, P->pat, sizeof(A.pat));
+    for (int a = 0; a < P->alphabet && a < 32; a++) A.self_score[a] = (int8_t)(char)kmer_submat[a * P->alphabet + a];
+    A.counts = d_counts.as<uint32_t>();
+    if ((int)c->db.max_len - P->pattern_len + 1 > 4096) {
+        // one uint32 per residue slot of the packed target array
+        uint64_t slots = 0;
+        for (uint32_t l : c->h_len) slots += ((uint64_t)l + 3) / 4 * 4;
+        X_TRY(d_scratch.alloc((slots + 64) * 4));
+    }
+    A.scratch = d_scratch.as<uint32_t>();
+    X_TRY(launch_ix_target(A, false, s));
+    // offsets = exclusive scan of the counts: 64 K chunks, chunk totals summed on the host
+    const uint32_t CH = 65536;
+    const uint32_t nch = (uint32_t)((table + CH - 1) / CH);
+    std::vector<uint32_t> choff(nch + 1);
+    for (uint32_t z = 0; z <= nch; z++) choff[z] = (uint32_t)std::min<uint64_t>((uint64_t)z * CH, table);
+    std::vector<uint64_t> chtot(nch), chbase(nch);
+    X_TRY(upload(d_chunk_off, choff, s));
+    X_TRY(d_chunk_tot.alloc((size_t)nch * 8));
+    X_TRY(d_chunk_base.alloc((size_t)nch * 8));
+    X_TRY(launch_pf_scan(d_counts.as<uint32_t>(), d_chunk_off.as<uint32_t>(), nch, nullptr, nullptr, d_chunk_tot.as<uint64_t>(), s));
+    X_TRY(hipMemcpyAsync(chtot.data(), d_chunk_tot.p, (size_t)nch * 8, hipMemcpyDeviceToHost, s));
+    X_TRY(hipStreamSynchronize(s));
+    uint64_t run = 0;
+    for (uint32_t z = 0; z < nch; z++) { chbase[z] = run; run += chtot[z]; }
+    if (run >= 0xFFFFFFFFull) { delete P; return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_pf_build_index: >= 2^32 index entries per shard"); }
+    P->n_entries = run;
+    X_TRY(hipMemcpyAsync(d_chunk_base.p, chbase.data(), (size_t)nch * 8, hipMemcpyHostToDevice, s));
+    X_TRY(launch_pf_scan(d_counts.as<uint32_t>(), d_chunk_off.as<uint32_t>(), nch, d_chunk_base.as<uint64_t>(), P->d_offsets.as<uint32_t>(), nullptr, s));
+    X_TRY(d_tmp.alloc(std::max<uint64_t>(run, 1) * 8));
+    X_TRY(P->d_entries.alloc(std::max<uint64_t>(run, 1) * 8));
+    X_TRY(hipMemsetAsync(d_counts.p, 0, table * 4, s));
+    A.offsets = P->d_offsets.as<uint32_t>();
+    A.entries = d_tmp.as<uint64_t>();
+    X_TRY(launch_ix_target(A, true, s));
+    IxSortArgs S;
+    S.table = table;
+    S.offsets = P->d_offsets.as<uint32_t>();
+    S.src = d_tmp.as<uint64_t>();
+    S.dst = P->d_entries.as<uint64_t>();
+    S.long_cap = (uint32_t)(run / 17 + 1);
+    X_TRY(d_long.alloc((size_t)S.long_cap * 4));
+    X_TRY(d_nlong.alloc(4));
+    X_TRY(hipMemsetAsync(d_nlong.p, 0, 4, s));
+    S.long_lists = d_long.as<uint32_t>();
+    S.n_long = d_nlong.as<uint32_t>();
+    X_TRY(launch_ix_sort_short(S, s));
+    uint32_t n_long = 0;
+    X_TRY(hipMemcpyAsync(&n_long, d_nlong.p, 4, hipMemcpyDeviceToHost, s));
+    X_TRY(hipStreamSynchronize(s));
+    X_TRY(launch_ix_sort_long(S, std::min(n_long, S.long_cap), s));
+    X_TRY(hipStreamSynchronize(s));
+#undef X_TRY
+    c->pf = P;
+    return MMGPU_OK;
+}
+
+// test hook: the resident index as the host builder would return it
+extern "C" int mmgpu_pf_debug_index(mmgpu_ctx *c, uint64_t *offsets, uint32_t *ids, uint16_t *pos, uint64_t *n_entries) {
+    if (!c || !c->pf || !n_entries) return fail(MMGPU_ERR_ARG, "mmgpu_pf_debug_index: no index");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const PfIndex &P = *c->pf;
+    *n_entries = P.n_entries;
+    if (offsets) {
+        std::vector<uint32_t> o(P.table + 1);
+        HIP_TRY(hipMemcpy(o.data(), P.d_offsets.p, (P.table + 1) * 4, hipMemcpyDeviceToHost));
+        for (uint64_t z = 0; z <= P.table; z++) offsets[z] = o[z];
+    }
+    if (ids && pos && P.n_entries) {
+        std::vector<uint64_t> e(P.n_entries);
+        HIP_TRY(hipMemcpy(e.data(), P.d_entries.p, P.n_entries * 8, hipMemcpyDeviceToHost));
+        for (uint64_t z = 0; z < P.n_entries; z++) { ids[z] = (uint32_t)e[z]; pos[z] = (uint16_t)(e[z] >> 32); }
+    }
     return MMGPU_OK;
 }
 

@@ -29,11 +29,11 @@ qs = wl.split(qres, qoff)
 gpu = mmseqs2_amd.MMGpu(0)
 thr = int(163.2 - 8.917 * args.sens)
 t0 = time.time(); s3, i3 = capi.host_score_matrix(km16, 3); t_sm = time.time() - t0
-t0 = time.time(); off, ids, pos = capi.host_index_build(tres, toff, km16, 6, True, thr); t_ix = time.time() - t0
 t0 = time.time()
 gpu.load_targets(tres, toff, 21)
-gpu.pf_load_index(6, 21, True, s3, i3, off, ids, pos, m["blosum62_ungapped"])
 t_load = time.time() - t0
+t0 = time.time(); gpu.pf_build_index(6, 21, True, s3, i3, km16, thr, m["blosum62_ungapped"]); gpu.synchronize(); t_ix = time.time() - t0
+ids = gpu.pf_debug_index(6, 21)[1] if args.check else np.zeros(0)
 t0 = time.time()
 cbs = [capi.host_comp_bias(km16, m["vtml80_pback"], q)[0] for q in qs]
 queries = [dict(q=q, comp_bias=cb, identity_id=None) for q, cb in zip(qs, cbs)]

@@ -234,3 +234,44 @@ def test_prefilter_overflow_path(gpu, nt, ql, frac):
         assert any("status" not in r for r in rep)
     orc.build_index(g["tres"], g["toff"], thr)
     chk.load_case(gpu, g, g["tres"], g["toff"], thr)
+
+
+def test_index_built_on_device_equals_host_index(gpu):
+    """mmgpu_pf_build_index (IndexBuilder::fillDatabase in HBM) against the host builder, which is itself identical to
+    the reference's index (tests/test_prefilter_oracle.py): offsets and every (seqId, position) entry, for the golden
+    DB, for a DB containing targets with more than 4096 windows (global-scratch path) and a repetitive one (long
+    lists), and for k = 7; then a search on the device-built index."""
+    from mmseqs2_amd import capi
+    g = pc.golden()
+    km16, um8 = g["vtml80_kmer16"], g["blosum62_ungapped"]
+    thr = int(g["kmer_thr"])
+    s3, i3 = capi.host_score_matrix(km16, 3, lib=gpu.L)
+    rng = np.random.default_rng(8)
+    tl = wl.split(g["tres"], g["toff"])[:300]
+    tl.append(rng.choice(20, size=9000, p=wl.BACKGROUND).astype(np.uint8))            # > 4096 windows
+    tl.append(np.tile(rng.choice(20, size=37, p=wl.BACKGROUND).astype(np.uint8), 200))  # repeats: few distinct k-mers
+    for _ in range(60):                                                                 # one k-mer in many targets
+        t = rng.choice(20, size=120, p=wl.BACKGROUND).astype(np.uint8)
+        t[40:52] = np.array([9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9], np.uint8)
+        tl.append(t)
+    big_res, big_off = wl.seqs_from_list(tl)
+    for tres, toff, k, kthr in ((g["tres"], g["toff"], 6, thr), (big_res, big_off, 6, thr), (big_res, big_off, 6, 0),
+                                (g["tres"][:int(g["toff"][200])], g["toff"][:201], 7, 122)):
+        gpu.load_targets(tres, toff, 21)
+        s2, i2 = capi.host_score_matrix(km16, 2, lib=gpu.L) if k == 7 else (None, None)
+        gpu.pf_build_index(k, 21, True, s3, i3, km16, kthr, um8, score2=s2, index2=i2)
+        off, ids, pos = gpu.pf_debug_index(k, 21)
+        hoff, hids, hpos = capi.host_index_build(tres, toff, km16, k, True, kthr, lib=gpu.L)
+        assert np.array_equal(off, hoff), (k, kthr)
+        assert np.array_equal(ids, hids) and np.array_equal(pos, hpos), (k, kthr)
+        assert len(ids) > 1000
+    # search on a device-built index: golden hit lists
+    gpu.load_targets(g["tres"], g["toff"], 21)
+    gpu.pf_build_index(6, 21, True, s3, i3, km16, thr, um8)
+    qs = pc.golden_queries(g)
+    hits, counts, status, stats = gpu.pf_batch(qs, thr, max_hits=300, ref_bins=2)
+    exp = pc.expected_hits(g, 0)
+    for qi in range(len(qs)):
+        n = int(counts[qi])
+        assert np.array_equal(hits[qi]["id"][:n], exp[qi][0]) and np.array_equal(hits[qi]["score"][:n], exp[qi][1])
+    chk.load_case(gpu, g, g["tres"], g["toff"], thr)
