@@ -118,6 +118,13 @@ int mmgpu_sw_batch(mmgpu_ctx *ctx, const mmgpu_sw_params *params, const mmgpu_sw
 typedef struct mmgpu_sw_batch_t mmgpu_sw_batch_t;
 int mmgpu_sw_prepare(mmgpu_ctx *ctx, const mmgpu_sw_params *params, const mmgpu_sw_query *queries,
                      uint32_t n_queries, int mode, mmgpu_sw_batch_t **batch);
+/* Fused hand-over: the alignment batch for the hit lists of a prefilter batch that has been run,
+ * without the lists leaving the device.  queries[i] supplies q / qlen / comp_bias / min_start_score (target_ids and
+ * n_targets are ignored); the result array has n_queries * min(max_hits, dbSize) slots, slot q * stride + k = hit k of
+ * query q's list (zeroed beyond the list's length).  mmgpu_pf_hit is declared further down. */
+struct mmgpu_pf_batch_t;
+int mmgpu_sw_prepare_from_pf(mmgpu_ctx *ctx, const mmgpu_sw_params *params, const mmgpu_sw_query *queries,
+                             uint32_t n_queries, int mode, struct mmgpu_pf_batch_t *pf_batch, mmgpu_sw_batch_t **batch);
 int mmgpu_sw_run(mmgpu_ctx *ctx, mmgpu_sw_batch_t *batch);
 int mmgpu_sw_fetch(mmgpu_ctx *ctx, mmgpu_sw_batch_t *batch, mmgpu_sw_hit *out);
 /* forward-DP cells of the batch = sum over pairs of qlen*tlen ("alignments calculated" x lengths,

@@ -51,7 +51,7 @@ EXPORTED_SYMBOLS = [
     "mmgpu_init", "mmgpu_destroy", "mmgpu_last_error", "mmgpu_set_stream", "mmgpu_synchronize",
     "mmgpu_device_info", "mmgpu_host_comp_bias", "mmgpu_host_round_comp_bias", "mmgpu_load_targets", "mmgpu_sw_batch", "mmgpu_sw_prepare", "mmgpu_sw_run",
     "mmgpu_sw_fetch", "mmgpu_sw_batch_stats", "mmgpu_sw_last_kernel_ms", "mmgpu_sw_kernel_ms_mean", "mmgpu_sw_free",
-    "mmgpu_sw_traceback",
+    "mmgpu_sw_traceback", "mmgpu_sw_prepare_from_pf",
     "mmgpu_host_score_matrix", "mmgpu_host_index_build", "mmgpu_pf_load_index", "mmgpu_pf_batch", "mmgpu_pf_prepare",
     "mmgpu_pf_run", "mmgpu_pf_fetch", "mmgpu_pf_stage_ms", "mmgpu_pf_last_cells", "mmgpu_pf_fetch_device", "mmgpu_pf_merge_splits", "mmgpu_pf_build_index", "mmgpu_pf_debug_index", "mmgpu_pf_debug_fetch", "mmgpu_pf_free",
 ]
@@ -100,6 +100,7 @@ def load_library():
     L.mmgpu_load_targets.argtypes = [c_p, c_p, c_p, ctypes.c_uint32, ctypes.c_int]
     L.mmgpu_sw_batch.argtypes = [c_p, ctypes.POINTER(SwParams), c_p, ctypes.c_uint32, ctypes.c_int, c_p]
     L.mmgpu_sw_prepare.argtypes = [c_p, ctypes.POINTER(SwParams), c_p, ctypes.c_uint32, ctypes.c_int, ctypes.POINTER(c_p)]
+    L.mmgpu_sw_prepare_from_pf.argtypes = [c_p, ctypes.POINTER(SwParams), c_p, ctypes.c_uint32, ctypes.c_int, c_p, ctypes.POINTER(c_p)]
     L.mmgpu_sw_run.argtypes = [c_p, c_p]
     L.mmgpu_sw_fetch.argtypes = [c_p, c_p, c_p]
     L.mmgpu_sw_batch_stats.argtypes = [c_p, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
@@ -242,12 +243,13 @@ class SwBatch:
         cells, pairs = ctypes.c_uint64(), ctypes.c_uint64()
         gpu._check(gpu.L.mmgpu_sw_batch_stats(handle, ctypes.byref(cells), ctypes.byref(pairs)))
         self.cells, self.pairs = cells.value, pairs.value
+        self.slots = None   # fused batches: result slots (n_queries * stride), pairs = slots that hold a hit
 
     def run(self):
         self.gpu._check(self.gpu.L.mmgpu_sw_run(self.gpu.ctx, self.handle))
 
     def fetch(self):
-        out = np.zeros(self.pairs, SW_HIT_DTYPE)
+        out = np.zeros(self.pairs if self.slots is None else self.slots, SW_HIT_DTYPE)
         self.gpu._check(self.gpu.L.mmgpu_sw_fetch(self.gpu.ctx, self.handle, _ptr(out)))
         return out
 
@@ -355,6 +357,19 @@ class MMGpu:
         h = c_p()
         self._check(self.L.mmgpu_sw_prepare(self.ctx, ctypes.byref(par), ctypes.cast(arr, c_p), len(queries), mode, ctypes.byref(h)))
         return SwBatch(self, h, keep)
+
+    def sw_prepare_from_pf(self, mat, gap_open, gap_extend, queries, pf_batch, mode=1):
+        """Alignment batch over the hit lists of a prefilter batch that has been run, lists stay on the device.
+        queries: dicts with q, comp_bias (int8), min_start_score.  fetch() returns n_queries * stride slots."""
+        qd = [dict(q=x["q"], comp_bias=x.get("comp_bias"), targets=np.zeros(0, np.uint32),
+                   min_start_score=x.get("min_start_score", 0)) for x in queries]
+        par, arr, keep = self._marshal(mat, gap_open, gap_extend, qd)
+        h = c_p()
+        self._check(self.L.mmgpu_sw_prepare_from_pf(self.ctx, ctypes.byref(par), ctypes.cast(arr, c_p), len(queries), mode,
+                                                    pf_batch.handle, ctypes.byref(h)))
+        b = SwBatch(self, h, keep)
+        b.slots = len(queries) * pf_batch.max_hits
+        return b
 
     # ---- prefilter ----
     def pf_load_index(self, k, alphabet, spaced, score3, index3, offsets, entry_ids, entry_pos, ungapped_mat,

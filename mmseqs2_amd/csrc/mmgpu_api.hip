@@ -170,9 +170,16 @@ struct mmgpu_sw_batch_t {
     int mode = 0;
     int alphabet = 0, gap_open = 0, gap_extend = 0;
     uint64_t cells = 0, pairs = 0;
+    uint64_t valid_pairs = 0;   // from_pf: slots actually holding a hit (pairs counts all slots)
     uint32_t n_queries = 0;
     std::vector<SwClass> classes;
     DevBuf d_qres, d_qcb, d_qoff, d_qbias, d_qminstart, d_hit_target, d_hit_out, d_out, d_mat;
+    // fused hand-over from a prefilter batch (mmgpu_sw_prepare_from_pf): lists, counts and statistics live on the device
+    bool from_pf = false;
+    const mmgpu_pf_hit *pf_hits = nullptr;
+    const uint32_t *pf_counts = nullptr;
+    uint32_t pf_stride = 0, slot_stride = 0;
+    DevBuf d_stats;                        // [2] unsigned long long: cells, pairs
     std::vector<uint32_t> h_out_target;   // target id of every result slot (kept for mmgpu_sw_traceback, mode >= START)
     std::vector<uint32_t> h_qout_off;     // [nq + 1] first result slot of every query
     std::vector<uint32_t> h_qoff;         // [nq + 1] residue offsets
@@ -194,9 +201,17 @@ static void pick_class(uint32_t qlen, int *rows_per_lane, bool *multi) {
     *multi = n_tiles > 1;
 }
 
-extern "C" int mmgpu_sw_prepare(mmgpu_ctx *c, const mmgpu_sw_params *par, const mmgpu_sw_query *qs, uint32_t nq,
-                                int mode, mmgpu_sw_batch_t **out) {
+static int sw_prepare_impl(mmgpu_ctx *c, const mmgpu_sw_params *par, const mmgpu_sw_query *qs, uint32_t nq, int mode,
+                           mmgpu_pf_batch_t *pf, mmgpu_sw_batch_t **out) {
     if (!c || !par || !out || (!qs && nq)) return fail(MMGPU_ERR_ARG, "mmgpu_sw_prepare: NULL argument");
+    const mmgpu_pf_hit *pf_hits = nullptr;
+    const uint32_t *pf_counts = nullptr;
+    uint32_t pf_stride = 0, pf_nq = 0;
+    if (pf) {
+        if (!pf_batch_device_lists(pf, &pf_hits, &pf_counts, &pf_stride, &pf_nq)) return fail(MMGPU_ERR_STATE, "mmgpu_sw_prepare_from_pf: the prefilter batch was never run");
+        if (pf_nq != nq) return fail(MMGPU_ERR_ARG, "mmgpu_sw_prepare_from_pf: query count differs from the prefilter batch");
+        if (pf_stride > (uint32_t)SW_PF_MAX_LIST) return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_sw_prepare_from_pf: lists longer than 4096");
+    }
     if (!c->db.res) return fail(MMGPU_ERR_STATE, "mmgpu_sw_prepare: no targets loaded");
     if (par->alphabet != c->db.alphabet) return fail(MMGPU_ERR_ARG, "mmgpu_sw_prepare: alphabet differs from the loaded targets");
     if (mode != MMGPU_SW_SCORE_END && mode != MMGPU_SW_START) return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_sw_prepare: unknown mode");
@@ -223,12 +238,12 @@ extern "C" int mmgpu_sw_prepare(mmgpu_ctx *c, const mmgpu_sw_params *par, const 
     for (uint32_t i = 0; i < nq; i++) {
         if (qs[i].qlen == 0 || qs[i].qlen > 65535 || !qs[i].q) { delete b; return fail(MMGPU_ERR_ARG, "mmgpu_sw_prepare: bad query"); }
         qoff[i + 1] = qoff[i] + qs[i].qlen;
-        total_hits += qs[i].n_targets;
+        total_hits += pf ? pf_stride : qs[i].n_targets;
     }
     if (total_hits > 0xFFFFFFF0ull) { delete b; return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_sw_prepare: more than 2^32 pairs in one batch"); }
     qres.resize(qoff[nq]);
     qcb.assign(qoff[nq], 0);
-    std::vector<uint32_t> hit_target((size_t)total_hits), hit_out((size_t)total_hits);
+    std::vector<uint32_t> hit_target(pf ? 0 : (size_t)total_hits), hit_out(pf ? 0 : (size_t)total_hits);
     b->classes.resize(32);   // [0,16): single tile R = 2..32, [16,32): multi-tile
     for (int k = 0; k < 32; k++) {
         b->classes[k].rows_per_lane = 2 * (k % 16 + 1);
@@ -237,7 +252,7 @@ extern "C" int mmgpu_sw_prepare(mmgpu_ctx *c, const mmgpu_sw_params *par, const 
     std::vector<uint32_t> order;
     uint32_t hit_cursor = 0, out_cursor = 0;
     b->h_qout_off.assign(nq + 1, 0);
-    if (mode >= MMGPU_SW_START) b->h_out_target.resize((size_t)total_hits);
+    if (mode >= MMGPU_SW_START && !pf) b->h_out_target.resize((size_t)total_hits);
     uint32_t max_tlen = 0;
     bool any_multi = false;
     for (uint32_t i = 0; i < nq; i++) {
@@ -254,6 +269,28 @@ extern "C" int mmgpu_sw_prepare(mmgpu_ctx *c, const mmgpu_sw_params *par, const 
         }
         qbias[i] = std::abs(minp) + std::abs(mincb);   // ssw_init :1397-1406
         qminstart[i] = Q.min_start_score;
+        int rpl; bool multi;
+        pick_class(Q.qlen, &rpl, &multi);
+        any_multi |= multi;
+        SwClass &cls = b->classes[(multi ? 16 : 0) + rpl / 2 - 1];
+        if (pf) {
+            // the list is on the device: fixed jobs of one workgroup round each over the query's slots, the kernel
+            // clips them to the list length (SwLaunch::q_hit_count); order and statistics come from sw_from_pf_kernel
+            for (uint32_t k = 0; k < pf_stride; k += JOB_ROUND) {
+                SwJob j;
+                j.query = i;
+                j.hit_begin = hit_cursor + k;
+                j.hit_end = hit_cursor + std::min<uint32_t>(k + JOB_ROUND, pf_stride);
+                j.pad = 0;
+                cls.jobs.push_back(j);
+                cls.job_cells.push_back(0);
+            }
+            max_tlen = c->db.max_len;
+            hit_cursor += pf_stride;
+            out_cursor += pf_stride;
+            b->h_qout_off[i + 1] = out_cursor;
+            continue;
+        }
         // sort the prefilter list by target length (longest first) so the 8 targets a wave runs together end together
         const bool same_list = i > 0 && Q.target_ids == qs[i - 1].target_ids && Q.n_targets == qs[i - 1].n_targets;
         if (!same_list) {   // all-vs-all callers hand the same list to every query: sort it once
@@ -265,10 +302,6 @@ extern "C" int mmgpu_sw_prepare(mmgpu_ctx *c, const mmgpu_sw_params *par, const 
                 return c->h_len[Q.target_ids[a]] > c->h_len[Q.target_ids[bb]];
             });
         }
-        int rpl; bool multi;
-        pick_class(Q.qlen, &rpl, &multi);
-        any_multi |= multi;
-        SwClass &cls = b->classes[(multi ? 16 : 0) + rpl / 2 - 1];
         for (uint32_t k = 0; k < Q.n_targets; k++) {
             const uint32_t t = Q.target_ids[order[k]];
             hit_target[hit_cursor + k] = t;
@@ -304,6 +337,11 @@ extern "C" int mmgpu_sw_prepare(mmgpu_ctx *c, const mmgpu_sw_params *par, const 
     }
     b->pairs = total_hits;
     b->h_qoff = qoff;
+    b->from_pf = pf != nullptr;
+    b->pf_hits = pf_hits;
+    b->pf_counts = pf_counts;
+    b->pf_stride = pf_stride;
+    b->slot_stride = pf_stride;
 
     hipStream_t s = c->stream;
     std::vector<int8_t> mat(par->mat, par->mat + par->alphabet * par->alphabet);
@@ -313,8 +351,15 @@ extern "C" int mmgpu_sw_prepare(mmgpu_ctx *c, const mmgpu_sw_params *par, const 
     B_TRY(upload(b->d_qoff, qoff, s));
     B_TRY(upload(b->d_qbias, qbias, s));
     B_TRY(upload(b->d_qminstart, qminstart, s));
-    B_TRY(upload(b->d_hit_target, hit_target, s));
-    B_TRY(upload(b->d_hit_out, hit_out, s));
+    if (pf) {
+        B_TRY(b->d_hit_target.alloc(std::max<size_t>((size_t)total_hits, 1) * 4));
+        B_TRY(b->d_hit_out.alloc(std::max<size_t>((size_t)total_hits, 1) * 4));
+        B_TRY(b->d_stats.alloc(16));
+        B_TRY(hipMemsetAsync(b->d_stats.p, 0, 16, s));
+    } else {
+        B_TRY(upload(b->d_hit_target, hit_target, s));
+        B_TRY(upload(b->d_hit_out, hit_out, s));
+    }
     B_TRY(upload(b->d_mat, mat, s));
     B_TRY(b->d_out.alloc(std::max<size_t>((size_t)total_hits, 1) * sizeof(mmgpu_sw_hit)));
     for (auto &cls : b->classes) {
@@ -333,10 +378,42 @@ extern "C" int mmgpu_sw_prepare(mmgpu_ctx *c, const mmgpu_sw_params *par, const 
             if (cls.multi && !cls.jobs.empty())
                 B_TRY(cls.d_scratch.alloc(cls.jobs.size() * 4 * 4 * 2 * (size_t)b->scratch_cols * sizeof(uint2)));
     }
+    if (pf) {
+        B_TRY(hipMemsetAsync(b->d_out.p, 0, std::max<size_t>((size_t)total_hits, 1) * sizeof(mmgpu_sw_hit), s));
+        SwFromPfArgs F;
+        F.pf_hits = pf_hits;
+        F.pf_stride = pf_stride;
+        F.hit_count = pf_counts;
+        F.stride = pf_stride;
+        F.q_off = b->d_qoff.as<uint32_t>();
+        F.t_len = c->db.len;
+        F.hit_target = b->d_hit_target.as<uint32_t>();
+        F.hit_out = b->d_hit_out.as<uint32_t>();
+        F.cells = b->d_stats.as<unsigned long long>();
+        F.pairs = b->d_stats.as<unsigned long long>() + 1;
+        B_TRY(launch_sw_from_pf(F, nq, s));
+    }
     B_TRY(hipStreamSynchronize(s));   // the host vectors above die with this scope
+    if (pf) {
+        unsigned long long st[2] = {0, 0};
+        B_TRY(hipMemcpy(st, b->d_stats.p, 16, hipMemcpyDeviceToHost));
+        b->cells = st[0];
+        b->valid_pairs = st[1];
+    }
 #undef B_TRY
     *out = b;
     return MMGPU_OK;
+}
+
+extern "C" int mmgpu_sw_prepare(mmgpu_ctx *c, const mmgpu_sw_params *par, const mmgpu_sw_query *qs, uint32_t nq,
+                                int mode, mmgpu_sw_batch_t **out) {
+    return sw_prepare_impl(c, par, qs, nq, mode, nullptr, out);
+}
+
+extern "C" int mmgpu_sw_prepare_from_pf(mmgpu_ctx *c, const mmgpu_sw_params *par, const mmgpu_sw_query *qs, uint32_t nq,
+                                        int mode, mmgpu_pf_batch_t *pf, mmgpu_sw_batch_t **out) {
+    if (!pf) return fail(MMGPU_ERR_ARG, "mmgpu_sw_prepare_from_pf: NULL prefilter batch");
+    return sw_prepare_impl(c, par, qs, nq, mode, pf, out);
 }
 
 extern "C" int mmgpu_sw_run(mmgpu_ctx *c, mmgpu_sw_batch_t *b) {
@@ -383,6 +460,8 @@ extern "C" int mmgpu_sw_run(mmgpu_ctx *c, mmgpu_sw_batch_t *b) {
             L.alphabet = b->alphabet;
             L.gap_open = b->gap_open;
             L.gap_extend = b->gap_extend;
+            L.q_hit_count = b->from_pf ? b->pf_counts : nullptr;
+            L.hit_stride = b->slot_stride;
             L.scratch = cls.d_scratch.as<uint2>();
             L.scratch_cols = b->scratch_cols;
             HIP_TRY(launch_sw(L, cls.rows_per_lane, cls.multi, pass == 1, st));
@@ -410,7 +489,7 @@ extern "C" int mmgpu_sw_fetch(mmgpu_ctx *c, mmgpu_sw_batch_t *b, mmgpu_sw_hit *o
 extern "C" int mmgpu_sw_batch_stats(mmgpu_sw_batch_t *b, uint64_t *cells, uint64_t *pairs) {
     if (!b) return fail(MMGPU_ERR_ARG, "mmgpu_sw_batch_stats: NULL argument");
     if (cells) *cells = b->cells;
-    if (pairs) *pairs = b->pairs;
+    if (pairs) *pairs = b->from_pf ? b->valid_pairs : b->pairs;
     return MMGPU_OK;
 }
 
@@ -474,6 +553,12 @@ extern "C" int mmgpu_sw_traceback(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const uint3
     std::vector<mmgpu_sw_hit> res((size_t)b->pairs);
     if (b->pairs) HIP_TRY(hipMemcpyAsync(res.data(), b->d_out.p, (size_t)b->pairs * sizeof(mmgpu_sw_hit), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    std::vector<mmgpu_pf_hit> pf_host;
+    if (b->from_pf) {   // the lists never left the device: fetch the target ids now
+        pf_host.resize((size_t)b->pairs);
+        if (b->pairs) HIP_TRY(hipMemcpy2D(pf_host.data(), (size_t)b->slot_stride * sizeof(mmgpu_pf_hit), b->pf_hits, (size_t)b->pf_stride * sizeof(mmgpu_pf_hit),
+                                          (size_t)b->slot_stride * sizeof(mmgpu_pf_hit), b->n_queries, hipMemcpyDeviceToHost));
+    }
     std::vector<BtJob> jobs;
     jobs.reserve(n);
     uint64_t off = 0;
@@ -493,7 +578,7 @@ extern "C" int mmgpu_sw_traceback(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const uint3
         BtJob j;
         j.slot = k;
         j.query = (uint32_t)(std::upper_bound(b->h_qout_off.begin(), b->h_qout_off.end(), p) - b->h_qout_off.begin() - 1);
-        j.target = b->h_out_target[p];
+        j.target = b->from_pf ? pf_host[p].id : b->h_out_target[p];
         j.q_start = h.q_start; j.q_end = h.q_end; j.t_start = h.t_start; j.t_end = h.t_end; j.score = h.score;
         j.bt_off = off;
         off += (uint64_t)(h.q_end - h.q_start + 1) + (uint64_t)(h.t_end - h.t_start + 1) + 1;

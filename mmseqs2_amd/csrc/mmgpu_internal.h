@@ -59,7 +59,25 @@ struct SwLaunch {
     // multi-tile scratch (H/F boundary rows), [n_jobs][4 waves][4 groups][scratch_cols] x uint2
     uint2 *scratch;
     uint32_t scratch_cols;
+    // fused hand-over from a prefilter batch: hits of query q live in slots [q * hit_stride, + q_hit_count[q])
+    const uint32_t *q_hit_count;   // null for caller-supplied lists
+    uint32_t hit_stride;
 };
+
+constexpr int SW_PF_MAX_LIST = 4096;   // == PF_MAX_HITS
+
+struct SwFromPfArgs {
+    const mmgpu_pf_hit *pf_hits;   // [nq][pf_stride]
+    uint32_t pf_stride;
+    const uint32_t *hit_count;     // [nq]
+    uint32_t stride;               // slots per query in the alignment batch
+    const uint32_t *q_off;
+    const uint32_t *t_len;
+    uint32_t *hit_target, *hit_out;
+    unsigned long long *cells, *pairs;
+};
+
+hipError_t launch_sw_from_pf(const SwFromPfArgs &A, uint32_t nq, hipStream_t stream);
 
 // rows_per_lane in {8,16,24,32}: a 16-lane group covers 16*rows_per_lane query rows per tile.
 // reverse = false: forward score/end scan; true: start-position scan over the reversed prefixes.
@@ -337,7 +355,10 @@ struct mmgpu_ctx {
     mmgpu::PfIndex *pf = nullptr;  // prefilter index resident in HBM (pf_api.hip)
 };
 
+struct mmgpu_pf_batch_t;
 namespace mmgpu {
 void pf_index_free(mmgpu_ctx *c);
+// device-resident results of a prefilter batch that has been run (false if it has not)
+bool pf_batch_device_lists(mmgpu_pf_batch_t *b, const mmgpu_pf_hit **hits, const uint32_t **counts, uint32_t *stride, uint32_t *nq);
 }
 #endif

@@ -482,6 +482,17 @@ struct mmgpu_pf_batch_t {
     bool ran = false;
 };
 
+namespace mmgpu {
+bool pf_batch_device_lists(mmgpu_pf_batch_t *b, const mmgpu_pf_hit **hits, const uint32_t **counts, uint32_t *stride, uint32_t *nq) {
+    if (!b || !b->ran) return false;
+    *hits = b->d_hits.as<mmgpu_pf_hit>();
+    *counts = b->d_hit_count.as<uint32_t>();
+    *stride = b->max_hits;
+    *nq = b->nq;
+    return true;
+}
+}  // namespace mmgpu
+
 static uint32_t reference_bins(uint64_t dbsize) {
     // QueryMatcher::initDiagonalMatcher (QueryMatcher.cpp:460-488), Util::getL2CacheSize (Util.cpp:346-361)
     uint64_t l2 = 262144;

@@ -114,7 +114,12 @@ __global__ __launch_bounds__(WAVES * 64) void sw_kernel(SwLaunch L) {
     using T = Tile<R>;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
-    const SwJob job = L.jobs[blockIdx.x];
+    SwJob job = L.jobs[blockIdx.x];
+    if (L.q_hit_count) {   // fused prefilter -> align hand-over: the list length of the query is only known on the device
+        const uint32_t lim = job.query * L.hit_stride + L.q_hit_count[job.query];
+        job.hit_end = job.hit_end < lim ? job.hit_end : lim;
+        if (job.hit_end <= job.hit_begin) return;
+    }
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane & (GROUP - 1);
@@ -371,7 +376,68 @@ hipError_t launch_r(const SwLaunch &L, bool multi, bool rev, hipStream_t stream)
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Fused prefilter -> align hand-over: what mmgpu_sw_prepare does on the host for caller
+// supplied lists, done on the device for the hit lists of a prefilter batch.  One workgroup per query: the list is
+// sorted by target length (longest first, stable) so that the targets a wavefront runs together end together;
+// hit_target / hit_out are written for the list's slots [q * stride, q * stride + count).
+__global__ __launch_bounds__(256) void sw_from_pf_kernel(SwFromPfArgs A) {
+    __shared__ uint32_t key[SW_PF_MAX_LIST];
+    const uint32_t q = blockIdx.x;
+    const uint32_t n = min(A.hit_count[q], A.stride);
+    const mmgpu_pf_hit *hits = A.pf_hits + (size_t)q * A.pf_stride;
+    uint32_t np2 = 1;
+    while (np2 < n) np2 <<= 1;
+    unsigned long long cells = 0;
+    const uint32_t qlen = A.q_off[q + 1] - A.q_off[q];
+    for (uint32_t k = threadIdx.x; k < np2; k += 256) {
+        uint32_t v = 0xFFFFFFFFu;
+        if (k < n) {
+            const uint32_t len = A.t_len[hits[k].id];
+            v = ((0xFFFFu - min(len, 0xFFFFu)) << 16) | k;      // length descending, list position ascending
+            cells += (unsigned long long)qlen * len;
+        }
+        key[k] = v;
+    }
+    __syncthreads();
+    for (uint32_t size = 2; size <= np2; size <<= 1) {
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            for (uint32_t k = threadIdx.x; k < np2 / 2; k += 256) {
+                const uint32_t i = 2 * k - (k & (stride - 1));
+                const uint32_t j = i + stride;
+                const bool up = (i & size) == 0;
+                const uint32_t a = key[i], b = key[j];
+                if ((a > b) == up) {
+                    key[i] = b;
+                    key[j] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    const uint32_t base = q * A.stride;
+    for (uint32_t r = threadIdx.x; r < n; r += 256) {
+        const uint32_t k = key[r] & 0xFFFFu;
+        A.hit_target[base + r] = hits[k].id;
+        A.hit_out[base + r] = base + k;
+    }
+    for (uint32_t r = n + threadIdx.x; r < A.stride; r += 256) {   // unused slots: defined contents
+        A.hit_target[base + r] = 0;
+        A.hit_out[base + r] = base + r;
+    }
+    // statistics (cells = forward DP cells, Alignment.cpp:380,530 convention)
+    for (int d = 1; d < 64; d <<= 1) cells += __shfl_xor(cells, d);
+    if ((threadIdx.x & 63u) == 0 && cells) atomicAdd(A.cells, cells);
+    if (threadIdx.x == 0 && n) atomicAdd(A.pairs, (unsigned long long)n);
+}
+
 }  // namespace
+
+hipError_t launch_sw_from_pf(const SwFromPfArgs &A, uint32_t nq, hipStream_t stream) {
+    if (nq == 0) return hipSuccess;
+    hipLaunchKernelGGL(sw_from_pf_kernel, dim3(nq), dim3(256), 0, stream, A);
+    return hipGetLastError();
+}
 
 size_t sw_lds_bytes(int rows_per_lane, int alphabet) {
     return (size_t)(alphabet + 1) * GROUP * lane_stride_bytes(rows_per_lane);

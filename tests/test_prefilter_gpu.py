@@ -275,3 +275,50 @@ def test_index_built_on_device_equals_host_index(gpu):
         n = int(counts[qi])
         assert np.array_equal(hits[qi]["id"][:n], exp[qi][0]) and np.array_equal(hits[qi]["score"][:n], exp[qi][1])
     chk.load_case(gpu, g, g["tres"], g["toff"], thr)
+
+
+def test_fused_prefilter_to_align_handover(gpu, matrices, oracle):
+    """mmgpu_sw_prepare_from_pf: the alignment of the prefilter's hit lists without the lists leaving the device gives,
+    slot by slot, what the two-call path through the host gives (and therefore what the oracle gives), incl. backtraces."""
+    from mmseqs2_amd import capi
+    g = pc.golden()
+    thr = int(g["kmer_thr"])
+    chk.load_case(gpu, g, g["tres"], g["toff"], thr)
+    qs = pc.golden_queries(g)
+    for qd in qs:
+        qd["identity_id"] = None
+    mat = matrices["blosum62_sw"]
+    sub16 = mat.astype(np.int16)
+    pfb = gpu.pf_prepare(qs, thr, max_hits=300, ref_bins=2)
+    pfb.run()
+    hits, counts, status, _ = pfb.fetch()
+    swq = [dict(q=qd["q"], comp_bias=capi.host_comp_bias(sub16, matrices["blosum62_pback"], qd["q"], lib=gpu.L)[1],
+                min_start_score=40) for qd in qs]
+    fused = gpu.sw_prepare_from_pf(mat, 11, 1, swq, pfb, mode=1)
+    fused.run()
+    fr = fused.fetch().reshape(len(qs), pfb.max_hits)
+    assert fused.pairs == int(counts.sum())
+    host_q = [dict(q=x["q"], comp_bias=x["comp_bias"], targets=hits[i]["id"][:counts[i]].copy(), min_start_score=40)
+              for i, x in enumerate(swq)]
+    sep = gpu.sw_prepare(mat, 11, 1, host_q, mode=1)
+    sep.run()
+    sr = sep.fetch()
+    assert sep.cells == fused.cells
+    off = 0
+    pick_f, pick_s = [], []
+    for i in range(len(qs)):
+        n = int(counts[i])
+        a, b = fr[i, :n], sr[off:off + n]
+        for f in ("score", "q_end", "t_end", "q_start", "t_start", "word"):
+            assert np.array_equal(a[f], b[f]), (i, f)
+        assert np.all(fr[i, n:]["score"] == 0)
+        for k in range(min(n, 3)):
+            pick_f.append(i * pfb.max_hits + k)
+            pick_s.append(off + k)
+        off += n
+    fi, fs = fused.traceback(np.array(pick_f, np.uint32))
+    si, ss = sep.traceback(np.array(pick_s, np.uint32))
+    assert fs == ss and np.array_equal(fi["ident"], si["ident"]) and np.array_equal(fi["status"], si["status"])
+    assert sum(1 for x in fs if x) > 20
+    for b in (fused, sep, pfb):
+        b.free()
