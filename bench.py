@@ -262,6 +262,11 @@ def search_section(args, gpu, torch, dist, rank, world, matrices, barrier):
                 full_lists.append((h[qi]["id"][:c[qi]].copy(), h[qi]["score"][:c[qi]].copy(), h[qi]["diagonal"][:c[qi]].copy()))
             nhits += int(c.sum())
 
+    if args.prefilter_only:      # counter passes (scripts/collect_profiles.sh): the prefilter kernels only
+        for b in batches:
+            b.free()
+        return {"prefilter_s": round(t_pf, 4), "db_matches": int(ent), "stage_ms_total_rank0": round(float(stage[6]), 2)} if rank == 0 else None
+
     # ---- spot check of the prefilter lists against the oracle on a reduced copy of the problem is done by the
     # tests; here: the alignment of the lists (Alignment::run behind the prefilter DB) ----
     mat = matrices["blosum62_sw"]
@@ -296,6 +301,57 @@ def search_section(args, gpu, torch, dist, rank, world, matrices, barrier):
     barrier()
     t_sw = (time.perf_counter() - t0) / args.pf_steps
     sw_cells, sw_pairs = swb.cells, swb.pairs
+    fused = None
+    if world == 1:
+        # the whole path as one device pipeline: prefilter batch -> hit lists sorted / scheduled on the device
+        # (mmgpu_sw_prepare_from_pf) -> alignment, nothing but the query descriptors crosses PCIe in between
+        msh = [gpu.sw_marshal_queries(mat, 11, 1, swq[i:i + bsz]) for i in range(0, nq, bsz)]
+        sep = swb.fetch()
+
+        def fused_pass(keep):
+            outs = []
+            for b, m in zip(batches, msh):
+                b.run()
+                fb = gpu.sw_prepare_from_pf(mat, 11, 1, None, b, mode=1, marshalled=m)
+                fb.run()
+                if keep:
+                    outs.append((fb.fetch().reshape(b.nq, -1), fb.cells, fb.pairs))
+                fb.free()
+            return outs
+
+        fused_pass(False)
+        gpu.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.pf_steps):
+            fused_pass(False)
+        gpu.synchronize()
+        t_fused = (time.perf_counter() - t0) / args.pf_steps
+        outs = fused_pass(True)
+        # where the pipeline's time goes (separate pass with a device sync after every call; sums to more than t_fused)
+        brk = np.zeros(4)
+        for b, m in zip(batches, msh):
+            ts = [time.perf_counter()]
+            b.run(); gpu.synchronize(); ts.append(time.perf_counter())
+            fb = gpu.sw_prepare_from_pf(mat, 11, 1, None, b, mode=1, marshalled=m); gpu.synchronize(); ts.append(time.perf_counter())
+            fb.run(); gpu.synchronize(); ts.append(time.perf_counter())
+            fb.free(); ts.append(time.perf_counter())
+            brk += np.diff(ts)
+        # slot by slot the same results as the two-call path through the host
+        bad, off, qi = 0, 0, 0
+        for fr, _, _ in outs:
+            for r in range(fr.shape[0]):
+                n = len(lists[qi])
+                a, bb = fr[r, :n], sep[off:off + n]
+                bad += int(sum(not np.array_equal(a[f], bb[f]) for f in ("score", "q_end", "t_end", "q_start", "t_start")))
+                off += n
+                qi += 1
+        fused = {"s": round(t_fused, 4), "queries_per_s": round(nq / t_fused, 1),
+                 "align_cells": int(sum(o[1] for o in outs)), "align_pairs": int(sum(o[2] for o in outs)),
+                 "queries_differing_from_two_call_path": bad,
+                 "synchronous_breakdown_ms": {"prefilter": round(brk[0] * 1e3, 2), "prepare_from_pf": round(brk[1] * 1e3, 2),
+                                              "align": round(brk[2] * 1e3, 2), "free": round(brk[3] * 1e3, 2)},
+                 "what": "per batch: prefilter, device-side list sort + job table, alignment (mmgpu_sw_prepare_from_pf); "
+                         "includes the alignment batch set-up (profile build, allocation)"}
     # backtraces (Matcher::SCORE_COV_SEQID / -a) for the hit lists of the first 1000 queries
     bt_n = int(sum(len(x) for x in lists[:1000]))
     t0 = time.perf_counter()
@@ -308,7 +364,7 @@ def search_section(args, gpu, torch, dist, rank, world, matrices, barrier):
     res = None
     if rank == 0:
         # the committed PMC passes were taken on exactly the default workload (10k x 1M, batches of 1024)
-        default_wl = (args.pf_families, args.pf_members, args.pf_queries, args.pf_batch) == (20000, 50, 10000, 1024)
+        default_wl = (args.pf_families, args.pf_members, args.pf_queries, args.pf_batch) == (20000, 50, 10000, 10000)
         traffic = pmc_traffic("pf_split_kernel") if default_wl else None
         # algorithmic HBM bytes of the gather/split kernel: ~20 B per index entry touched
         # (6 B entry gathered, 8 B written + 8 B re-read for the replay, amortised list descriptors)
@@ -319,8 +375,11 @@ def search_section(args, gpu, torch, dist, rank, world, matrices, barrier):
                         "-s 5.7 (k=6, k-mer thr %d), --max-seqs %d%s, then alignment of the hit lists (score, ends; starts for pairs passing -e 1e-3)"
                         % (nq, nt, args.pf_families, args.pf_members, kmer_thr, max_res,
                            " (per-split %d, Prefiltering.cpp:391-394)" % mh if world > 1 else ""),
-            "queries_per_s": round(nq / (t_pf + t_sw), 1), "prefilter_queries_per_s": round(nq / t_pf, 1),
-            "prefilter_s": round(t_pf, 4), "align_s": round(t_sw, 4), "handoff_s": round(t_handoff, 2),
+            # N = 1: the whole device pipeline incl. the hand-over (fused_pipeline); N > 1: prefilter (with the hit-list
+            # all-gather + merge) + alignment (with the result exchange), host-side list hand-over excluded
+            "queries_per_s": round(nq / t_fused, 1) if fused is not None else round(nq / (t_pf + t_sw), 1),
+            "queries_per_s_stages_only": round(nq / (t_pf + t_sw), 1), "prefilter_queries_per_s": round(nq / t_pf, 1),
+            "prefilter_s": round(t_pf, 4), "align_s": round(t_sw, 4), "handoff_s": round(t_handoff, 2), "fused_pipeline": fused,
             "targets_total": nt * world, "n_gpus": world,
             "stage_ms": {"kmers_lists": round(stage[0], 2), "gather_split": round(stage[1], 2), "replay_score_keepmax": round(stage[2], 2),
                          "large_bins_score": round(stage[3], 2), "large_bins_keepmax_and_overflow_path": round(stage[4], 2),
@@ -363,8 +422,9 @@ def main():
     ap.add_argument("--pf-families", type=int, default=20000)
     ap.add_argument("--pf-members", type=int, default=50)
     ap.add_argument("--pf-queries", type=int, default=10000)
-    ap.add_argument("--pf-batch", type=int, default=1024)
+    ap.add_argument("--pf-batch", type=int, default=10000)
     ap.add_argument("--pf-steps", type=int, default=2)
+    ap.add_argument("--prefilter-only", action="store_true", help="configs[2] section: stop after the prefilter (counter passes)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
 

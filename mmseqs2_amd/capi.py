@@ -358,17 +358,21 @@ class MMGpu:
         self._check(self.L.mmgpu_sw_prepare(self.ctx, ctypes.byref(par), ctypes.cast(arr, c_p), len(queries), mode, ctypes.byref(h)))
         return SwBatch(self, h, keep)
 
-    def sw_prepare_from_pf(self, mat, gap_open, gap_extend, queries, pf_batch, mode=1):
-        """Alignment batch over the hit lists of a prefilter batch that has been run, lists stay on the device.
-        queries: dicts with q, comp_bias (int8), min_start_score.  fetch() returns n_queries * stride slots."""
+    def sw_marshal_queries(self, mat, gap_open, gap_extend, queries):
+        """Query descriptors for sw_prepare_from_pf, built once (the ctypes marshalling is binding cost, not path cost)."""
         qd = [dict(q=x["q"], comp_bias=x.get("comp_bias"), targets=np.zeros(0, np.uint32),
                    min_start_score=x.get("min_start_score", 0)) for x in queries]
-        par, arr, keep = self._marshal(mat, gap_open, gap_extend, qd)
+        return self._marshal(mat, gap_open, gap_extend, qd) + (len(queries),)
+
+    def sw_prepare_from_pf(self, mat, gap_open, gap_extend, queries, pf_batch, mode=1, marshalled=None):
+        """Alignment batch over the hit lists of a prefilter batch that has been run, lists stay on the device.
+        queries: dicts with q, comp_bias (int8), min_start_score.  fetch() returns n_queries * stride slots."""
+        par, arr, keep, n = marshalled if marshalled is not None else self.sw_marshal_queries(mat, gap_open, gap_extend, queries)
         h = c_p()
-        self._check(self.L.mmgpu_sw_prepare_from_pf(self.ctx, ctypes.byref(par), ctypes.cast(arr, c_p), len(queries), mode,
+        self._check(self.L.mmgpu_sw_prepare_from_pf(self.ctx, ctypes.byref(par), ctypes.cast(arr, c_p), n, mode,
                                                     pf_batch.handle, ctypes.byref(h)))
         b = SwBatch(self, h, keep)
-        b.slots = len(queries) * pf_batch.max_hits
+        b.slots = n * pf_batch.max_hits
         return b
 
     # ---- prefilter ----

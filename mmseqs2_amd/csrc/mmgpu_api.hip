@@ -46,6 +46,11 @@ extern "C" void mmgpu_destroy(mmgpu_ctx *c) {
     (void)hipSetDevice(c->device);
     free_db(c->db);
     mmgpu::pf_index_free(c);
+    (void)hipDeviceSynchronize();
+    for (auto &st : c->side) if (st) (void)hipStreamDestroy(st);
+    if (c->fork) (void)hipEventDestroy(c->fork);
+    for (auto &e : c->join) if (e) (void)hipEventDestroy(e);
+    c->cache.trim();
     delete c;
 }
 
@@ -113,6 +118,9 @@ extern "C" int mmgpu_load_targets(mmgpu_ctx *c, const uint8_t *residues, const u
     db.alphabet = alphabet;
     c->db = db;
     c->h_len.assign(len.begin(), len.begin() + n);
+    uint64_t res_total = 0;
+    for (uint32_t i = 0; i < n; i++) res_total += len[i];
+    c->mean_len = n ? (uint32_t)(res_total / n) : 0;
     return MMGPU_OK;
 }
 
@@ -151,19 +159,11 @@ extern "C" int mmgpu_host_round_comp_bias(const float *bias, uint32_t len, int8_
 // Smith-Waterman batches
 // ---------------------------------------------------------------------------------------------------------
 namespace {
-constexpr uint32_t JOB_HITS = 256;   // most hits per workgroup (8 rounds of 32)
+constexpr uint32_t JOB_HITS = 256;   // most hits per workgroup (8 rounds of 32); the reverse pass packs a job with one thread per hit (sw_kernel.hip)
+static_assert(JOB_HITS <= 256, "a job may hold at most one hit per thread of the 256-thread workgroup");
 constexpr uint32_t JOB_ROUND = 32;   // targets a workgroup has in flight
 constexpr uint64_t JOB_CELLS = 60000000ull;   // cut a job once it holds this many forward cells
-constexpr int SW_STREAMS = 8;        // kernel instantiations (classes) run concurrently on side streams
-
-struct SwClass {            // all jobs sharing one kernel instantiation
-    int rows_per_lane = 0;
-    bool multi = false;
-    std::vector<SwJob> jobs;
-    std::vector<uint64_t> job_cells;
-    DevBuf d_jobs;
-    DevBuf d_scratch;   // multi-tile classes: [job][4 waves][4 groups][2 buffers][scratch_cols] x uint2
-};
+constexpr uint32_t LONG_QUERY = 1024;  // multi-tile queries from this length on are scheduled per wave (8 targets)
 }  // namespace
 
 struct mmgpu_sw_batch_t {
@@ -172,7 +172,12 @@ struct mmgpu_sw_batch_t {
     uint64_t cells = 0, pairs = 0;
     uint64_t valid_pairs = 0;   // from_pf: slots actually holding a hit (pairs counts all slots)
     uint32_t n_queries = 0;
-    std::vector<SwClass> classes;
+    // all jobs of the batch, by kernel group (sw_kernel.hip), longest first inside a group; SwJob::shape picks the body
+    uint32_t n_jobs = 0, n_multi_jobs = 0;
+    uint32_t group_begin[SW_GROUPS + 1] = {0, 0, 0, 0};
+    size_t group_lds[SW_GROUPS] = {0, 0, 0};   // largest profile of any shape present in the group
+    DevBuf d_jobs;
+    DevBuf d_scratch;             // multi-tile jobs: [scratch slot][4 waves][4 groups][2 buffers][scratch_cols] x uint2
     DevBuf d_qres, d_qcb, d_qoff, d_qbias, d_qminstart, d_hit_target, d_hit_out, d_out, d_mat;
     // fused hand-over from a prefilter batch (mmgpu_sw_prepare_from_pf): lists, counts and statistics live on the device
     bool from_pf = false;
@@ -184,9 +189,6 @@ struct mmgpu_sw_batch_t {
     std::vector<uint32_t> h_qout_off;     // [nq + 1] first result slot of every query
     std::vector<uint32_t> h_qoff;         // [nq + 1] residue offsets
     DevBuf d_bt_scratch, d_bt_jobs, d_bt_info, d_bt_str;
-    std::vector<hipStream_t> side;   // side streams the classes run on
-    hipEvent_t fork = nullptr;
-    std::vector<hipEvent_t> join;
     uint32_t scratch_cols = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;   // one pair per mmgpu_sw_run since prepare
     bool ran = false;
@@ -229,6 +231,9 @@ static int sw_prepare_impl(mmgpu_ctx *c, const mmgpu_sw_params *par, const mmgpu
     b->gap_open = par->gap_open;
     b->gap_extend = par->gap_extend;
     b->n_queries = nq;
+    for (DevBuf *d : {&b->d_qres, &b->d_qcb, &b->d_qoff, &b->d_qbias, &b->d_qminstart, &b->d_hit_target, &b->d_hit_out, &b->d_out,
+                      &b->d_mat, &b->d_stats, &b->d_bt_scratch, &b->d_bt_jobs, &b->d_bt_info, &b->d_bt_str})
+        d->bind(&c->cache);
 
     std::vector<uint8_t> qres;
     std::vector<int8_t> qcb;
@@ -244,11 +249,11 @@ static int sw_prepare_impl(mmgpu_ctx *c, const mmgpu_sw_params *par, const mmgpu
     qres.resize(qoff[nq]);
     qcb.assign(qoff[nq], 0);
     std::vector<uint32_t> hit_target(pf ? 0 : (size_t)total_hits), hit_out(pf ? 0 : (size_t)total_hits);
-    b->classes.resize(32);   // [0,16): single tile R = 2..32, [16,32): multi-tile
-    for (int k = 0; k < 32; k++) {
-        b->classes[k].rows_per_lane = 2 * (k % 16 + 1);
-        b->classes[k].multi = k >= 16;
-    }
+    b->d_jobs.bind(&c->cache);
+    b->d_scratch.bind(&c->cache);
+    std::vector<SwJob> jobs;
+    std::vector<uint64_t> job_cells;
+    uint32_t n_multi = 0;
     std::vector<uint32_t> order;
     uint32_t hit_cursor = 0, out_cursor = 0;
     b->h_qout_off.assign(nq + 1, 0);
@@ -272,18 +277,28 @@ static int sw_prepare_impl(mmgpu_ctx *c, const mmgpu_sw_params *par, const mmgpu
         int rpl; bool multi;
         pick_class(Q.qlen, &rpl, &multi);
         any_multi |= multi;
-        SwClass &cls = b->classes[(multi ? 16 : 0) + rpl / 2 - 1];
+        const uint32_t shape = (multi ? 16u : 0u) + (uint32_t)rpl / 2 - 1;   // [0,16): single tile R = 2..32, [16,32): multi-tile
+        const int grp = sw_shape_group(shape);
+        b->group_lds[grp] = std::max(b->group_lds[grp], sw_lds_bytes(rpl, par->alphabet));
+        // jobs are cut at multiples of one workgroup round (4 waves x 8 targets); for queries of several tiles a
+        // single wave's 8 targets already run for milliseconds, so those are cut per wave to shorten the tail
+        const uint32_t round = (multi && Q.qlen >= LONG_QUERY) ? JOB_ROUND / 4 : JOB_ROUND;
         if (pf) {
-            // the list is on the device: fixed jobs of one workgroup round each over the query's slots, the kernel
-            // clips them to the list length (SwLaunch::q_hit_count); order and statistics come from sw_from_pf_kernel
-            for (uint32_t k = 0; k < pf_stride; k += JOB_ROUND) {
+            // the list is on the device: fixed jobs over the query's slots, the kernel clips them to the list length
+            // (SwLaunch::q_hit_count); order and statistics come from sw_from_pf_kernel.  Hits per job: as many rounds as fit JOB_CELLS at the length the hits will probably have (prefilter hits are
+            // mostly about as long as the query; the database mean otherwise)
+            const uint64_t est_cells = (uint64_t)Q.qlen * ((Q.qlen + c->mean_len) / 2 + 1) * round;
+            const uint32_t per_job = round * (uint32_t)std::min<uint64_t>(JOB_HITS / round, std::max<uint64_t>(1, JOB_CELLS / est_cells));
+            for (uint32_t k = 0; k < pf_stride; k += per_job) {
                 SwJob j;
                 j.query = i;
                 j.hit_begin = hit_cursor + k;
-                j.hit_end = hit_cursor + std::min<uint32_t>(k + JOB_ROUND, pf_stride);
-                j.pad = 0;
-                cls.jobs.push_back(j);
-                cls.job_cells.push_back(0);
+                j.hit_end = hit_cursor + std::min<uint32_t>(k + per_job, pf_stride);
+                j.shape = shape | (multi ? n_multi++ << 8 : 0u);
+                jobs.push_back(j);
+                // stand-in for the cell count the host cannot see: query length x slots; the lists are sorted by
+                // target length on the device, so among equals a query's earlier jobs hold the longer targets
+                job_cells.push_back((uint64_t)Q.qlen * (j.hit_end - j.hit_begin) * 4096u + (pf_stride - k));
             }
             max_tlen = c->db.max_len;
             hit_cursor += pf_stride;
@@ -316,7 +331,7 @@ static int sw_prepare_impl(mmgpu_ctx *c, const mmgpu_sw_params *par, const mmgpu
             uint64_t jc = 0;
             uint32_t e = k;
             while (e < Q.n_targets && e - k < JOB_HITS) {
-                const uint32_t stop = std::min<uint32_t>(e + JOB_ROUND, Q.n_targets);
+                const uint32_t stop = std::min<uint32_t>(e + round, Q.n_targets);
                 for (; e < stop; e++) jc += (uint64_t)Q.qlen * c->h_len[hit_target[hit_cursor + e]];
                 if (jc >= JOB_CELLS) break;
             }
@@ -324,9 +339,9 @@ static int sw_prepare_impl(mmgpu_ctx *c, const mmgpu_sw_params *par, const mmgpu
             j.query = i;
             j.hit_begin = hit_cursor + k;
             j.hit_end = hit_cursor + e;
-            j.pad = 0;
-            cls.jobs.push_back(j);
-            cls.job_cells.push_back(jc);
+            j.shape = shape | (multi ? n_multi++ << 8 : 0u);
+            jobs.push_back(j);
+            job_cells.push_back(jc);
             k = e;
         }
         if (mode >= MMGPU_SW_START)
@@ -354,29 +369,36 @@ static int sw_prepare_impl(mmgpu_ctx *c, const mmgpu_sw_params *par, const mmgpu
     if (pf) {
         B_TRY(b->d_hit_target.alloc(std::max<size_t>((size_t)total_hits, 1) * 4));
         B_TRY(b->d_hit_out.alloc(std::max<size_t>((size_t)total_hits, 1) * 4));
-        B_TRY(b->d_stats.alloc(16));
-        B_TRY(hipMemsetAsync(b->d_stats.p, 0, 16, s));
+        B_TRY(b->d_stats.alloc(24));
+        B_TRY(hipMemsetAsync(b->d_stats.p, 0, 24, s));
     } else {
         B_TRY(upload(b->d_hit_target, hit_target, s));
         B_TRY(upload(b->d_hit_out, hit_out, s));
     }
     B_TRY(upload(b->d_mat, mat, s));
     B_TRY(b->d_out.alloc(std::max<size_t>((size_t)total_hits, 1) * sizeof(mmgpu_sw_hit)));
-    for (auto &cls : b->classes) {
+    {
         // longest job first: the dispatcher hands out workgroups in blockIdx order, so the tail is the shortest jobs
-        std::vector<uint32_t> ord(cls.jobs.size());
+        if (n_multi >= (1u << 24)) { delete b; return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_sw_prepare: more than 2^24 multi-tile jobs in one batch"); }
+        std::vector<uint32_t> ord(jobs.size());
         std::iota(ord.begin(), ord.end(), 0u);
-        std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t bb) { return cls.job_cells[a] > cls.job_cells[bb]; });
-        std::vector<SwJob> sorted(cls.jobs.size());
-        for (size_t z = 0; z < ord.size(); z++) sorted[z] = cls.jobs[ord[z]];
-        cls.jobs.swap(sorted);
-        B_TRY(upload(cls.d_jobs, cls.jobs, s));
+        std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t bb) {
+            const int ga = sw_shape_group(jobs[a].shape & 0xFFu), gb = sw_shape_group(jobs[bb].shape & 0xFFu);
+            return ga != gb ? ga < gb : job_cells[a] > job_cells[bb];
+        });
+        std::vector<SwJob> sorted(jobs.size());
+        for (size_t z = 0; z < ord.size(); z++) {
+            sorted[z] = jobs[ord[z]];
+            b->group_begin[sw_shape_group(sorted[z].shape & 0xFFu) + 1]++;
+        }
+        for (int g = 0; g < SW_GROUPS; g++) b->group_begin[g + 1] += b->group_begin[g];
+        b->n_jobs = (uint32_t)sorted.size();
+        b->n_multi_jobs = n_multi;
+        B_TRY(upload(b->d_jobs, sorted, s));
     }
-    if (any_multi) {
+    if (any_multi && !pf) {
         b->scratch_cols = max_tlen + 16;
-        for (auto &cls : b->classes)
-            if (cls.multi && !cls.jobs.empty())
-                B_TRY(cls.d_scratch.alloc(cls.jobs.size() * 4 * 4 * 2 * (size_t)b->scratch_cols * sizeof(uint2)));
+        B_TRY(b->d_scratch.alloc((size_t)n_multi * 4 * 4 * 2 * (size_t)b->scratch_cols * sizeof(uint2)));
     }
     if (pf) {
         B_TRY(hipMemsetAsync(b->d_out.p, 0, std::max<size_t>((size_t)total_hits, 1) * sizeof(mmgpu_sw_hit), s));
@@ -395,10 +417,14 @@ static int sw_prepare_impl(mmgpu_ctx *c, const mmgpu_sw_params *par, const mmgpu
     }
     B_TRY(hipStreamSynchronize(s));   // the host vectors above die with this scope
     if (pf) {
-        unsigned long long st[2] = {0, 0};
-        B_TRY(hipMemcpy(st, b->d_stats.p, 16, hipMemcpyDeviceToHost));
+        unsigned long long st[3] = {0, 0, 0};
+        B_TRY(hipMemcpy(st, b->d_stats.p, 24, hipMemcpyDeviceToHost));
         b->cells = st[0];
         b->valid_pairs = st[1];
+        if (any_multi) {   // column scratch of the multi-tile classes, sized by the longest target any list holds
+            b->scratch_cols = (uint32_t)st[2] + 16;
+            B_TRY(b->d_scratch.alloc((size_t)n_multi * 4 * 4 * 2 * (size_t)b->scratch_cols * sizeof(uint2)));
+        }
     }
 #undef B_TRY
     *out = b;
@@ -426,25 +452,29 @@ extern "C" int mmgpu_sw_run(mmgpu_ctx *c, mmgpu_sw_batch_t *b) {
         b->events.push_back(std::make_pair(ev0, ev1));
         HIP_TRY(hipEventRecord(ev0, c->stream));
     }
-    // Every class is its own kernel instantiation with its own (often small) grid: run them concurrently on side
-    // streams forked from the context's stream; the reverse scan of a class follows its forward scan in-stream.
-    if (b->side.empty()) {
-        b->side.resize(SW_STREAMS);
-        for (auto &st : b->side) HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-        HIP_TRY(hipEventCreateWithFlags(&b->fork, hipEventDisableTiming));
-        b->join.resize(SW_STREAMS);
-        for (auto &e : b->join) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    // one launch per pass and kernel group (jobs longest first); the groups run concurrently on side streams forked
+    // from / joined to the context's stream, and the reverse scan of a group follows
+    // its forward scan in-stream (it reads the forward results of its own pairs only)
+    if (!c->fork) {
+        // the group with the long multi-tile jobs gets the highest stream priority: its forward + reverse chain is
+        // the critical path, the other groups fill the CUs it leaves
+        int prio_low = 0, prio_high = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));   // numerically lower = higher priority
+        for (int g = 0; g < SW_GROUPS; g++) {
+            const int prio = g == SW_GROUPS - 1 ? prio_high : (g == 0 ? prio_low : (prio_low + prio_high) / 2);
+            HIP_TRY(hipStreamCreateWithPriority(&c->side[g], hipStreamNonBlocking, prio));
+        }
+        HIP_TRY(hipEventCreateWithFlags(&c->fork, hipEventDisableTiming));
+        for (auto &e : c->join) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
-    HIP_TRY(hipEventRecord(b->fork, c->stream));
-    for (auto &st : b->side) HIP_TRY(hipStreamWaitEvent(st, b->fork, 0));
-    int slot = 0;
-    for (auto &cls : b->classes) {
-        if (cls.jobs.empty()) continue;
-        hipStream_t st = b->side[slot++ % SW_STREAMS];
+    HIP_TRY(hipEventRecord(c->fork, c->stream));
+    for (auto &st : c->side) HIP_TRY(hipStreamWaitEvent(st, c->fork, 0));
+    for (int g = SW_GROUPS - 1; g >= 0; g--) {
+        hipStream_t st = c->side[g];
         for (int pass = 0; pass < (b->mode == MMGPU_SW_START ? 2 : 1); pass++) {
             SwLaunch L;
-            L.jobs = cls.d_jobs.as<SwJob>();
-            L.n_jobs = (uint32_t)cls.jobs.size();
+            L.jobs = b->d_jobs.as<SwJob>() + b->group_begin[g];
+            L.n_jobs = b->group_begin[g + 1] - b->group_begin[g];
             L.q_res = b->d_qres.as<uint8_t>();
             L.q_cb = b->d_qcb.as<int8_t>();
             L.q_off = b->d_qoff.as<uint32_t>();
@@ -462,14 +492,14 @@ extern "C" int mmgpu_sw_run(mmgpu_ctx *c, mmgpu_sw_batch_t *b) {
             L.gap_extend = b->gap_extend;
             L.q_hit_count = b->from_pf ? b->pf_counts : nullptr;
             L.hit_stride = b->slot_stride;
-            L.scratch = cls.d_scratch.as<uint2>();
+            L.scratch = b->d_scratch.as<uint2>();
             L.scratch_cols = b->scratch_cols;
-            HIP_TRY(launch_sw(L, cls.rows_per_lane, cls.multi, pass == 1, st));
+            HIP_TRY(launch_sw(L, g, b->group_lds[g], pass == 1, st));
         }
     }
-    for (int k = 0; k < SW_STREAMS; k++) {
-        HIP_TRY(hipEventRecord(b->join[k], b->side[k]));
-        HIP_TRY(hipStreamWaitEvent(c->stream, b->join[k], 0));
+    for (int k = 0; k < SW_GROUPS; k++) {
+        HIP_TRY(hipEventRecord(c->join[k], c->side[k]));
+        HIP_TRY(hipStreamWaitEvent(c->stream, c->join[k], 0));
     }
     if (ev1) HIP_TRY(hipEventRecord(ev1, c->stream));
     b->ran = true;
@@ -523,9 +553,6 @@ extern "C" void mmgpu_sw_free(mmgpu_ctx *c, mmgpu_sw_batch_t *b) {
     if (!b) return;
     if (c) (void)hipSetDevice(c->device);
     for (auto &e : b->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
-    for (auto &st : b->side) (void)hipStreamDestroy(st);
-    if (b->fork) (void)hipEventDestroy(b->fork);
-    for (auto &e : b->join) (void)hipEventDestroy(e);
     delete b;
 }
 

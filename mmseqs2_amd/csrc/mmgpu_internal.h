@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <string>
+#include <map>
 #include <vector>
 
 #include "../../include/mmgpu.h"
@@ -30,7 +31,7 @@ struct SwJob {
     uint32_t query;
     uint32_t hit_begin;
     uint32_t hit_end;
-    uint32_t pad;
+    uint32_t shape;   // low 8 bits: tile shape (rows per lane / 2 - 1, + 16 for multi-tile); high 24: multi-tile scratch slot
 };
 
 // Everything a Smith-Waterman launch needs, device pointers only.
@@ -56,7 +57,7 @@ struct SwLaunch {
     const int8_t *mat;        // alphabet*alphabet
     int alphabet;
     int gap_open, gap_extend;
-    // multi-tile scratch (H/F boundary rows), [n_jobs][4 waves][4 groups][scratch_cols] x uint2
+    // multi-tile scratch (H/F boundary rows), [scratch slot][4 waves][4 groups][2][scratch_cols] x uint2
     uint2 *scratch;
     uint32_t scratch_cols;
     // fused hand-over from a prefilter batch: hits of query q live in slots [q * hit_stride, + q_hit_count[q])
@@ -81,7 +82,9 @@ hipError_t launch_sw_from_pf(const SwFromPfArgs &A, uint32_t nq, hipStream_t str
 
 // rows_per_lane in {8,16,24,32}: a 16-lane group covers 16*rows_per_lane query rows per tile.
 // reverse = false: forward score/end scan; true: start-position scan over the reversed prefixes.
-hipError_t launch_sw(const SwLaunch &L, int rows_per_lane, bool multi_tile, bool reverse, hipStream_t stream);
+constexpr int SW_GROUPS = 3;   // kernels per pass: tile shapes grouped by register need (sw_kernel.hip)
+int sw_shape_group(uint32_t shape);
+hipError_t launch_sw(const SwLaunch &L, int group, size_t lds_bytes, bool reverse, hipStream_t stream);
 size_t sw_lds_bytes(int rows_per_lane, int alphabet);
 
 // ---------------------------------------------------------------------------------------------------------
@@ -314,18 +317,75 @@ inline int fail(int code, const std::string &msg) {
             return mmgpu::fail(MMGPU_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));         \
     } while (0)
 
+// Freed device blocks of one context, kept for the next batch: a streaming search prepares and frees one alignment
+// batch per prefilter batch, and hipMalloc / hipFree (which also drains the device) per buffer would cost more than
+// the kernels.  Reuse is safe because every use of a block is ordered on the context's stream.  Sizes are rounded to 3 significant bits so that batches of
+// similar shape hit the same classes.
+struct BlockCache {
+    std::multimap<size_t, void *> blocks;
+    size_t cached = 0;
+    static constexpr size_t LIMIT = 32ull << 30;
+    static size_t round_up(size_t n) {
+        if (n <= 512) return 512;
+        int top = 63 - __builtin_clzll((unsigned long long)n);
+        const size_t step = (size_t)1 << (top - 2);
+        return (n + step - 1) & ~(step - 1);
+    }
+    void *take(size_t cap) {
+        auto it = blocks.find(cap);
+        if (it == blocks.end()) return nullptr;
+        void *p = it->second;
+        blocks.erase(it);
+        cached -= cap;
+        return p;
+    }
+    void give(void *p, size_t cap) {
+        if (cached + cap > LIMIT) { (void)hipFree(p); return; }
+        blocks.emplace(cap, p);
+        cached += cap;
+    }
+    void trim() {
+        for (auto &kv : blocks) (void)hipFree(kv.second);
+        blocks.clear();
+        cached = 0;
+    }
+};
+
 struct DevBuf {
     void *p = nullptr;
     size_t bytes = 0;
+    size_t cap = 0;                // allocated size when the block came from / goes back to a cache
+    BlockCache *cache = nullptr;   // optional (bind): where freed blocks go
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
-    DevBuf(DevBuf &&o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
-    ~DevBuf() { if (p) (void)hipFree(p); }
+    DevBuf(DevBuf &&o) noexcept : p(o.p), bytes(o.bytes), cap(o.cap), cache(o.cache) { o.p = nullptr; o.bytes = 0; o.cap = 0; }
+    ~DevBuf() { release(); }
+    void bind(BlockCache *c) { cache = c; }
+    void release() {
+        if (!p) return;
+        if (cache && cap) cache->give(p, cap);
+        else (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
     hipError_t alloc(size_t n) {
-        if (p) { (void)hipFree(p); p = nullptr; }
+        release();
         bytes = n;
         if (n == 0) return hipSuccess;
+        if (cache) {
+            cap = BlockCache::round_up(n);
+            p = cache->take(cap);
+            if (p) return hipSuccess;
+            hipError_t e = hipMalloc(&p, cap);
+            if (e != hipSuccess) {      // out of memory with blocks parked in the cache: give them back and retry
+                (void)hipGetLastError();
+                cache->trim();
+                e = hipMalloc(&p, cap);
+            }
+            if (e != hipSuccess) { p = nullptr; cap = 0; }
+            return e;
+        }
         return hipMalloc(&p, n);
     }
     // grow-only (contents are not preserved)
@@ -350,9 +410,14 @@ struct mmgpu_ctx {
     hipStream_t stream = nullptr;
     mmgpu::DeviceDb db;
     std::vector<uint32_t> h_len;   // host copy of target lengths (scheduling)
+    uint32_t mean_len = 0;
     int compute_units = 0;
     std::string name;
     mmgpu::PfIndex *pf = nullptr;  // prefilter index resident in HBM (pf_api.hip)
+    mmgpu::BlockCache cache;       // device blocks of freed alignment batches
+    // the alignment kernel groups run concurrently on side streams forked from / joined to `stream` (mmgpu_sw_run)
+    hipStream_t side[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t fork = nullptr, join[3] = {nullptr, nullptr, nullptr};
 };
 
 struct mmgpu_pf_batch_t;

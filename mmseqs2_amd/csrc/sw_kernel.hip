@@ -110,16 +110,12 @@ __device__ __forceinline__ void build_profile(unsigned char *lds, const uint8_t 
 }
 
 template <int R, bool MULTI, bool REV>
-__global__ __launch_bounds__(WAVES * 64) void sw_kernel(SwLaunch L) {
+__device__ __forceinline__ void sw_body(const SwLaunch &L, const SwJob job) {
     using T = Tile<R>;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-
-    SwJob job = L.jobs[blockIdx.x];
-    if (L.q_hit_count) {   // fused prefilter -> align hand-over: the list length of the query is only known on the device
-        const uint32_t lim = job.query * L.hit_stride + L.q_hit_count[job.query];
-        job.hit_end = job.hit_end < lim ? job.hit_end : lim;
-        if (job.hit_end <= job.hit_begin) return;
-    }
+    // A multi-tile job is one long dependent chain (tiles x columns) however few targets it holds, and the batch ends
+    // with the longest of them: those waves take the issue slots first, the short jobs sharing the SIMD fill the gaps.
+    if (MULTI) __builtin_amdgcn_s_setprio(3);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane & (GROUP - 1);
@@ -141,16 +137,45 @@ __global__ __launch_bounds__(WAVES * 64) void sw_kernel(SwLaunch L) {
         __syncthreads();
     }
 
-    const uint32_t n_hits = job.hit_end - job.hit_begin;
+    uint32_t n_hits = job.hit_end - job.hit_begin;
+    // Reverse pass: only the pairs whose forward score reaches the query's start-score threshold are scanned
+    // (ssw_align_private, StripedSmithWaterman.cpp:857-863) - typically one hit in six, scattered over the
+    // length-sorted list.  They are packed to the front (order kept), so that the waves run full instead of every
+    // wave waiting for its one or two live targets.
+    __shared__ uint16_t live[WAVES * 64];
+    __shared__ uint32_t live_wave[WAVES];
+    if (REV) {
+        const int min_start = L.q_minstart[job.query];
+        bool pass = false;
+        if (threadIdx.x < n_hits) {   // a job holds at most WAVES * 64 hits (JOB_HITS)
+            const int s = (int)L.out[L.hit_out[job.hit_begin + threadIdx.x]].score;
+            pass = s > 0 && s >= min_start;
+        }
+        const unsigned long long bal = __ballot(pass);
+        if (lane == 0) live_wave[wave] = (uint32_t)__popcll(bal);
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) {
+            const uint32_t c = live_wave[w];
+            before += w < wave ? c : 0u;
+            total += c;
+        }
+        if (pass) live[before + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)threadIdx.x;
+        __syncthreads();
+        n_hits = total;
+    }
     const uint32_t n_iter = (n_hits + WAVES * HITS_PER_WAVE - 1) / (WAVES * HITS_PER_WAVE);
 
     for (uint32_t it = 0; it < n_iter; ++it) {
-        const uint32_t base = job.hit_begin + (it * WAVES + wave) * HITS_PER_WAVE;
-        if (!MULTI && base >= job.hit_end) break;   // wave-uniform; MULTI keeps every wave in the barrier loop
+        const uint32_t slot0 = (it * WAVES + wave) * HITS_PER_WAVE;
+        if (!MULTI && slot0 >= n_hits) break;   // wave-uniform; MULTI keeps every wave in the barrier loop
 
         // ---- the two targets of this group ------------------------------------------------------
-        const uint32_t hA = base + grp * 2, hB = hA + 1;
-        const bool vA = hA < job.hit_end, vB = hB < job.hit_end;
+        const uint32_t sA = slot0 + grp * 2, sB = sA + 1;
+        const bool vA = sA < n_hits, vB = sB < n_hits;
+        const uint32_t hA = job.hit_begin + (REV ? (uint32_t)live[vA ? sA : 0] : sA);
+        const uint32_t hB = job.hit_begin + (REV ? (uint32_t)live[vB ? sB : 0] : sB);
         const uint32_t tA = vA ? L.hit_target[hA] : 0u, tB = vB ? L.hit_target[hB] : 0u;
         const uint8_t *pA = L.t_res + (size_t)L.t_off4[tA] * 4;
         const uint8_t *pB = L.t_res + (size_t)L.t_off4[tB] * 4;
@@ -176,7 +201,7 @@ __global__ __launch_bounds__(WAVES * 64) void sw_kernel(SwLaunch L) {
         unsigned long long bestA = 0, bestB = 0;   // (score << 32) | (~col << 16) | ~row, maximised
 
         uint2 *scr = nullptr;
-        if (MULTI) scr = L.scratch + ((size_t)(blockIdx.x * WAVES + wave) * GROUPS_PER_WAVE + grp) * 2 * L.scratch_cols;
+        if (MULTI) scr = L.scratch + ((size_t)((job.shape >> 8) * WAVES + wave) * GROUPS_PER_WAVE + grp) * 2 * L.scratch_cols;
 
         for (int tile = 0; tile < n_tiles; ++tile) {
             const int tile_base = tile * T::ROWS;
@@ -360,20 +385,43 @@ __global__ __launch_bounds__(WAVES * 64) void sw_kernel(SwLaunch L) {
     }
 }
 
-template <int R>
-hipError_t launch_r(const SwLaunch &L, bool multi, bool rev, hipStream_t stream) {
-    const size_t lds = (size_t)(L.alphabet + 1) * Tile<R>::ROW_STRIDE;
-    dim3 grid(L.n_jobs), block(WAVES * 64);
-    if (L.n_jobs == 0) return hipSuccess;
-    if (!multi && !rev) hipLaunchKernelGGL((sw_kernel<R, false, false>), grid, block, lds, stream, L);
-    else if (!multi && rev) hipLaunchKernelGGL((sw_kernel<R, false, true>), grid, block, lds, stream, L);
-    else if constexpr (R >= 18) {
-        if (!rev) hipLaunchKernelGGL((sw_kernel<R, true, false>), grid, block, lds, stream, L);
-        else hipLaunchKernelGGL((sw_kernel<R, true, true>), grid, block, lds, stream, L);
-    } else {
-        return hipErrorInvalidValue;
+// Three launches per pass for the whole batch.  The tile shape (rows per lane R, single / multi tile) is a property
+// of the job: every shape is its own instantiation of sw_body, picked per workgroup.  A launch per shape (32 kernels
+// with grids from 50 to 3000 workgroups on side streams) left the chip underfilled - the runtime maps streams onto
+// four hardware queues, and the long multi-tile jobs of the few long queries ran nearly alone at the end.  Shapes
+// are grouped by register need instead (a kernel gets the registers of its largest body, which sets the occupancy of
+// all of them): S = R <= 12 (forward 80 / reverse 119 VGPRs), M = R 14..24 (140 / 212), L = R >= 26 and every
+// multi-tile shape (212 / 256).  Each group is one grid, longest job first; the three run concurrently.
+template <int G, bool REV>
+__global__ __launch_bounds__(WAVES * 64) void sw_kernel(SwLaunch L) {
+    SwJob job = L.jobs[blockIdx.x];
+    if (L.q_hit_count) {   // fused prefilter -> align hand-over: the list length of the query is only known on the device
+        const uint32_t lim = job.query * L.hit_stride + L.q_hit_count[job.query];
+        job.hit_end = job.hit_end < lim ? job.hit_end : lim;
+        if (job.hit_end <= job.hit_begin) return;
     }
-    return hipGetLastError();
+#define MMGPU_SW_SINGLE(R) case (R) / 2 - 1: sw_body<R, false, REV>(L, job); break;
+#define MMGPU_SW_MULTI(R) case 16 + (R) / 2 - 1: sw_body<R, true, REV>(L, job); break;
+    if constexpr (G == 0) {
+        switch (job.shape & 0xFFu) {   // workgroup-uniform
+            MMGPU_SW_SINGLE(2) MMGPU_SW_SINGLE(4) MMGPU_SW_SINGLE(6) MMGPU_SW_SINGLE(8) MMGPU_SW_SINGLE(10) MMGPU_SW_SINGLE(12)
+            default: break;
+        }
+    } else if constexpr (G == 1) {
+        switch (job.shape & 0xFFu) {
+            MMGPU_SW_SINGLE(14) MMGPU_SW_SINGLE(16) MMGPU_SW_SINGLE(18) MMGPU_SW_SINGLE(20) MMGPU_SW_SINGLE(22) MMGPU_SW_SINGLE(24)
+            default: break;
+        }
+    } else {
+        switch (job.shape & 0xFFu) {
+            MMGPU_SW_SINGLE(26) MMGPU_SW_SINGLE(28) MMGPU_SW_SINGLE(30) MMGPU_SW_SINGLE(32)
+            MMGPU_SW_MULTI(18) MMGPU_SW_MULTI(20) MMGPU_SW_MULTI(22) MMGPU_SW_MULTI(24) MMGPU_SW_MULTI(26) MMGPU_SW_MULTI(28)
+            MMGPU_SW_MULTI(30) MMGPU_SW_MULTI(32)
+            default: break;
+        }
+    }
+#undef MMGPU_SW_SINGLE
+#undef MMGPU_SW_MULTI
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -428,7 +476,10 @@ __global__ __launch_bounds__(256) void sw_from_pf_kernel(SwFromPfArgs A) {
     // statistics (cells = forward DP cells, Alignment.cpp:380,530 convention)
     for (int d = 1; d < 64; d <<= 1) cells += __shfl_xor(cells, d);
     if ((threadIdx.x & 63u) == 0 && cells) atomicAdd(A.cells, cells);
-    if (threadIdx.x == 0 && n) atomicAdd(A.pairs, (unsigned long long)n);
+    if (threadIdx.x == 0 && n) {
+        atomicAdd(A.pairs, (unsigned long long)n);
+        atomicMax(A.pairs + 1, (unsigned long long)(0xFFFFu - (key[0] >> 16)));   // longest target of any list
+    }
 }
 
 }  // namespace
@@ -443,16 +494,27 @@ size_t sw_lds_bytes(int rows_per_lane, int alphabet) {
     return (size_t)(alphabet + 1) * GROUP * lane_stride_bytes(rows_per_lane);
 }
 
-hipError_t launch_sw(const SwLaunch &L, int rows_per_lane, bool multi_tile, bool reverse, hipStream_t stream) {
-    static_assert(GROUP == 16, "dispatch table assumes 16-lane groups");
-    switch (rows_per_lane) {
-#define MMGPU_SW_CASE(R) case R: return launch_r<R>(L, multi_tile, reverse, stream);
-        MMGPU_SW_CASE(2) MMGPU_SW_CASE(4) MMGPU_SW_CASE(6) MMGPU_SW_CASE(8) MMGPU_SW_CASE(10) MMGPU_SW_CASE(12)
-        MMGPU_SW_CASE(14) MMGPU_SW_CASE(16) MMGPU_SW_CASE(18) MMGPU_SW_CASE(20) MMGPU_SW_CASE(22) MMGPU_SW_CASE(24)
-        MMGPU_SW_CASE(26) MMGPU_SW_CASE(28) MMGPU_SW_CASE(30) MMGPU_SW_CASE(32)
-#undef MMGPU_SW_CASE
+int sw_shape_group(uint32_t shape) {
+    if (shape >= 16) return 2;
+    const int R = 2 * ((int)shape + 1);
+    return R <= 12 ? 0 : (R <= 24 ? 1 : 2);
+}
+
+hipError_t launch_sw(const SwLaunch &L, int group, size_t lds_bytes, bool reverse, hipStream_t stream) {
+    static_assert(GROUP == 16, "the shape codes assume 16-lane groups");
+    if (L.n_jobs == 0) return hipSuccess;
+    dim3 grid(L.n_jobs), block(WAVES * 64);
+    const size_t lds = lds_bytes;
+    switch (group * 2 + (reverse ? 1 : 0)) {
+        case 0: hipLaunchKernelGGL((sw_kernel<0, false>), grid, block, lds, stream, L); break;
+        case 1: hipLaunchKernelGGL((sw_kernel<0, true>), grid, block, lds, stream, L); break;
+        case 2: hipLaunchKernelGGL((sw_kernel<1, false>), grid, block, lds, stream, L); break;
+        case 3: hipLaunchKernelGGL((sw_kernel<1, true>), grid, block, lds, stream, L); break;
+        case 4: hipLaunchKernelGGL((sw_kernel<2, false>), grid, block, lds, stream, L); break;
+        case 5: hipLaunchKernelGGL((sw_kernel<2, true>), grid, block, lds, stream, L); break;
         default: return hipErrorInvalidValue;
     }
+    return hipGetLastError();
 }
 
 }  // namespace mmgpu
