@@ -7,7 +7,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_HERE, "lib", "libmmgpu.so")
+_LIB = os.environ.get("MMGPU_LIB") or os.path.join(_HERE, "lib", "libmmgpu.so")
 
 c_p = ctypes.c_void_p
 

@@ -50,7 +50,8 @@ extern "C" void mmgpu_destroy(mmgpu_ctx *c) {
     for (auto &st : c->side) if (st) (void)hipStreamDestroy(st);
     if (c->fork) (void)hipEventDestroy(c->fork);
     for (auto &e : c->join) if (e) (void)hipEventDestroy(e);
-    c->cache.trim();
+    c->cache->trim();
+    c->cache->closed = true;
     delete c;
 }
 
@@ -194,13 +195,23 @@ struct mmgpu_sw_batch_t {
     bool ran = false;
 };
 
-// which kernel instantiation serves a query of this length: 16 lanes x R rows per tile, R even, at most 512 rows
-// per tile; longer queries are cut into equal tiles (multi-tile kernel).
+// which kernel body serves a query of this length: 16 lanes x R rows per tile, R even, at most 16 * SW_MAX_R rows
+// per tile; longer queries are cut into equal tiles (multi-tile bodies).
 static void pick_class(uint32_t qlen, int *rows_per_lane, bool *multi) {
-    const uint32_t n_tiles = (qlen + 511) / 512;
+    constexpr uint32_t max_rows = 16u * (uint32_t)SW_MAX_R;
+    const uint32_t n_tiles = (qlen + max_rows - 1) / max_rows;
     const uint32_t rows = (qlen + n_tiles - 1) / n_tiles;       // rows per tile before rounding
     *rows_per_lane = (int)(2 * ((rows + 31) / 32));
     *multi = n_tiles > 1;
+}
+
+// Slots of a job that should hold about `rounds` rounds of `round` hits: whole workgroup rounds (4 waves x 8), so
+// that no wave idles while its neighbours run a second round; only jobs below one workgroup round (long queries cut
+// per wave) may hold 8 or 16.
+static uint32_t job_slots(uint32_t round, uint64_t rounds) {
+    const uint64_t slots = std::max<uint64_t>(1, rounds) * round;
+    if (slots >= JOB_ROUND) return (uint32_t)std::min<uint64_t>(JOB_HITS, slots / JOB_ROUND * JOB_ROUND);
+    return slots >= 16 ? 16u : round;
 }
 
 static int sw_prepare_impl(mmgpu_ctx *c, const mmgpu_sw_params *par, const mmgpu_sw_query *qs, uint32_t nq, int mode,
@@ -233,7 +244,7 @@ static int sw_prepare_impl(mmgpu_ctx *c, const mmgpu_sw_params *par, const mmgpu
     b->n_queries = nq;
     for (DevBuf *d : {&b->d_qres, &b->d_qcb, &b->d_qoff, &b->d_qbias, &b->d_qminstart, &b->d_hit_target, &b->d_hit_out, &b->d_out,
                       &b->d_mat, &b->d_stats, &b->d_bt_scratch, &b->d_bt_jobs, &b->d_bt_info, &b->d_bt_str})
-        d->bind(&c->cache);
+        d->bind(c->cache);
 
     std::vector<uint8_t> qres;
     std::vector<int8_t> qcb;
@@ -249,8 +260,8 @@ static int sw_prepare_impl(mmgpu_ctx *c, const mmgpu_sw_params *par, const mmgpu
     qres.resize(qoff[nq]);
     qcb.assign(qoff[nq], 0);
     std::vector<uint32_t> hit_target(pf ? 0 : (size_t)total_hits), hit_out(pf ? 0 : (size_t)total_hits);
-    b->d_jobs.bind(&c->cache);
-    b->d_scratch.bind(&c->cache);
+    b->d_jobs.bind(c->cache);
+    b->d_scratch.bind(c->cache);
     std::vector<SwJob> jobs;
     std::vector<uint64_t> job_cells;
     uint32_t n_multi = 0;
@@ -288,7 +299,7 @@ static int sw_prepare_impl(mmgpu_ctx *c, const mmgpu_sw_params *par, const mmgpu
             // (SwLaunch::q_hit_count); order and statistics come from sw_from_pf_kernel.  Hits per job: as many rounds as fit JOB_CELLS at the length the hits will probably have (prefilter hits are
             // mostly about as long as the query; the database mean otherwise)
             const uint64_t est_cells = (uint64_t)Q.qlen * ((Q.qlen + c->mean_len) / 2 + 1) * round;
-            const uint32_t per_job = round * (uint32_t)std::min<uint64_t>(JOB_HITS / round, std::max<uint64_t>(1, JOB_CELLS / est_cells));
+            const uint32_t per_job = job_slots(round, JOB_CELLS / est_cells);
             for (uint32_t k = 0; k < pf_stride; k += per_job) {
                 SwJob j;
                 j.query = i;
@@ -333,7 +344,9 @@ static int sw_prepare_impl(mmgpu_ctx *c, const mmgpu_sw_params *par, const mmgpu
             while (e < Q.n_targets && e - k < JOB_HITS) {
                 const uint32_t stop = std::min<uint32_t>(e + round, Q.n_targets);
                 for (; e < stop; e++) jc += (uint64_t)Q.qlen * c->h_len[hit_target[hit_cursor + e]];
-                if (jc >= JOB_CELLS) break;
+                // cut at 8, 16 (long queries) or whole workgroup rounds: no wave idles while another runs a second round
+                const uint32_t held = e - k;
+                if (jc >= JOB_CELLS && (held <= 16 || held % JOB_ROUND == 0)) break;
             }
             SwJob j;
             j.query = i;
@@ -377,6 +390,7 @@ static int sw_prepare_impl(mmgpu_ctx *c, const mmgpu_sw_params *par, const mmgpu
     }
     B_TRY(upload(b->d_mat, mat, s));
     B_TRY(b->d_out.alloc(std::max<size_t>((size_t)total_hits, 1) * sizeof(mmgpu_sw_hit)));
+    std::vector<SwJob> sorted(jobs.size());   // uploaded asynchronously: must live until the stream is drained below
     {
         // longest job first: the dispatcher hands out workgroups in blockIdx order, so the tail is the shortest jobs
         if (n_multi >= (1u << 24)) { delete b; return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_sw_prepare: more than 2^24 multi-tile jobs in one batch"); }
@@ -386,7 +400,6 @@ static int sw_prepare_impl(mmgpu_ctx *c, const mmgpu_sw_params *par, const mmgpu
             const int ga = sw_shape_group(jobs[a].shape & 0xFFu), gb = sw_shape_group(jobs[bb].shape & 0xFFu);
             return ga != gb ? ga < gb : job_cells[a] > job_cells[bb];
         });
-        std::vector<SwJob> sorted(jobs.size());
         for (size_t z = 0; z < ord.size(); z++) {
             sorted[z] = jobs[ord[z]];
             b->group_begin[sw_shape_group(sorted[z].shape & 0xFFu) + 1]++;
@@ -452,9 +465,9 @@ extern "C" int mmgpu_sw_run(mmgpu_ctx *c, mmgpu_sw_batch_t *b) {
         b->events.push_back(std::make_pair(ev0, ev1));
         HIP_TRY(hipEventRecord(ev0, c->stream));
     }
-    // one launch per pass and kernel group (jobs longest first); the groups run concurrently on side streams forked
-    // from / joined to the context's stream, and the reverse scan of a group follows
-    // its forward scan in-stream (it reads the forward results of its own pairs only)
+    // one launch per kernel group (jobs longest first); the groups run concurrently on side streams forked from /
+    // joined to the context's stream.  With start positions asked for, a workgroup runs the reverse scan of its
+    // pairs right after their forward scan (it reads the forward results of its own pairs only).
     if (!c->fork) {
         // the group with the long multi-tile jobs gets the highest stream priority: its forward + reverse chain is
         // the critical path, the other groups fill the CUs it leaves
@@ -471,7 +484,7 @@ extern "C" int mmgpu_sw_run(mmgpu_ctx *c, mmgpu_sw_batch_t *b) {
     for (auto &st : c->side) HIP_TRY(hipStreamWaitEvent(st, c->fork, 0));
     for (int g = SW_GROUPS - 1; g >= 0; g--) {
         hipStream_t st = c->side[g];
-        for (int pass = 0; pass < (b->mode == MMGPU_SW_START ? 2 : 1); pass++) {
+        {
             SwLaunch L;
             L.jobs = b->d_jobs.as<SwJob>() + b->group_begin[g];
             L.n_jobs = b->group_begin[g + 1] - b->group_begin[g];
@@ -494,7 +507,7 @@ extern "C" int mmgpu_sw_run(mmgpu_ctx *c, mmgpu_sw_batch_t *b) {
             L.hit_stride = b->slot_stride;
             L.scratch = b->d_scratch.as<uint2>();
             L.scratch_cols = b->scratch_cols;
-            HIP_TRY(launch_sw(L, g, b->group_lds[g], pass == 1, st));
+            HIP_TRY(launch_sw(L, g, b->group_lds[g], b->mode == MMGPU_SW_START, st));
         }
     }
     for (int k = 0; k < SW_GROUPS; k++) {

@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <string>
 #include <map>
+#include <memory>
 #include <vector>
 
 #include "../../include/mmgpu.h"
@@ -82,9 +83,17 @@ hipError_t launch_sw_from_pf(const SwFromPfArgs &A, uint32_t nq, hipStream_t str
 
 // rows_per_lane in {8,16,24,32}: a 16-lane group covers 16*rows_per_lane query rows per tile.
 // reverse = false: forward score/end scan; true: start-position scan over the reversed prefixes.
+#ifndef MMGPU_SW_MAX_R
+#define MMGPU_SW_MAX_R 28
+#endif
+constexpr int SW_MAX_R = MMGPU_SW_MAX_R;   // rows per lane of the largest tile (16 lanes x SW_MAX_R query rows); longer queries are cut into tiles
+#ifndef MMGPU_SW_MIN_WAVES
+#define MMGPU_SW_MIN_WAVES 2
+#endif
+constexpr int SW_MIN_WAVES = MMGPU_SW_MIN_WAVES;   // occupancy floor (waves per SIMD) the alignment kernels are compiled for
 constexpr int SW_GROUPS = 3;   // kernels per pass: tile shapes grouped by register need (sw_kernel.hip)
 int sw_shape_group(uint32_t shape);
-hipError_t launch_sw(const SwLaunch &L, int group, size_t lds_bytes, bool reverse, hipStream_t stream);
+hipError_t launch_sw(const SwLaunch &L, int group, size_t lds_bytes, bool both_passes, hipStream_t stream);
 size_t sw_lds_bytes(int rows_per_lane, int alphabet);
 
 // ---------------------------------------------------------------------------------------------------------
@@ -324,6 +333,7 @@ inline int fail(int code, const std::string &msg) {
 struct BlockCache {
     std::multimap<size_t, void *> blocks;
     size_t cached = 0;
+    bool closed = false;   // the context is gone (batches may outlive it): blocks go straight back to the runtime
     static constexpr size_t LIMIT = 32ull << 30;
     static size_t round_up(size_t n) {
         if (n <= 512) return 512;
@@ -340,7 +350,7 @@ struct BlockCache {
         return p;
     }
     void give(void *p, size_t cap) {
-        if (cached + cap > LIMIT) { (void)hipFree(p); return; }
+        if (closed || cached + cap > LIMIT) { (void)hipFree(p); return; }
         blocks.emplace(cap, p);
         cached += cap;
     }
@@ -355,13 +365,13 @@ struct DevBuf {
     void *p = nullptr;
     size_t bytes = 0;
     size_t cap = 0;                // allocated size when the block came from / goes back to a cache
-    BlockCache *cache = nullptr;   // optional (bind): where freed blocks go
+    std::shared_ptr<BlockCache> cache;   // optional (bind): where freed blocks go
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
-    DevBuf(DevBuf &&o) noexcept : p(o.p), bytes(o.bytes), cap(o.cap), cache(o.cache) { o.p = nullptr; o.bytes = 0; o.cap = 0; }
+    DevBuf(DevBuf &&o) noexcept : p(o.p), bytes(o.bytes), cap(o.cap), cache(std::move(o.cache)) { o.p = nullptr; o.bytes = 0; o.cap = 0; }
     ~DevBuf() { release(); }
-    void bind(BlockCache *c) { cache = c; }
+    void bind(const std::shared_ptr<BlockCache> &c) { cache = c; }
     void release() {
         if (!p) return;
         if (cache && cap) cache->give(p, cap);
@@ -414,7 +424,7 @@ struct mmgpu_ctx {
     int compute_units = 0;
     std::string name;
     mmgpu::PfIndex *pf = nullptr;  // prefilter index resident in HBM (pf_api.hip)
-    mmgpu::BlockCache cache;       // device blocks of freed alignment batches
+    std::shared_ptr<mmgpu::BlockCache> cache = std::make_shared<mmgpu::BlockCache>();   // device blocks of freed alignment batches
     // the alignment kernel groups run concurrently on side streams forked from / joined to `stream` (mmgpu_sw_run)
     hipStream_t side[3] = {nullptr, nullptr, nullptr};
     hipEvent_t fork = nullptr, join[3] = {nullptr, nullptr, nullptr};

@@ -109,10 +109,17 @@ __device__ __forceinline__ void build_profile(unsigned char *lds, const uint8_t 
     }
 }
 
+constexpr int SW_LDS_HEADER = 1024;
+
 template <int R, bool MULTI, bool REV>
 __device__ __forceinline__ void sw_body(const SwLaunch &L, const SwJob job) {
     using T = Tile<R>;
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    // dynamic LDS: a 1 KB header (job-local scheduling state, below) followed by the query profile of the tile
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_all[];
+    uint16_t *live = reinterpret_cast<uint16_t *>(lds_all);                  // [WAVES * 64] packed live hits (reverse pass)
+    uint32_t *live_wave = reinterpret_cast<uint32_t *>(lds_all + 512);       // [WAVES]
+    uint32_t *next_chunk = reinterpret_cast<uint32_t *>(lds_all + 512 + 16); // next 8-hit chunk to hand to a wave
+    unsigned char *lds = lds_all + SW_LDS_HEADER;
     // A multi-tile job is one long dependent chain (tiles x columns) however few targets it holds, and the batch ends
     // with the longest of them: those waves take the issue slots first, the short jobs sharing the SIMD fill the gaps.
     if (MULTI) __builtin_amdgcn_s_setprio(3);
@@ -132,6 +139,7 @@ __device__ __forceinline__ void sw_body(const SwLaunch &L, const SwJob job) {
     const unsigned ge2 = (unsigned)L.gap_extend * 0x10001u;
     const unsigned pad_letter = (unsigned)L.alphabet;
 
+    if (threadIdx.x == 0) *next_chunk = 0;
     if (!MULTI) {
         build_profile<R, REV>(lds, q, cb, qlen, 0, L.mat, L.alphabet);
         __syncthreads();
@@ -142,8 +150,6 @@ __device__ __forceinline__ void sw_body(const SwLaunch &L, const SwJob job) {
     // (ssw_align_private, StripedSmithWaterman.cpp:857-863) - typically one hit in six, scattered over the
     // length-sorted list.  They are packed to the front (order kept), so that the waves run full instead of every
     // wave waiting for its one or two live targets.
-    __shared__ uint16_t live[WAVES * 64];
-    __shared__ uint32_t live_wave[WAVES];
     if (REV) {
         const int min_start = L.q_minstart[job.query];
         bool pass = false;
@@ -167,8 +173,16 @@ __device__ __forceinline__ void sw_body(const SwLaunch &L, const SwJob job) {
     }
     const uint32_t n_iter = (n_hits + WAVES * HITS_PER_WAVE - 1) / (WAVES * HITS_PER_WAVE);
 
-    for (uint32_t it = 0; it < n_iter; ++it) {
-        const uint32_t slot0 = (it * WAVES + wave) * HITS_PER_WAVE;
+    for (uint32_t it = 0; !MULTI || it < n_iter; ++it) {
+        // Single-tile jobs: a wave takes the next chunk of 8 hits when it is done with its last one (the hits are
+        // sorted by length, so fixed wave <-> chunk striping would give wave 0 the longest chunk of every round).
+        // Multi-tile jobs rebuild the profile per tile with all threads, so their waves stay in step.
+        uint32_t chunk = it * WAVES + wave;
+        if (!MULTI) {
+            if (lane == 0) chunk = atomicAdd(next_chunk, 1u);
+            chunk = __builtin_amdgcn_readfirstlane(chunk);
+        }
+        const uint32_t slot0 = chunk * HITS_PER_WAVE;
         if (!MULTI && slot0 >= n_hits) break;   // wave-uniform; MULTI keeps every wave in the barrier loop
 
         // ---- the two targets of this group ------------------------------------------------------
@@ -392,16 +406,30 @@ __device__ __forceinline__ void sw_body(const SwLaunch &L, const SwJob job) {
 // are grouped by register need instead (a kernel gets the registers of its largest body, which sets the occupancy of
 // all of them): S = R <= 12 (forward 80 / reverse 119 VGPRs), M = R 14..24 (140 / 212), L = R >= 26 and every
 // multi-tile shape (212 / 256).  Each group is one grid, longest job first; the three run concurrently.
-template <int G, bool REV>
-__global__ __launch_bounds__(WAVES * 64) void sw_kernel(SwLaunch L) {
+// BOTH = false: forward scan only (MMGPU_SW_SCORE_END).  BOTH = true: the workgroup runs the reverse scan of its own
+// pairs right after their forward scan - no grid-wide barrier between the passes, so the batch has one tail, not two.
+template <int R, bool MULTI, bool BOTH>
+__device__ __forceinline__ void sw_passes(const SwLaunch &L, const SwJob &job) {
+    if constexpr (R <= SW_MAX_R) {
+        sw_body<R, MULTI, false>(L, job);
+        if constexpr (BOTH) {
+            __threadfence_block();   // the forward results of this job, written by other waves of the workgroup
+            __syncthreads();
+            sw_body<R, MULTI, true>(L, job);
+        }
+    }
+}
+
+template <int G, bool BOTH>
+__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(SW_MIN_WAVES))) void sw_kernel(SwLaunch L) {
     SwJob job = L.jobs[blockIdx.x];
     if (L.q_hit_count) {   // fused prefilter -> align hand-over: the list length of the query is only known on the device
         const uint32_t lim = job.query * L.hit_stride + L.q_hit_count[job.query];
         job.hit_end = job.hit_end < lim ? job.hit_end : lim;
         if (job.hit_end <= job.hit_begin) return;
     }
-#define MMGPU_SW_SINGLE(R) case (R) / 2 - 1: sw_body<R, false, REV>(L, job); break;
-#define MMGPU_SW_MULTI(R) case 16 + (R) / 2 - 1: sw_body<R, true, REV>(L, job); break;
+#define MMGPU_SW_SINGLE(R) case (R) / 2 - 1: sw_passes<R, false, BOTH>(L, job); break;
+#define MMGPU_SW_MULTI(R) case 16 + (R) / 2 - 1: sw_passes<R, true, BOTH>(L, job); break;
     if constexpr (G == 0) {
         switch (job.shape & 0xFFu) {   // workgroup-uniform
             MMGPU_SW_SINGLE(2) MMGPU_SW_SINGLE(4) MMGPU_SW_SINGLE(6) MMGPU_SW_SINGLE(8) MMGPU_SW_SINGLE(10) MMGPU_SW_SINGLE(12)
@@ -415,8 +443,8 @@ __global__ __launch_bounds__(WAVES * 64) void sw_kernel(SwLaunch L) {
     } else {
         switch (job.shape & 0xFFu) {
             MMGPU_SW_SINGLE(26) MMGPU_SW_SINGLE(28) MMGPU_SW_SINGLE(30) MMGPU_SW_SINGLE(32)
-            MMGPU_SW_MULTI(18) MMGPU_SW_MULTI(20) MMGPU_SW_MULTI(22) MMGPU_SW_MULTI(24) MMGPU_SW_MULTI(26) MMGPU_SW_MULTI(28)
-            MMGPU_SW_MULTI(30) MMGPU_SW_MULTI(32)
+            MMGPU_SW_MULTI(16) MMGPU_SW_MULTI(18) MMGPU_SW_MULTI(20) MMGPU_SW_MULTI(22) MMGPU_SW_MULTI(24) MMGPU_SW_MULTI(26)
+            MMGPU_SW_MULTI(28) MMGPU_SW_MULTI(30) MMGPU_SW_MULTI(32)
             default: break;
         }
     }
@@ -500,12 +528,12 @@ int sw_shape_group(uint32_t shape) {
     return R <= 12 ? 0 : (R <= 24 ? 1 : 2);
 }
 
-hipError_t launch_sw(const SwLaunch &L, int group, size_t lds_bytes, bool reverse, hipStream_t stream) {
+hipError_t launch_sw(const SwLaunch &L, int group, size_t lds_bytes, bool both_passes, hipStream_t stream) {
     static_assert(GROUP == 16, "the shape codes assume 16-lane groups");
     if (L.n_jobs == 0) return hipSuccess;
     dim3 grid(L.n_jobs), block(WAVES * 64);
-    const size_t lds = lds_bytes;
-    switch (group * 2 + (reverse ? 1 : 0)) {
+    const size_t lds = lds_bytes + SW_LDS_HEADER;
+    switch (group * 2 + (both_passes ? 1 : 0)) {
         case 0: hipLaunchKernelGGL((sw_kernel<0, false>), grid, block, lds, stream, L); break;
         case 1: hipLaunchKernelGGL((sw_kernel<0, true>), grid, block, lds, stream, L); break;
         case 2: hipLaunchKernelGGL((sw_kernel<1, false>), grid, block, lds, stream, L); break;
