@@ -215,12 +215,15 @@ def search_section(args, gpu, torch, dist, rank, world, matrices, barrier):
     batches = [gpu.pf_prepare(queries[i:i + bsz], kmer_thr, max_hits=mh, min_diag_score=15, ref_bins=2)
                for i in range(0, nq, bsz)]
     shard_sizes = [nt] * world
+    # MMGPU_BENCH_FORCE_EXCHANGE=1: run the N > 1 exchange path (RCCL all-gather of the hit lists + device merge, RCCL
+    # exchange of the alignment results) on a single rank - a self-test of the collectives on a 1-GPU box
+    exchange = world > 1 or (dist is not None)
 
     def one_pass(keep):
         merged = []
         for b in batches:
             b.run()
-            if world > 1:
+            if exchange:
                 mh_t, mc_t = D.gather_and_merge_device(gpu, b, b.nq, mh, shard_sizes)
                 if keep:
                     merged.append((mh_t, mc_t))
@@ -246,7 +249,7 @@ def search_section(args, gpu, torch, dist, rank, world, matrices, barrier):
         ent += int(stats["db_matches"].sum())
         sim += int(stats["kmer_list_len"].sum())
         ovf += int((st != 0).sum())
-        if world > 1:
+        if exchange:
             mh_t, mc_t = merged[bi]
             hh = mh_t.cpu().numpy().reshape(b.nq, -1).view(capi.PF_HIT_DTYPE).reshape(b.nq, -1)
             cc2 = mc_t.cpu().numpy()
@@ -287,12 +290,19 @@ def search_section(args, gpu, torch, dist, rank, world, matrices, barrier):
     t_handoff = time.time() - t0
     swb.run()
     barrier()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    slot_t = local_t = None
+    if exchange:
+        slot_t = torch.from_numpy(np.concatenate(slot_index) if slot_index else np.zeros(0, np.int64)).to(dev)
+        local_t = torch.zeros((max(swb.pairs, 1), 6), dtype=torch.int32, device=dev)
+
     def align_pass():
         swb.run()
-        if world > 1:
-            # second exchange of the path: the alignment results of the merged lists, one all-reduce over RCCL
-            return D.exchange_sw_results(swb.fetch(), np.concatenate(slot_index) if slot_index else np.zeros(0, np.int64),
-                                         nq * world * mh, device=torch.device("cuda", torch.cuda.current_device()))
+        if exchange:
+            # second exchange of the path: the alignment results of the merged lists stay on the device - D2D copy
+            # out of the batch, scatter to the merged-list slots, one all-reduce over RCCL
+            swb.fetch_device(local_t.data_ptr())
+            return D.exchange_sw_results_tensor(local_t[:swb.pairs], slot_t, nq * world * mh)
         return None
 
     t0 = time.perf_counter()
@@ -302,7 +312,7 @@ def search_section(args, gpu, torch, dist, rank, world, matrices, barrier):
     t_sw = (time.perf_counter() - t0) / args.pf_steps
     sw_cells, sw_pairs = swb.cells, swb.pairs
     fused = None
-    if world == 1:
+    if not exchange:
         # the whole path as one device pipeline: prefilter batch -> hit lists sorted / scheduled on the device
         # (mmgpu_sw_prepare_from_pf) -> alignment, nothing but the query descriptors crosses PCIe in between
         msh = [gpu.sw_marshal_queries(mat, 11, 1, swq[i:i + bsz]) for i in range(0, nq, bsz)]
@@ -411,6 +421,11 @@ def search_section(args, gpu, torch, dist, rank, world, matrices, barrier):
 
 
 def main():
+    # exactly ONE line on stdout: libraries (RCCL prints a version banner) write to fd 1 behind Python's back, so
+    # fd 1 is pointed at stderr for the run and the JSON line goes to the saved descriptor at the end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -444,9 +459,10 @@ def main():
     device_index = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(device_index)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("MMGPU_BENCH_FORCE_EXCHANGE") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device_index))
         else:
@@ -552,7 +568,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(matrices, qs, cbs, tres, toff, args.cpu_seconds, res)
         if search is not None:
             out["search"] = search
-        print(json.dumps(out))
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     gpu.close()
     if dist is not None:
         dist.destroy_process_group()

@@ -127,6 +127,9 @@ int mmgpu_sw_prepare_from_pf(mmgpu_ctx *ctx, const mmgpu_sw_params *params, cons
                              uint32_t n_queries, int mode, struct mmgpu_pf_batch_t *pf_batch, mmgpu_sw_batch_t **batch);
 int mmgpu_sw_run(mmgpu_ctx *ctx, mmgpu_sw_batch_t *batch);
 int mmgpu_sw_fetch(mmgpu_ctx *ctx, mmgpu_sw_batch_t *batch, mmgpu_sw_hit *out);
+/* Same results, copied device -> device into caller-owned device memory (the multi-GPU result exchange works on
+ * device tensors); asynchronous on the context's stream. */
+int mmgpu_sw_fetch_device(mmgpu_ctx *ctx, mmgpu_sw_batch_t *batch, void *d_out);
 /* forward-DP cells of the batch = sum over pairs of qlen*tlen ("alignments calculated" x lengths,
  * Alignment.cpp:380,530) and the number of pairs */
 int mmgpu_sw_batch_stats(mmgpu_sw_batch_t *batch, uint64_t *cells, uint64_t *pairs);

@@ -51,7 +51,7 @@ EXPORTED_SYMBOLS = [
     "mmgpu_init", "mmgpu_destroy", "mmgpu_last_error", "mmgpu_set_stream", "mmgpu_synchronize",
     "mmgpu_device_info", "mmgpu_host_comp_bias", "mmgpu_host_round_comp_bias", "mmgpu_load_targets", "mmgpu_sw_batch", "mmgpu_sw_prepare", "mmgpu_sw_run",
     "mmgpu_sw_fetch", "mmgpu_sw_batch_stats", "mmgpu_sw_last_kernel_ms", "mmgpu_sw_kernel_ms_mean", "mmgpu_sw_free",
-    "mmgpu_sw_traceback", "mmgpu_sw_prepare_from_pf",
+    "mmgpu_sw_traceback", "mmgpu_sw_prepare_from_pf", "mmgpu_sw_fetch_device",
     "mmgpu_host_score_matrix", "mmgpu_host_index_build", "mmgpu_pf_load_index", "mmgpu_pf_batch", "mmgpu_pf_prepare",
     "mmgpu_pf_run", "mmgpu_pf_fetch", "mmgpu_pf_stage_ms", "mmgpu_pf_last_cells", "mmgpu_pf_fetch_device", "mmgpu_pf_merge_splits", "mmgpu_pf_build_index", "mmgpu_pf_debug_index", "mmgpu_pf_debug_fetch", "mmgpu_pf_free",
 ]
@@ -102,6 +102,7 @@ def load_library():
     L.mmgpu_sw_prepare.argtypes = [c_p, ctypes.POINTER(SwParams), c_p, ctypes.c_uint32, ctypes.c_int, ctypes.POINTER(c_p)]
     L.mmgpu_sw_prepare_from_pf.argtypes = [c_p, ctypes.POINTER(SwParams), c_p, ctypes.c_uint32, ctypes.c_int, c_p, ctypes.POINTER(c_p)]
     L.mmgpu_sw_run.argtypes = [c_p, c_p]
+    L.mmgpu_sw_fetch_device.argtypes = [c_p, c_p, c_p]
     L.mmgpu_sw_fetch.argtypes = [c_p, c_p, c_p]
     L.mmgpu_sw_batch_stats.argtypes = [c_p, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
     L.mmgpu_sw_last_kernel_ms.argtypes = [c_p, c_p, ctypes.POINTER(ctypes.c_float)]
@@ -247,6 +248,10 @@ class SwBatch:
 
     def run(self):
         self.gpu._check(self.gpu.L.mmgpu_sw_run(self.gpu.ctx, self.handle))
+
+    def fetch_device(self, d_out_ptr):
+        """D2D copy of the results (24 B records, fetch() order) into caller-owned device memory, on the context's stream."""
+        self.gpu._check(self.gpu.L.mmgpu_sw_fetch_device(self.gpu.ctx, self.handle, c_p(d_out_ptr)))
 
     def fetch(self):
         out = np.zeros(self.pairs if self.slots is None else self.slots, SW_HIT_DTYPE)

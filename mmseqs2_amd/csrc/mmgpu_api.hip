@@ -529,6 +529,15 @@ extern "C" int mmgpu_sw_fetch(mmgpu_ctx *c, mmgpu_sw_batch_t *b, mmgpu_sw_hit *o
     return MMGPU_OK;
 }
 
+extern "C" int mmgpu_sw_fetch_device(mmgpu_ctx *c, mmgpu_sw_batch_t *b, void *d_out) {
+    if (!c || !b || (!d_out && b->pairs)) return fail(MMGPU_ERR_ARG, "mmgpu_sw_fetch_device: NULL argument");
+    if (!b->ran) return fail(MMGPU_ERR_STATE, "mmgpu_sw_fetch_device: batch was never run");
+    HIP_TRY(hipSetDevice(c->device));
+    if (b->pairs)
+        HIP_TRY(hipMemcpyAsync(d_out, b->d_out.p, (size_t)b->pairs * sizeof(mmgpu_sw_hit), hipMemcpyDeviceToDevice, c->stream));
+    return MMGPU_OK;
+}
+
 extern "C" int mmgpu_sw_batch_stats(mmgpu_sw_batch_t *b, uint64_t *cells, uint64_t *pairs) {
     if (!b) return fail(MMGPU_ERR_ARG, "mmgpu_sw_batch_stats: NULL argument");
     if (cells) *cells = b->cells;

@@ -84,3 +84,14 @@ def exchange_sw_results(local_res, slot_index, n_slots, device=None, group=None)
         t = t.to(device)
     dist.all_reduce(t, group=group)
     return t.cpu().numpy().reshape(-1).view(capi.SW_HIT_DTYPE)
+
+
+def exchange_sw_results_tensor(local_res, slot_index, n_slots, group=None):
+    """exchange_sw_results on tensors, nothing staged through the host: local_res is an int32 tensor [n_pairs, 6] (the
+    24-byte mmgpu_sw_hit records of the pairs this rank aligned, e.g. filled by SwBatch.fetch_device), slot_index an
+    int64 tensor on the same device.  Returns the int32 tensor [n_slots, 6] every rank ends up with (one all-reduce)."""
+    full = torch.zeros((n_slots, 6), dtype=torch.int32, device=local_res.device)
+    if slot_index.numel():
+        full.index_copy_(0, slot_index, local_res)
+    dist.all_reduce(full, group=group)
+    return full

@@ -63,6 +63,10 @@ def _worker(rank, world, port, nq, q):
     loc["score"] = vals
     loc["q_end"] = rank + 1
     full = D.exchange_sw_results(loc, slots, nq * stride)
+    # the tensor form the GPU path uses (nothing staged through numpy) must give the same array
+    full_t = D.exchange_sw_results_tensor(torch.from_numpy(loc.view(np.int32).reshape(-1, 6).copy()),
+                                          torch.tensor(slots, dtype=torch.int64), nq * stride)
+    assert np.array_equal(full_t.numpy().reshape(-1).view(capi.SW_HIT_DTYPE), full)
     if rank == 0:
         q.put(([(m["id"].tolist(), m["score"].tolist(), m["diagonal"].tolist()) for m in merged],
                full["score"].tolist(), full["q_end"].tolist()))
