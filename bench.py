@@ -373,7 +373,7 @@ def search_section(args, gpu, torch, dist, rank, world, matrices, barrier):
     swb.free()
     res = None
     if rank == 0:
-        # the committed PMC passes were taken on exactly the default workload (10k x 1M, batches of 1024)
+        # the committed PMC passes were taken on exactly the default workload (10k x 1M, one batch)
         default_wl = (args.pf_families, args.pf_members, args.pf_queries, args.pf_batch) == (20000, 50, 10000, 10000)
         traffic = pmc_traffic("pf_split_kernel") if default_wl else None
         # algorithmic HBM bytes of the gather/split kernel: ~20 B per index entry touched
