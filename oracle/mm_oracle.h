@@ -121,4 +121,20 @@ void mmo_comp_bias(const int16_t *submat /*alphabet^2, row-major short matrix*/,
 #ifdef __cplusplus
 }
 #endif
+
+/* ---- nucleotide alignment step (oracle/nucl_oracle.c) ---- */
+typedef struct {
+    int32_t max, zdropped, max_q, max_t, mqe, mqe_t, mte, mte_q, score, n_cigar;
+} mmo_ksw_ez;
+typedef struct {
+    int32_t score, q_start, q_end, t_start, t_end;
+    uint32_t ident;
+    int32_t bt_len, cigar_len;
+} mmo_nucl_result;
+int mmo_ksw_extz2(int qlen, const uint8_t *query, int tlen, const uint8_t *target, int m, const int8_t *mat, int q, int e,
+                  int w, int zdrop, int flag, mmo_ksw_ez *ez, uint32_t *cigar, int cigar_cap);
+int mmo_nucl_align(const uint8_t *q_num, int qlen, const uint8_t *t_num, int tlen, const int8_t *mat, int alph,
+                   const uint8_t *rev_lookup, int gapo, int gape, int zdrop, unsigned diagonal16, int reverse,
+                   int past_end_q, int past_end_t, mmo_nucl_result *res, char *bt, int bt_cap);
+
 #endif

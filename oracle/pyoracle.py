@@ -452,3 +452,118 @@ class RefPrefilter:
         if want_lists:
             return sec, th.value, dbm.value, counts[:nq], dict(ids=ids[:nq], scores=sc[:nq], diags=dg[:nq], bins=bins.value)
         return sec, th.value, dbm.value, counts[:nq]
+
+
+# ---------------------------------------------------------------------------------------------------------
+# nucleotide alignment step: oracle/nucl_oracle.c and the real reference classes
+class KswEz(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ("max", "zdropped", "max_q", "max_t", "mqe", "mqe_t", "mte", "mte_q", "score", "n_cigar")]
+
+
+class NuclRes(ctypes.Structure):
+    _fields_ = [("score", ctypes.c_int32), ("q_start", ctypes.c_int32), ("q_end", ctypes.c_int32), ("t_start", ctypes.c_int32),
+                ("t_end", ctypes.c_int32), ("ident", ctypes.c_uint32), ("bt_len", ctypes.c_int32), ("cigar_len", ctypes.c_int32)]
+
+    def as_tuple(self):
+        return (self.score, self.q_start, self.q_end, self.t_start, self.t_end, self.ident, self.cigar_len)
+
+
+NUCL_LETTERS = "ACTGN"          # numeric codes 0..4 of NucleotideMatrix (nucleotide.out column order, N -> X)
+KSW_SCORE_ONLY, KSW_EXTZ_ONLY = 0x01, 0x40
+
+
+class NuclOracle:
+    """Plain-C restatement (oracle/nucl_oracle.c)."""
+
+    def __init__(self):
+        if not os.path.exists(ORACLE_SO):
+            build_oracle()
+        self.L = ctypes.CDLL(ORACLE_SO)
+
+    def ksw_extz2(self, q, t, mat, gapo, gape, w, zdrop, flag):
+        q = np.ascontiguousarray(q, np.uint8)
+        t = np.ascontiguousarray(t, np.uint8)
+        mat = np.ascontiguousarray(mat, np.int8)
+        ez = KswEz()
+        cap = len(q) + len(t) + 4
+        cg = np.zeros(cap, np.uint32)
+        n = self.L.mmo_ksw_extz2(len(q), _ptr(q), len(t), _ptr(t), 5, _ptr(mat), gapo, gape, w, zdrop, flag, ctypes.byref(ez),
+                                 _ptr(cg), cap)
+        return [getattr(ez, f) for f in ("max", "zdropped", "max_q", "max_t", "mqe", "mqe_t", "mte", "mte_q", "score")], cg[:max(n, 0)].copy()
+
+    def align(self, q, t, mat, rev_lookup, gapo, gape, zdrop, diagonal, reverse, past_end_q=4, past_end_t=4):
+        q = np.ascontiguousarray(q, np.uint8)
+        t = np.ascontiguousarray(t, np.uint8)
+        mat = np.ascontiguousarray(mat, np.int8)
+        rl = np.ascontiguousarray(rev_lookup, np.uint8)
+        res = NuclRes()
+        cap = len(q) + len(t) + 8
+        bt = ctypes.create_string_buffer(cap)
+        rc = self.L.mmo_nucl_align(_ptr(q), len(q), _ptr(t), len(t), _ptr(mat), 5, _ptr(rl), gapo, gape, zdrop,
+                                   ctypes.c_uint(diagonal & 0xFFFF), int(reverse), int(past_end_q), int(past_end_t),
+                                   ctypes.byref(res), bt, cap)
+        assert rc == 0
+        return res.as_tuple(), bt.value.decode()
+
+
+class RefNucl:
+    """The real BandedNucleotideAligner / ksw_extz2_sse (oracle/ref_shim_nucl.cpp); needs /root/reference/data."""
+
+    def __init__(self, max_len=70000, gap_open=5, gap_extend=2, zdrop=40, db_residues=100000000):
+        L = self.L = ctypes.CDLL(REF_SO)
+        L.mmref_nucl_new.restype = c_p
+        L.mmref_nucl_new.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint64]
+        L.mmref_nucl_free.argtypes = [c_p]
+        L.mmref_nucl_matrix.argtypes = [c_p, c_p]
+        L.mmref_nucl_aa2num.argtypes = [c_p, ctypes.c_char_p, ctypes.c_int, c_p]
+        L.mmref_nucl_reverse_lookup.argtypes = [c_p, c_p]
+        L.mmref_nucl_set_query.argtypes = [c_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]
+        L.mmref_nucl_align.argtypes = [c_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                       ctypes.POINTER(NuclRes), ctypes.c_char_p, ctypes.c_int]
+        L.mmref_ksw_extz2.argtypes = [ctypes.c_int, c_p, ctypes.c_int, c_p, ctypes.c_int, c_p, ctypes.c_int, ctypes.c_int,
+                                      ctypes.c_int, ctypes.c_int, ctypes.c_int, c_p, c_p, ctypes.c_int]
+        path = os.path.join(REFERENCE_ROOT, "data", "nucleotide.out").encode()
+        self.ctx = L.mmref_nucl_new(path, max_len, gap_open, gap_extend, zdrop, db_residues)
+        self._q = None
+
+    def matrix(self):
+        out = np.zeros((5, 5), np.int8)
+        self.L.mmref_nucl_matrix(self.ctx, _ptr(out))
+        return out
+
+    def reverse_lookup(self):
+        out = np.zeros(5, np.uint8)
+        self.L.mmref_nucl_reverse_lookup(self.ctx, _ptr(out))
+        return out
+
+    def aa2num(self, s):
+        out = np.zeros(len(s), np.uint8)
+        self.L.mmref_nucl_aa2num(self.ctx, s.encode(), len(s), _ptr(out))
+        return out
+
+    def set_query(self, s, past_end=4):
+        self._q = s.encode()           # the reference keeps the pointer
+        self.L.mmref_nucl_set_query(self.ctx, self._q, len(s), int(past_end))
+
+    def align(self, tseq, diagonal, reverse, past_end=4):
+        res = NuclRes()
+        cap = len(self._q) + len(tseq) + 8
+        bt = ctypes.create_string_buffer(cap)
+        tb = tseq.encode()
+        self.L.mmref_nucl_align(self.ctx, tb, len(tseq), int(past_end), int(diagonal), int(reverse), 0, ctypes.byref(res), bt, cap)
+        return res.as_tuple(), bt.value.decode()
+
+    def ksw_extz2(self, q, t, mat, gapo, gape, w, zdrop, flag):
+        q = np.ascontiguousarray(q, np.uint8)
+        t = np.ascontiguousarray(t, np.uint8)
+        mat = np.ascontiguousarray(mat, np.int8)
+        out = np.zeros(9, np.int32)
+        cap = len(q) + len(t) + 4
+        cg = np.zeros(cap, np.uint32)
+        n = self.L.mmref_ksw_extz2(len(q), _ptr(q), len(t), _ptr(t), 5, _ptr(mat), gapo, gape, w, zdrop, flag, _ptr(out), _ptr(cg), cap)
+        return out.tolist(), cg[:n].copy()
+
+    def close(self):
+        if self.ctx:
+            self.L.mmref_nucl_free(self.ctx)
+            self.ctx = None
