@@ -420,6 +420,51 @@ def search_section(args, gpu, torch, dist, rank, world, matrices, barrier):
     return res
 
 
+def nucl_section(args, gpu, matrices, rank):
+    """BASELINE.json configs[4], the nucleotide alignment step (BandedNucleotideAligner::align behind Alignment::run):
+    reads with 10 % substitutions / 2 % indels against their source contigs (true prefilter diagonal, both strands)
+    plus unrelated contigs.  The prefilter side of the nucleotide search is not part of this round (lists synthetic)."""
+    from mmseqs2_amd import workloads as wl
+    t0 = time.time()
+    queries, (tres, toff), pairs = wl.config5_nucleotide(args.nucl_contigs, args.nucl_reads, args.nucl_read_len, seed=20 + 1000 * rank)
+    t_gen = time.time() - t0
+    gpu.load_targets(tres, toff, 5)
+    mat, rl = matrices["nucleotide"], matrices["nucleotide_reverse"]
+    gpu.nucl_align(mat, rl, queries[:8], pairs[:8])            # warm-up (code load, block cache)
+    gpu.synchronize()
+    t0 = time.perf_counter()
+    hits, strs = gpu.nucl_align(mat, rl, queries, pairs, 5, 2, 40, 4, 4)
+    dt = time.perf_counter() - t0
+    if rank != 0:
+        return None
+    aligned = int(hits["bt_len"].sum())
+    res = {"workload": "BASELINE.json configs[4] (alignment step only): %d reads of %d nt (10%% substitutions, 2%% indels) x "
+                       "(source contig on the true diagonal + %d unrelated contigs), %d contigs ~LogNormal(20 kb), gap 5/2, "
+                       "band 64, z-drop 40" % (len(queries), args.nucl_read_len, 4, args.nucl_contigs),
+           "pairs": len(pairs), "pairs_per_s": round(len(pairs) / dt, 1), "s_incl_upload_and_download": round(dt, 4),
+           "aligned_columns": aligned, "aligned_columns_per_s": round(aligned / dt, 1),
+           "true_pairs_recovered": int(sum(1 for i in range(0, len(pairs), 5) if hits[i]["bt_len"] > 0.8 * args.nucl_read_len)),
+           "setup_s": {"generate": round(t_gen, 1)}}
+    if not args.no_cpu_baseline:
+        from oracle import pyoracle
+        if pyoracle.ref_available():
+            cores = os.cpu_count() or 1
+            ref = pyoracle.RefNucl(serialized=matrices["nucleotide_serialized"].tobytes())
+            letters = np.frombuffer(wl.NUCL_LETTERS.encode(), np.uint8)
+            qoff = np.concatenate([[0], np.cumsum([len(q) for q in queries])]).astype(np.uint64)
+            pa = np.array(pairs, np.int64)
+            sec, out, bl = ref.batch(letters[np.concatenate(queries)], qoff, letters[tres], toff, pa[:, 0], pa[:, 1], pa[:, 2],
+                                     pa[:, 3], cores)
+            ref.close()
+            got = np.stack([hits[f].astype(np.int64) for f in ("score", "q_start", "q_end", "t_start", "t_end", "ident")], 1)
+            bad = int((np.any(got != out, axis=1) | (hits["bt_len"] != bl)).sum())
+            res["cpu_baseline"] = {"value": round(len(pairs) / sec, 1), "unit": "pairs/s", "cores": cores, "kind": "reference",
+                                   "sample": "all %d pairs, BandedNucleotideAligner::align on %d threads, %.2f s wall" % (len(pairs), cores, sec),
+                                   "parity_vs_reference": {"pairs_compared": len(pairs), "pairs_differing": bad,
+                                                           "fields": "score, start / end positions, identities, backtrace length"}}
+    return res
+
+
 def main():
     # exactly ONE line on stdout: libraries (RCCL prints a version banner) write to fd 1 behind Python's back, so
     # fd 1 is pointed at stderr for the run and the JSON line goes to the saved descriptor at the end
@@ -439,6 +484,10 @@ def main():
     ap.add_argument("--pf-queries", type=int, default=10000)
     ap.add_argument("--pf-batch", type=int, default=10000)
     ap.add_argument("--pf-steps", type=int, default=2)
+    ap.add_argument("--no-nucl", action="store_true", help="skip the configs[4] nucleotide alignment section")
+    ap.add_argument("--nucl-contigs", type=int, default=4000)
+    ap.add_argument("--nucl-reads", type=int, default=1000)
+    ap.add_argument("--nucl-read-len", type=int, default=10000)
     ap.add_argument("--prefilter-only", action="store_true", help="configs[2] section: stop after the prefilter (counter passes)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
@@ -531,6 +580,9 @@ def main():
     search = None
     if not args.no_search:
         search = search_section(args, gpu, torch, dist, rank, world, matrices, barrier)
+    nucl = None
+    if not args.no_nucl and not args.prefilter_only:
+        nucl = nucl_section(args, gpu, matrices, rank)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -568,6 +620,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(matrices, qs, cbs, tres, toff, args.cpu_seconds, res)
         if search is not None:
             out["search"] = search
+        if nucl is not None:
+            out["nucleotide_align"] = nucl
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     gpu.close()
     if dist is not None:

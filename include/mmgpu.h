@@ -164,6 +164,52 @@ typedef struct {
 int mmgpu_sw_traceback(mmgpu_ctx *ctx, mmgpu_sw_batch_t *batch, const uint32_t *pair_index, uint32_t n_pairs,
                        mmgpu_sw_bt *info, char *bt, size_t bt_cap, size_t *bt_used);
 
+/* ---- nucleotide alignment step (behind Alignment::run for nucleotide databases) --------------------------------
+ * BandedNucleotideAligner::align (src/alignment/BandedNucleotideAligner.cpp:76-263; Matcher::getSWResult calls it
+ * instead of the Smith-Waterman for DBTYPE_NUCLEOTIDES, Matcher.cpp:76-79): ungapped seed on the prefilter diagonal,
+ * left extension on the reversed sequences, right extension with CIGAR by ksw_extz2_sse (band 64, z-drop), backtrace.
+ * Targets are the resident database (mmgpu_load_targets with alphabet 5, numeric codes of NucleotideMatrix:
+ * A C T G X = 0..4); wrapped scoring (circular genomes) is not supported.
+ *
+ * past_end_query / past_end_target: the reference reads ONE residue past the end of both sequences
+ * (SmithWaterman::seq_reverse is called with L where it expects L - 1, BandedNucleotideAligner.cpp:61,68,93), i.e.
+ * whatever Sequence::numSequence[L] holds from earlier sequences.  That letter is an explicit input here (4 = X
+ * scores 0 in the extension); a host that wants its own run reproduced passes what its buffers hold. */
+typedef struct {
+    const int8_t *mat;        /* 5 x 5, NucleotideMatrix::subMatrix as int8 (nucleotide.out: match 2, mismatch -3) */
+    const uint8_t *reverse;   /* [5] NucleotideMatrix::reverseResidue */
+    int gap_open, gap_extend; /* 5, 2 (Parameters: gapOpen / gapExtend for nucleotides) */
+    int zdrop;                /* par.zdrop (40) */
+    int past_end_query, past_end_target;
+} mmgpu_nucl_params;
+typedef struct {
+    const uint8_t *q;  /* Sequence::numSequence of the query (forward strand) */
+    uint32_t qlen;
+} mmgpu_nucl_query;
+typedef struct {
+    uint32_t query;    /* index into the queries of the call */
+    uint32_t target;   /* id in the resident database */
+    uint16_t diagonal; /* hit_t::diagonal of the prefilter hit */
+    uint8_t reverse;   /* 1: align the reverse complement of the query (Matcher::getSWResult's isReverse) */
+    uint8_t reserved;
+} mmgpu_nucl_pair;
+typedef struct {
+    int32_t score;              /* s_align::score1 */
+    int32_t q_start, q_end;     /* on the aligned strand, like s_align::qStartPos1 / qEndPos1 */
+    int32_t t_start, t_end;
+    uint32_t ident;             /* identicalAACnt */
+    uint32_t bt_len;            /* letters of the backtrace (M / I / D), 0-terminated in bt */
+    int32_t status;             /* MMGPU_NUCL_* */
+    uint64_t bt_off;            /* offset of this pair's string in bt */
+} mmgpu_nucl_hit;
+#define MMGPU_NUCL_OK 0
+#define MMGPU_NUCL_BT_OVERFLOW 1 /* bt_cap was too small for this pair's string: positions and score are valid */
+/* Synchronous.  out[i] belongs to pairs[i]; strings are packed into bt in completion order; *bt_used = bytes needed
+ * (sum of bt_len + 1).  bt_cap = sum over pairs of (qlen + tlen + 2) always suffices. */
+int mmgpu_nucl_align(mmgpu_ctx *ctx, const mmgpu_nucl_params *params, const mmgpu_nucl_query *queries, uint32_t n_queries,
+                     const mmgpu_nucl_pair *pairs, uint32_t n_pairs, mmgpu_nucl_hit *out, char *bt, uint64_t bt_cap,
+                     uint64_t *bt_used);
+
 /* ---- k-mer prefilter (behind Prefiltering::runSplit) ---------------------------------------------------------
  * Host-side table builders.  In a drop-in build the reference's own objects supply these tables
  * (ExtendedSubstitutionMatrix::calcScoreMatrix, Prefiltering.cpp:220-225; IndexBuilder::fillDatabase,

@@ -41,6 +41,21 @@ class SwQuery(ctypes.Structure):
                 ("n_targets", ctypes.c_uint32), ("min_start_score", ctypes.c_int32)]
 
 
+class NuclParams(ctypes.Structure):
+    _fields_ = [("mat", c_p), ("reverse", c_p), ("gap_open", ctypes.c_int), ("gap_extend", ctypes.c_int), ("zdrop", ctypes.c_int),
+                ("past_end_query", ctypes.c_int), ("past_end_target", ctypes.c_int)]
+
+
+class NuclQuery(ctypes.Structure):
+    _fields_ = [("q", c_p), ("qlen", ctypes.c_uint32)]
+
+
+NUCL_PAIR_DTYPE = np.dtype([("query", np.uint32), ("target", np.uint32), ("diagonal", np.uint16), ("reverse", np.uint8),
+                            ("reserved", np.uint8)])
+NUCL_HIT_DTYPE = np.dtype([("score", np.int32), ("q_start", np.int32), ("q_end", np.int32), ("t_start", np.int32),
+                           ("t_end", np.int32), ("ident", np.uint32), ("bt_len", np.uint32), ("status", np.int32),
+                           ("bt_off", np.uint64)])
+
 SW_BT_DTYPE = np.dtype([("bt_off", np.uint64), ("bt_len", np.uint32), ("ident", np.uint32), ("status", np.int32),
                         ("reserved", np.int32)])
 SW_HIT_DTYPE = np.dtype([("score", np.int32), ("q_end", np.int32), ("t_end", np.int32), ("q_start", np.int32),
@@ -51,7 +66,7 @@ EXPORTED_SYMBOLS = [
     "mmgpu_init", "mmgpu_destroy", "mmgpu_last_error", "mmgpu_set_stream", "mmgpu_synchronize",
     "mmgpu_device_info", "mmgpu_host_comp_bias", "mmgpu_host_round_comp_bias", "mmgpu_load_targets", "mmgpu_sw_batch", "mmgpu_sw_prepare", "mmgpu_sw_run",
     "mmgpu_sw_fetch", "mmgpu_sw_batch_stats", "mmgpu_sw_last_kernel_ms", "mmgpu_sw_kernel_ms_mean", "mmgpu_sw_free",
-    "mmgpu_sw_traceback", "mmgpu_sw_prepare_from_pf", "mmgpu_sw_fetch_device",
+    "mmgpu_sw_traceback", "mmgpu_sw_prepare_from_pf", "mmgpu_sw_fetch_device", "mmgpu_nucl_align",
     "mmgpu_host_score_matrix", "mmgpu_host_index_build", "mmgpu_pf_load_index", "mmgpu_pf_batch", "mmgpu_pf_prepare",
     "mmgpu_pf_run", "mmgpu_pf_fetch", "mmgpu_pf_stage_ms", "mmgpu_pf_last_cells", "mmgpu_pf_fetch_device", "mmgpu_pf_merge_splits", "mmgpu_pf_build_index", "mmgpu_pf_debug_index", "mmgpu_pf_debug_fetch", "mmgpu_pf_free",
 ]
@@ -102,6 +117,8 @@ def load_library():
     L.mmgpu_sw_prepare.argtypes = [c_p, ctypes.POINTER(SwParams), c_p, ctypes.c_uint32, ctypes.c_int, ctypes.POINTER(c_p)]
     L.mmgpu_sw_prepare_from_pf.argtypes = [c_p, ctypes.POINTER(SwParams), c_p, ctypes.c_uint32, ctypes.c_int, c_p, ctypes.POINTER(c_p)]
     L.mmgpu_sw_run.argtypes = [c_p, c_p]
+    L.mmgpu_nucl_align.argtypes = [c_p, ctypes.POINTER(NuclParams), c_p, ctypes.c_uint32, c_p, ctypes.c_uint32, c_p, c_p,
+                                   ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)]
     L.mmgpu_sw_fetch_device.argtypes = [c_p, c_p, c_p]
     L.mmgpu_sw_fetch.argtypes = [c_p, c_p, c_p]
     L.mmgpu_sw_batch_stats.argtypes = [c_p, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
@@ -334,6 +351,7 @@ class MMGpu:
         offsets = np.ascontiguousarray(offsets, np.uint64)
         self._check(self.L.mmgpu_load_targets(self.ctx, _ptr(residues), _ptr(offsets), len(offsets) - 1, alphabet))
         self.n_targets = len(offsets) - 1
+        self._target_lens = np.diff(offsets.astype(np.int64))
 
     def _marshal(self, mat, gap_open, gap_extend, queries):
         """queries: list of dicts {q: uint8[], comp_bias: int8[]|None, targets: uint32[], min_start_score: int}"""
@@ -379,6 +397,34 @@ class MMGpu:
         b = SwBatch(self, h, keep)
         b.slots = n * pf_batch.max_hits
         return b
+
+    # ---- nucleotide alignment step ----
+    def nucl_align(self, mat, reverse, queries, pairs, gap_open=5, gap_extend=2, zdrop=40, past_end_query=4, past_end_target=4):
+        """queries: list of uint8 arrays (codes 0..4); pairs: structured NUCL_PAIR_DTYPE array (or list of
+        (query, target, diagonal, reverse)).  Returns (NUCL_HIT_DTYPE array, list of backtrace strings)."""
+        mat = np.ascontiguousarray(mat, np.int8).reshape(-1)
+        rev = np.ascontiguousarray(reverse, np.uint8)
+        if not (isinstance(pairs, np.ndarray) and pairs.dtype == NUCL_PAIR_DTYPE):
+            pa = np.zeros(len(pairs), NUCL_PAIR_DTYPE)
+            for i, p in enumerate(pairs):
+                pa[i] = (p[0], p[1], p[2] & 0xFFFF, p[3], 0)
+            pairs = pa
+        pairs = np.ascontiguousarray(pairs)
+        qs = [np.ascontiguousarray(q, np.uint8) for q in queries]
+        arr = (NuclQuery * max(len(qs), 1))()
+        for i, q in enumerate(qs):
+            arr[i] = NuclQuery(_ptr(q), len(q))
+        par = NuclParams(_ptr(mat), _ptr(rev), gap_open, gap_extend, zdrop, past_end_query, past_end_target)
+        out = np.zeros(len(pairs), NUCL_HIT_DTYPE)
+        tl = self._target_lens
+        cap = int(sum(len(qs[int(p["query"])]) + int(tl[int(p["target"])]) + 2 for p in pairs)) if len(pairs) else 16
+        bt = np.zeros(max(cap, 16), np.uint8)
+        used = ctypes.c_uint64()
+        self._check(self.L.mmgpu_nucl_align(self.ctx, ctypes.byref(par), ctypes.cast(arr, c_p), len(qs), _ptr(pairs), len(pairs),
+                                            _ptr(out), _ptr(bt), cap, ctypes.byref(used)))
+        raw = bt.tobytes()
+        strs = [raw[int(h["bt_off"]):int(h["bt_off"]) + int(h["bt_len"])].decode() if h["status"] == 0 else None for h in out]
+        return out, strs
 
     # ---- prefilter ----
     def pf_load_index(self, k, alphabet, spaced, score3, index3, offsets, entry_ids, entry_pos, ungapped_mat,

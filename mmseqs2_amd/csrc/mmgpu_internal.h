@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../include/mmgpu.h"
+#include "nucl_core.h"
 
 namespace mmgpu {
 
@@ -410,6 +411,9 @@ inline hipError_t upload(DevBuf &b, const std::vector<T> &v, hipStream_t s) {
     if (v.empty()) return hipSuccess;
     return hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s);
 }
+
+// nucleotide alignment step (nucl_kernel.hip; NuclLaunch is declared in nucl_core.h)
+hipError_t launch_nucl_align(const NuclLaunch &L, unsigned blocks, hipStream_t stream);
 
 struct PfIndex;   // pf_api.hip
 

@@ -1,0 +1,105 @@
+// Host side of the nucleotide alignment step (include/mmgpu.h: mmgpu_nucl_align): uploads the queries and pairs,
+// orders the pairs longest first, sizes the per-group scratch and runs nucl_align_kernel.
+#include "mmgpu_internal.h"
+
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+
+using namespace mmgpu;
+
+
+extern "C" int mmgpu_nucl_align(mmgpu_ctx *c, const mmgpu_nucl_params *par, const mmgpu_nucl_query *qs, uint32_t nq,
+                                const mmgpu_nucl_pair *pairs, uint32_t n_pairs, mmgpu_nucl_hit *out, char *bt, uint64_t bt_cap,
+                                uint64_t *bt_used) {
+    if (!c || !par || !par->mat || !par->reverse || (!qs && nq) || (!pairs && n_pairs) || (!out && n_pairs))
+        return fail(MMGPU_ERR_ARG, "mmgpu_nucl_align: NULL argument");
+    if (!c->db.res) return fail(MMGPU_ERR_STATE, "mmgpu_nucl_align: no targets loaded");
+    if (c->db.alphabet != 5) return fail(MMGPU_ERR_ARG, "mmgpu_nucl_align: the resident targets are not nucleotides (alphabet 5)");
+    if (par->gap_open < 0 || par->gap_extend < 0 || par->gap_open + par->gap_extend > 60)
+        return fail(MMGPU_ERR_ARG, "mmgpu_nucl_align: gap penalties out of the 8-bit range of the extension");
+    if (bt_used) *bt_used = 0;
+    if (n_pairs == 0) return MMGPU_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    std::vector<uint32_t> qoff(nq + 1, 0);
+    for (uint32_t i = 0; i < nq; i++) {
+        if (!qs[i].q || qs[i].qlen == 0 || qs[i].qlen > 0x3FFFFFFFu) return fail(MMGPU_ERR_ARG, "mmgpu_nucl_align: bad query");
+        qoff[i + 1] = qoff[i] + qs[i].qlen;
+    }
+    std::vector<uint8_t> qres(qoff[nq]);
+    for (uint32_t i = 0; i < nq; i++) {
+        for (uint32_t k = 0; k < qs[i].qlen; k++)
+            if (qs[i].q[k] > 4) return fail(MMGPU_ERR_ARG, "mmgpu_nucl_align: query residue code > 4");
+        memcpy(qres.data() + qoff[i], qs[i].q, qs[i].qlen);
+    }
+    uint64_t longest = 0;
+    std::vector<uint64_t> work(n_pairs);
+    for (uint32_t i = 0; i < n_pairs; i++) {
+        if (pairs[i].query >= nq || pairs[i].target >= c->db.n) return fail(MMGPU_ERR_ARG, "mmgpu_nucl_align: pair index out of range");
+        const uint64_t span = (uint64_t)qs[pairs[i].query].qlen + c->h_len[pairs[i].target];
+        work[i] = span;
+        longest = std::max(longest, span);
+    }
+    std::vector<uint32_t> order(n_pairs);
+    std::iota(order.begin(), order.end(), 0u);
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return work[a] > work[b]; });
+
+    // one slice of direction bytes (6 blocks of 16 per anti-diagonal) and of backtrack letters per 16-lane group
+    const uint64_t p_stride = (longest * 6 + 2) * 16, w_stride = (longest + 16 + 15) / 16 * 16;
+    uint64_t groups = ((uint64_t)n_pairs + 15) / 16 * 16;
+    groups = std::min<uint64_t>(groups, (uint64_t)c->compute_units * 4 * 16);          // 4 workgroups of 16 groups per CU
+    const uint64_t budget = 96ull << 30;
+    while (groups > 16 && groups * (p_stride + w_stride) > budget) groups -= 16;
+    if (groups * (p_stride + w_stride) > budget) return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_nucl_align: sequences too long for the direction scratch");
+    const unsigned blocks = (unsigned)(groups / 16);
+
+    hipStream_t s = c->stream;
+    DevBuf d_pairs, d_order, d_qres, d_qoff, d_p, d_w, d_out, d_bt, d_ctr;
+    for (DevBuf *d : {&d_pairs, &d_order, &d_qres, &d_qoff, &d_p, &d_w, &d_out, &d_bt, &d_ctr}) d->bind(c->cache);
+    std::vector<mmgpu_nucl_pair> pv(pairs, pairs + n_pairs);
+    HIP_TRY(upload(d_pairs, pv, s));
+    HIP_TRY(upload(d_order, order, s));
+    HIP_TRY(upload(d_qres, qres, s));
+    HIP_TRY(upload(d_qoff, qoff, s));
+    HIP_TRY(d_p.alloc(groups * p_stride));
+    HIP_TRY(d_w.alloc(groups * w_stride));
+    HIP_TRY(d_out.alloc((size_t)n_pairs * sizeof(mmgpu_nucl_hit)));
+    HIP_TRY(d_bt.alloc(std::max<uint64_t>(bt_cap, 16)));
+    HIP_TRY(d_ctr.alloc(16));
+    HIP_TRY(hipMemsetAsync(d_ctr.p, 0, 16, s));
+    HIP_TRY(hipMemsetAsync(d_out.p, 0, (size_t)n_pairs * sizeof(mmgpu_nucl_hit), s));
+
+    NuclLaunch L;
+    L.pairs = d_pairs.as<mmgpu_nucl_pair>();
+    L.order = d_order.as<uint32_t>();
+    L.n_pairs = n_pairs;
+    L.q_res = d_qres.as<uint8_t>();
+    L.q_off = d_qoff.as<uint32_t>();
+    L.t_res = c->db.res;
+    L.t_off4 = c->db.off4;
+    L.t_len = c->db.len;
+    for (int i = 0; i < 25; i++) L.mat[i] = par->mat[i];
+    for (int i = 0; i < 8; i++) L.rev_lookup[i] = i < 5 ? par->reverse[i] : (uint8_t)4;
+    L.gapo = par->gap_open;
+    L.gape = par->gap_extend;
+    L.zdrop = par->zdrop;
+    L.past_end_q = par->past_end_query;
+    L.past_end_t = par->past_end_target;
+    L.pscratch = d_p.as<uint8_t>();
+    L.pscratch_stride = p_stride;
+    L.wscratch = d_w.as<char>();
+    L.wscratch_stride = w_stride;
+    L.out = d_out.as<mmgpu_nucl_hit>();
+    L.bt = d_bt.as<char>();
+    L.bt_cursor = d_ctr.as<unsigned long long>();
+    L.bt_cap = bt_cap;
+    L.next_pair = reinterpret_cast<uint32_t *>(d_ctr.as<unsigned long long>() + 1);
+    HIP_TRY(launch_nucl_align(L, blocks, s));
+    HIP_TRY(hipMemcpyAsync(out, d_out.p, (size_t)n_pairs * sizeof(mmgpu_nucl_hit), hipMemcpyDeviceToHost, s));
+    unsigned long long used = 0;
+    HIP_TRY(hipMemcpyAsync(&used, d_ctr.p, 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (bt && bt_cap) HIP_TRY(hipMemcpy(bt, d_bt.p, (size_t)std::min<uint64_t>(used, bt_cap), hipMemcpyDeviceToHost));
+    if (bt_used) *bt_used = used;
+    return MMGPU_OK;
+}

@@ -147,3 +147,46 @@ def config3_prefilter(n_families=20000, members=50, n_queries=10000, seed=10, ch
     qfam = rq.choice(n_families, n_queries, replace=False)
     qres, qoff = mutate_many(rq, sres, soff, qfam)
     return (qres, qoff), (tres, toff), fam, qfam
+
+
+# ---------------------------------------------------------------------------------------------------------
+# BASELINE.json configs[4] (nucleotide): reads sampled from contigs with substitutions and indels
+NUCL_LETTERS = "ACTGN"                       # numeric codes of NucleotideMatrix (nucleotide.out column order, N -> X = 4)
+NUCL_REVERSE = np.array([2, 3, 0, 1, 4], np.uint8)
+
+
+def mutate_nucl(rng, seq, sub=0.10, indel=0.02):
+    """substitutions at rate `sub`, insertions and deletions (1..3 bases) at rate `indel` / 2 each, vectorised"""
+    s = seq.copy()
+    m = rng.random(len(s)) < sub
+    s[m] = rng.integers(0, 4, size=int(m.sum())).astype(np.uint8)
+    keep = np.ones(len(s), bool)
+    for p in np.nonzero(rng.random(len(s)) < indel / 2)[0]:
+        keep[p:p + int(rng.integers(1, 4))] = False
+    s = s[keep]
+    ins = np.nonzero(rng.random(len(s)) < indel / 2)[0]
+    if len(ins):
+        s = np.insert(s, ins, rng.integers(0, 4, size=len(ins)).astype(np.uint8))
+    return s if len(s) else np.zeros(1, np.uint8)
+
+
+def config5_nucleotide(n_contigs=4000, n_reads=1000, read_len=10000, false_hits=4, seed=20):
+    """-> (queries list, (tres, toff), pairs [(query, target, diagonal16, reverse)]).  Contig lengths ~ LogNormal with
+    median 20 kb, clipped to [read_len + 500, 60000] (the reference splits longer sequences, Parameters.h:271).  Every
+    read has the pair a prefilter would report (its source contig, the true diagonal; every second read is stored as its
+    reverse complement and flagged `reverse`) and `false_hits` unrelated contigs with arbitrary diagonals."""
+    rng = np.random.default_rng(seed)
+    lens = np.clip(np.round(rng.lognormal(np.log(20000.0), 0.5, size=n_contigs)), read_len + 500, 60000).astype(np.int64)
+    toff = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    tres = rng.integers(0, 4, size=int(toff[-1])).astype(np.uint8)
+    queries, pairs = [], []
+    for r in range(n_reads):
+        c = int(rng.integers(0, n_contigs))
+        start = int(rng.integers(0, lens[c] - read_len))
+        read = mutate_nucl(rng, tres[int(toff[c]) + start:int(toff[c]) + start + read_len])
+        rev = r & 1
+        queries.append(NUCL_REVERSE[read[::-1]] if rev else read)
+        pairs.append((r, c, (-start) & 0xFFFF, rev))
+        for _ in range(false_hits):
+            pairs.append((r, int(rng.integers(0, n_contigs)), int(rng.integers(0, 65536)), int(rng.integers(0, 2))))
+    return queries, (tres, toff), pairs

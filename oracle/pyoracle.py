@@ -509,7 +509,8 @@ class NuclOracle:
 class RefNucl:
     """The real BandedNucleotideAligner / ksw_extz2_sse (oracle/ref_shim_nucl.cpp); needs /root/reference/data."""
 
-    def __init__(self, max_len=70000, gap_open=5, gap_extend=2, zdrop=40, db_residues=100000000):
+    def __init__(self, max_len=70000, gap_open=5, gap_extend=2, zdrop=40, db_residues=100000000, serialized=None):
+        """serialized: the "nucleotide.out:DATA" bytes of tests/golden/matrices.npz where /root/reference is absent"""
         L = self.L = ctypes.CDLL(REF_SO)
         L.mmref_nucl_new.restype = c_p
         L.mmref_nucl_new.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint64]
@@ -522,9 +523,38 @@ class RefNucl:
                                        ctypes.POINTER(NuclRes), ctypes.c_char_p, ctypes.c_int]
         L.mmref_ksw_extz2.argtypes = [ctypes.c_int, c_p, ctypes.c_int, c_p, ctypes.c_int, c_p, ctypes.c_int, ctypes.c_int,
                                       ctypes.c_int, ctypes.c_int, ctypes.c_int, c_p, c_p, ctypes.c_int]
-        path = os.path.join(REFERENCE_ROOT, "data", "nucleotide.out").encode()
-        self.ctx = L.mmref_nucl_new(path, max_len, gap_open, gap_extend, zdrop, db_residues)
+        self.path = bytes(serialized) if serialized is not None else os.path.join(REFERENCE_ROOT, "data", "nucleotide.out").encode()
+        self.args = (max_len, gap_open, gap_extend, zdrop)
+        self.ctx = L.mmref_nucl_new(self.path, max_len, gap_open, gap_extend, zdrop, db_residues)
         self._q = None
+
+    def serialized_matrix(self):
+        b = ctypes.create_string_buffer(1 << 16)
+        self.L.mmref_nucl_serialized_matrix.argtypes = [c_p, ctypes.c_char_p, ctypes.c_int]
+        n = self.L.mmref_nucl_serialized_matrix(self.ctx, b, 1 << 16)
+        assert n > 0
+        return b.raw[:n]
+
+    def batch(self, q_chars, q_off, t_chars, t_off, pair_q, pair_t, pair_diag, pair_rev, n_threads, past_end=4):
+        """BandedNucleotideAligner::align for every pair on n_threads host threads -> (seconds, [n, 6] int32 results
+        (score, q_start, q_end, t_start, t_end, ident), backtrace lengths)."""
+        L = self.L
+        L.mmref_nucl_batch.restype = ctypes.c_double
+        L.mmref_nucl_batch.argtypes = [ctypes.c_char_p] + [ctypes.c_int] * 6 + [c_p] * 8 + [ctypes.c_uint32, c_p, c_p]
+        q_off = np.ascontiguousarray(q_off, np.uint64)
+        t_off = np.ascontiguousarray(t_off, np.uint64)
+        pq = np.ascontiguousarray(pair_q, np.uint32)
+        pt = np.ascontiguousarray(pair_t, np.uint32)
+        pd = np.ascontiguousarray(pair_diag, np.uint16)
+        pr = np.ascontiguousarray(pair_rev, np.uint8)
+        out = np.zeros((len(pq), 6), np.int32)
+        bl = np.zeros(len(pq), np.uint32)
+        qc = np.ascontiguousarray(q_chars, np.uint8)
+        tc = np.ascontiguousarray(t_chars, np.uint8)
+        sec = L.mmref_nucl_batch(self.path, self.args[0], self.args[1], self.args[2], self.args[3], int(past_end), int(n_threads),
+                                 _ptr(qc), _ptr(q_off), _ptr(tc), _ptr(t_off), _ptr(pq), _ptr(pt), _ptr(pd), _ptr(pr), len(pq),
+                                 _ptr(out), _ptr(bl))
+        return sec, out, bl
 
     def matrix(self):
         out = np.zeros((5, 5), np.int8)

@@ -140,3 +140,52 @@ int mmref_ksw_extz2(int qlen, const uint8_t *query, int tlen, const uint8_t *tar
 }
 
 }  // extern "C"
+
+// Batch form for bench.py's cpu_baseline leg: pairs spread over OpenMP threads, one BandedNucleotideAligner and one
+// pair of Sequence objects per thread (what Alignment::run keeps per thread, Alignment.cpp:279-295).  Sequences are
+// ASCII (A C G T N); pairs must be grouped by query (the query is re-initialised when it changes).
+#include <omp.h>
+extern "C" double mmref_nucl_batch(const char *matrix_file, int max_len, int gap_open, int gap_extend, int zdrop, int past_end,
+                                   int n_threads, const char *q_chars, const uint64_t *q_off, const char *t_chars,
+                                   const uint64_t *t_off, const uint32_t *pair_q, const uint32_t *pair_t, const uint16_t *pair_diag,
+                                   const uint8_t *pair_rev, uint32_t n_pairs, int32_t *out /* n_pairs x 6 */, uint32_t *bt_len) {
+    Debug::setDebugLevel(Debug::ERROR);
+    std::vector<mmref_nucl_ctx *> ctxs(n_threads);
+    for (int t = 0; t < n_threads; t++) ctxs[t] = mmref_nucl_new(matrix_file, max_len, gap_open, gap_extend, zdrop, 100000000ull);
+    const double t0 = omp_get_wtime();
+#pragma omp parallel num_threads(n_threads)
+    {
+        mmref_nucl_ctx *c = ctxs[omp_get_thread_num()];
+        uint32_t cur_q = 0xFFFFFFFFu;
+        std::vector<char> bt;
+#pragma omp for schedule(dynamic, 4)
+        for (uint32_t i = 0; i < n_pairs; i++) {
+            const uint32_t q = pair_q[i], t = pair_t[i];
+            if (q != cur_q) {
+                mmref_nucl_set_query(c, q_chars + q_off[q], (int)(q_off[q + 1] - q_off[q]), past_end);
+                cur_q = q;
+            }
+            const int tlen = (int)(t_off[t + 1] - t_off[t]);
+            bt.resize((size_t)(q_off[q + 1] - q_off[q]) + tlen + 8);
+            mmref_nucl_result r;
+            mmref_nucl_align(c, t_chars + t_off[t], tlen, past_end, pair_diag[i], pair_rev[i], 0, &r, bt.data(), (int)bt.size());
+            out[i * 6 + 0] = r.score; out[i * 6 + 1] = r.q_start; out[i * 6 + 2] = r.q_end;
+            out[i * 6 + 3] = r.t_start; out[i * 6 + 4] = r.t_end; out[i * 6 + 5] = (int32_t)r.ident;
+            bt_len[i] = (uint32_t)r.bt_len;
+        }
+    }
+    const double dt = omp_get_wtime() - t0;
+    for (int t = 0; t < n_threads; t++) mmref_nucl_free(ctxs[t]);
+    return dt;
+}
+
+// "name:data" form of the matrix (BaseMatrix::serialize) so that the prebuilt library can build its NucleotideMatrix
+// on the GPU box, where /root/reference/data does not exist (stored in tests/golden/matrices.npz by make_golden.py)
+extern "C" int mmref_nucl_serialized_matrix(mmref_nucl_ctx *c, char *out, int cap) {
+    char *s = BaseMatrix::serialize(c->m->matrixName, c->m->matrixData);
+    int n = (int)strlen(s);
+    if (n + 1 > cap) { free(s); return -n; }
+    memcpy(out, s, (size_t)n + 1);
+    free(s);
+    return n;
+}

@@ -8,6 +8,8 @@ by `make -C oracle ref` from /root/reference).  Runs only where /root/reference 
 matrices.npz : the integer substitution matrices the reference derives from data/*.out
                (BaseMatrix::generateSubMatrix, BaseMatrix.cpp:141-154) and its background pBack
 sw_vectors.npz : (query, target) pairs with the reference's s_align fields in modes 0/1/2
+nucl_vectors.npz : nucleotide (query, target, diagonal, strand) cases with what BandedNucleotideAligner::align returns
+               (real reference classes through oracle/ref_shim_nucl.cpp): score, positions, identities, backtrace
 prefilter_vectors.npz : queries + targets with the hit_t lists QueryMatcher::matchQuery returns (real reference
                classes through oracle/ref_shim_pref.cpp) for several (max_hits, bin count) settings
 """
@@ -45,6 +47,12 @@ def matrices():
     km.L.mmref_get_pback(km.c, pb2.ctypes.data)
     d["vtml80_pback"] = pb2
     d["vtml80_serialized"] = np.frombuffer(km.serialized_matrix(), np.uint8)
+    from oracle.pyoracle import RefNucl
+    nu = RefNucl()
+    d["nucleotide"] = nu.matrix()
+    d["nucleotide_reverse"] = nu.reverse_lookup()
+    d["nucleotide_serialized"] = np.frombuffer(nu.serialized_matrix(), np.uint8)
+    nu.close()
     np.savez_compressed(os.path.join(OUT, "matrices.npz"), **d)
     print("matrices.npz", {k: v.shape for k, v in d.items()})
     return sw
@@ -134,7 +142,69 @@ def prefilter_vectors():
     np.savez_compressed(os.path.join(OUT, "prefilter_vectors.npz"), **d)
 
 
+def nucl_vectors():
+    """Reads with substitutions / indels against their source, both strands, right and wrong prefilter diagonals, short
+    and long (z-drop, redone backward pass) cases, N letters, all five past-the-end letters."""
+    from oracle import pyoracle as po
+    rng = np.random.default_rng(2024)
+    ref = po.RefNucl()
+    mat, rl = ref.matrix(), ref.reverse_lookup()
+
+    def mutate(s, sub, indel):
+        out, i = [], 0
+        while i < len(s):
+            r = rng.random()
+            if r < indel / 2:
+                out.append(int(rng.integers(0, 4)))
+                continue
+            if r < indel:
+                i += int(rng.integers(1, 4))
+                continue
+            out.append(int(rng.integers(0, 4)) if rng.random() < sub else int(s[i]))
+            i += 1
+        return np.array(out if out else [0], np.uint8)
+
+    def letters(a):
+        return "".join(po.NUCL_LETTERS[int(x)] for x in a)
+
+    qs, ts, meta, exp, bts = [], [], [], [], []
+    lens = [1, 2, 7, 15, 16, 17, 33, 64, 65, 100, 150, 257, 400, 800, 1500, 3000, 6000]
+    for L in lens:
+        for rep in range(4):
+            base = rng.integers(0, 4, size=L).astype(np.uint8)
+            if rep == 3 and L > 10:
+                base[rng.integers(0, L, size=max(1, L // 25))] = 4
+            q = mutate(base, [0.0, 0.03, 0.1, 0.25][rep], [0.0, 0.01, 0.04, 0.08][rep])
+            t = mutate(base, [0.0, 0.02, 0.05, 0.1][rep], [0.0, 0.01, 0.02, 0.05][rep])
+            if rep >= 2:
+                t = np.concatenate([rng.integers(0, 4, size=int(rng.integers(0, 120))).astype(np.uint8), t,
+                                    rng.integers(0, 4, size=int(rng.integers(0, 120))).astype(np.uint8)])
+            pq, pt = int(rng.integers(0, 5)), int(rng.integers(0, 5))
+            ref.set_query(letters(q), pq)
+            for reverse in (0, 1):
+                tt = np.array([rl[x] for x in t[::-1]], np.uint8) if reverse else t
+                for diag in (0, int(rng.integers(-len(tt), len(q) + 1)), int(rng.integers(0, 65536))):
+                    r, bt = ref.align(letters(tt), diag & 0xFFFF, reverse, pt)
+                    qs.append(q)
+                    ts.append(tt)
+                    meta.append((diag & 0xFFFF, reverse, pq, pt))
+                    exp.append(r)
+                    bts.append(bt)
+    qoff = np.concatenate([[0], np.cumsum([len(x) for x in qs])]).astype(np.uint64)
+    toff = np.concatenate([[0], np.cumsum([len(x) for x in ts])]).astype(np.uint64)
+    boff = np.concatenate([[0], np.cumsum([len(x) for x in bts])]).astype(np.uint64)
+    np.savez_compressed(os.path.join(OUT, "nucl_vectors.npz"), qres=np.concatenate(qs), qoff=qoff, tres=np.concatenate(ts),
+                        toff=toff, meta=np.array(meta, np.int32), expected=np.array(exp, np.int64),
+                        bt=np.frombuffer("".join(bts).encode(), np.uint8), boff=boff, mat=mat, reverse=rl)
+    ref.close()
+    print("nucl_vectors:", len(qs), "cases,", int(boff[-1]), "backtrace letters")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "nucl":
+        nucl_vectors()
+        sys.exit(0)
     ref = matrices()
     sw_vectors(ref)
     prefilter_vectors()
+    nucl_vectors()

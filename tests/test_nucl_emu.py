@@ -1,0 +1,71 @@
+"""CPU test of the GPU kernel's own source (mmseqs2_amd/csrc/nucl_core.h) for the nucleotide alignment step: the
+kernel body is compiled for the host with 16 cooperative contexts standing in for the 16 lanes of an alignment group
+(tests/nucl_emu.cpp) and run against the vectors recorded from the real reference.  It does not replace the GPU parity
+test (tests/test_nucl_gpu.py); it catches logic errors of the lane-parallel formulation where no GPU is at hand."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from mmseqs2_amd import capi
+from tests import nucl_common as nc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SO = os.path.join(ROOT, "tests", "_build", "libnuclemu.so")
+
+
+def _lib():
+    src = os.path.join(ROOT, "tests", "nucl_emu.cpp")
+    core = os.path.join(ROOT, "mmseqs2_amd", "csrc", "nucl_core.h")
+    if not os.path.exists(SO) or os.path.getmtime(SO) < max(os.path.getmtime(src), os.path.getmtime(core)):
+        os.makedirs(os.path.dirname(SO), exist_ok=True)
+        subprocess.check_call(["g++", "-O2", "-shared", "-fPIC", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
+                               "-I" + os.path.join(ROOT, "mmseqs2_amd", "csrc"), src, "-o", SO])
+    return ctypes.CDLL(SO)
+
+
+def emu_align(L, mat, reverse, queries, targets, pairs, past_q, past_t, gapo=5, gape=2, zdrop=40):
+    c_p = ctypes.c_void_p
+    mat = np.ascontiguousarray(mat, np.int8).reshape(-1)
+    rev = np.ascontiguousarray(reverse, np.uint8)
+    qs = [np.ascontiguousarray(q, np.uint8) for q in queries]
+    arr = (capi.NuclQuery * len(qs))()
+    for i, q in enumerate(qs):
+        arr[i] = capi.NuclQuery(q.ctypes.data_as(c_p), len(q))
+    tres = np.ascontiguousarray(np.concatenate(targets), np.uint8)
+    toff = np.concatenate([[0], np.cumsum([len(t) for t in targets])]).astype(np.uint64)
+    pa = np.zeros(len(pairs), capi.NUCL_PAIR_DTYPE)
+    for i, p in enumerate(pairs):
+        pa[i] = (p[0], p[1], p[2] & 0xFFFF, p[3], 0)
+    par = capi.NuclParams(mat.ctypes.data_as(c_p), rev.ctypes.data_as(c_p), gapo, gape, zdrop, past_q, past_t)
+    out = np.zeros(len(pairs), capi.NUCL_HIT_DTYPE)
+    cap = int(sum(len(qs[p[0]]) + len(targets[p[1]]) + 2 for p in pairs))
+    bt = np.zeros(cap, np.uint8)
+    used = ctypes.c_uint64()
+    L.nucl_emu_align(ctypes.byref(par), ctypes.cast(arr, c_p), len(qs), tres.ctypes.data_as(c_p), toff.ctypes.data_as(c_p),
+                     len(targets), pa.ctypes.data_as(c_p), len(pairs), out.ctypes.data_as(c_p), bt.ctypes.data_as(c_p),
+                     ctypes.c_uint64(cap), ctypes.byref(used))
+    raw = bt.tobytes()
+    return out, [raw[int(h["bt_off"]):int(h["bt_off"]) + int(h["bt_len"])].decode() for h in out]
+
+
+def test_kernel_source_on_emulated_lanes_matches_golden():
+    L = _lib()
+    g = nc.golden()
+    cases = [c for c in nc.golden_cases(g) if len(c[0]) + len(c[1]) <= 1800]
+    assert len(cases) > 250
+    n = 0
+    for pq in range(5):
+        for pt in range(5):
+            sub = [c for c in cases if c[4] == pq and c[5] == pt]
+            if not sub:
+                continue
+            hits, strs = emu_align(L, g["mat"], g["reverse"], [c[0] for c in sub], [c[1] for c in sub],
+                                   [(i, i, c[2], c[3]) for i, c in enumerate(sub)], pq, pt)
+            for c, h, s in zip(sub, hits, strs):
+                got = (int(h["score"]), int(h["q_start"]), int(h["q_end"]), int(h["t_start"]), int(h["t_end"]), int(h["ident"]))
+                assert got == c[6][:6] and s == c[7], (len(c[0]), len(c[1]), c[2], c[3], got, c[6], s[:40], c[7][:40])
+                n += 1
+    assert n == len(cases)
