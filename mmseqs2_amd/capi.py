@@ -417,7 +417,9 @@ class MMGpu:
         par = NuclParams(_ptr(mat), _ptr(rev), gap_open, gap_extend, zdrop, past_end_query, past_end_target)
         out = np.zeros(len(pairs), NUCL_HIT_DTYPE)
         tl = self._target_lens
-        cap = int(sum(len(qs[int(p["query"])]) + int(tl[int(p["target"])]) + 2 for p in pairs)) if len(pairs) else 16
+        # room for every backtrace; indices are clipped here, the library is the one that rejects bad ones
+        ql = np.array([len(q) for q in qs] + [0], np.int64)
+        cap = int((ql[np.minimum(pairs["query"], len(qs))] + tl[np.minimum(pairs["target"], len(tl) - 1)] + 2).sum()) if len(pairs) else 16
         bt = np.zeros(max(cap, 16), np.uint8)
         used = ctypes.c_uint64()
         self._check(self.L.mmgpu_nucl_align(self.ctx, ctypes.byref(par), ctypes.cast(arr, c_p), len(qs), _ptr(pairs), len(pairs),

@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstdlib>
 
 #include <algorithm>
 #include <string>
@@ -372,7 +373,10 @@ struct DevBuf {
     DevBuf &operator=(const DevBuf &) = delete;
     DevBuf(DevBuf &&o) noexcept : p(o.p), bytes(o.bytes), cap(o.cap), cache(std::move(o.cache)) { o.p = nullptr; o.bytes = 0; o.cap = 0; }
     ~DevBuf() { release(); }
-    void bind(const std::shared_ptr<BlockCache> &c) { cache = c; }
+    void bind(const std::shared_ptr<BlockCache> &c) {
+        static const bool off = getenv("MMGPU_NO_BLOCK_CACHE") != nullptr;   // debugging aid: every buffer straight from hipMalloc
+        if (!off) cache = c;
+    }
     void release() {
         if (!p) return;
         if (cache && cap) cache->give(p, cap);

@@ -4,9 +4,10 @@
 //   NUCL_HD                      function qualifiers
 //   NUCL_LANE()                  lane of the group, 0..15
 //   NUCL_SHFL(v, src) / NUCL_SHFL_XOR(v, mask) / NUCL_SHFL_U64(v, src)   exchange inside the group
-//   NUCL_SYNC()                  phase boundary: LDS / scratch written by one lane is read by another.  On the GPU the
-//                                lanes of a group run in lock step, so this only pins the order of the memory
-//                                operations; the emulator switches contexts here.
+//   NUCL_SYNC()                  phase boundary: LDS written by one lane is read by another.  On the GPU the lanes of a
+//                                group run in lock step, so this only pins the order of the LDS operations; the
+//                                emulator switches contexts here.
+//   NUCL_SYNC_MEM()              the same for the scratch in global memory (direction bytes, backtrack letters)
 //   NUCL_ATOMIC_ADD_U32 / _U64   work queue and output cursor
 #ifndef MMGPU_NUCL_CORE_H
 #define MMGPU_NUCL_CORE_H
@@ -419,10 +420,10 @@ NUCL_HD void align_group(const NuclLaunch &L, GroupLds &S, uint8_t *p, char *w) 
                 ksw_extz2<true>(qr, wq, tr, wt, L.mat, L.gapo, L.gape, L.zdrop, S, p, eza);
                 walk_reversed = true;
             }
-            NUCL_SYNC();
+            NUCL_SYNC_MEM();   // the direction bytes were written by all lanes
             if (lane == 0 && eza.max_t >= 0 && eza.max_q >= 0) n_bt = ksw_walk(p, wq, wt, eza.max_t, eza.max_q, w);
             n_bt = NUCL_SHFL(n_bt, 0);
-            NUCL_SYNC();
+            NUCL_SYNC_MEM();
             res.score = eza.max;
             res.q_start = q_start;
             res.q_end = q_start + eza.max_q;
@@ -432,7 +433,7 @@ NUCL_HD void align_group(const NuclLaunch &L, GroupLds &S, uint8_t *p, char *w) 
             // backward pass (CIGAR reversed once more by the caller) as they are
             walk_reversed = !walk_reversed;
         }
-        NUCL_SYNC();   // w[] was written by all lanes of the group, lane 0 reads it below
+        NUCL_SYNC_MEM();   // w[] was written by all lanes of the group, lane 0 reads it below
         // ---- output: reserve space, copy the string in alignment order, count identities (:231-258)
         unsigned long long off = NUCL_ATOMIC_ADD_U64(L.bt_cursor, lane == 0 ? (unsigned long long)n_bt + 1ull : 0ull);
         off = NUCL_SHFL_U64(off, 0);

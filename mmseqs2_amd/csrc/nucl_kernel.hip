@@ -20,11 +20,18 @@
 #define NUCL_SHFL(v, src) __shfl((v), (src), 16)
 #define NUCL_SHFL_XOR(v, mask) __shfl_xor((v), (mask), 16)
 #define NUCL_SHFL_U64(v, src) ((unsigned long long)__shfl((long long)(v), (src), 16))
-// the lanes of a group run in lock step: a phase boundary only has to keep the memory operations in order
-#define NUCL_SYNC()                                        \
-    do {                                                   \
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); \
-        __builtin_amdgcn_wave_barrier();                   \
+// the lanes of a group run in lock step: a phase boundary only has to keep the memory operations in order.  The LDS
+// form must not wait for the direction bytes still on their way to HBM (a full fence per phase made the kernel 20x
+// slower than its LDS chain).
+#define NUCL_SYNC()                                                     \
+    do {                                                                \
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local"); \
+        __builtin_amdgcn_wave_barrier();                                \
+    } while (0)
+#define NUCL_SYNC_MEM()                                        \
+    do {                                                       \
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); \
+        __builtin_amdgcn_wave_barrier();                       \
     } while (0)
 #define NUCL_ATOMIC_ADD_U32(p, v) atomicAdd((p), (v))
 #define NUCL_ATOMIC_ADD_U64(p, v) atomicAdd((p), (v))

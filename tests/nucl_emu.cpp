@@ -58,6 +58,7 @@ template <typename T> static inline T emu_shfl(T v, int src) { return (T)emu::ex
 #define NUCL_SHFL_XOR(v, mask) emu_shfl((v), emu::cur ^ (mask))
 #define NUCL_SHFL_U64(v, src) (emu::exchange((v), (src)))
 #define NUCL_SYNC() emu::sync()
+#define NUCL_SYNC_MEM() emu::sync()
 static inline unsigned emu_add32(uint32_t *p, unsigned v) { const unsigned o = *p; *p += v; return o; }
 static inline unsigned long long emu_add64(unsigned long long *p, unsigned long long v) { const unsigned long long o = *p; *p += v; return o; }
 #define NUCL_ATOMIC_ADD_U32(p, v) emu_add32((p), (v))
