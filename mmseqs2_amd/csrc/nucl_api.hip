@@ -3,6 +3,7 @@
 #include "mmgpu_internal.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 
@@ -32,25 +33,30 @@ extern "C" int mmgpu_nucl_align(mmgpu_ctx *c, const mmgpu_nucl_params *par, cons
             if (qs[i].q[k] > 4) return fail(MMGPU_ERR_ARG, "mmgpu_nucl_align: query residue code > 4");
         memcpy(qres.data() + qoff[i], qs[i].q, qs[i].qlen);
     }
-    uint64_t longest = 0;
+    // Anti-diagonals one extension can visit: the band (w = 64) leaves the shorter sequence after 2 * min + w of them.
+    uint64_t longest = 0, most_rows = 0;
     std::vector<uint64_t> work(n_pairs);
     for (uint32_t i = 0; i < n_pairs; i++) {
         if (pairs[i].query >= nq || pairs[i].target >= c->db.n) return fail(MMGPU_ERR_ARG, "mmgpu_nucl_align: pair index out of range");
-        const uint64_t span = (uint64_t)qs[pairs[i].query].qlen + c->h_len[pairs[i].target];
-        work[i] = span;
-        longest = std::max(longest, span);
+        const uint64_t ql = qs[pairs[i].query].qlen, tl = c->h_len[pairs[i].target];
+        const uint64_t rows = std::min<uint64_t>(ql + tl, 2 * std::min(ql, tl) + 66);
+        work[i] = rows;
+        longest = std::max(longest, ql + tl);
+        most_rows = std::max(most_rows, rows);
     }
     std::vector<uint32_t> order(n_pairs);
     std::iota(order.begin(), order.end(), 0u);
     std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return work[a] > work[b]; });
 
-    // one slice of direction bytes (6 blocks of 16 per anti-diagonal) and of backtrack letters per 16-lane group
-    const uint64_t p_stride = (longest * 6 + 2) * 16, w_stride = (longest + 16 + 15) / 16 * 16;
+    // one slice of direction bytes (6 blocks of 16 per anti-diagonal) and of backtrack letters per 16-lane group; the
+    // number of groups in flight is what fits the scratch budget (a group that finishes takes the next pair)
+    const uint64_t p_stride = (most_rows * 6 + 2) * 16, w_stride = (longest + 16 + 15) / 16 * 16;
     uint64_t groups = ((uint64_t)n_pairs + 15) / 16 * 16;
     groups = std::min<uint64_t>(groups, (uint64_t)c->compute_units * 4 * 16);          // 4 workgroups of 16 groups per CU
-    const uint64_t budget = 96ull << 30;
+    static const uint64_t budget_gb = getenv("MMGPU_NUCL_SCRATCH_GB") ? std::max(1, atoi(getenv("MMGPU_NUCL_SCRATCH_GB"))) : 16;
+    const uint64_t budget = budget_gb << 30;
     while (groups > 16 && groups * (p_stride + w_stride) > budget) groups -= 16;
-    if (groups * (p_stride + w_stride) > budget) return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_nucl_align: sequences too long for the direction scratch");
+    if (groups * (p_stride + w_stride) > (96ull << 30)) return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_nucl_align: sequences too long for the direction scratch");
     const unsigned blocks = (unsigned)(groups / 16);
 
     hipStream_t s = c->stream;
