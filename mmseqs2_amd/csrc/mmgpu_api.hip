@@ -508,6 +508,13 @@ extern "C" int mmgpu_sw_run(mmgpu_ctx *c, mmgpu_sw_batch_t *b) {
             L.scratch = b->d_scratch.as<uint2>();
             L.scratch_cols = b->scratch_cols;
             HIP_TRY(launch_sw(L, g, b->group_lds[g], b->mode == MMGPU_SW_START, st));
+            if (getenv("MMGPU_TRACE")) {   // debugging aid: run the groups one at a time and say which one is in flight
+                fprintf(stderr, "[sw_run] group %d jobs %u lds %zu both %d from_pf %d scratch_cols %u\n", g, L.n_jobs, b->group_lds[g], (int)(b->mode == MMGPU_SW_START), (int)b->from_pf, b->scratch_cols);
+                fflush(stderr);
+                hipError_t e = hipStreamSynchronize(st);
+                fprintf(stderr, "[sw_run] group %d done: %s\n", g, hipGetErrorString(e));
+                fflush(stderr);
+            }
         }
     }
     for (int k = 0; k < SW_GROUPS; k++) {

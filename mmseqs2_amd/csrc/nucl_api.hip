@@ -62,6 +62,9 @@ extern "C" int mmgpu_nucl_align(mmgpu_ctx *c, const mmgpu_nucl_params *par, cons
     hipStream_t s = c->stream;
     DevBuf d_pairs, d_order, d_qres, d_qoff, d_p, d_w, d_out, d_bt, d_ctr;
     // plain allocations: one synchronous call owns them, nothing to recycle between batches
+    // (MMGPU_NUCL_USE_CACHE=1 puts them through the context's block cache instead)
+    if (getenv("MMGPU_NUCL_USE_CACHE"))
+        for (DevBuf *d : {&d_pairs, &d_order, &d_qres, &d_qoff, &d_p, &d_w, &d_out, &d_bt, &d_ctr}) d->bind(c->cache);
     std::vector<mmgpu_nucl_pair> pv(pairs, pairs + n_pairs);
     HIP_TRY(upload(d_pairs, pv, s));
     HIP_TRY(upload(d_order, order, s));

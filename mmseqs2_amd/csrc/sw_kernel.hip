@@ -198,13 +198,20 @@ __device__ __forceinline__ void sw_body(const SwLaunch &L, const SwJob job) {
         int endA = 0, endB = 0;     // REV: forward t_end
         if (REV) {
             // reverse scan over q[0..q_end] x t[0..t_end], both walked backwards (:1143-1175)
-            const mmgpu_sw_hit fa = L.out[vA ? L.hit_out[hA] : 0], fb = L.out[vB ? L.hit_out[hB] : 0];
-            endA = fa.t_end; endB = fb.t_end;
+            // Lanes without a live pair must not take positions from a result slot: slot 0 may still be unwritten
+            // (another workgroup's forward pass), and an arbitrary t_end there becomes a wild target address below.
+            mmgpu_sw_hit fa, fb;
+            fa.score = 0; fa.q_end = 0; fa.t_end = 0;
+            fb = fa;
+            if (vA) fa = L.out[L.hit_out[hA]];
+            if (vB) fb = L.out[L.hit_out[hB]];
             const int min_start = L.q_minstart[job.query];
             colsA = (vA && fa.score > 0 && fa.score >= min_start) ? fa.t_end + 1 : 0;
             colsB = (vB && fb.score > 0 && fb.score >= min_start) ? fb.t_end + 1 : 0;
-            r0A = qlen - 1 - fa.q_end;
-            r0B = qlen - 1 - fb.q_end;
+            endA = colsA > 0 ? fa.t_end : 0;
+            endB = colsB > 0 ? fb.t_end : 0;
+            r0A = colsA > 0 ? qlen - 1 - fa.q_end : 0;
+            r0B = colsB > 0 ? qlen - 1 - fb.q_end : 0;
         }
         int ncols = colsA > colsB ? colsA : colsB;
         ncols = max(ncols, __shfl_xor(ncols, 16));
