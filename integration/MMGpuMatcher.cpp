@@ -1,0 +1,201 @@
+#include "MMGpuMatcher.h"
+
+#include <algorithm>
+#include <cstring>
+
+#include "StripedSmithWaterman.h"
+#include "SubstitutionMatrix.h"
+#include "Util.h"
+
+MMGpuMatcher::MMGpuMatcher(MMGpuAlignBackend *backend, BaseMatrix *m, EvalueComputation *evaluer, bool aaBiasCorrection,
+                           float aaBiasCorrectionScale, int gapOpen, int gapExtend)
+    : backend(backend), m(m), evaluer(evaluer), aaBiasCorrection(aaBiasCorrection),
+      aaBiasCorrectionScale(aaBiasCorrectionScale), gapOpen(gapOpen), gapExtend(gapExtend) {
+    const int a = m->alphabetSize;
+    tinySubMat.resize(a * a);
+    subMat16.resize(a * a);
+    for (int i = 0; i < a; i++)
+        for (int j = 0; j < a; j++) {
+            tinySubMat[i * a + j] = (int8_t)m->subMatrix[i][j];
+            subMat16[i * a + j] = (int16_t)m->subMatrix[i][j];
+        }
+}
+
+int MMGpuMatcher::minScoreForEvalue(double evalThr, int queryLength) const {
+    // computeEvalue falls monotonically with the score: bisect for the first score that passes
+    if (evaluer->computeEvalue(32767, queryLength) > evalThr) return 32768;
+    int lo = 1, hi = 32767;
+    while (lo < hi) {
+        const int mid = (lo + hi) / 2;
+        if (evaluer->computeEvalue(mid, queryLength) > evalThr) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+
+bool MMGpuMatcher::alignBlock(const std::vector<Query> &queries, int covMode, float covThr, double evalThr,
+                              unsigned int alignmentMode, unsigned int seqIdMode,
+                              std::vector<std::vector<Matcher::result_t> > &results) {
+    const size_t nq = queries.size();
+    results.assign(nq, std::vector<Matcher::result_t>());
+    // ---- per query: rounded composition bias as ssw_init builds it (StripedSmithWaterman.cpp:1364-1383) and the list
+    // of the non-identity targets (identity hits never reach the aligner, Matcher.cpp:88-90)
+    std::vector<std::vector<int8_t> > bias(nq);
+    std::vector<std::vector<uint32_t> > ids(nq);
+    std::vector<mmgpu_sw_query> dq(nq);
+    size_t total = 0;
+    for (size_t q = 0; q < nq; q++) {
+        Sequence *s = queries[q].seq;
+        bias[q].assign(s->L, 0);
+        if (aaBiasCorrection) {
+            std::vector<float> tmp(s->L);
+            SubstitutionMatrix::calcLocalAaBiasCorrection(m, s->numSequence, s->L, tmp.data(), aaBiasCorrectionScale);
+            for (int i = 0; i < s->L; i++)      // the statement of ssw_init, :1379 (the cast binds to the comparison)
+                bias[q][i] = (int8_t)(tmp[i] < 0.0) ? tmp[i] - 0.5 : tmp[i] + 0.5;
+        }
+        for (size_t k = 0; k < queries[q].targets.size(); k++)
+            if (!queries[q].targets[k].isIdentity) ids[q].push_back(queries[q].targets[k].id);
+        dq[q].q = s->numSequence;
+        dq[q].qlen = (uint32_t)s->L;
+        dq[q].comp_bias = bias[q].data();
+        dq[q].target_ids = ids[q].data();
+        dq[q].n_targets = (uint32_t)ids[q].size();
+        dq[q].min_start_score = alignmentMode == Matcher::SCORE_ONLY ? 0 : minScoreForEvalue(evalThr, s->L);
+        total += ids[q].size();
+    }
+    mmgpu_sw_params par;
+    par.mat = tinySubMat.data();
+    par.alphabet = m->alphabetSize;
+    par.gap_open = gapOpen;
+    par.gap_extend = gapExtend;
+    std::vector<mmgpu_sw_hit> hits(total);
+    const int mode = alignmentMode == Matcher::SCORE_ONLY ? MMGPU_SW_SCORE_END : MMGPU_SW_START;
+    if (total && backend->align(&par, dq.data(), (uint32_t)nq, mode, hits.data()) != 0) {
+        err = backend->lastError();
+        return false;
+    }
+
+    // ---- host part of ssw_align_private (StripedSmithWaterman.cpp:846-890) per pair; pairs that go on to the
+    // backtrace are collected for one traceback call
+    struct Pending {
+        s_align a;
+        bool early;     // returned before the start positions were needed
+    };
+    std::vector<Pending> aln(total);
+    std::vector<uint32_t> btPairs;
+    size_t p = 0;
+    for (size_t q = 0; q < nq; q++) {
+        const int qlen = queries[q].seq->L;
+        size_t k = 0;
+        for (size_t t = 0; t < queries[q].targets.size(); t++) {
+            if (queries[q].targets[t].isIdentity) continue;
+            const mmgpu_sw_hit &h = hits[p];
+            const int dbLen = queries[q].targets[t].length;
+            s_align a;
+            memset(&a, 0, sizeof(a));
+            a.score1 = (uint32_t)h.score;
+            a.qEndPos1 = h.q_end;
+            a.dbEndPos1 = h.t_end;
+            a.qStartPos1 = -1;
+            a.dbStartPos1 = -1;
+            a.word = h.word;
+            bool early = true;
+            if (a.dbEndPos1 != -1) {
+                a.qCov = SmithWaterman::computeCov(0, a.qEndPos1, qlen);
+                a.tCov = SmithWaterman::computeCov(0, a.dbEndPos1, dbLen);
+                const bool lowCov = !Util::hasCoverage(covThr, covMode, a.qCov, a.tCov);
+                a.evalue = evaluer->computeEvalue(a.score1, qlen);
+                const bool lowEval = a.evalue > evalThr;
+                if (!(alignmentMode == 0 || ((alignmentMode == 2 || alignmentMode == 1) && (lowEval || lowCov)))) {
+                    // alignStartPosBacktrace (:1129-1258): start positions from the reverse scan
+                    early = false;
+                    a.qStartPos1 = h.q_start;
+                    a.dbStartPos1 = h.t_start;
+                    a.qCov = SmithWaterman::computeCov(a.qStartPos1, a.qEndPos1, qlen);
+                    a.tCov = SmithWaterman::computeCov(a.dbStartPos1, a.dbEndPos1, dbLen);
+                    const bool lowCov2 = !Util::hasCoverage(covThr, covMode, a.qCov, a.tCov);
+                    if (!(alignmentMode == 1 || lowCov2)) btPairs.push_back((uint32_t)p);
+                }
+            }
+            aln[p].a = a;
+            aln[p].early = early;
+            p++;
+            k++;
+        }
+    }
+    std::vector<mmgpu_sw_bt> btInfo(btPairs.size());
+    std::string btStrings;
+    if (!btPairs.empty() && backend->traceback(btPairs.data(), (uint32_t)btPairs.size(), btInfo.data(), btStrings) != 0) {
+        err = backend->lastError();
+        return false;
+    }
+    std::vector<int> btOf(total, -1);
+    for (size_t i = 0; i < btPairs.size(); i++) btOf[btPairs[i]] = (int)i;
+
+    // ---- Matcher::getSWResult's tail (Matcher.cpp:93-143) ----
+    p = 0;
+    for (size_t q = 0; q < nq; q++) {
+        Sequence *qs = queries[q].seq;
+        const int origQueryLen = qs->L;
+        results[q].reserve(queries[q].targets.size());
+        for (size_t t = 0; t < queries[q].targets.size(); t++) {
+            const Target &tg = queries[q].targets[t];
+            s_align a;
+            std::string backtrace;
+            if (tg.isIdentity) {
+                // SmithWaterman::scoreIdentical (StripedSmithWaterman.cpp:1770-1805): the diagonal of the word profile
+                memset(&a, 0, sizeof(a));
+                a.qStartPos1 = alignmentMode == 0 ? -1 : 0;
+                a.dbStartPos1 = a.qStartPos1;
+                a.qEndPos1 = tg.length - 1;
+                a.dbEndPos1 = tg.length - 1;
+                a.qCov = 1.0f;
+                a.tCov = 1.0f;
+                short score = 0;
+                for (int pos = 0; pos < tg.length; pos++) {
+                    score += (short)(tinySubMat[qs->numSequence[pos] * m->alphabetSize + tg.numSequence[pos]] + bias[q][pos]);
+                    backtrace.push_back('M');
+                }
+                a.score1 = (uint32_t)score;
+                a.evalue = evaluer->computeEvalue(a.score1, origQueryLen);
+                a.identicalAACnt = (uint32_t)tg.length;
+            } else {
+                a = aln[p].a;
+                if (btOf[p] >= 0) {
+                    const mmgpu_sw_bt &bi = btInfo[btOf[p]];
+                    if (bi.status == MMGPU_BT_OK) {
+                        backtrace.assign(btStrings, (size_t)bi.bt_off, (size_t)bi.bt_len);
+                        a.identicalAACnt = bi.ident;
+                    } else {
+                        err = "a backtrace was refused by the device (band too large): run Matcher::getSWResult for this pair";
+                        return false;
+                    }
+                }
+                p++;
+            }
+            float qcov = 0.0f, dbcov = 0.0f, seqId = 0.0f;
+            const unsigned int qStartPos = a.qStartPos1, dbStartPos = a.dbStartPos1, qEndPos = a.qEndPos1, dbEndPos = a.dbEndPos1;
+            if (alignmentMode == Matcher::SCORE_COV || alignmentMode == Matcher::SCORE_COV_SEQID) {
+                qcov = a.qCov;
+                dbcov = a.tCov;
+            }
+            unsigned int alnLength = Matcher::computeAlnLength(qStartPos, qEndPos, dbStartPos, dbEndPos);
+            if (alignmentMode == Matcher::SCORE_COV_SEQID) {
+                if (backtrace.size() > 0) alnLength = backtrace.size();
+                seqId = Util::computeSeqId(seqIdMode, a.identicalAACnt, origQueryLen, tg.length, alnLength);
+            } else if (alignmentMode == Matcher::SCORE_COV) {
+                const unsigned int qAlnLen = std::max(qEndPos - qStartPos, static_cast<unsigned int>(1));
+                const unsigned int dbAlnLen = std::max(dbEndPos - dbStartPos, static_cast<unsigned int>(1));
+                seqId = Matcher::estimateSeqIdByScorePerCol(a.score1, qAlnLen, dbAlnLen);
+            } else if (alignmentMode == Matcher::SCORE_ONLY) {
+                const unsigned int qAlnLen = std::max(qEndPos, static_cast<unsigned int>(1));
+                const unsigned int dbAlnLen = std::max(dbEndPos, static_cast<unsigned int>(1));
+                seqId = Matcher::estimateSeqIdByScorePerCol(a.score1, qAlnLen, dbAlnLen);
+            }
+            const int bitScore = static_cast<int>(evaluer->computeBitScore(a.score1) + 0.5);
+            results[q].push_back(Matcher::result_t(tg.dbKey, bitScore, qcov, dbcov, seqId, a.evalue, alnLength, qStartPos, qEndPos,
+                                                   origQueryLen, dbStartPos, dbEndPos, tg.length, backtrace));
+        }
+    }
+    return true;
+}

@@ -1,0 +1,99 @@
+#include "MMGpuPrefilter.h"
+
+#include <climits>
+
+#include "SubstitutionMatrix.h"
+
+MMGpuPrefilter::MMGpuPrefilter(mmgpu_ctx *gpu, BaseMatrix *kmerSubMat, BaseMatrix *ungappedSubMat, bool aaBiasCorrection,
+                               float aaBiasCorrectionScale)
+    : gpu(gpu), kmerSubMat(kmerSubMat), ungappedSubMat(ungappedSubMat), aaBiasCorrection(aaBiasCorrection),
+      aaBiasCorrectionScale(aaBiasCorrectionScale), dbSize(0) {}
+
+bool MMGpuPrefilter::loadIndex(IndexTable *indexTable, SequenceLookup *sequenceLookup, ScoreMatrix &threeMer, ScoreMatrix &twoMer,
+                               bool spacedKmer) {
+    // targets: the (masked) numeric residues the ungapped scorer reads, exactly SequenceLookup's arrays
+    const size_t n = sequenceLookup->getSequenceCount();
+    std::vector<uint64_t> offsets(n + 1);
+    for (size_t i = 0; i <= n; i++) offsets[i] = sequenceLookup->getOffsets()[i];
+    if (mmgpu_load_targets(gpu, reinterpret_cast<const uint8_t *>(sequenceLookup->getData()), offsets.data(), (uint32_t)n,
+                           kmerSubMat->alphabetSize) != 0) {
+        err = mmgpu_last_error();
+        return false;
+    }
+    dbSize = n;
+    const int a = ungappedSubMat->alphabetSize;
+    std::vector<int8_t> ungapped(a * a);
+    for (int i = 0; i < a; i++)
+        for (int j = 0; j < a; j++) ungapped[i * a + j] = (int8_t)ungappedSubMat->subMatrix[i][j];
+    std::vector<uint64_t> tableOffsets(indexTable->getTableSize() + 1);
+    for (size_t i = 0; i <= indexTable->getTableSize(); i++) tableOffsets[i] = indexTable->getOffsets()[i];
+    mmgpu_pf_index ix;
+    memset(&ix, 0, sizeof(ix));
+    ix.kmer_size = indexTable->getKmerSize();
+    ix.alphabet = kmerSubMat->alphabetSize;
+    ix.spaced = spacedKmer ? 1 : 0;
+    ix.score3 = threeMer.score;
+    ix.index3 = threeMer.index;
+    ix.row3 = threeMer.rowSize;
+    ix.score2 = twoMer.isValid() ? twoMer.score : NULL;
+    ix.index2 = twoMer.isValid() ? twoMer.index : NULL;
+    ix.row2 = twoMer.isValid() ? twoMer.rowSize : 0;
+    ix.offsets = tableOffsets.data();
+    ix.entries6 = indexTable->getEntries();            // packed 6-byte IndexEntryLocal records
+    ix.n_entries = indexTable->getTableEntriesNum();
+    ix.ungapped_mat = ungapped.data();
+    if (mmgpu_pf_load_index(gpu, &ix) != 0) {
+        err = mmgpu_last_error();
+        return false;
+    }
+    return true;
+}
+
+bool MMGpuPrefilter::matchBlock(const std::vector<Query> &queries, int kmerThr, size_t maxResListLen, unsigned int minDiagScoreThr,
+                                std::vector<std::vector<hit_t> > &results, std::vector<bool> &needsCpu) {
+    const size_t nq = queries.size();
+    results.assign(nq, std::vector<hit_t>());
+    needsCpu.assign(nq, false);
+    if (nq == 0) return true;
+    // QueryMatcher::matchQuery's composition bias over the k-mer matrix (QueryMatcher.cpp:109-117), floats
+    std::vector<std::vector<float> > bias(nq);
+    std::vector<mmgpu_pf_query> dq(nq);
+    for (size_t q = 0; q < nq; q++) {
+        Sequence *s = queries[q].seq;
+        bias[q].assign(s->L, 0.0f);
+        if (aaBiasCorrection)
+            SubstitutionMatrix::calcLocalAaBiasCorrection(kmerSubMat, s->numSequence, s->L, bias[q].data(), aaBiasCorrectionScale);
+        dq[q].q = s->numSequence;
+        dq[q].qlen = (uint32_t)s->L;
+        dq[q].comp_bias = bias[q].data();
+        dq[q].identity_id = queries[q].identityId;
+    }
+    mmgpu_pf_params par;
+    par.kmer_thr = kmerThr;
+    par.max_hits = (uint32_t)maxResListLen;
+    par.min_diag_score = minDiagScoreThr;
+    par.ref_bins = 0;       // the CacheFriendlyOperations<N> this host would pick (QueryMatcher.cpp:460-488)
+    const uint32_t stride = (uint32_t)std::min(maxResListLen, dbSize);
+    std::vector<mmgpu_pf_hit> hits(nq * (size_t)stride);
+    std::vector<uint32_t> counts(nq);
+    std::vector<int32_t> status(nq);
+    if (mmgpu_pf_batch(gpu, &par, dq.data(), (uint32_t)nq, hits.data(), stride, counts.data(), status.data()) != 0) {
+        err = mmgpu_last_error();
+        return false;
+    }
+    for (size_t q = 0; q < nq; q++) {
+        if (status[q] == MMGPU_PF_OVERFLOW) {
+            needsCpu[q] = true;
+            continue;
+        }
+        results[q].resize(counts[q]);
+        for (uint32_t k = 0; k < counts[q]; k++) {
+            const mmgpu_pf_hit &h = hits[q * (size_t)stride + k];
+            hit_t &o = results[q][k];
+            o.seqId = h.id;
+            o.prefScore = h.score;
+            o.diagonal = h.diagonal;
+        }
+    }
+    return true;
+}

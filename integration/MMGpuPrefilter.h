@@ -1,0 +1,54 @@
+// Host side of the prefilter seam, in the reference's own types: what a maintainer compiles into MMseqs2 next to
+// src/prefiltering/Prefiltering.cpp.  MMGpuPrefilter takes the place of the per-thread QueryMatcher objects of
+// Prefiltering::runSplit (Prefiltering.cpp:826-842): loadIndex() hands the reference's IndexTable / SequenceLookup /
+// ScoreMatrix objects to the device once per split, matchBlock() is the batch form of QueryMatcher::matchQuery
+// (QueryMatcher.cpp:103-241) and returns hit_t lists in the reference's final order; the loop body after matchQuery
+// (:876-917: id -> key, canBeCovered, prefilterHitToBuffer) runs on them unchanged.  Queries the device declines
+// (MMGPU_PF_OVERFLOW) are reported so that the caller runs its CPU QueryMatcher for them.
+//
+// Includes reference headers: built (compile check against both header sets) by oracle/Makefile only where the reference
+// tree is present.
+#ifndef MMGPU_PREFILTER_H
+#define MMGPU_PREFILTER_H
+
+#include <string>
+#include <vector>
+
+#include "BaseMatrix.h"
+#include "IndexTable.h"
+#include "QueryMatcher.h"
+#include "ScoreMatrix.h"
+#include "Sequence.h"
+#include "SequenceLookup.h"
+
+#include "mmgpu.h"
+
+class MMGpuPrefilter {
+public:
+    MMGpuPrefilter(mmgpu_ctx *gpu, BaseMatrix *kmerSubMat, BaseMatrix *ungappedSubMat, bool aaBiasCorrection,
+                   float aaBiasCorrectionScale);
+
+    // once per target split: SequenceLookup -> resident targets, IndexTable + similar-k-mer tables -> resident index
+    bool loadIndex(IndexTable *indexTable, SequenceLookup *sequenceLookup, ScoreMatrix &threeMer, ScoreMatrix &twoMer, bool spacedKmer);
+
+    struct Query {
+        Sequence *seq;
+        unsigned int identityId;      // targetSeqId of Prefiltering.cpp:855-868, UINT_MAX = none
+    };
+    // results[q] = the hit_t list of QueryMatcher::matchQuery; needsCpu[q] = the device declined the query
+    bool matchBlock(const std::vector<Query> &queries, int kmerThr, size_t maxResListLen, unsigned int minDiagScoreThr,
+                    std::vector<std::vector<hit_t> > &results, std::vector<bool> &needsCpu);
+
+    const std::string &error() const { return err; }
+
+private:
+    mmgpu_ctx *gpu;
+    BaseMatrix *kmerSubMat;
+    BaseMatrix *ungappedSubMat;
+    bool aaBiasCorrection;
+    float aaBiasCorrectionScale;
+    size_t dbSize;
+    std::string err;
+};
+
+#endif

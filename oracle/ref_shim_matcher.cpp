@@ -1,0 +1,185 @@
+// TEST INFRASTRUCTURE - NOT PART OF THE PRODUCT PATH.
+//
+// Checks the host side of the alignment seam (integration/MMGpuMatcher.cpp: E-value / coverage gates, start-score
+// threshold, sequence identity, bit score, result_t assembly around the device results) against the REAL
+// Matcher::initQuery + Matcher::getSWResult (src/alignment/Matcher.cpp:49-144), pair by pair, on the CPU.  The device
+// is replaced by a backend that produces what libmmgpu produces - the GPU tests pin that the two are bit-identical -
+// from the reference's own SmithWaterman (modes 0 / 1 / 2 with the gates opened).
+#include <cfloat>
+#include <climits>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "Debug.h"
+#include "EvalueComputation.h"
+#include "Matcher.h"
+#include "Parameters.h"
+#include "Sequence.h"
+#include "StripedSmithWaterman.h"
+#include "SubstitutionMatrix.h"
+
+#include "../integration/MMGpuMatcher.h"
+
+namespace {
+
+class ReferenceBackedBackend : public MMGpuAlignBackend {
+public:
+    ReferenceBackedBackend(SubstitutionMatrix *m, EvalueComputation *ev, bool compBias, int maxLen, const uint8_t *tres,
+                           const uint64_t *toff)
+        : m(m), ev(ev), sw(maxLen, m->alphabetSize, compBias, 1.0f, m), q(maxLen, Parameters::DBTYPE_AMINO_ACIDS, m, 0, false, compBias),
+          tres(tres), toff(toff) {}
+    int align(const mmgpu_sw_params *par, const mmgpu_sw_query *qs, uint32_t nq, int mode, mmgpu_sw_hit *out) {
+        pairs.clear();
+        go = par->gap_open;
+        ge = par->gap_extend;
+        mat.assign(par->mat, par->mat + par->alphabet * par->alphabet);
+        size_t p = 0;
+        for (uint32_t i = 0; i < nq; i++) {
+            q.mapSequence(0, 0, std::make_pair((const unsigned char *)qs[i].q, (const unsigned int)qs[i].qlen));
+            sw.ssw_init(&q, mat.data(), m);
+            for (uint32_t k = 0; k < qs[i].n_targets; k++, p++) {
+                const uint32_t id = qs[i].target_ids[k];
+                const uint8_t *t = tres + toff[id];
+                const int tlen = (int)(toff[id + 1] - toff[id]);
+                std::string bt;
+                s_align a = sw.ssw_align(t, tlen, bt, go, ge, 0, DBL_MAX, ev, 0, 0.0f, 0.0f, q.L / 2);
+                mmgpu_sw_hit h;
+                h.score = (int32_t)a.score1; h.q_end = a.qEndPos1; h.t_end = a.dbEndPos1; h.q_start = -1; h.t_start = -1; h.word = a.word;
+                if (a.dbEndPos1 == -1) { h.q_end = 0; h.score = 0; }
+                if (mode == MMGPU_SW_START && a.dbEndPos1 != -1 && (int)a.score1 >= qs[i].min_start_score) {
+                    s_align b = sw.ssw_align(t, tlen, bt, go, ge, 1, DBL_MAX, ev, 0, 0.0f, 0.0f, q.L / 2);
+                    h.q_start = b.qStartPos1;
+                    h.t_start = b.dbStartPos1;
+                }
+                out[p] = h;
+                pairs.push_back(std::make_pair(i, id));
+            }
+            queries.push_back(std::vector<uint8_t>(qs[i].q, qs[i].q + qs[i].qlen));
+        }
+        return 0;
+    }
+    int traceback(const uint32_t *idx, uint32_t n, mmgpu_sw_bt *info, std::string &strings) {
+        strings.clear();
+        for (uint32_t i = 0; i < n; i++) {
+            const std::pair<uint32_t, uint32_t> pr = pairs[idx[i]];
+            const std::vector<uint8_t> &qq = queries[queries.size() - (size_t)nQueriesOfLast() + pr.first];
+            q.mapSequence(0, 0, std::make_pair((const unsigned char *)qq.data(), (const unsigned int)qq.size()));
+            sw.ssw_init(&q, mat.data(), m);
+            const uint8_t *t = tres + toff[pr.second];
+            const int tlen = (int)(toff[pr.second + 1] - toff[pr.second]);
+            std::string bt;
+            s_align a = sw.ssw_align(t, tlen, bt, go, ge, 2, DBL_MAX, ev, 0, 0.0f, 0.0f, q.L / 2);
+            info[i].bt_off = strings.size();
+            info[i].bt_len = (uint32_t)bt.size();
+            info[i].ident = a.identicalAACnt;
+            info[i].status = MMGPU_BT_OK;
+            info[i].reserved = 0;
+            strings += bt;
+            strings.push_back('\0');
+            delete[] a.cigar;
+        }
+        return 0;
+    }
+    const char *lastError() { return "reference-backed backend"; }
+    void beginBlock(size_t nq) { queries.clear(); lastNq = nq; }
+
+private:
+    size_t nQueriesOfLast() const { return lastNq; }
+    SubstitutionMatrix *m;
+    EvalueComputation *ev;
+    SmithWaterman sw;
+    Sequence q;
+    const uint8_t *tres;
+    const uint64_t *toff;
+    int go, ge;
+    std::vector<int8_t> mat;
+    std::vector<std::pair<uint32_t, uint32_t> > pairs;
+    std::vector<std::vector<uint8_t> > queries;
+    size_t lastNq = 0;
+};
+
+}  // namespace
+
+// Returns the number of (query, target) pairs whose result_t differs between MMGpuMatcher and the real Matcher
+// (-1 on a setup error); *n_pairs = pairs compared; msg = description of the first difference.
+extern "C" int mmref_matcher_check(const char *matrix_file, int gap_open, int gap_extend, int comp_bias, uint64_t db_residues,
+                                   const uint8_t *qres, const uint64_t *qoff, uint32_t nq, const uint8_t *tres, const uint64_t *toff,
+                                   uint32_t nt, const uint32_t *list_off, const uint32_t *list_ids, const uint8_t *list_identity,
+                                   int cov_mode, float cov_thr, double eval_thr, int alignment_mode, int seqid_mode, int *n_pairs,
+                                   char *msg, int msg_cap) {
+    Debug::setDebugLevel(Debug::ERROR);
+    (void)nt;
+    int maxLen = 0;
+    for (uint32_t i = 0; i < nq; i++) maxLen = std::max<int>(maxLen, (int)(qoff[i + 1] - qoff[i]));
+    for (uint32_t i = 0; i < nt; i++) maxLen = std::max<int>(maxLen, (int)(toff[i + 1] - toff[i]));
+    maxLen += 2;
+    SubstitutionMatrix m(matrix_file, 2.0f, 0.0f);
+    EvalueComputation ev(db_residues, &m, gap_open, gap_extend);
+    Matcher ref(Parameters::DBTYPE_AMINO_ACIDS, maxLen, &m, &ev, comp_bias != 0, 1.0f, gap_open, gap_extend, 0.0f, 40);
+    ReferenceBackedBackend backend(&m, &ev, comp_bias != 0, maxLen, tres, toff);
+    MMGpuMatcher mine(&backend, &m, &ev, comp_bias != 0, 1.0f, gap_open, gap_extend);
+
+    std::vector<Sequence *> qseq(nq);
+    std::vector<MMGpuMatcher::Query> block(nq);
+    for (uint32_t i = 0; i < nq; i++) {
+        qseq[i] = new Sequence(maxLen, Parameters::DBTYPE_AMINO_ACIDS, &m, 0, false, comp_bias != 0);
+        qseq[i]->mapSequence(i, i, std::make_pair((const unsigned char *)(qres + qoff[i]), (const unsigned int)(qoff[i + 1] - qoff[i])));
+        block[i].seq = qseq[i];
+        for (uint32_t k = list_off[i]; k < list_off[i + 1]; k++) {
+            MMGpuMatcher::Target t;
+            t.id = list_ids[k];
+            t.dbKey = list_ids[k];
+            t.length = (int)(toff[t.id + 1] - toff[t.id]);
+            t.numSequence = tres + toff[t.id];
+            t.isIdentity = list_identity[k] != 0;
+            block[i].targets.push_back(t);
+        }
+    }
+    backend.beginBlock(nq);
+    std::vector<std::vector<Matcher::result_t> > got;
+    if (!mine.alignBlock(block, cov_mode, cov_thr, eval_thr, (unsigned)alignment_mode, (unsigned)seqid_mode, got)) {
+        snprintf(msg, msg_cap, "alignBlock failed: %s", mine.error().c_str());
+        return -1;
+    }
+    int bad = 0, compared = 0;
+    Sequence dbSeq(maxLen, Parameters::DBTYPE_AMINO_ACIDS, &m, 0, false, comp_bias != 0);
+    msg[0] = 0;
+    for (uint32_t i = 0; i < nq; i++) {
+        ref.initQuery(qseq[i]);
+        for (uint32_t k = list_off[i]; k < list_off[i + 1]; k++) {
+            const uint32_t id = list_ids[k];
+            dbSeq.mapSequence(id, id, std::make_pair((const unsigned char *)(tres + toff[id]), (const unsigned int)(toff[id + 1] - toff[id])));
+            Matcher::result_t e = ref.getSWResult(&dbSeq, INT_MAX, false, cov_mode, cov_thr, eval_thr, (unsigned)alignment_mode,
+                                                  (unsigned)seqid_mode, list_identity[k] != 0);
+            const Matcher::result_t &g = got[i][k - list_off[i]];
+            compared++;
+            // a pair without any aligned residue leaves the reference's coverage / E-value fields uninitialised
+            // (alignScoreEndPos returns early, StripedSmithWaterman.cpp:848-851): only the defined fields are compared
+            const bool defined = e.dbEndPos != -1;
+            bool same = e.dbKey == g.dbKey && e.qEndPos == g.qEndPos && e.dbEndPos == g.dbEndPos && e.qStartPos == g.qStartPos &&
+                        e.dbStartPos == g.dbStartPos && e.qLen == g.qLen && e.dbLen == g.dbLen && e.backtrace == g.backtrace;
+            // with --alignment-mode 3 a pair that fails the E-value / coverage gate returns before identicalAACnt is ever
+            // set, and getSWResult derives seqId from that stale stack value (Matcher.cpp:115): undefined, not compared
+            const bool seqIdDefined = !(alignment_mode == 2 && e.qStartPos == -1 && list_identity[k] == 0);
+            if (defined)
+                same = same && e.score == g.score && e.alnLength == g.alnLength && memcmp(&e.qcov, &g.qcov, 4) == 0 &&
+                       memcmp(&e.dbcov, &g.dbcov, 4) == 0 && (!seqIdDefined || memcmp(&e.seqId, &g.seqId, 4) == 0) &&
+                       memcmp(&e.eval, &g.eval, 8) == 0;
+            if (!same) {
+                if (bad == 0)
+                    snprintf(msg, msg_cap, "query %u target %u: ref score %d q %d-%d t %d-%d cov %g %g id %g eval %g len %u bt %zu | "
+                             "got score %d q %d-%d t %d-%d cov %g %g id %g eval %g len %u bt %zu",
+                             i, id, e.score, e.qStartPos, e.qEndPos, e.dbStartPos, e.dbEndPos, e.qcov, e.dbcov, e.seqId, e.eval, e.alnLength,
+                             e.backtrace.size(), g.score, g.qStartPos, g.qEndPos, g.dbStartPos, g.dbEndPos, g.qcov, g.dbcov, g.seqId, g.eval,
+                             g.alnLength, g.backtrace.size());
+                bad++;
+            }
+        }
+    }
+    for (uint32_t i = 0; i < nq; i++) delete qseq[i];
+    *n_pairs = compared;
+    return bad;
+}
