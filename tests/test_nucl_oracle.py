@@ -72,3 +72,34 @@ def test_oracle_matches_reference_fuzz():
                 n_al += 1
     ref.close()
     assert n_ksw == 80 and n_al == 160
+
+
+@pytest.mark.skipif(not (po.ref_available() and po.ref_matrix_available()), reason="needs oracle/_ref and /root/reference/data")
+def test_long_targets_try_every_shift_of_the_16_bit_diagonal():
+    """targets of 32768 residues or more: the prefilter diagonal is a 16-bit value and computeUngappedAlignment tries every
+    65536-shift that fits (DistanceCalculator.h:93-112); oracle and the kernel source (emulated lanes) against the reference"""
+    from tests import test_nucl_emu as te
+    rng = np.random.default_rng(9)
+    ref, orc = po.RefNucl(), po.NuclOracle()
+    mat, rl = ref.matrix(), ref.reverse_lookup()
+    letters = lambda a: "".join(po.NUCL_LETTERS[int(x)] for x in a)
+    L = te._lib()
+    queries, targets, pairs, expected = [], [], [], []
+    for tlen, start, qlen in ((40000, 35000, 700), (65000, 60111, 400), (33000, 100, 900)):
+        contig = rng.integers(0, 4, size=tlen).astype(np.uint8)
+        read = nc.mutate(rng, contig[start:start + qlen], 0.05, 0.01)
+        queries.append(read)
+        targets.append(contig)
+        ref.set_query(letters(read), 4)
+        for diag in ((-start) & 0xFFFF, (-start + 3) & 0xFFFF, 12345):
+            e = ref.align(letters(contig), diag, 0, 4)
+            o = orc.align(read, contig, mat.reshape(-1), rl, 5, 2, 40, diag, 0, 4, 4)
+            assert e == o, (tlen, start, diag, e[0], o[0])
+            pairs.append((len(queries) - 1, len(targets) - 1, diag, 0))
+            expected.append(e)
+    assert max(len(e[1]) for e in expected) > 600          # the true diagonal was found beyond 16 bits
+    hits, strs = te.emu_align(L, mat, rl, queries, targets, pairs, 4, 4)
+    for e, h, s in zip(expected, hits, strs):
+        got = (int(h["score"]), int(h["q_start"]), int(h["q_end"]), int(h["t_start"]), int(h["t_end"]), int(h["ident"]))
+        assert got == e[0][:6] and s == e[1]
+    ref.close()
