@@ -417,7 +417,8 @@ inline hipError_t upload(DevBuf &b, const std::vector<T> &v, hipStream_t s) {
 }
 
 // nucleotide alignment step (nucl_kernel.hip; NuclLaunch is declared in nucl_core.h)
-hipError_t launch_nucl_align(const NuclLaunch &L, unsigned blocks, hipStream_t stream);
+hipError_t launch_nucl_align(const NuclLaunch &L, unsigned blocks, hipStream_t stream);     // 16 lanes per alignment
+hipError_t launch_nucl_align64(const NuclLaunch &L, unsigned blocks, hipStream_t stream);   // 64 lanes (experimental, nucl_kernel64.hip)
 
 struct PfIndex;   // pf_api.hip
 

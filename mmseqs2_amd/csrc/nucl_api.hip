@@ -51,13 +51,15 @@ extern "C" int mmgpu_nucl_align(mmgpu_ctx *c, const mmgpu_nucl_params *par, cons
     // one slice of direction bytes (6 blocks of 16 per anti-diagonal) and of backtrack letters per 16-lane group; the
     // number of groups in flight is what fits the scratch budget (a group that finishes takes the next pair)
     const uint64_t p_stride = (most_rows * 6 + 2) * 16, w_stride = (longest + 16 + 15) / 16 * 16;
-    uint64_t groups = ((uint64_t)n_pairs + 15) / 16 * 16;
+    static const int lanes = getenv("MMGPU_NUCL_LANES") && atoi(getenv("MMGPU_NUCL_LANES")) == 64 ? 64 : 16;   // 64: experimental kernel
+    const uint64_t gpb = 256 / lanes;                                                     // alignments per workgroup
+    uint64_t groups = ((uint64_t)n_pairs + gpb - 1) / gpb * gpb;
     groups = std::min<uint64_t>(groups, (uint64_t)c->compute_units * 4 * 16);          // 4 workgroups of 16 groups per CU
     static const uint64_t budget_gb = getenv("MMGPU_NUCL_SCRATCH_GB") ? std::max(1, atoi(getenv("MMGPU_NUCL_SCRATCH_GB"))) : 16;
     const uint64_t budget = budget_gb << 30;
-    while (groups > 16 && groups * (p_stride + w_stride) > budget) groups -= 16;
+    while (groups > gpb && groups * (p_stride + w_stride) > budget) groups -= gpb;
     if (groups * (p_stride + w_stride) > (96ull << 30)) return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_nucl_align: sequences too long for the direction scratch");
-    const unsigned blocks = (unsigned)(groups / 16);
+    const unsigned blocks = (unsigned)(groups / gpb);
 
     hipStream_t s = c->stream;
     DevBuf d_pairs, d_order, d_qres, d_qoff, d_p, d_w, d_out, d_bt, d_ctr;
@@ -103,7 +105,7 @@ extern "C" int mmgpu_nucl_align(mmgpu_ctx *c, const mmgpu_nucl_params *par, cons
     L.bt_cursor = d_ctr.as<unsigned long long>();
     L.bt_cap = bt_cap;
     L.next_pair = reinterpret_cast<uint32_t *>(d_ctr.as<unsigned long long>() + 1);
-    HIP_TRY(launch_nucl_align(L, blocks, s));
+    HIP_TRY(lanes == 64 ? launch_nucl_align64(L, blocks, s) : launch_nucl_align(L, blocks, s));
     HIP_TRY(hipMemcpyAsync(out, d_out.p, (size_t)n_pairs * sizeof(mmgpu_nucl_hit), hipMemcpyDeviceToHost, s));
     unsigned long long used = 0;
     HIP_TRY(hipMemcpyAsync(&used, d_ctr.p, 8, hipMemcpyDeviceToHost, s));

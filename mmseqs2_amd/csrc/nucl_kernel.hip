@@ -15,11 +15,16 @@
 // per-group scratch in HBM and are walked back by lane 0.  Work per alignment ~ (qlen + tlen) x 7 blocks, three
 // passes at most; bounded by the dependent chain over the anti-diagonals (LDS latency), not by HBM or VALU peak -
 // parallelism comes from the alignments (4 per wavefront, pulled from a length-sorted queue).
+#ifndef NUCL_NG
+#define NUCL_NG 16
+#define NUCL_NS nucl16
+#define NUCL_LAUNCH launch_nucl_align
+#endif
 #define NUCL_HD __device__ __forceinline__
-#define NUCL_LANE() ((int)(threadIdx.x & 15u))
-#define NUCL_SHFL(v, src) __shfl((v), (src), 16)
-#define NUCL_SHFL_XOR(v, mask) __shfl_xor((v), (mask), 16)
-#define NUCL_SHFL_U64(v, src) ((unsigned long long)__shfl((long long)(v), (src), 16))
+#define NUCL_LANE() ((int)(threadIdx.x & (unsigned)(NUCL_NG - 1)))
+#define NUCL_SHFL(v, src) __shfl((v), (src), NUCL_NG)
+#define NUCL_SHFL_XOR(v, mask) __shfl_xor((v), (mask), NUCL_NG)
+#define NUCL_SHFL_U64(v, src) ((unsigned long long)__shfl((long long)(v), (src), NUCL_NG))
 // the lanes of a group run in lock step: a phase boundary only has to keep the memory operations in order.  The LDS
 // form must not wait for the direction bytes still on their way to HBM (a full fence per phase made the kernel 20x
 // slower than its LDS chain).
@@ -42,15 +47,15 @@ namespace mmgpu {
 namespace {
 
 __global__ __launch_bounds__(256) void nucl_align_kernel(NuclLaunch L) {
-    __shared__ nucl::GroupLds lds[256 / nucl::NG];
-    const int gslot = (int)(threadIdx.x / nucl::NG);
-    const size_t slot = (size_t)blockIdx.x * (256 / nucl::NG) + (size_t)gslot;
-    nucl::align_group(L, lds[gslot], L.pscratch + slot * L.pscratch_stride, L.wscratch + slot * L.wscratch_stride);
+    __shared__ NUCL_NS::GroupLds lds[256 / NUCL_NS::NG];
+    const int gslot = (int)(threadIdx.x / NUCL_NS::NG);
+    const size_t slot = (size_t)blockIdx.x * (256 / NUCL_NS::NG) + (size_t)gslot;
+    NUCL_NS::align_group(L, lds[gslot], L.pscratch + slot * L.pscratch_stride, L.wscratch + slot * L.wscratch_stride);
 }
 
 }  // namespace
 
-hipError_t launch_nucl_align(const NuclLaunch &L, unsigned blocks, hipStream_t stream) {
+hipError_t NUCL_LAUNCH(const NuclLaunch &L, unsigned blocks, hipStream_t stream) {
     if (L.n_pairs == 0) return hipSuccess;
     hipLaunchKernelGGL(nucl_align_kernel, dim3(blocks), dim3(256), 0, stream, L);
     return hipGetLastError();

@@ -11,7 +11,10 @@
 #include <vector>
 
 namespace emu {
-constexpr int LANES = 16;
+#ifndef EMU_LANES
+#define EMU_LANES 16
+#endif
+constexpr int LANES = EMU_LANES;
 static ucontext_t ctx[LANES], main_ctx;
 static bool done[LANES];
 static int cur = 0, arrived = 0;
@@ -51,6 +54,7 @@ static unsigned long long exchange(unsigned long long v, int src) {
 }
 }  // namespace emu
 
+#define NUCL_NG EMU_LANES
 #define NUCL_HD inline
 #define NUCL_LANE() (emu::cur)
 template <typename T> static inline T emu_shfl(T v, int src) { return (T)emu::exchange((unsigned long long)(long long)v, src); }
@@ -67,12 +71,12 @@ static inline unsigned long long emu_add64(unsigned long long *p, unsigned long 
 
 namespace {
 const mmgpu::NuclLaunch *g_launch;
-mmgpu::nucl::GroupLds g_lds;
+mmgpu::NUCL_NS::GroupLds g_lds;
 uint8_t *g_p;
 char *g_w;
 
 void lane_main() {
-    mmgpu::nucl::align_group(*g_launch, g_lds, g_p, g_w);
+    mmgpu::NUCL_NS::align_group(*g_launch, g_lds, g_p, g_w);
     emu::done[emu::cur] = true;
     emu::switch_to_next();
 }
