@@ -582,7 +582,10 @@ def main():
         search = search_section(args, gpu, torch, dist, rank, world, matrices, barrier)
     nucl = None
     if not args.no_nucl and not args.prefilter_only:
-        nucl = nucl_section(args, gpu, matrices, rank)
+        try:
+            nucl = nucl_section(args, gpu, matrices, rank)
+        except Exception as e:      # the newest section must not take the headline line down with it: report, do not hide
+            nucl = {"error": "%s: %s" % (type(e).__name__, e)} if rank == 0 else None
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
