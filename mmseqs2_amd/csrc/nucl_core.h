@@ -141,6 +141,13 @@ NUCL_HD void ksw_extz2(const SeqView &qv, int qlen, const SeqView &tv, int tlen,
             int need = (st0 + ((en0 - st0) / 16 + 1) * 16 + 15) / 16;     // one past the last block the score pass writes
             need = need < en / 16 + 1 ? en / 16 + 1 : need;
             need = need > tlen_ ? tlen_ : need;
+#if NUCL_NG == 16   // one block per step: the form the GPU parity tests were run on, kept verbatim
+            for (int b = init_blocks; b < need; ++b) {
+                const int k = (b * 16 + lane) & (WIN - 1);
+                S.u[k] = 0; S.v[k] = 0; S.x[k] = 0; S.y[k] = 0; S.s[k] = 0;
+                S.H[k] = KSW_NEG_INF;
+            }
+#else
             for (int b0 = init_blocks; b0 < need; b0 += BPS) {
                 const int b = b0 + lane / 16;
                 if (b < need) {
@@ -149,6 +156,7 @@ NUCL_HD void ksw_extz2(const SeqView &qv, int qlen, const SeqView &tv, int tlen,
                     S.H[k] = KSW_NEG_INF;
                 }
             }
+#endif
             init_blocks = init_blocks > need ? init_blocks : need;
         }
         NUCL_SYNC();
@@ -168,10 +176,16 @@ NUCL_HD void ksw_extz2(const SeqView &qv, int qlen, const SeqView &tv, int tlen,
         }
         // scores of this anti-diagonal, whole 16-byte groups starting at st0 (:135-145); letter m - 1 is a wildcard.
         // Positions past the target read the allocation's zeros, query positions before its start likewise.
-        const int last_scored = st0 + ((en0 - st0) / 16 + 1) * 16 - 1;
+#if NUCL_NG == 16
+        for (int t0 = st0; t0 <= en0; t0 += 16) {
+            const int t = t0 + lane;
+            if (t < tlen_ * 16) {
+#else
+        const int last_scored = st0 + ((en0 - st0) / 16 + 1) * 16 - 1;   // the reference scores whole groups of 16 from st0
         for (int t0 = st0; t0 <= last_scored; t0 += NG) {
             const int t = t0 + lane;
             if (t <= last_scored && t < tlen_ * 16) {
+#endif
                 const uint8_t a = t < tlen ? tv.get(t) : (uint8_t)0;
                 const uint8_t b = (r - t >= 0 && r - t < qlen) ? qv.get(r - t) : (uint8_t)0;
                 int8_t sc = a == b ? sc_mch : sc_mis;
@@ -182,6 +196,13 @@ NUCL_HD void ksw_extz2(const SeqView &qv, int qlen, const SeqView &tv, int tlen,
         NUCL_SYNC();
         // core: blocks from the highest to the lowest - cell t reads x[t-1], v[t-1], which a lower block still holds
         const bool x1_neg = x1 < 0, v1_neg = v1 < 0;
+#if NUCL_NG == 16
+        for (int blk = en / 16; blk >= st / 16; --blk) {
+            const int t = blk * 16 + lane, k = t & (WIN - 1);
+            int8_t xt1, vt1;
+            if (t == st) { xt1 = x1; vt1 = v1; }
+            else { xt1 = (int8_t)S.x[(t - 1) & (WIN - 1)]; vt1 = (int8_t)S.v[(t - 1) & (WIN - 1)]; }
+#else
         for (int hb = en / 16; hb >= st / 16; hb -= BPS) {
             const int blk = hb - lane / 16;
             const bool on = blk >= st / 16;             // a step may reach below the lowest block
@@ -189,11 +210,19 @@ NUCL_HD void ksw_extz2(const SeqView &qv, int qlen, const SeqView &tv, int tlen,
             int8_t xt1 = 0, vt1 = 0;
             if (t == st) { xt1 = x1; vt1 = v1; }
             else if (on) { xt1 = (int8_t)S.x[(t - 1) & (WIN - 1)]; vt1 = (int8_t)S.v[(t - 1) & (WIN - 1)]; }
+#endif
             // _mm_cvtsi32_si128 of a negative carry-in also sets bytes 1..3 of the first block's shifted vectors (:151-152)
             if (t - st >= 1 && t - st <= 3) {
                 if (x1_neg) xt1 = (int8_t)0xFF;
                 if (v1_neg) vt1 = (int8_t)0xFF;
             }
+#if NUCL_NG == 16
+            int8_t z = s8((int8_t)S.s[k] + s8(qe * 2));
+            int8_t a = s8(xt1 + vt1);
+            const int8_t ut = (int8_t)S.u[k];
+            int8_t b = s8((int8_t)S.y[k] + ut);
+            NUCL_SYNC();   // all reads of the block before its writes (lane + 1 reads this lane's x, v)
+#else
             int8_t z = 0, ut = 0, b = 0;
             if (on) {
                 z = s8((int8_t)S.s[k] + s8(qe * 2));
@@ -203,6 +232,7 @@ NUCL_HD void ksw_extz2(const SeqView &qv, int qlen, const SeqView &tv, int tlen,
             int8_t a = s8(xt1 + vt1);
             NUCL_SYNC();   // all reads of the step before its writes (lane + 1 reads this lane's x, v)
             if (!on) continue;
+#endif
             uint8_t d = 0;
             if (WITH_P) d = a > z ? 1 : 0;
             z = z > a ? z : a;
