@@ -258,6 +258,10 @@ int mmgpu_pf_build_index(mmgpu_ctx *ctx, const mmgpu_pf_index *tables, const int
 /* test hook: copies the resident index back in the host builder's layout (any pointer may be NULL) */
 int mmgpu_pf_debug_index(mmgpu_ctx *ctx, uint64_t *offsets, uint32_t *ids, uint16_t *pos, uint64_t *n_entries);
 
+/* limits of the prefilter entry points: calls beyond them return MMGPU_ERR_UNSUPPORTED and the host keeps its CPU path */
+#define MMGPU_PF_MAX_HITS 4096      /* max_hits (--max-seqs) */
+#define MMGPU_PF_MAX_SEQ_LEN 32768  /* sequences must be shorter (UngappedAlignment::computeLongScore is not on the device) */
+
 typedef struct {
     int kmer_thr;            /* Prefiltering::getKmerThreshold */
     uint32_t max_hits;       /* maxResListLen (--max-seqs); min(., dbSize) is applied like QueryMatcher.cpp:47 */

@@ -1,0 +1,368 @@
+// Alignment::run (src/alignment/Alignment.cpp:248-542) with the Smith-Waterman work on libmmgpu.
+//
+// The reference's loop handles one query per OpenMP iteration: parse the prefilter list, matcher.initQuery (:340),
+// matcher.getSWResult per list entry (:379), checkCriteria, sort, resultToBuffer, DBWriter.  Here the same function runs
+// over blocks of queries: every thread parses lists and maps sequences, ONE device call aligns all pairs of the block
+// (MMGpuMatcher::alignBlock = the batch form of initQuery + getSWResult, MMGpuMatcher.cpp), then every thread replays
+// the reference's accept / reject bookkeeping (:344-397) on the results in list order, sorts with
+// Matcher::compareHits and serialises with Matcher::resultToBuffer - the reference's own functions, unchanged.
+// The output DB is the same DB, entry for entry (tests/test_mmseqs_dropin.py diffs it against the stock binary).
+//
+// Compiled into MMseqs2 by integration/build_mmseqs.sh (HAVE_MMGPU); Alignment.h declares the class a friend.
+#include <cfloat>
+#include <climits>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "Alignment.h"
+#include "DBWriter.h"
+#include "Debug.h"
+#include "EvalueComputation.h"
+#include "QueryMatcher.h"
+#include "StripedSmithWaterman.h"
+#include "Util.h"
+
+#include "MMGpuMatcher.h"
+#include "MMGpuRun.h"
+
+#ifdef OPENMP
+#include <omp.h>
+#endif
+
+MMGpuAlignBackend *mmgpuNewDeviceBackend(mmgpu_ctx *gpu);
+
+namespace {
+
+// MMGpuBlockBacktracer over the host's own SmithWaterman objects: ssw_init once per (thread, query), then the
+// reference's alignStartPosBacktraceBlock through the public wrapper the patch adds to SmithWaterman.
+class HostBlockBacktracer : public MMGpuBlockBacktracer {
+public:
+    HostBlockBacktracer(unsigned int threads, size_t maxSeqLen, BaseMatrix *m, bool compBias, float compBiasScale, int gapOpen,
+                        int gapExtend, int seqType)
+        : m(m), gapOpen(gapOpen), gapExtend(gapExtend), sw(threads, NULL), seq(threads, NULL), lastQuery(threads, (size_t)-1),
+          maxSeqLen(maxSeqLen), compBias(compBias), compBiasScale(compBiasScale), seqType(seqType) {
+        const int a = m->alphabetSize;
+        tiny.resize(a * a);
+        for (int i = 0; i < a; i++)
+            for (int j = 0; j < a; j++) tiny[i * a + j] = (int8_t)m->subMatrix[i][j];
+    }
+    ~HostBlockBacktracer() {
+        for (size_t i = 0; i < sw.size(); i++) {
+            delete sw[i];
+            delete seq[i];
+        }
+    }
+    void newBlock() { std::fill(lastQuery.begin(), lastQuery.end(), (size_t)-1); }
+    bool run(unsigned int thread, size_t queryIndex, const unsigned char *query, int queryLength, const unsigned char *target,
+             int targetLength, s_align &a, std::string &backtrace) {
+        if (sw[thread] == NULL) {
+            sw[thread] = new SmithWaterman(maxSeqLen, m->alphabetSize, compBias, compBiasScale, (SubstitutionMatrix *)m);
+            seq[thread] = new Sequence(maxSeqLen, seqType, m, 0, false, compBias);
+        }
+        if (lastQuery[thread] != queryIndex) {
+            seq[thread]->mapSequence(0, 0, std::make_pair(query, (const unsigned int)queryLength));
+            sw[thread]->ssw_init(seq[thread], tiny.data(), m);
+            lastQuery[thread] = queryIndex;
+        }
+        s_align r = sw[thread]->mmgpuBlockBacktrace(target, targetLength, (uint8_t)gapOpen, (uint8_t)gapExtend, backtrace, a);
+        if (r.score1 == UINT32_MAX) {
+            backtrace.clear();
+            return false;
+        }
+        a = r;
+        return true;
+    }
+
+private:
+    BaseMatrix *m;
+    int gapOpen, gapExtend;
+    std::vector<SmithWaterman *> sw;
+    std::vector<Sequence *> seq;
+    std::vector<size_t> lastQuery;
+    std::vector<int8_t> tiny;
+    size_t maxSeqLen;
+    bool compBias;
+    float compBiasScale;
+    int seqType;
+};
+
+struct ListEntry {
+    DBKeyType dbKey;
+    int target;     // index into MMGpuMatcher::Query::targets, -1: Util::canBeCovered said no (:370-373)
+};
+
+struct TargetStore {
+    std::vector<unsigned char> residues;
+    std::vector<uint64_t> offsets;
+};
+const unsigned char *lookupTarget(void *ctx, unsigned int id) {
+    TargetStore *s = static_cast<TargetStore *>(ctx);
+    return s->residues.data() + s->offsets[id];
+}
+
+}  // namespace
+
+bool MMGpuAlignRun::usable(const Alignment &a) {
+    if (!MMGpuRun::enabled()) return false;
+    const bool aa = Parameters::isEqualDbtype(a.querySeqType, Parameters::DBTYPE_AMINO_ACIDS) &&
+                    Parameters::isEqualDbtype(a.targetSeqType, Parameters::DBTYPE_AMINO_ACIDS);
+    // what the device path does not cover keeps the reference's CPU loop: profile / nucleotide databases,
+    // realignment, alternative alignments, wrapped scoring, LCA realignment, correlation score
+    if (!aa || a.realign || a.altAlignment > 0 || a.wrappedScoring || a.lcaAlign || a.correlationScoreWeight != 0.0f) {
+        Debug(Debug::INFO) << "MMGPU: alignment configuration not covered by the device path, using the CPU path\n";
+        return false;
+    }
+    return true;
+}
+
+bool MMGpuAlignRun::run(Alignment &al, const std::string &outDB, const std::string &outDBIndex, const size_t dbFrom,
+                        const size_t dbSize, bool merge) {
+    if (!usable(al)) return false;
+    mmgpu_ctx *gpu = MMGpuRun::context();     // EXITs with the library's message if no device can be opened
+
+    int dbtype = Parameters::DBTYPE_ALIGNMENT_RES;
+    if (al.alignmentOutputMode == Parameters::ALIGNMENT_OUTPUT_CLUSTER) {
+        dbtype = Parameters::DBTYPE_CLUSTER_RES;
+    }
+    dbtype = DBReader<DBKeyType>::setExtendedDbtype(dbtype, DBReader<DBKeyType>::getExtendedDbtype(al.prefdbr->getDbtype()));
+    DBWriter dbw(outDB.c_str(), outDBIndex.c_str(), al.threads, al.compressed, dbtype);
+    dbw.open();
+    if (dbSize == 0) {
+        dbw.close(merge);
+        return true;
+    }
+    EvalueComputation evaluer(al.tdbr->getAminoAcidDBSize(), al.m, al.gapOpen, al.gapExtend);
+    const unsigned int threads = al.threads;
+
+    // ---- resident targets: Sequence::numSequence of every entry of the target DB, ids = DBReader ids (:361,367)
+    TargetStore store;
+    const size_t nTargets = al.tdbr->getSize();
+    store.offsets.assign(nTargets + 1, 0);
+    for (size_t id = 0; id < nTargets; id++) store.offsets[id + 1] = store.offsets[id] + al.tdbr->getSeqLen(id);
+    store.residues.resize(store.offsets[nTargets] + 1);
+    std::vector<Sequence *> qSeqs(threads, NULL), dbSeqs(threads, NULL);
+#pragma omp parallel num_threads(threads)
+    {
+        unsigned int thread_idx = 0;
+#ifdef OPENMP
+        thread_idx = static_cast<unsigned int>(omp_get_thread_num());
+#endif
+        qSeqs[thread_idx] = new Sequence(al.maxSeqLen, al.querySeqType, al.m, 0, false, al.compBiasCorrection);
+        dbSeqs[thread_idx] = new Sequence(al.maxSeqLen, al.targetSeqType, al.m, 0, false, al.compBiasCorrection);
+        Sequence &dbSeq = *dbSeqs[thread_idx];
+#pragma omp for schedule(dynamic, 256)
+        for (size_t id = 0; id < nTargets; id++) {
+            char *data = al.tdbr->getData(id, thread_idx);
+            if (data == NULL) continue;
+            dbSeq.mapSequence(id, al.tdbr->getDbKey(id), data, al.tdbr->getSeqLen(id));
+            memcpy(store.residues.data() + store.offsets[id], dbSeq.numSequence, dbSeq.L);
+        }
+    }
+    if (mmgpu_load_targets(gpu, store.residues.data(), store.offsets.data(), (uint32_t)nTargets, al.m->alphabetSize) != 0) {
+        Debug(Debug::ERROR) << "MMGPU: " << mmgpu_last_error() << "\n";
+        EXIT(EXIT_FAILURE);
+    }
+
+    MMGpuAlignBackend *backend = mmgpuNewDeviceBackend(gpu);
+    MMGpuMatcher gpuMatcher(backend, al.m, &evaluer, al.compBiasCorrection, al.compBiasCorrectionScale, al.gapOpen, al.gapExtend);
+    const size_t maxMatcherSeqLen = std::max(al.tdbr->getMaxSeqLen(), al.qdbr->getMaxSeqLen());
+    HostBlockBacktracer blockHook(threads, maxMatcherSeqLen, al.m, al.compBiasCorrection, al.compBiasCorrectionScale, al.gapOpen,
+                                  al.gapExtend, al.querySeqType);
+    if (MMGpuRun::hostBlockAligner()) gpuMatcher.setBlockBacktracer(&blockHook, lookupTarget, &store);
+    std::vector<Matcher *> cpuMatchers(threads, NULL);      // only for pairs whose backtrace the device declines
+
+    // block = as many queries as keep the pair count of one device call bounded (a prefilter line has >= 6 bytes)
+    const size_t maxBlockQueries = MMGpuRun::envSize("MMGPU_ALIGN_BLOCK_QUERIES", 16384);
+    const size_t maxBlockBytes = MMGpuRun::envSize("MMGPU_ALIGN_BLOCK_BYTES", 192u << 20);
+    const bool remap = Util::getTotalSystemMemory() <= al.prefdbr->getTotalDataSize();
+
+    size_t alignmentsNum = 0;
+    size_t totalPassedNum = 0;
+    Debug::Progress progress(dbSize);
+    std::vector<MMGpuMatcher::Query> block;
+    std::vector<std::vector<unsigned char> > queryNum;
+    std::vector<std::vector<ListEntry> > lists;
+    std::vector<DBKeyType> queryKeys;
+    std::vector<std::vector<Matcher::result_t> > results;
+    std::vector<std::pair<size_t, size_t> > refused;
+    size_t next = dbFrom;
+    const size_t end = dbFrom + dbSize;
+    while (next < end) {
+        size_t blockEnd = next, bytes = 0;
+        while (blockEnd < end && blockEnd - next < maxBlockQueries && (bytes < maxBlockBytes || blockEnd == next)) {
+            bytes += al.prefdbr->getEntryLen(blockEnd);
+            blockEnd++;
+        }
+        const size_t nq = blockEnd - next;
+        block.assign(nq, MMGpuMatcher::Query());
+        queryNum.assign(nq, std::vector<unsigned char>());
+        lists.assign(nq, std::vector<ListEntry>());
+        queryKeys.assign(nq, 0);
+
+        // ---- parse: the list walk of :316-375 without the alignment
+#pragma omp parallel num_threads(threads)
+        {
+            unsigned int thread_idx = 0;
+#ifdef OPENMP
+            thread_idx = static_cast<unsigned int>(omp_get_thread_num());
+#endif
+            Sequence &qSeq = *qSeqs[thread_idx];
+            char buffer[1024 + 32768 * 4];
+#pragma omp for schedule(dynamic, 5)
+            for (size_t b = 0; b < nq; b++) {
+                const size_t id = next + b;
+                char *data = al.prefdbr->getData(id, thread_idx);
+                const DBKeyType queryDbKey = al.prefdbr->getDbKey(id);
+                queryKeys[b] = queryDbKey;
+                MMGpuMatcher::Query &q = block[b];
+                q.numSequence = NULL;
+                q.L = 0;
+                size_t origQueryLen = 0;
+                if (*data != '\0') {
+                    size_t qId = al.qdbr->getId(queryDbKey);
+                    char *querySeqData = al.qdbr->getData(qId, thread_idx);
+                    if (querySeqData == NULL) {
+                        Debug(Debug::ERROR) << "Query sequence " << queryDbKey
+                                            << " is required in the prefiltering, but is not contained in the query sequence database.\nPlease check your database.\n";
+                        EXIT(EXIT_FAILURE);
+                    }
+                    origQueryLen = al.qdbr->getSeqLen(qId);
+                    qSeq.mapSequence(qId, queryDbKey, querySeqData, origQueryLen);
+                    queryNum[b].assign(qSeq.numSequence, qSeq.numSequence + qSeq.L);
+                    q.numSequence = queryNum[b].data();
+                    q.L = qSeq.L;
+                }
+                while (*data != '\0') {
+                    Util::parseKey(data, buffer);
+                    const DBKeyType dbKey = Util::fast_atoi<DBKeyType>(buffer);
+                    data = Util::skipLine(data);
+                    const size_t dbId = al.tdbr->getId(dbKey);
+                    if (al.tdbr->getData(dbId, thread_idx) == NULL) {
+                        Debug(Debug::ERROR) << "Sequence " << dbKey << " is required in the prefiltering, but is not contained in the target sequence database!\nPlease check your database.\n";
+                        EXIT(EXIT_FAILURE);
+                    }
+                    const int dbLen = (int)(store.offsets[dbId + 1] - store.offsets[dbId]);
+                    ListEntry e;
+                    e.dbKey = dbKey;
+                    e.target = -1;
+                    if (Util::canBeCovered(al.canCovThr, al.covMode, static_cast<float>(origQueryLen), static_cast<float>(dbLen))) {
+                        MMGpuMatcher::Target t;
+                        t.id = (unsigned int)dbId;
+                        t.dbKey = dbKey;
+                        t.length = dbLen;
+                        t.numSequence = store.residues.data() + store.offsets[dbId];
+                        t.isIdentity = (queryDbKey == dbKey && (al.includeIdentity || al.sameQTDB)) ? true : false;
+                        e.target = (int)q.targets.size();
+                        q.targets.push_back(t);
+                    }
+                    lists[b].push_back(e);
+                }
+            }
+        }
+
+        // ---- one device call for the block
+        blockHook.newBlock();
+        if (!gpuMatcher.alignBlock(block, al.covMode, al.covThr, al.evalThr, al.swMode, al.seqIdMode, results, &refused)) {
+            Debug(Debug::ERROR) << "MMGPU: " << gpuMatcher.error() << "\n";
+            EXIT(EXIT_FAILURE);
+        }
+        // pairs whose backtrace the device declined (band storage above its budget): the reference's own call
+        for (size_t r = 0; r < refused.size(); r++) {
+            const size_t b = refused[r].first;
+            const MMGpuMatcher::Target &t = block[b].targets[refused[r].second];
+            if (cpuMatchers[0] == NULL)
+                cpuMatchers[0] = new Matcher(al.querySeqType, maxMatcherSeqLen, al.m, &evaluer, al.compBiasCorrection,
+                                             al.compBiasCorrectionScale, al.gapOpen, al.gapExtend, 0.0f, al.zdrop);
+            qSeqs[0]->mapSequence(0, queryKeys[b], std::make_pair(block[b].numSequence, (const unsigned int)block[b].L));
+            dbSeqs[0]->mapSequence(t.id, t.dbKey, std::make_pair(t.numSequence, (const unsigned int)t.length));
+            cpuMatchers[0]->initQuery(qSeqs[0]);
+            results[b][refused[r].second] = cpuMatchers[0]->getSWResult(dbSeqs[0], 0, false, al.covMode, al.covThr, al.evalThr,
+                                                                        al.swMode, al.seqIdMode, false, false);
+        }
+
+        // ---- replay of :344-397 on the results, sort, serialise, write
+#pragma omp parallel num_threads(threads)
+        {
+            unsigned int thread_idx = 0;
+#ifdef OPENMP
+            thread_idx = static_cast<unsigned int>(omp_get_thread_num());
+#endif
+            std::string alnResultsOutString;
+            alnResultsOutString.reserve(1024 * 1024);
+            char buffer[1024 + 32768 * 4];
+            std::vector<Matcher::result_t> swResults;
+            swResults.reserve(300);
+#pragma omp for schedule(dynamic, 5) reduction(+ : alignmentsNum, totalPassedNum)
+            for (size_t b = 0; b < nq; b++) {
+                progress.updateProgress();
+                size_t passedNum = 0;
+                unsigned int rejected = 0;
+                for (size_t k = 0; k < lists[b].size() && passedNum < al.maxAccept && rejected < al.maxReject; k++) {
+                    const ListEntry &e = lists[b][k];
+                    if (e.target < 0) {
+                        rejected++;
+                        continue;
+                    }
+                    Matcher::result_t &res = results[b][e.target];
+                    const bool isIdentity = block[b].targets[e.target].isIdentity;
+                    alignmentsNum++;
+                    if (isIdentity) {
+                        res.qcov = 1.0f;
+                        res.dbcov = 1.0f;
+                        res.seqId = 1.0f;
+                    }
+                    if (Alignment::checkCriteria(res, isIdentity, al.evalThr, al.seqIdThr, al.alnLenThr, al.covMode, al.covThr)) {
+                        swResults.emplace_back(res);
+                        passedNum++;
+                        totalPassedNum++;
+                        rejected = 0;
+                    } else {
+                        rejected++;
+                    }
+                }
+                if (swResults.size() > 1) {
+                    SORT_SERIAL(swResults.begin(), swResults.end(), Matcher::compareHits);
+                }
+                if (al.alignmentOutputMode == Parameters::ALIGNMENT_OUTPUT_CLUSTER) {
+                    for (size_t result = 0; result < swResults.size(); result++) {
+                        alnResultsOutString.append(SSTR(swResults[result].dbKey));
+                        alnResultsOutString.push_back('\n');
+                    }
+                } else {
+                    for (size_t result = 0; result < swResults.size(); result++) {
+                        size_t len = Matcher::resultToBuffer(buffer, swResults[result], al.addBacktrace);
+                        alnResultsOutString.append(buffer, len);
+                    }
+                }
+                dbw.writeData(alnResultsOutString.c_str(), alnResultsOutString.length(), queryKeys[b], thread_idx);
+                alnResultsOutString.clear();
+                swResults.clear();
+            }
+        }
+        next = blockEnd;
+        if (remap && next < end) al.prefdbr->remapData();
+    }
+    delete backend;
+    for (size_t i = 0; i < threads; i++) {
+        delete qSeqs[i];
+        delete dbSeqs[i];
+        delete cpuMatchers[i];
+    }
+    dbw.close(merge);
+
+    Debug(Debug::INFO) << alignmentsNum << " alignments calculated\n";
+    Debug(Debug::INFO) << totalPassedNum << " sequence pairs passed the thresholds";
+    if (alignmentsNum > 0) {
+        Debug(Debug::INFO) << " (" << ((float)totalPassedNum / (float)alignmentsNum) << " of overall calculated)";
+    }
+    Debug(Debug::INFO) << "\n";
+    if (dbSize > 0) {
+        size_t hits = totalPassedNum / dbSize;
+        size_t hits_rest = totalPassedNum % dbSize;
+        float hits_f = ((float)hits) + ((float)hits_rest) / (float)dbSize;
+        Debug(Debug::INFO) << hits_f << " hits per query sequence\n";
+    }
+    return true;
+}

@@ -1,16 +1,22 @@
 #include "MMGpuMatcher.h"
 
 #include <algorithm>
+#include <climits>
 #include <cstring>
 
 #include "StripedSmithWaterman.h"
 #include "SubstitutionMatrix.h"
 #include "Util.h"
 
+#ifdef OPENMP
+#include <omp.h>
+#endif
+
 MMGpuMatcher::MMGpuMatcher(MMGpuAlignBackend *backend, BaseMatrix *m, EvalueComputation *evaluer, bool aaBiasCorrection,
                            float aaBiasCorrectionScale, int gapOpen, int gapExtend)
     : backend(backend), m(m), evaluer(evaluer), aaBiasCorrection(aaBiasCorrection),
-      aaBiasCorrectionScale(aaBiasCorrectionScale), gapOpen(gapOpen), gapExtend(gapExtend) {
+      aaBiasCorrectionScale(aaBiasCorrectionScale), gapOpen(gapOpen), gapExtend(gapExtend), blockHook(NULL),
+      targetLookup(NULL), targetLookupCtx(NULL) {
     const int a = m->alphabetSize;
     tinySubMat.resize(a * a);
     subMat16.resize(a * a);
@@ -33,36 +39,49 @@ int MMGpuMatcher::minScoreForEvalue(double evalThr, int queryLength) const {
     return lo;
 }
 
+namespace {
+struct Pending {
+    s_align a;
+    bool wantsBacktrace;   // reaches banded_sw in alignStartPosBacktrace (mode 2 and coverage ok)
+    bool blockDone;        // start / backtrace / identities came from the host's block aligner
+    std::string blockBacktrace;
+};
+}  // namespace
+
 bool MMGpuMatcher::alignBlock(const std::vector<Query> &queries, int covMode, float covThr, double evalThr,
                               unsigned int alignmentMode, unsigned int seqIdMode,
-                              std::vector<std::vector<Matcher::result_t> > &results) {
+                              std::vector<std::vector<Matcher::result_t> > &results,
+                              std::vector<std::pair<size_t, size_t> > *refusedPairs) {
     const size_t nq = queries.size();
+    if (refusedPairs) refusedPairs->clear();
     results.assign(nq, std::vector<Matcher::result_t>());
     // ---- per query: rounded composition bias as ssw_init builds it (StripedSmithWaterman.cpp:1364-1383) and the list
     // of the non-identity targets (identity hits never reach the aligner, Matcher.cpp:88-90)
     std::vector<std::vector<int8_t> > bias(nq);
     std::vector<std::vector<uint32_t> > ids(nq);
     std::vector<mmgpu_sw_query> dq(nq);
-    size_t total = 0;
+    std::vector<size_t> firstPair(nq + 1, 0);
+#pragma omp parallel for schedule(dynamic, 16)
     for (size_t q = 0; q < nq; q++) {
-        Sequence *s = queries[q].seq;
-        bias[q].assign(s->L, 0);
+        const Query &qu = queries[q];
+        bias[q].assign(qu.L, 0);
         if (aaBiasCorrection) {
-            std::vector<float> tmp(s->L);
-            SubstitutionMatrix::calcLocalAaBiasCorrection(m, s->numSequence, s->L, tmp.data(), aaBiasCorrectionScale);
-            for (int i = 0; i < s->L; i++)      // the statement of ssw_init, :1379 (the cast binds to the comparison)
+            std::vector<float> tmp(qu.L);
+            SubstitutionMatrix::calcLocalAaBiasCorrection(m, qu.numSequence, qu.L, tmp.data(), aaBiasCorrectionScale);
+            for (int i = 0; i < qu.L; i++)      // the statement of ssw_init, :1379 (the cast binds to the comparison)
                 bias[q][i] = (int8_t)(tmp[i] < 0.0) ? tmp[i] - 0.5 : tmp[i] + 0.5;
         }
-        for (size_t k = 0; k < queries[q].targets.size(); k++)
-            if (!queries[q].targets[k].isIdentity) ids[q].push_back(queries[q].targets[k].id);
-        dq[q].q = s->numSequence;
-        dq[q].qlen = (uint32_t)s->L;
+        for (size_t k = 0; k < qu.targets.size(); k++)
+            if (!qu.targets[k].isIdentity) ids[q].push_back(qu.targets[k].id);
+        dq[q].q = qu.numSequence;
+        dq[q].qlen = (uint32_t)qu.L;
         dq[q].comp_bias = bias[q].data();
         dq[q].target_ids = ids[q].data();
         dq[q].n_targets = (uint32_t)ids[q].size();
-        dq[q].min_start_score = alignmentMode == Matcher::SCORE_ONLY ? 0 : minScoreForEvalue(evalThr, s->L);
-        total += ids[q].size();
+        dq[q].min_start_score = alignmentMode == Matcher::SCORE_ONLY ? 0 : minScoreForEvalue(evalThr, qu.L);
     }
+    for (size_t q = 0; q < nq; q++) firstPair[q + 1] = firstPair[q] + ids[q].size();
+    const size_t total = firstPair[nq];
     mmgpu_sw_params par;
     par.mat = tinySubMat.data();
     par.alphabet = m->alphabetSize;
@@ -77,20 +96,21 @@ bool MMGpuMatcher::alignBlock(const std::vector<Query> &queries, int covMode, fl
 
     // ---- host part of ssw_align_private (StripedSmithWaterman.cpp:846-890) per pair; pairs that go on to the
     // backtrace are collected for one traceback call
-    struct Pending {
-        s_align a;
-        bool early;     // returned before the start positions were needed
-    };
     std::vector<Pending> aln(total);
-    std::vector<uint32_t> btPairs;
-    size_t p = 0;
+#pragma omp parallel for schedule(dynamic, 4)
     for (size_t q = 0; q < nq; q++) {
-        const int qlen = queries[q].seq->L;
-        size_t k = 0;
+        unsigned int thread = 0;
+#ifdef OPENMP
+        thread = (unsigned int)omp_get_thread_num();
+#endif
+        const int qlen = queries[q].L;
+        size_t p = firstPair[q];
         for (size_t t = 0; t < queries[q].targets.size(); t++) {
-            if (queries[q].targets[t].isIdentity) continue;
+            const Target &tg = queries[q].targets[t];
+            if (tg.isIdentity) continue;
             const mmgpu_sw_hit &h = hits[p];
-            const int dbLen = queries[q].targets[t].length;
+            const int dbLen = tg.length;
+            Pending &pe = aln[p];
             s_align a;
             memset(&a, 0, sizeof(a));
             a.score1 = (uint32_t)h.score;
@@ -99,7 +119,8 @@ bool MMGpuMatcher::alignBlock(const std::vector<Query> &queries, int covMode, fl
             a.qStartPos1 = -1;
             a.dbStartPos1 = -1;
             a.word = h.word;
-            bool early = true;
+            pe.wantsBacktrace = false;
+            pe.blockDone = false;
             if (a.dbEndPos1 != -1) {
                 a.qCov = SmithWaterman::computeCov(0, a.qEndPos1, qlen);
                 a.tCov = SmithWaterman::computeCov(0, a.dbEndPos1, dbLen);
@@ -107,22 +128,34 @@ bool MMGpuMatcher::alignBlock(const std::vector<Query> &queries, int covMode, fl
                 a.evalue = evaluer->computeEvalue(a.score1, qlen);
                 const bool lowEval = a.evalue > evalThr;
                 if (!(alignmentMode == 0 || ((alignmentMode == 2 || alignmentMode == 1) && (lowEval || lowCov)))) {
-                    // alignStartPosBacktrace (:1129-1258): start positions from the reverse scan
-                    early = false;
-                    a.qStartPos1 = h.q_start;
-                    a.dbStartPos1 = h.t_start;
-                    a.qCov = SmithWaterman::computeCov(a.qStartPos1, a.qEndPos1, qlen);
-                    a.tCov = SmithWaterman::computeCov(a.dbStartPos1, a.dbEndPos1, dbLen);
-                    const bool lowCov2 = !Util::hasCoverage(covThr, covMode, a.qCov, a.tCov);
-                    if (!(alignmentMode == 1 || lowCov2)) btPairs.push_back((uint32_t)p);
+                    // word == 1: the stock reference asks the block aligner first (:865-882)
+                    if (a.word == 1 && blockHook != NULL) {
+                        s_align b = a;
+                        std::string bt;
+                        if (blockHook->run(thread, q, queries[q].numSequence, qlen, targetLookup(targetLookupCtx, tg.id), dbLen, b, bt)) {
+                            pe.blockDone = true;
+                            pe.blockBacktrace.swap(bt);
+                            a = b;
+                        }
+                    }
+                    if (!pe.blockDone) {
+                        // alignStartPosBacktrace (:1129-1258): start positions from the reverse scan
+                        a.qStartPos1 = h.q_start;
+                        a.dbStartPos1 = h.t_start;
+                        a.qCov = SmithWaterman::computeCov(a.qStartPos1, a.qEndPos1, qlen);
+                        a.tCov = SmithWaterman::computeCov(a.dbStartPos1, a.dbEndPos1, dbLen);
+                        const bool lowCov2 = !Util::hasCoverage(covThr, covMode, a.qCov, a.tCov);
+                        if (!(alignmentMode == 1 || lowCov2)) pe.wantsBacktrace = true;
+                    }
                 }
             }
-            aln[p].a = a;
-            aln[p].early = early;
+            pe.a = a;
             p++;
-            k++;
         }
     }
+    std::vector<uint32_t> btPairs;
+    for (size_t p = 0; p < total; p++)
+        if (aln[p].wantsBacktrace) btPairs.push_back((uint32_t)p);
     std::vector<mmgpu_sw_bt> btInfo(btPairs.size());
     std::string btStrings;
     if (!btPairs.empty() && backend->traceback(btPairs.data(), (uint32_t)btPairs.size(), btInfo.data(), btStrings) != 0) {
@@ -133,13 +166,16 @@ bool MMGpuMatcher::alignBlock(const std::vector<Query> &queries, int covMode, fl
     for (size_t i = 0; i < btPairs.size(); i++) btOf[btPairs[i]] = (int)i;
 
     // ---- Matcher::getSWResult's tail (Matcher.cpp:93-143) ----
-    p = 0;
+    bool refused = false;
+    std::vector<unsigned char> refusedFlag(total, 0);
+#pragma omp parallel for schedule(dynamic, 16)
     for (size_t q = 0; q < nq; q++) {
-        Sequence *qs = queries[q].seq;
-        const int origQueryLen = qs->L;
-        results[q].reserve(queries[q].targets.size());
-        for (size_t t = 0; t < queries[q].targets.size(); t++) {
-            const Target &tg = queries[q].targets[t];
+        const Query &qs = queries[q];
+        const int origQueryLen = qs.L;
+        size_t p = firstPair[q];
+        results[q].reserve(qs.targets.size());
+        for (size_t t = 0; t < qs.targets.size(); t++) {
+            const Target &tg = qs.targets[t];
             s_align a;
             std::string backtrace;
             if (tg.isIdentity) {
@@ -153,7 +189,7 @@ bool MMGpuMatcher::alignBlock(const std::vector<Query> &queries, int covMode, fl
                 a.tCov = 1.0f;
                 short score = 0;
                 for (int pos = 0; pos < tg.length; pos++) {
-                    score += (short)(tinySubMat[qs->numSequence[pos] * m->alphabetSize + tg.numSequence[pos]] + bias[q][pos]);
+                    score += (short)(tinySubMat[qs.numSequence[pos] * m->alphabetSize + tg.numSequence[pos]] + bias[q][pos]);
                     backtrace.push_back('M');
                 }
                 a.score1 = (uint32_t)score;
@@ -161,14 +197,16 @@ bool MMGpuMatcher::alignBlock(const std::vector<Query> &queries, int covMode, fl
                 a.identicalAACnt = (uint32_t)tg.length;
             } else {
                 a = aln[p].a;
-                if (btOf[p] >= 0) {
+                if (aln[p].blockDone) {
+                    backtrace.swap(aln[p].blockBacktrace);
+                } else if (btOf[p] >= 0) {
                     const mmgpu_sw_bt &bi = btInfo[btOf[p]];
                     if (bi.status == MMGPU_BT_OK) {
                         backtrace.assign(btStrings, (size_t)bi.bt_off, (size_t)bi.bt_len);
                         a.identicalAACnt = bi.ident;
                     } else {
-                        err = "a backtrace was refused by the device (band too large): run Matcher::getSWResult for this pair";
-                        return false;
+                        refused = true;          // every thread writes the same value
+                        refusedFlag[p] = 1;
                     }
                 }
                 p++;
@@ -195,6 +233,21 @@ bool MMGpuMatcher::alignBlock(const std::vector<Query> &queries, int covMode, fl
             const int bitScore = static_cast<int>(evaluer->computeBitScore(a.score1) + 0.5);
             results[q].push_back(Matcher::result_t(tg.dbKey, bitScore, qcov, dbcov, seqId, a.evalue, alnLength, qStartPos, qEndPos,
                                                    origQueryLen, dbStartPos, dbEndPos, tg.length, backtrace));
+        }
+    }
+    if (refused) {
+        // MMGPU_BT_TOO_LARGE / MMGPU_BT_FAILED: the caller runs Matcher::getSWResult for these pairs
+        if (refusedPairs == NULL) {
+            err = "a backtrace was refused by the device (band too large): run Matcher::getSWResult for this pair";
+            return false;
+        }
+        for (size_t q = 0; q < nq; q++) {
+            size_t p = firstPair[q];
+            for (size_t t = 0; t < queries[q].targets.size(); t++) {
+                if (queries[q].targets[t].isIdentity) continue;
+                if (refusedFlag[p]) refusedPairs->push_back(std::make_pair(q, t));
+                p++;
+            }
         }
     }
     return true;

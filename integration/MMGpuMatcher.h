@@ -19,6 +19,7 @@
 #include "EvalueComputation.h"
 #include "Matcher.h"
 #include "Sequence.h"
+#include "StripedSmithWaterman.h"
 
 #include "mmgpu.h"
 
@@ -36,6 +37,20 @@ public:
     virtual const char *lastError() = 0;
 };
 
+// Optional host hook for the pairs whose score left the uint8 range (s_align::word == 1).  The stock reference takes
+// start positions, backtrace and identities of those pairs from the Rust block-aligner
+// (alignStartPosBacktraceBlock, StripedSmithWaterman.cpp:865-882,943-1127) and only falls back to its own reverse scan +
+// banded_sw when that fails.  A build that links the real crate installs a hook that calls the host's own
+// alignStartPosBacktraceBlock with the score / end positions the device computed, so that those fields are the stock
+// binary's by construction; run() returns false when the block aligner declines (r.score1 == UINT32_MAX), in which
+// case the device's fallback results are used exactly like the reference's fallback.  Called from OpenMP threads.
+class MMGpuBlockBacktracer {
+public:
+    virtual ~MMGpuBlockBacktracer() {}
+    virtual bool run(unsigned int thread, size_t queryIndex, const unsigned char *query, int queryLength,
+                     const unsigned char *target, int targetLength, s_align &a, std::string &backtrace) = 0;
+};
+
 class MMGpuMatcher {
 public:
     struct Target {
@@ -46,8 +61,9 @@ public:
         bool isIdentity;        // Alignment.cpp:360-365: same key as the query and self-hit handling on
     };
     struct Query {
-        Sequence *seq;
-        std::vector<Target> targets;   // the prefilter list, in list order
+        const unsigned char *numSequence;   // Sequence::numSequence of the query (the caller keeps it alive)
+        int L;                              // Sequence::L
+        std::vector<Target> targets;        // the prefilter list, in list order
     };
 
     MMGpuMatcher(MMGpuAlignBackend *backend, BaseMatrix *m, EvalueComputation *evaluer, bool aaBiasCorrection,
@@ -55,11 +71,22 @@ public:
 
     // One call per block of queries; results[q][k] is what Matcher::getSWResult returns for queries[q].targets[k]
     // (diagonal unused, isReverse false, wrappedScoring false, correlationScoreWeight 0).
-    // Returns false (message in error()) if the device call failed.
+    // Returns false (message in error()) if the device call failed.  Pairs whose backtrace the device declined
+    // (MMGPU_BT_TOO_LARGE / MMGPU_BT_FAILED) are listed in refusedPairs as (query, index into targets): the caller
+    // recomputes those results with the host's Matcher::getSWResult (NULL: such a pair is an error).
     bool alignBlock(const std::vector<Query> &queries, int covMode, float covThr, double evalThr, unsigned int alignmentMode,
-                    unsigned int seqIdMode, std::vector<std::vector<Matcher::result_t> > &results);
+                    unsigned int seqIdMode, std::vector<std::vector<Matcher::result_t> > &results,
+                    std::vector<std::pair<size_t, size_t> > *refusedPairs = NULL);
 
     const std::string &error() const { return err; }
+
+    // targetSequence(id) must return the numeric residues of a resident target (needed by the hook only)
+    typedef const unsigned char *(*TargetLookup)(void *ctx, unsigned int id);
+    void setBlockBacktracer(MMGpuBlockBacktracer *hook, TargetLookup lookup, void *lookupCtx) {
+        blockHook = hook;
+        targetLookup = lookup;
+        targetLookupCtx = lookupCtx;
+    }
 
     // smallest raw score whose E-value passes evalThr for a query of this length (ssw_align_private's gate,
     // StripedSmithWaterman.cpp:857-863); 32768 if none does
@@ -75,6 +102,9 @@ private:
     std::vector<int8_t> tinySubMat;      // Matcher::setSubstitutionMatrix, Matcher.cpp:29-36
     std::vector<int16_t> subMat16;
     std::string err;
+    MMGpuBlockBacktracer *blockHook;
+    TargetLookup targetLookup;
+    void *targetLookupCtx;
 };
 
 #endif

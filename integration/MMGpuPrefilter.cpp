@@ -3,6 +3,14 @@
 #include <climits>
 
 #include "SubstitutionMatrix.h"
+#include "Util.h"
+
+unsigned int MMGpuPrefilter::referenceBins(size_t dbsize) {
+    const uint64_t l2CacheSize = Util::getL2CacheSize();
+    for (unsigned int b = 2; b <= 1024; b *= 2)
+        if (dbsize / b < l2CacheSize) return b;
+    return 2048;
+}
 
 MMGpuPrefilter::MMGpuPrefilter(mmgpu_ctx *gpu, BaseMatrix *kmerSubMat, BaseMatrix *ungappedSubMat, bool aaBiasCorrection,
                                float aaBiasCorrectionScale)
@@ -50,7 +58,8 @@ bool MMGpuPrefilter::loadIndex(IndexTable *indexTable, SequenceLookup *sequenceL
 }
 
 bool MMGpuPrefilter::matchBlock(const std::vector<Query> &queries, int kmerThr, size_t maxResListLen, unsigned int minDiagScoreThr,
-                                std::vector<std::vector<hit_t> > &results, std::vector<bool> &needsCpu) {
+                                std::vector<std::vector<hit_t> > &results, std::vector<bool> &needsCpu,
+                                std::vector<mmgpu_pf_qstat> *stats) {
     const size_t nq = queries.size();
     results.assign(nq, std::vector<hit_t>());
     needsCpu.assign(nq, false);
@@ -58,13 +67,14 @@ bool MMGpuPrefilter::matchBlock(const std::vector<Query> &queries, int kmerThr, 
     // QueryMatcher::matchQuery's composition bias over the k-mer matrix (QueryMatcher.cpp:109-117), floats
     std::vector<std::vector<float> > bias(nq);
     std::vector<mmgpu_pf_query> dq(nq);
+#pragma omp parallel for schedule(dynamic, 16)
     for (size_t q = 0; q < nq; q++) {
-        Sequence *s = queries[q].seq;
-        bias[q].assign(s->L, 0.0f);
+        const Query &s = queries[q];
+        bias[q].assign(s.L, 0.0f);
         if (aaBiasCorrection)
-            SubstitutionMatrix::calcLocalAaBiasCorrection(kmerSubMat, s->numSequence, s->L, bias[q].data(), aaBiasCorrectionScale);
-        dq[q].q = s->numSequence;
-        dq[q].qlen = (uint32_t)s->L;
+            SubstitutionMatrix::calcLocalAaBiasCorrection(kmerSubMat, s.numSequence, s.L, bias[q].data(), aaBiasCorrectionScale);
+        dq[q].q = s.numSequence;
+        dq[q].qlen = (uint32_t)s.L;
         dq[q].comp_bias = bias[q].data();
         dq[q].identity_id = queries[q].identityId;
     }
@@ -72,12 +82,18 @@ bool MMGpuPrefilter::matchBlock(const std::vector<Query> &queries, int kmerThr, 
     par.kmer_thr = kmerThr;
     par.max_hits = (uint32_t)maxResListLen;
     par.min_diag_score = minDiagScoreThr;
-    par.ref_bins = 0;       // the CacheFriendlyOperations<N> this host would pick (QueryMatcher.cpp:460-488)
+    par.ref_bins = referenceBins(dbSize);
     const uint32_t stride = (uint32_t)std::min(maxResListLen, dbSize);
     std::vector<mmgpu_pf_hit> hits(nq * (size_t)stride);
     std::vector<uint32_t> counts(nq);
     std::vector<int32_t> status(nq);
-    if (mmgpu_pf_batch(gpu, &par, dq.data(), (uint32_t)nq, hits.data(), stride, counts.data(), status.data()) != 0) {
+    mmgpu_pf_batch_t *batch = NULL;
+    int rc = mmgpu_pf_prepare(gpu, &par, dq.data(), (uint32_t)nq, &batch);
+    if (rc == 0) rc = mmgpu_pf_run(gpu, batch);
+    if (stats) stats->assign(nq, mmgpu_pf_qstat());
+    if (rc == 0) rc = mmgpu_pf_fetch(gpu, batch, hits.data(), stride, counts.data(), status.data(), stats ? stats->data() : NULL);
+    if (batch) mmgpu_pf_free(gpu, batch);
+    if (rc != 0) {
         err = mmgpu_last_error();
         return false;
     }

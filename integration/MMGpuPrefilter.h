@@ -32,12 +32,18 @@ public:
     bool loadIndex(IndexTable *indexTable, SequenceLookup *sequenceLookup, ScoreMatrix &threeMer, ScoreMatrix &twoMer, bool spacedKmer);
 
     struct Query {
-        Sequence *seq;
+        const unsigned char *numSequence;   // Sequence::numSequence (the caller keeps it alive)
+        int L;
         unsigned int identityId;      // targetSeqId of Prefiltering.cpp:855-868, UINT_MAX = none
     };
-    // results[q] = the hit_t list of QueryMatcher::matchQuery; needsCpu[q] = the device declined the query
+    // results[q] = the hit_t list of QueryMatcher::matchQuery; needsCpu[q] = the device declined the query;
+    // stats[q] (optional) = what QueryMatcher::getStatistics() would report for the query
     bool matchBlock(const std::vector<Query> &queries, int kmerThr, size_t maxResListLen, unsigned int minDiagScoreThr,
-                    std::vector<std::vector<hit_t> > &results, std::vector<bool> &needsCpu);
+                    std::vector<std::vector<hit_t> > &results, std::vector<bool> &needsCpu,
+                    std::vector<mmgpu_pf_qstat> *stats = NULL);
+
+    // the CacheFriendlyOperations<N> QueryMatcher::initDiagonalMatcher picks on this host (QueryMatcher.cpp:460-488)
+    static unsigned int referenceBins(size_t dbSize);
 
     const std::string &error() const { return err; }
 

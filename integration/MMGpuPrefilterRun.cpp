@@ -1,0 +1,213 @@
+// The query loop of Prefiltering::runSplit (src/prefiltering/Prefiltering.cpp:820-918) with QueryMatcher::matchQuery on
+// libmmgpu.
+//
+// Everything before the loop stays the reference's: the target split, getIndexTable (IndexBuilder::fillDatabase with
+// tantan masking, or the precomputed index), the similar-k-mer score matrices.  The IndexTable, the (masked)
+// SequenceLookup and the ScoreMatrix tables are handed to the device once per split (MMGpuPrefilter::loadIndex); the loop
+// then runs over blocks of queries: every thread maps sequences, ONE device call returns the hit_t lists of the block
+// (MMGpuPrefilter::matchBlock = the batch form of matchQuery), every thread finishes its queries with the reference's own
+// statements (:876-917: local id -> key, canBeCovered, prefilterHitToBuffer, DBWriter, statistics).  Queries the device
+// declines (more than 62 flushes of the databaseHits buffer) go through a host QueryMatcher.
+//
+// Compiled into MMseqs2 by integration/build_mmseqs.sh (HAVE_MMGPU); Prefiltering.h declares the class a friend.
+#include <climits>
+#include <cstring>
+#include <list>
+#include <string>
+#include <vector>
+
+#include "DBWriter.h"
+#include "Debug.h"
+#include "Prefiltering.h"
+#include "QueryMatcher.h"
+#include "Util.h"
+
+#include "MMGpuPrefilter.h"
+#include "MMGpuRun.h"
+
+#ifdef OPENMP
+#include <omp.h>
+#endif
+
+bool MMGpuPrefilterRun::usable(Prefiltering &p) {
+    if (!MMGpuRun::enabled()) return false;
+    const bool aa = Parameters::isEqualDbtype(p.querySeqType, Parameters::DBTYPE_AMINO_ACIDS) &&
+                    Parameters::isEqualDbtype(p.targetSeqType, Parameters::DBTYPE_AMINO_ACIDS);
+    const char *why = NULL;
+    if (!aa) why = "profile / nucleotide databases";
+    else if (p.indexTable == NULL || p.sequenceLookup == NULL) why = "no index table / sequence lookup in memory";
+    else if (p.takeOnlyBestKmer) why = "exact k-mer matching";
+    else if (!p._3merSubMatrix.isValid() || !p._2merSubMatrix.isValid()) why = "no similar-k-mer score matrices";
+    else if (p.diagonalScoring == 0) why = "--diag-score 0";
+    else if (p.minDiagScoreThr < 1) why = "--min-ungapped-score 0";
+    else if (p.kmerSize != 6 && p.kmerSize != 7) why = "k-mer size other than 6 / 7";
+    else if (p.ungappedSubMatAux != NULL) why = "auxiliary ungapped matrix";
+    else if (p.taxonomyHook != NULL) why = "taxonomy filter";
+    else if (p.maxResListLen > MMGPU_PF_MAX_HITS) why = "--max-seqs above the device limit";
+    else if (std::max(p.tdbr->getMaxSeqLen(), p.qdbr->getMaxSeqLen()) >= MMGPU_PF_MAX_SEQ_LEN) why = "sequences too long for the device";
+    if (why != NULL) {
+        Debug(Debug::INFO) << "MMGPU: prefilter configuration not covered by the device path (" << why << "), using the CPU path\n";
+        return false;
+    }
+    return true;
+}
+
+bool MMGpuPrefilterRun::run(Prefiltering &p, DBWriter &tmpDbw, size_t dbFrom, size_t dbSize, size_t queryFrom, size_t querySize,
+                            char *notEmpty, std::list<int> **reslens, size_t localThreads, Debug::Progress &progress,
+                            MMGpuPrefilterStats &st) {
+    if (!usable(p)) return false;
+    mmgpu_ctx *gpu = MMGpuRun::context();
+    MMGpuPrefilter device(gpu, p.kmerSubMat, p.ungappedSubMat, p.aaBiasCorrection, p.aaBiasCorrectionScale);
+    if (!device.loadIndex(p.indexTable, p.sequenceLookup, p._3merSubMatrix, p._2merSubMatrix, p.spacedKmer)) {
+        Debug(Debug::ERROR) << "MMGPU: " << device.error() << "\n";
+        EXIT(EXIT_FAILURE);
+    }
+    const size_t maxBlockQueries = MMGpuRun::envSize("MMGPU_PREF_BLOCK_QUERIES", 2048);
+
+    std::vector<Sequence *> seqs(localThreads, NULL);
+    std::vector<QueryMatcher *> cpuMatchers(localThreads, NULL);
+    std::vector<std::vector<unsigned char> > queryNum;
+    std::vector<MMGpuPrefilter::Query> block;
+    std::vector<std::vector<hit_t> > results;
+    std::vector<bool> needsCpu;
+    std::vector<mmgpu_pf_qstat> qstats;
+    double kmersPerPos = 0;
+    size_t dbMatches = 0, doubleMatches = 0, querySeqLenSum = 0, resSize = 0, diagonalOverflow = 0;
+
+    for (size_t next = queryFrom; next < queryFrom + querySize;) {
+        const size_t nq = std::min(maxBlockQueries, queryFrom + querySize - next);
+        queryNum.assign(nq, std::vector<unsigned char>());
+        block.assign(nq, MMGpuPrefilter::Query());
+#pragma omp parallel num_threads(localThreads)
+        {
+            unsigned int thread_idx = 0;
+#ifdef OPENMP
+            thread_idx = static_cast<unsigned int>(omp_get_thread_num());
+#endif
+            if (seqs[thread_idx] == NULL)
+                seqs[thread_idx] = new Sequence(p.qdbr->getMaxSeqLen(), p.querySeqType, p.kmerSubMat, p.kmerSize, p.spacedKmer,
+                                                p.aaBiasCorrection, true, p.spacedKmerPattern);
+            Sequence &seq = *seqs[thread_idx];
+#pragma omp for schedule(dynamic, 16)
+            for (size_t b = 0; b < nq; b++) {
+                const size_t id = next + b;
+                char *seqData = p.qdbr->getData(id, thread_idx);
+                DBKeyType qKey = p.qdbr->getDbKey(id);
+                seq.mapSequence(id, qKey, seqData, p.qdbr->getSeqLen(id));
+                queryNum[b].assign(seq.numSequence, seq.numSequence + seq.L);
+                block[b].numSequence = queryNum[b].data();
+                block[b].L = seq.L;
+                // :855-868
+                DBLocalId targetSeqId = DB_LOCAL_ID_INVALID;
+                if (p.sameQTDB || p.includeIdentical) {
+                    size_t foundTargetSeqId = p.tdbr->getId(seq.getDbKey());
+                    if (foundTargetSeqId >= dbFrom && foundTargetSeqId < (dbFrom + dbSize) && foundTargetSeqId != DB_ENTRY_NOT_FOUND) {
+                        targetSeqId = static_cast<DBLocalId>(foundTargetSeqId - dbFrom);
+                        if (targetSeqId > p.tdbr->getSize()) {
+                            Debug(Debug::ERROR) << "targetSeqId: " << targetSeqId << " > target database size: " << p.tdbr->getSize() << "\n";
+                            EXIT(EXIT_FAILURE);
+                        }
+                    }
+                }
+                block[b].identityId = targetSeqId == DB_LOCAL_ID_INVALID ? UINT_MAX : (unsigned int)targetSeqId;
+            }
+        }
+
+        if (!device.matchBlock(block, p.kmerThr, p.maxResListLen, p.minDiagScoreThr, results, needsCpu, &qstats)) {
+            Debug(Debug::ERROR) << "MMGPU: " << device.error() << "\n";
+            EXIT(EXIT_FAILURE);
+        }
+
+#pragma omp parallel num_threads(localThreads)
+        {
+            unsigned int thread_idx = 0;
+#ifdef OPENMP
+            thread_idx = static_cast<unsigned int>(omp_get_thread_num());
+#endif
+            Sequence &seq = *seqs[thread_idx];
+            char buffer[128];
+            std::string result;
+            result.reserve(1000000);
+#pragma omp for schedule(dynamic, 16) reduction(+ : kmersPerPos, resSize, dbMatches, doubleMatches, querySeqLenSum, diagonalOverflow)
+            for (size_t b = 0; b < nq; b++) {
+                progress.updateProgress();
+                const size_t id = next + b;
+                const DBKeyType qKey = p.qdbr->getDbKey(id);
+                hit_t *hits = results[b].data();
+                size_t resultSize = results[b].size();
+                statistics_t cpuStats;
+                bool haveCpuStats = false;
+                if (needsCpu[b]) {
+                    // the reference's own matcher for the queries the device declined (QueryMatcher.cpp:310-346 with > 62 flushes)
+                    if (cpuMatchers[thread_idx] == NULL) {
+                        cpuMatchers[thread_idx] = new QueryMatcher(p.indexTable, p.sequenceLookup, p.kmerSubMat, p.ungappedSubMat, p.kmerThr,
+                                                                   p.kmerSize, dbSize, std::max(p.tdbr->getMaxSeqLen(), p.qdbr->getMaxSeqLen()),
+                                                                   p.maxResListLen, p.aaBiasCorrection, p.aaBiasCorrectionScale, p.diagonalScoring,
+                                                                   p.minDiagScoreThr, p.takeOnlyBestKmer, false, p.ungappedSubMatAux, p.targetSeqType);
+                        cpuMatchers[thread_idx]->setSubstitutionMatrix(&p._3merSubMatrix, &p._2merSubMatrix);
+                    }
+                    seq.mapSequence(id, qKey, p.qdbr->getData(id, thread_idx), p.qdbr->getSeqLen(id));
+                    const DBLocalId identityId = block[b].identityId == UINT_MAX ? DB_LOCAL_ID_INVALID : (DBLocalId)block[b].identityId;
+                    std::pair<hit_t *, size_t> r = cpuMatchers[thread_idx]->matchQuery(&seq, identityId, false);
+                    hits = r.first;
+                    resultSize = r.second;
+                    cpuStats = *cpuMatchers[thread_idx]->getStatistics();
+                    haveCpuStats = true;
+                }
+                const float queryLength = static_cast<float>(p.qdbr->getSeqLen(id));
+                for (size_t i = 0; i < resultSize; i++) {
+                    hit_t *res = hits + i;
+                    // correct the 0 indexed sequence id again to its real identifier
+                    size_t targetSeqId1 = res->seqId + dbFrom;
+                    // replace id with key
+                    res->seqId = p.tdbr->getDbKey(targetSeqId1);
+                    if (UNLIKELY(targetSeqId1 >= p.tdbr->getSize())) {
+                        Debug(Debug::WARNING) << "Wrong prefiltering result for query: " << p.qdbr->getDbKey(id) << " -> " << targetSeqId1 << "\t" << res->prefScore << "\n";
+                    }
+                    if (p.covThr > 0.0 && (p.covMode == Parameters::COV_MODE_BIDIRECTIONAL || p.covMode == Parameters::COV_MODE_QUERY ||
+                                           p.covMode == Parameters::COV_MODE_LENGTH_SHORTER)) {
+                        const float targetLength = static_cast<float>(p.tdbr->getSeqLen(targetSeqId1));
+                        if (Util::canBeCovered(p.covThr, p.covMode, queryLength, targetLength) == false) {
+                            continue;
+                        }
+                    }
+                    int len = QueryMatcher::prefilterHitToBuffer(buffer, *res);
+                    result.append(buffer, len);
+                }
+                tmpDbw.writeData(result.c_str(), result.length(), qKey, thread_idx);
+                result.clear();
+                if (resultSize != 0) {
+                    notEmpty[id - queryFrom] = 1;
+                }
+                if (Debug::debugLevel >= Debug::INFO) {
+                    if (haveCpuStats) {
+                        kmersPerPos += cpuStats.kmersPerPos;
+                        dbMatches += cpuStats.dbMatches;
+                        doubleMatches += cpuStats.doubleMatches;
+                        diagonalOverflow += cpuStats.diagonalOverflow;
+                    } else {
+                        // QueryMatcher::match's counters (QueryMatcher.cpp:366-374)
+                        kmersPerPos += (double)qstats[b].kmer_list_len / (double)block[b].L;
+                        dbMatches += qstats[b].db_matches;
+                        // statistics_t::doubleMatches is only counted with --diag-score 0 (QueryMatcher.cpp:366-371)
+                    }
+                    querySeqLenSum += block[b].L;
+                    resSize += resultSize;
+                    reslens[thread_idx]->emplace_back(resultSize);
+                }
+            }
+        }
+        next += nq;
+    }
+    for (size_t i = 0; i < localThreads; i++) {
+        delete seqs[i];
+        delete cpuMatchers[i];
+    }
+    st.kmersPerPos = kmersPerPos;
+    st.dbMatches = dbMatches;
+    st.doubleMatches = doubleMatches;
+    st.querySeqLenSum = querySeqLenSum;
+    st.resSize = resSize;
+    st.diagonalOverflow = diagonalOverflow;
+    return true;
+}

@@ -1,0 +1,59 @@
+// Entry points the patched reference calls (integration/mmseqs_mmgpu.patch): one static function per seam, each
+// returning false when the configuration is not covered by the device path so that the reference's own CPU loop runs.
+//
+//   Alignment::run          -> MMGpuAlignRun::run        (src/alignment/Alignment.cpp:248)
+//   Prefiltering::runSplit  -> MMGpuPrefilterRun::run    (src/prefiltering/Prefiltering.cpp:820, the query loop)
+//
+// Run-time switches (environment, read once):
+//   MMGPU_DISABLE=1            keep the CPU path everywhere (the binary then behaves like the stock one)
+//   MMGPU_DEVICE=<n>           HIP device of this process (default 0; multi-GPU runs start one process per device)
+//   MMGPU_BLOCK_ALIGNER=device start positions / backtraces of hits whose score left the uint8 range come from the
+//                              device's reverse scan + banded_sw (the reference's own fallback) instead of the host's
+//                              block aligner; default "host": those fields are the stock binary's by construction
+//   MMGPU_ALIGN_BLOCK_QUERIES, MMGPU_ALIGN_BLOCK_BYTES, MMGPU_PREF_BLOCK_QUERIES   block sizes of the device calls
+#ifndef MMGPU_RUN_H
+#define MMGPU_RUN_H
+
+#include <cstddef>
+#include <list>
+#include <string>
+
+#include "Debug.h"
+#include "mmgpu.h"
+
+class Alignment;
+class Prefiltering;
+class DBWriter;
+
+class MMGpuRun {
+public:
+    static bool enabled();
+    static bool hostBlockAligner();
+    static size_t envSize(const char *name, size_t fallback);
+    // the process-wide context; logs the library's message and EXITs if the device cannot be opened
+    static mmgpu_ctx *context();
+};
+
+class MMGpuAlignRun {
+public:
+    static bool usable(const Alignment &a);
+    static bool run(Alignment &a, const std::string &outDB, const std::string &outDBIndex, const size_t dbFrom, const size_t dbSize,
+                    bool merge);
+};
+
+struct MMGpuPrefilterStats {
+    double kmersPerPos;
+    size_t dbMatches, doubleMatches, querySeqLenSum, resSize, diagonalOverflow;
+};
+
+class MMGpuPrefilterRun {
+public:
+    static bool usable(Prefiltering &p);
+    // the `omp parallel` block of Prefiltering::runSplit (:820-918): writes every query's entry to tmpDbw, fills the
+    // statistics the caller prints
+    static bool run(Prefiltering &p, DBWriter &tmpDbw, size_t dbFrom, size_t dbSize, size_t queryFrom, size_t querySize,
+                    char *notEmpty, std::list<int> **reslens, size_t localThreads, Debug::Progress &progress,
+                    MMGpuPrefilterStats &stats);
+};
+
+#endif

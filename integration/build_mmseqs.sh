@@ -1,0 +1,64 @@
+#!/bin/bash
+# Builds two `mmseqs` binaries from the reference tree where it lies (never copied into this repository):
+#
+#   oracle/_ref/mmseqs_stock   the reference as shipped (CPU, AVX2), the Rust block-aligner crate replaced by the
+#                              generated do-nothing stubs of oracle/gen_block_stub.py (no rustc in this image; the
+#                              reference then takes its own Smith-Waterman fallback)
+#   oracle/_ref/mmseqs_mmgpu   the same tree + integration/mmseqs_mmgpu.patch (7 hunks, all under #ifdef HAVE_MMGPU),
+#                              integration/*.cpp compiled in, linked against mmseqs2_amd/lib/libmmgpu.so
+#
+# Both are checkers / demonstrators of the drop-in (tests/test_mmseqs_dropin.py diffs their result DBs); they are git-ignored
+# and travel to the GPU box with the snapshot.  Uses the reference's CMake files on a scratch copy.
+#
+#   REF=/root/reference  MMGPU_BUILD_DIR=/tmp/mmgpu_mmseqs_build  integration/build_mmseqs.sh [stock|mmgpu|all]
+set -euo pipefail
+HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+REPO="$(dirname "$HERE")"
+REF="${REF:-/root/reference}"
+WORK="${MMGPU_BUILD_DIR:-/tmp/mmgpu_mmseqs_build}"
+OUT="$REPO/oracle/_ref"
+WHAT="${1:-all}"
+JOBS="${JOBS:-$(nproc)}"
+[ -d "$REF/src" ] || { echo "build_mmseqs: no reference tree at $REF" >&2; exit 2; }
+mkdir -p "$WORK" "$OUT"
+
+prepare_tree() {   # $1 = destination
+    if [ ! -d "$1" ]; then
+        cp -r "$REF" "$1"
+        chmod -R u+w "$1"
+        python3 - "$1" <<'PY'
+import sys
+p = sys.argv[1] + '/CMakeLists.txt'
+s = open(p).read()
+start = s.index('set(ENV{CARGO_NET_OFFLINE} true)')
+end = s.index('if (USE_SYSTEM_ZSTD)')
+s = s[:start] + 'add_library(block_aligner_c STATIC ${CMAKE_CURRENT_SOURCE_DIR}/block_stub.c)\ninclude_directories(lib/block-aligner/c)\n' + s[end:]
+open(p, 'w').write(s)
+PY
+        python3 "$REPO/oracle/gen_block_stub.py" "$1" "$1/block_stub.c"
+        touch "$1/data/resources/K4000.crf"     # large blob absent from the checkout (.MISSING_LARGE_BLOBS)
+    fi
+}
+
+if [ "$WHAT" = stock ] || [ "$WHAT" = all ]; then
+    prepare_tree "$WORK/ref_stock"
+    cmake -S "$WORK/ref_stock" -B "$WORK/build_stock" -DHAVE_AVX2=1 -DCMAKE_BUILD_TYPE=Release -DHAVE_TESTS=0 -DHAVE_SHELLCHECK=0 > "$WORK/cmake_stock.log" 2>&1
+    make -C "$WORK/build_stock" -j"$JOBS" mmseqs > "$WORK/make_stock.log" 2>&1 || { tail -30 "$WORK/make_stock.log"; exit 1; }
+    cp "$WORK/build_stock/src/mmseqs" "$OUT/mmseqs_stock"
+    echo "built $OUT/mmseqs_stock"
+fi
+
+if [ "$WHAT" = mmgpu ] || [ "$WHAT" = all ]; then
+    LIB="${MMGPU_LIBRARY:-$REPO/mmseqs2_amd/lib/libmmgpu.so}"
+    [ -f "$LIB" ] || { echo "build_mmseqs: $LIB missing (run make -C mmseqs2_amd/csrc first)" >&2; exit 2; }
+    if [ ! -d "$WORK/ref_mmgpu" ]; then
+        prepare_tree "$WORK/ref_mmgpu"
+        patch -d "$WORK/ref_mmgpu" -p1 < "$HERE/mmseqs_mmgpu.patch"
+    fi
+    cmake -S "$WORK/ref_mmgpu" -B "$WORK/build_mmgpu" -DHAVE_AVX2=1 -DCMAKE_BUILD_TYPE=Release -DHAVE_TESTS=0 -DHAVE_SHELLCHECK=0 \
+        -DHAVE_MMGPU=1 -DMMGPU_DIR="$REPO" -DMMGPU_LIBRARY="$LIB" \
+        -DCMAKE_EXE_LINKER_FLAGS="-Wl,-rpath,'\$ORIGIN/../../mmseqs2_amd/lib' -Wl,-rpath-link,/opt/rocm/lib" > "$WORK/cmake_mmgpu.log" 2>&1
+    make -C "$WORK/build_mmgpu" -j"$JOBS" mmseqs > "$WORK/make_mmgpu.log" 2>&1 || { grep -B2 -A12 "error" "$WORK/make_mmgpu.log" | head -80; exit 1; }
+    cp "$WORK/build_mmgpu/src/mmseqs" "$OUT/mmseqs_mmgpu"
+    echo "built $OUT/mmseqs_mmgpu"
+fi

@@ -1,0 +1,320 @@
+// TEST INFRASTRUCTURE - NOT PART OF THE PRODUCT PATH.
+//
+// A CPU stand-in for the subset of the libmmgpu C-ABI (include/mmgpu.h) that the patched mmseqs binary calls
+// (integration/MMGpu*.cpp), built on the plain-C oracle (oracle/*.c).  It exists for ONE purpose: to run the HOST side of
+// the drop-in - the patched Alignment::run / Prefiltering::runSplit, their block logic, accept / reject replay, id <-> key
+// mapping, serialisation - in a container without a GPU and diff the result DBs against the stock CPU binary
+// (tests/test_mmseqs_dropin.py, `-m "not gpu"`).  The library is built as oracle/_build/emu/libmmgpu.so and is only ever
+// put in front of the real one by that test through LD_LIBRARY_PATH; nothing in mmseqs2_amd/, include/ or integration/
+// refers to it, and the GPU tests of the same script run against the real mmseqs2_amd/lib/libmmgpu.so.
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../include/mmgpu.h"
+#include "mm_oracle.h"
+
+struct mmgpu_ctx {
+    std::vector<uint8_t> tres;
+    std::vector<uint64_t> toff;
+    uint32_t n;
+    int alphabet;
+    // prefilter index
+    bool have_index;
+    int k, spaced, kalph;
+    std::vector<int16_t> s3, s2;
+    std::vector<uint32_t> i3, i2;
+    std::vector<uint64_t> offsets;
+    std::vector<uint32_t> ids;
+    std::vector<uint16_t> pos;
+    std::vector<int8_t> ungapped;
+    mmo_pf_gen gen;
+};
+
+struct mmgpu_sw_batch_t {
+    std::vector<int8_t> mat;
+    int alphabet, go, ge, mode;
+    std::vector<std::vector<uint8_t> > q;
+    std::vector<std::vector<int8_t> > cb;
+    std::vector<std::vector<uint32_t> > ids;
+    std::vector<int32_t> min_start;
+    std::vector<mmgpu_sw_hit> res;
+    std::vector<std::pair<uint32_t, uint32_t> > pair;   // (query, target id) of every result slot
+};
+
+struct mmgpu_pf_batch_t {
+    mmgpu_pf_params par;
+    std::vector<std::vector<uint8_t> > q;
+    std::vector<std::vector<float> > bias;
+    std::vector<uint32_t> identity;
+    std::vector<std::vector<mmo_pf_hit> > hits;
+    std::vector<mmo_pf_stats> stats;
+};
+
+static std::string g_err;
+static int fail(int code, const char *msg) {
+    g_err = msg;
+    return code;
+}
+
+extern "C" {
+
+int mmgpu_init(mmgpu_ctx **ctx, int) {
+    *ctx = new mmgpu_ctx();
+    (*ctx)->n = 0;
+    (*ctx)->have_index = false;
+    return 0;
+}
+void mmgpu_destroy(mmgpu_ctx *ctx) { delete ctx; }
+const char *mmgpu_last_error(void) { return g_err.c_str(); }
+int mmgpu_device_info(mmgpu_ctx *, int *cus, char *name, int cap) {
+    if (cus) *cus = 0;
+    if (name && cap > 0) snprintf(name, cap, "CPU emulation of the C-ABI (test only)");
+    return 0;
+}
+int mmgpu_synchronize(mmgpu_ctx *) { return 0; }
+
+int mmgpu_load_targets(mmgpu_ctx *c, const uint8_t *res, const uint64_t *off, uint32_t n, int alphabet) {
+    c->tres.assign(res, res + off[n]);
+    c->toff.assign(off, off + n + 1);
+    c->n = n;
+    c->alphabet = alphabet;
+    c->have_index = false;
+    return 0;
+}
+
+int mmgpu_sw_prepare(mmgpu_ctx *c, const mmgpu_sw_params *p, const mmgpu_sw_query *qs, uint32_t nq, int mode, mmgpu_sw_batch_t **out) {
+    if (c->n == 0) return fail(MMGPU_ERR_STATE, "no targets");
+    mmgpu_sw_batch_t *b = new mmgpu_sw_batch_t();
+    b->mat.assign(p->mat, p->mat + p->alphabet * p->alphabet);
+    b->alphabet = p->alphabet;
+    b->go = p->gap_open;
+    b->ge = p->gap_extend;
+    b->mode = mode;
+    for (uint32_t i = 0; i < nq; i++) {
+        b->q.push_back(std::vector<uint8_t>(qs[i].q, qs[i].q + qs[i].qlen));
+        if (qs[i].comp_bias) b->cb.push_back(std::vector<int8_t>(qs[i].comp_bias, qs[i].comp_bias + qs[i].qlen));
+        else b->cb.push_back(std::vector<int8_t>(qs[i].qlen, 0));
+        b->ids.push_back(std::vector<uint32_t>(qs[i].target_ids, qs[i].target_ids + qs[i].n_targets));
+        b->min_start.push_back(qs[i].min_start_score);
+        for (uint32_t k = 0; k < qs[i].n_targets; k++) {
+            if (qs[i].target_ids[k] >= c->n) {
+                delete b;
+                return fail(MMGPU_ERR_ARG, "target id out of range");
+            }
+            b->pair.push_back(std::make_pair(i, qs[i].target_ids[k]));
+        }
+    }
+    b->res.resize(b->pair.size());
+    *out = b;
+    return 0;
+}
+
+int mmgpu_sw_run(mmgpu_ctx *c, mmgpu_sw_batch_t *b) {
+#pragma omp parallel for schedule(dynamic, 64)
+    for (size_t p = 0; p < b->pair.size(); p++) {
+        const uint32_t qi = b->pair[p].first, id = b->pair[p].second;
+        const std::vector<uint8_t> &q = b->q[qi];
+        const uint8_t *t = c->tres.data() + c->toff[id];
+        const int tlen = (int)(c->toff[id + 1] - c->toff[id]);
+        mmo_sw_res r;
+        mmo_sw_score_end(q.data(), (int)q.size(), b->cb[qi].data(), t, tlen, b->mat.data(), b->alphabet, b->go, b->ge, &r);
+        mmgpu_sw_hit h;
+        h.score = r.score;
+        h.q_end = r.q_end;
+        h.t_end = r.t_end;
+        h.q_start = -1;
+        h.t_start = -1;
+        h.word = r.word;
+        if (r.t_end == -1) {
+            h.score = 0;
+            h.q_end = 0;
+        } else if (b->mode == MMGPU_SW_START && r.score >= b->min_start[qi]) {
+            mmo_sw_start(q.data(), (int)q.size(), b->cb[qi].data(), t, b->mat.data(), b->alphabet, b->go, b->ge, &r);
+            h.q_start = r.q_start;
+            h.t_start = r.t_start;
+        }
+        b->res[p] = h;
+    }
+    return 0;
+}
+
+int mmgpu_sw_fetch(mmgpu_ctx *, mmgpu_sw_batch_t *b, mmgpu_sw_hit *out) {
+    if (!b->res.empty()) memcpy(out, b->res.data(), b->res.size() * sizeof(mmgpu_sw_hit));
+    return 0;
+}
+void mmgpu_sw_free(mmgpu_ctx *, mmgpu_sw_batch_t *b) { delete b; }
+
+int mmgpu_sw_traceback(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const uint32_t *idx, uint32_t n, mmgpu_sw_bt *info, char *bt, size_t cap,
+                       size_t *used) {
+    size_t need = 0;
+    std::vector<size_t> off(n);
+    for (uint32_t i = 0; i < n; i++) {
+        const mmgpu_sw_hit &h = b->res[idx[i]];
+        off[i] = need;
+        if (h.q_start >= 0) need += (size_t)(h.q_end - h.q_start + 1) + (size_t)(h.t_end - h.t_start + 1) + 1;
+        else need += 1;
+    }
+    *used = need;
+    if (bt == NULL || cap < need) return fail(MMGPU_ERR_ARG, "bt buffer too small");
+#pragma omp parallel for schedule(dynamic, 16)
+    for (uint32_t i = 0; i < n; i++) {
+        const mmgpu_sw_hit &h = b->res[idx[i]];
+        info[i].bt_off = off[i];
+        info[i].bt_len = 0;
+        info[i].ident = 0;
+        info[i].reserved = 0;
+        if (h.q_start < 0) {
+            info[i].status = MMGPU_BT_NO_START;
+            continue;
+        }
+        const uint32_t qi = b->pair[idx[i]].first, id = b->pair[idx[i]].second;
+        const std::vector<uint8_t> &q = b->q[qi];
+        const uint8_t *t = c->tres.data() + c->toff[id];
+        const int ql = h.q_end - h.q_start + 1, tl = h.t_end - h.t_start + 1;
+        const int len = mmo_sw_banded_backtrace(t + h.t_start, q.data() + h.q_start, b->cb[qi].data() + h.q_start, tl, ql, h.score, b->go,
+                                                b->ge, b->mat.data(), b->alphabet, bt + off[i], ql + tl + 1);
+        if (len < 0) {
+            info[i].status = MMGPU_BT_FAILED;
+            continue;
+        }
+        int qp = h.q_start, tp = h.t_start;
+        uint32_t ident = 0;
+        for (int k = 0; k < len; k++) {
+            const char ch = bt[off[i] + k];
+            if (ch == 'M') {
+                ident += q[qp] == t[tp];
+                qp++;
+                tp++;
+            } else if (ch == 'I') qp++;
+            else tp++;
+        }
+        info[i].bt_len = (uint32_t)len;
+        info[i].ident = ident;
+        info[i].status = MMGPU_BT_OK;
+    }
+    return 0;
+}
+
+int mmgpu_pf_load_index(mmgpu_ctx *c, const mmgpu_pf_index *ix) {
+    if (c->n == 0) return fail(MMGPU_ERR_STATE, "no targets");
+    c->k = ix->kmer_size;
+    c->spaced = ix->spaced;
+    c->kalph = ix->alphabet - 1;
+    const size_t n3 = (size_t)c->kalph * c->kalph * c->kalph, n2 = (size_t)c->kalph * c->kalph;
+    c->s3.resize(n3 * n3);
+    c->i3.resize(n3 * n3);
+    for (size_t r = 0; r < n3; r++) {
+        memcpy(&c->s3[r * n3], ix->score3 + r * ix->row3, n3 * sizeof(int16_t));
+        memcpy(&c->i3[r * n3], ix->index3 + r * ix->row3, n3 * sizeof(uint32_t));
+    }
+    c->s2.clear();
+    c->i2.clear();
+    if (ix->score2) {
+        c->s2.resize(n2 * n2);
+        c->i2.resize(n2 * n2);
+        for (size_t r = 0; r < n2; r++) {
+            memcpy(&c->s2[r * n2], ix->score2 + r * ix->row2, n2 * sizeof(int16_t));
+            memcpy(&c->i2[r * n2], ix->index2 + r * ix->row2, n2 * sizeof(uint32_t));
+        }
+    }
+    size_t nk = 1;
+    for (int i = 0; i < c->k; i++) nk *= c->kalph;
+    c->offsets.assign(ix->offsets, ix->offsets + nk + 1);
+    c->ids.resize(ix->n_entries);
+    c->pos.resize(ix->n_entries);
+    if (ix->entries6) {
+        const uint8_t *e = (const uint8_t *)ix->entries6;
+        for (uint64_t i = 0; i < ix->n_entries; i++) {
+            memcpy(&c->ids[i], e + i * 6, 4);
+            memcpy(&c->pos[i], e + i * 6 + 4, 2);
+        }
+    } else {
+        memcpy(c->ids.data(), ix->entry_ids, ix->n_entries * 4);
+        memcpy(c->pos.data(), ix->entry_pos, ix->n_entries * 2);
+    }
+    c->ungapped.assign(ix->ungapped_mat, ix->ungapped_mat + ix->alphabet * ix->alphabet);
+    c->gen.k = c->k;
+    c->gen.kalph = c->kalph;
+    c->gen.s3 = c->s3.data();
+    c->gen.i3 = c->i3.data();
+    c->gen.s2 = c->s2.empty() ? NULL : c->s2.data();
+    c->gen.i2 = c->i2.empty() ? NULL : c->i2.data();
+    c->have_index = true;
+    return 0;
+}
+
+int mmgpu_pf_prepare(mmgpu_ctx *c, const mmgpu_pf_params *p, const mmgpu_pf_query *qs, uint32_t nq, mmgpu_pf_batch_t **out) {
+    if (!c->have_index) return fail(MMGPU_ERR_STATE, "no index");
+    mmgpu_pf_batch_t *b = new mmgpu_pf_batch_t();
+    b->par = *p;
+    for (uint32_t i = 0; i < nq; i++) {
+        b->q.push_back(std::vector<uint8_t>(qs[i].q, qs[i].q + qs[i].qlen));
+        if (qs[i].comp_bias) b->bias.push_back(std::vector<float>(qs[i].comp_bias, qs[i].comp_bias + qs[i].qlen));
+        else b->bias.push_back(std::vector<float>(qs[i].qlen, 0.0f));
+        b->identity.push_back(qs[i].identity_id);
+    }
+    b->hits.resize(nq);
+    b->stats.resize(nq);
+    *out = b;
+    return 0;
+}
+
+int mmgpu_pf_run(mmgpu_ctx *c, mmgpu_pf_batch_t *b) {
+    mmo_pf_params P;
+    memset(&P, 0, sizeof(P));
+    P.gen = &c->gen;
+    P.alphabet = c->alphabet;
+    P.spaced = c->spaced;
+    P.kmer_thr = b->par.kmer_thr;
+    P.offsets = c->offsets.data();
+    P.ids = c->ids.data();
+    P.pos = c->pos.data();
+    P.tdata = c->tres.data();
+    P.toff = c->toff.data();
+    P.n_targets = c->n;
+    P.ungapped_mat = c->ungapped.data();
+    P.bins = b->par.ref_bins;
+    P.max_hits = b->par.max_hits;
+    P.min_diag_score = b->par.min_diag_score;
+    const size_t cap = (size_t)std::min<uint64_t>(b->par.max_hits, c->n) + 1;
+    int bad = 0;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (size_t i = 0; i < b->q.size(); i++) {
+        b->hits[i].resize(cap);
+        uint64_t nh = 0;
+        if (mmo_pf_match_query(&P, b->q[i].data(), (int)b->q[i].size(), b->bias[i].data(), b->identity[i], b->hits[i].data(), cap, &nh,
+                               &b->stats[i], NULL) != 0)
+            bad = 1;
+        b->hits[i].resize(nh);
+    }
+    return bad ? fail(MMGPU_ERR_ARG, "mmo_pf_match_query failed") : 0;
+}
+
+int mmgpu_pf_fetch(mmgpu_ctx *, mmgpu_pf_batch_t *b, mmgpu_pf_hit *hits, uint32_t stride, uint32_t *counts, int32_t *status,
+                   mmgpu_pf_qstat *stats) {
+    for (size_t i = 0; i < b->q.size(); i++) {
+        counts[i] = (uint32_t)b->hits[i].size();
+        status[i] = MMGPU_PF_OK;
+        for (size_t k = 0; k < b->hits[i].size() && k < stride; k++) {
+            mmgpu_pf_hit &o = hits[i * (size_t)stride + k];
+            o.id = b->hits[i][k].id;
+            o.score = b->hits[i][k].score;
+            o.diagonal = b->hits[i][k].diagonal;
+            o.reserved = 0;
+        }
+        if (stats) {
+            stats[i].db_matches = b->stats[i].db_matches;
+            stats[i].kmer_list_len = b->stats[i].kmer_list_len;
+            stats[i].double_hits = (uint32_t)b->stats[i].after_keepmax;
+            stats[i].diag_thr = b->stats[i].diag_thr;
+        }
+    }
+    return 0;
+}
+void mmgpu_pf_free(mmgpu_ctx *, mmgpu_pf_batch_t *b) { delete b; }
+
+}  // extern "C"

@@ -127,7 +127,8 @@ extern "C" int mmref_matcher_check(const char *matrix_file, int gap_open, int ga
     for (uint32_t i = 0; i < nq; i++) {
         qseq[i] = new Sequence(maxLen, Parameters::DBTYPE_AMINO_ACIDS, &m, 0, false, comp_bias != 0);
         qseq[i]->mapSequence(i, i, std::make_pair((const unsigned char *)(qres + qoff[i]), (const unsigned int)(qoff[i + 1] - qoff[i])));
-        block[i].seq = qseq[i];
+        block[i].numSequence = qseq[i]->numSequence;
+        block[i].L = qseq[i]->L;
         for (uint32_t k = list_off[i]; k < list_off[i + 1]; k++) {
             MMGpuMatcher::Target t;
             t.id = list_ids[k];
