@@ -46,6 +46,10 @@ if [ "$WHAT" = stock ] || [ "$WHAT" = all ]; then
     make -C "$WORK/build_stock" -j"$JOBS" mmseqs > "$WORK/make_stock.log" 2>&1 || { tail -30 "$WORK/make_stock.log"; exit 1; }
     cp "$WORK/build_stock/src/mmseqs" "$OUT/mmseqs_stock"
     echo "built $OUT/mmseqs_stock"
+    # BASELINE.json configs[0]: the reference's example proteins as a sequence DB (createdb output, not the FASTA itself)
+    # for the drop-in tests on the GPU box, where /root/reference does not exist
+    rm -rf "$OUT/dropin_data" && mkdir -p "$OUT/dropin_data"
+    "$OUT/mmseqs_stock" createdb "$REF/examples/QUERY.fasta" "$OUT/dropin_data/examples" -v 1
 fi
 
 if [ "$WHAT" = mmgpu ] || [ "$WHAT" = all ]; then

@@ -77,6 +77,18 @@ def config2_align_only(n_queries=1000, n_targets=100000, planted_frac=0.10, seed
     return (qres, qoff), (tres, toff)
 
 
+def write_fasta(path, res, off, prefix="s"):
+    """numeric sequences -> FASTA with the letters of NUM2AA (input of `mmseqs createdb`)"""
+    lut = np.frombuffer(NUM2AA.encode(), np.uint8)
+    letters = lut[res]
+    off = off.astype(np.int64)
+    with open(path, "wb") as fh:
+        for i in range(len(off) - 1):
+            fh.write(b">%s%d\n" % (prefix.encode(), i))
+            fh.write(letters[off[i]:off[i + 1]].tobytes())
+            fh.write(b"\n")
+
+
 def split(res, off):
     return [res[int(off[i]):int(off[i + 1])] for i in range(len(off) - 1)]
 

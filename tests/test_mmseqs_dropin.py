@@ -1,0 +1,174 @@
+"""The drop-in, exercised as a drop-in (b): `mmseqs prefilter` / `align` / `search` of a
+reference build patched with integration/mmseqs_mmgpu.patch and linked to libmmgpu.so, against the STOCK reference binary
+on the same inputs; the result DBs must agree entry by entry, byte for byte.
+
+Both binaries are built by integration/build_mmseqs.sh from the reference tree (oracle/_ref/mmseqs_stock,
+oracle/_ref/mmseqs_mmgpu; the Rust block-aligner is stubbed in both, so both take the reference's Smith-Waterman
+fallback for int16-range hits - SURVEY.md section 8c) and travel to the GPU box with the snapshot, together with the createdb
+output of the reference's example proteins (oracle/_ref/dropin_data/examples = BASELINE.json configs[0]).
+
+ * `-m gpu` tests: the patched binary runs on the device (the real mmseqs2_amd/lib/libmmgpu.so).
+ * `-m "not gpu"` tests: the same binary with the C-ABI served by the CPU stand-in oracle/_build/emu/libmmgpu.so
+   (LD_PRELOAD, test infrastructure) - this pins the HOST side of the drop-in (block logic, accept / reject replay,
+   key mapping, masked index hand-over, serialisation) where no GPU exists.
+"""
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from mmseqs2_amd import dbio
+from mmseqs2_amd import workloads as wl
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+STOCK = os.path.join(ROOT, "oracle", "_ref", "mmseqs_stock")
+MMGPU = os.path.join(ROOT, "oracle", "_ref", "mmseqs_mmgpu")
+EXAMPLES = os.path.join(ROOT, "oracle", "_ref", "dropin_data", "examples")
+EMU = os.path.join(ROOT, "oracle", "_build", "emu", "libmmgpu.so")
+
+pytestmark = pytest.mark.skipif(not (os.path.exists(STOCK) and os.path.exists(MMGPU) and os.path.exists(EXAMPLES)),
+                                reason="needs oracle/_ref/mmseqs_stock, mmseqs_mmgpu, dropin_data (integration/build_mmseqs.sh)")
+
+THREADS = str(min(os.cpu_count() or 1, 32))
+
+ALIGN_CASES = [
+    ["--alignment-mode", "1"],
+    ["--alignment-mode", "2"],
+    ["--alignment-mode", "3"],
+    ["-a"],
+    ["--alignment-mode", "3", "--max-rejected", "5", "--max-accept", "3"],
+    ["-a", "-e", "10", "-c", "0.5", "--cov-mode", "2"],
+    ["--alignment-mode", "2", "--min-seq-id", "0.5", "--comp-bias-corr", "0"],
+    ["-a", "--add-self-matches", "1"],
+]
+
+
+def run(binary, args, cwd, emulate=False, extra_env=None):
+    env = dict(os.environ)
+    env.pop("LD_PRELOAD", None)
+    if emulate:
+        env["LD_PRELOAD"] = EMU
+    if extra_env:
+        env.update(extra_env)
+    r = subprocess.run([binary] + args, cwd=cwd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, "%s %s failed:\n%s" % (os.path.basename(binary), " ".join(args), r.stdout[-3000:])
+    return r.stdout
+
+
+def same(a, b):
+    n, bad, msgs = dbio.diff_dbs(a, b)
+    assert bad == 0, "%d of %d entries differ: %s" % (bad, n, "; ".join(msgs))
+    return n
+
+
+def copy_db(src, dst):
+    d = os.path.dirname(src)
+    base = os.path.basename(src)
+    for f in os.listdir(d):
+        if f == base or f.startswith(base + ".") or f.startswith(base + "_h"):
+            shutil.copy(os.path.join(d, f), os.path.join(os.path.dirname(dst), os.path.basename(dst) + f[len(base):]))
+
+
+def examples_pipeline(tmp, emulate):
+    """QUERY.fasta vs itself with the defaults of `mmseqs search` (-s 5.7, --mask 1, --max-seqs 300, comp. bias on)"""
+    w = str(tmp)
+    copy_db(EXAMPLES, os.path.join(w, "q"))
+    run(STOCK, ["prefilter", "q", "q", "pref_s", "-s", "5.7", "--threads", THREADS, "-v", "2"], w)
+    log = run(MMGPU, ["prefilter", "q", "q", "pref_g", "-s", "5.7", "--threads", THREADS, "-v", "3"], w, emulate)
+    assert "MMGPU: device" in log and "using the CPU path" not in log, log[-2000:]
+    assert same(os.path.join(w, "pref_s"), os.path.join(w, "pref_g")) == 500
+    for i, case in enumerate(ALIGN_CASES):
+        run(STOCK, ["align", "q", "q", "pref_s", "aln_s%d" % i] + case + ["--threads", THREADS, "-v", "2"], w)
+        log = run(MMGPU, ["align", "q", "q", "pref_s", "aln_g%d" % i] + case + ["--threads", THREADS, "-v", "3"], w, emulate)
+        assert "MMGPU: device" in log and "using the CPU path" not in log, log[-2000:]
+        assert same(os.path.join(w, "aln_s%d" % i), os.path.join(w, "aln_g%d" % i)) == 500, case
+
+
+def test_examples_prefilter_align_host_side_emulated(tmp_path):
+    """host side of both seams on real proteins, device replaced by the CPU stand-in"""
+    if not os.path.exists(EMU):
+        pytest.skip("oracle/_build/emu/libmmgpu.so not built (make -C oracle emu)")
+    examples_pipeline(tmp_path, emulate=True)
+
+
+def test_disabled_binary_is_the_stock_path(tmp_path):
+    """MMGPU_DISABLE=1: the patched binary must take the reference's own loops (and needs no device)"""
+    w = str(tmp_path)
+    copy_db(EXAMPLES, os.path.join(w, "q"))
+    run(STOCK, ["prefilter", "q", "q", "pref_s", "-s", "4", "--threads", THREADS, "-v", "2"], w)
+    log = run(MMGPU, ["prefilter", "q", "q", "pref_g", "-s", "4", "--threads", THREADS, "-v", "3"], w, extra_env={"MMGPU_DISABLE": "1"})
+    assert "MMGPU: device" not in log
+    same(os.path.join(w, "pref_s"), os.path.join(w, "pref_g"))
+
+
+@pytest.mark.gpu
+def test_examples_prefilter_align_on_device(tmp_path):
+    """BASELINE.json configs[0] inputs through the device: prefilter DB and 8 align configurations identical to stock"""
+    examples_pipeline(tmp_path, emulate=False)
+
+
+@pytest.mark.gpu
+def test_examples_search_workflow_on_device(tmp_path):
+    """`mmseqs search` (blastp.sh: prefilter + align as sub-commands of the same binary) unchanged on the command line"""
+    w = str(tmp_path)
+    copy_db(EXAMPLES, os.path.join(w, "q"))
+    for s in ["1", "5.7"]:
+        run(STOCK, ["search", "q", "q", "res_s" + s, "tmp_s" + s, "-s", s, "-a", "--threads", THREADS, "-v", "2"], w)
+        log = run(MMGPU, ["search", "q", "q", "res_g" + s, "tmp_g" + s, "-s", s, "-a", "--threads", THREADS, "-v", "3"], w)
+        assert log.count("MMGPU: device") >= 2, log[-3000:]
+        assert same(os.path.join(w, "res_s" + s), os.path.join(w, "res_g" + s)) == 500
+
+
+def _config3_tenth(w):
+    (qres, qoff), (tres, toff), _, _ = wl.config3_prefilter(n_families=2000, members=50, n_queries=1000, seed=10)
+    wl.write_fasta(os.path.join(w, "q.fasta"), qres, qoff, "q")
+    wl.write_fasta(os.path.join(w, "t.fasta"), tres, toff, "t")
+    run(STOCK, ["createdb", "q.fasta", "q", "-v", "1"], w)
+    run(STOCK, ["createdb", "t.fasta", "t", "-v", "1"], w)
+
+
+@pytest.mark.gpu
+def test_config3_tenth_scale_on_device(tmp_path):
+    """BASELINE.json configs[2] at 1/10 scale (1000 queries vs 100 000 family-structured targets, -s 5.7, default masking):
+    prefilter DB, alignment DBs (modes 2 and 3 with backtraces) and the search result identical to the stock binary"""
+    w = str(tmp_path)
+    _config3_tenth(w)
+    run(STOCK, ["prefilter", "q", "t", "pref_s", "-s", "5.7", "--threads", THREADS, "-v", "2"], w)
+    log = run(MMGPU, ["prefilter", "q", "t", "pref_g", "-s", "5.7", "--threads", THREADS, "-v", "3"], w)
+    assert "MMGPU: device" in log and "using the CPU path" not in log, log[-2000:]
+    assert same(os.path.join(w, "pref_s"), os.path.join(w, "pref_g")) == 1000
+    for i, case in enumerate([["--alignment-mode", "2"], ["-a"]]):
+        run(STOCK, ["align", "q", "t", "pref_s", "aln_s%d" % i] + case + ["--threads", THREADS, "-v", "2"], w)
+        log = run(MMGPU, ["align", "q", "t", "pref_s", "aln_g%d" % i] + case + ["--threads", THREADS, "-v", "3"], w)
+        assert "MMGPU: device" in log and "using the CPU path" not in log, log[-2000:]
+        assert same(os.path.join(w, "aln_s%d" % i), os.path.join(w, "aln_g%d" % i)) == 1000
+
+
+def test_small_synthetic_host_side_emulated(tmp_path):
+    """family-structured synthetic set small enough for the CPU stand-in: masked index hand-over, self hits across two
+    different DBs, lists cut by --max-seqs"""
+    if not os.path.exists(EMU):
+        pytest.skip("oracle/_build/emu/libmmgpu.so not built (make -C oracle emu)")
+    w = str(tmp_path)
+    (qres, qoff), (tres, toff), _, _ = wl.config3_prefilter(n_families=60, members=20, n_queries=40, seed=5)
+    # low-complexity stretches so that tantan masks something
+    rng = np.random.default_rng(3)
+    tl = wl.split(tres, toff)
+    for i in rng.choice(len(tl), 200, replace=False):
+        p = int(rng.integers(0, max(1, len(tl[i]) - 40)))
+        tl[i][p:p + 40] = np.tile(rng.choice(20, 2), 20)[:len(tl[i][p:p + 40])]
+    tres, toff = wl.seqs_from_list(tl)
+    wl.write_fasta(os.path.join(w, "q.fasta"), qres, qoff, "q")
+    wl.write_fasta(os.path.join(w, "t.fasta"), tres, toff, "t")
+    run(STOCK, ["createdb", "q.fasta", "q", "-v", "1"], w)
+    run(STOCK, ["createdb", "t.fasta", "t", "-v", "1"], w)
+    for k, extra in enumerate([[], ["--max-seqs", "7"], ["--mask", "0", "--comp-bias-corr", "0", "--min-ungapped-score", "30"]]):
+        run(STOCK, ["prefilter", "q", "t", "pref_s%d" % k, "-s", "5.7", "--threads", THREADS, "-v", "2"] + extra, w)
+        log = run(MMGPU, ["prefilter", "q", "t", "pref_g%d" % k, "-s", "5.7", "--threads", THREADS, "-v", "3"] + extra, w, True)
+        assert "MMGPU: device" in log and "using the CPU path" not in log, log[-2000:]
+        same(os.path.join(w, "pref_s%d" % k), os.path.join(w, "pref_g%d" % k))
+    run(STOCK, ["align", "q", "t", "pref_s0", "aln_s", "-a", "--threads", THREADS, "-v", "2"], w)
+    run(MMGPU, ["align", "q", "t", "pref_s0", "aln_g", "-a", "--threads", THREADS, "-v", "3"], w, True)
+    same(os.path.join(w, "aln_s"), os.path.join(w, "aln_g"))
