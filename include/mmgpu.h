@@ -68,6 +68,8 @@ int mmgpu_host_round_comp_bias(const float *bias, uint32_t len, int8_t *out);
  * the reference's dbFrom convention, Prefiltering.cpp:879-881). */
 int mmgpu_load_targets(mmgpu_ctx *ctx, const uint8_t *residues, const uint64_t *offsets, uint32_t n_targets,
                        int alphabet);
+/* Loading a database drops a resident prefilter index (it indexes the previous database): call mmgpu_pf_load_index /
+ * mmgpu_pf_build_index again, and free prefilter batches prepared against the old index first. */
 
 /* ---- gapped alignment (behind Alignment::run) -------------------------------------------------- */
 typedef struct {
@@ -121,7 +123,8 @@ int mmgpu_sw_prepare(mmgpu_ctx *ctx, const mmgpu_sw_params *params, const mmgpu_
 /* Fused hand-over: the alignment batch for the hit lists of a prefilter batch that has been run,
  * without the lists leaving the device.  queries[i] supplies q / qlen / comp_bias / min_start_score (target_ids and
  * n_targets are ignored); the result array has n_queries * min(max_hits, dbSize) slots, slot q * stride + k = hit k of
- * query q's list (zeroed beyond the list's length).  mmgpu_pf_hit is declared further down. */
+ * query q's list (zeroed beyond the list's length).  mmgpu_pf_hit is declared further down.  The alignment batch copies what
+ * it needs (list lengths, target id of every slot) during this call: afterwards the prefilter batch may be re-run or freed. */
 struct mmgpu_pf_batch_t;
 int mmgpu_sw_prepare_from_pf(mmgpu_ctx *ctx, const mmgpu_sw_params *params, const mmgpu_sw_query *queries,
                              uint32_t n_queries, int mode, struct mmgpu_pf_batch_t *pf_batch, mmgpu_sw_batch_t **batch);

@@ -83,6 +83,8 @@ extern "C" int mmgpu_load_targets(mmgpu_ctx *c, const uint8_t *residues, const u
     if (!c || !residues || !offsets) return fail(MMGPU_ERR_ARG, "mmgpu_load_targets: NULL argument");
     if (alphabet < 2 || alphabet > 254) return fail(MMGPU_ERR_ARG, "mmgpu_load_targets: bad alphabet size");
     HIP_TRY(hipSetDevice(c->device));
+    // a resident prefilter index belongs to the database it was built / loaded for: it goes with it
+    mmgpu::pf_index_free(c);
     free_db(c->db);
     std::vector<uint32_t> off4(std::max<uint32_t>(n, 1)), len(std::max<uint32_t>(n, 1));
     uint64_t cur4 = 0;
@@ -107,12 +109,14 @@ extern "C" int mmgpu_load_targets(mmgpu_ctx *c, const uint8_t *residues, const u
         memcpy(packed.data() + (size_t)off4[i] * 4, residues + offsets[i], len[i]);
     }
     DeviceDb db;
-    HIP_TRY(hipMalloc((void **)&db.res, bytes));
-    HIP_TRY(hipMalloc((void **)&db.off4, off4.size() * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc((void **)&db.len, len.size() * sizeof(uint32_t)));
-    HIP_TRY(hipMemcpy(db.res, packed.data(), bytes, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(db.off4, off4.data(), off4.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(db.len, len.data(), len.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+#define DB_TRY(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { free_db(db); return fail(MMGPU_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__)); } } while (0)
+    DB_TRY(hipMalloc((void **)&db.res, bytes));
+    DB_TRY(hipMalloc((void **)&db.off4, off4.size() * sizeof(uint32_t)));
+    DB_TRY(hipMalloc((void **)&db.len, len.size() * sizeof(uint32_t)));
+    DB_TRY(hipMemcpy(db.res, packed.data(), bytes, hipMemcpyHostToDevice));
+    DB_TRY(hipMemcpy(db.off4, off4.data(), off4.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    DB_TRY(hipMemcpy(db.len, len.data(), len.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+#undef DB_TRY
     db.n = n;
     db.max_len = max_len;
     db.total_residues = total;
@@ -179,11 +183,12 @@ struct mmgpu_sw_batch_t {
     size_t group_lds[SW_GROUPS] = {0, 0, 0};   // largest profile of any shape present in the group
     DevBuf d_jobs;
     DevBuf d_scratch;             // multi-tile jobs: [scratch slot][4 waves][4 groups][2 buffers][scratch_cols] x uint2
+    DevBuf d_scratch_busy;        // one flag per slot of the pool (sw_kernel claims / releases)
+    uint32_t scratch_slots = 0;
+    DevBuf d_pf_counts, d_slot_target;   // from_pf: list lengths and slot -> target id, copied out of the prefilter batch
     DevBuf d_qres, d_qcb, d_qoff, d_qbias, d_qminstart, d_hit_target, d_hit_out, d_out, d_mat;
     // fused hand-over from a prefilter batch (mmgpu_sw_prepare_from_pf): lists, counts and statistics live on the device
     bool from_pf = false;
-    const mmgpu_pf_hit *pf_hits = nullptr;
-    const uint32_t *pf_counts = nullptr;
     uint32_t pf_stride = 0, slot_stride = 0;
     DevBuf d_stats;                        // [2] unsigned long long: cells, pairs
     std::vector<uint32_t> h_out_target;   // target id of every result slot (kept for mmgpu_sw_traceback, mode >= START)
@@ -243,7 +248,8 @@ static int sw_prepare_impl(mmgpu_ctx *c, const mmgpu_sw_params *par, const mmgpu
     b->gap_extend = par->gap_extend;
     b->n_queries = nq;
     for (DevBuf *d : {&b->d_qres, &b->d_qcb, &b->d_qoff, &b->d_qbias, &b->d_qminstart, &b->d_hit_target, &b->d_hit_out, &b->d_out,
-                      &b->d_mat, &b->d_stats, &b->d_bt_scratch, &b->d_bt_jobs, &b->d_bt_info, &b->d_bt_str})
+                      &b->d_mat, &b->d_stats, &b->d_bt_scratch, &b->d_bt_jobs, &b->d_bt_info, &b->d_bt_str, &b->d_scratch_busy,
+                      &b->d_pf_counts, &b->d_slot_target})
         d->bind(c->cache);
 
     std::vector<uint8_t> qres;
@@ -366,8 +372,6 @@ static int sw_prepare_impl(mmgpu_ctx *c, const mmgpu_sw_params *par, const mmgpu
     b->pairs = total_hits;
     b->h_qoff = qoff;
     b->from_pf = pf != nullptr;
-    b->pf_hits = pf_hits;
-    b->pf_counts = pf_counts;
     b->pf_stride = pf_stride;
     b->slot_stride = pf_stride;
 
@@ -384,6 +388,8 @@ static int sw_prepare_impl(mmgpu_ctx *c, const mmgpu_sw_params *par, const mmgpu
         B_TRY(b->d_hit_out.alloc(std::max<size_t>((size_t)total_hits, 1) * 4));
         B_TRY(b->d_stats.alloc(24));
         B_TRY(hipMemsetAsync(b->d_stats.p, 0, 24, s));
+        B_TRY(b->d_pf_counts.alloc(std::max<size_t>(nq, 1) * 4));
+        B_TRY(b->d_slot_target.alloc(std::max<size_t>((size_t)total_hits, 1) * 4));
     } else {
         B_TRY(upload(b->d_hit_target, hit_target, s));
         B_TRY(upload(b->d_hit_out, hit_out, s));
@@ -393,7 +399,6 @@ static int sw_prepare_impl(mmgpu_ctx *c, const mmgpu_sw_params *par, const mmgpu
     std::vector<SwJob> sorted(jobs.size());   // uploaded asynchronously: must live until the stream is drained below
     {
         // longest job first: the dispatcher hands out workgroups in blockIdx order, so the tail is the shortest jobs
-        if (n_multi >= (1u << 24)) { delete b; return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_sw_prepare: more than 2^24 multi-tile jobs in one batch"); }
         std::vector<uint32_t> ord(jobs.size());
         std::iota(ord.begin(), ord.end(), 0u);
         std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t bb) {
@@ -409,10 +414,20 @@ static int sw_prepare_impl(mmgpu_ctx *c, const mmgpu_sw_params *par, const mmgpu
         b->n_multi_jobs = n_multi;
         B_TRY(upload(b->d_jobs, sorted, s));
     }
-    if (any_multi && !pf) {
-        b->scratch_cols = max_tlen + 16;
-        B_TRY(b->d_scratch.alloc((size_t)n_multi * 4 * 4 * 2 * (size_t)b->scratch_cols * sizeof(uint2)));
-    }
+    // column scratch of the multi-tile jobs: a pool with one slot per workgroup that can be resident at once (not one
+    // per job: a batch of long queries against one very long target would ask for 100+ GB), sized by the longest
+    // target any list holds
+    auto alloc_scratch = [&](uint32_t longest) -> hipError_t {
+        b->scratch_cols = longest + 16;
+        b->scratch_slots = std::min<uint32_t>(std::max<uint32_t>(n_multi, 1),
+                                              sw_multi_resident_blocks(b->group_lds[SW_GROUPS - 1], mode == MMGPU_SW_START, c->compute_units));
+        hipError_t e = b->d_scratch.alloc((size_t)b->scratch_slots * 4 * 4 * 2 * (size_t)b->scratch_cols * sizeof(uint2));
+        if (e != hipSuccess) return e;
+        e = b->d_scratch_busy.alloc((size_t)b->scratch_slots * 4);
+        if (e != hipSuccess) return e;
+        return hipMemsetAsync(b->d_scratch_busy.p, 0, (size_t)b->scratch_slots * 4, s);
+    };
+    if (any_multi && !pf) B_TRY(alloc_scratch(max_tlen));
     if (pf) {
         B_TRY(hipMemsetAsync(b->d_out.p, 0, std::max<size_t>((size_t)total_hits, 1) * sizeof(mmgpu_sw_hit), s));
         SwFromPfArgs F;
@@ -426,6 +441,8 @@ static int sw_prepare_impl(mmgpu_ctx *c, const mmgpu_sw_params *par, const mmgpu
         F.hit_out = b->d_hit_out.as<uint32_t>();
         F.cells = b->d_stats.as<unsigned long long>();
         F.pairs = b->d_stats.as<unsigned long long>() + 1;
+        F.count_copy = b->d_pf_counts.as<uint32_t>();
+        F.slot_target = b->d_slot_target.as<uint32_t>();
         B_TRY(launch_sw_from_pf(F, nq, s));
     }
     B_TRY(hipStreamSynchronize(s));   // the host vectors above die with this scope
@@ -434,9 +451,9 @@ static int sw_prepare_impl(mmgpu_ctx *c, const mmgpu_sw_params *par, const mmgpu
         B_TRY(hipMemcpy(st, b->d_stats.p, 24, hipMemcpyDeviceToHost));
         b->cells = st[0];
         b->valid_pairs = st[1];
-        if (any_multi) {   // column scratch of the multi-tile classes, sized by the longest target any list holds
-            b->scratch_cols = (uint32_t)st[2] + 16;
-            B_TRY(b->d_scratch.alloc((size_t)n_multi * 4 * 4 * 2 * (size_t)b->scratch_cols * sizeof(uint2)));
+        if (any_multi) {
+            B_TRY(alloc_scratch((uint32_t)st[2]));
+            B_TRY(hipStreamSynchronize(s));
         }
     }
 #undef B_TRY
@@ -503,10 +520,12 @@ extern "C" int mmgpu_sw_run(mmgpu_ctx *c, mmgpu_sw_batch_t *b) {
             L.alphabet = b->alphabet;
             L.gap_open = b->gap_open;
             L.gap_extend = b->gap_extend;
-            L.q_hit_count = b->from_pf ? b->pf_counts : nullptr;
+            L.q_hit_count = b->from_pf ? b->d_pf_counts.as<uint32_t>() : nullptr;
             L.hit_stride = b->slot_stride;
             L.scratch = b->d_scratch.as<uint2>();
             L.scratch_cols = b->scratch_cols;
+            L.scratch_busy = b->d_scratch_busy.as<uint32_t>();
+            L.scratch_slots = std::max<uint32_t>(b->scratch_slots, 1);
             HIP_TRY(launch_sw(L, g, b->group_lds[g], b->mode == MMGPU_SW_START, st));
             if (getenv("MMGPU_TRACE")) {   // debugging aid: run the groups one at a time and say which one is in flight
                 fprintf(stderr, "[sw_run] group %d jobs %u lds %zu both %d from_pf %d scratch_cols %u\n", g, L.n_jobs, b->group_lds[g], (int)(b->mode == MMGPU_SW_START), (int)b->from_pf, b->scratch_cols);
@@ -609,11 +628,10 @@ extern "C" int mmgpu_sw_traceback(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const uint3
     std::vector<mmgpu_sw_hit> res((size_t)b->pairs);
     if (b->pairs) HIP_TRY(hipMemcpyAsync(res.data(), b->d_out.p, (size_t)b->pairs * sizeof(mmgpu_sw_hit), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    std::vector<mmgpu_pf_hit> pf_host;
-    if (b->from_pf) {   // the lists never left the device: fetch the target ids now
+    std::vector<uint32_t> pf_host;
+    if (b->from_pf) {   // the lists never left the device: fetch the target id of every slot (the batch's own copy)
         pf_host.resize((size_t)b->pairs);
-        if (b->pairs) HIP_TRY(hipMemcpy2D(pf_host.data(), (size_t)b->slot_stride * sizeof(mmgpu_pf_hit), b->pf_hits, (size_t)b->pf_stride * sizeof(mmgpu_pf_hit),
-                                          (size_t)b->slot_stride * sizeof(mmgpu_pf_hit), b->n_queries, hipMemcpyDeviceToHost));
+        if (b->pairs) HIP_TRY(hipMemcpy(pf_host.data(), b->d_slot_target.p, (size_t)b->pairs * sizeof(uint32_t), hipMemcpyDeviceToHost));
     }
     std::vector<BtJob> jobs;
     jobs.reserve(n);
@@ -634,7 +652,7 @@ extern "C" int mmgpu_sw_traceback(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const uint3
         BtJob j;
         j.slot = k;
         j.query = (uint32_t)(std::upper_bound(b->h_qout_off.begin(), b->h_qout_off.end(), p) - b->h_qout_off.begin() - 1);
-        j.target = b->from_pf ? pf_host[p].id : b->h_out_target[p];
+        j.target = b->from_pf ? pf_host[p] : b->h_out_target[p];
         j.q_start = h.q_start; j.q_end = h.q_end; j.t_start = h.t_start; j.t_end = h.t_end; j.score = h.score;
         j.bt_off = off;
         off += (uint64_t)(h.q_end - h.q_start + 1) + (uint64_t)(h.t_end - h.t_start + 1) + 1;

@@ -60,9 +60,13 @@ struct SwLaunch {
     const int8_t *mat;        // alphabet*alphabet
     int alphabet;
     int gap_open, gap_extend;
-    // multi-tile scratch (H/F boundary rows), [scratch slot][4 waves][4 groups][2][scratch_cols] x uint2
+    // multi-tile scratch (H/F boundary rows), [scratch slot][4 waves][4 groups][2][scratch_cols] x uint2.  Slots are a
+    // pool sized by the workgroups that can be resident at once, not by the jobs of the batch: a workgroup claims a free
+    // slot when it starts (scratch_busy, one flag per slot) and releases it when it ends.
     uint2 *scratch;
     uint32_t scratch_cols;
+    uint32_t *scratch_busy;
+    uint32_t scratch_slots;
     // fused hand-over from a prefilter batch: hits of query q live in slots [q * hit_stride, + q_hit_count[q])
     const uint32_t *q_hit_count;   // null for caller-supplied lists
     uint32_t hit_stride;
@@ -79,9 +83,14 @@ struct SwFromPfArgs {
     const uint32_t *t_len;
     uint32_t *hit_target, *hit_out;
     unsigned long long *cells, *pairs;
+    // copies owned by the alignment batch, so that it does not depend on the prefilter batch after this kernel:
+    uint32_t *count_copy;          // [nq] list lengths (clipped to stride)
+    uint32_t *slot_target;         // [nq * stride] target id of every result slot (list order), 0 beyond the list
 };
 
 hipError_t launch_sw_from_pf(const SwFromPfArgs &A, uint32_t nq, hipStream_t stream);
+// workgroups of the multi-tile kernel group that can be resident on the device at once (sizes the scratch pool)
+uint32_t sw_multi_resident_blocks(size_t lds_bytes, bool both_passes, int compute_units);
 
 // rows_per_lane in {8,16,24,32}: a 16-lane group covers 16*rows_per_lane query rows per tile.
 // reverse = false: forward score/end scan; true: start-position scan over the reversed prefixes.

@@ -435,6 +435,20 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(SW_M
         job.hit_end = job.hit_end < lim ? job.hit_end : lim;
         if (job.hit_end <= job.hit_begin) return;
     }
+    // multi-tile jobs (group 2 only): claim a slot of the column-scratch pool.  The pool has at least as many slots as
+    // workgroups of this kernel can be resident at once, so the search always ends; a slot is only ever read after its
+    // owner wrote it (tile t writes what tile t + 1 reads), so stale content is harmless.
+    __shared__ uint32_t scratch_slot;
+    const bool claims = G == 2 && (job.shape & 0xFFu) >= 16u;
+    if (claims) {
+        if (threadIdx.x == 0) {
+            uint32_t s = blockIdx.x % L.scratch_slots;
+            while (atomicCAS(&L.scratch_busy[s], 0u, 1u) != 0u) s = s + 1 == L.scratch_slots ? 0u : s + 1;
+            scratch_slot = s;
+        }
+        __syncthreads();
+        job.shape = (job.shape & 0xFFu) | (scratch_slot << 8);
+    }
 #define MMGPU_SW_SINGLE(R) case (R) / 2 - 1: sw_passes<R, false, BOTH>(L, job); break;
 #define MMGPU_SW_MULTI(R) case 16 + (R) / 2 - 1: sw_passes<R, true, BOTH>(L, job); break;
     if constexpr (G == 0) {
@@ -457,6 +471,13 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(SW_M
     }
 #undef MMGPU_SW_SINGLE
 #undef MMGPU_SW_MULTI
+    if (claims) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __threadfence();
+            atomicExch(&L.scratch_busy[scratch_slot], 0u);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -503,11 +524,14 @@ __global__ __launch_bounds__(256) void sw_from_pf_kernel(SwFromPfArgs A) {
         const uint32_t k = key[r] & 0xFFFFu;
         A.hit_target[base + r] = hits[k].id;
         A.hit_out[base + r] = base + k;
+        A.slot_target[base + r] = hits[r].id;
     }
     for (uint32_t r = n + threadIdx.x; r < A.stride; r += 256) {   // unused slots: defined contents
         A.hit_target[base + r] = 0;
         A.hit_out[base + r] = base + r;
+        A.slot_target[base + r] = 0;
     }
+    if (threadIdx.x == 0) A.count_copy[q] = n;
     // statistics (cells = forward DP cells, Alignment.cpp:380,530 convention)
     for (int d = 1; d < 64; d <<= 1) cells += __shfl_xor(cells, d);
     if ((threadIdx.x & 63u) == 0 && cells) atomicAdd(A.cells, cells);
@@ -523,6 +547,17 @@ hipError_t launch_sw_from_pf(const SwFromPfArgs &A, uint32_t nq, hipStream_t str
     if (nq == 0) return hipSuccess;
     hipLaunchKernelGGL(sw_from_pf_kernel, dim3(nq), dim3(256), 0, stream, A);
     return hipGetLastError();
+}
+
+uint32_t sw_multi_resident_blocks(size_t lds_bytes, bool both_passes, int compute_units) {
+    int per_cu = 0;
+    const size_t lds = lds_bytes + SW_LDS_HEADER;
+    hipError_t e = both_passes ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sw_kernel<2, true>, WAVES * 64, lds)
+                               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sw_kernel<2, false>, WAVES * 64, lds);
+    // a CU holds at most 32 wavefronts = 8 workgroups of 4; one more than the occupancy query says, as a margin
+    if (e != hipSuccess || per_cu < 1) per_cu = 8;
+    per_cu = per_cu + 1 > 8 ? 8 : per_cu + 1;
+    return (uint32_t)per_cu * (uint32_t)(compute_units > 0 ? compute_units : 256);
 }
 
 size_t sw_lds_bytes(int rows_per_lane, int alphabet) {

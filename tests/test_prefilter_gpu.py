@@ -295,8 +295,14 @@ def test_fused_prefilter_to_align_handover(gpu, matrices, oracle):
     swq = [dict(q=qd["q"], comp_bias=capi.host_comp_bias(sub16, matrices["blosum62_pback"], qd["q"], lib=gpu.L)[1],
                 min_start_score=40) for qd in qs]
     fused = gpu.sw_prepare_from_pf(mat, 11, 1, swq, pfb, mode=1)
+    # the alignment batch owns copies of what it needs (list lengths, slot -> target): the prefilter batch may be
+    # re-run with other queries or freed before the alignment runs (it used to keep raw pointers into it)
+    max_hits = pfb.max_hits
+    pfb.free()
+    other = gpu.pf_prepare(qs[::-1], thr, max_hits=300, ref_bins=2)
+    other.run()
     fused.run()
-    fr = fused.fetch().reshape(len(qs), pfb.max_hits)
+    fr = fused.fetch().reshape(len(qs), max_hits)
     assert fused.pairs == int(counts.sum())
     host_q = [dict(q=x["q"], comp_bias=x["comp_bias"], targets=hits[i]["id"][:counts[i]].copy(), min_start_score=40)
               for i, x in enumerate(swq)]
@@ -313,12 +319,12 @@ def test_fused_prefilter_to_align_handover(gpu, matrices, oracle):
             assert np.array_equal(a[f], b[f]), (i, f)
         assert np.all(fr[i, n:]["score"] == 0)
         for k in range(min(n, 3)):
-            pick_f.append(i * pfb.max_hits + k)
+            pick_f.append(i * max_hits + k)
             pick_s.append(off + k)
         off += n
     fi, fs = fused.traceback(np.array(pick_f, np.uint32))
     si, ss = sep.traceback(np.array(pick_s, np.uint32))
     assert fs == ss and np.array_equal(fi["ident"], si["ident"]) and np.array_equal(fi["status"], si["status"])
     assert sum(1 for x in fs if x) > 20
-    for b in (fused, sep, pfb):
+    for b in (fused, sep, other):
         b.free()

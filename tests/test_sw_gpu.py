@@ -88,6 +88,32 @@ def test_multi_tile_vs_oracle(gpu, oracle, matrices, qlen):
     _check(out, oracle, mat, q, cb, tres, toff, ids, True, "multi%d" % qlen)
 
 
+def test_many_long_queries_and_one_very_long_target(gpu, oracle, matrices):
+    """The column scratch of the multi-tile jobs is a pool sized by resident workgroups, not by jobs: 600 queries of
+    600..2200 residues, each with a list that contains a 60 000-residue target, would need 600 x 17 MB per-job scratch
+    (the round-1 sizing) - the pool needs a few hundred MB.  Results against the oracle for a sample of the pairs."""
+    rng = np.random.default_rng(77)
+    mat = matrices["blosum62_sw"]
+    tl = [rng.choice(20, size=60000, p=wl.BACKGROUND).astype(np.uint8)]
+    qs = [rng.choice(20, size=int(rng.integers(600, 2200)), p=wl.BACKGROUND).astype(np.uint8) for _ in range(600)]
+    for i in range(40):
+        tl.append(wl.mutate(rng, qs[i], 0.6))
+    for _ in range(60):
+        tl.append(rng.choice(20, size=int(rng.integers(50, 900)), p=wl.BACKGROUND).astype(np.uint8))
+    # plant a homolog of query 3 far inside the long target
+    tl[0][41000:41000 + len(qs[3])] = wl.mutate(rng, qs[3], 0.8)[:len(qs[3])]
+    tres, toff = wl.seqs_from_list(tl)
+    gpu.load_targets(tres, toff, 21)
+    queries = []
+    for i, q in enumerate(qs):
+        ids = np.concatenate([[0], rng.integers(1, len(tl), 9)]).astype(np.uint32)
+        queries.append(dict(q=q, comp_bias=None, targets=ids, min_start_score=0))
+    out = gpu.sw_batch(mat, GO, GE, queries, mode=1).reshape(len(qs), 10)
+    for i in [0, 3, 7, 123, 599]:
+        _check(out[i], oracle, mat, qs[i], None, tres, toff, queries[i]["targets"], True, "pool%d" % i)
+    assert out[3, 0]["t_end"] > 41000 and out[3, 0]["score"] > 500
+
+
 def test_many_queries_ragged_lists_and_empty(gpu, oracle, matrices):
     """Several queries of different classes in one batch, lists of 0, 1, 33 and 600 targets, duplicate ids."""
     rng = np.random.default_rng(7)
