@@ -1,24 +1,27 @@
 #!/usr/bin/env python3
-"""bench.py - headline benchmark of the MI355X-native prefilter->align path.
+"""bench.py - headline benchmark of the MI355X-native prefilter -> align path.
 
-Metric (BASELINE.json): giga-cells/s of the Gotoh Smith-Waterman stage, cells = sum over computed
-alignments of qlen*tlen (forward DP only, Alignment.cpp:380,530 convention).
+Metric (BASELINE.json): "giga-cells/s (SW) + query seqs/s, 10k queries vs 1M targets, 1/2/4/8 GPU".
 
-Workload at N=1: BASELINE.json configs[1] - "mmseqs align only: 1k random L~350 protein queries vs 100k
-targets" (10 % of targets carry a planted homolog), every query against every target as `mmseqs align` sees
-it behind the all-vs-all fake prefilter (data/workflow/blastp.sh:22-33): 1e8 alignments, ~1.2e13 cells per
-step.  A "step" = one pass of the hot path (forward scan, score + end positions) over that batch with the
-target DB, the queries and the prefilter lists already resident in HBM.
+Workload = BASELINE.json configs[2] (and configs[3] for N > 1): 10 000 protein queries against 1 000 000 family-structured
+targets (UniRef50-like lengths), `-s 5.7` (k = 6, spaced), `--max-seqs 300`, then the gapped alignment
+of every hit list with start positions for the pairs passing `-e 1e-3` (what `mmseqs search` runs: prefilter + align
+--alignment-mode 2).  A STEP = one pass of the whole hot path over the query set with the target DB, the k-mer index and
+the prepared query batch resident in HBM:
 
-N>1 (launched by torch.distributed.run, one process per GPU): every rank owns an independent target shard of
-the same size and its own prefilter lists (weak scaling, no data-path collective in this round); value =
-cells of all ranks / max-over-ranks time.
+  N = 1: prefilter kernels -> device-side hand-over of the hit lists (mmgpu_sw_prepare_from_pf) -> alignment kernels.
+  N > 1 (one process per GPU, torch.distributed / RCCL): the SAME 1M targets dealt to the ranks by length bucket (strong
+         scaling): prefilter of the shard -> ONE all-gather of 16-byte exchange records -> merge (result identical to the
+         1-GPU run) -> every rank aligns the pairs whose target it holds -> all-gather of the owned alignment records.
+         `--scaling weak` gives every rank its own 1M-target shard of an N-million database instead.
 
-The same line carries a second object, "search": BASELINE.json configs[2] (10k queries x 1M targets, -s 5.7,
-UniRef50-like lengths, 50-member families) through the k-mer prefilter and the gapped alignment of its hit lists -
-queries/s, per-stage milliseconds, the roofline of the HBM-bound gather kernel and the reference's own prefilter
-loop timed on the host cores.  With N>1 every rank holds its own 1M-target shard (weak scaling), the per-query hit
-lists are all-gathered over RCCL and merged on the device (mergeTargetSplits semantics).
+`value` = SW giga-cells/s: forward DP cells of the step (sum of qlen*tlen over the aligned pairs, Alignment.cpp:380,530
+convention; reverse-scan cells are NOT counted) divided by the time of the alignment stage inside the step (HIP events on
+the launch stream).  `queries_per_s` = queries / whole step time and `ms_per_step` (the whole step) stand beside it.
+
+Secondary sections of the same line: "align_only" (configs[1]: 1000 x 100 000 all-vs-all alignment), "nucleotide_align"
+(configs[4], alignment step).  CPU baselines = the real reference (oracle/_ref/libmmref.so) on the host cores, bounded
+samples; they double as full-size parity checks of the timed run's results.
 
 Prints ONE JSON line on rank 0.
 """
@@ -39,86 +42,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 # packed-int16 (VOP3P) VALU ops issue at 16 lanes/clk/SIMD on gfx950: measured 38.1 Tlane-op/s for v_pk_max_i16 /
 # v_pk_sub_u16 / v_perm_b32 (profiles/r01_valu_issue_rate_probe.txt) = 256 CU x 4 SIMD x 16 lanes x 2.4 GHz = 39.3e12
 VALU_LANE_OPS_PER_S = 256 * 4 * 16 * 2.4e9
-
-
-def cpu_baseline(matrices, qs, cbs, tres, toff, budget_s=15.0, gpu_res=None):
-    """Reported (not optimised-against) CPU baseline on the GPU box's host cores, bounded sample.
-    kind "reference": the real AVX2 striped Smith-Waterman of the reference (oracle/_ref/libmmref.so, uint8 pass
-    + int16 re-run), one SmithWaterman object per thread as Alignment::run does (Alignment.cpp:279-295).
-    kind "port": the scalar C oracle, when the reference library did not travel."""
-    from oracle import pyoracle
-    cores = os.cpu_count() or 1
-    n_t = len(toff) - 1
-    tlen_sum = int(toff[-1])
-    use_ref = pyoracle.ref_available()
-    ids = np.arange(n_t, dtype=np.uint32)
-    mat = matrices["blosum62_sw"]
-    if use_ref:
-        ser = matrices["blosum62_serialized"]
-        ctxs = [pyoracle.RefLib(serialized=ser, max_len=70000, db_residues=tlen_sum) for _ in range(cores)]
-    else:
-        ctxs = [pyoracle.Oracle()] * cores
-    # work item = one query against a chunk of `chunk` targets; a first parallel round (one item per thread)
-    # calibrates the aggregate rate under full load, then the sample is sized to ~budget_s of wall time
-    chunk = min(n_t, 2000)
-    chunks = [ids[k:k + chunk] for k in range(0, n_t, chunk)]
-    csum = np.array([float(toff[int(c[-1]) + 1] - toff[int(c[0])]) for c in chunks])
-    qlens = np.array([len(q) for q in qs], np.float64)
-    items = [(qi, ci) for qi in range(len(qs)) for ci in range(len(chunks))]
-
-    mism = [0, 0]   # pairs compared with the device results, pairs that differ (score, q_end, t_end)
-
-    def run_items(sub):
-        work = list(sub)
-        lock = threading.Lock()
-
-        def worker(ctx):
-            last_q = -1
-            while True:
-                with lock:
-                    if not work:
-                        return
-                    qi, ci = work.pop()
-                if use_ref and qi != last_q:
-                    ctx.sw_set_query(qs[qi])   # ssw_init recomputes the composition bias itself
-                    last_q = qi
-                if use_ref:
-                    sc, qe, te = ctx.sw_batch_score(tres, toff, chunks[ci])
-                else:
-                    sc, qe, te, _ = ctx.sw_batch_score(qs[qi], cbs[qi], tres, toff, chunks[ci], mat, 11, 1)
-                if gpu_res is not None:
-                    g = gpu_res[qi, chunks[ci]]
-                    # the reference's uint8 pass leaves q_end undefined (0) when the score is 0
-                    pos = sc > 0
-                    bad = int(np.count_nonzero(g["score"] != sc)) + int(np.count_nonzero((g["t_end"] != te) & pos)) \
-                        + int(np.count_nonzero((g["q_end"] != qe) & pos))
-                    with lock:
-                        mism[0] += len(sc)
-                        mism[1] += bad
-
-        th = [threading.Thread(target=worker, args=(ctxs[i],)) for i in range(cores)]
-        t0 = time.time()
-        for t in th:
-            t.start()
-        for t in th:
-            t.join()
-        return time.time() - t0, float(sum(qlens[qi] * csum[ci] for qi, ci in sub))
-
-    cal = items[:cores]
-    dt_cal, cells_cal = run_items(cal)
-    rate = cells_cal / max(dt_cal, 1e-3)
-    per_item = cells_cal / len(cal)
-    n_items = int(min(len(items) - len(cal), max(cores, rate * budget_s / per_item)))
-    sample = items[len(cal):len(cal) + n_items]
-    dt, cells = run_items(sample)
-    nq = len(set(qi for qi, _ in sample))
-    parity = None
-    if gpu_res is not None:
-        parity = {"pairs_compared": mism[0], "field_mismatches": mism[1], "fields": "score, q_end, t_end"}
-    return {"value": round(cells / dt / 1e9, 3), "unit": "GCUPS", "cores": cores, "parity_vs_baseline": parity,
-            "kind": "reference" if use_ref else "port",
-            "sample": "%d (query, %d-target chunk) items over %d queries of the same workload (%.3g cells), "
-                      "%.1f s wall, %d threads" % (len(sample), chunk, nq, cells, dt, cores)}
+PROFILE_ROUND = "r02"
 
 
 def allreduce(torch, dist, values, op="sum"):
@@ -131,7 +55,7 @@ def allreduce(torch, dist, values, op="sum"):
     return [float(v) for v in t.cpu()]
 
 
-def pmc_traffic(kernel, stem="r01_prefilter_config3"):
+def pmc_traffic(kernel, stem):
     """HBM bytes per launch of `kernel` (summed over its template instantiations) from the committed rocprofv3 PMC
     passes of this same workload (profiles/<stem>_pmc_{fetch,write}_size.txt: separate --pmc FETCH_SIZE / WRITE_SIZE
     runs, unit KB, mean per dispatch).  FETCH_SIZE is reported as measured; MI355X_MICROARCH.md notes it under-counts
@@ -151,11 +75,74 @@ def pmc_traffic(kernel, stem="r01_prefilter_config3"):
     return {"bytes_per_launch": round(tot), "source": "profiles/%s_pmc_*_size.txt (FETCH_SIZE + WRITE_SIZE, KB)" % stem}
 
 
-def search_cpu_baseline(matrices, qres, qoff, tres, toff, kmer_thr, budget_s, gpu_lists=None):
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU baselines (the real reference on the host cores; outside every timed region)
+def sw_cpu_baseline_lists(matrices, qs, lists, tres, toff, budget_s, gpu_res):
+    """Alignment::run's inner loop on the box's host cores: the reference's striped AVX2 Smith-Waterman (uint8 pass +
+    int16 re-run, one SmithWaterman object per thread as Alignment.cpp:279-295) over the SAME hit lists the device
+    aligned; a bounded sample of the queries.  gpu_res[q] = the device's records of query q's list (list order): every
+    compared field must agree."""
+    from oracle import pyoracle
+    if not pyoracle.ref_available():
+        return None
+    cores = os.cpu_count() or 1
+    tlen = (toff[1:] - toff[:-1]).astype(np.int64)
+    ser = matrices["blosum62_serialized"]
+    ctxs = [pyoracle.RefLib(serialized=ser, max_len=70000, db_residues=int(toff[-1])) for _ in range(cores)]
+    cells_q = np.array([len(q) * int(tlen[l].sum()) for q, l in zip(qs, lists)], np.float64)
+    mism = [0, 0]
+    lock = threading.Lock()
+
+    def run_items(items):
+        work = list(items)
+
+        def worker(ctx):
+            while True:
+                with lock:
+                    if not work:
+                        return
+                    qi = work.pop()
+                if len(lists[qi]) == 0:
+                    continue
+                ctx.sw_set_query(qs[qi])
+                sc, qe, te = ctx.sw_batch_score(tres, toff, lists[qi])
+                g = gpu_res[qi]
+                pos = sc > 0
+                bad = int(np.count_nonzero(g["score"] != sc)) + int(np.count_nonzero((g["t_end"] != te) & pos)) \
+                    + int(np.count_nonzero((g["q_end"] != qe) & pos))
+                with lock:
+                    mism[0] += len(sc)
+                    mism[1] += bad
+
+        th = [threading.Thread(target=worker, args=(ctxs[i],)) for i in range(cores)]
+        t0 = time.time()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        return time.time() - t0, float(sum(cells_q[i] for i in items))
+
+    n = len(qs)
+    cal = list(range(min(n, cores)))
+    dt_cal, cells_cal = run_items(cal)
+    rate = cells_cal / max(dt_cal, 1e-3)
+    per_item = cells_cal / max(len(cal), 1)
+    n_items = int(min(n - len(cal), max(cores, rate * budget_s / max(per_item, 1.0))))
+    sample = list(range(len(cal), len(cal) + n_items))
+    if not sample:
+        sample, dt, cells = cal, dt_cal, cells_cal
+    else:
+        dt, cells = run_items(sample)
+    return {"value": round(cells / dt / 1e9, 3), "unit": "GCUPS", "cores": cores, "kind": "reference",
+            "sample": "the hit lists of %d of the %d queries of the same workload (%.3g forward cells), %.1f s wall, %d threads"
+                      % (len(sample), n, cells, dt, cores),
+            "parity_vs_baseline": {"pairs_compared": mism[0], "field_mismatches": mism[1], "fields": "score, q_end, t_end"}}
+
+
+def prefilter_cpu_baseline(matrices, qres, qoff, tres, toff, kmer_thr, budget_s, gpu_lists):
     """The reference's own prefilter query loop (QueryMatcher::matchQuery per OpenMP thread, Prefiltering.cpp:820-917)
     from oracle/_ref/libmmref.so on the host cores, bounded sample of the same queries against the same targets.
-    The lists it produces are also the checker of the device lists at full size (gpu_lists = per-query
-    (ids, scores, diagonals) of the timed run): bit-identical or counted as a mismatch."""
+    The lists it produces are also the checker of the device lists at full size."""
     from oracle import pyoracle
     if not pyoracle.ref_available():
         return None
@@ -174,256 +161,241 @@ def search_cpu_baseline(matrices, qres, qoff, tres, toff, kmer_thr, budget_s, gp
            "sample": "first %d of the %d queries against the same %d targets, %.1f s wall, %d threads; reference index build "
                      "%.1f s (not counted)" % (n, nq, len(toff) - 1, sec, cores, t_index),
            "db_matches_per_query": round(dbm / n), "hits_per_query": round(hits / n, 1)}
-    if gpu_lists is not None:
-        bad = 0
-        for qi in range(n):
-            gi, gs, gd = gpu_lists[qi]
-            c = int(counts[qi])
-            same = (len(gi) == c and np.array_equal(gi, lists["ids"][qi, :c]) and np.array_equal(gs, lists["scores"][qi, :c])
-                    and np.array_equal(gd, lists["diags"][qi, :c]))
-            bad += not same
-        out["parity_vs_reference"] = {"queries_compared": n, "queries_with_different_hit_lists": int(bad),
-                                      "reference_cache_bins": int(lists["bins"]),
-                                      "fields": "hit ids, prefilter scores, diagonals, order"}
+    bad = 0
+    for qi in range(n):
+        gi, gs, gd = gpu_lists[qi]
+        c = int(counts[qi])
+        same = (len(gi) == c and np.array_equal(gi, lists["ids"][qi, :c]) and np.array_equal(gs, lists["scores"][qi, :c])
+                and np.array_equal(gd, lists["diags"][qi, :c]))
+        bad += not same
+    out["parity_vs_reference"] = {"queries_compared": n, "queries_with_different_hit_lists": int(bad),
+                                  "reference_cache_bins": int(lists["bins"]),
+                                  "fields": "hit ids, prefilter scores, diagonals, order"}
     return out
 
 
-def search_section(args, gpu, torch, dist, rank, world, matrices, barrier):
-    """BASELINE.json configs[2]/[3]: k-mer prefilter + gapped alignment of the hit lists, one target shard per rank."""
-    from mmseqs2_amd import capi, workloads as wl
+# ---------------------------------------------------------------------------------------------------------------------
+def search_headline(args, gpu, torch, dist, rank, world, matrices, barrier):
+    """BASELINE.json configs[2] / configs[3]: the timed steps and everything derived from them."""
+    from mmseqs2_amd import capi, evalue, workloads as wl
     from mmseqs2_amd import distributed as D
     km16 = matrices["vtml80_kmer"].astype(np.int16)
+    mat = matrices["blosum62_sw"]
+    sub16 = mat.astype(np.int16)
     sens, k, max_res = 5.7, 6, 300
     kmer_thr = int(163.2 - 8.917 * sens)          # Prefiltering::getKmerThreshold, Prefiltering.cpp:1080-1095
+    sharded = dist is not None                    # world > 1, or the single-rank self-test of the exchange path
+    weak = args.scaling == "weak" and world > 1
     t0 = time.time()
     (qres, qoff), (tres, toff), _, _ = wl.config3_prefilter(args.pf_families, args.pf_members, args.pf_queries, seed=10,
-                                                             target_seed=11 + 1000 * rank)
+                                                             target_seed=(11 + 1000 * rank) if weak else None)
     t_gen = time.time() - t0
     qs = wl.split(qres, qoff)
-    nq, nt = len(qs), len(toff) - 1
+    nq = len(qs)
+    n_local_gen = len(toff) - 1
     t0 = time.time()
     s3, i3 = capi.host_score_matrix(km16, 3)
-    gpu.load_targets(tres, toff, 21)
+    shard = None
+    if sharded and not weak:
+        # strong scaling: the same database, dealt to the ranks by length bucket (mmgpu_host_partition_targets)
+        shard = D.setup_shard(gpu, rank, world, tres, toff)
+        n_global, db_residues = len(toff) - 1, float(toff[-1])
+    elif sharded:
+        # weak scaling: rank r holds targets [r * n, (r + 1) * n) of an N-fold database (its own family members)
+        n_global = n_local_gen * world
+        gids = (rank * n_local_gen + np.arange(n_local_gen)).astype(np.uint32)
+        shard_of = (np.arange(n_global) // n_local_gen).astype(np.uint32)
+        local_id = (np.arange(n_global) % n_local_gen).astype(np.uint32)
+        gpu.load_targets(tres, toff, 21)
+        gpu.pf_set_shard(world, rank, n_global, gids, shard_of, local_id)
+        shard = dict(shard_of=shard_of, local_id=local_id, global_ids=gids, n_global=n_global)
+        db_residues = float(toff[-1]) * world
+    else:
+        gpu.load_targets(tres, toff, 21)
+        n_global, db_residues = len(toff) - 1, float(toff[-1])
     # the k-mer index is built in HBM from the resident targets (IndexBuilder::fillDatabase, masking off)
     gpu.pf_build_index(k, 21, True, s3, i3, km16, kmer_thr, matrices["blosum62_ungapped"])
     gpu.synchronize()
     t_index = time.time() - t0
     cbs = [capi.host_comp_bias(km16, matrices["vtml80_pback"], q)[0] for q in qs]
     queries = [dict(q=q, comp_bias=cb, identity_id=None) for q, cb in zip(qs, cbs)]
-    mh = capi.split_max_hits(max_res, world)      # Prefiltering.cpp:391-394
-    bsz = args.pf_batch
-    batches = [gpu.pf_prepare(queries[i:i + bsz], kmer_thr, max_hits=mh, min_diag_score=15, ref_bins=2)
-               for i in range(0, nq, bsz)]
-    shard_sizes = [nt] * world
-    # MMGPU_BENCH_FORCE_EXCHANGE=1: run the N > 1 exchange path (RCCL all-gather of the hit lists + device merge, RCCL
-    # exchange of the alignment results) on a single rank - a self-test of the collectives on a 1-GPU box
-    exchange = world > 1 or (dist is not None)
+    pfb = gpu.pf_prepare(queries, kmer_thr, max_hits=max_res, min_diag_score=15, ref_bins=2)
+    stride = pfb.max_hits
+    # start positions (reverse scan) only for the pairs that pass -e 1e-3: the smallest raw score whose E-value (ALP
+    # parameters of BLOSUM62 11/1, mmseqs2_amd/evalue.py == EvalueComputation.h:37-41) passes, per query length
+    thr_of_len = {}
+    swq = []
+    for q in qs:
+        L = len(q)
+        if L not in thr_of_len:
+            thr_of_len[L] = evalue.min_score_for_evalue(1e-3, L, db_residues)
+        swq.append(dict(q=q, comp_bias=capi.host_comp_bias(sub16, matrices["blosum62_pback"], q)[1], min_start_score=thr_of_len[L]))
+    msh = gpu.sw_marshal_queries(mat, 11, 1, swq)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    res_t = torch.zeros((nq, stride, 6), dtype=torch.int32, device=dev) if sharded else None
+    stat = {"pf_ms": [], "align_ms": [], "cells": 0, "pairs": 0}
+    keep = {}
 
-    def one_pass(keep):
-        merged = []
-        for b in batches:
-            b.run()
-            if exchange:
-                mh_t, mc_t = D.gather_and_merge_device(gpu, b, b.nq, mh, shard_sizes)
-                if keep:
-                    merged.append((mh_t, mc_t))
-        return merged
+    def step(record):
+        pfb.run()
+        if not sharded:
+            fb = gpu.sw_prepare_from_pf(mat, 11, 1, None, pfb, mode=1, marshalled=msh)
+            fb.run()
+            a_ms = fb.kernel_ms()            # synchronises: the step is complete here
+            if record:
+                stat["pf_ms"].append(pfb.stage_ms()[6])
+                stat["align_ms"].append(a_ms)
+                stat["cells"], stat["pairs"] = fb.cells, fb.pairs
+            if record == "keep":
+                keep["fused"] = fb.fetch().reshape(nq, stride)
+            fb.free()
+            return
+        mh_t, mc_t, mf_t = D.exchange_and_merge_device(gpu, pfb, nq, stride)
+        b, lc, ls = D.align_owned_pairs(gpu, mat, 11, 1, msh, mh_t, mc_t, nq, stride, mode=1)
+        b.run()
+        b.fetch_device(res_t.data_ptr())
+        a_ms = b.kernel_ms()
+        full = D.gather_owned_results(res_t, lc, ls, nq, stride)
+        if record:
+            stat["pf_ms"].append(pfb.stage_ms()[6])
+            stat["align_ms"].append(a_ms)
+            stat["cells"], stat["pairs"] = b.cells, b.pairs
+        if record == "keep":
+            keep["merged"] = (mh_t.cpu().numpy(), mc_t.cpu().numpy(), mf_t.cpu().numpy())
+            keep["full"] = full.cpu().numpy()
+        b.free()
 
-    one_pass(False)                                # warm-up, sizes the working buffers
+    for _ in range(max(args.warmup, 1)):          # at least one untimed pass sizes the working buffers
+        step(None)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.pf_steps):
-        merged = one_pass(True)
+    for _ in range(args.steps):
+        step(True)
     barrier()
-    t_pf = (time.perf_counter() - t0) / args.pf_steps
-    t_pf = allreduce(torch, dist, [t_pf], "max")[0]
-    stage = np.zeros(7)
-    ent = sim = cells = cands = nhits = ovf = 0
-    lists, slot_index, full_lists = [], [], []
-    for bi, b in enumerate(batches):
-        stage += np.array(b.stage_ms())
-        h, c, st, stats = b.fetch()
-        cc = b.last_cells()
-        cells += cc[0]
-        cands += cc[1]
-        ent += int(stats["db_matches"].sum())
-        sim += int(stats["kmer_list_len"].sum())
-        ovf += int((st != 0).sum())
-        if exchange:
-            mh_t, mc_t = merged[bi]
-            hh = mh_t.cpu().numpy().reshape(b.nq, -1).view(capi.PF_HIT_DTYPE).reshape(b.nq, -1)
-            cc2 = mc_t.cpu().numpy()
-            for qi in range(b.nq):
-                ids = hh[qi]["id"][:cc2[qi]]
-                own = (ids >= rank * nt) & (ids < (rank + 1) * nt)     # pairs run on the GPU owning the target
-                lists.append((ids[own] - rank * nt).astype(np.uint32))
-                slot_index.append((len(lists) - 1) * world * mh + np.nonzero(own)[0])
-            nhits += int(cc2.sum())
-        else:
-            for qi in range(b.nq):
-                lists.append(h[qi]["id"][:c[qi]].copy())
-                full_lists.append((h[qi]["id"][:c[qi]].copy(), h[qi]["score"][:c[qi]].copy(), h[qi]["diagonal"][:c[qi]].copy()))
-            nhits += int(c.sum())
+    elapsed = time.perf_counter() - t0
+    elapsed = allreduce(torch, dist, [elapsed], "max")[0]
+    align_ms = allreduce(torch, dist, [float(np.mean(stat["align_ms"]))], "max")[0]
+    pf_ms = allreduce(torch, dist, [float(np.mean(stat["pf_ms"]))], "max")[0]
+    cells, pairs = allreduce(torch, dist, [stat["cells"], stat["pairs"]])
+    step("keep")                                  # one more pass whose results are downloaded for the checks below
 
-    if args.prefilter_only:      # counter passes (scripts/collect_profiles.sh): the prefilter kernels only
-        for b in batches:
-            b.free()
-        return {"prefilter_s": round(t_pf, 4), "db_matches": int(ent), "stage_ms_total_rank0": round(float(stage[6]), 2)} if rank == 0 else None
+    # ---- per-stage counters of the prefilter (last pass) ----
+    stage = np.array(pfb.stage_ms())
+    pf_cells, pf_cands = pfb.last_cells()
+    out = {"elapsed_s": elapsed, "align_ms": align_ms, "pf_ms": pf_ms, "cells": cells, "pairs": pairs, "nq": nq,
+           "n_global": n_global, "n_local": gpu.n_targets, "kmer_thr": kmer_thr, "max_res": max_res, "stage": stage,
+           "pf_cells": pf_cells, "pf_cands": pf_cands, "t_gen": t_gen, "t_index": t_index, "weak": weak, "sharded": sharded,
+           "thr_example": thr_of_len.get(len(qs[0]))}
+    if rank != 0:
+        pfb.free()
+        return out
 
-    # ---- spot check of the prefilter lists against the oracle on a reduced copy of the problem is done by the
-    # tests; here: the alignment of the lists (Alignment::run behind the prefilter DB) ----
+    # ---- everything below: rank 0, outside the timed region ----
+    tlen = (toff[1:] - toff[:-1]).astype(np.int64)
+    # without the lists on the host (N > 1): sum of target lengths ~ cells / mean query length
+    out["alg_bytes"] = 28.0 * pairs + cells / max(float(np.mean([len(q) for q in qs])), 1.0) + 2.0 * float(qoff[-1])
+    if not sharded:
+        hits, counts, status, stats = pfb.fetch()
+        out["ent"] = int(stats["db_matches"].sum())
+        out["sim"] = int(stats["kmer_list_len"].sum())
+        out["ovf"] = int((status != 0).sum())
+        out["nhits"] = int(counts.sum())
+        lists = [hits[qi]["id"][:counts[qi]].copy() for qi in range(nq)]
+        full_lists = [(hits[qi]["id"][:counts[qi]].copy(), hits[qi]["score"][:counts[qi]].copy(), hits[qi]["diagonal"][:counts[qi]].copy())
+                      for qi in range(nq)]
+        fused = keep["fused"]
+        gpu_res = [fused[qi, :counts[qi]] for qi in range(nq)]
+        out["alg_bytes"] = float(sum(int(tlen[l].sum()) + 28 * len(l) for l in lists)) + 2.0 * float(qoff[-1])
+        # the two-call path a patched Alignment::run takes (lists through the host): timed end to end, and its results
+        # must equal the fused path's slot by slot
+        t0 = time.perf_counter()
+        host_q = [dict(q=x["q"], comp_bias=x["comp_bias"], targets=lists[i], min_start_score=x["min_start_score"]) for i, x in enumerate(swq)]
+        swb = gpu.sw_prepare(mat, 11, 1, host_q, mode=1)
+        t_prep = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        swb.run()
+        sep = swb.fetch()
+        t_run_fetch = time.perf_counter() - t0
+        bad, off = 0, 0
+        for qi in range(nq):
+            n = len(lists[qi])
+            a, bb = fused[qi, :n], sep[off:off + n]
+            bad += int(sum(not np.array_equal(a[f], bb[f]) for f in ("score", "q_end", "t_end", "q_start", "t_start")))
+            off += n
+        # backtraces (Matcher::SCORE_COV_SEQID / -a) for the hit lists of the first 1000 queries
+        bt_n = int(sum(len(x) for x in lists[:1000]))
+        t0 = time.perf_counter()
+        bt_info, _ = swb.traceback(np.arange(bt_n, dtype=np.uint32)) if bt_n else (np.zeros(0, capi.SW_BT_DTYPE), [])
+        t_bt = time.perf_counter() - t0
+        out["two_call"] = {"prepare_s_host_scheduling_and_upload": round(t_prep, 3), "run_and_fetch_s": round(t_run_fetch, 4),
+                           "fields_differing_from_fused_path": bad,
+                           "what": "mmgpu_sw_prepare (caller-supplied lists) + mmgpu_sw_run + mmgpu_sw_fetch, mode START"}
+        out["backtrace"] = {"pairs": bt_n, "with_cigar": int((bt_info["status"] == 0).sum()) if bt_n else 0,
+                            "s_incl_download": round(t_bt, 4), "pairs_per_s": round(bt_n / t_bt, 1) if t_bt > 0 else None}
+        swb.free()
+        started = int(sum(int((g["q_start"] >= 0).sum()) for g in gpu_res))
+        out["pairs_with_start"] = started
+        if not args.no_cpu_baseline:
+            out["cpu_sw"] = sw_cpu_baseline_lists(matrices, qs, lists, tres, toff, args.cpu_seconds, gpu_res)
+            out["cpu_pf"] = prefilter_cpu_baseline(matrices, qres, qoff, tres, toff, kmer_thr, args.cpu_seconds, full_lists)
+    else:
+        mh, mc, mf = keep["merged"]
+        mh = mh.reshape(nq, stride * 3).view(capi.PF_HIT_DTYPE).reshape(nq, stride)
+        out["nhits"] = int(mc.sum())
+        out["inexact_queries"] = int((mf != 0).sum())
+        full = keep["full"].reshape(-1).view(capi.SW_HIT_DTYPE).reshape(nq, stride)
+        out["merged_lists_sorted"] = bool(all(np.all(np.diff(mh[qi]["score"][:mc[qi]].astype(np.int64)) <= 0) for qi in range(0, nq, 97)))
+        out["aligned_slots_filled"] = int(sum(int((full[qi, :mc[qi]]["score"] > 0).sum()) for qi in range(nq)))
+    pfb.free()
+    return out
+
+
+def align_only_section(args, gpu, torch, matrices, rank):
+    """BASELINE.json configs[1]: 1000 x 100 000 all-vs-all alignment (score + end positions), kernel-only rate."""
+    from mmseqs2_amd import workloads as wl
+    from mmseqs2_amd.capi import host_comp_bias
     mat = matrices["blosum62_sw"]
     sub16 = mat.astype(np.int16)
+    (qres, qoff), (tres, toff) = wl.config2_align_only(args.queries, args.targets, seed=1 + 1000 * rank)
+    qs = wl.split(qres, qoff)
+    cbs = [host_comp_bias(sub16, matrices["blosum62_pback"], q)[1] for q in qs]
+    gpu.load_targets(tres, toff, 21)
+    ids = np.arange(args.targets, dtype=np.uint32)
+    queries = [dict(q=q, comp_bias=cb, targets=ids, min_start_score=0) for q, cb in zip(qs, cbs)]
     t0 = time.time()
-    swq = []
-    # Start positions (reverse scan) are computed only for pairs that pass -e 1e-3, like ssw_align_private
-    # (StripedSmithWaterman.cpp:857-863).  The reference gets the E-value from ALP (host); here the threshold is the
-    # Karlin-Altschul bound E = K m n exp(-lambda S) with the gapped BLOSUM62 11/1 constants (lambda 0.267, K 0.041),
-    # n = residues of all shards.
-    import math
-    db_res = float(toff[-1]) * world
-    for q, ids in zip(qs, lists):
-        min_start = int(math.ceil(math.log(0.041 * len(q) * db_res / 1e-3) / 0.267))
-        swq.append(dict(q=q, comp_bias=capi.host_comp_bias(sub16, matrices["blosum62_pback"], q)[1], targets=ids,
-                        min_start_score=max(min_start, 1)))
-    swb = gpu.sw_prepare(mat, 11, 1, swq, mode=1)
-    t_handoff = time.time() - t0
-    swb.run()
-    barrier()
-    dev = torch.device("cuda", torch.cuda.current_device())
-    slot_t = local_t = None
-    if exchange:
-        slot_t = torch.from_numpy(np.concatenate(slot_index) if slot_index else np.zeros(0, np.int64)).to(dev)
-        local_t = torch.zeros((max(swb.pairs, 1), 6), dtype=torch.int32, device=dev)
-
-    def align_pass():
-        swb.run()
-        if exchange:
-            # second exchange of the path: the alignment results of the merged lists stay on the device - D2D copy
-            # out of the batch, scatter to the merged-list slots, one all-reduce over RCCL
-            swb.fetch_device(local_t.data_ptr())
-            return D.exchange_sw_results_tensor(local_t[:swb.pairs], slot_t, nq * world * mh)
+    batch = gpu.sw_prepare(mat, 11, 1, queries, mode=0)
+    prep_s = time.time() - t0
+    batch.run()
+    gpu.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.align_steps):
+        batch.run()
+    gpu.synchronize()
+    dt = (time.perf_counter() - t0) / args.align_steps
+    k_ms = batch.kernel_ms_mean(args.align_steps)[0]
+    if rank != 0:
+        batch.free()
         return None
-
     t0 = time.perf_counter()
-    for _ in range(args.pf_steps):
-        sw_all = align_pass()
-    barrier()
-    t_sw = (time.perf_counter() - t0) / args.pf_steps
-    sw_cells, sw_pairs = swb.cells, swb.pairs
-    fused = None
-    if not exchange:
-        # the whole path as one device pipeline: prefilter batch -> hit lists sorted / scheduled on the device
-        # (mmgpu_sw_prepare_from_pf) -> alignment, nothing but the query descriptors crosses PCIe in between
-        msh = [gpu.sw_marshal_queries(mat, 11, 1, swq[i:i + bsz]) for i in range(0, nq, bsz)]
-        sep = swb.fetch()
-
-        def fused_pass(keep):
-            outs = []
-            for b, m in zip(batches, msh):
-                b.run()
-                fb = gpu.sw_prepare_from_pf(mat, 11, 1, None, b, mode=1, marshalled=m)
-                fb.run()
-                if keep:
-                    outs.append((fb.fetch().reshape(b.nq, -1), fb.cells, fb.pairs))
-                fb.free()
-            return outs
-
-        fused_pass(False)
-        gpu.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.pf_steps):
-            fused_pass(False)
-        gpu.synchronize()
-        t_fused = (time.perf_counter() - t0) / args.pf_steps
-        outs = fused_pass(True)
-        # where the pipeline's time goes (separate pass with a device sync after every call; sums to more than t_fused)
-        brk = np.zeros(4)
-        for b, m in zip(batches, msh):
-            ts = [time.perf_counter()]
-            b.run(); gpu.synchronize(); ts.append(time.perf_counter())
-            fb = gpu.sw_prepare_from_pf(mat, 11, 1, None, b, mode=1, marshalled=m); gpu.synchronize(); ts.append(time.perf_counter())
-            fb.run(); gpu.synchronize(); ts.append(time.perf_counter())
-            fb.free(); ts.append(time.perf_counter())
-            brk += np.diff(ts)
-        # slot by slot the same results as the two-call path through the host
-        bad, off, qi = 0, 0, 0
-        for fr, _, _ in outs:
-            for r in range(fr.shape[0]):
-                n = len(lists[qi])
-                a, bb = fr[r, :n], sep[off:off + n]
-                bad += int(sum(not np.array_equal(a[f], bb[f]) for f in ("score", "q_end", "t_end", "q_start", "t_start")))
-                off += n
-                qi += 1
-        fused = {"s": round(t_fused, 4), "queries_per_s": round(nq / t_fused, 1),
-                 "align_cells": int(sum(o[1] for o in outs)), "align_pairs": int(sum(o[2] for o in outs)),
-                 "queries_differing_from_two_call_path": bad,
-                 "synchronous_breakdown_ms": {"prefilter": round(brk[0] * 1e3, 2), "prepare_from_pf": round(brk[1] * 1e3, 2),
-                                              "align": round(brk[2] * 1e3, 2), "free": round(brk[3] * 1e3, 2)},
-                 "what": "per batch: prefilter, device-side list sort + job table, alignment (mmgpu_sw_prepare_from_pf); "
-                         "includes the alignment batch set-up (profile build, allocation)"}
-    # backtraces (Matcher::SCORE_COV_SEQID / -a) for the hit lists of the first 1000 queries
-    bt_n = int(sum(len(x) for x in lists[:1000]))
-    t0 = time.perf_counter()
-    bt_info, _ = swb.traceback(np.arange(bt_n, dtype=np.uint32)) if bt_n else (np.zeros(0, capi.SW_BT_DTYPE), [])
-    t_bt = time.perf_counter() - t0
-    bt_ok = int((bt_info["status"] == 0).sum()) if bt_n else 0
-    t_sw = allreduce(torch, dist, [t_sw], "max")[0]
-    sw_cells, sw_pairs = allreduce(torch, dist, [sw_cells, sw_pairs])
-    swb.free()
-    res = None
-    if rank == 0:
-        # the committed PMC passes were taken on exactly the default workload (10k x 1M, one batch)
-        default_wl = (args.pf_families, args.pf_members, args.pf_queries, args.pf_batch) == (20000, 50, 10000, 10000)
-        traffic = pmc_traffic("pf_split_kernel") if default_wl else None
-        # algorithmic HBM bytes of the gather/split kernel (SURVEY.md section 8d): ~20 B per index entry touched
-        # (6 B entry gathered, 8 B written + 8 B re-read for the replay, amortised list descriptors)
-        alg = 20.0 * ent
-        achieved = alg / (stage[1] * 1e-3) / 1e9 if stage[1] > 0 else 0.0
-        res = {
-            "workload": "BASELINE.json configs[2]: %d queries x %d targets per GPU (%d families x %d members, L~LogNormal(5.45,0.6)), "
-                        "-s 5.7 (k=6, k-mer thr %d), --max-seqs %d%s, then alignment of the hit lists (score, ends; starts for pairs passing -e 1e-3)"
-                        % (nq, nt, args.pf_families, args.pf_members, kmer_thr, max_res,
-                           " (per-split %d, Prefiltering.cpp:391-394)" % mh if world > 1 else ""),
-            # N = 1: the whole device pipeline incl. the hand-over (fused_pipeline); N > 1: prefilter (with the hit-list
-            # all-gather + merge) + alignment (with the result exchange), host-side list hand-over excluded
-            "queries_per_s": round(nq / t_fused, 1) if fused is not None else round(nq / (t_pf + t_sw), 1),
-            "queries_per_s_stages_only": round(nq / (t_pf + t_sw), 1), "prefilter_queries_per_s": round(nq / t_pf, 1),
-            "prefilter_s": round(t_pf, 4), "align_s": round(t_sw, 4), "handoff_s": round(t_handoff, 2), "fused_pipeline": fused,
-            "targets_total": nt * world, "n_gpus": world,
-            "stage_ms": {"kmers_lists": round(stage[0], 2), "gather_split": round(stage[1], 2), "replay_score_keepmax": round(stage[2], 2),
-                         "large_bins_score": round(stage[3], 2), "large_bins_keepmax_and_overflow_path": round(stage[4], 2),
-                         "select": round(stage[5], 2),
-                         "total_rank0": round(stage[6], 2)},
-            "db_matches": int(ent), "similar_kmers": int(sim), "double_diagonal_candidates": int(cands),
-            "ungapped_cells": int(cells), "prefilter_hits": int(nhits), "overflow_queries": int(ovf),
-            "align_pairs": int(sw_pairs), "align_cells": int(sw_cells),
-            "align_gcups": round(sw_cells / t_sw / 1e9, 1),
-            "backtrace": {"pairs": bt_n, "with_cigar": bt_ok, "s_incl_download": round(t_bt, 4),
-                          "pairs_per_s": round(bt_n / t_bt, 1) if t_bt > 0 else None},
-            "roofline": {"kernel": "pf_split_kernel (index gather + stable bin split)", "bound": "hbm",
-                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel_ms": round(stage[1], 3), "launches": len(batches),
-                         "algorithmic_bytes_per_launch": round(alg / len(batches)), "algorithmic_bytes_per_entry": 20,
-                         "replay_score": {"kernel": "pf_replay_kernel (double-diagonal replay + ungapped scoring)",
-                                          "bound": "latency / LDS+VALU issue", "kernel_ms": round(stage[2], 3),
-                                          "entries_per_s": round(ent / (stage[2] * 1e-3), 1) if stage[2] > 0 else None,
-                                          "ungapped_cells_per_s": round(cells / (stage[2] * 1e-3), 1) if stage[2] > 0 else None,
-                                          "algorithmic_GBps": round((8.0 * ent + 1.0 * cells) / (stage[2] * 1e-3) / 1e9, 1) if stage[2] > 0 else None}},
-            "setup_s": {"generate": round(t_gen, 1), "score_tables_upload_and_device_index_build": round(t_index, 2)},
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = search_cpu_baseline(matrices, qres, qoff, tres, toff, kmer_thr, args.cpu_seconds, full_lists)
-    for b in batches:
-        b.free()
-    return res
+    res = batch.fetch().reshape(args.queries, args.targets)
+    t_fetch = time.perf_counter() - t0
+    lane_ops = batch.cells / 2.0 * 10.0
+    out = {"workload": "BASELINE.json configs[1]: align-only, %d random L~N(350,35) queries x %d targets (10%% planted homologs), "
+                       "all-vs-all lists, BLOSUM62 gap 11/1, comp-bias on, score + end positions" % (args.queries, args.targets),
+           "gcups_kernels_only": round(batch.cells / dt / 1e9, 1), "ms_per_pass": round(dt * 1e3, 2), "kernel_ms": round(k_ms, 2),
+           "pairs": int(batch.pairs), "cells": int(batch.cells),
+           "end_to_end_s": {"prepare_host_scheduling_and_upload": round(prep_s, 2), "run": round(dt, 3), "fetch_2.4GB_of_results": round(t_fetch, 3),
+                            "gcups_incl_prepare_and_fetch": round(batch.cells / (prep_s + dt + t_fetch) / 1e9, 1)},
+           "valu_roofline_frac": round(lane_ops / (k_ms * 1e-3) / VALU_LANE_OPS_PER_S, 4),
+           "score_checksum": int(res["score"].astype(np.int64).sum())}
+    batch.free()
+    return out
 
 
 def nucl_section(args, gpu, matrices, rank):
     """BASELINE.json configs[4], the nucleotide alignment step (BandedNucleotideAligner::align behind Alignment::run):
     reads with 10 % substitutions / 2 % indels against their source contigs (true prefilter diagonal, both strands)
-    plus unrelated contigs.  The prefilter side of the nucleotide search is not part of this round (lists synthetic)."""
+    plus unrelated contigs.  The prefilter side of the nucleotide search is not built (lists synthetic)."""
     from mmseqs2_amd import workloads as wl
     t0 = time.time()
     queries, (tres, toff), pairs = wl.config5_nucleotide(args.nucl_contigs, args.nucl_reads, args.nucl_read_len, seed=20 + 1000 * rank)
@@ -473,29 +445,28 @@ def main():
     os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--queries", type=int, default=1000)
-    ap.add_argument("--targets", type=int, default=100000)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-search", action="store_true", help="skip the configs[2] prefilter+align section")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="N > 1: strong = the same 1M targets dealt to the ranks (BASELINE.json configs[3]); weak = 1M targets per rank")
     ap.add_argument("--pf-families", type=int, default=20000)
     ap.add_argument("--pf-members", type=int, default=50)
     ap.add_argument("--pf-queries", type=int, default=10000)
-    ap.add_argument("--pf-batch", type=int, default=10000)
-    ap.add_argument("--pf-steps", type=int, default=2)
+    ap.add_argument("--queries", type=int, default=1000, help="align_only section (configs[1])")
+    ap.add_argument("--targets", type=int, default=100000)
+    ap.add_argument("--align-steps", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-align-only", action="store_true", help="skip the configs[1] section")
     ap.add_argument("--no-nucl", action="store_true", help="skip the configs[4] nucleotide alignment section")
     ap.add_argument("--nucl-contigs", type=int, default=4000)
     ap.add_argument("--nucl-reads", type=int, default=1000)
     ap.add_argument("--nucl-read-len", type=int, default=10000)
-    ap.add_argument("--prefilter-only", action="store_true", help="configs[2] section: stop after the prefilter (counter passes)")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--headline-only", action="store_true", help="counter passes (scripts/collect_profiles.sh): the timed steps only")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
     import torch
     import mmseqs2_amd
-    from mmseqs2_amd import workloads as wl
-    from mmseqs2_amd.capi import host_comp_bias
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -508,6 +479,7 @@ def main():
     device_index = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(device_index)
     dist = None
+    # MMGPU_BENCH_FORCE_EXCHANGE=1: run the N > 1 path (shard description, RCCL all-gathers, merge) with a single rank
     if world > 1 or os.environ.get("MMGPU_BENCH_FORCE_EXCHANGE") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -518,25 +490,9 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     matrices = dict(np.load(os.path.join(ROOT, "tests", "golden", "matrices.npz")))
-    mat = matrices["blosum62_sw"]
-    sub16 = mat.astype(np.int16)
-
-    # ---- synthetic workload: same queries on every rank, rank-specific target shard (weak scaling) ----------
-    (qres, qoff), (tres, toff) = wl.config2_align_only(args.queries, args.targets, seed=1 + 1000 * rank)
-    if rank != 0:
-        (qres, qoff), _ = wl.config2_align_only(args.queries, 1, planted_frac=0.0, seed=1)
-    qs = wl.split(qres, qoff)
-    cbs = [host_comp_bias(sub16, matrices["blosum62_pback"], q)[1] for q in qs]
-
     gpu = mmseqs2_amd.MMGpu(device_index)
     stream = torch.cuda.current_stream()
     gpu.set_stream(stream.cuda_stream)
-    gpu.load_targets(tres, toff, 21)
-    ids = np.arange(args.targets, dtype=np.uint32)
-    queries = [dict(q=q, comp_bias=cb, targets=ids, min_start_score=0) for q, cb in zip(qs, cbs)]
-    t0 = time.time()
-    batch = gpu.sw_prepare(mat, 11, 1, queries, mode=0)      # H2D + scheduling: outside the timed region
-    prep_s = time.time() - t0
 
     def barrier():
         torch.cuda.synchronize()
@@ -544,87 +500,85 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        batch.run()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        batch.run()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    # HIP events recorded by the library on the launch stream around the kernels of each timed step
-    kern_ms = [batch.kernel_ms_mean(args.steps)[0]]
-    elapsed = allreduce(torch, dist, [elapsed], "max")[0]
-    total_cells = allreduce(torch, dist, [batch.cells])[0]
-
-    # ---- spot-check the timed batch's results against the oracle (checker only, outside the timed region) ----
-    check = None
-    res = None
-    if rank == 0:
-        from oracle.pyoracle import Oracle
-        res = batch.fetch().reshape(args.queries, args.targets)
-        orc = Oracle()
-        rng = np.random.default_rng(0)
-        bad = 0
-        n_chk = 400
-        for _ in range(n_chk):
-            qi, ti = int(rng.integers(0, args.queries)), int(rng.integers(0, args.targets))
-            r = orc.sw_align(qs[qi], cbs[qi], tres[int(toff[ti]):int(toff[ti + 1])], mat, 11, 1)
-            h = res[qi, ti]
-            bad += (int(h["score"]), int(h["q_end"]), int(h["t_end"]), int(h["word"])) != (r["score"], r["q_end"], r["t_end"], r["word"])
-        check = {"pairs_checked_vs_oracle": n_chk, "mismatches": bad,
-                 "score_checksum": int(res["score"].astype(np.int64).sum())}
-
-    batch_cells, batch_pairs = batch.cells, batch.pairs
-    batch.free()
-    search = None
-    if not args.no_search:
-        search = search_section(args, gpu, torch, dist, rank, world, matrices, barrier)
-    nucl = None
-    if not args.no_nucl and not args.prefilter_only:
-        try:
-            nucl = nucl_section(args, gpu, matrices, rank)
-        except Exception as e:      # the newest section must not take the headline line down with it: report, do not hide
-            nucl = {"error": "%s: %s" % (type(e).__name__, e)} if rank == 0 else None
+    H = search_headline(args, gpu, torch, dist, rank, world, matrices, barrier)
+    side = {}
+    if not args.headline_only:
+        if not args.no_align_only:
+            try:
+                side["align_only"] = align_only_section(args, gpu, torch, matrices, rank)
+            except Exception as e:      # a secondary section must not take the headline line down with it: report, do not hide
+                side["align_only"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if not args.no_nucl:
+            try:
+                side["nucleotide_align"] = nucl_section(args, gpu, matrices, rank)
+            except Exception as e:
+                side["nucleotide_align"] = {"error": "%s: %s" % (type(e).__name__, e)}
 
     if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        value = total_cells * args.steps / elapsed / 1e9
-        k_ms = float(np.mean(kern_ms))
-        # algorithmic HBM bytes of one launch: tlen + 28 bytes per alignment + the query
-        # residues/bias once per workgroup-visible query
-        tlen = (toff[1:] - toff[:-1]).astype(np.float64)
-        alg_bytes = float(args.queries) * float((tlen + 28).sum()) + 2.0 * float(qoff[-1])
+        nq = H["nq"]
+        ms_per_step = H["elapsed_s"] / args.steps * 1e3
+        k_ms = H["align_ms"]
+        value = H["cells"] / (k_ms * 1e-3) / 1e9
+        stage = H["stage"]
+        default_wl = (args.pf_families, args.pf_members, args.pf_queries) == (20000, 50, 10000) and world == 1
+        # algorithmic HBM bytes of the alignment kernels: tlen + 28 bytes per pair + the query once
+        alg_bytes = H["alg_bytes"]
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
-        # packed-int16 VALU work the algorithm needs: 10 VOP3P lane-ops per pair of cells
-        lane_ops = batch_cells / 2.0 * 10.0
+        lane_ops = H["cells"] / 2.0 * 10.0       # 10 VOP3P lane-ops per pair of cells, forward scan only
         out = {
-            "metric": "sw_gcells_per_s", "value": round(value, 2), "unit": "GCUPS",
+            "metric": "sw_gcells_per_s", "value": round(value, 1), "unit": "GCUPS",
+            "queries_per_s": round(nq * args.steps / H["elapsed_s"], 1),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int16", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1]: align-only, %d random L~N(350,35) queries x %d targets "
-                                   "(10%% planted homologs), all-vs-all prefilter lists, BLOSUM62 gap 11/1, comp-bias on, "
-                                   "score+end positions" % (args.queries, args.targets),
-                       "pairs_per_gpu": int(batch_pairs), "cells_per_gpu": int(batch_cells),
-                       "parallelism": "1 process/GPU, independent target shards" if world > 1 else "single GPU"},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "higher_is_better": True, "scaling": "weak" if H["weak"] else "strong", "vs_baseline": None, "dtype": "int16", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[%d]: %d queries x %d targets (%d families x %d members, L~LogNormal(5.45,0.6)), "
+                                   "-s 5.7 (k=6 spaced, k-mer threshold %d), --max-seqs %d, --mask 0, then Gotoh SW of every hit list "
+                                   "(BLOSUM62 11/1, comp-bias on): score + end positions, start positions for pairs passing -e 1e-3"
+                                   % (3 if world > 1 else 2, nq, H["n_global"], args.pf_families, args.pf_members, H["kmer_thr"], H["max_res"]),
+                       "step": "prefilter kernels -> device-side hand-over -> alignment kernels (fused path)" if not H["sharded"] else
+                               "prefilter of the shard -> all-gather of exchange records -> merge (== unsplit result) -> alignment of owned pairs -> all-gather of results",
+                       "value_is": "forward DP cells of the step / alignment-stage time of the step (HIP events); queries_per_s = queries / whole step",
+                       "targets_per_gpu": int(H["n_local"]), "align_pairs_per_step": int(H["pairs"]), "align_cells_per_step": int(H["cells"]),
+                       "parallelism": "single GPU" if world == 1 else "1 process/GPU, targets dealt by length bucket, RCCL all-gather x2 per step"},
+            "ms_per_step_stages": {"prefilter_kernels": round(H["pf_ms"], 2), "align_kernels": round(k_ms, 2),
+                                   "handover_exchange_and_host": round(ms_per_step - H["pf_ms"] - k_ms, 2)},
+            "roofline": {"kernel": "sw_kernel<G,true> (three grids: tile shapes grouped by register need, forward + reverse scan)",
+                         "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6),
-                         # per step = one launch of every sw_kernel<R> instantiation; PMC passes of this exact workload
-                         "traffic": pmc_traffic("sw_kernel<", "r01_sw_config2") if (args.queries, args.targets) == (1000, 100000) else None,
-                         "algorithmic_bytes_per_launch": round(alg_bytes),
-                         "kernel_ms": round(k_ms, 3),
-                         "note": "Gotoh SW is VALU-bound (0.003 B/cell); see valu_roofline for the binding resource",
+                         "traffic": pmc_traffic("sw_kernel<", PROFILE_ROUND + "_search") if default_wl else None,
+                         "algorithmic_bytes_per_launch": round(alg_bytes), "kernel_ms": round(k_ms, 3),
+                         "note": "Gotoh SW is VALU-issue bound (0.003 B/cell, SURVEY.md section 8d): the binding roof is valu_roofline",
                          "valu_roofline": {"achieved_lane_ops_per_s": round(lane_ops / (k_ms * 1e-3), 1),
                                            "peak_lane_ops_per_s": VALU_LANE_OPS_PER_S,
-                                           "frac": round(lane_ops / (k_ms * 1e-3) / VALU_LANE_OPS_PER_S, 4)}},
-            "prepare_s": round(prep_s, 2), "check": check,
+                                           "frac": round(lane_ops / (k_ms * 1e-3) / VALU_LANE_OPS_PER_S, 4),
+                                           "counts": "forward cells only; the reverse scan of the pairs passing -e 1e-3 runs inside the same kernels"}},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(matrices, qs, cbs, tres, toff, args.cpu_seconds, res)
-        if search is not None:
-            out["search"] = search
-        if nucl is not None:
-            out["nucleotide_align"] = nucl
+        pf = {"queries_per_s": round(nq / (H["pf_ms"] * 1e-3), 1),
+              "stage_ms": {"kmers_lists": round(stage[0], 2), "gather_split": round(stage[1], 2), "replay_score_keepmax": round(stage[2], 2),
+                           "large_bins_score": round(stage[3], 2), "large_bins_keepmax_and_overflow_path": round(stage[4], 2),
+                           "select": round(stage[5], 2), "total": round(stage[6], 2)},
+              "ungapped_cells": int(H["pf_cells"]), "double_diagonal_candidates": int(H["pf_cands"]), "prefilter_hits": int(H.get("nhits", 0))}
+        if "ent" in H:
+            ent = H["ent"]
+            alg = 20.0 * ent        # ~20 B per index entry touched
+            ach = alg / (stage[1] * 1e-3) / 1e9 if stage[1] > 0 else 0.0
+            pf.update({"db_matches": int(ent), "similar_kmers": int(H["sim"]), "overflow_queries": int(H["ovf"]),
+                       "roofline": {"kernel": "pf_split_kernel (index gather + stable bin split)", "bound": "hbm",
+                                    "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                                    "traffic": pmc_traffic("pf_split_kernel", PROFILE_ROUND + "_search") if default_wl else None,
+                                    "kernel_ms": round(stage[1], 3), "algorithmic_bytes_per_launch": round(alg),
+                                    "algorithmic_bytes_per_entry": 20}})
+        out["prefilter"] = pf
+        for kname in ("two_call", "backtrace", "pairs_with_start", "inexact_queries", "merged_lists_sorted", "aligned_slots_filled"):
+            if kname in H:
+                out[kname] = H[kname]
+        out["setup_s"] = {"generate": round(H["t_gen"], 1), "score_tables_upload_and_device_index_build": round(H["t_index"], 2)}
+        if H.get("cpu_sw") is not None:
+            out["cpu_baseline"] = H["cpu_sw"]
+        if H.get("cpu_pf") is not None:
+            out["cpu_baseline_prefilter"] = H["cpu_pf"]
+        for kname, v in side.items():
+            if v is not None:
+                out[kname] = v
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     gpu.close()
     if dist is not None:

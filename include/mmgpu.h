@@ -60,6 +60,13 @@ int mmgpu_host_comp_bias(const int16_t *submat, const double *pback, int alphabe
 /* ssw_init's rounding of that bias to int8 (StripedSmithWaterman.cpp:1378-1380) */
 int mmgpu_host_round_comp_bias(const float *bias, uint32_t len, int8_t *out);
 
+/* Length-bucket sharding of the target database over n_shards devices (multi-GPU runs, one process per device): shard_of[i]
+ * and local_id[i] for every target (local ids ascend with the global ids inside a shard), shard_sizes[n_shards], optional
+ * shard_residues[n_shards].  Every shard gets the same length distribution, so residues, index entries and alignment work
+ * balance (the reference balances residues over its target splits, src/commons/DBReader.cpp:1108-1150). */
+int mmgpu_host_partition_targets(const uint64_t *offsets, uint32_t n_targets, uint32_t n_shards, uint32_t *shard_of,
+                                 uint32_t *local_id, uint32_t *shard_sizes, uint64_t *shard_residues);
+
 /* ---- target database ---------------------------------------------------------------------------
  * residues/offsets are SequenceLookup's `data` / `offsets[n+1]` (src/prefiltering/SequenceLookup.h:44-48),
  * or equivalently Sequence::numSequence of every DBReader entry concatenated.  Replaces Marv::loadDb
@@ -128,6 +135,11 @@ int mmgpu_sw_prepare(mmgpu_ctx *ctx, const mmgpu_sw_params *params, const mmgpu_
 struct mmgpu_pf_batch_t;
 int mmgpu_sw_prepare_from_pf(mmgpu_ctx *ctx, const mmgpu_sw_params *params, const mmgpu_sw_query *queries,
                              uint32_t n_queries, int mode, struct mmgpu_pf_batch_t *pf_batch, mmgpu_sw_batch_t **batch);
+/* The same for hit lists in DEVICE memory that did not come from a prefilter batch of this context (multi-GPU runs: the
+ * merged lists, localised by mmgpu_pf_localize_lists): d_hits [n_queries][stride] mmgpu_pf_hit with ids of the resident
+ * targets, d_counts [n_queries] uint32.  The lists are copied during the call. */
+int mmgpu_sw_prepare_from_lists(mmgpu_ctx *ctx, const mmgpu_sw_params *params, const mmgpu_sw_query *queries, uint32_t n_queries,
+                                int mode, const void *d_hits, const void *d_counts, uint32_t stride, mmgpu_sw_batch_t **batch);
 int mmgpu_sw_run(mmgpu_ctx *ctx, mmgpu_sw_batch_t *batch);
 int mmgpu_sw_fetch(mmgpu_ctx *ctx, mmgpu_sw_batch_t *batch, mmgpu_sw_hit *out);
 /* Same results, copied device -> device into caller-owned device memory (the multi-GPU result exchange works on
@@ -323,6 +335,51 @@ int mmgpu_pf_fetch_device(mmgpu_ctx *ctx, mmgpu_pf_batch_t *batch, void *d_hits,
  * maxResListLen per split, Prefiltering.cpp:391-394 - pass that value as max_hits of each split's batch). */
 int mmgpu_pf_merge_splits(mmgpu_ctx *ctx, const void *d_hits, const void *d_counts, uint32_t n_splits, uint32_t n_queries,
                           uint32_t stride, const uint32_t *id_offsets, void *d_out_hits, void *d_out_counts);
+/* ---- multi-GPU runs whose merged result equals the UNSPLIT run (one process per device) ----------
+ * The reference's own target-split mode shortens the per-split lists (Prefiltering.cpp:391-394), which changes the
+ * result against a single-split run; mmgpu_pf_merge_splits above reproduces that mode.  The calls below instead
+ * reproduce the single-split run exactly: a device that holds one shard selects its candidates by the unsplit run's
+ * own total order - 8-bit diagonal score, CacheFriendlyOperations bin of the GLOBAL target id, arrival order (which
+ * similar-k-mer list emitted the element: a function of the query alone, then target id) - and hands them over as
+ * exchange records; after ONE all-gather of the records (RCCL) every device redoes the reference's threshold /
+ * truncation / rescoring / final sort over the union.  Not covered: queries on the databaseHits overflow path
+ * (QueryMatcher.cpp:310-346) - the flush points depend on the size of the database a process holds, so the reference's
+ * own result differs between split and unsplit runs there; such queries are flagged. */
+typedef struct {
+    uint32_t n_shards, shard;         /* this device's shard */
+    uint32_t global_db_size;          /* targets of the whole database */
+    const uint32_t *global_ids;       /* [targets of this shard] local -> global id, ascending */
+    const uint32_t *shard_of;         /* [global_db_size] mmgpu_host_partition_targets */
+    const uint32_t *local_id;         /* [global_db_size] */
+} mmgpu_pf_shard;
+/* after mmgpu_load_targets (which resets it); NULL = the device holds the whole database.  While a shard is set,
+ * mmgpu_pf_prepare batches are exchange batches: max_hits / ref_bins refer to the whole database, the results are read
+ * with mmgpu_pf_fetch_exchange (mmgpu_pf_fetch / mmgpu_sw_prepare_from_pf refuse them). */
+int mmgpu_pf_set_shard(mmgpu_ctx *ctx, const mmgpu_pf_shard *shard);
+typedef struct {
+    uint32_t id;        /* GLOBAL target id */
+    uint32_t score;     /* exact ungapped score of the target's best diagonal */
+    uint16_t diagonal;
+    uint16_t flags;     /* MMGPU_PF_X_* */
+    uint32_t order;     /* ordinal of the emitting similar-k-mer list in the query's list stream */
+} mmgpu_pf_xhit;
+#define MMGPU_PF_X_INEXACT_ORDER 1 /* query on the overflow path in this shard: `order` is not shard independent */
+#define MMGPU_PF_X_IDENTITY 2      /* the element of the query's own target (takes part in the score histogram only) */
+/* device -> device copy of an exchange batch's records: d_xhits [nq][stride] mmgpu_pf_xhit, d_counts [nq] uint32 */
+int mmgpu_pf_fetch_exchange(mmgpu_ctx *ctx, mmgpu_pf_batch_t *batch, void *d_xhits, uint32_t stride, void *d_counts);
+/* d_xhits [n_shards][nq][stride], d_counts [n_shards][nq] (device, all-gathered); `batch` = this device's batch of the
+ * same queries (supplies max_hits, min_diag_score, ref_bins, self scores); identity_global [nq] (host, may be NULL) =
+ * global id of each query's own target (UINT32_MAX none).  d_out_hits [nq][out_stride] mmgpu_pf_hit with GLOBAL ids in
+ * the reference's final order, d_out_counts [nq], d_out_flags [nq] (may be NULL; bit 0: inexact tie order, see above). */
+int mmgpu_pf_merge_exchange(mmgpu_ctx *ctx, mmgpu_pf_batch_t *batch, const void *d_xhits, const void *d_counts, uint32_t n_shards,
+                            uint32_t stride, const uint32_t *identity_global, void *d_out_hits, uint32_t out_stride,
+                            void *d_out_counts, void *d_out_flags);
+/* The part of merged lists (global ids) this device owns, as lists of local ids in list order: d_local_hits [nq][stride],
+ * d_local_counts [nq], d_local_slot [nq][stride] (position of each kept hit in its merged list).  Feeds
+ * mmgpu_sw_prepare_from_lists: every (query, target) pair is aligned on the device that holds the target. */
+int mmgpu_pf_localize_lists(mmgpu_ctx *ctx, const void *d_hits, const void *d_counts, uint32_t n_queries, uint32_t stride,
+                            void *d_local_hits, void *d_local_counts, void *d_local_slot);
+
 /* milliseconds per stage of the last run (HIP events on the context's stream; synchronises):
  * ms[0] similar k-mers + index lists, ms[1] gather + bin split, ms[2] double-diagonal replay + ungapped scoring + best
  * element per target (bins with <= 64 candidates, i.e. nearly all), ms[3] ungapped scoring of larger bins, ms[4] best

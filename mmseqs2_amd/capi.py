@@ -69,6 +69,8 @@ EXPORTED_SYMBOLS = [
     "mmgpu_sw_traceback", "mmgpu_sw_prepare_from_pf", "mmgpu_sw_fetch_device", "mmgpu_nucl_align",
     "mmgpu_host_score_matrix", "mmgpu_host_index_build", "mmgpu_pf_load_index", "mmgpu_pf_batch", "mmgpu_pf_prepare",
     "mmgpu_pf_run", "mmgpu_pf_fetch", "mmgpu_pf_stage_ms", "mmgpu_pf_last_cells", "mmgpu_pf_fetch_device", "mmgpu_pf_merge_splits", "mmgpu_pf_build_index", "mmgpu_pf_debug_index", "mmgpu_pf_debug_fetch", "mmgpu_pf_free",
+    "mmgpu_host_partition_targets", "mmgpu_pf_set_shard", "mmgpu_pf_fetch_exchange", "mmgpu_pf_merge_exchange",
+    "mmgpu_pf_localize_lists", "mmgpu_sw_prepare_from_lists",
 ]
 
 
@@ -88,6 +90,13 @@ class PfQuery(ctypes.Structure):
     _fields_ = [("q", c_p), ("qlen", ctypes.c_uint32), ("comp_bias", c_p), ("identity_id", ctypes.c_uint32)]
 
 
+class PfShard(ctypes.Structure):
+    _fields_ = [("n_shards", ctypes.c_uint32), ("shard", ctypes.c_uint32), ("global_db_size", ctypes.c_uint32),
+                ("global_ids", c_p), ("shard_of", c_p), ("local_id", c_p)]
+
+
+PF_XHIT_DTYPE = np.dtype([("id", np.uint32), ("score", np.uint32), ("diagonal", np.uint16), ("flags", np.uint16),
+                          ("order", np.uint32)])
 PF_HIT_DTYPE = np.dtype([("id", np.uint32), ("score", np.int32), ("diagonal", np.uint16), ("reserved", np.uint16)])
 PF_QSTAT_DTYPE = np.dtype([("db_matches", np.uint64), ("kmer_list_len", np.uint64), ("double_hits", np.uint32),
                            ("diag_thr", np.uint32)])
@@ -144,6 +153,13 @@ def load_library():
     L.mmgpu_pf_debug_fetch.argtypes = [c_p, c_p, ctypes.c_int, c_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
     L.mmgpu_pf_free.argtypes = [c_p, c_p]
     L.mmgpu_pf_free.restype = None
+    L.mmgpu_host_partition_targets.argtypes = [c_p, ctypes.c_uint32, ctypes.c_uint32, c_p, c_p, c_p, c_p]
+    L.mmgpu_pf_set_shard.argtypes = [c_p, ctypes.POINTER(PfShard)]
+    L.mmgpu_pf_fetch_exchange.argtypes = [c_p, c_p, c_p, ctypes.c_uint32, c_p]
+    L.mmgpu_pf_merge_exchange.argtypes = [c_p, c_p, c_p, c_p, ctypes.c_uint32, ctypes.c_uint32, c_p, c_p, ctypes.c_uint32, c_p, c_p]
+    L.mmgpu_pf_localize_lists.argtypes = [c_p, c_p, c_p, ctypes.c_uint32, ctypes.c_uint32, c_p, c_p, c_p]
+    L.mmgpu_sw_prepare_from_lists.argtypes = [c_p, ctypes.POINTER(SwParams), c_p, ctypes.c_uint32, ctypes.c_int, c_p, c_p,
+                                              ctypes.c_uint32, ctypes.POINTER(c_p)]
     return L
 
 
@@ -198,6 +214,32 @@ def host_index_build(residues, offsets, kmer_submat16, k, spaced, kmer_thr, lib=
     return koff, ids[:ne.value], pos[:ne.value]
 
 
+def partition_targets(offsets, n_shards, lib=None):
+    """Length-bucket sharding (mmgpu_host_partition_targets): -> (shard_of[n], local_id[n], shard_sizes[n_shards],
+    shard_residues[n_shards])."""
+    L = lib or load_library()
+    off = np.ascontiguousarray(offsets, np.uint64)
+    n = len(off) - 1
+    shard_of = np.zeros(max(n, 1), np.uint32)
+    local_id = np.zeros(max(n, 1), np.uint32)
+    sizes = np.zeros(n_shards, np.uint32)
+    res = np.zeros(n_shards, np.uint64)
+    if L.mmgpu_host_partition_targets(_ptr(off), n, int(n_shards), _ptr(shard_of), _ptr(local_id), _ptr(sizes), _ptr(res)) != 0:
+        raise MMGpuError(L.mmgpu_last_error().decode())
+    return shard_of[:n], local_id[:n], sizes, res
+
+
+def shard_sequences(residues, offsets, shard_of, shard):
+    """The sequences of one shard, in ascending global id order: -> (residues, offsets, global_ids)."""
+    off = np.asarray(offsets, np.int64)
+    gids = np.nonzero(shard_of == shard)[0].astype(np.uint32)
+    lens = (off[1:] - off[:-1])[gids]
+    soff = np.zeros(len(gids) + 1, np.uint64)
+    soff[1:] = np.cumsum(lens)
+    idx = np.repeat(off[:-1][gids] - soff[:-1].astype(np.int64), lens) + np.arange(int(soff[-1]), dtype=np.int64)
+    return np.ascontiguousarray(residues[idx]), soff, gids
+
+
 class PfBatch:
     """A prepared prefilter batch (queries resident in HBM)."""
 
@@ -221,6 +263,17 @@ class PfBatch:
     def fetch_device(self, d_hits_ptr, stride, d_counts_ptr):
         """D2D copy of the hit lists into caller-owned device memory (raw pointers, e.g. torch tensor.data_ptr())."""
         self.gpu._check(self.gpu.L.mmgpu_pf_fetch_device(self.gpu.ctx, self.handle, c_p(d_hits_ptr), stride, c_p(d_counts_ptr)))
+
+    def fetch_exchange(self, d_xhits_ptr, stride, d_counts_ptr):
+        """sharded run: D2D copy of the exchange records ([nq][stride] PF_XHIT_DTYPE) and their counts"""
+        self.gpu._check(self.gpu.L.mmgpu_pf_fetch_exchange(self.gpu.ctx, self.handle, c_p(d_xhits_ptr), stride, c_p(d_counts_ptr)))
+
+    def merge_exchange(self, d_xhits_ptr, d_counts_ptr, n_shards, stride, identity_global, d_out_hits_ptr, out_stride,
+                       d_out_counts_ptr, d_out_flags_ptr=None):
+        ident = None if identity_global is None else np.ascontiguousarray(identity_global, np.uint32)
+        self.gpu._check(self.gpu.L.mmgpu_pf_merge_exchange(self.gpu.ctx, self.handle, c_p(d_xhits_ptr), c_p(d_counts_ptr), n_shards, stride,
+                                                           _ptr(ident), c_p(d_out_hits_ptr), out_stride, c_p(d_out_counts_ptr),
+                                                           c_p(d_out_flags_ptr) if d_out_flags_ptr else None))
 
     def stage_ms(self):
         ms = (ctypes.c_float * 7)()
@@ -351,6 +404,7 @@ class MMGpu:
         offsets = np.ascontiguousarray(offsets, np.uint64)
         self._check(self.L.mmgpu_load_targets(self.ctx, _ptr(residues), _ptr(offsets), len(offsets) - 1, alphabet))
         self.n_targets = len(offsets) - 1
+        self.global_db_size = None      # mmgpu_load_targets resets the shard description
         self._target_lens = np.diff(offsets.astype(np.int64))
 
     def _marshal(self, mat, gap_open, gap_extend, queries):
@@ -485,7 +539,8 @@ class MMGpu:
         par = PfParams(int(kmer_thr), int(max_hits), int(min_diag_score), int(ref_bins))
         h = c_p()
         self._check(self.L.mmgpu_pf_prepare(self.ctx, ctypes.byref(par), ctypes.cast(arr, c_p), len(queries), ctypes.byref(h)))
-        return PfBatch(self, h, keep, len(queries), min(int(max_hits), self.n_targets))
+        db = getattr(self, "global_db_size", None) or self.n_targets
+        return PfBatch(self, h, keep, len(queries), min(int(max_hits), db))
 
     def pf_batch(self, queries, kmer_thr, max_hits=300, min_diag_score=15, ref_bins=0):
         b = self.pf_prepare(queries, kmer_thr, max_hits, min_diag_score, ref_bins)
@@ -493,6 +548,33 @@ class MMGpu:
         out = b.fetch()
         b.free()
         return out
+
+    def pf_set_shard(self, n_shards, shard, global_db_size, global_ids, shard_of, local_id):
+        """this context holds shard `shard` of a database of global_db_size targets (None-like: pf_clear_shard)"""
+        g = np.ascontiguousarray(global_ids, np.uint32)
+        so = np.ascontiguousarray(shard_of, np.uint32)
+        li = np.ascontiguousarray(local_id, np.uint32)
+        sh = PfShard(int(n_shards), int(shard), int(global_db_size), _ptr(g), _ptr(so), _ptr(li))
+        self._check(self.L.mmgpu_pf_set_shard(self.ctx, ctypes.byref(sh)))
+        self.global_db_size = int(global_db_size)
+
+    def pf_clear_shard(self):
+        self._check(self.L.mmgpu_pf_set_shard(self.ctx, None))
+        self.global_db_size = None
+
+    def pf_localize_lists(self, d_hits_ptr, d_counts_ptr, nq, stride, d_local_hits_ptr, d_local_counts_ptr, d_local_slot_ptr):
+        self._check(self.L.mmgpu_pf_localize_lists(self.ctx, c_p(d_hits_ptr), c_p(d_counts_ptr), nq, stride, c_p(d_local_hits_ptr),
+                                                   c_p(d_local_counts_ptr), c_p(d_local_slot_ptr)))
+
+    def sw_prepare_from_lists(self, mat, gap_open, gap_extend, queries, d_hits_ptr, d_counts_ptr, stride, mode=1, marshalled=None):
+        """Alignment batch over device-resident lists of LOCAL target ids ([nq][stride] PF_HIT_DTYPE + counts)."""
+        par, arr, keep, n = marshalled if marshalled is not None else self.sw_marshal_queries(mat, gap_open, gap_extend, queries)
+        h = c_p()
+        self._check(self.L.mmgpu_sw_prepare_from_lists(self.ctx, ctypes.byref(par), ctypes.cast(arr, c_p), n, mode, c_p(d_hits_ptr),
+                                                       c_p(d_counts_ptr), stride, ctypes.byref(h)))
+        b = SwBatch(self, h, keep)
+        b.slots = n * stride
+        return b
 
     def pf_merge_splits(self, d_hits_ptr, d_counts_ptr, n_splits, nq, stride, id_offsets, d_out_hits_ptr, d_out_counts_ptr):
         off = np.ascontiguousarray(id_offsets, np.uint32)
@@ -519,3 +601,80 @@ def merge_hit_lists_host(lists, id_offsets):
     allh = np.concatenate(parts) if parts else np.zeros(0, PF_HIT_DTYPE)
     order = np.lexsort((allh["id"], -np.abs(allh["score"].astype(np.int64))))
     return allh[order]
+
+
+def merge_exchange_host(records, max_hits, min_diag_score, ref_bins, self_score, identity_global=None):
+    """Host mirror of mmgpu_pf_merge_exchange for one query (CPU tests of the multi-GPU path, never a fallback):
+    records = PF_XHIT_DTYPE array, the concatenation of every shard's exchange list -> PF_HIT_DTYPE list (global ids) in
+    the reference's final order.  Follows pf_xmerge_kernel step by step (QueryMatcher.cpp:161-241, 401-458, 563-586)."""
+    r = np.asarray(records)
+    cnt = np.minimum(r["score"], 255).astype(np.int64)
+    hist = np.bincount(cnt, minlength=256)
+    found, thr = 0, 0
+    for thr in range(255, 0, -1):
+        found += int(hist[thr])
+        if found >= max_hits:
+            break
+    else:
+        thr = 0
+    dthr = max(int(min_diag_score), thr)
+    trunc = dthr >= 255
+    ms = min(max(int(self_score) - 255, 1), 65535)
+    ident = 0xFFFFFFFF if identity_global is None else int(identity_global)
+    if trunc:
+        ns = np.minimum(r["score"].astype(np.int64) - 255, 65535).astype(np.float32)
+        resc = ((ns / np.float32(ms)) * np.float32(255.0)).astype(np.float32).astype(np.float64) + 0.5
+        kc = resc.astype(np.int64) & 0xFF
+        elig = (cnt >= 255) & (r["id"] != ident)
+    else:
+        kc = cnt
+        elig = (cnt >= dthr) & (r["id"] != ident)
+    idx = np.nonzero(elig)[0]
+    key_a = ((255 - kc[idx]) << 11) | (r["id"][idx].astype(np.int64) & (ref_bins - 1))
+    order = np.lexsort((r["id"][idx], r["order"][idx], key_a))
+    has_ident = 1 if ident != 0xFFFFFFFF else 0
+    want = max(max_hits - has_ident, 0)
+    sel = idx[order][:want]
+    if trunc:
+        pref = 255 + (kc[sel] * ms) // 255
+    else:
+        pref = np.where(cnt[sel] >= 255, r["score"][sel].astype(np.int64), cnt[sel])
+    out = np.zeros(len(sel) + (has_ident if max_hits > 0 else 0), PF_HIT_DTYPE)
+    fin = np.lexsort((r["id"][sel], -pref))
+    o = has_ident if max_hits > 0 else 0
+    out["id"][o:] = r["id"][sel][fin]
+    out["score"][o:] = pref[fin]
+    out["diagonal"][o:] = r["diagonal"][sel][fin]
+    if has_ident and max_hits > 0:
+        out[0] = (ident, 65535, 0, 0)
+    return out
+
+
+def select_exchange_host(records, max_hits, min_diag_score, ref_bins, self_score):
+    """Host mirror of the shard-side selection (pf_select_kernel<true>) for one query: records = PF_XHIT_DTYPE array of
+    ALL surviving elements of the shard (one per target) -> the shard's exchange list: its top max_hits by the unsplit
+    run's order, the mode (truncated threshold or not) decided from the shard's own histogram."""
+    r = np.asarray(records)
+    cnt = np.minimum(r["score"], 255).astype(np.int64)
+    hist = np.bincount(cnt, minlength=256)
+    found, thr = 0, 0
+    for thr in range(255, 0, -1):
+        found += int(hist[thr])
+        if found >= max_hits:
+            break
+    else:
+        thr = 0
+    dthr = max(int(min_diag_score), thr)
+    ms = min(max(int(self_score) - 255, 1), 65535)
+    if dthr >= 255:
+        ns = np.minimum(r["score"].astype(np.int64) - 255, 65535).astype(np.float32)
+        resc = ((ns / np.float32(ms)) * np.float32(255.0)).astype(np.float32).astype(np.float64) + 0.5
+        kc = resc.astype(np.int64) & 0xFF
+        elig = cnt >= 255
+    else:
+        kc = cnt
+        elig = cnt >= dthr
+    idx = np.nonzero(elig)[0]
+    key_a = ((255 - kc[idx]) << 11) | (r["id"][idx].astype(np.int64) & (ref_bins - 1))
+    order = np.lexsort((r["id"][idx], r["order"][idx], key_a))
+    return r[idx[order][:max_hits]]

@@ -85,6 +85,7 @@ extern "C" int mmgpu_load_targets(mmgpu_ctx *c, const uint8_t *residues, const u
     HIP_TRY(hipSetDevice(c->device));
     // a resident prefilter index belongs to the database it was built / loaded for: it goes with it
     mmgpu::pf_index_free(c);
+    c->shard.on = false;
     free_db(c->db);
     std::vector<uint32_t> off4(std::max<uint32_t>(n, 1)), len(std::max<uint32_t>(n, 1));
     uint64_t cur4 = 0;
@@ -154,6 +155,44 @@ extern "C" int mmgpu_host_comp_bias(const int16_t *submat, const double *pback, 
     return MMGPU_OK;
 }
 
+// Length-bucket sharding of a target database over n_shards devices (the reference balances
+// residues over its splits, DBReader::decomposeDomainByAminoAcid, src/commons/DBReader.cpp:1108-1150, and libmarv deals
+// length partitions to devices).  Targets are binned by length (boundaries below), the bins are walked from the longest
+// to the shortest and their members dealt round-robin, the deal continuing from bin to bin: every shard receives the same
+// length distribution (+-1 sequence per bin) and therefore the same number of residues, index entries and alignment
+// cells to within a fraction of a percent.  Inside a shard the local ids follow the global ids (ascending), so that
+// "same score -> smaller id first" orders of the shard and of the whole database agree.
+extern "C" int mmgpu_host_partition_targets(const uint64_t *offsets, uint32_t n, uint32_t n_shards, uint32_t *shard_of,
+                                            uint32_t *local_id, uint32_t *shard_sizes, uint64_t *shard_residues) {
+    if (!offsets || !shard_of || !local_id || !shard_sizes || n_shards == 0) return fail(MMGPU_ERR_ARG, "mmgpu_host_partition_targets: bad argument");
+    static const uint32_t bound[] = {32, 64, 96, 128, 160, 192, 224, 256, 288, 320, 352, 384, 448, 512, 576, 640, 768, 896, 1024,
+                                     1280, 1536, 2048, 2560, 3072, 4096, 6144, 8192, 12288, 16384, 24576, 32768, 49152, 65536};
+    const int nb = (int)(sizeof(bound) / sizeof(bound[0]));
+    std::vector<uint8_t> bin(n);
+    for (uint32_t i = 0; i < n; i++) {
+        const uint64_t len = offsets[i + 1] - offsets[i];
+        int b = 0;
+        while (b < nb - 1 && len > bound[b]) b++;
+        bin[i] = (uint8_t)b;
+    }
+    uint32_t next = 0;
+    for (int b = nb - 1; b >= 0; b--)
+        for (uint32_t i = 0; i < n; i++)
+            if (bin[i] == b) {
+                shard_of[i] = next;
+                next = next + 1 == n_shards ? 0 : next + 1;
+            }
+    for (uint32_t s = 0; s < n_shards; s++) {
+        shard_sizes[s] = 0;
+        if (shard_residues) shard_residues[s] = 0;
+    }
+    for (uint32_t i = 0; i < n; i++) {
+        local_id[i] = shard_sizes[shard_of[i]]++;
+        if (shard_residues) shard_residues[shard_of[i]] += offsets[i + 1] - offsets[i];
+    }
+    return MMGPU_OK;
+}
+
 extern "C" int mmgpu_host_round_comp_bias(const float *bias, uint32_t len, int8_t *out) {
     if ((!bias || !out) && len) return fail(MMGPU_ERR_ARG, "mmgpu_host_round_comp_bias: NULL argument");
     for (uint32_t i = 0; i < len; i++) out[i] = (int8_t)((bias[i] < 0.0f) ? bias[i] - 0.5 : bias[i] + 0.5);
@@ -219,15 +258,23 @@ static uint32_t job_slots(uint32_t round, uint64_t rounds) {
     return slots >= 16 ? 16u : round;
 }
 
+// device-resident hit lists an alignment batch is built from (the fused hand-over and the multi-GPU path)
+struct DeviceLists {
+    const mmgpu_pf_hit *hits = nullptr;
+    const uint32_t *counts = nullptr;
+    uint32_t stride = 0;
+};
+
 static int sw_prepare_impl(mmgpu_ctx *c, const mmgpu_sw_params *par, const mmgpu_sw_query *qs, uint32_t nq, int mode,
-                           mmgpu_pf_batch_t *pf, mmgpu_sw_batch_t **out) {
+                           const DeviceLists *pf, mmgpu_sw_batch_t **out) {
     if (!c || !par || !out || (!qs && nq)) return fail(MMGPU_ERR_ARG, "mmgpu_sw_prepare: NULL argument");
     const mmgpu_pf_hit *pf_hits = nullptr;
     const uint32_t *pf_counts = nullptr;
-    uint32_t pf_stride = 0, pf_nq = 0;
+    uint32_t pf_stride = 0;
     if (pf) {
-        if (!pf_batch_device_lists(pf, &pf_hits, &pf_counts, &pf_stride, &pf_nq)) return fail(MMGPU_ERR_STATE, "mmgpu_sw_prepare_from_pf: the prefilter batch was never run");
-        if (pf_nq != nq) return fail(MMGPU_ERR_ARG, "mmgpu_sw_prepare_from_pf: query count differs from the prefilter batch");
+        pf_hits = pf->hits;
+        pf_counts = pf->counts;
+        pf_stride = pf->stride;
         if (pf_stride > (uint32_t)SW_PF_MAX_LIST) return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_sw_prepare_from_pf: lists longer than 4096");
     }
     if (!c->db.res) return fail(MMGPU_ERR_STATE, "mmgpu_sw_prepare: no targets loaded");
@@ -469,7 +516,23 @@ extern "C" int mmgpu_sw_prepare(mmgpu_ctx *c, const mmgpu_sw_params *par, const 
 extern "C" int mmgpu_sw_prepare_from_pf(mmgpu_ctx *c, const mmgpu_sw_params *par, const mmgpu_sw_query *qs, uint32_t nq,
                                         int mode, mmgpu_pf_batch_t *pf, mmgpu_sw_batch_t **out) {
     if (!pf) return fail(MMGPU_ERR_ARG, "mmgpu_sw_prepare_from_pf: NULL prefilter batch");
-    return sw_prepare_impl(c, par, qs, nq, mode, pf, out);
+    DeviceLists L;
+    uint32_t pf_nq = 0;
+    if (!pf_batch_device_lists(pf, &L.hits, &L.counts, &L.stride, &pf_nq))
+        return fail(MMGPU_ERR_STATE, "mmgpu_sw_prepare_from_pf: the prefilter batch was never run, or is an exchange batch of a sharded run");
+    if (pf_nq != nq) return fail(MMGPU_ERR_ARG, "mmgpu_sw_prepare_from_pf: query count differs from the prefilter batch");
+    return sw_prepare_impl(c, par, qs, nq, mode, &L, out);
+}
+
+extern "C" int mmgpu_sw_prepare_from_lists(mmgpu_ctx *c, const mmgpu_sw_params *par, const mmgpu_sw_query *qs, uint32_t nq, int mode,
+                                           const void *d_hits, const void *d_counts, uint32_t stride, mmgpu_sw_batch_t **out) {
+    if ((!d_hits || !d_counts) && nq) return fail(MMGPU_ERR_ARG, "mmgpu_sw_prepare_from_lists: NULL list pointers");
+    if (stride == 0) return fail(MMGPU_ERR_ARG, "mmgpu_sw_prepare_from_lists: stride must be >= 1");
+    DeviceLists L;
+    L.hits = (const mmgpu_pf_hit *)d_hits;
+    L.counts = (const uint32_t *)d_counts;
+    L.stride = stride;
+    return sw_prepare_impl(c, par, qs, nq, mode, &L, out);
 }
 
 extern "C" int mmgpu_sw_run(mmgpu_ctx *c, mmgpu_sw_batch_t *b) {

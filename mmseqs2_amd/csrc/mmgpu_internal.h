@@ -206,7 +206,40 @@ struct PfSelectArgs {
     mmgpu_pf_hit *hits;
     uint32_t hit_stride;
     uint32_t *hit_count, *q_diag_thr;
+    // shard of a multi-GPU run (mmgpu_pf_set_shard): exchange records instead of hit lists
+    mmgpu_pf_xhit *xhits;             // null = ordinary run
+    const uint32_t *global_ids;       // [n_targets] local -> global id
+    const uint32_t *q_nseg;           // overflow-path queries (their order key is not shard independent), may be null
+    const uint32_t *q_off, *peb, *list_base;
+    const PfList *lists;
 };
+
+// ---- multi-GPU merge (pf_shard_kernels.hip)
+constexpr int PF_XMERGE_CAP = 4096;    // exchange records per query (n_shards * stride) the merge kernel holds in LDS
+struct PfXMergeArgs {
+    const mmgpu_pf_xhit *xhits;       // [n_shards][nq][stride]
+    const uint32_t *counts;           // [n_shards][nq]
+    uint32_t n_shards, nq, stride;
+    uint32_t max_hits, min_diag_score, ref_bins;
+    const int32_t *q_self_score;      // [nq]
+    const uint32_t *q_identity;       // [nq] GLOBAL id of the self hit, 0xFFFFFFFF = none
+    mmgpu_pf_hit *out_hits;           // [nq][out_stride]
+    uint32_t out_stride;
+    uint32_t *out_counts;             // [nq]
+    uint32_t *out_flags;              // [nq] bit 0: an overflow-path element took part (tie order at the cut not exact)
+};
+hipError_t launch_pf_xmerge(const PfXMergeArgs &A, hipStream_t s);
+
+struct PfLocalizeArgs {
+    const mmgpu_pf_hit *hits;         // [nq][stride] global ids
+    const uint32_t *counts;
+    uint32_t nq, stride, shard;
+    const uint32_t *shard_of, *local_id;   // [global_db_size]
+    mmgpu_pf_hit *local_hits;         // [nq][stride] local ids, list order kept
+    uint32_t *local_counts;
+    uint32_t *local_slot;             // [nq][stride] position of the hit in the query's merged list
+};
+hipError_t launch_pf_localize(const PfLocalizeArgs &A, hipStream_t s);
 
 constexpr int PF_MAX_SEG = 62;         // databaseHits flushes per query the device emulates (QueryMatcher.cpp:310-346)
 
@@ -442,6 +475,12 @@ struct mmgpu_ctx {
     int compute_units = 0;
     std::string name;
     mmgpu::PfIndex *pf = nullptr;  // prefilter index resident in HBM (pf_api.hip)
+    // shard of a multi-GPU run (mmgpu_pf_set_shard); reset by mmgpu_load_targets
+    struct Shard {
+        bool on = false;
+        uint32_t n_shards = 1, shard = 0, global_n = 0;
+        mmgpu::DevBuf d_global_ids, d_shard_of, d_local_id;
+    } shard;
     std::shared_ptr<mmgpu::BlockCache> cache = std::make_shared<mmgpu::BlockCache>();   // device blocks of freed alignment batches
     // the alignment kernel groups run concurrently on side streams forked from / joined to `stream` (mmgpu_sw_run)
     hipStream_t side[3] = {nullptr, nullptr, nullptr};

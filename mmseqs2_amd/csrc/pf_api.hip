@@ -472,6 +472,7 @@ struct mmgpu_pf_batch_t {
     DevBuf d_qtile_base, d_qntiles, d_bucket_count, d_bucket_off;
     DevBuf d_ovf_queries, d_qnseg, d_seg_start, d_qfinal, d_ovf_base, d_ovf_a, d_ovf_b, d_ovf_ocount, d_ovf_totals;
     DevBuf d_cand_small, d_cand_base, d_cand_count, d_cells, d_surv_count, d_hits, d_hit_count, d_diag_thr;
+    bool exchange = false;     // prepared while a shard was set (mmgpu_pf_set_shard): d_hits holds mmgpu_pf_xhit records
     // host mirrors of the last run
     std::vector<uint64_t> q_lists, q_entries;
     std::vector<int32_t> status;
@@ -484,7 +485,7 @@ struct mmgpu_pf_batch_t {
 
 namespace mmgpu {
 bool pf_batch_device_lists(mmgpu_pf_batch_t *b, const mmgpu_pf_hit **hits, const uint32_t **counts, uint32_t *stride, uint32_t *nq) {
-    if (!b || !b->ran) return false;
+    if (!b || !b->ran || b->exchange) return false;
     *hits = b->d_hits.as<mmgpu_pf_hit>();
     *counts = b->d_hit_count.as<uint32_t>();
     *stride = b->max_hits;
@@ -512,7 +513,10 @@ extern "C" int mmgpu_pf_prepare(mmgpu_ctx *c, const mmgpu_pf_params *par, const 
     if (par->min_diag_score < 1) return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_pf_prepare: min_diag_score must be >= 1");
     if (par->max_hits < 1) return fail(MMGPU_ERR_ARG, "mmgpu_pf_prepare: max_hits must be >= 1");
     const PfIndex &P = *c->pf;
-    const uint32_t max_hits = (uint32_t)std::min<uint64_t>(par->max_hits, c->db.n);
+    // a shard of a multi-GPU run answers for the whole database: list length and cache bins as in the unsplit run
+    const bool exchange = c->shard.on;
+    const uint64_t db_size = exchange ? c->shard.global_n : c->db.n;
+    const uint32_t max_hits = (uint32_t)std::min<uint64_t>(par->max_hits, db_size);
     if (max_hits > PF_MAX_HITS) return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_pf_prepare: max_hits above 4096 is not implemented");
     if (par->ref_bins && (par->ref_bins < 2 || par->ref_bins > 2048 || (par->ref_bins & (par->ref_bins - 1))))
         return fail(MMGPU_ERR_ARG, "mmgpu_pf_prepare: ref_bins must be a power of two in [2, 2048]");
@@ -526,7 +530,8 @@ extern "C" int mmgpu_pf_prepare(mmgpu_ctx *c, const mmgpu_pf_params *par, const 
     b->nq = nq;
     b->max_hits = max_hits;
     b->bins = bins;
-    b->ref_bins = par->ref_bins ? par->ref_bins : reference_bins(c->db.n);
+    b->ref_bins = par->ref_bins ? par->ref_bins : reference_bins(db_size);
+    b->exchange = exchange;
     b->max_db_matches = std::max<uint64_t>(1000000, c->db.n) * 2;   // QueryMatcher.cpp:44-45
     b->q_off.assign(nq + 1, 0);
     uint64_t tot = 0;
@@ -610,7 +615,7 @@ extern "C" int mmgpu_pf_prepare(mmgpu_ctx *c, const mmgpu_pf_params *par, const 
     B_TRY(b->d_cand_small.alloc((size_t)nqq * bins * PF_CAND0 * sizeof(PfCand)));
     B_TRY(b->d_cells.alloc((size_t)nqq * 8));
     B_TRY(b->d_surv_count.alloc(nqq * 4));
-    B_TRY(b->d_hits.alloc((size_t)nqq * max_hits * sizeof(mmgpu_pf_hit)));
+    B_TRY(b->d_hits.alloc((size_t)nqq * max_hits * (exchange ? sizeof(mmgpu_pf_xhit) : sizeof(mmgpu_pf_hit))));
     B_TRY(b->d_hit_count.alloc(nqq * 4));
     B_TRY(b->d_diag_thr.alloc(nqq * 4));
     for (auto &e : b->ev) B_TRY(hipEventCreate(&e));
@@ -871,6 +876,22 @@ extern "C" int mmgpu_pf_run(mmgpu_ctx *c, mmgpu_pf_batch_t *b) {
     S.q_diag_thr = b->d_diag_thr.as<uint32_t>();
     S.cand_base = b->d_cand_base.as<uint32_t>();
     S.bins = B;
+    S.xhits = nullptr;
+    S.global_ids = nullptr;
+    S.q_nseg = nullptr;
+    S.q_off = S.peb = S.list_base = nullptr;
+    S.lists = nullptr;
+    if (b->exchange) {
+        if (!c->shard.on) return fail(MMGPU_ERR_STATE, "mmgpu_pf_run: the batch was prepared for a sharded run, but no shard is set");
+        S.xhits = b->d_hits.as<mmgpu_pf_xhit>();
+        S.hits = nullptr;
+        S.global_ids = c->shard.d_global_ids.as<uint32_t>();
+        S.q_nseg = ovf_q.empty() ? nullptr : b->d_qnseg.as<uint32_t>();
+        S.q_off = b->d_qoff.as<uint32_t>();
+        S.peb = b->d_peb.as<uint32_t>();
+        S.list_base = b->d_list_base.as<uint32_t>();
+        S.lists = P.w_lists.as<PfList>();
+    }
     HIP_TRY(launch_pf_select(S, nq, s));
     HIP_TRY(hipEventRecord(b->ev[4], s));
     b->ran = true;
@@ -881,6 +902,7 @@ extern "C" int mmgpu_pf_fetch(mmgpu_ctx *c, mmgpu_pf_batch_t *b, mmgpu_pf_hit *h
                               int32_t *status, mmgpu_pf_qstat *stats) {
     if (!c || !b || ((!hits || !counts) && b->nq)) return fail(MMGPU_ERR_ARG, "mmgpu_pf_fetch: NULL argument");
     if (!b->ran) return fail(MMGPU_ERR_STATE, "mmgpu_pf_fetch: batch was never run");
+    if (b->exchange) return fail(MMGPU_ERR_STATE, "mmgpu_pf_fetch: exchange batch of a sharded run (use mmgpu_pf_fetch_exchange + mmgpu_pf_merge_exchange)");
     if (hit_stride < b->max_hits) return fail(MMGPU_ERR_ARG, "mmgpu_pf_fetch: hit_stride smaller than min(max_hits, dbSize)");
     const uint32_t nq = b->nq;
     if (nq == 0) return MMGPU_OK;
@@ -909,6 +931,7 @@ extern "C" int mmgpu_pf_fetch(mmgpu_ctx *c, mmgpu_pf_batch_t *b, mmgpu_pf_hit *h
 extern "C" int mmgpu_pf_fetch_device(mmgpu_ctx *c, mmgpu_pf_batch_t *b, void *d_hits, uint32_t hit_stride, void *d_counts) {
     if (!c || !b || ((!d_hits || !d_counts) && b->nq)) return fail(MMGPU_ERR_ARG, "mmgpu_pf_fetch_device: NULL argument");
     if (!b->ran) return fail(MMGPU_ERR_STATE, "mmgpu_pf_fetch_device: batch was never run");
+    if (b->exchange) return fail(MMGPU_ERR_STATE, "mmgpu_pf_fetch_device: exchange batch of a sharded run (use mmgpu_pf_fetch_exchange)");
     if (hit_stride < b->max_hits) return fail(MMGPU_ERR_ARG, "mmgpu_pf_fetch_device: hit_stride smaller than min(max_hits, dbSize)");
     if (b->nq == 0) return MMGPU_OK;
     HIP_TRY(hipSetDevice(c->device));
@@ -936,6 +959,103 @@ extern "C" int mmgpu_pf_merge_splits(mmgpu_ctx *c, const void *d_hits, const voi
     A.out_hits = (mmgpu_pf_hit *)d_out_hits;
     A.out_counts = (uint32_t *)d_out_counts;
     HIP_TRY(launch_pf_merge(A, c->stream));
+    return MMGPU_OK;
+}
+
+// ---- multi-GPU runs equal to the unsplit run (see include/mmgpu.h) ----
+extern "C" int mmgpu_pf_set_shard(mmgpu_ctx *c, const mmgpu_pf_shard *sh) {
+    if (!c) return fail(MMGPU_ERR_ARG, "mmgpu_pf_set_shard: NULL context");
+    if (!sh) { c->shard.on = false; return MMGPU_OK; }
+    if (!c->db.res) return fail(MMGPU_ERR_STATE, "mmgpu_pf_set_shard: no targets loaded");
+    if (!sh->global_ids || !sh->shard_of || !sh->local_id || sh->n_shards < 1 || sh->n_shards > 64 || sh->shard >= sh->n_shards ||
+        sh->global_db_size < c->db.n)
+        return fail(MMGPU_ERR_ARG, "mmgpu_pf_set_shard: bad shard description");
+    for (uint32_t i = 0; i < c->db.n; i++) {
+        const uint32_t g = sh->global_ids[i];
+        if (g >= sh->global_db_size || (i && g <= sh->global_ids[i - 1]) || sh->shard_of[g] != sh->shard || sh->local_id[g] != i)
+            return fail(MMGPU_ERR_ARG, "mmgpu_pf_set_shard: global_ids must ascend and agree with shard_of / local_id");
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(c->shard.d_global_ids.alloc(std::max<size_t>(c->db.n, 1) * 4));
+    HIP_TRY(c->shard.d_shard_of.alloc((size_t)sh->global_db_size * 4));
+    HIP_TRY(c->shard.d_local_id.alloc((size_t)sh->global_db_size * 4));
+    HIP_TRY(hipMemcpy(c->shard.d_global_ids.p, sh->global_ids, (size_t)c->db.n * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->shard.d_shard_of.p, sh->shard_of, (size_t)sh->global_db_size * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->shard.d_local_id.p, sh->local_id, (size_t)sh->global_db_size * 4, hipMemcpyHostToDevice));
+    c->shard.n_shards = sh->n_shards;
+    c->shard.shard = sh->shard;
+    c->shard.global_n = sh->global_db_size;
+    c->shard.on = true;
+    return MMGPU_OK;
+}
+
+extern "C" int mmgpu_pf_fetch_exchange(mmgpu_ctx *c, mmgpu_pf_batch_t *b, void *d_xhits, uint32_t stride, void *d_counts) {
+    if (!c || !b || ((!d_xhits || !d_counts) && b->nq)) return fail(MMGPU_ERR_ARG, "mmgpu_pf_fetch_exchange: NULL argument");
+    if (!b->ran || !b->exchange) return fail(MMGPU_ERR_STATE, "mmgpu_pf_fetch_exchange: not an exchange batch that has been run");
+    if (stride < b->max_hits) return fail(MMGPU_ERR_ARG, "mmgpu_pf_fetch_exchange: stride smaller than min(max_hits, dbSize)");
+    if (b->nq == 0) return MMGPU_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpy2DAsync(d_xhits, (size_t)stride * sizeof(mmgpu_pf_xhit), b->d_hits.p, (size_t)b->max_hits * sizeof(mmgpu_pf_xhit),
+                             (size_t)b->max_hits * sizeof(mmgpu_pf_xhit), b->nq, hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(d_counts, b->d_hit_count.p, (size_t)b->nq * 4, hipMemcpyDeviceToDevice, c->stream));
+    return MMGPU_OK;
+}
+
+extern "C" int mmgpu_pf_merge_exchange(mmgpu_ctx *c, mmgpu_pf_batch_t *b, const void *d_xhits, const void *d_counts, uint32_t n_shards,
+                                       uint32_t stride, const uint32_t *identity_global, void *d_out_hits, uint32_t out_stride,
+                                       void *d_out_counts, void *d_out_flags) {
+    if (!c || !b || ((!d_xhits || !d_counts || !d_out_hits || !d_out_counts) && b->nq))
+        return fail(MMGPU_ERR_ARG, "mmgpu_pf_merge_exchange: NULL argument");
+    if (!b->exchange) return fail(MMGPU_ERR_STATE, "mmgpu_pf_merge_exchange: `batch` must be this device's exchange batch of the same queries");
+    if (n_shards < 1 || n_shards > 64) return fail(MMGPU_ERR_ARG, "mmgpu_pf_merge_exchange: n_shards must be in [1, 64]");
+    if ((uint64_t)n_shards * stride > PF_XMERGE_CAP) return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_pf_merge_exchange: more than 4096 records per query");
+    if (out_stride < b->max_hits) return fail(MMGPU_ERR_ARG, "mmgpu_pf_merge_exchange: out_stride smaller than min(max_hits, dbSize)");
+    if (b->nq == 0) return MMGPU_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    std::vector<uint32_t> ident(b->nq, 0xFFFFFFFFu);
+    if (identity_global) ident.assign(identity_global, identity_global + b->nq);
+    // the batch's identity buffer holds the LOCAL id for the select kernel; the merge wants the global one
+    DevBuf d_ident;
+    HIP_TRY(d_ident.alloc((size_t)b->nq * 4));
+    HIP_TRY(hipMemcpyAsync(d_ident.p, ident.data(), (size_t)b->nq * 4, hipMemcpyHostToDevice, c->stream));
+    PfXMergeArgs A;
+    A.xhits = (const mmgpu_pf_xhit *)d_xhits;
+    A.counts = (const uint32_t *)d_counts;
+    A.n_shards = n_shards;
+    A.nq = b->nq;
+    A.stride = stride;
+    A.max_hits = b->max_hits;
+    A.min_diag_score = b->par.min_diag_score;
+    A.ref_bins = b->ref_bins;
+    A.q_self_score = b->d_qself.as<int32_t>();
+    A.q_identity = d_ident.as<uint32_t>();
+    A.out_hits = (mmgpu_pf_hit *)d_out_hits;
+    A.out_stride = out_stride;
+    A.out_counts = (uint32_t *)d_out_counts;
+    A.out_flags = (uint32_t *)d_out_flags;
+    HIP_TRY(launch_pf_xmerge(A, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));   // `ident` (pageable) and d_ident die with this scope
+    return MMGPU_OK;
+}
+
+extern "C" int mmgpu_pf_localize_lists(mmgpu_ctx *c, const void *d_hits, const void *d_counts, uint32_t nq, uint32_t stride,
+                                       void *d_local_hits, void *d_local_counts, void *d_local_slot) {
+    if (!c || ((!d_hits || !d_counts || !d_local_hits || !d_local_counts || !d_local_slot) && nq))
+        return fail(MMGPU_ERR_ARG, "mmgpu_pf_localize_lists: NULL argument");
+    if (!c->shard.on) return fail(MMGPU_ERR_STATE, "mmgpu_pf_localize_lists: no shard set (mmgpu_pf_set_shard)");
+    HIP_TRY(hipSetDevice(c->device));
+    PfLocalizeArgs A;
+    A.hits = (const mmgpu_pf_hit *)d_hits;
+    A.counts = (const uint32_t *)d_counts;
+    A.nq = nq;
+    A.stride = stride;
+    A.shard = c->shard.shard;
+    A.shard_of = c->shard.d_shard_of.as<uint32_t>();
+    A.local_id = c->shard.d_local_id.as<uint32_t>();
+    A.local_hits = (mmgpu_pf_hit *)d_local_hits;
+    A.local_counts = (uint32_t *)d_local_counts;
+    A.local_slot = (uint32_t *)d_local_slot;
+    HIP_TRY(launch_pf_localize(A, c->stream));
     return MMGPU_OK;
 }
 

@@ -1215,6 +1215,32 @@ __device__ __forceinline__ uint32_t rescaled_count(uint32_t score, float fms) {
     return (uint32_t)(int)dd & 0xFFu;
 }
 
+// Ordinal, in the query's stream of similar-k-mer lists, of the list that holds arrival index `arr`: the part of the
+// CPU's arrival order that does not depend on which targets a shard holds (windows and their similar k-mers are a
+// function of the query alone), used to order elements of different shards of a multi-GPU run (pf_shard_kernels.hip).
+__device__ uint32_t list_ordinal(const PfSelectArgs &A, uint32_t q, uint32_t arr) {
+    const uint32_t p0 = A.q_off[q], p1 = A.q_off[q + 1];
+    uint32_t lo = p0, hi = p1 - 1;            // largest window p with peb[p] <= arr
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi + 1) >> 1;
+        if (A.peb[mid] <= arr) lo = mid; else hi = mid - 1;
+    }
+    const uint32_t rel = arr - A.peb[lo];
+    uint32_t a = A.list_base[lo], b = A.list_base[lo + 1];
+    if (b <= a) return a - A.list_base[p0];
+    b -= 1;                                    // largest record r of the window with lprefix <= rel
+    while (a < b) {
+        const uint32_t mid = (a + b + 1) >> 1;
+        if (A.lists[mid].lprefix <= rel) a = mid; else b = mid - 1;
+    }
+    return a - A.list_base[p0];
+}
+
+// XCHG = false: the query's final hit list (QueryMatcher::matchQuery's result).
+// XCHG = true : this device holds one shard of the database (mmgpu_pf_set_shard): the top max_hits elements by the
+//               unsplit run's own order - count, the reference's cache bin of the GLOBAL id, arrival order - as exchange
+//               records for pf_merge_exchange_kernel, which redoes threshold / truncation / final scores over all shards.
+template <bool XCHG>
 __global__ __launch_bounds__(256) void pf_select_kernel(PfSelectArgs A) {
     __shared__ uint32_t hist[256];
     __shared__ uint32_t sh_thr, sh_trunc, sh_nelig, sh_nsel;
@@ -1268,7 +1294,9 @@ __global__ __launch_bounds__(256) void pf_select_kernel(PfSelectArgs A) {
         }
         // order inside the CPU's array: arrival index (ordinary queries) or the 48-bit merge key of the overflow path
         const uint64_t ord = ((uint64_t)c.pad << 32) | (uint64_t)c.arr;
-        return ((uint64_t)(255u - kc) << 56) | ((uint64_t)(c.id & refmask) << 45) | (ord & ((1ull << 45) - 1));
+        const uint32_t gid = XCHG ? A.global_ids[c.id] : c.id;
+        if (XCHG) *elig = trunc ? cnt >= 255u : cnt >= dthr;   // the self hit's element takes part (see the merge kernel)
+        return ((uint64_t)(255u - kc) << 56) | ((uint64_t)(gid & refmask) << 45) | (ord & ((1ull << 45) - 1));
     };
 
     uint32_t mine = 0;
@@ -1280,7 +1308,7 @@ __global__ __launch_bounds__(256) void pf_select_kernel(PfSelectArgs A) {
     if (mine) atomicAdd(&sh_nelig, mine);
     __syncthreads();
     const uint32_t nelig = sh_nelig;
-    const uint32_t has_ident = ident != 0xFFFFFFFFu ? 1u : 0u;
+    const uint32_t has_ident = (!XCHG && ident != 0xFFFFFFFFu) ? 1u : 0u;
     const uint32_t want = max_hits > has_ident ? max_hits - has_ident : 0u;
 
     // radix select of the `want` smallest keys (keys are unique: the arrival index is)
@@ -1326,7 +1354,18 @@ __global__ __launch_bounds__(256) void pf_select_kernel(PfSelectArgs A) {
             const uint64_t key = key_of(c, &el);
             if (el && key <= kstar) {
                 const uint32_t slot = atomicAdd(&sh_nsel, 1u);
-                if (slot < PF_MAX_HITS) {
+                if (XCHG) {
+                    if (slot < max_hits) {
+                        const bool ovf = A.q_nseg != nullptr && A.q_nseg[q] != 0;
+                        mmgpu_pf_xhit x;
+                        x.id = A.global_ids[c.id];
+                        x.score = c.score;
+                        x.diagonal = c.diag;
+                        x.flags = (uint16_t)((ovf ? MMGPU_PF_X_INEXACT_ORDER : 0) | (c.id == ident ? MMGPU_PF_X_IDENTITY : 0));
+                        x.order = ovf ? c.arr : list_ordinal(A, q, c.arr);
+                        A.xhits[(size_t)q * A.hit_stride + slot] = x;
+                    }
+                } else if (slot < PF_MAX_HITS) {
                     uint32_t pref;
                     const uint32_t cnt = min(255u, c.score);
                     if (trunc) pref = 255u + (rescaled_count(c.score, fms) * (uint32_t)ms / 255u);
@@ -1338,6 +1377,13 @@ __global__ __launch_bounds__(256) void pf_select_kernel(PfSelectArgs A) {
         }
     }
     __syncthreads();
+    if (XCHG) {
+        if (threadIdx.x == 0) {
+            A.hit_count[q] = min(sh_nsel, max_hits);
+            A.q_diag_thr[q] = dthr | (trunc ? 0x80000000u : 0u);
+        }
+        return;
+    }
     const uint32_t nsel = min(sh_nsel, (uint32_t)PF_MAX_HITS);
     // bitonic sort by (prefScore desc, id asc)   (hit_t::compareHitsByScoreAndId, QueryMatcher.h:38-49)
     uint32_t np2 = 1;
@@ -1519,7 +1565,8 @@ hipError_t launch_pf_merge(const PfMergeArgs &A, hipStream_t s) {
 
 hipError_t launch_pf_select(const PfSelectArgs &A, uint32_t nq, hipStream_t s) {
     if (nq == 0) return hipSuccess;
-    hipLaunchKernelGGL(pf_select_kernel, dim3(nq), dim3(256), 0, s, A);
+    if (A.xhits) hipLaunchKernelGGL(pf_select_kernel<true>, dim3(nq), dim3(256), 0, s, A);
+    else hipLaunchKernelGGL(pf_select_kernel<false>, dim3(nq), dim3(256), 0, s, A);
     return hipGetLastError();
 }
 

@@ -95,3 +95,108 @@ def exchange_sw_results_tensor(local_res, slot_index, n_slots, group=None):
         full.index_copy_(0, slot_index, local_res)
     dist.all_reduce(full, group=group)
     return full
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Sharded search whose merged result equals the UNSPLIT run (include/mmgpu.h, "multi-GPU runs whose merged result equals
+# the unsplit run"): the target database is dealt to the ranks by length bucket (capi.partition_targets), every rank
+# searches its shard, ONE all-gather of 16-byte exchange records per query batch, the merge kernel redoes the reference's
+# threshold / truncation / final sort over the union, every rank aligns the pairs whose target it holds and the
+# alignment records of the owned pairs are all-gathered (variable counts, padded to the largest rank).
+
+
+def setup_shard(gpu, rank, world, tres, toff):
+    """Partition the database, make this rank's shard resident and describe it to the library.
+    -> dict(shard_of, local_id, global_ids, sizes, residues, n_global)"""
+    shard_of, local_id, sizes, residues = capi.partition_targets(toff, world, lib=gpu.L)
+    sres, soff, gids = capi.shard_sequences(tres, toff, shard_of, rank)
+    gpu.load_targets(sres, soff, 21)
+    gpu.pf_set_shard(world, rank, len(toff) - 1, gids, shard_of, local_id)
+    return dict(shard_of=shard_of, local_id=local_id, global_ids=gids, sizes=sizes, residues=residues, n_global=len(toff) - 1)
+
+
+def _all_gather_rows(t, group=None):
+    """[...] tensor of identical shape on every rank -> [world, ...]"""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1 and not dist.is_initialized():
+        return t.unsqueeze(0)
+    out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+    if t.is_cuda and dist.get_backend(group) == "gloo":       # debugging aid: several ranks on one GPU
+        return _all_gather_rows(t.cpu(), group).to(t.device)
+    if t.is_cuda:
+        dist.all_gather_into_tensor(out, t.contiguous(), group=group)
+    else:
+        parts = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(parts, t.contiguous(), group=group)
+        out = torch.stack(parts)
+    return out
+
+
+def exchange_and_merge_device(gpu, pf_batch, nq, stride, identity_global=None, group=None):
+    """exchange batch that has been run -> (merged hits int32 [nq, stride, 3] with GLOBAL ids, counts int32 [nq],
+    flags int32 [nq]) on the GPU, identical on every rank"""
+    dev = torch.device("cuda", torch.cuda.current_device())
+    xh = torch.zeros((nq, stride, 4), dtype=torch.int32, device=dev)
+    xc = torch.zeros((nq,), dtype=torch.int32, device=dev)
+    pf_batch.fetch_exchange(xh.data_ptr(), stride, xc.data_ptr())
+    gh, gc = _all_gather_rows(xh, group), _all_gather_rows(xc, group)
+    out_h = torch.zeros((nq, stride, 3), dtype=torch.int32, device=dev)
+    out_c = torch.zeros((nq,), dtype=torch.int32, device=dev)
+    out_f = torch.zeros((nq,), dtype=torch.int32, device=dev)
+    pf_batch.merge_exchange(gh.data_ptr(), gc.data_ptr(), gh.shape[0], stride, identity_global, out_h.data_ptr(), stride,
+                            out_c.data_ptr(), out_f.data_ptr())
+    return out_h, out_c, out_f
+
+
+def exchange_and_merge_host(xhits, counts, max_hits, min_diag_score, ref_bins, self_scores, identity_global=None, group=None):
+    """CPU / gloo mirror used by the tests: xhits PF_XHIT_DTYPE [nq, stride], counts [nq] of THIS rank -> list of merged
+    PF_HIT_DTYPE lists (capi.merge_exchange_host per query)"""
+    nq, stride = xhits.shape
+    h32 = torch.from_numpy(np.ascontiguousarray(xhits).view(np.int32).reshape(nq, stride, 4))
+    c32 = torch.from_numpy(np.ascontiguousarray(counts).astype(np.int32))
+    gh, gc = _all_gather_rows(h32, group), _all_gather_rows(c32, group)
+    gh = gh.numpy().reshape(gh.shape[0], nq, stride * 4).view(capi.PF_XHIT_DTYPE).reshape(gh.shape[0], nq, stride)
+    gc = gc.numpy()
+    out = []
+    for q in range(nq):
+        rec = np.concatenate([gh[s, q, :gc[s, q]] for s in range(gh.shape[0])])
+        out.append(capi.merge_exchange_host(rec, max_hits, min_diag_score, ref_bins, self_scores[q],
+                                            None if identity_global is None else identity_global[q]))
+    return out
+
+
+def align_owned_pairs(gpu, mat, gap_open, gap_extend, marshalled, merged_hits, merged_counts, nq, stride, mode=1):
+    """merged lists (global ids, on the GPU) -> alignment batch of the pairs whose target this rank holds.
+    -> (SwBatch, local_counts int32 [nq], local_slot int32 [nq, stride]); the batch's result slot q*stride+k belongs
+    to position local_slot[q, k] of query q's merged list"""
+    dev = merged_hits.device
+    lh = torch.zeros((nq, stride, 3), dtype=torch.int32, device=dev)
+    lc = torch.zeros((nq,), dtype=torch.int32, device=dev)
+    ls = torch.zeros((nq, stride), dtype=torch.int32, device=dev)
+    gpu.pf_localize_lists(merged_hits.data_ptr(), merged_counts.data_ptr(), nq, stride, lh.data_ptr(), lc.data_ptr(), ls.data_ptr())
+    b = gpu.sw_prepare_from_lists(mat, gap_open, gap_extend, None, lh.data_ptr(), lc.data_ptr(), stride, mode=mode, marshalled=marshalled)
+    return b, lc, ls
+
+
+def gather_owned_results(local_res, local_counts, local_slot, nq, stride, group=None):
+    """local_res int32 [nq, stride, 6] (mmgpu_sw_hit records of this rank's batch), local_counts [nq], local_slot
+    [nq, stride] -> int32 [nq, stride, 6]: the records of every rank's owned pairs in merged-list order, on every rank.
+    Every rank contributes only its owned pairs: an all-gather of (record, slot) rows padded to the largest rank, instead
+    of an all-reduce of the dense array."""
+    dev = local_res.device
+    mask = torch.arange(stride, device=dev, dtype=torch.int32)[None, :] < local_counts[:, None]
+    rows = local_res[mask]                                                     # [P, 6]
+    slots = (torch.arange(nq, device=dev, dtype=torch.int64)[:, None] * stride + local_slot.to(torch.int64))[mask]
+    packed = torch.cat([rows, slots.to(torch.int32)[:, None]], dim=1)          # [P, 7]
+    n_mine = torch.tensor([packed.shape[0]], dtype=torch.int64, device=dev)
+    n_all = _all_gather_rows(n_mine, group).reshape(-1)
+    cap = int(n_all.max().item())
+    pad = torch.zeros((cap, 7), dtype=torch.int32, device=dev)
+    pad[:packed.shape[0]] = packed
+    allp = _all_gather_rows(pad, group)                                        # [world, cap, 7]
+    full = torch.zeros((nq * stride, 6), dtype=torch.int32, device=dev)
+    for r in range(allp.shape[0]):
+        n = int(n_all[r].item())
+        if n:
+            full.index_copy_(0, allp[r, :n, 6].to(torch.int64), allp[r, :n, :6])
+    return full.reshape(nq, stride, 6)

@@ -112,3 +112,106 @@ def test_two_rank_allgather_merge_matches_split_semantics():
     # with one split the merged list is the plain list
     one = capi.merge_hit_lists_host([per[0][0][0, :per[0][1][0]]], [0])
     assert one["id"].tolist() == per[0][0][0]["id"][:per[0][1][0]].tolist()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The path whose merged result equals the UNSPLIT run: length-bucket partition, all-gather of exchange records, merge over
+# the union (host mirror of pf_xmerge_kernel), all-gather of the owned alignment records.  The records here are synthetic
+# (what produces them needs a GPU: tests/test_sharded_gpu.py); the expectation is computed without communication.
+def _query_truth(n_global, seed, qi):
+    """all surviving elements of one query over the whole database (the same draw on every rank)"""
+    from mmseqs2_amd import capi
+    qr = np.random.default_rng(seed * 1000 + qi)
+    rec = np.zeros(n_global, capi.PF_XHIT_DTYPE)
+    rec["id"] = np.arange(n_global)
+    # even queries: few saturated scores; odd queries: more saturated elements than max_hits (truncated-threshold path)
+    if qi % 2 == 0:
+        rec["score"] = qr.choice([16, 17, 18, 40, 200, 254, 255, 300], size=n_global, p=[.3, .3, .2, .1, .05, .03, .01, .01])
+    else:
+        rec["score"] = qr.choice([16, 17, 255, 300, 400, 900, 1200], size=n_global)
+    rec["diagonal"] = np.arange(n_global) % 7
+    rec["order"] = qr.integers(0, 50, size=n_global)
+    return rec
+
+
+def _synthetic_records(nq, n_global, shard_of, rank, seed, max_hits=25):
+    """what a shard hands over: its top max_hits by the unsplit run's order (host mirror of pf_select_kernel<true>)"""
+    from mmseqs2_amd import capi
+    rec = np.zeros((nq, max_hits), capi.PF_XHIT_DTYPE)
+    counts = np.zeros(nq, np.uint32)
+    for qi in range(nq):
+        mine = _query_truth(n_global, seed, qi)[shard_of == rank]
+        sel = capi.select_exchange_host(mine, max_hits, 15, 4, 700 + qi)
+        rec[qi][:len(sel)] = sel
+        counts[qi] = len(sel)
+    return rec, counts
+
+
+def _worker_unsplit(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mmseqs2_amd import capi, distributed as D
+    lens = np.random.default_rng(1).integers(30, 4000, 500)
+    toff = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    shard_of, local_id, sizes, residues = capi.partition_targets(toff, world)
+    nq = 6
+    rec, counts = _synthetic_records(nq, 500, shard_of, rank, 9)
+    merged = D.exchange_and_merge_host(rec, counts, 25, 15, 4, [700 + i for i in range(nq)])
+    # owned alignment records: value = f(query, global id), gathered into merged-list order
+    stride = 25
+    lres = torch.zeros((nq, stride, 6), dtype=torch.int32)
+    lcnt = torch.zeros((nq,), dtype=torch.int32)
+    lslot = torch.zeros((nq, stride), dtype=torch.int32)
+    for qi, m in enumerate(merged):
+        k = 0
+        for pos, gid in enumerate(m["id"].tolist()):
+            if shard_of[gid] == rank:
+                lres[qi, k, 0] = gid * 3 + qi
+                lres[qi, k, 1] = rank + 1
+                lslot[qi, k] = pos
+                k += 1
+        lcnt[qi] = k
+    full = D.gather_owned_results(lres, lcnt, lslot, nq, stride)
+    if rank == 0:
+        q.put(([(m["id"].tolist(), m["score"].tolist()) for m in merged], full.numpy().tolist(), sizes.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_unsplit_equal_path_plumbing():
+    from mmseqs2_amd import capi
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker_unsplit, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got, full, sizes = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    lens = np.random.default_rng(1).integers(30, 4000, 500)
+    toff = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    shard_of, local_id, sz, residues = capi.partition_targets(toff, world)
+    assert sizes == sz.tolist() and abs(int(sz[0]) - int(sz[1])) <= 1
+    assert abs(int(residues[0]) - int(residues[1])) < 0.02 * int(residues.sum())
+    # local ids ascend with the global ids inside a shard
+    for r in range(world):
+        g = np.nonzero(shard_of == r)[0]
+        assert np.array_equal(local_id[g], np.arange(len(g)))
+    # expectation: the selection over the WHOLE database's elements at once (what the unsplit run sees) - the shards'
+    # top lists must be sufficient, in the plain and in the truncated-threshold mode
+    nq = 6
+    modes = set()
+    for qi in range(nq):
+        truth = _query_truth(500, 9, qi)
+        whole = capi.merge_exchange_host(truth, 25, 15, 4, 700 + qi)
+        modes.add(int((np.minimum(truth["score"], 255) == 255).sum() >= 25))
+        assert got[qi][0] == whole["id"].tolist() and got[qi][1] == whole["score"].tolist(), qi
+        assert len(whole) == 25
+        for pos, gid in enumerate(got[qi][0]):
+            assert full[qi][pos][0] == gid * 3 + qi and full[qi][pos][1] == shard_of[gid] + 1
+    assert modes == {0, 1}

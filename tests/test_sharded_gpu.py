@@ -1,0 +1,214 @@
+"""GPU tests of the multi-GPU path whose merged result must equal the UNSPLIT run: the N shards
+are run one after the other on the one GPU of the box (same context, same code a rank runs), the exchange records are
+stacked as the all-gather would deliver them, and the merged lists / alignment results are compared with
+
+  * the unsplit run of the same device path (bit for bit: ids, scores, diagonals, order), which tests/test_prefilter_gpu.py
+    pins against the oracle and the reference-recorded vectors, and
+  * the unsplit ORACLE directly for a sample of the queries.
+"""
+import numpy as np
+import pytest
+import torch
+
+from mmseqs2_amd import capi
+from mmseqs2_amd import distributed as D
+from mmseqs2_amd import workloads as wl
+from tests import pf_common as pc
+
+pytestmark = pytest.mark.gpu
+
+
+def _tables(gpu, g):
+    km16, um8 = g["vtml80_kmer16"], g["blosum62_ungapped"]
+    s3, i3 = capi.host_score_matrix(km16, 3, lib=gpu.L)
+    return km16, um8, s3, i3
+
+
+def _unsplit(gpu, g, tres, toff, queries, thr, max_hits, ref_bins):
+    km16, um8, s3, i3 = _tables(gpu, g)
+    gpu.load_targets(tres, toff, 21)
+    gpu.pf_build_index(6, 21, True, s3, i3, km16, thr, um8)
+    b = gpu.pf_prepare(queries, thr, max_hits=max_hits, ref_bins=ref_bins)
+    b.run()
+    out = b.fetch()
+    b.free()
+    return out
+
+
+def _sharded(gpu, g, tres, toff, queries, thr, max_hits, ref_bins, world, identity_global=None):
+    """-> merged hits (PF_HIT_DTYPE [nq, stride]), counts, flags, per-shard state for the alignment step"""
+    km16, um8, s3, i3 = _tables(gpu, g)
+    nq = len(queries)
+    dev = torch.device("cuda", 0)
+    stride = min(max_hits, len(toff) - 1)
+    xh_all = torch.zeros((world, nq, stride, 4), dtype=torch.int32, device=dev)
+    xc_all = torch.zeros((world, nq), dtype=torch.int32, device=dev)
+    last = None
+    for r in range(world):
+        info = D.setup_shard(gpu, r, world, tres, toff)
+        gpu.pf_build_index(6, 21, True, s3, i3, km16, thr, um8)
+        qs = []
+        for qi, qd in enumerate(queries):
+            ident = None
+            if identity_global is not None and identity_global[qi] != 0xFFFFFFFF and info["shard_of"][identity_global[qi]] == r:
+                ident = int(info["local_id"][identity_global[qi]])
+            qs.append(dict(q=qd["q"], comp_bias=qd["comp_bias"], identity_id=ident))
+        b = gpu.pf_prepare(qs, thr, max_hits=max_hits, ref_bins=ref_bins)
+        b.run()
+        b.fetch_exchange(xh_all[r].data_ptr(), stride, xc_all[r].data_ptr())
+        gpu.synchronize()
+        if last is not None:
+            last.free()
+        last = b
+    out_h = torch.zeros((nq, stride, 3), dtype=torch.int32, device=dev)
+    out_c = torch.zeros((nq,), dtype=torch.int32, device=dev)
+    out_f = torch.zeros((nq,), dtype=torch.int32, device=dev)
+    last.merge_exchange(xh_all.data_ptr(), xc_all.data_ptr(), world, stride, identity_global, out_h.data_ptr(), stride,
+                        out_c.data_ptr(), out_f.data_ptr())
+    hits = out_h.cpu().numpy().reshape(nq, stride * 3).view(capi.PF_HIT_DTYPE).reshape(nq, stride)
+    # the host mirror of the merge kernel must agree with it (it is what the gloo tests use)
+    xh = xh_all.cpu().numpy().reshape(world, nq, stride * 4).view(capi.PF_XHIT_DTYPE).reshape(world, nq, stride)
+    xc = xc_all.cpu().numpy()
+    last.free()
+    return hits, out_c.cpu().numpy(), out_f.cpu().numpy(), (xh, xc)
+
+
+def _self_score(g, qd):
+    """rescoreHits' self score as mmgpu_pf_prepare computes it (UngappedAlignment.cpp:396-400, QueryMatcher.cpp:566)"""
+    um8 = g["blosum62_ungapped"].astype(np.int64)
+    q = qd["q"].astype(np.int64)
+    cb = qd["comp_bias"].astype(np.float32)
+    v = np.where(cb < 0.0, cb / np.float32(4) - np.float32(0.5), cb / np.float32(4) + np.float32(0.5))
+    corr = np.trunc(v).astype(np.int8).astype(np.int64)
+    cur = (um8[q, q] + corr).astype(np.int8).astype(np.int64)
+    sc = mx = 0
+    for c in cur.tolist():
+        sc = max(sc + c, 0)
+        mx = max(mx, sc)
+    return mx
+
+
+def _case(seed, n_fam, members, nq):
+    (qres, qoff), (tres, toff), _, _ = wl.config3_prefilter(n_families=n_fam, members=members, n_queries=nq, seed=seed)
+    return wl.split(qres, qoff), tres, toff
+
+
+@pytest.mark.parametrize("world,max_hits,ref_bins", [(2, 300, 2), (3, 40, 4), (8, 25, 2), (4, 300, 0)])
+def test_merged_shards_equal_unsplit_run(gpu, world, max_hits, ref_bins):
+    """lists cut at ties (max_hits far below the family size), uneven shard counts, the host's own bin count"""
+    g = pc.golden()
+    thr = int(g["kmer_thr"])
+    qs, tres, toff = _case(31 + world, 150, 60, 48)
+    km16 = g["vtml80_kmer16"]
+    queries = [dict(q=q, comp_bias=capi.host_comp_bias(km16, g["vtml80_pback"], q, lib=gpu.L)[0], identity_id=None) for q in qs]
+    hits_u, counts_u, status_u, _ = _unsplit(gpu, g, tres, toff, queries, thr, max_hits, ref_bins)
+    hits_s, counts_s, flags, (xh, xc) = _sharded(gpu, g, tres, toff, queries, thr, max_hits, ref_bins, world)
+    assert np.all(status_u == 0) and np.all(flags == 0)
+    truncated = 0
+    for qi in range(len(qs)):
+        n = int(counts_u[qi])
+        assert int(counts_s[qi]) == n, (qi, int(counts_s[qi]), n)
+        for f in ("id", "score", "diagonal"):
+            assert np.array_equal(hits_s[qi][f][:n], hits_u[qi][f][:n]), (qi, f)
+        truncated += n == min(max_hits, len(toff) - 1)
+    assert truncated > len(qs) // 2 or max_hits >= 300      # the tie order at the cut was actually exercised
+    # host mirror of the merge kernel (what the gloo tests run) on the very same records
+    if ref_bins:
+        for qi in range(len(qs)):
+            rec = np.concatenate([xh[s, qi, :xc[s, qi]] for s in range(world)])
+            m = capi.merge_exchange_host(rec, min(max_hits, len(toff) - 1), 15, ref_bins, _self_score(g, queries[qi]))
+            n = int(counts_s[qi])
+            assert len(m) == n and all(np.array_equal(m[f], hits_s[qi][f][:n]) for f in ("id", "score", "diagonal")), qi
+    orc = pc.pf_oracle()
+    orc.build_index(tres, toff, thr)
+    rb = ref_bins if ref_bins else None
+    for qi in (0, 7, 21):
+        if rb is None:
+            break
+        o = orc.match(queries[qi]["q"], queries[qi]["comp_bias"], rb, max_hits=max_hits)
+        n = int(counts_s[qi])
+        assert n == len(o["id"]) and np.array_equal(hits_s[qi]["id"][:n], o["id"]) and \
+            np.array_equal(hits_s[qi]["score"][:n], o["score"]) and np.array_equal(hits_s[qi]["diagonal"][:n], o["diagonal"]), qi
+
+
+def test_merged_shards_with_self_hits_and_saturated_scores(gpu):
+    """queries that are database members (self hit first, score 65535) with many near-identical family members: the
+    truncated-threshold path (more than max_hits saturated elements) and the exact rescoring"""
+    g = pc.golden()
+    thr = int(g["kmer_thr"])
+    rng = np.random.default_rng(5)
+    seeds = [rng.choice(20, size=int(rng.integers(150, 500)), p=wl.BACKGROUND).astype(np.uint8) for _ in range(6)]
+    tl = []
+    for s in seeds:
+        for _ in range(80):
+            tl.append(wl.mutate(rng, s, float(rng.uniform(0.85, 0.99))))
+    for _ in range(400):
+        tl.append(rng.choice(20, size=int(rng.integers(50, 600)), p=wl.BACKGROUND).astype(np.uint8))
+    perm = rng.permutation(len(tl))
+    tl = [tl[i] for i in perm]
+    tres, toff = wl.seqs_from_list(tl)
+    km16 = g["vtml80_kmer16"]
+    qids = np.array([int(np.nonzero(perm == k * 80 + 3)[0][0]) for k in range(6)], np.uint32)
+    queries = [dict(q=tl[i], comp_bias=capi.host_comp_bias(km16, g["vtml80_pback"], tl[i], lib=gpu.L)[0], identity_id=int(i))
+               for i in qids]
+    for max_hits in (30, 300):
+        hits_u, counts_u, status_u, stats_u = _unsplit(gpu, g, tres, toff, queries, thr, max_hits, 2)
+        hits_s, counts_s, flags, (xh, xc) = _sharded(gpu, g, tres, toff, queries, thr, max_hits, 2, 4, identity_global=qids)
+        if max_hits == 30:
+            assert np.any(stats_u["diag_thr"] >> 31), "the truncated-threshold path was not reached"
+        for qi in range(len(queries)):
+            n = int(counts_u[qi])
+            assert int(counts_s[qi]) == n
+            assert hits_s[qi]["id"][0] == qids[qi] and hits_s[qi]["score"][0] == 65535
+            rec = np.concatenate([xh[s, qi, :xc[s, qi]] for s in range(4)])
+            m = capi.merge_exchange_host(rec, max_hits, 15, 2, _self_score(g, queries[qi]), int(qids[qi]))
+            assert len(m) == n and all(np.array_equal(m[f], hits_s[qi][f][:n]) for f in ("id", "score", "diagonal")), (max_hits, qi)
+            for f in ("id", "score", "diagonal"):
+                assert np.array_equal(hits_s[qi][f][:n], hits_u[qi][f][:n]), (max_hits, qi, f)
+
+
+def test_alignment_of_owned_pairs_equals_unsplit(gpu, matrices):
+    """every (query, target) pair is aligned by the shard that holds the target; the gathered records equal those of the
+    unsplit alignment of the same merged lists, slot by slot"""
+    g = pc.golden()
+    thr = int(g["kmer_thr"])
+    qs, tres, toff = _case(77, 100, 40, 32)
+    km16, um8, s3, i3 = _tables(gpu, g)
+    mat = matrices["blosum62_sw"]
+    sub16 = mat.astype(np.int16)
+    queries = [dict(q=q, comp_bias=capi.host_comp_bias(km16, g["vtml80_pback"], q, lib=gpu.L)[0], identity_id=None) for q in qs]
+    swq = [dict(q=q, comp_bias=capi.host_comp_bias(sub16, matrices["blosum62_pback"], q, lib=gpu.L)[1], min_start_score=30) for q in qs]
+    world, max_hits = 3, 60
+    hits_s, counts_s, _, _ = _sharded(gpu, g, tres, toff, queries, thr, max_hits, 2, world)
+    nq, stride = hits_s.shape
+    dev = torch.device("cuda", 0)
+    mh = torch.from_numpy(np.ascontiguousarray(hits_s).view(np.int32).reshape(nq, stride, 3)).to(dev)
+    mc = torch.from_numpy(counts_s.astype(np.int32)).to(dev)
+    full = torch.zeros((nq * stride, 6), dtype=torch.int32, device=dev)
+    owned = 0
+    for r in range(world):
+        D.setup_shard(gpu, r, world, tres, toff)
+        m = gpu.sw_marshal_queries(mat, 11, 1, swq)
+        b, lc, ls = D.align_owned_pairs(gpu, mat, 11, 1, m, mh, mc, nq, stride, mode=1)
+        b.run()
+        res = torch.zeros((nq, stride, 6), dtype=torch.int32, device=dev)
+        b.fetch_device(res.data_ptr())
+        gpu.synchronize()
+        mask = torch.arange(stride, device=dev, dtype=torch.int32)[None, :] < lc[:, None]
+        slots = (torch.arange(nq, device=dev, dtype=torch.int64)[:, None] * stride + ls.to(torch.int64))[mask]
+        full.index_copy_(0, slots, res[mask])
+        owned += int(lc.sum().item())
+        b.free()
+    assert owned == int(counts_s.sum())
+    got = full.cpu().numpy().reshape(-1).view(capi.SW_HIT_DTYPE).reshape(nq, stride)
+    # unsplit alignment of the same lists
+    gpu.load_targets(tres, toff, 21)
+    host_q = [dict(q=x["q"], comp_bias=x["comp_bias"], targets=hits_s[i]["id"][:counts_s[i]].copy(), min_start_score=30)
+              for i, x in enumerate(swq)]
+    exp = gpu.sw_batch(mat, 11, 1, host_q, mode=1)
+    off = 0
+    for i in range(nq):
+        n = int(counts_s[i])
+        for f in ("score", "q_end", "t_end", "q_start", "t_start", "word"):
+            assert np.array_equal(got[i, :n][f], exp[off:off + n][f]), (i, f)
+        off += n
