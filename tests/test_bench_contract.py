@@ -1,6 +1,7 @@
-"""The bench line the driver parses: the committed round-1 line (profiles/r01_bench_n1.json, produced by `python bench.py`
-on the GPU box) must carry the contract's keys, and bench.py's reader of the committed PMC passes must find the kernels it
-quotes as `roofline.traffic`."""
+"""The bench line the driver parses: the committed line of this round (profiles/r02_bench_n1.json, produced by
+`python bench.py` on the GPU box) must carry the contract's keys, be quoted on BASELINE.json's metric configuration (10k
+queries x 1M targets), and its CPU-baseline legs - which double as full-size parity checks against the real reference -
+must have found no difference."""
 import json
 import os
 import sys
@@ -9,29 +10,33 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _line():
-    return json.loads(open(os.path.join(ROOT, "profiles", "r01_bench_n1.json")).read())
+    return json.loads(open(os.path.join(ROOT, "profiles", "r02_bench_n1.json")).read())
 
 
 def test_committed_bench_line_has_the_contract_keys():
     d = _line()
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-              "dtype", "data", "config", "roofline", "cpu_baseline"):
+              "dtype", "data", "config", "roofline", "cpu_baseline", "queries_per_s"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert d["steps"] >= 10
     assert "workload" in d["config"] and "model" not in d["config"]
+    assert "configs[2]" in d["config"]["workload"] and "10000 queries x 1000000 targets" in d["config"]["workload"]
     r = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
     assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+    # value = forward cells / alignment-stage time; queries_per_s = queries / whole step
+    assert abs(d["value"] - d["config"]["align_cells_per_step"] / (r["kernel_ms"] * 1e-3) / 1e9) < 0.01 * d["value"]
+    assert abs(d["queries_per_s"] - 10000 / (d["ms_per_step"] * 1e-3)) < 0.01 * d["queries_per_s"]
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] in ("reference", "port")
-    # the two CPU legs double as full-size parity checks: they must have found nothing
-    assert c["parity_vs_baseline"]["field_mismatches"] == 0
-    s = d["search"]
-    assert s["cpu_baseline"]["parity_vs_reference"]["queries_with_different_hit_lists"] == 0
-    assert s["fused_pipeline"]["queries_differing_from_two_call_path"] == 0
+    # the CPU legs double as full-size parity checks: they must have found nothing
+    assert c["parity_vs_baseline"]["field_mismatches"] == 0 and c["parity_vs_baseline"]["pairs_compared"] > 2000000
+    assert d["cpu_baseline_prefilter"]["parity_vs_reference"]["queries_with_different_hit_lists"] == 0
+    assert d["two_call"]["fields_differing_from_fused_path"] == 0
     assert d["nucleotide_align"]["cpu_baseline"]["parity_vs_reference"]["pairs_differing"] == 0
 
 

@@ -101,7 +101,8 @@ def test_many_long_queries_and_one_very_long_target(gpu, oracle, matrices):
     for _ in range(60):
         tl.append(rng.choice(20, size=int(rng.integers(50, 900)), p=wl.BACKGROUND).astype(np.uint8))
     # plant a homolog of query 3 far inside the long target
-    tl[0][41000:41000 + len(qs[3])] = wl.mutate(rng, qs[3], 0.8)[:len(qs[3])]
+    hom = wl.mutate(rng, qs[3], 0.8)
+    tl[0][41000:41000 + len(hom)] = hom
     tres, toff = wl.seqs_from_list(tl)
     gpu.load_targets(tres, toff, 21)
     queries = []
