@@ -460,7 +460,7 @@ inline hipError_t upload(DevBuf &b, const std::vector<T> &v, hipStream_t s) {
 
 // nucleotide alignment step (nucl_kernel.hip; NuclLaunch is declared in nucl_core.h)
 hipError_t launch_nucl_align(const NuclLaunch &L, unsigned blocks, hipStream_t stream);     // 16 lanes per alignment
-hipError_t launch_nucl_align64(const NuclLaunch &L, unsigned blocks, hipStream_t stream);   // 64 lanes (experimental, nucl_kernel64.hip)
+hipError_t launch_nucl_align_wave(const NuclLaunch &L, unsigned blocks, hipStream_t stream);   // one wavefront per alignment, state in registers (nucl_wave.h): the default
 
 struct PfIndex;   // pf_api.hip
 

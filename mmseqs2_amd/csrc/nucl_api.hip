@@ -48,13 +48,15 @@ extern "C" int mmgpu_nucl_align(mmgpu_ctx *c, const mmgpu_nucl_params *par, cons
     std::iota(order.begin(), order.end(), 0u);
     std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return work[a] > work[b]; });
 
-    // one slice of direction bytes (6 blocks of 16 per anti-diagonal) and of backtrack letters per 16-lane group; the
-    // number of groups in flight is what fits the scratch budget (a group that finishes takes the next pair)
+    // one slice of direction bytes (6 blocks of 16 per anti-diagonal) and of backtrack letters per alignment in flight:
+    // a wavefront per alignment (nucl_wave.h; MMGPU_NUCL_LANES=16 selects the 16-lane LDS formulation of nucl_core.h,
+    // kept as a cross-check); the number in flight is what the chip holds and what fits the scratch budget (a wavefront
+    // that finishes takes the next pair)
     const uint64_t p_stride = (most_rows * 6 + 2) * 16, w_stride = (longest + 16 + 15) / 16 * 16;
-    static const int lanes = getenv("MMGPU_NUCL_LANES") && atoi(getenv("MMGPU_NUCL_LANES")) == 64 ? 64 : 16;   // 64: experimental kernel
+    static const int lanes = getenv("MMGPU_NUCL_LANES") && atoi(getenv("MMGPU_NUCL_LANES")) == 16 ? 16 : 64;
     const uint64_t gpb = 256 / lanes;                                                     // alignments per workgroup
     uint64_t groups = ((uint64_t)n_pairs + gpb - 1) / gpb * gpb;
-    groups = std::min<uint64_t>(groups, (uint64_t)c->compute_units * 4 * 16);          // 4 workgroups of 16 groups per CU
+    groups = std::min<uint64_t>(groups, (uint64_t)c->compute_units * 4 * gpb);          // 4 workgroups per CU
     static const uint64_t budget_gb = getenv("MMGPU_NUCL_SCRATCH_GB") ? std::max(1, atoi(getenv("MMGPU_NUCL_SCRATCH_GB"))) : 16;
     const uint64_t budget = budget_gb << 30;
     while (groups > gpb && groups * (p_stride + w_stride) > budget) groups -= gpb;
@@ -63,10 +65,9 @@ extern "C" int mmgpu_nucl_align(mmgpu_ctx *c, const mmgpu_nucl_params *par, cons
 
     hipStream_t s = c->stream;
     DevBuf d_pairs, d_order, d_qres, d_qoff, d_p, d_w, d_out, d_bt, d_ctr;
-    // plain allocations: one synchronous call owns them, nothing to recycle between batches
-    // (MMGPU_NUCL_USE_CACHE=1 puts them through the context's block cache instead)
-    if (getenv("MMGPU_NUCL_USE_CACHE"))
-        for (DevBuf *d : {&d_pairs, &d_order, &d_qres, &d_qoff, &d_p, &d_w, &d_out, &d_bt, &d_ctr}) d->bind(c->cache);
+    // through the context's block cache: a process aligns batch after batch, the (large) scratch is allocated once
+    // (MMGPU_NO_BLOCK_CACHE=1 switches the cache off)
+    for (DevBuf *d : {&d_pairs, &d_order, &d_qres, &d_qoff, &d_p, &d_w, &d_out, &d_bt, &d_ctr}) d->bind(c->cache);
     std::vector<mmgpu_nucl_pair> pv(pairs, pairs + n_pairs);
     HIP_TRY(upload(d_pairs, pv, s));
     HIP_TRY(upload(d_order, order, s));
@@ -105,7 +106,7 @@ extern "C" int mmgpu_nucl_align(mmgpu_ctx *c, const mmgpu_nucl_params *par, cons
     L.bt_cursor = d_ctr.as<unsigned long long>();
     L.bt_cap = bt_cap;
     L.next_pair = reinterpret_cast<uint32_t *>(d_ctr.as<unsigned long long>() + 1);
-    HIP_TRY(lanes == 64 ? launch_nucl_align64(L, blocks, s) : launch_nucl_align(L, blocks, s));
+    HIP_TRY(lanes == 64 ? launch_nucl_align_wave(L, blocks, s) : launch_nucl_align(L, blocks, s));
     HIP_TRY(hipMemcpyAsync(out, d_out.p, (size_t)n_pairs * sizeof(mmgpu_nucl_hit), hipMemcpyDeviceToHost, s));
     unsigned long long used = 0;
     HIP_TRY(hipMemcpyAsync(&used, d_ctr.p, 8, hipMemcpyDeviceToHost, s));

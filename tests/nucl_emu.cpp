@@ -68,15 +68,28 @@ static inline unsigned long long emu_add64(unsigned long long *p, unsigned long 
 #define NUCL_ATOMIC_ADD_U32(p, v) emu_add32((p), (v))
 #define NUCL_ATOMIC_ADD_U64(p, v) emu_add64((p), (v))
 #include "nucl_core.h"
+#ifdef EMU_WAVE   // the one-wavefront-per-alignment kernel (nucl_wave.h): 64 emulated lanes, its two extra primitives
+#define NUCL_ROR1_U32(v) ((unsigned)emu::exchange((unsigned long long)(unsigned)(v), (emu::cur + emu::LANES - 1) % emu::LANES))
+#define NUCL_READLANE(v, l) ((int)emu::exchange((unsigned long long)(long long)(int)(v), (l)))
+#include "nucl_wave.h"
+#endif
 
 namespace {
 const mmgpu::NuclLaunch *g_launch;
+#ifdef EMU_WAVE
+mmgpu::nuclw::WaveLds g_lds;
+#else
 mmgpu::NUCL_NS::GroupLds g_lds;
+#endif
 uint8_t *g_p;
 char *g_w;
 
 void lane_main() {
+#ifdef EMU_WAVE
+    mmgpu::nuclw::align_wave(*g_launch, g_lds, g_p, g_w);
+#else
     mmgpu::NUCL_NS::align_group(*g_launch, g_lds, g_p, g_w);
+#endif
     emu::done[emu::cur] = true;
     emu::switch_to_next();
 }

@@ -13,16 +13,16 @@ from mmseqs2_amd import capi
 from tests import nucl_common as nc
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-def _lib(lanes=16):
-    """the kernel source compiled for the host with `lanes` emulated lanes per alignment (16 = the default GPU kernel, 64 = the
-    experimental one-wavefront-per-alignment kernel, nucl_kernel64.hip)"""
-    so = os.path.join(ROOT, "tests", "_build", "libnuclemu%d.so" % lanes)
+def _lib(lanes=16, wave=False):
+    """the kernel source compiled for the host with `lanes` emulated lanes per alignment: 16 = the LDS formulation of
+    nucl_core.h, 64 + wave = the default GPU kernel (one wavefront per alignment, state in registers: nucl_wave.h)"""
+    so = os.path.join(ROOT, "tests", "_build", "libnuclemu%d%s.so" % (lanes, "w" if wave else ""))
     src = os.path.join(ROOT, "tests", "nucl_emu.cpp")
-    core = os.path.join(ROOT, "mmseqs2_amd", "csrc", "nucl_core.h")
-    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(core)):
+    deps = [src] + [os.path.join(ROOT, "mmseqs2_amd", "csrc", f) for f in ("nucl_core.h", "nucl_wave.h")]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(d) for d in deps):
         os.makedirs(os.path.dirname(so), exist_ok=True)
-        subprocess.check_call(["g++", "-O2", "-shared", "-fPIC", "-std=c++17", "-DEMU_LANES=%d" % lanes,
-                               "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "mmseqs2_amd", "csrc"), src, "-o", so])
+        subprocess.check_call(["g++", "-O2", "-shared", "-fPIC", "-std=c++17", "-DEMU_LANES=%d" % lanes] + (["-DEMU_WAVE"] if wave else []) +
+                              ["-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "mmseqs2_amd", "csrc"), src, "-o", so])
     return ctypes.CDLL(so)
 
 
@@ -51,9 +51,9 @@ def emu_align(L, mat, reverse, queries, targets, pairs, past_q, past_t, gapo=5, 
     return out, [raw[int(h["bt_off"]):int(h["bt_off"]) + int(h["bt_len"])].decode() for h in out]
 
 
-@pytest.mark.parametrize("lanes", [16, 64])
-def test_kernel_source_on_emulated_lanes_matches_golden(lanes):
-    L = _lib(lanes)
+@pytest.mark.parametrize("lanes,wave", [(16, False), (64, True)])
+def test_kernel_source_on_emulated_lanes_matches_golden(lanes, wave):
+    L = _lib(lanes, wave)
     g = nc.golden()
     cases = [c for c in nc.golden_cases(g) if len(c[0]) + len(c[1]) <= 1800]
     assert len(cases) > 250

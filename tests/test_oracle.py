@@ -81,3 +81,24 @@ def test_oracle_fuzz_vs_reference(oracle, reflib):
 def test_golden_matrices_match_reference(reflib, matrices):
     assert np.array_equal(reflib.matrix(), matrices["blosum62_sw"])
     assert reflib.num2aa() == bytes(matrices["num2aa"]).decode() == wl.NUM2AA
+
+
+def test_word_hits_backtrace_rescored_equals_score(sw_vectors, matrices):
+    """for hits whose score left the uint8 range (word == 1) the stock reference takes start and CIGAR
+    from the Rust block-aligner, which cannot be built here.  The contract that can be pinned: re-scoring the backtrace the
+    fallback path produces (what the device returns too) reproduces score1 and ends at (qEnd, dbEnd) - for EVERY recorded
+    pair, word == 1 or not."""
+    from tests.rescore import rescore
+    v = sw_vectors
+    mat = matrices["blosum62_sw"]
+    qoff, toff = v["qoff"].astype(np.int64), v["toff"].astype(np.int64)
+    n_word = 0
+    for i in range(len(qoff) - 1):
+        score, q_end, t_end, q_start, t_start, word, ident = [int(x) for x in v["expect"][i]]
+        if score <= 0 or not v["bt"][i]:
+            continue
+        q, cb, t = v["qres"][qoff[i]:qoff[i + 1]], v["cb"][qoff[i]:qoff[i + 1]], v["tres"][toff[i]:toff[i + 1]]
+        s, qe, te = rescore(q, cb, t, mat, int(v["gap_open"]), int(v["gap_extend"]), q_start, t_start, v["bt"][i])
+        assert (s, qe, te) == (score, q_end, t_end), (i, word, s, score)
+        n_word += word
+    assert n_word >= 20

@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 
 from mmseqs2_amd import workloads as wl
+from tests.rescore import rescore
 
 pytestmark = pytest.mark.gpu
 
@@ -209,7 +210,7 @@ def test_traceback_golden_vectors(gpu, matrices, sw_vectors):
     b.run()
     res = b.fetch()
     info, strs = b.traceback(np.arange(len(queries), dtype=np.uint32))
-    n_bt = 0
+    n_bt = n_word = 0
     for i in range(len(queries)):
         if res[i]["score"] <= 0:
             assert info[i]["status"] == 3 and strs[i] == ""
@@ -217,8 +218,14 @@ def test_traceback_golden_vectors(gpu, matrices, sw_vectors):
         assert info[i]["status"] == 0, (i, int(info[i]["status"]))
         assert strs[i] == v["bt"][i], (i, strs[i][:60], v["bt"][i][:60])
         assert int(info[i]["ident"]) == int(v["expect"][i][6]), i
+        # SURVEY.md section 8c's contract for word == 1 hits (and every other one): the path re-scores to score1
+        toff = v["toff"].astype(np.int64)
+        s, qe, te = rescore(queries[i]["q"], queries[i]["comp_bias"], v["tres"][toff[i]:toff[i + 1]], mat, GO, GE,
+                            int(res[i]["q_start"]), int(res[i]["t_start"]), strs[i])
+        assert (s, qe, te) == (int(res[i]["score"]), int(res[i]["q_end"]), int(res[i]["t_end"])), (i, int(res[i]["word"]))
+        n_word += int(res[i]["word"])
         n_bt += 1
-    assert n_bt > 150
+    assert n_bt > 150 and n_word >= 20
     b.free()
 
 
