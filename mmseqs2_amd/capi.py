@@ -476,8 +476,11 @@ class MMGpu:
         cap = int((ql[np.minimum(pairs["query"], len(qs))] + tl[np.minimum(pairs["target"], len(tl) - 1)] + 2).sum()) if len(pairs) else 16
         bt = np.zeros(max(cap, 16), np.uint8)
         used = ctypes.c_uint64()
+        import time
+        t0 = time.perf_counter()
         self._check(self.L.mmgpu_nucl_align(self.ctx, ctypes.byref(par), ctypes.cast(arr, c_p), len(qs), _ptr(pairs), len(pairs),
                                             _ptr(out), _ptr(bt), cap, ctypes.byref(used)))
+        self.last_nucl_call_s = time.perf_counter() - t0     # the C-ABI call alone (upload, kernel, download), no binding work
         raw = bt.tobytes()
         strs = [raw[int(h["bt_off"]):int(h["bt_off"]) + int(h["bt_len"])].decode() if h["status"] == 0 else None for h in out]
         return out, strs

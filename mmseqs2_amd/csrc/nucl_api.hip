@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <numeric>
 
 using namespace mmgpu;
@@ -22,6 +23,10 @@ extern "C" int mmgpu_nucl_align(mmgpu_ctx *c, const mmgpu_nucl_params *par, cons
     if (bt_used) *bt_used = 0;
     if (n_pairs == 0) return MMGPU_OK;
     HIP_TRY(hipSetDevice(c->device));
+    const bool trace = getenv("MMGPU_TRACE") != nullptr;     // debugging aid: where the call's time goes
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(now() - t).count(); };
+    const auto t_begin = now();
     std::vector<uint32_t> qoff(nq + 1, 0);
     for (uint32_t i = 0; i < nq; i++) {
         if (!qs[i].q || qs[i].qlen == 0 || qs[i].qlen > 0x3FFFFFFFu) return fail(MMGPU_ERR_ARG, "mmgpu_nucl_align: bad query");
@@ -106,12 +111,20 @@ extern "C" int mmgpu_nucl_align(mmgpu_ctx *c, const mmgpu_nucl_params *par, cons
     L.bt_cursor = d_ctr.as<unsigned long long>();
     L.bt_cap = bt_cap;
     L.next_pair = reinterpret_cast<uint32_t *>(d_ctr.as<unsigned long long>() + 1);
+    double t_setup = 0, t_kernel = 0;
+    if (trace) { HIP_TRY(hipStreamSynchronize(s)); t_setup = ms_since(t_begin); }
+    const auto t_k = now();
     HIP_TRY(lanes == 64 ? launch_nucl_align_wave(L, blocks, s) : launch_nucl_align(L, blocks, s));
+    if (trace) { HIP_TRY(hipStreamSynchronize(s)); t_kernel = ms_since(t_k); }
     HIP_TRY(hipMemcpyAsync(out, d_out.p, (size_t)n_pairs * sizeof(mmgpu_nucl_hit), hipMemcpyDeviceToHost, s));
     unsigned long long used = 0;
     HIP_TRY(hipMemcpyAsync(&used, d_ctr.p, 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     if (bt && bt_cap) HIP_TRY(hipMemcpy(bt, d_bt.p, (size_t)std::min<uint64_t>(used, bt_cap), hipMemcpyDeviceToHost));
     if (bt_used) *bt_used = used;
+    if (trace)
+        fprintf(stderr, "[nucl_align] %u pairs, %u workgroups x %d lanes/alignment: host prep + upload + alloc %.2f ms, kernel %.2f ms, total %.2f ms "
+                "(scratch %.2f GB, strings %.1f MB)\n", n_pairs, blocks, lanes, t_setup, t_kernel, ms_since(t_begin),
+                (double)(groups * (p_stride + w_stride)) / 1073741824.0, (double)used / 1048576.0);
     return MMGPU_OK;
 }

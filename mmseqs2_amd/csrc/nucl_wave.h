@@ -22,7 +22,7 @@
 //
 // Included after nucl_core.h with NUCL_NG = 64 (SeqView, Ez, seeds, band_of come from there).  The includer supplies,
 // besides nucl_core.h's macros:  NUCL_ROR1_U32(v)  value of lane - 1 (lane 0: lane 63);  NUCL_READLANE(v, l)  value of
-// the (wave-uniform) lane l.
+// the (wave-uniform) lane l;  NUCL_WAVE_MAX_I32(v) / NUCL_WAVE_MIN_U32(v)  reduction over the wave, result in every lane.
 #ifndef MMGPU_NUCL_WAVE_H
 #define MMGPU_NUCL_WAVE_H
 
@@ -100,18 +100,21 @@ NUCL_HD void ksw_extz2_wave(const SeqView &qv, int qlen, const SeqView &tv, int 
             int need = (last_scored + 1 + 15) / 16;     // one past the last block the score pass writes
             need = need < en / 16 + 1 ? en / 16 + 1 : need;
             need = need > tlen_ ? tlen_ : need;
-            if ((ta >> 4) >= init_blocks && (ta >> 4) < need) { ua = va = xa = ya = sa = 0; Ha = KSW_NEG_INF; }
-            if ((tb >> 4) >= init_blocks && (tb >> 4) < need) { ub = vb = xb = yb = sb = 0; Hb = KSW_NEG_INF; }
-            init_blocks = init_blocks > need ? init_blocks : need;
+            if (need > init_blocks) {       // wave-uniform: once per 16 positions the band advances
+                if ((ta >> 4) >= init_blocks && (ta >> 4) < need) { ua = va = xa = ya = sa = 0; Ha = KSW_NEG_INF; }
+                if ((tb >> 4) >= init_blocks && (tb >> 4) < need) { ub = vb = xb = yb = sb = 0; Hb = KSW_NEG_INF; }
+                init_blocks = need;
+            }
         }
+        // x and v of both slots as one register: the carry-in below and the neighbour exchange further down read it
+        const unsigned xv_packed = (unsigned)xa | ((unsigned)va << 8) | ((unsigned)xb << 16) | ((unsigned)vb << 24);
         // what enters the lowest block from the left (:126-132)
         int8_t x1, v1;
         if (st > 0) {
             if (st - 1 >= last_st && st - 1 <= last_en) {
-                const int l1 = (st - 1) & 63;
-                const bool odd = ((st - 1) >> 6) & 1;
-                x1 = (int8_t)(uint8_t)NUCL_READLANE((int)(odd ? xb : xa), l1);
-                v1 = (int8_t)(uint8_t)NUCL_READLANE((int)(odd ? vb : va), l1);
+                const unsigned w1 = (unsigned)NUCL_READLANE((int)xv_packed, (st - 1) & 63) >> ((((st - 1) >> 6) & 1) * 16);
+                x1 = (int8_t)(uint8_t)(w1 & 0xFFu);
+                v1 = (int8_t)(uint8_t)((w1 >> 8) & 0xFFu);
             } else x1 = v1 = 0;
         } else {
             x1 = 0;
@@ -144,10 +147,10 @@ NUCL_HD void ksw_extz2_wave(const SeqView &qv, int qlen, const SeqView &tv, int 
             sb = (uint8_t)sc;
         }
         // x[t-1], v[t-1] of the previous anti-diagonal: one rotate of the packed bytes
-        unsigned nb = NUCL_ROR1_U32((unsigned)xa | ((unsigned)va << 8) | ((unsigned)xb << 16) | ((unsigned)vb << 24));
+        unsigned nb = NUCL_ROR1_U32(xv_packed);
         if (lane == 0) nb = (nb >> 16) | (nb << 16);     // lane 63's other slot
         const bool x1_neg = x1 < 0, v1_neg = v1 < 0;
-        const size_t prow_off = (size_t)r * (size_t)(n_col_ * 16);
+        uint8_t *const prow_ptr = WITH_P ? p + (size_t)r * (size_t)(n_col_ * 16) : nullptr;   // wave-uniform
 #define NUCLW_CELL(T, U, V, X, Y, SC, XT1, VT1)                                                         \
         if ((T) >= st && (T) <= en) {                                                                   \
             int8_t xt1 = (int8_t)(uint8_t)(XT1), vt1 = (int8_t)(uint8_t)(VT1);                          \
@@ -177,7 +180,7 @@ NUCL_HD void ksw_extz2_wave(const SeqView &qv, int qlen, const SeqView &tv, int 
             if (WITH_P) {                                                                               \
                 if (a > 0) d |= 0x08;                                                                   \
                 if (b > 0) d |= 0x10;                                                                   \
-                p[prow_off + (size_t)((T) - st)] = d;                                                   \
+                prow_ptr[(unsigned)((T) - st)] = d;                                                     \
             }                                                                                           \
         }
         NUCLW_CELL(ta, ua, va, xa, ya, sa, nb & 0xFFu, (nb >> 8) & 0xFFu)
@@ -214,7 +217,11 @@ NUCL_HD void ksw_extz2_wave(const SeqView &qv, int qlen, const SeqView &tv, int 
             }
             if (ta == en0) Ha = h_en0;
             if (tb == en0) Hb = h_en0;
-            group_best(best_h, best_o);
+            // (largest H, among those the smallest order) over the wave: two reductions on DPP row operations instead of
+            // six dependent shuffle pairs through the LDS crossbar
+            const int wave_h = NUCL_WAVE_MAX_I32(best_h);
+            best_o = NUCL_WAVE_MIN_U32(best_h == wave_h ? best_o : 0xFFFFFFFFu);
+            best_h = wave_h;
             max_H = best_h;
             if (best_o == 0) max_t = en0;
             else if (best_o <= 4u * 0x100000u) max_t = st0 + (int)((best_o - 1u) & 0xFFFFFu) * 4 + (int)((best_o - 1u) >> 20);
@@ -225,10 +232,13 @@ NUCL_HD void ksw_extz2_wave(const SeqView &qv, int qlen, const SeqView &tv, int 
             max_H = h0;
             max_t = 0;
         }
-        {
-            const int h_en0 = NUCL_READLANE(odd_en0 ? Hb : Ha, l_en0), h_st0 = NUCL_READLANE(odd_st0 ? Hb : Ha, l_st0);
-            if (en0 == tlen - 1 && h_en0 > ez.mte) { ez.mte = h_en0; ez.mte_q = r - en; }
-            if (r - st0 == qlen - 1 && h_st0 > ez.mqe) { ez.mqe = h_st0; ez.mqe_t = st0; }
+        if (en0 == tlen - 1) {          // wave-uniform: only while the band touches the end of the target
+            const int h_en0 = NUCL_READLANE(odd_en0 ? Hb : Ha, l_en0);
+            if (h_en0 > ez.mte) { ez.mte = h_en0; ez.mte_q = r - en; }
+        }
+        if (r - st0 == qlen - 1) {      // ... the end of the query
+            const int h_st0 = NUCL_READLANE(odd_st0 ? Hb : Ha, l_st0);
+            if (h_st0 > ez.mqe) { ez.mqe = h_st0; ez.mqe_t = st0; }
         }
         // ksw_apply_zdrop (ksw2.h:182-199)
         if (max_H > ez.max) {

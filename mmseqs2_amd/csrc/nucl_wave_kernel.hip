@@ -30,6 +30,49 @@
 #endif
 #define NUCL_READLANE(v, l) __builtin_amdgcn_readlane((int)(v), (l))
 #include "mmgpu_internal.h"   // pulls in nucl_core.h with the macros above (SeqView, seeds, band_of ...)
+// Wave reduction on DPP: row_shr 1 / 2 / 4 / 8 inside the rows of 16 lanes (lanes without a source keep their own value:
+// old = v, op(v, v) = v), row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3; lane 63 holds the result.
+#define NUCL_DPP_STEP(v, OP, ctrl, rmask)                                                  \
+    do {                                                                                   \
+        const int o__ = __builtin_amdgcn_update_dpp((v), (v), (ctrl), (rmask), 0xF, false); \
+        (v) = OP((v), o__);                                                                \
+    } while (0)
+static __device__ __forceinline__ int nucl_max_i32(int a, int b) { return a > b ? a : b; }
+static __device__ __forceinline__ int nucl_min_u32(int a, int b) { return (unsigned)a < (unsigned)b ? a : b; }
+static __device__ __forceinline__ int nucl_wave_reduce_max(int v) {
+    NUCL_DPP_STEP(v, nucl_max_i32, 0x111, 0xF);
+    NUCL_DPP_STEP(v, nucl_max_i32, 0x112, 0xF);
+    NUCL_DPP_STEP(v, nucl_max_i32, 0x114, 0xF);
+    NUCL_DPP_STEP(v, nucl_max_i32, 0x118, 0xF);
+    NUCL_DPP_STEP(v, nucl_max_i32, 0x142, 0xA);
+    NUCL_DPP_STEP(v, nucl_max_i32, 0x143, 0xC);
+    return __builtin_amdgcn_readlane(v, 63);
+}
+static __device__ __forceinline__ unsigned nucl_wave_reduce_minu(unsigned u) {
+    int v = (int)u;
+    NUCL_DPP_STEP(v, nucl_min_u32, 0x111, 0xF);
+    NUCL_DPP_STEP(v, nucl_min_u32, 0x112, 0xF);
+    NUCL_DPP_STEP(v, nucl_min_u32, 0x114, 0xF);
+    NUCL_DPP_STEP(v, nucl_min_u32, 0x118, 0xF);
+    NUCL_DPP_STEP(v, nucl_min_u32, 0x142, 0xA);
+    NUCL_DPP_STEP(v, nucl_min_u32, 0x143, 0xC);
+    return (unsigned)__builtin_amdgcn_readlane(v, 63);
+}
+#ifdef MMGPU_NUCL_NO_DPP
+static __device__ __forceinline__ int nucl_wave_reduce_max_shfl(int v) {
+    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_xor(v, d, 64); v = o > v ? o : v; }
+    return v;
+}
+static __device__ __forceinline__ unsigned nucl_wave_reduce_minu_shfl(unsigned v) {
+    for (int d = 1; d < 64; d <<= 1) { const unsigned o = (unsigned)__shfl_xor((int)v, d, 64); v = o < v ? o : v; }
+    return v;
+}
+#define NUCL_WAVE_MAX_I32(v) nucl_wave_reduce_max_shfl(v)
+#define NUCL_WAVE_MIN_U32(v) nucl_wave_reduce_minu_shfl(v)
+#else
+#define NUCL_WAVE_MAX_I32(v) nucl_wave_reduce_max(v)
+#define NUCL_WAVE_MIN_U32(v) nucl_wave_reduce_minu(v)
+#endif
 #include "nucl_wave.h"
 
 namespace mmgpu {

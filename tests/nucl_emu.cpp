@@ -71,6 +71,16 @@ static inline unsigned long long emu_add64(unsigned long long *p, unsigned long 
 #ifdef EMU_WAVE   // the one-wavefront-per-alignment kernel (nucl_wave.h): 64 emulated lanes, its two extra primitives
 #define NUCL_ROR1_U32(v) ((unsigned)emu::exchange((unsigned long long)(unsigned)(v), (emu::cur + emu::LANES - 1) % emu::LANES))
 #define NUCL_READLANE(v, l) ((int)emu::exchange((unsigned long long)(long long)(int)(v), (l)))
+static inline int emu_wave_max(int v) {
+    for (int d = 1; d < emu::LANES; d <<= 1) { const int o = (int)emu::exchange((unsigned long long)(long long)v, emu::cur ^ d); v = o > v ? o : v; }
+    return v;
+}
+static inline unsigned emu_wave_minu(unsigned v) {
+    for (int d = 1; d < emu::LANES; d <<= 1) { const unsigned o = (unsigned)emu::exchange((unsigned long long)v, emu::cur ^ d); v = o < v ? o : v; }
+    return v;
+}
+#define NUCL_WAVE_MAX_I32(v) emu_wave_max(v)
+#define NUCL_WAVE_MIN_U32(v) emu_wave_minu(v)
 #include "nucl_wave.h"
 #endif
 
