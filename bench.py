@@ -330,8 +330,13 @@ def search_headline(args, gpu, torch, dist, rank, world, matrices, barrier):
         out["two_call"] = {"prepare_s_host_scheduling_and_upload": round(t_prep, 3), "run_and_fetch_s": round(t_run_fetch, 4),
                            "fields_differing_from_fused_path": bad,
                            "what": "mmgpu_sw_prepare (caller-supplied lists) + mmgpu_sw_run + mmgpu_sw_fetch, mode START"}
-        out["backtrace"] = {"pairs": bt_n, "with_cigar": int((bt_info["status"] == 0).sum()) if bt_n else 0,
-                            "s_incl_download": round(t_bt, 4), "pairs_per_s": round(bt_n / t_bt, 1) if t_bt > 0 else None}
+        t_bt_c = getattr(swb, "last_traceback_call_s", t_bt)
+        n_cig = int((bt_info["status"] == 0).sum()) if bt_n else 0
+        out["backtrace"] = {"pairs": bt_n, "with_cigar": n_cig, "s_c_abi_calls_incl_download": round(t_bt_c, 4),
+                            "s_incl_python_binding": round(t_bt, 4), "pairs_per_s": round(bt_n / t_bt_c, 1) if t_bt_c > 0 else None,
+                            "cigars_per_s": round(n_cig / t_bt_c, 1) if t_bt_c > 0 else None,
+                            "what": "mmgpu_sw_traceback for every pair of the first 1000 queries' lists (pairs below the start-score "
+                                    "threshold have no start position and are answered MMGPU_BT_NO_START)"}
         swb.free()
         started = int(sum(int((g["q_start"] >= 0).sum()) for g in gpu_res))
         out["pairs_with_start"] = started

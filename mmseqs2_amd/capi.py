@@ -331,15 +331,20 @@ class SwBatch:
     def traceback(self, pair_index):
         """Backtrace strings ('M','I','D') and identity counts of the selected result slots (batch mode >= 1).
         Returns (info SW_BT_DTYPE[n], list of str)."""
+        import time
         idx = np.ascontiguousarray(pair_index, np.uint32)
         info = np.zeros(max(len(idx), 1), SW_BT_DTYPE)
         used = ctypes.c_size_t(0)
+        t0 = time.perf_counter()
         rc = self.gpu.L.mmgpu_sw_traceback(self.gpu.ctx, self.handle, _ptr(idx), len(idx), _ptr(info), None, 0, ctypes.byref(used))
+        t1 = time.perf_counter()
         if rc != 0 and used.value == 0:
             self.gpu._check(rc)
         buf = np.zeros(max(used.value, 1), np.uint8)
+        t2 = time.perf_counter()
         self.gpu._check(self.gpu.L.mmgpu_sw_traceback(self.gpu.ctx, self.handle, _ptr(idx), len(idx), _ptr(info), _ptr(buf),
                                                       buf.size, ctypes.byref(used)))
+        self.last_traceback_call_s = (t1 - t0) + (time.perf_counter() - t2)     # the two C-ABI calls, no binding work
         info = info[:len(idx)]
         strs = [bytes(buf[int(r["bt_off"]):int(r["bt_off"]) + int(r["bt_len"])]).decode() for r in info]
         return info, strs

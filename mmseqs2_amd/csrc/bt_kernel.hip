@@ -11,9 +11,10 @@
 //   * one LANE per alignment (the host sorts the jobs by size so the 64 lanes of a wavefront run similar loops);
 //     the DP is a short-band recurrence with a serial F chain - there is nothing to vectorise inside one alignment
 //     and there are up to 300 x n_queries independent ones;
-//   * the three band rows (H previous, E, H current; H rows ping-pong instead of being copied) and the direction
-//     bits live in a per-wavefront scratch area in HBM, interleaved by lane (word k of lane l at (k * 64 + l)), so
-//     lanes that sit at the same band offset - they do, the loops are driven by the band index - coalesce;
+//   * the three band rows (H previous, E, H current; H rows ping-pong instead of being copied) live in LDS for bands up
+//     to 32 (first tier: nearly every job), lane-interleaved (word k of lane l at k * 64 + l: no bank conflicts), in
+//     a per-wavefront scratch area in HBM with the same interleave for wider bands; the direction bits always go to
+//     that scratch (lanes that sit at the same band offset - the loops are driven by the band index - coalesce);
 //   * directions are packed to 4 bits per cell (E bit, F bit, 2-bit H source) instead of 3 bytes: 0.5 B/cell written.
 // Work per alignment ~ qlen * (2 * band + 1) cells, only for the pairs the host asks a backtrace for
 // (Matcher::SCORE_COV_SEQID / -a), so this kernel is bounded by per-lane latency, not by HBM or VALU peak.
@@ -23,8 +24,16 @@ namespace mmgpu {
 
 namespace {
 
+// LDS_ROWS: the three band rows live in LDS (bands up to BT_LDS_BAND wide - nearly every alignment of a hit list: the
+// band is |tlen - qlen| + 1); every cell reads / writes them in a dependent chain, which through HBM-backed scratch costs a
+// memory round trip per access.  Wider bands keep the rows in the lane-interleaved global scratch (the second and
+// third tier).  The direction bits are write-only during the DP and go to global scratch in both forms.
+constexpr int BT_LDS_WIDTH = 67;     // 2 * band + 3 words per row, band <= 32
+
+template <bool LDS_ROWS>
 __global__ __launch_bounds__(64) void sw_traceback_kernel(BtLaunch L) {
     __shared__ int8_t smat[32 * 32];
+    __shared__ uint32_t srows[LDS_ROWS ? 3 * BT_LDS_WIDTH * 64 : 1];
     const int lane = (int)threadIdx.x;
     for (int k = lane; k < 32 * 32; k += 64) smat[k] = k < L.alphabet * L.alphabet ? L.mat[k] : (int8_t)0;
     __syncthreads();
@@ -33,14 +42,15 @@ __global__ __launch_bounds__(64) void sw_traceback_kernel(BtLaunch L) {
     const BtJob J = L.jobs[jidx];
     const uint32_t ji = J.slot;
     uint32_t *W = L.scratch + (size_t)blockIdx.x * L.words_per_lane * 64u;
-#define AT(idx) W[(size_t)(idx) * 64u + (uint32_t)lane]
+#define DIRW(idx) W[(size_t)(idx) * 64u + (uint32_t)lane]
+#define AT(idx) (LDS_ROWS ? srows[(uint32_t)(idx) * 64u + (uint32_t)lane] : W[(size_t)(idx) * 64u + (uint32_t)lane])
     const int ql = J.q_end - J.q_start + 1, tl = J.t_end - J.t_start + 1;
     const uint8_t *q = L.q_res + L.q_off[J.query] + J.q_start;
     const int8_t *cb = L.q_cb + L.q_off[J.query] + J.q_start;
     const uint8_t *t = L.t_res + (size_t)L.t_off4[J.target] * 4 + J.t_start;
     const int go = L.gap_open, ge = L.gap_extend, alph = L.alphabet;
-    const uint32_t HC = L.band_cap;                 // words per band row
-    const uint32_t DIR0 = 3u * HC;                  // direction words start here
+    const uint32_t HC = LDS_ROWS ? (uint32_t)BT_LDS_WIDTH : L.band_cap;   // words per band row
+    const uint32_t DIR0 = LDS_ROWS ? 0u : 3u * HC;  // direction words start here (the LDS form keeps no rows in W)
     const uint64_t DIRCAP = (uint64_t)L.words_per_lane - DIR0;
     mmgpu_sw_bt info;
     info.bt_off = J.bt_off;
@@ -82,7 +92,10 @@ __global__ __launch_bounds__(64) void sw_traceback_kernel(BtLaunch L) {
             int f = 0, hleft = 0;                   // h_c[b]: H of the cell to the left (h_c[0] = 0)
             uint32_t word = 0;
             const uint32_t dbase = DIR0 + (uint32_t)i * row_words;
+            uint8_t t_next = t[beg];                // the letter of the next cell is requested one cell ahead
             for (int j = beg; j <= end; j++) {
+                const uint8_t t_cur = t_next;
+                if (j < end) t_next = t[j + 1];
                 const int u = j - sh_i + 1, e = j - sh_p + 1, d = e - 1;
                 const int x = j - sh_i;
                 int temp1 = i == 0 ? -go : (int)AT(hb + e) - go;
@@ -97,7 +110,7 @@ __global__ __launch_bounds__(64) void sw_traceback_kernel(BtLaunch L) {
                 const int f1 = f > 0 ? f : 0;
                 const int e1 = ev > 0 ? ev : 0;
                 temp1 = e1 > f1 ? e1 : f1;
-                temp2 = (int)AT(hb + d) + (int)smat[qi + (int)t[j]] + cbi;
+                temp2 = (int)AT(hb + d) + (int)smat[qi + (int)t_cur] + cbi;
                 const int h = temp1 > temp2 ? temp1 : temp2;
                 AT(hc + u) = (uint32_t)h;
                 hleft = h;
@@ -105,7 +118,7 @@ __global__ __launch_bounds__(64) void sw_traceback_kernel(BtLaunch L) {
                 const uint32_t hsel = temp1 <= temp2 ? 0u : (e1 > f1 ? 1u : 2u);
                 word |= (de | (df << 1) | (hsel << 2)) << ((x & 7) * 4);
                 if ((x & 7) == 7 || j == end) {
-                    AT(dbase + (uint32_t)(x >> 3)) = word;
+                    DIRW(dbase + (uint32_t)(x >> 3)) = word;
                     word = 0;
                 }
             }
@@ -135,7 +148,7 @@ __global__ __launch_bounds__(64) void sw_traceback_kernel(BtLaunch L) {
             ok = false;   // the walk left the band: the reference would read unrelated direction bytes here
             break;
         }
-        const uint32_t w = AT(DIR0 + (uint32_t)i * row_words + (uint32_t)(x >> 3));
+        const uint32_t w = DIRW(DIR0 + (uint32_t)i * row_words + (uint32_t)(x >> 3));
         const uint32_t nib = (w >> ((x & 7) * 4)) & 0xFu;
         uint32_t dir;
         if (state == 0) dir = (nib & 1u) ? 3u : 2u;
@@ -171,13 +184,15 @@ __global__ __launch_bounds__(64) void sw_traceback_kernel(BtLaunch L) {
     info.ident = ident;
     L.info[ji] = info;
 #undef AT
+#undef DIRW
 }
 
 }  // namespace
 
 hipError_t launch_sw_traceback(const BtLaunch &L, hipStream_t stream) {
     if (L.n_jobs == 0) return hipSuccess;
-    hipLaunchKernelGGL(sw_traceback_kernel, dim3((L.n_jobs + 63) / 64), dim3(64), 0, stream, L);
+    if (L.band_cap == 0) hipLaunchKernelGGL(sw_traceback_kernel<true>, dim3((L.n_jobs + 63) / 64), dim3(64), 0, stream, L);
+    else hipLaunchKernelGGL(sw_traceback_kernel<false>, dim3((L.n_jobs + 63) / 64), dim3(64), 0, stream, L);
     return hipGetLastError();
 }
 

@@ -237,6 +237,10 @@ struct mmgpu_sw_batch_t {
     uint32_t scratch_cols = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;   // one pair per mmgpu_sw_run since prepare
     bool ran = false;
+    // mmgpu_sw_traceback's host copies of the last run's results
+    std::vector<mmgpu_sw_hit> h_res;
+    std::vector<uint32_t> h_slot_target;
+    bool h_res_valid = false;
 };
 
 // which kernel body serves a query of this length: 16 lanes x R rows per tile, R even, at most 16 * SW_MAX_R rows
@@ -605,6 +609,7 @@ extern "C" int mmgpu_sw_run(mmgpu_ctx *c, mmgpu_sw_batch_t *b) {
     }
     if (ev1) HIP_TRY(hipEventRecord(ev1, c->stream));
     b->ran = true;
+    b->h_res_valid = false;
     return MMGPU_OK;
 }
 
@@ -688,14 +693,20 @@ extern "C" int mmgpu_sw_traceback(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const uint3
     if (!b->ran) return fail(MMGPU_ERR_STATE, "mmgpu_sw_traceback: batch was never run");
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = c->stream;
-    std::vector<mmgpu_sw_hit> res((size_t)b->pairs);
-    if (b->pairs) HIP_TRY(hipMemcpyAsync(res.data(), b->d_out.p, (size_t)b->pairs * sizeof(mmgpu_sw_hit), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    std::vector<uint32_t> pf_host;
-    if (b->from_pf) {   // the lists never left the device: fetch the target id of every slot (the batch's own copy)
-        pf_host.resize((size_t)b->pairs);
-        if (b->pairs) HIP_TRY(hipMemcpy(pf_host.data(), b->d_slot_target.p, (size_t)b->pairs * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    // host copies of the results (and, for device-resident lists, of the slot -> target map): fetched once per run of the
+    // batch, callers ask for the size first and for the strings second
+    if (!b->h_res_valid) {
+        b->h_res.resize((size_t)b->pairs);
+        if (b->pairs) HIP_TRY(hipMemcpyAsync(b->h_res.data(), b->d_out.p, (size_t)b->pairs * sizeof(mmgpu_sw_hit), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (b->from_pf) {
+            b->h_slot_target.resize((size_t)b->pairs);
+            if (b->pairs) HIP_TRY(hipMemcpy(b->h_slot_target.data(), b->d_slot_target.p, (size_t)b->pairs * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        }
+        b->h_res_valid = true;
     }
+    const std::vector<mmgpu_sw_hit> &res = b->h_res;
+    const std::vector<uint32_t> &pf_host = b->h_slot_target;
     std::vector<BtJob> jobs;
     jobs.reserve(n);
     uint64_t off = 0;
@@ -746,11 +757,13 @@ extern "C" int mmgpu_sw_traceback(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const uint3
     L.gap_extend = b->gap_extend;
     L.info = b->d_bt_info.as<mmgpu_sw_bt>();
     L.bt = b->d_bt_str.as<char>();
-    // tier 1: every job, 39 KB of scratch per lane (band <= 256, 64 K cells); tier 2: the jobs tier 1 refused,
-    // 4 MB per lane (band <= 4096, 8 M cells), few at a time
-    const uint32_t tier_band[2] = {515u, 8195u}, tier_dir[2] = {8192u, 1048576u}, tier_blocks[2] = {8192u, 48u};
+    // tier 0: every job, band rows in LDS (band <= 32), 32 KB of direction scratch per lane (64 K cells); tier 1: the jobs
+    // tier 0 refused, rows in scratch too (band <= 256); tier 2: 4 MB per lane (band <= 4096, 8 M cells), few at a time.
+    // band 0 in BtLaunch selects the LDS form.
+    const int n_tiers = 3;
+    const uint32_t tier_band[n_tiers] = {0u, 515u, 8195u}, tier_dir[n_tiers] = {8192u, 8192u, 1048576u}, tier_blocks[n_tiers] = {16384u, 8192u, 48u};
     std::vector<mmgpu_sw_bt> back((size_t)n);
-    for (int tier = 0; tier < 2; tier++) {
+    for (int tier = 0; tier < n_tiers; tier++) {
         const uint32_t wpl = 3u * tier_band[tier] + tier_dir[tier];
         const size_t blocks_max = tier_blocks[tier];
         const size_t njobs = jobs.size();
@@ -766,7 +779,7 @@ extern "C" int mmgpu_sw_traceback(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const uint3
         }
         HIP_TRY(hipMemcpyAsync(back.data(), b->d_bt_info.p, (size_t)n * sizeof(mmgpu_sw_bt), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
-        if (tier == 1) break;
+        if (tier == n_tiers - 1) break;
         std::vector<BtJob> again;
         for (const BtJob &j : jobs)
             if (back[j.slot].status == MMGPU_BT_TOO_LARGE) again.push_back(j);
