@@ -275,7 +275,7 @@ int mmgpu_pf_debug_index(mmgpu_ctx *ctx, uint64_t *offsets, uint32_t *ids, uint1
 
 /* limits of the prefilter entry points: calls beyond them return MMGPU_ERR_UNSUPPORTED and the host keeps its CPU path */
 #define MMGPU_PF_MAX_HITS 4096      /* max_hits (--max-seqs) */
-#define MMGPU_PF_MAX_SEQ_LEN 32768  /* sequences must be shorter (UngappedAlignment::computeLongScore is not on the device) */
+#define MMGPU_PF_MAX_SEQ_LEN 65536  /* Parameters.h:271; queries / candidates of 32768 residues or more: MMGPU_PF_LONG_SEQ */
 
 typedef struct {
     int kmer_thr;            /* Prefiltering::getKmerThreshold */
@@ -305,6 +305,10 @@ typedef struct {
 #define MMGPU_PF_OVERFLOW 1 /* the query needs more than 62 flushes of the reference's databaseHits buffer
                                (QueryMatcher.cpp:310-346; up to 62 are emulated on the device): not computed here,
                                the host must run QueryMatcher::matchQuery for this query */
+#define MMGPU_PF_LONG_SEQ 2 /* the query, or the target of one of its double-diagonal candidates, has 32768 residues or more:
+                               the reference scores those with UngappedAlignment::computeLongScore (every 65536-shift of the
+                               16-bit diagonal, UngappedAlignment.cpp:295-312, and a batching quirk at :265-273) - not on the
+                               device; the host must run QueryMatcher::matchQuery for this query */
 
 typedef struct {
     uint64_t db_matches;     /* statistics_t::dbMatches */

@@ -78,7 +78,8 @@ bool MMGpuMatcher::alignBlock(const std::vector<Query> &queries, int covMode, fl
         dq[q].comp_bias = bias[q].data();
         dq[q].target_ids = ids[q].data();
         dq[q].n_targets = (uint32_t)ids[q].size();
-        dq[q].min_start_score = alignmentMode == Matcher::SCORE_ONLY ? 0 : minScoreForEvalue(evalThr, qu.L);
+        // (a query with an empty prefilter list is never mapped, Alignment.cpp:322: nothing to align, no threshold)
+        dq[q].min_start_score = (alignmentMode == Matcher::SCORE_ONLY || qu.L <= 0 || ids[q].empty()) ? 0 : minScoreForEvalue(evalThr, qu.L);
     }
     for (size_t q = 0; q < nq; q++) firstPair[q + 1] = firstPair[q] + ids[q].size();
     const size_t total = firstPair[nq];

@@ -98,7 +98,7 @@ bool MMGpuPrefilter::matchBlock(const std::vector<Query> &queries, int kmerThr, 
         return false;
     }
     for (size_t q = 0; q < nq; q++) {
-        if (status[q] == MMGPU_PF_OVERFLOW) {
+        if (status[q] != MMGPU_PF_OK) {     // MMGPU_PF_OVERFLOW / MMGPU_PF_LONG_SEQ: the host's own matcher runs this query
             needsCpu[q] = true;
             continue;
         }

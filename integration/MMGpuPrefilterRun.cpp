@@ -7,7 +7,8 @@
 // then runs over blocks of queries: every thread maps sequences, ONE device call returns the hit_t lists of the block
 // (MMGpuPrefilter::matchBlock = the batch form of matchQuery), every thread finishes its queries with the reference's own
 // statements (:876-917: local id -> key, canBeCovered, prefilterHitToBuffer, DBWriter, statistics).  Queries the device
-// declines (more than 62 flushes of the databaseHits buffer) go through a host QueryMatcher.
+// declines (more than 62 flushes of the databaseHits buffer; a sequence of 32768 residues or more involved, which the
+// reference scores with computeLongScore) go through a host QueryMatcher.
 //
 // Compiled into MMseqs2 by integration/build_mmseqs.sh (HAVE_MMGPU); Prefiltering.h declares the class a friend.
 #include <climits>
@@ -44,7 +45,6 @@ bool MMGpuPrefilterRun::usable(Prefiltering &p) {
     else if (p.ungappedSubMatAux != NULL) why = "auxiliary ungapped matrix";
     else if (p.taxonomyHook != NULL) why = "taxonomy filter";
     else if (p.maxResListLen > MMGPU_PF_MAX_HITS) why = "--max-seqs above the device limit";
-    else if (std::max(p.tdbr->getMaxSeqLen(), p.qdbr->getMaxSeqLen()) >= MMGPU_PF_MAX_SEQ_LEN) why = "sequences too long for the device";
     if (why != NULL) {
         Debug(Debug::INFO) << "MMGPU: prefilter configuration not covered by the device path (" << why << "), using the CPU path\n";
         return false;

@@ -309,7 +309,9 @@ static int sw_prepare_impl(mmgpu_ctx *c, const mmgpu_sw_params *par, const mmgpu
     std::vector<int32_t> qbias(std::max<uint32_t>(nq, 1), 0), qminstart(std::max<uint32_t>(nq, 1), 0);
     uint64_t total_hits = 0;
     for (uint32_t i = 0; i < nq; i++) {
-        if (qs[i].qlen == 0 || qs[i].qlen > 65535 || !qs[i].q) { delete b; return fail(MMGPU_ERR_ARG, "mmgpu_sw_prepare: bad query"); }
+        // a query without targets may come without residues (Alignment::run never maps the query of an empty list, :322)
+        const bool empty_ok = !pf && qs[i].n_targets == 0 && qs[i].qlen == 0;
+        if (!empty_ok && (qs[i].qlen == 0 || qs[i].qlen > 65535 || !qs[i].q)) { delete b; return fail(MMGPU_ERR_ARG, "mmgpu_sw_prepare: bad query"); }
         qoff[i + 1] = qoff[i] + qs[i].qlen;
         total_hits += pf ? pf_stride : qs[i].n_targets;
     }
@@ -330,6 +332,10 @@ static int sw_prepare_impl(mmgpu_ctx *c, const mmgpu_sw_params *par, const mmgpu
     bool any_multi = false;
     for (uint32_t i = 0; i < nq; i++) {
         const mmgpu_sw_query &Q = qs[i];
+        if (Q.qlen == 0) {      // empty list, no residues: no jobs, no result slots
+            b->h_qout_off[i + 1] = out_cursor;
+            continue;
+        }
         memcpy(qres.data() + qoff[i], Q.q, Q.qlen);
         int mincb = 0;
         for (uint32_t k = 0; k < Q.qlen; k++) {

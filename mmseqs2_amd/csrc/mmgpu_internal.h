@@ -190,6 +190,8 @@ struct PfDedupArgs {
     const uint8_t *t_res;
     const uint32_t *t_off4, *t_len;
     uint32_t min_diag_score;
+    uint32_t *q_flags;                // [nq] bit 0: a candidate's target has >= 32768 residues (UngappedAlignment::computeLongScore,
+                                      // UngappedAlignment.cpp:295-312, is not on the device: the host runs the query)
     // overflow emulation (null when the batch has no query on the overflow path)
     const uint32_t *q_nseg;           // [nq] databaseHits flushes of the query (0 = ordinary query)
     const uint32_t *seg_start;        // [nq][PF_MAX_SEG + 2] arrival index at which segment k starts
@@ -210,6 +212,7 @@ struct PfSelectArgs {
     mmgpu_pf_xhit *xhits;             // null = ordinary run
     const uint32_t *global_ids;       // [n_targets] local -> global id
     const uint32_t *q_nseg;           // overflow-path queries (their order key is not shard independent), may be null
+    const uint32_t *q_flags;          // long-sequence queries (scores not computed on the device), may be null
     const uint32_t *q_off, *peb, *list_base;
     const PfList *lists;
 };

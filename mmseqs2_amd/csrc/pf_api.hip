@@ -249,7 +249,6 @@ static int pf_setup(mmgpu_ctx *c, const mmgpu_pf_index *ix, bool from_host, PfIn
         if (!ix->entries6 && !(ix->entry_ids && ix->entry_pos) && ix->n_entries) return fail(MMGPU_ERR_ARG, "mmgpu_pf_load_index: no index entries");
         if (ix->n_entries >= 0xFFFFFFFFull) return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_pf_load_index: >= 2^32 index entries per shard");
     }
-    if (c->db.max_len >= 32768) return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_pf_load_index: targets of length >= 32768 (computeLongScore) are not implemented");
     HIP_TRY(hipSetDevice(c->device));
     pf_index_free(c);
     PfIndex *P = new PfIndex();
@@ -471,7 +470,8 @@ struct mmgpu_pf_batch_t {
     DevBuf d_nsim, d_qtot, d_qbase, d_list_base, d_pos_entries, d_peb, d_qentries;
     DevBuf d_qtile_base, d_qntiles, d_bucket_count, d_bucket_off;
     DevBuf d_ovf_queries, d_qnseg, d_seg_start, d_qfinal, d_ovf_base, d_ovf_a, d_ovf_b, d_ovf_ocount, d_ovf_totals;
-    DevBuf d_cand_small, d_cand_base, d_cand_count, d_cells, d_surv_count, d_hits, d_hit_count, d_diag_thr;
+    DevBuf d_cand_small, d_cand_base, d_cand_count, d_cells, d_surv_count, d_hits, d_hit_count, d_diag_thr, d_qflags;
+    std::vector<uint8_t> long_query;   // queries of 32768 residues or more: not processed on the device (MMGPU_PF_LONG_SEQ)
     bool exchange = false;     // prepared while a shard was set (mmgpu_pf_set_shard): d_hits holds mmgpu_pf_xhit records
     // host mirrors of the last run
     std::vector<uint64_t> q_lists, q_entries;
@@ -537,12 +537,14 @@ extern "C" int mmgpu_pf_prepare(mmgpu_ctx *c, const mmgpu_pf_params *par, const 
     uint64_t tot = 0;
     for (uint32_t i = 0; i < nq; i++) {
         if (!qs[i].q || qs[i].qlen == 0) { delete b; return fail(MMGPU_ERR_ARG, "mmgpu_pf_prepare: bad query"); }
-        if (qs[i].qlen >= 32768) { delete b; return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_pf_prepare: queries of length >= 32768 (computeLongScore) are not implemented"); }
+        if (qs[i].qlen > 65535) { delete b; return fail(MMGPU_ERR_ARG, "mmgpu_pf_prepare: query longer than 65535 (Parameters.h:271)"); }
         tot += qs[i].qlen;
         if (tot > 0x7FFFFFFFull) { delete b; return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_pf_prepare: more than 2^31 query residues per batch"); }
         b->q_off[i + 1] = (uint32_t)tot;
     }
     b->n_pos = (uint32_t)tot;
+    b->long_query.assign(nq, 0);
+    for (uint32_t i = 0; i < nq; i++) b->long_query[i] = qs[i].qlen >= 32768 ? 1 : 0;
     std::vector<uint8_t> qres(tot + 64, 0);    // + slack: the ungapped kernel reads whole dwords
     std::vector<int16_t> qthr(tot, -1);
     std::vector<int8_t> qcorr(tot + 64, 0);
@@ -559,8 +561,9 @@ extern "C" int mmgpu_pf_prepare(mmgpu_ctx *c, const mmgpu_pf_params *par, const 
                 qres[o + p] = Q.q[p];
             }
             qident[i] = Q.identity_id;
-            // QueryMatcher::match, QueryMatcher.cpp:255-274: per-window threshold
-            for (int p = 0; p + P.pattern_len <= L; p++) {
+            // QueryMatcher::match, QueryMatcher.cpp:255-274: per-window threshold (a query handed back to the host gets none:
+            // no window, no work)
+            for (int p = 0; p + P.pattern_len <= L && !b->long_query[i]; p++) {
                 float bc = 0;
                 bool x = false;
                 for (int z = 0; z < P.k; z++) {
@@ -618,6 +621,7 @@ extern "C" int mmgpu_pf_prepare(mmgpu_ctx *c, const mmgpu_pf_params *par, const 
     B_TRY(b->d_hits.alloc((size_t)nqq * max_hits * (exchange ? sizeof(mmgpu_pf_xhit) : sizeof(mmgpu_pf_hit))));
     B_TRY(b->d_hit_count.alloc(nqq * 4));
     B_TRY(b->d_diag_thr.alloc(nqq * 4));
+    B_TRY(b->d_qflags.alloc(nqq * 4));
     for (auto &e : b->ev) B_TRY(hipEventCreate(&e));
     B_TRY(hipStreamSynchronize(s));
 #undef B_TRY
@@ -634,6 +638,8 @@ extern "C" int mmgpu_pf_run(mmgpu_ctx *c, mmgpu_pf_batch_t *b) {
     hipStream_t s = c->stream;
     const uint32_t nq = b->nq;
     b->status.assign(nq, MMGPU_PF_OK);
+    for (uint32_t i = 0; i < nq; i++)
+        if (b->long_query[i]) b->status[i] = MMGPU_PF_LONG_SEQ;
     b->q_lists.assign(nq, 0);
     b->q_entries.assign(nq, 0);
     if (nq == 0) { b->ran = true; return MMGPU_OK; }
@@ -743,7 +749,7 @@ extern "C" int mmgpu_pf_run(mmgpu_ctx *c, mmgpu_pf_batch_t *b) {
     uint64_t total_entries = 0;
     for (uint32_t i = 0; i < nq; i++) {
         uint64_t e = b->q_entries[i];
-        if (b->status[i] == MMGPU_PF_OVERFLOW) e = 0;   // not processed on the device
+        if (b->status[i] != MMGPU_PF_OK) e = 0;   // not processed on the device
         qent[i] = (uint32_t)e;
         qebase[i] = total_entries;
         total_entries += e;
@@ -776,6 +782,7 @@ extern "C" int mmgpu_pf_run(mmgpu_ctx *c, mmgpu_pf_batch_t *b) {
     HIP_TRY(hipMemsetAsync(b->d_bucket_count.p, 0, (size_t)nq * B * 4, s));
     HIP_TRY(hipMemsetAsync(b->d_surv_count.p, 0, (size_t)nq * 4, s));
     HIP_TRY(hipMemsetAsync(b->d_cells.p, 0, (size_t)nq * 8, s));
+    HIP_TRY(hipMemsetAsync(b->d_qflags.p, 0, (size_t)nq * 4, s));
 
     // ---- stage 1: gather + stable split ----
     PfSplitArgs SA;
@@ -829,6 +836,7 @@ extern "C" int mmgpu_pf_run(mmgpu_ctx *c, mmgpu_pf_batch_t *b) {
     D.q_nseg = ovf_q.empty() ? nullptr : b->d_qnseg.as<uint32_t>();
     D.seg_start = ovf_q.empty() ? nullptr : b->d_seg_start.as<uint32_t>();
     D.cell_counter = b->d_cells.as<uint64_t>();
+    D.q_flags = b->d_qflags.as<uint32_t>();
     HIP_TRY(launch_pf_dedup(D, b->ev[5], b->ev[6], s));
     if (!ovf_q.empty()) {
         // the flushes of the overflow path, one launch per flush (the total kept after flush k decides what flush k+1 does)
@@ -879,6 +887,7 @@ extern "C" int mmgpu_pf_run(mmgpu_ctx *c, mmgpu_pf_batch_t *b) {
     S.xhits = nullptr;
     S.global_ids = nullptr;
     S.q_nseg = nullptr;
+    S.q_flags = b->d_qflags.as<uint32_t>();
     S.q_off = S.peb = S.list_base = nullptr;
     S.lists = nullptr;
     if (b->exchange) {
@@ -908,7 +917,8 @@ extern "C" int mmgpu_pf_fetch(mmgpu_ctx *c, mmgpu_pf_batch_t *b, mmgpu_pf_hit *h
     if (nq == 0) return MMGPU_OK;
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = c->stream;
-    std::vector<uint32_t> thr(nq), surv(nq);
+    std::vector<uint32_t> thr(nq), surv(nq), flags(nq);
+    HIP_TRY(hipMemcpyAsync(flags.data(), b->d_qflags.p, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpy2DAsync(hits, (size_t)hit_stride * sizeof(mmgpu_pf_hit), b->d_hits.p, (size_t)b->max_hits * sizeof(mmgpu_pf_hit),
                              (size_t)b->max_hits * sizeof(mmgpu_pf_hit), nq, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(counts, b->d_hit_count.p, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
@@ -916,6 +926,7 @@ extern "C" int mmgpu_pf_fetch(mmgpu_ctx *c, mmgpu_pf_batch_t *b, mmgpu_pf_hit *h
     HIP_TRY(hipMemcpyAsync(surv.data(), b->d_surv_count.p, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     for (uint32_t i = 0; i < nq; i++) {
+        if (flags[i] && b->status[i] == MMGPU_PF_OK) b->status[i] = MMGPU_PF_LONG_SEQ;
         if (b->status[i] != MMGPU_PF_OK) counts[i] = 0;
         if (status) status[i] = b->status[i];
         if (stats) {

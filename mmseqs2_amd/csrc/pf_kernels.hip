@@ -590,6 +590,9 @@ __device__ __forceinline__ uint64_t score_chunk(const PfDedupArgs &A, const int8
         }
         my_addr = (unsigned long long)reinterpret_cast<uintptr_t>(t + ts);
         cells = (uint64_t)my_len;
+        // targets of 32768 residues or more take the reference's computeLongScore (every 65536-shift of the 16-bit
+        // diagonal, and a batch quirk of scoreDiagonalAndUpdateHits): the query is handed back to the host
+        if (tlen >= 32768 && A.q_flags) atomicOr(&A.q_flags[q], 1u);
     }
     int my_score = 0;
     constexpr int UN = 2;   // candidates per group in flight: 4 groups x UN = 8 per round trip
@@ -1127,6 +1130,7 @@ __global__ __launch_bounds__(256) void pf_overflow_kernel(PfOvfArgs A) {
             const uint32_t id = cur[idx].id;
             const int d = (int)(short)cur[idx].diag;
             const int tlen = (int)D.t_len[id];
+            if (tlen >= 32768 && D.q_flags) atomicOr(&D.q_flags[q], 1u);
             const uint8_t *t = D.t_res + (size_t)D.t_off4[id] * 4;
             const int mind = d < 0 ? -d : d;
             int len = 0, qs = 0, ts = 0;
@@ -1356,7 +1360,7 @@ __global__ __launch_bounds__(256) void pf_select_kernel(PfSelectArgs A) {
                 const uint32_t slot = atomicAdd(&sh_nsel, 1u);
                 if (XCHG) {
                     if (slot < max_hits) {
-                        const bool ovf = A.q_nseg != nullptr && A.q_nseg[q] != 0;
+                        const bool ovf = (A.q_nseg != nullptr && A.q_nseg[q] != 0) || (A.q_flags != nullptr && A.q_flags[q] != 0);
                         mmgpu_pf_xhit x;
                         x.id = A.global_ids[c.id];
                         x.score = c.score;

@@ -294,11 +294,16 @@ int mmgpu_pf_run(mmgpu_ctx *c, mmgpu_pf_batch_t *b) {
     return bad ? fail(MMGPU_ERR_ARG, "mmo_pf_match_query failed") : 0;
 }
 
-int mmgpu_pf_fetch(mmgpu_ctx *, mmgpu_pf_batch_t *b, mmgpu_pf_hit *hits, uint32_t stride, uint32_t *counts, int32_t *status,
+int mmgpu_pf_fetch(mmgpu_ctx *c, mmgpu_pf_batch_t *b, mmgpu_pf_hit *hits, uint32_t stride, uint32_t *counts, int32_t *status,
                    mmgpu_pf_qstat *stats) {
+    // sequences of 32768 residues or more are not restated in the oracle (UngappedAlignment::computeLongScore): like the
+    // device, hand such queries back to the host - here, conservatively, every query once the database holds a long target
+    bool long_target = false;
+    for (uint32_t t = 0; t < c->n; t++) long_target |= c->toff[t + 1] - c->toff[t] >= 32768;
     for (size_t i = 0; i < b->q.size(); i++) {
         counts[i] = (uint32_t)b->hits[i].size();
-        status[i] = MMGPU_PF_OK;
+        status[i] = (long_target || b->q[i].size() >= 32768) ? MMGPU_PF_LONG_SEQ : MMGPU_PF_OK;
+        if (status[i] != MMGPU_PF_OK) counts[i] = 0;
         for (size_t k = 0; k < b->hits[i].size() && k < stride; k++) {
             mmgpu_pf_hit &o = hits[i * (size_t)stride + k];
             o.id = b->hits[i][k].id;

@@ -172,3 +172,51 @@ def test_small_synthetic_host_side_emulated(tmp_path):
     run(STOCK, ["align", "q", "t", "pref_s0", "aln_s", "-a", "--threads", THREADS, "-v", "2"], w)
     run(MMGPU, ["align", "q", "t", "pref_s0", "aln_g", "-a", "--threads", THREADS, "-v", "3"], w, True)
     same(os.path.join(w, "aln_s"), os.path.join(w, "aln_g"))
+
+
+def _long_case(w):
+    """a database with a 40 000-residue target that carries homologs of two queries, and a 33 000-residue query"""
+    rng = np.random.default_rng(11)
+    (qres, qoff), (tres, toff), _, _ = wl.config3_prefilter(n_families=40, members=20, n_queries=12, seed=8)
+    qs, tl = wl.split(qres, qoff), wl.split(tres, toff)
+    big = rng.choice(20, size=40000, p=wl.BACKGROUND).astype(np.uint8)
+    for k, at in ((0, 1000), (1, 34000)):
+        h = wl.mutate(rng, qs[k], 0.8)
+        big[at:at + len(h)] = h
+    tl.append(big)
+    longq = rng.choice(20, size=33000, p=wl.BACKGROUND).astype(np.uint8)
+    longq[5000:5000 + len(tl[3])] = tl[3]
+    qs.append(longq)
+    wl.write_fasta(os.path.join(w, "q.fasta"), *wl.seqs_from_list(qs), "q")
+    wl.write_fasta(os.path.join(w, "t.fasta"), *wl.seqs_from_list(tl), "t")
+    run(STOCK, ["createdb", "q.fasta", "q", "-v", "1"], w)
+    run(STOCK, ["createdb", "t.fasta", "t", "-v", "1"], w)
+
+
+def _long_pipeline(w, emulate):
+    _long_case(w)
+    run(STOCK, ["prefilter", "q", "t", "pref_s", "-s", "5.7", "--threads", THREADS, "-v", "2"], w)
+    log = run(MMGPU, ["prefilter", "q", "t", "pref_g", "-s", "5.7", "--threads", THREADS, "-v", "3"], w, emulate)
+    assert "MMGPU: device" in log and "using the CPU path" not in log, log[-2000:]
+    assert same(os.path.join(w, "pref_s"), os.path.join(w, "pref_g")) == 13
+    # the long target is found by the queries planted in it, the long query finds its planted target
+    pref = dbio.read_db(os.path.join(w, "pref_s"))
+    long_key = [line.split("\t")[0] for line in open(os.path.join(w, "t.index")) if int(line.split("\t")[2]) > 40000][0].encode()
+    assert sum(any(l.split(b"\t")[0] == long_key for l in e.split(b"\n") if l) for e in pref.values()) >= 2
+    run(STOCK, ["align", "q", "t", "pref_s", "aln_s", "-a", "--threads", THREADS, "-v", "2"], w)
+    log = run(MMGPU, ["align", "q", "t", "pref_s", "aln_g", "-a", "--threads", THREADS, "-v", "3"], w, emulate)
+    assert "MMGPU: device" in log and "using the CPU path" not in log, log[-2000:]
+    assert same(os.path.join(w, "aln_s"), os.path.join(w, "aln_g")) == 13
+
+
+def test_long_sequences_host_side_emulated(tmp_path):
+    """sequences of 32768 residues or more: the prefilter hands those queries back to the host matcher (computeLongScore),
+    the alignment runs them on the device path"""
+    if not os.path.exists(EMU):
+        pytest.skip("oracle/_build/emu/libmmgpu.so not built (make -C oracle emu)")
+    _long_pipeline(str(tmp_path), True)
+
+
+@pytest.mark.gpu
+def test_long_sequences_on_device(tmp_path):
+    _long_pipeline(str(tmp_path), False)
