@@ -57,6 +57,10 @@ public:
     void newBlock() { std::fill(lastQuery.begin(), lastQuery.end(), (size_t)-1); }
     bool run(unsigned int thread, size_t queryIndex, const unsigned char *query, int queryLength, const unsigned char *target,
              int targetLength, s_align &a, std::string &backtrace) {
+        if (thread >= sw.size()) {
+            Debug(Debug::ERROR) << "MMGPU: OpenMP thread " << thread << " outside the " << sw.size() << " threads of this run\n";
+            EXIT(EXIT_FAILURE);
+        }
         if (sw[thread] == NULL) {
             sw[thread] = new SmithWaterman(maxSeqLen, m->alphabetSize, compBias, compBiasScale, (SubstitutionMatrix *)m);
             seq[thread] = new Sequence(maxSeqLen, seqType, m, 0, false, compBias);
@@ -170,6 +174,7 @@ bool MMGpuAlignRun::run(Alignment &al, const std::string &outDB, const std::stri
     const size_t maxMatcherSeqLen = std::max(al.tdbr->getMaxSeqLen(), al.qdbr->getMaxSeqLen());
     HostBlockBacktracer blockHook(threads, maxMatcherSeqLen, al.m, al.compBiasCorrection, al.compBiasCorrectionScale, al.gapOpen,
                                   al.gapExtend, al.querySeqType);
+    gpuMatcher.setThreads(threads);
     if (MMGpuRun::hostBlockAligner()) gpuMatcher.setBlockBacktracer(&blockHook, lookupTarget, &store);
     std::vector<Matcher *> cpuMatchers(threads, NULL);      // only for pairs whose backtrace the device declines
 
@@ -263,11 +268,13 @@ bool MMGpuAlignRun::run(Alignment &al, const std::string &outDB, const std::stri
         }
 
         // ---- one device call for the block
+        if (getenv("MMGPU_TRACE")) fprintf(stderr, "[mmgpu align] block of %zu queries parsed\n", nq);
         blockHook.newBlock();
         if (!gpuMatcher.alignBlock(block, al.covMode, al.covThr, al.evalThr, al.swMode, al.seqIdMode, results, &refused)) {
             Debug(Debug::ERROR) << "MMGPU: " << gpuMatcher.error() << "\n";
             EXIT(EXIT_FAILURE);
         }
+        if (getenv("MMGPU_TRACE")) fprintf(stderr, "[mmgpu align] block aligned, %zu backtraces handed back to the host\n", refused.size());
         // pairs whose backtrace the device declined (band storage above its budget): the reference's own call
         for (size_t r = 0; r < refused.size(); r++) {
             const size_t b = refused[r].first;

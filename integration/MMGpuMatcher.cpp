@@ -2,6 +2,8 @@
 
 #include <algorithm>
 #include <climits>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "StripedSmithWaterman.h"
@@ -15,7 +17,7 @@
 MMGpuMatcher::MMGpuMatcher(MMGpuAlignBackend *backend, BaseMatrix *m, EvalueComputation *evaluer, bool aaBiasCorrection,
                            float aaBiasCorrectionScale, int gapOpen, int gapExtend)
     : backend(backend), m(m), evaluer(evaluer), aaBiasCorrection(aaBiasCorrection),
-      aaBiasCorrectionScale(aaBiasCorrectionScale), gapOpen(gapOpen), gapExtend(gapExtend), blockHook(NULL),
+      aaBiasCorrectionScale(aaBiasCorrectionScale), gapOpen(gapOpen), gapExtend(gapExtend), numThreads(0), blockHook(NULL),
       targetLookup(NULL), targetLookupCtx(NULL) {
     const int a = m->alphabetSize;
     tinySubMat.resize(a * a);
@@ -53,6 +55,10 @@ bool MMGpuMatcher::alignBlock(const std::vector<Query> &queries, int covMode, fl
                               std::vector<std::vector<Matcher::result_t> > &results,
                               std::vector<std::pair<size_t, size_t> > *refusedPairs) {
     const size_t nq = queries.size();
+    int nthreads = 1;
+#ifdef OPENMP
+    nthreads = numThreads > 0 ? (int)numThreads : omp_get_max_threads();
+#endif
     if (refusedPairs) refusedPairs->clear();
     results.assign(nq, std::vector<Matcher::result_t>());
     // ---- per query: rounded composition bias as ssw_init builds it (StripedSmithWaterman.cpp:1364-1383) and the list
@@ -61,7 +67,7 @@ bool MMGpuMatcher::alignBlock(const std::vector<Query> &queries, int covMode, fl
     std::vector<std::vector<uint32_t> > ids(nq);
     std::vector<mmgpu_sw_query> dq(nq);
     std::vector<size_t> firstPair(nq + 1, 0);
-#pragma omp parallel for schedule(dynamic, 16)
+#pragma omp parallel for schedule(dynamic, 16) num_threads(nthreads)
     for (size_t q = 0; q < nq; q++) {
         const Query &qu = queries[q];
         bias[q].assign(qu.L, 0);
@@ -81,6 +87,7 @@ bool MMGpuMatcher::alignBlock(const std::vector<Query> &queries, int covMode, fl
         // (a query with an empty prefilter list is never mapped, Alignment.cpp:322: nothing to align, no threshold)
         dq[q].min_start_score = (alignmentMode == Matcher::SCORE_ONLY || qu.L <= 0 || ids[q].empty()) ? 0 : minScoreForEvalue(evalThr, qu.L);
     }
+    if (getenv("MMGPU_TRACE")) fprintf(stderr, "[mmgpu matcher] composition bias done\n");
     for (size_t q = 0; q < nq; q++) firstPair[q + 1] = firstPair[q] + ids[q].size();
     const size_t total = firstPair[nq];
     mmgpu_sw_params par;
@@ -95,10 +102,11 @@ bool MMGpuMatcher::alignBlock(const std::vector<Query> &queries, int covMode, fl
         return false;
     }
 
+    if (getenv("MMGPU_TRACE")) fprintf(stderr, "[mmgpu matcher] device alignment returned\n");
     // ---- host part of ssw_align_private (StripedSmithWaterman.cpp:846-890) per pair; pairs that go on to the
     // backtrace are collected for one traceback call
     std::vector<Pending> aln(total);
-#pragma omp parallel for schedule(dynamic, 4)
+#pragma omp parallel for schedule(dynamic, 4) num_threads(nthreads)
     for (size_t q = 0; q < nq; q++) {
         unsigned int thread = 0;
 #ifdef OPENMP
@@ -154,6 +162,7 @@ bool MMGpuMatcher::alignBlock(const std::vector<Query> &queries, int covMode, fl
             p++;
         }
     }
+    if (getenv("MMGPU_TRACE")) fprintf(stderr, "[mmgpu matcher] %zu pairs aligned on the device, gates + block hook done\n", total);
     std::vector<uint32_t> btPairs;
     for (size_t p = 0; p < total; p++)
         if (aln[p].wantsBacktrace) btPairs.push_back((uint32_t)p);
@@ -163,13 +172,14 @@ bool MMGpuMatcher::alignBlock(const std::vector<Query> &queries, int covMode, fl
         err = backend->lastError();
         return false;
     }
+    if (getenv("MMGPU_TRACE")) fprintf(stderr, "[mmgpu matcher] %zu backtraces returned\n", btPairs.size());
     std::vector<int> btOf(total, -1);
     for (size_t i = 0; i < btPairs.size(); i++) btOf[btPairs[i]] = (int)i;
 
     // ---- Matcher::getSWResult's tail (Matcher.cpp:93-143) ----
     bool refused = false;
     std::vector<unsigned char> refusedFlag(total, 0);
-#pragma omp parallel for schedule(dynamic, 16)
+#pragma omp parallel for schedule(dynamic, 16) num_threads(nthreads)
     for (size_t q = 0; q < nq; q++) {
         const Query &qs = queries[q];
         const int origQueryLen = qs.L;

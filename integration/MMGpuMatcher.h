@@ -80,6 +80,10 @@ public:
 
     const std::string &error() const { return err; }
 
+    // threads of the parallel loops inside alignBlock (Alignment lowers its thread count to the number of queries,
+    // Alignment.cpp:128, while the OpenMP default stays at --threads: per-thread state is sized by the former)
+    void setThreads(unsigned int n) { numThreads = n; }
+
     // targetSequence(id) must return the numeric residues of a resident target (needed by the hook only)
     typedef const unsigned char *(*TargetLookup)(void *ctx, unsigned int id);
     void setBlockBacktracer(MMGpuBlockBacktracer *hook, TargetLookup lookup, void *lookupCtx) {
@@ -102,6 +106,7 @@ private:
     std::vector<int8_t> tinySubMat;      // Matcher::setSubstitutionMatrix, Matcher.cpp:29-36
     std::vector<int16_t> subMat16;
     std::string err;
+    unsigned int numThreads;
     MMGpuBlockBacktracer *blockHook;
     TargetLookup targetLookup;
     void *targetLookupCtx;

@@ -9,6 +9,8 @@
 
 #include "mmgpu_internal.h"
 
+#include <chrono>
+
 using namespace mmgpu;
 
 namespace mmgpu {
@@ -603,8 +605,10 @@ extern "C" int mmgpu_sw_run(mmgpu_ctx *c, mmgpu_sw_batch_t *b) {
             if (getenv("MMGPU_TRACE")) {   // debugging aid: run the groups one at a time and say which one is in flight
                 fprintf(stderr, "[sw_run] group %d jobs %u lds %zu both %d from_pf %d scratch_cols %u\n", g, L.n_jobs, b->group_lds[g], (int)(b->mode == MMGPU_SW_START), (int)b->from_pf, b->scratch_cols);
                 fflush(stderr);
+                const auto t0 = std::chrono::steady_clock::now();
                 hipError_t e = hipStreamSynchronize(st);
-                fprintf(stderr, "[sw_run] group %d done: %s\n", g, hipGetErrorString(e));
+                fprintf(stderr, "[sw_run] group %d done after %.2f ms: %s\n", g,
+                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), hipGetErrorString(e));
                 fflush(stderr);
             }
         }

@@ -171,6 +171,12 @@ int mmgpu_sw_traceback(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const uint32_t *idx, u
             info[i].status = MMGPU_BT_NO_START;
             continue;
         }
+        // test switch: decline long backtraces like the device does when the band storage exceeds its scratch budget,
+        // so that the host's fallback (Matcher::getSWResult for the pair) is exercised without a GPU
+        if (getenv("MMGPU_EMU_REFUSE_BT") && (h.q_end - h.q_start + 1) + (h.t_end - h.t_start + 1) > atoi(getenv("MMGPU_EMU_REFUSE_BT"))) {
+            info[i].status = MMGPU_BT_TOO_LARGE;
+            continue;
+        }
         const uint32_t qi = b->pair[idx[i]].first, id = b->pair[idx[i]].second;
         const std::vector<uint8_t> &q = b->q[qi];
         const uint8_t *t = c->tres.data() + c->toff[id];

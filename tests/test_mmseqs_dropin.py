@@ -194,6 +194,9 @@ def _long_case(w):
 
 
 def _long_pipeline(w, emulate):
+    # 13 queries on 48 threads: Alignment lowers its own thread count to the number of queries (Alignment.cpp:128) while
+    # the OpenMP default stays at --threads - per-thread state of the device path must follow the former
+    THREADS = "48"
     _long_case(w)
     run(STOCK, ["prefilter", "q", "t", "pref_s", "-s", "5.7", "--threads", THREADS, "-v", "2"], w)
     log = run(MMGPU, ["prefilter", "q", "t", "pref_g", "-s", "5.7", "--threads", THREADS, "-v", "3"], w, emulate)

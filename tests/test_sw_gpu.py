@@ -267,3 +267,44 @@ def test_traceback_vs_oracle_lists(gpu, oracle, matrices):
         n_ok += 1
     assert n_ok > 500
     b.free()
+
+
+def test_very_long_query_and_target(gpu, oracle, matrices):
+    """a 33 000-residue query (74 tiles) and a 40 000-residue target with planted homologs: scores, ends, starts and the
+    backtraces of the planted pairs against the oracle"""
+    rng = np.random.default_rng(11)
+    mat = matrices["blosum62_sw"]
+    small = [rng.choice(20, size=int(rng.integers(150, 400)), p=wl.BACKGROUND).astype(np.uint8) for _ in range(6)]
+    big_t = rng.choice(20, size=40000, p=wl.BACKGROUND).astype(np.uint8)
+    big_t[1000:1000 + len(small[0])] = small[0]
+    h = wl.mutate(rng, small[1], 0.8)
+    big_t[34000:34000 + len(h)] = h
+    big_q = rng.choice(20, size=33000, p=wl.BACKGROUND).astype(np.uint8)
+    big_q[5000:5000 + len(small[3])] = small[3]
+    tl = small + [big_t]
+    tres, toff = wl.seqs_from_list(tl)
+    gpu.load_targets(tres, toff, 21)
+    ids = np.arange(len(tl), dtype=np.uint32)
+    qs = [small[0], small[1], big_q]
+    queries = [dict(q=q, comp_bias=_round_cb(oracle, matrices, q), targets=ids, min_start_score=40) for q in qs]
+    b = gpu.sw_prepare(mat, GO, GE, queries, mode=1)
+    b.run()
+    out = b.fetch().reshape(3, len(tl))
+    for qi, qd in enumerate(queries):
+        for k in range(len(tl)):
+            r = oracle.sw_align(qd["q"], qd["comp_bias"], tl[k], mat, GO, GE, need_start=True)
+            g = out[qi, k]
+            assert (int(g["score"]), int(g["q_end"]), int(g["t_end"]), int(g["word"])) == (r["score"], r["q_end"], r["t_end"], r["word"]), (qi, k)
+            if r["score"] >= 40:
+                assert (int(g["q_start"]), int(g["t_start"])) == (r["q_start"], r["t_start"]), (qi, k)
+    pick = np.array([0 * len(tl) + 6, 1 * len(tl) + 6, 2 * len(tl) + 3, 2 * len(tl) + 6], np.uint32)
+    info, strs = b.traceback(pick)
+    for k, p in enumerate(pick.tolist()):
+        qi, ti = divmod(p, len(tl))
+        if out[qi, ti]["score"] < 40:
+            continue
+        r = oracle.sw_align(queries[qi]["q"], queries[qi]["comp_bias"], tl[ti], mat, GO, GE, need_start=True, need_bt=True)
+        assert int(info[k]["status"]) in (0, 1), (k, int(info[k]["status"]))
+        if int(info[k]["status"]) == 0:
+            assert strs[k] == r["bt"] and int(info[k]["ident"]) == r["ident"], k
+    b.free()
