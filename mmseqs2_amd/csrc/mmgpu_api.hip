@@ -753,7 +753,6 @@ extern "C" int mmgpu_sw_traceback(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const uint3
     HIP_TRY(b->d_bt_jobs.reserve(jobs.size() * sizeof(BtJob)));
     HIP_TRY(b->d_bt_info.reserve((size_t)n * sizeof(mmgpu_sw_bt)));
     HIP_TRY(b->d_bt_str.reserve((size_t)off + 16));
-    HIP_TRY(hipMemcpyAsync(b->d_bt_jobs.p, jobs.data(), jobs.size() * sizeof(BtJob), hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(b->d_bt_info.p, info, (size_t)n * sizeof(mmgpu_sw_bt), hipMemcpyHostToDevice, s));
     BtLaunch L;
     L.q_res = b->d_qres.as<uint8_t>();
@@ -767,18 +766,38 @@ extern "C" int mmgpu_sw_traceback(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const uint3
     L.gap_extend = b->gap_extend;
     L.info = b->d_bt_info.as<mmgpu_sw_bt>();
     L.bt = b->d_bt_str.as<char>();
-    // tier 0: every job, band rows in LDS (band <= 32), 32 KB of direction scratch per lane (64 K cells); tier 1: the jobs
-    // tier 0 refused, rows in scratch too (band <= 256); tier 2: 4 MB per lane (band <= 4096, 8 M cells), few at a time.
-    // band 0 in BtLaunch selects the LDS form.
-    const int n_tiers = 3;
-    const uint32_t tier_band[n_tiers] = {0u, 515u, 8195u}, tier_dir[n_tiers] = {8192u, 8192u, 1048576u}, tier_blocks[n_tiers] = {16384u, 8192u, 48u};
+    // Scratch tiers (band rows | direction words per lane | blocks of 64 alignments in flight):
+    //   0: rows in LDS (band <= 32),     8 K words (64 K cells)  - nearly every pair of a hit list
+    //   1: rows in LDS (band <= 32),   128 K words (1 M cells)   - long alignments with a narrow band
+    //   2: rows in scratch (band <= 256), 128 K words
+    //   3: rows in scratch (band <= 4096),  1 M words (8 M cells), few at a time; beyond: MMGPU_BT_TOO_LARGE, the host runs banded_sw
+    // A job starts at the first tier its initial band (|tlen - qlen| + 1) fits and moves up when the doubling outgrows it.
+    // band 0 in BtLaunch selects the LDS form of the kernel.
+    const int n_tiers = 4;
+    const uint32_t tier_band[n_tiers] = {0u, 0u, 515u, 8195u}, tier_dir[n_tiers] = {8192u, 131072u, 131072u, 1048576u};
+    const uint32_t tier_blocks[n_tiers] = {16384u, 256u, 256u, 48u};
+    auto first_tier = [&](const BtJob &j) {
+        const int64_t ql = j.q_end - j.q_start + 1, tl = j.t_end - j.t_start + 1;
+        const int64_t bw = std::llabs(tl - ql) + 1, width = 2 * bw + 3, words = (2 * bw + 1 + 7) / 8 * ql;
+        for (int t = 0; t < n_tiers; t++) {
+            const int64_t cap = tier_band[t] ? (int64_t)tier_band[t] : 67;
+            if (width <= cap && words <= (int64_t)tier_dir[t]) return t;
+        }
+        return n_tiers - 1;
+    };
     std::vector<mmgpu_sw_bt> back((size_t)n);
-    for (int tier = 0; tier < n_tiers; tier++) {
+    std::vector<BtJob> pending = jobs, now;
+    for (int tier = 0; tier < n_tiers && !pending.empty(); tier++) {
+        now.clear();
+        std::vector<BtJob> later;
+        for (const BtJob &j : pending) (first_tier(j) <= tier ? now : later).push_back(j);
+        if (now.empty()) continue;
         const uint32_t wpl = 3u * tier_band[tier] + tier_dir[tier];
         const size_t blocks_max = tier_blocks[tier];
-        const size_t njobs = jobs.size();
+        const size_t njobs = now.size();
         const size_t blocks_needed = std::min<size_t>((njobs + 63) / 64, blocks_max);
         HIP_TRY(b->d_bt_scratch.reserve(blocks_needed * (size_t)wpl * 64 * sizeof(uint32_t)));
+        HIP_TRY(hipMemcpyAsync(b->d_bt_jobs.p, now.data(), now.size() * sizeof(BtJob), hipMemcpyHostToDevice, s));
         L.scratch = b->d_bt_scratch.as<uint32_t>();
         L.words_per_lane = wpl;
         L.band_cap = tier_band[tier];
@@ -789,13 +808,9 @@ extern "C" int mmgpu_sw_traceback(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const uint3
         }
         HIP_TRY(hipMemcpyAsync(back.data(), b->d_bt_info.p, (size_t)n * sizeof(mmgpu_sw_bt), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
-        if (tier == n_tiers - 1) break;
-        std::vector<BtJob> again;
-        for (const BtJob &j : jobs)
-            if (back[j.slot].status == MMGPU_BT_TOO_LARGE) again.push_back(j);
-        if (again.empty()) break;
-        jobs.swap(again);
-        HIP_TRY(hipMemcpyAsync(b->d_bt_jobs.p, jobs.data(), jobs.size() * sizeof(BtJob), hipMemcpyHostToDevice, s));
+        for (const BtJob &j : now)
+            if (back[j.slot].status == MMGPU_BT_TOO_LARGE && tier + 1 < n_tiers) later.push_back(j);
+        pending.swap(later);
     }
     for (uint32_t k = 0; k < n; k++)
         if (info[k].status != MMGPU_BT_NO_START) info[k] = back[k];
