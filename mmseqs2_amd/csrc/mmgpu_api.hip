@@ -235,7 +235,7 @@ struct mmgpu_sw_batch_t {
     std::vector<uint32_t> h_out_target;   // target id of every result slot (kept for mmgpu_sw_traceback, mode >= START)
     std::vector<uint32_t> h_qout_off;     // [nq + 1] first result slot of every query
     std::vector<uint32_t> h_qoff;         // [nq + 1] residue offsets
-    DevBuf d_bt_scratch, d_bt_jobs, d_bt_info, d_bt_str;
+    DevBuf d_bt_scratch, d_bt_jobs, d_bt_info, d_bt_str, d_bt_cursor;
     uint32_t scratch_cols = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;   // one pair per mmgpu_sw_run since prepare
     bool ran = false;
@@ -301,7 +301,7 @@ static int sw_prepare_impl(mmgpu_ctx *c, const mmgpu_sw_params *par, const mmgpu
     b->gap_extend = par->gap_extend;
     b->n_queries = nq;
     for (DevBuf *d : {&b->d_qres, &b->d_qcb, &b->d_qoff, &b->d_qbias, &b->d_qminstart, &b->d_hit_target, &b->d_hit_out, &b->d_out,
-                      &b->d_mat, &b->d_stats, &b->d_bt_scratch, &b->d_bt_jobs, &b->d_bt_info, &b->d_bt_str, &b->d_scratch_busy,
+                      &b->d_mat, &b->d_stats, &b->d_bt_scratch, &b->d_bt_jobs, &b->d_bt_info, &b->d_bt_str, &b->d_bt_cursor, &b->d_scratch_busy,
                       &b->d_pf_counts, &b->d_slot_target})
         d->bind(c->cache);
 
@@ -787,6 +787,50 @@ extern "C" int mmgpu_sw_traceback(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const uint3
     };
     std::vector<mmgpu_sw_bt> back((size_t)n);
     std::vector<BtJob> pending = jobs, now;
+    const bool trace = getenv("MMGPU_TRACE") != nullptr;
+    L.dir_pool = nullptr;
+    L.dir_pool_bytes = 0;
+    L.dir_cursor = nullptr;
+    static const bool lane_kernel_only = getenv("MMGPU_BT_LANE_KERNEL") != nullptr;   // cross-check switch: skip the wave kernel
+    if (!lane_kernel_only) {
+        // ---- the wave kernel takes every job first (bt_wave_kernel.hip); what it declines (band beyond its LDS ring,
+        // direction pool exhausted) goes through the tiers of the lane-per-alignment kernel below
+        uint64_t want = 0;
+        for (const BtJob &j : jobs) {
+            const uint64_t ql = (uint64_t)(j.q_end - j.q_start + 1), tl = (uint64_t)(j.t_end - j.t_start + 1);
+            const uint64_t bw0 = (ql > tl ? ql - tl : tl - ql) + 1;
+            want += ql * (2 * std::min<uint64_t>(4 * bw0, 510) + 1);
+        }
+        const uint64_t pool = std::min<uint64_t>(std::max<uint64_t>(want, 64ull << 20), 8ull << 30);
+        HIP_TRY(b->d_bt_scratch.reserve(pool + 16));
+        HIP_TRY(b->d_bt_cursor.reserve(16));
+        HIP_TRY(hipMemsetAsync(b->d_bt_cursor.p, 0, 16, s));
+        HIP_TRY(hipMemcpyAsync(b->d_bt_jobs.p, jobs.data(), jobs.size() * sizeof(BtJob), hipMemcpyHostToDevice, s));
+        L.dir_pool = b->d_bt_scratch.as<uint8_t>();
+        L.dir_pool_bytes = pool;
+        L.dir_cursor = b->d_bt_cursor.as<unsigned long long>();
+        L.jobs = b->d_bt_jobs.as<BtJob>();
+        L.n_jobs = (uint32_t)jobs.size();
+        HIP_TRY(launch_sw_traceback_wave(L, s));
+        HIP_TRY(hipMemcpyAsync(back.data(), b->d_bt_info.p, (size_t)n * sizeof(mmgpu_sw_bt), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        pending.clear();
+        for (const BtJob &j : jobs)
+            if (back[j.slot].status == MMGPU_BT_TOO_LARGE) pending.push_back(j);
+        if (trace) {
+            const auto t = std::chrono::steady_clock::now();
+            fprintf(stderr, "[sw_traceback] wave kernel: %zu jobs, %zu declined, pool %.1f MB\n", jobs.size(), pending.size(), (double)pool / 1048576.0);
+            (void)t;
+        }
+    }
+    auto t_prev = std::chrono::steady_clock::now();
+    auto lap = [&]() {
+        const auto t = std::chrono::steady_clock::now();
+        const double ms = std::chrono::duration<double, std::milli>(t - t_prev).count();
+        t_prev = t;
+        return ms;
+    };
+    if (trace) fprintf(stderr, "[sw_traceback] %u pairs asked, %zu with a start position\n", n, jobs.size());
     for (int tier = 0; tier < n_tiers && !pending.empty(); tier++) {
         now.clear();
         std::vector<BtJob> later;
@@ -808,13 +852,16 @@ extern "C" int mmgpu_sw_traceback(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const uint3
         }
         HIP_TRY(hipMemcpyAsync(back.data(), b->d_bt_info.p, (size_t)n * sizeof(mmgpu_sw_bt), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
+        size_t moved = 0;
         for (const BtJob &j : now)
-            if (back[j.slot].status == MMGPU_BT_TOO_LARGE && tier + 1 < n_tiers) later.push_back(j);
+            if (back[j.slot].status == MMGPU_BT_TOO_LARGE && tier + 1 < n_tiers) { later.push_back(j); moved++; }
+        if (trace) fprintf(stderr, "[sw_traceback] tier %d: %zu jobs, %zu moved up, %.2f ms\n", tier, now.size(), moved, lap());
         pending.swap(later);
     }
     for (uint32_t k = 0; k < n; k++)
         if (info[k].status != MMGPU_BT_NO_START) info[k] = back[k];
     if (off) HIP_TRY(hipMemcpyAsync(bt, b->d_bt_str.p, (size_t)off, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    if (trace) fprintf(stderr, "[sw_traceback] strings downloaded (%.1f MB), %.2f ms\n", (double)off / 1048576.0, lap());
     return MMGPU_OK;
 }

@@ -355,9 +355,14 @@ struct BtLaunch {
     uint32_t band_cap;          // words per band row (3 rows), the rest of words_per_lane holds direction bits
     mmgpu_sw_bt *info;          // indexed by BtJob::slot
     char *bt;
+    // wave kernel (bt_wave_kernel.hip): one pool of direction bytes, carved up by a bump allocator
+    uint8_t *dir_pool;
+    unsigned long long dir_pool_bytes;
+    unsigned long long *dir_cursor;
 };
 
 hipError_t launch_sw_traceback(const BtLaunch &L, hipStream_t stream);
+hipError_t launch_sw_traceback_wave(const BtLaunch &L, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------------------
 // host-side plumbing shared by mmgpu_api.hip and pf_api.hip

@@ -51,4 +51,9 @@ t0 = time.perf_counter()
 fb.run()
 gpu.synchronize()
 print("traced (groups serialised) total %.2f ms" % ((time.perf_counter() - t0) * 1e3))
+for rep in range(2):
+    t0 = time.perf_counter()
+    info, _ = fb.traceback(np.arange(300 * min(1000, nq), dtype=np.uint32))
+    print("traceback of the first 1000 lists: %.1f ms incl. python, %.1f ms in the C-ABI calls, %d cigars" %
+          ((time.perf_counter() - t0) * 1e3, fb.last_traceback_call_s * 1e3, int((info["status"] == 0).sum())))
 fb.free()
