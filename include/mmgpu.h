@@ -97,6 +97,12 @@ typedef struct {
                                  The host derives it from the E-value threshold (the smallest raw score whose
                                  EvalueComputation::computeEvalue passes -e; ssw_align_private returns early
                                  otherwise, StripedSmithWaterman.cpp:857-863).  <= 1 means every scoring pair. */
+    const int8_t *profile;    /* profile query (Parameters::DBTYPE_HMM_PROFILE): Sequence::getAlignmentProfile(), int8
+                                 [PROFILE_AA_SIZE = 20 or more letters][qlen] letter-major, as ssw_init receives it
+                                 (StripedSmithWaterman.cpp:1364-1420); q = the consensus sequence (numSequence, used for the
+                                 identity count of the backtrace only), comp_bias is ignored (:1375-1384).  Letters from
+                                 profile_letters on (the X state) score 0 (:1389-1390).  NULL = sequence query. */
+    uint32_t profile_letters; /* letters the profile holds rows for (Sequence::PROFILE_AA_SIZE = 20); 0 with profile == NULL */
 } mmgpu_sw_query;
 
 /* s_align (StripedSmithWaterman.h:52-67) restricted to what the kernels produce. */

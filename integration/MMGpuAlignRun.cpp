@@ -110,9 +110,11 @@ const unsigned char *lookupTarget(void *ctx, unsigned int id) {
 
 bool MMGpuAlignRun::usable(const Alignment &a) {
     if (!MMGpuRun::enabled()) return false;
-    const bool aa = Parameters::isEqualDbtype(a.querySeqType, Parameters::DBTYPE_AMINO_ACIDS) &&
+    const bool profileQuery = Parameters::isEqualDbtype(a.querySeqType, Parameters::DBTYPE_HMM_PROFILE);
+    const bool aa = (Parameters::isEqualDbtype(a.querySeqType, Parameters::DBTYPE_AMINO_ACIDS) ||
+                     (profileQuery && !a.includeIdentity && !a.sameQTDB)) &&
                     Parameters::isEqualDbtype(a.targetSeqType, Parameters::DBTYPE_AMINO_ACIDS);
-    // what the device path does not cover keeps the reference's CPU loop: profile / nucleotide databases,
+    // what the device path does not cover keeps the reference's CPU loop: profile targets / nucleotide databases,
     // realignment, alternative alignments, wrapped scoring, LCA realignment, correlation score
     if (!aa || a.realign || a.altAlignment > 0 || a.wrappedScoring || a.lcaAlign || a.correlationScoreWeight != 0.0f) {
         Debug(Debug::INFO) << "MMGPU: alignment configuration not covered by the device path, using the CPU path\n";
@@ -188,6 +190,9 @@ bool MMGpuAlignRun::run(Alignment &al, const std::string &outDB, const std::stri
     Debug::Progress progress(dbSize);
     std::vector<MMGpuMatcher::Query> block;
     std::vector<std::vector<unsigned char> > queryNum;
+    std::vector<std::vector<int8_t> > queryProfile;       // profile queries: Sequence::getAlignmentProfile()
+    std::vector<size_t> queryIds;
+    const bool profileQuery = Parameters::isEqualDbtype(al.querySeqType, Parameters::DBTYPE_HMM_PROFILE);
     std::vector<std::vector<ListEntry> > lists;
     std::vector<DBKeyType> queryKeys;
     std::vector<std::vector<Matcher::result_t> > results;
@@ -203,6 +208,8 @@ bool MMGpuAlignRun::run(Alignment &al, const std::string &outDB, const std::stri
         const size_t nq = blockEnd - next;
         block.assign(nq, MMGpuMatcher::Query());
         queryNum.assign(nq, std::vector<unsigned char>());
+        queryProfile.assign(nq, std::vector<int8_t>());
+        queryIds.assign(nq, 0);
         lists.assign(nq, std::vector<ListEntry>());
         queryKeys.assign(nq, 0);
 
@@ -238,6 +245,12 @@ bool MMGpuAlignRun::run(Alignment &al, const std::string &outDB, const std::stri
                     queryNum[b].assign(qSeq.numSequence, qSeq.numSequence + qSeq.L);
                     q.numSequence = queryNum[b].data();
                     q.L = qSeq.L;
+                    queryIds[b] = qId;
+                    if (profileQuery) {     // Matcher::initQuery: the aligner gets the profile's own score rows (Matcher.cpp:49-60)
+                        const int8_t *ap = qSeq.getAlignmentProfile();
+                        queryProfile[b].assign(ap, ap + Sequence::PROFILE_AA_SIZE * (size_t)qSeq.L);
+                        q.profile = queryProfile[b].data();
+                    }
                 }
                 while (*data != '\0') {
                     Util::parseKey(data, buffer);
@@ -282,7 +295,8 @@ bool MMGpuAlignRun::run(Alignment &al, const std::string &outDB, const std::stri
             if (cpuMatchers[0] == NULL)
                 cpuMatchers[0] = new Matcher(al.querySeqType, maxMatcherSeqLen, al.m, &evaluer, al.compBiasCorrection,
                                              al.compBiasCorrectionScale, al.gapOpen, al.gapExtend, 0.0f, al.zdrop);
-            qSeqs[0]->mapSequence(0, queryKeys[b], std::make_pair(block[b].numSequence, (const unsigned int)block[b].L));
+            if (profileQuery) qSeqs[0]->mapSequence(queryIds[b], queryKeys[b], al.qdbr->getData(queryIds[b], 0), al.qdbr->getSeqLen(queryIds[b]));
+            else qSeqs[0]->mapSequence(0, queryKeys[b], std::make_pair(block[b].numSequence, (const unsigned int)block[b].L));
             dbSeqs[0]->mapSequence(t.id, t.dbKey, std::make_pair(t.numSequence, (const unsigned int)t.length));
             cpuMatchers[0]->initQuery(qSeqs[0]);
             results[b][refused[r].second] = cpuMatchers[0]->getSWResult(dbSeqs[0], 0, false, al.covMode, al.covThr, al.evalThr,

@@ -46,6 +46,7 @@ struct Pending {
     s_align a;
     bool wantsBacktrace;   // reaches banded_sw in alignStartPosBacktrace (mode 2 and coverage ok)
     bool blockDone;        // start / backtrace / identities came from the host's block aligner
+    bool refuse;           // the pair is recomputed by the host's Matcher (profile query in block-aligner range)
     std::string blockBacktrace;
 };
 }  // namespace
@@ -71,7 +72,7 @@ bool MMGpuMatcher::alignBlock(const std::vector<Query> &queries, int covMode, fl
     for (size_t q = 0; q < nq; q++) {
         const Query &qu = queries[q];
         bias[q].assign(qu.L, 0);
-        if (aaBiasCorrection) {
+        if (aaBiasCorrection && qu.profile == NULL) {      // ssw_init: no correction for profile queries (:1375-1384)
             std::vector<float> tmp(qu.L);
             SubstitutionMatrix::calcLocalAaBiasCorrection(m, qu.numSequence, qu.L, tmp.data(), aaBiasCorrectionScale);
             for (int i = 0; i < qu.L; i++)      // the statement of ssw_init, :1379 (the cast binds to the comparison)
@@ -81,7 +82,9 @@ bool MMGpuMatcher::alignBlock(const std::vector<Query> &queries, int covMode, fl
             if (!qu.targets[k].isIdentity) ids[q].push_back(qu.targets[k].id);
         dq[q].q = qu.numSequence;
         dq[q].qlen = (uint32_t)qu.L;
-        dq[q].comp_bias = bias[q].data();
+        dq[q].comp_bias = qu.profile ? NULL : bias[q].data();
+        dq[q].profile = qu.profile;
+        dq[q].profile_letters = qu.profile ? (uint32_t)Sequence::PROFILE_AA_SIZE : 0u;
         dq[q].target_ids = ids[q].data();
         dq[q].n_targets = (uint32_t)ids[q].size();
         // (a query with an empty prefilter list is never mapped, Alignment.cpp:322: nothing to align, no threshold)
@@ -130,6 +133,7 @@ bool MMGpuMatcher::alignBlock(const std::vector<Query> &queries, int covMode, fl
             a.word = h.word;
             pe.wantsBacktrace = false;
             pe.blockDone = false;
+            pe.refuse = false;
             if (a.dbEndPos1 != -1) {
                 a.qCov = SmithWaterman::computeCov(0, a.qEndPos1, qlen);
                 a.tCov = SmithWaterman::computeCov(0, a.dbEndPos1, dbLen);
@@ -138,7 +142,11 @@ bool MMGpuMatcher::alignBlock(const std::vector<Query> &queries, int covMode, fl
                 const bool lowEval = a.evalue > evalThr;
                 if (!(alignmentMode == 0 || ((alignmentMode == 2 || alignmentMode == 1) && (lowEval || lowCov)))) {
                     // word == 1: the stock reference asks the block aligner first (:865-882)
-                    if (a.word == 1 && blockHook != NULL) {
+                    if (a.word == 1 && blockHook != NULL && queries[q].profile != NULL) {
+                        // the stock reference runs the block aligner's profile form here; the hook below only speaks
+                        // sequences, so the pair goes back to the host's own Matcher::getSWResult as a whole
+                        pe.refuse = true;
+                    } else if (a.word == 1 && blockHook != NULL) {
                         s_align b = a;
                         std::string bt;
                         if (blockHook->run(thread, q, queries[q].numSequence, qlen, targetLookup(targetLookupCtx, tg.id), dbLen, b, bt)) {
@@ -147,7 +155,7 @@ bool MMGpuMatcher::alignBlock(const std::vector<Query> &queries, int covMode, fl
                             a = b;
                         }
                     }
-                    if (!pe.blockDone) {
+                    if (!pe.blockDone && !pe.refuse) {
                         // alignStartPosBacktrace (:1129-1258): start positions from the reverse scan
                         a.qStartPos1 = h.q_start;
                         a.dbStartPos1 = h.t_start;
@@ -189,7 +197,7 @@ bool MMGpuMatcher::alignBlock(const std::vector<Query> &queries, int covMode, fl
             const Target &tg = qs.targets[t];
             s_align a;
             std::string backtrace;
-            if (tg.isIdentity) {
+            if (tg.isIdentity) {      // (callers do not mark identity hits for profile queries: MMGpuAlignRun::usable)
                 // SmithWaterman::scoreIdentical (StripedSmithWaterman.cpp:1770-1805): the diagonal of the word profile
                 memset(&a, 0, sizeof(a));
                 a.qStartPos1 = alignmentMode == 0 ? -1 : 0;
@@ -208,7 +216,10 @@ bool MMGpuMatcher::alignBlock(const std::vector<Query> &queries, int covMode, fl
                 a.identicalAACnt = (uint32_t)tg.length;
             } else {
                 a = aln[p].a;
-                if (aln[p].blockDone) {
+                if (aln[p].refuse) {
+                    refused = true;
+                    refusedFlag[p] = 1;
+                } else if (aln[p].blockDone) {
                     backtrace.swap(aln[p].blockBacktrace);
                 } else if (btOf[p] >= 0) {
                     const mmgpu_sw_bt &bi = btInfo[btOf[p]];

@@ -1,6 +1,6 @@
 // Host side of the alignment seam, in the reference's own types: what a maintainer compiles into MMseqs2 next to
 // src/alignment/Matcher.cpp.  MMGpuMatcher is the batch form of Matcher::initQuery + Matcher::getSWResult
-// (src/alignment/Matcher.cpp:49-144) for amino-acid sequence queries: the Smith-Waterman scans, the start positions
+// (src/alignment/Matcher.cpp:49-144) for amino-acid sequence and profile queries against amino-acid targets: the Smith-Waterman scans, the start positions
 // and the backtraces come from libmmgpu (include/mmgpu.h) for a whole block of queries at once, everything
 // getSWResult and ssw_align_private do around them on the host - composition bias, E-value and coverage gates,
 // sequence identity, bit score, the result_t record - is done here with the reference's own functions, so that
@@ -64,6 +64,10 @@ public:
         const unsigned char *numSequence;   // Sequence::numSequence of the query (the caller keeps it alive)
         int L;                              // Sequence::L
         std::vector<Target> targets;        // the prefilter list, in list order
+        // profile query (DBTYPE_HMM_PROFILE): Sequence::getAlignmentProfile(), [Sequence::PROFILE_AA_SIZE][L], kept alive by
+        // the caller; numSequence is then the consensus sequence.  NULL: sequence query.  (Matcher::initQuery, Matcher.cpp:49-60)
+        const int8_t *profile;
+        Query() : numSequence(NULL), L(0), profile(NULL) {}
     };
 
     MMGpuMatcher(MMGpuAlignBackend *backend, BaseMatrix *m, EvalueComputation *evaluer, bool aaBiasCorrection,

@@ -38,7 +38,8 @@ class SwParams(ctypes.Structure):
 
 class SwQuery(ctypes.Structure):
     _fields_ = [("q", c_p), ("qlen", ctypes.c_uint32), ("comp_bias", c_p), ("target_ids", c_p),
-                ("n_targets", ctypes.c_uint32), ("min_start_score", ctypes.c_int32)]
+                ("n_targets", ctypes.c_uint32), ("min_start_score", ctypes.c_int32), ("profile", c_p),
+                ("profile_letters", ctypes.c_uint32)]
 
 
 class NuclParams(ctypes.Structure):
@@ -413,7 +414,8 @@ class MMGpu:
         self._target_lens = np.diff(offsets.astype(np.int64))
 
     def _marshal(self, mat, gap_open, gap_extend, queries):
-        """queries: list of dicts {q: uint8[], comp_bias: int8[]|None, targets: uint32[], min_start_score: int}"""
+        """queries: list of dicts {q: uint8[], comp_bias: int8[]|None, targets: uint32[], min_start_score: int,
+        profile: int8[letters][qlen]|None (profile query: Sequence::getAlignmentProfile, q = consensus)}"""
         mat = np.ascontiguousarray(mat, np.int8)
         par = SwParams(_ptr(mat), mat.shape[0], gap_open, gap_extend)
         arr = (SwQuery * max(len(queries), 1))()
@@ -422,8 +424,12 @@ class MMGpu:
             q = np.ascontiguousarray(qd["q"], np.uint8)
             cb = None if qd.get("comp_bias") is None else np.ascontiguousarray(qd["comp_bias"], np.int8)
             t = np.ascontiguousarray(qd["targets"], np.uint32)
-            keep += [q, cb, t]
-            arr[i] = SwQuery(_ptr(q), len(q), _ptr(cb), _ptr(t), len(t), int(qd.get("min_start_score", 0)))
+            prof = None if qd.get("profile") is None else np.ascontiguousarray(qd["profile"], np.int8)
+            if prof is not None and (prof.ndim != 2 or prof.shape[1] != len(q)):
+                raise ValueError("profile must be [letters][qlen]")
+            keep += [q, cb, t, prof]
+            arr[i] = SwQuery(_ptr(q), len(q), _ptr(cb), _ptr(t), len(t), int(qd.get("min_start_score", 0)), _ptr(prof),
+                             0 if prof is None else prof.shape[0])
         return par, arr, keep
 
     def sw_batch(self, mat, gap_open, gap_extend, queries, mode=0):
@@ -443,7 +449,7 @@ class MMGpu:
     def sw_marshal_queries(self, mat, gap_open, gap_extend, queries):
         """Query descriptors for sw_prepare_from_pf, built once (the ctypes marshalling is binding cost, not path cost)."""
         qd = [dict(q=x["q"], comp_bias=x.get("comp_bias"), targets=np.zeros(0, np.uint32),
-                   min_start_score=x.get("min_start_score", 0)) for x in queries]
+                   min_start_score=x.get("min_start_score", 0), profile=x.get("profile")) for x in queries]
         return self._marshal(mat, gap_open, gap_extend, qd) + (len(queries),)
 
     def sw_prepare_from_pf(self, mat, gap_open, gap_extend, queries, pf_batch, mode=1, marshalled=None):

@@ -49,6 +49,13 @@ __global__ __launch_bounds__(64) void sw_traceback_kernel(BtLaunch L) {
     const int8_t *cb = L.q_cb + L.q_off[J.query] + J.q_start;
     const uint8_t *t = L.t_res + (size_t)L.t_off4[J.target] * 4 + J.t_start;
     const int go = L.gap_open, ge = L.gap_extend, alph = L.alphabet;
+    // profile query: score of (row i, letter t) = prof[t * full query length + q_start + i], no bias (:1565-1567)
+    const int8_t *prof = nullptr;
+    int qfull = 0;
+    if (L.q_prof_off && L.q_prof_off[J.query] != 0xFFFFFFFFu) {
+        qfull = (int)(L.q_off[J.query + 1] - L.q_off[J.query]);
+        prof = L.q_prof + L.q_prof_off[J.query] + J.q_start;
+    }
     const uint32_t HC = LDS_ROWS ? (uint32_t)BT_LDS_WIDTH : L.band_cap;   // words per band row
     const uint32_t DIR0 = LDS_ROWS ? 0u : 3u * HC;  // direction words start here (the LDS form keeps no rows in W)
     const uint64_t DIRCAP = (uint64_t)L.words_per_lane - DIR0;
@@ -110,7 +117,7 @@ __global__ __launch_bounds__(64) void sw_traceback_kernel(BtLaunch L) {
                 const int f1 = f > 0 ? f : 0;
                 const int e1 = ev > 0 ? ev : 0;
                 temp1 = e1 > f1 ? e1 : f1;
-                temp2 = (int)AT(hb + d) + (int)smat[qi + (int)t_cur] + cbi;
+                temp2 = (int)AT(hb + d) + (prof ? (int)prof[(int)t_cur * qfull + i] : (int)smat[qi + (int)t_cur] + cbi);
                 const int h = temp1 > temp2 ? temp1 : temp2;
                 AT(hc + u) = (uint32_t)h;
                 hleft = h;

@@ -55,7 +55,8 @@ __device__ __forceinline__ int btw_shift_up(int v, int first) {
 // One pass of the banded DP at half-width bw.  WRITE: direction bytes to dir[i * width_d + (j - shift_i)].
 template <bool WRITE>
 __device__ __forceinline__ int btw_pass(const uint8_t *q, const int8_t *cb, const uint8_t *t, int ql, int tl, int bw, int go, int ge,
-                                        int alph, const int8_t *smat, int *Hring, int *Ering, uint8_t *dir) {
+                                        int alph, const int8_t *smat, int *Hring, int *Ering, uint8_t *dir,
+                                        const int8_t *prof, int qfull) {
     const int lane = (int)(threadIdx.x & 63u);
     const int width_d = 2 * bw + 1;
     int lane_max = 0;
@@ -83,7 +84,8 @@ __device__ __forceinline__ int btw_pass(const uint8_t *q, const int8_t *cb, cons
             const unsigned de = te1 > te2 ? 1u : 0u;
             const int e1 = ev > 0 ? ev : 0;
             const int tj = act ? (int)t[j] : 0;
-            const int diag = hd + (int)smat[qi + tj] + cbi;
+            // profile query: prof points at row q_start of the letter-major profile, qfull = its row length (:1565-1567)
+            const int diag = hd + (prof ? (int)prof[tj * qfull + i] : (int)smat[qi + tj] + cbi);
             const int hnf = e1 > diag ? e1 : diag;
             // F: max-plus prefix scan over the chunk
             const int f_in = max(hnf_carry - go, f_carry - ge);
@@ -135,6 +137,12 @@ __global__ __launch_bounds__(256) void sw_traceback_wave_kernel(BtLaunch L) {
     const int8_t *cb = L.q_cb + L.q_off[J.query] + J.q_start;
     const uint8_t *t = L.t_res + (size_t)L.t_off4[J.target] * 4 + J.t_start;
     const int go = L.gap_open, ge = L.gap_extend, alph = L.alphabet;
+    const int8_t *prof = nullptr;
+    int qfull = 0;
+    if (L.q_prof_off && L.q_prof_off[J.query] != 0xFFFFFFFFu) {
+        qfull = (int)(L.q_off[J.query + 1] - L.q_off[J.query]);
+        prof = L.q_prof + L.q_prof_off[J.query] + J.q_start;
+    }
     mmgpu_sw_bt info;
     info.bt_off = J.bt_off;
     info.bt_len = 0;
@@ -147,7 +155,7 @@ __global__ __launch_bounds__(256) void sw_traceback_wave_kernel(BtLaunch L) {
     bool fail = false;
     for (;;) {
         if (2 * bw + 2 > BTW_RING) { fail = true; break; }
-        const int mx = btw_pass<false>(q, cb, t, ql, tl, bw, go, ge, alph, smat, Hring, Ering, nullptr);
+        const int mx = btw_pass<false>(q, cb, t, ql, tl, bw, go, ge, alph, smat, Hring, Ering, nullptr, prof, qfull);
         if (mx >= J.score) break;
         bw *= 2;
     }
@@ -166,7 +174,7 @@ __global__ __launch_bounds__(256) void sw_traceback_wave_kernel(BtLaunch L) {
         return;
     }
     uint8_t *dir = L.dir_pool + off;
-    (void)btw_pass<true>(q, cb, t, ql, tl, bw, go, ge, alph, smat, Hring, Ering, dir);
+    (void)btw_pass<true>(q, cb, t, ql, tl, bw, go, ge, alph, smat, Hring, Ering, dir, prof, qfull);
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");     // the direction bytes were written by all lanes
     __builtin_amdgcn_wave_barrier();
 

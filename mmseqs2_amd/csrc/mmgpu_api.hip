@@ -220,6 +220,7 @@ struct mmgpu_sw_batch_t {
     uint32_t n_queries = 0;
     // all jobs of the batch, by kernel group (sw_kernel.hip), longest first inside a group; SwJob::shape picks the body
     uint32_t n_jobs = 0, n_multi_jobs = 0;
+    uint32_t n_rev_jobs = 0;      // reverse-scan jobs of the multi-tile queries (mode START), behind the forward jobs in d_jobs
     uint32_t group_begin[SW_GROUPS + 1] = {0, 0, 0, 0};
     size_t group_lds[SW_GROUPS] = {0, 0, 0};   // largest profile of any shape present in the group
     DevBuf d_jobs;
@@ -228,6 +229,8 @@ struct mmgpu_sw_batch_t {
     uint32_t scratch_slots = 0;
     DevBuf d_pf_counts, d_slot_target;   // from_pf: list lengths and slot -> target id, copied out of the prefilter batch
     DevBuf d_qres, d_qcb, d_qoff, d_qbias, d_qminstart, d_hit_target, d_hit_out, d_out, d_mat;
+    DevBuf d_qprof, d_qprof_off;   // profile queries only (empty otherwise)
+    bool any_profile = false;
     // fused hand-over from a prefilter batch (mmgpu_sw_prepare_from_pf): lists, counts and statistics live on the device
     bool from_pf = false;
     uint32_t pf_stride = 0, slot_stride = 0;
@@ -302,13 +305,15 @@ static int sw_prepare_impl(mmgpu_ctx *c, const mmgpu_sw_params *par, const mmgpu
     b->n_queries = nq;
     for (DevBuf *d : {&b->d_qres, &b->d_qcb, &b->d_qoff, &b->d_qbias, &b->d_qminstart, &b->d_hit_target, &b->d_hit_out, &b->d_out,
                       &b->d_mat, &b->d_stats, &b->d_bt_scratch, &b->d_bt_jobs, &b->d_bt_info, &b->d_bt_str, &b->d_bt_cursor, &b->d_scratch_busy,
-                      &b->d_pf_counts, &b->d_slot_target})
+                      &b->d_pf_counts, &b->d_slot_target, &b->d_qprof, &b->d_qprof_off})
         d->bind(c->cache);
 
     std::vector<uint8_t> qres;
     std::vector<int8_t> qcb;
     std::vector<uint32_t> qoff(nq + 1, 0);
     std::vector<int32_t> qbias(std::max<uint32_t>(nq, 1), 0), qminstart(std::max<uint32_t>(nq, 1), 0);
+    std::vector<int8_t> qprof;                       // profile queries: [alphabet][qlen] blocks, concatenated
+    std::vector<uint32_t> qprof_off(std::max<uint32_t>(nq, 1), 0xFFFFFFFFu);
     uint64_t total_hits = 0;
     for (uint32_t i = 0; i < nq; i++) {
         // a query without targets may come without residues (Alignment::run never maps the query of an empty list, :322)
@@ -324,6 +329,8 @@ static int sw_prepare_impl(mmgpu_ctx *c, const mmgpu_sw_params *par, const mmgpu
     b->d_jobs.bind(c->cache);
     b->d_scratch.bind(c->cache);
     std::vector<SwJob> jobs;
+    std::vector<SwJob> rev_jobs;          // multi-tile queries, mode START: the reverse scan runs per query (sw_rev_multi_kernel)
+    std::vector<uint64_t> rev_cells;
     std::vector<uint64_t> job_cells;
     uint32_t n_multi = 0;
     std::vector<uint32_t> order;
@@ -332,6 +339,22 @@ static int sw_prepare_impl(mmgpu_ctx *c, const mmgpu_sw_params *par, const mmgpu
     if (mode >= MMGPU_SW_START && !pf) b->h_out_target.resize((size_t)total_hits);
     uint32_t max_tlen = 0;
     bool any_multi = false;
+    // Reverse-scan jobs of a multi-tile query: consecutive slots of its list, as many as hold about six forward jobs'
+    // worth of cells (one pair in six reaches the start-score threshold on hit lists), whole workgroup rounds, at most
+    // SW_REV_JOB_MAX; the kernel packs the live pairs of a job before it deals them to its waves.
+    auto add_rev_jobs = [&](uint32_t query, uint32_t first, uint32_t n, uint32_t shape, uint64_t cells_per_hit) {
+        uint64_t per = 6 * JOB_CELLS / std::max<uint64_t>(cells_per_hit, 1);
+        per = std::min<uint64_t>(std::max<uint64_t>(per / JOB_ROUND * JOB_ROUND, JOB_ROUND), (uint64_t)SW_REV_JOB_MAX);
+        for (uint32_t k = 0; k < n; k += (uint32_t)per) {
+            SwJob j;
+            j.query = query;
+            j.hit_begin = first + k;
+            j.hit_end = first + std::min<uint32_t>(k + (uint32_t)per, n);
+            j.shape = shape;
+            rev_jobs.push_back(j);
+            rev_cells.push_back(cells_per_hit * (j.hit_end - j.hit_begin) * 4096u + (n - k));
+        }
+    };
     for (uint32_t i = 0; i < nq; i++) {
         const mmgpu_sw_query &Q = qs[i];
         if (Q.qlen == 0) {      // empty list, no residues: no jobs, no result slots
@@ -340,15 +363,32 @@ static int sw_prepare_impl(mmgpu_ctx *c, const mmgpu_sw_params *par, const mmgpu
         }
         memcpy(qres.data() + qoff[i], Q.q, Q.qlen);
         int mincb = 0;
+        int qminp = minp;
         for (uint32_t k = 0; k < Q.qlen; k++) {
             if (Q.q[k] >= par->alphabet) { delete b; return fail(MMGPU_ERR_ARG, "mmgpu_sw_prepare: query residue code >= alphabet"); }
-            if (Q.comp_bias) { qcb[qoff[i] + k] = Q.comp_bias[k]; mincb = std::min<int>(mincb, Q.comp_bias[k]); }
+            if (Q.comp_bias && !Q.profile) { qcb[qoff[i] + k] = Q.comp_bias[k]; mincb = std::min<int>(mincb, Q.comp_bias[k]); }
         }
-        if (!(minp + mincb + par->gap_extend > -par->gap_open)) {
+        if (Q.profile) {
+            // ssw_init with a profile query (StripedSmithWaterman.cpp:1386-1406): the first PROFILE_AA_SIZE letter rows are the
+            // profile, the X row scores 0, no composition bias; bias = |min| over the profile rows
+            if (Q.profile_letters == 0 || (int)Q.profile_letters > par->alphabet) {
+                delete b;
+                return fail(MMGPU_ERR_ARG, "mmgpu_sw_prepare: profile_letters must be in [1, alphabet]");
+            }
+            if (qprof.size() + (size_t)par->alphabet * Q.qlen > 0xFFFFFFF0ull) { delete b; return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_sw_prepare: more than 4 GB of query profiles in one batch"); }
+            qprof_off[i] = (uint32_t)qprof.size();
+            qprof.resize(qprof.size() + (size_t)par->alphabet * Q.qlen, 0);
+            const uint32_t rows = std::min<uint32_t>(Q.profile_letters, (uint32_t)par->alphabet - 1);   // :1389-1390 zeroes the last letter (X)
+            memcpy(qprof.data() + qprof_off[i], Q.profile, (size_t)rows * Q.qlen);
+            qminp = 0;
+            for (size_t k = 0; k < (size_t)Q.profile_letters * Q.qlen; k++) qminp = std::min<int>(qminp, Q.profile[k]);
+            b->any_profile = true;
+        }
+        if (!(qminp + mincb + par->gap_extend > -par->gap_open)) {
             delete b;
             return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_sw_prepare: gap penalties too small for this matrix (adjacent insertion+deletion could win)");
         }
-        qbias[i] = std::abs(minp) + std::abs(mincb);   // ssw_init :1397-1406
+        qbias[i] = std::abs(qminp) + std::abs(mincb);   // ssw_init :1397-1406
         qminstart[i] = Q.min_start_score;
         int rpl; bool multi;
         pick_class(Q.qlen, &rpl, &multi);
@@ -376,6 +416,7 @@ static int sw_prepare_impl(mmgpu_ctx *c, const mmgpu_sw_params *par, const mmgpu
                 // target length on the device, so among equals a query's earlier jobs hold the longer targets
                 job_cells.push_back((uint64_t)Q.qlen * (j.hit_end - j.hit_begin) * 4096u + (pf_stride - k));
             }
+            if (multi && mode >= MMGPU_SW_START) add_rev_jobs(i, hit_cursor, pf_stride, shape, (uint64_t)Q.qlen * ((Q.qlen + c->mean_len) / 2 + 1));
             max_tlen = c->db.max_len;
             hit_cursor += pf_stride;
             out_cursor += pf_stride;
@@ -422,6 +463,8 @@ static int sw_prepare_impl(mmgpu_ctx *c, const mmgpu_sw_params *par, const mmgpu
             job_cells.push_back(jc);
             k = e;
         }
+        if (multi && mode >= MMGPU_SW_START && Q.n_targets)
+            add_rev_jobs(i, hit_cursor, Q.n_targets, shape, (uint64_t)Q.qlen * (c->h_len[hit_target[hit_cursor + Q.n_targets / 2]] + 1));
         if (mode >= MMGPU_SW_START)
             for (uint32_t k = 0; k < Q.n_targets; k++) b->h_out_target[out_cursor + k] = Q.target_ids[k];
         hit_cursor += Q.n_targets;
@@ -442,6 +485,10 @@ static int sw_prepare_impl(mmgpu_ctx *c, const mmgpu_sw_params *par, const mmgpu
     B_TRY(upload(b->d_qoff, qoff, s));
     B_TRY(upload(b->d_qbias, qbias, s));
     B_TRY(upload(b->d_qminstart, qminstart, s));
+    if (b->any_profile) {
+        B_TRY(upload(b->d_qprof, qprof, s));
+        B_TRY(upload(b->d_qprof_off, qprof_off, s));
+    }
     if (pf) {
         B_TRY(b->d_hit_target.alloc(std::max<size_t>((size_t)total_hits, 1) * 4));
         B_TRY(b->d_hit_out.alloc(std::max<size_t>((size_t)total_hits, 1) * 4));
@@ -471,6 +518,13 @@ static int sw_prepare_impl(mmgpu_ctx *c, const mmgpu_sw_params *par, const mmgpu
         for (int g = 0; g < SW_GROUPS; g++) b->group_begin[g + 1] += b->group_begin[g];
         b->n_jobs = (uint32_t)sorted.size();
         b->n_multi_jobs = n_multi;
+        {
+            std::vector<uint32_t> ro(rev_jobs.size());
+            std::iota(ro.begin(), ro.end(), 0u);
+            std::stable_sort(ro.begin(), ro.end(), [&](uint32_t a, uint32_t bb) { return rev_cells[a] > rev_cells[bb]; });
+            for (uint32_t z : ro) sorted.push_back(rev_jobs[z]);
+            b->n_rev_jobs = (uint32_t)rev_jobs.size();
+        }
         B_TRY(upload(b->d_jobs, sorted, s));
     }
     // column scratch of the multi-tile jobs: a pool with one slot per workgroup that can be resident at once (not one
@@ -478,7 +532,7 @@ static int sw_prepare_impl(mmgpu_ctx *c, const mmgpu_sw_params *par, const mmgpu
     // target any list holds
     auto alloc_scratch = [&](uint32_t longest) -> hipError_t {
         b->scratch_cols = longest + 16;
-        b->scratch_slots = std::min<uint32_t>(std::max<uint32_t>(n_multi, 1),
+        b->scratch_slots = std::min<uint32_t>(std::max<uint32_t>(std::max<uint32_t>(n_multi, (uint32_t)rev_jobs.size()), 1),
                                               sw_multi_resident_blocks(b->group_lds[SW_GROUPS - 1], mode == MMGPU_SW_START, c->compute_units));
         hipError_t e = b->d_scratch.alloc((size_t)b->scratch_slots * 4 * 4 * 2 * (size_t)b->scratch_cols * sizeof(uint2));
         if (e != hipSuccess) return e;
@@ -585,6 +639,8 @@ extern "C" int mmgpu_sw_run(mmgpu_ctx *c, mmgpu_sw_batch_t *b) {
             L.q_off = b->d_qoff.as<uint32_t>();
             L.q_bias = b->d_qbias.as<int32_t>();
             L.q_minstart = b->d_qminstart.as<int32_t>();
+            L.q_prof = b->any_profile ? b->d_qprof.as<int8_t>() : nullptr;
+            L.q_prof_off = b->any_profile ? b->d_qprof_off.as<uint32_t>() : nullptr;
             L.t_res = c->db.res;
             L.t_off4 = c->db.off4;
             L.t_len = c->db.len;
@@ -602,6 +658,12 @@ extern "C" int mmgpu_sw_run(mmgpu_ctx *c, mmgpu_sw_batch_t *b) {
             L.scratch_busy = b->d_scratch_busy.as<uint32_t>();
             L.scratch_slots = std::max<uint32_t>(b->scratch_slots, 1);
             HIP_TRY(launch_sw(L, g, b->group_lds[g], b->mode == MMGPU_SW_START, st));
+            if (g == SW_GROUPS - 1 && b->n_rev_jobs && b->mode == MMGPU_SW_START) {   // reads the forward results of this stream's kernel
+                SwLaunch Rv = L;
+                Rv.jobs = b->d_jobs.as<SwJob>() + b->n_jobs;
+                Rv.n_jobs = b->n_rev_jobs;
+                HIP_TRY(launch_sw_rev_multi(Rv, b->group_lds[g], st));
+            }
             if (getenv("MMGPU_TRACE")) {   // debugging aid: run the groups one at a time and say which one is in flight
                 fprintf(stderr, "[sw_run] group %d jobs %u lds %zu both %d from_pf %d scratch_cols %u\n", g, L.n_jobs, b->group_lds[g], (int)(b->mode == MMGPU_SW_START), (int)b->from_pf, b->scratch_cols);
                 fflush(stderr);
@@ -758,6 +820,8 @@ extern "C" int mmgpu_sw_traceback(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const uint3
     L.q_res = b->d_qres.as<uint8_t>();
     L.q_cb = b->d_qcb.as<int8_t>();
     L.q_off = b->d_qoff.as<uint32_t>();
+    L.q_prof = b->any_profile ? b->d_qprof.as<int8_t>() : nullptr;
+    L.q_prof_off = b->any_profile ? b->d_qprof_off.as<uint32_t>() : nullptr;
     L.t_res = c->db.res;
     L.t_off4 = c->db.off4;
     L.mat = b->d_mat.as<int8_t>();

@@ -47,6 +47,10 @@ struct SwLaunch {
     const uint32_t *q_off;    // [nq+1]
     const int32_t *q_bias;    // [nq] ssw_init bias (StripedSmithWaterman.cpp:1397-1406), decides `word`
     const int32_t *q_minstart; // [nq] reverse scan only for pairs with score >= this
+    // profile queries (ssw_init with DBTYPE_HMM_PROFILE): int8 [alphabet][qlen] per query, letter-major, concatenated;
+    // q_prof_off[q] = byte offset of the query's block, 0xFFFFFFFF for a sequence query; q_prof_off null = none in the batch
+    const int8_t *q_prof;
+    const uint32_t *q_prof_off;
     // targets
     const uint8_t *t_res;
     const uint32_t *t_off4;
@@ -88,6 +92,8 @@ struct SwFromPfArgs {
     uint32_t *slot_target;         // [nq * stride] target id of every result slot (list order), 0 beyond the list
 };
 
+constexpr int SW_REV_JOB_MAX = 1024;   // most hits of one reverse-scan job of a multi-tile query (sw_rev_multi_kernel)
+hipError_t launch_sw_rev_multi(const SwLaunch &L, size_t lds_bytes, hipStream_t stream);
 hipError_t launch_sw_from_pf(const SwFromPfArgs &A, uint32_t nq, hipStream_t stream);
 // workgroups of the multi-tile kernel group that can be resident on the device at once (sizes the scratch pool)
 uint32_t sw_multi_resident_blocks(size_t lds_bytes, bool both_passes, int compute_units);
@@ -98,6 +104,7 @@ uint32_t sw_multi_resident_blocks(size_t lds_bytes, bool both_passes, int comput
 #define MMGPU_SW_MAX_R 28
 #endif
 constexpr int SW_MAX_R = MMGPU_SW_MAX_R;   // rows per lane of the largest tile (16 lanes x SW_MAX_R query rows); longer queries are cut into tiles
+static_assert(SW_MAX_R >= 16 && SW_MAX_R <= 32 && SW_MAX_R % 2 == 0, "multi-tile bodies exist for 8..32 rows per lane: a query cut into tiles gets at least SW_MAX_R / 2");
 #ifndef MMGPU_SW_MIN_WAVES
 #define MMGPU_SW_MIN_WAVES 2
 #endif
@@ -346,6 +353,8 @@ struct BtLaunch {
     const uint8_t *q_res;
     const int8_t *q_cb;
     const uint32_t *q_off;
+    const int8_t *q_prof;       // profile queries, as in SwLaunch (banded_sw<PROFILE_SEQ>, StripedSmithWaterman.cpp:1565-1567)
+    const uint32_t *q_prof_off;
     const uint8_t *t_res;
     const uint32_t *t_off4;
     const int8_t *mat;

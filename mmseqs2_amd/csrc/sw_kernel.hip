@@ -92,7 +92,7 @@ struct Tile {
 // -32768, which keeps H at max(E, F) there and can never raise a running maximum.
 template <int R, bool REV>
 __device__ __forceinline__ void build_profile(unsigned char *lds, const uint8_t *q, const int8_t *cb, int qlen,
-                                              int tile_base, const int8_t *mat, int alphabet) {
+                                              int tile_base, const int8_t *mat, int alphabet, const int8_t *prof) {
     using T = Tile<R>;
     const int total = (alphabet + 1) * T::ROWS;
     for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
@@ -102,23 +102,26 @@ __device__ __forceinline__ void build_profile(unsigned char *lds, const uint8_t 
         short v = (short)-32768;
         if (letter < alphabet && rg < qlen) {
             const int qi = REV ? (qlen - 1 - rg) : rg;
-            v = (short)((int)mat[letter * alphabet + q[qi]] + (int)cb[qi]);
+            // profile query: the score row of the letter (createQueryProfile<PROFILE>, StripedSmithWaterman.cpp:773-776)
+            v = prof ? (short)prof[letter * qlen + qi] : (short)((int)mat[letter * alphabet + q[qi]] + (int)cb[qi]);
         }
         const int lane = row / R, r = row - lane * R;
         *reinterpret_cast<short *>(lds + letter * T::ROW_STRIDE + lane * T::LANE_STRIDE + r * 2) = v;
     }
 }
 
-constexpr int SW_LDS_HEADER = 1024;
+constexpr int SW_REV_JOB_HITS = 1024;   // most hits a reverse-scan job may hold (mmgpu_internal.h: SW_REV_JOB_MAX)
+static_assert(SW_REV_JOB_HITS == SW_REV_JOB_MAX, "host and kernel disagree on the reverse job size");
+constexpr int SW_LDS_HEADER = SW_REV_JOB_HITS * 2 + 64;
 
 template <int R, bool MULTI, bool REV>
 __device__ __forceinline__ void sw_body(const SwLaunch &L, const SwJob job) {
     using T = Tile<R>;
     // dynamic LDS: a 1 KB header (job-local scheduling state, below) followed by the query profile of the tile
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_all[];
-    uint16_t *live = reinterpret_cast<uint16_t *>(lds_all);                  // [WAVES * 64] packed live hits (reverse pass)
-    uint32_t *live_wave = reinterpret_cast<uint32_t *>(lds_all + 512);       // [WAVES]
-    uint32_t *next_chunk = reinterpret_cast<uint32_t *>(lds_all + 512 + 16); // next 8-hit chunk to hand to a wave
+    uint16_t *live = reinterpret_cast<uint16_t *>(lds_all);                  // [SW_REV_JOB_HITS] packed live hits (reverse pass)
+    uint32_t *live_wave = reinterpret_cast<uint32_t *>(lds_all + SW_REV_JOB_HITS * 2);       // [WAVES]
+    uint32_t *next_chunk = reinterpret_cast<uint32_t *>(lds_all + SW_REV_JOB_HITS * 2 + 16); // next 8-hit chunk to hand to a wave
     unsigned char *lds = lds_all + SW_LDS_HEADER;
     // A multi-tile job is one long dependent chain (tiles x columns) however few targets it holds, and the batch ends
     // with the longest of them: those waves take the issue slots first, the short jobs sharing the SIMD fill the gaps.
@@ -133,6 +136,11 @@ __device__ __forceinline__ void sw_body(const SwLaunch &L, const SwJob job) {
     const uint8_t *q = L.q_res + qbeg;
     const int8_t *cb = L.q_cb + qbeg;
     const int qbias = L.q_bias[job.query];
+    const int8_t *prof = nullptr;
+    if (L.q_prof_off) {
+        const uint32_t po = L.q_prof_off[job.query];
+        if (po != 0xFFFFFFFFu) prof = L.q_prof + po;
+    }
     const int n_tiles = MULTI ? (qlen + T::ROWS - 1) / T::ROWS : 1;
 
     const unsigned go2 = (unsigned)L.gap_open * 0x10001u;
@@ -141,7 +149,7 @@ __device__ __forceinline__ void sw_body(const SwLaunch &L, const SwJob job) {
 
     if (threadIdx.x == 0) *next_chunk = 0;
     if (!MULTI) {
-        build_profile<R, REV>(lds, q, cb, qlen, 0, L.mat, L.alphabet);
+        build_profile<R, REV>(lds, q, cb, qlen, 0, L.mat, L.alphabet, prof);
         __syncthreads();
     }
 
@@ -152,23 +160,28 @@ __device__ __forceinline__ void sw_body(const SwLaunch &L, const SwJob job) {
     // wave waiting for its one or two live targets.
     if (REV) {
         const int min_start = L.q_minstart[job.query];
-        bool pass = false;
-        if (threadIdx.x < n_hits) {   // a job holds at most WAVES * 64 hits (JOB_HITS)
-            const int s = (int)L.out[L.hit_out[job.hit_begin + threadIdx.x]].score;
-            pass = s > 0 && s >= min_start;
-        }
-        const unsigned long long bal = __ballot(pass);
-        if (lane == 0) live_wave[wave] = (uint32_t)__popcll(bal);
-        __syncthreads();
-        uint32_t before = 0, total = 0;
+        uint32_t total = 0;
+        for (uint32_t base = 0; base < n_hits; base += WAVES * 64) {   // a job of the BOTH kernels holds at most 256 hits: one round
+            const uint32_t idx = base + threadIdx.x;
+            bool pass = false;
+            if (idx < n_hits) {
+                const int s = (int)L.out[L.hit_out[job.hit_begin + idx]].score;
+                pass = s > 0 && s >= min_start;
+            }
+            const unsigned long long bal = __ballot(pass);
+            if (lane == 0) live_wave[wave] = (uint32_t)__popcll(bal);
+            __syncthreads();
+            uint32_t before = 0, round_total = 0;
 #pragma unroll
-        for (int w = 0; w < WAVES; ++w) {
-            const uint32_t c = live_wave[w];
-            before += w < wave ? c : 0u;
-            total += c;
+            for (int w = 0; w < WAVES; ++w) {
+                const uint32_t c = live_wave[w];
+                before += w < wave ? c : 0u;
+                round_total += c;
+            }
+            if (pass) live[total + before + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)idx;
+            total += round_total;
+            __syncthreads();
         }
-        if (pass) live[before + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)threadIdx.x;
-        __syncthreads();
         n_hits = total;
     }
     const uint32_t n_iter = (n_hits + WAVES * HITS_PER_WAVE - 1) / (WAVES * HITS_PER_WAVE);
@@ -228,7 +241,7 @@ __device__ __forceinline__ void sw_body(const SwLaunch &L, const SwJob job) {
             const int tile_base = tile * T::ROWS;
             if (MULTI) {
                 __syncthreads();   // everyone is done reading the previous tile's profile
-                build_profile<R, REV>(lds, q, cb, qlen, tile_base, L.mat, L.alphabet);
+                build_profile<R, REV>(lds, q, cb, qlen, tile_base, L.mat, L.alphabet, prof);
                 __syncthreads();
             }
             const uint2 *scr_in = MULTI ? scr + (size_t)((tile + 1) & 1) * L.scratch_cols : nullptr;
@@ -419,7 +432,8 @@ template <int R, bool MULTI, bool BOTH>
 __device__ __forceinline__ void sw_passes(const SwLaunch &L, const SwJob &job) {
     if constexpr (R <= SW_MAX_R) {
         sw_body<R, MULTI, false>(L, job);
-        if constexpr (BOTH) {
+        // multi-tile queries get their reverse scan from sw_rev_multi_kernel (below), per query instead of per job
+        if constexpr (BOTH && !MULTI) {
             __threadfence_block();   // the forward results of this job, written by other waves of the workgroup
             __syncthreads();
             sw_body<R, MULTI, true>(L, job);
@@ -464,7 +478,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(SW_M
     } else {
         switch (job.shape & 0xFFu) {
             MMGPU_SW_SINGLE(26) MMGPU_SW_SINGLE(28) MMGPU_SW_SINGLE(30) MMGPU_SW_SINGLE(32)
-            MMGPU_SW_MULTI(16) MMGPU_SW_MULTI(18) MMGPU_SW_MULTI(20) MMGPU_SW_MULTI(22) MMGPU_SW_MULTI(24) MMGPU_SW_MULTI(26)
+            MMGPU_SW_MULTI(8) MMGPU_SW_MULTI(10) MMGPU_SW_MULTI(12) MMGPU_SW_MULTI(14) MMGPU_SW_MULTI(16) MMGPU_SW_MULTI(18) MMGPU_SW_MULTI(20) MMGPU_SW_MULTI(22) MMGPU_SW_MULTI(24) MMGPU_SW_MULTI(26)
             MMGPU_SW_MULTI(28) MMGPU_SW_MULTI(30) MMGPU_SW_MULTI(32)
             default: break;
         }
@@ -477,6 +491,41 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(SW_M
             __threadfence();
             atomicExch(&L.scratch_busy[scratch_slot], 0u);
         }
+    }
+}
+
+// Reverse scan of the multi-tile queries.  A forward job of a long query holds few hits (8 or 16 per workgroup for
+// queries of 1024 residues or more, so that the batch has no long tail), of which one in six needs a reverse scan: done
+// inside the forward job, one or two 16-lane groups of one wave worked while the workgroup held four waves' registers
+// and a profile (measured: +19 ms on the 10k x 1M lists for 11 % of the pairs).  Here a job is up to SW_REV_JOB_HITS
+// hits of one query - normally its whole list - whose live pairs are packed before they are dealt to the waves.
+// Launched behind the group-2 kernel on the same stream (it reads that kernel's forward results).
+__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(SW_MIN_WAVES))) void sw_rev_multi_kernel(SwLaunch L) {
+    SwJob job = L.jobs[blockIdx.x];
+    if (L.q_hit_count) {
+        const uint32_t lim = job.query * L.hit_stride + L.q_hit_count[job.query];
+        job.hit_end = job.hit_end < lim ? job.hit_end : lim;
+        if (job.hit_end <= job.hit_begin) return;
+    }
+    __shared__ uint32_t scratch_slot;
+    if (threadIdx.x == 0) {
+        uint32_t s = blockIdx.x % L.scratch_slots;
+        while (atomicCAS(&L.scratch_busy[s], 0u, 1u) != 0u) s = s + 1 == L.scratch_slots ? 0u : s + 1;
+        scratch_slot = s;
+    }
+    __syncthreads();
+    job.shape = (job.shape & 0xFFu) | (scratch_slot << 8);
+#define MMGPU_SW_REV(R) case 16 + (R) / 2 - 1: if constexpr ((R) <= SW_MAX_R) sw_body<R, true, true>(L, job); break;
+    switch (job.shape & 0xFFu) {
+        MMGPU_SW_REV(8) MMGPU_SW_REV(10) MMGPU_SW_REV(12) MMGPU_SW_REV(14) MMGPU_SW_REV(16) MMGPU_SW_REV(18) MMGPU_SW_REV(20)
+        MMGPU_SW_REV(22) MMGPU_SW_REV(24) MMGPU_SW_REV(26) MMGPU_SW_REV(28) MMGPU_SW_REV(30) MMGPU_SW_REV(32)
+        default: break;
+    }
+#undef MMGPU_SW_REV
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        atomicExch(&L.scratch_busy[scratch_slot], 0u);
     }
 }
 
@@ -554,6 +603,10 @@ uint32_t sw_multi_resident_blocks(size_t lds_bytes, bool both_passes, int comput
     const size_t lds = lds_bytes + SW_LDS_HEADER;
     hipError_t e = both_passes ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sw_kernel<2, true>, WAVES * 64, lds)
                                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sw_kernel<2, false>, WAVES * 64, lds);
+    if (e == hipSuccess && both_passes) {   // the reverse kernel of the multi-tile queries draws on the same pool
+        int rev = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&rev, sw_rev_multi_kernel, WAVES * 64, lds) == hipSuccess) per_cu = std::max(per_cu, rev);
+    }
     // a CU holds at most 32 wavefronts = 8 workgroups of 4; one more than the occupancy query says, as a margin
     if (e != hipSuccess || per_cu < 1) per_cu = 8;
     per_cu = per_cu + 1 > 8 ? 8 : per_cu + 1;
@@ -562,6 +615,12 @@ uint32_t sw_multi_resident_blocks(size_t lds_bytes, bool both_passes, int comput
 
 size_t sw_lds_bytes(int rows_per_lane, int alphabet) {
     return (size_t)(alphabet + 1) * GROUP * lane_stride_bytes(rows_per_lane);
+}
+
+hipError_t launch_sw_rev_multi(const SwLaunch &L, size_t lds_bytes, hipStream_t stream) {
+    if (L.n_jobs == 0) return hipSuccess;
+    hipLaunchKernelGGL(sw_rev_multi_kernel, dim3(L.n_jobs), dim3(WAVES * 64), lds_bytes + SW_LDS_HEADER, stream, L);
+    return hipGetLastError();
 }
 
 int sw_shape_group(uint32_t shape) {

@@ -36,6 +36,10 @@ int mmo_sw_banded_backtrace(const uint8_t *t, const uint8_t *q, const int8_t *co
 int mmo_sw_align(const uint8_t *q, int qlen, const int8_t *comp_bias, const uint8_t *t, int tlen,
                  const int8_t *mat, int alphabet, int gap_open, int gap_extend, int need_start, int need_bt,
                  mmo_sw_res *r, char *bt, int bt_cap);
+/* profile query (DBTYPE_HMM_PROFILE): profile = int8 [profile_letters][qlen], cons = consensus sequence */
+int mmo_sw_align_profile(const int8_t *profile, int profile_letters, const uint8_t *cons, int qlen, const uint8_t *t,
+                         int tlen, int alphabet, int gap_open, int gap_extend, int need_start, int need_bt,
+                         mmo_sw_res *r, char *bt, int bt_cap);
 int mmo_sw_score_identical(const uint8_t *q, int qlen, const int8_t *comp_bias, const uint8_t *t,
                            const int8_t *mat, int alphabet);
 /* batch driver used by tests and bench.py's cpu_baseline ("port" kind): one query, n targets from a

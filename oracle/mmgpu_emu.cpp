@@ -39,6 +39,8 @@ struct mmgpu_sw_batch_t {
     int alphabet, go, ge, mode;
     std::vector<std::vector<uint8_t> > q;
     std::vector<std::vector<int8_t> > cb;
+    std::vector<std::vector<int8_t> > prof;      // profile queries: [letters][qlen]
+    std::vector<int> prof_letters;
     std::vector<std::vector<uint32_t> > ids;
     std::vector<int32_t> min_start;
     std::vector<mmgpu_sw_hit> res;
@@ -98,6 +100,9 @@ int mmgpu_sw_prepare(mmgpu_ctx *c, const mmgpu_sw_params *p, const mmgpu_sw_quer
         b->q.push_back(std::vector<uint8_t>(qs[i].q, qs[i].q + qs[i].qlen));
         if (qs[i].comp_bias) b->cb.push_back(std::vector<int8_t>(qs[i].comp_bias, qs[i].comp_bias + qs[i].qlen));
         else b->cb.push_back(std::vector<int8_t>(qs[i].qlen, 0));
+        if (qs[i].profile) b->prof.push_back(std::vector<int8_t>(qs[i].profile, qs[i].profile + (size_t)qs[i].profile_letters * qs[i].qlen));
+        else b->prof.push_back(std::vector<int8_t>());
+        b->prof_letters.push_back(qs[i].profile ? (int)qs[i].profile_letters : 0);
         b->ids.push_back(std::vector<uint32_t>(qs[i].target_ids, qs[i].target_ids + qs[i].n_targets));
         b->min_start.push_back(qs[i].min_start_score);
         for (uint32_t k = 0; k < qs[i].n_targets; k++) {
@@ -121,7 +126,10 @@ int mmgpu_sw_run(mmgpu_ctx *c, mmgpu_sw_batch_t *b) {
         const uint8_t *t = c->tres.data() + c->toff[id];
         const int tlen = (int)(c->toff[id + 1] - c->toff[id]);
         mmo_sw_res r;
-        mmo_sw_score_end(q.data(), (int)q.size(), b->cb[qi].data(), t, tlen, b->mat.data(), b->alphabet, b->go, b->ge, &r);
+        const bool isProf = b->prof_letters[qi] > 0;
+        char dummy[8];
+        if (isProf) mmo_sw_align_profile(b->prof[qi].data(), b->prof_letters[qi], q.data(), (int)q.size(), t, tlen, b->alphabet, b->go, b->ge, 0, 0, &r, dummy, 0);
+        else mmo_sw_score_end(q.data(), (int)q.size(), b->cb[qi].data(), t, tlen, b->mat.data(), b->alphabet, b->go, b->ge, &r);
         mmgpu_sw_hit h;
         h.score = r.score;
         h.q_end = r.q_end;
@@ -133,7 +141,8 @@ int mmgpu_sw_run(mmgpu_ctx *c, mmgpu_sw_batch_t *b) {
             h.score = 0;
             h.q_end = 0;
         } else if (b->mode == MMGPU_SW_START && r.score >= b->min_start[qi]) {
-            mmo_sw_start(q.data(), (int)q.size(), b->cb[qi].data(), t, b->mat.data(), b->alphabet, b->go, b->ge, &r);
+            if (isProf) mmo_sw_align_profile(b->prof[qi].data(), b->prof_letters[qi], q.data(), (int)q.size(), t, tlen, b->alphabet, b->go, b->ge, 1, 0, &r, dummy, 0);
+            else mmo_sw_start(q.data(), (int)q.size(), b->cb[qi].data(), t, b->mat.data(), b->alphabet, b->go, b->ge, &r);
             h.q_start = r.q_start;
             h.t_start = r.t_start;
         }
@@ -181,8 +190,17 @@ int mmgpu_sw_traceback(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const uint32_t *idx, u
         const std::vector<uint8_t> &q = b->q[qi];
         const uint8_t *t = c->tres.data() + c->toff[id];
         const int ql = h.q_end - h.q_start + 1, tl = h.t_end - h.t_start + 1;
-        const int len = mmo_sw_banded_backtrace(t + h.t_start, q.data() + h.q_start, b->cb[qi].data() + h.q_start, tl, ql, h.score, b->go,
-                                                b->ge, b->mat.data(), b->alphabet, bt + off[i], ql + tl + 1);
+        int len;
+        if (b->prof_letters[qi] > 0) {
+            mmo_sw_res r;
+            const int tlen = (int)(c->toff[id + 1] - c->toff[id]);
+            const int rc = mmo_sw_align_profile(b->prof[qi].data(), b->prof_letters[qi], q.data(), (int)q.size(), t, tlen, b->alphabet, b->go, b->ge,
+                                                1, 1, &r, bt + off[i], ql + tl + 1);
+            len = rc == 0 ? r.bt_len : -1;
+        } else {
+            len = mmo_sw_banded_backtrace(t + h.t_start, q.data() + h.q_start, b->cb[qi].data() + h.q_start, tl, ql, h.score, b->go,
+                                          b->ge, b->mat.data(), b->alphabet, bt + off[i], ql + tl + 1);
+        }
         if (len < 0) {
             info[i].status = MMGPU_BT_FAILED;
             continue;

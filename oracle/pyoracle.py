@@ -82,6 +82,21 @@ class Oracle:
         return dict(score=r.score, q_start=r.q_start, q_end=r.q_end, t_start=r.t_start, t_end=r.t_end,
                     word=r.word, ident=r.ident, bt=bt.value.decode() if r.bt_len else "")
 
+    def sw_align_profile(self, profile, cons, t, alphabet, go, ge, need_start=False, need_bt=False):
+        """profile: int8 [letters][qlen] (Sequence::getAlignmentProfile), cons: consensus sequence (numSequence)."""
+        profile = np.ascontiguousarray(profile, np.int8)
+        cons = np.ascontiguousarray(cons, np.uint8)
+        t = np.ascontiguousarray(t, np.uint8)
+        r = SwRes()
+        cap = len(cons) + len(t) + 8
+        bt = ctypes.create_string_buffer(cap)
+        rc = self.L.mmo_sw_align_profile(_ptr(profile), profile.shape[0], _ptr(cons), len(cons), _ptr(t), len(t), alphabet, go, ge,
+                                         int(need_start), int(need_bt), ctypes.byref(r), bt, cap)
+        if rc != 0:
+            raise RuntimeError("mmo_sw_align_profile rc=%d" % rc)
+        return dict(score=r.score, q_start=r.q_start, q_end=r.q_end, t_start=r.t_start, t_end=r.t_end,
+                    word=r.word, ident=r.ident, bt=bt.value.decode() if r.bt_len else "")
+
     def sw_batch_score(self, q, cb, tdata, toff, ids, mat, go, ge):
         q = np.ascontiguousarray(q, np.uint8)
         mat = np.ascontiguousarray(mat, np.int8)
@@ -172,6 +187,18 @@ class RefLib:
     def sw_set_query(self, q):
         self._q = np.ascontiguousarray(q, np.uint8)
         self.L.mmref_sw_set_query(self.c, _ptr(self._q), len(self._q))
+
+    def sw_set_profile_query(self, entry):
+        """entry: uint8/int8 [qlen][25] = one profile-database entry (Sequence::PROFILE_READIN_SIZE bytes per position).
+        Returns (alignment profile int8 [20][qlen], consensus/query sequence uint8 [qlen]) as the reference derives them."""
+        e = np.ascontiguousarray(entry).view(np.int8).reshape(-1, 25)
+        n = e.shape[0]
+        prof = np.zeros((20, n), np.int8)
+        cons = np.zeros(n, np.uint8)
+        self._pq = e
+        self._q = cons
+        self.L.mmref_sw_set_profile_query(self.c, _ptr(e), n, _ptr(prof), _ptr(cons))
+        return prof, cons
 
     def sw_align(self, t, mode=0, evalue_thr=1e300, cov_mode=0, cov_thr=0.0):
         t = np.ascontiguousarray(t, np.uint8)

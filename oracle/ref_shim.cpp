@@ -46,6 +46,8 @@ struct mmref_ctx {
     SmithWaterman *sw;
     Sequence *q;
     Sequence *t;
+    Sequence *qprof;      // profile query (DBTYPE_HMM_PROFILE), created on first use
+    bool profileQuery;
     int gapOpen, gapExtend;
     size_t maxLen;
     bool compBias;
@@ -68,12 +70,15 @@ mmref_ctx *mmref_new(const char *matrix_file, float bit_factor, float score_bias
     }
     c->q = new Sequence(max_len, Parameters::DBTYPE_AMINO_ACIDS, c->m, 0, false, c->compBias);
     c->t = new Sequence(max_len, Parameters::DBTYPE_AMINO_ACIDS, c->m, 0, false, c->compBias);
+    c->qprof = NULL;
+    c->profileQuery = false;
     c->gapOpen = gap_open;
     c->gapExtend = gap_extend;
     return c;
 }
 
 void mmref_free(mmref_ctx *c) {
+    delete c->qprof;
     delete c->q;
     delete c->t;
     delete c->sw;
@@ -107,6 +112,7 @@ void mmref_comp_bias(mmref_ctx *c, const uint8_t *num, int len, float scale, flo
 
 // query given as numeric codes (SequenceLookup-style mapSequence overload, Sequence.h:88)
 void mmref_sw_set_query(mmref_ctx *c, const uint8_t *qnum, int qlen) {
+    c->profileQuery = false;
     c->q->mapSequence(0, 0, std::make_pair((const unsigned char *)qnum, (const unsigned int)qlen));
     int a = c->m->alphabetSize;
     std::vector<int8_t> tiny(a * a);
@@ -114,11 +120,24 @@ void mmref_sw_set_query(mmref_ctx *c, const uint8_t *qnum, int qlen) {
     c->sw->ssw_init(c->q, tiny.data(), c->m);
 }
 
+// Profile query: `data` is one entry of a profile database, Sequence::PROFILE_READIN_SIZE (25) bytes per position
+// (20 scores x 4, query letter, consensus letter, Neff, 2 reserved; Sequence.cpp:301-340).  Alignment::run maps it with
+// Sequence::mapSequence (-> mapProfile) and Matcher::initQuery hands getAlignmentProfile() to ssw_init (Matcher.cpp:49-60).
+// prof_out [PROFILE_AA_SIZE * qlen] / cons_out [qlen] receive what the reference aligns with (may be NULL).
+void mmref_sw_set_profile_query(mmref_ctx *c, const char *data, int qlen, int8_t *prof_out, uint8_t *cons_out) {
+    if (c->qprof == NULL) c->qprof = new Sequence(c->maxLen, Parameters::DBTYPE_HMM_PROFILE, c->m, 0, false, false);
+    c->profileQuery = true;
+    c->qprof->mapSequence(0, 0, data, (unsigned int)qlen);
+    c->sw->ssw_init(c->qprof, c->qprof->getAlignmentProfile(), c->m);
+    if (prof_out) memcpy(prof_out, c->qprof->getAlignmentProfile(), Sequence::PROFILE_AA_SIZE * (size_t)c->qprof->L);
+    if (cons_out) memcpy(cons_out, c->qprof->numSequence, (size_t)c->qprof->L);
+}
+
 // mode: Matcher::SCORE_ONLY=0, SCORE_COV=1, SCORE_COV_SEQID=2 (Matcher.h:24-26)
 void mmref_sw_align(mmref_ctx *c, const uint8_t *tnum, int tlen, int mode, double evalue_thr, int cov_mode,
                     float cov_thr, mmref_sw_result *res, char *bt, int bt_cap) {
     std::string backtrace;
-    int32_t maskLen = c->q->L / 2;
+    int32_t maskLen = (c->profileQuery ? c->qprof->L : c->q->L) / 2;
     s_align a = c->sw->ssw_align(tnum, tlen, backtrace, c->gapOpen, c->gapExtend, mode, evalue_thr, c->evaluer,
                                  cov_mode, cov_thr, 0.0f, maskLen);
     res->score = a.score1;

@@ -223,3 +223,38 @@ def test_long_sequences_host_side_emulated(tmp_path):
 @pytest.mark.gpu
 def test_long_sequences_on_device(tmp_path):
     _long_pipeline(str(tmp_path), False)
+
+
+def _profile_pipeline(w, emulate):
+    """Profile queries through `mmseqs align` (alignment half): a profile database made by the stock
+    binary (search -> result2profile) aligned against the sequences; the prefilter of profile queries stays the
+    reference's CPU code (the patched binary says so), the alignment runs on the device with the profile's score rows."""
+    (qres, qoff), (tres, toff), _, _ = wl.config3_prefilter(n_families=50, members=20, n_queries=30, seed=21)
+    wl.write_fasta(os.path.join(w, "q.fasta"), qres, qoff, "q")
+    wl.write_fasta(os.path.join(w, "t.fasta"), tres, toff, "t")
+    run(STOCK, ["createdb", "q.fasta", "q", "-v", "1"], w)
+    run(STOCK, ["createdb", "t.fasta", "t", "-v", "1"], w)
+    run(STOCK, ["search", "q", "t", "res0", "tmp0", "-s", "5.7", "-a", "--threads", THREADS, "-v", "1"], w)
+    run(STOCK, ["result2profile", "q", "t", "res0", "prof", "--threads", THREADS, "-v", "1"], w)
+    run(STOCK, ["prefilter", "prof", "t", "pref_p", "-s", "5.7", "--threads", THREADS, "-v", "1"], w)
+    for i, case in enumerate([["--alignment-mode", "1"], ["-a"], ["--alignment-mode", "3", "-e", "10", "-c", "0.3"]]):
+        run(STOCK, ["align", "prof", "t", "pref_p", "paln_s%d" % i] + case + ["--threads", THREADS, "-v", "2"], w)
+        log = run(MMGPU, ["align", "prof", "t", "pref_p", "paln_g%d" % i] + case + ["--threads", THREADS, "-v", "3"], w, emulate)
+        assert "MMGPU: device" in log and "using the CPU path" not in log, log[-2000:]
+        assert same(os.path.join(w, "paln_s%d" % i), os.path.join(w, "paln_g%d" % i)) == 30, case
+    # the whole profile search through the patched binary: prefilter on the CPU path (announced), alignment on the device
+    run(STOCK, ["search", "prof", "t", "pres_s", "ptmp_s", "-s", "5.7", "-a", "--threads", THREADS, "-v", "1"], w)
+    log = run(MMGPU, ["search", "prof", "t", "pres_g", "ptmp_g", "-s", "5.7", "-a", "--threads", THREADS, "-v", "3"], w, emulate)
+    assert "MMGPU: device" in log, log[-3000:]
+    assert same(os.path.join(w, "pres_s"), os.path.join(w, "pres_g")) == 30
+
+
+def test_profile_queries_host_side_emulated(tmp_path):
+    if not os.path.exists(EMU):
+        pytest.skip("oracle/_build/emu/libmmgpu.so not built (make -C oracle emu)")
+    _profile_pipeline(str(tmp_path), emulate=True)
+
+
+@pytest.mark.gpu
+def test_profile_queries_on_device(tmp_path):
+    _profile_pipeline(str(tmp_path), emulate=False)
