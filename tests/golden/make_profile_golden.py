@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 sys.path.insert(0, os.path.dirname(HERE))
 from oracle.pyoracle import RefLib          # noqa: E402
-from test_profile_query import cases        # noqa: E402
+from tests.test_profile_query import cases        # noqa: E402
 
 ref = RefLib(comp_bias=False)
 mat = np.load(os.path.join(HERE, "matrices.npz"))["blosum62_sw"]
