@@ -297,6 +297,13 @@ typedef struct {
     uint32_t qlen;
     const float *comp_bias;  /* QueryMatcher::compositionBias (mmgpu_host_comp_bias over the k-mer matrix), NULL = 0 */
     uint32_t identity_id;    /* targetSeqId of Prefiltering.cpp:855-868, UINT32_MAX = none */
+    /* profile query (DBTYPE_HMM_PROFILE; Prefiltering.cpp:832-834 hands Sequence::profile_matrix to the matcher): q = numSequence
+     * (only the X test of the k-mer window reads it), comp_bias is ignored (QueryMatcher.cpp:110-114), and the three
+     * arrays below are what Sequence::mapProfile left in the Sequence (Sequence.cpp:301-352).  All NULL: sequence query. */
+    const int16_t *profile_score;   /* Sequence::profile_score: [qlen][profile_row], 20 scores per position sorted descending */
+    const uint32_t *profile_index;  /* Sequence::profile_index: the letters in that order */
+    uint32_t profile_row;           /* Sequence::profile_row_size */
+    const int8_t *profile;          /* Sequence::getAlignmentProfile(): [20][qlen] (UngappedAlignment::createProfile :405-411) */
 } mmgpu_pf_query;
 
 /* == hit_t (QueryMatcher.h:33-49) */

@@ -71,12 +71,16 @@ bool MMGpuPrefilter::matchBlock(const std::vector<Query> &queries, int kmerThr, 
     for (size_t q = 0; q < nq; q++) {
         const Query &s = queries[q];
         bias[q].assign(s.L, 0.0f);
-        if (aaBiasCorrection)
+        if (aaBiasCorrection && s.profile == NULL)      // no correction for profile queries (QueryMatcher.cpp:110-114)
             SubstitutionMatrix::calcLocalAaBiasCorrection(kmerSubMat, s.numSequence, s.L, bias[q].data(), aaBiasCorrectionScale);
         dq[q].q = s.numSequence;
         dq[q].qlen = (uint32_t)s.L;
-        dq[q].comp_bias = bias[q].data();
+        dq[q].comp_bias = s.profile ? NULL : bias[q].data();
         dq[q].identity_id = queries[q].identityId;
+        dq[q].profile_score = s.profileScore;
+        dq[q].profile_index = s.profileIndex;
+        dq[q].profile_row = s.profileRow;
+        dq[q].profile = s.profile;
     }
     mmgpu_pf_params par;
     par.kmer_thr = kmerThr;

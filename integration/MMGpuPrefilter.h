@@ -35,6 +35,13 @@ public:
         const unsigned char *numSequence;   // Sequence::numSequence (the caller keeps it alive)
         int L;
         unsigned int identityId;      // targetSeqId of Prefiltering.cpp:855-868, UINT_MAX = none
+        // profile query (Prefiltering.cpp:832-834): copies of Sequence::profile_score / profile_index ([L][profileRow], rows
+        // sorted by Sequence::mapProfile) and Sequence::getAlignmentProfile() ([20][L]); all NULL for a sequence query
+        const short *profileScore;
+        const unsigned int *profileIndex;
+        unsigned int profileRow;
+        const int8_t *profile;
+        Query() : numSequence(NULL), L(0), identityId(0xFFFFFFFFu), profileScore(NULL), profileIndex(NULL), profileRow(0), profile(NULL) {}
     };
     // results[q] = the hit_t list of QueryMatcher::matchQuery; needsCpu[q] = the device declined the query;
     // stats[q] (optional) = what QueryMatcher::getStatistics() would report for the query

@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "DBWriter.h"
+#include "ExtendedSubstitutionMatrix.h"
 #include "Debug.h"
 #include "Prefiltering.h"
 #include "QueryMatcher.h"
@@ -32,13 +33,14 @@
 
 bool MMGpuPrefilterRun::usable(Prefiltering &p) {
     if (!MMGpuRun::enabled()) return false;
-    const bool aa = Parameters::isEqualDbtype(p.querySeqType, Parameters::DBTYPE_AMINO_ACIDS) &&
+    const bool profileQuery = Parameters::isEqualDbtype(p.querySeqType, Parameters::DBTYPE_HMM_PROFILE);
+    const bool aa = (Parameters::isEqualDbtype(p.querySeqType, Parameters::DBTYPE_AMINO_ACIDS) || profileQuery) &&
                     Parameters::isEqualDbtype(p.targetSeqType, Parameters::DBTYPE_AMINO_ACIDS);
     const char *why = NULL;
-    if (!aa) why = "profile / nucleotide databases";
+    if (!aa) why = "profile targets / nucleotide databases";
     else if (p.indexTable == NULL || p.sequenceLookup == NULL) why = "no index table / sequence lookup in memory";
     else if (p.takeOnlyBestKmer) why = "exact k-mer matching";
-    else if (!p._3merSubMatrix.isValid() || !p._2merSubMatrix.isValid()) why = "no similar-k-mer score matrices";
+    else if (!profileQuery && (!p._3merSubMatrix.isValid() || !p._2merSubMatrix.isValid())) why = "no similar-k-mer score matrices";
     else if (p.diagonalScoring == 0) why = "--diag-score 0";
     else if (p.minDiagScoreThr < 1) why = "--min-ungapped-score 0";
     else if (p.kmerSize != 6 && p.kmerSize != 7) why = "k-mer size other than 6 / 7";
@@ -58,15 +60,33 @@ bool MMGpuPrefilterRun::run(Prefiltering &p, DBWriter &tmpDbw, size_t dbFrom, si
     if (!usable(p)) return false;
     mmgpu_ctx *gpu = MMGpuRun::context();
     MMGpuPrefilter device(gpu, p.kmerSubMat, p.ungappedSubMat, p.aaBiasCorrection, p.aaBiasCorrectionScale);
-    if (!device.loadIndex(p.indexTable, p.sequenceLookup, p._3merSubMatrix, p._2merSubMatrix, p.spacedKmer)) {
+    const bool profileQuery = Parameters::isEqualDbtype(p.querySeqType, Parameters::DBTYPE_HMM_PROFILE);
+    // The library's index hand-over carries the 3-mer / 2-mer score tables of sequence queries; Prefiltering only builds
+    // them for amino-acid queries (Prefiltering.cpp:218-225), so a profile run computes them here the same way.
+    ScoreMatrix local3, local2;
+    if (profileQuery && (!p._3merSubMatrix.isValid() || !p._2merSubMatrix.isValid())) {
+        const int alph = p.kmerSubMat->alphabetSize;
+        p.kmerSubMat->alphabetSize = alph - 1;
+        local2 = ExtendedSubstitutionMatrix::calcScoreMatrix(*p.kmerSubMat, 2);
+        local3 = ExtendedSubstitutionMatrix::calcScoreMatrix(*p.kmerSubMat, 3);
+        p.kmerSubMat->alphabetSize = alph;
+    }
+    ScoreMatrix &three = local3.isValid() ? local3 : p._3merSubMatrix;
+    ScoreMatrix &two = local2.isValid() ? local2 : p._2merSubMatrix;
+    if (!device.loadIndex(p.indexTable, p.sequenceLookup, three, two, p.spacedKmer)) {
         Debug(Debug::ERROR) << "MMGPU: " << device.error() << "\n";
         EXIT(EXIT_FAILURE);
     }
+    if (local3.isValid()) ExtendedSubstitutionMatrix::freeScoreMatrix(local3);     // the library copied the tables
+    if (local2.isValid()) ExtendedSubstitutionMatrix::freeScoreMatrix(local2);
     const size_t maxBlockQueries = MMGpuRun::envSize("MMGPU_PREF_BLOCK_QUERIES", 2048);
 
     std::vector<Sequence *> seqs(localThreads, NULL);
     std::vector<QueryMatcher *> cpuMatchers(localThreads, NULL);
     std::vector<std::vector<unsigned char> > queryNum;
+    std::vector<std::vector<short> > queryProfScore;         // profile queries: copies of the Sequence's profile arrays
+    std::vector<std::vector<unsigned int> > queryProfIndex;
+    std::vector<std::vector<int8_t> > queryProfAln;
     std::vector<MMGpuPrefilter::Query> block;
     std::vector<std::vector<hit_t> > results;
     std::vector<bool> needsCpu;
@@ -77,6 +97,9 @@ bool MMGpuPrefilterRun::run(Prefiltering &p, DBWriter &tmpDbw, size_t dbFrom, si
     for (size_t next = queryFrom; next < queryFrom + querySize;) {
         const size_t nq = std::min(maxBlockQueries, queryFrom + querySize - next);
         queryNum.assign(nq, std::vector<unsigned char>());
+        queryProfScore.assign(nq, std::vector<short>());
+        queryProfIndex.assign(nq, std::vector<unsigned int>());
+        queryProfAln.assign(nq, std::vector<int8_t>());
         block.assign(nq, MMGpuPrefilter::Query());
 #pragma omp parallel num_threads(localThreads)
         {
@@ -97,6 +120,17 @@ bool MMGpuPrefilterRun::run(Prefiltering &p, DBWriter &tmpDbw, size_t dbFrom, si
                 queryNum[b].assign(seq.numSequence, seq.numSequence + seq.L);
                 block[b].numSequence = queryNum[b].data();
                 block[b].L = seq.L;
+                if (profileQuery) {
+                    const size_t row = seq.profile_row_size;
+                    queryProfScore[b].assign(seq.profile_score, seq.profile_score + (size_t)seq.L * row);
+                    queryProfIndex[b].assign(seq.profile_index, seq.profile_index + (size_t)seq.L * row);
+                    const int8_t *ap = seq.getAlignmentProfile();
+                    queryProfAln[b].assign(ap, ap + Sequence::PROFILE_AA_SIZE * (size_t)seq.L);
+                    block[b].profileScore = queryProfScore[b].data();
+                    block[b].profileIndex = queryProfIndex[b].data();
+                    block[b].profileRow = (unsigned int)row;
+                    block[b].profile = queryProfAln[b].data();
+                }
                 // :855-868
                 DBLocalId targetSeqId = DB_LOCAL_ID_INVALID;
                 if (p.sameQTDB || p.includeIdentical) {
@@ -144,7 +178,8 @@ bool MMGpuPrefilterRun::run(Prefiltering &p, DBWriter &tmpDbw, size_t dbFrom, si
                                                                    p.kmerSize, dbSize, std::max(p.tdbr->getMaxSeqLen(), p.qdbr->getMaxSeqLen()),
                                                                    p.maxResListLen, p.aaBiasCorrection, p.aaBiasCorrectionScale, p.diagonalScoring,
                                                                    p.minDiagScoreThr, p.takeOnlyBestKmer, false, p.ungappedSubMatAux, p.targetSeqType);
-                        cpuMatchers[thread_idx]->setSubstitutionMatrix(&p._3merSubMatrix, &p._2merSubMatrix);
+                        if (seq.profile_matrix != NULL) cpuMatchers[thread_idx]->setProfileMatrix(seq.profile_matrix);     // :832-836
+                        else cpuMatchers[thread_idx]->setSubstitutionMatrix(&p._3merSubMatrix, &p._2merSubMatrix);
                     }
                     seq.mapSequence(id, qKey, p.qdbr->getData(id, thread_idx), p.qdbr->getSeqLen(id));
                     const DBLocalId identityId = block[b].identityId == UINT_MAX ? DB_LOCAL_ID_INVALID : (DBLocalId)block[b].identityId;

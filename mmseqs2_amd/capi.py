@@ -88,7 +88,8 @@ class PfParams(ctypes.Structure):
 
 
 class PfQuery(ctypes.Structure):
-    _fields_ = [("q", c_p), ("qlen", ctypes.c_uint32), ("comp_bias", c_p), ("identity_id", ctypes.c_uint32)]
+    _fields_ = [("q", c_p), ("qlen", ctypes.c_uint32), ("comp_bias", c_p), ("identity_id", ctypes.c_uint32),
+                ("profile_score", c_p), ("profile_index", c_p), ("profile_row", ctypes.c_uint32), ("profile", c_p)]
 
 
 class PfShard(ctypes.Structure):
@@ -537,15 +538,26 @@ class MMGpu:
         return off, ids[:ne.value], pos[:ne.value]
 
     def _pf_marshal(self, queries):
-        """queries: list of dicts {q: uint8[], comp_bias: float32[]|None, identity_id: int|None}"""
+        """queries: list of dicts {q: uint8[], comp_bias: float32[]|None, identity_id: int|None}; a profile query adds
+        profile_score int16 [qlen][row], profile_index uint32 [qlen][row] (Sequence::profile_score / profile_index) and
+        profile int8 [20][qlen] (Sequence::getAlignmentProfile)"""
         arr = (PfQuery * max(len(queries), 1))()
         keep = []
         for i, qd in enumerate(queries):
             q = np.ascontiguousarray(qd["q"], np.uint8)
             cb = None if qd.get("comp_bias") is None else np.ascontiguousarray(qd["comp_bias"], np.float32)
-            keep += [q, cb]
             ident = qd.get("identity_id")
-            arr[i] = PfQuery(_ptr(q), len(q), _ptr(cb), 0xFFFFFFFF if ident is None else int(ident))
+            ps = pi = pa = None
+            row = 0
+            if qd.get("profile") is not None:
+                ps = np.ascontiguousarray(qd["profile_score"], np.int16)
+                pi = np.ascontiguousarray(qd["profile_index"], np.uint32)
+                pa = np.ascontiguousarray(qd["profile"], np.int8)
+                if ps.shape != pi.shape or ps.shape[0] != len(q) or pa.shape != (20, len(q)):
+                    raise ValueError("profile query: profile_score / profile_index must be [qlen][row], profile [20][qlen]")
+                row = ps.shape[1]
+            keep += [q, cb, ps, pi, pa]
+            arr[i] = PfQuery(_ptr(q), len(q), _ptr(cb), 0xFFFFFFFF if ident is None else int(ident), _ptr(ps), _ptr(pi), row, _ptr(pa))
         return arr, keep
 
     def pf_prepare(self, queries, kmer_thr, max_hits=300, min_diag_score=15, ref_bins=0):

@@ -137,6 +137,9 @@ struct PfCand {        // double-diagonal candidate / surviving element
     uint16_t pad;
 };
 
+constexpr int PF_PROW = 32;            // bytes per position of the profile-query score rows (21 letters used)
+constexpr int PF_PROF_LETTERS = 20;    // Sequence::PROFILE_AA_SIZE
+
 struct PfKmerArgs {
     const uint8_t *q_res;      // batch residues, concatenated
     const int16_t *q_thr;      // per position: adjusted k-mer threshold, -1 = no window / X in window
@@ -156,6 +159,11 @@ struct PfKmerArgs {
     const uint16_t *cum2;      // [n2][cum2_w]
     uint32_t cum2_w;
     int32_t score2_min;
+    // profile queries (Sequence::profile_score / profile_index of the positions of profile queries, 20 per position,
+    // sorted descending as Sequence::mapProfile leaves them): q_kind[gp] = 1 marks their positions (null: none in the batch)
+    const uint8_t *q_kind;
+    const int16_t *prof_score;    // [n_pos][20]
+    const uint8_t *prof_letter;   // [n_pos][20]
     // count pass
     uint32_t *nsim;
     // emit pass
@@ -194,6 +202,10 @@ struct PfDedupArgs {
     const int8_t *q_corr;             // UngappedAlignment::aaCorrectionScore per position
     const int8_t *mat;                // ungapped matrix, alphabet x alphabet
     int alphabet;
+    // profile queries: UngappedAlignment::queryProfile rows (createProfile's profile branch, UngappedAlignment.cpp:405-411),
+    // [n_pos][PF_PROW] int8, letter-indexed, filled for the positions of profile queries; q_isprof[q] picks the path
+    const int8_t *q_rows;
+    const uint8_t *q_isprof;
     const uint8_t *t_res;
     const uint32_t *t_off4, *t_len;
     uint32_t min_diag_score;

@@ -466,6 +466,8 @@ struct mmgpu_pf_batch_t {
     std::vector<uint32_t> q_off;
     // device: inputs
     DevBuf d_qres, d_qthr, d_qcorr, d_qoff, d_qident, d_qself;
+    DevBuf d_qkind, d_qisprof, d_pscore, d_pletter, d_qrows;   // profile queries only
+    bool any_profile = false;
     // device: working set (grow-only, reused across runs)
     DevBuf d_nsim, d_qtot, d_qbase, d_list_base, d_pos_entries, d_peb, d_qentries;
     DevBuf d_qtile_base, d_qntiles, d_bucket_count, d_bucket_off;
@@ -550,6 +552,28 @@ extern "C" int mmgpu_pf_prepare(mmgpu_ctx *c, const mmgpu_pf_params *par, const 
     std::vector<int8_t> qcorr(tot + 64, 0);
     std::vector<uint32_t> qident(std::max<uint32_t>(nq, 1), 0xFFFFFFFFu);
     std::vector<int32_t> qself(std::max<uint32_t>(nq, 1), 0);
+    // profile queries: per-position kind flag, the 20 sorted scores / letters of every position, the ungapped score rows
+    bool any_prof = false;
+    for (uint32_t i = 0; i < nq; i++) {
+        if (!qs[i].profile_score && !qs[i].profile_index && !qs[i].profile) continue;
+        if (!qs[i].profile_score || !qs[i].profile_index || !qs[i].profile || qs[i].profile_row < (uint32_t)PF_PROF_LETTERS) {
+            delete b;
+            return fail(MMGPU_ERR_ARG, "mmgpu_pf_prepare: a profile query needs profile_score, profile_index (row >= 20) and profile");
+        }
+        if (P.kalph != PF_PROF_LETTERS) { delete b; return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_pf_prepare: profile queries need the 20-letter k-mer alphabet"); }
+        any_prof = true;
+    }
+    std::vector<uint8_t> qkind, qisprof, pletter;
+    std::vector<int16_t> pscore;
+    std::vector<int8_t> qrows;
+    if (any_prof) {
+        qkind.assign(tot + 64, 0);
+        qisprof.assign(std::max<uint32_t>(nq, 1), 0);
+        pscore.assign((tot + 64) * PF_PROF_LETTERS, 0);
+        pletter.assign((tot + 64) * PF_PROF_LETTERS, 0);
+        qrows.assign((tot + 64) * PF_PROW, 0);
+    }
+    b->any_profile = any_prof;
     std::atomic<bool> bad(false);
     parallel_for(nq, [&](size_t a, size_t e) {
         for (size_t i = a; i < e; i++) {
@@ -561,13 +585,29 @@ extern "C" int mmgpu_pf_prepare(mmgpu_ctx *c, const mmgpu_pf_params *par, const 
                 qres[o + p] = Q.q[p];
             }
             qident[i] = Q.identity_id;
+            const bool prof = Q.profile != nullptr;
+            const float *cbias = prof ? nullptr : Q.comp_bias;     // no composition bias for profile queries (QueryMatcher.cpp:110-114)
+            if (prof) {
+                qisprof[i] = 1;
+                for (int p = 0; p < L; p++) {
+                    qkind[o + p] = 1;
+                    for (int z = 0; z < PF_PROF_LETTERS; z++) {
+                        pscore[(size_t)(o + p) * PF_PROF_LETTERS + z] = Q.profile_score[(size_t)p * Q.profile_row + z];
+                        const uint32_t le = Q.profile_index[(size_t)p * Q.profile_row + z];
+                        if (le >= (uint32_t)P.kalph) bad = true;
+                        pletter[(size_t)(o + p) * PF_PROF_LETTERS + z] = (uint8_t)le;
+                        // UngappedAlignment::createProfile, profile branch: queryProfile[pos][aa] = alignment profile, X = 0
+                        qrows[(size_t)(o + p) * PF_PROW + z] = Q.profile[(size_t)z * L + p];
+                    }
+                }
+            }
             // QueryMatcher::match, QueryMatcher.cpp:255-274: per-window threshold (a query handed back to the host gets none:
             // no window, no work)
             for (int p = 0; p + P.pattern_len <= L && !b->long_query[i]; p++) {
                 float bc = 0;
                 bool x = false;
                 for (int z = 0; z < P.k; z++) {
-                    bc += Q.comp_bias ? Q.comp_bias[p + (short)P.pat[z]] : 0.0f;
+                    bc += cbias ? cbias[p + (short)P.pat[z]] : 0.0f;
                     if (Q.q[p + P.pat[z]] >= P.kalph) x = true;
                 }
                 if (x) continue;
@@ -577,14 +617,15 @@ extern "C" int mmgpu_pf_prepare(mmgpu_ctx *c, const mmgpu_pf_params *par, const 
             }
             // UngappedAlignment::createProfile, UngappedAlignment.cpp:396-400
             for (int p = 0; p < L; p++) {
-                float v = Q.comp_bias ? Q.comp_bias[p] : 0.0f;
+                float v = cbias ? cbias[p] : 0.0f;
                 v = (v < 0.0) ? v / 4 - 0.5 : v / 4 + 0.5;
                 qcorr[o + p] = (int8_t)(char)v;
             }
             // rescoreHits' self score (QueryMatcher.cpp:566): best ungapped segment of the query against itself
             int sc = 0, mx = 0;
             for (int p = 0; p < L && !bad; p++) {
-                const int cur = (int)(int8_t)(P.h_mat[(size_t)Q.q[p] * P.alphabet + Q.q[p]] + qcorr[o + p]);
+                const int cur = prof ? (int)qrows[(size_t)(o + p) * PF_PROW + (Q.q[p] & (PF_PROW - 1))]
+                                     : (int)(int8_t)(P.h_mat[(size_t)Q.q[p] * P.alphabet + Q.q[p]] + qcorr[o + p]);
                 sc += cur;
                 sc = sc < 0 ? 0 : sc;
                 mx = sc > mx ? sc : mx;
@@ -601,6 +642,13 @@ extern "C" int mmgpu_pf_prepare(mmgpu_ctx *c, const mmgpu_pf_params *par, const 
     B_TRY(upload(b->d_qoff, b->q_off, s));
     B_TRY(upload(b->d_qident, qident, s));
     B_TRY(upload(b->d_qself, qself, s));
+    if (any_prof) {
+        B_TRY(upload(b->d_qkind, qkind, s));
+        B_TRY(upload(b->d_qisprof, qisprof, s));
+        B_TRY(upload(b->d_pscore, pscore, s));
+        B_TRY(upload(b->d_pletter, pletter, s));
+        B_TRY(upload(b->d_qrows, qrows, s));
+    }
     const size_t np = std::max<size_t>(tot, 1), nqq = std::max<uint32_t>(nq, 1);
     B_TRY(b->d_nsim.alloc(np * 4));
     B_TRY(b->d_list_base.alloc((np + 1) * 4));
@@ -651,6 +699,11 @@ extern "C" int mmgpu_pf_run(mmgpu_ctx *c, mmgpu_pf_batch_t *b) {
     K.q_res = b->d_qres.as<uint8_t>();
     K.q_thr = b->d_qthr.as<int16_t>();
     K.n_pos = b->n_pos;
+    if (b->any_profile) {
+        K.q_kind = b->d_qkind.as<uint8_t>();
+        K.prof_score = b->d_pscore.as<int16_t>();
+        K.prof_letter = b->d_pletter.as<uint8_t>();
+    }
     memcpy(K.pat, P.pat, sizeof(K.pat));
     K.kalph = (uint32_t)P.kalph;
     K.n3 = P.n3;
@@ -825,6 +878,8 @@ extern "C" int mmgpu_pf_run(mmgpu_ctx *c, mmgpu_pf_batch_t *b) {
     D.q_off = b->d_qoff.as<uint32_t>();
     D.q_res = b->d_qres.as<uint8_t>();
     D.q_corr = b->d_qcorr.as<int8_t>();
+    D.q_rows = b->any_profile ? b->d_qrows.as<int8_t>() : nullptr;
+    D.q_isprof = b->any_profile ? b->d_qisprof.as<uint8_t>() : nullptr;
     D.mat = P.d_mat.as<int8_t>();
     D.alphabet = P.alphabet;
     D.t_res = c->db.res;

@@ -114,6 +114,7 @@ __global__ __launch_bounds__(256) void pf_kmers_kernel(PfKmerArgs A) {
     const int lane = lane_id();
     const uint32_t gp = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (gp >= A.n_pos) return;
+    if (A.q_kind && A.q_kind[gp]) return;   // position of a profile query: pf_kmers_prof_kernel
     const int thr = A.q_thr[gp];
     if (thr < 0) {   // no window here, or the window contains X (QueryMatcher.cpp:264-268)
         if (lane == 0) {
@@ -195,6 +196,7 @@ __global__ __launch_bounds__(256) void pf_kmers7_kernel(PfKmerArgs A) {
     const int lane = lane_id();
     const uint32_t gp = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (gp >= A.n_pos) return;
+    if (A.q_kind && A.q_kind[gp]) return;
     const int thr = A.q_thr[gp];
     if (thr < 0) {
         if (lane == 0) {
@@ -287,6 +289,122 @@ __global__ __launch_bounds__(256) void pf_kmers7_kernel(PfKmerArgs A) {
     }
     if (lane == 0) {
         if (EMIT) A.pos_entries[gp] = running; else A.nsim[gp] = nlists;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Profile queries: KmerGenerator::setDivideStrategy(ScoreMatrix **one) (KmerGenerator.cpp:32-41) - k steps of ONE residue
+// each; step i multiplies the running list with the 20 score-sorted entries of query position gp + pattern[i]
+// (Sequence::nextProfileKmer, Sequence.cpp:354-365), cutoff thr - score - (sum of the best scores of the later steps),
+// first step with the early exit at thr - rest[0] (generateKmerList :126-166, calculateArrayProduct :187-216).  The output
+// order is the nested-loop order, so the enumeration is a depth-first expansion: each lane holds one element of the
+// current level, counts its children (entries of the next row above its cutoff), the children are laid out by a
+// prefix sum and expanded 64 at a time; the last level emits the index lists exactly like the sequence kernels.
+struct ProfGen {
+    const int16_t *sc[8];       // the k rows of this window (scores, descending)
+    const uint8_t *le[8];       // their letters
+    int rest[8];                // possibleRest
+    uint32_t mult[8];           // Indexer::powers
+    int thr;
+    uint32_t nlists, running, lbase, gp;
+};
+
+__device__ __forceinline__ uint32_t prof_count_ge(const int16_t *row, int c) {   // entries of a descending row with score >= c
+    uint32_t lo = 0, hi = PF_PROF_LETTERS;      // first index with row[idx] < c
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if ((int)row[mid] >= c) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+template <int LVL, int K, bool EMIT>
+__device__ __forceinline__ void prof_expand(const PfKmerArgs &A, ProfGen &G, bool act, int sc, uint32_t idx) {
+    const int lane = lane_id();
+    uint32_t n = 0;
+    if (act) n = prof_count_ge(G.sc[LVL], (int)(short)(G.thr - sc - G.rest[LVL]));
+    const uint32_t incl = wave_incl_scan(n);
+    const uint32_t total = __shfl(incl, 63);
+    const uint32_t excl = incl - n;
+    for (uint32_t e0 = 0; e0 < total; e0 += 64) {
+        const uint32_t x = e0 + (uint32_t)lane;
+        const bool actE = x < total;
+        const int m = seg_find(excl, x);
+        const uint32_t ex_m = __shfl(excl, m);
+        const int sc_p = __shfl(sc, m);
+        const uint32_t idx_p = __shfl(idx, m);
+        int sc_c = 0;
+        uint32_t idx_c = 0;
+        if (actE) {
+            const uint32_t j = x - ex_m;
+            sc_c = (int)(short)(sc_p + (int)G.sc[LVL][j]);
+            idx_c = idx_p + (uint32_t)G.le[LVL][j] * G.mult[LVL];
+        }
+        if constexpr (LVL + 1 < K) {
+            prof_expand<LVL + 1, K, EMIT>(A, G, actE, sc_c, idx_c);
+        } else {
+            const uint32_t cnt = min(64u, total - e0);
+            if (EMIT) {
+                uint32_t start = 0, len = 0;
+                if (actE) {
+                    const U32Pair o = *reinterpret_cast<const U32Pair *>(A.offsets + idx_c);
+                    start = o.a;
+                    len = o.b - o.a;
+                }
+                const uint32_t li = wave_incl_scan(len);
+                if (actE) {
+                    PfList rec;
+                    rec.start = start;
+                    rec.len = len;
+                    rec.lprefix = G.running + li - len;
+                    rec.pos = G.gp;
+                    A.lists[(size_t)G.lbase + G.nlists + (uint32_t)lane] = rec;
+                }
+                G.running += __shfl(li, 63);
+            }
+            G.nlists += cnt;
+        }
+    }
+}
+
+template <int K, bool EMIT>
+__global__ __launch_bounds__(256) void pf_kmers_prof_kernel(PfKmerArgs A) {
+    const int lane = lane_id();
+    const uint32_t gp = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (gp >= A.n_pos) return;
+    if (!A.q_kind[gp]) return;             // position of a sequence query
+    const int thr = A.q_thr[gp];
+    if (thr < 0) {
+        if (lane == 0) {
+            if (EMIT) A.pos_entries[gp] = 0; else A.nsim[gp] = 0;
+        }
+        return;
+    }
+    ProfGen G;
+    uint32_t pw = 1;
+#pragma unroll
+    for (int i = 0; i < K; i++) {
+        G.sc[i] = A.prof_score + (size_t)(gp + A.pat[i]) * PF_PROF_LETTERS;
+        G.le[i] = A.prof_letter + (size_t)(gp + A.pat[i]) * PF_PROF_LETTERS;
+        G.mult[i] = pw;
+        pw *= A.kalph;
+    }
+    G.rest[K - 1] = 0;
+#pragma unroll
+    for (int i = K - 1; i >= 1; i--) G.rest[i - 1] = (int)(short)((int)G.sc[i][0] + G.rest[i]);
+    G.thr = thr;
+    G.nlists = 0;
+    G.running = 0;
+    G.gp = gp;
+    G.lbase = EMIT ? A.list_base[gp] : 0u;
+    // first step: entries of row 0 with score >= thr - rest[0]
+    const uint32_t n0 = prof_count_ge(G.sc[0], (int)(short)(thr - G.rest[0]));
+    const bool act = (uint32_t)lane < n0;
+    const int sc0 = act ? (int)G.sc[0][lane] : 0;
+    const uint32_t idx0 = act ? (uint32_t)G.le[0][lane] : 0u;
+    prof_expand<1, K, EMIT>(A, G, act, sc0, idx0);
+    if (lane == 0) {
+        if (EMIT) A.pos_entries[gp] = G.running; else A.nsim[gp] = G.nlists;
     }
 }
 
@@ -534,6 +652,23 @@ __device__ __forceinline__ Seg seg_cells(const uint32_t tw[4], const uint32_t qw
     }
     return g;
 }
+// profile query: the score of cell k is row (first position + k) of the query's score rows at the target letter
+__device__ __forceinline__ Seg seg_cells_rows(const uint32_t tw[4], const int8_t *rows, int nn) {
+    Seg g;
+    g.a = 0; g.b = 0; g.P = -(1 << 28); g.M = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        if (k < nn) {
+            const int tb_ = (int)((tw[k >> 2] >> ((k & 3) * 8)) & 0xFFu);
+            const int x = (int)rows[k * PF_PROW + (tb_ & (PF_PROW - 1))];
+            g.b += x;
+            g.a = max(0, g.a + x);
+            g.P = max(g.P, g.b);
+            g.M = max(g.M, g.a);
+        }
+    }
+    return g;
+}
 __device__ __forceinline__ Seg seg_tree16(Seg g, int gl) {   // ordered tree over the 16 lanes of a group; result in lane 0
 #pragma unroll
     for (int d = 1; d < 16; d <<= 1) {
@@ -563,6 +698,7 @@ __device__ __forceinline__ uint64_t score_chunk(const PfDedupArgs &A, const int8
     const uint32_t qsh = qp0 & 3u;
     const int alph = A.alphabet;
     const bool has = (uint32_t)lane < nin;
+    const int8_t *prows = (A.q_isprof && A.q_isprof[q]) ? A.q_rows + (size_t)qp0 * PF_PROW : nullptr;   // wave-uniform
     auto query16 = [&](int off, uint32_t qw[4], uint32_t cw[4]) {
         if (s_qres) {
             load16_lds(s_qres, qsh + (uint32_t)off, qw);
@@ -611,7 +747,7 @@ __device__ __forceinline__ uint64_t score_chunk(const PfDedupArgs &A, const int8
             for (int z = 0; z < 4; z++) { tw[u][z] = 0; qw[u][z] = 0; cw[u][z] = 0; }
             if (gl * 16 < len_u[u]) {
                 load16(reinterpret_cast<const uint8_t *>((uintptr_t)addr_u[u]) + gl * 16, tw[u]);
-                query16(qs_u[u] + gl * 16, qw[u], cw[u]);
+                if (!prows) query16(qs_u[u] + gl * 16, qw[u], cw[u]);
             }
         }
 #pragma unroll
@@ -619,7 +755,10 @@ __device__ __forceinline__ uint64_t score_chunk(const PfDedupArgs &A, const int8
             const int len = len_u[u];
             Seg g;
             g.a = 0; g.b = 0; g.P = -(1 << 28); g.M = 0;
-            if (gl * 16 < len) g = seg_cells(tw[u], qw[u], cw[u], min(16, len - gl * 16), smat, alph);
+            if (gl * 16 < len) {
+                if (prows) g = seg_cells_rows(tw[u], prows + (size_t)(qs_u[u] + gl * 16) * PF_PROW, min(16, len - gl * 16));
+                else g = seg_cells(tw[u], qw[u], cw[u], min(16, len - gl * 16), smat, alph);
+            }
             g = seg_tree16(g, gl);
             int sc = 0, best = 0;
             if (gl == 0 && len > 0) {
@@ -636,8 +775,11 @@ __device__ __forceinline__ uint64_t score_chunk(const PfDedupArgs &A, const int8
                 if (o < len) {
                     uint32_t t2[4], q2[4], c2[4];
                     load16(reinterpret_cast<const uint8_t *>((uintptr_t)addr_u[u]) + o, t2);
-                    query16(qs_u[u] + o, q2, c2);
-                    h = seg_cells(t2, q2, c2, min(16, len - o), smat, alph);
+                    if (prows) h = seg_cells_rows(t2, prows + (size_t)(qs_u[u] + o) * PF_PROW, min(16, len - o));
+                    else {
+                        query16(qs_u[u] + o, q2, c2);
+                        h = seg_cells(t2, q2, c2, min(16, len - o), smat, alph);
+                    }
                 }
                 h = seg_tree16(h, gl);
                 if (gl == 0 && p0 < len) {
@@ -1124,6 +1266,7 @@ __global__ __launch_bounds__(256) void pf_overflow_kernel(PfOvfArgs A) {
     const int qlen = (int)(D.q_off[q + 1] - qp0);
     const uint8_t *qr = D.q_res + qp0;
     const int8_t *qc = D.q_corr + qp0;
+    const int8_t *prows = (D.q_isprof && D.q_isprof[q]) ? D.q_rows + (size_t)qp0 * PF_PROW : nullptr;
     for (uint32_t r0 = 0; r0 < n; r0 += 64) {
         const uint32_t idx = r0 + (uint32_t)lane;
         if (idx < n && cur[idx].score == 0) {
@@ -1138,7 +1281,8 @@ __global__ __launch_bounds__(256) void pf_overflow_kernel(PfOvfArgs A) {
             else if (d < 0 && mind < tlen) { len = min(tlen - mind, qlen); ts = mind; }
             int sc = 0, mx = 0;
             for (int p = 0; p < len; p++) {
-                const int x = (int)(int8_t)(smat[((int)qr[qs + p] * D.alphabet + (int)t[ts + p]) & 1023] + qc[qs + p]);
+                const int x = prows ? (int)prows[(size_t)(qs + p) * PF_PROW + ((int)t[ts + p] & (PF_PROW - 1))]
+                                    : (int)(int8_t)(smat[((int)qr[qs + p] * D.alphabet + (int)t[ts + p]) & 1023] + qc[qs + p]);
                 sc += x;
                 sc = sc < 0 ? 0 : sc;
                 mx = sc > mx ? sc : mx;
@@ -1516,6 +1660,15 @@ hipError_t launch_pf_kmers(const PfKmerArgs &A, bool emit, hipStream_t s) {
     } else {
         if (emit) hipLaunchKernelGGL(pf_kmers_kernel<true>, grid, block, 0, s, A);
         else hipLaunchKernelGGL(pf_kmers_kernel<false>, grid, block, 0, s, A);
+    }
+    if (A.q_kind) {      // the batch holds profile queries: their positions are enumerated by the profile generator
+        if (A.k == 7) {
+            if (emit) hipLaunchKernelGGL((pf_kmers_prof_kernel<7, true>), grid, block, 0, s, A);
+            else hipLaunchKernelGGL((pf_kmers_prof_kernel<7, false>), grid, block, 0, s, A);
+        } else {
+            if (emit) hipLaunchKernelGGL((pf_kmers_prof_kernel<6, true>), grid, block, 0, s, A);
+            else hipLaunchKernelGGL((pf_kmers_prof_kernel<6, false>), grid, block, 0, s, A);
+        }
     }
     return hipGetLastError();
 }

@@ -177,6 +177,11 @@ int mmgpu_pf_prepare(mmgpu_ctx *c, const mmgpu_pf_params *p, const mmgpu_pf_quer
         q.put<uint32_t>(qs[i].identity_id);
         q.put_bytes(qs[i].q, qs[i].qlen);
         q.put_bytes(qs[i].comp_bias, qs[i].comp_bias ? (size_t)qs[i].qlen * 4 : 0);
+        const bool prof = qs[i].profile && qs[i].profile_score && qs[i].profile_index;
+        q.put<uint32_t>(prof ? qs[i].profile_row : 0u);
+        q.put_bytes(qs[i].profile_score, prof ? (size_t)qs[i].qlen * qs[i].profile_row * 2 : 0);
+        q.put_bytes(qs[i].profile_index, prof ? (size_t)qs[i].qlen * qs[i].profile_row * 4 : 0);
+        q.put_bytes(qs[i].profile, prof ? (size_t)20 * qs[i].qlen : 0);
     }
     const int rc = call(c, OP_PF_PREPARE, q, &r);
     if (rc != MMGPU_OK) return rc;

@@ -205,7 +205,10 @@ bool handle(Server &S, int fd, const WireHdr &h, Buf &in) {
             const uint32_t nq = in.get<uint32_t>();
             std::vector<mmgpu_pf_query> qs(nq);
             std::vector<std::vector<float> > cb(nq);
+            std::vector<std::vector<int16_t> > ps(nq);
+            std::vector<std::vector<uint32_t> > pi(nq);
             for (uint32_t i = 0; i < nq && !in.bad; i++) {
+                memset(&qs[i], 0, sizeof(qs[i]));
                 qs[i].identity_id = in.get<uint32_t>();
                 size_t n = 0;
                 qs[i].q = in.get_bytes(&n);
@@ -214,6 +217,16 @@ bool handle(Server &S, int fd, const WireHdr &h, Buf &in) {
                 cb[i].resize(n / 4);
                 if (n) memcpy(cb[i].data(), b, n);
                 qs[i].comp_bias = n ? cb[i].data() : nullptr;
+                qs[i].profile_row = in.get<uint32_t>();
+                b = in.get_bytes(&n);
+                ps[i].resize(n / 2);
+                if (n) memcpy(ps[i].data(), b, n);
+                b = in.get_bytes(&n);
+                pi[i].resize(n / 4);
+                if (n) memcpy(pi[i].data(), b, n);
+                qs[i].profile = reinterpret_cast<const int8_t *>(in.get_bytes(&n));
+                qs[i].profile_score = ps[i].empty() ? nullptr : ps[i].data();
+                qs[i].profile_index = pi[i].empty() ? nullptr : pi[i].data();
             }
             if (in.bad) return reply_err(fd, h.op, MMGPU_ERR_ARG, "mmgpu_server: malformed PF_PREPARE");
             mmgpu_pf_batch_t *b = nullptr;

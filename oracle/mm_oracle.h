@@ -106,6 +106,18 @@ typedef struct {
 } mmo_pf_dump;
 
 void mmo_pf_score_matrix(const int16_t *submat, int alphabet, int kalph, int span, int16_t *score, uint32_t *index);
+/* profile query (Sequence with DBTYPE_HMM_PROFILE and kmerSize != 0, Sequence.cpp:301-352) */
+typedef struct {
+    const int16_t *score;  /* Sequence::profile_score: [qlen][row], 20 scores per position sorted descending */
+    const uint32_t *index; /* Sequence::profile_index: [qlen][row], the letters in that order */
+    int row;               /* Sequence::profile_row_size */
+    const int8_t *aln;     /* Sequence::getAlignmentProfile(): [20][qlen] */
+} mmo_pf_profile;
+size_t mmo_pf_kmer_list_profile(const int16_t *pscore, const uint32_t *pindex, int row, int k, const uint8_t *pat, int pos,
+                                int kalph, int threshold, uint64_t *out, size_t cap);
+int mmo_pf_match_query_profile(const mmo_pf_params *P, const uint8_t *q, int qlen, const mmo_pf_profile *prof,
+                               uint32_t identity_id, mmo_pf_hit *hits, uint64_t hit_cap, uint64_t *n_hits, mmo_pf_stats *st,
+                               mmo_pf_dump *dump);
 size_t mmo_pf_kmer_list(const mmo_pf_gen *g, const uint8_t *kmer, int threshold, uint64_t *out, size_t cap);
 int mmo_pf_pattern(int k, int spaced, uint8_t *pos_in_pattern);
 uint64_t mmo_pf_index_build(const uint8_t *tdata, const uint64_t *toff, uint32_t n, const int16_t *kmer_submat,

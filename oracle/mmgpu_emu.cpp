@@ -52,6 +52,10 @@ struct mmgpu_pf_batch_t {
     std::vector<std::vector<uint8_t> > q;
     std::vector<std::vector<float> > bias;
     std::vector<uint32_t> identity;
+    std::vector<std::vector<int16_t> > pscore;     // profile queries (empty rows otherwise)
+    std::vector<std::vector<uint32_t> > pindex;
+    std::vector<std::vector<int8_t> > paln;
+    std::vector<int> prow;
     std::vector<std::vector<mmo_pf_hit> > hits;
     std::vector<mmo_pf_stats> stats;
 };
@@ -280,6 +284,18 @@ int mmgpu_pf_prepare(mmgpu_ctx *c, const mmgpu_pf_params *p, const mmgpu_pf_quer
         if (qs[i].comp_bias) b->bias.push_back(std::vector<float>(qs[i].comp_bias, qs[i].comp_bias + qs[i].qlen));
         else b->bias.push_back(std::vector<float>(qs[i].qlen, 0.0f));
         b->identity.push_back(qs[i].identity_id);
+        if (qs[i].profile) {
+            const size_t n = (size_t)qs[i].qlen * qs[i].profile_row;
+            b->pscore.push_back(std::vector<int16_t>(qs[i].profile_score, qs[i].profile_score + n));
+            b->pindex.push_back(std::vector<uint32_t>(qs[i].profile_index, qs[i].profile_index + n));
+            b->paln.push_back(std::vector<int8_t>(qs[i].profile, qs[i].profile + (size_t)20 * qs[i].qlen));
+            b->prow.push_back((int)qs[i].profile_row);
+        } else {
+            b->pscore.push_back(std::vector<int16_t>());
+            b->pindex.push_back(std::vector<uint32_t>());
+            b->paln.push_back(std::vector<int8_t>());
+            b->prow.push_back(0);
+        }
     }
     b->hits.resize(nq);
     b->stats.resize(nq);
@@ -310,8 +326,20 @@ int mmgpu_pf_run(mmgpu_ctx *c, mmgpu_pf_batch_t *b) {
     for (size_t i = 0; i < b->q.size(); i++) {
         b->hits[i].resize(cap);
         uint64_t nh = 0;
-        if (mmo_pf_match_query(&P, b->q[i].data(), (int)b->q[i].size(), b->bias[i].data(), b->identity[i], b->hits[i].data(), cap, &nh,
-                               &b->stats[i], NULL) != 0)
+        int rc;
+        if (b->prow[i] > 0) {
+            mmo_pf_profile pr;
+            pr.score = b->pscore[i].data();
+            pr.index = b->pindex[i].data();
+            pr.row = b->prow[i];
+            pr.aln = b->paln[i].data();
+            rc = mmo_pf_match_query_profile(&P, b->q[i].data(), (int)b->q[i].size(), &pr, b->identity[i], b->hits[i].data(), cap, &nh,
+                                            &b->stats[i], NULL);
+        } else {
+            rc = mmo_pf_match_query(&P, b->q[i].data(), (int)b->q[i].size(), b->bias[i].data(), b->identity[i], b->hits[i].data(), cap, &nh,
+                                    &b->stats[i], NULL);
+        }
+        if (rc != 0)
             bad = 1;
         b->hits[i].resize(nh);
     }

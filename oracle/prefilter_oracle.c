@@ -187,6 +187,72 @@ size_t mmo_pf_kmer_list(const mmo_pf_gen *g, const uint8_t *kmer, int threshold_
     return in_n;
 }
 
+/* Profile queries: KmerGenerator::setDivideStrategy(ScoreMatrix **one) (KmerGenerator.cpp:32-41) - k steps of one
+ * residue, step i reads the score-sorted row of query position pos + pattern[i] (Sequence::nextProfileKmer,
+ * Sequence.cpp:354-365: profile_score / profile_index, 20 entries per row sorted by rankedDescSort20); the k-mer window
+ * itself is all zeros (Sequence.h:400-406), so every row index is 0.  Same product / cutoff logic as above. */
+size_t mmo_pf_kmer_list_profile(const int16_t *pscore, const uint32_t *pindex, int row, int k, const uint8_t *pat, int pos,
+                                int kalph, int threshold_in, uint64_t *out, size_t cap) {
+    const short threshold = (short)threshold_in;
+    const int16_t *srow[16];
+    const uint32_t *irow[16];
+    size_t mult[16];
+    short high[16], rest[16];
+    const size_t elem = 20; /* Sequence::PROFILE_AA_SIZE */
+    for (int i = 0; i < k; i++) {
+        srow[i] = pscore + (size_t)(pos + pat[i]) * row;
+        irow[i] = pindex + (size_t)(pos + pat[i]) * row;
+        mult[i] = ipow((size_t)kalph, i);
+        high[i] = srow[i][0];
+    }
+    rest[k - 1] = 0;
+    for (int i = k - 1; i >= 1; i--) rest[i - 1] = (short)(high[i] + rest[i]);
+    short cutoff1 = (short)(threshold - rest[0]);
+    size_t in_n = 0;
+    while (in_n < elem && srow[0][in_n] >= cutoff1) in_n++;
+    short *in_s = (short *)malloc((in_n + 1) * sizeof(short));
+    uint64_t *in_i = (uint64_t *)malloc((in_n + 1) * sizeof(uint64_t));
+    for (size_t p = 0; p < in_n; p++) {
+        in_s[p] = srow[0][p];
+        in_i[p] = irow[0][p];
+    }
+    for (int i = 0; i < k - 1; i++) {
+        const int16_t *s2 = srow[i + 1];
+        const uint32_t *i2 = irow[i + 1];
+        size_t ocap = 1024, counter = 0;
+        short *os = (short *)malloc(ocap * sizeof(short));
+        uint64_t *oi = (uint64_t *)malloc(ocap * sizeof(uint64_t));
+        for (size_t a = 0; a < in_n; a++) {
+            short score_i = in_s[a];
+            if (score_i < cutoff1) break;
+            uint64_t kmer_i = in_i[a];
+            short cutoff2 = (short)(threshold - score_i - rest[i + 1]);
+            for (size_t b = 0; b < elem && (counter + 1 < MMO_MAX_KMER_RESULT) && s2[b] >= cutoff2; b++) {
+                if (counter == ocap) {
+                    ocap *= 2;
+                    os = (short *)realloc(os, ocap * sizeof(short));
+                    oi = (uint64_t *)realloc(oi, ocap * sizeof(uint64_t));
+                }
+                os[counter] = (short)(score_i + s2[b]);
+                oi[counter] = kmer_i + (uint64_t)i2[b] * mult[i + 1];
+                counter++;
+            }
+            if (counter + 1 >= MMO_MAX_KMER_RESULT) break;
+        }
+        free(in_s);
+        free(in_i);
+        in_s = os;
+        in_i = oi;
+        in_n = counter;
+        cutoff1 = -1000;
+    }
+    size_t w = in_n < cap ? in_n : cap;
+    for (size_t z = 0; z < w; z++) out[z] = in_i[z];
+    free(in_s);
+    free(in_i);
+    return in_n;
+}
+
 /* ---------------------------------------------------------------------------------------------------------
  * Sequence k-mer iteration (src/commons/Sequence.h:94-121,399; spaced patterns Sequence.h:24-27) */
 static const uint8_t MMO_SPACED6[] = {1, 1, 0, 1, 0, 1, 0, 0, 1, 1};
@@ -302,33 +368,42 @@ void mmo_pf_ungapped_corr(const float *bias, int qlen, int8_t *corr) {
 
 /* scalarDiagonalScoring (:45-57) over the overlap that computeSingelSequenceScores (:423-437) selects;
  * diagonal is the signed value (short)(u16) for sequences < 32768 (scoreSingleSequence :453-460). */
-static int mmo_diag_score(const uint8_t *q, const int8_t *corr, int qlen, const int8_t *mat, int alphabet,
-                          const uint8_t *t, int tlen, int diagonal) {
+/* qprof != NULL: profile query - UngappedAlignment::createProfile's profile branch (:405-411): the row of query position p
+ * is the alignment profile's column, [qlen][21] here, letter 20 (X) scores 0; q / corr / mat are not read. */
+static int mmo_diag_score_p(const uint8_t *q, const int8_t *corr, int qlen, const int8_t *mat, int alphabet,
+                            const uint8_t *t, int tlen, int diagonal, const int8_t *qprof) {
     int mind = diagonal < 0 ? -diagonal : diagonal;
     const uint8_t *qs, *ts;
     const int8_t *cs;
-    int len;
+    int len, q0;
     if (diagonal >= 0 && mind < qlen) {
         len = tlen < qlen - mind ? tlen : qlen - mind;
         qs = q + mind;
         cs = corr + mind;
+        q0 = mind;
         ts = t;
     } else if (diagonal < 0 && mind < tlen) {
         len = tlen - mind < qlen ? tlen - mind : qlen;
         qs = q;
         cs = corr;
+        q0 = 0;
         ts = t + mind;
     } else {
         return 0;
     }
     int max = 0, score = 0;
     for (int p = 0; p < len; p++) {
-        int curr = (signed char)(char)(mat[qs[p] * alphabet + ts[p]] + cs[p]);
+        int curr = qprof ? (int)qprof[(size_t)(q0 + p) * 21 + ts[p]] : (signed char)(char)(mat[qs[p] * alphabet + ts[p]] + cs[p]);
         score += curr;
         score = score < 0 ? 0 : score;
         max = score > max ? score : max;
     }
     return max;
+}
+
+static int mmo_diag_score(const uint8_t *q, const int8_t *corr, int qlen, const int8_t *mat, int alphabet,
+                          const uint8_t *t, int tlen, int diagonal) {
+    return mmo_diag_score_p(q, corr, qlen, mat, alphabet, t, tlen, diagonal, NULL);
 }
 
 int mmo_pf_ungapped_score(const uint8_t *q, const int8_t *corr, int qlen, const int8_t *mat, int alphabet,
@@ -502,12 +577,13 @@ static size_t mmo_merge_diag_dup(mmo_cr *io, size_t n, uint32_t bins, uint32_t n
 }
 
 /* UngappedAlignment::computeScores (UngappedAlignment.cpp:315-346): only elements without a score are scored */
-static void mmo_score_unscored(mmo_cr *fd, size_t n, const mmo_pf_params *P, const uint8_t *q, const int8_t *corr, int qlen) {
+static void mmo_score_unscored(mmo_cr *fd, size_t n, const mmo_pf_params *P, const uint8_t *q, const int8_t *corr, int qlen,
+                               const int8_t *qprof) {
     for (size_t z = 0; z < n; z++) {
         if (fd[z].count != 0) continue;
         const uint8_t *t = P->tdata + P->toff[fd[z].id];
         int tlen = (int)(P->toff[fd[z].id + 1] - P->toff[fd[z].id]);
-        int sc = mmo_diag_score(q, corr, qlen, P->ungapped_mat, P->alphabet, t, tlen, (int)(short)fd[z].diagonal);
+        int sc = mmo_diag_score_p(q, corr, qlen, P->ungapped_mat, P->alphabet, t, tlen, (int)(short)fd[z].diagonal, qprof);
         fd[z].count = (uint8_t)(sc > 255 ? 255 : sc);
     }
 }
@@ -545,10 +621,35 @@ static int mmo_hit_cmp(const void *a, const void *b) { /* hit_t::compareHitsBySc
  *   arr_id/arr_diag      arrival-ordered index entries (databaseHits), capacity arr_cap
  *   dd_*                 foundDiagonals after findDuplicates (bin order) + ungapped count, capacity dd_cap */
 
+static int match_query_impl(const mmo_pf_params *P, const uint8_t *q, int qlen, const float *comp_bias, const mmo_pf_profile *prof,
+                            uint32_t identity_id, mmo_pf_hit *hits, uint64_t hit_cap, uint64_t *n_hits, mmo_pf_stats *st,
+                            mmo_pf_dump *dump);
+
 int mmo_pf_match_query(const mmo_pf_params *P, const uint8_t *q, int qlen, const float *comp_bias,
                        uint32_t identity_id, mmo_pf_hit *hits, uint64_t hit_cap, uint64_t *n_hits, mmo_pf_stats *st,
                        mmo_pf_dump *dump) {
+    return match_query_impl(P, q, qlen, comp_bias, NULL, identity_id, hits, hit_cap, n_hits, st, dump);
+}
+
+/* Profile query (DBTYPE_HMM_PROFILE): q = Sequence::numSequence (the profile's query letters: only the X test of the
+ * window reads them, QueryMatcher.cpp:264), no composition bias (:110-114), similar k-mers from the profile's own sorted
+ * rows, ungapped scores from its alignment profile. */
+int mmo_pf_match_query_profile(const mmo_pf_params *P, const uint8_t *q, int qlen, const mmo_pf_profile *prof,
+                               uint32_t identity_id, mmo_pf_hit *hits, uint64_t hit_cap, uint64_t *n_hits, mmo_pf_stats *st,
+                               mmo_pf_dump *dump) {
+    return match_query_impl(P, q, qlen, NULL, prof, identity_id, hits, hit_cap, n_hits, st, dump);
+}
+
+static int match_query_impl(const mmo_pf_params *P, const uint8_t *q, int qlen, const float *comp_bias, const mmo_pf_profile *prof,
+                            uint32_t identity_id, mmo_pf_hit *hits, uint64_t hit_cap, uint64_t *n_hits, mmo_pf_stats *st,
+                            mmo_pf_dump *dump) {
     const int k = P->gen->k, kalph = P->gen->kalph, alphabet = P->alphabet;
+    int8_t *qprof = NULL;
+    if (prof) {
+        qprof = (int8_t *)calloc((size_t)qlen * 21 + 1, 1);
+        for (int p = 0; p < qlen; p++)
+            for (int a = 0; a < 20; a++) qprof[(size_t)p * 21 + a] = prof->aln[(size_t)a * qlen + p];
+    }
     uint8_t pat[16];
     const int plen = mmo_pf_pattern(k, P->spaced, pat);
     mmo_pf_stats S;
@@ -586,11 +687,13 @@ int mmo_pf_match_query(const mmo_pf_params *P, const uint8_t *q, int qlen, const
         short bias = (short)((bc < 0.0) ? bc - 0.5 : bc + 0.5); /* :270 */
         int t0 = P->kmer_thr - bias;
         short kthr = (short)(t0 > 0 ? t0 : 0); /* :271 */
-        size_t ns = mmo_pf_kmer_list(P->gen, w, kthr, sim, simcap);
+        size_t ns = prof ? mmo_pf_kmer_list_profile(prof->score, prof->index, prof->row, k, pat, i, kalph, kthr, sim, simcap)
+                         : mmo_pf_kmer_list(P->gen, w, kthr, sim, simcap);
         if (ns > simcap) {
             simcap = ns + 16;
             sim = (uint64_t *)realloc(sim, simcap * sizeof(uint64_t));
-            ns = mmo_pf_kmer_list(P->gen, w, kthr, sim, simcap);
+            ns = prof ? mmo_pf_kmer_list_profile(prof->score, prof->index, prof->row, k, pat, i, kalph, kthr, sim, simcap)
+                      : mmo_pf_kmer_list(P->gen, w, kthr, sim, simcap);
         }
         S.kmer_list_len += ns;
         if (dump && dump->thr_out) dump->thr_out[i] = kthr;
@@ -605,7 +708,7 @@ int mmo_pf_match_query(const mmo_pf_params *P, const uint8_t *q, int qlen, const
                                                 found_cap - overflow_hits);
                 if (overflow_hits != 0) { /* second overflow onwards (:320-328) */
                     overflow_hits = mmo_merge_keep_scored(fd, hc + overflow_hits, P->bins, P->n_targets);
-                    mmo_score_unscored(fd, overflow_hits, P, q, corr, qlen);
+                    mmo_score_unscored(fd, overflow_hits, P, q, corr, qlen, qprof);
                     overflow_hits = mmo_keep_max(fd, overflow_hits, P->bins, P->n_targets);
                 } else {
                     overflow_hits = hc;
@@ -645,7 +748,7 @@ int mmo_pf_match_query(const mmo_pf_params *P, const uint8_t *q, int qlen, const
         }
         S.double_hits = rs;
         /* ---- ungappedAlignment->align (:131): count = min(255, best ungapped score), unscored elements only ---- */
-        mmo_score_unscored(fd, rs, P, q, corr, qlen);
+        mmo_score_unscored(fd, rs, P, q, corr, qlen, qprof);
         if (dump && dump->dd_id)
             for (size_t z = 0; z < rs && z < dump->dd_cap; z++) {
                 dump->dd_id[z] = fd[z].id;
@@ -684,7 +787,7 @@ int mmo_pf_match_query(const mmo_pf_params *P, const uint8_t *q, int qlen, const
         if (truncated) {
             /* rescoreHits (:563-586) */
             memset(sizes, 0, sizeof(sizes));
-            int self = mmo_diag_score(q, corr2, qlen, P->ungapped_mat, alphabet, q, qlen, 0);
+            int self = mmo_diag_score_p(q, corr2, qlen, P->ungapped_mat, alphabet, q, qlen, 0, qprof);
             int ms = self - (int)max_diag_thr;
             ms = ms > 1 ? ms : 1;
             ms = ms < USHRT_MAX ? ms : USHRT_MAX;
@@ -693,8 +796,8 @@ int mmo_pf_match_query(const mmo_pf_params *P, const uint8_t *q, int qlen, const
             for (size_t z = 0; z < above && rd[z].count >= max_diag_thr; z++) {
                 const uint8_t *t = P->tdata + P->toff[rd[z].id];
                 int tlen = (int)(P->toff[rd[z].id + 1] - P->toff[rd[z].id]);
-                unsigned ns = (unsigned)mmo_diag_score(q, corr2, qlen, P->ungapped_mat, alphabet, t, tlen,
-                                                       (int)(short)rd[z].diagonal);
+                unsigned ns = (unsigned)mmo_diag_score_p(q, corr2, qlen, P->ungapped_mat, alphabet, t, tlen,
+                                                         (int)(short)rd[z].diagonal, qprof);
                 ns -= max_diag_thr;
                 float sc = (float)(ns < (unsigned)USHRT_MAX ? ns : (unsigned)USHRT_MAX);
                 rd[z].count = (unsigned char)((sc / fms) * (float)UCHAR_MAX + 0.5);
@@ -729,8 +832,8 @@ int mmo_pf_match_query(const mmo_pf_params *P, const uint8_t *q, int qlen, const
                 } else if ((int)sc >= 255) {
                     const uint8_t *t = P->tdata + P->toff[rd[z].id];
                     int tlen = (int)(P->toff[rd[z].id + 1] - P->toff[rd[z].id]);
-                    hits[cur].score = mmo_diag_score(q, corr2, qlen, P->ungapped_mat, alphabet, t, tlen,
-                                                     (int)(short)rd[z].diagonal);
+                    hits[cur].score = mmo_diag_score_p(q, corr2, qlen, P->ungapped_mat, alphabet, t, tlen,
+                                                       (int)(short)rd[z].diagonal, qprof);
                 }
                 cur++;
             }
@@ -745,6 +848,7 @@ int mmo_pf_match_query(const mmo_pf_params *P, const uint8_t *q, int qlen, const
         *n_hits = cur;
         free(corr);
         free(fd);
+        free(qprof);
     }
     free(aid);
     free(adg);

@@ -372,6 +372,39 @@ class PfOracle:
         return out
 
 
+class PfProfile(ctypes.Structure):
+    _fields_ = [("score", c_p), ("index", c_p), ("row", ctypes.c_int), ("aln", c_p)]
+
+
+def _pf_match_profile(self, letters, pscore, pindex, aln, bins, kmer_thr, max_hits=300, min_diag_score=15, identity_id=None):
+    """Profile query: letters = Sequence::numSequence, pscore / pindex = Sequence::profile_score / profile_index
+    ([qlen][row], rows sorted descending), aln = Sequence::getAlignmentProfile() [20][qlen]."""
+    q = np.ascontiguousarray(letters, np.uint8)
+    pscore = np.ascontiguousarray(pscore, np.int16)
+    pindex = np.ascontiguousarray(pindex, np.uint32)
+    aln = np.ascontiguousarray(aln, np.int8)
+    assert pscore.shape == pindex.shape and pscore.shape[0] == len(q) and aln.shape == (20, len(q))
+    prof = PfProfile(pscore.ctypes.data, pindex.ctypes.data, pscore.shape[1], aln.ctypes.data)
+    # (the index of a profile search is built with threshold 0, the matcher still runs with the profile k-mer threshold)
+    P = PfParams(ctypes.pointer(self.gen), self.alphabet, self.spaced, int(kmer_thr), self.offsets.ctypes.data,
+                 self.ids.ctypes.data, self.pos.ctypes.data, self.tdata.ctypes.data, self.toff.ctypes.data,
+                 self.n_targets, self.ungapped_mat.ctypes.data, bins, max_hits, min_diag_score)
+    cap = int(min(max_hits, self.n_targets)) + 2
+    hits = np.zeros(cap, PF_HIT_DTYPE)
+    nh = ctypes.c_uint64(0)
+    st = PfStats()
+    ident = 0xFFFFFFFF if identity_id is None else int(identity_id)
+    rc = self.L.mmo_pf_match_query_profile(ctypes.byref(P), _ptr(q), len(q), ctypes.byref(prof), ctypes.c_uint32(ident), _ptr(hits),
+                                           ctypes.c_uint64(cap), ctypes.byref(nh), ctypes.byref(st), None)
+    stats = {f: getattr(st, f) for f, _ in PfStats._fields_}
+    stats["rc"] = rc
+    res = hits[: nh.value]
+    return dict(id=res["id"].copy(), score=res["score"].copy(), diagonal=res["diagonal"].copy(), stats=stats)
+
+
+PfOracle.match_profile = _pf_match_profile
+
+
 class RefPrefilter:
     """The real reference prefilter classes (needs /root/reference/data at run time)."""
 
@@ -455,6 +488,38 @@ class RefPrefilter:
                                     ctypes.c_uint64(cap), ctypes.byref(dbm), ctypes.byref(kpp))
         return dict(id=ids[:n].copy(), score=sc[:n].copy(), diagonal=dg[:n].copy(), db_matches=dbm.value,
                     kmers_per_pos=kpp.value)
+
+    def match_profile(self, entry, kmer_thr, max_hits=300, min_diag_score=15, max_seq_len=32000, force_bins=0, identity_id=None):
+        """entry: [qlen][25] profile-database entry.  Returns the hit list and what the reference derived from the entry
+        (sorted score rows, their letters, alignment profile, query letters)."""
+        e = np.ascontiguousarray(entry).view(np.int8).reshape(-1, 25)
+        n = e.shape[0]
+        cap = max_hits + 2
+        ids = np.zeros(cap, np.uint32)
+        sc = np.zeros(cap, np.int32)
+        dg = np.zeros(cap, np.uint16)
+        dbm = ctypes.c_uint64(0)
+        row = ctypes.c_uint32(0)
+        ps = np.zeros((n, 64), np.int16)
+        pi = np.zeros((n, 64), np.uint32)
+        aln = np.zeros((20, n), np.int8)
+        letters = np.zeros(n, np.uint8)
+        ident = 0xFFFFFFFF if identity_id is None else int(identity_id)
+        # first call only asks for the row size (the arrays above are sized for up to 64)
+        self.L.mmref_pref_match_profile.restype = ctypes.c_uint64
+        k = self.L.mmref_pref_match_profile(self.c, _ptr(e), n, int(kmer_thr), max_seq_len, ctypes.c_uint64(max_hits),
+                                            min_diag_score, int(self.spaced), int(force_bins), ctypes.c_uint32(ident),
+                                            _ptr(ids), _ptr(sc), _ptr(dg), ctypes.c_uint64(cap), ctypes.byref(dbm),
+                                            None, None, ctypes.byref(row), _ptr(aln), _ptr(letters))
+        r = int(row.value)
+        ps = np.zeros((n, r), np.int16)
+        pi = np.zeros((n, r), np.uint32)
+        self.L.mmref_pref_match_profile(self.c, _ptr(e), n, int(kmer_thr), max_seq_len, ctypes.c_uint64(max_hits),
+                                        min_diag_score, int(self.spaced), int(force_bins), ctypes.c_uint32(ident),
+                                        _ptr(ids), _ptr(sc), _ptr(dg), ctypes.c_uint64(cap), ctypes.byref(dbm),
+                                        _ptr(ps), _ptr(pi), ctypes.byref(row), _ptr(aln), _ptr(letters))
+        return dict(id=ids[:k].copy(), score=sc[:k].copy(), diagonal=dg[:k].copy(), db_matches=dbm.value,
+                    pscore=ps, pindex=pi, aln=aln, letters=letters)
 
     def match_batch(self, qres, qoff, n_threads, max_hits=300, comp_bias=True, min_diag_score=15, max_seq_len=32000,
                     want_lists=False):

@@ -227,6 +227,39 @@ uint64_t mmref_pref_match(void *h, const uint8_t *q, uint32_t qlen, uint32_t ide
     return r.second;
 }
 
+// Profile query (DBTYPE_HMM_PROFILE): `entry` = one profile-database entry (25 bytes per position, Sequence.cpp:301-325).
+// Prefiltering::runSplit maps it with a Sequence of that type built WITH a k-mer size (mapProfile then sorts the rows,
+// :343-351) and hands Sequence::profile_matrix to the matcher (Prefiltering.cpp:832-834); matchQuery as above.
+// Outputs for the caller (any may be NULL): what the reference derived from the entry - the sorted score rows and their
+// letters [qlen][row_size], the alignment profile [20][qlen], the query letters [qlen].
+uint64_t mmref_pref_match_profile(void *h, const char *entry, uint32_t qlen, int kmer_thr, unsigned max_seq_len, uint64_t max_hits,
+                                  unsigned min_diag_score, int spaced, unsigned force_bins, uint32_t identity_id,
+                                  uint32_t *ids, int32_t *scores, uint16_t *diags, uint64_t cap, uint64_t *db_matches,
+                                  int16_t *pscore, uint32_t *pindex, uint32_t *row_size, int8_t *aln, uint8_t *letters) {
+    PrefCtx *c = (PrefCtx *)h;
+    unsigned ml = std::max(max_seq_len, c->maxLen);
+    MatcherProbe matcher(c->index, c->lookup, c->kmerMat, c->ungappedMat, (short)kmer_thr, c->kmerSize, c->dbSize, ml, max_hits,
+                         true, 1.0f, true, min_diag_score, false, false);
+    if (force_bins) matcher.forceBins(force_bins);
+    Sequence seq(ml, Parameters::DBTYPE_HMM_PROFILE, c->kmerMat, c->kmerSize, spaced != 0, true, true);
+    matcher.setProfileMatrix(seq.profile_matrix);
+    seq.mapSequence(0, 0, entry, qlen);
+    if (row_size) *row_size = (uint32_t)seq.profile_row_size;
+    if (pscore) memcpy(pscore, seq.profile_score, (size_t)seq.L * seq.profile_row_size * sizeof(short));
+    if (pindex) memcpy(pindex, seq.profile_index, (size_t)seq.L * seq.profile_row_size * sizeof(unsigned int));
+    if (aln) memcpy(aln, seq.getAlignmentProfile(), Sequence::PROFILE_AA_SIZE * (size_t)seq.L);
+    if (letters) memcpy(letters, seq.numSequence, (size_t)seq.L);
+    DBLocalId ident = identity_id == UINT32_MAX ? DB_LOCAL_ID_INVALID : (DBLocalId)identity_id;
+    std::pair<hit_t *, size_t> r = matcher.matchQuery(&seq, ident, false);
+    for (size_t i = 0; i < r.second && i < cap; i++) {
+        ids[i] = (uint32_t)r.first[i].seqId;
+        scores[i] = r.first[i].prefScore;
+        diags[i] = r.first[i].diagonal;
+    }
+    if (db_matches) *db_matches = matcher.getStatistics()->dbMatches;
+    return r.second;
+}
+
 // CPU baseline: the query loop of Prefiltering::runSplit (Prefiltering.cpp:820-917) - one QueryMatcher + Sequence per
 // OpenMP thread, dynamic schedule - over nq queries; returns the wall time of the loop (matcher construction excluded,
 // as the reference's own "Time for processing" excludes setup) and the total number of hits / index matches.

@@ -227,8 +227,8 @@ def test_long_sequences_on_device(tmp_path):
 
 def _profile_pipeline(w, emulate):
     """Profile queries through `mmseqs align` (alignment half): a profile database made by the stock
-    binary (search -> result2profile) aligned against the sequences; the prefilter of profile queries stays the
-    reference's CPU code (the patched binary says so), the alignment runs on the device with the profile's score rows."""
+    binary (search -> result2profile) searched against the sequences: prefilter (similar k-mers from the profile's own
+    sorted score rows, ungapped scores from its alignment profile) and alignment (the profile's score rows) on the device."""
     (qres, qoff), (tres, toff), _, _ = wl.config3_prefilter(n_families=50, members=20, n_queries=30, seed=21)
     wl.write_fasta(os.path.join(w, "q.fasta"), qres, qoff, "q")
     wl.write_fasta(os.path.join(w, "t.fasta"), tres, toff, "t")
@@ -237,15 +237,21 @@ def _profile_pipeline(w, emulate):
     run(STOCK, ["search", "q", "t", "res0", "tmp0", "-s", "5.7", "-a", "--threads", THREADS, "-v", "1"], w)
     run(STOCK, ["result2profile", "q", "t", "res0", "prof", "--threads", THREADS, "-v", "1"], w)
     run(STOCK, ["prefilter", "prof", "t", "pref_p", "-s", "5.7", "--threads", THREADS, "-v", "1"], w)
+    # the prefilter of profile queries: k-mers from the profile's own score rows, index built with threshold 0
+    for k, extra in enumerate([[], ["--max-seqs", "9"]]):
+        run(STOCK, ["prefilter", "prof", "t", "ppref_s%d" % k, "-s", "5.7", "--threads", THREADS, "-v", "2"] + extra, w)
+        log = run(MMGPU, ["prefilter", "prof", "t", "ppref_g%d" % k, "-s", "5.7", "--threads", THREADS, "-v", "3"] + extra, w, emulate)
+        assert "MMGPU: device" in log and "using the CPU path" not in log, log[-2000:]
+        assert same(os.path.join(w, "ppref_s%d" % k), os.path.join(w, "ppref_g%d" % k)) == 30
     for i, case in enumerate([["--alignment-mode", "1"], ["-a"], ["--alignment-mode", "3", "-e", "10", "-c", "0.3"]]):
         run(STOCK, ["align", "prof", "t", "pref_p", "paln_s%d" % i] + case + ["--threads", THREADS, "-v", "2"], w)
         log = run(MMGPU, ["align", "prof", "t", "pref_p", "paln_g%d" % i] + case + ["--threads", THREADS, "-v", "3"], w, emulate)
         assert "MMGPU: device" in log and "using the CPU path" not in log, log[-2000:]
         assert same(os.path.join(w, "paln_s%d" % i), os.path.join(w, "paln_g%d" % i)) == 30, case
-    # the whole profile search through the patched binary: prefilter on the CPU path (announced), alignment on the device
+    # the whole profile search through the patched binary: both stages on the device
     run(STOCK, ["search", "prof", "t", "pres_s", "ptmp_s", "-s", "5.7", "-a", "--threads", THREADS, "-v", "1"], w)
     log = run(MMGPU, ["search", "prof", "t", "pres_g", "ptmp_g", "-s", "5.7", "-a", "--threads", THREADS, "-v", "3"], w, emulate)
-    assert "MMGPU: device" in log, log[-3000:]
+    assert log.count("MMGPU: device") >= 2 and "using the CPU path" not in log, log[-3000:]
     assert same(os.path.join(w, "pres_s"), os.path.join(w, "pres_g")) == 30
 
 

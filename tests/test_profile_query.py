@@ -107,7 +107,7 @@ def test_golden_profile_vectors_against_oracle():
 
 
 @pytest.mark.gpu
-def test_device_profile_queries_equal_reference_vectors():
+def test_device_profile_queries_equal_reference_vectors(gpu):
     import mmseqs2_amd
     from mmseqs2_amd import workloads as wl
     mat = np.load(os.path.join(HERE, "golden", "matrices.npz"))["blosum62_sw"]
@@ -116,7 +116,6 @@ def test_device_profile_queries_equal_reference_vectors():
     for _, ts, _, _ in gold:
         targets += ts
     tres, toff = wl.seqs_from_list(targets)
-    gpu = mmseqs2_amd.MMGpu(0)
     gpu.load_targets(tres, toff, 21)
     queries = []
     base = 0
@@ -145,7 +144,7 @@ def test_device_profile_queries_equal_reference_vectors():
 
 
 @pytest.mark.gpu
-def test_device_profile_queries_equal_oracle_random():
+def test_device_profile_queries_equal_oracle_random(gpu):
     """Mixed batch: profile and sequence queries side by side, single- and multi-tile, against the oracle."""
     import mmseqs2_amd
     from mmseqs2_amd import workloads as wl
@@ -159,7 +158,6 @@ def test_device_profile_queries_equal_oracle_random():
     for _, ts in cs:
         targets += ts
     tres, toff = wl.seqs_from_list(targets)
-    gpu = mmseqs2_amd.MMGpu(0)
     gpu.load_targets(tres, toff, 21)
     ids = np.arange(len(targets), dtype=np.uint32)
     queries = []
@@ -188,3 +186,135 @@ def test_device_profile_queries_equal_oracle_random():
                 assert (int(h["q_start"]), int(h["t_start"])) == (o["q_start"], o["t_start"])
                 assert int(info[p]["status"]) == 0 and strs[p] == o["bt"] and int(info[p]["ident"]) == o["ident"]
     b.free()
+
+
+PF_PROFILE_THR = 99                                      # getKmerThreshold(5.7, profile, k = 6): 134.35 - 6.15 * 5.7
+PF_PROFILE_SETTINGS = [(300, 2), (10, 32), (4, 2)]       # (max_hits, CacheFriendlyOperations bins)
+GOLD_PF = os.path.join(HERE, "golden", "profile_pf.npz")
+
+
+# ---- prefilter of profile queries (QueryMatcher::matchQuery with Sequence::profile_matrix, Prefiltering.cpp:832-834) -----------
+def pf_profile_case(seed, n_queries=6, n_targets=1500):
+    """profile entries + a target set with planted homologs of their consensus sequences"""
+    from mmseqs2_amd import workloads as wl
+    mat = np.load(os.path.join(HERE, "golden", "matrices.npz"))["blosum62_sw"]
+    rng = np.random.default_rng(seed)
+    entries = []
+    tl = [rng.choice(20, size=int(rng.integers(40, 500)), p=wl.BACKGROUND).astype(np.uint8) for _ in range(n_targets)]
+    for qi in range(n_queries):
+        L = int(rng.integers(30, 400))
+        e, cons = make_entry(rng, mat, L, sharp=1.6 if qi % 2 else 1.1)     # real profiles score on the x4 scale up to ~60
+        entries.append(e)
+        for k in rng.choice(n_targets, 25, replace=False):
+            tl[k] = mutate(rng, cons, float(rng.uniform(0.35, 0.9)))
+    tres, toff = wl.seqs_from_list(tl)
+    return entries, tres, toff
+
+
+@pytest.mark.skipif(not (ref_available() and ref_matrix_available()), reason="needs oracle/_ref and /root/reference/data")
+def test_oracle_profile_prefilter_equals_reference():
+    from oracle import pyoracle
+    from tests import pf_common as pc
+    ref = pyoracle.RefPrefilter(6)
+    o = pc.pf_oracle()
+    entries, tres, toff = pf_profile_case(31)
+    ref.build_index(tres, toff, 0)          # profile searches index every target k-mer (Prefiltering.cpp:555-557)
+    o.build_index(tres, toff, 0)
+    thr = 99                                # getKmerThreshold(5.7, profile, k = 6): 134.35 - 6.15 * 5.7
+    n_hits = n_sat = 0
+    for mh, fb in ((300, 0), (10, 32), (4, 2)):
+        for qi, e in enumerate(entries):
+            ident = None if qi % 2 else qi
+            r = ref.match_profile(e, thr, max_hits=mh, force_bins=fb, identity_id=ident)
+            assert (r["aln"] == (e[:, :20].astype(np.int32) / 4).astype(np.int8).T).all()
+            bins = fb if fb else 2          # a 1500-target database picks CacheFriendlyOperations<2> (QueryMatcher.cpp:460-488)
+            x = o.match_profile(r["letters"], r["pscore"], r["pindex"], r["aln"], bins, thr, max_hits=mh, identity_id=ident)
+            assert x["stats"]["rc"] == 0 and r["db_matches"] == x["stats"]["db_matches"], (mh, qi)
+            assert np.array_equal(r["id"], x["id"]) and np.array_equal(r["score"], x["score"]) and np.array_equal(r["diagonal"], x["diagonal"]), (mh, qi)
+            n_hits += len(r["id"])
+            n_sat += int((r["score"] > 255).sum())
+    assert n_hits > 200 and n_sat > 5
+
+
+def load_pf_golden():
+    g = np.load(GOLD_PF, allow_pickle=False)
+    qs = []
+    for qi in range(int(g["n_queries"])):
+        qs.append(dict(q=g["letters_%d" % qi], profile_score=g["pscore_%d" % qi], profile_index=g["pindex_%d" % qi],
+                       profile=g["aln_%d" % qi], comp_bias=None, identity_id=None if qi % 2 else qi))
+    return g, qs
+
+
+def test_golden_profile_prefilter_against_oracle():
+    from tests import pf_common as pc
+    g, qs = load_pf_golden()
+    o = pc.pf_oracle()
+    o.build_index(g["tres"], g["toff"], 0)
+    for si, (mh, bins) in enumerate(g["settings"].tolist()):
+        for qi, qd in enumerate(qs):
+            x = o.match_profile(qd["q"], qd["profile_score"], qd["profile_index"], qd["profile"], bins, int(g["thr"]), max_hits=mh,
+                                identity_id=qd["identity_id"])
+            exp = g["hits_%d_%d" % (si, qi)]
+            assert np.array_equal(x["id"], exp[0]) and np.array_equal(x["score"], exp[1]) and np.array_equal(x["diagonal"], exp[2]), (si, qi)
+
+
+@pytest.mark.gpu
+def test_device_profile_prefilter_equals_reference_vectors(gpu):
+    """device prefilter with profile queries = the hit lists the real reference produced (ids, scores, diagonals, order)"""
+    import mmseqs2_amd
+    from mmseqs2_amd import capi
+    from tests import pf_common as pc
+    g, qs = load_pf_golden()
+    m = np.load(os.path.join(HERE, "golden", "matrices.npz"))
+    km16 = m["vtml80_kmer"].astype(np.int16)
+    gpu.load_targets(g["tres"], g["toff"], 21)
+    s3, i3 = capi.host_score_matrix(km16, 3)
+    gpu.pf_build_index(6, 21, True, s3, i3, km16, 0, m["blosum62_ungapped"])     # threshold 0: every target k-mer is indexed
+    n_sat = 0
+    for si, (mh, bins) in enumerate(g["settings"].tolist()):
+        hits, counts, status = gpu.pf_batch(qs, int(g["thr"]), max_hits=mh, ref_bins=bins)[:3]
+        for qi in range(len(qs)):
+            exp = g["hits_%d_%d" % (si, qi)]
+            assert int(status[qi]) == 0
+            h = hits[qi][: int(counts[qi])]
+            assert np.array_equal(h["id"], exp[0]) and np.array_equal(h["score"], exp[1]) and np.array_equal(h["diagonal"], exp[2]), (si, qi)
+            n_sat += int((h["score"] > 255).sum())
+    assert n_sat > 5
+
+
+@pytest.mark.gpu
+def test_device_mixed_profile_and_sequence_prefilter_equals_oracle(gpu):
+    """profile and sequence queries in one batch, against the oracle, on a larger target set"""
+    import mmseqs2_amd
+    from mmseqs2_amd import capi, workloads as wl
+    from oracle import pyoracle
+    from tests import pf_common as pc
+    m = np.load(os.path.join(HERE, "golden", "matrices.npz"))
+    km16 = m["vtml80_kmer"].astype(np.int16)
+    g, qs = load_pf_golden()
+    rng = np.random.default_rng(9)
+    # sequence queries: consensus of the profiles' letters, mutated
+    seqq = [dict(q=mutate(rng, qd["q"], 0.9), identity_id=None) for qd in qs[:4]]
+    for d in seqq:
+        d["comp_bias"] = capi.host_comp_bias(km16, m["vtml80_pback"], d["q"])[0]
+    batch = []
+    for a, b_ in zip(qs, seqq + [None] * len(qs)):
+        batch.append(a)
+        if b_ is not None:
+            batch.append(b_)
+    gpu.load_targets(g["tres"], g["toff"], 21)
+    s3, i3 = capi.host_score_matrix(km16, 3)
+    gpu.pf_build_index(6, 21, True, s3, i3, km16, 0, m["blosum62_ungapped"])
+    o = pc.pf_oracle()
+    o.build_index(g["tres"], g["toff"], 0)
+    thr = int(g["thr"])
+    hits, counts, status = gpu.pf_batch(batch, thr, max_hits=50, ref_bins=2)[:3]
+    for qi, qd in enumerate(batch):
+        if qd.get("profile") is not None:
+            x = o.match_profile(qd["q"], qd["profile_score"], qd["profile_index"], qd["profile"], 2, thr, max_hits=50, identity_id=qd["identity_id"])
+        else:
+            o.kmer_thr = thr
+            x = o.match(qd["q"], qd["comp_bias"], 2, max_hits=50, identity_id=None)
+        h = hits[qi][: int(counts[qi])]
+        assert int(status[qi]) == 0
+        assert np.array_equal(h["id"], x["id"]) and np.array_equal(h["score"], x["score"]) and np.array_equal(h["diagonal"], x["diagonal"]), qi
