@@ -356,8 +356,10 @@ __device__ __forceinline__ void sw_body(const SwLaunch &L, const SwJob job) {
                     const unsigned diff = nm ^ vmax;
                     const unsigned mask = ((diff & 0xFFFFu) ? 0xFFFFu : 0u) | ((diff >> 16) ? 0xFFFF0000u : 0u);
                     bestcol = bfi(mask, ((unsigned)col & 0xFFFFu) * 0x10001u, bestcol);
+#ifndef MMGPU_SW_EXPERIMENT_NO_SNAPSHOT      // timing experiment only (wrong q_end): upper bound of what the snapshot costs
 #pragma unroll
                     for (int r = 0; r < R; ++r) snap[r] = bfi(mask, Hp[r], snap[r]);
+#endif
                     vmax = nm;
                 }
             }
