@@ -264,3 +264,52 @@ def test_profile_queries_host_side_emulated(tmp_path):
 @pytest.mark.gpu
 def test_profile_queries_on_device(tmp_path):
     _profile_pipeline(str(tmp_path), emulate=False)
+
+
+def _translated_pipeline(w, emulate):
+    """Translated search (the 6-frame half): nucleotide queries against protein targets run
+    extractorfs -> translatenucs -> prefilter -> align -> offsetalignment (data/workflow/translated_search.sh); the two
+    middle stages are amino-acid databases and go through the device hooks unchanged."""
+    rng = np.random.default_rng(17)
+    (qres, qoff), (tres, toff), _, _ = wl.config3_prefilter(n_families=40, members=15, n_queries=24, seed=33)
+    # back-translate the protein queries (one codon per residue, random synonymous choice), half of them reverse-complemented,
+    # embedded in random flanks
+    aa = "ACDEFGHIKLMNPQRSTVWYX"
+    codons = {"A": ["GCT", "GCC", "GCA", "GCG"], "C": ["TGT", "TGC"], "D": ["GAT", "GAC"], "E": ["GAA", "GAG"], "F": ["TTT", "TTC"],
+              "G": ["GGT", "GGC", "GGA", "GGG"], "H": ["CAT", "CAC"], "I": ["ATT", "ATC", "ATA"], "K": ["AAA", "AAG"],
+              "L": ["TTA", "TTG", "CTT", "CTC", "CTA", "CTG"], "M": ["ATG"], "N": ["AAT", "AAC"], "P": ["CCT", "CCC", "CCA", "CCG"],
+              "Q": ["CAA", "CAG"], "R": ["CGT", "CGC", "CGA", "CGG", "AGA", "AGG"], "S": ["TCT", "TCC", "TCA", "TCG", "AGT", "AGC"],
+              "T": ["ACT", "ACC", "ACA", "ACG"], "V": ["GTT", "GTC", "GTA", "GTG"], "W": ["TGG"], "Y": ["TAT", "TAC"], "X": ["NNN"]}
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A", "N": "N"}
+    order = wl.NUM2AA
+    qs = wl.split(qres, qoff)
+    with open(os.path.join(w, "qn.fasta"), "w") as f:
+        for i, q in enumerate(qs):
+            prot = "".join(order[int(c)] if order[int(c)] in codons else "X" for c in q)
+            nt = "".join(codons[c][int(rng.integers(len(codons[c])))] for c in prot)
+            nt = "".join(rng.choice(list("ACGT"), 30)) + "ATG" + nt + "TAA" + "".join(rng.choice(list("ACGT"), 30))
+            if i % 2:
+                nt = "".join(comp[c] for c in reversed(nt))
+            f.write(">qn%d\n%s\n" % (i, nt))
+    wl.write_fasta(os.path.join(w, "t.fasta"), tres, toff, "t")
+    run(STOCK, ["createdb", "qn.fasta", "qn", "-v", "1"], w)
+    run(STOCK, ["createdb", "t.fasta", "t", "-v", "1"], w)
+    run(STOCK, ["search", "qn", "t", "tres_s", "ttmp_s", "-s", "5.7", "-a", "--threads", THREADS, "-v", "1"], w)
+    log = run(MMGPU, ["search", "qn", "t", "tres_g", "ttmp_g", "-s", "5.7", "-a", "--threads", THREADS, "-v", "3"], w, emulate)
+    assert log.count("MMGPU: device") >= 2 and "using the CPU path" not in log, log[-3000:]
+    n = same(os.path.join(w, "tres_s"), os.path.join(w, "tres_g"))
+    assert n == 24
+    # the search found the planted proteins: every query has hits
+    d = dbio.read_db(os.path.join(w, "tres_g"))
+    assert sum(1 for v in d.values() if len(v) > 1) >= 20
+
+
+def test_translated_search_host_side_emulated(tmp_path):
+    if not os.path.exists(EMU):
+        pytest.skip("oracle/_build/emu/libmmgpu.so not built (make -C oracle emu)")
+    _translated_pipeline(str(tmp_path), emulate=True)
+
+
+@pytest.mark.gpu
+def test_translated_search_on_device(tmp_path):
+    _translated_pipeline(str(tmp_path), emulate=False)
