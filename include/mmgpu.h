@@ -249,7 +249,7 @@ int mmgpu_host_index_build(const uint8_t *residues, const uint64_t *seq_offsets,
 
 /* Everything QueryMatcher's constructor receives that lives in memory (Prefiltering.cpp:826-842). */
 typedef struct {
-    int kmer_size;              /* 6 or 7 */
+    int kmer_size;              /* 6 or 7 with the similar-k-mer tables; 4..15 for exact k-mer matching (score3 == NULL) */
     int alphabet;               /* subMat->alphabetSize, 21 */
     int spaced;                 /* spaced k-mer pattern of Sequence.h:24-27 */
     const int16_t *score3;      /* ScoreMatrix::score of _3merSubMatrix */
@@ -290,6 +290,10 @@ typedef struct {
     uint32_t ref_bins;       /* the CacheFriendlyOperations<N> the CPU run would use (QueryMatcher.cpp:460-488);
                                 only decides which of several equal-score hits survive the max_hits cut.
                                 0 = derive from dbSize and this host's L2 size like the reference */
+    uint32_t exact_kmer;     /* takeOnlyBestKmer (--exact-kmer-matching; always on in nucleotide searches, Search.cpp:186): every
+                                window matches its own k-mer only, kmer_thr is not read (QueryMatcher.cpp:279-282) */
+    uint32_t nucleotide;     /* the target database is nucleotide: matchQuery's isNucleotide branch (QueryMatcher.cpp:147-177) - of
+                                several saturated (>= 255) diagonals of one target the one with the best exact score is kept */
 } mmgpu_pf_params;
 
 typedef struct {
@@ -318,6 +322,10 @@ typedef struct {
 #define MMGPU_PF_OVERFLOW 1 /* the query needs more than 62 flushes of the reference's databaseHits buffer
                                (QueryMatcher.cpp:310-346; up to 62 are emulated on the device): not computed here,
                                the host must run QueryMatcher::matchQuery for this query */
+#define MMGPU_PF_SAT_TIE 3  /* nucleotide searches: two saturated diagonals of one target tie on the exact score - the reference's
+                               choice depends on the element order its (unstable) std::sort by id left (QueryMatcher.cpp:154); or the
+                               query took the databaseHits overflow path.  Not decided on the device: the host runs
+                               QueryMatcher::matchQuery for this query */
 #define MMGPU_PF_LONG_SEQ 2 /* the query, or the target of one of its double-diagonal candidates, has 32768 residues or more:
                                the reference scores those with UngappedAlignment::computeLongScore (every 65536-shift of the
                                16-bit diagonal, UngappedAlignment.cpp:295-312, and a batching quirk at :265-273) - not on the

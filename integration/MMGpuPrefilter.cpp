@@ -15,7 +15,7 @@ unsigned int MMGpuPrefilter::referenceBins(size_t dbsize) {
 MMGpuPrefilter::MMGpuPrefilter(mmgpu_ctx *gpu, BaseMatrix *kmerSubMat, BaseMatrix *ungappedSubMat, bool aaBiasCorrection,
                                float aaBiasCorrectionScale)
     : gpu(gpu), kmerSubMat(kmerSubMat), ungappedSubMat(ungappedSubMat), aaBiasCorrection(aaBiasCorrection),
-      aaBiasCorrectionScale(aaBiasCorrectionScale), dbSize(0) {}
+      aaBiasCorrectionScale(aaBiasCorrectionScale), dbSize(0), exactKmerMatching(false), nucleotideSearch(false) {}
 
 bool MMGpuPrefilter::loadIndex(IndexTable *indexTable, SequenceLookup *sequenceLookup, ScoreMatrix &threeMer, ScoreMatrix &twoMer,
                                bool spacedKmer) {
@@ -40,9 +40,10 @@ bool MMGpuPrefilter::loadIndex(IndexTable *indexTable, SequenceLookup *sequenceL
     ix.kmer_size = indexTable->getKmerSize();
     ix.alphabet = kmerSubMat->alphabetSize;
     ix.spaced = spacedKmer ? 1 : 0;
-    ix.score3 = threeMer.score;
-    ix.index3 = threeMer.index;
-    ix.row3 = threeMer.rowSize;
+    // (no similar-k-mer tables where Prefiltering built none - nucleotide searches: the library then serves exact k-mers only)
+    ix.score3 = threeMer.isValid() ? threeMer.score : NULL;
+    ix.index3 = threeMer.isValid() ? threeMer.index : NULL;
+    ix.row3 = threeMer.isValid() ? threeMer.rowSize : 0;
     ix.score2 = twoMer.isValid() ? twoMer.score : NULL;
     ix.index2 = twoMer.isValid() ? twoMer.index : NULL;
     ix.row2 = twoMer.isValid() ? twoMer.rowSize : 0;
@@ -71,7 +72,8 @@ bool MMGpuPrefilter::matchBlock(const std::vector<Query> &queries, int kmerThr, 
     for (size_t q = 0; q < nq; q++) {
         const Query &s = queries[q];
         bias[q].assign(s.L, 0.0f);
-        if (aaBiasCorrection && s.profile == NULL)      // no correction for profile queries (QueryMatcher.cpp:110-114)
+        // no correction for profile and nucleotide queries (QueryMatcher.cpp:110-114: amino-acid sequences only)
+        if (aaBiasCorrection && s.profile == NULL && !nucleotideSearch)
             SubstitutionMatrix::calcLocalAaBiasCorrection(kmerSubMat, s.numSequence, s.L, bias[q].data(), aaBiasCorrectionScale);
         dq[q].q = s.numSequence;
         dq[q].qlen = (uint32_t)s.L;
@@ -87,6 +89,8 @@ bool MMGpuPrefilter::matchBlock(const std::vector<Query> &queries, int kmerThr, 
     par.max_hits = (uint32_t)maxResListLen;
     par.min_diag_score = minDiagScoreThr;
     par.ref_bins = referenceBins(dbSize);
+    par.exact_kmer = exactKmerMatching ? 1u : 0u;
+    par.nucleotide = nucleotideSearch ? 1u : 0u;
     const uint32_t stride = (uint32_t)std::min(maxResListLen, dbSize);
     std::vector<mmgpu_pf_hit> hits(nq * (size_t)stride);
     std::vector<uint32_t> counts(nq);

@@ -49,6 +49,12 @@ public:
                     std::vector<std::vector<hit_t> > &results, std::vector<bool> &needsCpu,
                     std::vector<mmgpu_pf_qstat> *stats = NULL);
 
+    // takeOnlyBestKmer (--exact-kmer-matching; every nucleotide search) / nucleotide target database (matchQuery's isNucleotide)
+    void setMode(bool exactKmer, bool nucleotide) {
+        exactKmerMatching = exactKmer;
+        nucleotideSearch = nucleotide;
+    }
+
     // the CacheFriendlyOperations<N> QueryMatcher::initDiagonalMatcher picks on this host (QueryMatcher.cpp:460-488)
     static unsigned int referenceBins(size_t dbSize);
 
@@ -62,6 +68,7 @@ private:
     float aaBiasCorrectionScale;
     size_t dbSize;
     std::string err;
+    bool exactKmerMatching, nucleotideSearch;
 };
 
 #endif

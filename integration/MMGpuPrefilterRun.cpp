@@ -34,16 +34,20 @@
 bool MMGpuPrefilterRun::usable(Prefiltering &p) {
     if (!MMGpuRun::enabled()) return false;
     const bool profileQuery = Parameters::isEqualDbtype(p.querySeqType, Parameters::DBTYPE_HMM_PROFILE);
+    const bool nucl = Parameters::isEqualDbtype(p.querySeqType, Parameters::DBTYPE_NUCLEOTIDES) &&
+                      Parameters::isEqualDbtype(p.targetSeqType, Parameters::DBTYPE_NUCLEOTIDES);
     const bool aa = (Parameters::isEqualDbtype(p.querySeqType, Parameters::DBTYPE_AMINO_ACIDS) || profileQuery) &&
                     Parameters::isEqualDbtype(p.targetSeqType, Parameters::DBTYPE_AMINO_ACIDS);
     const char *why = NULL;
-    if (!aa) why = "profile targets / nucleotide databases";
+    if (!aa && !nucl) why = "profile targets / mixed database types";
     else if (p.indexTable == NULL || p.sequenceLookup == NULL) why = "no index table / sequence lookup in memory";
-    else if (p.takeOnlyBestKmer) why = "exact k-mer matching";
-    else if (!profileQuery && (!p._3merSubMatrix.isValid() || !p._2merSubMatrix.isValid())) why = "no similar-k-mer score matrices";
+    else if (nucl && !p.takeOnlyBestKmer) why = "nucleotide search without exact k-mer matching";
+    else if (profileQuery && p.takeOnlyBestKmer) why = "exact k-mer matching with profile queries";
+    else if (!p.takeOnlyBestKmer && !profileQuery && (!p._3merSubMatrix.isValid() || !p._2merSubMatrix.isValid())) why = "no similar-k-mer score matrices";
     else if (p.diagonalScoring == 0) why = "--diag-score 0";
     else if (p.minDiagScoreThr < 1) why = "--min-ungapped-score 0";
-    else if (p.kmerSize != 6 && p.kmerSize != 7) why = "k-mer size other than 6 / 7";
+    else if (p.takeOnlyBestKmer ? (p.kmerSize < 4 || p.kmerSize > 15) : (p.kmerSize != 6 && p.kmerSize != 7)) why = "k-mer size not covered (6 / 7; 4..15 with exact k-mer matching)";
+    else if (p.spacedKmerPattern.empty() == false) why = "user-defined spaced k-mer pattern";
     else if (p.ungappedSubMatAux != NULL) why = "auxiliary ungapped matrix";
     else if (p.taxonomyHook != NULL) why = "taxonomy filter";
     else if (p.maxResListLen > MMGPU_PF_MAX_HITS) why = "--max-seqs above the device limit";
@@ -71,6 +75,8 @@ bool MMGpuPrefilterRun::run(Prefiltering &p, DBWriter &tmpDbw, size_t dbFrom, si
         local3 = ExtendedSubstitutionMatrix::calcScoreMatrix(*p.kmerSubMat, 3);
         p.kmerSubMat->alphabetSize = alph;
     }
+    const bool nuclSearch = Parameters::isEqualDbtype(p.targetSeqType, Parameters::DBTYPE_NUCLEOTIDES);
+    device.setMode(p.takeOnlyBestKmer, nuclSearch);
     ScoreMatrix &three = local3.isValid() ? local3 : p._3merSubMatrix;
     ScoreMatrix &two = local2.isValid() ? local2 : p._2merSubMatrix;
     if (!device.loadIndex(p.indexTable, p.sequenceLookup, three, two, p.spacedKmer)) {
@@ -177,13 +183,13 @@ bool MMGpuPrefilterRun::run(Prefiltering &p, DBWriter &tmpDbw, size_t dbFrom, si
                         cpuMatchers[thread_idx] = new QueryMatcher(p.indexTable, p.sequenceLookup, p.kmerSubMat, p.ungappedSubMat, p.kmerThr,
                                                                    p.kmerSize, dbSize, std::max(p.tdbr->getMaxSeqLen(), p.qdbr->getMaxSeqLen()),
                                                                    p.maxResListLen, p.aaBiasCorrection, p.aaBiasCorrectionScale, p.diagonalScoring,
-                                                                   p.minDiagScoreThr, p.takeOnlyBestKmer, false, p.ungappedSubMatAux, p.targetSeqType);
+                                                                   p.minDiagScoreThr, p.takeOnlyBestKmer, nuclSearch, p.ungappedSubMatAux, p.targetSeqType);
                         if (seq.profile_matrix != NULL) cpuMatchers[thread_idx]->setProfileMatrix(seq.profile_matrix);     // :832-836
                         else cpuMatchers[thread_idx]->setSubstitutionMatrix(&p._3merSubMatrix, &p._2merSubMatrix);
                     }
                     seq.mapSequence(id, qKey, p.qdbr->getData(id, thread_idx), p.qdbr->getSeqLen(id));
                     const DBLocalId identityId = block[b].identityId == UINT_MAX ? DB_LOCAL_ID_INVALID : (DBLocalId)block[b].identityId;
-                    std::pair<hit_t *, size_t> r = cpuMatchers[thread_idx]->matchQuery(&seq, identityId, false);
+                    std::pair<hit_t *, size_t> r = cpuMatchers[thread_idx]->matchQuery(&seq, identityId, nuclSearch);
                     hits = r.first;
                     resultSize = r.second;
                     cpuStats = *cpuMatchers[thread_idx]->getStatistics();

@@ -84,7 +84,7 @@ class PfIndexDesc(ctypes.Structure):
 
 class PfParams(ctypes.Structure):
     _fields_ = [("kmer_thr", ctypes.c_int), ("max_hits", ctypes.c_uint32), ("min_diag_score", ctypes.c_uint32),
-                ("ref_bins", ctypes.c_uint32)]
+                ("ref_bins", ctypes.c_uint32), ("exact_kmer", ctypes.c_uint32), ("nucleotide", ctypes.c_uint32)]
 
 
 class PfQuery(ctypes.Structure):
@@ -500,8 +500,8 @@ class MMGpu:
     # ---- prefilter ----
     def pf_load_index(self, k, alphabet, spaced, score3, index3, offsets, entry_ids, entry_pos, ungapped_mat,
                       score2=None, index2=None):
-        score3 = np.ascontiguousarray(score3, np.int16)
-        index3 = np.ascontiguousarray(index3, np.uint32)
+        score3 = None if score3 is None else np.ascontiguousarray(score3, np.int16)     # None: exact k-mer matching only
+        index3 = None if index3 is None else np.ascontiguousarray(index3, np.uint32)
         offsets = np.ascontiguousarray(offsets, np.uint64)
         entry_ids = np.ascontiguousarray(entry_ids, np.uint32)
         entry_pos = np.ascontiguousarray(entry_pos, np.uint16)
@@ -509,22 +509,23 @@ class MMGpu:
         if score2 is not None:
             score2 = np.ascontiguousarray(score2, np.int16)
             index2 = np.ascontiguousarray(index2, np.uint32)
-        d = PfIndexDesc(k, alphabet, int(spaced), _ptr(score3), _ptr(index3), score3.shape[1], _ptr(score2), _ptr(index2),
+        d = PfIndexDesc(k, alphabet, int(spaced), _ptr(score3), _ptr(index3), 0 if score3 is None else score3.shape[1], _ptr(score2), _ptr(index2),
                         0 if score2 is None else score2.shape[1], _ptr(offsets),
                         _ptr(entry_ids), _ptr(entry_pos), None, len(entry_ids), _ptr(ungapped_mat))
         self._check(self.L.mmgpu_pf_load_index(self.ctx, ctypes.byref(d)))
 
     def pf_build_index(self, k, alphabet, spaced, score3, index3, kmer_submat16, kmer_thr, ungapped_mat, score2=None,
                        index2=None):
-        """Index construction on the device over the loaded targets (masking off)."""
-        score3 = np.ascontiguousarray(score3, np.int16)
-        index3 = np.ascontiguousarray(index3, np.uint32)
+        """Index construction on the device over the loaded targets (masking off).  score3 / index3 None: no similar-k-mer
+        tables (exact k-mer matching only; k in 4..15, e.g. nucleotide databases)."""
+        score3 = None if score3 is None else np.ascontiguousarray(score3, np.int16)
+        index3 = None if index3 is None else np.ascontiguousarray(index3, np.uint32)
         ungapped_mat = np.ascontiguousarray(ungapped_mat, np.int8)
         km = np.ascontiguousarray(kmer_submat16, np.int16)
         if score2 is not None:
             score2 = np.ascontiguousarray(score2, np.int16)
             index2 = np.ascontiguousarray(index2, np.uint32)
-        d = PfIndexDesc(k, alphabet, int(spaced), _ptr(score3), _ptr(index3), score3.shape[1], _ptr(score2), _ptr(index2),
+        d = PfIndexDesc(k, alphabet, int(spaced), _ptr(score3), _ptr(index3), 0 if score3 is None else score3.shape[1], _ptr(score2), _ptr(index2),
                         0 if score2 is None else score2.shape[1], None, None, None, None, 0, _ptr(ungapped_mat))
         self._check(self.L.mmgpu_pf_build_index(self.ctx, ctypes.byref(d), _ptr(km), int(kmer_thr)))
 
@@ -560,16 +561,16 @@ class MMGpu:
             arr[i] = PfQuery(_ptr(q), len(q), _ptr(cb), 0xFFFFFFFF if ident is None else int(ident), _ptr(ps), _ptr(pi), row, _ptr(pa))
         return arr, keep
 
-    def pf_prepare(self, queries, kmer_thr, max_hits=300, min_diag_score=15, ref_bins=0):
+    def pf_prepare(self, queries, kmer_thr, max_hits=300, min_diag_score=15, ref_bins=0, exact=False, nucleotide=False):
         arr, keep = self._pf_marshal(queries)
-        par = PfParams(int(kmer_thr), int(max_hits), int(min_diag_score), int(ref_bins))
+        par = PfParams(int(kmer_thr), int(max_hits), int(min_diag_score), int(ref_bins), int(exact), int(nucleotide))
         h = c_p()
         self._check(self.L.mmgpu_pf_prepare(self.ctx, ctypes.byref(par), ctypes.cast(arr, c_p), len(queries), ctypes.byref(h)))
         db = getattr(self, "global_db_size", None) or self.n_targets
         return PfBatch(self, h, keep, len(queries), min(int(max_hits), db))
 
-    def pf_batch(self, queries, kmer_thr, max_hits=300, min_diag_score=15, ref_bins=0):
-        b = self.pf_prepare(queries, kmer_thr, max_hits, min_diag_score, ref_bins)
+    def pf_batch(self, queries, kmer_thr, max_hits=300, min_diag_score=15, ref_bins=0, exact=False, nucleotide=False):
+        b = self.pf_prepare(queries, kmer_thr, max_hits, min_diag_score, ref_bins, exact, nucleotide)
         b.run()
         out = b.fetch()
         b.free()

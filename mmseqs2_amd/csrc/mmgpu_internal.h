@@ -144,7 +144,7 @@ struct PfKmerArgs {
     const uint8_t *q_res;      // batch residues, concatenated
     const int16_t *q_thr;      // per position: adjusted k-mer threshold, -1 = no window / X in window
     uint32_t n_pos;
-    uint8_t pat[8];            // Sequence::aaPosInSpacedPattern
+    uint8_t pat[16];           // Sequence::aaPosInSpacedPattern
     uint32_t kalph, n3;
     const int16_t *s3;         // [n3][n3] ScoreMatrix::score of the 3-mer matrix (no padding columns)
     const uint32_t *i3;        // [n3][n3] ScoreMatrix::index
@@ -164,6 +164,7 @@ struct PfKmerArgs {
     const uint8_t *q_kind;
     const int16_t *prof_score;    // [n_pos][20]
     const uint8_t *prof_letter;   // [n_pos][20]
+    int exact;                 // takeOnlyBestKmer: every window matches its own k-mer only (QueryMatcher.cpp:279-282)
     // count pass
     uint32_t *nsim;
     // emit pass
@@ -206,6 +207,10 @@ struct PfDedupArgs {
     // [n_pos][PF_PROW] int8, letter-indexed, filled for the positions of profile queries; q_isprof[q] picks the path
     const int8_t *q_rows;
     const uint8_t *q_isprof;
+    // nucleotide searches (QueryMatcher.cpp:147-177): every bucket goes through pf_keepmax_nucl_kernel
+    int nucl;
+    uint32_t sort_cap;                // foundDiagonalsSize / 2: the branch is skipped for larger candidate sets (:146)
+    uint32_t *q_ncand;                // [nq] double-diagonal candidates of the query (nucleotide mode only)
     const uint8_t *t_res;
     const uint32_t *t_off4, *t_len;
     uint32_t min_diag_score;
@@ -232,6 +237,7 @@ struct PfSelectArgs {
     const uint32_t *global_ids;       // [n_targets] local -> global id
     const uint32_t *q_nseg;           // overflow-path queries (their order key is not shard independent), may be null
     const uint32_t *q_flags;          // long-sequence queries (scores not computed on the device), may be null
+    int nucl;                         // nucleotide searches: saturated elements are ordered by target id (QueryMatcher.cpp:154)
     const uint32_t *q_off, *peb, *list_base;
     const PfList *lists;
 };
@@ -328,7 +334,7 @@ struct IxArgs {
     uint32_t n_targets;
     int k, pattern_len, kmer_thr;
     uint32_t kalph;
-    uint8_t pat[8];
+    uint8_t pat[16];
     int8_t self_score[32];      // (char) subMatrix[a][a], IndexBuilder.cpp:11-22
     uint32_t *counts;           // [table]: count pass = list lengths, fill pass = write cursors
     const uint32_t *offsets;    // [table + 1] (fill pass)

@@ -15,8 +15,9 @@ namespace mmgpu {
 
 struct PfIndex {
     int k = 0, alphabet = 0, kalph = 0, spaced = 0;
-    uint8_t pat[8] = {0};
+    uint8_t pat[16] = {0};
     int pattern_len = 0;
+    bool has_tables = false;   // similar-k-mer score tables present (false: exact k-mer matching only)
     uint32_t n3 = 0;
     uint64_t table = 0, n_entries = 0;
     DevBuf d_s3, d_i3, d_cum3, d_s2, d_i2, d_cum2, d_offsets, d_entries, d_mat;
@@ -38,19 +39,20 @@ void pf_index_free(mmgpu_ctx *c) {
 
 }  // namespace mmgpu
 
-static const uint8_t SPACED6[] = {1, 1, 0, 1, 0, 1, 0, 0, 1, 1};      // Sequence.h:25
-static const uint8_t SPACED7[] = {1, 1, 0, 1, 0, 1, 1, 0, 0, 1, 1};   // Sequence.h:27
+// spaced_seed_<k> of Sequence.h:20-50 as bit masks (bit i = pattern position i) and their lengths
+static const uint32_t SPACED_BITS[16] = {0, 0, 0, 0, 0x17u, 0xA13u, 0x32Bu, 0x66Bu, 0xCEBu, 0x366Bu, 0x6D6Bu, 0x1B66Bu, 0x6B66Bu, 0xD6CEBu,
+                                         0x1B6CEBu, 0x6D1BD7u};
+static const uint8_t SPACED_LEN[16] = {0, 0, 0, 0, 5, 12, 10, 11, 12, 14, 15, 17, 19, 20, 21, 23};
 
-static int window_pattern(int k, int spaced, uint8_t *pat) {
+static int window_pattern(int k, int spaced, uint8_t *pat) {     // k in [4, 15]
     if (!spaced) {
         for (int i = 0; i < k; i++) pat[i] = (uint8_t)i;
         return k;
     }
-    const uint8_t *p = k == 6 ? SPACED6 : SPACED7;
-    const int n = k == 6 ? 10 : 11;
+    const int n = SPACED_LEN[k];
     int c = 0;
     for (int i = 0; i < n; i++)
-        if (p[i]) pat[c++] = (uint8_t)i;
+        if ((SPACED_BITS[k] >> i) & 1u) pat[c++] = (uint8_t)i;
     return n;
 }
 
@@ -140,7 +142,7 @@ extern "C" int mmgpu_host_score_matrix(const int16_t *submat, int alphabet, int 
 namespace {
 struct KmerWindows {
     int k, ka, alphabet, plen, thr;
-    uint8_t pat[8];
+    uint8_t pat[16];
     int8_t self[32];   // (char) subMatrix[a][a], IndexBuilder.cpp:11-22
     // unique k-mers of one target with their first position, sorted by k-mer; key = kmer << 16 | pos
     void extract(const uint8_t *s, uint64_t len, std::vector<uint64_t> &buf) const {
@@ -240,10 +242,18 @@ extern "C" int mmgpu_host_index_build(const uint8_t *residues, const uint64_t *s
 static int pf_setup(mmgpu_ctx *c, const mmgpu_pf_index *ix, bool from_host, PfIndex **out) {
     if (!c || !ix) return fail(MMGPU_ERR_ARG, "mmgpu_pf_load_index: NULL argument");
     if (!c->db.res) return fail(MMGPU_ERR_STATE, "mmgpu_pf_load_index: load the targets (SequenceLookup) first");
-    if (ix->kmer_size != 6 && ix->kmer_size != 7) return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_pf_load_index: k must be 6 or 7");
-    if (ix->kmer_size == 7 && (!ix->score2 || !ix->index2)) return fail(MMGPU_ERR_ARG, "mmgpu_pf_load_index: k = 7 needs the 2-mer ScoreMatrix");
+    const bool tables = ix->score3 != nullptr && ix->index3 != nullptr;    // without them: exact k-mer matching only
+    if (tables && ix->kmer_size != 6 && ix->kmer_size != 7) return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_pf_load_index: similar k-mers need k = 6 or 7");
+    if (ix->kmer_size < 4 || ix->kmer_size > 15) return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_pf_load_index: k must be in [4, 15]");
+    if (tables && ix->kmer_size == 7 && (!ix->score2 || !ix->index2)) return fail(MMGPU_ERR_ARG, "mmgpu_pf_load_index: k = 7 needs the 2-mer ScoreMatrix");
     if (ix->alphabet != c->db.alphabet) return fail(MMGPU_ERR_ARG, "mmgpu_pf_load_index: alphabet differs from the loaded targets");
-    if (!ix->score3 || !ix->index3 || !ix->ungapped_mat) return fail(MMGPU_ERR_ARG, "mmgpu_pf_load_index: NULL table");
+    if (ix->alphabet < 2 || ix->alphabet > 32) return fail(MMGPU_ERR_ARG, "mmgpu_pf_load_index: alphabet must be in [2, 32]");
+    if (!ix->ungapped_mat) return fail(MMGPU_ERR_ARG, "mmgpu_pf_load_index: NULL table");
+    {
+        double tb = 1;
+        for (int i = 0; i < ix->kmer_size; i++) tb *= (double)(ix->alphabet - 1);
+        if (tb > 2147483648.0) return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_pf_load_index: more than 2^31 k-mers");
+    }
     if (from_host) {
         if (!ix->offsets) return fail(MMGPU_ERR_ARG, "mmgpu_pf_load_index: NULL table");
         if (!ix->entries6 && !(ix->entry_ids && ix->entry_pos) && ix->n_entries) return fail(MMGPU_ERR_ARG, "mmgpu_pf_load_index: no index entries");
@@ -261,13 +271,16 @@ static int pf_setup(mmgpu_ctx *c, const mmgpu_pf_index *ix, bool from_host, PfIn
     P->table = 1;
     for (int i = 0; i < P->k; i++) P->table *= (uint64_t)P->kalph;
     P->n_entries = from_host ? ix->n_entries : 0;
+    P->has_tables = tables;
     const size_t n3 = P->n3;
-    if (ix->row3 < n3) { delete P; return fail(MMGPU_ERR_ARG, "mmgpu_pf_load_index: row3 smaller than kalph^3"); }
+    if (tables && ix->row3 < n3) { delete P; return fail(MMGPU_ERR_ARG, "mmgpu_pf_load_index: row3 smaller than kalph^3"); }
 #define P_TRY(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { delete P; return fail(MMGPU_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__)); } } while (0)
-    P_TRY(P->d_s3.alloc(n3 * n3 * sizeof(int16_t)));
-    P_TRY(P->d_i3.alloc(n3 * n3 * sizeof(uint32_t)));
-    P_TRY(hipMemcpy2D(P->d_s3.p, n3 * sizeof(int16_t), ix->score3, ix->row3 * sizeof(int16_t), n3 * sizeof(int16_t), n3, hipMemcpyHostToDevice));
-    P_TRY(hipMemcpy2D(P->d_i3.p, n3 * sizeof(uint32_t), ix->index3, ix->row3 * sizeof(uint32_t), n3 * sizeof(uint32_t), n3, hipMemcpyHostToDevice));
+    if (tables) {
+        P_TRY(P->d_s3.alloc(n3 * n3 * sizeof(int16_t)));
+        P_TRY(P->d_i3.alloc(n3 * n3 * sizeof(uint32_t)));
+        P_TRY(hipMemcpy2D(P->d_s3.p, n3 * sizeof(int16_t), ix->score3, ix->row3 * sizeof(int16_t), n3 * sizeof(int16_t), n3, hipMemcpyHostToDevice));
+        P_TRY(hipMemcpy2D(P->d_i3.p, n3 * sizeof(uint32_t), ix->index3, ix->row3 * sizeof(uint32_t), n3 * sizeof(uint32_t), n3, hipMemcpyHostToDevice));
+    }
     // cumulative counts per row: #entries with score >= c is one lookup instead of a binary search in the row
     auto build_cum = [&](const int16_t *score, size_t row_stride, size_t n, DevBuf &dst, uint32_t *w_out, int32_t *min_out) -> int {
         int lo = 32767, hi = -32768;
@@ -293,11 +306,11 @@ static int pf_setup(mmgpu_ctx *c, const mmgpu_pf_index *ix, bool from_host, PfIn
         *min_out = lo;
         return 0;
     };
-    {
+    if (tables) {
         const int rc = build_cum(ix->score3, ix->row3, n3, P->d_cum3, &P->cum_w, &P->score_min);
         if (rc) { delete P; return fail(rc == 1 ? MMGPU_ERR_ARG : MMGPU_ERR_HIP, rc == 1 ? "mmgpu_pf_load_index: score3 rows are not sorted by descending score" : "mmgpu_pf_load_index: upload failed"); }
     }
-    if (P->k == 7) {
+    if (tables && P->k == 7) {
         const size_t n2 = (size_t)P->kalph * P->kalph;
         if (ix->row2 < n2) { delete P; return fail(MMGPU_ERR_ARG, "mmgpu_pf_load_index: row2 smaller than kalph^2"); }
         P_TRY(P->d_s2.alloc(n2 * n2 * sizeof(int16_t)));
@@ -467,6 +480,7 @@ struct mmgpu_pf_batch_t {
     // device: inputs
     DevBuf d_qres, d_qthr, d_qcorr, d_qoff, d_qident, d_qself;
     DevBuf d_qkind, d_qisprof, d_pscore, d_pletter, d_qrows;   // profile queries only
+    DevBuf d_qncand;                                           // nucleotide searches only
     bool any_profile = false;
     // device: working set (grow-only, reused across runs)
     DevBuf d_nsim, d_qtot, d_qbase, d_list_base, d_pos_entries, d_peb, d_qentries;
@@ -515,6 +529,8 @@ extern "C" int mmgpu_pf_prepare(mmgpu_ctx *c, const mmgpu_pf_params *par, const 
     if (par->min_diag_score < 1) return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_pf_prepare: min_diag_score must be >= 1");
     if (par->max_hits < 1) return fail(MMGPU_ERR_ARG, "mmgpu_pf_prepare: max_hits must be >= 1");
     const PfIndex &P = *c->pf;
+    if (!par->exact_kmer && !P.has_tables) return fail(MMGPU_ERR_STATE, "mmgpu_pf_prepare: the index was loaded without similar-k-mer tables (exact k-mer matching only)");
+    if (par->nucleotide && c->shard.on) return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_pf_prepare: nucleotide searches on a sharded database are not implemented");
     // a shard of a multi-GPU run answers for the whole database: list length and cache bins as in the unsplit run
     const bool exchange = c->shard.on;
     const uint64_t db_size = exchange ? c->shard.global_n : c->db.n;
@@ -670,6 +686,7 @@ extern "C" int mmgpu_pf_prepare(mmgpu_ctx *c, const mmgpu_pf_params *par, const 
     B_TRY(b->d_hit_count.alloc(nqq * 4));
     B_TRY(b->d_diag_thr.alloc(nqq * 4));
     B_TRY(b->d_qflags.alloc(nqq * 4));
+    if (par->nucleotide) B_TRY(b->d_qncand.alloc(nqq * 4));
     for (auto &e : b->ev) B_TRY(hipEventCreate(&e));
     B_TRY(hipStreamSynchronize(s));
 #undef B_TRY
@@ -699,6 +716,7 @@ extern "C" int mmgpu_pf_run(mmgpu_ctx *c, mmgpu_pf_batch_t *b) {
     K.q_res = b->d_qres.as<uint8_t>();
     K.q_thr = b->d_qthr.as<int16_t>();
     K.n_pos = b->n_pos;
+    K.exact = b->par.exact_kmer ? 1 : 0;
     if (b->any_profile) {
         K.q_kind = b->d_qkind.as<uint8_t>();
         K.prof_score = b->d_pscore.as<int16_t>();
@@ -836,6 +854,7 @@ extern "C" int mmgpu_pf_run(mmgpu_ctx *c, mmgpu_pf_batch_t *b) {
     HIP_TRY(hipMemsetAsync(b->d_surv_count.p, 0, (size_t)nq * 4, s));
     HIP_TRY(hipMemsetAsync(b->d_cells.p, 0, (size_t)nq * 8, s));
     HIP_TRY(hipMemsetAsync(b->d_qflags.p, 0, (size_t)nq * 4, s));
+    if (b->par.nucleotide) HIP_TRY(hipMemsetAsync(b->d_qncand.p, 0, (size_t)nq * 4, s));
 
     // ---- stage 1: gather + stable split ----
     PfSplitArgs SA;
@@ -878,6 +897,9 @@ extern "C" int mmgpu_pf_run(mmgpu_ctx *c, mmgpu_pf_batch_t *b) {
     D.q_off = b->d_qoff.as<uint32_t>();
     D.q_res = b->d_qres.as<uint8_t>();
     D.q_corr = b->d_qcorr.as<int8_t>();
+    D.nucl = b->par.nucleotide ? 1 : 0;
+    D.sort_cap = (uint32_t)(std::max<uint64_t>(1000000, c->db.n) / 2);     // foundDiagonalsSize / 2 (QueryMatcher.cpp:44,146)
+    D.q_ncand = b->par.nucleotide ? b->d_qncand.as<uint32_t>() : nullptr;
     D.q_rows = b->any_profile ? b->d_qrows.as<int8_t>() : nullptr;
     D.q_isprof = b->any_profile ? b->d_qisprof.as<uint8_t>() : nullptr;
     D.mat = P.d_mat.as<int8_t>();
@@ -943,6 +965,7 @@ extern "C" int mmgpu_pf_run(mmgpu_ctx *c, mmgpu_pf_batch_t *b) {
     S.global_ids = nullptr;
     S.q_nseg = nullptr;
     S.q_flags = b->d_qflags.as<uint32_t>();
+    S.nucl = b->par.nucleotide ? 1 : 0;
     S.q_off = S.peb = S.list_base = nullptr;
     S.lists = nullptr;
     if (b->exchange) {
@@ -981,7 +1004,8 @@ extern "C" int mmgpu_pf_fetch(mmgpu_ctx *c, mmgpu_pf_batch_t *b, mmgpu_pf_hit *h
     HIP_TRY(hipMemcpyAsync(surv.data(), b->d_surv_count.p, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     for (uint32_t i = 0; i < nq; i++) {
-        if (flags[i] && b->status[i] == MMGPU_PF_OK) b->status[i] = MMGPU_PF_LONG_SEQ;
+        if ((flags[i] & 1u) && b->status[i] == MMGPU_PF_OK) b->status[i] = MMGPU_PF_LONG_SEQ;
+        if ((flags[i] & 2u) && b->status[i] == MMGPU_PF_OK) b->status[i] = MMGPU_PF_SAT_TIE;
         if (b->status[i] != MMGPU_PF_OK) counts[i] = 0;
         if (status) status[i] = b->status[i];
         if (stats) {

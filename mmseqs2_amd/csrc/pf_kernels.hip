@@ -293,6 +293,37 @@ __global__ __launch_bounds__(256) void pf_kmers7_kernel(PfKmerArgs A) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// takeOnlyBestKmer (--exact-kmer-matching; every nucleotide search, Search.cpp:186): the window matches its own k-mer only
+// (QueryMatcher.cpp:279-282) - one index list per window, no similar k-mers, no threshold.  One thread per position.
+template <bool EMIT>
+__global__ __launch_bounds__(256) void pf_kmers_exact_kernel(PfKmerArgs A) {
+    const uint32_t gp = blockIdx.x * 256u + threadIdx.x;
+    if (gp >= A.n_pos) return;
+    if (A.q_thr[gp] < 0) {     // no window here, or the window contains X / N
+        if (EMIT) A.pos_entries[gp] = 0; else A.nsim[gp] = 0;
+        return;
+    }
+    if (!EMIT) {
+        A.nsim[gp] = 1;
+        return;
+    }
+    const uint8_t *q = A.q_res + gp;
+    uint32_t idx = 0, pw = 1;
+    for (int i = 0; i < A.k; i++) {
+        idx += (uint32_t)q[A.pat[i]] * pw;
+        pw *= A.kalph;
+    }
+    const uint32_t o0 = A.offsets[idx], o1 = A.offsets[idx + 1];
+    PfList rec;
+    rec.start = o0;
+    rec.len = o1 - o0;
+    rec.lprefix = 0;
+    rec.pos = gp;
+    A.lists[A.list_base[gp]] = rec;
+    A.pos_entries[gp] = o1 - o0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Profile queries: KmerGenerator::setDivideStrategy(ScoreMatrix **one) (KmerGenerator.cpp:32-41) - k steps of ONE residue
 // each; step i multiplies the running list with the 20 score-sorted entries of query position gp + pattern[i]
 // (Sequence::nextProfileKmer, Sequence.cpp:354-365), cutoff thr - score - (sum of the best scores of the later steps),
@@ -795,7 +826,7 @@ __device__ __forceinline__ uint64_t score_chunk(const PfDedupArgs &A, const int8
     }
     c.score = (uint32_t)my_score;
     if (has) cand_slot(A, bucket, cb0 + (uint32_t)lane)->score = c.score;
-    if (ncand <= 64) {
+    if (ncand <= 64 && !A.nucl) {
         // keepMaxElement for the whole bucket right here (the common case; larger buckets go to pf_keepmax_kernel):
         // per target the first candidate holding the target's maximum count
         const uint32_t cnt = min(255u, c.score);
@@ -1027,6 +1058,7 @@ __global__ __launch_bounds__(256) void pf_keepmax_kernel(PfDedupArgs A) {
     if (bucket >= (uint64_t)A.n_queries * B) return;
     const uint32_t ncand = A.cand_count[bucket];
     const uint32_t q = (uint32_t)(bucket / B);
+    if (A.nucl) return;                                      // pf_keepmax_nucl_kernel
     if (ncand <= 64 || (A.q_nseg && A.q_nseg[q])) return;   // scored and reduced already / overflow path
     uint32_t *S = s_tab[wave];
     int bshift = 0;
@@ -1052,6 +1084,81 @@ __global__ __launch_bounds__(256) void pf_keepmax_kernel(PfDedupArgs A) {
             const uint32_t cnt = min(255u, c.score);
             const uint32_t k2 = (cnt << 24) | (0xFFFFFFu - min(ci, 0xFFFFFEu));
             win = S[c.id >> bshift] == k2 && cnt >= A.min_diag_score;
+        }
+        const uint64_t wb = __ballot(win);
+        if (wb) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&A.surv_count[q], (uint32_t)__popcll(wb));
+            base = __shfl(base, 0);
+            if (win) surv[base + (uint32_t)__popcll(wb & lanes_below(lane))] = c;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Nucleotide searches (QueryMatcher.cpp:147-177): before keepMaxScoreElementOnly the reference brings the SATURATED elements
+// (count == 255) of every target together and writes the diagonal with the best exact score
+// (scoreSingleSequenceCombined) into the first of them; the others lose the keepMax that follows.  Per target: a saturated
+// element with the best exact score wins (two different diagonals with the same best score: the reference's choice
+// depends on an unstable sort - the query is flagged for the host); without saturated elements the ordinary rule (highest
+// count, earliest arrival).  One wavefront per (query, bin), every bucket (the replay kernel leaves keepMax alone in this
+// mode); two LDS tables: best key per target, and the first candidate holding it.
+__global__ __launch_bounds__(128) void pf_keepmax_nucl_kernel(PfDedupArgs A) {
+    __shared__ uint32_t s_key[2][PF_IDS_PER_BIN];
+    __shared__ uint32_t s_first[2][PF_IDS_PER_BIN];
+    const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
+    const uint32_t B = A.bins;
+    const uint64_t bucket = (uint64_t)blockIdx.x * 2u + (uint32_t)wave;
+    if (bucket >= (uint64_t)A.n_queries * B) return;
+    const uint32_t ncand = A.cand_count[bucket];
+    const uint32_t q = (uint32_t)(bucket / B);
+    if (ncand == 0) return;
+    if (lane == 0) {
+        const uint32_t before = atomicAdd(&A.q_ncand[q], ncand);
+        if (before + ncand >= A.sort_cap && A.q_flags) atomicOr(&A.q_flags[q], 2u);    // canBeSorted is false (:146): not restated
+    }
+    if (A.q_nseg && A.q_nseg[q]) {      // overflow path of a nucleotide query: left to the host
+        if (lane == 0 && A.q_flags) atomicOr(&A.q_flags[q], 2u);
+        return;
+    }
+    uint32_t *K = s_key[wave], *F = s_first[wave];
+    int bshift = 0;
+    while ((1u << bshift) < B) bshift++;
+    for (int k = lane; k < PF_IDS_PER_BIN; k += 64) { K[k] = 0; F[k] = 0xFFFFFFFFu; }
+    auto key_of = [&](const PfCand &c, uint32_t ci) -> uint32_t {
+        const uint32_t cnt = min(255u, c.score);
+        return cnt >= 255u ? (0xFF000000u | min(c.score, 0xFFFFFFu)) : ((cnt << 24) | (0xFFFFFFu - min(ci, 0xFFFFFEu)));
+    };
+    for (uint32_t c0 = 0; c0 < ncand; c0 += 64) {
+        const uint32_t ci = c0 + (uint32_t)lane;
+        if (ci < ncand) {
+            const PfCand c = *cand_slot(A, bucket, ci);
+            atomicMax(&K[c.id >> bshift], key_of(c, ci));
+        }
+    }
+    for (uint32_t c0 = 0; c0 < ncand; c0 += 64) {
+        const uint32_t ci = c0 + (uint32_t)lane;
+        if (ci < ncand) {
+            const PfCand c = *cand_slot(A, bucket, ci);
+            if (K[c.id >> bshift] == key_of(c, ci)) atomicMin(&F[c.id >> bshift], ci);
+        }
+    }
+    PfCand *surv = A.surv + A.cand_base[(uint64_t)q * B];
+    for (uint32_t c0 = 0; c0 < ncand; c0 += 64) {
+        const uint32_t ci = c0 + (uint32_t)lane;
+        bool win = false;
+        PfCand c;
+        c.id = 0; c.arr = 0; c.score = 0; c.diag = 0; c.pad = 0;
+        if (ci < ncand) {
+            c = *cand_slot(A, bucket, ci);
+            const uint32_t t = c.id >> bshift;
+            const uint32_t cnt = min(255u, c.score);
+            const bool top = K[t] == key_of(c, ci);
+            win = top && F[t] == ci && cnt >= A.min_diag_score;
+            if (top && F[t] != ci && cnt >= 255u) {      // another saturated element with the same exact score
+                const PfCand w = *cand_slot(A, bucket, F[t]);
+                if (w.diag != c.diag && A.q_flags) atomicOr(&A.q_flags[q], 2u);
+            }
         }
         const uint64_t wb = __ballot(win);
         if (wb) {
@@ -1441,7 +1548,8 @@ __global__ __launch_bounds__(256) void pf_select_kernel(PfSelectArgs A) {
             kc = cnt;
         }
         // order inside the CPU's array: arrival index (ordinary queries) or the 48-bit merge key of the overflow path
-        const uint64_t ord = ((uint64_t)c.pad << 32) | (uint64_t)c.arr;
+        // (nucleotide searches: the saturated elements were sorted by target id before keepMax, QueryMatcher.cpp:154)
+        const uint64_t ord = (A.nucl && cnt >= 255u) ? (uint64_t)c.id : (((uint64_t)c.pad << 32) | (uint64_t)c.arr);
         const uint32_t gid = XCHG ? A.global_ids[c.id] : c.id;
         if (XCHG) *elig = trunc ? cnt >= 255u : cnt >= dthr;   // the self hit's element takes part (see the merge kernel)
         return ((uint64_t)(255u - kc) << 56) | ((uint64_t)(gid & refmask) << 45) | (ord & ((1ull << 45) - 1));
@@ -1653,6 +1761,12 @@ __global__ __launch_bounds__(256) void pf_merge_kernel(PfMergeArgs A) {
 
 hipError_t launch_pf_kmers(const PfKmerArgs &A, bool emit, hipStream_t s) {
     if (A.n_pos == 0) return hipSuccess;
+    if (A.exact) {
+        const dim3 g1((A.n_pos + 255) / 256), b1(256);
+        if (emit) hipLaunchKernelGGL(pf_kmers_exact_kernel<true>, g1, b1, 0, s, A);
+        else hipLaunchKernelGGL(pf_kmers_exact_kernel<false>, g1, b1, 0, s, A);
+        return hipGetLastError();
+    }
     const dim3 grid((A.n_pos + 3) / 4), block(256);
     if (A.k == 7) {
         if (emit) hipLaunchKernelGGL(pf_kmers7_kernel<true>, grid, block, 0, s, A);
@@ -1697,7 +1811,8 @@ hipError_t launch_pf_dedup(const PfDedupArgs &A, hipEvent_t after_replay, hipEve
     hipLaunchKernelGGL(pf_ungapped_kernel, grid, block, 0, s, A);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (after_ungapped && (e = hipEventRecord(after_ungapped, s)) != hipSuccess) return e;
-    hipLaunchKernelGGL(pf_keepmax_kernel, grid, block, 0, s, A);
+    if (A.nucl) hipLaunchKernelGGL(pf_keepmax_nucl_kernel, dim3((unsigned)((buckets + 1) / 2)), dim3(128), 0, s, A);
+    else hipLaunchKernelGGL(pf_keepmax_kernel, grid, block, 0, s, A);
     return hipGetLastError();
 }
 

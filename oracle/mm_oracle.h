@@ -81,6 +81,8 @@ typedef struct {
     uint32_t bins;              /* CacheFriendlyOperations<BINS>, QueryMatcher.cpp:460-488 */
     uint64_t max_hits;          /* maxHitsPerQuery before min(., dbSize) */
     uint32_t min_diag_score;
+    int exact_kmer;             /* takeOnlyBestKmer (--exact-kmer-matching; always on in nucleotide searches, Search.cpp:186) */
+    int nucleotide;             /* matchQuery's isNucleotide branch (QueryMatcher.cpp:147-177) */
 } mmo_pf_params;
 
 typedef struct {
@@ -91,6 +93,8 @@ typedef struct {
     uint32_t diag_thr;
     int truncated;
     int overflow; /* 1 = the databaseHits overflow path would trigger (not restated) */
+    int sat_tie;  /* nucleotide branch: a target has two saturated (>= 255) elements on different diagonals with the same exact
+                     score - the reference's choice then depends on the element order an unstable std::sort left (:154) */
 } mmo_pf_stats;
 
 typedef struct {

@@ -233,11 +233,15 @@ int mmgpu_pf_load_index(mmgpu_ctx *c, const mmgpu_pf_index *ix) {
     c->spaced = ix->spaced;
     c->kalph = ix->alphabet - 1;
     const size_t n3 = (size_t)c->kalph * c->kalph * c->kalph, n2 = (size_t)c->kalph * c->kalph;
-    c->s3.resize(n3 * n3);
-    c->i3.resize(n3 * n3);
-    for (size_t r = 0; r < n3; r++) {
-        memcpy(&c->s3[r * n3], ix->score3 + r * ix->row3, n3 * sizeof(int16_t));
-        memcpy(&c->i3[r * n3], ix->index3 + r * ix->row3, n3 * sizeof(uint32_t));
+    c->s3.clear();
+    c->i3.clear();
+    if (ix->score3 && ix->index3) {       // absent: exact k-mer matching only (nucleotide databases)
+        c->s3.resize(n3 * n3);
+        c->i3.resize(n3 * n3);
+        for (size_t r = 0; r < n3; r++) {
+            memcpy(&c->s3[r * n3], ix->score3 + r * ix->row3, n3 * sizeof(int16_t));
+            memcpy(&c->i3[r * n3], ix->index3 + r * ix->row3, n3 * sizeof(uint32_t));
+        }
     }
     c->s2.clear();
     c->i2.clear();
@@ -267,8 +271,8 @@ int mmgpu_pf_load_index(mmgpu_ctx *c, const mmgpu_pf_index *ix) {
     c->ungapped.assign(ix->ungapped_mat, ix->ungapped_mat + ix->alphabet * ix->alphabet);
     c->gen.k = c->k;
     c->gen.kalph = c->kalph;
-    c->gen.s3 = c->s3.data();
-    c->gen.i3 = c->i3.data();
+    c->gen.s3 = c->s3.empty() ? NULL : c->s3.data();
+    c->gen.i3 = c->i3.empty() ? NULL : c->i3.data();
     c->gen.s2 = c->s2.empty() ? NULL : c->s2.data();
     c->gen.i2 = c->i2.empty() ? NULL : c->i2.data();
     c->have_index = true;
@@ -320,6 +324,8 @@ int mmgpu_pf_run(mmgpu_ctx *c, mmgpu_pf_batch_t *b) {
     P.bins = b->par.ref_bins;
     P.max_hits = b->par.max_hits;
     P.min_diag_score = b->par.min_diag_score;
+    P.exact_kmer = (int)b->par.exact_kmer;
+    P.nucleotide = (int)b->par.nucleotide;
     const size_t cap = (size_t)std::min<uint64_t>(b->par.max_hits, c->n) + 1;
     int bad = 0;
 #pragma omp parallel for schedule(dynamic, 1)
@@ -355,6 +361,7 @@ int mmgpu_pf_fetch(mmgpu_ctx *c, mmgpu_pf_batch_t *b, mmgpu_pf_hit *hits, uint32
     for (size_t i = 0; i < b->q.size(); i++) {
         counts[i] = (uint32_t)b->hits[i].size();
         status[i] = (long_target || b->q[i].size() >= 32768) ? MMGPU_PF_LONG_SEQ : MMGPU_PF_OK;
+        if (status[i] == MMGPU_PF_OK && (b->stats[i].sat_tie || (b->par.nucleotide && b->stats[i].overflow))) status[i] = MMGPU_PF_SAT_TIE;
         if (status[i] != MMGPU_PF_OK) counts[i] = 0;
         for (size_t k = 0; k < b->hits[i].size() && k < stride; k++) {
             mmgpu_pf_hit &o = hits[i * (size_t)stride + k];

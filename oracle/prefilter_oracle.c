@@ -255,19 +255,32 @@ size_t mmo_pf_kmer_list_profile(const int16_t *pscore, const uint32_t *pindex, i
 
 /* ---------------------------------------------------------------------------------------------------------
  * Sequence k-mer iteration (src/commons/Sequence.h:94-121,399; spaced patterns Sequence.h:24-27) */
-static const uint8_t MMO_SPACED6[] = {1, 1, 0, 1, 0, 1, 0, 0, 1, 1};
-static const uint8_t MMO_SPACED7[] = {1, 1, 0, 1, 0, 1, 1, 0, 0, 1, 1};
+/* spaced_seed_<k> of Sequence.h:20-50, one bit per pattern position (bit i = position i), and their lengths */
+static const uint32_t MMO_SPACED_BITS[16] = {0, 0, 0, 0,
+    /* 4 */ 0x17u,       /* 1 1 1 0 1 */
+    /* 5 */ 0xA13u,      /* 1 1 0 0 1 0 0 0 0 1 0 1 */
+    /* 6 */ 0x32Bu,      /* 1 1 0 1 0 1 0 0 1 1 */
+    /* 7 */ 0x66Bu,      /* 1 1 0 1 0 1 1 0 0 1 1 */
+    /* 8 */ 0xCEBu,      /* 1 1 0 1 0 1 1 1 0 0 1 1 */
+    /* 9 */ 0x366Bu,     /* 1 1 0 1 0 1 1 0 0 1 1 0 1 1 */
+    /* 10 */ 0x6D6Bu,    /* 1 1 0 1 0 1 1 0 1 0 1 1 0 1 1 */
+    /* 11 */ 0x1B66Bu,   /* 1 1 0 1 0 1 1 0 0 1 1 0 1 1 0 1 1 */
+    /* 12 */ 0x6B66Bu,   /* 1 1 0 1 0 1 1 0 0 1 1 0 1 1 0 1 0 1 1 */
+    /* 13 */ 0xD6CEBu,   /* 1 1 0 1 0 1 1 1 0 0 1 1 0 1 1 0 1 0 1 1 */
+    /* 14 */ 0x1B6CEBu,  /* 1 1 0 1 0 1 1 1 0 0 1 1 0 1 1 0 1 1 0 1 1 */
+    /* 15 */ 0x6D1BD7u}; /* 1 1 1 0 1 0 1 1 1 1 0 1 1 0 0 0 1 0 1 1 0 1 1 */
+static const uint8_t MMO_SPACED_LEN[16] = {0, 0, 0, 0, 5, 12, 10, 11, 12, 14, 15, 17, 19, 20, 21, 23};
 
 int mmo_pf_pattern(int k, int spaced, uint8_t *pos_in_pattern) {
     if (!spaced) {
         for (int i = 0; i < k; i++) pos_in_pattern[i] = (uint8_t)i;
         return k;
     }
-    const uint8_t *pat = k == 6 ? MMO_SPACED6 : MMO_SPACED7;
-    int plen = k == 6 ? 10 : 11, c = 0;
+    if (k < 4 || k > 15) return -1;
+    int plen = MMO_SPACED_LEN[k], c = 0;
     for (int i = 0; i < plen; i++)
-        if (pat[i]) pos_in_pattern[c++] = (uint8_t)i;
-    return plen;
+        if ((MMO_SPACED_BITS[k] >> i) & 1u) pos_in_pattern[c++] = (uint8_t)i;
+    return c == k ? plen : -1;
 }
 
 /* ---------------------------------------------------------------------------------------------------------
@@ -675,7 +688,7 @@ static int match_query_impl(const mmo_pf_params *P, const uint8_t *q, int qlen, 
         for (int i = 0; i < qlen; i++) dump->nsim_out[i] = 0;
     int aborted = 0;
     for (int i = 0; i + plen <= qlen && !aborted; i++) {
-        uint8_t w[8];
+        uint8_t w[16];
         float bc = 0;
         int hasx = 0;
         for (int p = 0; p < k; p++) {
@@ -687,8 +700,19 @@ static int match_query_impl(const mmo_pf_params *P, const uint8_t *q, int qlen, 
         short bias = (short)((bc < 0.0) ? bc - 0.5 : bc + 0.5); /* :270 */
         int t0 = P->kmer_thr - bias;
         short kthr = (short)(t0 > 0 ? t0 : 0); /* :271 */
-        size_t ns = prof ? mmo_pf_kmer_list_profile(prof->score, prof->index, prof->row, k, pat, i, kalph, kthr, sim, simcap)
-                         : mmo_pf_kmer_list(P->gen, w, kthr, sim, simcap);
+        size_t ns;
+        if (P->exact_kmer) { /* takeOnlyBestKmer (:279-282): the window's own k-mer */
+            uint64_t idx = 0, pw = 1;
+            for (int p = 0; p < k; p++) {
+                idx += (uint64_t)w[p] * pw;
+                pw *= (uint64_t)kalph;
+            }
+            sim[0] = idx;
+            ns = 1;
+        } else {
+            ns = prof ? mmo_pf_kmer_list_profile(prof->score, prof->index, prof->row, k, pat, i, kalph, kthr, sim, simcap)
+                      : mmo_pf_kmer_list(P->gen, w, kthr, sim, simcap);
+        }
         if (ns > simcap) {
             simcap = ns + 16;
             sim = (uint64_t *)realloc(sim, simcap * sizeof(uint64_t));
@@ -755,7 +779,56 @@ static int match_query_impl(const mmo_pf_params *P, const uint8_t *q, int qlen, 
                 dump->dd_diag[z] = fd[z].diagonal;
                 dump->dd_count[z] = fd[z].count;
             }
-        /* ---- :147 canBeSorted branch is nucleotide-only; amino acids: :179-180 ---- */
+        /* ---- :147-177 nucleotide searches: radix sort by score at the minimum diagonal score, then among the saturated elements
+         * (count == 255) of one target the diagonal with the best exact score is written into the target's first element
+         * (the elements are brought together by SORT_SERIAL(.., sortById) :154 - an unstable sort; which element is
+         * "first" only matters when two diagonals tie on the exact score, reported as sat_tie), then keepMax.  The
+         * restatement sorts the saturated prefix stably by id. ---- */
+        if (P->nucleotide && rs < found_cap / 2) {
+            unsigned sz[256];
+            memset(sz, 0, sizeof(sz));
+            for (size_t z = 0; z < rs; z++) sz[fd[z].count]++;
+            mmo_cr *wr0 = fd + rs;
+            size_t above = mmo_radix_by_score(sz, wr0, P->min_diag_score, fd, rs);
+            size_t len = 0;
+            while (len < above && wr0[len].count >= 255) len++;
+            /* stable sort of the saturated prefix by id (insertion into a temporary by counting would do; the prefix is short) */
+            for (size_t a = 1; a < len; a++) {
+                mmo_cr t = wr0[a];
+                size_t b = a;
+                while (b > 0 && wr0[b - 1].id > t.id) {
+                    wr0[b] = wr0[b - 1];
+                    b--;
+                }
+                wr0[b] = t;
+            }
+            for (size_t a = 0; a < len;) {
+                size_t e = a + 1;
+                while (e < len && wr0[e].id == wr0[a].id) e++;
+                if (e - a > 1) {
+                    const uint8_t *t = P->tdata + P->toff[wr0[a].id];
+                    int tlen = (int)(P->toff[wr0[a].id + 1] - P->toff[wr0[a].id]);
+                    unsigned best = 0;
+                    uint16_t bd = wr0[a].diagonal;
+                    int ties = 0;
+                    for (size_t z = a; z < e; z++) {
+                        unsigned sc = (unsigned)mmo_diag_score_p(q, corr, qlen, P->ungapped_mat, alphabet, t, tlen, (int)(short)wr0[z].diagonal, qprof);
+                        if (z == a || sc > best) {
+                            best = sc;
+                            bd = wr0[z].diagonal;
+                            ties = 0;
+                        } else if (sc == best && wr0[z].diagonal != bd) {
+                            ties = 1;
+                        }
+                    }
+                    if (ties) S.sat_tie = 1;
+                    wr0[a].diagonal = bd;
+                }
+                a = e;
+            }
+            memmove(fd, wr0, above * sizeof(mmo_cr));
+            rs = above;
+        }
         rs = mmo_keep_max(fd, rs, P->bins, P->n_targets);
         S.after_keepmax = rs;
         mmo_cr *rd = fd, *wr = fd + rs;

@@ -239,13 +239,14 @@ class PfParams(ctypes.Structure):
     _fields_ = [("gen", ctypes.POINTER(PfGen)), ("alphabet", ctypes.c_int), ("spaced", ctypes.c_int),
                 ("kmer_thr", ctypes.c_int), ("offsets", c_p), ("ids", c_p), ("pos", c_p), ("tdata", c_p),
                 ("toff", c_p), ("n_targets", ctypes.c_uint32), ("ungapped_mat", c_p), ("bins", ctypes.c_uint32),
-                ("max_hits", ctypes.c_uint64), ("min_diag_score", ctypes.c_uint32)]
+                ("max_hits", ctypes.c_uint64), ("min_diag_score", ctypes.c_uint32), ("exact_kmer", ctypes.c_int),
+                ("nucleotide", ctypes.c_int)]
 
 
 class PfStats(ctypes.Structure):
     _fields_ = [("db_matches", ctypes.c_uint64), ("kmer_list_len", ctypes.c_uint64),
                 ("double_hits", ctypes.c_uint64), ("after_keepmax", ctypes.c_uint64),
-                ("diag_thr", ctypes.c_uint32), ("truncated", ctypes.c_int), ("overflow", ctypes.c_int)]
+                ("diag_thr", ctypes.c_uint32), ("truncated", ctypes.c_int), ("overflow", ctypes.c_int), ("sat_tie", ctypes.c_int)]
 
 
 class PfDump(ctypes.Structure):
@@ -330,12 +331,12 @@ class PfOracle:
         return self.L.mmo_pf_ungapped_score(_ptr(q), _ptr(corr), len(q), _ptr(self.ungapped_mat), self.alphabet,
                                             _ptr(t), len(t), ctypes.c_uint16(int(diagonal) & 0xFFFF))
 
-    def match(self, q, comp_bias, bins, max_hits=300, min_diag_score=15, identity_id=None, dump=False):
+    def match(self, q, comp_bias, bins, max_hits=300, min_diag_score=15, identity_id=None, dump=False, exact=False, nucleotide=False):
         q = np.ascontiguousarray(q, np.uint8)
         cb = None if comp_bias is None else np.ascontiguousarray(comp_bias, np.float32)
         P = PfParams(ctypes.pointer(self.gen), self.alphabet, self.spaced, self.kmer_thr, self.offsets.ctypes.data,
                      self.ids.ctypes.data, self.pos.ctypes.data, self.tdata.ctypes.data, self.toff.ctypes.data,
-                     self.n_targets, self.ungapped_mat.ctypes.data, bins, max_hits, min_diag_score)
+                     self.n_targets, self.ungapped_mat.ctypes.data, bins, max_hits, min_diag_score, int(exact), int(nucleotide))
         cap = int(min(max_hits, self.n_targets)) + 2
         hits = np.zeros(cap, PF_HIT_DTYPE)
         nh = ctypes.c_uint64(0)
@@ -388,7 +389,7 @@ def _pf_match_profile(self, letters, pscore, pindex, aln, bins, kmer_thr, max_hi
     # (the index of a profile search is built with threshold 0, the matcher still runs with the profile k-mer threshold)
     P = PfParams(ctypes.pointer(self.gen), self.alphabet, self.spaced, int(kmer_thr), self.offsets.ctypes.data,
                  self.ids.ctypes.data, self.pos.ctypes.data, self.tdata.ctypes.data, self.toff.ctypes.data,
-                 self.n_targets, self.ungapped_mat.ctypes.data, bins, max_hits, min_diag_score)
+                 self.n_targets, self.ungapped_mat.ctypes.data, bins, max_hits, min_diag_score, 0, 0)
     cap = int(min(max_hits, self.n_targets)) + 2
     hits = np.zeros(cap, PF_HIT_DTYPE)
     nh = ctypes.c_uint64(0)
@@ -544,6 +545,52 @@ class RefPrefilter:
         if want_lists:
             return sec, th.value, dbm.value, counts[:nq], dict(ids=ids[:nq], scores=sc[:nq], diags=dg[:nq], bins=bins.value)
         return sec, th.value, dbm.value, counts[:nq]
+
+
+class RefNuclPrefilter:
+    """The real reference classes driven as a nucleotide prefilter (exact k-mers, isNucleotide branch of matchQuery)."""
+
+    def __init__(self, k=15, spaced=True, serialized=None):
+        L = self.L = ctypes.CDLL(REF_SO)
+        L.mmref_npref_new.restype = c_p
+        L.mmref_npref_new.argtypes = [ctypes.c_char_p, ctypes.c_int]
+        L.mmref_npref_match.restype = ctypes.c_uint64
+        L.mmref_npref_index_entries.restype = ctypes.c_uint64
+        L.mmref_npref_index_entries.argtypes = [c_p]
+        path = bytes(serialized) if serialized is not None else os.path.join(REFERENCE_ROOT, "data", "nucleotide.out").encode()
+        self.c = c_p(L.mmref_npref_new(path, int(k)))
+        self.k = k
+        self.spaced = bool(spaced)
+
+    def matrix(self):
+        out = np.zeros((5, 5), np.int8)
+        self.L.mmref_npref_matrix(self.c, _ptr(out))
+        return out
+
+    def build_index(self, tdata, toff):
+        self._t = (np.ascontiguousarray(tdata, np.uint8), np.ascontiguousarray(toff, np.uint64))
+        self.L.mmref_npref_build_index(self.c, _ptr(self._t[0]), _ptr(self._t[1]), len(self._t[1]) - 1, int(self.spaced))
+
+    def index_dump(self):
+        n = int(self.L.mmref_npref_index_entries(self.c))
+        off = np.zeros(4 ** self.k + 1, np.uint64)
+        ids = np.zeros(max(n, 1), np.uint32)
+        pos = np.zeros(max(n, 1), np.uint16)
+        self.L.mmref_npref_index_dump(self.c, _ptr(off), _ptr(ids), _ptr(pos))
+        return off, ids[:n], pos[:n]
+
+    def match(self, q, max_hits=300, min_diag_score=15, max_seq_len=32000, force_bins=0, identity_id=None):
+        q = np.ascontiguousarray(q, np.uint8)
+        cap = max_hits + 2
+        ids = np.zeros(cap, np.uint32)
+        sc = np.zeros(cap, np.int32)
+        dg = np.zeros(cap, np.uint16)
+        dbm = ctypes.c_uint64(0)
+        ident = 0xFFFFFFFF if identity_id is None else int(identity_id)
+        n = self.L.mmref_npref_match(self.c, _ptr(q), len(q), int(max_seq_len), ctypes.c_uint64(max_hits), int(min_diag_score),
+                                     int(self.spaced), int(force_bins), ctypes.c_uint32(ident), _ptr(ids), _ptr(sc), _ptr(dg),
+                                     ctypes.c_uint64(cap), ctypes.byref(dbm))
+        return dict(id=ids[:n].copy(), score=sc[:n].copy(), diagonal=dg[:n].copy(), db_matches=dbm.value)
 
 
 # ---------------------------------------------------------------------------------------------------------

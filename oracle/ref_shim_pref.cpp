@@ -27,6 +27,7 @@
 #include "QueryMatcher.h"
 #include "Sequence.h"
 #include "SequenceLookup.h"
+#include "NucleotideMatrix.h"
 #include "SubstitutionMatrix.h"
 
 namespace {
@@ -251,6 +252,115 @@ uint64_t mmref_pref_match_profile(void *h, const char *entry, uint32_t qlen, int
     if (letters) memcpy(letters, seq.numSequence, (size_t)seq.L);
     DBLocalId ident = identity_id == UINT32_MAX ? DB_LOCAL_ID_INVALID : (DBLocalId)identity_id;
     std::pair<hit_t *, size_t> r = matcher.matchQuery(&seq, ident, false);
+    for (size_t i = 0; i < r.second && i < cap; i++) {
+        ids[i] = (uint32_t)r.first[i].seqId;
+        scores[i] = r.first[i].prefScore;
+        diags[i] = r.first[i].diagonal;
+    }
+    if (db_matches) *db_matches = matcher.getStatistics()->dbMatches;
+    return r.second;
+}
+
+// ---- nucleotide prefilter (Search.cpp:180-198: exact k-mers, k = 15; Prefiltering.cpp:62-66: one NucleotideMatrix for seeding and
+// ungapped scoring, k-mer threshold 0, :555-563 index over the 4-letter alphabet; QueryMatcher::matchQuery's isNucleotide
+// branch :147-177) - the same classes, driven for nucleotide sequences given as numeric codes (A C T G N = 0..4).
+struct NPrefCtx {
+    NucleotideMatrix *mat;
+    IndexTable *index;
+    SequenceLookup *lookup;
+    int kmerSize;
+    size_t dbSize;
+    unsigned maxLen;
+};
+
+void *mmref_npref_new(const char *nucl_matrix, int kmer_size) {
+    Debug::setDebugLevel(Debug::ERROR);
+    NPrefCtx *c = new NPrefCtx();
+    c->mat = new NucleotideMatrix(nucl_matrix, 1.0f, 0.0f);
+    c->kmerSize = kmer_size;
+    c->index = NULL;
+    c->lookup = NULL;
+    return c;
+}
+
+void mmref_npref_matrix(void *h, int8_t *out /* alphabet^2 */) {
+    NPrefCtx *c = (NPrefCtx *)h;
+    const int a = c->mat->alphabetSize;
+    for (int i = 0; i < a; i++)
+        for (int j = 0; j < a; j++) out[i * a + j] = (int8_t)c->mat->subMatrix[i][j];
+}
+
+void mmref_npref_build_index(void *h, const uint8_t *tdata, const uint64_t *toff, uint32_t n, int spaced) {
+    NPrefCtx *c = (NPrefCtx *)h;
+    const int alph = c->mat->alphabetSize;
+    unsigned maxLen = 1;
+    for (uint32_t i = 0; i < n; i++) maxLen = std::max<unsigned>(maxLen, (unsigned)(toff[i + 1] - toff[i]));
+    c->maxLen = maxLen + 1;
+    c->dbSize = n;
+    delete c->index;
+    delete c->lookup;
+    c->index = new IndexTable(alph - 1, c->kmerSize, false);
+    c->lookup = new SequenceLookup(n, toff[n]);
+    char *idScore = new char[alph];
+    for (int a = 0; a < alph; a++) idScore[a] = (char)c->mat->subMatrix[a][a];
+    size_t tableSize = 0;
+    {
+        Sequence s(c->maxLen, Parameters::DBTYPE_NUCLEOTIDES, c->mat, c->kmerSize, spaced != 0, false, true);
+        Indexer idxer(alph - 1, c->kmerSize);
+        std::vector<unsigned int> buffer(c->maxLen + 8);
+        for (uint32_t i = 0; i < n; i++) {
+            unsigned len = (unsigned)(toff[i + 1] - toff[i]);
+            s.mapSequence(i, i, std::make_pair((const unsigned char *)(tdata + toff[i]), (const unsigned int)len));
+            c->index->addKmerCount(&s, &idxer, buffer.data(), 0, idScore);
+            c->lookup->addSequence(s.numSequence, s.L, i, toff[i]);
+            tableSize += len;
+        }
+    }
+    c->index->initMemory(tableSize);
+    c->index->init();
+    {
+        Sequence s(c->maxLen, Parameters::DBTYPE_NUCLEOTIDES, c->mat, c->kmerSize, spaced != 0, false, true);
+        Indexer idxer(alph - 1, c->kmerSize);
+        IndexEntryLocalTmp *tmp = (IndexEntryLocalTmp *)malloc((c->maxLen + 8) * sizeof(IndexEntryLocalTmp));
+        for (uint32_t i = 0; i < n; i++) {
+            s.mapSequence(i, i, c->lookup->getSequence(i));
+            c->index->addSequence(&s, &idxer, &tmp, c->maxLen + 8, 0, idScore);
+        }
+        free(tmp);
+    }
+    delete[] idScore;
+    c->index->revertPointer();
+    c->index->sortDBSeqLists();
+}
+
+uint64_t mmref_npref_index_entries(void *h) { return ((NPrefCtx *)h)->index->getTableEntriesNum(); }
+void mmref_npref_index_dump(void *h, uint64_t *offsets, uint32_t *seq_id, uint16_t *pos_j) {
+    NPrefCtx *c = (NPrefCtx *)h;
+    size_t ts = c->index->getTableSize();
+    for (size_t k = 0; k <= ts; k++) offsets[k] = c->index->getOffsets()[k];
+    IndexEntryLocal *e = c->index->getEntries();
+    for (uint64_t k = 0; k < c->index->getTableEntriesNum(); k++) {
+        seq_id[k] = e[k].seqId;
+        pos_j[k] = e[k].position_j;
+    }
+}
+
+uint64_t mmref_npref_match(void *h, const uint8_t *q, uint32_t qlen, unsigned max_seq_len, uint64_t max_hits, unsigned min_diag_score,
+                           int spaced, unsigned force_bins, uint32_t identity_id, uint32_t *ids, int32_t *scores, uint16_t *diags,
+                           uint64_t cap, uint64_t *db_matches) {
+    NPrefCtx *c = (NPrefCtx *)h;
+    unsigned ml = std::max(max_seq_len, c->maxLen);
+    // Prefiltering.cpp:826-831: kmerThr 0, composition bias as configured (zero for nucleotides inside matchQuery),
+    // diagonal scoring, takeOnlyBestKmer (exact k-mers), isNucleotide
+    MatcherProbe matcher(c->index, c->lookup, c->mat, c->mat, 0, c->kmerSize, c->dbSize, ml, max_hits, true, 1.0f, true, min_diag_score,
+                         true, true);
+    if (force_bins) matcher.forceBins(force_bins);
+    ScoreMatrix none3, none2;      // Prefiltering::runSplit hands its (empty) 3-mer / 2-mer tables over for nucleotides as well (:835)
+    matcher.setSubstitutionMatrix(&none3, &none2);
+    Sequence seq(ml, Parameters::DBTYPE_NUCLEOTIDES, c->mat, c->kmerSize, spaced != 0, true, true);
+    seq.mapSequence(0, 0, std::make_pair((const unsigned char *)q, (const unsigned int)qlen));
+    DBLocalId ident = identity_id == UINT32_MAX ? DB_LOCAL_ID_INVALID : (DBLocalId)identity_id;
+    std::pair<hit_t *, size_t> r = matcher.matchQuery(&seq, ident, true);
     for (size_t i = 0; i < r.second && i < cap; i++) {
         ids[i] = (uint32_t)r.first[i].seqId;
         scores[i] = r.first[i].prefScore;

@@ -313,3 +313,62 @@ def test_translated_search_host_side_emulated(tmp_path):
 @pytest.mark.gpu
 def test_translated_search_on_device(tmp_path):
     _translated_pipeline(str(tmp_path), emulate=False)
+
+
+def _nucleotide_pipeline(w, emulate, k="15"):
+    """Nucleotide search: `mmseqs prefilter` of nucleotide databases with the search's parameters
+    (exact k-mers, k = 15, Search.cpp:180-198) on the device, and the whole blastn workflow (`search --search-type 3`:
+    extractframes / splitsequence -> prefilter -> align -> offsetalignment) through the patched binary: prefilter on the
+    device, the banded nucleotide alignment on the reference's CPU path (announced)."""
+    rng = np.random.default_rng(23)
+    letters = np.array(list("ACGT"))
+    targets = ["".join(letters[rng.integers(0, 4, int(rng.integers(3000, 12000)))]) for _ in range(60)]
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    queries = []
+    for i in range(30):
+        t = targets[int(rng.integers(0, len(targets)))]
+        L = int(rng.integers(300, 2500))
+        a = int(rng.integers(0, len(t) - L))
+        piece = list(t[a:a + L])
+        for p in np.nonzero(rng.random(L) < 0.06)[0]:
+            piece[p] = "ACGT"[int(rng.integers(0, 4))]
+        s = "".join(piece)
+        if i % 2:
+            s = "".join(comp[c] for c in reversed(s))
+        queries.append(s)
+    with open(os.path.join(w, "nq.fasta"), "w") as f:
+        for i, s in enumerate(queries):
+            f.write(">q%d\n%s\n" % (i, s))
+    with open(os.path.join(w, "nt.fasta"), "w") as f:
+        for i, s in enumerate(targets):
+            f.write(">t%d\n%s\n" % (i, s))
+    run(STOCK, ["createdb", "nq.fasta", "nq", "-v", "1"], w)
+    run(STOCK, ["createdb", "nt.fasta", "nt", "-v", "1"], w)
+    # the reverse strands as separate query entries, like the workflow's extractframes step
+    run(STOCK, ["extractframes", "nq", "nqf", "--forward-frames", "1", "--reverse-frames", "1", "--threads", THREADS, "-v", "1"], w)
+    # (k: the search's own 15 on the device; the CPU stand-in runs the same code at k = 12 - 4^15 offsets per process are slow there)
+    for n, extra in enumerate([[], ["--max-seqs", "4"], ["-k", "11", "--spaced-kmer-mode", "0"]]):
+        args = ["--exact-kmer-matching", "1", "--max-seq-len", "10000", "--threads", THREADS]
+        if "-k" not in extra:
+            args += ["-k", k]
+        run(STOCK, ["prefilter", "nqf", "nt", "npref_s%d" % n] + args + extra + ["-v", "2"], w)
+        log = run(MMGPU, ["prefilter", "nqf", "nt", "npref_g%d" % n] + args + extra + ["-v", "3"], w, emulate)
+        assert "MMGPU: device" in log and "using the CPU path" not in log, log[-2000:]
+        assert same(os.path.join(w, "npref_s%d" % n), os.path.join(w, "npref_g%d" % n)) == 60
+    d = dbio.read_db(os.path.join(w, "npref_g0"))
+    assert sum(1 for v in d.values() if len(v) > 1) >= 25          # every read finds its contig on one of the two strands
+    run(STOCK, ["search", "nq", "nt", "nres_s", "ntmp_s", "--search-type", "3", "-k", k, "-a", "--threads", THREADS, "-v", "1"], w)
+    log = run(MMGPU, ["search", "nq", "nt", "nres_g", "ntmp_g", "--search-type", "3", "-k", k, "-a", "--threads", THREADS, "-v", "3"], w, emulate)
+    assert "MMGPU: device" in log, log[-3000:]
+    assert same(os.path.join(w, "nres_s"), os.path.join(w, "nres_g")) == 30
+
+
+def test_nucleotide_search_host_side_emulated(tmp_path):
+    if not os.path.exists(EMU):
+        pytest.skip("oracle/_build/emu/libmmgpu.so not built (make -C oracle emu)")
+    _nucleotide_pipeline(str(tmp_path), emulate=True, k="12")
+
+
+@pytest.mark.gpu
+def test_nucleotide_search_on_device(tmp_path):
+    _nucleotide_pipeline(str(tmp_path), emulate=False)
