@@ -444,6 +444,98 @@ def nucl_section(args, gpu, matrices, rank):
     return res
 
 
+def nucl_search_section(args, gpu, matrices):
+    """BASELINE.json configs[4] as a SEARCH: reads and their reverse complements (the workflow's extractframes
+    step) against contigs cut at 10 000 nt (its splitsequence step, Search.cpp:194-198): exact 15-mer prefilter with the
+    isNucleotide branch on the device -> the hit lists' diagonals -> the nucleotide alignment kernel.  CPU side: the real
+    QueryMatcher on a sample of the reads, one thread, which is also the parity check of the hit lists."""
+    from mmseqs2_amd import capi, workloads as wl
+    t0 = time.time()
+    queries, (tres, toff), _ = wl.config5_nucleotide(args.nucl_contigs, args.nucl_reads, args.nucl_read_len, seed=20)
+    # splitsequence: pieces of at most 10 000 nt
+    cut = 10000
+    pieces, src = [], []
+    for c in range(len(toff) - 1):
+        a, e = int(toff[c]), int(toff[c + 1])
+        for p in range(a, e, cut):
+            pieces.append(tres[p:min(p + cut, e)])
+            src.append(c)
+    pres, poff = wl.seqs_from_list(pieces)
+    both = []
+    for q in queries:
+        both.append(q)
+        both.append(wl.NUCL_REVERSE[q[::-1]])
+    t_gen = time.time() - t0
+    mat = matrices["nucleotide"].astype(np.int8).reshape(5, 5)
+    rl = matrices["nucleotide_reverse"]
+    t0 = time.perf_counter()
+    gpu.load_targets(pres, poff, 5)
+    gpu.pf_build_index(15, 5, True, None, None, mat.astype(np.int16), 0, mat)
+    gpu.synchronize()
+    t_index = time.perf_counter() - t0
+    pq = [dict(q=q, comp_bias=None, identity_id=None) for q in both]
+    b = gpu.pf_prepare(pq, 0, max_hits=300, min_diag_score=15, ref_bins=2, exact=True, nucleotide=True)
+    b.run()                      # warm-up
+    gpu.synchronize()
+    t0 = time.perf_counter()
+    b.run()
+    gpu.synchronize()
+    t_pf = time.perf_counter() - t0
+    hits, counts, status, _ = b.fetch()
+    b.free()
+    pairs = np.zeros(int(counts.sum()), capi.NUCL_PAIR_DTYPE)
+    k = 0
+    for qi in range(len(both)):
+        n = int(counts[qi])
+        pairs["query"][k:k + n] = qi
+        pairs["target"][k:k + n] = hits[qi]["id"][:n]
+        pairs["diagonal"][k:k + n] = hits[qi]["diagonal"][:n]
+        k += n
+    gpu.nucl_align(mat, rl, both[:4], pairs[:4] if len(pairs) >= 4 else pairs)
+    al, _ = gpu.nucl_align(mat, rl, both, pairs, 5, 2, 40, 4, 4)
+    t_al = gpu.last_nucl_call_s
+    found = 0
+    for qi in range(len(both)):
+        # (a 10 kb read usually straddles two 10 kb pieces of its contig: count reads with a long alignment on either strand)
+        if counts[qi] and al["bt_len"][pairs["query"] == qi].max(initial=0) > 0.25 * args.nucl_read_len:
+            found += 1
+    res = {"workload": "BASELINE.json configs[4] as a search: %d reads of %d nt + their reverse complements x %d contig pieces (<= 10 000 nt, "
+                       "%d contigs ~LogNormal(20 kb)); exact 15-mer prefilter (spaced, --max-seqs 300, isNucleotide branch) -> banded "
+                       "nucleotide alignment of every hit" % (len(queries), args.nucl_read_len, len(pieces), args.nucl_contigs),
+           "reads": len(queries), "query_entries": len(both), "prefilter_s": round(t_pf, 4),
+           "prefilter_entries_per_s": round(len(both) / t_pf, 1), "prefilter_hits": int(counts.sum()),
+           "queries_handed_to_host": int((status != 0).sum()),
+           "align_pairs": len(pairs), "align_s_incl_upload_and_download": round(t_al, 4),
+           "reads_per_s_prefilter_plus_alignment": round(len(queries) / (t_pf + t_al), 1),
+           "query_entries_with_an_alignment_over_a_quarter_of_the_read": found,
+           "setup_s": {"generate_and_split": round(t_gen, 1), "upload_and_device_index_build_4^15_offsets": round(t_index, 2)}}
+    if not args.no_cpu_baseline:
+        from oracle import pyoracle
+        if pyoracle.ref_available():
+            t0 = time.perf_counter()
+            ref = pyoracle.RefNuclPrefilter(15, True, serialized=matrices["nucleotide_serialized"].tobytes())
+            ref.build_index(pres, poff)
+            t_ref_index = time.perf_counter() - t0
+            n_s = min(len(both), 64)
+            bad = 0
+            t0 = time.perf_counter()
+            refl = [ref.match(both[qi], max_hits=300, force_bins=2, max_seq_len=args.nucl_read_len + 64) for qi in range(n_s)]
+            sec = time.perf_counter() - t0
+            for qi in range(n_s):
+                if status[qi] != 0:
+                    continue
+                n = int(counts[qi])
+                r = refl[qi]
+                if not (np.array_equal(r["id"], hits[qi]["id"][:n]) and np.array_equal(r["score"], hits[qi]["score"][:n]) and
+                        np.array_equal(r["diagonal"], hits[qi]["diagonal"][:n])):
+                    bad += 1
+            res["cpu_baseline"] = {"value": round(n_s / sec, 1), "unit": "query entries/s (prefilter only)", "cores": 1, "kind": "reference",
+                                   "sample": "first %d query entries through QueryMatcher::matchQuery(isNucleotide), one thread, %.2f s; "
+                                             "reference index build %.1f s (not counted)" % (n_s, sec, t_ref_index),
+                                   "parity_vs_reference": {"queries_compared": n_s, "queries_with_different_hit_lists": bad}}
+    return res
+
+
 def main():
     # exactly ONE line on stdout: libraries (RCCL prints a version banner) write to fd 1 behind Python's back, so
     # fd 1 is pointed at stderr for the run and the JSON line goes to the saved descriptor at the end
@@ -518,6 +610,11 @@ def main():
         if not args.no_nucl:
             try:
                 side["nucleotide_align"] = nucl_section(args, gpu, matrices, rank)
+                if rank == 0:
+                    try:
+                        side["nucleotide_search"] = nucl_search_section(args, gpu, matrices)
+                    except Exception as e:      # a secondary section must not lose the line
+                        side["nucleotide_search"] = {"error": repr(e)[:300]}
             except Exception as e:
                 side["nucleotide_align"] = {"error": "%s: %s" % (type(e).__name__, e)}
 
