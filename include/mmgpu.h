@@ -280,7 +280,8 @@ int mmgpu_pf_build_index(mmgpu_ctx *ctx, const mmgpu_pf_index *tables, const int
 int mmgpu_pf_debug_index(mmgpu_ctx *ctx, uint64_t *offsets, uint32_t *ids, uint16_t *pos, uint64_t *n_entries);
 
 /* limits of the prefilter entry points: calls beyond them return MMGPU_ERR_UNSUPPORTED and the host keeps its CPU path */
-#define MMGPU_PF_MAX_HITS 4096      /* max_hits (--max-seqs) */
+#define MMGPU_PF_MAX_HITS 131072    /* max_hits (--max-seqs); above 4096 the final sort of a list runs in HBM instead of LDS */
+#define MMGPU_PF_MAX_FUSED_HITS 4096 /* ... except mmgpu_sw_prepare_from_pf and sharded (exchange) batches, which stay at 4096 */
 #define MMGPU_PF_MAX_SEQ_LEN 65536  /* Parameters.h:271; queries / candidates of 32768 residues or more: MMGPU_PF_LONG_SEQ */
 
 typedef struct {

@@ -120,7 +120,8 @@ constexpr int PF_T = 4096;             // arrival-ordered index entries per tile
 constexpr int PF_IDS_PER_BIN = 4096;   // targets per replay bin (one 16 KB LDS state table per wavefront)
 constexpr int PF_CAND0 = 32;            // candidates per (query, bin) kept in the dense array
 constexpr int PF_QSTAGE = 2048;         // longest query whose residues the ungapped kernel stages in LDS
-constexpr int PF_MAX_HITS = 4096;      // largest --max-seqs the select kernel sorts in LDS
+constexpr int PF_MAX_HITS = 4096;      // largest --max-seqs the select kernel sorts in LDS (larger lists: global scratch, PF_MAX_HITS_BIG)
+constexpr int PF_MAX_HITS_BIG = 131072;   // == MMGPU_PF_MAX_HITS
 
 struct PfList {        // index list of one similar k-mer of one query position
     uint32_t start;    // first entry in the index arrays
@@ -238,6 +239,10 @@ struct PfSelectArgs {
     const uint32_t *q_nseg;           // overflow-path queries (their order key is not shard independent), may be null
     const uint32_t *q_flags;          // long-sequence queries (scores not computed on the device), may be null
     int nucl;                         // nucleotide searches: saturated elements are ordered by target id (QueryMatcher.cpp:154)
+    // max_hits above PF_MAX_HITS: the selected elements are sorted in global scratch, [nq][big_stride] keys + diagonals
+    uint64_t *big_keys;
+    uint16_t *big_diags;
+    uint32_t big_stride;              // power of two >= max_hits
     const uint32_t *q_off, *peb, *list_base;
     const PfList *lists;
 };

@@ -481,6 +481,8 @@ struct mmgpu_pf_batch_t {
     DevBuf d_qres, d_qthr, d_qcorr, d_qoff, d_qident, d_qself;
     DevBuf d_qkind, d_qisprof, d_pscore, d_pletter, d_qrows;   // profile queries only
     DevBuf d_qncand;                                           // nucleotide searches only
+    DevBuf d_big_keys, d_big_diags;                            // max_hits > PF_MAX_HITS only: the select kernel's sort scratch
+    uint32_t big_stride = 0;
     bool any_profile = false;
     // device: working set (grow-only, reused across runs)
     DevBuf d_nsim, d_qtot, d_qbase, d_list_base, d_pos_entries, d_peb, d_qentries;
@@ -535,7 +537,8 @@ extern "C" int mmgpu_pf_prepare(mmgpu_ctx *c, const mmgpu_pf_params *par, const 
     const bool exchange = c->shard.on;
     const uint64_t db_size = exchange ? c->shard.global_n : c->db.n;
     const uint32_t max_hits = (uint32_t)std::min<uint64_t>(par->max_hits, db_size);
-    if (max_hits > PF_MAX_HITS) return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_pf_prepare: max_hits above 4096 is not implemented");
+    if (max_hits > (uint32_t)PF_MAX_HITS_BIG) return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_pf_prepare: max_hits above 131072 is not implemented");
+    if (max_hits > (uint32_t)PF_MAX_HITS && exchange) return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_pf_prepare: max_hits above 4096 on a sharded database is not implemented");
     if (par->ref_bins && (par->ref_bins < 2 || par->ref_bins > 2048 || (par->ref_bins & (par->ref_bins - 1))))
         return fail(MMGPU_ERR_ARG, "mmgpu_pf_prepare: ref_bins must be a power of two in [2, 2048]");
     uint32_t bins = 1;
@@ -687,6 +690,12 @@ extern "C" int mmgpu_pf_prepare(mmgpu_ctx *c, const mmgpu_pf_params *par, const 
     B_TRY(b->d_diag_thr.alloc(nqq * 4));
     B_TRY(b->d_qflags.alloc(nqq * 4));
     if (par->nucleotide) B_TRY(b->d_qncand.alloc(nqq * 4));
+    if (max_hits > (uint32_t)PF_MAX_HITS) {
+        b->big_stride = 1;
+        while (b->big_stride < max_hits) b->big_stride <<= 1;
+        B_TRY(b->d_big_keys.alloc((size_t)nqq * b->big_stride * 8));
+        B_TRY(b->d_big_diags.alloc((size_t)nqq * b->big_stride * 2));
+    }
     for (auto &e : b->ev) B_TRY(hipEventCreate(&e));
     B_TRY(hipStreamSynchronize(s));
 #undef B_TRY
@@ -966,6 +975,9 @@ extern "C" int mmgpu_pf_run(mmgpu_ctx *c, mmgpu_pf_batch_t *b) {
     S.q_nseg = nullptr;
     S.q_flags = b->d_qflags.as<uint32_t>();
     S.nucl = b->par.nucleotide ? 1 : 0;
+    S.big_keys = b->big_stride ? b->d_big_keys.as<uint64_t>() : nullptr;
+    S.big_diags = b->big_stride ? b->d_big_diags.as<uint16_t>() : nullptr;
+    S.big_stride = b->big_stride;
     S.q_off = S.peb = S.list_base = nullptr;
     S.lists = nullptr;
     if (b->exchange) {

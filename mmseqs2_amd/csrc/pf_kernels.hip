@@ -1495,15 +1495,20 @@ __device__ uint32_t list_ordinal(const PfSelectArgs &A, uint32_t q, uint32_t arr
 // XCHG = true : this device holds one shard of the database (mmgpu_pf_set_shard): the top max_hits elements by the
 //               unsplit run's own order - count, the reference's cache bin of the GLOBAL id, arrival order - as exchange
 //               records for pf_merge_exchange_kernel, which redoes threshold / truncation / final scores over all shards.
-template <bool XCHG>
+// BIG = true: --max-seqs above PF_MAX_HITS - the selected elements do not fit the LDS arrays and are sorted in the query's slice of
+// a global scratch instead (same network, global loads / stores; such lists are rare and long anyway).
+template <bool XCHG, bool BIG>
 __global__ __launch_bounds__(256) void pf_select_kernel(PfSelectArgs A) {
     __shared__ uint32_t hist[256];
     __shared__ uint32_t sh_thr, sh_trunc, sh_nelig, sh_nsel;
     __shared__ uint64_t sh_prefix, sh_mask;
     __shared__ uint32_t sh_remaining;
-    __shared__ uint64_t skey[PF_MAX_HITS];
-    __shared__ uint16_t sdiag[PF_MAX_HITS];
+    __shared__ uint64_t skey_lds[BIG ? 1 : PF_MAX_HITS];
+    __shared__ uint16_t sdiag_lds[BIG ? 1 : PF_MAX_HITS];
     const uint32_t q = blockIdx.x;
+    uint64_t *skey = BIG ? A.big_keys + (size_t)q * A.big_stride : skey_lds;
+    uint16_t *sdiag = BIG ? A.big_diags + (size_t)q * A.big_stride : sdiag_lds;
+    const uint32_t sort_cap = BIG ? A.big_stride : (uint32_t)PF_MAX_HITS;
     const uint32_t n = A.surv_count[q];
     const PfCand *S = A.surv + A.cand_base[(uint64_t)q * A.bins];
     const uint32_t ident = A.q_identity[q];
@@ -1621,7 +1626,7 @@ __global__ __launch_bounds__(256) void pf_select_kernel(PfSelectArgs A) {
                         x.order = ovf ? c.arr : list_ordinal(A, q, c.arr);
                         A.xhits[(size_t)q * A.hit_stride + slot] = x;
                     }
-                } else if (slot < PF_MAX_HITS) {
+                } else if (slot < sort_cap) {
                     uint32_t pref;
                     const uint32_t cnt = min(255u, c.score);
                     if (trunc) pref = 255u + (rescaled_count(c.score, fms) * (uint32_t)ms / 255u);
@@ -1640,7 +1645,8 @@ __global__ __launch_bounds__(256) void pf_select_kernel(PfSelectArgs A) {
         }
         return;
     }
-    const uint32_t nsel = min(sh_nsel, (uint32_t)PF_MAX_HITS);
+    if (BIG) __threadfence();      // the scratch slice is read back by other threads of the workgroup
+    const uint32_t nsel = min(sh_nsel, sort_cap);
     // bitonic sort by (prefScore desc, id asc)   (hit_t::compareHitsByScoreAndId, QueryMatcher.h:38-49)
     uint32_t np2 = 1;
     while (np2 < nsel) np2 <<= 1;
@@ -1648,6 +1654,7 @@ __global__ __launch_bounds__(256) void pf_select_kernel(PfSelectArgs A) {
         skey[k] = ~0ull;
         sdiag[k] = 0;
     }
+    if (BIG) __threadfence();
     __syncthreads();
     for (uint32_t size = 2; size <= np2; size <<= 1) {
         for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
@@ -1664,6 +1671,7 @@ __global__ __launch_bounds__(256) void pf_select_kernel(PfSelectArgs A) {
                     sdiag[j] = t;
                 }
             }
+            if (BIG) __threadfence();
             __syncthreads();
         }
     }
@@ -1837,8 +1845,9 @@ hipError_t launch_pf_merge(const PfMergeArgs &A, hipStream_t s) {
 
 hipError_t launch_pf_select(const PfSelectArgs &A, uint32_t nq, hipStream_t s) {
     if (nq == 0) return hipSuccess;
-    if (A.xhits) hipLaunchKernelGGL(pf_select_kernel<true>, dim3(nq), dim3(256), 0, s, A);
-    else hipLaunchKernelGGL(pf_select_kernel<false>, dim3(nq), dim3(256), 0, s, A);
+    if (A.xhits) hipLaunchKernelGGL((pf_select_kernel<true, false>), dim3(nq), dim3(256), 0, s, A);
+    else if (A.big_keys) hipLaunchKernelGGL((pf_select_kernel<false, true>), dim3(nq), dim3(256), 0, s, A);
+    else hipLaunchKernelGGL((pf_select_kernel<false, false>), dim3(nq), dim3(256), 0, s, A);
     return hipGetLastError();
 }
 

@@ -3,7 +3,7 @@ lists against the oracle, and the final lists against the golden vectors recorde
 import numpy as np
 import pytest
 
-from mmseqs2_amd import workloads as wl
+from mmseqs2_amd import capi, workloads as wl
 from tests import pf_common as pc
 from tests import pf_gpu_check as chk
 
@@ -328,3 +328,33 @@ def test_fused_prefilter_to_align_handover(gpu, matrices, oracle):
     assert sum(1 for x in fs if x) > 20
     for b in (fused, sep, other):
         b.free()
+
+
+def test_max_seqs_above_4096(gpu):
+    """--max-seqs above 4096 (unsupported before): the final sort of a list runs in global scratch instead of LDS.
+    One family of 7000 members so that a query collects thousands of hits; truncation (5000 of ~7000) and the full list."""
+    from mmseqs2_amd import workloads as wl
+    g = pc.golden()
+    rng = np.random.default_rng(12)
+    base = rng.choice(20, size=260, p=wl.BACKGROUND).astype(np.uint8)
+    tl = [wl.mutate(rng, base, float(rng.uniform(0.55, 0.95))) for _ in range(7000)]
+    tl += [rng.choice(20, size=int(rng.integers(80, 400)), p=wl.BACKGROUND).astype(np.uint8) for _ in range(1500)]
+    tres, toff = wl.seqs_from_list(tl)
+    km16 = g["vtml80_kmer16"]
+    thr = int(g["kmer_thr"])
+    s3, i3 = capi.host_score_matrix(km16, 3)
+    gpu.load_targets(tres, toff, 21)
+    gpu.pf_build_index(6, 21, True, s3, i3, km16, thr, g["blosum62_ungapped"])
+    orc = pc.pf_oracle()
+    orc.build_index(tres, toff, thr)
+    qs = [base, wl.mutate(rng, base, 0.8), tl[7100]]
+    queries = [dict(q=q, comp_bias=capi.host_comp_bias(km16, g["vtml80_pback"], q)[0], identity_id=None) for q in qs]
+    for mh in (5000, 8500):
+        hits, counts, status, _ = gpu.pf_batch(queries, thr, max_hits=mh, ref_bins=2)
+        for qi, qd in enumerate(queries):
+            x = orc.match(qd["q"], qd["comp_bias"], 2, max_hits=mh)
+            assert int(status[qi]) == 0
+            h = hits[qi][: int(counts[qi])]
+            assert len(x["id"]) == len(h), (mh, qi, len(x["id"]), len(h))
+            assert np.array_equal(h["id"], x["id"]) and np.array_equal(h["score"], x["score"]) and np.array_equal(h["diagonal"], x["diagonal"]), (mh, qi)
+        assert int(counts[0]) > 4096
