@@ -55,8 +55,8 @@ def allreduce(torch, dist, values, op="sum"):
     return [float(v) for v in t.cpu()]
 
 
-def pmc_traffic(kernel, stem):
-    """HBM bytes per launch of `kernel` (summed over its template instantiations) from the committed rocprofv3 PMC
+def pmc_traffic(kernels, stem):
+    """HBM bytes per launch of the named kernels (substrings; summed over their template instantiations) from the committed rocprofv3 PMC
     passes of this same workload (profiles/<stem>_pmc_{fetch,write}_size.txt: separate --pmc FETCH_SIZE / WRITE_SIZE
     runs, unit KB, mean per dispatch).  FETCH_SIZE is reported as measured; MI355X_MICROARCH.md notes it under-counts
     wide coalesced reads by 2x on gfx950, so this is a lower bound."""
@@ -67,12 +67,12 @@ def pmc_traffic(kernel, stem):
             return None
         found = False
         for line in open(path):
-            if kernel in line and "_SIZE" in line and "mean=" in line:
+            if any(k in line for k in kernels) and "_SIZE" in line and "mean=" in line:
                 tot += float(line.split("mean=")[1]) * 1024.0
                 found = True
         if not found:
             return None
-    return {"bytes_per_launch": round(tot), "source": "profiles/%s_pmc_*_size.txt (FETCH_SIZE + WRITE_SIZE, KB)" % stem}
+    return round(tot)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -648,7 +648,8 @@ def main():
             "roofline": {"kernel": "sw_kernel<G,true> (three grids: tile shapes grouped by register need, forward + reverse scan)",
                          "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6),
-                         "traffic": pmc_traffic("sw_kernel<", PROFILE_ROUND + "_search") if default_wl else None,
+                         "traffic": pmc_traffic(("sw_kernel<", "sw_rev_multi_kernel"), PROFILE_ROUND + "_search") if default_wl else None,
+                         "traffic_source": "profiles/%s_search_pmc_{fetch,write}_size.txt: FETCH_SIZE + WRITE_SIZE (KB) per launch, separate --pmc passes" % PROFILE_ROUND,
                          "algorithmic_bytes_per_launch": round(alg_bytes), "kernel_ms": round(k_ms, 3),
                          "note": "Gotoh SW is VALU-issue bound (0.003 B/cell, SURVEY.md section 8d): the binding roof is valu_roofline",
                          "valu_roofline": {"achieved_lane_ops_per_s": round(lane_ops / (k_ms * 1e-3), 1),
@@ -668,7 +669,7 @@ def main():
             pf.update({"db_matches": int(ent), "similar_kmers": int(H["sim"]), "overflow_queries": int(H["ovf"]),
                        "roofline": {"kernel": "pf_split_kernel (index gather + stable bin split)", "bound": "hbm",
                                     "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                                    "traffic": pmc_traffic("pf_split_kernel", PROFILE_ROUND + "_search") if default_wl else None,
+                                    "traffic": pmc_traffic(("pf_split_kernel",), PROFILE_ROUND + "_search") if default_wl else None,
                                     "kernel_ms": round(stage[1], 3), "algorithmic_bytes_per_launch": round(alg),
                                     "algorithmic_bytes_per_entry": 20}})
         out["prefilter"] = pf

@@ -38,11 +38,14 @@ def test_committed_bench_line_has_the_contract_keys():
     assert d["cpu_baseline_prefilter"]["parity_vs_reference"]["queries_with_different_hit_lists"] == 0
     assert d["two_call"]["fields_differing_from_fused_path"] == 0
     assert d["nucleotide_align"]["cpu_baseline"]["parity_vs_reference"]["pairs_differing"] == 0
+    assert d["nucleotide_search"]["cpu_baseline"]["parity_vs_reference"]["queries_with_different_hit_lists"] == 0
+    assert isinstance(d["roofline"]["traffic"], (int, float)) and d["roofline"]["traffic"] > d["roofline"]["algorithmic_bytes_per_launch"]
 
 
 def test_pmc_reader_finds_the_quoted_kernels():
     sys.path.insert(0, ROOT)
     import bench
-    for kernel, stem in (("pf_split_kernel", "r01_prefilter_config3"), ("sw_kernel<", "r01_sw_config2")):
-        t = bench.pmc_traffic(kernel, stem)
-        assert t is not None and t["bytes_per_launch"] > 1e9, (kernel, t)
+    for kernels, stem in ((("pf_split_kernel",), "r01_prefilter_config3"), (("sw_kernel<",), "r01_sw_config2"),
+                          (("pf_split_kernel",), "r02_search"), (("sw_kernel<", "sw_rev_multi_kernel"), "r02_search")):
+        t = bench.pmc_traffic(kernels, stem)
+        assert t is not None and t > 1e9, (kernels, t)
