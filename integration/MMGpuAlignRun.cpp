@@ -126,7 +126,9 @@ bool MMGpuAlignRun::usable(const Alignment &a) {
 bool MMGpuAlignRun::run(Alignment &al, const std::string &outDB, const std::string &outDBIndex, const size_t dbFrom,
                         const size_t dbSize, bool merge) {
     if (!usable(al)) return false;
+    MMGpuStopwatch watch("align");
     mmgpu_ctx *gpu = MMGpuRun::context();     // EXITs with the library's message if no device can be opened
+    watch.lap("open device");
 
     int dbtype = Parameters::DBTYPE_ALIGNMENT_RES;
     if (al.alignmentOutputMode == Parameters::ALIGNMENT_OUTPUT_CLUSTER) {
@@ -171,6 +173,7 @@ bool MMGpuAlignRun::run(Alignment &al, const std::string &outDB, const std::stri
         EXIT(EXIT_FAILURE);
     }
 
+    watch.lap("map + upload targets");
     MMGpuAlignBackend *backend = mmgpuNewDeviceBackend(gpu);
     MMGpuMatcher gpuMatcher(backend, al.m, &evaluer, al.compBiasCorrection, al.compBiasCorrectionScale, al.gapOpen, al.gapExtend);
     const size_t maxMatcherSeqLen = std::max(al.tdbr->getMaxSeqLen(), al.qdbr->getMaxSeqLen());
@@ -281,13 +284,13 @@ bool MMGpuAlignRun::run(Alignment &al, const std::string &outDB, const std::stri
         }
 
         // ---- one device call for the block
-        if (getenv("MMGPU_TRACE")) fprintf(stderr, "[mmgpu align] block of %zu queries parsed\n", nq);
+        watch.lap("parse block");
         blockHook.newBlock();
         if (!gpuMatcher.alignBlock(block, al.covMode, al.covThr, al.evalThr, al.swMode, al.seqIdMode, results, &refused)) {
             Debug(Debug::ERROR) << "MMGPU: " << gpuMatcher.error() << "\n";
             EXIT(EXIT_FAILURE);
         }
-        if (getenv("MMGPU_TRACE")) fprintf(stderr, "[mmgpu align] block aligned, %zu backtraces handed back to the host\n", refused.size());
+        watch.lap("alignBlock");
         // pairs whose backtrace the device declined (band storage above its budget): the reference's own call
         for (size_t r = 0; r < refused.size(); r++) {
             const size_t b = refused[r].first;
@@ -362,6 +365,7 @@ bool MMGpuAlignRun::run(Alignment &al, const std::string &outDB, const std::stri
                 swResults.clear();
             }
         }
+        watch.lap("accept / sort / write");
         next = blockEnd;
         if (remap && next < end) al.prefdbr->remapData();
     }

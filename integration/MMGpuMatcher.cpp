@@ -1,4 +1,5 @@
 #include "MMGpuMatcher.h"
+#include "MMGpuRun.h"
 
 #include <algorithm>
 #include <climits>
@@ -68,6 +69,7 @@ bool MMGpuMatcher::alignBlock(const std::vector<Query> &queries, int covMode, fl
     std::vector<std::vector<uint32_t> > ids(nq);
     std::vector<mmgpu_sw_query> dq(nq);
     std::vector<size_t> firstPair(nq + 1, 0);
+    MMGpuStopwatch watch("matcher");
 #pragma omp parallel for schedule(dynamic, 16) num_threads(nthreads)
     for (size_t q = 0; q < nq; q++) {
         const Query &qu = queries[q];
@@ -90,7 +92,7 @@ bool MMGpuMatcher::alignBlock(const std::vector<Query> &queries, int covMode, fl
         // (a query with an empty prefilter list is never mapped, Alignment.cpp:322: nothing to align, no threshold)
         dq[q].min_start_score = (alignmentMode == Matcher::SCORE_ONLY || qu.L <= 0 || ids[q].empty()) ? 0 : minScoreForEvalue(evalThr, qu.L);
     }
-    if (getenv("MMGPU_TRACE")) fprintf(stderr, "[mmgpu matcher] composition bias done\n");
+    watch.lap("composition bias + thresholds");
     for (size_t q = 0; q < nq; q++) firstPair[q + 1] = firstPair[q] + ids[q].size();
     const size_t total = firstPair[nq];
     mmgpu_sw_params par;
@@ -105,7 +107,7 @@ bool MMGpuMatcher::alignBlock(const std::vector<Query> &queries, int covMode, fl
         return false;
     }
 
-    if (getenv("MMGPU_TRACE")) fprintf(stderr, "[mmgpu matcher] device alignment returned\n");
+    watch.lap("device alignment (prepare, run, fetch)");
     // ---- host part of ssw_align_private (StripedSmithWaterman.cpp:846-890) per pair; pairs that go on to the
     // backtrace are collected for one traceback call
     std::vector<Pending> aln(total);
@@ -170,7 +172,7 @@ bool MMGpuMatcher::alignBlock(const std::vector<Query> &queries, int covMode, fl
             p++;
         }
     }
-    if (getenv("MMGPU_TRACE")) fprintf(stderr, "[mmgpu matcher] %zu pairs aligned on the device, gates + block hook done\n", total);
+    watch.lap("E-value / coverage gates + block hook");
     std::vector<uint32_t> btPairs;
     for (size_t p = 0; p < total; p++)
         if (aln[p].wantsBacktrace) btPairs.push_back((uint32_t)p);
@@ -180,7 +182,7 @@ bool MMGpuMatcher::alignBlock(const std::vector<Query> &queries, int covMode, fl
         err = backend->lastError();
         return false;
     }
-    if (getenv("MMGPU_TRACE")) fprintf(stderr, "[mmgpu matcher] %zu backtraces returned\n", btPairs.size());
+    watch.lap("device traceback");
     std::vector<int> btOf(total, -1);
     for (size_t i = 0; i < btPairs.size(); i++) btOf[btPairs[i]] = (int)i;
 
@@ -257,6 +259,7 @@ bool MMGpuMatcher::alignBlock(const std::vector<Query> &queries, int covMode, fl
                                                    origQueryLen, dbStartPos, dbEndPos, tg.length, backtrace));
         }
     }
+    watch.lap("result_t records");
     if (refused) {
         // MMGPU_BT_TOO_LARGE / MMGPU_BT_FAILED: the caller runs Matcher::getSWResult for these pairs
         if (refusedPairs == NULL) {

@@ -1,4 +1,5 @@
 #include "MMGpuPrefilter.h"
+#include "MMGpuRun.h"
 
 #include <climits>
 
@@ -33,8 +34,7 @@ bool MMGpuPrefilter::loadIndex(IndexTable *indexTable, SequenceLookup *sequenceL
     std::vector<int8_t> ungapped(a * a);
     for (int i = 0; i < a; i++)
         for (int j = 0; j < a; j++) ungapped[i * a + j] = (int8_t)ungappedSubMat->subMatrix[i][j];
-    std::vector<uint64_t> tableOffsets(indexTable->getTableSize() + 1);
-    for (size_t i = 0; i <= indexTable->getTableSize(); i++) tableOffsets[i] = indexTable->getOffsets()[i];
+    static_assert(sizeof(size_t) == sizeof(uint64_t), "IndexTable::getOffsets() is handed over as it is");
     mmgpu_pf_index ix;
     memset(&ix, 0, sizeof(ix));
     ix.kmer_size = indexTable->getKmerSize();
@@ -47,7 +47,7 @@ bool MMGpuPrefilter::loadIndex(IndexTable *indexTable, SequenceLookup *sequenceL
     ix.score2 = twoMer.isValid() ? twoMer.score : NULL;
     ix.index2 = twoMer.isValid() ? twoMer.index : NULL;
     ix.row2 = twoMer.isValid() ? twoMer.rowSize : 0;
-    ix.offsets = tableOffsets.data();
+    ix.offsets = reinterpret_cast<const uint64_t *>(indexTable->getOffsets());       // tableSize + 1 entries
     ix.entries6 = indexTable->getEntries();            // packed 6-byte IndexEntryLocal records
     ix.n_entries = indexTable->getTableEntriesNum();
     ix.ungapped_mat = ungapped.data();
@@ -96,11 +96,16 @@ bool MMGpuPrefilter::matchBlock(const std::vector<Query> &queries, int kmerThr, 
     std::vector<uint32_t> counts(nq);
     std::vector<int32_t> status(nq);
     mmgpu_pf_batch_t *batch = NULL;
+    MMGpuStopwatch watch("prefilter block");
+    watch.lap("composition bias");
     int rc = mmgpu_pf_prepare(gpu, &par, dq.data(), (uint32_t)nq, &batch);
+    watch.lap("mmgpu_pf_prepare");
     if (rc == 0) rc = mmgpu_pf_run(gpu, batch);
     if (stats) stats->assign(nq, mmgpu_pf_qstat());
     if (rc == 0) rc = mmgpu_pf_fetch(gpu, batch, hits.data(), stride, counts.data(), status.data(), stats ? stats->data() : NULL);
+    watch.lap("mmgpu_pf_run + fetch");
     if (batch) mmgpu_pf_free(gpu, batch);
+    watch.lap("mmgpu_pf_free");
     if (rc != 0) {
         err = mmgpu_last_error();
         return false;

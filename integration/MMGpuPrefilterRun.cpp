@@ -62,7 +62,9 @@ bool MMGpuPrefilterRun::run(Prefiltering &p, DBWriter &tmpDbw, size_t dbFrom, si
                             char *notEmpty, std::list<int> **reslens, size_t localThreads, Debug::Progress &progress,
                             MMGpuPrefilterStats &st) {
     if (!usable(p)) return false;
+    MMGpuStopwatch watch("prefilter");
     mmgpu_ctx *gpu = MMGpuRun::context();
+    watch.lap("open device");
     MMGpuPrefilter device(gpu, p.kmerSubMat, p.ungappedSubMat, p.aaBiasCorrection, p.aaBiasCorrectionScale);
     const bool profileQuery = Parameters::isEqualDbtype(p.querySeqType, Parameters::DBTYPE_HMM_PROFILE);
     // The library's index hand-over carries the 3-mer / 2-mer score tables of sequence queries; Prefiltering only builds
@@ -83,6 +85,7 @@ bool MMGpuPrefilterRun::run(Prefiltering &p, DBWriter &tmpDbw, size_t dbFrom, si
         Debug(Debug::ERROR) << "MMGPU: " << device.error() << "\n";
         EXIT(EXIT_FAILURE);
     }
+    watch.lap("hand over targets + index");
     if (local3.isValid()) ExtendedSubstitutionMatrix::freeScoreMatrix(local3);     // the library copied the tables
     if (local2.isValid()) ExtendedSubstitutionMatrix::freeScoreMatrix(local2);
     const size_t maxBlockQueries = MMGpuRun::envSize("MMGPU_PREF_BLOCK_QUERIES", 2048);
@@ -101,6 +104,7 @@ bool MMGpuPrefilterRun::run(Prefiltering &p, DBWriter &tmpDbw, size_t dbFrom, si
     size_t dbMatches = 0, doubleMatches = 0, querySeqLenSum = 0, resSize = 0, diagonalOverflow = 0;
 
     for (size_t next = queryFrom; next < queryFrom + querySize;) {
+        const double tBlock0 = watch.now();
         const size_t nq = std::min(maxBlockQueries, queryFrom + querySize - next);
         queryNum.assign(nq, std::vector<unsigned char>());
         queryProfScore.assign(nq, std::vector<short>());
@@ -153,10 +157,14 @@ bool MMGpuPrefilterRun::run(Prefiltering &p, DBWriter &tmpDbw, size_t dbFrom, si
             }
         }
 
+        const double tBlock1 = watch.now();
+        watch.add(0, tBlock1 - tBlock0);
         if (!device.matchBlock(block, p.kmerThr, p.maxResListLen, p.minDiagScoreThr, results, needsCpu, &qstats)) {
             Debug(Debug::ERROR) << "MMGPU: " << device.error() << "\n";
             EXIT(EXIT_FAILURE);
         }
+        const double tBlock2 = watch.now();
+        watch.add(1, tBlock2 - tBlock1);
 
 #pragma omp parallel num_threads(localThreads)
         {
@@ -239,6 +247,11 @@ bool MMGpuPrefilterRun::run(Prefiltering &p, DBWriter &tmpDbw, size_t dbFrom, si
             }
         }
         next += nq;
+        watch.add(2, watch.now() - tBlock2);
+    }
+    {
+        static const char *const names[3] = {"map queries", "device block (bias, prepare, run, fetch)", "serialise + write"};
+        watch.report(names, 3);
     }
     for (size_t i = 0; i < localThreads; i++) {
         delete seqs[i];

@@ -56,4 +56,19 @@ public:
                     MMGpuPrefilterStats &stats);
 };
 
+// MMGPU_TRACE=1: where the wall time of a hooked module goes (stderr), e.g. "[mmgpu prefilter] load index 1.234 s"
+class MMGpuStopwatch {
+public:
+    explicit MMGpuStopwatch(const char *module);
+    void lap(const char *what);          // time since the previous lap
+    void add(int slot, double s) { acc[slot] += s; }
+    double now() const;
+    void report(const char *const *names, int n);
+private:
+    const char *module;
+    bool on;
+    double last;
+    double acc[8];
+};
+
 #endif

@@ -106,11 +106,15 @@ extern "C" int mmgpu_load_targets(mmgpu_ctx *c, const uint8_t *residues, const u
     }
     const size_t bytes = (size_t)cur4 * 4 + max_len + 64;
     std::vector<uint8_t> packed(bytes, (uint8_t)alphabet);   // padding = the "no letter" code
-    for (uint32_t i = 0; i < n; i++) {
-        for (uint64_t k = offsets[i]; k < offsets[i + 1]; k++)
-            if (residues[k] >= alphabet) return fail(MMGPU_ERR_ARG, "mmgpu_load_targets: residue code >= alphabet");
-        memcpy(packed.data() + (size_t)off4[i] * 4, residues + offsets[i], len[i]);
-    }
+    std::atomic<bool> bad_res(false);
+    parallel_for((size_t)n, [&](size_t a, size_t b) {
+        for (size_t i = a; i < b; i++) {
+            for (uint64_t k = offsets[i]; k < offsets[i + 1]; k++)
+                if (residues[k] >= alphabet) bad_res = true;
+            memcpy(packed.data() + (size_t)off4[i] * 4, residues + offsets[i], len[i]);
+        }
+    });
+    if (bad_res) return fail(MMGPU_ERR_ARG, "mmgpu_load_targets: residue code >= alphabet");
     DeviceDb db;
 #define DB_TRY(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { free_db(db); return fail(MMGPU_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__)); } } while (0)
     DB_TRY(hipMalloc((void **)&db.res, bytes));

@@ -11,6 +11,8 @@
 #include <map>
 #include <memory>
 #include <vector>
+#include <thread>
+#include <atomic>
 
 #include "../../include/mmgpu.h"
 #include "nucl_core.h"
@@ -395,6 +397,28 @@ struct BtLaunch {
 
 hipError_t launch_sw_traceback(const BtLaunch &L, hipStream_t stream);
 hipError_t launch_sw_traceback_wave(const BtLaunch &L, hipStream_t stream);
+
+// host-side loops over targets / index entries / queries: plain std::thread chunks (the library carries no OpenMP runtime)
+inline unsigned host_threads() {
+    unsigned n = std::thread::hardware_concurrency();
+    return n == 0 ? 1 : std::min(n, 64u);
+}
+
+template <typename F>
+inline void parallel_for(size_t n, F f) {
+    const unsigned nt = (unsigned)std::min<size_t>(host_threads(), std::max<size_t>(n, 1));
+    if (nt <= 1 || n < 4096) {
+        f((size_t)0, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    const size_t chunk = (n + nt - 1) / nt;
+    for (unsigned t = 0; t < nt; t++) {
+        const size_t a = std::min(n, (size_t)t * chunk), b = std::min(n, a + chunk);
+        if (a < b) th.emplace_back([=] { f(a, b); });
+    }
+    for (auto &x : th) x.join();
+}
 
 // ---------------------------------------------------------------------------------------------------------
 // host-side plumbing shared by mmgpu_api.hip and pf_api.hip

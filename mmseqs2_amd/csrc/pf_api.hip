@@ -56,27 +56,6 @@ static int window_pattern(int k, int spaced, uint8_t *pat) {     // k in [4, 15]
     return n;
 }
 
-static unsigned host_threads() {
-    unsigned n = std::thread::hardware_concurrency();
-    return n == 0 ? 1 : std::min(n, 64u);
-}
-
-template <typename F>
-static void parallel_for(size_t n, F f) {
-    const unsigned nt = (unsigned)std::min<size_t>(host_threads(), std::max<size_t>(n, 1));
-    if (nt <= 1) {
-        f(0, n);
-        return;
-    }
-    std::vector<std::thread> th;
-    const size_t chunk = (n + nt - 1) / nt;
-    for (unsigned t = 0; t < nt; t++) {
-        const size_t a = std::min(n, (size_t)t * chunk), b = std::min(n, a + chunk);
-        if (a < b) th.emplace_back([=] { f(a, b); });
-    }
-    for (auto &x : th) x.join();
-}
-
 // ---------------------------------------------------------------------------------------------------------
 // ExtendedSubstitutionMatrix::calcScoreMatrix (src/prefiltering/ExtendedSubstitutionMatrix.cpp:20-71).  Row r lists
 // every span-mer by descending score; the reference uses std::stable_sort over the cartesian-product enumeration
@@ -323,10 +302,14 @@ static int pf_setup(mmgpu_ctx *c, const mmgpu_pf_index *ix, bool from_host, PfIn
     if (from_host) {
         {
             std::vector<uint32_t> off32(P->table + 1);
-            for (uint64_t z = 0; z <= P->table; z++) {
-                if (ix->offsets[z] > ix->n_entries || (z && ix->offsets[z] < ix->offsets[z - 1])) { delete P; return fail(MMGPU_ERR_ARG, "mmgpu_pf_load_index: offsets not monotone / out of range"); }
-                off32[z] = (uint32_t)ix->offsets[z];
-            }
+            std::atomic<bool> bad_off(false);
+            parallel_for((size_t)P->table + 1, [&](size_t a, size_t b) {
+                for (size_t z = a; z < b; z++) {
+                    if (ix->offsets[z] > ix->n_entries || (z && ix->offsets[z] < ix->offsets[z - 1])) bad_off = true;
+                    off32[z] = (uint32_t)ix->offsets[z];
+                }
+            });
+            if (bad_off) { delete P; return fail(MMGPU_ERR_ARG, "mmgpu_pf_load_index: offsets not monotone / out of range"); }
             P_TRY(upload(P->d_offsets, off32, nullptr));
             P_TRY(hipDeviceSynchronize());
         }
@@ -334,19 +317,24 @@ static int pf_setup(mmgpu_ctx *c, const mmgpu_pf_index *ix, bool from_host, PfIn
             const size_t ne = (size_t)ix->n_entries;
             std::vector<uint64_t> ent(std::max<size_t>(ne, 1));
             const uint8_t *e6 = (const uint8_t *)ix->entries6;
-            for (size_t e = 0; e < ne; e++) {
-                uint32_t id;
-                uint16_t pj;
-                if (ix->entry_ids) {
-                    id = ix->entry_ids[e];
-                    pj = ix->entry_pos[e];
-                } else {
-                    memcpy(&id, e6 + e * 6, 4);
-                    memcpy(&pj, e6 + e * 6 + 4, 2);
+            std::atomic<bool> bad_ent(false);
+            const uint32_t ntargets = c->db.n;
+            parallel_for(ne, [&](size_t a, size_t b) {
+                for (size_t e = a; e < b; e++) {
+                    uint32_t id;
+                    uint16_t pj;
+                    if (ix->entry_ids) {
+                        id = ix->entry_ids[e];
+                        pj = ix->entry_pos[e];
+                    } else {
+                        memcpy(&id, e6 + e * 6, 4);
+                        memcpy(&pj, e6 + e * 6 + 4, 2);
+                    }
+                    if (id >= ntargets) bad_ent = true;
+                    ent[e] = (uint64_t)id | ((uint64_t)pj << 32);
                 }
-                if (id >= c->db.n) { delete P; return fail(MMGPU_ERR_ARG, "mmgpu_pf_load_index: index entry names a target that is not loaded"); }
-                ent[e] = (uint64_t)id | ((uint64_t)pj << 32);
-            }
+            });
+            if (bad_ent) { delete P; return fail(MMGPU_ERR_ARG, "mmgpu_pf_load_index: index entry names a target that is not loaded"); }
             P_TRY(upload(P->d_entries, ent, nullptr));
             P_TRY(hipDeviceSynchronize());
         }
