@@ -58,6 +58,43 @@ bool MMGpuPrefilter::loadIndex(IndexTable *indexTable, SequenceLookup *sequenceL
     return true;
 }
 
+bool MMGpuPrefilter::buildIndex(SequenceLookup *sequenceLookup, int kmerSize, int indexKmerThr, ScoreMatrix &threeMer,
+                                ScoreMatrix &twoMer, bool spacedKmer) {
+    const size_t n = sequenceLookup->getSequenceCount();
+    static_assert(sizeof(size_t) == sizeof(uint64_t), "SequenceLookup::getOffsets() is handed over as it is");
+    if (mmgpu_load_targets(gpu, reinterpret_cast<const uint8_t *>(sequenceLookup->getData()),
+                           reinterpret_cast<const uint64_t *>(sequenceLookup->getOffsets()), (uint32_t)n, kmerSubMat->alphabetSize) != 0) {
+        err = mmgpu_last_error();
+        return false;
+    }
+    dbSize = n;
+    const int a = ungappedSubMat->alphabetSize;
+    std::vector<int8_t> ungapped(a * a);
+    std::vector<int16_t> kmer16(a * a);
+    for (int i = 0; i < a; i++)
+        for (int j = 0; j < a; j++) {
+            ungapped[i * a + j] = (int8_t)ungappedSubMat->subMatrix[i][j];
+            kmer16[i * a + j] = (int16_t)kmerSubMat->subMatrix[i][j];
+        }
+    mmgpu_pf_index ix;
+    memset(&ix, 0, sizeof(ix));
+    ix.kmer_size = kmerSize;
+    ix.alphabet = kmerSubMat->alphabetSize;
+    ix.spaced = spacedKmer ? 1 : 0;
+    ix.score3 = threeMer.isValid() ? threeMer.score : NULL;
+    ix.index3 = threeMer.isValid() ? threeMer.index : NULL;
+    ix.row3 = threeMer.isValid() ? threeMer.rowSize : 0;
+    ix.score2 = twoMer.isValid() ? twoMer.score : NULL;
+    ix.index2 = twoMer.isValid() ? twoMer.index : NULL;
+    ix.row2 = twoMer.isValid() ? twoMer.rowSize : 0;
+    ix.ungapped_mat = ungapped.data();
+    if (mmgpu_pf_build_index(gpu, &ix, kmer16.data(), indexKmerThr) != 0) {
+        err = mmgpu_last_error();
+        return false;
+    }
+    return true;
+}
+
 bool MMGpuPrefilter::matchBlock(const std::vector<Query> &queries, int kmerThr, size_t maxResListLen, unsigned int minDiagScoreThr,
                                 std::vector<std::vector<hit_t> > &results, std::vector<bool> &needsCpu,
                                 std::vector<mmgpu_pf_qstat> *stats) {

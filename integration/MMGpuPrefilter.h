@@ -49,6 +49,11 @@ public:
                     std::vector<std::vector<hit_t> > &results, std::vector<bool> &needsCpu,
                     std::vector<mmgpu_pf_qstat> *stats = NULL);
 
+    // the same hand-over without a host index: the index is built on the device from the (masked) SequenceLookup with the
+    // k-mer threshold IndexBuilder::fillDatabase would have used (IndexTable.h:146-154); tables may be invalid (exact k-mers)
+    bool buildIndex(SequenceLookup *sequenceLookup, int kmerSize, int indexKmerThr, ScoreMatrix &threeMer, ScoreMatrix &twoMer,
+                    bool spacedKmer);
+
     // takeOnlyBestKmer (--exact-kmer-matching; every nucleotide search) / nucleotide target database (matchQuery's isNucleotide)
     void setMode(bool exactKmer, bool nucleotide) {
         exactKmerMatching = exactKmer;

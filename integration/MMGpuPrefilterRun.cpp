@@ -19,7 +19,9 @@
 
 #include "DBWriter.h"
 #include "ExtendedSubstitutionMatrix.h"
+#include "IndexBuilder.h"
 #include "Debug.h"
+#include "Parameters.h"
 #include "Prefiltering.h"
 #include "QueryMatcher.h"
 #include "Util.h"
@@ -31,7 +33,9 @@
 #include <omp.h>
 #endif
 
-bool MMGpuPrefilterRun::usable(Prefiltering &p) {
+bool MMGpuPrefilterRun::usable(Prefiltering &p) { return usableConfig(p, true); }
+
+bool MMGpuPrefilterRun::usableConfig(Prefiltering &p, bool indexExists) {
     if (!MMGpuRun::enabled()) return false;
     const bool profileQuery = Parameters::isEqualDbtype(p.querySeqType, Parameters::DBTYPE_HMM_PROFILE);
     const bool nucl = Parameters::isEqualDbtype(p.querySeqType, Parameters::DBTYPE_NUCLEOTIDES) &&
@@ -40,7 +44,7 @@ bool MMGpuPrefilterRun::usable(Prefiltering &p) {
                     Parameters::isEqualDbtype(p.targetSeqType, Parameters::DBTYPE_AMINO_ACIDS);
     const char *why = NULL;
     if (!aa && !nucl) why = "profile targets / mixed database types";
-    else if (p.indexTable == NULL || p.sequenceLookup == NULL) why = "no index table / sequence lookup in memory";
+    else if (indexExists && (p.indexTable == NULL || p.sequenceLookup == NULL)) why = "no index table / sequence lookup in memory";
     else if (nucl && !p.takeOnlyBestKmer) why = "nucleotide search without exact k-mer matching";
     else if (profileQuery && p.takeOnlyBestKmer) why = "exact k-mer matching with profile queries";
     else if (!p.takeOnlyBestKmer && !profileQuery && (!p._3merSubMatrix.isValid() || !p._2merSubMatrix.isValid())) why = "no similar-k-mer score matrices";
@@ -49,13 +53,38 @@ bool MMGpuPrefilterRun::usable(Prefiltering &p) {
     else if (p.takeOnlyBestKmer ? (p.kmerSize < 4 || p.kmerSize > 15) : (p.kmerSize != 6 && p.kmerSize != 7)) why = "k-mer size not covered (6 / 7; 4..15 with exact k-mer matching)";
     else if (p.spacedKmerPattern.empty() == false) why = "user-defined spaced k-mer pattern";
     else if (p.ungappedSubMatAux != NULL) why = "auxiliary ungapped matrix";
-    else if (p.taxonomyHook != NULL) why = "taxonomy filter";
+    // (the constructor creates the taxonomy hook after it built the index: before that the parameter says whether it will)
+    else if (indexExists ? p.taxonomyHook != NULL : Parameters::getInstance().taxonList.length() > 0) why = "taxonomy filter";
     else if (p.maxResListLen > MMGPU_PF_MAX_HITS) why = "--max-seqs above the device limit";
     if (why != NULL) {
         Debug(Debug::INFO) << "MMGPU: prefilter configuration not covered by the device path (" << why << "), using the CPU path\n";
         return false;
     }
     return true;
+}
+
+bool MMGpuPrefilterRun::deviceBuildsIndex(Prefiltering &p) {
+    if (getenv("MMGPU_HOST_INDEX") != NULL && getenv("MMGPU_HOST_INDEX")[0] == '1') return false;
+    if (p.templateDBIsIndex) return false;
+    // the same conditions run() will check at the seam, on what is known before the index exists
+    const bool ok = usableConfig(p, false);
+    if (ok) Debug(Debug::INFO) << "MMGPU: the k-mer index will be built on the device (MMGPU_HOST_INDEX=1 keeps the host's)\n";
+    return ok;
+}
+
+void MMGpuPrefilterRun::ensureHostIndex(Prefiltering &p, size_t dbFrom, size_t dbSize) {
+    if (!p.mmgpuDeviceIndex) return;
+    // IndexBuilder::fillDatabase as Prefiltering::getIndexTable calls it (:564-569); it also fills a second SequenceLookup,
+    // which replaces the first (same content)
+    Debug(Debug::INFO) << "MMGPU: building the host index for queries handed back by the device\n";
+    Sequence tseq(p.maxSeqLen, p.targetSeqType, p.kmerSubMat, p.kmerSize, p.spacedKmer, p.aaBiasCorrection, true, p.spacedKmerPattern);
+    SequenceLookup *second = NULL;
+    IndexBuilder::fillDatabase(p.indexTable, &second, *p.kmerSubMat, p._3merSubMatrix, p._2merSubMatrix, &tseq, p.tdbr, dbFrom,
+                               dbFrom + dbSize, p.mmgpuIndexKmerThr, p.maskMode, p.maskLowerCaseMode, p.maskProb, p.maskNrepeats,
+                               p.targetSearchMode);
+    delete p.sequenceLookup;
+    p.sequenceLookup = second;
+    p.mmgpuDeviceIndex = false;
 }
 
 bool MMGpuPrefilterRun::run(Prefiltering &p, DBWriter &tmpDbw, size_t dbFrom, size_t dbSize, size_t queryFrom, size_t querySize,
@@ -81,11 +110,13 @@ bool MMGpuPrefilterRun::run(Prefiltering &p, DBWriter &tmpDbw, size_t dbFrom, si
     device.setMode(p.takeOnlyBestKmer, nuclSearch);
     ScoreMatrix &three = local3.isValid() ? local3 : p._3merSubMatrix;
     ScoreMatrix &two = local2.isValid() ? local2 : p._2merSubMatrix;
-    if (!device.loadIndex(p.indexTable, p.sequenceLookup, three, two, p.spacedKmer)) {
+    const bool handedOver = p.mmgpuDeviceIndex ? device.buildIndex(p.sequenceLookup, p.kmerSize, p.mmgpuIndexKmerThr, three, two, p.spacedKmer)
+                                               : device.loadIndex(p.indexTable, p.sequenceLookup, three, two, p.spacedKmer);
+    if (!handedOver) {
         Debug(Debug::ERROR) << "MMGPU: " << device.error() << "\n";
         EXIT(EXIT_FAILURE);
     }
-    watch.lap("hand over targets + index");
+    watch.lap(p.mmgpuDeviceIndex ? "hand over targets, build the index on the device" : "hand over targets + index");
     if (local3.isValid()) ExtendedSubstitutionMatrix::freeScoreMatrix(local3);     // the library copied the tables
     if (local2.isValid()) ExtendedSubstitutionMatrix::freeScoreMatrix(local2);
     const size_t maxBlockQueries = MMGpuRun::envSize("MMGPU_PREF_BLOCK_QUERIES", 2048);
@@ -163,6 +194,11 @@ bool MMGpuPrefilterRun::run(Prefiltering &p, DBWriter &tmpDbw, size_t dbFrom, si
             Debug(Debug::ERROR) << "MMGPU: " << device.error() << "\n";
             EXIT(EXIT_FAILURE);
         }
+        for (size_t b = 0; b < nq; b++)
+            if (needsCpu[b]) {      // the reference's matcher needs the reference's index
+                ensureHostIndex(p, dbFrom, dbSize);
+                break;
+            }
         const double tBlock2 = watch.now();
         watch.add(1, tBlock2 - tBlock1);
 

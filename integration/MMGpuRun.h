@@ -49,6 +49,13 @@ struct MMGpuPrefilterStats {
 class MMGpuPrefilterRun {
 public:
     static bool usable(Prefiltering &p);
+    static bool usableConfig(Prefiltering &p, bool indexExists);
+    // Prefiltering::getIndexTable asks before it builds the index: true = the device will build it from the masked
+    // SequenceLookup (mmgpu_pf_build_index), the host only masks (IndexBuilder::fillDatabase without an index table);
+    // MMGPU_HOST_INDEX=1 keeps the host's index
+    static bool deviceBuildsIndex(Prefiltering &p);
+    // the reference's own index for queries the device hands back (overflow, long sequences, ties), built when first needed
+    static void ensureHostIndex(Prefiltering &p, size_t dbFrom, size_t dbSize);
     // the `omp parallel` block of Prefiltering::runSplit (:820-918): writes every query's entry to tmpDbw, fills the
     // statistics the caller prints
     static bool run(Prefiltering &p, DBWriter &tmpDbw, size_t dbFrom, size_t dbSize, size_t queryFrom, size_t querySize,

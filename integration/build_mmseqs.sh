@@ -4,7 +4,7 @@
 #   oracle/_ref/mmseqs_stock   the reference as shipped (CPU, AVX2), the Rust block-aligner crate replaced by the
 #                              generated do-nothing stubs of oracle/gen_block_stub.py (no rustc in this image; the
 #                              reference then takes its own Smith-Waterman fallback)
-#   oracle/_ref/mmseqs_mmgpu   the same tree + integration/mmseqs_mmgpu.patch (7 hunks, all under #ifdef HAVE_MMGPU),
+#   oracle/_ref/mmseqs_mmgpu   the same tree + integration/mmseqs_mmgpu.patch (7 files, every change under #ifdef HAVE_MMGPU),
 #                              integration/*.cpp compiled in, linked against mmseqs2_amd/lib/libmmgpu.so
 #
 # Both are checkers / demonstrators of the drop-in (tests/test_mmseqs_dropin.py diffs their result DBs); they are git-ignored

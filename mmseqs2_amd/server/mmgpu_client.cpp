@@ -167,6 +167,39 @@ int mmgpu_pf_load_index(mmgpu_ctx *c, const mmgpu_pf_index *ix) {
     return call(c, OP_LOAD_INDEX, q, nullptr);
 }
 
+// the index built on the device from the resident targets (the hook's default): resident already if this database, these
+// tables and this threshold were seen before
+int mmgpu_pf_build_index(mmgpu_ctx *c, const mmgpu_pf_index *ix, const int16_t *kmer_submat, int kmer_thr) {
+    if (!c || !ix || !kmer_submat || !ix->ungapped_mat) return fail(MMGPU_ERR_ARG, "mmgpu_pf_build_index: NULL argument");
+    const size_t kalph = (size_t)ix->alphabet - 1;
+    const size_t n3 = kalph * kalph * kalph, n2 = kalph * kalph, a2 = (size_t)ix->alphabet * ix->alphabet;
+    const bool three = ix->score3 && ix->index3, two = ix->score2 && ix->index2;
+    uint64_t fp = c->targets_fp ^ 0x6275696C64212121ull;
+    const int32_t scal[6] = {ix->kmer_size, ix->alphabet, ix->spaced, three ? 1 : 0, two ? 1 : 0, kmer_thr};
+    fp = fingerprint(scal, sizeof(scal), fp);
+    if (three) fp = fingerprint(ix->score3, n3 * ix->row3 * 2, fp);
+    fp = fingerprint(kmer_submat, a2 * 2, fp);
+    fp = fingerprint(ix->ungapped_mat, a2, fp);
+    Buf q, r;
+    q.put<uint64_t>(fp);
+    int rc = call(c, OP_HAS_INDEX, q, &r);
+    if (rc != MMGPU_OK) return rc;
+    if (r.get<uint32_t>()) return MMGPU_OK;
+    q.put<int32_t>(ix->kmer_size);
+    q.put<int32_t>(ix->alphabet);
+    q.put<int32_t>(ix->spaced);
+    q.put<int32_t>(kmer_thr);
+    q.put<uint64_t>((uint64_t)(three ? ix->row3 : 0));
+    q.put<uint64_t>((uint64_t)(two ? ix->row2 : 0));
+    q.put_bytes(three ? ix->score3 : nullptr, three ? n3 * ix->row3 * 2 : 0);
+    q.put_bytes(three ? ix->index3 : nullptr, three ? n3 * ix->row3 * 4 : 0);
+    q.put_bytes(two ? ix->score2 : nullptr, two ? n2 * ix->row2 * 2 : 0);
+    q.put_bytes(two ? ix->index2 : nullptr, two ? n2 * ix->row2 * 4 : 0);
+    q.put_bytes(kmer_submat, a2 * 2);
+    q.put_bytes(ix->ungapped_mat, a2);
+    return call(c, OP_BUILD_INDEX, q, nullptr);
+}
+
 // ---- prefilter ---------------------------------------------------------------------------------------------------
 int mmgpu_pf_prepare(mmgpu_ctx *c, const mmgpu_pf_params *p, const mmgpu_pf_query *qs, uint32_t nq, mmgpu_pf_batch_t **out) {
     if (!c || !p || !out || (!qs && nq)) return fail(MMGPU_ERR_ARG, "mmgpu_pf_prepare: NULL argument");

@@ -200,6 +200,42 @@ bool handle(Server &S, int fd, const WireHdr &h, Buf &in) {
             }
             return reply(fd, h.op, rc, out);
         }
+        case OP_BUILD_INDEX: {
+            const uint64_t fp = in.get<uint64_t>();
+            mmgpu_pf_index ix;
+            memset(&ix, 0, sizeof(ix));
+            ix.kmer_size = in.get<int32_t>();
+            ix.alphabet = in.get<int32_t>();
+            ix.spaced = in.get<int32_t>();
+            const int32_t kmer_thr = in.get<int32_t>();
+            ix.row3 = (size_t)in.get<uint64_t>();
+            ix.row2 = (size_t)in.get<uint64_t>();
+            size_t n = 0;
+            std::vector<int16_t> s3, s2, km;
+            std::vector<uint32_t> i3, i2;
+            const uint8_t *p;
+            p = in.get_bytes(&n); s3.resize(n / 2); if (n) memcpy(s3.data(), p, n);
+            p = in.get_bytes(&n); i3.resize(n / 4); if (n) memcpy(i3.data(), p, n);
+            p = in.get_bytes(&n); s2.resize(n / 2); if (n) memcpy(s2.data(), p, n);
+            p = in.get_bytes(&n); i2.resize(n / 4); if (n) memcpy(i2.data(), p, n);
+            p = in.get_bytes(&n); km.resize(n / 2); if (n) memcpy(km.data(), p, n);
+            const uint8_t *um = in.get_bytes(&n);
+            if (in.bad || km.empty()) return reply_err(fd, h.op, MMGPU_ERR_ARG, "mmgpu_server: malformed BUILD_INDEX");
+            ix.score3 = s3.empty() ? nullptr : s3.data();
+            ix.index3 = i3.empty() ? nullptr : i3.data();
+            ix.score2 = s2.empty() ? nullptr : s2.data();
+            ix.index2 = i2.empty() ? nullptr : i2.data();
+            ix.ungapped_mat = reinterpret_cast<const int8_t *>(um);
+            drop_batches(S);
+            S.slots[S.cur].have_index = false;
+            const int rc = mmgpu_pf_build_index(S.ctx, &ix, km.data(), kmer_thr);
+            if (rc == MMGPU_OK) {
+                S.slots[S.cur].have_index = true;
+                S.slots[S.cur].index_fp = fp;
+                S.st.index_uploads++;
+            }
+            return reply(fd, h.op, rc, out);
+        }
         case OP_PF_PREPARE: {
             const mmgpu_pf_params par = in.get<mmgpu_pf_params>();
             const uint32_t nq = in.get<uint32_t>();

@@ -30,7 +30,7 @@ enum Op : uint32_t {
     OP_HAS_TARGETS, OP_LOAD_TARGETS, OP_HAS_INDEX, OP_LOAD_INDEX,
     OP_PF_PREPARE, OP_PF_RUN, OP_PF_FETCH, OP_PF_FREE,
     OP_SW_PREPARE, OP_SW_RUN, OP_SW_FETCH, OP_SW_TRACEBACK, OP_SW_FREE,
-    OP_STATS, OP_SHUTDOWN
+    OP_BUILD_INDEX, OP_STATS, OP_SHUTDOWN
 };
 
 struct WireHdr {

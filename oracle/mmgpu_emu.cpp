@@ -279,6 +279,27 @@ int mmgpu_pf_load_index(mmgpu_ctx *c, const mmgpu_pf_index *ix) {
     return 0;
 }
 
+// IndexBuilder::fillDatabase's index from the resident (already masked) targets: the oracle's builder
+int mmgpu_pf_build_index(mmgpu_ctx *c, const mmgpu_pf_index *ix, const int16_t *kmer_submat, int kmer_thr) {
+    if (c->n == 0) return fail(MMGPU_ERR_STATE, "no targets");
+    mmgpu_pf_index full = *ix;
+    size_t nk = 1;
+    for (int i = 0; i < ix->kmer_size; i++) nk *= (size_t)(ix->alphabet - 1);
+    std::vector<uint64_t> off(nk + 1);
+    const uint64_t total = mmo_pf_index_build(c->tres.data(), c->toff.data(), c->n, kmer_submat, ix->alphabet, ix->kmer_size, ix->spaced,
+                                              kmer_thr, off.data(), NULL, NULL);
+    std::vector<uint32_t> ids(total + 1);
+    std::vector<uint16_t> pos(total + 1);
+    mmo_pf_index_build(c->tres.data(), c->toff.data(), c->n, kmer_submat, ix->alphabet, ix->kmer_size, ix->spaced, kmer_thr, off.data(),
+                       ids.data(), pos.data());
+    full.offsets = off.data();
+    full.entry_ids = ids.data();
+    full.entry_pos = pos.data();
+    full.entries6 = NULL;
+    full.n_entries = total;
+    return mmgpu_pf_load_index(c, &full);
+}
+
 int mmgpu_pf_prepare(mmgpu_ctx *c, const mmgpu_pf_params *p, const mmgpu_pf_query *qs, uint32_t nq, mmgpu_pf_batch_t **out) {
     if (!c->have_index) return fail(MMGPU_ERR_STATE, "no index");
     mmgpu_pf_batch_t *b = new mmgpu_pf_batch_t();
