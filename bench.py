@@ -277,6 +277,7 @@ def search_headline(args, gpu, torch, dist, rank, world, matrices, barrier):
     align_ms = allreduce(torch, dist, [float(np.mean(stat["align_ms"]))], "max")[0]
     pf_ms = allreduce(torch, dist, [float(np.mean(stat["pf_ms"]))], "max")[0]
     cells, pairs = allreduce(torch, dist, [stat["cells"], stat["pairs"]])
+    mem_free, mem_total = gpu.device_memory()     # after the timed steps: targets + index + every working buffer at its high-water mark
     step("keep")                                  # one more pass whose results are downloaded for the checks below
 
     # ---- per-stage counters of the prefilter (last pass) ----
@@ -285,7 +286,7 @@ def search_headline(args, gpu, torch, dist, rank, world, matrices, barrier):
     out = {"elapsed_s": elapsed, "align_ms": align_ms, "pf_ms": pf_ms, "cells": cells, "pairs": pairs, "nq": nq,
            "n_global": n_global, "n_local": gpu.n_targets, "kmer_thr": kmer_thr, "max_res": max_res, "stage": stage,
            "pf_cells": pf_cells, "pf_cands": pf_cands, "t_gen": t_gen, "t_index": t_index, "weak": weak, "sharded": sharded,
-           "thr_example": thr_of_len.get(len(qs[0]))}
+           "thr_example": thr_of_len.get(len(qs[0])), "hbm_in_use_gb": round((mem_total - mem_free) / 2 ** 30, 1)}
     if rank != 0:
         pfb.free()
         return out
@@ -661,6 +662,7 @@ def main():
               "stage_ms": {"kmers_lists": round(stage[0], 2), "gather_split": round(stage[1], 2), "replay_score_keepmax": round(stage[2], 2),
                            "large_bins_score": round(stage[3], 2), "large_bins_keepmax_and_overflow_path": round(stage[4], 2),
                            "select": round(stage[5], 2), "total": round(stage[6], 2)},
+              "hbm_in_use_gb_after_steps": H["hbm_in_use_gb"],
               "ungapped_cells": int(H["pf_cells"]), "double_diagonal_candidates": int(H["pf_cands"]), "prefilter_hits": int(H.get("nhits", 0))}
         if "ent" in H:
             ent = H["ent"]

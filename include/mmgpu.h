@@ -50,6 +50,9 @@ int mmgpu_set_stream(mmgpu_ctx *ctx, void *hip_stream);
 int mmgpu_synchronize(mmgpu_ctx *ctx);
 /* number of compute units / device name, for reports */
 int mmgpu_device_info(mmgpu_ctx *ctx, int *compute_units, char *name, int name_cap);
+/* free / total HBM of the context's device in bytes (hipMemGetInfo): what the caller sizes its query blocks against -
+ * the scratch arrays of a context grow to the largest batch it has seen and are kept until mmgpu_destroy */
+int mmgpu_device_memory(mmgpu_ctx *ctx, uint64_t *free_bytes, uint64_t *total_bytes);
 
 /* ---- host-side helpers (run on the CPU in the reference too) ------------------
  * SubstitutionMatrix::calcLocalAaBiasCorrection (src/commons/SubstitutionMatrix.cpp:79-112): float composition

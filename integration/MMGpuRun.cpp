@@ -40,25 +40,3 @@ mmgpu_ctx *MMGpuRun::context() {
     }
     return ctx;
 }
-
-#include <sys/time.h>
-#include <cstdio>
-
-double MMGpuStopwatch::now() const {
-    struct timeval tv;
-    gettimeofday(&tv, NULL);
-    return (double)tv.tv_sec + 1e-6 * (double)tv.tv_usec;
-}
-MMGpuStopwatch::MMGpuStopwatch(const char *module) : module(module), on(getenv("MMGPU_TRACE") != NULL), last(0) {
-    for (int i = 0; i < 8; i++) acc[i] = 0;
-    last = now();
-}
-void MMGpuStopwatch::lap(const char *what) {
-    const double t = now();
-    if (on) fprintf(stderr, "[mmgpu %s] %s %.3f s\n", module, what, t - last);
-    last = t;
-}
-void MMGpuStopwatch::report(const char *const *names, int n) {
-    if (!on) return;
-    for (int i = 0; i < n && i < 8; i++) fprintf(stderr, "[mmgpu %s] %s %.3f s (all blocks)\n", module, names[i], acc[i]);
-}

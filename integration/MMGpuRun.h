@@ -14,7 +14,11 @@
 #ifndef MMGPU_RUN_H
 #define MMGPU_RUN_H
 
+#include <sys/time.h>
+
 #include <cstddef>
+#include <cstdio>
+#include <cstdlib>
 #include <list>
 #include <string>
 
@@ -66,11 +70,25 @@ public:
 // MMGPU_TRACE=1: where the wall time of a hooked module goes (stderr), e.g. "[mmgpu prefilter] load index 1.234 s"
 class MMGpuStopwatch {
 public:
-    explicit MMGpuStopwatch(const char *module);
-    void lap(const char *what);          // time since the previous lap
+    explicit MMGpuStopwatch(const char *module) : module(module), on(getenv("MMGPU_TRACE") != NULL), last(0) {
+        for (int i = 0; i < 8; i++) acc[i] = 0;
+        last = now();
+    }
+    void lap(const char *what) {         // time since the previous lap
+        const double t = now();
+        if (on) fprintf(stderr, "[mmgpu %s] %s %.3f s\n", module, what, t - last);
+        last = t;
+    }
     void add(int slot, double s) { acc[slot] += s; }
-    double now() const;
-    void report(const char *const *names, int n);
+    double now() const {
+        struct timeval tv;
+        gettimeofday(&tv, NULL);
+        return (double)tv.tv_sec + 1e-6 * (double)tv.tv_usec;
+    }
+    void report(const char *const *names, int n) {
+        if (!on) return;
+        for (int i = 0; i < n && i < 8; i++) fprintf(stderr, "[mmgpu %s] %s %.3f s (all blocks)\n", module, names[i], acc[i]);
+    }
 private:
     const char *module;
     bool on;

@@ -65,7 +65,7 @@ SW_HIT_DTYPE = np.dtype([("score", np.int32), ("q_end", np.int32), ("t_end", np.
 # every symbol include/mmgpu.h declares (tests check the built library exports all of them)
 EXPORTED_SYMBOLS = [
     "mmgpu_init", "mmgpu_destroy", "mmgpu_last_error", "mmgpu_set_stream", "mmgpu_synchronize",
-    "mmgpu_device_info", "mmgpu_host_comp_bias", "mmgpu_host_round_comp_bias", "mmgpu_load_targets", "mmgpu_sw_batch", "mmgpu_sw_prepare", "mmgpu_sw_run",
+    "mmgpu_device_info", "mmgpu_device_memory", "mmgpu_host_comp_bias", "mmgpu_host_round_comp_bias", "mmgpu_load_targets", "mmgpu_sw_batch", "mmgpu_sw_prepare", "mmgpu_sw_run",
     "mmgpu_sw_fetch", "mmgpu_sw_batch_stats", "mmgpu_sw_last_kernel_ms", "mmgpu_sw_kernel_ms_mean", "mmgpu_sw_free",
     "mmgpu_sw_traceback", "mmgpu_sw_prepare_from_pf", "mmgpu_sw_fetch_device", "mmgpu_nucl_align",
     "mmgpu_host_score_matrix", "mmgpu_host_index_build", "mmgpu_pf_load_index", "mmgpu_pf_batch", "mmgpu_pf_prepare",
@@ -121,6 +121,7 @@ def load_library():
     L.mmgpu_set_stream.argtypes = [c_p, c_p]
     L.mmgpu_synchronize.argtypes = [c_p]
     L.mmgpu_device_info.argtypes = [c_p, ctypes.POINTER(ctypes.c_int), ctypes.c_char_p, ctypes.c_int]
+    L.mmgpu_device_memory.argtypes = [c_p, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
     L.mmgpu_host_comp_bias.argtypes = [c_p, c_p, ctypes.c_int, c_p, ctypes.c_uint32, ctypes.c_float, c_p]
     L.mmgpu_host_round_comp_bias.argtypes = [c_p, ctypes.c_uint32, c_p]
     L.mmgpu_load_targets.argtypes = [c_p, c_p, c_p, ctypes.c_uint32, ctypes.c_int]
@@ -405,6 +406,12 @@ class MMGpu:
         name = ctypes.create_string_buffer(256)
         self._check(self.L.mmgpu_device_info(self.ctx, ctypes.byref(cus), name, 256))
         return cus.value, name.value.decode()
+
+    def device_memory(self):
+        """(free, total) bytes of HBM on the context's device"""
+        f, t = ctypes.c_uint64(), ctypes.c_uint64()
+        self._check(self.L.mmgpu_device_memory(self.ctx, ctypes.byref(f), ctypes.byref(t)))
+        return f.value, t.value
 
     def load_targets(self, residues, offsets, alphabet=21):
         residues = np.ascontiguousarray(residues, np.uint8)

@@ -80,6 +80,16 @@ extern "C" int mmgpu_device_info(mmgpu_ctx *c, int *cus, char *name, int cap) {
     return MMGPU_OK;
 }
 
+extern "C" int mmgpu_device_memory(mmgpu_ctx *c, uint64_t *free_bytes, uint64_t *total_bytes) {
+    if (!c) return fail(MMGPU_ERR_ARG, "ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    size_t f = 0, t = 0;
+    HIP_TRY(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
+    return MMGPU_OK;
+}
+
 extern "C" int mmgpu_load_targets(mmgpu_ctx *c, const uint8_t *residues, const uint64_t *offsets, uint32_t n,
                                   int alphabet) {
     if (!c || !residues || !offsets) return fail(MMGPU_ERR_ARG, "mmgpu_load_targets: NULL argument");

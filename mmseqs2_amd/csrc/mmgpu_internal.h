@@ -191,7 +191,9 @@ struct PfSplitArgs {
 };
 
 struct PfDedupArgs {
-    uint32_t n_queries, bins;
+    uint32_t n_queries, bins;         // queries of this launch: q_first .. q_first + n_queries - 1 of the batch
+    uint32_t q_first;
+    uint32_t cand_origin;             // cand/surv hold the entries cand_origin .. of the batch (stage chunks, pf_api.hip)
     const uint32_t *q_tile_base, *q_ntiles;
     const uint64_t *split;
     const uint16_t *bin_off;
@@ -225,6 +227,7 @@ struct PfDedupArgs {
 };
 
 struct PfSelectArgs {
+    uint32_t q_first, cand_origin;    // as in PfDedupArgs
     const PfCand *surv;
     const uint32_t *cand_base;        // survivors of query q start at cand_base[q * bins]
     uint32_t bins;

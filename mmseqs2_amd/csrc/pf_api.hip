@@ -4,6 +4,7 @@
 
 #include <atomic>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 
@@ -482,7 +483,9 @@ struct mmgpu_pf_batch_t {
     // host mirrors of the last run
     std::vector<uint64_t> q_lists, q_entries;
     std::vector<int32_t> status;
-    hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // 5, 6: inside stage 2
+    hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // 5, 6: inside stage 2 (first chunk)
+    std::vector<hipEvent_t> chunk_ev;  // later stage chunks: after replay, after ungapped, after stage 2, after stage 3
+    uint32_t last_chunks = 0;
     uint64_t last_cells = 0;
     uint64_t last_lists = 0, last_entries = 0;
     uint32_t last_tiles = 0;
@@ -845,8 +848,36 @@ extern "C" int mmgpu_pf_run(mmgpu_ctx *c, mmgpu_pf_batch_t *b) {
     }
     HIP_TRY(P.w_split.reserve(std::max<size_t>(n_tiles, 1) * PF_T * sizeof(uint64_t)));
     HIP_TRY(P.w_bin_off.reserve(std::max<size_t>(n_tiles, 1) * (B + 1) * sizeof(uint16_t)));
-    HIP_TRY(P.w_cand.reserve(std::max<uint64_t>(total_entries, 1) * sizeof(PfCand)));
-    HIP_TRY(P.w_surv.reserve(std::max<uint64_t>(total_entries, 1) * sizeof(PfCand)));
+    // Stages 2 and 3 run over CHUNKS of consecutive queries: the candidate / survivor arrays are entry-sized (every entry
+    // of a bin can be a candidate), 32 B per entry, of which ~1 % is touched - 115 GB for a 10 000-query batch against
+    // 1 M targets.  A chunk is the longest run of queries whose entries fit MMGPU_PF_STAGE_GB (default 16 GB for both
+    // arrays); the arrays are re-used from chunk to chunk (same stream, so the order is the program order).
+    std::vector<uint32_t> chunk_first;
+    uint64_t chunk_max_entries = 0;
+    {
+        double gb = 16.0;
+        if (const char *e = getenv("MMGPU_PF_STAGE_GB")) gb = atof(e);
+        const uint64_t cap = std::max<uint64_t>((uint64_t)(gb * 1073741824.0 / (2.0 * sizeof(PfCand))), 1);
+        uint64_t run = 0;
+        for (uint32_t i = 0; i < nq; i++) {
+            if (i == 0 || run + qent[i] > cap) {
+                chunk_first.push_back(i);
+                run = 0;
+            }
+            run += qent[i];
+            chunk_max_entries = std::max(chunk_max_entries, run);
+        }
+        chunk_first.push_back(nq);
+    }
+    const uint32_t n_chunks = (uint32_t)chunk_first.size() - 1;
+    b->last_chunks = n_chunks;
+    while (b->chunk_ev.size() < (size_t)4 * n_chunks) {
+        hipEvent_t e = nullptr;
+        HIP_TRY(hipEventCreate(&e));
+        b->chunk_ev.push_back(e);
+    }
+    HIP_TRY(P.w_cand.reserve(std::max<uint64_t>(chunk_max_entries, 1) * sizeof(PfCand)));
+    HIP_TRY(P.w_surv.reserve(std::max<uint64_t>(chunk_max_entries, 1) * sizeof(PfCand)));
     HIP_TRY(hipMemsetAsync(b->d_bucket_count.p, 0, (size_t)nq * B * 4, s));
     HIP_TRY(hipMemsetAsync(b->d_surv_count.p, 0, (size_t)nq * 4, s));
     HIP_TRY(hipMemsetAsync(b->d_cells.p, 0, (size_t)nq * 8, s));
@@ -911,37 +942,31 @@ extern "C" int mmgpu_pf_run(mmgpu_ctx *c, mmgpu_pf_batch_t *b) {
     D.seg_start = ovf_q.empty() ? nullptr : b->d_seg_start.as<uint32_t>();
     D.cell_counter = b->d_cells.as<uint64_t>();
     D.q_flags = b->d_qflags.as<uint32_t>();
-    HIP_TRY(launch_pf_dedup(D, b->ev[5], b->ev[6], s));
+    // the flushes of the overflow path: per-query bases relative to the first overflow query of the same chunk
+    std::vector<uint32_t> ovf_chunk_lo(n_chunks + 1, 0);
+    PfOvfArgs O;
     if (!ovf_q.empty()) {
-        // the flushes of the overflow path, one launch per flush (the total kept after flush k decides what flush k+1 does)
         std::vector<uint64_t> obase(ovf_q.size());
-        uint64_t oe = 0;
-        for (size_t z = 0; z < ovf_q.size(); z++) { obase[z] = oe; oe += qent[ovf_q[z]]; }
+        uint64_t oe_max = 0;
+        size_t z = 0;
+        for (uint32_t ch = 0; ch < n_chunks; ch++) {
+            ovf_chunk_lo[ch] = (uint32_t)z;
+            uint64_t oe = 0;
+            for (; z < ovf_q.size() && ovf_q[z] < chunk_first[ch + 1]; z++) { obase[z] = oe; oe += qent[ovf_q[z]]; }
+            oe_max = std::max(oe_max, oe);
+        }
+        ovf_chunk_lo[n_chunks] = (uint32_t)ovf_q.size();
         HIP_TRY(b->d_ovf_base.reserve(obase.size() * 8));
-        HIP_TRY(b->d_ovf_a.reserve(std::max<uint64_t>(oe, 1) * sizeof(PfOvfElem)));
-        HIP_TRY(b->d_ovf_b.reserve(std::max<uint64_t>(oe, 1) * sizeof(PfOvfElem)));
+        HIP_TRY(b->d_ovf_a.reserve(std::max<uint64_t>(oe_max, 1) * sizeof(PfOvfElem)));
+        HIP_TRY(b->d_ovf_b.reserve(std::max<uint64_t>(oe_max, 1) * sizeof(PfOvfElem)));
         HIP_TRY(b->d_ovf_ocount.reserve(ovf_q.size() * (size_t)B * 4));
         HIP_TRY(b->d_ovf_totals.reserve(ovf_q.size() * (size_t)(PF_MAX_SEG + 2) * 4));
         HIP_TRY(hipMemcpyAsync(b->d_ovf_base.p, obase.data(), obase.size() * 8, hipMemcpyHostToDevice, s));
         HIP_TRY(hipMemsetAsync(b->d_ovf_ocount.p, 0, ovf_q.size() * (size_t)B * 4, s));
         HIP_TRY(hipMemsetAsync(b->d_ovf_totals.p, 0, ovf_q.size() * (size_t)(PF_MAX_SEG + 2) * 4, s));
-        PfOvfArgs O;
-        O.D = D;
-        O.ovf_queries = b->d_ovf_queries.as<uint32_t>();
-        O.n_ovf = (uint32_t)ovf_q.size();
-        O.q_final = b->d_qfinal.as<uint32_t>();
-        O.ovf_base = b->d_ovf_base.as<uint64_t>();
-        O.buf_a = b->d_ovf_a.as<PfOvfElem>();
-        O.buf_b = b->d_ovf_b.as<PfOvfElem>();
-        O.o_count = b->d_ovf_ocount.as<uint32_t>();
-        O.totals = b->d_ovf_totals.as<uint32_t>();
-        for (uint32_t step = 1; step <= max_seg + 1; step++) {
-            O.step = step;
-            HIP_TRY(launch_pf_overflow(O, s));
-        }
         HIP_TRY(hipStreamSynchronize(s));   // obase is pageable
+        O.q_final = b->d_qfinal.as<uint32_t>();
     }
-    HIP_TRY(hipEventRecord(b->ev[3], s));
 
     // ---- stage 3: top max_hits per query ----
     PfSelectArgs S;
@@ -979,7 +1004,39 @@ extern "C" int mmgpu_pf_run(mmgpu_ctx *c, mmgpu_pf_batch_t *b) {
         S.list_base = b->d_list_base.as<uint32_t>();
         S.lists = P.w_lists.as<PfList>();
     }
-    HIP_TRY(launch_pf_select(S, nq, s));
+    for (uint32_t ch = 0; ch < n_chunks; ch++) {
+        const uint32_t q0 = chunk_first[ch], cn = chunk_first[ch + 1] - q0;
+        hipEvent_t *cev = &b->chunk_ev[(size_t)4 * ch];
+        // ---- stage 2: replay, ungapped score, best element per target ----
+        D.q_first = q0;
+        D.n_queries = cn;
+        D.cand_origin = (uint32_t)qebase[q0];
+        HIP_TRY(launch_pf_dedup(D, cev[0], cev[1], s));
+        const uint32_t z0 = ovf_chunk_lo[ch], z1 = ovf_chunk_lo[ch + 1];
+        if (z1 > z0) {
+            // one launch per flush (the total kept after flush k decides what flush k+1 does)
+            O.D = D;
+            O.ovf_queries = b->d_ovf_queries.as<uint32_t>() + z0;
+            O.n_ovf = z1 - z0;
+            O.ovf_base = b->d_ovf_base.as<uint64_t>() + z0;
+            O.buf_a = b->d_ovf_a.as<PfOvfElem>();
+            O.buf_b = b->d_ovf_b.as<PfOvfElem>();
+            O.o_count = b->d_ovf_ocount.as<uint32_t>() + (size_t)z0 * B;
+            O.totals = b->d_ovf_totals.as<uint32_t>() + (size_t)z0 * (PF_MAX_SEG + 2);
+            uint32_t chunk_seg = 0;
+            for (uint32_t zz = z0; zz < z1; zz++) chunk_seg = std::max(chunk_seg, h_nseg[ovf_q[zz]]);
+            for (uint32_t step = 1; step <= chunk_seg + 1; step++) {
+                O.step = step;
+                HIP_TRY(launch_pf_overflow(O, s));
+            }
+        }
+        HIP_TRY(hipEventRecord(cev[2], s));
+        // ---- stage 3: top max_hits per query ----
+        S.q_first = q0;
+        S.cand_origin = D.cand_origin;
+        HIP_TRY(launch_pf_select(S, cn, s));
+        HIP_TRY(hipEventRecord(cev[3], s));
+    }
     HIP_TRY(hipEventRecord(b->ev[4], s));
     b->ran = true;
     return MMGPU_OK;
@@ -1156,10 +1213,16 @@ extern "C" int mmgpu_pf_stage_ms(mmgpu_ctx *c, mmgpu_pf_batch_t *b, float ms[7])
     HIP_TRY(hipEventSynchronize(b->ev[4]));
     HIP_TRY(hipEventElapsedTime(&ms[0], b->ev[0], b->ev[1]));
     HIP_TRY(hipEventElapsedTime(&ms[1], b->ev[1], b->ev[2]));
-    HIP_TRY(hipEventElapsedTime(&ms[2], b->ev[2], b->ev[5]));
-    HIP_TRY(hipEventElapsedTime(&ms[3], b->ev[5], b->ev[6]));
-    HIP_TRY(hipEventElapsedTime(&ms[4], b->ev[6], b->ev[3]));
-    HIP_TRY(hipEventElapsedTime(&ms[5], b->ev[3], b->ev[4]));
+    ms[2] = ms[3] = ms[4] = ms[5] = 0.f;     // summed over the stage chunks
+    for (uint32_t ch = 0; ch < b->last_chunks; ch++) {
+        hipEvent_t *cev = &b->chunk_ev[(size_t)4 * ch];
+        hipEvent_t from = ch == 0 ? b->ev[2] : b->chunk_ev[(size_t)4 * ch - 1];
+        for (int k = 0; k < 4; k++) {
+            float t = 0.f;
+            HIP_TRY(hipEventElapsedTime(&t, k == 0 ? from : cev[k - 1], cev[k]));
+            ms[2 + k] += t;
+        }
+    }
     HIP_TRY(hipEventElapsedTime(&ms[6], b->ev[0], b->ev[4]));
     return MMGPU_OK;
 }
@@ -1204,7 +1267,11 @@ extern "C" int mmgpu_pf_debug_fetch(mmgpu_ctx *c, mmgpu_pf_batch_t *b, int what,
         case MMGPU_PF_DBG_SPLIT: src = P.w_split.p; n = (size_t)b->last_tiles * PF_T * 8; break;
         case MMGPU_PF_DBG_BIN_OFF: src = P.w_bin_off.p; n = (size_t)b->last_tiles * (b->bins + 1) * 2; break;
         case MMGPU_PF_DBG_CAND_BASE: src = b->d_cand_base.p; n = ((size_t)b->nq * b->bins + 1) * 4; break;
-        case MMGPU_PF_DBG_SURV: src = P.w_surv.p; n = (size_t)b->last_entries * sizeof(PfCand); break;
+        case MMGPU_PF_DBG_SURV:
+            if (b->last_chunks > 1) return fail(MMGPU_ERR_STATE, "mmgpu_pf_debug_fetch: the survivors of a batch run in several stage chunks are gone (raise MMGPU_PF_STAGE_GB)");
+            src = P.w_surv.p;
+            n = (size_t)b->last_entries * sizeof(PfCand);
+            break;
         case MMGPU_PF_DBG_SURV_COUNT: src = b->d_surv_count.p; n = (size_t)b->nq * 4; break;
         case MMGPU_PF_DBG_BINS:
             *bytes = sizeof(binsv);
@@ -1222,6 +1289,8 @@ extern "C" void mmgpu_pf_free(mmgpu_ctx *c, mmgpu_pf_batch_t *b) {
     if (!b) return;
     if (c) (void)hipSetDevice(c->device);
     for (auto &e : b->ev)
+        if (e) (void)hipEventDestroy(e);
+    for (auto e : b->chunk_ev)
         if (e) (void)hipEventDestroy(e);
     delete b;
 }

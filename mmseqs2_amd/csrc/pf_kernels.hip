@@ -92,7 +92,7 @@ __device__ __forceinline__ uint32_t wave_search_le(const uint32_t *base, uint32_
 // candidates at configs[2]; the dense array keeps the replay/score/keepmax kernels inside a few hundred MB instead of
 // a region as large as all index entries), later ones in the bucket's slice of the entry-sized overflow array.
 __device__ __forceinline__ PfCand *cand_slot(const PfDedupArgs &A, uint64_t bucket, uint32_t k) {
-    return k < (uint32_t)PF_CAND0 ? A.cand_small + bucket * PF_CAND0 + k : A.cand + A.cand_base[bucket] + k;
+    return k < (uint32_t)PF_CAND0 ? A.cand_small + bucket * PF_CAND0 + k : A.cand + (A.cand_base[bucket] - A.cand_origin) + k;
 }
 
 struct __attribute__((packed, aligned(4))) U32Pair {   // two adjacent uint32 at 4-byte alignment: global_load_dwordx2
@@ -844,7 +844,7 @@ __device__ __forceinline__ uint64_t score_chunk(const PfDedupArgs &A, const int8
         win = win && cnt >= A.min_diag_score;
         const uint64_t wb = __ballot(win);
         if (wb) {
-            PfCand *surv = A.surv + A.cand_base[(uint64_t)q * A.bins];
+            PfCand *surv = A.surv + (A.cand_base[(uint64_t)q * A.bins] - A.cand_origin);
             uint32_t base = 0;
             if (lane == 0) base = atomicAdd(&A.surv_count[q], (uint32_t)__popcll(wb));
             base = __shfl(base, 0);
@@ -870,8 +870,8 @@ __global__ __launch_bounds__(256) void pf_replay_kernel(PfDedupArgs A) {
     for (int k = (int)threadIdx.x; k < 32 * 32; k += 256) smat[k] = k < A.alphabet * A.alphabet ? A.mat[k] : (int8_t)0;
     __syncthreads();
     const uint32_t B = A.bins;
-    const uint64_t bucket = (uint64_t)blockIdx.x * 4u + (uint32_t)wave;
-    if (bucket >= (uint64_t)A.n_queries * B) return;
+    const uint64_t bucket = (uint64_t)A.q_first * B + (uint64_t)blockIdx.x * 4u + (uint32_t)wave;
+    if (bucket >= (uint64_t)(A.q_first + A.n_queries) * B) return;
     const uint32_t q = (uint32_t)(bucket / B), bin = (uint32_t)(bucket % B);
     const uint32_t ntiles = A.q_ntiles[q];
     if (ntiles == 0) {
@@ -1025,8 +1025,8 @@ __global__ __launch_bounds__(256) void pf_ungapped_kernel(PfDedupArgs A) {
     for (int k = A.alphabet * A.alphabet + (int)threadIdx.x; k < 32 * 32; k += 256) smat[k] = 0;
     __syncthreads();
     const uint32_t B = A.bins;
-    const uint64_t bucket = (uint64_t)blockIdx.x * 4u + (uint32_t)wave;
-    if (bucket >= (uint64_t)A.n_queries * B) return;
+    const uint64_t bucket = (uint64_t)A.q_first * B + (uint64_t)blockIdx.x * 4u + (uint32_t)wave;
+    if (bucket >= (uint64_t)(A.q_first + A.n_queries) * B) return;
     const uint32_t ncand = A.cand_count[bucket];
     const uint32_t q = (uint32_t)(bucket / B);
     if (ncand <= 64 || (A.q_nseg && A.q_nseg[q])) return;   // small bins are done; overflow queries have their own path
@@ -1054,8 +1054,8 @@ __global__ __launch_bounds__(256) void pf_keepmax_kernel(PfDedupArgs A) {
     __shared__ uint32_t s_tab[4][PF_IDS_PER_BIN];
     const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
     const uint32_t B = A.bins;
-    const uint64_t bucket = (uint64_t)blockIdx.x * 4u + (uint32_t)wave;
-    if (bucket >= (uint64_t)A.n_queries * B) return;
+    const uint64_t bucket = (uint64_t)A.q_first * B + (uint64_t)blockIdx.x * 4u + (uint32_t)wave;
+    if (bucket >= (uint64_t)(A.q_first + A.n_queries) * B) return;
     const uint32_t ncand = A.cand_count[bucket];
     const uint32_t q = (uint32_t)(bucket / B);
     if (A.nucl) return;                                      // pf_keepmax_nucl_kernel
@@ -1073,7 +1073,7 @@ __global__ __launch_bounds__(256) void pf_keepmax_kernel(PfDedupArgs A) {
             atomicMax(&S[cp->id >> bshift], k2);
         }
     }
-    PfCand *surv = A.surv + A.cand_base[(uint64_t)q * B];
+    PfCand *surv = A.surv + (A.cand_base[(uint64_t)q * B] - A.cand_origin);
     for (uint32_t c0 = 0; c0 < ncand; c0 += 64) {
         const uint32_t ci = c0 + (uint32_t)lane;
         bool win = false;
@@ -1108,8 +1108,8 @@ __global__ __launch_bounds__(128) void pf_keepmax_nucl_kernel(PfDedupArgs A) {
     __shared__ uint32_t s_first[2][PF_IDS_PER_BIN];
     const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
     const uint32_t B = A.bins;
-    const uint64_t bucket = (uint64_t)blockIdx.x * 2u + (uint32_t)wave;
-    if (bucket >= (uint64_t)A.n_queries * B) return;
+    const uint64_t bucket = (uint64_t)A.q_first * B + (uint64_t)blockIdx.x * 2u + (uint32_t)wave;
+    if (bucket >= (uint64_t)(A.q_first + A.n_queries) * B) return;
     const uint32_t ncand = A.cand_count[bucket];
     const uint32_t q = (uint32_t)(bucket / B);
     if (ncand == 0) return;
@@ -1143,7 +1143,7 @@ __global__ __launch_bounds__(128) void pf_keepmax_nucl_kernel(PfDedupArgs A) {
             if (K[c.id >> bshift] == key_of(c, ci)) atomicMin(&F[c.id >> bshift], ci);
         }
     }
-    PfCand *surv = A.surv + A.cand_base[(uint64_t)q * B];
+    PfCand *surv = A.surv + (A.cand_base[(uint64_t)q * B] - A.cand_origin);
     for (uint32_t c0 = 0; c0 < ncand; c0 += 64) {
         const uint32_t ci = c0 + (uint32_t)lane;
         bool win = false;
@@ -1409,7 +1409,7 @@ __global__ __launch_bounds__(256) void pf_overflow_kernel(PfOvfArgs A) {
     }
     PfOvfElem *dst = cur == O ? S : O;
     uint32_t m = 0;
-    PfCand *surv = D.surv + D.cand_base[(uint64_t)q * B];
+    PfCand *surv = D.surv + (D.cand_base[(uint64_t)q * B] - D.cand_origin);
     for (uint32_t r0 = 0; r0 < n; r0 += 64) {
         const uint32_t idx = r0 + (uint32_t)lane;
         bool keep = false;
@@ -1505,12 +1505,12 @@ __global__ __launch_bounds__(256) void pf_select_kernel(PfSelectArgs A) {
     __shared__ uint32_t sh_remaining;
     __shared__ uint64_t skey_lds[BIG ? 1 : PF_MAX_HITS];
     __shared__ uint16_t sdiag_lds[BIG ? 1 : PF_MAX_HITS];
-    const uint32_t q = blockIdx.x;
+    const uint32_t q = A.q_first + blockIdx.x;
     uint64_t *skey = BIG ? A.big_keys + (size_t)q * A.big_stride : skey_lds;
     uint16_t *sdiag = BIG ? A.big_diags + (size_t)q * A.big_stride : sdiag_lds;
     const uint32_t sort_cap = BIG ? A.big_stride : (uint32_t)PF_MAX_HITS;
     const uint32_t n = A.surv_count[q];
-    const PfCand *S = A.surv + A.cand_base[(uint64_t)q * A.bins];
+    const PfCand *S = A.surv + (A.cand_base[(uint64_t)q * A.bins] - A.cand_origin);
     const uint32_t ident = A.q_identity[q];
     const uint32_t max_hits = A.max_hits;   // already min(maxHitsPerQuery, dbSize)
     mmgpu_pf_hit *out = A.hits + (size_t)q * A.hit_stride;

@@ -358,3 +358,49 @@ def test_max_seqs_above_4096(gpu):
             assert len(x["id"]) == len(h), (mh, qi, len(x["id"]), len(h))
             assert np.array_equal(h["id"], x["id"]) and np.array_equal(h["score"], x["score"]) and np.array_equal(h["diagonal"], x["diagonal"]), (mh, qi)
         assert int(counts[0]) > 4096
+
+
+def test_stage_chunks_give_the_same_lists(gpu, monkeypatch):
+    """Stages 2-3 of a batch run over chunks of queries that share one candidate / survivor array (MMGPU_PF_STAGE_GB, 16 GB
+    by default: one chunk for every test batch).  Forced down to one query per chunk and to a few queries per chunk, with
+    overflow-path queries at chunk borders: same lists, same statistics; the unchunked run is checked against the oracle."""
+    from oracle.pyoracle import Oracle
+    g = pc.golden()
+    rng = np.random.default_rng(21)
+    (qres, qoff), (tres, toff) = wl.config2_align_only(12, 60000, 0.2, seed=19)
+    thr = int(g["kmer_thr"])
+    orc = pc.pf_oracle()
+    orc.build_index(tres, toff, thr)
+    chk.load_case(gpu, g, tres, toff, thr)
+    swo = Oracle()
+    tl = wl.split(tres, toff)
+    ql = wl.split(qres, qoff)
+    seqs = [ql[0], _long_query(rng, tl, 30000, 0.5)] + ql[1:7] + [_long_query(rng, tl, 29000, 0.5), ql[0][:5].copy()] + ql[7:]
+    qs = [dict(q=q, comp_bias=swo.comp_bias(g["vtml80_kmer16"], g["vtml80_pback"], q), identity_id=None) for q in seqs]
+    monkeypatch.delenv("MMGPU_PF_STAGE_GB", raising=False)
+    ok, rep = chk.check(gpu, orc, qs, 300, 2, stages=False, label="one chunk")
+    assert ok, "\n".join(rep)
+
+    def run():
+        b = gpu.pf_prepare(qs, thr, max_hits=300, ref_bins=2)
+        b.run()
+        out = b.fetch()
+        ms = b.stage_ms()
+        b.free()
+        return out, ms
+
+    (h0, c0, s0, t0), ms0 = run()
+    assert int(c0.sum()) > 0 and int(s0[1]) == 0 and int(s0[8]) == 0      # the overflow queries ran on the device
+    entries = int(sum(int(x["db_matches"]) for x in t0))
+    for gb in (1e-7, 32.0 * entries / 5 / 2 ** 30):        # every query alone; ~5 chunks
+        monkeypatch.setenv("MMGPU_PF_STAGE_GB", repr(gb))
+        (h1, c1, s1, t1), ms1 = run()
+        assert np.array_equal(c0, c1) and np.array_equal(s0, s1)
+        assert np.array_equal(t0, t1)
+        for qi in range(len(qs)):
+            n = int(c0[qi])
+            assert np.array_equal(h0[qi][:n], h1[qi][:n]), (gb, qi)
+        assert len(ms1) == 7 and all(x >= 0 for x in ms1)
+    monkeypatch.delenv("MMGPU_PF_STAGE_GB", raising=False)
+    orc.build_index(g["tres"], g["toff"], thr)
+    chk.load_case(gpu, g, g["tres"], g["toff"], thr)
