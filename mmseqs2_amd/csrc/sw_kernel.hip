@@ -269,23 +269,48 @@ __device__ __forceinline__ void sw_body(const SwLaunch &L, const SwJob job) {
                 if (c < 0) c = 0;
                 return REV ? p + (end - c) : p + c;
             };
-            unsigned la0 = *letter_addr(pA, colsA, endA, 0), lb0 = *letter_addr(pB, colsB, endB, 0);
-            unsigned la1 = *letter_addr(pA, colsA, endA, 1), lb1 = *letter_addr(pB, colsB, endB, 1);
+            unsigned la0 = 0, lb0 = 0, la1 = 0, lb1 = 0;
+            constexpr bool DW = !REV;
+            // Forward scan: four columns' letters per dword load (targets start 4-byte aligned and the residue buffer
+            // ends with max_len + 64 bytes of slack, mmgpu_load_targets, so no clamping is needed: columns past a
+            // target's end are replaced by the padding letter below).  One v_bfe per target and column instead of an
+            // address computation and a byte load: 16-18 fewer instructions per column (R = 12: 194 -> 177).
+            const unsigned *dA = reinterpret_cast<const unsigned *>(pA), *dB = reinterpret_cast<const unsigned *>(pB);
+            unsigned wA = 0, wB = 0, wA_next = 0, wB_next = 0;
+            if (!DW) {
+                la0 = *letter_addr(pA, colsA, endA, 0); lb0 = *letter_addr(pB, colsB, endB, 0);
+                la1 = *letter_addr(pA, colsA, endA, 1); lb1 = *letter_addr(pB, colsB, endB, 1);
+            } else {
+                wA = dA[0]; wB = dB[0];
+                wA_next = dA[1]; wB_next = dB[1];
+            }
             uint2 up0 = make_uint2(0, 0), up1 = make_uint2(0, 0);
             if (has_above) {
                 up0 = scr_in[0];
                 up1 = scr_in[min(1, ncols - 1 < 0 ? 0 : ncols - 1)];
             }
 
-            for (int s = 0; s < nsteps; ++s) {
+            // blocks of four columns (one dword of letters per target) where the dword path is used, else one block
+            for (int s0 = 0; s0 < nsteps; s0 = DW ? s0 + 4 : nsteps) {
+            const int jn = DW ? min(4, nsteps - s0) : nsteps;
+#pragma nounroll
+            for (int j = 0; j < jn; ++j) {
+                const int s = s0 + j;
                 // ---- inputs of this step: from the lane above, or the tile boundary for the head lane ----
+                if (DW) {
+                    const unsigned sh = (unsigned)j * 8u;   // wave-uniform
+                    la0 = __builtin_amdgcn_ubfe(wA, sh, 8u);
+                    lb0 = __builtin_amdgcn_ubfe(wB, sh, 8u);
+                }
                 const unsigned head_let = (s < colsA ? la0 : pad_letter) | ((s < colsB ? lb0 : pad_letter) << 8);
                 const unsigned Hup = from_lane_above(up0.x, out_H);
                 unsigned f = from_lane_above(up0.y, out_F);
                 const unsigned let = from_lane_above(head_let, out_let);
-                la0 = la1; lb0 = lb1;
-                la1 = *letter_addr(pA, colsA, endA, s + 2);
-                lb1 = *letter_addr(pB, colsB, endB, s + 2);
+                if (!DW) {
+                    la0 = la1; lb0 = lb1;
+                    la1 = *letter_addr(pA, colsA, endA, s + 2);
+                    lb1 = *letter_addr(pB, colsB, endB, s + 2);
+                }
                 if (has_above) {
                     up0 = up1;
                     int c = s + 2; if (c > ncols - 1) c = ncols - 1; if (c < 0) c = 0;
@@ -362,6 +387,12 @@ __device__ __forceinline__ void sw_body(const SwLaunch &L, const SwJob job) {
 #endif
                     vmax = nm;
                 }
+            }
+            if (DW) {   // the next four columns' letters; the load after that is in flight for four steps
+                wA = wA_next; wB = wB_next;
+                const int k = (s0 >> 2) + 2;
+                wA_next = dA[k]; wB_next = dB[k];
+            }
             }
 
             // ---- fold this tile's lanes into the pair's running best (tie rules in the key order) ----
