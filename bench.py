@@ -341,6 +341,9 @@ def search_headline(args, gpu, torch, dist, rank, world, matrices, barrier):
         swb.free()
         started = int(sum(int((g["q_start"] >= 0).sum()) for g in gpu_res))
         out["pairs_with_start"] = started
+        # cells of the reverse scan (q[0..q_end] x t[0..t_end] of every pair that got start positions, StripedSmithWaterman.cpp:1143-1175)
+        out["reverse_cells"] = int(sum(int(((g["q_end"].astype(np.int64) + 1) * (g["t_end"].astype(np.int64) + 1))[g["q_start"] >= 0].sum())
+                                       for g in gpu_res))
         if not args.no_cpu_baseline:
             out["cpu_sw"] = sw_cpu_baseline_lists(matrices, qs, lists, tres, toff, args.cpu_seconds, gpu_res)
             out["cpu_pf"] = prefilter_cpu_baseline(matrices, qres, qoff, tres, toff, kmer_thr, args.cpu_seconds, full_lists)
@@ -656,7 +659,10 @@ def main():
                          "valu_roofline": {"achieved_lane_ops_per_s": round(lane_ops / (k_ms * 1e-3), 1),
                                            "peak_lane_ops_per_s": VALU_LANE_OPS_PER_S,
                                            "frac": round(lane_ops / (k_ms * 1e-3) / VALU_LANE_OPS_PER_S, 4),
-                                           "counts": "forward cells only; the reverse scan of the pairs passing -e 1e-3 runs inside the same kernels"}},
+                                           "counts": "forward cells only; the reverse scan of the pairs passing -e 1e-3 runs inside the same kernels",
+                                           "reverse_scan_cells": H.get("reverse_cells"),
+                                           "frac_incl_reverse_scan": (round((H["cells"] + H["reverse_cells"]) / 2.0 * 10.0 / (k_ms * 1e-3) / VALU_LANE_OPS_PER_S, 4)
+                                                                      if H.get("reverse_cells") is not None else None)}},
         }
         pf = {"queries_per_s": round(nq / (H["pf_ms"] * 1e-3), 1),
               "stage_ms": {"kmers_lists": round(stage[0], 2), "gather_split": round(stage[1], 2), "replay_score_keepmax": round(stage[2], 2),

@@ -93,16 +93,21 @@ def _case(seed, n_fam, members, nq):
     return wl.split(qres, qoff), tres, toff
 
 
-@pytest.mark.parametrize("world,max_hits,ref_bins", [(2, 300, 2), (3, 40, 4), (8, 25, 2), (4, 300, 0)])
-def test_merged_shards_equal_unsplit_run(gpu, world, max_hits, ref_bins):
-    """lists cut at ties (max_hits far below the family size), uneven shard counts, the host's own bin count"""
+@pytest.mark.parametrize("world,max_hits,ref_bins,stage_gb", [(2, 300, 2, None), (3, 40, 4, "1e-7"), (8, 25, 2, None), (4, 300, 0, "2e-4")])
+def test_merged_shards_equal_unsplit_run(gpu, monkeypatch, world, max_hits, ref_bins, stage_gb):
+    """lists cut at ties (max_hits far below the family size), uneven shard counts, the host's own bin count; two of the
+    cases run the shards' stages 2-3 in chunks of queries (one query per chunk / a few), the unsplit run in one chunk"""
     g = pc.golden()
     thr = int(g["kmer_thr"])
     qs, tres, toff = _case(31 + world, 150, 60, 48)
     km16 = g["vtml80_kmer16"]
     queries = [dict(q=q, comp_bias=capi.host_comp_bias(km16, g["vtml80_pback"], q, lib=gpu.L)[0], identity_id=None) for q in qs]
+    monkeypatch.delenv("MMGPU_PF_STAGE_GB", raising=False)
     hits_u, counts_u, status_u, _ = _unsplit(gpu, g, tres, toff, queries, thr, max_hits, ref_bins)
+    if stage_gb:
+        monkeypatch.setenv("MMGPU_PF_STAGE_GB", stage_gb)
     hits_s, counts_s, flags, (xh, xc) = _sharded(gpu, g, tres, toff, queries, thr, max_hits, ref_bins, world)
+    monkeypatch.delenv("MMGPU_PF_STAGE_GB", raising=False)
     assert np.all(status_u == 0) and np.all(flags == 0)
     truncated = 0
     for qi in range(len(qs)):
