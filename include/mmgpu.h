@@ -298,6 +298,12 @@ typedef struct {
                                 window matches its own k-mer only, kmer_thr is not read (QueryMatcher.cpp:279-282) */
     uint32_t nucleotide;     /* the target database is nucleotide: matchQuery's isNucleotide branch (QueryMatcher.cpp:147-177) - of
                                 several saturated (>= 255) diagonals of one target the one with the best exact score is kept */
+    uint32_t kmer_score;     /* --diag-score 0 (Prefiltering::diagonalScoring == false): no ungapped scoring - the prefilter score of a
+                                target is the number of its double k-mer matches, saturating at 255 (findDuplicates with
+                                computeTotalScore, CacheFriendlyOperations.cpp:218-239; QueryMatcher.cpp:215-232, getResult<KMER_SCORE>);
+                                the self hit scores 255.  Queries on the databaseHits overflow path, or with 500 000 or more
+                                elements, come back MMGPU_PF_OVERFLOW / MMGPU_PF_SAT_TIE (the host runs the reference for them);
+                                not with sharded databases, profile queries or nucleotide searches */
 } mmgpu_pf_params;
 
 typedef struct {
@@ -338,7 +344,8 @@ typedef struct {
 typedef struct {
     uint64_t db_matches;     /* statistics_t::dbMatches */
     uint64_t kmer_list_len;  /* sum over positions of similar k-mers (kmersPerPos * L) */
-    uint32_t double_hits;    /* elements after keepMaxScoreElementOnly with count >= min_diag_score */
+    uint32_t double_hits;    /* elements after keepMaxScoreElementOnly with count >= min_diag_score; with kmer_score
+                                statistics_t::doubleMatches, the sum of the match counts (QueryMatcher.cpp:366-385) */
     uint32_t diag_thr;       /* diagonalThr; bit 31 = scoreIsTruncated */
 } mmgpu_pf_qstat;
 

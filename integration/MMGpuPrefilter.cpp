@@ -16,7 +16,7 @@ unsigned int MMGpuPrefilter::referenceBins(size_t dbsize) {
 MMGpuPrefilter::MMGpuPrefilter(mmgpu_ctx *gpu, BaseMatrix *kmerSubMat, BaseMatrix *ungappedSubMat, bool aaBiasCorrection,
                                float aaBiasCorrectionScale)
     : gpu(gpu), kmerSubMat(kmerSubMat), ungappedSubMat(ungappedSubMat), aaBiasCorrection(aaBiasCorrection),
-      aaBiasCorrectionScale(aaBiasCorrectionScale), dbSize(0), exactKmerMatching(false), nucleotideSearch(false) {}
+      aaBiasCorrectionScale(aaBiasCorrectionScale), dbSize(0), exactKmerMatching(false), nucleotideSearch(false), kmerScore(false) {}
 
 bool MMGpuPrefilter::loadIndex(IndexTable *indexTable, SequenceLookup *sequenceLookup, ScoreMatrix &threeMer, ScoreMatrix &twoMer,
                                bool spacedKmer) {
@@ -128,6 +128,7 @@ bool MMGpuPrefilter::matchBlock(const std::vector<Query> &queries, int kmerThr, 
     par.ref_bins = referenceBins(dbSize);
     par.exact_kmer = exactKmerMatching ? 1u : 0u;
     par.nucleotide = nucleotideSearch ? 1u : 0u;
+    par.kmer_score = kmerScore ? 1u : 0u;
     const uint32_t stride = (uint32_t)std::min(maxResListLen, dbSize);
     std::vector<mmgpu_pf_hit> hits(nq * (size_t)stride);
     std::vector<uint32_t> counts(nq);

@@ -55,9 +55,10 @@ public:
                     bool spacedKmer);
 
     // takeOnlyBestKmer (--exact-kmer-matching; every nucleotide search) / nucleotide target database (matchQuery's isNucleotide)
-    void setMode(bool exactKmer, bool nucleotide) {
+    void setMode(bool exactKmer, bool nucleotide, bool kmerScoring = false) {
         exactKmerMatching = exactKmer;
         nucleotideSearch = nucleotide;
+        kmerScore = kmerScoring;      // --diag-score 0
     }
 
     // the CacheFriendlyOperations<N> QueryMatcher::initDiagonalMatcher picks on this host (QueryMatcher.cpp:460-488)
@@ -73,7 +74,7 @@ private:
     float aaBiasCorrectionScale;
     size_t dbSize;
     std::string err;
-    bool exactKmerMatching, nucleotideSearch;
+    bool exactKmerMatching, nucleotideSearch, kmerScore;
 };
 
 #endif

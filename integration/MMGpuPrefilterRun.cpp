@@ -48,7 +48,7 @@ bool MMGpuPrefilterRun::usableConfig(Prefiltering &p, bool indexExists) {
     else if (nucl && !p.takeOnlyBestKmer) why = "nucleotide search without exact k-mer matching";
     else if (profileQuery && p.takeOnlyBestKmer) why = "exact k-mer matching with profile queries";
     else if (!p.takeOnlyBestKmer && !profileQuery && (!p._3merSubMatrix.isValid() || !p._2merSubMatrix.isValid())) why = "no similar-k-mer score matrices";
-    else if (p.diagonalScoring == 0) why = "--diag-score 0";
+    else if (p.diagonalScoring == 0 && (profileQuery || nucl)) why = "--diag-score 0 with profile queries / nucleotide databases";
     else if (p.minDiagScoreThr < 1) why = "--min-ungapped-score 0";
     else if (p.takeOnlyBestKmer ? (p.kmerSize < 4 || p.kmerSize > 15) : (p.kmerSize != 6 && p.kmerSize != 7)) why = "k-mer size not covered (6 / 7; 4..15 with exact k-mer matching)";
     else if (p.spacedKmerPattern.empty() == false) why = "user-defined spaced k-mer pattern";
@@ -107,7 +107,7 @@ bool MMGpuPrefilterRun::run(Prefiltering &p, DBWriter &tmpDbw, size_t dbFrom, si
         p.kmerSubMat->alphabetSize = alph;
     }
     const bool nuclSearch = Parameters::isEqualDbtype(p.targetSeqType, Parameters::DBTYPE_NUCLEOTIDES);
-    device.setMode(p.takeOnlyBestKmer, nuclSearch);
+    device.setMode(p.takeOnlyBestKmer, nuclSearch, p.diagonalScoring == 0);
     ScoreMatrix &three = local3.isValid() ? local3 : p._3merSubMatrix;
     ScoreMatrix &two = local2.isValid() ? local2 : p._2merSubMatrix;
     const bool handedOver = p.mmgpuDeviceIndex ? device.buildIndex(p.sequenceLookup, p.kmerSize, p.mmgpuIndexKmerThr, three, two, p.spacedKmer)
@@ -275,6 +275,7 @@ bool MMGpuPrefilterRun::run(Prefiltering &p, DBWriter &tmpDbw, size_t dbFrom, si
                         kmersPerPos += (double)qstats[b].kmer_list_len / (double)block[b].L;
                         dbMatches += qstats[b].db_matches;
                         // statistics_t::doubleMatches is only counted with --diag-score 0 (QueryMatcher.cpp:366-371)
+                        if (p.diagonalScoring == 0) doubleMatches += qstats[b].double_hits;
                     }
                     querySeqLenSum += block[b].L;
                     resSize += resultSize;

@@ -84,7 +84,8 @@ class PfIndexDesc(ctypes.Structure):
 
 class PfParams(ctypes.Structure):
     _fields_ = [("kmer_thr", ctypes.c_int), ("max_hits", ctypes.c_uint32), ("min_diag_score", ctypes.c_uint32),
-                ("ref_bins", ctypes.c_uint32), ("exact_kmer", ctypes.c_uint32), ("nucleotide", ctypes.c_uint32)]
+                ("ref_bins", ctypes.c_uint32), ("exact_kmer", ctypes.c_uint32), ("nucleotide", ctypes.c_uint32),
+                ("kmer_score", ctypes.c_uint32)]
 
 
 class PfQuery(ctypes.Structure):
@@ -568,16 +569,16 @@ class MMGpu:
             arr[i] = PfQuery(_ptr(q), len(q), _ptr(cb), 0xFFFFFFFF if ident is None else int(ident), _ptr(ps), _ptr(pi), row, _ptr(pa))
         return arr, keep
 
-    def pf_prepare(self, queries, kmer_thr, max_hits=300, min_diag_score=15, ref_bins=0, exact=False, nucleotide=False):
+    def pf_prepare(self, queries, kmer_thr, max_hits=300, min_diag_score=15, ref_bins=0, exact=False, nucleotide=False, kmer_score=False):
         arr, keep = self._pf_marshal(queries)
-        par = PfParams(int(kmer_thr), int(max_hits), int(min_diag_score), int(ref_bins), int(exact), int(nucleotide))
+        par = PfParams(int(kmer_thr), int(max_hits), int(min_diag_score), int(ref_bins), int(exact), int(nucleotide), int(kmer_score))
         h = c_p()
         self._check(self.L.mmgpu_pf_prepare(self.ctx, ctypes.byref(par), ctypes.cast(arr, c_p), len(queries), ctypes.byref(h)))
         db = getattr(self, "global_db_size", None) or self.n_targets
         return PfBatch(self, h, keep, len(queries), min(int(max_hits), db))
 
-    def pf_batch(self, queries, kmer_thr, max_hits=300, min_diag_score=15, ref_bins=0, exact=False, nucleotide=False):
-        b = self.pf_prepare(queries, kmer_thr, max_hits, min_diag_score, ref_bins, exact, nucleotide)
+    def pf_batch(self, queries, kmer_thr, max_hits=300, min_diag_score=15, ref_bins=0, exact=False, nucleotide=False, kmer_score=False):
+        b = self.pf_prepare(queries, kmer_thr, max_hits, min_diag_score, ref_bins, exact, nucleotide, kmer_score)
         b.run()
         out = b.fetch()
         b.free()

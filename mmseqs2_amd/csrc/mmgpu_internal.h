@@ -228,6 +228,7 @@ struct PfDedupArgs {
 
 struct PfSelectArgs {
     uint32_t q_first, cand_origin;    // as in PfDedupArgs
+    int kmer_score;                   // --diag-score 0: scores are match counts (no rescoring, self hit 255)
     const PfCand *surv;
     const uint32_t *cand_base;        // survivors of query q start at cand_base[q * bins]
     uint32_t bins;
@@ -334,6 +335,7 @@ hipError_t launch_pf_scan(const uint32_t *in, const uint32_t *q_off, uint32_t nq
                           uint64_t *totals, hipStream_t s);
 hipError_t launch_pf_split(const PfSplitArgs &A, uint32_t n_tiles, hipStream_t s);
 hipError_t launch_pf_dedup(const PfDedupArgs &A, hipEvent_t after_replay, hipEvent_t after_ungapped, hipStream_t s);
+hipError_t launch_pf_count(const PfDedupArgs &A, hipEvent_t after_a, hipEvent_t after_b, hipStream_t s);   // --diag-score 0
 hipError_t launch_pf_select(const PfSelectArgs &A, uint32_t nq, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------------------------

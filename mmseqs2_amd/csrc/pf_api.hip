@@ -524,6 +524,11 @@ extern "C" int mmgpu_pf_prepare(mmgpu_ctx *c, const mmgpu_pf_params *par, const 
     const PfIndex &P = *c->pf;
     if (!par->exact_kmer && !P.has_tables) return fail(MMGPU_ERR_STATE, "mmgpu_pf_prepare: the index was loaded without similar-k-mer tables (exact k-mer matching only)");
     if (par->nucleotide && c->shard.on) return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_pf_prepare: nucleotide searches on a sharded database are not implemented");
+    if (par->kmer_score) {     // --diag-score 0
+        if (c->shard.on || par->nucleotide) return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_pf_prepare: kmer_score (--diag-score 0) with a sharded database or a nucleotide search is not implemented");
+        for (uint32_t i = 0; i < nq; i++)
+            if (qs[i].profile_score) return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_pf_prepare: kmer_score (--diag-score 0) with profile queries is not implemented");
+    }
     // a shard of a multi-GPU run answers for the whole database: list length and cache bins as in the unsplit run
     const bool exchange = c->shard.on;
     const uint64_t db_size = exchange ? c->shard.global_n : c->db.n;
@@ -680,7 +685,7 @@ extern "C" int mmgpu_pf_prepare(mmgpu_ctx *c, const mmgpu_pf_params *par, const 
     B_TRY(b->d_hit_count.alloc(nqq * 4));
     B_TRY(b->d_diag_thr.alloc(nqq * 4));
     B_TRY(b->d_qflags.alloc(nqq * 4));
-    if (par->nucleotide) B_TRY(b->d_qncand.alloc(nqq * 4));
+    if (par->nucleotide || par->kmer_score) B_TRY(b->d_qncand.alloc(nqq * 4));
     if (max_hits > (uint32_t)PF_MAX_HITS) {
         b->big_stride = 1;
         while (b->big_stride < max_hits) b->big_stride <<= 1;
@@ -797,7 +802,8 @@ extern "C" int mmgpu_pf_run(mmgpu_ctx *c, mmgpu_pf_batch_t *b) {
         bool rewrite = false;
         std::vector<uint32_t> keep;
         for (uint32_t i : ovf_q) {
-            if (h_nseg[i] == 0 || h_nseg[i] > (uint32_t)PF_MAX_SEG || b->q_entries[i] > 0xFFFFFFFFull) {
+            // (--diag-score 0 merges the segments by score, QueryMatcher.cpp:514-533: not on the device either)
+            if (h_nseg[i] == 0 || h_nseg[i] > (uint32_t)PF_MAX_SEG || b->q_entries[i] > 0xFFFFFFFFull || b->par.kmer_score) {
                 h_nseg[i] = 0;      // more flushes than the device emulates: the host runs the reference for this query
                 b->status[i] = MMGPU_PF_OVERFLOW;
                 rewrite = true;
@@ -882,7 +888,7 @@ extern "C" int mmgpu_pf_run(mmgpu_ctx *c, mmgpu_pf_batch_t *b) {
     HIP_TRY(hipMemsetAsync(b->d_surv_count.p, 0, (size_t)nq * 4, s));
     HIP_TRY(hipMemsetAsync(b->d_cells.p, 0, (size_t)nq * 8, s));
     HIP_TRY(hipMemsetAsync(b->d_qflags.p, 0, (size_t)nq * 4, s));
-    if (b->par.nucleotide) HIP_TRY(hipMemsetAsync(b->d_qncand.p, 0, (size_t)nq * 4, s));
+    if (b->par.nucleotide || b->par.kmer_score) HIP_TRY(hipMemsetAsync(b->d_qncand.p, 0, (size_t)nq * 4, s));
 
     // ---- stage 1: gather + stable split ----
     PfSplitArgs SA;
@@ -927,7 +933,7 @@ extern "C" int mmgpu_pf_run(mmgpu_ctx *c, mmgpu_pf_batch_t *b) {
     D.q_corr = b->d_qcorr.as<int8_t>();
     D.nucl = b->par.nucleotide ? 1 : 0;
     D.sort_cap = (uint32_t)(std::max<uint64_t>(1000000, c->db.n) / 2);     // foundDiagonalsSize / 2 (QueryMatcher.cpp:44,146)
-    D.q_ncand = b->par.nucleotide ? b->d_qncand.as<uint32_t>() : nullptr;
+    D.q_ncand = (b->par.nucleotide || b->par.kmer_score) ? b->d_qncand.as<uint32_t>() : nullptr;
     D.q_rows = b->any_profile ? b->d_qrows.as<int8_t>() : nullptr;
     D.q_isprof = b->any_profile ? b->d_qisprof.as<uint8_t>() : nullptr;
     D.mat = P.d_mat.as<int8_t>();
@@ -988,6 +994,7 @@ extern "C" int mmgpu_pf_run(mmgpu_ctx *c, mmgpu_pf_batch_t *b) {
     S.q_nseg = nullptr;
     S.q_flags = b->d_qflags.as<uint32_t>();
     S.nucl = b->par.nucleotide ? 1 : 0;
+    S.kmer_score = b->par.kmer_score ? 1 : 0;
     S.big_keys = b->big_stride ? b->d_big_keys.as<uint64_t>() : nullptr;
     S.big_diags = b->big_stride ? b->d_big_diags.as<uint16_t>() : nullptr;
     S.big_stride = b->big_stride;
@@ -1011,7 +1018,8 @@ extern "C" int mmgpu_pf_run(mmgpu_ctx *c, mmgpu_pf_batch_t *b) {
         D.q_first = q0;
         D.n_queries = cn;
         D.cand_origin = (uint32_t)qebase[q0];
-        HIP_TRY(launch_pf_dedup(D, cev[0], cev[1], s));
+        if (b->par.kmer_score) HIP_TRY(launch_pf_count(D, cev[0], cev[1], s));
+        else HIP_TRY(launch_pf_dedup(D, cev[0], cev[1], s));
         const uint32_t z0 = ovf_chunk_lo[ch], z1 = ovf_chunk_lo[ch + 1];
         if (z1 > z0) {
             // one launch per flush (the total kept after flush k decides what flush k+1 does)
@@ -1059,6 +1067,11 @@ extern "C" int mmgpu_pf_fetch(mmgpu_ctx *c, mmgpu_pf_batch_t *b, mmgpu_pf_hit *h
     HIP_TRY(hipMemcpyAsync(counts, b->d_hit_count.p, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(thr.data(), b->d_diag_thr.p, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(surv.data(), b->d_surv_count.p, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
+    std::vector<uint64_t> match_sum;      // --diag-score 0: statistics_t::doubleMatches (sum of the match counts)
+    if (b->par.kmer_score && stats) {
+        match_sum.resize(nq);
+        HIP_TRY(hipMemcpyAsync(match_sum.data(), b->d_cells.p, (size_t)nq * 8, hipMemcpyDeviceToHost, s));
+    }
     HIP_TRY(hipStreamSynchronize(s));
     for (uint32_t i = 0; i < nq; i++) {
         if ((flags[i] & 1u) && b->status[i] == MMGPU_PF_OK) b->status[i] = MMGPU_PF_LONG_SEQ;
@@ -1068,7 +1081,7 @@ extern "C" int mmgpu_pf_fetch(mmgpu_ctx *c, mmgpu_pf_batch_t *b, mmgpu_pf_hit *h
         if (stats) {
             stats[i].db_matches = b->q_entries[i];
             stats[i].kmer_list_len = b->q_lists[i];
-            stats[i].double_hits = surv[i];
+            stats[i].double_hits = match_sum.empty() ? surv[i] : match_sum[i];
             stats[i].diag_thr = thr[i];
         }
     }

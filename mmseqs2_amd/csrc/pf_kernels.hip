@@ -1047,6 +1047,127 @@ __global__ __launch_bounds__(256) void pf_ungapped_kernel(PfDedupArgs A) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// --diag-score 0 (mmgpu_pf_params::kmer_score): findDuplicates with computeTotalScore (CacheFriendlyOperations.cpp:
+// 194-239).  The first pass is the same as above (an entry is flagged when its diagonal byte equals the previous entry's of
+// the same target); then the flagged entries are COUNTED per target (saturating at 255) and the target's element is its
+// first flagged entry (id, that entry's diagonal) with count = that number.  One wavefront per (query, bin); state per
+// target in LDS: previous diagonal byte | count << 8, plus the "has an element" bit.  Elements are listed in the order
+// of their first flagged entry (the reference's output order inside a bin); the counts are attached at the end, elements
+// with count >= min_diag_score go to the query's survivor list (the cut of QueryMatcher.cpp:216-219 is never lower).
+__global__ __launch_bounds__(256) void pf_count_kernel(PfDedupArgs A) {
+    __shared__ uint16_t s_state[4][PF_IDS_PER_BIN];
+    __shared__ uint32_t s_emit[4][PF_IDS_PER_BIN / 32];
+    const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
+    const uint32_t B = A.bins;
+    const uint64_t bucket = (uint64_t)A.q_first * B + (uint64_t)blockIdx.x * 4u + (uint32_t)wave;
+    if (bucket >= (uint64_t)(A.q_first + A.n_queries) * B) return;
+    const uint32_t q = (uint32_t)(bucket / B), bin = (uint32_t)(bucket % B);
+    const uint32_t ntiles = A.q_ntiles[q];
+    if (lane == 0) A.cand_count[bucket] = 0;      // nothing for the scoring kernels of the other mode
+    if (ntiles == 0) return;
+    const uint32_t tb = A.q_tile_base[q];
+    uint16_t *S = s_state[wave];
+    uint32_t *E = s_emit[wave];
+    int bshift = 0;
+    while ((1u << bshift) < B) bshift++;
+    for (int k = lane; k < PF_IDS_PER_BIN; k += 64) S[k] = 0;
+    for (int k = lane; k < PF_IDS_PER_BIN / 32; k += 64) E[k] = 0;
+    uint32_t ncand = 0;
+    const uint64_t below = lanes_below(lane);
+    for (uint32_t t0 = 0; t0 < ntiles; t0 += 64) {
+        const uint32_t tl = t0 + (uint32_t)lane;
+        uint32_t o0 = 0, n = 0;
+        if (tl < ntiles) {
+            const uint16_t *bo = A.bin_off + (size_t)(tb + tl) * (B + 1) + bin;
+            o0 = bo[0];
+            n = (uint32_t)bo[1] - o0;
+        }
+        const uint32_t incl = wave_incl_scan(n);
+        const uint32_t total = __shfl(incl, 63);
+        const uint32_t excl = incl - n;
+        for (uint32_t x0 = 0; x0 < total; x0 += 64) {
+            const uint32_t x = x0 + (uint32_t)lane;
+            const bool now = x < total;
+            const int m = seg_find(excl, now ? x : 0u);
+            const uint32_t ex_m = __shfl(excl, m), o_m = __shfl(o0, m);
+            const uint32_t tile = t0 + (uint32_t)m;
+            uint64_t e = 0;
+            if (now) e = A.split[(size_t)(tb + tile) * PF_T + o_m + (x - ex_m)];
+            const uint32_t id = (uint32_t)e;
+            const uint32_t diag = (uint32_t)(e >> 32) & 0xFFFFu;
+            const uint32_t d8 = diag & 0xFFu;
+            const uint32_t key = id >> bshift;   // < PF_IDS_PER_BIN
+            const uint32_t arr = tile * (uint32_t)PF_T + (uint32_t)(e >> 48);
+            const uint64_t same = match_lanes(key, 12, now);
+            uint32_t st = 0, em = 0;
+            if (now) {
+                st = S[key];
+                em = (E[key >> 5] >> (key & 31u)) & 1u;
+            }
+            // is my diagonal byte the previous entry's of this target?  (:194-208; the table starts at zero)
+            const uint64_t pm = same & below;
+            const int pl = pm ? highest_lane(pm) : lane;
+            const uint32_t d_pl = __shfl(d8, pl);
+            const uint32_t prevd = pm ? d_pl : (st & 0xFFu);
+            const bool flag = now && d8 == prevd;
+            const uint64_t fl = __ballot(flag);
+            const uint64_t fm = same & fl;
+            // the last lane of a target's group writes the state: its byte, the count so far + the group's flagged entries
+            if (now && (same & ~below & ~(1ull << lane)) == 0) {
+                const uint32_t cnt = min(255u, (st >> 8) + (uint32_t)__popcll(fm));
+                S[key] = (uint16_t)(d8 | (cnt << 8));
+            }
+            // the target's element: its first flagged entry
+            const bool keep = flag && (fm & below) == 0 && em == 0u;
+            if (keep) atomicOr(&E[key >> 5], 1u << (key & 31u));
+            const uint64_t kb = __ballot(keep);
+            if (keep) {
+                PfCand c;
+                c.id = id;
+                c.arr = arr;
+                c.score = 0;
+                c.diag = (uint16_t)diag;
+                c.pad = 0;
+                *cand_slot(A, bucket, ncand + (uint32_t)__popcll(kb & below)) = c;
+            }
+            ncand += (uint32_t)__popcll(kb);
+        }
+    }
+    if (ncand == 0) return;
+    __threadfence();      // the elements were written by other lanes of this wavefront
+    if (lane == 0 && A.q_ncand) {
+        const uint32_t before = atomicAdd(&A.q_ncand[q], ncand);
+        // resultSize >= foundDiagonalsSize / 2: the reference sorts with an unstable std::sort (QueryMatcher.cpp:221-231)
+        if (before + ncand >= A.sort_cap && A.q_flags) atomicOr(&A.q_flags[q], 2u);
+    }
+    PfCand *surv = A.surv + (A.cand_base[(uint64_t)q * B] - A.cand_origin);
+    unsigned long long total_count = 0;
+    for (uint32_t c0 = 0; c0 < ncand; c0 += 64) {
+        const uint32_t ci = c0 + (uint32_t)lane;
+        PfCand c;
+        c.id = 0; c.arr = 0; c.score = 0; c.diag = 0; c.pad = 0;
+        bool win = false;
+        if (ci < ncand) {
+            c = *cand_slot(A, bucket, ci);
+            c.score = (uint32_t)S[c.id >> bshift] >> 8;
+            total_count += c.score;
+            win = c.score >= A.min_diag_score;
+        }
+        const uint64_t wb = __ballot(win);
+        if (wb) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&A.surv_count[q], (uint32_t)__popcll(wb));
+            base = __shfl(base, 0);
+            if (win) surv[base + (uint32_t)__popcll(wb & below)] = c;
+        }
+    }
+    if (A.cell_counter) {   // statistics_t::doubleMatches = sum of the counts (QueryMatcher.cpp:366-385)
+        for (int dd = 1; dd < 64; dd <<= 1) total_count += __shfl_xor(total_count, dd);
+        if (lane == 0 && total_count) atomicAdd((unsigned long long *)&A.cell_counter[q], total_count);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // keepMaxElement (CacheFriendlyOperations.cpp:354-384): per target keep the first candidate (bin order = arrival
 // order) whose count = min(255, score) is the target's maximum; survivors with count >= min_diag_score are appended
 // to the query's list.  One wavefront per (query, bin); LDS table of (count << 24 | ~candidate index) per target.
@@ -1528,7 +1649,7 @@ __global__ __launch_bounds__(256) void pf_select_kernel(PfSelectArgs A) {
         }
         const uint32_t dthr = max(A.min_diag_score, thr);
         sh_thr = dthr;
-        sh_trunc = dthr >= 255u ? 1u : 0u;
+        sh_trunc = (dthr >= 255u && !A.kmer_score) ? 1u : 0u;   // getResult<KMER_SCORE> has no truncated-threshold path
         sh_nelig = 0;
         sh_nsel = 0;
     }
@@ -1630,7 +1751,7 @@ __global__ __launch_bounds__(256) void pf_select_kernel(PfSelectArgs A) {
                     uint32_t pref;
                     const uint32_t cnt = min(255u, c.score);
                     if (trunc) pref = 255u + (rescaled_count(c.score, fms) * (uint32_t)ms / 255u);
-                    else pref = cnt >= 255u ? c.score : cnt;
+                    else pref = (cnt >= 255u && !A.kmer_score) ? c.score : cnt;
                     skey[slot] = ((uint64_t)(0xFFFFFFFFu - pref) << 32) | (uint64_t)c.id;
                     sdiag[slot] = c.diag;
                 }
@@ -1687,7 +1808,7 @@ __global__ __launch_bounds__(256) void pf_select_kernel(PfSelectArgs A) {
         if (has_ident && max_hits > 0) {   // self hit first, score USHRT_MAX (getResult :408-424)
             mmgpu_pf_hit h;
             h.id = ident;
-            h.score = 65535;
+            h.score = A.kmer_score ? 255 : 65535;      // UCHAR_MAX for getResult<KMER_SCORE> (:410-413)
             h.diagonal = 0;
             h.reserved = 0;
             out[0] = h;
@@ -1822,6 +1943,17 @@ hipError_t launch_pf_dedup(const PfDedupArgs &A, hipEvent_t after_replay, hipEve
     if (A.nucl) hipLaunchKernelGGL(pf_keepmax_nucl_kernel, dim3((unsigned)((buckets + 1) / 2)), dim3(128), 0, s, A);
     else hipLaunchKernelGGL(pf_keepmax_kernel, grid, block, 0, s, A);
     return hipGetLastError();
+}
+
+hipError_t launch_pf_count(const PfDedupArgs &A, hipEvent_t after_a, hipEvent_t after_b, hipStream_t s) {
+    const uint64_t buckets = (uint64_t)A.n_queries * A.bins;
+    if (buckets == 0) return hipSuccess;
+    hipLaunchKernelGGL(pf_count_kernel, dim3((unsigned)((buckets + 3) / 4)), dim3(256), 0, s, A);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    if (after_a && (e = hipEventRecord(after_a, s)) != hipSuccess) return e;
+    if (after_b && (e = hipEventRecord(after_b, s)) != hipSuccess) return e;
+    return hipSuccess;
 }
 
 hipError_t launch_pf_segments(const PfSegArgs &A, hipStream_t s) {

@@ -83,6 +83,8 @@ typedef struct {
     uint32_t min_diag_score;
     int exact_kmer;             /* takeOnlyBestKmer (--exact-kmer-matching; always on in nucleotide searches, Search.cpp:186) */
     int nucleotide;             /* matchQuery's isNucleotide branch (QueryMatcher.cpp:147-177) */
+    int kmer_score;             /* --diag-score 0 (diagonalScoring == false): the prefilter score of a target is the number of its
+                                   double k-mer matches, no ungapped scoring (QueryMatcher.cpp:215-232, CacheFriendlyOperations.cpp:218-239) */
 } mmo_pf_params;
 
 typedef struct {
@@ -92,7 +94,9 @@ typedef struct {
     uint64_t after_keepmax;
     uint32_t diag_thr;
     int truncated;
-    int overflow; /* 1 = the databaseHits overflow path would trigger (not restated) */
+    int overflow; /* 1 = the databaseHits overflow path would trigger (not restated in kmer_score mode) */
+    int big_list; /* kmer_score mode: the element list reached foundDiagonalsSize / 2, where the reference sorts with an
+                     unstable std::sort (QueryMatcher.cpp:221-231): not restated */
     int sat_tie;  /* nucleotide branch: a target has two saturated (>= 255) elements on different diagonals with the same exact
                      score - the reference's choice then depends on the element order an unstable std::sort left (:154) */
 } mmo_pf_stats;

@@ -347,6 +347,7 @@ int mmgpu_pf_run(mmgpu_ctx *c, mmgpu_pf_batch_t *b) {
     P.min_diag_score = b->par.min_diag_score;
     P.exact_kmer = (int)b->par.exact_kmer;
     P.nucleotide = (int)b->par.nucleotide;
+    P.kmer_score = (int)b->par.kmer_score;
     const size_t cap = (size_t)std::min<uint64_t>(b->par.max_hits, c->n) + 1;
     int bad = 0;
 #pragma omp parallel for schedule(dynamic, 1)
@@ -383,6 +384,8 @@ int mmgpu_pf_fetch(mmgpu_ctx *c, mmgpu_pf_batch_t *b, mmgpu_pf_hit *hits, uint32
         counts[i] = (uint32_t)b->hits[i].size();
         status[i] = (long_target || b->q[i].size() >= 32768) ? MMGPU_PF_LONG_SEQ : MMGPU_PF_OK;
         if (status[i] == MMGPU_PF_OK && (b->stats[i].sat_tie || (b->par.nucleotide && b->stats[i].overflow))) status[i] = MMGPU_PF_SAT_TIE;
+        if (status[i] == MMGPU_PF_OK && b->par.kmer_score && b->stats[i].overflow) status[i] = MMGPU_PF_OVERFLOW;
+        if (status[i] == MMGPU_PF_OK && b->par.kmer_score && b->stats[i].big_list) status[i] = MMGPU_PF_SAT_TIE;
         if (status[i] != MMGPU_PF_OK) counts[i] = 0;
         for (size_t k = 0; k < b->hits[i].size() && k < stride; k++) {
             mmgpu_pf_hit &o = hits[i * (size_t)stride + k];

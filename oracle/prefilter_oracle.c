@@ -436,8 +436,16 @@ typedef struct {
 
 /* findDuplicates for diagonal scoring (CacheFriendlyOperations.cpp:38-49,185-278, computeTotalScore=false):
  * in: arrival-ordered (id, diag16); out: CounterResult list in bin order. */
+static size_t mmo_find_duplicates_mode(const uint32_t *aid, const uint16_t *adiag, size_t n, uint32_t bins,
+                                       uint32_t n_targets, mmo_cr *out, size_t out_cap, int total_score);
 static size_t mmo_find_duplicates(const uint32_t *aid, const uint16_t *adiag, size_t n, uint32_t bins,
                                   uint32_t n_targets, mmo_cr *out, size_t out_cap) {
+    return mmo_find_duplicates_mode(aid, adiag, n, bins, n_targets, out, out_cap, 0);
+}
+/* total_score != 0: computeTotalScore (:218-239, --diag-score 0): one element per target that has a flagged entry in the
+ * bin - the first flagged entry's diagonal, count = number of flagged entries (saturating at 255) */
+static size_t mmo_find_duplicates_mode(const uint32_t *aid, const uint16_t *adiag, size_t n, uint32_t bins,
+                                       uint32_t n_targets, mmo_cr *out, size_t out_cap, int total_score) {
     uint32_t bits = 0;
     while ((1u << bits) < bins) bits++;
     size_t tabsz = ((size_t)n_targets >> bits) + 2;
@@ -469,14 +477,30 @@ static size_t mmo_find_duplicates(const uint32_t *aid, const uint16_t *adiag, si
             dup[h] = curd;
         }
         if (outn + ec >= out_cap) break; /* :214-216 */
-        for (size_t z = ec; z-- > 0;) dup[tid[z] >> bits] = (uint8_t)((uint8_t)tdg[z] + 1); /* :242-247 */
-        for (size_t z = 0; z < ec; z++) { /* :250-265 */
-            size_t h = tid[z] >> bits;
-            out[outn].id = tid[z];
-            out[outn].count = 0;
-            out[outn].diagonal = tdg[z];
-            outn += (dup[h] != (uint8_t)tdg[z]);
-            dup[h] = (uint8_t)tdg[z];
+        if (total_score) {
+            for (size_t z = 0; z < ec; z++) dup[tid[z] >> bits] = 0; /* :219-222 */
+            for (size_t z = 0; z < ec; z++) { /* :224-227 */
+                size_t h = tid[z] >> bits;
+                dup[h] += (dup[h] < 255) ? 1 : 0;
+            }
+            for (size_t z = 0; z < ec; z++) { /* :229-239 */
+                size_t h = tid[z] >> bits;
+                out[outn].id = tid[z];
+                out[outn].count = dup[h];
+                out[outn].diagonal = tdg[z];
+                outn += (dup[h] != 0);
+                dup[h] = 0;
+            }
+        } else {
+            for (size_t z = ec; z-- > 0;) dup[tid[z] >> bits] = (uint8_t)((uint8_t)tdg[z] + 1); /* :242-247 */
+            for (size_t z = 0; z < ec; z++) { /* :250-265 */
+                size_t h = tid[z] >> bits;
+                out[outn].id = tid[z];
+                out[outn].count = 0;
+                out[outn].diagonal = tdg[z];
+                outn += (dup[h] != (uint8_t)tdg[z]);
+                dup[h] = (uint8_t)tdg[z];
+            }
         }
         for (size_t z = s; z < e; z++) dup[bid[z] >> bits] = 0; /* :268-275 */
     }
@@ -727,6 +751,10 @@ static int match_query_impl(const mmo_pf_params *P, const uint8_t *q, int qlen, 
             size_t len = (size_t)(o1 - o0);
             if (an + len >= max_db_matches) { /* :310 (sequenceHits + seqListSize) >= lastSequenceHit */
                 S.overflow++;
+                if (P->kmer_score) { /* the merge of the segments by score (:514-533) is not restated */
+                    aborted = 1;
+                    break;
+                }
                 /* everything gathered so far (incl. the lists of this position) is matched on its own */
                 size_t hc = mmo_find_duplicates(aid, adg, an, P->bins, P->n_targets, fd + overflow_hits,
                                                 found_cap - overflow_hits);
@@ -763,7 +791,54 @@ static int match_query_impl(const mmo_pf_params *P, const uint8_t *q, int qlen, 
             dump->arr_diag[e] = adg[e];
         }
 
-    {
+    if (P->kmer_score) {
+        /* ---- diagonalScoring == false: match() ends with findDuplicates(computeTotalScore) and the histogram of the counts
+         * (:353-371); matchQuery cuts at max(minDiagScoreThr, computeScoreThreshold) in radix order (:215-220) and getResult
+         * <KMER_SCORE> writes the counts as prefScore (self hit: UCHAR_MAX, :410-413) ---- */
+        size_t rs = 0;
+        if (an > 0 && !S.overflow) rs = mmo_find_duplicates_mode(aid, adg, an, P->bins, P->n_targets, fd, found_cap, 1);
+        S.double_hits = rs;
+        S.after_keepmax = rs;
+        unsigned sizes[256];
+        memset(sizes, 0, sizeof(sizes));
+        for (size_t z = 0; z < rs; z++) sizes[fd[z].count]++;
+        size_t foundh = 0, thr = 0;
+        for (thr = 255; thr > 0; thr--) {
+            foundh += sizes[thr];
+            if (foundh >= max_hits) break;
+        }
+        unsigned cut = (unsigned)thr > P->min_diag_score ? (unsigned)thr : P->min_diag_score;
+        S.diag_thr = cut;
+        if (rs >= found_cap / 2) S.big_list = 1;
+        mmo_cr *wr = fd + rs;
+        size_t above = mmo_radix_by_score(sizes, wr, cut, fd, rs);
+        size_t cur = 0;
+        if (identity_id != UINT32_MAX && cur < hit_cap) {
+            hits[cur].id = identity_id;
+            hits[cur].score = UCHAR_MAX;
+            hits[cur].diagonal = 0;
+            cur++;
+        }
+        for (size_t z = 0; z < above && cur < max_hits; z++) {
+            if (wr[z].count >= (cut & 0xFFFFu) && wr[z].id != identity_id) {
+                if (cur >= hit_cap) break;
+                hits[cur].id = wr[z].id;
+                hits[cur].score = (int)wr[z].count;
+                hits[cur].diagonal = wr[z].diagonal;
+                cur++;
+            }
+        }
+        if (cur > 1) {
+            if (identity_id != UINT32_MAX)
+                qsort(hits + 1, cur - 1, sizeof(mmo_pf_hit), mmo_hit_cmp);
+            else
+                qsort(hits, cur, sizeof(mmo_pf_hit), mmo_hit_cmp);
+        }
+        *n_hits = cur;
+        free(corr);
+        free(fd);
+        free(qprof);
+    } else {
         /* ---- last segment (:353-362): findDuplicates, and after an overflow the merge with the earlier hits ---- */
         size_t rs = 0;
         if (an > 0) {

@@ -240,13 +240,14 @@ class PfParams(ctypes.Structure):
                 ("kmer_thr", ctypes.c_int), ("offsets", c_p), ("ids", c_p), ("pos", c_p), ("tdata", c_p),
                 ("toff", c_p), ("n_targets", ctypes.c_uint32), ("ungapped_mat", c_p), ("bins", ctypes.c_uint32),
                 ("max_hits", ctypes.c_uint64), ("min_diag_score", ctypes.c_uint32), ("exact_kmer", ctypes.c_int),
-                ("nucleotide", ctypes.c_int)]
+                ("nucleotide", ctypes.c_int), ("kmer_score", ctypes.c_int)]
 
 
 class PfStats(ctypes.Structure):
     _fields_ = [("db_matches", ctypes.c_uint64), ("kmer_list_len", ctypes.c_uint64),
                 ("double_hits", ctypes.c_uint64), ("after_keepmax", ctypes.c_uint64),
-                ("diag_thr", ctypes.c_uint32), ("truncated", ctypes.c_int), ("overflow", ctypes.c_int), ("sat_tie", ctypes.c_int)]
+                ("diag_thr", ctypes.c_uint32), ("truncated", ctypes.c_int), ("overflow", ctypes.c_int), ("big_list", ctypes.c_int),
+                ("sat_tie", ctypes.c_int)]
 
 
 class PfDump(ctypes.Structure):
@@ -331,12 +332,14 @@ class PfOracle:
         return self.L.mmo_pf_ungapped_score(_ptr(q), _ptr(corr), len(q), _ptr(self.ungapped_mat), self.alphabet,
                                             _ptr(t), len(t), ctypes.c_uint16(int(diagonal) & 0xFFFF))
 
-    def match(self, q, comp_bias, bins, max_hits=300, min_diag_score=15, identity_id=None, dump=False, exact=False, nucleotide=False):
+    def match(self, q, comp_bias, bins, max_hits=300, min_diag_score=15, identity_id=None, dump=False, exact=False, nucleotide=False,
+              kmer_score=False):
         q = np.ascontiguousarray(q, np.uint8)
         cb = None if comp_bias is None else np.ascontiguousarray(comp_bias, np.float32)
         P = PfParams(ctypes.pointer(self.gen), self.alphabet, self.spaced, self.kmer_thr, self.offsets.ctypes.data,
                      self.ids.ctypes.data, self.pos.ctypes.data, self.tdata.ctypes.data, self.toff.ctypes.data,
-                     self.n_targets, self.ungapped_mat.ctypes.data, bins, max_hits, min_diag_score, int(exact), int(nucleotide))
+                     self.n_targets, self.ungapped_mat.ctypes.data, bins, max_hits, min_diag_score, int(exact), int(nucleotide),
+                     int(kmer_score))
         cap = int(min(max_hits, self.n_targets)) + 2
         hits = np.zeros(cap, PF_HIT_DTYPE)
         nh = ctypes.c_uint64(0)
@@ -470,10 +473,10 @@ class RefPrefilter:
         return out[:min(n, cap)].copy(), n
 
     def make_matcher(self, max_seq_len=32000, max_hits=300, comp_bias=True, comp_bias_scale=1.0, min_diag_score=15,
-                     force_bins=0):
+                     force_bins=0, diag_score=True):
         self.max_hits = max_hits
         return self.L.mmref_pref_make_matcher(self.c, self.kmer_thr, max_seq_len, ctypes.c_uint64(max_hits),
-                                              int(comp_bias), ctypes.c_float(comp_bias_scale), 1, min_diag_score,
+                                              int(comp_bias), ctypes.c_float(comp_bias_scale), int(diag_score), min_diag_score,
                                               int(self.spaced), int(force_bins))
 
     def match(self, q, identity_id=None):

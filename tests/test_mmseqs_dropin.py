@@ -372,3 +372,31 @@ def test_nucleotide_search_host_side_emulated(tmp_path):
 @pytest.mark.gpu
 def test_nucleotide_search_on_device(tmp_path):
     _nucleotide_pipeline(str(tmp_path), emulate=False)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# --diag-score 0: the prefilter scores are double-k-mer-match counts (no ungapped scoring; mmgpu_pf_params::kmer_score)
+def kmer_score_pipeline(tmp, emulate):
+    w = str(tmp)
+    copy_db(EXAMPLES, os.path.join(w, "q"))
+    n_entries = 0
+    for i, extra in enumerate((["--min-ungapped-score", "15"], ["--min-ungapped-score", "2", "--max-seqs", "20"],
+                               ["--min-ungapped-score", "1", "--mask", "0", "--comp-bias-corr", "0"])):
+        args = ["-s", "5.7", "--diag-score", "0"] + extra + ["--threads", THREADS]
+        run(STOCK, ["prefilter", "q", "q", "pref_s%d" % i] + args + ["-v", "2"], w)
+        log = run(MMGPU, ["prefilter", "q", "q", "pref_g%d" % i] + args + ["-v", "3"], w, emulate)
+        assert "MMGPU: device" in log and "using the CPU path" not in log, log[-2000:]
+        assert same(os.path.join(w, "pref_s%d" % i), os.path.join(w, "pref_g%d" % i)) == 500
+        n_entries += sum(int(line.split()[2]) > 1 for line in open(os.path.join(w, "pref_g%d.index" % i)))
+    assert n_entries > 1000      # most queries have a non-empty list (at least their self hit)
+
+
+def test_kmer_score_prefilter_host_side_emulated(tmp_path):
+    if not os.path.exists(EMU):
+        pytest.skip("oracle/_build/emu/libmmgpu.so not built (make -C oracle emu)")
+    kmer_score_pipeline(tmp_path, emulate=True)
+
+
+@pytest.mark.gpu
+def test_kmer_score_prefilter_on_device(tmp_path):
+    kmer_score_pipeline(tmp_path, emulate=False)
