@@ -400,3 +400,32 @@ def test_kmer_score_prefilter_host_side_emulated(tmp_path):
 @pytest.mark.gpu
 def test_kmer_score_prefilter_on_device(tmp_path):
     kmer_score_pipeline(tmp_path, emulate=False)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# --split: the reference's way to a database larger than memory - runSplit once per target split (reduced list length per
+# split, merged by the reference's mergeTargetSplits afterwards) or per query split; the hook sees one split at a time
+SPLIT_CASES = [["--split", "3", "--split-mode", "0"], ["--split", "2", "--split-mode", "1"],
+               ["--split", "4", "--split-mode", "0", "--max-seqs", "50"]]
+
+
+def split_pipeline(tmp, emulate):
+    w = str(tmp)
+    copy_db(EXAMPLES, os.path.join(w, "q"))
+    for i, extra in enumerate(SPLIT_CASES):
+        args = ["-s", "5.7"] + extra + ["--threads", THREADS]
+        run(STOCK, ["prefilter", "q", "q", "pref_s%d" % i] + args + ["-v", "2"], w)
+        log = run(MMGPU, ["prefilter", "q", "q", "pref_g%d" % i] + args + ["-v", "3"], w, emulate)
+        assert "MMGPU: device" in log and "using the CPU path" not in log, log[-2000:]
+        assert same(os.path.join(w, "pref_s%d" % i), os.path.join(w, "pref_g%d" % i)) == 500, extra
+
+
+def test_split_modes_host_side_emulated(tmp_path):
+    if not os.path.exists(EMU):
+        pytest.skip("oracle/_build/emu/libmmgpu.so not built (make -C oracle emu)")
+    split_pipeline(tmp_path, emulate=True)
+
+
+@pytest.mark.gpu
+def test_split_modes_on_device(tmp_path):
+    split_pipeline(tmp_path, emulate=False)
