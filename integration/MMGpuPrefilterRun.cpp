@@ -66,6 +66,9 @@ bool MMGpuPrefilterRun::usableConfig(Prefiltering &p, bool indexExists) {
 bool MMGpuPrefilterRun::deviceBuildsIndex(Prefiltering &p) {
     if (getenv("MMGPU_HOST_INDEX") != NULL && getenv("MMGPU_HOST_INDEX")[0] == '1') return false;
     if (p.templateDBIsIndex) return false;
+    // --target-search-mode 1: the index holds the SIMILAR k-mers of every target position (IndexBuilder.cpp:63,
+    // isTargetSimiliarKmerSearch) and the queries match exactly; that index is the host's to build, it is handed over as it is
+    if (p.targetSearchMode != 0) return false;
     // the same conditions run() will check at the seam, on what is known before the index exists
     const bool ok = usableConfig(p, false);
     if (ok) Debug(Debug::INFO) << "MMGPU: the k-mer index will be built on the device (MMGPU_HOST_INDEX=1 keeps the host's)\n";

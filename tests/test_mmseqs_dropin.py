@@ -406,14 +406,20 @@ def test_kmer_score_prefilter_on_device(tmp_path):
 # --split: the reference's way to a database larger than memory - runSplit once per target split (reduced list length per
 # split, merged by the reference's mergeTargetSplits afterwards) or per query split; the hook sees one split at a time
 SPLIT_CASES = [["--split", "3", "--split-mode", "0"], ["--split", "2", "--split-mode", "1"],
-               ["--split", "4", "--split-mode", "0", "--max-seqs", "50"]]
+               ["--split", "4", "--split-mode", "0", "--max-seqs", "50"],
+               # the index holds the similar k-mers of the targets, the queries match exactly (IndexBuilder.cpp:63): the host's
+               # index is handed over as it is (found by scripts/dropin_option_sweep.py: the device-built index was the plain one)
+               ["--target-search-mode", "1"],
+               # other matrices / alphabets / k through the same seam
+               ["--seed-sub-mat", "aa:VTML40.out,nucl:nucleotide.out", "--alph-size", "aa:13,nucl:5"]]
+SLOW_CASES = [["-k", "7", "--spaced-kmer-mode", "0", "-s", "4"]]      # k = 7 tables: minutes through the CPU stand-in, device only
 
 
 def split_pipeline(tmp, emulate):
     w = str(tmp)
     copy_db(EXAMPLES, os.path.join(w, "q"))
-    for i, extra in enumerate(SPLIT_CASES):
-        args = ["-s", "5.7"] + extra + ["--threads", THREADS]
+    for i, extra in enumerate(SPLIT_CASES + ([] if emulate else SLOW_CASES)):
+        args = (["-s", "5.7"] if "-s" not in extra else []) + extra + ["--threads", THREADS]
         run(STOCK, ["prefilter", "q", "q", "pref_s%d" % i] + args + ["-v", "2"], w)
         log = run(MMGPU, ["prefilter", "q", "q", "pref_g%d" % i] + args + ["-v", "3"], w, emulate)
         assert "MMGPU: device" in log and "using the CPU path" not in log, log[-2000:]
