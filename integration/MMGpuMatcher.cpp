@@ -100,11 +100,60 @@ bool MMGpuMatcher::alignBlock(const std::vector<Query> &queries, int covMode, fl
     par.alphabet = m->alphabetSize;
     par.gap_open = gapOpen;
     par.gap_extend = gapExtend;
+    // The device computes the textbook Gotoh recurrence; the reference's striped lazy-F loop equals it only while
+    // min(P) + gapExtend > -gapOpen (include/mmgpu.h, mmgpu_sw_prepare refuses a batch otherwise).  With small gap
+    // penalties (--gap-open 9 --gap-extend 2) a query with a strongly negative composition bias leaves that regime: its
+    // pairs go to the host's own Matcher::getSWResult as a whole (refusedPairs), the other queries of the block to the device.
+    std::vector<unsigned char> hostQuery(nq, 0);
+    size_t nHost = 0;
+    {
+        int minMat = 0;
+        for (size_t i = 0; i < tinySubMat.size(); i++) minMat = std::min(minMat, (int)tinySubMat[i]);
+        for (size_t q = 0; q < nq; q++) {
+            const Query &qu = queries[q];
+            int minP = minMat, minCb = 0;
+            if (qu.profile != NULL) {
+                minP = 0;
+                for (size_t i = 0; i < (size_t)Sequence::PROFILE_AA_SIZE * (size_t)qu.L; i++) minP = std::min(minP, (int)qu.profile[i]);
+            } else {
+                for (int i = 0; i < qu.L; i++) minCb = std::min(minCb, (int)bias[q][i]);
+            }
+            if (!(minP + minCb + gapExtend > -gapOpen) && !ids[q].empty()) {
+                hostQuery[q] = 1;
+                nHost++;
+            }
+        }
+    }
+    if (nHost != 0 && refusedPairs == NULL) {
+        err = "gap penalties too small for this matrix and query (the caller must run Matcher::getSWResult for such queries)";
+        return false;
+    }
+    // pair p of the block is pair devPair[p] of the device batch (the same without host queries)
+    std::vector<uint32_t> devPair;
     std::vector<mmgpu_sw_hit> hits(total);
     const int mode = alignmentMode == Matcher::SCORE_ONLY ? MMGPU_SW_SCORE_END : MMGPU_SW_START;
-    if (total && backend->align(&par, dq.data(), (uint32_t)nq, mode, hits.data()) != 0) {
-        err = backend->lastError();
-        return false;
+    if (nHost == 0) {
+        if (total && backend->align(&par, dq.data(), (uint32_t)nq, mode, hits.data()) != 0) {
+            err = backend->lastError();
+            return false;
+        }
+    } else {
+        std::vector<mmgpu_sw_query> dqDev;
+        devPair.assign(total, 0xFFFFFFFFu);
+        size_t totalDev = 0;
+        for (size_t q = 0; q < nq; q++) {
+            if (hostQuery[q]) continue;
+            dqDev.push_back(dq[q]);
+            for (size_t k = 0; k < ids[q].size(); k++) devPair[firstPair[q] + k] = (uint32_t)(totalDev + k);
+            totalDev += ids[q].size();
+        }
+        std::vector<mmgpu_sw_hit> hitsDev(totalDev);
+        if (totalDev && backend->align(&par, dqDev.data(), (uint32_t)dqDev.size(), mode, hitsDev.data()) != 0) {
+            err = backend->lastError();
+            return false;
+        }
+        for (size_t p = 0; p < total; p++)
+            if (devPair[p] != 0xFFFFFFFFu) hits[p] = hitsDev[devPair[p]];
     }
 
     watch.lap("device alignment (prepare, run, fetch)");
@@ -135,8 +184,8 @@ bool MMGpuMatcher::alignBlock(const std::vector<Query> &queries, int covMode, fl
             a.word = h.word;
             pe.wantsBacktrace = false;
             pe.blockDone = false;
-            pe.refuse = false;
-            if (a.dbEndPos1 != -1) {
+            pe.refuse = hostQuery[q] != 0;
+            if (a.dbEndPos1 != -1 && !pe.refuse) {
                 a.qCov = SmithWaterman::computeCov(0, a.qEndPos1, qlen);
                 a.tCov = SmithWaterman::computeCov(0, a.dbEndPos1, dbLen);
                 const bool lowCov = !Util::hasCoverage(covThr, covMode, a.qCov, a.tCov);
@@ -173,9 +222,12 @@ bool MMGpuMatcher::alignBlock(const std::vector<Query> &queries, int covMode, fl
         }
     }
     watch.lap("E-value / coverage gates + block hook");
-    std::vector<uint32_t> btPairs;
+    std::vector<uint32_t> btPairs, btBlockPair;      // device pair index / pair index inside the block
     for (size_t p = 0; p < total; p++)
-        if (aln[p].wantsBacktrace) btPairs.push_back((uint32_t)p);
+        if (aln[p].wantsBacktrace) {
+            btPairs.push_back(devPair.empty() ? (uint32_t)p : devPair[p]);
+            btBlockPair.push_back((uint32_t)p);
+        }
     std::vector<mmgpu_sw_bt> btInfo(btPairs.size());
     std::string btStrings;
     if (!btPairs.empty() && backend->traceback(btPairs.data(), (uint32_t)btPairs.size(), btInfo.data(), btStrings) != 0) {
@@ -184,7 +236,7 @@ bool MMGpuMatcher::alignBlock(const std::vector<Query> &queries, int covMode, fl
     }
     watch.lap("device traceback");
     std::vector<int> btOf(total, -1);
-    for (size_t i = 0; i < btPairs.size(); i++) btOf[btPairs[i]] = (int)i;
+    for (size_t i = 0; i < btBlockPair.size(); i++) btOf[btBlockPair[i]] = (int)i;
 
     // ---- Matcher::getSWResult's tail (Matcher.cpp:93-143) ----
     bool refused = false;
