@@ -115,8 +115,9 @@ bool MMGpuAlignRun::usable(const Alignment &a) {
                      (profileQuery && !a.includeIdentity && !a.sameQTDB)) &&
                     Parameters::isEqualDbtype(a.targetSeqType, Parameters::DBTYPE_AMINO_ACIDS);
     // what the device path does not cover keeps the reference's CPU loop: profile targets / nucleotide databases,
-    // realignment, alternative alignments, wrapped scoring, LCA realignment, correlation score
-    if (!aa || a.realign || a.altAlignment > 0 || a.wrappedScoring || a.lcaAlign || a.correlationScoreWeight != 0.0f) {
+    // alternative alignments, wrapped scoring, LCA realignment, correlation score, realignment of profile queries
+    // (--realign with sequence queries - the first iteration of an iterative search - is served: run() below)
+    if (!aa || (a.realign && profileQuery) || a.altAlignment > 0 || a.wrappedScoring || a.lcaAlign || a.correlationScoreWeight != 0.0f) {
         Debug(Debug::INFO) << "MMGPU: alignment configuration not covered by the device path, using the CPU path\n";
         return false;
     }
@@ -182,6 +183,18 @@ bool MMGpuAlignRun::run(Alignment &al, const std::string &outDB, const std::stri
     gpuMatcher.setThreads(threads);
     if (MMGpuRun::hostBlockAligner()) gpuMatcher.setBlockBacktracer(&blockHook, lookupTarget, &store);
     std::vector<Matcher *> cpuMatchers(threads, NULL);      // only for pairs whose backtrace the device declines
+    // --realign (:298-305,408-437): the accepted hits of a query are aligned a second time with the (biased) realign matrix
+    // for their boundaries and backtraces; scores and E-values stay the first pass's
+    BaseMatrix *realignMat = al.realign_m != NULL ? al.realign_m : al.m;
+    MMGpuMatcher gpuRealigner(backend, realignMat, &evaluer, al.compBiasCorrection, al.compBiasCorrectionScale, al.gapOpen, al.gapExtend);
+    HostBlockBacktracer realignBlockHook(threads, maxMatcherSeqLen, realignMat, al.compBiasCorrection, al.compBiasCorrectionScale, al.gapOpen,
+                                         al.gapExtend, al.querySeqType);
+    gpuRealigner.setThreads(threads);
+    if (MMGpuRun::hostBlockAligner()) gpuRealigner.setBlockBacktracer(&realignBlockHook, lookupTarget, &store);
+    Matcher *cpuRealigner = NULL;
+    std::vector<std::vector<Matcher::result_t> > accepted, realigned;
+    std::vector<MMGpuMatcher::Query> block2;
+    std::vector<std::pair<size_t, size_t> > refused2;
 
     // block = as many queries as keep the pair count of one device call bounded (a prefilter line has >= 6 bytes)
     const size_t maxBlockQueries = MMGpuRun::envSize("MMGPU_ALIGN_BLOCK_QUERIES", 16384);
@@ -306,21 +319,13 @@ bool MMGpuAlignRun::run(Alignment &al, const std::string &outDB, const std::stri
                                                                         al.swMode, al.seqIdMode, false, false);
         }
 
-        // ---- replay of :344-397 on the results, sort, serialise, write
+        // ---- replay of :344-397 on the results, sort
+        accepted.assign(nq, std::vector<Matcher::result_t>());
 #pragma omp parallel num_threads(threads)
         {
-            unsigned int thread_idx = 0;
-#ifdef OPENMP
-            thread_idx = static_cast<unsigned int>(omp_get_thread_num());
-#endif
-            std::string alnResultsOutString;
-            alnResultsOutString.reserve(1024 * 1024);
-            char buffer[1024 + 32768 * 4];
-            std::vector<Matcher::result_t> swResults;
-            swResults.reserve(300);
 #pragma omp for schedule(dynamic, 5) reduction(+ : alignmentsNum, totalPassedNum)
             for (size_t b = 0; b < nq; b++) {
-                progress.updateProgress();
+                std::vector<Matcher::result_t> &swResults = accepted[b];
                 size_t passedNum = 0;
                 unsigned int rejected = 0;
                 for (size_t k = 0; k < lists[b].size() && passedNum < al.maxAccept && rejected < al.maxReject; k++) {
@@ -349,6 +354,83 @@ bool MMGpuAlignRun::run(Alignment &al, const std::string &outDB, const std::stri
                 if (swResults.size() > 1) {
                     SORT_SERIAL(swResults.begin(), swResults.end(), Matcher::compareHits);
                 }
+            }
+        }
+        // ---- --realign: second device call over the accepted hits (:408-437)
+        if (al.realign) {
+            watch.lap("accept / sort");
+            block2.assign(nq, MMGpuMatcher::Query());
+            for (size_t b = 0; b < nq; b++) {
+                MMGpuMatcher::Query &q = block2[b];
+                q.numSequence = block[b].numSequence;
+                q.L = block[b].L;
+                q.profile = NULL;
+                if (lists[b].empty()) continue;       // *origData == '\0': the first pass's (empty) result is written
+                for (size_t r = 0; r < accepted[b].size(); r++) {
+                    const DBKeyType dbKey = accepted[b][r].dbKey;
+                    const size_t dbId = al.tdbr->getId(dbKey);
+                    MMGpuMatcher::Target t;
+                    t.id = (unsigned int)dbId;
+                    t.dbKey = dbKey;
+                    t.length = (int)(store.offsets[dbId + 1] - store.offsets[dbId]);
+                    t.numSequence = store.residues.data() + store.offsets[dbId];
+                    t.isIdentity = (queryKeys[b] == dbKey && (al.includeIdentity || al.sameQTDB)) ? true : false;
+                    q.targets.push_back(t);
+                }
+            }
+            realignBlockHook.newBlock();
+            if (!gpuRealigner.alignBlock(block2, al.covMode, al.realignCov, FLT_MAX, al.realignSwMode, al.seqIdMode, realigned, &refused2)) {
+                Debug(Debug::ERROR) << "MMGPU: " << gpuRealigner.error() << "\n";
+                EXIT(EXIT_FAILURE);
+            }
+            for (size_t r = 0; r < refused2.size(); r++) {
+                const size_t b = refused2[r].first;
+                const MMGpuMatcher::Target &t = block2[b].targets[refused2[r].second];
+                if (cpuRealigner == NULL)
+                    cpuRealigner = new Matcher(al.querySeqType, maxMatcherSeqLen, realignMat, &evaluer, al.compBiasCorrection,
+                                               al.compBiasCorrectionScale, al.gapOpen, al.gapExtend, 0.0f, al.zdrop);
+                qSeqs[0]->mapSequence(0, queryKeys[b], std::make_pair(block2[b].numSequence, (const unsigned int)block2[b].L));
+                dbSeqs[0]->mapSequence(t.id, t.dbKey, std::make_pair(t.numSequence, (const unsigned int)t.length));
+                cpuRealigner->initQuery(qSeqs[0]);
+                realigned[b][refused2[r].second] = cpuRealigner->getSWResult(dbSeqs[0], INT_MAX, false, al.covMode, al.realignCov, FLT_MAX,
+                                                                             al.realignSwMode, al.seqIdMode, t.isIdentity);
+            }
+            watch.lap("realign block");
+#pragma omp parallel for schedule(dynamic, 16) num_threads(threads)
+            for (size_t b = 0; b < nq; b++) {
+                if (lists[b].empty()) continue;
+                std::vector<Matcher::result_t> out;
+                int realignAccepted = 0;
+                for (size_t r = 0; r < accepted[b].size() && realignAccepted < al.realignMaxSeqs; r++) {
+                    Matcher::result_t res = realigned[b][r];
+                    const bool covOK = Util::hasCoverage(al.realignCov, al.covMode, res.qcov, res.dbcov);
+                    if (covOK == true || block2[b].targets[r].isIdentity) {
+                        res.score = accepted[b][r].score;
+                        res.eval = accepted[b][r].eval;
+                        out.emplace_back(res);
+                        realignAccepted++;
+                    }
+                }
+                if (out.size() > 1) {
+                    SORT_SERIAL(out.begin(), out.end(), Matcher::compareHits);
+                }
+                accepted[b].swap(out);
+            }
+        }
+        // ---- serialise, write
+#pragma omp parallel num_threads(threads)
+        {
+            unsigned int thread_idx = 0;
+#ifdef OPENMP
+            thread_idx = static_cast<unsigned int>(omp_get_thread_num());
+#endif
+            std::string alnResultsOutString;
+            alnResultsOutString.reserve(1024 * 1024);
+            char buffer[1024 + 32768 * 4];
+#pragma omp for schedule(dynamic, 5)
+            for (size_t b = 0; b < nq; b++) {
+                progress.updateProgress();
+                const std::vector<Matcher::result_t> &swResults = accepted[b];
                 if (al.alignmentOutputMode == Parameters::ALIGNMENT_OUTPUT_CLUSTER) {
                     for (size_t result = 0; result < swResults.size(); result++) {
                         alnResultsOutString.append(SSTR(swResults[result].dbKey));
@@ -362,7 +444,6 @@ bool MMGpuAlignRun::run(Alignment &al, const std::string &outDB, const std::stri
                 }
                 dbw.writeData(alnResultsOutString.c_str(), alnResultsOutString.length(), queryKeys[b], thread_idx);
                 alnResultsOutString.clear();
-                swResults.clear();
             }
         }
         watch.lap("accept / sort / write");
@@ -370,6 +451,7 @@ bool MMGpuAlignRun::run(Alignment &al, const std::string &outDB, const std::stri
         if (remap && next < end) al.prefdbr->remapData();
     }
     delete backend;
+    delete cpuRealigner;
     for (size_t i = 0; i < threads; i++) {
         delete qSeqs[i];
         delete dbSeqs[i];

@@ -46,6 +46,9 @@ ALIGN_CASES = [
     # textbook recurrence are aligned by the host's Matcher, the others on the device (found by scripts/dropin_option_sweep.py)
     ["-a", "--gap-open", "aa:9,nucl:5", "--gap-extend", "aa:2,nucl:2"],
     ["--alignment-mode", "3", "--gap-open", "aa:8,nucl:5", "--gap-extend", "aa:2,nucl:2"],
+    # --realign (the first iteration of an iterative search): second alignment of the accepted hits with the biased matrix
+    ["-a", "--realign", "1"],
+    ["--realign", "1", "--realign-score-bias", "-0.4", "--realign-max-seqs", "5", "-c", "0.5"],
 ]
 
 
@@ -123,6 +126,13 @@ def test_examples_search_workflow_on_device(tmp_path):
         log = run(MMGPU, ["search", "q", "q", "res_g" + s, "tmp_g" + s, "-s", s, "-a", "--threads", THREADS, "-v", "3"], w)
         assert log.count("MMGPU: device") >= 2, log[-3000:]
         assert same(os.path.join(w, "res_s" + s), os.path.join(w, "res_g" + s)) == 500
+    # iterative profile search (blastpgp.sh): realigned first iteration, profile queries in the second - every prefilter /
+    # align call of the workflow on the device
+    it = ["--num-iterations", "2", "-s", "4", "--threads", THREADS]
+    run(STOCK, ["search", "q", "q", "res_it_s", "tmp_it_s"] + it + ["-v", "2"], w)
+    log = run(MMGPU, ["search", "q", "q", "res_it_g", "tmp_it_g"] + it + ["-v", "3"], w)
+    assert log.count("MMGPU: device") >= 4 and "using the CPU path" not in log, log[-3000:]
+    assert same(os.path.join(w, "res_it_s"), os.path.join(w, "res_it_g")) == 500
 
 
 def _config3_tenth(w):
