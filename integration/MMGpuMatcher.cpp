@@ -105,7 +105,7 @@ bool MMGpuMatcher::alignBlock(const std::vector<Query> &queries, int covMode, fl
     // penalties (--gap-open 9 --gap-extend 2) a query with a strongly negative composition bias leaves that regime: its
     // pairs go to the host's own Matcher::getSWResult as a whole (refusedPairs), the other queries of the block to the device.
     std::vector<unsigned char> hostQuery(nq, 0);
-    size_t nHost = 0;
+    size_t nHost = 0, nHostPairs = 0;
     {
         int minMat = 0;
         for (size_t i = 0; i < tinySubMat.size(); i++) minMat = std::min(minMat, (int)tinySubMat[i]);
@@ -118,13 +118,14 @@ bool MMGpuMatcher::alignBlock(const std::vector<Query> &queries, int covMode, fl
             } else {
                 for (int i = 0; i < qu.L; i++) minCb = std::min(minCb, (int)bias[q][i]);
             }
-            if (!(minP + minCb + gapExtend > -gapOpen) && !ids[q].empty()) {
+            if (!(minP + minCb + gapExtend > -gapOpen)) {     // (also without pairs: the device checks every query it is given)
                 hostQuery[q] = 1;
                 nHost++;
+                if (!ids[q].empty()) nHostPairs += ids[q].size();
             }
         }
     }
-    if (nHost != 0 && refusedPairs == NULL) {
+    if (nHostPairs != 0 && refusedPairs == NULL) {
         err = "gap penalties too small for this matrix and query (the caller must run Matcher::getSWResult for such queries)";
         return false;
     }

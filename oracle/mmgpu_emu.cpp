@@ -100,6 +100,23 @@ int mmgpu_sw_prepare(mmgpu_ctx *c, const mmgpu_sw_params *p, const mmgpu_sw_quer
     b->go = p->gap_open;
     b->ge = p->gap_extend;
     b->mode = mode;
+    // the device library's precondition (mmgpu_api.hip, sw_prepare_impl): outside it the textbook recurrence the kernels
+    // compute is not the reference's striped loop; the stand-in refuses the same batches so that the host side is tested for it
+    int minp = 0;
+    for (int i = 0; i < p->alphabet * p->alphabet; i++) minp = std::min<int>(minp, p->mat[i]);
+    for (uint32_t i = 0; i < nq; i++) {
+        int qminp = minp, mincb = 0;
+        if (qs[i].profile) {
+            qminp = 0;
+            for (size_t k = 0; k < (size_t)qs[i].profile_letters * qs[i].qlen; k++) qminp = std::min<int>(qminp, qs[i].profile[k]);
+        } else if (qs[i].comp_bias) {
+            for (uint32_t k = 0; k < qs[i].qlen; k++) mincb = std::min<int>(mincb, qs[i].comp_bias[k]);
+        }
+        if (qs[i].qlen && !(qminp + mincb + p->gap_extend > -p->gap_open)) {
+            delete b;
+            return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_sw_prepare: gap penalties too small for this matrix (adjacent insertion+deletion could win)");
+        }
+    }
     for (uint32_t i = 0; i < nq; i++) {
         b->q.push_back(std::vector<uint8_t>(qs[i].q, qs[i].q + qs[i].qlen));
         if (qs[i].comp_bias) b->cb.push_back(std::vector<int8_t>(qs[i].comp_bias, qs[i].comp_bias + qs[i].qlen));
