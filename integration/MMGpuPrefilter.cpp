@@ -133,21 +133,33 @@ bool MMGpuPrefilter::matchBlock(const std::vector<Query> &queries, int kmerThr, 
     std::vector<mmgpu_pf_hit> hits(nq * (size_t)stride);
     std::vector<uint32_t> counts(nq);
     std::vector<int32_t> status(nq);
-    mmgpu_pf_batch_t *batch = NULL;
     MMGpuStopwatch watch("prefilter block");
     watch.lap("composition bias");
-    int rc = mmgpu_pf_prepare(gpu, &par, dq.data(), (uint32_t)nq, &batch);
-    watch.lap("mmgpu_pf_prepare");
-    if (rc == 0) rc = mmgpu_pf_run(gpu, batch);
     if (stats) stats->assign(nq, mmgpu_pf_qstat());
-    if (rc == 0) rc = mmgpu_pf_fetch(gpu, batch, hits.data(), stride, counts.data(), status.data(), stats ? stats->data() : NULL);
-    watch.lap("mmgpu_pf_run + fetch");
-    if (batch) mmgpu_pf_free(gpu, batch);
-    watch.lap("mmgpu_pf_free");
-    if (rc != 0) {
-        err = mmgpu_last_error();
-        return false;
+    // One device batch for the block; a batch the device cannot hold (out of HBM, or 2^32 index entries and more - a large
+    // database with long or repetitive queries) is cut in halves and retried, down to single queries.
+    std::vector<std::pair<size_t, size_t> > todo(1, std::make_pair((size_t)0, nq));
+    while (!todo.empty()) {
+        const size_t lo = todo.back().first, hi = todo.back().second;
+        todo.pop_back();
+        mmgpu_pf_batch_t *batch = NULL;
+        int rc = mmgpu_pf_prepare(gpu, &par, dq.data() + lo, (uint32_t)(hi - lo), &batch);
+        if (rc == 0) rc = mmgpu_pf_run(gpu, batch);
+        if (rc == 0) rc = mmgpu_pf_fetch(gpu, batch, hits.data() + lo * (size_t)stride, stride, counts.data() + lo, status.data() + lo,
+                                         stats ? stats->data() + lo : NULL);
+        if (rc != 0) err = mmgpu_last_error();
+        if (batch) mmgpu_pf_free(gpu, batch);
+        if (rc != 0) {
+            if ((rc == MMGPU_ERR_HIP || rc == MMGPU_ERR_UNSUPPORTED) && hi - lo > 1) {
+                const size_t mid = lo + (hi - lo) / 2;
+                todo.push_back(std::make_pair(mid, hi));
+                todo.push_back(std::make_pair(lo, mid));
+                continue;
+            }
+            return false;
+        }
     }
+    watch.lap("mmgpu_pf_prepare + run + fetch");
     for (size_t q = 0; q < nq; q++) {
         if (status[q] != MMGPU_PF_OK) {     // MMGPU_PF_OVERFLOW / MMGPU_PF_LONG_SEQ: the host's own matcher runs this query
             needsCpu[q] = true;

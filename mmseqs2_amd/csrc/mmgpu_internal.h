@@ -509,10 +509,12 @@ struct DevBuf {
                 cache->trim();
                 e = hipMalloc(&p, cap);
             }
-            if (e != hipSuccess) { p = nullptr; cap = 0; }
+            if (e != hipSuccess) { p = nullptr; cap = 0; bytes = 0; }   // (bytes = 0: a later, smaller reserve() must allocate)
             return e;
         }
-        return hipMalloc(&p, n);
+        const hipError_t e = hipMalloc(&p, n);
+        if (e != hipSuccess) { p = nullptr; bytes = 0; (void)hipGetLastError(); }
+        return e;
     }
     // grow-only (contents are not preserved)
     hipError_t reserve(size_t n) { return n <= bytes ? hipSuccess : alloc(n + n / 8); }

@@ -319,6 +319,9 @@ int mmgpu_pf_build_index(mmgpu_ctx *c, const mmgpu_pf_index *ix, const int16_t *
 
 int mmgpu_pf_prepare(mmgpu_ctx *c, const mmgpu_pf_params *p, const mmgpu_pf_query *qs, uint32_t nq, mmgpu_pf_batch_t **out) {
     if (!c->have_index) return fail(MMGPU_ERR_STATE, "no index");
+    // test knob: behave like a device whose memory holds at most this many queries per batch (the host must cut the block)
+    if (const char *e = getenv("MMGPU_EMU_MAX_BATCH"))
+        if (nq > (uint32_t)atoi(e)) return fail(MMGPU_ERR_HIP, "hipMalloc: out of memory (emulated)");
     mmgpu_pf_batch_t *b = new mmgpu_pf_batch_t();
     b->par = *p;
     for (uint32_t i = 0; i < nq; i++) {

@@ -449,3 +449,17 @@ def test_split_modes_host_side_emulated(tmp_path):
 @pytest.mark.gpu
 def test_split_modes_on_device(tmp_path):
     split_pipeline(tmp_path, emulate=False)
+
+
+def test_block_too_large_for_the_device_is_cut_and_retried(tmp_path):
+    """a batch the device cannot hold (out of HBM / 2^32 index entries) is halved and retried by the prefilter hook; the
+    stand-in plays a device that holds at most 37 queries per batch (MMGPU_EMU_MAX_BATCH)"""
+    if not os.path.exists(EMU):
+        pytest.skip("oracle/_build/emu/libmmgpu.so not built (make -C oracle emu)")
+    w = str(tmp_path)
+    copy_db(EXAMPLES, os.path.join(w, "q"))
+    args = ["-s", "4", "--threads", THREADS]
+    run(STOCK, ["prefilter", "q", "q", "pref_s"] + args + ["-v", "2"], w)
+    log = run(MMGPU, ["prefilter", "q", "q", "pref_g"] + args + ["-v", "3"], w, True, extra_env={"MMGPU_EMU_MAX_BATCH": "37"})
+    assert "MMGPU: device" in log and "using the CPU path" not in log, log[-2000:]
+    assert same(os.path.join(w, "pref_s"), os.path.join(w, "pref_g")) == 500
