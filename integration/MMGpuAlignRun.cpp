@@ -115,9 +115,10 @@ bool MMGpuAlignRun::usable(const Alignment &a) {
                      (profileQuery && !a.includeIdentity && !a.sameQTDB)) &&
                     Parameters::isEqualDbtype(a.targetSeqType, Parameters::DBTYPE_AMINO_ACIDS);
     // what the device path does not cover keeps the reference's CPU loop: profile targets / nucleotide databases,
-    // alternative alignments, wrapped scoring, LCA realignment, correlation score, realignment of profile queries
+    // alternative alignments together with realignment, wrapped scoring, LCA realignment, correlation score, realignment of profile queries
     // (--realign with sequence queries - the first iteration of an iterative search - is served: run() below)
-    if (!aa || (a.realign && profileQuery) || a.altAlignment > 0 || a.wrappedScoring || a.lcaAlign || a.correlationScoreWeight != 0.0f) {
+    // (--alt-ali without --realign is served: the list on the device, the few re-alignments of masked targets on the host)
+    if (!aa || (a.realign && profileQuery) || (a.altAlignment > 0 && a.realign) || a.wrappedScoring || a.lcaAlign || a.correlationScoreWeight != 0.0f) {
         Debug(Debug::INFO) << "MMGPU: alignment configuration not covered by the device path, using the CPU path\n";
         return false;
     }
@@ -350,6 +351,24 @@ bool MMGpuAlignRun::run(Alignment &al, const std::string &outDB, const std::stri
                     } else {
                         rejected++;
                     }
+                }
+                // --alt-ali (:399-401, computeAlternativeAlignment :569-601): the aligned range of an accepted target is masked
+                // with X and the pair aligned again, up to altAlignment times.  The masked targets are not the resident ones
+                // and there are few of them: the reference's own function with a host Matcher per thread.
+                if (al.altAlignment > 0 && al.realign == false && al.wrappedScoring == false && !swResults.empty()) {
+                    unsigned int thread_idx = 0;
+#ifdef OPENMP
+                    thread_idx = static_cast<unsigned int>(omp_get_thread_num());
+#endif
+                    if (cpuMatchers[thread_idx] == NULL)
+                        cpuMatchers[thread_idx] = new Matcher(al.querySeqType, maxMatcherSeqLen, al.m, &evaluer, al.compBiasCorrection,
+                                                              al.compBiasCorrectionScale, al.gapOpen, al.gapExtend, 0.0f, al.zdrop);
+                    Sequence &qSeq = *qSeqs[thread_idx];
+                    if (profileQuery) qSeq.mapSequence(queryIds[b], queryKeys[b], al.qdbr->getData(queryIds[b], thread_idx), al.qdbr->getSeqLen(queryIds[b]));
+                    else qSeq.mapSequence(0, queryKeys[b], std::make_pair(block[b].numSequence, (const unsigned int)block[b].L));
+                    cpuMatchers[thread_idx]->initQuery(&qSeq);
+                    al.computeAlternativeAlignment(queryKeys[b], *dbSeqs[thread_idx], swResults, *cpuMatchers[thread_idx], al.covThr, al.evalThr,
+                                                   al.swMode, thread_idx);
                 }
                 if (swResults.size() > 1) {
                     SORT_SERIAL(swResults.begin(), swResults.end(), Matcher::compareHits);
