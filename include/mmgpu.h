@@ -290,7 +290,7 @@ int mmgpu_pf_debug_index(mmgpu_ctx *ctx, uint64_t *offsets, uint32_t *ids, uint1
 typedef struct {
     int kmer_thr;            /* Prefiltering::getKmerThreshold */
     uint32_t max_hits;       /* maxResListLen (--max-seqs); min(., dbSize) is applied like QueryMatcher.cpp:47 */
-    uint32_t min_diag_score; /* --min-ungapped-score (15); must be >= 1 */
+    uint32_t min_diag_score; /* --min-ungapped-score (15); must be >= 1 (0 is accepted with kmer_score, where it equals 1) */
     uint32_t ref_bins;       /* the CacheFriendlyOperations<N> the CPU run would use (QueryMatcher.cpp:460-488);
                                 only decides which of several equal-score hits survive the max_hits cut.
                                 0 = derive from dbSize and this host's L2 size like the reference */

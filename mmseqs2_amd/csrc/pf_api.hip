@@ -519,7 +519,9 @@ extern "C" int mmgpu_pf_prepare(mmgpu_ctx *c, const mmgpu_pf_params *par, const 
                                 mmgpu_pf_batch_t **out) {
     if (!c || !par || !out || (!qs && nq)) return fail(MMGPU_ERR_ARG, "mmgpu_pf_prepare: NULL argument");
     if (!c->pf || !c->db.res) return fail(MMGPU_ERR_STATE, "mmgpu_pf_prepare: no index loaded");
-    if (par->min_diag_score < 1) return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_pf_prepare: min_diag_score must be >= 1");
+    // (with kmer_score every element has a count >= 1, so a cut at 0 is the cut at 1: `mmseqs cluster` runs its first
+    // prefilter with --diag-score 0 --min-ungapped-score 0, Cluster.cpp:225-227)
+    if (par->min_diag_score < 1 && !par->kmer_score) return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_pf_prepare: min_diag_score must be >= 1");
     if (par->max_hits < 1) return fail(MMGPU_ERR_ARG, "mmgpu_pf_prepare: max_hits must be >= 1");
     const PfIndex &P = *c->pf;
     if (!par->exact_kmer && !P.has_tables) return fail(MMGPU_ERR_STATE, "mmgpu_pf_prepare: the index was loaded without similar-k-mer tables (exact k-mer matching only)");
@@ -544,6 +546,7 @@ extern "C" int mmgpu_pf_prepare(mmgpu_ctx *c, const mmgpu_pf_params *par, const 
 
     mmgpu_pf_batch_t *b = new mmgpu_pf_batch_t();
     b->par = *par;
+    if (b->par.min_diag_score < 1) b->par.min_diag_score = 1;
     b->nq = nq;
     b->max_hits = max_hits;
     b->bins = bins;

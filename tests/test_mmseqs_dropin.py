@@ -397,8 +397,10 @@ def kmer_score_pipeline(tmp, emulate):
     copy_db(EXAMPLES, os.path.join(w, "q"))
     n_entries = 0
     for i, extra in enumerate((["--min-ungapped-score", "15"], ["--min-ungapped-score", "2", "--max-seqs", "20"],
-                               ["--min-ungapped-score", "1", "--mask", "0", "--comp-bias-corr", "0"])):
-        args = ["-s", "5.7", "--diag-score", "0"] + extra + ["--threads", THREADS]
+                               ["--min-ungapped-score", "1", "--mask", "0", "--comp-bias-corr", "0"],
+                               # what `mmseqs cluster` runs first (Cluster.cpp:225-228)
+                               ["--min-ungapped-score", "0", "--comp-bias-corr", "0", "-s", "1"])):
+        args = (["-s", "5.7"] if "-s" not in extra else []) + ["--diag-score", "0"] + extra + ["--threads", THREADS]
         run(STOCK, ["prefilter", "q", "q", "pref_s%d" % i] + args + ["-v", "2"], w)
         log = run(MMGPU, ["prefilter", "q", "q", "pref_g%d" % i] + args + ["-v", "3"], w, emulate)
         assert "MMGPU: device" in log and "using the CPU path" not in log, log[-2000:]
@@ -465,3 +467,27 @@ def test_block_too_large_for_the_device_is_cut_and_retried(tmp_path):
     log = run(MMGPU, ["prefilter", "q", "q", "pref_g"] + args + ["-v", "3"], w, True, extra_env={"MMGPU_EMU_MAX_BATCH": "37"})
     assert "MMGPU: device" in log and "using the CPU path" not in log, log[-2000:]
     assert same(os.path.join(w, "pref_s"), os.path.join(w, "pref_g")) == 500
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# `mmseqs cluster` (cascaded clustering): its first prefilter runs with --diag-score 0 --min-ungapped-score 0 --comp-bias-corr 0
+# (Cluster.cpp:225-228), the later steps with rising sensitivity; every prefilter / align call of the workflow on the device
+def cluster_pipeline(tmp, emulate):
+    w = str(tmp)
+    copy_db(EXAMPLES, os.path.join(w, "q"))
+    for i, a in enumerate((["--min-seq-id", "0.3", "-s", "4"], ["-c", "0.9", "--cov-mode", "1", "--cluster-mode", "2"])):
+        run(STOCK, ["cluster", "q", "clu_s%d" % i, "tmp_s%d" % i] + a + ["--threads", THREADS, "-v", "2"], w)
+        log = run(MMGPU, ["cluster", "q", "clu_g%d" % i, "tmp_g%d" % i] + a + ["--threads", THREADS, "-v", "3"], w, emulate)
+        assert log.count("MMGPU: device") >= 6 and "using the CPU path" not in log, log[-3000:]
+        assert same(os.path.join(w, "clu_s%d" % i), os.path.join(w, "clu_g%d" % i)) > 400
+
+
+def test_cluster_workflow_host_side_emulated(tmp_path):
+    if not os.path.exists(EMU):
+        pytest.skip("oracle/_build/emu/libmmgpu.so not built (make -C oracle emu)")
+    cluster_pipeline(tmp_path, emulate=True)
+
+
+@pytest.mark.gpu
+def test_cluster_workflow_on_device(tmp_path):
+    cluster_pipeline(tmp_path, emulate=False)
