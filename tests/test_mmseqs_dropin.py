@@ -491,3 +491,30 @@ def test_cluster_workflow_host_side_emulated(tmp_path):
 @pytest.mark.gpu
 def test_cluster_workflow_on_device(tmp_path):
     cluster_pipeline(tmp_path, emulate=False)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# a target database with a precomputed index (`mmseqs createindex`): Prefiltering reads IndexTable / SequenceLookup from the
+# .idx file (PrefilteringIndexReader) and the hook hands them over as they are
+def indexed_target_pipeline(tmp, emulate):
+    w = str(tmp)
+    copy_db(EXAMPLES, os.path.join(w, "q"))
+    copy_db(EXAMPLES, os.path.join(w, "t"))
+    run(STOCK, ["createindex", "t", "tmpidx", "--threads", THREADS, "-v", "2"], w)
+    assert os.path.exists(os.path.join(w, "t.idx"))
+    args = ["-s", "5.7", "-a", "--threads", THREADS]
+    run(STOCK, ["search", "q", "t", "res_s", "tmp_s"] + args + ["-v", "2"], w)
+    log = run(MMGPU, ["search", "q", "t", "res_g", "tmp_g"] + args + ["-v", "3"], w, emulate)
+    assert log.count("MMGPU: device") >= 2 and "using the CPU path" not in log, log[-3000:]
+    assert same(os.path.join(w, "res_s"), os.path.join(w, "res_g")) == 500
+
+
+def test_indexed_target_db_host_side_emulated(tmp_path):
+    if not os.path.exists(EMU):
+        pytest.skip("oracle/_build/emu/libmmgpu.so not built (make -C oracle emu)")
+    indexed_target_pipeline(tmp_path, emulate=True)
+
+
+@pytest.mark.gpu
+def test_indexed_target_db_on_device(tmp_path):
+    indexed_target_pipeline(tmp_path, emulate=False)
