@@ -115,10 +115,10 @@ bool MMGpuAlignRun::usable(const Alignment &a) {
                      (profileQuery && !a.includeIdentity && !a.sameQTDB)) &&
                     Parameters::isEqualDbtype(a.targetSeqType, Parameters::DBTYPE_AMINO_ACIDS);
     // what the device path does not cover keeps the reference's CPU loop: profile targets / nucleotide databases,
-    // alternative alignments together with realignment, wrapped scoring, LCA realignment, correlation score, realignment of profile queries
+    // wrapped scoring, LCA realignment, correlation score, realignment of profile queries
     // (--realign with sequence queries - the first iteration of an iterative search - is served: run() below)
-    // (--alt-ali without --realign is served: the list on the device, the few re-alignments of masked targets on the host)
-    if (!aa || (a.realign && profileQuery) || (a.altAlignment > 0 && a.realign) || a.wrappedScoring || a.lcaAlign || a.correlationScoreWeight != 0.0f) {
+    // (--alt-ali is served: the list on the device, the few re-alignments of masked targets on the host)
+    if (!aa || (a.realign && profileQuery) || a.wrappedScoring || a.lcaAlign || a.correlationScoreWeight != 0.0f) {
         Debug(Debug::INFO) << "MMGPU: alignment configuration not covered by the device path, using the CPU path\n";
         return false;
     }
@@ -192,7 +192,7 @@ bool MMGpuAlignRun::run(Alignment &al, const std::string &outDB, const std::stri
                                          al.gapExtend, al.querySeqType);
     gpuRealigner.setThreads(threads);
     if (MMGpuRun::hostBlockAligner()) gpuRealigner.setBlockBacktracer(&realignBlockHook, lookupTarget, &store);
-    Matcher *cpuRealigner = NULL;
+    std::vector<Matcher *> cpuRealigners(threads, NULL);      // refused pairs of the realignment, --alt-ali after --realign
     std::vector<std::vector<Matcher::result_t> > accepted, realigned;
     std::vector<MMGpuMatcher::Query> block2;
     std::vector<std::pair<size_t, size_t> > refused2;
@@ -405,14 +405,14 @@ bool MMGpuAlignRun::run(Alignment &al, const std::string &outDB, const std::stri
             for (size_t r = 0; r < refused2.size(); r++) {
                 const size_t b = refused2[r].first;
                 const MMGpuMatcher::Target &t = block2[b].targets[refused2[r].second];
-                if (cpuRealigner == NULL)
-                    cpuRealigner = new Matcher(al.querySeqType, maxMatcherSeqLen, realignMat, &evaluer, al.compBiasCorrection,
-                                               al.compBiasCorrectionScale, al.gapOpen, al.gapExtend, 0.0f, al.zdrop);
+                if (cpuRealigners[0] == NULL)
+                    cpuRealigners[0] = new Matcher(al.querySeqType, maxMatcherSeqLen, realignMat, &evaluer, al.compBiasCorrection,
+                                                   al.compBiasCorrectionScale, al.gapOpen, al.gapExtend, 0.0f, al.zdrop);
                 qSeqs[0]->mapSequence(0, queryKeys[b], std::make_pair(block2[b].numSequence, (const unsigned int)block2[b].L));
                 dbSeqs[0]->mapSequence(t.id, t.dbKey, std::make_pair(t.numSequence, (const unsigned int)t.length));
-                cpuRealigner->initQuery(qSeqs[0]);
-                realigned[b][refused2[r].second] = cpuRealigner->getSWResult(dbSeqs[0], INT_MAX, false, al.covMode, al.realignCov, FLT_MAX,
-                                                                             al.realignSwMode, al.seqIdMode, t.isIdentity);
+                cpuRealigners[0]->initQuery(qSeqs[0]);
+                realigned[b][refused2[r].second] = cpuRealigners[0]->getSWResult(dbSeqs[0], INT_MAX, false, al.covMode, al.realignCov, FLT_MAX,
+                                                                                 al.realignSwMode, al.seqIdMode, t.isIdentity);
             }
             watch.lap("realign block");
 #pragma omp parallel for schedule(dynamic, 16) num_threads(threads)
@@ -429,6 +429,20 @@ bool MMGpuAlignRun::run(Alignment &al, const std::string &outDB, const std::stri
                         out.emplace_back(res);
                         realignAccepted++;
                     }
+                }
+                if (al.altAlignment > 0 && !out.empty()) {      // :433-435, with the realigner and the realignment's thresholds
+                    unsigned int thread_idx = 0;
+#ifdef OPENMP
+                    thread_idx = static_cast<unsigned int>(omp_get_thread_num());
+#endif
+                    if (cpuRealigners[thread_idx] == NULL)
+                        cpuRealigners[thread_idx] = new Matcher(al.querySeqType, maxMatcherSeqLen, realignMat, &evaluer, al.compBiasCorrection,
+                                                                al.compBiasCorrectionScale, al.gapOpen, al.gapExtend, 0.0f, al.zdrop);
+                    Sequence &qSeq = *qSeqs[thread_idx];
+                    qSeq.mapSequence(0, queryKeys[b], std::make_pair(block2[b].numSequence, (const unsigned int)block2[b].L));
+                    cpuRealigners[thread_idx]->initQuery(&qSeq);
+                    al.computeAlternativeAlignment(queryKeys[b], *dbSeqs[thread_idx], out, *cpuRealigners[thread_idx], al.realignCov, FLT_MAX,
+                                                   al.realignSwMode, thread_idx);
                 }
                 if (out.size() > 1) {
                     SORT_SERIAL(out.begin(), out.end(), Matcher::compareHits);
@@ -470,8 +484,8 @@ bool MMGpuAlignRun::run(Alignment &al, const std::string &outDB, const std::stri
         if (remap && next < end) al.prefdbr->remapData();
     }
     delete backend;
-    delete cpuRealigner;
     for (size_t i = 0; i < threads; i++) {
+        delete cpuRealigners[i];
         delete qSeqs[i];
         delete dbSeqs[i];
         delete cpuMatchers[i];

@@ -51,6 +51,7 @@ ALIGN_CASES = [
     ["--realign", "1", "--realign-score-bias", "-0.4", "--realign-max-seqs", "5", "-c", "0.5"],
     # --alt-ali: the list on the device, the re-alignments of the masked accepted targets by the reference's own function
     ["-a", "--alt-ali", "2"],
+    ["-a", "--alt-ali", "1", "--realign", "1"],
 ]
 
 
