@@ -115,10 +115,10 @@ bool MMGpuAlignRun::usable(const Alignment &a) {
                      (profileQuery && !a.includeIdentity && !a.sameQTDB)) &&
                     Parameters::isEqualDbtype(a.targetSeqType, Parameters::DBTYPE_AMINO_ACIDS);
     // what the device path does not cover keeps the reference's CPU loop: profile targets / nucleotide databases,
-    // wrapped scoring, LCA realignment, correlation score, realignment of profile queries
+    // wrapped scoring, LCA realignment, realignment of profile queries, the correlation score with profile queries / realignment
     // (--realign with sequence queries - the first iteration of an iterative search - is served: run() below)
     // (--alt-ali is served: the list on the device, the few re-alignments of masked targets on the host)
-    if (!aa || (a.realign && profileQuery) || a.wrappedScoring || a.lcaAlign || a.correlationScoreWeight != 0.0f) {
+    if (!aa || (a.realign && profileQuery) || a.wrappedScoring || a.lcaAlign || (a.correlationScoreWeight != 0.0f && (profileQuery || a.realign))) {
         Debug(Debug::INFO) << "MMGPU: alignment configuration not covered by the device path, using the CPU path\n";
         return false;
     }
@@ -182,6 +182,7 @@ bool MMGpuAlignRun::run(Alignment &al, const std::string &outDB, const std::stri
     HostBlockBacktracer blockHook(threads, maxMatcherSeqLen, al.m, al.compBiasCorrection, al.compBiasCorrectionScale, al.gapOpen,
                                   al.gapExtend, al.querySeqType);
     gpuMatcher.setThreads(threads);
+    gpuMatcher.setCorrelationScoreWeight(al.correlationScoreWeight);
     if (MMGpuRun::hostBlockAligner()) gpuMatcher.setBlockBacktracer(&blockHook, lookupTarget, &store);
     std::vector<Matcher *> cpuMatchers(threads, NULL);      // only for pairs whose backtrace the device declines
     // --realign (:298-305,408-437): the accepted hits of a query are aligned a second time with the (biased) realign matrix
@@ -311,7 +312,7 @@ bool MMGpuAlignRun::run(Alignment &al, const std::string &outDB, const std::stri
             const MMGpuMatcher::Target &t = block[b].targets[refused[r].second];
             if (cpuMatchers[0] == NULL)
                 cpuMatchers[0] = new Matcher(al.querySeqType, maxMatcherSeqLen, al.m, &evaluer, al.compBiasCorrection,
-                                             al.compBiasCorrectionScale, al.gapOpen, al.gapExtend, 0.0f, al.zdrop);
+                                             al.compBiasCorrectionScale, al.gapOpen, al.gapExtend, al.correlationScoreWeight, al.zdrop);
             if (profileQuery) qSeqs[0]->mapSequence(queryIds[b], queryKeys[b], al.qdbr->getData(queryIds[b], 0), al.qdbr->getSeqLen(queryIds[b]));
             else qSeqs[0]->mapSequence(0, queryKeys[b], std::make_pair(block[b].numSequence, (const unsigned int)block[b].L));
             dbSeqs[0]->mapSequence(t.id, t.dbKey, std::make_pair(t.numSequence, (const unsigned int)t.length));
@@ -362,7 +363,7 @@ bool MMGpuAlignRun::run(Alignment &al, const std::string &outDB, const std::stri
 #endif
                     if (cpuMatchers[thread_idx] == NULL)
                         cpuMatchers[thread_idx] = new Matcher(al.querySeqType, maxMatcherSeqLen, al.m, &evaluer, al.compBiasCorrection,
-                                                              al.compBiasCorrectionScale, al.gapOpen, al.gapExtend, 0.0f, al.zdrop);
+                                                              al.compBiasCorrectionScale, al.gapOpen, al.gapExtend, al.correlationScoreWeight, al.zdrop);
                     Sequence &qSeq = *qSeqs[thread_idx];
                     if (profileQuery) qSeq.mapSequence(queryIds[b], queryKeys[b], al.qdbr->getData(queryIds[b], thread_idx), al.qdbr->getSeqLen(queryIds[b]));
                     else qSeq.mapSequence(0, queryKeys[b], std::make_pair(block[b].numSequence, (const unsigned int)block[b].L));

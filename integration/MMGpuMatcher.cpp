@@ -18,7 +18,7 @@
 MMGpuMatcher::MMGpuMatcher(MMGpuAlignBackend *backend, BaseMatrix *m, EvalueComputation *evaluer, bool aaBiasCorrection,
                            float aaBiasCorrectionScale, int gapOpen, int gapExtend)
     : backend(backend), m(m), evaluer(evaluer), aaBiasCorrection(aaBiasCorrection),
-      aaBiasCorrectionScale(aaBiasCorrectionScale), gapOpen(gapOpen), gapExtend(gapExtend), numThreads(0), blockHook(NULL),
+      aaBiasCorrectionScale(aaBiasCorrectionScale), gapOpen(gapOpen), gapExtend(gapExtend), numThreads(0), correlationScoreWeight(0.0f), blockHook(NULL),
       targetLookup(NULL), targetLookupCtx(NULL) {
     const int a = m->alphabetSize;
     tinySubMat.resize(a * a);
@@ -281,6 +281,34 @@ bool MMGpuMatcher::alignBlock(const std::vector<Query> &queries, int covMode, fl
                     if (bi.status == MMGPU_BT_OK) {
                         backtrace.assign(btStrings, (size_t)bi.bt_off, (size_t)bi.bt_len);
                         a.identicalAACnt = bi.ident;
+                        if (correlationScoreWeight > 0.0f) {
+                            // computerBacktrace's scorePerCol (:1291) and computeCorrelationScore (:1338-1362)
+                            std::vector<int8_t> col;
+                            col.reserve(backtrace.size());
+                            int qp = a.qStartPos1, tp = a.dbStartPos1;
+                            for (size_t c = 0; c < backtrace.size(); c++) {
+                                if (backtrace[c] == 'M') {
+                                    col.push_back((int8_t)(tinySubMat[qs.numSequence[qp] * m->alphabetSize + tg.numSequence[tp]] + bias[q][qp]));
+                                    qp++;
+                                    tp++;
+                                } else if (backtrace[c] == 'I') {
+                                    qp++;
+                                } else {
+                                    tp++;
+                                }
+                            }
+                            int c1 = 0, c2 = 0, c3 = 0, c4 = 0;
+                            const size_t len = col.size();
+                            for (size_t st = 1; st < len; st++) {
+                                c1 += col[st] * col[st - 1];
+                                if (st >= 2) c2 += col[st] * col[st - 2];
+                                if (st >= 3) c3 += col[st] * col[st - 3];
+                                if (st >= 4) c4 += col[st] * col[st - 4];
+                            }
+                            a.score1 += static_cast<float>(c1 + c2 + c3 + c4) * correlationScoreWeight;     // the statement of :1251
+                            // (`query_length` is the aligned query span by then: the function re-uses the variable at :1221)
+                            a.evalue = evaluer->computeEvalue(a.score1, a.qEndPos1 - a.qStartPos1 + 1);
+                        }
                     } else {
                         refused = true;          // every thread writes the same value
                         refusedFlag[p] = 1;

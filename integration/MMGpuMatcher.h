@@ -87,6 +87,9 @@ public:
     // threads of the parallel loops inside alignBlock (Alignment lowers its thread count to the number of queries,
     // Alignment.cpp:128, while the OpenMP default stays at --threads: per-thread state is sized by the former)
     void setThreads(unsigned int n) { numThreads = n; }
+    // --corr-score-weight (alignStartPosBacktrace, StripedSmithWaterman.cpp:1249-1253): after the backtrace the score gains
+    // weight x the lag-1..4 autocorrelation of the per-column scores of the aligned pairs, the E-value follows
+    void setCorrelationScoreWeight(float w) { correlationScoreWeight = w; }
 
     // targetSequence(id) must return the numeric residues of a resident target (needed by the hook only)
     typedef const unsigned char *(*TargetLookup)(void *ctx, unsigned int id);
@@ -111,6 +114,7 @@ private:
     std::vector<int16_t> subMat16;
     std::string err;
     unsigned int numThreads;
+    float correlationScoreWeight;
     MMGpuBlockBacktracer *blockHook;
     TargetLookup targetLookup;
     void *targetLookupCtx;

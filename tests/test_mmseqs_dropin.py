@@ -52,6 +52,9 @@ ALIGN_CASES = [
     # --alt-ali: the list on the device, the re-alignments of the masked accepted targets by the reference's own function
     ["-a", "--alt-ali", "2"],
     ["-a", "--alt-ali", "1", "--realign", "1"],
+    # --corr-score-weight: the score gains weight x the autocorrelation of the per-column scores along the backtrace, the
+    # E-value is recomputed over the aligned query span (StripedSmithWaterman.cpp:1221,1249-1253) - host code after the traceback
+    ["-a", "--corr-score-weight", "0.5"],
 ]
 
 
