@@ -115,10 +115,10 @@ bool MMGpuAlignRun::usable(const Alignment &a) {
                      (profileQuery && !a.includeIdentity && !a.sameQTDB)) &&
                     Parameters::isEqualDbtype(a.targetSeqType, Parameters::DBTYPE_AMINO_ACIDS);
     // what the device path does not cover keeps the reference's CPU loop: profile targets / nucleotide databases,
-    // wrapped scoring, LCA realignment, realignment of profile queries, the correlation score with profile queries / realignment
+    // wrapped scoring, realignment (incl. the LCA form) of profile queries, the correlation score with profile queries / realignment
     // (--realign with sequence queries - the first iteration of an iterative search - is served: run() below)
     // (--alt-ali is served: the list on the device, the few re-alignments of masked targets on the host)
-    if (!aa || (a.realign && profileQuery) || a.wrappedScoring || a.lcaAlign || (a.correlationScoreWeight != 0.0f && (profileQuery || a.realign))) {
+    if (!aa || (a.realign && profileQuery) || a.wrappedScoring || (a.correlationScoreWeight != 0.0f && (profileQuery || a.realign))) {
         Debug(Debug::INFO) << "MMGPU: alignment configuration not covered by the device path, using the CPU path\n";
         return false;
     }
@@ -195,7 +195,8 @@ bool MMGpuAlignRun::run(Alignment &al, const std::string &outDB, const std::stri
     if (MMGpuRun::hostBlockAligner()) gpuRealigner.setBlockBacktracer(&realignBlockHook, lookupTarget, &store);
     std::vector<Matcher *> cpuRealigners(threads, NULL);      // refused pairs of the realignment, --alt-ali after --realign
     std::vector<std::vector<Matcher::result_t> > accepted, realigned;
-    std::vector<MMGpuMatcher::Query> block2;
+    std::vector<MMGpuMatcher::Query> block2, block3;
+    std::vector<std::vector<Matcher::result_t> > lcaResults;
     std::vector<std::pair<size_t, size_t> > refused2;
 
     // block = as many queries as keep the pair count of one device call bounded (a prefilter line has >= 6 bytes)
@@ -386,7 +387,10 @@ bool MMGpuAlignRun::run(Alignment &al, const std::string &outDB, const std::stri
                 q.L = block[b].L;
                 q.profile = NULL;
                 if (lists[b].empty()) continue;       // *origData == '\0': the first pass's (empty) result is written
-                for (size_t r = 0; r < accepted[b].size(); r++) {
+                // (with a small --realign-max-seqs - lcaalign sets 1 - only the first hits go to the device; the loop below
+                // takes later ones, if the first do not pass, from the host's Matcher one by one like the reference)
+                const size_t onDevice = std::min(accepted[b].size(), (size_t)std::min<long long>((long long)al.realignMaxSeqs * 4ll, 1ll << 30));
+                for (size_t r = 0; r < onDevice; r++) {
                     const DBKeyType dbKey = accepted[b][r].dbKey;
                     const size_t dbId = al.tdbr->getId(dbKey);
                     MMGpuMatcher::Target t;
@@ -422,9 +426,31 @@ bool MMGpuAlignRun::run(Alignment &al, const std::string &outDB, const std::stri
                 std::vector<Matcher::result_t> out;
                 int realignAccepted = 0;
                 for (size_t r = 0; r < accepted[b].size() && realignAccepted < al.realignMaxSeqs; r++) {
-                    Matcher::result_t res = realigned[b][r];
+                    Matcher::result_t res;
+                    bool isIdentity;
+                    if (r < block2[b].targets.size()) {
+                        res = realigned[b][r];
+                        isIdentity = block2[b].targets[r].isIdentity;
+                    } else {      // beyond the hits that went to the device: the reference's own call
+                        unsigned int thread_idx = 0;
+#ifdef OPENMP
+                        thread_idx = static_cast<unsigned int>(omp_get_thread_num());
+#endif
+                        if (cpuRealigners[thread_idx] == NULL)
+                            cpuRealigners[thread_idx] = new Matcher(al.querySeqType, maxMatcherSeqLen, realignMat, &evaluer, al.compBiasCorrection,
+                                                                    al.compBiasCorrectionScale, al.gapOpen, al.gapExtend, 0.0f, al.zdrop);
+                        const DBKeyType dbKey = accepted[b][r].dbKey;
+                        const size_t dbId = al.tdbr->getId(dbKey);
+                        isIdentity = (queryKeys[b] == dbKey && (al.includeIdentity || al.sameQTDB)) ? true : false;
+                        qSeqs[thread_idx]->mapSequence(0, queryKeys[b], std::make_pair(block2[b].numSequence, (const unsigned int)block2[b].L));
+                        dbSeqs[thread_idx]->mapSequence(dbId, dbKey, std::make_pair(store.residues.data() + store.offsets[dbId],
+                                                                                   (const unsigned int)(store.offsets[dbId + 1] - store.offsets[dbId])));
+                        cpuRealigners[thread_idx]->initQuery(qSeqs[thread_idx]);
+                        res = cpuRealigners[thread_idx]->getSWResult(dbSeqs[thread_idx], INT_MAX, false, al.covMode, al.realignCov, FLT_MAX,
+                                                                     al.realignSwMode, al.seqIdMode, isIdentity);
+                    }
                     const bool covOK = Util::hasCoverage(al.realignCov, al.covMode, res.qcov, res.dbcov);
-                    if (covOK == true || block2[b].targets[r].isIdentity) {
+                    if (covOK == true || isIdentity) {
                         res.score = accepted[b][r].score;
                         res.eval = accepted[b][r].eval;
                         out.emplace_back(res);
@@ -444,6 +470,69 @@ bool MMGpuAlignRun::run(Alignment &al, const std::string &outDB, const std::stri
                     cpuRealigners[thread_idx]->initQuery(&qSeq);
                     al.computeAlternativeAlignment(queryKeys[b], *dbSeqs[thread_idx], out, *cpuRealigners[thread_idx], al.realignCov, FLT_MAX,
                                                    al.realignSwMode, thread_idx);
+                }
+                if (out.size() > 1) {
+                    SORT_SERIAL(out.begin(), out.end(), Matcher::compareHits);
+                }
+                accepted[b].swap(out);
+            }
+        }
+        // ---- lcaalign (:444-498): the aligned stretch of the top hit's TARGET becomes the query, every entry of the prefilter
+        // list is aligned against it under the top hit's E-value; what passes is the result
+        if (al.lcaAlign) {
+            block3.assign(nq, MMGpuMatcher::Query());
+            for (size_t b = 0; b < nq; b++) {
+                MMGpuMatcher::Query &q = block3[b];
+                if (accepted[b].empty()) continue;
+                const Matcher::result_t &top = accepted[b][0];
+                const size_t topId = al.tdbr->getId(top.dbKey);
+                q.numSequence = store.residues.data() + store.offsets[topId] + top.dbStartPos;
+                q.L = top.dbEndPos - top.dbStartPos + 1;
+                q.profile = NULL;
+                q.evalThr = top.eval;
+                for (size_t k = 0; k < lists[b].size(); k++) {
+                    const size_t dbId = al.tdbr->getId(lists[b][k].dbKey);
+                    MMGpuMatcher::Target t;
+                    t.id = (unsigned int)dbId;
+                    t.dbKey = lists[b][k].dbKey;
+                    t.length = (int)(store.offsets[dbId + 1] - store.offsets[dbId]);
+                    t.numSequence = store.residues.data() + store.offsets[dbId];
+                    t.isIdentity = false;
+                    q.targets.push_back(t);
+                }
+            }
+            realignBlockHook.newBlock();
+            if (!gpuRealigner.alignBlock(block3, al.covMode, al.realignCov, 0.0, al.lcaSwMode, al.seqIdMode, lcaResults, &refused2)) {
+                Debug(Debug::ERROR) << "MMGPU: " << gpuRealigner.error() << "\n";
+                EXIT(EXIT_FAILURE);
+            }
+            for (size_t r = 0; r < refused2.size(); r++) {
+                const size_t b = refused2[r].first;
+                const MMGpuMatcher::Target &t = block3[b].targets[refused2[r].second];
+                if (cpuRealigners[0] == NULL)
+                    cpuRealigners[0] = new Matcher(al.querySeqType, maxMatcherSeqLen, realignMat, &evaluer, al.compBiasCorrection,
+                                                   al.compBiasCorrectionScale, al.gapOpen, al.gapExtend, 0.0f, al.zdrop);
+                qSeqs[0]->mapSequence(0, queryKeys[b], std::make_pair(block3[b].numSequence, (const unsigned int)block3[b].L));
+                dbSeqs[0]->mapSequence(t.id, t.dbKey, std::make_pair(t.numSequence, (const unsigned int)t.length));
+                cpuRealigners[0]->initQuery(qSeqs[0]);
+                lcaResults[b][refused2[r].second] = cpuRealigners[0]->getSWResult(dbSeqs[0], INT_MAX, false, al.covMode, al.realignCov,
+                                                                                  block3[b].evalThr, al.lcaSwMode, al.seqIdMode, false);
+            }
+            watch.lap("lca block");
+#pragma omp parallel for schedule(dynamic, 16) num_threads(threads)
+            for (size_t b = 0; b < nq; b++) {
+                if (accepted[b].empty()) continue;
+                const double topHitEval = block3[b].evalThr;
+                std::vector<Matcher::result_t> out;
+                unsigned int rejected = 0;
+                for (size_t k = 0; k < lists[b].size() && rejected < al.maxReject; k++) {
+                    Matcher::result_t &res = lcaResults[b][k];
+                    if (Alignment::checkCriteria(res, false, topHitEval, al.seqIdThr, al.alnLenThr, al.covMode, al.realignCov)) {
+                        out.emplace_back(res);
+                        rejected = 0;
+                    } else {
+                        rejected++;
+                    }
                 }
                 if (out.size() > 1) {
                     SORT_SERIAL(out.begin(), out.end(), Matcher::compareHits);

@@ -90,7 +90,8 @@ bool MMGpuMatcher::alignBlock(const std::vector<Query> &queries, int covMode, fl
         dq[q].target_ids = ids[q].data();
         dq[q].n_targets = (uint32_t)ids[q].size();
         // (a query with an empty prefilter list is never mapped, Alignment.cpp:322: nothing to align, no threshold)
-        dq[q].min_start_score = (alignmentMode == Matcher::SCORE_ONLY || qu.L <= 0 || ids[q].empty()) ? 0 : minScoreForEvalue(evalThr, qu.L);
+        dq[q].min_start_score = (alignmentMode == Matcher::SCORE_ONLY || qu.L <= 0 || ids[q].empty()) ? 0
+                                    : minScoreForEvalue(qu.evalThr >= 0.0 ? qu.evalThr : evalThr, qu.L);
     }
     watch.lap("composition bias + thresholds");
     for (size_t q = 0; q < nq; q++) firstPair[q + 1] = firstPair[q] + ids[q].size();
@@ -191,7 +192,7 @@ bool MMGpuMatcher::alignBlock(const std::vector<Query> &queries, int covMode, fl
                 a.tCov = SmithWaterman::computeCov(0, a.dbEndPos1, dbLen);
                 const bool lowCov = !Util::hasCoverage(covThr, covMode, a.qCov, a.tCov);
                 a.evalue = evaluer->computeEvalue(a.score1, qlen);
-                const bool lowEval = a.evalue > evalThr;
+                const bool lowEval = a.evalue > (queries[q].evalThr >= 0.0 ? queries[q].evalThr : evalThr);
                 if (!(alignmentMode == 0 || ((alignmentMode == 2 || alignmentMode == 1) && (lowEval || lowCov)))) {
                     // word == 1: the stock reference asks the block aligner first (:865-882)
                     if (a.word == 1 && blockHook != NULL && queries[q].profile != NULL) {

@@ -67,7 +67,10 @@ public:
         // profile query (DBTYPE_HMM_PROFILE): Sequence::getAlignmentProfile(), [Sequence::PROFILE_AA_SIZE][L], kept alive by
         // the caller; numSequence is then the consensus sequence.  NULL: sequence query.  (Matcher::initQuery, Matcher.cpp:49-60)
         const int8_t *profile;
-        Query() : numSequence(NULL), L(0), profile(NULL) {}
+        // E-value threshold of this query when it differs from the block's (the LCA pass aligns every query of a block under
+        // its own top hit's E-value, Alignment.cpp:456,483); negative: the block's
+        double evalThr;
+        Query() : numSequence(NULL), L(0), profile(NULL), evalThr(-1.0) {}
     };
 
     MMGpuMatcher(MMGpuAlignBackend *backend, BaseMatrix *m, EvalueComputation *evaluer, bool aaBiasCorrection,

@@ -522,3 +522,33 @@ def test_indexed_target_db_host_side_emulated(tmp_path):
 @pytest.mark.gpu
 def test_indexed_target_db_on_device(tmp_path):
     indexed_target_pipeline(tmp_path, emulate=False)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# `mmseqs lcaalign` (the alignment module of `mmseqs taxonomy`'s approximate 2bLCA mode, Alignment.cpp:37-43,444-498): score-only
+# pass over the list, realignment of the top hit, then the aligned stretch of the top hit's target as the query against
+# every entry of the list under the top hit's E-value - three device calls per block
+def lca_pipeline(tmp, emulate):
+    w = str(tmp)
+    copy_db(EXAMPLES, os.path.join(w, "q"))
+    run(STOCK, ["prefilter", "q", "q", "pref", "-s", "5.7", "--threads", THREADS, "-v", "2"], w)
+    filled = 0
+    for i, extra in enumerate(([], ["-e", "1e-5", "--max-rejected", "5"], ["-c", "0.5", "--cov-mode", "0"])):
+        args = extra + ["--threads", THREADS]
+        run(STOCK, ["lcaalign", "q", "q", "pref", "lca_s%d" % i] + args + ["-v", "2"], w)
+        log = run(MMGPU, ["lcaalign", "q", "q", "pref", "lca_g%d" % i] + args + ["-v", "3"], w, emulate)
+        assert "MMGPU: device" in log and "using the CPU path" not in log, log[-2000:]
+        assert same(os.path.join(w, "lca_s%d" % i), os.path.join(w, "lca_g%d" % i)) == 500, extra
+        filled += sum(int(line.split()[2]) > 1 for line in open(os.path.join(w, "lca_g%d.index" % i)))
+    assert filled >= 900       # the results are not empty
+
+
+def test_lcaalign_host_side_emulated(tmp_path):
+    if not os.path.exists(EMU):
+        pytest.skip("oracle/_build/emu/libmmgpu.so not built (make -C oracle emu)")
+    lca_pipeline(tmp_path, emulate=True)
+
+
+@pytest.mark.gpu
+def test_lcaalign_on_device(tmp_path):
+    lca_pipeline(tmp_path, emulate=False)
