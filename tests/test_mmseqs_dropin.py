@@ -552,3 +552,36 @@ def test_lcaalign_host_side_emulated(tmp_path):
 @pytest.mark.gpu
 def test_lcaalign_on_device(tmp_path):
     lca_pipeline(tmp_path, emulate=False)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# compressed databases (--compressed 1, zstd per entry): inputs read through the reference's DBReader, outputs written through
+# its DBWriter; compared after `mmseqs decompress` (the index of a compressed DB holds uncompressed lengths)
+def compressed_pipeline(tmp, emulate):
+    w = str(tmp)
+    copy_db(EXAMPLES, os.path.join(w, "q"))
+    run(STOCK, ["compress", "q", "qc", "--threads", THREADS, "-v", "1"], w)
+    for f in os.listdir(w):
+        if f.startswith("q_h"):
+            shutil.copy(os.path.join(w, f), os.path.join(w, "qc" + f[1:]))
+    run(STOCK, ["prefilter", "qc", "qc", "pref_s", "-s", "5.7", "--compressed", "1", "--threads", THREADS, "-v", "2"], w)
+    log = run(MMGPU, ["prefilter", "qc", "qc", "pref_g", "-s", "5.7", "--compressed", "1", "--threads", THREADS, "-v", "3"], w, emulate)
+    assert "MMGPU: device" in log and "using the CPU path" not in log, log[-2000:]
+    run(STOCK, ["align", "qc", "qc", "pref_s", "aln_s", "-a", "--compressed", "1", "--threads", THREADS, "-v", "2"], w)
+    log = run(MMGPU, ["align", "qc", "qc", "pref_s", "aln_g", "-a", "--compressed", "1", "--threads", THREADS, "-v", "3"], w, emulate)
+    assert "MMGPU: device" in log and "using the CPU path" not in log, log[-2000:]
+    for a, b in (("pref_s", "pref_g"), ("aln_s", "aln_g")):
+        run(STOCK, ["decompress", a, a + "_d", "--threads", THREADS, "-v", "1"], w)
+        run(STOCK, ["decompress", b, b + "_d", "--threads", THREADS, "-v", "1"], w)
+        assert same(os.path.join(w, a + "_d"), os.path.join(w, b + "_d")) == 500
+
+
+def test_compressed_databases_host_side_emulated(tmp_path):
+    if not os.path.exists(EMU):
+        pytest.skip("oracle/_build/emu/libmmgpu.so not built (make -C oracle emu)")
+    compressed_pipeline(tmp_path, emulate=True)
+
+
+@pytest.mark.gpu
+def test_compressed_databases_on_device(tmp_path):
+    compressed_pipeline(tmp_path, emulate=False)
