@@ -29,7 +29,6 @@ import argparse
 import json
 import os
 import sys
-import threading
 import time
 
 import numpy as np
@@ -42,7 +41,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 # packed-int16 (VOP3P) VALU ops issue at 16 lanes/clk/SIMD on gfx950: measured 38.1 Tlane-op/s for v_pk_max_i16 /
 # v_pk_sub_u16 / v_perm_b32 (profiles/r01_valu_issue_rate_probe.txt) = 256 CU x 4 SIMD x 16 lanes x 2.4 GHz = 39.3e12
 VALU_LANE_OPS_PER_S = 256 * 4 * 16 * 2.4e9
-PROFILE_ROUND = "r02"
+PROFILE_ROUND = "r03"
 
 
 def allreduce(torch, dist, values, op="sum"):
@@ -77,66 +76,87 @@ def pmc_traffic(kernels, stem):
 
 # ---------------------------------------------------------------------------------------------------------------------
 # CPU baselines (the real reference on the host cores; outside every timed region)
-def sw_cpu_baseline_lists(matrices, qs, lists, tres, toff, budget_s, gpu_res):
-    """Alignment::run's inner loop on the box's host cores: the reference's striped AVX2 Smith-Waterman (uint8 pass +
-    int16 re-run, one SmithWaterman object per thread as Alignment.cpp:279-295) over the SAME hit lists the device
-    aligned; a bounded sample of the queries.  gpu_res[q] = the device's records of query q's list (list order): every
-    compared field must agree."""
+def host_cpu_topology():
+    """(hardware threads, physical cores) of the box, from /proc/cpuinfo."""
+    threads = os.cpu_count() or 1
+    cores = set()
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":")[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    cores.add((phys, core))
+                phys = core = None
+    except OSError:
+        pass
+    return threads, (len(cores) or threads)
+
+
+def sw_cpu_baseline_lists(matrices, qres, qoff, lists, tres, toff, budget_s, gpu_res, evalue_thr=1e-3):
+    """Alignment::run's inner loop on the box's host cores as ONE native OpenMP call (oracle/ref_shim.cpp
+    mmref_sw_lists_omp: one SmithWaterman per thread, schedule(dynamic, 5), Alignment.cpp:279-313): the reference's striped
+    AVX2 Smith-Waterman (uint8 pass + int16 re-run) with start positions for the pairs passing -e (alignment mode
+    SCORE_COV, what the timed device step computes) over the SAME hit lists; a bounded sample of the queries.  Nothing is
+    compared inside the timed region: the result arrays are checked against the device's records afterwards."""
     from oracle import pyoracle
     if not pyoracle.ref_available():
         return None
-    cores = os.cpu_count() or 1
+    hw_threads, phys_cores = host_cpu_topology()
+    nq = len(lists)
     tlen = (toff[1:] - toff[:-1]).astype(np.int64)
+    qlen = (qoff[1:] - qoff[:-1]).astype(np.int64)
     ser = matrices["blosum62_serialized"]
-    ctxs = [pyoracle.RefLib(serialized=ser, max_len=70000, db_residues=int(toff[-1])) for _ in range(cores)]
-    cells_q = np.array([len(q) * int(tlen[l].sum()) for q, l in zip(qs, lists)], np.float64)
-    mism = [0, 0]
-    lock = threading.Lock()
+    l_off = np.concatenate([[0], np.cumsum([len(l) for l in lists])]).astype(np.uint64)
+    l_ids = np.concatenate(lists).astype(np.uint32) if nq else np.zeros(0, np.uint32)
+    cells_q = np.array([int(qlen[i]) * int(tlen[lists[i]].sum()) for i in range(nq)], np.float64)
 
-    def run_items(items):
-        work = list(items)
+    def run(q_from, q_to, threads, mode):
+        sec, used, res = pyoracle.ref_sw_lists_omp(ser, qres, qoff, l_ids, l_off, tres, toff, q_from, q_to, threads, mode=mode,
+                                                   evalue_thr=evalue_thr, db_residues=int(toff[-1]))
+        return sec, used, res, float(cells_q[q_from:q_to].sum())
 
-        def worker(ctx):
-            while True:
-                with lock:
-                    if not work:
-                        return
-                    qi = work.pop()
-                if len(lists[qi]) == 0:
-                    continue
-                ctx.sw_set_query(qs[qi])
-                sc, qe, te = ctx.sw_batch_score(tres, toff, lists[qi])
-                g = gpu_res[qi]
-                pos = sc > 0
-                bad = int(np.count_nonzero(g["score"] != sc)) + int(np.count_nonzero((g["t_end"] != te) & pos)) \
-                    + int(np.count_nonzero((g["q_end"] != qe) & pos))
-                with lock:
-                    mism[0] += len(sc)
-                    mism[1] += bad
-
-        th = [threading.Thread(target=worker, args=(ctxs[i],)) for i in range(cores)]
-        t0 = time.time()
-        for t in th:
-            t.start()
-        for t in th:
-            t.join()
-        return time.time() - t0, float(sum(cells_q[i] for i in items))
-
-    n = len(qs)
-    cal = list(range(min(n, cores)))
-    dt_cal, cells_cal = run_items(cal)
-    rate = cells_cal / max(dt_cal, 1e-3)
-    per_item = cells_cal / max(len(cal), 1)
-    n_items = int(min(n - len(cal), max(cores, rate * budget_s / max(per_item, 1.0))))
-    sample = list(range(len(cal), len(cal) + n_items))
-    if not sample:
-        sample, dt, cells = cal, dt_cal, cells_cal
-    else:
-        dt, cells = run_items(sample)
-    return {"value": round(cells / dt / 1e9, 3), "unit": "GCUPS", "cores": cores, "kind": "reference",
-            "sample": "the hit lists of %d of the %d queries of the same workload (%.3g forward cells), %.1f s wall, %d threads"
-                      % (len(sample), n, cells, dt, cores),
-            "parity_vs_baseline": {"pairs_compared": mism[0], "field_mismatches": mism[1], "fields": "score, q_end, t_end"}}
+    # calibration pass (also warms the page cache of the targets), then a sample sized for the budget
+    n_cal = min(nq, max(64, hw_threads))
+    sec, used, _, cells = run(0, n_cal, hw_threads, 1)
+    rate = cells / max(sec, 1e-3)
+    per_q = float(cells_q.mean()) if nq else 1.0
+    n_s = int(min(nq - n_cal, max(4 * hw_threads, rate * (budget_s / 3.0) / max(per_q, 1.0))))
+    lo, hi = (n_cal, n_cal + n_s) if n_s > 0 else (0, n_cal)
+    runs = {}
+    sec_a, used_a, res, cells = run(lo, hi, hw_threads, 1)
+    runs["all_hardware_threads"] = {"threads": used_a, "seconds": round(sec_a, 3), "gcups": round(cells / sec_a / 1e9, 2)}
+    if phys_cores != hw_threads:
+        sec_p, used_p, _, _ = run(lo, hi, phys_cores, 1)
+        runs["one_thread_per_physical_core"] = {"threads": used_p, "seconds": round(sec_p, 3), "gcups": round(cells / sec_p / 1e9, 2)}
+    sec_s, used_s, _, _ = run(lo, hi, hw_threads, 0)
+    runs["score_and_end_only_all_hardware_threads"] = {"threads": used_s, "seconds": round(sec_s, 3), "gcups": round(cells / sec_s / 1e9, 2)}
+    best = max(("all_hardware_threads", "one_thread_per_physical_core"), key=lambda k: runs.get(k, {"gcups": 0})["gcups"])
+    # parity of the timed device run against these results (after the timers)
+    a, b = int(l_off[lo]), int(l_off[hi])
+    g = np.concatenate([gpu_res[qi] for qi in range(lo, hi)]) if hi > lo else np.zeros(0, gpu_res[0].dtype)
+    sc = res["score"][a:b].astype(np.int64)
+    pos = sc > 0
+    bad = int(np.count_nonzero(g["score"].astype(np.int64) != sc)) + int(np.count_nonzero((g["t_end"] != res["t_end"][a:b]) & pos)) \
+        + int(np.count_nonzero((g["q_end"] != res["q_end"][a:b]) & pos))
+    g_st, r_st = g["q_start"] >= 0, res["q_start"][a:b] >= 0
+    both = g_st & r_st
+    bad_start = int(np.count_nonzero((g["q_start"] != res["q_start"][a:b]) & both)) + int(np.count_nonzero((g["t_start"] != res["t_start"][a:b]) & both))
+    return {"value": runs[best]["gcups"], "unit": "GCUPS", "cores": phys_cores, "threads": runs[best]["threads"],
+            "hardware_threads": hw_threads, "kind": "reference",
+            "gcups_per_thread": round(runs[best]["gcups"] / max(runs[best]["threads"], 1), 3),
+            "what": "the reference's own ssw_init + ssw_align (AVX2 striped uint8 pass, int16 re-run, reverse scan for the pairs "
+                    "passing -e 1e-3) in one native OpenMP call, one SmithWaterman per thread, schedule(dynamic,5) as Alignment.cpp:279-313; "
+                    "forward cells / wall seconds inside the call, the same accounting as the device value",
+            "sample": "the hit lists of queries [%d, %d) of the %d queries of the same workload (%d pairs, %.4g forward cells); runs: %s"
+                      % (lo, hi, nq, b - a, cells, best),
+            "runs": runs,
+            "parity_vs_baseline": {"pairs_compared": b - a, "field_mismatches": bad, "fields": "score, q_end, t_end",
+                                   "pairs_with_start_on_both": int(both.sum()), "start_field_mismatches": bad_start,
+                                   "pairs_with_start_on_one_side_only": int(np.count_nonzero(g_st != r_st))}}
 
 
 def prefilter_cpu_baseline(matrices, qres, qoff, tres, toff, kmer_thr, budget_s, gpu_lists):
@@ -172,6 +192,114 @@ def prefilter_cpu_baseline(matrices, qres, qoff, tres, toff, kmer_thr, budget_s,
                                   "reference_cache_bins": int(lists["bins"]),
                                   "fields": "hit ids, prefilter scores, diagonals, order"}
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def end_to_end_pass(gpu, matrices, qres, qoff, kmer_thr, max_res, db_residues, fused_ref, counts_ref):
+    """SURVEY.md section 8d's queries/s: host numeric sequences in -> host hit_t lists + mmgpu_sw_hit records out.  Inside the
+    timed region: both composition-bias passes on the host (prefilter: float over the k-mer matrix; alignment: ssw_init's int8
+    over BLOSUM62), the per-query start-score thresholds from -e, the query descriptors, mmgpu_pf_prepare (host k-mer
+    thresholds + upload), the prefilter kernels, the device-side hand-over, the alignment kernels, and both downloads.
+    Resident from before: targets + k-mer index (their set-up time is reported beside this).  Pass A runs without any
+    intermediate synchronisation (the number); pass B synchronises after every stage (the breakdown)."""
+    from mmseqs2_amd import capi, evalue
+    km16 = matrices["vtml80_kmer"].astype(np.int16)
+    mat = matrices["blosum62_sw"]
+    sub16 = mat.astype(np.int16)
+    qlens = (qoff[1:] - qoff[:-1]).astype(np.int64)
+    nq = len(qlens)
+    evalue.min_scores_for_evalue(1e-3, qlens[:4], db_residues)       # import scipy outside the timed region
+    out = {}
+    for label, sync in (("no_intermediate_sync", False), ("stage_breakdown", True)):
+        stages = {}
+        t_all = time.perf_counter()
+
+        def mark(name, t0):
+            if sync:
+                gpu.synchronize()
+                stages[name] = round((time.perf_counter() - t0) * 1e3, 2)
+            return time.perf_counter()
+
+        t0 = time.perf_counter()
+        cbf, _ = capi.host_comp_bias_batch(km16, matrices["vtml80_pback"], qres, qoff, want_round=False)
+        _, cbr = capi.host_comp_bias_batch(sub16, matrices["blosum62_pback"], qres, qoff, want_float=False)
+        thr = evalue.min_scores_for_evalue(1e-3, qlens, db_residues)
+        t0 = mark("host_composition_bias_x2_and_evalue_thresholds", t0)
+        pfb = gpu.pf_prepare_flat(qres, qoff, cbf, kmer_thr, max_hits=max_res, min_diag_score=15, ref_bins=2)
+        msh = gpu.sw_marshal_flat(mat, 11, 1, qres, qoff, cbr, thr)
+        t0 = mark("descriptors_pf_prepare_upload", t0)
+        pfb.run()
+        t0 = mark("prefilter_kernels", t0)
+        fb = gpu.sw_prepare_from_pf(mat, 11, 1, None, pfb, mode=1, marshalled=msh)
+        fb.run()
+        t0 = mark("handover_and_alignment_kernels", t0)
+        hits, counts, status, _ = pfb.fetch()
+        res = fb.fetch()
+        t0 = mark("download_hit_lists_and_alignment_records", t0)
+        wall = time.perf_counter() - t_all
+        if not sync:
+            res = res.reshape(nq, pfb.max_hits)
+            same = bool(np.array_equal(counts, counts_ref)) and all(
+                np.array_equal(res[qi, :counts[qi]], fused_ref[qi, :counts[qi]]) for qi in range(0, nq, 7))
+            out.update({"seconds": round(wall, 4), "queries_per_s_end_to_end": round(nq / wall, 1),
+                        "results_equal_to_the_timed_steps": same,
+                        "bytes_downloaded": int(hits.nbytes + counts.nbytes + status.nbytes + res.nbytes)})
+        else:
+            out["stage_ms_with_synchronisation"] = stages
+            out["seconds_with_synchronisation"] = round(wall, 4)
+        fb.free()
+        pfb.free()
+    out["what"] = ("host numeric query sequences in -> host hit_t lists + mmgpu_sw_hit records out, one call sequence over the C-ABI for the "
+                   "whole query set: composition bias x2 + E-value thresholds on the host, descriptors, mmgpu_pf_prepare, prefilter, "
+                   "mmgpu_sw_prepare_from_pf, alignment (score, ends, starts for pairs passing -e 1e-3), both downloads; targets and k-mer "
+                   "index resident (set-up reported in setup_s)")
+    return out
+
+
+def module_seconds(args, qres, qoff, tres, toff):
+    """Wall seconds of `mmseqs prefilter` and `mmseqs align` (default flags: --mask 1, all host threads) through the stock
+    binary and through the binary with integration/mmseqs_mmgpu.patch, on the headline workload written as FASTA; the two
+    alignment databases are compared entry by entry.  Needs oracle/_ref/mmseqs_{stock,mmgpu} (integration/build_mmseqs.sh)."""
+    import shutil
+    import subprocess
+    import tempfile
+    from mmseqs2_amd import workloads as wl, dbio
+    stock = os.path.join(ROOT, "oracle", "_ref", "mmseqs_stock")
+    patched = os.path.join(ROOT, "oracle", "_ref", "mmseqs_mmgpu")
+    if not (os.path.exists(stock) and os.path.exists(patched)):
+        return None
+    threads = str(os.cpu_count() or 1)
+    w = tempfile.mkdtemp(prefix="mmgpu_modules_")
+    try:
+        wl.write_fasta(os.path.join(w, "q.fasta"), qres, qoff, "q")
+        wl.write_fasta(os.path.join(w, "t.fasta"), tres, toff, "t")
+        env = dict(os.environ)
+        env["LD_LIBRARY_PATH"] = os.path.join(ROOT, "mmseqs2_amd", "lib") + ":" + env.get("LD_LIBRARY_PATH", "")
+
+        def run(b, a):
+            t0 = time.perf_counter()
+            r = subprocess.run([b] + a, cwd=w, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, timeout=args.module_timeout)
+            if r.returncode != 0:
+                raise RuntimeError("%s %s failed: %s" % (os.path.basename(b), a[0], r.stdout[-400:]))
+            return time.perf_counter() - t0, r.stdout
+
+        run(stock, ["createdb", "q.fasta", "q", "-v", "1"])
+        run(stock, ["createdb", "t.fasta", "t", "-v", "1"])
+        out = {"workload": "the headline workload through `mmseqs prefilter -s 5.7` + `mmseqs align --alignment-mode 2 -e 0.001` (what "
+                           "`mmseqs search` runs), default flags otherwise (--mask 1, --max-seqs 300), --threads %s" % threads}
+        for name, b in (("stock", stock), ("patched", patched)):
+            tp, log = run(b, ["prefilter", "q", "t", "pref_" + name, "-s", "5.7", "--threads", threads, "-v", "3"])
+            ta, _ = run(b, ["align", "q", "t", "pref_" + name, "aln_" + name, "--alignment-mode", "2", "-e", "0.001", "--threads", threads, "-v", "3"])
+            out[name] = {"prefilter_wall_s": round(tp, 2), "align_wall_s": round(ta, 2),
+                         "queries_per_s_prefilter_plus_align": round((len(qoff) - 1) / (tp + ta), 1)}
+        n, bad, _ = dbio.diff_dbs(os.path.join(w, "aln_stock"), os.path.join(w, "aln_patched"))
+        out["alignment_dbs_identical"] = bad == 0
+        out["entries_compared"] = n
+        out["speedup_prefilter_plus_align"] = round((out["stock"]["prefilter_wall_s"] + out["stock"]["align_wall_s"]) /
+                                                    (out["patched"]["prefilter_wall_s"] + out["patched"]["align_wall_s"]), 2)
+        return out
+    finally:
+        shutil.rmtree(w, ignore_errors=True)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -344,8 +472,17 @@ def search_headline(args, gpu, torch, dist, rank, world, matrices, barrier):
         # cells of the reverse scan (q[0..q_end] x t[0..t_end] of every pair that got start positions, StripedSmithWaterman.cpp:1143-1175)
         out["reverse_cells"] = int(sum(int(((g["q_end"].astype(np.int64) + 1) * (g["t_end"].astype(np.int64) + 1))[g["q_start"] >= 0].sum())
                                        for g in gpu_res))
+        try:
+            out["end_to_end"] = end_to_end_pass(gpu, matrices, qres, qoff, kmer_thr, max_res, db_residues, fused, counts)
+        except Exception as e:          # a secondary measurement must not take the headline line down with it
+            out["end_to_end"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if not (args.no_modules or args.headline_only):
+            try:
+                out["modules"] = module_seconds(args, qres, qoff, tres, toff)
+            except Exception as e:
+                out["modules"] = {"error": "%s: %s" % (type(e).__name__, str(e)[-300:])}
         if not args.no_cpu_baseline:
-            out["cpu_sw"] = sw_cpu_baseline_lists(matrices, qs, lists, tres, toff, args.cpu_seconds, gpu_res)
+            out["cpu_sw"] = sw_cpu_baseline_lists(matrices, qres, qoff, lists, tres, toff, args.cpu_seconds, gpu_res)
             out["cpu_pf"] = prefilter_cpu_baseline(matrices, qres, qoff, tres, toff, kmer_thr, args.cpu_seconds, full_lists)
     else:
         mh, mc, mf = keep["merged"]
@@ -566,6 +703,8 @@ def main():
     ap.add_argument("--nucl-read-len", type=int, default=10000)
     ap.add_argument("--headline-only", action="store_true", help="counter passes (scripts/collect_profiles.sh): the timed steps only")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-modules", action="store_true", help="skip the stock-vs-patched `mmseqs prefilter` / `align` wall times")
+    ap.add_argument("--module-timeout", type=float, default=240.0)
     args = ap.parse_args()
 
     import torch
@@ -636,6 +775,7 @@ def main():
         out = {
             "metric": "sw_gcells_per_s", "value": round(value, 1), "unit": "GCUPS",
             "queries_per_s": round(nq * args.steps / H["elapsed_s"], 1),
+            "queries_per_s_is": "queries / whole step with queries, targets and index resident (kernels + hand-over); the host-in/host-out rate is queries_per_s_end_to_end",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak" if H["weak"] else "strong", "vs_baseline": None, "dtype": "int16", "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[%d]: %d queries x %d targets (%d families x %d members, L~LogNormal(5.45,0.6)), "
@@ -681,6 +821,14 @@ def main():
                                     "kernel_ms": round(stage[1], 3), "algorithmic_bytes_per_launch": round(alg),
                                     "algorithmic_bytes_per_entry": 20}})
         out["prefilter"] = pf
+        if H.get("end_to_end") is not None:
+            e2e = dict(H["end_to_end"])
+            e2e["setup_s_not_included"] = {"score_tables_upload_and_device_index_build": round(H["t_index"], 2)}
+            if H.get("modules") is not None:
+                e2e["mmseqs_modules_stock_vs_patched"] = H["modules"]
+            out["end_to_end"] = e2e
+            if "queries_per_s_end_to_end" in e2e:
+                out["queries_per_s_end_to_end"] = e2e["queries_per_s_end_to_end"]
         for kname in ("two_call", "backtrace", "pairs_with_start", "inexact_queries", "merged_lists_sorted", "aligned_slots_filled"):
             if kname in H:
                 out[kname] = H[kname]

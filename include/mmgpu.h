@@ -63,6 +63,12 @@ int mmgpu_host_comp_bias(const int16_t *submat, const double *pback, int alphabe
 /* ssw_init's rounding of that bias to int8 (StripedSmithWaterman.cpp:1378-1380) */
 int mmgpu_host_round_comp_bias(const float *bias, uint32_t len, int8_t *out);
 
+/* The two helpers above over a block of sequences (residues / offsets[n + 1] as in SequenceLookup), dealt to n_threads host
+ * threads - what the reference computes per query inside the OpenMP loops of Prefiltering::runSplit (QueryMatcher.cpp:108-116)
+ * and Alignment::run (ssw_init, StripedSmithWaterman.cpp:1371-1381).  out_float / out_round may each be NULL; indexed like residues. */
+int mmgpu_host_comp_bias_batch(const int16_t *submat, const double *pback, int alphabet, const uint8_t *residues,
+                               const uint64_t *offsets, uint32_t n, float scale, float *out_float, int8_t *out_round, int n_threads);
+
 /* Length-bucket sharding of the target database over n_shards devices (multi-GPU runs, one process per device): shard_of[i]
  * and local_id[i] for every target (local ids ascend with the global ids inside a shard), shard_sizes[n_shards], optional
  * shard_residues[n_shards].  Every shard gets the same length distribution, so residues, index entries and alignment work

@@ -65,7 +65,7 @@ SW_HIT_DTYPE = np.dtype([("score", np.int32), ("q_end", np.int32), ("t_end", np.
 # every symbol include/mmgpu.h declares (tests check the built library exports all of them)
 EXPORTED_SYMBOLS = [
     "mmgpu_init", "mmgpu_destroy", "mmgpu_last_error", "mmgpu_set_stream", "mmgpu_synchronize",
-    "mmgpu_device_info", "mmgpu_device_memory", "mmgpu_host_comp_bias", "mmgpu_host_round_comp_bias", "mmgpu_load_targets", "mmgpu_sw_batch", "mmgpu_sw_prepare", "mmgpu_sw_run",
+    "mmgpu_device_info", "mmgpu_device_memory", "mmgpu_host_comp_bias", "mmgpu_host_round_comp_bias", "mmgpu_host_comp_bias_batch", "mmgpu_load_targets", "mmgpu_sw_batch", "mmgpu_sw_prepare", "mmgpu_sw_run",
     "mmgpu_sw_fetch", "mmgpu_sw_batch_stats", "mmgpu_sw_last_kernel_ms", "mmgpu_sw_kernel_ms_mean", "mmgpu_sw_free",
     "mmgpu_sw_traceback", "mmgpu_sw_prepare_from_pf", "mmgpu_sw_fetch_device", "mmgpu_nucl_align",
     "mmgpu_host_score_matrix", "mmgpu_host_index_build", "mmgpu_pf_load_index", "mmgpu_pf_batch", "mmgpu_pf_prepare",
@@ -125,6 +125,7 @@ def load_library():
     L.mmgpu_device_memory.argtypes = [c_p, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
     L.mmgpu_host_comp_bias.argtypes = [c_p, c_p, ctypes.c_int, c_p, ctypes.c_uint32, ctypes.c_float, c_p]
     L.mmgpu_host_round_comp_bias.argtypes = [c_p, ctypes.c_uint32, c_p]
+    L.mmgpu_host_comp_bias_batch.argtypes = [c_p, c_p, ctypes.c_int, c_p, c_p, ctypes.c_uint32, ctypes.c_float, c_p, c_p, ctypes.c_int]
     L.mmgpu_load_targets.argtypes = [c_p, c_p, c_p, ctypes.c_uint32, ctypes.c_int]
     L.mmgpu_sw_batch.argtypes = [c_p, ctypes.POINTER(SwParams), c_p, ctypes.c_uint32, ctypes.c_int, c_p]
     L.mmgpu_sw_prepare.argtypes = [c_p, ctypes.POINTER(SwParams), c_p, ctypes.c_uint32, ctypes.c_int, ctypes.POINTER(c_p)]
@@ -184,6 +185,33 @@ def host_comp_bias(submat16, pback, seq, scale=1.0, lib=None):
     if L.mmgpu_host_round_comp_bias(_ptr(f), len(f), _ptr(r)) != 0:
         raise MMGpuError(L.mmgpu_last_error().decode())
     return f, r
+
+
+def host_comp_bias_batch(submat16, pback, residues, offsets, scale=1.0, want_float=True, want_round=True, threads=0, lib=None):
+    """mmgpu_host_comp_bias_batch: the correction of a whole block of sequences (concatenated residues + offsets[n+1]) on
+    `threads` host threads (0 = all); returns (float32[] or None, int8[] or None), indexed like residues."""
+    L = lib or load_library()
+    submat16 = np.ascontiguousarray(submat16, np.int16)
+    pback = np.ascontiguousarray(pback, np.float64)
+    residues = np.ascontiguousarray(residues, np.uint8)
+    offsets = np.ascontiguousarray(offsets, np.uint64)
+    f = np.empty(len(residues), np.float32) if want_float else None
+    r = np.empty(len(residues), np.int8) if want_round else None
+    if L.mmgpu_host_comp_bias_batch(_ptr(submat16), _ptr(pback), submat16.shape[0], _ptr(residues), _ptr(offsets), len(offsets) - 1,
+                                    scale, _ptr(f), _ptr(r), int(threads) or (os.cpu_count() or 1)) != 0:
+        raise MMGpuError(L.mmgpu_last_error().decode())
+    return f, r
+
+
+# the two query descriptors as numpy records (same layout as the ctypes Structures above / include/mmgpu.h), for callers
+# that hold their queries as one residue array + offsets: the descriptor array is filled with vector operations
+SW_QUERY_DTYPE = np.dtype([("q", np.uint64), ("qlen", np.uint32), ("_p0", np.uint32), ("comp_bias", np.uint64), ("target_ids", np.uint64),
+                           ("n_targets", np.uint32), ("min_start_score", np.int32), ("profile", np.uint64),
+                           ("profile_letters", np.uint32), ("_p1", np.uint32)])
+PF_QUERY_DTYPE = np.dtype([("q", np.uint64), ("qlen", np.uint32), ("_p0", np.uint32), ("comp_bias", np.uint64), ("identity_id", np.uint32),
+                           ("_p1", np.uint32), ("profile_score", np.uint64), ("profile_index", np.uint64), ("profile_row", np.uint32),
+                           ("_p2", np.uint32), ("profile", np.uint64)])
+assert SW_QUERY_DTYPE.itemsize == ctypes.sizeof(SwQuery) and PF_QUERY_DTYPE.itemsize == ctypes.sizeof(PfQuery)
 
 
 def host_score_matrix(submat16, span, lib=None):
@@ -460,6 +488,41 @@ class MMGpu:
         qd = [dict(q=x["q"], comp_bias=x.get("comp_bias"), targets=np.zeros(0, np.uint32),
                    min_start_score=x.get("min_start_score", 0), profile=x.get("profile")) for x in queries]
         return self._marshal(mat, gap_open, gap_extend, qd) + (len(queries),)
+
+    def sw_marshal_flat(self, mat, gap_open, gap_extend, residues, offsets, comp_bias_round, min_start_score):
+        """sw_marshal_queries for sequence queries held as one residue array: residues uint8[], offsets uint64[n+1],
+        comp_bias_round int8[] (indexed like residues) or None, min_start_score int32[n]."""
+        mat = np.ascontiguousarray(mat, np.int8)
+        residues = np.ascontiguousarray(residues, np.uint8)
+        off = np.ascontiguousarray(offsets, np.uint64)
+        n = len(off) - 1
+        arr = np.zeros(max(n, 1), SW_QUERY_DTYPE)
+        arr["q"][:n] = residues.ctypes.data + off[:-1]
+        arr["qlen"][:n] = (off[1:] - off[:-1]).astype(np.uint32)
+        if comp_bias_round is not None:
+            comp_bias_round = np.ascontiguousarray(comp_bias_round, np.int8)
+            arr["comp_bias"][:n] = comp_bias_round.ctypes.data + off[:-1]
+        arr["min_start_score"][:n] = min_start_score
+        par = SwParams(_ptr(mat), mat.shape[0], gap_open, gap_extend)
+        return par, arr.ctypes.data_as(c_p), [mat, residues, off, comp_bias_round, arr], n
+
+    def pf_prepare_flat(self, residues, offsets, comp_bias_float, kmer_thr, max_hits=300, min_diag_score=15, ref_bins=0):
+        """pf_prepare for sequence queries held as one residue array (no identity ids, no profiles)."""
+        residues = np.ascontiguousarray(residues, np.uint8)
+        off = np.ascontiguousarray(offsets, np.uint64)
+        n = len(off) - 1
+        arr = np.zeros(max(n, 1), PF_QUERY_DTYPE)
+        arr["q"][:n] = residues.ctypes.data + off[:-1]
+        arr["qlen"][:n] = (off[1:] - off[:-1]).astype(np.uint32)
+        if comp_bias_float is not None:
+            comp_bias_float = np.ascontiguousarray(comp_bias_float, np.float32)
+            arr["comp_bias"][:n] = comp_bias_float.ctypes.data + 4 * off[:-1]
+        arr["identity_id"] = 0xFFFFFFFF
+        par = PfParams(int(kmer_thr), int(max_hits), int(min_diag_score), int(ref_bins), 0, 0, 0)
+        h = c_p()
+        self._check(self.L.mmgpu_pf_prepare(self.ctx, ctypes.byref(par), arr.ctypes.data_as(c_p), n, ctypes.byref(h)))
+        db = getattr(self, "global_db_size", None) or self.n_targets
+        return PfBatch(self, h, [residues, off, comp_bias_float, arr], n, min(int(max_hits), db))
 
     def sw_prepare_from_pf(self, mat, gap_open, gap_extend, queries, pf_batch, mode=1, marshalled=None):
         """Alignment batch over the hit lists of a prefilter batch that has been run, lists stay on the device.

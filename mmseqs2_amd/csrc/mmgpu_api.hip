@@ -1,6 +1,8 @@
 // Host side of libmmgpu: context, target database residency, batch scheduling, launches.
 // Everything here is plumbing around the kernels in sw_kernel.hip; see include/mmgpu.h for the contract.
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <cstdio>
 #include <cstring>
 #include <numeric>
@@ -169,6 +171,39 @@ extern "C" int mmgpu_host_comp_bias(const int16_t *submat, const double *pback, 
         out[i] = scale * delta;
     }
     return MMGPU_OK;
+}
+
+// The same correction for a whole block of queries (what Prefiltering::runSplit / Alignment::run compute per query inside
+// their OpenMP loops, QueryMatcher.cpp:108-116, Matcher::initQuery -> ssw_init StripedSmithWaterman.cpp:1371-1381): sequences
+// are dealt to n_threads host threads.  out_float (may be NULL) receives the float bias, out_round (may be NULL) ssw_init's int8
+// rounding of it; both are indexed like `residues`.
+extern "C" int mmgpu_host_comp_bias_batch(const int16_t *submat, const double *pback, int alphabet, const uint8_t *residues,
+                                          const uint64_t *offsets, uint32_t n, float scale, float *out_float, int8_t *out_round,
+                                          int n_threads) {
+    if (!submat || !pback || !offsets || (!residues && n && offsets[n])) return fail(MMGPU_ERR_ARG, "mmgpu_host_comp_bias_batch: NULL argument");
+    if (n_threads < 1) n_threads = 1;
+    n_threads = (int)std::min<uint32_t>((uint32_t)n_threads, std::max<uint32_t>(n, 1u));
+    std::atomic<uint32_t> next(0);
+    std::atomic<int> bad(0);
+    auto work = [&]() {
+        std::vector<float> tmp;
+        for (;;) {
+            const uint32_t b = next.fetch_add(64);
+            if (b >= n) return;
+            for (uint32_t i = b; i < std::min(n, b + 64); i++) {
+                const uint64_t o = offsets[i];
+                const uint32_t len = (uint32_t)(offsets[i + 1] - o);
+                float *dst = out_float ? out_float + o : (tmp.resize(len), tmp.data());
+                if (mmgpu_host_comp_bias(submat, pback, alphabet, residues + o, len, scale, dst) != MMGPU_OK) { bad = 1; return; }
+                if (out_round) mmgpu_host_round_comp_bias(dst, len, out_round + o);
+            }
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < n_threads; t++) th.emplace_back(work);
+    work();
+    for (auto &t : th) t.join();
+    return bad ? fail(MMGPU_ERR_ARG, "mmgpu_host_comp_bias_batch: residue code >= alphabet") : MMGPU_OK;
 }
 
 // Length-bucket sharding of a target database over n_shards devices (the reference balances

@@ -65,3 +65,44 @@ def min_score_for_evalue(evalue_thr, qlen, db_residues, par=BLOSUM62_11_1):
         else:
             hi = mid
     return lo
+
+
+def min_scores_for_evalue(evalue_thr, qlens, db_residues, par=BLOSUM62_11_1):
+    """min_score_for_evalue for an array of query lengths at once (numpy; the same bisection on the same expression,
+    scipy's erfc in place of math.erfc - both are the C library's): int32[len(qlens)]."""
+    import numpy as np
+    from scipy.special import erfc
+    lam, K, a_i, b_i, a_j, b_j, al_i, be_i, al_j, be_j, sigma, tau = par
+    vi_thr = max(_NAT_CUT_OFF_IN_MAX * al_i / lam, 0.0)
+    vj_thr = max(_NAT_CUT_OFF_IN_MAX * al_j / lam, 0.0)
+    c_thr = max(_NAT_CUT_OFF_IN_MAX * sigma / lam, 0.0)
+    uniq, inv = np.unique(np.asarray(qlens, np.int64), return_inverse=True)
+    n = uniq.astype(np.float64)
+    m = float(db_residues)
+
+    def ev(y):
+        y = y.astype(np.float64)
+        m_li = m - (a_i * y + b_i)
+        sv = np.sqrt(np.maximum(vi_thr, al_i * y + be_i))
+        m_f = np.where(sv == 0.0, 1e100, m_li / np.where(sv == 0.0, 1.0, sv))
+        p_m = 0.5 * erfc(-m_f / math.sqrt(2.0))
+        p1 = m_li * p_m + sv * _CONST * np.exp(-0.5 * m_f * m_f)
+        n_lj = n - (a_j * y + b_j)
+        sw = np.sqrt(np.maximum(vj_thr, al_j * y + be_j))
+        n_f = np.where(sw == 0.0, 1e100, n_lj / np.where(sw == 0.0, 1.0, sw))
+        p_n = 0.5 * erfc(-n_f / math.sqrt(2.0))
+        p2 = n_lj * p_n + sw * _CONST * np.exp(-0.5 * n_f * n_f)
+        c_y = np.maximum(c_thr, sigma * y + tau)
+        return K * np.exp(-lam * y) * (p1 * p2 + c_y * p_m * p_n)
+
+    lo = np.ones(len(uniq), np.int64)
+    hi = np.full(len(uniq), 32767, np.int64)
+    none = ev(hi) > evalue_thr
+    while np.any(lo < hi):
+        mid = (lo + hi) // 2
+        worse = ev(mid) > evalue_thr
+        act = lo < hi
+        lo = np.where(act & worse, mid + 1, lo)
+        hi = np.where(act & ~worse, mid, hi)
+    out = np.where(none, 32768, lo).astype(np.int32)
+    return out[inv]

@@ -229,6 +229,37 @@ class RefLib:
         return self.L.mmref_bitscore(self.c, float(score))
 
 
+def ref_sw_lists_omp(serialized, qres, qoff, lists_ids, lists_off, tres, toff, q_from, q_to, threads, mode=1,
+                     evalue_thr=1e-3, db_residues=None, max_len=70000, gap_open=11, gap_extend=1, comp_bias=True,
+                     want_starts=True):
+    """Alignment::run's inner loop as ONE native OpenMP call of the real reference (oracle/ref_shim.cpp
+    mmref_sw_lists_omp): queries [q_from, q_to) against their lists.  Returns (seconds inside the call's timed
+    region, threads used, dict of result arrays indexed like lists_ids)."""
+    L = ctypes.CDLL(REF_SO)
+    f = L.mmref_sw_lists_omp
+    f.restype = ctypes.c_double
+    f.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint64, ctypes.c_int,
+                  ctypes.c_int, ctypes.c_double, c_p, c_p, ctypes.c_uint32, ctypes.c_uint32, c_p, c_p, c_p, c_p,
+                  c_p, c_p, c_p, c_p, c_p, ctypes.POINTER(ctypes.c_int)]
+    qres = np.ascontiguousarray(qres, np.uint8)
+    qoff = np.ascontiguousarray(qoff, np.uint64)
+    lists_ids = np.ascontiguousarray(lists_ids, np.uint32)
+    lists_off = np.ascontiguousarray(lists_off, np.uint64)
+    tres = np.ascontiguousarray(tres, np.uint8)
+    toff = np.ascontiguousarray(toff, np.uint64)
+    n = len(lists_ids)
+    out = {"score": np.zeros(n, np.uint32), "q_end": np.full(n, -1, np.int32), "t_end": np.full(n, -1, np.int32),
+           "q_start": np.full(n, -1, np.int32), "t_start": np.full(n, -1, np.int32)}
+    used = ctypes.c_int(0)
+    sec = f(bytes(serialized), max_len, gap_open, gap_extend, int(comp_bias),
+            int(db_residues if db_residues is not None else toff[-1]), int(threads), int(mode), float(evalue_thr),
+            _ptr(qres), _ptr(qoff), int(q_from), int(q_to), _ptr(lists_ids), _ptr(lists_off), _ptr(tres), _ptr(toff),
+            _ptr(out["score"]), _ptr(out["q_end"]), _ptr(out["t_end"]),
+            _ptr(out["q_start"]) if want_starts else None, _ptr(out["t_start"]) if want_starts else None,
+            ctypes.byref(used))
+    return sec, used.value, out
+
+
 # ---------------------------------------------------------------------------------------------------------
 # prefilter (prefilter_oracle.c / ref_shim_pref.cpp)
 class PfGen(ctypes.Structure):

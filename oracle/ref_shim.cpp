@@ -18,6 +18,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <omp.h>
 #include <string>
 #include <vector>
 
@@ -175,6 +176,65 @@ void mmref_sw_batch_score(mmref_ctx *c, const uint8_t *tdata, const uint64_t *to
         qend[i] = a.qEndPos1;
         tend[i] = a.dbEndPos1;
     }
+}
+
+// Alignment::run's inner loop as ONE native call (bench.py's cpu_baseline): OpenMP over the queries,
+// one SmithWaterman + one query Sequence per thread exactly as Alignment.cpp:279-295, dynamic schedule like the reference's
+// `#pragma omp for schedule(dynamic, 5)` (:313); per query ssw_init (Matcher::initQuery, Matcher.cpp:49-60) and then
+// ssw_align of every list entry in list order (Matcher::getSWResult, :62-144).  mode 0 = score + end positions
+// (Matcher::SCORE_ONLY); mode 1 = start positions too for pairs whose E-value passes evalue_thr (SCORE_COV), which is what
+// `mmseqs search` runs.  Nothing is compared or converted inside the timed region; results land in caller arrays.
+// Returns the wall seconds between the barrier after thread set-up and the end of the loop.
+double mmref_sw_lists_omp(const char *matrix_file, int max_len, int gap_open, int gap_extend, int comp_bias,
+                          uint64_t db_residues, int n_threads, int mode, double evalue_thr,
+                          const uint8_t *qdata, const uint64_t *qoff, uint32_t q_from, uint32_t q_to,
+                          const uint32_t *list_ids, const uint64_t *list_off,
+                          const uint8_t *tdata, const uint64_t *toff,
+                          uint32_t *score, int32_t *qend, int32_t *tend, int32_t *qstart, int32_t *tstart,
+                          int *threads_used) {
+    Debug::setDebugLevel(Debug::ERROR);
+    SubstitutionMatrix m(matrix_file, 2.0f, 0.0f);
+    EvalueComputation evaluer(db_residues, &m, gap_open, gap_extend);
+    int a = m.alphabetSize;
+    std::vector<int8_t> tiny(a * a);
+    for (int i = 0; i < a; i++)
+        for (int j = 0; j < a; j++) tiny[i * a + j] = (int8_t)m.subMatrix[i][j];
+    double seconds = 0.0;
+    if (n_threads < 1) n_threads = 1;
+#pragma omp parallel num_threads(n_threads)
+    {
+        SmithWaterman sw(max_len, a, comp_bias != 0, 1.0f, &m);
+        Sequence q(max_len, Parameters::DBTYPE_AMINO_ACIDS, &m, 0, false, comp_bias != 0);
+        std::string backtrace;
+#pragma omp master
+        *threads_used = omp_get_num_threads();
+#pragma omp barrier
+        double t0 = omp_get_wtime();
+#pragma omp for schedule(dynamic, 5)
+        for (int64_t qi = (int64_t)q_from; qi < (int64_t)q_to; qi++) {
+            uint64_t b = list_off[qi], e = list_off[qi + 1];
+            if (b == e) continue;
+            q.mapSequence(0, 0, std::make_pair((const unsigned char *)(qdata + qoff[qi]),
+                                               (const unsigned int)(qoff[qi + 1] - qoff[qi])));
+            sw.ssw_init(&q, tiny.data(), &m);
+            int32_t maskLen = q.L / 2;
+            for (uint64_t k = b; k < e; k++) {
+                uint32_t id = list_ids[k];
+                int tlen = (int)(toff[id + 1] - toff[id]);
+                s_align r = sw.ssw_align(tdata + toff[id], tlen, backtrace, gap_open, gap_extend, mode, evalue_thr, &evaluer,
+                                         0, 0.0f, 0.0f, maskLen);
+                score[k] = r.score1;
+                qend[k] = r.qEndPos1;
+                tend[k] = r.dbEndPos1;
+                if (qstart) { qstart[k] = r.qStartPos1; tstart[k] = r.dbStartPos1; }
+                delete[] r.cigar;
+            }
+        }
+        double t1 = omp_get_wtime();   // after the implicit barrier of the omp for
+#pragma omp master
+        seconds = t1 - t0;
+    }
+    return seconds;
 }
 
 double mmref_evalue(mmref_ctx *c, double score, double qlen) { return c->evaluer->computeEvalue(score, qlen); }

@@ -56,3 +56,34 @@ def test_host_comp_bias_matches_oracle(oracle, matrices):
         fo = oracle.comp_bias(sub, pb, s, 1.0)
         assert np.array_equal(f.view(np.uint32), fo.view(np.uint32))
         assert np.array_equal(r, oracle.round_comp_bias(fo))
+
+
+def test_host_comp_bias_batch_equals_per_sequence_calls(matrices):
+    """mmgpu_host_comp_bias_batch (threads) = mmgpu_host_comp_bias + mmgpu_host_round_comp_bias per sequence, incl. empty
+    sequences and a single thread."""
+    import numpy as np
+    rng = np.random.default_rng(5)
+    sub = matrices["vtml80_kmer"].astype(np.int16)
+    pb = matrices["vtml80_pback"]
+    lens = [0, 1, 19, 40, 41, 350, 0, 1200] + [int(x) for x in rng.integers(1, 400, 300)]
+    res = rng.integers(0, 21, sum(lens)).astype(np.uint8)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    for threads in (1, 3, 16):
+        f, r = capi.host_comp_bias_batch(sub, pb, res, off, threads=threads)
+        for i in range(len(lens)):
+            a, b = int(off[i]), int(off[i + 1])
+            f1, r1 = capi.host_comp_bias(sub, pb, res[a:b])
+            assert np.array_equal(f[a:b].view(np.uint32), f1.view(np.uint32)) and np.array_equal(r[a:b], r1)
+    bad = res.copy()
+    bad[5] = 77
+    with pytest.raises(capi.MMGpuError):
+        capi.host_comp_bias_batch(sub, pb, bad, off)
+
+
+def test_flat_query_descriptors_match_the_struct_layout():
+    import ctypes
+    import numpy as np
+    for dt, st in ((capi.SW_QUERY_DTYPE, capi.SwQuery), (capi.PF_QUERY_DTYPE, capi.PfQuery)):
+        assert dt.itemsize == ctypes.sizeof(st)
+        for name, _ in st._fields_:
+            assert dt.fields[name][1] == getattr(st, name).offset, name

@@ -27,3 +27,12 @@ def test_evalue_and_thresholds_match_reference(db_res):
                     hi = mid
             assert ev.min_score_for_evalue(thr, qlen, db_res) == lo, (qlen, thr)
     assert abs(ref.bitscore(100) - ev.bit_score(100)) < 1e-9
+
+
+def test_vectorised_thresholds_equal_the_scalar_ones():
+    L = np.array([30, 31, 59, 120, 233, 233, 350, 777, 2000, 5000, 32000])
+    for db_res in (150000, 2.8e8):
+        for thr in (1e-3, 10.0, 1e-30, 1e-300):
+            a = ev.min_scores_for_evalue(thr, L, db_res)
+            b = np.array([ev.min_score_for_evalue(thr, int(x), db_res) for x in L])
+            assert np.array_equal(a, b), (db_res, thr)
