@@ -96,6 +96,22 @@ def host_cpu_topology():
     return threads, (len(cores) or threads)
 
 
+def host_limits():
+    """What bounds the host side of this box besides its core count: cgroup CPU quota, load, CPU model."""
+    out = {}
+    for key, path in (("cgroup_cpu_max", "/sys/fs/cgroup/cpu.max"), ("loadavg", "/proc/loadavg")):
+        try:
+            out[key] = open(path).read().strip()
+        except OSError:
+            out[key] = None
+    try:
+        out["model"] = next(l.split(":")[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
+        out["mhz_first_cpus"] = [round(float(l.split(":")[1])) for l in open("/proc/cpuinfo") if l.startswith("cpu MHz")][:4]
+    except (OSError, StopIteration):
+        pass
+    return out
+
+
 def sw_cpu_baseline_lists(matrices, qres, qoff, lists, tres, toff, budget_s, gpu_res, evalue_thr=1e-3):
     """Alignment::run's inner loop on the box's host cores as ONE native OpenMP call (oracle/ref_shim.cpp
     mmref_sw_lists_omp: one SmithWaterman per thread, schedule(dynamic, 5), Alignment.cpp:279-313): the reference's striped
@@ -134,6 +150,15 @@ def sw_cpu_baseline_lists(matrices, qres, qoff, lists, tres, toff, budget_s, gpu
         runs["one_thread_per_physical_core"] = {"threads": used_p, "seconds": round(sec_p, 3), "gcups": round(cells / sec_p / 1e9, 2)}
     sec_s, used_s, _, _ = run(lo, hi, hw_threads, 0)
     runs["score_and_end_only_all_hardware_threads"] = {"threads": used_s, "seconds": round(sec_s, 3), "gcups": round(cells / sec_s / 1e9, 2)}
+    # thread scaling on a slice of the sample: what one thread delivers on this box, and where the box stops scaling
+    # (a container's CPU quota or shared host shows up here, not in the thread count the OS reports)
+    scaling = {}
+    n_sc = min(hi - lo, 256)
+    for th in (1, 8, 32):
+        if th <= hw_threads:
+            q_to = lo + (max(8, n_sc // 8) if th == 1 else n_sc)
+            sec_t, used_t, _, cells_t = run(lo, q_to, th, 1)
+            scaling[str(used_t)] = round(cells_t / sec_t / 1e9, 2)
     best = max(("all_hardware_threads", "one_thread_per_physical_core"), key=lambda k: runs.get(k, {"gcups": 0})["gcups"])
     # parity of the timed device run against these results (after the timers)
     a, b = int(l_off[lo]), int(l_off[hi])
@@ -153,7 +178,7 @@ def sw_cpu_baseline_lists(matrices, qres, qoff, lists, tres, toff, budget_s, gpu
                     "forward cells / wall seconds inside the call, the same accounting as the device value",
             "sample": "the hit lists of queries [%d, %d) of the %d queries of the same workload (%d pairs, %.4g forward cells); runs: %s"
                       % (lo, hi, nq, b - a, cells, best),
-            "runs": runs,
+            "runs": runs, "gcups_by_thread_count_on_a_slice": scaling, "host": host_limits(),
             "parity_vs_baseline": {"pairs_compared": b - a, "field_mismatches": bad, "fields": "score, q_end, t_end",
                                    "pairs_with_start_on_both": int(both.sum()), "start_field_mismatches": bad_start,
                                    "pairs_with_start_on_one_side_only": int(np.count_nonzero(g_st != r_st))}}
