@@ -366,6 +366,25 @@ def search_headline(args, gpu, torch, dist, rank, world, matrices, barrier):
     else:
         gpu.load_targets(tres, toff, 21)
         n_global, db_residues = len(toff) - 1, float(toff[-1])
+    # the exchange steps run inside the library (RCCL communicator owned by it, include/mmgpu.h); torch.distributed carries the
+    # 128-byte communicator id and the barriers only.  MMGPU_BENCH_COLLECTIVES=torch keeps round 2's torch.distributed collectives.
+    lib_comm = False
+    comm_note = "torch.distributed"
+    if sharded and os.environ.get("MMGPU_BENCH_COLLECTIVES", "library") == "library":
+        try:
+            if dist.get_backend() == "nccl":
+                idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
+                if rank == 0:
+                    idt.copy_(torch.from_numpy(gpu.comm_unique_id()))
+                dist.broadcast(idt, 0)
+                gpu.comm_init_rank(idt.cpu().numpy(), rank, world)
+                lib_comm = True
+                comm_note = "library: RCCL communicator owned by libmmgpu (mmgpu_comm_init_rank), %d ranks" % world
+            elif world == 1:
+                lib_comm = True         # a context without a communicator is its own single rank (device copies)
+                comm_note = "library: single rank, device copies"
+        except Exception as e:          # report, and keep the run alive on the torch.distributed path
+            comm_note = "torch.distributed (library communicator failed: %s)" % str(e)[:200]
     # the k-mer index is built in HBM from the resident targets (IndexBuilder::fillDatabase, masking off)
     gpu.pf_build_index(k, 21, True, s3, i3, km16, kmer_thr, matrices["blosum62_ungapped"])
     gpu.synchronize()
@@ -403,6 +422,30 @@ def search_headline(args, gpu, torch, dist, rank, world, matrices, barrier):
                 keep["fused"] = fb.fetch().reshape(nq, stride)
             fb.free()
             return
+        if lib_comm:
+            # prefilter of the shard -> all-gather + merge -> owned pairs -> gather: all enqueued by the library on its stream
+            dh, dc, df, _ = pfb.exchange_merge()
+            b = gpu.sw_prepare_owned(mat, 11, 1, None, pfb, mode=1, marshalled=msh)
+            b.run()
+            b.gather_owned()
+            a_ms = b.kernel_ms()          # synchronises on the alignment kernels' event
+            gpu.synchronize()             # ... and on the gather behind them: the step is complete here
+            if record:
+                stat["pf_ms"].append(pfb.stage_ms()[6])
+                stat["align_ms"].append(a_ms)
+                stat["cells"], stat["pairs"] = b.cells, b.pairs
+            if record == "keep":
+                import ctypes
+                hip = ctypes.CDLL("libamdhip64.so")
+                mh, mc, mf = np.zeros((nq, stride, 3), np.int32), np.zeros(nq, np.int32), np.zeros(nq, np.int32)
+                for dst, src in ((mh, dh), (mc, dc), (mf, df)):
+                    assert hip.hipMemcpy(dst.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(src), dst.nbytes, 2) == 0      # device -> host
+                keep["merged"] = (mh, mc, mf)
+                full, nrec = b.fetch_owned()
+                keep["full"] = full.view(np.int32).reshape(nq, stride, 6)
+                keep["records_gathered"] = nrec
+            b.free()
+            return
         mh_t, mc_t, mf_t = D.exchange_and_merge_device(gpu, pfb, nq, stride)
         b, lc, ls = D.align_owned_pairs(gpu, mat, 11, 1, msh, mh_t, mc_t, nq, stride, mode=1)
         b.run()
@@ -439,7 +482,8 @@ def search_headline(args, gpu, torch, dist, rank, world, matrices, barrier):
     out = {"elapsed_s": elapsed, "align_ms": align_ms, "pf_ms": pf_ms, "cells": cells, "pairs": pairs, "nq": nq,
            "n_global": n_global, "n_local": gpu.n_targets, "kmer_thr": kmer_thr, "max_res": max_res, "stage": stage,
            "pf_cells": pf_cells, "pf_cands": pf_cands, "t_gen": t_gen, "t_index": t_index, "weak": weak, "sharded": sharded,
-           "thr_example": thr_of_len.get(len(qs[0])), "hbm_in_use_gb": round((mem_total - mem_free) / 2 ** 30, 1)}
+           "thr_example": thr_of_len.get(len(qs[0])), "hbm_in_use_gb": round((mem_total - mem_free) / 2 ** 30, 1),
+           "collectives": comm_note if sharded else None}
     if rank != 0:
         pfb.free()
         return out
@@ -514,7 +558,9 @@ def search_headline(args, gpu, torch, dist, rank, world, matrices, barrier):
         mh = mh.reshape(nq, stride * 3).view(capi.PF_HIT_DTYPE).reshape(nq, stride)
         out["nhits"] = int(mc.sum())
         out["inexact_queries"] = int((mf != 0).sum())
-        full = keep["full"].reshape(-1).view(capi.SW_HIT_DTYPE).reshape(nq, stride)
+        full = np.ascontiguousarray(keep["full"]).reshape(-1).view(capi.SW_HIT_DTYPE).reshape(nq, stride)
+        if "records_gathered" in keep:
+            out["records_gathered"] = int(keep["records_gathered"])
         out["merged_lists_sorted"] = bool(all(np.all(np.diff(mh[qi]["score"][:mc[qi]].astype(np.int64)) <= 0) for qi in range(0, nq, 97)))
         out["aligned_slots_filled"] = int(sum(int((full[qi, :mc[qi]]["score"] > 0).sum()) for qi in range(nq)))
     pfb.free()
@@ -811,7 +857,8 @@ def main():
                                "prefilter of the shard -> all-gather of exchange records -> merge (== unsplit result) -> alignment of owned pairs -> all-gather of results",
                        "value_is": "forward DP cells of the step / alignment-stage time of the step (HIP events); queries_per_s = queries / whole step",
                        "targets_per_gpu": int(H["n_local"]), "align_pairs_per_step": int(H["pairs"]), "align_cells_per_step": int(H["cells"]),
-                       "parallelism": "single GPU" if world == 1 else "1 process/GPU, targets dealt by length bucket, RCCL all-gather x2 per step"},
+                       "parallelism": "single GPU" if world == 1 else "1 process/GPU, targets dealt by length bucket, RCCL all-gather x2 per step",
+                       "collectives": H.get("collectives")},
             "ms_per_step_stages": {"prefilter_kernels": round(H["pf_ms"], 2), "align_kernels": round(k_ms, 2),
                                    "handover_exchange_and_host": round(ms_per_step - H["pf_ms"] - k_ms, 2)},
             "roofline": {"kernel": "sw_kernel<G,true> (three grids: tile shapes grouped by register need, forward + reverse scan)",
@@ -854,7 +901,7 @@ def main():
             out["end_to_end"] = e2e
             if "queries_per_s_end_to_end" in e2e:
                 out["queries_per_s_end_to_end"] = e2e["queries_per_s_end_to_end"]
-        for kname in ("two_call", "backtrace", "pairs_with_start", "inexact_queries", "merged_lists_sorted", "aligned_slots_filled"):
+        for kname in ("two_call", "backtrace", "pairs_with_start", "inexact_queries", "merged_lists_sorted", "aligned_slots_filled", "records_gathered"):
             if kname in H:
                 out[kname] = H[kname]
         out["setup_s"] = {"generate": round(H["t_gen"], 1), "score_tables_upload_and_device_index_build": round(H["t_index"], 2)}

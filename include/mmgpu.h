@@ -340,12 +340,18 @@ typedef struct {
                                the host must run QueryMatcher::matchQuery for this query */
 #define MMGPU_PF_SAT_TIE 3  /* nucleotide searches: two saturated diagonals of one target tie on the exact score - the reference's
                                choice depends on the element order its (unstable) std::sort by id left (QueryMatcher.cpp:154); or the
-                               query took the databaseHits overflow path.  Not decided on the device: the host runs
+                               query took the databaseHits overflow path.  Any search: the query's double-diagonal candidates number
+                               max(1M, dbSize) / 2 or more, where the reference may take its unsorted branch (unstable std::sort, no
+                               rescoring, QueryMatcher.cpp:188,204-214).  Not decided on the device: the host runs
                                QueryMatcher::matchQuery for this query */
 #define MMGPU_PF_LONG_SEQ 2 /* the query, or the target of one of its double-diagonal candidates, has 32768 residues or more:
                                the reference scores those with UngappedAlignment::computeLongScore (every 65536-shift of the
                                16-bit diagonal, UngappedAlignment.cpp:295-312, and a batching quirk at :265-273) - not on the
                                device; the host must run QueryMatcher::matchQuery for this query */
+
+#define MMGPU_PF_SHARD_INEXACT 4 /* sharded runs (mmgpu_multi_pf_fetch): an element of the query's merged list took the reference's
+                               overflow path on a shard, or was not scored on the device - the tie order at the cut is not the
+                               unsplit run's; the caller re-runs the query unsplit (or on the host) */
 
 typedef struct {
     uint64_t db_matches;     /* statistics_t::dbMatches */
@@ -421,6 +427,76 @@ int mmgpu_pf_merge_exchange(mmgpu_ctx *ctx, mmgpu_pf_batch_t *batch, const void 
  * mmgpu_sw_prepare_from_lists: every (query, target) pair is aligned on the device that holds the target. */
 int mmgpu_pf_localize_lists(mmgpu_ctx *ctx, const void *d_hits, const void *d_counts, uint32_t n_queries, uint32_t stride,
                             void *d_local_hits, void *d_local_counts, void *d_local_slot);
+
+/* ---- the communicator of a multi-GPU run, owned by the library -------------------------------
+ * The shards of ONE target database live in N contexts (one per GPU); the two exchange steps of a query batch - the
+ * all-gather of the per-shard hit lists and the gather of the alignment records - are RCCL collectives over xGMI that the
+ * library enqueues on the context's stream, with no host synchronisation.  This replaces what the reference does between
+ * MPI ranks through files (Prefiltering::runMpiSplits + mergeTargetSplits, Prefiltering.cpp:605-689,412-526).
+ *   one process per GPU : rank 0 calls mmgpu_comm_unique_id, the MMGPU_COMM_ID_BYTES bytes reach the other ranks by the
+ *                         host's own means (MPI_Bcast in an MPI build of mmseqs, the launcher's store under torchrun),
+ *                         every rank calls mmgpu_comm_init_rank on its context (collective: all ranks must call it);
+ *   one process, N GPUs : mmgpu_init_multi below creates the contexts and the communicator together.
+ * RCCL is loaded on first use (dlopen librccl.so.1, or $MMGPU_RCCL_LIB); single-GPU callers never load it. */
+#define MMGPU_COMM_ID_BYTES 128
+int mmgpu_comm_unique_id(uint8_t *id /* MMGPU_COMM_ID_BYTES */);
+int mmgpu_comm_init_rank(mmgpu_ctx *ctx, const uint8_t *id, int rank, int n_ranks);
+int mmgpu_comm_info(mmgpu_ctx *ctx, int *rank, int *n_ranks, char *transport, int transport_cap);   /* "rccl" | "copy" | "none" */
+void mmgpu_comm_destroy(mmgpu_ctx *ctx);      /* also done by mmgpu_destroy */
+/* Exchange step 1, for an exchange batch that has been run on every rank (same queries, same parameters): all-gather of the
+ * records over the context's communicator (a context without one is its own single rank) and the merge kernel - threshold,
+ * truncation and final order of the UNSPLIT run.  Everything is enqueued on the context's stream.  The merged lists stay
+ * in device buffers owned by the batch (valid until it is run again or freed): *d_hits [nq][*stride] mmgpu_pf_hit with GLOBAL
+ * ids, *d_counts [nq] uint32, *d_flags [nq] uint32 (bit 0: MMGPU_PF_X_INEXACT_ORDER took part); any of them may be NULL.
+ * identity_global [nq] (host, may be NULL) = global id of each query's own target.  The communicator's rank count must equal
+ * the shard description's n_shards. */
+int mmgpu_pf_exchange_merge(mmgpu_ctx *ctx, mmgpu_pf_batch_t *batch, const uint32_t *identity_global, const void **d_hits,
+                            const void **d_counts, const void **d_flags, uint32_t *stride);
+/* Exchange step 2.  mmgpu_sw_prepare_owned: the alignment batch of the pairs of the merged lists (left in `merged` by
+ * mmgpu_pf_exchange_merge) whose target this context's shard holds; queries as for mmgpu_sw_prepare_from_pf.  After
+ * mmgpu_sw_run, mmgpu_sw_gather_owned all-gathers the owned records (compacted, 32 bytes each) and scatters them into
+ * *d_full: mmgpu_sw_hit [nq * stride] in merged-list order (slot q * stride + k = hit k of query q's merged list; zero where
+ * the list ends), identical on every rank; *d_status: uint32 [2] = records gathered, ranks whose send buffer overflowed
+ * (the deal by length bucket is even: the buffer holds 1.5 x the even share; MMGPU_SW_GATHER_DENSE=1 sizes it for the worst
+ * case).  mmgpu_sw_fetch_owned copies the array to the host and fails on overflow. */
+int mmgpu_sw_prepare_owned(mmgpu_ctx *ctx, const mmgpu_sw_params *params, const mmgpu_sw_query *queries, uint32_t n_queries,
+                           int mode, mmgpu_pf_batch_t *merged, mmgpu_sw_batch_t **batch);
+int mmgpu_sw_gather_owned(mmgpu_ctx *ctx, mmgpu_sw_batch_t *batch, const void **d_full, const void **d_status);
+int mmgpu_sw_fetch_owned(mmgpu_ctx *ctx, mmgpu_sw_batch_t *batch, mmgpu_sw_hit *out, uint32_t *records);
+
+/* ---- one process, several GPUs (the form the patched `mmseqs` binary uses) ----------------------------------------------
+ * mmgpu_init_multi creates one context per device id, each with a stream of its own, and the communicator over them
+ * (ncclCommInitAll).  A repeated device id, or MMGPU_MULTI_TRANSPORT=copy, selects the "copy" transport instead: the
+ * all-gathers become device-to-device copies ordered by events (hipMemcpyPeerAsync between devices) - it lets several shards
+ * share one GPU (tests on a 1-GPU box) and stands in where RCCL is missing.  The mmgpu_multi_* calls drive every step over
+ * all contexts from the calling thread; each step only enqueues work (the collectives of a step inside one RCCL group). */
+typedef struct mmgpu_multi mmgpu_multi;
+typedef struct mmgpu_multi_pf_batch mmgpu_multi_pf_batch;
+int mmgpu_init_multi(mmgpu_multi **multi, const int *device_ids, int n_devices);
+void mmgpu_destroy_multi(mmgpu_multi *multi);
+int mmgpu_multi_size(mmgpu_multi *multi);
+mmgpu_ctx *mmgpu_multi_ctx(mmgpu_multi *multi, int i);      /* context of shard i (owned by `multi`) */
+int mmgpu_multi_synchronize(mmgpu_multi *multi);
+/* the database dealt to the contexts by length bucket (mmgpu_host_partition_targets), shard descriptions set */
+int mmgpu_multi_load_targets(mmgpu_multi *multi, const uint8_t *residues, const uint64_t *offsets, uint32_t n, int alphabet);
+/* every shard's k-mer index built on its device (mmgpu_pf_build_index) */
+int mmgpu_multi_pf_build_index(mmgpu_multi *multi, const mmgpu_pf_index *index, const int16_t *kmer_submat, int kmer_thr);
+/* One prefilter batch over all shards whose merged lists EQUAL the unsplit run's.  queries[i].identity_id is the GLOBAL id.
+ * run = per-shard prefilter -> all-gather of the exchange records -> merge kernel on every context (enqueues only);
+ * fetch = merged lists from context 0 (global ids), status MMGPU_PF_OK or MMGPU_PF_SHARD_INEXACT (count 0: re-run unsplit). */
+int mmgpu_multi_pf_prepare(mmgpu_multi *multi, const mmgpu_pf_params *params, const mmgpu_pf_query *queries, uint32_t n_queries,
+                           mmgpu_multi_pf_batch **batch);
+int mmgpu_multi_pf_run(mmgpu_multi *multi, mmgpu_multi_pf_batch *batch);
+int mmgpu_multi_pf_fetch(mmgpu_multi *multi, mmgpu_multi_pf_batch *batch, mmgpu_pf_hit *hits, uint32_t hit_stride, uint32_t *counts,
+                         int32_t *status);
+uint32_t mmgpu_multi_pf_stride(mmgpu_multi_pf_batch *batch);   /* slots per query of the merged lists, 0 before the first run */
+void mmgpu_multi_pf_free(mmgpu_multi *multi, mmgpu_multi_pf_batch *batch);
+/* Alignment of the merged lists of a batch that has been run: every context aligns the pairs whose target its shard holds
+ * (mmgpu_sw_prepare_owned + mmgpu_sw_run), the records are gathered over the communicator, out [n_queries * stride] receives
+ * them in merged-list order.  queries as for mmgpu_sw_prepare_from_pf.  cells / kernel_ms (may be NULL): forward cells of all
+ * shards, alignment-kernel time of the slowest context. */
+int mmgpu_multi_sw_from_pf(mmgpu_multi *multi, const mmgpu_sw_params *params, const mmgpu_sw_query *queries, uint32_t n_queries,
+                           int mode, mmgpu_multi_pf_batch *batch, mmgpu_sw_hit *out, uint64_t *cells, float *kernel_ms);
 
 /* milliseconds per stage of the last run (HIP events on the context's stream; synchronises):
  * ms[0] similar k-mers + index lists, ms[1] gather + bin split, ms[2] double-diagonal replay + ungapped scoring + best

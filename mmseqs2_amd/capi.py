@@ -72,6 +72,11 @@ EXPORTED_SYMBOLS = [
     "mmgpu_pf_run", "mmgpu_pf_fetch", "mmgpu_pf_stage_ms", "mmgpu_pf_last_cells", "mmgpu_pf_fetch_device", "mmgpu_pf_merge_splits", "mmgpu_pf_build_index", "mmgpu_pf_debug_index", "mmgpu_pf_debug_fetch", "mmgpu_pf_free",
     "mmgpu_host_partition_targets", "mmgpu_pf_set_shard", "mmgpu_pf_fetch_exchange", "mmgpu_pf_merge_exchange",
     "mmgpu_pf_localize_lists", "mmgpu_sw_prepare_from_lists",
+    "mmgpu_comm_unique_id", "mmgpu_comm_init_rank", "mmgpu_comm_info", "mmgpu_comm_destroy", "mmgpu_pf_exchange_merge",
+    "mmgpu_sw_prepare_owned", "mmgpu_sw_gather_owned", "mmgpu_sw_fetch_owned",
+    "mmgpu_init_multi", "mmgpu_destroy_multi", "mmgpu_multi_size", "mmgpu_multi_ctx", "mmgpu_multi_synchronize",
+    "mmgpu_multi_load_targets", "mmgpu_multi_pf_build_index", "mmgpu_multi_pf_prepare", "mmgpu_multi_pf_run", "mmgpu_multi_pf_fetch",
+    "mmgpu_multi_pf_stride", "mmgpu_multi_pf_free", "mmgpu_multi_sw_from_pf",
 ]
 
 
@@ -165,6 +170,33 @@ def load_library():
     L.mmgpu_pf_localize_lists.argtypes = [c_p, c_p, c_p, ctypes.c_uint32, ctypes.c_uint32, c_p, c_p, c_p]
     L.mmgpu_sw_prepare_from_lists.argtypes = [c_p, ctypes.POINTER(SwParams), c_p, ctypes.c_uint32, ctypes.c_int, c_p, c_p,
                                               ctypes.c_uint32, ctypes.POINTER(c_p)]
+    L.mmgpu_comm_unique_id.argtypes = [c_p]
+    L.mmgpu_comm_init_rank.argtypes = [c_p, c_p, ctypes.c_int, ctypes.c_int]
+    L.mmgpu_comm_info.argtypes = [c_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.c_char_p, ctypes.c_int]
+    L.mmgpu_comm_destroy.argtypes = [c_p]
+    L.mmgpu_comm_destroy.restype = None
+    L.mmgpu_pf_exchange_merge.argtypes = [c_p, c_p, c_p, ctypes.POINTER(c_p), ctypes.POINTER(c_p), ctypes.POINTER(c_p), ctypes.POINTER(ctypes.c_uint32)]
+    L.mmgpu_sw_prepare_owned.argtypes = [c_p, ctypes.POINTER(SwParams), c_p, ctypes.c_uint32, ctypes.c_int, c_p, ctypes.POINTER(c_p)]
+    L.mmgpu_sw_gather_owned.argtypes = [c_p, c_p, ctypes.POINTER(c_p), ctypes.POINTER(c_p)]
+    L.mmgpu_sw_fetch_owned.argtypes = [c_p, c_p, c_p, ctypes.POINTER(ctypes.c_uint32)]
+    L.mmgpu_init_multi.argtypes = [ctypes.POINTER(c_p), c_p, ctypes.c_int]
+    L.mmgpu_destroy_multi.argtypes = [c_p]
+    L.mmgpu_destroy_multi.restype = None
+    L.mmgpu_multi_size.argtypes = [c_p]
+    L.mmgpu_multi_ctx.argtypes = [c_p, ctypes.c_int]
+    L.mmgpu_multi_ctx.restype = c_p
+    L.mmgpu_multi_synchronize.argtypes = [c_p]
+    L.mmgpu_multi_load_targets.argtypes = [c_p, c_p, c_p, ctypes.c_uint32, ctypes.c_int]
+    L.mmgpu_multi_pf_build_index.argtypes = [c_p, ctypes.POINTER(PfIndexDesc), c_p, ctypes.c_int]
+    L.mmgpu_multi_pf_prepare.argtypes = [c_p, ctypes.POINTER(PfParams), c_p, ctypes.c_uint32, ctypes.POINTER(c_p)]
+    L.mmgpu_multi_pf_run.argtypes = [c_p, c_p]
+    L.mmgpu_multi_pf_fetch.argtypes = [c_p, c_p, c_p, ctypes.c_uint32, c_p, c_p]
+    L.mmgpu_multi_pf_stride.argtypes = [c_p]
+    L.mmgpu_multi_pf_stride.restype = ctypes.c_uint32
+    L.mmgpu_multi_pf_free.argtypes = [c_p, c_p]
+    L.mmgpu_multi_pf_free.restype = None
+    L.mmgpu_multi_sw_from_pf.argtypes = [c_p, ctypes.POINTER(SwParams), c_p, ctypes.c_uint32, ctypes.c_int, c_p, c_p,
+                                         ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_float)]
     return L
 
 
@@ -307,6 +339,15 @@ class PfBatch:
                                                            _ptr(ident), c_p(d_out_hits_ptr), out_stride, c_p(d_out_counts_ptr),
                                                            c_p(d_out_flags_ptr) if d_out_flags_ptr else None))
 
+    def exchange_merge(self, identity_global=None):
+        """mmgpu_pf_exchange_merge: all-gather over the context's communicator + merge, enqueued on its stream.
+        -> (d_hits, d_counts, d_flags device pointers owned by the batch, stride)"""
+        ig = None if identity_global is None else np.ascontiguousarray(identity_global, np.uint32)
+        dh, dc, df, st = c_p(), c_p(), c_p(), ctypes.c_uint32()
+        self.gpu._check(self.gpu.L.mmgpu_pf_exchange_merge(self.gpu.ctx, self.handle, _ptr(ig), ctypes.byref(dh), ctypes.byref(dc),
+                                                           ctypes.byref(df), ctypes.byref(st)))
+        return dh.value, dc.value, df.value, st.value
+
     def stage_ms(self):
         ms = (ctypes.c_float * 7)()
         self.gpu._check(self.gpu.L.mmgpu_pf_stage_ms(self.gpu.ctx, self.handle, ms))
@@ -380,6 +421,19 @@ class SwBatch:
         info = info[:len(idx)]
         strs = [bytes(buf[int(r["bt_off"]):int(r["bt_off"]) + int(r["bt_len"])]).decode() for r in info]
         return info, strs
+
+    def gather_owned(self):
+        """mmgpu_sw_gather_owned -> (d_full, d_status) device pointers owned by the batch"""
+        df, ds = c_p(), c_p()
+        self.gpu._check(self.gpu.L.mmgpu_sw_gather_owned(self.gpu.ctx, self.handle, ctypes.byref(df), ctypes.byref(ds)))
+        return df.value, ds.value
+
+    def fetch_owned(self):
+        """mmgpu_sw_fetch_owned -> (SW_HIT_DTYPE [slots] in merged-list order, records gathered)"""
+        out = np.zeros(self.slots, SW_HIT_DTYPE)
+        n = ctypes.c_uint32()
+        self.gpu._check(self.gpu.L.mmgpu_sw_fetch_owned(self.gpu.ctx, self.handle, _ptr(out), ctypes.byref(n)))
+        return out, n.value
 
     def kernel_ms(self):
         ms = ctypes.c_float()
@@ -674,6 +728,32 @@ class MMGpu:
         b.slots = n * stride
         return b
 
+    # ---- communicator owned by the library (RCCL) ----
+    def comm_unique_id(self):
+        b = np.zeros(128, np.uint8)
+        self._check(self.L.mmgpu_comm_unique_id(_ptr(b)))
+        return b
+
+    def comm_init_rank(self, comm_id, rank, n_ranks):
+        b = np.ascontiguousarray(comm_id, np.uint8)
+        assert b.size == 128
+        self._check(self.L.mmgpu_comm_init_rank(self.ctx, _ptr(b), int(rank), int(n_ranks)))
+
+    def comm_info(self):
+        r, n = ctypes.c_int(), ctypes.c_int()
+        t = ctypes.create_string_buffer(32)
+        self._check(self.L.mmgpu_comm_info(self.ctx, ctypes.byref(r), ctypes.byref(n), t, 32))
+        return r.value, n.value, t.value.decode()
+
+    def sw_prepare_owned(self, mat, gap_open, gap_extend, queries, pf_batch, mode=1, marshalled=None):
+        """alignment batch of the pairs of pf_batch's merged lists whose target this context's shard holds"""
+        par, arr, keep, n = marshalled if marshalled is not None else self.sw_marshal_queries(mat, gap_open, gap_extend, queries)
+        h = c_p()
+        self._check(self.L.mmgpu_sw_prepare_owned(self.ctx, ctypes.byref(par), ctypes.cast(arr, c_p), n, mode, pf_batch.handle, ctypes.byref(h)))
+        b = SwBatch(self, h, keep)
+        b.slots = n * pf_batch.max_hits
+        return b
+
     def pf_merge_splits(self, d_hits_ptr, d_counts_ptr, n_splits, nq, stride, id_offsets, d_out_hits_ptr, d_out_counts_ptr):
         off = np.ascontiguousarray(id_offsets, np.uint32)
         self._check(self.L.mmgpu_pf_merge_splits(self.ctx, c_p(d_hits_ptr), c_p(d_counts_ptr), n_splits, nq, stride, _ptr(off),
@@ -776,3 +856,85 @@ def select_exchange_host(records, max_hits, min_diag_score, ref_bins, self_score
     key_a = ((255 - kc[idx]) << 11) | (r["id"][idx].astype(np.int64) & (ref_bins - 1))
     order = np.lexsort((r["id"][idx], r["order"][idx], key_a))
     return r[idx[order][:max_hits]]
+
+
+class MMGpuMulti:
+    """mmgpu_init_multi: one process, several contexts (one per shard of the target database) + their communicator."""
+
+    def __init__(self, device_ids):
+        self.L = load_library()
+        ids = np.ascontiguousarray(device_ids, np.int32)
+        h = c_p()
+        rc = self.L.mmgpu_init_multi(ctypes.byref(h), _ptr(ids), len(ids))
+        if rc != 0:
+            raise MMGpuError("mmgpu_init_multi failed (%d): %s" % (rc, self.L.mmgpu_last_error().decode()))
+        self.h = h
+        self.n = len(ids)
+        self._keep = None
+
+    def _check(self, rc):
+        if rc != 0:
+            raise MMGpuError("libmmgpu error %d: %s" % (rc, self.L.mmgpu_last_error().decode()))
+
+    def close(self):
+        if self.h is not None:
+            self.L.mmgpu_destroy_multi(self.h)
+            self.h = None
+
+    def transport(self):
+        t = ctypes.create_string_buffer(32)
+        self._check(self.L.mmgpu_comm_info(c_p(self.L.mmgpu_multi_ctx(self.h, 0)), None, None, t, 32))
+        return t.value.decode()
+
+    def synchronize(self):
+        self._check(self.L.mmgpu_multi_synchronize(self.h))
+
+    def load_targets(self, residues, offsets, alphabet=21):
+        residues = np.ascontiguousarray(residues, np.uint8)
+        offsets = np.ascontiguousarray(offsets, np.uint64)
+        self._check(self.L.mmgpu_multi_load_targets(self.h, _ptr(residues), _ptr(offsets), len(offsets) - 1, alphabet))
+        self.n_targets = len(offsets) - 1
+
+    def pf_build_index(self, k, alphabet, spaced, score3, index3, kmer_submat16, kmer_thr, ungapped_mat):
+        score3 = np.ascontiguousarray(score3, np.int16)
+        index3 = np.ascontiguousarray(index3, np.uint32)
+        um = np.ascontiguousarray(ungapped_mat, np.int8)
+        km = np.ascontiguousarray(kmer_submat16, np.int16)
+        d = PfIndexDesc(k, alphabet, int(spaced), _ptr(score3), _ptr(index3), score3.shape[1], None, None, 0, None, None, None, None, 0, _ptr(um))
+        self._check(self.L.mmgpu_multi_pf_build_index(self.h, ctypes.byref(d), _ptr(km), int(kmer_thr)))
+
+    def pf_prepare(self, queries, kmer_thr, max_hits=300, min_diag_score=15, ref_bins=0):
+        """queries as for MMGpu.pf_prepare; identity_id is the GLOBAL id.  -> opaque batch handle (c_p)"""
+        arr, keep = MMGpu._pf_marshal(None, queries)
+        par = PfParams(int(kmer_thr), int(max_hits), int(min_diag_score), int(ref_bins), 0, 0, 0)
+        h = c_p()
+        self._check(self.L.mmgpu_multi_pf_prepare(self.h, ctypes.byref(par), ctypes.cast(arr, c_p), len(queries), ctypes.byref(h)))
+        self._keep = keep
+        return h
+
+    def pf_run(self, batch):
+        self._check(self.L.mmgpu_multi_pf_run(self.h, batch))
+
+    def pf_fetch(self, batch, nq):
+        stride = int(self.L.mmgpu_multi_pf_stride(batch))
+        hits = np.zeros((nq, max(stride, 1)), PF_HIT_DTYPE)
+        counts = np.zeros(nq, np.uint32)
+        status = np.zeros(nq, np.int32)
+        self._check(self.L.mmgpu_multi_pf_fetch(self.h, batch, _ptr(hits), max(stride, 1), _ptr(counts), _ptr(status)))
+        return hits, counts, status
+
+    def pf_free(self, batch):
+        self.L.mmgpu_multi_pf_free(self.h, batch)
+
+    def sw_from_pf(self, mat, gap_open, gap_extend, queries, batch, nq, mode=1):
+        """-> (SW_HIT_DTYPE [nq, stride] in merged-list order, forward cells, slowest context's kernel ms)"""
+        qd = [dict(q=x["q"], comp_bias=x.get("comp_bias"), targets=np.zeros(0, np.uint32), min_start_score=x.get("min_start_score", 0))
+              for x in queries]
+        par, arr, keep = MMGpu._marshal(None, mat, gap_open, gap_extend, qd)
+        stride = int(self.L.mmgpu_multi_pf_stride(batch))
+        out = np.zeros((nq, max(stride, 1)), SW_HIT_DTYPE)
+        cells, ms = ctypes.c_uint64(), ctypes.c_float()
+        self._check(self.L.mmgpu_multi_sw_from_pf(self.h, ctypes.byref(par), ctypes.cast(arr, c_p), nq, mode, batch, _ptr(out),
+                                                  ctypes.byref(cells), ctypes.byref(ms)))
+        del keep
+        return out, cells.value, ms.value

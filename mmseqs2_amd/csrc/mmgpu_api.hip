@@ -51,6 +51,8 @@ extern "C" void mmgpu_destroy(mmgpu_ctx *c) {
     free_db(c->db);
     mmgpu::pf_index_free(c);
     (void)hipDeviceSynchronize();
+    mmgpu::comm_free(c);
+    if (c->owns_stream && c->stream) (void)hipStreamDestroy(c->stream);
     for (auto &st : c->side) if (st) (void)hipStreamDestroy(st);
     if (c->fork) (void)hipEventDestroy(c->fork);
     for (auto &e : c->join) if (e) (void)hipEventDestroy(e);
@@ -102,7 +104,7 @@ extern "C" int mmgpu_load_targets(mmgpu_ctx *c, const uint8_t *residues, const u
     c->shard.on = false;
     free_db(c->db);
     std::vector<uint32_t> off4(std::max<uint32_t>(n, 1)), len(std::max<uint32_t>(n, 1));
-    uint64_t cur4 = 0;
+    uint64_t cur4 = 16;      // 64 bytes of padding in front: the reverse scan reads up to 3 bytes before a target (sw_kernel.hip)
     uint32_t max_len = 0;
     uint64_t total = 0;
     for (uint32_t i = 0; i < n; i++) {
@@ -295,6 +297,12 @@ struct mmgpu_sw_batch_t {
     std::vector<mmgpu_sw_hit> h_res;
     std::vector<uint32_t> h_slot_target;
     bool h_res_valid = false;
+    // pairs this rank owns of a sharded run's merged lists (mmgpu_sw_prepare_owned / mmgpu_sw_gather_owned)
+    bool owned = false;
+    uint32_t o_stride = 0, o_cap = 0;
+    int o_ranks = 0;
+    DevBuf o_lhits, o_lcounts, o_lslot;        // merged lists restricted to this shard's targets (local ids) + their list positions
+    DevBuf o_send, o_counter, o_recv, o_recv_counters, o_full, o_status;
 };
 
 // which kernel body serves a query of this length: 16 lanes x R rows per tile, R even, at most 16 * SW_MAX_R rows
@@ -648,6 +656,137 @@ extern "C" int mmgpu_sw_prepare_from_lists(mmgpu_ctx *c, const mmgpu_sw_params *
     L.counts = (const uint32_t *)d_counts;
     L.stride = stride;
     return sw_prepare_impl(c, par, qs, nq, mode, &L, out);
+}
+
+// ---- multi-GPU: every rank aligns the pairs of the merged lists whose target it holds; the records are gathered over the
+// communicator in merged-list order ("run each pair on the GPU owning t; gather mmgpu_sw_hits per query") ----
+extern "C" int mmgpu_sw_prepare_owned(mmgpu_ctx *c, const mmgpu_sw_params *par, const mmgpu_sw_query *qs, uint32_t nq, int mode,
+                                      mmgpu_pf_batch_t *merged, mmgpu_sw_batch_t **out) {
+    if (!c || !merged || !out) return fail(MMGPU_ERR_ARG, "mmgpu_sw_prepare_owned: NULL argument");
+    if (!c->shard.on) return fail(MMGPU_ERR_STATE, "mmgpu_sw_prepare_owned: no shard set (mmgpu_pf_set_shard)");
+    const mmgpu_pf_hit *mh = nullptr;
+    const uint32_t *mc = nullptr;
+    uint32_t stride = 0, mnq = 0;
+    if (!mmgpu::pf_batch_merged_lists(merged, &mh, &mc, &stride, &mnq)) return fail(MMGPU_ERR_STATE, "mmgpu_sw_prepare_owned: the prefilter batch holds no merged lists (mmgpu_pf_exchange_merge first)");
+    if (mnq != nq) return fail(MMGPU_ERR_ARG, "mmgpu_sw_prepare_owned: query count differs from the prefilter batch");
+    HIP_TRY(hipSetDevice(c->device));
+    DevBuf lh, lc, ls;
+    lh.bind(c->cache); lc.bind(c->cache); ls.bind(c->cache);
+    HIP_TRY(lh.alloc(std::max<size_t>((size_t)nq * stride, 1) * sizeof(mmgpu_pf_hit)));
+    HIP_TRY(lc.alloc(std::max<size_t>(nq, 1) * 4));
+    HIP_TRY(ls.alloc(std::max<size_t>((size_t)nq * stride, 1) * 4));
+    PfLocalizeArgs A;
+    A.hits = mh;
+    A.counts = mc;
+    A.nq = nq;
+    A.stride = stride;
+    A.shard = c->shard.shard;
+    A.shard_of = c->shard.d_shard_of.as<uint32_t>();
+    A.local_id = c->shard.d_local_id.as<uint32_t>();
+    A.local_hits = lh.as<mmgpu_pf_hit>();
+    A.local_counts = lc.as<uint32_t>();
+    A.local_slot = ls.as<uint32_t>();
+    HIP_TRY(launch_pf_localize(A, c->stream));
+    DeviceLists L;
+    L.hits = lh.as<mmgpu_pf_hit>();
+    L.counts = lc.as<uint32_t>();
+    L.stride = stride;
+    if (int e = sw_prepare_impl(c, par, qs, nq, mode, &L, out)) return e;
+    mmgpu_sw_batch_t *b = *out;
+    b->owned = true;
+    b->o_stride = stride;
+    b->o_lhits = std::move(lh);
+    b->o_lcounts = std::move(lc);
+    b->o_lslot = std::move(ls);
+    return MMGPU_OK;
+}
+
+namespace mmgpu {
+
+// phase 1: pack the owned records (compacted with a device counter) and name the two all-gathers of the step.  The send
+// buffer holds 1.5 x the even share of the slots (+ 4096): the deal by length bucket gives every rank its share to within
+// a few percent; a rank that packs more reports it in its counter and the scatter phase raises the batch's overflow status.
+int sw_gather_begin(mmgpu_ctx *c, mmgpu_sw_batch_t *b, int n_ranks, XchgBlock blocks[2]) {
+    if (!c || !b) return fail(MMGPU_ERR_ARG, "mmgpu_sw_gather_owned: NULL argument");
+    if (!b->owned || !b->ran) return fail(MMGPU_ERR_STATE, "mmgpu_sw_gather_owned: not a batch of mmgpu_sw_prepare_owned that has been run");
+    HIP_TRY(hipSetDevice(c->device));
+    const uint64_t slots = (uint64_t)b->n_queries * b->o_stride;
+    static const char *dense = getenv("MMGPU_SW_GATHER_DENSE");      // every rank may own everything (no overflow possible)
+    const uint64_t cap64 = (dense || n_ranks == 1) ? slots : std::min<uint64_t>(slots, slots / (uint64_t)n_ranks * 3 / 2 + 4096);
+    const uint32_t cap = (uint32_t)std::max<uint64_t>(cap64, 1);
+    if (b->o_cap != cap || b->o_ranks != n_ranks) {
+        for (DevBuf *d : {&b->o_send, &b->o_counter, &b->o_recv, &b->o_recv_counters, &b->o_full, &b->o_status}) d->bind(c->cache);
+        HIP_TRY(b->o_send.alloc((size_t)cap * sizeof(SwOwnedRec)));
+        HIP_TRY(b->o_counter.alloc(8));
+        HIP_TRY(b->o_recv.alloc((size_t)cap * sizeof(SwOwnedRec) * n_ranks));
+        HIP_TRY(b->o_recv_counters.alloc((size_t)8 * n_ranks));
+        HIP_TRY(b->o_full.alloc(std::max<size_t>(slots, 1) * sizeof(mmgpu_sw_hit)));
+        HIP_TRY(b->o_status.alloc(8));
+        b->o_cap = cap;
+        b->o_ranks = n_ranks;
+    }
+    HIP_TRY(hipMemsetAsync(b->o_counter.p, 0, 8, c->stream));
+    SwOwnedPackArgs P;
+    P.res = b->d_out.as<mmgpu_sw_hit>();
+    P.local_counts = b->o_lcounts.as<uint32_t>();
+    P.local_slot = b->o_lslot.as<uint32_t>();
+    P.nq = b->n_queries;
+    P.stride = b->o_stride;
+    P.send = b->o_send.as<SwOwnedRec>();
+    P.cap = cap;
+    P.counter = b->o_counter.as<uint32_t>();
+    HIP_TRY(launch_sw_owned_pack(P, c->stream));
+    blocks[0] = XchgBlock{b->o_send.p, b->o_recv.p, (size_t)cap * sizeof(SwOwnedRec)};
+    blocks[1] = XchgBlock{b->o_counter.p, b->o_recv_counters.p, 8};
+    return MMGPU_OK;
+}
+
+// phase 3: scatter every rank's records into the merged-list order
+int sw_gather_finish(mmgpu_ctx *c, mmgpu_sw_batch_t *b, int n_ranks) {
+    HIP_TRY(hipSetDevice(c->device));
+    const uint64_t slots = (uint64_t)b->n_queries * b->o_stride;
+    HIP_TRY(hipMemsetAsync(b->o_full.p, 0, std::max<size_t>(slots, 1) * sizeof(mmgpu_sw_hit), c->stream));
+    HIP_TRY(hipMemsetAsync(b->o_status.p, 0, 8, c->stream));
+    SwOwnedScatterArgs S;
+    S.recv = b->o_recv.as<SwOwnedRec>();
+    S.counters = b->o_recv_counters.as<uint32_t>();
+    S.n_ranks = (uint32_t)n_ranks;
+    S.cap = b->o_cap;
+    S.n_slots = (uint32_t)slots;
+    S.full = b->o_full.as<mmgpu_sw_hit>();
+    S.status = b->o_status.as<uint32_t>();
+    HIP_TRY(launch_sw_owned_scatter(S, c->stream));
+    return MMGPU_OK;
+}
+
+}  // namespace mmgpu
+
+extern "C" int mmgpu_sw_gather_owned(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const void **d_full, const void **d_status) {
+    if (!c || !b) return fail(MMGPU_ERR_ARG, "mmgpu_sw_gather_owned: NULL argument");
+    const int n = c->comm ? c->comm->n_ranks : 1;
+    mmgpu::XchgBlock blk[2];
+    if (int e = mmgpu::sw_gather_begin(c, b, n, blk)) return e;
+    for (int k = 0; k < 2; k++)
+        if (int e = mmgpu::comm_allgather(c, blk[k].send, blk[k].recv, blk[k].bytes)) return e;
+    if (int e = mmgpu::sw_gather_finish(c, b, n)) return e;
+    if (d_full) *d_full = b->o_full.p;
+    if (d_status) *d_status = b->o_status.p;
+    return MMGPU_OK;
+}
+
+// host copy of the gathered records (synchronises the context's stream); MMGPU_ERR_STATE if a rank's send buffer overflowed
+// (rerun the gather with MMGPU_SW_GATHER_DENSE=1)
+extern "C" int mmgpu_sw_fetch_owned(mmgpu_ctx *c, mmgpu_sw_batch_t *b, mmgpu_sw_hit *out, uint32_t *records) {
+    if (!c || !b) return fail(MMGPU_ERR_ARG, "mmgpu_sw_fetch_owned: NULL argument");
+    if (!b->owned || !b->o_full.p) return fail(MMGPU_ERR_STATE, "mmgpu_sw_fetch_owned: nothing gathered (mmgpu_sw_gather_owned first)");
+    HIP_TRY(hipSetDevice(c->device));
+    uint32_t st[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(st, b->o_status.p, 8, hipMemcpyDeviceToHost, c->stream));
+    if (out) HIP_TRY(hipMemcpyAsync(out, b->o_full.p, (size_t)b->n_queries * b->o_stride * sizeof(mmgpu_sw_hit), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (records) *records = st[0];
+    if (st[1]) return fail(MMGPU_ERR_STATE, "mmgpu_sw_fetch_owned: the send buffer of a rank overflowed (uneven shards); rerun the gather with MMGPU_SW_GATHER_DENSE=1");
+    return MMGPU_OK;
 }
 
 extern "C" int mmgpu_sw_run(mmgpu_ctx *c, mmgpu_sw_batch_t *b) {

@@ -7,6 +7,7 @@
 #include <cstdlib>
 
 #include <algorithm>
+#include <array>
 #include <string>
 #include <map>
 #include <memory>
@@ -243,7 +244,12 @@ struct PfSelectArgs {
     mmgpu_pf_xhit *xhits;             // null = ordinary run
     const uint32_t *global_ids;       // [n_targets] local -> global id
     const uint32_t *q_nseg;           // overflow-path queries (their order key is not shard independent), may be null
-    const uint32_t *q_flags;          // long-sequence queries (scores not computed on the device), may be null
+    uint32_t *q_flags;                // long-sequence queries (scores not computed on the device), may be null; bit 1 is set here (below)
+    // diagonal scoring of sequences: a query whose double-diagonal candidates number foundDiagonalsSize / 2 or more MAY take the
+    // reference's unsorted branch (QueryMatcher.cpp:188,204-214: filter, unstable std::sort, exact scores, no rescoring) - the
+    // candidate total bounds resultSize from above, such queries are flagged (bit 1 -> MMGPU_PF_SAT_TIE) and left to the host
+    const uint32_t *cand_count;       // [nq * bins] candidates per (query, bin), null = no check (modes that count elsewhere)
+    uint32_t cand_cap;
     int nucl;                         // nucleotide searches: saturated elements are ordered by target id (QueryMatcher.cpp:154)
     // max_hits above PF_MAX_HITS: the selected elements are sorted in global scratch, [nq][big_stride] keys + diagonals
     uint64_t *big_keys;
@@ -279,6 +285,31 @@ struct PfLocalizeArgs {
     uint32_t *local_slot;             // [nq][stride] position of the hit in the query's merged list
 };
 hipError_t launch_pf_localize(const PfLocalizeArgs &A, hipStream_t s);
+
+// ---- alignment records of the pairs a rank owns, gathered over the ranks (pf_shard_kernels.hip) ----
+struct SwOwnedRec {                   // 32 bytes: one aligned pair and where it goes in the merged-list order
+    mmgpu_sw_hit hit;
+    uint32_t slot;                    // q * stride + position in query q's merged list
+    uint32_t pad;
+};
+struct SwOwnedPackArgs {
+    const mmgpu_sw_hit *res;          // [nq * stride] the batch's records, local list order
+    const uint32_t *local_counts;     // [nq]
+    const uint32_t *local_slot;       // [nq * stride]
+    uint32_t nq, stride;
+    SwOwnedRec *send;                 // [cap]
+    uint32_t cap;
+    uint32_t *counter;                // [2]: records packed, records that did not fit (overflow)
+};
+struct SwOwnedScatterArgs {
+    const SwOwnedRec *recv;           // [n_ranks][cap]
+    const uint32_t *counters;         // [n_ranks][2]
+    uint32_t n_ranks, cap, n_slots;
+    mmgpu_sw_hit *full;               // [n_slots], zeroed before
+    uint32_t *status;                 // [2]: records scattered, ranks whose send buffer overflowed
+};
+hipError_t launch_sw_owned_pack(const SwOwnedPackArgs &A, hipStream_t s);
+hipError_t launch_sw_owned_scatter(const SwOwnedScatterArgs &A, hipStream_t s);
 
 constexpr int PF_MAX_SEG = 62;         // databaseHits flushes per query the device emulates (QueryMatcher.cpp:310-346)
 
@@ -483,6 +514,14 @@ struct DevBuf {
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
     DevBuf(DevBuf &&o) noexcept : p(o.p), bytes(o.bytes), cap(o.cap), cache(std::move(o.cache)) { o.p = nullptr; o.bytes = 0; o.cap = 0; }
+    DevBuf &operator=(DevBuf &&o) noexcept {
+        if (this != &o) {
+            release();
+            p = o.p; bytes = o.bytes; cap = o.cap; cache = std::move(o.cache);
+            o.p = nullptr; o.bytes = 0; o.cap = 0;
+        }
+        return *this;
+    }
     ~DevBuf() { release(); }
     void bind(const std::shared_ptr<BlockCache> &c) {
         static const bool off = getenv("MMGPU_NO_BLOCK_CACHE") != nullptr;   // debugging aid: every buffer straight from hipMalloc
@@ -537,9 +576,20 @@ struct PfIndex;   // pf_api.hip
 
 }  // namespace mmgpu
 
+namespace mmgpu {
+// communicator over the contexts that hold the shards of one target database (comm.hip)
+struct Comm {
+    void *nccl = nullptr;          // ncclComm_t; null = the copy transport of a one-process run (multi_api.hip)
+    int rank = 0, n_ranks = 1;
+    std::string transport;         // "rccl" | "copy"
+};
+}  // namespace mmgpu
+
 struct mmgpu_ctx {
     int device = 0;
+    mmgpu::Comm *comm = nullptr;   // multi-GPU runs: mmgpu_comm_init_rank / mmgpu_init_multi
     hipStream_t stream = nullptr;
+    bool owns_stream = false;      // mmgpu_init_multi gives every context a stream of its own
     mmgpu::DeviceDb db;
     std::vector<uint32_t> h_len;   // host copy of target lengths (scheduling)
     uint32_t mean_len = 0;
@@ -559,7 +609,24 @@ struct mmgpu_ctx {
 };
 
 struct mmgpu_pf_batch_t;
+struct mmgpu_sw_batch_t;
 namespace mmgpu {
+// comm.hip
+int comm_require_rccl();
+int comm_group_start();
+int comm_group_end();
+int comm_init_all(mmgpu_ctx **ctxs, int n);
+int comm_allgather(mmgpu_ctx *c, const void *send, void *recv, size_t bytes);
+void comm_free(mmgpu_ctx *c);
+// the phases of the two exchange steps (pf_api.hip, mmgpu_api.hip); mmgpu_pf_exchange_merge / mmgpu_sw_gather_owned run them on
+// one context, multi_api.hip runs each phase over the contexts of a process (the collective inside an RCCL group)
+struct XchgBlock { const void *send; void *recv; size_t bytes; };   // one all-gather: `bytes` per rank
+int pf_xchg_begin(mmgpu_ctx *c, mmgpu_pf_batch_t *b, int n_ranks, XchgBlock blocks[2]);
+int pf_xchg_merge(mmgpu_ctx *c, mmgpu_pf_batch_t *b, int n_ranks, const uint32_t *identity_global);
+int sw_gather_begin(mmgpu_ctx *c, mmgpu_sw_batch_t *b, int n_ranks, XchgBlock blocks[2]);
+int sw_gather_finish(mmgpu_ctx *c, mmgpu_sw_batch_t *b, int n_ranks);
+int pf_batch_merged_flags(mmgpu_pf_batch_t *b, const void **d_flags);
+bool pf_batch_merged_lists(mmgpu_pf_batch_t *b, const mmgpu_pf_hit **hits, const uint32_t **counts, uint32_t *stride, uint32_t *nq);
 void pf_index_free(mmgpu_ctx *c);
 // device-resident results of a prefilter batch that has been run (false if it has not)
 bool pf_batch_device_lists(mmgpu_pf_batch_t *b, const mmgpu_pf_hit **hits, const uint32_t **counts, uint32_t *stride, uint32_t *nq);

@@ -490,6 +490,10 @@ struct mmgpu_pf_batch_t {
     uint64_t last_lists = 0, last_entries = 0;
     uint32_t last_tiles = 0;
     bool ran = false;
+    // exchange step of a sharded run (mmgpu_pf_exchange_merge): every rank's records, and the merged lists (global ids)
+    DevBuf x_recv_hits, x_recv_counts, x_hits, x_counts, x_flags, x_ident;
+    std::vector<uint32_t> x_ident_host;
+    int x_ranks = 0;           // ranks of the last merge; 0 = no merged lists yet
 };
 
 namespace mmgpu {
@@ -552,7 +556,11 @@ extern "C" int mmgpu_pf_prepare(mmgpu_ctx *c, const mmgpu_pf_params *par, const 
     b->bins = bins;
     b->ref_bins = par->ref_bins ? par->ref_bins : reference_bins(db_size);
     b->exchange = exchange;
-    b->max_db_matches = std::max<uint64_t>(1000000, c->db.n) * 2;   // QueryMatcher.cpp:44-45
+    b->max_db_matches = std::max<uint64_t>(1000000, db_size) * 2;   // QueryMatcher.cpp:44-45 (dbSize of the WHOLE database)
+    // a shard gathers its share of a query's index entries: the unsplit run's overflow path (QueryMatcher.cpp:310-346) is taken
+    // when the shares add up to max_db_matches.  The deal by length bucket is even; a shard treats half its share as the limit,
+    // such queries carry MMGPU_PF_X_INEXACT_ORDER and are re-run unsplit by the caller
+    if (exchange) b->max_db_matches = std::max<uint64_t>(1, b->max_db_matches / (2ull * std::max<uint32_t>(1, c->shard.n_shards)));
     b->q_off.assign(nq + 1, 0);
     uint64_t tot = 0;
     for (uint32_t i = 0; i < nq; i++) {
@@ -935,7 +943,7 @@ extern "C" int mmgpu_pf_run(mmgpu_ctx *c, mmgpu_pf_batch_t *b) {
     D.q_res = b->d_qres.as<uint8_t>();
     D.q_corr = b->d_qcorr.as<int8_t>();
     D.nucl = b->par.nucleotide ? 1 : 0;
-    D.sort_cap = (uint32_t)(std::max<uint64_t>(1000000, c->db.n) / 2);     // foundDiagonalsSize / 2 (QueryMatcher.cpp:44,146)
+    D.sort_cap = (uint32_t)(std::max<uint64_t>(1000000, b->exchange ? c->shard.global_n : c->db.n) / 2);     // foundDiagonalsSize / 2 (QueryMatcher.cpp:44,146)
     D.q_ncand = (b->par.nucleotide || b->par.kmer_score) ? b->d_qncand.as<uint32_t>() : nullptr;
     D.q_rows = b->any_profile ? b->d_qrows.as<int8_t>() : nullptr;
     D.q_isprof = b->any_profile ? b->d_qisprof.as<uint8_t>() : nullptr;
@@ -998,6 +1006,15 @@ extern "C" int mmgpu_pf_run(mmgpu_ctx *c, mmgpu_pf_batch_t *b) {
     S.q_flags = b->d_qflags.as<uint32_t>();
     S.nucl = b->par.nucleotide ? 1 : 0;
     S.kmer_score = b->par.kmer_score ? 1 : 0;
+    {   // foundDiagonalsSize / 2 over the WHOLE database (QueryMatcher.cpp:44,188); a shard sees its share of the candidates,
+        // the deal by length bucket is even, so a shard flags at half its share (the query is then re-run unsplit)
+        const uint64_t db_all = b->exchange ? c->shard.global_n : c->db.n;
+        uint64_t cap = std::max<uint64_t>(1000000, db_all) / 2;
+        if (b->exchange) cap = std::max<uint64_t>(1, cap / (2ull * std::max<uint32_t>(1, c->shard.n_shards)));
+        if (const char *e = getenv("MMGPU_PF_SORT_CAP")) cap = strtoull(e, nullptr, 10);     // tests: a small database reaches the branch
+        S.cand_cap = (uint32_t)std::min<uint64_t>(cap, 0xFFFFFFFFull);
+        S.cand_count = (b->par.nucleotide || b->par.kmer_score) ? nullptr : b->d_cand_count.as<uint32_t>();
+    }
     S.big_keys = b->big_stride ? b->d_big_keys.as<uint64_t>() : nullptr;
     S.big_diags = b->big_stride ? b->d_big_diags.as<uint16_t>() : nullptr;
     S.big_stride = b->big_stride;
@@ -1198,6 +1215,94 @@ extern "C" int mmgpu_pf_merge_exchange(mmgpu_ctx *c, mmgpu_pf_batch_t *b, const 
     A.out_flags = (uint32_t *)d_out_flags;
     HIP_TRY(launch_pf_xmerge(A, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));   // `ident` (pageable) and d_ident die with this scope
+    return MMGPU_OK;
+}
+
+// ---- the exchange step with the collectives inside the library (Prefiltering::mergeTargetSplits'
+// role, Prefiltering.cpp:412-526, but with the unsplit run's result) ----
+namespace mmgpu {
+
+// phase 1: receive buffers; the two all-gathers of the step read the batch's own result buffers (no staging copy)
+int pf_xchg_begin(mmgpu_ctx *c, mmgpu_pf_batch_t *b, int n_ranks, XchgBlock blocks[2]) {
+    if (!c || !b) return fail(MMGPU_ERR_ARG, "mmgpu_pf_exchange_merge: NULL argument");
+    if (!b->ran || !b->exchange) return fail(MMGPU_ERR_STATE, "mmgpu_pf_exchange_merge: not an exchange batch that has been run (mmgpu_pf_set_shard before mmgpu_pf_prepare)");
+    if (!c->shard.on || (int)c->shard.n_shards != n_ranks)
+        return fail(MMGPU_ERR_STATE, "mmgpu_pf_exchange_merge: the communicator's ranks and the shard description's n_shards differ");
+    if ((uint64_t)n_ranks * b->max_hits > PF_XMERGE_CAP) return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_pf_exchange_merge: more than 4096 records per query");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t hb = (size_t)b->nq * b->max_hits * sizeof(mmgpu_pf_xhit), cb = (size_t)b->nq * 4;
+    if (b->x_recv_hits.bytes != hb * n_ranks) HIP_TRY(b->x_recv_hits.alloc(hb * n_ranks));
+    if (b->x_recv_counts.bytes != cb * n_ranks) HIP_TRY(b->x_recv_counts.alloc(cb * n_ranks));
+    if (b->x_hits.bytes != (size_t)b->nq * b->max_hits * sizeof(mmgpu_pf_hit)) {
+        HIP_TRY(b->x_hits.alloc((size_t)b->nq * b->max_hits * sizeof(mmgpu_pf_hit)));
+        HIP_TRY(b->x_counts.alloc(cb));
+        HIP_TRY(b->x_flags.alloc(cb));
+        HIP_TRY(b->x_ident.alloc(cb));
+    }
+    blocks[0] = XchgBlock{b->d_hits.p, b->x_recv_hits.p, hb};
+    blocks[1] = XchgBlock{b->d_hit_count.p, b->x_recv_counts.p, cb};
+    return MMGPU_OK;
+}
+
+// phase 3: threshold, truncation and final order of the unsplit run over the union (pf_xmerge_kernel)
+int pf_xchg_merge(mmgpu_ctx *c, mmgpu_pf_batch_t *b, int n_ranks, const uint32_t *identity_global) {
+    if (b->nq == 0) { b->x_ranks = n_ranks; return MMGPU_OK; }
+    HIP_TRY(hipSetDevice(c->device));
+    // the batch's identity buffer holds the LOCAL id for the select kernel; the merge wants the global one.  The host copy
+    // lives in the batch: the asynchronous upload may read it after this call returns
+    b->x_ident_host.assign(b->nq, 0xFFFFFFFFu);
+    if (identity_global) b->x_ident_host.assign(identity_global, identity_global + b->nq);
+    HIP_TRY(hipMemcpyAsync(b->x_ident.p, b->x_ident_host.data(), (size_t)b->nq * 4, hipMemcpyHostToDevice, c->stream));
+    PfXMergeArgs A;
+    A.xhits = b->x_recv_hits.as<mmgpu_pf_xhit>();
+    A.counts = b->x_recv_counts.as<uint32_t>();
+    A.n_shards = (uint32_t)n_ranks;
+    A.nq = b->nq;
+    A.stride = b->max_hits;
+    A.max_hits = b->max_hits;
+    A.min_diag_score = b->par.min_diag_score;
+    A.ref_bins = b->ref_bins;
+    A.q_self_score = b->d_qself.as<int32_t>();
+    A.q_identity = b->x_ident.as<uint32_t>();
+    A.out_hits = b->x_hits.as<mmgpu_pf_hit>();
+    A.out_stride = b->max_hits;
+    A.out_counts = b->x_counts.as<uint32_t>();
+    A.out_flags = b->x_flags.as<uint32_t>();
+    HIP_TRY(launch_pf_xmerge(A, c->stream));
+    b->x_ranks = n_ranks;
+    return MMGPU_OK;
+}
+
+int pf_batch_merged_flags(mmgpu_pf_batch_t *b, const void **d_flags) {
+    if (!b || !b->x_ranks) return fail(MMGPU_ERR_STATE, "no merged lists in this batch");
+    *d_flags = b->x_flags.p;
+    return MMGPU_OK;
+}
+
+bool pf_batch_merged_lists(mmgpu_pf_batch_t *b, const mmgpu_pf_hit **hits, const uint32_t **counts, uint32_t *stride, uint32_t *nq) {
+    if (!b || !b->x_ranks) return false;
+    *hits = b->x_hits.as<mmgpu_pf_hit>();
+    *counts = b->x_counts.as<uint32_t>();
+    *stride = b->max_hits;
+    *nq = b->nq;
+    return true;
+}
+
+}  // namespace mmgpu
+
+extern "C" int mmgpu_pf_exchange_merge(mmgpu_ctx *c, mmgpu_pf_batch_t *b, const uint32_t *identity_global, const void **d_hits,
+                                       const void **d_counts, const void **d_flags, uint32_t *stride) {
+    if (!c || !b) return fail(MMGPU_ERR_ARG, "mmgpu_pf_exchange_merge: NULL argument");
+    const int n = c->comm ? c->comm->n_ranks : 1;
+    mmgpu::XchgBlock blk[2];
+    if (int e = mmgpu::pf_xchg_begin(c, b, n, blk)) return e;
+    for (int k = 0; k < 2; k++)
+        if (int e = mmgpu::comm_allgather(c, blk[k].send, blk[k].recv, blk[k].bytes)) return e;
+    if (int e = mmgpu::pf_xchg_merge(c, b, n, identity_global)) return e;
+    if (d_hits) *d_hits = b->x_hits.p;
+    if (d_counts) *d_counts = b->x_counts.p;
+    if (d_flags) *d_flags = b->x_flags.p;
+    if (stride) *stride = b->max_hits;
     return MMGPU_OK;
 }
 

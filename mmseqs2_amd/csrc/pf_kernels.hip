@@ -1637,7 +1637,17 @@ __global__ __launch_bounds__(256) void pf_select_kernel(PfSelectArgs A) {
     mmgpu_pf_hit *out = A.hits + (size_t)q * A.hit_stride;
 
     for (int k = (int)threadIdx.x; k < 256; k += 256) hist[k] = 0;
+    if (threadIdx.x == 0) sh_remaining = 0;
     __syncthreads();
+    if (A.cand_count != nullptr) {      // resultSize >= foundDiagonalsSize / 2 (QueryMatcher.cpp:188): not this kernel's branch
+        uint32_t loc = 0;
+        for (uint32_t k = threadIdx.x; k < A.bins; k += 256) loc += A.cand_count[(uint64_t)q * A.bins + k];
+        for (int d = 1; d < 64; d <<= 1) loc += __shfl_xor(loc, d);
+        if ((threadIdx.x & 63u) == 0 && loc) atomicAdd(&sh_remaining, loc);
+        __syncthreads();
+        if (threadIdx.x == 0 && sh_remaining >= A.cand_cap && A.q_flags) A.q_flags[q] |= 2u;
+        __syncthreads();
+    }
     for (uint32_t k = threadIdx.x; k < n; k += 256) atomicAdd(&hist[min(255u, S[k].score)], 1u);
     __syncthreads();
     if (threadIdx.x == 0) {

@@ -264,7 +264,60 @@ __global__ __launch_bounds__(256) void pf_localize_kernel(PfLocalizeArgs A) {
     if (threadIdx.x == 0) A.local_counts[q] = kept;
 }
 
+// Alignment records of the pairs this rank owns -> a dense send buffer (order is free: every record carries its slot).
+// One atomic per wavefront; records beyond the buffer are counted, not written.
+__global__ __launch_bounds__(256) void sw_owned_pack_kernel(SwOwnedPackArgs A) {
+    const uint64_t idx = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    const uint32_t q = (uint32_t)(idx / A.stride), k = (uint32_t)(idx % A.stride);
+    const bool valid = q < A.nq && k < min(A.local_counts[q < A.nq ? q : 0], A.stride);
+    const uint64_t m = __ballot(valid);
+    if (m == 0) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&A.counter[0], (uint32_t)__popcll(m));
+    base = __shfl(base, 0);
+    if (!valid) return;
+    const uint32_t p = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    if (p >= A.cap) {
+        atomicAdd(&A.counter[1], 1u);
+        return;
+    }
+    SwOwnedRec r;
+    r.hit = A.res[idx];
+    r.slot = q * A.stride + A.local_slot[idx];
+    r.pad = 0;
+    A.send[p] = r;
+}
+
+// every rank's records -> the dense array in merged-list order (each slot is owned by exactly one rank)
+__global__ __launch_bounds__(256) void sw_owned_scatter_kernel(SwOwnedScatterArgs A) {
+    const uint32_t r = blockIdx.y;
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t packed = A.counters[2 * r], lost = A.counters[2 * r + 1];
+    const uint32_t n = min(packed, A.cap);
+    if (i == 0) {
+        atomicAdd(&A.status[0], n);
+        if (lost || packed > A.cap) atomicAdd(&A.status[1], 1u);
+    }
+    if (i >= n) return;
+    const SwOwnedRec rec = A.recv[(size_t)r * A.cap + i];
+    if (rec.slot < A.n_slots) A.full[rec.slot] = rec.hit;
+}
+
 }  // namespace
+
+hipError_t launch_sw_owned_pack(const SwOwnedPackArgs &A, hipStream_t s) {
+    const uint64_t n = (uint64_t)A.nq * A.stride;
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(sw_owned_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, A);
+    return hipGetLastError();
+}
+
+hipError_t launch_sw_owned_scatter(const SwOwnedScatterArgs &A, hipStream_t s) {
+    if (A.cap == 0 || A.n_ranks == 0) return hipSuccess;
+    hipLaunchKernelGGL(sw_owned_scatter_kernel, dim3((A.cap + 255) / 256, A.n_ranks), dim3(256), 0, s, A);
+    return hipGetLastError();
+}
 
 hipError_t launch_pf_xmerge(const PfXMergeArgs &A, hipStream_t s) {
     if (A.nq == 0) return hipSuccess;

@@ -209,6 +209,7 @@ __device__ __forceinline__ void sw_body(const SwLaunch &L, const SwJob job) {
         int colsA = vA ? (int)L.t_len[tA] : 0, colsB = vB ? (int)L.t_len[tB] : 0;
         int r0A = 0, r0B = 0;       // REV: first live row of the reversed query
         int endA = 0, endB = 0;     // REV: forward t_end
+        unsigned rev_target = 0xFFFFFFFFu;
         if (REV) {
             // reverse scan over q[0..q_end] x t[0..t_end], both walked backwards (:1143-1175)
             // Lanes without a live pair must not take positions from a result slot: slot 0 may still be unwritten
@@ -225,6 +226,8 @@ __device__ __forceinline__ void sw_body(const SwLaunch &L, const SwJob job) {
             endB = colsB > 0 ? fb.t_end : 0;
             r0A = colsA > 0 ? qlen - 1 - fa.q_end : 0;
             r0B = colsB > 0 ? qlen - 1 - fb.q_end : 0;
+            // the score the reverse scan has to reach (terminate = r.score1, :1159-1175); 0xFFFF can never be reached
+            rev_target = (colsA > 0 ? (unsigned)fa.score & 0xFFFFu : 0xFFFFu) | ((colsB > 0 ? (unsigned)fb.score & 0xFFFFu : 0xFFFFu) << 16);
         }
         int ncols = colsA > colsB ? colsA : colsB;
         ncols = max(ncols, __shfl_xor(ncols, 16));
@@ -249,72 +252,79 @@ __device__ __forceinline__ void sw_body(const SwLaunch &L, const SwJob job) {
             const bool has_above = MULTI && tile > 0;
             const bool has_below = MULTI && tile + 1 < n_tiles;
 
-            unsigned Hp[R], E[R], snap[R], rmask[R];
+            // forward: snap[] = the strip's H values in the column where the running maximum last rose (q_end);
+            // reverse: rmask[] = rows of the reversed query that lie inside q[0..q_end] - the reverse scan needs no
+            // snapshot, it ends in the first column that reaches the forward score (see below), so the two bodies of a
+            // kernel need the same number of registers and the forward scan keeps its own occupancy
+            unsigned Hp[R], E[R], aux[R];
 #pragma unroll
-            for (int r = 0; r < R; ++r) { Hp[r] = 0; E[r] = 0; snap[r] = 0; }
+            for (int r = 0; r < R; ++r) { Hp[r] = 0; E[r] = 0; aux[r] = 0; }
             if (REV) {
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     const int rg = tile_base + g * R + r;
-                    rmask[r] = (rg >= r0A ? 0xFFFFu : 0u) | (rg >= r0B ? 0xFFFF0000u : 0u);
+                    aux[r] = (rg >= r0A ? 0xFFFFu : 0u) | (rg >= r0B ? 0xFFFF0000u : 0u);
                 }
             }
             unsigned vmax = 0, bestcol = 0xFFFFFFFFu;
+            unsigned rev_rowA = 0, rev_rowB = 0;   // REV: first row holding the forward score in the column that reached it
             unsigned Hup_prev = 0;
             unsigned out_H = 0, out_F = 0, out_let = pad_letter * 0x101u;
 
-            // two-deep letter prefetch for the head lane (every lane of the group loads the same byte)
-            auto letter_addr = [&](const uint8_t *p, int cols, int end, int col) -> const uint8_t * {
-                int c = col < cols ? col : cols - 1;
-                if (c < 0) c = 0;
-                return REV ? p + (end - c) : p + c;
+            unsigned la0 = 0, lb0 = 0;
+            // Four columns' letters per dword load (every lane of the group loads the same word).  Forward: targets
+            // start 4-byte aligned and the residue buffer ends with max_len + 64 bytes of slack (mmgpu_load_targets), so
+            // no clamping is needed: columns past a target's end are replaced by the padding letter below.  Reverse:
+            // column c is byte t[t_end - c], block k = the (unaligned) word at t_end - 3 - 4k read from its top byte down;
+            // words wholly before the target are clamped to offset -3 (the buffer starts with 64 bytes of padding).
+            // One v_bfe per target and column instead of an address computation and a byte load: 16-18 fewer
+            // instructions per column (R = 12: 194 -> 177).
+            auto letters4 = [&](const uint8_t *p, int end, int k) -> unsigned {
+                if (!REV) return reinterpret_cast<const unsigned *>(p)[k];
+                int o = end - 3 - 4 * k;
+                o = o < -3 ? -3 : o;
+                unsigned w;
+                __builtin_memcpy(&w, p + o, 4);
+                return w;
             };
-            unsigned la0 = 0, lb0 = 0, la1 = 0, lb1 = 0;
-            constexpr bool DW = !REV;
-            // Forward scan: four columns' letters per dword load (targets start 4-byte aligned and the residue buffer
-            // ends with max_len + 64 bytes of slack, mmgpu_load_targets, so no clamping is needed: columns past a
-            // target's end are replaced by the padding letter below).  One v_bfe per target and column instead of an
-            // address computation and a byte load: 16-18 fewer instructions per column (R = 12: 194 -> 177).
-            const unsigned *dA = reinterpret_cast<const unsigned *>(pA), *dB = reinterpret_cast<const unsigned *>(pB);
-            unsigned wA = 0, wB = 0, wA_next = 0, wB_next = 0;
-            if (!DW) {
-                la0 = *letter_addr(pA, colsA, endA, 0); lb0 = *letter_addr(pB, colsB, endB, 0);
-                la1 = *letter_addr(pA, colsA, endA, 1); lb1 = *letter_addr(pB, colsB, endB, 1);
-            } else {
-                wA = dA[0]; wB = dB[0];
-                wA_next = dA[1]; wB_next = dB[1];
-            }
-            uint2 up0 = make_uint2(0, 0), up1 = make_uint2(0, 0);
+            unsigned wA = letters4(pA, endA, 0), wB = letters4(pB, endB, 0);
+            unsigned wA_next = letters4(pA, endA, 1), wB_next = letters4(pB, endB, 1);
+            // boundary row of the tile above: column s is needed at step s; the load of column s + UPD is issued at step s
+            // (UPD columns of ~300-400 instructions each cover the L2 round trip at two waves per SIMD)
+#ifndef MMGPU_SW_UP_DEPTH
+#define MMGPU_SW_UP_DEPTH 4
+#endif
+            constexpr int UPD = MMGPU_SW_UP_DEPTH;
+            uint2 up[UPD];
+#pragma unroll
+            for (int k = 0; k < UPD; ++k) up[k] = make_uint2(0, 0);
             if (has_above) {
-                up0 = scr_in[0];
-                up1 = scr_in[min(1, ncols - 1 < 0 ? 0 : ncols - 1)];
+                const int last = ncols - 1 < 0 ? 0 : ncols - 1;
+#pragma unroll
+                for (int k = 0; k < UPD; ++k) up[k] = scr_in[min(k, last)];
             }
 
             // blocks of four columns (one dword of letters per target) where the dword path is used, else one block
-            for (int s0 = 0; s0 < nsteps; s0 = DW ? s0 + 4 : nsteps) {
-            const int jn = DW ? min(4, nsteps - s0) : nsteps;
+            for (int s0 = 0; s0 < nsteps; s0 += 4) {
+            const int jn = min(4, nsteps - s0);
 #pragma nounroll
             for (int j = 0; j < jn; ++j) {
                 const int s = s0 + j;
                 // ---- inputs of this step: from the lane above, or the tile boundary for the head lane ----
-                if (DW) {
-                    const unsigned sh = (unsigned)j * 8u;   // wave-uniform
+                {
+                    const unsigned sh = (unsigned)(REV ? 3 - j : j) * 8u;   // wave-uniform
                     la0 = __builtin_amdgcn_ubfe(wA, sh, 8u);
                     lb0 = __builtin_amdgcn_ubfe(wB, sh, 8u);
                 }
                 const unsigned head_let = (s < colsA ? la0 : pad_letter) | ((s < colsB ? lb0 : pad_letter) << 8);
-                const unsigned Hup = from_lane_above(up0.x, out_H);
-                unsigned f = from_lane_above(up0.y, out_F);
+                const unsigned Hup = from_lane_above(up[0].x, out_H);
+                unsigned f = from_lane_above(up[0].y, out_F);
                 const unsigned let = from_lane_above(head_let, out_let);
-                if (!DW) {
-                    la0 = la1; lb0 = lb1;
-                    la1 = *letter_addr(pA, colsA, endA, s + 2);
-                    lb1 = *letter_addr(pB, colsB, endB, s + 2);
-                }
                 if (has_above) {
-                    up0 = up1;
-                    int c = s + 2; if (c > ncols - 1) c = ncols - 1; if (c < 0) c = 0;
-                    up1 = scr_in[c];
+#pragma unroll
+                    for (int k = 0; k + 1 < UPD; ++k) up[k] = up[k + 1];
+                    int c = s + UPD; if (c > ncols - 1) c = ncols - 1; if (c < 0) c = 0;
+                    up[UPD - 1] = scr_in[c];
                 }
 
                 const unsigned a = let & 0xFFu, b = (let >> 8) & 0xFFu;
@@ -354,7 +364,9 @@ __device__ __forceinline__ void sw_body(const SwLaunch &L, const SwJob job) {
                 for (int r = 0; r < R; ++r) {
                     // (score of target A's letter, score of target B's letter) for query row r
                     unsigned P = __builtin_amdgcn_perm(pbv[r / 2], pav[r / 2], (r & 1) ? 0x07060302u : 0x05040100u);
-                    if (REV) P = bfi(rmask[r], P, NEG2);
+                    // v_bitop3 (a ? b : c, table 0xCA) as an intrinsic: written as and/or the compiler hoists NEG2 & ~mask
+                    // out of the column loop - R more live registers
+                    if (REV) P = __builtin_amdgcn_bitop3_b32(aux[r], P, NEG2, 0xCA);
                     pre[r] = pk_max_s(pk_add_sat(r == 0 ? hd : Hp[r - 1], P), E[r]);
                     es[r] = pk_sub_sat_u(E[r], ge2);
                 }
@@ -379,29 +391,52 @@ __device__ __forceinline__ void sw_body(const SwLaunch &L, const SwJob job) {
                 const unsigned nm = pk_max_u(vmax, cmax);
                 if (nm != vmax) {
                     const unsigned diff = nm ^ vmax;
-                    const unsigned mask = ((diff & 0xFFFFu) ? 0xFFFFu : 0u) | ((diff >> 16) ? 0xFFFF0000u : 0u);
-                    bestcol = bfi(mask, ((unsigned)col & 0xFFFFu) * 0x10001u, bestcol);
-#ifndef MMGPU_SW_EXPERIMENT_NO_SNAPSHOT      // timing experiment only (wrong q_end): upper bound of what the snapshot costs
+                    if (!REV) {
+                        const unsigned mask = ((diff & 0xFFFFu) ? 0xFFFFu : 0u) | ((diff >> 16) ? 0xFFFF0000u : 0u);
+                        bestcol = bfi(mask, ((unsigned)col & 0xFFFFu) * 0x10001u, bestcol);
 #pragma unroll
-                    for (int r = 0; r < R; ++r) snap[r] = bfi(mask, Hp[r], snap[r]);
-#endif
+                        for (int r = 0; r < R; ++r) aux[r] = bfi(mask, Hp[r], aux[r]);
+                    } else {
+                        // Reverse scan: nothing in q[0..q_end] x t[0..t_end] scores above the forward score, and the
+                        // reference stops in the first column whose maximum equals it (terminate, :232-248 / :414-425 with
+                        // :1159-1175): the column in which this strip's maximum rises TO that score is the strip's candidate,
+                        // its first row holding it the row - found once per pair, no snapshot of the strip is kept.
+                        const unsigned x = nm ^ rev_target;
+                        const bool hitA = (diff & 0xFFFFu) && !(x & 0xFFFFu), hitB = (diff >> 16) && !(x >> 16);
+                        if (hitA | hitB) {
+                            asm volatile("" ::: "memory");   // a real branch: if-converted, the row search below runs in every column
+                            unsigned ra = 0, rb = 0;
+#pragma unroll
+                            for (int r = R - 1; r >= 0; --r) {
+                                if ((Hp[r] & 0xFFFFu) == (rev_target & 0xFFFFu)) ra = (unsigned)r;
+                                if ((Hp[r] >> 16) == (rev_target >> 16)) rb = (unsigned)r;
+                            }
+                            if (hitA) { bestcol = (bestcol & 0xFFFF0000u) | ((unsigned)col & 0xFFFFu); rev_rowA = ra; }
+                            if (hitB) { bestcol = (bestcol & 0xFFFFu) | ((unsigned)col << 16); rev_rowB = rb; }
+                        }
+                    }
                     vmax = nm;
                 }
             }
-            if (DW) {   // the next four columns' letters; the load after that is in flight for four steps
+            {   // the next four columns' letters; the load after that is in flight for four steps
                 wA = wA_next; wB = wB_next;
                 const int k = (s0 >> 2) + 2;
-                wA_next = dA[k]; wB_next = dB[k];
+                wA_next = letters4(pA, endA, k); wB_next = letters4(pB, endB, k);
             }
             }
 
             // ---- fold this tile's lanes into the pair's running best (tie rules in the key order) ----
-            unsigned rowA_first = 0, rowB_first = 0;
-            const unsigned sA = vmax & 0xFFFFu, sB = vmax >> 16;
+            unsigned rowA_first = rev_rowA, rowB_first = rev_rowB;
+            unsigned sA = vmax & 0xFFFFu, sB = vmax >> 16;
+            if (!REV) {
 #pragma unroll
-            for (int r = R - 1; r >= 0; --r) {
-                if ((snap[r] & 0xFFFFu) == sA) rowA_first = (unsigned)r;
-                if ((snap[r] >> 16) == sB) rowB_first = (unsigned)r;
+                for (int r = R - 1; r >= 0; --r) {
+                    if ((aux[r] & 0xFFFFu) == sA) rowA_first = (unsigned)r;
+                    if ((aux[r] >> 16) == sB) rowB_first = (unsigned)r;
+                }
+            } else {   // a strip that never reached the forward score has no candidate
+                sA = sA == (rev_target & 0xFFFFu) ? sA : 0u;
+                sB = sB == (rev_target >> 16) ? sB : 0u;
             }
             const unsigned rgA = (unsigned)(tile_base + g * R) + rowA_first;
             const unsigned rgB = (unsigned)(tile_base + g * R) + rowB_first;
@@ -443,8 +478,9 @@ __device__ __forceinline__ void sw_body(const SwLaunch &L, const SwJob job) {
                     const int cols = half ? colsB : colsA;
                     if (cols > 0) {
                         // column index counts backwards from t_end; row is an index into the reversed query
-                        o->t_start = (score == o->score) ? end - col : -2;   // -2: forward/backward mismatch (:1191)
-                        o->q_start = qlen - 1 - row;
+                        // score 0: no strip reached the forward score - "Score of forward/backward SW differ" (:1191-1201)
+                        o->t_start = (score == o->score) ? end - col : -2;
+                        o->q_start = (score == o->score) ? qlen - 1 - row : -2;
                     }
                 }
             }
@@ -474,8 +510,25 @@ __device__ __forceinline__ void sw_passes(const SwLaunch &L, const SwJob &job) {
     }
 }
 
+// occupancy floor (waves per SIMD; 512 registers per lane and SIMD) per group and kernel kind: what the compiler is told to
+// fit.  Measured on the 10k x 1M lists (profiles/r03_exp_sw_occupancy_floors.txt): the floor changes the schedule even
+// where the register count already fits.
+#ifndef MMGPU_SW_WAVES_G0F
+#define MMGPU_SW_WAVES_G0F 4
+#endif
+#ifndef MMGPU_SW_WAVES_G0B
+#define MMGPU_SW_WAVES_G0B 2
+#endif
+#ifndef MMGPU_SW_WAVES_G1F
+#define MMGPU_SW_WAVES_G1F 3
+#endif
+#ifndef MMGPU_SW_WAVES_G1B
+#define MMGPU_SW_WAVES_G1B 2
+#endif
 template <int G, bool BOTH>
-__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(SW_MIN_WAVES))) void sw_kernel(SwLaunch L) {
+__global__ __launch_bounds__(WAVES * 64)
+__attribute__((amdgpu_waves_per_eu(G == 0 ? (BOTH ? MMGPU_SW_WAVES_G0B : MMGPU_SW_WAVES_G0F)
+                                           : (G == 1 ? (BOTH ? MMGPU_SW_WAVES_G1B : MMGPU_SW_WAVES_G1F) : SW_MIN_WAVES)))) void sw_kernel(SwLaunch L) {
     SwJob job = L.jobs[blockIdx.x];
     if (L.q_hit_count) {   // fused prefilter -> align hand-over: the list length of the query is only known on the device
         const uint32_t lim = job.query * L.hit_stride + L.q_hit_count[job.query];

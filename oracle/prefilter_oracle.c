@@ -919,7 +919,9 @@ static int match_query_impl(const mmo_pf_params *P, const uint8_t *q, int qlen, 
         unsigned diag_thr = (unsigned)thr > P->min_diag_score ? (unsigned)thr : P->min_diag_score;
         S.diag_thr = diag_thr;
         size_t cur = 0;
-        /* rs < foundDiagonalsSize/2 always holds on the non-overflow path we restate (:188) */
+        /* Restated: the sorted branch, rs < foundDiagonalsSize/2 (:188-203).  A query that leaves max(1M, dbSize)/2 elements or more
+         * takes :204-214 (filter, unstable std::sort, no rescoring) in the reference - not restated here; S.after_keepmax tells a
+         * caller which branch the reference would take, and the device hands such queries to the host (MMGPU_PF_SAT_TIE). */
         const unsigned max_diag_thr = 255; /* UCHAR_MAX - getQueryBias() (=0) */
         int truncated = diag_thr >= max_diag_thr;
         S.truncated = truncated;

@@ -404,3 +404,29 @@ def test_stage_chunks_give_the_same_lists(gpu, monkeypatch):
     monkeypatch.delenv("MMGPU_PF_STAGE_GB", raising=False)
     orc.build_index(g["tres"], g["toff"], thr)
     chk.load_case(gpu, g, g["tres"], g["toff"], thr)
+
+
+def test_candidate_sets_of_half_the_diagonal_array_go_to_the_host(gpu, golden_case, monkeypatch):
+    """QueryMatcher.cpp:188,204-214: when keepMaxScoreElementOnly leaves foundDiagonalsSize / 2 = max(1M, dbSize) / 2 elements
+    or more, the reference filters and sorts with an unstable std::sort instead of the radix pass, without rescoring - a branch
+    the device does not restate.  The double-diagonal candidate total bounds that size from above; queries that reach the
+    limit come back MMGPU_PF_SAT_TIE (the host runs matchQuery for them), the others are untouched.  The limit is lowered to
+    the median candidate count of the golden queries (MMGPU_PF_SORT_CAP) so that a small database reaches the branch."""
+    g, orc = golden_case
+    qs = pc.golden_queries(g)
+    thr = int(g["kmer_thr"])
+    monkeypatch.delenv("MMGPU_PF_SORT_CAP", raising=False)
+    h0, c0, s0, _ = gpu.pf_batch(qs, thr, max_hits=300, min_diag_score=15, ref_bins=2)
+    assert int((s0 != 0).sum()) == 0
+    cands = np.array([orc.match(q["q"], q.get("comp_bias"), 2, max_hits=300, min_diag_score=15,
+                                identity_id=q.get("identity_id"))["stats"]["double_hits"] for q in qs], np.int64)
+    cap = int(np.median(cands))
+    assert cands.min() < cap <= cands.max()
+    monkeypatch.setenv("MMGPU_PF_SORT_CAP", str(cap))
+    h1, c1, s1, _ = gpu.pf_batch(qs, thr, max_hits=300, min_diag_score=15, ref_bins=2)
+    monkeypatch.delenv("MMGPU_PF_SORT_CAP", raising=False)
+    for qi in range(len(qs)):
+        if cands[qi] >= cap:
+            assert s1[qi] == 3 and c1[qi] == 0, (qi, int(cands[qi]), cap)      # MMGPU_PF_SAT_TIE
+        else:
+            assert s1[qi] == 0 and c1[qi] == c0[qi] and np.array_equal(h1[qi][:c1[qi]], h0[qi][:c0[qi]]), qi

@@ -217,3 +217,110 @@ def test_alignment_of_owned_pairs_equals_unsplit(gpu, matrices):
         for f in ("score", "q_end", "t_end", "q_start", "t_start", "word"):
             assert np.array_equal(got[i, :n][f], exp[off:off + n][f]), (i, f)
         off += n
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the collectives inside the library (mmgpu_init_multi / mmgpu_pf_exchange_merge / mmgpu_sw_gather_owned)
+def _sw_queries(g, matrices, qs, lib):
+    sub16 = matrices["blosum62_sw"].astype(np.int16)
+    return [dict(q=q, comp_bias=capi.host_comp_bias(sub16, matrices["blosum62_pback"], q, lib=lib)[1], min_start_score=1) for q in qs]
+
+
+@pytest.mark.parametrize("world,max_hits", [(3, 40), (4, 300)])
+def test_multi_context_run_equals_unsplit_run(gpu, matrices, world, max_hits):
+    """mmgpu_init_multi with `world` contexts on the one GPU of the box (copy transport: RCCL refuses two ranks on one
+    device): the database dealt by length bucket, every shard's index built on the device, ONE mmgpu_multi_pf_run (shard
+    prefilters -> all-gather -> merge kernel on every context) and ONE mmgpu_multi_sw_from_pf (owned pairs -> gather).
+    Merged lists and alignment records must equal the unsplit fused run of the single context, bit for bit."""
+    g = pc.golden()
+    thr = int(g["kmer_thr"])
+    qs, tres, toff = _case(77 + world, 150, 60, 40)
+    km16, um8, s3, i3 = _tables(gpu, g)
+    ident = np.full(len(qs), 0xFFFFFFFF, np.uint32)
+    ident[::5] = (np.arange(len(qs))[::5] * 97) % (len(toff) - 1)
+    queries = [dict(q=q, comp_bias=capi.host_comp_bias(km16, g["vtml80_pback"], q, lib=gpu.L)[0],
+                    identity_id=None if ident[i] == 0xFFFFFFFF else int(ident[i])) for i, q in enumerate(qs)]
+    swq = _sw_queries(g, matrices, qs, gpu.L)
+    mat = matrices["blosum62_sw"]
+    # unsplit: prefilter + fused alignment on the single context
+    gpu.load_targets(tres, toff, 21)
+    gpu.pf_build_index(6, 21, True, s3, i3, km16, thr, um8)
+    b = gpu.pf_prepare(queries, thr, max_hits=max_hits, ref_bins=2)
+    b.run()
+    fb = gpu.sw_prepare_from_pf(mat, 11, 1, swq, b, mode=1)
+    fb.run()
+    res_u = fb.fetch().reshape(len(qs), b.max_hits)
+    hits_u, counts_u, status_u, _ = b.fetch()
+    cells_u = fb.cells
+    fb.free()
+    b.free()
+    assert np.all(status_u == 0)
+    m = capi.MMGpuMulti([0] * world)
+    try:
+        assert m.transport() == "copy"
+        m.load_targets(tres, toff, 21)
+        m.pf_build_index(6, 21, True, s3, i3, km16, thr, um8)
+        mb = m.pf_prepare(queries, thr, max_hits=max_hits, ref_bins=2)
+        for _ in range(2):          # a second run re-uses every buffer of the step
+            m.pf_run(mb)
+        hits_s, counts_s, status_s = m.pf_fetch(mb, len(qs))
+        res_s, cells_s, ms = m.sw_from_pf(mat, 11, 1, swq, mb, len(qs), mode=1)
+        m.pf_free(mb)
+    finally:
+        m.close()
+    assert np.all(status_s == 0)
+    assert np.array_equal(counts_s, counts_u)
+    assert cells_s == cells_u and ms > 0
+    for qi in range(len(qs)):
+        n = int(counts_u[qi])
+        for f in ("id", "score", "diagonal"):
+            assert np.array_equal(hits_s[qi][f][:n], hits_u[qi][f][:n]), (qi, f)
+        for f in ("score", "q_end", "t_end", "q_start", "t_start", "word"):
+            assert np.array_equal(res_s[qi][f][:n], res_u[qi][f][:n]), (qi, f)
+        assert not res_s[qi]["score"][n:].any()
+
+
+def test_library_communicator_single_rank_rccl(gpu, matrices, monkeypatch):
+    """The RCCL transport itself, as far as a 1-GPU box can run it: mmgpu_comm_unique_id + mmgpu_comm_init_rank with one
+    rank, the exchange step's all-gathers as real ncclAllGather calls on the context's stream (MMGPU_COMM_SELF_RCCL),
+    merged lists and gathered alignment records = the unsplit run."""
+    g = pc.golden()
+    thr = int(g["kmer_thr"])
+    qs, tres, toff = _case(5, 100, 40, 24)
+    km16, um8, s3, i3 = _tables(gpu, g)
+    queries = [dict(q=q, comp_bias=capi.host_comp_bias(km16, g["vtml80_pback"], q, lib=gpu.L)[0], identity_id=None) for q in qs]
+    swq = _sw_queries(g, matrices, qs, gpu.L)
+    mat = matrices["blosum62_sw"]
+    hits_u, counts_u, status_u, _ = _unsplit(gpu, g, tres, toff, queries, thr, 300, 2)
+    g2 = capi.MMGpu(0)
+    try:
+        g2.comm_init_rank(g2.comm_unique_id(), 0, 1)
+        assert g2.comm_info() == (0, 1, "rccl")
+        monkeypatch.setenv("MMGPU_COMM_SELF_RCCL", "1")
+        D.setup_shard(g2, 0, 1, tres, toff)
+        g2.pf_build_index(6, 21, True, s3, i3, km16, thr, um8)
+        b = g2.pf_prepare(queries, thr, max_hits=300, ref_bins=2)
+        b.run()
+        dh, dc, df, stride = b.exchange_merge()
+        sb = g2.sw_prepare_owned(mat, 11, 1, swq, b, mode=1)
+        sb.run()
+        sb.gather_owned()
+        res, nrec = sb.fetch_owned()
+        nq = len(qs)
+        hits = np.zeros((nq, stride), capi.PF_HIT_DTYPE)
+        counts = np.zeros(nq, np.uint32)
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        assert hip.hipMemcpy(hits.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(dh), hits.nbytes, 2) == 0
+        assert hip.hipMemcpy(counts.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(dc), counts.nbytes, 2) == 0
+        sb.free()
+        b.free()
+    finally:
+        g2.close()
+    assert np.array_equal(counts, counts_u) and nrec == int(counts_u.sum())
+    res = res.reshape(nq, stride)
+    for qi in range(nq):
+        n = int(counts_u[qi])
+        for f in ("id", "score", "diagonal"):
+            assert np.array_equal(hits[qi][f][:n], hits_u[qi][f][:n]), (qi, f)
+        assert np.all(res[qi]["score"][:n] > 0)
