@@ -462,7 +462,10 @@ static int sw_prepare_impl(mmgpu_ctx *c, const mmgpu_sw_params *par, const mmgpu
             // mostly about as long as the query; the database mean otherwise)
             const uint64_t est_cells = (uint64_t)Q.qlen * ((Q.qlen + c->mean_len) / 2 + 1) * round;
             const uint32_t per_job = job_slots(round, JOB_CELLS / est_cells);
-            for (uint32_t k = 0; k < pf_stride; k += per_job) {
+            // timing aid (results incomplete): MMGPU_SW_DEBUG_SKIP=multi | single2 | revmulti leaves a class of jobs out
+            static const char *dbg_skip = getenv("MMGPU_SW_DEBUG_SKIP");
+            const bool skip_fwd = dbg_skip && ((multi && strstr(dbg_skip, "multi") == dbg_skip) || (!multi && grp == 2 && strstr(dbg_skip, "single2")));
+            for (uint32_t k = 0; k < pf_stride && !skip_fwd; k += per_job) {
                 SwJob j;
                 j.query = i;
                 j.hit_begin = hit_cursor + k;
@@ -473,7 +476,8 @@ static int sw_prepare_impl(mmgpu_ctx *c, const mmgpu_sw_params *par, const mmgpu
                 // target length on the device, so among equals a query's earlier jobs hold the longer targets
                 job_cells.push_back((uint64_t)Q.qlen * (j.hit_end - j.hit_begin) * 4096u + (pf_stride - k));
             }
-            if (multi && mode >= MMGPU_SW_START) add_rev_jobs(i, hit_cursor, pf_stride, shape, (uint64_t)Q.qlen * ((Q.qlen + c->mean_len) / 2 + 1));
+            if (multi && mode >= MMGPU_SW_START && !(dbg_skip && (strstr(dbg_skip, "revmulti") || skip_fwd)))
+                add_rev_jobs(i, hit_cursor, pf_stride, shape, (uint64_t)Q.qlen * ((Q.qlen + c->mean_len) / 2 + 1));
             max_tlen = c->db.max_len;
             hit_cursor += pf_stride;
             out_cursor += pf_stride;

@@ -21,6 +21,10 @@ import sys
 
 def main():
     ref, out = sys.argv[1], sys.argv[2]
+    # --skip a,b,c : functions defined elsewhere (oracle/ref_block_capi.cpp over the restated block aligner)
+    skip = set()
+    if "--skip" in sys.argv:
+        skip = set(sys.argv[sys.argv.index("--skip") + 1].split(","))
     hdr = ref + "/lib/block-aligner/c/block_aligner.h"
     h = open(hdr).read()
     h2 = re.sub(r"/\*.*?\*/", "", h, flags=re.S)
@@ -30,6 +34,8 @@ def main():
     n = 0
     for full, name, _args in protos:
         if not (name.startswith("block_") or name.startswith("_block") or name.startswith("aaprofile")):
+            continue
+        if name in skip:
             continue
         ret = full[: full.index(name)].strip()
         if ret == "void":

@@ -17,6 +17,8 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_SO = os.path.join(HERE, "_build", "libmmoracle.so")
 REF_SO = os.path.join(HERE, "_ref", "libmmref.so")
+# the same reference with its block-aligner branch alive (the restated block aligner behind the crate's C API, oracle/Makefile refblock)
+REF_BLOCK_SO = os.path.join(HERE, "_ref", "libmmref_block.so")
 REFERENCE_ROOT = "/root/reference"
 
 c_p = ctypes.c_void_p
@@ -82,6 +84,56 @@ class Oracle:
         return dict(score=r.score, q_start=r.q_start, q_end=r.q_end, t_start=r.t_start, t_end=r.t_end,
                     word=r.word, ident=r.ident, bt=bt.value.decode() if r.bt_len else "")
 
+    def block_backtrace(self, q, cb, t, mat, go, ge, score, q_end, t_end):
+        """alignStartPosBacktraceBlock<SEQ_SEQ> (block_oracle.c: the restated block aligner).  -> dict(ok, q_start, t_start,
+        ident, bt, block_size) ; ok False = "Block alignment failed" (the reference then falls back to its SW traceback)."""
+        q = np.ascontiguousarray(q, np.uint8)
+        t = np.ascontiguousarray(t, np.uint8)
+        mat = np.ascontiguousarray(mat, np.int8)
+        cbp = None if cb is None else np.ascontiguousarray(cb, np.int8)
+        cap = int(q_end) + int(t_end) + 16
+        bt = ctypes.create_string_buffer(cap)
+        qs, ts, bl, bs = ctypes.c_int(-1), ctypes.c_int(-1), ctypes.c_int(0), ctypes.c_int(0)
+        ident = ctypes.c_uint32(0)
+        f = self.L.mmo_sw_block_backtrace
+        f.argtypes = [c_p, c_p, ctypes.c_int, c_p, ctypes.c_int, c_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                      ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint32),
+                      ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+        ok = f(_ptr(q), _ptr(cbp), len(q), _ptr(t), len(t), _ptr(mat), mat.shape[0], go, ge, int(score), int(q_end), int(t_end),
+               ctypes.byref(qs), ctypes.byref(ts), ctypes.byref(ident), bt, cap, ctypes.byref(bl), ctypes.byref(bs))
+        return dict(ok=bool(ok), q_start=qs.value, t_start=ts.value, ident=ident.value, bt=bt.raw[:bl.value].decode() if ok else "",
+                    block_size=bs.value)
+
+    def block_align(self, q, r, mat, gap_open, gap_extend, min_size, max_size, x_drop, qbias=None, rbias=None):
+        """one Block<true, true>::align_aa call: -> (score, query_idx, reference_idx, ops origin -> end as a string of M / I / D)"""
+        q = np.ascontiguousarray(q, np.uint8)
+        r = np.ascontiguousarray(r, np.uint8)
+        mat = np.ascontiguousarray(mat, np.int8)
+        qb = None if qbias is None else np.ascontiguousarray(qbias, np.int16)
+        rb = None if rbias is None else np.ascontiguousarray(rbias, np.int16)
+
+        class Res(ctypes.Structure):
+            _fields_ = [("score", ctypes.c_int32), ("qi", ctypes.c_uint32), ("ri", ctypes.c_uint32)]
+        res = Res()
+        ops = np.zeros(len(q) + len(r) + 8, np.uint8)
+        n = ctypes.c_uint32()
+        f = self.L.mmo_block_align
+        f.argtypes = [c_p, c_p, ctypes.c_int, c_p, c_p, ctypes.c_int, c_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                      ctypes.c_int, ctypes.POINTER(Res), c_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32)]
+        rc = f(_ptr(q), _ptr(qb), len(q), _ptr(r), _ptr(rb), len(r), _ptr(mat), mat.shape[0], gap_open, gap_extend, min_size, max_size, x_drop,
+               ctypes.byref(res), _ptr(ops), len(ops), ctypes.byref(n))
+        if rc != 0:
+            raise RuntimeError("mmo_block_align rc=%d" % rc)
+        letters = {1: "M", 4: "I", 5: "D"}
+        return res.score, res.qi, res.ri, "".join(letters[int(x)] for x in ops[:n.value][::-1])
+
+    def block_prefix_scan(self, v, gap):
+        v = np.ascontiguousarray(v, np.int16)
+        out = np.zeros(16, np.int16)
+        self.L.mmo_block_prefix_scan.argtypes = [c_p, ctypes.c_int, c_p]
+        self.L.mmo_block_prefix_scan(_ptr(v), int(gap), _ptr(out))
+        return out
+
     def sw_align_profile(self, profile, cons, t, alphabet, go, ge, need_start=False, need_bt=False):
         """profile: int8 [letters][qlen] (Sequence::getAlignmentProfile), cons: consensus sequence (numSequence)."""
         profile = np.ascontiguousarray(profile, np.int8)
@@ -139,10 +191,10 @@ class RefLib:
     """The real reference (needs /root/reference/data/*.out at run time for the matrices)."""
 
     def __init__(self, matrix="blosum62.out", bit_factor=2.0, score_bias=0.0, max_len=70000, gap_open=11,
-                 gap_extend=1, comp_bias=True, db_residues=1000000, serialized=None):
+                 gap_extend=1, comp_bias=True, db_residues=1000000, serialized=None, lib_path=None):
         """matrix: file name under /root/reference/data, or - where that tree is absent (GPU box) -
         `serialized` = the "name.out:DATA" bytes stored in tests/golden/matrices.npz."""
-        L = self.L = ctypes.CDLL(REF_SO)
+        L = self.L = ctypes.CDLL(lib_path or REF_SO)
         L.mmref_new.restype = c_p
         L.mmref_new.argtypes = [ctypes.c_char_p, ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.c_int,
                                 ctypes.c_int, ctypes.c_int, ctypes.c_uint64]

@@ -1,0 +1,137 @@
+"""The block aligner restatement (oracle/block_oracle.c; SURVEY.md section 8 row a15: start position + CIGAR of int16-range hits,
+StripedSmithWaterman.cpp:943-1127 -> lib/block-aligner 0.4.0, AVX2 configuration).
+
+PARITY STATUS: the Rust crate cannot be built in this image, so the restatement is NOT pinned against the Rust-linked
+binary here.  What these tests pin:
+  * the crate's own unit-test vectors that apply to the configuration the reference uses (avx2.rs test_prefix_scan;
+    scan_block.rs test_x_drop, test_trace case 1);
+  * the invariants the reference relies on: a block alignment is only accepted when its score equals the striped SW score
+    (:1058) - the restatement reaches it on every int16-range pair tried, its CIGAR re-scores to exactly that score and ends
+    at (q_end, t_end);
+  * the glue (reversed prefixes, bias hand-over, run order of the cigar, identity count, start positions): the REAL
+    alignStartPosBacktraceBlock code of the reference, compiled here, running over the crate's C API implemented on the
+    restatement (oracle/_ref/libmmref_block.so) must return what the restatement's own wrapper returns;
+  * tests/golden/block_vectors.npz, if a Rust-equipped box has recorded it (scripts/make_block_goldens.sh): exact equality."""
+import os
+
+import numpy as np
+import pytest
+
+from mmseqs2_amd import workloads as wl
+from oracle import pyoracle as po
+from tests.rescore import rescore
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden", "block_vectors.npz")
+
+
+@pytest.fixture(scope="module")
+def orc():
+    return po.Oracle()
+
+
+def _ar_matrix():
+    """BLOSUM62 entries of the letters the crate's tests use, at the crate's codes (letter - 'A'): A = 0, R = 17"""
+    m = np.full((26, 26), -4, np.int8)
+    m[0, 0], m[0, 17], m[17, 0], m[17, 17] = 4, -1, -1, 5
+    return m
+
+
+def _codes(s):
+    return np.frombuffer(s.encode(), np.uint8) - ord("A")
+
+
+def test_crate_prefix_scan_vectors(orc):
+    """avx2.rs: test_prefix_scan"""
+    v = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 15, 12, 13, 14, 11]
+    assert orc.block_prefix_scan(v, 0).tolist() == [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 15, 15, 15, 15, 15]
+    assert orc.block_prefix_scan(v, -1).tolist() == [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 15, 14, 13, 14, 13]
+
+
+def test_crate_x_drop_vectors(orc):
+    """scan_block.rs: test_x_drop (Block<_, true>::align with BLOSUM62, gaps -11 / -1) and test_trace's first case"""
+    m = _ar_matrix()
+    assert orc.block_align(_codes("AAAAAA"), _codes("AAARRA"), m, -11, -1, 16, 16, 1)[:3] == (14, 6, 6)
+    assert orc.block_align(_codes("A" * 44), _codes("A" * 15 + "R" * 16 + "A" * 13), m, -11, -1, 16, 16, 1)[:3] == (60, 15, 15)
+    assert orc.block_align(_codes("A" * 2048), _codes("A" * 2048), m, -11, -1, 2048, 2048, 100)[:3] == (8192, 2048, 2048)
+    s, qi, ri, ops = orc.block_align(_codes("AAAAAA"), _codes("AAARRA"), m, -11, -1, 16, 16, 100)
+    assert (s, qi, ri, ops) == (14, 6, 6, "MMMMMM")       # "3=2X1=" with = / X folded into M
+
+
+def _family_pairs(seed, n_fam, members, per_query):
+    (qres, qoff), (tres, toff), fam_t, fam_q = wl.config3_prefilter(n_fam, members, n_fam, seed=seed)
+    qs, ts = wl.split(qres, qoff), wl.split(tres, toff)
+    for qi, q in enumerate(qs):
+        for ti in np.nonzero(fam_t == fam_q[qi])[0][:per_query]:
+            yield q, ts[ti]
+
+
+def test_block_alignment_reaches_and_rescores_to_the_sw_score(orc, matrices):
+    mat = matrices["blosum62_sw"]
+    sub16 = mat.astype(np.int16)
+    n = w1 = differs = 0
+    for q, t in _family_pairs(9, 220, 6, 3):
+        cb = orc.round_comp_bias(orc.comp_bias(sub16, matrices["blosum62_pback"], q, 1.0))
+        r = orc.sw_align(q, cb, t, mat, 11, 1, need_start=True, need_bt=True)
+        if r["score"] < 40:
+            continue
+        b = orc.block_backtrace(q, cb, t, mat, 11, 1, r["score"], r["q_end"], r["t_end"])
+        assert b["ok"], "block alignment did not reach the SW score"
+        sc, qe, te = rescore(q, cb, t, mat, 11, 1, b["q_start"], b["t_start"], b["bt"])
+        assert (sc, qe, te) == (r["score"], r["q_end"], r["t_end"])
+        assert b["bt"][0] == "M" and b["bt"][-1] == "M" and b["q_start"] >= 0 and b["t_start"] >= 0
+        qp, tp, ids = b["q_start"], b["t_start"], 0
+        for c in b["bt"]:
+            if c == "M":
+                ids += int(q[qp] == t[tp])
+            qp += c != "D"
+            tp += c != "I"
+        assert ids == b["ident"]
+        n += 1
+        w1 += r["word"]
+        differs += b["bt"] != r["bt"]
+    assert n > 400 and w1 > 200
+    # the block aligner's path is NOT always the banded traceback's: that is why a15 is a row of its own
+    assert differs > 0
+
+
+@pytest.mark.skipif(not (os.path.exists(po.REF_BLOCK_SO) and po.ref_matrix_available()), reason="needs oracle/_ref/libmmref_block.so (make -C oracle refblock)")
+def test_reference_glue_over_the_c_api_equals_the_restated_wrapper(orc, matrices):
+    mat = matrices["blosum62_sw"]
+    sub16 = mat.astype(np.int16)
+    ref = po.RefLib(db_residues=300000000, lib_path=po.REF_BLOCK_SO)
+    n = 0
+    last_q = None
+    for q, t in _family_pairs(21, 150, 6, 3):
+        if last_q is not q:
+            ref.sw_set_query(q)
+            cb = orc.round_comp_bias(orc.comp_bias(sub16, matrices["blosum62_pback"], q, 1.0))
+            last_q = q
+        r = ref.sw_align(t, mode=2, evalue_thr=1e300)
+        if r["word"] != 1:
+            continue
+        b = orc.block_backtrace(q, cb, t, mat, 11, 1, r["score"], r["q_end"], r["t_end"])
+        assert b["ok"]
+        assert (b["q_start"], b["t_start"], b["ident"], b["bt"]) == (r["q_start"], r["t_start"], r["ident"], r["bt"])
+        n += 1
+    assert n > 150
+
+
+def test_recorded_rust_vectors(orc, matrices):
+    if not os.path.exists(GOLDEN):
+        pytest.skip("PARITY UNPINNED: tests/golden/block_vectors.npz is absent - no Rust toolchain in this image; a Rust-equipped box "
+                    "records it with scripts/make_block_goldens.sh (lib/block-aligner 0.4.0, --features simd_avx2)")
+    g = np.load(GOLDEN)
+    mat = g["matrix"]
+    for k in range(len(g["score"])):
+        q = g["q_res"][g["q_off"][k]:g["q_off"][k + 1]]
+        t = g["t_res"][g["t_off"][k]:g["t_off"][k + 1]]
+        cb = g["q_cb"][g["q_off"][k]:g["q_off"][k + 1]]
+        b = orc.block_backtrace(q, cb, t, mat, 11, 1, int(g["score"][k]), int(g["q_end"][k]), int(g["t_end"][k]))
+        bt = bytes(g["bt"][g["bt_off"][k]:g["bt_off"][k + 1]]).decode()
+        want = (int(g["q_start"][k]), int(g["t_start"][k]), int(g["ident"][k]), bt)
+        if b["ok"]:
+            assert (b["q_start"], b["t_start"], b["ident"], b["bt"]) == want, k
+        else:       # "Block alignment failed": the recorded result must then be the reference's Smith-Waterman fallback (:873-882)
+            sw = orc.sw_align(q, cb, t, mat, 11, 1, need_start=True, need_bt=True)
+            assert (sw["q_start"], sw["t_start"], sw["ident"], sw["bt"]) == want, k
