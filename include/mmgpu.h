@@ -194,6 +194,33 @@ typedef struct {
 int mmgpu_sw_traceback(mmgpu_ctx *ctx, mmgpu_sw_batch_t *batch, const uint32_t *pair_index, uint32_t n_pairs,
                        mmgpu_sw_bt *info, char *bt, size_t bt_cap, size_t *bt_used);
 
+/* Int16-range hits (mmgpu_sw_hit::word == 1) whose start position the reference takes from the block aligner, not from the
+ * reverse scan: SmithWaterman::alignStartPosBacktraceBlock<SEQ_SEQ> (StripedSmithWaterman.cpp:943-1127 -> lib/block-aligner
+ * 0.4.0, AVX2 configuration) on the device (block_kernel.hip), for sequence queries.  One call serves what the reference gets
+ * from one block-aligner run: start positions (modes >= 1), identities and the backtrace string (mode 3 / -a).
+ * Restated from the crate's source; this image has no Rust toolchain, so equality with a Rust-linked build is pinned only as
+ * far as tests/test_block_oracle.py goes (the crate's own test vectors, the invariants the reference checks, the recorded
+ * vectors of scripts/make_block_goldens.sh once a Rust-equipped box has produced them). */
+typedef struct {
+    int32_t q_start, t_start;   /* qStartPos1 / dbStartPos1 (:1111-1112) */
+    uint32_t ident;             /* identicalAACnt */
+    uint32_t bt_len;
+    uint64_t bt_off;            /* the pair's backtrace in the caller's bt buffer ('M', 'I', 'D'; forward order) */
+    int32_t status;
+    int32_t reserved;
+} mmgpu_sw_block;
+#define MMGPU_BLOCK_OK 0
+#define MMGPU_BLOCK_DECLINED 1   /* "Block alignment failed" (:1058,873-882): the block aligner's score differs from the pair's -
+                                    the reference falls back to the reverse scan + banded traceback (q_start / t_start of
+                                    mmgpu_sw_fetch, mmgpu_sw_traceback) */
+#define MMGPU_BLOCK_TOO_LARGE 2  /* the crate would grow its block beyond 512 rows, or the pair exceeds the scratch slot: not
+                                    decided on the device, the host runs its own alignStartPosBacktraceBlock */
+#define MMGPU_BLOCK_NOT_WORD 3   /* not an int16-range hit of a sequence query with a positive score */
+/* pair_index as for mmgpu_sw_traceback (any mode: only score / q_end / t_end of the forward scan are read); every pair reserves
+ * (q_end + 1) + (t_end + 1) + 1 bytes of bt. */
+int mmgpu_sw_block_backtrace(mmgpu_ctx *ctx, mmgpu_sw_batch_t *batch, const uint32_t *pair_index, uint32_t n_pairs,
+                             mmgpu_sw_block *out, char *bt, size_t bt_cap, size_t *bt_used);
+
 /* ---- nucleotide alignment step (behind Alignment::run for nucleotide databases) --------------------------------
  * BandedNucleotideAligner::align (src/alignment/BandedNucleotideAligner.cpp:76-263; Matcher::getSWResult calls it
  * instead of the Smith-Waterman for DBTYPE_NUCLEOTIDES, Matcher.cpp:76-79): ungapped seed on the prefilter diagonal,

@@ -184,6 +184,7 @@ bool MMGpuAlignRun::run(Alignment &al, const std::string &outDB, const std::stri
     gpuMatcher.setThreads(threads);
     gpuMatcher.setCorrelationScoreWeight(al.correlationScoreWeight);
     if (MMGpuRun::hostBlockAligner()) gpuMatcher.setBlockBacktracer(&blockHook, lookupTarget, &store);
+    gpuMatcher.setDeviceBlockAligner(MMGpuRun::deviceBlockAligner());
     std::vector<Matcher *> cpuMatchers(threads, NULL);      // only for pairs whose backtrace the device declines
     // --realign (:298-305,408-437): the accepted hits of a query are aligned a second time with the (biased) realign matrix
     // for their boundaries and backtraces; scores and E-values stay the first pass's
@@ -193,6 +194,7 @@ bool MMGpuAlignRun::run(Alignment &al, const std::string &outDB, const std::stri
                                          al.gapExtend, al.querySeqType);
     gpuRealigner.setThreads(threads);
     if (MMGpuRun::hostBlockAligner()) gpuRealigner.setBlockBacktracer(&realignBlockHook, lookupTarget, &store);
+    gpuRealigner.setDeviceBlockAligner(MMGpuRun::deviceBlockAligner());
     std::vector<Matcher *> cpuRealigners(threads, NULL);      // refused pairs of the realignment, --alt-ali after --realign
     std::vector<std::vector<Matcher::result_t> > accepted, realigned;
     std::vector<MMGpuMatcher::Query> block2, block3;

@@ -30,6 +30,13 @@ public:
         strings.assign((size_t)need, '\0');
         return mmgpu_sw_traceback(gpu, batch, pairIndex, n, info, &strings[0], need, &need);
     }
+    int blockBacktrace(const uint32_t *pairIndex, uint32_t n, mmgpu_sw_block *out, std::string &strings) {
+        size_t need = 0;
+        int rc = mmgpu_sw_block_backtrace(gpu, batch, pairIndex, n, out, NULL, 0, &need);
+        if (rc != 0 && need == 0) return rc;
+        strings.assign((size_t)need, '\0');
+        return mmgpu_sw_block_backtrace(gpu, batch, pairIndex, n, out, need ? &strings[0] : NULL, need, &need);
+    }
     const char *lastError() { return mmgpu_last_error(); }
 
 private:

@@ -18,7 +18,7 @@
 MMGpuMatcher::MMGpuMatcher(MMGpuAlignBackend *backend, BaseMatrix *m, EvalueComputation *evaluer, bool aaBiasCorrection,
                            float aaBiasCorrectionScale, int gapOpen, int gapExtend)
     : backend(backend), m(m), evaluer(evaluer), aaBiasCorrection(aaBiasCorrection),
-      aaBiasCorrectionScale(aaBiasCorrectionScale), gapOpen(gapOpen), gapExtend(gapExtend), numThreads(0), correlationScoreWeight(0.0f), blockHook(NULL),
+      aaBiasCorrectionScale(aaBiasCorrectionScale), gapOpen(gapOpen), gapExtend(gapExtend), numThreads(0), correlationScoreWeight(0.0f), deviceBlockAligner(false), blockHook(NULL),
       targetLookup(NULL), targetLookupCtx(NULL) {
     const int a = m->alphabetSize;
     tinySubMat.resize(a * a);
@@ -48,6 +48,7 @@ struct Pending {
     bool wantsBacktrace;   // reaches banded_sw in alignStartPosBacktrace (mode 2 and coverage ok)
     bool blockDone;        // start / backtrace / identities came from the host's block aligner
     bool refuse;           // the pair is recomputed by the host's Matcher (profile query in block-aligner range)
+    bool needsBlock;       // int16-range pair that passed the gates: waits for the device's block aligner
     std::string blockBacktrace;
 };
 }  // namespace
@@ -186,6 +187,7 @@ bool MMGpuMatcher::alignBlock(const std::vector<Query> &queries, int covMode, fl
             a.word = h.word;
             pe.wantsBacktrace = false;
             pe.blockDone = false;
+            pe.needsBlock = false;
             pe.refuse = hostQuery[q] != 0;
             if (a.dbEndPos1 != -1 && !pe.refuse) {
                 a.qCov = SmithWaterman::computeCov(0, a.qEndPos1, qlen);
@@ -195,10 +197,12 @@ bool MMGpuMatcher::alignBlock(const std::vector<Query> &queries, int covMode, fl
                 const bool lowEval = a.evalue > (queries[q].evalThr >= 0.0 ? queries[q].evalThr : evalThr);
                 if (!(alignmentMode == 0 || ((alignmentMode == 2 || alignmentMode == 1) && (lowEval || lowCov)))) {
                     // word == 1: the stock reference asks the block aligner first (:865-882)
-                    if (a.word == 1 && blockHook != NULL && queries[q].profile != NULL) {
-                        // the stock reference runs the block aligner's profile form here; the hook below only speaks
-                        // sequences, so the pair goes back to the host's own Matcher::getSWResult as a whole
+                    if (a.word == 1 && (blockHook != NULL || deviceBlockAligner) && queries[q].profile != NULL) {
+                        // the stock reference runs the block aligner's profile form here; neither the device kernel nor the
+                        // hook below speaks profiles, so the pair goes back to the host's own Matcher::getSWResult as a whole
                         pe.refuse = true;
+                    } else if (a.word == 1 && deviceBlockAligner) {
+                        pe.needsBlock = true;      // one device call for all of them, below
                     } else if (a.word == 1 && blockHook != NULL) {
                         s_align b = a;
                         std::string bt;
@@ -208,7 +212,7 @@ bool MMGpuMatcher::alignBlock(const std::vector<Query> &queries, int covMode, fl
                             a = b;
                         }
                     }
-                    if (!pe.blockDone && !pe.refuse) {
+                    if (!pe.blockDone && !pe.refuse && !pe.needsBlock) {
                         // alignStartPosBacktrace (:1129-1258): start positions from the reverse scan
                         a.qStartPos1 = h.q_start;
                         a.dbStartPos1 = h.t_start;
@@ -224,6 +228,79 @@ bool MMGpuMatcher::alignBlock(const std::vector<Query> &queries, int covMode, fl
         }
     }
     watch.lap("E-value / coverage gates + block hook");
+    // ---- int16-range pairs: the block aligner on the device (mmgpu_sw_block_backtrace; StripedSmithWaterman.cpp:865-882,
+    // 943-1127).  OK: start / identities / backtrace are the block aligner's.  DECLINED ("Block alignment failed"): the
+    // reference's own fallback, i.e. the reverse scan's start positions and the banded traceback.  TOO_LARGE: the host's
+    // block aligner if one is installed, else the host's Matcher for the whole pair.
+    if (deviceBlockAligner) {
+        std::vector<uint32_t> blkPairs, blkBlockPair;
+        for (size_t p = 0; p < total; p++)
+            if (aln[p].needsBlock) {
+                blkPairs.push_back(devPair.empty() ? (uint32_t)p : devPair[p]);
+                blkBlockPair.push_back((uint32_t)p);
+            }
+        std::vector<mmgpu_sw_block> blk(blkPairs.size());
+        std::string blkStrings;
+        if (!blkPairs.empty() && backend->blockBacktrace(blkPairs.data(), (uint32_t)blkPairs.size(), blk.data(), blkStrings) != 0) {
+            err = backend->lastError();
+            return false;
+        }
+        std::vector<uint32_t> pairQuery(blkPairs.empty() ? 0 : total), pairTarget(blkPairs.empty() ? 0 : total);
+        if (!blkPairs.empty())
+            for (size_t q = 0; q < nq; q++) {
+                size_t p = firstPair[q];
+                for (size_t t = 0; t < queries[q].targets.size(); t++) {
+                    if (queries[q].targets[t].isIdentity) continue;
+                    pairQuery[p] = (uint32_t)q;
+                    pairTarget[p] = (uint32_t)t;
+                    p++;
+                }
+            }
+#pragma omp parallel for schedule(dynamic, 16) num_threads(nthreads)
+        for (size_t k = 0; k < blkBlockPair.size(); k++) {
+            unsigned int thread = 0;
+#ifdef OPENMP
+            thread = (unsigned int)omp_get_thread_num();
+#endif
+            const size_t p = blkBlockPair[k];
+            Pending &pe = aln[p];
+            const size_t q = pairQuery[p];
+            const Target &tg = queries[q].targets[pairTarget[p]];
+            const int qlen = queries[q].L, dbLen = tg.length;
+            const mmgpu_sw_block &bk = blk[k];
+            s_align &a = pe.a;
+            if (bk.status == MMGPU_BLOCK_OK) {
+                a.qStartPos1 = bk.q_start;
+                a.dbStartPos1 = bk.t_start;
+                a.identicalAACnt = bk.ident;
+                a.qCov = SmithWaterman::computeCov(a.qStartPos1, a.qEndPos1, qlen);       // :1114-1115
+                a.tCov = SmithWaterman::computeCov(a.dbStartPos1, a.dbEndPos1, dbLen);
+                pe.blockBacktrace.assign(blkStrings, (size_t)bk.bt_off, (size_t)bk.bt_len);
+                pe.blockDone = true;
+                continue;
+            }
+            if (bk.status == MMGPU_BLOCK_TOO_LARGE) {
+                if (blockHook == NULL) { pe.refuse = true; continue; }
+                s_align b = a;
+                std::string bt;
+                if (blockHook->run(thread, q, queries[q].numSequence, qlen, targetLookup(targetLookupCtx, tg.id), dbLen, b, bt)) {
+                    pe.blockDone = true;
+                    pe.blockBacktrace.swap(bt);
+                    a = b;
+                    continue;
+                }
+            }
+            // DECLINED (or the host's block aligner declined as well): alignStartPosBacktrace (:1129-1258)
+            const mmgpu_sw_hit &h = hits[p];
+            a.qStartPos1 = h.q_start;
+            a.dbStartPos1 = h.t_start;
+            a.qCov = SmithWaterman::computeCov(a.qStartPos1, a.qEndPos1, qlen);
+            a.tCov = SmithWaterman::computeCov(a.dbStartPos1, a.dbEndPos1, dbLen);
+            const bool lowCov2 = !Util::hasCoverage(covThr, covMode, a.qCov, a.tCov);
+            if (!(alignmentMode == 1 || lowCov2)) pe.wantsBacktrace = true;
+        }
+        watch.lap("device block aligner (int16-range pairs)");
+    }
     std::vector<uint32_t> btPairs, btBlockPair;      // device pair index / pair index inside the block
     for (size_t p = 0; p < total; p++)
         if (aln[p].wantsBacktrace) {

@@ -12,6 +12,7 @@
 #ifndef MMGPU_MATCHER_H
 #define MMGPU_MATCHER_H
 
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -34,6 +35,14 @@ public:
                       mmgpu_sw_hit *out) = 0;
     // backtraces (banded_sw + walk) of pairs of the last align() call, by index into its result array
     virtual int traceback(const uint32_t *pairIndex, uint32_t n, mmgpu_sw_bt *info, std::string &strings) = 0;
+    // the block aligner's start positions / identities / backtraces of int16-range pairs of the last align() call
+    // (mmgpu_sw_block_backtrace); the default says "not here" for every pair, which sends them to the host's block aligner
+    virtual int blockBacktrace(const uint32_t *pairIndex, uint32_t n, mmgpu_sw_block *out, std::string &strings) {
+        (void)pairIndex;
+        strings.clear();
+        for (uint32_t k = 0; k < n; k++) { memset(&out[k], 0, sizeof(out[k])); out[k].status = MMGPU_BLOCK_TOO_LARGE; }
+        return 0;
+    }
     virtual const char *lastError() = 0;
 };
 
@@ -96,6 +105,9 @@ public:
 
     // targetSequence(id) must return the numeric residues of a resident target (needed by the hook only)
     typedef const unsigned char *(*TargetLookup)(void *ctx, unsigned int id);
+    // int16-range pairs go to the device's block aligner first (MMGPU_BLOCK_ALIGNER=device, the default of the patched binary);
+    // the host hook, if installed, then only serves what the device declines as too large
+    void setDeviceBlockAligner(bool on) { deviceBlockAligner = on; }
     void setBlockBacktracer(MMGpuBlockBacktracer *hook, TargetLookup lookup, void *lookupCtx) {
         blockHook = hook;
         targetLookup = lookup;
@@ -118,6 +130,7 @@ private:
     std::string err;
     unsigned int numThreads;
     float correlationScoreWeight;
+    bool deviceBlockAligner;
     MMGpuBlockBacktracer *blockHook;
     TargetLookup targetLookup;
     void *targetLookupCtx;

@@ -11,9 +11,14 @@ bool MMGpuRun::enabled() {
     return !(e != NULL && e[0] != '\0' && e[0] != '0');
 }
 
-bool MMGpuRun::hostBlockAligner() {
+// MMGPU_BLOCK_ALIGNER: "device" (default) | "host" | "sw"
+bool MMGpuRun::hostBlockAligner() {      // the host's alignStartPosBacktraceBlock is installed as a hook
     const char *e = getenv("MMGPU_BLOCK_ALIGNER");
-    return !(e != NULL && strcmp(e, "device") == 0);
+    return !(e != NULL && strcmp(e, "sw") == 0);
+}
+bool MMGpuRun::deviceBlockAligner() {
+    const char *e = getenv("MMGPU_BLOCK_ALIGNER");
+    return e == NULL || e[0] == '\0' || strcmp(e, "device") == 0;
 }
 
 size_t MMGpuRun::envSize(const char *name, size_t fallback) {

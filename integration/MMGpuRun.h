@@ -7,9 +7,14 @@
 // Run-time switches (environment, read once):
 //   MMGPU_DISABLE=1            keep the CPU path everywhere (the binary then behaves like the stock one)
 //   MMGPU_DEVICE=<n>           HIP device of this process (default 0; multi-GPU runs start one process per device)
-//   MMGPU_BLOCK_ALIGNER=device start positions / backtraces of hits whose score left the uint8 range come from the
-//                              device's reverse scan + banded_sw (the reference's own fallback) instead of the host's
-//                              block aligner; default "host": those fields are the stock binary's by construction
+//   MMGPU_BLOCK_ALIGNER        hits whose score left the uint8 range (s_align::word == 1) take start position, identities and
+//                              backtrace from the block aligner (StripedSmithWaterman.cpp:865-882,943-1127):
+//                                device (default)  the device's block aligner (mmgpu_sw_block_backtrace); what it declines as
+//                                                  too large goes to the host's own alignStartPosBacktraceBlock
+//                                host              the host's alignStartPosBacktraceBlock for every such pair: those fields
+//                                                  are the stock binary's by construction (a Rust-linked build: the crate's)
+//                                sw                the reverse scan + banded traceback for all of them (the reference's
+//                                                  fallback; what rounds 1-2 called "device")
 //   MMGPU_ALIGN_BLOCK_QUERIES, MMGPU_ALIGN_BLOCK_BYTES, MMGPU_PREF_BLOCK_QUERIES   block sizes of the device calls
 #ifndef MMGPU_RUN_H
 #define MMGPU_RUN_H
@@ -33,6 +38,7 @@ class MMGpuRun {
 public:
     static bool enabled();
     static bool hostBlockAligner();
+    static bool deviceBlockAligner();
     static size_t envSize(const char *name, size_t fallback);
     // the process-wide context; logs the library's message and EXITs if the device cannot be opened
     static mmgpu_ctx *context();

@@ -59,6 +59,8 @@ NUCL_HIT_DTYPE = np.dtype([("score", np.int32), ("q_start", np.int32), ("q_end",
 
 SW_BT_DTYPE = np.dtype([("bt_off", np.uint64), ("bt_len", np.uint32), ("ident", np.uint32), ("status", np.int32),
                         ("reserved", np.int32)])
+SW_BLOCK_DTYPE = np.dtype([("q_start", np.int32), ("t_start", np.int32), ("ident", np.uint32), ("bt_len", np.uint32), ("bt_off", np.uint64),
+                           ("status", np.int32), ("reserved", np.int32)])
 SW_HIT_DTYPE = np.dtype([("score", np.int32), ("q_end", np.int32), ("t_end", np.int32), ("q_start", np.int32),
                          ("t_start", np.int32), ("word", np.int32)])
 
@@ -73,7 +75,7 @@ EXPORTED_SYMBOLS = [
     "mmgpu_host_partition_targets", "mmgpu_pf_set_shard", "mmgpu_pf_fetch_exchange", "mmgpu_pf_merge_exchange",
     "mmgpu_pf_localize_lists", "mmgpu_sw_prepare_from_lists",
     "mmgpu_comm_unique_id", "mmgpu_comm_init_rank", "mmgpu_comm_info", "mmgpu_comm_destroy", "mmgpu_pf_exchange_merge",
-    "mmgpu_sw_prepare_owned", "mmgpu_sw_gather_owned", "mmgpu_sw_fetch_owned",
+    "mmgpu_sw_prepare_owned", "mmgpu_sw_gather_owned", "mmgpu_sw_fetch_owned", "mmgpu_sw_block_backtrace",
     "mmgpu_init_multi", "mmgpu_destroy_multi", "mmgpu_multi_size", "mmgpu_multi_ctx", "mmgpu_multi_synchronize",
     "mmgpu_multi_load_targets", "mmgpu_multi_pf_build_index", "mmgpu_multi_pf_prepare", "mmgpu_multi_pf_run", "mmgpu_multi_pf_fetch",
     "mmgpu_multi_pf_stride", "mmgpu_multi_pf_free", "mmgpu_multi_sw_from_pf",
@@ -170,6 +172,7 @@ def load_library():
     L.mmgpu_pf_localize_lists.argtypes = [c_p, c_p, c_p, ctypes.c_uint32, ctypes.c_uint32, c_p, c_p, c_p]
     L.mmgpu_sw_prepare_from_lists.argtypes = [c_p, ctypes.POINTER(SwParams), c_p, ctypes.c_uint32, ctypes.c_int, c_p, c_p,
                                               ctypes.c_uint32, ctypes.POINTER(c_p)]
+    L.mmgpu_sw_block_backtrace.argtypes = [c_p, c_p, c_p, ctypes.c_uint32, c_p, c_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
     L.mmgpu_comm_unique_id.argtypes = [c_p]
     L.mmgpu_comm_init_rank.argtypes = [c_p, c_p, ctypes.c_int, ctypes.c_int]
     L.mmgpu_comm_info.argtypes = [c_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.c_char_p, ctypes.c_int]
@@ -434,6 +437,20 @@ class SwBatch:
         n = ctypes.c_uint32()
         self.gpu._check(self.gpu.L.mmgpu_sw_fetch_owned(self.gpu.ctx, self.handle, _ptr(out), ctypes.byref(n)))
         return out, n.value
+
+    def block_backtrace(self, pair_index):
+        """mmgpu_sw_block_backtrace: the block aligner's start positions / identities / backtraces of int16-range hits.
+        -> (SW_BLOCK_DTYPE array, list of backtrace strings (None unless status == 0))"""
+        pi = np.ascontiguousarray(pair_index, np.uint32)
+        out = np.zeros(len(pi), SW_BLOCK_DTYPE)
+        used = ctypes.c_size_t()
+        rc = self.gpu.L.mmgpu_sw_block_backtrace(self.gpu.ctx, self.handle, _ptr(pi), len(pi), _ptr(out), None, 0, ctypes.byref(used))
+        bt = np.zeros(max(used.value, 1), np.uint8)
+        self.gpu._check(self.gpu.L.mmgpu_sw_block_backtrace(self.gpu.ctx, self.handle, _ptr(pi), len(pi), _ptr(out), _ptr(bt), used.value,
+                                                            ctypes.byref(used)))
+        raw = bt.tobytes()
+        strs = [raw[int(o["bt_off"]):int(o["bt_off"]) + int(o["bt_len"])].decode() if o["status"] == 0 else None for o in out]
+        return out, strs
 
     def kernel_ms(self):
         ms = ctypes.c_float()

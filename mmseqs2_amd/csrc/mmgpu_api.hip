@@ -289,6 +289,7 @@ struct mmgpu_sw_batch_t {
     std::vector<uint32_t> h_out_target;   // target id of every result slot (kept for mmgpu_sw_traceback, mode >= START)
     std::vector<uint32_t> h_qout_off;     // [nq + 1] first result slot of every query
     std::vector<uint32_t> h_qoff;         // [nq + 1] residue offsets
+    std::vector<uint8_t> h_query_is_profile;   // profile queries of the batch (empty: none)
     DevBuf d_bt_scratch, d_bt_jobs, d_bt_info, d_bt_str, d_bt_cursor;
     uint32_t scratch_cols = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;   // one pair per mmgpu_sw_run since prepare
@@ -440,6 +441,8 @@ static int sw_prepare_impl(mmgpu_ctx *c, const mmgpu_sw_params *par, const mmgpu
             qminp = 0;
             for (size_t k = 0; k < (size_t)Q.profile_letters * Q.qlen; k++) qminp = std::min<int>(qminp, Q.profile[k]);
             b->any_profile = true;
+            b->h_query_is_profile.resize(nq, 0);
+            b->h_query_is_profile[i] = 1;
         }
         if (!(qminp + mincb + par->gap_extend > -par->gap_open)) {
             delete b;
@@ -950,6 +953,107 @@ extern "C" int mmgpu_sw_batch(mmgpu_ctx *c, const mmgpu_sw_params *par, const mm
 // ---------------------------------------------------------------------------------------------------------
 // backtrace
 // ---------------------------------------------------------------------------------------------------------
+// ---- a15: the block aligner's start position / backtrace for int16-range hits (block_kernel.hip) ----
+extern "C" int mmgpu_sw_block_backtrace(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const uint32_t *pair_index, uint32_t n, mmgpu_sw_block *out,
+                                        char *bt, size_t bt_cap, size_t *bt_used) {
+    if (!c || !b || (!pair_index && n) || (!out && n)) return fail(MMGPU_ERR_ARG, "mmgpu_sw_block_backtrace: NULL argument");
+    if (!b->ran) return fail(MMGPU_ERR_STATE, "mmgpu_sw_block_backtrace: batch was never run");
+    if (b->alphabet > 26) return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_sw_block_backtrace: alphabet above 26 letters");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    if (!b->h_res_valid) {
+        b->h_res.resize((size_t)b->pairs);
+        if (b->pairs) HIP_TRY(hipMemcpyAsync(b->h_res.data(), b->d_out.p, (size_t)b->pairs * sizeof(mmgpu_sw_hit), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (b->from_pf) {
+            b->h_slot_target.resize((size_t)b->pairs);
+            if (b->pairs) HIP_TRY(hipMemcpy(b->h_slot_target.data(), b->d_slot_target.p, (size_t)b->pairs * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        }
+        b->h_res_valid = true;
+    }
+    if (b->mode < MMGPU_SW_START && !b->from_pf && b->h_out_target.empty())
+        return fail(MMGPU_ERR_STATE, "mmgpu_sw_block_backtrace: the batch keeps no slot -> target map (prepare it with MMGPU_SW_START)");
+    std::vector<BlockJob> jobs;
+    std::vector<uint64_t> bt_off(std::max<uint32_t>(n, 1), 0);
+    uint64_t off = 0, longest = 0;
+    for (uint32_t k = 0; k < n; k++) {
+        const uint32_t p = pair_index[k];
+        if (p >= b->pairs) return fail(MMGPU_ERR_ARG, "mmgpu_sw_block_backtrace: pair index out of range");
+        const mmgpu_sw_hit &h = b->h_res[p];
+        out[k].q_start = -1; out[k].t_start = -1; out[k].ident = 0; out[k].bt_len = 0; out[k].bt_off = off; out[k].reserved = 0;
+        bt_off[k] = off;
+        const uint32_t q = (uint32_t)(std::upper_bound(b->h_qout_off.begin(), b->h_qout_off.end(), p) - b->h_qout_off.begin() - 1);
+        const bool profile_query = b->any_profile && b->h_query_is_profile.size() > q && b->h_query_is_profile[q];
+        if (h.score <= 0 || h.word != 1 || h.t_end < 0 || profile_query) {
+            out[k].status = MMGPU_BLOCK_NOT_WORD;
+            continue;
+        }
+        out[k].status = MMGPU_BLOCK_TOO_LARGE;    // overwritten by the kernel
+        BlockJob j;
+        j.query = q;
+        j.target = b->from_pf ? b->h_slot_target[p] : b->h_out_target[p];
+        j.score = h.score; j.q_end = h.q_end; j.t_end = h.t_end;
+        j.slot = k;
+        jobs.push_back(j);
+        const uint64_t len = (uint64_t)h.q_end + 1 + (uint64_t)h.t_end + 1;
+        off += len + 1;
+        longest = std::max(longest, len);
+    }
+    if (bt_used) *bt_used = (size_t)off;
+    if (off > bt_cap || (!bt && off)) return fail(MMGPU_ERR_ARG, "mmgpu_sw_block_backtrace: bt buffer too small (see *bt_used)");
+    if (jobs.empty()) return MMGPU_OK;
+    std::stable_sort(jobs.begin(), jobs.end(), [](const BlockJob &x, const BlockJob &y) { return x.q_end + x.t_end > y.q_end + y.t_end; });
+    // the AAMatrix as ssw_init leaves it: new_simple(1, -1) with the substitution matrix written over it (:708,:1469-1474)
+    std::vector<int8_t> mat((size_t)b->alphabet * b->alphabet), scores(27 * 32, (int8_t)-128);
+    HIP_TRY(hipMemcpy(mat.data(), b->d_mat.p, mat.size(), hipMemcpyDeviceToHost));
+    for (int x = 0; x < 26; x++)
+        for (int y = 0; y < 26; y++) scores[x * 32 + y] = x == y ? 1 : -1;
+    for (int x = 0; x < b->alphabet; x++)
+        for (int y = 0; y < b->alphabet; y++) { scores[x * 32 + y] = mat[(size_t)x * b->alphabet + y]; scores[y * 32 + x] = mat[(size_t)x * b->alphabet + y]; }
+    // scratch slot: block list + trace of the longest pair the kernel takes: (BLOCK_MAX_SIZE / 64) entries of 32 bytes per column
+    // of the trace, len + 2 * BLOCK_MAX_SIZE columns (Trace::new, scan_block.rs:1742-1748), pairs beyond 16384 residues declined
+    const uint64_t cap_len = std::min<uint64_t>(longest, 16384);
+    const uint64_t slot_bytes = (((cap_len + 64) * 16 + 31) & ~31ull) + (uint64_t)(BLOCK_MAX_SIZE / 64) * 32 * (cap_len + 2 * BLOCK_MAX_SIZE);
+    const uint32_t slots = (uint32_t)std::min<uint64_t>(jobs.size(), (uint64_t)std::max(c->compute_units, 1) * 16);
+    DevBuf d_jobs, d_out, d_btoff, d_bt, d_scores, d_pool, d_busy;
+    for (DevBuf *d : {&d_jobs, &d_out, &d_btoff, &d_bt, &d_scores, &d_pool, &d_busy}) d->bind(c->cache);
+    HIP_TRY(d_jobs.alloc(jobs.size() * sizeof(BlockJob)));
+    HIP_TRY(d_out.alloc((size_t)n * sizeof(mmgpu_sw_block)));
+    HIP_TRY(d_btoff.alloc((size_t)n * 8));
+    HIP_TRY(d_bt.alloc((size_t)off + 16));
+    HIP_TRY(d_scores.alloc(scores.size()));
+    HIP_TRY(d_pool.alloc((size_t)slot_bytes * slots));
+    HIP_TRY(d_busy.alloc((size_t)slots * 4));
+    HIP_TRY(hipMemsetAsync(d_busy.p, 0, (size_t)slots * 4, s));
+    HIP_TRY(hipMemcpyAsync(d_jobs.p, jobs.data(), jobs.size() * sizeof(BlockJob), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_out.p, out, (size_t)n * sizeof(mmgpu_sw_block), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_btoff.p, bt_off.data(), (size_t)n * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_scores.p, scores.data(), scores.size(), hipMemcpyHostToDevice, s));
+    BlockLaunch L;
+    L.jobs = d_jobs.as<BlockJob>();
+    L.n_jobs = (uint32_t)jobs.size();
+    L.q_res = b->d_qres.as<uint8_t>();
+    L.q_cb = b->d_qcb.as<int8_t>();
+    L.q_off = b->d_qoff.as<uint32_t>();
+    L.t_res = c->db.res;
+    L.t_off4 = c->db.off4;
+    L.scores = d_scores.as<int8_t>();
+    L.gap_open = -b->gap_open;
+    L.gap_extend = -b->gap_extend;
+    L.out = d_out.as<mmgpu_sw_block>();
+    L.bt_off = d_btoff.as<uint64_t>();
+    L.bt = d_bt.as<char>();
+    L.pool = d_pool.as<uint8_t>();
+    L.slot_bytes = slot_bytes;
+    L.n_pool_slots = slots;
+    L.pool_busy = d_busy.as<uint32_t>();
+    HIP_TRY(launch_sw_block(L, s));
+    HIP_TRY(hipMemcpyAsync(out, d_out.p, (size_t)n * sizeof(mmgpu_sw_block), hipMemcpyDeviceToHost, s));
+    if (off) HIP_TRY(hipMemcpyAsync(bt, d_bt.p, (size_t)off, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));      // the host vectors and the buffers above die with this scope
+    return MMGPU_OK;
+}
+
 extern "C" int mmgpu_sw_traceback(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const uint32_t *pair_index, uint32_t n, mmgpu_sw_bt *info,
                                   char *bt, size_t bt_cap, size_t *bt_used) {
     if (!c || !b || (!pair_index && n) || (!info && n)) return fail(MMGPU_ERR_ARG, "mmgpu_sw_traceback: NULL argument");

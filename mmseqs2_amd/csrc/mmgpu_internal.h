@@ -431,6 +431,34 @@ struct BtLaunch {
     unsigned long long *dir_cursor;
 };
 
+// ---- block aligner on the device (block_kernel.hip; row a15): int16-range hits ----
+constexpr int BLOCK_MAX_SIZE = 512;        // largest block this kernel holds in LDS
+constexpr int BLOCK_REF_MAX_SIZE = 4096;   // MAX_SIZE of the reference (StripedSmithWaterman.cpp:37)
+struct BlockJob {
+    uint32_t query, target;
+    int32_t score, q_end, t_end;
+    uint32_t slot;                // index into out / bt_off
+};
+struct BlockLaunch {
+    const BlockJob *jobs;
+    uint32_t n_jobs;
+    const uint8_t *q_res;
+    const int8_t *q_cb;
+    const uint32_t *q_off;
+    const uint8_t *t_res;
+    const uint32_t *t_off4;
+    const int8_t *scores;         // AAMatrix::scores [27 * 32] as ssw_init leaves it (new_simple(1, -1) + set_num of the matrix)
+    int gap_open, gap_extend;     // the crate's convention: negative
+    mmgpu_sw_block *out;
+    const uint64_t *bt_off;
+    char *bt;
+    uint8_t *pool;                // scratch slots: block list + trace of one pair
+    uint64_t slot_bytes;
+    uint32_t n_pool_slots;
+    uint32_t *pool_busy;
+};
+hipError_t launch_sw_block(const BlockLaunch &L, hipStream_t stream);
+
 hipError_t launch_sw_traceback(const BtLaunch &L, hipStream_t stream);
 hipError_t launch_sw_traceback_wave(const BtLaunch &L, hipStream_t stream);
 

@@ -178,6 +178,55 @@ int mmgpu_sw_fetch(mmgpu_ctx *, mmgpu_sw_batch_t *b, mmgpu_sw_hit *out) {
 }
 void mmgpu_sw_free(mmgpu_ctx *, mmgpu_sw_batch_t *b) { delete b; }
 
+// the device's block aligner (block_kernel.hip) stand-in: the plain-C restatement (oracle/block_oracle.c).
+// MMGPU_EMU_REFUSE_BLOCK=<len>: decline pairs whose reversed prefixes are longer, like the device does beyond its scratch slot
+int mmgpu_sw_block_backtrace(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const uint32_t *idx, uint32_t n, mmgpu_sw_block *out, char *bt, size_t cap,
+                             size_t *used) {
+    size_t need = 0;
+    std::vector<size_t> off(n);
+    for (uint32_t i = 0; i < n; i++) {
+        const mmgpu_sw_hit &h = b->res[idx[i]];
+        const bool word = h.score > 0 && h.word == 1 && h.t_end >= 0 && b->prof_letters[b->pair[idx[i]].first] == 0;
+        off[i] = need;
+        if (word) need += (size_t)h.q_end + 1 + (size_t)h.t_end + 1 + 1;
+    }
+    if (used) *used = need;
+    if (need && (bt == NULL || cap < need)) return fail(MMGPU_ERR_ARG, "bt buffer too small");
+#pragma omp parallel for schedule(dynamic, 16)
+    for (uint32_t i = 0; i < n; i++) {
+        const mmgpu_sw_hit &h = b->res[idx[i]];
+        const uint32_t qi = b->pair[idx[i]].first, id = b->pair[idx[i]].second;
+        memset(&out[i], 0, sizeof(out[i]));
+        out[i].q_start = out[i].t_start = -1;
+        out[i].bt_off = off[i];
+        if (!(h.score > 0 && h.word == 1 && h.t_end >= 0 && b->prof_letters[qi] == 0)) {
+            out[i].status = MMGPU_BLOCK_NOT_WORD;
+            continue;
+        }
+        if (getenv("MMGPU_EMU_REFUSE_BLOCK") && h.q_end + h.t_end + 2 > atoi(getenv("MMGPU_EMU_REFUSE_BLOCK"))) {
+            out[i].status = MMGPU_BLOCK_TOO_LARGE;
+            continue;
+        }
+        const std::vector<uint8_t> &q = b->q[qi];
+        const uint8_t *t = c->tres.data() + c->toff[id];
+        const int tlen = (int)(c->toff[id + 1] - c->toff[id]);
+        int qs = -1, ts = -1, len = 0, bs = 0;
+        uint32_t ident = 0;
+        const int ok = mmo_sw_block_backtrace(q.data(), b->cb[qi].data(), (int)q.size(), t, tlen, b->mat.data(), b->alphabet, b->go, b->ge, h.score,
+                                              h.q_end, h.t_end, &qs, &ts, &ident, bt + off[i], h.q_end + h.t_end + 3, &len, &bs);
+        if (!ok) {
+            out[i].status = MMGPU_BLOCK_DECLINED;
+            continue;
+        }
+        out[i].status = MMGPU_BLOCK_OK;
+        out[i].q_start = qs;
+        out[i].t_start = ts;
+        out[i].ident = ident;
+        out[i].bt_len = (uint32_t)len;
+    }
+    return 0;
+}
+
 int mmgpu_sw_traceback(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const uint32_t *idx, uint32_t n, mmgpu_sw_bt *info, char *bt, size_t cap,
                        size_t *used) {
     size_t need = 0;

@@ -308,3 +308,46 @@ def test_very_long_query_and_target(gpu, oracle, matrices):
         if int(info[k]["status"]) == 0:
             assert strs[k] == r["bt"] and int(info[k]["ident"]) == r["ident"], k
     b.free()
+
+
+def test_block_aligner_on_device_equals_restatement(gpu, matrices, oracle):
+    """Row a15: start position, identities and backtrace of int16-range hits from the device's block aligner
+    (mmgpu_sw_block_backtrace, block_kernel.hip) against the plain-C restatement of the crate (oracle/block_oracle.c,
+    tests/test_block_oracle.py): every pair the device answers must equal it field by field; what it declines it must name."""
+    from mmseqs2_amd import workloads as wl
+    mat = matrices["blosum62_sw"]
+    sub16 = mat.astype(np.int16)
+    (qres, qoff), (tres, toff), fam_t, fam_q = wl.config3_prefilter(160, 6, 160, seed=33)
+    qs, ts = wl.split(qres, qoff), wl.split(tres, toff)
+    gpu.load_targets(tres, toff, 21)
+    queries = []
+    for qi, q in enumerate(qs):
+        own = np.nonzero(fam_t == fam_q[qi])[0][:4].astype(np.uint32)
+        other = np.array([(qi * 7 + 3) % len(ts)], np.uint32)
+        cb = oracle.round_comp_bias(oracle.comp_bias(sub16, matrices["blosum62_pback"], q, 1.0))
+        queries.append(dict(q=q, comp_bias=cb, targets=np.concatenate([own, other]), min_start_score=0))
+    b = gpu.sw_prepare(mat, 11, 1, queries, mode=1)
+    b.run()
+    res = b.fetch()
+    blk, strs = b.block_backtrace(np.arange(len(res), dtype=np.uint32))
+    b.free()
+    k = n_ok = n_word = n_large = 0
+    for qd in queries:
+        for t_id in qd["targets"]:
+            r, o = res[k], blk[k]
+            if r["word"] != 1 or r["score"] <= 0:
+                assert o["status"] == 3, k
+            else:
+                n_word += 1
+                w = oracle.block_backtrace(qd["q"], qd["comp_bias"], ts[int(t_id)], mat, 11, 1, int(r["score"]), int(r["q_end"]), int(r["t_end"]))
+                if o["status"] == 0:
+                    assert w["ok"], k
+                    assert (int(o["q_start"]), int(o["t_start"]), int(o["ident"]), strs[k]) == (w["q_start"], w["t_start"], w["ident"], w["bt"]), k
+                    n_ok += 1
+                elif o["status"] == 1:
+                    assert not w["ok"], k
+                else:
+                    assert o["status"] == 2 and w["block_size"] >= 32, k
+                    n_large += 1
+            k += 1
+    assert n_word > 250 and n_ok >= n_word - max(3, n_word // 20), (n_word, n_ok, n_large)
