@@ -32,6 +32,7 @@
 #endif
 
 MMGpuAlignBackend *mmgpuNewDeviceBackend(mmgpu_ctx *gpu);
+MMGpuAlignBackend *mmgpuNewMultiDeviceBackend(const std::vector<mmgpu_ctx *> &gpus);
 
 namespace {
 
@@ -170,13 +171,19 @@ bool MMGpuAlignRun::run(Alignment &al, const std::string &outDB, const std::stri
             memcpy(store.residues.data() + store.offsets[id], dbSeq.numSequence, dbSeq.L);
         }
     }
-    if (mmgpu_load_targets(gpu, store.residues.data(), store.offsets.data(), (uint32_t)nTargets, al.m->alphabetSize) != 0) {
-        Debug(Debug::ERROR) << "MMGPU: " << mmgpu_last_error() << "\n";
-        EXIT(EXIT_FAILURE);
-    }
+    // MMGPU_DEVICES: every device holds the targets, the queries of a block are dealt to them (MMGpuMultiDeviceBackend)
+    std::vector<mmgpu_ctx *> devices;
+    if (mmgpu_multi *multi = MMGpuRun::multi())
+        for (int d = 0; d < mmgpu_multi_size(multi); d++) devices.push_back(mmgpu_multi_ctx(multi, d));
+    if (devices.empty()) devices.push_back(gpu);
+    for (size_t d = 0; d < devices.size(); d++)
+        if (mmgpu_load_targets(devices[d], store.residues.data(), store.offsets.data(), (uint32_t)nTargets, al.m->alphabetSize) != 0) {
+            Debug(Debug::ERROR) << "MMGPU: " << mmgpu_last_error() << "\n";
+            EXIT(EXIT_FAILURE);
+        }
 
     watch.lap("map + upload targets");
-    MMGpuAlignBackend *backend = mmgpuNewDeviceBackend(gpu);
+    MMGpuAlignBackend *backend = devices.size() > 1 ? mmgpuNewMultiDeviceBackend(devices) : mmgpuNewDeviceBackend(gpu);
     MMGpuMatcher gpuMatcher(backend, al.m, &evaluer, al.compBiasCorrection, al.compBiasCorrectionScale, al.gapOpen, al.gapExtend);
     const size_t maxMatcherSeqLen = std::max(al.tdbr->getMaxSeqLen(), al.qdbr->getMaxSeqLen());
     HostBlockBacktracer blockHook(threads, maxMatcherSeqLen, al.m, al.compBiasCorrection, al.compBiasCorrectionScale, al.gapOpen,

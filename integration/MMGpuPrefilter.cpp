@@ -15,7 +15,7 @@ unsigned int MMGpuPrefilter::referenceBins(size_t dbsize) {
 
 MMGpuPrefilter::MMGpuPrefilter(mmgpu_ctx *gpu, BaseMatrix *kmerSubMat, BaseMatrix *ungappedSubMat, bool aaBiasCorrection,
                                float aaBiasCorrectionScale)
-    : gpu(gpu), kmerSubMat(kmerSubMat), ungappedSubMat(ungappedSubMat), aaBiasCorrection(aaBiasCorrection),
+    : gpu(gpu), multi(NULL), kmerSubMat(kmerSubMat), ungappedSubMat(ungappedSubMat), aaBiasCorrection(aaBiasCorrection),
       aaBiasCorrectionScale(aaBiasCorrectionScale), dbSize(0), exactKmerMatching(false), nucleotideSearch(false), kmerScore(false) {}
 
 bool MMGpuPrefilter::loadIndex(IndexTable *indexTable, SequenceLookup *sequenceLookup, ScoreMatrix &threeMer, ScoreMatrix &twoMer,
@@ -62,8 +62,10 @@ bool MMGpuPrefilter::buildIndex(SequenceLookup *sequenceLookup, int kmerSize, in
                                 ScoreMatrix &twoMer, bool spacedKmer) {
     const size_t n = sequenceLookup->getSequenceCount();
     static_assert(sizeof(size_t) == sizeof(uint64_t), "SequenceLookup::getOffsets() is handed over as it is");
-    if (mmgpu_load_targets(gpu, reinterpret_cast<const uint8_t *>(sequenceLookup->getData()),
-                           reinterpret_cast<const uint64_t *>(sequenceLookup->getOffsets()), (uint32_t)n, kmerSubMat->alphabetSize) != 0) {
+    const uint8_t *res = reinterpret_cast<const uint8_t *>(sequenceLookup->getData());
+    const uint64_t *off = reinterpret_cast<const uint64_t *>(sequenceLookup->getOffsets());
+    if ((multi ? mmgpu_multi_load_targets(multi, res, off, (uint32_t)n, kmerSubMat->alphabetSize)
+               : mmgpu_load_targets(gpu, res, off, (uint32_t)n, kmerSubMat->alphabetSize)) != 0) {
         err = mmgpu_last_error();
         return false;
     }
@@ -88,7 +90,7 @@ bool MMGpuPrefilter::buildIndex(SequenceLookup *sequenceLookup, int kmerSize, in
     ix.index2 = twoMer.isValid() ? twoMer.index : NULL;
     ix.row2 = twoMer.isValid() ? twoMer.rowSize : 0;
     ix.ungapped_mat = ungapped.data();
-    if (mmgpu_pf_build_index(gpu, &ix, kmer16.data(), indexKmerThr) != 0) {
+    if ((multi ? mmgpu_multi_pf_build_index(multi, &ix, kmer16.data(), indexKmerThr) : mmgpu_pf_build_index(gpu, &ix, kmer16.data(), indexKmerThr)) != 0) {
         err = mmgpu_last_error();
         return false;
     }
@@ -142,13 +144,26 @@ bool MMGpuPrefilter::matchBlock(const std::vector<Query> &queries, int kmerThr, 
     while (!todo.empty()) {
         const size_t lo = todo.back().first, hi = todo.back().second;
         todo.pop_back();
-        mmgpu_pf_batch_t *batch = NULL;
-        int rc = mmgpu_pf_prepare(gpu, &par, dq.data() + lo, (uint32_t)(hi - lo), &batch);
-        if (rc == 0) rc = mmgpu_pf_run(gpu, batch);
-        if (rc == 0) rc = mmgpu_pf_fetch(gpu, batch, hits.data() + lo * (size_t)stride, stride, counts.data() + lo, status.data() + lo,
-                                         stats ? stats->data() + lo : NULL);
-        if (rc != 0) err = mmgpu_last_error();
-        if (batch) mmgpu_pf_free(gpu, batch);
+        int rc;
+        if (multi) {
+            // every shard's prefilter, the exchange of the lists over the library's communicator, the merge (== unsplit lists);
+            // MMGPU_PF_SHARD_INEXACT queries come back through needsCpu.  (Per-query statistics - log output only - are not
+            // gathered over the shards.)
+            mmgpu_multi_pf_batch *mb = NULL;
+            rc = mmgpu_multi_pf_prepare(multi, &par, dq.data() + lo, (uint32_t)(hi - lo), &mb);
+            if (rc == 0) rc = mmgpu_multi_pf_run(multi, mb);
+            if (rc == 0) rc = mmgpu_multi_pf_fetch(multi, mb, hits.data() + lo * (size_t)stride, stride, counts.data() + lo, status.data() + lo);
+            if (rc != 0) err = mmgpu_last_error();
+            if (mb) mmgpu_multi_pf_free(multi, mb);
+        } else {
+            mmgpu_pf_batch_t *batch = NULL;
+            rc = mmgpu_pf_prepare(gpu, &par, dq.data() + lo, (uint32_t)(hi - lo), &batch);
+            if (rc == 0) rc = mmgpu_pf_run(gpu, batch);
+            if (rc == 0) rc = mmgpu_pf_fetch(gpu, batch, hits.data() + lo * (size_t)stride, stride, counts.data() + lo, status.data() + lo,
+                                             stats ? stats->data() + lo : NULL);
+            if (rc != 0) err = mmgpu_last_error();
+            if (batch) mmgpu_pf_free(gpu, batch);
+        }
         if (rc != 0) {
             if ((rc == MMGPU_ERR_HIP || rc == MMGPU_ERR_UNSUPPORTED) && hi - lo > 1) {
                 const size_t mid = lo + (hi - lo) / 2;

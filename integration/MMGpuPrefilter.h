@@ -27,6 +27,13 @@ class MMGpuPrefilter {
 public:
     MMGpuPrefilter(mmgpu_ctx *gpu, BaseMatrix *kmerSubMat, BaseMatrix *ungappedSubMat, bool aaBiasCorrection,
                    float aaBiasCorrectionScale);
+    // Several devices (MMGpuRun::multi()): buildIndex() deals the targets to them by length bucket and builds one index per
+    // device, matchBlock() runs every shard, exchanges the lists over the library's communicator and returns the merged lists,
+    // which equal the single-device ones.  Sequence queries with diagonal scoring only (the caller checks multiCapable()).
+    void useDevices(mmgpu_multi *m) { multi = m; }
+    static bool multiCapable(bool profileQuery, bool nucleotide, bool kmerScoring, size_t maxResListLen, int nDevices) {
+        return !profileQuery && !nucleotide && !kmerScoring && maxResListLen * (size_t)nDevices <= 4096;
+    }
 
     // once per target split: SequenceLookup -> resident targets, IndexTable + similar-k-mer tables -> resident index
     bool loadIndex(IndexTable *indexTable, SequenceLookup *sequenceLookup, ScoreMatrix &threeMer, ScoreMatrix &twoMer, bool spacedKmer);
@@ -68,6 +75,7 @@ public:
 
 private:
     mmgpu_ctx *gpu;
+    mmgpu_multi *multi;
     BaseMatrix *kmerSubMat;
     BaseMatrix *ungappedSubMat;
     bool aaBiasCorrection;

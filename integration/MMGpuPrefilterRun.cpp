@@ -99,6 +99,16 @@ bool MMGpuPrefilterRun::run(Prefiltering &p, DBWriter &tmpDbw, size_t dbFrom, si
     watch.lap("open device");
     MMGpuPrefilter device(gpu, p.kmerSubMat, p.ungappedSubMat, p.aaBiasCorrection, p.aaBiasCorrectionScale);
     const bool profileQuery = Parameters::isEqualDbtype(p.querySeqType, Parameters::DBTYPE_HMM_PROFILE);
+    // MMGPU_DEVICES: the targets of this split dealt to several devices (device-built index only: a host index is one table)
+    if (mmgpu_multi *multi = MMGpuRun::multi()) {
+        const bool nuclDb = Parameters::isEqualDbtype(p.targetSeqType, Parameters::DBTYPE_NUCLEOTIDES);
+        if (p.mmgpuDeviceIndex && MMGpuPrefilter::multiCapable(profileQuery, nuclDb, p.diagonalScoring == 0, p.maxResListLen, mmgpu_multi_size(multi))) {
+            device.useDevices(multi);
+        } else {
+            Debug(Debug::INFO) << "MMGPU: this prefilter configuration runs on one device (several devices: sequence queries, diagonal "
+                                  "scoring, device-built index, --max-seqs x devices <= 4096)\n";
+        }
+    }
     // The library's index hand-over carries the 3-mer / 2-mer score tables of sequence queries; Prefiltering only builds
     // them for amino-acid queries (Prefiltering.cpp:218-225), so a profile run computes them here the same way.
     ScoreMatrix local3, local2;

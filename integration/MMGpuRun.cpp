@@ -2,6 +2,7 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 #include "Debug.h"
 #include "Util.h"
@@ -44,4 +45,32 @@ mmgpu_ctx *MMGpuRun::context() {
             Debug(Debug::INFO) << "MMGPU: device " << device << " " << name << " (" << cus << " compute units)\n";
     }
     return ctx;
+}
+
+// MMGPU_DEVICES=0,1,2,...: all listed devices of the node work on one module call (a repeated id puts several contexts on one
+// device: the shard logic can then be exercised on a 1-GPU box).  NULL: one device (MMGPU_DEVICE).
+mmgpu_multi *MMGpuRun::multi() {
+    static mmgpu_multi *m = NULL;
+    static bool tried = false;
+    if (tried) return m;
+    tried = true;
+    const char *e = getenv("MMGPU_DEVICES");
+    if (e == NULL || e[0] == '\0') return NULL;
+    std::vector<int> ids;
+    for (const char *p = e; *p != '\0';) {
+        char *end = NULL;
+        const long v = strtol(p, &end, 10);
+        if (end == p) break;
+        ids.push_back((int)v);
+        p = *end == ',' ? end + 1 : end;
+    }
+    if (ids.size() < 2) return NULL;
+    if (mmgpu_init_multi(&m, ids.data(), (int)ids.size()) != 0) {
+        Debug(Debug::ERROR) << "MMGPU: cannot open the devices of MMGPU_DEVICES=" << e << ": " << mmgpu_last_error() << "\n";
+        EXIT(EXIT_FAILURE);
+    }
+    char transport[32] = "";
+    mmgpu_comm_info(mmgpu_multi_ctx(m, 0), NULL, NULL, transport, sizeof(transport));
+    Debug(Debug::INFO) << "MMGPU: " << ids.size() << " device contexts (MMGPU_DEVICES=" << e << "), exchange transport: " << transport << "\n";
+    return m;
 }

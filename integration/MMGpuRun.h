@@ -6,7 +6,11 @@
 //
 // Run-time switches (environment, read once):
 //   MMGPU_DISABLE=1            keep the CPU path everywhere (the binary then behaves like the stock one)
-//   MMGPU_DEVICE=<n>           HIP device of this process (default 0; multi-GPU runs start one process per device)
+//   MMGPU_DEVICE=<n>           HIP device of this process (default 0)
+//   MMGPU_DEVICES=a,b,...      two or more devices for one module call: `prefilter` deals the target database to them by length
+//                              bucket (one k-mer index per device, the hit lists exchanged over the library's RCCL
+//                              communicator, merged lists = the unsplit run's); `align` keeps the targets on every device and
+//                              deals the queries of each block to them
 //   MMGPU_BLOCK_ALIGNER        hits whose score left the uint8 range (s_align::word == 1) take start position, identities and
 //                              backtrace from the block aligner (StripedSmithWaterman.cpp:865-882,943-1127):
 //                                device (default)  the device's block aligner (mmgpu_sw_block_backtrace); what it declines as
@@ -42,6 +46,8 @@ public:
     static size_t envSize(const char *name, size_t fallback);
     // the process-wide context; logs the library's message and EXITs if the device cannot be opened
     static mmgpu_ctx *context();
+    // all devices of MMGPU_DEVICES (two or more ids) as one multi-device object, NULL otherwise (mmgpu_init_multi)
+    static mmgpu_multi *multi();
 };
 
 class MMGpuAlignRun {

@@ -161,6 +161,9 @@ int mmo_nucl_align(const uint8_t *q_num, int qlen, const uint8_t *t_num, int tle
                    const uint8_t *rev_lookup, int gapo, int gape, int zdrop, unsigned diagonal16, int reverse,
                    int past_end_q, int past_end_t, mmo_nucl_result *res, char *bt, int bt_cap);
 
+#ifdef __cplusplus
+extern "C" {
+#endif
 /* ---- block aligner (block_oracle.c): lib/block-aligner 0.4.0, AVX2 configuration, as the reference calls it ---- */
 typedef struct { int32_t score; uint32_t query_idx, reference_idx; } mmo_block_res;
 int mmo_block_align(const uint8_t *q, const int16_t *qbias, int qlen, const uint8_t *r, const int16_t *rbias, int rlen, const int8_t *mat,
@@ -173,5 +176,9 @@ void mmo_block_prefix_scan(const int16_t *v16, int gap, int16_t *out16);
 int mmo_sw_block_backtrace(const uint8_t *q, const int8_t *comp_bias, int qlen, const uint8_t *t, int tlen, const int8_t *mat, int alphabet,
                            int gap_open /* > 0, as the reference's */, int gap_extend, int score, int q_end, int t_end, int *q_start, int *t_start,
                            uint32_t *ident, char *bt, int bt_cap, int *bt_len, int *block_size_used);
+
+#ifdef __cplusplus
+}
+#endif
 
 #endif

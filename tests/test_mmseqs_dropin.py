@@ -585,3 +585,56 @@ def test_compressed_databases_host_side_emulated(tmp_path):
 @pytest.mark.gpu
 def test_compressed_databases_on_device(tmp_path):
     compressed_pipeline(tmp_path, emulate=False)
+
+
+@pytest.mark.gpu
+def test_several_device_contexts_in_one_process(tmp_path):
+    """MMGPU_DEVICES=0,0,0: three device contexts in one `mmseqs` process (the box has one GPU; the library then uses its copy
+    transport instead of RCCL).  `prefilter`: the targets dealt to the contexts by length bucket, one k-mer index each, the hit
+    lists exchanged and merged inside the library - the result database must equal the stock binary's (= the unsplit run).
+    `align -a`: the targets on every context, the queries of each block dealt to them."""
+    w = str(tmp_path)
+    copy_db(EXAMPLES, os.path.join(w, "q"))
+    env = {"MMGPU_DEVICES": "0,0,0"}
+    run(STOCK, ["prefilter", "q", "q", "pref_s", "-s", "5.7", "--threads", THREADS, "-v", "2"], w)
+    log = run(MMGPU, ["prefilter", "q", "q", "pref_g", "-s", "5.7", "--threads", THREADS, "-v", "3"], w, extra_env=env)
+    assert "3 device contexts" in log and "runs on one device" not in log and "using the CPU path" not in log, log[-2000:]
+    assert same(os.path.join(w, "pref_s"), os.path.join(w, "pref_g")) == 500
+    for i, case in enumerate([["-a"], ["--alignment-mode", "2"]]):
+        run(STOCK, ["align", "q", "q", "pref_s", "aln_s%d" % i] + case + ["--threads", THREADS, "-v", "2"], w)
+        log = run(MMGPU, ["align", "q", "q", "pref_s", "aln_g%d" % i] + case + ["--threads", THREADS, "-v", "3"], w, extra_env=env)
+        assert "3 device contexts" in log and "using the CPU path" not in log, log[-2000:]
+        assert same(os.path.join(w, "aln_s%d" % i), os.path.join(w, "aln_g%d" % i)) == 500, case
+
+
+def _block_aligner_modes(tmp, emulate):
+    """int16-range hits (most true homologs): the stock binary of this image runs the RESTATED block aligner behind the crate's C
+    API (integration/build_mmseqs.sh); the patched binary must produce the same databases whichever way it answers those pairs:
+    the device's block aligner (default), the host's alignStartPosBacktraceBlock as a hook, or - with the device declining every
+    pair as too large - the hook behind the device."""
+    w = str(tmp)
+    copy_db(EXAMPLES, os.path.join(w, "q"))
+    run(STOCK, ["prefilter", "q", "q", "pref_s", "-s", "4", "--threads", THREADS, "-v", "2"], w)
+    run(STOCK, ["align", "q", "q", "pref_s", "aln_s", "-a", "--threads", THREADS, "-v", "2"], w)
+    for name, env in (("device", {}), ("host", {"MMGPU_BLOCK_ALIGNER": "host"})):
+        log = run(MMGPU, ["align", "q", "q", "pref_s", "aln_" + name, "-a", "--threads", THREADS, "-v", "3"], w, emulate, extra_env=env)
+        assert "using the CPU path" not in log, log[-2000:]
+        assert same(os.path.join(w, "aln_s"), os.path.join(w, "aln_" + name)) == 500, name
+    if emulate:      # the stand-in declines long pairs like the device does beyond its scratch slot: the hook serves them
+        run(MMGPU, ["align", "q", "q", "pref_s", "aln_mixed", "-a", "--threads", THREADS, "-v", "3"], w, emulate, extra_env={"MMGPU_EMU_REFUSE_BLOCK": "300"})
+        assert same(os.path.join(w, "aln_s"), os.path.join(w, "aln_mixed")) == 500
+    # "sw": the reference's fallback for every int16-range pair - a DIFFERENT (equally scoring) answer for some of them
+    run(MMGPU, ["align", "q", "q", "pref_s", "aln_sw", "-a", "--threads", THREADS, "-v", "3"], w, emulate, extra_env={"MMGPU_BLOCK_ALIGNER": "sw"})
+    n, bad, _ = dbio.diff_dbs(os.path.join(w, "aln_s"), os.path.join(w, "aln_sw"))
+    assert n == 500 and bad > 0
+
+
+def test_block_aligner_modes_host_side_emulated(tmp_path):
+    if not os.path.exists(EMU):
+        pytest.skip("oracle/_build/emu/libmmgpu.so not built (make -C oracle emu)")
+    _block_aligner_modes(tmp_path, emulate=True)
+
+
+@pytest.mark.gpu
+def test_block_aligner_modes_on_device(tmp_path):
+    _block_aligner_modes(tmp_path, emulate=False)
