@@ -96,6 +96,15 @@ def host_cpu_topology():
     return threads, (len(cores) or threads)
 
 
+def cpu_quota_cores():
+    """cores' worth of CPU time the cgroup grants this process (cpu.max = "<quota> <period>"), None if unlimited / unknown"""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        return None
+
+
 def host_limits():
     """What bounds the host side of this box besides its core count: cgroup CPU quota, load, CPU model."""
     out = {}
@@ -148,6 +157,17 @@ def sw_cpu_baseline_lists(matrices, qres, qoff, lists, tres, toff, budget_s, gpu
     if phys_cores != hw_threads:
         sec_p, used_p, _, _ = run(lo, hi, phys_cores, 1)
         runs["one_thread_per_physical_core"] = {"threads": used_p, "seconds": round(sec_p, 3), "gcups": round(cells / sec_p / 1e9, 2)}
+    # a container's CPU quota (cgroup cpu.max) decides how many cores this process really gets: more threads than that only
+    # add contention, so the reference is also run with one and two threads per core of the quota
+    quota = cpu_quota_cores()
+    if quota is not None:
+        for mult in (1, 2):
+            th = int(max(1, min(hw_threads, round(quota * mult))))
+            if all(th != r["threads"] for r in runs.values()):
+                sec_q, used_q, _, _ = run(lo, hi, th, 1)
+                runs["%d_thread%s_per_core_of_the_cpu_quota" % (mult, "" if mult == 1 else "s")] = {
+                    "threads": used_q, "seconds": round(sec_q, 3), "gcups": round(cells / sec_q / 1e9, 2)}
+    timed = [k for k in runs]
     sec_s, used_s, _, _ = run(lo, hi, hw_threads, 0)
     runs["score_and_end_only_all_hardware_threads"] = {"threads": used_s, "seconds": round(sec_s, 3), "gcups": round(cells / sec_s / 1e9, 2)}
     # thread scaling on a slice of the sample: what one thread delivers on this box, and where the box stops scaling
@@ -159,7 +179,7 @@ def sw_cpu_baseline_lists(matrices, qres, qoff, lists, tres, toff, budget_s, gpu
             q_to = lo + (max(8, n_sc // 8) if th == 1 else n_sc)
             sec_t, used_t, _, cells_t = run(lo, q_to, th, 1)
             scaling[str(used_t)] = round(cells_t / sec_t / 1e9, 2)
-    best = max(("all_hardware_threads", "one_thread_per_physical_core"), key=lambda k: runs.get(k, {"gcups": 0})["gcups"])
+    best = max(timed, key=lambda k: runs[k]["gcups"])
     # parity of the timed device run against these results (after the timers)
     a, b = int(l_off[lo]), int(l_off[hi])
     g = np.concatenate([gpu_res[qi] for qi in range(lo, hi)]) if hi > lo else np.zeros(0, gpu_res[0].dtype)
@@ -170,7 +190,9 @@ def sw_cpu_baseline_lists(matrices, qres, qoff, lists, tres, toff, budget_s, gpu
     g_st, r_st = g["q_start"] >= 0, res["q_start"][a:b] >= 0
     both = g_st & r_st
     bad_start = int(np.count_nonzero((g["q_start"] != res["q_start"][a:b]) & both)) + int(np.count_nonzero((g["t_start"] != res["t_start"][a:b]) & both))
-    return {"value": runs[best]["gcups"], "unit": "GCUPS", "cores": phys_cores, "threads": runs[best]["threads"],
+    usable = phys_cores if quota is None else max(1, min(phys_cores, int(round(quota))))
+    return {"value": runs[best]["gcups"], "unit": "GCUPS", "cores": usable, "physical_cores": phys_cores, "cpu_quota_cores": quota,
+            "threads": runs[best]["threads"],
             "hardware_threads": hw_threads, "kind": "reference",
             "gcups_per_thread": round(runs[best]["gcups"] / max(runs[best]["threads"], 1), 3),
             "what": "the reference's own ssw_init + ssw_align (AVX2 striped uint8 pass, int16 re-run, reverse scan for the pairs "
@@ -312,11 +334,17 @@ def module_seconds(args, qres, qoff, tres, toff):
         run(stock, ["createdb", "t.fasta", "t", "-v", "1"])
         out = {"workload": "the headline workload through `mmseqs prefilter -s 5.7` + `mmseqs align --alignment-mode 2 -e 0.001` (what "
                            "`mmseqs search` runs), default flags otherwise (--mask 1, --max-seqs 300), --threads %s" % threads}
-        for name, b in (("stock", stock), ("patched", patched)):
+        stub = os.path.join(ROOT, "oracle", "_ref", "mmseqs_stock_stub")
+        binaries = [("stock", stock), ("patched", patched)] + ([("stock_block_aligner_stubbed", stub)] if os.path.exists(stub) else [])
+        for name, b in binaries:
             tp, log = run(b, ["prefilter", "q", "t", "pref_" + name, "-s", "5.7", "--threads", threads, "-v", "3"])
             ta, _ = run(b, ["align", "q", "t", "pref_" + name, "aln_" + name, "--alignment-mode", "2", "-e", "0.001", "--threads", threads, "-v", "3"])
             out[name] = {"prefilter_wall_s": round(tp, 2), "align_wall_s": round(ta, 2),
                          "queries_per_s_prefilter_plus_align": round((len(qoff) - 1) / (tp + ta), 1)}
+        out["note"] = ("no Rust toolchain in this image: `stock` links the block-aligner crate's C API over a scalar C restatement of the crate "
+                       "(oracle/ref_block_capi.cpp), slower than the crate's AVX2 code; `stock_block_aligner_stubbed` is the same tree with do-nothing "
+                       "stubs, i.e. every int16-range hit takes the reference's Smith-Waterman fallback (rounds 1-2's stock) - the real stock "
+                       "`align` time lies near it")
         n, bad, _ = dbio.diff_dbs(os.path.join(w, "aln_stock"), os.path.join(w, "aln_patched"))
         out["alignment_dbs_identical"] = bad == 0
         out["entries_compared"] = n

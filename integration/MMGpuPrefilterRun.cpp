@@ -93,7 +93,12 @@ void MMGpuPrefilterRun::ensureHostIndex(Prefiltering &p, size_t dbFrom, size_t d
 bool MMGpuPrefilterRun::run(Prefiltering &p, DBWriter &tmpDbw, size_t dbFrom, size_t dbSize, size_t queryFrom, size_t querySize,
                             char *notEmpty, std::list<int> **reslens, size_t localThreads, Debug::Progress &progress,
                             MMGpuPrefilterStats &st) {
-    if (!usable(p)) return false;
+    if (!usable(p)) {
+        // the index may have been left to the device by getIndexTable (deviceBuildsIndex): the reference's loop that runs now
+        // needs the host's
+        ensureHostIndex(p, dbFrom, dbSize);
+        return false;
+    }
     MMGpuStopwatch watch("prefilter");
     mmgpu_ctx *gpu = MMGpuRun::context();
     watch.lap("open device");

@@ -13,7 +13,7 @@
 # Both are checkers / demonstrators of the drop-in (tests/test_mmseqs_dropin.py diffs their result DBs); they are git-ignored
 # and travel to the GPU box with the snapshot.  Uses the reference's CMake files on a scratch copy.
 #
-#   REF=/root/reference  MMGPU_BUILD_DIR=/tmp/mmgpu_mmseqs_build  integration/build_mmseqs.sh [stock|mmgpu|all]
+#   REF=/root/reference  MMGPU_BUILD_DIR=/tmp/mmgpu_mmseqs_build  integration/build_mmseqs.sh [stock|stub|mmgpu|all]
 set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 REPO="$(dirname "$HERE")"
@@ -67,6 +67,19 @@ if [ "$WHAT" = stock ] || [ "$WHAT" = all ]; then
     # for the drop-in tests on the GPU box, where /root/reference does not exist
     rm -rf "$OUT/dropin_data" && mkdir -p "$OUT/dropin_data"
     "$OUT/mmseqs_stock" createdb "$REF/examples/QUERY.fasta" "$OUT/dropin_data/examples" -v 1
+fi
+
+# timing partner only (bench.py `modules`): the stock tree with do-nothing block-aligner stubs, as in rounds 1-2 - every int16-range
+# hit then takes the reference's Smith-Waterman fallback, whose cost is close to the real (AVX2, Rust) crate's; the restated crate
+# above is scalar C and slower
+if [ "$WHAT" = stub ] || [ "$WHAT" = all ]; then
+    if [ -z "${MMGPU_BLOCK_STUB_ONLY:-}" ]; then
+        MMGPU_BLOCK_STUB_ONLY=1 prepare_tree "$WORK/ref_stock_stub"
+        cmake -S "$WORK/ref_stock_stub" -B "$WORK/build_stock_stub" -DHAVE_AVX2=1 -DCMAKE_BUILD_TYPE=Release -DHAVE_TESTS=0 -DHAVE_SHELLCHECK=0 > "$WORK/cmake_stock_stub.log" 2>&1
+        make -C "$WORK/build_stock_stub" -j"$JOBS" mmseqs > "$WORK/make_stock_stub.log" 2>&1 || { tail -30 "$WORK/make_stock_stub.log"; exit 1; }
+        cp "$WORK/build_stock_stub/src/mmseqs" "$OUT/mmseqs_stock_stub"
+        echo "built $OUT/mmseqs_stock_stub"
+    fi
 fi
 
 if [ "$WHAT" = mmgpu ] || [ "$WHAT" = all ]; then

@@ -558,9 +558,10 @@ extern "C" int mmgpu_pf_prepare(mmgpu_ctx *c, const mmgpu_pf_params *par, const 
     b->exchange = exchange;
     b->max_db_matches = std::max<uint64_t>(1000000, db_size) * 2;   // QueryMatcher.cpp:44-45 (dbSize of the WHOLE database)
     // a shard gathers its share of a query's index entries: the unsplit run's overflow path (QueryMatcher.cpp:310-346) is taken
-    // when the shares add up to max_db_matches.  The deal by length bucket is even; a shard treats half its share as the limit,
-    // such queries carry MMGPU_PF_X_INEXACT_ORDER and are re-run unsplit by the caller
-    if (exchange) b->max_db_matches = std::max<uint64_t>(1, b->max_db_matches / (2ull * std::max<uint32_t>(1, c->shard.n_shards)));
+    // when the shares add up to max_db_matches.  If NO shard reaches max_db_matches / n_shards the sum stays below the limit:
+    // a shard that reaches its share flags the query (bit 31 of its exchanged count -> MMGPU_PF_X_INEXACT_ORDER in the merge,
+    // whichever elements survive) and the caller re-runs it unsplit
+    if (exchange) b->max_db_matches = std::max<uint64_t>(1, b->max_db_matches / std::max<uint32_t>(1, c->shard.n_shards));
     b->q_off.assign(nq + 1, 0);
     uint64_t tot = 0;
     for (uint32_t i = 0; i < nq; i++) {
@@ -1006,11 +1007,11 @@ extern "C" int mmgpu_pf_run(mmgpu_ctx *c, mmgpu_pf_batch_t *b) {
     S.q_flags = b->d_qflags.as<uint32_t>();
     S.nucl = b->par.nucleotide ? 1 : 0;
     S.kmer_score = b->par.kmer_score ? 1 : 0;
-    {   // foundDiagonalsSize / 2 over the WHOLE database (QueryMatcher.cpp:44,188); a shard sees its share of the candidates,
-        // the deal by length bucket is even, so a shard flags at half its share (the query is then re-run unsplit)
+    {   // foundDiagonalsSize / 2 over the WHOLE database (QueryMatcher.cpp:44,188); a shard sees its share of the candidates:
+        // if no shard reaches cap / n_shards the total stays below cap, so a shard flags at its share (the query is then re-run unsplit)
         const uint64_t db_all = b->exchange ? c->shard.global_n : c->db.n;
         uint64_t cap = std::max<uint64_t>(1000000, db_all) / 2;
-        if (b->exchange) cap = std::max<uint64_t>(1, cap / (2ull * std::max<uint32_t>(1, c->shard.n_shards)));
+        if (b->exchange) cap = std::max<uint64_t>(1, cap / std::max<uint32_t>(1, c->shard.n_shards));
         if (const char *e = getenv("MMGPU_PF_SORT_CAP")) cap = strtoull(e, nullptr, 10);     // tests: a small database reaches the branch
         S.cand_cap = (uint32_t)std::min<uint64_t>(cap, 0xFFFFFFFFull);
         S.cand_count = (b->par.nucleotide || b->par.kmer_score) ? nullptr : b->d_cand_count.as<uint32_t>();

@@ -1771,7 +1771,11 @@ __global__ __launch_bounds__(256) void pf_select_kernel(PfSelectArgs A) {
     __syncthreads();
     if (XCHG) {
         if (threadIdx.x == 0) {
-            A.hit_count[q] = min(sh_nsel, max_hits);
+            // bit 31 of the exchanged count: this shard saw the query take (or possibly take) a branch of the reference that
+            // depends on the WHOLE database - the databaseHits overflow path (its share of the entries reached its share of the
+            // limit), an unscored long sequence, the unsorted branch.  The merge flags the query whichever elements survive.
+            const bool whole_db = (A.q_nseg != nullptr && A.q_nseg[q] != 0) || (A.q_flags != nullptr && A.q_flags[q] != 0);
+            A.hit_count[q] = min(sh_nsel, max_hits) | (whole_db ? 0x80000000u : 0u);
             A.q_diag_thr[q] = dthr | (trunc ? 0x80000000u : 0u);
         }
         return;

@@ -48,13 +48,16 @@ __global__ __launch_bounds__(256) void pf_xmerge_kernel(PfXMergeArgs A) {
     const uint32_t q = blockIdx.x;
     if (threadIdx.x == 0) {
         uint32_t run = 0;
+        uint32_t any_flag = 0;
         for (uint32_t sp = 0; sp < A.n_shards; sp++) {
             sbase[sp] = run;
-            run += min(A.counts[(size_t)sp * A.nq + q], A.stride);
+            const uint32_t c = A.counts[(size_t)sp * A.nq + q];      // bit 31: the shard's "depends on the whole database" flag
+            any_flag |= c >> 31;
+            run += min(c & 0x7FFFFFFFu, A.stride);
         }
         sbase[A.n_shards] = run;
         sh_nelig = 0;
-        sh_inexact = 0;
+        sh_inexact = any_flag;
     }
     for (int k = (int)threadIdx.x; k < 256; k += 256) hist[k] = 0;
     __syncthreads();

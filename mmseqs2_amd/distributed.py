@@ -156,7 +156,7 @@ def exchange_and_merge_host(xhits, counts, max_hits, min_diag_score, ref_bins, s
     c32 = torch.from_numpy(np.ascontiguousarray(counts).astype(np.int32))
     gh, gc = _all_gather_rows(h32, group), _all_gather_rows(c32, group)
     gh = gh.numpy().reshape(gh.shape[0], nq, stride * 4).view(capi.PF_XHIT_DTYPE).reshape(gh.shape[0], nq, stride)
-    gc = gc.numpy()
+    gc = gc.numpy().astype(np.int64) & 0x7FFFFFFF      # bit 31 of an exchanged count is the shard's "whole database" flag
     out = []
     for q in range(nq):
         rec = np.concatenate([gh[s, q, :gc[s, q]] for s in range(gh.shape[0])])

@@ -335,6 +335,31 @@ int mmgpu_sw_traceback(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const uint32_t *idx, u
     return MMGPU_OK;
 }
 
+// same conversation as mmgpu_sw_traceback: sizing call and real call both travel, the library's code rides in the payload
+int mmgpu_sw_block_backtrace(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const uint32_t *idx, uint32_t n, mmgpu_sw_block *out, char *bt, size_t cap,
+                             size_t *used) {
+    if (!b || (!idx && n) || (!out && n)) return fail(MMGPU_ERR_ARG, "mmgpu_sw_block_backtrace: NULL argument");
+    Buf q, r;
+    q.put<uint64_t>(b->handle);
+    q.put<uint64_t>(bt ? (uint64_t)cap : 0ull);
+    q.put_bytes(idx, (size_t)n * 4);
+    WireHdr h;
+    if (!c || c->fd < 0 || !send_msg(c->fd, OP_SW_BLOCK_BACKTRACE, 0, q.d.data(), q.d.size()) || !recv_msg(c->fd, &h, &r))
+        return fail(MMGPU_ERR_STATE, "mmgpu client: connection to mmgpu_server lost");
+    if (h.status != MMGPU_OK) return fail(h.status, std::string(reinterpret_cast<const char *>(r.d.data()), r.d.size()));
+    const int32_t rc = r.get<int32_t>();
+    const uint64_t u = r.get<uint64_t>();
+    if (used) *used = (size_t)u;
+    size_t nb = 0;
+    const uint8_t *p = r.get_bytes(&nb);
+    if (nb && out) memcpy(out, p, nb);
+    p = r.get_bytes(&nb);
+    if (nb && bt && nb <= cap) memcpy(bt, p, nb);
+    p = r.get_bytes(&nb);
+    if (rc != MMGPU_OK) return fail(rc, std::string(reinterpret_cast<const char *>(p), nb));
+    return MMGPU_OK;
+}
+
 void mmgpu_sw_free(mmgpu_ctx *c, mmgpu_sw_batch_t *b) {
     if (!b) return;
     Buf q;

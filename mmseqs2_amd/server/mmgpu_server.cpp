@@ -9,6 +9,7 @@
 #include <signal.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <new>
 #include <sys/socket.h>
 #include <sys/stat.h>
 #include <sys/un.h>
@@ -118,6 +119,10 @@ bool handle(Server &S, int fd, const WireHdr &h, Buf &in) {
             if (in.bad || nb != ((size_t)n + 1) * 8) return reply_err(fd, h.op, MMGPU_ERR_ARG, "mmgpu_server: malformed LOAD_TARGETS");
             std::vector<uint64_t> o((size_t)n + 1);
             memcpy(o.data(), off, nb);
+            // the offsets must describe exactly the residues that came with them (mmgpu_load_targets reads residues[o[i] .. o[i+1]))
+            bool ok = o[0] == 0 && o[n] == nr;
+            for (uint32_t i = 0; i < n && ok; i++) ok = o[i] <= o[i + 1];
+            if (!ok) return reply_err(fd, h.op, MMGPU_ERR_ARG, "mmgpu_server: LOAD_TARGETS offsets do not match the residues sent");
             drop_batches(S);
             // an empty slot, else a new one while there is room, else the least recently used
             int pick = -1;
@@ -342,7 +347,7 @@ bool handle(Server &S, int fd, const WireHdr &h, Buf &in) {
             }
             return reply(fd, h.op, rc, out);
         }
-        case OP_SW_RUN: case OP_SW_FETCH: case OP_SW_FREE: case OP_SW_TRACEBACK: {
+        case OP_SW_RUN: case OP_SW_FETCH: case OP_SW_FREE: case OP_SW_TRACEBACK: case OP_SW_BLOCK_BACKTRACE: {
             const uint64_t hd = in.get<uint64_t>();
             auto it = S.sw.find(hd);
             if (it == S.sw.end()) return reply_err(fd, h.op, MMGPU_ERR_ARG, "mmgpu_server: unknown alignment batch");
@@ -363,7 +368,21 @@ bool handle(Server &S, int fd, const WireHdr &h, Buf &in) {
             const uint8_t *ip = in.get_bytes(&n);
             std::vector<uint32_t> idx(n / 4);
             if (n) memcpy(idx.data(), ip, n);
-            if (in.bad) return reply_err(fd, h.op, MMGPU_ERR_ARG, "mmgpu_server: malformed SW_TRACEBACK");
+            if (in.bad || cap > MMGPU_WIRE_MAX_MSG) return reply_err(fd, h.op, MMGPU_ERR_ARG, "mmgpu_server: malformed SW_TRACEBACK");
+            if (h.op == OP_SW_BLOCK_BACKTRACE) {
+                std::vector<mmgpu_sw_block> blk(idx.size());
+                std::vector<char> bts((size_t)cap);
+                size_t used_b = 0;
+                const int rcb = mmgpu_sw_block_backtrace(S.ctx, it->second.b, idx.data(), (uint32_t)idx.size(), blk.data(), cap ? bts.data() : nullptr,
+                                                         (size_t)cap, &used_b);
+                out.put<int32_t>(rcb);
+                out.put<uint64_t>((uint64_t)used_b);
+                out.put_bytes(blk.data(), blk.size() * sizeof(mmgpu_sw_block));
+                out.put_bytes(bts.data(), rcb == MMGPU_OK ? std::min<size_t>(used_b, (size_t)cap) : 0);
+                const char *eb = rcb == MMGPU_OK ? "" : mmgpu_last_error();
+                out.put_bytes(eb, strlen(eb));
+                return reply(fd, h.op, MMGPU_OK, out);
+            }
             std::vector<mmgpu_sw_bt> info(idx.size());
             std::vector<char> bt((size_t)cap);
             size_t used = 0;
@@ -432,6 +451,7 @@ int main(int argc, char **argv) {
     strcpy(a.sun_path, path.c_str());
     unlink(path.c_str());
     g_listen = socket(AF_UNIX, SOCK_STREAM, 0);
+    umask(077);      // the socket is created private (chmod below only narrows what an odd umask left)
     if (g_listen < 0 || bind(g_listen, reinterpret_cast<sockaddr *>(&a), sizeof(a)) != 0 || listen(g_listen, 16) != 0) {
         fprintf(stderr, "mmgpu_server: cannot listen on %s: %s\n", path.c_str(), strerror(errno));
         return 1;
@@ -457,8 +477,12 @@ int main(int argc, char **argv) {
         S.st.clients++;
         WireHdr h;
         Buf in;
-        while (g_run && recv_msg(fd, &h, &in)) {
-            if (!handle(S, fd, h, in)) break;
+        try {
+            while (g_run && recv_msg(fd, &h, &in)) {
+                if (!handle(S, fd, h, in)) break;
+            }
+        } catch (const std::bad_alloc &) {      // a request too large for this host: this client loses its connection, the server stays
+            fprintf(stderr, "mmgpu_server: out of host memory while serving a request; connection closed\n");
         }
         close(fd);
         drop_batches(S);       // the database stays resident, the client's batches do not

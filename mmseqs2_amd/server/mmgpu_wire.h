@@ -30,7 +30,8 @@ enum Op : uint32_t {
     OP_HAS_TARGETS, OP_LOAD_TARGETS, OP_HAS_INDEX, OP_LOAD_INDEX,
     OP_PF_PREPARE, OP_PF_RUN, OP_PF_FETCH, OP_PF_FREE,
     OP_SW_PREPARE, OP_SW_RUN, OP_SW_FETCH, OP_SW_TRACEBACK, OP_SW_FREE,
-    OP_BUILD_INDEX, OP_STATS, OP_SHUTDOWN
+    OP_BUILD_INDEX, OP_STATS, OP_SHUTDOWN,
+    OP_SW_BLOCK_BACKTRACE      // appended: the ops above keep their numbers
 };
 
 struct WireHdr {
@@ -127,8 +128,11 @@ inline bool send_msg(int fd, uint32_t op, int32_t status, const void *payload, s
     return write_all(fd, &h, sizeof(h)) && (len == 0 || write_all(fd, payload, len));
 }
 
+// largest message accepted (targets + index of a large database are a few GB)
+static const uint64_t MMGPU_WIRE_MAX_MSG = 1ull << 38;
 inline bool recv_msg(int fd, WireHdr *h, Buf *b) {
     if (!read_all(fd, h, sizeof(*h)) || h->magic != MAGIC) return false;
+    if (h->len > MMGPU_WIRE_MAX_MSG) return false;      // a length no honest client sends: drop the connection, do not allocate
     b->d.resize((size_t)h->len);
     b->rd = 0;
     b->bad = false;

@@ -68,7 +68,7 @@ def _sharded(gpu, g, tres, toff, queries, thr, max_hits, ref_bins, world, identi
     hits = out_h.cpu().numpy().reshape(nq, stride * 3).view(capi.PF_HIT_DTYPE).reshape(nq, stride)
     # the host mirror of the merge kernel must agree with it (it is what the gloo tests use)
     xh = xh_all.cpu().numpy().reshape(world, nq, stride * 4).view(capi.PF_XHIT_DTYPE).reshape(world, nq, stride)
-    xc = xc_all.cpu().numpy()
+    xc = xc_all.cpu().numpy().astype(np.int64) & 0x7FFFFFFF      # bit 31: the shard's "depends on the whole database" flag
     last.free()
     return hits, out_c.cpu().numpy(), out_f.cpu().numpy(), (xh, xc)
 
