@@ -304,7 +304,7 @@ def end_to_end_pass(gpu, matrices, qres, qoff, kmer_thr, max_res, db_residues, f
 
 
 def module_seconds(args, qres, qoff, tres, toff):
-    """Wall seconds of `mmseqs prefilter` and `mmseqs align` (default flags: --mask 1, all host threads) through the stock
+    """Wall seconds of `mmseqs prefilter` and `mmseqs align` (default flags: --mask 1; threads: see below) through the stock
     binary and through the binary with integration/mmseqs_mmgpu.patch, on the headline workload written as FASTA; the two
     alignment databases are compared entry by entry.  Needs oracle/_ref/mmseqs_{stock,mmgpu} (integration/build_mmseqs.sh)."""
     import shutil
@@ -315,7 +315,11 @@ def module_seconds(args, qres, qoff, tres, toff):
     patched = os.path.join(ROOT, "oracle", "_ref", "mmseqs_mmgpu")
     if not (os.path.exists(stock) and os.path.exists(patched)):
         return None
-    threads = str(os.cpu_count() or 1)
+    # threads: what serves the reference best on this box - two per core of the cgroup's CPU quota when there is one (the
+    # thread sweep of cpu_baseline shows more only adds contention), all hardware threads otherwise; the same for both binaries
+    quota = cpu_quota_cores()
+    hw = os.cpu_count() or 1
+    threads = str(hw if quota is None else int(max(1, min(hw, round(2 * quota)))))
     w = tempfile.mkdtemp(prefix="mmgpu_modules_")
     try:
         wl.write_fasta(os.path.join(w, "q.fasta"), qres, qoff, "q")

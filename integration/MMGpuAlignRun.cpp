@@ -153,6 +153,7 @@ bool MMGpuAlignRun::run(Alignment &al, const std::string &outDB, const std::stri
     store.offsets.assign(nTargets + 1, 0);
     for (size_t id = 0; id < nTargets; id++) store.offsets[id + 1] = store.offsets[id] + al.tdbr->getSeqLen(id);
     store.residues.resize(store.offsets[nTargets] + 1);
+    watch.lap("target offsets + host buffer");
     std::vector<Sequence *> qSeqs(threads, NULL), dbSeqs(threads, NULL);
 #pragma omp parallel num_threads(threads)
     {
@@ -171,6 +172,7 @@ bool MMGpuAlignRun::run(Alignment &al, const std::string &outDB, const std::stri
             memcpy(store.residues.data() + store.offsets[id], dbSeq.numSequence, dbSeq.L);
         }
     }
+    watch.lap("map targets");
     // MMGPU_DEVICES: every device holds the targets, the queries of a block are dealt to them (MMGpuMultiDeviceBackend)
     std::vector<mmgpu_ctx *> devices;
     if (mmgpu_multi *multi = MMGpuRun::multi())
@@ -182,7 +184,7 @@ bool MMGpuAlignRun::run(Alignment &al, const std::string &outDB, const std::stri
             EXIT(EXIT_FAILURE);
         }
 
-    watch.lap("map + upload targets");
+    watch.lap("mmgpu_load_targets");
     MMGpuAlignBackend *backend = devices.size() > 1 ? mmgpuNewMultiDeviceBackend(devices) : mmgpuNewDeviceBackend(gpu);
     MMGpuMatcher gpuMatcher(backend, al.m, &evaluer, al.compBiasCorrection, al.compBiasCorrectionScale, al.gapOpen, al.gapExtend);
     const size_t maxMatcherSeqLen = std::max(al.tdbr->getMaxSeqLen(), al.qdbr->getMaxSeqLen());

@@ -1,3 +1,4 @@
+#include <cstring>
 #include "MMGpuPrefilter.h"
 #include "MMGpuRun.h"
 
@@ -16,7 +17,9 @@ unsigned int MMGpuPrefilter::referenceBins(size_t dbsize) {
 MMGpuPrefilter::MMGpuPrefilter(mmgpu_ctx *gpu, BaseMatrix *kmerSubMat, BaseMatrix *ungappedSubMat, bool aaBiasCorrection,
                                float aaBiasCorrectionScale)
     : gpu(gpu), multi(NULL), kmerSubMat(kmerSubMat), ungappedSubMat(ungappedSubMat), aaBiasCorrection(aaBiasCorrection),
-      aaBiasCorrectionScale(aaBiasCorrectionScale), dbSize(0), exactKmerMatching(false), nucleotideSearch(false), kmerScore(false) {}
+      aaBiasCorrectionScale(aaBiasCorrectionScale), dbSize(0), exactKmerMatching(false), nucleotideSearch(false), kmerScore(false) {
+    memset(handedBack, 0, sizeof(handedBack));
+}
 
 bool MMGpuPrefilter::loadIndex(IndexTable *indexTable, SequenceLookup *sequenceLookup, ScoreMatrix &threeMer, ScoreMatrix &twoMer,
                                bool spacedKmer) {
@@ -158,9 +161,13 @@ bool MMGpuPrefilter::matchBlock(const std::vector<Query> &queries, int kmerThr, 
         } else {
             mmgpu_pf_batch_t *batch = NULL;
             rc = mmgpu_pf_prepare(gpu, &par, dq.data() + lo, (uint32_t)(hi - lo), &batch);
+            watch.lap("mmgpu_pf_prepare");
             if (rc == 0) rc = mmgpu_pf_run(gpu, batch);
+            if (rc == 0 && getenv("MMGPU_TRACE") != NULL) mmgpu_synchronize(gpu);     // the lap shows the kernels, not the enqueue
+            watch.lap("mmgpu_pf_run");
             if (rc == 0) rc = mmgpu_pf_fetch(gpu, batch, hits.data() + lo * (size_t)stride, stride, counts.data() + lo, status.data() + lo,
                                              stats ? stats->data() + lo : NULL);
+            watch.lap("mmgpu_pf_fetch");
             if (rc != 0) err = mmgpu_last_error();
             if (batch) mmgpu_pf_free(gpu, batch);
         }
@@ -174,10 +181,10 @@ bool MMGpuPrefilter::matchBlock(const std::vector<Query> &queries, int kmerThr, 
             return false;
         }
     }
-    watch.lap("mmgpu_pf_prepare + run + fetch");
     for (size_t q = 0; q < nq; q++) {
         if (status[q] != MMGPU_PF_OK) {     // MMGPU_PF_OVERFLOW / MMGPU_PF_LONG_SEQ: the host's own matcher runs this query
             needsCpu[q] = true;
+            handedBack[status[q] & 7]++;
             continue;
         }
         results[q].resize(counts[q]);
@@ -189,5 +196,6 @@ bool MMGpuPrefilter::matchBlock(const std::vector<Query> &queries, int kmerThr, 
             o.diagonal = h.diagonal;
         }
     }
+    watch.lap("hit_t lists");
     return true;
 }

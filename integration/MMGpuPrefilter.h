@@ -73,6 +73,9 @@ public:
 
     const std::string &error() const { return err; }
 
+    // queries handed back to the host's matcher so far, by status (MMGPU_PF_OVERFLOW ... MMGPU_PF_SHARD_INEXACT)
+    size_t handedBack[8];
+
 private:
     mmgpu_ctx *gpu;
     mmgpu_multi *multi;

@@ -14,7 +14,9 @@
 #include <climits>
 #include <cstring>
 #include <list>
+#include <functional>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "DBWriter.h"
@@ -141,25 +143,40 @@ bool MMGpuPrefilterRun::run(Prefiltering &p, DBWriter &tmpDbw, size_t dbFrom, si
 
     std::vector<Sequence *> seqs(localThreads, NULL);
     std::vector<QueryMatcher *> cpuMatchers(localThreads, NULL);
-    std::vector<std::vector<unsigned char> > queryNum;
-    std::vector<std::vector<short> > queryProfScore;         // profile queries: copies of the Sequence's profile arrays
-    std::vector<std::vector<unsigned int> > queryProfIndex;
-    std::vector<std::vector<int8_t> > queryProfAln;
-    std::vector<MMGpuPrefilter::Query> block;
-    std::vector<std::vector<hit_t> > results;
-    std::vector<bool> needsCpu;
-    std::vector<mmgpu_pf_qstat> qstats;
+    // Three blocks are in flight: while the device works on block b (matchBlock, on a helper thread: descriptors, kernels,
+    // downloads), this thread finishes block b - 1 (key mapping, coverage gate, DBWriter) and maps the sequences of block b + 1.
+    struct Block {
+        size_t first, nq;
+        std::vector<std::vector<unsigned char> > queryNum;
+        std::vector<std::vector<short> > queryProfScore;         // profile queries: copies of the Sequence's profile arrays
+        std::vector<std::vector<unsigned int> > queryProfIndex;
+        std::vector<std::vector<int8_t> > queryProfAln;
+        std::vector<MMGpuPrefilter::Query> block;
+        std::vector<std::vector<hit_t> > results;
+        std::vector<bool> needsCpu;
+        std::vector<mmgpu_pf_qstat> qstats;
+        bool ok;
+    };
+    Block ring[3];
     double kmersPerPos = 0;
     size_t dbMatches = 0, doubleMatches = 0, querySeqLenSum = 0, resSize = 0, diagonalOverflow = 0;
+    const bool pipelined = !(getenv("MMGPU_PREF_PIPELINE") != NULL && getenv("MMGPU_PREF_PIPELINE")[0] == '0');
 
-    for (size_t next = queryFrom; next < queryFrom + querySize;) {
-        const double tBlock0 = watch.now();
+    auto mapBlock = [&](Block &B, size_t next) {
+        const double t0 = watch.now();
         const size_t nq = std::min(maxBlockQueries, queryFrom + querySize - next);
-        queryNum.assign(nq, std::vector<unsigned char>());
-        queryProfScore.assign(nq, std::vector<short>());
-        queryProfIndex.assign(nq, std::vector<unsigned int>());
-        queryProfAln.assign(nq, std::vector<int8_t>());
-        block.assign(nq, MMGpuPrefilter::Query());
+        B.first = next;
+        B.nq = nq;
+        B.queryNum.assign(nq, std::vector<unsigned char>());
+        B.queryProfScore.assign(nq, std::vector<short>());
+        B.queryProfIndex.assign(nq, std::vector<unsigned int>());
+        B.queryProfAln.assign(nq, std::vector<int8_t>());
+        B.block.assign(nq, MMGpuPrefilter::Query());
+        std::vector<std::vector<unsigned char> > &queryNum = B.queryNum;
+        std::vector<std::vector<short> > &queryProfScore = B.queryProfScore;
+        std::vector<std::vector<unsigned int> > &queryProfIndex = B.queryProfIndex;
+        std::vector<std::vector<int8_t> > &queryProfAln = B.queryProfAln;
+        std::vector<MMGpuPrefilter::Query> &block = B.block;
 #pragma omp parallel num_threads(localThreads)
         {
             unsigned int thread_idx = 0;
@@ -205,21 +222,27 @@ bool MMGpuPrefilterRun::run(Prefiltering &p, DBWriter &tmpDbw, size_t dbFrom, si
                 block[b].identityId = targetSeqId == DB_LOCAL_ID_INVALID ? UINT_MAX : (unsigned int)targetSeqId;
             }
         }
+        watch.add(0, watch.now() - t0);
+    };
 
-        const double tBlock1 = watch.now();
-        watch.add(0, tBlock1 - tBlock0);
-        if (!device.matchBlock(block, p.kmerThr, p.maxResListLen, p.minDiagScoreThr, results, needsCpu, &qstats)) {
-            Debug(Debug::ERROR) << "MMGPU: " << device.error() << "\n";
-            EXIT(EXIT_FAILURE);
-        }
+    auto deviceBlock = [&](Block &B) {
+        const double t0 = watch.now();
+        B.ok = device.matchBlock(B.block, p.kmerThr, p.maxResListLen, p.minDiagScoreThr, B.results, B.needsCpu, &B.qstats);
+        watch.add(1, watch.now() - t0);
+    };
+
+    auto writeBlock = [&](Block &B) {
+        const double t0 = watch.now();
+        const size_t nq = B.nq, next = B.first;
+        std::vector<MMGpuPrefilter::Query> &block = B.block;
+        std::vector<std::vector<hit_t> > &results = B.results;
+        std::vector<bool> &needsCpu = B.needsCpu;
+        std::vector<mmgpu_pf_qstat> &qstats = B.qstats;
         for (size_t b = 0; b < nq; b++)
             if (needsCpu[b]) {      // the reference's matcher needs the reference's index
                 ensureHostIndex(p, dbFrom, dbSize);
                 break;
             }
-        const double tBlock2 = watch.now();
-        watch.add(1, tBlock2 - tBlock1);
-
 #pragma omp parallel num_threads(localThreads)
         {
             unsigned int thread_idx = 0;
@@ -301,12 +324,42 @@ bool MMGpuPrefilterRun::run(Prefiltering &p, DBWriter &tmpDbw, size_t dbFrom, si
                 }
             }
         }
-        next += nq;
-        watch.add(2, watch.now() - tBlock2);
+        watch.add(2, watch.now() - t0);
+    };
+
+    std::vector<size_t> starts;
+    for (size_t next = queryFrom; next < queryFrom + querySize; next += maxBlockQueries) starts.push_back(next);
+    if (!starts.empty()) mapBlock(ring[0], starts[0]);
+    for (size_t k = 0; k < starts.size(); k++) {
+        Block &cur = ring[k % 3];
+        if (pipelined) {
+            std::thread worker(deviceBlock, std::ref(cur));
+            if (k > 0) writeBlock(ring[(k - 1) % 3]);
+            if (k + 1 < starts.size()) mapBlock(ring[(k + 1) % 3], starts[k + 1]);
+            worker.join();
+        } else {
+            deviceBlock(cur);
+            if (k > 0) writeBlock(ring[(k - 1) % 3]);
+            if (k + 1 < starts.size()) mapBlock(ring[(k + 1) % 3], starts[k + 1]);
+        }
+        if (!cur.ok) {
+            Debug(Debug::ERROR) << "MMGPU: " << device.error() << "\n";
+            EXIT(EXIT_FAILURE);
+        }
     }
+    if (!starts.empty()) writeBlock(ring[(starts.size() - 1) % 3]);
     {
         static const char *const names[3] = {"map queries", "device block (bias, prepare, run, fetch)", "serialise + write"};
         watch.report(names, 3);
+    }
+    {
+        size_t back = 0;
+        for (size_t i = 0; i < 8; i++) back += device.handedBack[i];
+        if (back != 0)
+            Debug(Debug::INFO) << "MMGPU: " << back << " of " << querySize << " queries ran through the host's matcher (database-hit buffer flushes beyond the device's: "
+                               << device.handedBack[MMGPU_PF_OVERFLOW] << ", sequences of 32768 residues or more: " << device.handedBack[MMGPU_PF_LONG_SEQ]
+                               << ", candidate array / saturated-diagonal ties: " << device.handedBack[MMGPU_PF_SAT_TIE]
+                               << ", shard-dependent order: " << device.handedBack[MMGPU_PF_SHARD_INEXACT] << ")\n";
     }
     for (size_t i = 0; i < localThreads; i++) {
         delete seqs[i];

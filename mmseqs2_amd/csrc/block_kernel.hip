@@ -26,9 +26,19 @@ __device__ __forceinline__ int adds16(int a, int b) { const int s = a + b; retur
 __device__ __forceinline__ int subs16(int a, int b) { const int s = a - b; return s > 32767 ? 32767 : (s < -32768 ? -32768 : s); }
 __device__ __forceinline__ int sext16(int a) { return (int)(short)a; }
 // simd_sllz_i16!(x, n): byte shift inside each 128-bit half (8 lanes), zeros shifted in (avx2.rs:152-164)
-__device__ __forceinline__ int sllz8(int x, int n, int lane) {
-    const int v = __shfl_up(x, (unsigned)n, 64);
-    return (lane & 7) >= n ? v : 0;
+// (cross-lane moves are DPP row shifts / readlanes, not ds_bpermute: the column loop is one long dependent chain and the
+// LDS-crossbar round trip of a bpermute was most of its latency)
+template <int N>
+__device__ __forceinline__ int sllz8(int x, int lane) {
+    const int v = __builtin_amdgcn_update_dpp(0, x, 0x110 + N /* row_shr:N */, 0xF, 0xF, true);
+    return (lane & 7) >= N ? v : 0;
+}
+// lane 7 of the caller's 16-lane row
+__device__ __forceinline__ int row_lane7(int v, int lane) {
+    const int a = __builtin_amdgcn_readlane(v, 7), b = __builtin_amdgcn_readlane(v, 23), c = __builtin_amdgcn_readlane(v, 39),
+              d = __builtin_amdgcn_readlane(v, 55);
+    const int row = lane >> 4;
+    return row == 0 ? a : (row == 1 ? b : (row == 2 ? c : d));
 }
 // lane - 1's value; lane 0 receives `first`
 __device__ __forceinline__ int shift_up1(int v, int first) {
@@ -38,10 +48,10 @@ __device__ __forceinline__ int shift_up1(int v, int first) {
 struct BkConsts { int gap_all, consts; };   // per lane (lane & 15): avx2.rs:294-309
 
 __device__ __forceinline__ BkConsts bk_consts(int g, int lane) {
-    const int s1 = adds16(sllz8(g, 1, lane), g);
-    const int s2 = adds16(sllz8(s1, 2, lane), s1);
-    const int s4 = adds16(sllz8(s2, 4, lane), s2);
-    const int w7 = __shfl(s4, (lane & ~15) + 7, 64);
+    const int s1 = adds16(sllz8<1>(g, lane), g);
+    const int s2 = adds16(sllz8<2>(s1, lane), s1);
+    const int s4 = adds16(sllz8<4>(s2, lane), s2);
+    const int w7 = row_lane7(s4, lane);
     BkConsts c;
     c.gap_all = adds16((lane & 15) < 8 ? 0 : w7, s4);
     c.consts = s4;
@@ -50,12 +60,14 @@ __device__ __forceinline__ BkConsts bk_consts(int g, int lane) {
 
 // simd_prefix_scan_i16 (avx2.rs:311-337) on every 16-lane row of the wavefront
 __device__ __forceinline__ int bk_prefix_scan(int R, int g, int consts, int lane) {
-    const int s1 = max(R, adds16(sllz8(R, 1, lane), g));
-    const int s2 = max(s1, adds16(sllz8(s1, 2, lane), sext16(g << 1)));
-    const int s4 = max(s2, adds16(sllz8(s2, 4, lane), sext16(g << 2)));
+    const int s1 = max(R, adds16(sllz8<1>(R, lane), g));
+    const int s2 = max(s1, adds16(sllz8<2>(s1, lane), sext16(g << 1)));
+    const int s4 = max(s2, adds16(sllz8<4>(s2, lane), sext16(g << 2)));
     const int k = lane & 15;
-    const int src = k < 4 ? lane : (k < 8 ? lane - 4 : (lane & ~15) + 7);
-    const int c1 = adds16(__shfl(s4, src, 64), consts);
+    // source lane: itself (k < 4), four lanes down (k < 8), lane 7 of the row (k >= 8)
+    const int down4 = __builtin_amdgcn_update_dpp(0, s4, 0x114 /* row_shr:4 */, 0xF, 0xF, true);
+    const int from = k < 4 ? s4 : (k < 8 ? down4 : row_lane7(s4, lane));
+    const int c1 = adds16(from, consts);
     return max(s4, c1);
 }
 
@@ -101,8 +113,7 @@ __device__ __forceinline__ BkMax bk_place_block(const BlockLaunch &L, const int8
             const int D10 = act ? (int)D_col[i] : BK_MIN, C10 = act ? (int)C_col[i] : BK_MIN;
             const int D00 = shift_up1(D10, corner);
             const int last = min(63, height - 1 - (it << 6));
-            corner = __builtin_amdgcn_readlane(D10, 63);
-            if (last < 63) corner = __shfl(D10, last, 64);
+            corner = __builtin_amdgcn_readlane(D10, last);
             const int ql = bk_letter(query, start_i + i);
             const int sc = (int)scores[c * 32 + (ql & 31)];
             const int pos_bias = adds16(rbias, bk_bias(query, start_i + i));
@@ -118,12 +129,12 @@ __device__ __forceinline__ BkMax bk_place_block(const BlockLaunch &L, const int8
             for (int ch = 0; ch < 4; ch++) {
                 const int add = adds16(carryR, K.gap_all);
                 if ((lane >> 4) == ch) R11 = max(R11, add);
-                if ((it << 6) + ch * 16 < height) carryR = __shfl(R11, ch * 16 + 15, 64);
+                if ((it << 6) + ch * 16 < height) carryR = __builtin_amdgcn_readlane(R11, ch * 16 + 15);
             }
             D11 = max(D11, R11);
             const bool tempR = R11 == D11_open;
             const int trR = shift_up1(tempR ? 1 : 0, carry_tr);
-            carry_tr = __shfl(tempR ? 1 : 0, last, 64);
+            carry_tr = __builtin_amdgcn_readlane(tempR ? 1 : 0, last);
             const unsigned long long bDC = __ballot(act && D11 == C11), bDR = __ballot(act && D11 == R11);
             const unsigned long long bCO = __ballot(act && C11 == C11_open), bTR = __ballot(act && trR != 0);
             if (S.trace_idx >= S.trace_cap) S.overflow = true;
@@ -140,7 +151,7 @@ __device__ __forceinline__ BkMax bk_place_block(const BlockLaunch &L, const int8
             }
         }
         const int lastl = (height - 1) & 63;
-        const int dl = __shfl(D11, lastl, 64), rl = __shfl(R11, lastl, 64);
+        const int dl = __builtin_amdgcn_readlane(D11, lastl), rl = __builtin_amdgcn_readlane(R11, lastl);
         if (lane == 0) { D_row[j] = (int16_t)dl; R_row[j] = (int16_t)rl; }
         D_corner = BK_MIN;
     }
@@ -160,8 +171,13 @@ __device__ __forceinline__ BkMax bk_fold_vector_lanes(BkMax m) {
     return m;
 }
 __device__ __forceinline__ int bk_wave_max(int v) {
-    for (int d = 1; d < 64; d <<= 1) v = max(v, __shfl_xor(v, d, 64));
-    return v;
+    // inclusive max scan along every 16-lane row (lanes without a source keep their own value), then the four row ends
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x111 /* row_shr:1 */, 0xF, 0xF, false));
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x112 /* row_shr:2 */, 0xF, 0xF, false));
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x114 /* row_shr:4 */, 0xF, 0xF, false));
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x118 /* row_shr:8 */, 0xF, 0xF, false));
+    return max(max(__builtin_amdgcn_readlane(v, 15), __builtin_amdgcn_readlane(v, 31)),
+               max(__builtin_amdgcn_readlane(v, 47), __builtin_amdgcn_readlane(v, 63)));
 }
 
 __device__ __forceinline__ void bk_add_block(BkState &S, int i, int j, int width, int height, int right, int lane) {

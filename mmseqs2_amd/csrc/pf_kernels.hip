@@ -26,6 +26,8 @@
 //     target; a workgroup per query selects the top max_hits by (score, CPU bin order, arrival index) with a
 //     radix select and sorts them.
 // Integer/byte work throughout: no MFMA; the rooflines are HBM (gather, split) and LDS/VALU issue (replay).
+#include <type_traits>
+
 #include "mmgpu_internal.h"
 
 namespace mmgpu {
@@ -35,13 +37,33 @@ namespace {
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 __device__ __forceinline__ uint64_t lanes_below(int lane) { return (1ull << lane) - 1ull; }
 
+// Inclusive scans over the wavefront with DPP moves (row shifts inside the 16-lane rows, then the row ends handed to the
+// following rows): six VALU operations instead of six ds_bpermute round trips.
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
-    const int lane = lane_id();
-#pragma unroll
+#ifdef MMGPU_PF_OLD_SCAN
+    const int lane_ = lane_id();
     for (int d = 1; d < 64; d <<= 1) {
         const uint32_t t = __shfl_up(v, d);
-        if (lane >= d) v += t;
+        if (lane_ >= d) v += t;
     }
+    return v;
+#endif
+    int x = (int)v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111 /* row_shr:1 */, 0xF, 0xF, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112 /* row_shr:2 */, 0xF, 0xF, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114 /* row_shr:4 */, 0xF, 0xF, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118 /* row_shr:8 */, 0xF, 0xF, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142 /* row_bcast:15 */, 0xA, 0xF, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143 /* row_bcast:31 */, 0xC, 0xF, false);
+    return (uint32_t)x;
+}
+__device__ __forceinline__ int wave_incl_max_scan(int v) {      // v >= 0
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false));
     return v;
 }
 
@@ -59,6 +81,7 @@ __device__ __forceinline__ int seg_find(uint32_t start_mine, uint32_t x) {
 
 // Lanes of the wave whose `key` (low nbits) equals mine, among lanes with active == true.
 __device__ __forceinline__ uint64_t match_lanes(uint32_t key, int nbits, bool active) {
+#ifdef MMGPU_PF_OLD_MATCH
     uint64_t m = __ballot(active);
     for (int b = 0; b < nbits; b++) {
         const bool bit = (key >> b) & 1u;
@@ -66,6 +89,18 @@ __device__ __forceinline__ uint64_t match_lanes(uint32_t key, int nbits, bool ac
         m &= bit ? bal : ~bal;
     }
     return m;
+#endif
+    const uint64_t act = __ballot(active);
+    uint32_t lo = (uint32_t)act, hi = (uint32_t)(act >> 32);
+    for (int b = 0; b < nbits; b++) {
+        // per bit: m &= (my bit set ? lanes with the bit : lanes without) = m & ~(ballot ^ my bit spread over the word):
+        // one v_bfe_i32, one compare, one v_bitop3 per half
+        const int ext = __builtin_amdgcn_sbfe((int)key, (unsigned)b, 1u);      // 0 or -1
+        const uint64_t bal = __ballot(ext != 0);
+        lo = __builtin_amdgcn_bitop3_b32(lo, (uint32_t)bal, (uint32_t)ext, 0x90);
+        hi = __builtin_amdgcn_bitop3_b32(hi, (uint32_t)(bal >> 32), (uint32_t)ext, 0x90);
+    }
+    return (uint64_t)lo | ((uint64_t)hi << 32);
 }
 
 __device__ __forceinline__ int highest_lane(uint64_t m) { return 63 - __clzll((long long)m); }
@@ -478,11 +513,28 @@ __global__ __launch_bounds__(256) void pf_scan_kernel(const uint32_t *in, const 
 // arrival-ordered index entries of one query.  Gathers (seqId, position_j) -> (id, diagonal = i - j), splits the
 // tile stably by bin = id & (B-1), writes it grouped by bin plus the B+1 bin offsets of the tile.
 // Entry word: id | diagonal << 32 | slot-in-tile << 48  (slot = arrival index - tile start).
-__global__ __launch_bounds__(256) void pf_split_kernel(PfSplitArgs A) {
+#ifndef MMGPU_PF_SPLIT_PAD
+#define MMGPU_PF_SPLIT_PAD 0
+#endif
+#ifndef MMGPU_PF_SPLIT_WAVES
+#define MMGPU_PF_SPLIT_WAVES 8
+#endif
+// Wavefronts per tile.  The kernel waits on dependent LDS / cross-lane / gather latencies, so its throughput follows the
+// number of resident wavefronts (measured: half the occupancy = 1.65x the time); the tile's 32 KB stage allows four
+// workgroups per CU, eight wavefronts each fill the SIMDs' eight slots (the per-(wave, bin) counters are 16 bit for that).
+constexpr int SPW = MMGPU_PF_SPLIT_WAVES;
+#ifndef MMGPU_PF_SPLIT_EU
+#define MMGPU_PF_SPLIT_EU 6
+#endif
+__global__ __launch_bounds__(SPW * 64) __attribute__((amdgpu_waves_per_eu(MMGPU_PF_SPLIT_EU))) void pf_split_kernel(PfSplitArgs A) {
+#if MMGPU_PF_SPLIT_PAD
+    __shared__ volatile uint32_t s_pad[MMGPU_PF_SPLIT_PAD / 4];      // occupancy experiment
+    if (A.bins == 0xFFFFFFFFu) s_pad[threadIdx.x] = 1;
+#endif
     __shared__ uint64_t stage[PF_T];
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
-    uint32_t *cnt = reinterpret_cast<uint32_t *>(dyn_lds);   // [4][B]
-    __shared__ uint32_t wsum[4];
+    uint16_t *cnt = reinterpret_cast<uint16_t *>(dyn_lds);   // [SPW][B]: counts <= PF_T / SPW, then tile offsets < PF_T
+    __shared__ uint32_t wsum[SPW];
     const uint32_t B = A.bins;
     const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
     const uint32_t t = blockIdx.x;
@@ -492,11 +544,11 @@ __global__ __launch_bounds__(256) void pf_split_kernel(PfSplitArgs A) {
     const uint32_t tile_n = min((uint32_t)PF_T, q_entries - a0);
     const uint32_t qp0 = A.q_off[q], qlen = A.q_off[q + 1] - qp0;
 
-    for (uint32_t k = threadIdx.x; k < 4 * B; k += 256) cnt[k] = 0;
+    for (uint32_t k = threadIdx.x; k < (uint32_t)SPW * B; k += (uint32_t)SPW * 64u) cnt[k] = 0;
 
-    // ---- phase A: gather this wave's quarter of the tile into `stage`, arrival order ----
-    const uint32_t wa = a0 + (uint32_t)wave * (PF_T / 4);
-    const uint32_t wb = min(a0 + tile_n, wa + PF_T / 4);
+    // ---- phase A: gather this wave's share of the tile into `stage`, arrival order ----
+    const uint32_t wa = a0 + (uint32_t)wave * (PF_T / SPW);
+    const uint32_t wb = min(a0 + tile_n, wa + PF_T / SPW);
     if (wa < wb) {
         // position holding arrival index wa (largest p with peb[p] <= wa), then the list inside it
         const uint32_t pidx = wave_search_le(A.pos_entry_base + qp0, 1, 0, qlen - 1, wa);
@@ -558,13 +610,13 @@ __global__ __launch_bounds__(256) void pf_split_kernel(PfSplitArgs A) {
     // ---- phase B: per-(wave, bin) counts and each entry's rank inside its (wave, bin) ----
     int nbits = 0;
     while ((1u << nbits) < B) nbits++;
-    constexpr int ROUNDS = PF_T / 256;   // entries per thread
+    constexpr int ROUNDS = PF_T / (64 * SPW);   // entries per thread
     uint64_t ent[ROUNDS];
     uint32_t rk[ROUNDS];
-    uint32_t *mycnt = cnt + (uint32_t)wave * B;
+    uint16_t *mycnt = cnt + (uint32_t)wave * B;
 #pragma unroll
     for (int r = 0; r < ROUNDS; r++) {
-        const uint32_t slot = (uint32_t)wave * (PF_T / 4) + (uint32_t)r * 64u + (uint32_t)lane;
+        const uint32_t slot = (uint32_t)wave * (PF_T / SPW) + (uint32_t)r * 64u + (uint32_t)lane;
         const bool valid = slot < tile_n;
         ent[r] = valid ? stage[slot] : 0ull;
         const uint32_t bin = (uint32_t)ent[r] & (B - 1);
@@ -573,7 +625,7 @@ __global__ __launch_bounds__(256) void pf_split_kernel(PfSplitArgs A) {
         uint32_t c = 0;
         if (valid) c = mycnt[bin];
         rk[r] = c + rank;
-        if (valid && rank == 0) mycnt[bin] = c + (uint32_t)__popcll(m);
+        if (valid && rank == 0) mycnt[bin] = (uint16_t)(c + (uint32_t)__popcll(m));
     }
     __syncthreads();
 
@@ -584,7 +636,7 @@ __global__ __launch_bounds__(256) void pf_split_kernel(PfSplitArgs A) {
         uint32_t s = 0;
         if (b0 < B)
             for (uint32_t b = b0; b < b0 + bpt; b++)
-                for (int w = 0; w < 4; w++) s += cnt[(uint32_t)w * B + b];
+                for (int w = 0; w < SPW; w++) s += cnt[(uint32_t)w * B + b];
         const uint32_t incl = wave_incl_scan(s);
         if (lane == 63) wsum[wave] = incl;
         __syncthreads();
@@ -595,9 +647,9 @@ __global__ __launch_bounds__(256) void pf_split_kernel(PfSplitArgs A) {
             for (uint32_t b = b0; b < b0 + bpt; b++) {
                 bo[b] = (uint16_t)run;
                 uint32_t tot = 0;
-                for (int w = 0; w < 4; w++) {
+                for (int w = 0; w < SPW; w++) {
                     const uint32_t c = cnt[(uint32_t)w * B + b];
-                    cnt[(uint32_t)w * B + b] = run + tot;
+                    cnt[(uint32_t)w * B + b] = (uint16_t)(run + tot);
                     tot += c;
                 }
                 if (tot) atomicAdd(&A.bucket_count[(size_t)q * B + b], tot);
@@ -611,7 +663,7 @@ __global__ __launch_bounds__(256) void pf_split_kernel(PfSplitArgs A) {
     // ---- phase C: stable scatter inside LDS (every entry is in a register now), then coalesced write-out ----
 #pragma unroll
     for (int r = 0; r < ROUNDS; r++) {
-        const uint32_t slot = (uint32_t)wave * (PF_T / 4) + (uint32_t)r * 64u + (uint32_t)lane;
+        const uint32_t slot = (uint32_t)wave * (PF_T / SPW) + (uint32_t)r * 64u + (uint32_t)lane;
         if (slot < tile_n) {
             const uint32_t bin = (uint32_t)ent[r] & (B - 1);
             stage[mycnt[bin] + rk[r]] = ent[r];
@@ -619,7 +671,7 @@ __global__ __launch_bounds__(256) void pf_split_kernel(PfSplitArgs A) {
     }
     __syncthreads();
     uint64_t *dst = A.split + (size_t)t * PF_T;
-    for (uint32_t s = threadIdx.x; s < tile_n; s += 256) dst[s] = stage[s];
+    for (uint32_t s = threadIdx.x; s < tile_n; s += (uint32_t)SPW * 64u) dst[s] = stage[s];
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -858,33 +910,64 @@ __device__ __forceinline__ uint64_t score_chunk(const PfDedupArgs &A, const int8
 // a7: one wavefront per (query, bin), four per workgroup: replay of the bin's entries in arrival order.
 // Per target the CPU keeps `prev` = low byte of the previous entry's diagonal (zero-initialised,
 // CacheFriendlyOperations.cpp:186-208) and emits an entry whose byte equals it; the emitted list is then run-length
-// de-duplicated per target on that byte (:240-265).  State per target in LDS: uint16 = prev | last emitted byte << 8,
-// plus one "has emitted" bit (8.5 KB per wavefront).  Output: candidates (id, diagonal, arrival index) in arrival
+// de-duplicated per target on that byte (:240-265).  Output: candidates (id, diagonal, arrival index) in arrival
 // order at cand[cand_base[bucket] ..), their number in cand_count[bucket].
-__global__ __launch_bounds__(256) void pf_replay_kernel(PfDedupArgs A) {
-    __shared__ uint16_t s_state[4][PF_IDS_PER_BIN];
-    __shared__ uint32_t s_emit[4][PF_IDS_PER_BIN / 32];
-    __shared__ uint32_t s_cand[4][3][64];   // first 64 candidates of the bucket: id, arrival index, diagonal
-    __shared__ int8_t smat[32 * 32];
+//
+// The kernel waits on chains of LDS and cross-lane operations, so its throughput follows the number of resident wavefronts
+// (measured: half the occupancy = 1.74x the time), and LDS is what bounds them.  Two forms of the per-target state:
+//   COMPACT: `prev` as one byte per target (4 KB) + one "has emitted" bit; the byte last emitted is only kept for the targets
+//            that HAVE emitted - a handful per bucket - in a table of PF_EMIT_TAB (key, byte) pairs, one per lane.  5.8 KB per
+//            wavefront: six workgroups per CU.  A bucket with more emitting targets than the table holds is put on the
+//            redo list.
+//   full:    uint16 = prev | last emitted byte << 8 for every target (8.5 KB per wavefront); runs the redo list.
+#ifndef MMGPU_PF_REPLAY_PD
+#define MMGPU_PF_REPLAY_PD 1
+#endif
+#ifndef MMGPU_PF_REPLAY_EU
+#define MMGPU_PF_REPLAY_EU 6
+#endif
+constexpr int PF_EMIT_TAB = 64;
+
+template <bool COMPACT>
+struct ReplayLds {
+    typename std::conditional<COMPACT, uint8_t, uint16_t>::type state[4][PF_IDS_PER_BIN];
+    uint32_t emit[4][PF_IDS_PER_BIN / 32];
+    uint32_t tab[COMPACT ? 4 : 1][COMPACT ? PF_EMIT_TAB : 1];   // key << 8 | byte last emitted
+    uint32_t cand[4][3][64];   // first 64 candidates of the bucket: id, arrival index, diagonal
+    uint8_t mark[4][64];       // segment starts of a round (request)
+    int8_t smat[32 * 32];
+};
+
+// returns false when the bucket has to be redone with the full state (COMPACT only)
+template <bool COMPACT>
+__device__ __forceinline__ bool replay_bucket(const PfDedupArgs &A, ReplayLds<COMPACT> &M, uint64_t bucket) {
     const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
-    for (int k = (int)threadIdx.x; k < 32 * 32; k += 256) smat[k] = k < A.alphabet * A.alphabet ? A.mat[k] : (int8_t)0;
-    __syncthreads();
     const uint32_t B = A.bins;
-    const uint64_t bucket = (uint64_t)A.q_first * B + (uint64_t)blockIdx.x * 4u + (uint32_t)wave;
-    if (bucket >= (uint64_t)(A.q_first + A.n_queries) * B) return;
     const uint32_t q = (uint32_t)(bucket / B), bin = (uint32_t)(bucket % B);
     const uint32_t ntiles = A.q_ntiles[q];
     if (ntiles == 0) {
         if (lane == 0) A.cand_count[bucket] = 0;
-        return;
+        return true;
     }
     const uint32_t tb = A.q_tile_base[q];
-    uint16_t *S = s_state[wave];
-    uint32_t *E = s_emit[wave];
+    auto *S = M.state[wave];
+    uint32_t *E = M.emit[wave];
+    uint32_t *T = M.tab[COMPACT ? wave : 0];
+    uint8_t *mark = M.mark[wave];
     int bshift = 0;
     while ((1u << bshift) < B) bshift++;
-    for (int k = lane; k < PF_IDS_PER_BIN; k += 64) S[k] = 0;
-    for (int k = lane; k < PF_IDS_PER_BIN / 32; k += 64) E[k] = 0;
+    auto clear_state = [&]() {
+        if (COMPACT) {
+            uint32_t *S4 = reinterpret_cast<uint32_t *>(S);
+            for (int k = lane; k < PF_IDS_PER_BIN / 4; k += 64) S4[k] = 0;
+        } else {
+            for (int k = lane; k < PF_IDS_PER_BIN; k += 64) S[k] = 0;
+        }
+        for (int k = lane; k < PF_IDS_PER_BIN / 32; k += 64) E[k] = 0;
+    };
+    clear_state();
+    uint32_t nem = 0;                 // COMPACT: entries of the emitter table
+    const uint32_t emit_cap = COMPACT ? min((uint32_t)PF_EMIT_TAB, A.emit_cap) : 0u;
 
     uint32_t ncand = 0;
     const uint64_t below = lanes_below(lane);
@@ -902,28 +985,56 @@ __global__ __launch_bounds__(256) void pf_replay_kernel(PfDedupArgs A) {
         const uint32_t incl = wave_incl_scan(n);
         const uint32_t total = __shfl(incl, 63);
         const uint32_t excl = incl - n;
-        // software pipeline: the entry of round r+1 is requested before round r is processed
-        uint64_t e_next = 0;
-        uint32_t tile_next = 0;
-        {
-            const uint32_t x = (uint32_t)lane;
-            const int m = seg_find(excl, x);
-            const uint32_t ex_m = __shfl(excl, m), o_m = __shfl(o0, m);
-            tile_next = t0 + (uint32_t)m;
-            if (x < total) e_next = A.split[(size_t)(tb + tile_next) * PF_T + o_m + (x - ex_m)];
-        }
-        for (uint32_t x0 = 0; x0 < total; x0 += 64) {
-            const uint64_t e = e_next;
-            const uint32_t tile_cur = tile_next;
-            const bool act = x0 + (uint32_t)lane < total;
-            if (x0 + 64 < total) {
-                const uint32_t x = x0 + 64 + (uint32_t)lane;
-                const int m = seg_find(excl, x);
-                const uint32_t ex_m = __shfl(excl, m), o_m = __shfl(o0, m);
-                tile_next = t0 + (uint32_t)m;
-                e_next = 0;
-                if (x < total) e_next = A.split[(size_t)(tb + tile_next) * PF_T + o_m + (x - ex_m)];
+        // software pipeline: the entries of the next MMGPU_PF_REPLAY_PD rounds are in flight while a round is processed
+        // (one round ahead is enough: deeper pipelines measured the same)
+        uint64_t e_q[MMGPU_PF_REPLAY_PD];
+        uint32_t tile_q[MMGPU_PF_REPLAY_PD];
+        // Tile whose segment holds the bucket's entry x, for the 64 entries of a round at once (rounds are requested in
+        // increasing order): every tile whose non-empty segment starts inside the round marks its slot, a running maximum
+        // along the lanes spreads the marks, the segment that reaches into the round from before is the last one of the
+        // previous request.  (A search over the segment starts costs six dependent cross-lane round trips per round.)
+        int m_carry = 0;
+        const uint32_t seg_delta = o0 - excl;      // entry x of the bucket is entry x + seg_delta of its tile
+        auto request = [&](uint32_t xr, uint64_t &e_out, uint32_t &tile_out) {
+            const uint32_t x = xr + (uint32_t)lane;
+#ifdef MMGPU_PF_OLD_SEGFIND
+            {
+                const int m0 = seg_find(excl, x);
+                const uint32_t d0 = (uint32_t)__shfl((int)seg_delta, m0);
+                tile_out = t0 + (uint32_t)m0;
+                e_out = 0;
+                if (x < total) e_out = A.split[(size_t)(tb + tile_out) * PF_T + (uint32_t)(x + d0)];
+                return;
             }
+#endif
+            mark[lane] = 0;
+            const uint32_t rel = excl - xr;
+            if (n != 0u && rel < 64u) mark[rel] = (uint8_t)lane;
+            // (another lane's mark may sit in this lane's slot: the compiler must not forward this lane's own zero to the load)
+            asm volatile("" ::: "memory");
+            int m = (int)mark[lane];
+            m = max(wave_incl_max_scan(m), m_carry);
+            m_carry = __builtin_amdgcn_readlane(m, 63);
+            const uint32_t d_m = (uint32_t)__shfl((int)seg_delta, m);
+            tile_out = t0 + (uint32_t)m;
+            e_out = 0;
+            if (x < total) e_out = A.split[(size_t)(tb + tile_out) * PF_T + (uint32_t)(x + d_m)];      // (the sum wraps in 32 bits)
+        };
+#pragma unroll
+        for (int k = 0; k < MMGPU_PF_REPLAY_PD; k++) {
+            e_q[k] = 0;
+            tile_q[k] = 0;
+            if ((uint32_t)k * 64u < total) request((uint32_t)k * 64u, e_q[k], tile_q[k]);
+        }
+        for (uint32_t xg = 0; xg < total; xg += 64u * MMGPU_PF_REPLAY_PD) {
+#pragma unroll
+          for (int pk = 0; pk < MMGPU_PF_REPLAY_PD; pk++) {
+            const uint32_t x0 = xg + 64u * (uint32_t)pk;
+            if (x0 >= total) break;
+            const uint64_t e = e_q[pk];
+            const uint32_t tile_cur = tile_q[pk];
+            const bool act = x0 + (uint32_t)lane < total;
+            if (x0 + 64u * MMGPU_PF_REPLAY_PD < total) request(x0 + 64u * MMGPU_PF_REPLAY_PD, e_q[pk], tile_q[pk]);
             const uint32_t id = (uint32_t)e;
             const uint32_t diag = (uint32_t)(e >> 32) & 0xFFFFu;
             const uint32_t d8 = diag & 0xFFu;
@@ -954,13 +1065,55 @@ __global__ __launch_bounds__(256) void pf_replay_kernel(PfDedupArgs A) {
                     const uint64_t fbelow = fm & below;
                     const int fpl = fbelow ? highest_lane(fbelow) : lane;
                     const uint32_t d_fpl = __shfl(d8, fpl);
-                    bool keep;
-                    if (fbelow) keep = flag && d_fpl != d8;
-                    else keep = flag && (em == 0u || ((st >> 8) & 0xFFu) != d8);
-                    // state update by the last lane of every target group
+                    const bool group_last = now && (same & ~below & ~(1ull << lane)) == 0;   // last lane of its target
                     const int fhi = fm ? highest_lane(fm) : lane;
                     const uint32_t d_fhi = __shfl(d8, fhi);
-                    if (now && (same & ~below & ~(1ull << lane)) == 0) {
+                    uint32_t last_emitted = (st >> 8) & 0xFFu;       // full state; COMPACT: from the table
+                    uint32_t tab_idx = 0;
+                    if (COMPACT) {
+                        // targets of this round that emit again: their group's last lane looks the table entry up, the
+                        // group's first flagged lane (the one the byte decides for) reads it from there
+                        const uint64_t again = __ballot(group_last && fm != 0 && em != 0u);
+                        uint32_t lb_mine = 0;
+                        if (again) {
+                            asm volatile("" ::: "memory");      // the table is written by other lanes
+                            const uint32_t tv = T[lane];
+                            uint64_t w = again;
+                            while (w) {
+                                const int l = __ffsll((long long)w) - 1;
+                                w &= w - 1;
+                                const uint32_t k = (uint32_t)__shfl((int)key, l);
+                                const uint64_t hit = __ballot((uint32_t)lane < nem && (tv >> 8) == k);
+                                const int idx = hit ? __ffsll((long long)hit) - 1 : 0;     // an emitter is in the table
+                                const uint32_t v = (uint32_t)__shfl((int)tv, idx);
+                                if (lane == l) {
+                                    lb_mine = v & 0xFFu;
+                                    tab_idx = (uint32_t)idx;
+                                }
+                            }
+                        }
+                        last_emitted = (uint32_t)__shfl((int)lb_mine, highest_lane(same | (1ull << lane)));
+                    }
+                    bool keep;
+                    if (fbelow) keep = flag && d_fpl != d8;
+                    else keep = flag && (em == 0u || last_emitted != d8);
+                    // state update by the last lane of every target group
+                    if (COMPACT) {
+                        const bool fresh = group_last && fm != 0 && em == 0u;
+                        const uint64_t fb = __ballot(fresh);
+                        if (nem + (uint32_t)__popcll(fb) > emit_cap) return false;      // wave-uniform
+                        if (group_last) {
+                            S[key] = (uint8_t)d8;
+                            if (fm) {
+                                if (em == 0u) {
+                                    tab_idx = nem + (uint32_t)__popcll(fb & below);
+                                    atomicOr(&E[key >> 5], 1u << (key & 31u));
+                                }
+                                T[tab_idx] = (key << 8) | d_fhi;
+                            }
+                        }
+                        nem += (uint32_t)__popcll(fb);
+                    } else if (group_last) {
                         uint32_t ns = d8;
                         if (fm) {
                             ns |= d_fhi << 8;
@@ -981,21 +1134,22 @@ __global__ __launch_bounds__(256) void pf_replay_kernel(PfDedupArgs A) {
                         const uint32_t ck = ncand + (uint32_t)__popcll(kb & below);
                         *cand_slot(A, bucket, ck) = c;
                         if (ck < 64) {
-                            s_cand[wave][0][ck] = c.id;
-                            s_cand[wave][1][ck] = c.arr;
-                            s_cand[wave][2][ck] = diag;
+                            M.cand[wave][0][ck] = c.id;
+                            M.cand[wave][1][ck] = c.arr;
+                            M.cand[wave][2][ck] = diag;
                         }
                     }
                     ncand += (uint32_t)__popcll(kb);
                 }
                 todo &= ~__ballot(now);
                 if (todo) {   // the remaining entries belong to the next segment: fresh state
-                    for (int k = lane; k < PF_IDS_PER_BIN; k += 64) S[k] = 0;
-                    for (int k = lane; k < PF_IDS_PER_BIN / 32; k += 64) E[k] = 0;
+                    clear_state();
+                    nem = 0;
                     cur_seg++;
                     next_boundary = cur_seg + 1 <= nseg ? segs[cur_seg + 1] : 0xFFFFFFFFu;
                 }
             }
+          }
         }
     }
     if (lane == 0) A.cand_count[bucket] = ncand;
@@ -1005,16 +1159,37 @@ __global__ __launch_bounds__(256) void pf_replay_kernel(PfDedupArgs A) {
         PfCand c;
         c.id = 0; c.arr = 0; c.score = 0; c.diag = 0; c.pad = 0;
         if ((uint32_t)lane < ncand) {
-            c.id = s_cand[wave][0][lane];
-            c.arr = s_cand[wave][1][lane];
-            c.diag = (uint16_t)s_cand[wave][2][lane];
+            c.id = M.cand[wave][0][lane];
+            c.arr = M.cand[wave][1][lane];
+            c.diag = (uint16_t)M.cand[wave][2][lane];
         }
-        uint64_t cells = score_chunk(A, smat, nullptr, nullptr, bucket, q, 0, ncand, ncand, c, bshift);
+        uint64_t cells = score_chunk(A, M.smat, nullptr, nullptr, bucket, q, 0, ncand, ncand, c, bshift);
         if (A.cell_counter) {
             for (int dd = 1; dd < 64; dd <<= 1) cells += __shfl_xor((unsigned long long)cells, dd);
             if (lane == 0 && cells) atomicAdd((unsigned long long *)&A.cell_counter[q], (unsigned long long)cells);
         }
     }
+    return true;
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MMGPU_PF_REPLAY_EU))) void pf_replay_kernel(PfDedupArgs A) {
+    __shared__ ReplayLds<true> M;
+    const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
+    for (int k = (int)threadIdx.x; k < 32 * 32; k += 256) M.smat[k] = k < A.alphabet * A.alphabet ? A.mat[k] : (int8_t)0;
+    __syncthreads();
+    const uint64_t bucket = (uint64_t)A.q_first * A.bins + (uint64_t)blockIdx.x * 4u + (uint32_t)wave;
+    if (bucket >= (uint64_t)(A.q_first + A.n_queries) * A.bins) return;
+    if (!replay_bucket<true>(A, M, bucket) && lane == 0) A.redo_list[atomicAdd(A.redo_count, 1u)] = (uint32_t)bucket;
+}
+
+// the buckets the compact form gave up on, with the full per-target state; the grid is fixed (the list length lives on the device)
+__global__ __launch_bounds__(256) void pf_replay_redo_kernel(PfDedupArgs A) {
+    __shared__ ReplayLds<false> M;
+    const int wave = (int)(threadIdx.x >> 6);
+    for (int k = (int)threadIdx.x; k < 32 * 32; k += 256) M.smat[k] = k < A.alphabet * A.alphabet ? A.mat[k] : (int8_t)0;
+    __syncthreads();
+    const uint32_t n = *A.redo_count;
+    for (uint32_t i = blockIdx.x * 4u + (uint32_t)wave; i < n; i += gridDim.x * 4u) replay_bucket<false>(A, M, A.redo_list[i]);
 }
 
 // Buckets with more than 64 candidates (the replay kernel scores the others itself): one wavefront per (query, bin).
@@ -1939,7 +2114,7 @@ hipError_t launch_pf_scan(const uint32_t *in, const uint32_t *q_off, uint32_t nq
 
 hipError_t launch_pf_split(const PfSplitArgs &A, uint32_t n_tiles, hipStream_t s) {
     if (n_tiles == 0) return hipSuccess;
-    hipLaunchKernelGGL(pf_split_kernel, dim3(n_tiles), dim3(256), 4 * A.bins * sizeof(uint32_t), s, A);
+    hipLaunchKernelGGL(pf_split_kernel, dim3(n_tiles), dim3(SPW * 64), (size_t)SPW * A.bins * sizeof(uint16_t), s, A);
     return hipGetLastError();
 }
 
@@ -1947,9 +2122,12 @@ hipError_t launch_pf_dedup(const PfDedupArgs &A, hipEvent_t after_replay, hipEve
     const uint64_t buckets = (uint64_t)A.n_queries * A.bins;
     if (buckets == 0) return hipSuccess;
     const dim3 grid((unsigned)((buckets + 3) / 4)), block(256);
-    hipLaunchKernelGGL(pf_replay_kernel, grid, block, 0, s, A);
-    hipError_t e = hipGetLastError();
+    hipError_t e = hipMemsetAsync(A.redo_count, 0, sizeof(uint32_t), s);
     if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(pf_replay_kernel, grid, block, 0, s, A);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    hipLaunchKernelGGL(pf_replay_redo_kernel, dim3((unsigned)std::min<uint64_t>((buckets + 3) / 4, 1024)), block, 0, s, A);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
     if (after_replay && (e = hipEventRecord(after_replay, s)) != hipSuccess) return e;
     hipLaunchKernelGGL(pf_ungapped_kernel, grid, block, 0, s, A);
     if ((e = hipGetLastError()) != hipSuccess) return e;

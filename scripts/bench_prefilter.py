@@ -23,7 +23,15 @@ args = ap.parse_args()
 m = dict(np.load(os.path.join(ROOT, "tests", "golden", "matrices.npz")))
 km16 = m["vtml80_kmer"].astype(np.int16)
 t0 = time.time()
-(qres, qoff), (tres, toff), fam, qfam = wl.config3_prefilter(args.families, args.members, args.queries)
+cache = os.environ.get("MMGPU_WL_CACHE")      # A/B runs inside one GPU-box call: generate the workload once
+cache = cache and "%s_%d_%d_%d.npz" % (cache, args.families, args.members, args.queries)
+if cache and os.path.exists(cache):
+    z = np.load(cache)
+    (qres, qoff), (tres, toff) = (z["qres"], z["qoff"]), (z["tres"], z["toff"])
+else:
+    (qres, qoff), (tres, toff), fam, qfam = wl.config3_prefilter(args.families, args.members, args.queries)
+    if cache:
+        np.savez(cache, qres=qres, qoff=qoff, tres=tres, toff=toff)
 t_gen = time.time() - t0
 qs = wl.split(qres, qoff)
 gpu = mmseqs2_amd.MMGpu(0)
@@ -76,6 +84,13 @@ out = dict(batches=len(batches), queries=len(qs), targets=len(toff) - 1, residue
            gather_GBps=round(ent * 20 / (stage[1] * 1e-3) / 1e9, 2) if stage[1] else None,
            entries_per_query=round(ent / max(len(qs), 1)), t_gen=round(t_gen, 1), t_score_matrix=round(t_sm, 1),
            t_index_build=round(t_ix, 1), t_load=round(t_load, 1), t_prepare=round(t_prep, 1))
+import zlib
+crc = 0
+for h, c, st in allhits:      # a digest of every list (A/B runs of library variants must agree)
+    for w in range(len(c)):
+        crc = zlib.crc32(np.ascontiguousarray(h[w][:int(c[w])]).tobytes(), crc)
+    crc = zlib.crc32(np.ascontiguousarray(c).tobytes() + np.ascontiguousarray(st).tobytes(), crc)
+out["lists_crc32"] = crc
 # family recall: fraction of (query, same-family target) pairs the hit lists contain
 where = {qi: (bi, wi) for bi, g in enumerate(groups) for wi, qi in enumerate(g)}
 if args.check:

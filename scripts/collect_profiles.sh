@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs on the GPU box (gpurun -- 'bash scripts/collect_profiles.sh'): the rocprofv3 passes behind profiles/.
 # Kernel trace and every PMC counter in its own run (counters are never combined with other trace domains).
-# Summaries land in gpurun_out/profiles_new/ ; copy the ones to be judged into profiles/ (prefix r02_).
+# Summaries land in gpurun_out/profiles_new/ ; copy the ones to be judged into profiles/ (prefix r03_).
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/profiles_new
 mkdir -p $OUT
@@ -12,7 +12,7 @@ run() {   # name, rocprof args..., -- , command
     timeout 900 rocprofv3 "$@" > $OUT/$name.log 2>&1
 }
 # 1. kernel trace of the default bench command (the headline line's own run: 10 steps of the 10k x 1M search + sections)
-run trace --kernel-trace --stats -d /tmp/prof_trace -o trace -- python $R/bench.py --no-cpu-baseline
+run trace --kernel-trace --stats -d /tmp/prof_trace -o trace -- python $R/bench.py --no-cpu-baseline --no-modules
 python $R/scripts/rocprof_summary.py /tmp/prof_trace/trace_results.db $OUT/bench_kernel_trace_stats.txt
 python $R/scripts/rocprof_timeline.py /tmp/prof_trace/trace_results.db sw_kernel $OUT/bench_sw_timeline.txt
 # 2. HBM traffic of the headline's kernels (prefilter + alignment of the hit lists), one timed step after the warm-up

@@ -430,3 +430,27 @@ def test_candidate_sets_of_half_the_diagonal_array_go_to_the_host(gpu, golden_ca
             assert s1[qi] == 3 and c1[qi] == 0, (qi, int(cands[qi]), cap)      # MMGPU_PF_SAT_TIE
         else:
             assert s1[qi] == 0 and c1[qi] == c0[qi] and np.array_equal(h1[qi][:c1[qi]], h0[qi][:c0[qi]]), qi
+
+
+@pytest.mark.parametrize("cap", [0, 1, 3])
+def test_replay_redo_list_gives_the_same_lists(gpu, golden_case, monkeypatch, cap):
+    """The replay kernel keeps the byte a target emitted last only for the targets that have emitted, in a 64-entry table per
+    (query, bin); a bucket with more emitting targets goes through the full-state kernel (pf_replay_redo_kernel).  With the
+    table cut to `cap` entries (MMGPU_PF_EMIT_CAP) nearly every bucket with a candidate takes that path: every stage and the
+    final lists must still equal the oracle's."""
+    g, orc = golden_case
+    monkeypatch.setenv("MMGPU_PF_EMIT_CAP", str(cap))
+    try:
+        ok, rep = chk.check(gpu, orc, pc.golden_queries(g), 300, 2, stages=True, label="golden/redo%d" % cap)
+    finally:
+        monkeypatch.delenv("MMGPU_PF_EMIT_CAP", raising=False)
+    assert ok, "\n".join(rep)
+
+
+def test_replay_redo_list_on_the_overflow_path(gpu, monkeypatch):
+    """... and with segments (databaseHits flushes): the table is emptied at every segment boundary like the rest of the state"""
+    monkeypatch.setenv("MMGPU_PF_EMIT_CAP", "2")
+    try:
+        test_prefilter_overflow_path(gpu, 60000, 30000, 0.5)
+    finally:
+        monkeypatch.delenv("MMGPU_PF_EMIT_CAP", raising=False)
