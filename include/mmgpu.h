@@ -248,8 +248,11 @@ typedef struct {
     uint32_t target;   /* id in the resident database */
     uint16_t diagonal; /* hit_t::diagonal of the prefilter hit */
     uint8_t reverse;   /* 1: align the reverse complement of the query (Matcher::getSWResult's isReverse) */
-    uint8_t reserved;
+    uint8_t past_end;  /* 0: the letters of mmgpu_nucl_params; MMGPU_NUCL_PAST_END(q, t): this pair's own letters one residue
+                          past the query's / the target's end - what a host that replays the reference's buffer history
+                          (integration/MMGpuNuclAlignRun.cpp) knows per pair */
 } mmgpu_nucl_pair;
+#define MMGPU_NUCL_PAST_END(q, t) ((uint8_t)(0x80u | ((unsigned)(q) & 7u) | (((unsigned)(t) & 7u) << 3)))
 typedef struct {
     int32_t score;              /* s_align::score1 */
     int32_t q_start, q_end;     /* on the aligned strand, like s_align::qStartPos1 / qEndPos1 */

@@ -111,11 +111,13 @@ const unsigned char *lookupTarget(void *ctx, unsigned int id) {
 
 bool MMGpuAlignRun::usable(const Alignment &a) {
     if (!MMGpuRun::enabled()) return false;
+    if (usableNucleotide(a)) return true;
     const bool profileQuery = Parameters::isEqualDbtype(a.querySeqType, Parameters::DBTYPE_HMM_PROFILE);
     const bool aa = (Parameters::isEqualDbtype(a.querySeqType, Parameters::DBTYPE_AMINO_ACIDS) ||
                      (profileQuery && !a.includeIdentity && !a.sameQTDB)) &&
                     Parameters::isEqualDbtype(a.targetSeqType, Parameters::DBTYPE_AMINO_ACIDS);
-    // what the device path does not cover keeps the reference's CPU loop: profile targets / nucleotide databases,
+    // what the device path does not cover keeps the reference's CPU loop: profile targets, nucleotide databases outside
+    // MMGpuNuclAlignRun.cpp's conditions,
     // wrapped scoring, realignment (incl. the LCA form) of profile queries, the correlation score with profile queries / realignment
     // (--realign with sequence queries - the first iteration of an iterative search - is served: run() below)
     // (--alt-ali is served: the list on the device, the few re-alignments of masked targets on the host)
@@ -129,6 +131,7 @@ bool MMGpuAlignRun::usable(const Alignment &a) {
 bool MMGpuAlignRun::run(Alignment &al, const std::string &outDB, const std::string &outDBIndex, const size_t dbFrom,
                         const size_t dbSize, bool merge) {
     if (!usable(al)) return false;
+    if (usableNucleotide(al)) return runNucleotide(al, outDB, outDBIndex, dbFrom, dbSize, merge);
     MMGpuStopwatch watch("align");
     mmgpu_ctx *gpu = MMGpuRun::context();     // EXITs with the library's message if no device can be opened
     watch.lap("open device");

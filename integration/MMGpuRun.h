@@ -55,6 +55,10 @@ public:
     static bool usable(const Alignment &a);
     static bool run(Alignment &a, const std::string &outDB, const std::string &outDBIndex, const size_t dbFrom, const size_t dbSize,
                     bool merge);
+    // nucleotide databases: BandedNucleotideAligner::align on the device (MMGpuNuclAlignRun.cpp; MMGPU_NUCL_ALIGN=0 keeps the CPU loop)
+    static bool usableNucleotide(const Alignment &a);
+    static bool runNucleotide(Alignment &a, const std::string &outDB, const std::string &outDBIndex, const size_t dbFrom, const size_t dbSize,
+                              bool merge);
 };
 
 struct MMGpuPrefilterStats {

@@ -52,7 +52,7 @@ class NuclQuery(ctypes.Structure):
 
 
 NUCL_PAIR_DTYPE = np.dtype([("query", np.uint32), ("target", np.uint32), ("diagonal", np.uint16), ("reverse", np.uint8),
-                            ("reserved", np.uint8)])
+                            ("past_end", np.uint8)])      # 0, or 0x80 | query letter | target letter << 3 (MMGPU_NUCL_PAST_END)
 NUCL_HIT_DTYPE = np.dtype([("score", np.int32), ("q_start", np.int32), ("q_end", np.int32), ("t_start", np.int32),
                            ("t_end", np.int32), ("ident", np.uint32), ("bt_len", np.uint32), ("status", np.int32),
                            ("bt_off", np.uint64)])
@@ -609,13 +609,13 @@ class MMGpu:
     # ---- nucleotide alignment step ----
     def nucl_align(self, mat, reverse, queries, pairs, gap_open=5, gap_extend=2, zdrop=40, past_end_query=4, past_end_target=4):
         """queries: list of uint8 arrays (codes 0..4); pairs: structured NUCL_PAIR_DTYPE array (or list of
-        (query, target, diagonal, reverse)).  Returns (NUCL_HIT_DTYPE array, list of backtrace strings)."""
+        (query, target, diagonal, reverse[, past_end])).  Returns (NUCL_HIT_DTYPE array, list of backtrace strings)."""
         mat = np.ascontiguousarray(mat, np.int8).reshape(-1)
         rev = np.ascontiguousarray(reverse, np.uint8)
         if not (isinstance(pairs, np.ndarray) and pairs.dtype == NUCL_PAIR_DTYPE):
             pa = np.zeros(len(pairs), NUCL_PAIR_DTYPE)
             for i, p in enumerate(pairs):
-                pa[i] = (p[0], p[1], p[2] & 0xFFFF, p[3], 0)
+                pa[i] = (p[0], p[1], p[2] & 0xFFFF, p[3], p[4] if len(p) > 4 else 0)
             pairs = pa
         pairs = np.ascontiguousarray(pairs)
         qs = [np.ascontiguousarray(q, np.uint8) for q in queries]

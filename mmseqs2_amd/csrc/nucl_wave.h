@@ -321,10 +321,10 @@ NUCL_HD void align_wave(const NuclLaunch &L, WaveLds &S, uint8_t *p, char *w) {
         SeqView qv, tv;
         qv.base = L.q_res + L.q_off[P.query];
         qv.rl = P.reverse ? L.rev_lookup : nullptr;
-        qv.L = qlen; qv.off = 0; qv.past = L.past_end_q; qv.reversed = false;
+        qv.L = qlen; qv.off = 0; qv.past = (P.past_end & 0x80u) ? (int)(P.past_end & 7u) : L.past_end_q; qv.reversed = false;
         tv.base = L.t_res + (size_t)L.t_off4[P.target] * 4;
         tv.rl = nullptr;
-        tv.L = tlen; tv.off = 0; tv.past = L.past_end_t; tv.reversed = false;
+        tv.L = tlen; tv.off = 0; tv.past = (P.past_end & 0x80u) ? (int)((P.past_end >> 3) & 7u) : L.past_end_t; tv.reversed = false;
 
         // ---- ungapped seed: every 65536-shift of the 16-bit prefilter diagonal that fits (DistanceCalculator.h:93-112)
         Seed best;

@@ -146,6 +146,9 @@ void mmo_comp_bias(const int16_t *submat /*alphabet^2, row-major short matrix*/,
 }
 #endif
 
+#ifdef __cplusplus
+extern "C" {
+#endif
 /* ---- nucleotide alignment step (oracle/nucl_oracle.c) ---- */
 typedef struct {
     int32_t max, zdropped, max_q, max_t, mqe, mqe_t, mte, mte_q, score, n_cigar;
@@ -161,9 +164,6 @@ int mmo_nucl_align(const uint8_t *q_num, int qlen, const uint8_t *t_num, int tle
                    const uint8_t *rev_lookup, int gapo, int gape, int zdrop, unsigned diagonal16, int reverse,
                    int past_end_q, int past_end_t, mmo_nucl_result *res, char *bt, int bt_cap);
 
-#ifdef __cplusplus
-extern "C" {
-#endif
 /* ---- block aligner (block_oracle.c): lib/block-aligner 0.4.0, AVX2 configuration, as the reference calls it ---- */
 typedef struct { int32_t score; uint32_t query_idx, reference_idx; } mmo_block_res;
 int mmo_block_align(const uint8_t *q, const int16_t *qbias, int qlen, const uint8_t *r, const int16_t *rbias, int rlen, const int8_t *mat,

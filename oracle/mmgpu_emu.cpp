@@ -474,4 +474,40 @@ int mmgpu_pf_fetch(mmgpu_ctx *c, mmgpu_pf_batch_t *b, mmgpu_pf_hit *hits, uint32
 }
 void mmgpu_pf_free(mmgpu_ctx *, mmgpu_pf_batch_t *b) { delete b; }
 
+// nucleotide alignment step: the restatement of BandedNucleotideAligner::align per pair (nucl_oracle.c)
+int mmgpu_nucl_align(mmgpu_ctx *c, const mmgpu_nucl_params *par, const mmgpu_nucl_query *qs, uint32_t nq, const mmgpu_nucl_pair *pairs,
+                     uint32_t np, mmgpu_nucl_hit *out, char *bt, uint64_t bt_cap, uint64_t *bt_used) {
+    if (c->alphabet != 5) {
+        g_err = "mmgpu_nucl_align (emu): the resident targets are not nucleotides";
+        return MMGPU_ERR_ARG;
+    }
+    uint64_t used = 0;
+    for (uint32_t i = 0; i < np; i++) {
+        const mmgpu_nucl_pair &p = pairs[i];
+        if (p.query >= nq || p.target >= c->n) {
+            g_err = "mmgpu_nucl_align (emu): pair index out of range";
+            return MMGPU_ERR_ARG;
+        }
+        const int qlen = (int)qs[p.query].qlen, tlen = (int)(c->toff[p.target + 1] - c->toff[p.target]);
+        const int pq = (p.past_end & 0x80u) ? (int)(p.past_end & 7u) : par->past_end_query;
+        const int pt = (p.past_end & 0x80u) ? (int)((p.past_end >> 3) & 7u) : par->past_end_target;
+        std::vector<char> s((size_t)qlen + tlen + 2);
+        mmo_nucl_result r;
+        mmo_nucl_align(qs[p.query].q, qlen, c->tres.data() + c->toff[p.target], tlen, par->mat, 5, par->reverse, par->gap_open, par->gap_extend,
+                       par->zdrop, p.diagonal, p.reverse, pq, pt, &r, s.data(), (int)s.size());
+        mmgpu_nucl_hit &o = out[i];
+        o.score = r.score; o.q_start = r.q_start; o.q_end = r.q_end; o.t_start = r.t_start; o.t_end = r.t_end;
+        o.ident = r.ident; o.bt_len = (uint32_t)r.bt_len; o.bt_off = used;
+        o.status = MMGPU_NUCL_OK;
+        if (used + (uint64_t)r.bt_len + 1 > bt_cap) o.status = MMGPU_NUCL_BT_OVERFLOW;
+        else {
+            memcpy(bt + used, s.data(), (size_t)r.bt_len);
+            bt[used + r.bt_len] = '\0';
+        }
+        used += (uint64_t)r.bt_len + 1;
+    }
+    if (bt_used) *bt_used = used;
+    return 0;
+}
+
 }  // extern "C"

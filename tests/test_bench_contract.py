@@ -1,4 +1,4 @@
-"""The bench line the driver parses: the committed line of this round (profiles/r02_bench_n1.json, produced by
+"""The bench line the driver parses: the committed line of this round (profiles/r03_bench_n1.json, produced by
 `python bench.py` on the GPU box) must carry the contract's keys, be quoted on BASELINE.json's metric configuration (10k
 queries x 1M targets), and its CPU-baseline legs - which double as full-size parity checks against the real reference -
 must have found no difference."""
@@ -10,13 +10,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _line():
-    return json.loads(open(os.path.join(ROOT, "profiles", "r02_bench_n1.json")).read())
+    return json.loads(open(os.path.join(ROOT, "profiles", "r03_bench_n1.json")).read())
 
 
 def test_committed_bench_line_has_the_contract_keys():
     d = _line()
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-              "dtype", "data", "config", "roofline", "cpu_baseline", "queries_per_s"):
+              "dtype", "data", "config", "roofline", "cpu_baseline", "queries_per_s", "end_to_end", "queries_per_s_end_to_end"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None and d["data"] == "synthetic"
     assert d["steps"] >= 10
@@ -34,18 +34,28 @@ def test_committed_bench_line_has_the_contract_keys():
         assert k in c, k
     assert c["kind"] in ("reference", "port")
     # the CPU legs double as full-size parity checks: they must have found nothing
-    assert c["parity_vs_baseline"]["field_mismatches"] == 0 and c["parity_vs_baseline"]["pairs_compared"] > 2000000
+    # (a bounded sample of the hit lists through the reference's own OpenMP loop: > 1 M pairs, starts included)
+    assert c["parity_vs_baseline"]["field_mismatches"] == 0 and c["parity_vs_baseline"]["pairs_compared"] > 1000000
+    assert c["kind"] == "reference" and c["threads"] >= c["cores"] >= 1 and "runs" in c
     assert d["cpu_baseline_prefilter"]["parity_vs_reference"]["queries_with_different_hit_lists"] == 0
     assert d["two_call"]["fields_differing_from_fused_path"] == 0
     assert d["nucleotide_align"]["cpu_baseline"]["parity_vs_reference"]["pairs_differing"] == 0
     assert d["nucleotide_search"]["cpu_baseline"]["parity_vs_reference"]["queries_with_different_hit_lists"] == 0
     assert isinstance(d["roofline"]["traffic"], (int, float)) and d["roofline"]["traffic"] > d["roofline"]["algorithmic_bytes_per_launch"]
+    # host numeric sequences in -> host lists out, and the two modules through the stock and the patched binary (default --mask 1)
+    e = d["end_to_end"]
+    assert e["results_equal_to_the_timed_steps"] is True
+    assert abs(d["queries_per_s_end_to_end"] - 10000 / e["seconds"]) < 0.01 * d["queries_per_s_end_to_end"]
+    m = e["mmseqs_modules_stock_vs_patched"]
+    assert m["alignment_dbs_identical"] is True and m["entries_compared"] == 10000
+    assert m["patched"]["prefilter_wall_s"] < m["stock"]["prefilter_wall_s"] and m["patched"]["align_wall_s"] < m["stock_block_aligner_stubbed"]["align_wall_s"]
 
 
 def test_pmc_reader_finds_the_quoted_kernels():
     sys.path.insert(0, ROOT)
     import bench
     for kernels, stem in ((("pf_split_kernel",), "r01_prefilter_config3"), (("sw_kernel<",), "r01_sw_config2"),
-                          (("pf_split_kernel",), "r02_search"), (("sw_kernel<", "sw_rev_multi_kernel"), "r02_search")):
+                          (("pf_split_kernel",), "r02_search"), (("sw_kernel<", "sw_rev_multi_kernel"), "r02_search"),
+                          (("pf_split_kernel",), "r03_search"), (("sw_kernel<", "sw_rev_multi_kernel"), "r03_search")):
         t = bench.pmc_traffic(kernels, stem)
         assert t is not None and t > 1e9, (kernels, t)

@@ -38,7 +38,7 @@ def emu_align(L, mat, reverse, queries, targets, pairs, past_q, past_t, gapo=5, 
     toff = np.concatenate([[0], np.cumsum([len(t) for t in targets])]).astype(np.uint64)
     pa = np.zeros(len(pairs), capi.NUCL_PAIR_DTYPE)
     for i, p in enumerate(pairs):
-        pa[i] = (p[0], p[1], p[2] & 0xFFFF, p[3], 0)
+        pa[i] = (p[0], p[1], p[2] & 0xFFFF, p[3], p[4] if len(p) > 4 else 0)
     par = capi.NuclParams(mat.ctypes.data_as(c_p), rev.ctypes.data_as(c_p), gapo, gape, zdrop, past_q, past_t)
     out = np.zeros(len(pairs), capi.NUCL_HIT_DTYPE)
     cap = int(sum(len(qs[p[0]]) + len(targets[p[1]]) + 2 for p in pairs))
@@ -70,3 +70,17 @@ def test_kernel_source_on_emulated_lanes_matches_golden(lanes, wave):
                 assert got == c[6][:6] and s == c[7], (len(c[0]), len(c[1]), c[2], c[3], got, c[6], s[:40], c[7][:40])
                 n += 1
     assert n == len(cases)
+
+
+def test_past_end_letters_per_pair_equal_the_per_call_ones():
+    """mmgpu_nucl_pair::past_end (MMGPU_NUCL_PAST_END): every golden case in ONE call, each pair carrying the letters the
+    reference found past the ends when the vector was recorded; the call's own letters are set to something else."""
+    L = _lib(64, True)
+    g = nc.golden()
+    cases = [c for c in nc.golden_cases(g) if len(c[0]) + len(c[1]) <= 1800][:120]
+    pairs = [(i, i, c[2], c[3], 0x80 | (c[4] & 7) | ((c[5] & 7) << 3)) for i, c in enumerate(cases)]
+    hits, strs = emu_align(L, g["mat"], g["reverse"], [c[0] for c in cases], [c[1] for c in cases], pairs, 2, 1)
+    assert len({(c[4], c[5]) for c in cases}) > 3
+    for c, h, s in zip(cases, hits, strs):
+        got = (int(h["score"]), int(h["q_start"]), int(h["q_end"]), int(h["t_start"]), int(h["t_end"]), int(h["ident"]))
+        assert got == c[6][:6] and s == c[7], (c[4], c[5], got, c[6])
