@@ -92,6 +92,7 @@ bool MMGpuAlignRun::runNucleotide(Alignment &al, const std::string &outDB, const
                                   const size_t dbSize, bool merge) {
     MMGpuStopwatch watch("align (nucleotide)");
     mmgpu_ctx *gpu = MMGpuRun::context();
+    Debug(Debug::INFO) << "MMGPU: nucleotide alignment on the device (results = the reference's loop with one thread; MMGPU_NUCL_ALIGN=0 keeps the CPU loop)\n";
     watch.lap("open device");
     int dbtype = Parameters::DBTYPE_ALIGNMENT_RES;
     if (al.alignmentOutputMode == Parameters::ALIGNMENT_OUTPUT_CLUSTER) dbtype = Parameters::DBTYPE_CLUSTER_RES;

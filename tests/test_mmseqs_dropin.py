@@ -339,7 +339,7 @@ def _nucleotide_pipeline(w, emulate, k="15"):
     """Nucleotide search: `mmseqs prefilter` of nucleotide databases with the search's parameters
     (exact k-mers, k = 15, Search.cpp:180-198) on the device, and the whole blastn workflow (`search --search-type 3`:
     extractframes / splitsequence -> prefilter -> align -> offsetalignment) through the patched binary: prefilter on the
-    device, the banded nucleotide alignment on the reference's CPU path (announced)."""
+    device, the banded nucleotide alignment on the device as well (the reference's loop where its conditions are not met)."""
     rng = np.random.default_rng(23)
     letters = np.array(list("ACGT"))
     targets = ["".join(letters[rng.integers(0, 4, int(rng.integers(3000, 12000)))]) for _ in range(60)]
@@ -377,9 +377,25 @@ def _nucleotide_pipeline(w, emulate, k="15"):
         assert same(os.path.join(w, "npref_s%d" % n), os.path.join(w, "npref_g%d" % n)) == 60
     d = dbio.read_db(os.path.join(w, "npref_g0"))
     assert sum(1 for v in d.values() if len(v) > 1) >= 25          # every read finds its contig on one of the two strands
-    run(STOCK, ["search", "nq", "nt", "nres_s", "ntmp_s", "--search-type", "3", "-k", k, "-a", "--threads", THREADS, "-v", "1"], w)
+    # `mmseqs align` of the nucleotide lists: BandedNucleotideAligner::align on the device (integration/MMGpuNuclAlignRun.cpp).  The
+    # reference reads one residue past the end of its per-thread buffers, so its own output depends on what a thread mapped
+    # before: the comparison is with its one-thread run (which is what the hook replays), whatever --threads the patched binary has
+    for n, extra in enumerate([["-a"], ["--alignment-mode", "3", "-c", "0.5"], ["-e", "1e-5", "--min-seq-id", "0.9", "-a"],
+                               ["--cov-mode", "2", "-c", "0.3", "--alignment-output-mode", "0"]]):
+        run(STOCK, ["align", "nqf", "nt", "npref_s0", "naln_s%d" % n, "--threads", "1", "-v", "1"] + extra, w)
+        log = run(MMGPU, ["align", "nqf", "nt", "npref_s0", "naln_g%d" % n, "--threads", THREADS, "-v", "3"] + extra, w, emulate)
+        assert "MMGPU: nucleotide alignment on the device" in log, log[-2000:]
+        assert same(os.path.join(w, "naln_s%d" % n), os.path.join(w, "naln_g%d" % n)) == 60
+    d = dbio.read_db(os.path.join(w, "naln_g0"))
+    assert sum(1 for v in d.values() if len(v) > 1) >= 25
+    # where the loop stops decides what the reference's buffers hold afterwards: finite --max-rejected stays on the CPU loop
+    run(STOCK, ["align", "nqf", "nt", "npref_s0", "naln_s9", "--threads", "1", "--max-rejected", "3", "-v", "1"], w)
+    log = run(MMGPU, ["align", "nqf", "nt", "npref_s0", "naln_g9", "--threads", "1", "--max-rejected", "3", "-v", "3"], w, emulate)
+    assert "MMGPU: nucleotide alignment on the device" not in log and "using the CPU path" in log, log[-2000:]
+    assert same(os.path.join(w, "naln_s9"), os.path.join(w, "naln_g9")) == 60
+    run(STOCK, ["search", "nq", "nt", "nres_s", "ntmp_s", "--search-type", "3", "-k", k, "-a", "--threads", "1", "-v", "1"], w)
     log = run(MMGPU, ["search", "nq", "nt", "nres_g", "ntmp_g", "--search-type", "3", "-k", k, "-a", "--threads", THREADS, "-v", "3"], w, emulate)
-    assert "MMGPU: device" in log, log[-3000:]
+    assert "MMGPU: device" in log and "MMGPU: nucleotide alignment on the device" in log, log[-3000:]
     assert same(os.path.join(w, "nres_s"), os.path.join(w, "nres_g")) == 30
 
 

@@ -35,6 +35,21 @@ def test_golden_vectors(gpu):
     assert n == len(cases)
 
 
+def test_past_end_letters_per_pair(gpu):
+    """mmgpu_nucl_pair::past_end (MMGPU_NUCL_PAST_END): all golden cases in ONE call, every pair carrying the letters the
+    reference found past the ends when the vector was recorded (the call's own letters are set to something else)"""
+    g = nc.golden()
+    cases = nc.golden_cases(g)
+    tres = np.concatenate([c[1] for c in cases])
+    toff = np.concatenate([[0], np.cumsum([len(c[1]) for c in cases])]).astype(np.uint64)
+    gpu.load_targets(tres, toff, 5)
+    pairs = [(i, i, c[2], c[3], 0x80 | (c[4] & 7) | ((c[5] & 7) << 3)) for i, c in enumerate(cases)]
+    hits, strs = gpu.nucl_align(g["mat"], g["reverse"], [c[0] for c in cases], pairs, 5, 2, 40, 2, 1)
+    for c, h, s in zip(cases, hits, strs):
+        got = (int(h["score"]), int(h["q_start"]), int(h["q_end"]), int(h["t_start"]), int(h["t_end"]), int(h["ident"]))
+        assert h["status"] == 0 and got == c[6][:6] and s == c[7], (c[4], c[5], got, c[6])
+
+
 def test_random_reads_vs_oracle(gpu):
     """config-5-like reads (10 % substitutions, 2 % indels) up to 10 kb against their source contig window, both
     strands, plus unrelated pairs; many queries against one database in a single call"""
