@@ -935,6 +935,7 @@ struct ReplayLds {
     uint32_t tab[COMPACT ? 4 : 1][COMPACT ? PF_EMIT_TAB : 1];   // key << 8 | byte last emitted
     uint32_t cand[4][3][64];   // first 64 candidates of the bucket: id, arrival index, diagonal
     uint8_t mark[4][64];       // segment starts of a round (request)
+    uint32_t dup[4][PF_IDS_PER_BIN / 32];     // one bit per target: set and taken back within a round (all zero between rounds)
     int8_t smat[32 * 32];
 };
 
@@ -954,6 +955,7 @@ __device__ __forceinline__ bool replay_bucket(const PfDedupArgs &A, ReplayLds<CO
     uint32_t *E = M.emit[wave];
     uint32_t *T = M.tab[COMPACT ? wave : 0];
     uint8_t *mark = M.mark[wave];
+    uint32_t *Dup = M.dup[wave];
     int bshift = 0;
     while ((1u << bshift) < B) bshift++;
     auto clear_state = [&]() {
@@ -966,6 +968,7 @@ __device__ __forceinline__ bool replay_bucket(const PfDedupArgs &A, ReplayLds<CO
         for (int k = lane; k < PF_IDS_PER_BIN / 32; k += 64) E[k] = 0;
     };
     clear_state();
+    for (int k = lane; k < PF_IDS_PER_BIN / 32; k += 64) Dup[k] = 0;
     uint32_t nem = 0;                 // COMPACT: entries of the emitter table
     const uint32_t emit_cap = COMPACT ? min((uint32_t)PF_EMIT_TAB, A.emit_cap) : 0u;
 
@@ -1047,33 +1050,57 @@ __device__ __forceinline__ bool replay_bucket(const PfDedupArgs &A, ReplayLds<CO
             while (todo) {
                 const bool now = act && ((todo >> lane) & 1ull) && arr < next_boundary;
                 if (__ballot(now)) {
-                    const uint64_t same = match_lanes(key, 12, now);
                     uint32_t st = 0, em = 0;
                     if (now) {
                         st = S[key];
                         em = (E[key >> 5] >> (key & 31u)) & 1u;
                     }
-                    // stage 1: does my diagonal byte equal the previous entry's of this target?
-                    const uint64_t pm = same & below;
-                    const int pl = pm ? highest_lane(pm) : lane;
-                    const uint32_t d_pl = __shfl(d8, pl);
-                    const uint32_t prevd = pm ? d_pl : (st & 0xFFu);
-                    const bool flag = now && d8 == prevd;
-                    // stage 2: run-length de-duplication over the flagged entries of this target
-                    const uint64_t fl = __ballot(flag);
-                    const uint64_t fm = same & fl;
-                    const uint64_t fbelow = fm & below;
-                    const int fpl = fbelow ? highest_lane(fbelow) : lane;
-                    const uint32_t d_fpl = __shfl(d8, fpl);
-                    const bool group_last = now && (same & ~below & ~(1ull << lane)) == 0;   // last lane of its target
-                    const int fhi = fm ? highest_lane(fm) : lane;
-                    const uint32_t d_fhi = __shfl(d8, fhi);
+                    // Does a target occur twice in this round?  One LDS bit per target: an atomic OR that returns the old word
+                    // tells a lane that another lane of the round has set its bit; the bits are taken back right away.  In most
+                    // rounds (64 entries over 4096 targets) none does, and the bookkeeping between the entries of one target
+                    // (matching the keys of all lanes, predecessor / run searches) is skipped.
+                    bool twice = false;
+                    if (now) twice = (atomicOr(&Dup[key >> 5], 1u << (key & 31u)) >> (key & 31u)) & 1u;
+                    const bool uniq = __ballot(twice) == 0;
+                    if (now) atomicAnd(&Dup[key >> 5], ~(1u << (key & 31u)));
+                    bool flag, has_fm, has_fbelow, group_last;
+                    uint32_t d_fpl, d_fhi;
+                    int group_hi;
+                    if (uniq) {
+                        flag = now && d8 == (st & 0xFFu);
+                        has_fm = flag;
+                        has_fbelow = false;
+                        group_last = now;
+                        d_fpl = d8;
+                        d_fhi = d8;
+                        group_hi = lane;
+                    } else {
+                        const uint64_t same = match_lanes(key, 12, now);
+                        // stage 1: does my diagonal byte equal the previous entry's of this target?
+                        const uint64_t pm = same & below;
+                        const int pl = pm ? highest_lane(pm) : lane;
+                        const uint32_t d_pl = __shfl(d8, pl);
+                        const uint32_t prevd = pm ? d_pl : (st & 0xFFu);
+                        flag = now && d8 == prevd;
+                        // stage 2: run-length de-duplication over the flagged entries of this target
+                        const uint64_t fl = __ballot(flag);
+                        const uint64_t fm = same & fl;
+                        const uint64_t fbelow = fm & below;
+                        const int fpl = fbelow ? highest_lane(fbelow) : lane;
+                        d_fpl = __shfl(d8, fpl);
+                        group_last = now && (same & ~below & ~(1ull << lane)) == 0;   // last lane of its target
+                        const int fhi = fm ? highest_lane(fm) : lane;
+                        d_fhi = __shfl(d8, fhi);
+                        has_fm = fm != 0;
+                        has_fbelow = fbelow != 0;
+                        group_hi = highest_lane(same | (1ull << lane));
+                    }
                     uint32_t last_emitted = (st >> 8) & 0xFFu;       // full state; COMPACT: from the table
                     uint32_t tab_idx = 0;
                     if (COMPACT) {
                         // targets of this round that emit again: their group's last lane looks the table entry up, the
                         // group's first flagged lane (the one the byte decides for) reads it from there
-                        const uint64_t again = __ballot(group_last && fm != 0 && em != 0u);
+                        const uint64_t again = __ballot(group_last && has_fm && em != 0u);
                         uint32_t lb_mine = 0;
                         if (again) {
                             asm volatile("" ::: "memory");      // the table is written by other lanes
@@ -1092,19 +1119,19 @@ __device__ __forceinline__ bool replay_bucket(const PfDedupArgs &A, ReplayLds<CO
                                 }
                             }
                         }
-                        last_emitted = (uint32_t)__shfl((int)lb_mine, highest_lane(same | (1ull << lane)));
+                        last_emitted = uniq ? lb_mine : (uint32_t)__shfl((int)lb_mine, group_hi);
                     }
                     bool keep;
-                    if (fbelow) keep = flag && d_fpl != d8;
+                    if (has_fbelow) keep = flag && d_fpl != d8;
                     else keep = flag && (em == 0u || last_emitted != d8);
                     // state update by the last lane of every target group
                     if (COMPACT) {
-                        const bool fresh = group_last && fm != 0 && em == 0u;
+                        const bool fresh = group_last && has_fm && em == 0u;
                         const uint64_t fb = __ballot(fresh);
                         if (nem + (uint32_t)__popcll(fb) > emit_cap) return false;      // wave-uniform
                         if (group_last) {
                             S[key] = (uint8_t)d8;
-                            if (fm) {
+                            if (has_fm) {
                                 if (em == 0u) {
                                     tab_idx = nem + (uint32_t)__popcll(fb & below);
                                     atomicOr(&E[key >> 5], 1u << (key & 31u));
@@ -1115,7 +1142,7 @@ __device__ __forceinline__ bool replay_bucket(const PfDedupArgs &A, ReplayLds<CO
                         nem += (uint32_t)__popcll(fb);
                     } else if (group_last) {
                         uint32_t ns = d8;
-                        if (fm) {
+                        if (has_fm) {
                             ns |= d_fhi << 8;
                             if (em == 0u) atomicOr(&E[key >> 5], 1u << (key & 31u));
                         } else {
