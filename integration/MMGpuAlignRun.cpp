@@ -153,8 +153,32 @@ bool MMGpuAlignRun::run(Alignment &al, const std::string &outDB, const std::stri
     // ---- resident targets: Sequence::numSequence of every entry of the target DB, ids = DBReader ids (:361,367)
     TargetStore store;
     const size_t nTargets = al.tdbr->getSize();
+    // (only the targets some prefilter list of this run names are mapped and uploaded - a few queries against a large database
+    // do not pay for the whole database; the others keep their id with length 0.  One extra pass over the list text.)
+    std::vector<unsigned char> named(nTargets, 1);
+    if (Util::getTotalSystemMemory() > al.prefdbr->getTotalDataSize()) {
+        std::fill(named.begin(), named.end(), 0);
+#pragma omp parallel num_threads(al.threads)
+        {
+            unsigned int thread_idx = 0;
+#ifdef OPENMP
+            thread_idx = static_cast<unsigned int>(omp_get_thread_num());
+#endif
+            char key[255 + 1];
+#pragma omp for schedule(dynamic, 64)
+            for (size_t id = dbFrom; id < dbFrom + dbSize; id++) {
+                char *data = al.prefdbr->getData(id, thread_idx);
+                while (*data != '\0') {
+                    Util::parseKey(data, key);
+                    const size_t dbId = al.tdbr->getId(Util::fast_atoi<DBKeyType>(key));
+                    if (dbId < nTargets) named[dbId] = 1;
+                    data = Util::skipLine(data);
+                }
+            }
+        }
+    }
     store.offsets.assign(nTargets + 1, 0);
-    for (size_t id = 0; id < nTargets; id++) store.offsets[id + 1] = store.offsets[id] + al.tdbr->getSeqLen(id);
+    for (size_t id = 0; id < nTargets; id++) store.offsets[id + 1] = store.offsets[id] + (named[id] ? al.tdbr->getSeqLen(id) : 0);
     store.residues.resize(store.offsets[nTargets] + 1);
     watch.lap("target offsets + host buffer");
     std::vector<Sequence *> qSeqs(threads, NULL), dbSeqs(threads, NULL);
@@ -169,6 +193,7 @@ bool MMGpuAlignRun::run(Alignment &al, const std::string &outDB, const std::stri
         Sequence &dbSeq = *dbSeqs[thread_idx];
 #pragma omp for schedule(dynamic, 256)
         for (size_t id = 0; id < nTargets; id++) {
+            if (!named[id]) continue;
             char *data = al.tdbr->getData(id, thread_idx);
             if (data == NULL) continue;
             dbSeq.mapSequence(id, al.tdbr->getDbKey(id), data, al.tdbr->getSeqLen(id));
