@@ -153,6 +153,7 @@ struct PfKmerArgs {
     const int16_t *s3;         // [n3][n3] ScoreMatrix::score of the 3-mer matrix (no padding columns)
     const uint32_t *i3;        // [n3][n3] ScoreMatrix::index
     const uint32_t *offsets;   // IndexTable::offsets, [kalph^k + 1]
+    const uint32_t *nonempty;  // one bit per k-mer: list not empty (null: not used, the index is dense)
     const uint16_t *cum3;      // [n3][cum_w]: cum3[row][k] = number of entries of the row with score >= score_min + k
     uint32_t cum_w;
     int32_t score_min;
@@ -366,6 +367,7 @@ struct PfMergeArgs {
 
 hipError_t launch_pf_merge(const PfMergeArgs &A, hipStream_t s);
 hipError_t launch_pf_kmers(const PfKmerArgs &A, bool emit, hipStream_t s);
+hipError_t launch_pf_bitmap(const uint32_t *offsets, uint64_t table, uint32_t *bitmap, unsigned long long *nonempty, hipStream_t s);
 hipError_t launch_pf_scan(const uint32_t *in, const uint32_t *q_off, uint32_t nq, const uint64_t *base, uint32_t *out,
                           uint64_t *totals, hipStream_t s);
 hipError_t launch_pf_split(const PfSplitArgs &A, uint32_t n_tiles, hipStream_t s);

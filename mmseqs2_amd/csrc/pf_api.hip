@@ -22,6 +22,9 @@ struct PfIndex {
     uint32_t n3 = 0;
     uint64_t table = 0, n_entries = 0;
     DevBuf d_s3, d_i3, d_cum3, d_s2, d_i2, d_cum2, d_offsets, d_entries, d_mat;
+    DevBuf d_nonempty;           // one bit per k-mer (pf_bitmap_kernel), used when the index is sparse
+    bool use_bitmap = false;
+    double nonempty_frac = 1.0;  // k-mers with a list / all k-mers
     uint32_t cum_w = 0, cum2_w = 0;
     int32_t score_min = 0, score2_min = 0;
     std::vector<int8_t> h_mat;   // ungapped matrix (host copy for the self score)
@@ -30,6 +33,29 @@ struct PfIndex {
     DevBuf w_lists, w_split, w_bin_off, w_cand, w_surv, w_tile_q, w_tile_idx;
     const void *w_owner = nullptr;   // batch whose last run the working buffers hold (debug fetch)
 };
+
+// Sparse indexes (a shard of a multi-GPU run holds 1/N of the entries over the same k-mer space; small databases): most similar
+// k-mers of a query have no list.  The bit table is consulted by pf_kmers_kernel when fewer than 60 % of the k-mers have one
+// (MMGPU_PF_BITMAP=1 / 0 forces / forbids it); similar-k-mer searches with k = 6 only (the table of k = 7 has 1.3e9 k-mers).
+static hipError_t pf_index_bitmap(mmgpu_ctx *c, PfIndex *P) {
+    P->use_bitmap = false;
+    const char *e = getenv("MMGPU_PF_BITMAP");
+    if (!P->has_tables || P->k != 6 || P->table > (1ull << 28) || (e && e[0] == '0')) return hipSuccess;
+    hipStream_t s = c->stream;
+    DevBuf d_cnt;
+    hipError_t rc = P->d_nonempty.alloc(((P->table + 31) / 32 + 1) * 4);
+    if (rc == hipSuccess) rc = d_cnt.alloc(8);
+    if (rc == hipSuccess) rc = hipMemsetAsync(d_cnt.p, 0, 8, s);
+    if (rc == hipSuccess) rc = launch_pf_bitmap(P->d_offsets.as<uint32_t>(), P->table, P->d_nonempty.as<uint32_t>(), d_cnt.as<unsigned long long>(), s);
+    unsigned long long n = 0;
+    if (rc == hipSuccess) rc = hipMemcpyAsync(&n, d_cnt.p, 8, hipMemcpyDeviceToHost, s);
+    if (rc == hipSuccess) rc = hipStreamSynchronize(s);
+    if (rc != hipSuccess) return rc;
+    P->nonempty_frac = P->table ? (double)n / (double)P->table : 1.0;
+    P->use_bitmap = (e && e[0] == '1') || P->nonempty_frac < 0.6;
+    if (!P->use_bitmap) P->d_nonempty.release();
+    return hipSuccess;
+}
 
 void pf_index_free(mmgpu_ctx *c) {
     if (c && c->pf) {
@@ -353,6 +379,7 @@ extern "C" int mmgpu_pf_load_index(mmgpu_ctx *c, const mmgpu_pf_index *ix) {
     PfIndex *P = nullptr;
     const int rc = pf_setup(c, ix, true, &P);
     if (rc != MMGPU_OK) return rc;
+    HIP_TRY(pf_index_bitmap(c, P));
     c->pf = P;
     return MMGPU_OK;
 }
@@ -434,6 +461,7 @@ extern "C" int mmgpu_pf_build_index(mmgpu_ctx *c, const mmgpu_pf_index *ix, cons
     X_TRY(launch_ix_sort_long(S, std::min(n_long, S.long_cap), s));
     X_TRY(hipStreamSynchronize(s));
 #undef X_TRY
+    HIP_TRY(pf_index_bitmap(c, P));
     c->pf = P;
     return MMGPU_OK;
 }
@@ -747,6 +775,7 @@ extern "C" int mmgpu_pf_run(mmgpu_ctx *c, mmgpu_pf_batch_t *b) {
     K.s3 = P.d_s3.as<int16_t>();
     K.i3 = P.d_i3.as<uint32_t>();
     K.offsets = P.d_offsets.as<uint32_t>();
+    K.nonempty = P.use_bitmap ? P.d_nonempty.as<uint32_t>() : nullptr;
     K.cum3 = P.d_cum3.as<uint16_t>();
     K.cum_w = P.cum_w;
     K.score_min = P.score_min;

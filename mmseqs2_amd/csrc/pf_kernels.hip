@@ -197,9 +197,12 @@ __global__ __launch_bounds__(256) void pf_kmers_kernel(PfKmerArgs A) {
                 uint32_t start = 0, len = 0;
                 if (act) {
                     const uint32_t kmer = k_a + iB[x - ex_m] * n3;
-                    const U32Pair o = *reinterpret_cast<const U32Pair *>(A.offsets + kmer);   // one 8-byte request
-                    start = o.a;
-                    len = o.b - o.a;
+                    // (sparse index: the bit table says whether the list is empty before a sector of the offset table is touched)
+                    if (!A.nonempty || ((A.nonempty[kmer >> 5] >> (kmer & 31u)) & 1u)) {
+                        const U32Pair o = *reinterpret_cast<const U32Pair *>(A.offsets + kmer);   // one 8-byte request
+                        start = o.a;
+                        len = o.b - o.a;
+                    }
                 }
                 const uint32_t li = wave_incl_scan(len);
                 if (act) {
@@ -2129,6 +2132,32 @@ hipError_t launch_pf_kmers(const PfKmerArgs &A, bool emit, hipStream_t s) {
             else hipLaunchKernelGGL((pf_kmers_prof_kernel<6, false>), grid, block, 0, s, A);
         }
     }
+    return hipGetLastError();
+}
+
+// one bit per k-mer: does its index list hold an entry?  (a sparse index - a shard of a multi-GPU run, a small database - answers most
+// similar k-mers of a query from this 8 MB table instead of a 64-byte sector of the 256 MB offset table)
+__global__ __launch_bounds__(256) void pf_bitmap_kernel(const uint32_t *offsets, uint64_t table, uint32_t *bitmap, unsigned long long *nonempty) {
+    const uint64_t w = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    const uint64_t k0 = w * 32u;
+    uint32_t bits = 0;
+    if (k0 < table) {
+        uint32_t prev = offsets[k0];
+        for (uint32_t b = 0; b < 32u && k0 + b < table; b++) {
+            const uint32_t next = offsets[k0 + b + 1];
+            if (next != prev) bits |= 1u << b;
+            prev = next;
+        }
+        bitmap[w] = bits;
+    }
+    unsigned long long n = (unsigned long long)__popc(bits);
+    for (int d = 1; d < 64; d <<= 1) n += __shfl_xor(n, d);
+    if (lane_id() == 0 && n) atomicAdd(nonempty, n);
+}
+
+hipError_t launch_pf_bitmap(const uint32_t *offsets, uint64_t table, uint32_t *bitmap, unsigned long long *nonempty, hipStream_t s) {
+    const uint64_t words = (table + 31) / 32;
+    hipLaunchKernelGGL(pf_bitmap_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s, offsets, table, bitmap, nonempty);
     return hipGetLastError();
 }
 
