@@ -367,6 +367,7 @@ struct PfMergeArgs {
 
 hipError_t launch_pf_merge(const PfMergeArgs &A, hipStream_t s);
 hipError_t launch_pf_kmers(const PfKmerArgs &A, bool emit, hipStream_t s);
+hipError_t launch_pf_tiles(const uint32_t *q_tile_base, const uint32_t *q_ntiles, uint32_t nq, uint32_t *tile_q, uint32_t *tile_idx, hipStream_t s);
 hipError_t launch_pf_bitmap(const uint32_t *offsets, uint64_t table, uint32_t *bitmap, unsigned long long *nonempty, hipStream_t s);
 hipError_t launch_pf_scan(const uint32_t *in, const uint32_t *q_off, uint32_t nq, const uint64_t *base, uint32_t *out,
                           uint64_t *totals, hipStream_t s);

@@ -864,24 +864,22 @@ extern "C" int mmgpu_pf_run(mmgpu_ctx *c, mmgpu_pf_batch_t *b) {
     }
 
     // ---- tiles ----
-    std::vector<uint32_t> qent(nq), qtb(nq), qnt(nq), tile_q, tile_idx;
+    std::vector<uint32_t> qent(nq), qtb(nq), qnt(nq);      // (the per-tile lists are written on the device: pf_tiles_kernel)
     std::vector<uint64_t> qebase(nq);
-    uint64_t total_entries = 0;
+    uint64_t total_entries = 0, tiles_so_far = 0;
     for (uint32_t i = 0; i < nq; i++) {
         uint64_t e = b->q_entries[i];
         if (b->status[i] != MMGPU_PF_OK) e = 0;   // not processed on the device
         qent[i] = (uint32_t)e;
         qebase[i] = total_entries;
         total_entries += e;
-        qtb[i] = (uint32_t)tile_q.size();
+        qtb[i] = (uint32_t)tiles_so_far;
         qnt[i] = (uint32_t)((e + PF_T - 1) / PF_T);
-        for (uint32_t t = 0; t < qnt[i]; t++) {
-            tile_q.push_back(i);
-            tile_idx.push_back(t);
-        }
+        tiles_so_far += qnt[i];
     }
+    if (tiles_so_far >= 0xFFFFFFFFull) return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_pf_run: >= 2^32 tiles in one batch; use smaller batches");
     if (total_entries >= 0xFFFFFFFFull) return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_pf_run: >= 2^32 index entries in one batch; use smaller batches");
-    const uint32_t n_tiles = (uint32_t)tile_q.size();
+    const uint32_t n_tiles = (uint32_t)tiles_so_far;
     b->last_tiles = n_tiles;
     b->last_entries = total_entries;
     const uint32_t B = b->bins;
@@ -891,10 +889,7 @@ extern "C" int mmgpu_pf_run(mmgpu_ctx *c, mmgpu_pf_batch_t *b) {
     HIP_TRY(hipMemcpyAsync(b->d_qbase.p, qebase.data(), nq * 8, hipMemcpyHostToDevice, s));
     HIP_TRY(P.w_tile_q.reserve(std::max<size_t>(n_tiles, 1) * 4));
     HIP_TRY(P.w_tile_idx.reserve(std::max<size_t>(n_tiles, 1) * 4));
-    if (n_tiles) {
-        HIP_TRY(hipMemcpyAsync(P.w_tile_q.p, tile_q.data(), (size_t)n_tiles * 4, hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemcpyAsync(P.w_tile_idx.p, tile_idx.data(), (size_t)n_tiles * 4, hipMemcpyHostToDevice, s));
-    }
+    if (n_tiles) HIP_TRY(launch_pf_tiles(b->d_qtile_base.as<uint32_t>(), b->d_qntiles.as<uint32_t>(), nq, P.w_tile_q.as<uint32_t>(), P.w_tile_idx.as<uint32_t>(), s));
     HIP_TRY(P.w_split.reserve(std::max<size_t>(n_tiles, 1) * PF_T * sizeof(uint64_t)));
     HIP_TRY(P.w_bin_off.reserve(std::max<size_t>(n_tiles, 1) * (B + 1) * sizeof(uint16_t)));
     // Stages 2 and 3 run over CHUNKS of consecutive queries: the candidate / survivor arrays are entry-sized (every entry

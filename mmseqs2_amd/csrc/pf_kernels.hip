@@ -2155,6 +2155,23 @@ __global__ __launch_bounds__(256) void pf_bitmap_kernel(const uint32_t *offsets,
     if (lane_id() == 0 && n) atomicAdd(nonempty, n);
 }
 
+// tile t of query q: (tile_q, tile_idx) = (q, t) - the split kernel's work list, written where it is read
+__global__ __launch_bounds__(256) void pf_tiles_kernel(const uint32_t *q_tile_base, const uint32_t *q_ntiles, uint32_t nq, uint32_t *tile_q, uint32_t *tile_idx) {
+    const uint32_t q = blockIdx.x;
+    if (q >= nq) return;
+    const uint32_t base = q_tile_base[q], n = q_ntiles[q];
+    for (uint32_t t = threadIdx.x; t < n; t += 256) {
+        tile_q[base + t] = q;
+        tile_idx[base + t] = t;
+    }
+}
+
+hipError_t launch_pf_tiles(const uint32_t *q_tile_base, const uint32_t *q_ntiles, uint32_t nq, uint32_t *tile_q, uint32_t *tile_idx, hipStream_t s) {
+    if (nq == 0) return hipSuccess;
+    hipLaunchKernelGGL(pf_tiles_kernel, dim3(nq), dim3(256), 0, s, q_tile_base, q_ntiles, nq, tile_q, tile_idx);
+    return hipGetLastError();
+}
+
 hipError_t launch_pf_bitmap(const uint32_t *offsets, uint64_t table, uint32_t *bitmap, unsigned long long *nonempty, hipStream_t s) {
     const uint64_t words = (table + 31) / 32;
     hipLaunchKernelGGL(pf_bitmap_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s, offsets, table, bitmap, nonempty);
