@@ -368,9 +368,10 @@ typedef struct {
 #define MMGPU_PF_OVERFLOW 1 /* the query needs more than 62 flushes of the reference's databaseHits buffer
                                (QueryMatcher.cpp:310-346; up to 62 are emulated on the device): not computed here,
                                the host must run QueryMatcher::matchQuery for this query */
-#define MMGPU_PF_SAT_TIE 3  /* nucleotide searches: two saturated diagonals of one target tie on the exact score - the reference's
-                               choice depends on the element order its (unstable) std::sort by id left (QueryMatcher.cpp:154); or the
-                               query took the databaseHits overflow path.  Any search: the query's double-diagonal candidates number
+#define MMGPU_PF_SAT_TIE 3  /* nucleotide searches: two saturated diagonals of one target tie on the exact score in a query with more than
+                               16 saturated elements - the reference's choice then depends on the element order its std::sort by id
+                               left (QueryMatcher.cpp:154; up to 16 elements libstdc++ sorts by insertion, i.e. stably, and the device
+                               makes the same choice); or the query took the databaseHits overflow path.  Any search: the query's double-diagonal candidates number
                                max(1M, dbSize) / 2 or more, where the reference may take its unsorted branch (unstable std::sort, no
                                rescoring, QueryMatcher.cpp:188,204-214).  Not decided on the device: the host runs
                                QueryMatcher::matchQuery for this query */

@@ -1127,6 +1127,9 @@ extern "C" int mmgpu_pf_fetch(mmgpu_ctx *c, mmgpu_pf_batch_t *b, mmgpu_pf_hit *h
     for (uint32_t i = 0; i < nq; i++) {
         if ((flags[i] & 1u) && b->status[i] == MMGPU_PF_OK) b->status[i] = MMGPU_PF_LONG_SEQ;
         if ((flags[i] & 2u) && b->status[i] == MMGPU_PF_OK) b->status[i] = MMGPU_PF_SAT_TIE;
+        // nucleotide searches: a tie between saturated diagonals of one target, in a query whose saturated elements are more than
+        // std::sort's insertion-sort range (pf_keepmax_nucl_kernel)
+        if ((flags[i] & 4u) && (flags[i] >> 8) > 16u && b->status[i] == MMGPU_PF_OK) b->status[i] = MMGPU_PF_SAT_TIE;
         if (b->status[i] != MMGPU_PF_OK) counts[i] = 0;
         if (status) status[i] = b->status[i];
         if (stats) {

@@ -1425,9 +1425,13 @@ __global__ __launch_bounds__(256) void pf_keepmax_kernel(PfDedupArgs A) {
 // Nucleotide searches (QueryMatcher.cpp:147-177): before keepMaxScoreElementOnly the reference brings the SATURATED elements
 // (count == 255) of every target together and writes the diagonal with the best exact score
 // (scoreSingleSequenceCombined) into the first of them; the others lose the keepMax that follows.  Per target: a saturated
-// element with the best exact score wins (two different diagonals with the same best score: the reference's choice
-// depends on an unstable sort - the query is flagged for the host); without saturated elements the ordinary rule (highest
-// count, earliest arrival).  One wavefront per (query, bin), every bucket (the replay kernel leaves keepMax alone in this
+// element with the best exact score wins; two different diagonals with the same best score: the first in the order the
+// reference's std::sort by id left.  libstdc++'s std::sort of at most 16 elements is an insertion sort, i.e. stable, and the
+// order before it is the arrival order for one target - the earliest candidate holding the best score (F below) is the
+// reference's choice as well.  With more than 16 saturated elements in the QUERY the sort partitions and the order of equal
+// ids is not restated: bit 2 of q_flags records such a tie, bits 8.. count the query's saturated elements, and
+// mmgpu_pf_fetch hands the query to the host (MMGPU_PF_SAT_TIE) when both say so.  Without saturated elements the ordinary
+// rule (highest count, earliest arrival).  One wavefront per (query, bin), every bucket (the replay kernel leaves keepMax alone in this
 // mode); two LDS tables: best key per target, and the first candidate holding it.
 __global__ __launch_bounds__(128) void pf_keepmax_nucl_kernel(PfDedupArgs A) {
     __shared__ uint32_t s_key[2][PF_IDS_PER_BIN];
@@ -1455,13 +1459,18 @@ __global__ __launch_bounds__(128) void pf_keepmax_nucl_kernel(PfDedupArgs A) {
         const uint32_t cnt = min(255u, c.score);
         return cnt >= 255u ? (0xFF000000u | min(c.score, 0xFFFFFFu)) : ((cnt << 24) | (0xFFFFFFu - min(ci, 0xFFFFFEu)));
     };
+    uint32_t nsat = 0;      // saturated elements of this bucket: the length of the range the reference sorts is their total over the query
     for (uint32_t c0 = 0; c0 < ncand; c0 += 64) {
         const uint32_t ci = c0 + (uint32_t)lane;
+        bool sat = false;
         if (ci < ncand) {
             const PfCand c = *cand_slot(A, bucket, ci);
             atomicMax(&K[c.id >> bshift], key_of(c, ci));
+            sat = c.score >= 255u;
         }
+        nsat += (uint32_t)__popcll(__ballot(sat));
     }
+    if (lane == 0 && nsat && A.q_flags) atomicAdd(&A.q_flags[q], min(nsat, 17u) << 8);      // (capped per bucket: only '> 16' is asked)
     for (uint32_t c0 = 0; c0 < ncand; c0 += 64) {
         const uint32_t ci = c0 + (uint32_t)lane;
         if (ci < ncand) {
@@ -1483,7 +1492,7 @@ __global__ __launch_bounds__(128) void pf_keepmax_nucl_kernel(PfDedupArgs A) {
             win = top && F[t] == ci && cnt >= A.min_diag_score;
             if (top && F[t] != ci && cnt >= 255u) {      // another saturated element with the same exact score
                 const PfCand w = *cand_slot(A, bucket, F[t]);
-                if (w.diag != c.diag && A.q_flags) atomicOr(&A.q_flags[q], 2u);
+                if (w.diag != c.diag && A.q_flags) atomicOr(&A.q_flags[q], 4u);      // decided with the query's saturated total (fetch)
             }
         }
         const uint64_t wb = __ballot(win);
