@@ -121,6 +121,7 @@ size_t sw_lds_bytes(int rows_per_lane, int alphabet);
 // prefilter (pf_kernels.hip)
 constexpr int PF_T = 4096;             // arrival-ordered index entries per tile (2048: 22 % slower, more tiles)
 constexpr int PF_IDS_PER_BIN = 4096;   // targets per replay bin (one 16 KB LDS state table per wavefront)
+constexpr int PF_SAT_CAP = 1024;        // saturated elements per query exported in nucleotide mode (16 KB per query)
 constexpr int PF_CAND0 = 32;            // candidates per (query, bin) kept in the dense array
 constexpr int PF_QSTAGE = 2048;         // longest query whose residues the ungapped kernel stages in LDS
 constexpr int PF_MAX_HITS = 4096;      // largest --max-seqs the select kernel sorts in LDS (larger lists: global scratch, PF_MAX_HITS_BIG)
@@ -218,6 +219,10 @@ struct PfDedupArgs {
     int nucl;
     uint32_t sort_cap;                // foundDiagonalsSize / 2: the branch is skipped for larger candidate sets (:146)
     uint32_t *q_ncand;                // [nq] double-diagonal candidates of the query (nucleotide mode only)
+    // nucleotide mode: the saturated elements of every query, for the host's replay of the reference's std::sort (mmgpu_pf_fetch)
+    PfCand *sat;                      // [nq][sat_cap], any order
+    uint32_t *q_nsat;                 // [nq] their number (may exceed sat_cap: then the list is incomplete)
+    uint32_t sat_cap;
     const uint8_t *t_res;
     const uint32_t *t_off4, *t_len;
     uint32_t min_diag_score;

@@ -498,6 +498,7 @@ struct mmgpu_pf_batch_t {
     DevBuf d_qres, d_qthr, d_qcorr, d_qoff, d_qident, d_qself;
     DevBuf d_qkind, d_qisprof, d_pscore, d_pletter, d_qrows;   // profile queries only
     DevBuf d_qncand;                                           // nucleotide searches only
+    DevBuf d_sat, d_qnsat;                                     // nucleotide searches: saturated elements per query (PF_SAT_CAP each) + their number
     DevBuf d_big_keys, d_big_diags;                            // max_hits > PF_MAX_HITS only: the select kernel's sort scratch
     uint32_t big_stride = 0;
     bool any_profile = false;
@@ -728,6 +729,10 @@ extern "C" int mmgpu_pf_prepare(mmgpu_ctx *c, const mmgpu_pf_params *par, const 
     B_TRY(b->d_qflags.alloc(nqq * 4));
     B_TRY(b->d_redo.alloc(((size_t)nqq * bins + 1) * 4));
     if (par->nucleotide || par->kmer_score) B_TRY(b->d_qncand.alloc(nqq * 4));
+    if (par->nucleotide) {
+        B_TRY(b->d_sat.alloc((size_t)nqq * PF_SAT_CAP * sizeof(PfCand)));
+        B_TRY(b->d_qnsat.alloc(nqq * 4));
+    }
     if (max_hits > (uint32_t)PF_MAX_HITS) {
         b->big_stride = 1;
         while (b->big_stride < max_hits) b->big_stride <<= 1;
@@ -927,6 +932,7 @@ extern "C" int mmgpu_pf_run(mmgpu_ctx *c, mmgpu_pf_batch_t *b) {
     HIP_TRY(hipMemsetAsync(b->d_cells.p, 0, (size_t)nq * 8, s));
     HIP_TRY(hipMemsetAsync(b->d_qflags.p, 0, (size_t)nq * 4, s));
     if (b->par.nucleotide || b->par.kmer_score) HIP_TRY(hipMemsetAsync(b->d_qncand.p, 0, (size_t)nq * 4, s));
+    if (b->par.nucleotide) HIP_TRY(hipMemsetAsync(b->d_qnsat.p, 0, (size_t)nq * 4, s));
 
     // ---- stage 1: gather + stable split ----
     PfSplitArgs SA;
@@ -972,6 +978,9 @@ extern "C" int mmgpu_pf_run(mmgpu_ctx *c, mmgpu_pf_batch_t *b) {
     D.nucl = b->par.nucleotide ? 1 : 0;
     D.sort_cap = (uint32_t)(std::max<uint64_t>(1000000, b->exchange ? c->shard.global_n : c->db.n) / 2);     // foundDiagonalsSize / 2 (QueryMatcher.cpp:44,146)
     D.q_ncand = (b->par.nucleotide || b->par.kmer_score) ? b->d_qncand.as<uint32_t>() : nullptr;
+    D.sat = b->par.nucleotide ? b->d_sat.as<PfCand>() : nullptr;
+    D.q_nsat = b->par.nucleotide ? b->d_qnsat.as<uint32_t>() : nullptr;
+    D.sat_cap = (uint32_t)PF_SAT_CAP;
     D.q_rows = b->any_profile ? b->d_qrows.as<int8_t>() : nullptr;
     D.q_isprof = b->any_profile ? b->d_qisprof.as<uint8_t>() : nullptr;
     D.mat = P.d_mat.as<int8_t>();
@@ -1101,6 +1110,51 @@ extern "C" int mmgpu_pf_run(mmgpu_ctx *c, mmgpu_pf_batch_t *b) {
     return MMGPU_OK;
 }
 
+// QueryMatcher.cpp:147-177 for one nucleotide query whose saturated elements tie (see pf_keepmax_nucl_kernel): the reference
+// sorts its saturated elements by target id with std::sort and gives a target the diagonal of the FIRST of its elements, in
+// the order the sort left, that reaches the best exact score.  Beyond 16 elements that order belongs to libstdc++'s introsort;
+// the same std::sort (this library and the reference are built against the same libstdc++) over the same elements in the
+// same initial order - the reference's array order: cache bin, then arrival - gives it.  Only the diagonal of the target's
+// hit can differ from what the device chose (score and count are equal by the definition of the tie).
+static int pf_resolve_saturated_ties(mmgpu_ctx *c, mmgpu_pf_batch_t *b, uint32_t q, uint32_t n, mmgpu_pf_hit *hits, uint32_t n_hits) {
+    std::vector<PfCand> el(n);
+    hipError_t e = hipMemcpy(el.data(), b->d_sat.as<PfCand>() + (size_t)q * PF_SAT_CAP, (size_t)n * sizeof(PfCand), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return fail(MMGPU_ERR_HIP, std::string("mmgpu_pf_fetch: ") + hipGetErrorString(e));
+    const uint32_t refmask = b->ref_bins - 1;
+    std::sort(el.begin(), el.end(), [&](const PfCand &x, const PfCand &y) {      // the order before the reference's sort (keys are unique)
+        const uint64_t kx = ((uint64_t)(x.id & refmask) << 32) | x.arr, ky = ((uint64_t)(y.id & refmask) << 32) | y.arr;
+        return kx < ky;
+    });
+    std::sort(el.begin(), el.end(), [](const PfCand &x, const PfCand &y) { return x.id < y.id; });      // CounterResult::sortById
+    uint32_t prev = 0xFFFFFFFFu;
+    size_t first = 0;
+    uint64_t best = 0;
+    for (size_t i = 0; i < el.size(); i++) {      // :158-171
+        if (prev == el[i].id) {
+            if ((uint64_t)el[i].score > best) {
+                best = el[i].score;
+                el[first].diag = el[i].diag;
+            }
+        } else {
+            best = (i + 1 < el.size() && el[i + 1].id == el[i].id) ? el[i].score : 0;
+            first = i;
+        }
+        prev = el[i].id;
+    }
+    prev = 0xFFFFFFFFu;
+    for (size_t i = 0; i < el.size(); i++) {      // the first element of every target now carries the diagonal the reference keeps
+        if (el[i].id == prev) continue;
+        prev = el[i].id;
+        for (uint32_t k = 0; k < n_hits; k++)
+            if (hits[k].id == el[i].id) {
+                hits[k].diagonal = el[i].diag;
+                break;
+            }
+    }
+    (void)c;
+    return MMGPU_OK;
+}
+
 extern "C" int mmgpu_pf_fetch(mmgpu_ctx *c, mmgpu_pf_batch_t *b, mmgpu_pf_hit *hits, uint32_t hit_stride, uint32_t *counts,
                               int32_t *status, mmgpu_pf_qstat *stats) {
     if (!c || !b || ((!hits || !counts) && b->nq)) return fail(MMGPU_ERR_ARG, "mmgpu_pf_fetch: NULL argument");
@@ -1123,13 +1177,25 @@ extern "C" int mmgpu_pf_fetch(mmgpu_ctx *c, mmgpu_pf_batch_t *b, mmgpu_pf_hit *h
         match_sum.resize(nq);
         HIP_TRY(hipMemcpyAsync(match_sum.data(), b->d_cells.p, (size_t)nq * 8, hipMemcpyDeviceToHost, s));
     }
+    std::vector<uint32_t> nsat;
+    if (b->par.nucleotide && b->d_qnsat.p) {
+        nsat.resize(nq);
+        HIP_TRY(hipMemcpyAsync(nsat.data(), b->d_qnsat.p, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
+    }
     HIP_TRY(hipStreamSynchronize(s));
     for (uint32_t i = 0; i < nq; i++) {
         if ((flags[i] & 1u) && b->status[i] == MMGPU_PF_OK) b->status[i] = MMGPU_PF_LONG_SEQ;
         if ((flags[i] & 2u) && b->status[i] == MMGPU_PF_OK) b->status[i] = MMGPU_PF_SAT_TIE;
-        // nucleotide searches: a tie between saturated diagonals of one target, in a query whose saturated elements are more than
-        // std::sort's insertion-sort range (pf_keepmax_nucl_kernel)
-        if ((flags[i] & 4u) && (flags[i] >> 8) > 16u && b->status[i] == MMGPU_PF_OK) b->status[i] = MMGPU_PF_SAT_TIE;
+        // nucleotide searches: a tie between saturated diagonals of one target (pf_keepmax_nucl_kernel).  Up to 16 saturated elements
+        // in the query the device's choice is the reference's (insertion sort = stable); beyond, the reference's std::sort is
+        // replayed over the exported elements and the hit's diagonal corrected
+        if ((flags[i] & 4u) && b->status[i] == MMGPU_PF_OK && i < nsat.size() && nsat[i] > 16u) {
+            if (nsat[i] > (uint32_t)PF_SAT_CAP) b->status[i] = MMGPU_PF_SAT_TIE;
+            else {
+                const int rc = pf_resolve_saturated_ties(c, b, i, nsat[i], hits + (size_t)i * hit_stride, counts[i]);
+                if (rc != MMGPU_OK) return rc;
+            }
+        }
         if (b->status[i] != MMGPU_PF_OK) counts[i] = 0;
         if (status) status[i] = b->status[i];
         if (stats) {

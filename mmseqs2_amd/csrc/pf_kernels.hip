@@ -1429,9 +1429,9 @@ __global__ __launch_bounds__(256) void pf_keepmax_kernel(PfDedupArgs A) {
 // reference's std::sort by id left.  libstdc++'s std::sort of at most 16 elements is an insertion sort, i.e. stable, and the
 // order before it is the arrival order for one target - the earliest candidate holding the best score (F below) is the
 // reference's choice as well.  With more than 16 saturated elements in the QUERY the sort partitions and the order of equal
-// ids is not restated: bit 2 of q_flags records such a tie, bits 8.. count the query's saturated elements, and
-// mmgpu_pf_fetch hands the query to the host (MMGPU_PF_SAT_TIE) when both say so.  Without saturated elements the ordinary
-// rule (highest count, earliest arrival).  One wavefront per (query, bin), every bucket (the replay kernel leaves keepMax alone in this
+// ids is a property of introsort: bit 2 of q_flags records such a tie, the query's saturated elements are exported (A.sat,
+// A.q_nsat) and mmgpu_pf_fetch runs the same std::sort over them on the host and corrects the diagonal of the target's hit.
+// Without saturated elements the ordinary rule (highest count, earliest arrival).  One wavefront per (query, bin), every bucket (the replay kernel leaves keepMax alone in this
 // mode); two LDS tables: best key per target, and the first candidate holding it.
 __global__ __launch_bounds__(128) void pf_keepmax_nucl_kernel(PfDedupArgs A) {
     __shared__ uint32_t s_key[2][PF_IDS_PER_BIN];
@@ -1459,18 +1459,26 @@ __global__ __launch_bounds__(128) void pf_keepmax_nucl_kernel(PfDedupArgs A) {
         const uint32_t cnt = min(255u, c.score);
         return cnt >= 255u ? (0xFF000000u | min(c.score, 0xFFFFFFu)) : ((cnt << 24) | (0xFFFFFFu - min(ci, 0xFFFFFEu)));
     };
-    uint32_t nsat = 0;      // saturated elements of this bucket: the length of the range the reference sorts is their total over the query
+    // the saturated elements also go to the query's export list: the range the reference sorts is all of them (fetch)
     for (uint32_t c0 = 0; c0 < ncand; c0 += 64) {
         const uint32_t ci = c0 + (uint32_t)lane;
         bool sat = false;
+        PfCand c;
+        c.id = 0; c.arr = 0; c.score = 0; c.diag = 0; c.pad = 0;
         if (ci < ncand) {
-            const PfCand c = *cand_slot(A, bucket, ci);
+            c = *cand_slot(A, bucket, ci);
             atomicMax(&K[c.id >> bshift], key_of(c, ci));
             sat = c.score >= 255u;
         }
-        nsat += (uint32_t)__popcll(__ballot(sat));
+        const uint64_t sb = __ballot(sat);
+        if (sb && A.q_nsat) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&A.q_nsat[q], (uint32_t)__popcll(sb));
+            base = __shfl(base, 0);
+            const uint32_t slot = base + (uint32_t)__popcll(sb & lanes_below(lane));
+            if (sat && slot < A.sat_cap) A.sat[(size_t)q * A.sat_cap + slot] = c;
+        }
     }
-    if (lane == 0 && nsat && A.q_flags) atomicAdd(&A.q_flags[q], min(nsat, 17u) << 8);      // (capped per bucket: only '> 16' is asked)
     for (uint32_t c0 = 0; c0 < ncand; c0 += 64) {
         const uint32_t ci = c0 + (uint32_t)lane;
         if (ci < ncand) {

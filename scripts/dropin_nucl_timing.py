@@ -65,7 +65,7 @@ run(STOCK, ["createdb", "q.fasta", "q", "-v", "1"])
 run(STOCK, ["createdb", "t.fasta", "t", "-v", "1"])
 res = {"workload": "%d reads of %d nt vs %d contigs (median 20 kb), `mmseqs search --search-type 3 -a`" % (reads, read_len, contigs)}
 for name, b, th in (("stock_threads_%d" % threads, STOCK, threads), ("stock_threads_1", STOCK, 1), ("patched_threads_%d" % threads, MMGPU, threads)):
-    t, log = run(b, ["search", "q", "t", "res_" + name, "tmp_" + name, "--search-type", "3", "-a", "--threads", str(th), "-v", "3"] + extra)
+    t, log = run(b, ["search", "q", "t", "res_" + name, "tmp_" + name, "--search-type", "3", "-a", "--threads", str(th), "-v", "3", "--remove-tmp-files", "0"] + extra)
     res[name] = dict(workflow_wall_s=round(t, 2), **module_times(log))
     if b == MMGPU:
         res[name]["nucleotide_alignment_on_the_device"] = "MMGPU: nucleotide alignment on the device" in log
@@ -78,6 +78,17 @@ def same(a, b):
     return sum(1 for k in da if da[k] != db.get(k)) + sum(1 for k in db if k not in da), len(da)
 
 
+def find(tmp, name):
+    for root, _, files in os.walk(os.path.join(w, tmp)):
+        if name + ".index" in files:      # (the data may be in per-thread files name.0, name.1, ...)
+            return os.path.relpath(os.path.join(root, name), w)
+    return None
+
+
+# the prefilter databases of the workflows (strand-queries x split targets), entry by entry
+pa, pb = find("tmp_patched_threads_%d" % threads, "pref_0"), find("tmp_stock_threads_1", "pref_0")
+if pa and pb:
+    res["prefilter_entries_differing_patched_vs_stock"], res["prefilter_entries"] = same(pa, pb)
 res["entries_differing_patched_vs_stock_one_thread"], res["entries"] = same("res_patched_threads_%d" % threads, "res_stock_threads_1")
 res["entries_differing_stock_%d_threads_vs_stock_one_thread" % threads] = same("res_stock_threads_%d" % threads, "res_stock_threads_1")[0]
 print(json.dumps(res))
