@@ -814,8 +814,10 @@ extern "C" int mmgpu_sw_run(mmgpu_ctx *c, mmgpu_sw_batch_t *b) {
         // the critical path, the other groups fill the CUs it leaves
         int prio_low = 0, prio_high = 0;
         HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));   // numerically lower = higher priority
+        const char *pe = getenv("MMGPU_SW_PRIORITY");      // experiments: one of h / m / l per group, e.g. "lhm"
         for (int g = 0; g < SW_GROUPS; g++) {
-            const int prio = g == SW_GROUPS - 1 ? prio_high : (g == 0 ? prio_low : (prio_low + prio_high) / 2);
+            int prio = g == SW_GROUPS - 1 ? prio_high : (g == 0 ? prio_low : (prio_low + prio_high) / 2);
+            if (pe && strlen(pe) == (size_t)SW_GROUPS) prio = pe[g] == 'h' ? prio_high : (pe[g] == 'l' ? prio_low : (prio_low + prio_high) / 2);
             HIP_TRY(hipStreamCreateWithPriority(&c->side[g], hipStreamNonBlocking, prio));
         }
         HIP_TRY(hipEventCreateWithFlags(&c->fork, hipEventDisableTiming));
