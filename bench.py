@@ -893,7 +893,7 @@ def main():
                        "collectives": H.get("collectives")},
             "ms_per_step_stages": {"prefilter_kernels": round(H["pf_ms"], 2), "align_kernels": round(k_ms, 2),
                                    "handover_exchange_and_host": round(ms_per_step - H["pf_ms"] - k_ms, 2)},
-            "roofline": {"kernel": "sw_kernel<G,true> (three grids: tile shapes grouped by register need, forward + reverse scan)",
+            "roofline": {"kernel": "sw_kernel<G,true> (four concurrent grids: tile shapes grouped by register need, forward + reverse scan; + sw_rev_multi_kernel)",
                          "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6),
                          "traffic": pmc_traffic(("sw_kernel<", "sw_rev_multi_kernel"), PROFILE_ROUND + "_search") if default_wl else None,

@@ -272,8 +272,8 @@ struct mmgpu_sw_batch_t {
     // all jobs of the batch, by kernel group (sw_kernel.hip), longest first inside a group; SwJob::shape picks the body
     uint32_t n_jobs = 0, n_multi_jobs = 0;
     uint32_t n_rev_jobs = 0;      // reverse-scan jobs of the multi-tile queries (mode START), behind the forward jobs in d_jobs
-    uint32_t group_begin[SW_GROUPS + 1] = {0, 0, 0, 0};
-    size_t group_lds[SW_GROUPS] = {0, 0, 0};   // largest profile of any shape present in the group
+    uint32_t group_begin[SW_GROUPS + 1] = {};
+    size_t group_lds[SW_GROUPS] = {};   // largest profile of any shape present in the group
     DevBuf d_jobs;
     DevBuf d_scratch;             // multi-tile jobs: [scratch slot][4 waves][4 groups][2 buffers][scratch_cols] x uint2
     DevBuf d_scratch_busy;        // one flag per slot of the pool (sw_kernel claims / releases)
@@ -824,7 +824,7 @@ extern "C" int mmgpu_sw_run(mmgpu_ctx *c, mmgpu_sw_batch_t *b) {
         for (auto &e : c->join) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     HIP_TRY(hipEventRecord(c->fork, c->stream));
-    for (auto &st : c->side) HIP_TRY(hipStreamWaitEvent(st, c->fork, 0));
+    for (int g = 0; g < SW_GROUPS; g++) HIP_TRY(hipStreamWaitEvent(c->side[g], c->fork, 0));
     for (int g = SW_GROUPS - 1; g >= 0; g--) {
         hipStream_t st = c->side[g];
         {

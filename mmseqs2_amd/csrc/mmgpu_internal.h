@@ -112,7 +112,13 @@ static_assert(SW_MAX_R >= 16 && SW_MAX_R <= 32 && SW_MAX_R % 2 == 0, "multi-tile
 #define MMGPU_SW_MIN_WAVES 2
 #endif
 constexpr int SW_MIN_WAVES = MMGPU_SW_MIN_WAVES;   // occupancy floor (waves per SIMD) the alignment kernels are compiled for
-constexpr int SW_GROUPS = 3;   // kernels per pass: tile shapes grouped by register need (sw_kernel.hip)
+#ifndef MMGPU_SW_GROUPS
+#define MMGPU_SW_GROUPS 4
+#endif
+// kernels per pass: tile shapes grouped by register need (sw_kernel.hip): R <= 12, R <= 24, single tiles of R >= 26, and - always
+// the last group - the queries cut into several tiles (3: the last two in one kernel, rounds 1-2)
+constexpr int SW_GROUPS = MMGPU_SW_GROUPS;
+static_assert(SW_GROUPS == 3 || SW_GROUPS == 4, "three or four kernel groups");
 int sw_shape_group(uint32_t shape);
 hipError_t launch_sw(const SwLaunch &L, int group, size_t lds_bytes, bool both_passes, hipStream_t stream);
 size_t sw_lds_bytes(int rows_per_lane, int alphabet);
@@ -644,8 +650,8 @@ struct mmgpu_ctx {
     } shard;
     std::shared_ptr<mmgpu::BlockCache> cache = std::make_shared<mmgpu::BlockCache>();   // device blocks of freed alignment batches
     // the alignment kernel groups run concurrently on side streams forked from / joined to `stream` (mmgpu_sw_run)
-    hipStream_t side[3] = {nullptr, nullptr, nullptr};
-    hipEvent_t fork = nullptr, join[3] = {nullptr, nullptr, nullptr};
+    hipStream_t side[4] = {};      // (SW_GROUPS of them are used)
+    hipEvent_t fork = nullptr, join[4] = {};
 };
 
 struct mmgpu_pf_batch_t;

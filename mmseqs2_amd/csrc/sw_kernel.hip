@@ -539,7 +539,7 @@ __attribute__((amdgpu_waves_per_eu(G == 0 ? (BOTH ? MMGPU_SW_WAVES_G0B : MMGPU_S
     // workgroups of this kernel can be resident at once, so the search always ends; a slot is only ever read after its
     // owner wrote it (tile t writes what tile t + 1 reads), so stale content is harmless.
     __shared__ uint32_t scratch_slot;
-    const bool claims = G == 2 && (job.shape & 0xFFu) >= 16u;
+    const bool claims = G == SW_GROUPS - 1 && (job.shape & 0xFFu) >= 16u;
     if (claims) {
         if (threadIdx.x == 0) {
             uint32_t s = blockIdx.x % L.scratch_slots;
@@ -559,6 +559,17 @@ __attribute__((amdgpu_waves_per_eu(G == 0 ? (BOTH ? MMGPU_SW_WAVES_G0B : MMGPU_S
     } else if constexpr (G == 1) {
         switch (job.shape & 0xFFu) {
             MMGPU_SW_SINGLE(14) MMGPU_SW_SINGLE(16) MMGPU_SW_SINGLE(18) MMGPU_SW_SINGLE(20) MMGPU_SW_SINGLE(22) MMGPU_SW_SINGLE(24)
+            default: break;
+        }
+    } else if constexpr (SW_GROUPS == 4 && G == 2) {
+        switch (job.shape & 0xFFu) {
+            MMGPU_SW_SINGLE(26) MMGPU_SW_SINGLE(28) MMGPU_SW_SINGLE(30) MMGPU_SW_SINGLE(32)
+            default: break;
+        }
+    } else if constexpr (SW_GROUPS == 4) {
+        switch (job.shape & 0xFFu) {
+            MMGPU_SW_MULTI(8) MMGPU_SW_MULTI(10) MMGPU_SW_MULTI(12) MMGPU_SW_MULTI(14) MMGPU_SW_MULTI(16) MMGPU_SW_MULTI(18) MMGPU_SW_MULTI(20) MMGPU_SW_MULTI(22) MMGPU_SW_MULTI(24) MMGPU_SW_MULTI(26)
+            MMGPU_SW_MULTI(28) MMGPU_SW_MULTI(30) MMGPU_SW_MULTI(32)
             default: break;
         }
     } else {
@@ -687,8 +698,8 @@ hipError_t launch_sw_from_pf(const SwFromPfArgs &A, uint32_t nq, hipStream_t str
 uint32_t sw_multi_resident_blocks(size_t lds_bytes, bool both_passes, int compute_units) {
     int per_cu = 0;
     const size_t lds = lds_bytes + SW_LDS_HEADER;
-    hipError_t e = both_passes ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sw_kernel<2, true>, WAVES * 64, lds)
-                               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sw_kernel<2, false>, WAVES * 64, lds);
+    hipError_t e = both_passes ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sw_kernel<SW_GROUPS - 1, true>, WAVES * 64, lds)
+                               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sw_kernel<SW_GROUPS - 1, false>, WAVES * 64, lds);
     if (e == hipSuccess && both_passes) {   // the reverse kernel of the multi-tile queries draws on the same pool
         int rev = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&rev, sw_rev_multi_kernel, WAVES * 64, lds) == hipSuccess) per_cu = std::max(per_cu, rev);
@@ -710,7 +721,7 @@ hipError_t launch_sw_rev_multi(const SwLaunch &L, size_t lds_bytes, hipStream_t 
 }
 
 int sw_shape_group(uint32_t shape) {
-    if (shape >= 16) return 2;
+    if (shape >= 16) return SW_GROUPS - 1;
     const int R = 2 * ((int)shape + 1);
     return R <= 12 ? 0 : (R <= 24 ? 1 : 2);
 }
@@ -727,6 +738,8 @@ hipError_t launch_sw(const SwLaunch &L, int group, size_t lds_bytes, bool both_p
         case 3: hipLaunchKernelGGL((sw_kernel<1, true>), grid, block, lds, stream, L); break;
         case 4: hipLaunchKernelGGL((sw_kernel<2, false>), grid, block, lds, stream, L); break;
         case 5: hipLaunchKernelGGL((sw_kernel<2, true>), grid, block, lds, stream, L); break;
+        case 6: hipLaunchKernelGGL((sw_kernel<SW_GROUPS - 1, false>), grid, block, lds, stream, L); break;      // (SW_GROUPS == 4 only)
+        case 7: hipLaunchKernelGGL((sw_kernel<SW_GROUPS - 1, true>), grid, block, lds, stream, L); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
