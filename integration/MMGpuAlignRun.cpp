@@ -142,11 +142,12 @@ bool MMGpuAlignRun::run(Alignment &al, const std::string &outDB, const std::stri
     }
     dbtype = DBReader<DBKeyType>::setExtendedDbtype(dbtype, DBReader<DBKeyType>::getExtendedDbtype(al.prefdbr->getDbtype()));
     DBWriter dbw(outDB.c_str(), outDBIndex.c_str(), al.threads, al.compressed, dbtype);
-    dbw.open();
     if (dbSize == 0) {
+        dbw.open();
         dbw.close(merge);
         return true;
     }
+    // (the writer's files are created once the targets are resident: a database the device cannot hold leaves the run to the CPU loop)
     EvalueComputation evaluer(al.tdbr->getAminoAcidDBSize(), al.m, al.gapOpen, al.gapExtend);
     const unsigned int threads = al.threads;
 
@@ -208,9 +209,14 @@ bool MMGpuAlignRun::run(Alignment &al, const std::string &outDB, const std::stri
     if (devices.empty()) devices.push_back(gpu);
     for (size_t d = 0; d < devices.size(); d++)
         if (mmgpu_load_targets(devices[d], store.residues.data(), store.offsets.data(), (uint32_t)nTargets, al.m->alphabetSize) != 0) {
-            Debug(Debug::ERROR) << "MMGPU: " << mmgpu_last_error() << "\n";
-            EXIT(EXIT_FAILURE);
+            Debug(Debug::WARNING) << "MMGPU: the targets of this run cannot be made resident (" << mmgpu_last_error() << "), using the CPU path\n";
+            for (size_t i = 0; i < threads; i++) {
+                delete qSeqs[i];
+                delete dbSeqs[i];
+            }
+            return false;
         }
+    dbw.open();
 
     watch.lap("mmgpu_load_targets");
     MMGpuAlignBackend *backend = devices.size() > 1 ? mmgpuNewMultiDeviceBackend(devices) : mmgpuNewDeviceBackend(gpu);

@@ -137,6 +137,11 @@ int mmgpu_pf_load_index(mmgpu_ctx *c, const mmgpu_pf_index *ix) {
     const int32_t scal[4] = {ix->kmer_size, ix->alphabet, ix->spaced, two ? 1 : 0};
     fp = fingerprint(scal, sizeof(scal), fp);
     fp = fingerprint(ix->score3, n3 * ix->row3 * 2, fp);
+    fp = fingerprint(ix->index3, n3 * ix->row3 * 4, fp);
+    if (two) {
+        fp = fingerprint(ix->score2, n2 * ix->row2 * 2, fp);
+        fp = fingerprint(ix->index2, n2 * ix->row2 * 4, fp);
+    }
     fp = fingerprint(ix->offsets, (table + 1) * 8, fp);
     if (ix->entries6) fp = fingerprint(ix->entries6, (size_t)ix->n_entries * 6, fp);
     else {
