@@ -1,0 +1,44 @@
+// State of one Alignment::run on the device (MMGpuAlignRun.cpp, MMGpuNuclAlignRun.cpp): the resident targets and, bucket by
+// bucket of queries, the results the reference's loop takes at getSWResult's call site.
+#ifndef MMGPU_ALIGN_SESSION_H
+#define MMGPU_ALIGN_SESSION_H
+
+#include <vector>
+
+#include "Matcher.h"
+
+#include "MMGpuMatcher.h"
+#include "MMGpuRun.h"
+
+class Alignment;
+class EvalueComputation;
+struct MMGpuNuclState;      // MMGpuNuclAlignRun.cpp
+
+struct MMGpuAlignSession {
+    MMGpuAlignSession(Alignment &al, EvalueComputation &evaluer);
+    ~MMGpuAlignSession();
+
+    Alignment &al;
+    EvalueComputation &evaluer;
+    mmgpu_ctx *gpu;
+    bool nucleotide;
+    MMGpuStopwatch watch;
+    // resident targets: Sequence::numSequence of the entries the lists name, ids = DBReader ids
+    std::vector<unsigned char> targetResidues;
+    std::vector<uint64_t> targetOffsets;
+    // amino-acid / profile queries
+    MMGpuAlignBackend *backend;
+    MMGpuMatcher *matcher;
+    MMGpuBlockBacktracer *blockHook;
+    // the bucket in flight: queries [start, start + size) of the prefilter database
+    size_t start, size;
+    std::vector<MMGpuMatcher::Query> block;
+    std::vector<std::vector<unsigned char> > queryNum;
+    std::vector<std::vector<int8_t> > queryProfile;       // profile queries: Sequence::getAlignmentProfile()
+    std::vector<std::vector<Matcher::result_t> > results;     // [query][k-th entry that reaches getSWResult]
+    std::vector<std::vector<unsigned char> > hostPair;        // same shape: 1 = the loop's own Matcher computes it (take)
+    // nucleotide databases
+    MMGpuNuclState *nucl;
+};
+
+#endif

@@ -1,7 +1,7 @@
-// Alignment::run (src/alignment/Alignment.cpp:248-542) for nucleotide databases with BandedNucleotideAligner::align
-// (src/alignment/BandedNucleotideAligner.cpp:76-263, called by Matcher::getSWResult, Matcher.cpp:72-79) on libmmgpu:
-// one mmgpu_nucl_align call per block of queries, then the reference's own statements on the results (getSWResult's tail
-// Matcher.cpp:91-146, checkCriteria, Matcher::compareHits, Matcher::resultToBuffer, DBWriter).
+// The hook behind Alignment::run (MMGpuAlignRun.cpp) for nucleotide databases: BandedNucleotideAligner::align
+// (src/alignment/BandedNucleotideAligner.cpp:76-263, called by Matcher::getSWResult, Matcher.cpp:72-79) on libmmgpu - one
+// mmgpu_nucl_align call per bucket of queries, getSWResult's tail (Matcher.cpp:91-146) on the results; the reference's loop
+// takes them at getSWResult's call site (MMGpuAlignRun::take).
 //
 // The letter past the end.  The reference reverses both sequences with SmithWaterman::seq_reverse(dst, src, L) where the
 // function expects L - 1 (BandedNucleotideAligner.cpp:61,68,93): the reversed copies start with src[L], one residue past
@@ -14,15 +14,15 @@
 // pair its two letters (mmgpu_nucl_pair::past_end); memory no sequence has written yet counts as 0 (= 'A'), which is what a
 // fresh heap gives the reference.  Output = `mmseqs align --threads 1` of the stock binary, whatever --threads is here.
 //
-// Not served (the reference's loop runs, MMGpuAlignRun::usable): wrapped scoring, --realign, --alt-ali, lcaalign and finite
-// --max-accept / --max-rejected (where the loop stops decides what the buffers hold for the next query).
+// Not served (the reference's loop computes, MMGpuAlignRun::usableNucleotide): wrapped scoring, --realign, --alt-ali, lcaalign
+// and finite --max-accept / --max-rejected (where the loop stops, and what it aligns a second time, decides what the buffers
+// hold for the next query).
 #include <climits>
 #include <cstring>
 #include <string>
 #include <vector>
 
 #include "Alignment.h"
-#include "DBWriter.h"
 #include "Debug.h"
 #include "EvalueComputation.h"
 #include "NucleotideMatrix.h"
@@ -30,7 +30,7 @@
 #include "StripedSmithWaterman.h"
 #include "Util.h"
 
-#include "MMGpuRun.h"
+#include "MMGpuAlignSession.h"
 
 #ifdef OPENMP
 #include <omp.h>
@@ -49,7 +49,7 @@ public:
         it.len = len;
         items.push_back(it);
     }
-    // the forward residue index of the sequence that owns buffer index `idx` right now, or false: nothing written there yet
+    // the sequence that owns buffer index `idx` right now, or false: nothing written there yet
     bool owner(size_t idx, const unsigned char **seq, size_t *len) const {
         for (size_t k = items.size(); k-- > 0;)
             if (items[k].len > idx) {
@@ -74,10 +74,19 @@ struct Entry {          // one line of a prefilter list (:345-360)
     unsigned short diagonal;
     bool reverse;
     bool covered;       // Util::canBeCovered (:370)
-    unsigned char pastEnd;
 };
 
 }  // namespace
+
+struct MMGpuNuclState {
+    int8_t mat[25];
+    uint8_t rev[5];
+    mmgpu_nucl_params par;
+    // what one thread of the reference would have in its three buffers
+    BufferHistory qHistory, rcHistory, tHistory;
+    // (the queries of earlier buckets stay alive: the histories point into them)
+    std::vector<std::vector<std::vector<unsigned char> > *> keepQueries;
+};
 
 bool MMGpuAlignRun::usableNucleotide(const Alignment &a) {
     const bool nucl = Parameters::isEqualDbtype(a.querySeqType, Parameters::DBTYPE_NUCLEOTIDES) &&
@@ -88,293 +97,179 @@ bool MMGpuAlignRun::usableNucleotide(const Alignment &a) {
            a.m->alphabetSize == 5;
 }
 
-bool MMGpuAlignRun::runNucleotide(Alignment &al, const std::string &outDB, const std::string &outDBIndex, const size_t dbFrom,
-                                  const size_t dbSize, bool merge) {
-    MMGpuStopwatch watch("align (nucleotide)");
-    mmgpu_ctx *gpu = MMGpuRun::context();
+void MMGpuAlignRun::beginNucleotide(MMGpuAlignSession *s) {
+    Alignment &al = s->al;
     Debug(Debug::INFO) << "MMGPU: nucleotide alignment on the device (results = the reference's loop with one thread; MMGPU_NUCL_ALIGN=0 keeps the CPU loop)\n";
-    watch.lap("open device");
-    int dbtype = Parameters::DBTYPE_ALIGNMENT_RES;
-    if (al.alignmentOutputMode == Parameters::ALIGNMENT_OUTPUT_CLUSTER) dbtype = Parameters::DBTYPE_CLUSTER_RES;
-    dbtype = DBReader<DBKeyType>::setExtendedDbtype(dbtype, DBReader<DBKeyType>::getExtendedDbtype(al.prefdbr->getDbtype()));
-    DBWriter dbw(outDB.c_str(), outDBIndex.c_str(), al.threads, al.compressed, dbtype);
-    dbw.open();
-    if (dbSize == 0) {
-        dbw.close(merge);
-        return true;
-    }
-    EvalueComputation evaluer(al.tdbr->getAminoAcidDBSize(), al.m, al.gapOpen, al.gapExtend);
+    MMGpuNuclState *n = new MMGpuNuclState();
     NucleotideMatrix *nm = static_cast<NucleotideMatrix *>(al.m);
-    const unsigned int threads = al.threads;
+    for (int i = 0; i < 5; i++) {
+        for (int j = 0; j < 5; j++) n->mat[i * 5 + j] = (int8_t)al.m->subMatrix[i][j];      // BandedNucleotideAligner.cpp:28-34
+        n->rev[i] = (uint8_t)nm->reverseResidue(i);
+    }
+    n->par.mat = n->mat;
+    n->par.reverse = n->rev;
+    n->par.gap_open = al.gapOpen;
+    n->par.gap_extend = al.gapExtend;
+    n->par.zdrop = al.zdrop;
+    n->par.past_end_query = 0;
+    n->par.past_end_target = 0;
+    s->nucl = n;
+}
 
-    // ---- resident targets: Sequence::numSequence of every entry of the target DB
-    const size_t nTargets = al.tdbr->getSize();
-    std::vector<uint64_t> tOff(nTargets + 1, 0);
-    for (size_t id = 0; id < nTargets; id++) tOff[id + 1] = tOff[id] + al.tdbr->getSeqLen(id);
-    std::vector<unsigned char> tRes(tOff[nTargets] + 1);
-    std::vector<Sequence *> seqs(threads, NULL);
-#pragma omp parallel num_threads(threads)
+void MMGpuAlignRun::endNucleotide(MMGpuAlignSession *s) {
+    if (s->nucl == NULL) return;
+    for (size_t i = 0; i < s->nucl->keepQueries.size(); i++) delete s->nucl->keepQueries[i];
+    delete s->nucl;
+    s->nucl = NULL;
+}
+
+void MMGpuAlignRun::planNucleotide(MMGpuAlignSession *s) {
+    Alignment &al = s->al;
+    MMGpuNuclState &N = *s->nucl;
+    NucleotideMatrix *nm = static_cast<NucleotideMatrix *>(al.m);
+    const std::vector<uint64_t> &tOff = s->targetOffsets;
+    const std::vector<unsigned char> &tRes = s->targetResidues;
+    const size_t nq = s->size, next = s->start;
+    std::vector<std::vector<unsigned char> > *queryNumPtr = new std::vector<std::vector<unsigned char> >(nq);
+    N.keepQueries.push_back(queryNumPtr);
+    std::vector<std::vector<unsigned char> > &queryNum = *queryNumPtr;
+    std::vector<std::vector<Entry> > lists(nq);
+    std::vector<DBKeyType> queryKeys(nq, 0);
+
+    // ---- parse: the list walk of :316-375 without the alignment
+#pragma omp parallel num_threads(al.threads)
     {
         unsigned int thread_idx = 0;
 #ifdef OPENMP
         thread_idx = static_cast<unsigned int>(omp_get_thread_num());
 #endif
-        seqs[thread_idx] = new Sequence(al.maxSeqLen, al.targetSeqType, al.m, 0, false, false);
-        Sequence &s = *seqs[thread_idx];
-#pragma omp for schedule(dynamic, 256)
-        for (size_t id = 0; id < nTargets; id++) {
-            char *data = al.tdbr->getData(id, thread_idx);
-            if (data == NULL) continue;
-            s.mapSequence(id, al.tdbr->getDbKey(id), data, al.tdbr->getSeqLen(id));
-            memcpy(tRes.data() + tOff[id], s.numSequence, s.L);
+        Sequence qSeq(al.maxSeqLen, al.querySeqType, al.m, 0, false, false);
+        char buffer[1024];
+        const char *words[10];
+#pragma omp for schedule(dynamic, 5)
+        for (size_t b = 0; b < nq; b++) {
+            const size_t id = next + b;
+            char *data = al.prefdbr->getData(id, thread_idx);
+            const DBKeyType queryDbKey = al.prefdbr->getDbKey(id);
+            queryKeys[b] = queryDbKey;
+            size_t origQueryLen = 0;
+            if (*data != '\0') {
+                const size_t qId = al.qdbr->getId(queryDbKey);
+                char *querySeqData = al.qdbr->getData(qId, thread_idx);
+                if (querySeqData == NULL) continue;      // (the loop reports it)
+                origQueryLen = al.qdbr->getSeqLen(qId);
+                qSeq.mapSequence(qId, queryDbKey, querySeqData, origQueryLen);
+                queryNum[b].assign(qSeq.numSequence, qSeq.numSequence + qSeq.L);
+            }
+            while (*data != '\0') {
+                Util::parseKey(data, buffer);
+                Entry e;
+                e.dbKey = Util::fast_atoi<DBKeyType>(buffer);
+                const size_t elements = Util::getWordsOfLine(data, words, 10);
+                e.diagonal = 0;
+                e.reverse = false;
+                if (elements == 3) {
+                    hit_t hit = QueryMatcher::parsePrefilterHit(data);
+                    e.reverse = al.reversePrefilterResult && (hit.prefScore < 0);
+                    e.diagonal = (unsigned short)static_cast<short>(hit.diagonal);
+                }
+                data = Util::skipLine(data);
+                const size_t dbId = al.tdbr->getId(e.dbKey);
+                if (dbId >= al.tdbr->getSize() || al.tdbr->getData(dbId, thread_idx) == NULL) break;      // (the loop reports it and ends the run)
+                e.dbId = (unsigned int)dbId;
+                e.covered = Util::canBeCovered(al.canCovThr, al.covMode, static_cast<float>(origQueryLen),
+                                               static_cast<float>(tOff[dbId + 1] - tOff[dbId]));
+                lists[b].push_back(e);
+            }
         }
     }
-    if (mmgpu_load_targets(gpu, tRes.data(), tOff.data(), (uint32_t)nTargets, 5) != 0) {
+    s->watch.lap("parse bucket");
+
+    // ---- the buffers of one reference thread, query by query and line by line (:337-338 mapSequence + initQuery, :368 mapSequence)
+    std::vector<mmgpu_nucl_query> dq;
+    std::vector<mmgpu_nucl_pair> pairs;
+    std::vector<size_t> firstPair(nq + 1, 0);
+    uint64_t btCap = 16;
+    for (size_t b = 0; b < nq; b++) {
+        firstPair[b] = pairs.size();
+        if (lists[b].empty()) continue;
+        const std::vector<unsigned char> &q = queryNum[b];
+        const size_t L = q.size();
+        N.qHistory.map(q.data(), L);
+        N.rcHistory.map(q.data(), L);
+        const unsigned char *os;
+        size_t ol;
+        unsigned int pastForward = 0, pastReverse = 0;
+        if (N.qHistory.owner(L, &os, &ol)) pastForward = os[L];
+        // queryRevCompSeq[(len - 1) - pos] = reverseResidue(numSequence[pos]) (:64-67)
+        if (N.rcHistory.owner(L, &os, &ol)) pastReverse = (unsigned int)nm->reverseResidue(os[ol - 1 - L]);
+        mmgpu_nucl_query nqy;
+        nqy.q = q.data();
+        nqy.qlen = (uint32_t)L;
+        const uint32_t qIndex = (uint32_t)dq.size();
+        dq.push_back(nqy);
+        for (size_t k = 0; k < lists[b].size(); k++) {
+            Entry &e = lists[b][k];
+            const size_t tl = (size_t)(tOff[e.dbId + 1] - tOff[e.dbId]);
+            N.tHistory.map(tRes.data() + tOff[e.dbId], tl);
+            if (!e.covered) continue;
+            unsigned int pastTarget = 0;
+            if (N.tHistory.owner(tl, &os, &ol)) pastTarget = os[tl];
+            mmgpu_nucl_pair p;
+            p.query = qIndex;
+            p.target = e.dbId;
+            p.diagonal = e.diagonal;
+            p.reverse = e.reverse ? 1 : 0;
+            p.past_end = MMGPU_NUCL_PAST_END(e.reverse ? pastReverse : pastForward, pastTarget);
+            pairs.push_back(p);
+            btCap += (uint64_t)L + tl + 2;
+        }
+    }
+    firstPair[nq] = pairs.size();
+    s->watch.lap("buffer history");
+
+    // ---- one device call for the bucket
+    std::vector<mmgpu_nucl_hit> hits(pairs.size());
+    std::vector<char> bt(btCap);
+    uint64_t btUsed = 0;
+    if (!pairs.empty() && mmgpu_nucl_align(s->gpu, &N.par, dq.data(), (uint32_t)dq.size(), pairs.data(), (uint32_t)pairs.size(), hits.data(),
+                                           bt.data(), btCap, &btUsed) != 0) {
         Debug(Debug::ERROR) << "MMGPU: " << mmgpu_last_error() << "\n";
         EXIT(EXIT_FAILURE);
     }
-    watch.lap("map + upload targets");
+    s->watch.lap("mmgpu_nucl_align");
 
-    int8_t mat[25];
-    uint8_t rev[5];
-    for (int i = 0; i < 5; i++) {
-        for (int j = 0; j < 5; j++) mat[i * 5 + j] = (int8_t)al.m->subMatrix[i][j];      // BandedNucleotideAligner.cpp:28-34
-        rev[i] = (uint8_t)nm->reverseResidue(i);
-    }
-    mmgpu_nucl_params par;
-    par.mat = mat;
-    par.reverse = rev;
-    par.gap_open = al.gapOpen;
-    par.gap_extend = al.gapExtend;
-    par.zdrop = al.zdrop;
-    par.past_end_query = 0;
-    par.past_end_target = 0;
-
-    // what one thread of the reference would have in its three buffers
-    BufferHistory qHistory, rcHistory, tHistory;
-    // (the queries of earlier blocks stay alive: the histories point into them)
-    std::vector<std::vector<std::vector<unsigned char> > *> keepQueries;
-
-    const size_t maxBlockQueries = MMGpuRun::envSize("MMGPU_ALIGN_BLOCK_QUERIES", 16384);
-    const size_t maxBlockBytes = MMGpuRun::envSize("MMGPU_ALIGN_BLOCK_BYTES", 192u << 20);
-    const bool remap = Util::getTotalSystemMemory() <= al.prefdbr->getTotalDataSize();
-    size_t alignmentsNum = 0, totalPassedNum = 0;
-    Debug::Progress progress(dbSize);
-    size_t next = dbFrom;
-    const size_t end = dbFrom + dbSize;
-    while (next < end) {
-        size_t blockEnd = next, bytes = 0;
-        while (blockEnd < end && blockEnd - next < maxBlockQueries && (bytes < maxBlockBytes || blockEnd == next)) {
-            bytes += al.prefdbr->getEntryLen(blockEnd);
-            blockEnd++;
-        }
-        const size_t nq = blockEnd - next;
-        std::vector<std::vector<unsigned char> > *queryNumPtr = new std::vector<std::vector<unsigned char> >(nq);
-        keepQueries.push_back(queryNumPtr);
-        std::vector<std::vector<unsigned char> > &queryNum = *queryNumPtr;
-        std::vector<std::vector<Entry> > lists(nq);
-        std::vector<DBKeyType> queryKeys(nq, 0);
-
-        // ---- parse: the list walk of :316-375 without the alignment
-#pragma omp parallel num_threads(threads)
-        {
-            unsigned int thread_idx = 0;
-#ifdef OPENMP
-            thread_idx = static_cast<unsigned int>(omp_get_thread_num());
-#endif
-            Sequence &qSeq = *seqs[thread_idx];
-            char buffer[1024];
-            const char *words[10];
-#pragma omp for schedule(dynamic, 5)
-            for (size_t b = 0; b < nq; b++) {
-                const size_t id = next + b;
-                char *data = al.prefdbr->getData(id, thread_idx);
-                const DBKeyType queryDbKey = al.prefdbr->getDbKey(id);
-                queryKeys[b] = queryDbKey;
-                size_t origQueryLen = 0;
-                if (*data != '\0') {
-                    const size_t qId = al.qdbr->getId(queryDbKey);
-                    char *querySeqData = al.qdbr->getData(qId, thread_idx);
-                    if (querySeqData == NULL) {
-                        Debug(Debug::ERROR) << "Query sequence " << queryDbKey
-                                            << " is required in the prefiltering, but is not contained in the query sequence database.\nPlease check your database.\n";
-                        EXIT(EXIT_FAILURE);
-                    }
-                    origQueryLen = al.qdbr->getSeqLen(qId);
-                    qSeq.mapSequence(qId, queryDbKey, querySeqData, origQueryLen);
-                    queryNum[b].assign(qSeq.numSequence, qSeq.numSequence + qSeq.L);
-                }
-                while (*data != '\0') {
-                    Util::parseKey(data, buffer);
-                    Entry e;
-                    e.dbKey = Util::fast_atoi<DBKeyType>(buffer);
-                    const size_t elements = Util::getWordsOfLine(data, words, 10);
-                    e.diagonal = 0;
-                    e.reverse = false;
-                    if (elements == 3) {
-                        hit_t hit = QueryMatcher::parsePrefilterHit(data);
-                        e.reverse = al.reversePrefilterResult && (hit.prefScore < 0);
-                        e.diagonal = (unsigned short)static_cast<short>(hit.diagonal);
-                    }
-                    data = Util::skipLine(data);
-                    const size_t dbId = al.tdbr->getId(e.dbKey);
-                    if (al.tdbr->getData(dbId, thread_idx) == NULL) {
-                        Debug(Debug::ERROR) << "Sequence " << e.dbKey << " is required in the prefiltering, but is not contained in the target sequence database!\nPlease check your database.\n";
-                        EXIT(EXIT_FAILURE);
-                    }
-                    e.dbId = (unsigned int)dbId;
-                    e.covered = Util::canBeCovered(al.canCovThr, al.covMode, static_cast<float>(origQueryLen),
-                                                   static_cast<float>(tOff[dbId + 1] - tOff[dbId]));
-                    e.pastEnd = 0;
-                    lists[b].push_back(e);
-                }
+    // ---- getSWResult's tail per pair: BandedNucleotideAligner.cpp:224-231, Matcher.cpp:91-137 with alignmentMode = SCORE_COV_SEQID (:78)
+    s->results.assign(nq, std::vector<Matcher::result_t>());
+    EvalueComputation &evaluer = s->evaluer;
+#pragma omp parallel for schedule(dynamic, 5) num_threads(al.threads)
+    for (size_t b = 0; b < nq; b++) {
+        const int queryLen = (int)queryNum[b].size();
+        size_t pi = firstPair[b];
+        std::vector<Matcher::result_t> &out = s->results[b];
+        out.reserve(firstPair[b + 1] - firstPair[b]);
+        for (size_t k = 0; k < lists[b].size(); k++) {
+            const Entry &e = lists[b][k];
+            if (!e.covered) continue;
+            const mmgpu_nucl_hit &h = hits[pi++];
+            if (h.status != MMGPU_NUCL_OK) {
+                Debug(Debug::ERROR) << "MMGPU: backtrace buffer too small for query " << queryKeys[b] << "\n";
+                EXIT(EXIT_FAILURE);
             }
+            const int dbLen = (int)(tOff[e.dbId + 1] - tOff[e.dbId]);
+            const float qcov = SmithWaterman::computeCov(h.q_start, h.q_end, queryLen);
+            const float dbcov = SmithWaterman::computeCov(h.t_start, h.t_end, dbLen);
+            const double evalue = evaluer.computeEvalue(h.score, queryLen);
+            std::string backtrace(bt.data() + h.bt_off, h.bt_len);
+            unsigned int alnLength = Matcher::computeAlnLength(h.q_start, h.q_end, h.t_start, h.t_end);
+            if (backtrace.size() > 0) alnLength = backtrace.size();
+            const float seqId = Util::computeSeqId(al.seqIdMode, h.ident, queryLen, dbLen, alnLength);
+            const int bitScore = static_cast<int>(evaluer.computeBitScore(h.score) + 0.5);
+            if (e.reverse) out.emplace_back(Matcher::result_t(e.dbKey, bitScore, qcov, dbcov, seqId, evalue, alnLength, h.q_start, h.q_end, queryLen,
+                                                               h.t_end, h.t_start, dbLen, backtrace));
+            else out.emplace_back(Matcher::result_t(e.dbKey, bitScore, qcov, dbcov, seqId, evalue, alnLength, h.q_start, h.q_end, queryLen,
+                                                    h.t_start, h.t_end, dbLen, backtrace));
         }
-        watch.lap("parse block");
-
-        // ---- the buffers of one reference thread, query by query and line by line (:337-338 mapSequence + initQuery, :368 mapSequence)
-        std::vector<mmgpu_nucl_query> dq;
-        std::vector<mmgpu_nucl_pair> pairs;
-        std::vector<size_t> firstPair(nq + 1, 0);
-        uint64_t btCap = 16;
-        for (size_t b = 0; b < nq; b++) {
-            firstPair[b] = pairs.size();
-            if (lists[b].empty()) continue;
-            const std::vector<unsigned char> &q = queryNum[b];
-            const size_t L = q.size();
-            qHistory.map(q.data(), L);
-            rcHistory.map(q.data(), L);
-            const unsigned char *os;
-            size_t ol;
-            unsigned int pastForward = 0, pastReverse = 0;
-            if (qHistory.owner(L, &os, &ol)) pastForward = os[L];
-            // queryRevCompSeq[(len - 1) - pos] = reverseResidue(numSequence[pos]) (:64-67)
-            if (rcHistory.owner(L, &os, &ol)) pastReverse = (unsigned int)nm->reverseResidue(os[ol - 1 - L]);
-            mmgpu_nucl_query nqy;
-            nqy.q = q.data();
-            nqy.qlen = (uint32_t)L;
-            const uint32_t qIndex = (uint32_t)dq.size();
-            dq.push_back(nqy);
-            for (size_t k = 0; k < lists[b].size(); k++) {
-                Entry &e = lists[b][k];
-                const size_t tl = (size_t)(tOff[e.dbId + 1] - tOff[e.dbId]);
-                tHistory.map(tRes.data() + tOff[e.dbId], tl);
-                if (!e.covered) continue;
-                unsigned int pastTarget = 0;
-                if (tHistory.owner(tl, &os, &ol)) pastTarget = os[tl];
-                mmgpu_nucl_pair p;
-                p.query = qIndex;
-                p.target = e.dbId;
-                p.diagonal = e.diagonal;
-                p.reverse = e.reverse ? 1 : 0;
-                p.past_end = MMGPU_NUCL_PAST_END(e.reverse ? pastReverse : pastForward, pastTarget);
-                pairs.push_back(p);
-                btCap += (uint64_t)L + tl + 2;
-            }
-        }
-        firstPair[nq] = pairs.size();
-        watch.lap("buffer history");
-
-        // ---- one device call for the block
-        std::vector<mmgpu_nucl_hit> hits(pairs.size());
-        std::vector<char> bt(btCap);
-        uint64_t btUsed = 0;
-        if (!pairs.empty() && mmgpu_nucl_align(gpu, &par, dq.data(), (uint32_t)dq.size(), pairs.data(), (uint32_t)pairs.size(), hits.data(),
-                                               bt.data(), btCap, &btUsed) != 0) {
-            Debug(Debug::ERROR) << "MMGPU: " << mmgpu_last_error() << "\n";
-            EXIT(EXIT_FAILURE);
-        }
-        watch.lap("mmgpu_nucl_align");
-
-        // ---- getSWResult's tail, accept / reject (:382-397), sort, serialise
-#pragma omp parallel num_threads(threads)
-        {
-            unsigned int thread_idx = 0;
-#ifdef OPENMP
-            thread_idx = static_cast<unsigned int>(omp_get_thread_num());
-#endif
-            std::string out;
-            out.reserve(1024 * 1024);
-            char buffer[1024 + 32768 * 4];
-            std::vector<Matcher::result_t> swResults;
-#pragma omp for schedule(dynamic, 5) reduction(+ : alignmentsNum, totalPassedNum)
-            for (size_t b = 0; b < nq; b++) {
-                progress.updateProgress();
-                swResults.clear();
-                const int queryLen = (int)queryNum[b].size();
-                size_t pi = firstPair[b];
-                for (size_t k = 0; k < lists[b].size(); k++) {
-                    const Entry &e = lists[b][k];
-                    if (!e.covered) continue;
-                    const mmgpu_nucl_hit &h = hits[pi++];
-                    if (h.status != MMGPU_NUCL_OK) {
-                        Debug(Debug::ERROR) << "MMGPU: backtrace buffer too small for query " << queryKeys[b] << "\n";
-                        EXIT(EXIT_FAILURE);
-                    }
-                    const int dbLen = (int)(tOff[e.dbId + 1] - tOff[e.dbId]);
-                    // BandedNucleotideAligner.cpp:224-231, Matcher.cpp:91-137 with alignmentMode = SCORE_COV_SEQID (:78)
-                    const float qcov = SmithWaterman::computeCov(h.q_start, h.q_end, queryLen);
-                    const float dbcov = SmithWaterman::computeCov(h.t_start, h.t_end, dbLen);
-                    const double evalue = evaluer.computeEvalue(h.score, queryLen);
-                    std::string backtrace(bt.data() + h.bt_off, h.bt_len);
-                    unsigned int alnLength = Matcher::computeAlnLength(h.q_start, h.q_end, h.t_start, h.t_end);
-                    if (backtrace.size() > 0) alnLength = backtrace.size();
-                    const float seqId = Util::computeSeqId(al.seqIdMode, h.ident, queryLen, dbLen, alnLength);
-                    const int bitScore = static_cast<int>(evaluer.computeBitScore(h.score) + 0.5);
-                    Matcher::result_t res;
-                    if (e.reverse) res = Matcher::result_t(e.dbKey, bitScore, qcov, dbcov, seqId, evalue, alnLength, h.q_start, h.q_end, queryLen,
-                                                           h.t_end, h.t_start, dbLen, backtrace);
-                    else res = Matcher::result_t(e.dbKey, bitScore, qcov, dbcov, seqId, evalue, alnLength, h.q_start, h.q_end, queryLen,
-                                                 h.t_start, h.t_end, dbLen, backtrace);
-                    alignmentsNum++;
-                    const bool isIdentity = (queryKeys[b] == e.dbKey && (al.includeIdentity || al.sameQTDB)) ? true : false;
-                    if (isIdentity) {
-                        res.qcov = 1.0f;
-                        res.dbcov = 1.0f;
-                        res.seqId = 1.0f;
-                    }
-                    if (Alignment::checkCriteria(res, isIdentity, al.evalThr, al.seqIdThr, al.alnLenThr, al.covMode, al.covThr)) {
-                        swResults.emplace_back(res);
-                        totalPassedNum++;
-                    }
-                }
-                if (swResults.size() > 1) {
-                    SORT_SERIAL(swResults.begin(), swResults.end(), Matcher::compareHits);
-                }
-                if (al.alignmentOutputMode == Parameters::ALIGNMENT_OUTPUT_CLUSTER) {
-                    for (size_t r = 0; r < swResults.size(); r++) {
-                        out.append(SSTR(swResults[r].dbKey));
-                        out.push_back('\n');
-                    }
-                } else {
-                    for (size_t r = 0; r < swResults.size(); r++) {
-                        size_t len = Matcher::resultToBuffer(buffer, swResults[r], al.addBacktrace);
-                        out.append(buffer, len);
-                    }
-                }
-                dbw.writeData(out.c_str(), out.length(), queryKeys[b], thread_idx);
-                out.clear();
-            }
-        }
-        watch.lap("results, accept / sort / write");
-        next = blockEnd;
-        if (remap && next < end) al.prefdbr->remapData();
     }
-    for (size_t i = 0; i < keepQueries.size(); i++) delete keepQueries[i];
-    for (size_t i = 0; i < threads; i++) delete seqs[i];
-    dbw.close(merge);
-
-    Debug(Debug::INFO) << alignmentsNum << " alignments calculated\n";
-    Debug(Debug::INFO) << totalPassedNum << " sequence pairs passed the thresholds";
-    if (alignmentsNum > 0) {
-        Debug(Debug::INFO) << " (" << ((float)totalPassedNum / (float)alignmentsNum) << " of overall calculated)";
-    }
-    Debug(Debug::INFO) << "\n";
-    if (dbSize > 0) {
-        size_t hits = totalPassedNum / dbSize;
-        size_t hits_rest = totalPassedNum % dbSize;
-        float hits_f = ((float)hits) + ((float)hits_rest) / (float)dbSize;
-        Debug(Debug::INFO) << hits_f << " hits per query sequence\n";
-    }
-    return true;
+    s->watch.lap("result_t records");
 }

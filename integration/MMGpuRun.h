@@ -32,6 +32,7 @@
 #include <string>
 
 #include "Debug.h"
+#include "Matcher.h"
 #include "mmgpu.h"
 
 class Alignment;
@@ -50,15 +51,26 @@ public:
     static mmgpu_multi *multi();
 };
 
+struct MMGpuAlignSession;
+class EvalueComputation;
+class Sequence;
+
+// Alignment::run (integration/mmseqs_mmgpu.patch): begin before the bucket loop, plan before a bucket's OpenMP region, take at
+// getSWResult's call site, end after the loop (MMGpuAlignRun.cpp; nucleotide databases: MMGpuNuclAlignRun.cpp)
 class MMGpuAlignRun {
 public:
     static bool usable(const Alignment &a);
-    static bool run(Alignment &a, const std::string &outDB, const std::string &outDBIndex, const size_t dbFrom, const size_t dbSize,
-                    bool merge);
-    // nucleotide databases: BandedNucleotideAligner::align on the device (MMGpuNuclAlignRun.cpp; MMGPU_NUCL_ALIGN=0 keeps the CPU loop)
+    static MMGpuAlignSession *begin(Alignment &a, EvalueComputation &evaluer, size_t dbFrom, size_t dbSize);      // NULL: CPU path
+    static size_t bucketQueries(MMGpuAlignSession *s);
+    static void plan(MMGpuAlignSession *s, size_t start, size_t bucketSize);
+    static Matcher::result_t take(MMGpuAlignSession *s, size_t id, size_t entry, Matcher &matcher, Sequence *dbSeq, int diagonal, bool isReverse,
+                                  bool isIdentity);
+    static void end(MMGpuAlignSession *s);
+    // nucleotide databases: BandedNucleotideAligner::align on the device (MMGPU_NUCL_ALIGN=0 keeps the CPU loop)
     static bool usableNucleotide(const Alignment &a);
-    static bool runNucleotide(Alignment &a, const std::string &outDB, const std::string &outDBIndex, const size_t dbFrom, const size_t dbSize,
-                              bool merge);
+    static void beginNucleotide(MMGpuAlignSession *s);
+    static void planNucleotide(MMGpuAlignSession *s);
+    static void endNucleotide(MMGpuAlignSession *s);
 };
 
 struct MMGpuPrefilterStats {
