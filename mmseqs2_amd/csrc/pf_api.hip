@@ -9,6 +9,7 @@
 #include <thread>
 
 #include "mmgpu_internal.h"
+#include "sat_ties.h"
 
 using namespace mmgpu;
 
@@ -1110,38 +1111,15 @@ extern "C" int mmgpu_pf_run(mmgpu_ctx *c, mmgpu_pf_batch_t *b) {
     return MMGPU_OK;
 }
 
-// QueryMatcher.cpp:147-177 for one nucleotide query whose saturated elements tie (see pf_keepmax_nucl_kernel): the reference
-// sorts its saturated elements by target id with std::sort and gives a target the diagonal of the FIRST of its elements, in
-// the order the sort left, that reaches the best exact score.  Beyond 16 elements that order belongs to libstdc++'s introsort;
-// the same std::sort (this library and the reference are built against the same libstdc++) over the same elements in the
-// same initial order - the reference's array order: cache bin, then arrival - gives it.  Only the diagonal of the target's
-// hit can differ from what the device chose (score and count are equal by the definition of the tie).
+// Ties between saturated diagonals of one target in a nucleotide query with more than 16 saturated elements: the reference's
+// std::sort replayed over the exported elements (sat_ties.h); only the diagonal of the target's hit can differ from what the device
+// chose (score and count are equal by the definition of the tie).
 static int pf_resolve_saturated_ties(mmgpu_ctx *c, mmgpu_pf_batch_t *b, uint32_t q, uint32_t n, mmgpu_pf_hit *hits, uint32_t n_hits) {
     std::vector<PfCand> el(n);
     hipError_t e = hipMemcpy(el.data(), b->d_sat.as<PfCand>() + (size_t)q * PF_SAT_CAP, (size_t)n * sizeof(PfCand), hipMemcpyDeviceToHost);
     if (e != hipSuccess) return fail(MMGPU_ERR_HIP, std::string("mmgpu_pf_fetch: ") + hipGetErrorString(e));
-    const uint32_t refmask = b->ref_bins - 1;
-    std::sort(el.begin(), el.end(), [&](const PfCand &x, const PfCand &y) {      // the order before the reference's sort (keys are unique)
-        const uint64_t kx = ((uint64_t)(x.id & refmask) << 32) | x.arr, ky = ((uint64_t)(y.id & refmask) << 32) | y.arr;
-        return kx < ky;
-    });
-    std::sort(el.begin(), el.end(), [](const PfCand &x, const PfCand &y) { return x.id < y.id; });      // CounterResult::sortById
+    mmgpu::resolve_saturated_ties(el, b->ref_bins - 1);
     uint32_t prev = 0xFFFFFFFFu;
-    size_t first = 0;
-    uint64_t best = 0;
-    for (size_t i = 0; i < el.size(); i++) {      // :158-171
-        if (prev == el[i].id) {
-            if ((uint64_t)el[i].score > best) {
-                best = el[i].score;
-                el[first].diag = el[i].diag;
-            }
-        } else {
-            best = (i + 1 < el.size() && el[i + 1].id == el[i].id) ? el[i].score : 0;
-            first = i;
-        }
-        prev = el[i].id;
-    }
-    prev = 0xFFFFFFFFu;
     for (size_t i = 0; i < el.size(); i++) {      // the first element of every target now carries the diagonal the reference keeps
         if (el[i].id == prev) continue;
         prev = el[i].id;

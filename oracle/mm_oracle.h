@@ -98,7 +98,9 @@ typedef struct {
     int big_list; /* kmer_score mode: the element list reached foundDiagonalsSize / 2, where the reference sorts with an
                      unstable std::sort (QueryMatcher.cpp:221-231): not restated */
     int sat_tie;  /* nucleotide branch: a target has two saturated (>= 255) elements on different diagonals with the same exact
-                     score - the reference's choice then depends on the element order an unstable std::sort left (:154) */
+                     score - the reference's choice then depends on the element order its std::sort left (:154) */
+    int sat_len;  /* nucleotide branch: number of saturated elements of the query = length of the range that std::sort sorts.  Up to 16
+                     libstdc++ sorts by insertion (stable), and the restatement's stable choice IS the reference's; beyond, introsort */
 } mmo_pf_stats;
 
 typedef struct {

@@ -867,6 +867,7 @@ static int match_query_impl(const mmo_pf_params *P, const uint8_t *q, int qlen, 
             size_t above = mmo_radix_by_score(sz, wr0, P->min_diag_score, fd, rs);
             size_t len = 0;
             while (len < above && wr0[len].count >= 255) len++;
+            S.sat_len = (int)len;
             /* stable sort of the saturated prefix by id (insertion into a temporary by counting would do; the prefix is short) */
             for (size_t a = 1; a < len; a++) {
                 mmo_cr t = wr0[a];

@@ -330,7 +330,7 @@ class PfStats(ctypes.Structure):
     _fields_ = [("db_matches", ctypes.c_uint64), ("kmer_list_len", ctypes.c_uint64),
                 ("double_hits", ctypes.c_uint64), ("after_keepmax", ctypes.c_uint64),
                 ("diag_thr", ctypes.c_uint32), ("truncated", ctypes.c_int), ("overflow", ctypes.c_int), ("big_list", ctypes.c_int),
-                ("sat_tie", ctypes.c_int)]
+                ("sat_tie", ctypes.c_int), ("sat_len", ctypes.c_int)]
 
 
 class PfDump(ctypes.Structure):
