@@ -452,7 +452,9 @@ int mmgpu_pf_fetch(mmgpu_ctx *c, mmgpu_pf_batch_t *b, mmgpu_pf_hit *hits, uint32
     for (size_t i = 0; i < b->q.size(); i++) {
         counts[i] = (uint32_t)b->hits[i].size();
         status[i] = (long_target || b->q[i].size() >= 32768) ? MMGPU_PF_LONG_SEQ : MMGPU_PF_OK;
-        if (status[i] == MMGPU_PF_OK && (b->stats[i].sat_tie || (b->par.nucleotide && b->stats[i].overflow))) status[i] = MMGPU_PF_SAT_TIE;
+        // (ties among up to 16 saturated elements: the restatement's stable choice is the reference's, as on the device; beyond, the
+        // device replays std::sort - the stand-in hands the query back)
+        if (status[i] == MMGPU_PF_OK && ((b->stats[i].sat_tie && b->stats[i].sat_len > 16) || (b->par.nucleotide && b->stats[i].overflow))) status[i] = MMGPU_PF_SAT_TIE;
         if (status[i] == MMGPU_PF_OK && b->par.kmer_score && b->stats[i].overflow) status[i] = MMGPU_PF_OVERFLOW;
         if (status[i] == MMGPU_PF_OK && b->par.kmer_score && b->stats[i].big_list) status[i] = MMGPU_PF_SAT_TIE;
         if (status[i] != MMGPU_PF_OK) counts[i] = 0;
