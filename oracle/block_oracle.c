@@ -128,13 +128,28 @@ static void trace_add_block(btrace *t, size_t i, size_t j, size_t width, size_t 
     t->block_idx++;
 }
 
+enum { BK_AA = 0, BK_NUC = 1, BK_BYTES = 2 };
 typedef struct {
-    const int8_t *scores;   /* AAMatrix::scores [27 * 32] (scores.rs:47-49) */
+    const int8_t *scores;   /* AAMatrix::scores [27 * 32] (scores.rs:47-49) | NucMatrix::scores [8 * 16] (:157) | ByteMatrix {match, mismatch} (:238-241) */
     int gap_open, gap_extend;
+    int kind;               /* which Matrix impl `scores` belongs to */
+    int trace, xdrop;       /* Block<TRACE, X_DROP> (scan_block.rs:115); the reference instantiates <true, true> only */
 } bparams;
 
-/* place_block_aa, scan_block.rs:1449-1613 (TRACE and X_DROP both true).  `query` is what the rows run over, `reference`
- * what the columns run over; a down shift calls it with the roles exchanged (:237-252). */
+/* Matrix::get_scores for one lane: the score of reference byte c against query byte v */
+static int16_t lookup_score(const bparams *P, uint8_t c, uint8_t v) {
+    if (P->kind == BK_NUC)      /* scores.rs:216-221 -> halfsimd_lookup1_i16 (avx2.rs:352-356): pshufb, row c & 7, entry v & 15, 0 if bit 7 of v */
+        return (v & 0x80) ? 0 : P->scores[(size_t)(c & 7) * 16 + (v & 15)];
+    if (P->kind == BK_BYTES)    /* scores.rs:276-280 -> halfsimd_lookup_bytes_i16 (avx2.rs:358-364) */
+        return c == v ? P->scores[0] : P->scores[1];
+    /* AAMatrix::get_scores (scores.rs:133-139) -> halfsimd_lookup2_i16 (avx2.rs:340-350): row c of the matrix, entry = low 5 bits
+     * of the query byte (pshufb on the low 4 bits, blendv on bit 4), sign extended */
+    return (v & 0x80) ? 0 : P->scores[(size_t)c * 32 + (v & 31)];
+}
+
+/* place_block_aa, scan_block.rs:1449-1613; with zero biases it is place_block (:1145-1277), whose only other difference is the
+ * Matrix behind get_scores.  `query` is what the rows run over, `reference` what the columns run over; a down shift calls it with
+ * the roles exchanged (:237-252). */
 static void place_block_aa(const bparams *P, bseq query, bseq reference, btrace *tr, size_t start_i, size_t start_j, size_t width,
                            size_t height, int16_t *D_col, int16_t *C_col, int16_t *D_row, int16_t *R_row, bvec D_corner,
                            bvec *oD_max, bvec *oD_argmax_i, bvec *oD_argmax_j) {
@@ -151,11 +166,9 @@ static void place_block_aa(const bparams *P, bseq query, bseq reference, btrace 
             const bvec D10 = v_load(D_col + i), C10 = v_load(C_col + i);
             const bvec D00 = v_sl1(D10, D_corner);
             D_corner = D10;
-            /* AAMatrix::get_scores (scores.rs:133-139) -> halfsimd_lookup2_i16 (avx2.rs:340-348): row c of the matrix,
-             * entry = low 5 bits of the query byte, sign extended */
             bvec scores, query_bias;
             for (int k = 0; k < BL; k++) {
-                scores.v[k] = P->scores[(size_t)c * 32 + (query.s[start_i + i + k] & 31)];
+                scores.v[k] = lookup_score(P, c, query.s[start_i + i + k]);
                 query_bias.v[k] = query.bias[start_i + i + k];      /* PosBias::get_biases, scores.rs:737-739 */
             }
             const bvec pos_bias = v_adds(reference_bias, query_bias);
@@ -169,7 +182,7 @@ static void place_block_aa(const bparams *P, bseq query, bseq reference, btrace 
             R11 = v_max(R11, v_adds(v_broadcasthi(R01), gap_extend_all));
             D11 = v_max(D11, R11);
             R01 = R11;
-            {   /* TRACE, :1559-1577 */
+            if (P->trace) {   /* TRACE, :1559-1577 */
                 const bvec trace_D_C = v_cmpeq(D11, C11), trace_D_R = v_cmpeq(D11, R11);
                 const uint32_t trace_data = trace_word(trace_D_C, trace_D_R);
                 const bvec temp_trace_R = v_cmpeq(R11, D11_open);
@@ -182,7 +195,7 @@ static void place_block_aa(const bparams *P, bseq query, bseq reference, btrace 
                 tr->trace_idx++;
             }
             D_max = v_max(D_max, D11);
-            {   /* X_DROP, :1581-1586 */
+            if (P->xdrop) {   /* X_DROP, :1581-1586 */
                 const bvec mask = v_cmpeq(D_max, D11);
                 D_argmax_i = v_blend16(D_argmax_i, v_set1((int16_t)i), mask);
                 D_argmax_j = v_blend16(D_argmax_j, v_set1((int16_t)j), mask);
@@ -193,6 +206,10 @@ static void place_block_aa(const bparams *P, bseq query, bseq reference, btrace 
         D_corner = v_set1(B_MIN);
         D_row[j] = D11.v[BL - 1];
         R_row[j] = R11.v[BL - 1];
+        if (!P->xdrop && start_i + height > (size_t)query.len && start_j + j >= (size_t)reference.len) {   /* :1601-1609 */
+            if (P->trace) tr->trace_idx += (width - 1 - j) * (height / BL);
+            break;
+        }
     }
     *oD_max = D_max;
     *oD_argmax_i = D_argmax_i;
@@ -259,7 +276,7 @@ static void align_aa_core(const bparams *P, bseq query, bseq reference, size_t m
         if (dir == DIR_RIGHT) {
             off = off_max;
             const bvec off_add = v_set1(clamp16(prev_off - off));
-            trace_add_block(tr, st_i, st_j + block_size - B_STEP, B_STEP, block_size, 1);
+            if (P->trace) trace_add_block(tr, st_i, st_j + block_size - B_STEP, B_STEP, block_size, 1);
             just_offset(block_size, A->D_col, A->C_col, off_add);
             place_block_aa(P, query, reference, tr, st_i, st_j + block_size - B_STEP, B_STEP, block_size, A->D_col, A->C_col, A->temp1, A->temp2,
                            prev_dir == DIR_DOWN ? v_adds(D_corner, off_add) : v_set1(B_MIN), &D_max, &D_argmax_i, &D_argmax_j);
@@ -269,7 +286,7 @@ static void align_aa_core(const bparams *P, bseq query, bseq reference, size_t m
         } else if (dir == DIR_DOWN) {
             off = off_max;
             const bvec off_add = v_set1(clamp16(prev_off - off));
-            trace_add_block(tr, st_i + block_size - B_STEP, st_j, block_size, B_STEP, 0);
+            if (P->trace) trace_add_block(tr, st_i + block_size - B_STEP, st_j, block_size, B_STEP, 0);
             just_offset(block_size, A->D_row, A->R_row, off_add);
             place_block_aa(P, reference, query, tr, st_j, st_i + block_size - B_STEP, B_STEP, block_size, A->D_row, A->R_row, A->temp1, A->temp2,
                            prev_dir == DIR_RIGHT ? v_adds(D_corner, off_add) : v_set1(B_MIN), &D_max, &D_argmax_i, &D_argmax_j);
@@ -279,11 +296,11 @@ static void align_aa_core(const bparams *P, bseq query, bseq reference, size_t m
         } else {
             D_corner = v_set1(B_MIN);
             const size_t grow_step = block_size - prev_size;
-            trace_add_block(tr, st_i + prev_size, st_j, prev_size, grow_step, 0);
+            if (P->trace) trace_add_block(tr, st_i + prev_size, st_j, prev_size, grow_step, 0);
             bvec D_max1, D_ai1, D_aj1;
             place_block_aa(P, reference, query, tr, st_j, st_i + prev_size, grow_step, prev_size, A->D_row, A->R_row, A->D_col + prev_size,
                            A->C_col + prev_size, v_set1(B_MIN), &D_max1, &D_ai1, &D_aj1);
-            trace_add_block(tr, st_i, st_j + prev_size, grow_step, block_size, 1);
+            if (P->trace) trace_add_block(tr, st_i, st_j + prev_size, grow_step, block_size, 1);
             place_block_aa(P, query, reference, tr, st_i, st_j + prev_size, grow_step, block_size, A->D_col, A->C_col, A->D_row + prev_size,
                            A->R_row + prev_size, v_set1(B_MIN), &D_max, &D_argmax_i, &D_argmax_j);
             right_max = prefix_max(A->D_col);
@@ -305,7 +322,7 @@ static void align_aa_core(const bparams *P, bseq query, bseq reference, size_t m
         y_drop_iter++;
         int grow_no_max = dir == DIR_GROW;
         if (off_max > best_max) {
-            {   /* X_DROP: location of the maximum, ties to the larger column, then the larger row (:374-444) */
+            if (P->xdrop) {   /* X_DROP: location of the maximum, ties to the larger column, then the larger row (:374-444) */
                 size_t best_i = 0, best_j = 0;
                 const int grow = dir == DIR_GROW && D_max_max < grow_max;
                 const int16_t curr_max = grow ? grow_max : D_max_max;
@@ -339,11 +356,13 @@ static void align_aa_core(const bparams *P, bseq query, bseq reference, size_t m
             best_max = off_max;
             y_drop_iter = 0;
         }
-        if (off_max < best_max - x_drop) {      /* :477-488 */
-            if (x_drop_iter < B_X_DROP_ITER - 1) x_drop_iter++;
-            else break;
-        } else {
-            x_drop_iter = 0;
+        if (P->xdrop) {
+            if (off_max < best_max - x_drop) {      /* :477-488 */
+                if (x_drop_iter < B_X_DROP_ITER - 1) x_drop_iter++;
+                else break;
+            } else {
+                x_drop_iter = 0;
+            }
         }
         if (st_i + block_size > qlen && st_j + block_size > rlen) break;
         if (st_j + block_size > rlen) { st_i += B_STEP; dir = DIR_DOWN; continue; }
@@ -396,14 +415,21 @@ static void align_aa_core(const bparams *P, bseq query, bseq reference, size_t m
         if (down_max > right_max) { st_i += B_STEP; dir = DIR_DOWN; }
         else { st_j += B_STEP; dir = DIR_RIGHT; }
     }
-    *res_score = best_max;
-    *res_i = best_argmax_i;
-    *res_j = best_argmax_j;
+    if (P->xdrop) {      /* :604-631 */
+        *res_score = best_max;
+        *res_i = best_argmax_i;
+        *res_j = best_argmax_j;
+    } else {             /* global alignment: the cell (|q|, |r|), read from the border the last shift left it on */
+        if (dir == DIR_DOWN) *res_score = off + (int32_t)A->D_row[rlen - st_j] - (int32_t)B_ZERO;
+        else *res_score = off + (int32_t)A->D_col[qlen - st_i] - (int32_t)B_ZERO;
+        *res_i = qlen;
+        *res_j = rlen;
+    }
 }
 
 /* Trace::cigar_core<false>, scan_block.rs:1844-2006; ops (cigar.rs:10-31: M = 1, I = 4, D = 5) are appended to `ops` in the
  * order the walk produces them, i.e. from the end position back to the origin.  Returns their number. */
-static size_t trace_cigar(const btrace *t, size_t i, size_t j, uint8_t *ops, size_t cap) {
+static size_t trace_cigar(const btrace *t, size_t i, size_t j, uint8_t *ops, size_t cap, const uint8_t *eq_q, const uint8_t *eq_r) {
     enum { T_D = 0, T_C = 1, T_R = 2 };
     size_t block_idx = t->block_idx, trace_idx = t->trace_idx, n = 0;
     int table = T_D;
@@ -443,6 +469,7 @@ static size_t trace_cigar(const btrace *t, size_t i, size_t j, uint8_t *ops, siz
                 else { op = 5; di = 0; dj = 1; nt = (t2 & 2u) ? T_D : T_C; }
             }
             if ((size_t)di > i || (size_t)dj > j) abort();      /* would be an out-of-range walk in the crate as well */
+            if (eq_q && op == 1) op = eq_q[i] == eq_r[j] ? 2 : 3;      /* cigar_eq: Operation::Eq / X (:1957-1965), PaddedBytes::get(i) = s[i] */
             i -= (size_t)di;
             j -= (size_t)dj;
             table = nt;
@@ -469,21 +496,18 @@ int mmo_block_align(const uint8_t *q, const int16_t *qbias, int qlen, const uint
     return mmo_block_align_table(q, qbias, qlen, r, rbias, rlen, scores, gap_open, gap_extend, min_size, max_size, x_drop, res, ops, ops_cap, n_ops);
 }
 
-/* the same with the AAMatrix table itself: scores27x32[a * 32 + b] (what the C API objects of oracle/ref_block_capi.cpp hold) */
-int mmo_block_align_table(const uint8_t *q, const int16_t *qbias, int qlen, const uint8_t *r, const int16_t *rbias, int rlen,
-                          const int8_t *scores, int gap_open, int gap_extend, int min_size, int max_size, int x_drop, mmo_block_res *res,
-                          uint8_t *ops, uint32_t ops_cap, uint32_t *n_ops) {
-    if (qlen < 0 || rlen < 0 || gap_open >= 0 || gap_extend >= 0 || gap_open >= gap_extend) return -1;
-    size_t mn = (size_t)(min_size < BL ? BL : min_size), mx = (size_t)(max_size < BL ? BL : max_size);      /* :1024-1025 */
+/* Block<TRACE, X_DROP>::align / align_aa (scan_block.rs:862-892, :1016-1052) on PaddedBytes built from q / r (bytes AFTER
+ * Matrix::convert_char), padded with `null_byte` (Matrix::NULL after convert_char).  eq: walk with cigar_eq instead of cigar. */
+static int block_run(const uint8_t *q, const int16_t *qbias, int qlen, const uint8_t *r, const int16_t *rbias, int rlen, const bparams *P,
+                     uint8_t null_byte, int min_size, int max_size, int x_drop, mmo_block_res *res, uint8_t *ops, uint32_t ops_cap,
+                     uint32_t *n_ops, int eq) {
+    if (qlen < 0 || rlen < 0 || P->gap_open >= 0 || P->gap_extend >= 0 || P->gap_open >= P->gap_extend) return -1;      /* :864-867 */
+    size_t mn = (size_t)(min_size < BL ? BL : min_size), mx = (size_t)(max_size < BL ? BL : max_size);      /* :868-869, :1024-1025 */
     if ((mn & (mn - 1)) || (mx & (mx - 1)) || mn > mx || mx >= 65535) return -1;
-    bparams P;
-    P.scores = scores;
-    P.gap_open = gap_open;
-    P.gap_extend = gap_extend;
     uint8_t *qs = (uint8_t *)malloc((size_t)qlen + mx + 1 + BL), *rs = (uint8_t *)malloc((size_t)rlen + mx + 1 + BL);
     int16_t *qb = (int16_t *)calloc((size_t)qlen + mx + 1 + BL, 2), *rb = (int16_t *)calloc((size_t)rlen + mx + 1 + BL, 2);
-    memset(qs, B_NULL, (size_t)qlen + mx + 1 + BL);
-    memset(rs, B_NULL, (size_t)rlen + mx + 1 + BL);
+    memset(qs, null_byte, (size_t)qlen + mx + 1 + BL);
+    memset(rs, null_byte, (size_t)rlen + mx + 1 + BL);
     if (qlen) memcpy(qs + 1, q, (size_t)qlen);
     if (rlen) memcpy(rs + 1, r, (size_t)rlen);
     for (int k = 0; k < qlen && qbias; k++) qb[1 + k] = qbias[k];
@@ -508,16 +532,48 @@ int mmo_block_align_table(const uint8_t *q, const int16_t *qbias, int qlen, cons
     }
     int32_t score = 0;
     size_t ri = 0, rj = 0;
-    align_aa_core(&P, Q, R, mn, mx, x_drop, &A, &T, &score, &ri, &rj);
+    align_aa_core(P, Q, R, mn, mx, x_drop, &A, &T, &score, &ri, &rj);
     res->score = score;
     res->query_idx = (uint32_t)ri;
     res->reference_idx = (uint32_t)rj;
     if (n_ops) *n_ops = 0;
-    if (ops && n_ops) *n_ops = (uint32_t)trace_cigar(&T, ri, rj, ops, ops_cap);
+    if (ops && n_ops && P->trace) *n_ops = (uint32_t)trace_cigar(&T, ri, rj, ops, ops_cap, eq ? qs : NULL, eq ? rs : NULL);
     for (int k = 0; k < 10; k++) free(*bufs[k]);
     free(T.trace); free(T.trace2); free(T.right); free(T.block_start); free(T.block_size);
     free(qs); free(rs); free(qb); free(rb);
     return 0;
+}
+
+/* the same with the AAMatrix table itself: scores27x32[a * 32 + b] (what the C API objects of oracle/ref_block_capi.cpp hold) */
+int mmo_block_align_table(const uint8_t *q, const int16_t *qbias, int qlen, const uint8_t *r, const int16_t *rbias, int rlen,
+                          const int8_t *scores, int gap_open, int gap_extend, int min_size, int max_size, int x_drop, mmo_block_res *res,
+                          uint8_t *ops, uint32_t ops_cap, uint32_t *n_ops) {
+    bparams P;
+    P.scores = scores;
+    P.gap_open = gap_open;
+    P.gap_extend = gap_extend;
+    P.kind = BK_AA;
+    P.trace = P.xdrop = 1;
+    return block_run(q, qbias, qlen, r, rbias, rlen, &P, B_NULL, min_size, max_size, x_drop, res, ops, ops_cap, n_ops, 0);
+}
+
+/* Every instantiation the crate's own unit tests use (scan_block.rs:2267-2432): Block<trace, xdrop>::align over an AAMatrix
+ * (kind 0: table [27 * 32], bytes = letter - 'A', NULL = 26), a NucMatrix (kind 1: table [8 * 16], bytes = upper-case ASCII,
+ * NULL = 'Z') or a ByteMatrix (kind 2: table = {match, mismatch}, raw bytes, NULL = 0).  ops: Operation codes of cigar.rs:10-31
+ * (M 1, = 2, X 3, I 4, D 5) from the end position back to the origin; eq selects cigar_eq. */
+int mmo_block_align_generic(const uint8_t *q, int qlen, const uint8_t *r, int rlen, int kind, const int8_t *table, int gap_open, int gap_extend,
+                            int min_size, int max_size, int x_drop, int trace, int xdrop, int eq, mmo_block_res *res, uint8_t *ops,
+                            uint32_t ops_cap, uint32_t *n_ops) {
+    if (kind < BK_AA || kind > BK_BYTES || (xdrop && x_drop < 0)) return -1;      /* :872-874 */
+    bparams P;
+    P.scores = table;
+    P.gap_open = gap_open;
+    P.gap_extend = gap_extend;
+    P.kind = kind;
+    P.trace = trace != 0;
+    P.xdrop = xdrop != 0;
+    const uint8_t null_byte = kind == BK_AA ? B_NULL : (kind == BK_NUC ? (uint8_t)'Z' : 0);
+    return block_run(q, NULL, qlen, r, NULL, rlen, &P, null_byte, min_size, max_size, x_drop, res, ops, ops_cap, n_ops, eq);
 }
 
 /* SmithWaterman::alignStartPosBacktraceBlock<SEQ_SEQ> (StripedSmithWaterman.cpp:943-1127) for one pair whose forward scan

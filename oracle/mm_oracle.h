@@ -174,6 +174,11 @@ int mmo_block_align(const uint8_t *q, const int16_t *qbias, int qlen, const uint
 int mmo_block_align_table(const uint8_t *q, const int16_t *qbias, int qlen, const uint8_t *r, const int16_t *rbias, int rlen,
                           const int8_t *scores27x32, int gap_open, int gap_extend, int min_size, int max_size, int x_drop, mmo_block_res *res,
                           uint8_t *ops, uint32_t ops_cap, uint32_t *n_ops);
+/* any Block<trace, xdrop>::align the crate's unit tests use; kind 0 AAMatrix [27 * 32] (bytes = letter - 'A'), 1 NucMatrix [8 * 16]
+ * (upper-case ASCII), 2 ByteMatrix {match, mismatch} (raw bytes); ops: cigar.rs Operation codes (M 1, = 2, X 3, I 4, D 5), end -> origin */
+int mmo_block_align_generic(const uint8_t *q, int qlen, const uint8_t *r, int rlen, int kind, const int8_t *table, int gap_open, int gap_extend,
+                            int min_size, int max_size, int x_drop, int trace, int xdrop, int eq, mmo_block_res *res, uint8_t *ops,
+                            uint32_t ops_cap, uint32_t *n_ops);
 void mmo_block_prefix_scan(const int16_t *v16, int gap, int16_t *out16);
 int mmo_sw_block_backtrace(const uint8_t *q, const int8_t *comp_bias, int qlen, const uint8_t *t, int tlen, const int8_t *mat, int alphabet,
                            int gap_open /* > 0, as the reference's */, int gap_extend, int score, int q_end, int t_end, int *q_start, int *t_start,

@@ -127,6 +127,39 @@ class Oracle:
         letters = {1: "M", 4: "I", 5: "D"}
         return res.score, res.qi, res.ri, "".join(letters[int(x)] for x in ops[:n.value][::-1])
 
+    def block_align_generic(self, q, r, kind, table, gap_open, gap_extend, min_size, max_size, x_drop, trace, xdrop, eq=False):
+        """Block<trace, xdrop>::align over an AAMatrix (kind 0) / NucMatrix (1) / ByteMatrix (2) table, q / r = bytes after
+        Matrix::convert_char -> (score, query_idx, reference_idx, CIGAR in the crate's Display format or None without trace)"""
+        q = np.ascontiguousarray(q, np.uint8)
+        r = np.ascontiguousarray(r, np.uint8)
+        table = np.ascontiguousarray(table, np.int8)
+
+        class Res(ctypes.Structure):
+            _fields_ = [("score", ctypes.c_int32), ("qi", ctypes.c_uint32), ("ri", ctypes.c_uint32)]
+        res = Res()
+        ops = np.zeros(len(q) + len(r) + 8, np.uint8)
+        n = ctypes.c_uint32()
+        f = self.L.mmo_block_align_generic
+        f.argtypes = [c_p, ctypes.c_int, c_p, ctypes.c_int, ctypes.c_int, c_p] + [ctypes.c_int] * 8 + \
+                     [ctypes.POINTER(Res), c_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32)]
+        rc = f(_ptr(q), len(q), _ptr(r), len(r), int(kind), _ptr(table), gap_open, gap_extend, min_size, max_size, x_drop, int(trace),
+               int(xdrop), int(eq), ctypes.byref(res), _ptr(ops), len(ops), ctypes.byref(n))
+        if rc != 0:
+            raise RuntimeError("mmo_block_align_generic rc=%d" % rc)
+        cigar = None
+        if trace:       # Display for Cigar (cigar.rs:139-155): run-length encoded, origin -> end
+            cigar, run, last = "", 0, None
+            for x in ops[:n.value][::-1]:
+                c = {1: "M", 2: "=", 3: "X", 4: "I", 5: "D"}[int(x)]
+                if c != last and last is not None:
+                    cigar += "%d%s" % (run, last)
+                    run = 0
+                last = c
+                run += 1
+            if last is not None:
+                cigar += "%d%s" % (run, last)
+        return res.score, res.qi, res.ri, cigar
+
     def block_prefix_scan(self, v, gap):
         v = np.ascontiguousarray(v, np.int16)
         out = np.zeros(16, np.int16)

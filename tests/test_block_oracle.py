@@ -58,6 +58,41 @@ def test_crate_x_drop_vectors(orc):
     assert (s, qi, ri, ops) == (14, 6, 6, "MMMMMM")       # "3=2X1=" with = / X folded into M
 
 
+def _crate_vectors():
+    import json
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "block_crate_vectors.json")))
+    return g["matrices"], g["vectors"]
+
+
+def _crate_bytes(s, alphabet):
+    """Matrix::convert_char: AAMatrix letter - 'A' (scores.rs:142-146), NucMatrix upper case (:224-228), ByteMatrix as is (:283-285)"""
+    b = np.frombuffer(s.encode(), np.uint8)
+    if alphabet == "AAMatrix":
+        return b - ord("A")
+    if alphabet == "NucMatrix":
+        return np.frombuffer(s.upper().encode(), np.uint8)
+    return b
+
+
+@pytest.mark.parametrize("idx", range(23))
+def test_every_crate_unit_test_vector(orc, idx):
+    """scan_block.rs #[cfg(test)]: test_no_x_drop (13: Block<false, false>, global score), test_x_drop (3: <false, true> and
+    <true, true> at block size 2048), test_trace (5: <true, false>, CIGARs with indels `3M1D`, `2M6I16M3D`, `9=2I4=1I`) and test_bytes
+    (2) - every instantiation of Block<TRACE, X_DROP>, not only the <true, true> one the reference links."""
+    matrices, vectors = _crate_vectors()
+    assert len(vectors) == 23
+    v = vectors[idx]
+    m = matrices[v["matrix"]]
+    s, qi, ri, cigar = orc.block_align_generic(_crate_bytes(v["q"], v["alphabet"]), _crate_bytes(v["r"], v["alphabet"]), m["kind"],
+                                               np.array(m["table"], np.int8), v["gap_open"], v["gap_extend"], v["min_size"], v["max_size"],
+                                               v["x_drop"], v["trace"], v["x_drop_mode"], eq=v.get("eq", False))
+    assert s == v["score"], (v, s)
+    if "query_idx" in v:
+        assert (qi, ri) == (v["query_idx"], v["reference_idx"]), (v, qi, ri)
+    if "cigar" in v:
+        assert cigar == v["cigar"], (v, cigar)
+
+
 def _family_pairs(seed, n_fam, members, per_query):
     (qres, qoff), (tres, toff), fam_t, fam_q = wl.config3_prefilter(n_fam, members, n_fam, seed=seed)
     qs, ts = wl.split(qres, qoff), wl.split(tres, toff)
