@@ -567,6 +567,47 @@ def search_headline(args, gpu, torch, dist, rank, world, matrices, barrier):
                             "cigars_per_s": round(n_cig / t_bt_c, 1) if t_bt_c > 0 else None,
                             "what": "mmgpu_sw_traceback for every pair of the first 1000 queries' lists (pairs below the start-score "
                                     "threshold have no start position and are answered MMGPU_BT_NO_START)"}
+        # a15: every int16-range pair (word == 1) of the workload that gets start positions, through the device's block aligner
+        # (blocks up to the crate's 4096 rows: nothing is handed to the host); a sample of the answers is re-scored
+        try:
+            word_idx = np.nonzero((sep["word"] == 1) & (sep["q_start"] >= 0))[0].astype(np.uint32)
+            t0 = time.perf_counter()
+            blk, bstr = swb.block_backtrace(word_idx)
+            t_blk = time.perf_counter() - t0
+            tier1, tier2 = swb.block_tiers()
+            pair_q = np.repeat(np.arange(nq), [len(x) for x in lists])
+            pair_t = np.concatenate(lists) if lists else np.zeros(0, np.uint32)
+            ok_idx = np.nonzero(blk["status"] == 0)[0]
+            sample = ok_idx[::max(1, len(ok_idx) // 3000)]
+            resc_ok = 0
+            for k in sample:
+                p = int(word_idx[k])
+                qi, ti = int(pair_q[p]), int(pair_t[p])
+                q, cbq = swq[qi]["q"], swq[qi]["comp_bias"]
+                t = tres[int(toff[ti]):int(toff[ti + 1])]
+                qp, tp, sc, prev = int(blk[k]["q_start"]), int(blk[k]["t_start"]), 0, "M"
+                for ch in bstr[k]:
+                    if ch == "M":
+                        sc += int(mat[int(q[qp]), int(t[tp])]) + int(cbq[qp])
+                        qp += 1
+                        tp += 1
+                    else:
+                        sc -= 1 if prev == ch else 11
+                        qp += ch == "I"
+                        tp += ch == "D"
+                    prev = ch
+                resc_ok += int((sc, qp - 1, tp - 1) == (int(sep[p]["score"]), int(sep[p]["q_end"]), int(sep[p]["t_end"])))
+            out["block_aligner"] = {"pairs": int(len(word_idx)), "device": int((blk["status"] == 0).sum()),
+                                    "declined": int((blk["status"] == 1).sum()), "too_large": int((blk["status"] == 2).sum()),
+                                    "first_tier_512_rows_lds": int(tier1), "second_tier_4096_rows": int(tier2),
+                                    "rescored_sample": int(len(sample)), "rescored_equal": int(resc_ok), "s_c_abi_calls_incl_download": round(getattr(swb, "last_block_call_s", t_blk), 4),
+                                    "s_incl_python_binding": round(t_blk, 4),
+                                    "what": "mmgpu_sw_block_backtrace over every word == 1 pair of the hit lists that has a start position "
+                                            "(score passes -e 1e-3); device = answered by block_kernel.hip, declined = 'Block alignment "
+                                            "failed' (the reference falls back too), too_large = left to the host (must be 0); "
+                                            "rescored_equal = sampled CIGARs whose path re-scores to the SW score and ends at (q_end, t_end)"}
+        except Exception as e:
+            out["block_aligner"] = {"error": "%s: %s" % (type(e).__name__, str(e)[-300:])}
         swb.free()
         started = int(sum(int((g["q_start"] >= 0).sum()) for g in gpu_res))
         out["pairs_with_start"] = started
@@ -933,7 +974,7 @@ def main():
             out["end_to_end"] = e2e
             if "queries_per_s_end_to_end" in e2e:
                 out["queries_per_s_end_to_end"] = e2e["queries_per_s_end_to_end"]
-        for kname in ("two_call", "backtrace", "pairs_with_start", "inexact_queries", "merged_lists_sorted", "aligned_slots_filled", "records_gathered"):
+        for kname in ("two_call", "backtrace", "block_aligner", "pairs_with_start", "inexact_queries", "merged_lists_sorted", "aligned_slots_filled", "records_gathered"):
             if kname in H:
                 out[kname] = H[kname]
         out["setup_s"] = {"generate": round(H["t_gen"], 1), "score_tables_upload_and_device_index_build": round(H["t_index"], 2)}

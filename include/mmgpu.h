@@ -213,13 +213,17 @@ typedef struct {
 #define MMGPU_BLOCK_DECLINED 1   /* "Block alignment failed" (:1058,873-882): the block aligner's score differs from the pair's -
                                     the reference falls back to the reverse scan + banded traceback (q_start / t_start of
                                     mmgpu_sw_fetch, mmgpu_sw_traceback) */
-#define MMGPU_BLOCK_TOO_LARGE 2  /* the crate would grow its block beyond 512 rows, or the pair exceeds the scratch slot: not
-                                    decided on the device, the host runs its own alignStartPosBacktraceBlock */
+#define MMGPU_BLOCK_TOO_LARGE 2  /* not decided on the device: the pair's scratch (4096-row blocks, as the crate's) could not be
+                                    allocated.  Blocks grow to the crate's own 4096 rows (second launch for the pairs that
+                                    leave the 512-row LDS form), so this no longer depends on the pair */
 #define MMGPU_BLOCK_NOT_WORD 3   /* not an int16-range hit of a sequence query with a positive score */
 /* pair_index as for mmgpu_sw_traceback (any mode: only score / q_end / t_end of the forward scan are read); every pair reserves
  * (q_end + 1) + (t_end + 1) + 1 bytes of bt. */
 int mmgpu_sw_block_backtrace(mmgpu_ctx *ctx, mmgpu_sw_batch_t *batch, const uint32_t *pair_index, uint32_t n_pairs,
                              mmgpu_sw_block *out, char *bt, size_t bt_cap, size_t *bt_used);
+/* reporting: how many pairs of the batch's LAST mmgpu_sw_block_backtrace call were decided with blocks up to 512 rows (borders
+ * in LDS) and how many needed the second launch with the crate's full 4096-row blocks (borders in HBM) */
+int mmgpu_sw_block_tiers(const mmgpu_sw_batch_t *batch, uint32_t *first_tier, uint32_t *second_tier);
 
 /* ---- nucleotide alignment step (behind Alignment::run for nucleotide databases) --------------------------------
  * BandedNucleotideAligner::align (src/alignment/BandedNucleotideAligner.cpp:76-263; Matcher::getSWResult calls it

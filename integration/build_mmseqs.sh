@@ -8,7 +8,10 @@
 #                              Smith-Waterman fallback).  MMGPU_BLOCK_STUB_ONLY=1: stubs for everything,
 #                              as in rounds 1-2.
 #   oracle/_ref/mmseqs_mmgpu   the same tree + integration/mmseqs_mmgpu.patch (7 files, every change under #ifdef HAVE_MMGPU),
-#                              integration/*.cpp compiled in, linked against mmseqs2_amd/lib/libmmgpu.so
+#                              integration/*.cpp compiled in, linked against mmseqs2_amd/lib/libmmgpu.so.  ALWAYS with the
+#                              do-nothing block-aligner stubs (round 4): nothing of oracle/*.c is on the product-side binary's link
+#                              line - int16-range pairs get start / CIGAR from the device's block aligner (block_kernel.hip, blocks
+#                              up to the crate's 4096 rows); a maintainer's build links the real Rust crate here instead
 #
 # Both are checkers / demonstrators of the drop-in (tests/test_mmseqs_dropin.py diffs their result DBs); they are git-ignored
 # and travel to the GPU box with the snapshot.  Uses the reference's CMake files on a scratch copy.
@@ -85,8 +88,8 @@ fi
 if [ "$WHAT" = mmgpu ] || [ "$WHAT" = all ]; then
     LIB="${MMGPU_LIBRARY:-$REPO/mmseqs2_amd/lib/libmmgpu.so}"
     [ -f "$LIB" ] || { echo "build_mmseqs: $LIB missing (run make -C mmseqs2_amd/csrc first)" >&2; exit 2; }
-    prepare_tree "$WORK/ref_mmgpu" "$HERE/mmseqs_mmgpu.patch"
-    cmake -S "$WORK/ref_mmgpu" -B "$WORK/build_mmgpu" -DHAVE_AVX2=1 -DCMAKE_BUILD_TYPE=Release -DHAVE_TESTS=0 -DHAVE_SHELLCHECK=0 \
+    MMGPU_BLOCK_STUB_ONLY=1 prepare_tree "$WORK/ref_mmgpu_stubonly" "$HERE/mmseqs_mmgpu.patch"
+    cmake -S "$WORK/ref_mmgpu_stubonly" -B "$WORK/build_mmgpu" -DHAVE_AVX2=1 -DCMAKE_BUILD_TYPE=Release -DHAVE_TESTS=0 -DHAVE_SHELLCHECK=0 \
         -DHAVE_MMGPU=1 -DMMGPU_DIR="$REPO" -DMMGPU_LIBRARY="$LIB" \
         -DCMAKE_EXE_LINKER_FLAGS="-Wl,-rpath,'\$ORIGIN/../../mmseqs2_amd/lib' -Wl,-rpath-link,/opt/rocm/lib" > "$WORK/cmake_mmgpu.log" 2>&1
     make -C "$WORK/build_mmgpu" -j"$JOBS" mmseqs > "$WORK/make_mmgpu.log" 2>&1 || { grep -B2 -A12 "error" "$WORK/make_mmgpu.log" | head -80; exit 1; }

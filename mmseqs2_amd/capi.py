@@ -75,7 +75,7 @@ EXPORTED_SYMBOLS = [
     "mmgpu_host_partition_targets", "mmgpu_pf_set_shard", "mmgpu_pf_fetch_exchange", "mmgpu_pf_merge_exchange",
     "mmgpu_pf_localize_lists", "mmgpu_sw_prepare_from_lists",
     "mmgpu_comm_unique_id", "mmgpu_comm_init_rank", "mmgpu_comm_info", "mmgpu_comm_destroy", "mmgpu_pf_exchange_merge",
-    "mmgpu_sw_prepare_owned", "mmgpu_sw_gather_owned", "mmgpu_sw_fetch_owned", "mmgpu_sw_block_backtrace",
+    "mmgpu_sw_prepare_owned", "mmgpu_sw_gather_owned", "mmgpu_sw_fetch_owned", "mmgpu_sw_block_backtrace", "mmgpu_sw_block_tiers",
     "mmgpu_init_multi", "mmgpu_destroy_multi", "mmgpu_multi_size", "mmgpu_multi_ctx", "mmgpu_multi_synchronize",
     "mmgpu_multi_load_targets", "mmgpu_multi_pf_build_index", "mmgpu_multi_pf_prepare", "mmgpu_multi_pf_run", "mmgpu_multi_pf_fetch",
     "mmgpu_multi_pf_stride", "mmgpu_multi_pf_free", "mmgpu_multi_sw_from_pf",
@@ -173,6 +173,7 @@ def load_library():
     L.mmgpu_sw_prepare_from_lists.argtypes = [c_p, ctypes.POINTER(SwParams), c_p, ctypes.c_uint32, ctypes.c_int, c_p, c_p,
                                               ctypes.c_uint32, ctypes.POINTER(c_p)]
     L.mmgpu_sw_block_backtrace.argtypes = [c_p, c_p, c_p, ctypes.c_uint32, c_p, c_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
+    L.mmgpu_sw_block_tiers.argtypes = [c_p, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]
     L.mmgpu_comm_unique_id.argtypes = [c_p]
     L.mmgpu_comm_init_rank.argtypes = [c_p, c_p, ctypes.c_int, ctypes.c_int]
     L.mmgpu_comm_info.argtypes = [c_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.c_char_p, ctypes.c_int]
@@ -444,13 +445,22 @@ class SwBatch:
         pi = np.ascontiguousarray(pair_index, np.uint32)
         out = np.zeros(len(pi), SW_BLOCK_DTYPE)
         used = ctypes.c_size_t()
+        import time
+        t0 = time.perf_counter()
         rc = self.gpu.L.mmgpu_sw_block_backtrace(self.gpu.ctx, self.handle, _ptr(pi), len(pi), _ptr(out), None, 0, ctypes.byref(used))
         bt = np.zeros(max(used.value, 1), np.uint8)
         self.gpu._check(self.gpu.L.mmgpu_sw_block_backtrace(self.gpu.ctx, self.handle, _ptr(pi), len(pi), _ptr(out), _ptr(bt), used.value,
                                                             ctypes.byref(used)))
+        self.last_block_call_s = time.perf_counter() - t0      # the two C-ABI calls without the string decoding below
         raw = bt.tobytes()
         strs = [raw[int(o["bt_off"]):int(o["bt_off"]) + int(o["bt_len"])].decode() if o["status"] == 0 else None for o in out]
         return out, strs
+
+    def block_tiers(self):
+        """mmgpu_sw_block_tiers: (pairs decided with <= 512-row blocks, pairs that needed the 4096-row launch) of the last call"""
+        a, b = ctypes.c_uint32(), ctypes.c_uint32()
+        self.gpu._check(self.gpu.L.mmgpu_sw_block_tiers(self.handle, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
 
     def kernel_ms(self):
         ms = ctypes.c_float()

@@ -12,8 +12,11 @@
 // Same operations in the same order on the same int16 values (saturating adds), so the result - score, end position,
 // every trace bit - equals the crate's; the block's border arrays (D_col, C_col, D_row, R_row, their checkpoints) live in LDS,
 // the trace (2 x 2 bits per cell, as ballots) and the block list in a scratch slot in HBM, the walk back is serial.
-// Blocks grow to 512 rows here (the crate: 4096); pairs that ask for more, or whose reversed prefixes exceed the scratch slot,
-// are answered MMGPU_BLOCK_TOO_LARGE and left to the host.
+// Two instantiations: blocks up to 512 rows with the border arrays in LDS (every pair goes here first), and the crate's full
+// 4096 rows with the border arrays in the pair's scratch slot in HBM (second launch, only for the pairs the first one answered
+// MMGPU_BLOCK_TOO_LARGE: the crate would have grown the block beyond 512 rows, or the score was not reached with min_size <= 512).
+// A single wavefront owns a slot, its stores and loads go through one L1 in program order, so the HBM borders need no fence
+// beyond the wave barriers the LDS form already has.
 #include "mmgpu_internal.h"
 
 namespace mmgpu {
@@ -371,8 +374,9 @@ __device__ void bk_align(const BlockLaunch &L, const int8_t *scores, BkState &S,
     *res_j = best_j;
 }
 
+template <int MAXB, bool LDS_BORDERS>
 __global__ __launch_bounds__(64) void sw_block_kernel(BlockLaunch L) {
-    __shared__ int16_t s_buf[8][BLOCK_MAX_SIZE];
+    __shared__ int16_t s_lds[LDS_BORDERS ? 8 * MAXB : 8];
     __shared__ int16_t s_temp[2][64];
     __shared__ int8_t s_scores[27 * 32];
     __shared__ uint32_t s_slot;
@@ -386,16 +390,25 @@ __global__ __launch_bounds__(64) void sw_block_kernel(BlockLaunch L) {
     __syncthreads();
     const BlockJob J = L.jobs[blockIdx.x];
     BkState S;
-    S.D_col = s_buf[0]; S.C_col = s_buf[1]; S.D_row = s_buf[2]; S.R_row = s_buf[3];
-    S.D_col_ck = s_buf[4]; S.C_col_ck = s_buf[5]; S.D_row_ck = s_buf[6]; S.R_row_ck = s_buf[7];
-    S.temp1 = s_temp[0]; S.temp2 = s_temp[1];
     uint8_t *slot = L.pool + (size_t)s_slot * L.slot_bytes;
+    uint64_t slot_bytes = L.slot_bytes;
+    int16_t *s_buf;
+    if (LDS_BORDERS) {
+        s_buf = s_lds;
+    } else {      // the first 8 * MAXB int16 of the slot
+        s_buf = reinterpret_cast<int16_t *>(slot);
+        slot += (size_t)8 * MAXB * sizeof(int16_t);
+        slot_bytes -= (uint64_t)8 * MAXB * sizeof(int16_t);
+    }
+    S.D_col = s_buf; S.C_col = s_buf + MAXB; S.D_row = s_buf + 2 * MAXB; S.R_row = s_buf + 3 * MAXB;
+    S.D_col_ck = s_buf + 4 * MAXB; S.C_col_ck = s_buf + 5 * MAXB; S.D_row_ck = s_buf + 6 * MAXB; S.R_row_ck = s_buf + 7 * MAXB;
+    S.temp1 = s_temp[0]; S.temp2 = s_temp[1];
     const int qa = J.q_end + 1, ta = J.t_end + 1;
     S.block_cap = (uint32_t)(qa + ta + 64);
     S.blocks = reinterpret_cast<BkBlock *>(slot);
     const size_t blocks_bytes = ((size_t)S.block_cap * sizeof(BkBlock) + 31) & ~(size_t)31;
     S.trace = reinterpret_cast<unsigned long long *>(slot + blocks_bytes);
-    S.trace_cap = blocks_bytes < L.slot_bytes ? (uint32_t)((L.slot_bytes - blocks_bytes) / 32) : 0u;
+    S.trace_cap = blocks_bytes < slot_bytes ? (uint32_t)std::min<uint64_t>((slot_bytes - blocks_bytes) / 32, 0xFFFFFFFFull) : 0u;
     BkSeq Q, T;
     Q.res = L.q_res + L.q_off[J.query];
     Q.bias = L.q_cb + L.q_off[J.query];
@@ -410,26 +423,28 @@ __global__ __launch_bounds__(64) void sw_block_kernel(BlockLaunch L) {
     out.q_start = -1; out.t_start = -1; out.ident = 0; out.bt_len = 0; out.bt_off = L.bt_off[J.slot];
     out.status = MMGPU_BLOCK_DECLINED;
     int score = -1000000000, ri = 0, rj = 0;
-    bool too_large = blocks_bytes >= L.slot_bytes;
-    for (int min_size = 32; min_size <= BLOCK_MAX_SIZE && score < J.score && !too_large; min_size *= 2) {      // :1021-1038
-        for (int k = lane; k < BLOCK_MAX_SIZE; k += 64)
-            for (int b = 0; b < 8; b++) s_buf[b][k] = BK_MIN;      // Allocated::clear
+    bool too_large = blocks_bytes >= slot_bytes;
+    const long long t_begin = clock64();
+    long long t_walk = t_begin;
+    for (int min_size = 32; min_size <= MAXB && score < J.score && !too_large; min_size *= 2) {      // :1021-1038
+        for (int k = lane; k < 8 * MAXB; k += 64) s_buf[k] = BK_MIN;      // Allocated::clear
         s_temp[0][lane] = BK_MIN;
         s_temp[1][lane] = BK_MIN;
         S.trace_idx = S.block_idx = S.ck_trace_idx = S.ck_block_idx = 0;
         S.overflow = false;
         const int x_drop = -(min_size * L.gap_extend + L.gap_open);
-        bk_align(L, s_scores, S, Q, T, min_size, BLOCK_MAX_SIZE, x_drop, K, lane, &score, &ri, &rj);
+        bk_align(L, s_scores, S, Q, T, min_size, MAXB, x_drop, K, lane, &score, &ri, &rj);
         if (S.overflow) too_large = true;
     }
-    // the crate would go on to larger minimum sizes (up to 4096) when the score is not reached: not decided here
-    if (!too_large && score < J.score) too_large = true;
+    // MAXB < 4096: the crate would go on to larger minimum sizes when the score is not reached - not decided by this instantiation
+    if (MAXB < BLOCK_REF_MAX_SIZE && !too_large && score < J.score) too_large = true;
     if (too_large) {
         out.status = MMGPU_BLOCK_TOO_LARGE;
     } else if (!(score != J.score && !(J.score == 32767 && score >= J.score))) {      // :1058
         // Trace::cigar_core (scan_block.rs:1844-2006): serial walk from the end position to the origin; the reference
         // reverses the run order and then the string (:1071-1110), which leaves exactly the walk order
         __threadfence_block();
+        t_walk = clock64();
         uint32_t block_idx = S.block_idx;
         int i = ri, j = rj, table = 0;      // 0 = D, 1 = C, 2 = R
         uint32_t n = 0, ids = 0;
@@ -479,6 +494,10 @@ __global__ __launch_bounds__(64) void sw_block_kernel(BlockLaunch L) {
         out.ident = ids;
         out.bt_len = n;
     }
+    {   // profiling aid in the reserved field: share of the pair's time spent in the serial walk back, in 1/1000
+        const long long t_end = clock64();
+        out.reserved = (t_walk > t_begin && t_end > t_begin) ? (int32_t)(((t_end - t_walk) * 1000) / (t_end - t_begin)) : 0;
+    }
     if (lane == 0) {
         L.out[J.slot] = out;
         __threadfence();
@@ -488,9 +507,10 @@ __global__ __launch_bounds__(64) void sw_block_kernel(BlockLaunch L) {
 
 }  // namespace
 
-hipError_t launch_sw_block(const BlockLaunch &L, hipStream_t stream) {
+hipError_t launch_sw_block(const BlockLaunch &L, bool full_size, hipStream_t stream) {
     if (L.n_jobs == 0) return hipSuccess;
-    hipLaunchKernelGGL(sw_block_kernel, dim3(L.n_jobs), dim3(64), 0, stream, L);
+    if (full_size) hipLaunchKernelGGL((sw_block_kernel<BLOCK_REF_MAX_SIZE, false>), dim3(L.n_jobs), dim3(64), 0, stream, L);
+    else hipLaunchKernelGGL((sw_block_kernel<BLOCK_MAX_SIZE, true>), dim3(L.n_jobs), dim3(64), 0, stream, L);
     return hipGetLastError();
 }
 

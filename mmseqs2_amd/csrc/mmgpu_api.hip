@@ -298,6 +298,7 @@ struct mmgpu_sw_batch_t {
     std::vector<mmgpu_sw_hit> h_res;
     std::vector<uint32_t> h_slot_target;
     bool h_res_valid = false;
+    uint32_t block_pairs_first_tier = 0, block_pairs_second_tier = 0;   // last mmgpu_sw_block_backtrace call
     // pairs this rank owns of a sharded run's merged lists (mmgpu_sw_prepare_owned / mmgpu_sw_gather_owned)
     bool owned = false;
     uint32_t o_stride = 0, o_cap = 0;
@@ -1012,8 +1013,9 @@ extern "C" int mmgpu_sw_block_backtrace(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const
         for (int y = 0; y < 26; y++) scores[x * 32 + y] = x == y ? 1 : -1;
     for (int x = 0; x < b->alphabet; x++)
         for (int y = 0; y < b->alphabet; y++) { scores[x * 32 + y] = mat[(size_t)x * b->alphabet + y]; scores[y * 32 + x] = mat[(size_t)x * b->alphabet + y]; }
-    // scratch slot: block list + trace of the longest pair the kernel takes: (BLOCK_MAX_SIZE / 64) entries of 32 bytes per column
-    // of the trace, len + 2 * BLOCK_MAX_SIZE columns (Trace::new, scan_block.rs:1742-1748), pairs beyond 16384 residues declined
+    // First tier: blocks up to 512 rows, borders in LDS.  Scratch slot = block list + trace of the longest pair it takes:
+    // (BLOCK_MAX_SIZE / 64) entries of 32 bytes per column of the trace, len + 2 * BLOCK_MAX_SIZE columns (Trace::new,
+    // scan_block.rs:1742-1748); pairs beyond 16384 residues overflow the slot, are answered TOO_LARGE and go to the second tier.
     const uint64_t cap_len = std::min<uint64_t>(longest, 16384);
     const uint64_t slot_bytes = (((cap_len + 64) * 16 + 31) & ~31ull) + (uint64_t)(BLOCK_MAX_SIZE / 64) * 32 * (cap_len + 2 * BLOCK_MAX_SIZE);
     const uint32_t slots = (uint32_t)std::min<uint64_t>(jobs.size(), (uint64_t)std::max(c->compute_units, 1) * 16);
@@ -1049,10 +1051,54 @@ extern "C" int mmgpu_sw_block_backtrace(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const
     L.slot_bytes = slot_bytes;
     L.n_pool_slots = slots;
     L.pool_busy = d_busy.as<uint32_t>();
-    HIP_TRY(launch_sw_block(L, s));
+    const bool skip_first_tier = getenv("MMGPU_BLOCK_FULL_SIZE_ONLY") != nullptr;      // test aid: everything through the second tier
+    if (!skip_first_tier) HIP_TRY(launch_sw_block(L, false, s));
     HIP_TRY(hipMemcpyAsync(out, d_out.p, (size_t)n * sizeof(mmgpu_sw_block), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    // Second tier: what the first one left undecided, with the crate's own 4096-row limit.  Slot = 8 border arrays of 4096 int16 +
+    // block list + (4096 / 64) x 32 bytes per trace column, len + 2 * 4096 columns; as many slots as fit MMGPU_BLOCK_POOL_MB
+    // (default 16 GB of the 288), at least one - the kernel's slot loop serialises the rest.
+    std::vector<BlockJob> big;
+    uint64_t big_longest = 0;
+    for (const BlockJob &j : jobs)
+        if (out[j.slot].status == MMGPU_BLOCK_TOO_LARGE) {
+            big.push_back(j);
+            big_longest = std::max<uint64_t>(big_longest, (uint64_t)j.q_end + 1 + (uint64_t)j.t_end + 1);
+        }
+    b->block_pairs_first_tier = (uint32_t)(jobs.size() - big.size());
+    b->block_pairs_second_tier = (uint32_t)big.size();
+    if (!big.empty()) {
+        const uint64_t big_slot = (uint64_t)8 * BLOCK_REF_MAX_SIZE * 2 + (((big_longest + 64) * 16 + 31) & ~31ull) +
+                                  (uint64_t)(BLOCK_REF_MAX_SIZE / 64) * 32 * (big_longest + 2 * BLOCK_REF_MAX_SIZE);
+        static const uint64_t pool_limit = (getenv("MMGPU_BLOCK_POOL_MB") ? strtoull(getenv("MMGPU_BLOCK_POOL_MB"), nullptr, 10) : 16384ull) << 20;
+        const uint32_t big_slots = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>({(uint64_t)big.size(), pool_limit / big_slot,
+                                                                                       (uint64_t)std::max(c->compute_units, 1) * 4}));
+        DevBuf d_bigjobs, d_bigpool, d_bigbusy;
+        for (DevBuf *d : {&d_bigjobs, &d_bigpool, &d_bigbusy}) d->bind(c->cache);
+        HIP_TRY(d_bigjobs.alloc(big.size() * sizeof(BlockJob)));
+        HIP_TRY(d_bigpool.alloc((size_t)big_slot * big_slots));
+        HIP_TRY(d_bigbusy.alloc((size_t)big_slots * 4));
+        HIP_TRY(hipMemsetAsync(d_bigbusy.p, 0, (size_t)big_slots * 4, s));
+        HIP_TRY(hipMemcpyAsync(d_bigjobs.p, big.data(), big.size() * sizeof(BlockJob), hipMemcpyHostToDevice, s));
+        L.jobs = d_bigjobs.as<BlockJob>();
+        L.n_jobs = (uint32_t)big.size();
+        L.pool = d_bigpool.as<uint8_t>();
+        L.slot_bytes = big_slot;
+        L.n_pool_slots = big_slots;
+        L.pool_busy = d_bigbusy.as<uint32_t>();
+        HIP_TRY(launch_sw_block(L, true, s));
+        HIP_TRY(hipMemcpyAsync(out, d_out.p, (size_t)n * sizeof(mmgpu_sw_block), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
     if (off) HIP_TRY(hipMemcpyAsync(bt, d_bt.p, (size_t)off, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));      // the host vectors and the buffers above die with this scope
+    return MMGPU_OK;
+}
+
+extern "C" int mmgpu_sw_block_tiers(const mmgpu_sw_batch_t *b, uint32_t *first_tier, uint32_t *second_tier) {
+    if (!b) return fail(MMGPU_ERR_ARG, "mmgpu_sw_block_tiers: NULL batch");
+    if (first_tier) *first_tier = b->block_pairs_first_tier;
+    if (second_tier) *second_tier = b->block_pairs_second_tier;
     return MMGPU_OK;
 }
 

@@ -450,7 +450,7 @@ struct BtLaunch {
 };
 
 // ---- block aligner on the device (block_kernel.hip; row a15): int16-range hits ----
-constexpr int BLOCK_MAX_SIZE = 512;        // largest block this kernel holds in LDS
+constexpr int BLOCK_MAX_SIZE = 512;        // largest block the first-tier kernel holds in LDS
 constexpr int BLOCK_REF_MAX_SIZE = 4096;   // MAX_SIZE of the reference (StripedSmithWaterman.cpp:37)
 struct BlockJob {
     uint32_t query, target;
@@ -475,7 +475,8 @@ struct BlockLaunch {
     uint32_t n_pool_slots;
     uint32_t *pool_busy;
 };
-hipError_t launch_sw_block(const BlockLaunch &L, hipStream_t stream);
+// full_size: blocks up to BLOCK_REF_MAX_SIZE rows, border arrays in the first 8 * 4096 * 2 bytes of the pair's scratch slot
+hipError_t launch_sw_block(const BlockLaunch &L, bool full_size, hipStream_t stream);
 
 hipError_t launch_sw_traceback(const BtLaunch &L, hipStream_t stream);
 hipError_t launch_sw_traceback_wave(const BtLaunch &L, hipStream_t stream);

@@ -227,6 +227,12 @@ int mmgpu_sw_block_backtrace(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const uint32_t *
     return 0;
 }
 
+int mmgpu_sw_block_tiers(const mmgpu_sw_batch_t *, uint32_t *first_tier, uint32_t *second_tier) {
+    if (first_tier) *first_tier = 0;
+    if (second_tier) *second_tier = 0;
+    return 0;
+}
+
 int mmgpu_sw_traceback(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const uint32_t *idx, uint32_t n, mmgpu_sw_bt *info, char *bt, size_t cap,
                        size_t *used) {
     size_t need = 0;

@@ -2,10 +2,19 @@
 reference build patched with integration/mmseqs_mmgpu.patch and linked to libmmgpu.so, against the STOCK reference binary
 on the same inputs; the result DBs must agree entry by entry, byte for byte.
 
-Both binaries are built by integration/build_mmseqs.sh from the reference tree (oracle/_ref/mmseqs_stock,
-oracle/_ref/mmseqs_mmgpu; the Rust block-aligner is stubbed in both, so both take the reference's Smith-Waterman
-fallback for int16-range hits - SURVEY.md section 8c) and travel to the GPU box with the snapshot, together with the createdb
-output of the reference's example proteins (oracle/_ref/dropin_data/examples = BASELINE.json configs[0]).
+The binaries are built by integration/build_mmseqs.sh from the reference tree and travel to the GPU box with the snapshot,
+together with the createdb output of the reference's example proteins (oracle/_ref/dropin_data/examples = BASELINE.json
+configs[0]).  The Rust block-aligner crate (start / CIGAR of int16-range hits, row a15) cannot be built in this image:
+  oracle/_ref/mmseqs_stock       the crate's C API served by the plain-C restatement (oracle/block_oracle.c) - what a Rust-linked
+                                 build computes, as far as tests/test_block_oracle.py pins the restatement
+  oracle/_ref/mmseqs_stock_stub  do-nothing stubs in the crate's place: every int16-range pair takes the reference's documented
+                                 Smith-Waterman fallback (StripedSmithWaterman.cpp:873-882)
+  oracle/_ref/mmseqs_mmgpu       patched + libmmgpu.so, stubs in the crate's place (round 4: nothing of oracle/*.c inside): the
+                                 int16-range pairs of the device path come from the device's block aligner
+Runs in which every first alignment is the device's are compared with mmseqs_stock.  Runs in which the HOST's own Matcher also
+aligns int16-range pairs (--realign / --alt-ali second alignments, `cluster`) can only equal a build with the same host-side
+block aligner: they run with MMGPU_BLOCK_ALIGNER=sw (the fallback on the device side too) against mmseqs_stock_stub
+(`reference_for`).
 
  * `-m gpu` tests: the patched binary runs on the device (the real mmseqs2_amd/lib/libmmgpu.so).
  * `-m "not gpu"` tests: the same binary with the C-ABI served by the CPU stand-in oracle/_build/emu/libmmgpu.so
@@ -25,6 +34,7 @@ from mmseqs2_amd import workloads as wl
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 STOCK = os.path.join(ROOT, "oracle", "_ref", "mmseqs_stock")
 MMGPU = os.path.join(ROOT, "oracle", "_ref", "mmseqs_mmgpu")
+STOCK_STUB = os.path.join(ROOT, "oracle", "_ref", "mmseqs_stock_stub")
 EXAMPLES = os.path.join(ROOT, "oracle", "_ref", "dropin_data", "examples")
 EMU = os.path.join(ROOT, "oracle", "_build", "emu", "libmmgpu.so")
 
@@ -70,6 +80,14 @@ def run(binary, args, cwd, emulate=False, extra_env=None):
     return r.stdout
 
 
+def reference_for(args):
+    """-> (reference binary, extra environment of the patched binary) for a command line: see the module docstring"""
+    host_side = any(a in ("--realign", "--alt-ali", "cluster", "--num-iterations") for a in args)
+    if host_side:
+        return STOCK_STUB, {"MMGPU_BLOCK_ALIGNER": "sw"}
+    return STOCK, {}
+
+
 def same(a, b):
     n, bad, msgs = dbio.diff_dbs(a, b)
     assert bad == 0, "%d of %d entries differ: %s" % (bad, n, "; ".join(msgs))
@@ -93,8 +111,9 @@ def examples_pipeline(tmp, emulate):
     assert "MMGPU: device" in log and "using the CPU path" not in log, log[-2000:]
     assert same(os.path.join(w, "pref_s"), os.path.join(w, "pref_g")) == 500
     for i, case in enumerate(ALIGN_CASES):
-        run(STOCK, ["align", "q", "q", "pref_s", "aln_s%d" % i] + case + ["--threads", THREADS, "-v", "2"], w)
-        log = run(MMGPU, ["align", "q", "q", "pref_s", "aln_g%d" % i] + case + ["--threads", THREADS, "-v", "3"], w, emulate)
+        ref, env = reference_for(case)
+        run(ref, ["align", "q", "q", "pref_s", "aln_s%d" % i] + case + ["--threads", THREADS, "-v", "2"], w)
+        log = run(MMGPU, ["align", "q", "q", "pref_s", "aln_g%d" % i] + case + ["--threads", THREADS, "-v", "3"], w, emulate, extra_env=env)
         assert "MMGPU: device" in log and "using the CPU path" not in log, log[-2000:]
         assert same(os.path.join(w, "aln_s%d" % i), os.path.join(w, "aln_g%d" % i)) == 500, case
 
@@ -135,8 +154,9 @@ def test_examples_search_workflow_on_device(tmp_path):
     # iterative profile search (blastpgp.sh): realigned first iteration, profile queries in the second - every prefilter /
     # align call of the workflow on the device
     it = ["--num-iterations", "2", "-s", "4", "--threads", THREADS]
-    run(STOCK, ["search", "q", "q", "res_it_s", "tmp_it_s"] + it + ["-v", "2"], w)
-    log = run(MMGPU, ["search", "q", "q", "res_it_g", "tmp_it_g"] + it + ["-v", "3"], w)
+    ref, env = reference_for(it)
+    run(ref, ["search", "q", "q", "res_it_s", "tmp_it_s"] + it + ["-v", "2"], w)
+    log = run(MMGPU, ["search", "q", "q", "res_it_g", "tmp_it_g"] + it + ["-v", "3"], w, extra_env=env)
     assert log.count("MMGPU: device") >= 4 and "using the CPU path" not in log, log[-3000:]
     assert same(os.path.join(w, "res_it_s"), os.path.join(w, "res_it_g")) == 500
 
@@ -496,8 +516,9 @@ def cluster_pipeline(tmp, emulate):
     w = str(tmp)
     copy_db(EXAMPLES, os.path.join(w, "q"))
     for i, a in enumerate((["--min-seq-id", "0.3", "-s", "4"], ["-c", "0.9", "--cov-mode", "1", "--cluster-mode", "2"])):
-        run(STOCK, ["cluster", "q", "clu_s%d" % i, "tmp_s%d" % i] + a + ["--threads", THREADS, "-v", "2"], w)
-        log = run(MMGPU, ["cluster", "q", "clu_g%d" % i, "tmp_g%d" % i] + a + ["--threads", THREADS, "-v", "3"], w, emulate)
+        ref, env = reference_for(["cluster"])
+        run(ref, ["cluster", "q", "clu_s%d" % i, "tmp_s%d" % i] + a + ["--threads", THREADS, "-v", "2"], w)
+        log = run(MMGPU, ["cluster", "q", "clu_g%d" % i, "tmp_g%d" % i] + a + ["--threads", THREADS, "-v", "3"], w, emulate, extra_env=env)
         assert log.count("MMGPU: device") >= 6 and "using the CPU path" not in log, log[-3000:]
         assert same(os.path.join(w, "clu_s%d" % i), os.path.join(w, "clu_g%d" % i)) > 400
 
@@ -625,24 +646,32 @@ def test_several_device_contexts_in_one_process(tmp_path):
 
 def _block_aligner_modes(tmp, emulate):
     """int16-range hits (most true homologs): the stock binary of this image runs the RESTATED block aligner behind the crate's C
-    API (integration/build_mmseqs.sh); the patched binary must produce the same databases whichever way it answers those pairs:
-    the device's block aligner (default), the host's alignStartPosBacktraceBlock as a hook, or - with the device declining every
-    pair as too large - the hook behind the device."""
+    API (integration/build_mmseqs.sh).  The patched binary is linked with do-nothing stubs in the crate's place (round 4: nothing of
+    oracle/*.c on its link line), so every such pair is answered by the device's block aligner - blocks up to the crate's 4096
+    rows - and the databases must equal the stock binary's.  MMGPU_BLOCK_ALIGNER=sw selects the reference's documented fallback
+    (reverse scan + banded traceback) for all of them: a different, equally scoring answer for some."""
     w = str(tmp)
     copy_db(EXAMPLES, os.path.join(w, "q"))
     run(STOCK, ["prefilter", "q", "q", "pref_s", "-s", "4", "--threads", THREADS, "-v", "2"], w)
     run(STOCK, ["align", "q", "q", "pref_s", "aln_s", "-a", "--threads", THREADS, "-v", "2"], w)
-    for name, env in (("device", {}), ("host", {"MMGPU_BLOCK_ALIGNER": "host"})):
-        log = run(MMGPU, ["align", "q", "q", "pref_s", "aln_" + name, "-a", "--threads", THREADS, "-v", "3"], w, emulate, extra_env=env)
-        assert "using the CPU path" not in log, log[-2000:]
-        assert same(os.path.join(w, "aln_s"), os.path.join(w, "aln_" + name)) == 500, name
-    if emulate:      # the stand-in declines long pairs like the device does beyond its scratch slot: the hook serves them
-        run(MMGPU, ["align", "q", "q", "pref_s", "aln_mixed", "-a", "--threads", THREADS, "-v", "3"], w, emulate, extra_env={"MMGPU_EMU_REFUSE_BLOCK": "300"})
-        assert same(os.path.join(w, "aln_s"), os.path.join(w, "aln_mixed")) == 500
-    # "sw": the reference's fallback for every int16-range pair - a DIFFERENT (equally scoring) answer for some of them
+    log = run(MMGPU, ["align", "q", "q", "pref_s", "aln_device", "-a", "--threads", THREADS, "-v", "3"], w, emulate)
+    assert "using the CPU path" not in log and "Block alignment failed" not in log, log[-2000:]
+    assert same(os.path.join(w, "aln_s"), os.path.join(w, "aln_device")) == 500
     run(MMGPU, ["align", "q", "q", "pref_s", "aln_sw", "-a", "--threads", THREADS, "-v", "3"], w, emulate, extra_env={"MMGPU_BLOCK_ALIGNER": "sw"})
     n, bad, _ = dbio.diff_dbs(os.path.join(w, "aln_s"), os.path.join(w, "aln_sw"))
     assert n == 500 and bad > 0
+
+
+def test_patched_binary_links_nothing_of_the_oracle():
+    """the product-side binary: reference + patch + libmmgpu.so; the block-aligner crate's place is taken by do-nothing stubs, no
+    restated code (symbols of oracle/block_oracle.c / ref_block_capi.cpp) inside"""
+    if not os.path.exists(MMGPU):
+        pytest.skip("oracle/_ref/mmseqs_mmgpu not built")
+    import subprocess
+    syms = subprocess.run(["nm", "-C", "--defined-only", MMGPU], capture_output=True, text=True).stdout
+    for name in ("mmo_block_align", "mmo_sw_block_backtrace", "mmo_block_align_table", "mmo_block_prefix_scan"):
+        assert name not in syms, name
+    assert "block_align_aa_trace_xdrop_posbias" in syms      # the stub of the crate's C API
 
 
 def test_block_aligner_modes_host_side_emulated(tmp_path):

@@ -347,7 +347,80 @@ def test_block_aligner_on_device_equals_restatement(gpu, matrices, oracle):
                 elif o["status"] == 1:
                     assert not w["ok"], k
                 else:
-                    assert o["status"] == 2 and w["block_size"] >= 32, k
                     n_large += 1
             k += 1
-    assert n_word > 250 and n_ok >= n_word - max(3, n_word // 20), (n_word, n_ok, n_large)
+    # round 4: blocks grow to the crate's 4096 rows on the device, so nothing is left undecided
+    assert n_word > 250 and n_large == 0 and n_ok >= n_word - max(3, n_word // 20), (n_word, n_ok, n_large)
+
+
+def _long_gap_pairs(matrices, oracle, n, seed):
+    """pairs whose alignment carries one long gap between two strongly similar flanks: the block aligner has to grow its block
+    well beyond 512 rows to follow it (the x-drop at small sizes ends in the first flank and the score is not reached)"""
+    rng = np.random.default_rng(seed)
+    bg = matrices["blosum62_pback"].astype(np.float64)[:20]
+    bg = bg / bg.sum()
+    qs, ts = [], []
+    for k in range(n):
+        a = rng.choice(20, size=int(rng.integers(170, 260)), p=bg).astype(np.uint8)
+        bfl = rng.choice(20, size=int(rng.integers(170, 260)), p=bg).astype(np.uint8)
+        z = rng.choice(20, size=int(rng.integers(300, 1500)), p=bg).astype(np.uint8)
+        q = np.concatenate([a, bfl])
+        t = np.concatenate([a, z, bfl]) if k % 2 == 0 else np.concatenate([rng.choice(20, size=40, p=bg).astype(np.uint8), a, z, bfl])
+        if k % 3 == 2:      # gap on the other side
+            q, t = t, q
+        # a few substitutions so that ties and mismatches occur inside the flanks
+        q = q.copy()
+        for p in rng.integers(0, len(q), size=len(q) // 25):
+            q[p] = rng.integers(0, 20)
+        qs.append(q)
+        ts.append(t)
+    return qs, ts
+
+
+@pytest.mark.parametrize("full_only", [False, True])
+def test_block_aligner_grows_to_the_crates_4096_rows(gpu, matrices, oracle, full_only, monkeypatch):
+    """a15, blocks beyond 512 rows: the second launch (sw_block_kernel<4096, borders in HBM>) answers what the LDS form leaves,
+    equal to the restatement field by field; with MMGPU_BLOCK_FULL_SIZE_ONLY every pair (also the short ones of the family
+    workload) runs through the 4096-row instantiation."""
+    from mmseqs2_amd import workloads as wl
+    mat = matrices["blosum62_sw"]
+    sub16 = mat.astype(np.int16)
+    qs, ts = _long_gap_pairs(matrices, oracle, 24, seed=5)
+    if full_only:
+        monkeypatch.setenv("MMGPU_BLOCK_FULL_SIZE_ONLY", "1")
+        (qres, qoff), (tres2, toff2), fam_t, fam_q = wl.config3_prefilter(30, 4, 30, seed=41)
+        fq, ft = wl.split(qres, qoff), wl.split(tres2, toff2)
+        for qi, q in enumerate(fq):
+            for ti in np.nonzero(fam_t == fam_q[qi])[0][:2]:
+                qs.append(q)
+                ts.append(ft[ti])
+    toff = np.zeros(len(ts) + 1, np.uint64)
+    toff[1:] = np.cumsum([len(t) for t in ts])
+    gpu.load_targets(np.concatenate(ts), toff, 21)
+    queries = []
+    for qi, q in enumerate(qs):
+        cb = oracle.round_comp_bias(oracle.comp_bias(sub16, matrices["blosum62_pback"], q, 1.0))
+        queries.append(dict(q=q, comp_bias=cb, targets=np.array([qi], np.uint32), min_start_score=0))
+    b = gpu.sw_prepare(mat, 11, 1, queries, mode=1)
+    b.run()
+    res = b.fetch()
+    blk, strs = b.block_backtrace(np.arange(len(res), dtype=np.uint32))
+    first, second = b.block_tiers()
+    b.free()
+    n_ok = n_big = 0
+    for k, qd in enumerate(queries):
+        r, o = res[k], blk[k]
+        if r["word"] != 1 or r["score"] <= 0:
+            assert o["status"] == 3, k
+            continue
+        w = oracle.block_backtrace(qd["q"], qd["comp_bias"], ts[k], mat, 11, 1, int(r["score"]), int(r["q_end"]), int(r["t_end"]))
+        assert int(o["status"]) == (0 if w["ok"] else 1), (k, int(o["status"]), w["ok"], w["block_size"])
+        if w["ok"]:
+            assert (int(o["q_start"]), int(o["t_start"]), int(o["ident"]), strs[k]) == (w["q_start"], w["t_start"], w["ident"], w["bt"]), k
+            n_ok += 1
+            n_big += w["block_size"] > 512 or ("D" * 300 in w["bt"]) or ("I" * 300 in w["bt"])
+    assert n_ok >= 20 and n_big >= 12, (n_ok, n_big)
+    if full_only:
+        assert first == 0 and second >= n_ok
+    else:
+        assert second >= 2 and first > 0, (first, second)      # (a 512-row block usually follows these gaps; a few pairs grow further)
