@@ -28,8 +28,11 @@
 #include "QueryMatcher.h"
 #include "Util.h"
 
+#include "MMGpuFusedSearch.h"
 #include "MMGpuPrefilter.h"
 #include "MMGpuRun.h"
+
+void mmgpuFusedPrepareCapture(size_t threads);      // MMGpuFusedSearch.cpp
 
 #ifdef OPENMP
 #include <omp.h>
@@ -140,6 +143,10 @@ bool MMGpuPrefilterRun::run(Prefiltering &p, DBWriter &tmpDbw, size_t dbFrom, si
     if (local3.isValid()) ExtendedSubstitutionMatrix::freeScoreMatrix(local3);     // the library copied the tables
     if (local2.isValid()) ExtendedSubstitutionMatrix::freeScoreMatrix(local2);
     const size_t maxBlockQueries = MMGpuRun::envSize("MMGPU_PREF_BLOCK_QUERIES", 2048);
+    // fused search (MMGpuFusedSearch): the entries of an unsplit run stay in memory for the alignment module of this process;
+    // split runs merge their parts through files (mergePrefilterSplits / mergeTargetSplits) and are written as ever
+    const bool capture = p.splits == 1 && MMGpuFusedSearch::capturing(tmpDbw.getDataFileName());
+    if (capture) mmgpuFusedPrepareCapture(localThreads);
 
     std::vector<Sequence *> seqs(localThreads, NULL);
     std::vector<QueryMatcher *> cpuMatchers(localThreads, NULL);
@@ -300,7 +307,8 @@ bool MMGpuPrefilterRun::run(Prefiltering &p, DBWriter &tmpDbw, size_t dbFrom, si
                     int len = QueryMatcher::prefilterHitToBuffer(buffer, *res);
                     result.append(buffer, len);
                 }
-                tmpDbw.writeData(result.c_str(), result.length(), qKey, thread_idx);
+                if (capture) MMGpuFusedSearch::capture(qKey, result.c_str(), result.length(), thread_idx);
+                else tmpDbw.writeData(result.c_str(), result.length(), qKey, thread_idx);
                 result.clear();
                 if (resultSize != 0) {
                     notEmpty[id - queryFrom] = 1;

@@ -2,6 +2,7 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "Debug.h"
@@ -31,6 +32,8 @@ size_t MMGpuRun::envSize(const char *name, size_t fallback) {
 
 mmgpu_ctx *MMGpuRun::context() {
     static mmgpu_ctx *ctx = NULL;
+    static std::mutex lock;      // a fused search opens the device on a helper thread while the prefilter module sets itself up
+    std::lock_guard<std::mutex> guard(lock);
     if (ctx == NULL) {
         const int device = (int)envSize("MMGPU_DEVICE", 0);
         if (mmgpu_init(&ctx, device) != 0) {

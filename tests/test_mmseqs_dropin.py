@@ -141,16 +141,45 @@ def test_examples_prefilter_align_on_device(tmp_path):
     examples_pipeline(tmp_path, emulate=False)
 
 
+def search_workflow(tmp, emulate):
+    """`mmseqs search` unchanged on the command line.  Round 4 (row f2): the plain sequence search runs its prefilter and align
+    modules INSIDE the search process (integration/MMGpuFusedSearch.cpp) - one device context, the hit lists kept in memory, no
+    pref_0 database on disk; MMGPU_FUSED=0 keeps blastp.sh with its two child processes; MMGPU_FUSED_PREF_ON_DISK=1 keeps the
+    prefilter result as a database.  All three must give the stock binary's result database."""
+    w = str(tmp)
+    copy_db(EXAMPLES, os.path.join(w, "q"))
+    for s, extra in (("1", ["-a"]), ("5.7", ["-a"]), ("4", []), ("5.7", ["-e", "10", "-c", "0.5", "--cov-mode", "2", "--alignment-mode", "3"])):
+        tag = s + "_" + str(len(extra))
+        run(STOCK, ["search", "q", "q", "res_s" + tag, "tmp_s" + tag, "-s", s] + extra + ["--threads", THREADS, "-v", "2"], w)
+        log = run(MMGPU, ["search", "q", "q", "res_g" + tag, "tmp_g" + tag, "-s", s] + extra + ["--threads", THREADS, "-v", "3"], w, emulate)
+        assert "prefilter and align run inside this process" in log and log.count("MMGPU: device") == 1, log[-3000:]
+        assert "using the CPU path" not in log, log[-3000:]
+        assert same(os.path.join(w, "res_s" + tag), os.path.join(w, "res_g" + tag)) == 500
+        assert not os.path.exists(os.path.join(w, "tmp_g" + tag, "latest", "pref_0.dbtype"))
+    # the workflow script with its child processes, and the fused run with the prefilter result on disk
+    log = run(MMGPU, ["search", "q", "q", "res_script", "tmp_script", "-s", "5.7", "-a", "--threads", THREADS, "-v", "3"], w, emulate,
+              extra_env={"MMGPU_FUSED": "0"})
+    assert "inside this process" not in log and log.count("MMGPU: device") >= 2, log[-3000:]
+    assert same(os.path.join(w, "res_s5.7_1"), os.path.join(w, "res_script")) == 500
+    log = run(MMGPU, ["search", "q", "q", "res_disk", "tmp_disk", "-s", "5.7", "-a", "--threads", THREADS, "-v", "3"], w, emulate,
+              extra_env={"MMGPU_FUSED_PREF_ON_DISK": "1"})
+    assert "inside this process" in log and os.path.exists(os.path.join(w, "tmp_disk", "latest", "pref_0.dbtype")), log[-3000:]
+    assert same(os.path.join(w, "res_s5.7_1"), os.path.join(w, "res_disk")) == 500
+    # --remove-tmp-files and a second search into the same tmp directory
+    run(MMGPU, ["search", "q", "q", "res_rm", "tmp_disk", "-s", "4", "--remove-tmp-files", "1", "--threads", THREADS, "-v", "3"], w, emulate)
+    assert same(os.path.join(w, "res_s4_0"), os.path.join(w, "res_rm")) == 500
+
+
+def test_search_workflow_host_side_emulated(tmp_path):
+    if not os.path.exists(EMU):
+        pytest.skip("oracle/_build/emu/libmmgpu.so not built (make -C oracle emu)")
+    search_workflow(tmp_path, emulate=True)
+
+
 @pytest.mark.gpu
 def test_examples_search_workflow_on_device(tmp_path):
-    """`mmseqs search` (blastp.sh: prefilter + align as sub-commands of the same binary) unchanged on the command line"""
+    search_workflow(tmp_path, emulate=False)
     w = str(tmp_path)
-    copy_db(EXAMPLES, os.path.join(w, "q"))
-    for s in ["1", "5.7"]:
-        run(STOCK, ["search", "q", "q", "res_s" + s, "tmp_s" + s, "-s", s, "-a", "--threads", THREADS, "-v", "2"], w)
-        log = run(MMGPU, ["search", "q", "q", "res_g" + s, "tmp_g" + s, "-s", s, "-a", "--threads", THREADS, "-v", "3"], w)
-        assert log.count("MMGPU: device") >= 2, log[-3000:]
-        assert same(os.path.join(w, "res_s" + s), os.path.join(w, "res_g" + s)) == 500
     # iterative profile search (blastpgp.sh): realigned first iteration, profile queries in the second - every prefilter /
     # align call of the workflow on the device
     it = ["--num-iterations", "2", "-s", "4", "--threads", THREADS]
