@@ -218,7 +218,9 @@ typedef struct {
                                     leave the 512-row LDS form), so this no longer depends on the pair */
 #define MMGPU_BLOCK_NOT_WORD 3   /* not an int16-range hit of a sequence query with a positive score */
 /* pair_index as for mmgpu_sw_traceback (any mode: only score / q_end / t_end of the forward scan are read); every pair reserves
- * (q_end + 1) + (t_end + 1) + 1 bytes of bt. */
+ * (q_end + 1) + (t_end + 1) + 1 bytes of bt.  bt == NULL with bt_cap == MMGPU_BLOCK_NO_STRINGS: the caller wants start positions,
+ * identities and bt_len only (a run without -a: the strings stay on the device, no download). */
+#define MMGPU_BLOCK_NO_STRINGS ((size_t)-1)
 int mmgpu_sw_block_backtrace(mmgpu_ctx *ctx, mmgpu_sw_batch_t *batch, const uint32_t *pair_index, uint32_t n_pairs,
                              mmgpu_sw_block *out, char *bt, size_t bt_cap, size_t *bt_used);
 /* reporting: how many pairs of the batch's LAST mmgpu_sw_block_backtrace call were decided with blocks up to 512 rows (borders

@@ -154,6 +154,8 @@ MMGpuAlignSession *MMGpuAlignRun::begin(Alignment &al, EvalueComputation &evalue
     s->matcher->setCorrelationScoreWeight(al.correlationScoreWeight);
     if (MMGpuRun::hostBlockAligner()) s->matcher->setBlockBacktracer(hook, lookupTarget, s);
     s->matcher->setDeviceBlockAligner(MMGpuRun::deviceBlockAligner());
+    // result_t::backtrace is read by resultToBuffer with -a (Matcher.cpp:317-323), by --realign (:397) and --alt-ali only
+    s->matcher->setNeedBacktraceStrings(al.addBacktrace || al.realign || al.altAlignment > 0 || al.lcaAlign);
     return s;
 }
 

@@ -32,8 +32,12 @@ public:
         strings.assign((size_t)need, '\0');
         return mmgpu_sw_traceback(gpu, batch, pairIndex, n, info, &strings[0], need, &need);
     }
-    int blockBacktrace(const uint32_t *pairIndex, uint32_t n, mmgpu_sw_block *out, std::string &strings) {
+    int blockBacktrace(const uint32_t *pairIndex, uint32_t n, mmgpu_sw_block *out, std::string &strings, bool wantStrings) {
         size_t need = 0;
+        if (!wantStrings) {
+            strings.clear();
+            return mmgpu_sw_block_backtrace(gpu, batch, pairIndex, n, out, NULL, MMGPU_BLOCK_NO_STRINGS, &need);
+        }
         int rc = mmgpu_sw_block_backtrace(gpu, batch, pairIndex, n, out, NULL, 0, &need);
         if (rc != 0 && need == 0) return rc;
         strings.assign((size_t)need, '\0');
@@ -95,7 +99,8 @@ public:
     int traceback(const uint32_t *pairIndex, uint32_t n, mmgpu_sw_bt *info, std::string &strings) {
         return split<mmgpu_sw_bt>(pairIndex, n, info, strings, true);
     }
-    int blockBacktrace(const uint32_t *pairIndex, uint32_t n, mmgpu_sw_block *out, std::string &strings) {
+    int blockBacktrace(const uint32_t *pairIndex, uint32_t n, mmgpu_sw_block *out, std::string &strings, bool wantStrings) {
+        (void)wantStrings;      // (several devices: the strings are always collected)
         return split<mmgpu_sw_block>(pairIndex, n, out, strings, false);
     }
     const char *lastError() { return mmgpu_last_error(); }

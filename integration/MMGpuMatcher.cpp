@@ -18,7 +18,7 @@
 MMGpuMatcher::MMGpuMatcher(MMGpuAlignBackend *backend, BaseMatrix *m, EvalueComputation *evaluer, bool aaBiasCorrection,
                            float aaBiasCorrectionScale, int gapOpen, int gapExtend)
     : backend(backend), m(m), evaluer(evaluer), aaBiasCorrection(aaBiasCorrection),
-      aaBiasCorrectionScale(aaBiasCorrectionScale), gapOpen(gapOpen), gapExtend(gapExtend), numThreads(0), correlationScoreWeight(0.0f), deviceBlockAligner(false), blockHook(NULL),
+      aaBiasCorrectionScale(aaBiasCorrectionScale), gapOpen(gapOpen), gapExtend(gapExtend), numThreads(0), correlationScoreWeight(0.0f), deviceBlockAligner(false), needBacktraceStrings(true), blockHook(NULL),
       targetLookup(NULL), targetLookupCtx(NULL) {
     const int a = m->alphabetSize;
     tinySubMat.resize(a * a);
@@ -50,6 +50,7 @@ struct Pending {
     bool refuse;           // the pair is recomputed by the host's Matcher (profile query in block-aligner range)
     bool needsBlock;       // int16-range pair that passed the gates: waits for the device's block aligner
     std::string blockBacktrace;
+    uint32_t blockBtLen;   // its length when the string itself was not fetched
 };
 }  // namespace
 
@@ -186,6 +187,7 @@ bool MMGpuMatcher::alignBlock(const std::vector<Query> &queries, int covMode, fl
             a.dbStartPos1 = -1;
             a.word = h.word;
             pe.wantsBacktrace = false;
+            pe.blockBtLen = 0;
             pe.blockDone = false;
             pe.needsBlock = false;
             pe.refuse = hostQuery[q] != 0;
@@ -241,7 +243,7 @@ bool MMGpuMatcher::alignBlock(const std::vector<Query> &queries, int covMode, fl
             }
         std::vector<mmgpu_sw_block> blk(blkPairs.size());
         std::string blkStrings;
-        if (!blkPairs.empty() && backend->blockBacktrace(blkPairs.data(), (uint32_t)blkPairs.size(), blk.data(), blkStrings) != 0) {
+        if (!blkPairs.empty() && backend->blockBacktrace(blkPairs.data(), (uint32_t)blkPairs.size(), blk.data(), blkStrings, needBacktraceStrings) != 0) {
             err = backend->lastError();
             return false;
         }
@@ -275,7 +277,8 @@ bool MMGpuMatcher::alignBlock(const std::vector<Query> &queries, int covMode, fl
                 a.identicalAACnt = bk.ident;
                 a.qCov = SmithWaterman::computeCov(a.qStartPos1, a.qEndPos1, qlen);       // :1114-1115
                 a.tCov = SmithWaterman::computeCov(a.dbStartPos1, a.dbEndPos1, dbLen);
-                pe.blockBacktrace.assign(blkStrings, (size_t)bk.bt_off, (size_t)bk.bt_len);
+                if (!blkStrings.empty()) pe.blockBacktrace.assign(blkStrings, (size_t)bk.bt_off, (size_t)bk.bt_len);
+                pe.blockBtLen = bk.bt_len;
                 pe.blockDone = true;
                 continue;
             }
@@ -330,6 +333,7 @@ bool MMGpuMatcher::alignBlock(const std::vector<Query> &queries, int covMode, fl
             const Target &tg = qs.targets[t];
             s_align a;
             std::string backtrace;
+            size_t btLen = 0;      // backtrace.size(), also when the string was left on the device
             if (tg.isIdentity) {      // (callers do not mark identity hits for profile queries: MMGpuAlignRun::usable)
                 // SmithWaterman::scoreIdentical (StripedSmithWaterman.cpp:1770-1805): the diagonal of the word profile
                 memset(&a, 0, sizeof(a));
@@ -354,6 +358,7 @@ bool MMGpuMatcher::alignBlock(const std::vector<Query> &queries, int covMode, fl
                     refusedFlag[p] = 1;
                 } else if (aln[p].blockDone) {
                     backtrace.swap(aln[p].blockBacktrace);
+                    btLen = backtrace.empty() ? aln[p].blockBtLen : backtrace.size();
                 } else if (btOf[p] >= 0) {
                     const mmgpu_sw_bt &bi = btInfo[btOf[p]];
                     if (bi.status == MMGPU_BT_OK) {
@@ -401,8 +406,9 @@ bool MMGpuMatcher::alignBlock(const std::vector<Query> &queries, int covMode, fl
                 dbcov = a.tCov;
             }
             unsigned int alnLength = Matcher::computeAlnLength(qStartPos, qEndPos, dbStartPos, dbEndPos);
+            if (backtrace.size() > 0) btLen = backtrace.size();
             if (alignmentMode == Matcher::SCORE_COV_SEQID) {
-                if (backtrace.size() > 0) alnLength = backtrace.size();
+                if (btLen > 0) alnLength = btLen;
                 seqId = Util::computeSeqId(seqIdMode, a.identicalAACnt, origQueryLen, tg.length, alnLength);
             } else if (alignmentMode == Matcher::SCORE_COV) {
                 const unsigned int qAlnLen = std::max(qEndPos - qStartPos, static_cast<unsigned int>(1));

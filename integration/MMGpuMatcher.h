@@ -37,8 +37,10 @@ public:
     virtual int traceback(const uint32_t *pairIndex, uint32_t n, mmgpu_sw_bt *info, std::string &strings) = 0;
     // the block aligner's start positions / identities / backtraces of int16-range pairs of the last align() call
     // (mmgpu_sw_block_backtrace); the default says "not here" for every pair, which sends them to the host's block aligner
-    virtual int blockBacktrace(const uint32_t *pairIndex, uint32_t n, mmgpu_sw_block *out, std::string &strings) {
+    // wantStrings == false: only start positions, identities and lengths are needed (a run that writes no backtraces)
+    virtual int blockBacktrace(const uint32_t *pairIndex, uint32_t n, mmgpu_sw_block *out, std::string &strings, bool wantStrings = true) {
         (void)pairIndex;
+        (void)wantStrings;
         strings.clear();
         for (uint32_t k = 0; k < n; k++) { memset(&out[k], 0, sizeof(out[k])); out[k].status = MMGPU_BLOCK_TOO_LARGE; }
         return 0;
@@ -108,6 +110,9 @@ public:
     // int16-range pairs go to the device's block aligner first (MMGPU_BLOCK_ALIGNER=device, the default of the patched binary);
     // the host hook, if installed, then only serves what the device declines as too large
     void setDeviceBlockAligner(bool on) { deviceBlockAligner = on; }
+    // false: the caller never reads result_t::backtrace (no -a / --realign / --alt-ali): the strings of block-aligned pairs stay on
+    // the device; the alignment length of those pairs (Matcher.cpp:111-114) comes from the string's length alone
+    void setNeedBacktraceStrings(bool on) { needBacktraceStrings = on; }
     void setBlockBacktracer(MMGpuBlockBacktracer *hook, TargetLookup lookup, void *lookupCtx) {
         blockHook = hook;
         targetLookup = lookup;
@@ -131,6 +136,7 @@ private:
     unsigned int numThreads;
     float correlationScoreWeight;
     bool deviceBlockAligner;
+    bool needBacktraceStrings;
     MMGpuBlockBacktracer *blockHook;
     TargetLookup targetLookup;
     void *targetLookupCtx;

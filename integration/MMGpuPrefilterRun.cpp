@@ -142,7 +142,11 @@ bool MMGpuPrefilterRun::run(Prefiltering &p, DBWriter &tmpDbw, size_t dbFrom, si
     watch.lap(p.mmgpuDeviceIndex ? "hand over targets, build the index on the device" : "hand over targets + index");
     if (local3.isValid()) ExtendedSubstitutionMatrix::freeScoreMatrix(local3);     // the library copied the tables
     if (local2.isValid()) ExtendedSubstitutionMatrix::freeScoreMatrix(local2);
-    const size_t maxBlockQueries = MMGpuRun::envSize("MMGPU_PREF_BLOCK_QUERIES", 2048);
+    // Block size: the library's working buffers grow with the index entries a block touches (about 15 MB per query at 1 M
+    // targets) and on some hosts the driver maps fresh device memory at only ~27 GB/s - blocks of 1024 queries and 4 GB candidate
+    // stages cost nothing measurable in kernel time and keep a module's first device call short.
+    const size_t maxBlockQueries = MMGpuRun::envSize("MMGPU_PREF_BLOCK_QUERIES", 1024);
+    setenv("MMGPU_PF_STAGE_GB", "4", 0);
     // fused search (MMGpuFusedSearch): the entries of an unsplit run stay in memory for the alignment module of this process;
     // split runs merge their parts through files (mergePrefilterSplits / mergeTargetSplits) and are written as ever
     const bool capture = p.splits == 1 && MMGpuFusedSearch::capturing(tmpDbw.getDataFileName());

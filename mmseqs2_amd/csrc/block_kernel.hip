@@ -12,9 +12,10 @@
 // Same operations in the same order on the same int16 values (saturating adds), so the result - score, end position,
 // every trace bit - equals the crate's; the block's border arrays (D_col, C_col, D_row, R_row, their checkpoints) live in LDS,
 // the trace (2 x 2 bits per cell, as ballots) and the block list in a scratch slot in HBM, the walk back is serial.
-// Two instantiations: blocks up to 512 rows with the border arrays in LDS (every pair goes here first), and the crate's full
-// 4096 rows with the border arrays in the pair's scratch slot in HBM (second launch, only for the pairs the first one answered
-// MMGPU_BLOCK_TOO_LARGE: the crate would have grown the block beyond 512 rows, or the score was not reached with min_size <= 512).
+// Three instantiations: blocks up to 512 rows with the border arrays in LDS (8 KB; every pair goes here first, with a scratch
+// slot sized for the usual case), up to 2048 rows in LDS (32 KB) and the crate's full 4096 rows with the border arrays in the
+// pair's scratch slot in HBM - later launches only for the pairs the one before answered MMGPU_BLOCK_TOO_LARGE (the crate would
+// have grown the block further, the score was not reached with the minimum sizes this instantiation tries, or the slot overflowed).
 // A single wavefront owns a slot, its stores and loads go through one L1 in program order, so the HBM borders need no fence
 // beyond the wave barriers the LDS form already has.
 #include "mmgpu_internal.h"
@@ -507,9 +508,10 @@ __global__ __launch_bounds__(64) void sw_block_kernel(BlockLaunch L) {
 
 }  // namespace
 
-hipError_t launch_sw_block(const BlockLaunch &L, bool full_size, hipStream_t stream) {
+hipError_t launch_sw_block(const BlockLaunch &L, int tier, hipStream_t stream) {
     if (L.n_jobs == 0) return hipSuccess;
-    if (full_size) hipLaunchKernelGGL((sw_block_kernel<BLOCK_REF_MAX_SIZE, false>), dim3(L.n_jobs), dim3(64), 0, stream, L);
+    if (tier == 2) hipLaunchKernelGGL((sw_block_kernel<BLOCK_REF_MAX_SIZE, false>), dim3(L.n_jobs), dim3(64), 0, stream, L);
+    else if (tier == 1) hipLaunchKernelGGL((sw_block_kernel<BLOCK_MID_SIZE, true>), dim3(L.n_jobs), dim3(64), 0, stream, L);
     else hipLaunchKernelGGL((sw_block_kernel<BLOCK_MAX_SIZE, true>), dim3(L.n_jobs), dim3(64), 0, stream, L);
     return hipGetLastError();
 }

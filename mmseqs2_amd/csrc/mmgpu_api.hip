@@ -298,7 +298,7 @@ struct mmgpu_sw_batch_t {
     std::vector<mmgpu_sw_hit> h_res;
     std::vector<uint32_t> h_slot_target;
     bool h_res_valid = false;
-    uint32_t block_pairs_first_tier = 0, block_pairs_second_tier = 0;   // last mmgpu_sw_block_backtrace call
+    uint32_t block_pairs_tier[3] = {0, 0, 0};   // last mmgpu_sw_block_backtrace call: pairs decided with blocks <= 512 / 2048 / 4096 rows
     // pairs this rank owns of a sharded run's merged lists (mmgpu_sw_prepare_owned / mmgpu_sw_gather_owned)
     bool owned = false;
     uint32_t o_stride = 0, o_cap = 0;
@@ -392,7 +392,8 @@ static int sw_prepare_impl(mmgpu_ctx *c, const mmgpu_sw_params *par, const mmgpu
     std::vector<uint64_t> rev_cells;
     std::vector<uint64_t> job_cells;
     uint32_t n_multi = 0;
-    std::vector<uint32_t> order;
+    struct Deferred { uint32_t query, hit_cursor, out_cursor, shape, round; bool multi; };   // caller-supplied lists, scheduled below
+    std::vector<Deferred> deferred;
     uint32_t hit_cursor = 0, out_cursor = 0;
     b->h_qout_off.assign(nq + 1, 0);
     if (mode >= MMGPU_SW_START && !pf) b->h_out_target.resize((size_t)total_hits);
@@ -488,53 +489,110 @@ static int sw_prepare_impl(mmgpu_ctx *c, const mmgpu_sw_params *par, const mmgpu
             b->h_qout_off[i + 1] = out_cursor;
             continue;
         }
-        // sort the prefilter list by target length (longest first) so the 8 targets a wave runs together end together
-        const bool same_list = i > 0 && Q.target_ids == qs[i - 1].target_ids && Q.n_targets == qs[i - 1].n_targets;
-        if (!same_list) {   // all-vs-all callers hand the same list to every query: sort it once
-            order.resize(Q.n_targets);
-            std::iota(order.begin(), order.end(), 0u);
-            for (uint32_t k = 0; k < Q.n_targets; k++)
-                if (Q.target_ids[k] >= c->db.n) { delete b; return fail(MMGPU_ERR_ARG, "mmgpu_sw_prepare: target id out of range"); }
-            std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t bb) {
-                return c->h_len[Q.target_ids[a]] > c->h_len[Q.target_ids[bb]];
-            });
-        }
-        for (uint32_t k = 0; k < Q.n_targets; k++) {
-            const uint32_t t = Q.target_ids[order[k]];
-            hit_target[hit_cursor + k] = t;
-            hit_out[hit_cursor + k] = out_cursor + order[k];
-            b->cells += (uint64_t)Q.qlen * c->h_len[t];
-            max_tlen = std::max(max_tlen, c->h_len[t]);
-        }
-        // Jobs: consecutive hits of the (length-sorted) list, cut at multiples of one workgroup round (32 targets)
-        // once a job holds JOB_CELLS forward cells, at the latest after JOB_HITS hits - a 5000-residue query against
-        // 300 long targets must not become one 7e9-cell workgroup.
-        for (uint32_t k = 0; k < Q.n_targets;) {
-            uint64_t jc = 0;
-            uint32_t e = k;
-            while (e < Q.n_targets && e - k < JOB_HITS) {
-                const uint32_t stop = std::min<uint32_t>(e + round, Q.n_targets);
-                for (; e < stop; e++) jc += (uint64_t)Q.qlen * c->h_len[hit_target[hit_cursor + e]];
-                // cut at 8, 16 (long queries) or whole workgroup rounds: no wave idles while another runs a second round
-                const uint32_t held = e - k;
-                if (jc >= JOB_CELLS && (held <= 16 || held % JOB_ROUND == 0)) break;
-            }
-            SwJob j;
-            j.query = i;
-            j.hit_begin = hit_cursor + k;
-            j.hit_end = hit_cursor + e;
-            j.shape = shape | (multi ? n_multi++ << 8 : 0u);
-            jobs.push_back(j);
-            job_cells.push_back(jc);
-            k = e;
-        }
-        if (multi && mode >= MMGPU_SW_START && Q.n_targets)
-            add_rev_jobs(i, hit_cursor, Q.n_targets, shape, (uint64_t)Q.qlen * (c->h_len[hit_target[hit_cursor + Q.n_targets / 2]] + 1));
-        if (mode >= MMGPU_SW_START)
-            for (uint32_t k = 0; k < Q.n_targets; k++) b->h_out_target[out_cursor + k] = Q.target_ids[k];
+        // caller-supplied list: the sort by target length and the job cuts are done for all queries in parallel below
+        deferred.push_back(Deferred{i, hit_cursor, out_cursor, shape, round, multi});
         hit_cursor += Q.n_targets;
         out_cursor += Q.n_targets;
         b->h_qout_off[i + 1] = out_cursor;
+    }
+    if (!deferred.empty()) {
+        // Per query: sort the prefilter list by target length (longest first) so the 8 targets a wave runs together end
+        // together, cut it into jobs.  3 M pairs of a 10 000-query block cost 0.2 s on one thread (the sort's comparisons
+        // read the length table at random) - the queries are independent, so threads take contiguous ranges of them; the jobs
+        // are concatenated in query order afterwards, so the result does not depend on the number of threads.
+        struct PerQuery { std::vector<SwJob> jobs; std::vector<uint64_t> cells; uint64_t sum_cells = 0; uint32_t max_tlen = 0; uint32_t rev_mid_len = 0; bool bad = false; };
+        std::vector<PerQuery> pq(deferred.size());
+        auto work = [&](size_t from, size_t to) {
+            std::vector<uint32_t> ord;
+            for (size_t d = from; d < to; d++) {
+                const Deferred &D = deferred[d];
+                const mmgpu_sw_query &Q = qs[D.query];
+                PerQuery &P = pq[d];
+                const bool same_list = d > from && Q.target_ids == qs[deferred[d - 1].query].target_ids && Q.n_targets == qs[deferred[d - 1].query].n_targets;
+                if (!same_list) {   // all-vs-all callers hand the same list to every query: sort it once (per thread)
+                    ord.resize(Q.n_targets);
+                    std::iota(ord.begin(), ord.end(), 0u);
+                    for (uint32_t k = 0; k < Q.n_targets; k++)
+                        if (Q.target_ids[k] >= c->db.n) { P.bad = true; break; }
+                    if (P.bad) continue;
+                    std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t bb) {
+                        return c->h_len[Q.target_ids[a]] > c->h_len[Q.target_ids[bb]];
+                    });
+                }
+                for (uint32_t k = 0; k < Q.n_targets; k++) {
+                    const uint32_t t = Q.target_ids[ord[k]];
+                    hit_target[D.hit_cursor + k] = t;
+                    hit_out[D.hit_cursor + k] = D.out_cursor + ord[k];
+                    P.sum_cells += (uint64_t)Q.qlen * c->h_len[t];
+                    P.max_tlen = std::max(P.max_tlen, c->h_len[t]);
+                }
+                // Jobs: consecutive hits of the (length-sorted) list, cut at multiples of one workgroup round (32 targets)
+                // once a job holds JOB_CELLS forward cells, at the latest after JOB_HITS hits - a 5000-residue query against
+                // 300 long targets must not become one 7e9-cell workgroup.
+                for (uint32_t k = 0; k < Q.n_targets;) {
+                    uint64_t jc = 0;
+                    uint32_t e = k;
+                    while (e < Q.n_targets && e - k < JOB_HITS) {
+                        const uint32_t stop = std::min<uint32_t>(e + D.round, Q.n_targets);
+                        for (; e < stop; e++) jc += (uint64_t)Q.qlen * c->h_len[hit_target[D.hit_cursor + e]];
+                        // cut at 8, 16 (long queries) or whole workgroup rounds: no wave idles while another runs a second round
+                        const uint32_t held = e - k;
+                        if (jc >= JOB_CELLS && (held <= 16 || held % JOB_ROUND == 0)) break;
+                    }
+                    SwJob j;
+                    j.query = D.query;
+                    j.hit_begin = D.hit_cursor + k;
+                    j.hit_end = D.hit_cursor + e;
+                    j.shape = D.shape;      // (multi-tile jobs get their scratch slot number when the lists are joined)
+                    P.jobs.push_back(j);
+                    P.cells.push_back(jc);
+                    k = e;
+                }
+                if (Q.n_targets) P.rev_mid_len = c->h_len[hit_target[D.hit_cursor + Q.n_targets / 2]];
+                if (mode >= MMGPU_SW_START)
+                    for (uint32_t k = 0; k < Q.n_targets; k++) b->h_out_target[D.out_cursor + k] = Q.target_ids[k];
+            }
+        };
+        static const unsigned host_threads = [] {
+            const char *e = getenv("MMGPU_HOST_THREADS");
+            const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+            return e && atoi(e) > 0 ? (unsigned)atoi(e) : std::min(16u, hw);
+        }();
+        const size_t n_thr = std::max<size_t>(1, std::min<size_t>(host_threads, total_hits / 65536 + 1));
+        if (n_thr <= 1) {
+            work(0, deferred.size());
+        } else {
+            // ranges of about equal numbers of pairs
+            std::vector<std::thread> pool;
+            size_t from = 0;
+            uint64_t acc = 0;
+            const uint64_t share = total_hits / n_thr + 1;
+            for (size_t d = 0; d < deferred.size(); d++) {
+                acc += qs[deferred[d].query].n_targets;
+                if (acc >= share || d + 1 == deferred.size()) {
+                    pool.emplace_back(work, from, d + 1);
+                    from = d + 1;
+                    acc = 0;
+                }
+            }
+            for (std::thread &t : pool) t.join();
+        }
+        for (size_t d = 0; d < deferred.size(); d++) {
+            const Deferred &D = deferred[d];
+            PerQuery &P = pq[d];
+            if (P.bad) { delete b; return fail(MMGPU_ERR_ARG, "mmgpu_sw_prepare: target id out of range"); }
+            b->cells += P.sum_cells;
+            max_tlen = std::max(max_tlen, P.max_tlen);
+            for (size_t z = 0; z < P.jobs.size(); z++) {
+                SwJob j = P.jobs[z];
+                if (D.multi) j.shape |= n_multi++ << 8;
+                jobs.push_back(j);
+                job_cells.push_back(P.cells[z]);
+            }
+            const uint32_t n_t = qs[D.query].n_targets;
+            if (D.multi && mode >= MMGPU_SW_START && n_t)
+                add_rev_jobs(D.query, D.hit_cursor, n_t, D.shape, (uint64_t)qs[D.query].qlen * (P.rev_mid_len + 1));
+        }
     }
     b->pairs = total_hits;
     b->h_qoff = qoff;
@@ -1003,7 +1061,8 @@ extern "C" int mmgpu_sw_block_backtrace(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const
         longest = std::max(longest, len);
     }
     if (bt_used) *bt_used = (size_t)off;
-    if (off > bt_cap || (!bt && off)) return fail(MMGPU_ERR_ARG, "mmgpu_sw_block_backtrace: bt buffer too small (see *bt_used)");
+    const bool no_strings = bt == nullptr && bt_cap == MMGPU_BLOCK_NO_STRINGS;      // start positions / identities / lengths only
+    if (!no_strings && (off > bt_cap || (!bt && off))) return fail(MMGPU_ERR_ARG, "mmgpu_sw_block_backtrace: bt buffer too small (see *bt_used)");
     if (jobs.empty()) return MMGPU_OK;
     std::stable_sort(jobs.begin(), jobs.end(), [](const BlockJob &x, const BlockJob &y) { return x.q_end + x.t_end > y.q_end + y.t_end; });
     // the AAMatrix as ssw_init leaves it: new_simple(1, -1) with the substitution matrix written over it (:708,:1469-1474)
@@ -1013,29 +1072,42 @@ extern "C" int mmgpu_sw_block_backtrace(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const
         for (int y = 0; y < 26; y++) scores[x * 32 + y] = x == y ? 1 : -1;
     for (int x = 0; x < b->alphabet; x++)
         for (int y = 0; y < b->alphabet; y++) { scores[x * 32 + y] = mat[(size_t)x * b->alphabet + y]; scores[y * 32 + x] = mat[(size_t)x * b->alphabet + y]; }
-    // First tier: blocks up to 512 rows, borders in LDS.  Scratch slot = block list + trace of the longest pair it takes:
-    // (BLOCK_MAX_SIZE / 64) entries of 32 bytes per column of the trace, len + 2 * BLOCK_MAX_SIZE columns (Trace::new,
-    // scan_block.rs:1742-1748); pairs beyond 16384 residues overflow the slot, are answered TOO_LARGE and go to the second tier.
-    const uint64_t cap_len = std::min<uint64_t>(longest, 16384);
-    const uint64_t slot_bytes = (((cap_len + 64) * 16 + 31) & ~31ull) + (uint64_t)(BLOCK_MAX_SIZE / 64) * 32 * (cap_len + 2 * BLOCK_MAX_SIZE);
-    const uint32_t slots = (uint32_t)std::min<uint64_t>(jobs.size(), (uint64_t)std::max(c->compute_units, 1) * 16);
-    DevBuf d_jobs, d_out, d_btoff, d_bt, d_scores, d_pool, d_busy;
-    for (DevBuf *d : {&d_jobs, &d_out, &d_btoff, &d_bt, &d_scores, &d_pool, &d_busy}) d->bind(c->cache);
-    HIP_TRY(d_jobs.alloc(jobs.size() * sizeof(BlockJob)));
+    // Three tiers (block_kernel.hip), each a launch over what the one before left undecided (TOO_LARGE), all carved out of ONE
+    // scratch pool (hipMalloc costs ~40 ms per GB on this platform, so the pool is sized for the usual case, not the worst):
+    //   tier 0  blocks <= 512 rows, borders in LDS; slot = block list + TWO trace entries (32 B per 64 rows) per column for the
+    //           256th-longest pair - nearly every pair stays at 32 / 64-row blocks; a pair that is longer or grows further
+    //           overflows its slot and moves on
+    //   tier 1  blocks <= 2048 rows in LDS, slot = the crate's own bound for that size (Trace::new, scan_block.rs:1742-1748)
+    //   tier 2  the crate's 4096 rows, borders in the slot
+    static const bool trace_on = getenv("MMGPU_TRACE") != nullptr;
+    auto now_s = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_mark = now_s();
+    auto lap = [&](const char *what) {
+        if (!trace_on) return;
+        const double t = now_s();
+        fprintf(stderr, "[mmgpu block aligner] %s %.3f s\n", what, t - t_mark);
+        t_mark = t;
+    };
+    auto pair_len = [](const BlockJob &j) { return (uint64_t)j.q_end + 1 + (uint64_t)j.t_end + 1; };
+    auto slot_size = [](uint64_t len, uint64_t entries_per_col, uint64_t max_rows, bool borders) {
+        return (borders ? (uint64_t)8 * BLOCK_REF_MAX_SIZE * 2 : 0ull) + (((len + 64) * 16 + 31) & ~31ull) + entries_per_col * 32 * (len + 2 * max_rows);
+    };
+    static const uint64_t pool_limit = (getenv("MMGPU_BLOCK_POOL_MB") ? strtoull(getenv("MMGPU_BLOCK_POOL_MB"), nullptr, 10) : 16384ull) << 20;
+    // (small calls: slots for the longest pair, everything starts in tier 0)
+    const uint64_t typical_len = pair_len(jobs[jobs.size() > 1024 ? 255 : 0]);
+    DevBuf d_out, d_btoff, d_bt, d_scores, d_jobs[3], d_pool[3], d_busy[3];
+    for (DevBuf *d : {&d_out, &d_btoff, &d_bt, &d_scores, &d_jobs[0], &d_jobs[1], &d_jobs[2], &d_pool[0], &d_pool[1], &d_pool[2], &d_busy[0], &d_busy[1], &d_busy[2]})
+        d->bind(c->cache);
     HIP_TRY(d_out.alloc((size_t)n * sizeof(mmgpu_sw_block)));
     HIP_TRY(d_btoff.alloc((size_t)n * 8));
     HIP_TRY(d_bt.alloc((size_t)off + 16));
     HIP_TRY(d_scores.alloc(scores.size()));
-    HIP_TRY(d_pool.alloc((size_t)slot_bytes * slots));
-    HIP_TRY(d_busy.alloc((size_t)slots * 4));
-    HIP_TRY(hipMemsetAsync(d_busy.p, 0, (size_t)slots * 4, s));
-    HIP_TRY(hipMemcpyAsync(d_jobs.p, jobs.data(), jobs.size() * sizeof(BlockJob), hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(d_out.p, out, (size_t)n * sizeof(mmgpu_sw_block), hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(d_btoff.p, bt_off.data(), (size_t)n * 8, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(d_scores.p, scores.data(), scores.size(), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    lap("buffers + uploads");
     BlockLaunch L;
-    L.jobs = d_jobs.as<BlockJob>();
-    L.n_jobs = (uint32_t)jobs.size();
     L.q_res = b->d_qres.as<uint8_t>();
     L.q_cb = b->d_qcb.as<int8_t>();
     L.q_off = b->d_qoff.as<uint32_t>();
@@ -1047,58 +1119,76 @@ extern "C" int mmgpu_sw_block_backtrace(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const
     L.out = d_out.as<mmgpu_sw_block>();
     L.bt_off = d_btoff.as<uint64_t>();
     L.bt = d_bt.as<char>();
-    L.pool = d_pool.as<uint8_t>();
-    L.slot_bytes = slot_bytes;
-    L.n_pool_slots = slots;
-    L.pool_busy = d_busy.as<uint32_t>();
-    const bool skip_first_tier = getenv("MMGPU_BLOCK_FULL_SIZE_ONLY") != nullptr;      // test aid: everything through the second tier
-    if (!skip_first_tier) HIP_TRY(launch_sw_block(L, false, s));
-    HIP_TRY(hipMemcpyAsync(out, d_out.p, (size_t)n * sizeof(mmgpu_sw_block), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    // Second tier: what the first one left undecided, with the crate's own 4096-row limit.  Slot = 8 border arrays of 4096 int16 +
-    // block list + (4096 / 64) x 32 bytes per trace column, len + 2 * 4096 columns; as many slots as fit MMGPU_BLOCK_POOL_MB
-    // (default 16 GB of the 288), at least one - the kernel's slot loop serialises the rest.
-    std::vector<BlockJob> big;
-    uint64_t big_longest = 0;
-    for (const BlockJob &j : jobs)
-        if (out[j.slot].status == MMGPU_BLOCK_TOO_LARGE) {
-            big.push_back(j);
-            big_longest = std::max<uint64_t>(big_longest, (uint64_t)j.q_end + 1 + (uint64_t)j.t_end + 1);
+    const int first_tier = getenv("MMGPU_BLOCK_FIRST_TIER") ? std::max(0, std::min(2, atoi(getenv("MMGPU_BLOCK_FIRST_TIER")))) : 0;      // test aid
+    // Rounds: the tiers that have pairs waiting run side by side (a stream, a pool, a job list each).  Round one = tier 0 for the
+    // pairs up to the typical length and, at the same time, tier 1 for the longer ones (they would overflow tier 0's slots, and
+    // each of them is a long serial chain: starting them first keeps them off the critical path); what a tier leaves undecided
+    // joins the next tier in the following round.
+    std::vector<BlockJob> wait[3];      // longest first inside each
+    for (const BlockJob &j : jobs) wait[first_tier == 0 && pair_len(j) > typical_len ? 1 : first_tier].push_back(j);
+    b->block_pairs_tier[0] = b->block_pairs_tier[1] = b->block_pairs_tier[2] = 0;
+    hipStream_t extra[2] = {nullptr, nullptr};
+    auto release_streams = [&] { for (hipStream_t &x : extra) if (x) { (void)hipStreamDestroy(x); x = nullptr; } };
+    while (!wait[0].empty() || !wait[1].empty() || !wait[2].empty()) {
+        int n_launched = 0;
+        for (int tier = 2; tier >= 0; tier--) {      // (the long chains first)
+            std::vector<BlockJob> &todo = wait[tier];
+            if (todo.empty()) continue;
+            const uint64_t longest_todo = pair_len(todo.front());
+            const uint64_t slot_bytes = tier == 0   ? slot_size(typical_len, 2, BLOCK_MAX_SIZE, false)
+                                        : tier == 1 ? slot_size(longest_todo, BLOCK_MID_SIZE / 64, BLOCK_MID_SIZE, false)
+                                                    : slot_size(longest_todo, BLOCK_REF_MAX_SIZE / 64, BLOCK_REF_MAX_SIZE, true);
+            const uint64_t want = std::min<uint64_t>(todo.size(), (uint64_t)std::max(c->compute_units, 1) * (tier == 0 ? 16 : 4));
+            const uint32_t slots = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(want, pool_limit / slot_bytes));
+            hipStream_t st = s;
+            if (n_launched > 0) {
+                if (!extra[n_launched - 1] && hipStreamCreateWithFlags(&extra[n_launched - 1], hipStreamNonBlocking) != hipSuccess) { release_streams(); return fail(MMGPU_ERR_HIP, "mmgpu_sw_block_backtrace: hipStreamCreate"); }
+                st = extra[n_launched - 1];
+            }
+#define R_TRY(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { release_streams(); return fail(MMGPU_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__)); } } while (0)
+            if ((size_t)slot_bytes * slots > d_pool[tier].bytes) R_TRY(d_pool[tier].alloc((size_t)slot_bytes * slots));
+            if ((size_t)slots * 4 > d_busy[tier].bytes) R_TRY(d_busy[tier].alloc((size_t)slots * 4));
+            if (todo.size() * sizeof(BlockJob) > d_jobs[tier].bytes) R_TRY(d_jobs[tier].alloc(todo.size() * sizeof(BlockJob)));
+            R_TRY(hipMemsetAsync(d_busy[tier].p, 0, (size_t)slots * 4, st));
+            R_TRY(hipMemcpyAsync(d_jobs[tier].p, todo.data(), todo.size() * sizeof(BlockJob), hipMemcpyHostToDevice, st));
+            L.jobs = d_jobs[tier].as<BlockJob>();
+            L.n_jobs = (uint32_t)todo.size();
+            L.pool = d_pool[tier].as<uint8_t>();
+            L.slot_bytes = slot_bytes;
+            L.n_pool_slots = slots;
+            L.pool_busy = d_busy[tier].as<uint32_t>();
+            R_TRY(launch_sw_block(L, tier, st));
+            if (trace_on) fprintf(stderr, "[mmgpu block aligner] tier %d: %zu pairs, %u slots of %.1f KB\n", tier, todo.size(), slots, slot_bytes / 1024.0);
+            n_launched++;
         }
-    b->block_pairs_first_tier = (uint32_t)(jobs.size() - big.size());
-    b->block_pairs_second_tier = (uint32_t)big.size();
-    if (!big.empty()) {
-        const uint64_t big_slot = (uint64_t)8 * BLOCK_REF_MAX_SIZE * 2 + (((big_longest + 64) * 16 + 31) & ~31ull) +
-                                  (uint64_t)(BLOCK_REF_MAX_SIZE / 64) * 32 * (big_longest + 2 * BLOCK_REF_MAX_SIZE);
-        static const uint64_t pool_limit = (getenv("MMGPU_BLOCK_POOL_MB") ? strtoull(getenv("MMGPU_BLOCK_POOL_MB"), nullptr, 10) : 16384ull) << 20;
-        const uint32_t big_slots = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>({(uint64_t)big.size(), pool_limit / big_slot,
-                                                                                       (uint64_t)std::max(c->compute_units, 1) * 4}));
-        DevBuf d_bigjobs, d_bigpool, d_bigbusy;
-        for (DevBuf *d : {&d_bigjobs, &d_bigpool, &d_bigbusy}) d->bind(c->cache);
-        HIP_TRY(d_bigjobs.alloc(big.size() * sizeof(BlockJob)));
-        HIP_TRY(d_bigpool.alloc((size_t)big_slot * big_slots));
-        HIP_TRY(d_bigbusy.alloc((size_t)big_slots * 4));
-        HIP_TRY(hipMemsetAsync(d_bigbusy.p, 0, (size_t)big_slots * 4, s));
-        HIP_TRY(hipMemcpyAsync(d_bigjobs.p, big.data(), big.size() * sizeof(BlockJob), hipMemcpyHostToDevice, s));
-        L.jobs = d_bigjobs.as<BlockJob>();
-        L.n_jobs = (uint32_t)big.size();
-        L.pool = d_bigpool.as<uint8_t>();
-        L.slot_bytes = big_slot;
-        L.n_pool_slots = big_slots;
-        L.pool_busy = d_bigbusy.as<uint32_t>();
-        HIP_TRY(launch_sw_block(L, true, s));
-        HIP_TRY(hipMemcpyAsync(out, d_out.p, (size_t)n * sizeof(mmgpu_sw_block), hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
+        for (hipStream_t x : extra) if (x) R_TRY(hipStreamSynchronize(x));
+        R_TRY(hipStreamSynchronize(s));
+        R_TRY(hipMemcpy(out, d_out.p, (size_t)n * sizeof(mmgpu_sw_block), hipMemcpyDeviceToHost));
+#undef R_TRY
+        std::vector<BlockJob> next[3];
+        for (int tier = 0; tier < 3; tier++) {
+            size_t left = 0;
+            for (const BlockJob &j : wait[tier])
+                if (out[j.slot].status == MMGPU_BLOCK_TOO_LARGE && tier < 2) { next[tier + 1].push_back(j); left++; }
+            b->block_pairs_tier[tier] += (uint32_t)(wait[tier].size() - left);
+        }
+        for (int tier = 0; tier < 3; tier++) {
+            std::stable_sort(next[tier].begin(), next[tier].end(), [&](const BlockJob &x, const BlockJob &y) { return pair_len(x) > pair_len(y); });
+            wait[tier].swap(next[tier]);
+        }
+        lap("round of tier launches + status download");
     }
-    if (off) HIP_TRY(hipMemcpyAsync(bt, d_bt.p, (size_t)off, hipMemcpyDeviceToHost, s));
+    release_streams();
+    if (off && !no_strings) HIP_TRY(hipMemcpyAsync(bt, d_bt.p, (size_t)off, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));      // the host vectors and the buffers above die with this scope
+    lap("backtrace strings download");
     return MMGPU_OK;
 }
 
 extern "C" int mmgpu_sw_block_tiers(const mmgpu_sw_batch_t *b, uint32_t *first_tier, uint32_t *second_tier) {
     if (!b) return fail(MMGPU_ERR_ARG, "mmgpu_sw_block_tiers: NULL batch");
-    if (first_tier) *first_tier = b->block_pairs_first_tier;
-    if (second_tier) *second_tier = b->block_pairs_second_tier;
+    if (first_tier) *first_tier = b->block_pairs_tier[0];
+    if (second_tier) *second_tier = b->block_pairs_tier[1] + b->block_pairs_tier[2];
     return MMGPU_OK;
 }
 

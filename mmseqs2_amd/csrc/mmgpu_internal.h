@@ -10,6 +10,7 @@
 #include <array>
 #include <string>
 #include <map>
+#include <chrono>
 #include <memory>
 #include <vector>
 #include <thread>
@@ -451,7 +452,8 @@ struct BtLaunch {
 
 // ---- block aligner on the device (block_kernel.hip; row a15): int16-range hits ----
 constexpr int BLOCK_MAX_SIZE = 512;        // largest block the first-tier kernel holds in LDS
-constexpr int BLOCK_REF_MAX_SIZE = 4096;   // MAX_SIZE of the reference (StripedSmithWaterman.cpp:37)
+constexpr int BLOCK_MID_SIZE = 2048;       // second tier: still in LDS (32 KB)
+constexpr int BLOCK_REF_MAX_SIZE = 4096;   // MAX_SIZE of the reference (StripedSmithWaterman.cpp:37); third tier, borders in HBM
 struct BlockJob {
     uint32_t query, target;
     int32_t score, q_end, t_end;
@@ -475,8 +477,9 @@ struct BlockLaunch {
     uint32_t n_pool_slots;
     uint32_t *pool_busy;
 };
-// full_size: blocks up to BLOCK_REF_MAX_SIZE rows, border arrays in the first 8 * 4096 * 2 bytes of the pair's scratch slot
-hipError_t launch_sw_block(const BlockLaunch &L, bool full_size, hipStream_t stream);
+// tier 0: blocks up to BLOCK_MAX_SIZE rows (LDS), 1: up to BLOCK_MID_SIZE (LDS), 2: up to BLOCK_REF_MAX_SIZE rows, border arrays
+// in the first 8 * 4096 * 2 bytes of the pair's scratch slot
+hipError_t launch_sw_block(const BlockLaunch &L, int tier, hipStream_t stream);
 
 hipError_t launch_sw_traceback(const BtLaunch &L, hipStream_t stream);
 hipError_t launch_sw_traceback_wave(const BtLaunch &L, hipStream_t stream);
@@ -552,6 +555,18 @@ struct BlockCache {
     }
 };
 
+// MMGPU_ALLOC_TRACE=1: every hipMalloc of a device buffer with its size and wall time on stderr (where a module's first device
+// call spends its time)
+inline hipError_t traced_malloc(void **p, size_t n) {
+    static const bool on = getenv("MMGPU_ALLOC_TRACE") != nullptr;
+    if (!on) return hipMalloc(p, n);
+    const auto t0 = std::chrono::steady_clock::now();
+    const hipError_t e = hipMalloc(p, n);
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    fprintf(stderr, "[mmgpu alloc] hipMalloc %.1f MB %.2f ms\n", (double)n / 1048576.0, ms);
+    return e;
+}
+
 struct DevBuf {
     void *p = nullptr;
     size_t bytes = 0;
@@ -589,7 +604,7 @@ struct DevBuf {
             cap = BlockCache::round_up(n);
             p = cache->take(cap);
             if (p) return hipSuccess;
-            hipError_t e = hipMalloc(&p, cap);
+            hipError_t e = traced_malloc(&p, cap);
             if (e != hipSuccess) {      // out of memory with blocks parked in the cache: give them back and retry
                 (void)hipGetLastError();
                 cache->trim();
@@ -598,7 +613,7 @@ struct DevBuf {
             if (e != hipSuccess) { p = nullptr; cap = 0; bytes = 0; }   // (bytes = 0: a later, smaller reserve() must allocate)
             return e;
         }
-        const hipError_t e = hipMalloc(&p, n);
+        const hipError_t e = traced_malloc(&p, n);
         if (e != hipSuccess) { p = nullptr; bytes = 0; (void)hipGetLastError(); }
         return e;
     }

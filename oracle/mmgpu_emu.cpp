@@ -191,7 +191,12 @@ int mmgpu_sw_block_backtrace(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const uint32_t *
         if (word) need += (size_t)h.q_end + 1 + (size_t)h.t_end + 1 + 1;
     }
     if (used) *used = need;
-    if (need && (bt == NULL || cap < need)) return fail(MMGPU_ERR_ARG, "bt buffer too small");
+    const bool noStrings = bt == NULL && cap == MMGPU_BLOCK_NO_STRINGS;
+    std::vector<char> scratch;
+    if (noStrings) {
+        scratch.resize(need + 1);
+        bt = scratch.data();
+    } else if (need && (bt == NULL || cap < need)) return fail(MMGPU_ERR_ARG, "bt buffer too small");
 #pragma omp parallel for schedule(dynamic, 16)
     for (uint32_t i = 0; i < n; i++) {
         const mmgpu_sw_hit &h = b->res[idx[i]];

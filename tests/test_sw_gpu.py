@@ -377,17 +377,18 @@ def _long_gap_pairs(matrices, oracle, n, seed):
     return qs, ts
 
 
-@pytest.mark.parametrize("full_only", [False, True])
-def test_block_aligner_grows_to_the_crates_4096_rows(gpu, matrices, oracle, full_only, monkeypatch):
-    """a15, blocks beyond 512 rows: the second launch (sw_block_kernel<4096, borders in HBM>) answers what the LDS form leaves,
-    equal to the restatement field by field; with MMGPU_BLOCK_FULL_SIZE_ONLY every pair (also the short ones of the family
-    workload) runs through the 4096-row instantiation."""
+@pytest.mark.parametrize("first_tier", [0, 1, 2])
+def test_block_aligner_grows_to_the_crates_4096_rows(gpu, matrices, oracle, first_tier, monkeypatch):
+    """a15, blocks beyond 512 rows: the later launches (sw_block_kernel<2048, LDS> and <4096, borders in HBM>) answer what the
+    512-row form leaves, equal to the restatement field by field; with MMGPU_BLOCK_FIRST_TIER = 1 / 2 every pair (also the short
+    ones of the family workload) starts in the 2048-row / 4096-row instantiation."""
+    full_only = first_tier > 0
     from mmseqs2_amd import workloads as wl
     mat = matrices["blosum62_sw"]
     sub16 = mat.astype(np.int16)
     qs, ts = _long_gap_pairs(matrices, oracle, 24, seed=5)
     if full_only:
-        monkeypatch.setenv("MMGPU_BLOCK_FULL_SIZE_ONLY", "1")
+        monkeypatch.setenv("MMGPU_BLOCK_FIRST_TIER", str(first_tier))
         (qres, qoff), (tres2, toff2), fam_t, fam_q = wl.config3_prefilter(30, 4, 30, seed=41)
         fq, ft = wl.split(qres, qoff), wl.split(tres2, toff2)
         for qi, q in enumerate(fq):
