@@ -520,7 +520,8 @@ int mmgpu_multi_load_targets(mmgpu_multi *multi, const uint8_t *residues, const 
 int mmgpu_multi_pf_build_index(mmgpu_multi *multi, const mmgpu_pf_index *index, const int16_t *kmer_submat, int kmer_thr);
 /* One prefilter batch over all shards whose merged lists EQUAL the unsplit run's.  queries[i].identity_id is the GLOBAL id.
  * run = per-shard prefilter -> all-gather of the exchange records -> merge kernel on every context (enqueues only);
- * fetch = merged lists from context 0 (global ids), status MMGPU_PF_OK or MMGPU_PF_SHARD_INEXACT (count 0: re-run unsplit). */
+ * fetch = merged lists from context 0 (global ids), status MMGPU_PF_OK, MMGPU_PF_SHARD_INEXACT (count 0: re-run unsplit) or what a
+ * shard's own run decided for the query (MMGPU_PF_LONG_SEQ, MMGPU_PF_OVERFLOW: count 0, the host runs the reference for it). */
 int mmgpu_multi_pf_prepare(mmgpu_multi *multi, const mmgpu_pf_params *params, const mmgpu_pf_query *queries, uint32_t n_queries,
                            mmgpu_multi_pf_batch **batch);
 int mmgpu_multi_pf_run(mmgpu_multi *multi, mmgpu_multi_pf_batch *batch);

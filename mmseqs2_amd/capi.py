@@ -64,6 +64,8 @@ SW_BLOCK_DTYPE = np.dtype([("q_start", np.int32), ("t_start", np.int32), ("ident
 SW_HIT_DTYPE = np.dtype([("score", np.int32), ("q_end", np.int32), ("t_end", np.int32), ("q_start", np.int32),
                          ("t_start", np.int32), ("word", np.int32)])
 
+PF_OK, PF_OVERFLOW, PF_LONG_SEQ, PF_SAT_TIE, PF_SHARD_INEXACT = 0, 1, 2, 3, 4      # mmgpu_pf status codes (include/mmgpu.h)
+
 # every symbol include/mmgpu.h declares (tests check the built library exports all of them)
 EXPORTED_SYMBOLS = [
     "mmgpu_init", "mmgpu_destroy", "mmgpu_last_error", "mmgpu_set_stream", "mmgpu_synchronize",

@@ -688,6 +688,7 @@ int pf_xchg_merge(mmgpu_ctx *c, mmgpu_pf_batch_t *b, int n_ranks, const uint32_t
 int sw_gather_begin(mmgpu_ctx *c, mmgpu_sw_batch_t *b, int n_ranks, XchgBlock blocks[2]);
 int sw_gather_finish(mmgpu_ctx *c, mmgpu_sw_batch_t *b, int n_ranks);
 int pf_batch_merged_flags(mmgpu_pf_batch_t *b, const void **d_flags);
+const int32_t *pf_batch_host_status(const mmgpu_pf_batch_t *b);
 bool pf_batch_merged_lists(mmgpu_pf_batch_t *b, const mmgpu_pf_hit **hits, const uint32_t **counts, uint32_t *stride, uint32_t *nq);
 void pf_index_free(mmgpu_ctx *c);
 // device-resident results of a prefilter batch that has been run (false if it has not)

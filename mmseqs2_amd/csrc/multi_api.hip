@@ -262,8 +262,16 @@ extern "C" int mmgpu_multi_pf_fetch(mmgpu_multi *m, mmgpu_multi_pf_batch *mb, mm
     HIP_TRY(hipStreamSynchronize(c->stream));
     for (uint32_t q = 0; q < nq; q++) {
         const bool inexact = (flags[q] & 1u) != 0;
-        if (status) status[q] = inexact ? MMGPU_PF_SHARD_INEXACT : MMGPU_PF_OK;
-        if (inexact) counts[q] = 0;
+        int32_t st = inexact ? MMGPU_PF_SHARD_INEXACT : MMGPU_PF_OK;
+        // what a shard's mmgpu_pf_run decided on the host never reaches the merged flag word: a query of 32768 residues or more
+        // (MMGPU_PF_LONG_SEQ) or with more list segments than the device handles (MMGPU_PF_OVERFLOW) contributed nothing on that
+        // shard - the merged list would silently miss its hits.  The worst status of any shard is the query's.
+        for (size_t s = 0; s < mb->b.size(); s++) {
+            const int32_t *hs = mmgpu::pf_batch_host_status(mb->b[s]);
+            if (hs && hs[q] != MMGPU_PF_OK && (st == MMGPU_PF_OK || st == MMGPU_PF_SHARD_INEXACT)) st = hs[q];
+        }
+        if (status) status[q] = st;
+        if (st != MMGPU_PF_OK) counts[q] = 0;
     }
     return MMGPU_OK;
 }

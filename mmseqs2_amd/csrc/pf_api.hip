@@ -1317,6 +1317,15 @@ int pf_xchg_begin(mmgpu_ctx *c, mmgpu_pf_batch_t *b, int n_ranks, XchgBlock bloc
         HIP_TRY(b->x_flags.alloc(cb));
         HIP_TRY(b->x_ident.alloc(cb));
     }
+    // A query mmgpu_pf_run declined on the HOST (MMGPU_PF_LONG_SEQ, MMGPU_PF_OVERFLOW beyond PF_MAX_SEG) contributed no records
+    // on this shard: its exchanged count says so in bit 31 (the "depends on the whole database" flag the merge kernel ORs over
+    // the shards), so every rank reports the merged list as not exact instead of one that silently lacks this shard's hits.
+    {
+        static const uint32_t declined = 0x80000000u;      // (outlives the asynchronous copies)
+        for (uint32_t q = 0; q < b->nq && q < b->status.size(); q++)
+            if (b->status[q] != MMGPU_PF_OK)
+                HIP_TRY(hipMemcpyAsync(b->d_hit_count.as<uint32_t>() + q, &declined, 4, hipMemcpyHostToDevice, c->stream));
+    }
     blocks[0] = XchgBlock{b->d_hits.p, b->x_recv_hits.p, hb};
     blocks[1] = XchgBlock{b->d_hit_count.p, b->x_recv_counts.p, cb};
     return MMGPU_OK;
@@ -1356,6 +1365,10 @@ int pf_batch_merged_flags(mmgpu_pf_batch_t *b, const void **d_flags) {
     *d_flags = b->x_flags.p;
     return MMGPU_OK;
 }
+
+// the status mmgpu_pf_run decided on the HOST for each query of a batch (MMGPU_PF_LONG_SEQ, MMGPU_PF_OVERFLOW beyond PF_MAX_SEG):
+// such a query contributes no records to the exchange and its device-side flag stays clear
+const int32_t *pf_batch_host_status(const mmgpu_pf_batch_t *b) { return b && b->status.size() == b->nq ? b->status.data() : nullptr; }
 
 bool pf_batch_merged_lists(mmgpu_pf_batch_t *b, const mmgpu_pf_hit **hits, const uint32_t **counts, uint32_t *stride, uint32_t *nq) {
     if (!b || !b->x_ranks) return false;

@@ -280,6 +280,47 @@ def test_multi_context_run_equals_unsplit_run(gpu, matrices, world, max_hits):
         assert not res_s[qi]["score"][n:].any()
 
 
+def test_queries_a_shard_declines_on_the_host_are_reported_not_silently_short(gpu):
+    """MMGPU_PF_LONG_SEQ is decided by mmgpu_pf_run on the HOST of each shard (a query of 32768 residues or more) -
+    such a query contributes no exchange records, and the merged flag word used to stay clear: the sharded fetch then returned an
+    empty list with status OK.  The status of the worst shard must reach the caller (who hands the query to the CPU matcher), and
+    the other queries of the batch must still equal the unsplit run."""
+    g = pc.golden()
+    thr = int(g["kmer_thr"])
+    qs, tres, toff = _case(91, 120, 40, 30)
+    rng = np.random.default_rng(5)
+    long_q = rng.integers(0, 20, size=33000).astype(np.uint8)
+    long_q[100:100 + len(qs[3])] = qs[3]
+    qs = list(qs[:6]) + [long_q] + list(qs[6:12])
+    km16, um8, s3, i3 = _tables(gpu, g)
+    queries = [dict(q=q, comp_bias=capi.host_comp_bias(km16, g["vtml80_pback"], q, lib=gpu.L)[0], identity_id=None) for q in qs]
+    gpu.load_targets(tres, toff, 21)
+    gpu.pf_build_index(6, 21, True, s3, i3, km16, thr, um8)
+    b = gpu.pf_prepare(queries, thr, max_hits=50, ref_bins=2)
+    b.run()
+    hits_u, counts_u, status_u, _ = b.fetch()
+    b.free()
+    assert status_u[6] == capi.PF_LONG_SEQ and counts_u[6] == 0
+    m = capi.MMGpuMulti([0] * 3)
+    try:
+        m.load_targets(tres, toff, 21)
+        m.pf_build_index(6, 21, True, s3, i3, km16, thr, um8)
+        mb = m.pf_prepare(queries, thr, max_hits=50, ref_bins=2)
+        m.pf_run(mb)
+        hits_s, counts_s, status_s = m.pf_fetch(mb, len(qs))
+        m.pf_free(mb)
+    finally:
+        m.close()
+    assert status_s[6] == capi.PF_LONG_SEQ and counts_s[6] == 0
+    for qi in range(len(qs)):
+        if qi == 6:
+            continue
+        assert status_s[qi] == 0 and counts_s[qi] == counts_u[qi], qi
+        n = int(counts_u[qi])
+        for f in ("id", "score", "diagonal"):
+            assert np.array_equal(hits_s[qi][f][:n], hits_u[qi][f][:n]), (qi, f)
+
+
 def test_library_communicator_single_rank_rccl(gpu, matrices, monkeypatch):
     """The RCCL transport itself, as far as a 1-GPU box can run it: mmgpu_comm_unique_id + mmgpu_comm_init_rank with one
     rank, the exchange step's all-gathers as real ncclAllGather calls on the context's stream (MMGPU_COMM_SELF_RCCL),
