@@ -321,6 +321,18 @@ int mmgpu_pf_load_index(mmgpu_ctx *ctx, const mmgpu_pf_index *index);
  * matrix (short, alphabet x alphabet), kmer_thr the k-mer threshold that also gates which target k-mers are indexed
  * (IndexTable.h:146-154). */
 int mmgpu_pf_build_index(mmgpu_ctx *ctx, const mmgpu_pf_index *tables, const int16_t *kmer_submat, int kmer_thr);
+/* tantan repeat masking of the resident targets, for the prefilter only (the masking step of IndexBuilder::fillDatabase,
+ * IndexBuilder.cpp:148 -> Masker::maskSequence with maskTantan, Masker.cpp:14-57 -> tantan::maskSequences, lib/tantan/tantan.cpp
+ * :469-487, maxRepeatOffset 50, repeatProb 0.005, repeatEndProb 0.05, decay 0.9, no gaps): call it after mmgpu_load_targets with
+ * the UNMASKED residues and before mmgpu_pf_build_index; the k-mer index and the ungapped scorer then see the masked letters
+ * (replaced by mask_letter = X), the alignment kernels the original ones - one resident database serves both stages.
+ * likelihood_ratios: alphabet x alphabet doubles, probMatrix[i][j] / (pBack[i] * pBack[j]) of the k-mer matrix (ProbabilityMatrix,
+ * BaseMatrix.h:83-101); min_mask_prob: --mask-prob as the reference passes it (its float, widened).  The repeat probabilities
+ * are computed as the reference's AVX2 + FMA build computes them (tantan_kernel.hip; tests/test_tantan.py). */
+int mmgpu_pf_mask_targets(mmgpu_ctx *ctx, const double *likelihood_ratios, int alphabet, double min_mask_prob, int mask_letter,
+                          uint64_t *n_masked /* may be NULL */);
+/* test hook: the prefilter's view of the resident targets (masked if mmgpu_pf_mask_targets ran) in the caller's layout */
+int mmgpu_pf_debug_masked_targets(mmgpu_ctx *ctx, const uint64_t *offsets, uint32_t n_targets, uint8_t *residues);
 /* test hook: copies the resident index back in the host builder's layout (any pointer may be NULL) */
 int mmgpu_pf_debug_index(mmgpu_ctx *ctx, uint64_t *offsets, uint32_t *ids, uint16_t *pos, uint64_t *n_entries);
 

@@ -73,7 +73,7 @@ EXPORTED_SYMBOLS = [
     "mmgpu_sw_fetch", "mmgpu_sw_batch_stats", "mmgpu_sw_last_kernel_ms", "mmgpu_sw_kernel_ms_mean", "mmgpu_sw_free",
     "mmgpu_sw_traceback", "mmgpu_sw_prepare_from_pf", "mmgpu_sw_fetch_device", "mmgpu_nucl_align",
     "mmgpu_host_score_matrix", "mmgpu_host_index_build", "mmgpu_pf_load_index", "mmgpu_pf_batch", "mmgpu_pf_prepare",
-    "mmgpu_pf_run", "mmgpu_pf_fetch", "mmgpu_pf_stage_ms", "mmgpu_pf_last_cells", "mmgpu_pf_fetch_device", "mmgpu_pf_merge_splits", "mmgpu_pf_build_index", "mmgpu_pf_debug_index", "mmgpu_pf_debug_fetch", "mmgpu_pf_free",
+    "mmgpu_pf_run", "mmgpu_pf_fetch", "mmgpu_pf_stage_ms", "mmgpu_pf_last_cells", "mmgpu_pf_fetch_device", "mmgpu_pf_merge_splits", "mmgpu_pf_build_index", "mmgpu_pf_mask_targets", "mmgpu_pf_debug_masked_targets", "mmgpu_pf_debug_index", "mmgpu_pf_debug_fetch", "mmgpu_pf_free",
     "mmgpu_host_partition_targets", "mmgpu_pf_set_shard", "mmgpu_pf_fetch_exchange", "mmgpu_pf_merge_exchange",
     "mmgpu_pf_localize_lists", "mmgpu_sw_prepare_from_lists",
     "mmgpu_comm_unique_id", "mmgpu_comm_init_rank", "mmgpu_comm_info", "mmgpu_comm_destroy", "mmgpu_pf_exchange_merge",
@@ -682,6 +682,21 @@ class MMGpu:
         d = PfIndexDesc(k, alphabet, int(spaced), _ptr(score3), _ptr(index3), 0 if score3 is None else score3.shape[1], _ptr(score2), _ptr(index2),
                         0 if score2 is None else score2.shape[1], None, None, None, None, 0, _ptr(ungapped_mat))
         self._check(self.L.mmgpu_pf_build_index(self.ctx, ctypes.byref(d), _ptr(km), int(kmer_thr)))
+
+    def pf_mask_targets(self, likelihood_ratios, min_mask_prob=0.9, mask_letter=20):
+        """mmgpu_pf_mask_targets: tantan masking of the resident targets for the prefilter -> residues masked"""
+        lr = np.ascontiguousarray(likelihood_ratios, np.float64)
+        n = ctypes.c_uint64()
+        self.L.mmgpu_pf_mask_targets.argtypes = [c_p, c_p, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]
+        self._check(self.L.mmgpu_pf_mask_targets(self.ctx, _ptr(lr), lr.shape[0], float(min_mask_prob), int(mask_letter), ctypes.byref(n)))
+        return n.value
+
+    def pf_debug_masked_targets(self, offsets):
+        off = np.ascontiguousarray(offsets, np.uint64)
+        res = np.zeros(int(off[-1]), np.uint8)
+        self.L.mmgpu_pf_debug_masked_targets.argtypes = [c_p, c_p, ctypes.c_uint32, c_p]
+        self._check(self.L.mmgpu_pf_debug_masked_targets(self.ctx, _ptr(off), len(off) - 1, _ptr(res)))
+        return res
 
     def pf_debug_index(self, k, alphabet):
         ne = ctypes.c_uint64()

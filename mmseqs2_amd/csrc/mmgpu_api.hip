@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <atomic>
 #include <thread>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <numeric>
@@ -49,6 +50,7 @@ extern "C" void mmgpu_destroy(mmgpu_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     free_db(c->db);
+    if (c->pf_masked_res) { (void)hipFree(c->pf_masked_res); c->pf_masked_res = nullptr; }
     mmgpu::pf_index_free(c);
     (void)hipDeviceSynchronize();
     mmgpu::comm_free(c);
@@ -102,6 +104,7 @@ extern "C" int mmgpu_load_targets(mmgpu_ctx *c, const uint8_t *residues, const u
     // a resident prefilter index belongs to the database it was built / loaded for: it goes with it
     mmgpu::pf_index_free(c);
     c->shard.on = false;
+    if (c->pf_masked_res) { (void)hipFree(c->pf_masked_res); c->pf_masked_res = nullptr; }
     free_db(c->db);
     std::vector<uint32_t> off4(std::max<uint32_t>(n, 1)), len(std::max<uint32_t>(n, 1));
     uint64_t cur4 = 16;      // 64 bytes of padding in front: the reverse scan reads up to 3 bytes before a target (sw_kernel.hip)
@@ -139,6 +142,7 @@ extern "C" int mmgpu_load_targets(mmgpu_ctx *c, const uint8_t *residues, const u
     DB_TRY(hipMemcpy(db.len, len.data(), len.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
 #undef DB_TRY
     db.n = n;
+    db.res_bytes = bytes;
     db.max_len = max_len;
     db.total_residues = total;
     db.alphabet = alphabet;
@@ -147,6 +151,103 @@ extern "C" int mmgpu_load_targets(mmgpu_ctx *c, const uint8_t *residues, const u
     uint64_t res_total = 0;
     for (uint32_t i = 0; i < n; i++) res_total += len[i];
     c->mean_len = n ? (uint32_t)(res_total / n) : 0;
+    return MMGPU_OK;
+}
+
+// tantan masking of the resident targets for the prefilter (tantan_kernel.hip): what IndexBuilder::fillDatabase does to every
+// target before it counts k-mers (IndexBuilder.cpp:148, Masker.cpp:14-57 with maskTantan only).  The alignment kernels keep
+// reading the unmasked residues.
+extern "C" int mmgpu_pf_mask_targets(mmgpu_ctx *c, const double *likelihood_ratios, int alphabet, double min_mask_prob, int mask_letter,
+                                     uint64_t *n_masked) {
+    if (!c || !likelihood_ratios) return fail(MMGPU_ERR_ARG, "mmgpu_pf_mask_targets: NULL argument");
+    if (!c->db.res) return fail(MMGPU_ERR_STATE, "mmgpu_pf_mask_targets: no targets loaded");
+    if (alphabet != c->db.alphabet || alphabet > 32) return fail(MMGPU_ERR_ARG, "mmgpu_pf_mask_targets: alphabet differs from the loaded targets (or exceeds 32)");
+    if (mask_letter < 0 || mask_letter >= alphabet) return fail(MMGPU_ERR_ARG, "mmgpu_pf_mask_targets: mask letter outside the alphabet");
+    HIP_TRY(hipSetDevice(c->device));
+    mmgpu::pf_index_free(c);      // an index built from the unmasked residues does not describe the masked ones
+    hipStream_t s = c->stream;
+    const uint32_t n = c->db.n;
+    if (!c->pf_masked_res) HIP_TRY(hipMalloc((void **)&c->pf_masked_res, c->db.res_bytes));
+    HIP_TRY(hipMemcpyAsync(c->pf_masked_res, c->db.res, c->db.res_bytes, hipMemcpyDeviceToDevice, s));
+    // targets in order of length (longest first): 64 consecutive ones share a wavefront and end together; counting sort
+    std::vector<uint32_t> order(std::max<uint32_t>(n, 1));
+    {
+        std::vector<uint32_t> first(65536 + 2, 0);
+        for (uint32_t i = 0; i < n; i++) first[65535 - std::min<uint32_t>(c->h_len[i], 65535) + 1]++;
+        for (size_t k = 1; k < first.size(); k++) first[k] += first[k - 1];
+        for (uint32_t i = 0; i < n; i++) order[first[65535 - std::min<uint32_t>(c->h_len[i], 65535)]++] = i;
+    }
+    const uint32_t n_waves = (n + 63) / 64;
+    std::vector<uint64_t> pbase(std::max<uint32_t>(n_waves, 1)), sbase(std::max<uint32_t>(n_waves, 1));
+    uint64_t pcur = 0, scur = 0;
+    for (uint32_t w = 0; w < n_waves; w++) {
+        const uint64_t longest = c->h_len[order[(size_t)w * 64]];      // the first of a wavefront is its longest
+        pbase[w] = pcur;
+        sbase[w] = scur;
+        pcur += longest * 64;
+        scur += (longest / 16 + 1) * 64;
+    }
+    // Tantan's constructor (tantan.cpp:94-131) with the Masker's constants (Masker.cpp:22-31)
+    const double repeat_prob = 0.005, repeat_end_prob = 0.05, decay = 0.9;
+    const int max_offset = 50;
+    std::vector<double> b2f(max_offset);
+    {
+        const double first_prob = (decay < 1 || decay > 1) ? (1 - decay) / (1 - std::pow(decay, max_offset)) : 1.0 / max_offset;   // :38-44
+        double p = repeat_prob * first_prob;
+        for (int i = 0; i < max_offset; i++) {
+            b2f[i] = p;
+            p *= decay;
+        }
+    }
+    DevBuf d_order, d_pbase, d_sbase, d_lr, d_b2f, d_probs, d_scales, d_count;
+    for (DevBuf *d : {&d_order, &d_pbase, &d_sbase, &d_lr, &d_b2f, &d_probs, &d_scales, &d_count}) d->bind(c->cache);
+    HIP_TRY(upload(d_order, order, s));
+    HIP_TRY(upload(d_pbase, pbase, s));
+    HIP_TRY(upload(d_sbase, sbase, s));
+    std::vector<double> lr(likelihood_ratios, likelihood_ratios + (size_t)alphabet * alphabet);
+    HIP_TRY(upload(d_lr, lr, s));
+    HIP_TRY(upload(d_b2f, b2f, s));
+    HIP_TRY(d_probs.alloc(std::max<uint64_t>(pcur, 1) * sizeof(float)));
+    HIP_TRY(d_scales.alloc(std::max<uint64_t>(scur, 1) * sizeof(double)));
+    HIP_TRY(d_count.alloc(8));
+    HIP_TRY(hipMemsetAsync(d_count.p, 0, 8, s));
+    TantanArgs A;
+    A.t_res = c->db.res;
+    A.out_res = c->pf_masked_res;
+    A.t_off4 = c->db.off4;
+    A.t_len = c->db.len;
+    A.order = d_order.as<uint32_t>();
+    A.n = n;
+    A.lr = d_lr.as<double>();
+    A.b2f = d_b2f.as<double>();
+    A.alphabet = alphabet;
+    A.repeat_prob = repeat_prob;
+    A.repeat_end_prob = repeat_end_prob;
+    A.min_mask_prob = min_mask_prob;
+    A.mask_letter = (uint8_t)mask_letter;
+    A.probs = d_probs.as<float>();
+    A.scales = d_scales.as<double>();
+    A.wave_prob_base = d_pbase.as<uint64_t>();
+    A.wave_scale_base = d_sbase.as<uint64_t>();
+    A.n_masked = d_count.as<unsigned long long>();
+    HIP_TRY(launch_tantan_mask(A, s));
+    unsigned long long masked = 0;
+    HIP_TRY(hipMemcpyAsync(&masked, d_count.p, 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));      // the host vectors above die with this scope
+    if (n_masked) *n_masked = masked;
+    return MMGPU_OK;
+}
+
+// test hook: the prefilter's (masked) view of the resident targets back on the host, in the caller's layout
+extern "C" int mmgpu_pf_debug_masked_targets(mmgpu_ctx *c, const uint64_t *offsets, uint32_t n, uint8_t *residues) {
+    if (!c || !offsets || !residues) return fail(MMGPU_ERR_ARG, "mmgpu_pf_debug_masked_targets: NULL argument");
+    if (!c->db.res || n != c->db.n) return fail(MMGPU_ERR_STATE, "mmgpu_pf_debug_masked_targets: not the resident target set");
+    HIP_TRY(hipSetDevice(c->device));
+    std::vector<uint8_t> packed(c->db.res_bytes);
+    HIP_TRY(hipMemcpy(packed.data(), c->pf_res(), packed.size(), hipMemcpyDeviceToHost));
+    std::vector<uint32_t> off4(std::max<uint32_t>(n, 1));
+    HIP_TRY(hipMemcpy(off4.data(), c->db.off4, (size_t)n * 4, hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < n; i++) memcpy(residues + offsets[i], packed.data() + (size_t)off4[i] * 4, (size_t)(offsets[i + 1] - offsets[i]));
     return MMGPU_OK;
 }
 

@@ -31,6 +31,7 @@ struct DeviceDb {
     uint32_t max_len = 0;
     uint64_t total_residues = 0;
     int alphabet = 0;
+    size_t res_bytes = 0;        // allocated size of `res`
 };
 
 // One workgroup's share of a batch: hits [hit_begin, hit_end) of one query (already sorted by target length).
@@ -415,6 +416,25 @@ struct IxSortArgs {
 };
 
 hipError_t launch_ix_target(const IxArgs &A, bool fill, hipStream_t s);
+
+// tantan masking of the resident targets (tantan_kernel.hip)
+struct TantanArgs {
+    const uint8_t *t_res;              // unmasked residues
+    uint8_t *out_res;                  // the masked copy (same layout; only masked positions are written)
+    const uint32_t *t_off4, *t_len;
+    const uint32_t *order;             // [n] target ids, longest first: 64 consecutive ones share a wavefront
+    uint32_t n;
+    const double *lr;                  // [alphabet][alphabet] likelihood ratios (ProbabilityMatrix, BaseMatrix.h:83-101)
+    const double *b2f;                 // [50] background -> repeat state probabilities (Tantan constructor, tantan.cpp:118-131)
+    int alphabet;
+    double repeat_prob, repeat_end_prob, min_mask_prob;
+    uint8_t mask_letter;
+    float *probs;                      // forward background probabilities, [wave][position][64 lanes]
+    double *scales;                    // scale factors, [wave][position / 16][64 lanes]
+    const uint64_t *wave_prob_base, *wave_scale_base;
+    unsigned long long *n_masked;
+};
+hipError_t launch_tantan_mask(const TantanArgs &A, hipStream_t s);
 hipError_t launch_ix_sort_short(const IxSortArgs &A, hipStream_t s);
 hipError_t launch_ix_sort_long(const IxSortArgs &A, uint32_t n_long, hipStream_t s);
 
@@ -658,6 +678,11 @@ struct mmgpu_ctx {
     int compute_units = 0;
     std::string name;
     mmgpu::PfIndex *pf = nullptr;  // prefilter index resident in HBM (pf_api.hip)
+    // the prefilter's view of the targets when it differs from the alignment's: residues with tantan-masked letters replaced by
+    // X (mmgpu_pf_mask_targets; same offsets / lengths as `db`).  null: the prefilter reads db.res (--mask 0, or a caller that
+    // loaded an already masked SequenceLookup)
+    uint8_t *pf_masked_res = nullptr;
+    const uint8_t *pf_res() const { return pf_masked_res ? pf_masked_res : db.res; }
     // shard of a multi-GPU run (mmgpu_pf_set_shard); reset by mmgpu_load_targets
     struct Shard {
         bool on = false;

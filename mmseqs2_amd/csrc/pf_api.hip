@@ -401,7 +401,7 @@ extern "C" int mmgpu_pf_build_index(mmgpu_ctx *c, const mmgpu_pf_index *ix, cons
     X_TRY(hipMemsetAsync(d_counts.p, 0, table * 4, s));
     IxArgs A;
     memset(&A, 0, sizeof(A));
-    A.t_res = c->db.res;
+    A.t_res = c->pf_res();
     A.t_off4 = c->db.off4;
     A.t_len = c->db.len;
     A.n_targets = c->db.n;
@@ -986,7 +986,7 @@ extern "C" int mmgpu_pf_run(mmgpu_ctx *c, mmgpu_pf_batch_t *b) {
     D.q_isprof = b->any_profile ? b->d_qisprof.as<uint8_t>() : nullptr;
     D.mat = P.d_mat.as<int8_t>();
     D.alphabet = P.alphabet;
-    D.t_res = c->db.res;
+    D.t_res = c->pf_res();
     D.t_off4 = c->db.off4;
     D.t_len = c->db.len;
     D.min_diag_score = b->par.min_diag_score;

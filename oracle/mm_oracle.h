@@ -184,6 +184,12 @@ int mmo_sw_block_backtrace(const uint8_t *q, const int8_t *comp_bias, int qlen, 
                            int gap_open /* > 0, as the reference's */, int gap_extend, int score, int q_end, int t_end, int *q_start, int *t_start,
                            uint32_t *ident, char *bt, int bt_cap, int *bt_len, int *block_size_used);
 
+/* ---- tantan repeat masking (tantan_oracle.c): lib/tantan as the reference's AVX2 + FMA build computes it ---- */
+void mmo_tantan_b2f(double repeatProb, double decay, int maxRepeatOffset, double *b2f);
+void mmo_tantan_probs(const uint8_t *seq, int len, const double *lr, int alph, double repeatProb, double repeatEndProb, double decay,
+                      int maxRepeatOffset, float *probs);
+int mmo_tantan_mask(uint8_t *seq, int len, const double *lr, int alph, double min_mask_prob, uint8_t mask_letter, float *probs_out);
+
 #ifdef __cplusplus
 }
 #endif

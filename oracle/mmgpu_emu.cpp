@@ -18,6 +18,8 @@
 #include "mm_oracle.h"
 
 struct mmgpu_ctx {
+    std::vector<uint8_t> pf_tres;      // the prefilter's (tantan-masked) view, empty = tres
+    const uint8_t *pf_res() const { return pf_tres.empty() ? tres.data() : pf_tres.data(); }
     std::vector<uint8_t> tres;
     std::vector<uint64_t> toff;
     uint32_t n;
@@ -85,6 +87,7 @@ int mmgpu_synchronize(mmgpu_ctx *) { return 0; }
 
 int mmgpu_load_targets(mmgpu_ctx *c, const uint8_t *res, const uint64_t *off, uint32_t n, int alphabet) {
     c->tres.assign(res, res + off[n]);
+    c->pf_tres.clear();
     c->toff.assign(off, off + n + 1);
     c->n = n;
     c->alphabet = alphabet;
@@ -356,6 +359,25 @@ int mmgpu_pf_load_index(mmgpu_ctx *c, const mmgpu_pf_index *ix) {
     return 0;
 }
 
+// the device's tantan masking stand-in: the plain-C restatement (oracle/tantan_oracle.c)
+int mmgpu_pf_mask_targets(mmgpu_ctx *c, const double *lr, int alphabet, double min_mask_prob, int mask_letter, uint64_t *n_masked) {
+    if (c->n == 0 && c->tres.empty()) return fail(MMGPU_ERR_STATE, "no targets");
+    c->pf_tres = c->tres;
+    uint64_t masked = 0;
+#pragma omp parallel for schedule(dynamic, 64) reduction(+ : masked)
+    for (uint32_t i = 0; i < c->n; i++)
+        masked += (uint64_t)mmo_tantan_mask(c->pf_tres.data() + c->toff[i], (int)(c->toff[i + 1] - c->toff[i]), lr, alphabet, min_mask_prob,
+                                            (uint8_t)mask_letter, NULL);
+    if (n_masked) *n_masked = masked;
+    c->have_index = false;
+    return 0;
+}
+int mmgpu_pf_debug_masked_targets(mmgpu_ctx *c, const uint64_t *offsets, uint32_t n, uint8_t *residues) {
+    if (n != c->n) return fail(MMGPU_ERR_STATE, "not the resident target set");
+    memcpy(residues, c->pf_res(), (size_t)offsets[n]);
+    return 0;
+}
+
 // IndexBuilder::fillDatabase's index from the resident (already masked) targets: the oracle's builder
 int mmgpu_pf_build_index(mmgpu_ctx *c, const mmgpu_pf_index *ix, const int16_t *kmer_submat, int kmer_thr) {
     if (c->n == 0) return fail(MMGPU_ERR_STATE, "no targets");
@@ -363,11 +385,11 @@ int mmgpu_pf_build_index(mmgpu_ctx *c, const mmgpu_pf_index *ix, const int16_t *
     size_t nk = 1;
     for (int i = 0; i < ix->kmer_size; i++) nk *= (size_t)(ix->alphabet - 1);
     std::vector<uint64_t> off(nk + 1);
-    const uint64_t total = mmo_pf_index_build(c->tres.data(), c->toff.data(), c->n, kmer_submat, ix->alphabet, ix->kmer_size, ix->spaced,
+    const uint64_t total = mmo_pf_index_build(c->pf_res(), c->toff.data(), c->n, kmer_submat, ix->alphabet, ix->kmer_size, ix->spaced,
                                               kmer_thr, off.data(), NULL, NULL);
     std::vector<uint32_t> ids(total + 1);
     std::vector<uint16_t> pos(total + 1);
-    mmo_pf_index_build(c->tres.data(), c->toff.data(), c->n, kmer_submat, ix->alphabet, ix->kmer_size, ix->spaced, kmer_thr, off.data(),
+    mmo_pf_index_build(c->pf_res(), c->toff.data(), c->n, kmer_submat, ix->alphabet, ix->kmer_size, ix->spaced, kmer_thr, off.data(),
                        ids.data(), pos.data());
     full.offsets = off.data();
     full.entry_ids = ids.data();
@@ -418,7 +440,7 @@ int mmgpu_pf_run(mmgpu_ctx *c, mmgpu_pf_batch_t *b) {
     P.offsets = c->offsets.data();
     P.ids = c->ids.data();
     P.pos = c->pos.data();
-    P.tdata = c->tres.data();
+    P.tdata = c->pf_res();
     P.toff = c->toff.data();
     P.n_targets = c->n;
     P.ungapped_mat = c->ungapped.data();

@@ -160,6 +160,31 @@ class Oracle:
                 cigar += "%d%s" % (run, last)
         return res.score, res.qi, res.ri, cigar
 
+    def tantan_probs(self, seq, lr):
+        """repeat probabilities of one sequence (tantan_oracle.c, the Masker's constants)"""
+        seq = np.ascontiguousarray(seq, np.uint8)
+        lr = np.ascontiguousarray(lr, np.float64)
+        probs = np.zeros(max(len(seq), 1), np.float32)
+        f = self.L.mmo_tantan_probs
+        f.argtypes = [c_p, ctypes.c_int, c_p, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_int, c_p]
+        f.restype = None
+        f(_ptr(seq), len(seq), _ptr(lr), lr.shape[0], 0.005, 0.05, 0.9, 50, _ptr(probs))
+        return probs[:len(seq)]
+
+    def tantan_mask(self, tres, toff, lr, mask_prob=0.9, mask_letter=20):
+        """every sequence masked by the restatement -> (masked copy, residues masked)"""
+        res = np.ascontiguousarray(tres, np.uint8).copy()
+        lr = np.ascontiguousarray(lr, np.float64)
+        f = self.L.mmo_tantan_mask
+        f.argtypes = [c_p, ctypes.c_int, c_p, ctypes.c_int, ctypes.c_double, ctypes.c_uint8, c_p]
+        f.restype = ctypes.c_int
+        masked = 0
+        base = res.ctypes.data
+        for i in range(len(toff) - 1):
+            a, b = int(toff[i]), int(toff[i + 1])
+            masked += f(c_p(base + a), b - a, _ptr(lr), lr.shape[0], float(mask_prob), mask_letter, None)
+        return res, masked
+
     def block_prefix_scan(self, v, gap):
         v = np.ascontiguousarray(v, np.int16)
         out = np.zeros(16, np.int16)
@@ -556,6 +581,20 @@ class RefPrefilter:
         pb = np.zeros(a, np.float64)
         self.L.mmref_pref_get_matrices(self.c, _ptr(km), _ptr(um), _ptr(km16), _ptr(pb))
         return km, um, km16, pb
+
+    def tantan_mask(self, tres, toff, mask_prob=0.9):
+        """the reference's own tantan masking of numeric targets (Masker::maskSequence, maskTantan only) -> (masked copy,
+        residues masked, likelihood-ratio table [alphabet, alphabet], repeat probabilities of sequence 0)"""
+        res = np.ascontiguousarray(tres, np.uint8).copy()
+        off = np.ascontiguousarray(toff, np.uint64)
+        a = self.alphabet
+        lr = np.zeros((a, a), np.float64)
+        n = len(off) - 1
+        probs = np.zeros(int(off[1] - off[0]) if n else 1, np.float32)
+        self.L.mmref_tantan_mask.restype = ctypes.c_uint64
+        self.L.mmref_tantan_mask.argtypes = [c_p, c_p, c_p, ctypes.c_uint32, ctypes.c_double, c_p, c_p]
+        masked = self.L.mmref_tantan_mask(self.c, _ptr(res), _ptr(off), n, float(mask_prob), _ptr(lr), _ptr(probs))
+        return res, int(masked), lr, probs
 
     def score_matrix(self, which):
         rs = ctypes.c_uint64(0)

@@ -20,6 +20,7 @@
 
 #include "Debug.h"
 #include "ExtendedSubstitutionMatrix.h"
+#include "tantan.h"
 #include "IndexTable.h"
 #include "Indexer.h"
 #include "KmerGenerator.h"
@@ -88,6 +89,32 @@ void *mmref_pref_new(const char *kmer_matrix, const char *ungapped_matrix, int k
 }
 
 int mmref_pref_alphabet(void *h) { return ((PrefCtx *)h)->kmerMat->alphabetSize; }
+
+// tantan masking exactly as IndexBuilder::fillDatabase applies it to amino-acid targets (IndexBuilder.cpp:148, Masker.cpp:14-57
+// with maskTantan only): tantan::maskSequences over Sequence::numSequence with the k-mer matrix's likelihood ratios
+// (ProbabilityMatrix, BaseMatrix.h:83-101), then finalizeMasking.  seqs are masked in place; lr_out (may be NULL) receives the
+// alphabet x alphabet likelihood-ratio table, probs_out (may be NULL) the per-letter repeat probabilities of sequence 0.
+uint64_t mmref_tantan_mask(void *h, uint8_t *tdata, const uint64_t *toff, uint32_t n, double mask_prob, double *lr_out, float *probs_out) {
+    PrefCtx *c = (PrefCtx *)h;
+    ProbabilityMatrix pm(*c->kmerMat);
+    const int a = c->kmerMat->alphabetSize;
+    if (lr_out)
+        for (int i = 0; i < a; i++)
+            for (int j = 0; j < a; j++) lr_out[i * a + j] = pm.probMatrixPointers[i][j];
+    if (probs_out && n > 0)
+        tantan::getProbabilities(tdata + toff[0], tdata + toff[1], 50, pm.probMatrixPointers, 0.005, 0.05, 0.9, 0, 0, probs_out);
+    uint64_t masked = 0;
+    const unsigned char maskLetter = c->kmerMat->aa2num[(int)'X'];
+#pragma omp parallel for schedule(dynamic, 64) reduction(+ : masked)
+    for (uint32_t i = 0; i < n; i++) {
+        uint8_t *s = tdata + toff[i];
+        const size_t len = toff[i + 1] - toff[i];
+        masked += tantan::maskSequences(s, s + len, 50, pm.probMatrixPointers, 0.005, 0.05, 0.9, 0, 0, mask_prob, pm.hardMaskTable);
+        const unsigned char maskChar = pm.hardMaskTable[0];      // Masker::finalizeMasking (Masker.cpp:119-126)
+        for (size_t k = 0; k < len; k++) s[k] = (s[k] == maskChar || s[k] == maskLetter) ? maskLetter : s[k];
+    }
+    return masked;
+}
 
 void mmref_pref_get_matrices(void *h, int8_t *kmer_mat, int8_t *ungapped_mat, int16_t *kmer_mat16, double *kmer_pback) {
     PrefCtx *c = (PrefCtx *)h;
