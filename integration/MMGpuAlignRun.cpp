@@ -22,6 +22,7 @@
 #include "Util.h"
 
 #include "MMGpuAlignSession.h"
+#include "MMGpuFusedSearch.h"
 #include "MMGpuHostBlock.h"
 
 #ifdef OPENMP
@@ -35,14 +36,14 @@ namespace {
 
 const unsigned char *lookupTarget(void *ctx, unsigned int id) {
     MMGpuAlignSession *s = static_cast<MMGpuAlignSession *>(ctx);
-    return s->targetResidues.data() + s->targetOffsets[id];
+    return s->tData + s->tOff[id];
 }
 
 }  // namespace
 
 MMGpuAlignSession::MMGpuAlignSession(Alignment &al, EvalueComputation &evaluer)
     : al(al), evaluer(evaluer), gpu(NULL), nucleotide(false), watch("align"), backend(NULL), matcher(NULL), blockHook(NULL), start(0), size(0),
-      nucl(NULL) {}
+      tData(NULL), tOff(NULL), nucl(NULL) {}
 
 MMGpuAlignSession::~MMGpuAlignSession() {
     delete matcher;
@@ -85,60 +86,72 @@ MMGpuAlignSession *MMGpuAlignRun::begin(Alignment &al, EvalueComputation &evalue
     s->nucleotide = usableNucleotide(al);
     const unsigned int threads = al.threads;
     const size_t nTargets = al.tdbr->getSize();
-    std::vector<unsigned char> named(nTargets, 1);
-    if (Util::getTotalSystemMemory() > al.prefdbr->getTotalDataSize()) {
-        std::fill(named.begin(), named.end(), 0);
+    // fused search with the masking on the device: the prefilter module of this process left the unmasked targets resident, host
+    // copy included (the same Sequence::numSequence, the same ids: checked key by key)
+    bool residentAlready = false;
+    std::vector<mmgpu_ctx *> devices;
+    if (!s->nucleotide && MMGpuRun::multi() == NULL && MMGpuFusedSearch::residentTargets(al.tdbr, s->gpu, &s->tData, &s->tOff)) {
+        residentAlready = true;
+        devices.push_back(s->gpu);
+        s->watch.lap("targets already resident (fused search)");
+    }
+    if (!residentAlready) {
+        std::vector<unsigned char> named(nTargets, 1);
+        if (Util::getTotalSystemMemory() > al.prefdbr->getTotalDataSize()) {
+            std::fill(named.begin(), named.end(), 0);
+#pragma omp parallel num_threads(threads)
+            {
+                unsigned int thread_idx = 0;
+#ifdef OPENMP
+                thread_idx = static_cast<unsigned int>(omp_get_thread_num());
+#endif
+                char key[255 + 1];
+#pragma omp for schedule(dynamic, 64)
+                for (size_t id = dbFrom; id < dbFrom + dbSize; id++) {
+                    char *data = al.prefdbr->getData(id, thread_idx);
+                    while (*data != '\0') {
+                        Util::parseKey(data, key);
+                        const size_t dbId = al.tdbr->getId(Util::fast_atoi<DBKeyType>(key));
+                        if (dbId < nTargets) named[dbId] = 1;
+                        data = Util::skipLine(data);
+                    }
+                }
+            }
+        }
+        s->targetOffsets.assign(nTargets + 1, 0);
+        for (size_t id = 0; id < nTargets; id++) s->targetOffsets[id + 1] = s->targetOffsets[id] + (named[id] ? al.tdbr->getSeqLen(id) : 0);
+        s->targetResidues.resize(s->targetOffsets[nTargets] + 1);
 #pragma omp parallel num_threads(threads)
         {
             unsigned int thread_idx = 0;
 #ifdef OPENMP
             thread_idx = static_cast<unsigned int>(omp_get_thread_num());
 #endif
-            char key[255 + 1];
-#pragma omp for schedule(dynamic, 64)
-            for (size_t id = dbFrom; id < dbFrom + dbSize; id++) {
-                char *data = al.prefdbr->getData(id, thread_idx);
-                while (*data != '\0') {
-                    Util::parseKey(data, key);
-                    const size_t dbId = al.tdbr->getId(Util::fast_atoi<DBKeyType>(key));
-                    if (dbId < nTargets) named[dbId] = 1;
-                    data = Util::skipLine(data);
-                }
+            Sequence dbSeq(al.maxSeqLen, al.targetSeqType, al.m, 0, false, al.compBiasCorrection);
+#pragma omp for schedule(dynamic, 256)
+            for (size_t id = 0; id < nTargets; id++) {
+                if (!named[id]) continue;
+                char *data = al.tdbr->getData(id, thread_idx);
+                if (data == NULL) continue;
+                dbSeq.mapSequence(id, al.tdbr->getDbKey(id), data, al.tdbr->getSeqLen(id));
+                memcpy(s->targetResidues.data() + s->targetOffsets[id], dbSeq.numSequence, dbSeq.L);
             }
         }
+        s->watch.lap("map targets");
+        // MMGPU_DEVICES: every device holds the targets, the queries of a bucket are dealt to them (MMGpuMultiDeviceBackend)
+        if (!s->nucleotide)
+            if (mmgpu_multi *multi = MMGpuRun::multi())
+                for (int d = 0; d < mmgpu_multi_size(multi); d++) devices.push_back(mmgpu_multi_ctx(multi, d));
+        if (devices.empty()) devices.push_back(s->gpu);
+        for (size_t d = 0; d < devices.size(); d++)
+            if (mmgpu_load_targets(devices[d], s->targetResidues.data(), s->targetOffsets.data(), (uint32_t)nTargets, al.m->alphabetSize) != 0) {
+                Debug(Debug::WARNING) << "MMGPU: the targets of this run cannot be made resident (" << mmgpu_last_error() << "), using the CPU path\n";
+                delete s;
+                return NULL;
+            }
+        s->tData = s->targetResidues.data();
+        s->tOff = s->targetOffsets.data();
     }
-    s->targetOffsets.assign(nTargets + 1, 0);
-    for (size_t id = 0; id < nTargets; id++) s->targetOffsets[id + 1] = s->targetOffsets[id] + (named[id] ? al.tdbr->getSeqLen(id) : 0);
-    s->targetResidues.resize(s->targetOffsets[nTargets] + 1);
-#pragma omp parallel num_threads(threads)
-    {
-        unsigned int thread_idx = 0;
-#ifdef OPENMP
-        thread_idx = static_cast<unsigned int>(omp_get_thread_num());
-#endif
-        Sequence dbSeq(al.maxSeqLen, al.targetSeqType, al.m, 0, false, al.compBiasCorrection);
-#pragma omp for schedule(dynamic, 256)
-        for (size_t id = 0; id < nTargets; id++) {
-            if (!named[id]) continue;
-            char *data = al.tdbr->getData(id, thread_idx);
-            if (data == NULL) continue;
-            dbSeq.mapSequence(id, al.tdbr->getDbKey(id), data, al.tdbr->getSeqLen(id));
-            memcpy(s->targetResidues.data() + s->targetOffsets[id], dbSeq.numSequence, dbSeq.L);
-        }
-    }
-    s->watch.lap("map targets");
-    // MMGPU_DEVICES: every device holds the targets, the queries of a bucket are dealt to them (MMGpuMultiDeviceBackend)
-    std::vector<mmgpu_ctx *> devices;
-    if (!s->nucleotide)
-        if (mmgpu_multi *multi = MMGpuRun::multi())
-            for (int d = 0; d < mmgpu_multi_size(multi); d++) devices.push_back(mmgpu_multi_ctx(multi, d));
-    if (devices.empty()) devices.push_back(s->gpu);
-    for (size_t d = 0; d < devices.size(); d++)
-        if (mmgpu_load_targets(devices[d], s->targetResidues.data(), s->targetOffsets.data(), (uint32_t)nTargets, al.m->alphabetSize) != 0) {
-            Debug(Debug::WARNING) << "MMGPU: the targets of this run cannot be made resident (" << mmgpu_last_error() << "), using the CPU path\n";
-            delete s;
-            return NULL;
-        }
     s->watch.lap("mmgpu_load_targets");
     if (s->nucleotide) {
         beginNucleotide(s);
@@ -211,13 +224,13 @@ void MMGpuAlignRun::plan(MMGpuAlignSession *s, size_t start, size_t bucketSize) 
                 data = Util::skipLine(data);
                 const size_t dbId = al.tdbr->getId(dbKey);
                 if (dbId >= al.tdbr->getSize() || al.tdbr->getData(dbId, thread_idx) == NULL) break;      // (the loop reports it and ends the run)
-                const int dbLen = (int)(s->targetOffsets[dbId + 1] - s->targetOffsets[dbId]);
+                const int dbLen = (int)(s->tOff[dbId + 1] - s->tOff[dbId]);
                 if (!Util::canBeCovered(al.canCovThr, al.covMode, static_cast<float>(origQueryLen), static_cast<float>(dbLen))) continue;
                 MMGpuMatcher::Target t;
                 t.id = (unsigned int)dbId;
                 t.dbKey = dbKey;
                 t.length = dbLen;
-                t.numSequence = s->targetResidues.data() + s->targetOffsets[dbId];
+                t.numSequence = s->tData + s->tOff[dbId];
                 t.isIdentity = (queryDbKey == dbKey && (al.includeIdentity || al.sameQTDB)) ? true : false;
                 q.targets.push_back(t);
             }

@@ -26,6 +26,10 @@ struct MMGpuAlignSession {
     // resident targets: Sequence::numSequence of the entries the lists name, ids = DBReader ids
     std::vector<unsigned char> targetResidues;
     std::vector<uint64_t> targetOffsets;
+    // ... or, in a fused search, the lookup the prefilter module left resident (MMGpuFusedSearch::residentTargets): what the
+    // amino-acid path reads
+    const unsigned char *tData;
+    const uint64_t *tOff;
     // amino-acid / profile queries
     MMGpuAlignBackend *backend;
     MMGpuMatcher *matcher;

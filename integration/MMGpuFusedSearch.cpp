@@ -10,6 +10,7 @@
 #include "Debug.h"
 #include "FileUtil.h"
 #include "Parameters.h"
+#include "SequenceLookup.h"
 #include "Timer.h"
 #include "Util.h"
 
@@ -29,6 +30,14 @@ struct PrefStore {
     PrefStore() : on(false) {}
 };
 PrefStore store;
+
+struct ResidentTargets {
+    SequenceLookup *lookup;
+    std::vector<unsigned int> keys;
+    void *gpu;
+    ResidentTargets() : lookup(NULL), gpu(NULL) {}
+};
+ResidentTargets resident;
 
 std::vector<std::string> words(const std::string &s) {      // the shell's word splitting of an unquoted $PAR (values with
     std::vector<std::string> w;                             // white space are base64-encoded by createParameterString)
@@ -120,6 +129,8 @@ int MMGpuFusedSearch::run(Parameters &par, const std::string &query, const std::
         status = module(par, "align", a);
     }
     store.on = false;
+    delete resident.lookup;
+    resident.lookup = NULL;
     if (status != EXIT_SUCCESS) {
         Debug(Debug::ERROR) << "Alignment died\n";
         EXIT(EXIT_FAILURE);
@@ -131,6 +142,33 @@ int MMGpuFusedSearch::run(Parameters &par, const std::string &query, const std::
 }
 
 bool MMGpuFusedSearch::capturing(const std::string &db) { return store.on && db == store.db; }
+
+bool MMGpuFusedSearch::keepsTargets() { return store.on; }
+
+void MMGpuFusedSearch::keepResidentTargets(SequenceLookup *lookup, DBReader<unsigned int> *tdbr, void *gpu) {
+    delete resident.lookup;
+    resident.lookup = lookup;
+    resident.gpu = gpu;
+    const size_t n = lookup->getSequenceCount();
+    resident.keys.resize(n);
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; i++) resident.keys[i] = tdbr->getDbKey(i);
+}
+
+bool MMGpuFusedSearch::residentTargets(DBReader<unsigned int> *tdbr, void *gpu, const unsigned char **data, const uint64_t **offsets) {
+    if (resident.lookup == NULL || resident.gpu != gpu) return false;
+    const size_t n = resident.lookup->getSequenceCount();
+    if (tdbr->getSize() != n) return false;
+    static_assert(sizeof(size_t) == sizeof(uint64_t), "SequenceLookup::getOffsets() is handed over as it is");
+    const uint64_t *off = reinterpret_cast<const uint64_t *>(resident.lookup->getOffsets());
+    bool same = true;
+#pragma omp parallel for schedule(static) reduction(&& : same)
+    for (size_t i = 0; i < n; i++) same = same && tdbr->getDbKey(i) == resident.keys[i] && tdbr->getSeqLen(i) == off[i + 1] - off[i];
+    if (!same) return false;
+    *data = reinterpret_cast<const unsigned char *>(resident.lookup->getData());
+    *offsets = off;
+    return true;
+}
 
 void MMGpuFusedSearch::capture(unsigned int queryKey, const char *data, size_t len, unsigned int thread) {
     // (called from inside the hook's parallel region: one slot per thread, sized by the hook's first call outside of it)

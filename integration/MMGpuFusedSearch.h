@@ -17,6 +17,7 @@
 #include "DBReader.h"
 
 class Parameters;
+class SequenceLookup;
 
 class MMGpuFusedSearch {
 public:
@@ -33,6 +34,15 @@ public:
     static void capture(unsigned int queryKey, const char *data, size_t len, unsigned int thread);
     // Alignment's constructor: a DBReader over the captured entries (NULL = none for this name: open the database on disk)
     static DBReader<unsigned int> *openCaptured(const std::string &db, int threads);
+
+    // ---- the target set, resident once ----
+    // With the masking on the device (mmgpu_pf_mask_targets) the prefilter module hands over the UNMASKED SequenceLookup - the very
+    // residues the alignment module would map and upload again.  The prefilter hook leaves the lookup here (it takes it away from
+    // the Prefiltering object, which would free it) together with the database keys of its ids; the alignment hook asks for it and
+    // gets it only if its own reader numbers the same sequences the same way.
+    static bool keepsTargets();      // a fused run is in progress: worth handing the lookup over
+    static void keepResidentTargets(SequenceLookup *lookup, DBReader<unsigned int> *tdbr, void *gpu);
+    static bool residentTargets(DBReader<unsigned int> *tdbr, void *gpu, const unsigned char **data, const uint64_t **offsets);
 };
 
 #endif

@@ -31,6 +31,7 @@ public:
     // device, matchBlock() runs every shard, exchanges the lists over the library's communicator and returns the merged lists,
     // which equal the single-device ones.  Sequence queries with diagonal scoring only (the caller checks multiCapable()).
     void useDevices(mmgpu_multi *m) { multi = m; }
+    bool usesSeveralDevices() const { return multi != NULL; }
     static bool multiCapable(bool profileQuery, bool nucleotide, bool kmerScoring, size_t maxResListLen, int nDevices) {
         return !profileQuery && !nucleotide && !kmerScoring && maxResListLen * (size_t)nDevices <= 4096;
     }
@@ -59,7 +60,7 @@ public:
     // the same hand-over without a host index: the index is built on the device from the (masked) SequenceLookup with the
     // k-mer threshold IndexBuilder::fillDatabase would have used (IndexTable.h:146-154); tables may be invalid (exact k-mers)
     bool buildIndex(SequenceLookup *sequenceLookup, int kmerSize, int indexKmerThr, ScoreMatrix &threeMer, ScoreMatrix &twoMer,
-                    bool spacedKmer);
+                    bool spacedKmer, bool maskOnDevice = false, double maskProb = 0.9);
 
     // takeOnlyBestKmer (--exact-kmer-matching; every nucleotide search) / nucleotide target database (matchQuery's isNucleotide)
     void setMode(bool exactKmer, bool nucleotide, bool kmerScoring = false) {

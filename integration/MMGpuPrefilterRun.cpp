@@ -80,6 +80,16 @@ bool MMGpuPrefilterRun::deviceBuildsIndex(Prefiltering &p) {
     return ok;
 }
 
+bool MMGpuPrefilterRun::deviceMasks(Prefiltering &p) {
+    const char *e = getenv("MMGPU_DEVICE_MASK");
+    if (e != NULL && e[0] == '0') return false;
+    // what the kernel restates: Masker::maskSequence with tantan alone (Masker.cpp:20-32) on amino-acid sequences
+    if (p.maskMode != 1 || p.maskLowerCaseMode != 0 || p.maskNrepeats > 0) return false;
+    if (!Parameters::isEqualDbtype(p.targetSeqType, Parameters::DBTYPE_AMINO_ACIDS)) return false;
+    if (getenv("MMGPU_DEVICES") != NULL && getenv("MMGPU_DEVICES")[0] != '\0') return false;      // (shards are masked on the host)
+    return true;
+}
+
 void MMGpuPrefilterRun::ensureHostIndex(Prefiltering &p, size_t dbFrom, size_t dbSize) {
     if (!p.mmgpuDeviceIndex) return;
     // IndexBuilder::fillDatabase as Prefiltering::getIndexTable calls it (:564-569); it also fills a second SequenceLookup,
@@ -133,7 +143,8 @@ bool MMGpuPrefilterRun::run(Prefiltering &p, DBWriter &tmpDbw, size_t dbFrom, si
     device.setMode(p.takeOnlyBestKmer, nuclSearch, p.diagonalScoring == 0);
     ScoreMatrix &three = local3.isValid() ? local3 : p._3merSubMatrix;
     ScoreMatrix &two = local2.isValid() ? local2 : p._2merSubMatrix;
-    const bool handedOver = p.mmgpuDeviceIndex ? device.buildIndex(p.sequenceLookup, p.kmerSize, p.mmgpuIndexKmerThr, three, two, p.spacedKmer)
+    const bool handedOver = p.mmgpuDeviceIndex ? device.buildIndex(p.sequenceLookup, p.kmerSize, p.mmgpuIndexKmerThr, three, two, p.spacedKmer,
+                                                                   p.mmgpuDeviceMask, (double)p.maskProb)
                                                : device.loadIndex(p.indexTable, p.sequenceLookup, three, two, p.spacedKmer);
     if (!handedOver) {
         Debug(Debug::ERROR) << "MMGPU: " << device.error() << "\n";
@@ -376,6 +387,13 @@ bool MMGpuPrefilterRun::run(Prefiltering &p, DBWriter &tmpDbw, size_t dbFrom, si
     for (size_t i = 0; i < localThreads; i++) {
         delete seqs[i];
         delete cpuMatchers[i];
+    }
+    // fused search: the unmasked lookup (device masking) is what the alignment module would map and upload again - it stays
+    // resident and the lookup goes to the fused run instead of being freed with this Prefiltering object
+    if (capture && p.mmgpuDeviceMask && p.mmgpuDeviceIndex && !device.usesSeveralDevices() && dbFrom == 0 && dbSize == p.tdbr->getSize() &&
+        MMGpuFusedSearch::keepsTargets() && p.sequenceLookup != NULL) {
+        MMGpuFusedSearch::keepResidentTargets(p.sequenceLookup, p.tdbr, gpu);
+        p.sequenceLookup = NULL;
     }
     st.kmersPerPos = kmersPerPos;
     st.dbMatches = dbMatches;

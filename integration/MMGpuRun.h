@@ -86,6 +86,9 @@ public:
     // SequenceLookup (mmgpu_pf_build_index), the host only masks (IndexBuilder::fillDatabase without an index table);
     // MMGPU_HOST_INDEX=1 keeps the host's index
     static bool deviceBuildsIndex(Prefiltering &p);
+    // ... and whether the device also does the masking fillDatabase would do (tantan only, one device): mmgpu_pf_mask_targets;
+    // MMGPU_DEVICE_MASK=0 keeps the host's Masker
+    static bool deviceMasks(Prefiltering &p);
     // the reference's own index for queries the device hands back (overflow, long sequences, ties), built when first needed
     static void ensureHostIndex(Prefiltering &p, size_t dbFrom, size_t dbSize);
     // the `omp parallel` block of Prefiltering::runSplit (:820-918): writes every query's entry to tmpDbw, fills the

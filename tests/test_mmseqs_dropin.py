@@ -88,6 +88,12 @@ def reference_for(args):
     return STOCK, {}
 
 
+def both_modules_on_device(log):
+    """a search whose prefilter and align modules both ran on the device: two device openings (the workflow script's child
+    processes), or one for the fused run (plain sequence / profile-query searches, MMGpuFusedSearch)"""
+    return log.count("MMGPU: device") >= 2 or ("prefilter and align run inside this process" in log and log.count("MMGPU: device") == 1)
+
+
 def same(a, b):
     n, bad, msgs = dbio.diff_dbs(a, b)
     assert bad == 0, "%d of %d entries differ: %s" % (bad, n, "; ".join(msgs))
@@ -320,7 +326,7 @@ def _profile_pipeline(w, emulate):
     # the whole profile search through the patched binary: both stages on the device
     run(STOCK, ["search", "prof", "t", "pres_s", "ptmp_s", "-s", "5.7", "-a", "--threads", THREADS, "-v", "1"], w)
     log = run(MMGPU, ["search", "prof", "t", "pres_g", "ptmp_g", "-s", "5.7", "-a", "--threads", THREADS, "-v", "3"], w, emulate)
-    assert log.count("MMGPU: device") >= 2 and "using the CPU path" not in log, log[-3000:]
+    assert both_modules_on_device(log) and "using the CPU path" not in log, log[-3000:]
     assert same(os.path.join(w, "pres_s"), os.path.join(w, "pres_g")) == 30
 
 
@@ -365,7 +371,7 @@ def _translated_pipeline(w, emulate):
     run(STOCK, ["createdb", "t.fasta", "t", "-v", "1"], w)
     run(STOCK, ["search", "qn", "t", "tres_s", "ttmp_s", "-s", "5.7", "-a", "--threads", THREADS, "-v", "1"], w)
     log = run(MMGPU, ["search", "qn", "t", "tres_g", "ttmp_g", "-s", "5.7", "-a", "--threads", THREADS, "-v", "3"], w, emulate)
-    assert log.count("MMGPU: device") >= 2 and "using the CPU path" not in log, log[-3000:]
+    assert both_modules_on_device(log) and "using the CPU path" not in log, log[-3000:]
     n = same(os.path.join(w, "tres_s"), os.path.join(w, "tres_g"))
     assert n == 24
     # the search found the planted proteins: every query has hits
@@ -575,7 +581,7 @@ def indexed_target_pipeline(tmp, emulate):
     args = ["-s", "5.7", "-a", "--threads", THREADS]
     run(STOCK, ["search", "q", "t", "res_s", "tmp_s"] + args + ["-v", "2"], w)
     log = run(MMGPU, ["search", "q", "t", "res_g", "tmp_g"] + args + ["-v", "3"], w, emulate)
-    assert log.count("MMGPU: device") >= 2 and "using the CPU path" not in log, log[-3000:]
+    assert both_modules_on_device(log) and "using the CPU path" not in log, log[-3000:]
     assert same(os.path.join(w, "res_s"), os.path.join(w, "res_g")) == 500
 
 
