@@ -206,7 +206,7 @@ def sw_cpu_baseline_lists(matrices, qres, qoff, lists, tres, toff, budget_s, gpu
                                    "pairs_with_start_on_one_side_only": int(np.count_nonzero(g_st != r_st))}}
 
 
-def prefilter_cpu_baseline(matrices, qres, qoff, tres, toff, kmer_thr, budget_s, gpu_lists):
+def prefilter_cpu_baseline(matrices, qres, qoff, tres, toff, kmer_thr, budget_s, gpu_lists, mask=False):
     """The reference's own prefilter query loop (QueryMatcher::matchQuery per OpenMP thread, Prefiltering.cpp:820-917)
     from oracle/_ref/libmmref.so on the host cores, bounded sample of the same queries against the same targets.
     The lists it produces are also the checker of the device lists at full size."""
@@ -216,6 +216,10 @@ def prefilter_cpu_baseline(matrices, qres, qoff, tres, toff, kmer_thr, budget_s,
     cores = os.cpu_count() or 1
     ref = pyoracle.RefPrefilter(6, serialized=(matrices["vtml80_serialized"].tobytes(), matrices["blosum62_serialized"].tobytes()))
     t0 = time.time()
+    mask_note = ""
+    if mask:      # the reference's own tantan (Masker::maskSequence, maskTantan) over the targets, then its index over the masked ones
+        tres, n_masked, _, _ = ref.tantan_mask(tres, toff, float(np.float32(0.9)))
+        mask_note = "; targets masked by the reference's tantan (%d residues, %.1f s)" % (n_masked, time.time() - t0)
     ref.build_index(tres, toff, kmer_thr)
     t_index = time.time() - t0
     nq = len(qoff) - 1
@@ -226,7 +230,7 @@ def prefilter_cpu_baseline(matrices, qres, qoff, tres, toff, kmer_thr, budget_s,
     sec, hits, dbm, counts, lists = ref.match_batch(qres[:int(qoff[n])], qoff[:n + 1], cores, want_lists=True)
     out = {"value": round(n / sec, 1), "unit": "queries/s (prefilter only)", "cores": cores, "kind": "reference",
            "sample": "first %d of the %d queries against the same %d targets, %.1f s wall, %d threads; reference index build "
-                     "%.1f s (not counted)" % (n, nq, len(toff) - 1, sec, cores, t_index),
+                     "%.1f s (not counted)%s" % (n, nq, len(toff) - 1, sec, cores, t_index, mask_note),
            "db_matches_per_query": round(dbm / n), "hits_per_query": round(hits / n, 1)}
     bad = 0
     for qi in range(n):
@@ -352,6 +356,23 @@ def module_seconds(args, qres, qoff, tres, toff):
         n, bad, _ = dbio.diff_dbs(os.path.join(w, "aln_stock"), os.path.join(w, "aln_patched"))
         out["alignment_dbs_identical"] = bad == 0
         out["entries_compared"] = n
+        # round 4 (row f2): `mmseqs search` through the patched binary runs both modules inside the search process (one device
+        # context, tantan masking + index on the device, hit lists in memory, targets resident once): wall time of the whole
+        # command, best of two, and its result database against the stock binary's align database above
+        best = None
+        for rep in range(2):
+            ts_, _ = run(patched, ["search", "q", "t", "res_fused%d" % rep, "tmp_fused%d" % rep, "-s", "5.7", "--threads", threads, "-v", "3"])
+            best = ts_ if best is None else min(best, ts_)
+        n2, bad2, _ = dbio.diff_dbs(os.path.join(w, "aln_stock"), os.path.join(w, "res_fused0"))
+        stock_total = out["stock"]["prefilter_wall_s"] + out["stock"]["align_wall_s"]
+        out["patched_search_fused"] = {"wall_s": round(best, 2), "queries_per_s": round((len(qoff) - 1) / best, 1),
+                                       "result_db_identical_to_stock_align_db": bad2 == 0, "entries_compared": n2,
+                                       "what": "`mmseqs search q t res tmp -s 5.7` (default flags), whole command incl. process start, database "
+                                               "opening, masking, index build, prefilter, alignment, result database"}
+        out["speedup_search_fused_vs_stock_prefilter_plus_align"] = round(stock_total / best, 2)
+        if "stock_block_aligner_stubbed" in out:
+            sb = out["stock_block_aligner_stubbed"]
+            out["speedup_search_fused_vs_stubbed_stock_prefilter_plus_align"] = round((sb["prefilter_wall_s"] + sb["align_wall_s"]) / best, 2)
         out["speedup_prefilter_plus_align"] = round((out["stock"]["prefilter_wall_s"] + out["stock"]["align_wall_s"]) /
                                                     (out["patched"]["prefilter_wall_s"] + out["patched"]["align_wall_s"]), 2)
         return out
@@ -417,7 +438,16 @@ def search_headline(args, gpu, torch, dist, rank, world, matrices, barrier):
                 comm_note = "library: single rank, device copies"
         except Exception as e:          # report, and keep the run alive on the torch.distributed path
             comm_note = "torch.distributed (library communicator failed: %s)" % str(e)[:200]
-    # the k-mer index is built in HBM from the resident targets (IndexBuilder::fillDatabase, masking off)
+    # --mask 1 (the default of `mmseqs prefilter`): tantan masking of the resident targets for the prefilter (the masking step of
+    # IndexBuilder::fillDatabase, on the device); the k-mer index is then built in HBM from the masked view, the alignment kernels
+    # keep reading the unmasked residues
+    t_mask, n_masked = 0.0, 0
+    if args.mask:
+        tv = np.load(os.path.join(ROOT, "tests", "golden", "tantan_vectors.npz"))      # constants: VTML80 likelihood ratios, 0.9f
+        gpu.synchronize()
+        tm0 = time.time()
+        n_masked = gpu.pf_mask_targets(tv["vtml80_likelihood_ratios"], float(tv["mask_prob"]), 20)
+        t_mask = time.time() - tm0
     gpu.pf_build_index(k, 21, True, s3, i3, km16, kmer_thr, matrices["blosum62_ungapped"])
     gpu.synchronize()
     t_index = time.time() - t0
@@ -515,6 +545,7 @@ def search_headline(args, gpu, torch, dist, rank, world, matrices, barrier):
            "n_global": n_global, "n_local": gpu.n_targets, "kmer_thr": kmer_thr, "max_res": max_res, "stage": stage,
            "pf_cells": pf_cells, "pf_cands": pf_cands, "t_gen": t_gen, "t_index": t_index, "weak": weak, "sharded": sharded,
            "thr_example": thr_of_len.get(len(qs[0])), "hbm_in_use_gb": round((mem_total - mem_free) / 2 ** 30, 1),
+           "mask": int(args.mask), "t_mask": t_mask, "n_masked": int(n_masked),
            "collectives": comm_note if sharded else None}
     if rank != 0:
         pfb.free()
@@ -625,7 +656,7 @@ def search_headline(args, gpu, torch, dist, rank, world, matrices, barrier):
                 out["modules"] = {"error": "%s: %s" % (type(e).__name__, str(e)[-300:])}
         if not args.no_cpu_baseline:
             out["cpu_sw"] = sw_cpu_baseline_lists(matrices, qres, qoff, lists, tres, toff, args.cpu_seconds, gpu_res)
-            out["cpu_pf"] = prefilter_cpu_baseline(matrices, qres, qoff, tres, toff, kmer_thr, args.cpu_seconds, full_lists)
+            out["cpu_pf"] = prefilter_cpu_baseline(matrices, qres, qoff, tres, toff, kmer_thr, args.cpu_seconds, full_lists, mask=bool(args.mask))
     else:
         mh, mc, mf = keep["merged"]
         mh = mh.reshape(nq, stride * 3).view(capi.PF_HIT_DTYPE).reshape(nq, stride)
@@ -847,6 +878,8 @@ def main():
     ap.add_argument("--nucl-read-len", type=int, default=10000)
     ap.add_argument("--headline-only", action="store_true", help="counter passes (scripts/collect_profiles.sh): the timed steps only")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--mask", type=int, default=1, choices=[0, 1],
+                    help="1 (mmseqs' default): the targets are tantan-masked for the prefilter on the device (mmgpu_pf_mask_targets), the alignment reads them unmasked")
     ap.add_argument("--no-modules", action="store_true", help="skip the stock-vs-patched `mmseqs prefilter` / `align` wall times")
     ap.add_argument("--module-timeout", type=float, default=240.0)
     args = ap.parse_args()
@@ -923,9 +956,10 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak" if H["weak"] else "strong", "vs_baseline": None, "dtype": "int16", "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[%d]: %d queries x %d targets (%d families x %d members, L~LogNormal(5.45,0.6)), "
-                                   "-s 5.7 (k=6 spaced, k-mer threshold %d), --max-seqs %d, --mask 0, then Gotoh SW of every hit list "
+                                   "-s 5.7 (k=6 spaced, k-mer threshold %d), --max-seqs %d, --mask %d%s, then Gotoh SW of every hit list "
                                    "(BLOSUM62 11/1, comp-bias on): score + end positions, start positions for pairs passing -e 1e-3"
-                                   % (3 if world > 1 else 2, nq, H["n_global"], args.pf_families, args.pf_members, H["kmer_thr"], H["max_res"]),
+                                   % (3 if world > 1 else 2, nq, H["n_global"], args.pf_families, args.pf_members, H["kmer_thr"], H["max_res"], H["mask"],
+                                      " (tantan on the device: %d residues masked in %.3f s, set-up)" % (H["n_masked"], H["t_mask"]) if H["mask"] else ""),
                        "step": "prefilter kernels -> device-side hand-over -> alignment kernels (fused path)" if not H["sharded"] else
                                "prefilter of the shard -> all-gather of exchange records -> merge (== unsplit result) -> alignment of owned pairs -> all-gather of results",
                        "value_is": "forward DP cells of the step / alignment-stage time of the step (HIP events); queries_per_s = queries / whole step",
