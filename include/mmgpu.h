@@ -284,6 +284,10 @@ int mmgpu_nucl_align(mmgpu_ctx *ctx, const mmgpu_nucl_params *params, const mmgp
 /* ScoreMatrix of all span-mers over the first kalph = alphabet-1 letters (ExtendedSubstitutionMatrix.cpp:20-71):
  * score/index are [n][n], n = kalph^span, rows sorted by descending score, ties in enumeration order. */
 int mmgpu_host_score_matrix(const int16_t *submat, int alphabet, int span, int16_t *score, uint32_t *index);
+/* the same into rows of row_stride elements (ScoreMatrix::rowSize, ExtendedSubstitutionMatrix.cpp:24-25); the padding elements
+ * behind each row are left to the caller.  What the patched Prefiltering constructor calls in place of calcScoreMatrix: a stable
+ * counting sort per row instead of std::stable_sort (0.45 s -> 0.05 s for the 8000 x 8000 3-mer table on 32 threads). */
+int mmgpu_host_score_matrix_rows(const int16_t *submat, int alphabet, int span, size_t row_stride, int16_t *score, uint32_t *index);
 /* IndexTable over numeric targets, masking off (IndexTable.h:135-191,350-403; IndexBuilder.cpp:118-166,226-270):
  * one entry (seqId, first position) per distinct k-mer of a target whose window has no X and whose self score
  * is >= kmer_thr.  offsets has (alphabet-1)^k + 1 elements.  Call with ids == pos == NULL to get the entry
@@ -321,6 +325,10 @@ int mmgpu_pf_load_index(mmgpu_ctx *ctx, const mmgpu_pf_index *index);
  * matrix (short, alphabet x alphabet), kmer_thr the k-mer threshold that also gates which target k-mers are indexed
  * (IndexTable.h:146-154). */
 int mmgpu_pf_build_index(mmgpu_ctx *ctx, const mmgpu_pf_index *tables, const int16_t *kmer_submat, int kmer_thr);
+/* optional: loads the kernels' code objects now instead of at their first launch (0.1 - 0.2 s otherwise paid inside the first
+ * prefilter block / alignment batch of a process); thread-safe with respect to other calls on the context */
+int mmgpu_warmup(mmgpu_ctx *ctx);
+
 /* tantan repeat masking of the resident targets, for the prefilter only (the masking step of IndexBuilder::fillDatabase,
  * IndexBuilder.cpp:148 -> Masker::maskSequence with maskTantan, Masker.cpp:14-57 -> tantan::maskSequences, lib/tantan/tantan.cpp
  * :469-487, maxRepeatOffset 50, repeatProb 0.005, repeatEndProb 0.05, decay 0.9, no gaps): call it after mmgpu_load_targets with

@@ -96,7 +96,7 @@ int MMGpuFusedSearch::run(Parameters &par, const std::string &query, const std::
         EXIT(EXIT_FAILURE);
     }
     // the device is opened while the prefilter module parses, opens and masks the databases
-    std::thread opener([]() { MMGpuRun::context(); });
+    std::thread opener([]() { mmgpu_warmup(MMGpuRun::context()); });      // ... and the kernels' code objects loaded
     const bool onDisk = getenv("MMGPU_FUSED_PREF_ON_DISK") != NULL && getenv("MMGPU_FUSED_PREF_ON_DISK")[0] == '1';
     // Entries kept in memory: the module's DBWriter still creates its (then empty) database, and the alignment module's parameter
     // check wants to see it.  It gets a name blastp.sh does not know, so that a run that died half-way never leaves an empty

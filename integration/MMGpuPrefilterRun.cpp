@@ -27,6 +27,7 @@
 #include "Prefiltering.h"
 #include "QueryMatcher.h"
 #include "Util.h"
+#include "simd.h"
 
 #include "MMGpuFusedSearch.h"
 #include "MMGpuPrefilter.h"
@@ -78,6 +79,35 @@ bool MMGpuPrefilterRun::deviceBuildsIndex(Prefiltering &p) {
     const bool ok = usableConfig(p, false);
     if (ok) Debug(Debug::INFO) << "MMGPU: the k-mer index will be built on the device (MMGPU_HOST_INDEX=1 keeps the host's)\n";
     return ok;
+}
+
+ScoreMatrix MMGpuPrefilterRun::scoreMatrix(Prefiltering &p, const BaseMatrix &matrix, size_t kmerSize) {
+    if (!MMGpuRun::enabled() || p.templateDBIsIndex || (kmerSize != 2 && kmerSize != 3) || matrix.alphabetSize + 1 > 32 ||
+        (getenv("MMGPU_HOST_SCORE_MATRIX") != NULL && getenv("MMGPU_HOST_SCORE_MATRIX")[0] == '0'))
+        return p.getScoreMatrix(matrix, kmerSize);
+    // the caller took X out of the alphabet (Prefiltering.cpp:221): alphabetSize letters, subMatrix rows of the full matrix
+    const int ka = matrix.alphabetSize, a = ka + 1;
+    std::vector<int16_t> flat((size_t)a * a, 0);
+    for (int i = 0; i < ka; i++)
+        for (int j = 0; j < ka; j++) flat[(size_t)i * a + j] = (int16_t)matrix.subMatrix[i][j];
+    size_t size = 1;
+    for (size_t i = 0; i < kmerSize; i++) size *= (size_t)ka;
+    const size_t rowSize = (size / MAX_ALIGN_INT + 1) * MAX_ALIGN_INT;      // ExtendedSubstitutionMatrix.cpp:24-25
+    short *score = (short *)mem_align(MAX_ALIGN_INT, size * rowSize * sizeof(short));
+    unsigned int *index = (unsigned int *)mem_align(MAX_ALIGN_INT, size * rowSize * sizeof(unsigned int));
+    static_assert(sizeof(short) == sizeof(int16_t) && sizeof(unsigned int) == sizeof(uint32_t), "ScoreMatrix element types");
+    if (mmgpu_host_score_matrix_rows(flat.data(), a, (int)kmerSize, rowSize, reinterpret_cast<int16_t *>(score), reinterpret_cast<uint32_t *>(index)) != 0) {
+        free(score);
+        free(index);
+        return p.getScoreMatrix(matrix, kmerSize);
+    }
+#pragma omp parallel for schedule(static)
+    for (size_t r = 0; r < size; r++)
+        for (size_t z = size; z < rowSize; z++) {      // :50-53
+            score[r * rowSize + z] = -255;
+            index[r * rowSize + z] = 0;
+        }
+    return ScoreMatrix(score, index, size, rowSize);
 }
 
 bool MMGpuPrefilterRun::deviceMasks(Prefiltering &p) {

@@ -33,6 +33,8 @@
 
 #include "Debug.h"
 #include "Matcher.h"
+#include "ScoreMatrix.h"
+#include "BaseMatrix.h"
 #include "mmgpu.h"
 
 class Alignment;
@@ -85,6 +87,10 @@ public:
     // Prefiltering::getIndexTable asks before it builds the index: true = the device will build it from the masked
     // SequenceLookup (mmgpu_pf_build_index), the host only masks (IndexBuilder::fillDatabase without an index table);
     // MMGPU_HOST_INDEX=1 keeps the host's index
+    // Prefiltering's constructor: the score-sorted 2-mer / 3-mer tables (getScoreMatrix -> ExtendedSubstitutionMatrix::calcScoreMatrix,
+    // 0.45 s of every prefilter process for the 8000 x 8000 table) by the library's stable counting sort - the same table
+    // (mmgpu_host_score_matrix_rows); a precomputed index or a disabled device path keeps the reference's own function
+    static ScoreMatrix scoreMatrix(Prefiltering &p, const BaseMatrix &matrix, size_t kmerSize);
     static bool deviceBuildsIndex(Prefiltering &p);
     // ... and whether the device also does the masking fillDatabase would do (tantan only, one device): mmgpu_pf_mask_targets;
     // MMGPU_DEVICE_MASK=0 keeps the host's Masker

@@ -68,11 +68,11 @@ PF_OK, PF_OVERFLOW, PF_LONG_SEQ, PF_SAT_TIE, PF_SHARD_INEXACT = 0, 1, 2, 3, 4   
 
 # every symbol include/mmgpu.h declares (tests check the built library exports all of them)
 EXPORTED_SYMBOLS = [
-    "mmgpu_init", "mmgpu_destroy", "mmgpu_last_error", "mmgpu_set_stream", "mmgpu_synchronize",
+    "mmgpu_init", "mmgpu_warmup", "mmgpu_destroy", "mmgpu_last_error", "mmgpu_set_stream", "mmgpu_synchronize",
     "mmgpu_device_info", "mmgpu_device_memory", "mmgpu_host_comp_bias", "mmgpu_host_round_comp_bias", "mmgpu_host_comp_bias_batch", "mmgpu_load_targets", "mmgpu_sw_batch", "mmgpu_sw_prepare", "mmgpu_sw_run",
     "mmgpu_sw_fetch", "mmgpu_sw_batch_stats", "mmgpu_sw_last_kernel_ms", "mmgpu_sw_kernel_ms_mean", "mmgpu_sw_free",
     "mmgpu_sw_traceback", "mmgpu_sw_prepare_from_pf", "mmgpu_sw_fetch_device", "mmgpu_nucl_align",
-    "mmgpu_host_score_matrix", "mmgpu_host_index_build", "mmgpu_pf_load_index", "mmgpu_pf_batch", "mmgpu_pf_prepare",
+    "mmgpu_host_score_matrix", "mmgpu_host_score_matrix_rows", "mmgpu_host_index_build", "mmgpu_pf_load_index", "mmgpu_pf_batch", "mmgpu_pf_prepare",
     "mmgpu_pf_run", "mmgpu_pf_fetch", "mmgpu_pf_stage_ms", "mmgpu_pf_last_cells", "mmgpu_pf_fetch_device", "mmgpu_pf_merge_splits", "mmgpu_pf_build_index", "mmgpu_pf_mask_targets", "mmgpu_pf_debug_masked_targets", "mmgpu_pf_debug_index", "mmgpu_pf_debug_fetch", "mmgpu_pf_free",
     "mmgpu_host_partition_targets", "mmgpu_pf_set_shard", "mmgpu_pf_fetch_exchange", "mmgpu_pf_merge_exchange",
     "mmgpu_pf_localize_lists", "mmgpu_sw_prepare_from_lists",

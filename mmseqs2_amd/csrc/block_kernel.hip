@@ -516,4 +516,10 @@ hipError_t launch_sw_block(const BlockLaunch &L, int tier, hipStream_t stream) {
     return hipGetLastError();
 }
 
+// first use of any kernel of this file loads its code object (tens of milliseconds): mmgpu_warmup does it ahead of time
+void warm_block() {
+    hipFuncAttributes a;
+    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&(sw_block_kernel<BLOCK_MAX_SIZE, true>)));
+}
+
 }  // namespace mmgpu

@@ -251,4 +251,10 @@ hipError_t launch_sw_traceback_wave(const BtLaunch &L, hipStream_t stream) {
     return hipGetLastError();
 }
 
+// first use of any kernel of this file loads its code object (tens of milliseconds): mmgpu_warmup does it ahead of time
+void warm_bt() {
+    hipFuncAttributes a;
+    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&sw_traceback_wave_kernel));
+}
+
 }  // namespace mmgpu

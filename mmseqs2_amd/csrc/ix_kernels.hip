@@ -131,4 +131,10 @@ hipError_t launch_ix_sort_long(const IxSortArgs &A, uint32_t n_long, hipStream_t
     return hipGetLastError();
 }
 
+// first use of any kernel of this file loads its code object (tens of milliseconds): mmgpu_warmup does it ahead of time
+void warm_ix() {
+    hipFuncAttributes a;
+    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&ix_target_kernel<true>));
+}
+
 }  // namespace mmgpu

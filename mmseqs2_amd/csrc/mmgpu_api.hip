@@ -154,6 +154,22 @@ extern "C" int mmgpu_load_targets(mmgpu_ctx *c, const uint8_t *residues, const u
     return MMGPU_OK;
 }
 
+// Loads the code objects of the hot kernels now instead of at their first launch (the runtime loads a translation unit's code
+// object lazily: 0.1 - 0.2 s in total, paid inside the first prefilter block and the first alignment batch of a process).  A
+// caller that has something else to do meanwhile - the fused search masks / reads its databases on the host - calls this on a
+// helper thread right after mmgpu_init.
+extern "C" int mmgpu_warmup(mmgpu_ctx *c) {
+    if (!c) return fail(MMGPU_ERR_ARG, "mmgpu_warmup: NULL context");
+    HIP_TRY(hipSetDevice(c->device));
+    mmgpu::warm_tantan();
+    mmgpu::warm_ix();
+    mmgpu::warm_pf();
+    mmgpu::warm_sw();
+    mmgpu::warm_block();
+    mmgpu::warm_bt();
+    return MMGPU_OK;
+}
+
 // tantan masking of the resident targets for the prefilter (tantan_kernel.hip): what IndexBuilder::fillDatabase does to every
 // target before it counts k-mers (IndexBuilder.cpp:148, Masker.cpp:14-57 with maskTantan only).  The alignment kernels keep
 // reading the unmasked residues.

@@ -435,6 +435,13 @@ struct TantanArgs {
     unsigned long long *n_masked;
 };
 hipError_t launch_tantan_mask(const TantanArgs &A, hipStream_t s);
+// code-object loading ahead of the first launch (mmgpu_warmup)
+void warm_sw();
+void warm_block();
+void warm_pf();
+void warm_ix();
+void warm_tantan();
+void warm_bt();
 hipError_t launch_ix_sort_short(const IxSortArgs &A, hipStream_t s);
 hipError_t launch_ix_sort_long(const IxSortArgs &A, uint32_t n_long, hipStream_t s);
 

@@ -89,11 +89,19 @@ static int window_pattern(int k, int spaced, uint8_t *pat) {     // k in [4, 15]
 // every span-mer by descending score; the reference uses std::stable_sort over the cartesian-product enumeration
 // (first residue slowest, :103-128).  Scores are small integers, so a stable counting sort per row does the same.
 extern "C" int mmgpu_host_score_matrix(const int16_t *submat, int alphabet, int span, int16_t *score, uint32_t *index) {
+    return mmgpu_host_score_matrix_rows(submat, alphabet, span, 0, score, index);
+}
+
+// the same into rows of row_stride elements (ScoreMatrix::rowSize: the reference pads its rows for SIMD loads, :24-25; the
+// padding elements are the caller's); row_stride 0 = (alphabet - 1)^span, no padding
+extern "C" int mmgpu_host_score_matrix_rows(const int16_t *submat, int alphabet, int span, size_t row_stride, int16_t *score, uint32_t *index) {
     if (!submat || !score || !index) return fail(MMGPU_ERR_ARG, "mmgpu_host_score_matrix: NULL argument");
     if (alphabet < 3 || alphabet > 32 || span < 1 || span > 3) return fail(MMGPU_ERR_ARG, "mmgpu_host_score_matrix: bad alphabet/span");
     const int ka = alphabet - 1;
     size_t n = 1;
     for (int i = 0; i < span; i++) n *= (size_t)ka;
+    const size_t stride = row_stride ? row_stride : n;
+    if (stride < n) return fail(MMGPU_ERR_ARG, "mmgpu_host_score_matrix_rows: row_stride smaller than the row");
     // enumeration e -> (index in int2index order, residues)
     std::vector<uint32_t> e2idx(n);
     std::vector<uint8_t> e2res(n * (size_t)span);
@@ -131,8 +139,8 @@ extern "C" int mmgpu_host_score_matrix(const int16_t *submat, int alphabet, int 
                 cursor[(size_t)(smax - s) + 1]++;   // bucket 0 = highest score
             }
             for (int z = 0; z < range; z++) cursor[(size_t)z + 1] += cursor[z];
-            int16_t *srow = score + (size_t)e2idx[e] * n;
-            uint32_t *irow = index + (size_t)e2idx[e] * n;
+            int16_t *srow = score + (size_t)e2idx[e] * stride;
+            uint32_t *irow = index + (size_t)e2idx[e] * stride;
             for (size_t f = 0; f < n; f++) {
                 const uint32_t o = cursor[(size_t)(smax - sc[f])]++;
                 srow[o] = sc[f];

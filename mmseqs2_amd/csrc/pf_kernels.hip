@@ -2265,4 +2265,10 @@ hipError_t launch_pf_select(const PfSelectArgs &A, uint32_t nq, hipStream_t s) {
     return hipGetLastError();
 }
 
+// first use of any kernel of this file loads its code object (tens of milliseconds): mmgpu_warmup does it ahead of time
+void warm_pf() {
+    hipFuncAttributes a;
+    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&pf_kmers_kernel<true>));
+}
+
 }  // namespace mmgpu

@@ -745,4 +745,10 @@ hipError_t launch_sw(const SwLaunch &L, int group, size_t lds_bytes, bool both_p
     return hipGetLastError();
 }
 
+// first use of any kernel of this file loads its code object (tens of milliseconds): mmgpu_warmup does it ahead of time
+void warm_sw() {
+    hipFuncAttributes a;
+    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&sw_rev_multi_kernel));
+}
+
 }  // namespace mmgpu

@@ -219,4 +219,10 @@ hipError_t launch_tantan_mask(const TantanArgs &A, hipStream_t s) {
     return hipGetLastError();
 }
 
+// first use of any kernel of this file loads its code object (tens of milliseconds): mmgpu_warmup does it ahead of time
+void warm_tantan() {
+    hipFuncAttributes a;
+    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&tantan_mask_kernel));
+}
+
 }  // namespace mmgpu
