@@ -125,6 +125,11 @@ void MMGpuPrefilterRun::ensureHostIndex(Prefiltering &p, size_t dbFrom, size_t d
     // IndexBuilder::fillDatabase as Prefiltering::getIndexTable calls it (:564-569); it also fills a second SequenceLookup,
     // which replaces the first (same content)
     Debug(Debug::INFO) << "MMGPU: building the host index for queries handed back by the device\n";
+    {   // getIndexTable created the table without its offset array (the device was going to build the index): a real one now
+        IndexTable *table = new IndexTable(p.indexTable->getAlphabetSize(), p.kmerSize, false);
+        delete p.indexTable;
+        p.indexTable = table;
+    }
     Sequence tseq(p.maxSeqLen, p.targetSeqType, p.kmerSubMat, p.kmerSize, p.spacedKmer, p.aaBiasCorrection, true, p.spacedKmerPattern);
     SequenceLookup *second = NULL;
     IndexBuilder::fillDatabase(p.indexTable, &second, *p.kmerSubMat, p._3merSubMatrix, p._2merSubMatrix, &tseq, p.tdbr, dbFrom,
