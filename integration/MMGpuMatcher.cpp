@@ -1,4 +1,7 @@
 #include "MMGpuMatcher.h"
+
+#include <memory>
+#include <mutex>
 #include "MMGpuRun.h"
 
 #include <algorithm>
@@ -49,7 +52,8 @@ struct Pending {
     bool blockDone;        // start / backtrace / identities came from the host's block aligner
     bool refuse;           // the pair is recomputed by the host's Matcher (profile query in block-aligner range)
     bool needsBlock;       // int16-range pair that passed the gates: waits for the device's block aligner
-    std::string blockBacktrace;
+    int32_t blockBt;       // index of the pair's block-aligner backtrace in the call's string store, -1 = none (a block of 10 000
+                           // queries holds 3 M of these records, one in twelve with a string: the record itself stays plain data)
     uint32_t blockBtLen;   // its length when the string itself was not fetched
 };
 }  // namespace
@@ -163,7 +167,11 @@ bool MMGpuMatcher::alignBlock(const std::vector<Query> &queries, int covMode, fl
     watch.lap("device alignment (prepare, run, fetch)");
     // ---- host part of ssw_align_private (StripedSmithWaterman.cpp:846-890) per pair; pairs that go on to the
     // backtrace are collected for one traceback call
-    std::vector<Pending> aln(total);
+    // (plain data, every field written by the gate loop below: no 400 MB of zero-fill and string destructors on one thread)
+    std::unique_ptr<Pending[]> alnStore(new Pending[total ? total : 1]);
+    Pending *aln = alnStore.get();
+    std::vector<std::string> btStore;      // block-aligner backtraces: host hook (rare, appended under a lock) + the device call's
+    std::mutex btLock;
 #pragma omp parallel for schedule(dynamic, 4) num_threads(nthreads)
     for (size_t q = 0; q < nq; q++) {
         unsigned int thread = 0;
@@ -187,6 +195,7 @@ bool MMGpuMatcher::alignBlock(const std::vector<Query> &queries, int covMode, fl
             a.dbStartPos1 = -1;
             a.word = h.word;
             pe.wantsBacktrace = false;
+            pe.blockBt = -1;
             pe.blockBtLen = 0;
             pe.blockDone = false;
             pe.needsBlock = false;
@@ -210,7 +219,12 @@ bool MMGpuMatcher::alignBlock(const std::vector<Query> &queries, int covMode, fl
                         std::string bt;
                         if (blockHook->run(thread, q, queries[q].numSequence, qlen, targetLookup(targetLookupCtx, tg.id), dbLen, b, bt)) {
                             pe.blockDone = true;
-                            pe.blockBacktrace.swap(bt);
+                            {
+                                std::lock_guard<std::mutex> g(btLock);
+                                pe.blockBt = (int32_t)btStore.size();
+                                btStore.push_back(std::string());
+                                btStore.back().swap(bt);
+                            }
                             a = b;
                         }
                     }
@@ -258,6 +272,8 @@ bool MMGpuMatcher::alignBlock(const std::vector<Query> &queries, int covMode, fl
                     p++;
                 }
             }
+        const size_t btBase = btStore.size();
+        btStore.resize(btBase + blkBlockPair.size());
 #pragma omp parallel for schedule(dynamic, 16) num_threads(nthreads)
         for (size_t k = 0; k < blkBlockPair.size(); k++) {
             unsigned int thread = 0;
@@ -277,7 +293,8 @@ bool MMGpuMatcher::alignBlock(const std::vector<Query> &queries, int covMode, fl
                 a.identicalAACnt = bk.ident;
                 a.qCov = SmithWaterman::computeCov(a.qStartPos1, a.qEndPos1, qlen);       // :1114-1115
                 a.tCov = SmithWaterman::computeCov(a.dbStartPos1, a.dbEndPos1, dbLen);
-                if (!blkStrings.empty()) pe.blockBacktrace.assign(blkStrings, (size_t)bk.bt_off, (size_t)bk.bt_len);
+                if (!blkStrings.empty()) btStore[btBase + k].assign(blkStrings, (size_t)bk.bt_off, (size_t)bk.bt_len);
+                pe.blockBt = (int32_t)(btBase + k);
                 pe.blockBtLen = bk.bt_len;
                 pe.blockDone = true;
                 continue;
@@ -288,7 +305,8 @@ bool MMGpuMatcher::alignBlock(const std::vector<Query> &queries, int covMode, fl
                 std::string bt;
                 if (blockHook->run(thread, q, queries[q].numSequence, qlen, targetLookup(targetLookupCtx, tg.id), dbLen, b, bt)) {
                     pe.blockDone = true;
-                    pe.blockBacktrace.swap(bt);
+                    btStore[btBase + k].swap(bt);
+                    pe.blockBt = (int32_t)(btBase + k);
                     a = b;
                     continue;
                 }
@@ -357,7 +375,7 @@ bool MMGpuMatcher::alignBlock(const std::vector<Query> &queries, int covMode, fl
                     refused = true;
                     refusedFlag[p] = 1;
                 } else if (aln[p].blockDone) {
-                    backtrace.swap(aln[p].blockBacktrace);
+                    if (aln[p].blockBt >= 0) backtrace.swap(btStore[(size_t)aln[p].blockBt]);
                     btLen = backtrace.empty() ? aln[p].blockBtLen : backtrace.size();
                 } else if (btOf[p] >= 0) {
                     const mmgpu_sw_bt &bi = btInfo[btOf[p]];
