@@ -381,6 +381,29 @@ def module_seconds(args, qres, qoff, tres, toff):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+def choose_query_groups(n_ranks, requested=0):
+    """G of the G x S layout (search_headline).  Model from the N = 1 stage times of the headline workload (ms per 10 000 queries x
+    1 M targets, profiles/r04_bench_n1.json): the similar-k-mer stage k is per query, everything else e scales with the index
+    entries / pairs a rank touches; a group's exchange costs x per step.  t(G, S) = k / G + e / (G * S) + x * (S > 1).  At least
+    two target shards per group whenever N >= 2: the hit-list exchange over RCCL is the path BASELINE.json configs[3] names."""
+    if requested > 0:
+        if n_ranks % requested:
+            raise SystemExit("--query-groups must divide --gpus")
+        return requested
+    k, e, x = 19.5, 152.8, 3.0
+    best, best_t = 1, None
+    for g in range(1, n_ranks + 1):
+        if n_ranks % g:
+            continue
+        s_ = n_ranks // g
+        if n_ranks >= 2 and s_ < 2:
+            continue
+        t = k / g + e / (g * s_) + (x if s_ > 1 else 0.0)
+        if best_t is None or t < best_t - 1e-9:
+            best, best_t = g, t
+    return best
+
+
 def search_headline(args, gpu, torch, dist, rank, world, matrices, barrier):
     """BASELINE.json configs[2] / configs[3]: the timed steps and everything derived from them."""
     from mmseqs2_amd import capi, evalue, workloads as wl
@@ -397,6 +420,26 @@ def search_headline(args, gpu, torch, dist, rank, world, matrices, barrier):
                                                              target_seed=(11 + 1000 * rank) if weak else None)
     t_gen = time.time() - t0
     qs = wl.split(qres, qoff)
+    nq_all = len(qs)
+    # ---- layout of an N-rank run: G query groups x S target shards (G * S = N) --------------------------------------------
+    # Sharding the targets divides everything that scales with index entries (gather / split, replay, scoring, alignment) by S,
+    # but not the similar-k-mer stage, which is per query (19.5 of the 172 ms of the N = 1 step): with S = N = 8 it is half of
+    # the step and the speed-up ends near 4x.  Dealing the QUERIES to G groups divides that stage as well; inside a group the
+    # database is dealt to S = N / G ranks by length bucket and the hit lists are exchanged over the group's own communicator -
+    # the exchange step of north_star, between fewer ranks.  Groups never talk to each other (different queries).
+    G = choose_query_groups(world, args.query_groups) if (sharded and not weak) else 1
+    S = world // G
+    group_index, group_rank = rank // S, rank % S
+    world_all, rank_all = world, rank
+    pg = None
+    if G > 1:
+        groups = [dist.new_group(list(range(g * S, (g + 1) * S))) for g in range(G)]      # (every rank creates every group)
+        pg = groups[group_index]
+        lo, hi = group_index * nq_all // G, (group_index + 1) * nq_all // G
+        qs = qs[lo:hi]
+        qoff_g = (qoff[lo:hi + 1] - qoff[lo]).astype(qoff.dtype)
+        qres, qoff = qres[int(qoff[lo]):int(qoff[hi])], qoff_g
+        world, rank = S, group_rank      # from here on: this rank's group
     nq = len(qs)
     n_local_gen = len(toff) - 1
     t0 = time.time()
@@ -429,10 +472,10 @@ def search_headline(args, gpu, torch, dist, rank, world, matrices, barrier):
                 idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
                 if rank == 0:
                     idt.copy_(torch.from_numpy(gpu.comm_unique_id()))
-                dist.broadcast(idt, 0)
+                dist.broadcast(idt, group_index * S, group=pg)      # the group's first rank made the id
                 gpu.comm_init_rank(idt.cpu().numpy(), rank, world)
                 lib_comm = True
-                comm_note = "library: RCCL communicator owned by libmmgpu (mmgpu_comm_init_rank), %d ranks" % world
+                comm_note = "library: RCCL communicator owned by libmmgpu (mmgpu_comm_init_rank), %d ranks per communicator, %d query group(s)" % (world, G)
             elif world == 1:
                 lib_comm = True         # a context without a communicator is its own single rank (device copies)
                 comm_note = "library: single rank, device copies"
@@ -508,12 +551,12 @@ def search_headline(args, gpu, torch, dist, rank, world, matrices, barrier):
                 keep["records_gathered"] = nrec
             b.free()
             return
-        mh_t, mc_t, mf_t = D.exchange_and_merge_device(gpu, pfb, nq, stride)
+        mh_t, mc_t, mf_t = D.exchange_and_merge_device(gpu, pfb, nq, stride, group=pg)
         b, lc, ls = D.align_owned_pairs(gpu, mat, 11, 1, msh, mh_t, mc_t, nq, stride, mode=1)
         b.run()
         b.fetch_device(res_t.data_ptr())
         a_ms = b.kernel_ms()
-        full = D.gather_owned_results(res_t, lc, ls, nq, stride)
+        full = D.gather_owned_results(res_t, lc, ls, nq, stride, group=pg)
         if record:
             stat["pf_ms"].append(pfb.stage_ms()[6])
             stat["align_ms"].append(a_ms)
@@ -541,13 +584,14 @@ def search_headline(args, gpu, torch, dist, rank, world, matrices, barrier):
     # ---- per-stage counters of the prefilter (last pass) ----
     stage = np.array(pfb.stage_ms())
     pf_cells, pf_cands = pfb.last_cells()
-    out = {"elapsed_s": elapsed, "align_ms": align_ms, "pf_ms": pf_ms, "cells": cells, "pairs": pairs, "nq": nq,
+    out = {"elapsed_s": elapsed, "align_ms": align_ms, "pf_ms": pf_ms, "cells": cells, "pairs": pairs, "nq": nq_all,
+           "query_groups": G, "target_shards_per_group": S if sharded else 1,
            "n_global": n_global, "n_local": gpu.n_targets, "kmer_thr": kmer_thr, "max_res": max_res, "stage": stage,
            "pf_cells": pf_cells, "pf_cands": pf_cands, "t_gen": t_gen, "t_index": t_index, "weak": weak, "sharded": sharded,
            "thr_example": thr_of_len.get(len(qs[0])), "hbm_in_use_gb": round((mem_total - mem_free) / 2 ** 30, 1),
            "mask": int(args.mask), "t_mask": t_mask, "n_masked": int(n_masked),
            "collectives": comm_note if sharded else None}
-    if rank != 0:
+    if rank_all != 0:
         pfb.free()
         return out
 
@@ -864,6 +908,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
                     help="N > 1: strong = the same 1M targets dealt to the ranks (BASELINE.json configs[3]); weak = 1M targets per rank")
+    ap.add_argument("--query-groups", type=int, default=0,
+                    help="N > 1: G groups of ranks, each with its own slice of the queries; inside a group the targets are dealt to "
+                         "N / G ranks by length bucket and the hit lists exchanged over the group's RCCL communicator.  0 = chosen "
+                         "from the N = 1 stage times (the similar-k-mer stage does not shrink with the target shard), keeping at least "
+                         "two target shards per group")
     ap.add_argument("--pf-families", type=int, default=20000)
     ap.add_argument("--pf-members", type=int, default=50)
     ap.add_argument("--pf-queries", type=int, default=10000)
@@ -964,7 +1013,9 @@ def main():
                                "prefilter of the shard -> all-gather of exchange records -> merge (== unsplit result) -> alignment of owned pairs -> all-gather of results",
                        "value_is": "forward DP cells of the step / alignment-stage time of the step (HIP events); queries_per_s = queries / whole step",
                        "targets_per_gpu": int(H["n_local"]), "align_pairs_per_step": int(H["pairs"]), "align_cells_per_step": int(H["cells"]),
-                       "parallelism": "single GPU" if world == 1 else "1 process/GPU, targets dealt by length bucket, RCCL all-gather x2 per step",
+                       "parallelism": "single GPU" if world == 1 else
+                                      "1 process/GPU, %d query group(s) x %d target shards: queries dealt to the groups, inside a group the targets dealt by "
+                                      "length bucket and two RCCL all-gathers per step over the group's communicator" % (H.get("query_groups", 1), H.get("target_shards_per_group", world)),
                        "collectives": H.get("collectives")},
             "ms_per_step_stages": {"prefilter_kernels": round(H["pf_ms"], 2), "align_kernels": round(k_ms, 2),
                                    "handover_exchange_and_host": round(ms_per_step - H["pf_ms"] - k_ms, 2)},

@@ -215,3 +215,85 @@ def test_two_rank_unsplit_equal_path_plumbing():
         for pos, gid in enumerate(got[qi][0]):
             assert full[qi][pos][0] == gid * 3 + qi and full[qi][pos][1] == shard_of[gid] + 1
     assert modes == {0, 1}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Round 4: G query groups x S target shards (bench.py --query-groups; search_headline's layout).  Four ranks = 2 groups of 2
+# shards: every group merges ITS queries over ITS communicator (a torch.distributed sub-group here), the groups never talk to each
+# other, and what comes out must be the unsplit run's lists for all queries.
+def _worker_groups(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mmseqs2_amd import capi, distributed as D
+    n_groups, shards = 2, 2
+    groups = [dist.new_group(list(range(g * shards, (g + 1) * shards))) for g in range(n_groups)]      # every rank creates every group
+    gi, gr = rank // shards, rank % shards
+    lens = np.random.default_rng(1).integers(30, 4000, 500)
+    toff = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    shard_of, local_id, sizes, residues = capi.partition_targets(toff, shards)
+    nq_all = 8
+    mine = list(range(gi * nq_all // n_groups, (gi + 1) * nq_all // n_groups))      # this group's slice of the queries
+    rec = np.zeros((len(mine), 25), capi.PF_XHIT_DTYPE)
+    counts = np.zeros(len(mine), np.uint32)
+    for k, qi in enumerate(mine):
+        own = _query_truth(500, 9, qi)[shard_of == gr]
+        sel = capi.select_exchange_host(own, 25, 15, 4, 700 + qi)
+        rec[k][:len(sel)] = sel
+        counts[k] = len(sel)
+    merged = D.exchange_and_merge_host(rec, counts, 25, 15, 4, [700 + qi for qi in mine], group=groups[gi])
+    stride = 25
+    lres = torch.zeros((len(mine), stride, 6), dtype=torch.int32)
+    lcnt = torch.zeros((len(mine),), dtype=torch.int32)
+    lslot = torch.zeros((len(mine), stride), dtype=torch.int32)
+    for k, m in enumerate(merged):
+        n = 0
+        for pos, gid in enumerate(m["id"].tolist()):
+            if shard_of[gid] == gr:
+                lres[k, n, 0] = gid * 3 + mine[k]
+                lres[k, n, 1] = rank + 1
+                lslot[k, n] = pos
+                n += 1
+        lcnt[k] = n
+    full = D.gather_owned_results(lres, lcnt, lslot, len(mine), stride, group=groups[gi])
+    if gr == 0:      # one report per group
+        q.put((gi, mine, [(m["id"].tolist(), m["score"].tolist()) for m in merged], full.numpy().tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_four_ranks_as_two_query_groups_of_two_target_shards():
+    from mmseqs2_amd import capi
+    world = 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker_groups, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    reports = [q.get(timeout=600) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    lens = np.random.default_rng(1).integers(30, 4000, 500)
+    toff = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    shard_of, _, _, _ = capi.partition_targets(toff, 2)
+    seen = []
+    for gi, mine, got, full in reports:
+        for k, qi in enumerate(mine):
+            whole = capi.merge_exchange_host(_query_truth(500, 9, qi), 25, 15, 4, 700 + qi)      # the unsplit run's list
+            assert got[k][0] == whole["id"].tolist() and got[k][1] == whole["score"].tolist(), (gi, qi)
+            for pos, gid in enumerate(got[k][0]):      # every slot filled by the rank of THIS group that owns the target
+                assert full[k][pos][0] == gid * 3 + qi and full[k][pos][1] == gi * 2 + shard_of[gid] + 1
+            seen.append(qi)
+    assert sorted(seen) == list(range(8))
+
+
+def test_query_group_chooser_keeps_target_shards_and_follows_the_stage_model():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    assert [b.choose_query_groups(n) for n in (1, 2, 4, 8)] == [1, 1, 2, 4]
+    assert b.choose_query_groups(8, 2) == 2 and b.choose_query_groups(8, 8) == 8

@@ -280,6 +280,52 @@ def test_multi_context_run_equals_unsplit_run(gpu, matrices, world, max_hits):
         assert not res_s[qi]["score"][n:].any()
 
 
+def test_two_query_groups_of_two_target_shards_equal_the_unsplit_run(gpu, matrices):
+    """Round 4 layout (bench.py --query-groups): G = 2 groups x S = 2 target shards on four contexts of the one GPU.  Each group is
+    an mmgpu_multi of two contexts (its own communicator, here the copy transport) that holds the whole database dealt by length
+    bucket and runs HALF of the queries; together they must give the unsplit run's lists and alignment records for all queries."""
+    g = pc.golden()
+    thr = int(g["kmer_thr"])
+    qs, tres, toff = _case(123, 150, 60, 40)
+    km16, um8, s3, i3 = _tables(gpu, g)
+    queries = [dict(q=q, comp_bias=capi.host_comp_bias(km16, g["vtml80_pback"], q, lib=gpu.L)[0], identity_id=None) for q in qs]
+    swq = _sw_queries(g, matrices, qs, gpu.L)
+    mat = matrices["blosum62_sw"]
+    gpu.load_targets(tres, toff, 21)
+    gpu.pf_build_index(6, 21, True, s3, i3, km16, thr, um8)
+    b = gpu.pf_prepare(queries, thr, max_hits=100, ref_bins=2)
+    b.run()
+    fb = gpu.sw_prepare_from_pf(mat, 11, 1, swq, b, mode=1)
+    fb.run()
+    res_u = fb.fetch().reshape(len(qs), b.max_hits)
+    hits_u, counts_u, status_u, _ = b.fetch()
+    fb.free()
+    b.free()
+    assert np.all(status_u == 0)
+    half = len(qs) // 2
+    groups = [capi.MMGpuMulti([0, 0]), capi.MMGpuMulti([0, 0])]
+    try:
+        for gi, m in enumerate(groups):
+            lo, hi = (0, half) if gi == 0 else (half, len(qs))
+            m.load_targets(tres, toff, 21)
+            m.pf_build_index(6, 21, True, s3, i3, km16, thr, um8)
+            mb = m.pf_prepare(queries[lo:hi], thr, max_hits=100, ref_bins=2)
+            m.pf_run(mb)
+            hits_s, counts_s, status_s = m.pf_fetch(mb, hi - lo)
+            res_s, _, _ = m.sw_from_pf(mat, 11, 1, swq[lo:hi], mb, hi - lo, mode=1)
+            m.pf_free(mb)
+            assert np.all(status_s == 0) and np.array_equal(counts_s, counts_u[lo:hi])
+            for k in range(hi - lo):
+                n = int(counts_s[k])
+                for f in ("id", "score", "diagonal"):
+                    assert np.array_equal(hits_s[k][f][:n], hits_u[lo + k][f][:n]), (gi, k, f)
+                for f in ("score", "q_end", "t_end", "q_start", "t_start", "word"):
+                    assert np.array_equal(res_s[k][f][:n], res_u[lo + k][f][:n]), (gi, k, f)
+    finally:
+        for m in groups:
+            m.close()
+
+
 def test_queries_a_shard_declines_on_the_host_are_reported_not_silently_short(gpu):
     """MMGPU_PF_LONG_SEQ is decided by mmgpu_pf_run on the HOST of each shard (a query of 32768 residues or more) -
     such a query contributes no exchange records, and the merged flag word used to stay clear: the sharded fetch then returned an
