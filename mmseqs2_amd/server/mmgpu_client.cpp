@@ -22,6 +22,7 @@ struct mmgpu_ctx {
     int cus;
     std::string name;
     uint64_t targets_fp;
+    uint64_t mask_fp;      // 0 = the prefilter reads the targets as loaded; else the tantan parameters they were masked with
 };
 struct mmgpu_sw_batch_t {
     uint64_t handle;
@@ -113,6 +114,7 @@ int mmgpu_load_targets(mmgpu_ctx *c, const uint8_t *res, const uint64_t *off, ui
     uint64_t fp = fingerprint(off, ((size_t)n + 1) * 8, 0x7461726765747321ull ^ (uint64_t)alphabet);
     fp = fingerprint(res, (size_t)off[n], fp);
     c->targets_fp = fp;
+    c->mask_fp = 0;
     Buf q, r;
     q.put<uint64_t>(fp);
     q.put<uint32_t>(n);
@@ -123,6 +125,35 @@ int mmgpu_load_targets(mmgpu_ctx *c, const uint8_t *res, const uint64_t *off, ui
     q.put_bytes(off, ((size_t)n + 1) * 8);
     q.put_bytes(res, (size_t)off[n]);
     return call(c, OP_LOAD_TARGETS, q, nullptr);
+}
+
+// tantan masking of the resident targets for the prefilter: the server remembers with which parameters a slot's targets are
+// masked, a client that asks for the same again (the next `mmseqs prefilter` of the same database) finds it done
+int mmgpu_pf_mask_targets(mmgpu_ctx *c, const double *lr, int alphabet, double min_mask_prob, int mask_letter, uint64_t *n_masked) {
+    if (!c || !lr || alphabet < 1 || alphabet > 64) return fail(MMGPU_ERR_ARG, "mmgpu_pf_mask_targets: bad argument");
+    uint64_t fp = fingerprint(lr, (size_t)alphabet * alphabet * 8, 0x74616E74616E2121ull ^ (uint64_t)mask_letter);
+    fp = fingerprint(&min_mask_prob, 8, fp) | 1ull;
+    Buf q, r;
+    q.put<uint64_t>(fp);
+    q.put<int32_t>(alphabet);
+    q.put<int32_t>(mask_letter);
+    q.put_bytes(&min_mask_prob, 8);
+    q.put_bytes(lr, (size_t)alphabet * alphabet * 8);
+    const int rc = call(c, OP_MASK_TARGETS, q, &r);
+    if (rc != MMGPU_OK) return rc;
+    c->mask_fp = fp;
+    const uint64_t masked = r.get<uint64_t>();
+    if (n_masked) *n_masked = masked;
+    return MMGPU_OK;
+}
+
+// nothing to load on this side of the socket
+int mmgpu_warmup(mmgpu_ctx *) { return MMGPU_OK; }
+
+int mmgpu_sw_block_tiers(const mmgpu_sw_batch_t *, uint32_t *first_tier, uint32_t *second_tier) {
+    if (first_tier) *first_tier = 0;
+    if (second_tier) *second_tier = 0;
+    return MMGPU_OK;
 }
 
 int mmgpu_pf_load_index(mmgpu_ctx *c, const mmgpu_pf_index *ix) {
@@ -179,7 +210,7 @@ int mmgpu_pf_build_index(mmgpu_ctx *c, const mmgpu_pf_index *ix, const int16_t *
     const size_t kalph = (size_t)ix->alphabet - 1;
     const size_t n3 = kalph * kalph * kalph, n2 = kalph * kalph, a2 = (size_t)ix->alphabet * ix->alphabet;
     const bool three = ix->score3 && ix->index3, two = ix->score2 && ix->index2;
-    uint64_t fp = c->targets_fp ^ 0x6275696C64212121ull;
+    uint64_t fp = c->targets_fp ^ 0x6275696C64212121ull ^ c->mask_fp;      // (an index over masked targets is another index)
     const int32_t scal[6] = {ix->kmer_size, ix->alphabet, ix->spaced, three ? 1 : 0, two ? 1 : 0, kmer_thr};
     fp = fingerprint(scal, sizeof(scal), fp);
     if (three) fp = fingerprint(ix->score3, n3 * ix->row3 * 2, fp);
@@ -346,7 +377,7 @@ int mmgpu_sw_block_backtrace(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const uint32_t *
     if (!b || (!idx && n) || (!out && n)) return fail(MMGPU_ERR_ARG, "mmgpu_sw_block_backtrace: NULL argument");
     Buf q, r;
     q.put<uint64_t>(b->handle);
-    q.put<uint64_t>(bt ? (uint64_t)cap : 0ull);
+    q.put<uint64_t>(bt ? (uint64_t)cap : (cap == MMGPU_BLOCK_NO_STRINGS ? ~0ull : 0ull));      // all ones: no strings wanted
     q.put_bytes(idx, (size_t)n * 4);
     WireHdr h;
     if (!c || c->fd < 0 || !send_msg(c->fd, OP_SW_BLOCK_BACKTRACE, 0, q.d.data(), q.d.size()) || !recv_msg(c->fd, &h, &r))

@@ -47,7 +47,7 @@ struct SwRec {
 // sequences), so a search keeps two slots busy; slots are reused least-recently-used first.
 struct Slot {
     mmgpu_ctx *ctx = nullptr;
-    uint64_t targets_fp = 0, index_fp = 0;
+    uint64_t targets_fp = 0, index_fp = 0, mask_fp = 0;      // mask_fp: tantan parameters the prefilter's view is masked with (0: none)
     bool have_targets = false, have_index = false;
     uint64_t last_use = 0;
 };
@@ -143,6 +143,7 @@ bool handle(Server &S, int fd, const WireHdr &h, Buf &in) {
             S.cur = pick;
             S.ctx = sl.ctx;
             sl.have_targets = sl.have_index = false;      // mmgpu_load_targets drops the index of the previous database
+            sl.mask_fp = 0;
             const int rc = mmgpu_load_targets(S.ctx, res, o.data(), n, alphabet);
             if (rc == MMGPU_OK) {
                 sl.have_targets = true;
@@ -151,6 +152,32 @@ bool handle(Server &S, int fd, const WireHdr &h, Buf &in) {
                 S.st.target_uploads++;
             }
             return reply(fd, h.op, rc, out);
+        }
+        case OP_MASK_TARGETS: {
+            const uint64_t fp = in.get<uint64_t>();
+            const int32_t alphabet = in.get<int32_t>();
+            const int32_t mask_letter = in.get<int32_t>();
+            size_t nb = 0, nl = 0;
+            const uint8_t *pp = in.get_bytes(&nb);
+            const uint8_t *lp = in.get_bytes(&nl);
+            if (in.bad || nb != 8 || alphabet < 1 || alphabet > 64 || nl != (size_t)alphabet * alphabet * 8)
+                return reply_err(fd, h.op, MMGPU_ERR_ARG, "mmgpu_server: malformed MASK_TARGETS");
+            Slot &sl = S.slots[S.cur];
+            if (!sl.have_targets) return reply_err(fd, h.op, MMGPU_ERR_STATE, "mmgpu_server: MASK_TARGETS without targets");
+            uint64_t masked = 0;
+            if (sl.mask_fp != fp) {      // (masked like this already: the index over it stays as well)
+                double prob;
+                memcpy(&prob, pp, 8);
+                std::vector<double> lr((size_t)alphabet * alphabet);
+                memcpy(lr.data(), lp, nl);
+                drop_batches(S);
+                sl.have_index = false;      // mmgpu_pf_mask_targets frees the index
+                const int rc = mmgpu_pf_mask_targets(S.ctx, lr.data(), alphabet, prob, mask_letter, &masked);
+                if (rc != MMGPU_OK) return reply_err(fd, h.op, rc, mmgpu_last_error());
+                sl.mask_fp = fp;
+            }
+            out.put<uint64_t>(masked);
+            return reply(fd, h.op, MMGPU_OK, out);
         }
         case OP_HAS_INDEX: {
             const uint64_t fp = in.get<uint64_t>();
@@ -368,17 +395,20 @@ bool handle(Server &S, int fd, const WireHdr &h, Buf &in) {
             const uint8_t *ip = in.get_bytes(&n);
             std::vector<uint32_t> idx(n / 4);
             if (n) memcpy(idx.data(), ip, n);
-            if (in.bad || cap > MMGPU_WIRE_MAX_MSG) return reply_err(fd, h.op, MMGPU_ERR_ARG, "mmgpu_server: malformed SW_TRACEBACK");
+            const bool no_strings = h.op == OP_SW_BLOCK_BACKTRACE && cap == ~0ull;      // MMGPU_BLOCK_NO_STRINGS on the client side
+            if (in.bad || (!no_strings && cap > MMGPU_WIRE_MAX_MSG)) return reply_err(fd, h.op, MMGPU_ERR_ARG, "mmgpu_server: malformed SW_TRACEBACK");
             if (h.op == OP_SW_BLOCK_BACKTRACE) {
                 std::vector<mmgpu_sw_block> blk(idx.size());
-                std::vector<char> bts((size_t)cap);
+                std::vector<char> bts(no_strings ? 0 : (size_t)cap);
                 size_t used_b = 0;
-                const int rcb = mmgpu_sw_block_backtrace(S.ctx, it->second.b, idx.data(), (uint32_t)idx.size(), blk.data(), cap ? bts.data() : nullptr,
-                                                         (size_t)cap, &used_b);
+                const int rcb = no_strings ? mmgpu_sw_block_backtrace(S.ctx, it->second.b, idx.data(), (uint32_t)idx.size(), blk.data(), nullptr,
+                                                                      MMGPU_BLOCK_NO_STRINGS, &used_b)
+                                           : mmgpu_sw_block_backtrace(S.ctx, it->second.b, idx.data(), (uint32_t)idx.size(), blk.data(),
+                                                                      cap ? bts.data() : nullptr, (size_t)cap, &used_b);
                 out.put<int32_t>(rcb);
                 out.put<uint64_t>((uint64_t)used_b);
                 out.put_bytes(blk.data(), blk.size() * sizeof(mmgpu_sw_block));
-                out.put_bytes(bts.data(), rcb == MMGPU_OK ? std::min<size_t>(used_b, (size_t)cap) : 0);
+                out.put_bytes(bts.data(), (rcb == MMGPU_OK && !no_strings) ? std::min<size_t>(used_b, (size_t)cap) : 0);
                 const char *eb = rcb == MMGPU_OK ? "" : mmgpu_last_error();
                 out.put_bytes(eb, strlen(eb));
                 return reply(fd, h.op, MMGPU_OK, out);

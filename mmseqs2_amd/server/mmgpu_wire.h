@@ -31,7 +31,8 @@ enum Op : uint32_t {
     OP_PF_PREPARE, OP_PF_RUN, OP_PF_FETCH, OP_PF_FREE,
     OP_SW_PREPARE, OP_SW_RUN, OP_SW_FETCH, OP_SW_TRACEBACK, OP_SW_FREE,
     OP_BUILD_INDEX, OP_STATS, OP_SHUTDOWN,
-    OP_SW_BLOCK_BACKTRACE      // appended: the ops above keep their numbers
+    OP_SW_BLOCK_BACKTRACE,     // appended: the ops above keep their numbers
+    OP_MASK_TARGETS            // round 4: mmgpu_pf_mask_targets (tantan on the device)
 };
 
 struct WireHdr {
