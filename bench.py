@@ -41,7 +41,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 # packed-int16 (VOP3P) VALU ops issue at 16 lanes/clk/SIMD on gfx950: measured 38.1 Tlane-op/s for v_pk_max_i16 /
 # v_pk_sub_u16 / v_perm_b32 (profiles/r01_valu_issue_rate_probe.txt) = 256 CU x 4 SIMD x 16 lanes x 2.4 GHz = 39.3e12
 VALU_LANE_OPS_PER_S = 256 * 4 * 16 * 2.4e9
-PROFILE_ROUND = "r03"
+PROFILE_ROUND = "r04"
 
 
 def allreduce(torch, dist, values, op="sum"):
@@ -760,7 +760,8 @@ def align_only_section(args, gpu, torch, matrices, rank):
 def nucl_section(args, gpu, matrices, rank):
     """BASELINE.json configs[4], the nucleotide alignment step (BandedNucleotideAligner::align behind Alignment::run):
     reads with 10 % substitutions / 2 % indels against their source contigs (true prefilter diagonal, both strands)
-    plus unrelated contigs.  The prefilter side of the nucleotide search is not built (lists synthetic)."""
+    plus unrelated contigs.  The lists of this section are synthetic (the nucleotide k-mer prefilter runs in the drop-in
+    tests, tests/test_mmseqs_dropin.py, not here)."""
     from mmseqs2_amd import workloads as wl
     t0 = time.time()
     queries, (tres, toff), pairs = wl.config5_nucleotide(args.nucl_contigs, args.nucl_reads, args.nucl_read_len, seed=20 + 1000 * rank)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs on the GPU box (gpurun -- 'bash scripts/collect_profiles.sh'): the rocprofv3 passes behind profiles/.
 # Kernel trace and every PMC counter in its own run (counters are never combined with other trace domains).
-# Summaries land in gpurun_out/profiles_new/ ; copy the ones to be judged into profiles/ (prefix r03_).
+# Summaries land in gpurun_out/profiles_new/ ; copy the ones to be judged into profiles/ (prefix r04_).
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/profiles_new
 mkdir -p $OUT
