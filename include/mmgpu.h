@@ -536,6 +536,10 @@ mmgpu_ctx *mmgpu_multi_ctx(mmgpu_multi *multi, int i);      /* context of shard 
 int mmgpu_multi_synchronize(mmgpu_multi *multi);
 /* the database dealt to the contexts by length bucket (mmgpu_host_partition_targets), shard descriptions set */
 int mmgpu_multi_load_targets(mmgpu_multi *multi, const uint8_t *residues, const uint64_t *offsets, uint32_t n, int alphabet);
+/* tantan masking of every shard's resident targets (mmgpu_pf_mask_targets per context; n_masked = the sum): between
+ * mmgpu_multi_load_targets and mmgpu_multi_pf_build_index */
+int mmgpu_multi_pf_mask_targets(mmgpu_multi *multi, const double *likelihood_ratios, int alphabet, double min_mask_prob,
+                                int mask_letter, uint64_t *n_masked /* may be NULL */);
 /* every shard's k-mer index built on its device (mmgpu_pf_build_index) */
 int mmgpu_multi_pf_build_index(mmgpu_multi *multi, const mmgpu_pf_index *index, const int16_t *kmer_submat, int kmer_thr);
 /* One prefilter batch over all shards whose merged lists EQUAL the unsplit run's.  queries[i].identity_id is the GLOBAL id.

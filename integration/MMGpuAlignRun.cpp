@@ -90,7 +90,7 @@ MMGpuAlignSession *MMGpuAlignRun::begin(Alignment &al, EvalueComputation &evalue
     // copy included (the same Sequence::numSequence, the same ids: checked key by key)
     bool residentAlready = false;
     std::vector<mmgpu_ctx *> devices;
-    if (!s->nucleotide && MMGpuRun::multi() == NULL && MMGpuFusedSearch::residentTargets(al.tdbr, s->gpu, &s->tData, &s->tOff)) {
+    if (!s->nucleotide && MMGpuRun::deviceIds().empty() && MMGpuFusedSearch::residentTargets(al.tdbr, s->gpu, &s->tData, &s->tOff)) {
         residentAlready = true;
         devices.push_back(s->gpu);
         s->watch.lap("targets already resident (fused search)");
@@ -139,9 +139,7 @@ MMGpuAlignSession *MMGpuAlignRun::begin(Alignment &al, EvalueComputation &evalue
         }
         s->watch.lap("map targets");
         // MMGPU_DEVICES: every device holds the targets, the queries of a bucket are dealt to them (MMGpuMultiDeviceBackend)
-        if (!s->nucleotide)
-            if (mmgpu_multi *multi = MMGpuRun::multi())
-                for (int d = 0; d < mmgpu_multi_size(multi); d++) devices.push_back(mmgpu_multi_ctx(multi, d));
+        if (!s->nucleotide) devices = MMGpuRun::allContexts();
         if (devices.empty()) devices.push_back(s->gpu);
         for (size_t d = 0; d < devices.size(); d++)
             if (mmgpu_load_targets(devices[d], s->targetResidues.data(), s->targetOffsets.data(), (uint32_t)nTargets, al.m->alphabetSize) != 0) {

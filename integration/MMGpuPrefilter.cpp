@@ -64,7 +64,7 @@ bool MMGpuPrefilter::loadIndex(IndexTable *indexTable, SequenceLookup *sequenceL
 }
 
 bool MMGpuPrefilter::buildIndex(SequenceLookup *sequenceLookup, int kmerSize, int indexKmerThr, ScoreMatrix &threeMer,
-                                ScoreMatrix &twoMer, bool spacedKmer, bool maskOnDevice, double maskProb) {
+                                ScoreMatrix &twoMer, bool spacedKmer, bool maskOnDevice, double maskProb, bool logMasked) {
     const size_t n = sequenceLookup->getSequenceCount();
     static_assert(sizeof(size_t) == sizeof(uint64_t), "SequenceLookup::getOffsets() is handed over as it is");
     const uint8_t *res = reinterpret_cast<const uint8_t *>(sequenceLookup->getData());
@@ -77,21 +77,19 @@ bool MMGpuPrefilter::buildIndex(SequenceLookup *sequenceLookup, int kmerSize, in
     dbSize = n;
     if (maskOnDevice) {
         // Masker's likelihood ratios (ProbabilityMatrix over the k-mer matrix, IndexBuilder.cpp:99, BaseMatrix.h:83-101)
-        if (multi) {
-            err = "device masking with several devices";
-            return false;
-        }
         ProbabilityMatrix pm(*kmerSubMat);
         const int ka = kmerSubMat->alphabetSize;
         std::vector<double> lr((size_t)ka * ka);
         for (int i = 0; i < ka; i++)
             for (int j = 0; j < ka; j++) lr[(size_t)i * ka + j] = pm.probMatrixPointers[i][j];
         uint64_t masked = 0;
-        if (mmgpu_pf_mask_targets(gpu, lr.data(), ka, maskProb, (int)kmerSubMat->aa2num[(int)'X'], &masked) != 0) {
+        const int maskLetter = (int)kmerSubMat->aa2num[(int)'X'];
+        if ((multi ? mmgpu_multi_pf_mask_targets(multi, lr.data(), ka, maskProb, maskLetter, &masked)
+                   : mmgpu_pf_mask_targets(gpu, lr.data(), ka, maskProb, maskLetter, &masked)) != 0) {
             err = mmgpu_last_error();
             return false;
         }
-        Debug(Debug::INFO) << "Index table: Masked residues: " << masked << " (tantan on the device)\n";
+        if (logMasked) Debug(Debug::INFO) << "Index table: Masked residues: " << masked << " (tantan on the device)\n";
     }
     const int a = ungappedSubMat->alphabetSize;
     std::vector<int8_t> ungapped(a * a);

@@ -27,7 +27,7 @@ class MMGpuPrefilter {
 public:
     MMGpuPrefilter(mmgpu_ctx *gpu, BaseMatrix *kmerSubMat, BaseMatrix *ungappedSubMat, bool aaBiasCorrection,
                    float aaBiasCorrectionScale);
-    // Several devices (MMGpuRun::multi()): buildIndex() deals the targets to them by length bucket and builds one index per
+    // Several devices (one group of MMGpuRun::groups()): buildIndex() deals the targets to them by length bucket and builds one index per
     // device, matchBlock() runs every shard, exchanges the lists over the library's communicator and returns the merged lists,
     // which equal the single-device ones.  Sequence queries with diagonal scoring only (the caller checks multiCapable()).
     void useDevices(mmgpu_multi *m) { multi = m; }
@@ -60,7 +60,7 @@ public:
     // the same hand-over without a host index: the index is built on the device from the (masked) SequenceLookup with the
     // k-mer threshold IndexBuilder::fillDatabase would have used (IndexTable.h:146-154); tables may be invalid (exact k-mers)
     bool buildIndex(SequenceLookup *sequenceLookup, int kmerSize, int indexKmerThr, ScoreMatrix &threeMer, ScoreMatrix &twoMer,
-                    bool spacedKmer, bool maskOnDevice = false, double maskProb = 0.9);
+                    bool spacedKmer, bool maskOnDevice = false, double maskProb = 0.9, bool logMasked = true);
 
     // takeOnlyBestKmer (--exact-kmer-matching; every nucleotide search) / nucleotide target database (matchQuery's isNucleotide)
     void setMode(bool exactKmer, bool nucleotide, bool kmerScoring = false) {

@@ -11,6 +11,7 @@
 // reference scores with computeLongScore) go through a host QueryMatcher.
 //
 // Compiled into MMseqs2 by integration/build_mmseqs.sh (HAVE_MMGPU); Prefiltering.h declares the class a friend.
+#include <algorithm>
 #include <climits>
 #include <cstring>
 #include <list>
@@ -116,7 +117,6 @@ bool MMGpuPrefilterRun::deviceMasks(Prefiltering &p) {
     // what the kernel restates: Masker::maskSequence with tantan alone (Masker.cpp:20-32) on amino-acid sequences
     if (p.maskMode != 1 || p.maskLowerCaseMode != 0 || p.maskNrepeats > 0) return false;
     if (!Parameters::isEqualDbtype(p.targetSeqType, Parameters::DBTYPE_AMINO_ACIDS)) return false;
-    if (getenv("MMGPU_DEVICES") != NULL && getenv("MMGPU_DEVICES")[0] != '\0') return false;      // (shards are masked on the host)
     return true;
 }
 
@@ -152,18 +152,33 @@ bool MMGpuPrefilterRun::run(Prefiltering &p, DBWriter &tmpDbw, size_t dbFrom, si
     MMGpuStopwatch watch("prefilter");
     mmgpu_ctx *gpu = MMGpuRun::context();
     watch.lap("open device");
-    MMGpuPrefilter device(gpu, p.kmerSubMat, p.ungappedSubMat, p.aaBiasCorrection, p.aaBiasCorrectionScale);
     const bool profileQuery = Parameters::isEqualDbtype(p.querySeqType, Parameters::DBTYPE_HMM_PROFILE);
-    // MMGPU_DEVICES: the targets of this split dealt to several devices (device-built index only: a host index is one table)
-    if (mmgpu_multi *multi = MMGpuRun::multi()) {
+    // MMGPU_DEVICES: G query groups x S target shards (MMGpuRun::queryGroups).  A group is one MMGpuPrefilter: the targets of this
+    // split dealt to its S contexts (sequence queries, diagonal scoring, device-built index - a host index is one table - and
+    // --max-seqs x S <= 4096), or, with S = 1, the whole split and its index on the one context; query blocks are dealt to the groups.
+    std::vector<MMGpuPrefilter *> devices;
+    if (!MMGpuRun::deviceIds().empty()) {
+        const int n = (int)MMGpuRun::deviceIds().size();
         const bool nuclDb = Parameters::isEqualDbtype(p.targetSeqType, Parameters::DBTYPE_NUCLEOTIDES);
-        if (p.mmgpuDeviceIndex && MMGpuPrefilter::multiCapable(profileQuery, nuclDb, p.diagonalScoring == 0, p.maxResListLen, mmgpu_multi_size(multi))) {
-            device.useDevices(multi);
-        } else {
-            Debug(Debug::INFO) << "MMGPU: this prefilter configuration runs on one device (several devices: sequence queries, diagonal "
-                                  "scoring, device-built index, --max-seqs x devices <= 4096)\n";
+        const bool shards = p.mmgpuDeviceIndex && MMGpuPrefilter::multiCapable(profileQuery, nuclDb, p.diagonalScoring == 0, p.maxResListLen, 2);
+        int g = MMGpuRun::queryGroups(n, shards);
+        while (n / g > 1 && !MMGpuPrefilter::multiCapable(profileQuery, nuclDb, p.diagonalScoring == 0, p.maxResListLen, n / g)) {
+            do g++; while (n % g != 0);      // fewer shards per group until the merged list fits the exchange
         }
+        if (!shards)
+            Debug(Debug::INFO) << "MMGPU: this prefilter configuration runs without target shards (shards: sequence queries, diagonal "
+                                  "scoring, device-built index, --max-seqs x shards <= 4096): every device holds the whole split\n";
+        const std::vector<mmgpu_multi *> &groups = MMGpuRun::groups(g);
+        for (size_t i = 0; i < groups.size(); i++) {
+            const bool single = mmgpu_multi_size(groups[i]) == 1;
+            devices.push_back(new MMGpuPrefilter(single ? mmgpu_multi_ctx(groups[i], 0) : gpu, p.kmerSubMat, p.ungappedSubMat, p.aaBiasCorrection,
+                                                 p.aaBiasCorrectionScale));
+            if (!single) devices.back()->useDevices(groups[i]);
+        }
+    } else {
+        devices.push_back(new MMGpuPrefilter(gpu, p.kmerSubMat, p.ungappedSubMat, p.aaBiasCorrection, p.aaBiasCorrectionScale));
     }
+    const size_t nGroups = devices.size();
     // The library's index hand-over carries the 3-mer / 2-mer score tables of sequence queries; Prefiltering only builds
     // them for amino-acid queries (Prefiltering.cpp:218-225), so a profile run computes them here the same way.
     ScoreMatrix local3, local2;
@@ -175,15 +190,26 @@ bool MMGpuPrefilterRun::run(Prefiltering &p, DBWriter &tmpDbw, size_t dbFrom, si
         p.kmerSubMat->alphabetSize = alph;
     }
     const bool nuclSearch = Parameters::isEqualDbtype(p.targetSeqType, Parameters::DBTYPE_NUCLEOTIDES);
-    device.setMode(p.takeOnlyBestKmer, nuclSearch, p.diagonalScoring == 0);
     ScoreMatrix &three = local3.isValid() ? local3 : p._3merSubMatrix;
     ScoreMatrix &two = local2.isValid() ? local2 : p._2merSubMatrix;
-    const bool handedOver = p.mmgpuDeviceIndex ? device.buildIndex(p.sequenceLookup, p.kmerSize, p.mmgpuIndexKmerThr, three, two, p.spacedKmer,
-                                                                   p.mmgpuDeviceMask, (double)p.maskProb)
+    {
+        std::vector<char> handedOver(nGroups, 0);
+        auto handOver = [&](size_t g) {
+            MMGpuPrefilter &device = *devices[g];
+            device.setMode(p.takeOnlyBestKmer, nuclSearch, p.diagonalScoring == 0);
+            handedOver[g] = p.mmgpuDeviceIndex ? device.buildIndex(p.sequenceLookup, p.kmerSize, p.mmgpuIndexKmerThr, three, two, p.spacedKmer,
+                                                                   p.mmgpuDeviceMask, (double)p.maskProb, g == 0)
                                                : device.loadIndex(p.indexTable, p.sequenceLookup, three, two, p.spacedKmer);
-    if (!handedOver) {
-        Debug(Debug::ERROR) << "MMGPU: " << device.error() << "\n";
-        EXIT(EXIT_FAILURE);
+        };
+        std::vector<std::thread> helpers;
+        for (size_t g = 1; g < nGroups; g++) helpers.push_back(std::thread(handOver, g));
+        handOver(0);
+        for (size_t g = 0; g < helpers.size(); g++) helpers[g].join();
+        for (size_t g = 0; g < nGroups; g++)
+            if (!handedOver[g]) {
+                Debug(Debug::ERROR) << "MMGPU: " << devices[g]->error() << "\n";
+                EXIT(EXIT_FAILURE);
+            }
     }
     watch.lap(p.mmgpuDeviceIndex ? "hand over targets, build the index on the device" : "hand over targets + index");
     if (local3.isValid()) ExtendedSubstitutionMatrix::freeScoreMatrix(local3);     // the library copied the tables
@@ -214,7 +240,8 @@ bool MMGpuPrefilterRun::run(Prefiltering &p, DBWriter &tmpDbw, size_t dbFrom, si
         std::vector<mmgpu_pf_qstat> qstats;
         bool ok;
     };
-    Block ring[3];
+    std::vector<Block> ring(3 * nGroups);      // (with G query groups a step is G blocks, one per group)
+    std::vector<double> deviceSeconds(nGroups, 0.0);
     double kmersPerPos = 0;
     size_t dbMatches = 0, doubleMatches = 0, querySeqLenSum = 0, resSize = 0, diagonalOverflow = 0;
     const bool pipelined = !(getenv("MMGPU_PREF_PIPELINE") != NULL && getenv("MMGPU_PREF_PIPELINE")[0] == '0');
@@ -282,10 +309,10 @@ bool MMGpuPrefilterRun::run(Prefiltering &p, DBWriter &tmpDbw, size_t dbFrom, si
         watch.add(0, watch.now() - t0);
     };
 
-    auto deviceBlock = [&](Block &B) {
+    auto deviceBlock = [&](Block &B, size_t g) {
         const double t0 = watch.now();
-        B.ok = device.matchBlock(B.block, p.kmerThr, p.maxResListLen, p.minDiagScoreThr, B.results, B.needsCpu, &B.qstats);
-        watch.add(1, watch.now() - t0);
+        B.ok = devices[g]->matchBlock(B.block, p.kmerThr, p.maxResListLen, p.minDiagScoreThr, B.results, B.needsCpu, &B.qstats);
+        deviceSeconds[g] = watch.now() - t0;
     };
 
     auto writeBlock = [&](Block &B) {
@@ -387,37 +414,48 @@ bool MMGpuPrefilterRun::run(Prefiltering &p, DBWriter &tmpDbw, size_t dbFrom, si
 
     std::vector<size_t> starts;
     for (size_t next = queryFrom; next < queryFrom + querySize; next += maxBlockQueries) starts.push_back(next);
-    if (!starts.empty()) mapBlock(ring[0], starts[0]);
-    for (size_t k = 0; k < starts.size(); k++) {
-        Block &cur = ring[k % 3];
-        if (pipelined) {
-            std::thread worker(deviceBlock, std::ref(cur));
-            if (k > 0) writeBlock(ring[(k - 1) % 3]);
-            if (k + 1 < starts.size()) mapBlock(ring[(k + 1) % 3], starts[k + 1]);
-            worker.join();
-        } else {
-            deviceBlock(cur);
-            if (k > 0) writeBlock(ring[(k - 1) % 3]);
-            if (k + 1 < starts.size()) mapBlock(ring[(k + 1) % 3], starts[k + 1]);
-        }
-        if (!cur.ok) {
-            Debug(Debug::ERROR) << "MMGPU: " << device.error() << "\n";
-            EXIT(EXIT_FAILURE);
-        }
+    const size_t steps = (starts.size() + nGroups - 1) / nGroups;
+    auto blocksOf = [&](size_t step) { return std::min(nGroups, starts.size() - step * nGroups); };
+    auto slot = [&](size_t step, size_t g) -> Block & { return ring[(step % 3) * nGroups + g]; };
+    if (steps > 0)
+        for (size_t g = 0; g < blocksOf(0); g++) mapBlock(slot(0, g), starts[g]);
+    for (size_t k = 0; k < steps; k++) {
+        const size_t nb = blocksOf(k);
+        std::vector<std::thread> workers;
+        if (pipelined || nb > 1)
+            for (size_t g = 0; g < nb; g++) workers.push_back(std::thread(deviceBlock, std::ref(slot(k, g)), g));
+        else
+            deviceBlock(slot(k, 0), 0);
+        if (k > 0)
+            for (size_t g = 0; g < blocksOf(k - 1); g++) writeBlock(slot(k - 1, g));
+        if (k + 1 < steps)
+            for (size_t g = 0; g < blocksOf(k + 1); g++) mapBlock(slot(k + 1, g), starts[(k + 1) * nGroups + g]);
+        for (size_t g = 0; g < workers.size(); g++) workers[g].join();
+        watch.add(1, *std::max_element(deviceSeconds.begin(), deviceSeconds.begin() + nb));
+        for (size_t g = 0; g < nb; g++)
+            if (!slot(k, g).ok) {
+                Debug(Debug::ERROR) << "MMGPU: " << devices[g]->error() << "\n";
+                EXIT(EXIT_FAILURE);
+            }
     }
-    if (!starts.empty()) writeBlock(ring[(starts.size() - 1) % 3]);
+    if (steps > 0)
+        for (size_t g = 0; g < blocksOf(steps - 1); g++) writeBlock(slot(steps - 1, g));
     {
         static const char *const names[3] = {"map queries", "device block (bias, prepare, run, fetch)", "serialise + write"};
         watch.report(names, 3);
     }
     {
-        size_t back = 0;
-        for (size_t i = 0; i < 8; i++) back += device.handedBack[i];
+        size_t handedBack[8] = {0, 0, 0, 0, 0, 0, 0, 0}, back = 0;
+        for (size_t g = 0; g < nGroups; g++)
+            for (size_t i = 0; i < 8; i++) {
+                handedBack[i] += devices[g]->handedBack[i];
+                back += devices[g]->handedBack[i];
+            }
         if (back != 0)
             Debug(Debug::INFO) << "MMGPU: " << back << " of " << querySize << " queries ran through the host's matcher (database-hit buffer flushes beyond the device's: "
-                               << device.handedBack[MMGPU_PF_OVERFLOW] << ", sequences of 32768 residues or more: " << device.handedBack[MMGPU_PF_LONG_SEQ]
-                               << ", candidate array / saturated-diagonal ties: " << device.handedBack[MMGPU_PF_SAT_TIE]
-                               << ", shard-dependent order: " << device.handedBack[MMGPU_PF_SHARD_INEXACT] << ")\n";
+                               << handedBack[MMGPU_PF_OVERFLOW] << ", sequences of 32768 residues or more: " << handedBack[MMGPU_PF_LONG_SEQ]
+                               << ", candidate array / saturated-diagonal ties: " << handedBack[MMGPU_PF_SAT_TIE]
+                               << ", shard-dependent order: " << handedBack[MMGPU_PF_SHARD_INEXACT] << ")\n";
     }
     for (size_t i = 0; i < localThreads; i++) {
         delete seqs[i];
@@ -425,11 +463,12 @@ bool MMGpuPrefilterRun::run(Prefiltering &p, DBWriter &tmpDbw, size_t dbFrom, si
     }
     // fused search: the unmasked lookup (device masking) is what the alignment module would map and upload again - it stays
     // resident and the lookup goes to the fused run instead of being freed with this Prefiltering object
-    if (capture && p.mmgpuDeviceMask && p.mmgpuDeviceIndex && !device.usesSeveralDevices() && dbFrom == 0 && dbSize == p.tdbr->getSize() &&
+    if (capture && p.mmgpuDeviceMask && p.mmgpuDeviceIndex && MMGpuRun::deviceIds().empty() && dbFrom == 0 && dbSize == p.tdbr->getSize() &&
         MMGpuFusedSearch::keepsTargets() && p.sequenceLookup != NULL) {
         MMGpuFusedSearch::keepResidentTargets(p.sequenceLookup, p.tdbr, gpu);
         p.sequenceLookup = NULL;
     }
+    for (size_t g = 0; g < nGroups; g++) delete devices[g];
     st.kmersPerPos = kmersPerPos;
     st.dbMatches = dbMatches;
     st.doubleMatches = doubleMatches;

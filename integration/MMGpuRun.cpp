@@ -51,15 +51,14 @@ mmgpu_ctx *MMGpuRun::context() {
 }
 
 // MMGPU_DEVICES=0,1,2,...: all listed devices of the node work on one module call (a repeated id puts several contexts on one
-// device: the shard logic can then be exercised on a 1-GPU box).  NULL: one device (MMGPU_DEVICE).
-mmgpu_multi *MMGpuRun::multi() {
-    static mmgpu_multi *m = NULL;
-    static bool tried = false;
-    if (tried) return m;
-    tried = true;
+// device: the shard logic can then be exercised on a 1-GPU box).  Fewer than two ids: one device (MMGPU_DEVICE).
+const std::vector<int> &MMGpuRun::deviceIds() {
+    static std::vector<int> ids;
+    static bool parsed = false;
+    if (parsed) return ids;
+    parsed = true;
     const char *e = getenv("MMGPU_DEVICES");
-    if (e == NULL || e[0] == '\0') return NULL;
-    std::vector<int> ids;
+    if (e == NULL || e[0] == '\0') return ids;
     for (const char *p = e; *p != '\0';) {
         char *end = NULL;
         const long v = strtol(p, &end, 10);
@@ -67,13 +66,76 @@ mmgpu_multi *MMGpuRun::multi() {
         ids.push_back((int)v);
         p = *end == ',' ? end + 1 : end;
     }
-    if (ids.size() < 2) return NULL;
-    if (mmgpu_init_multi(&m, ids.data(), (int)ids.size()) != 0) {
-        Debug(Debug::ERROR) << "MMGPU: cannot open the devices of MMGPU_DEVICES=" << e << ": " << mmgpu_last_error() << "\n";
-        EXIT(EXIT_FAILURE);
+    if (ids.size() < 2) ids.clear();
+    return ids;
+}
+
+// The layout of a prefilter run over N device contexts: G query groups x S target shards (N = G * S).  A group holds the whole
+// target split, dealt to its S contexts; the query blocks of a run are dealt to the groups.  The model behind the default is
+// bench.py's choose_query_groups() (stage times of the 10 000 x 1 M search on one device, ms: the similar-k-mer stage k = 19.5
+// follows the queries only, e = 152.8 follows the index entries a context holds, x = 3 per exchange step): t = k / G + e / (G S)
+// + x (S > 1), with two shards or more per group, so that a device holds half of the index at most.
+int MMGpuRun::queryGroups(int nDevices, bool shardsPossible) {
+    if (nDevices < 2) return 1;
+    if (!shardsPossible) return nDevices;      // no exchange for this configuration: every context holds the split, queries dealt
+    const char *e = getenv("MMGPU_QUERY_GROUPS");
+    if (e != NULL && e[0] != '\0') {
+        const int g = atoi(e);
+        if (g < 1 || nDevices % g != 0) {
+            Debug(Debug::ERROR) << "MMGPU: MMGPU_QUERY_GROUPS=" << e << " does not divide the " << nDevices << " contexts of MMGPU_DEVICES\n";
+            EXIT(EXIT_FAILURE);
+        }
+        return g;
     }
-    char transport[32] = "";
-    mmgpu_comm_info(mmgpu_multi_ctx(m, 0), NULL, NULL, transport, sizeof(transport));
-    Debug(Debug::INFO) << "MMGPU: " << ids.size() << " device contexts (MMGPU_DEVICES=" << e << "), exchange transport: " << transport << "\n";
-    return m;
+    const double k = 19.5, ent = 152.8, x = 3.0;
+    int best = 1;
+    double bestT = -1;
+    for (int g = 1; g <= nDevices; g++) {
+        if (nDevices % g != 0 || nDevices / g < 2) continue;
+        const int s = nDevices / g;
+        const double t = k / g + ent / ((double)g * s) + x;
+        if (bestT < 0 || t < bestT - 1e-9) {
+            best = g;
+            bestT = t;
+        }
+    }
+    return best;
+}
+
+namespace {
+std::vector<mmgpu_multi *> layout;      // the groups opened last (a process runs one module at a time)
+std::mutex layoutLock;
+}
+
+const std::vector<mmgpu_multi *> &MMGpuRun::groups(int g) {
+    std::lock_guard<std::mutex> guard(layoutLock);
+    const std::vector<int> &ids = deviceIds();
+    if (ids.empty()) return layout;      // (empty)
+    if (g < 1) g = layout.empty() ? 1 : (int)layout.size();
+    if ((int)layout.size() == g) return layout;
+    for (size_t i = 0; i < layout.size(); i++) mmgpu_destroy_multi(layout[i]);
+    layout.clear();
+    const int s = (int)ids.size() / g;
+    for (int i = 0; i < g; i++) {
+        mmgpu_multi *m = NULL;
+        if (mmgpu_init_multi(&m, ids.data() + (size_t)i * s, s) != 0) {
+            Debug(Debug::ERROR) << "MMGPU: cannot open the devices of MMGPU_DEVICES=" << getenv("MMGPU_DEVICES") << ": " << mmgpu_last_error() << "\n";
+            EXIT(EXIT_FAILURE);
+        }
+        layout.push_back(m);
+    }
+    char transport[32] = "none";
+    if (s > 1) mmgpu_comm_info(mmgpu_multi_ctx(layout[0], 0), NULL, NULL, transport, sizeof(transport));
+    Debug(Debug::INFO) << "MMGPU: " << ids.size() << " device contexts (MMGPU_DEVICES=" << getenv("MMGPU_DEVICES") << "): " << g
+                       << " query group" << (g > 1 ? "s" : "") << " x " << s << " target shard" << (s > 1 ? "s" : "")
+                       << ", exchange transport: " << transport << "\n";
+    return layout;
+}
+
+std::vector<mmgpu_ctx *> MMGpuRun::allContexts() {
+    const std::vector<mmgpu_multi *> &gs = groups(0);
+    std::vector<mmgpu_ctx *> all;
+    for (size_t i = 0; i < gs.size(); i++)
+        for (int d = 0; d < mmgpu_multi_size(gs[i]); d++) all.push_back(mmgpu_multi_ctx(gs[i], d));
+    return all;
 }

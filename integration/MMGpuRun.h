@@ -7,10 +7,12 @@
 // Run-time switches (environment, read once):
 //   MMGPU_DISABLE=1            keep the CPU path everywhere (the binary then behaves like the stock one)
 //   MMGPU_DEVICE=<n>           HIP device of this process (default 0)
-//   MMGPU_DEVICES=a,b,...      two or more devices for one module call: `prefilter` deals the target database to them by length
-//                              bucket (one k-mer index per device, the hit lists exchanged over the library's RCCL
-//                              communicator, merged lists = the unsplit run's); `align` keeps the targets on every device and
-//                              deals the queries of each block to them
+//   MMGPU_DEVICES=a,b,...      two or more devices for one module call.  `prefilter`: G query groups x S target shards - a
+//                              group deals the target database to its S devices by length bucket (one k-mer index per
+//                              device, the hit lists exchanged over the group's RCCL communicator, merged lists = the unsplit
+//                              run's) and the query blocks are dealt to the groups; `align` keeps the targets on every device
+//                              and deals the queries of each block to them
+//   MMGPU_QUERY_GROUPS=G       G of that layout (default: the stage model of MMGpuRun::queryGroups, S >= 2)
 //   MMGPU_BLOCK_ALIGNER        hits whose score left the uint8 range (s_align::word == 1) take start position, identities and
 //                              backtrace from the block aligner (StripedSmithWaterman.cpp:865-882,943-1127):
 //                                device (default)  the device's block aligner (mmgpu_sw_block_backtrace); what it declines as
@@ -35,6 +37,9 @@
 #include "Matcher.h"
 #include "ScoreMatrix.h"
 #include "BaseMatrix.h"
+
+#include <vector>
+
 #include "mmgpu.h"
 
 class Alignment;
@@ -49,8 +54,15 @@ public:
     static size_t envSize(const char *name, size_t fallback);
     // the process-wide context; logs the library's message and EXITs if the device cannot be opened
     static mmgpu_ctx *context();
-    // all devices of MMGPU_DEVICES (two or more ids) as one multi-device object, NULL otherwise (mmgpu_init_multi)
-    static mmgpu_multi *multi();
+    // MMGPU_DEVICES (two ids or more; empty otherwise)
+    static const std::vector<int> &deviceIds();
+    // G of the G query groups x S target shards layout of a prefilter run over n contexts (MMGPU_QUERY_GROUPS, or the stage
+    // model's choice); shardsPossible = the configuration can run with its targets dealt to several contexts
+    static int queryGroups(int nDevices, bool shardsPossible);
+    // the contexts of MMGPU_DEVICES as g multi-device objects of n / g contexts each (mmgpu_init_multi; g = 0: the layout
+    // opened last, one group if none); empty without MMGPU_DEVICES.  Opening another layout closes the previous one.
+    static const std::vector<mmgpu_multi *> &groups(int g);
+    static std::vector<mmgpu_ctx *> allContexts();
 };
 
 struct MMGpuAlignSession;

@@ -79,7 +79,7 @@ EXPORTED_SYMBOLS = [
     "mmgpu_comm_unique_id", "mmgpu_comm_init_rank", "mmgpu_comm_info", "mmgpu_comm_destroy", "mmgpu_pf_exchange_merge",
     "mmgpu_sw_prepare_owned", "mmgpu_sw_gather_owned", "mmgpu_sw_fetch_owned", "mmgpu_sw_block_backtrace", "mmgpu_sw_block_tiers",
     "mmgpu_init_multi", "mmgpu_destroy_multi", "mmgpu_multi_size", "mmgpu_multi_ctx", "mmgpu_multi_synchronize",
-    "mmgpu_multi_load_targets", "mmgpu_multi_pf_build_index", "mmgpu_multi_pf_prepare", "mmgpu_multi_pf_run", "mmgpu_multi_pf_fetch",
+    "mmgpu_multi_load_targets", "mmgpu_multi_pf_mask_targets", "mmgpu_multi_pf_build_index", "mmgpu_multi_pf_prepare", "mmgpu_multi_pf_run", "mmgpu_multi_pf_fetch",
     "mmgpu_multi_pf_stride", "mmgpu_multi_pf_free", "mmgpu_multi_sw_from_pf",
 ]
 
@@ -938,6 +938,14 @@ class MMGpuMulti:
         offsets = np.ascontiguousarray(offsets, np.uint64)
         self._check(self.L.mmgpu_multi_load_targets(self.h, _ptr(residues), _ptr(offsets), len(offsets) - 1, alphabet))
         self.n_targets = len(offsets) - 1
+
+    def pf_mask_targets(self, likelihood_ratios, min_mask_prob=0.9, mask_letter=20):
+        """mmgpu_multi_pf_mask_targets: tantan masking of every shard -> residues masked over all shards"""
+        lr = np.ascontiguousarray(likelihood_ratios, np.float64)
+        n = ctypes.c_uint64()
+        self.L.mmgpu_multi_pf_mask_targets.argtypes = [c_p, c_p, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]
+        self._check(self.L.mmgpu_multi_pf_mask_targets(self.h, _ptr(lr), lr.shape[0], float(min_mask_prob), int(mask_letter), ctypes.byref(n)))
+        return n.value
 
     def pf_build_index(self, k, alphabet, spaced, score3, index3, kmer_submat16, kmer_thr, ungapped_mat):
         score3 = np.ascontiguousarray(score3, np.int16)

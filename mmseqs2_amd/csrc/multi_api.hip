@@ -191,6 +191,21 @@ extern "C" int mmgpu_multi_load_targets(mmgpu_multi *m, const uint8_t *residues,
     return MMGPU_OK;
 }
 
+// tantan masking shard by shard (mmgpu_pf_mask_targets): the model runs over one sequence at a time, so the masked shards
+// together are the masked database
+extern "C" int mmgpu_multi_pf_mask_targets(mmgpu_multi *m, const double *likelihood_ratios, int alphabet, double min_mask_prob,
+                                           int mask_letter, uint64_t *n_masked) {
+    if (!m) return fail(MMGPU_ERR_ARG, "mmgpu_multi_pf_mask_targets: NULL argument");
+    uint64_t total = 0;
+    for (mmgpu_ctx *c : m->ctx) {
+        uint64_t n = 0;
+        if (int e = mmgpu_pf_mask_targets(c, likelihood_ratios, alphabet, min_mask_prob, mask_letter, &n)) return e;
+        total += n;
+    }
+    if (n_masked) *n_masked = total;
+    return MMGPU_OK;
+}
+
 // IndexBuilder::fillDatabase of every shard on its own device (mmgpu_pf_build_index)
 extern "C" int mmgpu_multi_pf_build_index(mmgpu_multi *m, const mmgpu_pf_index *ix, const int16_t *kmer_submat, int kmer_thr) {
     if (!m) return fail(MMGPU_ERR_ARG, "mmgpu_multi_pf_build_index: NULL argument");

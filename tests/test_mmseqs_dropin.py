@@ -679,6 +679,37 @@ def test_several_device_contexts_in_one_process(tmp_path):
         assert same(os.path.join(w, "aln_s%d" % i), os.path.join(w, "aln_g%d" % i)) == 500, case
 
 
+@pytest.mark.gpu
+def test_query_groups_by_target_shards_in_one_process(tmp_path):
+    """MMGPU_DEVICES=0,0,0,0: the prefilter hook lays the four contexts out as G query groups x S target shards (MMGpuRun::queryGroups:
+    2 x 2 by the stage model, or MMGPU_QUERY_GROUPS).  Every group holds the whole database dealt to its S contexts - tantan-masked on
+    the device shard by shard, one k-mer index per context, lists exchanged and merged inside the group - and the query blocks (64
+    queries here, so that every group gets several) are dealt to the groups.  The result database must equal the stock binary's for
+    every layout; configurations without target shards (--diag-score 0, a profile query database) run as four groups of one."""
+    w = str(tmp_path)
+    copy_db(EXAMPLES, os.path.join(w, "q"))
+    run(STOCK, ["prefilter", "q", "q", "pref_s", "-s", "5.7", "--threads", THREADS, "-v", "2"], w)
+    for groups, layout in ((None, "2 query groups x 2 target shards"), ("1", "1 query group x 4 target shards"),
+                           ("4", "4 query groups x 1 target shard,")):
+        env = {"MMGPU_DEVICES": "0,0,0,0", "MMGPU_PREF_BLOCK_QUERIES": "64"}
+        if groups is not None:
+            env["MMGPU_QUERY_GROUPS"] = groups
+        out = "pref_g" + (groups or "auto")
+        log = run(MMGPU, ["prefilter", "q", "q", out, "-s", "5.7", "--threads", THREADS, "-v", "3"], w, extra_env=env)
+        assert layout in log and "using the CPU path" not in log and "tantan on the device" in log, log[-2500:]
+        assert same(os.path.join(w, "pref_s"), os.path.join(w, out)) == 500, layout
+    env = {"MMGPU_DEVICES": "0,0,0,0", "MMGPU_PREF_BLOCK_QUERIES": "64"}
+    run(STOCK, ["prefilter", "q", "q", "pref_s0", "-s", "4", "--diag-score", "0", "--threads", THREADS, "-v", "2"], w)
+    log = run(MMGPU, ["prefilter", "q", "q", "pref_g0", "-s", "4", "--diag-score", "0", "--threads", THREADS, "-v", "3"], w, extra_env=env)
+    assert "runs without target shards" in log and "4 query groups x 1 target shard," in log and "using the CPU path" not in log, log[-2500:]
+    assert same(os.path.join(w, "pref_s0"), os.path.join(w, "pref_g0")) == 500
+    # the whole search: the alignment module of the same process deals its queries to the four contexts the prefilter opened
+    run(STOCK, ["search", "q", "q", "res_s", "tmp_s", "-s", "5.7", "-a", "--threads", THREADS, "-v", "2"], w)
+    log = run(MMGPU, ["search", "q", "q", "res_g", "tmp_g", "-s", "5.7", "-a", "--threads", THREADS, "-v", "3"], w, extra_env=env)
+    assert "2 query groups x 2 target shards" in log and "using the CPU path" not in log, log[-2500:]
+    assert same(os.path.join(w, "res_s"), os.path.join(w, "res_g")) == 500
+
+
 def _block_aligner_modes(tmp, emulate):
     """int16-range hits (most true homologs): the stock binary of this image runs the RESTATED block aligner behind the crate's C
     API (integration/build_mmseqs.sh).  The patched binary is linked with do-nothing stubs in the crate's place (round 4: nothing of
