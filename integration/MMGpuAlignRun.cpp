@@ -67,7 +67,11 @@ bool MMGpuAlignRun::usable(const Alignment &a) {
     return true;
 }
 
-size_t MMGpuAlignRun::bucketQueries(MMGpuAlignSession *) { return MMGpuRun::envSize("MMGPU_ALIGN_BLOCK_QUERIES", 16384); }
+size_t MMGpuAlignRun::bucketQueries(MMGpuAlignSession *) {
+    // overlapped fused search: a bucket starts as soon as the prefilter module has written its entries - smaller buckets start earlier
+    if (MMGpuFusedSearch::overlappedRun()) return MMGpuRun::envSize("MMGPU_FUSED_BUCKET_QUERIES", 2048);
+    return MMGpuRun::envSize("MMGPU_ALIGN_BLOCK_QUERIES", 16384);
+}
 
 void MMGpuAlignRun::end(MMGpuAlignSession *s) {
     if (s == NULL) return;
@@ -97,6 +101,7 @@ MMGpuAlignSession *MMGpuAlignRun::begin(Alignment &al, EvalueComputation &evalue
     }
     if (!residentAlready) {
         std::vector<unsigned char> named(nTargets, 1);
+        MMGpuFusedSearch::waitForEntries(dbFrom, dbSize);      // (overlapped fused search without resident targets: all lists first)
         if (Util::getTotalSystemMemory() > al.prefdbr->getTotalDataSize()) {
             std::fill(named.begin(), named.end(), 0);
 #pragma omp parallel num_threads(threads)
@@ -175,6 +180,7 @@ MMGpuAlignSession *MMGpuAlignRun::begin(Alignment &al, EvalueComputation &evalue
 void MMGpuAlignRun::plan(MMGpuAlignSession *s, size_t start, size_t bucketSize) {
     s->start = start;
     s->size = bucketSize;
+    MMGpuFusedSearch::waitForEntries(start, bucketSize);      // (overlapped fused search: the prefilter module may still be at work)
     if (s->nucleotide) {
         planNucleotide(s);
         return;

@@ -43,6 +43,15 @@ public:
     static bool keepsTargets();      // a fused run is in progress: worth handing the lookup over
     static void keepResidentTargets(SequenceLookup *lookup, DBReader<unsigned int> *tdbr, void *gpu);
     static bool residentTargets(DBReader<unsigned int> *tdbr, void *gpu, const unsigned char **data, const uint64_t **offsets);
+
+    // ---- overlapped run: the alignment module works while the prefilter module still produces (MMGpuFusedSearch.cpp, bothModules) ----
+    static bool overlappedRun();
+    // the lookup was handed over by keepResidentTargets (early, in an overlapped run): the Prefiltering object must not free it
+    static bool holdsLookup(const SequenceLookup *lookup);
+    // prefilter hook, after a block's entries went through capture(): the alignment module may read them
+    static void publish();
+    // alignment hook, before it reads the entries of ids [firstId, firstId + count) of the prefilter database
+    static void waitForEntries(size_t firstId, size_t count);
 };
 
 #endif

@@ -118,33 +118,49 @@ bool MMGpuPrefilter::buildIndex(SequenceLookup *sequenceLookup, int kmerSize, in
     return true;
 }
 
-bool MMGpuPrefilter::matchBlock(const std::vector<Query> &queries, int kmerThr, size_t maxResListLen, unsigned int minDiagScoreThr,
-                                std::vector<std::vector<hit_t> > &results, std::vector<bool> &needsCpu,
-                                std::vector<mmgpu_pf_qstat> *stats) {
+// One block in flight: what submitBlock() enqueued and finishBlock() collects.
+struct MMGpuPrefilter::Pending {
+    const std::vector<Query> *queries;
+    std::vector<std::vector<float> > bias;      // composition bias of the queries that came without one
+    std::vector<mmgpu_pf_query> dq;
+    mmgpu_pf_params par;
+    uint32_t stride;
+    mmgpu_pf_batch_t *batch;
+    mmgpu_multi_pf_batch *mb;
+    bool enqueued;      // the whole block is on the device (otherwise finishBlock runs it in pieces)
+    Pending() : queries(NULL), stride(0), batch(NULL), mb(NULL), enqueued(false) {}
+};
+
+void MMGpuPrefilter::compositionBias(const Query &s, std::vector<float> &bias) const {
+    bias.assign(s.L, 0.0f);
+    // no correction for profile and nucleotide queries (QueryMatcher.cpp:110-114: amino-acid sequences only)
+    if (aaBiasCorrection && s.profile == NULL && !nucleotideSearch)
+        SubstitutionMatrix::calcLocalAaBiasCorrection(kmerSubMat, s.numSequence, s.L, bias.data(), aaBiasCorrectionScale);
+}
+
+MMGpuPrefilter::Pending *MMGpuPrefilter::submitBlock(const std::vector<Query> &queries, int kmerThr, size_t maxResListLen,
+                                                     unsigned int minDiagScoreThr) {
+    Pending *P = new Pending();
     const size_t nq = queries.size();
-    results.assign(nq, std::vector<hit_t>());
-    needsCpu.assign(nq, false);
-    if (nq == 0) return true;
+    P->queries = &queries;
+    if (nq == 0) return P;
     // QueryMatcher::matchQuery's composition bias over the k-mer matrix (QueryMatcher.cpp:109-117), floats
-    std::vector<std::vector<float> > bias(nq);
-    std::vector<mmgpu_pf_query> dq(nq);
-#pragma omp parallel for schedule(dynamic, 16)
+    P->bias.resize(nq);
+    P->dq.resize(nq);
     for (size_t q = 0; q < nq; q++) {
         const Query &s = queries[q];
-        bias[q].assign(s.L, 0.0f);
-        // no correction for profile and nucleotide queries (QueryMatcher.cpp:110-114: amino-acid sequences only)
-        if (aaBiasCorrection && s.profile == NULL && !nucleotideSearch)
-            SubstitutionMatrix::calcLocalAaBiasCorrection(kmerSubMat, s.numSequence, s.L, bias[q].data(), aaBiasCorrectionScale);
-        dq[q].q = s.numSequence;
-        dq[q].qlen = (uint32_t)s.L;
-        dq[q].comp_bias = s.profile ? NULL : bias[q].data();
-        dq[q].identity_id = queries[q].identityId;
-        dq[q].profile_score = s.profileScore;
-        dq[q].profile_index = s.profileIndex;
-        dq[q].profile_row = s.profileRow;
-        dq[q].profile = s.profile;
+        if (s.compBias == NULL && s.profile == NULL) compositionBias(s, P->bias[q]);
+        mmgpu_pf_query &d = P->dq[q];
+        d.q = s.numSequence;
+        d.qlen = (uint32_t)s.L;
+        d.comp_bias = s.profile ? NULL : (s.compBias ? s.compBias : P->bias[q].data());
+        d.identity_id = s.identityId;
+        d.profile_score = s.profileScore;
+        d.profile_index = s.profileIndex;
+        d.profile_row = s.profileRow;
+        d.profile = s.profile;
     }
-    mmgpu_pf_params par;
+    mmgpu_pf_params &par = P->par;
     par.kmer_thr = kmerThr;
     par.max_hits = (uint32_t)maxResListLen;
     par.min_diag_score = minDiagScoreThr;
@@ -152,43 +168,83 @@ bool MMGpuPrefilter::matchBlock(const std::vector<Query> &queries, int kmerThr, 
     par.exact_kmer = exactKmerMatching ? 1u : 0u;
     par.nucleotide = nucleotideSearch ? 1u : 0u;
     par.kmer_score = kmerScore ? 1u : 0u;
-    const uint32_t stride = (uint32_t)std::min(maxResListLen, dbSize);
+    P->stride = (uint32_t)std::min(maxResListLen, dbSize);
+    // One device batch for the block, enqueued here and collected by finishBlock(): the caller submits the next block before it
+    // collects this one, so that the device never waits for the host between blocks.
+    MMGpuStopwatch watch("prefilter block");
+    int rc;
+    if (multi) {
+        // every shard's prefilter, the exchange of the lists over the library's communicator, the merge (== unsplit lists);
+        // MMGPU_PF_SHARD_INEXACT queries come back through needsCpu.  (Per-query statistics - log output only - are not
+        // gathered over the shards.)
+        rc = mmgpu_multi_pf_prepare(multi, &par, P->dq.data(), (uint32_t)nq, &P->mb);
+        if (rc == 0) rc = mmgpu_multi_pf_run(multi, P->mb);
+    } else {
+        rc = mmgpu_pf_prepare(gpu, &par, P->dq.data(), (uint32_t)nq, &P->batch);
+        watch.lap("mmgpu_pf_prepare");
+        if (rc == 0) rc = mmgpu_pf_run(gpu, P->batch);
+        if (rc == 0 && getenv("MMGPU_TRACE") != NULL && getenv("MMGPU_TRACE")[0] == '2') mmgpu_synchronize(gpu);     // the lap shows the kernels, not the enqueue
+        watch.lap("mmgpu_pf_run");
+    }
+    P->enqueued = rc == 0;
+    if (rc != 0) {      // finishBlock() runs the block in pieces
+        if (P->mb) mmgpu_multi_pf_free(multi, P->mb);
+        if (P->batch) mmgpu_pf_free(gpu, P->batch);
+        P->mb = NULL;
+        P->batch = NULL;
+    }
+    return P;
+}
+
+bool MMGpuPrefilter::finishBlock(Pending *P, std::vector<std::vector<hit_t> > &results, std::vector<bool> &needsCpu,
+                                 std::vector<mmgpu_pf_qstat> *stats) {
+    const std::vector<Query> &queries = *P->queries;
+    const size_t nq = queries.size();
+    results.assign(nq, std::vector<hit_t>());
+    needsCpu.assign(nq, false);
+    if (nq == 0) {
+        delete P;
+        return true;
+    }
+    const uint32_t stride = P->stride;
     std::vector<mmgpu_pf_hit> hits(nq * (size_t)stride);
     std::vector<uint32_t> counts(nq);
     std::vector<int32_t> status(nq);
-    MMGpuStopwatch watch("prefilter block");
-    watch.lap("composition bias");
     if (stats) stats->assign(nq, mmgpu_pf_qstat());
-    // One device batch for the block; a batch the device cannot hold (out of HBM, or 2^32 index entries and more - a large
-    // database with long or repetitive queries) is cut in halves and retried, down to single queries.
+    MMGpuStopwatch watch("prefilter block");
+    // A batch the device cannot hold (out of HBM, or 2^32 index entries and more - a large database with long or repetitive
+    // queries) is cut in halves and retried, down to single queries.
     std::vector<std::pair<size_t, size_t> > todo(1, std::make_pair((size_t)0, nq));
-    while (!todo.empty()) {
+    bool ok = true;
+    while (!todo.empty() && ok) {
         const size_t lo = todo.back().first, hi = todo.back().second;
         todo.pop_back();
-        int rc;
+        const bool whole = lo == 0 && hi == nq && P->enqueued;
+        int rc = 0;
         if (multi) {
-            // every shard's prefilter, the exchange of the lists over the library's communicator, the merge (== unsplit lists);
-            // MMGPU_PF_SHARD_INEXACT queries come back through needsCpu.  (Per-query statistics - log output only - are not
-            // gathered over the shards.)
-            mmgpu_multi_pf_batch *mb = NULL;
-            rc = mmgpu_multi_pf_prepare(multi, &par, dq.data() + lo, (uint32_t)(hi - lo), &mb);
-            if (rc == 0) rc = mmgpu_multi_pf_run(multi, mb);
+            mmgpu_multi_pf_batch *mb = whole ? P->mb : NULL;
+            if (!whole) {
+                rc = mmgpu_multi_pf_prepare(multi, &P->par, P->dq.data() + lo, (uint32_t)(hi - lo), &mb);
+                if (rc == 0) rc = mmgpu_multi_pf_run(multi, mb);
+            }
             if (rc == 0) rc = mmgpu_multi_pf_fetch(multi, mb, hits.data() + lo * (size_t)stride, stride, counts.data() + lo, status.data() + lo);
             if (rc != 0) err = mmgpu_last_error();
             if (mb) mmgpu_multi_pf_free(multi, mb);
+            if (whole) P->mb = NULL;
         } else {
-            mmgpu_pf_batch_t *batch = NULL;
-            rc = mmgpu_pf_prepare(gpu, &par, dq.data() + lo, (uint32_t)(hi - lo), &batch);
-            watch.lap("mmgpu_pf_prepare");
-            if (rc == 0) rc = mmgpu_pf_run(gpu, batch);
-            if (rc == 0 && getenv("MMGPU_TRACE") != NULL) mmgpu_synchronize(gpu);     // the lap shows the kernels, not the enqueue
-            watch.lap("mmgpu_pf_run");
+            mmgpu_pf_batch_t *batch = whole ? P->batch : NULL;
+            if (!whole) {
+                rc = mmgpu_pf_prepare(gpu, &P->par, P->dq.data() + lo, (uint32_t)(hi - lo), &batch);
+                if (rc == 0) rc = mmgpu_pf_run(gpu, batch);
+            }
             if (rc == 0) rc = mmgpu_pf_fetch(gpu, batch, hits.data() + lo * (size_t)stride, stride, counts.data() + lo, status.data() + lo,
                                              stats ? stats->data() + lo : NULL);
             watch.lap("mmgpu_pf_fetch");
             if (rc != 0) err = mmgpu_last_error();
             if (batch) mmgpu_pf_free(gpu, batch);
+            if (whole) P->batch = NULL;
         }
+        P->enqueued = false;
         if (rc != 0) {
             if ((rc == MMGPU_ERR_HIP || rc == MMGPU_ERR_UNSUPPORTED) && hi - lo > 1) {
                 const size_t mid = lo + (hi - lo) / 2;
@@ -196,9 +252,13 @@ bool MMGpuPrefilter::matchBlock(const std::vector<Query> &queries, int kmerThr, 
                 todo.push_back(std::make_pair(lo, mid));
                 continue;
             }
-            return false;
+            ok = false;
         }
     }
+    if (P->mb) mmgpu_multi_pf_free(multi, P->mb);
+    if (P->batch) mmgpu_pf_free(gpu, P->batch);
+    delete P;
+    if (!ok) return false;
     for (size_t q = 0; q < nq; q++) {
         if (status[q] != MMGPU_PF_OK) {     // MMGPU_PF_OVERFLOW / MMGPU_PF_LONG_SEQ: the host's own matcher runs this query
             needsCpu[q] = true;
@@ -216,4 +276,10 @@ bool MMGpuPrefilter::matchBlock(const std::vector<Query> &queries, int kmerThr, 
     }
     watch.lap("hit_t lists");
     return true;
+}
+
+bool MMGpuPrefilter::matchBlock(const std::vector<Query> &queries, int kmerThr, size_t maxResListLen, unsigned int minDiagScoreThr,
+                                std::vector<std::vector<hit_t> > &results, std::vector<bool> &needsCpu,
+                                std::vector<mmgpu_pf_qstat> *stats) {
+    return finishBlock(submitBlock(queries, kmerThr, maxResListLen, minDiagScoreThr), results, needsCpu, stats);
 }

@@ -49,13 +49,26 @@ public:
         const unsigned int *profileIndex;
         unsigned int profileRow;
         const int8_t *profile;
-        Query() : numSequence(NULL), L(0), identityId(0xFFFFFFFFu), profileScore(NULL), profileIndex(NULL), profileRow(0), profile(NULL) {}
+        // sequence query: compositionBias() of it if the caller has it already (L floats, kept alive by the caller), else NULL
+        const float *compBias;
+        Query() : numSequence(NULL), L(0), identityId(0xFFFFFFFFu), profileScore(NULL), profileIndex(NULL), profileRow(0), profile(NULL),
+                  compBias(NULL) {}
     };
     // results[q] = the hit_t list of QueryMatcher::matchQuery; needsCpu[q] = the device declined the query;
     // stats[q] (optional) = what QueryMatcher::getStatistics() would report for the query
     bool matchBlock(const std::vector<Query> &queries, int kmerThr, size_t maxResListLen, unsigned int minDiagScoreThr,
                     std::vector<std::vector<hit_t> > &results, std::vector<bool> &needsCpu,
                     std::vector<mmgpu_pf_qstat> *stats = NULL);
+
+    // The same in two halves, so that the device has the next block queued while the host collects this one: submitBlock()
+    // enqueues (descriptors, uploads, kernels), finishBlock() downloads and converts (and deletes the Pending).  `queries` must
+    // stay alive in between.  A block the device cannot take whole is run in pieces by finishBlock().
+    struct Pending;
+    Pending *submitBlock(const std::vector<Query> &queries, int kmerThr, size_t maxResListLen, unsigned int minDiagScoreThr);
+    bool finishBlock(Pending *pending, std::vector<std::vector<hit_t> > &results, std::vector<bool> &needsCpu,
+                     std::vector<mmgpu_pf_qstat> *stats = NULL);
+    // QueryMatcher::matchQuery's composition bias of a sequence query (QueryMatcher.cpp:109-117): zeros where the reference applies none
+    void compositionBias(const Query &query, std::vector<float> &bias) const;
 
     // the same hand-over without a host index: the index is built on the device from the (masked) SequenceLookup with the
     // k-mer threshold IndexBuilder::fillDatabase would have used (IndexTable.h:146-154); tables may be invalid (exact k-mers)

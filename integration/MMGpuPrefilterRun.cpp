@@ -13,8 +13,10 @@
 // Compiled into MMseqs2 by integration/build_mmseqs.sh (HAVE_MMGPU); Prefiltering.h declares the class a friend.
 #include <algorithm>
 #include <climits>
+#include <condition_variable>
 #include <cstring>
 #include <list>
+#include <mutex>
 #include <functional>
 #include <string>
 #include <thread>
@@ -120,6 +122,12 @@ bool MMGpuPrefilterRun::deviceMasks(Prefiltering &p) {
     return true;
 }
 
+bool MMGpuPrefilterRun::runsUnsplitWithResidentTargets(Prefiltering &p, size_t *maxResListLen) {
+    *maxResListLen = p.maxResListLen;
+    // (index and lookup of an unsplit run exist once the constructor has returned: Prefiltering.cpp:196-199)
+    return p.splits == 1 && p.sequenceLookup != NULL && p.mmgpuDeviceIndex && p.mmgpuDeviceMask && MMGpuRun::deviceIds().empty() && usable(p);
+}
+
 void MMGpuPrefilterRun::ensureHostIndex(Prefiltering &p, size_t dbFrom, size_t dbSize) {
     if (!p.mmgpuDeviceIndex) return;
     // IndexBuilder::fillDatabase as Prefiltering::getIndexTable calls it (:564-569); it also fills a second SequenceLookup,
@@ -135,6 +143,7 @@ void MMGpuPrefilterRun::ensureHostIndex(Prefiltering &p, size_t dbFrom, size_t d
     IndexBuilder::fillDatabase(p.indexTable, &second, *p.kmerSubMat, p._3merSubMatrix, p._2merSubMatrix, &tseq, p.tdbr, dbFrom,
                                dbFrom + dbSize, p.mmgpuIndexKmerThr, p.maskMode, p.maskLowerCaseMode, p.maskProb, p.maskNrepeats,
                                p.targetSearchMode);
+    if (MMGpuFusedSearch::holdsLookup(p.sequenceLookup)) p.sequenceLookup = NULL;      // (the alignment module of the fused search reads it)
     delete p.sequenceLookup;
     p.sequenceLookup = second;
     p.mmgpuDeviceIndex = false;
@@ -223,24 +232,34 @@ bool MMGpuPrefilterRun::run(Prefiltering &p, DBWriter &tmpDbw, size_t dbFrom, si
     // split runs merge their parts through files (mergePrefilterSplits / mergeTargetSplits) and are written as ever
     const bool capture = p.splits == 1 && MMGpuFusedSearch::capturing(tmpDbw.getDataFileName());
     if (capture) mmgpuFusedPrepareCapture(localThreads);
+    // fused search: the unmasked lookup (device masking) is what the alignment module would map and upload again - it stays
+    // resident and the lookup goes to the fused run instead of being freed with this Prefiltering object.  An overlapped run
+    // (the alignment module is already waiting) gets it now, the others when this run is over.
+    const bool leaveTargets = capture && p.mmgpuDeviceMask && p.mmgpuDeviceIndex && MMGpuRun::deviceIds().empty() && dbFrom == 0 &&
+                              dbSize == p.tdbr->getSize() && MMGpuFusedSearch::keepsTargets() && p.sequenceLookup != NULL;
+    if (MMGpuFusedSearch::overlappedRun()) MMGpuFusedSearch::keepResidentTargets(leaveTargets ? p.sequenceLookup : NULL, p.tdbr, gpu);
 
     std::vector<Sequence *> seqs(localThreads, NULL);
     std::vector<QueryMatcher *> cpuMatchers(localThreads, NULL);
-    // Three blocks are in flight: while the device works on block b (matchBlock, on a helper thread: descriptors, kernels,
-    // downloads), this thread finishes block b - 1 (key mapping, coverage gate, DBWriter) and maps the sequences of block b + 1.
+    // Four blocks per query group are in flight.  A group's helper thread submits block b (descriptors, uploads, kernels enqueued)
+    // and only then collects block b - 1 (downloads, hit_t lists), so the device always has the next block queued; this thread
+    // maps the sequences of the blocks ahead (with their composition bias) and finishes the collected ones in order (key mapping,
+    // coverage gate, DBWriter).
     struct Block {
         size_t first, nq;
         std::vector<std::vector<unsigned char> > queryNum;
         std::vector<std::vector<short> > queryProfScore;         // profile queries: copies of the Sequence's profile arrays
         std::vector<std::vector<unsigned int> > queryProfIndex;
         std::vector<std::vector<int8_t> > queryProfAln;
+        std::vector<std::vector<float> > queryBias;
         std::vector<MMGpuPrefilter::Query> block;
         std::vector<std::vector<hit_t> > results;
         std::vector<bool> needsCpu;
         std::vector<mmgpu_pf_qstat> qstats;
         bool ok;
     };
-    std::vector<Block> ring(3 * nGroups);      // (with G query groups a step is G blocks, one per group)
+    const size_t ringSlots = 4 * nGroups;
+    std::vector<Block> ring(ringSlots);
     std::vector<double> deviceSeconds(nGroups, 0.0);
     double kmersPerPos = 0;
     size_t dbMatches = 0, doubleMatches = 0, querySeqLenSum = 0, resSize = 0, diagonalOverflow = 0;
@@ -255,6 +274,7 @@ bool MMGpuPrefilterRun::run(Prefiltering &p, DBWriter &tmpDbw, size_t dbFrom, si
         B.queryProfScore.assign(nq, std::vector<short>());
         B.queryProfIndex.assign(nq, std::vector<unsigned int>());
         B.queryProfAln.assign(nq, std::vector<int8_t>());
+        B.queryBias.assign(nq, std::vector<float>());
         B.block.assign(nq, MMGpuPrefilter::Query());
         std::vector<std::vector<unsigned char> > &queryNum = B.queryNum;
         std::vector<std::vector<short> > &queryProfScore = B.queryProfScore;
@@ -304,15 +324,13 @@ bool MMGpuPrefilterRun::run(Prefiltering &p, DBWriter &tmpDbw, size_t dbFrom, si
                     }
                 }
                 block[b].identityId = targetSeqId == DB_LOCAL_ID_INVALID ? UINT_MAX : (unsigned int)targetSeqId;
+                if (!profileQuery) {
+                    devices[0]->compositionBias(block[b], B.queryBias[b]);
+                    block[b].compBias = B.queryBias[b].data();
+                }
             }
         }
         watch.add(0, watch.now() - t0);
-    };
-
-    auto deviceBlock = [&](Block &B, size_t g) {
-        const double t0 = watch.now();
-        B.ok = devices[g]->matchBlock(B.block, p.kmerThr, p.maxResListLen, p.minDiagScoreThr, B.results, B.needsCpu, &B.qstats);
-        deviceSeconds[g] = watch.now() - t0;
     };
 
     auto writeBlock = [&](Block &B) {
@@ -414,34 +432,72 @@ bool MMGpuPrefilterRun::run(Prefiltering &p, DBWriter &tmpDbw, size_t dbFrom, si
 
     std::vector<size_t> starts;
     for (size_t next = queryFrom; next < queryFrom + querySize; next += maxBlockQueries) starts.push_back(next);
-    const size_t steps = (starts.size() + nGroups - 1) / nGroups;
-    auto blocksOf = [&](size_t step) { return std::min(nGroups, starts.size() - step * nGroups); };
-    auto slot = [&](size_t step, size_t g) -> Block & { return ring[(step % 3) * nGroups + g]; };
-    if (steps > 0)
-        for (size_t g = 0; g < blocksOf(0); g++) mapBlock(slot(0, g), starts[g]);
-    for (size_t k = 0; k < steps; k++) {
-        const size_t nb = blocksOf(k);
-        std::vector<std::thread> workers;
-        if (pipelined || nb > 1)
-            for (size_t g = 0; g < nb; g++) workers.push_back(std::thread(deviceBlock, std::ref(slot(k, g)), g));
-        else
-            deviceBlock(slot(k, 0), 0);
-        if (k > 0)
-            for (size_t g = 0; g < blocksOf(k - 1); g++) writeBlock(slot(k - 1, g));
-        if (k + 1 < steps)
-            for (size_t g = 0; g < blocksOf(k + 1); g++) mapBlock(slot(k + 1, g), starts[(k + 1) * nGroups + g]);
-        for (size_t g = 0; g < workers.size(); g++) workers[g].join();
-        watch.add(1, *std::max_element(deviceSeconds.begin(), deviceSeconds.begin() + nb));
-        for (size_t g = 0; g < nb; g++)
-            if (!slot(k, g).ok) {
-                Debug(Debug::ERROR) << "MMGPU: " << devices[g]->error() << "\n";
-                EXIT(EXIT_FAILURE);
+    const size_t nBlocks = starts.size();
+    std::mutex lock;
+    std::condition_variable changed;
+    size_t mapped = 0;                        // blocks [0, mapped) are ready for the device
+    std::vector<char> collected(nBlocks, 0);  // the device's answer for block k is in its ring slot
+    auto groupWorker = [&](size_t g) {        // blocks g, g + G, g + 2 G, ...
+        MMGpuPrefilter::Pending *before = NULL;
+        size_t beforeK = 0;
+        auto collect = [&]() {
+            Block &B = ring[beforeK % ringSlots];
+            B.ok = devices[g]->finishBlock(before, B.results, B.needsCpu, &B.qstats);
+            {
+                std::lock_guard<std::mutex> guard(lock);
+                collected[beforeK] = 1;
             }
+            changed.notify_all();
+            before = NULL;
+        };
+        for (size_t k = g; k < nBlocks; k += nGroups) {
+            {
+                std::unique_lock<std::mutex> guard(lock);
+                changed.wait(guard, [&]() { return mapped > k; });
+            }
+            const double t0 = watch.now();
+            MMGpuPrefilter::Pending *cur = devices[g]->submitBlock(ring[k % ringSlots].block, p.kmerThr, p.maxResListLen, p.minDiagScoreThr);
+            if (before != NULL) collect();
+            before = cur;
+            beforeK = k;
+            if (!pipelined) collect();
+            deviceSeconds[g] += watch.now() - t0;
+        }
+        if (before != NULL) {
+            const double t0 = watch.now();
+            collect();
+            deviceSeconds[g] += watch.now() - t0;
+        }
+    };
+    std::vector<std::thread> workers;
+    for (size_t g = 0; g < nGroups && g < nBlocks; g++) workers.push_back(std::thread(groupWorker, g));
+    for (size_t nextMap = 0, nextWrite = 0; nextWrite < nBlocks;) {
+        if (nextMap < nBlocks && nextMap - nextWrite < ringSlots) {
+            mapBlock(ring[nextMap % ringSlots], starts[nextMap]);
+            {
+                std::lock_guard<std::mutex> guard(lock);
+                mapped = ++nextMap;
+            }
+            changed.notify_all();
+            continue;
+        }
+        {
+            std::unique_lock<std::mutex> guard(lock);
+            changed.wait(guard, [&]() { return collected[nextWrite] != 0; });
+        }
+        Block &B = ring[nextWrite % ringSlots];
+        if (!B.ok) {
+            Debug(Debug::ERROR) << "MMGPU: " << devices[nextWrite % nGroups]->error() << "\n";
+            EXIT(EXIT_FAILURE);
+        }
+        writeBlock(B);
+        if (capture) MMGpuFusedSearch::publish();
+        nextWrite++;
     }
-    if (steps > 0)
-        for (size_t g = 0; g < blocksOf(steps - 1); g++) writeBlock(slot(steps - 1, g));
+    for (size_t g = 0; g < workers.size(); g++) workers[g].join();
+    watch.add(1, *std::max_element(deviceSeconds.begin(), deviceSeconds.end()));
     {
-        static const char *const names[3] = {"map queries", "device block (bias, prepare, run, fetch)", "serialise + write"};
+        static const char *const names[3] = {"map queries", "device blocks (prepare, run, fetch; the busiest query group)", "serialise + write"};
         watch.report(names, 3);
     }
     {
@@ -461,12 +517,9 @@ bool MMGpuPrefilterRun::run(Prefiltering &p, DBWriter &tmpDbw, size_t dbFrom, si
         delete seqs[i];
         delete cpuMatchers[i];
     }
-    // fused search: the unmasked lookup (device masking) is what the alignment module would map and upload again - it stays
-    // resident and the lookup goes to the fused run instead of being freed with this Prefiltering object
-    if (capture && p.mmgpuDeviceMask && p.mmgpuDeviceIndex && MMGpuRun::deviceIds().empty() && dbFrom == 0 && dbSize == p.tdbr->getSize() &&
-        MMGpuFusedSearch::keepsTargets() && p.sequenceLookup != NULL) {
-        MMGpuFusedSearch::keepResidentTargets(p.sequenceLookup, p.tdbr, gpu);
-        p.sequenceLookup = NULL;
+    if (leaveTargets) {
+        if (!MMGpuFusedSearch::overlappedRun()) MMGpuFusedSearch::keepResidentTargets(p.sequenceLookup, p.tdbr, gpu);
+        if (MMGpuFusedSearch::holdsLookup(p.sequenceLookup)) p.sequenceLookup = NULL;
     }
     for (size_t g = 0; g < nGroups; g++) delete devices[g];
     st.kmersPerPos = kmersPerPos;

@@ -107,6 +107,9 @@ public:
     // ... and whether the device also does the masking fillDatabase would do (tantan only, one device): mmgpu_pf_mask_targets;
     // MMGPU_DEVICE_MASK=0 keeps the host's Masker
     static bool deviceMasks(Prefiltering &p);
+    // fused search: this object will run unsplit through the device path and leave its targets resident for the alignment
+    // module (MMGpuFusedSearch::keepResidentTargets) - the alignment module can then start before the prefilter has finished
+    static bool runsUnsplitWithResidentTargets(Prefiltering &p, size_t *maxResListLen);
     // the reference's own index for queries the device hands back (overflow, long sequences, ties), built when first needed
     static void ensureHostIndex(Prefiltering &p, size_t dbFrom, size_t dbSize);
     // the `omp parallel` block of Prefiltering::runSplit (:820-918): writes every query's entry to tmpDbw, fills the

@@ -10,6 +10,7 @@
 #include <array>
 #include <string>
 #include <map>
+#include <mutex>
 #include <chrono>
 #include <memory>
 #include <vector>
@@ -555,6 +556,7 @@ struct BlockCache {
     std::multimap<size_t, void *> blocks;
     size_t cached = 0;
     bool closed = false;   // the context is gone (batches may outlive it): blocks go straight back to the runtime
+    std::mutex lock;       // a prefilter thread and an alignment thread may work on one context (the fused search of the drop-in)
     static constexpr size_t LIMIT = 32ull << 30;
     static size_t round_up(size_t n) {
         if (n <= 512) return 512;
@@ -562,20 +564,26 @@ struct BlockCache {
         const size_t step = (size_t)1 << (top - 2);
         return (n + step - 1) & ~(step - 1);
     }
-    void *take(size_t cap) {
-        auto it = blocks.find(cap);
-        if (it == blocks.end()) return nullptr;
+    // the smallest parked block of cap .. 2 cap bytes (cap becomes its size): the buffers of consecutive batches differ in size by
+    // what their queries happen to need, and on some hosts a fresh hipMalloc costs 25 - 40 ms per GB
+    void *take(size_t &cap) {
+        std::lock_guard<std::mutex> guard(lock);
+        auto it = blocks.lower_bound(cap);
+        if (it == blocks.end() || it->first > 2 * cap) return nullptr;
         void *p = it->second;
+        cap = it->first;
         blocks.erase(it);
         cached -= cap;
         return p;
     }
     void give(void *p, size_t cap) {
+        std::lock_guard<std::mutex> guard(lock);
         if (closed || cached + cap > LIMIT) { (void)hipFree(p); return; }
         blocks.emplace(cap, p);
         cached += cap;
     }
     void trim() {
+        std::lock_guard<std::mutex> guard(lock);
         for (auto &kv : blocks) (void)hipFree(kv.second);
         blocks.clear();
         cached = 0;

@@ -162,6 +162,12 @@ def search_workflow(tmp, emulate):
         assert "using the CPU path" not in log, log[-3000:]
         assert same(os.path.join(w, "res_s" + tag), os.path.join(w, "res_g" + tag)) == 500
         assert not os.path.exists(os.path.join(w, "tmp_g" + tag, "latest", "pref_0.dbtype"))
+    # MMGPU_FUSED_OVERLAP=1: the two modules side by side, with blocks small enough to interleave - the alignment module takes
+    # buckets of 100 queries as soon as the prefilter module has written them (blocks of 64)
+    log = run(MMGPU, ["search", "q", "q", "res_small", "tmp_small", "-s", "5.7", "-a", "--threads", THREADS, "-v", "3"], w, emulate,
+              extra_env={"MMGPU_FUSED_OVERLAP": "1", "MMGPU_PREF_BLOCK_QUERIES": "64", "MMGPU_FUSED_BUCKET_QUERIES": "100"})
+    assert "the alignment module starts while the prefilter module runs" in log, log[-3000:]
+    assert same(os.path.join(w, "res_s5.7_1"), os.path.join(w, "res_small")) == 500
     # the workflow script with its child processes, and the fused run with the prefilter result on disk
     log = run(MMGPU, ["search", "q", "q", "res_script", "tmp_script", "-s", "5.7", "-a", "--threads", THREADS, "-v", "3"], w, emulate,
               extra_env={"MMGPU_FUSED": "0"})
