@@ -805,14 +805,14 @@ def nucl_section(args, gpu, matrices, rank):
     return res
 
 
-def nucl_search_section(args, gpu, matrices):
+def nucl_search_section(args, gpu, matrices, n_contigs, with_reference):
     """BASELINE.json configs[4] as a SEARCH: reads and their reverse complements (the workflow's extractframes
     step) against contigs cut at 10 000 nt (its splitsequence step, Search.cpp:194-198): exact 15-mer prefilter with the
     isNucleotide branch on the device -> the hit lists' diagonals -> the nucleotide alignment kernel.  CPU side: the real
     QueryMatcher on a sample of the reads, one thread, which is also the parity check of the hit lists."""
     from mmseqs2_amd import capi, workloads as wl
     t0 = time.time()
-    queries, (tres, toff), _ = wl.config5_nucleotide(args.nucl_contigs, args.nucl_reads, args.nucl_read_len, seed=20)
+    queries, (tres, toff), _ = wl.config5_nucleotide(n_contigs, args.nucl_reads, args.nucl_read_len, seed=20)
     # splitsequence: pieces of at most 10 000 nt
     cut = 10000
     pieces, src = [], []
@@ -862,7 +862,7 @@ def nucl_search_section(args, gpu, matrices):
             found += 1
     res = {"workload": "BASELINE.json configs[4] as a search: %d reads of %d nt + their reverse complements x %d contig pieces (<= 10 000 nt, "
                        "%d contigs ~LogNormal(20 kb)); exact 15-mer prefilter (spaced, --max-seqs 300, isNucleotide branch) -> banded "
-                       "nucleotide alignment of every hit" % (len(queries), args.nucl_read_len, len(pieces), args.nucl_contigs),
+                       "nucleotide alignment of every hit" % (len(queries), args.nucl_read_len, len(pieces), n_contigs),
            "reads": len(queries), "query_entries": len(both), "prefilter_s": round(t_pf, 4),
            "prefilter_entries_per_s": round(len(both) / t_pf, 1), "prefilter_hits": int(counts.sum()),
            "queries_handed_to_host": int((status != 0).sum()),
@@ -870,7 +870,7 @@ def nucl_search_section(args, gpu, matrices):
            "reads_per_s_prefilter_plus_alignment": round(len(queries) / (t_pf + t_al), 1),
            "query_entries_with_an_alignment_over_a_quarter_of_the_read": found,
            "setup_s": {"generate_and_split": round(t_gen, 1), "upload_and_device_index_build_4^15_offsets": round(t_index, 2)}}
-    if not args.no_cpu_baseline:
+    if with_reference and not args.no_cpu_baseline:
         from oracle import pyoracle
         if pyoracle.ref_available():
             t0 = time.perf_counter()
@@ -895,6 +895,71 @@ def nucl_search_section(args, gpu, matrices):
                                              "reference index build %.1f s (not counted)" % (n_s, sec, t_ref_index),
                                    "parity_vs_reference": {"queries_compared": n_s, "queries_with_different_hit_lists": bad}}
     return res
+
+
+def translated_search_section(args):
+    """BASELINE.json configs[4] as its text says - a 6-frame TRANSLATED search of 10 kb reads against contigs - through the binaries:
+    `mmseqs search reads contigs res tmp --search-type 2` (data/workflow/translated_search.sh: extractorfs of both sides ->
+    translatenucs -> prefilter -> align -> offsetalignment).  The frames are cut and translated by the reference's own modules on the
+    host; `prefilter` and `align` of the translated ORFs run on the device through the patched binary (amino-acid kernels).  CPU
+    baseline and parity: the stock binary on a sample of the reads and contigs (its result database must equal the patched
+    binary's entry by entry); the full size is timed through the patched binary only."""
+    import shutil
+    import subprocess
+    import tempfile
+    from mmseqs2_amd import workloads as wl, dbio
+    stock = os.path.join(ROOT, "oracle", "_ref", "mmseqs_stock")
+    patched = os.path.join(ROOT, "oracle", "_ref", "mmseqs_mmgpu")
+    if not (os.path.exists(stock) and os.path.exists(patched)):
+        return None
+    quota = cpu_quota_cores()
+    hw = os.cpu_count() or 1
+    threads = str(hw if quota is None else int(max(1, min(hw, round(2 * quota)))))
+    s_reads, s_contigs = (int(x) for x in args.translated_sample.split("x"))
+    w = tempfile.mkdtemp(prefix="mmgpu_translated_")
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = os.path.join(ROOT, "mmseqs2_amd", "lib") + ":" + env.get("LD_LIBRARY_PATH", "")
+
+    def run(b, a):
+        t0 = time.perf_counter()
+        r = subprocess.run([b] + a, cwd=w, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, timeout=args.module_timeout)
+        if r.returncode != 0:
+            raise RuntimeError("%s %s failed: %s" % (os.path.basename(b), a[0], r.stdout[-400:]))
+        return time.perf_counter() - t0, r.stdout
+
+    try:
+        t0 = time.perf_counter()
+        queries, (tres, toff), _ = wl.config5_nucleotide(args.translated_contigs, args.nucl_reads, args.nucl_read_len, seed=20)
+        contigs = wl.split(tres, toff)
+        wl.write_nucl_fasta(os.path.join(w, "contigs.fasta"), contigs, "c")
+        wl.write_nucl_fasta(os.path.join(w, "reads.fasta"), queries, "r")
+        # the sample: the first reads whose source contig lies among the first s_contigs, and those contigs
+        wl.write_nucl_fasta(os.path.join(w, "s_contigs.fasta"), contigs[:s_contigs], "c")
+        wl.write_nucl_fasta(os.path.join(w, "s_reads.fasta"), queries[:s_reads], "r")
+        for n in ("contigs", "reads", "s_contigs", "s_reads"):
+            run(stock, ["createdb", n + ".fasta", n, "-v", "1"])
+        t_setup = time.perf_counter() - t0
+        flags = ["--search-type", "2", "--threads", threads, "-v", "3"]
+        t_full, log = run(patched, ["search", "reads", "contigs", "res_full", "tmp_full"] + flags)
+        orfs = [int(l.split()[3]) for l in log.splitlines() if l.startswith(("Query database size:", "Target database size:"))][:2]
+        t_sp, _ = run(patched, ["search", "s_reads", "s_contigs", "res_sp", "tmp_sp"] + flags)
+        t_ss, _ = run(stock, ["search", "s_reads", "s_contigs", "res_ss", "tmp_ss"] + flags)
+        n, bad, _ = dbio.diff_dbs(os.path.join(w, "res_ss"), os.path.join(w, "res_sp"))
+        return {"workload": "BASELINE.json configs[4] as a translated search: `mmseqs search reads contigs --search-type 2` (default flags), %d reads "
+                            "of %d nt x %d contigs (~LogNormal(20 kb), %d nt); --threads %s"
+                            % (len(queries), args.nucl_read_len, args.translated_contigs, int(toff[-1]), threads),
+                "patched_wall_s": round(t_full, 2), "reads_per_s": round(len(queries) / t_full, 1),
+                "translated_orfs_query_target": orfs, "modules_on_device": log.count("MMGPU: device"),
+                "cpu_path_messages": len([l for l in log.splitlines() if "using the CPU path" in l]),
+                "setup_s": {"generate_fasta_createdb": round(t_setup, 1)},
+                "cpu_baseline": {"value": round(s_reads / t_ss, 1), "unit": "reads/s", "cores": int(threads), "kind": "reference",
+                                 "sample": "the stock binary, same command, on the first %d reads x the first %d contigs: %.2f s wall "
+                                           "(patched binary on the same sample: %.2f s)" % (s_reads, s_contigs, t_ss, t_sp),
+                                 "stock_wall_s": round(t_ss, 2), "patched_wall_s_same_sample": round(t_sp, 2),
+                                 "parity_vs_reference": {"result_entries_compared": n, "entries_differing": bad}},
+                "full_size": "50 000 contigs through the patched binary: profiles/r04_translated_search_50k.json (scripts/exp_translated_search.py)"}
+    finally:
+        shutil.rmtree(w, ignore_errors=True)
 
 
 def main():
@@ -923,7 +988,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-align-only", action="store_true", help="skip the configs[1] section")
     ap.add_argument("--no-nucl", action="store_true", help="skip the configs[4] nucleotide alignment section")
-    ap.add_argument("--nucl-contigs", type=int, default=4000)
+    ap.add_argument("--nucl-contigs", type=int, default=50000, help="configs[4]: 50 k contigs (~1.1e9 nt)")
+    ap.add_argument("--nucl-parity-contigs", type=int, default=4000,
+                    help="nucleotide search: size of the second, smaller run whose hit lists are compared with the reference's matcher "
+                         "(the reference's 4^15-offset index build over 50 k contigs alone takes minutes)")
+    ap.add_argument("--translated-contigs", type=int, default=5000, help="configs[4] as `search --search-type 2` through the binaries")
+    ap.add_argument("--translated-sample", type=str, default="100x2000", help="reads x contigs of the stock-binary run (CPU baseline + parity)")
+    ap.add_argument("--no-translated", action="store_true")
     ap.add_argument("--nucl-reads", type=int, default=1000)
     ap.add_argument("--nucl-read-len", type=int, default=10000)
     ap.add_argument("--headline-only", action="store_true", help="counter passes (scripts/collect_profiles.sh): the timed steps only")
@@ -982,9 +1053,16 @@ def main():
                 side["nucleotide_align"] = nucl_section(args, gpu, matrices, rank)
                 if rank == 0:
                     try:
-                        side["nucleotide_search"] = nucl_search_section(args, gpu, matrices)
+                        side["nucleotide_search"] = nucl_search_section(args, gpu, matrices, args.nucl_contigs, args.nucl_contigs <= args.nucl_parity_contigs)
+                        if args.nucl_contigs > args.nucl_parity_contigs and not args.no_cpu_baseline:
+                            side["nucleotide_search"]["parity_run"] = nucl_search_section(args, gpu, matrices, args.nucl_parity_contigs, True)
                     except Exception as e:      # a secondary section must not lose the line
                         side["nucleotide_search"] = {"error": repr(e)[:300]}
+                    if not (args.no_translated or args.no_modules):
+                        try:
+                            side["translated_search"] = translated_search_section(args)
+                        except Exception as e:
+                            side["translated_search"] = {"error": repr(e)[-300:]}
             except Exception as e:
                 side["nucleotide_align"] = {"error": "%s: %s" % (type(e).__name__, e)}
 

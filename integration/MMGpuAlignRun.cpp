@@ -90,6 +90,12 @@ MMGpuAlignSession *MMGpuAlignRun::begin(Alignment &al, EvalueComputation &evalue
     s->nucleotide = usableNucleotide(al);
     const unsigned int threads = al.threads;
     const size_t nTargets = al.tdbr->getSize();
+    {
+        bool dense = true;
+#pragma omp parallel for schedule(static) reduction(&& : dense) num_threads(threads)
+        for (size_t i = 0; i < nTargets; i++) dense = dense && al.tdbr->getDbKey(i) == i;
+        s->denseTargetKeys = dense;
+    }
     // fused search with the masking on the device: the prefilter module of this process left the unmasked targets resident, host
     // copy included (the same Sequence::numSequence, the same ids: checked key by key)
     bool residentAlready = false;
@@ -116,7 +122,7 @@ MMGpuAlignSession *MMGpuAlignRun::begin(Alignment &al, EvalueComputation &evalue
                     char *data = al.prefdbr->getData(id, thread_idx);
                     while (*data != '\0') {
                         Util::parseKey(data, key);
-                        const size_t dbId = al.tdbr->getId(Util::fast_atoi<DBKeyType>(key));
+                        const size_t dbId = s->targetId(al.tdbr, Util::fast_atoi<DBKeyType>(key));
                         if (dbId < nTargets) named[dbId] = 1;
                         data = Util::skipLine(data);
                     }
@@ -226,7 +232,7 @@ void MMGpuAlignRun::plan(MMGpuAlignSession *s, size_t start, size_t bucketSize) 
                 Util::parseKey(data, buffer);
                 const DBKeyType dbKey = Util::fast_atoi<DBKeyType>(buffer);
                 data = Util::skipLine(data);
-                const size_t dbId = al.tdbr->getId(dbKey);
+                const size_t dbId = s->targetId(al.tdbr, dbKey);
                 if (dbId >= al.tdbr->getSize() || al.tdbr->getData(dbId, thread_idx) == NULL) break;      // (the loop reports it and ends the run)
                 const int dbLen = (int)(s->tOff[dbId + 1] - s->tOff[dbId]);
                 if (!Util::canBeCovered(al.canCovThr, al.covMode, static_cast<float>(origQueryLen), static_cast<float>(dbLen))) continue;

@@ -30,6 +30,12 @@ struct MMGpuAlignSession {
     // amino-acid path reads
     const unsigned char *tData;
     const uint64_t *tOff;
+    // the target database numbers its sequences by their keys (key i = id i, what createdb writes): DBReader::getId's binary
+    // search per list entry - half of the list parsing at millions of targets - is then the identity
+    bool denseTargetKeys;
+    size_t targetId(DBReader<unsigned int> *tdbr, unsigned int key) const {
+        return denseTargetKeys ? (key < tdbr->getSize() ? (size_t)key : SIZE_MAX) : tdbr->getId(key);
+    }
     // amino-acid / profile queries
     MMGpuAlignBackend *backend;
     MMGpuMatcher *matcher;

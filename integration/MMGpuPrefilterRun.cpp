@@ -166,18 +166,29 @@ bool MMGpuPrefilterRun::run(Prefiltering &p, DBWriter &tmpDbw, size_t dbFrom, si
     // split dealt to its S contexts (sequence queries, diagonal scoring, device-built index - a host index is one table - and
     // --max-seqs x S <= 4096), or, with S = 1, the whole split and its index on the one context; query blocks are dealt to the groups.
     std::vector<MMGpuPrefilter *> devices;
-    if (!MMGpuRun::deviceIds().empty()) {
-        const int n = (int)MMGpuRun::deviceIds().size();
-        const bool nuclDb = Parameters::isEqualDbtype(p.targetSeqType, Parameters::DBTYPE_NUCLEOTIDES);
+    const bool nuclDb = Parameters::isEqualDbtype(p.targetSeqType, Parameters::DBTYPE_NUCLEOTIDES);
+    // one device, but more targets in this split than a context indexes: as many contexts on the device as it takes (one group of
+    // shards, the lists merged like those of several devices; usable() has checked that the configuration can be sharded)
+    const size_t maxTargets = MMGpuRun::envSize("MMGPU_TEST_MAX_TARGETS", MMGPU_PF_MAX_TARGETS);      // (tests: the path with a small database)
+    const int virtualShards = MMGpuRun::deviceIds().empty() && dbSize > maxTargets ? (int)((dbSize + maxTargets - 1) / maxTargets) : 0;
+    if (virtualShards > 1 && !(p.mmgpuDeviceIndex && MMGpuPrefilter::multiCapable(profileQuery, nuclDb, p.diagonalScoring == 0, p.maxResListLen, virtualShards))) {
+        Debug(Debug::INFO) << "MMGPU: " << dbSize << " targets in this split - a device context indexes " << MMGPU_PF_MAX_TARGETS
+                           << ", and this configuration cannot be dealt to several (sequence queries, diagonal scoring, device-built index, "
+                              "--max-seqs x contexts <= 4096) - using the CPU path\n";
+        ensureHostIndex(p, dbFrom, dbSize);
+        return false;
+    }
+    if (!MMGpuRun::deviceIds().empty() || virtualShards > 1) {
+        const int n = virtualShards > 1 ? virtualShards : (int)MMGpuRun::deviceIds().size();
         const bool shards = p.mmgpuDeviceIndex && MMGpuPrefilter::multiCapable(profileQuery, nuclDb, p.diagonalScoring == 0, p.maxResListLen, 2);
-        int g = MMGpuRun::queryGroups(n, shards);
-        while (n / g > 1 && !MMGpuPrefilter::multiCapable(profileQuery, nuclDb, p.diagonalScoring == 0, p.maxResListLen, n / g)) {
+        int g = virtualShards > 1 ? 1 : MMGpuRun::queryGroups(n, shards);
+        while (virtualShards <= 1 && n / g > 1 && !MMGpuPrefilter::multiCapable(profileQuery, nuclDb, p.diagonalScoring == 0, p.maxResListLen, n / g)) {
             do g++; while (n % g != 0);      // fewer shards per group until the merged list fits the exchange
         }
         if (!shards)
             Debug(Debug::INFO) << "MMGPU: this prefilter configuration runs without target shards (shards: sequence queries, diagonal "
                                   "scoring, device-built index, --max-seqs x shards <= 4096): every device holds the whole split\n";
-        const std::vector<mmgpu_multi *> &groups = MMGpuRun::groups(g);
+        const std::vector<mmgpu_multi *> &groups = MMGpuRun::groups(g, virtualShards);
         for (size_t i = 0; i < groups.size(); i++) {
             const bool single = mmgpu_multi_size(groups[i]) == 1;
             devices.push_back(new MMGpuPrefilter(single ? mmgpu_multi_ctx(groups[i], 0) : gpu, p.kmerSubMat, p.ungappedSubMat, p.aaBiasCorrection,
@@ -225,8 +236,11 @@ bool MMGpuPrefilterRun::run(Prefiltering &p, DBWriter &tmpDbw, size_t dbFrom, si
     if (local2.isValid()) ExtendedSubstitutionMatrix::freeScoreMatrix(local2);
     // Block size: the library's working buffers grow with the index entries a block touches (about 15 MB per query at 1 M
     // targets) and on some hosts the driver maps fresh device memory at only ~27 GB/s - blocks of 1024 queries and 4 GB candidate
-    // stages cost nothing measurable in kernel time and keep a module's first device call short.
+    // stages cost nothing measurable in kernel time and keep a module's first device call short.  The buffers follow the query
+    // residues rather than the query count: a block is MMGPU_PREF_BLOCK_QUERIES queries of 384 residues' worth, 16 times as many
+    // queries at most (the ORFs of a translated search are ~45 residues long: blocks of 1024 of them spent 17 ms each on 2 ms of kernels)
     const size_t maxBlockQueries = MMGpuRun::envSize("MMGPU_PREF_BLOCK_QUERIES", 1024);
+    const size_t maxBlockResidues = maxBlockQueries * 384;
     setenv("MMGPU_PF_STAGE_GB", "4", 0);
     // fused search (MMGpuFusedSearch): the entries of an unsplit run stay in memory for the alignment module of this process;
     // split runs merge their parts through files (mergePrefilterSplits / mergeTargetSplits) and are written as ever
@@ -235,7 +249,7 @@ bool MMGpuPrefilterRun::run(Prefiltering &p, DBWriter &tmpDbw, size_t dbFrom, si
     // fused search: the unmasked lookup (device masking) is what the alignment module would map and upload again - it stays
     // resident and the lookup goes to the fused run instead of being freed with this Prefiltering object.  An overlapped run
     // (the alignment module is already waiting) gets it now, the others when this run is over.
-    const bool leaveTargets = capture && p.mmgpuDeviceMask && p.mmgpuDeviceIndex && MMGpuRun::deviceIds().empty() && dbFrom == 0 &&
+    const bool leaveTargets = capture && p.mmgpuDeviceMask && p.mmgpuDeviceIndex && MMGpuRun::deviceIds().empty() && virtualShards <= 1 && dbFrom == 0 &&
                               dbSize == p.tdbr->getSize() && MMGpuFusedSearch::keepsTargets() && p.sequenceLookup != NULL;
     if (MMGpuFusedSearch::overlappedRun()) MMGpuFusedSearch::keepResidentTargets(leaveTargets ? p.sequenceLookup : NULL, p.tdbr, gpu);
 
@@ -265,9 +279,25 @@ bool MMGpuPrefilterRun::run(Prefiltering &p, DBWriter &tmpDbw, size_t dbFrom, si
     size_t dbMatches = 0, doubleMatches = 0, querySeqLenSum = 0, resSize = 0, diagonalOverflow = 0;
     const bool pipelined = !(getenv("MMGPU_PREF_PIPELINE") != NULL && getenv("MMGPU_PREF_PIPELINE")[0] == '0');
 
-    auto mapBlock = [&](Block &B, size_t next) {
+    std::vector<size_t> starts;      // first query of every block, and the end of the last
+    {
+        size_t residues = 0, count = 0;
+        for (size_t next = queryFrom; next < queryFrom + querySize; next++) {
+            const size_t len = p.qdbr->getSeqLen(next);
+            const bool full = count >= 16 * maxBlockQueries || (count >= maxBlockQueries && residues + len > maxBlockResidues);
+            if (count == 0 || full) {
+                starts.push_back(next);
+                residues = 0;
+                count = 0;
+            }
+            residues += len;
+            count++;
+        }
+        starts.push_back(queryFrom + querySize);
+    }
+
+    auto mapBlock = [&](Block &B, size_t next, size_t nq) {
         const double t0 = watch.now();
-        const size_t nq = std::min(maxBlockQueries, queryFrom + querySize - next);
         B.first = next;
         B.nq = nq;
         B.queryNum.assign(nq, std::vector<unsigned char>());
@@ -430,9 +460,7 @@ bool MMGpuPrefilterRun::run(Prefiltering &p, DBWriter &tmpDbw, size_t dbFrom, si
         watch.add(2, watch.now() - t0);
     };
 
-    std::vector<size_t> starts;
-    for (size_t next = queryFrom; next < queryFrom + querySize; next += maxBlockQueries) starts.push_back(next);
-    const size_t nBlocks = starts.size();
+    const size_t nBlocks = starts.size() - 1;
     std::mutex lock;
     std::condition_variable changed;
     size_t mapped = 0;                        // blocks [0, mapped) are ready for the device
@@ -473,7 +501,7 @@ bool MMGpuPrefilterRun::run(Prefiltering &p, DBWriter &tmpDbw, size_t dbFrom, si
     for (size_t g = 0; g < nGroups && g < nBlocks; g++) workers.push_back(std::thread(groupWorker, g));
     for (size_t nextMap = 0, nextWrite = 0; nextWrite < nBlocks;) {
         if (nextMap < nBlocks && nextMap - nextWrite < ringSlots) {
-            mapBlock(ring[nextMap % ringSlots], starts[nextMap]);
+            mapBlock(ring[nextMap % ringSlots], starts[nextMap], starts[nextMap + 1] - starts[nextMap]);
             {
                 std::lock_guard<std::mutex> guard(lock);
                 mapped = ++nextMap;

@@ -3,6 +3,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <string>
 #include <vector>
 
 #include "Debug.h"
@@ -104,37 +105,42 @@ int MMGpuRun::queryGroups(int nDevices, bool shardsPossible) {
 
 namespace {
 std::vector<mmgpu_multi *> layout;      // the groups opened last (a process runs one module at a time)
+size_t layoutContexts = 0;
 std::mutex layoutLock;
 }
 
-const std::vector<mmgpu_multi *> &MMGpuRun::groups(int g) {
+const std::vector<mmgpu_multi *> &MMGpuRun::groups(int g, int shardsOfOneDevice) {
     std::lock_guard<std::mutex> guard(layoutLock);
-    const std::vector<int> &ids = deviceIds();
+    std::vector<int> ids = deviceIds();
+    // no MMGPU_DEVICES, but a target split beyond what one context indexes (MMGPU_PF_MAX_TARGETS): that many contexts on the one device
+    if (ids.empty() && shardsOfOneDevice > 1) ids.assign((size_t)shardsOfOneDevice, (int)envSize("MMGPU_DEVICE", 0));
     if (ids.empty()) return layout;      // (empty)
     if (g < 1) g = layout.empty() ? 1 : (int)layout.size();
-    if ((int)layout.size() == g) return layout;
+    if ((int)layout.size() == g && layoutContexts == ids.size()) return layout;
     for (size_t i = 0; i < layout.size(); i++) mmgpu_destroy_multi(layout[i]);
     layout.clear();
+    layoutContexts = ids.size();
     const int s = (int)ids.size() / g;
     for (int i = 0; i < g; i++) {
         mmgpu_multi *m = NULL;
         if (mmgpu_init_multi(&m, ids.data() + (size_t)i * s, s) != 0) {
-            Debug(Debug::ERROR) << "MMGPU: cannot open the devices of MMGPU_DEVICES=" << getenv("MMGPU_DEVICES") << ": " << mmgpu_last_error() << "\n";
+            Debug(Debug::ERROR) << "MMGPU: cannot open " << ids.size() << " device contexts: " << mmgpu_last_error() << "\n";
             EXIT(EXIT_FAILURE);
         }
         layout.push_back(m);
     }
     char transport[32] = "none";
     if (s > 1) mmgpu_comm_info(mmgpu_multi_ctx(layout[0], 0), NULL, NULL, transport, sizeof(transport));
-    Debug(Debug::INFO) << "MMGPU: " << ids.size() << " device contexts (MMGPU_DEVICES=" << getenv("MMGPU_DEVICES") << "): " << g
+    Debug(Debug::INFO) << "MMGPU: " << ids.size() << " device contexts (" << (deviceIds().empty() ? "one device, target split above the limit of a context" : "MMGPU_DEVICES=" + std::string(getenv("MMGPU_DEVICES"))) << "): " << g
                        << " query group" << (g > 1 ? "s" : "") << " x " << s << " target shard" << (s > 1 ? "s" : "")
                        << ", exchange transport: " << transport << "\n";
     return layout;
 }
 
 std::vector<mmgpu_ctx *> MMGpuRun::allContexts() {
-    const std::vector<mmgpu_multi *> &gs = groups(0);
     std::vector<mmgpu_ctx *> all;
+    if (deviceIds().empty()) return all;
+    const std::vector<mmgpu_multi *> &gs = groups(0);
     for (size_t i = 0; i < gs.size(); i++)
         for (int d = 0; d < mmgpu_multi_size(gs[i]); d++) all.push_back(mmgpu_multi_ctx(gs[i], d));
     return all;

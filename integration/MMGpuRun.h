@@ -61,7 +61,9 @@ public:
     static int queryGroups(int nDevices, bool shardsPossible);
     // the contexts of MMGPU_DEVICES as g multi-device objects of n / g contexts each (mmgpu_init_multi; g = 0: the layout
     // opened last, one group if none); empty without MMGPU_DEVICES.  Opening another layout closes the previous one.
-    static const std::vector<mmgpu_multi *> &groups(int g);
+    // shardsOfOneDevice > 1 without MMGPU_DEVICES: that many contexts on the one device (a target split of more than
+    // MMGPU_PF_MAX_TARGETS sequences is dealt to them like to several devices)
+    static const std::vector<mmgpu_multi *> &groups(int g, int shardsOfOneDevice = 0);
     static std::vector<mmgpu_ctx *> allContexts();
 };
 

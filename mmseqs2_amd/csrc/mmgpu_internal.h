@@ -557,7 +557,7 @@ struct BlockCache {
     size_t cached = 0;
     bool closed = false;   // the context is gone (batches may outlive it): blocks go straight back to the runtime
     std::mutex lock;       // a prefilter thread and an alignment thread may work on one context (the fused search of the drop-in)
-    static constexpr size_t LIMIT = 32ull << 30;
+    static constexpr size_t LIMIT = 96ull << 30;     // (of 288 GB; an allocation that fails trims the cache and retries)
     static size_t round_up(size_t n) {
         if (n <= 512) return 512;
         int top = 63 - __builtin_clzll((unsigned long long)n);

@@ -588,6 +588,16 @@ extern "C" int mmgpu_pf_prepare(mmgpu_ctx *c, const mmgpu_pf_params *par, const 
     HIP_TRY(hipSetDevice(c->device));
 
     mmgpu_pf_batch_t *b = new mmgpu_pf_batch_t();
+    // the batch's buffers come from / go back to the context's block cache: a process prepares batch after batch (and, like the
+    // drop-in's prefilter hook, the next one while this one runs), a fresh hipMalloc costs 25 - 40 ms per GB on some hosts
+    for (DevBuf *d : {&b->d_qres, &b->d_qthr, &b->d_qcorr, &b->d_qoff, &b->d_qident, &b->d_qself, &b->d_qkind, &b->d_qisprof, &b->d_pscore,
+                      &b->d_pletter, &b->d_qrows, &b->d_qncand, &b->d_sat, &b->d_qnsat, &b->d_big_keys, &b->d_big_diags, &b->d_nsim, &b->d_qtot,
+                      &b->d_qbase, &b->d_list_base, &b->d_pos_entries, &b->d_peb, &b->d_qentries, &b->d_qtile_base, &b->d_qntiles,
+                      &b->d_bucket_count, &b->d_bucket_off, &b->d_ovf_queries, &b->d_qnseg, &b->d_seg_start, &b->d_qfinal, &b->d_ovf_base,
+                      &b->d_ovf_a, &b->d_ovf_b, &b->d_ovf_ocount, &b->d_ovf_totals, &b->d_cand_small, &b->d_cand_base, &b->d_cand_count,
+                      &b->d_cells, &b->d_surv_count, &b->d_hits, &b->d_hit_count, &b->d_diag_thr, &b->d_qflags, &b->d_redo, &b->x_recv_hits,
+                      &b->x_recv_counts, &b->x_hits, &b->x_counts, &b->x_flags, &b->x_ident})
+        d->bind(c->cache);
     b->par = *par;
     if (b->par.min_diag_score < 1) b->par.min_diag_score = 1;
     b->nq = nq;

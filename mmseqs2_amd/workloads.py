@@ -182,6 +182,16 @@ def mutate_nucl(rng, seq, sub=0.10, indel=0.02):
     return s if len(s) else np.zeros(1, np.uint8)
 
 
+def write_nucl_fasta(path, seqs, prefix="s"):
+    """numeric nucleotide sequences (codes of NUCL_LETTERS) -> FASTA (input of `mmseqs createdb`)"""
+    lut = np.frombuffer(NUCL_LETTERS.encode(), np.uint8)
+    with open(path, "wb") as fh:
+        for i, s in enumerate(seqs):
+            fh.write(b">%s%d\n" % (prefix.encode(), i))
+            fh.write(lut[s].tobytes())
+            fh.write(b"\n")
+
+
 def config5_nucleotide(n_contigs=4000, n_reads=1000, read_len=10000, false_hits=4, seed=20):
     """-> (queries list, (tres, toff), pairs [(query, target, diagonal16, reverse)]).  Contig lengths ~ LogNormal with
     median 20 kb, clipped to [read_len + 500, 60000] (the reference splits longer sequences, Parameters.h:271).  Every
@@ -190,7 +200,7 @@ def config5_nucleotide(n_contigs=4000, n_reads=1000, read_len=10000, false_hits=
     rng = np.random.default_rng(seed)
     lens = np.clip(np.round(rng.lognormal(np.log(20000.0), 0.5, size=n_contigs)), read_len + 500, 60000).astype(np.int64)
     toff = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
-    tres = rng.integers(0, 4, size=int(toff[-1])).astype(np.uint8)
+    tres = rng.integers(0, 4, size=int(toff[-1]), dtype=np.uint8)      # (1.1e9 letters for the 50 000 contigs of configs[4])
     queries, pairs = [], []
     for r in range(n_reads):
         c = int(rng.integers(0, n_contigs))

@@ -709,11 +709,21 @@ def test_query_groups_by_target_shards_in_one_process(tmp_path):
     log = run(MMGPU, ["prefilter", "q", "q", "pref_g0", "-s", "4", "--diag-score", "0", "--threads", THREADS, "-v", "3"], w, extra_env=env)
     assert "runs without target shards" in log and "4 query groups x 1 target shard," in log and "using the CPU path" not in log, log[-2500:]
     assert same(os.path.join(w, "pref_s0"), os.path.join(w, "pref_g0")) == 500
+    # a target split with more sequences than one context indexes (8 388 608; 200 for this test) on ONE device: the hook opens as
+    # many contexts on it as it takes and merges their lists
+    log = run(MMGPU, ["prefilter", "q", "q", "pref_v", "-s", "5.7", "--threads", THREADS, "-v", "3"], w,
+              extra_env={"MMGPU_TEST_MAX_TARGETS": "200", "MMGPU_PREF_BLOCK_QUERIES": "64"})
+    assert "3 device contexts (one device" in log and "1 query group x 3 target shards" in log and "using the CPU path" not in log, log[-2500:]
+    assert same(os.path.join(w, "pref_s"), os.path.join(w, "pref_v")) == 500
+    log = run(MMGPU, ["search", "q", "q", "res_v", "tmp_v", "-s", "5.7", "-a", "--threads", THREADS, "-v", "3"], w,
+              extra_env={"MMGPU_TEST_MAX_TARGETS": "200"})
+    assert "1 query group x 3 target shards" in log and "using the CPU path" not in log, log[-2500:]
     # the whole search: the alignment module of the same process deals its queries to the four contexts the prefilter opened
     run(STOCK, ["search", "q", "q", "res_s", "tmp_s", "-s", "5.7", "-a", "--threads", THREADS, "-v", "2"], w)
     log = run(MMGPU, ["search", "q", "q", "res_g", "tmp_g", "-s", "5.7", "-a", "--threads", THREADS, "-v", "3"], w, extra_env=env)
     assert "2 query groups x 2 target shards" in log and "using the CPU path" not in log, log[-2500:]
     assert same(os.path.join(w, "res_s"), os.path.join(w, "res_g")) == 500
+    assert same(os.path.join(w, "res_s"), os.path.join(w, "res_v")) == 500
 
 
 def _block_aligner_modes(tmp, emulate):
