@@ -1303,6 +1303,8 @@ extern "C" int mmgpu_sw_block_backtrace(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const
             const uint64_t slot_bytes = tier == 0   ? slot_size(typical_len, 2, BLOCK_MAX_SIZE, false)
                                         : tier == 1 ? slot_size(longest_todo, BLOCK_MID_SIZE / 64, BLOCK_MID_SIZE, false)
                                                     : slot_size(longest_todo, BLOCK_REF_MAX_SIZE / 64, BLOCK_REF_MAX_SIZE, true);
+            // (tier 0: 16 wavefronts per CU is what its 9 KB of LDS allows; 8 per CU, or 32 with a 128-row first tier, move the call by
+            // +12 % / -3 %, profiles/r04_exp_block_occupancy.txt - the kernel is bound by its ~200 instructions per column, not by latency)
             const uint64_t want = std::min<uint64_t>(todo.size(), (uint64_t)std::max(c->compute_units, 1) * (tier == 0 ? 16 : 4));
             const uint32_t slots = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(want, pool_limit / slot_bytes));
             hipStream_t st = s;
