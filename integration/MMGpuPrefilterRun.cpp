@@ -122,6 +122,28 @@ bool MMGpuPrefilterRun::deviceMasks(Prefiltering &p) {
     return true;
 }
 
+namespace {
+// a target split of more sequences than one context indexes is dealt to several contexts on the device - where the configuration
+// allows it (MMGpuPrefilter::multiCapable); 0 = no such split
+int contextsForLargeSplit(size_t dbSize) {
+    const size_t maxTargets = MMGpuRun::envSize("MMGPU_TEST_MAX_TARGETS", MMGPU_PF_MAX_TARGETS);      // (tests: the path with a small database)
+    return MMGpuRun::deviceIds().empty() && dbSize > maxTargets ? (int)((dbSize + maxTargets - 1) / maxTargets) : 0;
+}
+bool largeSplitNeedsHost(Prefiltering &p, size_t dbSize, bool deviceIndex, size_t maxResListLen, int querySeqType, int targetSeqType, int diagonalScoring) {
+    const int n = contextsForLargeSplit(dbSize);
+    if (n <= 1) return false;
+    (void)p;
+    return !(deviceIndex && MMGpuPrefilter::multiCapable(Parameters::isEqualDbtype(querySeqType, Parameters::DBTYPE_HMM_PROFILE),
+                                                         Parameters::isEqualDbtype(targetSeqType, Parameters::DBTYPE_NUCLEOTIDES),
+                                                         diagonalScoring == 0, maxResListLen, n));
+}
+}
+
+bool MMGpuPrefilterRun::keepsEntriesInMemory(Prefiltering &p, const std::string &resultDB, size_t dbSize) {
+    return p.splits == 1 && MMGpuFusedSearch::capturing(resultDB) && usable(p) &&
+           !largeSplitNeedsHost(p, dbSize, p.mmgpuDeviceIndex, p.maxResListLen, p.querySeqType, p.targetSeqType, p.diagonalScoring);
+}
+
 bool MMGpuPrefilterRun::runsUnsplitWithResidentTargets(Prefiltering &p, size_t *maxResListLen) {
     *maxResListLen = p.maxResListLen;
     // (index and lookup of an unsplit run exist once the constructor has returned: Prefiltering.cpp:196-199)
@@ -169,9 +191,8 @@ bool MMGpuPrefilterRun::run(Prefiltering &p, DBWriter &tmpDbw, size_t dbFrom, si
     const bool nuclDb = Parameters::isEqualDbtype(p.targetSeqType, Parameters::DBTYPE_NUCLEOTIDES);
     // one device, but more targets in this split than a context indexes: as many contexts on the device as it takes (one group of
     // shards, the lists merged like those of several devices; usable() has checked that the configuration can be sharded)
-    const size_t maxTargets = MMGpuRun::envSize("MMGPU_TEST_MAX_TARGETS", MMGPU_PF_MAX_TARGETS);      // (tests: the path with a small database)
-    const int virtualShards = MMGpuRun::deviceIds().empty() && dbSize > maxTargets ? (int)((dbSize + maxTargets - 1) / maxTargets) : 0;
-    if (virtualShards > 1 && !(p.mmgpuDeviceIndex && MMGpuPrefilter::multiCapable(profileQuery, nuclDb, p.diagonalScoring == 0, p.maxResListLen, virtualShards))) {
+    const int virtualShards = contextsForLargeSplit(dbSize);
+    if (largeSplitNeedsHost(p, dbSize, p.mmgpuDeviceIndex, p.maxResListLen, p.querySeqType, p.targetSeqType, p.diagonalScoring)) {
         Debug(Debug::INFO) << "MMGPU: " << dbSize << " targets in this split - a device context indexes " << MMGPU_PF_MAX_TARGETS
                            << ", and this configuration cannot be dealt to several (sequence queries, diagonal scoring, device-built index, "
                               "--max-seqs x contexts <= 4096) - using the CPU path\n";

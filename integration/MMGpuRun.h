@@ -112,6 +112,9 @@ public:
     // fused search: this object will run unsplit through the device path and leave its targets resident for the alignment
     // module (MMGpuFusedSearch::keepResidentTargets) - the alignment module can then start before the prefilter has finished
     static bool runsUnsplitWithResidentTargets(Prefiltering &p, size_t *maxResListLen);
+    // Prefiltering::runSplit, before it opens its DBWriter: every entry of this split will go to the fused search's in-memory
+    // store (MMGpuPrefilterRun::run decides the same way), none to the writer
+    static bool keepsEntriesInMemory(Prefiltering &p, const std::string &resultDB, size_t dbSize);
     // the reference's own index for queries the device hands back (overflow, long sequences, ties), built when first needed
     static void ensureHostIndex(Prefiltering &p, size_t dbFrom, size_t dbSize);
     // the `omp parallel` block of Prefiltering::runSplit (:820-918): writes every query's entry to tmpDbw, fills the
