@@ -40,9 +40,9 @@ extern "C" int mmgpu_init(mmgpu_ctx **out, int device_id) {
 }
 
 static void free_db(DeviceDb &db) {
-    if (db.res) (void)hipFree(db.res);
-    if (db.off4) (void)hipFree(db.off4);
-    if (db.len) (void)hipFree(db.len);
+    dev_free(db.res);
+    dev_free(db.off4);
+    dev_free(db.len);
     db = DeviceDb();
 }
 
@@ -50,7 +50,7 @@ extern "C" void mmgpu_destroy(mmgpu_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     free_db(c->db);
-    if (c->pf_masked_res) { (void)hipFree(c->pf_masked_res); c->pf_masked_res = nullptr; }
+    if (c->pf_masked_res) { dev_free(c->pf_masked_res); c->pf_masked_res = nullptr; }
     mmgpu::pf_index_free(c);
     (void)hipDeviceSynchronize();
     mmgpu::comm_free(c);
@@ -104,7 +104,7 @@ extern "C" int mmgpu_load_targets(mmgpu_ctx *c, const uint8_t *residues, const u
     // a resident prefilter index belongs to the database it was built / loaded for: it goes with it
     mmgpu::pf_index_free(c);
     c->shard.on = false;
-    if (c->pf_masked_res) { (void)hipFree(c->pf_masked_res); c->pf_masked_res = nullptr; }
+    if (c->pf_masked_res) { dev_free(c->pf_masked_res); c->pf_masked_res = nullptr; }
     free_db(c->db);
     std::vector<uint32_t> off4(std::max<uint32_t>(n, 1)), len(std::max<uint32_t>(n, 1));
     uint64_t cur4 = 16;      // 64 bytes of padding in front: the reverse scan reads up to 3 bytes before a target (sw_kernel.hip)
@@ -138,9 +138,9 @@ extern "C" int mmgpu_load_targets(mmgpu_ctx *c, const uint8_t *residues, const u
         if (up) (void)hipStreamDestroy(up);
     };
 #define DB_TRY(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { drop(); free_db(db); return fail(MMGPU_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__)); } } while (0)
-    DB_TRY(hipMalloc((void **)&db.res, bytes));
-    DB_TRY(hipMalloc((void **)&db.off4, off4.size() * sizeof(uint32_t)));
-    DB_TRY(hipMalloc((void **)&db.len, len.size() * sizeof(uint32_t)));
+    DB_TRY(dev_malloc((void **)&db.res, bytes));
+    DB_TRY(dev_malloc((void **)&db.off4, off4.size() * sizeof(uint32_t)));
+    DB_TRY(dev_malloc((void **)&db.len, len.size() * sizeof(uint32_t)));
     DB_TRY(hipStreamCreateWithFlags(&up, hipStreamNonBlocking));
     DB_TRY(hipMemsetAsync(db.res, alphabet, bytes, up));
     DB_TRY(hipMemcpyAsync(db.off4, off4.data(), off4.size() * sizeof(uint32_t), hipMemcpyHostToDevice, up));
@@ -218,6 +218,23 @@ extern "C" int mmgpu_warmup(mmgpu_ctx *c) {
     return MMGPU_OK;
 }
 
+// Device memory reserved now for the allocations to come (DeviceArena, mmgpu_internal.h): `bytes` in chunks of 4 GB, each usable
+// as soon as it exists - a caller runs this on a helper thread while it reads its input.  Reserved memory stays with the process.
+extern "C" int mmgpu_reserve(mmgpu_ctx *c, uint64_t bytes) {
+    if (!c) return fail(MMGPU_ERR_ARG, "mmgpu_reserve: NULL context");
+    HIP_TRY(hipSetDevice(c->device));
+    DeviceArena &a = DeviceArena::of(c->device);
+    const uint64_t chunk = 4ull << 30;
+    for (uint64_t done = 0; done < bytes; done += chunk) {
+        const size_t n = (size_t)std::min<uint64_t>(chunk, bytes - done);
+        void *p = nullptr;
+        const hipError_t e = hipMalloc(&p, n);
+        if (e != hipSuccess) { (void)hipGetLastError(); break; }      // (less than asked for: later requests fall back to hipMalloc)
+        a.add(p, n);
+    }
+    return MMGPU_OK;
+}
+
 // tantan masking of the resident targets for the prefilter (tantan_kernel.hip): what IndexBuilder::fillDatabase does to every
 // target before it counts k-mers (IndexBuilder.cpp:148, Masker.cpp:14-57 with maskTantan only).  The alignment kernels keep
 // reading the unmasked residues.
@@ -231,7 +248,7 @@ extern "C" int mmgpu_pf_mask_targets(mmgpu_ctx *c, const double *likelihood_rati
     mmgpu::pf_index_free(c);      // an index built from the unmasked residues does not describe the masked ones
     hipStream_t s = c->stream;
     const uint32_t n = c->db.n;
-    if (!c->pf_masked_res) HIP_TRY(hipMalloc((void **)&c->pf_masked_res, c->db.res_bytes));
+    if (!c->pf_masked_res) HIP_TRY(dev_malloc((void **)&c->pf_masked_res, c->db.res_bytes));
     HIP_TRY(hipMemcpyAsync(c->pf_masked_res, c->db.res, c->db.res_bytes, hipMemcpyDeviceToDevice, s));
     // targets in order of length (longest first): 64 consecutive ones share a wavefront and end together; counting sort
     std::vector<uint32_t> order(std::max<uint32_t>(n, 1));

@@ -548,6 +548,96 @@ inline int fail(int code, const std::string &msg) {
             return mmgpu::fail(MMGPU_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));         \
     } while (0)
 
+// Device memory reserved ahead of its use (mmgpu_reserve): on some hosts the driver maps fresh device memory at only 25 - 40 GB/s,
+// i.e. a process that allocates 20 GB on its way pays half a second inside hipMalloc.  A caller that has something else to do
+// first - the fused search reads its databases - reserves chunks on a helper thread; dev_malloc carves later requests out of
+// them (first fit over the freed pieces, then the untouched tail of a chunk) and falls back to hipMalloc when nothing fits;
+// dev_free returns a piece to its chunk after draining the device, as hipFree does.  One arena per device of the process.
+struct DeviceArena {
+    struct Chunk { uint8_t *base; size_t size, used; };
+    std::mutex lock;
+    std::atomic<int> n_chunks{0};                       // (read without the lock: "is there an arena at all")
+    std::vector<Chunk> chunks;
+    std::map<uint8_t *, size_t> live;                   // carved pieces in use
+    std::multimap<size_t, uint8_t *> freed;             // pieces given back, by size
+    static DeviceArena &of(int device) {
+        static std::mutex m;
+        static std::map<int, DeviceArena *> all;
+        std::lock_guard<std::mutex> g(m);
+        DeviceArena *&a = all[device];
+        if (!a) a = new DeviceArena();
+        return *a;
+    }
+    void add(void *base, size_t size) {
+        std::lock_guard<std::mutex> g(lock);
+        chunks.push_back(Chunk{static_cast<uint8_t *>(base), size, 0});
+        n_chunks++;
+    }
+    void *take(size_t n) {
+        n = (n + 4095) & ~(size_t)4095;
+        std::lock_guard<std::mutex> g(lock);
+        auto it = freed.lower_bound(n);
+        if (it != freed.end() && it->first <= n + n / 4) {      // (a piece much larger than the request stays for a larger one)
+            uint8_t *p = it->second;
+            live[p] = it->first;
+            freed.erase(it);
+            return p;
+        }
+        for (Chunk &c : chunks)
+            if (c.size - c.used >= n) {
+                uint8_t *p = c.base + c.used;
+                c.used += n;
+                live[p] = n;
+                return p;
+            }
+        return nullptr;
+    }
+    bool owns(const void *p) {
+        std::lock_guard<std::mutex> g(lock);
+        return live.find(static_cast<uint8_t *>(const_cast<void *>(p))) != live.end();
+    }
+    bool give(void *p) {
+        std::lock_guard<std::mutex> g(lock);
+        auto it = live.find(static_cast<uint8_t *>(p));
+        if (it == live.end()) return false;
+        freed.emplace(it->second, it->first);
+        live.erase(it);
+        return true;
+    }
+};
+
+// every device buffer of the library is allocated and freed through these two
+// (MMGPU_ALLOC_TRACE=1: every hipMalloc with its size and wall time on stderr - where a module's first device call spends its time)
+inline hipError_t dev_malloc(void **p, size_t n) {
+    int device = 0;
+    if (hipGetDevice(&device) == hipSuccess) {
+        DeviceArena &a = DeviceArena::of(device);
+        if (a.n_chunks.load() > 0) {
+            if (void *q = a.take(n)) { *p = q; return hipSuccess; }
+        }
+    }
+    static const bool on = getenv("MMGPU_ALLOC_TRACE") != nullptr;
+    if (!on) return hipMalloc(p, n);
+    const auto t0 = std::chrono::steady_clock::now();
+    const hipError_t e = hipMalloc(p, n);
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    fprintf(stderr, "[mmgpu alloc] hipMalloc %.1f MB %.2f ms\n", (double)n / 1048576.0, ms);
+    return e;
+}
+inline void dev_free(void *p) {
+    if (!p) return;
+    int device = 0;
+    if (hipGetDevice(&device) == hipSuccess) {
+        DeviceArena &a = DeviceArena::of(device);
+        if (a.n_chunks.load() > 0 && a.owns(p)) {
+            (void)hipDeviceSynchronize();      // hipFree's guarantee: nothing in flight reads the block any more
+            (void)a.give(p);
+            return;
+        }
+    }
+    (void)hipFree(p);
+}
+
 // Freed device blocks of one context, kept for the next batch: a streaming search prepares and frees one alignment
 // batch per prefilter batch, and hipMalloc / hipFree (which also drains the device) per buffer would cost more than
 // the kernels.  Reuse is safe because every use of a block is ordered on the context's stream.  Sizes are rounded to 3 significant bits so that batches of
@@ -578,29 +668,17 @@ struct BlockCache {
     }
     void give(void *p, size_t cap) {
         std::lock_guard<std::mutex> guard(lock);
-        if (closed || cached + cap > LIMIT) { (void)hipFree(p); return; }
+        if (closed || cached + cap > LIMIT) { dev_free(p); return; }
         blocks.emplace(cap, p);
         cached += cap;
     }
     void trim() {
         std::lock_guard<std::mutex> guard(lock);
-        for (auto &kv : blocks) (void)hipFree(kv.second);
+        for (auto &kv : blocks) dev_free(kv.second);
         blocks.clear();
         cached = 0;
     }
 };
-
-// MMGPU_ALLOC_TRACE=1: every hipMalloc of a device buffer with its size and wall time on stderr (where a module's first device
-// call spends its time)
-inline hipError_t traced_malloc(void **p, size_t n) {
-    static const bool on = getenv("MMGPU_ALLOC_TRACE") != nullptr;
-    if (!on) return hipMalloc(p, n);
-    const auto t0 = std::chrono::steady_clock::now();
-    const hipError_t e = hipMalloc(p, n);
-    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    fprintf(stderr, "[mmgpu alloc] hipMalloc %.1f MB %.2f ms\n", (double)n / 1048576.0, ms);
-    return e;
-}
 
 struct DevBuf {
     void *p = nullptr;
@@ -627,7 +705,7 @@ struct DevBuf {
     void release() {
         if (!p) return;
         if (cache && cap) cache->give(p, cap);
-        else (void)hipFree(p);
+        else dev_free(p);
         p = nullptr;
         cap = 0;
     }
@@ -639,16 +717,16 @@ struct DevBuf {
             cap = BlockCache::round_up(n);
             p = cache->take(cap);
             if (p) return hipSuccess;
-            hipError_t e = traced_malloc(&p, cap);
+            hipError_t e = dev_malloc(&p, cap);
             if (e != hipSuccess) {      // out of memory with blocks parked in the cache: give them back and retry
                 (void)hipGetLastError();
                 cache->trim();
-                e = hipMalloc(&p, cap);
+                e = dev_malloc(&p, cap);
             }
             if (e != hipSuccess) { p = nullptr; cap = 0; bytes = 0; }   // (bytes = 0: a later, smaller reserve() must allocate)
             return e;
         }
-        const hipError_t e = traced_malloc(&p, n);
+        const hipError_t e = dev_malloc(&p, n);
         if (e != hipSuccess) { p = nullptr; bytes = 0; (void)hipGetLastError(); }
         return e;
     }

@@ -149,6 +149,7 @@ int mmgpu_pf_mask_targets(mmgpu_ctx *c, const double *lr, int alphabet, double m
 
 // nothing to load on this side of the socket
 int mmgpu_warmup(mmgpu_ctx *) { return MMGPU_OK; }
+int mmgpu_reserve(mmgpu_ctx *, uint64_t) { return MMGPU_OK; }      // (the server owns the device memory)
 
 int mmgpu_sw_block_tiers(const mmgpu_sw_batch_t *, uint32_t *first_tier, uint32_t *second_tier) {
     if (first_tier) *first_tier = 0;
