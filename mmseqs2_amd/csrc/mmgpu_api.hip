@@ -528,6 +528,15 @@ static int sw_prepare_impl(mmgpu_ctx *c, const mmgpu_sw_params *par, const mmgpu
         if (pf_stride > (uint32_t)SW_PF_MAX_LIST) return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_sw_prepare_from_pf: lists longer than 4096");
     }
     if (!c->db.res) return fail(MMGPU_ERR_STATE, "mmgpu_sw_prepare: no targets loaded");
+    static const bool prep_trace = getenv("MMGPU_TRACE") != nullptr;      // where the host side of a batch's preparation goes
+    auto prep_now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double prep_mark = prep_now();
+    auto prep_lap = [&](const char *what) {
+        if (!prep_trace) return;
+        const double t = prep_now();
+        fprintf(stderr, "[mmgpu sw_prepare] %s %.3f s\n", what, t - prep_mark);
+        prep_mark = t;
+    };
     if (par->alphabet != c->db.alphabet) return fail(MMGPU_ERR_ARG, "mmgpu_sw_prepare: alphabet differs from the loaded targets");
     if (mode != MMGPU_SW_SCORE_END && mode != MMGPU_SW_START) return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_sw_prepare: unknown mode");
     if (par->gap_open < par->gap_extend || par->gap_extend < 0 || par->gap_open > 32767)
@@ -677,6 +686,7 @@ static int sw_prepare_impl(mmgpu_ctx *c, const mmgpu_sw_params *par, const mmgpu
         out_cursor += Q.n_targets;
         b->h_qout_off[i + 1] = out_cursor;
     }
+    prep_lap("queries copied, buffers sized");
     if (!deferred.empty()) {
         // Per query: sort the prefilter list by target length (longest first) so the 8 targets a wave runs together end
         // together, cut it into jobs.  3 M pairs of a 10 000-query block cost 0.2 s on one thread (the sort's comparisons
@@ -759,6 +769,7 @@ static int sw_prepare_impl(mmgpu_ctx *c, const mmgpu_sw_params *par, const mmgpu
             }
             for (std::thread &t : pool) t.join();
         }
+        prep_lap("lists sorted by target length, jobs cut (threads)");
         for (size_t d = 0; d < deferred.size(); d++) {
             const Deferred &D = deferred[d];
             PerQuery &P = pq[d];
@@ -776,6 +787,7 @@ static int sw_prepare_impl(mmgpu_ctx *c, const mmgpu_sw_params *par, const mmgpu
                 add_rev_jobs(D.query, D.hit_cursor, n_t, D.shape, (uint64_t)qs[D.query].qlen * (P.rev_mid_len + 1));
         }
     }
+    prep_lap("jobs joined");
     b->pairs = total_hits;
     b->h_qoff = qoff;
     b->from_pf = pf != nullptr;
@@ -832,6 +844,7 @@ static int sw_prepare_impl(mmgpu_ctx *c, const mmgpu_sw_params *par, const mmgpu
         }
         B_TRY(upload(b->d_jobs, sorted, s));
     }
+    prep_lap("uploads enqueued, jobs ordered");
     // column scratch of the multi-tile jobs: a pool with one slot per workgroup that can be resident at once (not one
     // per job: a batch of long queries against one very long target would ask for 100+ GB), sized by the longest
     // target any list holds
@@ -875,6 +888,7 @@ static int sw_prepare_impl(mmgpu_ctx *c, const mmgpu_sw_params *par, const mmgpu
         }
     }
 #undef B_TRY
+    prep_lap("scratch + stream drained");
     *out = b;
     return MMGPU_OK;
 }
