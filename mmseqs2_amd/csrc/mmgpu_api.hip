@@ -485,6 +485,7 @@ struct mmgpu_sw_batch_t {
     bool owned = false;
     uint32_t o_stride = 0, o_cap = 0;
     int o_ranks = 0;
+    bool o_dense = false;          // a rank's send buffer overflowed once: every rank's buffer holds all slots from now on
     DevBuf o_lhits, o_lcounts, o_lslot;        // merged lists restricted to this shard's targets (local ids) + their list positions
     DevBuf o_send, o_counter, o_recv, o_recv_counters, o_full, o_status;
 };
@@ -974,7 +975,7 @@ int sw_gather_begin(mmgpu_ctx *c, mmgpu_sw_batch_t *b, int n_ranks, XchgBlock bl
     HIP_TRY(hipSetDevice(c->device));
     const uint64_t slots = (uint64_t)b->n_queries * b->o_stride;
     static const char *dense = getenv("MMGPU_SW_GATHER_DENSE");      // every rank may own everything (no overflow possible)
-    const uint64_t cap64 = (dense || n_ranks == 1) ? slots : std::min<uint64_t>(slots, slots / (uint64_t)n_ranks * 3 / 2 + 4096);
+    const uint64_t cap64 = (dense || b->o_dense || n_ranks == 1) ? slots : std::min<uint64_t>(slots, slots / (uint64_t)n_ranks * 3 / 2 + 4096);
     const uint32_t cap = (uint32_t)std::max<uint64_t>(cap64, 1);
     if (b->o_cap != cap || b->o_ranks != n_ranks) {
         for (DevBuf *d : {&b->o_send, &b->o_counter, &b->o_recv, &b->o_recv_counters, &b->o_full, &b->o_status}) d->bind(c->cache);
@@ -1003,6 +1004,18 @@ int sw_gather_begin(mmgpu_ctx *c, mmgpu_sw_batch_t *b, int n_ranks, XchgBlock bl
     return MMGPU_OK;
 }
 
+// after phase 3: did a rank pack more than its send buffer holds (hits clustered in one shard)?  Every rank sees all counters, so
+// every rank answers the same; the caller then repeats the three phases with buffers that hold every slot (o_dense).
+int sw_gather_overflowed(mmgpu_ctx *c, mmgpu_sw_batch_t *b, bool *overflowed) {
+    HIP_TRY(hipSetDevice(c->device));
+    uint32_t st[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(st, b->o_status.p, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *overflowed = st[1] != 0 && !b->o_dense;
+    if (*overflowed) b->o_dense = true;
+    return MMGPU_OK;
+}
+
 // phase 3: scatter every rank's records into the merged-list order
 int sw_gather_finish(mmgpu_ctx *c, mmgpu_sw_batch_t *b, int n_ranks) {
     HIP_TRY(hipSetDevice(c->device));
@@ -1026,18 +1039,25 @@ int sw_gather_finish(mmgpu_ctx *c, mmgpu_sw_batch_t *b, int n_ranks) {
 extern "C" int mmgpu_sw_gather_owned(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const void **d_full, const void **d_status) {
     if (!c || !b) return fail(MMGPU_ERR_ARG, "mmgpu_sw_gather_owned: NULL argument");
     const int n = c->comm ? c->comm->n_ranks : 1;
-    mmgpu::XchgBlock blk[2];
-    if (int e = mmgpu::sw_gather_begin(c, b, n, blk)) return e;
-    for (int k = 0; k < 2; k++)
-        if (int e = mmgpu::comm_allgather(c, blk[k].send, blk[k].recv, blk[k].bytes)) return e;
-    if (int e = mmgpu::sw_gather_finish(c, b, n)) return e;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        mmgpu::XchgBlock blk[2];
+        if (int e = mmgpu::sw_gather_begin(c, b, n, blk)) return e;
+        for (int k = 0; k < 2; k++)
+            if (int e = mmgpu::comm_allgather(c, blk[k].send, blk[k].recv, blk[k].bytes)) return e;
+        if (int e = mmgpu::sw_gather_finish(c, b, n)) return e;
+        // uneven shards: one more round with send buffers that hold every slot (all ranks decide alike: they see all counters)
+        bool again = false;
+        if (n > 1 && attempt == 0)
+            if (int e = mmgpu::sw_gather_overflowed(c, b, &again)) return e;
+        if (!again) break;
+    }
     if (d_full) *d_full = b->o_full.p;
     if (d_status) *d_status = b->o_status.p;
     return MMGPU_OK;
 }
 
 // host copy of the gathered records (synchronises the context's stream); MMGPU_ERR_STATE if a rank's send buffer overflowed
-// (rerun the gather with MMGPU_SW_GATHER_DENSE=1)
+// (cannot happen after mmgpu_sw_gather_owned's own second round; kept as the check it is)
 extern "C" int mmgpu_sw_fetch_owned(mmgpu_ctx *c, mmgpu_sw_batch_t *b, mmgpu_sw_hit *out, uint32_t *records) {
     if (!c || !b) return fail(MMGPU_ERR_ARG, "mmgpu_sw_fetch_owned: NULL argument");
     if (!b->owned || !b->o_full.p) return fail(MMGPU_ERR_STATE, "mmgpu_sw_fetch_owned: nothing gathered (mmgpu_sw_gather_owned first)");

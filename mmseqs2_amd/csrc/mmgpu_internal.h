@@ -805,6 +805,7 @@ int pf_xchg_begin(mmgpu_ctx *c, mmgpu_pf_batch_t *b, int n_ranks, XchgBlock bloc
 int pf_xchg_merge(mmgpu_ctx *c, mmgpu_pf_batch_t *b, int n_ranks, const uint32_t *identity_global);
 int sw_gather_begin(mmgpu_ctx *c, mmgpu_sw_batch_t *b, int n_ranks, XchgBlock blocks[2]);
 int sw_gather_finish(mmgpu_ctx *c, mmgpu_sw_batch_t *b, int n_ranks);
+int sw_gather_overflowed(mmgpu_ctx *c, mmgpu_sw_batch_t *b, bool *overflowed);   // true once: the caller repeats the phases (dense buffers)
 int pf_batch_merged_flags(mmgpu_pf_batch_t *b, const void **d_flags);
 const int32_t *pf_batch_host_status(const mmgpu_pf_batch_t *b);
 bool pf_batch_merged_lists(mmgpu_pf_batch_t *b, const mmgpu_pf_hit **hits, const uint32_t **counts, uint32_t *stride, uint32_t *nq);

@@ -316,10 +316,20 @@ extern "C" int mmgpu_multi_sw_from_pf(mmgpu_multi *m, const mmgpu_sw_params *par
     int err = MMGPU_OK;
     for (int i = 0; i < n && !err; i++) err = mmgpu_sw_prepare_owned(m->ctx[i], par, qs, nq, mode, mb->b[i], &sb[i]);
     for (int i = 0; i < n && !err; i++) err = mmgpu_sw_run(m->ctx[i], sb[i]);
-    std::vector<std::array<XchgBlock, 2>> blk(n);
-    for (int i = 0; i < n && !err; i++) err = mmgpu::sw_gather_begin(m->ctx[i], sb[i], n, blk[i].data());
-    if (!err) err = all_gather_step(m, blk);
-    for (int i = 0; i < n && !err; i++) err = mmgpu::sw_gather_finish(m->ctx[i], sb[i], n);
+    for (int attempt = 0; attempt < 2 && !err; attempt++) {
+        std::vector<std::array<XchgBlock, 2>> blk(n);
+        for (int i = 0; i < n && !err; i++) err = mmgpu::sw_gather_begin(m->ctx[i], sb[i], n, blk[i].data());
+        if (!err) err = all_gather_step(m, blk);
+        for (int i = 0; i < n && !err; i++) err = mmgpu::sw_gather_finish(m->ctx[i], sb[i], n);
+        // a shard that owns more of the hits than its send buffer holds: once more with buffers for every slot
+        bool again = false;
+        for (int i = 0; i < n && !err && attempt == 0 && n > 1; i++) {
+            bool a = false;
+            err = mmgpu::sw_gather_overflowed(m->ctx[i], sb[i], &a);
+            again |= a;
+        }
+        if (!again) break;
+    }
     uint32_t records = 0;
     if (!err) err = mmgpu_sw_fetch_owned(m->ctx[0], sb[0], out, &records);
     if (!err && (cells || kernel_ms)) {

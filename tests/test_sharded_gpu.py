@@ -280,6 +280,67 @@ def test_multi_context_run_equals_unsplit_run(gpu, matrices, world, max_hits):
         assert not res_s[qi]["score"][n:].any()
 
 
+def test_hits_clustered_in_one_shard_are_gathered_in_a_second_round(gpu, matrices):
+    """The owned-pairs gather sizes a rank's send buffer at 1.5 x its even share of the slots (+ 4096).  Here every hit of every
+    list lies in shard 0 (family members at the even ids of one length bucket, decoys at the odd ones): shard 0 packs more than
+    that, every rank sees it in the gathered counters, and the library repeats the gather with buffers that hold every slot -
+    the records still equal the unsplit run's (before: MMGPU_ERR_STATE unless the caller had set MMGPU_SW_GATHER_DENSE)."""
+    g = pc.golden()
+    thr = int(g["kmer_thr"])
+    rng = np.random.default_rng(123)
+    L, fam, members, nq = 208, 2, 700, 128
+    seeds = [rng.choice(20, size=L, p=wl.BACKGROUND).astype(np.uint8) for _ in range(fam)]
+    sres, soff = wl.seqs_from_list(seeds)
+    mres, moff = wl.mutate_many(rng, sres, soff, np.repeat(np.arange(fam), members), id_lo=0.6, id_hi=0.95, max_indels=0)
+    mem = wl.split(mres, moff)
+    assert all(len(x) == L for x in mem)
+    targets = []
+    for x in mem:      # member, decoy, member, decoy, ...: one length bucket, dealt alternately
+        targets.append(x)
+        targets.append(rng.choice(20, size=L, p=wl.BACKGROUND).astype(np.uint8))
+    tres, toff = wl.seqs_from_list(targets)
+    qres, qoff = wl.mutate_many(rng, sres, soff, np.arange(nq) % fam, id_lo=0.7, id_hi=0.95, max_indels=0)
+    qs = wl.split(qres, qoff)
+    shard_of = capi.partition_targets(toff, 2, lib=gpu.L)[0]
+    assert np.all(shard_of[0::2] == 0) and np.all(shard_of[1::2] == 1)
+    km16, um8, s3, i3 = _tables(gpu, g)
+    queries = [dict(q=q, comp_bias=capi.host_comp_bias(km16, g["vtml80_pback"], q, lib=gpu.L)[0], identity_id=None) for q in qs]
+    swq = _sw_queries(g, matrices, qs, gpu.L)
+    mat = matrices["blosum62_sw"]
+    max_hits = 300
+    gpu.load_targets(tres, toff, 21)
+    gpu.pf_build_index(6, 21, True, s3, i3, km16, thr, um8)
+    b = gpu.pf_prepare(queries, thr, max_hits=max_hits, ref_bins=2)
+    b.run()
+    fb = gpu.sw_prepare_from_pf(mat, 11, 1, swq, b, mode=1)
+    fb.run()
+    res_u = fb.fetch().reshape(len(qs), b.max_hits)
+    hits_u, counts_u, status_u, _ = b.fetch()
+    fb.free()
+    b.free()
+    assert np.all(status_u == 0)
+    owned0 = int(sum(int((shard_of[hits_u[qi]["id"][:int(counts_u[qi])]] == 0).sum()) for qi in range(len(qs))))
+    slots = len(qs) * max_hits
+    assert owned0 > slots // 2 * 3 // 2 + 4096, (owned0, slots)      # the first round's send buffer of shard 0 is too small
+    m = capi.MMGpuMulti([0, 0])
+    try:
+        m.load_targets(tres, toff, 21)
+        m.pf_build_index(6, 21, True, s3, i3, km16, thr, um8)
+        mb = m.pf_prepare(queries, thr, max_hits=max_hits, ref_bins=2)
+        m.pf_run(mb)
+        hits_s, counts_s, status_s = m.pf_fetch(mb, len(qs))
+        res_s, _, _ = m.sw_from_pf(mat, 11, 1, swq, mb, len(qs), mode=1)
+        m.pf_free(mb)
+    finally:
+        m.close()
+    assert np.all(status_s == 0) and np.array_equal(counts_s, counts_u)
+    for qi in range(len(qs)):
+        n = int(counts_u[qi])
+        assert np.array_equal(hits_s[qi]["id"][:n], hits_u[qi]["id"][:n]), qi
+        for f in ("score", "q_end", "t_end", "q_start", "t_start", "word"):
+            assert np.array_equal(res_s[qi][f][:n], res_u[qi][f][:n]), (qi, f)
+
+
 def test_two_query_groups_of_two_target_shards_equal_the_unsplit_run(gpu, matrices):
     """Round 4 layout (bench.py --query-groups): G = 2 groups x S = 2 target shards on four contexts of the one GPU.  Each group is
     an mmgpu_multi of two contexts (its own communicator, here the copy transport) that holds the whole database dealt by length
