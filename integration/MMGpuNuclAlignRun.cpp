@@ -54,9 +54,8 @@ struct MMGpuNuclState {
     uint8_t rev[5];
     mmgpu_nucl_params par;
     // what one thread of the reference would have in its three buffers
-    BufferHistory qHistory, rcHistory, tHistory;
-    // (the queries of earlier buckets stay alive: the histories point into them)
-    std::vector<std::vector<std::vector<unsigned char> > *> keepQueries;
+    BufferHistory qHistory, rcHistory, tHistory;      // (the query histories keep copies: a bucket's queries are freed with the bucket)
+    MMGpuNuclState() : qHistory(true), rcHistory(true), tHistory(false) {}
 };
 
 bool MMGpuAlignRun::usableNucleotide(const Alignment &a) {
@@ -89,7 +88,6 @@ void MMGpuAlignRun::beginNucleotide(MMGpuAlignSession *s) {
 
 void MMGpuAlignRun::endNucleotide(MMGpuAlignSession *s) {
     if (s->nucl == NULL) return;
-    for (size_t i = 0; i < s->nucl->keepQueries.size(); i++) delete s->nucl->keepQueries[i];
     delete s->nucl;
     s->nucl = NULL;
 }
@@ -101,9 +99,7 @@ void MMGpuAlignRun::planNucleotide(MMGpuAlignSession *s) {
     const std::vector<uint64_t> &tOff = s->targetOffsets;
     const std::vector<unsigned char> &tRes = s->targetResidues;
     const size_t nq = s->size, next = s->start;
-    std::vector<std::vector<unsigned char> > *queryNumPtr = new std::vector<std::vector<unsigned char> >(nq);
-    N.keepQueries.push_back(queryNumPtr);
-    std::vector<std::vector<unsigned char> > &queryNum = *queryNumPtr;
+    std::vector<std::vector<unsigned char> > queryNum(nq);
     std::vector<std::vector<Entry> > lists(nq);
     std::vector<DBKeyType> queryKeys(nq, 0);
 

@@ -449,6 +449,12 @@ def _nucleotide_pipeline(w, emulate, k="15"):
         assert same(os.path.join(w, "naln_s%d" % n), os.path.join(w, "naln_g%d" % n)) == 60
     d = dbio.read_db(os.path.join(w, "naln_g0"))
     assert sum(1 for v in d.values() if len(v) > 1) >= 25
+    # buckets of seven queries: what shows through a buffer comes from queries of buckets that are gone by then (the hook's
+    # histories keep their own copies)
+    log = run(MMGPU, ["align", "nqf", "nt", "npref_s0", "naln_g0_buckets", "--threads", THREADS, "-v", "3", "-a"], w, emulate,
+              extra_env={"MMGPU_ALIGN_BLOCK_QUERIES": "7"})
+    assert "MMGPU: nucleotide alignment on the device" in log, log[-2000:]
+    assert same(os.path.join(w, "naln_s0"), os.path.join(w, "naln_g0_buckets")) == 60
     # where the loop stops decides what the reference's buffers hold afterwards: finite --max-rejected stays on the CPU loop
     run(STOCK, ["align", "nqf", "nt", "npref_s0", "naln_s9", "--threads", "1", "--max-rejected", "3", "-v", "1"], w)
     log = run(MMGPU, ["align", "nqf", "nt", "npref_s0", "naln_g9", "--threads", "1", "--max-rejected", "3", "-v", "3"], w, emulate)
