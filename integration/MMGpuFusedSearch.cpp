@@ -114,34 +114,27 @@ void closeProgressive() {
 // the alignment module once the Prefiltering object is complete.  Not overlapped (the prefilter runs to its end, *aligned stays
 // false and the caller starts the alignment module as a whole): split prefilter runs, configurations the prefilter hook leaves to
 // the CPU loop or runs without the resident-target hand-over, more slots than a quarter of the memory.
-int bothModules(Parameters &par, const std::vector<std::string> &prefArgs, const std::vector<std::string> &alnArgs, bool *aligned) {
+int bothModules(Parameters &par, const std::vector<std::string> &prefArgs, const std::vector<std::string> &alnArgs, bool sideBySide, bool *aligned) {
     const Command *pc = getCommandByName("prefilter"), *ac = getCommandByName("align");
     if (pc == NULL || ac == NULL) {
         Debug(Debug::ERROR) << "MMGPU: no prefilter / align module\n";
         EXIT(EXIT_FAILURE);
     }
+    // (index databases, profiles, nucleotides: the module's own checks and paths, Main.cpp:22-46)
+    const int queryDbType = FileUtil::parseDbType(prefArgs[0].c_str());
+    const int targetDbType = FileUtil::parseDbType(prefArgs[1].c_str());
+    if (!Parameters::isEqualDbtype(queryDbType, Parameters::DBTYPE_AMINO_ACIDS) || !Parameters::isEqualDbtype(targetDbType, Parameters::DBTYPE_AMINO_ACIDS))
+        return module(par, "prefilter", prefArgs);
     Timer prefTimer;
     freshParameters(par, *pc);
     std::vector<const char *> argv;
     for (size_t i = 0; i < prefArgs.size(); i++) argv.push_back(prefArgs[i].c_str());
     par.parseParameters((int)argv.size(), argv.data(), *pc, true, 0, MMseqsParameter::COMMAND_PREFILTER);
-    const int queryDbType = FileUtil::parseDbType(par.db1.c_str());
-    const int targetDbType = FileUtil::parseDbType(par.db2.c_str());
-    if (queryDbType == -1 || targetDbType == -1) {
-        Debug(Debug::ERROR) << "Please recreate your database or add a .dbtype file to your sequence/profile database.\n";
-        return EXIT_FAILURE;
-    }
-    if (!Parameters::isEqualDbtype(queryDbType, Parameters::DBTYPE_AMINO_ACIDS) || !Parameters::isEqualDbtype(targetDbType, Parameters::DBTYPE_AMINO_ACIDS)) {
-        // (index databases, profiles, nucleotides: the module's own checks and paths)
-        const int status = pc->commandFunction((int)argv.size(), argv.data(), *pc);      // parses again; nothing else has happened yet
-        Debug(Debug::INFO) << "Time for processing: " << prefTimer.lap() << "\n";
-        return status;
-    }
     const std::string prefDb = par.db3, prefDbIndex = par.db3Index, queryDb = par.db1, queryDbIndex = par.db1Index;
     const bool taxonFilter = par.taxonList.length() > 0;
     Prefiltering *pref = new Prefiltering(par.db1, par.db1Index, par.db2, par.db2Index, queryDbType, targetDbType, par);
     size_t maxResListLen = 0;
-    bool overlap = !taxonFilter && MMGpuPrefilterRun::runsUnsplitWithResidentTargets(*pref, &maxResListLen);
+    bool overlap = sideBySide && !taxonFilter && MMGpuPrefilterRun::runsUnsplitWithResidentTargets(*pref, &maxResListLen);
     if (overlap) {
         // one slot per query, ids = ascending keys (the order of a DBReader's index)
         DBReader<unsigned int> qr(queryDb.c_str(), queryDbIndex.c_str(), 1, DBReader<unsigned int>::USE_INDEX);
@@ -163,8 +156,9 @@ int bothModules(Parameters &par, const std::vector<std::string> &prefArgs, const
     if (!overlap) {
         std::vector<unsigned int>().swap(store.keys);
         pref->runAllSplits(prefDb, prefDbIndex);
-        delete pref;
         Debug(Debug::INFO) << "Time for processing: " << prefTimer.lap() << "\n";
+        // the object goes (its readers unmapped, tables freed: 0.06 s at 1 M targets) while the alignment module starts
+        std::thread([pref]() { delete pref; }).detach();
         return EXIT_SUCCESS;
     }
     Debug(Debug::INFO) << "MMGPU: the alignment module starts while the prefilter module runs (MMGPU_FUSED_OVERLAP=1)\n";
@@ -265,17 +259,18 @@ int MMGpuFusedSearch::run(Parameters &par, const std::string &query, const std::
         const std::vector<std::string> p = words(prefilterPar);
         a.insert(a.end(), p.begin(), p.end());
         a.push_back("-s"); a.push_back(sens);
-        // MMGPU_FUSED_OVERLAP=1: the alignment module starts while the prefilter module still runs (bothModules).  Off by default:
-        // at 10 000 x 1 M the alignment hook's per-bucket costs and the contention of the two modules for the host threads outweigh
-        // the overlap (1.86 - 2.11 s for buckets of 5120 ... 1024 queries against 1.77 s one after the other,
+        // the prefilter module as prefilter() runs it (src/prefiltering/Main.cpp:13-62), the object built and released here
+        // (bothModules).  MMGPU_FUSED_OVERLAP=1 also starts the alignment module beside it.  That is off by default: at 10 000 x 1 M
+        // the alignment hook's per-bucket costs and the contention of the two modules for the host threads outweigh the overlap
+        // (1.86 - 2.11 s for buckets of 5120 ... 1024 queries against 1.77 s one after the other,
         // profiles/r04_fused_overlap_variants.json).
         const char *e = getenv("MMGPU_FUSED_OVERLAP");
-        if (!onDisk && e != NULL && e[0] == '1') {
+        if (!onDisk) {
             std::vector<std::string> b;
             b.push_back(query); b.push_back(target); b.push_back(pref); b.push_back(result);
             const std::vector<std::string> q = words(alignPar);
             b.insert(b.end(), q.begin(), q.end());
-            status = bothModules(par, a, b, &aligned);
+            status = bothModules(par, a, b, e != NULL && e[0] == '1', &aligned);
         } else {
             status = module(par, "prefilter", a);
         }
