@@ -37,12 +37,14 @@ __device__ __forceinline__ int sllz8(int x, int lane) {
     const int v = __builtin_amdgcn_update_dpp(0, x, 0x110 + N /* row_shr:N */, 0xF, 0xF, true);
     return (lane & 7) >= N ? v : 0;
 }
-// lane 7 of the caller's 16-lane row
+// lane 7 of the caller's 16-lane row (DPP row_newbcast: one move instead of four readlanes and three selects)
 __device__ __forceinline__ int row_lane7(int v, int lane) {
-    const int a = __builtin_amdgcn_readlane(v, 7), b = __builtin_amdgcn_readlane(v, 23), c = __builtin_amdgcn_readlane(v, 39),
-              d = __builtin_amdgcn_readlane(v, 55);
-    const int row = lane >> 4;
-    return row == 0 ? a : (row == 1 ? b : (row == 2 ? c : d));
+    (void)lane;
+    return __builtin_amdgcn_update_dpp(0, v, 0x157 /* row_newbcast:7 */, 0xF, 0xF, false);
+}
+// lane 15 of the row below the caller's (row 0 receives `first`): DPP row_bcast:15
+__device__ __forceinline__ int prev_row_lane15(int v, int first) {
+    return __builtin_amdgcn_update_dpp(first, v, 0x142 /* row_bcast:15 */, 0xE, 0xF, false);
 }
 // lane - 1's value; lane 0 receives `first`
 __device__ __forceinline__ int shift_up1(int v, int first) {
@@ -70,7 +72,8 @@ __device__ __forceinline__ int bk_prefix_scan(int R, int g, int consts, int lane
     const int k = lane & 15;
     // source lane: itself (k < 4), four lanes down (k < 8), lane 7 of the row (k >= 8)
     const int down4 = __builtin_amdgcn_update_dpp(0, s4, 0x114 /* row_shr:4 */, 0xF, 0xF, true);
-    const int from = k < 4 ? s4 : (k < 8 ? down4 : row_lane7(s4, lane));
+    const int l7 = row_lane7(s4, lane);      // (outside the selection: a DPP move reads nothing from lanes that are switched off)
+    const int from = k < 4 ? s4 : (k < 8 ? down4 : l7);
     const int c1 = adds16(from, consts);
     return max(s4, c1);
 }
@@ -106,6 +109,9 @@ __device__ __forceinline__ BkMax bk_place_block(const BlockLaunch &L, const int8
     M.dmax = BK_MIN; M.ai = 0; M.aj = 0;
     if (width == 0 || height == 0) return M;
     const int iters = (height + 63) >> 6;
+    // blocks of up to 64 rows (nearly all): a lane's row - its letter and bias - is the same for every column
+    const int row_letter0 = bk_letter(query, start_i + lane), row_bias0 = bk_bias(query, start_i + lane);
+    const int row = lane >> 4;
     for (int j = 0; j < width; j++) {
         const int c = bk_letter(reference, start_j + j);
         const int rbias = bk_bias(reference, start_j + j);
@@ -114,13 +120,14 @@ __device__ __forceinline__ BkMax bk_place_block(const BlockLaunch &L, const int8
         for (int it = 0; it < iters; it++) {
             const int i = (it << 6) + lane;
             const bool act = i < height;
+            const bool more = it + 1 < iters;      // (uniform) another 64-row step of this column follows: it needs the carries
             const int D10 = act ? (int)D_col[i] : BK_MIN, C10 = act ? (int)C_col[i] : BK_MIN;
             const int D00 = shift_up1(D10, corner);
             const int last = min(63, height - 1 - (it << 6));
-            corner = __builtin_amdgcn_readlane(D10, last);
-            const int ql = bk_letter(query, start_i + i);
+            if (more) corner = __builtin_amdgcn_readlane(D10, 63);
+            const int ql = iters == 1 ? row_letter0 : bk_letter(query, start_i + i);
             const int sc = (int)scores[c * 32 + (ql & 31)];
-            const int pos_bias = adds16(rbias, bk_bias(query, start_i + i));
+            const int pos_bias = adds16(rbias, iters == 1 ? row_bias0 : bk_bias(query, start_i + i));
             D11 = adds16(D00, adds16(sc, pos_bias));
             if (start_i + i == 0 && start_j + j == 0) D11 = BK_ZERO;
             const int C11_open = adds16(D10, go);
@@ -128,17 +135,24 @@ __device__ __forceinline__ BkMax bk_place_block(const BlockLaunch &L, const int8
             D11 = max(D11, C11);
             const int D11_open = adds16(D11, subs16(go, ge));
             R11 = bk_prefix_scan(D11_open, ge, K.consts, lane);
-            // R11 = max(R11, broadcasthi(R01) + gap_extend_all), chunk by chunk (R01 = the previous chunk's R11)
-#pragma unroll
-            for (int ch = 0; ch < 4; ch++) {
+            // R11 = max(R11, broadcasthi(R01) + gap_extend_all), chunk by chunk (R01 = the previous chunk's R11): row 0 takes the
+            // carry of the step before, rows 1..3 the last lane of the row below, one after the other
+            {
                 const int add = adds16(carryR, K.gap_all);
-                if ((lane >> 4) == ch) R11 = max(R11, add);
-                if ((it << 6) + ch * 16 < height) carryR = __builtin_amdgcn_readlane(R11, ch * 16 + 15);
+                if (row == 0) R11 = max(R11, add);
             }
+#pragma unroll
+            for (int ch = 1; ch < 4; ch++) {
+                const int add = adds16(prev_row_lane15(R11, BK_MIN), K.gap_all);
+                if (row == ch) R11 = max(R11, add);
+            }
+            // the carry into the next step: the last lane of the last chunk that exists (every chunk of a step but the column's last does)
+            if (more) carryR = __builtin_amdgcn_readlane(R11, 63);
             D11 = max(D11, R11);
             const bool tempR = R11 == D11_open;
             const int trR = shift_up1(tempR ? 1 : 0, carry_tr);
-            carry_tr = __builtin_amdgcn_readlane(tempR ? 1 : 0, last);
+            if (more) carry_tr = __builtin_amdgcn_readlane(tempR ? 1 : 0, 63);
+            (void)last;
             const unsigned long long bDC = __ballot(act && D11 == C11), bDR = __ballot(act && D11 == R11);
             const unsigned long long bCO = __ballot(act && C11 == C11_open), bTR = __ballot(act && trR != 0);
             if (S.trace_idx >= S.trace_cap) S.overflow = true;
@@ -427,7 +441,8 @@ __global__ __launch_bounds__(64) void sw_block_kernel(BlockLaunch L) {
     bool too_large = blocks_bytes >= slot_bytes;
     const long long t_begin = clock64();
     long long t_walk = t_begin;
-    for (int min_size = 32; min_size <= MAXB && score < J.score && !too_large; min_size *= 2) {      // :1021-1038
+    int attempts = 0;
+    for (int min_size = 32; min_size <= MAXB && score < J.score && !too_large; min_size *= 2, attempts++) {      // :1021-1038
         for (int k = lane; k < 8 * MAXB; k += 64) s_buf[k] = BK_MIN;      // Allocated::clear
         s_temp[0][lane] = BK_MIN;
         s_temp[1][lane] = BK_MIN;
@@ -495,9 +510,11 @@ __global__ __launch_bounds__(64) void sw_block_kernel(BlockLaunch L) {
         out.ident = ids;
         out.bt_len = n;
     }
-    {   // profiling aid in the reserved field: share of the pair's time spent in the serial walk back, in 1/1000
+    {   // profiling aid in the reserved field: share of the pair's time spent in the serial walk back, in 1/1000 (low 16 bits),
+        // and the number of minimum block sizes tried (32, 64, ...: bits 16-23)
         const long long t_end = clock64();
-        out.reserved = (t_walk > t_begin && t_end > t_begin) ? (int32_t)(((t_end - t_walk) * 1000) / (t_end - t_begin)) : 0;
+        const int share = (t_walk > t_begin && t_end > t_begin) ? (int)(((t_end - t_walk) * 1000) / (t_end - t_begin)) : 0;
+        out.reserved = (int32_t)((share & 0xFFFF) | ((attempts & 0xFF) << 16));
     }
     if (lane == 0) {
         L.out[J.slot] = out;

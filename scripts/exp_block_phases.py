@@ -40,7 +40,9 @@ def main():
         out["c_abi_s_%d" % rep] = round(b.last_block_call_s, 4)
     out["tiers"] = b.block_tiers()
     out["status"] = {int(k): int(v) for k, v in zip(*np.unique(blk["status"], return_counts=True))}
-    share = blk["reserved"][blk["status"] == 0]
+    share = blk["reserved"][blk["status"] == 0] & 0xFFFF
+    tries = (blk["reserved"][blk["status"] == 0] >> 16) & 0xFF
+    out["min_block_sizes_tried"] = {int(k): int(v) for k, v in zip(*np.unique(tries, return_counts=True))}
     out["walk_share_permille"] = {"p10": int(np.percentile(share, 10)), "p50": int(np.percentile(share, 50)), "p90": int(np.percentile(share, 90)),
                                   "mean": float(share.mean())}
     out["bt_len_mean"] = float(blk["bt_len"][blk["status"] == 0].mean())
