@@ -461,49 +461,85 @@ __global__ __launch_bounds__(64) void sw_block_kernel(BlockLaunch L) {
         // reverses the run order and then the string (:1071-1110), which leaves exactly the walk order
         __threadfence_block();
         t_walk = clock64();
+        // The walk is one dependent chain, but what each step needs comes from memory the wavefront can fetch 64 items at a time:
+        // all lanes walk together on identical state, and a step reads its trace bits and the two letters out of register
+        // windows (16 trace entries = 64 qwords, 64 letters of each sequence, 64 operations to write) with readlanes - one
+        // coalesced load per ~16 - 64 steps instead of four dependent loads per step by a single lane (~770 cycles a step before).
         uint32_t block_idx = S.block_idx;
-        int i = ri, j = rj, table = 0;      // 0 = D, 1 = C, 2 = R
+        int i = __builtin_amdgcn_readfirstlane(ri), j = __builtin_amdgcn_readfirstlane(rj), table = 0;      // 0 = D, 1 = C, 2 = R
         uint32_t n = 0, ids = 0;
         char *bt = L.bt + out.bt_off;
-        if (lane == 0) {
-            while (i > 0 || j > 0) {
-                BkBlock b;
-                for (;;) {
-                    block_idx--;
-                    b = S.blocks[block_idx];
-                    if (i >= (int)b.i && j >= (int)b.j) break;
+        uint32_t win_lo = 0xFFFFFFFFu;                  // trace entries [win_lo, win_lo + 16): lane l holds qword (l & 3) of entry win_lo + (l >> 2)
+        unsigned win_w0 = 0, win_w1 = 0;
+        int qf_lo = -1, tf_lo = -1;                     // forward indices [lo, lo + 64) of the two sequences, one letter per lane
+        int qwin = 0, twin = 0;
+        int my_op = 0;                                  // operation n of the current group of 64 sits in lane n & 63
+        while (i > 0 || j > 0) {
+            int bi, bj, bh, bw, bright;
+            uint32_t btstart;
+            for (;;) {
+                block_idx--;
+                const BkBlock b = S.blocks[block_idx];
+                bi = __builtin_amdgcn_readfirstlane((int)b.i); bj = __builtin_amdgcn_readfirstlane((int)b.j);
+                bh = __builtin_amdgcn_readfirstlane((int)b.h); bw = __builtin_amdgcn_readfirstlane((int)b.w);
+                bright = __builtin_amdgcn_readfirstlane((int)b.right);
+                btstart = (uint32_t)__builtin_amdgcn_readfirstlane((int)b.tstart);
+                if (i >= bi && j >= bj) break;
+            }
+            while (i >= bi && j >= bj && (i > 0 || j > 0)) {
+                const int ci = i - bi, cj = j - bj;
+                uint32_t idx;
+                int bit;
+                if (bright) { idx = btstart + (uint32_t)(ci >> 6) + (uint32_t)cj * (uint32_t)((bh + 63) >> 6); bit = ci & 63; }
+                else { idx = btstart + (uint32_t)(cj >> 6) + (uint32_t)ci * (uint32_t)((bw + 63) >> 6); bit = cj & 63; }
+                if (idx < win_lo || idx - win_lo >= 16u) {      // (also the first step: win_lo = 2^32 - 1)
+                    win_lo = idx >= 15u ? idx - 15u : 0u;
+                    const unsigned long long v = S.trace[(size_t)win_lo * 4 + lane];
+                    win_w0 = (unsigned)v;
+                    win_w1 = (unsigned)(v >> 32);
                 }
-                while (i >= (int)b.i && j >= (int)b.j && (i > 0 || j > 0)) {
-                    const int ci = i - (int)b.i, cj = j - (int)b.j;
-                    uint32_t idx;
-                    int bit;
-                    if (b.right) { idx = b.tstart + (uint32_t)(ci >> 6) + (uint32_t)cj * (uint32_t)((b.h + 63) >> 6); bit = ci & 63; }
-                    else { idx = b.tstart + (uint32_t)(cj >> 6) + (uint32_t)ci * (uint32_t)((b.w + 63) >> 6); bit = cj & 63; }
-                    const unsigned long long *t = S.trace + (size_t)idx * 4;
-                    const unsigned tt = (unsigned)((t[0] >> bit) & 1ull) | ((unsigned)((t[1] >> bit) & 1ull) << 1);
-                    const unsigned t2 = (unsigned)((t[2] >> bit) & 1ull) | ((unsigned)((t[3] >> bit) & 1ull) << 1);
-                    int op, di, dj, nt;      // OP_LUT (:1870-1933)
-                    if (b.right) {
-                        if (table == 1) { op = 5; di = 0; dj = 1; nt = (t2 & 1u) ? 0 : 1; }
-                        else if (table == 2) { op = 4; di = 1; dj = 0; nt = (t2 & 2u) ? 0 : 2; }
-                        else if (tt == 0) { op = 1; di = 1; dj = 1; nt = 0; }
-                        else if (tt & 1u) { op = 5; di = 0; dj = 1; nt = (t2 & 1u) ? 0 : 1; }
-                        else { op = 4; di = 1; dj = 0; nt = (t2 & 2u) ? 0 : 2; }
-                    } else {
-                        if (table == 2) { op = 4; di = 1; dj = 0; nt = (t2 & 1u) ? 0 : 2; }
-                        else if (table == 1) { op = 5; di = 0; dj = 1; nt = (t2 & 2u) ? 0 : 1; }
-                        else if (tt == 0) { op = 1; di = 1; dj = 1; nt = 0; }
-                        else if (tt & 1u) { op = 4; di = 1; dj = 0; nt = (t2 & 1u) ? 0 : 2; }
-                        else { op = 5; di = 0; dj = 1; nt = (t2 & 2u) ? 0 : 1; }
+                const unsigned half = bit & 32 ? win_w1 : win_w0;
+                const int e = (int)(idx - win_lo) * 4;
+                const unsigned sh = (unsigned)bit & 31u;
+                const unsigned tt = (((unsigned)__builtin_amdgcn_readlane((int)half, e) >> sh) & 1u) |
+                                    ((((unsigned)__builtin_amdgcn_readlane((int)half, e + 1) >> sh) & 1u) << 1);
+                const unsigned t2 = (((unsigned)__builtin_amdgcn_readlane((int)half, e + 2) >> sh) & 1u) |
+                                    ((((unsigned)__builtin_amdgcn_readlane((int)half, e + 3) >> sh) & 1u) << 1);
+                int op, di, dj, nt;      // OP_LUT (:1870-1933)
+                if (bright) {
+                    if (table == 1) { op = 5; di = 0; dj = 1; nt = (t2 & 1u) ? 0 : 1; }
+                    else if (table == 2) { op = 4; di = 1; dj = 0; nt = (t2 & 2u) ? 0 : 2; }
+                    else if (tt == 0) { op = 1; di = 1; dj = 1; nt = 0; }
+                    else if (tt & 1u) { op = 5; di = 0; dj = 1; nt = (t2 & 1u) ? 0 : 1; }
+                    else { op = 4; di = 1; dj = 0; nt = (t2 & 2u) ? 0 : 2; }
+                } else {
+                    if (table == 2) { op = 4; di = 1; dj = 0; nt = (t2 & 1u) ? 0 : 2; }
+                    else if (table == 1) { op = 5; di = 0; dj = 1; nt = (t2 & 2u) ? 0 : 1; }
+                    else if (tt == 0) { op = 1; di = 1; dj = 1; nt = 0; }
+                    else if (tt & 1u) { op = 4; di = 1; dj = 0; nt = (t2 & 1u) ? 0 : 2; }
+                    else { op = 5; di = 0; dj = 1; nt = (t2 & 2u) ? 0 : 1; }
+                }
+                if (op == 1) {      // identities: the letters of DP indices i, j = forward indices end - (i - 1), end - (j - 1), both rising along the walk
+                    const int qf = Q.end - (i - 1), tf = T.end - (j - 1);
+                    if ((unsigned)(qf - qf_lo) >= 64u || qf_lo < 0) {
+                        qf_lo = qf;
+                        qwin = qf_lo + lane <= Q.end ? (int)Q.res[qf_lo + lane] : 255;
                     }
-                    if (op == 1) ids += Q.res[Q.end - (i - 1)] == T.res[T.end - (j - 1)] ? 1u : 0u;
-                    bt[n++] = op == 1 ? 'M' : (op == 4 ? 'I' : 'D');
-                    i -= di;
-                    j -= dj;
-                    table = nt;
+                    if ((unsigned)(tf - tf_lo) >= 64u || tf_lo < 0) {
+                        tf_lo = tf;
+                        twin = tf_lo + lane <= T.end ? (int)T.res[tf_lo + lane] : 254;
+                    }
+                    ids += __builtin_amdgcn_readlane(qwin, qf - qf_lo) == __builtin_amdgcn_readlane(twin, tf - tf_lo) ? 1u : 0u;
                 }
+                if (lane == (int)(n & 63u)) my_op = op == 1 ? 'M' : (op == 4 ? 'I' : 'D');
+                n++;
+                if ((n & 63u) == 0) bt[n - 64 + lane] = (char)my_op;
+                i -= di;
+                j -= dj;
+                table = nt;
             }
         }
+        if ((n & 63u) != 0 && lane < (int)(n & 63u)) bt[(n & ~63u) + lane] = (char)my_op;
         out.status = MMGPU_BLOCK_OK;
         out.q_start = J.q_end + 1 - ri;       // :1111-1112
         out.t_start = J.t_end + 1 - rj;
