@@ -62,7 +62,7 @@ struct mmgpu_pf_batch_t {
     std::vector<mmo_pf_stats> stats;
 };
 
-static std::string g_err;
+static thread_local std::string g_err;      // (the hooks drive several contexts from several threads)
 static int fail(int code, const char *msg) {
     g_err = msg;
     return code;
@@ -546,6 +546,65 @@ int mmgpu_nucl_align(mmgpu_ctx *c, const mmgpu_nucl_params *par, const mmgpu_nuc
     }
     if (bt_used) *bt_used = used;
     return 0;
+}
+
+// ---- several contexts (mmgpu_init_multi): what the hooks' MMGPU_DEVICES / large-split paths drive.  The contract of the real
+// library is that the merged lists of the shards EQUAL the unsplit run's (tests/test_sharded_gpu.py pins that on the device), so
+// the stand-in keeps the whole database on context 0 and answers from there; the other contexts exist for the alignment hook,
+// which loads the targets on every context and deals its queries to them.
+struct mmgpu_multi { std::vector<mmgpu_ctx *> ctx; };
+struct mmgpu_multi_pf_batch { mmgpu_pf_batch_t *b; };
+
+int mmgpu_init_multi(mmgpu_multi **out, const int *ids, int n) {
+    if (!out || !ids || n < 1) return fail(MMGPU_ERR_ARG, "mmgpu_init_multi (emu): bad argument");
+    mmgpu_multi *m = new mmgpu_multi();
+    for (int i = 0; i < n; i++) {
+        mmgpu_ctx *c = NULL;
+        mmgpu_init(&c, ids[i]);
+        m->ctx.push_back(c);
+    }
+    *out = m;
+    return 0;
+}
+void mmgpu_destroy_multi(mmgpu_multi *m) {
+    if (!m) return;
+    for (size_t i = 0; i < m->ctx.size(); i++) mmgpu_destroy(m->ctx[i]);
+    delete m;
+}
+int mmgpu_multi_size(mmgpu_multi *m) { return m ? (int)m->ctx.size() : 0; }
+mmgpu_ctx *mmgpu_multi_ctx(mmgpu_multi *m, int i) { return (m && i >= 0 && i < (int)m->ctx.size()) ? m->ctx[i] : NULL; }
+int mmgpu_multi_synchronize(mmgpu_multi *) { return 0; }
+int mmgpu_comm_info(mmgpu_ctx *, int *rank, int *n_ranks, char *transport, int cap) {
+    if (rank) *rank = 0;
+    if (n_ranks) *n_ranks = 1;
+    if (transport && cap > 0) snprintf(transport, cap, "emulated");
+    return 0;
+}
+int mmgpu_multi_load_targets(mmgpu_multi *m, const uint8_t *res, const uint64_t *off, uint32_t n, int alphabet) {
+    return mmgpu_load_targets(m->ctx[0], res, off, n, alphabet);
+}
+int mmgpu_multi_pf_mask_targets(mmgpu_multi *m, const double *lr, int alphabet, double min_mask_prob, int mask_letter, uint64_t *n_masked) {
+    return mmgpu_pf_mask_targets(m->ctx[0], lr, alphabet, min_mask_prob, mask_letter, n_masked);
+}
+int mmgpu_multi_pf_build_index(mmgpu_multi *m, const mmgpu_pf_index *ix, const int16_t *kmer_submat, int kmer_thr) {
+    return mmgpu_pf_build_index(m->ctx[0], ix, kmer_submat, kmer_thr);
+}
+int mmgpu_multi_pf_prepare(mmgpu_multi *m, const mmgpu_pf_params *p, const mmgpu_pf_query *qs, uint32_t nq, mmgpu_multi_pf_batch **out) {
+    mmgpu_pf_batch_t *b = NULL;
+    const int rc = mmgpu_pf_prepare(m->ctx[0], p, qs, nq, &b);
+    if (rc != 0) return rc;
+    *out = new mmgpu_multi_pf_batch();
+    (*out)->b = b;
+    return 0;
+}
+int mmgpu_multi_pf_run(mmgpu_multi *m, mmgpu_multi_pf_batch *mb) { return mmgpu_pf_run(m->ctx[0], mb->b); }
+int mmgpu_multi_pf_fetch(mmgpu_multi *m, mmgpu_multi_pf_batch *mb, mmgpu_pf_hit *hits, uint32_t stride, uint32_t *counts, int32_t *status) {
+    return mmgpu_pf_fetch(m->ctx[0], mb->b, hits, stride, counts, status, NULL);
+}
+void mmgpu_multi_pf_free(mmgpu_multi *m, mmgpu_multi_pf_batch *mb) {
+    if (!mb) return;
+    mmgpu_pf_free(m->ctx[0], mb->b);
+    delete mb;
 }
 
 }  // extern "C"

@@ -671,8 +671,7 @@ def test_compressed_databases_on_device(tmp_path):
     compressed_pipeline(tmp_path, emulate=False)
 
 
-@pytest.mark.gpu
-def test_several_device_contexts_in_one_process(tmp_path):
+def _several_device_contexts(tmp_path, emulate):
     """MMGPU_DEVICES=0,0,0: three device contexts in one `mmseqs` process (the box has one GPU; the library then uses its copy
     transport instead of RCCL).  `prefilter`: the targets dealt to the contexts by length bucket, one k-mer index each, the hit
     lists exchanged and merged inside the library - the result database must equal the stock binary's (= the unsplit run).
@@ -681,18 +680,30 @@ def test_several_device_contexts_in_one_process(tmp_path):
     copy_db(EXAMPLES, os.path.join(w, "q"))
     env = {"MMGPU_DEVICES": "0,0,0"}
     run(STOCK, ["prefilter", "q", "q", "pref_s", "-s", "5.7", "--threads", THREADS, "-v", "2"], w)
-    log = run(MMGPU, ["prefilter", "q", "q", "pref_g", "-s", "5.7", "--threads", THREADS, "-v", "3"], w, extra_env=env)
+    log = run(MMGPU, ["prefilter", "q", "q", "pref_g", "-s", "5.7", "--threads", THREADS, "-v", "3"], w, emulate, extra_env=env)
     assert "3 device contexts" in log and "runs on one device" not in log and "using the CPU path" not in log, log[-2000:]
     assert same(os.path.join(w, "pref_s"), os.path.join(w, "pref_g")) == 500
     for i, case in enumerate([["-a"], ["--alignment-mode", "2"]]):
         run(STOCK, ["align", "q", "q", "pref_s", "aln_s%d" % i] + case + ["--threads", THREADS, "-v", "2"], w)
-        log = run(MMGPU, ["align", "q", "q", "pref_s", "aln_g%d" % i] + case + ["--threads", THREADS, "-v", "3"], w, extra_env=env)
+        log = run(MMGPU, ["align", "q", "q", "pref_s", "aln_g%d" % i] + case + ["--threads", THREADS, "-v", "3"], w, emulate, extra_env=env)
         assert "3 device contexts" in log and "using the CPU path" not in log, log[-2000:]
         assert same(os.path.join(w, "aln_s%d" % i), os.path.join(w, "aln_g%d" % i)) == 500, case
 
 
+def test_several_device_contexts_host_side_emulated(tmp_path):
+    """(the stand-in library answers a multi-context prefilter from one context - what runs here is the hooks' side: context
+    layout, shard-capable / not, the alignment hook dealing its queries to three contexts)"""
+    if not os.path.exists(EMU):
+        pytest.skip("oracle/_build/emu/libmmgpu.so not built (make -C oracle emu)")
+    _several_device_contexts(tmp_path, emulate=True)
+
+
 @pytest.mark.gpu
-def test_query_groups_by_target_shards_in_one_process(tmp_path):
+def test_several_device_contexts_in_one_process(tmp_path):
+    _several_device_contexts(tmp_path, emulate=False)
+
+
+def _query_groups_by_target_shards(tmp_path, emulate):
     """MMGPU_DEVICES=0,0,0,0: the prefilter hook lays the four contexts out as G query groups x S target shards (MMGpuRun::queryGroups:
     2 x 2 by the stage model, or MMGPU_QUERY_GROUPS).  Every group holds the whole database dealt to its S contexts - tantan-masked on
     the device shard by shard, one k-mer index per context, lists exchanged and merged inside the group - and the query blocks (64
@@ -707,29 +718,41 @@ def test_query_groups_by_target_shards_in_one_process(tmp_path):
         if groups is not None:
             env["MMGPU_QUERY_GROUPS"] = groups
         out = "pref_g" + (groups or "auto")
-        log = run(MMGPU, ["prefilter", "q", "q", out, "-s", "5.7", "--threads", THREADS, "-v", "3"], w, extra_env=env)
+        log = run(MMGPU, ["prefilter", "q", "q", out, "-s", "5.7", "--threads", THREADS, "-v", "3"], w, emulate, extra_env=env)
         assert layout in log and "using the CPU path" not in log and "tantan on the device" in log, log[-2500:]
         assert same(os.path.join(w, "pref_s"), os.path.join(w, out)) == 500, layout
     env = {"MMGPU_DEVICES": "0,0,0,0", "MMGPU_PREF_BLOCK_QUERIES": "64"}
     run(STOCK, ["prefilter", "q", "q", "pref_s0", "-s", "4", "--diag-score", "0", "--threads", THREADS, "-v", "2"], w)
-    log = run(MMGPU, ["prefilter", "q", "q", "pref_g0", "-s", "4", "--diag-score", "0", "--threads", THREADS, "-v", "3"], w, extra_env=env)
+    log = run(MMGPU, ["prefilter", "q", "q", "pref_g0", "-s", "4", "--diag-score", "0", "--threads", THREADS, "-v", "3"], w, emulate, extra_env=env)
     assert "runs without target shards" in log and "4 query groups x 1 target shard," in log and "using the CPU path" not in log, log[-2500:]
     assert same(os.path.join(w, "pref_s0"), os.path.join(w, "pref_g0")) == 500
     # a target split with more sequences than one context indexes (8 388 608; 200 for this test) on ONE device: the hook opens as
     # many contexts on it as it takes and merges their lists
-    log = run(MMGPU, ["prefilter", "q", "q", "pref_v", "-s", "5.7", "--threads", THREADS, "-v", "3"], w,
+    log = run(MMGPU, ["prefilter", "q", "q", "pref_v", "-s", "5.7", "--threads", THREADS, "-v", "3"], w, emulate,
               extra_env={"MMGPU_TEST_MAX_TARGETS": "200", "MMGPU_PREF_BLOCK_QUERIES": "64"})
     assert "3 device contexts (one device" in log and "1 query group x 3 target shards" in log and "using the CPU path" not in log, log[-2500:]
     assert same(os.path.join(w, "pref_s"), os.path.join(w, "pref_v")) == 500
-    log = run(MMGPU, ["search", "q", "q", "res_v", "tmp_v", "-s", "5.7", "-a", "--threads", THREADS, "-v", "3"], w,
+    log = run(MMGPU, ["search", "q", "q", "res_v", "tmp_v", "-s", "5.7", "-a", "--threads", THREADS, "-v", "3"], w, emulate,
               extra_env={"MMGPU_TEST_MAX_TARGETS": "200"})
     assert "1 query group x 3 target shards" in log and "using the CPU path" not in log, log[-2500:]
     # the whole search: the alignment module of the same process deals its queries to the four contexts the prefilter opened
     run(STOCK, ["search", "q", "q", "res_s", "tmp_s", "-s", "5.7", "-a", "--threads", THREADS, "-v", "2"], w)
-    log = run(MMGPU, ["search", "q", "q", "res_g", "tmp_g", "-s", "5.7", "-a", "--threads", THREADS, "-v", "3"], w, extra_env=env)
+    log = run(MMGPU, ["search", "q", "q", "res_g", "tmp_g", "-s", "5.7", "-a", "--threads", THREADS, "-v", "3"], w, emulate, extra_env=env)
     assert "2 query groups x 2 target shards" in log and "using the CPU path" not in log, log[-2500:]
     assert same(os.path.join(w, "res_s"), os.path.join(w, "res_g")) == 500
     assert same(os.path.join(w, "res_s"), os.path.join(w, "res_v")) == 500
+
+
+def test_query_groups_by_target_shards_host_side_emulated(tmp_path):
+    """(as above: the hooks' layout of groups, helper threads and blocks, the large-split path, the fused search over four contexts)"""
+    if not os.path.exists(EMU):
+        pytest.skip("oracle/_build/emu/libmmgpu.so not built (make -C oracle emu)")
+    _query_groups_by_target_shards(tmp_path, emulate=True)
+
+
+@pytest.mark.gpu
+def test_query_groups_by_target_shards_in_one_process(tmp_path):
+    _query_groups_by_target_shards(tmp_path, emulate=False)
 
 
 def _block_aligner_modes(tmp, emulate):
