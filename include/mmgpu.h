@@ -232,7 +232,7 @@ int mmgpu_sw_block_tiers(const mmgpu_sw_batch_t *batch, uint32_t *first_tier, ui
  * instead of the Smith-Waterman for DBTYPE_NUCLEOTIDES, Matcher.cpp:76-79): ungapped seed on the prefilter diagonal,
  * left extension on the reversed sequences, right extension with CIGAR by ksw_extz2_sse (band 64, z-drop), backtrace.
  * Targets are the resident database (mmgpu_load_targets with alphabet 5, numeric codes of NucleotideMatrix:
- * A C T G X = 0..4); wrapped scoring (circular genomes) is not supported.
+ * A C T G X = 0..4).
  *
  * past_end_query / past_end_target: the reference reads ONE residue past the end of both sequences
  * (SmithWaterman::seq_reverse is called with L where it expects L - 1, BandedNucleotideAligner.cpp:61,68,93), i.e.
@@ -244,6 +244,8 @@ typedef struct {
     int gap_open, gap_extend; /* 5, 2 (Parameters: gapOpen / gapExtend for nucleotides) */
     int zdrop;                /* par.zdrop (40) */
     int past_end_query, past_end_target;
+    int wrapped;              /* --wrapped-scoring (circular sequences): every query is its sequence written twice (Alignment.cpp:332-337);
+                               * the seed may wrap around, the extensions run over the original length at most (:98-113,171-174,189-191) */
 } mmgpu_nucl_params;
 typedef struct {
     const uint8_t *q;  /* Sequence::numSequence of the query (forward strand) */

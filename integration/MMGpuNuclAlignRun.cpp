@@ -14,7 +14,9 @@
 // pair its two letters (mmgpu_nucl_pair::past_end); memory no sequence has written yet counts as 0 (= 'A'), which is what a
 // fresh heap gives the reference.  Output = `mmseqs align --threads 1` of the stock binary, whatever --threads is here.
 //
-// Not served (the reference's loop computes, MMGpuAlignRun::usableNucleotide): wrapped scoring, --realign, --alt-ali, lcaalign
+// --wrapped-scoring (circular sequences) is served: the query goes to the device written twice, as Alignment.cpp:332-337 hands it to
+// the matcher (mmgpu_nucl_params::wrapped), coverage / E-value / identity use the original length (Matcher.cpp:68).
+// Not served (the reference's loop computes, MMGpuAlignRun::usableNucleotide): --realign, --alt-ali, lcaalign
 // and finite --max-accept / --max-rejected (where the loop stops, and what it aligns a second time, decides what the buffers
 // hold for the next query).
 #include <climits>
@@ -63,8 +65,8 @@ bool MMGpuAlignRun::usableNucleotide(const Alignment &a) {
                       Parameters::isEqualDbtype(a.targetSeqType, Parameters::DBTYPE_NUCLEOTIDES);
     if (!nucl) return false;
     if (getenv("MMGPU_NUCL_ALIGN") != NULL && getenv("MMGPU_NUCL_ALIGN")[0] == '0') return false;
-    return !a.wrappedScoring && !a.realign && a.altAlignment == 0 && !a.lcaAlign && a.maxAccept == INT_MAX && a.maxReject == INT_MAX &&
-           a.m->alphabetSize == 5;
+    // (--wrapped-scoring runs on the device since round 4: mmgpu_nucl_params::wrapped)
+    return !a.realign && a.altAlignment == 0 && !a.lcaAlign && a.maxAccept == INT_MAX && a.maxReject == INT_MAX && a.m->alphabetSize == 5;
 }
 
 void MMGpuAlignRun::beginNucleotide(MMGpuAlignSession *s) {
@@ -83,6 +85,7 @@ void MMGpuAlignRun::beginNucleotide(MMGpuAlignSession *s) {
     n->par.zdrop = al.zdrop;
     n->par.past_end_query = 0;
     n->par.past_end_target = 0;
+    n->par.wrapped = al.wrappedScoring ? 1 : 0;
     s->nucl = n;
 }
 
@@ -125,7 +128,13 @@ void MMGpuAlignRun::planNucleotide(MMGpuAlignSession *s) {
                 char *querySeqData = al.qdbr->getData(qId, thread_idx);
                 if (querySeqData == NULL) continue;      // (the loop reports it)
                 origQueryLen = al.qdbr->getSeqLen(qId);
-                qSeq.mapSequence(qId, queryDbKey, querySeqData, origQueryLen);
+                if (al.wrappedScoring) {      // :332-337: the query written twice
+                    std::string twice(querySeqData, origQueryLen);
+                    twice += twice;
+                    qSeq.mapSequence(qId, queryDbKey, twice.c_str(), origQueryLen * 2);
+                } else {
+                    qSeq.mapSequence(qId, queryDbKey, querySeqData, origQueryLen);
+                }
                 queryNum[b].assign(qSeq.numSequence, qSeq.numSequence + qSeq.L);
             }
             while (*data != '\0') {
@@ -211,7 +220,8 @@ void MMGpuAlignRun::planNucleotide(MMGpuAlignSession *s) {
     EvalueComputation &evaluer = s->evaluer;
 #pragma omp parallel for schedule(dynamic, 5) num_threads(al.threads)
     for (size_t b = 0; b < nq; b++) {
-        const int queryLen = (int)queryNum[b].size();
+        const int queryLen = (int)queryNum[b].size();      // (the doubled length with wrapped scoring)
+        const int origQueryLen = al.wrappedScoring ? queryLen / 2 : queryLen;      // Matcher.cpp:68
         size_t pi = firstPair[b];
         std::vector<Matcher::result_t> &out = s->results[b];
         out.reserve(firstPair[b + 1] - firstPair[b]);
@@ -224,17 +234,18 @@ void MMGpuAlignRun::planNucleotide(MMGpuAlignSession *s) {
                 EXIT(EXIT_FAILURE);
             }
             const int dbLen = (int)(tOff[e.dbId + 1] - tOff[e.dbId]);
-            const float qcov = SmithWaterman::computeCov(h.q_start, h.q_end, queryLen);
+            float qcov = SmithWaterman::computeCov(h.q_start, h.q_end, queryLen);
+            if (al.wrappedScoring) qcov = std::min(1.0f, qcov * 2);      // BandedNucleotideAligner.cpp:146-147,225-227
             const float dbcov = SmithWaterman::computeCov(h.t_start, h.t_end, dbLen);
-            const double evalue = evaluer.computeEvalue(h.score, queryLen);
+            const double evalue = evaluer.computeEvalue(h.score, origQueryLen);
             std::string backtrace(bt.data() + h.bt_off, h.bt_len);
             unsigned int alnLength = Matcher::computeAlnLength(h.q_start, h.q_end, h.t_start, h.t_end);
             if (backtrace.size() > 0) alnLength = backtrace.size();
-            const float seqId = Util::computeSeqId(al.seqIdMode, h.ident, queryLen, dbLen, alnLength);
+            const float seqId = Util::computeSeqId(al.seqIdMode, h.ident, origQueryLen, dbLen, alnLength);
             const int bitScore = static_cast<int>(evaluer.computeBitScore(h.score) + 0.5);
-            if (e.reverse) out.emplace_back(Matcher::result_t(e.dbKey, bitScore, qcov, dbcov, seqId, evalue, alnLength, h.q_start, h.q_end, queryLen,
+            if (e.reverse) out.emplace_back(Matcher::result_t(e.dbKey, bitScore, qcov, dbcov, seqId, evalue, alnLength, h.q_start, h.q_end, origQueryLen,
                                                                h.t_end, h.t_start, dbLen, backtrace));
-            else out.emplace_back(Matcher::result_t(e.dbKey, bitScore, qcov, dbcov, seqId, evalue, alnLength, h.q_start, h.q_end, queryLen,
+            else out.emplace_back(Matcher::result_t(e.dbKey, bitScore, qcov, dbcov, seqId, evalue, alnLength, h.q_start, h.q_end, origQueryLen,
                                                     h.t_start, h.t_end, dbLen, backtrace));
         }
     }

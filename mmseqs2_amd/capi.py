@@ -44,7 +44,7 @@ class SwQuery(ctypes.Structure):
 
 class NuclParams(ctypes.Structure):
     _fields_ = [("mat", c_p), ("reverse", c_p), ("gap_open", ctypes.c_int), ("gap_extend", ctypes.c_int), ("zdrop", ctypes.c_int),
-                ("past_end_query", ctypes.c_int), ("past_end_target", ctypes.c_int)]
+                ("past_end_query", ctypes.c_int), ("past_end_target", ctypes.c_int), ("wrapped", ctypes.c_int)]
 
 
 class NuclQuery(ctypes.Structure):
@@ -624,7 +624,7 @@ class MMGpu:
         return b
 
     # ---- nucleotide alignment step ----
-    def nucl_align(self, mat, reverse, queries, pairs, gap_open=5, gap_extend=2, zdrop=40, past_end_query=4, past_end_target=4):
+    def nucl_align(self, mat, reverse, queries, pairs, gap_open=5, gap_extend=2, zdrop=40, past_end_query=4, past_end_target=4, wrapped=False):
         """queries: list of uint8 arrays (codes 0..4); pairs: structured NUCL_PAIR_DTYPE array (or list of
         (query, target, diagonal, reverse[, past_end])).  Returns (NUCL_HIT_DTYPE array, list of backtrace strings)."""
         mat = np.ascontiguousarray(mat, np.int8).reshape(-1)
@@ -639,7 +639,7 @@ class MMGpu:
         arr = (NuclQuery * max(len(qs), 1))()
         for i, q in enumerate(qs):
             arr[i] = NuclQuery(_ptr(q), len(q))
-        par = NuclParams(_ptr(mat), _ptr(rev), gap_open, gap_extend, zdrop, past_end_query, past_end_target)
+        par = NuclParams(_ptr(mat), _ptr(rev), gap_open, gap_extend, zdrop, past_end_query, past_end_target, int(bool(wrapped)))
         out = np.zeros(len(pairs), NUCL_HIT_DTYPE)
         tl = self._target_lens
         # room for every backtrace; indices are clipped here, the library is the one that rejects bad ones

@@ -100,6 +100,7 @@ extern "C" int mmgpu_nucl_align(mmgpu_ctx *c, const mmgpu_nucl_params *par, cons
     L.gapo = par->gap_open;
     L.gape = par->gap_extend;
     L.zdrop = par->zdrop;
+    L.wrapped = par->wrapped ? 1 : 0;
     L.past_end_q = par->past_end_query;
     L.past_end_t = par->past_end_target;
     L.pscratch = d_p.as<uint8_t>();

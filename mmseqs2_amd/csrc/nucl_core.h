@@ -33,6 +33,7 @@ struct NuclLaunch {
     uint8_t rev_lookup[8];
     int gapo, gape, zdrop;
     int past_end_q, past_end_t;
+    int wrapped;                   // --wrapped-scoring: every query is its sequence written twice
     uint8_t *pscratch;             // direction bytes, one slice per 16-lane group of the grid
     uint64_t pscratch_stride;
     char *wscratch;                // backtrack letters, one slice per group
@@ -396,6 +397,42 @@ NUCL_HD Seed seed_on_diagonal(const SeqView &qv, unsigned qlen, const SeqView &t
     return r;
 }
 
+// The ungapped seed of BandedNucleotideAligner::align (:98-113).  Plain: every 65536-shift of the 16-bit prefilter diagonal that
+// fits (computeUngappedAlignment, DistanceCalculator.h:93-112).  Wrapped scoring: the query is its sequence written twice - where
+// it is at least twice the target, every window of half its length that starts at a shift of the diagonal is laid on the target
+// from position 0 (computeUngappedWrappedAlignment, :56-90; the loop bounds are the reference's unsigned comparisons), otherwise
+// the plain seed over the first half.
+NUCL_HD Seed pick_seed(const SeqView &qv, int qlen, const SeqView &tv, int tlen, unsigned diag16, bool wrapped, const int8_t *mat) {
+    Seed best;
+    best.start = -1; best.end = -1; best.score = 0; best.dist = 0; best.diagonal = 0;
+    if (wrapped && qlen >= tlen * 2) {
+        const unsigned half = (unsigned)qlen / 2u;
+        const unsigned len = (unsigned)tlen < half ? (unsigned)tlen : half;
+        for (int pass = 0; pass < 2; pass++)
+            for (unsigned d = pass == 0 ? 1u : 0u;
+                 pass == 0 ? (0u - d * 65536u + diag16) > 0u - (unsigned)tlen : (d * 65536u + diag16) < half; d++) {
+                const int real = pass == 0 ? (int)((0u - d * 65536u + diag16) + half) : (int)(d * 65536u + diag16);
+                Seed t;
+                t.dist = (unsigned)(real < 0 ? -real : real);
+                t.diagonal = real;
+                int s, e, sc;
+                seed_segment(qv, real, tv, 0, len, mat, s, e, sc);
+                t.start = s; t.end = e; t.score = (unsigned)sc;
+                if (t.score > best.score) best = t;
+            }
+        return best;
+    }
+    const unsigned ql = wrapped ? (unsigned)qlen / 2u : (unsigned)qlen;
+    for (unsigned d = 1; d <= 1u + (unsigned)tlen / 32768u; d++) {
+        const Seed t = seed_on_diagonal(qv, ql, tv, (unsigned)tlen, (int)(0u - d * 65536u + diag16), mat);
+        if (t.score > best.score) best = t;
+    }
+    for (unsigned d = 0; d <= ql / 65536u; d++) {
+        const Seed t = seed_on_diagonal(qv, ql, tv, (unsigned)tlen, (int)(d * 65536u + diag16), mat);
+        if (t.score > best.score) best = t;
+    }
+    return best;
+}
 
 // One 16-lane group: pulls pairs from the queue until it is empty.
 NUCL_HD void align_group(const NuclLaunch &L, GroupLds &S, uint8_t *p, char *w) {
@@ -420,17 +457,10 @@ NUCL_HD void align_group(const NuclLaunch &L, GroupLds &S, uint8_t *p, char *w) 
         tv.rl = nullptr;
         tv.L = tlen; tv.off = 0; tv.past = (P.past_end & 0x80u) ? (int)((P.past_end >> 3) & 7u) : L.past_end_t; tv.reversed = false;
 
-        // ---- ungapped seed: every 65536-shift of the 16-bit prefilter diagonal that fits (DistanceCalculator.h:93-112)
-        Seed best;
-        best.start = -1; best.end = -1; best.score = 0; best.dist = 0; best.diagonal = 0;
-        for (unsigned d = 1; d <= 1u + (unsigned)tlen / 32768u; d++) {
-            const Seed t = seed_on_diagonal(qv, (unsigned)qlen, tv, (unsigned)tlen, (int)(0u - d * 65536u + (unsigned)P.diagonal), L.mat);
-            if (t.score > best.score) best = t;
-        }
-        for (unsigned d = 0; d <= (unsigned)qlen / 65536u; d++) {
-            const Seed t = seed_on_diagonal(qv, (unsigned)qlen, tv, (unsigned)tlen, (int)(d * 65536u + (unsigned)P.diagonal), L.mat);
-            if (t.score > best.score) best = t;
-        }
+        // ---- ungapped seed (pick_seed); origQueryLen of the reference: half of a wrapped query
+        const bool wrapped = L.wrapped != 0;
+        const int orig = wrapped ? qlen / 2 : qlen;
+        const Seed best = pick_seed(qv, qlen, tv, tlen, (unsigned)P.diagonal, wrapped, L.mat);
         int qs, qe_, ts, te;
         if (best.diagonal >= 0) { qs = best.start + (int)best.dist; qe_ = best.end + (int)best.dist; ts = best.start; te = best.end; }
         else { qs = best.start; qe_ = best.end; ts = best.start + (int)best.dist; te = best.end + (int)best.dist; }
@@ -440,12 +470,12 @@ NUCL_HD void align_group(const NuclLaunch &L, GroupLds &S, uint8_t *p, char *w) 
         res.status = MMGPU_NUCL_OK;
         int n_bt = 0;
         bool walk_reversed = false;     // w[] holds the letters last column first
-        if (qe_ - qs == qlen - 1 && ts == 0 && te == tlen - 1) {
+        if (qe_ - qs == orig - 1 && ts == 0 && te == tlen - 1) {
             // the seed spans both sequences (:130-160)
             res.score = (int32_t)best.score;
             res.q_start = qs; res.q_end = qe_; res.t_start = ts; res.t_end = te;
-            for (int i = lane; i < qlen; i += NG) w[i] = 'M';
-            n_bt = qlen;
+            for (int i = lane; i < orig; i += NG) w[i] = 'M';
+            n_bt = orig;
         } else {
             // left extension, score only, on the (shifted) reversed sequences from the seed's end backwards (:165-181)
             const int q_start_rev = qlen - qe_ - 1, t_start_rev = tlen - te - 1;
@@ -453,18 +483,20 @@ NUCL_HD void align_group(const NuclLaunch &L, GroupLds &S, uint8_t *p, char *w) 
             qr.reversed = true; qr.off = q_start_rev;
             tr.reversed = true; tr.off = t_start_rev;
             Ez ez, eza;
-            ksw_extz2<false>(qr, qlen - q_start_rev, tr, tlen - t_start_rev, L.mat, L.gapo, L.gape, L.zdrop, S, nullptr, ez);
+            // (wrapped scoring: neither extension runs over more than the original query, :171-174,189-191)
+            const int q_rev_len = wrapped && qlen - q_start_rev > orig ? orig : qlen - q_start_rev;
+            ksw_extz2<false>(qr, q_rev_len, tr, tlen - t_start_rev, L.mat, L.gapo, L.gape, L.zdrop, S, nullptr, ez);
             const int q_start = qlen - (q_start_rev + ez.max_q) - 1, t_start = tlen - (t_start_rev + ez.max_t) - 1;
             // right extension with directions from that start (:183-196)
             SeqView qf = qv, tf = tv;
             qf.off = q_start;
             tf.off = t_start;
-            int wq = qlen - q_start, wt = tlen - t_start;
+            int wq = wrapped && qlen - q_start > orig ? orig : qlen - q_start, wt = tlen - t_start;
             ksw_extz2<true>(qf, wq, tf, wt, L.mat, L.gapo, L.gape, L.zdrop, S, p, eza);
             if (ez.max_q > eza.max_q && ez.max_t > eza.max_t) {
                 // the forward pass fell short of the backward pass: the backward pass is redone with directions and
                 // its CIGAR reversed (:201-210)
-                wq = qlen - q_start_rev;
+                wq = q_rev_len;
                 wt = tlen - t_start_rev;
                 ksw_extz2<true>(qr, wq, tr, wt, L.mat, L.gapo, L.gape, L.zdrop, S, p, eza);
                 walk_reversed = true;

@@ -326,17 +326,10 @@ NUCL_HD void align_wave(const NuclLaunch &L, WaveLds &S, uint8_t *p, char *w) {
         tv.rl = nullptr;
         tv.L = tlen; tv.off = 0; tv.past = (P.past_end & 0x80u) ? (int)((P.past_end >> 3) & 7u) : L.past_end_t; tv.reversed = false;
 
-        // ---- ungapped seed: every 65536-shift of the 16-bit prefilter diagonal that fits (DistanceCalculator.h:93-112)
-        Seed best;
-        best.start = -1; best.end = -1; best.score = 0; best.dist = 0; best.diagonal = 0;
-        for (unsigned d = 1; d <= 1u + (unsigned)tlen / 32768u; d++) {
-            const Seed t = seed_on_diagonal(qv, (unsigned)qlen, tv, (unsigned)tlen, (int)(0u - d * 65536u + (unsigned)P.diagonal), L.mat);
-            if (t.score > best.score) best = t;
-        }
-        for (unsigned d = 0; d <= (unsigned)qlen / 65536u; d++) {
-            const Seed t = seed_on_diagonal(qv, (unsigned)qlen, tv, (unsigned)tlen, (int)(d * 65536u + (unsigned)P.diagonal), L.mat);
-            if (t.score > best.score) best = t;
-        }
+        // ---- ungapped seed (pick_seed); origQueryLen of the reference: half of a wrapped query
+        const bool wrapped = L.wrapped != 0;
+        const int orig = wrapped ? qlen / 2 : qlen;
+        const Seed best = pick_seed(qv, qlen, tv, tlen, (unsigned)P.diagonal, wrapped, L.mat);
         int qs, qe_, ts, te;
         if (best.diagonal >= 0) { qs = best.start + (int)best.dist; qe_ = best.end + (int)best.dist; ts = best.start; te = best.end; }
         else { qs = best.start; qe_ = best.end; ts = best.start + (int)best.dist; te = best.end + (int)best.dist; }
@@ -346,12 +339,12 @@ NUCL_HD void align_wave(const NuclLaunch &L, WaveLds &S, uint8_t *p, char *w) {
         res.status = MMGPU_NUCL_OK;
         int n_bt = 0;
         bool walk_reversed = false;     // w[] holds the letters last column first
-        if (qe_ - qs == qlen - 1 && ts == 0 && te == tlen - 1) {
+        if (qe_ - qs == orig - 1 && ts == 0 && te == tlen - 1) {
             // the seed spans both sequences (:130-160)
             res.score = (int32_t)best.score;
             res.q_start = qs; res.q_end = qe_; res.t_start = ts; res.t_end = te;
-            for (int i = lane; i < qlen; i += NG) w[i] = 'M';
-            n_bt = qlen;
+            for (int i = lane; i < orig; i += NG) w[i] = 'M';
+            n_bt = orig;
         } else {
             // left extension, score only, on the (shifted) reversed sequences from the seed's end backwards (:165-181)
             const int q_start_rev = qlen - qe_ - 1, t_start_rev = tlen - te - 1;
@@ -359,18 +352,20 @@ NUCL_HD void align_wave(const NuclLaunch &L, WaveLds &S, uint8_t *p, char *w) {
             qr.reversed = true; qr.off = q_start_rev;
             tr.reversed = true; tr.off = t_start_rev;
             Ez ez, eza;
-            ksw_extz2_wave<false>(qr, qlen - q_start_rev, tr, tlen - t_start_rev, L.mat, L.gapo, L.gape, L.zdrop, S, nullptr, ez);
+            // (wrapped scoring: neither extension runs over more than the original query, :171-174,189-191)
+            const int q_rev_len = wrapped && qlen - q_start_rev > orig ? orig : qlen - q_start_rev;
+            ksw_extz2_wave<false>(qr, q_rev_len, tr, tlen - t_start_rev, L.mat, L.gapo, L.gape, L.zdrop, S, nullptr, ez);
             const int q_start = qlen - (q_start_rev + ez.max_q) - 1, t_start = tlen - (t_start_rev + ez.max_t) - 1;
             // right extension with directions from that start (:183-196)
             SeqView qf = qv, tf = tv;
             qf.off = q_start;
             tf.off = t_start;
-            int wq = qlen - q_start, wt = tlen - t_start;
+            int wq = wrapped && qlen - q_start > orig ? orig : qlen - q_start, wt = tlen - t_start;
             ksw_extz2_wave<true>(qf, wq, tf, wt, L.mat, L.gapo, L.gape, L.zdrop, S, p, eza);
             if (ez.max_q > eza.max_q && ez.max_t > eza.max_t) {
                 // the forward pass fell short of the backward pass: the backward pass is redone with directions and
                 // its CIGAR reversed (:201-210)
-                wq = qlen - q_start_rev;
+                wq = q_rev_len;
                 wt = tlen - t_start_rev;
                 ksw_extz2_wave<true>(qr, wq, tr, wt, L.mat, L.gapo, L.gape, L.zdrop, S, p, eza);
                 walk_reversed = true;

@@ -165,6 +165,10 @@ int mmo_ksw_extz2(int qlen, const uint8_t *query, int tlen, const uint8_t *targe
 int mmo_nucl_align(const uint8_t *q_num, int qlen, const uint8_t *t_num, int tlen, const int8_t *mat, int alph,
                    const uint8_t *rev_lookup, int gapo, int gape, int zdrop, unsigned diagonal16, int reverse,
                    int past_end_q, int past_end_t, mmo_nucl_result *res, char *bt, int bt_cap);
+/* the same with the caller's --wrapped-scoring: q_num is the query written twice (qlen = the doubled length) */
+int mmo_nucl_align_wrapped(const uint8_t *q_num, int qlen, const uint8_t *t_num, int tlen, const int8_t *mat, int alph,
+                   const uint8_t *rev_lookup, int gapo, int gape, int zdrop, unsigned diagonal16, int reverse,
+                   int past_end_q, int past_end_t, int wrapped, mmo_nucl_result *res, char *bt, int bt_cap);
 
 /* ---- block aligner (block_oracle.c): lib/block-aligner 0.4.0, AVX2 configuration, as the reference calls it ---- */
 typedef struct { int32_t score; uint32_t query_idx, reference_idx; } mmo_block_res;

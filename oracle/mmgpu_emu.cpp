@@ -531,8 +531,8 @@ int mmgpu_nucl_align(mmgpu_ctx *c, const mmgpu_nucl_params *par, const mmgpu_nuc
         const int pt = (p.past_end & 0x80u) ? (int)((p.past_end >> 3) & 7u) : par->past_end_target;
         std::vector<char> s((size_t)qlen + tlen + 2);
         mmo_nucl_result r;
-        mmo_nucl_align(qs[p.query].q, qlen, c->tres.data() + c->toff[p.target], tlen, par->mat, 5, par->reverse, par->gap_open, par->gap_extend,
-                       par->zdrop, p.diagonal, p.reverse, pq, pt, &r, s.data(), (int)s.size());
+        mmo_nucl_align_wrapped(qs[p.query].q, qlen, c->tres.data() + c->toff[p.target], tlen, par->mat, 5, par->reverse, par->gap_open,
+                               par->gap_extend, par->zdrop, p.diagonal, p.reverse, pq, pt, par->wrapped ? 1 : 0, &r, s.data(), (int)s.size());
         mmgpu_nucl_hit &o = out[i];
         o.score = r.score; o.q_start = r.q_start; o.q_end = r.q_end; o.t_start = r.t_start; o.t_end = r.t_end;
         o.ident = r.ident; o.bt_len = (uint32_t)r.bt_len; o.bt_off = used;

@@ -321,7 +321,31 @@ static seed_t seed_best(const uint8_t *qs, unsigned qlen, const uint8_t *ts, uns
     return best;
 }
 
-/* BandedNucleotideAligner::align without wrapped scoring.  q_num / t_num: numeric codes (A C T G X = 0..4);
+/* DistanceCalculator.h:56-90 (computeUngappedWrappedAlignment): the query is the sequence written twice; every window of half its
+ * length that starts at a 65536-shift of the 16-bit diagonal is laid on the target from position 0.  The loop bounds are the
+ * reference's unsigned comparisons. */
+static seed_t seed_best_wrapped(const uint8_t *qs, unsigned qlen, const uint8_t *ts, unsigned tlen, unsigned short diagonal,
+                                const int8_t *mat, int alph) {
+    seed_t best = {-1, -1, 0, 0, 0};
+    for (unsigned d = 1; (0u - d * 65536u + diagonal) > 0u - tlen; d++) {
+        const int real = (int)((0u - d * 65536u + diagonal) + qlen / 2);
+        seed_t t = seed_on_diagonal(qs + real, qlen / 2, ts, tlen, 0, mat, alph);
+        t.diagonal += real;
+        t.dist = (unsigned)abs(real);
+        if (t.score > best.score) best = t;
+    }
+    for (unsigned d = 0; (d * 65536u + diagonal) < qlen / 2; d++) {
+        const int real = (int)(d * 65536u + diagonal);
+        seed_t t = seed_on_diagonal(qs + real, qlen / 2, ts, tlen, 0, mat, alph);
+        t.diagonal += real;
+        t.dist = (unsigned)abs(real);
+        if (t.score > best.score) best = t;
+    }
+    return best;
+}
+
+/* BandedNucleotideAligner::align; wrapped = the caller's --wrapped-scoring (the query is the sequence written twice, qlen its
+ * doubled length; BandedNucleotideAligner.cpp:98-113,131,146-147,171-174,189-191).  q_num / t_num: numeric codes (A C T G X = 0..4);
  * rev_lookup: NucleotideMatrix::reverseResidue.  past_end_q / past_end_t: the letter the reference finds one residue
  * past the end of the aligned query strand / of the target: SmithWaterman::seq_reverse is called with L where it
  * expects L - 1 (BandedNucleotideAligner.cpp:61,68,93, StripedSmithWaterman.h:224-233), so reversed[k] = seq[L - k]
@@ -330,6 +354,13 @@ static seed_t seed_best(const uint8_t *qs, unsigned qlen, const uint8_t *ts, uns
 int mmo_nucl_align(const uint8_t *q_num, int qlen, const uint8_t *t_num, int tlen, const int8_t *mat, int alph,
                    const uint8_t *rev_lookup, int gapo, int gape, int zdrop, unsigned diagonal16, int reverse,
                    int past_end_q, int past_end_t, mmo_nucl_result *res, char *bt, int bt_cap) {
+    return mmo_nucl_align_wrapped(q_num, qlen, t_num, tlen, mat, alph, rev_lookup, gapo, gape, zdrop, diagonal16, reverse, past_end_q,
+                                  past_end_t, 0, res, bt, bt_cap);
+}
+
+int mmo_nucl_align_wrapped(const uint8_t *q_num, int qlen, const uint8_t *t_num, int tlen, const int8_t *mat, int alph,
+                           const uint8_t *rev_lookup, int gapo, int gape, int zdrop, unsigned diagonal16, int reverse,
+                           int past_end_q, int past_end_t, int wrapped, mmo_nucl_result *res, char *bt, int bt_cap) {
     uint8_t *qa = (uint8_t *)malloc((size_t)qlen + 1), *qrev = (uint8_t *)malloc((size_t)qlen + 1),
             *trev = (uint8_t *)malloc((size_t)tlen + 1);
     /* the strand that is aligned (:82-90, initQuery :62-69) and the (shifted) reversed copies for the left extension */
@@ -339,36 +370,43 @@ int mmo_nucl_align(const uint8_t *q_num, int qlen, const uint8_t *t_num, int tle
     for (int k = 0; k <= tlen; k++) trev[k] = k == 0 ? (uint8_t)past_end_t : t_num[tlen - k];
     int rc = 0;
     memset(res, 0, sizeof(*res));
-    const seed_t sd = seed_best(qa, (unsigned)qlen, t_num, (unsigned)tlen, (unsigned short)diagonal16, mat, alph);
+    const int orig = wrapped ? qlen / 2 : qlen;      /* origQueryLen */
+    const seed_t sd = !wrapped ? seed_best(qa, (unsigned)qlen, t_num, (unsigned)tlen, (unsigned short)diagonal16, mat, alph)
+                      : (qlen >= tlen * 2 ? seed_best_wrapped(qa, (unsigned)qlen, t_num, (unsigned)tlen, (unsigned short)diagonal16, mat, alph)
+                                          : seed_best(qa, (unsigned)(qlen / 2), t_num, (unsigned)tlen, (unsigned short)diagonal16, mat, alph));
     int qs, qe_, ts, te;
     if (sd.diagonal >= 0) { qs = sd.start + (int)sd.dist; qe_ = sd.end + (int)sd.dist; ts = sd.start; te = sd.end; }
     else { qs = sd.start; qe_ = sd.end; ts = sd.start + (int)sd.dist; te = sd.end + (int)sd.dist; }
     int n_bt = 0;
-    if (qe_ - qs == qlen - 1 && ts == 0 && te == tlen - 1) {   /* the seed spans both sequences (:130-160) */
+    if (qe_ - qs == orig - 1 && ts == 0 && te == tlen - 1) {   /* the seed spans both sequences (:130-160) */
         res->score = (int32_t)sd.score;
         res->q_start = qs; res->q_end = qe_; res->t_start = ts; res->t_end = te;
         res->cigar_len = 1;
         uint32_t ids = 0;
         for (int i = qs; i <= qe_; i++) ids += qa[i] == t_num[ts + (i - qs)];
         res->ident = ids;
-        if (qlen + 1 > bt_cap) rc = -1;
-        else { memset(bt, 'M', (size_t)qlen); bt[qlen] = 0; }
-        n_bt = qlen;
+        if (orig + 1 > bt_cap) rc = -1;
+        else { memset(bt, 'M', (size_t)orig); bt[orig] = 0; }
+        n_bt = orig;
     } else {
         /* left extension, score only, on the reversed sequences from the seed's end backwards (:165-181) */
         const int q_start_rev = qlen - qe_ - 1, t_start_rev = tlen - te - 1;
         mmo_ksw_ez ez, eza;
-        mmo_ksw_extz2(qlen - q_start_rev, qrev + q_start_rev, tlen - t_start_rev, trev + t_start_rev, 5, mat, gapo, gape, 64,
+        int q_rev_len = qlen - q_start_rev;      /* queryRevLenToAlign (:171-174) */
+        if (wrapped && q_rev_len > orig) q_rev_len = orig;
+        mmo_ksw_extz2(q_rev_len, qrev + q_start_rev, tlen - t_start_rev, trev + t_start_rev, 5, mat, gapo, gape, 64,
                       zdrop, EZ_SCORE_ONLY | EZ_EXTZ_ONLY, &ez, NULL, 0);
         const int q_start = qlen - (q_start_rev + ez.max_q) - 1, t_start = tlen - (t_start_rev + ez.max_t) - 1;
         /* right extension with CIGAR from that start (:183-196) */
         const int cap = qlen + tlen + 2;
         uint32_t *cg = (uint32_t *)malloc((size_t)cap * 4);
-        int n = mmo_ksw_extz2(qlen - q_start, qa + q_start, tlen - t_start, t_num + t_start, 5, mat, gapo, gape, 64, zdrop,
+        int q_len_fwd = qlen - q_start;          /* queryLenToAlign (:189-191) */
+        if (wrapped && q_len_fwd > orig) q_len_fwd = orig;
+        int n = mmo_ksw_extz2(q_len_fwd, qa + q_start, tlen - t_start, t_num + t_start, 5, mat, gapo, gape, 64, zdrop,
                               EZ_EXTZ_ONLY, &eza, cg, cap);
         if (ez.max_q > eza.max_q && ez.max_t > eza.max_t) {
             /* the forward pass fell short of the backward pass: the backward pass is redone with CIGAR and reversed (:201-210) */
-            n = mmo_ksw_extz2(qlen - q_start_rev, qrev + q_start_rev, tlen - t_start_rev, trev + t_start_rev, 5, mat, gapo, gape,
+            n = mmo_ksw_extz2(q_rev_len, qrev + q_start_rev, tlen - t_start_rev, trev + t_start_rev, 5, mat, gapo, gape,
                               64, zdrop, EZ_EXTZ_ONLY, &eza, cg, cap);
             for (int i = 0; i < n / 2; i++) { const uint32_t t = cg[i]; cg[i] = cg[n - 1 - i]; cg[n - 1 - i] = t; }
         }

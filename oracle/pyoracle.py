@@ -788,7 +788,8 @@ class NuclOracle:
                                  _ptr(cg), cap)
         return [getattr(ez, f) for f in ("max", "zdropped", "max_q", "max_t", "mqe", "mqe_t", "mte", "mte_q", "score")], cg[:max(n, 0)].copy()
 
-    def align(self, q, t, mat, rev_lookup, gapo, gape, zdrop, diagonal, reverse, past_end_q=4, past_end_t=4):
+    def align(self, q, t, mat, rev_lookup, gapo, gape, zdrop, diagonal, reverse, past_end_q=4, past_end_t=4, wrapped=False):
+        """wrapped: --wrapped-scoring, q is the query written twice"""
         q = np.ascontiguousarray(q, np.uint8)
         t = np.ascontiguousarray(t, np.uint8)
         mat = np.ascontiguousarray(mat, np.int8)
@@ -796,9 +797,9 @@ class NuclOracle:
         res = NuclRes()
         cap = len(q) + len(t) + 8
         bt = ctypes.create_string_buffer(cap)
-        rc = self.L.mmo_nucl_align(_ptr(q), len(q), _ptr(t), len(t), _ptr(mat), 5, _ptr(rl), gapo, gape, zdrop,
-                                   ctypes.c_uint(diagonal & 0xFFFF), int(reverse), int(past_end_q), int(past_end_t),
-                                   ctypes.byref(res), bt, cap)
+        rc = self.L.mmo_nucl_align_wrapped(_ptr(q), len(q), _ptr(t), len(t), _ptr(mat), 5, _ptr(rl), gapo, gape, zdrop,
+                                           ctypes.c_uint(diagonal & 0xFFFF), int(reverse), int(past_end_q), int(past_end_t), int(bool(wrapped)),
+                                           ctypes.byref(res), bt, cap)
         assert rc == 0
         return res.as_tuple(), bt.value.decode()
 
@@ -872,12 +873,12 @@ class RefNucl:
         self._q = s.encode()           # the reference keeps the pointer
         self.L.mmref_nucl_set_query(self.ctx, self._q, len(s), int(past_end))
 
-    def align(self, tseq, diagonal, reverse, past_end=4):
+    def align(self, tseq, diagonal, reverse, past_end=4, wrapped=False):
         res = NuclRes()
         cap = len(self._q) + len(tseq) + 8
         bt = ctypes.create_string_buffer(cap)
         tb = tseq.encode()
-        self.L.mmref_nucl_align(self.ctx, tb, len(tseq), int(past_end), int(diagonal), int(reverse), 0, ctypes.byref(res), bt, cap)
+        self.L.mmref_nucl_align(self.ctx, tb, len(tseq), int(past_end), int(diagonal), int(reverse), int(bool(wrapped)), ctypes.byref(res), bt, cap)
         return res.as_tuple(), bt.value.decode()
 
     def ksw_extz2(self, q, t, mat, gapo, gape, w, zdrop, flag):

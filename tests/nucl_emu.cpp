@@ -144,6 +144,7 @@ extern "C" int nucl_emu_align(const mmgpu_nucl_params *par, const mmgpu_nucl_que
     L.gapo = par->gap_open;
     L.gape = par->gap_extend;
     L.zdrop = par->zdrop;
+    L.wrapped = par->wrapped ? 1 : 0;
     L.past_end_q = par->past_end_query;
     L.past_end_t = par->past_end_target;
     L.pscratch = pbuf.data();

@@ -441,8 +441,10 @@ def _nucleotide_pipeline(w, emulate, k="15"):
     # `mmseqs align` of the nucleotide lists: BandedNucleotideAligner::align on the device (integration/MMGpuNuclAlignRun.cpp).  The
     # reference reads one residue past the end of its per-thread buffers, so its own output depends on what a thread mapped
     # before: the comparison is with its one-thread run (which is what the hook replays), whatever --threads the patched binary has
+    # (--wrapped-scoring: the queries go to the aligner written twice - circular sequences; round 4: on the device)
     for n, extra in enumerate([["-a"], ["--alignment-mode", "3", "-c", "0.5"], ["-e", "1e-5", "--min-seq-id", "0.9", "-a"],
-                               ["--cov-mode", "2", "-c", "0.3", "--alignment-output-mode", "0"]]):
+                               ["--cov-mode", "2", "-c", "0.3", "--alignment-output-mode", "0"], ["--wrapped-scoring", "1", "-a"],
+                               ["--wrapped-scoring", "1", "-c", "0.8", "--cov-mode", "2"]]):
         run(STOCK, ["align", "nqf", "nt", "npref_s0", "naln_s%d" % n, "--threads", "1", "-v", "1"] + extra, w)
         log = run(MMGPU, ["align", "nqf", "nt", "npref_s0", "naln_g%d" % n, "--threads", THREADS, "-v", "3"] + extra, w, emulate)
         assert "MMGPU: nucleotide alignment on the device" in log, log[-2000:]

@@ -26,7 +26,7 @@ def _lib(lanes=16, wave=False):
     return ctypes.CDLL(so)
 
 
-def emu_align(L, mat, reverse, queries, targets, pairs, past_q, past_t, gapo=5, gape=2, zdrop=40):
+def emu_align(L, mat, reverse, queries, targets, pairs, past_q, past_t, gapo=5, gape=2, zdrop=40, wrapped=False):
     c_p = ctypes.c_void_p
     mat = np.ascontiguousarray(mat, np.int8).reshape(-1)
     rev = np.ascontiguousarray(reverse, np.uint8)
@@ -39,7 +39,7 @@ def emu_align(L, mat, reverse, queries, targets, pairs, past_q, past_t, gapo=5, 
     pa = np.zeros(len(pairs), capi.NUCL_PAIR_DTYPE)
     for i, p in enumerate(pairs):
         pa[i] = (p[0], p[1], p[2] & 0xFFFF, p[3], p[4] if len(p) > 4 else 0)
-    par = capi.NuclParams(mat.ctypes.data_as(c_p), rev.ctypes.data_as(c_p), gapo, gape, zdrop, past_q, past_t)
+    par = capi.NuclParams(mat.ctypes.data_as(c_p), rev.ctypes.data_as(c_p), gapo, gape, zdrop, past_q, past_t, int(bool(wrapped)))
     out = np.zeros(len(pairs), capi.NUCL_HIT_DTYPE)
     cap = int(sum(len(qs[p[0]]) + len(targets[p[1]]) + 2 for p in pairs))
     bt = np.zeros(cap, np.uint8)
@@ -84,3 +84,35 @@ def test_past_end_letters_per_pair_equal_the_per_call_ones():
     for c, h, s in zip(cases, hits, strs):
         got = (int(h["score"]), int(h["q_start"]), int(h["q_end"]), int(h["t_start"]), int(h["t_end"]), int(h["ident"]))
         assert got == c[6][:6] and s == c[7], (c[4], c[5], got, c[6])
+
+
+@pytest.mark.parametrize("lanes,wave", [(16, False), (64, True)])
+def test_wrapped_scoring_on_emulated_lanes_equals_the_oracle(lanes, wave):
+    """--wrapped-scoring: doubled queries, the wrap-around seed where the doubled query is at least twice the target, extensions
+    capped at the original length - the kernel source against the restatement (which tests/test_nucl_oracle.py pins against
+    the reference's BandedNucleotideAligner::align(..., wrappedScoring = true))."""
+    from oracle import pyoracle as po
+    L = _lib(lanes, wave)
+    g = nc.golden()
+    mat, rl = np.asarray(g["mat"]).reshape(5, 5), np.asarray(g["reverse"])
+    orc = po.NuclOracle()
+    rng = np.random.default_rng(31)
+    queries, targets, pairs, expected = [], [], [], []
+    for it in range(12):
+        n = int(rng.choice([40, 64, 130, 400, 900]))
+        circle = rng.integers(0, 4, size=n).astype(np.uint8)
+        rot = int(rng.integers(0, n))
+        q1 = nc.mutate(rng, np.roll(circle, -rot), rng.choice([0.0, 0.04]), rng.choice([0.0, 0.02]))
+        queries.append(np.concatenate([q1, q1]))
+        for t in (nc.mutate(rng, circle, 0.03, 0.01), circle[: max(8, n // 3)].copy(), np.concatenate([circle, circle[: n // 2]])):
+            for rev in (0, 1):
+                tt = np.array([rl[x] for x in t[::-1]], np.uint8) if rev else t
+                targets.append(tt)
+                for diag in (0, rot & 0xFFFF, (-rot) & 0xFFFF, int(rng.integers(0, 65536))):
+                    pq, pt = int(rng.integers(0, 5)), int(rng.integers(0, 5))
+                    pairs.append((len(queries) - 1, len(targets) - 1, diag, rev, 0x80 | pq | (pt << 3)))
+                    expected.append(orc.align(queries[-1], tt, mat.reshape(-1), rl, 5, 2, 40, diag, rev, pq, pt, wrapped=True))
+    hits, strs = emu_align(L, mat, rl, queries, targets, pairs, 4, 4, wrapped=True)
+    for k, (e, h, s) in enumerate(zip(expected, hits, strs)):
+        got = (int(h["score"]), int(h["q_start"]), int(h["q_end"]), int(h["t_start"]), int(h["t_end"]), int(h["ident"]))
+        assert got == e[0][:6] and s == e[1], (k, pairs[k], got, e[0])

@@ -86,6 +86,39 @@ def test_random_reads_vs_oracle(gpu):
     assert longest > 5000
 
 
+def test_wrapped_scoring_vs_oracle(gpu):
+    """--wrapped-scoring (mmgpu_nucl_params::wrapped): doubled queries of circular sequences read from another origin, against the
+    circle, a piece of it and the circle with a repeated part, both strands, true / shifted / arbitrary diagonals - the
+    restatement is pinned against the reference's BandedNucleotideAligner::align(..., true) in tests/test_nucl_oracle.py"""
+    g = nc.golden()
+    mat, rl = g["mat"], g["reverse"]
+    rng = np.random.default_rng(41)
+    orc = po.NuclOracle()
+    queries, targets, pairs = [], [], []
+    for n in [40, 64, 130, 400, 900, 3000, 9000]:
+        for _ in range(3):
+            circle = rng.integers(0, 4, size=n).astype(np.uint8)
+            rot = int(rng.integers(0, n))
+            q1 = nc.mutate(rng, np.roll(circle, -rot), rng.choice([0.0, 0.04]), rng.choice([0.0, 0.02]))
+            queries.append(np.concatenate([q1, q1]))
+            for t in (nc.mutate(rng, circle, 0.03, 0.01), circle[: max(8, n // 3)].copy(), np.concatenate([circle, circle[: n // 2]])):
+                for rev in (0, 1):
+                    targets.append(np.array([rl[x] for x in t[::-1]], np.uint8) if rev else t)
+                    for diag in (0, rot & 0xFFFF, (-rot) & 0xFFFF, int(rng.integers(0, 65536))):
+                        pairs.append((len(queries) - 1, len(targets) - 1, diag, rev))
+    tres = np.concatenate(targets)
+    toff = np.concatenate([[0], np.cumsum([len(t) for t in targets])]).astype(np.uint64)
+    gpu.load_targets(tres, toff, 5)
+    hits, strs = gpu.nucl_align(mat, rl, queries, pairs, 5, 2, 40, 4, 4, wrapped=True)
+    wrapped_seed = 0
+    for (qi, ti, diag, rev), h, s in zip(pairs, hits, strs):
+        exp, bt = orc.align(queries[qi], targets[ti], mat.reshape(-1), rl, 5, 2, 40, diag, rev, 4, 4, wrapped=True)
+        got = (int(h["score"]), int(h["q_start"]), int(h["q_end"]), int(h["t_start"]), int(h["t_end"]), int(h["ident"]))
+        assert h["status"] == 0 and got == exp[:6] and s == bt, (qi, ti, diag, rev, got, exp)
+        wrapped_seed += len(queries[qi]) >= 2 * len(targets[ti])
+    assert len(pairs) == 7 * 3 * 3 * 2 * 4 and wrapped_seed > 100
+
+
 def test_errors_and_empty(gpu):
     from mmseqs2_amd import capi
     g = nc.golden()

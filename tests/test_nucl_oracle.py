@@ -75,6 +75,38 @@ def test_oracle_matches_reference_fuzz():
 
 
 @pytest.mark.skipif(not (po.ref_available() and po.ref_matrix_available()), reason="needs oracle/_ref and /root/reference/data")
+def test_oracle_matches_reference_with_wrapped_scoring():
+    """--wrapped-scoring (circular sequences): the query is handed over written twice (Alignment.cpp:332-337); the ungapped seed
+    wraps around (computeUngappedWrappedAlignment, when the doubled query is at least twice the target) or is taken over the first
+    half, the extensions are capped at the original length (BandedNucleotideAligner.cpp:98-113,171-174,189-191)."""
+    rng = np.random.default_rng(17)
+    ref, orc = po.RefNucl(), po.NuclOracle()
+    mat, rl = ref.matrix(), ref.reverse_lookup()
+    letters = lambda a: "".join(po.NUCL_LETTERS[int(x)] for x in a)
+    n = wrapped_seed = 0
+    for it in range(60):
+        L = int(rng.choice([40, 64, 130, 500, 1500]))
+        circle = rng.integers(0, 4, size=L).astype(np.uint8)
+        rot = int(rng.integers(0, L))
+        q1 = nc.mutate(rng, np.roll(circle, -rot), rng.choice([0.0, 0.04]), rng.choice([0.0, 0.02]))      # the circle read from another origin
+        q = np.concatenate([q1, q1])
+        # targets: the circle itself (longer than half the doubled query or not), a piece of it, and the circle with an insertion
+        for t in (nc.mutate(rng, circle, 0.03, 0.01), circle[: max(8, L // 3)].copy(), np.concatenate([circle, circle[: L // 2]])):
+            pq, pt = int(rng.integers(0, 5)), int(rng.integers(0, 5))
+            ref.set_query(letters(q), pq)
+            for rev in (0, 1):
+                tt = np.array([rl[x] for x in t[::-1]], np.uint8) if rev else t
+                for diag in (0, rot & 0xFFFF, (-rot) & 0xFFFF, int(rng.integers(0, 65536))):
+                    e = ref.align(letters(tt), diag, rev, pt, wrapped=True)
+                    o = orc.align(q, tt, mat.reshape(-1), rl, 5, 2, 40, diag, rev, pq, pt, wrapped=True)
+                    assert e == o, (L, len(tt), diag, rev, e[0], o[0])
+                    n += 1
+                    wrapped_seed += len(q) >= 2 * len(tt)
+    ref.close()
+    assert n == 60 * 3 * 2 * 4 and wrapped_seed > 300
+
+
+@pytest.mark.skipif(not (po.ref_available() and po.ref_matrix_available()), reason="needs oracle/_ref and /root/reference/data")
 def test_long_targets_try_every_shift_of_the_16_bit_diagonal():
     """targets of 32768 residues or more: the prefilter diagonal is a 16-bit value and computeUngappedAlignment tries every
     65536-shift that fits (DistanceCalculator.h:93-112); oracle and the kernel source (emulated lanes) against the reference"""
