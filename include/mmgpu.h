@@ -315,6 +315,9 @@ typedef struct {
     const void *entries6;       /* ... or IndexTable::getEntries(): packed 6-byte IndexEntryLocal records */
     uint64_t n_entries;
     const int8_t *ungapped_mat; /* ungappedSubMat as int8, alphabet x alphabet (blosum62, bit factor 2) */
+    int kmer_alphabet;          /* mmgpu_pf_load_index only: IndexTable::getAlphabetSize() if it is not alphabet - 1 (0 = alphabet - 1).  A
+                                 * profile TARGET database is indexed over the full alphabet (Prefiltering.cpp:560-563: X is a letter of
+                                 * the k-mer index, 21^k offsets), its queries match exactly; windows containing X are skipped as ever */
 } mmgpu_pf_index;
 /* Copies the tables into HBM.  The SequenceLookup the ungapped scorer reads is the database given to
  * mmgpu_load_targets (call that first, with the - possibly masked - SequenceLookup residues). */

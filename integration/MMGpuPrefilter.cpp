@@ -45,13 +45,16 @@ bool MMGpuPrefilter::loadIndex(IndexTable *indexTable, SequenceLookup *sequenceL
     ix.kmer_size = indexTable->getKmerSize();
     ix.alphabet = kmerSubMat->alphabetSize;
     ix.spaced = spacedKmer ? 1 : 0;
-    // (no similar-k-mer tables where Prefiltering built none - nucleotide searches: the library then serves exact k-mers only)
-    ix.score3 = threeMer.isValid() ? threeMer.score : NULL;
-    ix.index3 = threeMer.isValid() ? threeMer.index : NULL;
-    ix.row3 = threeMer.isValid() ? threeMer.rowSize : 0;
-    ix.score2 = twoMer.isValid() ? twoMer.score : NULL;
-    ix.index2 = twoMer.isValid() ? twoMer.index : NULL;
-    ix.row2 = twoMer.isValid() ? twoMer.rowSize : 0;
+    // (no similar-k-mer tables where Prefiltering built none - nucleotide searches - or where the queries match exactly anyway
+    // - profile targets, --target-search-mode 1, --exact-kmer-matching: the library then serves exact k-mers only, for k = 4 .. 15)
+    const bool tables = !exactKmerMatching && threeMer.isValid();
+    ix.score3 = tables ? threeMer.score : NULL;
+    ix.index3 = tables ? threeMer.index : NULL;
+    ix.row3 = tables ? threeMer.rowSize : 0;
+    ix.score2 = tables && twoMer.isValid() ? twoMer.score : NULL;
+    ix.index2 = tables && twoMer.isValid() ? twoMer.index : NULL;
+    ix.row2 = tables && twoMer.isValid() ? twoMer.rowSize : 0;
+    ix.kmer_alphabet = indexTable->getAlphabetSize();      // (the full alphabet where the targets are profiles, Prefiltering.cpp:560-563)
     ix.offsets = reinterpret_cast<const uint64_t *>(indexTable->getOffsets());       // tableSize + 1 entries
     ix.entries6 = indexTable->getEntries();            // packed 6-byte IndexEntryLocal records
     ix.n_entries = indexTable->getTableEntriesNum();

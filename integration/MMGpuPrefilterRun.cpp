@@ -49,10 +49,16 @@ bool MMGpuPrefilterRun::usableConfig(Prefiltering &p, bool indexExists) {
     const bool profileQuery = Parameters::isEqualDbtype(p.querySeqType, Parameters::DBTYPE_HMM_PROFILE);
     const bool nucl = Parameters::isEqualDbtype(p.querySeqType, Parameters::DBTYPE_NUCLEOTIDES) &&
                       Parameters::isEqualDbtype(p.targetSeqType, Parameters::DBTYPE_NUCLEOTIDES);
-    const bool aa = (Parameters::isEqualDbtype(p.querySeqType, Parameters::DBTYPE_AMINO_ACIDS) || profileQuery) &&
-                    Parameters::isEqualDbtype(p.targetSeqType, Parameters::DBTYPE_AMINO_ACIDS);
+    // Profile TARGETS with amino-acid queries (e.g. sequences against a Pfam-like profile database): the index holds the similar
+    // k-mers of the profiles' positions (IndexBuilder.cpp:63, isTargetSimiliarKmerSearch - built on the host and handed over), the
+    // lookup their consensus sequences (:128), the queries match exactly (Prefiltering.cpp:187-190) - the path of
+    // --target-search-mode 1.
+    const bool profileTarget = Parameters::isEqualDbtype(p.querySeqType, Parameters::DBTYPE_AMINO_ACIDS) &&
+                               Parameters::isEqualDbtype(p.targetSeqType, Parameters::DBTYPE_HMM_PROFILE) && p.takeOnlyBestKmer;
+    const bool aa = ((Parameters::isEqualDbtype(p.querySeqType, Parameters::DBTYPE_AMINO_ACIDS) || profileQuery) &&
+                     Parameters::isEqualDbtype(p.targetSeqType, Parameters::DBTYPE_AMINO_ACIDS)) || profileTarget;
     const char *why = NULL;
-    if (!aa && !nucl) why = "profile targets / mixed database types";
+    if (!aa && !nucl) why = "mixed database types";
     else if (indexExists && (p.indexTable == NULL || p.sequenceLookup == NULL)) why = "no index table / sequence lookup in memory";
     else if (nucl && !p.takeOnlyBestKmer) why = "nucleotide search without exact k-mer matching";
     else if (profileQuery && p.takeOnlyBestKmer) why = "exact k-mer matching with profile queries";
@@ -77,7 +83,7 @@ bool MMGpuPrefilterRun::deviceBuildsIndex(Prefiltering &p) {
     if (p.templateDBIsIndex) return false;
     // --target-search-mode 1: the index holds the SIMILAR k-mers of every target position (IndexBuilder.cpp:63,
     // isTargetSimiliarKmerSearch) and the queries match exactly; that index is the host's to build, it is handed over as it is
-    if (p.targetSearchMode != 0) return false;
+    if (p.targetSearchMode != 0 || Parameters::isEqualDbtype(p.targetSeqType, Parameters::DBTYPE_HMM_PROFILE)) return false;
     // the same conditions run() will check at the seam, on what is known before the index exists
     const bool ok = usableConfig(p, false);
     if (ok) Debug(Debug::INFO) << "MMGPU: the k-mer index will be built on the device (MMGPU_HOST_INDEX=1 keeps the host's)\n";

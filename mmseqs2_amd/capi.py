@@ -88,7 +88,7 @@ class PfIndexDesc(ctypes.Structure):
     _fields_ = [("kmer_size", ctypes.c_int), ("alphabet", ctypes.c_int), ("spaced", ctypes.c_int), ("score3", c_p),
                 ("index3", c_p), ("row3", ctypes.c_size_t), ("score2", c_p), ("index2", c_p), ("row2", ctypes.c_size_t),
                 ("offsets", c_p), ("entry_ids", c_p), ("entry_pos", c_p),
-                ("entries6", c_p), ("n_entries", ctypes.c_uint64), ("ungapped_mat", c_p)]
+                ("entries6", c_p), ("n_entries", ctypes.c_uint64), ("ungapped_mat", c_p), ("kmer_alphabet", ctypes.c_int)]
 
 
 class PfParams(ctypes.Structure):

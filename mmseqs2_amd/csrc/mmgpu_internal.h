@@ -160,6 +160,7 @@ struct PfKmerArgs {
     uint32_t n_pos;
     uint8_t pat[16];           // Sequence::aaPosInSpacedPattern
     uint32_t kalph, n3;
+    uint32_t kbase;            // base of the k-mer index (pf_kmers_exact_kernel): kalph, or the full alphabet for profile targets
     const int16_t *s3;         // [n3][n3] ScoreMatrix::score of the 3-mer matrix (no padding columns)
     const uint32_t *i3;        // [n3][n3] ScoreMatrix::index
     const uint32_t *offsets;   // IndexTable::offsets, [kalph^k + 1]

@@ -17,6 +17,7 @@ namespace mmgpu {
 
 struct PfIndex {
     int k = 0, alphabet = 0, kalph = 0, spaced = 0;
+    int kbase = 0;               // base of the k-mer index (kalph, or the full alphabet for a handed-over index of profile targets)
     uint8_t pat[16] = {0};
     int pattern_len = 0;
     bool has_tables = false;   // similar-k-mer score tables present (false: exact k-mer matching only)
@@ -264,9 +265,11 @@ static int pf_setup(mmgpu_ctx *c, const mmgpu_pf_index *ix, bool from_host, PfIn
     if (ix->alphabet != c->db.alphabet) return fail(MMGPU_ERR_ARG, "mmgpu_pf_load_index: alphabet differs from the loaded targets");
     if (ix->alphabet < 2 || ix->alphabet > 32) return fail(MMGPU_ERR_ARG, "mmgpu_pf_load_index: alphabet must be in [2, 32]");
     if (!ix->ungapped_mat) return fail(MMGPU_ERR_ARG, "mmgpu_pf_load_index: NULL table");
+    const int kbase = (from_host && ix->kmer_alphabet > 0) ? ix->kmer_alphabet : ix->alphabet - 1;
+    if (kbase < ix->alphabet - 1 || kbase > ix->alphabet) return fail(MMGPU_ERR_ARG, "mmgpu_pf_load_index: kmer_alphabet must be alphabet - 1 or alphabet");
     {
         double tb = 1;
-        for (int i = 0; i < ix->kmer_size; i++) tb *= (double)(ix->alphabet - 1);
+        for (int i = 0; i < ix->kmer_size; i++) tb *= (double)kbase;
         if (tb > 2147483648.0) return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_pf_load_index: more than 2^31 k-mers");
     }
     if (from_host) {
@@ -280,11 +283,12 @@ static int pf_setup(mmgpu_ctx *c, const mmgpu_pf_index *ix, bool from_host, PfIn
     P->k = ix->kmer_size;
     P->alphabet = ix->alphabet;
     P->kalph = ix->alphabet - 1;
+    P->kbase = kbase;
     P->spaced = ix->spaced;
     P->pattern_len = window_pattern(P->k, P->spaced, P->pat);
     P->n3 = (uint32_t)(P->kalph * P->kalph * P->kalph);
     P->table = 1;
-    for (int i = 0; i < P->k; i++) P->table *= (uint64_t)P->kalph;
+    for (int i = 0; i < P->k; i++) P->table *= (uint64_t)P->kbase;
     P->n_entries = from_host ? ix->n_entries : 0;
     P->has_tables = tables;
     const size_t n3 = P->n3;
@@ -587,6 +591,8 @@ extern "C" int mmgpu_pf_prepare(mmgpu_ctx *c, const mmgpu_pf_params *par, const 
     if (bins > 2048) return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_pf_prepare: more than 8M targets per shard");
     HIP_TRY(hipSetDevice(c->device));
 
+    if (c->pf && c->pf->kbase != c->pf->kalph && !par->exact_kmer)
+        return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_pf_prepare: an index over the full alphabet (profile targets) serves exact k-mer matching only");
     mmgpu_pf_batch_t *b = new mmgpu_pf_batch_t();
     // the batch's buffers come from / go back to the context's block cache: a process prepares batch after batch (and, like the
     // drop-in's prefilter hook, the next one while this one runs), a fresh hipMalloc costs 25 - 40 ms per GB on some hosts
@@ -795,6 +801,7 @@ extern "C" int mmgpu_pf_run(mmgpu_ctx *c, mmgpu_pf_batch_t *b) {
     }
     memcpy(K.pat, P.pat, sizeof(K.pat));
     K.kalph = (uint32_t)P.kalph;
+    K.kbase = (uint32_t)P.kbase;
     K.n3 = P.n3;
     K.s3 = P.d_s3.as<int16_t>();
     K.i3 = P.d_i3.as<uint32_t>();

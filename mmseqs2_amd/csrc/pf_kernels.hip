@@ -349,7 +349,7 @@ __global__ __launch_bounds__(256) void pf_kmers_exact_kernel(PfKmerArgs A) {
     uint32_t idx = 0, pw = 1;
     for (int i = 0; i < A.k; i++) {
         idx += (uint32_t)q[A.pat[i]] * pw;
-        pw *= A.kalph;
+        pw *= A.kbase;      // (the index's own base: kalph, or the full alphabet for profile targets)
     }
     const uint32_t o0 = A.offsets[idx], o1 = A.offsets[idx + 1];
     PfList rec;

@@ -159,17 +159,21 @@ int mmgpu_sw_block_tiers(const mmgpu_sw_batch_t *, uint32_t *first_tier, uint32_
 
 int mmgpu_pf_load_index(mmgpu_ctx *c, const mmgpu_pf_index *ix) {
     if (!c || !ix) return fail(MMGPU_ERR_ARG, "mmgpu_pf_load_index: NULL argument");
-    if (!ix->score3 || !ix->index3 || !ix->offsets || !ix->ungapped_mat) return fail(MMGPU_ERR_ARG, "mmgpu_pf_load_index: NULL table");
+    if (!ix->offsets || !ix->ungapped_mat) return fail(MMGPU_ERR_ARG, "mmgpu_pf_load_index: NULL table");
+    const bool three = ix->score3 && ix->index3;      // (absent: an index for exact k-mer matching)
     const size_t kalph = (size_t)ix->alphabet - 1;
     const size_t n3 = kalph * kalph * kalph, n2 = kalph * kalph;
+    const size_t kbase = ix->kmer_alphabet > 0 ? (size_t)ix->kmer_alphabet : kalph;      // (the index's own alphabet: profile targets)
     size_t table = 1;
-    for (int i = 0; i < ix->kmer_size; i++) table *= kalph;
-    const bool two = ix->score2 && ix->index2;
+    for (int i = 0; i < ix->kmer_size; i++) table *= kbase;
+    const bool two = three && ix->score2 && ix->index2;
     uint64_t fp = c->targets_fp ^ 0x696E646578212121ull;
-    const int32_t scal[4] = {ix->kmer_size, ix->alphabet, ix->spaced, two ? 1 : 0};
+    const int32_t scal[5] = {ix->kmer_size, ix->alphabet, ix->spaced, two ? 1 : 0, (int32_t)kbase};
     fp = fingerprint(scal, sizeof(scal), fp);
-    fp = fingerprint(ix->score3, n3 * ix->row3 * 2, fp);
-    fp = fingerprint(ix->index3, n3 * ix->row3 * 4, fp);
+    if (three) {
+        fp = fingerprint(ix->score3, n3 * ix->row3 * 2, fp);
+        fp = fingerprint(ix->index3, n3 * ix->row3 * 4, fp);
+    }
     if (two) {
         fp = fingerprint(ix->score2, n2 * ix->row2 * 2, fp);
         fp = fingerprint(ix->index2, n2 * ix->row2 * 4, fp);
@@ -189,11 +193,12 @@ int mmgpu_pf_load_index(mmgpu_ctx *c, const mmgpu_pf_index *ix) {
     q.put<int32_t>(ix->kmer_size);
     q.put<int32_t>(ix->alphabet);
     q.put<int32_t>(ix->spaced);
-    q.put<uint64_t>((uint64_t)ix->row3);
+    q.put<int32_t>((int32_t)kbase);
+    q.put<uint64_t>((uint64_t)(three ? ix->row3 : 0));
     q.put<uint64_t>((uint64_t)(two ? ix->row2 : 0));
     q.put<uint64_t>(ix->n_entries);
-    q.put_bytes(ix->score3, n3 * ix->row3 * 2);
-    q.put_bytes(ix->index3, n3 * ix->row3 * 4);
+    q.put_bytes(three ? ix->score3 : nullptr, three ? n3 * ix->row3 * 2 : 0);
+    q.put_bytes(three ? ix->index3 : nullptr, three ? n3 * ix->row3 * 4 : 0);
     q.put_bytes(two ? ix->score2 : nullptr, two ? n2 * ix->row2 * 2 : 0);
     q.put_bytes(two ? ix->index2 : nullptr, two ? n2 * ix->row2 * 4 : 0);
     q.put_bytes(ix->offsets, (table + 1) * 8);

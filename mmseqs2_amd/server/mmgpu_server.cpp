@@ -191,6 +191,7 @@ bool handle(Server &S, int fd, const WireHdr &h, Buf &in) {
             ix.kmer_size = in.get<int32_t>();
             ix.alphabet = in.get<int32_t>();
             ix.spaced = in.get<int32_t>();
+            ix.kmer_alphabet = in.get<int32_t>();
             ix.row3 = (size_t)in.get<uint64_t>();
             ix.row2 = (size_t)in.get<uint64_t>();
             ix.n_entries = in.get<uint64_t>();
@@ -213,8 +214,8 @@ bool handle(Server &S, int fd, const WireHdr &h, Buf &in) {
             size_t nm = 0;
             const uint8_t *um = in.get_bytes(&nm);
             if (in.bad) return reply_err(fd, h.op, MMGPU_ERR_ARG, "mmgpu_server: malformed LOAD_INDEX");
-            ix.score3 = s3.data();
-            ix.index3 = i3.data();
+            ix.score3 = s3.empty() ? nullptr : s3.data();
+            ix.index3 = i3.empty() ? nullptr : i3.data();
             ix.score2 = s2.empty() ? nullptr : s2.data();
             ix.index2 = i2.empty() ? nullptr : i2.data();
             ix.offsets = offs.data();

@@ -85,6 +85,8 @@ typedef struct {
     int nucleotide;             /* matchQuery's isNucleotide branch (QueryMatcher.cpp:147-177) */
     int kmer_score;             /* --diag-score 0 (diagonalScoring == false): the prefilter score of a target is the number of its
                                    double k-mer matches, no ungapped scoring (QueryMatcher.cpp:215-232, CacheFriendlyOperations.cpp:218-239) */
+    int index_base;             /* exact_kmer: base of the k-mer index if it is not alphabet - 1 (0 = alphabet - 1): the full alphabet
+                                   for an index over profile targets (Prefiltering.cpp:560-563) */
 } mmo_pf_params;
 
 typedef struct {

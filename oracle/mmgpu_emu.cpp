@@ -26,7 +26,7 @@ struct mmgpu_ctx {
     int alphabet;
     // prefilter index
     bool have_index;
-    int k, spaced, kalph;
+    int k, spaced, kalph, kbase;
     std::vector<int16_t> s3, s2;
     std::vector<uint32_t> i3, i2;
     std::vector<uint64_t> offsets;
@@ -312,6 +312,7 @@ int mmgpu_pf_load_index(mmgpu_ctx *c, const mmgpu_pf_index *ix) {
     c->k = ix->kmer_size;
     c->spaced = ix->spaced;
     c->kalph = ix->alphabet - 1;
+    c->kbase = ix->kmer_alphabet > 0 ? ix->kmer_alphabet : c->kalph;
     const size_t n3 = (size_t)c->kalph * c->kalph * c->kalph, n2 = (size_t)c->kalph * c->kalph;
     c->s3.clear();
     c->i3.clear();
@@ -334,7 +335,7 @@ int mmgpu_pf_load_index(mmgpu_ctx *c, const mmgpu_pf_index *ix) {
         }
     }
     size_t nk = 1;
-    for (int i = 0; i < c->k; i++) nk *= c->kalph;
+    for (int i = 0; i < c->k; i++) nk *= c->kbase;
     c->offsets.assign(ix->offsets, ix->offsets + nk + 1);
     c->ids.resize(ix->n_entries);
     c->pos.resize(ix->n_entries);
@@ -399,6 +400,7 @@ int mmgpu_pf_build_index(mmgpu_ctx *c, const mmgpu_pf_index *ix, const int16_t *
     full.entry_pos = pos.data();
     full.entries6 = NULL;
     full.n_entries = total;
+    full.kmer_alphabet = 0;      // (an index built here is over alphabet - 1 letters)
     return mmgpu_pf_load_index(c, &full);
 }
 
@@ -451,6 +453,7 @@ int mmgpu_pf_run(mmgpu_ctx *c, mmgpu_pf_batch_t *b) {
     P.max_hits = b->par.max_hits;
     P.min_diag_score = b->par.min_diag_score;
     P.exact_kmer = (int)b->par.exact_kmer;
+    P.index_base = c->kbase;
     P.nucleotide = (int)b->par.nucleotide;
     P.kmer_score = (int)b->par.kmer_score;
     const size_t cap = (size_t)std::min<uint64_t>(b->par.max_hits, c->n) + 1;

@@ -726,10 +726,12 @@ static int match_query_impl(const mmo_pf_params *P, const uint8_t *q, int qlen, 
         short kthr = (short)(t0 > 0 ? t0 : 0); /* :271 */
         size_t ns;
         if (P->exact_kmer) { /* takeOnlyBestKmer (:279-282): the window's own k-mer */
+            /* (the index's own base: kalph, or the full alphabet where the targets are profiles, Prefiltering.cpp:560-563) */
+            const uint64_t base = P->index_base > 0 ? (uint64_t)P->index_base : (uint64_t)kalph;
             uint64_t idx = 0, pw = 1;
             for (int p = 0; p < k; p++) {
                 idx += (uint64_t)w[p] * pw;
-                pw *= (uint64_t)kalph;
+                pw *= base;
             }
             sim[0] = idx;
             ns = 1;

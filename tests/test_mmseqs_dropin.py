@@ -329,6 +329,17 @@ def _profile_pipeline(w, emulate):
         log = run(MMGPU, ["align", "prof", "t", "pref_p", "paln_g%d" % i] + case + ["--threads", THREADS, "-v", "3"], w, emulate)
         assert "MMGPU: device" in log and "using the CPU path" not in log, log[-2000:]
         assert same(os.path.join(w, "paln_s%d" % i), os.path.join(w, "paln_g%d" % i)) == 30, case
+    # profile TARGETS: sequences against the profile database - the index holds the profiles' similar k-mers (host-built, handed
+    # over), the queries match exactly, the ungapped scores are taken on the consensus sequences
+    for k, extra in enumerate([[], ["--max-seqs", "7"]]):
+        run(STOCK, ["prefilter", "t", "prof", "tpref_s%d" % k, "-s", "5.7", "--threads", THREADS, "-v", "2"] + extra, w)
+        log = run(MMGPU, ["prefilter", "t", "prof", "tpref_g%d" % k, "-s", "5.7", "--threads", THREADS, "-v", "3"] + extra, w, emulate)
+        assert "MMGPU: device" in log and "using the CPU path" not in log, log[-2000:]
+        assert same(os.path.join(w, "tpref_s%d" % k), os.path.join(w, "tpref_g%d" % k)) == 1000
+    run(STOCK, ["search", "t", "prof", "tres_s", "ttmp_s", "-s", "5.7", "-a", "--threads", THREADS, "-v", "1"], w)
+    log = run(MMGPU, ["search", "t", "prof", "tres_g", "ttmp_g", "-s", "5.7", "-a", "--threads", THREADS, "-v", "3"], w, emulate)
+    assert "MMGPU: device" in log, log[-3000:]
+    assert same(os.path.join(w, "tres_s"), os.path.join(w, "tres_g")) == 1000
     # the whole profile search through the patched binary: both stages on the device
     run(STOCK, ["search", "prof", "t", "pres_s", "ptmp_s", "-s", "5.7", "-a", "--threads", THREADS, "-v", "1"], w)
     log = run(MMGPU, ["search", "prof", "t", "pres_g", "ptmp_g", "-s", "5.7", "-a", "--threads", THREADS, "-v", "3"], w, emulate)
