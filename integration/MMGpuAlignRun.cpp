@@ -228,10 +228,21 @@ void MMGpuAlignRun::plan(MMGpuAlignSession *s, size_t start, size_t bucketSize) 
                     q.profile = s->queryProfile[b].data();
                 }
             }
-            while (*data != '\0') {
-                Util::parseKey(data, buffer);
-                const DBKeyType dbKey = Util::fast_atoi<DBKeyType>(buffer);
-                data = Util::skipLine(data);
+            // the entry's target keys: parsed out of its lines (:345-347), or - fused search - as the prefilter hook of this process
+            // left them beside the text (MMGpuFusedSearch::capturedKeys; the reference's loop still walks the text for its take() calls)
+            const unsigned int *keptKeys = NULL;
+            size_t nKept = 0, nextKept = 0;
+            const bool kept = MMGpuFusedSearch::capturedKeys(al.prefdbr, id, &keptKeys, &nKept);
+            if (kept) q.targets.reserve(nKept);
+            while (kept ? nextKept < nKept : *data != '\0') {
+                DBKeyType dbKey;
+                if (kept) {
+                    dbKey = keptKeys[nextKept++];
+                } else {
+                    Util::parseKey(data, buffer);
+                    dbKey = Util::fast_atoi<DBKeyType>(buffer);
+                    data = Util::skipLine(data);
+                }
                 const size_t dbId = s->targetId(al.tdbr, dbKey);
                 if (dbId >= al.tdbr->getSize() || al.tdbr->getData(dbId, thread_idx) == NULL) break;      // (the loop reports it and ends the run)
                 const int dbLen = (int)(s->tOff[dbId + 1] - s->tOff[dbId]);

@@ -34,8 +34,12 @@ struct PrefStore {
     bool on;
     std::string db;                                  // the name the alignment module will ask for
     std::vector<std::vector<char> > perThread;       // serialised entries, appended by the prefilter hook's threads
-    struct Entry { unsigned int key; unsigned int thread; size_t offset, length; };
+    struct Entry { unsigned int key; unsigned int thread; size_t offset, length, keyOffset, keyCount; };
     std::vector<std::vector<Entry> > entries;
+    std::vector<std::vector<unsigned int> > perThreadKeys;      // the target keys of the entries, beside their text
+    std::vector<unsigned int> targetKeys;            // ... of all entries back to back, in the reader's id order
+    std::vector<size_t> targetKeyOffsets;            // [entries + 1]
+    const DBReader<unsigned int> *reader;            // the DBReader openCaptured handed out
     std::vector<char> data;                          // all entries back to back, NUL after each (DBWriter's layout), key order
     // overlapped run: the alignment module reads while the prefilter module still writes.  Every query has a slot of fixed size
     // (the longest list the prefilter can write for it), so the reader's index is known before the first entry exists.
@@ -47,7 +51,7 @@ struct PrefStore {
     std::vector<char> produced;                      // per id
     size_t producedCount;
     bool producerDone;                               // the prefilter module returned
-    PrefStore() : on(false), progressive(false), slotBytes(0), slots(NULL), mapped(0), producedCount(0), producerDone(false) {}
+    PrefStore() : on(false), reader(NULL), progressive(false), slotBytes(0), slots(NULL), mapped(0), producedCount(0), producerDone(false) {}
 };
 PrefStore store;
 
@@ -253,7 +257,9 @@ int MMGpuFusedSearch::run(Parameters &par, const std::string &query, const std::
         store.on = !onDisk;
         store.db = pref;
         store.perThread.clear();
+        store.perThreadKeys.clear();
         store.entries.clear();
+        store.reader = NULL;
         std::vector<std::string> a;
         a.push_back(query); a.push_back(target); a.push_back(pref);
         const std::vector<std::string> p = words(prefilterPar);
@@ -385,7 +391,8 @@ bool MMGpuFusedSearch::residentTargets(DBReader<unsigned int> *tdbr, void *gpu, 
     return true;
 }
 
-void MMGpuFusedSearch::capture(unsigned int queryKey, const char *data, size_t len, unsigned int thread) {
+void MMGpuFusedSearch::capture(unsigned int queryKey, const char *data, size_t len, unsigned int thread, const unsigned int *targetKeys,
+                               size_t nTargets) {
     if (store.progressive) {      // straight into the query's slot; MMGpuFusedSearch::publish() makes it visible to the reader
         const size_t id = std::lower_bound(store.keys.begin(), store.keys.end(), queryKey) - store.keys.begin();
         if (id >= store.keys.size() || store.keys[id] != queryKey || len + 1 > store.slotBytes) {
@@ -407,12 +414,24 @@ void MMGpuFusedSearch::capture(unsigned int queryKey, const char *data, size_t l
     e.length = len;
     buf.insert(buf.end(), data, data + len);
     buf.push_back('\0');
+    std::vector<unsigned int> &kb = store.perThreadKeys[thread];
+    e.keyOffset = kb.size();
+    e.keyCount = nTargets;
+    kb.insert(kb.end(), targetKeys, targetKeys + nTargets);
     store.entries[thread].push_back(e);
+}
+
+bool MMGpuFusedSearch::capturedKeys(const DBReader<unsigned int> *reader, size_t id, const unsigned int **keys, size_t *n) {
+    if (reader == NULL || reader != store.reader || store.progressive || id + 1 >= store.targetKeyOffsets.size()) return false;
+    *keys = store.targetKeys.data() + store.targetKeyOffsets[id];
+    *n = store.targetKeyOffsets[id + 1] - store.targetKeyOffsets[id];
+    return true;
 }
 
 void mmgpuFusedPrepareCapture(size_t threads) {
     if (store.perThread.size() < threads) {
         store.perThread.resize(threads);
+        store.perThreadKeys.resize(threads);
         store.entries.resize(threads);
     }
 }
@@ -452,11 +471,23 @@ DBReader<unsigned int> *MMGpuFusedSearch::openCaptured(const std::string &db, in
         maxLen = std::max(maxLen, index[i].length);
         off += all[i].length + 1;
     }
-    for (size_t t = 0; t < store.perThread.size(); t++) std::vector<char>().swap(store.perThread[t]);
+    // the same entries as lists of target keys (MMGpuAlignRun::plan builds its target lists from them instead of parsing the text)
+    store.targetKeyOffsets.assign(all.size() + 1, 0);
+    for (size_t i = 0; i < all.size(); i++) store.targetKeyOffsets[i + 1] = store.targetKeyOffsets[i] + all[i].keyCount;
+    store.targetKeys.resize(store.targetKeyOffsets[all.size()]);
+    for (size_t i = 0; i < all.size(); i++)
+        if (all[i].keyCount)
+            memcpy(store.targetKeys.data() + store.targetKeyOffsets[i], store.perThreadKeys[all[i].thread].data() + all[i].keyOffset,
+                   all[i].keyCount * sizeof(unsigned int));
+    for (size_t t = 0; t < store.perThread.size(); t++) {
+        std::vector<char>().swap(store.perThread[t]);
+        std::vector<unsigned int>().swap(store.perThreadKeys[t]);
+    }
     const unsigned int lastKey = all.empty() ? 0u : all.back().key;
     DBReader<unsigned int> *r = new DBReader<unsigned int>(index, all.size(), total, lastKey, Parameters::DBTYPE_PREFILTER_RES, maxLen, threads);
     r->open(DBReader<unsigned int>::NOSORT);
     r->setData(store.data.data(), total);
     r->setMode(DBReader<unsigned int>::USE_DATA);
+    store.reader = r;
     return r;
 }

@@ -31,9 +31,13 @@ public:
     // active(): a fused run is in progress and the prefilter database named `db` is the one to keep in memory
     static bool capturing(const std::string &db);
     // prefilter hook: the serialised hit list of one query (what DBWriter::writeData would receive), any thread
-    static void capture(unsigned int queryKey, const char *data, size_t len, unsigned int thread);
+    // (targetKeys / nTargets: the target keys of the entry's lines, in order - what a reader would parse out of them again)
+    static void capture(unsigned int queryKey, const char *data, size_t len, unsigned int thread, const unsigned int *targetKeys,
+                        size_t nTargets);
     // Alignment's constructor: a DBReader over the captured entries (NULL = none for this name: open the database on disk)
     static DBReader<unsigned int> *openCaptured(const std::string &db, int threads);
+    // alignment hook: the target keys of entry `id` of that reader without parsing its text (false: not this reader / no keys kept)
+    static bool capturedKeys(const DBReader<unsigned int> *reader, size_t id, const unsigned int **keys, size_t *n);
 
     // ---- the target set, resident once ----
     // With the masking on the device (mmgpu_pf_mask_targets) the prefilter module hands over the UNMASKED SequenceLookup - the very

@@ -412,6 +412,7 @@ bool MMGpuPrefilterRun::run(Prefiltering &p, DBWriter &tmpDbw, size_t dbFrom, si
             char buffer[128];
             std::string result;
             result.reserve(1000000);
+            std::vector<unsigned int> resultKeys;      // (fused search: the target keys of the entry's lines)
 #pragma omp for schedule(dynamic, 16) reduction(+ : kmersPerPos, resSize, dbMatches, doubleMatches, querySeqLenSum, diagonalOverflow)
             for (size_t b = 0; b < nq; b++) {
                 progress.updateProgress();
@@ -458,8 +459,12 @@ bool MMGpuPrefilterRun::run(Prefiltering &p, DBWriter &tmpDbw, size_t dbFrom, si
                     }
                     int len = QueryMatcher::prefilterHitToBuffer(buffer, *res);
                     result.append(buffer, len);
+                    if (capture) resultKeys.push_back(res->seqId);
                 }
-                if (capture) MMGpuFusedSearch::capture(qKey, result.c_str(), result.length(), thread_idx);
+                if (capture) {
+                    MMGpuFusedSearch::capture(qKey, result.c_str(), result.length(), thread_idx, resultKeys.data(), resultKeys.size());
+                    resultKeys.clear();
+                }
                 else tmpDbw.writeData(result.c_str(), result.length(), qKey, thread_idx);
                 result.clear();
                 if (resultSize != 0) {
