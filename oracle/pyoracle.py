@@ -381,7 +381,7 @@ class PfParams(ctypes.Structure):
                 ("kmer_thr", ctypes.c_int), ("offsets", c_p), ("ids", c_p), ("pos", c_p), ("tdata", c_p),
                 ("toff", c_p), ("n_targets", ctypes.c_uint32), ("ungapped_mat", c_p), ("bins", ctypes.c_uint32),
                 ("max_hits", ctypes.c_uint64), ("min_diag_score", ctypes.c_uint32), ("exact_kmer", ctypes.c_int),
-                ("nucleotide", ctypes.c_int), ("kmer_score", ctypes.c_int)]
+                ("nucleotide", ctypes.c_int), ("kmer_score", ctypes.c_int), ("index_base", ctypes.c_int)]
 
 
 class PfStats(ctypes.Structure):
