@@ -5,8 +5,8 @@
 // no X and whose self score reaches the k-mer threshold; every list sorted by seqId.
 //
 //   ix_target_kernel<false/true>  one workgroup per target: k-mer of every window into LDS (targets up to 4096
-//                                 windows; longer ones use a global scratch line), first-occurrence test by scanning
-//                                 the earlier windows (broadcast LDS reads), count / scatter with one atomic per entry
+//                                 windows; longer ones use a global scratch line), first-occurrence test through a hash
+//                                 set in LDS (k-mer -> smallest window), count / scatter with one atomic per entry
 //   (offsets = exclusive scan of the counts, pf_scan_kernel over 64 K chunks)
 //   ix_sort_short_kernel          one thread per k-mer list: lists of up to 16 entries are insertion-sorted into the
 //                                 final array, longer ones are queued
@@ -21,9 +21,25 @@ namespace {
 constexpr uint32_t IX_INVALID = 0xFFFFFFFFu;
 constexpr int IX_LDS_WINDOWS = 4096;
 
+// First occurrences through a hash set in LDS (round 5; before: every window scanned all earlier windows, O(L^2) per target -
+// 2.4 + 2.7 s for the 141 k pieces of <= 10 kb of a nucleotide database).  Slot = k-mer << 32 | smallest window holding it:
+// a 64-bit compare-and-swap claims an empty slot, a 64-bit minimum keeps the first window of a k-mer that is already there.
+// Targets with more distinct k-mers than half the table go through it in passes, each pass taking the k-mers of one hash
+// class; a pass whose probe sequence ever runs around the whole table (cannot happen below load 1) falls back to the scan.
+constexpr int IX_HASH_BITS = 12;
+constexpr uint32_t IX_HASH_SLOTS = 1u << IX_HASH_BITS;
+constexpr unsigned long long IX_EMPTY = ~0ull;
+
+__device__ __forceinline__ uint32_t ix_mix(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+
 template <bool FILL>
 __global__ __launch_bounds__(256) void ix_target_kernel(IxArgs A) {
     __shared__ uint32_t km[IX_LDS_WINDOWS];
+    __shared__ unsigned long long tab[IX_HASH_SLOTS];
+    __shared__ uint32_t s_full;
     const uint32_t t = blockIdx.x;
     const uint32_t len = A.t_len[t];
     const uint8_t *res = A.t_res + (size_t)A.t_off4[t] * 4;
@@ -45,19 +61,53 @@ __global__ __launch_bounds__(256) void ix_target_kernel(IxArgs A) {
         K[i] = idx;
     }
     __threadfence_block();
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < nwin; i += 256) {
-        const uint32_t k = K[i];
-        if (k == IX_INVALID) continue;
-        bool first = true;
-        for (uint32_t j = 0; j < i; j++)
-            if (K[j] == k) { first = false; break; }
-        if (!first) continue;
-        if (FILL) {
-            const uint32_t slot = atomicAdd(&A.counts[k], 1u);
-            A.entries[(size_t)A.offsets[k] + slot] = (uint64_t)t | ((uint64_t)i << 32);
-        } else {
-            atomicAdd(&A.counts[k], 1u);
+    const uint32_t n_pass = (nwin + IX_HASH_SLOTS / 2 - 1) / (IX_HASH_SLOTS / 2);
+    for (uint32_t pass = 0; pass < n_pass; pass++) {
+        __syncthreads();
+        for (uint32_t h = threadIdx.x; h < IX_HASH_SLOTS; h += 256) tab[h] = IX_EMPTY;
+        if (threadIdx.x == 0) s_full = 0;
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < nwin; i += 256) {
+            const uint32_t k = K[i];
+            if (k == IX_INVALID) continue;
+            const uint32_t hv = ix_mix(k);
+            if (n_pass > 1 && (hv >> IX_HASH_BITS) % n_pass != pass) continue;
+            const unsigned long long mine = ((unsigned long long)k << 32) | i;
+            uint32_t h = hv & (IX_HASH_SLOTS - 1), probes = 0;
+            for (;;) {
+                const unsigned long long cur = atomicCAS(&tab[h], IX_EMPTY, mine);      // (an atomic: no torn read of a slot in the making)
+                if (cur == IX_EMPTY) break;                       // claimed
+                if ((uint32_t)(cur >> 32) == k) {                 // the k-mer is there: keep its first window
+                    atomicMin(&tab[h], mine);
+                    break;
+                }
+                h = (h + 1) & (IX_HASH_SLOTS - 1);
+                if (++probes >= IX_HASH_SLOTS) { s_full = 1; break; }
+            }
+        }
+        __syncthreads();
+        const bool full = s_full != 0;      // workgroup-uniform
+        for (uint32_t i = threadIdx.x; i < nwin; i += 256) {
+            const uint32_t k = K[i];
+            if (k == IX_INVALID) continue;
+            const uint32_t hv = ix_mix(k);
+            if (n_pass > 1 && (hv >> IX_HASH_BITS) % n_pass != pass) continue;
+            bool first = true;
+            if (!full) {
+                uint32_t h = hv & (IX_HASH_SLOTS - 1);
+                while ((uint32_t)(tab[h] >> 32) != k) h = (h + 1) & (IX_HASH_SLOTS - 1);
+                first = (uint32_t)tab[h] == i;
+            } else {
+                for (uint32_t j = 0; j < i; j++)
+                    if (K[j] == k) { first = false; break; }
+            }
+            if (!first) continue;
+            if (FILL) {
+                const uint32_t slot = atomicAdd(&A.counts[k], 1u);
+                A.entries[(size_t)A.offsets[k] + slot] = (uint64_t)t | ((uint64_t)i << 32);
+            } else {
+                atomicAdd(&A.counts[k], 1u);
+            }
         }
     }
 }

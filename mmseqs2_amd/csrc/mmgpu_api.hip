@@ -490,13 +490,14 @@ struct mmgpu_sw_batch_t {
     DevBuf o_send, o_counter, o_recv, o_recv_counters, o_full, o_status;
 };
 
-// which kernel body serves a query of this length: 16 lanes x R rows per tile, R even, at most 16 * SW_MAX_R rows
-// per tile; longer queries are cut into equal tiles (multi-tile bodies).
+// which kernel body serves a query of this length: 16 lanes x R rows per tile (any R since round 5: the padding of a tile is
+// below 16 rows, it was below 32 with even R only), at most 16 * SW_MAX_R rows per tile; longer queries are cut into equal tiles
+// (multi-tile bodies).
 static void pick_class(uint32_t qlen, int *rows_per_lane, bool *multi) {
     constexpr uint32_t max_rows = 16u * (uint32_t)SW_MAX_R;
     const uint32_t n_tiles = (qlen + max_rows - 1) / max_rows;
     const uint32_t rows = (qlen + n_tiles - 1) / n_tiles;       // rows per tile before rounding
-    *rows_per_lane = (int)(2 * ((rows + 31) / 32));
+    *rows_per_lane = (int)std::max<uint32_t>(1u, (rows + 15) / 16);
     *multi = n_tiles > 1;
 }
 
@@ -647,7 +648,7 @@ static int sw_prepare_impl(mmgpu_ctx *c, const mmgpu_sw_params *par, const mmgpu
         int rpl; bool multi;
         pick_class(Q.qlen, &rpl, &multi);
         any_multi |= multi;
-        const uint32_t shape = (multi ? 16u : 0u) + (uint32_t)rpl / 2 - 1;   // [0,16): single tile R = 2..32, [16,32): multi-tile
+        const uint32_t shape = (multi ? 32u : 0u) + (uint32_t)rpl - 1;   // [0,32): single tile R = 1..32, [32,64): multi-tile
         const int grp = sw_shape_group(shape);
         b->group_lds[grp] = std::max(b->group_lds[grp], sw_lds_bytes(rpl, par->alphabet));
         // jobs are cut at multiples of one workgroup round (4 waves x 8 targets); for queries of several tiles a

@@ -40,7 +40,7 @@ struct SwJob {
     uint32_t query;
     uint32_t hit_begin;
     uint32_t hit_end;
-    uint32_t shape;   // low 8 bits: tile shape (rows per lane / 2 - 1, + 16 for multi-tile); high 24: multi-tile scratch slot
+    uint32_t shape;   // low 8 bits: tile shape (rows per lane - 1, + 32 for multi-tile); high 24: multi-tile scratch slot
 };
 
 // Everything a Smith-Waterman launch needs, device pointers only.
@@ -110,7 +110,7 @@ uint32_t sw_multi_resident_blocks(size_t lds_bytes, bool both_passes, int comput
 #define MMGPU_SW_MAX_R 28
 #endif
 constexpr int SW_MAX_R = MMGPU_SW_MAX_R;   // rows per lane of the largest tile (16 lanes x SW_MAX_R query rows); longer queries are cut into tiles
-static_assert(SW_MAX_R >= 16 && SW_MAX_R <= 32 && SW_MAX_R % 2 == 0, "multi-tile bodies exist for 8..32 rows per lane: a query cut into tiles gets at least SW_MAX_R / 2");
+static_assert(SW_MAX_R >= 16 && SW_MAX_R <= 32, "multi-tile bodies exist for 8..32 rows per lane: a query cut into tiles gets at least SW_MAX_R / 2");
 #ifndef MMGPU_SW_MIN_WAVES
 #define MMGPU_SW_MIN_WAVES 2
 #endif

@@ -15,7 +15,7 @@
 //    v_pk_max_i16/u16, v_pk_sub_u16 clamp): the low half of every register belongs to target A, the
 //    high half to target B, so one VALU lane-op advances two independent alignments.
 //  * a group of 16 lanes (one DPP row) owns one pair of targets; lane g owns R consecutive query rows
-//    (R = 2,4,..,32 -> 32..512 rows per tile) whose H/E state lives in registers for the whole scan.
+//    (R = 1,2,..,32 -> 16..512 rows per tile) whose H/E state lives in registers for the whole scan.
 //    Lanes run skewed by one column (anti-diagonal wavefront): at step s lane g works on column s - g.
 //    The hand-off lane g -> g+1 (H of the strip's last row, the F leaving it, and the two target
 //    letters) is three v_mov_b32_dpp row_shr:1 - no LDS, no bpermute.
@@ -334,23 +334,25 @@ __device__ __forceinline__ void sw_body(const SwLaunch &L, const SwJob job) {
                 unsigned hd = Hup_prev;
                 Hup_prev = Hup;
                 unsigned cmax = 0;
-                // R scores per target as R/2 packed dwords: ds_read_b128 for whole 16-byte slots, b64/b32 for the tail
-                unsigned pav[R / 2], pbv[R / 2];
+                // R scores per target as ND = ceil(R / 2) packed dwords (odd R: the high half of the last one is row padding
+                // nobody selects): ds_read_b128 for whole 16-byte slots, b64 / b32 for the tail
+                constexpr int ND = (R + 1) / 2;
+                unsigned pav[ND], pbv[ND];
 #pragma unroll
-                for (int k = 0; k < R / 8; ++k) {
+                for (int k = 0; k < ND / 4; ++k) {
                     const uint4 pa = rowA[k], pb = rowB[k];
                     pav[4 * k] = pa.x; pav[4 * k + 1] = pa.y; pav[4 * k + 2] = pa.z; pav[4 * k + 3] = pa.w;
                     pbv[4 * k] = pb.x; pbv[4 * k + 1] = pb.y; pbv[4 * k + 2] = pb.z; pbv[4 * k + 3] = pb.w;
                 }
-                if constexpr ((R / 2) % 4 >= 2) {
-                    const uint2 pa = *reinterpret_cast<const uint2 *>(rowA + R / 8);
-                    const uint2 pb = *reinterpret_cast<const uint2 *>(rowB + R / 8);
-                    pav[(R / 8) * 4] = pa.x; pav[(R / 8) * 4 + 1] = pa.y;
-                    pbv[(R / 8) * 4] = pb.x; pbv[(R / 8) * 4 + 1] = pb.y;
+                if constexpr (ND % 4 >= 2) {
+                    const uint2 pa = *reinterpret_cast<const uint2 *>(rowA + ND / 4);
+                    const uint2 pb = *reinterpret_cast<const uint2 *>(rowB + ND / 4);
+                    pav[(ND / 4) * 4] = pa.x; pav[(ND / 4) * 4 + 1] = pa.y;
+                    pbv[(ND / 4) * 4] = pb.x; pbv[(ND / 4) * 4 + 1] = pb.y;
                 }
-                if constexpr ((R / 2) % 2 == 1) {
-                    pav[R / 2 - 1] = reinterpret_cast<const unsigned *>(rowA)[R / 2 - 1];
-                    pbv[R / 2 - 1] = reinterpret_cast<const unsigned *>(rowB)[R / 2 - 1];
+                if constexpr (ND % 2 == 1) {
+                    pav[ND - 1] = reinterpret_cast<const unsigned *>(rowA)[ND - 1];
+                    pbv[ND - 1] = reinterpret_cast<const unsigned *>(rowB)[ND - 1];
                 }
                 // Phase 1 (no dependencies between rows): everything that only needs the previous column -
                 // diagonal + score, max with E, and E - ge.  Phase 2 is the serial F chain down the strip
@@ -525,6 +527,12 @@ __device__ __forceinline__ void sw_passes(const SwLaunch &L, const SwJob &job) {
 #ifndef MMGPU_SW_WAVES_G1B
 #define MMGPU_SW_WAVES_G1B 2
 #endif
+// (a query cut into tiles gets at least ceil(SW_MAX_R / 2) rows per lane: R = 8 .. 32 covers every SW_MAX_R the header allows)
+#define MMGPU_SW_MULTI_ALL                                                                                                          \
+    MMGPU_SW_MULTI(8) MMGPU_SW_MULTI(9) MMGPU_SW_MULTI(10) MMGPU_SW_MULTI(11) MMGPU_SW_MULTI(12) MMGPU_SW_MULTI(13) MMGPU_SW_MULTI(14) \
+    MMGPU_SW_MULTI(15) MMGPU_SW_MULTI(16) MMGPU_SW_MULTI(17) MMGPU_SW_MULTI(18) MMGPU_SW_MULTI(19) MMGPU_SW_MULTI(20) MMGPU_SW_MULTI(21) \
+    MMGPU_SW_MULTI(22) MMGPU_SW_MULTI(23) MMGPU_SW_MULTI(24) MMGPU_SW_MULTI(25) MMGPU_SW_MULTI(26) MMGPU_SW_MULTI(27) MMGPU_SW_MULTI(28) \
+    MMGPU_SW_MULTI(29) MMGPU_SW_MULTI(30) MMGPU_SW_MULTI(31) MMGPU_SW_MULTI(32)
 template <int G, bool BOTH>
 __global__ __launch_bounds__(WAVES * 64)
 __attribute__((amdgpu_waves_per_eu(G == 0 ? (BOTH ? MMGPU_SW_WAVES_G0B : MMGPU_SW_WAVES_G0F)
@@ -539,7 +547,7 @@ __attribute__((amdgpu_waves_per_eu(G == 0 ? (BOTH ? MMGPU_SW_WAVES_G0B : MMGPU_S
     // workgroups of this kernel can be resident at once, so the search always ends; a slot is only ever read after its
     // owner wrote it (tile t writes what tile t + 1 reads), so stale content is harmless.
     __shared__ uint32_t scratch_slot;
-    const bool claims = G == SW_GROUPS - 1 && (job.shape & 0xFFu) >= 16u;
+    const bool claims = G == SW_GROUPS - 1 && (job.shape & 0xFFu) >= 32u;
     if (claims) {
         if (threadIdx.x == 0) {
             uint32_t s = blockIdx.x % L.scratch_slots;
@@ -549,39 +557,42 @@ __attribute__((amdgpu_waves_per_eu(G == 0 ? (BOTH ? MMGPU_SW_WAVES_G0B : MMGPU_S
         __syncthreads();
         job.shape = (job.shape & 0xFFu) | (scratch_slot << 8);
     }
-#define MMGPU_SW_SINGLE(R) case (R) / 2 - 1: sw_passes<R, false, BOTH>(L, job); break;
-#define MMGPU_SW_MULTI(R) case 16 + (R) / 2 - 1: sw_passes<R, true, BOTH>(L, job); break;
+#define MMGPU_SW_SINGLE(R) case (R) - 1: sw_passes<R, false, BOTH>(L, job); break;
+#define MMGPU_SW_MULTI(R) case 32 + (R) - 1: sw_passes<R, true, BOTH>(L, job); break;
     if constexpr (G == 0) {
         switch (job.shape & 0xFFu) {   // workgroup-uniform
-            MMGPU_SW_SINGLE(2) MMGPU_SW_SINGLE(4) MMGPU_SW_SINGLE(6) MMGPU_SW_SINGLE(8) MMGPU_SW_SINGLE(10) MMGPU_SW_SINGLE(12)
+            MMGPU_SW_SINGLE(1) MMGPU_SW_SINGLE(2) MMGPU_SW_SINGLE(3) MMGPU_SW_SINGLE(4) MMGPU_SW_SINGLE(5) MMGPU_SW_SINGLE(6)
+            MMGPU_SW_SINGLE(7) MMGPU_SW_SINGLE(8) MMGPU_SW_SINGLE(9) MMGPU_SW_SINGLE(10) MMGPU_SW_SINGLE(11) MMGPU_SW_SINGLE(12)
             default: break;
         }
     } else if constexpr (G == 1) {
         switch (job.shape & 0xFFu) {
-            MMGPU_SW_SINGLE(14) MMGPU_SW_SINGLE(16) MMGPU_SW_SINGLE(18) MMGPU_SW_SINGLE(20) MMGPU_SW_SINGLE(22) MMGPU_SW_SINGLE(24)
+            MMGPU_SW_SINGLE(13) MMGPU_SW_SINGLE(14) MMGPU_SW_SINGLE(15) MMGPU_SW_SINGLE(16) MMGPU_SW_SINGLE(17) MMGPU_SW_SINGLE(18)
+            MMGPU_SW_SINGLE(19) MMGPU_SW_SINGLE(20) MMGPU_SW_SINGLE(21) MMGPU_SW_SINGLE(22) MMGPU_SW_SINGLE(23) MMGPU_SW_SINGLE(24)
             default: break;
         }
     } else if constexpr (SW_GROUPS == 4 && G == 2) {
         switch (job.shape & 0xFFu) {
-            MMGPU_SW_SINGLE(26) MMGPU_SW_SINGLE(28) MMGPU_SW_SINGLE(30) MMGPU_SW_SINGLE(32)
+            MMGPU_SW_SINGLE(25) MMGPU_SW_SINGLE(26) MMGPU_SW_SINGLE(27) MMGPU_SW_SINGLE(28) MMGPU_SW_SINGLE(29) MMGPU_SW_SINGLE(30)
+            MMGPU_SW_SINGLE(31) MMGPU_SW_SINGLE(32)
             default: break;
         }
     } else if constexpr (SW_GROUPS == 4) {
         switch (job.shape & 0xFFu) {
-            MMGPU_SW_MULTI(8) MMGPU_SW_MULTI(10) MMGPU_SW_MULTI(12) MMGPU_SW_MULTI(14) MMGPU_SW_MULTI(16) MMGPU_SW_MULTI(18) MMGPU_SW_MULTI(20) MMGPU_SW_MULTI(22) MMGPU_SW_MULTI(24) MMGPU_SW_MULTI(26)
-            MMGPU_SW_MULTI(28) MMGPU_SW_MULTI(30) MMGPU_SW_MULTI(32)
+            MMGPU_SW_MULTI_ALL
             default: break;
         }
     } else {
         switch (job.shape & 0xFFu) {
-            MMGPU_SW_SINGLE(26) MMGPU_SW_SINGLE(28) MMGPU_SW_SINGLE(30) MMGPU_SW_SINGLE(32)
-            MMGPU_SW_MULTI(8) MMGPU_SW_MULTI(10) MMGPU_SW_MULTI(12) MMGPU_SW_MULTI(14) MMGPU_SW_MULTI(16) MMGPU_SW_MULTI(18) MMGPU_SW_MULTI(20) MMGPU_SW_MULTI(22) MMGPU_SW_MULTI(24) MMGPU_SW_MULTI(26)
-            MMGPU_SW_MULTI(28) MMGPU_SW_MULTI(30) MMGPU_SW_MULTI(32)
+            MMGPU_SW_SINGLE(25) MMGPU_SW_SINGLE(26) MMGPU_SW_SINGLE(27) MMGPU_SW_SINGLE(28) MMGPU_SW_SINGLE(29) MMGPU_SW_SINGLE(30)
+            MMGPU_SW_SINGLE(31) MMGPU_SW_SINGLE(32)
+            MMGPU_SW_MULTI_ALL
             default: break;
         }
     }
 #undef MMGPU_SW_SINGLE
 #undef MMGPU_SW_MULTI
+#undef MMGPU_SW_MULTI_ALL
     if (claims) {
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -612,10 +623,12 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(SW_M
     }
     __syncthreads();
     job.shape = (job.shape & 0xFFu) | (scratch_slot << 8);
-#define MMGPU_SW_REV(R) case 16 + (R) / 2 - 1: if constexpr ((R) <= SW_MAX_R) sw_body<R, true, true>(L, job); break;
+#define MMGPU_SW_REV(R) case 32 + (R) - 1: if constexpr ((R) <= SW_MAX_R) sw_body<R, true, true>(L, job); break;
     switch (job.shape & 0xFFu) {
-        MMGPU_SW_REV(8) MMGPU_SW_REV(10) MMGPU_SW_REV(12) MMGPU_SW_REV(14) MMGPU_SW_REV(16) MMGPU_SW_REV(18) MMGPU_SW_REV(20)
-        MMGPU_SW_REV(22) MMGPU_SW_REV(24) MMGPU_SW_REV(26) MMGPU_SW_REV(28) MMGPU_SW_REV(30) MMGPU_SW_REV(32)
+        MMGPU_SW_REV(8) MMGPU_SW_REV(9) MMGPU_SW_REV(10) MMGPU_SW_REV(11) MMGPU_SW_REV(12) MMGPU_SW_REV(13) MMGPU_SW_REV(14) MMGPU_SW_REV(15)
+        MMGPU_SW_REV(16) MMGPU_SW_REV(17) MMGPU_SW_REV(18) MMGPU_SW_REV(19) MMGPU_SW_REV(20) MMGPU_SW_REV(21) MMGPU_SW_REV(22) MMGPU_SW_REV(23)
+        MMGPU_SW_REV(24) MMGPU_SW_REV(25) MMGPU_SW_REV(26) MMGPU_SW_REV(27) MMGPU_SW_REV(28) MMGPU_SW_REV(29) MMGPU_SW_REV(30) MMGPU_SW_REV(31)
+        MMGPU_SW_REV(32)
         default: break;
     }
 #undef MMGPU_SW_REV
@@ -721,8 +734,8 @@ hipError_t launch_sw_rev_multi(const SwLaunch &L, size_t lds_bytes, hipStream_t 
 }
 
 int sw_shape_group(uint32_t shape) {
-    if (shape >= 16) return SW_GROUPS - 1;
-    const int R = 2 * ((int)shape + 1);
+    if (shape >= 32) return SW_GROUPS - 1;
+    const int R = (int)shape + 1;
     return R <= 12 ? 0 : (R <= 24 ? 1 : 2);
 }
 

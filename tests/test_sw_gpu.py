@@ -48,9 +48,11 @@ def test_golden_vectors(gpu, oracle, matrices, sw_vectors):
         assert got == list(exp[i][:6]), (i, got, list(exp[i][:6]))
 
 
-@pytest.mark.parametrize("qlen", [1, 5, 33, 64, 97, 128, 129, 161, 200, 256, 275, 300, 340, 384, 385, 420, 470, 512])
+@pytest.mark.parametrize("qlen", [1, 5, 20, 33, 64, 70, 90, 97, 128, 129, 150, 161, 185, 200, 215, 235, 256, 265, 275, 300, 315, 330, 340,
+                                  360, 384, 385, 410, 420, 440, 448, 470, 512])
 def test_single_tile_classes_vs_oracle(gpu, oracle, matrices, qlen):
-    """One query per kernel instantiation boundary (R = 8/16/24/32) against 300 ragged targets incl. homologs."""
+    """One query per kernel instantiation (round 5: every R = 1 .. 28 rows per lane, tiles of 16 R rows; 470 and 512 are cut into
+    two tiles) against 300 ragged targets incl. homologs."""
     rng = np.random.default_rng(100 + qlen)
     mat = matrices["blosum62_sw"]
     q = rng.choice(20, size=qlen, p=wl.BACKGROUND).astype(np.uint8)
@@ -68,7 +70,7 @@ def test_single_tile_classes_vs_oracle(gpu, oracle, matrices, qlen):
     _check(out, oracle, mat, q, cb, tres, toff, ids, True, "qlen%d" % qlen)
 
 
-@pytest.mark.parametrize("qlen", [513, 600, 700, 830, 1025, 1400, 2500])
+@pytest.mark.parametrize("qlen", [449, 500, 513, 560, 600, 640, 670, 700, 730, 760, 790, 830, 880, 1025, 1400, 2500])
 def test_multi_tile_vs_oracle(gpu, oracle, matrices, qlen):
     rng = np.random.default_rng(200 + qlen)
     mat = matrices["blosum62_sw"]
