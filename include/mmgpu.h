@@ -345,7 +345,9 @@ int mmgpu_reserve(mmgpu_ctx *ctx, uint64_t bytes);
  * (replaced by mask_letter = X), the alignment kernels the original ones - one resident database serves both stages.
  * likelihood_ratios: alphabet x alphabet doubles, probMatrix[i][j] / (pBack[i] * pBack[j]) of the k-mer matrix (ProbabilityMatrix,
  * BaseMatrix.h:83-101); min_mask_prob: --mask-prob as the reference passes it (its float, widened).  The repeat probabilities
- * are computed as the reference's AVX2 + FMA build computes them (tantan_kernel.hip; tests/test_tantan.py). */
+ * are computed as the reference's AVX2 + FMA build computes them (tantan_kernel.hip; tests/test_tantan.py).
+ * likelihood_ratios == NULL takes the masked view back: the prefilter reads the residues as loaded again, the index over the
+ * masked ones is dropped (a resident database that serves a --mask 0 run after a --mask 1 run). */
 int mmgpu_pf_mask_targets(mmgpu_ctx *ctx, const double *likelihood_ratios, int alphabet, double min_mask_prob, int mask_letter,
                           uint64_t *n_masked /* may be NULL */);
 /* test hook: the prefilter's view of the resident targets (masked if mmgpu_pf_mask_targets ran) in the caller's layout */

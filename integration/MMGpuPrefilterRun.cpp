@@ -578,7 +578,11 @@ bool MMGpuPrefilterRun::run(Prefiltering &p, DBWriter &tmpDbw, size_t dbFrom, si
         delete cpuMatchers[i];
     }
     if (leaveTargets) {
-        if (!MMGpuFusedSearch::overlappedRun()) MMGpuFusedSearch::keepResidentTargets(p.sequenceLookup, p.tdbr, gpu);
+        // A query handed back to the CPU made ensureHostIndex replace the unmasked lookup by a host-masked copy (it clears
+        // mmgpuDeviceIndex): that copy is not what the device aligned against, so it is not handed over - the alignment module maps
+        // and uploads its own targets.  (An overlapped run handed the unmasked lookup over before the loop; ensureHostIndex leaves
+        // a lookup the fused search holds alone.)
+        if (!MMGpuFusedSearch::overlappedRun() && p.mmgpuDeviceIndex) MMGpuFusedSearch::keepResidentTargets(p.sequenceLookup, p.tdbr, gpu);
         if (MMGpuFusedSearch::holdsLookup(p.sequenceLookup)) p.sequenceLookup = NULL;
     }
     for (size_t g = 0; g < nGroups; g++) delete devices[g];

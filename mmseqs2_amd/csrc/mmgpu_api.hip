@@ -240,8 +240,17 @@ extern "C" int mmgpu_reserve(mmgpu_ctx *c, uint64_t bytes) {
 // reading the unmasked residues.
 extern "C" int mmgpu_pf_mask_targets(mmgpu_ctx *c, const double *likelihood_ratios, int alphabet, double min_mask_prob, int mask_letter,
                                      uint64_t *n_masked) {
-    if (!c || !likelihood_ratios) return fail(MMGPU_ERR_ARG, "mmgpu_pf_mask_targets: NULL argument");
+    if (!c) return fail(MMGPU_ERR_ARG, "mmgpu_pf_mask_targets: NULL argument");
     if (!c->db.res) return fail(MMGPU_ERR_STATE, "mmgpu_pf_mask_targets: no targets loaded");
+    if (!likelihood_ratios) {      // back to the unmasked view (--mask 0 after --mask 1 on a resident database): the masked copy and its index go
+        HIP_TRY(hipSetDevice(c->device));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        mmgpu::pf_index_free(c);
+        if (c->pf_masked_res) dev_free(c->pf_masked_res);
+        c->pf_masked_res = nullptr;
+        if (n_masked) *n_masked = 0;
+        return MMGPU_OK;
+    }
     if (alphabet != c->db.alphabet || alphabet > 32) return fail(MMGPU_ERR_ARG, "mmgpu_pf_mask_targets: alphabet differs from the loaded targets (or exceeds 32)");
     if (mask_letter < 0 || mask_letter >= alphabet) return fail(MMGPU_ERR_ARG, "mmgpu_pf_mask_targets: mask letter outside the alphabet");
     HIP_TRY(hipSetDevice(c->device));

@@ -165,6 +165,7 @@ struct PfKmerArgs {
     const uint32_t *i3;        // [n3][n3] ScoreMatrix::index
     const uint32_t *offsets;   // IndexTable::offsets, [kalph^k + 1]
     const uint32_t *nonempty;  // one bit per k-mer: list not empty (null: not used, the index is dense)
+    const uint4 *cofs;         // compact offset table (pf_kernels.hip: 32-byte blocks of 28 k-mers), null = look-ups read `offsets`
     const uint16_t *cum3;      // [n3][cum_w]: cum3[row][k] = number of entries of the row with score >= score_min + k
     uint32_t cum_w;
     int32_t score_min;
@@ -181,6 +182,7 @@ struct PfKmerArgs {
     const int16_t *prof_score;    // [n_pos][20]
     const uint8_t *prof_letter;   // [n_pos][20]
     int exact;                 // takeOnlyBestKmer: every window matches its own k-mer only (QueryMatcher.cpp:279-282)
+    const uint32_t *order;     // [n_pos] work order of the positions (launch_pf_order: grouped by the window's last 3-mer), null = as stored
     // count pass
     uint32_t *nsim;
     // emit pass
@@ -382,6 +384,9 @@ struct PfMergeArgs {
 
 hipError_t launch_pf_merge(const PfMergeArgs &A, hipStream_t s);
 hipError_t launch_pf_kmers(const PfKmerArgs &A, bool emit, hipStream_t s);
+hipError_t launch_pf_order(const PfKmerArgs &A, uint32_t *hist, uint32_t *order, hipStream_t s);
+size_t pf_cofs_bytes(uint64_t table);
+hipError_t launch_pf_cofs(const uint32_t *offsets, uint64_t table, void *cofs, hipStream_t s);
 hipError_t launch_pf_tiles(const uint32_t *q_tile_base, const uint32_t *q_ntiles, uint32_t nq, uint32_t *tile_q, uint32_t *tile_idx, hipStream_t s);
 hipError_t launch_pf_bitmap(const uint32_t *offsets, uint64_t table, uint32_t *bitmap, unsigned long long *nonempty, hipStream_t s);
 hipError_t launch_pf_scan(const uint32_t *in, const uint32_t *q_off, uint32_t nq, const uint64_t *base, uint32_t *out,

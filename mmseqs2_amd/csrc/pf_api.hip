@@ -24,6 +24,8 @@ struct PfIndex {
     uint32_t n3 = 0;
     uint64_t table = 0, n_entries = 0;
     DevBuf d_s3, d_i3, d_cum3, d_s2, d_i2, d_cum2, d_offsets, d_entries, d_mat;
+    DevBuf d_cofs;               // compact offset table (pf_cofs_kernel): what the similar-k-mer kernels look lists up in
+    bool use_cofs = false;
     DevBuf d_nonempty;           // one bit per k-mer (pf_bitmap_kernel), used when the index is sparse
     bool use_bitmap = false;
     double nonempty_frac = 1.0;  // k-mers with a list / all k-mers
@@ -57,6 +59,18 @@ static hipError_t pf_index_bitmap(mmgpu_ctx *c, PfIndex *P) {
     P->use_bitmap = (e && e[0] == '1') || P->nonempty_frac < 0.6;
     if (!P->use_bitmap) P->d_nonempty.release();
     return hipSuccess;
+}
+
+// the compact offset table of the similar-k-mer kernels (k = 6 and k = 7 with score tables; not for exact matching, whose one
+// look-up per window does not pay for it).  MMGPU_PF_COFS=0 keeps the look-ups on the full table (A/B runs).
+static hipError_t pf_index_cofs(mmgpu_ctx *c, PfIndex *P) {
+    P->use_cofs = false;
+    const char *e = getenv("MMGPU_PF_COFS");
+    if (!P->has_tables || P->n_entries >= (1ull << 31) || P->table > (1ull << 31) || (e && e[0] == '0')) return hipSuccess;
+    hipError_t rc = P->d_cofs.alloc(pf_cofs_bytes(P->table));
+    if (rc == hipSuccess) rc = launch_pf_cofs(P->d_offsets.as<uint32_t>(), P->table, P->d_cofs.p, c->stream);
+    if (rc == hipSuccess) P->use_cofs = true;
+    return rc;
 }
 
 void pf_index_free(mmgpu_ctx *c) {
@@ -393,6 +407,7 @@ extern "C" int mmgpu_pf_load_index(mmgpu_ctx *c, const mmgpu_pf_index *ix) {
     const int rc = pf_setup(c, ix, true, &P);
     if (rc != MMGPU_OK) return rc;
     HIP_TRY(pf_index_bitmap(c, P));
+    HIP_TRY(pf_index_cofs(c, P));
     c->pf = P;
     return MMGPU_OK;
 }
@@ -475,6 +490,7 @@ extern "C" int mmgpu_pf_build_index(mmgpu_ctx *c, const mmgpu_pf_index *ix, cons
     X_TRY(hipStreamSynchronize(s));
 #undef X_TRY
     HIP_TRY(pf_index_bitmap(c, P));
+    HIP_TRY(pf_index_cofs(c, P));
     c->pf = P;
     return MMGPU_OK;
 }
@@ -517,6 +533,8 @@ struct mmgpu_pf_batch_t {
     bool any_profile = false;
     // device: working set (grow-only, reused across runs)
     DevBuf d_nsim, d_qtot, d_qbase, d_list_base, d_pos_entries, d_peb, d_qentries;
+    DevBuf d_pos_order;                // [n_pos] work order of the similar-k-mer kernels (launch_pf_order), built by the first run
+    bool order_ready = false, has_order = false;
     DevBuf d_qtile_base, d_qntiles, d_bucket_count, d_bucket_off;
     DevBuf d_ovf_queries, d_qnseg, d_seg_start, d_qfinal, d_ovf_base, d_ovf_a, d_ovf_b, d_ovf_ocount, d_ovf_totals;
     DevBuf d_cand_small, d_cand_base, d_cand_count, d_cells, d_surv_count, d_hits, d_hit_count, d_diag_thr, d_qflags;
@@ -602,7 +620,7 @@ extern "C" int mmgpu_pf_prepare(mmgpu_ctx *c, const mmgpu_pf_params *par, const 
                       &b->d_bucket_count, &b->d_bucket_off, &b->d_ovf_queries, &b->d_qnseg, &b->d_seg_start, &b->d_qfinal, &b->d_ovf_base,
                       &b->d_ovf_a, &b->d_ovf_b, &b->d_ovf_ocount, &b->d_ovf_totals, &b->d_cand_small, &b->d_cand_base, &b->d_cand_count,
                       &b->d_cells, &b->d_surv_count, &b->d_hits, &b->d_hit_count, &b->d_diag_thr, &b->d_qflags, &b->d_redo, &b->x_recv_hits,
-                      &b->x_recv_counts, &b->x_hits, &b->x_counts, &b->x_flags, &b->x_ident})
+                      &b->x_recv_counts, &b->x_hits, &b->x_counts, &b->x_flags, &b->x_ident, &b->d_pos_order})
         d->bind(c->cache);
     b->par = *par;
     if (b->par.min_diag_score < 1) b->par.min_diag_score = 1;
@@ -807,6 +825,7 @@ extern "C" int mmgpu_pf_run(mmgpu_ctx *c, mmgpu_pf_batch_t *b) {
     K.i3 = P.d_i3.as<uint32_t>();
     K.offsets = P.d_offsets.as<uint32_t>();
     K.nonempty = P.use_bitmap ? P.d_nonempty.as<uint32_t>() : nullptr;
+    K.cofs = P.use_cofs ? P.d_cofs.as<uint4>() : nullptr;
     K.cum3 = P.d_cum3.as<uint16_t>();
     K.cum_w = P.cum_w;
     K.score_min = P.score_min;
@@ -817,6 +836,20 @@ extern "C" int mmgpu_pf_run(mmgpu_ctx *c, mmgpu_pf_batch_t *b) {
     K.cum2_w = P.cum2_w;
     K.score2_min = P.score2_min;
     K.nsim = b->d_nsim.as<uint32_t>();
+    // work order of the positions (pf_kernels.hip, "Work order of the similar-k-mer kernels"): built with the batch's first run
+    if (!b->order_ready && !K.exact) {
+        static const bool off = getenv("MMGPU_PF_NO_ORDER") != nullptr;      // A/B runs
+        if (!off) {
+            DevBuf d_hist;
+            d_hist.bind(c->cache);
+            HIP_TRY(d_hist.alloc(8 * ((size_t)K.n3 + 1) * 4));
+            HIP_TRY(b->d_pos_order.alloc((size_t)b->n_pos * 4));
+            HIP_TRY(launch_pf_order(K, d_hist.as<uint32_t>(), b->d_pos_order.as<uint32_t>(), s));
+            b->has_order = true;
+        }
+        b->order_ready = true;
+    }
+    K.order = b->has_order ? b->d_pos_order.as<uint32_t>() : nullptr;
     HIP_TRY(launch_pf_kmers(K, false, s));
     HIP_TRY(launch_pf_scan(b->d_nsim.as<uint32_t>(), b->d_qoff.as<uint32_t>(), nq, nullptr, nullptr, b->d_qtot.as<uint64_t>(), s));
     HIP_TRY(hipMemcpyAsync(b->q_lists.data(), b->d_qtot.p, nq * 8, hipMemcpyDeviceToHost, s));

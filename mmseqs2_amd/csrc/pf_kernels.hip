@@ -137,6 +137,124 @@ struct __attribute__((packed, aligned(4))) U32Quad {
     uint32_t a, b, c, d;
 };
 
+// XCD-aware order of a grid's workgroups.  The dispatcher places workgroup b on XCD b % 8 (observed, not a contract: a wrong guess
+// only costs speed); each XCD has its own 4 MB L2.  swz gives XCD x the x-th CONTIGUOUS eighth of the work items, in order, so
+// that items that are neighbours in the work order meet in one L2 (bijective for any grid size).
+__device__ __forceinline__ uint32_t xcd_contiguous(uint32_t bid, uint32_t nwg) {
+    const uint32_t xcd = bid & 7u, q = nwg >> 3, r = nwg & 7u;
+    return (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + (bid >> 3);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Work order of the similar-k-mer kernels (round 5).  A look-up into the 256 MB offset table that misses the L2 costs one of the
+// ~55 G memory-side requests per second the chip serves whatever the table size (profiles/r05_lookup_rate_probe.txt: 32 MB ... 1 GB
+// all alike, the Infinity Cache does not help; 2 MB, i.e. L2 hits, run at 250 G/s): 1.0e9 look-ups were the 18 ms of this stage.
+// The k-mers of a window are a + n3 * b with b from the similar 3-mers of the window's LAST three residues: every window with the
+// same last 3-mer reads the same ~11 stretches of 32 KB of the table.  So the windows of a batch are processed grouped by that
+// 3-mer, each group on one XCD: its stretches (~350 KB) stay in that XCD's L2 while the group's ~400 windows (10 000 queries)
+// read them ~20 times per line.  The output goes where it always went (list_base[gp]): only the order of the work changes.
+// Sort key: (group % 8, group) with group = the row of the 3-mer (k = 6: residues 3..5 of the window, k = 7: residues 4..6): XCD x
+// works through the x-th eighth of the sorted positions, i.e. (up to the uneven ends) the groups with group % 8 == x - whole groups
+// per L2, and every XCD a uniform sample of the 3-mers, so the shares are even (a contiguous range of rows is not: the similar
+// k-mers of a window depend on its residues).  Windows without k-mers (X, no window, profile positions) leave their wavefront at
+// once; they are dealt over the eight shares by position.
+__device__ __forceinline__ uint32_t pf_order_key(const PfKmerArgs &A, uint32_t gp) {
+    const uint32_t per = A.n3 + 1u;
+    if (A.q_thr[gp] < 0 || (A.q_kind && A.q_kind[gp])) return (gp & 7u) * per + A.n3;
+    const uint8_t *q = A.q_res + gp;
+    const int o = A.k == 7 ? 4 : 3;
+    const uint32_t g = q[A.pat[o]] + A.kalph * (q[A.pat[o + 1]] + A.kalph * q[A.pat[o + 2]]);
+    return (g & 7u) * per + g;
+}
+__global__ __launch_bounds__(256) void pf_order_count_kernel(PfKmerArgs A, uint32_t *hist) {
+    const uint32_t gp = blockIdx.x * 256u + threadIdx.x;
+    if (gp < A.n_pos) atomicAdd(&hist[pf_order_key(A, gp)], 1u);
+}
+__global__ __launch_bounds__(1024) void pf_order_scan_kernel(uint32_t *hist, uint32_t n) {      // exclusive scan in place, one workgroup
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry_s;
+    const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (uint32_t c = 0; c < n; c += 1024) {
+        const uint32_t i = c + threadIdx.x;
+        const uint32_t v = i < n ? hist[i] : 0u;
+        const uint32_t incl = wave_incl_scan(v);
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int w = 0; w < wave; w++) woff += wsum[w];
+        const uint32_t carry = carry_s;
+        if (i < n) hist[i] = carry + woff + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = carry + woff + incl;
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(256) void pf_order_fill_kernel(PfKmerArgs A, uint32_t *cursor, uint32_t *order) {
+    const uint32_t gp = blockIdx.x * 256u + threadIdx.x;
+    if (gp < A.n_pos) order[atomicAdd(&cursor[pf_order_key(A, gp)], 1u)] = gp;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Compact offset table (round 5): 32-byte blocks of 28 k-mers, { uint32 base = offsets[28 blk], 28 x uint8 list length }.  One
+// aligned 32-byte request answers (start, length); 1.14 bytes per k-mer instead of 4 - what matters is the footprint of a work
+// group's look-ups (above): a stretch of 8000 k-mers is 9 KB instead of 32 KB, ~100 stretches per 3-mer group fit an XCD's L2
+// several groups over.  A block with a list of 255 entries or more has bit 31 of its base set: its k-mers are answered by the full
+// table (databases of 2^31 index entries or more keep to the full table altogether, pf_api.hip).
+constexpr uint32_t PF_COFS_KMERS = 28;
+
+__global__ __launch_bounds__(256) void pf_cofs_kernel(const uint32_t *offsets, uint64_t table, uint4 *cofs) {
+    const uint64_t blk = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    const uint64_t k0 = blk * PF_COFS_KMERS;
+    if (k0 >= table) return;
+    uint32_t w[8];
+    const uint32_t base = offsets[k0];
+    bool big = false;
+    uint32_t prev = base;
+#pragma unroll
+    for (int d = 1; d < 8; d++) w[d] = 0;
+#pragma unroll
+    for (uint32_t r = 0; r < PF_COFS_KMERS; r++) {
+        uint32_t n = 0;
+        if (k0 + r < table) {
+            const uint32_t next = offsets[k0 + r + 1];
+            n = next - prev;
+            prev = next;
+        }
+        big |= n >= 255u;
+        w[1 + (r >> 2)] |= (n & 0xFFu) << ((r & 3u) * 8u);
+    }
+    w[0] = base | (big ? 0x80000000u : 0u);
+    cofs[2 * blk] = make_uint4(w[0], w[1], w[2], w[3]);
+    cofs[2 * blk + 1] = make_uint4(w[4], w[5], w[6], w[7]);
+}
+
+// (start, length) of the index list of `kmer`
+__device__ __forceinline__ void pf_lookup(const PfKmerArgs &A, uint32_t kmer, uint32_t &start, uint32_t &len) {
+    if (A.cofs) {
+        const uint32_t blk = kmer / PF_COFS_KMERS, r = kmer - blk * PF_COFS_KMERS;
+        const uint4 lo = A.cofs[2 * blk], hi = A.cofs[2 * blk + 1];
+        if (!(lo.x >> 31)) {
+            const uint32_t w[7] = {lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            uint32_t sum = 0, word = 0;
+#pragma unroll
+            for (int d = 0; d < 7; d++) {
+                const int rel = (int)r - 4 * d;      // bytes of this dword that lie before the k-mer's own
+                const uint32_t mask = rel >= 4 ? 0xFFFFFFFFu : (rel <= 0 ? 0u : (1u << (8 * rel)) - 1u);
+                sum = __builtin_amdgcn_sad_u8(w[d] & mask, 0u, sum);
+                word = (rel >= 0 && rel < 4) ? w[d] : word;
+            }
+            start = lo.x + sum;
+            len = (word >> ((r & 3u) * 8u)) & 0xFFu;
+            return;
+        }
+    }
+    const U32Pair o = *reinterpret_cast<const U32Pair *>(A.offsets + kmer);   // one 8-byte request
+    start = o.a;
+    len = o.b - o.a;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // a5 + first half of a6: one wavefront per query position.
 //   EMIT = false: nsim[gp] = number of similar k-mers of the window starting at gp
@@ -147,7 +265,12 @@ struct __attribute__((packed, aligned(4))) U32Quad {
 template <bool EMIT>
 __global__ __launch_bounds__(256) void pf_kmers_kernel(PfKmerArgs A) {
     const int lane = lane_id();
-    const uint32_t gp = blockIdx.x * 4u + (threadIdx.x >> 6);
+    uint32_t gp = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (A.order) {      // grouped by the window's last 3-mer, a contiguous share of the groups per XCD (above)
+        gp = xcd_contiguous(blockIdx.x, gridDim.x) * 4u + (threadIdx.x >> 6);
+        if (gp >= A.n_pos) return;
+        gp = A.order[gp];
+    }
     if (gp >= A.n_pos) return;
     if (A.q_kind && A.q_kind[gp]) return;   // position of a profile query: pf_kmers_prof_kernel
     const int thr = A.q_thr[gp];
@@ -198,11 +321,7 @@ __global__ __launch_bounds__(256) void pf_kmers_kernel(PfKmerArgs A) {
                 if (act) {
                     const uint32_t kmer = k_a + iB[x - ex_m] * n3;
                     // (sparse index: the bit table says whether the list is empty before a sector of the offset table is touched)
-                    if (!A.nonempty || ((A.nonempty[kmer >> 5] >> (kmer & 31u)) & 1u)) {
-                        const U32Pair o = *reinterpret_cast<const U32Pair *>(A.offsets + kmer);   // one 8-byte request
-                        start = o.a;
-                        len = o.b - o.a;
-                    }
+                    if (!A.nonempty || ((A.nonempty[kmer >> 5] >> (kmer & 31u)) & 1u)) pf_lookup(A, kmer, start, len);
                 }
                 const uint32_t li = wave_incl_scan(len);
                 if (act) {
@@ -232,7 +351,12 @@ __global__ __launch_bounds__(256) void pf_kmers_kernel(PfKmerArgs A) {
 template <bool EMIT>
 __global__ __launch_bounds__(256) void pf_kmers7_kernel(PfKmerArgs A) {
     const int lane = lane_id();
-    const uint32_t gp = blockIdx.x * 4u + (threadIdx.x >> 6);
+    uint32_t gp = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (A.order) {      // grouped by the window's last 3-mer, a contiguous share of the groups per XCD (above)
+        gp = xcd_contiguous(blockIdx.x, gridDim.x) * 4u + (threadIdx.x >> 6);
+        if (gp >= A.n_pos) return;
+        gp = A.order[gp];
+    }
     if (gp >= A.n_pos) return;
     if (A.q_kind && A.q_kind[gp]) return;
     const int thr = A.q_thr[gp];
@@ -306,9 +430,7 @@ __global__ __launch_bounds__(256) void pf_kmers7_kernel(PfKmerArgs A) {
                     uint32_t start = 0, len = 0;
                     if (act) {
                         const uint32_t kmer = k_e + iC[y - ex_e] * mult3;
-                        const U32Pair o = *reinterpret_cast<const U32Pair *>(A.offsets + kmer);
-                        start = o.a;
-                        len = o.b - o.a;
+                        pf_lookup(A, kmer, start, len);
                     }
                     const uint32_t li = wave_incl_scan(len);
                     if (act) {
@@ -1207,7 +1329,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MMGPU_PF_RE
     const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
     for (int k = (int)threadIdx.x; k < 32 * 32; k += 256) M.smat[k] = k < A.alphabet * A.alphabet ? A.mat[k] : (int8_t)0;
     __syncthreads();
-    const uint64_t bucket = (uint64_t)A.q_first * A.bins + (uint64_t)blockIdx.x * 4u + (uint32_t)wave;
+    // the buckets of one query read the same tiles (bin after bin of every tile): a contiguous run of queries per XCD would keep a
+    // tile's lines in one L2 instead of fetching them into all eight
+    // (measured, profiles/r05_exp_pf_order_and_swizzle.txt: 31.7 -> 35.6 ms - an eighth of the batch's queries per XCD is an
+    // uneven share of the work, the round-robin deal is not; kept as an experiment switch)
+#ifdef MMGPU_PF_REPLAY_SWZ
+    const uint32_t wg = xcd_contiguous(blockIdx.x, gridDim.x);
+#else
+    const uint32_t wg = blockIdx.x;
+#endif
+    const uint64_t bucket = (uint64_t)A.q_first * A.bins + (uint64_t)wg * 4u + (uint32_t)wave;
     if (bucket >= (uint64_t)(A.q_first + A.n_queries) * A.bins) return;
     if (!replay_bucket<true>(A, M, bucket) && lane == 0) A.redo_list[atomicAdd(A.redo_count, 1u)] = (uint32_t)bucket;
 }
@@ -2123,6 +2254,27 @@ __global__ __launch_bounds__(256) void pf_merge_kernel(PfMergeArgs A) {
 }
 
 }  // namespace
+
+// order[n_pos] = the positions sorted by pf_order_key; hist = 8 * (n3 + 1) counters of scratch (A needs q_res, q_thr, q_kind, pat, k, kalph, n3)
+hipError_t launch_pf_order(const PfKmerArgs &A, uint32_t *hist, uint32_t *order, hipStream_t s) {
+    if (A.n_pos == 0) return hipSuccess;
+    hipError_t e = hipMemsetAsync(hist, 0, 8 * ((size_t)A.n3 + 1) * 4, s);
+    if (e != hipSuccess) return e;
+    const dim3 g((A.n_pos + 255) / 256), b(256);
+    hipLaunchKernelGGL(pf_order_count_kernel, g, b, 0, s, A, hist);
+    hipLaunchKernelGGL(pf_order_scan_kernel, dim3(1), dim3(1024), 0, s, hist, 8u * (A.n3 + 1u));
+    hipLaunchKernelGGL(pf_order_fill_kernel, g, b, 0, s, A, hist, order);
+    return hipGetLastError();
+}
+
+// cofs: 2 x uint4 per block of PF_COFS_KMERS k-mers, ceil(table / PF_COFS_KMERS) blocks
+size_t pf_cofs_bytes(uint64_t table) { return (size_t)((table + PF_COFS_KMERS - 1) / PF_COFS_KMERS) * 32; }
+hipError_t launch_pf_cofs(const uint32_t *offsets, uint64_t table, void *cofs, hipStream_t s) {
+    if (table == 0) return hipSuccess;
+    const uint64_t blocks = (table + PF_COFS_KMERS - 1) / PF_COFS_KMERS;
+    hipLaunchKernelGGL(pf_cofs_kernel, dim3((unsigned)((blocks + 255) / 256)), dim3(256), 0, s, offsets, table, reinterpret_cast<uint4 *>(cofs));
+    return hipGetLastError();
+}
 
 hipError_t launch_pf_kmers(const PfKmerArgs &A, bool emit, hipStream_t s) {
     if (A.n_pos == 0) return hipSuccess;

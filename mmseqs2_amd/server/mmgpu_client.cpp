@@ -187,6 +187,7 @@ int mmgpu_pf_load_index(mmgpu_ctx *c, const mmgpu_pf_index *ix) {
     fp = fingerprint(ix->ungapped_mat, (size_t)ix->alphabet * ix->alphabet, fp);
     Buf q, r;
     q.put<uint64_t>(fp);
+    q.put<uint64_t>(c->mask_fp);      // the view this client's prefilter reads (0 = as loaded): the server drops another client's masked view
     int rc = call(c, OP_HAS_INDEX, q, &r);
     if (rc != MMGPU_OK) return rc;
     if (r.get<uint32_t>()) return MMGPU_OK;
@@ -224,6 +225,7 @@ int mmgpu_pf_build_index(mmgpu_ctx *c, const mmgpu_pf_index *ix, const int16_t *
     fp = fingerprint(ix->ungapped_mat, a2, fp);
     Buf q, r;
     q.put<uint64_t>(fp);
+    q.put<uint64_t>(c->mask_fp);      // the view this client's prefilter reads (0 = as loaded): the server drops another client's masked view
     int rc = call(c, OP_HAS_INDEX, q, &r);
     if (rc != MMGPU_OK) return rc;
     if (r.get<uint32_t>()) return MMGPU_OK;

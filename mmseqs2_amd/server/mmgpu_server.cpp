@@ -82,6 +82,19 @@ void drop_batches(Server &S) {
     S.sw.clear();
 }
 
+// The prefilter view of the connected client's slot: `want` = 0 (residues as loaded) or the tantan parameters the client masked
+// with.  A slot is found by its unmasked targets, so it may carry the masked view (and the index over it) of an earlier client.
+int sync_mask_view(Server &S, uint64_t want) {
+    Slot &sl = S.slots[S.cur];
+    if (!sl.have_targets || sl.mask_fp == want) return MMGPU_OK;
+    if (want != 0) return MMGPU_OK;      // (OP_MASK_TARGETS sets the view before an index is asked for; nothing to undo here)
+    drop_batches(S);
+    sl.have_index = false;
+    const int rc = mmgpu_pf_mask_targets(S.ctx, nullptr, 0, 0.0, 0, nullptr);
+    if (rc == MMGPU_OK) sl.mask_fp = 0;
+    return rc;
+}
+
 bool handle(Server &S, int fd, const WireHdr &h, Buf &in) {
     Buf out;
     S.st.requests++;
@@ -181,11 +194,23 @@ bool handle(Server &S, int fd, const WireHdr &h, Buf &in) {
         }
         case OP_HAS_INDEX: {
             const uint64_t fp = in.get<uint64_t>();
+            const uint64_t want_mask = in.get<uint64_t>();
+            if (in.bad) return reply_err(fd, h.op, MMGPU_ERR_ARG, "mmgpu_server: malformed HAS_INDEX");
+            {   // a slot found by its (unmasked) targets may still carry the masked view of an earlier client: a client that runs
+                // without masking (or never asked for this masking) gets the residues as loaded, and no index built over the masked ones
+                const int rc = sync_mask_view(S, want_mask);
+                if (rc != MMGPU_OK) return reply_err(fd, h.op, rc, mmgpu_last_error());
+            }
             out.put<uint32_t>(S.slots[S.cur].have_index && fp == S.slots[S.cur].index_fp ? 1u : 0u);
             return reply(fd, h.op, MMGPU_OK, out);
         }
         case OP_LOAD_INDEX: {
             const uint64_t fp = in.get<uint64_t>();
+            {
+                const uint64_t want_mask = in.get<uint64_t>();
+                const int rc = in.bad ? MMGPU_OK : sync_mask_view(S, want_mask);
+                if (rc != MMGPU_OK) return reply_err(fd, h.op, rc, mmgpu_last_error());
+            }
             mmgpu_pf_index ix;
             memset(&ix, 0, sizeof(ix));
             ix.kmer_size = in.get<int32_t>();
@@ -235,6 +260,11 @@ bool handle(Server &S, int fd, const WireHdr &h, Buf &in) {
         }
         case OP_BUILD_INDEX: {
             const uint64_t fp = in.get<uint64_t>();
+            {
+                const uint64_t want_mask = in.get<uint64_t>();
+                const int rc = in.bad ? MMGPU_OK : sync_mask_view(S, want_mask);
+                if (rc != MMGPU_OK) return reply_err(fd, h.op, rc, mmgpu_last_error());
+            }
             mmgpu_pf_index ix;
             memset(&ix, 0, sizeof(ix));
             ix.kmer_size = in.get<int32_t>();

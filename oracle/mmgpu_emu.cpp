@@ -366,6 +366,12 @@ int mmgpu_reserve(mmgpu_ctx *, uint64_t) { return 0; }
 // the device's tantan masking stand-in: the plain-C restatement (oracle/tantan_oracle.c)
 int mmgpu_pf_mask_targets(mmgpu_ctx *c, const double *lr, int alphabet, double min_mask_prob, int mask_letter, uint64_t *n_masked) {
     if (c->n == 0 && c->tres.empty()) return fail(MMGPU_ERR_STATE, "no targets");
+    if (!lr) {      // back to the unmasked view
+        c->pf_tres.clear();
+        c->have_index = false;
+        if (n_masked) *n_masked = 0;
+        return 0;
+    }
     c->pf_tres = c->tres;
     uint64_t masked = 0;
 #pragma omp parallel for schedule(dynamic, 64) reduction(+ : masked)

@@ -454,3 +454,57 @@ def test_replay_redo_list_on_the_overflow_path(gpu, monkeypatch):
         test_prefilter_overflow_path(gpu, 60000, 30000, 0.5)
     finally:
         monkeypatch.delenv("MMGPU_PF_EMIT_CAP", raising=False)
+
+
+def test_compact_offset_table_with_long_lists(gpu):
+    """The similar-k-mer kernels look lists up in the compact offset table (blocks of 28 k-mers: base + one-byte lengths); a
+    block holding a list of 255 entries or more is answered by the full table.  400 targets share a 14-residue motif (lists of
+    400), 250 another one (lists just below the limit): every stage against the oracle, with queries that contain the motifs,
+    and the same lists with the compact table switched off."""
+    import os
+    g = pc.golden()
+    rng = np.random.default_rng(31)
+    thr = int(g["kmer_thr"])
+    tl = wl.split(g["tres"], g["toff"])[:600]
+    motif_a = rng.choice(20, size=14, p=wl.BACKGROUND).astype(np.uint8)
+    motif_b = rng.choice(20, size=14, p=wl.BACKGROUND).astype(np.uint8)
+    for i in range(400):
+        t = rng.choice(20, size=int(rng.integers(60, 300)), p=wl.BACKGROUND).astype(np.uint8)
+        a = int(rng.integers(0, len(t) - 14))
+        t[a:a + 14] = motif_a
+        tl.append(t)
+    for i in range(250):
+        t = rng.choice(20, size=int(rng.integers(60, 300)), p=wl.BACKGROUND).astype(np.uint8)
+        a = int(rng.integers(0, len(t) - 14))
+        t[a:a + 14] = motif_b
+        tl.append(t)
+    tres, toff = wl.seqs_from_list(tl)
+    orc = pc.pf_oracle()
+    orc.build_index(tres, toff, thr)
+    tab = chk.load_case(gpu, g, tres, toff, thr)
+    lens = np.diff(tab["offsets"].astype(np.int64))
+    assert lens.max() >= 400 and np.any((lens >= 200) & (lens < 255))
+    from oracle.pyoracle import Oracle
+    swo = Oracle()
+    qs = []
+    for m in (motif_a, motif_b, np.concatenate([motif_a, motif_b])):
+        q = rng.choice(20, size=180, p=wl.BACKGROUND).astype(np.uint8)
+        q[50:50 + len(m)] = m
+        qs.append(dict(q=q, comp_bias=swo.comp_bias(g["vtml80_kmer16"], g["vtml80_pback"], q), identity_id=None))
+    qs += pc.golden_queries(g)[:4]
+    for qd in qs:
+        qd["identity_id"] = None
+    ok, rep = chk.check(gpu, orc, qs, 300, 2, stages=True, label="compact offsets / long lists")
+    assert ok, "\n".join(rep)
+    hits, counts, _, _ = gpu.pf_batch(qs, thr, max_hits=300, ref_bins=2)
+    os.environ["MMGPU_PF_COFS"] = "0"
+    try:
+        chk.load_case(gpu, g, tres, toff, thr)
+        hits0, counts0, _, _ = gpu.pf_batch(qs, thr, max_hits=300, ref_bins=2)
+    finally:
+        del os.environ["MMGPU_PF_COFS"]
+    assert np.array_equal(counts, counts0)
+    for qi in range(len(qs)):
+        n = int(counts[qi])
+        assert np.array_equal(hits[qi][:n], hits0[qi][:n])
+    chk.load_case(gpu, g, g["tres"], g["toff"], thr)
