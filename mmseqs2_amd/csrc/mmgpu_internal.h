@@ -182,6 +182,7 @@ struct PfKmerArgs {
     const int16_t *prof_score;    // [n_pos][20]
     const uint8_t *prof_letter;   // [n_pos][20]
     int exact;                 // takeOnlyBestKmer: every window matches its own k-mer only (QueryMatcher.cpp:279-282)
+    int order_mode;            // launch_pf_order: 1 = the default order, 2 / 3 = experiment variants (pf_order.hip)
     const uint32_t *order;     // [n_pos] work order of the positions (launch_pf_order: grouped by the window's last 3-mer), null = as stored
     // count pass
     uint32_t *nsim;
@@ -384,7 +385,6 @@ struct PfMergeArgs {
 
 hipError_t launch_pf_merge(const PfMergeArgs &A, hipStream_t s);
 hipError_t launch_pf_kmers(const PfKmerArgs &A, bool emit, hipStream_t s);
-hipError_t launch_pf_order(const PfKmerArgs &A, uint32_t *hist, uint32_t *order, hipStream_t s);
 size_t pf_cofs_bytes(uint64_t table);
 hipError_t launch_pf_cofs(const uint32_t *offsets, uint64_t table, void *cofs, hipStream_t s);
 hipError_t launch_pf_tiles(const uint32_t *q_tile_base, const uint32_t *q_ntiles, uint32_t nq, uint32_t *tile_q, uint32_t *tile_idx, hipStream_t s);
@@ -752,6 +752,8 @@ inline hipError_t upload(DevBuf &b, const std::vector<T> &v, hipStream_t s) {
 // nucleotide alignment step (nucl_kernel.hip; NuclLaunch is declared in nucl_core.h)
 hipError_t launch_nucl_align(const NuclLaunch &L, unsigned blocks, hipStream_t stream);     // 16 lanes per alignment
 hipError_t launch_nucl_align_wave(const NuclLaunch &L, unsigned blocks, hipStream_t stream);   // one wavefront per alignment, state in registers (nucl_wave.h): the default
+
+hipError_t launch_pf_order(const PfKmerArgs &A, uint32_t *order, const std::shared_ptr<BlockCache> &cache, hipStream_t s);   // pf_order.hip
 
 struct PfIndex;   // pf_api.hip
 

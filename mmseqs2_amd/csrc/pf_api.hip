@@ -836,15 +836,14 @@ extern "C" int mmgpu_pf_run(mmgpu_ctx *c, mmgpu_pf_batch_t *b) {
     K.cum2_w = P.cum2_w;
     K.score2_min = P.score2_min;
     K.nsim = b->d_nsim.as<uint32_t>();
-    // work order of the positions (pf_kernels.hip, "Work order of the similar-k-mer kernels"): built with the batch's first run
+    // work order of the positions (pf_order.hip): built with the batch's first run
     if (!b->order_ready && !K.exact) {
         static const bool off = getenv("MMGPU_PF_NO_ORDER") != nullptr;      // A/B runs
         if (!off) {
-            DevBuf d_hist;
-            d_hist.bind(c->cache);
-            HIP_TRY(d_hist.alloc(8 * ((size_t)K.n3 + 1) * 4));
+            K.order_mode = 1;
+            if (const char *m = getenv("MMGPU_PF_ORDER_MODE")) K.order_mode = atoi(m);
             HIP_TRY(b->d_pos_order.alloc((size_t)b->n_pos * 4));
-            HIP_TRY(launch_pf_order(K, d_hist.as<uint32_t>(), b->d_pos_order.as<uint32_t>(), s));
+            HIP_TRY(launch_pf_order(K, b->d_pos_order.as<uint32_t>(), c->cache, s));
             b->has_order = true;
         }
         b->order_ready = true;

@@ -35,6 +35,9 @@ namespace mmgpu {
 namespace {
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
+// __ballot() takes an int: a bool argument is materialised (v_cndmask 0 / 1) and compared with zero again - two VALU
+// instructions per ballot in kernels that are bound by instruction issue.  The builtin takes the condition as it is.
+__device__ __forceinline__ uint64_t ballot(bool b) { return __builtin_amdgcn_ballot_w64(b); }
 __device__ __forceinline__ uint64_t lanes_below(int lane) { return (1ull << lane) - 1ull; }
 
 // Inclusive scans over the wavefront with DPP moves (row shifts inside the 16-lane rows, then the row ends handed to the
@@ -82,21 +85,21 @@ __device__ __forceinline__ int seg_find(uint32_t start_mine, uint32_t x) {
 // Lanes of the wave whose `key` (low nbits) equals mine, among lanes with active == true.
 __device__ __forceinline__ uint64_t match_lanes(uint32_t key, int nbits, bool active) {
 #ifdef MMGPU_PF_OLD_MATCH
-    uint64_t m = __ballot(active);
+    uint64_t m = ballot(active);
     for (int b = 0; b < nbits; b++) {
         const bool bit = (key >> b) & 1u;
-        const uint64_t bal = __ballot(bit && active);
+        const uint64_t bal = ballot(bit && active);
         m &= bit ? bal : ~bal;
     }
     return m;
 #endif
-    const uint64_t act = __ballot(active);
+    const uint64_t act = ballot(active);
     uint32_t lo = (uint32_t)act, hi = (uint32_t)(act >> 32);
     for (int b = 0; b < nbits; b++) {
         // per bit: m &= (my bit set ? lanes with the bit : lanes without) = m & ~(ballot ^ my bit spread over the word):
         // one v_bfe_i32, one compare, one v_bitop3 per half
         const int ext = __builtin_amdgcn_sbfe((int)key, (unsigned)b, 1u);      // 0 or -1
-        const uint64_t bal = __ballot(ext != 0);
+        const uint64_t bal = ballot(ext != 0);
         lo = __builtin_amdgcn_bitop3_b32(lo, (uint32_t)bal, (uint32_t)ext, 0x90);
         hi = __builtin_amdgcn_bitop3_b32(hi, (uint32_t)(bal >> 32), (uint32_t)ext, 0x90);
     }
@@ -115,7 +118,7 @@ __device__ __forceinline__ uint32_t wave_search_le(const uint32_t *base, uint32_
         const uint32_t idx = lo + lane * step;
         const bool in = idx <= hi;
         const uint32_t v = in ? base[(size_t)idx * stride] : 0xFFFFFFFFu;
-        const uint64_t le = __ballot(in && v <= key);   // a prefix of the lanes
+        const uint64_t le = ballot(in && v <= key);   // a prefix of the lanes
         const uint32_t k = (uint32_t)__popcll(le) - 1u;
         lo += k * step;
         hi = min(hi, lo + step - 1u);
@@ -145,56 +148,7 @@ __device__ __forceinline__ uint32_t xcd_contiguous(uint32_t bid, uint32_t nwg) {
     return (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + (bid >> 3);
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// Work order of the similar-k-mer kernels (round 5).  A look-up into the 256 MB offset table that misses the L2 costs one of the
-// ~55 G memory-side requests per second the chip serves whatever the table size (profiles/r05_lookup_rate_probe.txt: 32 MB ... 1 GB
-// all alike, the Infinity Cache does not help; 2 MB, i.e. L2 hits, run at 250 G/s): 1.0e9 look-ups were the 18 ms of this stage.
-// The k-mers of a window are a + n3 * b with b from the similar 3-mers of the window's LAST three residues: every window with the
-// same last 3-mer reads the same ~11 stretches of 32 KB of the table.  So the windows of a batch are processed grouped by that
-// 3-mer, each group on one XCD: its stretches (~350 KB) stay in that XCD's L2 while the group's ~400 windows (10 000 queries)
-// read them ~20 times per line.  The output goes where it always went (list_base[gp]): only the order of the work changes.
-// Sort key: (group % 8, group) with group = the row of the 3-mer (k = 6: residues 3..5 of the window, k = 7: residues 4..6): XCD x
-// works through the x-th eighth of the sorted positions, i.e. (up to the uneven ends) the groups with group % 8 == x - whole groups
-// per L2, and every XCD a uniform sample of the 3-mers, so the shares are even (a contiguous range of rows is not: the similar
-// k-mers of a window depend on its residues).  Windows without k-mers (X, no window, profile positions) leave their wavefront at
-// once; they are dealt over the eight shares by position.
-__device__ __forceinline__ uint32_t pf_order_key(const PfKmerArgs &A, uint32_t gp) {
-    const uint32_t per = A.n3 + 1u;
-    if (A.q_thr[gp] < 0 || (A.q_kind && A.q_kind[gp])) return (gp & 7u) * per + A.n3;
-    const uint8_t *q = A.q_res + gp;
-    const int o = A.k == 7 ? 4 : 3;
-    const uint32_t g = q[A.pat[o]] + A.kalph * (q[A.pat[o + 1]] + A.kalph * q[A.pat[o + 2]]);
-    return (g & 7u) * per + g;
-}
-__global__ __launch_bounds__(256) void pf_order_count_kernel(PfKmerArgs A, uint32_t *hist) {
-    const uint32_t gp = blockIdx.x * 256u + threadIdx.x;
-    if (gp < A.n_pos) atomicAdd(&hist[pf_order_key(A, gp)], 1u);
-}
-__global__ __launch_bounds__(1024) void pf_order_scan_kernel(uint32_t *hist, uint32_t n) {      // exclusive scan in place, one workgroup
-    __shared__ uint32_t wsum[16];
-    __shared__ uint32_t carry_s;
-    const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
-    if (threadIdx.x == 0) carry_s = 0;
-    __syncthreads();
-    for (uint32_t c = 0; c < n; c += 1024) {
-        const uint32_t i = c + threadIdx.x;
-        const uint32_t v = i < n ? hist[i] : 0u;
-        const uint32_t incl = wave_incl_scan(v);
-        if (lane == 63) wsum[wave] = incl;
-        __syncthreads();
-        uint32_t woff = 0;
-        for (int w = 0; w < wave; w++) woff += wsum[w];
-        const uint32_t carry = carry_s;
-        if (i < n) hist[i] = carry + woff + incl - v;
-        __syncthreads();
-        if (threadIdx.x == 1023) carry_s = carry + woff + incl;
-        __syncthreads();
-    }
-}
-__global__ __launch_bounds__(256) void pf_order_fill_kernel(PfKmerArgs A, uint32_t *cursor, uint32_t *order) {
-    const uint32_t gp = blockIdx.x * 256u + threadIdx.x;
-    if (gp < A.n_pos) order[atomicAdd(&cursor[pf_order_key(A, gp)], 1u)] = gp;
-}
+// (the work order of the similar-k-mer kernels - PfKmerArgs::order - is built in pf_order.hip)
 
 // ---------------------------------------------------------------------------------------------------------
 // Compact offset table (round 5): 32-byte blocks of 28 k-mers, { uint32 base = offsets[28 blk], 28 x uint8 list length }.  One
@@ -266,7 +220,7 @@ template <bool EMIT>
 __global__ __launch_bounds__(256) void pf_kmers_kernel(PfKmerArgs A) {
     const int lane = lane_id();
     uint32_t gp = blockIdx.x * 4u + (threadIdx.x >> 6);
-    if (A.order) {      // grouped by the window's last 3-mer, a contiguous share of the groups per XCD (above)
+    if (A.order) {      // grouped by the window's last 3-mer, a contiguous share of the sorted positions per XCD (pf_order.hip)
         gp = xcd_contiguous(blockIdx.x, gridDim.x) * 4u + (threadIdx.x >> 6);
         if (gp >= A.n_pos) return;
         gp = A.order[gp];
@@ -352,7 +306,7 @@ template <bool EMIT>
 __global__ __launch_bounds__(256) void pf_kmers7_kernel(PfKmerArgs A) {
     const int lane = lane_id();
     uint32_t gp = blockIdx.x * 4u + (threadIdx.x >> 6);
-    if (A.order) {      // grouped by the window's last 3-mer, a contiguous share of the groups per XCD (above)
+    if (A.order) {      // grouped by the window's last 3-mer, a contiguous share of the sorted positions per XCD (pf_order.hip)
         gp = xcd_contiguous(blockIdx.x, gridDim.x) * 4u + (threadIdx.x >> 6);
         if (gp >= A.n_pos) return;
         gp = A.order[gp];
@@ -1010,7 +964,7 @@ __device__ __forceinline__ uint64_t score_chunk(const PfDedupArgs &A, const int8
         const uint64_t same = match_lanes(c.id >> bshift, 12, has);
         bool win = has;
         uint64_t m = same & ~(1ull << lane);
-        while (__ballot(m != 0)) {
+        while (ballot(m != 0)) {
             const int o = m ? __ffsll((long long)m) - 1 : lane;
             const uint32_t oc = __shfl(cnt, o);
             if (m) {
@@ -1019,7 +973,7 @@ __device__ __forceinline__ uint64_t score_chunk(const PfDedupArgs &A, const int8
             }
         }
         win = win && cnt >= A.min_diag_score;
-        const uint64_t wb = __ballot(win);
+        const uint64_t wb = ballot(win);
         if (wb) {
             PfCand *surv = A.surv + (A.cand_base[(uint64_t)q * A.bins] - A.cand_origin);
             uint32_t base = 0;
@@ -1053,6 +1007,16 @@ __device__ __forceinline__ uint64_t score_chunk(const PfDedupArgs &A, const int8
 #endif
 constexpr int PF_EMIT_TAB = 64;
 
+#ifdef MMGPU_PF_REPLAY_STATS
+// experiment build only (scripts/build_variant.sh ... -DMMGPU_PF_REPLAY_STATS): where the replay's rounds go.
+// [0] buckets [1] rounds [2] rounds with a target twice [3] lanes whose target occurs twice in their round [4] entries
+// [5] flagged entries [6] kept entries [7] rounds with an emitter looked up (again != 0) [8] tile chunks [9] candidates scored
+__device__ unsigned long long g_replay_stats[16];
+#define RSTAT(i, v) do { if (lane == 0) atomicAdd(&g_replay_stats[i], (unsigned long long)(v)); } while (0)
+#else
+#define RSTAT(i, v) do { } while (0)
+#endif
+
 template <bool COMPACT>
 struct ReplayLds {
     typename std::conditional<COMPACT, uint8_t, uint16_t>::type state[4][PF_IDS_PER_BIN];
@@ -1065,8 +1029,10 @@ struct ReplayLds {
 };
 
 // returns false when the bucket has to be redone with the full state (COMPACT only)
-template <bool COMPACT>
-__device__ __forceinline__ bool replay_bucket(const PfDedupArgs &A, ReplayLds<COMPACT> &M, uint64_t bucket) {
+// SEGS: the query is on the reference's overflow path (databaseHits flushes, nseg > 0).  The ordinary query's round is straight
+// line code: no boundary compare, no loop over the pieces of a round (round 5: the loop's exec-mask bookkeeping sat in every round).
+template <bool COMPACT, bool SEGS>
+__device__ __forceinline__ bool replay_bucket_impl(const PfDedupArgs &A, ReplayLds<COMPACT> &M, uint64_t bucket) {
     const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
     const uint32_t B = A.bins;
     const uint32_t q = (uint32_t)(bucket / B), bin = (uint32_t)(bucket % B);
@@ -1075,6 +1041,7 @@ __device__ __forceinline__ bool replay_bucket(const PfDedupArgs &A, ReplayLds<CO
         if (lane == 0) A.cand_count[bucket] = 0;
         return true;
     }
+    RSTAT(0, 1);
     const uint32_t tb = A.q_tile_base[q];
     auto *S = M.state[wave];
     uint32_t *E = M.emit[wave];
@@ -1099,9 +1066,9 @@ __device__ __forceinline__ bool replay_bucket(const PfDedupArgs &A, ReplayLds<CO
 
     uint32_t ncand = 0;
     const uint64_t below = lanes_below(lane);
-    const uint32_t nseg = A.q_nseg ? A.q_nseg[q] : 0u;
-    const uint32_t *segs = A.seg_start ? A.seg_start + (size_t)q * (PF_MAX_SEG + 2) : nullptr;
-    uint32_t cur_seg = 0, next_boundary = nseg ? segs[1] : 0xFFFFFFFFu;
+    const uint32_t nseg = SEGS ? A.q_nseg[q] : 0u;
+    const uint32_t *segs = SEGS ? A.seg_start + (size_t)q * (PF_MAX_SEG + 2) : nullptr;
+    uint32_t cur_seg = 0, next_boundary = SEGS ? segs[1] : 0xFFFFFFFFu;
     for (uint32_t t0 = 0; t0 < ntiles; t0 += 64) {
         const uint32_t tl = t0 + (uint32_t)lane;
         uint32_t o0 = 0, n = 0;
@@ -1113,6 +1080,8 @@ __device__ __forceinline__ bool replay_bucket(const PfDedupArgs &A, ReplayLds<CO
         const uint32_t incl = wave_incl_scan(n);
         const uint32_t total = __shfl(incl, 63);
         const uint32_t excl = incl - n;
+        RSTAT(8, 1);
+        RSTAT(4, total);
         // software pipeline: the entries of the next MMGPU_PF_REPLAY_PD rounds are in flight while a round is processed
         // (one round ahead is enough: deeper pipelines measured the same)
         uint64_t e_q[MMGPU_PF_REPLAY_PD];
@@ -1171,10 +1140,10 @@ __device__ __forceinline__ bool replay_bucket(const PfDedupArgs &A, ReplayLds<CO
             // Overflow path (nseg > 0): the reference flushes databaseHits at segment boundaries and starts the
             // double-diagonal state from scratch (QueryMatcher.cpp:310-346), so a round that straddles a boundary is
             // processed in pieces with the tables cleared in between.
-            uint64_t todo = __ballot(act);
+            uint64_t todo = SEGS ? ballot(act) : 1ull;
             while (todo) {
-                const bool now = act && ((todo >> lane) & 1ull) && arr < next_boundary;
-                if (__ballot(now)) {
+                const bool now = SEGS ? (act && ((todo >> lane) & 1ull) && arr < next_boundary) : act;
+                if (!SEGS || ballot(now)) {
                     uint32_t st = 0, em = 0;
                     if (now) {
                         st = S[key];
@@ -1186,7 +1155,10 @@ __device__ __forceinline__ bool replay_bucket(const PfDedupArgs &A, ReplayLds<CO
                     // (matching the keys of all lanes, predecessor / run searches) is skipped.
                     bool twice = false;
                     if (now) twice = (atomicOr(&Dup[key >> 5], 1u << (key & 31u)) >> (key & 31u)) & 1u;
-                    const bool uniq = __ballot(twice) == 0;
+                    const bool uniq = ballot(twice) == 0;
+                    RSTAT(1, 1);
+                    RSTAT(2, uniq ? 0 : 1);
+                    RSTAT(3, __popcll(ballot(twice)));
                     if (now) atomicAnd(&Dup[key >> 5], ~(1u << (key & 31u)));
                     bool flag, has_fm, has_fbelow, group_last;
                     uint32_t d_fpl, d_fhi;
@@ -1200,7 +1172,20 @@ __device__ __forceinline__ bool replay_bucket(const PfDedupArgs &A, ReplayLds<CO
                         d_fhi = d8;
                         group_hi = lane;
                     } else {
+                        // The lanes of my target.  Every target that occurs more than once has a lane that found its bit set
+                        // (`twice`): one pass per such target - a handful per round - instead of matching the 12 key bits of
+                        // all lanes against each other (72 instructions; the replay is bound by instruction issue).
+#ifdef MMGPU_PF_REPLAY_MATCH12
                         const uint64_t same = match_lanes(key, 12, now);
+#else
+                        uint64_t same = 1ull << lane;
+                        for (uint64_t dm = ballot(twice); dm != 0;) {
+                            const uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)key, __ffsll((long long)dm) - 1);
+                            const uint64_t g = ballot(now && key == k);
+                            if (key == k) same = g;
+                            dm &= ~g;
+                        }
+#endif
                         // stage 1: does my diagonal byte equal the previous entry's of this target?
                         const uint64_t pm = same & below;
                         const int pl = pm ? highest_lane(pm) : lane;
@@ -1208,7 +1193,7 @@ __device__ __forceinline__ bool replay_bucket(const PfDedupArgs &A, ReplayLds<CO
                         const uint32_t prevd = pm ? d_pl : (st & 0xFFu);
                         flag = now && d8 == prevd;
                         // stage 2: run-length de-duplication over the flagged entries of this target
-                        const uint64_t fl = __ballot(flag);
+                        const uint64_t fl = ballot(flag);
                         const uint64_t fm = same & fl;
                         const uint64_t fbelow = fm & below;
                         const int fpl = fbelow ? highest_lane(fbelow) : lane;
@@ -1225,7 +1210,8 @@ __device__ __forceinline__ bool replay_bucket(const PfDedupArgs &A, ReplayLds<CO
                     if (COMPACT) {
                         // targets of this round that emit again: their group's last lane looks the table entry up, the
                         // group's first flagged lane (the one the byte decides for) reads it from there
-                        const uint64_t again = __ballot(group_last && has_fm && em != 0u);
+                        const uint64_t again = ballot(group_last && has_fm && em != 0u);
+                        RSTAT(7, again ? 1 : 0);
                         uint32_t lb_mine = 0;
                         if (again) {
                             asm volatile("" ::: "memory");      // the table is written by other lanes
@@ -1235,7 +1221,7 @@ __device__ __forceinline__ bool replay_bucket(const PfDedupArgs &A, ReplayLds<CO
                                 const int l = __ffsll((long long)w) - 1;
                                 w &= w - 1;
                                 const uint32_t k = (uint32_t)__shfl((int)key, l);
-                                const uint64_t hit = __ballot((uint32_t)lane < nem && (tv >> 8) == k);
+                                const uint64_t hit = ballot((uint32_t)lane < nem && (tv >> 8) == k);
                                 const int idx = hit ? __ffsll((long long)hit) - 1 : 0;     // an emitter is in the table
                                 const uint32_t v = (uint32_t)__shfl((int)tv, idx);
                                 if (lane == l) {
@@ -1252,7 +1238,7 @@ __device__ __forceinline__ bool replay_bucket(const PfDedupArgs &A, ReplayLds<CO
                     // state update by the last lane of every target group
                     if (COMPACT) {
                         const bool fresh = group_last && has_fm && em == 0u;
-                        const uint64_t fb = __ballot(fresh);
+                        const uint64_t fb = ballot(fresh);
                         if (nem + (uint32_t)__popcll(fb) > emit_cap) return false;      // wave-uniform
                         if (group_last) {
                             S[key] = (uint8_t)d8;
@@ -1275,7 +1261,9 @@ __device__ __forceinline__ bool replay_bucket(const PfDedupArgs &A, ReplayLds<CO
                         }
                         S[key] = (uint16_t)ns;
                     }
-                    const uint64_t kb = __ballot(keep);
+                    const uint64_t kb = ballot(keep);
+                    RSTAT(5, __popcll(ballot(flag)));
+                    RSTAT(6, __popcll(kb));
                     if (keep) {
                         PfCand c;
                         c.id = id;
@@ -1293,7 +1281,8 @@ __device__ __forceinline__ bool replay_bucket(const PfDedupArgs &A, ReplayLds<CO
                     }
                     ncand += (uint32_t)__popcll(kb);
                 }
-                todo &= ~__ballot(now);
+                if (!SEGS) break;
+                todo &= ~ballot(now);
                 if (todo) {   // the remaining entries belong to the next segment: fresh state
                     clear_state();
                     nem = 0;
@@ -1322,6 +1311,12 @@ __device__ __forceinline__ bool replay_bucket(const PfDedupArgs &A, ReplayLds<CO
         }
     }
     return true;
+}
+
+template <bool COMPACT>
+__device__ __forceinline__ bool replay_bucket(const PfDedupArgs &A, ReplayLds<COMPACT> &M, uint64_t bucket) {
+    if (A.q_nseg && A.q_nseg[(uint32_t)(bucket / A.bins)]) return replay_bucket_impl<COMPACT, true>(A, M, bucket);      // wave-uniform
+    return replay_bucket_impl<COMPACT, false>(A, M, bucket);
 }
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MMGPU_PF_REPLAY_EU))) void pf_replay_kernel(PfDedupArgs A) {
@@ -1446,7 +1441,7 @@ __global__ __launch_bounds__(256) void pf_count_kernel(PfDedupArgs A) {
             const uint32_t d_pl = __shfl(d8, pl);
             const uint32_t prevd = pm ? d_pl : (st & 0xFFu);
             const bool flag = now && d8 == prevd;
-            const uint64_t fl = __ballot(flag);
+            const uint64_t fl = ballot(flag);
             const uint64_t fm = same & fl;
             // the last lane of a target's group writes the state: its byte, the count so far + the group's flagged entries
             if (now && (same & ~below & ~(1ull << lane)) == 0) {
@@ -1456,7 +1451,7 @@ __global__ __launch_bounds__(256) void pf_count_kernel(PfDedupArgs A) {
             // the target's element: its first flagged entry
             const bool keep = flag && (fm & below) == 0 && em == 0u;
             if (keep) atomicOr(&E[key >> 5], 1u << (key & 31u));
-            const uint64_t kb = __ballot(keep);
+            const uint64_t kb = ballot(keep);
             if (keep) {
                 PfCand c;
                 c.id = id;
@@ -1489,7 +1484,7 @@ __global__ __launch_bounds__(256) void pf_count_kernel(PfDedupArgs A) {
             total_count += c.score;
             win = c.score >= A.min_diag_score;
         }
-        const uint64_t wb = __ballot(win);
+        const uint64_t wb = ballot(win);
         if (wb) {
             uint32_t base = 0;
             if (lane == 0) base = atomicAdd(&A.surv_count[q], (uint32_t)__popcll(wb));
@@ -1542,7 +1537,7 @@ __global__ __launch_bounds__(256) void pf_keepmax_kernel(PfDedupArgs A) {
             const uint32_t k2 = (cnt << 24) | (0xFFFFFFu - min(ci, 0xFFFFFEu));
             win = S[c.id >> bshift] == k2 && cnt >= A.min_diag_score;
         }
-        const uint64_t wb = __ballot(win);
+        const uint64_t wb = ballot(win);
         if (wb) {
             uint32_t base = 0;
             if (lane == 0) base = atomicAdd(&A.surv_count[q], (uint32_t)__popcll(wb));
@@ -1601,7 +1596,7 @@ __global__ __launch_bounds__(128) void pf_keepmax_nucl_kernel(PfDedupArgs A) {
             atomicMax(&K[c.id >> bshift], key_of(c, ci));
             sat = c.score >= 255u;
         }
-        const uint64_t sb = __ballot(sat);
+        const uint64_t sb = ballot(sat);
         if (sb && A.q_nsat) {
             uint32_t base = 0;
             if (lane == 0) base = atomicAdd(&A.q_nsat[q], (uint32_t)__popcll(sb));
@@ -1634,7 +1629,7 @@ __global__ __launch_bounds__(128) void pf_keepmax_nucl_kernel(PfDedupArgs A) {
                 if (w.diag != c.diag && A.q_flags) atomicOr(&A.q_flags[q], 4u);      // decided with the query's saturated total (fetch)
             }
         }
-        const uint64_t wb = __ballot(win);
+        const uint64_t wb = ballot(win);
         if (wb) {
             uint32_t base = 0;
             if (lane == 0) base = atomicAdd(&A.surv_count[q], (uint32_t)__popcll(wb));
@@ -1673,7 +1668,7 @@ __global__ __launch_bounds__(64) void pf_segments_kernel(PfSegArgs A) {
                 const PfList r = A.lists[idx];
                 ge = (uint64_t)A.pos_entry_base[r.pos] + r.lprefix + r.len >= limit;
             }
-            const uint64_t m = __ballot(ge);                  // a suffix of the lanes
+            const uint64_t m = ballot(ge);                  // a suffix of the lanes
             const uint32_t first = m ? (uint32_t)(__ffsll((long long)m) - 1) : 64u;
             // the answer lies in (lo + (first-1)*step, lo + first*step]
             const uint32_t nhi = min(hi, lo + first * step);
@@ -1749,8 +1744,8 @@ __global__ __launch_bounds__(256) void pf_overflow_kernel(PfOvfArgs A) {
         const uint32_t ci = c0 + (uint32_t)lane;
         uint32_t tag = 0xFFFFu;
         if (ci < ncand) tag = cand_slot(D, bucket, ci)->pad;
-        c_lo += (uint32_t)__popcll(__ballot(ci < ncand && tag < step - 1));
-        c_hi += (uint32_t)__popcll(__ballot(ci < ncand && tag <= step - 1));
+        c_lo += (uint32_t)__popcll(ballot(ci < ncand && tag < step - 1));
+        c_hi += (uint32_t)__popcll(ballot(ci < ncand && tag <= step - 1));
     }
     const uint32_t nC = c_hi - c_lo;
     const uint32_t prev_total = step > 1 ? totals[step - 1] : 0u;
@@ -1790,7 +1785,7 @@ __global__ __launch_bounds__(256) void pf_overflow_kernel(PfOvfArgs A) {
             if (act) prev = pm ? d_pl : tab[key];
             const bool keep = act && (e.score != 0 || prev != d8);
             if (act && (same & ~below & ~(1ull << lane)) == 0) tab[key] = d8;
-            const uint64_t kb = __ballot(keep);
+            const uint64_t kb = ballot(keep);
             if (keep) {
                 e.ord = -e.ord;
                 S[m + (uint32_t)__popcll(kb & below)] = e;
@@ -1826,7 +1821,7 @@ __global__ __launch_bounds__(256) void pf_overflow_kernel(PfOvfArgs A) {
             if (act) prev = pm ? d_pl : tab[key];
             const bool keep = act && prev != d8;
             if (act && (same & ~below & ~(1ull << lane)) == 0) tab[key] = d8;
-            const uint64_t kb = __ballot(keep);
+            const uint64_t kb = ballot(keep);
             if (keep) S[m + (uint32_t)__popcll(kb & below)] = e;
             m += (uint32_t)__popcll(kb);
         }
@@ -1896,7 +1891,7 @@ __global__ __launch_bounds__(256) void pf_overflow_kernel(PfOvfArgs A) {
             keep = idx == first || (cnt == 0 && idx > first);
             if (final_step) keep = keep && cnt >= D.min_diag_score;
         }
-        const uint64_t kb = __ballot(keep);
+        const uint64_t kb = ballot(keep);
         if (final_step) {
             if (kb) {
                 uint32_t sb = 0;
@@ -2255,18 +2250,6 @@ __global__ __launch_bounds__(256) void pf_merge_kernel(PfMergeArgs A) {
 
 }  // namespace
 
-// order[n_pos] = the positions sorted by pf_order_key; hist = 8 * (n3 + 1) counters of scratch (A needs q_res, q_thr, q_kind, pat, k, kalph, n3)
-hipError_t launch_pf_order(const PfKmerArgs &A, uint32_t *hist, uint32_t *order, hipStream_t s) {
-    if (A.n_pos == 0) return hipSuccess;
-    hipError_t e = hipMemsetAsync(hist, 0, 8 * ((size_t)A.n3 + 1) * 4, s);
-    if (e != hipSuccess) return e;
-    const dim3 g((A.n_pos + 255) / 256), b(256);
-    hipLaunchKernelGGL(pf_order_count_kernel, g, b, 0, s, A, hist);
-    hipLaunchKernelGGL(pf_order_scan_kernel, dim3(1), dim3(1024), 0, s, hist, 8u * (A.n3 + 1u));
-    hipLaunchKernelGGL(pf_order_fill_kernel, g, b, 0, s, A, hist, order);
-    return hipGetLastError();
-}
-
 // cofs: 2 x uint4 per block of PF_COFS_KMERS k-mers, ceil(table / PF_COFS_KMERS) blocks
 size_t pf_cofs_bytes(uint64_t table) { return (size_t)((table + PF_COFS_KMERS - 1) / PF_COFS_KMERS) * 32; }
 hipError_t launch_pf_cofs(const uint32_t *offsets, uint64_t table, void *cofs, hipStream_t s) {
@@ -2368,6 +2351,15 @@ hipError_t launch_pf_dedup(const PfDedupArgs &A, hipEvent_t after_replay, hipEve
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(pf_replay_kernel, grid, block, 0, s, A);
     if ((e = hipGetLastError()) != hipSuccess) return e;
+#ifdef MMGPU_PF_REPLAY_STATS
+    {
+        unsigned long long h[16];
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_replay_stats), sizeof(h));
+        fprintf(stderr, "[replay stats, cumulative] buckets %llu rounds %llu dup_rounds %llu dup_lanes %llu entries %llu flagged %llu kept %llu again_rounds %llu chunks %llu\n",
+                h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8]);
+    }
+#endif
     hipLaunchKernelGGL(pf_replay_redo_kernel, dim3((unsigned)std::min<uint64_t>((buckets + 3) / 4, 1024)), block, 0, s, A);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (after_replay && (e = hipEventRecord(after_replay, s)) != hipSuccess) return e;
