@@ -41,7 +41,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 # packed-int16 (VOP3P) VALU ops issue at 16 lanes/clk/SIMD on gfx950: measured 38.1 Tlane-op/s for v_pk_max_i16 /
 # v_pk_sub_u16 / v_perm_b32 (profiles/r01_valu_issue_rate_probe.txt) = 256 CU x 4 SIMD x 16 lanes x 2.4 GHz = 39.3e12
 VALU_LANE_OPS_PER_S = 256 * 4 * 16 * 2.4e9
-PROFILE_ROUND = "r04"
+PROFILE_ROUND = "r05"
 
 
 def allreduce(torch, dist, values, op="sum"):
@@ -54,15 +54,42 @@ def allreduce(torch, dist, values, op="sum"):
     return [float(v) for v in t.cpu()]
 
 
-def pmc_traffic(kernels, stem):
+def csrc_digest():
+    """digest of the device sources this process runs with (scripts/csrc_digest.py)"""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    try:
+        from csrc_digest import csrc_digest as f
+        return f(ROOT)
+    except Exception:
+        return None
+
+
+def pmc_file_digest(path):
+    """the csrc digest a committed rocprof summary was taken with (header line written by scripts/rocprof_summary.py), or None"""
+    try:
+        for line in open(path):
+            if line.startswith("# csrc_digest:"):
+                return line.split(":", 1)[1].strip()
+            if not line.startswith("#"):
+                break
+    except OSError:
+        pass
+    return None
+
+
+def pmc_traffic(kernels, stem, check_digest=True):
     """HBM bytes per launch of the named kernels (substrings; summed over their template instantiations) from the committed rocprofv3 PMC
     passes of this same workload (profiles/<stem>_pmc_{fetch,write}_size.txt: separate --pmc FETCH_SIZE / WRITE_SIZE
     runs, unit KB, mean per dispatch).  FETCH_SIZE is reported as measured; MI355X_MICROARCH.md notes it under-counts
-    wide coalesced reads by 2x on gfx950, so this is a lower bound."""
+    wide coalesced reads by 2x on gfx950, so this is a lower bound.  check_digest: the passes must have been taken with the device
+    sources this process runs with (their header names the digest, scripts/csrc_digest.py) - counters of other kernels are not
+    reported as this run's traffic (None)."""
     tot = 0.0
     for kind in ("fetch", "write"):
         path = os.path.join(ROOT, "profiles", "%s_pmc_%s_size.txt" % (stem, kind))
         if not os.path.exists(path):
+            return None
+        if check_digest and pmc_file_digest(path) != csrc_digest():
             return None
         found = False
         for line in open(path):
@@ -439,7 +466,7 @@ def choose_query_groups(n_ranks, requested=0):
     return best
 
 
-def search_headline(args, gpu, torch, dist, rank, world, matrices, barrier):
+def search_headline(args, gpu, torch, dist, rank, world, matrices, barrier, device_index=0):
     """BASELINE.json configs[2] / configs[3]: the timed steps and everything derived from them."""
     from mmseqs2_amd import capi, evalue, workloads as wl
     from mmseqs2_amd import distributed as D
@@ -746,8 +773,72 @@ def search_headline(args, gpu, torch, dist, rank, world, matrices, barrier):
             out["records_gathered"] = int(keep["records_gathered"])
         out["merged_lists_sorted"] = bool(all(np.all(np.diff(mh[qi]["score"][:mc[qi]].astype(np.int64)) <= 0) for qi in range(0, nq, 97)))
         out["aligned_slots_filled"] = int(sum(int((full[qi, :mc[qi]]["score"] > 0).sum()) for qi in range(nq)))
+        if not weak and os.environ.get("MMGPU_BENCH_NO_UNSPLIT_CHECK") is None:
+            # N ranks against ONE: rank 0 runs its group's queries once more against the whole database in a second context of its
+            # device (outside the timed region) and compares hit lists and alignment records field by field; the digests go into the line
+            try:
+                out["parity_vs_unsplit"] = unsplit_parity(args, device_index, matrices, qs, queries, swq, tres, toff, kmer_thr, max_res, k, s3, i3,
+                                                          km16, mat, mh, mc, mf, full, stride)
+            except Exception as e:
+                out["parity_vs_unsplit"] = {"error": "%s: %s" % (type(e).__name__, str(e)[-300:])}
     pfb.free()
     return out
+
+
+def unsplit_parity(args, device_index, matrices, qs, queries, swq, tres, toff, kmer_thr, max_res, k, s3, i3, km16, mat, mh, mc, mf, full, stride):
+    """The N-rank step's merged hit lists (global ids, scores, diagonals, order) and gathered alignment records against the same
+    queries run UNSPLIT on one device: Prefiltering's own target-split mode shortens the lists, this design claims equality
+     - here it is checked inside the bench run.  Queries whose merged list carries the inexact flag (an
+    overflow-path element took part in a tie at the cut) are counted, not compared."""
+    import zlib
+    import mmseqs2_amd
+    from mmseqs2_amd import capi
+    g2 = mmseqs2_amd.MMGpu(device_index)
+    try:
+        g2.load_targets(tres, toff, 21)
+        if args.mask:
+            tv = np.load(os.path.join(ROOT, "tests", "golden", "tantan_vectors.npz"))
+            g2.pf_mask_targets(tv["vtml80_likelihood_ratios"], float(tv["mask_prob"]), 20)
+        g2.pf_build_index(k, 21, True, s3, i3, km16, kmer_thr, matrices["blosum62_ungapped"])
+        pfb = g2.pf_prepare(queries, kmer_thr, max_hits=max_res, min_diag_score=15, ref_bins=2)
+        pfb.run()
+        msh = g2.sw_marshal_queries(mat, 11, 1, swq)
+        fb = g2.sw_prepare_from_pf(mat, 11, 1, None, pfb, mode=1, marshalled=msh)
+        fb.run()
+        nq = len(qs)
+        one = fb.fetch().reshape(nq, pfb.max_hits)
+        hits, counts, status, _ = pfb.fetch()
+        fb.free()
+        pfb.free()
+    finally:
+        g2.close()
+    crc_n = crc_1 = 0
+    lists_diff = rec_diff = skipped = 0
+    for qi in range(nq):
+        if mf[qi] != 0 or status[qi] != 0:
+            skipped += 1
+            continue
+        n1, nn = int(counts[qi]), int(mc[qi])
+        a = np.ascontiguousarray(mh[qi][:nn])
+        b = np.ascontiguousarray(hits[qi][:n1])
+        same = n1 == nn and all(np.array_equal(a[f], b[f]) for f in ("id", "score", "diagonal"))
+        lists_diff += not same
+        ra = np.ascontiguousarray(full[qi, :nn])
+        rb = np.ascontiguousarray(one[qi, :n1])
+        fields = ("score", "q_end", "t_end", "q_start", "t_start")
+        rsame = n1 == nn and all(np.array_equal(ra[f], rb[f]) for f in fields)
+        rec_diff += not rsame
+        for f in ("id", "score", "diagonal"):
+            crc_n = zlib.crc32(np.ascontiguousarray(a[f]).tobytes(), crc_n)
+            crc_1 = zlib.crc32(np.ascontiguousarray(b[f]).tobytes(), crc_1)
+        for f in fields:
+            crc_n = zlib.crc32(np.ascontiguousarray(ra[f]).tobytes(), crc_n)
+            crc_1 = zlib.crc32(np.ascontiguousarray(rb[f]).tobytes(), crc_1)
+    return {"queries_compared": int(nq - skipped), "queries_flagged_inexact_or_handed_back": int(skipped),
+            "hit_lists_differing": int(lists_diff), "alignment_record_lists_differing": int(rec_diff),
+            "digest_n_ranks": int(crc_n), "digest_unsplit": int(crc_1), "equal": bool(lists_diff == 0 and rec_diff == 0 and crc_n == crc_1),
+            "what": "rank 0: merged hit lists (id, score, diagonal, order) and gathered alignment records (score, ends, starts) of its query "
+                    "group from the N-rank step vs the same queries against the unsplit database in a second context of the same device"}
 
 
 def align_only_section(args, gpu, torch, matrices, rank):
@@ -1075,7 +1166,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    H = search_headline(args, gpu, torch, dist, rank, world, matrices, barrier)
+    H = search_headline(args, gpu, torch, dist, rank, world, matrices, barrier, device_index)
     side = {}
     if not args.headline_only:
         if not args.no_align_only:
@@ -1137,7 +1228,9 @@ def main():
                          "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6),
                          "traffic": pmc_traffic(("sw_kernel<", "sw_rev_multi_kernel"), PROFILE_ROUND + "_search") if default_wl else None,
-                         "traffic_source": "profiles/%s_search_pmc_{fetch,write}_size.txt: FETCH_SIZE + WRITE_SIZE (KB) per launch, separate --pmc passes" % PROFILE_ROUND,
+                         "traffic_source": "profiles/%s_search_pmc_{fetch,write}_size.txt: FETCH_SIZE + WRITE_SIZE (KB) per launch, separate --pmc passes; "
+                                           "null unless those passes were taken with the device sources of this run (csrc_digest)" % PROFILE_ROUND,
+                         "csrc_digest": csrc_digest(),
                          "algorithmic_bytes_per_launch": round(alg_bytes), "kernel_ms": round(k_ms, 3),
                          "note": "Gotoh SW is VALU-issue bound (0.003 B/cell, SURVEY.md section 8d): the binding roof is valu_roofline",
                          "valu_roofline": {"achieved_lane_ops_per_s": round(lane_ops / (k_ms * 1e-3), 1),
@@ -1157,13 +1250,27 @@ def main():
         if "ent" in H:
             ent = H["ent"]
             alg = 20.0 * ent        # ~20 B per index entry touched
-            ach = alg / (stage[1] * 1e-3) / 1e9 if stage[1] > 0 else 0.0
+            ach = alg / (stage[6] * 1e-3) / 1e9 if stage[6] > 0 else 0.0          # the STAGE: every prefilter kernel of the step
+            ach_split = alg / (stage[1] * 1e-3) / 1e9 if stage[1] > 0 else 0.0
+            pf_kernels = ("pf_kmers", "pf_split_kernel", "pf_replay", "pf_ungapped_kernel", "pf_keepmax", "pf_select_kernel", "pf_overflow_kernel",
+                          "pf_scan_kernel", "pf_tiles_kernel")
+            # memory-side requests: the k-mer look-ups and the index gather are random 8 ... 40 byte reads, and the chip serves ~55 G of
+            # those per second whatever their size (profiles/r05_lookup_rate_probe.txt) - the roof these two kernels actually sit under
+            sim = float(H["sim"])
             pf.update({"db_matches": int(ent), "similar_kmers": int(H["sim"]), "overflow_queries": int(H["ovf"]),
-                       "roofline": {"kernel": "pf_split_kernel (index gather + stable bin split)", "bound": "hbm",
+                       "roofline": {"kernel": "prefilter stage (pf_kmers + pf_split + pf_replay + scoring / keepMax / select kernels)", "bound": "hbm",
                                     "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                                    "traffic": pmc_traffic(("pf_split_kernel",), PROFILE_ROUND + "_search") if default_wl else None,
-                                    "kernel_ms": round(stage[1], 3), "algorithmic_bytes_per_launch": round(alg),
-                                    "algorithmic_bytes_per_entry": 20}})
+                                    "traffic": pmc_traffic(pf_kernels, PROFILE_ROUND + "_search") if default_wl else None,
+                                    "kernel_ms": round(stage[6], 3), "algorithmic_bytes_per_launch": round(alg),
+                                    "algorithmic_bytes_per_entry": 20,
+                                    "split_kernel": {"achieved": round(ach_split, 1), "frac": round(ach_split / HBM_PEAK_GBS, 4), "kernel_ms": round(stage[1], 3),
+                                                     "traffic": pmc_traffic(("pf_split_kernel",), PROFILE_ROUND + "_search") if default_wl else None},
+                                    "random_request_roofline": {
+                                        "what": "index lists gathered by pf_split_kernel: one memory-side request per list and 64-byte line it touches, "
+                                                "against the measured rate of random requests that miss the L2",
+                                        "lists_gathered": int(sim), "peak_requests_per_s": 55e9,
+                                        "achieved_lists_per_s": round(sim / (stage[1] * 1e-3), 1) if stage[1] > 0 else None,
+                                        "frac": round(sim / (stage[1] * 1e-3) / 55e9, 4) if stage[1] > 0 else None}}})
         out["prefilter"] = pf
         if H.get("end_to_end") is not None:
             e2e = dict(H["end_to_end"])
@@ -1173,7 +1280,8 @@ def main():
             out["end_to_end"] = e2e
             if "queries_per_s_end_to_end" in e2e:
                 out["queries_per_s_end_to_end"] = e2e["queries_per_s_end_to_end"]
-        for kname in ("two_call", "backtrace", "block_aligner", "pairs_with_start", "inexact_queries", "merged_lists_sorted", "aligned_slots_filled", "records_gathered"):
+        for kname in ("two_call", "backtrace", "block_aligner", "pairs_with_start", "inexact_queries", "merged_lists_sorted", "aligned_slots_filled", "records_gathered",
+                      "parity_vs_unsplit"):
             if kname in H:
                 out[kname] = H[kname]
         out["setup_s"] = {"generate": round(H["t_gen"], 1), "score_tables_upload_and_device_index_build": round(H["t_index"], 2)}

@@ -201,7 +201,8 @@ struct PfSplitArgs {
     const PfList *lists;
     const uint64_t *idx_entries;      // IndexEntryLocal re-packed to 8 bytes: seqId | position_j << 32 (one line per list)
     uint32_t bins;
-    uint64_t *split;                  // [n_tiles][PF_T]
+    uint32_t *split;                  // [n_tiles][PF_T] (id >> log2 bins) | low diagonal byte << 12 | slot in tile << 20
+    uint8_t *split_hi;                // [n_tiles][PF_T] high diagonal byte (same layout)
     uint16_t *bin_off;                // [n_tiles][bins + 1]
     uint32_t *bucket_count;           // [nq][bins]
 };
@@ -211,7 +212,8 @@ struct PfDedupArgs {
     uint32_t q_first;
     uint32_t cand_origin;             // cand/surv hold the entries cand_origin .. of the batch (stage chunks, pf_api.hip)
     const uint32_t *q_tile_base, *q_ntiles;
-    const uint64_t *split;
+    const uint32_t *split;
+    const uint8_t *split_hi;
     const uint16_t *bin_off;
     const uint32_t *cand_base;        // [nq * bins + 1]
     PfCand *cand, *surv;

@@ -34,7 +34,7 @@ struct PfIndex {
     std::vector<int8_t> h_mat;   // ungapped matrix (host copy for the self score)
     // Large working buffers, shared by all batches of this context (grow-only; batches run one at a time on the
     // context's stream): index lists, split tiles, candidates, survivors.
-    DevBuf w_lists, w_split, w_bin_off, w_cand, w_surv, w_tile_q, w_tile_idx;
+    DevBuf w_lists, w_split, w_split_hi, w_bin_off, w_cand, w_surv, w_tile_q, w_tile_idx;
     const void *w_owner = nullptr;   // batch whose last run the working buffers hold (debug fetch)
 };
 
@@ -953,7 +953,9 @@ extern "C" int mmgpu_pf_run(mmgpu_ctx *c, mmgpu_pf_batch_t *b) {
     HIP_TRY(P.w_tile_q.reserve(std::max<size_t>(n_tiles, 1) * 4));
     HIP_TRY(P.w_tile_idx.reserve(std::max<size_t>(n_tiles, 1) * 4));
     if (n_tiles) HIP_TRY(launch_pf_tiles(b->d_qtile_base.as<uint32_t>(), b->d_qntiles.as<uint32_t>(), nq, P.w_tile_q.as<uint32_t>(), P.w_tile_idx.as<uint32_t>(), s));
-    HIP_TRY(P.w_split.reserve(std::max<size_t>(n_tiles, 1) * PF_T * sizeof(uint64_t)));
+    if ((uint64_t)n_tiles * PF_T >= 0xFFFFFFFFull) return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_pf_run: >= 2^32 tile slots in one batch; use smaller batches");
+    HIP_TRY(P.w_split.reserve(std::max<size_t>(n_tiles, 1) * PF_T * sizeof(uint32_t)));
+    HIP_TRY(P.w_split_hi.reserve(std::max<size_t>(n_tiles, 1) * PF_T));
     HIP_TRY(P.w_bin_off.reserve(std::max<size_t>(n_tiles, 1) * (B + 1) * sizeof(uint16_t)));
     // Stages 2 and 3 run over CHUNKS of consecutive queries: the candidate / survivor arrays are entry-sized (every entry
     // of a bin can be a candidate), 32 B per entry, of which ~1 % is touched - 115 GB for a 10 000-query batch against
@@ -1003,7 +1005,8 @@ extern "C" int mmgpu_pf_run(mmgpu_ctx *c, mmgpu_pf_batch_t *b) {
     SA.lists = P.w_lists.as<PfList>();
     SA.idx_entries = P.d_entries.as<uint64_t>();
     SA.bins = B;
-    SA.split = P.w_split.as<uint64_t>();
+    SA.split = P.w_split.as<uint32_t>();
+    SA.split_hi = P.w_split_hi.as<uint8_t>();
     SA.bin_off = P.w_bin_off.as<uint16_t>();
     SA.bucket_count = b->d_bucket_count.as<uint32_t>();
     HIP_TRY(launch_pf_split(SA, n_tiles, s));
@@ -1024,7 +1027,8 @@ extern "C" int mmgpu_pf_run(mmgpu_ctx *c, mmgpu_pf_batch_t *b) {
     D.bins = B;
     D.q_tile_base = b->d_qtile_base.as<uint32_t>();
     D.q_ntiles = b->d_qntiles.as<uint32_t>();
-    D.split = P.w_split.as<uint64_t>();
+    D.split = P.w_split.as<uint32_t>();
+    D.split_hi = P.w_split_hi.as<uint8_t>();
     D.bin_off = P.w_bin_off.as<uint16_t>();
     D.cand_base = b->d_cand_base.as<uint32_t>();
     D.cand = P.w_cand.as<PfCand>();
@@ -1533,7 +1537,42 @@ extern "C" int mmgpu_pf_debug_fetch(mmgpu_ctx *c, mmgpu_pf_batch_t *b, int what,
         case MMGPU_PF_DBG_LIST_BASE: src = b->d_list_base.p; n = ((size_t)b->n_pos + 1) * 4; break;
         case MMGPU_PF_DBG_LISTS: src = P.w_lists.p; n = (size_t)b->last_lists * sizeof(PfList); break;
         case MMGPU_PF_DBG_PEB: src = b->d_peb.p; n = ((size_t)b->n_pos + 1) * 4; break;
-        case MMGPU_PF_DBG_SPLIT: src = P.w_split.p; n = (size_t)b->last_tiles * PF_T * 8; break;
+        case MMGPU_PF_DBG_SPLIT: {
+            // the tiles in the form the tests read (one 8-byte word per entry: id | diagonal << 32 | slot << 48), put together from
+            // the device's 4-byte words, the high diagonal bytes and the bin offsets (the bin is where an entry stands)
+            n = (size_t)b->last_tiles * PF_T * 8;
+            *bytes = n;
+            if (!dst || cap < n) return MMGPU_OK;
+            const size_t nt = b->last_tiles, B = b->bins;
+            std::vector<uint32_t> w(nt * PF_T);
+            std::vector<uint8_t> hi(nt * PF_T);
+            std::vector<uint16_t> bo(nt * (B + 1));
+            if (nt) {
+                HIP_TRY(hipMemcpy(w.data(), P.w_split.p, w.size() * 4, hipMemcpyDeviceToHost));
+                HIP_TRY(hipMemcpy(hi.data(), P.w_split_hi.p, hi.size(), hipMemcpyDeviceToHost));
+                HIP_TRY(hipMemcpy(bo.data(), P.w_bin_off.p, bo.size() * 2, hipMemcpyDeviceToHost));
+            }
+            int bshift = 0;
+            while ((1u << bshift) < B) bshift++;
+            uint64_t *o = static_cast<uint64_t *>(dst);
+            for (size_t t = 0; t < nt; t++) {
+                const uint16_t *tb = bo.data() + t * (B + 1);
+                size_t bin = 0;
+                const size_t tn = tb[B];
+                for (size_t k = 0; k < (size_t)PF_T; k++) {
+                    uint64_t v = 0;
+                    if (k < tn) {
+                        while (bin + 1 < B && k >= tb[bin + 1]) bin++;
+                        const uint32_t e = w[t * PF_T + k];
+                        const uint64_t id = ((uint64_t)(e & 0xFFFu) << bshift) | bin;
+                        const uint64_t diag = ((e >> 12) & 0xFFu) | ((uint64_t)hi[t * PF_T + k] << 8);
+                        v = id | (diag << 32) | ((uint64_t)(e >> 20) << 48);
+                    }
+                    o[t * PF_T + k] = v;
+                }
+            }
+            return MMGPU_OK;
+        }
         case MMGPU_PF_DBG_BIN_OFF: src = P.w_bin_off.p; n = (size_t)b->last_tiles * (b->bins + 1) * 2; break;
         case MMGPU_PF_DBG_CAND_BASE: src = b->d_cand_base.p; n = ((size_t)b->nq * b->bins + 1) * 4; break;
         case MMGPU_PF_DBG_SURV:

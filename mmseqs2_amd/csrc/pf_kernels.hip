@@ -184,6 +184,20 @@ __global__ __launch_bounds__(256) void pf_cofs_kernel(const uint32_t *offsets, u
     cofs[2 * blk + 1] = make_uint4(w[4], w[5], w[6], w[7]);
 }
 
+// A list record is written once and read once, by the split kernel, after every record of the batch has been written: stored
+// with the non-temporal hint it does not push the offset-table blocks (the lines this kernel lives on) out of the L2.
+__device__ __forceinline__ void pf_store_list(PfList *dst, uint32_t start, uint32_t len, uint32_t lprefix, uint32_t pos) {
+#ifdef MMGPU_PF_LISTS_PLAIN_STORE
+    PfList rec;
+    rec.start = start; rec.len = len; rec.lprefix = lprefix; rec.pos = pos;
+    *dst = rec;
+#else
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 v = {start, len, lprefix, pos};
+    __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(dst));
+#endif
+}
+
 // (start, length) of the index list of `kmer`
 __device__ __forceinline__ void pf_lookup(const PfKmerArgs &A, uint32_t kmer, uint32_t &start, uint32_t &len) {
     if (A.cofs) {
@@ -278,14 +292,7 @@ __global__ __launch_bounds__(256) void pf_kmers_kernel(PfKmerArgs A) {
                     if (!A.nonempty || ((A.nonempty[kmer >> 5] >> (kmer & 31u)) & 1u)) pf_lookup(A, kmer, start, len);
                 }
                 const uint32_t li = wave_incl_scan(len);
-                if (act) {
-                    PfList rec;
-                    rec.start = start;
-                    rec.len = len;
-                    rec.lprefix = running + li - len;
-                    rec.pos = gp;
-                    A.lists[(size_t)lbase + nlists + x] = rec;
-                }
+                if (act) pf_store_list(&A.lists[(size_t)lbase + nlists + x], start, len, running + li - len, gp);
                 running += __shfl(li, 63);
             }
         }
@@ -387,14 +394,7 @@ __global__ __launch_bounds__(256) void pf_kmers7_kernel(PfKmerArgs A) {
                         pf_lookup(A, kmer, start, len);
                     }
                     const uint32_t li = wave_incl_scan(len);
-                    if (act) {
-                        PfList rec;
-                        rec.start = start;
-                        rec.len = len;
-                        rec.lprefix = running + li - len;
-                        rec.pos = gp;
-                        A.lists[(size_t)lbase + nlists + y] = rec;
-                    }
+                    if (act) pf_store_list(&A.lists[(size_t)lbase + nlists + y], start, len, running + li - len, gp);
                     running += __shfl(li, 63);
                 }
             }
@@ -591,7 +591,12 @@ __global__ __launch_bounds__(256) void pf_scan_kernel(const uint32_t *in, const 
 // second half of a6 + hashIndexEntry (CacheFriendlyOperations.cpp:341-351): one workgroup per tile of PF_T
 // arrival-ordered index entries of one query.  Gathers (seqId, position_j) -> (id, diagonal = i - j), splits the
 // tile stably by bin = id & (B-1), writes it grouped by bin plus the B+1 bin offsets of the tile.
-// Entry word: id | diagonal << 32 | slot-in-tile << 48  (slot = arrival index - tile start).
+// Staged entry word (LDS): id | diagonal << 32 | slot-in-tile << 48  (slot = arrival index - tile start).
+// Written out (round 5): 4 bytes per entry - (id >> log2 B) | low diagonal byte << 12 | slot << 20: the bin is where the entry
+// stands, the 12 id bits above it number the <= 4096 targets of a bin, the replay's state machine needs the low diagonal byte only -
+// plus the high diagonal byte in a byte array of the same layout, which only the ~1 % of entries that become candidates are
+// looked up in.  Every request to memory costs the same whatever it carries (~55 G/s chip wide, pf_order.hip): the tiles were
+// 29 GB written and 29 GB read back per 10 000 queries, now 18 and 14.5.
 #ifndef MMGPU_PF_SPLIT_PAD
 #define MMGPU_PF_SPLIT_PAD 0
 #endif
@@ -739,18 +744,33 @@ __global__ __launch_bounds__(SPW * 64) __attribute__((amdgpu_waves_per_eu(MMGPU_
     }
     __syncthreads();
 
-    // ---- phase C: stable scatter inside LDS (every entry is in a register now), then coalesced write-out ----
+    // ---- phase C: stable scatter inside LDS (every entry is in a register now: the stage is free), in the output format -
+    // the 4-byte words in the first half of the stage, the high diagonal bytes behind them - then coalesced write-out ----
+    uint32_t *stage_w = reinterpret_cast<uint32_t *>(stage);
+    uint8_t *stage_h = reinterpret_cast<uint8_t *>(stage) + (size_t)PF_T * 4;
 #pragma unroll
     for (int r = 0; r < ROUNDS; r++) {
         const uint32_t slot = (uint32_t)wave * (PF_T / SPW) + (uint32_t)r * 64u + (uint32_t)lane;
         if (slot < tile_n) {
-            const uint32_t bin = (uint32_t)ent[r] & (B - 1);
-            stage[mycnt[bin] + rk[r]] = ent[r];
+            const uint32_t id = (uint32_t)ent[r];
+            const uint32_t bin = id & (B - 1);
+            const uint32_t diag = (uint32_t)(ent[r] >> 32) & 0xFFFFu;
+            const uint32_t at = mycnt[bin] + rk[r];
+            stage_w[at] = (id >> nbits) | ((diag & 0xFFu) << 12) | ((uint32_t)(ent[r] >> 48) << 20);
+            stage_h[at] = (uint8_t)(diag >> 8);
         }
     }
     __syncthreads();
-    uint64_t *dst = A.split + (size_t)t * PF_T;
-    for (uint32_t s = threadIdx.x; s < tile_n; s += (uint32_t)SPW * 64u) dst[s] = stage[s];
+    uint32_t *dst = A.split + (size_t)t * PF_T;
+    uint32_t *dst_h = reinterpret_cast<uint32_t *>(A.split_hi + (size_t)t * PF_T);
+    const uint32_t *src_h = reinterpret_cast<const uint32_t *>(stage_h);
+#ifdef MMGPU_PF_SPLIT_NT
+    for (uint32_t s = threadIdx.x; s < tile_n; s += (uint32_t)SPW * 64u) __builtin_nontemporal_store(stage_w[s], &dst[s]);
+    for (uint32_t s = threadIdx.x; s < (tile_n + 3u) / 4u; s += (uint32_t)SPW * 64u) __builtin_nontemporal_store(src_h[s], &dst_h[s]);
+#else
+    for (uint32_t s = threadIdx.x; s < tile_n; s += (uint32_t)SPW * 64u) dst[s] = stage_w[s];
+    for (uint32_t s = threadIdx.x; s < (tile_n + 3u) / 4u; s += (uint32_t)SPW * 64u) dst_h[s] = src_h[s];
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -873,6 +893,10 @@ __device__ __forceinline__ uint64_t score_chunk(const PfDedupArgs &A, const int8
     int my_len = 0, my_qs = 0;
     unsigned long long my_addr = 0;
     uint64_t cells = 0;
+    // A candidate of an ordinary query arrives with the low byte of its diagonal and, in `score`, where its entry stands in the
+    // split tiles (replay_bucket_impl): the high byte is read here, one round trip for the whole chunk, and written back with the
+    // score.  (Overflow-path queries and --diag-score 0 complete their diagonals in the replay / count kernels.)
+    if (has && !(A.q_nseg && A.q_nseg[q])) c.diag = (uint16_t)((c.diag & 0xFFu) | ((uint32_t)A.split_hi[c.score] << 8));
     if (has) {
         const int d = (int)(short)c.diag;
         const int tlen = (int)A.t_len[c.id];
@@ -956,7 +980,11 @@ __device__ __forceinline__ uint64_t score_chunk(const PfDedupArgs &A, const int8
         }
     }
     c.score = (uint32_t)my_score;
-    if (has) cand_slot(A, bucket, cb0 + (uint32_t)lane)->score = c.score;
+    if (has) {
+        PfCand *slot = cand_slot(A, bucket, cb0 + (uint32_t)lane);
+        slot->score = c.score;
+        slot->diag = c.diag;
+    }
     if (ncand <= 64 && !A.nucl) {
         // keepMaxElement for the whole bucket right here (the common case; larger buckets go to pf_keepmax_kernel):
         // per target the first candidate holding the target's maximum count
@@ -1022,7 +1050,7 @@ struct ReplayLds {
     typename std::conditional<COMPACT, uint8_t, uint16_t>::type state[4][PF_IDS_PER_BIN];
     uint32_t emit[4][PF_IDS_PER_BIN / 32];
     uint32_t tab[COMPACT ? 4 : 1][COMPACT ? PF_EMIT_TAB : 1];   // key << 8 | byte last emitted
-    uint32_t cand[4][3][64];   // first 64 candidates of the bucket: id, arrival index, diagonal
+    uint32_t cand[4][4][64];   // first 64 candidates of the bucket: id, arrival index, diagonal, index of the entry in the split tiles
     uint8_t mark[4][64];       // segment starts of a round (request)
     uint32_t dup[4][PF_IDS_PER_BIN / 32];     // one bit per target: set and taken back within a round (all zero between rounds)
     int8_t smat[32 * 32];
@@ -1084,26 +1112,16 @@ __device__ __forceinline__ bool replay_bucket_impl(const PfDedupArgs &A, ReplayL
         RSTAT(4, total);
         // software pipeline: the entries of the next MMGPU_PF_REPLAY_PD rounds are in flight while a round is processed
         // (one round ahead is enough: deeper pipelines measured the same)
-        uint64_t e_q[MMGPU_PF_REPLAY_PD];
-        uint32_t tile_q[MMGPU_PF_REPLAY_PD];
+        uint32_t e_q[MMGPU_PF_REPLAY_PD];
+        uint32_t tile_q[MMGPU_PF_REPLAY_PD], at_q[MMGPU_PF_REPLAY_PD];      // tile of the entry, and where it stands in that tile
         // Tile whose segment holds the bucket's entry x, for the 64 entries of a round at once (rounds are requested in
         // increasing order): every tile whose non-empty segment starts inside the round marks its slot, a running maximum
         // along the lanes spreads the marks, the segment that reaches into the round from before is the last one of the
         // previous request.  (A search over the segment starts costs six dependent cross-lane round trips per round.)
         int m_carry = 0;
         const uint32_t seg_delta = o0 - excl;      // entry x of the bucket is entry x + seg_delta of its tile
-        auto request = [&](uint32_t xr, uint64_t &e_out, uint32_t &tile_out) {
+        auto request = [&](uint32_t xr, uint32_t &e_out, uint32_t &tile_out, uint32_t &at_out) {
             const uint32_t x = xr + (uint32_t)lane;
-#ifdef MMGPU_PF_OLD_SEGFIND
-            {
-                const int m0 = seg_find(excl, x);
-                const uint32_t d0 = (uint32_t)__shfl((int)seg_delta, m0);
-                tile_out = t0 + (uint32_t)m0;
-                e_out = 0;
-                if (x < total) e_out = A.split[(size_t)(tb + tile_out) * PF_T + (uint32_t)(x + d0)];
-                return;
-            }
-#endif
             mark[lane] = 0;
             const uint32_t rel = excl - xr;
             if (n != 0u && rel < 64u) mark[rel] = (uint8_t)lane;
@@ -1114,29 +1132,31 @@ __device__ __forceinline__ bool replay_bucket_impl(const PfDedupArgs &A, ReplayL
             m_carry = __builtin_amdgcn_readlane(m, 63);
             const uint32_t d_m = (uint32_t)__shfl((int)seg_delta, m);
             tile_out = t0 + (uint32_t)m;
+            at_out = (uint32_t)(x + d_m);      // (the sum wraps in 32 bits)
             e_out = 0;
-            if (x < total) e_out = A.split[(size_t)(tb + tile_out) * PF_T + (uint32_t)(x + d_m)];      // (the sum wraps in 32 bits)
+            if (x < total) e_out = A.split[(size_t)(tb + tile_out) * PF_T + at_out];
         };
 #pragma unroll
         for (int k = 0; k < MMGPU_PF_REPLAY_PD; k++) {
             e_q[k] = 0;
             tile_q[k] = 0;
-            if ((uint32_t)k * 64u < total) request((uint32_t)k * 64u, e_q[k], tile_q[k]);
+            at_q[k] = 0;
+            if ((uint32_t)k * 64u < total) request((uint32_t)k * 64u, e_q[k], tile_q[k], at_q[k]);
         }
         for (uint32_t xg = 0; xg < total; xg += 64u * MMGPU_PF_REPLAY_PD) {
 #pragma unroll
           for (int pk = 0; pk < MMGPU_PF_REPLAY_PD; pk++) {
             const uint32_t x0 = xg + 64u * (uint32_t)pk;
             if (x0 >= total) break;
-            const uint64_t e = e_q[pk];
+            const uint32_t e = e_q[pk];
             const uint32_t tile_cur = tile_q[pk];
+            const uint32_t where = (tb + tile_cur) * (uint32_t)PF_T + at_q[pk];      // the entry's place in the split arrays (< 2^32: pf_api.hip)
             const bool act = x0 + (uint32_t)lane < total;
-            if (x0 + 64u * MMGPU_PF_REPLAY_PD < total) request(x0 + 64u * MMGPU_PF_REPLAY_PD, e_q[pk], tile_q[pk]);
-            const uint32_t id = (uint32_t)e;
-            const uint32_t diag = (uint32_t)(e >> 32) & 0xFFFFu;
-            const uint32_t d8 = diag & 0xFFu;
-            const uint32_t key = id >> bshift;   // < PF_IDS_PER_BIN
-            const uint32_t arr = tile_cur * (uint32_t)PF_T + (uint32_t)(e >> 48);
+            if (x0 + 64u * MMGPU_PF_REPLAY_PD < total) request(x0 + 64u * MMGPU_PF_REPLAY_PD, e_q[pk], tile_q[pk], at_q[pk]);
+            const uint32_t key = e & 0xFFFu;   // < PF_IDS_PER_BIN
+            const uint32_t id = (key << bshift) | bin;
+            const uint32_t d8 = (e >> 12) & 0xFFu;
+            const uint32_t arr = tile_cur * (uint32_t)PF_T + (e >> 20);
             // Overflow path (nseg > 0): the reference flushes databaseHits at segment boundaries and starts the
             // double-diagonal state from scratch (QueryMatcher.cpp:310-346), so a round that straddles a boundary is
             // processed in pieces with the tables cleared in between.
@@ -1268,15 +1288,18 @@ __device__ __forceinline__ bool replay_bucket_impl(const PfDedupArgs &A, ReplayL
                         PfCand c;
                         c.id = id;
                         c.arr = arr;
-                        c.score = 0;
-                        c.diag = (uint16_t)diag;
+                        // ordinary query: the scoring step reads the high diagonal byte (score_chunk); the overflow path's
+                        // kernels take the candidates as they are, so their diagonals are completed here
+                        c.score = SEGS ? 0u : where;
+                        c.diag = (uint16_t)(SEGS ? (d8 | ((uint32_t)A.split_hi[where] << 8)) : d8);
                         c.pad = (uint16_t)cur_seg;
                         const uint32_t ck = ncand + (uint32_t)__popcll(kb & below);
                         *cand_slot(A, bucket, ck) = c;
                         if (ck < 64) {
                             M.cand[wave][0][ck] = c.id;
                             M.cand[wave][1][ck] = c.arr;
-                            M.cand[wave][2][ck] = diag;
+                            M.cand[wave][2][ck] = c.diag;
+                            M.cand[wave][3][ck] = c.score;
                         }
                     }
                     ncand += (uint32_t)__popcll(kb);
@@ -1303,6 +1326,7 @@ __device__ __forceinline__ bool replay_bucket_impl(const PfDedupArgs &A, ReplayL
             c.id = M.cand[wave][0][lane];
             c.arr = M.cand[wave][1][lane];
             c.diag = (uint16_t)M.cand[wave][2][lane];
+            c.score = M.cand[wave][3][lane];
         }
         uint64_t cells = score_chunk(A, M.smat, nullptr, nullptr, bucket, q, 0, ncand, ncand, c, bshift);
         if (A.cell_counter) {
@@ -1422,13 +1446,13 @@ __global__ __launch_bounds__(256) void pf_count_kernel(PfDedupArgs A) {
             const int m = seg_find(excl, now ? x : 0u);
             const uint32_t ex_m = __shfl(excl, m), o_m = __shfl(o0, m);
             const uint32_t tile = t0 + (uint32_t)m;
-            uint64_t e = 0;
-            if (now) e = A.split[(size_t)(tb + tile) * PF_T + o_m + (x - ex_m)];
-            const uint32_t id = (uint32_t)e;
-            const uint32_t diag = (uint32_t)(e >> 32) & 0xFFFFu;
-            const uint32_t d8 = diag & 0xFFu;
-            const uint32_t key = id >> bshift;   // < PF_IDS_PER_BIN
-            const uint32_t arr = tile * (uint32_t)PF_T + (uint32_t)(e >> 48);
+            uint32_t e = 0;
+            const uint32_t where = (tb + tile) * (uint32_t)PF_T + o_m + (x - ex_m);
+            if (now) e = A.split[where];
+            const uint32_t key = e & 0xFFFu;   // < PF_IDS_PER_BIN
+            const uint32_t id = (key << bshift) | bin;
+            const uint32_t d8 = (e >> 12) & 0xFFu;
+            const uint32_t arr = tile * (uint32_t)PF_T + (e >> 20);
             const uint64_t same = match_lanes(key, 12, now);
             uint32_t st = 0, em = 0;
             if (now) {
@@ -1457,7 +1481,7 @@ __global__ __launch_bounds__(256) void pf_count_kernel(PfDedupArgs A) {
                 c.id = id;
                 c.arr = arr;
                 c.score = 0;
-                c.diag = (uint16_t)diag;
+                c.diag = (uint16_t)(d8 | ((uint32_t)A.split_hi[where] << 8));
                 c.pad = 0;
                 *cand_slot(A, bucket, ncand + (uint32_t)__popcll(kb & below)) = c;
             }

@@ -18,6 +18,13 @@ def main():
         "from kernels group by name order by sum(end-start) desc").fetchall()
     total = sum(r[2] for r in rows) or 1
     out.write("# rocprofv3 --kernel-trace --stats summary (from %s)\n" % db)
+    try:      # which kernels this was taken with (scripts/csrc_digest.py)
+        import os
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        from csrc_digest import csrc_digest
+        out.write("# csrc_digest: %s\n" % csrc_digest())
+    except Exception:
+        pass
     out.write("%-90s %6s %14s %14s %14s %14s %7s %5s %5s %5s %7s %10s %5s\n" % (
         "kernel", "calls", "total_ns", "avg_ns", "min_ns", "max_ns", "pct", "vgpr", "agpr", "sgpr", "lds_B", "grid_x", "wg_x"))
     for r in rows:
