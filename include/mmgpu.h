@@ -355,6 +355,29 @@ int mmgpu_pf_debug_masked_targets(mmgpu_ctx *ctx, const uint64_t *offsets, uint3
 /* test hook: copies the resident index back in the host builder's layout (any pointer may be NULL) */
 int mmgpu_pf_debug_index(mmgpu_ctx *ctx, uint64_t *offsets, uint32_t *ids, uint16_t *pos, uint64_t *n_entries);
 
+/* ---- persisted device layout -------------------------------------------------------------------------
+ * The reference prepares a database for its GPU path ahead of time (`makepaddedseqdb`, src/util/makepaddedseqdb.cpp) and keeps
+ * precomputed prefilter indexes on disk (`createindex`; src/prefiltering/PrefilteringIndexReader.cpp reads them back).  The
+ * counterpart: ONE file with what a context has resident, in the layout it has on the device - the targets (4-byte aligned
+ * residues, offsets, lengths), the prefilter's masked view when mmgpu_pf_mask_targets ran, and the k-mer index (offsets + entries)
+ * when index_fingerprint != 0.  mmgpu_db_load brings a context to the same state without the host touching a sequence (no
+ * SequenceLookup fill, no masking, no index build); the similar-k-mer score tables and the ungapped matrix are the caller's, as
+ * for mmgpu_pf_build_index (`tables`: offsets / entries fields ignored).  The two fingerprints are the caller's: of the source
+ * database (the drop-in hashes the keys and lengths of the DBReader), and of everything else the index depends on (k, pattern,
+ * k-mer threshold, matrices, mask parameters).  A file that does not match - or is not there - is answered MMGPU_ERR_STATE and
+ * the caller builds as ever (and may save).  index_fingerprint == 0: save / load the targets only (the alignment module's view). */
+typedef struct mmgpu_db_info {
+    uint64_t source_fingerprint, index_fingerprint;
+    uint32_t n_targets, alphabet;
+    uint64_t total_residues;
+    int32_t has_masked_view, has_index, kmer_size, spaced;
+    uint64_t n_entries, file_bytes;
+} mmgpu_db_info;
+int mmgpu_db_save(mmgpu_ctx *ctx, const char *path, uint64_t source_fingerprint, uint64_t index_fingerprint);
+int mmgpu_db_probe(const char *path, mmgpu_db_info *info);      /* the header alone: no device needed */
+int mmgpu_db_load(mmgpu_ctx *ctx, const char *path, uint64_t source_fingerprint, uint64_t index_fingerprint,
+                  const mmgpu_pf_index *tables /* may be NULL when index_fingerprint == 0 */);
+
 /* limits of the prefilter entry points: calls beyond them return MMGPU_ERR_UNSUPPORTED and the host keeps its CPU path */
 #define MMGPU_PF_MAX_HITS 131072    /* max_hits (--max-seqs); above 4096 the final sort of a list runs in HBM instead of LDS */
 #define MMGPU_PF_MAX_FUSED_HITS 4096 /* ... except mmgpu_sw_prepare_from_pf and sharded (exchange) batches, which stay at 4096 */

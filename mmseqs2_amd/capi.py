@@ -81,7 +81,25 @@ EXPORTED_SYMBOLS = [
     "mmgpu_init_multi", "mmgpu_destroy_multi", "mmgpu_multi_size", "mmgpu_multi_ctx", "mmgpu_multi_synchronize",
     "mmgpu_multi_load_targets", "mmgpu_multi_pf_mask_targets", "mmgpu_multi_pf_build_index", "mmgpu_multi_pf_prepare", "mmgpu_multi_pf_run", "mmgpu_multi_pf_fetch",
     "mmgpu_multi_pf_stride", "mmgpu_multi_pf_free", "mmgpu_multi_sw_from_pf",
+    "mmgpu_db_save", "mmgpu_db_probe", "mmgpu_db_load",
 ]
+
+
+class DbInfo(ctypes.Structure):      # mmgpu_db_info
+    _fields_ = [("source_fingerprint", ctypes.c_uint64), ("index_fingerprint", ctypes.c_uint64), ("n_targets", ctypes.c_uint32),
+                ("alphabet", ctypes.c_uint32), ("total_residues", ctypes.c_uint64), ("has_masked_view", ctypes.c_int32),
+                ("has_index", ctypes.c_int32), ("kmer_size", ctypes.c_int32), ("spaced", ctypes.c_int32), ("n_entries", ctypes.c_uint64),
+                ("file_bytes", ctypes.c_uint64)]
+
+
+def db_probe(path, lib=None):
+    """mmgpu_db_probe: the header of a persisted device layout (no device needed) -> dict, or None if `path` is not one"""
+    L = lib or load_library()
+    info = DbInfo()
+    L.mmgpu_db_probe.argtypes = [ctypes.c_char_p, c_p]
+    if L.mmgpu_db_probe(str(path).encode(), ctypes.byref(info)) != 0:
+        return None
+    return {k: getattr(info, k) for k, _ in DbInfo._fields_}
 
 
 class PfIndexDesc(ctypes.Structure):
@@ -687,6 +705,34 @@ class MMGpu:
         d = PfIndexDesc(k, alphabet, int(spaced), _ptr(score3), _ptr(index3), 0 if score3 is None else score3.shape[1], _ptr(score2), _ptr(index2),
                         0 if score2 is None else score2.shape[1], None, None, None, None, 0, _ptr(ungapped_mat))
         self._check(self.L.mmgpu_pf_build_index(self.ctx, ctypes.byref(d), _ptr(km), int(kmer_thr)))
+
+    def db_save(self, path, source_fp, index_fp=0):
+        """mmgpu_db_save: targets (+ masked view, + index when index_fp != 0) of this context into one file in the device layout"""
+        self.L.mmgpu_db_save.argtypes = [c_p, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint64]
+        self._check(self.L.mmgpu_db_save(self.ctx, str(path).encode(), int(source_fp), int(index_fp)))
+
+    def db_load(self, path, source_fp, index_fp=0, k=6, alphabet=21, spaced=True, score3=None, index3=None, ungapped_mat=None,
+                score2=None, index2=None):
+        """mmgpu_db_load -> True when the file matched and is resident now, False when the caller has to build (MMGPU_ERR_STATE)"""
+        d = None
+        if index_fp:
+            score3 = None if score3 is None else np.ascontiguousarray(score3, np.int16)
+            index3 = None if index3 is None else np.ascontiguousarray(index3, np.uint32)
+            ungapped_mat = np.ascontiguousarray(ungapped_mat, np.int8)
+            if score2 is not None:
+                score2 = np.ascontiguousarray(score2, np.int16)
+                index2 = np.ascontiguousarray(index2, np.uint32)
+            d = PfIndexDesc(k, alphabet, int(spaced), _ptr(score3), _ptr(index3), 0 if score3 is None else score3.shape[1], _ptr(score2),
+                            _ptr(index2), 0 if score2 is None else score2.shape[1], None, None, None, None, 0, _ptr(ungapped_mat))
+        self.L.mmgpu_db_load.argtypes = [c_p, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint64, c_p]
+        rc = self.L.mmgpu_db_load(self.ctx, str(path).encode(), int(source_fp), int(index_fp), ctypes.byref(d) if d is not None else None)
+        if rc == -3:      # MMGPU_ERR_STATE: no such file / another database / other index parameters
+            return False
+        self._check(rc)
+        self._db_keep = None
+        info = db_probe(path, self.L)
+        self.n_targets = int(info["n_targets"])
+        return True
 
     def pf_mask_targets(self, likelihood_ratios, min_mask_prob=0.9, mask_letter=20):
         """mmgpu_pf_mask_targets: tantan masking of the resident targets for the prefilter -> residues masked"""

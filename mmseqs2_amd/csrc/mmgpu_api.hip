@@ -46,6 +46,18 @@ static void free_db(DeviceDb &db) {
     db = DeviceDb();
 }
 
+namespace mmgpu {
+// what mmgpu_load_targets drops before it loads: the resident targets, their masked view, the index over them, the shard description
+void db_release(mmgpu_ctx *c) {
+    pf_index_free(c);
+    c->shard.on = false;
+    if (c->pf_masked_res) { dev_free(c->pf_masked_res); c->pf_masked_res = nullptr; }
+    free_db(c->db);
+    c->h_len.clear();
+    c->mean_len = 0;
+}
+}  // namespace mmgpu
+
 extern "C" void mmgpu_destroy(mmgpu_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);

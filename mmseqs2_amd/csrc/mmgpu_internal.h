@@ -820,6 +820,7 @@ int pf_batch_merged_flags(mmgpu_pf_batch_t *b, const void **d_flags);
 const int32_t *pf_batch_host_status(const mmgpu_pf_batch_t *b);
 bool pf_batch_merged_lists(mmgpu_pf_batch_t *b, const mmgpu_pf_hit **hits, const uint32_t **counts, uint32_t *stride, uint32_t *nq);
 void pf_index_free(mmgpu_ctx *c);
+void db_release(mmgpu_ctx *c);      // mmgpu_api.hip: targets, masked view, index and shard description of a context
 // device-resident results of a prefilter batch that has been run (false if it has not)
 bool pf_batch_device_lists(mmgpu_pf_batch_t *b, const mmgpu_pf_hit **hits, const uint32_t **counts, uint32_t *stride, uint32_t *nq);
 }

@@ -11,6 +11,11 @@
 #include "mmgpu_internal.h"
 #include "sat_ties.h"
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 using namespace mmgpu;
 
 namespace mmgpu {
@@ -964,7 +969,13 @@ extern "C" int mmgpu_pf_run(mmgpu_ctx *c, mmgpu_pf_batch_t *b) {
     std::vector<uint32_t> chunk_first;
     uint64_t chunk_max_entries = 0;
     {
+        // (one chunk per ~40 GB on a 288 GB device: every chunk ends with the tail of its replay grid and four small launches -
+        // 7 chunks of 16 GB cost the 10 000-query batch 1 ms more than 3 of 40, profiles/r05_exp_pf_stage_chunks.txt)
         double gb = 16.0;
+        {
+            size_t mem_free = 0, mem_total = 0;
+            if (hipMemGetInfo(&mem_free, &mem_total) == hipSuccess && mem_total >= (192ull << 30) && mem_free >= (120ull << 30)) gb = 40.0;
+        }
         if (const char *e = getenv("MMGPU_PF_STAGE_GB")) gb = atof(e);
         const uint64_t cap = std::max<uint64_t>((uint64_t)(gb * 1073741824.0 / (2.0 * sizeof(PfCand))), 1);
         uint64_t run = 0;
@@ -1590,6 +1601,250 @@ extern "C" int mmgpu_pf_debug_fetch(mmgpu_ctx *c, mmgpu_pf_batch_t *b, int what,
     *bytes = n;
     const size_t m = std::min(n, cap);
     if (dst && m) HIP_TRY(hipMemcpy(dst, src, m, hipMemcpyDeviceToHost));
+    return MMGPU_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Persisted device layout.  The reference prepares a database for its GPU path ahead of time
+// (`makepaddedseqdb`, src/util/makepaddedseqdb.cpp: sequences padded and ordered for the device) and keeps precomputed prefilter
+// indexes on disk (`createindex`; PrefilteringIndexReader.cpp reads them back).  Here it is ONE file with what a context has
+// resident, in the layout it has on the device: targets (4-byte aligned residues, offsets, lengths), the prefilter's masked view
+// when there is one, and the k-mer index (uint32 offsets, 8-byte entries).  mmgpu_db_load brings it back without the host
+// touching a sequence: no SequenceLookup fill, no masking, no index build.  What is NOT in the file: the similar-k-mer score
+// tables (they belong to the matrix, the caller hands them over as for mmgpu_pf_build_index) and anything derived on the device in
+// milliseconds (compact offset table, non-empty bit table).
+namespace {
+
+struct DbFileHeader {
+    char magic[8];                 // "MMGPUDB1"
+    uint32_t version, header_bytes;
+    uint64_t source_fp, index_fp;  // the caller's fingerprints: of the source database; of what the index depends on beyond it
+    uint32_t n, alphabet, max_len, mean_len;
+    uint64_t total_residues, res_bytes;
+    uint32_t has_masked, has_index;
+    int32_t k, spaced, kbase, pad0;
+    uint64_t table, n_entries;
+    uint64_t at_off4, at_len, at_res, at_masked, at_offsets, at_entries, file_bytes;
+};
+static const char DB_MAGIC[8] = {'M', 'M', 'G', 'P', 'U', 'D', 'B', '1'};
+
+static uint64_t align4k(uint64_t x) { return (x + 4095ull) & ~4095ull; }
+
+// device -> file, through a pinned staging buffer
+static int write_section(FILE *f, uint64_t at, const void *dev, size_t bytes) {
+    if (fseeko(f, (off_t)at, SEEK_SET) != 0) return fail(MMGPU_ERR_ARG, "mmgpu_db_save: seek failed");
+    const size_t chunk = 64ull << 20;
+    uint8_t *stage = nullptr;
+    HIP_TRY(hipHostMalloc((void **)&stage, std::min(chunk, std::max<size_t>(bytes, 1)), hipHostMallocDefault));
+    int rc = MMGPU_OK;
+    for (size_t o = 0; o < bytes && rc == MMGPU_OK; o += chunk) {
+        const size_t m = std::min(chunk, bytes - o);
+        if (hipMemcpy(stage, static_cast<const uint8_t *>(dev) + o, m, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(MMGPU_ERR_HIP, "mmgpu_db_save: device read failed");
+        else if (fwrite(stage, 1, m, f) != m) rc = fail(MMGPU_ERR_ARG, "mmgpu_db_save: write failed (disk full?)");
+    }
+    (void)hipHostFree(stage);
+    return rc;
+}
+
+// file (mapped) -> device: host threads copy chunk j + 1 out of the page cache into one of two pinned buffers while the copy
+// engine moves chunk j
+static int upload_section(void *dev, const uint8_t *src, size_t bytes, hipStream_t up, uint8_t *stage[2], hipEvent_t moved[2], size_t chunk) {
+    for (size_t o = 0, j = 0; o < bytes; o += chunk, j++) {
+        const int k = (int)(j & 1);
+        const size_t m = std::min(chunk, bytes - o);
+        HIP_TRY(hipEventSynchronize(moved[k]));
+        uint8_t *dst = stage[k];
+        const uint8_t *from = src + o;
+        parallel_for(m, [&](size_t a, size_t b) { memcpy(dst + a, from + a, b - a); });
+        HIP_TRY(hipMemcpyAsync(static_cast<uint8_t *>(dev) + o, dst, m, hipMemcpyHostToDevice, up));
+        HIP_TRY(hipEventRecord(moved[k], up));
+    }
+    return MMGPU_OK;
+}
+
+}  // namespace
+
+extern "C" int mmgpu_db_save(mmgpu_ctx *c, const char *path, uint64_t source_fingerprint, uint64_t index_fingerprint) {
+    if (!c || !path) return fail(MMGPU_ERR_ARG, "mmgpu_db_save: NULL argument");
+    if (!c->db.res) return fail(MMGPU_ERR_STATE, "mmgpu_db_save: no targets loaded");
+    if (c->shard.on) return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_db_save: the context holds a shard of a multi-GPU run (save the unsplit database)");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const PfIndex *P = c->pf;
+    const bool with_index = P != nullptr && index_fingerprint != 0 && P->d_offsets.p && P->kbase == P->kalph;
+    DbFileHeader h;
+    memset(&h, 0, sizeof(h));
+    memcpy(h.magic, DB_MAGIC, 8);
+    h.version = 1;
+    h.header_bytes = (uint32_t)sizeof(h);
+    h.source_fp = source_fingerprint;
+    h.index_fp = with_index ? index_fingerprint : 0;
+    h.n = c->db.n;
+    h.alphabet = (uint32_t)c->db.alphabet;
+    h.max_len = c->db.max_len;
+    h.mean_len = c->mean_len;
+    h.total_residues = c->db.total_residues;
+    h.res_bytes = c->db.res_bytes;
+    h.has_masked = c->pf_masked_res ? 1u : 0u;
+    h.has_index = with_index ? 1u : 0u;
+    const size_t nn = std::max<uint32_t>(c->db.n, 1);
+    uint64_t at = align4k(sizeof(h));
+    h.at_off4 = at; at = align4k(at + nn * 4);
+    h.at_len = at; at = align4k(at + nn * 4);
+    h.at_res = at; at = align4k(at + h.res_bytes);
+    if (h.has_masked) { h.at_masked = at; at = align4k(at + h.res_bytes); }
+    if (with_index) {
+        h.k = P->k; h.spaced = P->spaced; h.kbase = P->kbase;
+        h.table = P->table; h.n_entries = P->n_entries;
+        h.at_offsets = at; at = align4k(at + (P->table + 1) * 4);
+        h.at_entries = at; at = align4k(at + std::max<uint64_t>(P->n_entries, 1) * 8);
+    }
+    h.file_bytes = at;
+    const std::string tmp = std::string(path) + ".tmp";
+    FILE *f = fopen(tmp.c_str(), "wb");
+    if (!f) return fail(MMGPU_ERR_ARG, std::string("mmgpu_db_save: cannot create ") + tmp);
+    int rc = MMGPU_OK;
+    if (fwrite(&h, sizeof(h), 1, f) != 1) rc = fail(MMGPU_ERR_ARG, "mmgpu_db_save: write failed");
+    if (rc == MMGPU_OK) rc = write_section(f, h.at_off4, c->db.off4, nn * 4);
+    if (rc == MMGPU_OK) rc = write_section(f, h.at_len, c->db.len, nn * 4);
+    if (rc == MMGPU_OK) rc = write_section(f, h.at_res, c->db.res, h.res_bytes);
+    if (rc == MMGPU_OK && h.has_masked) rc = write_section(f, h.at_masked, c->pf_masked_res, h.res_bytes);
+    if (rc == MMGPU_OK && with_index) rc = write_section(f, h.at_offsets, P->d_offsets.p, (P->table + 1) * 4);
+    if (rc == MMGPU_OK && with_index && P->n_entries) rc = write_section(f, h.at_entries, P->d_entries.p, P->n_entries * 8);
+    if (rc == MMGPU_OK && (ftruncate(fileno(f), (off_t)h.file_bytes) != 0)) rc = fail(MMGPU_ERR_ARG, "mmgpu_db_save: cannot size the file");
+    if (fclose(f) != 0 && rc == MMGPU_OK) rc = fail(MMGPU_ERR_ARG, "mmgpu_db_save: close failed");
+    if (rc == MMGPU_OK && rename(tmp.c_str(), path) != 0) rc = fail(MMGPU_ERR_ARG, std::string("mmgpu_db_save: cannot rename to ") + path);
+    if (rc != MMGPU_OK) (void)remove(tmp.c_str());
+    return rc;
+}
+
+static int db_read_header(const char *path, DbFileHeader *h, int *fd_out) {
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return fail(MMGPU_ERR_STATE, std::string("mmgpu_db: cannot open ") + path);
+    struct stat st;
+    const bool ok = read(fd, h, sizeof(*h)) == (ssize_t)sizeof(*h) && memcmp(h->magic, DB_MAGIC, 8) == 0 && h->version == 1 &&
+                    h->header_bytes == sizeof(*h) && fstat(fd, &st) == 0 && (uint64_t)st.st_size >= h->file_bytes &&
+                    h->at_res + h->res_bytes <= h->file_bytes && (!h->has_index || h->at_entries + h->n_entries * 8 <= h->file_bytes);
+    if (!ok) {
+        close(fd);
+        return fail(MMGPU_ERR_STATE, std::string("mmgpu_db: not a database file of this library version: ") + path);
+    }
+    if (fd_out) *fd_out = fd; else close(fd);
+    return MMGPU_OK;
+}
+
+extern "C" int mmgpu_db_probe(const char *path, mmgpu_db_info *info) {
+    if (!path || !info) return fail(MMGPU_ERR_ARG, "mmgpu_db_probe: NULL argument");
+    DbFileHeader h;
+    const int rc = db_read_header(path, &h, nullptr);
+    if (rc != MMGPU_OK) return rc;
+    memset(info, 0, sizeof(*info));
+    info->source_fingerprint = h.source_fp;
+    info->index_fingerprint = h.index_fp;
+    info->n_targets = h.n;
+    info->alphabet = h.alphabet;
+    info->total_residues = h.total_residues;
+    info->has_masked_view = (int32_t)h.has_masked;
+    info->has_index = (int32_t)h.has_index;
+    info->kmer_size = h.k;
+    info->spaced = h.spaced;
+    info->n_entries = h.n_entries;
+    info->file_bytes = h.file_bytes;
+    return MMGPU_OK;
+}
+
+extern "C" int mmgpu_db_load(mmgpu_ctx *c, const char *path, uint64_t source_fingerprint, uint64_t index_fingerprint, const mmgpu_pf_index *tables) {
+    if (!c || !path) return fail(MMGPU_ERR_ARG, "mmgpu_db_load: NULL argument");
+    DbFileHeader h;
+    int fd = -1;
+    int rc = db_read_header(path, &h, &fd);
+    if (rc != MMGPU_OK) return rc;
+    if (h.source_fp != source_fingerprint) { close(fd); return fail(MMGPU_ERR_STATE, "mmgpu_db_load: the file was made from another database (source fingerprint differs)"); }
+    const bool want_index = index_fingerprint != 0;
+    if (want_index && (!h.has_index || h.index_fp != index_fingerprint)) { close(fd); return fail(MMGPU_ERR_STATE, "mmgpu_db_load: the file holds no index built with these parameters (index fingerprint differs)"); }
+    if (want_index && !tables) { close(fd); return fail(MMGPU_ERR_ARG, "mmgpu_db_load: the index needs the caller's score tables"); }
+    if (want_index && (tables->kmer_size != h.k || tables->spaced != h.spaced || tables->alphabet != (int)h.alphabet)) { close(fd); return fail(MMGPU_ERR_STATE, "mmgpu_db_load: k-mer size / pattern / alphabet differ from the file's index"); }
+    const uint8_t *map = static_cast<const uint8_t *>(mmap(nullptr, (size_t)h.file_bytes, PROT_READ, MAP_PRIVATE, fd, 0));
+    close(fd);
+    if (map == MAP_FAILED) return fail(MMGPU_ERR_STATE, "mmgpu_db_load: cannot map the file");
+    (void)madvise(const_cast<uint8_t *>(map), (size_t)h.file_bytes, MADV_SEQUENTIAL);
+    struct Unmap { const uint8_t *p; size_t n; ~Unmap() { munmap(const_cast<uint8_t *>(p), n); } } unmap{map, (size_t)h.file_bytes};
+    HIP_TRY(hipSetDevice(c->device));
+    db_release(c);
+    const size_t nn = std::max<uint32_t>(h.n, 1);
+    DeviceDb db;
+    uint8_t *masked = nullptr;
+    uint8_t *stage[2] = {nullptr, nullptr};
+    hipEvent_t moved[2] = {nullptr, nullptr};
+    hipStream_t up = nullptr;
+    PfIndex *P = nullptr;
+    auto drop = [&]() {
+        for (int k = 0; k < 2; k++) {
+            if (stage[k]) (void)hipHostFree(stage[k]);
+            if (moved[k]) (void)hipEventDestroy(moved[k]);
+        }
+        if (up) (void)hipStreamDestroy(up);
+    };
+    auto undo = [&]() {
+        drop();
+        dev_free(db.res); dev_free(db.off4); dev_free(db.len);
+        if (masked) dev_free(masked);
+        delete P;
+    };
+#define L_TRY(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { undo(); return fail(MMGPU_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__)); } } while (0)
+#define L_RC(expr) do { const int r__ = (expr); if (r__ != MMGPU_OK) { undo(); return r__; } } while (0)
+    const size_t chunk = 32ull << 20;
+    L_TRY(hipStreamCreateWithFlags(&up, hipStreamNonBlocking));
+    for (int k = 0; k < 2; k++) {
+        L_TRY(hipHostMalloc((void **)&stage[k], chunk, hipHostMallocDefault));
+        L_TRY(hipEventCreateWithFlags(&moved[k], hipEventDisableTiming));
+    }
+    L_TRY(dev_malloc((void **)&db.res, (size_t)h.res_bytes));
+    L_TRY(dev_malloc((void **)&db.off4, nn * 4));
+    L_TRY(dev_malloc((void **)&db.len, nn * 4));
+    L_RC(upload_section(db.off4, map + h.at_off4, nn * 4, up, stage, moved, chunk));
+    L_RC(upload_section(db.len, map + h.at_len, nn * 4, up, stage, moved, chunk));
+    L_RC(upload_section(db.res, map + h.at_res, (size_t)h.res_bytes, up, stage, moved, chunk));
+    if (h.has_masked && want_index) {      // (the masked view serves the prefilter only: a caller that asks for the targets alone gets them alone)
+        L_TRY(dev_malloc((void **)&masked, (size_t)h.res_bytes));
+        L_RC(upload_section(masked, map + h.at_masked, (size_t)h.res_bytes, up, stage, moved, chunk));
+    }
+    db.n = h.n;
+    db.res_bytes = (size_t)h.res_bytes;
+    db.max_len = h.max_len;
+    db.total_residues = h.total_residues;
+    db.alphabet = (int)h.alphabet;
+    std::vector<uint32_t> hlen(map + h.at_len, map + h.at_len) ;
+    hlen.resize(h.n);
+    if (h.n) memcpy(hlen.data(), map + h.at_len, (size_t)h.n * 4);
+    L_TRY(hipStreamSynchronize(up));
+    // the context owns the database from here on (pf_setup checks the alphabet against it)
+    c->db = db;
+    db = DeviceDb();
+    c->pf_masked_res = masked;
+    masked = nullptr;
+    c->h_len.swap(hlen);
+    c->mean_len = h.mean_len;
+    if (want_index) {
+        int rc2 = pf_setup(c, tables, false, &P);
+        if (rc2 == MMGPU_OK && (P->table != h.table || P->kbase != h.kbase)) rc2 = fail(MMGPU_ERR_STATE, "mmgpu_db_load: k-mer table size differs from the file's index");
+        if (rc2 != MMGPU_OK) { drop(); delete P; db_release(c); return rc2; }
+        P->n_entries = h.n_entries;
+        hipError_t e = P->d_offsets.alloc((P->table + 1) * 4);
+        if (e == hipSuccess) e = P->d_entries.alloc(std::max<uint64_t>(P->n_entries, 1) * 8);
+        int rc3 = e == hipSuccess ? MMGPU_OK : fail(MMGPU_ERR_HIP, "mmgpu_db_load: out of device memory for the index");
+        if (rc3 == MMGPU_OK) rc3 = upload_section(P->d_offsets.p, map + h.at_offsets, (P->table + 1) * 4, up, stage, moved, chunk);
+        if (rc3 == MMGPU_OK && P->n_entries) rc3 = upload_section(P->d_entries.p, map + h.at_entries, P->n_entries * 8, up, stage, moved, chunk);
+        if (rc3 == MMGPU_OK && hipStreamSynchronize(up) != hipSuccess) rc3 = fail(MMGPU_ERR_HIP, "mmgpu_db_load: upload failed");
+        if (rc3 == MMGPU_OK && pf_index_bitmap(c, P) != hipSuccess) rc3 = fail(MMGPU_ERR_HIP, "mmgpu_db_load: bit table failed");
+        if (rc3 == MMGPU_OK && pf_index_cofs(c, P) != hipSuccess) rc3 = fail(MMGPU_ERR_HIP, "mmgpu_db_load: compact offset table failed");
+        if (rc3 != MMGPU_OK) { drop(); delete P; db_release(c); return rc3; }
+        c->pf = P;
+        P = nullptr;
+    }
+    drop();
+#undef L_TRY
+#undef L_RC
     return MMGPU_OK;
 }
 

@@ -410,6 +410,88 @@ int mmgpu_pf_build_index(mmgpu_ctx *c, const mmgpu_pf_index *ix, const int16_t *
     return mmgpu_pf_load_index(c, &full);
 }
 
+// persisted layout (include/mmgpu.h "persisted device layout"): the emulation writes what it holds in a format of its own - the
+// hooks' logic around the calls (fingerprints, fall-back to building, save after a build) is what the CPU tests exercise
+struct EmuDbHeader {
+    char magic[8];
+    uint64_t source_fp, index_fp, n, alphabet, res_bytes, masked_bytes, table, n_entries;
+    int32_t k, spaced, kalph, kbase;
+};
+int mmgpu_db_save(mmgpu_ctx *c, const char *path, uint64_t sfp, uint64_t ifp) {
+    if (c->n == 0) return fail(MMGPU_ERR_STATE, "no targets");
+    EmuDbHeader h;
+    memset(&h, 0, sizeof(h));
+    memcpy(h.magic, "MMGPUEMU", 8);
+    const bool idx = ifp != 0 && c->have_index && c->kbase == c->kalph;
+    h.source_fp = sfp; h.index_fp = idx ? ifp : 0; h.n = c->n; h.alphabet = (uint64_t)c->alphabet;
+    h.res_bytes = c->tres.size(); h.masked_bytes = c->pf_tres.size();
+    if (idx) { h.table = c->offsets.size(); h.n_entries = c->ids.size(); h.k = c->k; h.spaced = c->spaced; h.kalph = c->kalph; h.kbase = c->kbase; }
+    FILE *f = fopen(path, "wb");
+    if (!f) return fail(MMGPU_ERR_ARG, "cannot create the file");
+    bool ok = fwrite(&h, sizeof(h), 1, f) == 1 && fwrite(c->toff.data(), 8, c->n + 1, f) == c->n + 1 &&
+              (c->tres.empty() || fwrite(c->tres.data(), 1, c->tres.size(), f) == c->tres.size()) &&
+              (c->pf_tres.empty() || fwrite(c->pf_tres.data(), 1, c->pf_tres.size(), f) == c->pf_tres.size());
+    if (ok && idx)
+        ok = fwrite(c->offsets.data(), 8, c->offsets.size(), f) == c->offsets.size() &&
+             (c->ids.empty() || (fwrite(c->ids.data(), 4, c->ids.size(), f) == c->ids.size() && fwrite(c->pos.data(), 2, c->pos.size(), f) == c->pos.size()));
+    ok = fclose(f) == 0 && ok;
+    return ok ? 0 : fail(MMGPU_ERR_ARG, "write failed");
+}
+static int emu_read_header(const char *path, EmuDbHeader *h, FILE **out) {
+    FILE *f = fopen(path, "rb");
+    if (!f) return fail(MMGPU_ERR_STATE, "no such file");
+    if (fread(h, sizeof(*h), 1, f) != 1 || memcmp(h->magic, "MMGPUEMU", 8) != 0) {
+        fclose(f);
+        return fail(MMGPU_ERR_STATE, "not a database file of the emulation");
+    }
+    if (out) *out = f; else fclose(f);
+    return 0;
+}
+int mmgpu_db_probe(const char *path, mmgpu_db_info *info) {
+    EmuDbHeader h;
+    const int rc = emu_read_header(path, &h, NULL);
+    if (rc != 0) return rc;
+    memset(info, 0, sizeof(*info));
+    info->source_fingerprint = h.source_fp; info->index_fingerprint = h.index_fp; info->n_targets = (uint32_t)h.n;
+    info->alphabet = (uint32_t)h.alphabet; info->total_residues = h.res_bytes; info->has_masked_view = h.masked_bytes != 0;
+    info->has_index = h.index_fp != 0; info->kmer_size = h.k; info->spaced = h.spaced; info->n_entries = h.n_entries;
+    return 0;
+}
+int mmgpu_db_load(mmgpu_ctx *c, const char *path, uint64_t sfp, uint64_t ifp, const mmgpu_pf_index *tables) {
+    EmuDbHeader h;
+    FILE *f = NULL;
+    const int rc = emu_read_header(path, &h, &f);
+    if (rc != 0) return rc;
+    if (h.source_fp != sfp || (ifp != 0 && h.index_fp != ifp) || (ifp != 0 && !tables)) {
+        fclose(f);
+        return fail(MMGPU_ERR_STATE, "fingerprint differs");
+    }
+    std::vector<uint64_t> toff(h.n + 1), offsets(ifp ? h.table : 0);
+    std::vector<uint8_t> tres(h.res_bytes), masked(h.masked_bytes);
+    std::vector<uint32_t> ids(ifp ? h.n_entries : 0);
+    std::vector<uint16_t> pos(ifp ? h.n_entries : 0);
+    bool ok = fread(toff.data(), 8, h.n + 1, f) == h.n + 1 && (tres.empty() || fread(tres.data(), 1, tres.size(), f) == tres.size()) &&
+              (masked.empty() || fread(masked.data(), 1, masked.size(), f) == masked.size());
+    if (ok && ifp)
+        ok = fread(offsets.data(), 8, offsets.size(), f) == offsets.size() &&
+             (ids.empty() || (fread(ids.data(), 4, ids.size(), f) == ids.size() && fread(pos.data(), 2, pos.size(), f) == pos.size()));
+    fclose(f);
+    if (!ok) return fail(MMGPU_ERR_STATE, "short file");
+    mmgpu_load_targets(c, tres.data(), toff.data(), (uint32_t)h.n, (int)h.alphabet);
+    if (ifp) {
+        c->pf_tres.swap(masked);
+        mmgpu_pf_index full = *tables;
+        full.offsets = offsets.data();
+        full.entry_ids = ids.data();
+        full.entry_pos = pos.data();
+        full.entries6 = NULL;
+        full.n_entries = h.n_entries;
+        full.kmer_alphabet = 0;
+        return mmgpu_pf_load_index(c, &full);
+    }
+    return 0;
+}
+
 int mmgpu_pf_prepare(mmgpu_ctx *c, const mmgpu_pf_params *p, const mmgpu_pf_query *qs, uint32_t nq, mmgpu_pf_batch_t **out) {
     if (!c->have_index) return fail(MMGPU_ERR_STATE, "no index");
     // test knob: behave like a device whose memory holds at most this many queries per batch (the host must cut the block)

@@ -1,0 +1,79 @@
+"""Persisted device layout (include/mmgpu.h mmgpu_db_save / mmgpu_db_probe / mmgpu_db_load): a context
+brought back from the file answers prefilter and alignment calls exactly like the context the file was written from, a file of
+another database or with other index parameters is refused (the caller builds as ever), and the header can be read without a
+device."""
+import numpy as np
+import pytest
+
+from mmseqs2_amd import capi, workloads as wl
+from tests import pf_common as pc
+
+
+def test_probe_refuses_what_is_not_a_database_file(tmp_path):
+    assert capi.db_probe(tmp_path / "missing.mmgpu") is None
+    junk = tmp_path / "junk.mmgpu"
+    junk.write_bytes(b"MMGPUDB1" + b"\0" * 100)
+    assert capi.db_probe(junk) is None
+
+
+@pytest.mark.gpu
+def test_saved_database_answers_like_the_resident_one(gpu, matrices, oracle, tmp_path):
+    import mmseqs2_amd
+    g = pc.golden()
+    km16, um8 = g["vtml80_kmer16"], g["blosum62_ungapped"]
+    thr = int(g["kmer_thr"])
+    tv = np.load(pc.GOLDEN + "/tantan_vectors.npz")
+    s3, i3 = capi.host_score_matrix(km16, 3, lib=gpu.L)
+    gpu.load_targets(g["tres"], g["toff"], 21)
+    n_masked = gpu.pf_mask_targets(tv["vtml80_likelihood_ratios"], float(tv["mask_prob"]), 20)
+    gpu.pf_build_index(6, 21, True, s3, i3, km16, thr, um8)
+    qs = pc.golden_queries(g)
+    for qd in qs:
+        qd["identity_id"] = None
+    hits_a, counts_a, status_a, _ = gpu.pf_batch(qs, thr, max_hits=300, ref_bins=2)
+    off_a, ids_a, pos_a = gpu.pf_debug_index(6, 21)
+    path = tmp_path / "golden.mmgpu"
+    gpu.db_save(path, source_fp=0x1234, index_fp=0x77)
+    info = capi.db_probe(path, gpu.L)
+    assert info is not None and info["n_targets"] == len(g["toff"]) - 1 and info["has_index"] == 1 and info["kmer_size"] == 6
+    assert info["has_masked_view"] == (1 if n_masked >= 0 else 0) and info["source_fingerprint"] == 0x1234 and info["index_fingerprint"] == 0x77
+    assert info["n_entries"] == len(ids_a) and info["total_residues"] == int(g["toff"][-1])
+
+    other = mmseqs2_amd.MMGpu(0)
+    try:
+        # another database / other index parameters: refused, the context stays as it was (empty)
+        assert other.db_load(path, 0x9999, 0x77, 6, 21, True, s3, i3, um8) is False
+        assert other.db_load(path, 0x1234, 0x78, 6, 21, True, s3, i3, um8) is False
+        assert other.db_load(tmp_path / "missing.mmgpu", 0x1234, 0x77, 6, 21, True, s3, i3, um8) is False
+        # the real thing: no sequence handed over, no masking, no index build
+        assert other.db_load(path, 0x1234, 0x77, 6, 21, True, s3, i3, um8) is True
+        off_b, ids_b, pos_b = other.pf_debug_index(6, 21)
+        assert np.array_equal(off_a, off_b) and np.array_equal(ids_a, ids_b) and np.array_equal(pos_a, pos_b)
+        assert np.array_equal(other.pf_debug_masked_targets(g["toff"]), gpu.pf_debug_masked_targets(g["toff"]))
+        hits_b, counts_b, status_b, _ = other.pf_batch(qs, thr, max_hits=300, ref_bins=2)
+        assert np.array_equal(counts_a, counts_b) and np.array_equal(status_a, status_b)
+        for qi in range(len(qs)):
+            n = int(counts_a[qi])
+            assert np.array_equal(hits_a[qi][:n], hits_b[qi][:n])
+        # the alignment kernels read the UNMASKED residues of the file
+        mat = matrices["blosum62_sw"]
+        q = qs[0]["q"]
+        ids = np.arange(40, dtype=np.uint32)
+        sw_q = [dict(q=q, comp_bias=None, targets=ids, min_start_score=0)]
+        a = gpu.sw_batch(mat, 11, 1, sw_q, mode=1)
+        b = other.sw_batch(mat, 11, 1, sw_q, mode=1)
+        assert np.array_equal(a, b)
+        tl = wl.split(g["tres"], g["toff"])
+        for k in (0, 7, 39):
+            r = oracle.sw_align(q, None, tl[k], mat, 11, 1, need_start=True)
+            assert (int(b[k]["score"]), int(b[k]["q_end"]), int(b[k]["t_end"])) == (r["score"], r["q_end"], r["t_end"])
+        # targets only (what an alignment module asks for): no index afterwards
+        assert other.db_load(path, 0x1234, 0) is True
+        assert np.array_equal(other.sw_batch(mat, 11, 1, sw_q, mode=1), a)
+        with pytest.raises(capi.MMGpuError):
+            other.pf_batch(qs[:1], thr, max_hits=300, ref_bins=2)
+    finally:
+        other.close()
+    # restore the module's golden case for the tests that follow
+    from tests import pf_gpu_check as chk
+    chk.load_case(gpu, g, g["tres"], g["toff"], thr)

@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 C_STRUCTS = [("mmgpu_sw_params", capi.SwParams), ("mmgpu_sw_query", capi.SwQuery), ("mmgpu_nucl_params", capi.NuclParams),
              ("mmgpu_nucl_query", capi.NuclQuery), ("mmgpu_pf_index", capi.PfIndexDesc), ("mmgpu_pf_params", capi.PfParams),
-             ("mmgpu_pf_query", capi.PfQuery), ("mmgpu_pf_shard", capi.PfShard),
+             ("mmgpu_pf_query", capi.PfQuery), ("mmgpu_pf_shard", capi.PfShard), ("mmgpu_db_info", capi.DbInfo),
              ("mmo_pf_gen", po.PfGen), ("mmo_pf_params", po.PfParams), ("mmo_pf_stats", po.PfStats), ("mmo_pf_profile", po.PfProfile),
              ("mmo_ksw_ez", po.KswEz), ("mmo_nucl_result", po.NuclRes)]
 C_RECORDS = [("mmgpu_sw_hit", capi.SW_HIT_DTYPE), ("mmgpu_pf_hit", capi.PF_HIT_DTYPE), ("mmgpu_nucl_pair", capi.NUCL_PAIR_DTYPE),
@@ -24,7 +24,7 @@ C_RECORDS = [("mmgpu_sw_hit", capi.SW_HIT_DTYPE), ("mmgpu_pf_hit", capi.PF_HIT_D
 # (a field that fits into tail padding does not change the size: the last fields are compared by offset as well)
 LAST_FIELDS = [("mmgpu_nucl_params", capi.NuclParams, "wrapped"), ("mmgpu_pf_index", capi.PfIndexDesc, "kmer_alphabet"),
                ("mmgpu_pf_params", capi.PfParams, "kmer_score"), ("mmo_pf_params", po.PfParams, "index_base"),
-               ("mmgpu_sw_query", capi.SwQuery, None), ("mmgpu_pf_query", capi.PfQuery, None)]
+               ("mmgpu_sw_query", capi.SwQuery, None), ("mmgpu_pf_query", capi.PfQuery, None), ("mmgpu_db_info", capi.DbInfo, "file_bytes")]
 
 
 def test_ctypes_mirrors_have_the_c_sizes(tmp_path):
