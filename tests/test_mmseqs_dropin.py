@@ -131,6 +131,38 @@ def test_examples_prefilter_align_host_side_emulated(tmp_path):
     examples_pipeline(tmp_path, emulate=True)
 
 
+def persisted_layout_pipeline(tmp, emulate):
+    """MMGPU_DB_FILE (the reference's makepaddedseqdb / createindex as one file in the device layout): the first prefilter run
+    builds and saves, the second loads - no upload of the lookup, no masking, no index build - and writes the same database; a
+    run with other index parameters refuses the file, builds, and replaces it."""
+    w = str(tmp)
+    copy_db(EXAMPLES, os.path.join(w, "q"))
+    run(STOCK, ["prefilter", "q", "q", "pref_s", "-s", "5.7", "--threads", THREADS, "-v", "2"], w)
+    env = {"MMGPU_DB_FILE": os.path.join(w, "q.mmgpu")}
+    log = run(MMGPU, ["prefilter", "q", "q", "pref_g1", "-s", "5.7", "--threads", THREADS, "-v", "3"], w, emulate, extra_env=env)
+    assert "not usable" in log and "device layout saved to" in log, log[-2000:]
+    assert os.path.getsize(env["MMGPU_DB_FILE"]) > 100000
+    log = run(MMGPU, ["prefilter", "q", "q", "pref_g2", "-s", "5.7", "--threads", THREADS, "-v", "3"], w, emulate, extra_env=env)
+    assert "k-mer index loaded from" in log and "device layout saved to" not in log, log[-2000:]
+    assert same(os.path.join(w, "pref_s"), os.path.join(w, "pref_g1")) == 500
+    assert same(os.path.join(w, "pref_s"), os.path.join(w, "pref_g2")) == 500
+    # another sensitivity = another k-mer threshold of the index: the file is refused, the run builds its own and saves it
+    run(STOCK, ["prefilter", "q", "q", "pref_s4", "-s", "4", "--threads", THREADS, "-v", "2"], w)
+    log = run(MMGPU, ["prefilter", "q", "q", "pref_g4", "-s", "4", "--threads", THREADS, "-v", "3"], w, emulate, extra_env=env)
+    assert same(os.path.join(w, "pref_s4"), os.path.join(w, "pref_g4")) == 500
+
+
+def test_persisted_device_layout_host_side_emulated(tmp_path):
+    if not os.path.exists(EMU):
+        pytest.skip("oracle/_build/emu/libmmgpu.so not built (make -C oracle emu)")
+    persisted_layout_pipeline(tmp_path, emulate=True)
+
+
+@pytest.mark.gpu
+def test_persisted_device_layout_on_device(tmp_path):
+    persisted_layout_pipeline(tmp_path, emulate=False)
+
+
 def test_disabled_binary_is_the_stock_path(tmp_path):
     """MMGPU_DISABLE=1: the patched binary must take the reference's own loops (and needs no device)"""
     w = str(tmp_path)
