@@ -739,6 +739,9 @@ def search_headline(args, gpu, torch, dist, rank, world, matrices, barrier, devi
                                     "first_tier_512_rows_lds": int(tier1), "second_tier_4096_rows": int(tier2),
                                     "rescored_sample": int(len(sample)), "rescored_equal": int(resc_ok), "s_c_abi_calls_incl_download": round(getattr(swb, "last_block_call_s", t_blk), 4),
                                     "s_incl_python_binding": round(t_blk, 4),
+                                    "pinned_against": "the C restatement oracle/block_oracle.c, which passes the 23 unit-test vectors parsed from the Rust "
+                                                      "crate's own source (tests/golden/block_crate_vectors.json); NOT pinned against a Rust-linked build "
+                                                      "(no cargo in this image: scripts/make_block_goldens.sh is the recipe)",
                                     "what": "mmgpu_sw_block_backtrace over every word == 1 pair of the hit lists that has a start position "
                                             "(score passes -e 1e-3); device = answered by block_kernel.hip, declined = 'Block alignment "
                                             "failed' (the reference falls back too), too_large = left to the host (must be 0); "

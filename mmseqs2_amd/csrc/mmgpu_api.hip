@@ -150,9 +150,9 @@ extern "C" int mmgpu_load_targets(mmgpu_ctx *c, const uint8_t *residues, const u
         if (up) (void)hipStreamDestroy(up);
     };
 #define DB_TRY(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { drop(); free_db(db); return fail(MMGPU_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__)); } } while (0)
-    DB_TRY(dev_malloc((void **)&db.res, bytes));
-    DB_TRY(dev_malloc((void **)&db.off4, off4.size() * sizeof(uint32_t)));
-    DB_TRY(dev_malloc((void **)&db.len, len.size() * sizeof(uint32_t)));
+    DB_TRY(dev_malloc_ctx(c, (void **)&db.res, bytes));
+    DB_TRY(dev_malloc_ctx(c, (void **)&db.off4, off4.size() * sizeof(uint32_t)));
+    DB_TRY(dev_malloc_ctx(c, (void **)&db.len, len.size() * sizeof(uint32_t)));
     DB_TRY(hipStreamCreateWithFlags(&up, hipStreamNonBlocking));
     DB_TRY(hipMemsetAsync(db.res, alphabet, bytes, up));
     DB_TRY(hipMemcpyAsync(db.off4, off4.data(), off4.size() * sizeof(uint32_t), hipMemcpyHostToDevice, up));
@@ -269,7 +269,7 @@ extern "C" int mmgpu_pf_mask_targets(mmgpu_ctx *c, const double *likelihood_rati
     mmgpu::pf_index_free(c);      // an index built from the unmasked residues does not describe the masked ones
     hipStream_t s = c->stream;
     const uint32_t n = c->db.n;
-    if (!c->pf_masked_res) HIP_TRY(dev_malloc((void **)&c->pf_masked_res, c->db.res_bytes));
+    if (!c->pf_masked_res) HIP_TRY(dev_malloc_ctx(c, (void **)&c->pf_masked_res, c->db.res_bytes));
     HIP_TRY(hipMemcpyAsync(c->pf_masked_res, c->db.res, c->db.res_bytes, hipMemcpyDeviceToDevice, s));
     // targets in order of length (longest first): 64 consecutive ones share a wavefront and end together; counting sort
     std::vector<uint32_t> order(std::max<uint32_t>(n, 1));

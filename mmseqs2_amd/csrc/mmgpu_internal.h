@@ -165,7 +165,7 @@ struct PfKmerArgs {
     const uint32_t *i3;        // [n3][n3] ScoreMatrix::index
     const uint32_t *offsets;   // IndexTable::offsets, [kalph^k + 1]
     const uint32_t *nonempty;  // one bit per k-mer: list not empty (null: not used, the index is dense)
-    const uint4 *cofs;         // compact offset table (pf_kernels.hip: 32-byte blocks of 28 k-mers), null = look-ups read `offsets`
+    const uint4 *cofs;         // compact offset table (pf_kernels.hip: 16-byte blocks of 12 k-mers), null = look-ups read `offsets`
     const uint16_t *cum3;      // [n3][cum_w]: cum3[row][k] = number of entries of the row with score >= score_min + k
     uint32_t cum_w;
     int32_t score_min;
@@ -568,13 +568,33 @@ struct DeviceArena {
     std::vector<Chunk> chunks;
     std::map<uint8_t *, size_t> live;                   // carved pieces in use
     std::multimap<size_t, uint8_t *> freed;             // pieces given back, by size
+    static std::mutex &registry_lock() { static std::mutex m; return m; }
+    static std::map<int, DeviceArena *> &registry() { static std::map<int, DeviceArena *> all; return all; }
     static DeviceArena &of(int device) {
-        static std::mutex m;
-        static std::map<int, DeviceArena *> all;
-        std::lock_guard<std::mutex> g(m);
-        DeviceArena *&a = all[device];
+        std::lock_guard<std::mutex> g(registry_lock());
+        DeviceArena *&a = registry()[device];
         if (!a) a = new DeviceArena();
         return *a;
+    }
+    // the arena a pointer was carved from, whatever device is current on the calling thread (a free may be issued while another
+    // device is current: multi-context destroy, a helper thread); null = not an arena pointer
+    static DeviceArena *owner_of(const void *p) {
+        std::vector<DeviceArena *> all;
+        {
+            std::lock_guard<std::mutex> g(registry_lock());
+            for (auto &kv : registry()) all.push_back(kv.second);
+        }
+        for (DeviceArena *a : all)
+            if (a->n_chunks.load() > 0 && a->inside(p)) return a;
+        return nullptr;
+    }
+    // p lies inside one of the reserved chunks (carved piece or not)
+    bool inside(const void *p) {
+        std::lock_guard<std::mutex> g(lock);
+        const uint8_t *q = static_cast<const uint8_t *>(p);
+        for (const Chunk &c : chunks)
+            if (q >= c.base && q < c.base + c.size) return true;
+        return false;
     }
     void add(void *base, size_t size) {
         std::lock_guard<std::mutex> g(lock);
@@ -634,14 +654,10 @@ inline hipError_t dev_malloc(void **p, size_t n) {
 }
 inline void dev_free(void *p) {
     if (!p) return;
-    int device = 0;
-    if (hipGetDevice(&device) == hipSuccess) {
-        DeviceArena &a = DeviceArena::of(device);
-        if (a.n_chunks.load() > 0 && a.owns(p)) {
-            (void)hipDeviceSynchronize();      // hipFree's guarantee: nothing in flight reads the block any more
-            (void)a.give(p);
-            return;
-        }
+    if (DeviceArena *a = DeviceArena::owner_of(p)) {      // (never hipFree a pointer into a reserved chunk, whichever device is current)
+        (void)hipDeviceSynchronize();      // hipFree's guarantee: nothing in flight reads the block any more
+        (void)a->give(p);
+        return;
     }
     (void)hipFree(p);
 }
@@ -655,7 +671,15 @@ struct BlockCache {
     size_t cached = 0;
     bool closed = false;   // the context is gone (batches may outlive it): blocks go straight back to the runtime
     std::mutex lock;       // a prefilter thread and an alignment thread may work on one context (the fused search of the drop-in)
-    static constexpr size_t LIMIT = 96ull << 30;     // (of 288 GB; an allocation that fails trims the cache and retries)
+    // a third of the device's memory (96 GB of 288), read once; an allocation that fails trims the cache and retries
+    static size_t limit() {
+        static const size_t v = []() -> size_t {
+            size_t f = 0, t = 0;
+            if (hipMemGetInfo(&f, &t) != hipSuccess || t == 0) return (size_t)16 << 30;
+            return t / 3;
+        }();
+        return v;
+    }
     static size_t round_up(size_t n) {
         if (n <= 512) return 512;
         int top = 63 - __builtin_clzll((unsigned long long)n);
@@ -676,7 +700,7 @@ struct BlockCache {
     }
     void give(void *p, size_t cap) {
         std::lock_guard<std::mutex> guard(lock);
-        if (closed || cached + cap > LIMIT) { dev_free(p); return; }
+        if (closed || cached + cap > limit()) { dev_free(p); return; }
         blocks.emplace(cap, p);
         cached += cap;
     }
@@ -797,6 +821,18 @@ struct mmgpu_ctx {
     hipStream_t side[4] = {};      // (SW_GROUPS of them are used)
     hipEvent_t fork = nullptr, join[4] = {};
 };
+
+// device memory for a context's long-lived buffers (targets, masked view): when the runtime is out of memory the blocks the
+// context's own cache has parked go back first (DevBuf::alloc does the same for batch buffers)
+inline hipError_t dev_malloc_ctx(mmgpu_ctx *c, void **p, size_t n) {
+    hipError_t e = mmgpu::dev_malloc(p, n);
+    if (e != hipSuccess && c && c->cache) {
+        (void)hipGetLastError();
+        c->cache->trim();
+        e = mmgpu::dev_malloc(p, n);
+    }
+    return e;
+}
 
 struct mmgpu_pf_batch_t;
 struct mmgpu_sw_batch_t;

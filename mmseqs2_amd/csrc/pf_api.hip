@@ -1799,14 +1799,14 @@ extern "C" int mmgpu_db_load(mmgpu_ctx *c, const char *path, uint64_t source_fin
         L_TRY(hipHostMalloc((void **)&stage[k], chunk, hipHostMallocDefault));
         L_TRY(hipEventCreateWithFlags(&moved[k], hipEventDisableTiming));
     }
-    L_TRY(dev_malloc((void **)&db.res, (size_t)h.res_bytes));
-    L_TRY(dev_malloc((void **)&db.off4, nn * 4));
-    L_TRY(dev_malloc((void **)&db.len, nn * 4));
+    L_TRY(dev_malloc_ctx(c, (void **)&db.res, (size_t)h.res_bytes));
+    L_TRY(dev_malloc_ctx(c, (void **)&db.off4, nn * 4));
+    L_TRY(dev_malloc_ctx(c, (void **)&db.len, nn * 4));
     L_RC(upload_section(db.off4, map + h.at_off4, nn * 4, up, stage, moved, chunk));
     L_RC(upload_section(db.len, map + h.at_len, nn * 4, up, stage, moved, chunk));
     L_RC(upload_section(db.res, map + h.at_res, (size_t)h.res_bytes, up, stage, moved, chunk));
     if (h.has_masked && want_index) {      // (the masked view serves the prefilter only: a caller that asks for the targets alone gets them alone)
-        L_TRY(dev_malloc((void **)&masked, (size_t)h.res_bytes));
+        L_TRY(dev_malloc_ctx(c, (void **)&masked, (size_t)h.res_bytes));
         L_RC(upload_section(masked, map + h.at_masked, (size_t)h.res_bytes, up, stage, moved, chunk));
     }
     db.n = h.n;

@@ -151,23 +151,30 @@ __device__ __forceinline__ uint32_t xcd_contiguous(uint32_t bid, uint32_t nwg) {
 // (the work order of the similar-k-mer kernels - PfKmerArgs::order - is built in pf_order.hip)
 
 // ---------------------------------------------------------------------------------------------------------
-// Compact offset table (round 5): 32-byte blocks of 28 k-mers, { uint32 base = offsets[28 blk], 28 x uint8 list length }.  One
-// aligned 32-byte request answers (start, length); 1.14 bytes per k-mer instead of 4 - what matters is the footprint of a work
-// group's look-ups (above): a stretch of 8000 k-mers is 9 KB instead of 32 KB, ~100 stretches per 3-mer group fit an XCD's L2
-// several groups over.  A block with a list of 255 entries or more has bit 31 of its base set: its k-mers are answered by the full
-// table (databases of 2^31 index entries or more keep to the full table altogether, pf_api.hip).
-constexpr uint32_t PF_COFS_KMERS = 28;
+// Compact offset table (round 5): blocks of { uint32 base = offsets[first k-mer of the block], one uint8 list length per k-mer }.
+// One aligned request answers (start, length); what matters is the footprint of a work group's look-ups (pf_order.hip): a stretch
+// of 8000 k-mers is ~10 KB instead of 32 KB, ~90 stretches per 3-mer group fit an XCD's L2 several groups over.  A block with a
+// list of 255 entries or more has bit 31 of its base set: its k-mers are answered by the full table (databases of 2^31 index
+// entries or more keep to the full table altogether, pf_api.hip).  Block size: 16 bytes = base + 12 lengths - ONE dwordx4 load
+// per look-up (a wavefront's 64 look-ups are 64 different lines: the address unit takes a clock per lane and instruction, so the
+// 32-byte form - base + 28 lengths, two loads, MMGPU_PF_COFS32 - pays that twice for 15 % less footprint;
+// profiles/r05_exp_pf_cofs_block.txt).
+#ifdef MMGPU_PF_COFS32
+constexpr uint32_t PF_COFS_KMERS = 28, PF_COFS_DWORDS = 8;
+#else
+constexpr uint32_t PF_COFS_KMERS = 12, PF_COFS_DWORDS = 4;
+#endif
 
-__global__ __launch_bounds__(256) void pf_cofs_kernel(const uint32_t *offsets, uint64_t table, uint4 *cofs) {
+__global__ __launch_bounds__(256) void pf_cofs_kernel(const uint32_t *offsets, uint64_t table, uint32_t *cofs) {
     const uint64_t blk = (uint64_t)blockIdx.x * 256u + threadIdx.x;
     const uint64_t k0 = blk * PF_COFS_KMERS;
     if (k0 >= table) return;
-    uint32_t w[8];
+    uint32_t w[PF_COFS_DWORDS];
     const uint32_t base = offsets[k0];
     bool big = false;
     uint32_t prev = base;
 #pragma unroll
-    for (int d = 1; d < 8; d++) w[d] = 0;
+    for (uint32_t d = 1; d < PF_COFS_DWORDS; d++) w[d] = 0;
 #pragma unroll
     for (uint32_t r = 0; r < PF_COFS_KMERS; r++) {
         uint32_t n = 0;
@@ -180,8 +187,8 @@ __global__ __launch_bounds__(256) void pf_cofs_kernel(const uint32_t *offsets, u
         w[1 + (r >> 2)] |= (n & 0xFFu) << ((r & 3u) * 8u);
     }
     w[0] = base | (big ? 0x80000000u : 0u);
-    cofs[2 * blk] = make_uint4(w[0], w[1], w[2], w[3]);
-    cofs[2 * blk + 1] = make_uint4(w[4], w[5], w[6], w[7]);
+#pragma unroll
+    for (uint32_t d = 0; d < PF_COFS_DWORDS; d++) cofs[blk * PF_COFS_DWORDS + d] = w[d];
 }
 
 // A list record is written once and read once, by the split kernel, after every record of the batch has been written: stored
@@ -202,18 +209,25 @@ __device__ __forceinline__ void pf_store_list(PfList *dst, uint32_t start, uint3
 __device__ __forceinline__ void pf_lookup(const PfKmerArgs &A, uint32_t kmer, uint32_t &start, uint32_t &len) {
     if (A.cofs) {
         const uint32_t blk = kmer / PF_COFS_KMERS, r = kmer - blk * PF_COFS_KMERS;
-        const uint4 lo = A.cofs[2 * blk], hi = A.cofs[2 * blk + 1];
-        if (!(lo.x >> 31)) {
-            const uint32_t w[7] = {lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        uint32_t base, w[PF_COFS_DWORDS - 1];
+        {
+            const uint4 lo = A.cofs[(size_t)blk * (PF_COFS_DWORDS / 4)];
+            base = lo.x; w[0] = lo.y; w[1] = lo.z; w[2] = lo.w;
+#ifdef MMGPU_PF_COFS32
+            const uint4 hi = A.cofs[(size_t)blk * 2 + 1];
+            w[3] = hi.x; w[4] = hi.y; w[5] = hi.z; w[6] = hi.w;
+#endif
+        }
+        if (!(base >> 31)) {
             uint32_t sum = 0, word = 0;
 #pragma unroll
-            for (int d = 0; d < 7; d++) {
+            for (int d = 0; d < (int)PF_COFS_DWORDS - 1; d++) {
                 const int rel = (int)r - 4 * d;      // bytes of this dword that lie before the k-mer's own
                 const uint32_t mask = rel >= 4 ? 0xFFFFFFFFu : (rel <= 0 ? 0u : (1u << (8 * rel)) - 1u);
                 sum = __builtin_amdgcn_sad_u8(w[d] & mask, 0u, sum);
                 word = (rel >= 0 && rel < 4) ? w[d] : word;
             }
-            start = lo.x + sum;
+            start = base + sum;
             len = (word >> ((r & 3u) * 8u)) & 0xFFu;
             return;
         }
@@ -2274,12 +2288,12 @@ __global__ __launch_bounds__(256) void pf_merge_kernel(PfMergeArgs A) {
 
 }  // namespace
 
-// cofs: 2 x uint4 per block of PF_COFS_KMERS k-mers, ceil(table / PF_COFS_KMERS) blocks
-size_t pf_cofs_bytes(uint64_t table) { return (size_t)((table + PF_COFS_KMERS - 1) / PF_COFS_KMERS) * 32; }
+// cofs: PF_COFS_DWORDS dwords per block of PF_COFS_KMERS k-mers, ceil(table / PF_COFS_KMERS) blocks
+size_t pf_cofs_bytes(uint64_t table) { return (size_t)((table + PF_COFS_KMERS - 1) / PF_COFS_KMERS) * PF_COFS_DWORDS * 4; }
 hipError_t launch_pf_cofs(const uint32_t *offsets, uint64_t table, void *cofs, hipStream_t s) {
     if (table == 0) return hipSuccess;
     const uint64_t blocks = (table + PF_COFS_KMERS - 1) / PF_COFS_KMERS;
-    hipLaunchKernelGGL(pf_cofs_kernel, dim3((unsigned)((blocks + 255) / 256)), dim3(256), 0, s, offsets, table, reinterpret_cast<uint4 *>(cofs));
+    hipLaunchKernelGGL(pf_cofs_kernel, dim3((unsigned)((blocks + 255) / 256)), dim3(256), 0, s, offsets, table, reinterpret_cast<uint32_t *>(cofs));
     return hipGetLastError();
 }
 

@@ -10,4 +10,4 @@ m = dict(np.load(os.path.join(ROOT, "tests", "golden", "matrices.npz")))
 gpu = mmseqs2_amd.MMGpu(0)
 a = argparse.Namespace(nucl_contigs=int(sys.argv[1]) if len(sys.argv) > 1 else 4000, nucl_reads=int(sys.argv[2]) if len(sys.argv) > 2 else 1000,
                        nucl_read_len=10000, no_cpu_baseline=False)
-print(json.dumps(bench.nucl_search_section(a, gpu, m), indent=1))
+print(json.dumps(bench.nucl_search_section(a, gpu, m, a.nucl_contigs, False), indent=1))

@@ -1,4 +1,4 @@
-"""The bench line the driver parses: the committed line of this round (profiles/r03_bench_n1.json, produced by
+"""The bench line the driver parses: the committed line of this round (profiles/r05_bench_n1.json, produced by
 `python bench.py` on the GPU box) must carry the contract's keys, be quoted on BASELINE.json's metric configuration (10k
 queries x 1M targets), and its CPU-baseline legs - which double as full-size parity checks against the real reference -
 must have found no difference."""
@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _line():
-    return json.loads(open(os.path.join(ROOT, "profiles", "r03_bench_n1.json")).read())
+    return json.loads(open(os.path.join(ROOT, "profiles", "r05_bench_n1.json")).read())
 
 
 def test_committed_bench_line_has_the_contract_keys():
@@ -42,6 +42,17 @@ def test_committed_bench_line_has_the_contract_keys():
     assert d["nucleotide_align"]["cpu_baseline"]["parity_vs_reference"]["pairs_differing"] == 0
     assert d["nucleotide_search"]["cpu_baseline"]["parity_vs_reference"]["queries_with_different_hit_lists"] == 0
     assert isinstance(d["roofline"]["traffic"], (int, float)) and d["roofline"]["traffic"] > d["roofline"]["algorithmic_bytes_per_launch"]
+    # round 5: the prefilter roofline is quoted for the STAGE (every prefilter kernel of the step), the split kernel is a sub-field,
+    # and the look-up / gather kernels are priced against the measured rate of random memory-side requests
+    pr = d["prefilter"]["roofline"]
+    assert abs(pr["kernel_ms"] - d["prefilter"]["stage_ms"]["total"]) < 0.01 and abs(pr["frac"] - pr["achieved"] / pr["peak"]) < 1e-3
+    assert abs(pr["achieved"] - pr["algorithmic_bytes_per_launch"] / (pr["kernel_ms"] * 1e-3) / 1e9) < 0.01 * pr["achieved"]
+    assert pr["split_kernel"]["kernel_ms"] == d["prefilter"]["stage_ms"]["gather_split"] and 0 < pr["random_request_roofline"]["frac"] < 1
+    assert isinstance(pr["traffic"], (int, float)) and pr["traffic"] > 0
+    # block aligner (a15): counts, and what the restatement is pinned against
+    b = d["block_aligner"]
+    assert b["device"] == b["pairs"] and b["too_large"] == 0 and b["rescored_equal"] == b["rescored_sample"]
+    assert "pinned_against" in b and "Rust" in b["pinned_against"]
     # host numeric sequences in -> host lists out, and the two modules through the stock and the patched binary (default --mask 1)
     e = d["end_to_end"]
     assert e["results_equal_to_the_timed_steps"] is True
@@ -57,5 +68,21 @@ def test_pmc_reader_finds_the_quoted_kernels():
     for kernels, stem in ((("pf_split_kernel",), "r01_prefilter_config3"), (("sw_kernel<",), "r01_sw_config2"),
                           (("pf_split_kernel",), "r02_search"), (("sw_kernel<", "sw_rev_multi_kernel"), "r02_search"),
                           (("pf_split_kernel",), "r03_search"), (("sw_kernel<", "sw_rev_multi_kernel"), "r03_search")):
-        t = bench.pmc_traffic(kernels, stem)
+        t = bench.pmc_traffic(kernels, stem, check_digest=False)      # (earlier rounds' passes carry no digest)
         assert t is not None and t > 1e9, (kernels, t)
+
+
+def test_this_rounds_pmc_passes_were_taken_with_these_device_sources():
+    """`roofline.traffic` is read from profiles/r05_search_pmc_{fetch,write}_size.txt: their header names the digest of
+    mmseqs2_amd/csrc they were taken with (scripts/csrc_digest.py; for a clean tree it changes exactly when
+    `git rev-parse HEAD:mmseqs2_amd/csrc` does).  Kernels changed after the passes were collected = this test fails until
+    scripts/collect_profiles.sh has been run again and its summaries committed."""
+    sys.path.insert(0, ROOT)
+    import bench
+    now = bench.csrc_digest()
+    assert now is not None
+    for kind in ("fetch", "write"):
+        path = os.path.join(ROOT, "profiles", "%s_search_pmc_%s_size.txt" % (bench.PROFILE_ROUND, kind))
+        assert bench.pmc_file_digest(path) == now, (path, bench.pmc_file_digest(path), now)
+    assert bench.pmc_traffic(("sw_kernel<", "sw_rev_multi_kernel"), bench.PROFILE_ROUND + "_search") > 1e9
+    assert _line()["roofline"]["csrc_digest"] == now

@@ -10,6 +10,7 @@ from tests import pf_common as pc
 
 
 def test_probe_refuses_what_is_not_a_database_file(tmp_path):
+    import torch  # noqa: F401  (before libmmgpu.so, as in conftest.gpu: the process must end up with one HIP runtime)
     assert capi.db_probe(tmp_path / "missing.mmgpu") is None
     junk = tmp_path / "junk.mmgpu"
     junk.write_bytes(b"MMGPUDB1" + b"\0" * 100)
