@@ -129,11 +129,28 @@ static void trace_add_block(btrace *t, size_t i, size_t j, size_t width, size_t 
 }
 
 enum { BK_AA = 0, BK_NUC = 1, BK_BYTES = 2 };
+/* AAProfile (scores.rs:475-489): position-specific scores both ways round and position-specific gap costs; index 0 is the
+ * padding position in front (set(i + 1, ..) stores position i), curr_len = str_len + block_size + 1 entries per array, every
+ * entry that was never set is i8::MIN (:494-506) */
+typedef struct {
+    const int8_t *pos_aa;                                   /* [curr_len][32] */
+    const int16_t *aa_pos;                                  /* [32][curr_len] = the transpose */
+    const int16_t *gap_open_C, *gap_close_C, *gap_open_R;   /* [curr_len] */
+    int gap_extend;
+    int len;                                                /* str_len */
+    size_t curr_len;
+    /* The vendored crate carries two edits by the reference's authors (scan_block.rs:724-725 and :731-732: the upstream lines are
+     * left as comments above them): opening a gap costs gap_open in the tree, gap_open + gap_extend upstream.  The crate's
+     * test_profile assertions were NOT updated with the edit - they hold for the upstream form only.  upstream_gaps = 1 computes
+     * that form (to replay the crate's vectors); the reference links the edited form (0). */
+    int upstream_gaps;
+} bprofile;
 typedef struct {
     const int8_t *scores;   /* AAMatrix::scores [27 * 32] (scores.rs:47-49) | NucMatrix::scores [8 * 16] (:157) | ByteMatrix {match, mismatch} (:238-241) */
     int gap_open, gap_extend;
     int kind;               /* which Matrix impl `scores` belongs to */
     int trace, xdrop;       /* Block<TRACE, X_DROP> (scan_block.rs:115); the reference instantiates <true, true> only */
+    const bprofile *prof;   /* align_profile (scan_block.rs:919-944): the "reference" is this profile, `scores` / gap_open are unused */
 } bparams;
 
 /* Matrix::get_scores for one lane: the score of reference byte c against query byte v */
@@ -150,9 +167,9 @@ static int16_t lookup_score(const bparams *P, uint8_t c, uint8_t v) {
 /* place_block_aa, scan_block.rs:1449-1613; with zero biases it is place_block (:1145-1277), whose only other difference is the
  * Matrix behind get_scores.  `query` is what the rows run over, `reference` what the columns run over; a down shift calls it with
  * the roles exchanged (:237-252). */
-static void place_block_aa(const bparams *P, bseq query, bseq reference, btrace *tr, size_t start_i, size_t start_j, size_t width,
-                           size_t height, int16_t *D_col, int16_t *C_col, int16_t *D_row, int16_t *R_row, bvec D_corner,
-                           bvec *oD_max, bvec *oD_argmax_i, bvec *oD_argmax_j) {
+static void place_block_mat(const bparams *P, bseq query, bseq reference, btrace *tr, size_t start_i, size_t start_j, size_t width,
+                            size_t height, int16_t *D_col, int16_t *C_col, int16_t *D_row, int16_t *R_row, bvec D_corner,
+                            bvec *oD_max, bvec *oD_argmax_i, bvec *oD_argmax_j) {
     const bvec gap_open = v_set1((int16_t)P->gap_open), gap_extend = v_set1((int16_t)P->gap_extend);
     bvec gap_extend_all, consts;
     prefix_scan_consts(gap_extend, &gap_extend_all, &consts);
@@ -214,6 +231,105 @@ static void place_block_aa(const bparams *P, bseq query, bseq reference, btrace 
     *oD_max = D_max;
     *oD_argmax_i = D_argmax_i;
     *oD_argmax_j = D_argmax_j;
+}
+
+/* place_block_profile_gen!, scan_block.rs:649-815, instantiated twice (:1279-1280): `right` = rows run over the sequence `seq`,
+ * columns over profile positions (place_block_profile_right); !right = rows run over profile positions - 16 consecutive ones per
+ * vector - and columns over the letters of `seq` (place_block_profile_down, called with the roles and start_i / start_j
+ * exchanged, :237-252).  The gap costs are the profile's: per column when shifting right, per vector lane when shifting down, with
+ * the C and R roles exchanged there (:709-714); a closing cost exists for the C gap only (right: added to C, down: added to R). */
+static void place_block_profile(const bparams *P, int right, bseq seq, btrace *tr, size_t start_i, size_t start_j, size_t width,
+                                size_t height, int16_t *D_col, int16_t *C_col, int16_t *D_row, int16_t *R_row, bvec D_corner,
+                                bvec *oD_max, bvec *oD_argmax_i, bvec *oD_argmax_j) {
+    const bprofile *pr = P->prof;
+    const bvec gap_extend = v_set1((int16_t)pr->gap_extend);
+    bvec gap_extend_all, consts;
+    prefix_scan_consts(gap_extend, &gap_extend_all, &consts);
+    bvec D_max = v_set1(B_MIN), D_argmax_i = v_set1(0), D_argmax_j = v_set1(0);
+    bvec gap_open_C = v_set1(B_MIN), gap_close_C = v_set1(B_MIN), gap_open_R = v_set1(B_MIN), gap_close_R = v_set1(B_MIN);
+    if (width == 0 || height == 0) { *oD_max = D_max; *oD_argmax_i = D_argmax_i; *oD_argmax_j = D_argmax_j; return; }
+    /* `$query.len()` / `$reference.len()` of the macro are the lengths of what the rows / the columns run over */
+    const size_t rows_len = right ? (size_t)seq.len : (size_t)pr->len, cols_len = right ? (size_t)pr->len : (size_t)seq.len;
+    for (size_t j = 0; j < width; j++) {
+        bvec R01 = v_set1(B_MIN), D11 = v_set1(B_MIN), R11 = v_set1(B_MIN), prev_trace_R = v_set1(0);
+        size_t idx = 0;
+        if (right) {                                                    /* :699-704 */
+            idx = start_j + j;
+            gap_open_C = v_set1(pr->gap_open_C[idx]);
+            gap_close_C = v_set1(pr->gap_close_C[idx]);
+            gap_open_R = v_set1(pr->gap_open_R[idx]);
+        }
+        for (size_t i = 0; i < height; i += BL) {
+            const bvec D10 = v_load(D_col + i), C10 = v_load(C_col + i);
+            const bvec D00 = v_sl1(D10, D_corner);
+            D_corner = D10;
+            bvec scores;
+            if (!right) {                                               /* :709-714 */
+                idx = start_i + i;
+                gap_open_C = v_load(pr->gap_open_R + idx);
+                gap_open_R = v_load(pr->gap_open_C + idx);
+                gap_close_R = v_load(pr->gap_close_C + idx);
+                const uint8_t c = seq.s[start_j + j];                   /* get_scores_aa, scores.rs:634-637 */
+                for (int k = 0; k < BL; k++) scores.v[k] = pr->aa_pos[(size_t)c * pr->curr_len + idx + k];
+            } else {                                                    /* get_scores_pos, scores.rs:621-627 -> halfsimd_lookup2_i16 */
+                for (int k = 0; k < BL; k++) {
+                    const uint8_t v = seq.s[start_i + i + k];
+                    scores.v[k] = (v & 0x80) ? 0 : pr->pos_aa[idx * 32 + (v & 31)];
+                }
+            }
+            D11 = v_adds(D00, scores);
+            if (start_i + i == 0 && start_j + j == 0) D11.v[0] = B_ZERO;       /* :722-724 */
+            const bvec C11_open = pr->upstream_gaps ? v_adds(D10, v_adds(gap_open_C, gap_extend)) : v_adds(D10, gap_open_C);
+            const bvec C11 = v_max(v_adds(C10, gap_extend), C11_open);
+            const bvec C11_end = right ? v_adds(C11, gap_close_C) : C11;
+            D11 = v_max(D11, C11_end);
+            const bvec D11_open = pr->upstream_gaps ? v_adds(D11, gap_open_R) : v_adds(D11, v_subs(gap_open_R, gap_extend));
+            R11 = prefix_scan(D11_open, gap_extend, consts);
+            R11 = v_max(R11, v_adds(v_broadcasthi(R01), gap_extend_all));
+            const bvec R11_end = right ? R11 : v_adds(R11, gap_close_R);
+            D11 = v_max(D11, R11_end);
+            R01 = R11;
+            if (P->trace) {   /* :758-776 */
+                const bvec trace_D_C = v_cmpeq(D11, C11_end), trace_D_R = v_cmpeq(D11, R11_end);
+                const uint32_t trace_data = trace_word(trace_D_C, trace_D_R);
+                const bvec temp_trace_R = v_cmpeq(R11, D11_open);
+                const bvec trace_R = v_sl1(temp_trace_R, prev_trace_R);
+                const uint32_t trace_data2 = trace_word(v_cmpeq(C11, C11_open), trace_R);
+                prev_trace_R = temp_trace_R;
+                if (tr->trace_idx >= tr->trace_cap) abort();
+                tr->trace[tr->trace_idx] = trace_data;
+                tr->trace2[tr->trace_idx] = trace_data2;
+                tr->trace_idx++;
+            }
+            D_max = v_max(D_max, D11);
+            if (P->xdrop) {   /* :780-785 */
+                const bvec mask = v_cmpeq(D_max, D11);
+                D_argmax_i = v_blend16(D_argmax_i, v_set1((int16_t)i), mask);
+                D_argmax_j = v_blend16(D_argmax_j, v_set1((int16_t)j), mask);
+            }
+            v_store(D_col + i, D11);
+            v_store(C_col + i, C11);
+        }
+        D_corner = v_set1(B_MIN);
+        D_row[j] = D11.v[BL - 1];
+        R_row[j] = R11.v[BL - 1];
+        if (!P->xdrop && start_i + height > rows_len && start_j + j >= cols_len) {   /* :797-805 */
+            if (P->trace) tr->trace_idx += (width - 1 - j) * (height / BL);
+            break;
+        }
+    }
+    *oD_max = D_max;
+    *oD_argmax_i = D_argmax_i;
+    *oD_argmax_j = D_argmax_j;
+}
+
+/* what align_core_gen! is instantiated with (:1054-1057): the matrix forms take (rows, columns) as two sequences; the profile
+ * forms take the sequence and read the profile from the parameters.  `right`: the caller's first sequence runs down the rows. */
+static void place_block_aa(const bparams *P, int right, bseq rows, bseq cols, btrace *tr, size_t start_i, size_t start_j, size_t width,
+                           size_t height, int16_t *D_col, int16_t *C_col, int16_t *D_row, int16_t *R_row, bvec D_corner,
+                           bvec *oD_max, bvec *oD_argmax_i, bvec *oD_argmax_j) {
+    if (P->prof) place_block_profile(P, right, right ? rows : cols, tr, start_i, start_j, width, height, D_col, C_col, D_row, R_row, D_corner, oD_max, oD_argmax_i, oD_argmax_j);
+    else place_block_mat(P, rows, cols, tr, start_i, start_j, width, height, D_col, C_col, D_row, R_row, D_corner, oD_max, oD_argmax_i, oD_argmax_j);
 }
 
 static void just_offset(size_t block_size, int16_t *buf1, int16_t *buf2, bvec off_add) {   /* :1065-1074 */
@@ -278,7 +394,7 @@ static void align_aa_core(const bparams *P, bseq query, bseq reference, size_t m
             const bvec off_add = v_set1(clamp16(prev_off - off));
             if (P->trace) trace_add_block(tr, st_i, st_j + block_size - B_STEP, B_STEP, block_size, 1);
             just_offset(block_size, A->D_col, A->C_col, off_add);
-            place_block_aa(P, query, reference, tr, st_i, st_j + block_size - B_STEP, B_STEP, block_size, A->D_col, A->C_col, A->temp1, A->temp2,
+            place_block_aa(P, 1, query, reference, tr, st_i, st_j + block_size - B_STEP, B_STEP, block_size, A->D_col, A->C_col, A->temp1, A->temp2,
                            prev_dir == DIR_DOWN ? v_adds(D_corner, off_add) : v_set1(B_MIN), &D_max, &D_argmax_i, &D_argmax_j);
             right_max = prefix_max(A->D_col);
             D_corner = shift_and_offset(block_size, A->D_row, A->R_row, A->temp1, A->temp2, off_add);
@@ -288,7 +404,7 @@ static void align_aa_core(const bparams *P, bseq query, bseq reference, size_t m
             const bvec off_add = v_set1(clamp16(prev_off - off));
             if (P->trace) trace_add_block(tr, st_i + block_size - B_STEP, st_j, block_size, B_STEP, 0);
             just_offset(block_size, A->D_row, A->R_row, off_add);
-            place_block_aa(P, reference, query, tr, st_j, st_i + block_size - B_STEP, B_STEP, block_size, A->D_row, A->R_row, A->temp1, A->temp2,
+            place_block_aa(P, 0, reference, query, tr, st_j, st_i + block_size - B_STEP, B_STEP, block_size, A->D_row, A->R_row, A->temp1, A->temp2,
                            prev_dir == DIR_RIGHT ? v_adds(D_corner, off_add) : v_set1(B_MIN), &D_max, &D_argmax_i, &D_argmax_j);
             down_max = prefix_max(A->D_row);
             D_corner = shift_and_offset(block_size, A->D_col, A->C_col, A->temp1, A->temp2, off_add);
@@ -298,10 +414,10 @@ static void align_aa_core(const bparams *P, bseq query, bseq reference, size_t m
             const size_t grow_step = block_size - prev_size;
             if (P->trace) trace_add_block(tr, st_i + prev_size, st_j, prev_size, grow_step, 0);
             bvec D_max1, D_ai1, D_aj1;
-            place_block_aa(P, reference, query, tr, st_j, st_i + prev_size, grow_step, prev_size, A->D_row, A->R_row, A->D_col + prev_size,
+            place_block_aa(P, 0, reference, query, tr, st_j, st_i + prev_size, grow_step, prev_size, A->D_row, A->R_row, A->D_col + prev_size,
                            A->C_col + prev_size, v_set1(B_MIN), &D_max1, &D_ai1, &D_aj1);
             if (P->trace) trace_add_block(tr, st_i, st_j + prev_size, grow_step, block_size, 1);
-            place_block_aa(P, query, reference, tr, st_i, st_j + prev_size, grow_step, block_size, A->D_col, A->C_col, A->D_row + prev_size,
+            place_block_aa(P, 1, query, reference, tr, st_i, st_j + prev_size, grow_step, block_size, A->D_col, A->C_col, A->D_row + prev_size,
                            A->R_row + prev_size, v_set1(B_MIN), &D_max, &D_argmax_i, &D_argmax_j);
             right_max = prefix_max(A->D_col);
             down_max = prefix_max(A->D_row);
@@ -501,7 +617,9 @@ int mmo_block_align(const uint8_t *q, const int16_t *qbias, int qlen, const uint
 static int block_run(const uint8_t *q, const int16_t *qbias, int qlen, const uint8_t *r, const int16_t *rbias, int rlen, const bparams *P,
                      uint8_t null_byte, int min_size, int max_size, int x_drop, mmo_block_res *res, uint8_t *ops, uint32_t ops_cap,
                      uint32_t *n_ops, int eq) {
-    if (qlen < 0 || rlen < 0 || P->gap_open >= 0 || P->gap_extend >= 0 || P->gap_open >= P->gap_extend) return -1;      /* :864-867 */
+    if (P->prof) {
+        if (qlen < 0 || rlen < 0 || P->prof->gap_extend >= 0) return -1;                                                  /* :921 */
+    } else if (qlen < 0 || rlen < 0 || P->gap_open >= 0 || P->gap_extend >= 0 || P->gap_open >= P->gap_extend) return -1;      /* :864-867 */
     size_t mn = (size_t)(min_size < BL ? BL : min_size), mx = (size_t)(max_size < BL ? BL : max_size);      /* :868-869, :1024-1025 */
     if ((mn & (mn - 1)) || (mx & (mx - 1)) || mn > mx || mx >= 65535) return -1;
     uint8_t *qs = (uint8_t *)malloc((size_t)qlen + mx + 1 + BL), *rs = (uint8_t *)malloc((size_t)rlen + mx + 1 + BL);
@@ -509,7 +627,7 @@ static int block_run(const uint8_t *q, const int16_t *qbias, int qlen, const uin
     memset(qs, null_byte, (size_t)qlen + mx + 1 + BL);
     memset(rs, null_byte, (size_t)rlen + mx + 1 + BL);
     if (qlen) memcpy(qs + 1, q, (size_t)qlen);
-    if (rlen) memcpy(rs + 1, r, (size_t)rlen);
+    if (rlen && r) memcpy(rs + 1, r, (size_t)rlen);      /* (profile alignments have no reference bytes: place_block_profile never reads them) */
     for (int k = 0; k < qlen && qbias; k++) qb[1 + k] = qbias[k];
     for (int k = 0; k < rlen && rbias; k++) rb[1 + k] = rbias[k];
     bseq Q = {qs, qb, qlen}, R = {rs, rb, rlen};
@@ -554,6 +672,7 @@ int mmo_block_align_table(const uint8_t *q, const int16_t *qbias, int qlen, cons
     P.gap_extend = gap_extend;
     P.kind = BK_AA;
     P.trace = P.xdrop = 1;
+    P.prof = NULL;
     return block_run(q, qbias, qlen, r, rbias, rlen, &P, B_NULL, min_size, max_size, x_drop, res, ops, ops_cap, n_ops, 0);
 }
 
@@ -572,6 +691,7 @@ int mmo_block_align_generic(const uint8_t *q, int qlen, const uint8_t *r, int rl
     P.kind = kind;
     P.trace = trace != 0;
     P.xdrop = xdrop != 0;
+    P.prof = NULL;
     const uint8_t null_byte = kind == BK_AA ? B_NULL : (kind == BK_NUC ? (uint8_t)'Z' : 0);
     return block_run(q, NULL, qlen, r, NULL, rlen, &P, null_byte, min_size, max_size, x_drop, res, ops, ops_cap, n_ops, eq);
 }
@@ -627,5 +747,127 @@ int mmo_sw_block_backtrace(const uint8_t *q, const int8_t *comp_bias, int qlen, 
         ok = 1;
     }
     free(qr); free(trv); free(qb); free(ops);
+    return ok;
+}
+
+/* ---- profile alignments: Block<TRACE, X_DROP>::align_profile (scan_block.rs:919-944) ---------------------------------------------
+ * An AAProfile as AAProfile::new leaves it (scores.rs:494-507: every score and gap cost i8::MIN) with `pos_aa_rows` installed for
+ * the positions 1 .. plen (row p = 32 int8 scores of profile position p - 1, indexed by the converted query byte; set / set_all /
+ * the reference's memcpy all write these rows, :544-551, StripedSmithWaterman.cpp:970-989) and the three gap-cost arrays for the
+ * indices 0 .. gap_n - 1 (from_bytes sets 0 .. plen, :519-523; set_all_gap_* fill all curr_len entries, :575-587).  pad_block =
+ * the block_size the profile was created with (curr_len = plen + pad_block + 1). */
+typedef struct {
+    bprofile p;
+    int8_t *pos_aa;
+    int16_t *aa_pos, *goc, *gcc, *gor;
+} bprofile_own;
+
+static int profile_build(bprofile_own *o, int plen, int pad_block, const int8_t *pos_aa_rows, const int16_t *gap_open_C, const int16_t *gap_close_C,
+                         const int16_t *gap_open_R, int gap_n, int gap_extend) {
+    const size_t cl = (size_t)plen + (size_t)pad_block + 1;
+    if (plen < 0 || pad_block < BL || gap_n < 0 || (size_t)gap_n > cl) return -1;
+    o->pos_aa = (int8_t *)malloc((cl + BL) * 32);
+    o->aa_pos = (int16_t *)malloc(32 * (cl + BL) * 2);
+    o->goc = (int16_t *)malloc((cl + BL) * 2);
+    o->gcc = (int16_t *)malloc((cl + BL) * 2);
+    o->gor = (int16_t *)malloc((cl + BL) * 2);
+    memset(o->pos_aa, -128, (cl + BL) * 32);
+    for (size_t k = 0; k < cl + BL; k++) o->goc[k] = o->gcc[k] = o->gor[k] = -128;
+    for (int p = 0; p < plen; p++) memcpy(o->pos_aa + (size_t)(p + 1) * 32, pos_aa_rows + (size_t)p * 32, 32);
+    for (size_t k = 0; k < 32 * (cl + BL); k++) o->aa_pos[k] = -128;
+    for (size_t i = 0; i < cl; i++)
+        for (int b = 0; b < 32; b++) o->aa_pos[(size_t)b * cl + i] = o->pos_aa[i * 32 + b];      /* both arrays are written together, :544-551 */
+    for (int k = 0; k < gap_n; k++) { o->goc[k] = gap_open_C[k]; o->gcc[k] = gap_close_C[k]; o->gor[k] = gap_open_R[k]; }
+    o->p.pos_aa = o->pos_aa; o->p.aa_pos = o->aa_pos; o->p.gap_open_C = o->goc; o->p.gap_close_C = o->gcc; o->p.gap_open_R = o->gor;
+    o->p.gap_extend = gap_extend; o->p.len = plen; o->p.curr_len = cl;
+    o->p.upstream_gaps = 0;
+    return 0;
+}
+static void profile_free(bprofile_own *o) { free(o->pos_aa); free(o->aa_pos); free(o->goc); free(o->gcc); free(o->gor); }
+
+/* Block<trace, xdrop>::align_profile(query, profile, min_size ..= max_size, x_drop) + res (+ cigar): q = query bytes after
+ * AAMatrix::convert_char (letter - 'A'; padded with 26); the rest as profile_build.  The crate's test_profile vectors
+ * (scan_block.rs:2432-2477) run through this (tests/test_block_oracle.py). */
+int mmo_block_align_profile(const uint8_t *q, int qlen, int plen, int pad_block, const int8_t *pos_aa_rows, const int16_t *gap_open_C,
+                            const int16_t *gap_close_C, const int16_t *gap_open_R, int gap_n, int gap_extend, int min_size, int max_size,
+                            int x_drop, int trace, int xdrop, mmo_block_res *res, uint8_t *ops, uint32_t ops_cap, uint32_t *n_ops) {
+    if (xdrop && x_drop < 0) return -1;      /* :927-929 */
+    bprofile_own o;
+    /* trace / xdrop bit 1: the upstream crate's gap-open form (bprofile::upstream_gaps) - test hook */
+    const int upstream = (trace & 2) != 0;
+    trace &= 1;
+    if (profile_build(&o, plen, pad_block, pos_aa_rows, gap_open_C, gap_close_C, gap_open_R, gap_n, gap_extend) != 0) return -1;
+    o.p.upstream_gaps = upstream;
+    bparams P;
+    P.scores = NULL;
+    P.gap_open = P.gap_extend = 0;
+    P.kind = BK_AA;
+    P.trace = trace != 0;
+    P.xdrop = xdrop != 0;
+    P.prof = &o.p;
+    const int rc = block_run(q, NULL, qlen, NULL, NULL, plen, &P, B_NULL, min_size, max_size, x_drop, res, ops, ops_cap, n_ops, 0);
+    profile_free(&o);
+    return rc;
+}
+
+/* SmithWaterman::alignStartPosBacktraceBlock<PROFILE_SEQ> (StripedSmithWaterman.cpp:943-1127) for one (profile query, target) pair
+ * whose forward scan ended at (q_end, t_end) with `score`.  prof = the query's int8 score rows [alphabet][qlen] (ssw_init's
+ * profile->mat for a profile query, what mmgpu_sw_query.profile carries), q = its consensus sequence (identities are counted
+ * against it, :1076).  The profile handed to the crate is the reversed prefix 0 .. q_end (pos_aa_rev rows, :970-980), every gap
+ * opening costs gap_open, closing costs nothing, extension gap_extend (:988-990); the TARGET is the crate's `query` (rows of its DP
+ * matrix), so its I / D operations change sides on the way back (:1083-1101).  Same return contract as mmo_sw_block_backtrace. */
+int mmo_sw_block_backtrace_profile(const int8_t *prof, const uint8_t *q, int qlen, const uint8_t *t, int tlen, int alphabet, int gap_open,
+                                   int gap_extend, int score, int q_end, int t_end, int *q_start, int *t_start, uint32_t *ident, char *bt,
+                                   int bt_cap, int *bt_len, int *block_size_used) {
+    (void)tlen;
+    if (alphabet < 1 || alphabet > 32) return 0;
+    const int qa = q_end + 1, ta = t_end + 1;
+    int8_t *rows = (int8_t *)malloc((size_t)qa * 32 + 32);
+    memset(rows, -128, (size_t)qa * 32 + 32);                       /* memset(pos_aa_rev, 0x80, ..), :1452; only alphabetSize entries are copied, :975-980 */
+    uint8_t *qr = (uint8_t *)malloc((size_t)qa + 1), *trv = (uint8_t *)malloc((size_t)ta + 1);
+    for (int k = 0; k < qa; k++) {
+        qr[k] = q[q_end - k];
+        for (int a = 0; a < alphabet; a++) rows[(size_t)k * 32 + a] = prof[(size_t)a * qlen + (q_end - k)];
+    }
+    for (int k = 0; k < ta; k++) trv[k] = t[t_end - k];
+    const int pad_block = 4096;                                      /* block_new_aaprofile(queryAlnLen, MAX_SIZE, gaps.extend), :965 */
+    const size_t cl = (size_t)qa + pad_block + 1;
+    int16_t *goc = (int16_t *)malloc(cl * 2), *gcc = (int16_t *)malloc(cl * 2), *gor = (int16_t *)malloc(cl * 2);
+    for (size_t k = 0; k < cl; k++) { goc[k] = (int16_t)(-gap_open); gcc[k] = 0; gor[k] = (int16_t)(-gap_open); }   /* set_all_gap_*, :988-990 */
+    uint8_t *ops = (uint8_t *)malloc((size_t)qa + ta + 8);
+    mmo_block_res res;
+    res.score = -1000000000;
+    res.query_idx = res.reference_idx = 0;
+    uint32_t n_ops = 0;
+    int used = 0;
+    for (int min_size = 32; min_size <= 4096 && res.score < score; min_size *= 2) {                            /* :1039-1049 */
+        const int x_drop = -(min_size * (-gap_extend) + (-gap_open));
+        mmo_block_align_profile(trv, ta, qa, pad_block, rows, goc, gcc, gor, (int)cl, -gap_extend, min_size, 4096, x_drop, 1, 1, &res, ops,
+                                (uint32_t)(qa + ta + 8), &n_ops);
+        used = min_size;
+    }
+    int ok = 0;
+    if (block_size_used) *block_size_used = used;
+    if (!(res.score != score && !(score == 32767 && res.score >= score))) {                                    /* :1058 */
+        uint32_t ids = 0, qp = 0, tp = 0;
+        int n = 0;
+        for (uint32_t k = n_ops; k-- > 0;) {
+            char ch;
+            if (ops[k] == 1) { ids += qr[qp] == trv[tp]; qp++; tp++; ch = 'M'; }      /* :1073-1082 */
+            else if (ops[k] == 4) { tp++; ch = 'D'; }                                 /* PROFILE_SEQ: I of the crate = the target advances, :1088-1091 */
+            else { qp++; ch = 'I'; }                                                  /* :1099-1102 */
+            if (bt && n < bt_cap) bt[n] = ch;
+            n++;
+        }
+        if (bt && n <= bt_cap) {
+            for (int a = 0, b = n - 1; a < b; a++, b--) { const char c = bt[a]; bt[a] = bt[b]; bt[b] = c; }
+        }
+        if (bt_len) *bt_len = n;
+        if (ident) *ident = ids;
+        if (q_start) *q_start = (q_end + 1) - (int)qp;
+        if (t_start) *t_start = (t_end + 1) - (int)tp;
+        ok = 1;
+    }
+    free(rows); free(qr); free(trv); free(goc); free(gcc); free(gor); free(ops);
     return ok;
 }

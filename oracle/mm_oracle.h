@@ -185,6 +185,17 @@ int mmo_block_align_table(const uint8_t *q, const int16_t *qbias, int qlen, cons
 int mmo_block_align_generic(const uint8_t *q, int qlen, const uint8_t *r, int rlen, int kind, const int8_t *table, int gap_open, int gap_extend,
                             int min_size, int max_size, int x_drop, int trace, int xdrop, int eq, mmo_block_res *res, uint8_t *ops,
                             uint32_t ops_cap, uint32_t *n_ops);
+/* Block<trace, xdrop>::align_profile (scan_block.rs:919-944) of query bytes q (letter - 'A') against an AAProfile of plen positions:
+ * pos_aa_rows [plen][32] int8, gap costs for the indices 0 .. gap_n - 1 (index 0 = the padding position in front), everything else
+ * as AAProfile::new leaves it (i8::MIN); pad_block = the block_size the profile was created with */
+int mmo_block_align_profile(const uint8_t *q, int qlen, int plen, int pad_block, const int8_t *pos_aa_rows, const int16_t *gap_open_C,
+                            const int16_t *gap_close_C, const int16_t *gap_open_R, int gap_n, int gap_extend, int min_size, int max_size,
+                            int x_drop, int trace, int xdrop, mmo_block_res *res, uint8_t *ops, uint32_t ops_cap, uint32_t *n_ops);
+/* SmithWaterman::alignStartPosBacktraceBlock<PROFILE_SEQ> (StripedSmithWaterman.cpp:943-1127): prof = int8 [alphabet][qlen] score rows
+ * of the profile query, q = its consensus sequence */
+int mmo_sw_block_backtrace_profile(const int8_t *prof, const uint8_t *q, int qlen, const uint8_t *t, int tlen, int alphabet, int gap_open,
+                                   int gap_extend, int score, int q_end, int t_end, int *q_start, int *t_start, uint32_t *ident, char *bt,
+                                   int bt_cap, int *bt_len, int *block_size_used);
 void mmo_block_prefix_scan(const int16_t *v16, int gap, int16_t *out16);
 int mmo_sw_block_backtrace(const uint8_t *q, const int8_t *comp_bias, int qlen, const uint8_t *t, int tlen, const int8_t *mat, int alphabet,
                            int gap_open /* > 0, as the reference's */, int gap_extend, int score, int q_end, int t_end, int *q_start, int *t_start,

@@ -127,6 +127,61 @@ class Oracle:
         letters = {1: "M", 4: "I", 5: "D"}
         return res.score, res.qi, res.ri, "".join(letters[int(x)] for x in ops[:n.value][::-1])
 
+    def block_align_profile(self, q, pos_aa_rows, gap_open_C, gap_close_C, gap_open_R, gap_extend, pad_block, min_size, max_size, x_drop,
+                            trace, xdrop, upstream_gaps=False):
+        """Block<trace, xdrop>::align_profile: q = query bytes (letter - 'A'), pos_aa_rows int8 [plen, 32], gap arrays int16 for the
+        indices 0 .. len - 1 of the profile's arrays -> (score, query_idx, reference_idx, CIGAR in the crate's Display format or None)"""
+        q = np.ascontiguousarray(q, np.uint8)
+        rows = np.ascontiguousarray(pos_aa_rows, np.int8).reshape(-1, 32)
+        goc, gcc, gor = (np.ascontiguousarray(x, np.int16) for x in (gap_open_C, gap_close_C, gap_open_R))
+        assert len(goc) == len(gcc) == len(gor)
+
+        class Res(ctypes.Structure):
+            _fields_ = [("score", ctypes.c_int32), ("qi", ctypes.c_uint32), ("ri", ctypes.c_uint32)]
+        res = Res()
+        ops = np.zeros(len(q) + len(rows) + 8, np.uint8)
+        n = ctypes.c_uint32()
+        f = self.L.mmo_block_align_profile
+        f.argtypes = [c_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_p, c_p, c_p, c_p] + [ctypes.c_int] * 7 + \
+                     [ctypes.POINTER(Res), c_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32)]
+        rc = f(_ptr(q), len(q), len(rows), int(pad_block), _ptr(rows), _ptr(goc), _ptr(gcc), _ptr(gor), len(goc), int(gap_extend), int(min_size),
+               int(max_size), int(x_drop), int(bool(trace)) | (2 if upstream_gaps else 0), int(xdrop), ctypes.byref(res), _ptr(ops), len(ops),
+               ctypes.byref(n))
+        if rc != 0:
+            raise RuntimeError("mmo_block_align_profile rc=%d" % rc)
+        cigar = None
+        if trace:
+            cigar, run, last = "", 0, None
+            for x in ops[:n.value][::-1]:
+                c = {1: "M", 2: "=", 3: "X", 4: "I", 5: "D"}[int(x)]
+                if c != last and last is not None:
+                    cigar += "%d%s" % (run, last)
+                    run = 0
+                last = c
+                run += 1
+            if last is not None:
+                cigar += "%d%s" % (run, last)
+        return res.score, res.qi, res.ri, cigar
+
+    def sw_block_backtrace_profile(self, prof, q, t, gap_open, gap_extend, score, q_end, t_end):
+        """alignStartPosBacktraceBlock<PROFILE_SEQ>: prof int8 [alphabet, qlen], q = consensus -> None ("Block alignment failed") or
+        dict(q_start, t_start, ident, bt, block_size)"""
+        prof = np.ascontiguousarray(prof, np.int8)
+        q = np.ascontiguousarray(q, np.uint8)
+        t = np.ascontiguousarray(t, np.uint8)
+        qs, ts, bl, bs = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        ident = ctypes.c_uint32()
+        cap = len(q) + len(t) + 8
+        bt = np.zeros(cap, np.uint8)
+        f = self.L.mmo_sw_block_backtrace_profile
+        f.argtypes = [c_p, c_p, ctypes.c_int, c_p, ctypes.c_int] + [ctypes.c_int] * 6 + [ctypes.POINTER(ctypes.c_int)] * 2 + \
+                     [ctypes.POINTER(ctypes.c_uint32), c_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+        ok = f(_ptr(prof), _ptr(q), len(q), _ptr(t), len(t), prof.shape[0], int(gap_open), int(gap_extend), int(score), int(q_end), int(t_end),
+               ctypes.byref(qs), ctypes.byref(ts), ctypes.byref(ident), _ptr(bt), cap, ctypes.byref(bl), ctypes.byref(bs))
+        if not ok:
+            return None
+        return dict(q_start=qs.value, t_start=ts.value, ident=ident.value, bt=bt[:bl.value].tobytes().decode(), block_size=bs.value)
+
     def block_align_generic(self, q, r, kind, table, gap_open, gap_extend, min_size, max_size, x_drop, trace, xdrop, eq=False):
         """Block<trace, xdrop>::align over an AAMatrix (kind 0) / NucMatrix (1) / ByteMatrix (2) table, q / r = bytes after
         Matrix::convert_char -> (score, query_idx, reference_idx, CIGAR in the crate's Display format or None without trace)"""

@@ -5,12 +5,13 @@
 // (SmithWaterman::alignStartPosBacktraceBlock<SEQ_SEQ>, src/alignment/StripedSmithWaterman.cpp:943-1127, and the set-up in
 // the constructor / ssw_init, :706-710, :1464-1474), on top of the plain-C restatement oracle/block_oracle.c.  Linked into
 // oracle/_ref/libmmref_block.so and into the two `mmseqs` binaries of integration/build_mmseqs.sh INSTEAD of the do-nothing
-// stubs (oracle/gen_block_stub.py keeps generating stubs for everything not defined here: the profile calls report failure,
-// so a profile query still takes the reference's documented Smith-Waterman fallback, :873-882).  With it the reference's
+// stubs (oracle/gen_block_stub.py keeps generating stubs for everything not defined here).  Round 5: the AAProfile object and
+// block_align_profile_aa_trace_xdrop are served too, so profile queries run the reference's PROFILE_SEQ branch (:963-990).  With it the reference's
 // own code runs the block-aligner branch for int16-range hits, and the drop-in tests compare against a block-aligning
 // reference.  Parity of the restatement itself against the Rust crate: see the header of block_oracle.c.
 #include <cstdint>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
@@ -23,6 +24,13 @@ struct AAMatrix { int8_t scores[27 * 32]; };                       // scores.rs:
 struct PaddedBytes { std::vector<uint8_t> b; };                    // the bytes between the paddings (scan_block.rs:2149-2152)
 struct PosBias { std::vector<int16_t> b; };                        // scores.rs:703-706
 struct Cigar { std::vector<OpLen> runs; };                         // runs in block_get_cigar order (origin -> end), cigar.rs:88-90
+struct AAProfile {                                                 // scores.rs:475-489
+    std::vector<int8_t> pos_aa;                                    // [max_len][32]
+    std::vector<int16_t> aa_pos;                                   // [32][max_len]
+    std::vector<int16_t> goc, gcc, gor;                            // pos_gap_open_C / pos_gap_close_C / pos_gap_open_R
+    int8_t gap_extend;
+    size_t max_len, curr_len, str_len;
+};
 struct MMBlock {                                                   // Block<true, true>: result + traceback of the last alignment
     AlignResult res;
     std::vector<uint8_t> ops;                                      // walk order (end -> origin) for the end position in `res`
@@ -81,12 +89,46 @@ void block_align_aa_trace_xdrop_posbias(BlockHandle h, const struct PaddedBytes 
     b->res.query_idx = res.query_idx;
     b->res.reference_idx = res.reference_idx;
 }
-// profile queries (PROFILE_SEQ, :1039-1051): not restated - the call reports failure, the reference falls back (:873-882)
-void block_align_profile_aa_trace_xdrop(BlockHandle h, const struct PaddedBytes *, const struct AAProfile *, struct SizeRange, int32_t) {
+// profile queries (PROFILE_SEQ, :963-990, :1039-1051): the AAProfile object as the reference fills it - through the raw pointers to
+// its two score arrays and the set_all gap setters - and Block<true, true>::align_profile on the restatement (round 5)
+struct AAProfile *block_new_aaprofile(uintptr_t str_len, uintptr_t block_size, int8_t gap_extend) {       // AAProfile::new, scores.rs:494-507
+    AAProfile *p = new AAProfile();
+    p->max_len = p->curr_len = str_len + block_size + 1;
+    p->str_len = str_len;
+    p->gap_extend = gap_extend;
+    p->pos_aa.assign(p->max_len * 32, (int8_t)-128);
+    p->aa_pos.assign(32 * p->max_len, (int16_t)-128);
+    p->goc.assign(p->max_len, (int16_t)-128);
+    p->gcc.assign(p->max_len, (int16_t)-128);
+    p->gor.assign(p->max_len, (int16_t)-128);
+    return p;
+}
+int8_t *aaprofile_pos_aa(struct AAProfile *p) { return p->pos_aa.data(); }
+int16_t *aaprofile_aa_pos(struct AAProfile *p) { return p->aa_pos.data(); }
+size_t block_get_curr_len_aaprofile(const struct AAProfile *p) { return p->curr_len; }
+void block_set_all_gap_open_C_aaprofile(struct AAProfile *p, int8_t gap) { std::fill(p->goc.begin(), p->goc.begin() + p->curr_len, (int16_t)gap); }     // :575-578
+void block_set_all_gap_close_C_aaprofile(struct AAProfile *p, int8_t gap) { std::fill(p->gcc.begin(), p->gcc.begin() + p->curr_len, (int16_t)gap); }    // :580-582
+void block_set_all_gap_open_R_aaprofile(struct AAProfile *p, int8_t gap) { std::fill(p->gor.begin(), p->gor.begin() + p->curr_len, (int16_t)gap); }     // :584-587
+void block_free_aaprofile(struct AAProfile *p) { delete p; }
+void block_align_profile_aa_trace_xdrop(BlockHandle h, const struct PaddedBytes *q, const struct AAProfile *r, struct SizeRange s, int32_t x) {
     MMBlock *b = static_cast<MMBlock *>(h);
-    b->res.score = -1000000000;
-    b->res.query_idx = b->res.reference_idx = 0;
+    const int ql = (int)q->b.size(), pl = (int)r->str_len;
+    // the reference writes aa_pos as the transpose of the rows it copied into pos_aa (:982-987): the restatement derives it the same way;
+    // a caller that wrote the two arrays inconsistently would be a different program
+    for (size_t i = 0; i <= r->str_len; i++)
+        for (int a = 0; a < 32; a++)
+            if (r->aa_pos[(size_t)a * r->curr_len + i] != (int16_t)r->pos_aa[i * 32 + a]) abort();
+    b->ops.resize((size_t)ql + pl + 8);
+    mmo_block_res res;
+    res.score = -1000000000;
+    res.query_idx = res.reference_idx = 0;
     b->n_ops = 0;
+    if (mmo_block_align_profile(q->b.data(), ql, pl, (int)(r->max_len - r->str_len - 1), r->pos_aa.data() + 32, r->goc.data(), r->gcc.data(), r->gor.data(),
+                                (int)r->curr_len, r->gap_extend, (int)s.min, (int)s.max, x, 1, 1, &res, b->ops.data(), (uint32_t)b->ops.size(), &b->n_ops) != 0)
+        abort();
+    b->res.score = res.score;
+    b->res.query_idx = res.query_idx;
+    b->res.reference_idx = res.reference_idx;
 }
 struct AlignResult block_res_aa_trace_xdrop(BlockHandle h) { return static_cast<MMBlock *>(h)->res; }
 

@@ -4,7 +4,7 @@ a15) as a fixture: tests/golden/block_crate_vectors.json.
 The crate cannot be built in this image (no rustc), so its tests cannot be RUN here; what can be done is to read the expected
 values its authors wrote down.  This script parses, from the reference tree,
 
-  /root/reference/lib/block-aligner/src/scan_block.rs   #[cfg(test)] mod tests: test_no_x_drop, test_x_drop, test_trace, test_bytes
+  /root/reference/lib/block-aligner/src/scan_block.rs   #[cfg(test)] mod tests: test_no_x_drop, test_x_drop, test_trace, test_bytes, test_profile
   /root/reference/lib/block-aligner/matrices/BLOSUM62   the AAMatrix table behind `BLOSUM62` (scores.rs:303)
   /root/reference/lib/block-aligner/src/scores.rs       NucMatrix::new_simple's index rule (:161-176), NW1 / BYTES1 (:293, :340)
 
@@ -108,9 +108,63 @@ def main():
         assert "score" in v, v
     counts = {t: sum(v["test"] == t for v in vectors) for t in wanted}
     assert counts == {"test_no_x_drop": 13, "test_x_drop": 3, "test_trace": 5, "test_bytes": 2}, counts
+    profile_vectors = parse_test_profile(src)
+    assert len(profile_vectors) == 6, len(profile_vectors)
     json.dump({"source": "lib/block-aligner 0.4.0 src/scan_block.rs #[cfg(test)] (parsed, not executed)", "matrices": matrices,
-               "vectors": vectors}, open(OUT, "w"), indent=0)
-    print("wrote", OUT, counts)
+               "vectors": vectors, "profile_vectors": profile_vectors}, open(OUT, "w"), indent=0)
+    print("wrote", OUT, counts, "test_profile:", len(profile_vectors))
+
+
+def parse_test_profile(src):
+    """test_profile (scan_block.rs:2432-2477): every a.align_profile(&q, &r, ..) with the AAProfile::from_bytes arguments of r
+    (bytes, block_size, match, mismatch, gap_open_C, gap_close_C, gap_open_R, gap_extend), the set_gap_close_C calls that follow it,
+    and the assertions."""
+    out = []
+    inside = False
+    block = None
+    prof = {}
+    seq = {}
+    for no, line in enumerate(src, 1):
+        m = re.match(r"\s*fn (test_\w+)\(\)", line)
+        if m:
+            inside = m.group(1) == "test_profile"
+            continue
+        if not inside:
+            continue
+        m = re.search(r"let mut a = Block::<(true|false), (true|false)>::new\(", line)
+        if m:
+            block = (m.group(1) == "true", m.group(2) == "true")
+        m = re.search(r"let (?:mut )?(\w+) = AAProfile::from_bytes\(b\"(\w+)\", (\d+), (-?\d+), (-?\d+), (-?\d+), (-?\d+), (-?\d+), (-?\d+)\);", line)
+        if m:
+            prof[m.group(1)] = {"bytes": m.group(2), "block_size": int(m.group(3)), "match": int(m.group(4)), "mismatch": int(m.group(5)),
+                                "gap_open_C": int(m.group(6)), "gap_close_C": int(m.group(7)), "gap_open_R": int(m.group(8)),
+                                "gap_extend": int(m.group(9)), "gap_close_C_at": []}
+        m = re.search(r"(\w+)\.set_gap_close_C\((\d+), (-?\d+)\);", line)
+        if m:
+            prof[m.group(1)]["gap_close_C_at"].append([int(m.group(2)), int(m.group(3))])
+        m = re.search(r"let (\w+) = PaddedBytes::from_bytes::<AAMatrix>\(b\"(\w+)\", (\d+)\);", line)
+        if m:
+            seq[m.group(1)] = m.group(2)
+        m = re.search(r"a\.align_profile\(&(\w+), &(\w+), (\d+)\.\.=(\d+), (\d+)\);", line)
+        if m:
+            v = {"line": no, "trace": block[0], "x_drop_mode": block[1], "q": seq[m.group(1)], "min_size": int(m.group(3)),
+                 "max_size": int(m.group(4)), "x_drop": int(m.group(5))}
+            v.update({k: (list(map(list, x)) if k == "gap_close_C_at" else x) for k, x in prof[m.group(2)].items()})
+            out.append(v)
+            continue
+        if not out:
+            continue
+        v = out[-1]
+        m = re.search(r"assert_eq!\(a\.res\(\)\.score, (-?\d+)\);", line)
+        if m:
+            v["score"] = int(m.group(1))
+        m = re.search(r"assert_eq!\(res, AlignResult \{ score: (-?\d+), query_idx: (\d+), reference_idx: (\d+) \}\);", line)
+        if m:
+            v["score"], v["query_idx"], v["reference_idx"] = int(m.group(1)), int(m.group(2)), int(m.group(3))
+        m = re.search(r"assert_eq!\(cigar\.to_string\(\), \"([^\"]*)\"\);", line)
+        if m:
+            v["cigar"] = m.group(1)
+    return out
 
 
 if __name__ == "__main__":

@@ -93,6 +93,44 @@ def test_every_crate_unit_test_vector(orc, idx):
         assert cigar == v["cigar"], (v, cigar)
 
 
+def _profile_from_bytes(v):
+    """AAProfile::from_bytes (scores.rs:510-526): row p = the scores of profile position p for the letters A .. Z (index letter - 'A'),
+    everything else as AAProfile::new leaves it (i8::MIN); gap costs set for the indices 0 .. len"""
+    b = v["bytes"]
+    rows = np.full((len(b), 32), -128, np.int8)
+    for i, c in enumerate(b):
+        rows[i, :26] = v["mismatch"]
+        rows[i, ord(c) - ord("A")] = v["match"]
+    n = len(b) + 1
+    goc = np.full(n, v["gap_open_C"], np.int16)
+    gcc = np.full(n, v["gap_close_C"], np.int16)
+    gor = np.full(n, v["gap_open_R"], np.int16)
+    for i, g in v["gap_close_C_at"]:
+        gcc[i] = g
+    return rows, goc, gcc, gor
+
+
+@pytest.mark.parametrize("idx", range(6))
+def test_crate_profile_vectors(orc, idx):
+    """scan_block.rs test_profile (:2432-2477): Block<false, false> / <true, false>::align_profile of a sequence against an AAProfile
+    with position-specific gap costs - scores 4 / 1 / 0, and the traces `2M6I16M3D` (twice, with and without a closing cost) and
+    `2M6I14M3D2M` (closing costs changed at two positions).  The path the reference takes for PROFILE queries in the block aligner's
+    range (alignStartPosBacktraceBlock<PROFILE_SEQ>, StripedSmithWaterman.cpp:963-990, :1039-1049)."""
+    import json
+    v = json.load(open(os.path.join(ROOT, "tests", "golden", "block_crate_vectors.json")))["profile_vectors"][idx]
+    rows, goc, gcc, gor = _profile_from_bytes(v)
+    # The asserts of test_profile are upstream 0.4.0's: the vendored crate carries two edited lines (scan_block.rs:724-725, :731-732,
+    # the upstream lines left as comments: opening a gap no longer adds the extension) and its tests were not updated.  The
+    # restatement replays the vectors in the upstream form; the form the reference links is the other value of the same switch.
+    s, qi, ri, cigar = orc.block_align_profile(_codes(v["q"]), rows, goc, gcc, gor, v["gap_extend"], v["block_size"], v["min_size"],
+                                               v["max_size"], v["x_drop"], v["trace"], v["x_drop_mode"], upstream_gaps=True)
+    assert s == v["score"], (v, s)
+    if "query_idx" in v:
+        assert (qi, ri) == (v["query_idx"], v["reference_idx"]), (v, qi, ri)
+    if "cigar" in v:
+        assert cigar == v["cigar"], (v, cigar)
+
+
 def _family_pairs(seed, n_fam, members, per_query):
     (qres, qoff), (tres, toff), fam_t, fam_q = wl.config3_prefilter(n_fam, members, n_fam, seed=seed)
     qs, ts = wl.split(qres, qoff), wl.split(tres, toff)
@@ -150,6 +188,47 @@ def test_reference_glue_over_the_c_api_equals_the_restated_wrapper(orc, matrices
         assert (b["q_start"], b["t_start"], b["ident"], b["bt"]) == (r["q_start"], r["t_start"], r["ident"], r["bt"])
         n += 1
     assert n > 150
+
+
+@pytest.mark.skipif(not (os.path.exists(po.REF_BLOCK_SO) and po.ref_matrix_available()), reason="needs oracle/_ref/libmmref_block.so (make -C oracle refblock)")
+def test_reference_profile_glue_over_the_c_api_equals_the_restated_wrapper(orc, matrices):
+    """PROFILE queries: the reference's own alignStartPosBacktraceBlock<PROFILE_SEQ> (compiled here) - the AAProfile it fills through
+    the crate's raw pointers, its loop over the block sizes, its walk over the CIGAR with I / D changing sides - running over the
+    crate's C API served by the restatement, against the restated wrapper mmo_sw_block_backtrace_profile: start positions,
+    identities, backtrace strings; and every path re-scores on the profile to the SW score."""
+    from tests.test_profile_query import cases
+    mat = matrices["blosum62_sw"]
+    ref = po.RefLib(db_residues=300000000, lib_path=po.REF_BLOCK_SO, comp_bias=False)
+    rng = np.random.default_rng(77)
+    n = block = 0
+    for e, ts in cases(rng, mat, n_queries=8):
+        prof20, cons = ref.sw_set_profile_query(e)
+        prof = np.concatenate([prof20, np.zeros((1, prof20.shape[1]), np.int8)])      # ssw_init: the X row is neutral (:1391)
+        for t in ts:
+            r = ref.sw_align(t, mode=2, evalue_thr=1e300)
+            if r["t_end"] == -1 or r["word"] != 1:
+                continue
+            n += 1
+            b = orc.sw_block_backtrace_profile(prof, cons, t, 11, 1, r["score"], r["q_end"], r["t_end"])
+            if b is None:       # "Block alignment failed": the reference fell back to its reverse scan + banded traceback
+                o = orc.sw_align_profile(prof20, cons, t, 21, 11, 1, need_start=True, need_bt=True)
+                assert (o["q_start"], o["t_start"], o["ident"], o["bt"]) == (r["q_start"], r["t_start"], r["ident"], r["bt"])
+                continue
+            block += 1
+            assert (b["q_start"], b["t_start"], b["ident"], b["bt"]) == (r["q_start"], r["t_start"], r["ident"], r["bt"])
+            qp, tp, sc, prev = b["q_start"], b["t_start"], 0, "M"
+            for ch in b["bt"]:
+                if ch == "M":
+                    sc += int(prof[int(t[tp]), qp])
+                    qp += 1
+                    tp += 1
+                else:
+                    sc -= 1 if prev == ch else 11
+                    qp += ch == "I"
+                    tp += ch == "D"
+                prev = ch
+            assert (sc, qp - 1, tp - 1) == (r["score"], r["q_end"], r["t_end"])
+    assert n >= 12 and block >= 10, (n, block)
 
 
 def test_recorded_rust_vectors(orc, matrices):
