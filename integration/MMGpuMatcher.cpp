@@ -208,12 +208,13 @@ bool MMGpuMatcher::alignBlock(const std::vector<Query> &queries, int covMode, fl
                 const bool lowEval = a.evalue > (queries[q].evalThr >= 0.0 ? queries[q].evalThr : evalThr);
                 if (!(alignmentMode == 0 || ((alignmentMode == 2 || alignmentMode == 1) && (lowEval || lowCov)))) {
                     // word == 1: the stock reference asks the block aligner first (:865-882)
-                    if (a.word == 1 && (blockHook != NULL || deviceBlockAligner) && queries[q].profile != NULL) {
-                        // the stock reference runs the block aligner's profile form here; neither the device kernel nor the
-                        // hook below speaks profiles, so the pair goes back to the host's own Matcher::getSWResult as a whole
+                    if (a.word == 1 && deviceBlockAligner) {
+                        // one device call for all of them, below - profile queries included (round 5: the kernel takes the query's
+                        // score rows in place of matrix + bias, alignStartPosBacktraceBlock<PROFILE_SEQ>)
+                        pe.needsBlock = true;
+                    } else if (a.word == 1 && blockHook != NULL && queries[q].profile != NULL) {
+                        // the host-side hook below speaks sequences only: the pair goes back to the host's own Matcher::getSWResult
                         pe.refuse = true;
-                    } else if (a.word == 1 && deviceBlockAligner) {
-                        pe.needsBlock = true;      // one device call for all of them, below
                     } else if (a.word == 1 && blockHook != NULL) {
                         s_align b = a;
                         std::string bt;

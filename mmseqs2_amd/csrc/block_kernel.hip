@@ -83,10 +83,23 @@ struct BkSeq {
     const int8_t *bias;   // per-position bias of the forward sequence (nullptr = 0)
     int end;              // forward index of reversed position 1
     int len;              // reversed prefix length (end + 1)
+    // Profile query (alignStartPosBacktraceBlock<PROFILE_SEQ>, StripedSmithWaterman.cpp:963-990): this "sequence" is the AAProfile
+    // the reference builds from the reversed prefix of the query's score rows - prof = int8 [alphabet][plen] (ssw_init's
+    // profile->mat, the X row neutral), its elements are POSITIONS, the score of a cell is the row of the other sequence's letter
+    // at that position; letters beyond the alphabet and padding positions score i8::MIN (AAProfile::new, scores.rs:494-507).
+    // With the gap costs the reference sets (every opening gap_open, closing 0, :988-990) place_block_profile (scan_block.rs:
+    // 649-815) is place_block_aa with this score: one kernel body serves both.  res = the consensus sequence (identities, :1076).
+    const int8_t *prof;
+    int plen, alphabet;
 };
 // PaddedBytes::get / PosBias::get at DP index p: index 0 and everything past the end is the padding letter / bias 0
 __device__ __forceinline__ int bk_letter(const BkSeq &s, int p) { return (p >= 1 && p <= s.len) ? (int)s.res[s.end - (p - 1)] : 26; }
 __device__ __forceinline__ int bk_bias(const BkSeq &s, int p) { return (s.bias && p >= 1 && p <= s.len) ? (int)s.bias[s.end - (p - 1)] : 0; }
+// a profile's element at DP index p: the forward position, -1 for the padding in front and behind
+__device__ __forceinline__ int bk_pos(const BkSeq &s, int p) { return (p >= 1 && p <= s.len) ? s.end - (p - 1) : -1; }
+__device__ __forceinline__ int bk_prof_score(const BkSeq &pr, int pos, int letter) {
+    return (pos >= 0 && letter < pr.alphabet) ? (int)pr.prof[(size_t)letter * pr.plen + pos] : -128;
+}
 
 struct BkBlock { uint32_t i, j; uint16_t h, w; uint32_t right, tstart; };   // Trace::block_start / block_size / right + first trace entry
 
@@ -109,11 +122,12 @@ __device__ __forceinline__ BkMax bk_place_block(const BlockLaunch &L, const int8
     M.dmax = BK_MIN; M.ai = 0; M.aj = 0;
     if (width == 0 || height == 0) return M;
     const int iters = (height + 63) >> 6;
-    // blocks of up to 64 rows (nearly all): a lane's row - its letter and bias - is the same for every column
-    const int row_letter0 = bk_letter(query, start_i + lane), row_bias0 = bk_bias(query, start_i + lane);
+    const bool rows_prof = query.prof != nullptr, cols_prof = reference.prof != nullptr;      // wave-uniform; at most one of them
+    // blocks of up to 64 rows (nearly all): a lane's row - its letter (position, for a profile) and bias - is the same for every column
+    const int row_letter0 = rows_prof ? bk_pos(query, start_i + lane) : bk_letter(query, start_i + lane), row_bias0 = bk_bias(query, start_i + lane);
     const int row = lane >> 4;
     for (int j = 0; j < width; j++) {
-        const int c = bk_letter(reference, start_j + j);
+        const int c = cols_prof ? bk_pos(reference, start_j + j) : bk_letter(reference, start_j + j);
         const int rbias = bk_bias(reference, start_j + j);
         int carryR = BK_MIN, corner = D_corner, carry_tr = 0;
         int D11 = BK_MIN, R11 = BK_MIN;
@@ -125,8 +139,11 @@ __device__ __forceinline__ BkMax bk_place_block(const BlockLaunch &L, const int8
             const int D00 = shift_up1(D10, corner);
             const int last = min(63, height - 1 - (it << 6));
             if (more) corner = __builtin_amdgcn_readlane(D10, 63);
-            const int ql = iters == 1 ? row_letter0 : bk_letter(query, start_i + i);
-            const int sc = (int)scores[c * 32 + (ql & 31)];
+            const int ql = iters == 1 ? row_letter0 : (rows_prof ? bk_pos(query, start_i + i) : bk_letter(query, start_i + i));
+            int sc;
+            if (cols_prof) sc = bk_prof_score(reference, c, ql);            // get_scores_pos: the column's position, the rows' letters
+            else if (rows_prof) sc = bk_prof_score(query, ql, c);           // get_scores_aa: the column's letter, the rows' positions
+            else sc = (int)scores[c * 32 + (ql & 31)];
             const int pos_bias = adds16(rbias, iters == 1 ? row_bias0 : bk_bias(query, start_i + i));
             D11 = adds16(D00, adds16(sc, pos_bias));
             if (start_i + i == 0 && start_j + j == 0) D11 = BK_ZERO;
@@ -429,10 +446,18 @@ __global__ __launch_bounds__(64) void sw_block_kernel(BlockLaunch L) {
     Q.bias = L.q_cb + L.q_off[J.query];
     Q.end = J.q_end;
     Q.len = qa;
+    Q.prof = nullptr; Q.plen = 0; Q.alphabet = L.alphabet;
+    if (L.q_prof_off != nullptr && L.q_prof_off[J.query] != 0xFFFFFFFFu) {      // profile query (wave-uniform)
+        Q.prof = L.q_prof + L.q_prof_off[J.query];
+        Q.plen = (int)(L.q_off[J.query + 1] - L.q_off[J.query]);
+        Q.bias = nullptr;      // (no composition bias on profile queries)
+    }
+    const bool prof = Q.prof != nullptr;
     T.res = L.t_res + (size_t)L.t_off4[J.target] * 4;
     T.bias = nullptr;
     T.end = J.t_end;
     T.len = ta;
+    T.prof = nullptr; T.plen = 0; T.alphabet = L.alphabet;
     const BkConsts K = bk_consts(L.gap_extend, lane);
     mmgpu_sw_block out;
     out.q_start = -1; out.t_start = -1; out.ident = 0; out.bt_len = 0; out.bt_off = L.bt_off[J.slot];
@@ -449,7 +474,10 @@ __global__ __launch_bounds__(64) void sw_block_kernel(BlockLaunch L) {
         S.trace_idx = S.block_idx = S.ck_trace_idx = S.ck_block_idx = 0;
         S.overflow = false;
         const int x_drop = -(min_size * L.gap_extend + L.gap_open);
-        bk_align(L, s_scores, S, Q, T, min_size, MAXB, x_drop, K, lane, &score, &ri, &rj);
+        // a profile query is the crate's `reference` (the columns), the target its `query` (block_align_profile_aa_trace_xdrop(trace,
+        // target, queryProfile, ..), :1047): ri then counts target residues, rj profile positions
+        if (prof) bk_align(L, s_scores, S, T, Q, min_size, MAXB, x_drop, K, lane, &score, &ri, &rj);
+        else bk_align(L, s_scores, S, Q, T, min_size, MAXB, x_drop, K, lane, &score, &ri, &rj);
         if (S.overflow) too_large = true;
     }
     // MAXB < 4096: the crate would go on to larger minimum sizes when the score is not reached - not decided by this instantiation
@@ -520,7 +548,7 @@ __global__ __launch_bounds__(64) void sw_block_kernel(BlockLaunch L) {
                     else { op = 5; di = 0; dj = 1; nt = (t2 & 2u) ? 0 : 1; }
                 }
                 if (op == 1) {      // identities: the letters of DP indices i, j = forward indices end - (i - 1), end - (j - 1), both rising along the walk
-                    const int qf = Q.end - (i - 1), tf = T.end - (j - 1);
+                    const int qf = Q.end - ((prof ? j : i) - 1), tf = T.end - ((prof ? i : j) - 1);
                     if ((unsigned)(qf - qf_lo) >= 64u || qf_lo < 0) {
                         qf_lo = qf;
                         qwin = qf_lo + lane <= Q.end ? (int)Q.res[qf_lo + lane] : 255;
@@ -531,7 +559,8 @@ __global__ __launch_bounds__(64) void sw_block_kernel(BlockLaunch L) {
                     }
                     ids += __builtin_amdgcn_readlane(qwin, qf - qf_lo) == __builtin_amdgcn_readlane(twin, tf - tf_lo) ? 1u : 0u;
                 }
-                if (lane == (int)(n & 63u)) my_op = op == 1 ? 'M' : (op == 4 ? 'I' : 'D');
+                // (a profile query sits on the crate's reference side: its I consumes the target = the reference's 'D', :1083-1101)
+                if (lane == (int)(n & 63u)) my_op = op == 1 ? 'M' : ((op == 4) != prof ? 'I' : 'D');
                 n++;
                 if ((n & 63u) == 0) bt[n - 64 + lane] = (char)my_op;
                 i -= di;
@@ -541,8 +570,8 @@ __global__ __launch_bounds__(64) void sw_block_kernel(BlockLaunch L) {
         }
         if ((n & 63u) != 0 && lane < (int)(n & 63u)) bt[(n & ~63u) + lane] = (char)my_op;
         out.status = MMGPU_BLOCK_OK;
-        out.q_start = J.q_end + 1 - ri;       // :1111-1112
-        out.t_start = J.t_end + 1 - rj;
+        out.q_start = J.q_end + 1 - (prof ? rj : ri);       // :1111-1112
+        out.t_start = J.t_end + 1 - (prof ? ri : rj);
         out.ident = ids;
         out.bt_len = n;
     }

@@ -1282,8 +1282,8 @@ extern "C" int mmgpu_sw_block_backtrace(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const
         out[k].q_start = -1; out[k].t_start = -1; out[k].ident = 0; out[k].bt_len = 0; out[k].bt_off = off; out[k].reserved = 0;
         bt_off[k] = off;
         const uint32_t q = (uint32_t)(std::upper_bound(b->h_qout_off.begin(), b->h_qout_off.end(), p) - b->h_qout_off.begin() - 1);
-        const bool profile_query = b->any_profile && b->h_query_is_profile.size() > q && b->h_query_is_profile[q];
-        if (h.score <= 0 || h.word != 1 || h.t_end < 0 || profile_query) {
+        // (profile queries run the same kernel with the query's score rows in place of matrix + bias: block_kernel.hip, BkSeq::prof)
+        if (h.score <= 0 || h.word != 1 || h.t_end < 0) {
             out[k].status = MMGPU_BLOCK_NOT_WORD;
             continue;
         }
@@ -1352,6 +1352,9 @@ extern "C" int mmgpu_sw_block_backtrace(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const
     L.t_res = c->db.res;
     L.t_off4 = c->db.off4;
     L.scores = d_scores.as<int8_t>();
+    L.q_prof = b->any_profile ? b->d_qprof.as<int8_t>() : nullptr;
+    L.q_prof_off = b->any_profile ? b->d_qprof_off.as<uint32_t>() : nullptr;
+    L.alphabet = b->alphabet;
     L.gap_open = -b->gap_open;
     L.gap_extend = -b->gap_extend;
     L.out = d_out.as<mmgpu_sw_block>();

@@ -503,6 +503,9 @@ struct BlockLaunch {
     const uint32_t *q_off;
     const uint8_t *t_res;
     const uint32_t *t_off4;
+    const int8_t *q_prof;         // profile queries, as in SwLaunch: int8 [alphabet][qlen] per query; null = none in the batch
+    const uint32_t *q_prof_off;
+    int alphabet;
     const int8_t *scores;         // AAMatrix::scores [27 * 32] as ssw_init leaves it (new_simple(1, -1) + set_num of the matrix)
     int gap_open, gap_extend;     // the crate's convention: negative
     mmgpu_sw_block *out;

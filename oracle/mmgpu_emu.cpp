@@ -189,7 +189,7 @@ int mmgpu_sw_block_backtrace(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const uint32_t *
     std::vector<size_t> off(n);
     for (uint32_t i = 0; i < n; i++) {
         const mmgpu_sw_hit &h = b->res[idx[i]];
-        const bool word = h.score > 0 && h.word == 1 && h.t_end >= 0 && b->prof_letters[b->pair[idx[i]].first] == 0;
+        const bool word = h.score > 0 && h.word == 1 && h.t_end >= 0;
         off[i] = need;
         if (word) need += (size_t)h.q_end + 1 + (size_t)h.t_end + 1 + 1;
     }
@@ -207,7 +207,7 @@ int mmgpu_sw_block_backtrace(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const uint32_t *
         memset(&out[i], 0, sizeof(out[i]));
         out[i].q_start = out[i].t_start = -1;
         out[i].bt_off = off[i];
-        if (!(h.score > 0 && h.word == 1 && h.t_end >= 0 && b->prof_letters[qi] == 0)) {
+        if (!(h.score > 0 && h.word == 1 && h.t_end >= 0)) {
             out[i].status = MMGPU_BLOCK_NOT_WORD;
             continue;
         }
@@ -220,8 +220,17 @@ int mmgpu_sw_block_backtrace(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const uint32_t *
         const int tlen = (int)(c->toff[id + 1] - c->toff[id]);
         int qs = -1, ts = -1, len = 0, bs = 0;
         uint32_t ident = 0;
-        const int ok = mmo_sw_block_backtrace(q.data(), b->cb[qi].data(), (int)q.size(), t, tlen, b->mat.data(), b->alphabet, b->go, b->ge, h.score,
-                                              h.q_end, h.t_end, &qs, &ts, &ident, bt + off[i], h.q_end + h.t_end + 3, &len, &bs);
+        int ok;
+        if (b->prof_letters[qi] != 0) {      // profile query: its score rows with the X row neutral (ssw_init :1389-1391), the query on the crate's reference side
+            std::vector<int8_t> rows((size_t)b->alphabet * q.size(), 0);
+            const int letters = std::min(b->prof_letters[qi], b->alphabet - 1);
+            memcpy(rows.data(), b->prof[qi].data(), (size_t)letters * q.size());
+            ok = mmo_sw_block_backtrace_profile(rows.data(), q.data(), (int)q.size(), t, tlen, b->alphabet, b->go, b->ge, h.score, h.q_end, h.t_end, &qs, &ts,
+                                                &ident, bt + off[i], h.q_end + h.t_end + 3, &len, &bs);
+        } else {
+            ok = mmo_sw_block_backtrace(q.data(), b->cb[qi].data(), (int)q.size(), t, tlen, b->mat.data(), b->alphabet, b->go, b->ge, h.score,
+                                        h.q_end, h.t_end, &qs, &ts, &ident, bt + off[i], h.q_end + h.t_end + 3, &len, &bs);
+        }
         if (!ok) {
             out[i].status = MMGPU_BLOCK_DECLINED;
             continue;

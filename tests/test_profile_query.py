@@ -188,6 +188,61 @@ def test_device_profile_queries_equal_oracle_random(gpu):
     b.free()
 
 
+@pytest.mark.gpu
+def test_device_block_aligner_for_profile_queries_equals_the_restatement(gpu):
+    """a15 for PROFILE queries (round 5): mmgpu_sw_block_backtrace on the int16-range pairs of profile queries - the query's score rows
+    in place of matrix + bias, the query on the crate's reference side (block_kernel.hip, BkSeq::prof) - against the restated
+    alignStartPosBacktraceBlock<PROFILE_SEQ> (oracle/block_oracle.c, itself equal to the reference's compiled glue over the restated
+    crate, tests/test_block_oracle.py); a sequence query rides in the same batch."""
+    from mmseqs2_amd.capi import host_comp_bias
+    mats = np.load(os.path.join(HERE, "golden", "matrices.npz"))
+    mat = mats["blosum62_sw"]
+    orc = Oracle()
+    rng = np.random.default_rng(91)
+    cs = cases(rng, mat, n_queries=7)
+    targets = [t for _, ts in cs for t in ts]
+    from mmseqs2_amd import workloads as wl
+    tres, toff = wl.seqs_from_list(targets)
+    gpu.load_targets(tres, toff, 21)
+    ids = np.arange(len(targets), dtype=np.uint32)
+    queries = []
+    for qi, (e, ts) in enumerate(cs):
+        cons = e[:, 20].astype(np.uint8)
+        if qi == 3:
+            _, cb = host_comp_bias(mat.astype(np.int16), mats["blosum62_pback"], cons)
+            queries.append(dict(q=cons, comp_bias=cb, targets=ids, min_start_score=0))
+        else:
+            prof = (e[:, :20].astype(np.int32) / 4).astype(np.int8).T.copy()
+            queries.append(dict(q=cons, comp_bias=None, profile=prof, targets=ids, min_start_score=0))
+    b = gpu.sw_prepare(mat, 11, 1, queries, mode=1)
+    b.run()
+    out = b.fetch().reshape(len(queries), len(targets))
+    blk, strs = b.block_backtrace(np.arange(out.size, dtype=np.uint32))
+    n_prof = n_seq = 0
+    for qi, qd in enumerate(queries):
+        for k, t in enumerate(targets):
+            p = qi * len(targets) + k
+            h = out[qi, k]
+            if int(h["word"]) != 1 or int(h["score"]) <= 0:
+                assert int(blk[p]["status"]) == 3      # MMGPU_BLOCK_NOT_WORD
+                continue
+            if "profile" in qd:
+                prof21 = np.concatenate([qd["profile"], np.zeros((1, qd["profile"].shape[1]), np.int8)])
+                w = orc.sw_block_backtrace_profile(prof21, qd["q"], t, 11, 1, int(h["score"]), int(h["q_end"]), int(h["t_end"]))
+                n_prof += 1
+            else:
+                r = orc.block_backtrace(qd["q"], qd["comp_bias"], t, mat, 11, 1, int(h["score"]), int(h["q_end"]), int(h["t_end"]))
+                w = dict(q_start=r["q_start"], t_start=r["t_start"], ident=r["ident"], bt=r["bt"]) if r["ok"] else None
+                n_seq += 1
+            if w is None:
+                assert int(blk[p]["status"]) == 1, (qi, k)      # MMGPU_BLOCK_DECLINED: "Block alignment failed"
+                continue
+            assert int(blk[p]["status"]) == 0, (qi, k, int(blk[p]["status"]))
+            assert (int(blk[p]["q_start"]), int(blk[p]["t_start"]), int(blk[p]["ident"]), strs[p]) == (w["q_start"], w["t_start"], w["ident"], w["bt"]), (qi, k)
+    assert n_prof >= 10 and n_seq >= 1, (n_prof, n_seq)
+    b.free()
+
+
 PF_PROFILE_THR = 99                                      # getKmerThreshold(5.7, profile, k = 6): 134.35 - 6.15 * 5.7
 PF_PROFILE_SETTINGS = [(300, 2), (10, 32), (4, 2)]       # (max_hits, CacheFriendlyOperations bins)
 GOLD_PF = os.path.join(HERE, "golden", "profile_pf.npz")
