@@ -195,8 +195,9 @@ int mmgpu_sw_traceback(mmgpu_ctx *ctx, mmgpu_sw_batch_t *batch, const uint32_t *
                        mmgpu_sw_bt *info, char *bt, size_t bt_cap, size_t *bt_used);
 
 /* Int16-range hits (mmgpu_sw_hit::word == 1) whose start position the reference takes from the block aligner, not from the
- * reverse scan: SmithWaterman::alignStartPosBacktraceBlock<SEQ_SEQ> (StripedSmithWaterman.cpp:943-1127 -> lib/block-aligner
- * 0.4.0, AVX2 configuration) on the device (block_kernel.hip), for sequence queries.  One call serves what the reference gets
+ * reverse scan: SmithWaterman::alignStartPosBacktraceBlock<SEQ_SEQ> and, since round 5, <PROFILE_SEQ> (StripedSmithWaterman.cpp:
+ * 943-1127 -> lib/block-aligner 0.4.0, AVX2 configuration; a profile query's score rows take the place of matrix + bias and the
+ * query sits on the crate's reference side, :963-990) on the device (block_kernel.hip).  One call serves what the reference gets
  * from one block-aligner run: start positions (modes >= 1), identities and the backtrace string (mode 3 / -a).
  * Restated from the crate's source; this image has no Rust toolchain, so equality with a Rust-linked build is pinned only as
  * far as tests/test_block_oracle.py goes (the crate's own test vectors, the invariants the reference checks, the recorded
@@ -216,7 +217,7 @@ typedef struct {
 #define MMGPU_BLOCK_TOO_LARGE 2  /* not decided on the device: the pair's scratch (4096-row blocks, as the crate's) could not be
                                     allocated.  Blocks grow to the crate's own 4096 rows (second launch for the pairs that
                                     leave the 512-row LDS form), so this no longer depends on the pair */
-#define MMGPU_BLOCK_NOT_WORD 3   /* not an int16-range hit of a sequence query with a positive score */
+#define MMGPU_BLOCK_NOT_WORD 3   /* not an int16-range hit with a positive score */
 /* pair_index as for mmgpu_sw_traceback (any mode: only score / q_end / t_end of the forward scan are read); every pair reserves
  * (q_end + 1) + (t_end + 1) + 1 bytes of bt.  bt == NULL with bt_cap == MMGPU_BLOCK_NO_STRINGS: the caller wants start positions,
  * identities and bt_len only (a run without -a: the strings stay on the device, no download). */
