@@ -224,6 +224,13 @@ typedef struct {
 #define MMGPU_BLOCK_NO_STRINGS ((size_t)-1)
 int mmgpu_sw_block_backtrace(mmgpu_ctx *ctx, mmgpu_sw_batch_t *batch, const uint32_t *pair_index, uint32_t n_pairs,
                              mmgpu_sw_block *out, char *bt, size_t bt_cap, size_t *bt_used);
+/* Test aid (the growth-sequence test of tests/test_sw_gpu.py): the same run without strings, plus every pair's block list as it
+ * stands when the crate's align_core returns - Trace::block_start / block_size / right, i.e. the sequence of grow / shift-right /
+ * shift-down steps with their sizes after every x-drop restore.  growth: n_pairs x (1 + 4 * growth_cap) words, per pair the number
+ * of blocks (it may exceed growth_cap: the list is cut, not the count; 0 for MMGPU_BLOCK_TOO_LARGE) and (i, j, height << 16 | width,
+ * right) per block. */
+int mmgpu_sw_block_growth(mmgpu_ctx *ctx, mmgpu_sw_batch_t *batch, const uint32_t *pair_index, uint32_t n_pairs, mmgpu_sw_block *out,
+                          uint32_t *growth, uint32_t growth_cap);
 /* reporting: how many pairs of the batch's LAST mmgpu_sw_block_backtrace call were decided with blocks up to 512 rows (borders
  * in LDS) and how many needed the second launch with the crate's full 4096-row blocks (borders in HBM) */
 int mmgpu_sw_block_tiers(const mmgpu_sw_batch_t *batch, uint32_t *first_tier, uint32_t *second_tier);

@@ -36,19 +36,37 @@ namespace {
 
 const unsigned char *lookupTarget(void *ctx, unsigned int id) {
     MMGpuAlignSession *s = static_cast<MMGpuAlignSession *>(ctx);
-    return s->tData + s->tOff[id];
+    return MMGpuAlignRun::targetResidues(s, id);
 }
 
 }  // namespace
 
+const unsigned char *MMGpuAlignRun::targetResidues(MMGpuAlignSession *s, size_t id) {
+    if (s->tData != NULL) return s->tData + s->tOff[id];
+    Alignment &al = s->al;
+    std::lock_guard<std::mutex> guard(s->onDemandLock);
+    std::unordered_map<size_t, std::vector<unsigned char> >::iterator it = s->onDemand.find(id);
+    if (it != s->onDemand.end()) return it->second.data();
+    if (s->onDemandSeq == NULL) s->onDemandSeq = new Sequence(al.maxSeqLen, al.targetSeqType, al.m, 0, false, al.compBiasCorrection);
+    char *data = al.tdbr->getDataUncompressed(id);      // (MMGpuFusedSearch::residentTargets: never a compressed database)
+    std::vector<unsigned char> &v = s->onDemand[id];
+    if (data != NULL) {
+        s->onDemandSeq->mapSequence(id, al.tdbr->getDbKey(id), data, al.tdbr->getSeqLen(id));
+        v.assign(s->onDemandSeq->numSequence, s->onDemandSeq->numSequence + s->onDemandSeq->L);
+    }
+    v.push_back(0);
+    return v.data();
+}
+
 MMGpuAlignSession::MMGpuAlignSession(Alignment &al, EvalueComputation &evaluer)
     : al(al), evaluer(evaluer), gpu(NULL), nucleotide(false), watch("align"), backend(NULL), matcher(NULL), blockHook(NULL), start(0), size(0),
-      tData(NULL), tOff(NULL), nucl(NULL) {}
+      tData(NULL), tOff(NULL), onDemandSeq(NULL), nucl(NULL) {}
 
 MMGpuAlignSession::~MMGpuAlignSession() {
     delete matcher;
     delete backend;
     delete static_cast<HostBlockBacktracer *>(blockHook);
+    delete onDemandSeq;
 }
 
 bool MMGpuAlignRun::usable(const Alignment &a) {
@@ -194,6 +212,7 @@ void MMGpuAlignRun::plan(MMGpuAlignSession *s, size_t start, size_t bucketSize) 
     Alignment &al = s->al;
     const size_t nq = bucketSize;
     const bool profileQuery = Parameters::isEqualDbtype(al.querySeqType, Parameters::DBTYPE_HMM_PROFILE);
+    s->onDemand.clear();
     s->block.assign(nq, MMGpuMatcher::Query());
     s->queryNum.assign(nq, std::vector<unsigned char>());
     s->queryProfile.assign(nq, std::vector<int8_t>());
@@ -251,8 +270,8 @@ void MMGpuAlignRun::plan(MMGpuAlignSession *s, size_t start, size_t bucketSize) 
                 t.id = (unsigned int)dbId;
                 t.dbKey = dbKey;
                 t.length = dbLen;
-                t.numSequence = s->tData + s->tOff[dbId];
                 t.isIdentity = (queryDbKey == dbKey && (al.includeIdentity || al.sameQTDB)) ? true : false;
+                t.numSequence = s->tData != NULL ? s->tData + s->tOff[dbId] : ((t.isIdentity || al.correlationScoreWeight > 0.0f) ? targetResidues(s, dbId) : NULL);
                 q.targets.push_back(t);
             }
             s->hostPair[b].assign(q.targets.size(), 0);

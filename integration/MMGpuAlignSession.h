@@ -3,6 +3,8 @@
 #ifndef MMGPU_ALIGN_SESSION_H
 #define MMGPU_ALIGN_SESSION_H
 
+#include <mutex>
+#include <unordered_map>
 #include <vector>
 
 #include "Matcher.h"
@@ -30,6 +32,13 @@ struct MMGpuAlignSession {
     // amino-acid path reads
     const unsigned char *tData;
     const uint64_t *tOff;
+    // ... or nothing on the host at all (tData == NULL: the prefilter module loaded a persisted device layout,
+    // MMGpuFusedSearch::keepResidentTargetsOnDevice): the few sequences the host still reads - identity hits, --corr-score-weight,
+    // the test binary's host-side block aligner - are mapped when asked for and kept for the bucket
+    // (MMGpuAlignRun::targetResidues)
+    std::mutex onDemandLock;
+    std::unordered_map<size_t, std::vector<unsigned char> > onDemand;
+    Sequence *onDemandSeq;
     // the target database numbers its sequences by their keys (key i = id i, what createdb writes): DBReader::getId's binary
     // search per list entry - half of the list parsing at millions of targets - is then the identity
     bool denseTargetKeys;

@@ -58,9 +58,11 @@ PrefStore store;
 struct ResidentTargets {
     SequenceLookup *lookup;
     std::vector<unsigned int> keys;
+    std::vector<uint64_t> offsets;                   // device-only hand-over (persisted layout): no lookup, the lengths as the reader gave them
+    bool deviceOnly;
     void *gpu;
     bool decided;                                    // overlapped run: the prefilter hook has offered the lookup, or never will
-    ResidentTargets() : lookup(NULL), gpu(NULL), decided(false) {}
+    ResidentTargets() : lookup(NULL), deviceOnly(false), gpu(NULL), decided(false) {}
 };
 ResidentTargets resident;
 
@@ -297,6 +299,7 @@ int MMGpuFusedSearch::run(Parameters &par, const std::string &query, const std::
     store.on = false;
     delete resident.lookup;
     resident.lookup = NULL;
+    resident.deviceOnly = false;
     if (status != EXIT_SUCCESS) {
         Debug(Debug::ERROR) << "Alignment died\n";
         EXIT(EXIT_FAILURE);
@@ -342,6 +345,29 @@ void MMGpuFusedSearch::keepResidentTargets(SequenceLookup *lookup, DBReader<unsi
     fusedChanged.notify_all();
 }
 
+void MMGpuFusedSearch::keepResidentTargetsOnDevice(DBReader<unsigned int> *tdbr, void *gpu) {
+    const size_t n = tdbr->getSize();
+    std::vector<unsigned int> keys(n);
+    std::vector<uint64_t> offsets(n + 1, 0);
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; i++) {
+        keys[i] = tdbr->getDbKey(i);
+        offsets[i + 1] = tdbr->getSeqLen(i);
+    }
+    for (size_t i = 0; i < n; i++) offsets[i + 1] += offsets[i];
+    {
+        std::lock_guard<std::mutex> guard(fusedLock);
+        delete resident.lookup;
+        resident.lookup = NULL;
+        resident.deviceOnly = true;
+        resident.gpu = gpu;
+        resident.keys.swap(keys);
+        resident.offsets.swap(offsets);
+        resident.decided = true;
+    }
+    fusedChanged.notify_all();
+}
+
 bool MMGpuFusedSearch::overlappedRun() { return overlapped; }
 
 bool MMGpuFusedSearch::holdsLookup(const SequenceLookup *lookup) { return lookup != NULL && lookup == resident.lookup; }
@@ -377,16 +403,19 @@ bool MMGpuFusedSearch::residentTargets(DBReader<unsigned int> *tdbr, void *gpu, 
         std::unique_lock<std::mutex> guard(fusedLock);
         fusedChanged.wait(guard, []() { return resident.decided || store.producerDone; });
     }
-    if (resident.lookup == NULL || resident.gpu != gpu) return false;
-    const size_t n = resident.lookup->getSequenceCount();
+    if ((resident.lookup == NULL && !resident.deviceOnly) || resident.gpu != gpu) return false;
+    // (device only: single sequences are mapped on demand by the alignment hook, through the reader's first thread slot - an
+    // uncompressed database has no per-thread buffers behind getData)
+    if (resident.deviceOnly && tdbr->isCompressed()) return false;
+    const size_t n = resident.deviceOnly ? resident.keys.size() : resident.lookup->getSequenceCount();
     if (tdbr->getSize() != n) return false;
     static_assert(sizeof(size_t) == sizeof(uint64_t), "SequenceLookup::getOffsets() is handed over as it is");
-    const uint64_t *off = reinterpret_cast<const uint64_t *>(resident.lookup->getOffsets());
+    const uint64_t *off = resident.deviceOnly ? resident.offsets.data() : reinterpret_cast<const uint64_t *>(resident.lookup->getOffsets());
     bool same = true;
 #pragma omp parallel for schedule(static) reduction(&& : same)
     for (size_t i = 0; i < n; i++) same = same && tdbr->getDbKey(i) == resident.keys[i] && tdbr->getSeqLen(i) == off[i + 1] - off[i];
     if (!same) return false;
-    *data = reinterpret_cast<const unsigned char *>(resident.lookup->getData());
+    *data = resident.deviceOnly ? NULL : reinterpret_cast<const unsigned char *>(resident.lookup->getData());
     *offsets = off;
     return true;
 }

@@ -46,6 +46,9 @@ public:
     // gets it only if its own reader numbers the same sequences the same way.
     static bool keepsTargets();      // a fused run is in progress: worth handing the lookup over
     static void keepResidentTargets(SequenceLookup *lookup, DBReader<unsigned int> *tdbr, void *gpu);
+    // ... or, after a persisted device layout was loaded (MMGpuPrefilterRun::loadPersisted), nothing but the fact that the device
+    // holds the database's sequences: residentTargets() then returns the offsets (lengths as the reader gives them) and data = NULL
+    static void keepResidentTargetsOnDevice(DBReader<unsigned int> *tdbr, void *gpu);
     static bool residentTargets(DBReader<unsigned int> *tdbr, void *gpu, const unsigned char **data, const uint64_t **offsets);
 
     // ---- overlapped run: the alignment module works while the prefilter module still produces (MMGpuFusedSearch.cpp, bothModules) ----

@@ -66,9 +66,7 @@ bool MMGpuPrefilter::loadIndex(IndexTable *indexTable, SequenceLookup *sequenceL
     return true;
 }
 
-namespace {
-// FNV-1a, for the fingerprints of the persisted device layout (mmgpu_db_load / mmgpu_db_save)
-uint64_t mmgpuFnv(const void *p, size_t n, uint64_t h) {
+uint64_t MMGpuPrefilter::fingerprint(const void *p, size_t n, uint64_t h) {
     const unsigned char *b = static_cast<const unsigned char *>(p);
     for (size_t i = 0; i < n; i++) {
         h ^= b[i];
@@ -76,10 +74,60 @@ uint64_t mmgpuFnv(const void *p, size_t n, uint64_t h) {
     }
     return h;
 }
+
+uint64_t MMGpuPrefilter::indexFingerprint(int kmerSize, bool spacedKmer, int indexKmerThr, bool maskOnDevice, double maskProb,
+                                          bool similarKmerTables, const int32_t *more, size_t nMore) const {
+    const int a = ungappedSubMat->alphabetSize;
+    std::vector<int16_t> flat((size_t)2 * a * a);
+    for (int i = 0; i < a; i++)
+        for (int j = 0; j < a; j++) {
+            flat[(size_t)i * a + j] = (int16_t)kmerSubMat->subMatrix[i][j];
+            flat[(size_t)a * a + (size_t)i * a + j] = (int16_t)ungappedSubMat->subMatrix[i][j];
+        }
+    const int32_t scal[6] = {kmerSize, spacedKmer ? 1 : 0, indexKmerThr, maskOnDevice ? 1 : 0, kmerSubMat->alphabetSize, similarKmerTables ? 1 : 0};
+    uint64_t fp = fingerprint(scal, sizeof(scal));
+    fp = fingerprint(&maskProb, sizeof(maskProb), fp);
+    if (nMore) fp = fingerprint(more, nMore * sizeof(int32_t), fp);
+    return fingerprint(flat.data(), flat.size() * sizeof(int16_t), fp) | 1ull;      // (0 = "no index" in the library's calls)
+}
+
+namespace {
+void scoreTables(mmgpu_pf_index &ix, int kmerSize, int alphabet, bool spacedKmer, ScoreMatrix &threeMer, ScoreMatrix &twoMer, const int8_t *ungapped) {
+    memset(&ix, 0, sizeof(ix));
+    ix.kmer_size = kmerSize;
+    ix.alphabet = alphabet;
+    ix.spaced = spacedKmer ? 1 : 0;
+    ix.score3 = threeMer.isValid() ? threeMer.score : NULL;
+    ix.index3 = threeMer.isValid() ? threeMer.index : NULL;
+    ix.row3 = threeMer.isValid() ? threeMer.rowSize : 0;
+    ix.score2 = twoMer.isValid() ? twoMer.score : NULL;
+    ix.index2 = twoMer.isValid() ? twoMer.index : NULL;
+    ix.row2 = twoMer.isValid() ? twoMer.rowSize : 0;
+    ix.ungapped_mat = ungapped;
+}
+}
+
+bool MMGpuPrefilter::loadPersisted(const Persisted &file, size_t nTargets, int kmerSize, ScoreMatrix &threeMer, ScoreMatrix &twoMer, bool spacedKmer) {
+    if (multi != NULL) {
+        err = "a persisted layout holds one context's database (shards are dealt per run)";
+        return false;
+    }
+    const int a = ungappedSubMat->alphabetSize;
+    std::vector<int8_t> ungapped(a * a);
+    for (int i = 0; i < a; i++)
+        for (int j = 0; j < a; j++) ungapped[i * a + j] = (int8_t)ungappedSubMat->subMatrix[i][j];
+    mmgpu_pf_index ix;
+    scoreTables(ix, kmerSize, kmerSubMat->alphabetSize, spacedKmer, threeMer, twoMer, ungapped.data());
+    if (mmgpu_db_load(gpu, file.path.c_str(), file.sourceFp, file.indexFp, &ix) != 0) {
+        err = mmgpu_last_error();
+        return false;
+    }
+    dbSize = nTargets;
+    return true;
 }
 
 bool MMGpuPrefilter::buildIndex(SequenceLookup *sequenceLookup, int kmerSize, int indexKmerThr, ScoreMatrix &threeMer,
-                                ScoreMatrix &twoMer, bool spacedKmer, bool maskOnDevice, double maskProb, bool logMasked) {
+                                ScoreMatrix &twoMer, bool spacedKmer, bool maskOnDevice, double maskProb, bool logMasked, const Persisted *saveAs) {
     const size_t n = sequenceLookup->getSequenceCount();
     static_assert(sizeof(size_t) == sizeof(uint64_t), "SequenceLookup::getOffsets() is handed over as it is");
     const uint8_t *res = reinterpret_cast<const uint8_t *>(sequenceLookup->getData());
@@ -93,40 +141,17 @@ bool MMGpuPrefilter::buildIndex(SequenceLookup *sequenceLookup, int kmerSize, in
             kmer16[i * a + j] = (int16_t)kmerSubMat->subMatrix[i][j];
         }
     mmgpu_pf_index ix;
-    memset(&ix, 0, sizeof(ix));
-    ix.kmer_size = kmerSize;
-    ix.alphabet = kmerSubMat->alphabetSize;
-    ix.spaced = spacedKmer ? 1 : 0;
-    ix.score3 = threeMer.isValid() ? threeMer.score : NULL;
-    ix.index3 = threeMer.isValid() ? threeMer.index : NULL;
-    ix.row3 = threeMer.isValid() ? threeMer.rowSize : 0;
-    ix.score2 = twoMer.isValid() ? twoMer.score : NULL;
-    ix.index2 = twoMer.isValid() ? twoMer.index : NULL;
-    ix.row2 = twoMer.isValid() ? twoMer.rowSize : 0;
-    ix.ungapped_mat = ungapped.data();
-    // Persisted device layout (include/mmgpu.h; the reference's makepaddedseqdb / createindex): MMGPU_DB_FILE names one file with the
-    // targets, their masked view and the k-mer index as they lie on the device.  A file made from this database with these index
-    // parameters is loaded - no upload of the lookup, no masking, no index build; anything else is built as ever and saved for the
-    // next run.  One context only (shards are dealt per run).
-    const char *dbFile = multi ? NULL : getenv("MMGPU_DB_FILE");
-    uint64_t sourceFp = 0, indexFp = 0;
-    if (dbFile != NULL && dbFile[0] != '\0') {
-        const uint64_t total = off[n];
-        sourceFp = mmgpuFnv(off, (n + 1) * sizeof(uint64_t), 1469598103934665603ull ^ (uint64_t)n);
-        sourceFp = mmgpuFnv(res, std::min<uint64_t>(total, 65536), sourceFp);
-        for (uint64_t z = 65536; z + 64 < total; z += 4096) sourceFp = mmgpuFnv(res + z, 8, sourceFp);      // a sample: the lengths carry most of the identity
-        if (total > 65536) sourceFp = mmgpuFnv(res + total - 65536, 65536, sourceFp);
-        const int32_t scal[6] = {kmerSize, spacedKmer ? 1 : 0, indexKmerThr, maskOnDevice ? 1 : 0, kmerSubMat->alphabetSize, threeMer.isValid() ? 1 : 0};
-        indexFp = mmgpuFnv(scal, sizeof(scal), 1469598103934665603ull);
-        indexFp = mmgpuFnv(&maskProb, sizeof(maskProb), indexFp);
-        indexFp = mmgpuFnv(kmer16.data(), kmer16.size() * sizeof(int16_t), indexFp);
-        indexFp = mmgpuFnv(ungapped.data(), ungapped.size(), indexFp) | 1ull;
-        if (mmgpu_db_load(gpu, dbFile, sourceFp, indexFp, &ix) == 0) {
+    scoreTables(ix, kmerSize, kmerSubMat->alphabetSize, spacedKmer, threeMer, twoMer, ungapped.data());
+    // MMGPU_DB_FILE (saveAs): a file made from this database with these index parameters is loaded - no upload of the lookup, no
+    // masking, no index build; anything else is built as ever and saved for the next run.  (Where the caller could tell before it
+    // filled the lookup, it loaded the file itself and this function is not called: MMGpuPrefilterRun::loadPersisted.)
+    if (saveAs != NULL && multi == NULL) {
+        if (mmgpu_db_load(gpu, saveAs->path.c_str(), saveAs->sourceFp, saveAs->indexFp, &ix) == 0) {
             dbSize = n;
-            Debug(Debug::INFO) << "MMGPU: targets, masked view and k-mer index loaded from " << dbFile << "\n";
+            Debug(Debug::INFO) << "MMGPU: targets, masked view and k-mer index loaded from " << saveAs->path << "\n";
             return true;
         }
-        Debug(Debug::INFO) << "MMGPU: " << dbFile << " not usable (" << mmgpu_last_error() << "): building\n";
+        Debug(Debug::INFO) << "MMGPU: " << saveAs->path << " not usable (" << mmgpu_last_error() << "): building\n";
     }
     if ((multi ? mmgpu_multi_load_targets(multi, res, off, (uint32_t)n, kmerSubMat->alphabetSize)
                : mmgpu_load_targets(gpu, res, off, (uint32_t)n, kmerSubMat->alphabetSize)) != 0) {
@@ -154,9 +179,9 @@ bool MMGpuPrefilter::buildIndex(SequenceLookup *sequenceLookup, int kmerSize, in
         err = mmgpu_last_error();
         return false;
     }
-    if (dbFile != NULL && dbFile[0] != '\0') {
-        if (mmgpu_db_save(gpu, dbFile, sourceFp, indexFp) == 0) Debug(Debug::INFO) << "MMGPU: device layout saved to " << dbFile << "\n";
-        else Debug(Debug::WARNING) << "MMGPU: could not save " << dbFile << ": " << mmgpu_last_error() << "\n";
+    if (saveAs != NULL && multi == NULL) {
+        if (mmgpu_db_save(gpu, saveAs->path.c_str(), saveAs->sourceFp, saveAs->indexFp) == 0) Debug(Debug::INFO) << "MMGPU: device layout saved to " << saveAs->path << "\n";
+        else Debug(Debug::WARNING) << "MMGPU: could not save " << saveAs->path << ": " << mmgpu_last_error() << "\n";
     }
     return true;
 }

@@ -72,8 +72,26 @@ public:
 
     // the same hand-over without a host index: the index is built on the device from the (masked) SequenceLookup with the
     // k-mer threshold IndexBuilder::fillDatabase would have used (IndexTable.h:146-154); tables may be invalid (exact k-mers)
+    // Persisted device layout (include/mmgpu.h, mmgpu_db_save / mmgpu_db_load; the reference's makepaddedseqdb + createindex): one
+    // file with the targets, their masked view and the k-mer index as they lie on the device.  The fingerprints say what it was made
+    // from: the target database (keys, lengths, a sample of its bytes - read off the DBReader, no sequence is mapped for it) and the
+    // index parameters.
+    struct Persisted {
+        std::string path;
+        uint64_t sourceFp, indexFp;
+        Persisted() : sourceFp(0), indexFp(0) {}
+    };
+    static uint64_t fingerprint(const void *p, size_t n, uint64_t h = 1469598103934665603ull);      // FNV-1a
+    uint64_t indexFingerprint(int kmerSize, bool spacedKmer, int indexKmerThr, bool maskOnDevice, double maskProb, bool similarKmerTables,
+                              const int32_t *more, size_t nMore) const;
+    // brings the context to the state buildIndex() leaves, from the file: no lookup, no masking, no index build.  false = no such
+    // file / made from something else (error() says which): the caller builds as ever
+    bool loadPersisted(const Persisted &file, size_t nTargets, int kmerSize, ScoreMatrix &threeMer, ScoreMatrix &twoMer, bool spacedKmer);
+    // ... and the context already holds it (loaded by an earlier MMGpuPrefilter over the same context)
+    void adoptResident(size_t nTargets) { dbSize = nTargets; }
+
     bool buildIndex(SequenceLookup *sequenceLookup, int kmerSize, int indexKmerThr, ScoreMatrix &threeMer, ScoreMatrix &twoMer,
-                    bool spacedKmer, bool maskOnDevice = false, double maskProb = 0.9, bool logMasked = true);
+                    bool spacedKmer, bool maskOnDevice = false, double maskProb = 0.9, bool logMasked = true, const Persisted *saveAs = NULL);
 
     // takeOnlyBestKmer (--exact-kmer-matching; every nucleotide search) / nucleotide target database (matchQuery's isNucleotide)
     void setMode(bool exactKmer, bool nucleotide, bool kmerScoring = false) {

@@ -59,7 +59,7 @@ bool MMGpuPrefilterRun::usableConfig(Prefiltering &p, bool indexExists) {
                      Parameters::isEqualDbtype(p.targetSeqType, Parameters::DBTYPE_AMINO_ACIDS)) || profileTarget;
     const char *why = NULL;
     if (!aa && !nucl) why = "mixed database types";
-    else if (indexExists && (p.indexTable == NULL || p.sequenceLookup == NULL)) why = "no index table / sequence lookup in memory";
+    else if (indexExists && (p.indexTable == NULL || (p.sequenceLookup == NULL && !p.mmgpuPersisted))) why = "no index table / sequence lookup in memory";
     else if (nucl && !p.takeOnlyBestKmer) why = "nucleotide search without exact k-mer matching";
     else if (profileQuery && p.takeOnlyBestKmer) why = "exact k-mer matching with profile queries";
     else if (!p.takeOnlyBestKmer && !profileQuery && (!p._3merSubMatrix.isValid() || !p._2merSubMatrix.isValid())) why = "no similar-k-mer score matrices";
@@ -145,6 +145,65 @@ bool largeSplitNeedsHost(Prefiltering &p, size_t dbSize, bool deviceIndex, size_
 }
 }
 
+namespace {
+// MMGPU_DB_FILE: the file and the fingerprints of what this split would put into it.  The source fingerprint is read off the
+// DBReader - keys, lengths, the first bytes of every 64th entry - so that it can be compared before any sequence is mapped.
+bool persistedLayout(Prefiltering &p, DBReader<unsigned int> *tdbr, size_t dbFrom, size_t dbSize, bool maskOnDevice, int indexKmerThr, int kmerSize,
+                     bool spacedKmer, double maskProb, int maskMode, int maskLowerCaseMode, int maskNrepeats, int targetSearchMode, bool tables,
+                     const MMGpuPrefilter &device, MMGpuPrefilter::Persisted *out) {
+    (void)p;
+    const char *file = getenv("MMGPU_DB_FILE");
+    if (file == NULL || file[0] == '\0') return false;
+    out->path = file;
+    std::vector<uint64_t> ident(2 * dbSize + 2);
+    ident[0] = dbSize;
+    ident[1] = tdbr->getSize();
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < dbSize; i++) {
+        ident[2 + 2 * i] = tdbr->getDbKey(dbFrom + i);
+        ident[3 + 2 * i] = tdbr->getSeqLen(dbFrom + i);
+    }
+    uint64_t fp = MMGpuPrefilter::fingerprint(ident.data(), ident.size() * sizeof(uint64_t));
+    if (!tdbr->isCompressed()) {
+        for (size_t i = 0; i < dbSize; i += 64) {
+            const char *data = tdbr->getDataUncompressed(dbFrom + i);
+            if (data != NULL) fp = MMGpuPrefilter::fingerprint(data, std::min<size_t>(tdbr->getSeqLen(dbFrom + i), 32), fp);
+        }
+    }
+    out->sourceFp = fp | 1ull;
+    const int32_t more[5] = {maskMode, maskLowerCaseMode, maskNrepeats, targetSearchMode, (int32_t)dbFrom};
+    out->indexFp = device.indexFingerprint(kmerSize, spacedKmer, indexKmerThr, maskOnDevice, maskProb, tables, more, 5);
+    return true;
+}
+}
+
+bool MMGpuPrefilterRun::loadPersisted(Prefiltering &p, size_t dbFrom, size_t dbSize) {
+    const char *file = getenv("MMGPU_DB_FILE");
+    if (file == NULL || file[0] == '\0' || !p.mmgpuDeviceIndex) return false;
+    // one context, one unsplit database; sequence queries (a profile run computes its score tables in run()); an uncompressed
+    // database (the alignment module of a fused search reads single sequences on demand, see MMGpuAlignRun)
+    if (p.splits != 1 || !MMGpuRun::deviceIds().empty() || contextsForLargeSplit(dbSize) > 1) return false;
+    if (Parameters::isEqualDbtype(p.querySeqType, Parameters::DBTYPE_HMM_PROFILE)) return false;
+    mmgpu_db_info info;
+    if (mmgpu_db_probe(file, &info) != 0) return false;      // (no file yet: run() builds and saves it)
+    MMGpuPrefilter device(NULL, p.kmerSubMat, p.ungappedSubMat, p.aaBiasCorrection, p.aaBiasCorrectionScale);
+    MMGpuPrefilter::Persisted layout;
+    if (!persistedLayout(p, p.tdbr, dbFrom, dbSize, p.mmgpuDeviceMask, p.mmgpuIndexKmerThr, p.kmerSize, p.spacedKmer, (double)p.maskProb,
+                         p.mmgpuDeviceMask ? 0 : p.maskMode, p.maskLowerCaseMode, p.maskNrepeats, p.targetSearchMode, p._3merSubMatrix.isValid(), device, &layout))
+        return false;
+    if (info.source_fingerprint != layout.sourceFp || info.index_fingerprint != layout.indexFp || info.n_targets != dbSize) {
+        Debug(Debug::INFO) << "MMGPU: " << file << " was made from another database or with other index parameters: building (and replacing it)\n";
+        return false;
+    }
+    MMGpuPrefilter onDevice(MMGpuRun::context(), p.kmerSubMat, p.ungappedSubMat, p.aaBiasCorrection, p.aaBiasCorrectionScale);
+    if (!onDevice.loadPersisted(layout, dbSize, p.kmerSize, p._3merSubMatrix, p._2merSubMatrix, p.spacedKmer)) {
+        Debug(Debug::INFO) << "MMGPU: " << file << " not usable (" << onDevice.error() << "): building\n";
+        return false;
+    }
+    Debug(Debug::INFO) << "MMGPU: targets, masked view and k-mer index loaded from " << file << " (no sequence lookup on the host)\n";
+    return true;
+}
+
 bool MMGpuPrefilterRun::keepsEntriesInMemory(Prefiltering &p, const std::string &resultDB, size_t dbSize) {
     return p.splits == 1 && MMGpuFusedSearch::capturing(resultDB) && usable(p) &&
            !largeSplitNeedsHost(p, dbSize, p.mmgpuDeviceIndex, p.maxResListLen, p.querySeqType, p.targetSeqType, p.diagonalScoring);
@@ -153,7 +212,7 @@ bool MMGpuPrefilterRun::keepsEntriesInMemory(Prefiltering &p, const std::string 
 bool MMGpuPrefilterRun::runsUnsplitWithResidentTargets(Prefiltering &p, size_t *maxResListLen) {
     *maxResListLen = p.maxResListLen;
     // (index and lookup of an unsplit run exist once the constructor has returned: Prefiltering.cpp:196-199)
-    return p.splits == 1 && p.sequenceLookup != NULL && p.mmgpuDeviceIndex && p.mmgpuDeviceMask && MMGpuRun::deviceIds().empty() && usable(p);
+    return p.splits == 1 && (p.sequenceLookup != NULL || p.mmgpuPersisted) && p.mmgpuDeviceIndex && p.mmgpuDeviceMask && MMGpuRun::deviceIds().empty() && usable(p);
 }
 
 void MMGpuPrefilterRun::ensureHostIndex(Prefiltering &p, size_t dbFrom, size_t dbSize) {
@@ -240,12 +299,24 @@ bool MMGpuPrefilterRun::run(Prefiltering &p, DBWriter &tmpDbw, size_t dbFrom, si
     ScoreMatrix &three = local3.isValid() ? local3 : p._3merSubMatrix;
     ScoreMatrix &two = local2.isValid() ? local2 : p._2merSubMatrix;
     {
+        // MMGPU_DB_FILE: an unsplit run on one context keeps its device layout in a file (loaded here if getIndexTable could not
+        // tell - profile queries -, else built and saved; a run that loaded it there, p.mmgpuPersisted, has no lookup to hand over)
+        MMGpuPrefilter::Persisted layout;
+        const bool persist = p.mmgpuDeviceIndex && !p.mmgpuPersisted && nGroups == 1 && MMGpuRun::deviceIds().empty() && virtualShards <= 1 && p.splits == 1 &&
+                             persistedLayout(p, p.tdbr, dbFrom, dbSize, p.mmgpuDeviceMask, p.mmgpuIndexKmerThr, p.kmerSize, p.spacedKmer, (double)p.maskProb,
+                                             p.mmgpuDeviceMask ? 0 : p.maskMode, p.maskLowerCaseMode, p.maskNrepeats, p.targetSearchMode, three.isValid(),
+                                             *devices[0], &layout);
         std::vector<char> handedOver(nGroups, 0);
         auto handOver = [&](size_t g) {
             MMGpuPrefilter &device = *devices[g];
             device.setMode(p.takeOnlyBestKmer, nuclSearch, p.diagonalScoring == 0);
+            if (p.mmgpuPersisted) {
+                device.adoptResident(dbSize);
+                handedOver[g] = 1;
+                return;
+            }
             handedOver[g] = p.mmgpuDeviceIndex ? device.buildIndex(p.sequenceLookup, p.kmerSize, p.mmgpuIndexKmerThr, three, two, p.spacedKmer,
-                                                                   p.mmgpuDeviceMask, (double)p.maskProb, g == 0)
+                                                                   p.mmgpuDeviceMask, (double)p.maskProb, g == 0, persist ? &layout : NULL)
                                                : device.loadIndex(p.indexTable, p.sequenceLookup, three, two, p.spacedKmer);
         };
         std::vector<std::thread> helpers;
@@ -258,7 +329,7 @@ bool MMGpuPrefilterRun::run(Prefiltering &p, DBWriter &tmpDbw, size_t dbFrom, si
                 EXIT(EXIT_FAILURE);
             }
     }
-    watch.lap(p.mmgpuDeviceIndex ? "hand over targets, build the index on the device" : "hand over targets + index");
+    watch.lap(p.mmgpuPersisted ? "targets + index already resident (persisted layout)" : p.mmgpuDeviceIndex ? "hand over targets, build the index on the device" : "hand over targets + index");
     if (local3.isValid()) ExtendedSubstitutionMatrix::freeScoreMatrix(local3);     // the library copied the tables
     if (local2.isValid()) ExtendedSubstitutionMatrix::freeScoreMatrix(local2);
     // Block size: the library's working buffers grow with the index entries a block touches (about 15 MB per query at 1 M
@@ -277,8 +348,12 @@ bool MMGpuPrefilterRun::run(Prefiltering &p, DBWriter &tmpDbw, size_t dbFrom, si
     // resident and the lookup goes to the fused run instead of being freed with this Prefiltering object.  An overlapped run
     // (the alignment module is already waiting) gets it now, the others when this run is over.
     const bool leaveTargets = capture && p.mmgpuDeviceMask && p.mmgpuDeviceIndex && MMGpuRun::deviceIds().empty() && virtualShards <= 1 && dbFrom == 0 &&
-                              dbSize == p.tdbr->getSize() && MMGpuFusedSearch::keepsTargets() && p.sequenceLookup != NULL;
-    if (MMGpuFusedSearch::overlappedRun()) MMGpuFusedSearch::keepResidentTargets(leaveTargets ? p.sequenceLookup : NULL, p.tdbr, gpu);
+                              dbSize == p.tdbr->getSize() && MMGpuFusedSearch::keepsTargets() && (p.sequenceLookup != NULL || p.mmgpuPersisted);
+    // (a persisted layout leaves no host copy: the alignment module is told that the device holds the database's sequences, unmasked)
+    if (MMGpuFusedSearch::overlappedRun()) {
+        if (leaveTargets && p.mmgpuPersisted) MMGpuFusedSearch::keepResidentTargetsOnDevice(p.tdbr, gpu);
+        else MMGpuFusedSearch::keepResidentTargets(leaveTargets ? p.sequenceLookup : NULL, p.tdbr, gpu);
+    }
 
     std::vector<Sequence *> seqs(localThreads, NULL);
     std::vector<QueryMatcher *> cpuMatchers(localThreads, NULL);
@@ -582,7 +657,10 @@ bool MMGpuPrefilterRun::run(Prefiltering &p, DBWriter &tmpDbw, size_t dbFrom, si
         // mmgpuDeviceIndex): that copy is not what the device aligned against, so it is not handed over - the alignment module maps
         // and uploads its own targets.  (An overlapped run handed the unmasked lookup over before the loop; ensureHostIndex leaves
         // a lookup the fused search holds alone.)
-        if (!MMGpuFusedSearch::overlappedRun() && p.mmgpuDeviceIndex) MMGpuFusedSearch::keepResidentTargets(p.sequenceLookup, p.tdbr, gpu);
+        if (!MMGpuFusedSearch::overlappedRun() && p.mmgpuDeviceIndex) {
+            if (p.mmgpuPersisted) MMGpuFusedSearch::keepResidentTargetsOnDevice(p.tdbr, gpu);
+            else MMGpuFusedSearch::keepResidentTargets(p.sequenceLookup, p.tdbr, gpu);
+        }
         if (MMGpuFusedSearch::holdsLookup(p.sequenceLookup)) p.sequenceLookup = NULL;
     }
     for (size_t g = 0; g < nGroups; g++) delete devices[g];

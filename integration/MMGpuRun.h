@@ -82,6 +82,9 @@ public:
     static Matcher::result_t take(MMGpuAlignSession *s, size_t id, size_t entry, Matcher &matcher, Sequence *dbSeq, int diagonal, bool isReverse,
                                   bool isIdentity);
     static void end(MMGpuAlignSession *s);
+    // Sequence::numSequence of target `id`: out of the session's host copy, or - where the targets came to the device from a persisted
+    // layout and the host holds none - mapped now and kept for the bucket
+    static const unsigned char *targetResidues(MMGpuAlignSession *s, size_t id);
     // nucleotide databases: BandedNucleotideAligner::align on the device (MMGPU_NUCL_ALIGN=0 keeps the CPU loop)
     static bool usableNucleotide(const Alignment &a);
     static void beginNucleotide(MMGpuAlignSession *s);
@@ -109,6 +112,10 @@ public:
     // ... and whether the device also does the masking fillDatabase would do (tantan only, one device): mmgpu_pf_mask_targets;
     // MMGPU_DEVICE_MASK=0 keeps the host's Masker
     static bool deviceMasks(Prefiltering &p);
+    // ... and, before fillDatabase maps a single sequence: MMGPU_DB_FILE names a persisted device layout (mmgpu_db_save) made from
+    // this target database with this run's index parameters - it is loaded (targets, masked view, index) and the split runs without
+    // a SequenceLookup on the host.  false: nothing loaded, the lookup is filled and handed over as ever (and the layout saved)
+    static bool loadPersisted(Prefiltering &p, size_t dbFrom, size_t dbSize);
     // fused search: this object will run unsplit through the device path and leave its targets resident for the alignment
     // module (MMGpuFusedSearch::keepResidentTargets) - the alignment module can then start before the prefilter has finished
     static bool runsUnsplitWithResidentTargets(Prefiltering &p, size_t *maxResListLen);

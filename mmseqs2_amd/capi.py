@@ -77,7 +77,7 @@ EXPORTED_SYMBOLS = [
     "mmgpu_host_partition_targets", "mmgpu_pf_set_shard", "mmgpu_pf_fetch_exchange", "mmgpu_pf_merge_exchange",
     "mmgpu_pf_localize_lists", "mmgpu_sw_prepare_from_lists",
     "mmgpu_comm_unique_id", "mmgpu_comm_init_rank", "mmgpu_comm_info", "mmgpu_comm_destroy", "mmgpu_pf_exchange_merge",
-    "mmgpu_sw_prepare_owned", "mmgpu_sw_gather_owned", "mmgpu_sw_fetch_owned", "mmgpu_sw_block_backtrace", "mmgpu_sw_block_tiers",
+    "mmgpu_sw_prepare_owned", "mmgpu_sw_gather_owned", "mmgpu_sw_fetch_owned", "mmgpu_sw_block_backtrace", "mmgpu_sw_block_growth", "mmgpu_sw_block_tiers",
     "mmgpu_init_multi", "mmgpu_destroy_multi", "mmgpu_multi_size", "mmgpu_multi_ctx", "mmgpu_multi_synchronize",
     "mmgpu_multi_load_targets", "mmgpu_multi_pf_mask_targets", "mmgpu_multi_pf_build_index", "mmgpu_multi_pf_prepare", "mmgpu_multi_pf_run", "mmgpu_multi_pf_fetch",
     "mmgpu_multi_pf_stride", "mmgpu_multi_pf_free", "mmgpu_multi_sw_from_pf",
@@ -194,6 +194,7 @@ def load_library():
                                               ctypes.c_uint32, ctypes.POINTER(c_p)]
     L.mmgpu_sw_block_backtrace.argtypes = [c_p, c_p, c_p, ctypes.c_uint32, c_p, c_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
     L.mmgpu_sw_block_tiers.argtypes = [c_p, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]
+    L.mmgpu_sw_block_growth.argtypes = [c_p, c_p, c_p, ctypes.c_uint32, c_p, c_p, ctypes.c_uint32]
     L.mmgpu_comm_unique_id.argtypes = [c_p]
     L.mmgpu_comm_init_rank.argtypes = [c_p, c_p, ctypes.c_int, ctypes.c_int]
     L.mmgpu_comm_info.argtypes = [c_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.c_char_p, ctypes.c_int]
@@ -475,6 +476,20 @@ class SwBatch:
         raw = bt.tobytes()
         strs = [raw[int(o["bt_off"]):int(o["bt_off"]) + int(o["bt_len"])].decode() if o["status"] == 0 else None for o in out]
         return out, strs
+
+    def block_growth(self, pair_index, cap=4096):
+        """mmgpu_sw_block_growth (test aid): -> (records, lists): per pair the (i, j, height, width, right) rows of its block list"""
+        pi = np.ascontiguousarray(pair_index, dtype=np.uint32)
+        out = np.zeros(len(pi), dtype=SW_BLOCK_DTYPE)
+        g = np.zeros((len(pi), 1 + 4 * cap), dtype=np.uint32)
+        self.gpu._check(self.gpu.L.mmgpu_sw_block_growth(self.gpu.ctx, self.handle, _ptr(pi), len(pi), _ptr(out), _ptr(g), cap))
+        lists = []
+        for r in g:
+            n = int(r[0])
+            assert n <= cap, "block list longer than the capture buffer"
+            b = r[1:1 + 4 * n].reshape(n, 4).astype(np.int64)
+            lists.append(np.stack([b[:, 0], b[:, 1], b[:, 2] >> 16, b[:, 2] & 0xFFFF, b[:, 3]], axis=1))
+        return out, lists
 
     def block_tiers(self):
         """mmgpu_sw_block_tiers: (pairs decided with <= 512-row blocks, pairs that needed the 4096-row launch) of the last call"""

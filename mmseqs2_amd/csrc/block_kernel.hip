@@ -581,6 +581,19 @@ __global__ __launch_bounds__(64) void sw_block_kernel(BlockLaunch L) {
         const int share = (t_walk > t_begin && t_end > t_begin) ? (int)(((t_end - t_walk) * 1000) / (t_end - t_begin)) : 0;
         out.reserved = (int32_t)((share & 0xFFFF) | ((attempts & 0xFF) << 16));
     }
+    if (L.growth != nullptr) {      // test aid: the block list of the last run (wave-uniform branch; off in every product call)
+        __threadfence_block();
+        uint32_t *g = L.growth + (size_t)J.slot * (1 + 4 * (size_t)L.growth_cap);
+        const uint32_t nb = too_large ? 0u : S.block_idx;
+        if (lane == 0) g[0] = nb;
+        for (uint32_t k = (uint32_t)lane; k < nb && k < L.growth_cap; k += 64) {
+            const BkBlock bb = S.blocks[k];
+            g[1 + 4 * k] = bb.i;
+            g[2 + 4 * k] = bb.j;
+            g[3 + 4 * k] = (uint32_t)bb.h << 16 | bb.w;
+            g[4 + 4 * k] = bb.right;
+        }
+    }
     if (lane == 0) {
         L.out[J.slot] = out;
         __threadfence();

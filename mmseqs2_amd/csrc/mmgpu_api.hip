@@ -1253,8 +1253,8 @@ extern "C" int mmgpu_sw_batch(mmgpu_ctx *c, const mmgpu_sw_params *par, const mm
 // backtrace
 // ---------------------------------------------------------------------------------------------------------
 // ---- a15: the block aligner's start position / backtrace for int16-range hits (block_kernel.hip) ----
-extern "C" int mmgpu_sw_block_backtrace(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const uint32_t *pair_index, uint32_t n, mmgpu_sw_block *out,
-                                        char *bt, size_t bt_cap, size_t *bt_used) {
+static int block_backtrace(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const uint32_t *pair_index, uint32_t n, mmgpu_sw_block *out,
+                           char *bt, size_t bt_cap, size_t *bt_used, uint32_t *growth, uint32_t growth_cap) {
     if (!c || !b || (!pair_index && n) || (!out && n)) return fail(MMGPU_ERR_ARG, "mmgpu_sw_block_backtrace: NULL argument");
     if (!b->ran) return fail(MMGPU_ERR_STATE, "mmgpu_sw_block_backtrace: batch was never run");
     if (b->alphabet > 26) return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_sw_block_backtrace: alphabet above 26 letters");
@@ -1337,6 +1337,13 @@ extern "C" int mmgpu_sw_block_backtrace(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const
     for (DevBuf *d : {&d_out, &d_btoff, &d_bt, &d_scores, &d_jobs[0], &d_jobs[1], &d_jobs[2], &d_pool[0], &d_pool[1], &d_pool[2], &d_busy[0], &d_busy[1], &d_busy[2]})
         d->bind(c->cache);
     HIP_TRY(d_out.alloc((size_t)n * sizeof(mmgpu_sw_block)));
+    DevBuf d_growth;
+    d_growth.bind(c->cache);
+    const size_t growth_bytes = growth ? (size_t)n * (1 + 4 * (size_t)growth_cap) * 4 : 0;
+    if (growth) {
+        HIP_TRY(d_growth.alloc(growth_bytes));
+        HIP_TRY(hipMemsetAsync(d_growth.p, 0, growth_bytes, s));
+    }
     HIP_TRY(d_btoff.alloc((size_t)n * 8));
     HIP_TRY(d_bt.alloc((size_t)off + 16));
     HIP_TRY(d_scores.alloc(scores.size()));
@@ -1360,6 +1367,8 @@ extern "C" int mmgpu_sw_block_backtrace(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const
     L.out = d_out.as<mmgpu_sw_block>();
     L.bt_off = d_btoff.as<uint64_t>();
     L.bt = d_bt.as<char>();
+    L.growth = growth ? d_growth.as<uint32_t>() : nullptr;
+    L.growth_cap = growth_cap;
     const int first_tier = getenv("MMGPU_BLOCK_FIRST_TIER") ? std::max(0, std::min(2, atoi(getenv("MMGPU_BLOCK_FIRST_TIER")))) : 0;      // test aid
     // Rounds: the tiers that have pairs waiting run side by side (a stream, a pool, a job list each).  Round one = tier 0 for the
     // pairs up to the typical length and, at the same time, tier 1 for the longer ones (they would overflow tier 0's slots, and
@@ -1423,9 +1432,21 @@ extern "C" int mmgpu_sw_block_backtrace(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const
     }
     release_streams();
     if (off && !no_strings) HIP_TRY(hipMemcpyAsync(bt, d_bt.p, (size_t)off, hipMemcpyDeviceToHost, s));
+    if (growth) HIP_TRY(hipMemcpyAsync(growth, d_growth.p, growth_bytes, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));      // the host vectors and the buffers above die with this scope
     lap("backtrace strings download");
     return MMGPU_OK;
+}
+
+extern "C" int mmgpu_sw_block_backtrace(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const uint32_t *pair_index, uint32_t n, mmgpu_sw_block *out,
+                                        char *bt, size_t bt_cap, size_t *bt_used) {
+    return block_backtrace(c, b, pair_index, n, out, bt, bt_cap, bt_used, nullptr, 0);
+}
+
+extern "C" int mmgpu_sw_block_growth(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const uint32_t *pair_index, uint32_t n, mmgpu_sw_block *out,
+                                     uint32_t *growth, uint32_t growth_cap) {
+    if (!growth || growth_cap == 0) return fail(MMGPU_ERR_ARG, "mmgpu_sw_block_growth: no buffer");
+    return block_backtrace(c, b, pair_index, n, out, nullptr, MMGPU_BLOCK_NO_STRINGS, nullptr, growth, growth_cap);
 }
 
 extern "C" int mmgpu_sw_block_tiers(const mmgpu_sw_batch_t *b, uint32_t *first_tier, uint32_t *second_tier) {

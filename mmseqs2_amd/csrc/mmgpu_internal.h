@@ -515,6 +515,10 @@ struct BlockLaunch {
     uint64_t slot_bytes;
     uint32_t n_pool_slots;
     uint32_t *pool_busy;
+    // test aid (mmgpu_sw_block_growth): per pair 1 + 4 * growth_cap words - the number of blocks of the pair's last alignment run and
+    // (i, j, height << 16 | width, right) of each, i.e. Trace::block_start / block_size / right when align_core returns; null = off
+    uint32_t *growth = nullptr;
+    uint32_t growth_cap = 0;
 };
 // tier 0: blocks up to BLOCK_MAX_SIZE rows (LDS), 1: up to BLOCK_MID_SIZE (LDS), 2: up to BLOCK_REF_MAX_SIZE rows, border arrays
 // in the first 8 * 4096 * 2 bytes of the pair's scratch slot

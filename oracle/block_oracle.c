@@ -612,6 +612,15 @@ int mmo_block_align(const uint8_t *q, const int16_t *qbias, int qlen, const uint
     return mmo_block_align_table(q, qbias, qlen, r, rbias, rlen, scores, gap_open, gap_extend, min_size, max_size, x_drop, res, ops, ops_cap, n_ops);
 }
 
+/* Test aid: the block list of the LAST alignment run on this thread (Trace::block_start / block_size / right as they stand when
+ * align_core returns - the sequence of grow / right / down steps with their sizes, after every x-drop restore), four words per
+ * block: i, j, height << 16 | width, right.  mmo_block_growth_capture(buf, cap) arms it, mmo_block_growth_count() = blocks of
+ * the last run (may exceed cap: the list is cut, not the count). */
+static __thread uint32_t *growth_buf = NULL;
+static __thread uint32_t growth_cap = 0, growth_n = 0;
+void mmo_block_growth_capture(uint32_t *buf, uint32_t cap) { growth_buf = buf; growth_cap = buf ? cap : 0; growth_n = 0; }
+uint32_t mmo_block_growth_count(void) { return growth_n; }
+
 /* Block<TRACE, X_DROP>::align / align_aa (scan_block.rs:862-892, :1016-1052) on PaddedBytes built from q / r (bytes AFTER
  * Matrix::convert_char), padded with `null_byte` (Matrix::NULL after convert_char).  eq: walk with cigar_eq instead of cigar. */
 static int block_run(const uint8_t *q, const int16_t *qbias, int qlen, const uint8_t *r, const int16_t *rbias, int rlen, const bparams *P,
@@ -656,6 +665,15 @@ static int block_run(const uint8_t *q, const int16_t *qbias, int qlen, const uin
     res->reference_idx = (uint32_t)rj;
     if (n_ops) *n_ops = 0;
     if (ops && n_ops && P->trace) *n_ops = (uint32_t)trace_cigar(&T, ri, rj, ops, ops_cap, eq ? qs : NULL, eq ? rs : NULL);
+    if (growth_buf && P->trace) {
+        growth_n = (uint32_t)T.block_idx;
+        for (size_t k = 0; k < T.block_idx && k < growth_cap; k++) {
+            growth_buf[4 * k] = T.block_start[2 * k];
+            growth_buf[4 * k + 1] = T.block_start[2 * k + 1];
+            growth_buf[4 * k + 2] = (uint32_t)T.block_size[2 * k] << 16 | T.block_size[2 * k + 1];
+            growth_buf[4 * k + 3] = T.right[k];
+        }
+    }
     for (int k = 0; k < 10; k++) free(*bufs[k]);
     free(T.trace); free(T.trace2); free(T.right); free(T.block_start); free(T.block_size);
     free(qs); free(rs); free(qb); free(rb);

@@ -197,6 +197,9 @@ int mmo_sw_block_backtrace_profile(const int8_t *prof, const uint8_t *q, int qle
                                    int gap_extend, int score, int q_end, int t_end, int *q_start, int *t_start, uint32_t *ident, char *bt,
                                    int bt_cap, int *bt_len, int *block_size_used);
 void mmo_block_prefix_scan(const int16_t *v16, int gap, int16_t *out16);
+/* test aid: the block list (i, j, height << 16 | width, right per block) of the last alignment run on the calling thread */
+void mmo_block_growth_capture(uint32_t *buf, uint32_t cap);
+uint32_t mmo_block_growth_count(void);
 int mmo_sw_block_backtrace(const uint8_t *q, const int8_t *comp_bias, int qlen, const uint8_t *t, int tlen, const int8_t *mat, int alphabet,
                            int gap_open /* > 0, as the reference's */, int gap_extend, int score, int q_end, int t_end, int *q_start, int *t_start,
                            uint32_t *ident, char *bt, int bt_cap, int *bt_len, int *block_size_used);

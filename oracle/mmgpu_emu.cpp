@@ -244,6 +244,10 @@ int mmgpu_sw_block_backtrace(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const uint32_t *
     return 0;
 }
 
+int mmgpu_sw_block_growth(mmgpu_ctx *, mmgpu_sw_batch_t *, const uint32_t *, uint32_t, mmgpu_sw_block *, uint32_t *, uint32_t) {
+    return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_sw_block_growth: a test aid of the device kernel");
+}
+
 int mmgpu_sw_block_tiers(const mmgpu_sw_batch_t *, uint32_t *first_tier, uint32_t *second_tier) {
     if (first_tier) *first_tier = 0;
     if (second_tier) *second_tier = 0;

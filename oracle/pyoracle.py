@@ -84,6 +84,24 @@ class Oracle:
         return dict(score=r.score, q_start=r.q_start, q_end=r.q_end, t_start=r.t_start, t_end=r.t_end,
                     word=r.word, ident=r.ident, bt=bt.value.decode() if r.bt_len else "")
 
+    def block_growth(self, call, cap=4096):
+        """runs call() (block_backtrace / sw_block_backtrace_profile / block_align ...) with the block-list capture armed and returns
+        (its result, int64 [n, 5] rows (i, j, height, width, right) of the last alignment run's block list - Trace::block_start /
+        block_size / right when align_core returned)"""
+        buf = np.zeros(4 * cap, np.uint32)
+        self.L.mmo_block_growth_capture.argtypes = [c_p, ctypes.c_uint32]
+        self.L.mmo_block_growth_capture.restype = None
+        self.L.mmo_block_growth_count.restype = ctypes.c_uint32
+        self.L.mmo_block_growth_capture(_ptr(buf), cap)
+        try:
+            res = call()
+            n = int(self.L.mmo_block_growth_count())
+        finally:
+            self.L.mmo_block_growth_capture(None, 0)
+        assert n <= cap, "block list longer than the capture buffer"
+        b = buf[:4 * n].reshape(n, 4).astype(np.int64)
+        return res, np.stack([b[:, 0], b[:, 1], b[:, 2] >> 16, b[:, 2] & 0xFFFF, b[:, 3]], axis=1)
+
     def block_backtrace(self, q, cb, t, mat, go, ge, score, q_end, t_end):
         """alignStartPosBacktraceBlock<SEQ_SEQ> (block_oracle.c: the restated block aligner).  -> dict(ok, q_start, t_start,
         ident, bt, block_size) ; ok False = "Block alignment failed" (the reference then falls back to its SW traceback)."""

@@ -168,6 +168,35 @@ def test_block_alignment_reaches_and_rescores_to_the_sw_score(orc, matrices):
     assert differs > 0
 
 
+def test_block_lists_tile_the_walked_area_and_record_every_growth_step(orc, matrices):
+    """The growth capture behind the device's step-by-step test (tests/test_sw_gpu.py): the block list of a run - Trace::block_start /
+    block_size / right - is consistent in itself.  Blocks are 8 columns (right) or 8 rows (down) thick except the two halves of a
+    grow step; a shift continues where the block of the same kind before it ended; the sizes only take the powers of two the crate
+    grows through; and a pair with a long gap records blocks well beyond 512 rows."""
+    from tests.test_sw_gpu import _long_gap_pairs
+    mat = matrices["blosum62_sw"]
+    sub16 = mat.astype(np.int16)
+    qs, ts = _long_gap_pairs(matrices, orc, 6, seed=17)
+    biggest = 0
+    for q, t in zip(qs, ts):
+        cb = orc.round_comp_bias(orc.comp_bias(sub16, matrices["blosum62_pback"], q, 1.0))
+        r = orc.sw_align(q, cb, t, mat, 11, 1, need_start=True)
+        w, blocks = orc.block_growth(lambda: orc.block_backtrace(q, cb, t, mat, 11, 1, r["score"], r["q_end"], r["t_end"]))
+        w2, blocks2 = orc.block_growth(lambda: orc.block_backtrace(q, cb, t, mat, 11, 1, r["score"], r["q_end"], r["t_end"]))
+        assert w == w2 and np.array_equal(blocks, blocks2) and len(blocks) >= 2
+        # the first grow step at the origin (scan_block.rs:283-335): a down half over the prev_size = 0 columns there are so far,
+        # then the right half of min_size x min_size
+        ms = w["block_size"]
+        assert blocks[0].tolist() == [0, 0, ms, 0, 0] and blocks[1].tolist() == [0, 0, ms, ms, 1]
+        for i, j, h, wd, right in blocks[1:].tolist():
+            assert right in (0, 1)
+            thick, long_side = (wd, h) if right else (h, wd)
+            assert long_side & (long_side - 1) == 0 and 32 <= long_side <= 4096
+            assert thick == 8 or (thick & (thick - 1) == 0 and thick >= 32)      # a shift (Block::STEP = 8), or a half of a grow step
+        biggest = max(biggest, int(blocks[:, 2:4].max()))
+    assert biggest >= 1024
+
+
 @pytest.mark.skipif(not (os.path.exists(po.REF_BLOCK_SO) and po.ref_matrix_available()), reason="needs oracle/_ref/libmmref_block.so (make -C oracle refblock)")
 def test_reference_glue_over_the_c_api_equals_the_restated_wrapper(orc, matrices):
     mat = matrices["blosum62_sw"]

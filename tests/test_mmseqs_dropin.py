@@ -144,12 +144,26 @@ def persisted_layout_pipeline(tmp, emulate):
     assert os.path.getsize(env["MMGPU_DB_FILE"]) > 100000
     log = run(MMGPU, ["prefilter", "q", "q", "pref_g2", "-s", "5.7", "--threads", THREADS, "-v", "3"], w, emulate, extra_env=env)
     assert "k-mer index loaded from" in log and "device layout saved to" not in log, log[-2000:]
+    # ... before a sequence is mapped: the reference's fillDatabase ("Index table: counting k-mers" / "Masked residues") never ran
+    assert "no sequence lookup on the host" in log and "Masked residues" not in log, log[-2000:]
     assert same(os.path.join(w, "pref_s"), os.path.join(w, "pref_g1")) == 500
     assert same(os.path.join(w, "pref_s"), os.path.join(w, "pref_g2")) == 500
     # another sensitivity = another k-mer threshold of the index: the file is refused, the run builds its own and saves it
     run(STOCK, ["prefilter", "q", "q", "pref_s4", "-s", "4", "--threads", THREADS, "-v", "2"], w)
     log = run(MMGPU, ["prefilter", "q", "q", "pref_g4", "-s", "4", "--threads", THREADS, "-v", "3"], w, emulate, extra_env=env)
+    assert "made from another database or with other index parameters" in log and "device layout saved to" in log, log[-2000:]
     assert same(os.path.join(w, "pref_s4"), os.path.join(w, "pref_g4")) == 500
+    # the whole search on the layout: the alignment module of the fused run finds the targets on the device and holds no copy of its
+    # own - the self hits (identity pairs score their diagonal on the host) map their sequence on demand; -a: backtraces; the
+    # correlation score reads every aligned target on the host
+    for extra in (["-a"], ["--corr-score-weight", "0.5"]):
+        tag = str(len(extra))
+        run(STOCK, ["search", "q", "q", "res_s" + tag, "tmp_s" + tag, "-s", "4"] + extra + ["--threads", THREADS, "-v", "2"], w)
+        log = run(MMGPU, ["search", "q", "q", "res_g" + tag, "tmp_g" + tag, "-s", "4"] + extra + ["--threads", THREADS, "-v", "3"], w, emulate,
+                  extra_env=dict(env, MMGPU_TRACE="1"))
+        assert "no sequence lookup on the host" in log and "targets already resident (fused search)" in log, log[-3000:]
+        assert "using the CPU path" not in log, log[-3000:]
+        assert same(os.path.join(w, "res_s" + tag), os.path.join(w, "res_g" + tag)) == 500
 
 
 def test_persisted_device_layout_host_side_emulated(tmp_path):

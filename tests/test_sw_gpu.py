@@ -399,6 +399,52 @@ def _long_gap_pairs(matrices, oracle, n, seed):
     return qs, ts
 
 
+def test_block_aligner_growth_sequences_equal_the_restatement_step_by_step(gpu, matrices, oracle):
+    """a15, beyond the final CIGAR: the block LIST of every pair - where each block was placed, its height and width, whether it
+    was a shift right or down (a grow step adds one block of each kind) - as it stands when the crate's align_core returns, i.e.
+    the whole sequence of grow / shift decisions with the block sizes 32 -> ... -> 4096 after every x-drop restore, must equal the
+    restatement's list entry by entry.  Long-gap pairs (blocks grow to 512 - 4096 rows) and family pairs (32 / 64-row blocks)."""
+    from mmseqs2_amd import workloads as wl
+    mat = matrices["blosum62_sw"]
+    sub16 = mat.astype(np.int16)
+    qs, ts = _long_gap_pairs(matrices, oracle, 30, seed=17)
+    (qres, qoff), (tres2, toff2), fam_t, fam_q = wl.config3_prefilter(40, 4, 40, seed=43)
+    fq, ft = wl.split(qres, qoff), wl.split(tres2, toff2)
+    for qi, q in enumerate(fq):
+        for ti in np.nonzero(fam_t == fam_q[qi])[0][:2]:
+            qs.append(q)
+            ts.append(ft[ti])
+    toff = np.zeros(len(ts) + 1, np.uint64)
+    toff[1:] = np.cumsum([len(t) for t in ts])
+    gpu.load_targets(np.concatenate(ts), toff, 21)
+    queries = []
+    for qi, q in enumerate(qs):
+        cb = oracle.round_comp_bias(oracle.comp_bias(sub16, matrices["blosum62_pback"], q, 1.0))
+        queries.append(dict(q=q, comp_bias=cb, targets=np.array([qi], np.uint32), min_start_score=0))
+    b = gpu.sw_prepare(mat, 11, 1, queries, mode=1)
+    b.run()
+    res = b.fetch()
+    blk, lists = b.block_growth(np.arange(len(res), dtype=np.uint32))
+    b.free()
+    n = n_grown = 0
+    sizes_seen = set()
+    for k, qd in enumerate(queries):
+        r, o = res[k], blk[k]
+        if r["word"] != 1 or r["score"] <= 0:
+            continue
+        w, want = oracle.block_growth(lambda: oracle.block_backtrace(qd["q"], qd["comp_bias"], ts[k], mat, 11, 1, int(r["score"]), int(r["q_end"]),
+                                                                    int(r["t_end"])))
+        assert int(o["status"]) == (0 if w["ok"] else 1), k
+        got = lists[k]
+        assert got.shape == want.shape and np.array_equal(got, want), \
+            (k, got.shape, want.shape, next((i, got[i].tolist(), want[i].tolist()) for i in range(min(len(got), len(want))) if not np.array_equal(got[i], want[i])))
+        n += 1
+        big = int(max(want[:, 2].max(), want[:, 3].max())) if len(want) else 0
+        sizes_seen.add(big)
+        n_grown += big > 512
+    assert n >= 60 and n_grown >= 8 and len(sizes_seen) >= 4, (n, n_grown, sorted(sizes_seen))
+
+
 @pytest.mark.parametrize("first_tier", [0, 1, 2])
 def test_block_aligner_grows_to_the_crates_4096_rows(gpu, matrices, oracle, first_tier, monkeypatch):
     """a15, blocks beyond 512 rows: the later launches (sw_block_kernel<2048, LDS> and <4096, borders in HBM>) answer what the
