@@ -309,8 +309,28 @@ extern "C" int mmgpu_pf_mask_targets(mmgpu_ctx *c, const double *likelihood_rati
     std::vector<double> lr(likelihood_ratios, likelihood_ratios + (size_t)alphabet * alphabet);
     HIP_TRY(upload(d_lr, lr, s));
     HIP_TRY(upload(d_b2f, b2f, s));
-    HIP_TRY(d_probs.alloc(std::max<uint64_t>(pcur, 1) * sizeof(float)));
-    HIP_TRY(d_scales.alloc(std::max<uint64_t>(scur, 1) * sizeof(double)));
+    // The forward probabilities (4 B per residue) and scale factors (0.5 B) are scratch: wavefronts run in chunks whose scratch stays
+    // below MMGPU_TANTAN_SCRATCH_MB (default 8 GB; a quarter of the free memory if that is less) - one chunk for 1 M targets, several
+    // for a shard near the 16 G-residue limit, which would otherwise ask for 70 GB on top of the masked copy.
+    uint64_t budget = (getenv("MMGPU_TANTAN_SCRATCH_MB") ? strtoull(getenv("MMGPU_TANTAN_SCRATCH_MB"), nullptr, 10) : 8192ull) << 20;
+    {
+        size_t mem_free = 0, mem_total = 0;
+        if (hipMemGetInfo(&mem_free, &mem_total) == hipSuccess) budget = std::min<uint64_t>(budget, std::max<uint64_t>(mem_free / 4, 64ull << 20));
+    }
+    std::vector<uint32_t> chunk_first(1, 0);      // wavefronts [chunk_first[k], chunk_first[k + 1])
+    uint64_t chunk_p = 0, chunk_s = 0;            // the largest chunk's scratch (floats, doubles)
+    auto p_end = [&](uint32_t w) { return w < n_waves ? pbase[w] : pcur; };
+    auto s_end = [&](uint32_t w) { return w < n_waves ? sbase[w] : scur; };
+    for (uint32_t w0 = 0; w0 < n_waves;) {
+        uint32_t w1 = w0 + 1;      // (a single wavefront over the budget runs alone)
+        while (w1 < n_waves && (p_end(w1 + 1) - pbase[w0]) * 4 + (s_end(w1 + 1) - sbase[w0]) * 8 <= budget) w1++;
+        chunk_p = std::max(chunk_p, p_end(w1) - pbase[w0]);
+        chunk_s = std::max(chunk_s, s_end(w1) - sbase[w0]);
+        chunk_first.push_back(w1);
+        w0 = w1;
+    }
+    HIP_TRY(d_probs.alloc(std::max<uint64_t>(chunk_p, 1) * sizeof(float)));
+    HIP_TRY(d_scales.alloc(std::max<uint64_t>(chunk_s, 1) * sizeof(double)));
     HIP_TRY(d_count.alloc(8));
     HIP_TRY(hipMemsetAsync(d_count.p, 0, 8, s));
     TantanArgs A;
@@ -327,12 +347,18 @@ extern "C" int mmgpu_pf_mask_targets(mmgpu_ctx *c, const double *likelihood_rati
     A.repeat_end_prob = repeat_end_prob;
     A.min_mask_prob = min_mask_prob;
     A.mask_letter = (uint8_t)mask_letter;
-    A.probs = d_probs.as<float>();
-    A.scales = d_scales.as<double>();
-    A.wave_prob_base = d_pbase.as<uint64_t>();
-    A.wave_scale_base = d_sbase.as<uint64_t>();
     A.n_masked = d_count.as<unsigned long long>();
-    HIP_TRY(launch_tantan_mask(A, s));
+    for (size_t k = 0; k + 1 < chunk_first.size(); k++) {      // (same stream: a chunk's scratch is free again when the next one starts)
+        const uint32_t w0 = chunk_first[k], w1 = chunk_first[k + 1];
+        A.order = d_order.as<uint32_t>() + (size_t)w0 * 64;
+        A.n = std::min<uint32_t>(n - w0 * 64, (w1 - w0) * 64);
+        // the bases stay absolute: the scratch pointers are moved back by the chunk's first base instead
+        A.probs = d_probs.as<float>() - pbase[w0];
+        A.scales = d_scales.as<double>() - sbase[w0];
+        A.wave_prob_base = d_pbase.as<uint64_t>() + w0;
+        A.wave_scale_base = d_sbase.as<uint64_t>() + w0;
+        HIP_TRY(launch_tantan_mask(A, s));
+    }
     unsigned long long masked = 0;
     HIP_TRY(hipMemcpyAsync(&masked, d_count.p, 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));      // the host vectors above die with this scope

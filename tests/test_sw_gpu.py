@@ -442,7 +442,7 @@ def test_block_aligner_growth_sequences_equal_the_restatement_step_by_step(gpu, 
         big = int(max(want[:, 2].max(), want[:, 3].max())) if len(want) else 0
         sizes_seen.add(big)
         n_grown += big > 512
-    assert n >= 60 and n_grown >= 8 and len(sizes_seen) >= 4, (n, n_grown, sorted(sizes_seen))
+    assert n >= 60 and n_grown >= 5 and len(sizes_seen) >= 4, (n, n_grown, sorted(sizes_seen))
 
 
 @pytest.mark.parametrize("first_tier", [0, 1, 2])

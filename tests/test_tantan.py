@@ -70,9 +70,14 @@ def test_device_masking_equals_the_recorded_reference(gpu, vec):
 
 
 @pytest.mark.gpu
-def test_device_masking_equals_the_restatement_on_a_database(gpu, oracle, vec):
+@pytest.mark.parametrize("scratch_mb", [None, "1"])
+def test_device_masking_equals_the_restatement_on_a_database(gpu, oracle, vec, scratch_mb, monkeypatch):
     """20 000 family-structured targets with planted repeats (lengths 30 .. 5000: wavefronts of sequences of about equal length,
-    the partial first 50 positions, the rescaling every 16 letters, sequences shorter than one SIMD group of states)"""
+    the partial first 50 positions, the rescaling every 16 letters, sequences shorter than one SIMD group of states).  The second
+    case bounds the scratch (forward probabilities + scale factors) at 1 MB: the wavefronts then run in some thirty chunks, the
+    longest ones alone."""
+    if scratch_mb is not None:
+        monkeypatch.setenv("MMGPU_TANTAN_SCRATCH_MB", scratch_mb)
     rng = np.random.default_rng(5)
     (_, _), (tres, toff), _, _ = wl.config3_prefilter(400, 50, 10, seed=31)
     ts = wl.split(tres, toff)
