@@ -73,8 +73,8 @@ const std::vector<int> &MMGpuRun::deviceIds() {
 
 // The layout of a prefilter run over N device contexts: G query groups x S target shards (N = G * S).  A group holds the whole
 // target split, dealt to its S contexts; the query blocks of a run are dealt to the groups.  The model behind the default is
-// bench.py's choose_query_groups() (stage times of the 10 000 x 1 M search on one device, ms: the similar-k-mer stage k = 19.5
-// follows the queries only, e = 152.8 follows the index entries a context holds, x = 3 per exchange step): t = k / G + e / (G S)
+// bench.py's choose_query_groups() (stage times of the 10 000 x 1 M search on one device, ms, round 5: the similar-k-mer stage k = 10.5
+// follows the queries only, e = 142.4 follows the index entries a context holds, x = 3 per exchange step): t = k / G + e / (G S)
 // + x (S > 1), with two shards or more per group, so that a device holds half of the index at most.
 int MMGpuRun::queryGroups(int nDevices, bool shardsPossible) {
     if (nDevices < 2) return 1;
@@ -88,7 +88,7 @@ int MMGpuRun::queryGroups(int nDevices, bool shardsPossible) {
         }
         return g;
     }
-    const double k = 19.5, ent = 152.8, x = 3.0;
+    const double k = 10.5, ent = 142.4, x = 3.0;      // (ms per 10 000 queries x 1 M targets, profiles/r05_bench_n1.json)
     int best = 1;
     double bestT = -1;
     for (int g = 1; g <= nDevices; g++) {

@@ -40,14 +40,14 @@ def test_committed_bench_line_has_the_contract_keys():
     assert d["cpu_baseline_prefilter"]["parity_vs_reference"]["queries_with_different_hit_lists"] == 0
     assert d["two_call"]["fields_differing_from_fused_path"] == 0
     assert d["nucleotide_align"]["cpu_baseline"]["parity_vs_reference"]["pairs_differing"] == 0
-    assert d["nucleotide_search"]["cpu_baseline"]["parity_vs_reference"]["queries_with_different_hit_lists"] == 0
+    assert d["nucleotide_search"]["parity_run"]["cpu_baseline"]["parity_vs_reference"]["queries_with_different_hit_lists"] == 0
     assert isinstance(d["roofline"]["traffic"], (int, float)) and d["roofline"]["traffic"] > d["roofline"]["algorithmic_bytes_per_launch"]
     # round 5: the prefilter roofline is quoted for the STAGE (every prefilter kernel of the step), the split kernel is a sub-field,
     # and the look-up / gather kernels are priced against the measured rate of random memory-side requests
     pr = d["prefilter"]["roofline"]
     assert abs(pr["kernel_ms"] - d["prefilter"]["stage_ms"]["total"]) < 0.01 and abs(pr["frac"] - pr["achieved"] / pr["peak"]) < 1e-3
     assert abs(pr["achieved"] - pr["algorithmic_bytes_per_launch"] / (pr["kernel_ms"] * 1e-3) / 1e9) < 0.01 * pr["achieved"]
-    assert pr["split_kernel"]["kernel_ms"] == d["prefilter"]["stage_ms"]["gather_split"] and 0 < pr["random_request_roofline"]["frac"] < 1
+    assert abs(pr["split_kernel"]["kernel_ms"] - d["prefilter"]["stage_ms"]["gather_split"]) < 0.01 and 0 < pr["random_request_roofline"]["frac"] < 1
     assert isinstance(pr["traffic"], (int, float)) and pr["traffic"] > 0
     # block aligner (a15): counts, and what the restatement is pinned against
     b = d["block_aligner"]
@@ -60,6 +60,14 @@ def test_committed_bench_line_has_the_contract_keys():
     m = e["mmseqs_modules_stock_vs_patched"]
     assert m["alignment_dbs_identical"] is True and m["entries_compared"] == 10000
     assert m["patched"]["prefilter_wall_s"] < m["stock"]["prefilter_wall_s"] and m["patched"]["align_wall_s"] < m["stock_block_aligner_stubbed"]["align_wall_s"]
+    # round 5: the whole search, also on a persisted device layout (row f1) - result databases equal the stock binary's
+    for k in ("patched_search_fused", "patched_search_fused_persisted_layout", "patched_search_fused_resident_server"):
+        assert m[k]["result_db_identical_to_stock_align_db"] is True and m[k]["entries_compared"] == 10000, k
+    assert m["patched_search_fused_persisted_layout"]["loaded_without_host_lookup"] is True
+    # the translated search of configs[4] through both binaries: equal entries (up to the order of tied lines, which the stock
+    # binary itself does not keep from run to run)
+    t = d["translated_search"]["cpu_baseline"]["parity_vs_reference"]
+    assert t["entries_differing"] == 0 and t["result_entries_compared"] == 100
 
 
 def test_pmc_reader_finds_the_quoted_kernels():
