@@ -8,7 +8,7 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from mmseqs2_amd import dbio                                                   # noqa: E402
-from tests.test_mmseqs_dropin import STOCK, MMGPU, EXAMPLES, THREADS, run, copy_db   # noqa: E402
+from tests.test_mmseqs_dropin import STOCK, MMGPU, EXAMPLES, THREADS, run, copy_db, reference_for   # noqa: E402
 
 emulate = (sys.argv[1] if len(sys.argv) > 1 else "emu") == "emu"
 FLOWS = [
@@ -35,13 +35,16 @@ for i, (flow, args) in enumerate(FLOWS):
         base_s, base_g = ["cluster", "q", "res_s%d" % i, "tmp_s%d" % i], ["cluster", "q", "res_g%d" % i, "tmp_g%d" % i]
     else:
         base_s, base_g = [flow, "q", "q", "res_s%d" % i, "tmp_s%d" % i], [flow, "q", "q", "res_g%d" % i, "tmp_g%d" % i]
+    # (workflows with second alignments of accepted hits - iterations, --realign, --alt-ali, cluster - are compared with the stock tree
+    # that carries the same do-nothing block-aligner stubs as the patched test binary: tests/test_mmseqs_dropin.py::reference_for)
+    ref, env = reference_for([flow] + args)
     try:
-        run(STOCK, base_s + args + th + ["-v", "2"], w)
+        run(ref, base_s + args + th + ["-v", "2"], w)
     except AssertionError as e:
         print("%-8s %-55s stock binary fails: %s" % (flow, " ".join(args), str(e)[-160:].replace("\n", " | ")))
         continue
     try:
-        log = run(MMGPU, base_g + args + th + ["-v", "3"], w, emulate)
+        log = run(MMGPU, base_g + args + th + ["-v", "3"], w, emulate, extra_env=env)
     except AssertionError as e:
         print("%-8s %-55s PATCHED BINARY FAILED: %s" % (flow, " ".join(args), str(e)[-400:].replace("\n", " | ")))
         bad_total += 1
