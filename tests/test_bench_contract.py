@@ -94,3 +94,48 @@ def test_this_rounds_pmc_passes_were_taken_with_these_device_sources():
         assert bench.pmc_file_digest(path) == now, (path, bench.pmc_file_digest(path), now)
     assert bench.pmc_traffic(("sw_kernel<", "sw_rev_multi_kernel"), bench.PROFILE_ROUND + "_search") > 1e9
     assert _line()["roofline"]["csrc_digest"] == now
+
+
+def test_stage_traffic_counts_every_dispatch_of_a_run():
+    """`prefilter.roofline.traffic` is bytes per RUN of the stage: a kernel that is launched once per stage chunk (replay, scoring,
+    select: three times per run in the committed passes) contributes all of its dispatches, not its mean dispatch."""
+    sys.path.insert(0, ROOT)
+    import bench
+    stem = bench.PROFILE_ROUND + "_search"
+    once = bench.pmc_traffic(("pf_split_kernel",), stem)
+    assert abs(bench.pmc_traffic(("pf_split_kernel",), stem, per_run_of="pf_split_kernel") - once) <= 1e-6 * once
+    mean_replay = bench.pmc_traffic(("pf_replay_kernel",), stem)
+    run_replay = bench.pmc_traffic(("pf_replay_kernel",), stem, per_run_of="pf_split_kernel")
+    assert 2.5 * mean_replay < run_replay < 3.5 * mean_replay       # three stage chunks per run
+    line = _line()["prefilter"]["roofline"]
+    assert line["traffic"] > line["split_kernel"]["traffic"] + run_replay
+    assert bench.pmc_traffic(("pf_split_kernel",), stem, per_run_of="no_such_kernel") is None
+
+
+def test_result_databases_compare_up_to_the_order_of_tied_lines(tmp_path):
+    """mmseqs2_amd/dbio.py::diff_dbs_up_to_tie_order: lines of an entry with equal (bit score, E-value) may swap places - the stock
+    binary's own translated search does that from run to run - anything else is a difference."""
+    import struct
+    from mmseqs2_amd import dbio
+
+    def write(name, entries):
+        data, index, off = b"", "", 0
+        for k, e in entries:
+            blob = e + b"\0"
+            index += "%d\t%d\t%d\n" % (k, off, len(blob))
+            data += blob
+            off += len(blob)
+        p = str(tmp_path / name)
+        open(p, "wb").write(data)
+        open(p + ".index", "w").write(index)
+        open(p + ".dbtype", "wb").write(struct.pack("<i", 5))
+        return p
+
+    a = write("a", [(0, b"7\t64\t0.9\t1E-10\t1\t9\n7\t64\t0.8\t1E-10\t20\t29\n3\t50\t0.7\t1E-5\t2\t8\n"), (1, b"4\t30\t0.5\t1E-3\t1\t5\n")])
+    b = write("b", [(0, b"7\t64\t0.8\t1E-10\t20\t29\n7\t64\t0.9\t1E-10\t1\t9\n3\t50\t0.7\t1E-5\t2\t8\n"), (1, b"4\t30\t0.5\t1E-3\t1\t5\n")])
+    c = write("c", [(0, b"7\t64\t0.9\t1E-10\t1\t9\n3\t50\t0.7\t1E-5\t2\t8\n7\t64\t0.8\t1E-10\t20\t29\n"), (1, b"4\t30\t0.5\t1E-3\t1\t6\n")])
+    assert dbio.diff_dbs(a, b)[1] == 1
+    assert dbio.diff_dbs_up_to_tie_order(a, b)[:3] == (2, 0, 1)
+    # a tied line moved across a line with another key, and a changed field: both are differences
+    assert dbio.diff_dbs_up_to_tie_order(a, c)[:3] == (2, 2, 0)
+    assert dbio.diff_dbs_up_to_tie_order(a, a)[:3] == (2, 0, 0)

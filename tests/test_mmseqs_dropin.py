@@ -435,7 +435,11 @@ def _translated_pipeline(w, emulate):
     run(STOCK, ["search", "qn", "t", "tres_s", "ttmp_s", "-s", "5.7", "-a", "--threads", THREADS, "-v", "1"], w)
     log = run(MMGPU, ["search", "qn", "t", "tres_g", "ttmp_g", "-s", "5.7", "-a", "--threads", THREADS, "-v", "3"], w, emulate)
     assert both_modules_on_device(log) and "using the CPU path" not in log, log[-3000:]
-    n = same(os.path.join(w, "tres_s"), os.path.join(w, "tres_g"))
+    # (entry by entry; lines of an entry whose bit score and E-value tie are written by `offsetalignment` in a thread-dependent order -
+    # two runs of the STOCK binary differ that way at configs[4]'s size, bench.py `translated_search` - so such runs of lines are
+    # compared as sets)
+    n, bad, _, msgs = dbio.diff_dbs_up_to_tie_order(os.path.join(w, "tres_s"), os.path.join(w, "tres_g"))
+    assert bad == 0, msgs
     assert n == 24
     # the search found the planted proteins: every query has hits
     d = dbio.read_db(os.path.join(w, "tres_g"))
