@@ -164,6 +164,21 @@ def persisted_layout_pipeline(tmp, emulate):
         assert "no sequence lookup on the host" in log and "targets already resident (fused search)" in log, log[-3000:]
         assert "using the CPU path" not in log, log[-3000:]
         assert same(os.path.join(w, "res_s" + tag), os.path.join(w, "res_g" + tag)) == 500
+    # another target database (the same proteins, the last hundred dropped, two residues of the first one exchanged): keys and
+    # lengths of the first 400 agree with the file's, the count and the sampled bytes do not - refused, rebuilt, replaced
+    run(STOCK, ["convert2fasta", "q", "q.fasta", "-v", "1"], w)
+    recs = open(os.path.join(w, "q.fasta")).read().split(">")[1:401]
+    head, seq = recs[0].split("\n", 1)
+    recs[0] = head + "\n" + seq[1] + seq[0] + seq[2:]
+    open(os.path.join(w, "t2.fasta"), "w").write("".join(">" + r for r in recs))
+    run(STOCK, ["createdb", "t2.fasta", "t2", "-v", "1"], w)
+    run(STOCK, ["prefilter", "q", "t2", "pref_t2_s", "-s", "4", "--threads", THREADS, "-v", "2"], w)
+    log = run(MMGPU, ["prefilter", "q", "t2", "pref_t2_g", "-s", "4", "--threads", THREADS, "-v", "3"], w, emulate, extra_env=env)
+    assert "made from another database or with other index parameters" in log and "device layout saved to" in log, log[-2000:]
+    assert same(os.path.join(w, "pref_t2_s"), os.path.join(w, "pref_t2_g")) == 500
+    log = run(MMGPU, ["prefilter", "q", "t2", "pref_t2_g2", "-s", "4", "--threads", THREADS, "-v", "3"], w, emulate, extra_env=env)
+    assert "no sequence lookup on the host" in log
+    assert same(os.path.join(w, "pref_t2_s"), os.path.join(w, "pref_t2_g2")) == 500
 
 
 def test_persisted_device_layout_host_side_emulated(tmp_path):
