@@ -1043,7 +1043,7 @@ def nucl_search_section(args, gpu, matrices, n_contigs, with_reference):
             ref = pyoracle.RefNuclPrefilter(15, True, serialized=matrices["nucleotide_serialized"].tobytes())
             ref.build_index(pres, poff)
             t_ref_index = time.perf_counter() - t0
-            n_s = min(len(both), 64)
+            n_s = min(len(both), 1000)
             bad = 0
             t0 = time.perf_counter()
             refl = [ref.match(both[qi], max_hits=300, force_bins=2, max_seq_len=args.nucl_read_len + 64) for qi in range(n_s)]
@@ -1165,7 +1165,7 @@ def main():
                     help="nucleotide search: size of the second, smaller run whose hit lists are compared with the reference's matcher "
                          "(the reference's 4^15-offset index build over 50 k contigs alone takes minutes)")
     ap.add_argument("--translated-contigs", type=int, default=5000, help="configs[4] as `search --search-type 2` through the binaries")
-    ap.add_argument("--translated-sample", type=str, default="100x2000", help="reads x contigs of the stock-binary run (CPU baseline + parity)")
+    ap.add_argument("--translated-sample", type=str, default="200x4000", help="reads x contigs of the stock-binary run (CPU baseline + parity)")
     ap.add_argument("--no-translated", action="store_true")
     ap.add_argument("--nucl-reads", type=int, default=1000)
     ap.add_argument("--nucl-read-len", type=int, default=10000)
