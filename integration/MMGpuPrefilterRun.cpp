@@ -184,6 +184,9 @@ bool MMGpuPrefilterRun::loadPersisted(Prefiltering &p, size_t dbFrom, size_t dbS
     // database (the alignment module of a fused search reads single sequences on demand, see MMGpuAlignRun)
     if (p.splits != 1 || !MMGpuRun::deviceIds().empty() || contextsForLargeSplit(dbSize) > 1) return false;
     if (Parameters::isEqualDbtype(p.querySeqType, Parameters::DBTYPE_HMM_PROFILE)) return false;
+    // (amino-acid target databases: the layout of a nucleotide index - 4^15 offsets - is served by the library calls, but this
+    // binding has only been exercised with protein databases)
+    if (!Parameters::isEqualDbtype(p.targetSeqType, Parameters::DBTYPE_AMINO_ACIDS)) return false;
     mmgpu_db_info info;
     if (mmgpu_db_probe(file, &info) != 0) return false;      // (no file yet: run() builds and saves it)
     MMGpuPrefilter device(NULL, p.kmerSubMat, p.ungappedSubMat, p.aaBiasCorrection, p.aaBiasCorrectionScale);
@@ -303,6 +306,7 @@ bool MMGpuPrefilterRun::run(Prefiltering &p, DBWriter &tmpDbw, size_t dbFrom, si
         // tell - profile queries -, else built and saved; a run that loaded it there, p.mmgpuPersisted, has no lookup to hand over)
         MMGpuPrefilter::Persisted layout;
         const bool persist = p.mmgpuDeviceIndex && !p.mmgpuPersisted && nGroups == 1 && MMGpuRun::deviceIds().empty() && virtualShards <= 1 && p.splits == 1 &&
+                             Parameters::isEqualDbtype(p.targetSeqType, Parameters::DBTYPE_AMINO_ACIDS) &&
                              persistedLayout(p, p.tdbr, dbFrom, dbSize, p.mmgpuDeviceMask, p.mmgpuIndexKmerThr, p.kmerSize, p.spacedKmer, (double)p.maskProb,
                                              p.mmgpuDeviceMask ? 0 : p.maskMode, p.maskLowerCaseMode, p.maskNrepeats, p.targetSearchMode, three.isValid(),
                                              *devices[0], &layout);
