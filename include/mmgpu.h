@@ -219,9 +219,13 @@ typedef struct {
                                     leave the 512-row LDS form), so this no longer depends on the pair */
 #define MMGPU_BLOCK_NOT_WORD 3   /* not an int16-range hit with a positive score */
 /* pair_index as for mmgpu_sw_traceback (any mode: only score / q_end / t_end of the forward scan are read); every pair reserves
- * (q_end + 1) + (t_end + 1) + 1 bytes of bt.  bt == NULL with bt_cap == MMGPU_BLOCK_NO_STRINGS: the caller wants start positions,
- * identities and bt_len only (a run without -a: the strings stay on the device, no download). */
+ * (q_end + 1) + (t_end + 1) + 1 bytes of bt, rounded up to a multiple of four (*bt_used of a call with bt == NULL is the size to
+ * bring).  bt == NULL with bt_cap == MMGPU_BLOCK_NO_STRINGS: the caller wants start positions, identities and bt_len only (the
+ * strings stay on the device, no download).  bt == NULL with bt_cap == MMGPU_BLOCK_STARTS_ONLY: start positions and status only -
+ * what `mmseqs search` consumes in alignment mode 2 without -a (Matcher.cpp:107-127: neither identicalAACnt nor the backtrace
+ * reach the record there); ident and bt_len come back 0, the device keeps no trace and walks nothing back. */
 #define MMGPU_BLOCK_NO_STRINGS ((size_t)-1)
+#define MMGPU_BLOCK_STARTS_ONLY ((size_t)-2)
 int mmgpu_sw_block_backtrace(mmgpu_ctx *ctx, mmgpu_sw_batch_t *batch, const uint32_t *pair_index, uint32_t n_pairs,
                              mmgpu_sw_block *out, char *bt, size_t bt_cap, size_t *bt_used);
 /* Test aid (the growth-sequence test of tests/test_sw_gpu.py): the same run without strings, plus every pair's block list as it
@@ -231,8 +235,9 @@ int mmgpu_sw_block_backtrace(mmgpu_ctx *ctx, mmgpu_sw_batch_t *batch, const uint
  * right) per block. */
 int mmgpu_sw_block_growth(mmgpu_ctx *ctx, mmgpu_sw_batch_t *batch, const uint32_t *pair_index, uint32_t n_pairs, mmgpu_sw_block *out,
                           uint32_t *growth, uint32_t growth_cap);
-/* reporting: how many pairs of the batch's LAST mmgpu_sw_block_backtrace call were decided with blocks up to 512 rows (borders
- * in LDS) and how many needed the second launch with the crate's full 4096-row blocks (borders in HBM) */
+/* reporting: how many pairs of the batch's LAST mmgpu_sw_block_backtrace call were decided with blocks up to 512 rows (two pairs
+ * per wavefront with blocks up to 128 rows, then one pair per wavefront with the borders in LDS) and how many needed the later
+ * launches with the crate's full 4096-row blocks (borders in HBM) */
 int mmgpu_sw_block_tiers(const mmgpu_sw_batch_t *batch, uint32_t *first_tier, uint32_t *second_tier);
 
 /* ---- nucleotide alignment step (behind Alignment::run for nucleotide databases) --------------------------------

@@ -460,14 +460,20 @@ class SwBatch:
         self.gpu._check(self.gpu.L.mmgpu_sw_fetch_owned(self.gpu.ctx, self.handle, _ptr(out), ctypes.byref(n)))
         return out, n.value
 
-    def block_backtrace(self, pair_index):
+    def block_backtrace(self, pair_index, mode="strings"):
         """mmgpu_sw_block_backtrace: the block aligner's start positions / identities / backtraces of int16-range hits.
-        -> (SW_BLOCK_DTYPE array, list of backtrace strings (None unless status == 0))"""
+        -> (SW_BLOCK_DTYPE array, list of backtrace strings (None unless status == 0)).  mode "no_strings": start positions,
+        identities and lengths (MMGPU_BLOCK_NO_STRINGS); "starts": start positions only (MMGPU_BLOCK_STARTS_ONLY) - both -> (array, None)"""
         pi = np.ascontiguousarray(pair_index, np.uint32)
         out = np.zeros(len(pi), SW_BLOCK_DTYPE)
         used = ctypes.c_size_t()
         import time
         t0 = time.perf_counter()
+        if mode != "strings":
+            cap = ctypes.c_size_t(-1 if mode == "no_strings" else -2)
+            self.gpu._check(self.gpu.L.mmgpu_sw_block_backtrace(self.gpu.ctx, self.handle, _ptr(pi), len(pi), _ptr(out), None, cap, ctypes.byref(used)))
+            self.last_block_call_s = time.perf_counter() - t0
+            return out, None
         rc = self.gpu.L.mmgpu_sw_block_backtrace(self.gpu.ctx, self.handle, _ptr(pi), len(pi), _ptr(out), None, 0, ctypes.byref(used))
         bt = np.zeros(max(used.value, 1), np.uint8)
         self.gpu._check(self.gpu.L.mmgpu_sw_block_backtrace(self.gpu.ctx, self.handle, _ptr(pi), len(pi), _ptr(out), _ptr(bt), used.value,

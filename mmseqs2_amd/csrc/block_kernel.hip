@@ -101,7 +101,6 @@ __device__ __forceinline__ int bk_prof_score(const BkSeq &pr, int pos, int lette
     return (pos >= 0 && letter < pr.alphabet) ? (int)pr.prof[(size_t)letter * pr.plen + pos] : -128;
 }
 
-struct BkBlock { uint32_t i, j; uint16_t h, w; uint32_t right, tstart; };   // Trace::block_start / block_size / right + first trace entry
 
 struct BkState {
     int16_t *D_col, *C_col, *D_row, *R_row, *D_col_ck, *C_col_ck, *D_row_ck, *R_row_ck, *temp1, *temp2;

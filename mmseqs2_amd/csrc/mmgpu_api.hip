@@ -226,6 +226,7 @@ extern "C" int mmgpu_warmup(mmgpu_ctx *c) {
     mmgpu::warm_pf();
     mmgpu::warm_sw();
     mmgpu::warm_block();
+    mmgpu::warm_block2();
     mmgpu::warm_bt();
     return MMGPU_OK;
 }
@@ -528,6 +529,7 @@ struct mmgpu_sw_batch_t {
     std::vector<uint32_t> h_slot_target;
     bool h_res_valid = false;
     uint32_t block_pairs_tier[3] = {0, 0, 0};   // last mmgpu_sw_block_backtrace call: pairs decided with blocks <= 512 / 2048 / 4096 rows
+    uint32_t block_pairs_fast = 0;              // ... and by block2_kernel.hip (two pairs per wavefront, blocks <= 128 rows) before those
     // pairs this rank owns of a sharded run's merged lists (mmgpu_sw_prepare_owned / mmgpu_sw_gather_owned)
     bool owned = false;
     uint32_t o_stride = 0, o_cap = 0;
@@ -1321,11 +1323,12 @@ static int block_backtrace(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const uint32_t *pa
         j.slot = k;
         jobs.push_back(j);
         const uint64_t len = (uint64_t)h.q_end + 1 + (uint64_t)h.t_end + 1;
-        off += len + 1;
+        off += (len + 1 + 3) & ~3ull;      // (multiples of four: the walk kernel of block2_kernel.hip stores a string in dwords)
         longest = std::max(longest, len);
     }
     if (bt_used) *bt_used = (size_t)off;
-    const bool no_strings = bt == nullptr && bt_cap == MMGPU_BLOCK_NO_STRINGS;      // start positions / identities / lengths only
+    const bool starts_only = bt == nullptr && bt_cap == MMGPU_BLOCK_STARTS_ONLY;    // start positions only: no trace, no walk
+    const bool no_strings = starts_only || (bt == nullptr && bt_cap == MMGPU_BLOCK_NO_STRINGS);      // start positions / identities / lengths only
     if (!no_strings && (off > bt_cap || (!bt && off))) return fail(MMGPU_ERR_ARG, "mmgpu_sw_block_backtrace: bt buffer too small (see *bt_used)");
     if (jobs.empty()) return MMGPU_OK;
     std::stable_sort(jobs.begin(), jobs.end(), [](const BlockJob &x, const BlockJob &y) { return x.q_end + x.t_end > y.q_end + y.t_end; });
@@ -1358,7 +1361,7 @@ static int block_backtrace(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const uint32_t *pa
     };
     static const uint64_t pool_limit = (getenv("MMGPU_BLOCK_POOL_MB") ? strtoull(getenv("MMGPU_BLOCK_POOL_MB"), nullptr, 10) : 16384ull) << 20;
     // (small calls: slots for the longest pair, everything starts in tier 0)
-    const uint64_t typical_len = pair_len(jobs[jobs.size() > 1024 ? 255 : 0]);
+    uint64_t typical_len = pair_len(jobs[jobs.size() > 1024 ? 255 : 0]);
     DevBuf d_out, d_btoff, d_bt, d_scores, d_jobs[3], d_pool[3], d_busy[3];
     for (DevBuf *d : {&d_out, &d_btoff, &d_bt, &d_scores, &d_jobs[0], &d_jobs[1], &d_jobs[2], &d_pool[0], &d_pool[1], &d_pool[2], &d_busy[0], &d_busy[1], &d_busy[2]})
         d->bind(c->cache);
@@ -1395,14 +1398,82 @@ static int block_backtrace(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const uint32_t *pa
     L.bt = d_bt.as<char>();
     L.growth = growth ? d_growth.as<uint32_t>() : nullptr;
     L.growth_cap = growth_cap;
-    const int first_tier = getenv("MMGPU_BLOCK_FIRST_TIER") ? std::max(0, std::min(2, atoi(getenv("MMGPU_BLOCK_FIRST_TIER")))) : 0;      // test aid
+    const char *first_tier_env = getenv("MMGPU_BLOCK_FIRST_TIER");      // test aid: every pair through block_kernel.hip's tier 0 / 1 / 2
+    const int first_tier = first_tier_env ? std::max(0, std::min(2, atoi(first_tier_env))) : 0;
+    b->block_pairs_tier[0] = b->block_pairs_tier[1] = b->block_pairs_tier[2] = 0;
+    b->block_pairs_fast = 0;
+    // ---- block2_kernel.hip first: two pairs per wavefront, blocks up to 128 rows, sequence queries.  With a trace the pairs run in
+    // groups whose block lists + traces fit the pool (40 bytes per residue of the pair, the crate's usual 32 / 64-row blocks; a
+    // pair that needs more is answered TOO_LARGE like one whose blocks grow beyond 128 rows), each group = fill launch + walk launch
+    // on the context's stream, back to back ----
+    std::vector<BlockJob> slow_jobs;
+    if (!first_tier_env) {
+        std::vector<Block2Job> j2;
+        j2.reserve(jobs.size());
+        std::vector<uint32_t> group_begin(1, 0u);
+        static const uint64_t pool2_limit = (getenv("MMGPU_BLOCK2_POOL_MB") ? strtoull(getenv("MMGPU_BLOCK2_POOL_MB"), nullptr, 10) : 3072ull) << 20;
+        uint64_t pool_used = 0, pool_need = 0;
+        for (const BlockJob &j : jobs) {
+            if (!b->h_query_is_profile.empty() && b->h_query_is_profile[j.query]) { slow_jobs.push_back(j); continue; }
+            Block2Job x;
+            x.query = j.query; x.target = j.target; x.score = j.score; x.q_end = j.q_end; x.t_end = j.t_end; x.slot = j.slot;
+            x.pool_off = 0; x.pool_bytes = 0; x.pad = 0;
+            if (!starts_only) {
+                const uint64_t len = pair_len(j);
+                const uint64_t bytes = (((len + 64) * sizeof(BkBlock) + 31) & ~31ull) + 40 * (len + 256);
+                if (bytes > pool2_limit || bytes > 0xFFFFFFFFull) { slow_jobs.push_back(j); continue; }
+                if (pool_used + bytes > pool2_limit) { group_begin.push_back((uint32_t)j2.size()); pool_used = 0; }
+                x.pool_off = pool_used; x.pool_bytes = (uint32_t)bytes;
+                pool_used += bytes;
+                pool_need = std::max(pool_need, pool_used);
+            }
+            j2.push_back(x);
+        }
+        group_begin.push_back((uint32_t)j2.size());
+        if (!j2.empty()) {
+            const size_t n_groups = group_begin.size() - 1;
+            DevBuf d_j2, d_cnt, d_pool2;
+            d_j2.bind(c->cache); d_cnt.bind(c->cache); d_pool2.bind(c->cache);
+            HIP_TRY(d_j2.alloc(j2.size() * sizeof(Block2Job)));
+            HIP_TRY(d_cnt.alloc(n_groups * 4));
+            if (pool_need) HIP_TRY(d_pool2.alloc((size_t)pool_need));
+            HIP_TRY(hipMemcpyAsync(d_j2.p, j2.data(), j2.size() * sizeof(Block2Job), hipMemcpyHostToDevice, s));
+            HIP_TRY(hipMemsetAsync(d_cnt.p, 0, n_groups * 4, s));
+            Block2Launch L2;
+            L2.q_res = L.q_res; L2.q_cb = L.q_cb; L2.q_off = L.q_off; L2.t_res = L.t_res; L2.t_off4 = L.t_off4;
+            L2.scores = L.scores; L2.gap_open = L.gap_open; L2.gap_extend = L.gap_extend;
+            L2.out = L.out; L2.bt_off = L.bt_off; L2.bt = no_strings ? nullptr : L.bt;
+            L2.pool = d_pool2.as<uint8_t>();
+            L2.growth = L.growth; L2.growth_cap = L.growth_cap;
+            for (size_t g = 0; g < n_groups; g++) {
+                L2.jobs = d_j2.as<Block2Job>() + group_begin[g];
+                L2.n_jobs = group_begin[g + 1] - group_begin[g];
+                L2.counter = d_cnt.as<uint32_t>() + g;
+                const uint32_t waves = (uint32_t)std::min<uint64_t>((L2.n_jobs + 1) / 2, (uint64_t)std::max(c->compute_units, 1) * 12);
+                HIP_TRY(launch_sw_block2(L2, !starts_only, waves, s));
+                if (!starts_only) HIP_TRY(launch_sw_block2_walk(L2, s));
+            }
+            HIP_TRY(hipMemcpyAsync(out, d_out.p, (size_t)n * sizeof(mmgpu_sw_block), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            if (trace_on) fprintf(stderr, "[mmgpu block aligner] two pairs per wavefront: %zu pairs in %zu group(s), pool %.1f MB\n", j2.size(), n_groups, pool_need / 1048576.0);
+            for (const BlockJob &j : jobs)
+                if ((b->h_query_is_profile.empty() || !b->h_query_is_profile[j.query]) && out[j.slot].status == MMGPU_BLOCK_TOO_LARGE) slow_jobs.push_back(j);
+            std::stable_sort(slow_jobs.begin(), slow_jobs.end(), [&](const BlockJob &x, const BlockJob &y) { return pair_len(x) > pair_len(y); });
+            b->block_pairs_fast = (uint32_t)(jobs.size() - slow_jobs.size());
+            lap("two pairs per wavefront + status download");
+        }
+    } else {
+        slow_jobs = jobs;
+    }
     // Rounds: the tiers that have pairs waiting run side by side (a stream, a pool, a job list each).  Round one = tier 0 for the
     // pairs up to the typical length and, at the same time, tier 1 for the longer ones (they would overflow tier 0's slots, and
     // each of them is a long serial chain: starting them first keeps them off the critical path); what a tier leaves undecided
     // joins the next tier in the following round.
     std::vector<BlockJob> wait[3];      // longest first inside each
-    for (const BlockJob &j : jobs) wait[first_tier == 0 && pair_len(j) > typical_len ? 1 : first_tier].push_back(j);
-    b->block_pairs_tier[0] = b->block_pairs_tier[1] = b->block_pairs_tier[2] = 0;
+    // (what block2_kernel.hip handed on grows beyond 128 rows: tier 0's slots sized for blocks of 512 rows along the whole pair)
+    const uint64_t tier0_entries = first_tier_env ? 2 : BLOCK_MAX_SIZE / 64;
+    if (!slow_jobs.empty()) typical_len = pair_len(slow_jobs[slow_jobs.size() > 1024 ? 255 : 0]);
+    for (const BlockJob &j : slow_jobs) wait[first_tier == 0 && pair_len(j) > typical_len ? 1 : first_tier].push_back(j);
     hipStream_t extra[2] = {nullptr, nullptr};
     auto release_streams = [&] { for (hipStream_t &x : extra) if (x) { (void)hipStreamDestroy(x); x = nullptr; } };
     while (!wait[0].empty() || !wait[1].empty() || !wait[2].empty()) {
@@ -1411,7 +1482,7 @@ static int block_backtrace(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const uint32_t *pa
             std::vector<BlockJob> &todo = wait[tier];
             if (todo.empty()) continue;
             const uint64_t longest_todo = pair_len(todo.front());
-            const uint64_t slot_bytes = tier == 0   ? slot_size(typical_len, 2, BLOCK_MAX_SIZE, false)
+            const uint64_t slot_bytes = tier == 0   ? slot_size(typical_len, tier0_entries, BLOCK_MAX_SIZE, false)
                                         : tier == 1 ? slot_size(longest_todo, BLOCK_MID_SIZE / 64, BLOCK_MID_SIZE, false)
                                                     : slot_size(longest_todo, BLOCK_REF_MAX_SIZE / 64, BLOCK_REF_MAX_SIZE, true);
             // (tier 0: 16 wavefronts per CU is what its 9 KB of LDS allows; 8 per CU, or 32 with a 128-row first tier, move the call by
@@ -1477,7 +1548,7 @@ extern "C" int mmgpu_sw_block_growth(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const ui
 
 extern "C" int mmgpu_sw_block_tiers(const mmgpu_sw_batch_t *b, uint32_t *first_tier, uint32_t *second_tier) {
     if (!b) return fail(MMGPU_ERR_ARG, "mmgpu_sw_block_tiers: NULL batch");
-    if (first_tier) *first_tier = b->block_pairs_tier[0];
+    if (first_tier) *first_tier = b->block_pairs_fast + b->block_pairs_tier[0];
     if (second_tier) *second_tier = b->block_pairs_tier[1] + b->block_pairs_tier[2];
     return MMGPU_OK;
 }

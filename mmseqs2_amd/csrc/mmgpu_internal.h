@@ -447,6 +447,7 @@ hipError_t launch_tantan_mask(const TantanArgs &A, hipStream_t s);
 // code-object loading ahead of the first launch (mmgpu_warmup)
 void warm_sw();
 void warm_block();
+void warm_block2();
 void warm_pf();
 void warm_ix();
 void warm_tantan();
@@ -523,6 +524,39 @@ struct BlockLaunch {
 // tier 0: blocks up to BLOCK_MAX_SIZE rows (LDS), 1: up to BLOCK_MID_SIZE (LDS), 2: up to BLOCK_REF_MAX_SIZE rows, border arrays
 // in the first 8 * 4096 * 2 bytes of the pair's scratch slot
 hipError_t launch_sw_block(const BlockLaunch &L, int tier, hipStream_t stream);
+struct BkBlock { uint32_t i, j; uint16_t h, w; uint32_t right, tstart; };   // Trace::block_start / block_size / right + the block's first trace entry
+
+// ---- the same aligner, two pairs per wavefront, border arrays in registers (block2_kernel.hip): sequence queries, blocks up to
+// BLOCK2_MAX_SIZE rows; what it answers MMGPU_BLOCK_TOO_LARGE goes to the tiers above ----
+constexpr int BLOCK2_MAX_SIZE = 128;
+struct Block2Job {
+    uint32_t query, target;
+    int32_t score, q_end, t_end;
+    uint32_t slot;                // index into out / bt_off
+    uint64_t pool_off;            // the pair's scratch (block list + trace) in the pool; unused without a trace
+    uint32_t pool_bytes, pad;
+};
+struct Block2Launch {
+    const Block2Job *jobs;
+    uint32_t n_jobs;
+    uint32_t *counter;            // the queue's head (zero before the launch)
+    const uint8_t *q_res;
+    const int8_t *q_cb;
+    const uint32_t *q_off;
+    const uint8_t *t_res;
+    const uint32_t *t_off4;
+    const int8_t *scores;         // AAMatrix::scores [27 * 32], as BlockLaunch::scores
+    int gap_open, gap_extend;     // the crate's convention: negative
+    mmgpu_sw_block *out;
+    const uint64_t *bt_off;       // multiples of four
+    char *bt;                     // null: no strings
+    uint8_t *pool;
+    uint32_t *growth = nullptr;   // test aid, as BlockLaunch::growth
+    uint32_t growth_cap = 0;
+};
+// trace = false: start positions only (no scratch, no walk)
+hipError_t launch_sw_block2(const Block2Launch &L, bool trace, uint32_t n_waves, hipStream_t stream);
+hipError_t launch_sw_block2_walk(const Block2Launch &L, hipStream_t stream);
 
 hipError_t launch_sw_traceback(const BtLaunch &L, hipStream_t stream);
 hipError_t launch_sw_traceback_wave(const BtLaunch &L, hipStream_t stream);
