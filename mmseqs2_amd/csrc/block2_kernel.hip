@@ -40,6 +40,9 @@ __device__ __forceinline__ unsigned pk_max(unsigned a, unsigned b) {      // v_p
 __device__ __forceinline__ unsigned pk_minu(unsigned a, unsigned b) {     // v_pk_min_u16
     return __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(b2_u16x2, a), __builtin_bit_cast(b2_u16x2, b)));
 }
+__device__ __forceinline__ unsigned pk_subw(unsigned a, unsigned b) {     // v_pk_sub_u16 (wraps, per half)
+    return __builtin_bit_cast(unsigned, __builtin_bit_cast(b2_u16x2, a) - __builtin_bit_cast(b2_u16x2, b));
+}
 __device__ __forceinline__ unsigned b2_bfi(unsigned mask, unsigned a, unsigned b) { return (a & mask) | (b & ~mask); }
 __device__ __forceinline__ unsigned b2_splat(int v) { return ((unsigned)v & 0xFFFFu) | ((unsigned)v << 16); }
 __device__ __forceinline__ int b2_adds16(int a, int b) { const int s = a + b; return s > 32767 ? 32767 : (s < -32768 ? -32768 : s); }
@@ -104,6 +107,7 @@ struct B2Job {
     int corner;         // D_corner of the first column
     int out_base;       // grow jobs: where column j's outputs go in the other pair of arrays
     int origin;         // the cell (0, 0) is row 0 of column 0
+    int off_add;        // shift jobs: just_offset of the job's own arrays, applied on the way into the first octet
 };
 
 struct B2Pair {
@@ -112,9 +116,10 @@ struct B2Pair {
     uint32_t slot;      // index into out
     int active;
     // align_core (scan_block.rs:120-632)
-    int best_max, best_i, best_j, prev_dir, dir, prev_size, block_size, off, prev_off, off_max, y_drop_iter, x_drop_iter;
+    int best_max, best_i, best_j, prev_dir, dir, prev_size, block_size, off, off_max, y_drop_iter, x_drop_iter;
     int st_i, st_j, i_ck, j_ck, off_ck, D_corner, off_add;
-    int min_size, x_drop, score, ri, rj;
+    int min_size, x_drop, score, ri, rj, dbg_first, dbg_steps;
+    uint32_t dbg_d0, dbg_d1;
     // Trace
     uint32_t trace_idx, block_idx, ck_trace_idx, ck_block_idx, trace_cap, block_cap;   // trace in dwords
     int overflow;
@@ -123,8 +128,11 @@ struct B2Pair {
     B2Job job;
 };
 
-template <bool TRACE>
+// NCH = chunks of 64 rows the border arrays hold: blocks up to 64 NCH rows (NCH = 2: the launch every pair starts in; NCH = 8: the
+// launch for what that one answered TOO_LARGE)
+template <bool TRACE, int NCH>
 __global__ __launch_bounds__(64) void sw_block2_kernel(Block2Launch L) {
+    constexpr int MAXB = 64 * NCH;
     __shared__ int16_t s_sc[27 * 32];
     const int lane = (int)threadIdx.x;
     for (int k0 = 0; k0 < 27 * 32; k0 += 64)
@@ -146,25 +154,29 @@ __global__ __launch_bounds__(64) void sw_block2_kernel(Block2Launch L) {
     }
     const unsigned g1 = b2_splat(ge), g2 = b2_splat((int)(short)(ge << 1)), g4 = b2_splat((int)(short)(ge << 2));
     const unsigned go2 = b2_splat(go), ge2 = b2_splat(ge), gome2 = b2_splat(b2_subs16(go, ge));
-    const int curbase0 = lane & ~15, curbase1 = 64 + (lane & ~15);
 
     // ---- vector state: border arrays of both pairs (low half A, high half B), entry 64 c + lane in chunk c ----
-    unsigned COL1[2] = {0, 0}, COL2[2] = {0, 0}, ROW1[2] = {0, 0}, ROW2[2] = {0, 0};          // D_col, C_col, D_row, R_row
-    unsigned KCOL1[2] = {0, 0}, KCOL2[2] = {0, 0}, KROW1[2] = {0, 0}, KROW2[2] = {0, 0};      // their checkpoints
-    unsigned rowbias[2] = {0, 0}, act[2] = {0, 0};
+    // (vector VALUES, not C arrays: `right ? ROW1 : COL1` must be a select of registers - with arrays the compiler selects between their
+    // addresses and the arrays land in scratch memory)
+    typedef unsigned VN __attribute__((ext_vector_type(NCH)));
+    typedef int IN __attribute__((ext_vector_type(NCH)));
+    VN COL1 = 0u, COL2 = 0u, ROW1 = 0u, ROW2 = 0u;          // D_col, C_col, D_row, R_row
+    VN KCOL1 = 0u, KCOL2 = 0u, KROW1 = 0u, KROW2 = 0u;      // their checkpoints
+    VN rowbias = 0u, act = 0u;
+    IN rowidx0 = 26 * 2, rowidx1 = 26 * 2;                 // per pair and chunk: the row's letter (as a byte offset into a score row)
     unsigned Mmax = 0, Gmax = 0, OUT1 = 0, OUT2 = 0;
-    unsigned aij[2] = {0, 0}, gaij[2] = {0, 0};             // per pair: column << 16 | chunk base of the lane's LAST maximum
-    int rowidx[2][2] = {{26 * 2, 26 * 2}, {26 * 2, 26 * 2}};        // per pair and chunk: the row's letter (as a byte offset into a score row)
-    unsigned colinfo[2] = {26, 26};                                 // per pair: lane l = column l of the job (mod 64): letter | bias << 8
-    unsigned tacc00 = 0, tacc01 = 0, tacc10 = 0, tacc11 = 0;       // [chunk][first / second four columns]: the octet's trace bits, packed
+    unsigned Marg = 0, Garg = 0;           // per half: column | chunk << 9 of the lane's LAST maximum (D_argmax: the chunk's base row is 64 c + (lane & ~15))
+    unsigned colinfo[2] = {26, 26};        // per pair: lane l = column l of the job (mod 64): letter | bias << 8
+    VN tacc0 = 0u, tacc1 = 0u;             // [chunk], first / second four columns: the octet's trace bits, packed
     B2Pair S0, S1;
     S0.active = 0; S1.active = 0;
     S0.job.kind = B2_JOB_NONE; S1.job.kind = B2_JOB_NONE;
     S0.job.height = 0; S1.job.height = 0; S0.job.width = 8; S1.job.width = 8; S0.job.oct = 0; S1.job.oct = 0;
     S0.job.rq = 1; S1.job.rq = 1; S0.job.corner = 0; S1.job.corner = 0; S0.job.origin = 0; S1.job.origin = 0;
     S0.job.start_row = 0; S1.job.start_row = 0; S0.job.start_col = 0; S1.job.start_col = 0; S0.job.out_base = 0; S1.job.out_base = 0;
+    S0.job.off_add = 0; S1.job.off_add = 0;
 
-    auto chunks_of = [](int h) { return h > 64 ? 2 : 1; };
+    auto chunks_of = [](int h) { return h > 64 ? (h + 63) >> 6 : 1; };
 
     // ---- helpers on one pair's half of the arrays ----
     auto for_arrays = [&](auto f) { f(COL1, KCOL1); f(COL2, KCOL2); f(ROW1, KROW1); f(ROW2, KROW2); };
@@ -176,10 +188,11 @@ __global__ __launch_bounds__(64) void sw_block2_kernel(Block2Launch L) {
         const B2Seq &rows = J.rq ? S.Q : S.T, &cols = J.rq ? S.T : S.Q;
         const int nch = chunks_of(J.height);
 #pragma unroll
-        for (int c = 0; c < 2; c++) {
+        for (int c = 0; c < NCH; c++) {
             if (c < nch) {
                 const int p = J.start_row + c * 64 + lane;
-                rowidx[P][c] = b2_letter(rows, p) * 2;
+                if (P) rowidx1[c] = b2_letter(rows, p) * 2;
+                else rowidx0[c] = b2_letter(rows, p) * 2;
                 rowbias[c] = b2_put<P>(rowbias[c], (J.rq ? (unsigned)b2_bias(S.Q, p) : 0u) << (P ? 16 : 0));
                 const int x = c * 64 + lane;
                 act[c] = b2_put<P>(act[c], x < J.height ? ~0u : 0u);
@@ -201,7 +214,7 @@ __global__ __launch_bounds__(64) void sw_block2_kernel(Block2Launch L) {
     auto add_block = [&](B2Pair &S, int i, int j, int width, int height, int right) {
         if (!TRACE) return;
         const bool ok = S.block_idx < S.block_cap;      // (uniform state changes outside the per-lane branch)
-        if (ok && lane == 0) {
+        if (ok && S.active && lane == 0) {
             BkBlock b;
             b.i = (uint32_t)i; b.j = (uint32_t)j; b.h = (uint16_t)height; b.w = (uint16_t)width; b.right = (uint32_t)right; b.tstart = S.trace_idx;
             S.blocks[S.block_idx] = b;
@@ -220,33 +233,34 @@ __global__ __launch_bounds__(64) void sw_block2_kernel(Block2Launch L) {
         return __builtin_amdgcn_readlane(v, 7);
     };
     // entry x of an array (uniform x)
-    auto entry = [&](auto PC, const unsigned (&a)[2], int x) {
+    auto entry = [&](auto PC, const VN &a, int x) {
         constexpr int P = decltype(PC)::value;
-        const int v0 = __builtin_amdgcn_readlane((int)a[0], x & 63), v1 = __builtin_amdgcn_readlane((int)a[1], x & 63);
-        return b2_shalf<P>(x >= 64 ? v1 : v0);
-    };
-    // just_offset (scan_block.rs:1102-1123, the branch without a shift): entries below block_size += off_add
-    auto offset_one = [&](auto PC, unsigned a, int c, int off_add, int bs) {
-        constexpr int P = decltype(PC)::value;
-        const bool in = c * 64 + lane < bs;
-        return b2_put<P>(a, in ? pk_add(a, b2_splat(off_add)) : a);
+        int v = 0;
+#pragma unroll
+        for (int c = 0; c < NCH; c++)
+            if (c == (x >> 6)) v = __builtin_amdgcn_readlane((int)a[c], x & 63);
+        return b2_shalf<P>(v);
     };
     // shift_and_offset (:1102-1123): entries move down by STEP and take off_add, the last STEP entries are the job's outputs.
     // (by value: which pair of arrays is shifted depends on the direction, and a select between array ADDRESSES would put them in scratch)
-    struct B2Arr { unsigned c0, c1; };
-    auto shift_one = [&](auto PC, B2Arr a, unsigned out, int off_add, int bs) {
+    auto shift_one = [&](auto PC, VN a, unsigned out, int off_add, int bs) {
         constexpr int P = decltype(PC)::value;
         const unsigned o2 = b2_splat(off_add);
-        const unsigned t0 = b2_lane_from(a.c0, lane + 8);
-        const unsigned t1 = bs > 64 ? b2_lane_from(a.c1, lane + 8) : 0u;
         const unsigned o = b2_lane_from(out, lane - (bs - B2_STEP));
-        unsigned n0 = pk_add(lane < 56 ? t0 : t1, o2), n1 = pk_add(t1, o2);
-        const int x0 = lane, x1 = 64 + lane;
-        if (x0 >= bs - B2_STEP) n0 = o;
-        if (x1 >= bs - B2_STEP) n1 = o;
-        B2Arr r;
-        r.c0 = b2_put<P>(a.c0, x0 < bs ? n0 : a.c0);
-        r.c1 = bs > 64 ? b2_put<P>(a.c1, x1 < bs ? n1 : a.c1) : a.c1;
+        unsigned t[NCH + 1];
+#pragma unroll
+        for (int c = 0; c < NCH; c++) t[c] = c * 64 < bs ? b2_lane_from(a[c], lane + 8) : 0u;
+        t[NCH] = 0u;
+        VN r = a;
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+            if (c * 64 < bs) {
+                unsigned n = pk_add(lane < 56 ? t[c] : t[c + 1], o2);
+                const int x = c * 64 + lane;
+                if (x >= bs - B2_STEP) n = o;
+                r[c] = b2_put<P>(a[c], x < bs ? n : a[c]);
+            }
+        }
         return r;
     };
     // a grow job's outputs of one octet: entries base .. base + 7 of the other pair of arrays
@@ -256,25 +270,29 @@ __global__ __launch_bounds__(64) void sw_block2_kernel(Block2Launch L) {
         const unsigned d = (unsigned)(c * 64 + lane - base);
         return d < (unsigned)B2_STEP ? b2_put<P>(a, o) : a;
     };
+
     // ---- eight columns of both pairs' jobs ----
     auto octet = [&]() {
         const B2Job &JA = S0.job, &JB = S1.job;
         const int nch = max(S0.active ? chunks_of(JA.height) : 1, S1.active ? chunks_of(JB.height) : 1);
         const unsigned rqm = (JA.rq ? B2_LO : 0u) | (JB.rq ? B2_HI : 0u);
-        unsigned D10[2], C10[2];
+        const bool firstA = JA.oct == 0, firstB = JB.oct == 0;
+        // just_offset (scan_block.rs:1102-1123, the branch without a shift) of a shift job's own arrays: here, on the way in
+        const unsigned offpk = ((unsigned)((JA.kind == B2_JOB_SHIFT && firstA) ? JA.off_add : 0) & B2_LO) |
+                               ((unsigned)((JB.kind == B2_JOB_SHIFT && firstB) ? JB.off_add : 0) << 16);
+        VN D10, C10;
 #pragma unroll
-        for (int c = 0; c < 2; c++) {
-            D10[c] = b2_bfi(rqm, COL1[c], ROW1[c]);
-            C10[c] = b2_bfi(rqm, COL2[c], ROW2[c]);
+        for (int c = 0; c < NCH; c++) {
+            D10[c] = pk_add(b2_bfi(rqm, COL1[c], ROW1[c]), offpk);
+            C10[c] = pk_add(b2_bfi(rqm, COL2[c], ROW2[c]), offpk);
         }
         const int lastA = (JA.height - 1) & 63, lastB = (JB.height - 1) & 63;
-        const bool last1A = JA.height > 64, last1B = JB.height > 64;
+        const int lastcA = JA.height > 0 ? (JA.height - 1) >> 6 : 0, lastcB = JB.height > 0 ? (JB.height - 1) >> 6 : 0;
         const int colA = (JA.oct * 8) & 63, colB = (JB.oct * 8) & 63;
-        const int jA = JA.oct * 8, jB = JB.oct * 8;
-        const bool firstA = JA.oct == 0, firstB = JB.oct == 0;
+        const unsigned jpk = ((unsigned)(JA.oct * 8) & B2_LO) | ((unsigned)(JB.oct * 8) << 16);
 #pragma unroll 1
         for (int k2 = 0; k2 < 2; k2++) {
-            unsigned acc[2] = {0, 0};
+            VN acc = 0u;
 #pragma unroll 1
             for (int kq = 0; kq < 4; kq++) {
                 const int kk = k2 * 4 + kq;
@@ -283,16 +301,16 @@ __global__ __launch_bounds__(64) void sw_block2_kernel(Block2Launch L) {
                 const unsigned cbias = ((unsigned)(int)(int8_t)(ciA >> 8) & 0xFFFFu) | ((unsigned)(int)(int8_t)(ciB >> 8) << 16);
                 unsigned corner = (kk == 0) ? (((unsigned)(firstA ? JA.corner : B2_MIN) & 0xFFFFu) | ((unsigned)(firstB ? JB.corner : B2_MIN) << 16)) : 0u;
                 unsigned carryR = 0u /* MIN, MIN */, carry_tr = B2_ONE2 /* trace_R false */;
-                const unsigned curA = ((unsigned)(jA + kk) << 16), curB = ((unsigned)(jB + kk) << 16);
-                unsigned R11s[2] = {0, 0};
+                const unsigned cur0 = jpk + (unsigned)kk * 0x00010001u;      // per half: this column
+                int dA = 0, dB = 0, rA = 0, rB = 0;
 #pragma unroll
-                for (int c = 0; c < 2; c++) {
+                for (int c = 0; c < NCH; c++) {
                     if (c < nch) {
                         const bool more = c + 1 < nch;
                         const unsigned D00 = b2_shift_up1(D10[c], corner);
                         if (more) corner = (unsigned)__builtin_amdgcn_readlane((int)D10[c], 63);
-                        const int scA = *reinterpret_cast<const int16_t *>(reinterpret_cast<const char *>(s_sc) + soffA + rowidx[0][c]);
-                        const int scB = *reinterpret_cast<const int16_t *>(reinterpret_cast<const char *>(s_sc) + soffB + rowidx[1][c]);
+                        const int scA = *reinterpret_cast<const int16_t *>(reinterpret_cast<const char *>(s_sc) + soffA + rowidx0[c]);
+                        const int scB = *reinterpret_cast<const int16_t *>(reinterpret_cast<const char *>(s_sc) + soffB + rowidx1[c]);
                         const unsigned sc = ((unsigned)scA & 0xFFFFu) | ((unsigned)scB << 16);
                         const unsigned pb = pk_add(cbias, rowbias[c]);
                         unsigned D11 = pk_add(D00, pk_add(sc, pb));
@@ -312,16 +330,15 @@ __global__ __launch_bounds__(64) void sw_block2_kernel(Block2Launch L) {
                         const unsigned l7 = b2_row_lane7(p4);
                         const unsigned from = k16 < 4 ? p4 : (k16 < 8 ? down4 : l7);
                         unsigned R11 = pk_max(p4, pk_add(from, consts2));
-                        // R11 = max(R11, broadcast(R01's last lane) + gap_extend_all), vector by vector
+                        // R11 = max(R11, broadcast(R01's last lane) + gap_extend_all), vector by vector: row 0 takes the carry of the chunk
+                        // before, row ch the last lane of row ch - 1 (the DPP move writes row ch only; -32768 + gap stays -32768)
                         {
                             const unsigned add = pk_add(carryR, gap_all2);
                             R11 = pk_max(R11, row == 0 ? add : B2_NEG2);
                         }
-#pragma unroll
-                        for (int ch = 1; ch < 4; ch++) {
-                            const unsigned add = pk_add(b2_prev_row_lane15(R11), gap_all2);
-                            R11 = pk_max(R11, row == ch ? add : B2_NEG2);
-                        }
+                        R11 = pk_max(R11, pk_add((unsigned)__builtin_amdgcn_update_dpp((int)B2_NEG2, (int)R11, 0x142 /* row_bcast:15 */, 0x2, 0xF, false), gap_all2));
+                        R11 = pk_max(R11, pk_add((unsigned)__builtin_amdgcn_update_dpp((int)B2_NEG2, (int)R11, 0x142, 0x4, 0xF, false), gap_all2));
+                        R11 = pk_max(R11, pk_add((unsigned)__builtin_amdgcn_update_dpp((int)B2_NEG2, (int)R11, 0x142, 0x8, 0xF, false), gap_all2));
                         if (more) carryR = (unsigned)__builtin_amdgcn_readlane((int)R11, 63);
                         D11 = pk_max(D11, R11);
                         if (TRACE) {
@@ -335,34 +352,29 @@ __global__ __launch_bounds__(64) void sw_block2_kernel(Block2Launch L) {
                         {   // D_max / D_argmax of the lane (its rows of all chunks): the LAST cell that holds the maximum
                             const unsigned D11m = b2_bfi(act[c], D11, B2_NEG2);
                             const unsigned nm = pk_max(Mmax, D11m);
-                            const unsigned e = nm ^ D11m;
-                            const unsigned cb = (unsigned)(c ? curbase1 : curbase0);
-                            if ((e & B2_LO) == 0u) aij[0] = curA | cb;
-                            if ((e & B2_HI) == 0u) aij[1] = curB | cb;
+                            const unsigned eq = pk_subw(pk_minu(nm ^ D11m, B2_ONE2), B2_ONE2);      // per half: 0xFFFF where D11m is the maximum (0 - 1), 0 elsewhere (1 - 1)
+                            Marg = b2_bfi(eq, cur0 + (unsigned)c * 0x02000200u, Marg);
                             Mmax = nm;
                         }
                         D10[c] = D11;
                         C10[c] = C11;
-                        R11s[c] = R11;
+                        // D_row[j] / R_row[j]: the block's last row
+                        if (c == lastcA) { dA = __builtin_amdgcn_readlane((int)D11, lastA); rA = __builtin_amdgcn_readlane((int)R11, lastA); }
+                        if (c == lastcB) { dB = __builtin_amdgcn_readlane((int)D11, lastB); rB = __builtin_amdgcn_readlane((int)R11, lastB); }
                     }
                 }
-                // D_row[j] / R_row[j]: the block's last row
-                const int dA = last1A ? __builtin_amdgcn_readlane((int)D10[1], lastA) : __builtin_amdgcn_readlane((int)D10[0], lastA);
-                const int dB = last1B ? __builtin_amdgcn_readlane((int)D10[1], lastB) : __builtin_amdgcn_readlane((int)D10[0], lastB);
-                const int rA = last1A ? __builtin_amdgcn_readlane((int)R11s[1], lastA) : __builtin_amdgcn_readlane((int)R11s[0], lastA);
-                const int rB = last1B ? __builtin_amdgcn_readlane((int)R11s[1], lastB) : __builtin_amdgcn_readlane((int)R11s[0], lastB);
                 if (lane == kk) OUT1 = ((unsigned)dA & B2_LO) | ((unsigned)dB & B2_HI);
                 if (lane == kk) OUT2 = ((unsigned)rA & B2_LO) | ((unsigned)rB & B2_HI);
             }
             if (TRACE) {
-                if (k2 == 0) { tacc00 = acc[0]; tacc10 = acc[1]; }
-                else { tacc01 = acc[0]; tacc11 = acc[1]; }
+                if (k2 == 0) tacc0 = acc;
+                else tacc1 = acc;
             }
         }
         // back into the arrays the rows came from
         const unsigned ma = ((S0.active ? B2_LO : 0u) | (S1.active ? B2_HI : 0u));
 #pragma unroll
-        for (int c = 0; c < 2; c++) {
+        for (int c = 0; c < NCH; c++) {
             if (c < nch) {
                 const unsigned mc = act[c] & ma & rqm, mr = act[c] & ma & ~rqm;
                 COL1[c] = b2_bfi(mc, D10[c], COL1[c]);
@@ -382,8 +394,8 @@ __global__ __launch_bounds__(64) void sw_block2_kernel(Block2Launch L) {
         const uint32_t stride = J.height < 64 ? 32u : 64u;
         const bool ok = S.trace_idx + (uint32_t)nch * stride <= S.trace_cap;
 #pragma unroll
-        for (int c = 0; c < 2; c++) {
-            const unsigned t0 = c ? tacc10 : tacc00, t1 = c ? tacc11 : tacc01;
+        for (int c = 0; c < NCH; c++) {
+            const unsigned t0 = tacc0[c], t1 = tacc1[c];
             const unsigned w = P ? ((t0 >> 16) | (t1 & B2_HI)) : ((t0 & B2_LO) | (t1 << 16));
             if (ok && c < nch && (uint32_t)lane < stride) S.trace[S.trace_idx + (uint32_t)c * stride + (uint32_t)lane] = w;
         }
@@ -392,12 +404,15 @@ __global__ __launch_bounds__(64) void sw_block2_kernel(Block2Launch L) {
     };
 
     // ---- one pair's align_core between two jobs ----
-    auto fetch = [&](B2Pair &S) -> bool {      // the next pair of the queue
+    // the next pair of the queue.  Branch-free on purpose: past the end of the queue the half re-reads the last job and runs on as a
+    // masked-off dummy (S.active = 0 keeps it out of every store), because "same store on both sides of a branch" is what the compiler
+    // sinks into one store through a selected ADDRESS - and state addressed that way stays in scratch memory instead of registers
+    auto fetch = [&](B2Pair &S) -> bool {
         uint32_t idx = 0;
         if (lane == 0) idx = atomicAdd(L.counter, 1u);
         idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)idx);
-        if (idx >= L.n_jobs) { S.active = 0; S.job.kind = B2_JOB_NONE; S.job.height = 0; S.job.width = 8; S.job.oct = 0; S.job.origin = 0; return false; }
-        const Block2Job J = L.jobs[idx];
+        const bool ok = idx < L.n_jobs;
+        const Block2Job J = L.jobs[ok ? idx : L.n_jobs - 1];
         const uint32_t query = (uint32_t)__builtin_amdgcn_readfirstlane((int)J.query), target = (uint32_t)__builtin_amdgcn_readfirstlane((int)J.target);
         S.target = __builtin_amdgcn_readfirstlane(J.score);
         S.slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)J.slot);
@@ -410,31 +425,32 @@ __global__ __launch_bounds__(64) void sw_block2_kernel(Block2Launch L) {
             const uint64_t po = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(J.pool_off >> 32)) << 32) |
                                 (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)J.pool_off);
             const uint32_t pb = (uint32_t)__builtin_amdgcn_readfirstlane((int)J.pool_bytes);
-            S.block_cap = (uint32_t)(S.Q.len + S.T.len + 64);
-            const uint32_t blocks_bytes = (S.block_cap * (uint32_t)sizeof(BkBlock) + 31u) & ~31u;
+            const uint32_t cap = (uint32_t)(S.Q.len + S.T.len + 64);
+            const uint32_t blocks_bytes = (cap * (uint32_t)sizeof(BkBlock) + 31u) & ~31u;
             S.blocks = reinterpret_cast<BkBlock *>(L.pool + po);
             S.trace = reinterpret_cast<uint32_t *>(L.pool + po + blocks_bytes);
             S.trace_cap = pb > blocks_bytes ? (pb - blocks_bytes) / 4u : 0u;
-            if (pb <= blocks_bytes) S.block_cap = 0;
+            S.block_cap = pb > blocks_bytes ? cap : 0u;
         } else {
             S.block_cap = 0; S.trace_cap = 0; S.blocks = nullptr; S.trace = nullptr;
         }
-        S.active = 1;
+        S.active = ok ? 1 : 0;
         S.min_size = 32;
-        S.score = -1000000000; S.ri = 0; S.rj = 0;
-        return true;
+        S.score = -1000000000; S.ri = 0; S.rj = 0; S.dbg_first = -1; S.dbg_steps = 0; S.dbg_d0 = 0; S.dbg_d1 = 0;
+        return ok;
     };
 
     auto start_attempt = [&](auto PC, B2Pair &S) {      // Allocated::clear + align_core's initial state
         constexpr int P = decltype(PC)::value;
-        for_arrays([&](unsigned (&a)[2], unsigned (&k)[2]) {
-            a[0] = b2_put<P>(a[0], 0u); a[1] = b2_put<P>(a[1], 0u); k[0] = b2_put<P>(k[0], 0u); k[1] = b2_put<P>(k[1], 0u);
+        for_arrays([&](VN &a, VN &k) {
+#pragma unroll
+            for (int c = 0; c < NCH; c++) { a[c] = b2_put<P>(a[c], 0u); k[c] = b2_put<P>(k[c], 0u); }
         });
         OUT1 = b2_put<P>(OUT1, 0u); OUT2 = b2_put<P>(OUT2, 0u);
         S.best_max = 0; S.best_i = 0; S.best_j = 0;
         S.prev_dir = B2_GROW; S.dir = B2_GROW;
         S.prev_size = 0; S.block_size = S.min_size;
-        S.off = 0; S.off_max = 0; S.prev_off = 0;
+        S.off = 0; S.off_max = 0;
         S.y_drop_iter = 0; S.x_drop_iter = 0;
         S.st_i = 0; S.st_j = 0; S.i_ck = 0; S.j_ck = 0; S.off_ck = 0;
         S.D_corner = B2_MIN; S.off_add = 0;
@@ -445,58 +461,61 @@ __global__ __launch_bounds__(64) void sw_block2_kernel(Block2Launch L) {
 
     auto checkpoint = [&](auto PC) {
         constexpr int P = decltype(PC)::value;
-        for_arrays([&](unsigned (&a)[2], unsigned (&k)[2]) { k[0] = b2_put<P>(k[0], a[0]); k[1] = b2_put<P>(k[1], a[1]); });
+        for_arrays([&](VN &a, VN &k) {
+#pragma unroll
+            for (int c = 0; c < NCH; c++) k[c] = b2_put<P>(k[c], a[c]);
+        });
     };
     auto restore = [&](auto PC) {
         constexpr int P = decltype(PC)::value;
-        for_arrays([&](unsigned (&a)[2], unsigned (&k)[2]) { a[0] = b2_put<P>(a[0], k[0]); a[1] = b2_put<P>(a[1], k[1]); });
+        for_arrays([&](VN &a, VN &k) {
+#pragma unroll
+            for (int c = 0; c < NCH; c++) a[c] = b2_put<P>(a[c], k[c]);
+        });
     };
 
-    auto set_job = [&](auto PC, B2Pair &S, int kind, int rq, int start_row, int start_col, int width, int height, int corner, int out_base) {
+    auto set_job = [&](auto PC, B2Pair &S, int kind, int rq, int start_row, int start_col, int width, int height, int corner, int out_base, int off_add) {
         constexpr int P = decltype(PC)::value;
         B2Job &J = S.job;
         J.kind = kind; J.rq = rq; J.start_row = start_row; J.start_col = start_col; J.width = width; J.height = height;
-        J.oct = 0; J.corner = corner; J.out_base = out_base;
+        J.oct = 0; J.corner = corner; J.out_base = out_base; J.off_add = off_add;
         J.origin = (start_row == 0 && start_col == 0) ? 1 : 0;
         Mmax = b2_put<P>(Mmax, 0u /* MIN */);
-        aij[P] = 0u;
+        Marg = b2_put<P>(Marg, 0u);
         load_job(PC, S);
     };
 
     // the second grow job (and the only one of the first block): place_block(query, reference, st_i, st_j + prev_size, grow_step, block_size)
     auto begin_grow2 = [&](auto PC, B2Pair &S) {
         add_block(S, S.st_i, S.st_j + S.prev_size, S.block_size - S.prev_size, S.block_size, 1);
-        set_job(PC, S, B2_JOB_GROW2, 1, S.st_i, S.st_j + S.prev_size, S.block_size - S.prev_size, S.block_size, B2_MIN, S.prev_size);
+        set_job(PC, S, B2_JOB_GROW2, 1, S.st_i, S.st_j + S.prev_size, S.block_size - S.prev_size, S.block_size, B2_MIN, S.prev_size, 0);
     };
 
-    // top of align_core's loop: the next job of S.dir.  returns false if the job is empty (the first grow job of the first block)
+    // top of align_core's loop: the next job of S.dir
     auto begin_step = [&](auto PC, B2Pair &S) {
         constexpr int P = decltype(PC)::value;
-        S.prev_off = S.off;
+        if (S.dbg_first < 0) {      // debugging: the first attempt's directions, two bits a step
+            if (S.dbg_steps < 16) S.dbg_d0 |= (uint32_t)S.dir << (2 * S.dbg_steps);
+            else if (S.dbg_steps < 32) S.dbg_d1 |= (uint32_t)S.dir << (2 * (S.dbg_steps - 16));
+        }
+        const int prev_off = S.off;
         Gmax = b2_put<P>(Gmax, 0u);
-        gaij[P] = 0u;
+        Garg = b2_put<P>(Garg, 0u);
         const int bs = S.block_size;
-        if (S.dir == B2_RIGHT) {
+        if (S.dir == B2_RIGHT || S.dir == B2_DOWN) {
+            const bool r = S.dir == B2_RIGHT;
             S.off = S.off_max;
-            const int d = S.prev_off - S.off;
+            const int d = prev_off - S.off;
             S.off_add = d < -32768 ? -32768 : (d > 32767 ? 32767 : d);
-            add_block(S, S.st_i, S.st_j + bs - B2_STEP, B2_STEP, bs, 1);
-            COL1[0] = offset_one(PC, COL1[0], 0, S.off_add, bs); COL1[1] = offset_one(PC, COL1[1], 1, S.off_add, bs);
-            COL2[0] = offset_one(PC, COL2[0], 0, S.off_add, bs); COL2[1] = offset_one(PC, COL2[1], 1, S.off_add, bs);
-            set_job(PC, S, B2_JOB_SHIFT, 1, S.st_i, S.st_j + bs - B2_STEP, B2_STEP, bs, S.prev_dir == B2_DOWN ? b2_adds16(S.D_corner, S.off_add) : B2_MIN, 0);
-        } else if (S.dir == B2_DOWN) {
-            S.off = S.off_max;
-            const int d = S.prev_off - S.off;
-            S.off_add = d < -32768 ? -32768 : (d > 32767 ? 32767 : d);
-            add_block(S, S.st_i + bs - B2_STEP, S.st_j, bs, B2_STEP, 0);
-            ROW1[0] = offset_one(PC, ROW1[0], 0, S.off_add, bs); ROW1[1] = offset_one(PC, ROW1[1], 1, S.off_add, bs);
-            ROW2[0] = offset_one(PC, ROW2[0], 0, S.off_add, bs); ROW2[1] = offset_one(PC, ROW2[1], 1, S.off_add, bs);
-            set_job(PC, S, B2_JOB_SHIFT, 0, S.st_j, S.st_i + bs - B2_STEP, B2_STEP, bs, S.prev_dir == B2_RIGHT ? b2_adds16(S.D_corner, S.off_add) : B2_MIN, 0);
+            // (just_offset of the job's own arrays happens on the way into the octet: B2Job::off_add)
+            add_block(S, r ? S.st_i : S.st_i + bs - B2_STEP, r ? S.st_j + bs - B2_STEP : S.st_j, r ? B2_STEP : bs, r ? bs : B2_STEP, r ? 1 : 0);
+            const int corner = S.prev_dir == (r ? B2_DOWN : B2_RIGHT) ? b2_adds16(S.D_corner, S.off_add) : B2_MIN;
+            set_job(PC, S, B2_JOB_SHIFT, r ? 1 : 0, r ? S.st_i : S.st_j, (r ? S.st_j : S.st_i) + bs - B2_STEP, B2_STEP, bs, corner, 0, S.off_add);
         } else {
             S.D_corner = B2_MIN;
             const int grow_step = bs - S.prev_size;
             add_block(S, S.st_i + S.prev_size, S.st_j, S.prev_size, grow_step, 0);
-            if (S.prev_size > 0) set_job(PC, S, B2_JOB_GROW1, 0, S.st_j, S.st_i + S.prev_size, grow_step, S.prev_size, B2_MIN, S.prev_size);
+            if (S.prev_size > 0) set_job(PC, S, B2_JOB_GROW1, 0, S.st_j, S.st_i + S.prev_size, grow_step, S.prev_size, B2_MIN, S.prev_size, 0);
             else begin_grow2(PC, S);
         }
     };
@@ -506,7 +525,6 @@ __global__ __launch_bounds__(64) void sw_block2_kernel(Block2Launch L) {
         mmgpu_sw_block out;
         out.q_start = -1; out.t_start = -1; out.ident = 0; out.bt_len = 0; out.bt_off = L.bt_off ? L.bt_off[S.slot] : 0;
         out.reserved = 0;
-        uint32_t nb = 0;
         if (too_large) {
             out.status = MMGPU_BLOCK_TOO_LARGE;
         } else if (!(S.score != S.target && !(S.target == 32767 && S.score >= S.target))) {      // StripedSmithWaterman.cpp:1058
@@ -515,11 +533,11 @@ __global__ __launch_bounds__(64) void sw_block2_kernel(Block2Launch L) {
             out.t_start = S.T.end + 1 - S.rj;
             if (TRACE) {      // for the walk kernel: end cell and number of blocks
                 out.ident = (uint32_t)S.ri; out.bt_len = (uint32_t)S.rj; out.reserved = (int32_t)S.block_idx;
-                nb = S.block_idx;
             }
         } else {
             out.status = MMGPU_BLOCK_DECLINED;
         }
+        if (!TRACE) { out.reserved = S.dbg_first; out.ident = S.dbg_d0; out.bt_len = S.dbg_d1; }
         if (TRACE && L.growth != nullptr) {      // test aid: the block list of the last run
             __threadfence_block();
             uint32_t *g = L.growth + (size_t)S.slot * (1 + 4 * (size_t)L.growth_cap);
@@ -533,24 +551,21 @@ __global__ __launch_bounds__(64) void sw_block2_kernel(Block2Launch L) {
                 g[4 + 4 * k] = bb.right;
             }
         }
-        (void)nb;
         if (lane == 0) L.out[S.slot] = out;
     };
 
     // runs after the pair's job is complete (or at a fresh pair): everything up to the next job.  Leaves S.active = 0 when the queue is empty.
+    // (no loop in here: a loop whose header joins "next attempt" and "next pair" with the entry makes the compiler copy the whole
+    // vector state - some forty registers - into the header's registers and back on every call)
     auto advance = [&](auto PC, B2Pair &S, bool fresh) {
         constexpr int P = decltype(PC)::value;
-        bool need_attempt = fresh;
-        for (;;) {
-            if (need_attempt) {
-                start_attempt(PC, S);
-                begin_step(PC, S);
-                return;
-            }
+        if (fresh) {
+            start_attempt(PC, S);
+        } else {
             B2Job &J = S.job;
             if (J.kind == B2_JOB_GROW1) {      // grow_D_max = this job's maxima; the second job follows
                 Gmax = b2_put<P>(Gmax, Mmax);
-                gaij[P] = aij[P];
+                Garg = b2_put<P>(Garg, Marg);
                 begin_grow2(PC, S);
                 return;
             }
@@ -558,14 +573,12 @@ __global__ __launch_bounds__(64) void sw_block2_kernel(Block2Launch L) {
             const int bs = S.block_size;
             if (J.kind == B2_JOB_SHIFT) {
                 const bool r = S.dir == B2_RIGHT;      // the arrays the job did NOT run along are shifted: D_row / R_row after a shift right
-                B2Arr a1, a2;
-                a1.c0 = r ? ROW1[0] : COL1[0]; a1.c1 = r ? ROW1[1] : COL1[1];
-                a2.c0 = r ? ROW2[0] : COL2[0]; a2.c1 = r ? ROW2[1] : COL2[1];
-                S.D_corner = b2_adds16(b2_shalf<P>(__builtin_amdgcn_readlane((int)a1.c0, B2_STEP - 1)), S.off_add);
+                VN a1 = r ? ROW1 : COL1, a2 = r ? ROW2 : COL2;
+                S.D_corner = b2_adds16(b2_shalf<P>(__builtin_amdgcn_readlane((int)a1[0], B2_STEP - 1)), S.off_add);
                 a1 = shift_one(PC, a1, OUT1, S.off_add, bs);
                 a2 = shift_one(PC, a2, OUT2, S.off_add, bs);
-                if (r) { ROW1[0] = a1.c0; ROW1[1] = a1.c1; ROW2[0] = a2.c0; ROW2[1] = a2.c1; }
-                else { COL1[0] = a1.c0; COL1[1] = a1.c1; COL2[0] = a2.c0; COL2[1] = a2.c1; }
+                ROW1 = r ? a1 : ROW1; ROW2 = r ? a2 : ROW2;
+                COL1 = r ? COL1 : a1; COL2 = r ? COL2 : a2;
                 right_max = pmax8(PC, COL1[0]);
                 down_max = pmax8(PC, ROW1[0]);
             } else {
@@ -576,6 +589,7 @@ __global__ __launch_bounds__(64) void sw_block2_kernel(Block2Launch L) {
                 S.ck_block_idx = S.block_idx;
             }
             bool done = false;      // align_core returns
+            S.dbg_steps++;
             if (S.overflow) {
                 done = true;
             } else {
@@ -586,6 +600,13 @@ __global__ __launch_bounds__(64) void sw_block2_kernel(Block2Launch L) {
                 const int mx = max(D_max_max, grow_max);
                 S.off_max = S.off + mx - B2_ZERO;
                 S.y_drop_iter++;
+                if (TRACE && L.growth != nullptr && (L.dbg >> 8) == S.slot + 1 && S.dbg_first < 0 && S.dbg_steps <= 14) {      // debugging
+                    uint32_t *g = L.growth + (size_t)S.slot * (1 + 4 * (size_t)L.growth_cap) + 1 + 2048 + 12 * (S.dbg_steps - 1);
+                    if (lane == 0) {
+                        g[0] = (uint32_t)dir; g[1] = (uint32_t)bs; g[2] = (uint32_t)S.off_max; g[3] = (uint32_t)S.best_max; g[4] = (uint32_t)mx; g[5] = (uint32_t)D_max_max;
+                        g[6] = (uint32_t)grow_max; g[7] = (uint32_t)right_max; g[8] = (uint32_t)down_max; g[9] = (uint32_t)S.off; g[10] = (uint32_t)S.st_i; g[11] = (uint32_t)S.st_j;
+                    }
+                }
                 bool grow_no_max = dir == B2_GROW;
                 if (S.off_max > S.best_max) {
                     {   // location of the maximum: per vector lane the last cell that reached its maximum, over the vector lanes the
@@ -593,8 +614,8 @@ __global__ __launch_bounds__(64) void sw_block2_kernel(Block2Launch L) {
                         const bool grow = dir == B2_GROW && D_max_max < grow_max;
                         const int curr_max = grow ? grow_max : D_max_max;
                         int dm = b2_half<P>(grow ? Gmax : Mmax);
-                        const unsigned a = grow ? gaij[P] : aij[P];
-                        int ai = (int)(a & 0xFFFFu), aj = (int)(a >> 16);
+                        const unsigned code = (unsigned)b2_half<P>(grow ? Garg : Marg) & 0xFFFFu;
+                        int aj = (int)(code & 511u), ai = (int)((code >> 9) * 64u) + (lane & ~15);
 #pragma unroll
                         for (int d = 16; d < 64; d <<= 1) {      // lanes l, l + 16, l + 32, l + 48 are one vector lane
                             const int odm = __shfl_xor(dm, d, 64), oai = __shfl_xor(ai, d, 64), oaj = __shfl_xor(aj, d, 64);
@@ -645,7 +666,7 @@ __global__ __launch_bounds__(64) void sw_block2_kernel(Block2Launch L) {
                 if (!done && !cont) {
                     const int next_size = bs * 2;
                     const bool want_grow = S.y_drop_iter > (bs / B2_STEP) - 1 || grow_no_max;
-                    if (next_size <= BLOCK2_MAX_SIZE) {
+                    if (next_size <= MAXB) {
                         if (want_grow) {
                             S.prev_size = bs;
                             S.block_size = next_size;
@@ -670,10 +691,22 @@ __global__ __launch_bounds__(64) void sw_block2_kernel(Block2Launch L) {
                             S.prev_dir = B2_GROW;
                             const int nb = bs / 2;
                             S.block_size = nb;
-                            for_arrays([&](unsigned (&a)[2], unsigned (&k)[2]) {      // copy_vec(i, i + block_size)
+                            for_arrays([&](VN &a, VN &k) {      // copy_vec(i, i + block_size)
                                 (void)k;
-                                const unsigned src = nb == 64 ? a[1] : b2_lane_from(a[0], lane + 32);
-                                a[0] = b2_put<P>(a[0], lane < nb ? src : a[0]);
+                                if (nb < 64) {
+                                    const unsigned up = b2_lane_from(a[0], lane + 32);      // (every lane takes part: outside the selection)
+                                    a[0] = b2_put<P>(a[0], lane < nb ? up : a[0]);
+                                } else {
+                                    const int sh = nb >> 6;
+#pragma unroll
+                                    for (int c = 0; c < NCH / 2; c++) {
+                                        unsigned src = a[c];
+#pragma unroll
+                                        for (int c2 = c + 1; c2 < NCH; c2++)
+                                            if (c2 == c + sh) src = a[c2];
+                                        if (c < sh) a[c] = b2_put<P>(a[c], src);
+                                    }
+                                }
                             });
                             S.st_i += nb;
                             S.st_j += nb;
@@ -690,51 +723,53 @@ __global__ __launch_bounds__(64) void sw_block2_kernel(Block2Launch L) {
                     else { S.st_j += B2_STEP; S.dir = B2_RIGHT; }
                 }
             }
-            if (!done) {
-                begin_step(PC, S);
-                return;
+            if (done) {
+                // ---- align_core returned: the loop over minimum sizes (StripedSmithWaterman.cpp:1021-1038) ----
+                bool too_large = S.overflow != 0;
+                if (!too_large) { S.score = S.best_max; S.ri = S.best_i; S.rj = S.best_j; }
+                if (S.dbg_first < 0) S.dbg_first = (S.best_max & 0xFFFF) | (S.dbg_steps << 16);
+                S.min_size *= 2;
+                if (!too_large && S.score < S.target && S.min_size <= MAXB) {
+                    start_attempt(PC, S);
+                } else {
+                    // (the crate would go on to larger minimum sizes when the score is not reached - not decided by this kernel)
+                    if (MAXB < BLOCK_REF_MAX_SIZE && !too_large && S.score < S.target) too_large = true;
+                    finish_pair(S, too_large);
+                    fetch(S);      // (past the end of the queue: a dummy that computes on, masked off)
+                    start_attempt(PC, S);
+                }
             }
-            // ---- align_core returned: the loop over minimum sizes (StripedSmithWaterman.cpp:1021-1038) ----
-            bool too_large = S.overflow != 0;
-            if (!too_large) { S.score = S.best_max; S.ri = S.best_i; S.rj = S.best_j; }
-            S.min_size *= 2;
-            if (!too_large && S.score < S.target && S.min_size <= BLOCK2_MAX_SIZE) {
-                need_attempt = true;
-                continue;
-            }
-            // (the crate would go on to larger minimum sizes when the score is not reached - not decided by this kernel)
-            if (!too_large && S.score < S.target) too_large = true;
-            finish_pair(S, too_large);
-            if (!fetch(S)) return;
-            need_attempt = true;
         }
+        begin_step(PC, S);
     };
 
     auto post = [&](auto PC, B2Pair &S) {
-        constexpr int P = decltype(PC)::value;
         if (!S.active) return;
         B2Job &J = S.job;
         if (TRACE) store_trace(PC, S);
         if (J.kind == B2_JOB_GROW1 || J.kind == B2_JOB_GROW2) {
             const bool g1 = J.kind == B2_JOB_GROW1;      // the first grow job's outputs are D_col / C_col entries, the second's D_row / R_row
             const int base = J.out_base + J.oct * 8;
+            VN a1 = g1 ? COL1 : ROW1, a2 = g1 ? COL2 : ROW2;      // (whole values: see VN)
 #pragma unroll
-            for (int c = 0; c < 2; c++) {
-                const unsigned n1 = place_one(PC, g1 ? COL1[c] : ROW1[c], c, OUT1, base), n2 = place_one(PC, g1 ? COL2[c] : ROW2[c], c, OUT2, base);
-                if (g1) { COL1[c] = n1; COL2[c] = n2; }
-                else { ROW1[c] = n1; ROW2[c] = n2; }
+            for (int c = 0; c < NCH; c++) {
+                a1[c] = place_one(PC, a1[c], c, OUT1, base);
+                a2[c] = place_one(PC, a2[c], c, OUT2, base);
             }
+            COL1 = g1 ? a1 : COL1; COL2 = g1 ? a2 : COL2;
+            ROW1 = g1 ? ROW1 : a1; ROW2 = g1 ? ROW2 : a2;
         }
         J.oct++;
         if (J.oct * 8 >= J.width) advance(PC, S, false);
         else if ((J.oct & 7) == 0) reload_cols(PC, S);
-        (void)P;
     };
 
     using P0 = std::integral_constant<int, 0>;
     using P1 = std::integral_constant<int, 1>;
-    if (fetch(S0)) advance(P0{}, S0, true);
-    if (fetch(S1)) advance(P1{}, S1, true);
+    fetch(S0);
+    advance(P0{}, S0, true);
+    fetch(S1);
+    advance(P1{}, S1, true);
     while (S0.active || S1.active) {
         octet();
         post(P0{}, S0);
@@ -762,48 +797,49 @@ __global__ __launch_bounds__(64) void sw_block2_walk_kernel(Block2Launch L) {
     char *bt = L.bt ? L.bt + out.bt_off : nullptr;      // bt_off is a multiple of four
     int table = 0;      // 0 = D, 1 = C, 2 = R
     uint32_t n = 0, ids = 0, word = 0;
+    // one flat loop - an iteration either fetches the next block of the list or takes one step inside the current one - so that the
+    // lanes of a wavefront, each somewhere else in its own walk, share every trip (nested loops would serialise them)
+    int bi = 0x7FFFFFFF, bj = 0x7FFFFFFF, bright = 0;
+    uint32_t btstart = 0, nch = 1, stride = 32;
     while (i > 0 || j > 0) {
-        int bi, bj, bh, bw, bright;
-        uint32_t btstart;
-        for (;;) {
+        if (!(i >= bi && j >= bj)) {
             block_idx--;
             const BkBlock b = blocks[block_idx];
-            bi = (int)b.i; bj = (int)b.j; bh = (int)b.h; bw = (int)b.w; bright = (int)b.right; btstart = b.tstart;
-            if (i >= bi && j >= bj) break;
+            bi = (int)b.i; bj = (int)b.j; bright = (int)b.right; btstart = b.tstart;
+            const int rows = bright ? (int)b.h : (int)b.w;      // the job's rows (place_block's height)
+            nch = rows > 64 ? (uint32_t)(rows + 63) >> 6 : 1u;
+            stride = rows < 64 ? 32u : 64u;
+            continue;
         }
-        const int rows = bright ? bh : bw;                      // the job's rows (place_block's height)
-        const uint32_t nch = rows > 64 ? 2u : 1u, stride = rows < 64 ? 32u : 64u;
-        while (i >= bi && j >= bj && (i > 0 || j > 0)) {
-            const int ci = i - bi, cj = j - bj;
-            const int r = bright ? ci : cj, c = bright ? cj : ci;
-            const uint32_t w = trace[btstart + ((uint32_t)(c >> 3) * nch + (uint32_t)(r >> 6)) * stride + (uint32_t)(r & 63)];
-            const int k = c & 7;
-            const unsigned nib = ((w >> (k < 4 ? 12 - 4 * k : 44 - 4 * k)) & 0xFu) ^ 0xFu;
-            const unsigned tt = nib & 3u, t2 = nib >> 2;
-            int op, di, dj, nt;      // OP_LUT (:1870-1933)
-            if (bright) {
-                if (table == 1) { op = 5; di = 0; dj = 1; nt = (t2 & 1u) ? 0 : 1; }
-                else if (table == 2) { op = 4; di = 1; dj = 0; nt = (t2 & 2u) ? 0 : 2; }
-                else if (tt == 0) { op = 1; di = 1; dj = 1; nt = 0; }
-                else if (tt & 1u) { op = 5; di = 0; dj = 1; nt = (t2 & 1u) ? 0 : 1; }
-                else { op = 4; di = 1; dj = 0; nt = (t2 & 2u) ? 0 : 2; }
-            } else {
-                if (table == 2) { op = 4; di = 1; dj = 0; nt = (t2 & 1u) ? 0 : 2; }
-                else if (table == 1) { op = 5; di = 0; dj = 1; nt = (t2 & 2u) ? 0 : 1; }
-                else if (tt == 0) { op = 1; di = 1; dj = 1; nt = 0; }
-                else if (tt & 1u) { op = 4; di = 1; dj = 0; nt = (t2 & 1u) ? 0 : 2; }
-                else { op = 5; di = 0; dj = 1; nt = (t2 & 2u) ? 0 : 1; }
-            }
-            if (op == 1) ids += q[J.q_end - (i - 1)] == t[J.t_end - (j - 1)] ? 1u : 0u;
-            if (bt) {
-                word |= (uint32_t)(op == 1 ? 'M' : (op == 4 ? 'I' : 'D')) << (8 * (n & 3u));
-                if ((n & 3u) == 3u) { *reinterpret_cast<uint32_t *>(bt + (n & ~3u)) = word; word = 0; }
-            }
-            n++;
-            i -= di;
-            j -= dj;
-            table = nt;
+        const int ci = i - bi, cj = j - bj;
+        const int r = bright ? ci : cj, c = bright ? cj : ci;
+        const uint32_t w = trace[btstart + ((uint32_t)(c >> 3) * nch + (uint32_t)(r >> 6)) * stride + (uint32_t)(r & 63)];
+        const int k = c & 7;
+        const unsigned nib = ((w >> (k < 4 ? 12 - 4 * k : 44 - 4 * k)) & 0xFu) ^ 0xFu;
+        const unsigned tt = nib & 3u, t2 = nib >> 2;
+        int op, nt;      // OP_LUT (:1870-1933): 1 = match / mismatch, 4 = the row index moves (I), 5 = the column index moves (D)
+        if (bright) {
+            if (table == 1) { op = 5; nt = (t2 & 1u) ? 0 : 1; }
+            else if (table == 2) { op = 4; nt = (t2 & 2u) ? 0 : 2; }
+            else if (tt == 0) { op = 1; nt = 0; }
+            else if (tt & 1u) { op = 5; nt = (t2 & 1u) ? 0 : 1; }
+            else { op = 4; nt = (t2 & 2u) ? 0 : 2; }
+        } else {
+            if (table == 2) { op = 4; nt = (t2 & 1u) ? 0 : 2; }
+            else if (table == 1) { op = 5; nt = (t2 & 2u) ? 0 : 1; }
+            else if (tt == 0) { op = 1; nt = 0; }
+            else if (tt & 1u) { op = 4; nt = (t2 & 1u) ? 0 : 2; }
+            else { op = 5; nt = (t2 & 2u) ? 0 : 1; }
         }
+        if (op == 1) ids += q[J.q_end - (i - 1)] == t[J.t_end - (j - 1)] ? 1u : 0u;
+        if (bt) {
+            word |= (uint32_t)(op == 1 ? 'M' : (op == 4 ? 'I' : 'D')) << (8 * (n & 3u));
+            if ((n & 3u) == 3u) { *reinterpret_cast<uint32_t *>(bt + (n & ~3u)) = word; word = 0; }
+        }
+        n++;
+        i -= (op != 5) ? 1 : 0;
+        j -= (op != 4) ? 1 : 0;
+        table = nt;
     }
     if (bt && (n & 3u) != 0u) {
         for (uint32_t k = 0; k < (n & 3u); k++) bt[(n & ~3u) + k] = (char)(word >> (8 * k));
@@ -816,10 +852,15 @@ __global__ __launch_bounds__(64) void sw_block2_walk_kernel(Block2Launch L) {
 
 }  // namespace
 
-hipError_t launch_sw_block2(const Block2Launch &L, bool trace, uint32_t n_waves, hipStream_t stream) {
+hipError_t launch_sw_block2(const Block2Launch &L, bool trace, bool large, uint32_t n_waves, hipStream_t stream) {
     if (L.n_jobs == 0) return hipSuccess;
-    if (trace) hipLaunchKernelGGL((sw_block2_kernel<true>), dim3(n_waves), dim3(64), 0, stream, L);
-    else hipLaunchKernelGGL((sw_block2_kernel<false>), dim3(n_waves), dim3(64), 0, stream, L);
+    if (large) {
+        if (trace) hipLaunchKernelGGL((sw_block2_kernel<true, BLOCK2_LARGE_SIZE / 64>), dim3(n_waves), dim3(64), 0, stream, L);
+        else hipLaunchKernelGGL((sw_block2_kernel<false, BLOCK2_LARGE_SIZE / 64>), dim3(n_waves), dim3(64), 0, stream, L);
+    } else {
+        if (trace) hipLaunchKernelGGL((sw_block2_kernel<true, BLOCK2_MAX_SIZE / 64>), dim3(n_waves), dim3(64), 0, stream, L);
+        else hipLaunchKernelGGL((sw_block2_kernel<false, BLOCK2_MAX_SIZE / 64>), dim3(n_waves), dim3(64), 0, stream, L);
+    }
     return hipGetLastError();
 }
 
@@ -831,8 +872,8 @@ hipError_t launch_sw_block2_walk(const Block2Launch &L, hipStream_t stream) {
 
 void warm_block2() {
     hipFuncAttributes a;
-    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&(sw_block2_kernel<false>)));
-    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&(sw_block2_kernel<true>)));
+    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&(sw_block2_kernel<false, BLOCK2_MAX_SIZE / 64>)));
+    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&(sw_block2_kernel<true, BLOCK2_MAX_SIZE / 64>)));
     (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&sw_block2_walk_kernel));
 }
 

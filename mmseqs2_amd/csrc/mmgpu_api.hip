@@ -1408,35 +1408,40 @@ static int block_backtrace(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const uint32_t *pa
     // on the context's stream, back to back ----
     std::vector<BlockJob> slow_jobs;
     if (!first_tier_env) {
-        std::vector<Block2Job> j2;
-        j2.reserve(jobs.size());
-        std::vector<uint32_t> group_begin(1, 0u);
+        static const uint64_t block2_waves = getenv("MMGPU_BLOCK2_WAVES") ? strtoull(getenv("MMGPU_BLOCK2_WAVES"), nullptr, 10) : 16;      // per CU (tuning aid)
         static const uint64_t pool2_limit = (getenv("MMGPU_BLOCK2_POOL_MB") ? strtoull(getenv("MMGPU_BLOCK2_POOL_MB"), nullptr, 10) : 3072ull) << 20;
-        uint64_t pool_used = 0, pool_need = 0;
-        for (const BlockJob &j : jobs) {
-            if (!b->h_query_is_profile.empty() && b->h_query_is_profile[j.query]) { slow_jobs.push_back(j); continue; }
-            Block2Job x;
-            x.query = j.query; x.target = j.target; x.score = j.score; x.q_end = j.q_end; x.t_end = j.t_end; x.slot = j.slot;
-            x.pool_off = 0; x.pool_bytes = 0; x.pad = 0;
-            if (!starts_only) {
-                const uint64_t len = pair_len(j);
-                const uint64_t bytes = (((len + 64) * sizeof(BkBlock) + 31) & ~31ull) + 40 * (len + 256);
-                if (bytes > pool2_limit || bytes > 0xFFFFFFFFull) { slow_jobs.push_back(j); continue; }
-                if (pool_used + bytes > pool2_limit) { group_begin.push_back((uint32_t)j2.size()); pool_used = 0; }
-                x.pool_off = pool_used; x.pool_bytes = (uint32_t)bytes;
-                pool_used += bytes;
-                pool_need = std::max(pool_need, pool_used);
+        DevBuf d_j2, d_cnt, d_pool2;
+        d_j2.bind(c->cache); d_cnt.bind(c->cache); d_pool2.bind(c->cache);
+        // one pass: `todo` (longest first) through sw_block2_kernel<trace, 2 or 8 chunks>; what it hands on is appended to `left`
+        auto block2_pass = [&](const std::vector<BlockJob> &todo, bool large, std::vector<BlockJob> &left) -> int {
+            std::vector<Block2Job> j2;
+            j2.reserve(todo.size());
+            std::vector<uint32_t> group_begin(1, 0u);
+            uint64_t pool_used = 0, pool_need = 0;
+            // bytes of trace per residue of the pair: a dword per row and octet = 0.5 byte per cell; 32 / 64-row blocks in the first
+            // pass (a pair that needs more is answered TOO_LARGE like one whose blocks grow beyond 128 rows), 512 rows in the second
+            const uint64_t per_res = large ? 256 : 40, margin = large ? 1024 : 256;
+            for (const BlockJob &j : todo) {
+                Block2Job x;
+                x.query = j.query; x.target = j.target; x.score = j.score; x.q_end = j.q_end; x.t_end = j.t_end; x.slot = j.slot;
+                x.pool_off = 0; x.pool_bytes = 0; x.pad = 0;
+                if (!starts_only) {
+                    const uint64_t len = pair_len(j);
+                    const uint64_t bytes = (((len + 64) * sizeof(BkBlock) + 31) & ~31ull) + per_res * (len + margin);
+                    if (bytes > pool2_limit || bytes > 0xFFFFFFFFull) { left.push_back(j); continue; }
+                    if (pool_used + bytes > pool2_limit) { group_begin.push_back((uint32_t)j2.size()); pool_used = 0; }
+                    x.pool_off = pool_used; x.pool_bytes = (uint32_t)bytes;
+                    pool_used += bytes;
+                    pool_need = std::max(pool_need, pool_used);
+                }
+                j2.push_back(x);
             }
-            j2.push_back(x);
-        }
-        group_begin.push_back((uint32_t)j2.size());
-        if (!j2.empty()) {
+            group_begin.push_back((uint32_t)j2.size());
+            if (j2.empty()) return MMGPU_OK;
             const size_t n_groups = group_begin.size() - 1;
-            DevBuf d_j2, d_cnt, d_pool2;
-            d_j2.bind(c->cache); d_cnt.bind(c->cache); d_pool2.bind(c->cache);
-            HIP_TRY(d_j2.alloc(j2.size() * sizeof(Block2Job)));
-            HIP_TRY(d_cnt.alloc(n_groups * 4));
-            if (pool_need) HIP_TRY(d_pool2.alloc((size_t)pool_need));
+            if (j2.size() * sizeof(Block2Job) > d_j2.bytes) HIP_TRY(d_j2.alloc(j2.size() * sizeof(Block2Job)));
+            if (n_groups * 4 > d_cnt.bytes) HIP_TRY(d_cnt.alloc(n_groups * 4));
+            if (pool_need > d_pool2.bytes) HIP_TRY(d_pool2.alloc((size_t)pool_need));
             HIP_TRY(hipMemcpyAsync(d_j2.p, j2.data(), j2.size() * sizeof(Block2Job), hipMemcpyHostToDevice, s));
             HIP_TRY(hipMemsetAsync(d_cnt.p, 0, n_groups * 4, s));
             Block2Launch L2;
@@ -1445,33 +1450,49 @@ static int block_backtrace(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const uint32_t *pa
             L2.out = L.out; L2.bt_off = L.bt_off; L2.bt = no_strings ? nullptr : L.bt;
             L2.pool = d_pool2.as<uint8_t>();
             L2.growth = L.growth; L2.growth_cap = L.growth_cap;
+            L2.dbg = getenv("MMGPU_B2_DBG") ? (uint32_t)atoi(getenv("MMGPU_B2_DBG")) : 0u;
             for (size_t g = 0; g < n_groups; g++) {
                 L2.jobs = d_j2.as<Block2Job>() + group_begin[g];
                 L2.n_jobs = group_begin[g + 1] - group_begin[g];
                 L2.counter = d_cnt.as<uint32_t>() + g;
-                const uint32_t waves = (uint32_t)std::min<uint64_t>((L2.n_jobs + 1) / 2, (uint64_t)std::max(c->compute_units, 1) * 12);
-                HIP_TRY(launch_sw_block2(L2, !starts_only, waves, s));
+                // (resident wavefronts: 16 per CU at 112 registers, 4 per CU at the 8-chunk form's ~290)
+                const uint32_t waves = (uint32_t)std::min<uint64_t>((L2.n_jobs + 1) / 2, (uint64_t)std::max(c->compute_units, 1) * (large ? 4 : block2_waves));
+                HIP_TRY(launch_sw_block2(L2, !starts_only, large, waves, s));
                 if (!starts_only) HIP_TRY(launch_sw_block2_walk(L2, s));
             }
             HIP_TRY(hipMemcpyAsync(out, d_out.p, (size_t)n * sizeof(mmgpu_sw_block), hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
-            if (trace_on) fprintf(stderr, "[mmgpu block aligner] two pairs per wavefront: %zu pairs in %zu group(s), pool %.1f MB\n", j2.size(), n_groups, pool_need / 1048576.0);
-            for (const BlockJob &j : jobs)
-                if ((b->h_query_is_profile.empty() || !b->h_query_is_profile[j.query]) && out[j.slot].status == MMGPU_BLOCK_TOO_LARGE) slow_jobs.push_back(j);
-            std::stable_sort(slow_jobs.begin(), slow_jobs.end(), [&](const BlockJob &x, const BlockJob &y) { return pair_len(x) > pair_len(y); });
-            b->block_pairs_fast = (uint32_t)(jobs.size() - slow_jobs.size());
-            lap("two pairs per wavefront + status download");
+            if (trace_on) fprintf(stderr, "[mmgpu block aligner] two pairs per wavefront, blocks <= %d rows: %zu pairs in %zu group(s), pool %.1f MB\n",
+                                  large ? BLOCK2_LARGE_SIZE : BLOCK2_MAX_SIZE, j2.size(), n_groups, pool_need / 1048576.0);
+            for (const Block2Job &x : j2)
+                if (out[x.slot].status == MMGPU_BLOCK_TOO_LARGE) {
+                    BlockJob j;
+                    j.query = x.query; j.target = x.target; j.score = x.score; j.q_end = x.q_end; j.t_end = x.t_end; j.slot = x.slot;
+                    left.push_back(j);
+                }
+            return MMGPU_OK;
+        };
+        std::vector<BlockJob> seq_jobs, second;
+        for (const BlockJob &j : jobs) {
+            if (!b->h_query_is_profile.empty() && b->h_query_is_profile[j.query]) slow_jobs.push_back(j);
+            else seq_jobs.push_back(j);
         }
+        int rc2 = block2_pass(seq_jobs, false, second);
+        if (rc2 != MMGPU_OK) return rc2;
+        lap("two pairs per wavefront (blocks <= 128 rows) + status download");
+        std::stable_sort(second.begin(), second.end(), [&](const BlockJob &x, const BlockJob &y) { return pair_len(x) > pair_len(y); });
+        const size_t before = slow_jobs.size();
+        rc2 = block2_pass(second, true, slow_jobs);
+        if (rc2 != MMGPU_OK) return rc2;
+        if (!second.empty()) lap("two pairs per wavefront (blocks <= 512 rows) + status download");
+        std::stable_sort(slow_jobs.begin(), slow_jobs.end(), [&](const BlockJob &x, const BlockJob &y) { return pair_len(x) > pair_len(y); });
+        b->block_pairs_fast = (uint32_t)(seq_jobs.size() - (slow_jobs.size() - before));
     } else {
         slow_jobs = jobs;
     }
-    // Rounds: the tiers that have pairs waiting run side by side (a stream, a pool, a job list each).  Round one = tier 0 for the
-    // pairs up to the typical length and, at the same time, tier 1 for the longer ones (they would overflow tier 0's slots, and
-    // each of them is a long serial chain: starting them first keeps them off the critical path); what a tier leaves undecided
-    // joins the next tier in the following round.
-    std::vector<BlockJob> wait[3];      // longest first inside each
-    // (what block2_kernel.hip handed on grows beyond 128 rows: tier 0's slots sized for blocks of 512 rows along the whole pair)
+    // (what block2_kernel.hip handed on grows beyond 512 rows: tier 0's slots sized for blocks of 512 rows along the whole pair)
     const uint64_t tier0_entries = first_tier_env ? 2 : BLOCK_MAX_SIZE / 64;
+    std::vector<BlockJob> wait[3];      // longest first inside each
     if (!slow_jobs.empty()) typical_len = pair_len(slow_jobs[slow_jobs.size() > 1024 ? 255 : 0]);
     for (const BlockJob &j : slow_jobs) wait[first_tier == 0 && pair_len(j) > typical_len ? 1 : first_tier].push_back(j);
     hipStream_t extra[2] = {nullptr, nullptr};

@@ -528,7 +528,8 @@ struct BkBlock { uint32_t i, j; uint16_t h, w; uint32_t right, tstart; };   // T
 
 // ---- the same aligner, two pairs per wavefront, border arrays in registers (block2_kernel.hip): sequence queries, blocks up to
 // BLOCK2_MAX_SIZE rows; what it answers MMGPU_BLOCK_TOO_LARGE goes to the tiers above ----
-constexpr int BLOCK2_MAX_SIZE = 128;
+constexpr int BLOCK2_MAX_SIZE = 128;     // the launch every pair starts in
+constexpr int BLOCK2_LARGE_SIZE = 512;   // the launch for what that one answered MMGPU_BLOCK_TOO_LARGE
 struct Block2Job {
     uint32_t query, target;
     int32_t score, q_end, t_end;
@@ -553,9 +554,10 @@ struct Block2Launch {
     uint8_t *pool;
     uint32_t *growth = nullptr;   // test aid, as BlockLaunch::growth
     uint32_t growth_cap = 0;
+    uint32_t dbg = 0;
 };
 // trace = false: start positions only (no scratch, no walk)
-hipError_t launch_sw_block2(const Block2Launch &L, bool trace, uint32_t n_waves, hipStream_t stream);
+hipError_t launch_sw_block2(const Block2Launch &L, bool trace, bool large, uint32_t n_waves, hipStream_t stream);
 hipError_t launch_sw_block2_walk(const Block2Launch &L, hipStream_t stream);
 
 hipError_t launch_sw_traceback(const BtLaunch &L, hipStream_t stream);

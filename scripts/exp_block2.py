@@ -20,6 +20,7 @@ from mmseqs2_amd import workloads as wl
 def main():
     fams = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
     nq = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+    only_new = len(sys.argv) > 3 and sys.argv[3] == "new"      # timing runs: skip the comparison with block_kernel.hip
     mats = dict(np.load("tests/golden/matrices.npz"))
     mat = mats["blosum62_sw"]
     sub16 = mat.astype(np.int16)
@@ -50,6 +51,10 @@ def main():
     for rep in range(2):
         ns, _ = b.block_backtrace(idx, mode="no_strings")
         out["no_strings_call_s_%d" % rep] = round(b.last_block_call_s, 4)
+    if only_new:
+        out["status_new"] = {int(k): int(v) for k, v in zip(*np.unique(new["status"], return_counts=True))}
+        print(json.dumps(out))
+        return
     _, new_lists = b.block_growth(idx[:20000], cap=512)
     os.environ["MMGPU_BLOCK_FIRST_TIER"] = "0"
     for rep in range(2):
@@ -70,6 +75,16 @@ def main():
     bad["no_strings_bt_len"] = int((ns["bt_len"] != old["bt_len"]).sum())
     bad["block_lists"] = int(sum(1 for a, c in zip(new_lists, old_lists) if a.shape != c.shape or not np.array_equal(a, c)))
     out["differing"] = bad
+    ex = []
+    for k, (a, c) in enumerate(zip(new_lists, old_lists)):
+        if a.shape != c.shape or not np.array_equal(a, c):
+            m = min(len(a), len(c))
+            d = [int(x) for x in np.nonzero((a[:m] != c[:m]).any(axis=1))[0][:2]]
+            ex.append(dict(k=k, n_new=len(a), n_old=len(c), rows=d, new=[a[x].tolist() for x in d], old=[c[x].tolist() for x in d],
+                           max_new=int(a[:, 2:4].max()) if len(a) else 0, max_old=int(c[:, 2:4].max()) if len(c) else 0))
+    out["differing_lists"] = ex[:3] + ex[len(ex) // 2:len(ex) // 2 + 3]
+    out["differing_lists_same_length"] = sum(1 for e in ex if e["n_new"] == e["n_old"])
+    out["dbg"] = [dict(k=e["k"], target=int(res[idx[e["k"]]]["score"]), first=int(st[e["k"]]["reserved"]) & 0xFFFF, steps=int(st[e["k"]]["reserved"]) >> 16, d0=int(st[e["k"]]["ident"]), d1=int(st[e["k"]]["bt_len"]), pair=int(idx[e["k"]]), q_end=int(res[idx[e["k"]]]["q_end"]), t_end=int(res[idx[e["k"]]]["t_end"])) for e in out["differing_lists"]]
     first = [int(k) for k in np.nonzero((new["q_start"] != old["q_start"]) | (new["t_start"] != old["t_start"]) | (new["status"] != old["status"]))[0][:5]]
     out["first_differing"] = [dict(k=k, pair=int(idx[k]), new=[int(new[k][f]) for f in ("status", "q_start", "t_start", "ident", "bt_len")],
                                    old=[int(old[k][f]) for f in ("status", "q_start", "t_start", "ident", "bt_len")],
