@@ -1134,7 +1134,31 @@ def translated_search_section(args):
         shutil.rmtree(w, ignore_errors=True)
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` started as ONE process (the driver's form of the command; the reference starts its splits from one
+    command too, Prefiltering.cpp:605-689 runMpiSplits): re-run the same command line under torch.distributed.run, one rank per
+    GPU, rendezvous on 127.0.0.1 at a free port.  The ranks inherit this process's stdout: rank 0 prints the one JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    return subprocess.call(cmd, env=env)
+
+
 def main():
+    if "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        pre = argparse.ArgumentParser(add_help=False)
+        pre.add_argument("--gpus", type=int, default=1)
+        n = pre.parse_known_args()[0].gpus
+        if n > 1:
+            raise SystemExit(self_launch(n))
     # exactly ONE line on stdout: libraries (RCCL prints a version banner) write to fd 1 behind Python's back, so
     # fd 1 is pointed at stderr for the run and the JSON line goes to the saved descriptor at the end
     sys.stdout.flush()
@@ -1184,10 +1208,13 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: start `python bench.py --gpus N` (it launches its own ranks) or "
+                         "python -m torch.distributed.run --nproc-per-node N bench.py --gpus N" % (args.gpus, world))
     # MMGPU_BENCH_BACKEND=gloo lets several ranks share one GPU to exercise the N>1 code path on a 1-GPU box
     backend = os.environ.get("MMGPU_BENCH_BACKEND", "nccl")
+    if backend == "nccl" and world > max(torch.cuda.device_count(), 0):
+        raise SystemExit("--gpus %d with the RCCL backend needs %d visible devices (%d here); MMGPU_BENCH_BACKEND=gloo lets the ranks share "
+                         "a device" % (world, world, torch.cuda.device_count()))
     device_index = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(device_index)
     dist = None

@@ -140,3 +140,31 @@ def test_result_databases_compare_up_to_the_order_of_tied_lines(tmp_path):
     # a tied line moved across a line with another key, and a changed field: both are differences
     assert dbio.diff_dbs_up_to_tie_order(a, c)[:3] == (2, 2, 0)
     assert dbio.diff_dbs_up_to_tie_order(a, a)[:3] == (2, 0, 0)
+
+
+def test_bench_started_as_one_process_launches_its_own_ranks(monkeypatch):
+    """`python bench.py --gpus N` (the driver's form of the command) re-runs itself under torch.distributed.run, one rank per GPU,
+    rendezvous on 127.0.0.1; inside a launched rank (WORLD_SIZE set) nothing is re-launched."""
+    sys.path.insert(0, ROOT)
+    import subprocess
+    import bench
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 0
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--headline-only"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.delenv("RANK", raising=False)
+    try:
+        bench.main()
+        raise AssertionError("main() returned instead of leaving with the launcher's exit code")
+    except SystemExit as e:
+        assert e.code == 0
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert 0 < int(cmd[cmd.index("--master-port") + 1]) < 65536
+    assert cmd[-5:] == ["--gpus", "4", "--steps", "3", "--headline-only"] and cmd[-6].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
