@@ -227,6 +227,7 @@ extern "C" int mmgpu_warmup(mmgpu_ctx *c) {
     mmgpu::warm_sw();
     mmgpu::warm_block();
     mmgpu::warm_block2();
+    mmgpu::warm_block4();
     mmgpu::warm_bt();
     return MMGPU_OK;
 }
@@ -1409,9 +1410,13 @@ static int block_backtrace(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const uint32_t *pa
     std::vector<BlockJob> slow_jobs;
     if (!first_tier_env) {
         static const uint64_t block2_waves = getenv("MMGPU_BLOCK2_WAVES") ? strtoull(getenv("MMGPU_BLOCK2_WAVES"), nullptr, 10) : 16;      // per CU (tuning aid)
+        static const uint64_t block4_waves = getenv("MMGPU_BLOCK4_WAVES") ? strtoull(getenv("MMGPU_BLOCK4_WAVES"), nullptr, 10) : 16;
+        const bool use_block2 = getenv("MMGPU_BLOCK_KERNEL") && atoi(getenv("MMGPU_BLOCK_KERNEL")) == 2;      // A/B aid
+        static const uint64_t block4_per_res = getenv("MMGPU_BLOCK4_PER_RES") ? strtoull(getenv("MMGPU_BLOCK4_PER_RES"), nullptr, 10) : 48;      // trace bytes per residue of a pair
+        const bool block4_small = getenv("MMGPU_BLOCK4_ROWS") && atoi(getenv("MMGPU_BLOCK4_ROWS")) == 128;      // tuning aid
         static const uint64_t pool2_limit = (getenv("MMGPU_BLOCK2_POOL_MB") ? strtoull(getenv("MMGPU_BLOCK2_POOL_MB"), nullptr, 10) : 3072ull) << 20;
-        DevBuf d_j2, d_cnt, d_pool2;
-        d_j2.bind(c->cache); d_cnt.bind(c->cache); d_pool2.bind(c->cache);
+        DevBuf d_j2, d_cnt, d_pool2, d_ck;
+        d_j2.bind(c->cache); d_cnt.bind(c->cache); d_pool2.bind(c->cache); d_ck.bind(c->cache);
         // one pass: `todo` (longest first) through sw_block2_kernel<trace, 2 or 8 chunks>; what it hands on is appended to `left`
         auto block2_pass = [&](const std::vector<BlockJob> &todo, bool large, std::vector<BlockJob> &left) -> int {
             std::vector<Block2Job> j2;
@@ -1420,7 +1425,7 @@ static int block_backtrace(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const uint32_t *pa
             uint64_t pool_used = 0, pool_need = 0;
             // bytes of trace per residue of the pair: a dword per row and octet = 0.5 byte per cell; 32 / 64-row blocks in the first
             // pass (a pair that needs more is answered TOO_LARGE like one whose blocks grow beyond 128 rows), 512 rows in the second
-            const uint64_t per_res = large ? 256 : 40, margin = large ? 1024 : 256;
+            const uint64_t per_res = use_block2 ? (large ? 256 : 40) : block4_per_res, margin = use_block2 ? (large ? 1024 : 256) : 512;
             for (const BlockJob &j : todo) {
                 Block2Job x;
                 x.query = j.query; x.target = j.target; x.score = j.score; x.q_end = j.q_end; x.t_end = j.t_end; x.slot = j.slot;
@@ -1456,9 +1461,19 @@ static int block_backtrace(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const uint32_t *pa
                 L2.n_jobs = group_begin[g + 1] - group_begin[g];
                 L2.counter = d_cnt.as<uint32_t>() + g;
                 // (resident wavefronts: 16 per CU at 112 registers, 4 per CU at the 8-chunk form's ~290)
-                const uint32_t waves = (uint32_t)std::min<uint64_t>((L2.n_jobs + 1) / 2, (uint64_t)std::max(c->compute_units, 1) * (large ? 4 : block2_waves));
-                HIP_TRY(launch_sw_block2(L2, !starts_only, large, waves, s));
-                if (!starts_only) HIP_TRY(launch_sw_block2_walk(L2, s));
+                if (use_block2) {
+                    const uint32_t waves = (uint32_t)std::min<uint64_t>((L2.n_jobs + 1) / 2, (uint64_t)std::max(c->compute_units, 1) * (large ? 4 : block2_waves));
+                    HIP_TRY(launch_sw_block2(L2, !starts_only, large, waves, s));
+                    if (!starts_only) HIP_TRY(launch_sw_block2_walk(L2, s));
+                } else {
+                    // (resident wavefronts: 3.4 KB of score table + 4 / 8 KB of border arrays a wavefront)
+                    const uint32_t waves = (uint32_t)std::min<uint64_t>((L2.n_jobs + 3) / 4, (uint64_t)std::max(c->compute_units, 1) * block4_waves);
+                    const size_t ck_bytes = (size_t)waves * 4 * 8 * BLOCK4_LARGE_SIZE;
+                    if (ck_bytes > d_ck.bytes) HIP_TRY(d_ck.alloc(ck_bytes));
+                    L2.ck_pool = d_ck.as<uint8_t>();
+                    HIP_TRY(launch_sw_block4(L2, !starts_only, large, waves, s));
+                    if (!starts_only) HIP_TRY(launch_sw_block4_walk(L2, s));
+                }
             }
             HIP_TRY(hipMemcpyAsync(out, d_out.p, (size_t)n * sizeof(mmgpu_sw_block), hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
@@ -1477,14 +1492,21 @@ static int block_backtrace(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const uint32_t *pa
             if (!b->h_query_is_profile.empty() && b->h_query_is_profile[j.query]) slow_jobs.push_back(j);
             else seq_jobs.push_back(j);
         }
-        int rc2 = block2_pass(seq_jobs, false, second);
-        if (rc2 != MMGPU_OK) return rc2;
-        lap("two pairs per wavefront (blocks <= 128 rows) + status download");
-        std::stable_sort(second.begin(), second.end(), [&](const BlockJob &x, const BlockJob &y) { return pair_len(x) > pair_len(y); });
         const size_t before = slow_jobs.size();
-        rc2 = block2_pass(second, true, slow_jobs);
-        if (rc2 != MMGPU_OK) return rc2;
-        if (!second.empty()) lap("two pairs per wavefront (blocks <= 512 rows) + status download");
+        int rc2;
+        if (use_block2) {
+            rc2 = block2_pass(seq_jobs, false, second);
+            if (rc2 != MMGPU_OK) return rc2;
+            lap("two pairs per wavefront (blocks <= 128 rows) + status download");
+            std::stable_sort(second.begin(), second.end(), [&](const BlockJob &x, const BlockJob &y) { return pair_len(x) > pair_len(y); });
+            rc2 = block2_pass(second, true, slow_jobs);
+            if (rc2 != MMGPU_OK) return rc2;
+            if (!second.empty()) lap("two pairs per wavefront (blocks <= 512 rows) + status download");
+        } else {
+            rc2 = block2_pass(seq_jobs, !block4_small, slow_jobs);
+            if (rc2 != MMGPU_OK) return rc2;
+            lap("four pairs per wavefront + status download");
+        }
         std::stable_sort(slow_jobs.begin(), slow_jobs.end(), [&](const BlockJob &x, const BlockJob &y) { return pair_len(x) > pair_len(y); });
         b->block_pairs_fast = (uint32_t)(seq_jobs.size() - (slow_jobs.size() - before));
     } else {

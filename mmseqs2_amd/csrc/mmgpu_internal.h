@@ -555,10 +555,17 @@ struct Block2Launch {
     uint32_t *growth = nullptr;   // test aid, as BlockLaunch::growth
     uint32_t growth_cap = 0;
     uint32_t dbg = 0;
+    uint8_t *ck_pool = nullptr;   // block4_kernel.hip: checkpoint arrays, 8 * rows bytes per row of a wavefront (4 rows a wavefront)
 };
 // trace = false: start positions only (no scratch, no walk)
 hipError_t launch_sw_block2(const Block2Launch &L, bool trace, bool large, uint32_t n_waves, hipStream_t stream);
 hipError_t launch_sw_block2_walk(const Block2Launch &L, hipStream_t stream);
+// ---- four pairs per wavefront, one 16-lane DPP row = one vector of the crate = one pair (block4_kernel.hip); same launch record ----
+constexpr int BLOCK4_MAX_SIZE = 128;     // (tuning aid: MMGPU_BLOCK4_ROWS=128) 1 KB of LDS per pair
+constexpr int BLOCK4_LARGE_SIZE = 256;   // the default: 2 KB of LDS per pair
+hipError_t launch_sw_block4(const Block2Launch &L, bool trace, bool large, uint32_t n_waves, hipStream_t stream);
+hipError_t launch_sw_block4_walk(const Block2Launch &L, hipStream_t stream);
+void warm_block4();
 
 hipError_t launch_sw_traceback(const BtLaunch &L, hipStream_t stream);
 hipError_t launch_sw_traceback_wave(const BtLaunch &L, hipStream_t stream);

@@ -56,6 +56,18 @@ def main():
         print(json.dumps(out))
         return
     _, new_lists = b.block_growth(idx[:20000], cap=512)
+    # rows of the shift blocks (every eight residues of progress is one), and blocks per pair
+    hist, nblk = {}, []
+    for a in new_lists:
+        if not len(a):
+            continue
+        h, w, right = a[:, 2], a[:, 3], a[:, 4]
+        rows = np.where(right == 1, h, w)[((right == 1) & (w == 8)) | ((right == 0) & (h == 8))]
+        for r, c in zip(*np.unique(rows, return_counts=True)):
+            hist[int(r)] = hist.get(int(r), 0) + int(c)
+        nblk.append(len(a))
+    out["shift_block_rows_histogram"] = hist
+    out["blocks_per_pair_mean"] = float(np.mean(nblk)) if nblk else 0.0
     os.environ["MMGPU_BLOCK_FIRST_TIER"] = "0"
     for rep in range(2):
         old, old_s = b.block_backtrace(idx)
