@@ -70,23 +70,34 @@ __device__ __forceinline__ int b4_rowmax(int v) {
 enum { B4_RIGHT = 0, B4_DOWN = 1, B4_GROW = 2 };
 enum { B4_JOB_SHIFT = 1, B4_JOB_GROW1 = 2, B4_JOB_GROW2 = 3 };
 
-template <bool TRACE, int MAXB>
+// SKEW = false: four pairs per wavefront, as above.  SKEW = true: ONE pair per wavefront for the pairs whose blocks outgrow the
+// first form (MAXB 1024, then the crate's 4096) - the four rows work on the same octet, row r on columns r and r + 4, one chunk
+// behind row r - 1: cell (chunk, column) needs (chunk - 1, column) - the row's own previous trip - and (chunk, column - 1) - row
+// r - 1's previous trip, handed over through a two-slot ring in LDS; column 3's results go into the border array in place, where
+// row 0 picks them up for column 4.  An octet of n chunks takes max(n, 4) + n + 3 trips of ONE column-chunk each instead of
+// block_kernel.hip's 8 x n / 4 steps of 64 rows: a quarter of the dependent chain, and the chain is what these pairs cost.
+template <bool TRACE, int MAXB, bool SKEW>
 __global__ __launch_bounds__(64) void sw_block4_kernel(Block2Launch L) {
     __shared__ uint32_t s_sc[27 * 32];          // AAMatrix::scores as int16 patterns, a dword each (no masking after the load)
-    __shared__ int16_t s_arr[4][4 * MAXB];      // per pair: D_col, C_col, D_row, R_row
+    __shared__ int16_t s_arr[SKEW ? 1 : 4][4 * MAXB];      // per pair: D_col, C_col, D_row, R_row
+    __shared__ uint32_t s_ring[4][2][2][16];    // SKEW: row r's D11 / C11 (both halves) of its last trip, for row r + 1 (row 3's low half: for row 0's high half)
+    __shared__ int16_t s_out[2][8];             // SKEW: the octet's last row (D_row[j] / R_row[j])
+    __shared__ uint32_t s_col[2][8];            // SKEW: the octet's columns (score-row offset, bias)
     const int lane = (int)threadIdx.x;
     for (int x = lane; x < 27 * 32; x += 64) s_sc[x] = (uint32_t)(uint16_t)(int16_t)L.scores[x];
     __syncthreads();
     const int k = lane & 15;
-    int16_t *const A = s_arr[lane >> 4];
+    const int lid = SKEW ? lane : k, lstride = SKEW ? 64 : 16;      // loops over a pair's arrays: the pair's lanes
+    int16_t *const A = s_arr[SKEW ? 0 : lane >> 4];
     // the four checkpoint arrays of the row's pair: scratch in HBM (written at every new maximum, read when a block grows; the row's
     // own stores and loads, same lane, same address, one L1, program order)
-    uint32_t *const CK = reinterpret_cast<uint32_t *>(L.ck_pool) + ((size_t)blockIdx.x * 4 + (size_t)(lane >> 4)) * (size_t)(2 * MAXB);
+    uint32_t *const CK = reinterpret_cast<uint32_t *>(L.ck_pool) + (SKEW ? (size_t)blockIdx.x : (size_t)blockIdx.x * 4 + (size_t)(lane >> 4)) * (size_t)(2 * MAXB);
     const int go = L.gap_open, ge = L.gap_extend;
-    const unsigned m1 = (k & 7) >= 1 ? 0xFFFFu : 0u, m2 = (k & 7) >= 2 ? 0xFFFFu : 0u;
+    constexpr unsigned SPL = SKEW ? 0x00010001u : 1u;      // SKEW: both int16 halves of a register carry a cell
+    const unsigned m1 = (k & 7) >= 1 ? 0xFFFFu * SPL : 0u, m2 = (k & 7) >= 2 ? 0xFFFFu * SPL : 0u;
     unsigned gap_all, consts;
     {   // avx2.rs:294-309: the 1 .. 16 x gap_extend ladder of a vector
-        const unsigned g = b4_pat(ge);
+        const unsigned g = b4_pat(ge) * SPL;
         const unsigned s1 = b4_adds(b4_mov<0x111>(g) & m1, g);
         const unsigned s2 = b4_adds(b4_mov<0x112>(s1) & m2, s1);
         const unsigned s4 = b4_adds(b4_dpp<0x114, 0xB>(0u, s2), s2);
@@ -94,8 +105,8 @@ __global__ __launch_bounds__(64) void sw_block4_kernel(Block2Launch L) {
         gap_all = b4_adds(k < 8 ? 0u : w7, s4);
         consts = s4;
     }
-    const unsigned g1 = b4_pat(ge), g2 = b4_pat((int)(short)(ge << 1)), g4 = b4_pat((int)(short)(ge << 2));
-    const unsigned gop = b4_pat(go), gep = b4_pat(ge), gome = b4_pat(b4_subs_i(go, ge));
+    const unsigned g1 = b4_pat(ge) * SPL, g2 = b4_pat((int)(short)(ge << 1)) * SPL, g4 = b4_pat((int)(short)(ge << 2)) * SPL;
+    const unsigned gop = b4_pat(go) * SPL, gep = b4_pat(ge) * SPL, gome = b4_pat(b4_subs_i(go, ge)) * SPL;
 
     // ---- the row's pair (every value uniform inside the row) ----
     bool active = false;
@@ -106,13 +117,23 @@ __global__ __launch_bounds__(64) void sw_block4_kernel(Block2Launch L) {
     // align_core (scan_block.rs:120-632)
     int best_max = 0, best_i = 0, best_j = 0, prev_dir = B4_GROW, dir = B4_GROW, prev_size = 0, bs = 32, off = 0, off_max = 0;
     int y_drop_iter = 0, x_drop_iter = 0, st_i = 0, st_j = 0, i_ck = 0, j_ck = 0, off_ck = 0, D_corner = 0, off_add = 0;
-    int min_size = 32, x_drop = 0, score = 0, ri = 0, rj = 0;
+    int min_size = 32, x_drop = 0, score = 0, ri = 0, rj = 0, resume_min = 32;
     uint32_t trace_idx = 0, block_idx = 0, ck_trace_idx = 0, ck_block_idx = 0, trace_cap = 0, block_cap = 0;
-    bool overflow = false;
+    bool overflow = false, slot_overflow = false;      // (slot_overflow: the pair's trace / block-list slot was too small - not its blocks too large)
     // the current place_block job (scan_block.rs:1449-1613): eight columns (an octet) at a time, two chunks of the octet per trip
     int J_kind = B4_JOB_SHIFT, J_start_row = 0, J_start_col = 0, J_width = 8, J_height = 0, J_oct = 0, J_c = 0, J_corner = 0, J_out_base = 0, J_off_add = 0;
     bool J_rq = true, J_origin = false;      // rq: rows run over the query (shift right, second grow job), else over the reference
-    int Mkey = 0, Gkey = 0;                  // per lane: D_max << 16 | column << 8 | chunk of the LAST cell that reached it (this job's / the first grow job's)
+    // per lane: D_max, column and chunk of the LAST cell that reached it (this job's / the first grow job's) as ONE ordered key:
+    // D_max << 16 | column << 8 | chunk (SKEW, blocks up to 4096 rows: D_max << 32 | column << 8 | chunk)
+    typedef typename std::conditional<SKEW, long long, int>::type key_t;
+    key_t Mkey = 0, Gkey = 0;
+    auto make_key = [](unsigned d, unsigned column, unsigned chunk) -> key_t {
+        if (SKEW) return (key_t)(((long long)(int)(short)d << 32) | (long long)((column << 8) | chunk));
+        return (key_t)(int)((d << 16) | (column << 8) | chunk);
+    };
+    auto key_dm = [](key_t key) { return SKEW ? (int)((long long)key >> 32) : (int)key >> 16; };
+    auto key_aj = [](key_t key) { return SKEW ? (int)(((unsigned)key >> 8) & 0xFFFFFu) : ((int)key >> 8) & 0xFF; };
+    auto key_ai = [](key_t key) { return ((int)key & 0xFF) * 16; };
     // what a chunk hands to the one below, per column of the octet: its last lane's D (the corner of D00 one column later), R (R01)
     // and trace_R flag - column b in bank b of _lo (b < 4) / bank b - 4 of _hi.  After the octet's last chunk: D_row[j] / R_row[j]
     unsigned pD_lo = 0, pD_hi = 0, pR_lo = 0, pR_hi = 0, pT_lo = 0, pT_hi = 0, init15_prev = 0;
@@ -155,7 +176,6 @@ __global__ __launch_bounds__(64) void sw_block4_kernel(Block2Launch L) {
         const unsigned init15 = b4_bcast<15>(D10);
         unsigned nD_lo = 0, nD_hi = 0, nR_lo = 0, nR_hi = 0, nT_lo = 0, nT_hi = 0;
         unsigned acc = 0;
-        const unsigned kc = (unsigned)c | ((unsigned)(J_oct * 8) << 8);
         const bool omask = J_origin && first && c == 0 && k == 0;
         auto column = [&](auto JC) {
             constexpr int j = decltype(JC)::value;
@@ -189,7 +209,7 @@ __global__ __launch_bounds__(64) void sw_block4_kernel(Block2Launch L) {
                 if (j < 4) nT_lo = b4_dpp<0x15F, bank>(nT_lo, tempR);
                 else nT_hi = b4_dpp<0x15F, bank>(nT_hi, tempR);
             }
-            Mkey = max(Mkey, (int)((D11 << 16) | (kc + (unsigned)(j << 8))));
+            Mkey = max(Mkey, make_key(D11, (unsigned)(J_oct * 8 + j), (unsigned)c));
             if (j < 4) { nD_lo = b4_dpp<0x15F, bank>(nD_lo, D11); nR_lo = b4_dpp<0x15F, bank>(nR_lo, R11); }
             else { nD_hi = b4_dpp<0x15F, bank>(nD_hi, D11); nR_hi = b4_dpp<0x15F, bank>(nR_hi, R11); }
             D10 = D11;
@@ -211,7 +231,9 @@ __global__ __launch_bounds__(64) void sw_block4_kernel(Block2Launch L) {
     };
     // the octet's last-row values (pD / pR after its last chunk) into entries base .. base + 7 of two arrays
     auto put_outputs = [&](int16_t *a1, int16_t *a2, int base) {
-        if ((k & 3) == 0) {
+        if (SKEW) {
+            if (k < 8) { a1[base + k] = s_out[0][k]; a2[base + k] = s_out[1][k]; }
+        } else if ((k & 3) == 0) {
             const int b = base + (k >> 2);
             a1[b] = (int16_t)pD_lo; a1[b + 4] = (int16_t)pD_hi;
             a2[b] = (int16_t)pR_lo; a2[b + 4] = (int16_t)pR_hi;
@@ -228,15 +250,16 @@ __global__ __launch_bounds__(64) void sw_block4_kernel(Block2Launch L) {
             }
         } else {
             overflow = true;
+            slot_overflow = true;
         }
         block_idx++;
     };
     auto checkpoint = [&](int n) {      // n entries of the four arrays -> the checkpoint (as dwords)
-        for (int x = k; x < n / 2; x += 16)
+        for (int x = lid; x < n / 2; x += lstride)
             for (int a = 0; a < 4; a++) CK[a * (MAXB / 2) + x] = reinterpret_cast<const uint32_t *>(A + a * MAXB)[x];
     };
     auto restore = [&](int n) {
-        for (int x = k; x < n / 2; x += 16)
+        for (int x = lid; x < n / 2; x += lstride)
             for (int a = 0; a < 4; a++) reinterpret_cast<uint32_t *>(A + a * MAXB)[x] = CK[a * (MAXB / 2) + x];
     };
     auto pmax8 = [&](int a) {      // prefix_max: the maximum of the first STEP entries (scan_block.rs:1125-1140)
@@ -245,8 +268,13 @@ __global__ __launch_bounds__(64) void sw_block4_kernel(Block2Launch L) {
 
     auto fetch = [&]() {      // the next pair of the queue
         uint32_t idx = 0;
-        if (k == 0) idx = atomicAdd(L.counter, 1u);
-        idx = b4_bcast<0>(idx);
+        if (SKEW) {
+            if (lane == 0) idx = atomicAdd(L.counter, 1u);
+            idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)idx);
+        } else {
+            if (k == 0) idx = atomicAdd(L.counter, 1u);
+            idx = b4_bcast<0>(idx);
+        }
         active = idx < L.n_jobs;
         if (!active) return;
         const Block2Job J = L.jobs[idx];
@@ -258,15 +286,15 @@ __global__ __launch_bounds__(64) void sw_block4_kernel(Block2Launch L) {
             const uint32_t cap = (uint32_t)(Qlen + Tlen + 64);
             blocks_bytes = (cap * (uint32_t)sizeof(BkBlock) + 31u) & ~31u;
             pool_off = J.pool_off;
-            trace_cap = J.pool_bytes > blocks_bytes ? (J.pool_bytes - blocks_bytes) / 4u : 0u;
+            trace_cap = J.pool_bytes > blocks_bytes ? (J.pool_bytes - blocks_bytes) / (SKEW ? 1u : 4u) : 0u;      // dwords (SKEW: bytes)
             block_cap = J.pool_bytes > blocks_bytes ? cap : 0u;
         }
-        min_size = 32;
+        min_size = J.pad ? (int)J.pad : 32;      // (minimum sizes below it were tried by the launch before and did not reach the score)
         score = -1000000000; ri = 0; rj = 0;
     };
 
     auto start_attempt = [&]() {      // Allocated::clear + align_core's initial state
-        for (int x = k; x < 2 * MAXB; x += 16) reinterpret_cast<uint32_t *>(A)[x] = 0u;      // (the checkpoint is written before it is read)
+        for (int x = lid; x < 2 * MAXB; x += lstride) reinterpret_cast<uint32_t *>(A)[x] = 0u;      // (the checkpoint is written before it is read)
         best_max = 0; best_i = 0; best_j = 0;
         prev_dir = B4_GROW; dir = B4_GROW;
         prev_size = 0; bs = min_size;
@@ -275,7 +303,7 @@ __global__ __launch_bounds__(64) void sw_block4_kernel(Block2Launch L) {
         st_i = 0; st_j = 0; i_ck = 0; j_ck = 0; off_ck = 0;
         D_corner = 0; off_add = 0;
         trace_idx = 0; block_idx = 0; ck_trace_idx = 0; ck_block_idx = 0;
-        overflow = false;
+        overflow = false; slot_overflow = false;
         x_drop = -(min_size * ge + go);
     };
 
@@ -319,6 +347,7 @@ __global__ __launch_bounds__(64) void sw_block4_kernel(Block2Launch L) {
         out.reserved = 0;
         if (too_large) {
             out.status = MMGPU_BLOCK_TOO_LARGE;
+            out.reserved = resume_min | (slot_overflow ? 0x10000 : 0);      // the first minimum size the next launch has to try; bit 16: only the slot was too small
         } else if (!(score != target && !(target == 32767 && score >= target))) {      // StripedSmithWaterman.cpp:1058
             out.status = MMGPU_BLOCK_OK;
             out.q_start = q_end + 1 - ri;       // :1111-1112
@@ -349,6 +378,12 @@ __global__ __launch_bounds__(64) void sw_block4_kernel(Block2Launch L) {
     // runs after the row's job is complete (or at a fresh pair): everything of align_core up to the next job.  Leaves active = false
     // when the queue is empty.
     auto advance = [&]() {
+        if (SKEW) {      // the vector lane's maximum over the four rows' columns
+            for (int d = 16; d < 64; d <<= 1) {
+                const long long o = __shfl_xor((long long)Mkey, d, 64);
+                Mkey = (key_t)max((long long)Mkey, o);
+            }
+        }
         if (J_kind == B4_JOB_GROW1) {      // grow_D_max = this job's maxima; the second job follows
             Gkey = Mkey;
             begin_grow2();
@@ -361,7 +396,7 @@ __global__ __launch_bounds__(64) void sw_block4_kernel(Block2Launch L) {
             int16_t *const o1 = A + (dir == B4_RIGHT ? 2 : 0) * MAXB, *const o2 = o1 + MAXB;
             D_corner = b4_adds_i((int)o1[B4_STEP - 1], off_add);
             const unsigned offp = b4_pat(off_add);
-            for (int x = k; x < bs - B4_STEP; x += 16) {
+            for (int x = lid; x < bs - B4_STEP; x += lstride) {
                 const unsigned v1 = b4_adds((unsigned)(uint16_t)o1[x + B4_STEP], offp), v2 = b4_adds((unsigned)(uint16_t)o2[x + B4_STEP], offp);
                 o1[x] = (int16_t)v1;
                 o2[x] = (int16_t)v2;
@@ -382,8 +417,8 @@ __global__ __launch_bounds__(64) void sw_block4_kernel(Block2Launch L) {
         } else {
             const int cur = dir;
             prev_dir = cur;
-            const int D_max_max = b4_rowmax(Mkey >> 16);
-            const int grow_max = b4_rowmax(Gkey >> 16);      // (MIN unless this step grew)
+            const int D_max_max = b4_rowmax(key_dm(Mkey));
+            const int grow_max = b4_rowmax(key_dm(Gkey));      // (MIN unless this step grew)
             const int mx = max(D_max_max, grow_max);
             off_max = off + mx - B4_ZERO;
             y_drop_iter++;
@@ -393,8 +428,8 @@ __global__ __launch_bounds__(64) void sw_block4_kernel(Block2Launch L) {
                     // largest column, then the largest row (:374-444)
                     const bool grow = cur == B4_GROW && D_max_max < grow_max;
                     const int curr_max = grow ? grow_max : D_max_max;
-                    const int key = grow ? Gkey : Mkey;
-                    const int dm = key >> 16, aj = (key >> 8) & 0xFF, ai = (key & 0xFF) * 16;
+                    const key_t key = grow ? Gkey : Mkey;
+                    const int dm = key_dm(key), aj = key_aj(key), ai = key_ai(key);
                     const int r = ai + k, cc = (bs - B4_STEP) + aj;
                     int gi, gj;
                     if (grow) { gi = st_i + prev_size + aj; gj = st_j + ai + k; }
@@ -460,7 +495,7 @@ __global__ __launch_bounds__(64) void sw_block4_kernel(Block2Launch L) {
                     if (max(s1, s2) >= mx) {
                         prev_dir = B4_GROW;
                         bs /= 2;
-                        for (int x = k; x < bs; x += 16)      // copy_vec(i, i + block_size)
+                        for (int x = lid; x < bs; x += lstride)      // copy_vec(i, i + block_size)
                             for (int a = 0; a < 4; a++) A[a * MAXB + x] = A[a * MAXB + x + bs];
                         st_i += bs;
                         st_j += bs;
@@ -481,6 +516,7 @@ __global__ __launch_bounds__(64) void sw_block4_kernel(Block2Launch L) {
             // ---- align_core returned: the loop over minimum sizes (StripedSmithWaterman.cpp:1021-1038) ----
             bool too_large = overflow;
             if (!too_large) { score = best_max; ri = best_i; rj = best_j; }
+            resume_min = too_large ? min_size : min_size * 2;
             min_size *= 2;
             if (!too_large && score < target && min_size <= MAXB) {
                 start_attempt();
@@ -501,6 +537,127 @@ __global__ __launch_bounds__(64) void sw_block4_kernel(Block2Launch L) {
         start_attempt();
         begin_step();
     }
+    if (SKEW) {
+        // Eight pipeline stages on four rows: stage s = column s of the octet, one chunk behind stage s - 1.  Row r carries stage r in
+        // the LOW int16 half of its registers and stage r + 4 in the HIGH half - the packed operations, the DPP moves and the
+        // carries serve both at once; what differs per half (the chunk, the rows' letters, the column, where results go) is a
+        // few unpacked instructions around them.  An octet of n chunks takes n + 7 trips.
+        const int r = lane >> 4;
+        typedef unsigned short b4_u16x2 __attribute__((ext_vector_type(2)));
+        auto ne2 = [](unsigned a, unsigned b) {      // per half: 0 where equal, 1 where not (v_pk_min_u16)
+            return __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(b4_u16x2, a ^ b), __builtin_bit_cast(b4_u16x2, 0x00010001u)));
+        };
+        while (active) {      // (uniform over the wavefront: one pair)
+            const int nch = J_height >> 4;
+            const bool first = J_oct == 0;
+            const unsigned offp = (J_kind == B4_JOB_SHIFT && first) ? b4_pat(J_off_add) : 0u;
+            int16_t *const rA = A + (J_rq ? 0 : 2 * MAXB), *const rB = rA + MAXB;
+            const int rlen = J_rq ? Qlen : Tlen, rend = J_rq ? q_end : t_end, clen = J_rq ? Tlen : Qlen, cend = J_rq ? t_end : q_end;
+            const uint8_t *const rbase = J_rq ? q_ptr() : t_ptr(), *const cbase = J_rq ? t_ptr() : q_ptr();
+            const int ntrip = nch + 7;
+            const bool ok = !TRACE || trace_idx + (uint32_t)nch * 128u <= trace_cap;
+            uint8_t *const trace = L.pool + pool_off + blocks_bytes;
+            if (lane < 8) {      // the octet's columns, through LDS
+                const int pc = J_start_col + J_oct * 8 + lane;
+                const bool in = pc >= 1 && pc <= clen;
+                const int idx = in ? cend - (pc - 1) : 0;
+                const int letter = in ? (int)cbase[idx] : 26;
+                const int bias = (int)L.q_cb[Qoff + (J_rq ? 0 : idx)];
+                s_col[0][lane] = (unsigned)letter * 128u;
+                s_col[1][lane] = (!J_rq && in) ? b4_pat(bias) : 0u;
+            }
+            const unsigned soff_lo = s_col[0][r], soff_hi = s_col[0][r + 4];
+            const unsigned cbc = s_col[1][r] | (s_col[1][r + 4] << 16);
+            unsigned cR = 0, cT = 0x00010001u, cD15 = 0;      // from the chunk above, per half: R's last lane, trace_R false (as "not"), D10's last lane
+            // the rows' letters and biases one trip ahead of their use (a trip is short, a load is not): low half chunk c, high half chunk c - 4
+            unsigned n_ri_lo, n_ri_hi, n_rowb;
+            auto load_rows = [&](int c_lo) {
+                unsigned ri[2], rb[2];
+                for (int h = 0; h < 2; h++) {
+                    const int c = c_lo - 4 * h;
+                    const int p = J_start_row + 16 * (c < 0 ? 0 : c) + k;
+                    const bool in = p >= 1 && p <= rlen;
+                    const int idx = in ? rend - (p - 1) : 0;
+                    const int letter = (int)rbase[idx];
+                    const int rbias = (int)L.q_cb[Qoff + (J_rq ? idx : 0)];
+                    ri[h] = (unsigned)((in ? letter : 26) & 31) * 4u;
+                    rb[h] = (J_rq && in) ? b4_pat(rbias) : 0u;
+                }
+                n_ri_lo = ri[0]; n_ri_hi = ri[1]; n_rowb = rb[0] | (rb[1] << 16);
+            };
+            load_rows(0);
+            for (int t = 0; t < ntrip; t++) {
+                const int c_lo = t - r, c_hi = c_lo - 4;
+                const bool v_lo = c_lo >= 0 && c_lo < nch, v_hi = c_hi >= 0 && c_hi < nch;
+                if (v_lo || v_hi) {
+                    const unsigned ri_lo = n_ri_lo, ri_hi = n_ri_hi, rowb = n_rowb;
+                    load_rows(c_lo + 1);
+                    if (c_lo == 0) {      // the low half's column begins
+                        cR &= 0xFFFF0000u; cT |= 0x1u;
+                        cD15 = (cD15 & 0xFFFF0000u) | ((r == 0 && first) ? b4_pat(J_corner) : 0u);
+                    }
+                    if (c_hi == 0) { cR &= 0xFFFFu; cT |= 0x10000u; cD15 &= 0xFFFFu; }
+                    const int x_lo = 16 * (v_lo ? c_lo : 0) + k, x_hi = 16 * (v_hi ? c_hi : 0) + k;
+                    const int sl = (t + 1) & 1;
+                    unsigned D10, C10;
+                    if (r == 0) {      // column 0 out of the border arrays, column 4 after row 3's column 3
+                        D10 = b4_adds((unsigned)(uint16_t)rA[x_lo], offp) | (s_ring[3][sl][0][k] << 16);
+                        C10 = b4_adds((unsigned)(uint16_t)rB[x_lo], offp) | (s_ring[3][sl][1][k] << 16);
+                    } else {
+                        D10 = s_ring[r - 1][sl][0][k];
+                        C10 = s_ring[r - 1][sl][1][k];
+                    }
+                    const unsigned D00 = b4_dpp<0x111>(cD15, D10);
+                    cD15 = b4_bcast<15>(D10);
+                    const unsigned sc = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(s_sc) + ri_lo + soff_lo) |
+                                        (*reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(s_sc) + ri_hi + soff_hi) << 16);
+                    unsigned D11 = b4_adds(D00, b4_adds(sc, b4_adds(cbc, rowb)));
+                    if (J_origin && first && r == 0 && c_lo == 0 && k == 0) D11 = (D11 & 0xFFFF0000u) | (unsigned)B4_ZERO;
+                    const unsigned C11o = b4_adds(D10, gop);
+                    const unsigned C11 = b4_maxs(b4_adds(C10, gep), C11o);
+                    D11 = b4_maxs(D11, C11);
+                    const unsigned D11o = b4_adds(D11, gome);
+                    const unsigned p1 = b4_maxs(D11o, b4_adds(b4_mov<0x111>(D11o) & m1, g1));
+                    const unsigned p2 = b4_maxs(p1, b4_adds(b4_mov<0x112>(p1) & m2, g2));
+                    const unsigned p4 = b4_maxs(p2, b4_adds(b4_dpp<0x114, 0xB>(0u, p2), g4));
+                    const unsigned from = b4_dpp<0x157, 0xC>(b4_dpp<0x114>(p4, p4), p4);
+                    unsigned R11 = b4_maxs(p4, b4_adds(from, consts));
+                    R11 = b4_maxs(R11, b4_adds(cR, gap_all));
+                    cR = b4_bcast<15>(R11);
+                    D11 = b4_maxs(D11, R11);
+                    if (TRACE) {      // a byte per cell, stored as "not": D11 != C11, D11 != R11, C11 != C11_open, trace_R false
+                        const unsigned nT = ne2(R11, D11o);
+                        const unsigned ntr = b4_dpp<0x111>(cT, nT);
+                        cT = b4_bcast<15>(nT);
+                        const unsigned nib = (ne2(D11, C11) << 3) | (ne2(D11, R11) << 2) | (ne2(C11, C11o) << 1) | ntr;
+                        if (ok && v_lo) trace[trace_idx + (uint32_t)((c_lo * 8 + r) * 16 + k)] = (uint8_t)(nib & 0xFu);
+                        if (ok && v_hi) trace[trace_idx + (uint32_t)((c_hi * 8 + r + 4) * 16 + k)] = (uint8_t)((nib >> 16) & 0xFu);
+                    }
+                    if (v_lo) Mkey = max(Mkey, make_key(D11 & 0xFFFFu, (unsigned)(J_oct * 8 + r), (unsigned)c_lo));
+                    if (v_hi) Mkey = max(Mkey, make_key(D11 >> 16, (unsigned)(J_oct * 8 + r + 4), (unsigned)c_hi));
+                    s_ring[r][t & 1][0][k] = D11;
+                    s_ring[r][t & 1][1][k] = C11;
+                    if (r == 3 && v_hi) { rA[x_hi] = (int16_t)(D11 >> 16); rB[x_hi] = (int16_t)(C11 >> 16); }      // column 7: the border arrays, in place
+                    if (k == 15) {
+                        if (c_lo == nch - 1) { s_out[0][r] = (int16_t)D11; s_out[1][r] = (int16_t)R11; }
+                        if (c_hi == nch - 1) { s_out[0][r + 4] = (int16_t)(D11 >> 16); s_out[1][r + 4] = (int16_t)(R11 >> 16); }
+                    }
+                }
+            }
+            if (TRACE) {
+                overflow = overflow || !ok;
+                slot_overflow = slot_overflow || !ok;
+                trace_idx += (uint32_t)nch * 128u;
+            }
+            if (J_kind != B4_JOB_SHIFT) {
+                int16_t *const o1 = A + (J_kind == B4_JOB_GROW1 ? 0 : 2) * MAXB;
+                put_outputs(o1, o1 + MAXB, J_out_base + J_oct * 8);
+            }
+            J_oct++;
+            if (J_oct * 8 >= J_width) advance();
+        }
+        return;
+    }
     // Every trip: two chunks of the row's octet (block sizes are multiples of 32 rows, so rows at 32-row blocks - three shifts of
     // four - complete an octet and take their align_core step on every trip, together; a row at larger blocks needs more trips for
     // its octet and holds nobody up)
@@ -511,7 +668,8 @@ __global__ __launch_bounds__(64) void sw_block4_kernel(Block2Launch L) {
         J_c += 2;
         if (J_c * 16 >= J_height) {
             if (TRACE) {
-                overflow = overflow || trace_idx + (uint32_t)(J_height >> 4) * 16u > trace_cap;
+                slot_overflow = slot_overflow || trace_idx + (uint32_t)(J_height >> 4) * 16u > trace_cap;
+                overflow = overflow || slot_overflow;
                 trace_idx += (uint32_t)(J_height >> 4) * 16u;
             }
             if (J_kind != B4_JOB_SHIFT) {
@@ -560,8 +718,13 @@ __global__ __launch_bounds__(64) void sw_block4_walk_kernel(Block2Launch L) {
         }
         const int ci = i - bi, cj = j - bj;
         const int r = bright ? ci : cj, c = bright ? cj : ci;
-        const uint32_t w = trace[btstart + ((uint32_t)(c >> 3) * nch + (uint32_t)(r >> 4)) * 16u + (uint32_t)(r & 15)];
-        const unsigned nib = (w >> (28 - 4 * (c & 7))) & 0xFu;      // D == C, D == R, C == C_open, trace_R
+        unsigned nib;      // D == C, D == R, C == C_open, trace_R
+        if (L.trace_bytes) {      // the skewed form's trace: a byte per cell, [octet][chunk][column][lane]
+            nib = (unsigned)reinterpret_cast<const uint8_t *>(trace)[btstart + (((uint32_t)(c >> 3) * nch + (uint32_t)(r >> 4)) * 8u + (uint32_t)(c & 7)) * 16u + (uint32_t)(r & 15)] ^ 0xFu;
+        } else {
+            const uint32_t w = trace[btstart + ((uint32_t)(c >> 3) * nch + (uint32_t)(r >> 4)) * 16u + (uint32_t)(r & 15)];
+            nib = (w >> (28 - 4 * (c & 7))) & 0xFu;
+        }
         const unsigned tt = ((nib >> 3) & 1u) | (((nib >> 2) & 1u) << 1), t2 = ((nib >> 1) & 1u) | ((nib & 1u) << 1);
         int op, nt;      // OP_LUT (:1870-1933): 1 = match / mismatch, 4 = the row index moves (I), 5 = the column index moves (D)
         if (bright) {
@@ -598,14 +761,22 @@ __global__ __launch_bounds__(64) void sw_block4_walk_kernel(Block2Launch L) {
 
 }  // namespace
 
-hipError_t launch_sw_block4(const Block2Launch &L, bool trace, bool large, uint32_t n_waves, hipStream_t stream) {
+// form 0 / 1: four pairs per wavefront, blocks up to BLOCK4_MAX_SIZE / BLOCK4_LARGE_SIZE rows; form 2 / 3: the skewed form, one
+// pair per wavefront, blocks up to BLOCK4_SKEW_SIZE / BLOCK_REF_MAX_SIZE rows
+hipError_t launch_sw_block4(const Block2Launch &L, bool trace, int form, uint32_t n_waves, hipStream_t stream) {
     if (L.n_jobs == 0) return hipSuccess;
-    if (large) {
-        if (trace) hipLaunchKernelGGL((sw_block4_kernel<true, BLOCK4_LARGE_SIZE>), dim3(n_waves), dim3(64), 0, stream, L);
-        else hipLaunchKernelGGL((sw_block4_kernel<false, BLOCK4_LARGE_SIZE>), dim3(n_waves), dim3(64), 0, stream, L);
+    if (form == 3) {
+        if (trace) hipLaunchKernelGGL((sw_block4_kernel<true, BLOCK_REF_MAX_SIZE, true>), dim3(n_waves), dim3(64), 0, stream, L);
+        else hipLaunchKernelGGL((sw_block4_kernel<false, BLOCK_REF_MAX_SIZE, true>), dim3(n_waves), dim3(64), 0, stream, L);
+    } else if (form == 2) {
+        if (trace) hipLaunchKernelGGL((sw_block4_kernel<true, BLOCK4_SKEW_SIZE, true>), dim3(n_waves), dim3(64), 0, stream, L);
+        else hipLaunchKernelGGL((sw_block4_kernel<false, BLOCK4_SKEW_SIZE, true>), dim3(n_waves), dim3(64), 0, stream, L);
+    } else if (form == 1) {
+        if (trace) hipLaunchKernelGGL((sw_block4_kernel<true, BLOCK4_LARGE_SIZE, false>), dim3(n_waves), dim3(64), 0, stream, L);
+        else hipLaunchKernelGGL((sw_block4_kernel<false, BLOCK4_LARGE_SIZE, false>), dim3(n_waves), dim3(64), 0, stream, L);
     } else {
-        if (trace) hipLaunchKernelGGL((sw_block4_kernel<true, BLOCK4_MAX_SIZE>), dim3(n_waves), dim3(64), 0, stream, L);
-        else hipLaunchKernelGGL((sw_block4_kernel<false, BLOCK4_MAX_SIZE>), dim3(n_waves), dim3(64), 0, stream, L);
+        if (trace) hipLaunchKernelGGL((sw_block4_kernel<true, BLOCK4_MAX_SIZE, false>), dim3(n_waves), dim3(64), 0, stream, L);
+        else hipLaunchKernelGGL((sw_block4_kernel<false, BLOCK4_MAX_SIZE, false>), dim3(n_waves), dim3(64), 0, stream, L);
     }
     return hipGetLastError();
 }
@@ -618,8 +789,8 @@ hipError_t launch_sw_block4_walk(const Block2Launch &L, hipStream_t stream) {
 
 void warm_block4() {
     hipFuncAttributes a;
-    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&(sw_block4_kernel<false, BLOCK4_MAX_SIZE>)));
-    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&(sw_block4_kernel<true, BLOCK4_MAX_SIZE>)));
+    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&(sw_block4_kernel<false, BLOCK4_LARGE_SIZE, false>)));
+    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&(sw_block4_kernel<true, BLOCK4_LARGE_SIZE, false>)));
     (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&sw_block4_walk_kernel));
 }
 

@@ -226,7 +226,6 @@ extern "C" int mmgpu_warmup(mmgpu_ctx *c) {
     mmgpu::warm_pf();
     mmgpu::warm_sw();
     mmgpu::warm_block();
-    mmgpu::warm_block2();
     mmgpu::warm_block4();
     mmgpu::warm_bt();
     return MMGPU_OK;
@@ -530,7 +529,8 @@ struct mmgpu_sw_batch_t {
     std::vector<uint32_t> h_slot_target;
     bool h_res_valid = false;
     uint32_t block_pairs_tier[3] = {0, 0, 0};   // last mmgpu_sw_block_backtrace call: pairs decided with blocks <= 512 / 2048 / 4096 rows
-    uint32_t block_pairs_fast = 0;              // ... and by block2_kernel.hip (two pairs per wavefront, blocks <= 128 rows) before those
+    uint32_t block_pairs_fast = 0;              // ... by block4_kernel.hip's first launch (four pairs per wavefront, blocks <= 256 rows)
+    uint32_t block_pairs_skew = 0;              // ... and by its skewed launches (one pair per wavefront, blocks <= 1024 / 4096 rows)
     // pairs this rank owns of a sharded run's merged lists (mmgpu_sw_prepare_owned / mmgpu_sw_gather_owned)
     bool owned = false;
     uint32_t o_stride = 0, o_cap = 0;
@@ -1324,7 +1324,7 @@ static int block_backtrace(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const uint32_t *pa
         j.slot = k;
         jobs.push_back(j);
         const uint64_t len = (uint64_t)h.q_end + 1 + (uint64_t)h.t_end + 1;
-        off += (len + 1 + 3) & ~3ull;      // (multiples of four: the walk kernel of block2_kernel.hip stores a string in dwords)
+        off += (len + 1 + 3) & ~3ull;      // (multiples of four: the walk kernel of block4_kernel.hip stores a string in dwords)
         longest = std::max(longest, len);
     }
     if (bt_used) *bt_used = (size_t)off;
@@ -1403,33 +1403,42 @@ static int block_backtrace(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const uint32_t *pa
     const int first_tier = first_tier_env ? std::max(0, std::min(2, atoi(first_tier_env))) : 0;
     b->block_pairs_tier[0] = b->block_pairs_tier[1] = b->block_pairs_tier[2] = 0;
     b->block_pairs_fast = 0;
-    // ---- block2_kernel.hip first: two pairs per wavefront, blocks up to 128 rows, sequence queries.  With a trace the pairs run in
-    // groups whose block lists + traces fit the pool (40 bytes per residue of the pair, the crate's usual 32 / 64-row blocks; a
-    // pair that needs more is answered TOO_LARGE like one whose blocks grow beyond 128 rows), each group = fill launch + walk launch
-    // on the context's stream, back to back ----
+    b->block_pairs_skew = 0;
+    // ---- block4_kernel.hip: sequence queries.  Launch 1: four pairs per wavefront, blocks up to 256 rows.  What it answers
+    // TOO_LARGE (blocks would grow further, or the trace overflowed the pair's slot) goes through the skewed form - one pair per
+    // wavefront, its rows pipelined over the columns - with blocks up to 1024 rows, then the crate's 4096; each launch starts at the
+    // minimum block size the one before got to (mmgpu_sw_block::reserved of a TOO_LARGE answer).  With a trace the pairs of a launch
+    // run in groups whose block lists + traces fit the pool, each group = fill launch + walk launch on the context's stream ----
     std::vector<BlockJob> slow_jobs;
     if (!first_tier_env) {
-        static const uint64_t block2_waves = getenv("MMGPU_BLOCK2_WAVES") ? strtoull(getenv("MMGPU_BLOCK2_WAVES"), nullptr, 10) : 16;      // per CU (tuning aid)
-        static const uint64_t block4_waves = getenv("MMGPU_BLOCK4_WAVES") ? strtoull(getenv("MMGPU_BLOCK4_WAVES"), nullptr, 10) : 16;
-        const bool use_block2 = getenv("MMGPU_BLOCK_KERNEL") && atoi(getenv("MMGPU_BLOCK_KERNEL")) == 2;      // A/B aid
-        static const uint64_t block4_per_res = getenv("MMGPU_BLOCK4_PER_RES") ? strtoull(getenv("MMGPU_BLOCK4_PER_RES"), nullptr, 10) : 48;      // trace bytes per residue of a pair
-        const bool block4_small = getenv("MMGPU_BLOCK4_ROWS") && atoi(getenv("MMGPU_BLOCK4_ROWS")) == 128;      // tuning aid
-        static const uint64_t pool2_limit = (getenv("MMGPU_BLOCK2_POOL_MB") ? strtoull(getenv("MMGPU_BLOCK2_POOL_MB"), nullptr, 10) : 3072ull) << 20;
-        DevBuf d_j2, d_cnt, d_pool2, d_ck;
-        d_j2.bind(c->cache); d_cnt.bind(c->cache); d_pool2.bind(c->cache); d_ck.bind(c->cache);
-        // one pass: `todo` (longest first) through sw_block2_kernel<trace, 2 or 8 chunks>; what it hands on is appended to `left`
-        auto block2_pass = [&](const std::vector<BlockJob> &todo, bool large, std::vector<BlockJob> &left) -> int {
-            std::vector<Block2Job> j2;
+        static const uint64_t block4_waves = getenv("MMGPU_BLOCK4_WAVES") ? strtoull(getenv("MMGPU_BLOCK4_WAVES"), nullptr, 10) : 16;      // per CU (tuning aid)
+        static const uint64_t block4_per_res = getenv("MMGPU_BLOCK4_PER_RES") ? strtoull(getenv("MMGPU_BLOCK4_PER_RES"), nullptr, 10) : 48;      // trace bytes per residue of a pair, launch 1
+        static const uint64_t pool2_limit = (getenv("MMGPU_BLOCK4_POOL_MB") ? strtoull(getenv("MMGPU_BLOCK4_POOL_MB"), nullptr, 10) : 3072ull) << 20;
+        struct PassBufs {      // what a launch in flight holds: two of them run side by side (the long head, everything else)
+            DevBuf j2, cnt, pool, ck;
+            hipStream_t st = nullptr;
+            std::vector<Block2Job> jobs;
+        } PB[2];
+        for (PassBufs &x : PB) { x.j2.bind(c->cache); x.cnt.bind(c->cache); x.pool.bind(c->cache); x.ck.bind(c->cache); }
+        PB[0].st = s;
+        hipStream_t head_stream = nullptr;
+        auto drop_head_stream = [&] { if (head_stream) { (void)hipStreamDestroy(head_stream); head_stream = nullptr; } };
+        std::vector<uint32_t> resume((size_t)n, 0u);      // per slot: the first minimum block size still to try (bit 16: only the slot was too small)
+#define B_TRY(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { drop_head_stream(); return fail(MMGPU_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__)); } } while (0)
+        // one launch: `todo` (longest first) through form 1 (four pairs per wavefront, 256 rows) or 3 (skewed, one pair per wavefront,
+        // 4096 rows), slots of `per_res` trace bytes per residue of the pair; pairs whose slot would not fit the pool go to `left`
+        auto block4_launch = [&](PassBufs &B, const std::vector<BlockJob> &todo, int form, uint64_t per_res, uint64_t margin, uint64_t waves_per_cu,
+                                 std::vector<BlockJob> &left) -> int {
+            std::vector<Block2Job> &j2 = B.jobs;
+            j2.clear();
             j2.reserve(todo.size());
             std::vector<uint32_t> group_begin(1, 0u);
             uint64_t pool_used = 0, pool_need = 0;
-            // bytes of trace per residue of the pair: a dword per row and octet = 0.5 byte per cell; 32 / 64-row blocks in the first
-            // pass (a pair that needs more is answered TOO_LARGE like one whose blocks grow beyond 128 rows), 512 rows in the second
-            const uint64_t per_res = use_block2 ? (large ? 256 : 40) : block4_per_res, margin = use_block2 ? (large ? 1024 : 256) : 512;
+            const int rows = form == 1 ? BLOCK4_LARGE_SIZE : BLOCK_REF_MAX_SIZE;
             for (const BlockJob &j : todo) {
                 Block2Job x;
                 x.query = j.query; x.target = j.target; x.score = j.score; x.q_end = j.q_end; x.t_end = j.t_end; x.slot = j.slot;
-                x.pool_off = 0; x.pool_bytes = 0; x.pad = 0;
+                x.pool_off = 0; x.pool_bytes = 0; x.pad = resume[j.slot] & 0xFFFFu;
                 if (!starts_only) {
                     const uint64_t len = pair_len(j);
                     const uint64_t bytes = (((len + 64) * sizeof(BkBlock) + 31) & ~31ull) + per_res * (len + margin);
@@ -1444,75 +1453,113 @@ static int block_backtrace(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const uint32_t *pa
             group_begin.push_back((uint32_t)j2.size());
             if (j2.empty()) return MMGPU_OK;
             const size_t n_groups = group_begin.size() - 1;
-            if (j2.size() * sizeof(Block2Job) > d_j2.bytes) HIP_TRY(d_j2.alloc(j2.size() * sizeof(Block2Job)));
-            if (n_groups * 4 > d_cnt.bytes) HIP_TRY(d_cnt.alloc(n_groups * 4));
-            if (pool_need > d_pool2.bytes) HIP_TRY(d_pool2.alloc((size_t)pool_need));
-            HIP_TRY(hipMemcpyAsync(d_j2.p, j2.data(), j2.size() * sizeof(Block2Job), hipMemcpyHostToDevice, s));
-            HIP_TRY(hipMemsetAsync(d_cnt.p, 0, n_groups * 4, s));
+            if (j2.size() * sizeof(Block2Job) > B.j2.bytes) B_TRY(B.j2.alloc(j2.size() * sizeof(Block2Job)));
+            if (n_groups * 4 > B.cnt.bytes) B_TRY(B.cnt.alloc(n_groups * 4));
+            if (pool_need > B.pool.bytes) B_TRY(B.pool.alloc((size_t)pool_need));
+            B_TRY(hipMemcpyAsync(B.j2.p, j2.data(), j2.size() * sizeof(Block2Job), hipMemcpyHostToDevice, B.st));
+            B_TRY(hipMemsetAsync(B.cnt.p, 0, n_groups * 4, B.st));
             Block2Launch L2;
             L2.q_res = L.q_res; L2.q_cb = L.q_cb; L2.q_off = L.q_off; L2.t_res = L.t_res; L2.t_off4 = L.t_off4;
             L2.scores = L.scores; L2.gap_open = L.gap_open; L2.gap_extend = L.gap_extend;
             L2.out = L.out; L2.bt_off = L.bt_off; L2.bt = no_strings ? nullptr : L.bt;
-            L2.pool = d_pool2.as<uint8_t>();
+            L2.pool = B.pool.as<uint8_t>();
             L2.growth = L.growth; L2.growth_cap = L.growth_cap;
-            L2.dbg = getenv("MMGPU_B2_DBG") ? (uint32_t)atoi(getenv("MMGPU_B2_DBG")) : 0u;
+            L2.trace_bytes = form == 1 ? 0u : 1u;
             for (size_t g = 0; g < n_groups; g++) {
-                L2.jobs = d_j2.as<Block2Job>() + group_begin[g];
+                L2.jobs = B.j2.as<Block2Job>() + group_begin[g];
                 L2.n_jobs = group_begin[g + 1] - group_begin[g];
-                L2.counter = d_cnt.as<uint32_t>() + g;
-                // (resident wavefronts: 16 per CU at 112 registers, 4 per CU at the 8-chunk form's ~290)
-                if (use_block2) {
-                    const uint32_t waves = (uint32_t)std::min<uint64_t>((L2.n_jobs + 1) / 2, (uint64_t)std::max(c->compute_units, 1) * (large ? 4 : block2_waves));
-                    HIP_TRY(launch_sw_block2(L2, !starts_only, large, waves, s));
-                    if (!starts_only) HIP_TRY(launch_sw_block2_walk(L2, s));
-                } else {
-                    // (resident wavefronts: 3.4 KB of score table + 4 / 8 KB of border arrays a wavefront)
-                    const uint32_t waves = (uint32_t)std::min<uint64_t>((L2.n_jobs + 3) / 4, (uint64_t)std::max(c->compute_units, 1) * block4_waves);
-                    const size_t ck_bytes = (size_t)waves * 4 * 8 * BLOCK4_LARGE_SIZE;
-                    if (ck_bytes > d_ck.bytes) HIP_TRY(d_ck.alloc(ck_bytes));
-                    L2.ck_pool = d_ck.as<uint8_t>();
-                    HIP_TRY(launch_sw_block4(L2, !starts_only, large, waves, s));
-                    if (!starts_only) HIP_TRY(launch_sw_block4_walk(L2, s));
-                }
+                L2.counter = B.cnt.as<uint32_t>() + g;
+                const uint32_t waves = (uint32_t)std::min<uint64_t>(form == 1 ? (L2.n_jobs + 3) / 4 : L2.n_jobs, (uint64_t)std::max(c->compute_units, 1) * waves_per_cu);
+                const size_t ck_bytes = (size_t)waves * (form == 1 ? 4 : 1) * 8 * (size_t)rows;
+                if (ck_bytes > B.ck.bytes) B_TRY(B.ck.alloc(ck_bytes));
+                L2.ck_pool = B.ck.as<uint8_t>();
+                B_TRY(launch_sw_block4(L2, !starts_only, form, waves, B.st));
+                if (!starts_only) B_TRY(launch_sw_block4_walk(L2, B.st));
             }
-            HIP_TRY(hipMemcpyAsync(out, d_out.p, (size_t)n * sizeof(mmgpu_sw_block), hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipStreamSynchronize(s));
-            if (trace_on) fprintf(stderr, "[mmgpu block aligner] two pairs per wavefront, blocks <= %d rows: %zu pairs in %zu group(s), pool %.1f MB\n",
-                                  large ? BLOCK2_LARGE_SIZE : BLOCK2_MAX_SIZE, j2.size(), n_groups, pool_need / 1048576.0);
-            for (const Block2Job &x : j2)
+            if (trace_on) fprintf(stderr, "[mmgpu block aligner] %s, blocks <= %d rows, %llu trace bytes per residue: %zu pairs in %zu group(s), pool %.1f MB\n",
+                                  form == 1 ? "four pairs per wavefront" : "one pair per wavefront, rows skewed over columns", rows, (unsigned long long)per_res,
+                                  j2.size(), n_groups, pool_need / 1048576.0);
+            return MMGPU_OK;
+        };
+        // ... and its end: the answers; what it handed on (MMGPU_BLOCK_TOO_LARGE) is appended to `left`
+        auto block4_collect = [&](PassBufs &B, std::vector<BlockJob> &left) -> int {
+            if (B.jobs.empty()) return MMGPU_OK;
+            B_TRY(hipStreamSynchronize(B.st));
+            B_TRY(hipMemcpy(out, d_out.p, (size_t)n * sizeof(mmgpu_sw_block), hipMemcpyDeviceToHost));
+            for (const Block2Job &x : B.jobs)
                 if (out[x.slot].status == MMGPU_BLOCK_TOO_LARGE) {
                     BlockJob j;
                     j.query = x.query; j.target = x.target; j.score = x.score; j.q_end = x.q_end; j.t_end = x.t_end; j.slot = x.slot;
+                    const uint32_t rs = (uint32_t)out[x.slot].reserved;
+                    resume[x.slot] = std::max(32u, std::min(rs & 0xFFFFu, (uint32_t)BLOCK_REF_MAX_SIZE)) | (rs & 0x10000u);
                     left.push_back(j);
                 }
+            B.jobs.clear();
             return MMGPU_OK;
         };
-        std::vector<BlockJob> seq_jobs, second;
-        for (const BlockJob &j : jobs) {
+        auto longest_first = [&](std::vector<BlockJob> &v) {
+            std::stable_sort(v.begin(), v.end(), [&](const BlockJob &x, const BlockJob &y) { return pair_len(x) > pair_len(y); });
+        };
+        std::vector<BlockJob> seq_jobs, head, rest, handed, again, skew, skew_again;
+        for (const BlockJob &j : jobs) {      // (`jobs` is sorted longest first)
             if (!b->h_query_is_profile.empty() && b->h_query_is_profile[j.query]) slow_jobs.push_back(j);
             else seq_jobs.push_back(j);
         }
         const size_t before = slow_jobs.size();
+        // The longest pairs - one per CU - go straight to the skewed form on a stream of their own, beside everything else: the pairs
+        // whose blocks grow to thousands of rows are among them, each a dependent chain of tens of milliseconds that nothing shortens
+        // but starting it first.
+        static const uint64_t head_per_cu = getenv("MMGPU_BLOCK4_HEAD") ? strtoull(getenv("MMGPU_BLOCK4_HEAD"), nullptr, 10) : 1;
+        const size_t n_head = seq_jobs.size() >= 4096 ? std::min<size_t>(seq_jobs.size() / 16, (size_t)std::max(c->compute_units, 1) * head_per_cu) : 0;
+        head.assign(seq_jobs.begin(), seq_jobs.begin() + n_head);
+        rest.assign(seq_jobs.begin() + n_head, seq_jobs.end());
         int rc2;
-        if (use_block2) {
-            rc2 = block2_pass(seq_jobs, false, second);
-            if (rc2 != MMGPU_OK) return rc2;
-            lap("two pairs per wavefront (blocks <= 128 rows) + status download");
-            std::stable_sort(second.begin(), second.end(), [&](const BlockJob &x, const BlockJob &y) { return pair_len(x) > pair_len(y); });
-            rc2 = block2_pass(second, true, slow_jobs);
-            if (rc2 != MMGPU_OK) return rc2;
-            if (!second.empty()) lap("two pairs per wavefront (blocks <= 512 rows) + status download");
-        } else {
-            rc2 = block2_pass(seq_jobs, !block4_small, slow_jobs);
-            if (rc2 != MMGPU_OK) return rc2;
-            lap("four pairs per wavefront + status download");
+        if (n_head) {
+            if (hipStreamCreateWithFlags(&head_stream, hipStreamNonBlocking) != hipSuccess) return fail(MMGPU_ERR_HIP, "mmgpu_sw_block_backtrace: hipStreamCreate");
+            PB[1].st = head_stream;
+            B_TRY(hipStreamSynchronize(s));      // (the uploads above)
+            rc2 = block4_launch(PB[1], head, 3, 1024, 2048, 4, skew_again);
+            if (rc2 != MMGPU_OK) { drop_head_stream(); return rc2; }
         }
-        std::stable_sort(slow_jobs.begin(), slow_jobs.end(), [&](const BlockJob &x, const BlockJob &y) { return pair_len(x) > pair_len(y); });
-        b->block_pairs_fast = (uint32_t)(seq_jobs.size() - (slow_jobs.size() - before));
+        // launch 1: everything else, slots for the usual 32 / 64-row blocks (half a byte per cell).  Resident wavefronts by LDS: 3.4 KB of
+        // score table + 8 KB (four pairs' border arrays); the skewed form's 32 KB allow four
+        rc2 = block4_launch(PB[0], rest, 1, block4_per_res, 512, block4_waves, skew);
+        if (rc2 == MMGPU_OK) rc2 = block4_collect(PB[0], handed);
+        if (rc2 != MMGPU_OK) { drop_head_stream(); return rc2; }
+        lap("four pairs per wavefront + status download");
+        // ... once more for the pairs whose slot was too small (256-row blocks all the way: 128 bytes per residue)
+        for (const BlockJob &j : handed) (resume[j.slot] & 0x10000u ? again : skew).push_back(j);
+        if (!again.empty()) {
+            longest_first(again);
+            rc2 = block4_launch(PB[0], again, 1, 160, 2048, block4_waves, skew);
+            if (rc2 == MMGPU_OK) rc2 = block4_collect(PB[0], skew);
+            if (rc2 != MMGPU_OK) { drop_head_stream(); return rc2; }
+            lap("four pairs per wavefront, larger slots + status download");
+        }
+        // launch 2: the skewed form for blocks beyond 256 rows (a byte per cell: slots for blocks of 1024 rows, then the crate's bound)
+        longest_first(skew);
+        rc2 = block4_launch(PB[0], skew, 3, 1024, 2048, 4, skew_again);
+        if (rc2 == MMGPU_OK) rc2 = block4_collect(PB[0], skew_again);
+        if (rc2 == MMGPU_OK && n_head) rc2 = block4_collect(PB[1], skew_again);
+        if (rc2 != MMGPU_OK) { drop_head_stream(); return rc2; }
+        if (!skew.empty() || n_head) lap("skewed form (and the head) + status download");
+        const size_t n_skew = skew.size() + n_head;
+        if (!skew_again.empty()) {
+            longest_first(skew_again);
+            rc2 = block4_launch(PB[0], skew_again, 3, 4096, 8192, 4, slow_jobs);
+            if (rc2 == MMGPU_OK) rc2 = block4_collect(PB[0], slow_jobs);
+            if (rc2 != MMGPU_OK) { drop_head_stream(); return rc2; }
+            lap("skewed form, the crate's slots + status download");
+        }
+        drop_head_stream();
+#undef B_TRY
+        longest_first(slow_jobs);
+        b->block_pairs_skew = (uint32_t)(n_skew - (slow_jobs.size() - before));
+        b->block_pairs_fast = (uint32_t)(seq_jobs.size() - n_skew);
     } else {
         slow_jobs = jobs;
     }
-    // (what block2_kernel.hip handed on grows beyond 512 rows: tier 0's slots sized for blocks of 512 rows along the whole pair)
+    // (what is left: profile queries, pairs whose slot would not fit the pool)
     const uint64_t tier0_entries = first_tier_env ? 2 : BLOCK_MAX_SIZE / 64;
     std::vector<BlockJob> wait[3];      // longest first inside each
     if (!slow_jobs.empty()) typical_len = pair_len(slow_jobs[slow_jobs.size() > 1024 ? 255 : 0]);
@@ -1592,7 +1639,7 @@ extern "C" int mmgpu_sw_block_growth(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const ui
 extern "C" int mmgpu_sw_block_tiers(const mmgpu_sw_batch_t *b, uint32_t *first_tier, uint32_t *second_tier) {
     if (!b) return fail(MMGPU_ERR_ARG, "mmgpu_sw_block_tiers: NULL batch");
     if (first_tier) *first_tier = b->block_pairs_fast + b->block_pairs_tier[0];
-    if (second_tier) *second_tier = b->block_pairs_tier[1] + b->block_pairs_tier[2];
+    if (second_tier) *second_tier = b->block_pairs_skew + b->block_pairs_tier[1] + b->block_pairs_tier[2];
     return MMGPU_OK;
 }
 

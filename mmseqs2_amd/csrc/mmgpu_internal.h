@@ -447,7 +447,6 @@ hipError_t launch_tantan_mask(const TantanArgs &A, hipStream_t s);
 // code-object loading ahead of the first launch (mmgpu_warmup)
 void warm_sw();
 void warm_block();
-void warm_block2();
 void warm_pf();
 void warm_ix();
 void warm_tantan();
@@ -526,16 +525,14 @@ struct BlockLaunch {
 hipError_t launch_sw_block(const BlockLaunch &L, int tier, hipStream_t stream);
 struct BkBlock { uint32_t i, j; uint16_t h, w; uint32_t right, tstart; };   // Trace::block_start / block_size / right + the block's first trace entry
 
-// ---- the same aligner, two pairs per wavefront, border arrays in registers (block2_kernel.hip): sequence queries, blocks up to
-// BLOCK2_MAX_SIZE rows; what it answers MMGPU_BLOCK_TOO_LARGE goes to the tiers above ----
-constexpr int BLOCK2_MAX_SIZE = 128;     // the launch every pair starts in
-constexpr int BLOCK2_LARGE_SIZE = 512;   // the launch for what that one answered MMGPU_BLOCK_TOO_LARGE
+// ---- the same aligner, four pairs per wavefront (block4_kernel.hip): sequence queries; what a launch answers MMGPU_BLOCK_TOO_LARGE
+// goes to the next form ----
 struct Block2Job {
     uint32_t query, target;
     int32_t score, q_end, t_end;
     uint32_t slot;                // index into out / bt_off
     uint64_t pool_off;            // the pair's scratch (block list + trace) in the pool; unused without a trace
-    uint32_t pool_bytes, pad;
+    uint32_t pool_bytes, pad;     // pad: block4_kernel.hip - the first minimum block size to try (0 = 32)
 };
 struct Block2Launch {
     const Block2Job *jobs;
@@ -554,16 +551,15 @@ struct Block2Launch {
     uint8_t *pool;
     uint32_t *growth = nullptr;   // test aid, as BlockLaunch::growth
     uint32_t growth_cap = 0;
-    uint32_t dbg = 0;
-    uint8_t *ck_pool = nullptr;   // block4_kernel.hip: checkpoint arrays, 8 * rows bytes per row of a wavefront (4 rows a wavefront)
+    uint8_t *ck_pool = nullptr;   // block4_kernel.hip: checkpoint arrays, 8 * rows bytes per row of a wavefront (4 rows a wavefront; skewed form: one)
+    uint32_t trace_bytes = 0;     // walk kernel: the trace is the skewed form's (a byte per cell)
 };
 // trace = false: start positions only (no scratch, no walk)
-hipError_t launch_sw_block2(const Block2Launch &L, bool trace, bool large, uint32_t n_waves, hipStream_t stream);
-hipError_t launch_sw_block2_walk(const Block2Launch &L, hipStream_t stream);
 // ---- four pairs per wavefront, one 16-lane DPP row = one vector of the crate = one pair (block4_kernel.hip); same launch record ----
 constexpr int BLOCK4_MAX_SIZE = 128;     // (tuning aid: MMGPU_BLOCK4_ROWS=128) 1 KB of LDS per pair
 constexpr int BLOCK4_LARGE_SIZE = 256;   // the default: 2 KB of LDS per pair
-hipError_t launch_sw_block4(const Block2Launch &L, bool trace, bool large, uint32_t n_waves, hipStream_t stream);
+constexpr int BLOCK4_SKEW_SIZE = 1024;   // the skewed form (one pair per wavefront, rows pipelined over columns): first launch; the second holds BLOCK_REF_MAX_SIZE
+hipError_t launch_sw_block4(const Block2Launch &L, bool trace, int form, uint32_t n_waves, hipStream_t stream);
 hipError_t launch_sw_block4_walk(const Block2Launch &L, hipStream_t stream);
 void warm_block4();
 
