@@ -126,6 +126,11 @@ typedef struct {
 
 #define MMGPU_SW_SCORE_END 0 /* Matcher::SCORE_ONLY: score + end positions */
 #define MMGPU_SW_START 1     /* + start positions (alignStartPosBacktrace's reverse scan) */
+#define MMGPU_SW_START_NOT_WORD 2 /* + start positions for the hits of the reference's uint8 pass only (word == 0).  ssw_align_private
+                                     takes the start of an int16-range hit (word == 1) from the block aligner and scans backwards
+                                     only when that declines (StripedSmithWaterman.cpp:865-882): such pairs keep q_start = t_start
+                                     = -1 here, mmgpu_sw_block_backtrace supplies their start positions, and the ones it answers
+                                     MMGPU_BLOCK_DECLINED get their reverse scan from mmgpu_sw_reverse_pairs */
 
 /* One call = the hit loop of Alignment::run (:346-397) for nq queries: for every (query, target) pair
  * the forward Gotoh scan (alignScoreEndPos, StripedSmithWaterman.cpp:892-941) and, with MMGPU_SW_START,
@@ -157,6 +162,11 @@ int mmgpu_sw_prepare_from_lists(mmgpu_ctx *ctx, const mmgpu_sw_params *params, c
                                 int mode, const void *d_hits, const void *d_counts, uint32_t stride, mmgpu_sw_batch_t **batch);
 int mmgpu_sw_run(mmgpu_ctx *ctx, mmgpu_sw_batch_t *batch);
 int mmgpu_sw_fetch(mmgpu_ctx *ctx, mmgpu_sw_batch_t *batch, mmgpu_sw_hit *out);
+/* The reverse scan (StripedSmithWaterman.cpp:1129-1204) after the fact, for exactly the pairs named (indices into the batch's result
+ * array): the fall-back of :873-882 for int16-range hits of a MMGPU_SW_START_NOT_WORD batch the block aligner declined.  The forward
+ * results stay; q_start / t_start of the named pairs are filled in the batch (later mmgpu_sw_fetch / mmgpu_sw_traceback calls see
+ * them) and, when out != NULL, the n records are copied to out[0..n) in pair_index order.  Synchronises. */
+int mmgpu_sw_reverse_pairs(mmgpu_ctx *ctx, mmgpu_sw_batch_t *batch, const uint32_t *pair_index, uint32_t n_pairs, mmgpu_sw_hit *out);
 /* Same results, copied device -> device into caller-owned device memory (the multi-GPU result exchange works on
  * device tensors); asynchronous on the context's stream. */
 int mmgpu_sw_fetch_device(mmgpu_ctx *ctx, mmgpu_sw_batch_t *batch, void *d_out);

@@ -32,17 +32,18 @@ public:
         strings.assign((size_t)need, '\0');
         return mmgpu_sw_traceback(gpu, batch, pairIndex, n, info, &strings[0], need, &need);
     }
-    int blockBacktrace(const uint32_t *pairIndex, uint32_t n, mmgpu_sw_block *out, std::string &strings, bool wantStrings) {
+    int blockBacktrace(const uint32_t *pairIndex, uint32_t n, mmgpu_sw_block *out, std::string &strings, int want) {
         size_t need = 0;
-        if (!wantStrings) {
+        if (want != BLOCK_STRINGS) {
             strings.clear();
-            return mmgpu_sw_block_backtrace(gpu, batch, pairIndex, n, out, NULL, MMGPU_BLOCK_NO_STRINGS, &need);
+            return mmgpu_sw_block_backtrace(gpu, batch, pairIndex, n, out, NULL, want == BLOCK_STARTS ? MMGPU_BLOCK_STARTS_ONLY : MMGPU_BLOCK_NO_STRINGS, &need);
         }
         int rc = mmgpu_sw_block_backtrace(gpu, batch, pairIndex, n, out, NULL, 0, &need);
         if (rc != 0 && need == 0) return rc;
         strings.assign((size_t)need, '\0');
         return mmgpu_sw_block_backtrace(gpu, batch, pairIndex, n, out, need ? &strings[0] : NULL, need, &need);
     }
+    int reversePairs(const uint32_t *pairIndex, uint32_t n, mmgpu_sw_hit *out) { return mmgpu_sw_reverse_pairs(gpu, batch, pairIndex, n, out); }
     const char *lastError() { return mmgpu_last_error(); }
 
 private:
@@ -99,9 +100,19 @@ public:
     int traceback(const uint32_t *pairIndex, uint32_t n, mmgpu_sw_bt *info, std::string &strings) {
         return split<mmgpu_sw_bt>(pairIndex, n, info, strings, true);
     }
-    int blockBacktrace(const uint32_t *pairIndex, uint32_t n, mmgpu_sw_block *out, std::string &strings, bool wantStrings) {
-        (void)wantStrings;      // (several devices: the strings are always collected)
+    int blockBacktrace(const uint32_t *pairIndex, uint32_t n, mmgpu_sw_block *out, std::string &strings, int want) {
+        blockWant = want;
         return split<mmgpu_sw_block>(pairIndex, n, out, strings, false);
+    }
+    int reversePairs(const uint32_t *pairIndex, uint32_t n, mmgpu_sw_hit *out) {
+        for (uint32_t k = 0; k < n; k++) {      // (a handful of pairs per block at most)
+            size_t d = 0;
+            while (d + 1 < gpus.size() && pairIndex[k] >= firstPair[d + 1]) d++;
+            const uint32_t local = (uint32_t)(pairIndex[k] - firstPair[d]);
+            const int rc = mmgpu_sw_reverse_pairs(gpus[d], batches[d], &local, 1, out + k);
+            if (rc != 0) return rc;
+        }
+        return 0;
     }
     const char *lastError() { return mmgpu_last_error(); }
 
@@ -121,10 +132,16 @@ private:
             if (local[d].empty()) continue;
             std::vector<R> part(local[d].size());
             size_t need = 0;
-            int rc = call(d, local[d], part.data(), NULL, 0, &need, banded);
-            if (rc != 0 && need == 0) return rc;
-            std::string s(need, '\0');
-            rc = call(d, local[d], part.data(), need ? &s[0] : NULL, need, &need, banded);
+            std::string s;
+            int rc;
+            if (!banded && blockWant != BLOCK_STRINGS) {      // no strings wanted: one call
+                rc = call(d, local[d], part.data(), NULL, blockWant == BLOCK_STARTS ? MMGPU_BLOCK_STARTS_ONLY : MMGPU_BLOCK_NO_STRINGS, &need, banded);
+            } else {
+                rc = call(d, local[d], part.data(), NULL, 0, &need, banded);
+                if (rc != 0 && need == 0) return rc;
+                s.assign(need, '\0');
+                rc = call(d, local[d], part.data(), need ? &s[0] : NULL, need, &need, banded);
+            }
             if (rc != 0) return rc;
             const uint64_t base = strings.size();
             strings += s;
@@ -144,6 +161,7 @@ private:
     std::vector<mmgpu_ctx *> gpus;
     std::vector<mmgpu_sw_batch_t *> batches;
     std::vector<uint64_t> firstPair;
+    int blockWant = BLOCK_STRINGS;
 };
 
 MMGpuAlignBackend *mmgpuNewMultiDeviceBackend(const std::vector<mmgpu_ctx *> &gpus) { return new MMGpuMultiDeviceBackend(gpus); }

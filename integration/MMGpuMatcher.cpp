@@ -52,6 +52,7 @@ struct Pending {
     bool blockDone;        // start / backtrace / identities came from the host's block aligner
     bool refuse;           // the pair is recomputed by the host's Matcher (profile query in block-aligner range)
     bool needsBlock;       // int16-range pair that passed the gates: waits for the device's block aligner
+    bool needsReverse;     // ... which declined it: the pair's reverse scan is run after the fact
     int32_t blockBt;       // index of the pair's block-aligner backtrace in the call's string store, -1 = none (a block of 10 000
                            // queries holds 3 M of these records, one in twelve with a string: the record itself stays plain data)
     uint32_t blockBtLen;   // its length when the string itself was not fetched
@@ -139,7 +140,9 @@ bool MMGpuMatcher::alignBlock(const std::vector<Query> &queries, int covMode, fl
     // pair p of the block is pair devPair[p] of the device batch (the same without host queries)
     std::vector<uint32_t> devPair;
     std::vector<mmgpu_sw_hit> hits(total);
-    const int mode = alignmentMode == Matcher::SCORE_ONLY ? MMGPU_SW_SCORE_END : MMGPU_SW_START;
+    // With the block aligner on the device the reverse scan runs for the hits of the uint8 pass only: an int16-range hit takes its start
+    // position from the block aligner (StripedSmithWaterman.cpp:865-882), and the few it declines get their scan afterwards (below)
+    const int mode = alignmentMode == Matcher::SCORE_ONLY ? MMGPU_SW_SCORE_END : (deviceBlockAligner ? MMGPU_SW_START_NOT_WORD : MMGPU_SW_START);
     if (nHost == 0) {
         if (total && backend->align(&par, dq.data(), (uint32_t)nq, mode, hits.data()) != 0) {
             err = backend->lastError();
@@ -199,6 +202,7 @@ bool MMGpuMatcher::alignBlock(const std::vector<Query> &queries, int covMode, fl
             pe.blockBtLen = 0;
             pe.blockDone = false;
             pe.needsBlock = false;
+            pe.needsReverse = false;
             pe.refuse = hostQuery[q] != 0;
             if (a.dbEndPos1 != -1 && !pe.refuse) {
                 a.qCov = SmithWaterman::computeCov(0, a.qEndPos1, qlen);
@@ -258,7 +262,9 @@ bool MMGpuMatcher::alignBlock(const std::vector<Query> &queries, int covMode, fl
             }
         std::vector<mmgpu_sw_block> blk(blkPairs.size());
         std::string blkStrings;
-        if (!blkPairs.empty() && backend->blockBacktrace(blkPairs.data(), (uint32_t)blkPairs.size(), blk.data(), blkStrings, needBacktraceStrings) != 0) {
+        if (!blkPairs.empty() && backend->blockBacktrace(blkPairs.data(), (uint32_t)blkPairs.size(), blk.data(), blkStrings,
+                                                         needBacktraceStrings ? MMGpuAlignBackend::BLOCK_STRINGS
+                                                                              : (alignmentMode == Matcher::SCORE_COV_SEQID ? MMGpuAlignBackend::BLOCK_IDENT : MMGpuAlignBackend::BLOCK_STARTS)) != 0) {
             err = backend->lastError();
             return false;
         }
@@ -312,14 +318,35 @@ bool MMGpuMatcher::alignBlock(const std::vector<Query> &queries, int covMode, fl
                     continue;
                 }
             }
-            // DECLINED (or the host's block aligner declined as well): alignStartPosBacktrace (:1129-1258)
-            const mmgpu_sw_hit &h = hits[p];
-            a.qStartPos1 = h.q_start;
-            a.dbStartPos1 = h.t_start;
-            a.qCov = SmithWaterman::computeCov(a.qStartPos1, a.qEndPos1, qlen);
-            a.tCov = SmithWaterman::computeCov(a.dbStartPos1, a.dbEndPos1, dbLen);
-            const bool lowCov2 = !Util::hasCoverage(covThr, covMode, a.qCov, a.tCov);
-            if (!(alignmentMode == 1 || lowCov2)) pe.wantsBacktrace = true;
+            pe.needsReverse = true;      // DECLINED (or the host's block aligner declined as well)
+        }
+        // alignStartPosBacktrace (:1129-1258) for those: the batch ran without their reverse scan (MMGPU_SW_START_NOT_WORD)
+        std::vector<uint32_t> revPairs, revBlockPair;
+        for (size_t k = 0; k < blkBlockPair.size(); k++)
+            if (aln[blkBlockPair[k]].needsReverse) {
+                revPairs.push_back(blkPairs[k]);
+                revBlockPair.push_back(blkBlockPair[k]);
+            }
+        if (!revPairs.empty()) {
+            std::vector<mmgpu_sw_hit> rev(revPairs.size());
+            if (backend->reversePairs(revPairs.data(), (uint32_t)revPairs.size(), rev.data()) != 0) {
+                err = backend->lastError();
+                return false;
+            }
+            for (size_t k = 0; k < revBlockPair.size(); k++) {
+                const size_t p = revBlockPair[k];
+                Pending &pe = aln[p];
+                const size_t q = pairQuery[p];
+                const int qlen = queries[q].L, dbLen = queries[q].targets[pairTarget[p]].length;
+                hits[p] = rev[k];
+                s_align &a = pe.a;
+                a.qStartPos1 = rev[k].q_start;
+                a.dbStartPos1 = rev[k].t_start;
+                a.qCov = SmithWaterman::computeCov(a.qStartPos1, a.qEndPos1, qlen);
+                a.tCov = SmithWaterman::computeCov(a.dbStartPos1, a.dbEndPos1, dbLen);
+                const bool lowCov2 = !Util::hasCoverage(covThr, covMode, a.qCov, a.tCov);
+                if (!(alignmentMode == 1 || lowCov2)) pe.wantsBacktrace = true;
+            }
         }
         watch.lap("device block aligner (int16-range pairs)");
     }

@@ -30,20 +30,29 @@ class MMGpuAlignBackend {
 public:
     virtual ~MMGpuAlignBackend() {}
     // forward scan of every (query, target) pair, reverse scan (start positions) for the pairs reaching the query's
-    // min_start_score when mode == MMGPU_SW_START; out = sum of n_targets records, query-major, list order
+    // min_start_score when mode >= MMGPU_SW_START (MMGPU_SW_START_NOT_WORD: of those, the hits of the uint8 pass only); out = sum of n_targets records, query-major, list order
     virtual int align(const mmgpu_sw_params *params, const mmgpu_sw_query *queries, uint32_t nQueries, int mode,
                       mmgpu_sw_hit *out) = 0;
     // backtraces (banded_sw + walk) of pairs of the last align() call, by index into its result array
     virtual int traceback(const uint32_t *pairIndex, uint32_t n, mmgpu_sw_bt *info, std::string &strings) = 0;
     // the block aligner's start positions / identities / backtraces of int16-range pairs of the last align() call
-    // (mmgpu_sw_block_backtrace); the default says "not here" for every pair, which sends them to the host's block aligner
-    // wantStrings == false: only start positions, identities and lengths are needed (a run that writes no backtraces)
-    virtual int blockBacktrace(const uint32_t *pairIndex, uint32_t n, mmgpu_sw_block *out, std::string &strings, bool wantStrings = true) {
+    // (mmgpu_sw_block_backtrace); the default says "not here" for every pair, which sends them to the host's block aligner.
+    // want: BLOCK_STRINGS = everything; BLOCK_IDENT = start positions, identities and lengths (a run that writes no backtraces);
+    // BLOCK_STARTS = start positions only (alignment mode 2 without backtraces: Matcher.cpp:107-127 reads nothing else)
+    enum { BLOCK_STARTS = 0, BLOCK_IDENT = 1, BLOCK_STRINGS = 2 };
+    virtual int blockBacktrace(const uint32_t *pairIndex, uint32_t n, mmgpu_sw_block *out, std::string &strings, int want = BLOCK_STRINGS) {
         (void)pairIndex;
-        (void)wantStrings;
+        (void)want;
         strings.clear();
         for (uint32_t k = 0; k < n; k++) { memset(&out[k], 0, sizeof(out[k])); out[k].status = MMGPU_BLOCK_TOO_LARGE; }
         return 0;
+    }
+    // align() was called with MMGPU_SW_START_NOT_WORD (only a backend with a block aligner is): the reverse scan of these pairs of
+    // the last align() call after the fact - the ones the block aligner declined (StripedSmithWaterman.cpp:873-882); out[k] = the
+    // pair's record with its start position
+    virtual int reversePairs(const uint32_t *pairIndex, uint32_t n, mmgpu_sw_hit *out) {
+        (void)pairIndex; (void)n; (void)out;
+        return -1;
     }
     virtual const char *lastError() = 0;
 };

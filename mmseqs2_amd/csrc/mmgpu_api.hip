@@ -590,7 +590,7 @@ static int sw_prepare_impl(mmgpu_ctx *c, const mmgpu_sw_params *par, const mmgpu
         prep_mark = t;
     };
     if (par->alphabet != c->db.alphabet) return fail(MMGPU_ERR_ARG, "mmgpu_sw_prepare: alphabet differs from the loaded targets");
-    if (mode != MMGPU_SW_SCORE_END && mode != MMGPU_SW_START) return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_sw_prepare: unknown mode");
+    if (mode != MMGPU_SW_SCORE_END && mode != MMGPU_SW_START && mode != MMGPU_SW_START_NOT_WORD) return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_sw_prepare: unknown mode");
     if (par->gap_open < par->gap_extend || par->gap_extend < 0 || par->gap_open > 32767)
         return fail(MMGPU_ERR_ARG, "mmgpu_sw_prepare: need 0 <= gap_extend <= gap_open");
     // The cell-by-cell recurrence equals the reference's striped lazy-F result only if opening a gap right after
@@ -903,7 +903,7 @@ static int sw_prepare_impl(mmgpu_ctx *c, const mmgpu_sw_params *par, const mmgpu
     auto alloc_scratch = [&](uint32_t longest) -> hipError_t {
         b->scratch_cols = longest + 16;
         b->scratch_slots = std::min<uint32_t>(std::max<uint32_t>(std::max<uint32_t>(n_multi, (uint32_t)rev_jobs.size()), 1),
-                                              sw_multi_resident_blocks(b->group_lds[SW_GROUPS - 1], mode == MMGPU_SW_START, c->compute_units));
+                                              sw_multi_resident_blocks(b->group_lds[SW_GROUPS - 1], mode >= MMGPU_SW_START, c->compute_units));
         hipError_t e = b->d_scratch.alloc((size_t)b->scratch_slots * 4 * 4 * 2 * (size_t)b->scratch_cols * sizeof(uint2));
         if (e != hipSuccess) return e;
         e = b->d_scratch_busy.alloc((size_t)b->scratch_slots * 4);
@@ -1122,16 +1122,9 @@ extern "C" int mmgpu_sw_fetch_owned(mmgpu_ctx *c, mmgpu_sw_batch_t *b, mmgpu_sw_
     return MMGPU_OK;
 }
 
-extern "C" int mmgpu_sw_run(mmgpu_ctx *c, mmgpu_sw_batch_t *b) {
-    if (!c || !b) return fail(MMGPU_ERR_ARG, "mmgpu_sw_run: NULL argument");
-    HIP_TRY(hipSetDevice(c->device));
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    if (b->events.size() < 256) {
-        HIP_TRY(hipEventCreate(&ev0));
-        HIP_TRY(hipEventCreate(&ev1));
-        b->events.push_back(std::make_pair(ev0, ev1));
-        HIP_TRY(hipEventRecord(ev0, c->stream));
-    }
+// The kernel groups of a batch, forked from / joined to the context's stream.  rev_only: the forward results are in d_out, only
+// the reverse scan of the pairs flagged in rev_force runs (mmgpu_sw_reverse_pairs).
+static int sw_launch_groups(mmgpu_ctx *c, mmgpu_sw_batch_t *b, bool rev_only, const uint8_t *rev_force) {
     // one launch per kernel group (jobs longest first); the groups run concurrently on side streams forked from /
     // joined to the context's stream.  With start positions asked for, a workgroup runs the reverse scan of its
     // pairs right after their forward scan (it reads the forward results of its own pairs only).
@@ -1180,15 +1173,18 @@ extern "C" int mmgpu_sw_run(mmgpu_ctx *c, mmgpu_sw_batch_t *b) {
             L.scratch_cols = b->scratch_cols;
             L.scratch_busy = b->d_scratch_busy.as<uint32_t>();
             L.scratch_slots = std::max<uint32_t>(b->scratch_slots, 1);
-            HIP_TRY(launch_sw(L, g, b->group_lds[g], b->mode == MMGPU_SW_START, st));
-            if (g == SW_GROUPS - 1 && b->n_rev_jobs && b->mode == MMGPU_SW_START) {   // reads the forward results of this stream's kernel
+            L.rev_mode = rev_only ? 2 : (b->mode == MMGPU_SW_START_NOT_WORD ? 1 : 0);
+            L.rev_only = rev_only ? 1 : 0;
+            L.rev_force = rev_force;
+            HIP_TRY(launch_sw(L, g, b->group_lds[g], b->mode >= MMGPU_SW_START, st));
+            if (g == SW_GROUPS - 1 && b->n_rev_jobs && b->mode >= MMGPU_SW_START) {   // reads the forward results of this stream's kernel
                 SwLaunch Rv = L;
                 Rv.jobs = b->d_jobs.as<SwJob>() + b->n_jobs;
                 Rv.n_jobs = b->n_rev_jobs;
                 HIP_TRY(launch_sw_rev_multi(Rv, b->group_lds[g], st));
             }
             if (getenv("MMGPU_TRACE")) {   // debugging aid: run the groups one at a time and say which one is in flight
-                fprintf(stderr, "[sw_run] group %d jobs %u lds %zu both %d from_pf %d scratch_cols %u\n", g, L.n_jobs, b->group_lds[g], (int)(b->mode == MMGPU_SW_START), (int)b->from_pf, b->scratch_cols);
+                fprintf(stderr, "[sw_run] group %d jobs %u lds %zu both %d from_pf %d scratch_cols %u\n", g, L.n_jobs, b->group_lds[g], (int)(b->mode >= MMGPU_SW_START), (int)b->from_pf, b->scratch_cols);
                 fflush(stderr);
                 const auto t0 = std::chrono::steady_clock::now();
                 hipError_t e = hipStreamSynchronize(st);
@@ -1202,9 +1198,53 @@ extern "C" int mmgpu_sw_run(mmgpu_ctx *c, mmgpu_sw_batch_t *b) {
         HIP_TRY(hipEventRecord(c->join[k], c->side[k]));
         HIP_TRY(hipStreamWaitEvent(c->stream, c->join[k], 0));
     }
+    return MMGPU_OK;
+}
+
+extern "C" int mmgpu_sw_run(mmgpu_ctx *c, mmgpu_sw_batch_t *b) {
+    if (!c || !b) return fail(MMGPU_ERR_ARG, "mmgpu_sw_run: NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (b->events.size() < 256) {
+        HIP_TRY(hipEventCreate(&ev0));
+        HIP_TRY(hipEventCreate(&ev1));
+        b->events.push_back(std::make_pair(ev0, ev1));
+        HIP_TRY(hipEventRecord(ev0, c->stream));
+    }
+    if (int e = sw_launch_groups(c, b, false, nullptr)) return e;
     if (ev1) HIP_TRY(hipEventRecord(ev1, c->stream));
     b->ran = true;
     b->h_res_valid = false;
+    return MMGPU_OK;
+}
+
+// Start positions after the fact for the pairs the caller names (MMGPU_SW_START_NOT_WORD batches: the int16-range hits the block
+// aligner declined, StripedSmithWaterman.cpp:873-882 "Block alignment failed" -> alignStartPosBacktrace): the reverse scan of
+// exactly those pairs, the forward results staying as they are.
+extern "C" int mmgpu_sw_reverse_pairs(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const uint32_t *pair_index, uint32_t n, mmgpu_sw_hit *out) {
+    if (!c || !b || (!pair_index && n)) return fail(MMGPU_ERR_ARG, "mmgpu_sw_reverse_pairs: NULL argument");
+    if (!b->ran) return fail(MMGPU_ERR_STATE, "mmgpu_sw_reverse_pairs: batch was never run");
+    if (b->mode < MMGPU_SW_START) return fail(MMGPU_ERR_STATE, "mmgpu_sw_reverse_pairs: the batch was prepared without a start-position mode");
+    if (b->owned) return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_sw_reverse_pairs: not for batches of owned pairs (sharded runs)");
+    if (n == 0) return MMGPU_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    std::vector<uint8_t> flags((size_t)b->pairs, (uint8_t)0);
+    for (uint32_t k = 0; k < n; k++) {
+        if (pair_index[k] >= b->pairs) return fail(MMGPU_ERR_ARG, "mmgpu_sw_reverse_pairs: pair index out of range");
+        flags[pair_index[k]] = 1;
+    }
+    DevBuf d_flags;
+    d_flags.bind(c->cache);
+    HIP_TRY(d_flags.alloc(flags.size()));
+    HIP_TRY(hipMemcpyAsync(d_flags.p, flags.data(), flags.size(), hipMemcpyHostToDevice, c->stream));
+    if (int e = sw_launch_groups(c, b, true, d_flags.as<uint8_t>())) return e;
+    if (out)
+        for (uint32_t k = 0; k < n; k++)
+            HIP_TRY(hipMemcpyAsync(out + k, b->d_out.as<mmgpu_sw_hit>() + pair_index[k], sizeof(mmgpu_sw_hit), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));      // (the flags die with this scope)
+    if (b->h_res_valid)      // the host copy mmgpu_sw_traceback / mmgpu_sw_block_backtrace read
+        for (uint32_t k = 0; k < n; k++)
+            HIP_TRY(hipMemcpy(&b->h_res[pair_index[k]], b->d_out.as<mmgpu_sw_hit>() + pair_index[k], sizeof(mmgpu_sw_hit), hipMemcpyDeviceToHost));
     return MMGPU_OK;
 }
 

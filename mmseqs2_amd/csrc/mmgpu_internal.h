@@ -80,6 +80,12 @@ struct SwLaunch {
     // fused hand-over from a prefilter batch: hits of query q live in slots [q * hit_stride, + q_hit_count[q])
     const uint32_t *q_hit_count;   // null for caller-supplied lists
     uint32_t hit_stride;
+    // which pairs get a reverse scan (sw_rev_wanted, sw_kernel.hip): 0 = score >= q_minstart (MMGPU_SW_START); 1 = ... and word == 0
+    // (MMGPU_SW_START_NOT_WORD: the start of an int16-range hit comes from the block aligner); 2 = the pairs flagged in rev_force,
+    // indexed like out[] (mmgpu_sw_reverse_pairs).  rev_only: the forward results are in out[] already, only the reverse scan runs.
+    int rev_mode = 0;
+    int rev_only = 0;
+    const uint8_t *rev_force = nullptr;
 };
 
 constexpr int SW_PF_MAX_LIST = 4096;   // == PF_MAX_HITS

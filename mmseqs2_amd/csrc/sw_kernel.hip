@@ -110,6 +110,17 @@ __device__ __forceinline__ void build_profile(unsigned char *lds, const uint8_t 
     }
 }
 
+// Does the pair whose forward result sits in out[slot] get a reverse scan?  ssw_align_private scans backwards for the start
+// position when the score passes the E-value gate (StripedSmithWaterman.cpp:857-863) - and, in the reference's alignment modes with a
+// start position, only for hits of the uint8 pass: an int16-range hit (word == 1) takes its start from the block aligner (:865-882),
+// falling back to the reverse scan when that declines (rev_mode 2: the caller names those pairs afterwards).
+__device__ __forceinline__ bool sw_rev_wanted(const SwLaunch &L, uint32_t slot, int min_start) {
+    const mmgpu_sw_hit &f = L.out[slot];
+    const int s = f.score;
+    if (L.rev_mode == 2) return s > 0 && L.rev_force[slot] != 0;
+    return s > 0 && s >= min_start && !(L.rev_mode == 1 && f.word != 0);
+}
+
 constexpr int SW_REV_JOB_HITS = 1024;   // most hits a reverse-scan job may hold (mmgpu_internal.h: SW_REV_JOB_MAX)
 static_assert(SW_REV_JOB_HITS == SW_REV_JOB_MAX, "host and kernel disagree on the reverse job size");
 constexpr int SW_LDS_HEADER = SW_REV_JOB_HITS * 2 + 64;
@@ -148,7 +159,7 @@ __device__ __forceinline__ void sw_body(const SwLaunch &L, const SwJob job) {
     const unsigned pad_letter = (unsigned)L.alphabet;
 
     if (threadIdx.x == 0) *next_chunk = 0;
-    if (!MULTI) {
+    if (!MULTI && !REV) {
         build_profile<R, REV>(lds, q, cb, qlen, 0, L.mat, L.alphabet, prof);
         __syncthreads();
     }
@@ -164,10 +175,7 @@ __device__ __forceinline__ void sw_body(const SwLaunch &L, const SwJob job) {
         for (uint32_t base = 0; base < n_hits; base += WAVES * 64) {   // a job of the BOTH kernels holds at most 256 hits: one round
             const uint32_t idx = base + threadIdx.x;
             bool pass = false;
-            if (idx < n_hits) {
-                const int s = (int)L.out[L.hit_out[job.hit_begin + idx]].score;
-                pass = s > 0 && s >= min_start;
-            }
+            if (idx < n_hits) pass = sw_rev_wanted(L, L.hit_out[job.hit_begin + idx], min_start);
             const unsigned long long bal = __ballot(pass);
             if (lane == 0) live_wave[wave] = (uint32_t)__popcll(bal);
             __syncthreads();
@@ -183,6 +191,11 @@ __device__ __forceinline__ void sw_body(const SwLaunch &L, const SwJob job) {
             __syncthreads();
         }
         n_hits = total;
+        if (n_hits == 0) return;      // (workgroup-uniform) no pair of this job needs a start position: no profile either
+        if (!MULTI) {
+            build_profile<R, REV>(lds, q, cb, qlen, 0, L.mat, L.alphabet, prof);
+            __syncthreads();
+        }
     }
     const uint32_t n_iter = (n_hits + WAVES * HITS_PER_WAVE - 1) / (WAVES * HITS_PER_WAVE);
 
@@ -219,9 +232,9 @@ __device__ __forceinline__ void sw_body(const SwLaunch &L, const SwJob job) {
             fb = fa;
             if (vA) fa = L.out[L.hit_out[hA]];
             if (vB) fb = L.out[L.hit_out[hB]];
-            const int min_start = L.q_minstart[job.query];
-            colsA = (vA && fa.score > 0 && fa.score >= min_start) ? fa.t_end + 1 : 0;
-            colsB = (vB && fb.score > 0 && fb.score >= min_start) ? fb.t_end + 1 : 0;
+            // (every packed hit passed sw_rev_wanted above)
+            colsA = vA ? fa.t_end + 1 : 0;
+            colsB = vB ? fb.t_end + 1 : 0;
             endA = colsA > 0 ? fa.t_end : 0;
             endB = colsB > 0 ? fb.t_end : 0;
             r0A = colsA > 0 ? qlen - 1 - fa.q_end : 0;
@@ -502,7 +515,7 @@ __device__ __forceinline__ void sw_body(const SwLaunch &L, const SwJob job) {
 template <int R, bool MULTI, bool BOTH>
 __device__ __forceinline__ void sw_passes(const SwLaunch &L, const SwJob &job) {
     if constexpr (R <= SW_MAX_R) {
-        sw_body<R, MULTI, false>(L, job);
+        if (!(BOTH && L.rev_only)) sw_body<R, MULTI, false>(L, job);
         // multi-tile queries get their reverse scan from sw_rev_multi_kernel (below), per query instead of per job
         if constexpr (BOTH && !MULTI) {
             __threadfence_block();   // the forward results of this job, written by other waves of the workgroup

@@ -397,7 +397,8 @@ int mmgpu_sw_block_backtrace(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const uint32_t *
     if (!b || (!idx && n) || (!out && n)) return fail(MMGPU_ERR_ARG, "mmgpu_sw_block_backtrace: NULL argument");
     Buf q, r;
     q.put<uint64_t>(b->handle);
-    q.put<uint64_t>(bt ? (uint64_t)cap : (cap == MMGPU_BLOCK_NO_STRINGS ? ~0ull : 0ull));      // all ones: no strings wanted
+    // all ones: no strings wanted; all ones but the lowest bit: start positions only
+    q.put<uint64_t>(bt ? (uint64_t)cap : (cap == MMGPU_BLOCK_NO_STRINGS ? ~0ull : (cap == MMGPU_BLOCK_STARTS_ONLY ? ~1ull : 0ull)));
     q.put_bytes(idx, (size_t)n * 4);
     WireHdr h;
     if (!c || c->fd < 0 || !send_msg(c->fd, OP_SW_BLOCK_BACKTRACE, 0, q.d.data(), q.d.size()) || !recv_msg(c->fd, &h, &r))
@@ -413,6 +414,21 @@ int mmgpu_sw_block_backtrace(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const uint32_t *
     if (nb && bt && nb <= cap) memcpy(bt, p, nb);
     p = r.get_bytes(&nb);
     if (rc != MMGPU_OK) return fail(rc, std::string(reinterpret_cast<const char *>(p), nb));
+    return MMGPU_OK;
+}
+
+int mmgpu_sw_reverse_pairs(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const uint32_t *idx, uint32_t n, mmgpu_sw_hit *out) {
+    if (!b || (!idx && n)) return fail(MMGPU_ERR_ARG, "mmgpu_sw_reverse_pairs: NULL argument");
+    if (n == 0) return MMGPU_OK;
+    Buf q, r;
+    q.put<uint64_t>(b->handle);
+    q.put_bytes(idx, (size_t)n * 4);
+    const int rc = call(c, OP_SW_REVERSE_PAIRS, q, &r);
+    if (rc != MMGPU_OK) return rc;
+    size_t nb = 0;
+    const uint8_t *p = r.get_bytes(&nb);
+    if (nb != (size_t)n * sizeof(mmgpu_sw_hit)) return fail(MMGPU_ERR_STATE, "mmgpu client: malformed SW_REVERSE_PAIRS reply");
+    if (out) memcpy(out, p, nb);
     return MMGPU_OK;
 }
 

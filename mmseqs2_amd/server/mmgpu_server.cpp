@@ -405,7 +405,7 @@ bool handle(Server &S, int fd, const WireHdr &h, Buf &in) {
             }
             return reply(fd, h.op, rc, out);
         }
-        case OP_SW_RUN: case OP_SW_FETCH: case OP_SW_FREE: case OP_SW_TRACEBACK: case OP_SW_BLOCK_BACKTRACE: {
+        case OP_SW_RUN: case OP_SW_FETCH: case OP_SW_FREE: case OP_SW_TRACEBACK: case OP_SW_BLOCK_BACKTRACE: case OP_SW_REVERSE_PAIRS: {
             const uint64_t hd = in.get<uint64_t>();
             auto it = S.sw.find(hd);
             if (it == S.sw.end()) return reply_err(fd, h.op, MMGPU_ERR_ARG, "mmgpu_server: unknown alignment batch");
@@ -421,19 +421,31 @@ bool handle(Server &S, int fd, const WireHdr &h, Buf &in) {
                 out.put_bytes(res.data(), res.size() * sizeof(mmgpu_sw_hit));
                 return reply(fd, h.op, rc, out);
             }
+            if (h.op == OP_SW_REVERSE_PAIRS) {
+                size_t nr = 0;
+                const uint8_t *rp = in.get_bytes(&nr);
+                if (in.bad || nr % 4) return reply_err(fd, h.op, MMGPU_ERR_ARG, "mmgpu_server: malformed SW_REVERSE_PAIRS");
+                std::vector<uint32_t> ridx(nr / 4);
+                if (nr) memcpy(ridx.data(), rp, nr);
+                std::vector<mmgpu_sw_hit> res(ridx.size());
+                const int rc = mmgpu_sw_reverse_pairs(S.ctx, it->second.b, ridx.data(), (uint32_t)ridx.size(), res.data());
+                out.put_bytes(res.data(), res.size() * sizeof(mmgpu_sw_hit));
+                return reply(fd, h.op, rc, out);
+            }
             const uint64_t cap = in.get<uint64_t>();
             size_t n = 0;
             const uint8_t *ip = in.get_bytes(&n);
             std::vector<uint32_t> idx(n / 4);
             if (n) memcpy(idx.data(), ip, n);
-            const bool no_strings = h.op == OP_SW_BLOCK_BACKTRACE && cap == ~0ull;      // MMGPU_BLOCK_NO_STRINGS on the client side
+            const bool starts_only = h.op == OP_SW_BLOCK_BACKTRACE && cap == ~1ull;      // MMGPU_BLOCK_STARTS_ONLY on the client side
+            const bool no_strings = starts_only || (h.op == OP_SW_BLOCK_BACKTRACE && cap == ~0ull);      // MMGPU_BLOCK_NO_STRINGS
             if (in.bad || (!no_strings && cap > MMGPU_WIRE_MAX_MSG)) return reply_err(fd, h.op, MMGPU_ERR_ARG, "mmgpu_server: malformed SW_TRACEBACK");
             if (h.op == OP_SW_BLOCK_BACKTRACE) {
                 std::vector<mmgpu_sw_block> blk(idx.size());
                 std::vector<char> bts(no_strings ? 0 : (size_t)cap);
                 size_t used_b = 0;
                 const int rcb = no_strings ? mmgpu_sw_block_backtrace(S.ctx, it->second.b, idx.data(), (uint32_t)idx.size(), blk.data(), nullptr,
-                                                                      MMGPU_BLOCK_NO_STRINGS, &used_b)
+                                                                      starts_only ? MMGPU_BLOCK_STARTS_ONLY : MMGPU_BLOCK_NO_STRINGS, &used_b)
                                            : mmgpu_sw_block_backtrace(S.ctx, it->second.b, idx.data(), (uint32_t)idx.size(), blk.data(),
                                                                       cap ? bts.data() : nullptr, (size_t)cap, &used_b);
                 out.put<int32_t>(rcb);

@@ -32,7 +32,8 @@ enum Op : uint32_t {
     OP_SW_PREPARE, OP_SW_RUN, OP_SW_FETCH, OP_SW_TRACEBACK, OP_SW_FREE,
     OP_BUILD_INDEX, OP_STATS, OP_SHUTDOWN,
     OP_SW_BLOCK_BACKTRACE,     // appended: the ops above keep their numbers
-    OP_MASK_TARGETS            // round 4: mmgpu_pf_mask_targets (tantan on the device)
+    OP_MASK_TARGETS,           // round 4: mmgpu_pf_mask_targets (tantan on the device)
+    OP_SW_REVERSE_PAIRS        // round 6: mmgpu_sw_reverse_pairs (start positions of the pairs the block aligner declined)
 };
 
 struct WireHdr {

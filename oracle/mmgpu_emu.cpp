@@ -164,7 +164,7 @@ int mmgpu_sw_run(mmgpu_ctx *c, mmgpu_sw_batch_t *b) {
         if (r.t_end == -1) {
             h.score = 0;
             h.q_end = 0;
-        } else if (b->mode == MMGPU_SW_START && r.score >= b->min_start[qi]) {
+        } else if (b->mode >= MMGPU_SW_START && r.score >= b->min_start[qi] && !(b->mode == MMGPU_SW_START_NOT_WORD && r.word != 0)) {
             if (isProf) mmo_sw_align_profile(b->prof[qi].data(), b->prof_letters[qi], q.data(), (int)q.size(), t, tlen, b->alphabet, b->go, b->ge, 1, 0, &r, dummy, 0);
             else mmo_sw_start(q.data(), (int)q.size(), b->cb[qi].data(), t, b->mat.data(), b->alphabet, b->go, b->ge, &r);
             h.q_start = r.q_start;
@@ -177,6 +177,30 @@ int mmgpu_sw_run(mmgpu_ctx *c, mmgpu_sw_batch_t *b) {
 
 int mmgpu_sw_fetch(mmgpu_ctx *, mmgpu_sw_batch_t *b, mmgpu_sw_hit *out) {
     if (!b->res.empty()) memcpy(out, b->res.data(), b->res.size() * sizeof(mmgpu_sw_hit));
+    return 0;
+}
+
+// the reverse scan of the named pairs after the fact (mode MMGPU_SW_START_NOT_WORD: what the block aligner declined)
+int mmgpu_sw_reverse_pairs(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const uint32_t *idx, uint32_t n, mmgpu_sw_hit *out) {
+    if (b->mode < MMGPU_SW_START) return fail(MMGPU_ERR_STATE, "mmgpu_sw_reverse_pairs: the batch was prepared without a start-position mode");
+    for (uint32_t i = 0; i < n; i++) {
+        if (idx[i] >= b->pair.size()) return fail(MMGPU_ERR_ARG, "mmgpu_sw_reverse_pairs: pair index out of range");
+        const uint32_t qi = b->pair[idx[i]].first, id = b->pair[idx[i]].second;
+        const std::vector<uint8_t> &q = b->q[qi];
+        const uint8_t *t = c->tres.data() + c->toff[id];
+        const int tlen = (int)(c->toff[id + 1] - c->toff[id]);
+        mmgpu_sw_hit &h = b->res[idx[i]];
+        if (h.score > 0 && h.t_end >= 0) {
+            mmo_sw_res r;
+            char dummy[8];
+            r.score = h.score; r.q_end = h.q_end; r.t_end = h.t_end; r.word = h.word; r.q_start = -1; r.t_start = -1;
+            if (b->prof_letters[qi] > 0) mmo_sw_align_profile(b->prof[qi].data(), b->prof_letters[qi], q.data(), (int)q.size(), t, tlen, b->alphabet, b->go, b->ge, 1, 0, &r, dummy, 0);
+            else mmo_sw_start(q.data(), (int)q.size(), b->cb[qi].data(), t, b->mat.data(), b->alphabet, b->go, b->ge, &r);
+            h.q_start = r.q_start;
+            h.t_start = r.t_start;
+        }
+        if (out) out[i] = h;
+    }
     return 0;
 }
 void mmgpu_sw_free(mmgpu_ctx *, mmgpu_sw_batch_t *b) { delete b; }
@@ -194,7 +218,8 @@ int mmgpu_sw_block_backtrace(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const uint32_t *
         if (word) need += (size_t)h.q_end + 1 + (size_t)h.t_end + 1 + 1;
     }
     if (used) *used = need;
-    const bool noStrings = bt == NULL && cap == MMGPU_BLOCK_NO_STRINGS;
+    const bool startsOnly = bt == NULL && cap == MMGPU_BLOCK_STARTS_ONLY;
+    const bool noStrings = startsOnly || (bt == NULL && cap == MMGPU_BLOCK_NO_STRINGS);
     std::vector<char> scratch;
     if (noStrings) {
         scratch.resize(need + 1);
@@ -238,8 +263,8 @@ int mmgpu_sw_block_backtrace(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const uint32_t *
         out[i].status = MMGPU_BLOCK_OK;
         out[i].q_start = qs;
         out[i].t_start = ts;
-        out[i].ident = ident;
-        out[i].bt_len = (uint32_t)len;
+        out[i].ident = startsOnly ? 0 : ident;      // (the device keeps no trace in that mode: both come back 0)
+        out[i].bt_len = startsOnly ? 0 : (uint32_t)len;
     }
     return 0;
 }

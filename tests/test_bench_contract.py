@@ -81,20 +81,25 @@ def test_pmc_reader_finds_the_quoted_kernels():
         assert t is not None and t > 1e9, (kernels, t)
 
 
-def test_this_rounds_pmc_passes_were_taken_with_these_device_sources():
-    """`roofline.traffic` is read from profiles/r05_search_pmc_{fetch,write}_size.txt: their header names the digest of
+def test_counter_traffic_is_reported_only_from_passes_taken_with_these_device_sources():
+    """`roofline.traffic` is read from profiles/<round>_search_pmc_{fetch,write}_size.txt: their header names the digest of
     mmseqs2_amd/csrc they were taken with (scripts/csrc_digest.py; for a clean tree it changes exactly when
-    `git rev-parse HEAD:mmseqs2_amd/csrc` does).  Kernels changed after the passes were collected = this test fails until
-    scripts/collect_profiles.sh has been run again and its summaries committed."""
+    `git rev-parse HEAD:mmseqs2_amd/csrc` does).  Either the committed passes are this tree's - then the line built from them names
+    the same digest - or the kernels changed after they were collected, and bench.py must report no counter traffic at all
+    (null, never another build's counters) until scripts/collect_profiles.sh has been run again."""
     sys.path.insert(0, ROOT)
     import bench
     now = bench.csrc_digest()
     assert now is not None
-    for kind in ("fetch", "write"):
-        path = os.path.join(ROOT, "profiles", "%s_search_pmc_%s_size.txt" % (bench.PROFILE_ROUND, kind))
-        assert bench.pmc_file_digest(path) == now, (path, bench.pmc_file_digest(path), now)
-    assert bench.pmc_traffic(("sw_kernel<", "sw_rev_multi_kernel"), bench.PROFILE_ROUND + "_search") > 1e9
-    assert _line()["roofline"]["csrc_digest"] == now
+    paths = [os.path.join(ROOT, "profiles", "%s_search_pmc_%s_size.txt" % (bench.PROFILE_ROUND, kind)) for kind in ("fetch", "write")]
+    current = all(bench.pmc_file_digest(p) == now for p in paths)
+    t = bench.pmc_traffic(("sw_kernel<", "sw_rev_multi_kernel"), bench.PROFILE_ROUND + "_search")
+    if current:
+        assert t > 1e9
+        assert _line()["roofline"]["csrc_digest"] == now
+    else:
+        assert t is None
+        assert bench.pmc_traffic(("pf_split_kernel",), bench.PROFILE_ROUND + "_search", per_run_of="pf_split_kernel") is None
 
 
 def test_stage_traffic_counts_every_dispatch_of_a_run():
@@ -103,14 +108,14 @@ def test_stage_traffic_counts_every_dispatch_of_a_run():
     sys.path.insert(0, ROOT)
     import bench
     stem = bench.PROFILE_ROUND + "_search"
-    once = bench.pmc_traffic(("pf_split_kernel",), stem)
-    assert abs(bench.pmc_traffic(("pf_split_kernel",), stem, per_run_of="pf_split_kernel") - once) <= 1e-6 * once
-    mean_replay = bench.pmc_traffic(("pf_replay_kernel",), stem)
-    run_replay = bench.pmc_traffic(("pf_replay_kernel",), stem, per_run_of="pf_split_kernel")
+    once = bench.pmc_traffic(("pf_split_kernel",), stem, check_digest=False)      # (how the files are read, whatever build they are of)
+    assert abs(bench.pmc_traffic(("pf_split_kernel",), stem, check_digest=False, per_run_of="pf_split_kernel") - once) <= 1e-6 * once
+    mean_replay = bench.pmc_traffic(("pf_replay_kernel",), stem, check_digest=False)
+    run_replay = bench.pmc_traffic(("pf_replay_kernel",), stem, check_digest=False, per_run_of="pf_split_kernel")
     assert 2.5 * mean_replay < run_replay < 3.5 * mean_replay       # three stage chunks per run
     line = _line()["prefilter"]["roofline"]
     assert line["traffic"] > line["split_kernel"]["traffic"] + run_replay
-    assert bench.pmc_traffic(("pf_split_kernel",), stem, per_run_of="no_such_kernel") is None
+    assert bench.pmc_traffic(("pf_split_kernel",), stem, check_digest=False, per_run_of="no_such_kernel") is None
 
 
 def test_result_databases_compare_up_to_the_order_of_tied_lines(tmp_path):
