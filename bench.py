@@ -679,6 +679,36 @@ def search_headline(args, gpu, torch, dist, rank, world, matrices, barrier, devi
     mem_free, mem_total = gpu.device_memory()     # after the timed steps: targets + index + every working buffer at its high-water mark
     step("keep")                                  # one more pass whose results are downloaded for the checks below
 
+    # ---- the same batch with the semantics of `mmseqs search` (alignment mode 2, StripedSmithWaterman.cpp:857-882): start positions
+    # of the hits of the uint8 pass from the reverse scan, those of the int16-range hits from the block aligner, the reverse scan only
+    # for what it declines.  Timed beside the step above (whose definition `value` keeps): whole steps, wall clock, all on the device.
+    search = {"align_ms": [], "block_s": [], "pf_ms": []}
+    if not sharded:
+        def step_search(record):
+            pfb.run()
+            fb = gpu.sw_prepare_from_pf(mat, 11, 1, None, pfb, mode=2, marshalled=msh)
+            fb.run()
+            a_ms = fb.kernel_ms()            # synchronises on the alignment kernels
+            tb0 = time.perf_counter()
+            sel = fb.block_starts()          # selection, block aligner, scatter, reverse scan of declined pairs: synchronises
+            tb = time.perf_counter() - tb0
+            if record:
+                search["align_ms"].append(a_ms)
+                search["block_s"].append(tb)
+                search["pf_ms"].append(pfb.stage_ms()[6])
+                search["selected"], search["declined"], search["too_large"] = sel
+            if record == "keep":
+                keep["search"] = fb.fetch().reshape(nq, stride)
+            fb.free()
+        step_search(None)
+        gpu.synchronize()
+        ts0 = time.perf_counter()
+        for _ in range(args.steps):
+            step_search(True)
+        gpu.synchronize()
+        search["elapsed_s"] = time.perf_counter() - ts0
+        step_search("keep")
+
     # ---- per-stage counters of the prefilter (last pass) ----
     stage = np.array(pfb.stage_ms())
     pf_cells, pf_cands = pfb.last_cells()
@@ -688,7 +718,7 @@ def search_headline(args, gpu, torch, dist, rank, world, matrices, barrier, devi
            "pf_cells": pf_cells, "pf_cands": pf_cands, "t_gen": t_gen, "t_index": t_index, "weak": weak, "sharded": sharded,
            "thr_example": thr_of_len.get(len(qs[0])), "hbm_in_use_gb": round((mem_total - mem_free) / 2 ** 30, 1),
            "mask": int(args.mask), "t_mask": t_mask, "n_masked": int(n_masked),
-           "collectives": comm_note if sharded else None}
+           "collectives": comm_note if sharded else None, "search": search if not sharded else None}
     if rank_all != 0:
         pfb.free()
         return out
@@ -783,6 +813,22 @@ def search_headline(args, gpu, torch, dist, rank, world, matrices, barrier, devi
                                             "(score passes -e 1e-3); device = answered by block_kernel.hip, declined = 'Block alignment "
                                             "failed' (the reference falls back too), too_large = left to the host (must be 0); "
                                             "rescored_equal = sampled CIGARs whose path re-scores to the SW score and ends at (q_end, t_end)"}
+            # the search-semantics step's records: the step's own (mode START) with the block aligner's start positions for the pairs
+            # it answered - the choice MMGpuMatcher.cpp makes between the two sources on the host
+            if "search" in keep:
+                expect = sep.copy()
+                okm = blk["status"] == 0
+                expect["q_start"][word_idx[okm]] = blk["q_start"][okm]
+                expect["t_start"][word_idx[okm]] = blk["t_start"][okm]
+                sbad, soff = 0, 0
+                for qi in range(nq):
+                    n = len(lists[qi])
+                    sbad += int(not np.array_equal(keep["search"][qi, :n], expect[soff:soff + n]))
+                    soff += n
+                out["search_parity"] = {"queries_compared": nq, "queries_with_a_differing_record": sbad, "pairs_compared": int(soff),
+                                        "what": "records of the search-semantics step (MMGPU_SW_START_NOT_WORD + mmgpu_sw_block_starts) against the "
+                                                "timed step's records (MMGPU_SW_START) with the start positions mmgpu_sw_block_backtrace gives for the "
+                                                "int16-range pairs it answers: all six fields of every pair"}
         except Exception as e:
             out["block_aligner"] = {"error": "%s: %s" % (type(e).__name__, str(e)[-300:])}
         swb.free()
@@ -1356,6 +1402,22 @@ def main():
             out["end_to_end"] = e2e
             if "queries_per_s_end_to_end" in e2e:
                 out["queries_per_s_end_to_end"] = e2e["queries_per_s_end_to_end"]
+        S = H.get("search")
+        if S and S.get("elapsed_s"):
+            ss_ms = S["elapsed_s"] / args.steps * 1e3
+            out["ms_per_step_search_semantics"] = round(ss_ms, 3)
+            out["queries_per_s_search_semantics"] = round(nq / (ss_ms * 1e-3), 1)
+            out["search_semantics"] = {
+                "step": "prefilter kernels -> hand-over -> forward scan of every pair + reverse scan of the uint8-pass hits that pass -e "
+                        "(MMGPU_SW_START_NOT_WORD) -> mmgpu_sw_block_starts: the device selects the int16-range hits that pass -e, the block "
+                        "aligner (block4_kernel.hip) supplies their start positions, the reverse scan those of the pairs it declines; whole "
+                        "steps by the wall clock, records complete on the device at the end of each",
+                "stages_ms": {"prefilter_kernels": round(float(np.mean(S["pf_ms"])), 2), "align_kernels": round(float(np.mean(S["align_ms"])), 2),
+                              "block_starts_call": round(float(np.mean(S["block_s"])) * 1e3, 2)},
+                "int16_range_pairs_selected": int(S.get("selected", 0)), "declined_then_reverse_scanned": int(S.get("declined", 0)),
+                "left_undecided": int(S.get("too_large", 0)),
+                "parity": H.get("search_parity"),
+                "reference": "StripedSmithWaterman.cpp:857-882 (ssw_align_private: E-value gate, block aligner for word == 1, fall-back)"}
         for kname in ("two_call", "backtrace", "block_aligner", "pairs_with_start", "inexact_queries", "merged_lists_sorted", "aligned_slots_filled", "records_gathered",
                       "parity_vs_unsplit"):
             if kname in H:

@@ -238,6 +238,14 @@ typedef struct {
 #define MMGPU_BLOCK_STARTS_ONLY ((size_t)-2)
 int mmgpu_sw_block_backtrace(mmgpu_ctx *ctx, mmgpu_sw_batch_t *batch, const uint32_t *pair_index, uint32_t n_pairs,
                              mmgpu_sw_block *out, char *bt, size_t bt_cap, size_t *bt_used);
+/* Search semantics in one call, for a batch run with MMGPU_SW_START_NOT_WORD: the device itself picks every int16-range hit whose score
+ * reaches its query's min_start_score (what passes ssw_align_private's E-value gate and then asks the block aligner,
+ * StripedSmithWaterman.cpp:857-882), runs the block aligner for start positions only, writes q_start / t_start into the batch's result
+ * records, and runs the reverse scan for the pairs it declined (:873-882).  mmgpu_sw_fetch afterwards returns, for every pair that
+ * passes the gate, the start position the reference reports.  n_too_large: pairs left undecided (start positions -1; 0 unless the
+ * scratch pool could not be allocated).  Callers with gates of their own beyond the score (coverage pre-checks, Alignment.cpp) use
+ * mmgpu_sw_block_backtrace with their own pair list instead.  Synchronises. */
+int mmgpu_sw_block_starts(mmgpu_ctx *ctx, mmgpu_sw_batch_t *batch, uint32_t *n_selected, uint32_t *n_declined, uint32_t *n_too_large);
 /* Test aid (the growth-sequence test of tests/test_sw_gpu.py): the same run without strings, plus every pair's block list as it
  * stands when the crate's align_core returns - Trace::block_start / block_size / right, i.e. the sequence of grow / shift-right /
  * shift-down steps with their sizes after every x-drop restore.  growth: n_pairs x (1 + 4 * growth_cap) words, per pair the number

@@ -77,7 +77,7 @@ EXPORTED_SYMBOLS = [
     "mmgpu_host_partition_targets", "mmgpu_pf_set_shard", "mmgpu_pf_fetch_exchange", "mmgpu_pf_merge_exchange",
     "mmgpu_pf_localize_lists", "mmgpu_sw_prepare_from_lists",
     "mmgpu_comm_unique_id", "mmgpu_comm_init_rank", "mmgpu_comm_info", "mmgpu_comm_destroy", "mmgpu_pf_exchange_merge",
-    "mmgpu_sw_prepare_owned", "mmgpu_sw_gather_owned", "mmgpu_sw_fetch_owned", "mmgpu_sw_block_backtrace", "mmgpu_sw_block_growth", "mmgpu_sw_block_tiers", "mmgpu_sw_reverse_pairs",
+    "mmgpu_sw_prepare_owned", "mmgpu_sw_gather_owned", "mmgpu_sw_fetch_owned", "mmgpu_sw_block_backtrace", "mmgpu_sw_block_growth", "mmgpu_sw_block_tiers", "mmgpu_sw_reverse_pairs", "mmgpu_sw_block_starts",
     "mmgpu_init_multi", "mmgpu_destroy_multi", "mmgpu_multi_size", "mmgpu_multi_ctx", "mmgpu_multi_synchronize",
     "mmgpu_multi_load_targets", "mmgpu_multi_pf_mask_targets", "mmgpu_multi_pf_build_index", "mmgpu_multi_pf_prepare", "mmgpu_multi_pf_run", "mmgpu_multi_pf_fetch",
     "mmgpu_multi_pf_stride", "mmgpu_multi_pf_free", "mmgpu_multi_sw_from_pf",
@@ -195,6 +195,7 @@ def load_library():
     L.mmgpu_sw_block_backtrace.argtypes = [c_p, c_p, c_p, ctypes.c_uint32, c_p, c_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
     L.mmgpu_sw_block_tiers.argtypes = [c_p, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]
     L.mmgpu_sw_reverse_pairs.argtypes = [c_p, c_p, c_p, ctypes.c_uint32, c_p]
+    L.mmgpu_sw_block_starts.argtypes = [c_p, c_p, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]
     L.mmgpu_sw_block_growth.argtypes = [c_p, c_p, c_p, ctypes.c_uint32, c_p, c_p, ctypes.c_uint32]
     L.mmgpu_comm_unique_id.argtypes = [c_p]
     L.mmgpu_comm_init_rank.argtypes = [c_p, c_p, ctypes.c_int, ctypes.c_int]
@@ -426,6 +427,14 @@ class SwBatch:
         out = np.zeros(self.pairs if self.slots is None else self.slots, SW_HIT_DTYPE)
         self.gpu._check(self.gpu.L.mmgpu_sw_fetch(self.gpu.ctx, self.handle, _ptr(out)))
         return out
+
+    def block_starts(self):
+        """mmgpu_sw_block_starts (batches of mode 2): the device selects the int16-range hits that pass the start-score threshold, runs the
+        block aligner for their start positions, writes them into the records and scans backwards for what it declined
+        -> (selected, declined, too_large)"""
+        a, b, c = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint32()
+        self.gpu._check(self.gpu.L.mmgpu_sw_block_starts(self.gpu.ctx, self.handle, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+        return a.value, b.value, c.value
 
     def reverse_pairs(self, pair_index):
         """mmgpu_sw_reverse_pairs: the reverse scan of exactly these result slots (batches of mode 2: the int16-range hits the block

@@ -509,6 +509,7 @@ struct mmgpu_sw_batch_t {
     DevBuf d_scratch_busy;        // one flag per slot of the pool (sw_kernel claims / releases)
     uint32_t scratch_slots = 0;
     DevBuf d_pf_counts, d_slot_target;   // from_pf: list lengths and slot -> target id, copied out of the prefilter batch
+    DevBuf d_qout_off, d_out_target;     // mmgpu_sw_block_starts: h_qout_off / h_out_target on the device (uploaded on first use)
     DevBuf d_qres, d_qcb, d_qoff, d_qbias, d_qminstart, d_hit_target, d_hit_out, d_out, d_mat;
     DevBuf d_qprof, d_qprof_off;   // profile queries only (empty otherwise)
     bool any_profile = false;
@@ -607,7 +608,7 @@ static int sw_prepare_impl(mmgpu_ctx *c, const mmgpu_sw_params *par, const mmgpu
     b->n_queries = nq;
     for (DevBuf *d : {&b->d_qres, &b->d_qcb, &b->d_qoff, &b->d_qbias, &b->d_qminstart, &b->d_hit_target, &b->d_hit_out, &b->d_out,
                       &b->d_mat, &b->d_stats, &b->d_bt_scratch, &b->d_bt_jobs, &b->d_bt_info, &b->d_bt_str, &b->d_bt_cursor, &b->d_scratch_busy,
-                      &b->d_pf_counts, &b->d_slot_target, &b->d_qprof, &b->d_qprof_off})
+                      &b->d_pf_counts, &b->d_slot_target, &b->d_qprof, &b->d_qprof_off, &b->d_qout_off, &b->d_out_target})
         d->bind(c->cache);
 
     std::vector<uint8_t> qres;
@@ -1322,57 +1323,135 @@ extern "C" int mmgpu_sw_batch(mmgpu_ctx *c, const mmgpu_sw_params *par, const mm
 // backtrace
 // ---------------------------------------------------------------------------------------------------------
 // ---- a15: the block aligner's start position / backtrace for int16-range hits (block_kernel.hip) ----
+struct BlockAuto { uint32_t selected = 0, ok = 0, declined = 0, too_large = 0; };      // mmgpu_sw_block_starts: what the device selected / answered
+
 static int block_backtrace(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const uint32_t *pair_index, uint32_t n, mmgpu_sw_block *out,
-                           char *bt, size_t bt_cap, size_t *bt_used, uint32_t *growth, uint32_t growth_cap) {
-    if (!c || !b || (!pair_index && n) || (!out && n)) return fail(MMGPU_ERR_ARG, "mmgpu_sw_block_backtrace: NULL argument");
+                           char *bt, size_t bt_cap, size_t *bt_used, uint32_t *growth, uint32_t growth_cap, BlockAuto *au = nullptr) {
+    if (!c || !b || (!au && ((!pair_index && n) || (!out && n)))) return fail(MMGPU_ERR_ARG, "mmgpu_sw_block_backtrace: NULL argument");
     if (!b->ran) return fail(MMGPU_ERR_STATE, "mmgpu_sw_block_backtrace: batch was never run");
     if (b->alphabet > 26) return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_sw_block_backtrace: alphabet above 26 letters");
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = c->stream;
-    if (!b->h_res_valid) {
-        b->h_res.resize((size_t)b->pairs);
-        if (b->pairs) HIP_TRY(hipMemcpyAsync(b->h_res.data(), b->d_out.p, (size_t)b->pairs * sizeof(mmgpu_sw_hit), hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
-        if (b->from_pf) {
-            b->h_slot_target.resize((size_t)b->pairs);
-            if (b->pairs) HIP_TRY(hipMemcpy(b->h_slot_target.data(), b->d_slot_target.p, (size_t)b->pairs * sizeof(uint32_t), hipMemcpyDeviceToHost));
-        }
-        b->h_res_valid = true;
-    }
     if (b->mode < MMGPU_SW_START && !b->from_pf && b->h_out_target.empty())
         return fail(MMGPU_ERR_STATE, "mmgpu_sw_block_backtrace: the batch keeps no slot -> target map (prepare it with MMGPU_SW_START)");
+    static const bool trace_on = getenv("MMGPU_TRACE") != nullptr;
+    auto now_s = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_mark = now_s();
+    auto lap = [&](const char *what) {
+        if (!trace_on) return;
+        const double t = now_s();
+        fprintf(stderr, "[mmgpu block aligner] %s %.3f s\n", what, t - t_mark);
+        t_mark = t;
+    };
     std::vector<BlockJob> jobs;
-    std::vector<uint64_t> bt_off(std::max<uint32_t>(n, 1), 0);
+    std::vector<uint64_t> bt_off;
     uint64_t off = 0, longest = 0;
-    for (uint32_t k = 0; k < n; k++) {
-        const uint32_t p = pair_index[k];
-        if (p >= b->pairs) return fail(MMGPU_ERR_ARG, "mmgpu_sw_block_backtrace: pair index out of range");
-        const mmgpu_sw_hit &h = b->h_res[p];
-        out[k].q_start = -1; out[k].t_start = -1; out[k].ident = 0; out[k].bt_len = 0; out[k].bt_off = off; out[k].reserved = 0;
-        bt_off[k] = off;
-        const uint32_t q = (uint32_t)(std::upper_bound(b->h_qout_off.begin(), b->h_qout_off.end(), p) - b->h_qout_off.begin() - 1);
-        // (profile queries run the same kernel with the query's score rows in place of matrix + bias: block_kernel.hip, BkSeq::prof)
-        if (h.score <= 0 || h.word != 1 || h.t_end < 0) {
-            out[k].status = MMGPU_BLOCK_NOT_WORD;
-            continue;
+    DevBuf d_out, d_sel_jobs, d_sel_pairs, d_sel_cnt, d_flags;
+    for (DevBuf *d : {&d_out, &d_sel_jobs, &d_sel_pairs, &d_sel_cnt, &d_flags}) d->bind(c->cache);
+    std::vector<mmgpu_sw_block> out_auto;
+    if (au) {
+        // ---- the device picks the pairs (block_select.hip): int16-range hits that pass the query's start-score threshold ----
+        if (!b->d_qout_off.p) {
+            HIP_TRY(b->d_qout_off.alloc(b->h_qout_off.size() * 4));
+            HIP_TRY(hipMemcpyAsync(b->d_qout_off.p, b->h_qout_off.data(), b->h_qout_off.size() * 4, hipMemcpyHostToDevice, s));
         }
-        out[k].status = MMGPU_BLOCK_TOO_LARGE;    // overwritten by the kernel
-        BlockJob j;
-        j.query = q;
-        j.target = b->from_pf ? b->h_slot_target[p] : b->h_out_target[p];
-        j.score = h.score; j.q_end = h.q_end; j.t_end = h.t_end;
-        j.slot = k;
-        jobs.push_back(j);
-        const uint64_t len = (uint64_t)h.q_end + 1 + (uint64_t)h.t_end + 1;
-        off += (len + 1 + 3) & ~3ull;      // (multiples of four: the walk kernel of block4_kernel.hip stores a string in dwords)
-        longest = std::max(longest, len);
+        if (!b->from_pf && !b->d_out_target.p) {
+            HIP_TRY(b->d_out_target.alloc(std::max<size_t>(b->h_out_target.size(), 1) * 4));
+            HIP_TRY(hipMemcpyAsync(b->d_out_target.p, b->h_out_target.data(), b->h_out_target.size() * 4, hipMemcpyHostToDevice, s));
+        }
+        HIP_TRY(d_sel_cnt.alloc(32));
+        HIP_TRY(hipMemsetAsync(d_sel_cnt.p, 0, 32, s));
+        BlockSelectArgs A;
+        A.res = b->d_out.as<mmgpu_sw_hit>();
+        A.pairs = (uint32_t)b->pairs;
+        A.qout_off = b->d_qout_off.as<uint32_t>();
+        A.n_queries = (uint32_t)(b->h_qout_off.size() - 1);
+        A.q_minstart = b->d_qminstart.as<int32_t>();
+        A.slot_target = b->from_pf ? b->d_slot_target.as<uint32_t>() : b->d_out_target.as<uint32_t>();
+        A.jobs = nullptr; A.pair_of_slot = nullptr; A.blk = nullptr;
+        A.count = d_sel_cnt.as<uint32_t>();
+        A.cap = 0;      // first pass: count only
+        HIP_TRY(launch_block_select(A, s));
+        uint32_t cnt = 0;
+        HIP_TRY(hipMemcpyAsync(&cnt, d_sel_cnt.p, 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        n = cnt;
+        au->selected = n;
+        if (n == 0) return MMGPU_OK;
+        HIP_TRY(d_sel_jobs.alloc((size_t)n * sizeof(BlockJob)));
+        HIP_TRY(d_sel_pairs.alloc((size_t)n * 4));
+        HIP_TRY(d_out.alloc((size_t)n * sizeof(mmgpu_sw_block)));
+        HIP_TRY(hipMemsetAsync(d_sel_cnt.p, 0, 4, s));
+        A.jobs = d_sel_jobs.as<BlockJob>();
+        A.pair_of_slot = d_sel_pairs.as<uint32_t>();
+        A.blk = d_out.as<mmgpu_sw_block>();
+        A.cap = n;
+        HIP_TRY(launch_block_select(A, s));
+        jobs.resize(n);
+        HIP_TRY(hipMemcpyAsync(jobs.data(), d_sel_jobs.p, (size_t)n * sizeof(BlockJob), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        out_auto.resize(n);
+        out = out_auto.data();
+        // (string offsets as in the other form: block_kernel.hip - profile queries, pairs beyond the pool - walks back whatever is asked)
+        bt_off.assign(n, 0);
+        for (const BlockJob &j : jobs) {
+            const uint64_t len = (uint64_t)j.q_end + 1 + (uint64_t)j.t_end + 1;
+            bt_off[j.slot] = off;
+            off += (len + 1 + 3) & ~3ull;
+            longest = std::max(longest, len);
+        }
+        lap("device selection + job download");
+    } else {
+        if (!b->h_res_valid) {
+            b->h_res.resize((size_t)b->pairs);
+            if (b->pairs) HIP_TRY(hipMemcpyAsync(b->h_res.data(), b->d_out.p, (size_t)b->pairs * sizeof(mmgpu_sw_hit), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            if (b->from_pf) {
+                b->h_slot_target.resize((size_t)b->pairs);
+                if (b->pairs) HIP_TRY(hipMemcpy(b->h_slot_target.data(), b->d_slot_target.p, (size_t)b->pairs * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            }
+            b->h_res_valid = true;
+        }
+        bt_off.assign(std::max<uint32_t>(n, 1), 0);
+        for (uint32_t k = 0; k < n; k++) {
+            const uint32_t p = pair_index[k];
+            if (p >= b->pairs) return fail(MMGPU_ERR_ARG, "mmgpu_sw_block_backtrace: pair index out of range");
+            const mmgpu_sw_hit &h = b->h_res[p];
+            out[k].q_start = -1; out[k].t_start = -1; out[k].ident = 0; out[k].bt_len = 0; out[k].bt_off = off; out[k].reserved = 0;
+            bt_off[k] = off;
+            const uint32_t q = (uint32_t)(std::upper_bound(b->h_qout_off.begin(), b->h_qout_off.end(), p) - b->h_qout_off.begin() - 1);
+            // (profile queries run the same kernel with the query's score rows in place of matrix + bias: block_kernel.hip, BkSeq::prof)
+            if (h.score <= 0 || h.word != 1 || h.t_end < 0) {
+                out[k].status = MMGPU_BLOCK_NOT_WORD;
+                continue;
+            }
+            out[k].status = MMGPU_BLOCK_TOO_LARGE;    // overwritten by the kernel
+            BlockJob j;
+            j.query = q;
+            j.target = b->from_pf ? b->h_slot_target[p] : b->h_out_target[p];
+            j.score = h.score; j.q_end = h.q_end; j.t_end = h.t_end;
+            j.slot = k;
+            jobs.push_back(j);
+            const uint64_t len = (uint64_t)h.q_end + 1 + (uint64_t)h.t_end + 1;
+            off += (len + 1 + 3) & ~3ull;      // (multiples of four: the walk kernel of block4_kernel.hip stores a string in dwords)
+            longest = std::max(longest, len);
+        }
+        lap("result download + job list");
     }
     if (bt_used) *bt_used = (size_t)off;
-    const bool starts_only = bt == nullptr && bt_cap == MMGPU_BLOCK_STARTS_ONLY;    // start positions only: no trace, no walk
+    const bool starts_only = au != nullptr || (bt == nullptr && bt_cap == MMGPU_BLOCK_STARTS_ONLY);    // start positions only: no trace, no walk
     const bool no_strings = starts_only || (bt == nullptr && bt_cap == MMGPU_BLOCK_NO_STRINGS);      // start positions / identities / lengths only
     if (!no_strings && (off > bt_cap || (!bt && off))) return fail(MMGPU_ERR_ARG, "mmgpu_sw_block_backtrace: bt buffer too small (see *bt_used)");
     if (jobs.empty()) return MMGPU_OK;
-    std::stable_sort(jobs.begin(), jobs.end(), [](const BlockJob &x, const BlockJob &y) { return x.q_end + x.t_end > y.q_end + y.t_end; });
+    {   // longest pair first, stable: a counting sort over q_end + t_end (both below 65536)
+        std::vector<uint32_t> first((size_t)longest + 2, 0u);
+        for (const BlockJob &j : jobs) first[(size_t)(j.q_end + j.t_end + 2)]++;      // key = the pair's length
+        uint32_t run = 0;
+        for (size_t len = (size_t)longest + 1; len-- > 0;) { const uint32_t cnt = first[len]; first[len] = run; run += cnt; }
+        std::vector<BlockJob> sorted(jobs.size());
+        for (const BlockJob &j : jobs) sorted[first[(size_t)(j.q_end + j.t_end + 2)]++] = j;
+        jobs.swap(sorted);
+    }
     // the AAMatrix as ssw_init leaves it: new_simple(1, -1) with the substitution matrix written over it (:708,:1469-1474)
     std::vector<int8_t> mat((size_t)b->alphabet * b->alphabet), scores(27 * 32, (int8_t)-128);
     HIP_TRY(hipMemcpy(mat.data(), b->d_mat.p, mat.size(), hipMemcpyDeviceToHost));
@@ -1387,15 +1466,6 @@ static int block_backtrace(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const uint32_t *pa
     //           overflows its slot and moves on
     //   tier 1  blocks <= 2048 rows in LDS, slot = the crate's own bound for that size (Trace::new, scan_block.rs:1742-1748)
     //   tier 2  the crate's 4096 rows, borders in the slot
-    static const bool trace_on = getenv("MMGPU_TRACE") != nullptr;
-    auto now_s = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    double t_mark = now_s();
-    auto lap = [&](const char *what) {
-        if (!trace_on) return;
-        const double t = now_s();
-        fprintf(stderr, "[mmgpu block aligner] %s %.3f s\n", what, t - t_mark);
-        t_mark = t;
-    };
     auto pair_len = [](const BlockJob &j) { return (uint64_t)j.q_end + 1 + (uint64_t)j.t_end + 1; };
     auto slot_size = [](uint64_t len, uint64_t entries_per_col, uint64_t max_rows, bool borders) {
         return (borders ? (uint64_t)8 * BLOCK_REF_MAX_SIZE * 2 : 0ull) + (((len + 64) * 16 + 31) & ~31ull) + entries_per_col * 32 * (len + 2 * max_rows);
@@ -1403,10 +1473,10 @@ static int block_backtrace(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const uint32_t *pa
     static const uint64_t pool_limit = (getenv("MMGPU_BLOCK_POOL_MB") ? strtoull(getenv("MMGPU_BLOCK_POOL_MB"), nullptr, 10) : 16384ull) << 20;
     // (small calls: slots for the longest pair, everything starts in tier 0)
     uint64_t typical_len = pair_len(jobs[jobs.size() > 1024 ? 255 : 0]);
-    DevBuf d_out, d_btoff, d_bt, d_scores, d_jobs[3], d_pool[3], d_busy[3];
-    for (DevBuf *d : {&d_out, &d_btoff, &d_bt, &d_scores, &d_jobs[0], &d_jobs[1], &d_jobs[2], &d_pool[0], &d_pool[1], &d_pool[2], &d_busy[0], &d_busy[1], &d_busy[2]})
+    DevBuf d_btoff, d_bt, d_scores, d_jobs[3], d_pool[3], d_busy[3];
+    for (DevBuf *d : {&d_btoff, &d_bt, &d_scores, &d_jobs[0], &d_jobs[1], &d_jobs[2], &d_pool[0], &d_pool[1], &d_pool[2], &d_busy[0], &d_busy[1], &d_busy[2]})
         d->bind(c->cache);
-    HIP_TRY(d_out.alloc((size_t)n * sizeof(mmgpu_sw_block)));
+    if (!au) HIP_TRY(d_out.alloc((size_t)n * sizeof(mmgpu_sw_block)));
     DevBuf d_growth;
     d_growth.bind(c->cache);
     const size_t growth_bytes = growth ? (size_t)n * (1 + 4 * (size_t)growth_cap) * 4 : 0;
@@ -1414,11 +1484,11 @@ static int block_backtrace(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const uint32_t *pa
         HIP_TRY(d_growth.alloc(growth_bytes));
         HIP_TRY(hipMemsetAsync(d_growth.p, 0, growth_bytes, s));
     }
-    HIP_TRY(d_btoff.alloc((size_t)n * 8));
+    HIP_TRY(d_btoff.alloc(bt_off.size() * 8));
     HIP_TRY(d_bt.alloc((size_t)off + 16));
     HIP_TRY(d_scores.alloc(scores.size()));
-    HIP_TRY(hipMemcpyAsync(d_out.p, out, (size_t)n * sizeof(mmgpu_sw_block), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(d_btoff.p, bt_off.data(), (size_t)n * 8, hipMemcpyHostToDevice, s));
+    if (!au) HIP_TRY(hipMemcpyAsync(d_out.p, out, (size_t)n * sizeof(mmgpu_sw_block), hipMemcpyHostToDevice, s));      // (au: block_select_kernel wrote them)
+    HIP_TRY(hipMemcpyAsync(d_btoff.p, bt_off.data(), bt_off.size() * 8, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(d_scores.p, scores.data(), scores.size(), hipMemcpyHostToDevice, s));
     HIP_TRY(hipStreamSynchronize(s));
     lap("buffers + uploads");
@@ -1658,11 +1728,52 @@ static int block_backtrace(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const uint32_t *pa
         lap("round of tier launches + status download");
     }
     release_streams();
+    if (au) {
+        // ---- the answers into the batch's records; what the block aligner declined gets its reverse scan (:873-882) ----
+        HIP_TRY(d_flags.alloc((size_t)b->pairs));
+        HIP_TRY(hipMemsetAsync(d_flags.p, 0, (size_t)b->pairs, s));
+        HIP_TRY(hipMemsetAsync(d_sel_cnt.p, 0, 32, s));
+        BlockScatterArgs S;
+        S.blk = d_out.as<mmgpu_sw_block>();
+        S.pair_of_slot = d_sel_pairs.as<uint32_t>();
+        S.n = n;
+        S.res = b->d_out.as<mmgpu_sw_hit>();
+        S.rev_force = d_flags.as<uint8_t>();
+        S.counts = d_sel_cnt.as<uint32_t>();
+        HIP_TRY(launch_block_scatter(S, s));
+        uint32_t counts[3] = {0, 0, 0};
+        HIP_TRY(hipMemcpyAsync(counts, d_sel_cnt.p, 12, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        au->ok = counts[0]; au->declined = counts[1]; au->too_large = counts[2];
+        if (counts[1]) {
+            if (int e = sw_launch_groups(c, b, true, d_flags.as<uint8_t>())) return e;
+            HIP_TRY(hipStreamSynchronize(s));
+        }
+        b->h_res_valid = false;
+        lap("answers scattered into the records (+ reverse scan of declined pairs)");
+        return MMGPU_OK;
+    }
     if (off && !no_strings) HIP_TRY(hipMemcpyAsync(bt, d_bt.p, (size_t)off, hipMemcpyDeviceToHost, s));
     if (growth) HIP_TRY(hipMemcpyAsync(growth, d_growth.p, growth_bytes, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));      // the host vectors and the buffers above die with this scope
     lap("backtrace strings download");
     return MMGPU_OK;
+}
+
+// One call = what `mmseqs search` needs of the block aligner in alignment mode 2 without backtraces: the device picks every int16-range
+// hit that passes its query's start-score threshold, runs the block aligner for start positions only, writes them into the batch's
+// records and scans backwards for the pairs it declined.  Afterwards mmgpu_sw_fetch returns records whose start positions are the
+// reference's for every pair that passes the gate, whichever path they took.
+extern "C" int mmgpu_sw_block_starts(mmgpu_ctx *c, mmgpu_sw_batch_t *b, uint32_t *n_selected, uint32_t *n_declined, uint32_t *n_too_large) {
+    if (!c || !b) return fail(MMGPU_ERR_ARG, "mmgpu_sw_block_starts: NULL argument");
+    if (b->mode != MMGPU_SW_START_NOT_WORD) return fail(MMGPU_ERR_STATE, "mmgpu_sw_block_starts: the batch was not prepared with MMGPU_SW_START_NOT_WORD");
+    if (b->owned) return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_sw_block_starts: not for batches of owned pairs (sharded runs)");
+    BlockAuto au;
+    const int rc = block_backtrace(c, b, nullptr, 0, nullptr, nullptr, MMGPU_BLOCK_STARTS_ONLY, nullptr, nullptr, 0, &au);
+    if (n_selected) *n_selected = au.selected;
+    if (n_declined) *n_declined = au.declined;
+    if (n_too_large) *n_too_large = au.too_large;
+    return rc;
 }
 
 extern "C" int mmgpu_sw_block_backtrace(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const uint32_t *pair_index, uint32_t n, mmgpu_sw_block *out,

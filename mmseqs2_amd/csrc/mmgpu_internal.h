@@ -569,6 +569,31 @@ hipError_t launch_sw_block4(const Block2Launch &L, bool trace, int form, uint32_
 hipError_t launch_sw_block4_walk(const Block2Launch &L, hipStream_t stream);
 void warm_block4();
 
+// ---- search semantics on the device (block_select.hip, mmgpu_sw_block_starts) ----
+struct BlockSelectArgs {
+    const mmgpu_sw_hit *res;      // the batch's result records
+    uint32_t pairs;
+    const uint32_t *qout_off;     // [n_queries + 1] first result slot of every query
+    uint32_t n_queries;
+    const int32_t *q_minstart;
+    const uint32_t *slot_target;  // target id of every result slot
+    BlockJob *jobs;               // out: the selected pairs, slot = position in this list
+    uint32_t *pair_of_slot;       // out: their result slots
+    mmgpu_sw_block *blk;          // out: their answers, initialised (MMGPU_BLOCK_TOO_LARGE until a kernel decides)
+    uint32_t *count;              // out (zero before the launch)
+    uint32_t cap;
+};
+struct BlockScatterArgs {
+    const mmgpu_sw_block *blk;
+    const uint32_t *pair_of_slot;
+    uint32_t n;
+    mmgpu_sw_hit *res;
+    uint8_t *rev_force;           // [pairs], zero before the launch: set for the pairs the block aligner declined
+    uint32_t *counts;             // [3] OK / DECLINED / TOO_LARGE (zero before the launch)
+};
+hipError_t launch_block_select(const BlockSelectArgs &A, hipStream_t stream);
+hipError_t launch_block_scatter(const BlockScatterArgs &A, hipStream_t stream);
+
 hipError_t launch_sw_traceback(const BtLaunch &L, hipStream_t stream);
 hipError_t launch_sw_traceback_wave(const BtLaunch &L, hipStream_t stream);
 

@@ -549,7 +549,10 @@ __device__ __forceinline__ void sw_passes(const SwLaunch &L, const SwJob &job) {
 template <int G, bool BOTH>
 __global__ __launch_bounds__(WAVES * 64)
 __attribute__((amdgpu_waves_per_eu(G == 0 ? (BOTH ? MMGPU_SW_WAVES_G0B : MMGPU_SW_WAVES_G0F)
-                                           : (G == 1 ? (BOTH ? MMGPU_SW_WAVES_G1B : MMGPU_SW_WAVES_G1F) : SW_MIN_WAVES)))) void sw_kernel(SwLaunch L) {
+                                           : (G == 1 ? (BOTH ? MMGPU_SW_WAVES_G1B : MMGPU_SW_WAVES_G1F) : SW_MIN_WAVES),
+                                   // upper bound: the forward + reverse kernel of the middle group is at the edge of a third wavefront per
+                                   // SIMD (168 - 170 registers) and runs slower with it (83.4 against 78.7 ms for the stage, round 6) - pinned
+                                   G == 1 && BOTH ? MMGPU_SW_WAVES_G1B : 8))) void sw_kernel(SwLaunch L) {
     SwJob job = L.jobs[blockIdx.x];
     if (L.q_hit_count) {   // fused prefilter -> align hand-over: the list length of the query is only known on the device
         const uint32_t lim = job.query * L.hit_stride + L.q_hit_count[job.query];

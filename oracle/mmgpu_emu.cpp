@@ -269,6 +269,32 @@ int mmgpu_sw_block_backtrace(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const uint32_t *
     return 0;
 }
 
+// search semantics in one call: select, block aligner for start positions, reverse scan of what it declined
+int mmgpu_sw_block_starts(mmgpu_ctx *c, mmgpu_sw_batch_t *b, uint32_t *n_selected, uint32_t *n_declined, uint32_t *n_too_large) {
+    if (b->mode != MMGPU_SW_START_NOT_WORD) return fail(MMGPU_ERR_STATE, "mmgpu_sw_block_starts: the batch was not prepared with MMGPU_SW_START_NOT_WORD");
+    std::vector<uint32_t> sel;
+    for (size_t p = 0; p < b->res.size(); p++) {
+        const mmgpu_sw_hit &h = b->res[p];
+        if (h.score > 0 && h.word == 1 && h.t_end >= 0 && h.score >= b->min_start[b->pair[p].first]) sel.push_back((uint32_t)p);
+    }
+    std::vector<mmgpu_sw_block> blk(sel.size());
+    size_t used = 0;
+    int rc = sel.empty() ? 0 : mmgpu_sw_block_backtrace(c, b, sel.data(), (uint32_t)sel.size(), blk.data(), NULL, MMGPU_BLOCK_STARTS_ONLY, &used);
+    if (rc != 0) return rc;
+    std::vector<uint32_t> declined;
+    uint32_t tooLarge = 0;
+    for (size_t k = 0; k < sel.size(); k++) {
+        if (blk[k].status == MMGPU_BLOCK_OK) { b->res[sel[k]].q_start = blk[k].q_start; b->res[sel[k]].t_start = blk[k].t_start; }
+        else if (blk[k].status == MMGPU_BLOCK_DECLINED) declined.push_back(sel[k]);
+        else tooLarge++;
+    }
+    if (!declined.empty()) rc = mmgpu_sw_reverse_pairs(c, b, declined.data(), (uint32_t)declined.size(), NULL);
+    if (n_selected) *n_selected = (uint32_t)sel.size();
+    if (n_declined) *n_declined = (uint32_t)declined.size();
+    if (n_too_large) *n_too_large = tooLarge;
+    return rc;
+}
+
 int mmgpu_sw_block_growth(mmgpu_ctx *, mmgpu_sw_batch_t *, const uint32_t *, uint32_t, mmgpu_sw_block *, uint32_t *, uint32_t) {
     return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_sw_block_growth: a test aid of the device kernel");
 }

@@ -493,3 +493,100 @@ def test_block_aligner_grows_to_the_crates_4096_rows(gpu, matrices, oracle, firs
         assert first == 0 and second >= n_ok
     else:
         assert second >= 2 and first > 0, (first, second)      # (a 512-row block usually follows these gaps; a few pairs grow further)
+
+
+def _family_queries(matrices, oracle, seed, n_fam=120, min_start=0):
+    from mmseqs2_amd import workloads as wl
+    mat = matrices["blosum62_sw"]
+    sub16 = mat.astype(np.int16)
+    (qres, qoff), (tres, toff), fam_t, fam_q = wl.config3_prefilter(n_fam, 6, n_fam, seed=seed)
+    qs, ts = wl.split(qres, qoff), wl.split(tres, toff)
+    queries = []
+    for qi, q in enumerate(qs):
+        own = np.nonzero(fam_t == fam_q[qi])[0][:4].astype(np.uint32)
+        other = np.array([(qi * 7 + 3) % len(ts), (qi * 11 + 5) % len(ts)], np.uint32)
+        cb = oracle.round_comp_bias(oracle.comp_bias(sub16, matrices["blosum62_pback"], q, 1.0))
+        queries.append(dict(q=q, comp_bias=cb, targets=np.concatenate([own, other]), min_start_score=min_start))
+    return mat, queries, tres, toff
+
+
+def test_start_not_word_mode_and_reverse_pairs(gpu, matrices, oracle):
+    """MMGPU_SW_START_NOT_WORD (mode 2): the reverse scan runs for the hits of the reference's uint8 pass only - an int16-range hit takes
+    its start from the block aligner (StripedSmithWaterman.cpp:865-882) - and mmgpu_sw_reverse_pairs supplies, after the fact, the
+    start positions of exactly the pairs it is given (the fall-back of :873-882): together they equal mode 1 record by record."""
+    mat, queries, tres, toff = _family_queries(matrices, oracle, seed=51, min_start=60)
+    qs_long, ts_long = _long_gap_pairs(matrices, oracle, 6, seed=9)      # multi-tile queries as well
+    ts = wl.split(tres, toff) + ts_long
+    base = len(ts) - len(ts_long)
+    sub16 = mat.astype(np.int16)
+    for k, q in enumerate(qs_long):
+        cb = oracle.round_comp_bias(oracle.comp_bias(sub16, matrices["blosum62_pback"], q, 1.0))
+        queries.append(dict(q=q, comp_bias=cb, targets=np.array([base + k, k], np.uint32), min_start_score=60))
+    tres2, toff2 = wl.seqs_from_list(ts)
+    gpu.load_targets(tres2, toff2, 21)
+    b1 = gpu.sw_prepare(mat, 11, 1, queries, mode=1)
+    b1.run()
+    ref = b1.fetch()
+    b1.free()
+    b2 = gpu.sw_prepare(mat, 11, 1, queries, mode=2)
+    b2.run()
+    got = b2.fetch()
+    word = (ref["word"] == 1) & (ref["score"] >= 60)
+    assert word.sum() > 100 and ((ref["word"] == 0) & (ref["q_start"] >= 0)).sum() > 20
+    for f in ("score", "q_end", "t_end", "word"):
+        assert np.array_equal(got[f], ref[f]), f
+    assert np.array_equal(got["q_start"][~word], ref["q_start"][~word]) and np.array_equal(got["t_start"][~word], ref["t_start"][~word])
+    assert (got["q_start"][word] == -1).all() and (got["t_start"][word] == -1).all()
+    # every other int16-range pair, after the fact
+    pick = np.nonzero(word)[0][::2].astype(np.uint32)
+    back = b2.reverse_pairs(pick)
+    assert np.array_equal(back, ref[pick])
+    after = b2.fetch()
+    rest = np.nonzero(word)[0][1::2]
+    assert np.array_equal(after[pick], ref[pick]) and (after["q_start"][rest] == -1).all()
+    untouched = np.ones(len(ref), bool)
+    untouched[pick] = False
+    assert np.array_equal(after[untouched], got[untouched])
+    b2.free()
+
+
+def test_block_starts_is_the_search_semantics_of_one_call(gpu, matrices, oracle):
+    """mmgpu_sw_block_starts on a mode-2 batch: the device selects the int16-range hits that reach min_start_score, the block aligner
+    supplies their start positions, the reverse scan those of the pairs it declines - record for record what mode 1 + an explicit
+    mmgpu_sw_block_backtrace call + the host's choice between the two give (MMGpuMatcher.cpp), and what the restatement says."""
+    mat, queries, tres, toff = _family_queries(matrices, oracle, seed=52, n_fam=150, min_start=70)
+    ts = wl.split(tres, toff)
+    gpu.load_targets(tres, toff, 21)
+    b1 = gpu.sw_prepare(mat, 11, 1, queries, mode=1)
+    b1.run()
+    ref = b1.fetch()
+    sel = np.nonzero((ref["word"] == 1) & (ref["score"] >= 70) & (ref["score"] > 0))[0].astype(np.uint32)
+    blk, _ = b1.block_backtrace(sel, mode="starts")
+    b1.free()
+    expect = ref.copy()
+    ok = blk["status"] == 0
+    assert set(np.unique(blk["status"]).tolist()) <= {0, 1}
+    expect["q_start"][sel[ok]] = blk["q_start"][ok]
+    expect["t_start"][sel[ok]] = blk["t_start"][ok]
+    # pairs below the threshold keep -1 in both modes; int16-range pairs the block aligner declined keep the reverse scan's start
+    b2 = gpu.sw_prepare(mat, 11, 1, queries, mode=2)
+    b2.run()
+    n_sel, n_declined, n_large = b2.block_starts()
+    got = b2.fetch()
+    b2.free()
+    assert n_sel == len(sel) and n_declined == int((~ok).sum()) and n_large == 0
+    assert np.array_equal(got, expect)
+    # against the restatement, a sample
+    pair_q = np.repeat(np.arange(len(queries)), [len(q["targets"]) for q in queries])
+    pair_t = np.concatenate([q["targets"] for q in queries])
+    n_checked = 0
+    for p in sel[::7]:
+        qd = queries[int(pair_q[p])]
+        w = oracle.block_backtrace(qd["q"], qd["comp_bias"], ts[int(pair_t[p])], mat, 11, 1, int(ref[p]["score"]), int(ref[p]["q_end"]), int(ref[p]["t_end"]))
+        if w["ok"]:
+            assert (int(got[p]["q_start"]), int(got[p]["t_start"])) == (w["q_start"], w["t_start"]), p
+        else:
+            r = oracle.sw_align(qd["q"], qd["comp_bias"], ts[int(pair_t[p])], mat, 11, 1, need_start=True)
+            assert (int(got[p]["q_start"]), int(got[p]["t_start"])) == (r["q_start"], r["t_start"]), p
+        n_checked += 1
+    assert n_sel > 300 and n_checked > 40
