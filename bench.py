@@ -592,6 +592,21 @@ def search_headline(args, gpu, torch, dist, rank, world, matrices, barrier, devi
     gpu.pf_build_index(k, 21, True, s3, i3, km16, kmer_thr, matrices["blosum62_ungapped"])
     gpu.synchronize()
     t_index = time.time() - t0
+    # Strong scaling: every rank also holds the WHOLE database (3 GB at this size) in a second context of its device - the queries a
+    # step flags "inexact" (a shard reached its share of the reference's databaseHits buffer: ~0.1 % of the queries) run once more
+    # against it inside the step (mmgpu_pf_exchange_redo_unsplit), so that the N-rank step answers every query, like
+    # Prefiltering::mergeTargetSplits does (Prefiltering.cpp:412-526)
+    gpu_full, t_full = None, 0.0
+    if sharded and not weak and world > 1 and os.environ.get("MMGPU_BENCH_NO_UNSPLIT_CONTEXT") is None:
+        import mmseqs2_amd
+        tf0 = time.time()
+        gpu_full = mmseqs2_amd.MMGpu(device_index)
+        gpu_full.load_targets(tres, toff, 21)
+        if args.mask:
+            gpu_full.pf_mask_targets(tv["vtml80_likelihood_ratios"], float(tv["mask_prob"]), 20)
+        gpu_full.pf_build_index(k, 21, True, s3, i3, km16, kmer_thr, matrices["blosum62_ungapped"])
+        gpu_full.synchronize()
+        t_full = time.time() - tf0
     cbs = [capi.host_comp_bias(km16, matrices["vtml80_pback"], q)[0] for q in qs]
     queries = [dict(q=q, comp_bias=cb, identity_id=None) for q, cb in zip(qs, cbs)]
     pfb = gpu.pf_prepare(queries, kmer_thr, max_hits=max_res, min_diag_score=15, ref_bins=2)
@@ -628,6 +643,10 @@ def search_headline(args, gpu, torch, dist, rank, world, matrices, barrier, devi
         if lib_comm:
             # prefilter of the shard -> all-gather + merge -> owned pairs -> gather: all enqueued by the library on its stream
             dh, dc, df, _ = pfb.exchange_merge()
+            if gpu_full is not None:
+                rd = pfb.redo_unsplit(gpu_full)      # reads the merged flags back; re-runs what they name, replaces those lists
+                if record:
+                    stat["redone"], stat["redone_left"] = rd
             b = gpu.sw_prepare_owned(mat, 11, 1, None, pfb, mode=1, marshalled=msh)
             b.run()
             b.gather_owned()
@@ -650,6 +669,10 @@ def search_headline(args, gpu, torch, dist, rank, world, matrices, barrier, devi
             b.free()
             return
         mh_t, mc_t, mf_t = D.exchange_and_merge_device(gpu, pfb, nq, stride, group=pg)
+        if gpu_full is not None:
+            rd = D.rerun_flagged_unsplit(gpu_full, queries, kmer_thr, max_res, 15, 2, mh_t, mc_t, mf_t)
+            if record:
+                stat["redone"], stat["redone_left"] = rd
         b, lc, ls = D.align_owned_pairs(gpu, mat, 11, 1, msh, mh_t, mc_t, nq, stride, mode=1)
         b.run()
         b.fetch_device(res_t.data_ptr())
@@ -718,7 +741,13 @@ def search_headline(args, gpu, torch, dist, rank, world, matrices, barrier, devi
            "pf_cells": pf_cells, "pf_cands": pf_cands, "t_gen": t_gen, "t_index": t_index, "weak": weak, "sharded": sharded,
            "thr_example": thr_of_len.get(len(qs[0])), "hbm_in_use_gb": round((mem_total - mem_free) / 2 ** 30, 1),
            "mask": int(args.mask), "t_mask": t_mask, "n_masked": int(n_masked),
-           "collectives": comm_note if sharded else None, "search": search if not sharded else None}
+           "collectives": comm_note if sharded else None, "search": search if not sharded else None,
+           "rerun_unsplit": ({"queries_per_step": int(stat.get("redone", 0)), "of_those_left_to_the_host": int(stat.get("redone_left", 0)),
+                              "unsplit_context_setup_s": round(t_full, 2),
+                              "what": "queries whose merged list a step flags inexact, re-run inside the step against the whole database in a "
+                                      "second context of the rank's device (mmgpu_pf_exchange_redo_unsplit)"} if gpu_full is not None else None)}
+    if gpu_full is not None:
+        gpu_full.close()
     if rank_all != 0:
         pfb.free()
         return out
@@ -1418,7 +1447,7 @@ def main():
                 "left_undecided": int(S.get("too_large", 0)),
                 "parity": H.get("search_parity"),
                 "reference": "StripedSmithWaterman.cpp:857-882 (ssw_align_private: E-value gate, block aligner for word == 1, fall-back)"}
-        for kname in ("two_call", "backtrace", "block_aligner", "pairs_with_start", "inexact_queries", "merged_lists_sorted", "aligned_slots_filled", "records_gathered",
+        for kname in ("two_call", "backtrace", "block_aligner", "pairs_with_start", "inexact_queries", "rerun_unsplit", "merged_lists_sorted", "aligned_slots_filled", "records_gathered",
                       "parity_vs_unsplit"):
             if kname in H:
                 out[kname] = H[kname]

@@ -546,6 +546,15 @@ int mmgpu_pf_fetch_exchange(mmgpu_ctx *ctx, mmgpu_pf_batch_t *batch, void *d_xhi
 int mmgpu_pf_merge_exchange(mmgpu_ctx *ctx, mmgpu_pf_batch_t *batch, const void *d_xhits, const void *d_counts, uint32_t n_shards,
                             uint32_t stride, const uint32_t *identity_global, void *d_out_hits, uint32_t out_stride,
                             void *d_out_counts, void *d_out_flags);
+/* Prefiltering::mergeTargetSplits (Prefiltering.cpp:412-526) never hands a query back, and neither does a sharded run here: the
+ * queries whose merged list is flagged (MMGPU_PF_X_INEXACT_ORDER took part, or a shard declined the query) run once more against
+ * `full`, a context that holds the WHOLE database (same ids as the global ids) with its own index - 3 GB for the million targets of
+ * the headline, beside the shard - and that list replaces the merged one in the batch (hits, count, flag cleared) before the lists
+ * are localized and aligned.  params / queries: what the batch was prepared with (identity_id = the GLOBAL id).  *n_redone = queries
+ * re-run, *n_left = those of them the unsplit run itself leaves to the host (MMGPU_PF_OVERFLOW beyond 62 flushes, MMGPU_PF_LONG_SEQ ...:
+ * their flag stays set).  Reads the flags back (synchronises the context's stream); without a flagged query nothing else happens. */
+int mmgpu_pf_exchange_redo_unsplit(mmgpu_ctx *ctx, mmgpu_pf_batch_t *batch, mmgpu_ctx *full, const mmgpu_pf_params *params,
+                                   const mmgpu_pf_query *queries, uint32_t n_queries, uint32_t *n_redone, uint32_t *n_left);
 /* The part of merged lists (global ids) this device owns, as lists of local ids in list order: d_local_hits [nq][stride],
  * d_local_counts [nq], d_local_slot [nq][stride] (position of each kept hit in its merged list).  Feeds
  * mmgpu_sw_prepare_from_lists: every (query, target) pair is aligned on the device that holds the target. */
@@ -618,6 +627,14 @@ int mmgpu_multi_pf_prepare(mmgpu_multi *multi, const mmgpu_pf_params *params, co
 int mmgpu_multi_pf_run(mmgpu_multi *multi, mmgpu_multi_pf_batch *batch);
 int mmgpu_multi_pf_fetch(mmgpu_multi *multi, mmgpu_multi_pf_batch *batch, mmgpu_pf_hit *hits, uint32_t hit_stride, uint32_t *counts,
                          int32_t *status);
+/* When the first device has room for it beside its shard (three times 12 bytes per residue + 3 GB free), mmgpu_multi_load_targets /
+ * _pf_mask_targets / _pf_build_index also keep the WHOLE database in a context of its own there (mmgpu_multi_has_unsplit), and the
+ * queries a run flags MMGPU_PF_SHARD_INEXACT are run once more against it where the merged lists are first read (mmgpu_multi_pf_fetch,
+ * mmgpu_multi_sw_from_pf): no query is handed back for the way it was sharded (Prefiltering::mergeTargetSplits hands none back,
+ * Prefiltering.cpp:412-526).  mmgpu_multi_pf_redone: how many queries of the batch's last run took that path, and how many of them the
+ * unsplit run itself leaves to the host. */
+int mmgpu_multi_has_unsplit(mmgpu_multi *multi);
+int mmgpu_multi_pf_redone(mmgpu_multi_pf_batch *batch, uint32_t *n_redone, uint32_t *n_left);
 uint32_t mmgpu_multi_pf_stride(mmgpu_multi_pf_batch *batch);   /* slots per query of the merged lists, 0 before the first run */
 void mmgpu_multi_pf_free(mmgpu_multi *multi, mmgpu_multi_pf_batch *batch);
 /* Alignment of the merged lists of a batch that has been run: every context aligns the pairs whose target its shard holds

@@ -21,6 +21,7 @@ MMGpuPrefilter::MMGpuPrefilter(mmgpu_ctx *gpu, BaseMatrix *kmerSubMat, BaseMatri
     : gpu(gpu), multi(NULL), kmerSubMat(kmerSubMat), ungappedSubMat(ungappedSubMat), aaBiasCorrection(aaBiasCorrection),
       aaBiasCorrectionScale(aaBiasCorrectionScale), dbSize(0), exactKmerMatching(false), nucleotideSearch(false), kmerScore(false) {
     memset(handedBack, 0, sizeof(handedBack));
+    rerunUnsplit = 0;
 }
 
 bool MMGpuPrefilter::loadIndex(IndexTable *indexTable, SequenceLookup *sequenceLookup, ScoreMatrix &threeMer, ScoreMatrix &twoMer,
@@ -297,6 +298,10 @@ bool MMGpuPrefilter::finishBlock(Pending *P, std::vector<std::vector<hit_t> > &r
             }
             if (rc == 0) rc = mmgpu_multi_pf_fetch(multi, mb, hits.data() + lo * (size_t)stride, stride, counts.data() + lo, status.data() + lo);
             if (rc != 0) err = mmgpu_last_error();
+            if (rc == 0 && mb != NULL) {
+                uint32_t redone = 0;
+                if (mmgpu_multi_pf_redone(mb, &redone, NULL) == 0) rerunUnsplit += redone;
+            }
             if (mb) mmgpu_multi_pf_free(multi, mb);
             if (whole) P->mb = NULL;
         } else {

@@ -107,6 +107,9 @@ public:
 
     // queries handed back to the host's matcher so far, by status (MMGPU_PF_OVERFLOW ... MMGPU_PF_SHARD_INEXACT)
     size_t handedBack[8];
+    // sharded runs: queries whose merged list came back flagged and were run once more against the whole database ON A DEVICE
+    // (mmgpu_multi_pf_redone) - none of them reaches the host's matcher for the way the database was dealt
+    size_t rerunUnsplit;
 
 private:
     mmgpu_ctx *gpu;

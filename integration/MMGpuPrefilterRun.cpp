@@ -640,12 +640,17 @@ bool MMGpuPrefilterRun::run(Prefiltering &p, DBWriter &tmpDbw, size_t dbFrom, si
         watch.report(names, 3);
     }
     {
-        size_t handedBack[8] = {0, 0, 0, 0, 0, 0, 0, 0}, back = 0;
-        for (size_t g = 0; g < nGroups; g++)
+        size_t handedBack[8] = {0, 0, 0, 0, 0, 0, 0, 0}, back = 0, rerun = 0;
+        for (size_t g = 0; g < nGroups; g++) {
+            rerun += devices[g]->rerunUnsplit;
             for (size_t i = 0; i < 8; i++) {
                 handedBack[i] += devices[g]->handedBack[i];
                 back += devices[g]->handedBack[i];
             }
+        }
+        if (rerun != 0)
+            Debug(Debug::INFO) << "MMGPU: " << rerun << " of " << querySize << " queries ran once more against the unsplit database on the device "
+                               << "(a shard reached its share of the database-hit buffer)\n";
         if (back != 0)
             Debug(Debug::INFO) << "MMGPU: " << back << " of " << querySize << " queries ran through the host's matcher (database-hit buffer flushes beyond the device's: "
                                << handedBack[MMGPU_PF_OVERFLOW] << ", sequences of 32768 residues or more: " << handedBack[MMGPU_PF_LONG_SEQ]

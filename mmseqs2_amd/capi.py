@@ -80,7 +80,8 @@ EXPORTED_SYMBOLS = [
     "mmgpu_sw_prepare_owned", "mmgpu_sw_gather_owned", "mmgpu_sw_fetch_owned", "mmgpu_sw_block_backtrace", "mmgpu_sw_block_growth", "mmgpu_sw_block_tiers", "mmgpu_sw_reverse_pairs", "mmgpu_sw_block_starts",
     "mmgpu_init_multi", "mmgpu_destroy_multi", "mmgpu_multi_size", "mmgpu_multi_ctx", "mmgpu_multi_synchronize",
     "mmgpu_multi_load_targets", "mmgpu_multi_pf_mask_targets", "mmgpu_multi_pf_build_index", "mmgpu_multi_pf_prepare", "mmgpu_multi_pf_run", "mmgpu_multi_pf_fetch",
-    "mmgpu_multi_pf_stride", "mmgpu_multi_pf_free", "mmgpu_multi_sw_from_pf",
+    "mmgpu_multi_pf_stride", "mmgpu_multi_pf_free", "mmgpu_multi_sw_from_pf", "mmgpu_multi_has_unsplit", "mmgpu_multi_pf_redone",
+    "mmgpu_pf_exchange_redo_unsplit",
     "mmgpu_db_save", "mmgpu_db_probe", "mmgpu_db_load",
 ]
 
@@ -203,6 +204,9 @@ def load_library():
     L.mmgpu_comm_destroy.argtypes = [c_p]
     L.mmgpu_comm_destroy.restype = None
     L.mmgpu_pf_exchange_merge.argtypes = [c_p, c_p, c_p, ctypes.POINTER(c_p), ctypes.POINTER(c_p), ctypes.POINTER(c_p), ctypes.POINTER(ctypes.c_uint32)]
+    L.mmgpu_pf_exchange_redo_unsplit.argtypes = [c_p, c_p, c_p, c_p, c_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]
+    L.mmgpu_multi_has_unsplit.argtypes = [c_p]
+    L.mmgpu_multi_pf_redone.argtypes = [c_p, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]
     L.mmgpu_sw_prepare_owned.argtypes = [c_p, ctypes.POINTER(SwParams), c_p, ctypes.c_uint32, ctypes.c_int, c_p, ctypes.POINTER(c_p)]
     L.mmgpu_sw_gather_owned.argtypes = [c_p, c_p, ctypes.POINTER(c_p), ctypes.POINTER(c_p)]
     L.mmgpu_sw_fetch_owned.argtypes = [c_p, c_p, c_p, ctypes.POINTER(ctypes.c_uint32)]
@@ -365,6 +369,16 @@ class PfBatch:
         self.gpu._check(self.gpu.L.mmgpu_pf_merge_exchange(self.gpu.ctx, self.handle, c_p(d_xhits_ptr), c_p(d_counts_ptr), n_shards, stride,
                                                            _ptr(ident), c_p(d_out_hits_ptr), out_stride, c_p(d_out_counts_ptr),
                                                            c_p(d_out_flags_ptr) if d_out_flags_ptr else None))
+
+    def redo_unsplit(self, full_gpu):
+        """mmgpu_pf_exchange_redo_unsplit: the queries whose merged list is flagged inexact run once more against `full_gpu` (a context
+        holding the WHOLE database and its index); their merged lists in this batch are replaced.
+        -> (queries re-run, of those left to the host)"""
+        par, arr, n = self.prepared_with
+        a, b = ctypes.c_uint32(), ctypes.c_uint32()
+        self.gpu._check(self.gpu.L.mmgpu_pf_exchange_redo_unsplit(self.gpu.ctx, self.handle, full_gpu.ctx, ctypes.byref(par), ctypes.cast(arr, c_p), n,
+                                                                  ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
 
     def exchange_merge(self, identity_global=None):
         """mmgpu_pf_exchange_merge: all-gather over the context's communicator + merge, enqueued on its stream.
@@ -826,7 +840,9 @@ class MMGpu:
         h = c_p()
         self._check(self.L.mmgpu_pf_prepare(self.ctx, ctypes.byref(par), ctypes.cast(arr, c_p), len(queries), ctypes.byref(h)))
         db = getattr(self, "global_db_size", None) or self.n_targets
-        return PfBatch(self, h, keep, len(queries), min(int(max_hits), db))
+        b = PfBatch(self, h, keep, len(queries), min(int(max_hits), db))
+        b.prepared_with = (par, arr, len(queries))      # what mmgpu_pf_exchange_redo_unsplit is given again
+        return b
 
     def pf_batch(self, queries, kmer_thr, max_hits=300, min_diag_score=15, ref_bins=0, exact=False, nucleotide=False, kmer_score=False):
         b = self.pf_prepare(queries, kmer_thr, max_hits, min_diag_score, ref_bins, exact, nucleotide, kmer_score)
@@ -1064,6 +1080,16 @@ class MMGpuMulti:
         status = np.zeros(nq, np.int32)
         self._check(self.L.mmgpu_multi_pf_fetch(self.h, batch, _ptr(hits), max(stride, 1), _ptr(counts), _ptr(status)))
         return hits, counts, status
+
+    def has_unsplit(self):
+        """the first device also holds the whole database in a context of its own (queries flagged inexact are re-run there)"""
+        return bool(self.L.mmgpu_multi_has_unsplit(self.h))
+
+    def pf_redone(self, batch):
+        """(queries of the batch's last run that were re-run against the whole database, of those left to the host)"""
+        a, b = ctypes.c_uint32(), ctypes.c_uint32()
+        self._check(self.L.mmgpu_multi_pf_redone(batch, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
 
     def pf_free(self, batch):
         self.L.mmgpu_multi_pf_free(self.h, batch)

@@ -926,6 +926,19 @@ void comm_free(mmgpu_ctx *c);
 struct XchgBlock { const void *send; void *recv; size_t bytes; };   // one all-gather: `bytes` per rank
 int pf_xchg_begin(mmgpu_ctx *c, mmgpu_pf_batch_t *b, int n_ranks, XchgBlock blocks[2]);
 int pf_xchg_merge(mmgpu_ctx *c, mmgpu_pf_batch_t *b, int n_ranks, const uint32_t *identity_global);
+// sharded runs: the queries whose merged list is flagged inexact, run once more against a context that holds the whole database
+// (mmgpu_pf_exchange_redo_unsplit; multi_api.hip applies one run's rows to every context of the process)
+struct PfRedoRows {
+    std::vector<uint32_t> q;            // the flagged queries
+    std::vector<mmgpu_pf_hit> hits;     // [q.size()][stride]: the unsplit run's lists (ids of the whole database)
+    std::vector<uint32_t> counts;
+    std::vector<int32_t> status;        // the unsplit run's own status (MMGPU_PF_OK, or what the host has to do itself)
+    uint32_t stride = 0;
+};
+int pf_redo_flagged(mmgpu_ctx *c, mmgpu_pf_batch_t *b, std::vector<uint32_t> &flagged);      // synchronises the context's stream
+int pf_redo_run(mmgpu_ctx *full, const mmgpu_pf_params *par, const mmgpu_pf_query *qs, const std::vector<uint32_t> &flagged, PfRedoRows &rows);
+int pf_redo_apply(mmgpu_ctx *c, mmgpu_pf_batch_t *b, const PfRedoRows &rows);               // synchronises the context's stream
+const int32_t *pf_batch_redo_status(const mmgpu_pf_batch_t *b);      // [nq]: -1 = not re-run, else the unsplit run's status
 int sw_gather_begin(mmgpu_ctx *c, mmgpu_sw_batch_t *b, int n_ranks, XchgBlock blocks[2]);
 int sw_gather_finish(mmgpu_ctx *c, mmgpu_sw_batch_t *b, int n_ranks);
 int sw_gather_overflowed(mmgpu_ctx *c, mmgpu_sw_batch_t *b, bool *overflowed);   // true once: the caller repeats the phases (dense buffers)

@@ -25,6 +25,18 @@ struct mmgpu_multi {
     std::vector<uint32_t> shard_of, local_id, shard_sizes;
     std::vector<std::vector<uint32_t>> global_ids;
     uint32_t n_global = 0;
+    // the WHOLE database once more, in a context of its own on the first device (when it fits beside the shard): queries whose merged
+    // list comes back flagged inexact run against it (mmgpu_multi_pf_run), so that no query is handed back for the way it was sharded
+    mmgpu_ctx *full = nullptr;
+};
+
+// what mmgpu_multi_pf_run needs of the queries to run some of them again (the caller's arrays may be gone by then)
+struct MultiQueryCopy {
+    std::vector<uint8_t> q;
+    std::vector<float> comp_bias;
+    std::vector<int16_t> profile_score;
+    std::vector<uint32_t> profile_index;
+    std::vector<int8_t> profile;
 };
 
 struct mmgpu_multi_pf_batch {
@@ -32,6 +44,11 @@ struct mmgpu_multi_pf_batch {
     uint32_t nq = 0, stride = 0;
     std::vector<uint32_t> identity_global;
     bool has_identity = false;
+    mmgpu_pf_params par;
+    std::vector<MultiQueryCopy> copies;
+    std::vector<mmgpu_pf_query> queries;      // global identity ids, pointing into `copies`
+    uint32_t n_redone = 0, n_left = 0;        // of the last run
+    bool redo_pending = false;
 };
 
 namespace {
@@ -137,6 +154,7 @@ extern "C" void mmgpu_destroy_multi(mmgpu_multi *m) {
         if (i < m->ready.size() && m->ready[i]) (void)hipEventDestroy(m->ready[i]);
         mmgpu_destroy(m->ctx[i]);
     }
+    if (m->full) mmgpu_destroy(m->full);
     delete m;
 }
 
@@ -188,6 +206,18 @@ extern "C" int mmgpu_multi_load_targets(mmgpu_multi *m, const uint8_t *residues,
         sh.local_id = m->local_id.data();
         if (int e = mmgpu_pf_set_shard(m->ctx[s], &sh)) return e;
     }
+    // the unsplit copy: residues twice (masked view), 8-byte index entries, offset and score tables - when the first device has
+    // the room beside its shard (a database that is sharded because it does NOT fit one device keeps handing such queries back)
+    if (m->full) { mmgpu_destroy(m->full); m->full = nullptr; }
+    if (ns > 1 && n > 0) {
+        size_t free_b = 0, total_b = 0;
+        (void)hipSetDevice(m->ctx[0]->device);
+        const uint64_t need = 12ull * offsets[n] + (3ull << 30);
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (uint64_t)free_b > 2 * need) {
+            if (int e = mmgpu_init(&m->full, m->ctx[0]->device)) return e;
+            if (int e = mmgpu_load_targets(m->full, residues, offsets, n, alphabet)) return e;
+        }
+    }
     return MMGPU_OK;
 }
 
@@ -202,6 +232,8 @@ extern "C" int mmgpu_multi_pf_mask_targets(mmgpu_multi *m, const double *likelih
         if (int e = mmgpu_pf_mask_targets(c, likelihood_ratios, alphabet, min_mask_prob, mask_letter, &n)) return e;
         total += n;
     }
+    if (m->full)
+        if (int e = mmgpu_pf_mask_targets(m->full, likelihood_ratios, alphabet, min_mask_prob, mask_letter, nullptr)) return e;
     if (n_masked) *n_masked = total;
     return MMGPU_OK;
 }
@@ -211,6 +243,8 @@ extern "C" int mmgpu_multi_pf_build_index(mmgpu_multi *m, const mmgpu_pf_index *
     if (!m) return fail(MMGPU_ERR_ARG, "mmgpu_multi_pf_build_index: NULL argument");
     for (mmgpu_ctx *c : m->ctx)
         if (int e = mmgpu_pf_build_index(c, ix, kmer_submat, kmer_thr)) return e;
+    if (m->full)
+        if (int e = mmgpu_pf_build_index(m->full, ix, kmer_submat, kmer_thr)) return e;
     return MMGPU_OK;
 }
 
@@ -236,6 +270,27 @@ extern "C" int mmgpu_multi_pf_prepare(mmgpu_multi *m, const mmgpu_pf_params *par
         if (int e = mmgpu_pf_prepare(m->ctx[s], par, local.data(), nq, &b)) { mmgpu_multi_pf_free(m, mb); return e; }
         mb->b.push_back(b);
     }
+    mb->par = *par;
+    if (m->full) {      // (deep copies: mmgpu_pf_prepare copied what the shards need, a re-run needs the queries again)
+        mb->copies.resize(nq);
+        mb->queries.assign(qs, qs + nq);
+        for (uint32_t i = 0; i < nq; i++) {
+            MultiQueryCopy &cp = mb->copies[i];
+            mmgpu_pf_query &d = mb->queries[i];
+            cp.q.assign(qs[i].q, qs[i].q + qs[i].qlen);
+            d.q = cp.q.data();
+            if (qs[i].comp_bias) { cp.comp_bias.assign(qs[i].comp_bias, qs[i].comp_bias + qs[i].qlen); d.comp_bias = cp.comp_bias.data(); }
+            if (qs[i].profile_score && qs[i].profile_index && qs[i].profile) {
+                const size_t rows = (size_t)qs[i].qlen * qs[i].profile_row;
+                cp.profile_score.assign(qs[i].profile_score, qs[i].profile_score + rows);
+                cp.profile_index.assign(qs[i].profile_index, qs[i].profile_index + rows);
+                cp.profile.assign(qs[i].profile, qs[i].profile + (size_t)20 * qs[i].qlen);
+                d.profile_score = cp.profile_score.data();
+                d.profile_index = cp.profile_index.data();
+                d.profile = cp.profile.data();
+            }
+        }
+    }
     *out = mb;
     return MMGPU_OK;
 }
@@ -252,8 +307,37 @@ extern "C" int mmgpu_multi_pf_run(mmgpu_multi *m, mmgpu_multi_pf_batch *mb) {
     if (int e = all_gather_step(m, blk)) return e;
     for (int i = 0; i < n; i++)
         if (int e = mmgpu::pf_xchg_merge(m->ctx[i], mb->b[i], n, mb->has_identity ? mb->identity_global.data() : nullptr)) return e;
+    mb->n_redone = mb->n_left = 0;
+    mb->redo_pending = m->full != nullptr && mb->nq != 0;
     return MMGPU_OK;
 }
+
+// Queries whose merged list is flagged (every context computed the same flags): once more against the whole database, the rows
+// applied to every context's merged lists - the alignment step reads them there.  Runs where the batch's lists are first read
+// (mmgpu_multi_pf_fetch, mmgpu_multi_sw_from_pf): it reads the flags back, and mmgpu_multi_pf_run only enqueues.
+static int multi_redo_unsplit(mmgpu_multi *m, mmgpu_multi_pf_batch *mb) {
+    if (!mb->redo_pending) return MMGPU_OK;
+    mb->redo_pending = false;
+    std::vector<uint32_t> flagged;
+    if (int e = mmgpu::pf_redo_flagged(m->ctx[0], mb->b[0], flagged)) return e;
+    if (flagged.empty()) return MMGPU_OK;
+    mmgpu::PfRedoRows rows;
+    if (int e = mmgpu::pf_redo_run(m->full, &mb->par, mb->queries.data(), flagged, rows)) return e;
+    for (size_t i = 0; i < m->ctx.size(); i++)
+        if (int e = mmgpu::pf_redo_apply(m->ctx[i], mb->b[i], rows)) return e;
+    mb->n_redone = (uint32_t)flagged.size();
+    for (int32_t st : rows.status) mb->n_left += st != MMGPU_PF_OK;
+    return MMGPU_OK;
+}
+
+extern "C" int mmgpu_multi_pf_redone(mmgpu_multi_pf_batch *mb, uint32_t *n_redone, uint32_t *n_left) {
+    if (!mb) return fail(MMGPU_ERR_ARG, "mmgpu_multi_pf_redone: NULL batch");
+    if (n_redone) *n_redone = mb->n_redone;
+    if (n_left) *n_left = mb->n_left;
+    return MMGPU_OK;
+}
+
+extern "C" int mmgpu_multi_has_unsplit(mmgpu_multi *m) { return m && m->full ? 1 : 0; }
 
 // merged lists (global ids, the unsplit run's order) from context 0; status[q] = MMGPU_PF_X_INEXACT (4) where a shard's
 // element took the reference's overflow path or scores were not computed on the device: re-run such queries unsplit
@@ -265,6 +349,7 @@ extern "C" int mmgpu_multi_pf_fetch(mmgpu_multi *m, mmgpu_multi_pf_batch *mb, mm
     if (!mmgpu::pf_batch_merged_lists(mb->b[0], &dh, &dc, &stride, &nq)) return fail(MMGPU_ERR_STATE, "mmgpu_multi_pf_fetch: batch was never run");
     if (hit_stride < stride) return fail(MMGPU_ERR_ARG, "mmgpu_multi_pf_fetch: hit_stride smaller than min(max_hits, dbSize)");
     if (nq == 0) return MMGPU_OK;
+    if (int e = multi_redo_unsplit(m, mb)) return e;
     mmgpu_ctx *c = m->ctx[0];
     HIP_TRY(hipSetDevice(c->device));
     const void *df = nullptr;
@@ -285,6 +370,9 @@ extern "C" int mmgpu_multi_pf_fetch(mmgpu_multi *m, mmgpu_multi_pf_batch *mb, mm
             const int32_t *hs = mmgpu::pf_batch_host_status(mb->b[s]);
             if (hs && hs[q] != MMGPU_PF_OK && (st == MMGPU_PF_OK || st == MMGPU_PF_SHARD_INEXACT)) st = hs[q];
         }
+        // ... unless the query ran once more against the whole database: that run's word counts
+        const int32_t *rs = mmgpu::pf_batch_redo_status(mb->b[0]);
+        if (rs && rs[q] >= 0) st = rs[q];
         if (status) status[q] = st;
         if (st != MMGPU_PF_OK) counts[q] = 0;
     }
@@ -312,6 +400,7 @@ extern "C" int mmgpu_multi_sw_from_pf(mmgpu_multi *m, const mmgpu_sw_params *par
                                       mmgpu_multi_pf_batch *mb, mmgpu_sw_hit *out, uint64_t *cells, float *kernel_ms) {
     if (!m || !mb || mb->b.size() != m->ctx.size()) return fail(MMGPU_ERR_ARG, "mmgpu_multi_sw_from_pf: bad argument");
     const int n = (int)m->ctx.size();
+    if (int e = multi_redo_unsplit(m, mb)) return e;
     std::vector<mmgpu_sw_batch_t *> sb(n, nullptr);
     int err = MMGPU_OK;
     for (int i = 0; i < n && !err; i++) err = mmgpu_sw_prepare_owned(m->ctx[i], par, qs, nq, mode, mb->b[i], &sb[i]);

@@ -560,6 +560,7 @@ struct mmgpu_pf_batch_t {
     DevBuf x_recv_hits, x_recv_counts, x_hits, x_counts, x_flags, x_ident;
     std::vector<uint32_t> x_ident_host;
     int x_ranks = 0;           // ranks of the last merge; 0 = no merged lists yet
+    std::vector<int32_t> x_redo_status;      // [nq] after a merge: -1, or the status of the query's unsplit re-run (pf_redo_apply)
 };
 
 namespace mmgpu {
@@ -635,6 +636,7 @@ extern "C" int mmgpu_pf_prepare(mmgpu_ctx *c, const mmgpu_pf_params *par, const 
     b->ref_bins = par->ref_bins ? par->ref_bins : reference_bins(db_size);
     b->exchange = exchange;
     b->max_db_matches = std::max<uint64_t>(1000000, db_size) * 2;   // QueryMatcher.cpp:44-45 (dbSize of the WHOLE database)
+    if (const char *e = getenv("MMGPU_PF_MAX_DB_MATCHES")) b->max_db_matches = std::max<uint64_t>(64, strtoull(e, nullptr, 10));      // tests: a small database reaches the overflow path / a shard its share
     // a shard gathers its share of a query's index entries: the unsplit run's overflow path (QueryMatcher.cpp:310-346) is taken
     // when the shares add up to max_db_matches.  If NO shard reaches max_db_matches / n_shards the sum stays below the limit:
     // a shard that reaches its share flags the query (bit 31 of its exchanged count -> MMGPU_PF_X_INEXACT_ORDER in the merge,
@@ -1429,8 +1431,67 @@ int pf_xchg_merge(mmgpu_ctx *c, mmgpu_pf_batch_t *b, int n_ranks, const uint32_t
     A.out_flags = b->x_flags.as<uint32_t>();
     HIP_TRY(launch_pf_xmerge(A, c->stream));
     b->x_ranks = n_ranks;
+    b->x_redo_status.assign(b->nq, -1);
     return MMGPU_OK;
 }
+
+// ---- queries whose merged list is flagged inexact (a shard reached its share of the reference's databaseHits buffer, or declined
+// the query): Prefiltering::mergeTargetSplits (Prefiltering.cpp:412-526) never hands a query back, so neither does a sharded run
+// here - the query runs once more against a context that holds the WHOLE database, and that list replaces the merged one ----
+int pf_redo_flagged(mmgpu_ctx *c, mmgpu_pf_batch_t *b, std::vector<uint32_t> &flagged) {
+    flagged.clear();
+    if (!c || !b || !b->x_ranks) return fail(MMGPU_ERR_STATE, "mmgpu_pf_exchange_redo_unsplit: the batch holds no merged lists (mmgpu_pf_exchange_merge first)");
+    if (b->nq == 0) return MMGPU_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    std::vector<uint32_t> flags(b->nq);
+    HIP_TRY(hipMemcpyAsync(flags.data(), b->x_flags.p, (size_t)b->nq * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (uint32_t q = 0; q < b->nq; q++)
+        if (flags[q] & 1u) flagged.push_back(q);
+    return MMGPU_OK;
+}
+
+int pf_redo_run(mmgpu_ctx *full, const mmgpu_pf_params *par, const mmgpu_pf_query *qs, const std::vector<uint32_t> &flagged, PfRedoRows &rows) {
+    rows.q = flagged;
+    rows.hits.clear(); rows.counts.clear(); rows.status.clear();
+    if (flagged.empty()) return MMGPU_OK;
+    if (!full || !par || !qs) return fail(MMGPU_ERR_ARG, "mmgpu_pf_exchange_redo_unsplit: NULL argument");
+    if (full->shard.on) return fail(MMGPU_ERR_STATE, "mmgpu_pf_exchange_redo_unsplit: the second context holds a shard, not the whole database");
+    std::vector<mmgpu_pf_query> sub(flagged.size());
+    for (size_t k = 0; k < flagged.size(); k++) sub[k] = qs[flagged[k]];
+    mmgpu_pf_batch_t *fb = nullptr;
+    if (int e = mmgpu_pf_prepare(full, par, sub.data(), (uint32_t)sub.size(), &fb)) return e;
+    int rc = mmgpu_pf_run(full, fb);
+    rows.stride = std::max<uint32_t>(fb->max_hits, 1);
+    rows.hits.assign(flagged.size() * (size_t)rows.stride, mmgpu_pf_hit());
+    rows.counts.assign(flagged.size(), 0);
+    rows.status.assign(flagged.size(), 0);
+    if (rc == MMGPU_OK) rc = mmgpu_pf_fetch(full, fb, rows.hits.data(), rows.stride, rows.counts.data(), rows.status.data(), nullptr);
+    mmgpu_pf_free(full, fb);
+    return rc;
+}
+
+int pf_redo_apply(mmgpu_ctx *c, mmgpu_pf_batch_t *b, const PfRedoRows &rows) {
+    if (rows.q.empty()) return MMGPU_OK;
+    if (!c || !b || !b->x_ranks) return fail(MMGPU_ERR_STATE, "mmgpu_pf_exchange_redo_unsplit: the batch holds no merged lists");
+    if (rows.stride != b->max_hits) return fail(MMGPU_ERR_STATE, "mmgpu_pf_exchange_redo_unsplit: the unsplit run's lists have another stride (max_hits / database size differ)");
+    HIP_TRY(hipSetDevice(c->device));
+    static const uint32_t zero = 0;
+    for (size_t k = 0; k < rows.q.size(); k++) {
+        const uint32_t q = rows.q[k];
+        if (q >= b->nq) return fail(MMGPU_ERR_ARG, "mmgpu_pf_exchange_redo_unsplit: query index out of range");
+        b->x_redo_status[q] = rows.status[k];
+        if (rows.status[k] != MMGPU_PF_OK) continue;      // (the unsplit run hands it to the host as well: the flag stays)
+        HIP_TRY(hipMemcpyAsync(b->x_hits.as<mmgpu_pf_hit>() + (size_t)q * b->max_hits, rows.hits.data() + k * (size_t)rows.stride,
+                               (size_t)rows.stride * sizeof(mmgpu_pf_hit), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(b->x_counts.as<uint32_t>() + q, &rows.counts[k], 4, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(b->x_flags.as<uint32_t>() + q, &zero, 4, hipMemcpyHostToDevice, c->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));      // (the rows are the caller's)
+    return MMGPU_OK;
+}
+
+const int32_t *pf_batch_redo_status(const mmgpu_pf_batch_t *b) { return b && b->x_redo_status.size() == b->nq ? b->x_redo_status.data() : nullptr; }
 
 int pf_batch_merged_flags(mmgpu_pf_batch_t *b, const void **d_flags) {
     if (!b || !b->x_ranks) return fail(MMGPU_ERR_STATE, "no merged lists in this batch");
@@ -1466,6 +1527,25 @@ extern "C" int mmgpu_pf_exchange_merge(mmgpu_ctx *c, mmgpu_pf_batch_t *b, const 
     if (d_counts) *d_counts = b->x_counts.p;
     if (d_flags) *d_flags = b->x_flags.p;
     if (stride) *stride = b->max_hits;
+    return MMGPU_OK;
+}
+
+extern "C" int mmgpu_pf_exchange_redo_unsplit(mmgpu_ctx *c, mmgpu_pf_batch_t *b, mmgpu_ctx *full, const mmgpu_pf_params *par,
+                                              const mmgpu_pf_query *qs, uint32_t nq, uint32_t *n_redone, uint32_t *n_left) {
+    if (n_redone) *n_redone = 0;
+    if (n_left) *n_left = 0;
+    if (!c || !b || !full) return fail(MMGPU_ERR_ARG, "mmgpu_pf_exchange_redo_unsplit: NULL argument");
+    if (nq != b->nq) return fail(MMGPU_ERR_ARG, "mmgpu_pf_exchange_redo_unsplit: query count differs from the batch");
+    std::vector<uint32_t> flagged;
+    if (int e = mmgpu::pf_redo_flagged(c, b, flagged)) return e;
+    if (flagged.empty()) return MMGPU_OK;
+    mmgpu::PfRedoRows rows;
+    if (int e = mmgpu::pf_redo_run(full, par, qs, flagged, rows)) return e;
+    if (int e = mmgpu::pf_redo_apply(c, b, rows)) return e;
+    uint32_t left = 0;
+    for (int32_t st : rows.status) left += st != MMGPU_PF_OK;
+    if (n_redone) *n_redone = (uint32_t)flagged.size();
+    if (n_left) *n_left = left;
     return MMGPU_OK;
 }
 

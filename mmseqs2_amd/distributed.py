@@ -148,6 +148,33 @@ def exchange_and_merge_device(gpu, pf_batch, nq, stride, identity_global=None, g
     return out_h, out_c, out_f
 
 
+def rerun_flagged_unsplit(gpu_full, queries, kmer_thr, max_hits, min_diag_score, ref_bins, out_h, out_c, out_f):
+    """exchange_and_merge_device's lists with the flagged ones (bit 0 of out_f) replaced by the unsplit run's: the flagged queries run
+    once more on `gpu_full`, a context that holds the whole database (what mmgpu_pf_exchange_redo_unsplit does on a batch's own merged
+    lists when the library runs the exchange).  -> (queries re-run, of those left to the host)"""
+    flags = out_f.cpu().numpy()
+    flagged = np.nonzero(flags & 1)[0]
+    if len(flagged) == 0:
+        return 0, 0
+    b = gpu_full.pf_prepare([queries[int(q)] for q in flagged], kmer_thr, max_hits=max_hits, min_diag_score=min_diag_score, ref_bins=ref_bins)
+    b.run()
+    hits, counts, status, _ = b.fetch()
+    b.free()
+    left = 0
+    stride = out_h.shape[1]
+    for k, q in enumerate(flagged.tolist()):
+        if status[k] != 0:
+            left += 1
+            continue
+        row = np.zeros((stride, 3), np.int32)
+        n = int(counts[k])
+        row[:n] = np.ascontiguousarray(hits[k][:n]).view(np.int32).reshape(n, 3)
+        out_h[q].copy_(torch.from_numpy(row))
+        out_c[q] = n
+        out_f[q] = 0
+    return len(flagged), left
+
+
 def exchange_and_merge_host(xhits, counts, max_hits, min_diag_score, ref_bins, self_scores, identity_global=None, group=None):
     """CPU / gloo mirror used by the tests: xhits PF_XHIT_DTYPE [nq, stride], counts [nq] of THIS rank -> list of merged
     PF_HIT_DTYPE lists (capi.merge_exchange_host per query)"""

@@ -756,6 +756,12 @@ int mmgpu_multi_pf_run(mmgpu_multi *m, mmgpu_multi_pf_batch *mb) { return mmgpu_
 int mmgpu_multi_pf_fetch(mmgpu_multi *m, mmgpu_multi_pf_batch *mb, mmgpu_pf_hit *hits, uint32_t stride, uint32_t *counts, int32_t *status) {
     return mmgpu_pf_fetch(m->ctx[0], mb->b, hits, stride, counts, status, NULL);
 }
+int mmgpu_multi_has_unsplit(mmgpu_multi *) { return 1; }      // (the stand-in answers from the whole database in the first place)
+int mmgpu_multi_pf_redone(mmgpu_multi_pf_batch *, uint32_t *n_redone, uint32_t *n_left) {
+    if (n_redone) *n_redone = 0;
+    if (n_left) *n_left = 0;
+    return 0;
+}
 void mmgpu_multi_pf_free(mmgpu_multi *m, mmgpu_multi_pf_batch *mb) {
     if (!mb) return;
     mmgpu_pf_free(m->ctx[0], mb->b);

@@ -781,6 +781,26 @@ def test_several_device_contexts_in_one_process(tmp_path):
     _several_device_contexts(tmp_path, emulate=False)
 
 
+@pytest.mark.gpu
+def test_sharded_prefilter_reruns_flagged_queries_on_the_device(tmp_path):
+    """MMGPU_DEVICES=0,0 with the database-hit buffer cut down (MMGPU_PF_MAX_DB_MATCHES, the library's test aid) so that queries of the
+    500-sequence example database reach a shard's share of it: such queries come back flagged "shard-dependent order" - and are run once
+    more against the unsplit database ON THE DEVICE (mmgpu_multi_pf_run / mmgpu_multi_pf_fetch), never through a host index
+    (one flagged query made the run build the host's IndexTable).  The result equals the one-context run under the same
+    buffer size (the stock binary has no such knob)."""
+    w = str(tmp_path)
+    copy_db(EXAMPLES, os.path.join(w, "q"))
+    small = {"MMGPU_PF_MAX_DB_MATCHES": "1500"}
+    log1 = run(MMGPU, ["prefilter", "q", "q", "pref_1", "-s", "5.7", "--threads", THREADS, "-v", "3"], w, extra_env=small)
+    assert "using the CPU path" not in log1, log1[-2000:]
+    log2 = run(MMGPU, ["prefilter", "q", "q", "pref_2", "-s", "5.7", "--threads", THREADS, "-v", "3"], w,
+               extra_env=dict(small, MMGPU_DEVICES="0,0", MMGPU_QUERY_GROUPS="1"))
+    assert "1 query group x 2 target shards" in log2, log2[-2500:]
+    assert "ran once more against the unsplit database on the device" in log2, log2[-2500:]
+    assert "building the host index" not in log2 and "shard-dependent order" not in log2, log2[-2500:]
+    assert same(os.path.join(w, "pref_1"), os.path.join(w, "pref_2")) == 500
+
+
 def _query_groups_by_target_shards(tmp_path, emulate):
     """MMGPU_DEVICES=0,0,0,0: the prefilter hook lays the four contexts out as G query groups x S target shards (MMGpuRun::queryGroups:
     2 x 2 by the stage model, or MMGPU_QUERY_GROUPS).  Every group holds the whole database dealt to its S contexts - tantan-masked on

@@ -472,3 +472,104 @@ def test_library_communicator_single_rank_rccl(gpu, matrices, monkeypatch):
         for f in ("id", "score", "diagonal"):
             assert np.array_equal(hits[qi][f][:n], hits_u[qi][f][:n]), (qi, f)
         assert np.all(res[qi]["score"][:n] > 0)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_flagged_queries_are_rerun_against_the_unsplit_database(gpu, matrices, monkeypatch, world):
+    """Prefiltering::mergeTargetSplits (Prefiltering.cpp:412-526) hands no query back, and neither does a sharded run: a query whose
+    shard reaches its share of the reference's databaseHits buffer (flagged MMGPU_PF_SHARD_INEXACT - the tie order at the cut would be
+    shard dependent) runs once more against the WHOLE database, held in a context of its own on the first device, and comes back OK
+    with the unsplit run's list.  MMGPU_PF_MAX_DB_MATCHES makes a 9 000-target database reach that share."""
+    monkeypatch.setenv("MMGPU_PF_MAX_DB_MATCHES", "2500")
+    g = pc.golden()
+    thr = int(g["kmer_thr"])
+    qs, tres, toff = _case(301 + world, 150, 60, 48)
+    km16, um8, s3, i3 = _tables(gpu, g)
+    queries = [dict(q=q, comp_bias=capi.host_comp_bias(km16, g["vtml80_pback"], q, lib=gpu.L)[0], identity_id=None) for q in qs]
+    swq = _sw_queries(g, matrices, qs, gpu.L)
+    mat = matrices["blosum62_sw"]
+    gpu.load_targets(tres, toff, 21)
+    gpu.pf_build_index(6, 21, True, s3, i3, km16, thr, um8)
+    b = gpu.pf_prepare(queries, thr, max_hits=300, ref_bins=2)
+    b.run()
+    fb = gpu.sw_prepare_from_pf(mat, 11, 1, swq, b, mode=1)
+    fb.run()
+    res_u = fb.fetch().reshape(len(qs), b.max_hits)
+    hits_u, counts_u, status_u, stats_u = b.fetch()
+    fb.free()
+    b.free()
+    assert np.all(status_u == 0)
+    assert (stats_u["db_matches"] >= 2500).sum() >= 3      # queries that took the overflow path in the unsplit run
+    m = capi.MMGpuMulti([0] * world)
+    try:
+        m.load_targets(tres, toff, 21)
+        assert m.has_unsplit()
+        m.pf_build_index(6, 21, True, s3, i3, km16, thr, um8)
+        mb = m.pf_prepare(queries, thr, max_hits=300, ref_bins=2)
+        m.pf_run(mb)
+        res_s, _, _ = m.sw_from_pf(mat, 11, 1, swq, mb, len(qs), mode=1)      # (the first reader of the lists: the re-run happens here)
+        hits_s, counts_s, status_s = m.pf_fetch(mb, len(qs))
+        redone, left = m.pf_redone(mb)
+        m.pf_free(mb)
+    finally:
+        m.close()
+    assert redone >= 3 and left == 0, (redone, left)
+    assert np.all(status_s == 0) and np.array_equal(counts_s, counts_u)
+    for qi in range(len(qs)):
+        n = int(counts_u[qi])
+        for f in ("id", "score", "diagonal"):
+            assert np.array_equal(hits_s[qi][f][:n], hits_u[qi][f][:n]), (qi, f)
+        for f in ("score", "q_end", "t_end", "q_start", "t_start", "word"):
+            assert np.array_equal(res_s[qi][f][:n], res_u[qi][f][:n]), (qi, f)
+
+
+def test_one_rank_reruns_its_flagged_queries_in_a_second_context(gpu, matrices, monkeypatch):
+    """The same for one process per GPU (mmgpu_pf_exchange_redo_unsplit): the rank's own exchange batch, a second context on the device
+    with the whole database; flags cleared, lists equal to the unsplit run's, the other lists untouched."""
+    import mmseqs2_amd
+    monkeypatch.setenv("MMGPU_PF_MAX_DB_MATCHES", "2500")
+    g = pc.golden()
+    thr = int(g["kmer_thr"])
+    qs, tres, toff = _case(311, 150, 60, 40)
+    km16, um8, s3, i3 = _tables(gpu, g)
+    queries = [dict(q=q, comp_bias=capi.host_comp_bias(km16, g["vtml80_pback"], q, lib=gpu.L)[0], identity_id=None) for q in qs]
+    full = mmseqs2_amd.MMGpu(0)
+    try:
+        full.load_targets(tres, toff, 21)
+        full.pf_build_index(6, 21, True, s3, i3, km16, thr, um8)
+        bu = full.pf_prepare(queries, thr, max_hits=300, ref_bins=2)
+        bu.run()
+        hits_u, counts_u, status_u, _ = bu.fetch()
+        bu.free()
+        assert np.all(status_u == 0)
+        D.setup_shard(gpu, 0, 1, tres, toff)      # a context without a communicator is its own single rank
+        gpu.pf_build_index(6, 21, True, s3, i3, km16, thr, um8)
+        b = gpu.pf_prepare(queries, thr, max_hits=300, ref_bins=2)
+        b.run()
+        dh, dc, df, stride = b.exchange_merge()
+        gpu.synchronize()
+        nq = len(qs)
+
+        def merged():
+            import ctypes
+            hip = ctypes.CDLL("libamdhip64.so")
+            mh, mc, mf = np.zeros((nq, stride), capi.PF_HIT_DTYPE), np.zeros(nq, np.uint32), np.zeros(nq, np.uint32)
+            for dst, src in ((mh, dh), (mc, dc), (mf, df)):
+                assert hip.hipMemcpy(dst.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(src), dst.nbytes, 2) == 0
+            return mh, mc, mf
+        mh0, mc0, mf0 = merged()
+        assert (mf0 & 1).sum() >= 3
+        redone, left = b.redo_unsplit(full)
+        mh1, mc1, mf1 = merged()
+        b.free()
+    finally:
+        full.close()
+        gpu.pf_clear_shard()
+    assert redone == int((mf0 & 1).sum()) and left == 0 and not mf1.any()
+    assert np.array_equal(mc1, counts_u)
+    for qi in range(nq):
+        n = int(counts_u[qi])
+        for f in ("id", "score", "diagonal"):
+            assert np.array_equal(mh1[qi][f][:n], hits_u[qi][f][:n]), (qi, f)
+        if not mf0[qi] & 1:
+            assert np.array_equal(mh1[qi][:n], mh0[qi][:n]), qi
