@@ -253,9 +253,6 @@ struct PfDedupArgs {
     const uint32_t *q_nseg;           // [nq] databaseHits flushes of the query (0 = ordinary query)
     const uint32_t *seg_start;        // [nq][PF_MAX_SEG + 2] arrival index at which segment k starts
     // buckets the compact replay hands to the full-state one (more emitting targets than its table holds)
-    uint32_t *redo_count;             // [1], zeroed by launch_pf_dedup
-    uint32_t *redo_list;              // [nq * bins]
-    uint32_t emit_cap;                // table entries the compact replay may use (<= 64; tests lower it)
 };
 
 struct PfSelectArgs {

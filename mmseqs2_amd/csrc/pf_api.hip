@@ -543,7 +543,6 @@ struct mmgpu_pf_batch_t {
     DevBuf d_qtile_base, d_qntiles, d_bucket_count, d_bucket_off;
     DevBuf d_ovf_queries, d_qnseg, d_seg_start, d_qfinal, d_ovf_base, d_ovf_a, d_ovf_b, d_ovf_ocount, d_ovf_totals;
     DevBuf d_cand_small, d_cand_base, d_cand_count, d_cells, d_surv_count, d_hits, d_hit_count, d_diag_thr, d_qflags;
-    DevBuf d_redo;                     // [1 + nq * bins]: length + list of the buckets the compact replay hands on
     std::vector<uint8_t> long_query;   // queries of 32768 residues or more: not processed on the device (MMGPU_PF_LONG_SEQ)
     bool exchange = false;     // prepared while a shard was set (mmgpu_pf_set_shard): d_hits holds mmgpu_pf_xhit records
     // host mirrors of the last run
@@ -625,7 +624,7 @@ extern "C" int mmgpu_pf_prepare(mmgpu_ctx *c, const mmgpu_pf_params *par, const 
                       &b->d_qbase, &b->d_list_base, &b->d_pos_entries, &b->d_peb, &b->d_qentries, &b->d_qtile_base, &b->d_qntiles,
                       &b->d_bucket_count, &b->d_bucket_off, &b->d_ovf_queries, &b->d_qnseg, &b->d_seg_start, &b->d_qfinal, &b->d_ovf_base,
                       &b->d_ovf_a, &b->d_ovf_b, &b->d_ovf_ocount, &b->d_ovf_totals, &b->d_cand_small, &b->d_cand_base, &b->d_cand_count,
-                      &b->d_cells, &b->d_surv_count, &b->d_hits, &b->d_hit_count, &b->d_diag_thr, &b->d_qflags, &b->d_redo, &b->x_recv_hits,
+                      &b->d_cells, &b->d_surv_count, &b->d_hits, &b->d_hit_count, &b->d_diag_thr, &b->d_qflags, &b->x_recv_hits,
                       &b->x_recv_counts, &b->x_hits, &b->x_counts, &b->x_flags, &b->x_ident, &b->d_pos_order})
         d->bind(c->cache);
     b->par = *par;
@@ -777,7 +776,6 @@ extern "C" int mmgpu_pf_prepare(mmgpu_ctx *c, const mmgpu_pf_params *par, const 
     B_TRY(b->d_hit_count.alloc(nqq * 4));
     B_TRY(b->d_diag_thr.alloc(nqq * 4));
     B_TRY(b->d_qflags.alloc(nqq * 4));
-    B_TRY(b->d_redo.alloc(((size_t)nqq * bins + 1) * 4));
     if (par->nucleotide || par->kmer_score) B_TRY(b->d_qncand.alloc(nqq * 4));
     if (par->nucleotide) {
         B_TRY(b->d_sat.alloc((size_t)nqq * PF_SAT_CAP * sizeof(PfCand)));
@@ -1070,10 +1068,6 @@ extern "C" int mmgpu_pf_run(mmgpu_ctx *c, mmgpu_pf_batch_t *b) {
     D.seg_start = ovf_q.empty() ? nullptr : b->d_seg_start.as<uint32_t>();
     D.cell_counter = b->d_cells.as<uint64_t>();
     D.q_flags = b->d_qflags.as<uint32_t>();
-    D.redo_count = b->d_redo.as<uint32_t>();
-    D.redo_list = b->d_redo.as<uint32_t>() + 1;
-    D.emit_cap = 64;
-    if (const char *e = getenv("MMGPU_PF_EMIT_CAP")) D.emit_cap = (uint32_t)strtoul(e, nullptr, 10);      // tests: a small table reaches the redo path
     // the flushes of the overflow path: per-query bases relative to the first overflow query of the same chunk
     std::vector<uint32_t> ovf_chunk_lo(n_chunks + 1, 0);
     PfOvfArgs O;

@@ -1034,77 +1034,79 @@ __device__ __forceinline__ uint64_t score_chunk(const PfDedupArgs &A, const int8
 // de-duplicated per target on that byte (:240-265).  Output: candidates (id, diagonal, arrival index) in arrival
 // order at cand[cand_base[bucket] ..), their number in cand_count[bucket].
 //
-// The kernel waits on chains of LDS and cross-lane operations, so its throughput follows the number of resident wavefronts
-// (measured: half the occupancy = 1.74x the time), and LDS is what bounds them.  Two forms of the per-target state:
-//   COMPACT: `prev` as one byte per target (4 KB) + one "has emitted" bit; the byte last emitted is only kept for the targets
-//            that HAVE emitted - a handful per bucket - in a table of PF_EMIT_TAB (key, byte) pairs, one per lane.  5.8 KB per
-//            wavefront: six workgroups per CU.  A bucket with more emitting targets than the table holds is put on the
-//            redo list.
-//   full:    uint16 = prev | last emitted byte << 8 for every target (8.5 KB per wavefront); runs the redo list.
-#ifndef MMGPU_PF_REPLAY_PD
-#define MMGPU_PF_REPLAY_PD 1
-#endif
+// Round 6: the sequential semantics come from the LDS itself.  A round is 64 consecutive entries of the bucket, one per lane, and
+// the CPU's `prev = tmp[id]; tmp[id] = diagonal` is ONE instruction for all of them: ds_mskor_rtn_b32, a byte-granular atomic
+// exchange (the word's other three targets keep their bytes).  When several lanes of the instruction name the same target, the
+// LDS applies them one after the other IN ASCENDING LANE ORDER - arrival order - so that every lane receives exactly the byte its
+// predecessor left, within the round or before it (scripts/probes/lds_atomic_order.hip: 50 M lanes under every degree of conflict,
+// no deviation; tests/test_prefilter_gpu.py runs the same probe, and every hit list of the bench run is compared with the
+// reference's).  58 % of the rounds of the 10 000 x 1 M batch hold a target more than once (homologs hit on every position);
+// rounds 3 - 5 found those lanes with an LDS bit per target, matched their keys and walked predecessor masks - ~70 of the 222
+// VALU instructions of a round.  The second pass works the same way on the flagged lanes only: an atomic OR on the target's "has
+// emitted" bit (first emission?) and a second byte exchange on the byte last emitted.  No emitter table, no redo list.
+// Per wavefront: 4 KB previous bytes + 4 KB emitted bytes + 512 B bits + the first 64 candidates: 9.5 KB, four workgroups per CU.
 #ifndef MMGPU_PF_REPLAY_EU
-#define MMGPU_PF_REPLAY_EU 6
+#define MMGPU_PF_REPLAY_EU 4
 #endif
-constexpr int PF_EMIT_TAB = 64;
+// rounds whose entries are in flight while a round is processed: with ~70 instructions per round the kernel waits for memory, and a
+// wavefront's 256 bytes per round are few - the rounds ahead are what keeps the memory system busy
+#ifndef MMGPU_PF_REPLAY_PD
+#define MMGPU_PF_REPLAY_PD 4
+#endif
 
 #ifdef MMGPU_PF_REPLAY_STATS
 // experiment build only (scripts/build_variant.sh ... -DMMGPU_PF_REPLAY_STATS): where the replay's rounds go.
-// [0] buckets [1] rounds [2] rounds with a target twice [3] lanes whose target occurs twice in their round [4] entries
-// [5] flagged entries [6] kept entries [7] rounds with an emitter looked up (again != 0) [8] tile chunks [9] candidates scored
+// [0] buckets [1] rounds [2] rounds with a flagged entry [4] entries [5] flagged entries [6] kept entries [8] tile chunks
 __device__ unsigned long long g_replay_stats[16];
 #define RSTAT(i, v) do { if (lane == 0) atomicAdd(&g_replay_stats[i], (unsigned long long)(v)); } while (0)
 #else
 #define RSTAT(i, v) do { } while (0)
 #endif
 
-template <bool COMPACT>
 struct ReplayLds {
-    typename std::conditional<COMPACT, uint8_t, uint16_t>::type state[4][PF_IDS_PER_BIN];
-    uint32_t emit[4][PF_IDS_PER_BIN / 32];
-    uint32_t tab[COMPACT ? 4 : 1][COMPACT ? PF_EMIT_TAB : 1];   // key << 8 | byte last emitted
-    uint32_t cand[4][4][64];   // first 64 candidates of the bucket: id, arrival index, diagonal, index of the entry in the split tiles
+    uint32_t prev[4][PF_IDS_PER_BIN / 4];     // a byte per target: low diagonal byte of the target's previous entry
+    uint32_t last[4][PF_IDS_PER_BIN / 4];     // a byte per target: diagonal byte of its last emitted entry (read only where `emit` is set)
+    uint32_t emit[4][PF_IDS_PER_BIN / 32];    // a bit per target: has emitted
+    uint32_t cand[4][3][64];   // first 64 candidates of the bucket: key | diagonal byte << 12, arrival index, index of the entry in the split tiles
     uint8_t mark[4][64];       // segment starts of a round (request)
-    uint32_t dup[4][PF_IDS_PER_BIN / 32];     // one bit per target: set and taken back within a round (all zero between rounds)
     int8_t smat[32 * 32];
 };
 
-// returns false when the bucket has to be redone with the full state (COMPACT only)
+// byte-granular atomic exchange in LDS: the byte `shift / 8` of *word becomes `byte`, the old word comes back.  Lanes of one
+// instruction that name the same word are applied in ascending lane order (see above).
+__device__ __forceinline__ uint32_t lds_byte_exchange(uint32_t *word, uint32_t shift, uint32_t byte) {
+    uint32_t old;
+    const uint32_t addr = (uint32_t)(uintptr_t)word;
+    asm volatile("ds_mskor_rtn_b32 %0, %1, %2, %3\n\ts_waitcnt lgkmcnt(0)" : "=v"(old) : "v"(addr), "v"(0xFFu << shift), "v"(byte << shift) : "memory");
+    return old;
+}
+
 // SEGS: the query is on the reference's overflow path (databaseHits flushes, nseg > 0).  The ordinary query's round is straight
-// line code: no boundary compare, no loop over the pieces of a round (round 5: the loop's exec-mask bookkeeping sat in every round).
-template <bool COMPACT, bool SEGS>
-__device__ __forceinline__ bool replay_bucket_impl(const PfDedupArgs &A, ReplayLds<COMPACT> &M, uint64_t bucket) {
+// line code: no boundary compare, no loop over the pieces of a round.
+template <bool SEGS>
+__device__ __forceinline__ void replay_bucket_impl(const PfDedupArgs &A, ReplayLds &M, uint64_t bucket) {
     const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
     const uint32_t B = A.bins;
     const uint32_t q = (uint32_t)(bucket / B), bin = (uint32_t)(bucket % B);
     const uint32_t ntiles = A.q_ntiles[q];
     if (ntiles == 0) {
         if (lane == 0) A.cand_count[bucket] = 0;
-        return true;
+        return;
     }
     RSTAT(0, 1);
     const uint32_t tb = A.q_tile_base[q];
-    auto *S = M.state[wave];
+    uint32_t *P = M.prev[wave];
+    uint32_t *L = M.last[wave];
     uint32_t *E = M.emit[wave];
-    uint32_t *T = M.tab[COMPACT ? wave : 0];
     uint8_t *mark = M.mark[wave];
-    uint32_t *Dup = M.dup[wave];
     int bshift = 0;
     while ((1u << bshift) < B) bshift++;
-    auto clear_state = [&]() {
-        if (COMPACT) {
-            uint32_t *S4 = reinterpret_cast<uint32_t *>(S);
-            for (int k = lane; k < PF_IDS_PER_BIN / 4; k += 64) S4[k] = 0;
-        } else {
-            for (int k = lane; k < PF_IDS_PER_BIN; k += 64) S[k] = 0;
-        }
+    auto clear_state = [&]() {      // (the emitted bytes are only read under a set bit: the bits are what is cleared)
+        uint4 *P4 = reinterpret_cast<uint4 *>(P);
+        for (int k = lane; k < PF_IDS_PER_BIN / 16; k += 64) P4[k] = make_uint4(0u, 0u, 0u, 0u);
         for (int k = lane; k < PF_IDS_PER_BIN / 32; k += 64) E[k] = 0;
     };
     clear_state();
-    for (int k = lane; k < PF_IDS_PER_BIN / 32; k += 64) Dup[k] = 0;
-    uint32_t nem = 0;                 // COMPACT: entries of the emitter table
-    const uint32_t emit_cap = COMPACT ? min((uint32_t)PF_EMIT_TAB, A.emit_cap) : 0u;
 
     uint32_t ncand = 0;
     const uint64_t below = lanes_below(lane);
@@ -1124,10 +1126,6 @@ __device__ __forceinline__ bool replay_bucket_impl(const PfDedupArgs &A, ReplayL
         const uint32_t excl = incl - n;
         RSTAT(8, 1);
         RSTAT(4, total);
-        // software pipeline: the entries of the next MMGPU_PF_REPLAY_PD rounds are in flight while a round is processed
-        // (one round ahead is enough: deeper pipelines measured the same)
-        uint32_t e_q[MMGPU_PF_REPLAY_PD];
-        uint32_t tile_q[MMGPU_PF_REPLAY_PD], at_q[MMGPU_PF_REPLAY_PD];      // tile of the entry, and where it stands in that tile
         // Tile whose segment holds the bucket's entry x, for the 64 entries of a round at once (rounds are requested in
         // increasing order): every tile whose non-empty segment starts inside the round marks its slot, a running maximum
         // along the lanes spreads the marks, the segment that reaches into the round from before is the last one of the
@@ -1150,11 +1148,10 @@ __device__ __forceinline__ bool replay_bucket_impl(const PfDedupArgs &A, ReplayL
             e_out = 0;
             if (x < total) e_out = A.split[(size_t)(tb + tile_out) * PF_T + at_out];
         };
+        uint32_t e_q[MMGPU_PF_REPLAY_PD], tile_q[MMGPU_PF_REPLAY_PD], at_q[MMGPU_PF_REPLAY_PD];
 #pragma unroll
         for (int k = 0; k < MMGPU_PF_REPLAY_PD; k++) {
-            e_q[k] = 0;
-            tile_q[k] = 0;
-            at_q[k] = 0;
+            e_q[k] = 0; tile_q[k] = 0; at_q[k] = 0;
             if ((uint32_t)k * 64u < total) request((uint32_t)k * 64u, e_q[k], tile_q[k], at_q[k]);
         }
         for (uint32_t xg = 0; xg < total; xg += 64u * MMGPU_PF_REPLAY_PD) {
@@ -1168,9 +1165,10 @@ __device__ __forceinline__ bool replay_bucket_impl(const PfDedupArgs &A, ReplayL
             const bool act = x0 + (uint32_t)lane < total;
             if (x0 + 64u * MMGPU_PF_REPLAY_PD < total) request(x0 + 64u * MMGPU_PF_REPLAY_PD, e_q[pk], tile_q[pk], at_q[pk]);
             const uint32_t key = e & 0xFFFu;   // < PF_IDS_PER_BIN
-            const uint32_t id = (key << bshift) | bin;
             const uint32_t d8 = (e >> 12) & 0xFFu;
             const uint32_t arr = tile_cur * (uint32_t)PF_T + (e >> 20);
+            const uint32_t sh = (key & 3u) * 8u;
+            RSTAT(1, 1);
             // Overflow path (nseg > 0): the reference flushes databaseHits at segment boundaries and starts the
             // double-diagonal state from scratch (QueryMatcher.cpp:310-346), so a round that straddles a boundary is
             // processed in pieces with the tables cleared in between.
@@ -1178,151 +1176,47 @@ __device__ __forceinline__ bool replay_bucket_impl(const PfDedupArgs &A, ReplayL
             while (todo) {
                 const bool now = SEGS ? (act && ((todo >> lane) & 1ull) && arr < next_boundary) : act;
                 if (!SEGS || ballot(now)) {
-                    uint32_t st = 0, em = 0;
-                    if (now) {
-                        st = S[key];
-                        em = (E[key >> 5] >> (key & 31u)) & 1u;
-                    }
-                    // Does a target occur twice in this round?  One LDS bit per target: an atomic OR that returns the old word
-                    // tells a lane that another lane of the round has set its bit; the bits are taken back right away.  In most
-                    // rounds (64 entries over 4096 targets) none does, and the bookkeeping between the entries of one target
-                    // (matching the keys of all lanes, predecessor / run searches) is skipped.
-                    bool twice = false;
-                    if (now) twice = (atomicOr(&Dup[key >> 5], 1u << (key & 31u)) >> (key & 31u)) & 1u;
-                    const bool uniq = ballot(twice) == 0;
-                    RSTAT(1, 1);
-                    RSTAT(2, uniq ? 0 : 1);
-                    RSTAT(3, __popcll(ballot(twice)));
-                    if (now) atomicAnd(&Dup[key >> 5], ~(1u << (key & 31u)));
-                    bool flag, has_fm, has_fbelow, group_last;
-                    uint32_t d_fpl, d_fhi;
-                    int group_hi;
-                    if (uniq) {
-                        flag = now && d8 == (st & 0xFFu);
-                        has_fm = flag;
-                        has_fbelow = false;
-                        group_last = now;
-                        d_fpl = d8;
-                        d_fhi = d8;
-                        group_hi = lane;
-                    } else {
-                        // The lanes of my target.  Every target that occurs more than once has a lane that found its bit set
-                        // (`twice`): one pass per such target - a handful per round - instead of matching the 12 key bits of
-                        // all lanes against each other (72 instructions; the replay is bound by instruction issue).
-#ifdef MMGPU_PF_REPLAY_MATCH12
-                        const uint64_t same = match_lanes(key, 12, now);
-#else
-                        uint64_t same = 1ull << lane;
-                        for (uint64_t dm = ballot(twice); dm != 0;) {
-                            const uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)key, __ffsll((long long)dm) - 1);
-                            const uint64_t g = ballot(now && key == k);
-                            if (key == k) same = g;
-                            dm &= ~g;
+                    // first pass (:194-208): the byte the target's previous entry left, mine in its place
+                    bool flag = false;
+                    if (now) flag = ((lds_byte_exchange(&P[key >> 2], sh, d8) >> sh) & 0xFFu) == d8;
+                    if (ballot(flag)) {
+                        RSTAT(2, 1);
+                        RSTAT(5, __popcll(ballot(flag)));
+                        // second pass (:240-265) over the flagged entries, in their order: the first of a target is kept, a later one
+                        // when its byte differs from the one the target emitted last
+                        bool keep = false;
+                        if (flag) {
+                            const uint32_t bit = 1u << (key & 31u);
+                            const bool emitted_before = (atomicOr(&E[key >> 5], bit) & bit) != 0u;
+                            const uint32_t last_byte = (lds_byte_exchange(&L[key >> 2], sh, d8) >> sh) & 0xFFu;
+                            keep = !emitted_before || last_byte != d8;
                         }
-#endif
-                        // stage 1: does my diagonal byte equal the previous entry's of this target?
-                        const uint64_t pm = same & below;
-                        const int pl = pm ? highest_lane(pm) : lane;
-                        const uint32_t d_pl = __shfl(d8, pl);
-                        const uint32_t prevd = pm ? d_pl : (st & 0xFFu);
-                        flag = now && d8 == prevd;
-                        // stage 2: run-length de-duplication over the flagged entries of this target
-                        const uint64_t fl = ballot(flag);
-                        const uint64_t fm = same & fl;
-                        const uint64_t fbelow = fm & below;
-                        const int fpl = fbelow ? highest_lane(fbelow) : lane;
-                        d_fpl = __shfl(d8, fpl);
-                        group_last = now && (same & ~below & ~(1ull << lane)) == 0;   // last lane of its target
-                        const int fhi = fm ? highest_lane(fm) : lane;
-                        d_fhi = __shfl(d8, fhi);
-                        has_fm = fm != 0;
-                        has_fbelow = fbelow != 0;
-                        group_hi = highest_lane(same | (1ull << lane));
-                    }
-                    uint32_t last_emitted = (st >> 8) & 0xFFu;       // full state; COMPACT: from the table
-                    uint32_t tab_idx = 0;
-                    if (COMPACT) {
-                        // targets of this round that emit again: their group's last lane looks the table entry up, the
-                        // group's first flagged lane (the one the byte decides for) reads it from there
-                        const uint64_t again = ballot(group_last && has_fm && em != 0u);
-                        RSTAT(7, again ? 1 : 0);
-                        uint32_t lb_mine = 0;
-                        if (again) {
-                            asm volatile("" ::: "memory");      // the table is written by other lanes
-                            const uint32_t tv = T[lane];
-                            uint64_t w = again;
-                            while (w) {
-                                const int l = __ffsll((long long)w) - 1;
-                                w &= w - 1;
-                                const uint32_t k = (uint32_t)__shfl((int)key, l);
-                                const uint64_t hit = ballot((uint32_t)lane < nem && (tv >> 8) == k);
-                                const int idx = hit ? __ffsll((long long)hit) - 1 : 0;     // an emitter is in the table
-                                const uint32_t v = (uint32_t)__shfl((int)tv, idx);
-                                if (lane == l) {
-                                    lb_mine = v & 0xFFu;
-                                    tab_idx = (uint32_t)idx;
-                                }
+                        const uint64_t kb = ballot(keep);
+                        RSTAT(6, __popcll(kb));
+                        if (keep) {
+                            PfCand c;
+                            c.id = (key << bshift) | bin;
+                            c.arr = arr;
+                            // ordinary query: the scoring step reads the high diagonal byte (score_chunk); the overflow path's
+                            // kernels take the candidates as they are, so their diagonals are completed here
+                            c.score = SEGS ? 0u : where;
+                            c.diag = (uint16_t)(SEGS ? (d8 | ((uint32_t)A.split_hi[where] << 8)) : d8);
+                            c.pad = (uint16_t)cur_seg;
+                            const uint32_t ck = ncand + (uint32_t)__popcll(kb & below);
+                            *cand_slot(A, bucket, ck) = c;
+                            if (!SEGS && ck < 64) {
+                                M.cand[wave][0][ck] = key | (d8 << 12);
+                                M.cand[wave][1][ck] = arr;
+                                M.cand[wave][2][ck] = where;
                             }
                         }
-                        last_emitted = uniq ? lb_mine : (uint32_t)__shfl((int)lb_mine, group_hi);
+                        ncand += (uint32_t)__popcll(kb);
                     }
-                    bool keep;
-                    if (has_fbelow) keep = flag && d_fpl != d8;
-                    else keep = flag && (em == 0u || last_emitted != d8);
-                    // state update by the last lane of every target group
-                    if (COMPACT) {
-                        const bool fresh = group_last && has_fm && em == 0u;
-                        const uint64_t fb = ballot(fresh);
-                        if (nem + (uint32_t)__popcll(fb) > emit_cap) return false;      // wave-uniform
-                        if (group_last) {
-                            S[key] = (uint8_t)d8;
-                            if (has_fm) {
-                                if (em == 0u) {
-                                    tab_idx = nem + (uint32_t)__popcll(fb & below);
-                                    atomicOr(&E[key >> 5], 1u << (key & 31u));
-                                }
-                                T[tab_idx] = (key << 8) | d_fhi;
-                            }
-                        }
-                        nem += (uint32_t)__popcll(fb);
-                    } else if (group_last) {
-                        uint32_t ns = d8;
-                        if (has_fm) {
-                            ns |= d_fhi << 8;
-                            if (em == 0u) atomicOr(&E[key >> 5], 1u << (key & 31u));
-                        } else {
-                            ns |= st & 0xFF00u;
-                        }
-                        S[key] = (uint16_t)ns;
-                    }
-                    const uint64_t kb = ballot(keep);
-                    RSTAT(5, __popcll(ballot(flag)));
-                    RSTAT(6, __popcll(kb));
-                    if (keep) {
-                        PfCand c;
-                        c.id = id;
-                        c.arr = arr;
-                        // ordinary query: the scoring step reads the high diagonal byte (score_chunk); the overflow path's
-                        // kernels take the candidates as they are, so their diagonals are completed here
-                        c.score = SEGS ? 0u : where;
-                        c.diag = (uint16_t)(SEGS ? (d8 | ((uint32_t)A.split_hi[where] << 8)) : d8);
-                        c.pad = (uint16_t)cur_seg;
-                        const uint32_t ck = ncand + (uint32_t)__popcll(kb & below);
-                        *cand_slot(A, bucket, ck) = c;
-                        if (ck < 64) {
-                            M.cand[wave][0][ck] = c.id;
-                            M.cand[wave][1][ck] = c.arr;
-                            M.cand[wave][2][ck] = c.diag;
-                            M.cand[wave][3][ck] = c.score;
-                        }
-                    }
-                    ncand += (uint32_t)__popcll(kb);
                 }
                 if (!SEGS) break;
                 todo &= ~ballot(now);
                 if (todo) {   // the remaining entries belong to the next segment: fresh state
                     clear_state();
-                    nem = 0;
                     cur_seg++;
                     next_boundary = cur_seg + 1 <= nseg ? segs[cur_seg + 1] : 0xFFFFFFFFu;
                 }
@@ -1333,14 +1227,15 @@ __device__ __forceinline__ bool replay_bucket_impl(const PfDedupArgs &A, ReplayL
     if (lane == 0) A.cand_count[bucket] = ncand;
     // a8 + keepMaxElement for the common case of at most 64 candidates, straight from LDS (no second kernel's
     // count -> record -> metadata round trips); larger buckets are left to pf_ungapped_kernel / pf_keepmax_kernel
-    if (ncand > 0 && ncand <= 64 && nseg == 0) {
+    if (!SEGS && ncand > 0 && ncand <= 64) {
         PfCand c;
         c.id = 0; c.arr = 0; c.score = 0; c.diag = 0; c.pad = 0;
         if ((uint32_t)lane < ncand) {
-            c.id = M.cand[wave][0][lane];
+            const uint32_t kd = M.cand[wave][0][lane];
+            c.id = ((kd & 0xFFFu) << bshift) | bin;
             c.arr = M.cand[wave][1][lane];
-            c.diag = (uint16_t)M.cand[wave][2][lane];
-            c.score = M.cand[wave][3][lane];
+            c.diag = (uint16_t)(kd >> 12);
+            c.score = M.cand[wave][2][lane];
         }
         uint64_t cells = score_chunk(A, M.smat, nullptr, nullptr, bucket, q, 0, ncand, ncand, c, bshift);
         if (A.cell_counter) {
@@ -1348,42 +1243,19 @@ __device__ __forceinline__ bool replay_bucket_impl(const PfDedupArgs &A, ReplayL
             if (lane == 0 && cells) atomicAdd((unsigned long long *)&A.cell_counter[q], (unsigned long long)cells);
         }
     }
-    return true;
-}
-
-template <bool COMPACT>
-__device__ __forceinline__ bool replay_bucket(const PfDedupArgs &A, ReplayLds<COMPACT> &M, uint64_t bucket) {
-    if (A.q_nseg && A.q_nseg[(uint32_t)(bucket / A.bins)]) return replay_bucket_impl<COMPACT, true>(A, M, bucket);      // wave-uniform
-    return replay_bucket_impl<COMPACT, false>(A, M, bucket);
 }
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MMGPU_PF_REPLAY_EU))) void pf_replay_kernel(PfDedupArgs A) {
-    __shared__ ReplayLds<true> M;
-    const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
-    for (int k = (int)threadIdx.x; k < 32 * 32; k += 256) M.smat[k] = k < A.alphabet * A.alphabet ? A.mat[k] : (int8_t)0;
-    __syncthreads();
-    // the buckets of one query read the same tiles (bin after bin of every tile): a contiguous run of queries per XCD would keep a
-    // tile's lines in one L2 instead of fetching them into all eight
-    // (measured, profiles/r05_exp_pf_order_and_swizzle.txt: 31.7 -> 35.6 ms - an eighth of the batch's queries per XCD is an
-    // uneven share of the work, the round-robin deal is not; kept as an experiment switch)
-#ifdef MMGPU_PF_REPLAY_SWZ
-    const uint32_t wg = xcd_contiguous(blockIdx.x, gridDim.x);
-#else
-    const uint32_t wg = blockIdx.x;
-#endif
-    const uint64_t bucket = (uint64_t)A.q_first * A.bins + (uint64_t)wg * 4u + (uint32_t)wave;
-    if (bucket >= (uint64_t)(A.q_first + A.n_queries) * A.bins) return;
-    if (!replay_bucket<true>(A, M, bucket) && lane == 0) A.redo_list[atomicAdd(A.redo_count, 1u)] = (uint32_t)bucket;
-}
-
-// the buckets the compact form gave up on, with the full per-target state; the grid is fixed (the list length lives on the device)
-__global__ __launch_bounds__(256) void pf_replay_redo_kernel(PfDedupArgs A) {
-    __shared__ ReplayLds<false> M;
+    __shared__ ReplayLds M;
     const int wave = (int)(threadIdx.x >> 6);
     for (int k = (int)threadIdx.x; k < 32 * 32; k += 256) M.smat[k] = k < A.alphabet * A.alphabet ? A.mat[k] : (int8_t)0;
     __syncthreads();
-    const uint32_t n = *A.redo_count;
-    for (uint32_t i = blockIdx.x * 4u + (uint32_t)wave; i < n; i += gridDim.x * 4u) replay_bucket<false>(A, M, A.redo_list[i]);
+    // (the buckets of one query read the same tiles; a contiguous run of queries per XCD measured slower than the round-robin
+    // deal - an eighth of the batch's queries is an uneven share of the work: profiles/r05_exp_pf_order.txt)
+    const uint64_t bucket = (uint64_t)A.q_first * A.bins + (uint64_t)blockIdx.x * 4u + (uint32_t)wave;
+    if (bucket >= (uint64_t)(A.q_first + A.n_queries) * A.bins) return;
+    if (A.q_nseg && A.q_nseg[(uint32_t)(bucket / A.bins)]) replay_bucket_impl<true>(A, M, bucket);      // wave-uniform
+    else replay_bucket_impl<false>(A, M, bucket);
 }
 
 // Buckets with more than 64 candidates (the replay kernel scores the others itself): one wavefront per (query, bin).
@@ -2385,8 +2257,7 @@ hipError_t launch_pf_dedup(const PfDedupArgs &A, hipEvent_t after_replay, hipEve
     const uint64_t buckets = (uint64_t)A.n_queries * A.bins;
     if (buckets == 0) return hipSuccess;
     const dim3 grid((unsigned)((buckets + 3) / 4)), block(256);
-    hipError_t e = hipMemsetAsync(A.redo_count, 0, sizeof(uint32_t), s);
-    if (e != hipSuccess) return e;
+    hipError_t e;
     hipLaunchKernelGGL(pf_replay_kernel, grid, block, 0, s, A);
     if ((e = hipGetLastError()) != hipSuccess) return e;
 #ifdef MMGPU_PF_REPLAY_STATS
@@ -2394,12 +2265,10 @@ hipError_t launch_pf_dedup(const PfDedupArgs &A, hipEvent_t after_replay, hipEve
         unsigned long long h[16];
         (void)hipStreamSynchronize(s);
         (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_replay_stats), sizeof(h));
-        fprintf(stderr, "[replay stats, cumulative] buckets %llu rounds %llu dup_rounds %llu dup_lanes %llu entries %llu flagged %llu kept %llu again_rounds %llu chunks %llu\n",
-                h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8]);
+        fprintf(stderr, "[replay stats, cumulative] buckets %llu rounds %llu rounds_with_a_flag %llu entries %llu flagged %llu kept %llu chunks %llu\n",
+                h[0], h[1], h[2], h[4], h[5], h[6], h[8]);
     }
 #endif
-    hipLaunchKernelGGL(pf_replay_redo_kernel, dim3((unsigned)std::min<uint64_t>((buckets + 3) / 4, 1024)), block, 0, s, A);
-    if ((e = hipGetLastError()) != hipSuccess) return e;
     if (after_replay && (e = hipEventRecord(after_replay, s)) != hipSuccess) return e;
     hipLaunchKernelGGL(pf_ungapped_kernel, grid, block, 0, s, A);
     if ((e = hipGetLastError()) != hipSuccess) return e;

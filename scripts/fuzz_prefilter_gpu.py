@@ -38,11 +38,7 @@ for r in range(rounds):
                        identity_id=int(rng.integers(0, nt)) if i % 3 == 0 else None))
     orc = pc.pf_oracle()
     orc.build_index(tres, toff, thr)
-    for cap, bitmap in ((None, "0"), ("2", "1")):
-        if cap is None:
-            os.environ.pop("MMGPU_PF_EMIT_CAP", None)
-        else:
-            os.environ["MMGPU_PF_EMIT_CAP"] = cap
+    for cap, bitmap in ((None, "0"), (None, "1")):
         os.environ["MMGPU_PF_BITMAP"] = bitmap
         chk.load_case(gpu, g, tres, toff, thr)
         for mh, rb in ((300, 2), (int(rng.integers(5, 60)), int(rng.choice([2, 8, 64])))):

@@ -1,5 +1,7 @@
 """GPU parity tests of the prefilter (through the C-ABI): every stage of the device pipeline and the final hit_t
 lists against the oracle, and the final lists against the golden vectors recorded from the real reference."""
+import os
+
 import numpy as np
 import pytest
 
@@ -432,28 +434,40 @@ def test_candidate_sets_of_half_the_diagonal_array_go_to_the_host(gpu, golden_ca
             assert s1[qi] == 0 and c1[qi] == c0[qi] and np.array_equal(h1[qi][:c1[qi]], h0[qi][:c0[qi]]), qi
 
 
-@pytest.mark.parametrize("cap", [0, 1, 3])
-def test_replay_redo_list_gives_the_same_lists(gpu, golden_case, monkeypatch, cap):
-    """The replay kernel keeps the byte a target emitted last only for the targets that have emitted, in a 64-entry table per
-    (query, bin); a bucket with more emitting targets goes through the full-state kernel (pf_replay_redo_kernel).  With the
-    table cut to `cap` entries (MMGPU_PF_EMIT_CAP) nearly every bucket with a candidate takes that path: every stage and the
-    final lists must still equal the oracle's."""
-    g, orc = golden_case
-    monkeypatch.setenv("MMGPU_PF_EMIT_CAP", str(cap))
-    try:
-        ok, rep = chk.check(gpu, orc, pc.golden_queries(g), 300, 2, stages=True, label="golden/redo%d" % cap)
-    finally:
-        monkeypatch.delenv("MMGPU_PF_EMIT_CAP", raising=False)
-    assert ok, "\n".join(rep)
+def test_lds_applies_the_lanes_of_one_atomic_in_lane_order(gpu, tmp_path):
+    """What the replay kernel rests on since round 6 (pf_kernels.hip, lds_byte_exchange): lanes of ONE ds_mskor_rtn_b32 / ds_or_rtn_b32
+    that name the same LDS word are applied in ascending lane order, so that `prev = tmp[id]; tmp[id] = diagonal`
+    (CacheFriendlyOperations.cpp:194-208) for the 64 entries of a round is one instruction whatever targets repeat inside it.  The
+    probe replays 16.7 M lanes under every degree of conflict (2 ... 4096 distinct keys) against the sequential loop on the host."""
+    import subprocess
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "probes", "lds_atomic_order.hip")
+    exe = str(tmp_path / "lds_atomic_order")
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-Wno-unused-value", "-o", exe, src], check=True,
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0 and "mismatches 0, test-and-set mismatches 0" in r.stdout, r.stdout
 
 
-def test_replay_redo_list_on_the_overflow_path(gpu, monkeypatch):
-    """... and with segments (databaseHits flushes): the table is emptied at every segment boundary like the rest of the state"""
-    monkeypatch.setenv("MMGPU_PF_EMIT_CAP", "2")
+def test_replay_of_buckets_full_of_repeated_targets(gpu):
+    """Rounds in which nearly every lane names a target another lane names too (few targets, nearly all of them planted homologs of the
+    queries: hit on every query position): every stage against the oracle.  (With segments - databaseHits flushes - the same is
+    test_prefilter_overflow_path's long queries.)"""
+    from oracle.pyoracle import Oracle
+    swo = Oracle()
+    g = pc.golden()
+    thr = int(g["kmer_thr"])
+    (qres, qoff), (tres, toff) = pc.synthetic_case(24, 600, seed=77, planted=0.9)
+    orc = pc.pf_oracle()
+    orc.build_index(tres, toff, thr)
+    chk.load_case(gpu, g, tres, toff, thr)
+    qs = [dict(q=q, comp_bias=swo.comp_bias(g["vtml80_kmer16"], g["vtml80_pback"], q), identity_id=None) for q in wl.split(qres, qoff)]
     try:
-        test_prefilter_overflow_path(gpu, 60000, 30000, 0.5)
+        for mh, rb in ((300, 2), (40, 8)):
+            ok, rep = chk.check(gpu, orc, qs, mh, rb, stages=True, label="dense repeats/%d/%d" % (mh, rb))
+            assert ok, "\n".join(rep)
     finally:
-        monkeypatch.delenv("MMGPU_PF_EMIT_CAP", raising=False)
+        orc.build_index(g["tres"], g["toff"], thr)
+        chk.load_case(gpu, g, g["tres"], g["toff"], thr)
 
 
 def test_compact_offset_table_with_long_lists(gpu):
