@@ -995,7 +995,46 @@ def align_only_section(args, gpu, torch, matrices, rank):
            "valu_roofline_frac": round(lane_ops / (k_ms * 1e-3) / VALU_LANE_OPS_PER_S, 4),
            "score_checksum": int(res["score"].astype(np.int64).sum())}
     batch.free()
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = align_only_cpu_baseline(args, matrices, qres, qoff, tres, toff, res)
     return out
+
+
+def align_only_cpu_baseline(args, matrices, qres, qoff, tres, toff, res):
+    """configs[1] says "bit-exact scores vs CPU": the reference's own ssw_init + ssw_align (score + end positions, alignment mode
+    SCORE_ONLY: StripedSmithWaterman.cpp:892-941) through oracle/_ref/libmmref.so on a bounded sample of the same all-vs-all
+    lists (every sample query against an evenly spaced subset of the targets), timed on the host cores and compared with the
+    device's records of the timed run afterwards."""
+    from oracle import pyoracle
+    if not pyoracle.ref_available():
+        return None
+    hw_threads, phys_cores = host_cpu_topology()
+    quota = cpu_quota_cores()
+    threads = hw_threads if quota is None else int(max(1, min(hw_threads, round(quota))))
+    n_q = min(args.queries, args.align_sample_queries)
+    n_t = min(args.targets, args.align_sample_targets)
+    ids = np.linspace(0, args.targets - 1, n_t).astype(np.uint32)
+    l_ids = np.tile(ids, n_q)
+    l_off = (np.arange(n_q + 1, dtype=np.uint64) * np.uint64(n_t))
+    ser = matrices["blosum62_serialized"]
+    qlen = (qoff[1:] - qoff[:-1]).astype(np.int64)
+    tlen = (toff[1:] - toff[:-1]).astype(np.int64)
+    cells = float(qlen[:n_q].sum()) * float(tlen[ids].sum())
+    sec, used, ref = pyoracle.ref_sw_lists_omp(ser, qres, qoff, l_ids, l_off, tres, toff, 0, n_q, threads, mode=0,
+                                               db_residues=int(toff[-1]), want_starts=False)
+    g = res[:n_q][:, ids].reshape(-1)
+    sc = ref["score"].astype(np.int64)
+    pos = sc > 0
+    bad_score = int(np.count_nonzero(g["score"].astype(np.int64) != sc))
+    bad_end = int(np.count_nonzero(((g["t_end"] != ref["t_end"]) | (g["q_end"] != ref["q_end"])) & pos))
+    return {"value": round(cells / sec / 1e9, 2), "unit": "GCUPS", "cores": threads if quota is not None else phys_cores, "threads": used,
+            "kind": "reference",
+            "what": "the reference's ssw_init + ssw_align (AVX2 striped uint8 pass + int16 re-run, score and end positions) in one "
+                    "native OpenMP call (oracle/ref_shim.cpp mmref_sw_lists_omp)",
+            "sample": "queries [0, %d) x %d evenly spaced targets of the same workload (%d pairs, %.4g cells), %.2f s wall"
+                      % (n_q, n_t, n_q * n_t, cells, sec),
+            "parity_vs_reference": {"pairs_compared": int(n_q * n_t), "score_mismatches": bad_score,
+                                    "end_position_mismatches_among_positive_scores": bad_end, "fields": "score, q_end, t_end"}}
 
 
 def nucl_section(args, gpu, matrices, rank):
@@ -1254,6 +1293,8 @@ def main():
     ap.add_argument("--pf-members", type=int, default=50)
     ap.add_argument("--pf-queries", type=int, default=10000)
     ap.add_argument("--queries", type=int, default=1000, help="align_only section (configs[1])")
+    ap.add_argument("--align-sample-queries", type=int, default=200, help="align_only: queries of the reference's CPU run (baseline + parity)")
+    ap.add_argument("--align-sample-targets", type=int, default=5000, help="align_only: targets per sample query of the reference's CPU run")
     ap.add_argument("--targets", type=int, default=100000)
     ap.add_argument("--align-steps", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -364,10 +364,6 @@ int mmgpu_pf_build_index(mmgpu_ctx *ctx, const mmgpu_pf_index *tables, const int
 /* optional: loads the kernels' code objects now instead of at their first launch (0.1 - 0.2 s otherwise paid inside the first
  * prefilter block / alignment batch of a process); thread-safe with respect to other calls on the context */
 int mmgpu_warmup(mmgpu_ctx *ctx);
-/* optional: reserves `bytes` of device memory now, for the library's later allocations on this device to be carved out of (the
- * memory stays with the process).  On hosts whose driver maps fresh device memory slowly (25 - 40 ms per GB seen) a caller with
- * other work to do first - reading its databases - runs this on a helper thread; chunks become usable one by one. */
-int mmgpu_reserve(mmgpu_ctx *ctx, uint64_t bytes);
 
 /* tantan repeat masking of the resident targets, for the prefilter only (the masking step of IndexBuilder::fillDatabase,
  * IndexBuilder.cpp:148 -> Masker::maskSequence with maskTantan, Masker.cpp:14-57 -> tantan::maskSequences, lib/tantan/tantan.cpp

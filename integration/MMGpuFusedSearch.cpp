@@ -234,19 +234,8 @@ int MMGpuFusedSearch::run(Parameters &par, const std::string &query, const std::
         EXIT(EXIT_FAILURE);
     }
     // the device is opened while the prefilter module parses, opens and masks the databases
-    // ... and the kernels' code objects loaded.  MMGPU_FUSED_RESERVE_GB=<n>: device memory reserved on a second helper thread for
-    // what the modules will allocate (mmgpu_reserve).  Off by default: where the driver maps fresh device memory slowly (25 - 40 ms
-    // per GB on some hosts, ~10 GB at 10 000 x 1 M) the reservation does not run beside the hand-over but in front of it - the
-    // runtime serialises the two (2.08 - 2.66 s with 20 GB reserved against 1.88 s without, profiles/r04_fused_reserve_variants.json)
+    // ... and the kernels' code objects loaded
     std::thread opener([]() { mmgpu_warmup(MMGpuRun::context()); });
-    uint64_t reserveBytes = 0;
-    {
-        const char *gb = getenv("MMGPU_FUSED_RESERVE_GB");
-        if (gb != NULL) reserveBytes = (uint64_t)std::max(0ll, atoll(gb)) << 30;
-    }
-    std::thread reserver([reserveBytes]() {
-        if (reserveBytes > 0) mmgpu_reserve(MMGpuRun::context(), reserveBytes);
-    });
     const bool onDisk = getenv("MMGPU_FUSED_PREF_ON_DISK") != NULL && getenv("MMGPU_FUSED_PREF_ON_DISK")[0] == '1';
     // Entries kept in memory: the module's DBWriter still creates its (then empty) database, and the alignment module's parameter
     // check wants to see it.  It gets a name blastp.sh does not know, so that a run that died half-way never leaves an empty
@@ -311,7 +300,6 @@ int MMGpuFusedSearch::run(Parameters &par, const std::string &query, const std::
     // would unwind a process that holds ~70 GB of device mappings and the host copies of both databases: 0.2 s of runtime and
     // allocator teardown after the last result is on disk (profiles/r04_search_timeline.txt).  All writers are closed; the operating
     // system takes the rest back.  MMGPU_FUSED_UNWIND=1 returns normally (leak checkers).
-    reserver.join();
     const char *unwind = getenv("MMGPU_FUSED_UNWIND");
     if (!(unwind != NULL && unwind[0] == '1')) {
         std::cout.flush();

@@ -91,8 +91,7 @@ bool MMGpuPrefilterRun::deviceBuildsIndex(Prefiltering &p) {
 }
 
 ScoreMatrix MMGpuPrefilterRun::scoreMatrix(Prefiltering &p, const BaseMatrix &matrix, size_t kmerSize) {
-    if (!MMGpuRun::enabled() || p.templateDBIsIndex || (kmerSize != 2 && kmerSize != 3) || matrix.alphabetSize + 1 > 32 ||
-        (getenv("MMGPU_HOST_SCORE_MATRIX") != NULL && getenv("MMGPU_HOST_SCORE_MATRIX")[0] == '0'))
+    if (!MMGpuRun::enabled() || p.templateDBIsIndex || (kmerSize != 2 && kmerSize != 3) || matrix.alphabetSize + 1 > 32)
         return p.getScoreMatrix(matrix, kmerSize);
     // the caller took X out of the alphabet (Prefiltering.cpp:221): alphabetSize letters, subMatrix rows of the full matrix
     const int ka = matrix.alphabetSize, a = ka + 1;
@@ -383,7 +382,6 @@ bool MMGpuPrefilterRun::run(Prefiltering &p, DBWriter &tmpDbw, size_t dbFrom, si
     std::vector<double> deviceSeconds(nGroups, 0.0);
     double kmersPerPos = 0;
     size_t dbMatches = 0, doubleMatches = 0, querySeqLenSum = 0, resSize = 0, diagonalOverflow = 0;
-    const bool pipelined = !(getenv("MMGPU_PREF_PIPELINE") != NULL && getenv("MMGPU_PREF_PIPELINE")[0] == '0');
 
     std::vector<size_t> starts;      // first query of every block, and the end of the last
     {
@@ -599,7 +597,6 @@ bool MMGpuPrefilterRun::run(Prefiltering &p, DBWriter &tmpDbw, size_t dbFrom, si
             if (before != NULL) collect();
             before = cur;
             beforeK = k;
-            if (!pipelined) collect();
             deviceSeconds[g] += watch.now() - t0;
         }
         if (before != NULL) {

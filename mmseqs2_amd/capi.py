@@ -68,7 +68,7 @@ PF_OK, PF_OVERFLOW, PF_LONG_SEQ, PF_SAT_TIE, PF_SHARD_INEXACT = 0, 1, 2, 3, 4   
 
 # every symbol include/mmgpu.h declares (tests check the built library exports all of them)
 EXPORTED_SYMBOLS = [
-    "mmgpu_init", "mmgpu_warmup", "mmgpu_reserve", "mmgpu_destroy", "mmgpu_last_error", "mmgpu_set_stream", "mmgpu_synchronize",
+    "mmgpu_init", "mmgpu_warmup", "mmgpu_destroy", "mmgpu_last_error", "mmgpu_set_stream", "mmgpu_synchronize",
     "mmgpu_device_info", "mmgpu_device_memory", "mmgpu_host_comp_bias", "mmgpu_host_round_comp_bias", "mmgpu_host_comp_bias_batch", "mmgpu_load_targets", "mmgpu_sw_batch", "mmgpu_sw_prepare", "mmgpu_sw_run",
     "mmgpu_sw_fetch", "mmgpu_sw_batch_stats", "mmgpu_sw_last_kernel_ms", "mmgpu_sw_kernel_ms_mean", "mmgpu_sw_free",
     "mmgpu_sw_traceback", "mmgpu_sw_prepare_from_pf", "mmgpu_sw_fetch_device", "mmgpu_nucl_align",
@@ -583,11 +583,6 @@ class MMGpu:
 
     def synchronize(self):
         self._check(self.L.mmgpu_synchronize(self.ctx))
-
-    def reserve(self, n_bytes):
-        """mmgpu_reserve: device memory set aside now for the library's later allocations on this device"""
-        self.L.mmgpu_reserve.argtypes = [c_p, ctypes.c_uint64]
-        self._check(self.L.mmgpu_reserve(self.ctx, int(n_bytes)))
 
     def device_info(self):
         cus = ctypes.c_int()

@@ -231,23 +231,6 @@ extern "C" int mmgpu_warmup(mmgpu_ctx *c) {
     return MMGPU_OK;
 }
 
-// Device memory reserved now for the allocations to come (DeviceArena, mmgpu_internal.h): `bytes` in chunks of 4 GB, each usable
-// as soon as it exists - a caller runs this on a helper thread while it reads its input.  Reserved memory stays with the process.
-extern "C" int mmgpu_reserve(mmgpu_ctx *c, uint64_t bytes) {
-    if (!c) return fail(MMGPU_ERR_ARG, "mmgpu_reserve: NULL context");
-    HIP_TRY(hipSetDevice(c->device));
-    DeviceArena &a = DeviceArena::of(c->device);
-    const uint64_t chunk = 4ull << 30;
-    for (uint64_t done = 0; done < bytes; done += chunk) {
-        const size_t n = (size_t)std::min<uint64_t>(chunk, bytes - done);
-        void *p = nullptr;
-        const hipError_t e = hipMalloc(&p, n);
-        if (e != hipSuccess) { (void)hipGetLastError(); break; }      // (less than asked for: later requests fall back to hipMalloc)
-        a.add(p, n);
-    }
-    return MMGPU_OK;
-}
-
 // tantan masking of the resident targets for the prefilter (tantan_kernel.hip): what IndexBuilder::fillDatabase does to every
 // target before it counts k-mers (IndexBuilder.cpp:148, Masker.cpp:14-57 with maskTantan only).  The alignment kernels keep
 // reading the unmasked residues.
@@ -711,10 +694,7 @@ static int sw_prepare_impl(mmgpu_ctx *c, const mmgpu_sw_params *par, const mmgpu
             // mostly about as long as the query; the database mean otherwise)
             const uint64_t est_cells = (uint64_t)Q.qlen * ((Q.qlen + c->mean_len) / 2 + 1) * round;
             const uint32_t per_job = job_slots(round, JOB_CELLS / est_cells);
-            // timing aid (results incomplete): MMGPU_SW_DEBUG_SKIP=multi | single2 | revmulti leaves a class of jobs out
-            static const char *dbg_skip = getenv("MMGPU_SW_DEBUG_SKIP");
-            const bool skip_fwd = dbg_skip && ((multi && strstr(dbg_skip, "multi") == dbg_skip) || (!multi && grp == 2 && strstr(dbg_skip, "single2")));
-            for (uint32_t k = 0; k < pf_stride && !skip_fwd; k += per_job) {
+            for (uint32_t k = 0; k < pf_stride; k += per_job) {
                 SwJob j;
                 j.query = i;
                 j.hit_begin = hit_cursor + k;
@@ -725,7 +705,7 @@ static int sw_prepare_impl(mmgpu_ctx *c, const mmgpu_sw_params *par, const mmgpu
                 // target length on the device, so among equals a query's earlier jobs hold the longer targets
                 job_cells.push_back((uint64_t)Q.qlen * (j.hit_end - j.hit_begin) * 4096u + (pf_stride - k));
             }
-            if (multi && mode >= MMGPU_SW_START && !(dbg_skip && (strstr(dbg_skip, "revmulti") || skip_fwd)))
+            if (multi && mode >= MMGPU_SW_START)
                 add_rev_jobs(i, hit_cursor, pf_stride, shape, (uint64_t)Q.qlen * ((Q.qlen + c->mean_len) / 2 + 1));
             max_tlen = c->db.max_len;
             hit_cursor += pf_stride;
@@ -798,11 +778,7 @@ static int sw_prepare_impl(mmgpu_ctx *c, const mmgpu_sw_params *par, const mmgpu
                     for (uint32_t k = 0; k < Q.n_targets; k++) b->h_out_target[D.out_cursor + k] = Q.target_ids[k];
             }
         };
-        static const unsigned host_threads = [] {
-            const char *e = getenv("MMGPU_HOST_THREADS");
-            const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-            return e && atoi(e) > 0 ? (unsigned)atoi(e) : std::min(16u, hw);
-        }();
+        static const unsigned host_threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
         const size_t n_thr = std::max<size_t>(1, std::min<size_t>(host_threads, total_hits / 65536 + 1));
         if (n_thr <= 1) {
             work(0, deferred.size());
@@ -1134,10 +1110,8 @@ static int sw_launch_groups(mmgpu_ctx *c, mmgpu_sw_batch_t *b, bool rev_only, co
         // the critical path, the other groups fill the CUs it leaves
         int prio_low = 0, prio_high = 0;
         HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));   // numerically lower = higher priority
-        const char *pe = getenv("MMGPU_SW_PRIORITY");      // experiments: one of h / m / l per group, e.g. "lhm"
         for (int g = 0; g < SW_GROUPS; g++) {
-            int prio = g == SW_GROUPS - 1 ? prio_high : (g == 0 ? prio_low : (prio_low + prio_high) / 2);
-            if (pe && strlen(pe) == (size_t)SW_GROUPS) prio = pe[g] == 'h' ? prio_high : (pe[g] == 'l' ? prio_low : (prio_low + prio_high) / 2);
+            const int prio = g == SW_GROUPS - 1 ? prio_high : (g == 0 ? prio_low : (prio_low + prio_high) / 2);
             HIP_TRY(hipStreamCreateWithPriority(&c->side[g], hipStreamNonBlocking, prio));
         }
         HIP_TRY(hipEventCreateWithFlags(&c->fork, hipEventDisableTiming));
@@ -1470,7 +1444,7 @@ static int block_backtrace(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const uint32_t *pa
     auto slot_size = [](uint64_t len, uint64_t entries_per_col, uint64_t max_rows, bool borders) {
         return (borders ? (uint64_t)8 * BLOCK_REF_MAX_SIZE * 2 : 0ull) + (((len + 64) * 16 + 31) & ~31ull) + entries_per_col * 32 * (len + 2 * max_rows);
     };
-    static const uint64_t pool_limit = (getenv("MMGPU_BLOCK_POOL_MB") ? strtoull(getenv("MMGPU_BLOCK_POOL_MB"), nullptr, 10) : 16384ull) << 20;
+    constexpr uint64_t pool_limit = 16384ull << 20;
     // (small calls: slots for the longest pair, everything starts in tier 0)
     uint64_t typical_len = pair_len(jobs[jobs.size() > 1024 ? 255 : 0]);
     DevBuf d_btoff, d_bt, d_scores, d_jobs[3], d_pool[3], d_busy[3];
@@ -1521,9 +1495,9 @@ static int block_backtrace(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const uint32_t *pa
     // run in groups whose block lists + traces fit the pool, each group = fill launch + walk launch on the context's stream ----
     std::vector<BlockJob> slow_jobs;
     if (!first_tier_env) {
-        static const uint64_t block4_waves = getenv("MMGPU_BLOCK4_WAVES") ? strtoull(getenv("MMGPU_BLOCK4_WAVES"), nullptr, 10) : 16;      // per CU (tuning aid)
-        static const uint64_t block4_per_res = getenv("MMGPU_BLOCK4_PER_RES") ? strtoull(getenv("MMGPU_BLOCK4_PER_RES"), nullptr, 10) : 48;      // trace bytes per residue of a pair, launch 1
-        static const uint64_t pool2_limit = (getenv("MMGPU_BLOCK4_POOL_MB") ? strtoull(getenv("MMGPU_BLOCK4_POOL_MB"), nullptr, 10) : 3072ull) << 20;
+        constexpr uint64_t block4_waves = 16;        // wavefronts per CU
+        constexpr uint64_t block4_per_res = 48;      // trace bytes per residue of a pair, launch 1
+        constexpr uint64_t pool2_limit = 3072ull << 20;
         struct PassBufs {      // what a launch in flight holds: two of them run side by side (the long head, everything else)
             DevBuf j2, cnt, pool, ck;
             hipStream_t st = nullptr;
@@ -1619,8 +1593,7 @@ static int block_backtrace(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const uint32_t *pa
         // The longest pairs - one per CU - go straight to the skewed form on a stream of their own, beside everything else: the pairs
         // whose blocks grow to thousands of rows are among them, each a dependent chain of tens of milliseconds that nothing shortens
         // but starting it first.
-        static const uint64_t head_per_cu = getenv("MMGPU_BLOCK4_HEAD") ? strtoull(getenv("MMGPU_BLOCK4_HEAD"), nullptr, 10) : 1;
-        const size_t n_head = seq_jobs.size() >= 4096 ? std::min<size_t>(seq_jobs.size() / 16, (size_t)std::max(c->compute_units, 1) * head_per_cu) : 0;
+        const size_t n_head = seq_jobs.size() >= 4096 ? std::min<size_t>(seq_jobs.size() / 16, (size_t)std::max(c->compute_units, 1)) : 0;
         head.assign(seq_jobs.begin(), seq_jobs.begin() + n_head);
         rest.assign(seq_jobs.begin() + n_head, seq_jobs.end());
         int rc2;

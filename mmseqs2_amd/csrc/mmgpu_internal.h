@@ -188,7 +188,6 @@ struct PfKmerArgs {
     const int16_t *prof_score;    // [n_pos][20]
     const uint8_t *prof_letter;   // [n_pos][20]
     int exact;                 // takeOnlyBestKmer: every window matches its own k-mer only (QueryMatcher.cpp:279-282)
-    int order_mode;            // launch_pf_order: 1 = the default order, 2 / 3 = experiment variants (pf_order.hip)
     const uint32_t *order;     // [n_pos] work order of the positions (launch_pf_order: grouped by the window's last 3-mer), null = as stored
     // count pass
     uint32_t *nsim;
@@ -630,110 +629,10 @@ inline int fail(int code, const std::string &msg) {
             return mmgpu::fail(MMGPU_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));         \
     } while (0)
 
-// Device memory reserved ahead of its use (mmgpu_reserve): on some hosts the driver maps fresh device memory at only 25 - 40 GB/s,
-// i.e. a process that allocates 20 GB on its way pays half a second inside hipMalloc.  A caller that has something else to do
-// first - the fused search reads its databases - reserves chunks on a helper thread; dev_malloc carves later requests out of
-// them (first fit over the freed pieces, then the untouched tail of a chunk) and falls back to hipMalloc when nothing fits;
-// dev_free returns a piece to its chunk after draining the device, as hipFree does.  One arena per device of the process.
-struct DeviceArena {
-    struct Chunk { uint8_t *base; size_t size, used; };
-    std::mutex lock;
-    std::atomic<int> n_chunks{0};                       // (read without the lock: "is there an arena at all")
-    std::vector<Chunk> chunks;
-    std::map<uint8_t *, size_t> live;                   // carved pieces in use
-    std::multimap<size_t, uint8_t *> freed;             // pieces given back, by size
-    static std::mutex &registry_lock() { static std::mutex m; return m; }
-    static std::map<int, DeviceArena *> &registry() { static std::map<int, DeviceArena *> all; return all; }
-    static DeviceArena &of(int device) {
-        std::lock_guard<std::mutex> g(registry_lock());
-        DeviceArena *&a = registry()[device];
-        if (!a) a = new DeviceArena();
-        return *a;
-    }
-    // the arena a pointer was carved from, whatever device is current on the calling thread (a free may be issued while another
-    // device is current: multi-context destroy, a helper thread); null = not an arena pointer
-    static DeviceArena *owner_of(const void *p) {
-        std::vector<DeviceArena *> all;
-        {
-            std::lock_guard<std::mutex> g(registry_lock());
-            for (auto &kv : registry()) all.push_back(kv.second);
-        }
-        for (DeviceArena *a : all)
-            if (a->n_chunks.load() > 0 && a->inside(p)) return a;
-        return nullptr;
-    }
-    // p lies inside one of the reserved chunks (carved piece or not)
-    bool inside(const void *p) {
-        std::lock_guard<std::mutex> g(lock);
-        const uint8_t *q = static_cast<const uint8_t *>(p);
-        for (const Chunk &c : chunks)
-            if (q >= c.base && q < c.base + c.size) return true;
-        return false;
-    }
-    void add(void *base, size_t size) {
-        std::lock_guard<std::mutex> g(lock);
-        chunks.push_back(Chunk{static_cast<uint8_t *>(base), size, 0});
-        n_chunks++;
-    }
-    void *take(size_t n) {
-        n = (n + 4095) & ~(size_t)4095;
-        std::lock_guard<std::mutex> g(lock);
-        auto it = freed.lower_bound(n);
-        if (it != freed.end() && it->first <= n + n / 4) {      // (a piece much larger than the request stays for a larger one)
-            uint8_t *p = it->second;
-            live[p] = it->first;
-            freed.erase(it);
-            return p;
-        }
-        for (Chunk &c : chunks)
-            if (c.size - c.used >= n) {
-                uint8_t *p = c.base + c.used;
-                c.used += n;
-                live[p] = n;
-                return p;
-            }
-        return nullptr;
-    }
-    bool owns(const void *p) {
-        std::lock_guard<std::mutex> g(lock);
-        return live.find(static_cast<uint8_t *>(const_cast<void *>(p))) != live.end();
-    }
-    bool give(void *p) {
-        std::lock_guard<std::mutex> g(lock);
-        auto it = live.find(static_cast<uint8_t *>(p));
-        if (it == live.end()) return false;
-        freed.emplace(it->second, it->first);
-        live.erase(it);
-        return true;
-    }
-};
-
 // every device buffer of the library is allocated and freed through these two
-// (MMGPU_ALLOC_TRACE=1: every hipMalloc with its size and wall time on stderr - where a module's first device call spends its time)
-inline hipError_t dev_malloc(void **p, size_t n) {
-    int device = 0;
-    if (hipGetDevice(&device) == hipSuccess) {
-        DeviceArena &a = DeviceArena::of(device);
-        if (a.n_chunks.load() > 0) {
-            if (void *q = a.take(n)) { *p = q; return hipSuccess; }
-        }
-    }
-    static const bool on = getenv("MMGPU_ALLOC_TRACE") != nullptr;
-    if (!on) return hipMalloc(p, n);
-    const auto t0 = std::chrono::steady_clock::now();
-    const hipError_t e = hipMalloc(p, n);
-    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    fprintf(stderr, "[mmgpu alloc] hipMalloc %.1f MB %.2f ms\n", (double)n / 1048576.0, ms);
-    return e;
-}
+inline hipError_t dev_malloc(void **p, size_t n) { return hipMalloc(p, n); }
 inline void dev_free(void *p) {
-    if (!p) return;
-    if (DeviceArena *a = DeviceArena::owner_of(p)) {      // (never hipFree a pointer into a reserved chunk, whichever device is current)
-        (void)hipDeviceSynchronize();      // hipFree's guarantee: nothing in flight reads the block any more
-        (void)a->give(p);
-        return;
-    }
-    (void)hipFree(p);
+    if (p) (void)hipFree(p);
 }
 
 // Freed device blocks of one context, kept for the next batch: a streaming search prepares and frees one alignment
@@ -805,8 +704,7 @@ struct DevBuf {
     }
     ~DevBuf() { release(); }
     void bind(const std::shared_ptr<BlockCache> &c) {
-        static const bool off = getenv("MMGPU_NO_BLOCK_CACHE") != nullptr;   // debugging aid: every buffer straight from hipMalloc
-        if (!off) cache = c;
+        cache = c;
     }
     void release() {
         if (!p) return;

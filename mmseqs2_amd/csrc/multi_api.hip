@@ -111,8 +111,7 @@ extern "C" int mmgpu_init_multi(mmgpu_multi **out, const int *device_ids, int n_
     bool repeats = false;
     for (int i = 0; i < n_devices; i++)
         for (int j = 0; j < i; j++) repeats |= device_ids[i] == device_ids[j];
-    const char *tr = getenv("MMGPU_MULTI_TRANSPORT");
-    m->copy_transport = repeats || (tr && !strcmp(tr, "copy"));
+    m->copy_transport = repeats;
     for (int i = 0; i < n_devices; i++) {
         mmgpu_ctx *c = nullptr;
         if (int e = mmgpu_init(&c, device_ids[i])) { mmgpu_destroy_multi(m); return e; }

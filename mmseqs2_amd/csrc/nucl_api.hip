@@ -62,8 +62,7 @@ extern "C" int mmgpu_nucl_align(mmgpu_ctx *c, const mmgpu_nucl_params *par, cons
     const uint64_t gpb = 256 / lanes;                                                     // alignments per workgroup
     uint64_t groups = ((uint64_t)n_pairs + gpb - 1) / gpb * gpb;
     groups = std::min<uint64_t>(groups, (uint64_t)c->compute_units * 4 * gpb);          // 4 workgroups per CU
-    static const uint64_t budget_gb = getenv("MMGPU_NUCL_SCRATCH_GB") ? std::max(1, atoi(getenv("MMGPU_NUCL_SCRATCH_GB"))) : 16;
-    const uint64_t budget = budget_gb << 30;
+    const uint64_t budget = 16ull << 30;
     while (groups > gpb && groups * (p_stride + w_stride) > budget) groups -= gpb;
     if (groups * (p_stride + w_stride) > (96ull << 30)) return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_nucl_align: sequences too long for the direction scratch");
     const unsigned blocks = (unsigned)(groups / gpb);

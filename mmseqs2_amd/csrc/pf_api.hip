@@ -45,11 +45,10 @@ struct PfIndex {
 
 // Sparse indexes (a shard of a multi-GPU run holds 1/N of the entries over the same k-mer space; small databases): most similar
 // k-mers of a query have no list.  The bit table is consulted by pf_kmers_kernel when fewer than 60 % of the k-mers have one
-// (MMGPU_PF_BITMAP=1 / 0 forces / forbids it); similar-k-mer searches with k = 6 only (the table of k = 7 has 1.3e9 k-mers).
+// similar-k-mer searches with k = 6 only (the table of k = 7 has 1.3e9 k-mers).
 static hipError_t pf_index_bitmap(mmgpu_ctx *c, PfIndex *P) {
     P->use_bitmap = false;
-    const char *e = getenv("MMGPU_PF_BITMAP");
-    if (!P->has_tables || P->k != 6 || P->table > (1ull << 28) || (e && e[0] == '0')) return hipSuccess;
+    if (!P->has_tables || P->k != 6 || P->table > (1ull << 28)) return hipSuccess;
     hipStream_t s = c->stream;
     DevBuf d_cnt;
     hipError_t rc = P->d_nonempty.alloc(((P->table + 31) / 32 + 1) * 4);
@@ -61,7 +60,7 @@ static hipError_t pf_index_bitmap(mmgpu_ctx *c, PfIndex *P) {
     if (rc == hipSuccess) rc = hipStreamSynchronize(s);
     if (rc != hipSuccess) return rc;
     P->nonempty_frac = P->table ? (double)n / (double)P->table : 1.0;
-    P->use_bitmap = (e && e[0] == '1') || P->nonempty_frac < 0.6;
+    P->use_bitmap = P->nonempty_frac < 0.6;
     if (!P->use_bitmap) P->d_nonempty.release();
     return hipSuccess;
 }
@@ -843,14 +842,9 @@ extern "C" int mmgpu_pf_run(mmgpu_ctx *c, mmgpu_pf_batch_t *b) {
     K.nsim = b->d_nsim.as<uint32_t>();
     // work order of the positions (pf_order.hip): built with the batch's first run
     if (!b->order_ready && !K.exact) {
-        static const bool off = getenv("MMGPU_PF_NO_ORDER") != nullptr;      // A/B runs
-        if (!off) {
-            K.order_mode = 1;
-            if (const char *m = getenv("MMGPU_PF_ORDER_MODE")) K.order_mode = atoi(m);
-            HIP_TRY(b->d_pos_order.alloc((size_t)b->n_pos * 4));
-            HIP_TRY(launch_pf_order(K, b->d_pos_order.as<uint32_t>(), c->cache, s));
-            b->has_order = true;
-        }
+        HIP_TRY(b->d_pos_order.alloc((size_t)b->n_pos * 4));
+        HIP_TRY(launch_pf_order(K, b->d_pos_order.as<uint32_t>(), c->cache, s));
+        b->has_order = true;
         b->order_ready = true;
     }
     K.order = b->has_order ? b->d_pos_order.as<uint32_t>() : nullptr;

@@ -43,14 +43,6 @@ __device__ __forceinline__ uint64_t lanes_below(int lane) { return (1ull << lane
 // Inclusive scans over the wavefront with DPP moves (row shifts inside the 16-lane rows, then the row ends handed to the
 // following rows): six VALU operations instead of six ds_bpermute round trips.
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
-#ifdef MMGPU_PF_OLD_SCAN
-    const int lane_ = lane_id();
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t t = __shfl_up(v, d);
-        if (lane_ >= d) v += t;
-    }
-    return v;
-#endif
     int x = (int)v;
     x += __builtin_amdgcn_update_dpp(0, x, 0x111 /* row_shr:1 */, 0xF, 0xF, true);
     x += __builtin_amdgcn_update_dpp(0, x, 0x112 /* row_shr:2 */, 0xF, 0xF, true);
@@ -84,15 +76,6 @@ __device__ __forceinline__ int seg_find(uint32_t start_mine, uint32_t x) {
 
 // Lanes of the wave whose `key` (low nbits) equals mine, among lanes with active == true.
 __device__ __forceinline__ uint64_t match_lanes(uint32_t key, int nbits, bool active) {
-#ifdef MMGPU_PF_OLD_MATCH
-    uint64_t m = ballot(active);
-    for (int b = 0; b < nbits; b++) {
-        const bool bit = (key >> b) & 1u;
-        const uint64_t bal = ballot(bit && active);
-        m &= bit ? bal : ~bal;
-    }
-    return m;
-#endif
     const uint64_t act = ballot(active);
     uint32_t lo = (uint32_t)act, hi = (uint32_t)(act >> 32);
     for (int b = 0; b < nbits; b++) {
@@ -159,11 +142,7 @@ __device__ __forceinline__ uint32_t xcd_contiguous(uint32_t bid, uint32_t nwg) {
 // per look-up (a wavefront's 64 look-ups are 64 different lines: the address unit takes a clock per lane and instruction, so the
 // 32-byte form - base + 28 lengths, two loads, MMGPU_PF_COFS32 - pays that twice for 15 % less footprint;
 // profiles/r05_exp_pf_cofs_block.txt).
-#ifdef MMGPU_PF_COFS32
-constexpr uint32_t PF_COFS_KMERS = 28, PF_COFS_DWORDS = 8;
-#else
 constexpr uint32_t PF_COFS_KMERS = 12, PF_COFS_DWORDS = 4;
-#endif
 
 __global__ __launch_bounds__(256) void pf_cofs_kernel(const uint32_t *offsets, uint64_t table, uint32_t *cofs) {
     const uint64_t blk = (uint64_t)blockIdx.x * 256u + threadIdx.x;
@@ -194,15 +173,9 @@ __global__ __launch_bounds__(256) void pf_cofs_kernel(const uint32_t *offsets, u
 // A list record is written once and read once, by the split kernel, after every record of the batch has been written: stored
 // with the non-temporal hint it does not push the offset-table blocks (the lines this kernel lives on) out of the L2.
 __device__ __forceinline__ void pf_store_list(PfList *dst, uint32_t start, uint32_t len, uint32_t lprefix, uint32_t pos) {
-#ifdef MMGPU_PF_LISTS_PLAIN_STORE
-    PfList rec;
-    rec.start = start; rec.len = len; rec.lprefix = lprefix; rec.pos = pos;
-    *dst = rec;
-#else
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     u32x4 v = {start, len, lprefix, pos};
     __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(dst));
-#endif
 }
 
 // (start, length) of the index list of `kmer`
@@ -213,10 +186,6 @@ __device__ __forceinline__ void pf_lookup(const PfKmerArgs &A, uint32_t kmer, ui
         {
             const uint4 lo = A.cofs[(size_t)blk * (PF_COFS_DWORDS / 4)];
             base = lo.x; w[0] = lo.y; w[1] = lo.z; w[2] = lo.w;
-#ifdef MMGPU_PF_COFS32
-            const uint4 hi = A.cofs[(size_t)blk * 2 + 1];
-            w[3] = hi.x; w[4] = hi.y; w[5] = hi.z; w[6] = hi.w;
-#endif
         }
         if (!(base >> 31)) {
             uint32_t sum = 0, word = 0;
@@ -611,24 +580,12 @@ __global__ __launch_bounds__(256) void pf_scan_kernel(const uint32_t *in, const 
 // plus the high diagonal byte in a byte array of the same layout, which only the ~1 % of entries that become candidates are
 // looked up in.  Every request to memory costs the same whatever it carries (~55 G/s chip wide, pf_order.hip): the tiles were
 // 29 GB written and 29 GB read back per 10 000 queries, now 18 and 14.5.
-#ifndef MMGPU_PF_SPLIT_PAD
-#define MMGPU_PF_SPLIT_PAD 0
-#endif
-#ifndef MMGPU_PF_SPLIT_WAVES
-#define MMGPU_PF_SPLIT_WAVES 8
-#endif
 // Wavefronts per tile.  The kernel waits on dependent LDS / cross-lane / gather latencies, so its throughput follows the
 // number of resident wavefronts (measured: half the occupancy = 1.65x the time); the tile's 32 KB stage allows four
 // workgroups per CU, eight wavefronts each fill the SIMDs' eight slots (the per-(wave, bin) counters are 16 bit for that).
-constexpr int SPW = MMGPU_PF_SPLIT_WAVES;
-#ifndef MMGPU_PF_SPLIT_EU
-#define MMGPU_PF_SPLIT_EU 6
-#endif
-__global__ __launch_bounds__(SPW * 64) __attribute__((amdgpu_waves_per_eu(MMGPU_PF_SPLIT_EU))) void pf_split_kernel(PfSplitArgs A) {
-#if MMGPU_PF_SPLIT_PAD
-    __shared__ volatile uint32_t s_pad[MMGPU_PF_SPLIT_PAD / 4];      // occupancy experiment
-    if (A.bins == 0xFFFFFFFFu) s_pad[threadIdx.x] = 1;
-#endif
+constexpr int SPW = 8;
+constexpr int SPLIT_WAVES_PER_EU = 6;      // (profiles/r05_exp_pf_*: 4, 8 and padded-LDS occupancies measured slower)
+__global__ __launch_bounds__(SPW * 64) __attribute__((amdgpu_waves_per_eu(SPLIT_WAVES_PER_EU))) void pf_split_kernel(PfSplitArgs A) {
     __shared__ uint64_t stage[PF_T];
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
     uint16_t *cnt = reinterpret_cast<uint16_t *>(dyn_lds);   // [SPW][B]: counts <= PF_T / SPW, then tile offsets < PF_T
@@ -778,13 +735,8 @@ __global__ __launch_bounds__(SPW * 64) __attribute__((amdgpu_waves_per_eu(MMGPU_
     uint32_t *dst = A.split + (size_t)t * PF_T;
     uint32_t *dst_h = reinterpret_cast<uint32_t *>(A.split_hi + (size_t)t * PF_T);
     const uint32_t *src_h = reinterpret_cast<const uint32_t *>(stage_h);
-#ifdef MMGPU_PF_SPLIT_NT
-    for (uint32_t s = threadIdx.x; s < tile_n; s += (uint32_t)SPW * 64u) __builtin_nontemporal_store(stage_w[s], &dst[s]);
-    for (uint32_t s = threadIdx.x; s < (tile_n + 3u) / 4u; s += (uint32_t)SPW * 64u) __builtin_nontemporal_store(src_h[s], &dst_h[s]);
-#else
     for (uint32_t s = threadIdx.x; s < tile_n; s += (uint32_t)SPW * 64u) dst[s] = stage_w[s];
     for (uint32_t s = threadIdx.x; s < (tile_n + 3u) / 4u; s += (uint32_t)SPW * 64u) dst_h[s] = src_h[s];
-#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1045,23 +997,11 @@ __device__ __forceinline__ uint64_t score_chunk(const PfDedupArgs &A, const int8
 // VALU instructions of a round.  The second pass works the same way on the flagged lanes only: an atomic OR on the target's "has
 // emitted" bit (first emission?) and a second byte exchange on the byte last emitted.  No emitter table, no redo list.
 // Per wavefront: 4 KB previous bytes + 4 KB emitted bytes + 512 B bits + the first 64 candidates: 9.5 KB, four workgroups per CU.
-#ifndef MMGPU_PF_REPLAY_EU
-#define MMGPU_PF_REPLAY_EU 4
-#endif
+constexpr int REPLAY_WAVES_PER_EU = 4;
 // rounds whose entries are in flight while a round is processed: with ~70 instructions per round the kernel waits for memory, and a
 // wavefront's 256 bytes per round are few - the rounds ahead are what keeps the memory system busy
-#ifndef MMGPU_PF_REPLAY_PD
-#define MMGPU_PF_REPLAY_PD 4
-#endif
+constexpr int REPLAY_PD = 4;      // (1, 2 and 8 measured: gpurun r06h - 25.1 / 25.3 / 27.0 ms against 26.1 before the slots kept their registers)
 
-#ifdef MMGPU_PF_REPLAY_STATS
-// experiment build only (scripts/build_variant.sh ... -DMMGPU_PF_REPLAY_STATS): where the replay's rounds go.
-// [0] buckets [1] rounds [2] rounds with a flagged entry [4] entries [5] flagged entries [6] kept entries [8] tile chunks
-__device__ unsigned long long g_replay_stats[16];
-#define RSTAT(i, v) do { if (lane == 0) atomicAdd(&g_replay_stats[i], (unsigned long long)(v)); } while (0)
-#else
-#define RSTAT(i, v) do { } while (0)
-#endif
 
 struct ReplayLds {
     uint32_t prev[4][PF_IDS_PER_BIN / 4];     // a byte per target: low diagonal byte of the target's previous entry
@@ -1093,7 +1033,6 @@ __device__ __forceinline__ void replay_bucket_impl(const PfDedupArgs &A, ReplayL
         if (lane == 0) A.cand_count[bucket] = 0;
         return;
     }
-    RSTAT(0, 1);
     const uint32_t tb = A.q_tile_base[q];
     uint32_t *P = M.prev[wave];
     uint32_t *L = M.last[wave];
@@ -1110,6 +1049,9 @@ __device__ __forceinline__ void replay_bucket_impl(const PfDedupArgs &A, ReplayL
 
     uint32_t ncand = 0;
     const uint64_t below = lanes_below(lane);
+    // where the bucket's candidates go (cand_slot): read once - a load inside the rounds would make every later wait a full one
+    PfCand *const cand_small = A.cand_small + bucket * PF_CAND0;
+    PfCand *const cand_big = A.cand + (A.cand_base[bucket] - A.cand_origin);
     const uint32_t nseg = SEGS ? A.q_nseg[q] : 0u;
     const uint32_t *segs = SEGS ? A.seg_start + (size_t)q * (PF_MAX_SEG + 2) : nullptr;
     uint32_t cur_seg = 0, next_boundary = SEGS ? segs[1] : 0xFFFFFFFFu;
@@ -1124,8 +1066,6 @@ __device__ __forceinline__ void replay_bucket_impl(const PfDedupArgs &A, ReplayL
         const uint32_t incl = wave_incl_scan(n);
         const uint32_t total = __shfl(incl, 63);
         const uint32_t excl = incl - n;
-        RSTAT(8, 1);
-        RSTAT(4, total);
         // Tile whose segment holds the bucket's entry x, for the 64 entries of a round at once (rounds are requested in
         // increasing order): every tile whose non-empty segment starts inside the round marks its slot, a running maximum
         // along the lanes spreads the marks, the segment that reaches into the round from before is the last one of the
@@ -1148,27 +1088,26 @@ __device__ __forceinline__ void replay_bucket_impl(const PfDedupArgs &A, ReplayL
             e_out = 0;
             if (x < total) e_out = A.split[(size_t)(tb + tile_out) * PF_T + at_out];
         };
-        uint32_t e_q[MMGPU_PF_REPLAY_PD], tile_q[MMGPU_PF_REPLAY_PD], at_q[MMGPU_PF_REPLAY_PD];
+        uint32_t e_q[REPLAY_PD], tile_q[REPLAY_PD], at_q[REPLAY_PD];
 #pragma unroll
-        for (int k = 0; k < MMGPU_PF_REPLAY_PD; k++) {
+        for (int k = 0; k < REPLAY_PD; k++) {
             e_q[k] = 0; tile_q[k] = 0; at_q[k] = 0;
             if ((uint32_t)k * 64u < total) request((uint32_t)k * 64u, e_q[k], tile_q[k], at_q[k]);
         }
-        for (uint32_t xg = 0; xg < total; xg += 64u * MMGPU_PF_REPLAY_PD) {
+        for (uint32_t xg = 0; xg < total; xg += 64u * REPLAY_PD) {
 #pragma unroll
-          for (int pk = 0; pk < MMGPU_PF_REPLAY_PD; pk++) {
+          for (int pk = 0; pk < REPLAY_PD; pk++) {
             const uint32_t x0 = xg + 64u * (uint32_t)pk;
-            if (x0 >= total) break;
+            if (x0 < total) {      // (no break: the slots keep their registers through the unrolled body)
             const uint32_t e = e_q[pk];
             const uint32_t tile_cur = tile_q[pk];
             const uint32_t where = (tb + tile_cur) * (uint32_t)PF_T + at_q[pk];      // the entry's place in the split arrays (< 2^32: pf_api.hip)
             const bool act = x0 + (uint32_t)lane < total;
-            if (x0 + 64u * MMGPU_PF_REPLAY_PD < total) request(x0 + 64u * MMGPU_PF_REPLAY_PD, e_q[pk], tile_q[pk], at_q[pk]);
+            if (x0 + 64u * REPLAY_PD < total) request(x0 + 64u * REPLAY_PD, e_q[pk], tile_q[pk], at_q[pk]);
             const uint32_t key = e & 0xFFFu;   // < PF_IDS_PER_BIN
             const uint32_t d8 = (e >> 12) & 0xFFu;
             const uint32_t arr = tile_cur * (uint32_t)PF_T + (e >> 20);
             const uint32_t sh = (key & 3u) * 8u;
-            RSTAT(1, 1);
             // Overflow path (nseg > 0): the reference flushes databaseHits at segment boundaries and starts the
             // double-diagonal state from scratch (QueryMatcher.cpp:310-346), so a round that straddles a boundary is
             // processed in pieces with the tables cleared in between.
@@ -1180,8 +1119,6 @@ __device__ __forceinline__ void replay_bucket_impl(const PfDedupArgs &A, ReplayL
                     bool flag = false;
                     if (now) flag = ((lds_byte_exchange(&P[key >> 2], sh, d8) >> sh) & 0xFFu) == d8;
                     if (ballot(flag)) {
-                        RSTAT(2, 1);
-                        RSTAT(5, __popcll(ballot(flag)));
                         // second pass (:240-265) over the flagged entries, in their order: the first of a target is kept, a later one
                         // when its byte differs from the one the target emitted last
                         bool keep = false;
@@ -1192,7 +1129,6 @@ __device__ __forceinline__ void replay_bucket_impl(const PfDedupArgs &A, ReplayL
                             keep = !emitted_before || last_byte != d8;
                         }
                         const uint64_t kb = ballot(keep);
-                        RSTAT(6, __popcll(kb));
                         if (keep) {
                             PfCand c;
                             c.id = (key << bshift) | bin;
@@ -1203,7 +1139,7 @@ __device__ __forceinline__ void replay_bucket_impl(const PfDedupArgs &A, ReplayL
                             c.diag = (uint16_t)(SEGS ? (d8 | ((uint32_t)A.split_hi[where] << 8)) : d8);
                             c.pad = (uint16_t)cur_seg;
                             const uint32_t ck = ncand + (uint32_t)__popcll(kb & below);
-                            *cand_slot(A, bucket, ck) = c;
+                            *(ck < (uint32_t)PF_CAND0 ? cand_small + ck : cand_big + ck) = c;
                             if (!SEGS && ck < 64) {
                                 M.cand[wave][0][ck] = key | (d8 << 12);
                                 M.cand[wave][1][ck] = arr;
@@ -1220,6 +1156,7 @@ __device__ __forceinline__ void replay_bucket_impl(const PfDedupArgs &A, ReplayL
                     cur_seg++;
                     next_boundary = cur_seg + 1 <= nseg ? segs[cur_seg + 1] : 0xFFFFFFFFu;
                 }
+            }
             }
           }
         }
@@ -1245,7 +1182,7 @@ __device__ __forceinline__ void replay_bucket_impl(const PfDedupArgs &A, ReplayL
     }
 }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MMGPU_PF_REPLAY_EU))) void pf_replay_kernel(PfDedupArgs A) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(REPLAY_WAVES_PER_EU))) void pf_replay_kernel(PfDedupArgs A) {
     __shared__ ReplayLds M;
     const int wave = (int)(threadIdx.x >> 6);
     for (int k = (int)threadIdx.x; k < 32 * 32; k += 256) M.smat[k] = k < A.alphabet * A.alphabet ? A.mat[k] : (int8_t)0;
@@ -2260,15 +2197,6 @@ hipError_t launch_pf_dedup(const PfDedupArgs &A, hipEvent_t after_replay, hipEve
     hipError_t e;
     hipLaunchKernelGGL(pf_replay_kernel, grid, block, 0, s, A);
     if ((e = hipGetLastError()) != hipSuccess) return e;
-#ifdef MMGPU_PF_REPLAY_STATS
-    {
-        unsigned long long h[16];
-        (void)hipStreamSynchronize(s);
-        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_replay_stats), sizeof(h));
-        fprintf(stderr, "[replay stats, cumulative] buckets %llu rounds %llu rounds_with_a_flag %llu entries %llu flagged %llu kept %llu chunks %llu\n",
-                h[0], h[1], h[2], h[4], h[5], h[6], h[8]);
-    }
-#endif
     if (after_replay && (e = hipEventRecord(after_replay, s)) != hipSuccess) return e;
     hipLaunchKernelGGL(pf_ungapped_kernel, grid, block, 0, s, A);
     if ((e = hipGetLastError()) != hipSuccess) return e;

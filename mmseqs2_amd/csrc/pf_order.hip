@@ -29,7 +29,7 @@ namespace {
 __global__ __launch_bounds__(256) void pf_order_keys_kernel(PfKmerArgs A, unsigned long long *keys) {
     const uint32_t gp = blockIdx.x * 256u + threadIdx.x;
     if (gp >= A.n_pos) return;
-    uint32_t share = gp & 7u, hi = 8191u, lo = 0u;
+    uint32_t hi = 8191u, lo = 0u;
     if (A.q_thr[gp] >= 0 && !(A.q_kind && A.q_kind[gp])) {
         const uint8_t *q = A.q_res + gp;
         const uint32_t ka = A.kalph;
@@ -42,14 +42,8 @@ __global__ __launch_bounds__(256) void pf_order_keys_kernel(PfKmerArgs A, unsign
         }
         hi = hi > 8190u ? 8190u : hi;      // (13 bits each: alphabets up to 20 letters fit exactly; larger ones only lose order, not work)
         lo = lo > 8191u ? 8191u : lo;
-        share = 0;
-        // experiment switches (MMGPU_PF_ORDER_MODE): 2 = units of 20 neighbouring rows dealt to the XCDs round-robin, 3 = no sort by
-        // the first 3-mer
-        if (A.order_mode == 2) share = (hi / ka) & 7u;
-        if (A.order_mode == 3) lo = 0;
     }
-    if (A.order_mode != 2) share = 0;
-    keys[gp] = ((unsigned long long)((share << 26) | (hi << 13) | lo) << 32) | gp;
+    keys[gp] = ((unsigned long long)((hi << 13) | lo) << 32) | gp;
 }
 
 __global__ __launch_bounds__(256) void pf_order_extract_kernel(const unsigned long long *keys, uint32_t n, uint32_t *order) {
@@ -76,7 +70,10 @@ hipError_t launch_pf_order(const PfKmerArgs &A, uint32_t *order, const std::shar
     e = rocprim::radix_sort_keys(d_tmp.p, tmp_bytes, d_in.as<unsigned long long>(), d_out.as<unsigned long long>(), (size_t)A.n_pos, 32u, 61u, s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(pf_order_extract_kernel, g, b, 0, s, d_out.as<unsigned long long>(), A.n_pos, order);
-    return hipGetLastError();
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    // the scratch goes back to the shared cache at scope exit: nothing of this call may still be in flight then (a taker on
+    // another stream would overwrite the sort's input); once per batch
+    return hipStreamSynchronize(s);
 }
 
 }  // namespace mmgpu

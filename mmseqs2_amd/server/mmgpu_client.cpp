@@ -157,7 +157,6 @@ int mmgpu_db_load(mmgpu_ctx *, const char *, uint64_t, uint64_t, const mmgpu_pf_
 }
 
 int mmgpu_warmup(mmgpu_ctx *) { return MMGPU_OK; }
-int mmgpu_reserve(mmgpu_ctx *, uint64_t) { return MMGPU_OK; }      // (the server owns the device memory)
 
 int mmgpu_sw_block_starts(mmgpu_ctx *, mmgpu_sw_batch_t *, uint32_t *, uint32_t *, uint32_t *) {
     return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_sw_block_starts: not served through mmgpu_server (the drop-in hooks name their pairs: mmgpu_sw_block_backtrace)");

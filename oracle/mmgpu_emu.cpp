@@ -425,7 +425,6 @@ int mmgpu_pf_load_index(mmgpu_ctx *c, const mmgpu_pf_index *ix) {
 }
 
 int mmgpu_warmup(mmgpu_ctx *) { return 0; }
-int mmgpu_reserve(mmgpu_ctx *, uint64_t) { return 0; }
 
 // the device's tantan masking stand-in: the plain-C restatement (oracle/tantan_oracle.c)
 int mmgpu_pf_mask_targets(mmgpu_ctx *c, const double *lr, int alphabet, double min_mask_prob, int mask_letter, uint64_t *n_masked) {

@@ -38,8 +38,7 @@ for r in range(rounds):
                        identity_id=int(rng.integers(0, nt)) if i % 3 == 0 else None))
     orc = pc.pf_oracle()
     orc.build_index(tres, toff, thr)
-    for cap, bitmap in ((None, "0"), (None, "1")):
-        os.environ["MMGPU_PF_BITMAP"] = bitmap
+    for cap, bitmap in ((None, "auto"),):
         chk.load_case(gpu, g, tres, toff, thr)
         for mh, rb in ((300, 2), (int(rng.integers(5, 60)), int(rng.choice([2, 8, 64])))):
             ok, rep = chk.check(gpu, orc, qs, mh, rb, stages=True, label="fuzz %d nt=%d planted=%.2f cap=%s bitmap=%s" % (r, nt, planted, cap, bitmap))

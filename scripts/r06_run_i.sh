@@ -1,0 +1,12 @@
+# round 6: candidate-slot bases read once (replay kernel) - parity, stage times, then the default bench line and its kernel trace
+O=gpurun_out/r06i; mkdir -p $O
+python -m pytest tests/test_prefilter_gpu.py -q -m gpu -x > $O/gpu_tests_pf.log 2>&1; tail -3 $O/gpu_tests_pf.log | head -2
+export MMGPU_WL_CACHE=/tmp/mmgpu_wl
+python scripts/bench_prefilter.py --families 20000 --members 50 --queries 10000 --batch 10000 --sort 0 --steps 3 --check 12 2>$O/err.txt | tail -1 | python -c "
+import sys, json
+d = json.loads(sys.stdin.read())
+print({k: d.get(k) for k in ('s_per_pass', 'stage_ms', 'lists_crc32', 'overflow_queries', 'hits', 'checked_vs_oracle', 'mismatches')})" > $O/pf_stage.txt 2>&1
+cat $O/pf_stage.txt
+python bench.py > $O/bench_n1.json 2> $O/bench_err.txt; tail -c 3000 $O/bench_n1.json
+bash scripts/collect_kernel_trace.sh > $O/trace_collect.log 2>&1
+head -30 gpurun_out/profiles_new/bench_kernel_trace_stats.txt | cut -c1-220

@@ -140,26 +140,6 @@ def test_many_queries_ragged_lists_and_empty(gpu, oracle, matrices):
         pos += len(ids)
 
 
-def test_reserved_device_memory_serves_later_allocations(gpu, oracle, matrices):
-    """mmgpu_reserve: 256 MB set aside first; targets, batch buffers and their successors are carved out of it (pieces given back
-    are reused, a request that does not fit goes to hipMalloc) and the results are what they are without a reservation."""
-    gpu.reserve(256 << 20)
-    rng = np.random.default_rng(11)
-    mat = matrices["blosum62_sw"]
-    for rep in range(3):      # load_targets frees the previous database: pieces go back and are taken again
-        tres, toff = wl.random_seqs(rng, 300 + 50 * rep, 180, 100, min_len=1)
-        gpu.load_targets(tres, toff, 21)
-        q = rng.choice(20, size=150 + 60 * rep, p=wl.BACKGROUND).astype(np.uint8)
-        cb = _round_cb(oracle, matrices, q)
-        ids = rng.integers(0, len(toff) - 1, 200).astype(np.uint32)
-        out = gpu.sw_batch(mat, GO, GE, [dict(q=q, comp_bias=cb, targets=ids, min_start_score=0)], mode=1)
-        _check(out, oracle, mat, q, cb, tres, toff, ids, True, "rep%d" % rep)
-    off = np.arange(0, (400 << 20) + 1, 60000, dtype=np.uint64)      # 400 MB of targets: more than is left of the reservation
-    gpu.load_targets(np.zeros(int(off[-1]), np.uint8), off, 21)
-    out = gpu.sw_batch(mat, GO, GE, [dict(q=q, comp_bias=None, targets=np.array([0, len(off) - 2], np.uint32), min_start_score=0)], mode=0)
-    assert len(out) == 2 and out["score"][0] == out["score"][1]
-
-
 def test_min_start_score_gates_reverse_scan(gpu, oracle, matrices):
     rng = np.random.default_rng(9)
     mat = matrices["blosum62_sw"]
