@@ -41,7 +41,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 # packed-int16 (VOP3P) VALU ops issue at 16 lanes/clk/SIMD on gfx950: measured 38.1 Tlane-op/s for v_pk_max_i16 /
 # v_pk_sub_u16 / v_perm_b32 (profiles/r01_valu_issue_rate_probe.txt) = 256 CU x 4 SIMD x 16 lanes x 2.4 GHz = 39.3e12
 VALU_LANE_OPS_PER_S = 256 * 4 * 16 * 2.4e9
-PROFILE_ROUND = "r05"
+PROFILE_ROUND = "r06"
 
 
 def allreduce(torch, dist, values, op="sum"):
@@ -1222,12 +1222,13 @@ def translated_search_section(args):
         flags = ["--search-type", "2", "--threads", threads, "-v", "3"]
         t_full, log = run(patched, ["search", "reads", "contigs", "res_full", "tmp_full"] + flags)
         orfs = [int(l.split()[3]) for l in log.splitlines() if l.startswith(("Query database size:", "Target database size:"))][:2]
-        t_sp, _ = run(patched, ["search", "s_reads", "s_contigs", "res_sp", "tmp_sp"] + flags)
+        whole = s_reads >= len(queries) and s_contigs >= len(contigs)      # (the sample is the workload: the run above is the patched side)
+        t_sp = t_full if whole else run(patched, ["search", "s_reads", "s_contigs", "res_sp", "tmp_sp"] + flags)[0]
         t_ss, _ = run(stock, ["search", "s_reads", "s_contigs", "res_ss", "tmp_ss"] + flags)
         # (the stock binary's own runs of this command differ from each other in the ORDER of lines whose bit score and E-value tie -
         # `offsetalignment` merges the ORF hits of a read in a thread-dependent order - in 1 to 4 of these 100 entries at 32 threads;
         # entries are therefore compared up to the order inside such runs of tied lines, and how many needed that is reported)
-        n, bad, tied, _ = dbio.diff_dbs_up_to_tie_order(os.path.join(w, "res_ss"), os.path.join(w, "res_sp"))
+        n, bad, tied, _ = dbio.diff_dbs_up_to_tie_order(os.path.join(w, "res_ss"), os.path.join(w, "res_full" if whole else "res_sp"))
         return {"workload": "BASELINE.json configs[4] as a translated search: `mmseqs search reads contigs --search-type 2` (default flags), %d reads "
                             "of %d nt x %d contigs (~LogNormal(20 kb), %d nt); --threads %s"
                             % (len(queries), args.nucl_read_len, args.translated_contigs, int(toff[-1]), threads),
@@ -1243,6 +1244,11 @@ def translated_search_section(args):
                                                          "entries_equal_up_to_the_order_of_tied_lines": tied,
                                                          "note": "lines of an entry whose bit score and E-value tie are written in a thread-dependent "
                                                                  "order by the reference itself (two runs of the stock binary differ the same way)"}},
+                "timeline": "profiles/%s_translated_search_timeline.txt (MMGPU_TRACE laps of this command, scripts/search_timeline.py --translated): "
+                            "the align module is 7.3 s of 11.9 s, the device busy for ~6 ms of each ~490 ms bucket of 16 384 ORFs; the three largest "
+                            "host-side items are the reference's own accept / sort / write loop per bucket (~0.13 s x 14), the parse of a bucket's "
+                            "prefilter lists (~0.08 s x 14) and the fixed costs around the per-bucket device calls (result download + job lists of the "
+                            "block aligner ~0.06 s, prepare + fetch of the alignment batch ~0.08 s; x 14)" % PROFILE_ROUND,
                 "full_size": "50 000 contigs through the patched binary: profiles/r04_translated_search_50k.json (scripts/exp_translated_search.py)"}
     finally:
         shutil.rmtree(w, ignore_errors=True)
@@ -1305,7 +1311,7 @@ def main():
                     help="nucleotide search: size of the second, smaller run whose hit lists are compared with the reference's matcher "
                          "(the reference's 4^15-offset index build over 50 k contigs alone takes minutes)")
     ap.add_argument("--translated-contigs", type=int, default=5000, help="configs[4] as `search --search-type 2` through the binaries")
-    ap.add_argument("--translated-sample", type=str, default="200x4000", help="reads x contigs of the stock-binary run (CPU baseline + parity)")
+    ap.add_argument("--translated-sample", type=str, default="1000x5000", help="reads x contigs of the stock-binary run (CPU baseline + parity)")
     ap.add_argument("--no-translated", action="store_true")
     ap.add_argument("--nucl-reads", type=int, default=1000)
     ap.add_argument("--nucl-read-len", type=int, default=10000)

@@ -21,9 +21,11 @@
 #include <string>
 #include <thread>
 #include <vector>
+#include <sys/stat.h>
 
 #include "DBWriter.h"
 #include "ExtendedSubstitutionMatrix.h"
+#include "FileUtil.h"
 #include "IndexBuilder.h"
 #include "Debug.h"
 #include "Parameters.h"
@@ -163,11 +165,27 @@ bool persistedLayout(Prefiltering &p, DBReader<unsigned int> *tdbr, size_t dbFro
         ident[3 + 2 * i] = tdbr->getSeqLen(dbFrom + i);
     }
     uint64_t fp = MMGpuPrefilter::fingerprint(ident.data(), ident.size() * sizeof(uint64_t));
-    if (!tdbr->isCompressed()) {
-        for (size_t i = 0; i < dbSize; i += 64) {
-            const char *data = tdbr->getDataUncompressed(dbFrom + i);
-            if (data != NULL) fp = MMGpuPrefilter::fingerprint(data, std::min<size_t>(tdbr->getSeqLen(dbFrom + i), 32), fp);
+    // a compressed database is never served from a persisted layout (nothing of its content could be sampled here, and the alignment
+    // module of a fused search reads single sequences on demand)
+    if (tdbr->isCompressed()) return false;
+    // the data files themselves: size and modification time (a database rewritten in place with the same keys and lengths - edited
+    // residues, another masking, another translation table - is another database), and a sample of the content
+    {
+        const std::vector<std::string> files = FileUtil::findDatafiles(tdbr->getDataFileName());
+        std::vector<uint64_t> stamp;
+        for (size_t i = 0; i < files.size(); i++) {
+            struct stat st;
+            if (stat(files[i].c_str(), &st) != 0) return false;
+            stamp.push_back((uint64_t)st.st_size);
+            stamp.push_back((uint64_t)st.st_mtim.tv_sec);
+            stamp.push_back((uint64_t)st.st_mtim.tv_nsec);
         }
+        stamp.push_back(files.size());
+        fp = MMGpuPrefilter::fingerprint(stamp.data(), stamp.size() * sizeof(uint64_t), fp);
+    }
+    for (size_t i = 0; i < dbSize; i += 16) {
+        const char *data = tdbr->getDataUncompressed(dbFrom + i);
+        if (data != NULL) fp = MMGpuPrefilter::fingerprint(data, std::min<size_t>(tdbr->getSeqLen(dbFrom + i), 64), fp);
     }
     out->sourceFp = fp | 1ull;
     const int32_t more[5] = {maskMode, maskLowerCaseMode, maskNrepeats, targetSearchMode, (int32_t)dbFrom};

@@ -391,6 +391,10 @@ hipError_t launch_pf_merge(const PfMergeArgs &A, hipStream_t s);
 hipError_t launch_pf_kmers(const PfKmerArgs &A, bool emit, hipStream_t s);
 size_t pf_cofs_bytes(uint64_t table);
 hipError_t launch_pf_cofs(const uint32_t *offsets, uint64_t table, void *cofs, hipStream_t s);
+// persisted device layout (db_kernels.hip): checksum of a section where it lies on the device; the properties the kernels rely on
+hipError_t db_section_checksum(const void *dev, size_t bytes, unsigned long long *scratch, uint64_t *sum, hipStream_t s);
+hipError_t db_validate_layout(const uint32_t *off4, const uint32_t *len, uint32_t n, uint64_t res_bytes, uint32_t max_len, const uint32_t *offsets,
+                              uint64_t table, const uint64_t *entries, uint64_t n_entries, uint32_t *scratch, uint32_t *bad, hipStream_t s);
 hipError_t launch_pf_tiles(const uint32_t *q_tile_base, const uint32_t *q_ntiles, uint32_t nq, uint32_t *tile_q, uint32_t *tile_idx, hipStream_t s);
 hipError_t launch_pf_bitmap(const uint32_t *offsets, uint64_t table, uint32_t *bitmap, unsigned long long *nonempty, hipStream_t s);
 hipError_t launch_pf_scan(const uint32_t *in, const uint32_t *q_off, uint32_t nq, const uint64_t *base, uint32_t *out,

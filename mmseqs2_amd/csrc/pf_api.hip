@@ -908,7 +908,7 @@ extern "C" int mmgpu_pf_run(mmgpu_ctx *c, mmgpu_pf_batch_t *b) {
         std::vector<uint32_t> keep;
         for (uint32_t i : ovf_q) {
             // (--diag-score 0 merges the segments by score, QueryMatcher.cpp:514-533: not on the device either)
-            if (h_nseg[i] == 0 || h_nseg[i] > (uint32_t)PF_MAX_SEG || b->q_entries[i] > 0xFFFFFFFFull || b->par.kmer_score) {
+            if (h_nseg[i] == 0 || h_nseg[i] > (uint32_t)PF_MAX_SEG || b->q_entries[i] >= 0xF0000000ull || b->par.kmer_score) {
                 h_nseg[i] = 0;      // more flushes than the device emulates: the host runs the reference for this query
                 b->status[i] = MMGPU_PF_OVERFLOW;
                 rewrite = true;
@@ -940,7 +940,8 @@ extern "C" int mmgpu_pf_run(mmgpu_ctx *c, mmgpu_pf_batch_t *b) {
         tiles_so_far += qnt[i];
     }
     if (tiles_so_far >= 0xFFFFFFFFull) return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_pf_run: >= 2^32 tiles in one batch; use smaller batches");
-    if (total_entries >= 0xFFFFFFFFull) return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_pf_run: >= 2^32 index entries in one batch; use smaller batches");
+    // (total_entries may pass 2^32: the 32-bit bases derived from it - cand_base, cand_origin - only ever meet as differences
+    // inside one stage chunk, whose entries are bounded below)
     const uint32_t n_tiles = (uint32_t)tiles_so_far;
     b->last_tiles = n_tiles;
     b->last_entries = total_entries;
@@ -952,7 +953,6 @@ extern "C" int mmgpu_pf_run(mmgpu_ctx *c, mmgpu_pf_batch_t *b) {
     HIP_TRY(P.w_tile_q.reserve(std::max<size_t>(n_tiles, 1) * 4));
     HIP_TRY(P.w_tile_idx.reserve(std::max<size_t>(n_tiles, 1) * 4));
     if (n_tiles) HIP_TRY(launch_pf_tiles(b->d_qtile_base.as<uint32_t>(), b->d_qntiles.as<uint32_t>(), nq, P.w_tile_q.as<uint32_t>(), P.w_tile_idx.as<uint32_t>(), s));
-    if ((uint64_t)n_tiles * PF_T >= 0xFFFFFFFFull) return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_pf_run: >= 2^32 tile slots in one batch; use smaller batches");
     HIP_TRY(P.w_split.reserve(std::max<size_t>(n_tiles, 1) * PF_T * sizeof(uint32_t)));
     HIP_TRY(P.w_split_hi.reserve(std::max<size_t>(n_tiles, 1) * PF_T));
     HIP_TRY(P.w_bin_off.reserve(std::max<size_t>(n_tiles, 1) * (B + 1) * sizeof(uint16_t)));
@@ -971,7 +971,8 @@ extern "C" int mmgpu_pf_run(mmgpu_ctx *c, mmgpu_pf_batch_t *b) {
             if (hipMemGetInfo(&mem_free, &mem_total) == hipSuccess && mem_total >= (192ull << 30) && mem_free >= (120ull << 30)) gb = 40.0;
         }
         if (const char *e = getenv("MMGPU_PF_STAGE_GB")) gb = atof(e);
-        const uint64_t cap = std::max<uint64_t>((uint64_t)(gb * 1073741824.0 / (2.0 * sizeof(PfCand))), 1);
+        // (a chunk's entries stay below 2^32 whatever the budget: the candidate bases are 32-bit differences inside a chunk)
+        const uint64_t cap = std::min<uint64_t>(std::max<uint64_t>((uint64_t)(gb * 1073741824.0 / (2.0 * sizeof(PfCand))), 1), 0xF0000000ull);
         uint64_t run = 0;
         for (uint32_t i = 0; i < nq; i++) {
             if (i == 0 || run + qent[i] > cap) {
@@ -1693,7 +1694,9 @@ struct DbFileHeader {
     int32_t k, spaced, kbase, pad0;
     uint64_t table, n_entries;
     uint64_t at_off4, at_len, at_res, at_masked, at_offsets, at_entries, file_bytes;
+    uint64_t sum[6];               // version 2: checksum of every section (db_kernels.hip), in the order of the at_ fields
 };
+constexpr uint32_t DB_VERSION = 2;
 static const char DB_MAGIC[8] = {'M', 'M', 'G', 'P', 'U', 'D', 'B', '1'};
 
 static uint64_t align4k(uint64_t x) { return (x + 4095ull) & ~4095ull; }
@@ -1760,7 +1763,7 @@ extern "C" int mmgpu_db_save(mmgpu_ctx *c, const char *path, uint64_t source_fin
     DbFileHeader h;
     memset(&h, 0, sizeof(h));
     memcpy(h.magic, DB_MAGIC, 8);
-    h.version = 1;
+    h.version = DB_VERSION;
     h.header_bytes = (uint32_t)sizeof(h);
     h.source_fp = source_fingerprint;
     h.index_fp = with_index ? index_fingerprint : 0;
@@ -1785,6 +1788,19 @@ extern "C" int mmgpu_db_save(mmgpu_ctx *c, const char *path, uint64_t source_fin
         h.at_entries = at; at = align4k(at + std::max<uint64_t>(P->n_entries, 1) * 8);
     }
     h.file_bytes = at;
+    {   // the sections' checksums, taken where they lie
+        DevBuf d_sum;
+        HIP_TRY(d_sum.alloc(8));
+        unsigned long long *sc = d_sum.as<unsigned long long>();
+        HIP_TRY(db_section_checksum(c->db.off4, nn * 4, sc, &h.sum[0], c->stream));
+        HIP_TRY(db_section_checksum(c->db.len, nn * 4, sc, &h.sum[1], c->stream));
+        HIP_TRY(db_section_checksum(c->db.res, h.res_bytes, sc, &h.sum[2], c->stream));
+        if (h.has_masked) HIP_TRY(db_section_checksum(c->pf_masked_res, h.res_bytes, sc, &h.sum[3], c->stream));
+        if (with_index) {
+            HIP_TRY(db_section_checksum(P->d_offsets.p, (P->table + 1) * 4, sc, &h.sum[4], c->stream));
+            HIP_TRY(db_section_checksum(P->d_entries.p, P->n_entries * 8, sc, &h.sum[5], c->stream));
+        }
+    }
     const std::string tmp = std::string(path) + ".tmp";
     FILE *f = fopen(tmp.c_str(), "wb");
     if (!f) return fail(MMGPU_ERR_ARG, std::string("mmgpu_db_save: cannot create ") + tmp);
@@ -1807,9 +1823,17 @@ static int db_read_header(const char *path, DbFileHeader *h, int *fd_out) {
     const int fd = open(path, O_RDONLY);
     if (fd < 0) return fail(MMGPU_ERR_STATE, std::string("mmgpu_db: cannot open ") + path);
     struct stat st;
-    const bool ok = read(fd, h, sizeof(*h)) == (ssize_t)sizeof(*h) && memcmp(h->magic, DB_MAGIC, 8) == 0 && h->version == 1 &&
-                    h->header_bytes == sizeof(*h) && fstat(fd, &st) == 0 && (uint64_t)st.st_size >= h->file_bytes &&
-                    h->at_res + h->res_bytes <= h->file_bytes && (!h->has_index || h->at_entries + h->n_entries * 8 <= h->file_bytes);
+    bool ok = read(fd, h, sizeof(*h)) == (ssize_t)sizeof(*h) && memcmp(h->magic, DB_MAGIC, 8) == 0 && h->version == DB_VERSION &&
+              h->header_bytes == sizeof(*h) && fstat(fd, &st) == 0 && (uint64_t)st.st_size >= h->file_bytes;
+    // every section inside the file (sizes that cannot overflow the sums first)
+    auto inside = [&](uint64_t at, uint64_t bytes) { return at >= sizeof(*h) && bytes <= h->file_bytes && at <= h->file_bytes - bytes; };
+    if (ok) {
+        const uint64_t nn = std::max<uint32_t>(h->n, 1);
+        ok = h->table < (1ull << 40) && h->n_entries < (1ull << 40) && h->alphabet >= 1 && h->alphabet <= 255 &&
+             inside(h->at_off4, nn * 4) && inside(h->at_len, nn * 4) && inside(h->at_res, h->res_bytes) &&
+             (!h->has_masked || inside(h->at_masked, h->res_bytes)) &&
+             (!h->has_index || (inside(h->at_offsets, (h->table + 1) * 4) && inside(h->at_entries, h->n_entries * 8)));
+    }
     if (!ok) {
         close(fd);
         return fail(MMGPU_ERR_STATE, std::string("mmgpu_db: not a database file of this library version: ") + path);
@@ -1851,7 +1875,8 @@ extern "C" int mmgpu_db_load(mmgpu_ctx *c, const char *path, uint64_t source_fin
     if (want_index && (tables->kmer_size != h.k || tables->spaced != h.spaced || tables->alphabet != (int)h.alphabet)) { close(fd); return fail(MMGPU_ERR_STATE, "mmgpu_db_load: k-mer size / pattern / alphabet differ from the file's index"); }
     struct CloseFd { int fd; ~CloseFd() { close(fd); } } closer{fd};
     HIP_TRY(hipSetDevice(c->device));
-    db_release(c);
+    // (what the context holds stays until the file's content has been uploaded and checked: a file that turns out damaged leaves
+    // the context as it was)
     const size_t nn = std::max<uint32_t>(h.n, 1);
     DeviceDb db;
     uint8_t *masked = nullptr;
@@ -1897,17 +1922,52 @@ extern "C" int mmgpu_db_load(mmgpu_ctx *c, const char *path, uint64_t source_fin
     std::vector<uint32_t> hlen(h.n);
     if (h.n && pread(fd, hlen.data(), (size_t)h.n * 4, (off_t)h.at_len) != (ssize_t)((size_t)h.n * 4)) { undo(); return fail(MMGPU_ERR_STATE, "mmgpu_db_load: short read (file truncated?)"); }
     L_TRY(hipStreamSynchronize(up));
-    // the context owns the database from here on (pf_setup checks the alphabet against it)
+    // what arrived is what was saved, and it has the properties the kernels rely on
+    DevBuf d_chk;
+    L_TRY(d_chk.alloc(8));
+    auto section_ok = [&](const void *dev, size_t bytes, int which) {
+        uint64_t sum = 0;
+        return db_section_checksum(dev, bytes, d_chk.as<unsigned long long>(), &sum, up) == hipSuccess && sum == h.sum[which];
+    };
+    if (!section_ok(db.off4, nn * 4, 0) || !section_ok(db.len, nn * 4, 1) || !section_ok(db.res, (size_t)h.res_bytes, 2) ||
+        (masked && !section_ok(masked, (size_t)h.res_bytes, 3))) {
+        undo();
+        return fail(MMGPU_ERR_STATE, "mmgpu_db_load: a section's checksum differs from the one in the header (damaged file)");
+    }
+    {
+        uint32_t bad = 0;
+        L_TRY(db_validate_layout(db.off4, db.len, h.n, h.res_bytes, h.max_len, nullptr, 0, nullptr, 0, d_chk.as<uint32_t>(), &bad, up));
+        if (bad) { undo(); return fail(MMGPU_ERR_STATE, "mmgpu_db_load: a target of the file lies outside its residue block"); }
+    }
+    // the context takes the new database (pf_setup checks the alphabet against it); the old one is kept aside until the index is in
+    DeviceDb old_db = c->db;
+    uint8_t *old_masked = c->pf_masked_res;
+    PfIndex *old_pf = c->pf;
+    std::vector<uint32_t> old_hlen;
+    old_hlen.swap(c->h_len);
+    const uint32_t old_mean = c->mean_len;
+    const bool old_shard = c->shard.on;
+    c->pf = nullptr;
+    c->shard.on = false;
     c->db = db;
     db = DeviceDb();
     c->pf_masked_res = masked;
     masked = nullptr;
     c->h_len.swap(hlen);
     c->mean_len = h.mean_len;
+    auto back_to_old = [&]() {      // (the index failed: the new database goes, the old one is the context's again)
+        db_release(c);
+        c->db = old_db;
+        c->pf_masked_res = old_masked;
+        c->pf = old_pf;
+        c->h_len.swap(old_hlen);
+        c->mean_len = old_mean;
+        c->shard.on = old_shard;
+    };
     if (want_index) {
         int rc2 = pf_setup(c, tables, false, &P);
         if (rc2 == MMGPU_OK && (P->table != h.table || P->kbase != h.kbase)) rc2 = fail(MMGPU_ERR_STATE, "mmgpu_db_load: k-mer table size differs from the file's index");
-        if (rc2 != MMGPU_OK) { drop(); delete P; db_release(c); return rc2; }
+        if (rc2 != MMGPU_OK) { drop(); delete P; back_to_old(); return rc2; }
         P->n_entries = h.n_entries;
         hipError_t e = P->d_offsets.alloc((P->table + 1) * 4);
         if (e == hipSuccess) e = P->d_entries.alloc(std::max<uint64_t>(P->n_entries, 1) * 8);
@@ -1915,11 +1975,25 @@ extern "C" int mmgpu_db_load(mmgpu_ctx *c, const char *path, uint64_t source_fin
         if (rc3 == MMGPU_OK) rc3 = upload_section(c->device, P->d_offsets.p, fd, h.at_offsets, (P->table + 1) * 4, up, stage, moved);
         if (rc3 == MMGPU_OK && P->n_entries) rc3 = upload_section(c->device, P->d_entries.p, fd, h.at_entries, P->n_entries * 8, up, stage, moved);
         if (rc3 == MMGPU_OK && hipStreamSynchronize(up) != hipSuccess) rc3 = fail(MMGPU_ERR_HIP, "mmgpu_db_load: upload failed");
+        if (rc3 == MMGPU_OK && (!section_ok(P->d_offsets.p, (P->table + 1) * 4, 4) || !section_ok(P->d_entries.p, P->n_entries * 8, 5)))
+            rc3 = fail(MMGPU_ERR_STATE, "mmgpu_db_load: the index's checksum differs from the one in the header (damaged file)");
+        if (rc3 == MMGPU_OK) {
+            uint32_t bad = 0;
+            if (db_validate_layout(c->db.off4, c->db.len, h.n, h.res_bytes, h.max_len, P->d_offsets.as<uint32_t>(), P->table, P->d_entries.as<uint64_t>(),
+                                   P->n_entries, d_chk.as<uint32_t>(), &bad, up) != hipSuccess) rc3 = fail(MMGPU_ERR_HIP, "mmgpu_db_load: layout check failed");
+            else if (bad) rc3 = fail(MMGPU_ERR_STATE, "mmgpu_db_load: the file's index is not a k-mer index over these targets (offsets not monotone / entry out of range)");
+        }
         if (rc3 == MMGPU_OK && pf_index_bitmap(c, P) != hipSuccess) rc3 = fail(MMGPU_ERR_HIP, "mmgpu_db_load: bit table failed");
         if (rc3 == MMGPU_OK && pf_index_cofs(c, P) != hipSuccess) rc3 = fail(MMGPU_ERR_HIP, "mmgpu_db_load: compact offset table failed");
-        if (rc3 != MMGPU_OK) { drop(); delete P; db_release(c); return rc3; }
+        if (rc3 != MMGPU_OK) { drop(); delete P; back_to_old(); return rc3; }
         c->pf = P;
         P = nullptr;
+    }
+    {   // the old database goes
+        (void)hipStreamSynchronize(c->stream);
+        dev_free(old_db.res); dev_free(old_db.off4); dev_free(old_db.len);
+        if (old_masked) dev_free(old_masked);
+        delete old_pf;
     }
     drop();
 #undef L_TRY

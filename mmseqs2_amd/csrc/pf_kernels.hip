@@ -759,53 +759,57 @@ __device__ __forceinline__ Seg seg_combine(const Seg &l, const Seg &r) {   // l 
     o.M = max(max(l.M, r.M), l.a + r.P);
     return o;
 }
-__device__ __forceinline__ void load16(const uint8_t *p, uint32_t w[4]) {
-    // 16 bytes from an arbitrarily aligned address: one 16-byte + one 4-byte request on the enclosing aligned dwords
+// Round 6: a pass of 4 * NW cells per lane (NW = 4: 256 cells per group and pass, NW = 6: 384).  Most diagonals of a protein
+// search are 250 - 380 cells long: with 16 cells per lane they took a second pass - a whole pass's instructions for a few dozen
+// cells, and a second tree.  Cells past the segment's end count as score 0, which changes no summary (the prefix sums stay at the
+// sum of the real cells, a stays a); a lane with no cell at all keeps the identity.
+template <int NW>
+__device__ __forceinline__ void load_cells(const uint8_t *p, uint32_t (&w)[NW]) {
+    static_assert(NW == 4 || NW == 6, "16 or 24 bytes");
+    // 4 * NW bytes from an arbitrarily aligned address: a 16-byte request and a 4-byte (12-byte) one on the enclosing aligned dwords
     const uintptr_t u = reinterpret_cast<uintptr_t>(p);
     const uint32_t *a = reinterpret_cast<const uint32_t *>(u & ~(uintptr_t)3);
     const uint32_t sh = (uint32_t)(u & 3u);
     const U32Quad d = *reinterpret_cast<const U32Quad *>(a);
-    const uint32_t d4 = a[4];
     w[0] = __builtin_amdgcn_alignbyte(d.b, d.a, sh);
     w[1] = __builtin_amdgcn_alignbyte(d.c, d.b, sh);
     w[2] = __builtin_amdgcn_alignbyte(d.d, d.c, sh);
-    w[3] = __builtin_amdgcn_alignbyte(d4, d.d, sh);
+    if constexpr (NW == 4) {
+        w[3] = __builtin_amdgcn_alignbyte(a[4], d.d, sh);
+    } else {
+        typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+        const u32x3 e = *reinterpret_cast<const u32x3 *>(a + 4);      // (dwordx3: 4-byte alignment is enough)
+        w[3] = __builtin_amdgcn_alignbyte(e.x, d.d, sh);
+        w[4] = __builtin_amdgcn_alignbyte(e.y, e.x, sh);
+        w[5] = __builtin_amdgcn_alignbyte(e.z, e.y, sh);
+    }
 }
-__device__ __forceinline__ void load16_lds(const uint32_t *base, uint32_t byte_off, uint32_t w[4]) {
-    const uint32_t *a = base + (byte_off >> 2);
-    const uint32_t sh = byte_off & 3u;
-    const uint32_t d0 = a[0], d1 = a[1], d2 = a[2], d3 = a[3], d4 = a[4];
-    w[0] = __builtin_amdgcn_alignbyte(d1, d0, sh);
-    w[1] = __builtin_amdgcn_alignbyte(d2, d1, sh);
-    w[2] = __builtin_amdgcn_alignbyte(d3, d2, sh);
-    w[3] = __builtin_amdgcn_alignbyte(d4, d3, sh);
-}
-
-__device__ __forceinline__ Seg seg_cells(const uint32_t tw[4], const uint32_t qw[4], const uint32_t cw[4], int nn,
-                                         const int8_t *smat, int alph) {
+template <int NW>
+__device__ __forceinline__ Seg seg_cells_n(const uint32_t (&tw)[NW], const uint32_t (&qw)[NW], const uint32_t (&cw)[NW], int nn,
+                                           const int8_t *smat, int alph) {
     Seg g;
     g.a = 0; g.b = 0; g.P = -(1 << 28); g.M = 0;
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
+    for (int k = 0; k < 4 * NW; k++) {
         const int tb_ = (int)((tw[k >> 2] >> ((k & 3) * 8)) & 0xFFu);
         const int qb = (int)((qw[k >> 2] >> ((k & 3) * 8)) & 0xFFu);
         const int cb = (int)(int8_t)((cw[k >> 2] >> ((k & 3) * 8)) & 0xFFu);
-        const int x = (int)(int8_t)(smat[(qb * alph + tb_) & 1023] + cb);
-        if (k < nn) {
-            g.b += x;
-            g.a = max(0, g.a + x);
-            g.P = max(g.P, g.b);
-            g.M = max(g.M, g.a);
-        }
+        int x = (int)(int8_t)(smat[(qb * alph + tb_) & 1023] + cb);
+        x = k < nn ? x : 0;
+        g.b += x;
+        g.a = max(0, g.a + x);
+        g.P = max(g.P, g.b);
+        g.M = max(g.M, g.a);
     }
     return g;
 }
 // profile query: the score of cell k is row (first position + k) of the query's score rows at the target letter
-__device__ __forceinline__ Seg seg_cells_rows(const uint32_t tw[4], const int8_t *rows, int nn) {
+template <int NW>
+__device__ __forceinline__ Seg seg_cells_rows_n(const uint32_t (&tw)[NW], const int8_t *rows, int nn) {
     Seg g;
     g.a = 0; g.b = 0; g.P = -(1 << 28); g.M = 0;
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
+    for (int k = 0; k < 4 * NW; k++) {
         if (k < nn) {
             const int tb_ = (int)((tw[k >> 2] >> ((k & 3) * 8)) & 0xFFu);
             const int x = (int)rows[k * PF_PROW + (tb_ & (PF_PROW - 1))];
@@ -832,10 +836,9 @@ __device__ __forceinline__ Seg seg_tree16(Seg g, int gl) {   // ordered tree ove
 
 // Scores up to 64 candidates of one (query, bin) bucket - lane l holds candidate cb0 + l - and, when the bucket has no
 // more than 64 candidates, finishes keepMaxElement for it.  Latency plan: target metadata of the whole chunk in one
-// round trip, then the first 256 diagonal cells of 8 candidates at a time are requested together before any is scored.
-// s_q == nullptr: the query side is read from global memory (L1/L2) instead of the LDS copy.
-__device__ __forceinline__ uint64_t score_chunk(const PfDedupArgs &A, const int8_t *smat, const uint32_t *s_qres,
-                                                const uint32_t *s_qcorr, uint64_t bucket, uint32_t q, uint32_t cb0,
+// round trip, then the first pass (256 or 384 diagonal cells) of 8 candidates at a time is requested together before any is
+// scored.  The query side is read from global memory (L1/L2).
+__device__ __forceinline__ uint64_t score_chunk(const PfDedupArgs &A, const int8_t *smat, uint64_t bucket, uint32_t q, uint32_t cb0,
                                                 uint32_t nin, uint32_t ncand, PfCand c, int bshift) {
     const int lane = lane_id();
     const int grp = lane >> 4, gl = lane & 15;
@@ -843,26 +846,18 @@ __device__ __forceinline__ uint64_t score_chunk(const PfDedupArgs &A, const int8
     const int qlen = (int)(A.q_off[q + 1] - qp0);
     const uint8_t *qr = A.q_res + qp0;
     const uint8_t *qc = reinterpret_cast<const uint8_t *>(A.q_corr) + qp0;
-    const uint32_t qsh = qp0 & 3u;
     const int alph = A.alphabet;
     const bool has = (uint32_t)lane < nin;
     const int8_t *prows = (A.q_isprof && A.q_isprof[q]) ? A.q_rows + (size_t)qp0 * PF_PROW : nullptr;   // wave-uniform
-    auto query16 = [&](int off, uint32_t qw[4], uint32_t cw[4]) {
-        if (s_qres) {
-            load16_lds(s_qres, qsh + (uint32_t)off, qw);
-            load16_lds(s_qcorr, qsh + (uint32_t)off, cw);
-        } else {
-            load16(qr + off, qw);
-            load16(qc + off, cw);
-        }
-    };
     int my_len = 0, my_qs = 0;
     unsigned long long my_addr = 0;
     uint64_t cells = 0;
     // A candidate of an ordinary query arrives with the low byte of its diagonal and, in `score`, where its entry stands in the
-    // split tiles (replay_bucket_impl): the high byte is read here, one round trip for the whole chunk, and written back with the
-    // score.  (Overflow-path queries and --diag-score 0 complete their diagonals in the replay / count kernels.)
-    if (has && !(A.q_nseg && A.q_nseg[q])) c.diag = (uint16_t)((c.diag & 0xFFu) | ((uint32_t)A.split_hi[c.score] << 8));
+    // QUERY's split tiles (replay_bucket_impl; the tiles of a batch may hold 2^32 slots and more, a query's do not): the high byte
+    // is read here, one round trip for the whole chunk, and written back with the score.  (Overflow-path queries and
+    // --diag-score 0 complete their diagonals in the replay / count kernels.)
+    if (has && !(A.q_nseg && A.q_nseg[q]))
+        c.diag = (uint16_t)((c.diag & 0xFFu) | ((uint32_t)A.split_hi[(size_t)A.q_tile_base[q] * PF_T + c.score] << 8));
     if (has) {
         const int d = (int)(short)c.diag;
         const int tlen = (int)A.t_len[c.id];
@@ -884,8 +879,11 @@ __device__ __forceinline__ uint64_t score_chunk(const PfDedupArgs &A, const int8
     }
     int my_score = 0;
     constexpr int UN = 2;   // candidates per group in flight: 4 groups x UN = 8 per round trip
-    for (uint32_t k0 = 0; k0 < nin; k0 += 4 * UN) {
-        uint32_t tw[UN][4], qw[UN][4], cw[UN][4];
+    // one trip = 8 candidates; NW dwords (4 * NW cells) per lane and pass
+    auto trip = [&](auto nw_tag, const uint32_t k0) {
+        constexpr int NW = decltype(nw_tag)::value;
+        constexpr int CPL = 4 * NW, PASS = 16 * CPL;
+        uint32_t tw[UN][NW], qw[UN][NW], cw[UN][NW];
         int len_u[UN], qs_u[UN];
         unsigned long long addr_u[UN];
 #pragma unroll
@@ -896,10 +894,13 @@ __device__ __forceinline__ uint64_t score_chunk(const PfDedupArgs &A, const int8
             addr_u[u] = __shfl(my_addr, src);
             if ((uint32_t)src >= nin) len_u[u] = 0;
 #pragma unroll
-            for (int z = 0; z < 4; z++) { tw[u][z] = 0; qw[u][z] = 0; cw[u][z] = 0; }
-            if (gl * 16 < len_u[u]) {
-                load16(reinterpret_cast<const uint8_t *>((uintptr_t)addr_u[u]) + gl * 16, tw[u]);
-                if (!prows) query16(qs_u[u] + gl * 16, qw[u], cw[u]);
+            for (int z = 0; z < NW; z++) { tw[u][z] = 0; qw[u][z] = 0; cw[u][z] = 0; }
+            if (gl * CPL < len_u[u]) {
+                load_cells<NW>(reinterpret_cast<const uint8_t *>((uintptr_t)addr_u[u]) + gl * CPL, tw[u]);
+                if (!prows) {
+                    load_cells<NW>(qr + qs_u[u] + gl * CPL, qw[u]);
+                    load_cells<NW>(qc + qs_u[u] + gl * CPL, cw[u]);
+                }
             }
         }
 #pragma unroll
@@ -907,9 +908,9 @@ __device__ __forceinline__ uint64_t score_chunk(const PfDedupArgs &A, const int8
             const int len = len_u[u];
             Seg g;
             g.a = 0; g.b = 0; g.P = -(1 << 28); g.M = 0;
-            if (gl * 16 < len) {
-                if (prows) g = seg_cells_rows(tw[u], prows + (size_t)(qs_u[u] + gl * 16) * PF_PROW, min(16, len - gl * 16));
-                else g = seg_cells(tw[u], qw[u], cw[u], min(16, len - gl * 16), smat, alph);
+            if (gl * CPL < len) {
+                if (prows) g = seg_cells_rows_n<NW>(tw[u], prows + (size_t)(qs_u[u] + gl * CPL) * PF_PROW, min(CPL, len - gl * CPL));
+                else g = seg_cells_n<NW>(tw[u], qw[u], cw[u], min(CPL, len - gl * CPL), smat, alph);
             }
             g = seg_tree16(g, gl);
             int sc = 0, best = 0;
@@ -920,17 +921,18 @@ __device__ __forceinline__ uint64_t score_chunk(const PfDedupArgs &A, const int8
             int maxlen = len;
             maxlen = max(maxlen, __shfl_xor(maxlen, 16));
             maxlen = max(maxlen, __shfl_xor(maxlen, 32));
-            for (int p0 = 256; p0 < maxlen; p0 += 256) {      // diagonals longer than one pass
-                const int o = p0 + gl * 16;
+            for (int p0 = PASS; p0 < maxlen; p0 += PASS) {      // diagonals longer than one pass
+                const int o = p0 + gl * CPL;
                 Seg h;
                 h.a = 0; h.b = 0; h.P = -(1 << 28); h.M = 0;
                 if (o < len) {
-                    uint32_t t2[4], q2[4], c2[4];
-                    load16(reinterpret_cast<const uint8_t *>((uintptr_t)addr_u[u]) + o, t2);
-                    if (prows) h = seg_cells_rows(t2, prows + (size_t)(qs_u[u] + o) * PF_PROW, min(16, len - o));
+                    uint32_t t2[NW], q2[NW], c2[NW];
+                    load_cells<NW>(reinterpret_cast<const uint8_t *>((uintptr_t)addr_u[u]) + o, t2);
+                    if (prows) h = seg_cells_rows_n<NW>(t2, prows + (size_t)(qs_u[u] + o) * PF_PROW, min(CPL, len - o));
                     else {
-                        query16(qs_u[u] + o, q2, c2);
-                        h = seg_cells(t2, q2, c2, min(16, len - o), smat, alph);
+                        load_cells<NW>(qr + qs_u[u] + o, q2);
+                        load_cells<NW>(qc + qs_u[u] + o, c2);
+                        h = seg_cells_n<NW>(t2, q2, c2, min(CPL, len - o), smat, alph);
                     }
                 }
                 h = seg_tree16(h, gl);
@@ -944,6 +946,12 @@ __device__ __forceinline__ uint64_t score_chunk(const PfDedupArgs &A, const int8
             const int rel = lane - ((int)k0 + u * 4);
             if (rel >= 0 && rel < 4) my_score = rel == 0 ? r0 : (rel == 1 ? r1 : (rel == 2 ? r2 : r3));
         }
+    };
+    for (uint32_t k0 = 0; k0 < nin; k0 += 4 * UN) {
+        // the trip's longest diagonal decides the pass width (wave-uniform: the trip's eight candidates sit in lanes k0 .. k0 + 7)
+        const bool mine = (uint32_t)lane >= k0 && (uint32_t)lane < k0 + 4u * UN && has;
+        if (ballot(mine && my_len > 256)) trip(std::integral_constant<int, 6>{}, k0);
+        else trip(std::integral_constant<int, 4>{}, k0);
     }
     c.score = (uint32_t)my_score;
     if (has) {
@@ -1052,6 +1060,8 @@ __device__ __forceinline__ void replay_bucket_impl(const PfDedupArgs &A, ReplayL
     // where the bucket's candidates go (cand_slot): read once - a load inside the rounds would make every later wait a full one
     PfCand *const cand_small = A.cand_small + bucket * PF_CAND0;
     PfCand *const cand_big = A.cand + (A.cand_base[bucket] - A.cand_origin);
+    const uint8_t *const split_hi_q = A.split_hi + (size_t)tb * PF_T;
+    const uint32_t *const split_q = A.split + (size_t)tb * PF_T;
     const uint32_t nseg = SEGS ? A.q_nseg[q] : 0u;
     const uint32_t *segs = SEGS ? A.seg_start + (size_t)q * (PF_MAX_SEG + 2) : nullptr;
     uint32_t cur_seg = 0, next_boundary = SEGS ? segs[1] : 0xFFFFFFFFu;
@@ -1085,25 +1095,20 @@ __device__ __forceinline__ void replay_bucket_impl(const PfDedupArgs &A, ReplayL
             const uint32_t d_m = (uint32_t)__shfl((int)seg_delta, m);
             tile_out = t0 + (uint32_t)m;
             at_out = (uint32_t)(x + d_m);      // (the sum wraps in 32 bits)
-            e_out = 0;
-            if (x < total) e_out = A.split[(size_t)(tb + tile_out) * PF_T + at_out];
+            // every lane loads (a lane past the end of the group re-reads the query's first slot, one request for all of them): a
+            // load under a branch leaves the compiler no lower bound on the loads issued after it, and every wait becomes vmcnt(0)
+            e_out = split_q[x < total ? (size_t)tile_out * PF_T + at_out : (size_t)0];
         };
-        uint32_t e_q[REPLAY_PD], tile_q[REPLAY_PD], at_q[REPLAY_PD];
-#pragma unroll
-        for (int k = 0; k < REPLAY_PD; k++) {
-            e_q[k] = 0; tile_q[k] = 0; at_q[k] = 0;
-            if ((uint32_t)k * 64u < total) request((uint32_t)k * 64u, e_q[k], tile_q[k], at_q[k]);
-        }
-        for (uint32_t xg = 0; xg < total; xg += 64u * REPLAY_PD) {
-#pragma unroll
-          for (int pk = 0; pk < REPLAY_PD; pk++) {
-            const uint32_t x0 = xg + 64u * (uint32_t)pk;
-            if (x0 < total) {      // (no break: the slots keep their registers through the unrolled body)
-            const uint32_t e = e_q[pk];
-            const uint32_t tile_cur = tile_q[pk];
-            const uint32_t where = (tb + tile_cur) * (uint32_t)PF_T + at_q[pk];      // the entry's place in the split arrays (< 2^32: pf_api.hip)
+        // One round: the slot's entries are processed, the slot is refilled with the round REPLAY_PD rounds ahead.  The slots are
+        // NAMED SCALARS and the round has no condition of its own (a slot past the end of the group has no active lane, its refill
+        // loads and marks nothing): as arrays under per-slot branches the compiler kept each array in one register tuple and copied
+        // the tuple around every load - s_waitcnt vmcnt(0) before each request, i.e. no round in flight at all.
+        auto one_round = [&](const uint32_t x0, uint32_t &e_slot, uint32_t &tile_slot, uint32_t &at_slot) {
+            const uint32_t e = e_slot;
+            const uint32_t tile_cur = tile_slot;
+            const uint32_t where = tile_cur * (uint32_t)PF_T + at_slot;      // the entry's place in the query's tiles of the split arrays
             const bool act = x0 + (uint32_t)lane < total;
-            if (x0 + 64u * REPLAY_PD < total) request(x0 + 64u * REPLAY_PD, e_q[pk], tile_q[pk], at_q[pk]);
+            request(x0 + 64u * REPLAY_PD, e_slot, tile_slot, at_slot);
             const uint32_t key = e & 0xFFFu;   // < PF_IDS_PER_BIN
             const uint32_t d8 = (e >> 12) & 0xFFu;
             const uint32_t arr = tile_cur * (uint32_t)PF_T + (e >> 20);
@@ -1136,7 +1141,7 @@ __device__ __forceinline__ void replay_bucket_impl(const PfDedupArgs &A, ReplayL
                             // ordinary query: the scoring step reads the high diagonal byte (score_chunk); the overflow path's
                             // kernels take the candidates as they are, so their diagonals are completed here
                             c.score = SEGS ? 0u : where;
-                            c.diag = (uint16_t)(SEGS ? (d8 | ((uint32_t)A.split_hi[where] << 8)) : d8);
+                            c.diag = (uint16_t)(SEGS ? (d8 | ((uint32_t)split_hi_q[where] << 8)) : d8);
                             c.pad = (uint16_t)cur_seg;
                             const uint32_t ck = ncand + (uint32_t)__popcll(kb & below);
                             *(ck < (uint32_t)PF_CAND0 ? cand_small + ck : cand_big + ck) = c;
@@ -1157,8 +1162,18 @@ __device__ __forceinline__ void replay_bucket_impl(const PfDedupArgs &A, ReplayL
                     next_boundary = cur_seg + 1 <= nseg ? segs[cur_seg + 1] : 0xFFFFFFFFu;
                 }
             }
-            }
-          }
+        };
+        static_assert(REPLAY_PD == 4, "four named slots below");
+        uint32_t e0, e1, e2, e3, tile0, tile1, tile2, tile3, at0, at1, at2, at3;
+        request(0u, e0, tile0, at0);
+        request(64u, e1, tile1, at1);
+        request(128u, e2, tile2, at2);
+        request(192u, e3, tile3, at3);
+        for (uint32_t xg = 0; xg < total; xg += 64u * REPLAY_PD) {
+            one_round(xg, e0, tile0, at0);
+            one_round(xg + 64u, e1, tile1, at1);
+            one_round(xg + 128u, e2, tile2, at2);
+            one_round(xg + 192u, e3, tile3, at3);
         }
     }
     if (lane == 0) A.cand_count[bucket] = ncand;
@@ -1174,7 +1189,7 @@ __device__ __forceinline__ void replay_bucket_impl(const PfDedupArgs &A, ReplayL
             c.diag = (uint16_t)(kd >> 12);
             c.score = M.cand[wave][2][lane];
         }
-        uint64_t cells = score_chunk(A, M.smat, nullptr, nullptr, bucket, q, 0, ncand, ncand, c, bshift);
+        uint64_t cells = score_chunk(A, M.smat, bucket, q, 0, ncand, ncand, c, bshift);
         if (A.cell_counter) {
             for (int dd = 1; dd < 64; dd <<= 1) cells += __shfl_xor((unsigned long long)cells, dd);
             if (lane == 0 && cells) atomicAdd((unsigned long long *)&A.cell_counter[q], (unsigned long long)cells);
@@ -1216,7 +1231,7 @@ __global__ __launch_bounds__(256) void pf_ungapped_kernel(PfDedupArgs A) {
         PfCand c;
         c.id = 0; c.arr = 0; c.score = 0; c.diag = 0; c.pad = 0;
         if ((uint32_t)lane < nin) c = *cand_slot(A, bucket, cb0 + (uint32_t)lane);
-        cells += score_chunk(A, smat, nullptr, nullptr, bucket, q, cb0, nin, ncand, c, bshift);
+        cells += score_chunk(A, smat, bucket, q, cb0, nin, ncand, c, bshift);
     }
     if (A.cell_counter) {   // statistics: one counter per query (a single global counter serialises 2.6 M atomics)
         for (int dd = 1; dd < 64; dd <<= 1) cells += __shfl_xor((unsigned long long)cells, dd);
@@ -1270,7 +1285,7 @@ __global__ __launch_bounds__(256) void pf_count_kernel(PfDedupArgs A) {
             const uint32_t ex_m = __shfl(excl, m), o_m = __shfl(o0, m);
             const uint32_t tile = t0 + (uint32_t)m;
             uint32_t e = 0;
-            const uint32_t where = (tb + tile) * (uint32_t)PF_T + o_m + (x - ex_m);
+            const size_t where = (size_t)(tb + tile) * PF_T + o_m + (x - ex_m);
             if (now) e = A.split[where];
             const uint32_t key = e & 0xFFFu;   // < PF_IDS_PER_BIN
             const uint32_t id = (key << bshift) | bin;

@@ -150,7 +150,9 @@ int mmgpu_pf_mask_targets(mmgpu_ctx *c, const double *lr, int alphabet, double m
 // nothing to load on this side of the socket
 // the persisted device layout is a matter of the process that owns the device: the resident server keeps its databases between
 // commands anyway (found by fingerprint), so a client neither saves nor loads files - "no such file" makes the caller build as ever
-int mmgpu_db_save(mmgpu_ctx *, const char *, uint64_t, uint64_t) { return MMGPU_OK; }
+int mmgpu_db_save(mmgpu_ctx *, const char *, uint64_t, uint64_t) {
+    return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_db_save: not served through mmgpu_server (nothing written; the server keeps databases resident itself)");
+}
 int mmgpu_db_probe(const char *, mmgpu_db_info *) { return fail(MMGPU_ERR_STATE, "mmgpu_db_probe: not served through mmgpu_server"); }
 int mmgpu_db_load(mmgpu_ctx *, const char *, uint64_t, uint64_t, const mmgpu_pf_index *) {
     return fail(MMGPU_ERR_STATE, "mmgpu_db_load: not served through mmgpu_server (the server keeps databases resident itself)");

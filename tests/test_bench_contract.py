@@ -1,4 +1,4 @@
-"""The bench line the driver parses: the committed line of this round (profiles/r05_bench_n1.json, produced by
+"""The bench line the driver parses: the committed line of this round (profiles/r06_bench_n1.json, produced by
 `python bench.py` on the GPU box) must carry the contract's keys, be quoted on BASELINE.json's metric configuration (10k
 queries x 1M targets), and its CPU-baseline legs - which double as full-size parity checks against the real reference -
 must have found no difference."""
@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _line():
-    return json.loads(open(os.path.join(ROOT, "profiles", "r05_bench_n1.json")).read())
+    return json.loads(open(os.path.join(ROOT, "profiles", "r06_bench_n1.json")).read())
 
 
 def test_committed_bench_line_has_the_contract_keys():
@@ -68,7 +68,17 @@ def test_committed_bench_line_has_the_contract_keys():
     # the translated search of configs[4] through both binaries: equal entries (up to the order of tied lines, which the stock
     # binary itself does not keep from run to run)
     t = d["translated_search"]["cpu_baseline"]["parity_vs_reference"]
-    assert t["entries_differing"] == 0 and t["result_entries_compared"] == 200
+    assert t["entries_differing"] == 0 and t["result_entries_compared"] == 1000
+    assert "timeline" in d["translated_search"]
+    # round 6: configs[1] (align-only) carries its own parity against the reference's ssw_align and a CPU baseline
+    ao = d["align_only"]["cpu_baseline"]
+    assert ao["kind"] == "reference" and ao["parity_vs_reference"]["pairs_compared"] >= 100000
+    assert ao["parity_vs_reference"]["score_mismatches"] == 0 and ao["parity_vs_reference"]["end_position_mismatches_among_positive_scores"] == 0
+    # round 6: the search-semantics step (block aligner inside the timed step, reverse scan only where the block aligner declines)
+    ss = d["search_semantics"]
+    assert ss["parity"]["queries_with_a_differing_record"] == 0 and ss["parity"]["queries_compared"] == 10000 and ss["left_undecided"] == 0
+    assert abs(d["queries_per_s_search_semantics"] - 10000 / (d["ms_per_step_search_semantics"] * 1e-3)) < 0.01 * d["queries_per_s_search_semantics"]
+    assert d["ms_per_step_search_semantics"] <= 200.0
 
 
 def test_pmc_reader_finds_the_quoted_kernels():

@@ -15,6 +15,35 @@ def test_probe_refuses_what_is_not_a_database_file(tmp_path):
     junk = tmp_path / "junk.mmgpu"
     junk.write_bytes(b"MMGPUDB1" + b"\0" * 100)
     assert capi.db_probe(junk) is None
+    # a header of this version whose sections lie inside the file is accepted, the same header with any section (or its size)
+    # reaching past the end of the file is not - before a byte of it is sent to the device
+    import struct
+    fmt = "<8sIIQQIIIIQQIIiiiiQQ7Q6Q"
+    n, res_bytes, table, n_entries = 10, 8192, 21 ** 6, 100
+    at = [4096, 8192, 12288, 20480, 28672, 28672 + ((4 * (table + 1) + 4095) // 4096) * 4096]
+    file_bytes = at[5] + 4096
+
+    def header(**over):
+        f = dict(version=2, n=n, res_bytes=res_bytes, table=table, n_entries=n_entries, at=list(at), file_bytes=file_bytes)
+        f.update(over)
+        return struct.pack(fmt, b"MMGPUDB1", f["version"], struct.calcsize(fmt), 0x11, 0x22, f["n"], 21, 500, 300, 3000, f["res_bytes"], 1, 1,
+                           6, 1, 21, 0, f["table"], f["n_entries"], *f["at"], f["file_bytes"], *([0] * 6))
+
+    def probe(h):
+        q = tmp_path / "crafted.mmgpu"
+        q.write_bytes(h + b"\0" * (file_bytes - len(h)))
+        return capi.db_probe(q)
+    ok = probe(header())
+    assert ok is not None and ok["n_targets"] == n and ok["n_entries"] == n_entries and ok["kmer_size"] == 6
+    assert probe(header(version=1)) is None                                         # files of the previous layout: rebuilt, not read
+    for k in range(6):
+        moved = list(at)
+        moved[k] = file_bytes - 8
+        assert probe(header(at=moved)) is None, k
+    assert probe(header(res_bytes=file_bytes)) is None
+    assert probe(header(n_entries=2 ** 61)) is None and probe(header(table=2 ** 62)) is None      # (sizes that would wrap the sums)
+    assert probe(header(n=2 ** 31)) is None
+    assert probe(header(file_bytes=file_bytes + 1)) is None                         # truncated file
 
 
 @pytest.mark.gpu
@@ -73,6 +102,30 @@ def test_saved_database_answers_like_the_resident_one(gpu, matrices, oracle, tmp
         assert np.array_equal(other.sw_batch(mat, 11, 1, sw_q, mode=1), a)
         with pytest.raises(capi.MMGpuError):
             other.pf_batch(qs[:1], thr, max_hits=300, ref_bins=2)
+        # damaged files are refused and leave the context as it was: a flipped byte in the offset table, in the residues, a
+        # truncated file, a header whose section lies outside the file (the resident targets keep answering)
+        import struct
+        raw = bytearray(path.read_bytes())
+        fields = struct.unpack_from("<8sIIQQIIIIQQIIiiiiQQ7Q6Q", raw, 0)
+        at_off4, at_len, at_res, at_masked, at_offsets, at_entries, file_bytes = fields[19:26]
+        assert file_bytes == len(raw) and at_off4 < at_len < at_res < at_masked < at_offsets < at_entries
+        def damaged(name, change):
+            bad = bytearray(raw)
+            bad = change(bad) or bad
+            q = tmp_path / name
+            q.write_bytes(bytes(bad))
+            return q
+        def flip(at):
+            def f(bb):
+                bb[at] ^= 0x40
+            return f
+        cases = {"offsets": flip(at_offsets + 4 * 1000 + 1), "residues": flip(at_res + 777), "entries": flip(at_entries + 8 * 50),
+                 "lengths": flip(at_len + 9), "truncated": lambda bb: bb[:at_entries + 100],
+                 "section_outside": lambda bb: struct.pack_into("<Q", bb, 8 + 8 + 16 + 16 + 16 + 8 + 16 + 16 + 4 * 8, len(raw) + 4096)}
+        for name, change in cases.items():
+            q = damaged(name + ".mmgpu", change)
+            assert other.db_load(q, 0x1234, 0x77, 6, 21, True, s3, i3, um8) is False, name
+            assert np.array_equal(other.sw_batch(mat, 11, 1, sw_q, mode=1), a), name
     finally:
         other.close()
     # restore the module's golden case for the tests that follow

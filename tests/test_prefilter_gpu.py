@@ -522,3 +522,37 @@ def test_compact_offset_table_with_long_lists(gpu):
         n = int(counts[qi])
         assert np.array_equal(hits[qi][:n], hits0[qi][:n])
     chk.load_case(gpu, g, g["tres"], g["toff"], thr)
+
+
+def test_batch_with_more_than_2_32_index_entries_and_tile_slots(gpu):
+    """One batch whose queries meet more than 2^32 index entries (the split tiles then hold more than 2^32 slots): the 32-bit
+    places of the replay kernel are relative to the query's own tiles and the 32-bit candidate bases only meet inside a stage
+    chunk, so the batch runs as one.  2 000 targets that are lightly mutated copies of one sequence, every query that sequence:
+    each query meets ~10^6 entries, as many queries as it takes to pass 2^32 + 10 %.  The first query is checked against the
+    oracle stage by stage; every other query - those standing beyond the 2^32nd entry among them - must give the same list."""
+    g = pc.golden()
+    thr = int(g["kmer_thr"])
+    rng = np.random.default_rng(5)
+    base = rng.choice(20, size=220, p=wl.BACKGROUND).astype(np.uint8)
+    tl = [wl.mutate(rng, base, 0.9) for _ in range(2000)]
+    tres, toff = wl.seqs_from_list(tl)
+    orc = pc.pf_oracle()
+    orc.build_index(tres, toff, thr)
+    chk.load_case(gpu, g, tres, toff, thr)
+    try:
+        one = [dict(q=base, comp_bias=None, identity_id=None)]
+        ok, rep = chk.check(gpu, orc, one, 300, 2, stages=True, label="one query of the large batch")
+        assert ok, "\n".join(rep)
+        _, _, _, stats = gpu.pf_batch(one, thr, max_hits=300, ref_bins=2)
+        per_query = int(stats[0]["db_matches"])
+        assert 1e5 < per_query < 2e6      # (below maxDbMatches: the ordinary path)
+        nq = int(1.1 * 2 ** 32 / per_query) + 1
+        hits, counts, status, stats = gpu.pf_batch(one * nq, thr, max_hits=300, ref_bins=2)
+        assert int(stats["db_matches"].astype(np.int64).sum()) > 2 ** 32
+        assert np.all(status == 0) and np.all(counts == counts[0]) and counts[0] > 0
+        n = int(counts[0])
+        for f in ("id", "score", "diagonal"):
+            assert np.all(hits[:, :n][f] == hits[0, :n][f][None, :]), f
+    finally:
+        orc.build_index(g["tres"], g["toff"], thr)
+        chk.load_case(gpu, g, g["tres"], g["toff"], thr)
