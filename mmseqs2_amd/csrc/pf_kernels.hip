@@ -786,15 +786,17 @@ __device__ __forceinline__ void load_cells(const uint8_t *p, uint32_t (&w)[NW]) 
 }
 template <int NW>
 __device__ __forceinline__ Seg seg_cells_n(const uint32_t (&tw)[NW], const uint32_t (&qw)[NW], const uint32_t (&cw)[NW], int nn,
-                                           const int8_t *smat, int alph) {
+                                           const int8_t *smat) {
     Seg g;
     g.a = 0; g.b = 0; g.P = -(1 << 28); g.M = 0;
 #pragma unroll
     for (int k = 0; k < 4 * NW; k++) {
-        const int tb_ = (int)((tw[k >> 2] >> ((k & 3) * 8)) & 0xFFu);
-        const int qb = (int)((qw[k >> 2] >> ((k & 3) * 8)) & 0xFFu);
+        // (the matrix lies in LDS in rows of 32: the cell's entry is one shift-or away - q * alphabet + t with a run-time alphabet
+        // was a 64-bit multiply-add per cell; letters are below 32, what lies past a segment's end is masked below)
+        const uint32_t t5 = (tw[k >> 2] >> ((k & 3) * 8)) & 31u;
+        const uint32_t q5 = (qw[k >> 2] >> ((k & 3) * 8)) & 31u;
         const int cb = (int)(int8_t)((cw[k >> 2] >> ((k & 3) * 8)) & 0xFFu);
-        int x = (int)(int8_t)(smat[(qb * alph + tb_) & 1023] + cb);
+        int x = (int)(int8_t)(smat[(q5 << 5) | t5] + cb);
         x = k < nn ? x : 0;
         g.b += x;
         g.a = max(0, g.a + x);
@@ -846,7 +848,6 @@ __device__ __forceinline__ uint64_t score_chunk(const PfDedupArgs &A, const int8
     const int qlen = (int)(A.q_off[q + 1] - qp0);
     const uint8_t *qr = A.q_res + qp0;
     const uint8_t *qc = reinterpret_cast<const uint8_t *>(A.q_corr) + qp0;
-    const int alph = A.alphabet;
     const bool has = (uint32_t)lane < nin;
     const int8_t *prows = (A.q_isprof && A.q_isprof[q]) ? A.q_rows + (size_t)qp0 * PF_PROW : nullptr;   // wave-uniform
     int my_len = 0, my_qs = 0;
@@ -910,7 +911,7 @@ __device__ __forceinline__ uint64_t score_chunk(const PfDedupArgs &A, const int8
             g.a = 0; g.b = 0; g.P = -(1 << 28); g.M = 0;
             if (gl * CPL < len) {
                 if (prows) g = seg_cells_rows_n<NW>(tw[u], prows + (size_t)(qs_u[u] + gl * CPL) * PF_PROW, min(CPL, len - gl * CPL));
-                else g = seg_cells_n<NW>(tw[u], qw[u], cw[u], min(CPL, len - gl * CPL), smat, alph);
+                else g = seg_cells_n<NW>(tw[u], qw[u], cw[u], min(CPL, len - gl * CPL), smat);
             }
             g = seg_tree16(g, gl);
             int sc = 0, best = 0;
@@ -932,7 +933,7 @@ __device__ __forceinline__ uint64_t score_chunk(const PfDedupArgs &A, const int8
                     else {
                         load_cells<NW>(qr + qs_u[u] + o, q2);
                         load_cells<NW>(qc + qs_u[u] + o, c2);
-                        h = seg_cells_n<NW>(t2, q2, c2, min(CPL, len - o), smat, alph);
+                        h = seg_cells_n<NW>(t2, q2, c2, min(CPL, len - o), smat);
                     }
                 }
                 h = seg_tree16(h, gl);
@@ -1200,7 +1201,8 @@ __device__ __forceinline__ void replay_bucket_impl(const PfDedupArgs &A, ReplayL
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(REPLAY_WAVES_PER_EU))) void pf_replay_kernel(PfDedupArgs A) {
     __shared__ ReplayLds M;
     const int wave = (int)(threadIdx.x >> 6);
-    for (int k = (int)threadIdx.x; k < 32 * 32; k += 256) M.smat[k] = k < A.alphabet * A.alphabet ? A.mat[k] : (int8_t)0;
+    for (int k = (int)threadIdx.x; k < 32 * 32; k += 256)      // rows of 32 (seg_cells_n)
+        M.smat[k] = ((k >> 5) < A.alphabet && (k & 31) < A.alphabet) ? A.mat[(k >> 5) * A.alphabet + (k & 31)] : (int8_t)0;
     __syncthreads();
     // (the buckets of one query read the same tiles; a contiguous run of queries per XCD measured slower than the round-robin
     // deal - an eighth of the batch's queries is an uneven share of the work: profiles/r05_exp_pf_order.txt)
@@ -1214,8 +1216,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(REPLAY_WAVE
 __global__ __launch_bounds__(256) void pf_ungapped_kernel(PfDedupArgs A) {
     __shared__ int8_t smat[32 * 32];
     const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
-    for (int k = (int)threadIdx.x; k < A.alphabet * A.alphabet; k += 256) smat[k] = A.mat[k];
-    for (int k = A.alphabet * A.alphabet + (int)threadIdx.x; k < 32 * 32; k += 256) smat[k] = 0;
+    for (int k = (int)threadIdx.x; k < 32 * 32; k += 256)      // rows of 32 (seg_cells_n)
+        smat[k] = ((k >> 5) < A.alphabet && (k & 31) < A.alphabet) ? A.mat[(k >> 5) * A.alphabet + (k & 31)] : (int8_t)0;
     __syncthreads();
     const uint32_t B = A.bins;
     const uint64_t bucket = (uint64_t)A.q_first * B + (uint64_t)blockIdx.x * 4u + (uint32_t)wave;
