@@ -224,6 +224,52 @@ bool MMGpuPrefilterRun::loadPersisted(Prefiltering &p, size_t dbFrom, size_t dbS
     return true;
 }
 
+// `mmseqs makemmgpudb <targetDB> <layoutFile> [prefilter options]` (integration/MMGpuMakeDb.cpp; the shape of the reference's
+// makepaddedseqdb / createindex, src/util/makepaddedseqdb.cpp:14): what the first `prefilter` / `search` with MMGPU_DB_FILE would do on
+// its way - fill the lookup, hand it over, mask and index on the device, save - as a command of its own, so that no search pays for it.
+// The Prefiltering object was made with the target database on both sides and MMGPU_DB_FILE = the file to write.
+bool MMGpuPrefilterRun::buildAndSave(Prefiltering &p) {
+    const size_t dbSize = p.tdbr->getSize();
+    if (p.splits != 1 || !MMGpuRun::deviceIds().empty() || contextsForLargeSplit(dbSize) > 1) {
+        Debug(Debug::ERROR) << "MMGPU: makemmgpudb persists ONE unsplit database on one device (this one needs " << p.splits << " split(s))\n";
+        return false;
+    }
+    if (p.indexTable == NULL && !p.mmgpuPersisted) p.getIndexTable(0, 0, dbSize);      // (target-split mode builds it in runSplit)
+    if (p.mmgpuPersisted) {
+        Debug(Debug::INFO) << "MMGPU: the file already holds this database with these index parameters\n";
+        return true;
+    }
+    if (!usable(p) || !p.mmgpuDeviceIndex || !Parameters::isEqualDbtype(p.targetSeqType, Parameters::DBTYPE_AMINO_ACIDS)) {
+        Debug(Debug::ERROR) << "MMGPU: makemmgpudb covers amino-acid sequence databases whose index the device builds (see the message above)\n";
+        return false;
+    }
+    MMGpuStopwatch watch("makemmgpudb");
+    MMGpuPrefilter device(MMGpuRun::context(), p.kmerSubMat, p.ungappedSubMat, p.aaBiasCorrection, p.aaBiasCorrectionScale);
+    watch.lap("open device");
+    MMGpuPrefilter::Persisted layout;
+    if (!persistedLayout(p, p.tdbr, 0, dbSize, p.mmgpuDeviceMask, p.mmgpuIndexKmerThr, p.kmerSize, p.spacedKmer, (double)p.maskProb,
+                         p.mmgpuDeviceMask ? 0 : p.maskMode, p.maskLowerCaseMode, p.maskNrepeats, p.targetSearchMode, p._3merSubMatrix.isValid(), device,
+                         &layout)) {
+        Debug(Debug::ERROR) << "MMGPU: this database cannot be persisted (compressed, or its data files cannot be read)\n";
+        return false;
+    }
+    device.setMode(p.takeOnlyBestKmer, false, p.diagonalScoring == 0);
+    if (!device.buildIndex(p.sequenceLookup, p.kmerSize, p.mmgpuIndexKmerThr, p._3merSubMatrix, p._2merSubMatrix, p.spacedKmer, p.mmgpuDeviceMask,
+                           (double)p.maskProb, true, &layout)) {
+        Debug(Debug::ERROR) << "MMGPU: " << device.error() << "\n";
+        return false;
+    }
+    watch.lap("hand over targets, mask, build the index on the device, save");
+    mmgpu_db_info info;
+    if (mmgpu_db_probe(layout.path.c_str(), &info) != 0 || info.source_fingerprint != layout.sourceFp || info.index_fingerprint != layout.indexFp) {
+        Debug(Debug::ERROR) << "MMGPU: " << layout.path << " was not written (" << mmgpu_last_error() << ")\n";
+        return false;
+    }
+    Debug(Debug::INFO) << "MMGPU: " << info.n_targets << " targets, " << info.n_entries << " index entries (k = " << info.kmer_size << "), "
+                       << (info.file_bytes >> 20) << " MB in " << layout.path << "; searches find it with MMGPU_DB_FILE=" << layout.path << "\n";
+    return true;
+}
+
 bool MMGpuPrefilterRun::keepsEntriesInMemory(Prefiltering &p, const std::string &resultDB, size_t dbSize) {
     return p.splits == 1 && MMGpuFusedSearch::capturing(resultDB) && usable(p) &&
            !largeSplitNeedsHost(p, dbSize, p.mmgpuDeviceIndex, p.maxResListLen, p.querySeqType, p.targetSeqType, p.diagonalScoring);

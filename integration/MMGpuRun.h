@@ -116,6 +116,8 @@ public:
     // this target database with this run's index parameters - it is loaded (targets, masked view, index) and the split runs without
     // a SequenceLookup on the host.  false: nothing loaded, the lookup is filled and handed over as ever (and the layout saved)
     static bool loadPersisted(Prefiltering &p, size_t dbFrom, size_t dbSize);
+    // `mmseqs makemmgpudb` (MMGpuMakeDb.cpp): builds the device layout of p's target database and saves it to MMGPU_DB_FILE
+    static bool buildAndSave(Prefiltering &p);
     // fused search: this object will run unsplit through the device path and leave its targets resident for the alignment
     // module (MMGpuFusedSearch::keepResidentTargets) - the alignment module can then start before the prefilter has finished
     static bool runsUnsplitWithResidentTargets(Prefiltering &p, size_t *maxResListLen);

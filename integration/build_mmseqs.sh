@@ -7,7 +7,7 @@
 #                              oracle/gen_block_stub.py for the rest (profile queries then take the reference's own
 #                              Smith-Waterman fallback).  MMGPU_BLOCK_STUB_ONLY=1: stubs for everything,
 #                              as in rounds 1-2.
-#   oracle/_ref/mmseqs_mmgpu   the same tree + integration/mmseqs_mmgpu.patch (7 files, every change under #ifdef HAVE_MMGPU),
+#   oracle/_ref/mmseqs_mmgpu   the same tree + integration/mmseqs_mmgpu.patch (10 files, every change under #ifdef HAVE_MMGPU),
 #                              integration/*.cpp compiled in, linked against mmseqs2_amd/lib/libmmgpu.so.  ALWAYS with the
 #                              do-nothing block-aligner stubs (round 4): nothing of oracle/*.c is on the product-side binary's link
 #                              line - int16-range pairs get start / CIGAR from the device's block aligner (block_kernel.hip, blocks

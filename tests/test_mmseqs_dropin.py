@@ -179,6 +179,18 @@ def persisted_layout_pipeline(tmp, emulate):
     log = run(MMGPU, ["prefilter", "q", "t2", "pref_t2_g2", "-s", "4", "--threads", THREADS, "-v", "3"], w, emulate, extra_env=env)
     assert "no sequence lookup on the host" in log
     assert same(os.path.join(w, "pref_t2_s"), os.path.join(w, "pref_t2_g2")) == 500
+    # `mmseqs makemmgpudb` (round 6; the reference's makepaddedseqdb / createindex as one command): the file is written without a
+    # search, the FIRST search with it loads (no build, no save); other prefilter options = another index = refused as above
+    made = os.path.join(w, "made.mmgpu")
+    log = run(MMGPU, ["makemmgpudb", "q", made, "-s", "5.7", "--threads", THREADS, "-v", "3"], w, emulate)
+    assert "index entries (k = 6)" in log and os.path.getsize(made) > 100000, log[-2000:]
+    log = run(MMGPU, ["prefilter", "q", "q", "pref_made", "-s", "5.7", "--threads", THREADS, "-v", "3"], w, emulate, extra_env={"MMGPU_DB_FILE": made})
+    assert "no sequence lookup on the host" in log and "device layout saved to" not in log, log[-2000:]
+    assert same(os.path.join(w, "pref_s"), os.path.join(w, "pref_made")) == 500
+    log = run(MMGPU, ["makemmgpudb", "q", made, "-s", "5.7", "--threads", THREADS, "-v", "3"], w, emulate)
+    assert "already holds this database" in log, log[-2000:]
+    log = run(MMGPU, ["search", "q", "q", "res_made", "tmp_made", "-s", "4", "--threads", THREADS, "-v", "3"], w, emulate, extra_env={"MMGPU_DB_FILE": made})
+    assert "made from another database or with other index parameters" in log, log[-2000:]
 
 
 def test_persisted_device_layout_host_side_emulated(tmp_path):
