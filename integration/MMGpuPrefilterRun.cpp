@@ -67,7 +67,7 @@ bool MMGpuPrefilterRun::usableConfig(Prefiltering &p, bool indexExists) {
     else if (!p.takeOnlyBestKmer && !profileQuery && (!p._3merSubMatrix.isValid() || !p._2merSubMatrix.isValid())) why = "no similar-k-mer score matrices";
     else if (p.diagonalScoring == 0 && (profileQuery || nucl)) why = "--diag-score 0 with profile queries / nucleotide databases";
     else if (p.minDiagScoreThr < 1 && p.diagonalScoring != 0) why = "--min-ungapped-score 0";     // (with --diag-score 0 it equals 1)
-    else if (p.takeOnlyBestKmer ? (p.kmerSize < 4 || p.kmerSize > 15) : (p.kmerSize != 6 && p.kmerSize != 7)) why = "k-mer size not covered (6 / 7; 4..15 with exact k-mer matching)";
+    else if (p.takeOnlyBestKmer ? (p.kmerSize < 4 || p.kmerSize > 15) : (p.kmerSize < 5 || p.kmerSize > 7)) why = "k-mer size not covered (5 / 6 / 7; 4..15 with exact k-mer matching)";
     else if (p.spacedKmerPattern.empty() == false) why = "user-defined spaced k-mer pattern";
     else if (p.ungappedSubMatAux != NULL) why = "auxiliary ungapped matrix";
     // (the constructor creates the taxonomy hook after it built the index: before that the parameter says whether it will)

@@ -212,7 +212,7 @@ extern "C" int mmgpu_host_index_build(const uint8_t *residues, const uint64_t *s
                                       uint16_t *pos, uint64_t *n_entries) {
     if (!residues || !seq_off || !kmer_submat || !offsets || !n_entries)
         return fail(MMGPU_ERR_ARG, "mmgpu_host_index_build: NULL argument");
-    if ((k != 6 && k != 7) || alphabet < 3 || alphabet > 32) return fail(MMGPU_ERR_ARG, "mmgpu_host_index_build: bad k/alphabet");
+    if ((k < 5 || k > 7) || alphabet < 3 || alphabet > 32) return fail(MMGPU_ERR_ARG, "mmgpu_host_index_build: bad k/alphabet");
     if ((ids == nullptr) != (pos == nullptr)) return fail(MMGPU_ERR_ARG, "mmgpu_host_index_build: ids and pos go together");
     KmerWindows W;
     W.k = k;
@@ -277,9 +277,9 @@ static int pf_setup(mmgpu_ctx *c, const mmgpu_pf_index *ix, bool from_host, PfIn
     if (!c || !ix) return fail(MMGPU_ERR_ARG, "mmgpu_pf_load_index: NULL argument");
     if (!c->db.res) return fail(MMGPU_ERR_STATE, "mmgpu_pf_load_index: load the targets (SequenceLookup) first");
     const bool tables = ix->score3 != nullptr && ix->index3 != nullptr;    // without them: exact k-mer matching only
-    if (tables && ix->kmer_size != 6 && ix->kmer_size != 7) return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_pf_load_index: similar k-mers need k = 6 or 7");
+    if (tables && (ix->kmer_size < 5 || ix->kmer_size > 7)) return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_pf_load_index: similar k-mers need k = 5, 6 or 7");
     if (ix->kmer_size < 4 || ix->kmer_size > 15) return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_pf_load_index: k must be in [4, 15]");
-    if (tables && ix->kmer_size == 7 && (!ix->score2 || !ix->index2)) return fail(MMGPU_ERR_ARG, "mmgpu_pf_load_index: k = 7 needs the 2-mer ScoreMatrix");
+    if (tables && ix->kmer_size != 6 && (!ix->score2 || !ix->index2)) return fail(MMGPU_ERR_ARG, "mmgpu_pf_load_index: k = 5 and k = 7 need the 2-mer ScoreMatrix");
     if (ix->alphabet != c->db.alphabet) return fail(MMGPU_ERR_ARG, "mmgpu_pf_load_index: alphabet differs from the loaded targets");
     if (ix->alphabet < 2 || ix->alphabet > 32) return fail(MMGPU_ERR_ARG, "mmgpu_pf_load_index: alphabet must be in [2, 32]");
     if (!ix->ungapped_mat) return fail(MMGPU_ERR_ARG, "mmgpu_pf_load_index: NULL table");
@@ -347,7 +347,7 @@ static int pf_setup(mmgpu_ctx *c, const mmgpu_pf_index *ix, bool from_host, PfIn
         const int rc = build_cum(ix->score3, ix->row3, n3, P->d_cum3, &P->cum_w, &P->score_min);
         if (rc) { delete P; return fail(rc == 1 ? MMGPU_ERR_ARG : MMGPU_ERR_HIP, rc == 1 ? "mmgpu_pf_load_index: score3 rows are not sorted by descending score" : "mmgpu_pf_load_index: upload failed"); }
     }
-    if (tables && P->k == 7) {
+    if (tables && P->k != 6) {      // k = 5: (2, 3), k = 7: (2, 2, 3) - KmerGenerator::setDivideStrategy
         const size_t n2 = (size_t)P->kalph * P->kalph;
         if (ix->row2 < n2) { delete P; return fail(MMGPU_ERR_ARG, "mmgpu_pf_load_index: row2 smaller than kalph^2"); }
         P_TRY(P->d_s2.alloc(n2 * n2 * sizeof(int16_t)));

@@ -211,7 +211,8 @@ __device__ __forceinline__ void pf_lookup(const PfKmerArgs &A, uint32_t kmer, ui
 //   EMIT = false: nsim[gp] = number of similar k-mers of the window starting at gp
 //   EMIT = true : lists[list_base[gp] + r] = index list of the r-th similar k-mer, pos_entries[gp] = sum of lengths
 // k = 6: the k-mer splits into two 3-mers (KmerGenerator::setDivideStrategy, KmerGenerator.cpp:42-87); row A / row B
-// are the score-sorted 3-mer rows of the first / last three window residues.  Order of the output list:
+// are the score-sorted 3-mer rows of the first / last three window residues.  k = 5 (round 6): the split is (2, 3) - case
+// kmerSize % 3 == 2, reversed (:73-86) - i.e. row A is the 2-mer row of the first two residues and row B's index counts ka^2.  Order of the output list:
 // i over row A while sA[i] >= thr - sB[0], j over row B while sB[j] >= thr - sA[i]  (calculateArrayProduct :187-216).
 template <bool EMIT>
 __global__ __launch_bounds__(256) void pf_kmers_kernel(PfKmerArgs A) {
@@ -233,19 +234,22 @@ __global__ __launch_bounds__(256) void pf_kmers_kernel(PfKmerArgs A) {
     }
     const uint8_t *q = A.q_res + gp;
     const uint32_t ka = A.kalph;
-    const uint32_t rowA = q[A.pat[0]] + ka * (q[A.pat[1]] + ka * q[A.pat[2]]);
-    const uint32_t rowB = q[A.pat[3]] + ka * (q[A.pat[4]] + ka * q[A.pat[5]]);
+    const bool k5 = A.k == 5;      // (uniform over the launch)
+    const uint32_t rowA = k5 ? q[A.pat[0]] + ka * q[A.pat[1]] : q[A.pat[0]] + ka * (q[A.pat[1]] + ka * q[A.pat[2]]);
+    const uint32_t rowB = k5 ? q[A.pat[2]] + ka * (q[A.pat[3]] + ka * q[A.pat[4]]) : q[A.pat[3]] + ka * (q[A.pat[4]] + ka * q[A.pat[5]]);
     const uint32_t n3 = A.n3;
-    const int16_t *sA = A.s3 + (size_t)rowA * n3;
-    const uint32_t *iA = A.i3 + (size_t)rowA * n3;
+    const uint32_t nrowA = k5 ? ka * ka : n3;      // elements of row A = what row B's index is multiplied with (Indexer::powers)
+    const int16_t *sA = k5 ? A.s2 + (size_t)rowA * nrowA : A.s3 + (size_t)rowA * n3;
+    const uint32_t *iA = k5 ? A.i2 + (size_t)rowA * nrowA : A.i3 + (size_t)rowA * n3;
     const int16_t *sB = A.s3 + (size_t)rowB * n3;
     const uint32_t *iB = A.i3 + (size_t)rowB * n3;
     const int cutoff1 = (int)(short)(thr - (int)sB[0]);
     // number of entries of a score-sorted row with score >= c: one lookup in the per-row cumulative table
-    const uint16_t *cumA = A.cum3 + (size_t)rowA * A.cum_w;
+    const uint16_t *cumA = k5 ? A.cum2 + (size_t)rowA * A.cum2_w : A.cum3 + (size_t)rowA * A.cum_w;
     const uint16_t *cumB = A.cum3 + (size_t)rowB * A.cum_w;
     const int smin = A.score_min, smax = A.score_min + (int)A.cum_w - 2;
-    const uint32_t nA = cutoff1 <= smin ? n3 : (cutoff1 > smax ? 0u : (uint32_t)cumA[cutoff1 - smin]);
+    const int sminA = k5 ? A.score2_min : smin, smaxA = k5 ? A.score2_min + (int)A.cum2_w - 2 : smax;
+    const uint32_t nA = cutoff1 <= sminA ? nrowA : (cutoff1 > smaxA ? 0u : (uint32_t)cumA[cutoff1 - sminA]);
     uint32_t nlists = 0, running = 0;
     uint32_t lbase = 0;
     if (EMIT) lbase = A.list_base[gp];
@@ -270,7 +274,7 @@ __global__ __launch_bounds__(256) void pf_kmers_kernel(PfKmerArgs A) {
                 const uint32_t k_a = __shfl(my_idx, m);
                 uint32_t start = 0, len = 0;
                 if (act) {
-                    const uint32_t kmer = k_a + iB[x - ex_m] * n3;
+                    const uint32_t kmer = k_a + iB[x - ex_m] * nrowA;
                     // (sparse index: the bit table says whether the list is empty before a sector of the offset table is touched)
                     if (!A.nonempty || ((A.nonempty[kmer >> 5] >> (kmer & 31u)) & 1u)) pf_lookup(A, kmer, start, len);
                 }
@@ -2143,6 +2147,9 @@ hipError_t launch_pf_kmers(const PfKmerArgs &A, bool emit, hipStream_t s) {
         if (A.k == 7) {
             if (emit) hipLaunchKernelGGL((pf_kmers_prof_kernel<7, true>), grid, block, 0, s, A);
             else hipLaunchKernelGGL((pf_kmers_prof_kernel<7, false>), grid, block, 0, s, A);
+        } else if (A.k == 5) {
+            if (emit) hipLaunchKernelGGL((pf_kmers_prof_kernel<5, true>), grid, block, 0, s, A);
+            else hipLaunchKernelGGL((pf_kmers_prof_kernel<5, false>), grid, block, 0, s, A);
         } else {
             if (emit) hipLaunchKernelGGL((pf_kmers_prof_kernel<6, true>), grid, block, 0, s, A);
             else hipLaunchKernelGGL((pf_kmers_prof_kernel<6, false>), grid, block, 0, s, A);

@@ -36,6 +36,9 @@ __global__ __launch_bounds__(256) void pf_order_keys_kernel(PfKmerArgs A, unsign
         if (A.k == 7) {
             hi = q[A.pat[4]] + ka * (q[A.pat[5]] + ka * q[A.pat[6]]);
             lo = q[A.pat[2]] + ka * q[A.pat[3]];
+        } else if (A.k == 5) {
+            hi = q[A.pat[2]] + ka * (q[A.pat[3]] + ka * q[A.pat[4]]);
+            lo = q[A.pat[0]] + ka * q[A.pat[1]];
         } else {
             hi = q[A.pat[3]] + ka * (q[A.pat[4]] + ka * q[A.pat[5]]);
             lo = q[A.pat[0]] + ka * (q[A.pat[1]] + ka * q[A.pat[2]]);

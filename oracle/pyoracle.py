@@ -478,6 +478,8 @@ PF_HIT_DTYPE = np.dtype([("id", np.uint32), ("score", np.int32), ("diagonal", np
 
 def kmer_threshold(sens, k):
     """Prefiltering::getKmerThreshold (Prefiltering.cpp:1080-1095), sequence queries."""
+    if k == 5:
+        return int(np.float32(160.75) - np.float32(sens) * np.float32(12.75))
     if k == 6:
         return int(163.2 - 8.917 * sens)
     if k == 7:

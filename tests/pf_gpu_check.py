@@ -12,7 +12,7 @@ def load_case(gpu, g_or_mats, tres, toff, kmer_thr, k=6, spaced=True):
     km16 = g_or_mats["vtml80_kmer16"]
     um8 = g_or_mats["blosum62_ungapped"]
     s3, i3 = capi.host_score_matrix(km16, 3, lib=gpu.L)
-    s2, i2 = capi.host_score_matrix(km16, 2, lib=gpu.L) if k == 7 else (None, None)
+    s2, i2 = capi.host_score_matrix(km16, 2, lib=gpu.L) if k != 6 else (None, None)
     off, ids, pos = capi.host_index_build(tres, toff, km16, k, spaced, kmer_thr, lib=gpu.L)
     gpu.load_targets(tres, toff, 21)
     gpu.pf_load_index(k, 21, spaced, s3, i3, off, ids, pos, um8, score2=s2, index2=i2)

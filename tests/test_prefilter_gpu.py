@@ -199,6 +199,45 @@ def test_prefilter_k7(gpu):
     chk.load_case(gpu, g, g["tres"], g["toff"], thr)
 
 
+def test_prefilter_k5(gpu):
+    """k = 5 (round 6; `-k 5` took the CPU path before): the (2,3) similar-k-mer generator - row A from the 2-mer table -, a 20^5
+    offset table, every stage and the hit lists against the oracle (pinned against the real reference for k = 5 in
+    tests/test_prefilter_oracle.py); the index is also built on the device and compared with the host builder's."""
+    from oracle.pyoracle import PfOracle, kmer_threshold, PfGen
+    g = pc.golden()
+    thr5 = kmer_threshold(5.7, 5)
+    base = pc.pf_oracle()
+    orc = PfOracle.__new__(PfOracle)
+    orc.__dict__.update(base.__dict__)
+    orc.k = 5
+    orc.gen = PfGen(5, orc.kalph, orc.s3.ctypes.data, orc.i3.ctypes.data, orc.s2.ctypes.data, orc.i2.ctypes.data)
+    n = 600
+    tres, toff = g["tres"][:int(g["toff"][n])], g["toff"][:n + 1]
+    orc.build_index(tres, toff, thr5)
+    try:
+        tab = chk.load_case(gpu, g, tres, toff, thr5, k=5)
+        assert np.array_equal(tab["offsets"], orc.offsets)
+        qs = pc.golden_queries(g)[:12]
+        for qd in qs:
+            qd["identity_id"] = None
+        for mh, rb in ((300, 2), (20, 8)):
+            ok, rep = chk.check(gpu, orc, qs, mh, rb, stages=True, label="k5/%d/%d" % (mh, rb))
+            assert ok, "\n".join(rep)
+        hits_a, counts_a, _, _ = gpu.pf_batch(qs, thr5, max_hits=300, ref_bins=2)
+        km16, um8 = g["vtml80_kmer16"], g["blosum62_ungapped"]
+        s3, i3 = capi.host_score_matrix(km16, 3, lib=gpu.L)
+        s2, i2 = capi.host_score_matrix(km16, 2, lib=gpu.L)
+        gpu.pf_build_index(5, 21, True, s3, i3, km16, thr5, um8, score2=s2, index2=i2)
+        off_b, ids_b, pos_b = gpu.pf_debug_index(5, 21)
+        assert np.array_equal(off_b, tab["offsets"]) and np.array_equal(ids_b, tab["ids"]) and np.array_equal(pos_b, tab["pos"])
+        hits_b, counts_b, _, _ = gpu.pf_batch(qs, thr5, max_hits=300, ref_bins=2)
+        assert np.array_equal(counts_a, counts_b)
+        for qi in range(len(qs)):
+            assert np.array_equal(hits_a[qi][:int(counts_a[qi])], hits_b[qi][:int(counts_b[qi])])
+    finally:
+        chk.load_case(gpu, g, g["tres"], g["toff"], int(g["kmer_thr"]))
+
+
 def _long_query(rng, tl, ql, homolog_frac):
     parts = []
     while sum(len(p) for p in parts) < ql:

@@ -83,6 +83,33 @@ def test_oracle_fuzz_vs_reference():
         a, na = o7.kmer_list(kmer, thr)
         b, nb = ref7.kmer_list(kmer, thr)
         assert na == nb and np.array_equal(a, b)
+    # k = 5: (2,3) divide strategy (KmerGenerator.cpp:73-86) - the k-mer lists, then whole matchQuery runs on a k = 5 index
+    ref5 = pyoracle.RefPrefilter(5)
+    o5 = PfOracle.__new__(PfOracle)
+    o5.__dict__.update(o.__dict__)
+    o5.k = 5
+    o5.gen = PfGen(5, o.kalph, o.s3.ctypes.data, o.i3.ctypes.data, o.s2.ctypes.data, o.i2.ctypes.data)
+    for _ in range(100):
+        kmer = rng.integers(0, 20, 5).astype(np.uint8)
+        thr = int(rng.integers(50, 120))
+        a, na = o5.kmer_list(kmer, thr)
+        b, nb = ref5.kmer_list(kmer, thr)
+        assert na == nb and np.array_equal(a, b)
+    (qres5, qoff5), (tres5, toff5) = pc.synthetic_case(6, 500, seed=78, planted=0.5)
+    thr5 = pyoracle.kmer_threshold(5.7, 5)
+    ref5.build_index(tres5, toff5, thr5)
+    o5.build_index(tres5, toff5, thr5)
+    ro, ri, rp = ref5.index_dump()
+    assert np.array_equal(ro, o5.offsets) and np.array_equal(ri, o5.ids[:o5.n_entries])
+    swo5 = pyoracle.Oracle()
+    from mmseqs2_amd import workloads as wl5
+    bins5 = ref5.make_matcher(max_hits=300, force_bins=0)
+    for qi, q in enumerate(wl5.split(qres5, qoff5)):
+        cb = swo5.comp_bias(km16, pback, q)
+        r = ref5.match(q, None)
+        x = o5.match(q, cb, bins5, max_hits=300, identity_id=None)
+        assert np.array_equal(r["id"], x["id"]) and np.array_equal(r["score"], x["score"])
+        assert np.array_equal(r["diagonal"], x["diagonal"]) and r["db_matches"] == x["stats"]["db_matches"]
     (qres, qoff), (tres, toff) = pc.synthetic_case(10, 1200, seed=77, planted=0.5)
     thr = pyoracle.kmer_threshold(5.7, 6)
     ref.build_index(tres, toff, thr)
