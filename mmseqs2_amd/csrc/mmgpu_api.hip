@@ -1502,14 +1502,11 @@ static int block_backtrace(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const uint32_t *pa
             DevBuf j2, cnt, pool, ck;
             hipStream_t st = nullptr;
             std::vector<Block2Job> jobs;
-        } PB[3];
+        } PB[2];
         for (PassBufs &x : PB) { x.j2.bind(c->cache); x.cnt.bind(c->cache); x.pool.bind(c->cache); x.ck.bind(c->cache); }
         PB[0].st = s;
-        hipStream_t head_stream = nullptr, tail_stream = nullptr;
-        auto drop_head_stream = [&] {
-            if (head_stream) { (void)hipStreamDestroy(head_stream); head_stream = nullptr; }
-            if (tail_stream) { (void)hipStreamDestroy(tail_stream); tail_stream = nullptr; }
-        };
+        hipStream_t head_stream = nullptr;
+        auto drop_head_stream = [&] { if (head_stream) { (void)hipStreamDestroy(head_stream); head_stream = nullptr; } };
         std::vector<uint32_t> resume((size_t)n, 0u);      // per slot: the first minimum block size still to try (bit 16: only the slot was too small)
 #define B_TRY(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { drop_head_stream(); return fail(MMGPU_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__)); } } while (0)
         // one launch: `todo` (longest first) through form 1 (four pairs per wavefront, 256 rows) or 3 (skewed, one pair per wavefront,
@@ -1581,6 +1578,14 @@ static int block_backtrace(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const uint32_t *pa
                     resume[x.slot] = std::max(32u, std::min(rs & 0xFFFFu, (uint32_t)BLOCK_REF_MAX_SIZE)) | (rs & 0x10000u);
                     left.push_back(j);
                 }
+            if (trace_on && !B.jobs.empty()) {      // where in the (longest-first) launch the handed-on pairs stood
+                size_t by_16th[16] = {};
+                for (size_t k = 0; k < B.jobs.size(); k++)
+                    if (out[B.jobs[k].slot].status == MMGPU_BLOCK_TOO_LARGE) by_16th[k * 16 / B.jobs.size()]++;
+                fprintf(stderr, "[mmgpu block aligner] handed on, by sixteenth of the launch's %zu pairs:", B.jobs.size());
+                for (size_t z : by_16th) fprintf(stderr, " %zu", z);
+                fprintf(stderr, "\n");
+            }
             B.jobs.clear();
             return MMGPU_OK;
         };
@@ -1609,35 +1614,14 @@ static int block_backtrace(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const uint32_t *pa
         }
         // launch 1: everything else, slots for the usual 32 / 64-row blocks (half a byte per cell).  Resident wavefronts by LDS: 3.4 KB of
         // score table + 8 KB (four pairs' border arrays); the skewed form's 32 KB allow four
-        size_t n_skew_early = 0;
-        if (starts_only && rest.size() >= 32768) {
-            // Start positions only (no slots, no pools): the pairs launch 1 hands on - blocks beyond 256 rows - are dependent chains of up
-            // to ~20 ms each in the skewed form, and they could only start when the whole of launch 1 was over.  The launch is cut in
-            // two: the longest eighth of the pairs, whose hand-ons start their chains while the other seven eighths still run on a
-            // stream of their own.
-            if (hipStreamCreateWithFlags(&tail_stream, hipStreamNonBlocking) != hipSuccess) { drop_head_stream(); return fail(MMGPU_ERR_HIP, "mmgpu_sw_block_backtrace: hipStreamCreate"); }
-            PB[2].st = tail_stream;
-            B_TRY(hipStreamSynchronize(s));      // (the uploads above)
-            const std::vector<BlockJob> rest_a(rest.begin(), rest.begin() + rest.size() / 8), rest_b(rest.begin() + rest.size() / 8, rest.end());
-            rc2 = block4_launch(PB[0], rest_a, 1, block4_per_res, 512, block4_waves, skew);
-            if (rc2 == MMGPU_OK) rc2 = block4_launch(PB[2], rest_b, 1, block4_per_res, 512, block4_waves, skew);
-            if (rc2 == MMGPU_OK) rc2 = block4_collect(PB[0], skew);
-            if (rc2 != MMGPU_OK) { drop_head_stream(); return rc2; }
-            lap("four pairs per wavefront, the longest eighth + status download");
-            n_skew_early = skew.size();
-            longest_first(skew);
-            rc2 = block4_launch(PB[0], skew, 3, 1024, 2048, 4, skew_again);      // ... beside the rest of launch 1
-            if (rc2 == MMGPU_OK) rc2 = block4_collect(PB[2], handed);
-            if (rc2 == MMGPU_OK) rc2 = block4_collect(PB[0], skew_again);
-            if (rc2 != MMGPU_OK) { drop_head_stream(); return rc2; }
-            skew.clear();
-            lap("four pairs per wavefront, the rest, beside the skewed form of the first hand-ons + status downloads");
-        } else {
-            rc2 = block4_launch(PB[0], rest, 1, block4_per_res, 512, block4_waves, skew);
-            if (rc2 == MMGPU_OK) rc2 = block4_collect(PB[0], handed);
-            if (rc2 != MMGPU_OK) { drop_head_stream(); return rc2; }
-            lap("four pairs per wavefront + status download");
-        }
+        // (Measured and dropped in round 6: launch 1 cut in two - the longest eighth of the pairs first, so that its hand-ons could start
+        // their chains in the skewed form beside the other seven eighths.  500 of the 536 hand-ons of configs[2] do come from that
+        // eighth, but it takes 15 ms of its own - the longest pairs - and the 500 chains another 25: 44.7 ms per call against 43.5.
+        // The call is as long as ONE pair's chain through blocks of thousands of rows on one wavefront.)
+        rc2 = block4_launch(PB[0], rest, 1, block4_per_res, 512, block4_waves, skew);
+        if (rc2 == MMGPU_OK) rc2 = block4_collect(PB[0], handed);
+        if (rc2 != MMGPU_OK) { drop_head_stream(); return rc2; }
+        lap("four pairs per wavefront + status download");
         // ... once more for the pairs whose slot was too small (256-row blocks all the way: 128 bytes per residue)
         for (const BlockJob &j : handed) (resume[j.slot] & 0x10000u ? again : skew).push_back(j);
         if (!again.empty()) {
@@ -1654,7 +1638,7 @@ static int block_backtrace(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const uint32_t *pa
         if (rc2 == MMGPU_OK && n_head) rc2 = block4_collect(PB[1], skew_again);
         if (rc2 != MMGPU_OK) { drop_head_stream(); return rc2; }
         if (!skew.empty() || n_head) lap("skewed form (and the head) + status download");
-        const size_t n_skew = skew.size() + n_head + n_skew_early;
+        const size_t n_skew = skew.size() + n_head;
         if (!skew_again.empty()) {
             longest_first(skew_again);
             rc2 = block4_launch(PB[0], skew_again, 3, 4096, 8192, 4, slow_jobs);
