@@ -163,8 +163,15 @@ int bothModules(Parameters &par, const std::vector<std::string> &prefArgs, const
         std::vector<unsigned int>().swap(store.keys);
         pref->runAllSplits(prefDb, prefDbIndex);
         Debug(Debug::INFO) << "Time for processing: " << prefTimer.lap() << "\n";
-        // the object goes (its readers unmapped, tables freed: 0.06 s at 1 M targets) while the alignment module starts
-        std::thread([pref]() { delete pref; }).detach();
+        // The object is NOT taken apart while the alignment module starts (round 6): unmapping its readers and freeing its tables on a
+        // helper thread held the address-space lock for ~0.15 s in pieces, and the alignment module's first steps - its writer's 32
+        // buffers of 32 MB, its readers' mappings - waited on exactly that lock (0.17 s between "Calculation of alignments" and the
+        // hook's first lap at 1 M targets).  The search process ends through _exit (run(), below): the operating system takes the
+        // object back with everything else.  MMGPU_FUSED_UNWIND=1 (leak checkers) deletes it, in line.
+        {
+            const char *unwind = getenv("MMGPU_FUSED_UNWIND");
+            if (unwind != NULL && unwind[0] == '1') delete pref;
+        }
         return EXIT_SUCCESS;
     }
     Debug(Debug::INFO) << "MMGPU: the alignment module starts while the prefilter module runs (MMGPU_FUSED_OVERLAP=1)\n";
