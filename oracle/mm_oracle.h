@@ -141,6 +141,10 @@ int mmo_pf_ungapped_score(const uint8_t *q, const int8_t *corr, int qlen, const 
 int mmo_pf_match_query(const mmo_pf_params *P, const uint8_t *q, int qlen, const float *comp_bias,
                        uint32_t identity_id, mmo_pf_hit *hits, uint64_t hit_cap, uint64_t *n_hits, mmo_pf_stats *st,
                        mmo_pf_dump *dump);
+/* coverage of the long-sequence paths of the ungapped scoring since the last call (tests): elements of queries of 32768 residues or
+ * more, long targets in batches that were not full, long targets in full batches, of those the ones scored with another element's target */
+void mmo_pf_long_stats(uint64_t out[4]);
+
 
 /* compbias_oracle.c */
 void mmo_comp_bias(const int16_t *submat /*alphabet^2, row-major short matrix*/, const double *pback, int alphabet,

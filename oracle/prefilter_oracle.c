@@ -613,16 +613,135 @@ static size_t mmo_merge_diag_dup(mmo_cr *io, size_t n, uint32_t bins, uint32_t n
     return outn;
 }
 
-/* UngappedAlignment::computeScores (UngappedAlignment.cpp:315-346): only elements without a score are scored */
+/* UngappedAlignment::computeLongScore (UngappedAlignment.cpp:295-312): a sequence of 32768 residues or more does not fit the 16-bit
+ * diagonal - every 65536-shift of it is scored and the best taken.  The shifts are computed in unsigned int and read back as int
+ * (-devisions * 65536 + diagonal with an unsigned short diagonal), minDistToDiagonal = abs(realDiagonal). */
+static int mmo_long_score_p(const uint8_t *q, const int8_t *corr, int qlen, const int8_t *mat, int alphabet, const uint8_t *t,
+                            int tlen, uint16_t diagonal, const int8_t *qprof) {
+    int total = 0;
+    for (unsigned d = 1; d <= 1u + (unsigned)tlen / 32768u; d++) {
+        int real = (int)(0u - d * 65536u + (unsigned)diagonal);
+        int sc = mmo_diag_score_p(q, corr, qlen, mat, alphabet, t, tlen, real, qprof);
+        total = sc > total ? sc : total;
+    }
+    for (unsigned d = 0; d <= (unsigned)qlen / 65536u; d++) {
+        int real = (int)(d * 65536u + (unsigned)diagonal);
+        int sc = mmo_diag_score_p(q, corr, qlen, mat, alphabet, t, tlen, real, qprof);
+        total = sc > total ? sc : total;
+    }
+    return total;
+}
+
+/* UngappedAlignment::scoreSingleSequence (:453-461): what rescoreHits / getResult call for a saturated element */
+static int mmo_single_score_p(const uint8_t *q, const int8_t *corr, int qlen, const int8_t *mat, int alphabet, const uint8_t *t,
+                              int tlen, uint16_t diagonal, const int8_t *qprof) {
+    if (qlen >= 32768 || tlen >= 32768) return mmo_long_score_p(q, corr, qlen, mat, alphabet, t, tlen, diagonal, qprof);
+    return mmo_diag_score_p(q, corr, qlen, mat, alphabet, t, tlen, (int)(short)diagonal, qprof);
+}
+
+/* coverage counters for the tests (how often each path below ran since the last read): elements of a long query, long targets in
+ * batches that were not full, long targets in full batches, of those the ones that took ANOTHER element's target's score or 0 */
+static uint64_t mmo_long_stats[4];
+void mmo_pf_long_stats(uint64_t out[4]) {
+    for (int k = 0; k < 4; k++) {
+        out[k] = mmo_long_stats[k];
+        mmo_long_stats[k] = 0;
+    }
+}
+
+#define MMO_DIAGONALBINSIZE 8 /* UngappedAlignment.h:57, the AVX2 build (4 without AVX2: the batches below depend on it) */
+
+/* UngappedAlignment::scoreDiagonalAndUpdateHits (:187-293) for one batch of elements on one 16-bit diagonal.  For sequences below
+ * 32768 residues a batch is only a way to score eight diagonals at once; with longer ones the code paths differ:
+ *   - a query of 32768 residues or more: computeLongScore for every element (:199-208);
+ *   - a batch that is not full (the rest of a diagonal, :277-291): computeLongScore for the elements with a long target;
+ *   - a FULL batch (:210-276): the long targets enter the length sort with length 0, i.e. they come first, in their order (std::sort
+ *     of eight elements is an insertion sort in libstdc++, stable), and score 0; the loop that writes the scores back then asks, for
+ *     sorted position h holding a long target, whether the batch's element h IN ARRIVAL ORDER (hits[hitIdx], not
+ *     hits[seqs[hitIdx].id], :269) has a long target, and if so gives the element at sorted position h the long score of THAT
+ *     element's target.  The h-th long target of a full batch so receives computeLongScore of the batch's h-th element when that
+ *     one is long, and 0 otherwise. */
+static void mmo_score_batch(mmo_cr **hits, unsigned n, const mmo_pf_params *P, const uint8_t *q, const int8_t *corr, int qlen,
+                            const int8_t *qprof) {
+    const uint16_t diag = hits[0]->diagonal;
+    if (qlen >= 32768) {
+        for (unsigned h = 0; h < n; h++) {
+            const uint8_t *t = P->tdata + P->toff[hits[h]->id];
+            int tlen = (int)(P->toff[hits[h]->id + 1] - P->toff[hits[h]->id]);
+            int sc = mmo_long_score_p(q, corr, qlen, P->ungapped_mat, P->alphabet, t, tlen, diag, qprof);
+            hits[h]->count = (uint8_t)(sc > 255 ? 255 : sc);
+            mmo_long_stats[0]++;
+        }
+        return;
+    }
+    if (n == MMO_DIAGONALBINSIZE) {
+        unsigned n_long = 0, long_pos[MMO_DIAGONALBINSIZE];
+        for (unsigned h = 0; h < n; h++) {
+            const uint8_t *t = P->tdata + P->toff[hits[h]->id];
+            int tlen = (int)(P->toff[hits[h]->id + 1] - P->toff[hits[h]->id]);
+            if (tlen >= 32768) {
+                long_pos[n_long++] = h;
+                hits[h]->count = 0;
+            } else {
+                int sc = mmo_diag_score_p(q, corr, qlen, P->ungapped_mat, P->alphabet, t, tlen, (int)(short)diag, qprof);
+                hits[h]->count = (uint8_t)(sc > 255 ? 255 : sc);
+            }
+        }
+        for (unsigned h = 0; h < n_long; h++) { /* sorted position h = the h-th long target; hits[h] = arrival position h */
+            const uint8_t *t2 = P->tdata + P->toff[hits[h]->id];
+            int tlen2 = (int)(P->toff[hits[h]->id + 1] - P->toff[hits[h]->id]);
+            if (tlen2 >= 32768) {
+                int sc = mmo_long_score_p(q, corr, qlen, P->ungapped_mat, P->alphabet, t2, tlen2, diag, qprof);
+                hits[long_pos[h]]->count = (uint8_t)(sc > 255 ? 255 : sc);
+            }
+            mmo_long_stats[2]++;
+            if (long_pos[h] != h) mmo_long_stats[3]++;
+        }
+        return;
+    }
+    for (unsigned h = 0; h < n; h++) {
+        const uint8_t *t = P->tdata + P->toff[hits[h]->id];
+        int tlen = (int)(P->toff[hits[h]->id + 1] - P->toff[hits[h]->id]);
+        int sc = tlen >= 32768 ? mmo_long_score_p(q, corr, qlen, P->ungapped_mat, P->alphabet, t, tlen, diag, qprof)
+                               : mmo_diag_score_p(q, corr, qlen, P->ungapped_mat, P->alphabet, t, tlen, (int)(short)diag, qprof);
+        hits[h]->count = (uint8_t)(sc > 255 ? 255 : sc);
+        if (tlen >= 32768) mmo_long_stats[1]++;
+    }
+}
+
+/* UngappedAlignment::computeScores (UngappedAlignment.cpp:315-346): only elements without a score are scored; they are collected per
+ * 16-bit diagonal in array order and scored in batches of DIAGONALBINSIZE, the rest of every diagonal at the end.  Without a
+ * sequence of 32768 residues or more the batches do not show in the result and the elements are scored one by one. */
 static void mmo_score_unscored(mmo_cr *fd, size_t n, const mmo_pf_params *P, const uint8_t *q, const int8_t *corr, int qlen,
                                const int8_t *qprof) {
+    int any_long = qlen >= 32768;
+    for (size_t z = 0; z < n && !any_long; z++)
+        if (fd[z].count == 0 && P->toff[fd[z].id + 1] - P->toff[fd[z].id] >= 32768) any_long = 1;
+    if (!any_long) {
+        for (size_t z = 0; z < n; z++) {
+            if (fd[z].count != 0) continue;
+            const uint8_t *t = P->tdata + P->toff[fd[z].id];
+            int tlen = (int)(P->toff[fd[z].id + 1] - P->toff[fd[z].id]);
+            int sc = mmo_diag_score_p(q, corr, qlen, P->ungapped_mat, P->alphabet, t, tlen, (int)(short)fd[z].diagonal, qprof);
+            fd[z].count = (uint8_t)(sc > 255 ? 255 : sc);
+        }
+        return;
+    }
+    mmo_cr **matches = (mmo_cr **)malloc((size_t)65536 * MMO_DIAGONALBINSIZE * sizeof(mmo_cr *));
+    uint8_t *counter = (uint8_t *)calloc(65536, 1);
     for (size_t z = 0; z < n; z++) {
         if (fd[z].count != 0) continue;
-        const uint8_t *t = P->tdata + P->toff[fd[z].id];
-        int tlen = (int)(P->toff[fd[z].id + 1] - P->toff[fd[z].id]);
-        int sc = mmo_diag_score_p(q, corr, qlen, P->ungapped_mat, P->alphabet, t, tlen, (int)(short)fd[z].diagonal, qprof);
-        fd[z].count = (uint8_t)(sc > 255 ? 255 : sc);
+        const uint16_t d = fd[z].diagonal;
+        matches[(size_t)d * MMO_DIAGONALBINSIZE + counter[d]] = &fd[z];
+        if (++counter[d] == MMO_DIAGONALBINSIZE) {
+            mmo_score_batch(&matches[(size_t)d * MMO_DIAGONALBINSIZE], MMO_DIAGONALBINSIZE, P, q, corr, qlen, qprof);
+            counter[d] = 0;
+        }
     }
+    for (size_t d = 0; d < 65536; d++)
+        if (counter[d]) mmo_score_batch(&matches[d * MMO_DIAGONALBINSIZE], counter[d], P, q, corr, qlen, qprof);
+    free(matches);
+    free(counter);
 }
 
 /* radixSortByScoreSize (QueryMatcher.cpp:536-561) */
@@ -949,8 +1068,7 @@ static int match_query_impl(const mmo_pf_params *P, const uint8_t *q, int qlen, 
             for (size_t z = 0; z < above && rd[z].count >= max_diag_thr; z++) {
                 const uint8_t *t = P->tdata + P->toff[rd[z].id];
                 int tlen = (int)(P->toff[rd[z].id + 1] - P->toff[rd[z].id]);
-                unsigned ns = (unsigned)mmo_diag_score_p(q, corr2, qlen, P->ungapped_mat, alphabet, t, tlen,
-                                                         (int)(short)rd[z].diagonal, qprof);
+                unsigned ns = (unsigned)mmo_single_score_p(q, corr2, qlen, P->ungapped_mat, alphabet, t, tlen, rd[z].diagonal, qprof);
                 ns -= max_diag_thr;
                 float sc = (float)(ns < (unsigned)USHRT_MAX ? ns : (unsigned)USHRT_MAX);
                 rd[z].count = (unsigned char)((sc / fms) * (float)UCHAR_MAX + 0.5);
@@ -985,8 +1103,7 @@ static int match_query_impl(const mmo_pf_params *P, const uint8_t *q, int qlen, 
                 } else if ((int)sc >= 255) {
                     const uint8_t *t = P->tdata + P->toff[rd[z].id];
                     int tlen = (int)(P->toff[rd[z].id + 1] - P->toff[rd[z].id]);
-                    hits[cur].score = mmo_diag_score_p(q, corr2, qlen, P->ungapped_mat, alphabet, t, tlen,
-                                                       (int)(short)rd[z].diagonal, qprof);
+                    hits[cur].score = mmo_single_score_p(q, corr2, qlen, P->ungapped_mat, alphabet, t, tlen, rd[z].diagonal, qprof);
                 }
                 cur++;
             }

@@ -68,3 +68,45 @@ def shards(g, world):
         o = g["toff"][cut[r]:cut[r + 1] + 1].astype(np.int64)
         out.append((g["tres"][o[0]:o[-1]], (o - o[0]).astype(np.uint64)))
     return out, [cut[r + 1] - cut[r] for r in range(world)]
+
+
+def long_case(seed, long_query=False):
+    """Targets of 32768 residues or more among ordinary ones (UngappedAlignment::computeLongScore and the batches of
+    scoreDiagonalAndUpdateHits, UngappedAlignment.cpp:187-312).  Query 0 has a homolog inside a 40 000-residue target at 1 000 and
+    query 1 at 34 000 (a diagonal beyond the 16-bit range); query 2 has one at 66 000 of a 70 000-residue target (index positions wrap
+    at 65 536); query 3 meets MANY targets on diagonal 0 - substitution-only copies of itself, three of them at the start of long
+    targets and one at position 65 536 of a long target (diagonal -65 536 == 0 in 16 bits) - so that full batches of eight elements
+    of one diagonal hold long targets.  long_query: a 33 000-residue query that carries target 5 at 5 000 and a piece of a long
+    target.  Returns (queries, targets) as lists of uint8 arrays; the long targets are dealt among the others by the seed."""
+    rng = np.random.default_rng(seed)
+    (qres, qoff), (tres, toff) = wl.config2_align_only(6, 300, planted_frac=0.4, seed=seed)
+    qs, tl = wl.split(qres, qoff), wl.split(tres, toff)
+    bg = lambda n: rng.choice(20, size=n, p=wl.BACKGROUND).astype(np.uint8)
+    extra = []
+    big = bg(40000)
+    for k, at in ((0, 1000), (1, 34000)):
+        h = wl.mutate(rng, qs[k], 0.8)
+        big[at:at + len(h)] = h
+    extra.append(big)
+    big2 = bg(70000)
+    h = wl.mutate(rng, qs[2], 0.85)
+    big2[66000:66000 + len(h)] = h
+    extra.append(big2)
+    q3 = qs[3]
+    for _ in range(int(rng.integers(9, 20))):                       # ordinary targets on diagonal 0
+        extra.append(wl.mutate(rng, q3, 0.9, max_indels=0))
+    for n in (33000, 36000, 50000):                                 # long targets on diagonal 0
+        b = bg(n)
+        b[:len(q3)] = wl.mutate(rng, q3, 0.9, max_indels=0)
+        extra.append(b)
+    b = bg(67000)
+    b[65536:65536 + len(q3)] = wl.mutate(rng, q3, 0.9, max_indels=0)
+    extra.append(b)
+    if long_query:
+        lq = bg(33000)
+        lq[5000:5000 + len(tl[5])] = tl[5]
+        lq[20000:20600] = big[10000:10600]
+        qs.append(lq)
+    tl = tl + extra
+    perm = rng.permutation(len(tl))
+    return qs, [tl[i] for i in perm]

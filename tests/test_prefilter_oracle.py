@@ -127,3 +127,42 @@ def test_oracle_fuzz_vs_reference():
             x = o.match(q, cb, bins, max_hits=mh, identity_id=ident)
             assert np.array_equal(r["id"], x["id"]) and np.array_equal(r["score"], x["score"])
             assert np.array_equal(r["diagonal"], x["diagonal"]) and r["db_matches"] == x["stats"]["db_matches"]
+
+
+def test_oracle_long_sequences_vs_reference():
+    """Sequences of 32768 residues or more (UngappedAlignment.cpp:187-312): computeLongScore for the elements of a long query and for
+    long targets in batches that are not full, and the full batch of eight elements of one diagonal, where a long target receives the
+    long score of ANOTHER element's target or 0 (the restatement's mmo_score_batch says how).  Index, hit lists and statistics of
+    the restatement against the reference's own classes; the counters say that every one of those paths ran."""
+    import ctypes
+    from oracle import pyoracle
+    from mmseqs2_amd import workloads as wl
+    if not (pyoracle.ref_available() and pyoracle.ref_matrix_available()):
+        pytest.skip("real reference (oracle/_ref + /root/reference/data) not available here")
+    ref = pyoracle.RefPrefilter(6)
+    km8, um8, km16, pback = ref.matrices()
+    o = pc.pf_oracle()
+    swo = pyoracle.Oracle()
+    thr = pyoracle.kmer_threshold(5.7, 6)
+    stats = (ctypes.c_uint64 * 4)()
+    o.L.mmo_pf_long_stats(stats)
+    seen = np.zeros(4, np.int64)
+    for seed in (1, 2):
+        qs, tl = pc.long_case(seed, long_query=True)
+        tres, toff = wl.seqs_from_list(tl)
+        ref.build_index(tres, toff, thr)
+        o.build_index(tres, toff, thr)
+        ro, ri, rp = ref.index_dump()
+        assert np.array_equal(ro, o.offsets) and np.array_equal(ri, o.ids[:o.n_entries]) and np.array_equal(rp, o.pos[:o.n_entries])
+        for max_hits in (300, 12):
+            bins = ref.make_matcher(max_hits=max_hits, force_bins=0, max_seq_len=70000)
+            for qi, q in enumerate(qs):
+                cb = swo.comp_bias(km16, pback, q)
+                r = ref.match(q, None)
+                x = o.match(q, cb, bins, max_hits=max_hits, identity_id=None)
+                assert x["stats"]["rc"] == 0
+                assert np.array_equal(r["id"], x["id"]) and np.array_equal(r["score"], x["score"]), (seed, max_hits, qi)
+                assert np.array_equal(r["diagonal"], x["diagonal"]) and r["db_matches"] == x["stats"]["db_matches"]
+                o.L.mmo_pf_long_stats(stats)
+                seen += np.array(list(stats), np.int64)
+    assert (seen > 0).all(), seen
