@@ -464,10 +464,13 @@ typedef struct {
                                max(1M, dbSize) / 2 or more, where the reference may take its unsorted branch (unstable std::sort, no
                                rescoring, QueryMatcher.cpp:188,204-214).  Not decided on the device: the host runs
                                QueryMatcher::matchQuery for this query */
-#define MMGPU_PF_LONG_SEQ 2 /* the query, or the target of one of its double-diagonal candidates, has 32768 residues or more:
-                               the reference scores those with UngappedAlignment::computeLongScore (every 65536-shift of the
-                               16-bit diagonal, UngappedAlignment.cpp:295-312, and a batching quirk at :265-273) - not on the
-                               device; the host must run QueryMatcher::matchQuery for this query */
+#define MMGPU_PF_LONG_SEQ 2 /* sequences of 32768 residues or more are scored on the device since round 6 (UngappedAlignment::
+                               computeLongScore: every 65536-shift of the 16-bit diagonal, UngappedAlignment.cpp:295-312, and the
+                               batches of eight elements of scoreDiagonalAndUpdateHits, :187-293) - this status is left for: such a
+                               query in a sharded run's shard, a nucleotide search or --diag-score 0 (declined on the host); a query
+                               with candidates on such targets that is on the databaseHits overflow path, or has more than 1024
+                               candidates on the diagonals of those targets.  The host must run QueryMatcher::matchQuery for it
+                               (a sharded run re-runs it against the unsplit database when it holds one) */
 
 #define MMGPU_PF_SHARD_INEXACT 4 /* sharded runs (mmgpu_multi_pf_fetch): an element of the query's merged list took the reference's
                                overflow path on a shard, or was not scored on the device - the tie order at the cut is not the

@@ -157,6 +157,12 @@ struct PfCand {        // double-diagonal candidate / surviving element
     uint16_t pad;
 };
 
+// PfCand::score of an element whose count is NOT min(255, exact score): a target of 32768 residues or more in a full batch of
+// UngappedAlignment::scoreDiagonalAndUpdateHits takes its count from another element's target (pf_long_kernel), while the rescoring of
+// a saturated element (scoreSingleSequence) reads its own.  Bit 31 set: count in bits 30..23, exact score in bits 22..0.
+__host__ __device__ inline uint32_t pf_el_count(uint32_t s) { return (s & 0x80000000u) ? ((s >> 23) & 0xFFu) : (s < 255u ? s : 255u); }
+__host__ __device__ inline uint32_t pf_el_exact(uint32_t s) { return (s & 0x80000000u) ? (s & 0x7FFFFFu) : s; }
+
 constexpr int PF_PROW = 32;            // bytes per position of the profile-query score rows (21 letters used)
 constexpr int PF_PROF_LETTERS = 20;    // Sequence::PROFILE_AA_SIZE
 
@@ -247,7 +253,12 @@ struct PfDedupArgs {
     const uint32_t *t_off4, *t_len;
     uint32_t min_diag_score;
     uint32_t *q_flags;                // [nq] bit 0: a candidate's target has >= 32768 residues (UngappedAlignment::computeLongScore,
-                                      // UngappedAlignment.cpp:295-312, is not on the device: the host runs the query)
+                                      // UngappedAlignment.cpp:295-312): pf_long_kernel scores those and clears the bit; where it
+                                      // does not run or gives up (sharded / overflow-path / nucleotide queries) the host runs the query
+    uint32_t ref_bins;                // BINCOUNT of the reference's CacheFriendlyOperations: the order of its result array (pf_long_kernel)
+    // work list of the buckets with more than 64 candidates (bucket index relative to the launch's first bucket), appended by the
+    // replay kernel, walked by pf_ungapped_kernel / pf_keepmax_kernel; null: those kernels run one wavefront per bucket of the launch
+    uint32_t *big_list, *big_count;
     // overflow emulation (null when the batch has no query on the overflow path)
     const uint32_t *q_nseg;           // [nq] databaseHits flushes of the query (0 = ordinary query)
     const uint32_t *seg_start;        // [nq][PF_MAX_SEG + 2] arrival index at which segment k starts
@@ -402,6 +413,7 @@ hipError_t launch_pf_scan(const uint32_t *in, const uint32_t *q_off, uint32_t nq
 hipError_t launch_pf_split(const PfSplitArgs &A, uint32_t n_tiles, hipStream_t s);
 hipError_t launch_pf_dedup(const PfDedupArgs &A, hipEvent_t after_replay, hipEvent_t after_ungapped, hipStream_t s);
 hipError_t launch_pf_count(const PfDedupArgs &A, hipEvent_t after_a, hipEvent_t after_b, hipStream_t s);   // --diag-score 0
+hipError_t launch_pf_long(const PfDedupArgs &A, bool long_queries, hipStream_t s);   // after launch_pf_dedup: sequences of >= 32768 residues
 hipError_t launch_pf_select(const PfSelectArgs &A, uint32_t nq, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------------------------

@@ -532,6 +532,7 @@ struct mmgpu_pf_batch_t {
     DevBuf d_qkind, d_qisprof, d_pscore, d_pletter, d_qrows;   // profile queries only
     DevBuf d_qncand;                                           // nucleotide searches only
     DevBuf d_sat, d_qnsat;                                     // nucleotide searches: saturated elements per query (PF_SAT_CAP each) + their number
+    DevBuf d_work_list, d_work_count;                          // buckets with more than 64 candidates, per stage chunk (PfDedupArgs::big_list)
     DevBuf d_big_keys, d_big_diags;                            // max_hits > PF_MAX_HITS only: the select kernel's sort scratch
     uint32_t big_stride = 0;
     bool any_profile = false;
@@ -542,7 +543,8 @@ struct mmgpu_pf_batch_t {
     DevBuf d_qtile_base, d_qntiles, d_bucket_count, d_bucket_off;
     DevBuf d_ovf_queries, d_qnseg, d_seg_start, d_qfinal, d_ovf_base, d_ovf_a, d_ovf_b, d_ovf_ocount, d_ovf_totals;
     DevBuf d_cand_small, d_cand_base, d_cand_count, d_cells, d_surv_count, d_hits, d_hit_count, d_diag_thr, d_qflags;
-    std::vector<uint8_t> long_query;   // queries of 32768 residues or more: not processed on the device (MMGPU_PF_LONG_SEQ)
+    std::vector<uint8_t> long_query;   // queries of 32768 residues or more that are not processed on the device (MMGPU_PF_LONG_SEQ)
+    bool long_queries_on_device = false;   // ... and whether the batch holds one that is (pf_longq_kernel)
     bool exchange = false;     // prepared while a shard was set (mmgpu_pf_set_shard): d_hits holds mmgpu_pf_xhit records
     // host mirrors of the last run
     std::vector<uint64_t> q_lists, q_entries;
@@ -651,7 +653,17 @@ extern "C" int mmgpu_pf_prepare(mmgpu_ctx *c, const mmgpu_pf_params *par, const 
     }
     b->n_pos = (uint32_t)tot;
     b->long_query.assign(nq, 0);
-    for (uint32_t i = 0; i < nq; i++) b->long_query[i] = qs[i].qlen >= 32768 ? 1 : 0;
+    // queries of 32768 residues or more (UngappedAlignment::computeLongScore for every element): on the device for amino-acid and
+    // profile searches with diagonal scoring on an unsplit database (pf_longq_kernel); a shard, a nucleotide search and --diag-score 0
+    // decline them here, on the host (MMGPU_PF_LONG_SEQ)
+    bool any_long_on_device = false;
+    for (uint32_t i = 0; i < nq; i++) {
+        const bool is_long = qs[i].qlen >= 32768;
+        const bool declined = exchange || par->nucleotide || par->kmer_score;
+        b->long_query[i] = (is_long && declined) ? 1 : 0;
+        any_long_on_device = any_long_on_device || (is_long && !declined);
+    }
+    b->long_queries_on_device = any_long_on_device;
     std::vector<uint8_t> qres(tot + 64, 0);    // + slack: the ungapped kernel reads whole dwords
     std::vector<int16_t> qthr(tot, -1);
     std::vector<int8_t> qcorr(tot + 64, 0);
@@ -1063,6 +1075,18 @@ extern "C" int mmgpu_pf_run(mmgpu_ctx *c, mmgpu_pf_batch_t *b) {
     D.seg_start = ovf_q.empty() ? nullptr : b->d_seg_start.as<uint32_t>();
     D.cell_counter = b->d_cells.as<uint64_t>();
     D.q_flags = b->d_qflags.as<uint32_t>();
+    D.ref_bins = b->ref_bins;
+    D.big_list = D.big_count = nullptr;
+    {   // the work list of the larger buckets: one list (re-used from chunk to chunk, same stream) and one counter per chunk
+        uint64_t chunk_buckets = 0;
+        for (uint32_t ch = 0; ch < n_chunks; ch++) chunk_buckets = std::max<uint64_t>(chunk_buckets, (uint64_t)(chunk_first[ch + 1] - chunk_first[ch]) * B);
+        if (!b->par.kmer_score && chunk_buckets > 0 && chunk_buckets < 0xFFFFFFFFull) {
+            HIP_TRY(b->d_work_list.reserve(chunk_buckets * 4));
+            HIP_TRY(b->d_work_count.reserve((size_t)n_chunks * 4));
+            HIP_TRY(hipMemsetAsync(b->d_work_count.p, 0, (size_t)n_chunks * 4, s));
+            D.big_list = b->d_work_list.as<uint32_t>();
+        }
+    }
     // the flushes of the overflow path: per-query bases relative to the first overflow query of the same chunk
     std::vector<uint32_t> ovf_chunk_lo(n_chunks + 1, 0);
     PfOvfArgs O;
@@ -1142,8 +1166,14 @@ extern "C" int mmgpu_pf_run(mmgpu_ctx *c, mmgpu_pf_batch_t *b) {
         D.q_first = q0;
         D.n_queries = cn;
         D.cand_origin = (uint32_t)qebase[q0];
+        if (D.big_list) D.big_count = b->d_work_count.as<uint32_t>() + ch;
         if (b->par.kmer_score) HIP_TRY(launch_pf_count(D, cev[0], cev[1], s));
-        else HIP_TRY(launch_pf_dedup(D, cev[0], cev[1], s));
+        else {
+            HIP_TRY(launch_pf_dedup(D, cev[0], cev[1], s));
+            // candidates on targets of 32768 residues or more: computeLongScore and the batches of scoreDiagonalAndUpdateHits (a shard
+            // leaves such queries flagged: the unsplit re-run scores them)
+            if ((c->db.max_len >= 32768u || b->long_queries_on_device) && !b->exchange && !b->par.nucleotide) HIP_TRY(launch_pf_long(D, b->long_queries_on_device, s));
+        }
         const uint32_t z0 = ovf_chunk_lo[ch], z1 = ovf_chunk_lo[ch + 1];
         if (z1 > z0) {
             // one launch per flush (the total kept after flush k decides what flush k+1 does)
@@ -1435,8 +1465,10 @@ int pf_redo_flagged(mmgpu_ctx *c, mmgpu_pf_batch_t *b, std::vector<uint32_t> &fl
     std::vector<uint32_t> flags(b->nq);
     HIP_TRY(hipMemcpyAsync(flags.data(), b->x_flags.p, (size_t)b->nq * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    // (a query of 32768 residues or more is declined by a shard on the host and never reaches the merged flags: the unsplit
+    // context scores it, pf_longq_kernel)
     for (uint32_t q = 0; q < b->nq; q++)
-        if (flags[q] & 1u) flagged.push_back(q);
+        if ((flags[q] & 1u) || (q < b->long_query.size() && b->long_query[q])) flagged.push_back(q);
     return MMGPU_OK;
 }
 

@@ -1181,7 +1181,11 @@ __device__ __forceinline__ void replay_bucket_impl(const PfDedupArgs &A, ReplayL
             one_round(xg + 192u, e3, tile3, at3);
         }
     }
-    if (lane == 0) A.cand_count[bucket] = ncand;
+    if (lane == 0) {
+        A.cand_count[bucket] = ncand;
+        // the work list of the scoring / keepMax kernels of larger buckets (a few thousand of a batch's millions)
+        if (!SEGS && ncand > 64 && A.big_list) A.big_list[atomicAdd(A.big_count, 1u)] = (uint32_t)(bucket - (uint64_t)A.q_first * B);
+    }
     // a8 + keepMaxElement for the common case of at most 64 candidates, straight from LDS (no second kernel's
     // count -> record -> metadata round trips); larger buckets are left to pf_ungapped_kernel / pf_keepmax_kernel
     if (!SEGS && ncand > 0 && ncand <= 64) {
@@ -1217,15 +1221,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(REPLAY_WAVE
 }
 
 // Buckets with more than 64 candidates (the replay kernel scores the others itself): one wavefront per (query, bin).
-__global__ __launch_bounds__(256) void pf_ungapped_kernel(PfDedupArgs A) {
-    __shared__ int8_t smat[32 * 32];
-    const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
-    for (int k = (int)threadIdx.x; k < 32 * 32; k += 256)      // rows of 32 (seg_cells_n)
-        smat[k] = ((k >> 5) < A.alphabet && (k & 31) < A.alphabet) ? A.mat[(k >> 5) * A.alphabet + (k & 31)] : (int8_t)0;
-    __syncthreads();
+__device__ __forceinline__ void ungapped_bucket(const PfDedupArgs &A, const int8_t *smat, uint64_t bucket) {
+    const int lane = lane_id();
     const uint32_t B = A.bins;
-    const uint64_t bucket = (uint64_t)A.q_first * B + (uint64_t)blockIdx.x * 4u + (uint32_t)wave;
-    if (bucket >= (uint64_t)(A.q_first + A.n_queries) * B) return;
     const uint32_t ncand = A.cand_count[bucket];
     const uint32_t q = (uint32_t)(bucket / B);
     if (ncand <= 64 || (A.q_nseg && A.q_nseg[q])) return;   // small bins are done; overflow queries have their own path
@@ -1243,6 +1241,25 @@ __global__ __launch_bounds__(256) void pf_ungapped_kernel(PfDedupArgs A) {
         for (int dd = 1; dd < 64; dd <<= 1) cells += __shfl_xor((unsigned long long)cells, dd);
         if (lane == 0 && cells) atomicAdd((unsigned long long *)&A.cell_counter[q], (unsigned long long)cells);
     }
+}
+
+// Round 6: with a work list (A.big_list, written by the replay kernel) the grid is a fixed number of workgroups whose wavefronts
+// walk the list - a grid over every bucket of the chunk is hundreds of thousands of workgroups that find nothing to do.
+__global__ __launch_bounds__(256) void pf_ungapped_kernel(PfDedupArgs A) {
+    __shared__ int8_t smat[32 * 32];
+    const int wave = (int)(threadIdx.x >> 6);
+    for (int k = (int)threadIdx.x; k < 32 * 32; k += 256)      // rows of 32 (seg_cells_n)
+        smat[k] = ((k >> 5) < A.alphabet && (k & 31) < A.alphabet) ? A.mat[(k >> 5) * A.alphabet + (k & 31)] : (int8_t)0;
+    __syncthreads();
+    const uint32_t B = A.bins;
+    if (A.big_list) {
+        const uint32_t n = *A.big_count;
+        for (uint32_t i = blockIdx.x * 4u + (uint32_t)wave; i < n; i += gridDim.x * 4u) ungapped_bucket(A, smat, (uint64_t)A.q_first * B + A.big_list[i]);
+        return;
+    }
+    const uint64_t bucket = (uint64_t)A.q_first * B + (uint64_t)blockIdx.x * 4u + (uint32_t)wave;
+    if (bucket >= (uint64_t)(A.q_first + A.n_queries) * B) return;
+    ungapped_bucket(A, smat, bucket);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1370,17 +1387,12 @@ __global__ __launch_bounds__(256) void pf_count_kernel(PfDedupArgs A) {
 // keepMaxElement (CacheFriendlyOperations.cpp:354-384): per target keep the first candidate (bin order = arrival
 // order) whose count = min(255, score) is the target's maximum; survivors with count >= min_diag_score are appended
 // to the query's list.  One wavefront per (query, bin); LDS table of (count << 24 | ~candidate index) per target.
-__global__ __launch_bounds__(256) void pf_keepmax_kernel(PfDedupArgs A) {
-    __shared__ uint32_t s_tab[4][PF_IDS_PER_BIN];
-    const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
+__device__ __forceinline__ void keepmax_bucket(const PfDedupArgs &A, uint32_t *S, uint64_t bucket) {
+    const int lane = lane_id();
     const uint32_t B = A.bins;
-    const uint64_t bucket = (uint64_t)A.q_first * B + (uint64_t)blockIdx.x * 4u + (uint32_t)wave;
-    if (bucket >= (uint64_t)(A.q_first + A.n_queries) * B) return;
     const uint32_t ncand = A.cand_count[bucket];
     const uint32_t q = (uint32_t)(bucket / B);
-    if (A.nucl) return;                                      // pf_keepmax_nucl_kernel
     if (ncand <= 64 || (A.q_nseg && A.q_nseg[q])) return;   // scored and reduced already / overflow path
-    uint32_t *S = s_tab[wave];
     int bshift = 0;
     while ((1u << bshift) < B) bshift++;
     for (int k = lane; k < PF_IDS_PER_BIN; k += 64) S[k] = 0;
@@ -1413,6 +1425,289 @@ __global__ __launch_bounds__(256) void pf_keepmax_kernel(PfDedupArgs A) {
             if (win) surv[base + (uint32_t)__popcll(wb & lanes_below(lane))] = c;
         }
     }
+}
+
+__global__ __launch_bounds__(256) void pf_keepmax_kernel(PfDedupArgs A) {
+    __shared__ uint32_t s_tab[4][PF_IDS_PER_BIN];
+    const int wave = (int)(threadIdx.x >> 6);
+    const uint32_t B = A.bins;
+    if (A.nucl) return;                                      // pf_keepmax_nucl_kernel
+    if (A.big_list) {                                        // the replay kernel's work list (see pf_ungapped_kernel)
+        const uint32_t n = *A.big_count;
+        for (uint32_t i = blockIdx.x * 4u + (uint32_t)wave; i < n; i += gridDim.x * 4u) keepmax_bucket(A, s_tab[wave], (uint64_t)A.q_first * B + A.big_list[i]);
+        return;
+    }
+    const uint64_t bucket = (uint64_t)A.q_first * B + (uint64_t)blockIdx.x * 4u + (uint32_t)wave;
+    if (bucket >= (uint64_t)(A.q_first + A.n_queries) * B) return;
+    keepmax_bucket(A, s_tab[wave], bucket);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Targets of 32768 residues or more (UngappedAlignment.cpp:187-312).  The 16-bit diagonal of a candidate does not say where in
+// such a target the match lies: the reference scores every 65536-shift of it (computeLongScore :295-312) - and which TARGET it
+// scores depends on the batches of eight elements of one 16-bit diagonal that computeScores (:315-346) forms over the query's
+// result array: in a batch that is not full a long target gets its own long score; in a FULL batch the long targets enter the
+// length sort with length 0 (first, in their order) and the write-back loop gives the h-th of them the long score of the batch's
+// h-th element IN ARRAY ORDER when that one's target is long, and 0 otherwise (:262-275 reads hits[hitIdx], not hits[seqs[hitIdx].id];
+// oracle/prefilter_oracle.c mmo_score_batch restates it and is pinned against the reference).  The replay / scoring kernels give such
+// candidates a meaningless score and set bit 0 of the query's flags; this kernel, one workgroup per flagged query, after them:
+//   1. marks the 16-bit diagonals of the query's long-target candidates in an LDS bit set;
+//   2. pools ALL candidates of the query on those diagonals (key: diagonal, the reference's cache bin, arrival index = the order of
+//      the reference's result array), sorts the pool: a diagonal's run is its elements in array order, batches are its eighths;
+//   3. decides for every long-target candidate whose target scores it, scores (one wavefront per candidate, every shift), writes
+//      the count and - for the rescoring of saturated elements, which reads the element's own target (scoreSingleSequence :453-461) -
+//      the own exact score into the candidate's slot (pf_el_count / pf_el_exact);
+//   4. redoes keepMaxElement for every bucket of the query and clears the flag.
+// Queries it leaves flagged (handed to the host as before): overflow-path and nucleotide queries, more than PF_LONG_POOL pooled candidates.
+constexpr int PF_LONG_POOL = 1024;
+constexpr uint32_t PF_LONG_NONE = 0xFFFFu;
+
+// ungapped score of one diagonal (computeSingelSequenceScores :423-437) by a whole wavefront: passes of 64 x 16 cells
+__device__ int wave_diag_score(const int8_t *smat, const uint8_t *qr, const uint8_t *qc, const int8_t *prows, int qlen, const uint8_t *t,
+                               int tlen, int diag) {
+    const int lane = lane_id();
+    const int mind = diag < 0 ? -diag : diag;
+    int len, qs, ts;
+    if (diag >= 0 && mind < qlen) {
+        len = min(tlen, qlen - mind);
+        qs = mind;
+        ts = 0;
+    } else if (diag < 0 && mind < tlen) {
+        len = min(tlen - mind, qlen);
+        qs = 0;
+        ts = mind;
+    } else {
+        return 0;
+    }
+    int sc = 0, best = 0;
+    for (int p0 = 0; p0 < len; p0 += 1024) {
+        const int o = p0 + lane * 16;
+        Seg h;
+        h.a = 0; h.b = 0; h.P = -(1 << 28); h.M = 0;
+        if (o < len) {
+            uint32_t tw[4], qw[4], cw[4];
+            load_cells<4>(t + ts + o, tw);
+            if (prows) h = seg_cells_rows_n<4>(tw, prows + (size_t)(qs + o) * PF_PROW, min(16, len - o));
+            else {
+                load_cells<4>(qr + qs + o, qw);
+                load_cells<4>(qc + qs + o, cw);
+                h = seg_cells_n<4>(tw, qw, cw, min(16, len - o), smat);
+            }
+        }
+        h = seg_tree16(h, lane & 15);      // lanes 0, 16, 32, 48 hold their group's summary
+        Seg g[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            g[k].a = __shfl(h.a, 16 * k);
+            g[k].b = __shfl(h.b, 16 * k);
+            g[k].P = __shfl(h.P, 16 * k);
+            g[k].M = __shfl(h.M, 16 * k);
+        }
+        const Seg all = seg_combine(seg_combine(g[0], g[1]), seg_combine(g[2], g[3]));
+        best = max(best, max(all.M, sc + all.P));
+        sc = max(all.a, sc + all.b);
+    }
+    return best;
+}
+
+// computeLongScore (:295-312): the shifts are computed in unsigned int and read back as int
+__device__ int wave_long_score(const int8_t *smat, const uint8_t *qr, const uint8_t *qc, const int8_t *prows, int qlen, const uint8_t *t,
+                               int tlen, uint32_t diag16) {
+    int total = 0;
+    for (uint32_t d = 1; d <= 1u + (uint32_t)tlen / 32768u; d++)
+        total = max(total, wave_diag_score(smat, qr, qc, prows, qlen, t, tlen, (int)(0u - d * 65536u + diag16)));
+    for (uint32_t d = 0; d <= (uint32_t)qlen / 65536u; d++)
+        total = max(total, wave_diag_score(smat, qr, qc, prows, qlen, t, tlen, (int)(d * 65536u + diag16)));
+    return total;
+}
+
+// Queries of 32768 residues or more (:199-208): computeLongScore for every element, whatever its batch.  One wavefront per (query, bin)
+// like the scoring kernels; the query's flag is raised so that pf_long_kernel redoes its keepMaxElement (overflow-path queries stay
+// flagged and go to the host).
+__global__ __launch_bounds__(256) void pf_longq_kernel(PfDedupArgs A) {
+    __shared__ int8_t smat[32 * 32];
+    const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
+    for (int k = (int)threadIdx.x; k < 32 * 32; k += 256)
+        smat[k] = ((k >> 5) < A.alphabet && (k & 31) < A.alphabet) ? A.mat[(k >> 5) * A.alphabet + (k & 31)] : (int8_t)0;
+    __syncthreads();
+    const uint32_t B = A.bins;
+    const uint64_t bucket = (uint64_t)A.q_first * B + (uint64_t)blockIdx.x * 4u + (uint32_t)wave;
+    if (bucket >= (uint64_t)(A.q_first + A.n_queries) * B) return;
+    const uint32_t q = (uint32_t)(bucket / B);
+    const uint32_t qp0 = A.q_off[q];
+    const int qlen = (int)(A.q_off[q + 1] - qp0);
+    if (qlen < 32768) return;
+    if (lane == 0 && bucket == (uint64_t)q * B) atomicOr(&A.q_flags[q], 1u);
+    if (A.nucl || (A.q_nseg && A.q_nseg[q])) return;
+    const uint8_t *qr = A.q_res + qp0;
+    const uint8_t *qc = reinterpret_cast<const uint8_t *>(A.q_corr) + qp0;
+    const int8_t *prows = (A.q_isprof && A.q_isprof[q]) ? A.q_rows + (size_t)qp0 * PF_PROW : nullptr;
+    const uint32_t ncand = A.cand_count[bucket];
+    for (uint32_t ci = 0; ci < ncand; ci++) {
+        PfCand *slot = cand_slot(A, bucket, ci);
+        const uint32_t id = slot->id;
+        const int own = wave_long_score(smat, qr, qc, prows, qlen, A.t_res + (size_t)A.t_off4[id] * 4, (int)A.t_len[id], slot->diag);
+        if (lane == 0) slot->score = (uint32_t)own;
+    }
+}
+
+__global__ __launch_bounds__(256) void pf_long_kernel(PfDedupArgs A) {
+    __shared__ uint32_t s_tab[PF_IDS_PER_BIN];
+    __shared__ uint32_t s_dbits[65536 / 32];
+    __shared__ uint64_t s_key[PF_LONG_POOL];
+    __shared__ uint32_t s_ci[PF_LONG_POOL];        // candidate index inside its bucket | long target << 31
+    __shared__ uint16_t s_bucket[PF_LONG_POOL];
+    __shared__ uint16_t s_job[PF_LONG_POOL];       // long-target entries: pool position of the element whose target scores it
+    __shared__ int8_t smat[32 * 32];
+    __shared__ uint32_t sh_npool, sh_nlong;
+    const uint32_t q = A.q_first + blockIdx.x;
+    if (!(A.q_flags[q] & 1u)) return;
+    if (A.nucl || (A.q_nseg && A.q_nseg[q])) return;
+    const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
+    const uint32_t B = A.bins;
+    int bshift = 0;
+    while ((1u << bshift) < B) bshift++;
+    for (int k = (int)threadIdx.x; k < 32 * 32; k += 256)
+        smat[k] = ((k >> 5) < A.alphabet && (k & 31) < A.alphabet) ? A.mat[(k >> 5) * A.alphabet + (k & 31)] : (int8_t)0;
+    for (int k = (int)threadIdx.x; k < 65536 / 32; k += 256) s_dbits[k] = 0;
+    if (threadIdx.x == 0) {
+        sh_npool = 0;
+        sh_nlong = 0;
+    }
+    __syncthreads();
+    const uint32_t qp0 = A.q_off[q];
+    const int qlen = (int)(A.q_off[q + 1] - qp0);
+    // (a query of 32768 residues or more: pf_longq_kernel has given every candidate its own long score - no batches, :199-208)
+    if (qlen < 32768) {
+    // 1. diagonals of the long-target candidates
+    for (uint32_t bk = (uint32_t)wave; bk < B; bk += 4) {
+        const uint64_t bucket = (uint64_t)q * B + bk;
+        const uint32_t ncand = A.cand_count[bucket];
+        for (uint32_t ci = (uint32_t)lane; ci < ncand; ci += 64) {
+            const PfCand *cp = cand_slot(A, bucket, ci);
+            if (A.t_len[cp->id] >= 32768u) atomicOr(&s_dbits[cp->diag >> 5], 1u << (cp->diag & 31u));
+        }
+    }
+    __syncthreads();
+    // 2. every candidate of the query on one of those diagonals
+    const uint32_t refmask = A.ref_bins - 1;
+    for (uint32_t bk = (uint32_t)wave; bk < B; bk += 4) {
+        const uint64_t bucket = (uint64_t)q * B + bk;
+        const uint32_t ncand = A.cand_count[bucket];
+        for (uint32_t ci = (uint32_t)lane; ci < ncand; ci += 64) {
+            const PfCand *cp = cand_slot(A, bucket, ci);
+            const uint32_t d = cp->diag;
+            if (s_dbits[d >> 5] & (1u << (d & 31u))) {
+                const uint32_t at = atomicAdd(&sh_npool, 1u);
+                if (at < (uint32_t)PF_LONG_POOL) {
+                    const uint32_t is_long = A.t_len[cp->id] >= 32768u ? 1u : 0u;
+                    s_key[at] = ((uint64_t)d << 43) | ((uint64_t)(cp->id & refmask) << 32) | (uint64_t)cp->arr;
+                    s_ci[at] = ci | (is_long << 31);
+                    s_bucket[at] = (uint16_t)bk;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t npool = sh_npool;
+    if (npool > (uint32_t)PF_LONG_POOL) return;      // stays flagged: the host runs the query
+    uint32_t np2 = 1;
+    while (np2 < npool) np2 <<= 1;
+    for (uint32_t k = npool + threadIdx.x; k < np2; k += 256) {
+        s_key[k] = ~0ull;
+        s_ci[k] = 0;
+        s_bucket[k] = 0;
+    }
+    __syncthreads();
+    for (uint32_t size = 2; size <= np2; size <<= 1) {
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            for (uint32_t k = threadIdx.x; k < np2 / 2; k += 256) {
+                const uint32_t i = 2 * k - (k & (stride - 1));
+                const uint32_t j = i + stride;
+                const bool up = (i & size) == 0;
+                const uint64_t a = s_key[i], b = s_key[j];
+                if ((a > b) == up) {
+                    s_key[i] = b;
+                    s_key[j] = a;
+                    const uint32_t tc = s_ci[i];
+                    s_ci[i] = s_ci[j];
+                    s_ci[j] = tc;
+                    const uint16_t tb = s_bucket[i];
+                    s_bucket[i] = s_bucket[j];
+                    s_bucket[j] = tb;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // 3a. whose target scores a long-target element: its own (batch not full), the batch's h-th element's (full batch, when that
+    //     one's target is long), nobody's (score 0)
+    for (uint32_t p = threadIdx.x; p < npool; p += 256) {
+        uint16_t job = (uint16_t)PF_LONG_NONE;
+        if (s_ci[p] >> 31) {
+            const uint64_t d = s_key[p] >> 43;
+            uint32_t lo = p, hi = p;
+            while (lo > 0 && (s_key[lo - 1] >> 43) == d) lo--;
+            while (hi + 1 < npool && (s_key[hi + 1] >> 43) == d) hi++;
+            const uint32_t r = p - lo, n_d = hi - lo + 1, b0 = (r / 8u) * 8u;
+            if (b0 + 8u > n_d) job = (uint16_t)p;
+            else {
+                uint32_t h = 0;
+                for (uint32_t z = lo + b0; z < p; z++) h += s_ci[z] >> 31;
+                const uint32_t e = lo + b0 + h;
+                job = (s_ci[e] >> 31) ? (uint16_t)e : (uint16_t)PF_LONG_NONE;
+            }
+            atomicAdd(&sh_nlong, 1u);
+        }
+        s_job[p] = job;
+    }
+    __syncthreads();
+    // 3b. the scores: one wavefront per long-target element
+    const uint8_t *qr = A.q_res + qp0;
+    const uint8_t *qc = reinterpret_cast<const uint8_t *>(A.q_corr) + qp0;
+    const int8_t *prows = (A.q_isprof && A.q_isprof[q]) ? A.q_rows + (size_t)qp0 * PF_PROW : nullptr;
+    for (uint32_t p = (uint32_t)wave; p < npool; p += 4) {
+        if (!(s_ci[p] >> 31)) continue;                  // wave-uniform
+        PfCand *slot = cand_slot(A, (uint64_t)q * B + s_bucket[p], s_ci[p] & 0x7FFFFFFFu);
+        const uint32_t id = slot->id, d16 = slot->diag;
+        const int own = wave_long_score(smat, qr, qc, prows, qlen, A.t_res + (size_t)A.t_off4[id] * 4, (int)A.t_len[id], d16);
+        int by = 0;
+        const uint32_t job = s_job[p];
+        if (job == p) by = own;
+        else if (job != PF_LONG_NONE) {
+            const uint32_t id2 = cand_slot(A, (uint64_t)q * B + s_bucket[job], s_ci[job] & 0x7FFFFFFFu)->id;
+            by = wave_long_score(smat, qr, qc, prows, qlen, A.t_res + (size_t)A.t_off4[id2] * 4, (int)A.t_len[id2], d16);
+        }
+        const uint32_t cnt = (uint32_t)min(255, by), ex = (uint32_t)own;
+        if (lane == 0) slot->score = (cnt == min(255u, ex)) ? ex : (0x80000000u | (cnt << 23) | (ex & 0x7FFFFFu));
+    }
+    }
+    __threadfence();
+    __syncthreads();
+    // 4. keepMaxElement (CacheFriendlyOperations.cpp:354-384) over every bucket of the query, as pf_keepmax_kernel does it
+    if (threadIdx.x == 0) A.surv_count[q] = 0;
+    __syncthreads();
+    PfCand *surv = A.surv + (A.cand_base[(uint64_t)q * B] - A.cand_origin);
+    for (uint32_t bk = 0; bk < B; bk++) {
+        const uint64_t bucket = (uint64_t)q * B + bk;
+        const uint32_t ncand = A.cand_count[bucket];
+        if (ncand == 0) continue;                        // workgroup-uniform
+        for (uint32_t ci = threadIdx.x; ci < ncand; ci += 256) s_tab[cand_slot(A, bucket, ci)->id >> bshift] = 0;
+        __syncthreads();
+        for (uint32_t ci = threadIdx.x; ci < ncand; ci += 256) {
+            const PfCand *cp = cand_slot(A, bucket, ci);
+            atomicMax(&s_tab[cp->id >> bshift], (pf_el_count(cp->score) << 24) | (0xFFFFFFu - min(ci, 0xFFFFFEu)));
+        }
+        __syncthreads();
+        for (uint32_t ci = threadIdx.x; ci < ncand; ci += 256) {
+            const PfCand c = *cand_slot(A, bucket, ci);
+            const uint32_t cnt = pf_el_count(c.score);
+            if (s_tab[c.id >> bshift] == ((cnt << 24) | (0xFFFFFFu - min(ci, 0xFFFFFEu))) && cnt >= A.min_diag_score)
+                surv[atomicAdd(&A.surv_count[q], 1u)] = c;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) A.q_flags[q] &= ~1u;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1864,7 +2159,7 @@ __global__ __launch_bounds__(256) void pf_select_kernel(PfSelectArgs A) {
         if (threadIdx.x == 0 && sh_remaining >= A.cand_cap && A.q_flags) A.q_flags[q] |= 2u;
         __syncthreads();
     }
-    for (uint32_t k = threadIdx.x; k < n; k += 256) atomicAdd(&hist[min(255u, S[k].score)], 1u);
+    for (uint32_t k = threadIdx.x; k < n; k += 256) atomicAdd(&hist[pf_el_count(S[k].score)], 1u);
     __syncthreads();
     if (threadIdx.x == 0) {
         // computeScoreThreshold, QueryMatcher.h:211-221
@@ -1890,11 +2185,11 @@ __global__ __launch_bounds__(256) void pf_select_kernel(PfSelectArgs A) {
 
     // sort key of an element: (255 - count) : bin of the reference's CacheFriendlyOperations (11 bits) : order key (45 bits)
     auto key_of = [&](const PfCand &c, bool *elig) -> uint64_t {
-        const uint32_t cnt = min(255u, c.score);
+        const uint32_t cnt = pf_el_count(c.score);
         uint32_t kc;
         if (trunc) {
             *elig = cnt >= 255u && c.id != ident;
-            kc = rescaled_count(c.score, fms);
+            kc = rescaled_count(pf_el_exact(c.score), fms);
         } else {
             *elig = cnt >= dthr && c.id != ident;
             kc = cnt;
@@ -1975,9 +2270,9 @@ __global__ __launch_bounds__(256) void pf_select_kernel(PfSelectArgs A) {
                     }
                 } else if (slot < sort_cap) {
                     uint32_t pref;
-                    const uint32_t cnt = min(255u, c.score);
-                    if (trunc) pref = 255u + (rescaled_count(c.score, fms) * (uint32_t)ms / 255u);
-                    else pref = (cnt >= 255u && !A.kmer_score) ? c.score : cnt;
+                    const uint32_t cnt = pf_el_count(c.score);
+                    if (trunc) pref = 255u + (rescaled_count(pf_el_exact(c.score), fms) * (uint32_t)ms / 255u);
+                    else pref = (cnt >= 255u && !A.kmer_score) ? pf_el_exact(c.score) : cnt;
                     skey[slot] = ((uint64_t)(0xFFFFFFFFu - pref) << 32) | (uint64_t)c.id;
                     sdiag[slot] = c.diag;
                 }
@@ -2222,11 +2517,24 @@ hipError_t launch_pf_dedup(const PfDedupArgs &A, hipEvent_t after_replay, hipEve
     hipLaunchKernelGGL(pf_replay_kernel, grid, block, 0, s, A);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (after_replay && (e = hipEventRecord(after_replay, s)) != hipSuccess) return e;
-    hipLaunchKernelGGL(pf_ungapped_kernel, grid, block, 0, s, A);
+    // (with the replay kernel's work list of the larger buckets: a fixed grid whose wavefronts walk it)
+    const dim3 grid_big(A.big_list ? (unsigned)std::min<uint64_t>((buckets + 3) / 4, 2048) : grid.x);
+    hipLaunchKernelGGL(pf_ungapped_kernel, grid_big, block, 0, s, A);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (after_ungapped && (e = hipEventRecord(after_ungapped, s)) != hipSuccess) return e;
     if (A.nucl) hipLaunchKernelGGL(pf_keepmax_nucl_kernel, dim3((unsigned)((buckets + 1) / 2)), dim3(128), 0, s, A);
-    else hipLaunchKernelGGL(pf_keepmax_kernel, grid, block, 0, s, A);
+    else hipLaunchKernelGGL(pf_keepmax_kernel, grid_big, block, 0, s, A);
+    return hipGetLastError();
+}
+
+hipError_t launch_pf_long(const PfDedupArgs &A, bool long_queries, hipStream_t s) {
+    if (A.n_queries == 0 || A.q_flags == nullptr) return hipSuccess;
+    if (long_queries) {
+        const uint64_t buckets = (uint64_t)A.n_queries * A.bins;
+        hipLaunchKernelGGL(pf_longq_kernel, dim3((unsigned)((buckets + 3) / 4)), dim3(256), 0, s, A);
+        if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(pf_long_kernel, dim3(A.n_queries), dim3(256), 0, s, A);
     return hipGetLastError();
 }
 

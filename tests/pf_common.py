@@ -70,14 +70,16 @@ def shards(g, world):
     return out, [cut[r + 1] - cut[r] for r in range(world)]
 
 
-def long_case(seed, long_query=False):
+def long_case(seed, long_query=False, device=False):
     """Targets of 32768 residues or more among ordinary ones (UngappedAlignment::computeLongScore and the batches of
     scoreDiagonalAndUpdateHits, UngappedAlignment.cpp:187-312).  Query 0 has a homolog inside a 40 000-residue target at 1 000 and
     query 1 at 34 000 (a diagonal beyond the 16-bit range); query 2 has one at 66 000 of a 70 000-residue target (index positions wrap
     at 65 536); query 3 meets MANY targets on diagonal 0 - substitution-only copies of itself, three of them at the start of long
     targets and one at position 65 536 of a long target (diagonal -65 536 == 0 in 16 bits) - so that full batches of eight elements
     of one diagonal hold long targets.  long_query: a 33 000-residue query that carries target 5 at 5 000 and a piece of a long
-    target.  Returns (queries, targets) as lists of uint8 arrays; the long targets are dealt among the others by the seed."""
+    target.  device: no sequence beyond 65 535 residues (the reference's default --max-seq-len, Parameters.h:271, which is what the
+    library accepts): the 70 000-residue target becomes 65 535 with the homolog at 62 000, the copy at 65 536 one at 0.
+    Returns (queries, targets) as lists of uint8 arrays; the long targets are dealt among the others by the seed."""
     rng = np.random.default_rng(seed)
     (qres, qoff), (tres, toff) = wl.config2_align_only(6, 300, planted_frac=0.4, seed=seed)
     qs, tl = wl.split(qres, qoff), wl.split(tres, toff)
@@ -88,9 +90,10 @@ def long_case(seed, long_query=False):
         h = wl.mutate(rng, qs[k], 0.8)
         big[at:at + len(h)] = h
     extra.append(big)
-    big2 = bg(70000)
+    big2 = bg(65535 if device else 70000)
     h = wl.mutate(rng, qs[2], 0.85)
-    big2[66000:66000 + len(h)] = h
+    at2 = 62000 if device else 66000
+    big2[at2:at2 + len(h)] = h
     extra.append(big2)
     q3 = qs[3]
     for _ in range(int(rng.integers(9, 20))):                       # ordinary targets on diagonal 0
@@ -99,8 +102,9 @@ def long_case(seed, long_query=False):
         b = bg(n)
         b[:len(q3)] = wl.mutate(rng, q3, 0.9, max_indels=0)
         extra.append(b)
-    b = bg(67000)
-    b[65536:65536 + len(q3)] = wl.mutate(rng, q3, 0.9, max_indels=0)
+    b = bg(65000 if device else 67000)
+    at3 = 0 if device else 65536
+    b[at3:at3 + len(q3)] = wl.mutate(rng, q3, 0.9, max_indels=0)
     extra.append(b)
     if long_query:
         lq = bg(33000)

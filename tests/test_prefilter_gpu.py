@@ -595,3 +595,47 @@ def test_batch_with_more_than_2_32_index_entries_and_tile_slots(gpu):
     finally:
         orc.build_index(g["tres"], g["toff"], thr)
         chk.load_case(gpu, g, g["tres"], g["toff"], thr)
+
+
+def test_targets_of_32768_residues_or_more(gpu):
+    """Candidates on targets of 32768 residues or more are scored on the device (pf_long_kernel): computeLongScore over every
+    65536-shift of the 16-bit diagonal, and the reference's batches of eight elements of one diagonal, where a long target of a
+    FULL batch takes the long score of another element's target or 0 (UngappedAlignment.cpp:187-312).  The restatement is pinned
+    against the reference on cases of the same make (tests/test_prefilter_oracle.py); its counters say the cases run every path.
+    A query of 32768 residues or more: computeLongScore for every element (pf_longq_kernel).  No query is handed back; the index
+    built on the device equals the host builder's."""
+    import ctypes
+    from mmseqs2_amd import capi
+    from oracle.pyoracle import Oracle
+    g = pc.golden()
+    km16, um8 = g["vtml80_kmer16"], g["blosum62_ungapped"]
+    thr = int(g["kmer_thr"])
+    orc = pc.pf_oracle()
+    swo = Oracle()
+    stats = (ctypes.c_uint64 * 4)()
+    orc.L.mmo_pf_long_stats(stats)
+    seen = np.zeros(4, np.int64)
+    s3, i3 = capi.host_score_matrix(km16, 3, lib=gpu.L)
+    for seed in (1, 2, 5):
+        qs, tl = pc.long_case(seed, long_query=seed != 1, device=True)      # (seeds 2, 5: with a 33 000-residue query)
+        tres, toff = wl.seqs_from_list(tl)
+        orc.build_index(tres, toff, thr)
+        tab = chk.load_case(gpu, g, tres, toff, thr)
+        queries = [dict(q=q, comp_bias=swo.comp_bias(km16, g["vtml80_pback"], q), identity_id=None) for q in qs]
+        for mh, rb in ((300, 2), (12, 16)):
+            ok, rep = chk.check(gpu, orc, queries, mh, rb, stages=False, label="long/%d/%d/%d" % (seed, mh, rb))
+            assert ok, "\n".join(rep)
+            orc.L.mmo_pf_long_stats(stats)
+            seen += np.array(list(stats), np.int64)
+        if seed == 1:
+            gpu.load_targets(tres, toff, 21)
+            gpu.pf_build_index(6, 21, True, s3, i3, km16, thr, um8)
+            off, ids, pos = gpu.pf_debug_index(6, 21)
+            assert np.array_equal(off, tab["offsets"]) and np.array_equal(ids, tab["ids"]) and np.array_equal(pos, tab["pos"])
+            hits, counts, status, _ = gpu.pf_batch(queries, thr, max_hits=300, ref_bins=2)
+            for qi, qd in enumerate(queries):
+                o = orc.match(qd["q"], qd["comp_bias"], 2, max_hits=300, identity_id=None)
+                n = int(counts[qi])
+                assert status[qi] == 0 and np.array_equal(hits[qi]["id"][:n], o["id"]) and np.array_equal(hits[qi]["score"][:n], o["score"])
+    assert (seen > 0).all(), seen      # elements of a long query; long targets in batches that are not full, in full batches, scored by another element's target
+    chk.load_case(gpu, g, g["tres"], g["toff"], thr)

@@ -407,7 +407,8 @@ def test_queries_a_shard_declines_on_the_host_are_reported_not_silently_short(gp
     b.run()
     hits_u, counts_u, status_u, _ = b.fetch()
     b.free()
-    assert status_u[6] == capi.PF_LONG_SEQ and counts_u[6] == 0
+    # (the unsplit run scores a query of 32768 residues or more on the device since round 6: pf_longq_kernel; a shard still declines it)
+    assert status_u[6] == 0 and counts_u[6] > 0 and qs[3] is not None
     m = capi.MMGpuMulti([0] * 3)
     try:
         m.load_targets(tres, toff, 21)
@@ -415,12 +416,17 @@ def test_queries_a_shard_declines_on_the_host_are_reported_not_silently_short(gp
         mb = m.pf_prepare(queries, thr, max_hits=50, ref_bins=2)
         m.pf_run(mb)
         hits_s, counts_s, status_s = m.pf_fetch(mb, len(qs))
+        has_full = m.has_unsplit()
         m.pf_free(mb)
     finally:
         m.close()
-    assert status_s[6] == capi.PF_LONG_SEQ and counts_s[6] == 0
+    # with the whole database in a context of its own the long query is re-run there like a query flagged inexact, and answered
+    if has_full:
+        assert status_s[6] == 0
+    else:
+        assert status_s[6] == capi.PF_LONG_SEQ and counts_s[6] == 0
     for qi in range(len(qs)):
-        if qi == 6:
+        if qi == 6 and not has_full:
             continue
         assert status_s[qi] == 0 and counts_s[qi] == counts_u[qi], qi
         n = int(counts_u[qi])
