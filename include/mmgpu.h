@@ -468,7 +468,7 @@ typedef struct {
                                computeLongScore: every 65536-shift of the 16-bit diagonal, UngappedAlignment.cpp:295-312, and the
                                batches of eight elements of scoreDiagonalAndUpdateHits, :187-293) - this status is left for: such a
                                query in a sharded run's shard, a nucleotide search or --diag-score 0 (declined on the host); a query
-                               with candidates on such targets that is on the databaseHits overflow path, or has more than 1024
+                               with candidates on such targets that is on the databaseHits overflow path, or has more than 4096
                                candidates on the diagonals of those targets.  The host must run QueryMatcher::matchQuery for it
                                (a sharded run re-runs it against the unsplit database when it holds one) */
 

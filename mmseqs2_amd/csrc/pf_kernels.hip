@@ -1432,14 +1432,54 @@ __global__ __launch_bounds__(256) void pf_keepmax_kernel(PfDedupArgs A) {
     const int wave = (int)(threadIdx.x >> 6);
     const uint32_t B = A.bins;
     if (A.nucl) return;                                      // pf_keepmax_nucl_kernel
-    if (A.big_list) {                                        // the replay kernel's work list (see pf_ungapped_kernel)
-        const uint32_t n = *A.big_count;
-        for (uint32_t i = blockIdx.x * 4u + (uint32_t)wave; i < n; i += gridDim.x * 4u) keepmax_bucket(A, s_tab[wave], (uint64_t)A.q_first * B + A.big_list[i]);
-        return;
-    }
     const uint64_t bucket = (uint64_t)A.q_first * B + (uint64_t)blockIdx.x * 4u + (uint32_t)wave;
     if (bucket >= (uint64_t)(A.q_first + A.n_queries) * B) return;
     keepmax_bucket(A, s_tab[wave], bucket);
+}
+
+// The same over the replay kernel's work list (see pf_ungapped_kernel): a WORKGROUP of 16 wavefronts per listed bucket.  The list is
+// short (hundreds of buckets per stage chunk of the headline batch) and its time was that of its largest buckets - repeats that put
+// thousands of candidates into one bin -, which one wavefront walked 64 candidates at a time with an atomic round trip to the
+// query's survivor count per step (1.4 ms for a chunk's 625 buckets).
+__global__ __launch_bounds__(1024) void pf_keepmax_list_kernel(PfDedupArgs A) {
+    __shared__ uint32_t S[PF_IDS_PER_BIN];
+    const int lane = lane_id();
+    const uint32_t B = A.bins;
+    int bshift = 0;
+    while ((1u << bshift) < B) bshift++;
+    const uint32_t n = *A.big_count;
+    for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+        const uint64_t bucket = (uint64_t)A.q_first * B + A.big_list[i];
+        const uint32_t ncand = A.cand_count[bucket];
+        const uint32_t q = (uint32_t)(bucket / B);
+        for (uint32_t k = threadIdx.x; k < (uint32_t)PF_IDS_PER_BIN; k += 1024) S[k] = 0;
+        __syncthreads();
+        for (uint32_t ci = threadIdx.x; ci < ncand; ci += 1024) {
+            const PfCand *cp = cand_slot(A, bucket, ci);
+            atomicMax(&S[cp->id >> bshift], (min(255u, cp->score) << 24) | (0xFFFFFFu - min(ci, 0xFFFFFEu)));
+        }
+        __syncthreads();
+        PfCand *surv = A.surv + (A.cand_base[(uint64_t)q * B] - A.cand_origin);
+        for (uint32_t c0 = 0; c0 < ncand; c0 += 1024) {      // (every wavefront takes part in its ballot)
+            const uint32_t ci = c0 + threadIdx.x;
+            bool win = false;
+            PfCand c;
+            c.id = 0; c.arr = 0; c.score = 0; c.diag = 0; c.pad = 0;
+            if (ci < ncand) {
+                c = *cand_slot(A, bucket, ci);
+                const uint32_t cnt = min(255u, c.score);
+                win = S[c.id >> bshift] == ((cnt << 24) | (0xFFFFFFu - min(ci, 0xFFFFFEu))) && cnt >= A.min_diag_score;
+            }
+            const uint64_t wb = ballot(win);
+            if (wb) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&A.surv_count[q], (uint32_t)__popcll(wb));
+                base = __shfl(base, 0);
+                if (win) surv[base + (uint32_t)__popcll(wb & lanes_below(lane))] = c;
+            }
+        }
+        __syncthreads();
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1458,8 +1498,8 @@ __global__ __launch_bounds__(256) void pf_keepmax_kernel(PfDedupArgs A) {
 //      the count and - for the rescoring of saturated elements, which reads the element's own target (scoreSingleSequence :453-461) -
 //      the own exact score into the candidate's slot (pf_el_count / pf_el_exact);
 //   4. redoes keepMaxElement for every bucket of the query and clears the flag.
-// Queries it leaves flagged (handed to the host as before): overflow-path and nucleotide queries, more than PF_LONG_POOL pooled candidates.
-constexpr int PF_LONG_POOL = 1024;
+// Queries it leaves flagged (handed to the host as before): overflow-path and nucleotide queries, more than PF_LONG_POOL (4096) pooled candidates.
+constexpr int PF_LONG_POOL = 4096;     // (89 KB of LDS with the tables below: a workgroup of this kernel has a CU's LDS to itself if need be)
 constexpr uint32_t PF_LONG_NONE = 0xFFFFu;
 
 // ungapped score of one diagonal (computeSingelSequenceScores :423-437) by a whole wavefront: passes of 64 x 16 cells
@@ -2523,7 +2563,8 @@ hipError_t launch_pf_dedup(const PfDedupArgs &A, hipEvent_t after_replay, hipEve
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (after_ungapped && (e = hipEventRecord(after_ungapped, s)) != hipSuccess) return e;
     if (A.nucl) hipLaunchKernelGGL(pf_keepmax_nucl_kernel, dim3((unsigned)((buckets + 1) / 2)), dim3(128), 0, s, A);
-    else hipLaunchKernelGGL(pf_keepmax_kernel, grid_big, block, 0, s, A);
+    else if (A.big_list) hipLaunchKernelGGL(pf_keepmax_list_kernel, dim3((unsigned)std::min<uint64_t>(buckets, 1024)), dim3(1024), 0, s, A);
+    else hipLaunchKernelGGL(pf_keepmax_kernel, grid, block, 0, s, A);
     return hipGetLastError();
 }
 

@@ -638,4 +638,21 @@ def test_targets_of_32768_residues_or_more(gpu):
                 n = int(counts[qi])
                 assert status[qi] == 0 and np.array_equal(hits[qi]["id"][:n], o["id"]) and np.array_equal(hits[qi]["score"][:n], o["score"])
     assert (seen > 0).all(), seen      # elements of a long query; long targets in batches that are not full, in full batches, scored by another element's target
+    # more candidates on the diagonals of long targets than pf_long_kernel pools (4096): that query - and only that one - is
+    # handed back with MMGPU_PF_LONG_SEQ
+    rng = np.random.default_rng(9)
+    qs, tl = pc.long_case(1, device=True)
+    tl = tl + [wl.mutate(rng, qs[3], 0.9, max_indels=0) for _ in range(4200)]
+    tres, toff = wl.seqs_from_list(tl)
+    orc.build_index(tres, toff, thr)
+    chk.load_case(gpu, g, tres, toff, thr)
+    queries = [dict(q=q, comp_bias=swo.comp_bias(km16, g["vtml80_pback"], q), identity_id=None) for q in qs]
+    hits, counts, status, _ = gpu.pf_batch(queries, thr, max_hits=300, ref_bins=2)
+    for qi, qd in enumerate(queries):
+        if qi == 3:
+            assert status[qi] == capi.PF_LONG_SEQ
+            continue
+        o = orc.match(qd["q"], qd["comp_bias"], 2, max_hits=300, identity_id=None)
+        n = int(counts[qi])
+        assert status[qi] == 0 and np.array_equal(hits[qi]["id"][:n], o["id"]) and np.array_equal(hits[qi]["score"][:n], o["score"])
     chk.load_case(gpu, g, g["tres"], g["toff"], thr)
