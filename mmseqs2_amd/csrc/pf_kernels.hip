@@ -844,8 +844,10 @@ __device__ __forceinline__ Seg seg_tree16(Seg g, int gl) {   // ordered tree ove
 // more than 64 candidates, finishes keepMaxElement for it.  Latency plan: target metadata of the whole chunk in one
 // round trip, then the first pass (256 or 384 diagonal cells) of 8 candidates at a time is requested together before any is
 // scored.  The query side is read from global memory (L1/L2).
+// SLOTS = false (the overflow path's elements, which do not live in candidate slots): the scores only, handed back in *score_out.
+template <bool SLOTS = true>
 __device__ __forceinline__ uint64_t score_chunk(const PfDedupArgs &A, const int8_t *smat, uint64_t bucket, uint32_t q, uint32_t cb0,
-                                                uint32_t nin, uint32_t ncand, PfCand c, int bshift) {
+                                                uint32_t nin, uint32_t ncand, PfCand c, int bshift, uint32_t *score_out = nullptr) {
     const int lane = lane_id();
     const int grp = lane >> 4, gl = lane & 15;
     const uint32_t qp0 = A.q_off[q];
@@ -959,6 +961,8 @@ __device__ __forceinline__ uint64_t score_chunk(const PfDedupArgs &A, const int8
         else trip(std::integral_constant<int, 4>{}, k0);
     }
     c.score = (uint32_t)my_score;
+    if (score_out) *score_out = c.score;
+    if constexpr (!SLOTS) return cells;
     if (has) {
         PfCand *slot = cand_slot(A, bucket, cb0 + (uint32_t)lane);
         slot->score = c.score;
@@ -1918,7 +1922,8 @@ __global__ __launch_bounds__(256) void pf_overflow_kernel(PfOvfArgs A) {
     __shared__ int8_t smat[32 * 32];
     const PfDedupArgs &D = A.D;
     const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
-    for (int k = (int)threadIdx.x; k < 32 * 32; k += 256) smat[k] = k < D.alphabet * D.alphabet ? D.mat[k] : (int8_t)0;
+    for (int k = (int)threadIdx.x; k < 32 * 32; k += 256)      // rows of 32 (seg_cells_n)
+        smat[k] = ((k >> 5) < D.alphabet && (k & 31) < D.alphabet) ? D.mat[(k >> 5) * D.alphabet + (k & 31)] : (int8_t)0;
     __syncthreads();
     const uint32_t B = D.bins;
     const uint64_t w = (uint64_t)blockIdx.x * 4u + (uint32_t)wave;
@@ -2040,34 +2045,33 @@ __global__ __launch_bounds__(256) void pf_overflow_kernel(PfOvfArgs A) {
         }
         return;
     }
-    // UngappedAlignment::align: elements without a score only (computeScores, UngappedAlignment.cpp:322-324)
-    const uint32_t qp0 = D.q_off[q];
-    const int qlen = (int)(D.q_off[q + 1] - qp0);
-    const uint8_t *qr = D.q_res + qp0;
-    const int8_t *qc = D.q_corr + qp0;
-    const int8_t *prows = (D.q_isprof && D.q_isprof[q]) ? D.q_rows + (size_t)qp0 * PF_PROW : nullptr;
+    // UngappedAlignment::align: elements without a score only (computeScores, UngappedAlignment.cpp:322-324).  Round 6: with the
+    // scoring kernels' own scorer (score_chunk: a 16-lane group per element, dword loads, passes of 256 or 384 cells) - the queries on
+    // this path are the LONGEST of a batch (their index entries exceed the reference's buffer), and a lane walking one element's
+    // thousands of diagonal cells byte by byte made the final launch of nine such queries 1.27 ms long.  The unscored elements of a
+    // round of 64 are brought together in the low lanes (the bin's table is free between the merge and keepMax: lane numbers and
+    // scores pass through its first 128 words).
     for (uint32_t r0 = 0; r0 < n; r0 += 64) {
         const uint32_t idx = r0 + (uint32_t)lane;
-        if (idx < n && cur[idx].score == 0) {
-            const uint32_t id = cur[idx].id;
-            const int d = (int)(short)cur[idx].diag;
-            const int tlen = (int)D.t_len[id];
-            if (tlen >= 32768 && D.q_flags) atomicOr(&D.q_flags[q], 1u);
-            const uint8_t *t = D.t_res + (size_t)D.t_off4[id] * 4;
-            const int mind = d < 0 ? -d : d;
-            int len = 0, qs = 0, ts = 0;
-            if (d >= 0 && mind < qlen) { len = min(tlen, qlen - mind); qs = mind; }
-            else if (d < 0 && mind < tlen) { len = min(tlen - mind, qlen); ts = mind; }
-            int sc = 0, mx = 0;
-            for (int p = 0; p < len; p++) {
-                const int x = prows ? (int)prows[(size_t)(qs + p) * PF_PROW + ((int)t[ts + p] & (PF_PROW - 1))]
-                                    : (int)(int8_t)(smat[((int)qr[qs + p] * D.alphabet + (int)t[ts + p]) & 1023] + qc[qs + p]);
-                sc += x;
-                sc = sc < 0 ? 0 : sc;
-                mx = sc > mx ? sc : mx;
-            }
-            cur[idx].score = (uint32_t)mx;
-        }
+        const bool need = idx < n && cur[idx].score == 0;
+        const uint64_t nb = ballot(need);
+        if (!nb) continue;                                   // wave-uniform
+        const uint32_t cnt = (uint32_t)__popcll(nb), mine = (uint32_t)__popcll(nb & below);
+        if (need) tab[mine] = (uint32_t)lane;
+        __builtin_amdgcn_wave_barrier();
+        const int src = (uint32_t)lane < cnt ? (int)tab[lane] : 0;
+        const uint32_t my_id = idx < n ? cur[idx].id : 0u, my_diag = idx < n ? (uint32_t)cur[idx].diag : 0u;
+        PfCand c;
+        c.id = (uint32_t)__shfl((int)my_id, src);
+        c.arr = 0;
+        c.score = 0;
+        c.diag = (uint16_t)__shfl((int)my_diag, src);
+        c.pad = 0;
+        uint32_t sc = 0;
+        (void)score_chunk<false>(D, smat, bucket, q, 0, cnt, 65u, c, bshift, &sc);
+        tab[64 + lane] = sc;
+        __builtin_amdgcn_wave_barrier();
+        if (need) cur[idx].score = tab[64 + mine];
     }
     __threadfence();
     // keepMaxElement: per target the first element holding the maximum count, plus every zero-count element after it
