@@ -70,6 +70,7 @@ extern "C" void mmgpu_destroy(mmgpu_ctx *c) {
     for (auto &st : c->side) if (st) (void)hipStreamDestroy(st);
     if (c->fork) (void)hipEventDestroy(c->fork);
     for (auto &e : c->join) if (e) (void)hipEventDestroy(e);
+    if (c->pinned) (void)hipHostFree(c->pinned);
     c->cache->trim();
     c->cache->closed = true;
     delete c;
@@ -826,14 +827,34 @@ static int sw_prepare_impl(mmgpu_ctx *c, const mmgpu_sw_params *par, const mmgpu
     hipStream_t s = c->stream;
     std::vector<int8_t> mat(par->mat, par->mat + par->alphabet * par->alphabet);
 #define B_TRY(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { delete b; return fail(MMGPU_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__)); } } while (0)
-    B_TRY(upload(b->d_qres, qres, s));
-    B_TRY(upload(b->d_qcb, qcb, s));
-    B_TRY(upload(b->d_qoff, qoff, s));
-    B_TRY(upload(b->d_qbias, qbias, s));
-    B_TRY(upload(b->d_qminstart, qminstart, s));
+    // the fused hand-over (pf): the stream still holds the prefilter batch - the uploads go through pinned staging so that this
+    // thread is not parked behind it (mmgpu_ctx::pinned); sized here, once, for everything uploaded below
+    void *pin = nullptr;
+    size_t pin_cap = 0, pin_used = 0;
+    if (pf) {
+        size_t need = upload_pinned_need(qres.size()) + upload_pinned_need(qcb.size()) + upload_pinned_need(qoff.size() * 4) +
+                      upload_pinned_need(qbias.size() * 4) + upload_pinned_need(qminstart.size() * 4) + upload_pinned_need(mat.size()) +
+                      upload_pinned_need((jobs.size() + rev_jobs.size()) * sizeof(SwJob)) + upload_pinned_need(qprof.size()) +
+                      upload_pinned_need(qprof_off.size() * 4);
+        if (need > c->pinned_cap) {      // (nothing of an earlier batch is in flight from it: every prepare ends with the stream drained)
+            if (c->pinned) (void)hipHostFree(c->pinned);
+            c->pinned = nullptr;
+            c->pinned_cap = 0;
+            if (hipHostMalloc(&c->pinned, need + need / 4, hipHostMallocDefault) == hipSuccess) c->pinned_cap = need + need / 4;
+            else (void)hipGetLastError();   // pageable copies then
+        }
+        pin = c->pinned;
+        pin_cap = c->pinned_cap;
+    }
+#define UPLOAD(buf, vec) upload_pinned(buf, vec, s, pin, pin_cap, pin_used)
+    B_TRY(UPLOAD(b->d_qres, qres));
+    B_TRY(UPLOAD(b->d_qcb, qcb));
+    B_TRY(UPLOAD(b->d_qoff, qoff));
+    B_TRY(UPLOAD(b->d_qbias, qbias));
+    B_TRY(UPLOAD(b->d_qminstart, qminstart));
     if (b->any_profile) {
-        B_TRY(upload(b->d_qprof, qprof, s));
-        B_TRY(upload(b->d_qprof_off, qprof_off, s));
+        B_TRY(UPLOAD(b->d_qprof, qprof));
+        B_TRY(UPLOAD(b->d_qprof_off, qprof_off));
     }
     if (pf) {
         B_TRY(b->d_hit_target.alloc(std::max<size_t>((size_t)total_hits, 1) * 4));
@@ -846,7 +867,7 @@ static int sw_prepare_impl(mmgpu_ctx *c, const mmgpu_sw_params *par, const mmgpu
         B_TRY(upload(b->d_hit_target, hit_target, s));
         B_TRY(upload(b->d_hit_out, hit_out, s));
     }
-    B_TRY(upload(b->d_mat, mat, s));
+    B_TRY(UPLOAD(b->d_mat, mat));
     B_TRY(b->d_out.alloc(std::max<size_t>((size_t)total_hits, 1) * sizeof(mmgpu_sw_hit)));
     std::vector<SwJob> sorted(jobs.size());   // uploaded asynchronously: must live until the stream is drained below
     {
@@ -871,8 +892,9 @@ static int sw_prepare_impl(mmgpu_ctx *c, const mmgpu_sw_params *par, const mmgpu
             for (uint32_t z : ro) sorted.push_back(rev_jobs[z]);
             b->n_rev_jobs = (uint32_t)rev_jobs.size();
         }
-        B_TRY(upload(b->d_jobs, sorted, s));
+        B_TRY(UPLOAD(b->d_jobs, sorted));
     }
+#undef UPLOAD
     prep_lap("uploads enqueued, jobs ordered");
     // column scratch of the multi-tile jobs: a pool with one slot per workgroup that can be resident at once (not one
     // per job: a batch of long queries against one very long target would ask for 100+ GB), sized by the longest

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <cstdlib>
+#include <cstring>
 
 #include <algorithm>
 #include <array>
@@ -763,6 +764,22 @@ inline hipError_t upload(DevBuf &b, const std::vector<T> &v, hipStream_t s) {
     return hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s);
 }
 
+// the same through a slice of pinned staging memory (base / cap / used: the caller's arena, large enough - upload_pinned_need):
+// the copy is enqueued and the host goes on; the arena must stay untouched until the stream has passed the copy
+inline size_t upload_pinned_need(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
+template <typename T>
+inline hipError_t upload_pinned(DevBuf &b, const std::vector<T> &v, hipStream_t s, void *base, size_t cap, size_t &used) {
+    hipError_t e = b.alloc(std::max<size_t>(v.size(), 1) * sizeof(T));
+    if (e != hipSuccess) return e;
+    if (v.empty()) return hipSuccess;
+    const size_t n = v.size() * sizeof(T);
+    if (!base || used + upload_pinned_need(n) > cap) return hipMemcpyAsync(b.p, v.data(), n, hipMemcpyHostToDevice, s);
+    void *st = static_cast<char *>(base) + used;
+    used += upload_pinned_need(n);
+    memcpy(st, v.data(), n);
+    return hipMemcpyAsync(b.p, st, n, hipMemcpyHostToDevice, s);
+}
+
 // nucleotide alignment step (nucl_kernel.hip; NuclLaunch is declared in nucl_core.h)
 hipError_t launch_nucl_align(const NuclLaunch &L, unsigned blocks, hipStream_t stream);     // 16 lanes per alignment
 hipError_t launch_nucl_align_wave(const NuclLaunch &L, unsigned blocks, hipStream_t stream);   // one wavefront per alignment, state in registers (nucl_wave.h): the default
@@ -808,6 +825,11 @@ struct mmgpu_ctx {
     // the alignment kernel groups run concurrently on side streams forked from / joined to `stream` (mmgpu_sw_run)
     hipStream_t side[4] = {};      // (SW_GROUPS of them are used)
     hipEvent_t fork = nullptr, join[4] = {};
+    // pinned staging for the uploads of mmgpu_sw_prepare_from_pf: a copy from pageable memory blocks the calling thread until the
+    // stream has reached it - i.e. until the prefilter batch before it has finished - and everything the host still had to do for
+    // the alignment batch (ordering ~1e5 jobs) then ran with the device idle
+    void *pinned = nullptr;
+    size_t pinned_cap = 0, pinned_used = 0;
 };
 
 // device memory for a context's long-lived buffers (targets, masked view): when the runtime is out of memory the blocks the
