@@ -2176,7 +2176,7 @@ __device__ uint32_t list_ordinal(const PfSelectArgs &A, uint32_t q, uint32_t arr
 template <bool XCHG, bool BIG>
 __global__ __launch_bounds__(256) void pf_select_kernel(PfSelectArgs A) {
     __shared__ uint32_t hist[256];
-    __shared__ uint32_t sh_thr, sh_trunc, sh_nelig, sh_nsel;
+    __shared__ uint32_t sh_thr, sh_trunc, sh_nelig, sh_nsel, sh_ntie;
     __shared__ uint64_t sh_prefix, sh_mask;
     __shared__ uint32_t sh_remaining;
     __shared__ uint64_t skey_lds[BIG ? 1 : PF_MAX_HITS];
@@ -2286,8 +2286,47 @@ __global__ __launch_bounds__(256) void pf_select_kernel(PfSelectArgs A) {
                 sh_remaining = rem - cum;
                 sh_prefix = prefix | ((uint64_t)d << shift);
                 sh_mask = mask | (0xFFull << shift);
+                sh_ntie = hist[d];
             }
             __syncthreads();
+            if (!BIG && shift == 56 && sh_ntie <= sort_cap) {
+                // Round 6: the cut falls inside ONE count class (the top byte of the key), usually a few dozen elements: bring the class's
+                // keys into the sort array (free until the gather below), order them there and read the cut off - instead of seven
+                // more passes over all the query's survivors
+                const uint32_t m = sh_ntie, rem = sh_remaining;
+                const uint64_t prefix1 = sh_prefix;
+                __syncthreads();
+                if (threadIdx.x == 0) sh_ntie = 0;
+                __syncthreads();
+                for (uint32_t k = threadIdx.x; k < n; k += 256) {
+                    bool el;
+                    const uint64_t key = key_of(S[k], &el);
+                    if (el && (key & (0xFFull << 56)) == prefix1) skey[atomicAdd(&sh_ntie, 1u)] = key;
+                }
+                uint32_t mp2 = 1;
+                while (mp2 < m) mp2 <<= 1;
+                __syncthreads();
+                for (uint32_t k = m + threadIdx.x; k < mp2; k += 256) skey[k] = ~0ull;
+                __syncthreads();
+                for (uint32_t size = 2; size <= mp2; size <<= 1) {
+                    for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+                        for (uint32_t k = threadIdx.x; k < mp2 / 2; k += 256) {
+                            const uint32_t i = 2 * k - (k & (stride - 1));
+                            const uint32_t j = i + stride;
+                            const bool up = (i & size) == 0;
+                            const uint64_t a = skey[i], b = skey[j];
+                            if ((a > b) == up) {
+                                skey[i] = b;
+                                skey[j] = a;
+                            }
+                        }
+                        __syncthreads();
+                    }
+                }
+                if (threadIdx.x == 0) sh_prefix = skey[rem - 1];      // the rem-th smallest key of the class: everything up to it is taken
+                __syncthreads();
+                break;
+            }
         }
         kstar = sh_prefix;
     }

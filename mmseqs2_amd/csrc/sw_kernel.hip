@@ -679,6 +679,20 @@ __global__ __launch_bounds__(256) void sw_from_pf_kernel(SwFromPfArgs A) {
         key[k] = v;
     }
     __syncthreads();
+    const uint32_t base = q * A.stride;
+    if (n <= 512) {
+        // a list of --max-seqs 300: every element counts the keys below its own (the keys are distinct; all lanes read the same
+        // word of LDS at a time) - one pass instead of the 45 barrier-separated steps of the network below
+        for (uint32_t i = threadIdx.x; i < n; i += 256) {
+            const uint32_t mine = key[i];
+            uint32_t r = 0;
+            for (uint32_t j = 0; j < n; j++) r += key[j] < mine ? 1u : 0u;
+            A.hit_target[base + r] = hits[i].id;
+            A.hit_out[base + r] = base + i;
+            A.slot_target[base + i] = hits[i].id;
+            if (r == 0) atomicMax(A.pairs + 1, (unsigned long long)(0xFFFFu - (mine >> 16)));   // longest target of any list
+        }
+    } else {
     for (uint32_t size = 2; size <= np2; size <<= 1) {
         for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
             for (uint32_t k = threadIdx.x; k < np2 / 2; k += 256) {
@@ -694,12 +708,13 @@ __global__ __launch_bounds__(256) void sw_from_pf_kernel(SwFromPfArgs A) {
             __syncthreads();
         }
     }
-    const uint32_t base = q * A.stride;
     for (uint32_t r = threadIdx.x; r < n; r += 256) {
         const uint32_t k = key[r] & 0xFFFFu;
         A.hit_target[base + r] = hits[k].id;
         A.hit_out[base + r] = base + k;
         A.slot_target[base + r] = hits[r].id;
+    }
+    if (threadIdx.x == 0 && n) atomicMax(A.pairs + 1, (unsigned long long)(0xFFFFu - (key[0] >> 16)));   // longest target of any list
     }
     for (uint32_t r = n + threadIdx.x; r < A.stride; r += 256) {   // unused slots: defined contents
         A.hit_target[base + r] = 0;
@@ -710,10 +725,7 @@ __global__ __launch_bounds__(256) void sw_from_pf_kernel(SwFromPfArgs A) {
     // statistics (cells = forward DP cells, Alignment.cpp:380,530 convention)
     for (int d = 1; d < 64; d <<= 1) cells += __shfl_xor(cells, d);
     if ((threadIdx.x & 63u) == 0 && cells) atomicAdd(A.cells, cells);
-    if (threadIdx.x == 0 && n) {
-        atomicAdd(A.pairs, (unsigned long long)n);
-        atomicMax(A.pairs + 1, (unsigned long long)(0xFFFFu - (key[0] >> 16)));   // longest target of any list
-    }
+    if (threadIdx.x == 0 && n) atomicAdd(A.pairs, (unsigned long long)n);
 }
 
 }  // namespace
