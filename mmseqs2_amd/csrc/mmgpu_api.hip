@@ -859,8 +859,8 @@ static int sw_prepare_impl(mmgpu_ctx *c, const mmgpu_sw_params *par, const mmgpu
     if (pf) {
         B_TRY(b->d_hit_target.alloc(std::max<size_t>((size_t)total_hits, 1) * 4));
         B_TRY(b->d_hit_out.alloc(std::max<size_t>((size_t)total_hits, 1) * 4));
-        B_TRY(b->d_stats.alloc(24));
-        B_TRY(hipMemsetAsync(b->d_stats.p, 0, 24, s));
+        B_TRY(b->d_stats.alloc(SW_FROM_PF_STAT_SLOTS * 24));      // (cells, pairs, longest target) x slots: sw_from_pf_kernel
+        B_TRY(hipMemsetAsync(b->d_stats.p, 0, SW_FROM_PF_STAT_SLOTS * 24, s));
         B_TRY(b->d_pf_counts.alloc(std::max<size_t>(nq, 1) * 4));
         B_TRY(b->d_slot_target.alloc(std::max<size_t>((size_t)total_hits, 1) * 4));
     } else {
@@ -929,8 +929,13 @@ static int sw_prepare_impl(mmgpu_ctx *c, const mmgpu_sw_params *par, const mmgpu
     }
     B_TRY(hipStreamSynchronize(s));   // the host vectors above die with this scope
     if (pf) {
-        unsigned long long st[3] = {0, 0, 0};
-        B_TRY(hipMemcpy(st, b->d_stats.p, 24, hipMemcpyDeviceToHost));
+        unsigned long long st[3] = {0, 0, 0}, slots[SW_FROM_PF_STAT_SLOTS * 3];
+        B_TRY(hipMemcpy(slots, b->d_stats.p, sizeof(slots), hipMemcpyDeviceToHost));
+        for (int z = 0; z < SW_FROM_PF_STAT_SLOTS; z++) {
+            st[0] += slots[z * 3];
+            st[1] += slots[z * 3 + 1];
+            st[2] = std::max(st[2], slots[z * 3 + 2]);
+        }
         b->cells = st[0];
         b->valid_pairs = st[1];
         if (any_multi) {

@@ -90,6 +90,9 @@ struct SwLaunch {
 };
 
 constexpr int SW_PF_MAX_LIST = 4096;   // == PF_MAX_HITS
+// sw_from_pf_kernel's statistics (cells, pairs, longest target): one workgroup per query adds to slot blockIdx % SLOTS of
+// [SLOTS][3] - 10 000 workgroups x 6 atomics on three words serialised at the L2 and were most of the kernel's 0.73 ms
+constexpr int SW_FROM_PF_STAT_SLOTS = 64;
 
 struct SwFromPfArgs {
     const mmgpu_pf_hit *pf_hits;   // [nq][pf_stride]
@@ -99,7 +102,7 @@ struct SwFromPfArgs {
     const uint32_t *q_off;
     const uint32_t *t_len;
     uint32_t *hit_target, *hit_out;
-    unsigned long long *cells, *pairs;
+    unsigned long long *cells, *pairs;      // slot 0 of [SW_FROM_PF_STAT_SLOTS][3] (cells, pairs, longest target)
     // copies owned by the alignment batch, so that it does not depend on the prefilter batch after this kernel:
     uint32_t *count_copy;          // [nq] list lengths (clipped to stride)
     uint32_t *slot_target;         // [nq * stride] target id of every result slot (list order), 0 beyond the list

@@ -663,6 +663,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(SW_M
 __global__ __launch_bounds__(256) void sw_from_pf_kernel(SwFromPfArgs A) {
     __shared__ uint32_t key[SW_PF_MAX_LIST];
     const uint32_t q = blockIdx.x;
+    unsigned long long *const stat = A.cells + (size_t)(blockIdx.x % (uint32_t)SW_FROM_PF_STAT_SLOTS) * 3;      // (cells, pairs, longest target)
     const uint32_t n = min(A.hit_count[q], A.stride);
     const mmgpu_pf_hit *hits = A.pf_hits + (size_t)q * A.pf_stride;
     uint32_t np2 = 1;
@@ -690,7 +691,7 @@ __global__ __launch_bounds__(256) void sw_from_pf_kernel(SwFromPfArgs A) {
             A.hit_target[base + r] = hits[i].id;
             A.hit_out[base + r] = base + i;
             A.slot_target[base + i] = hits[i].id;
-            if (r == 0) atomicMax(A.pairs + 1, (unsigned long long)(0xFFFFu - (mine >> 16)));   // longest target of any list
+            if (r == 0) atomicMax(stat + 2, (unsigned long long)(0xFFFFu - (mine >> 16)));   // longest target of any list
         }
     } else {
     for (uint32_t size = 2; size <= np2; size <<= 1) {
@@ -714,7 +715,7 @@ __global__ __launch_bounds__(256) void sw_from_pf_kernel(SwFromPfArgs A) {
         A.hit_out[base + r] = base + k;
         A.slot_target[base + r] = hits[r].id;
     }
-    if (threadIdx.x == 0 && n) atomicMax(A.pairs + 1, (unsigned long long)(0xFFFFu - (key[0] >> 16)));   // longest target of any list
+    if (threadIdx.x == 0 && n) atomicMax(stat + 2, (unsigned long long)(0xFFFFu - (key[0] >> 16)));   // longest target of any list
     }
     for (uint32_t r = n + threadIdx.x; r < A.stride; r += 256) {   // unused slots: defined contents
         A.hit_target[base + r] = 0;
@@ -724,8 +725,8 @@ __global__ __launch_bounds__(256) void sw_from_pf_kernel(SwFromPfArgs A) {
     if (threadIdx.x == 0) A.count_copy[q] = n;
     // statistics (cells = forward DP cells, Alignment.cpp:380,530 convention)
     for (int d = 1; d < 64; d <<= 1) cells += __shfl_xor(cells, d);
-    if ((threadIdx.x & 63u) == 0 && cells) atomicAdd(A.cells, cells);
-    if (threadIdx.x == 0 && n) atomicAdd(A.pairs, (unsigned long long)n);
+    if ((threadIdx.x & 63u) == 0 && cells) atomicAdd(stat, cells);
+    if (threadIdx.x == 0 && n) atomicAdd(stat + 1, (unsigned long long)n);
 }
 
 }  // namespace
