@@ -373,3 +373,90 @@ def test_device_mixed_profile_and_sequence_prefilter_equals_oracle(gpu):
         h = hits[qi][: int(counts[qi])]
         assert int(status[qi]) == 0
         assert np.array_equal(h["id"], x["id"]) and np.array_equal(h["score"], x["score"]) and np.array_equal(h["diagonal"], x["diagonal"]), qi
+
+
+def pf_profile_long_case(seed):
+    """pf_profile_case plus targets of 32768 residues or more that carry homologs of the profiles' consensus sequences: one at
+    1 000 and one at 34 000 of a 40 000-residue target, and - for the batches of eight elements of one diagonal
+    (UngappedAlignment.cpp:187-293) - substitution-only copies of profile 3's consensus as ordinary targets and at the start of three
+    long ones."""
+    from mmseqs2_amd import workloads as wl
+    entries, tres, toff = pf_profile_case(seed, n_targets=600)
+    rng = np.random.default_rng(seed + 1000)
+    tl = wl.split(tres, toff)
+    bg = lambda n: rng.choice(20, size=n, p=wl.BACKGROUND).astype(np.uint8)
+    cons = [e[:, 20].astype(np.uint8) for e in entries]
+    big = bg(40000)
+    for k, at in ((0, 1000), (1, 34000)):
+        h = wl.mutate(rng, cons[k], 0.85)
+        big[at:at + len(h)] = h
+    extra = [big]
+    for _ in range(int(rng.integers(10, 18))):
+        extra.append(wl.mutate(rng, cons[3], 0.9, max_indels=0))
+    for n in (33000, 37000, 52000):
+        b = bg(n)
+        b[:len(cons[3])] = wl.mutate(rng, cons[3], 0.9, max_indels=0)
+        extra.append(b)
+    tl = tl + extra
+    perm = rng.permutation(len(tl))
+    tres, toff = wl.seqs_from_list([tl[i] for i in perm])
+    return entries, tres, toff
+
+
+@pytest.mark.skipif(not (ref_available() and ref_matrix_available()), reason="needs oracle/_ref and /root/reference/data")
+def test_oracle_profile_prefilter_with_long_targets_equals_reference():
+    """profile queries against targets of 32768 residues or more: computeLongScore and the batches of scoreDiagonalAndUpdateHits read
+    the profile's own score rows (UngappedAlignment::createProfile's profile branch) - restatement against the reference"""
+    import ctypes
+    from oracle import pyoracle
+    from tests import pf_common as pc
+    ref = pyoracle.RefPrefilter(6)
+    o = pc.pf_oracle()
+    stats = (ctypes.c_uint64 * 4)()
+    o.L.mmo_pf_long_stats(stats)
+    seen = np.zeros(4, np.int64)
+    for seed in (41, 42):
+        entries, tres, toff = pf_profile_long_case(seed)
+        ref.build_index(tres, toff, 0)
+        o.build_index(tres, toff, 0)
+        for mh in (300, 8):
+            for qi, e in enumerate(entries):
+                r = ref.match_profile(e, 99, max_hits=mh, max_seq_len=65535, identity_id=None)
+                x = o.match_profile(r["letters"], r["pscore"], r["pindex"], r["aln"], 2, 99, max_hits=mh, identity_id=None)
+                assert x["stats"]["rc"] == 0 and r["db_matches"] == x["stats"]["db_matches"], (seed, mh, qi)
+                assert np.array_equal(r["id"], x["id"]) and np.array_equal(r["score"], x["score"]) and np.array_equal(r["diagonal"], x["diagonal"]), (seed, mh, qi)
+                o.L.mmo_pf_long_stats(stats)
+                seen += np.array(list(stats), np.int64)
+    assert (seen[1:3] > 0).all(), seen      # long targets in batches that are not full and in full batches
+
+
+@pytest.mark.gpu
+def test_device_profile_prefilter_with_long_targets_equals_oracle(gpu):
+    """the same cases on the device (pf_long_kernel with the profile's score rows): device == restatement, no query handed back"""
+    from mmseqs2_amd import capi
+    from oracle import pyoracle
+    from tests import pf_common as pc
+    if not (ref_available() and ref_matrix_available()):
+        pytest.skip("the profile arrays of a query are made by the reference's Sequence::mapProfile (oracle/_ref)")
+    m = np.load(os.path.join(HERE, "golden", "matrices.npz"))
+    km16 = m["vtml80_kmer"].astype(np.int16)
+    ref = pyoracle.RefPrefilter(6)
+    o = pc.pf_oracle()
+    s3, i3 = capi.host_score_matrix(km16, 3)
+    for seed in (41, 42):
+        entries, tres, toff = pf_profile_long_case(seed)
+        ref.build_index(tres, toff, 0)
+        o.build_index(tres, toff, 0)
+        gpu.load_targets(tres, toff, 21)
+        gpu.pf_build_index(6, 21, True, s3, i3, km16, 0, m["blosum62_ungapped"])
+        batch = []
+        for e in entries:
+            r = ref.match_profile(e, 99, max_hits=300, max_seq_len=65535, identity_id=None)
+            batch.append(dict(q=r["letters"], profile_score=r["pscore"], profile_index=r["pindex"], profile=r["aln"], comp_bias=None, identity_id=None))
+        for mh in (300, 8):
+            hits, counts, status = gpu.pf_batch(batch, 99, max_hits=mh, ref_bins=2)[:3]
+            for qi, qd in enumerate(batch):
+                x = o.match_profile(qd["q"], qd["profile_score"], qd["profile_index"], qd["profile"], 2, 99, max_hits=mh, identity_id=None)
+                h = hits[qi][: int(counts[qi])]
+                assert int(status[qi]) == 0, (seed, mh, qi)
+                assert np.array_equal(h["id"], x["id"]) and np.array_equal(h["score"], x["score"]) and np.array_equal(h["diagonal"], x["diagonal"]), (seed, mh, qi)
