@@ -430,33 +430,60 @@ def test_oracle_profile_prefilter_with_long_targets_equals_reference():
     assert (seen[1:3] > 0).all(), seen      # long targets in batches that are not full and in full batches
 
 
-@pytest.mark.gpu
-def test_device_profile_prefilter_with_long_targets_equals_oracle(gpu):
-    """the same cases on the device (pf_long_kernel with the profile's score rows): device == restatement, no query handed back"""
-    from mmseqs2_amd import capi
-    from oracle import pyoracle
+PF_LONG_SEEDS = (41, 42)
+PF_LONG_MAX_HITS = (300, 8)
+GOLD_PF_LONG = os.path.join(HERE, "golden", "profile_long_pf.npz")
+
+
+def load_pf_long_golden(seed):
+    """the profile arrays the reference derived from the entries of pf_profile_long_case(seed) and its hit lists
+    (tests/golden/make_profile_long_pf_golden.py); the targets are regenerated here and checked against the recorded CRC"""
+    import zlib
+    g = np.load(GOLD_PF_LONG, allow_pickle=False)
+    entries, tres, toff = pf_profile_long_case(seed)
+    assert zlib.crc32(tres.tobytes()) == int(g["tres_crc_%d" % seed]), "the regenerated targets differ from the recorded ones"
+    qs = []
+    for qi in range(int(g["n_queries_%d" % seed])):
+        qs.append(dict(q=g["letters_%d_%d" % (seed, qi)], profile_score=g["pscore_%d_%d" % (seed, qi)],
+                       profile_index=g["pindex_%d_%d" % (seed, qi)].astype(np.uint32), profile=g["aln_%d_%d" % (seed, qi)],
+                       comp_bias=None, identity_id=None))
+    return g, qs, tres, toff
+
+
+def test_golden_profile_long_targets_against_oracle():
+    """the recorded lists of the reference against the restatement (runs without /root/reference)"""
     from tests import pf_common as pc
-    if not (ref_available() and ref_matrix_available()):
-        pytest.skip("the profile arrays of a query are made by the reference's Sequence::mapProfile (oracle/_ref)")
+    o = pc.pf_oracle()
+    for seed in PF_LONG_SEEDS[:1]:
+        g, qs, tres, toff = load_pf_long_golden(seed)
+        o.build_index(tres, toff, 0)
+        for mh in PF_LONG_MAX_HITS:
+            for qi, qd in enumerate(qs):
+                x = o.match_profile(qd["q"], qd["profile_score"], qd["profile_index"], qd["profile"], 2, 99, max_hits=mh, identity_id=None)
+                e = g["hits_%d_%d_%d" % (seed, mh, qi)]
+                assert np.array_equal(x["id"], e[0]) and np.array_equal(x["score"], e[1]) and np.array_equal(x["diagonal"], e[2]), (seed, mh, qi)
+
+
+@pytest.mark.gpu
+def test_device_profile_prefilter_with_long_targets_equals_reference_vectors(gpu):
+    """the same cases on the device (pf_long_kernel with the profile's score rows) against the lists recorded from the reference:
+    no query handed back"""
+    from mmseqs2_amd import capi
     m = np.load(os.path.join(HERE, "golden", "matrices.npz"))
     km16 = m["vtml80_kmer"].astype(np.int16)
-    ref = pyoracle.RefPrefilter(6)
-    o = pc.pf_oracle()
     s3, i3 = capi.host_score_matrix(km16, 3)
-    for seed in (41, 42):
-        entries, tres, toff = pf_profile_long_case(seed)
-        ref.build_index(tres, toff, 0)
-        o.build_index(tres, toff, 0)
+    n_long_hits = 0
+    for seed in PF_LONG_SEEDS:
+        g, batch, tres, toff = load_pf_long_golden(seed)
+        lens = np.diff(toff.astype(np.int64))
         gpu.load_targets(tres, toff, 21)
         gpu.pf_build_index(6, 21, True, s3, i3, km16, 0, m["blosum62_ungapped"])
-        batch = []
-        for e in entries:
-            r = ref.match_profile(e, 99, max_hits=300, max_seq_len=65535, identity_id=None)
-            batch.append(dict(q=r["letters"], profile_score=r["pscore"], profile_index=r["pindex"], profile=r["aln"], comp_bias=None, identity_id=None))
-        for mh in (300, 8):
+        for mh in PF_LONG_MAX_HITS:
             hits, counts, status = gpu.pf_batch(batch, 99, max_hits=mh, ref_bins=2)[:3]
-            for qi, qd in enumerate(batch):
-                x = o.match_profile(qd["q"], qd["profile_score"], qd["profile_index"], qd["profile"], 2, 99, max_hits=mh, identity_id=None)
+            for qi in range(len(batch)):
+                e = g["hits_%d_%d_%d" % (seed, mh, qi)]
                 h = hits[qi][: int(counts[qi])]
                 assert int(status[qi]) == 0, (seed, mh, qi)
-                assert np.array_equal(h["id"], x["id"]) and np.array_equal(h["score"], x["score"]) and np.array_equal(h["diagonal"], x["diagonal"]), (seed, mh, qi)
+                assert np.array_equal(h["id"], e[0]) and np.array_equal(h["score"], e[1]) and np.array_equal(h["diagonal"], e[2]), (seed, mh, qi)
+                n_long_hits += int((lens[e[0]] >= 32768).sum())
+    assert n_long_hits > 4      # the lists do hold targets of 32768 residues or more
