@@ -1389,10 +1389,30 @@ static int block_backtrace(mmgpu_ctx *c, mmgpu_sw_batch_t *b, const uint32_t *pa
         A.cap = n;
         HIP_TRY(launch_block_select(A, s));
         jobs.resize(n);
-        HIP_TRY(hipMemcpyAsync(jobs.data(), d_sel_jobs.p, (size_t)n * sizeof(BlockJob), hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
-        out_auto.resize(n);
-        out = out_auto.data();
+        // the selected jobs come back once and all n answers after every launch (block4_collect): through pinned memory where the
+        // context's staging area can be had (mmgpu_ctx::pinned; nothing else uses it between a batch's preparation and its free) -
+        // the copies of pageable memory were ~5 ms of a 45 ms call
+        const size_t out_bytes = (size_t)n * sizeof(mmgpu_sw_block), jobs_bytes = (size_t)n * sizeof(BlockJob);
+        const size_t pin_need = upload_pinned_need(out_bytes) + upload_pinned_need(jobs_bytes);
+        if (pin_need > c->pinned_cap) {
+            if (c->pinned) (void)hipHostFree(c->pinned);
+            c->pinned = nullptr;
+            c->pinned_cap = 0;
+            if (hipHostMalloc(&c->pinned, pin_need + pin_need / 4, hipHostMallocDefault) == hipSuccess) c->pinned_cap = pin_need + pin_need / 4;
+            else (void)hipGetLastError();
+        }
+        if (c->pinned_cap >= pin_need) {
+            BlockJob *pj = reinterpret_cast<BlockJob *>(static_cast<char *>(c->pinned) + upload_pinned_need(out_bytes));
+            HIP_TRY(hipMemcpyAsync(pj, d_sel_jobs.p, jobs_bytes, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            memcpy(jobs.data(), pj, jobs_bytes);
+            out = static_cast<mmgpu_sw_block *>(c->pinned);
+        } else {
+            HIP_TRY(hipMemcpyAsync(jobs.data(), d_sel_jobs.p, jobs_bytes, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            out_auto.resize(n);
+            out = out_auto.data();
+        }
         // (string offsets as in the other form: block_kernel.hip - profile queries, pairs beyond the pool - walks back whatever is asked)
         bt_off.assign(n, 0);
         for (const BlockJob &j : jobs) {
