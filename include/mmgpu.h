@@ -407,7 +407,8 @@ int mmgpu_db_load(mmgpu_ctx *ctx, const char *path, uint64_t source_fingerprint,
 
 /* limits of the prefilter entry points: calls beyond them return MMGPU_ERR_UNSUPPORTED and the host keeps its CPU path */
 #define MMGPU_PF_MAX_HITS 131072    /* max_hits (--max-seqs); above 4096 the final sort of a list runs in HBM instead of LDS */
-#define MMGPU_PF_MAX_FUSED_HITS 4096 /* ... except mmgpu_sw_prepare_from_pf and sharded (exchange) batches, which stay at 4096 */
+#define MMGPU_PF_MAX_FUSED_HITS 4096 /* ... except sharded (exchange) batches, which stay at 4096; mmgpu_sw_prepare_from_pf takes lists up to 16384 */
+#define MMGPU_SW_MAX_FUSED_LIST 16384
 #define MMGPU_PF_MAX_TARGETS 8388608 /* resident targets a context's prefilter can index (2048 bins of 4096 ids); larger databases: several
                                       * contexts (mmgpu_init_multi - a repeated device id puts them on one device), merged lists = unsplit */
 #define MMGPU_PF_MAX_SEQ_LEN 65536  /* Parameters.h:271; queries / candidates of 32768 residues or more: MMGPU_PF_LONG_SEQ */

@@ -562,7 +562,7 @@ static int sw_prepare_impl(mmgpu_ctx *c, const mmgpu_sw_params *par, const mmgpu
         pf_hits = pf->hits;
         pf_counts = pf->counts;
         pf_stride = pf->stride;
-        if (pf_stride > (uint32_t)SW_PF_MAX_LIST) return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_sw_prepare_from_pf: lists longer than 4096");
+        if (pf_stride > (uint32_t)SW_PF_MAX_LIST) return fail(MMGPU_ERR_UNSUPPORTED, "mmgpu_sw_prepare_from_pf: lists longer than 16384");
     }
     if (!c->db.res) return fail(MMGPU_ERR_STATE, "mmgpu_sw_prepare: no targets loaded");
     static const bool prep_trace = getenv("MMGPU_TRACE") != nullptr;      // where the host side of a batch's preparation goes
@@ -640,7 +640,7 @@ static int sw_prepare_impl(mmgpu_ctx *c, const mmgpu_sw_params *par, const mmgpu
             j.hit_end = first + std::min<uint32_t>(k + (uint32_t)per, n);
             j.shape = shape;
             rev_jobs.push_back(j);
-            rev_cells.push_back(cells_per_hit * (j.hit_end - j.hit_begin) * 4096u + (n - k));
+            rev_cells.push_back(cells_per_hit * (j.hit_end - j.hit_begin) * 65536u + (n - k));
         }
     };
     for (uint32_t i = 0; i < nq; i++) {
@@ -704,7 +704,7 @@ static int sw_prepare_impl(mmgpu_ctx *c, const mmgpu_sw_params *par, const mmgpu
                 jobs.push_back(j);
                 // stand-in for the cell count the host cannot see: query length x slots; the lists are sorted by
                 // target length on the device, so among equals a query's earlier jobs hold the longer targets
-                job_cells.push_back((uint64_t)Q.qlen * (j.hit_end - j.hit_begin) * 4096u + (pf_stride - k));
+                job_cells.push_back((uint64_t)Q.qlen * (j.hit_end - j.hit_begin) * 65536u + (pf_stride - k));
             }
             if (multi && mode >= MMGPU_SW_START)
                 add_rev_jobs(i, hit_cursor, pf_stride, shape, (uint64_t)Q.qlen * ((Q.qlen + c->mean_len) / 2 + 1));

@@ -89,7 +89,7 @@ struct SwLaunch {
     const uint8_t *rev_force = nullptr;
 };
 
-constexpr int SW_PF_MAX_LIST = 4096;   // == PF_MAX_HITS
+constexpr int SW_PF_MAX_LIST = 16384;  // longest list of the fused hand-over (sw_from_pf_kernel orders it in LDS, 4 bytes per slot; PF_MAX_HITS is the prefilter's own LDS limit)
 // sw_from_pf_kernel's statistics (cells, pairs, longest target): one workgroup per query adds to slot blockIdx % SLOTS of
 // [SLOTS][3] - 10 000 workgroups x 6 atomics on three words serialised at the L2 and were most of the kernel's 0.73 ms
 constexpr int SW_FROM_PF_STAT_SLOTS = 64;

@@ -661,7 +661,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(SW_M
 // sorted by target length (longest first, stable) so that the targets a wavefront runs together end together;
 // hit_target / hit_out are written for the list's slots [q * stride, q * stride + count).
 __global__ __launch_bounds__(256) void sw_from_pf_kernel(SwFromPfArgs A) {
-    __shared__ uint32_t key[SW_PF_MAX_LIST];
+    extern __shared__ uint32_t key[];      // next power of two >= the lists' stride (launch_sw_from_pf)
     const uint32_t q = blockIdx.x;
     unsigned long long *const stat = A.cells + (size_t)(blockIdx.x % (uint32_t)SW_FROM_PF_STAT_SLOTS) * 3;      // (cells, pairs, longest target)
     const uint32_t n = min(A.hit_count[q], A.stride);
@@ -733,7 +733,9 @@ __global__ __launch_bounds__(256) void sw_from_pf_kernel(SwFromPfArgs A) {
 
 hipError_t launch_sw_from_pf(const SwFromPfArgs &A, uint32_t nq, hipStream_t stream) {
     if (nq == 0) return hipSuccess;
-    hipLaunchKernelGGL(sw_from_pf_kernel, dim3(nq), dim3(256), 0, stream, A);
+    uint32_t np2 = 1;
+    while (np2 < A.stride) np2 <<= 1;
+    hipLaunchKernelGGL(sw_from_pf_kernel, dim3(nq), dim3(256), (size_t)np2 * sizeof(uint32_t), stream, A);
     return hipGetLastError();
 }
 

@@ -371,6 +371,49 @@ def test_fused_prefilter_to_align_handover(gpu, matrices, oracle):
         b.free()
 
 
+def test_fused_handover_with_lists_above_4096(gpu, matrices):
+    """mmgpu_sw_prepare_from_pf with --max-seqs above 4096 (lists up to 16384 are ordered in LDS by sw_from_pf_kernel; the prefilter's
+    select sorts such lists in global scratch): slot by slot what the two-call path through the host gives"""
+    from mmseqs2_amd import capi
+    g = pc.golden()
+    thr = int(g["kmer_thr"])
+    rng = np.random.default_rng(17)
+    (qres, qoff), (tres, toff) = pc.synthetic_case(3, 3000, seed=21, planted=0.1)
+    qs0 = wl.split(qres, qoff)
+    tl = wl.split(tres, toff) + [wl.mutate(rng, qs0[0], float(rng.uniform(0.6, 0.95))) for _ in range(5200)]
+    tl = [tl[i] for i in rng.permutation(len(tl))]
+    tres, toff = wl.seqs_from_list(tl)
+    chk.load_case(gpu, g, tres, toff, thr)
+    mat = matrices["blosum62_sw"]
+    sub16 = mat.astype(np.int16)
+    qs = [dict(q=q, comp_bias=capi.host_comp_bias(g["vtml80_kmer16"], g["vtml80_pback"], q, lib=gpu.L)[0], identity_id=None) for q in qs0]
+    pfb = gpu.pf_prepare(qs, thr, max_hits=6000, ref_bins=2)
+    pfb.run()
+    hits, counts, status, _ = pfb.fetch()
+    assert int(counts[0]) > 4096 and (status == 0).all()
+    swq = [dict(q=qd["q"], comp_bias=capi.host_comp_bias(sub16, matrices["blosum62_pback"], qd["q"], lib=gpu.L)[1], min_start_score=40) for qd in qs]
+    fused = gpu.sw_prepare_from_pf(mat, 11, 1, swq, pfb, mode=1)
+    max_hits = pfb.max_hits
+    fused.run()
+    fr = fused.fetch().reshape(len(qs), max_hits)
+    host_q = [dict(q=x["q"], comp_bias=x["comp_bias"], targets=hits[i]["id"][:counts[i]].copy(), min_start_score=40) for i, x in enumerate(swq)]
+    sep = gpu.sw_prepare(mat, 11, 1, host_q, mode=1)
+    sep.run()
+    sr = sep.fetch()
+    assert sep.cells == fused.cells and fused.pairs == int(counts.sum())
+    off = 0
+    for i in range(len(qs)):
+        n = int(counts[i])
+        a, b = fr[i, :n], sr[off:off + n]
+        for f in ("score", "q_end", "t_end", "q_start", "t_start", "word"):
+            assert np.array_equal(a[f], b[f]), (i, f)
+        assert np.all(fr[i, n:]["score"] == 0)
+        off += n
+    for b in (fused, sep, pfb):
+        b.free()
+    chk.load_case(gpu, g, g["tres"], g["toff"], thr)
+
+
 def test_max_seqs_above_4096(gpu):
     """--max-seqs above 4096 (unsupported before): the final sort of a list runs in global scratch instead of LDS.
     One family of 7000 members so that a query collects thousands of hits; truncation (5000 of ~7000) and the full list."""
